@@ -1,0 +1,309 @@
+/*
+ * orbgpu.h -- C-ABI of the MI355X-native ORB-SLAM3 hot path (liborbgpu.so).
+ *
+ * This is the drop-in boundary for the one hot path of yutongwangBIT/multi_orbslam3 that this
+ * repository re-implements for gfx950: ORBextractor, stereo matching, the Hamming matchers and
+ * Optimizer::LocalBundleAdjustment.  The reference has no FFI of its own (its interface is three
+ * C++ headers full of cv::Mat / STL / pointer graphs), so every entry point below cites the C++
+ * member it replaces; INTEGRATION.md shows the adapter a maintainer adds on the reference side.
+ *
+ * Conventions: plain pointers + sizes, no C++/torch types, every function returns an int status
+ * (ORBG_OK == 0, negative == error, never throws).  Unless a parameter is named d_*, pointers are
+ * HOST memory owned by the caller; handles own all device memory, pinned staging and HIP streams.
+ * Handles are thread-compatible (one thread at a time per handle), the library is re-entrant
+ * across handles.  File:line citations use the path shorthand of SURVEY.md
+ * (S/ = src/orb_slam3_ros/orb_slam3/src/, I/ = .../include/, G/ = .../Thirdparty/g2o/g2o/).
+ */
+#ifndef ORBGPU_H_
+#define ORBGPU_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status codes */
+enum {
+  ORBG_OK = 0,
+  ORBG_EMPTY = -1,         /* empty image: ORBextractor::operator() returns -1, S/ORBextractor.cc:1072-1073 */
+  ORBG_BAD_ARG = -2,
+  ORBG_CAP_EXCEEDED = -3,  /* caller-provided capacity (or a handle capacity) too small */
+  ORBG_HIP_ERROR = -4,
+  ORBG_NO_DEVICE = -5,     /* no HIP device / HIP runtime unusable: the product path never falls back to CPU */
+  ORBG_INTERNAL = -6
+};
+
+/* LBA outcome, lba_result.status (not errors: they mirror the reference's early returns) */
+enum {
+  LBA_APPLIED = 0,
+  LBA_ABORTED_BEFORE_OPT = 1,   /* *pbStopFlag set before optimize(): S/Optimizer.cc:2127-2129 */
+  LBA_REJECTED_OUTLIERS = 2     /* >= 50 % of the edges are outliers: S/Optimizer.cc:2257-2261 */
+};
+
+#define ORBG_MAX_LEVELS 16
+#define ORBG_DESC_BYTES 32
+#define ORBG_GRID_COLS 64      /* FRAME_GRID_COLS, I/Frame.h:39 */
+#define ORBG_GRID_ROWS 48      /* FRAME_GRID_ROWS, I/Frame.h:38 */
+
+/* ---------------------------------------------------------------- ORB extractor */
+
+/* ORBextractor ctor arguments (S/ORBextractor.cc:408-411, values from ORBParameters I/Datatypes.h:43-55)
+ * plus the sizes the handle pre-allocates for. */
+typedef struct orbx_config {
+  int32_t n_features;     /* nfeatures   */
+  float   scale_factor;   /* scaleFactor */
+  int32_t n_levels;       /* nlevels (<= ORBG_MAX_LEVELS) */
+  int32_t ini_th_fast;    /* iniThFAST   */
+  int32_t min_th_fast;    /* minThFAST   */
+  int32_t max_width;      /* largest image the handle will be given */
+  int32_t max_height;
+  int32_t n_cams;         /* 1 = mono, 2 = stereo rig (left = cam 0, right = cam 1) */
+  int32_t device;         /* HIP device ordinal (1 agent <-> 1 GPU) */
+} orbx_config;
+
+/* The cv::KeyPoint fields the reference sets/uses. 24 bytes. */
+typedef struct orbx_keypoint {
+  float   x, y;       /* pt, level-0 pixels (S/ORBextractor.cc:1131-1133) */
+  float   size;       /* (int)(31*mvScaleFactor[l]) (S/ORBextractor.cc:862,871) */
+  float   angle;      /* degrees [0,360) (S/ORBextractor.cc:475) */
+  float   response;   /* FAST score */
+  int32_t octave;     /* pyramid level (S/ORBextractor.cc:870) */
+} orbx_keypoint;
+
+typedef struct orbx_handle orbx_handle;
+
+/* ORBextractor::ORBextractor, S/ORBextractor.cc:408-468. */
+int orbx_create(const orbx_config* cfg, orbx_handle** out);
+int orbx_destroy(orbx_handle* h);
+
+/* Scale tables the reference exposes through getters (I/ORBextractor.h:65-85):
+ * mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2 (each n_levels floats) and
+ * mnFeaturesPerLevel.  Any output pointer may be NULL. */
+int orbx_get_tables(const orbx_handle* h, float* scale, float* inv_scale, float* sigma2,
+                    float* inv_sigma2, int32_t* features_per_level);
+
+/* int ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea),
+ * S/ORBextractor.cc:1068-1150.  img: u8 gray, row stride `stride` bytes.  Keypoints with
+ * lap0 <= x <= lap1 are written from the back (S/ORBextractor.cc:1135-1144); *n_mono is the
+ * reference's return value (monoIndex).  kps/desc hold `cap` entries; *n is the total count.
+ * Returns ORBG_EMPTY for a NULL / zero-sized image. */
+int orbx_extract(orbx_handle* h, int cam, const uint8_t* img, int width, int height, int stride,
+                 int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n, int* n_mono);
+
+/* The stereo Frame ctor's two concurrent ExtractORB calls (S/Frame.cc:92-95,393-400) as ONE
+ * batched submission: left+right share every kernel launch.  vLappingArea = {0,0} as there.
+ * Output pointers may be NULL (results then stay device-resident for orbx_stereo_match /
+ * orbm_frame_from_extractor). */
+int orbx_extract_stereo(orbx_handle* h, const uint8_t* img_left, const uint8_t* img_right,
+                        int width, int height, int stride,
+                        orbx_keypoint* kps_left, uint8_t* desc_left, int cap_left, int* n_left,
+                        orbx_keypoint* kps_right, uint8_t* desc_right, int cap_right, int* n_right);
+
+/* Same, images already resident in device memory (d_img_*: device pointers, stride in bytes). */
+int orbx_extract_stereo_dev(orbx_handle* h, const uint8_t* d_img_left, const uint8_t* d_img_right,
+                            int width, int height, int stride,
+                            orbx_keypoint* kps_left, uint8_t* desc_left, int cap_left, int* n_left,
+                            orbx_keypoint* kps_right, uint8_t* desc_right, int cap_right, int* n_right);
+
+/* mvImagePyramid[level] (public member read by Frame::ComputeStereoMatches, I/ORBextractor.h:87):
+ * dimensions, and a copy of the level (without its 19-px border) into host memory (may be NULL). */
+int orbx_get_level(orbx_handle* h, int cam, int level, uint8_t* host_out, int* width, int* height);
+
+/* Test/diagnostic view of ComputeKeyPointsOctTree's vToDistributeKeys (S/ORBextractor.cc:776-853)
+ * for the last extraction: per level, FAST candidates in the reference's cell-major order,
+ * coordinates relative to (minBorderX,minBorderY).  xys = cap x {x,y,score} int32. */
+int orbx_get_candidates(orbx_handle* h, int cam, int level, int32_t* xys, int cap, int* n);
+
+/* Frame::ComputeStereoMatches, S/Frame.cc:785-963, on the device-resident result of the last
+ * orbx_extract_stereo*: fills uright[n_left] / depth[n_left] (mvuRight / mvDepth, -1 = none).
+ * bf = mbf, b = mb (S/Frame.cc:815-817).  Host outputs may be NULL. */
+int orbx_stereo_match(orbx_handle* h, float bf, float b, float* uright, float* depth);
+
+/* ---------------------------------------------------------------- frame view + matchers */
+
+/* What the matchers read from a Frame. */
+typedef struct orbm_frame_view {
+  int32_t n;                      /* Frame::N */
+  const orbx_keypoint* kps;       /* mvKeysUn (== mvKeys when k1 == 0, S/Frame.cc:723-727) */
+  const uint8_t* desc;            /* mDescriptors, n x 32 */
+  const float* uright;            /* mvuRight, NULL = all -1 */
+  const float* depth;             /* mvDepth,  NULL = all -1 */
+  float min_x, max_x, min_y, max_y;   /* mnMinX.. (S/Frame.cc:127-144) */
+  float fx, fy, cx, cy, bf, b;    /* S/Frame.cc:136-146 */
+  int32_t n_levels;
+  float   scale_factor;           /* mfScaleFactor; mvScaleFactors rebuilt as S/ORBextractor.cc:413-421 */
+} orbm_frame_view;
+
+typedef struct orbm_frame orbm_frame;
+
+int orbm_frame_create(int device, int cap_features, orbm_frame** out);
+int orbm_frame_destroy(orbm_frame* f);
+/* Upload a host frame view and build the 64x48 feature grid on the device
+ * (Frame::AssignFeaturesToGrid / PosInGrid, S/Frame.cc:360-391,699-709). */
+int orbm_frame_upload(orbm_frame* f, const orbm_frame_view* view);
+/* Same, but features/uright/depth are taken device-to-device from the extractor handle's left
+ * camera (no host round trip); view->kps/desc/uright/depth are ignored, view->n must be the
+ * left feature count or -1. */
+int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const orbm_frame_view* view);
+/* Grid as CSR for tests: cell id = ix*48+iy, items in keypoint-index order (Appendix E-2). */
+int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start /*64*48+1*/, int32_t* cell_items /*n*/);
+
+/* int ORBmatcher::DescriptorDistance(a,b), S/ORBmatcher.cc:2358-2374, as a dense nq x nt matrix
+ * (row-major int32) -- the raw Hamming kernel. */
+int orbm_hamming_matrix(int device, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* dist);
+/* Best / second-best over all t for every q: out4 = nq x {best_dist,best_idx,second_dist,second_idx}. */
+int orbm_hamming_best2(int device, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out4);
+
+/* MapPoint fields read by SearchByProjection(Frame&, vector<MapPoint*>&...) after isInFrustum
+ * filled them (SURVEY.md Appendix E-3, S/Frame.cc:529-538).  SoA, m entries. */
+typedef struct orbm_mappoints_view {
+  int32_t m;
+  const uint8_t* track_in_view;   /* mbTrackInView */
+  const uint8_t* bad;             /* isBad() */
+  const float* proj_x;            /* mTrackProjX */
+  const float* proj_y;            /* mTrackProjY */
+  const float* proj_xr;           /* mTrackProjXR */
+  const float* track_depth;       /* mTrackDepth */
+  const int32_t* scale_level;     /* mnTrackScaleLevel */
+  const float* view_cos;          /* mTrackViewCos */
+  const uint8_t* desc;            /* GetDescriptor(), m x 32 */
+  const int32_t* n_obs;           /* Observations() */
+} orbm_mappoints_view;
+
+/* World-space map points for the fused isInFrustum + search path (Appendix E-3, second half). */
+typedef struct orbm_worldpoints_view {
+  int32_t m;
+  const float* pos;        /* m x 3  GetWorldPos() */
+  const float* normal;     /* m x 3  GetNormal() */
+  const float* min_dist;   /* m      mfMinDistance (raw; x0.8 applied as S/MapPoint.cc:617-621) */
+  const float* max_dist;   /* m      mfMaxDistance (raw; x1.2 applied as S/MapPoint.cc:623-627) */
+  const uint8_t* desc;     /* m x 32 */
+  const int32_t* n_obs;    /* m */
+  const uint8_t* bad;      /* m */
+  const uint8_t* skip;     /* m, 1 = not a candidate (already matched / mnLastFrameSeen, S/Tracking.cc:3088-3109); may be NULL */
+} orbm_worldpoints_view;
+
+/* bool Frame::isInFrustum(MapPoint*, 0.5) for m points, S/Frame.cc:466-543 (Nleft == -1 branch):
+ * fills the track fields.  Outputs are host arrays of m entries. */
+int orbm_is_in_frustum(orbm_frame* f, const float* Tcw /*16, row-major*/, const orbm_worldpoints_view* pts,
+                       float viewing_cos_limit, uint8_t* track_in_view, float* proj_x, float* proj_y,
+                       float* proj_xr, float* track_depth, int32_t* scale_level, float* view_cos);
+
+/* int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th, bFarPoints, thFarPoints),
+ * S/ORBmatcher.cc:44-214 (Nleft == -1).  assigned_mp[n] (in/out) is F.mvpMapPoints flattened:
+ * -1 = NULL, otherwise an index; indices written by this call are positions in `mps`.
+ * assigned_obs[n] (in/out) is Observations() of that map point.  *nmatches = return value. */
+int orbm_search_by_projection_mps(orbm_frame* f, const orbm_mappoints_view* mps, float th,
+                                  int far_points, float th_far_points, float nnratio,
+                                  int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+
+/* Fused Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153): isInFrustum(.,0.5) for every
+ * non-skipped point, then the search above, map points staying resident on the device. */
+typedef struct orbm_map orbm_map;
+int orbm_map_create(int device, int cap_points, orbm_map** out);
+int orbm_map_destroy(orbm_map* m);
+int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* pts);
+int orbm_search_local_points(orbm_frame* f, orbm_map* m, const float* Tcw, const uint8_t* skip /*m or NULL*/,
+                             float th, int far_points, float th_far_points, float nnratio,
+                             int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+
+/* LastFrame fields read by SearchByProjection(Frame &Cur, const Frame &Last, th, bMono)
+ * (SURVEY.md Appendix E-4). SoA, n entries (= LastFrame.N). */
+typedef struct orbm_lastframe_view {
+  int32_t n;
+  const uint8_t* mp_valid;    /* LastFrame.mvpMapPoints[i] != NULL */
+  const uint8_t* outlier;     /* LastFrame.mvbOutlier[i] */
+  const float* world_pos;     /* n x 3, pMP->GetWorldPos() */
+  const uint8_t* desc;        /* n x 32, pMP->GetDescriptor() */
+  const int32_t* octave;      /* LastFrame.mvKeys[i].octave */
+  const float* angle;         /* LastFrame.mvKeysUn[i].angle */
+  const int32_t* n_obs;       /* pMP->Observations() */
+  float Tcw[16];              /* LastFrame.mTcw, row-major */
+} orbm_lastframe_view;
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono),
+ * S/ORBmatcher.cc:1970-2186 (Nleft == -1).  Tcw_cur = CurrentFrame.mTcw.  assigned_* as above
+ * (indices are positions i in the last frame). */
+int orbm_search_by_projection_frame(orbm_frame* cur, const float* Tcw_cur, const orbm_lastframe_view* last,
+                                    float th, int mono, int check_orientation,
+                                    int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+
+/* DBoW2::FeatureVector flattened: sorted node ids, CSR feature lists. */
+typedef struct orbm_featvec_view {
+  int32_t n_nodes;
+  const uint32_t* node_id;    /* ascending */
+  const uint32_t* start;      /* n_nodes+1 */
+  const uint32_t* feat_idx;   /* start[n_nodes] entries */
+} orbm_featvec_view;
+
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*>& vpMapPointMatches),
+ * S/ORBmatcher.cc:269-471 (Nleft == -1).  kf_desc: nkf x 32; kf_mp_valid[i] = pMP && !isBad();
+ * kf_angle = pKF->mvKeysUn[i].angle.  matches[f->n] out: KF feature index or -1. */
+int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fv_frame,
+                       const uint8_t* kf_desc, int nkf, const uint8_t* kf_mp_valid, const float* kf_angle,
+                       const orbm_featvec_view* fv_kf, float nnratio, int check_orientation,
+                       int32_t* matches, int* nmatches);
+
+/* ---------------------------------------------------------------- local bundle adjustment */
+
+/* One reprojection edge (S/Optimizer.cc:2021-2084): mono if ur < 0, stereo otherwise. */
+typedef struct lba_edge {
+  int32_t pose;        /* index into poses[] */
+  int32_t point;       /* index into points[] */
+  float   u, v, ur;    /* kpUn.pt.x, kpUn.pt.y, mvuRight (<0 => monocular edge) */
+  float   inv_sigma2;  /* mvInvLevelSigma2[kpUn.octave] */
+} lba_edge;
+
+/* Everything S/Optimizer.cc:1934-2124 reads.  Poses MUST be ordered
+ * free/fixed arbitrarily but listed in ascending vertex id (Optimizer::GetID, I/Optimizer.h:104-112),
+ * points likewise; edges in creation order (per point, its observations). */
+typedef struct lba_problem {
+  int32_t n_poses, n_points, n_edges;
+  const float*   poses;        /* n_poses x 16, Tcw row-major float32 (KeyFrame::GetPose) */
+  const uint8_t* pose_fixed;   /* n_poses */
+  const float*   points;       /* n_points x 3 */
+  const lba_edge* edges;
+  float fx, fy, cx, cy, bf;
+  double lambda_init;          /* 0 = auto (tau*max diag); 100 for inertial maps, S/Optimizer.cc:1924-1925 */
+  int32_t its_round1, its_round2;  /* 5 and 10, S/Optimizer.cc:2132,2203 */
+  int32_t device;
+} lba_problem;
+
+typedef struct lba_result {
+  float*   poses;          /* n_poses x 16 (Converter::toCvMat(SE3Quat)), caller-allocated */
+  float*   points;         /* n_points x 3 */
+  double*  edge_chi2;      /* n_edges, e->chi2() at S/Optimizer.cc:2219,2249 */
+  uint8_t* edge_depth_pos; /* n_edges, e->isDepthPositive() */
+  uint8_t* edge_outlier;   /* n_edges, the vToErase predicate (S/Optimizer.cc:2219-2253) */
+  int32_t  status;         /* LBA_* */
+  int32_t  iters_round1, iters_round2;  /* LM iterations actually run */
+  int32_t  n_outliers;
+  double   chi2_initial, chi2_final;    /* activeRobustChi2 at first linearisation / after last accepted step */
+  double*  trace;          /* optional (may be NULL): per LM iteration {lambda, chi2, trials}; cap trace_cap rows */
+  int32_t  trace_cap, trace_len;
+} lba_result;
+
+/* void Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int&, int) numerical core,
+ * S/Optimizer.cc:1917-2267 + 2321-2396 (state write-back into result).  stop_flag may be NULL;
+ * it is polled between LM iterations/trials exactly where g2o polls forceStopFlag
+ * (G/core/sparse_optimizer.cpp:376, G/core/optimization_algorithm_levenberg.cpp:149). */
+int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
+
+/* Persistent LBA workspace variant: avoids per-call device allocation. */
+typedef struct lba_handle lba_handle;
+int lba_create(int device, int cap_poses, int cap_points, int cap_edges, lba_handle** out);
+int lba_destroy(lba_handle* h);
+int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
+
+/* ---------------------------------------------------------------- misc */
+const char* orbg_version(void);
+const char* orbg_strerror(int code);
+int orbg_device_count(void);
+/* Last per-stage device timings (ms, hipEvent) of a handle's most recent call, for bench.py. */
+int orbx_get_timings(orbx_handle* h, float* ms /*8*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBGPU_H_ */

@@ -1,0 +1,140 @@
+"""ctypes mirror of include/orbgpu.h and loader of the HIP library (liborbgpu.so).
+
+The library is the product; there is NO CPU fallback: if the shared object is missing or cannot be
+loaded, `load()` raises, and every entry point returns ORBG_NO_DEVICE when no HIP device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbgpu.so")
+
+ORBG_OK, ORBG_EMPTY, ORBG_BAD_ARG, ORBG_CAP_EXCEEDED, ORBG_HIP_ERROR, ORBG_NO_DEVICE, ORBG_INTERNAL = 0, -1, -2, -3, -4, -5, -6
+LBA_APPLIED, LBA_ABORTED_BEFORE_OPT, LBA_REJECTED_OUTLIERS = 0, 1, 2
+GRID_COLS, GRID_ROWS = 64, 48
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+u32p = C.POINTER(C.c_uint32)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4")])
+EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f4"), ("v", "<f4"), ("ur", "<f4"),
+                       ("inv_sigma2", "<f4")])
+assert KEYPOINT_DTYPE.itemsize == 24 and EDGE_DTYPE.itemsize == 24
+
+
+class OrbxConfig(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_width", C.c_int32),
+                ("max_height", C.c_int32), ("n_cams", C.c_int32), ("device", C.c_int32)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("kps", C.c_void_p), ("desc", C.c_void_p), ("uright", C.c_void_p),
+                ("depth", C.c_void_p), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("bf", C.c_float), ("b", C.c_float), ("n_levels", C.c_int32),
+                ("scale_factor", C.c_float)]
+
+
+class MapPointsView(C.Structure):
+    _fields_ = [("m", C.c_int32), ("track_in_view", C.c_void_p), ("bad", C.c_void_p), ("proj_x", C.c_void_p),
+                ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p), ("track_depth", C.c_void_p),
+                ("scale_level", C.c_void_p), ("view_cos", C.c_void_p), ("desc", C.c_void_p),
+                ("n_obs", C.c_void_p)]
+
+
+class WorldPointsView(C.Structure):
+    _fields_ = [("m", C.c_int32), ("pos", C.c_void_p), ("normal", C.c_void_p), ("min_dist", C.c_void_p),
+                ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("n_obs", C.c_void_p), ("bad", C.c_void_p),
+                ("skip", C.c_void_p)]
+
+
+class LastFrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("mp_valid", C.c_void_p), ("outlier", C.c_void_p), ("world_pos", C.c_void_p),
+                ("desc", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p), ("n_obs", C.c_void_p),
+                ("Tcw", C.c_float * 16)]
+
+
+class FeatVecView(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("start", C.c_void_p), ("feat_idx", C.c_void_p)]
+
+
+class LbaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p), ("edges", C.c_void_p),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("lambda_init", C.c_double), ("its_round1", C.c_int32), ("its_round2", C.c_int32),
+                ("device", C.c_int32)]
+
+
+class LbaResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("edge_chi2", C.c_void_p),
+                ("edge_depth_pos", C.c_void_p), ("edge_outlier", C.c_void_p), ("status", C.c_int32),
+                ("iters_round1", C.c_int32), ("iters_round2", C.c_int32), ("n_outliers", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("trace", C.c_void_p),
+                ("trace_cap", C.c_int32), ("trace_len", C.c_int32)]
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data
+
+
+# Every symbol include/orbgpu.h declares (tests assert that the library exports all of them).
+EXPORTED_SYMBOLS = [
+    "orbx_create", "orbx_destroy", "orbx_get_tables", "orbx_extract", "orbx_extract_stereo",
+    "orbx_extract_stereo_dev", "orbx_get_level", "orbx_get_candidates", "orbx_stereo_match",
+    "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_upload", "orbm_frame_from_extractor",
+    "orbm_frame_get_grid", "orbm_hamming_matrix", "orbm_hamming_best2", "orbm_is_in_frustum",
+    "orbm_search_by_projection_mps", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
+    "orbm_search_local_points", "orbm_search_by_projection_frame", "orbm_search_by_bow",
+    "lba_solve", "lba_create", "lba_destroy", "lba_solve_h",
+    "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings",
+]
+
+_lib = None
+
+
+class OrbGpuError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = "orbgpu error %d" % code
+        try:
+            msg += " (%s)" % load().orbg_strerror(code).decode()
+        except Exception:
+            pass
+        super().__init__(msg + (" in " + where if where else ""))
+
+
+def load():
+    """Load liborbgpu.so; raise loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("liborbgpu.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(expected at %s). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.orbg_version.restype = C.c_char_p
+    lib.orbg_strerror.restype = C.c_char_p
+    lib.orbg_strerror.argtypes = [C.c_int]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("orbg_version", "orbg_strerror"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code, where=""):
+    if code != ORBG_OK:
+        raise OrbGpuError(code, where)

@@ -1,0 +1,227 @@
+"""Seeded synthetic inputs for the hot path: stereo image sequences of a textured
+plane seen along a smooth trajectory, map points derived from stereo depth, and local-BA problems.
+
+Pure numpy; used by tests/, bench.py and __graft_entry__.smoke() for BOTH the HIP path and the oracle.
+"""
+import numpy as np
+
+from . import _capi as capi
+
+SEED_IMAGES = 0xC0FFEE
+SEED_LBA = 0xBA5EBA11
+
+
+def camera_for(width, height=None):
+    """Pinhole intrinsics scaled from R/ros/conf/EuRoC_mono_client.yaml:9-12 (fx=458.654 @ 752 px), bf=47.9 @ 752."""
+    s = width / 752.0
+    fx = np.float32(458.654 * s)
+    fy = fx
+    cx = np.float32(width / 2.0)
+    cy = np.float32((height if height else width * 3 // 4) / 2.0)
+    bf = np.float32(47.9 * s)
+    b = np.float32(bf / fx)
+    return dict(fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, b=b)
+
+
+def make_texture(seed=SEED_IMAGES, width=1600, height=1200):
+    """6 octaves of value noise + 400 random dark/bright rectangles and discs -> u8 texture with many FAST corners."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    tex = np.zeros((height, width), np.float32)
+    amp = 1.0
+    for o in range(6):
+        gh, gw = 4 * 2 ** o + 2, 5 * 2 ** o + 2
+        g = rng.rand(gh, gw).astype(np.float32)
+        ys = np.linspace(0, gh - 1.001, height, dtype=np.float32)
+        xs = np.linspace(0, gw - 1.001, width, dtype=np.float32)
+        y0 = ys.astype(np.int32); x0 = xs.astype(np.int32)
+        fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+        a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+        tex += amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+        amp *= 0.55
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    tex = 60 + 130 * tex
+    yy, xx = np.mgrid[0:height, 0:width]
+    for i in range(400):
+        val = float(rng.choice([15, 35, 215, 240]))
+        cx, cy = rng.randint(0, width), rng.randint(0, height)
+        if i % 2 == 0:
+            w, h = rng.randint(8, 60), rng.randint(8, 60)
+            tex[max(cy - h, 0):cy + h, max(cx - w, 0):cx + w] = val
+        else:
+            r = rng.randint(5, 30)
+            y0, y1, x0, x1 = max(cy - r, 0), min(cy + r + 1, height), max(cx - r, 0), min(cx + r + 1, width)
+            m = (yy[y0:y1, x0:x1] - cy) ** 2 + (xx[y0:y1, x0:x1] - cx) ** 2 <= r * r
+            tex[y0:y1, x0:x1][m] = val
+    return np.clip(tex, 0, 255).astype(np.uint8)
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+class Scene:
+    """A textured plane (world z = 0, texture at `px_per_m`) viewed by a rectified stereo rig."""
+
+    def __init__(self, width=640, height=480, seed=SEED_IMAGES, tex_size=(1600, 1200), px_per_m=200.0):
+        self.W, self.H = width, height
+        self.cam = camera_for(width, height)
+        self.tex = make_texture(seed, *tex_size)
+        self.px_per_m = px_per_m
+        self.seed = seed
+
+    def pose(self, k):
+        """Tcw (4x4 float64) of the LEFT camera at frame k: smooth drift + tilt, plane ~2.2-3.6 m away."""
+        t = 0.02 * k
+        R = _rot(0.32 + 0.04 * np.sin(0.7 * t + 0.3), -0.22 + 0.05 * np.sin(0.5 * t), 0.03 * np.sin(0.9 * t))
+        Cw = np.array([4.0 - 0.25 + 0.6 * t, 3.0 + 0.15 * np.sin(0.8 * t), -2.8 - 0.1 * np.sin(0.6 * t)])
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = -R @ Cw
+        return T
+
+    def _render(self, Tcw):
+        c = self.cam
+        K = np.array([[c["fx"], 0, c["cx"]], [0, c["fy"], c["cy"]], [0, 0, 1]], np.float64)
+        R, t = Tcw[:3, :3], Tcw[:3, 3]
+        Hm = K @ np.stack([R[:, 0], R[:, 1], t], axis=1)       # plane (X,Y,1) -> image
+        Hi = np.linalg.inv(Hm)
+        u, v = np.meshgrid(np.arange(self.W, dtype=np.float64), np.arange(self.H, dtype=np.float64))
+        q = Hi @ np.stack([u.ravel(), v.ravel(), np.ones(u.size)])
+        X, Y = q[0] / q[2], q[1] / q[2]
+        tx = np.clip(X * self.px_per_m, 0, self.tex.shape[1] - 1.001)
+        ty = np.clip(Y * self.px_per_m, 0, self.tex.shape[0] - 1.001)
+        x0 = tx.astype(np.int32); y0 = ty.astype(np.int32)
+        fx = tx - x0; fy = ty - y0
+        T = self.tex.astype(np.float64)
+        val = (T[y0, x0] * (1 - fx) + T[y0, x0 + 1] * fx) * (1 - fy) + (T[y0 + 1, x0] * (1 - fx) + T[y0 + 1, x0 + 1] * fx) * fy
+        return np.clip(np.rint(val), 0, 255).astype(np.uint8).reshape(self.H, self.W)
+
+    def stereo_pair(self, k):
+        Tl = self.pose(k)
+        Tr = Tl.copy()
+        Tr[0, 3] -= float(self.cam["b"])     # x_right = x_left - b
+        return self._render(Tl), self._render(Tr), Tl
+
+    def frame_view_params(self):
+        c = self.cam
+        return dict(bounds=(0.0, float(self.W), 0.0, float(self.H)),
+                    cam=(c["fx"], c["fy"], c["cx"], c["cy"], c["bf"], c["b"]))
+
+
+def unproject_to_world(kps, depth, Tcw, cam):
+    """Stereo unprojection as Frame::UnprojectStereo (S/Frame.cc) in float64 -> world points, valid mask."""
+    z = depth.astype(np.float64)
+    valid = z > 0
+    x = (kps["x"].astype(np.float64) - float(cam["cx"])) * z / float(cam["fx"])
+    y = (kps["y"].astype(np.float64) - float(cam["cy"])) * z / float(cam["fy"])
+    Pc = np.stack([x, y, z], axis=1)
+    R, t = Tcw[:3, :3], Tcw[:3, 3]
+    Pw = (Pc - t) @ R          # R^T (Pc - t)
+    return Pw.astype(np.float32), valid
+
+
+def map_from_frame(kps, desc, depth, Tcw, cam, scale_factor=1.2, n_levels=8):
+    """Map points as LocalMapping would create them from one stereo keyframe: position, normal,
+    min/max distance (MapPoint::UpdateNormalAndDepth, S/MapPoint.cc:545-609), descriptor."""
+    Pw, valid = unproject_to_world(kps, depth, Tcw, cam)
+    idx = np.nonzero(valid)[0]
+    Ow = (-Tcw[:3, :3].T @ Tcw[:3, 3]).astype(np.float32)
+    PO = Pw[idx] - Ow
+    dist = np.linalg.norm(PO, axis=1).astype(np.float32)
+    normal = (PO / dist[:, None]).astype(np.float32)
+    sf = np.float32(1.0)
+    scales = [sf]
+    for _ in range(1, n_levels):
+        sf = np.float32(sf * np.float32(scale_factor))
+        scales.append(sf)
+    scales = np.array(scales, np.float32)
+    lvl = kps["octave"][idx]
+    max_d = (dist * scales[lvl]).astype(np.float32)
+    min_d = (max_d / scales[n_levels - 1]).astype(np.float32)
+    return dict(pos=Pw[idx].copy(), normal=normal, min_dist=min_d, max_dist=max_d, desc=desc[idx].copy(),
+                n_obs=np.full(len(idx), 3, np.int32), bad=np.zeros(len(idx), np.uint8), src_idx=idx)
+
+
+def perturb_pose(Tcw, rng, sigma_rot_deg=0.5, sigma_t=0.01):
+    w = rng.randn(3) * np.deg2rad(sigma_rot_deg)
+    dR = _rot(*w)
+    T = Tcw.copy()
+    T[:3, :3] = dR @ Tcw[:3, :3]
+    T[:3, 3] = dR @ Tcw[:3, 3] + rng.randn(3) * sigma_t
+    return T
+
+
+# ---------------------------------------------------------------- local BA problems
+def make_lba_problem(n_free=20, n_fixed=10, n_points=2000, seed=SEED_LBA, width=640, height=480,
+                     outlier_frac=0.03, mono_frac=0.0, min_obs=3, max_obs=8):
+    """Synthetic LBA problem of SURVEY.md section 8d: poses on a trajectory, each point seen by a contiguous run of
+    min_obs..max_obs keyframes, pixel noise sigma = 1 px * scale[octave], gross outliers, float32 inputs.
+    Pose order: fixed poses first (lower keyframe ids), then free ones -- ascending vertex id."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    cam = camera_for(width, height)
+    fx, fy, cx, cy, bf = [float(cam[k]) for k in ("fx", "fy", "cx", "cy", "bf")]
+    P = n_free + n_fixed
+    poses_true = np.zeros((P, 4, 4))
+    for k in range(P):
+        R = _rot(0.02 * np.sin(0.3 * k), 0.03 * np.sin(0.2 * k + 1.0), 0.01 * np.sin(0.5 * k))
+        C = np.array([0.12 * k, 0.02 * np.sin(0.4 * k), 0.03 * np.cos(0.3 * k)])
+        poses_true[k] = np.eye(4)
+        poses_true[k, :3, :3] = R
+        poses_true[k, :3, 3] = -R @ C
+    scales = 1.2 ** np.arange(8)
+    level_p = np.array([217, 181, 151, 126, 105, 87, 73, 60], np.float64)
+    level_p /= level_p.sum()
+    points_true = np.zeros((n_points, 3))
+    edges = []
+    for j in range(n_points):
+        nobs = rng.randint(min_obs, max_obs + 1)
+        k0 = rng.randint(0, max(P - nobs, 0) + 1)
+        kc = min(k0 + nobs // 2, P - 1)
+        # a point in front of the middle observing camera
+        z = rng.uniform(2.0, 9.0)
+        u = rng.uniform(60, width - 60); v = rng.uniform(60, height - 60)
+        Pc = np.array([(u - cx) * z / fx, (v - cy) * z / fy, z])
+        Rc, tc = poses_true[kc, :3, :3], poses_true[kc, :3, 3]
+        Xw = Rc.T @ (Pc - tc)
+        points_true[j] = Xw
+        for k in range(k0, min(k0 + nobs, P)):
+            Xc = poses_true[k, :3, :3] @ Xw + poses_true[k, :3, 3]
+            if Xc[2] < 0.3:
+                continue
+            uu = fx * Xc[0] / Xc[2] + cx; vv = fy * Xc[1] / Xc[2] + cy
+            if not (0 <= uu < width and 0 <= vv < height):
+                continue
+            octave = rng.choice(8, p=level_p)
+            s = scales[octave]
+            nu, nv, nr = rng.randn(3) * s
+            ur = uu - bf / Xc[2] + nr
+            if rng.rand() < outlier_frac:
+                nu += rng.choice([-20, 20]); nv += rng.choice([-20, 20])
+            is_mono = rng.rand() < mono_frac
+            edges.append((k, j, uu + nu, vv + nv, -1.0 if is_mono else ur, 1.0 / (s * s)))
+    E = np.zeros(len(edges), dtype=capi.EDGE_DTYPE)
+    for i, e in enumerate(edges):
+        E[i] = (e[0], e[1], np.float32(e[2]), np.float32(e[3]), np.float32(e[4]), np.float32(np.float32(1.0) / np.float32(e[5] ** -1)))
+    # inv_sigma2 as the reference computes it: 1.0f / (scale*scale) in float32
+    sc = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sc[i] = np.float32(sc[i - 1] * np.float32(1.2))
+    inv_s2 = (np.float32(1.0) / (sc * sc)).astype(np.float32)
+    oct_of = np.array([int(round(np.log(np.sqrt(1.0 / e[5])) / np.log(1.2))) for e in edges], np.int32) if edges else np.zeros(0, np.int32)
+    E["inv_sigma2"] = inv_s2[oct_of]
+    # noisy initial estimates, float32
+    poses0 = np.zeros((P, 16), np.float32)
+    fixed = np.zeros(P, np.uint8)
+    fixed[:n_fixed] = 1
+    for k in range(P):
+        T = poses_true[k].copy()
+        if not fixed[k]:
+            T = perturb_pose(T, rng, sigma_rot_deg=0.3, sigma_t=0.01)
+        poses0[k] = T.astype(np.float32).reshape(16)
+    points0 = (points_true + rng.randn(n_points, 3) * 0.02).astype(np.float32)
+    return dict(poses=poses0, pose_fixed=fixed, points=points0, edges=E, cam=(fx, fy, cx, cy, bf),
+                poses_true=poses_true, points_true=points_true)

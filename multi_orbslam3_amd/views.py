@@ -1,0 +1,134 @@
+"""Builders for the flattened views of include/orbgpu.h from numpy arrays.
+
+Each builder returns (ctypes struct, keepalive list): the struct only holds raw pointers, so the
+caller must keep the keepalive list referenced while the struct is in use.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def _c(a, dtype):
+    if a is None:
+        return None
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def frame_view(kps, desc, uright=None, depth=None, bounds=None, cam=None, n_levels=8, scale_factor=1.2):
+    """bounds = (min_x, max_x, min_y, max_y); cam = (fx, fy, cx, cy, bf, b)."""
+    kps = np.ascontiguousarray(kps, dtype=capi.KEYPOINT_DTYPE)
+    desc = _c(desc, np.uint8)
+    uright = _c(uright, np.float32)
+    depth = _c(depth, np.float32)
+    v = capi.FrameView()
+    v.n = len(kps)
+    v.kps, v.desc, v.uright, v.depth = capi.ptr(kps), capi.ptr(desc), capi.ptr(uright), capi.ptr(depth)
+    v.min_x, v.max_x, v.min_y, v.max_y = [float(b) for b in bounds]
+    v.fx, v.fy, v.cx, v.cy, v.bf, v.b = [float(c) for c in cam]
+    v.n_levels = int(n_levels)
+    v.scale_factor = float(scale_factor)
+    return v, [kps, desc, uright, depth]
+
+
+def mappoints_view(track_in_view, bad, proj_x, proj_y, proj_xr, track_depth, scale_level, view_cos, desc, n_obs):
+    arrs = [_c(track_in_view, np.uint8), _c(bad, np.uint8), _c(proj_x, np.float32), _c(proj_y, np.float32),
+            _c(proj_xr, np.float32), _c(track_depth, np.float32), _c(scale_level, np.int32),
+            _c(view_cos, np.float32), _c(desc, np.uint8), _c(n_obs, np.int32)]
+    v = capi.MapPointsView()
+    v.m = len(arrs[0])
+    (v.track_in_view, v.bad, v.proj_x, v.proj_y, v.proj_xr, v.track_depth, v.scale_level, v.view_cos, v.desc,
+     v.n_obs) = [capi.ptr(a) for a in arrs]
+    return v, arrs
+
+
+def worldpoints_view(pos, normal, min_dist, max_dist, desc, n_obs, bad, skip=None):
+    arrs = [_c(pos, np.float32), _c(normal, np.float32), _c(min_dist, np.float32), _c(max_dist, np.float32),
+            _c(desc, np.uint8), _c(n_obs, np.int32), _c(bad, np.uint8), _c(skip, np.uint8)]
+    v = capi.WorldPointsView()
+    v.m = len(arrs[2])
+    v.pos, v.normal, v.min_dist, v.max_dist, v.desc, v.n_obs, v.bad, v.skip = [capi.ptr(a) for a in arrs]
+    return v, arrs
+
+
+def lastframe_view(mp_valid, outlier, world_pos, desc, octave, angle, n_obs, Tcw):
+    arrs = [_c(mp_valid, np.uint8), _c(outlier, np.uint8), _c(world_pos, np.float32), _c(desc, np.uint8),
+            _c(octave, np.int32), _c(angle, np.float32), _c(n_obs, np.int32)]
+    v = capi.LastFrameView()
+    v.n = len(arrs[0])
+    v.mp_valid, v.outlier, v.world_pos, v.desc, v.octave, v.angle, v.n_obs = [capi.ptr(a) for a in arrs]
+    T = np.asarray(Tcw, dtype=np.float32).reshape(16)
+    for i in range(16):
+        v.Tcw[i] = float(T[i])
+    return v, arrs
+
+
+def featvec_view(node_id, start, feat_idx):
+    arrs = [_c(node_id, np.uint32), _c(start, np.uint32), _c(feat_idx, np.uint32)]
+    v = capi.FeatVecView()
+    v.n_nodes = len(arrs[0])
+    v.node_id, v.start, v.feat_idx = [capi.ptr(a) for a in arrs]
+    return v, arrs
+
+
+def featvec_from_nodes(node_of_feature):
+    """Group feature indices by node id (ascending), as DBoW2::FeatureVector does (std::map + push_back)."""
+    node_of_feature = np.asarray(node_of_feature, dtype=np.int64)
+    order = np.argsort(node_of_feature, kind="stable")
+    nodes, counts = np.unique(node_of_feature, return_counts=True)
+    start = np.zeros(len(nodes) + 1, dtype=np.uint32)
+    start[1:] = np.cumsum(counts)
+    return nodes.astype(np.uint32), start, order.astype(np.uint32)
+
+
+def lba_problem(poses, pose_fixed, points, edges, cam, lambda_init=0.0, its=(5, 10), device=0):
+    """poses: (P,16) or (P,4,4) float32; edges: structured EDGE_DTYPE; cam = (fx, fy, cx, cy, bf)."""
+    poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 16))
+    pose_fixed = _c(pose_fixed, np.uint8)
+    points = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(-1, 3))
+    edges = np.ascontiguousarray(edges, dtype=capi.EDGE_DTYPE)
+    p = capi.LbaProblem()
+    p.n_poses, p.n_points, p.n_edges = len(poses), len(points), len(edges)
+    p.poses, p.pose_fixed, p.points, p.edges = capi.ptr(poses), capi.ptr(pose_fixed), capi.ptr(points), capi.ptr(edges)
+    p.fx, p.fy, p.cx, p.cy, p.bf = [float(c) for c in cam]
+    p.lambda_init = float(lambda_init)
+    p.its_round1, p.its_round2 = int(its[0]), int(its[1])
+    p.device = int(device)
+    return p, [poses, pose_fixed, points, edges]
+
+
+class LbaOutput:
+    """Owns the result arrays of one LBA call."""
+
+    def __init__(self, n_poses, n_points, n_edges, trace_cap=64):
+        self.poses = np.zeros((n_poses, 16), dtype=np.float32)
+        self.points = np.zeros((n_points, 3), dtype=np.float32)
+        self.edge_chi2 = np.zeros(n_edges, dtype=np.float64)
+        self.edge_depth_pos = np.zeros(n_edges, dtype=np.uint8)
+        self.edge_outlier = np.zeros(n_edges, dtype=np.uint8)
+        self.trace = np.zeros((trace_cap, 3), dtype=np.float64)
+        r = capi.LbaResult()
+        r.poses, r.points = capi.ptr(self.poses), capi.ptr(self.points)
+        r.edge_chi2, r.edge_depth_pos, r.edge_outlier = capi.ptr(self.edge_chi2), capi.ptr(self.edge_depth_pos), capi.ptr(self.edge_outlier)
+        r.trace, r.trace_cap, r.trace_len = capi.ptr(self.trace), trace_cap, 0
+        self.c = r
+
+    @property
+    def status(self):
+        return self.c.status
+
+    @property
+    def iters(self):
+        return (self.c.iters_round1, self.c.iters_round2)
+
+    @property
+    def n_outliers(self):
+        return self.c.n_outliers
+
+    @property
+    def chi2(self):
+        return (self.c.chi2_initial, self.c.chi2_final)
+
+    def trace_rows(self):
+        return self.trace[: self.c.trace_len].copy()

@@ -1,0 +1,298 @@
+"""ctypes binding of the CPU ORACLE (oracle/liboracle.so) -- test infrastructure only.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product
+package.  Builds the library on demand with oracle/Makefile (g++, no dependencies).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from multi_orbslam3_amd import _capi as capi
+from multi_orbslam3_amd import views
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("extractor.cc", "matching.cc", "lba.cc", "orb_oracle.h",
+                                             "orb_pattern_data.inc", "Makefile")]
+    srcs.append(os.path.join(_HERE, "..", "include", "orbgpu.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.oracle_fast_atan2.restype = C.c_float
+        _lib.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+    return _lib
+
+
+def _chk(code):
+    if code != 0:
+        raise RuntimeError("oracle error %d" % code)
+
+
+# ---------------------------------------------------------------- image primitives
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.zeros((dh, dw), dtype=np.uint8)
+    lib().oracle_resize_linear(C.c_void_p(src.ctypes.data), src.shape[1], src.shape[0], src.strides[0],
+                               C.c_void_p(dst.ctypes.data), dw, dh, dst.strides[0])
+    return dst
+
+
+def border_reflect101(src, border):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    dst = np.zeros((h + 2 * border, w + 2 * border), dtype=np.uint8)
+    lib().oracle_border_reflect101(C.c_void_p(src.ctypes.data), w, h, src.strides[0], C.c_void_p(dst.ctypes.data),
+                                   border, dst.strides[0])
+    return dst
+
+
+def fast_score(img, x, y):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    return lib().oracle_fast_score(C.c_void_p(img.ctypes.data), img.strides[0], x, y)
+
+
+def fast_detect(img, threshold, nonmax=True, cap=65536):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros((cap, 3), dtype=np.int32)
+    n = lib().oracle_fast_detect(C.c_void_p(img.ctypes.data), img.shape[1], img.shape[0], img.strides[0],
+                                 int(threshold), int(nonmax), C.c_void_p(out.ctypes.data), cap)
+    return out[:n].copy()
+
+
+def gaussian_blur7(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    dst = np.zeros_like(img)
+    lib().oracle_gaussian_blur7(C.c_void_p(img.ctypes.data), img.shape[1], img.shape[0], img.strides[0],
+                                C.c_void_p(dst.ctypes.data), dst.strides[0])
+    return dst
+
+
+def fast_atan2(y, x):
+    return float(lib().oracle_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return lib().oracle_hamming(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data))
+
+
+# ---------------------------------------------------------------- extractor
+def make_config(n_features=1000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7, max_width=640, max_height=480,
+                n_cams=1, device=0):
+    return capi.OrbxConfig(n_features, scale_factor, n_levels, ini_th, min_th, max_width, max_height, n_cams, device)
+
+
+class Extractor:
+    """oracle restatement of ORB_SLAM3::ORBextractor."""
+
+    def __init__(self, **kw):
+        self.cfg = make_config(**kw)
+        self.h = C.c_void_p()
+        _chk(lib().oracle_extractor_create(C.byref(self.cfg), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().oracle_extractor_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def tables(self):
+        nl = self.cfg.n_levels
+        arrs = [np.zeros(nl, np.float32) for _ in range(4)] + [np.zeros(nl, np.int32)]
+        _chk(lib().oracle_get_tables(self.h, *[C.c_void_p(a.ctypes.data) for a in arrs]))
+        return arrs
+
+    def umax(self):
+        u = np.zeros(16, np.int32)
+        lib().oracle_get_umax(self.h, C.c_void_p(u.ctypes.data))
+        return u
+
+    def extract(self, img, lap=(0, 0), cap=None):
+        cap = cap or self.cfg.n_features * 2 + 64
+        kps = np.zeros(cap, dtype=capi.KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n, nm = C.c_int(0), C.c_int(0)
+        if img is None or img.size == 0:
+            rc = lib().oracle_extract(self.h, None, 0, 0, 0, lap[0], lap[1], C.c_void_p(kps.ctypes.data),
+                                      C.c_void_p(desc.ctypes.data), cap, C.byref(n), C.byref(nm))
+            return rc, kps[:0], desc[:0], 0
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rc = lib().oracle_extract(self.h, C.c_void_p(img.ctypes.data), img.shape[1], img.shape[0], img.strides[0],
+                                  lap[0], lap[1], C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), cap,
+                                  C.byref(n), C.byref(nm))
+        return rc, kps[: n.value].copy(), desc[: n.value].copy(), nm.value
+
+    def level(self, l):
+        w, h = C.c_int(0), C.c_int(0)
+        _chk(lib().oracle_get_level(self.h, l, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _chk(lib().oracle_get_level(self.h, l, C.c_void_p(out.ctypes.data), C.byref(w), C.byref(h)))
+        return out
+
+    def candidates(self, l, cap=1 << 18):
+        out = np.zeros((cap, 3), np.int32)
+        n = C.c_int(0)
+        _chk(lib().oracle_get_candidates(self.h, l, C.c_void_p(out.ctypes.data), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+
+def distribute_octree(xys, min_x, max_x, min_y, max_y, n_target):
+    xys = np.ascontiguousarray(xys, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros((max(len(xys), 1), 3), np.int32)
+    n = lib().oracle_distribute_octree(C.c_void_p(xys.ctypes.data), len(xys), min_x, max_x, min_y, max_y, n_target,
+                                       C.c_void_p(out.ctypes.data), len(out))
+    return out[:n].copy()
+
+
+def stereo_match(ex_l, ex_r, kps_l, desc_l, kps_r, desc_r, bf, b):
+    kps_l = np.ascontiguousarray(kps_l, dtype=capi.KEYPOINT_DTYPE)
+    kps_r = np.ascontiguousarray(kps_r, dtype=capi.KEYPOINT_DTYPE)
+    desc_l = np.ascontiguousarray(desc_l, np.uint8)
+    desc_r = np.ascontiguousarray(desc_r, np.uint8)
+    ur = np.zeros(len(kps_l), np.float32)
+    dp = np.zeros(len(kps_l), np.float32)
+    _chk(lib().oracle_stereo_match(ex_l.h, ex_r.h, C.c_void_p(kps_l.ctypes.data), C.c_void_p(desc_l.ctypes.data),
+                                   len(kps_l), C.c_void_p(kps_r.ctypes.data), C.c_void_p(desc_r.ctypes.data),
+                                   len(kps_r), C.c_float(bf), C.c_float(b), C.c_void_p(ur.ctypes.data),
+                                   C.c_void_p(dp.ctypes.data)))
+    return ur, dp
+
+
+# ---------------------------------------------------------------- frame / matchers
+def build_grid(fv):
+    start = np.zeros(capi.GRID_COLS * capi.GRID_ROWS + 1, np.int32)
+    items = np.zeros(max(fv.n, 1), np.int32)
+    _chk(lib().oracle_build_grid(C.byref(fv), C.c_void_p(start.ctypes.data), C.c_void_p(items.ctypes.data)))
+    return start, items[: start[-1]].copy()
+
+
+def features_in_area(fv, x, y, r, min_level=-1, max_level=-1):
+    out = np.zeros(max(fv.n, 1), np.int32)
+    n = lib().oracle_features_in_area(C.byref(fv), C.c_float(x), C.c_float(y), C.c_float(r), min_level, max_level,
+                                      C.c_void_p(out.ctypes.data), len(out))
+    return out[:n].copy()
+
+
+def is_in_frustum(fv, Tcw, wv, limit=0.5):
+    m = wv.m
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    out = dict(track_in_view=np.zeros(m, np.uint8), proj_x=np.zeros(m, np.float32), proj_y=np.zeros(m, np.float32),
+               proj_xr=np.zeros(m, np.float32), track_depth=np.zeros(m, np.float32),
+               scale_level=np.zeros(m, np.int32), view_cos=np.zeros(m, np.float32))
+    _chk(lib().oracle_is_in_frustum(C.byref(fv), C.c_void_p(T.ctypes.data), C.byref(wv), C.c_float(limit),
+                                    *[C.c_void_p(out[k].ctypes.data) for k in
+                                      ("track_in_view", "proj_x", "proj_y", "proj_xr", "track_depth", "scale_level",
+                                       "view_cos")]))
+    return out
+
+
+def hamming_matrix(q, t):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    d = np.zeros((len(q), len(t)), np.int32)
+    _chk(lib().oracle_hamming_matrix(C.c_void_p(q.ctypes.data), len(q), C.c_void_p(t.ctypes.data), len(t),
+                                     C.c_void_p(d.ctypes.data)))
+    return d
+
+
+def hamming_best2(q, t):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    o = np.zeros((len(q), 4), np.int32)
+    _chk(lib().oracle_hamming_best2(C.c_void_p(q.ctypes.data), len(q), C.c_void_p(t.ctypes.data), len(t),
+                                    C.c_void_p(o.ctypes.data)))
+    return o
+
+
+def search_by_projection_mps(fv, mv, th, far, th_far, nnratio, assigned_mp, assigned_obs):
+    amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+    aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_projection_mps(C.byref(fv), C.byref(mv), C.c_float(th), int(far), C.c_float(th_far),
+                                               C.c_float(nnratio), C.c_void_p(amp.ctypes.data),
+                                               C.c_void_p(aob.ctypes.data), C.byref(n)))
+    return amp, aob, n.value
+
+
+def search_local_points(fv, wv, Tcw, th, far, th_far, nnratio, assigned_mp, assigned_obs):
+    amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+    aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_local_points(C.byref(fv), C.byref(wv), C.c_void_p(T.ctypes.data), C.c_float(th), int(far),
+                                          C.c_float(th_far), C.c_float(nnratio), C.c_void_p(amp.ctypes.data),
+                                          C.c_void_p(aob.ctypes.data), C.byref(n)))
+    return amp, aob, n.value
+
+
+def search_by_projection_frame(fv, Tcw_cur, lv, th, mono, check_ori, assigned_mp, assigned_obs):
+    amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+    aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+    T = np.ascontiguousarray(Tcw_cur, np.float32).reshape(16)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_projection_frame(C.byref(fv), C.c_void_p(T.ctypes.data), C.byref(lv), C.c_float(th),
+                                                 int(mono), int(check_ori), C.c_void_p(amp.ctypes.data),
+                                                 C.c_void_p(aob.ctypes.data), C.byref(n)))
+    return amp, aob, n.value
+
+
+def search_by_bow(fv, fvF, kf_desc, kf_mp_valid, kf_angle, fvK, nnratio, check_ori):
+    kf_desc = np.ascontiguousarray(kf_desc, np.uint8)
+    kf_mp_valid = np.ascontiguousarray(kf_mp_valid, np.uint8)
+    kf_angle = np.ascontiguousarray(kf_angle, np.float32)
+    matches = np.zeros(max(fv.n, 1), np.int32)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_bow(C.byref(fv), C.byref(fvF), C.c_void_p(kf_desc.ctypes.data), len(kf_desc),
+                                    C.c_void_p(kf_mp_valid.ctypes.data), C.c_void_p(kf_angle.ctypes.data),
+                                    C.byref(fvK), C.c_float(nnratio), int(check_ori), C.c_void_p(matches.ctypes.data),
+                                    C.byref(n)))
+    return matches[: fv.n].copy(), n.value
+
+
+# ---------------------------------------------------------------- LBA
+def lba_solve(problem, stop_flag=None, trace_cap=64):
+    out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)
+    sp = None
+    if stop_flag is not None:
+        sp = C.c_void_p(stop_flag.ctypes.data)
+    _chk(lib().oracle_lba_solve(C.byref(problem), sp, C.byref(out.c)))
+    return out
+
+
+def se3_exp(upd6):
+    u = np.ascontiguousarray(upd6, np.float64)
+    q = np.zeros(4)
+    t = np.zeros(3)
+    lib().oracle_se3_exp(C.c_void_p(u.ctypes.data), C.c_void_p(q.ctypes.data), C.c_void_p(t.ctypes.data))
+    return q, t
+
+
+def lba_edge_eval(q, t, X, cam5, edge):
+    q = np.ascontiguousarray(q, np.float64)
+    t = np.ascontiguousarray(t, np.float64)
+    X = np.ascontiguousarray(X, np.float64)
+    cam = np.ascontiguousarray(cam5, np.float32)
+    e = np.ascontiguousarray(edge, dtype=capi.EDGE_DTYPE).reshape(1)
+    err, A, B = np.zeros(3), np.zeros(9), np.zeros(18)
+    lib().oracle_lba_edge_eval(C.c_void_p(q.ctypes.data), C.c_void_p(t.ctypes.data), C.c_void_p(X.ctypes.data),
+                               C.c_void_p(cam.ctypes.data), C.c_void_p(e.ctypes.data), C.c_void_p(err.ctypes.data),
+                               C.c_void_p(A.ctypes.data), C.c_void_p(B.ctypes.data))
+    return err, A.reshape(3, 3), B.reshape(3, 6)

@@ -1,0 +1,543 @@
+// ORACLE (test infrastructure, not product code) -- see orb_oracle.h for status: parity unpinned.
+//
+// CPU restatement of Frame::ComputeStereoMatches / grid / isInFrustum (S/Frame.cc) and of the
+// ORBmatcher searches on the hot path (S/ORBmatcher.cc), over the flattened views of include/orbgpu.h.
+//
+// Float conventions for cv::Mat expressions (OpenCV 3.x gemm small-matrix path, core/src/matmul.cpp;
+// norm/dot accumulate in double):
+//   R*X + t      -> per row: float t0 = r0*X0 + r1*X1 + r2*X2 (float, left to right); out = (float)(t0 + t)
+//   -R^T * t     -> general gemm path: out_i = (float)(-(sum_k (double)R[k][i]*(double)t[k]))
+//   cv::norm(v)  -> (float) sqrt(sum (double)v_i^2);   a.dot(b) -> sum (double)a_i*b_i
+
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+const uint8_t* oracle_level_ptr(const oracle_extractor* e, int level, int* w, int* h, int* stride);
+const std::vector<float>& oracle_scale(const oracle_extractor* e);
+const std::vector<float>& oracle_inv_scale(const oracle_extractor* e);
+
+namespace {
+constexpr int TH_HIGH = 100;      // S/ORBmatcher.cc:36
+constexpr int TH_LOW = 50;        // :37
+constexpr int HISTO_LENGTH = 30;  // :38
+
+struct ScaleTables {
+  std::vector<float> scale;
+  float log_sf;
+  explicit ScaleTables(const orbm_frame_view* v) {
+    scale.resize(v->n_levels);
+    scale[0] = 1.0f;
+    for (int i = 1; i < v->n_levels; i++) scale[i] = scale[i - 1] * v->scale_factor;   // S/ORBextractor.cc:413-421
+    log_sf = std::log(v->scale_factor);   // mfLogScaleFactor = log(mfScaleFactor), float overload
+  }
+};
+
+struct Grid {
+  std::vector<int32_t> start, items;
+  float w_inv, h_inv;
+};
+
+// Frame::PosInGrid -- S/Frame.cc:699-709
+inline bool pos_in_grid(const orbm_frame_view* v, float w_inv, float h_inv, float x, float y, int* px, int* py) {
+  *px = (int)std::round((x - v->min_x) * w_inv);
+  *py = (int)std::round((y - v->min_y) * h_inv);
+  return !(*px < 0 || *px >= ORBG_GRID_COLS || *py < 0 || *py >= ORBG_GRID_ROWS);
+}
+
+// Frame::AssignFeaturesToGrid -- S/Frame.cc:360-391 (Nleft == -1); CSR cell id = ix*48+iy.
+Grid build_grid(const orbm_frame_view* v) {
+  Grid g;
+  g.w_inv = static_cast<float>(ORBG_GRID_COLS) / static_cast<float>(v->max_x - v->min_x);   // S/Frame.cc:127-144
+  g.h_inv = static_cast<float>(ORBG_GRID_ROWS) / static_cast<float>(v->max_y - v->min_y);
+  const int nc = ORBG_GRID_COLS * ORBG_GRID_ROWS;
+  g.start.assign(nc + 1, 0);
+  std::vector<int> cell(v->n, -1);
+  for (int i = 0; i < v->n; i++) {
+    int px, py;
+    if (pos_in_grid(v, g.w_inv, g.h_inv, v->kps[i].x, v->kps[i].y, &px, &py)) {
+      cell[i] = px * ORBG_GRID_ROWS + py;
+      g.start[cell[i] + 1]++;
+    }
+  }
+  for (int c = 0; c < nc; c++) g.start[c + 1] += g.start[c];
+  g.items.assign(g.start[nc], 0);
+  std::vector<int> fill(g.start.begin(), g.start.end() - 1);
+  for (int i = 0; i < v->n; i++)
+    if (cell[i] >= 0) g.items[fill[cell[i]]++] = i;
+  return g;
+}
+
+// Frame::GetFeaturesInArea -- S/Frame.cc:628-697 (bRight = false, Nleft == -1)
+void features_in_area(const orbm_frame_view* v, const Grid& g, float x, float y, float r, int minLevel, int maxLevel,
+                      std::vector<int>& out) {
+  out.clear();
+  const float factorX = r, factorY = r;
+  const int nMinCellX = std::max(0, (int)std::floor((x - v->min_x - factorX) * g.w_inv));
+  if (nMinCellX >= ORBG_GRID_COLS) return;
+  const int nMaxCellX = std::min((int)ORBG_GRID_COLS - 1, (int)std::ceil((x - v->min_x + factorX) * g.w_inv));
+  if (nMaxCellX < 0) return;
+  const int nMinCellY = std::max(0, (int)std::floor((y - v->min_y - factorY) * g.h_inv));
+  if (nMinCellY >= ORBG_GRID_ROWS) return;
+  const int nMaxCellY = std::min((int)ORBG_GRID_ROWS - 1, (int)std::ceil((y - v->min_y + factorY) * g.h_inv));
+  if (nMaxCellY < 0) return;
+  const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      const int c = ix * ORBG_GRID_ROWS + iy;
+      for (int j = g.start[c]; j < g.start[c + 1]; j++) {
+        const orbx_keypoint& kp = v->kps[g.items[j]];
+        if (bCheckLevels) {
+          if (kp.octave < minLevel) continue;
+          if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+        }
+        const float distx = kp.x - x, disty = kp.y - y;
+        if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) out.push_back(g.items[j]);
+      }
+    }
+}
+
+struct Pose {
+  float R[9], t[3], Ow[3];
+  explicit Pose(const float* T) {
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) R[3 * i + j] = T[4 * i + j];
+      t[i] = T[4 * i + 3];
+    }
+    for (int i = 0; i < 3; i++) {   // mOw = -mRcw.t()*mtcw  (S/Frame.cc:439-445)
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += (double)R[3 * k + i] * (double)t[k];
+      Ow[i] = (float)(-s);
+    }
+  }
+  void map(const float* X, float* out) const {   // R*X + t
+    for (int i = 0; i < 3; i++) {
+      float t0 = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2];
+      out[i] = (float)(t0 + t[i]);
+    }
+  }
+};
+
+inline float norm3(const float* v) {
+  double s = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2];
+  return (float)std::sqrt(s);
+}
+
+// Frame::isInFrustum -- S/Frame.cc:466-543 (Nleft == -1) with MapPoint::PredictScale S/MapPoint.cc:646-661
+struct TrackFields { bool in_view; float px, py, pxr, depth, view_cos; int level; };
+TrackFields is_in_frustum(const orbm_frame_view* v, const ScaleTables& st, const Pose& pose, const float* P,
+                          const float* Pn, float min_dist_raw, float max_dist_raw, float limit) {
+  TrackFields f{false, -1.f, -1.f, 0.f, 0.f, 0.f, 0};
+  float Pc[3];
+  pose.map(P, Pc);
+  const float Pc_dist = norm3(Pc);
+  const float PcZ = Pc[2];
+  const float invz = 1.0f / PcZ;
+  if (PcZ < 0.0f) return f;
+  const float u = v->fx * Pc[0] / Pc[2] + v->cx;    // Pinhole::project S/CameraModels/Pinhole.cpp:41-47
+  const float vv = v->fy * Pc[1] / Pc[2] + v->cy;
+  if (u < v->min_x || u > v->max_x) return f;
+  if (vv < v->min_y || vv > v->max_y) return f;
+  f.px = u; f.py = vv;
+  const float maxDistance = 1.2f * max_dist_raw;    // S/MapPoint.cc:617-627
+  const float minDistance = 0.8f * min_dist_raw;
+  const float PO[3] = {P[0] - pose.Ow[0], P[1] - pose.Ow[1], P[2] - pose.Ow[2]};
+  const float dist = norm3(PO);
+  if (dist < minDistance || dist > maxDistance) return f;
+  const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+  const float viewCos = (float)(dot / dist);
+  if (viewCos < limit) return f;
+  const float ratio = max_dist_raw / dist;          // PredictScale
+  int nScale = (int)std::ceil(std::log(ratio) / st.log_sf);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= v->n_levels) nScale = v->n_levels - 1;
+  f.in_view = true;
+  f.pxr = u - v->bf * invz;
+  f.depth = Pc_dist;
+  f.level = nScale;
+  f.view_cos = viewCos;
+  return f;
+}
+
+// ORBmatcher::ComputeThreeMaxima -- S/ORBmatcher.cc:2312-2353
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+inline int rot_bin(float a1, float a2) {   // S/ORBmatcher.cc:2082-2087 (factor = 1/HISTO_LENGTH, Appendix C-3)
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+}  // namespace
+
+// ORBmatcher::DescriptorDistance -- S/ORBmatcher.cc:2358-2374
+extern "C" int oracle_hamming(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t pa, pb;
+    std::memcpy(&pa, a + 4 * i, 4);
+    std::memcpy(&pb, b + 4 * i, 4);
+    unsigned int v = pa ^ pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+extern "C" int oracle_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* dist) {
+  for (int i = 0; i < nq; i++)
+    for (int j = 0; j < nt; j++) dist[(size_t)i * nt + j] = oracle_hamming(q + 32 * (size_t)i, t + 32 * (size_t)j);
+  return ORBG_OK;
+}
+
+// Sequential best / second-best scan exactly as the matcher inner loops do it (S/ORBmatcher.cc:104-120).
+extern "C" int oracle_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out4) {
+  for (int i = 0; i < nq; i++) {
+    int best = 256, best2 = 256, bi = -1, bi2 = -1;
+    for (int j = 0; j < nt; j++) {
+      int d = oracle_hamming(q + 32 * (size_t)i, t + 32 * (size_t)j);
+      if (d < best) { best2 = best; bi2 = bi; best = d; bi = j; }
+      else if (d < best2) { best2 = d; bi2 = j; }
+    }
+    out4[4 * i] = best; out4[4 * i + 1] = bi; out4[4 * i + 2] = best2; out4[4 * i + 3] = bi2;
+  }
+  return ORBG_OK;
+}
+
+extern "C" int oracle_build_grid(const orbm_frame_view* view, int32_t* cell_start, int32_t* cell_items) {
+  Grid g = build_grid(view);
+  std::memcpy(cell_start, g.start.data(), g.start.size() * sizeof(int32_t));
+  if (!g.items.empty()) std::memcpy(cell_items, g.items.data(), g.items.size() * sizeof(int32_t));
+  return ORBG_OK;
+}
+
+extern "C" int oracle_features_in_area(const orbm_frame_view* view, float x, float y, float r, int min_level,
+                                       int max_level, int32_t* out_idx, int cap) {
+  Grid g = build_grid(view);
+  std::vector<int> out;
+  features_in_area(view, g, x, y, r, min_level, max_level, out);
+  for (size_t i = 0; i < out.size() && (int)i < cap; i++) out_idx[i] = out[i];
+  return (int)out.size();
+}
+
+extern "C" int oracle_is_in_frustum(const orbm_frame_view* view, const float* Tcw, const orbm_worldpoints_view* pts,
+                                    float limit, uint8_t* track_in_view, float* proj_x, float* proj_y,
+                                    float* proj_xr, float* track_depth, int32_t* scale_level, float* view_cos) {
+  ScaleTables st(view);
+  Pose pose(Tcw);
+  for (int i = 0; i < pts->m; i++) {
+    TrackFields f = is_in_frustum(view, st, pose, pts->pos + 3 * i, pts->normal + 3 * i, pts->min_dist[i],
+                                  pts->max_dist[i], limit);
+    track_in_view[i] = f.in_view;
+    proj_x[i] = f.px; proj_y[i] = f.py; proj_xr[i] = f.pxr; track_depth[i] = f.depth;
+    scale_level[i] = f.level; view_cos[i] = f.view_cos;
+  }
+  return ORBG_OK;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
+// -- S/ORBmatcher.cc:44-214, Nleft == -1 branch only.
+extern "C" int oracle_search_by_projection_mps(const orbm_frame_view* view, const orbm_mappoints_view* mps, float th,
+                                               int far_points, float th_far_points, float nnratio,
+                                               int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches_out) {
+  ScaleTables st(view);
+  Grid g = build_grid(view);
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  std::vector<int> vIndices;
+  for (int iMP = 0; iMP < mps->m; iMP++) {
+    if (!mps->track_in_view[iMP]) continue;                                   // :53 (mbTrackInViewR false)
+    if (far_points && mps->track_depth[iMP] > th_far_points) continue;        // :56
+    if (mps->bad[iMP]) continue;                                              // :59
+    const int nPredictedLevel = mps->scale_level[iMP];
+    float r = (mps->view_cos[iMP] > 0.998) ? 2.5f : 4.0f;                     // RadiusByViewingCos :216-222
+    if (bFactor) r *= th;
+    features_in_area(view, g, mps->proj_x[iMP], mps->proj_y[iMP], r * st.scale[nPredictedLevel], nPredictedLevel - 1,
+                     nPredictedLevel, vIndices);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = mps->desc + 32 * (size_t)iMP;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (assigned_mp[idx] >= 0 && assigned_obs[idx] > 0) continue;           // :89-91
+      if (view->uright && view->uright[idx] > 0) {                             // :93-98
+        const float er = std::fabs(mps->proj_xr[iMP] - view->uright[idx]);
+        if (er > r * st.scale[nPredictedLevel]) continue;
+      }
+      const int dist = oracle_hamming(dMP, view->desc + 32 * (size_t)idx);
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel;
+        bestLevel = view->kps[idx].octave; bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = view->kps[idx].octave; bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {                                                 // :124-141
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+        assigned_mp[bestIdx] = iMP;
+        assigned_obs[bestIdx] = mps->n_obs[iMP];
+        nmatches++;
+      }
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
+// Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153): isInFrustum(.,0.5) then SearchByProjection.
+extern "C" int oracle_search_local_points(const orbm_frame_view* view, const orbm_worldpoints_view* pts, const float* Tcw,
+                                          float th, int far_points, float th_far_points, float nnratio,
+                                          int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches) {
+  const int m = pts->m;
+  std::vector<uint8_t> tiv(m);
+  std::vector<float> px(m), py(m), pxr(m), dep(m), vc(m);
+  std::vector<int32_t> lvl(m);
+  oracle_is_in_frustum(view, Tcw, pts, 0.5f, tiv.data(), px.data(), py.data(), pxr.data(), dep.data(), lvl.data(), vc.data());
+  for (int i = 0; i < m; i++)
+    if ((pts->skip && pts->skip[i]) || pts->bad[i]) tiv[i] = 0;
+  orbm_mappoints_view mv;
+  mv.m = m; mv.track_in_view = tiv.data(); mv.bad = pts->bad; mv.proj_x = px.data(); mv.proj_y = py.data();
+  mv.proj_xr = pxr.data(); mv.track_depth = dep.data(); mv.scale_level = lvl.data(); mv.view_cos = vc.data();
+  mv.desc = pts->desc; mv.n_obs = pts->n_obs;
+  return oracle_search_by_projection_mps(view, &mv, th, far_points, th_far_points, nnratio, assigned_mp, assigned_obs, nmatches);
+}
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
+// -- S/ORBmatcher.cc:1970-2186, Nleft == -1.
+extern "C" int oracle_search_by_projection_frame(const orbm_frame_view* cur, const float* Tcw_cur,
+                                                 const orbm_lastframe_view* last, float th, int mono, int check_ori,
+                                                 int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches_out) {
+  ScaleTables st(cur);
+  Grid g = build_grid(cur);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  Pose pc(Tcw_cur), pl(last->Tcw);
+  // twc = -Rcw.t()*tcw ; tlc = Rlw*twc+tlw   :1983-1988
+  float tlc[3];
+  pl.map(pc.Ow, tlc);
+  const bool bForward = tlc[2] > cur->b && !mono;
+  const bool bBackward = -tlc[2] > cur->b && !mono;
+  std::vector<int> vIndices2;
+  for (int i = 0; i < last->n; i++) {
+    if (!last->mp_valid[i] || last->outlier[i]) continue;
+    float x3Dc[3];
+    pc.map(last->world_pos + 3 * i, x3Dc);
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    if (invzc < 0) continue;
+    const float u = cur->fx * xc / x3Dc[2] + cur->cx;
+    const float v = cur->fy * yc / x3Dc[2] + cur->cy;
+    if (u < cur->min_x || u > cur->max_x) continue;
+    if (v < cur->min_y || v > cur->max_y) continue;
+    const int nLastOctave = last->octave[i];
+    const float radius = th * st.scale[nLastOctave];
+    if (bForward) features_in_area(cur, g, u, v, radius, nLastOctave, -1, vIndices2);
+    else if (bBackward) features_in_area(cur, g, u, v, radius, 0, nLastOctave, vIndices2);
+    else features_in_area(cur, g, u, v, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = last->desc + 32 * (size_t)i;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (assigned_mp[i2] >= 0 && assigned_obs[i2] > 0) continue;                // :2045-2047
+      if (cur->uright && cur->uright[i2] > 0) {                                   // :2049-2055
+        const float ur = u - cur->bf * invzc;
+        const float er = std::fabs(ur - cur->uright[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = oracle_hamming(dMP, cur->desc + 32 * (size_t)i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      assigned_mp[bestIdx2] = i;
+      assigned_obs[bestIdx2] = last->n_obs[i];
+      nmatches++;
+      if (check_ori) rotHist[rot_bin(last->angle[i], cur->kps[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (check_ori) {                                                                 // :2164-2183
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) {
+          assigned_mp[idx] = -1;
+          assigned_obs[idx] = 0;
+          nmatches--;
+        }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) -- S/ORBmatcher.cc:269-471, Nleft == -1.
+extern "C" int oracle_search_by_bow(const orbm_frame_view* view, const orbm_featvec_view* fvF,
+                                    const uint8_t* kf_desc, int nkf, const uint8_t* kf_mp_valid, const float* kf_angle,
+                                    const orbm_featvec_view* fvK, float nnratio, int check_ori,
+                                    int32_t* matches, int* nmatches_out) {
+  (void)nkf;
+  for (int i = 0; i < view->n; i++) matches[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int k = 0, f = 0;
+  while (k < fvK->n_nodes && f < fvF->n_nodes) {
+    if (fvK->node_id[k] == fvF->node_id[f]) {
+      for (uint32_t a = fvK->start[k]; a < fvK->start[k + 1]; a++) {
+        const uint32_t realIdxKF = fvK->feat_idx[a];
+        if (!kf_mp_valid[realIdxKF]) continue;                       // !pMP || pMP->isBad()
+        const uint8_t* dKF = kf_desc + 32 * (size_t)realIdxKF;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (uint32_t b = fvF->start[f]; b < fvF->start[f + 1]; b++) {
+          const uint32_t realIdxF = fvF->feat_idx[b];
+          if (matches[realIdxF] >= 0) continue;                      // :324-325
+          const int dist = oracle_hamming(dKF, view->desc + 32 * (size_t)realIdxF);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= TH_LOW) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches[bestIdxF] = (int)realIdxKF;
+            if (check_ori) rotHist[rot_bin(kf_angle[realIdxKF], view->kps[bestIdxF].angle)].push_back(bestIdxF);
+            nmatches++;
+          }
+        }
+      }
+      k++; f++;
+    } else if (fvK->node_id[k] < fvF->node_id[f]) {
+      // KFit = vFeatVecKF.lower_bound(Fit->first)
+      k = (int)(std::lower_bound(fvK->node_id, fvK->node_id + fvK->n_nodes, fvF->node_id[f]) - fvK->node_id);
+    } else {
+      f = (int)(std::lower_bound(fvF->node_id, fvF->node_id + fvF->n_nodes, fvK->node_id[k]) - fvF->node_id);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { matches[idx] = -1; nmatches--; }
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
+// Frame::ComputeStereoMatches -- S/Frame.cc:785-963.
+extern "C" int oracle_stereo_match(oracle_extractor* left, oracle_extractor* right,
+                                   const orbx_keypoint* kps_l, const uint8_t* desc_l, int N,
+                                   const orbx_keypoint* kps_r, const uint8_t* desc_r, int Nr,
+                                   float bf, float b, float* uright, float* depth) {
+  for (int i = 0; i < N; i++) { uright[i] = -1.0f; depth[i] = -1.0f; }
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  int w0, nRows, s0;
+  oracle_level_ptr(left, 0, &w0, &nRows, &s0);
+  const std::vector<float>& scaleF = oracle_scale(left);
+  const std::vector<float>& invScaleF = oracle_inv_scale(left);
+  std::vector<std::vector<int>> vRowIndices(nRows);
+  for (int iR = 0; iR < Nr; iR++) {                                            // :802-812
+    const float kpY = kps_r[iR].y;
+    const float r = 2.0f * scaleF[kps_r[iR].octave];
+    const int maxr = (int)std::ceil(kpY + r);
+    const int minr = (int)std::floor(kpY - r);
+    for (int yi = minr; yi <= maxr; yi++)
+      if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);                // clamp: Appendix C-8
+  }
+  const float minZ = b, minD = 0, maxD = bf / minZ;
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int iL = 0; iL < N; iL++) {
+    const orbx_keypoint& kpL = kps_l[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int row = (int)vL;
+    if (row < 0 || row >= nRows) continue;
+    const std::vector<int>& vCandidates = vRowIndices[row];
+    if (vCandidates.empty()) continue;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    int bestIdxR = 0;
+    const uint8_t* dL = desc_l + 32 * (size_t)iL;
+    for (int iR : vCandidates) {
+      const orbx_keypoint& kpR = kps_r[iR];
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = oracle_hamming(dL, desc_r + 32 * (size_t)iR);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {                                                // :871-946
+      const float uR0 = kps_r[bestIdxR].x;
+      const float scaleFactor = invScaleF[kpL.octave];
+      const float scaleduL = std::round(kpL.x * scaleFactor);
+      const float scaledvL = std::round(kpL.y * scaleFactor);
+      const float scaleduR0 = std::round(uR0 * scaleFactor);
+      const int w = 5;
+      int lw, lh, ls, rw, rh, rs;
+      const uint8_t* IL = oracle_level_ptr(left, kpL.octave, &lw, &lh, &ls);
+      const uint8_t* IR = oracle_level_ptr(right, kpL.octave, &rw, &rh, &rs);
+      const int cyL = (int)scaledvL, cxL = (int)scaleduL;
+      int bestDistS = INT_MAX, bestincR = 0;
+      const int L = 5;
+      float vDists[2 * 5 + 1];
+      const float iniu = scaleduR0 + L - w;
+      const float endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= rw) continue;
+      const int centreL = IL[(size_t)cyL * ls + cxL];
+      for (int incR = -L; incR <= +L; incR++) {
+        const int cxR = (int)(scaleduR0 + incR);
+        const int centreR = IR[(size_t)cyL * rs + cxR];
+        int sad = 0;
+        for (int dy = -w; dy <= w; dy++)
+          for (int dx = -w; dx <= w; dx++) {
+            int a = (int)IL[(size_t)(cyL + dy) * ls + cxL + dx] - centreL;     // CV_16S, IL - IL(w,w)
+            int c = (int)IR[(size_t)(cyL + dy) * rs + cxR + dx] - centreR;
+            sad += std::abs(a - c);
+          }
+        float dist = (float)sad;                                               // cv::norm(IL,IR,NORM_L1)
+        if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = scaleF[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = 0.01; bestuR = (float)(uL - 0.01); }   // double literals, :937-941
+        depth[iL] = bf / disparity;
+        uright[iL] = bestuR;
+        vDistIdx.push_back({bestDistS, iL});
+      }
+    }
+  }
+  if (vDistIdx.empty()) return ORBG_OK;   // reference indexes an empty vector here (UB); pinned to "no matches"
+  std::sort(vDistIdx.begin(), vDistIdx.end());                                 // :949-962
+  const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if (vDistIdx[i].first < thDist) break;
+    uright[vDistIdx[i].second] = -1;
+    depth[vDistIdx[i].second] = -1;
+  }
+  return ORBG_OK;
+}

@@ -1,0 +1,97 @@
+/*
+ * orb_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A dependency-free C++17 restatement of the reference's hot path (ORBextractor, stereo matching,
+ * Hamming matchers, LocalBundleAdjustment of yutongwangBIT/multi_orbslam3) used ONLY by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker / CPU baseline.  The
+ * product library (multi_orbslam3_amd/liborbgpu.so) never links, loads or calls anything in here.
+ *
+ * PARITY STATUS: "parity unpinned" -- the reference ships no tests, golden vectors or fixtures for
+ * this path and cannot be compiled in the authoring container (needs
+ * OpenCV, Eigen, ROS), so this restatement is pinned only against first-principles known-answer
+ * tests (tests/test_oracle_*.py).  Arithmetic that lives in un-vendored
+ * third parties (OpenCV 3.2-era cv::resize / cv::FAST / cv::GaussianBlur / cv::fastAtan2 /
+ * cvRound; Eigen >= 3.1 fixed-size algebra + SimplicialLDLT) is restated from their published
+ * algorithms.
+ *
+ * Shares only the plain-C struct layouts of include/orbgpu.h with the product.
+ */
+#ifndef ORB_ORACLE_H_
+#define ORB_ORACLE_H_
+
+#include "../include/orbgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_extractor oracle_extractor;
+
+/* ---- image primitives (Appendix A), exported for the known-answer tests */
+void oracle_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+void oracle_border_reflect101(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int border, int dstride);
+/* FAST-9/16 score (largest threshold at which the pixel is a corner, -1 if it is not one at t=0);
+ * needs a 3-px margin around (x,y). */
+int  oracle_fast_score(const uint8_t* img, int stride, int x, int y);
+/* cv::FAST(img, kps, threshold, nonmax=true) on a w x h sub-image: out = cap x {x,y,score}. */
+int  oracle_fast_detect(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax,
+                        int32_t* xys, int cap);
+void oracle_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+float oracle_fast_atan2(float y, float x);
+int  oracle_hamming(const uint8_t* a, const uint8_t* b);
+
+/* ---- extractor (S/ORBextractor.cc) */
+int oracle_extractor_create(const orbx_config* cfg, oracle_extractor** out);
+int oracle_extractor_destroy(oracle_extractor* e);
+int oracle_get_tables(const oracle_extractor* e, float* scale, float* inv_scale, float* sigma2,
+                      float* inv_sigma2, int32_t* features_per_level);
+int oracle_get_umax(const oracle_extractor* e, int32_t* umax16);
+int oracle_extract(oracle_extractor* e, const uint8_t* img, int width, int height, int stride,
+                   int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n, int* n_mono);
+int oracle_get_level(oracle_extractor* e, int level, uint8_t* host_out, int* width, int* height);
+int oracle_get_candidates(oracle_extractor* e, int level, int32_t* xys, int cap, int* n);
+/* DistributeOctTree alone (S/ORBextractor.cc:537-761): in = n x {x,y,score} (relative coords),
+ * out = kept candidates in list order. */
+int oracle_distribute_octree(const int32_t* xys, int n, int min_x, int max_x, int min_y, int max_y,
+                             int n_target, int32_t* out_xys, int cap);
+
+/* ---- Frame pieces (S/Frame.cc) */
+int oracle_stereo_match(oracle_extractor* left, oracle_extractor* right,
+                        const orbx_keypoint* kps_l, const uint8_t* desc_l, int n_l,
+                        const orbx_keypoint* kps_r, const uint8_t* desc_r, int n_r,
+                        float bf, float b, float* uright, float* depth);
+int oracle_build_grid(const orbm_frame_view* view, int32_t* cell_start, int32_t* cell_items);
+int oracle_features_in_area(const orbm_frame_view* view, float x, float y, float r, int min_level,
+                            int max_level, int32_t* out_idx, int cap);
+int oracle_is_in_frustum(const orbm_frame_view* view, const float* Tcw, const orbm_worldpoints_view* pts,
+                         float viewing_cos_limit, uint8_t* track_in_view, float* proj_x, float* proj_y,
+                         float* proj_xr, float* track_depth, int32_t* scale_level, float* view_cos);
+
+/* ---- matchers (S/ORBmatcher.cc) */
+int oracle_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* dist);
+int oracle_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out4);
+int oracle_search_by_projection_mps(const orbm_frame_view* view, const orbm_mappoints_view* mps, float th,
+                                    int far_points, float th_far_points, float nnratio,
+                                    int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+int oracle_search_local_points(const orbm_frame_view* view, const orbm_worldpoints_view* pts, const float* Tcw,
+                               float th, int far_points, float th_far_points, float nnratio,
+                               int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+int oracle_search_by_projection_frame(const orbm_frame_view* cur, const float* Tcw_cur,
+                                      const orbm_lastframe_view* last, float th, int mono, int check_orientation,
+                                      int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+int oracle_search_by_bow(const orbm_frame_view* view, const orbm_featvec_view* fv_frame,
+                         const uint8_t* kf_desc, int nkf, const uint8_t* kf_mp_valid, const float* kf_angle,
+                         const orbm_featvec_view* fv_kf, float nnratio, int check_orientation,
+                         int32_t* matches, int* nmatches);
+
+/* ---- LBA (S/Optimizer.cc:1810-2410 + vendored g2o) */
+int oracle_lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
+/* pieces for the known-answer tests */
+void oracle_se3_exp(const double* upd6 /*omega,upsilon*/, double* q4_xyzw, double* t3);
+void oracle_lba_edge_eval(const double* q4_xyzw, const double* t3, const double* X3, const float* cam5 /*fx fy cx cy bf*/,
+                          const lba_edge* e, double* err3, double* Jpoint9, double* Jpose18);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

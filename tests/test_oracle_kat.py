@@ -1,0 +1,349 @@
+"""Known-answer tests that pin the CPU oracle from first principles.
+The reference ships no tests or golden vectors for this path, so these KATs are what the oracle is pinned to."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from multi_orbslam3_amd import _capi as capi
+
+
+# ---------------------------------------------------------------- D-1 resize
+def test_resize_constant_and_2x2():
+    img = np.full((37, 53), 77, np.uint8)
+    assert (ob.resize_linear(img, 44, 31) == 77).all()
+    a = np.array([[10, 20], [30, 40]], np.uint8)
+    assert ob.resize_linear(a, 1, 1)[0, 0] == 25
+
+
+def _resize_model(src, dw, dh):
+    """Independent numpy model of the 11-bit fixed-point bilinear resize (Appendix A-1)."""
+    sh, sw = src.shape
+    def coeffs(d, s):
+        scale = 1.0 / (float(d) / s)
+        f = ((np.arange(d) + 0.5) * scale - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        f = (f - i.astype(np.float32)).astype(np.float32)
+        return i, f
+    sx, fx = coeffs(dw, sw)
+    lo = sx < 0; fx[lo] = 0; sx[lo] = 0
+    hi = sx >= sw - 1; fx[hi] = 0; sx[hi] = sw - 1
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64); a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+    sy, fy = coeffs(dh, sh)
+    b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int64); b1 = np.rint(fy * np.float32(2048)).astype(np.int64)
+    S = src.astype(np.int64)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    rows = S[:, sx] * a0 + S[:, sx1] * a1
+    y0 = np.clip(sy, 0, sh - 1); y1 = np.clip(sy + 1, 0, sh - 1)
+    out = (((b0[:, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def test_resize_matches_independent_model():
+    rng = np.random.RandomState(1)
+    for (h, w, dh, dw) in [(480, 640, 400, 533), (48, 64, 40, 53), (31, 17, 26, 14), (20, 20, 37, 41)]:
+        img = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        assert np.array_equal(ob.resize_linear(img, dw, dh), _resize_model(img, dw, dh))
+
+
+def test_resize_ramp_monotone_and_bounded():
+    img = np.tile(np.arange(0, 240, dtype=np.uint8), (16, 1))
+    out = ob.resize_linear(img, 200, 13)
+    assert (np.diff(out[0].astype(int)) >= 0).all()
+    assert out.min() >= img.min() and out.max() <= img.max()
+
+
+def test_border_reflect101():
+    a = np.arange(5 * 7, dtype=np.uint8).reshape(5, 7)
+    b = ob.border_reflect101(a, 3)
+    assert np.array_equal(b, np.pad(a, 3, mode="reflect"))
+
+
+# ---------------------------------------------------------------- D-2 FAST
+CIRCLE = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+          (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _arc_image(n_arc, centre=100, arc_val=150, other=100, start=0, size=15):
+    img = np.full((size, size), other, np.uint8)
+    c = size // 2
+    img[c, c] = centre
+    for k in range(n_arc):
+        dx, dy = CIRCLE[(start + k) % 16]
+        img[c + dy, c + dx] = arc_val
+    return img, c
+
+
+def _score_bruteforce(img, x, y):
+    v = int(img[y, x])
+    ring = [int(img[y + dy, x + dx]) for dx, dy in CIRCLE]
+    best = -1
+    for t in range(0, 256):
+        ok = False
+        for s in range(16):
+            seg = [ring[(s + k) % 16] for k in range(9)]
+            if all(c < v - t for c in seg) or all(c > v + t for c in seg):
+                ok = True
+                break
+        if ok:
+            best = t
+        else:
+            break
+    return best
+
+
+@pytest.mark.parametrize("start", [0, 5, 11, 15])
+def test_fast_arc_9_vs_8(start):
+    img9, c = _arc_image(9, start=start)
+    img8, _ = _arc_image(8, start=start)
+    assert ob.fast_score(img9, c, c) == 49          # |150-100| = 50 > t  <=>  t <= 49
+    assert ob.fast_score(img8, c, c) < 0
+    kp = ob.fast_detect(img9, 49)
+    assert [tuple(k) for k in kp] == [(c, c, 49)]
+    assert len(ob.fast_detect(img9, 50)) == 0       # strictness at the threshold edge
+    dark, c = _arc_image(9, centre=100, arc_val=60, start=start)
+    assert ob.fast_score(dark, c, c) == 39
+
+
+def test_fast_score_equals_bruteforce_max_threshold():
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, (24, 24)).astype(np.uint8)
+    img[8:16, 8:16] = rng.randint(0, 40, (8, 8))
+    for y in range(3, 21):
+        for x in range(3, 21):
+            assert max(ob.fast_score(img, x, y), -1) == _score_bruteforce(img, x, y)
+
+
+def test_fast_nms_plateau_and_order():
+    # two adjacent identical corners: equal scores => both suppressed (strict >)
+    img = np.full((20, 30), 100, np.uint8)
+    for cx in (10, 11):
+        for k in range(16):
+            dx, dy = CIRCLE[k]
+            img[10 + dy, cx + dx] = 200
+    img[10, 10] = 100; img[10, 11] = 100
+    s = [ob.fast_score(img, x, 10) for x in (10, 11)]
+    kp = ob.fast_detect(img, 20)
+    if s[0] == s[1] and s[0] >= 20:
+        assert not any((k[0] in (10, 11) and k[1] == 10) for k in kp)
+    # output order is row-major
+    rng = np.random.RandomState(5)
+    noise = rng.randint(0, 256, (40, 50)).astype(np.uint8)
+    kp = ob.fast_detect(noise, 20)
+    keys = [(int(k[1]), int(k[0])) for k in kp]
+    assert keys == sorted(keys) and len(keys) > 0
+    # NMS result equals "strict local max of the thresholded score map"
+    sc = np.zeros((40, 50), int)
+    for y in range(3, 37):
+        for x in range(3, 47):
+            v = ob.fast_score(noise, x, y)
+            sc[y, x] = v if v >= 20 else 0
+    exp = []
+    for y in range(3, 37):
+        for x in range(3, 47):
+            if sc[y, x] > 0:
+                nb = sc[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = -1
+                if sc[y, x] > nb.max():
+                    exp.append((x, y, sc[y, x]))
+    assert [tuple(k) for k in kp] == exp
+
+
+def test_fast_invariant_to_intensity_shift():
+    rng = np.random.RandomState(7)
+    img = rng.randint(0, 200, (32, 32)).astype(np.uint8)
+    a = ob.fast_detect(img, 15)
+    b = ob.fast_detect((img + 40).astype(np.uint8), 15)
+    assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- D-3 Gaussian
+def test_gaussian_impulse_response():
+    img = np.zeros((21, 21), np.uint8)
+    img[10, 10] = 255
+    out = ob.gaussian_blur7(img)
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    exp = (255 * np.outer(k, k) + 32768) >> 16
+    assert np.array_equal(out[7:14, 7:14], exp.astype(np.uint8))
+    assert out[:7].sum() == 0 and out[:, :7].sum() == 0
+    # kernel sums to 257: a constant 255 image saturates, a constant 100 image becomes 100*257*257>>16
+    assert (ob.gaussian_blur7(np.full((9, 9), 255, np.uint8)) == 255).all()
+    assert (ob.gaussian_blur7(np.full((9, 9), 100, np.uint8)) == ((100 * 257 * 257 + 32768) >> 16)).all()
+
+
+def test_gaussian_reflect101_border():
+    rng = np.random.RandomState(11)
+    img = rng.randint(0, 256, (12, 15)).astype(np.uint8)
+    pad = np.pad(img, 3, mode="reflect").astype(np.int64)
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    rows = sum(k[i] * pad[:, i:i + 15] for i in range(7))
+    full = sum(k[i] * rows[i:i + 12, :] for i in range(7))
+    exp = np.clip((full + 32768) >> 16, 0, 255).astype(np.uint8)
+    assert np.array_equal(ob.gaussian_blur7(img), exp)
+
+
+# ---------------------------------------------------------------- D-4 fastAtan2
+def test_fast_atan2_octants_and_accuracy():
+    assert ob.fast_atan2(0, 0) == 0.0
+    for (y, x, deg) in [(0, 1, 0), (1, 1, 45), (1, 0, 90), (1, -1, 135), (0, -1, 180), (-1, -1, 225), (-1, 0, 270), (-1, 1, 315)]:
+        assert abs(ob.fast_atan2(y, x) - deg) < 0.3
+    rng = np.random.RandomState(2)
+    for _ in range(2000):
+        y, x = rng.randn(2) * 1000
+        ref = np.degrees(np.arctan2(y, x)) % 360
+        d = abs(ob.fast_atan2(float(y), float(x)) - ref)
+        assert min(d, 360 - d) < 0.3
+
+
+# ---------------------------------------------------------------- D-6 Hamming
+def test_hamming_kat():
+    z = np.zeros(32, np.uint8); o = np.full(32, 255, np.uint8)
+    assert ob.hamming(z, z) == 0 and ob.hamming(z, o) == 256
+    one = z.copy(); one[17] = 0x10
+    assert ob.hamming(z, one) == 1
+    rng = np.random.RandomState(4)
+    a = rng.randint(0, 256, (50, 32)).astype(np.uint8); b = rng.randint(0, 256, (60, 32)).astype(np.uint8)
+    D = ob.hamming_matrix(a, b)
+    exp = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(D, exp)
+    assert np.array_equal(ob.hamming_matrix(b, a), D.T)
+
+
+def test_best2_sequential_equals_lexicographic_top2():
+    """The matcher loops' running (best, second) equal the two smallest (dist, position) keys -- the
+    identity the GPU wavefront reduction relies on (ties included)."""
+    rng = np.random.RandomState(9)
+    q = rng.randint(0, 256, (40, 32)).astype(np.uint8)
+    t = np.repeat(rng.randint(0, 256, (25, 32)).astype(np.uint8), 3, axis=0)   # many exact ties
+    t = t[rng.permutation(len(t))]
+    o = ob.hamming_best2(q, t)
+    D = ob.hamming_matrix(q, t)
+    for i in range(len(q)):
+        keys = sorted((int(D[i, j]), j) for j in range(len(t)))
+        assert (o[i, 0], o[i, 1]) == keys[0]
+        assert (o[i, 2], o[i, 3]) == keys[1]
+
+
+# ---------------------------------------------------------------- extractor tables / D-5 descriptor
+def test_extractor_tables_match_survey():
+    ex = ob.Extractor(n_features=1000)
+    scale, inv_scale, s2, is2, fpl = ex.tables()
+    assert list(fpl) == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert list(ex.umax()) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    ex2 = ob.Extractor(n_features=2000, max_width=1280, max_height=720)
+    assert list(ex2.tables()[4]) == [434, 362, 302, 251, 209, 175, 145, 122]
+    f = np.float32(1.0)
+    for i in range(8):
+        assert scale[i] == f
+        f = np.float32(f * np.float32(1.2))
+
+
+def test_pyramid_sizes_match_survey(scene):
+    ex = ob.Extractor(n_features=1000)
+    L, _, _ = scene.stereo_pair(0)
+    rc, kps, desc, nm = ex.extract(L)
+    assert rc == 0 and nm == len(kps) and len(kps) >= 900
+    sizes = [ex.level(l).shape[::-1] for l in range(8)]
+    assert sizes == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+    assert np.array_equal(ex.level(0), L)
+    assert np.array_equal(ex.level(1), ob.resize_linear(L, 533, 400))
+    assert np.array_equal(ex.level(2), ob.resize_linear(ex.level(1), 444, 333))   # cascade, not from level 0
+
+
+def test_empty_image_returns_minus_one():
+    ex = ob.Extractor(n_features=100)
+    rc, kps, _, _ = ex.extract(None)
+    assert rc == capi.ORBG_EMPTY and len(kps) == 0
+
+
+def test_mono_lapping_reverses_order(scene):
+    ex = ob.Extractor(n_features=500)
+    L, _, _ = scene.stereo_pair(1)
+    rc, k0, d0, m0 = ex.extract(L, lap=(0, 0))
+    rc, k1, d1, m1 = ex.extract(L, lap=(0, 1000))      # Frame.cc:289 mono path
+    assert m0 == len(k0) and m1 == 0
+    assert np.array_equal(k1, k0[::-1]) and np.array_equal(d1, d0[::-1])
+
+
+def test_candidates_are_cellwise_fast(scene):
+    """vToDistributeKeys of a level == union over the 30-px cells of cv::FAST(ini) with the per-cell min fallback."""
+    ex = ob.Extractor(n_features=1000)
+    L, _, _ = scene.stereo_pair(2)
+    ex.extract(L)
+    for level in (0, 3, 7):
+        img = ex.level(level)
+        pad = ob.border_reflect101(img, 19)
+        h, w = img.shape
+        minB, maxBX, maxBY = 16, w - 16, h - 16
+        nCols, nRows = int((maxBX - minB) / 30), int((maxBY - minB) / 30)
+        wCell, hCell = int(np.ceil((maxBX - minB) / nCols)), int(np.ceil((maxBY - minB) / nRows))
+        exp = []
+        for i in range(nRows):
+            iniY = minB + i * hCell; maxY = min(iniY + hCell + 6, maxBY)
+            if iniY >= maxBY - 3:
+                continue
+            for j in range(nCols):
+                iniX = minB + j * wCell; maxX = min(iniX + wCell + 6, maxBX)
+                if iniX >= maxBX - 6:
+                    continue
+                sub = pad[19 + iniY:19 + maxY, 19 + iniX:19 + maxX]
+                k = ob.fast_detect(sub, 20)
+                if len(k) == 0:
+                    k = ob.fast_detect(sub, 7)
+                for x, y, s in k:
+                    exp.append((x + j * wCell, y + i * hCell, s))
+        got = [tuple(c) for c in ex.candidates(level)]
+        assert got == exp and len(got) > 0
+
+
+def test_descriptor_angle0_is_direct_pattern(scene):
+    """D-5: with angle forced to 0 the descriptor bits are direct pattern compares on the blurred level."""
+    import re, os
+    inc = open(os.path.join(os.path.dirname(ob.__file__), "orb_pattern_data.inc")).read()
+    vals = [int(v) for v in re.findall(r"-?\d+", inc.split("\n", 2)[2])]
+    pat = np.array(vals, int).reshape(256, 4)
+    ex = ob.Extractor(n_features=300)
+    L, _, _ = scene.stereo_pair(0)
+    rc, kps, desc, _ = ex.extract(L)
+    blur = ob.gaussian_blur7(ex.level(0)).astype(int)
+    checked = 0
+    for kp, d in zip(kps, desc):
+        if kp["octave"] != 0:
+            continue
+        ang = np.float32(kp["angle"]) * np.float32(np.pi / 180.0)
+        a, b = np.float32(np.cos(ang)), np.float32(np.sin(ang))
+        x0, y0 = int(kp["x"]), int(kp["y"])
+        bits = []
+        for (px0, py0, px1, py1) in pat:
+            def val(px, py):
+                r = int(np.rint(np.float64(np.float32(np.float32(px * b) + np.float32(py * a)))))
+                c = int(np.rint(np.float64(np.float32(np.float32(px * a) - np.float32(py * b)))))
+                return blur[y0 + r, x0 + c]
+            bits.append(1 if val(px0, py0) < val(px1, py1) else 0)
+        exp = np.packbits(np.array(bits, np.uint8).reshape(32, 8)[:, ::-1], axis=1).ravel()
+        assert np.array_equal(exp, d)
+        checked += 1
+        if checked >= 25:
+            break
+    assert checked >= 10
+
+
+def test_octree_properties():
+    rng = np.random.RandomState(21)
+    n = 3000
+    xs = rng.randint(0, 608, n); ys = rng.randint(0, 448, n); sc = rng.randint(7, 200, n)
+    _, first = np.unique(xs * 1000 + ys, return_index=True)       # FAST candidates have unique positions
+    xys = np.stack([xs, ys, sc], 1)[np.sort(first)].astype(np.int32)
+    for N in (50, 217, 1000):
+        out = ob.distribute_octree(xys, 16, 624, 16, 464, N)
+        assert N <= len(out) <= N + 3 * 4
+        assert len({(o[0], o[1]) for o in out}) == len(out)
+        s = {tuple(r) for r in xys}
+        assert all(tuple(o) in s for o in out)
+    few = xys[:20]
+    # fewer candidates than N: the loop stops at the first pass that does not add a node (:667), so close pairs
+    # may still share a leaf -- at most all of them are kept
+    assert 10 <= len(ob.distribute_octree(few, 16, 624, 16, 464, 217)) <= 20
+    assert len(ob.distribute_octree(few[:0], 16, 624, 16, 464, 217)) == 0
+    # determinism + max-response-per-leaf: a single root cell with two keys and N=1 keeps the stronger one
+    two = np.array([[10, 10, 50], [11, 10, 90]], np.int32)
+    out = ob.distribute_octree(two, 16, 464, 16, 464, 1)
+    assert len(out) == 1 and out[0][2] == 90
