@@ -1,0 +1,305 @@
+"""Python host mirror of the reference's interface for the hot path, over the C-ABI of liborbgpu.so.
+
+Class / method names follow the reference (ORBextractor::operator(), Frame::ComputeStereoMatches,
+ORBmatcher::SearchByProjection / SearchByBoW, Optimizer::LocalBundleAdjustment); arguments are the flattened
+numpy views of SURVEY.md Appendix E.  Every method raises OrbGpuError on a non-zero status -- in particular
+ORBG_NO_DEVICE when no MI355X is visible: there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from . import views
+
+
+def _vp(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class ORBextractor:
+    """ORB_SLAM3::ORBextractor (I/ORBextractor.h:47-113).  n_cams=2 gives the batched stereo rig."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, max_width=640,
+                 max_height=480, n_cams=1, device=0):
+        self.lib = capi.load()
+        self.cfg = capi.OrbxConfig(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width, max_height,
+                                   n_cams, device)
+        self.h = C.c_void_p()
+        capi.check(self.lib.orbx_create(C.byref(self.cfg), C.byref(self.h)), "orbx_create")
+        self.cap = 2 * nfeatures + 256
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orbx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # getters of I/ORBextractor.h:65-85
+    def tables(self):
+        nl = self.cfg.n_levels
+        arrs = [np.zeros(nl, np.float32) for _ in range(4)] + [np.zeros(nl, np.int32)]
+        capi.check(self.lib.orbx_get_tables(self.h, *[_vp(a) for a in arrs]))
+        return arrs
+
+    def GetScaleFactors(self):
+        return self.tables()[0]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self.tables()[3]
+
+    def __call__(self, image, vLappingArea=(0, 0)):
+        """-> (monoIndex or -1, keypoints, descriptors): S/ORBextractor.cc:1068-1150."""
+        kps = np.zeros(self.cap, dtype=capi.KEYPOINT_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n, nm = C.c_int(0), C.c_int(0)
+        if image is None or image.size == 0:
+            rc = self.lib.orbx_extract(self.h, 0, None, 0, 0, 0, 0, 0, _vp(kps), _vp(desc), self.cap, C.byref(n), C.byref(nm))
+            assert rc == capi.ORBG_EMPTY
+            return -1, kps[:0], desc[:0]
+        image = np.ascontiguousarray(image, np.uint8)
+        rc = self.lib.orbx_extract(self.h, 0, _vp(image), image.shape[1], image.shape[0], image.strides[0],
+                                   int(vLappingArea[0]), int(vLappingArea[1]), _vp(kps), _vp(desc), self.cap,
+                                   C.byref(n), C.byref(nm))
+        capi.check(rc, "orbx_extract")
+        return nm.value, kps[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_stereo(self, im_left, im_right, download=True):
+        """Both ExtractORB calls of the stereo Frame ctor (S/Frame.cc:92-95) in one batched submission."""
+        im_left = np.ascontiguousarray(im_left, np.uint8)
+        im_right = np.ascontiguousarray(im_right, np.uint8)
+        assert im_left.shape == im_right.shape and im_left.strides == im_right.strides
+        nl, nr = C.c_int(0), C.c_int(0)
+        if download:
+            kl = np.zeros(self.cap, capi.KEYPOINT_DTYPE); dl = np.zeros((self.cap, 32), np.uint8)
+            kr = np.zeros(self.cap, capi.KEYPOINT_DTYPE); dr = np.zeros((self.cap, 32), np.uint8)
+        else:
+            kl = dl = kr = dr = None
+        rc = self.lib.orbx_extract_stereo(self.h, _vp(im_left), _vp(im_right), im_left.shape[1], im_left.shape[0],
+                                          im_left.strides[0], _vp(kl), _vp(dl), self.cap, C.byref(nl), _vp(kr), _vp(dr),
+                                          self.cap, C.byref(nr))
+        capi.check(rc, "orbx_extract_stereo")
+        if not download:
+            return nl.value, nr.value
+        return (kl[: nl.value].copy(), dl[: nl.value].copy()), (kr[: nr.value].copy(), dr[: nr.value].copy())
+
+    def extract_stereo_dev(self, d_left, d_right, width, height, stride):
+        """Images already in HBM (raw device pointers, e.g. torch tensor .data_ptr()); results stay on the device."""
+        nl, nr = C.c_int(0), C.c_int(0)
+        rc = self.lib.orbx_extract_stereo_dev(self.h, C.c_void_p(d_left), C.c_void_p(d_right), width, height, stride,
+                                              None, None, 0, C.byref(nl), None, None, 0, C.byref(nr))
+        capi.check(rc, "orbx_extract_stereo_dev")
+        return nl.value, nr.value
+
+    def level(self, cam, level):
+        """mvImagePyramid[level] (I/ORBextractor.h:87) of the last extraction."""
+        w, h = C.c_int(0), C.c_int(0)
+        capi.check(self.lib.orbx_get_level(self.h, cam, level, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        capi.check(self.lib.orbx_get_level(self.h, cam, level, _vp(out), C.byref(w), C.byref(h)))
+        return out
+
+    def candidates(self, cam, level, cap=1 << 18):
+        out = np.zeros((cap, 3), np.int32)
+        n = C.c_int(0)
+        capi.check(self.lib.orbx_get_candidates(self.h, cam, level, _vp(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def ComputeStereoMatches(self, bf, b, n_left=None, download=True):
+        """Frame::ComputeStereoMatches (S/Frame.cc:785-963) on the device-resident stereo extraction."""
+        if not download:
+            capi.check(self.lib.orbx_stereo_match(self.h, C.c_float(bf), C.c_float(b), None, None))
+            return None
+        ur = np.zeros(max(n_left if n_left is not None else self.cap, 1), np.float32)
+        dp = np.zeros_like(ur)
+        capi.check(self.lib.orbx_stereo_match(self.h, C.c_float(bf), C.c_float(b), _vp(ur), _vp(dp)), "orbx_stereo_match")
+        if n_left is not None:
+            return ur[:n_left], dp[:n_left]
+        return ur, dp
+
+    def timings(self):
+        t = np.zeros(8, np.float32)
+        capi.check(self.lib.orbx_get_timings(self.h, _vp(t)))
+        return dict(pyramid_ms=float(t[0]), fast_ms=float(t[1]), octree_host_ms=float(t[2]), desc_ms=float(t[3]),
+                    stereo_ms=float(t[4]))
+
+
+class Frame:
+    """Device-resident frame view (features + 64x48 grid) the matchers work on."""
+
+    def __init__(self, cap_features=4096, device=0):
+        self.lib = capi.load()
+        self.h = C.c_void_p()
+        capi.check(self.lib.orbm_frame_create(device, cap_features, C.byref(self.h)), "orbm_frame_create")
+        self.n = 0
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orbm_frame_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, fv, keep=None):
+        self._keep = keep
+        capi.check(self.lib.orbm_frame_upload(self.h, C.byref(fv)), "orbm_frame_upload")
+        self.n = fv.n
+        return self
+
+    def from_extractor(self, extractor, fv):
+        capi.check(self.lib.orbm_frame_from_extractor(self.h, extractor.h, C.byref(fv)), "orbm_frame_from_extractor")
+        return self
+
+    def grid(self):
+        start = np.zeros(capi.GRID_COLS * capi.GRID_ROWS + 1, np.int32)
+        items = np.zeros(max(self.n, 1), np.int32)
+        capi.check(self.lib.orbm_frame_get_grid(self.h, _vp(start), _vp(items)))
+        return start, items[: start[-1]].copy()
+
+    def isInFrustum(self, Tcw, wv, viewingCosLimit=0.5):
+        m = wv.m
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        out = dict(track_in_view=np.zeros(m, np.uint8), proj_x=np.zeros(m, np.float32), proj_y=np.zeros(m, np.float32),
+                   proj_xr=np.zeros(m, np.float32), track_depth=np.zeros(m, np.float32),
+                   scale_level=np.zeros(m, np.int32), view_cos=np.zeros(m, np.float32))
+        capi.check(self.lib.orbm_is_in_frustum(self.h, _vp(T), C.byref(wv), C.c_float(viewingCosLimit),
+                                               *[_vp(out[k]) for k in ("track_in_view", "proj_x", "proj_y", "proj_xr",
+                                                                         "track_depth", "scale_level", "view_cos")]),
+                   "orbm_is_in_frustum")
+        return out
+
+
+class LocalMap:
+    """Device-resident local map points (positions, normals, distances, descriptors)."""
+
+    def __init__(self, cap_points=8192, device=0):
+        self.lib = capi.load()
+        self.h = C.c_void_p()
+        capi.check(self.lib.orbm_map_create(device, cap_points, C.byref(self.h)), "orbm_map_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orbm_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, wv):
+        capi.check(self.lib.orbm_map_upload(self.h, C.byref(wv)), "orbm_map_upload")
+        self.m = wv.m
+        return self
+
+
+class ORBmatcher:
+    """ORB_SLAM3::ORBmatcher (I/ORBmatcher.h:35-108), hot-path searches only."""
+
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.lib = capi.load()
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self.device = device
+
+    def DescriptorDistance(self, q, t):
+        """Dense Hamming matrix (S/ORBmatcher.cc:2358-2374 for every pair)."""
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        d = np.zeros((len(q), len(t)), np.int32)
+        capi.check(self.lib.orbm_hamming_matrix(self.device, _vp(q), len(q), _vp(t), len(t), _vp(d)), "orbm_hamming_matrix")
+        return d
+
+    def best2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        o = np.zeros((len(q), 4), np.int32)
+        capi.check(self.lib.orbm_hamming_best2(self.device, _vp(q), len(q), _vp(t), len(t), _vp(o)), "orbm_hamming_best2")
+        return o
+
+    def SearchByProjection(self, F, mv, th=1.0, bFarPoints=False, thFarPoints=50.0, assigned_mp=None, assigned_obs=None):
+        """(Frame&, vector<MapPoint*>&, th, bFarPoints, thFarPoints): S/ORBmatcher.cc:44-214."""
+        amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+        aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_projection_mps(F.h, C.byref(mv), C.c_float(th), int(bFarPoints),
+                                                          C.c_float(thFarPoints), C.c_float(self.mfNNratio), _vp(amp),
+                                                          _vp(aob), C.byref(n)), "orbm_search_by_projection_mps")
+        return amp, aob, n.value
+
+    def SearchLocalPoints(self, F, local_map, Tcw, th=1.0, bFarPoints=False, thFarPoints=50.0, assigned_mp=None,
+                          assigned_obs=None, skip=None):
+        """Fused Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153)."""
+        amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+        aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_local_points(F.h, local_map.h, _vp(T), _vp(sk), C.c_float(th), int(bFarPoints),
+                                                     C.c_float(thFarPoints), C.c_float(self.mfNNratio), _vp(amp), _vp(aob),
+                                                     C.byref(n)), "orbm_search_local_points")
+        return amp, aob, n.value
+
+    def SearchByProjectionFrame(self, CurrentFrame, Tcw_cur, lv, th, bMono, assigned_mp, assigned_obs):
+        """(Frame &CurrentFrame, const Frame &LastFrame, th, bMono): S/ORBmatcher.cc:1970-2186."""
+        amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+        aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+        T = np.ascontiguousarray(Tcw_cur, np.float32).reshape(16)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_projection_frame(CurrentFrame.h, _vp(T), C.byref(lv), C.c_float(th), int(bMono),
+                                                            int(self.mbCheckOrientation), _vp(amp), _vp(aob), C.byref(n)),
+                   "orbm_search_by_projection_frame")
+        return amp, aob, n.value
+
+    def SearchByBoW(self, F, fvF, kf_desc, kf_mp_valid, kf_angle, fvK):
+        """(KeyFrame*, Frame&, vector<MapPoint*>&): S/ORBmatcher.cc:269-471."""
+        kf_desc = np.ascontiguousarray(kf_desc, np.uint8)
+        kf_mp_valid = np.ascontiguousarray(kf_mp_valid, np.uint8)
+        kf_angle = np.ascontiguousarray(kf_angle, np.float32)
+        matches = np.zeros(max(F.n, 1), np.int32)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_bow(F.h, C.byref(fvF), _vp(kf_desc), len(kf_desc), _vp(kf_mp_valid), _vp(kf_angle),
+                                               C.byref(fvK), C.c_float(self.mfNNratio), int(self.mbCheckOrientation),
+                                               _vp(matches), C.byref(n)), "orbm_search_by_bow")
+        return matches[: F.n].copy(), n.value
+
+
+class Optimizer:
+    """ORB_SLAM3::Optimizer (I/Optimizer.h:30-113): LocalBundleAdjustment numerical core."""
+
+    def __init__(self, device=0):
+        self.lib = capi.load()
+        self.h = C.c_void_p()
+        capi.check(self.lib.lba_create(device, 0, 0, 0, C.byref(self.h)), "lba_create")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def LocalBundleAdjustment(self, problem, pbStopFlag=None, trace_cap=64):
+        """problem: views.lba_problem(...)[0]; pbStopFlag: np.int32[1] polled between LM iterations."""
+        out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)
+        sp = None if pbStopFlag is None else C.c_void_p(pbStopFlag.ctypes.data)
+        capi.check(self.lib.lba_solve_h(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_h")
+        return out

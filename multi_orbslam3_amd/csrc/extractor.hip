@@ -1,0 +1,1161 @@
+// liborbgpu -- ORB extractor for gfx950 (MI355X): pyramid, FAST-9/16 score + per-cell NMS/threshold
+// fallback, quad-tree keypoint selection, intensity-centroid angle, 7x7 blur and 256-bit rBRIEF.
+//
+// Replaces ORB_SLAM3::ORBextractor (S/ORBextractor.cc) behind the C-ABI of include/orbgpu.h.
+// Design (MI355X-first, not a translation of the OpenCV call sequence):
+//   * left+right images of a stereo rig share every launch (blockIdx.y/z = camera);
+//   * pyramid levels live in ONE bordered HBM buffer per camera (19-px REFLECT_101 border written by the
+//     same kernel that resizes, so no separate copyMakeBorder pass and no separate blur image);
+//   * FAST: one 256-thread workgroup per 30-px cell, the (w+6)x(h+6) sub-image staged in LDS, a full
+//     max-threshold score per pixel (branch-free sliding min/max over the 16-ring), NMS inside the cell's
+//     detection area, the iniTh -> minTh fallback decided per cell with one workgroup reduction, and an
+//     ORDER-PRESERVING compaction (row-major inside the cell, cells in the reference's i,j order);
+//   * the blurred level image is never materialised: each keypoint's 43x43 raw patch is staged in LDS by
+//     one wavefront, blurred separably in LDS (u16 row pass, exact integer), and the 512 rotated pattern
+//     lookups read LDS; the orientation moments use the same staged patch;
+//   * small, latency-bound hand-offs (candidate lists, selected keypoints) go through mapped pinned
+//     host memory written/read directly by the kernels -- no extra memcpy launches.
+// The quad-tree (DistributeOctTree) runs on the host between the two GPU phases (serial, pointer-chasing
+// in the reference; here an index/range based implementation with a pinned deterministic tie-break).
+//
+// Bit-exactness contract (tests/test_gpu_extractor.py): pyramid bytes, FAST candidate lists, kept
+// keypoints, angles (f32 bits) and descriptors are identical to the CPU oracle.
+// Compile with -ffp-contract=off (strict f32 for fastAtan2 and the pattern rotation).
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+using namespace orbg;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// geometry shared by host and kernels
+
+struct LevelGeom {
+  int w, h;        // level size (without border)
+  int stride;      // bytes per row of the bordered buffer
+  int off;         // byte offset of the bordered buffer inside the camera's pyramid allocation
+  int xt_off;      // offset into the x resize table (entries), level >= 1
+  int yt_off;      // offset into the y resize table
+  int cell_begin;  // first cell record of this level
+  int cell_end;
+};
+
+struct PyrGeom {
+  int n_levels;
+  int cam_stride;              // bytes between camera 0 and camera 1 pyramid allocations
+  LevelGeom lv[ORBG_MAX_LEVELS];
+  float scale[ORBG_MAX_LEVELS];
+};
+
+struct ResizeTap { short ofs, a0, a1, pad; };   // source index + the two 11-bit fixed-point weights
+
+struct CellRec {   // one FAST cell = one workgroup   (S/ORBextractor.cc:787-853)
+  short level;
+  short x0, y0;    // sub-image origin in level coordinates (iniX, iniY)
+  short cw, ch;    // sub-image size (maxX-iniX, maxY-iniY), <= 65
+  short offx, offy;  // j*wCell, i*hCell added to the keypoint coordinates (:847-848)
+  short pad;
+};
+
+struct SelKp {     // keypoint chosen by the quad-tree, in final output order
+  short x, y;      // level coordinates (border offset already added, :868-869)
+  short level;
+  short cam;
+  int out_idx;     // position in the camera's output arrays (lapping order, :1135-1144)
+  float response;
+};
+
+constexpr int kTile = 66;         // max sub-image side is 65 (wCell,hCell <= 59, +6)
+constexpr int kTileStride = 68;
+constexpr int kCellCap = 1024;    // >= ceil(59/2)^2 = 900 survivors of a strict 3x3 NMS
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+  // BORDER_REFLECT_101 for |overshoot| < n
+  p = p < 0 ? -p : p;
+  return p >= n ? 2 * n - 2 - p : p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pyramid  (ORBextractor::ComputePyramid, S/ORBextractor.cc:1152-1177; cv::resize INTER_LINEAR 8UC1,
+// SURVEY.md Appendix A-1; cv::copyMakeBorder REFLECT_101)
+
+__global__ __launch_bounds__(256) void pyr_level0_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1,
+                                                        int img_stride, uint8_t* __restrict__ pyr, PyrGeom g) {
+  const int cam = blockIdx.z;
+  const LevelGeom L = g.lv[0];
+  const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ox >= L.w + 2 * kEdge || oy >= L.h + 2 * kEdge) return;
+  const uint8_t* img = cam ? img1 : img0;
+  const int sx = reflect101(ox - kEdge, L.w), sy = reflect101(oy - kEdge, L.h);
+  pyr[(size_t)cam * g.cam_stride + L.off + (size_t)oy * L.stride + ox] = img[(size_t)sy * img_stride + sx];
+}
+
+__global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ pyr, PyrGeom g, int level,
+                                                        const ResizeTap* __restrict__ xtab, const ResizeTap* __restrict__ ytab) {
+  const int cam = blockIdx.z;
+  const LevelGeom D = g.lv[level];
+  const LevelGeom S = g.lv[level - 1];
+  const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ox >= D.w + 2 * kEdge || oy >= D.h + 2 * kEdge) return;
+  const int dx = reflect101(ox - kEdge, D.w), dy = reflect101(oy - kEdge, D.h);
+  const ResizeTap tx = xtab[D.xt_off + dx], ty = ytab[D.yt_off + dy];
+  uint8_t* base = pyr + (size_t)cam * g.cam_stride;
+  const uint8_t* src = base + S.off + (size_t)kEdge * S.stride + kEdge;
+  const int sx0 = tx.ofs, sx1 = min(sx0 + 1, S.w - 1);
+  const int sy0 = min(max((int)ty.ofs, 0), S.h - 1), sy1 = min(max((int)ty.ofs + 1, 0), S.h - 1);
+  const uint8_t* r0 = src + (size_t)sy0 * S.stride;
+  const uint8_t* r1 = src + (size_t)sy1 * S.stride;
+  const int t0 = r0[sx0] * tx.a0 + r0[sx1] * tx.a1;
+  const int t1 = r1[sx0] * tx.a0 + r1[sx1] * tx.a1;
+  const int v = ((((int)ty.a0 * (t0 >> 4)) >> 16) + (((int)ty.a1 * (t1 >> 4)) >> 16) + 2) >> 2;
+  base[D.off + (size_t)oy * D.stride + ox] = (uint8_t)v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 per cell  (cv::FAST via S/ORBextractor.cc:808-841)
+
+// max over the 16 arcs of 9 contiguous ring pixels of min(d) -- sliding-window minimum by doubling.
+__device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
+  int m2[16], m4[16], m8[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) m2[i] = min(d[i], d[(i + 1) & 15]);
+#pragma unroll
+  for (int i = 0; i < 16; i++) m4[i] = min(m2[i], m2[(i + 2) & 15]);
+#pragma unroll
+  for (int i = 0; i < 16; i++) m8[i] = min(m4[i], m4[(i + 4) & 15]);
+  int best = -1024;
+#pragma unroll
+  for (int i = 0; i < 16; i++) best = max(best, min(m8[i], d[(i + 8) & 15]));
+  return best;
+}
+
+// Packed (iniTh count | minTh count << 16) exclusive scan over a 256-thread workgroup.
+__device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned* total, unsigned* wsum /*LDS[4]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const unsigned s = wsum[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
+                                                        const CellRec* __restrict__ cells, int n_cells, int ini_th,
+                                                        int min_th, uint32_t* __restrict__ slots, int* __restrict__ counts) {
+  __shared__ uint8_t tile[kTile * kTileStride];
+  __shared__ uint8_t score[(kTile + 2) * kTileStride];   // +1 apron of zeros all around the detection area
+  __shared__ unsigned wsum[4];
+  const int cell = blockIdx.x, cam = blockIdx.y;
+  const CellRec c = cells[cell];
+  const LevelGeom L = g.lv[c.level];
+  const uint8_t* src = pyr + (size_t)cam * g.cam_stride + L.off + (size_t)(kEdge + c.y0) * L.stride + (kEdge + c.x0);
+  const int cw = c.cw, ch = c.ch;
+  for (int i = threadIdx.x; i < (kTile + 2) * kTileStride; i += 256) score[i] = 0;
+  // stage the sub-image: consecutive lanes read consecutive bytes of a row
+  for (int i = threadIdx.x; i < ch * kTileStride; i += 256) {
+    const int y = i / kTileStride, x = i - y * kTileStride;
+    if (x < cw) tile[i] = src[(size_t)y * L.stride + x];
+  }
+  __syncthreads();
+  const int wd = cw - 6, hd = ch - 6;       // detection area [3,cw-3) x [3,ch-3)
+  const int npix = wd > 0 && hd > 0 ? wd * hd : 0;
+  for (int p = threadIdx.x; p < npix; p += 256) {
+    const int y = p / wd, x = p - y * wd;
+    const uint8_t* q = &tile[(y + 3) * kTileStride + (x + 3)];
+    const int v = q[0];
+    int d[16];
+    d[0] = v - q[3 * kTileStride];          d[1] = v - q[3 * kTileStride + 1];
+    d[2] = v - q[2 * kTileStride + 2];      d[3] = v - q[kTileStride + 3];
+    d[4] = v - q[3];                        d[5] = v - q[-kTileStride + 3];
+    d[6] = v - q[-2 * kTileStride + 2];     d[7] = v - q[-3 * kTileStride + 1];
+    d[8] = v - q[-3 * kTileStride];         d[9] = v - q[-3 * kTileStride - 1];
+    d[10] = v - q[-2 * kTileStride - 2];    d[11] = v - q[-kTileStride - 3];
+    d[12] = v - q[-3];                      d[13] = v - q[kTileStride - 3];
+    d[14] = v - q[2 * kTileStride - 2];     d[15] = v - q[3 * kTileStride - 1];
+    int nd[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) nd[i] = -d[i];
+    const int s = max(arc9_maxmin(d), arc9_maxmin(nd)) - 1;   // cornerScore<16>: largest passing threshold
+    score[(y + 1) * kTileStride + (x + 1)] = (uint8_t)max(s, 0);
+  }
+  __syncthreads();
+  // NMS + threshold decision + ordered compaction; thread t owns pixels [t*K, (t+1)*K) in row-major order
+  const int K = (npix + 255) >> 8;
+  const int p0 = threadIdx.x * K, p1 = min(p0 + K, npix);
+  unsigned keep_ini = 0, keep_min = 0;
+  for (int p = p0; p < p1; p++) {
+    const int y = p / wd, x = p - y * wd;
+    const uint8_t* s = &score[(y + 1) * kTileStride + (x + 1)];
+    const int v = s[0];
+    if (v >= min_th) {
+      const int m = max(max(max((int)s[-kTileStride - 1], (int)s[-kTileStride]), max((int)s[-kTileStride + 1], (int)s[-1])),
+                        max(max((int)s[1], (int)s[kTileStride - 1]), max((int)s[kTileStride], (int)s[kTileStride + 1])));
+      if (v > m) {
+        keep_min |= 1u << (p - p0);
+        if (v >= ini_th) keep_ini |= 1u << (p - p0);
+      }
+    }
+  }
+  unsigned total;
+  const unsigned packed = (unsigned)__popc(keep_ini) | ((unsigned)__popc(keep_min) << 16);
+  const unsigned excl = block_excl_scan_256(packed, &total, wsum);
+  const bool use_min = (total & 0xFFFFu) == 0;             // vKeysCell.empty() after the iniTh pass (:825)
+  unsigned mask = use_min ? keep_min : keep_ini;
+  unsigned pos = use_min ? (excl >> 16) : (excl & 0xFFFFu);
+  uint32_t* out = slots + ((size_t)cam * n_cells + cell) * kCellCap;
+  while (mask) {
+    const int b = __ffs(mask) - 1;
+    mask &= mask - 1;
+    const int p = p0 + b;
+    const int y = p / wd, x = p - y * wd;
+    const unsigned sc = score[(y + 1) * kTileStride + (x + 1)];
+    out[pos++] = (unsigned)(x + 3 + c.offx) | ((unsigned)(y + 3 + c.offy) << 12) | (sc << 24);
+  }
+  if (threadIdx.x == 0) counts[cam * n_cells + cell] = use_min ? (total >> 16) : (total & 0xFFFFu);
+}
+
+// Compaction of the per-cell slots into one candidate list (camera-major, level-major, cell-major), written
+// straight into mapped pinned host memory together with the per-(camera,level) start offsets.
+__global__ __launch_bounds__(256) void gather_cells_kernel(const uint32_t* __restrict__ slots, const int* __restrict__ counts,
+                                                          PyrGeom g, const CellRec* __restrict__ cells, int n_cells,
+                                                          int n_cams, int* __restrict__ out_hdr, uint32_t* __restrict__ out_cand, int out_cap) {
+  __shared__ int wsum[4];
+  const int cell = blockIdx.x, cam = blockIdx.y;
+  const int gidx = cam * n_cells + cell;
+  int s = 0;
+  for (int i = threadIdx.x; i < gidx; i += 256) s += counts[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  const int n = counts[gidx];
+  const int level = cells[cell].level;
+  if (threadIdx.x == 0) {
+    if (cell == g.lv[level].cell_begin) out_hdr[cam * ORBG_MAX_LEVELS + level] = base;
+    if (cell == n_cells - 1 && cam == n_cams - 1) out_hdr[2 * ORBG_MAX_LEVELS] = base + n;   // grand total
+    if (cell == n_cells - 1) out_hdr[2 * ORBG_MAX_LEVELS + 1 + cam] = base + n;              // end of this camera
+  }
+  const uint32_t* in = slots + (size_t)gidx * kCellCap;
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (base + i < out_cap) out_cand[base + i] = in[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// orientation + blur + rBRIEF, one wavefront per keypoint
+// (IC_Angle S/ORBextractor.cc:75-102, GaussianBlur :1114-1115 / Appendix A-4, computeOrbDescriptor :106-145)
+
+__device__ const signed char d_pattern[1024] = {
+#include "orb_pattern_data.inc"
+};
+
+// cv::fastAtan2, Appendix A-5 (strict f32, no contraction)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, ax + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = __fdiv_rn(ax, ay + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+struct UMax { int v[16]; };
+
+constexpr int kPR = 21;              // patch radius: 18 (max rotated pattern reach) + 3 (blur)
+constexpr int kPW = 2 * kPR + 1;     // 43
+constexpr int kPS = 44;              // raw row stride
+constexpr int kBR = 18;
+constexpr int kBW = 2 * kBR + 1;     // 37
+constexpr int kHS = 38;              // row-pass stride (u16)
+constexpr int kBS = 40;              // blurred stride
+constexpr int kKpPerBlock = 4;
+
+__global__ __launch_bounds__(256) void orient_desc_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
+                                                         const SelKp* __restrict__ sel, int n_sel, UMax um, int cam1_base,
+                                                         orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
+  __shared__ uint8_t raw_s[kKpPerBlock][kPW * kPS];
+  __shared__ unsigned short hrow_s[kKpPerBlock][kPW * kHS];
+  __shared__ uint8_t blur_s[kKpPerBlock][kBW * kBS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = blockIdx.x * kKpPerBlock + wv;
+  if (k >= n_sel) return;            // whole wavefront exits together; no block-wide barrier below
+  uint8_t* raw = raw_s[wv];
+  unsigned short* hrow = hrow_s[wv];
+  uint8_t* blur = blur_s[wv];
+  const SelKp kp = sel[k];
+  const LevelGeom L = g.lv[kp.level];
+  const uint8_t* src = pyr + (size_t)kp.cam * g.cam_stride + L.off + (size_t)(kEdge + kp.y - kPR) * L.stride + (kEdge + kp.x - kPR);
+  for (int i = lane; i < kPW * kPS; i += 64) {
+    const int y = i / kPS, x = i - y * kPS;
+    if (x < kPW) raw[i] = src[(size_t)y * L.stride + x];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  // --- intensity centroid (exact integer sums -> order independent)
+  int m01 = 0, m10 = 0;
+  {
+    const uint8_t* c = raw + kPR * kPS + kPR;
+    for (int i = lane; i < 31 * 31; i += 64) {
+      const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
+      const int av = v < 0 ? -v : v;
+      if ((u < 0 ? -u : u) <= um.v[av]) {
+        const int val = c[v * kPS + u];
+        m10 += u * val;
+        m01 += v * val;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m01 += __shfl_xor(m01, o, 64); m10 += __shfl_xor(m10, o, 64); }
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  // --- separable 7x7 Gaussian, Q8 taps {18,34,49,55,49,34,18}: row pass fits u16 (257*255 = 65535)
+  for (int i = lane; i < kPW * kBW; i += 64) {
+    const int y = i / kBW, x = i - y * kBW;
+    const uint8_t* r = raw + y * kPS + x;       // x is already offset by -3 relative to the blurred column
+    const int acc = 18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 49 * (r[2] + r[4]) + 55 * r[3];
+    hrow[y * kHS + x] = (unsigned short)acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int i = lane; i < kBW * kBW; i += 64) {
+    const int y = i / kBW, x = i - y * kBW;
+    const unsigned short* r = hrow + y * kHS + x;
+    const int acc = 18 * ((int)r[0] + r[6 * kHS]) + 34 * ((int)r[kHS] + r[5 * kHS]) + 49 * ((int)r[2 * kHS] + r[4 * kHS]) + 55 * (int)r[3 * kHS];
+    const int v = (acc + 32768) >> 16;
+    blur[y * kBS + x] = (uint8_t)min(v, 255);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  // --- steered BRIEF: lane l evaluates tests 4l..4l+3 (16 pattern bytes = one 128-bit load)
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  const float ang = angle * factorPI;
+  const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+  const int4 praw = *reinterpret_cast<const int4*>(d_pattern + 16 * lane);
+  const signed char* pp = reinterpret_cast<const signed char*>(&praw);
+  const uint8_t* c = blur + kBR * kBS + kBR;
+  unsigned nib = 0;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    int val[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const float px = (float)pp[4 * t + 2 * e], py = (float)pp[4 * t + 2 * e + 1];
+      const int r = (int)rintf(px * b + py * a);      // cvRound: half-to-even of the f32 value
+      const int cc = (int)rintf(px * a - py * b);
+      val[e] = c[r * kBS + cc];
+    }
+    nib |= (unsigned)(val[0] < val[1]) << t;
+  }
+  const unsigned hi = __shfl_down(nib, 1, 64);
+  const size_t out = (size_t)(kp.cam ? cam1_base : 0) + kp.out_idx;
+  if ((lane & 1) == 0) desc[out * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+  if (lane == 0) {
+    const float s = g.scale[kp.level];
+    orbx_keypoint o;
+    o.x = kp.level ? (float)kp.x * s : (float)kp.x;    // keypoint->pt *= scale  (:1131-1133)
+    o.y = kp.level ? (float)kp.y * s : (float)kp.y;
+    o.size = (float)(int)((float)kPatch * s);           // scaledPatchSize (:862,871)
+    o.angle = angle;
+    o.response = kp.response;
+    o.octave = kp.level;
+    kps[out] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stereo matching on the device-resident features (Frame::ComputeStereoMatches, S/Frame.cc:785-963)
+
+__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// One wavefront per left keypoint: lanes sweep all right keypoints (row band + octave + disparity gates,
+// Hamming, wavefront min on the (dist, iR) key = "first minimum wins"), then the 11x11 SAD over 11 offsets.
+__global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
+                                                          const orbx_keypoint* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
+                                                          const orbx_keypoint* __restrict__ kr, const uint8_t* __restrict__ dr, int nr,
+                                                          float bf, float b, float* __restrict__ uright, float* __restrict__ depth,
+                                                          int* __restrict__ best_sad) {
+  const int lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (iL >= nl) return;
+  const orbx_keypoint kpL = kl[iL];
+  float out_u = -1.0f, out_d = -1.0f;
+  int out_sad = -1;
+  const int levelL = kpL.octave;
+  const float vL = kpL.y, uL = kpL.x;
+  const float minZ = b, minD = 0, maxD = bf / minZ;
+  const float minU = uL - maxD, maxU = uL - minD;
+  const int row = (int)vL;
+  const int nRows = g.lv[0].h;
+  unsigned bestKey = 0xFFFFFFFFu;
+  if (!(maxU < 0) && row >= 0 && row < nRows) {
+    const uint4 a0 = *reinterpret_cast<const uint4*>(dl + (size_t)iL * 32);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(dl + (size_t)iL * 32 + 16);
+    for (int iR = lane; iR < nr; iR += 64) {
+      const orbx_keypoint kpR = kr[iR];
+      const float r = 2.0f * g.scale[kpR.octave];
+      const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);   // vRowIndices band (:806-811)
+      if (row < minr || row > maxr) continue;
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      if (!(kpR.x >= minU && kpR.x <= maxU)) continue;
+      const uint4 b0 = *reinterpret_cast<const uint4*>(dr + (size_t)iR * 32);
+      const uint4 b1 = *reinterpret_cast<const uint4*>(dr + (size_t)iR * 32 + 16);
+      const unsigned key = ((unsigned)hamming256(a0, a1, b0, b1) << 16) | (unsigned)iR;
+      bestKey = min(bestKey, key);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bestKey = min(bestKey, (unsigned)__shfl_xor((int)bestKey, o, 64));
+  const int bestDist = bestKey == 0xFFFFFFFFu ? 100 : (int)(bestKey >> 16);
+  // bestDist starts at TH_HIGH = 100 with a strict '<' (:841,862); accepted below (100+50)/2 = 75 (:790,871)
+  if (bestDist < 75) {
+    const int bestIdxR = (int)(bestKey & 0xFFFF);
+    const float uR0 = kr[bestIdxR].x;
+    const float scaleFactor = __fdiv_rn(1.0f, g.scale[levelL]);       // mvInvScaleFactors
+    const float scaleduL = roundf(kpL.x * scaleFactor);
+    const float scaledvL = roundf(kpL.y * scaleFactor);
+    const float scaleduR0 = roundf(uR0 * scaleFactor);
+    const LevelGeom L = g.lv[levelL];
+    const float iniu = scaleduR0 + 5 - 5, endu = scaleduR0 + 5 + 5 + 1;
+    if (!(iniu < 0 || endu >= (float)L.w)) {
+      const uint8_t* IL = pyr + L.off + (size_t)kEdge * L.stride + kEdge;
+      const uint8_t* IR = IL + g.cam_stride;
+      const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
+      const int centreL = IL[(size_t)cy * L.stride + cxL];
+      int sad[11];
+#pragma unroll
+      for (int o = 0; o < 11; o++) sad[o] = 0;
+      for (int i = lane; i < 121; i += 64) {
+        const int dy = i / 11 - 5, dx = i - (dy + 5) * 11 - 5;
+        const int a = (int)IL[(size_t)(cy + dy) * L.stride + cxL + dx] - centreL;
+        const uint8_t* rrow = IR + (size_t)(cy + dy) * L.stride;
+#pragma unroll
+        for (int o = 0; o < 11; o++) {
+          const int cxR = cxR0 + o - 5;
+          const int centreR = IR[(size_t)cy * L.stride + cxR];
+          const int c = (int)rrow[cxR + dx] - centreR;
+          sad[o] += abs(a - c);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < 11; o++) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) sad[o] += __shfl_xor(sad[o], s, 64);
+      }
+      int bestS = 0x7FFFFFFF, bestinc = 0;
+#pragma unroll
+      for (int o = 0; o < 11; o++)
+        if (sad[o] < bestS) { bestS = sad[o]; bestinc = o - 5; }
+      if (!(bestinc == -5 || bestinc == 5)) {
+        float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+        for (int o = 1; o < 10; o++)
+          if (o - 5 == bestinc) { d1 = (float)sad[o - 1]; d2 = (float)sad[o]; d3 = (float)sad[o + 1]; }
+        const float deltaR = __fdiv_rn(d1 - d3, 2.0f * (d1 + d3 - 2.0f * d2));
+        if (!(deltaR < -1 || deltaR > 1)) {
+          float bestuR = g.scale[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+          float disparity = uL - bestuR;
+          if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }
+            out_d = __fdiv_rn(bf, disparity);
+            out_u = bestuR;
+            out_sad = bestS;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) { uright[iL] = out_u; depth[iL] = out_d; best_sad[iL] = out_sad; }
+}
+
+// median-of-SAD outlier rejection (:949-962): one workgroup; rank counting gives the element
+// vDistIdx[size/2].first of the sorted list without sorting.
+__global__ __launch_bounds__(1024) void stereo_finalize_kernel(float* __restrict__ uright, float* __restrict__ depth,
+                                                              const int* __restrict__ best_sad, int nl) {
+  __shared__ int s_cnt, s_median;
+  if (threadIdx.x == 0) { s_cnt = 0; s_median = -1; }
+  __syncthreads();
+  int local = 0;
+  for (int i = threadIdx.x; i < nl; i += 1024) local += best_sad[i] >= 0;
+  if (local) atomicAdd(&s_cnt, local);
+  __syncthreads();
+  const int n = s_cnt;
+  if (n == 0) return;
+  const int kth = n / 2;
+  // value v is the kth order statistic iff  #(x < v) <= kth < #(x <= v)
+  for (int i = threadIdx.x; i < nl; i += 1024) {
+    const int v = best_sad[i];
+    if (v < 0) continue;
+    int lt = 0, le = 0;
+    for (int j = 0; j < nl; j++) {
+      const int x = best_sad[j];
+      if (x >= 0) { lt += x < v; le += x <= v; }
+    }
+    if (lt <= kth && kth < le) s_median = v;     // every writer writes the same value
+  }
+  __syncthreads();
+  const float median = (float)s_median;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = threadIdx.x; i < nl; i += 1024) {
+    const int v = best_sad[i];
+    if (v >= 0 && !((float)v < thDist)) { uright[i] = -1; depth[i] = -1; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: quad-tree keypoint selection (DistributeOctTree, S/ORBextractor.cc:479-761)
+//
+// Nodes are axis-aligned boxes over a contiguous range of a key array (children = stable 4-way partition of
+// the parent's range), linked in a list with the reference's push_front order.  Tie-break of the
+// "largest node first" phase: (size, creation order), newest first -- the reference's order there depends
+// on heap addresses, so it is pinned, identically to the oracle.
+
+struct Cand { int x, y, score; };
+
+class QuadTree {
+ public:
+  void run(const Cand* c, int n, int minX, int maxX, int minY, int maxY, int N, std::vector<int>& out) {
+    out.clear();
+    if (n == 0) return;
+    c_ = c;
+    nodes_.clear();
+    keys_.resize(n);
+    tmp_.resize(n);
+    head_ = tail_ = -1;
+    size_ = 0;
+    int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+    if (nIni < 1) nIni = 1;
+    const float hX = static_cast<float>(maxX - minX) / nIni;
+    // bucket candidates by root (stable)
+    std::vector<int> cnt(nIni + 1, 0);
+    root_of_.resize(n);
+    for (int i = 0; i < n; i++) {
+      int r = (int)((float)c[i].x / hX);
+      if (r >= nIni) r = nIni - 1;
+      root_of_[i] = r;
+      cnt[r + 1]++;
+    }
+    for (int r = 0; r < nIni; r++) cnt[r + 1] += cnt[r];
+    {
+      std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+      for (int i = 0; i < n; i++) keys_[fill[root_of_[i]]++] = i;
+    }
+    for (int r = 0; r < nIni; r++) {
+      Node nd;
+      nd.x0 = (int)(hX * static_cast<float>(r)); nd.x1 = (int)(hX * static_cast<float>(r + 1));
+      nd.y0 = 0; nd.y1 = maxY - minY;
+      nd.b = cnt[r]; nd.e = cnt[r + 1];
+      nd.no_more = (nd.e - nd.b) == 1;
+      const int id = new_node(nd);
+      push_back(id);
+    }
+    for (int it = head_; it >= 0;) {
+      const int nx = nodes_[it].next;
+      if (nodes_[it].e == nodes_[it].b) erase(it);
+      it = nx;
+    }
+    bool finish = false;
+    while (!finish) {
+      const int prevSize = size_;
+      int nToExpand = 0;
+      work_.clear();
+      for (int it = head_; it >= 0;) {
+        if (nodes_[it].no_more) { it = nodes_[it].next; continue; }
+        const int nx = nodes_[it].next;
+        split(it, &nToExpand);
+        erase(it);
+        it = nx;
+      }
+      if (size_ >= N || size_ == prevSize) {
+        finish = true;
+      } else if (size_ + nToExpand * 3 > N) {
+        while (!finish) {
+          const int prev = size_;
+          prev_work_.swap(work_);
+          work_.clear();
+          std::sort(prev_work_.begin(), prev_work_.end());   // (size, node id) ascending; id == creation order
+          for (int j = (int)prev_work_.size() - 1; j >= 0; j--) {
+            const int id = prev_work_[j].second;
+            split(id, nullptr);
+            erase(id);
+            if (size_ >= N) break;
+          }
+          if (size_ >= N || size_ == prev) finish = true;
+        }
+      }
+    }
+    out.reserve(size_);
+    for (int it = head_; it >= 0; it = nodes_[it].next) {
+      const Node& nd = nodes_[it];
+      int best = keys_[nd.b];
+      for (int k = nd.b + 1; k < nd.e; k++)
+        if (c_[keys_[k]].score > c_[best].score) best = keys_[k];
+      out.push_back(best);
+    }
+  }
+
+ private:
+  struct Node { int x0, y0, x1, y1, b, e, prev, next; bool no_more; };
+  const Cand* c_ = nullptr;
+  std::vector<Node> nodes_;
+  std::vector<int> keys_, tmp_, root_of_;
+  std::vector<std::pair<int, int>> work_, prev_work_;
+  int head_ = -1, tail_ = -1, size_ = 0;
+
+  int new_node(const Node& n) { nodes_.push_back(n); return (int)nodes_.size() - 1; }
+  void push_front(int id) {
+    nodes_[id].prev = -1; nodes_[id].next = head_;
+    if (head_ >= 0) nodes_[head_].prev = id; else tail_ = id;
+    head_ = id; size_++;
+  }
+  void push_back(int id) {
+    nodes_[id].next = -1; nodes_[id].prev = tail_;
+    if (tail_ >= 0) nodes_[tail_].next = id; else head_ = id;
+    tail_ = id; size_++;
+  }
+  void erase(int id) {
+    const int p = nodes_[id].prev, n = nodes_[id].next;
+    if (p >= 0) nodes_[p].next = n; else head_ = n;
+    if (n >= 0) nodes_[n].prev = p; else tail_ = p;
+    size_--;
+  }
+  // ExtractorNode::DivideNode (:479-535) + the push_front of non-empty children (:619-658)
+  void split(int id, int* nToExpand) {
+    const Node p = nodes_[id];
+    const int halfX = (int)std::ceil(static_cast<float>(p.x1 - p.x0) / 2);
+    const int halfY = (int)std::ceil(static_cast<float>(p.y1 - p.y0) / 2);
+    const int mx = p.x0 + halfX, my = p.y0 + halfY;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int k = p.b; k < p.e; k++) {
+      const Cand& c = c_[keys_[k]];
+      const int q = ((float)c.x < (float)mx ? 0 : 1) + ((float)c.y < (float)my ? 0 : 2);
+      tmp_[k] = q;
+      cnt[q]++;
+    }
+    int start[4] = {p.b, p.b + cnt[0], p.b + cnt[0] + cnt[1], p.b + cnt[0] + cnt[1] + cnt[2]};
+    {
+      int fill[4] = {start[0], start[1], start[2], start[3]};
+      scratch_.resize(p.e - p.b);
+      for (int k = p.b; k < p.e; k++) scratch_[fill[tmp_[k]]++ - p.b] = keys_[k];
+      std::copy(scratch_.begin(), scratch_.begin() + (p.e - p.b), keys_.begin() + p.b);
+    }
+    const int bx[4][4] = {{p.x0, p.y0, mx, my}, {mx, p.y0, p.x1, my}, {p.x0, my, mx, p.y1}, {mx, my, p.x1, p.y1}};
+    for (int q = 0; q < 4; q++) {
+      if (!cnt[q]) continue;
+      Node ch;
+      ch.x0 = bx[q][0]; ch.y0 = bx[q][1]; ch.x1 = bx[q][2]; ch.y1 = bx[q][3];
+      ch.b = start[q]; ch.e = start[q] + cnt[q];
+      ch.no_more = cnt[q] == 1;
+      const int cid = new_node(ch);
+      push_front(cid);
+      if (cnt[q] > 1) {
+        if (nToExpand) (*nToExpand)++;
+        work_.push_back({cnt[q], cid});
+      }
+    }
+  }
+  std::vector<int> scratch_;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// handle
+
+struct orbx_handle {
+  orbx_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> feats_per_level;
+  UMax umax;
+  // geometry for the current image size
+  int cur_w = 0, cur_h = 0;
+  PyrGeom geom;
+  std::vector<CellRec> cells;
+  DevBuf<uint8_t> d_pyr, d_img;
+  DevBuf<ResizeTap> d_xtab, d_ytab;
+  DevBuf<CellRec> d_cells;
+  DevBuf<uint32_t> d_slots;
+  DevBuf<int> d_counts;
+  PinnedBuf<int> hdr;            // [2*MAX_LEVELS] level starts, [2*MAX_LEVELS] total, +1,+2 camera ends
+  PinnedBuf<uint32_t> cand;      // packed candidates
+  PinnedBuf<SelKp> sel;
+  DevBuf<orbx_keypoint> d_kps;   // [cam0 | cam1]
+  DevBuf<uint8_t> d_desc;
+  PinnedBuf<orbx_keypoint> h_kps;
+  PinnedBuf<uint8_t> h_desc;
+  DevBuf<float> d_uright, d_depth;
+  DevBuf<int> d_sad;
+  PinnedBuf<float> h_stereo;
+  int n_kp[2] = {0, 0};
+  int cand_cap = 0;
+  // per-level candidate views of the last extraction (for orbx_get_candidates)
+  std::vector<Cand> last_cands[2][ORBG_MAX_LEVELS];
+  QuadTree qt;
+  float timings[8] = {0};
+};
+
+static int setup_geometry(orbx_handle* h, int w, int hgt) {
+  if (w == h->cur_w && hgt == h->cur_h) return ORBG_OK;
+  const int nl = h->cfg.n_levels;
+  PyrGeom& g = h->geom;
+  g.n_levels = nl;
+  int off = 0, xt = 0, yt = 0;
+  h->cells.clear();
+  std::vector<ResizeTap> xtab, ytab;
+  for (int l = 0; l < nl; l++) {
+    LevelGeom& L = g.lv[l];
+    const float s = h->inv_scale[l];
+    L.w = (int)std::nearbyint((double)((float)w * s));       // cvRound((float)cols*scale) :1157
+    L.h = (int)std::nearbyint((double)((float)hgt * s));
+    if (L.w <= kEdge || L.h <= kEdge) return ORBG_BAD_ARG;   // REFLECT_101 of a 19-px border needs more than 19 px
+    L.stride = (L.w + 2 * kEdge + 63) & ~63;
+    L.off = off;
+    off += L.stride * (L.h + 2 * kEdge);
+    off = (off + 255) & ~255;
+    L.xt_off = xt; L.yt_off = yt;
+    g.scale[l] = h->scale[l];
+    if (l > 0) {
+      const LevelGeom& S = g.lv[l - 1];
+      // cv::resize coefficient tables (Appendix A-1)
+      const double scale_x = 1. / ((double)L.w / S.w), scale_y = 1. / ((double)L.h / S.h);
+      for (int dx = 0; dx < L.w; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+        ResizeTap t;
+        t.ofs = (short)sx;
+        t.a0 = (short)std::nearbyintf((1.f - fx) * 2048);
+        t.a1 = (short)std::nearbyintf(fx * 2048);
+        t.pad = 0;
+        xtab.push_back(t);
+      }
+      for (int dy = 0; dy < L.h; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)std::floor(fy);
+        fy -= sy;
+        ResizeTap t;
+        t.ofs = (short)sy;
+        t.a0 = (short)std::nearbyintf((1.f - fy) * 2048);
+        t.a1 = (short)std::nearbyintf(fy * 2048);
+        t.pad = 0;
+        ytab.push_back(t);
+      }
+      xt += L.w; yt += L.h;
+    }
+    // FAST cells (:771-804)
+    L.cell_begin = (int)h->cells.size();
+    const int minB = kEdge - 3, maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+    const float fw = (float)(maxBX - minB), fh = (float)(maxBY - minB);
+    const int nCols = (int)(fw / 30.f), nRows = (int)(fh / 30.f);
+    if (nCols >= 1 && nRows >= 1) {
+      const int wCell = (int)std::ceil(fw / nCols), hCell = (int)std::ceil(fh / nRows);
+      for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minB + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBY - 3) continue;
+        if (maxY > maxBY) maxY = (float)maxBY;
+        for (int j = 0; j < nCols; j++) {
+          const float iniX = (float)(minB + j * wCell);
+          float maxX = iniX + wCell + 6;
+          if (iniX >= maxBX - 6) continue;
+          if (maxX > maxBX) maxX = (float)maxBX;
+          CellRec c;
+          c.level = (short)l;
+          c.x0 = (short)(int)iniX; c.y0 = (short)(int)iniY;
+          c.cw = (short)((int)maxX - (int)iniX); c.ch = (short)((int)maxY - (int)iniY);
+          c.offx = (short)(j * wCell); c.offy = (short)(i * hCell);
+          c.pad = 0;
+          if (c.cw > kTile - 1 || c.ch > kTile - 1) return ORBG_INTERNAL;
+          h->cells.push_back(c);
+        }
+      }
+    }
+    L.cell_end = (int)h->cells.size();
+  }
+  g.cam_stride = off;
+  const int nc = h->cfg.n_cams;
+  int rc;
+  if ((rc = h->d_pyr.reserve((size_t)off * nc))) return rc;
+  if ((rc = h->d_img.reserve((size_t)w * hgt * nc))) return rc;
+  if ((rc = h->d_xtab.reserve(xtab.size() + 1))) return rc;
+  if ((rc = h->d_ytab.reserve(ytab.size() + 1))) return rc;
+  if ((rc = h->d_cells.reserve(h->cells.size() + 1))) return rc;
+  if ((rc = h->d_slots.reserve(h->cells.size() * (size_t)nc * kCellCap))) return rc;
+  if ((rc = h->d_counts.reserve(h->cells.size() * (size_t)nc))) return rc;
+  h->cand_cap = (int)std::min<size_t>(h->cells.size() * (size_t)nc * 64 + 4096, (size_t)1 << 22);
+  if ((rc = h->cand.reserve(h->cand_cap))) return rc;
+  if ((rc = h->hdr.reserve(2 * ORBG_MAX_LEVELS + 4))) return rc;
+  if (!xtab.empty()) ORBG_HIP(hipMemcpy(h->d_xtab.p, xtab.data(), xtab.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+  if (!ytab.empty()) ORBG_HIP(hipMemcpy(h->d_ytab.p, ytab.data(), ytab.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+  if (!h->cells.empty()) ORBG_HIP(hipMemcpy(h->d_cells.p, h->cells.data(), h->cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
+  h->cur_w = w; h->cur_h = hgt;
+  return ORBG_OK;
+}
+
+extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
+  if (!cfg || !out) return ORBG_BAD_ARG;
+  if (cfg->n_levels < 1 || cfg->n_levels > ORBG_MAX_LEVELS || cfg->n_features < 1 || cfg->n_cams < 1 || cfg->n_cams > 2 ||
+      !(cfg->scale_factor > 1.0f) || cfg->max_width > 4000 || cfg->max_height > 4000)
+    return ORBG_BAD_ARG;
+  int rc = select_device(cfg->device);
+  if (rc) return rc;
+  orbx_handle* h = new orbx_handle();
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  const int nl = cfg->n_levels;
+  // ORBextractor::ORBextractor (S/ORBextractor.cc:413-468)
+  h->scale.resize(nl); h->inv_scale.resize(nl); h->sigma2.resize(nl); h->inv_sigma2.resize(nl);
+  h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+  for (int i = 1; i < nl; i++) { h->scale[i] = h->scale[i - 1] * cfg->scale_factor; h->sigma2[i] = h->scale[i] * h->scale[i]; }
+  for (int i = 0; i < nl; i++) { h->inv_scale[i] = 1.0f / h->scale[i]; h->inv_sigma2[i] = 1.0f / h->sigma2[i]; }
+  h->feats_per_level.resize(nl);
+  const float factor = 1.0f / cfg->scale_factor;
+  float desired = cfg->n_features * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; l++) {
+    h->feats_per_level[l] = (int)std::nearbyint((double)desired);
+    sum += h->feats_per_level[l];
+    desired *= factor;
+  }
+  h->feats_per_level[nl - 1] = std::max(cfg->n_features - sum, 0);
+  {
+    int um[kHalfPatch + 2] = {0};
+    int v, v0;
+    const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) um[v] = (int)std::nearbyint(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+      while (um[v0] == um[v0 + 1]) ++v0;
+      um[v] = v0;
+      ++v0;
+    }
+    for (int i = 0; i < 16; i++) h->umax.v[i] = um[i];
+  }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
+  for (auto& e : h->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
+  const int cap = 2 * (cfg->n_features + 4 * nl + 64);
+  if ((rc = h->sel.reserve(cap)) || (rc = h->d_kps.reserve(cap)) || (rc = h->d_desc.reserve((size_t)cap * 32)) ||
+      (rc = h->h_kps.reserve(cap)) || (rc = h->h_desc.reserve((size_t)cap * 32)) || (rc = h->d_uright.reserve(cap)) ||
+      (rc = h->d_depth.reserve(cap)) || (rc = h->d_sad.reserve(cap)) || (rc = h->h_stereo.reserve(2 * (size_t)cap))) {
+    delete h;
+    return rc;
+  }
+  if (cfg->max_width > 0 && cfg->max_height > 0) {
+    rc = setup_geometry(h, cfg->max_width, cfg->max_height);
+    if (rc) { delete h; return rc; }
+  }
+  *out = h;
+  return ORBG_OK;
+}
+
+extern "C" int orbx_destroy(orbx_handle* h) {
+  if (!h) return ORBG_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->d_pyr.release(); h->d_img.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_cells.release();
+  h->d_slots.release(); h->d_counts.release(); h->hdr.release(); h->cand.release(); h->sel.release();
+  h->d_kps.release(); h->d_desc.release(); h->h_kps.release(); h->h_desc.release();
+  h->d_uright.release(); h->d_depth.release(); h->d_sad.release(); h->h_stereo.release();
+  for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return ORBG_OK;
+}
+
+extern "C" int orbx_get_tables(const orbx_handle* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                               int32_t* fpl) {
+  if (!h) return ORBG_BAD_ARG;
+  for (int i = 0; i < h->cfg.n_levels; i++) {
+    if (scale) scale[i] = h->scale[i];
+    if (inv_scale) inv_scale[i] = h->inv_scale[i];
+    if (sigma2) sigma2[i] = h->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = h->inv_sigma2[i];
+    if (fpl) fpl[i] = h->feats_per_level[i];
+  }
+  return ORBG_OK;
+}
+
+// Core: cams_mask selects which cameras of the rig are processed; d_img are device pointers.
+static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img0, const uint8_t* d_img1, int w, int hgt,
+                        int stride, const int lap[2][2], orbx_keypoint* kps_out[2], uint8_t* desc_out[2], const int cap[2],
+                        int* n_out[2], int* n_mono_out[2]) {
+  int rc = setup_geometry(h, w, hgt);
+  if (rc) return rc;
+  const PyrGeom& g = h->geom;
+  const int nl = g.n_levels;
+  const int ncams = (cams_mask & 2) ? 2 : 1;       // cameras [0, ncams) are launched; mask 2 alone is not supported
+  if (cams_mask == 2) return ORBG_BAD_ARG;
+  const int n_cells = (int)h->cells.size();
+  hipStream_t st = h->stream;
+  ORBG_HIP(hipEventRecord(h->ev[0], st));
+  {
+    const LevelGeom& L0 = g.lv[0];
+    dim3 grid((L0.w + 2 * kEdge + 63) / 64, (L0.h + 2 * kEdge + 3) / 4, ncams);
+    hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, d_img0, d_img1 ? d_img1 : d_img0, stride, h->d_pyr.p, g);
+    for (int l = 1; l < nl; l++) {
+      const LevelGeom& L = g.lv[l];
+      dim3 gr((L.w + 2 * kEdge + 63) / 64, (L.h + 2 * kEdge + 3) / 4, ncams);
+      hipLaunchKernelGGL(pyr_resize_kernel, gr, dim3(256), 0, st, h->d_pyr.p, g, l, h->d_xtab.p, h->d_ytab.p);
+    }
+  }
+  ORBG_HIP(hipEventRecord(h->ev[1], st));
+  if (n_cells > 0) {
+    hipLaunchKernelGGL(fast_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
+                       std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
+    hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
+                       h->d_cells.p, n_cells, ncams, h->hdr.d, h->cand.d, h->cand_cap);
+  }
+  ORBG_HIP(hipEventRecord(h->ev[2], st));
+  ORBG_HIP(hipStreamSynchronize(st));
+  const auto t_host0 = std::chrono::steady_clock::now();
+  // ---- host: quad-tree per (camera, level), lapping order (:1104-1146)
+  int total = n_cells > 0 ? h->hdr.h[2 * ORBG_MAX_LEVELS] : 0;
+  if (total > h->cand_cap) {
+    // candidate list did not fit the mapped buffer: grow it and ask the caller to retry is not acceptable for a
+    // drop-in, so re-run the gather with a larger buffer.
+    h->cand_cap = total + total / 2;
+    if ((rc = h->cand.reserve(h->cand_cap))) return rc;
+    hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
+                       h->d_cells.p, n_cells, ncams, h->hdr.d, h->cand.d, h->cand_cap);
+    ORBG_HIP(hipStreamSynchronize(st));
+  }
+  int n_sel_total = 0;
+  std::vector<int> keep;
+  for (int cam = 0; cam < ncams; cam++) {
+    std::vector<SelKp> level_kps;   // in level order, octree list order
+    for (int l = 0; l < nl; l++) {
+      std::vector<Cand>& cv = h->last_cands[cam][l];
+      cv.clear();
+      const LevelGeom& L = g.lv[l];
+      if (L.cell_end == L.cell_begin) continue;
+      const int b = h->hdr.h[cam * ORBG_MAX_LEVELS + l];
+      int e;
+      int nlv = l + 1;
+      while (nlv < nl && g.lv[nlv].cell_end == g.lv[nlv].cell_begin) nlv++;
+      if (nlv < nl) e = h->hdr.h[cam * ORBG_MAX_LEVELS + nlv];
+      else e = h->hdr.h[2 * ORBG_MAX_LEVELS + 1 + cam];
+      cv.resize(e - b);
+      for (int i = b; i < e; i++) {
+        const uint32_t p = h->cand.h[i];
+        cv[i - b] = Cand{(int)(p & 0xFFF), (int)((p >> 12) & 0xFFF), (int)(p >> 24)};
+      }
+      const int minB = kEdge - 3;
+      h->qt.run(cv.data(), (int)cv.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, h->feats_per_level[l], keep);
+      for (int k : keep) {
+        SelKp s;
+        s.x = (short)(cv[k].x + minB); s.y = (short)(cv[k].y + minB);
+        s.level = (short)l; s.cam = (short)cam; s.out_idx = 0; s.response = (float)cv[k].score;
+        level_kps.push_back(s);
+      }
+    }
+    const int nk = (int)level_kps.size();
+    h->n_kp[cam] = nk;
+    if (n_out[cam]) *n_out[cam] = nk;
+    if ((kps_out[cam] || desc_out[cam]) && nk > cap[cam]) return ORBG_CAP_EXCEEDED;
+    if ((size_t)(n_sel_total + nk) > h->sel.cap) return ORBG_CAP_EXCEEDED;
+    int monoIndex = 0, stereoIndex = nk - 1;
+    for (SelKp& s : level_kps) {
+      float px = (float)s.x;
+      if (s.level != 0) px *= h->scale[s.level];
+      if (px >= (float)lap[cam][0] && px <= (float)lap[cam][1]) s.out_idx = stereoIndex--;
+      else s.out_idx = monoIndex++;
+      h->sel.h[n_sel_total++] = s;
+    }
+    if (n_mono_out[cam]) *n_mono_out[cam] = monoIndex;
+  }
+  if (ncams == 1) h->n_kp[1] = 0;
+  const auto t_host1 = std::chrono::steady_clock::now();
+  // ---- GPU phase 2: orientation + descriptors, written in final order
+  ORBG_HIP(hipEventRecord(h->ev[3], st));
+  if (n_sel_total > 0) {
+    hipLaunchKernelGGL(orient_desc_kernel, dim3((n_sel_total + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st,
+                       h->d_pyr.p, g, h->sel.d, n_sel_total, h->umax, h->n_kp[0], h->d_kps.p, h->d_desc.p);
+  }
+  ORBG_HIP(hipEventRecord(h->ev[4], st));
+  const bool want_out = kps_out[0] || desc_out[0] || kps_out[1] || desc_out[1];
+  if (want_out && n_sel_total > 0) {
+    ORBG_HIP(hipMemcpyAsync(h->h_kps.h, h->d_kps.p, (size_t)n_sel_total * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, st));
+    ORBG_HIP(hipMemcpyAsync(h->h_desc.h, h->d_desc.p, (size_t)n_sel_total * 32, hipMemcpyDeviceToHost, st));
+  }
+  ORBG_HIP(hipStreamSynchronize(st));
+  if (want_out) {
+    int base = 0;
+    for (int cam = 0; cam < ncams; cam++) {
+      if (kps_out[cam]) memcpy(kps_out[cam], h->h_kps.h + base, (size_t)h->n_kp[cam] * sizeof(orbx_keypoint));
+      if (desc_out[cam]) memcpy(desc_out[cam], h->h_desc.h + (size_t)base * 32, (size_t)h->n_kp[cam] * 32);
+      base += h->n_kp[cam];
+    }
+  }
+  float ms;
+  if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->timings[0] = ms;   // pyramid
+  if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->timings[1] = ms;   // FAST + gather
+  h->timings[2] = std::chrono::duration<float, std::milli>(t_host1 - t_host0).count();  // host quad-tree
+  if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->timings[3] = ms;   // orientation + descriptors
+  return ORBG_OK;
+}
+
+static int upload_image(orbx_handle* h, int slot, const uint8_t* img, int w, int hgt, int stride) {
+  // pageable host -> device; rows are packed on the device (stride = w)
+  ORBG_HIP(hipMemcpy2DAsync(h->d_img.p + (size_t)slot * w * hgt, w, img, stride, w, hgt, hipMemcpyHostToDevice, h->stream));
+  return ORBG_OK;
+}
+
+extern "C" int orbx_extract(orbx_handle* h, int cam, const uint8_t* img, int width, int height, int stride, int lap0,
+                            int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n, int* n_mono) {
+  if (!h || !n) return ORBG_BAD_ARG;
+  if (!img || width <= 0 || height <= 0) return ORBG_EMPTY;     // S/ORBextractor.cc:1072-1073
+  if (cam != 0 || stride < width) return ORBG_BAD_ARG;          // one camera per call goes through slot 0
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  if ((rc = setup_geometry(h, width, height))) return rc;
+  if ((rc = upload_image(h, 0, img, width, height, stride))) return rc;
+  const int lap[2][2] = {{lap0, lap1}, {0, 0}};
+  orbx_keypoint* ko[2] = {kps, nullptr};
+  uint8_t* dout[2] = {desc, nullptr};
+  const int caps[2] = {cap, 0};
+  int* no[2] = {n, nullptr};
+  int* nm[2] = {n_mono, nullptr};
+  return extract_core(h, 1, h->d_img.p, nullptr, width, height, width, lap, ko, dout, caps, no, nm);
+}
+
+static int extract_stereo_impl(orbx_handle* h, const uint8_t* d0, const uint8_t* d1, int width, int height, int stride,
+                               orbx_keypoint* kl, uint8_t* dl, int cl, int* nl, orbx_keypoint* kr, uint8_t* dr, int cr, int* nr) {
+  const int lap[2][2] = {{0, 0}, {0, 0}};      // vLapping = {0,0} for the rectified stereo Frame ctor (S/Frame.cc:92-95)
+  orbx_keypoint* ko[2] = {kl, kr};
+  uint8_t* dout[2] = {dl, dr};
+  const int caps[2] = {cl, cr};
+  int* no[2] = {nl, nr};
+  int* nm[2] = {nullptr, nullptr};
+  return extract_core(h, 3, d0, d1, width, height, stride, lap, ko, dout, caps, no, nm);
+}
+
+extern "C" int orbx_extract_stereo(orbx_handle* h, const uint8_t* img_left, const uint8_t* img_right, int width, int height,
+                                   int stride, orbx_keypoint* kps_left, uint8_t* desc_left, int cap_left, int* n_left,
+                                   orbx_keypoint* kps_right, uint8_t* desc_right, int cap_right, int* n_right) {
+  if (!h || h->cfg.n_cams != 2) return ORBG_BAD_ARG;
+  if (!img_left || !img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
+  if (stride < width) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  if ((rc = setup_geometry(h, width, height))) return rc;
+  if ((rc = upload_image(h, 0, img_left, width, height, stride))) return rc;
+  if ((rc = upload_image(h, 1, img_right, width, height, stride))) return rc;
+  return extract_stereo_impl(h, h->d_img.p, h->d_img.p + (size_t)width * height, width, height, width, kps_left, desc_left,
+                             cap_left, n_left, kps_right, desc_right, cap_right, n_right);
+}
+
+extern "C" int orbx_extract_stereo_dev(orbx_handle* h, const uint8_t* d_img_left, const uint8_t* d_img_right, int width,
+                                       int height, int stride, orbx_keypoint* kps_left, uint8_t* desc_left, int cap_left,
+                                       int* n_left, orbx_keypoint* kps_right, uint8_t* desc_right, int cap_right, int* n_right) {
+  if (!h || h->cfg.n_cams != 2) return ORBG_BAD_ARG;
+  if (!d_img_left || !d_img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
+  if (stride < width) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  return extract_stereo_impl(h, d_img_left, d_img_right, width, height, stride, kps_left, desc_left, cap_left, n_left,
+                             kps_right, desc_right, cap_right, n_right);
+}
+
+extern "C" int orbx_get_level(orbx_handle* h, int cam, int level, uint8_t* host_out, int* width, int* height) {
+  if (!h || cam < 0 || cam >= h->cfg.n_cams || level < 0 || level >= h->cfg.n_levels || h->cur_w == 0) return ORBG_BAD_ARG;
+  const LevelGeom& L = h->geom.lv[level];
+  if (width) *width = L.w;
+  if (height) *height = L.h;
+  if (host_out) {
+    int rc = select_device(h->device);
+    if (rc) return rc;
+    const uint8_t* src = h->d_pyr.p + (size_t)cam * h->geom.cam_stride + L.off + (size_t)kEdge * L.stride + kEdge;
+    ORBG_HIP(hipMemcpy2D(host_out, L.w, src, L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+  }
+  return ORBG_OK;
+}
+
+extern "C" int orbx_get_candidates(orbx_handle* h, int cam, int level, int32_t* xys, int cap, int* n) {
+  if (!h || cam < 0 || cam >= h->cfg.n_cams || level < 0 || level >= h->cfg.n_levels || !n) return ORBG_BAD_ARG;
+  const std::vector<Cand>& cv = h->last_cands[cam][level];
+  *n = (int)cv.size();
+  for (int i = 0; i < *n && i < cap; i++) { xys[3 * i] = cv[i].x; xys[3 * i + 1] = cv[i].y; xys[3 * i + 2] = cv[i].score; }
+  return *n > cap ? ORBG_CAP_EXCEEDED : ORBG_OK;
+}
+
+extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* uright, float* depth) {
+  if (!h || h->cfg.n_cams != 2 || h->cur_w == 0) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  const int nl = h->n_kp[0], nr = h->n_kp[1];
+  hipStream_t st = h->stream;
+  ORBG_HIP(hipEventRecord(h->ev[5], st));
+  if (nl > 0) {
+    hipLaunchKernelGGL(stereo_match_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, h->d_pyr.p, h->geom, h->d_kps.p, h->d_desc.p,
+                       nl, h->d_kps.p + nl, h->d_desc.p + (size_t)nl * 32, nr, bf, b, h->d_uright.p, h->d_depth.p, h->d_sad.p);
+    hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(1024), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl);
+  }
+  ORBG_HIP(hipEventRecord(h->ev[6], st));
+  if (nl > 0 && (uright || depth)) {
+    ORBG_HIP(hipMemcpyAsync(h->h_stereo.h, h->d_uright.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));
+    ORBG_HIP(hipMemcpyAsync(h->h_stereo.h + nl, h->d_depth.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));
+  }
+  ORBG_HIP(hipStreamSynchronize(st));
+  if (nl > 0 && uright) memcpy(uright, h->h_stereo.h, (size_t)nl * 4);
+  if (nl > 0 && depth) memcpy(depth, h->h_stereo.h + nl, (size_t)nl * 4);
+  float ms;
+  if (hipEventElapsedTime(&ms, h->ev[5], h->ev[6]) == hipSuccess) h->timings[4] = ms;
+  return ORBG_OK;
+}
+
+extern "C" int orbx_get_timings(orbx_handle* h, float* ms) {
+  if (!h || !ms) return ORBG_BAD_ARG;
+  for (int i = 0; i < 8; i++) ms[i] = h->timings[i];
+  return ORBG_OK;
+}
+
+// accessors for matcher.hip (device-resident hand-over, same shared object)
+extern "C++" {
+int orbx_internal_left_features(orbx_handle* h, const orbx_keypoint** d_kps, const uint8_t** d_desc, const float** d_uright,
+                                const float** d_depth, int* n, hipStream_t* stream) {
+  if (!h) return ORBG_BAD_ARG;
+  *d_kps = h->d_kps.p; *d_desc = h->d_desc.p; *d_uright = h->d_uright.p; *d_depth = h->d_depth.p; *n = h->n_kp[0];
+  *stream = h->stream;
+  return ORBG_OK;
+}
+}

@@ -1,0 +1,1137 @@
+// liborbgpu -- Hamming matchers for gfx950 (MI355X): feature grid, isInFrustum, SearchByProjection (map and
+// frame variants) and SearchByBoW.  Replaces the ORBmatcher searches of S/ORBmatcher.cc and the Frame helpers
+// of S/Frame.cc behind the C-ABI of include/orbgpu.h.
+//
+// Design: frame features (keypoints, descriptors, uRight, 64x48 CSR grid) and the local map stay resident in HBM;
+// one 64-lane wavefront serves one query (map point / last-frame point / keyframe feature):
+//   * the query's window of grid cells (or its BoW node bucket) is enumerated in the reference's order, every
+//     candidate gets its position `pos` in that order;
+//   * the 256-bit descriptors are compared with v_popc on 8 dwords; each lane keeps its two smallest
+//     (dist<<20 | pos) keys and a butterfly merge over the wavefront yields the best / second best --
+//     identical to the reference's sequential strict-'<' scan (tests pin the equivalence, ties included);
+//   * the reference's matchers are greedy and order dependent (a feature claimed by an earlier query is skipped
+//     by later ones, S/ORBmatcher.cc:89-91,324-325,2045-2047).  Kernels evaluate all queries against the state at
+//     entry and also emit each query's (feature, distance) candidate list into mapped pinned memory; the host
+//     commits results in the reference's serial order and re-scans a query's list only if its best / second
+//     best feature has been claimed meanwhile.  Results are identical to the serial loop.
+// Float conventions mirror the oracle's documented OpenCV small-matrix rules (see oracle/matching.cc header).
+// Compile with -ffp-contract=off.
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace orbg;
+
+int orbx_internal_left_features(orbx_handle* h, const orbx_keypoint** d_kps, const uint8_t** d_desc, const float** d_uright,
+                                const float** d_depth, int* n, hipStream_t* stream);
+
+namespace {
+
+constexpr int TH_HIGH = 100;      // S/ORBmatcher.cc:36
+constexpr int TH_LOW = 50;        // :37
+constexpr int HISTO_LENGTH = 30;  // :38
+constexpr int kCells = ORBG_GRID_COLS * ORBG_GRID_ROWS;
+
+struct FrameParams {
+  int n;
+  float min_x, max_x, min_y, max_y;
+  float w_inv, h_inv;               // mfGridElementWidthInv / HeightInv (S/Frame.cc:127-144)
+  float fx, fy, cx, cy, bf, b;
+  int n_levels;
+  float log_sf;
+  float scale[ORBG_MAX_LEVELS];
+};
+
+struct PoseF {   // Tcw split as the reference does (S/Frame.cc:439-445)
+  float R[9], t[3], Ow[3];
+};
+
+struct QResult {   // per query, written to mapped pinned memory
+  int base, count;          // candidate list segment (count entries incl. filtered ones marked invalid)
+  int best_idx, best_dist, second_idx, second_dist;
+  float u, v;               // projection (frame-frame variant needs nothing else on the host)
+};
+
+__device__ __forceinline__ int popc256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+__device__ __forceinline__ void pose_map(const PoseF& P, const float* X, float* out) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float t0 = P.R[3 * i] * X[0] + P.R[3 * i + 1] * X[1] + P.R[3 * i + 2] * X[2];
+    out[i] = t0 + P.t[i];
+  }
+}
+
+__device__ __forceinline__ float norm3d(const float* v) {
+  const double s = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2];
+  return (float)sqrt(s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid  (Frame::AssignFeaturesToGrid / PosInGrid, S/Frame.cc:360-391,699-709); CSR, cell = ix*48+iy
+
+__global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* __restrict__ kps, FrameParams fp,
+                                                         int* __restrict__ cell_of, int* __restrict__ cell_start,
+                                                         int* __restrict__ cell_items) {
+  __shared__ int cnt[kCells];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x;
+  for (int c = tid; c < kCells; c += 1024) cnt[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < fp.n; i += 1024) {
+    const int px = (int)roundf((kps[i].x - fp.min_x) * fp.w_inv);
+    const int py = (int)roundf((kps[i].y - fp.min_y) * fp.h_inv);
+    int c = -1;
+    if (!(px < 0 || px >= ORBG_GRID_COLS || py < 0 || py >= ORBG_GRID_ROWS)) {
+      c = px * ORBG_GRID_ROWS + py;
+      atomicAdd(&cnt[c], 1);
+    }
+    cell_of[i] = c;
+  }
+  __syncthreads();
+  // exclusive scan of 3072 counts: 3 per thread
+  const int c0 = tid * 3;
+  const int a = cnt[c0], b = cnt[c0 + 1], c = cnt[c0 + 2];
+  int inc = a + b + c;
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  const int excl = base + inc - (a + b + c);
+  cell_start[c0] = excl; cell_start[c0 + 1] = excl + a; cell_start[c0 + 2] = excl + a + b;
+  if (tid == 1023) cell_start[kCells] = excl + a + b + c;
+  __syncthreads();
+  cnt[c0] = excl; cnt[c0 + 1] = excl + a; cnt[c0 + 2] = excl + a + b;   // running fill cursors
+  __syncthreads();
+  for (int i = tid; i < fp.n; i += 1024) {
+    const int cc = cell_of[i];
+    if (cc >= 0) cell_items[atomicAdd(&cnt[cc], 1)] = i;
+  }
+  __syncthreads();
+  __threadfence_block();
+  // restore insertion (= keypoint index) order inside every cell
+  for (int q = 0; q < 3; q++) {
+    const int cc = c0 + q;
+    const int s = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
+    const int e = cnt[cc];
+    for (int i = s + 1; i < e; i++) {
+      const int key = cell_items[i];
+      int j = i - 1;
+      while (j >= s && cell_items[j] > key) { cell_items[j + 1] = cell_items[j]; j--; }
+      cell_items[j + 1] = key;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// isInFrustum (S/Frame.cc:466-543, Nleft == -1) + MapPoint::PredictScale (S/MapPoint.cc:646-661)
+
+struct TrackFields { int in_view; float px, py, pxr, depth, view_cos; int level; };
+
+__device__ __forceinline__ TrackFields frustum_check(const FrameParams& fp, const PoseF& P, const float* X, const float* Pn,
+                                                     float min_raw, float max_raw, float limit) {
+  TrackFields f;
+  f.in_view = 0; f.px = -1.f; f.py = -1.f; f.pxr = 0.f; f.depth = 0.f; f.view_cos = 0.f; f.level = 0;
+  float Pc[3];
+  pose_map(P, X, Pc);
+  const float Pc_dist = norm3d(Pc);
+  const float PcZ = Pc[2];
+  const float invz = 1.0f / PcZ;
+  if (PcZ < 0.0f) return f;
+  const float u = fp.fx * Pc[0] / Pc[2] + fp.cx;
+  const float v = fp.fy * Pc[1] / Pc[2] + fp.cy;
+  if (u < fp.min_x || u > fp.max_x) return f;
+  if (v < fp.min_y || v > fp.max_y) return f;
+  f.px = u; f.py = v;
+  const float maxDistance = 1.2f * max_raw, minDistance = 0.8f * min_raw;
+  const float PO[3] = {X[0] - P.Ow[0], X[1] - P.Ow[1], X[2] - P.Ow[2]};
+  const float dist = norm3d(PO);
+  if (dist < minDistance || dist > maxDistance) return f;
+  const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+  const float viewCos = (float)(dot / (double)dist);
+  if (viewCos < limit) return f;
+  const float ratio = max_raw / dist;
+  // logf(ratio): correctly rounded via the f64 log (matches glibc logf wherever that is correctly rounded)
+  const float lg = (float)log((double)ratio);
+  int nScale = (int)ceilf(lg / fp.log_sf);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= fp.n_levels) nScale = fp.n_levels - 1;
+  f.in_view = 1;
+  f.pxr = u - fp.bf * invz;
+  f.depth = Pc_dist;
+  f.level = nScale;
+  f.view_cos = viewCos;
+  return f;
+}
+
+struct WorldPtsDev {
+  int m;
+  const float* pos; const float* normal; const float* min_dist; const float* max_dist;
+  const uint8_t* desc; const uint8_t* bad; const uint8_t* skip;
+};
+
+struct TrackDev {   // SoA track fields on the device
+  uint8_t* in_view; float* px; float* py; float* pxr; float* depth; int* level; float* view_cos;
+};
+
+__global__ __launch_bounds__(256) void frustum_kernel(FrameParams fp, PoseF P, WorldPtsDev w, float limit, TrackDev t) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w.m) return;
+  const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
+  const float N[3] = {w.normal[3 * i], w.normal[3 * i + 1], w.normal[3 * i + 2]};
+  const TrackFields f = frustum_check(fp, P, X, N, w.min_dist[i], w.max_dist[i], limit);
+  t.in_view[i] = (uint8_t)f.in_view; t.px[i] = f.px; t.py[i] = f.py; t.pxr[i] = f.pxr; t.depth[i] = f.depth;
+  t.level[i] = f.level; t.view_cos[i] = f.view_cos;
+}
+
+// ------------------------------------------------------------------------------------------------
+// window search: one wavefront per query
+
+struct Top2 { unsigned k1, k2; int i1, i2; };   // keys = dist<<20 | pos, k1 <= k2
+
+__device__ __forceinline__ void top2_insert(Top2& t, unsigned key, int idx) {
+  if (key < t.k1) { t.k2 = t.k1; t.i2 = t.i1; t.k1 = key; t.i1 = idx; }
+  else if (key < t.k2) { t.k2 = key; t.i2 = idx; }
+}
+
+__device__ __forceinline__ void top2_wave_merge(Top2& t) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned ok1 = (unsigned)__shfl_xor((int)t.k1, o, 64), ok2 = (unsigned)__shfl_xor((int)t.k2, o, 64);
+    const int oi1 = __shfl_xor(t.i1, o, 64), oi2 = __shfl_xor(t.i2, o, 64);
+    top2_insert(t, ok1, oi1);
+    top2_insert(t, ok2, oi2);
+  }
+}
+
+struct FrameDev {
+  const orbx_keypoint* kps; const uint8_t* desc; const float* uright;   // uright may be NULL
+  const int* cell_start; const int* cell_items;
+  const int* assigned_mp; const int* assigned_obs;                       // state at entry
+};
+
+struct Query { int valid; float x, y, r; int min_level, max_level; float ur_ref; };
+
+// GetFeaturesInArea (S/Frame.cc:628-697) + the candidate loop of the projection searches.
+// Emits the candidate list [base, base+count) (entry = idx | dist<<16, or 0xFFFFFFFF when filtered).
+__device__ __forceinline__ void window_search(const FrameParams& fp, const FrameDev& F, const Query& q, const uint8_t* qdesc,
+                                              int* __restrict__ list_counter, uint32_t* __restrict__ list, int list_cap,
+                                              QResult* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  QResult res;
+  res.base = 0; res.count = 0; res.best_idx = -1; res.best_dist = 256; res.second_idx = -1; res.second_dist = 256;
+  res.u = q.x; res.v = q.y;
+  bool empty = !q.valid;
+  int nMinCellX = 0, nMaxCellX = -1, nMinCellY = 0, nMaxCellY = -1;
+  if (!empty) {
+    nMinCellX = max(0, (int)floorf((q.x - fp.min_x - q.r) * fp.w_inv));
+    nMaxCellX = min(ORBG_GRID_COLS - 1, (int)ceilf((q.x - fp.min_x + q.r) * fp.w_inv));
+    nMinCellY = max(0, (int)floorf((q.y - fp.min_y - q.r) * fp.h_inv));
+    nMaxCellY = min(ORBG_GRID_ROWS - 1, (int)ceilf((q.y - fp.min_y + q.r) * fp.h_inv));
+    if (nMinCellX >= ORBG_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ORBG_GRID_ROWS || nMaxCellY < 0) empty = true;
+  }
+  if (empty) {
+    if (lane == 0) *out = res;
+    return;
+  }
+  const int ncy = nMaxCellY - nMinCellY + 1, ncx = nMaxCellX - nMinCellX + 1;
+  const int ncell = ncx * ncy;
+  // pass 1: total number of items in the window (upper bound of the list length)
+  int total = 0;
+  for (int c = lane; c < ncell; c += 64) {
+    const int ix = nMinCellX + c / ncy, iy = nMinCellY + c % ncy;
+    const int cell = ix * ORBG_GRID_ROWS + iy;
+    total += F.cell_start[cell + 1] - F.cell_start[cell];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+  if (total == 0) {
+    if (lane == 0) *out = res;
+    return;
+  }
+  int base = 0;
+  if (lane == 0) base = atomicAdd(list_counter, total);
+  base = __shfl(base, 0, 64);
+  const uint4 a0 = *reinterpret_cast<const uint4*>(qdesc);
+  const uint4 a1 = *reinterpret_cast<const uint4*>(qdesc + 16);
+  const bool bCheckLevels = (q.min_level > 0) || (q.max_level >= 0);
+  Top2 t;
+  t.k1 = t.k2 = 0xFFFFFFFFu; t.i1 = t.i2 = -1;
+  int run = 0;   // candidates before the current chunk of 64 cells
+  for (int c0 = 0; c0 < ncell; c0 += 64) {
+    const int c = c0 + lane;
+    int s = 0, n = 0;
+    if (c < ncell) {
+      const int ix = nMinCellX + c / ncy, iy = nMinCellY + c % ncy;
+      const int cell = ix * ORBG_GRID_ROWS + iy;
+      s = F.cell_start[cell];
+      n = F.cell_start[cell + 1] - s;
+    }
+    int inc = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    const int chunk_total = __shfl(inc, 63, 64);
+    const int my_pos0 = run + inc - n;
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    for (int j = 0; j < nmax; j++) {
+      if (j < n) {
+        const int idx = F.cell_items[s + j];
+        const int pos = my_pos0 + j;
+        const orbx_keypoint kp = F.kps[idx];
+        bool ok = true;
+        if (bCheckLevels) {
+          if (kp.octave < q.min_level) ok = false;
+          if (q.max_level >= 0 && kp.octave > q.max_level) ok = false;
+        }
+        const float distx = kp.x - q.x, disty = kp.y - q.y;
+        if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) ok = false;
+        if (ok && F.assigned_mp[idx] >= 0 && F.assigned_obs[idx] > 0) ok = false;
+        if (ok && F.uright) {
+          const float ur = F.uright[idx];
+          if (ur > 0) {
+            const float er = fabsf(q.ur_ref - ur);
+            if (er > q.r) ok = false;
+          }
+        }
+        unsigned entry = 0xFFFFFFFFu;
+        if (ok) {
+          const uint4 b0 = *reinterpret_cast<const uint4*>(F.desc + (size_t)idx * 32);
+          const uint4 b1 = *reinterpret_cast<const uint4*>(F.desc + (size_t)idx * 32 + 16);
+          const int d = popc256(a0, a1, b0, b1);
+          top2_insert(t, ((unsigned)d << 20) | (unsigned)pos, idx);
+          entry = (unsigned)idx | ((unsigned)d << 16);
+        }
+        if (base + pos < list_cap) list[base + pos] = entry;
+      }
+    }
+    run += chunk_total;
+  }
+  top2_wave_merge(t);
+  if (lane == 0) {
+    res.base = base; res.count = total;
+    if (t.i1 >= 0) { res.best_idx = t.i1; res.best_dist = (int)(t.k1 >> 20); }
+    if (t.i2 >= 0) { res.second_idx = t.i2; res.second_dist = (int)(t.k2 >> 20); }
+    *out = res;
+  }
+}
+
+// MODE 0: SearchByProjection(Frame, vector<MapPoint*>) with track fields given (S/ORBmatcher.cc:44-143)
+struct MpsDev {
+  int m;
+  const uint8_t* in_view; const uint8_t* bad; const float* px; const float* py; const float* pxr; const float* depth;
+  const int* level; const float* view_cos; const uint8_t* desc;
+};
+
+__global__ __launch_bounds__(256) void search_mps_kernel(FrameParams fp, FrameDev F, MpsDev mp, float th, int far_points,
+                                                        float th_far, int* list_counter, uint32_t* list, int list_cap,
+                                                        QResult* results) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= mp.m) return;
+  Query q;
+  q.valid = mp.in_view[i] && !(far_points && mp.depth[i] > th_far) && !mp.bad[i];
+  q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
+  if (q.valid) {
+    const int lvl = mp.level[i];
+    float r = (mp.view_cos[i] > 0.998) ? 2.5f : 4.0f;      // RadiusByViewingCos, :216-222 (double literal compare)
+    if (th != 1.0) r *= th;
+    q.x = mp.px[i]; q.y = mp.py[i];
+    q.r = r * fp.scale[lvl];
+    q.min_level = lvl - 1; q.max_level = lvl;
+    q.ur_ref = mp.pxr[i];
+  }
+  window_search(fp, F, q, mp.desc + (size_t)i * 32, list_counter, list, list_cap, results + i);
+}
+
+// MODE 2: SearchByProjection(CurrentFrame, LastFrame) (S/ORBmatcher.cc:1993-2066)
+struct LastDev {
+  int n;
+  const uint8_t* mp_valid; const uint8_t* outlier; const float* world_pos; const uint8_t* desc; const int* octave;
+};
+
+__global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, FrameDev F, LastDev L, PoseF Pc, float th,
+                                                          int forward, int backward, int* list_counter, uint32_t* list,
+                                                          int list_cap, QResult* results) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= L.n) return;
+  Query q;
+  q.valid = 0; q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
+  if (L.mp_valid[i] && !L.outlier[i]) {
+    const float X[3] = {L.world_pos[3 * i], L.world_pos[3 * i + 1], L.world_pos[3 * i + 2]};
+    float x3Dc[3];
+    pose_map(Pc, X, x3Dc);
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);
+    if (!(invzc < 0)) {
+      const float u = fp.fx * x3Dc[0] / x3Dc[2] + fp.cx;
+      const float v = fp.fy * x3Dc[1] / x3Dc[2] + fp.cy;
+      if (!(u < fp.min_x || u > fp.max_x) && !(v < fp.min_y || v > fp.max_y)) {
+        const int oct = L.octave[i];
+        q.valid = 1;
+        q.x = u; q.y = v;
+        q.r = th * fp.scale[oct];
+        if (forward) { q.min_level = oct; q.max_level = -1; }
+        else if (backward) { q.min_level = 0; q.max_level = oct; }
+        else { q.min_level = oct - 1; q.max_level = oct + 1; }
+        q.ur_ref = u - fp.bf * invzc;
+      }
+    }
+  }
+  window_search(fp, F, q, L.desc + (size_t)i * 32, list_counter, list, list_cap, results + i);
+}
+
+// SearchByBoW inner loops (S/ORBmatcher.cc:297-371): one wavefront per keyframe feature of a shared node.
+struct BowJob { int kf_idx; int f_begin, f_end; };   // frame-side bucket [f_begin,f_end) in fvF.feat_idx
+
+__global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restrict__ fdesc, const uint32_t* __restrict__ f_feat_idx,
+                                                        const uint8_t* __restrict__ kf_desc, const BowJob* __restrict__ jobs,
+                                                        int n_jobs, int* list_counter, uint32_t* list, int list_cap,
+                                                        QResult* results) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n_jobs) return;
+  const BowJob job = jobs[j];
+  const int total = job.f_end - job.f_begin;
+  QResult res;
+  res.base = 0; res.count = total; res.best_idx = -1; res.best_dist = 256; res.second_idx = -1; res.second_dist = 256;
+  res.u = res.v = 0;
+  int base = 0;
+  if (lane == 0 && total > 0) base = atomicAdd(list_counter, total);
+  base = __shfl(base, 0, 64);
+  const uint4 a0 = *reinterpret_cast<const uint4*>(kf_desc + (size_t)job.kf_idx * 32);
+  const uint4 a1 = *reinterpret_cast<const uint4*>(kf_desc + (size_t)job.kf_idx * 32 + 16);
+  Top2 t;
+  t.k1 = t.k2 = 0xFFFFFFFFu; t.i1 = t.i2 = -1;
+  for (int p = lane; p < total; p += 64) {
+    const int idx = (int)f_feat_idx[job.f_begin + p];
+    const uint4 b0 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32);
+    const uint4 b1 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32 + 16);
+    const int d = popc256(a0, a1, b0, b1);
+    top2_insert(t, ((unsigned)d << 20) | (unsigned)p, idx);
+    if (base + p < list_cap) list[base + p] = (unsigned)idx | ((unsigned)d << 16);
+  }
+  top2_wave_merge(t);
+  if (lane == 0) {
+    res.base = base;
+    if (t.i1 >= 0) { res.best_idx = t.i1; res.best_dist = (int)(t.k1 >> 20); }
+    if (t.i2 >= 0) { res.second_idx = t.i2; res.second_dist = (int)(t.k2 >> 20); }
+    results[j] = res;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// raw Hamming kernels (DescriptorDistance, S/ORBmatcher.cc:2358-2374)
+
+__global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t,
+                                                            int nt, int* __restrict__ dist) {
+  __shared__ uint4 qs[16][2];
+  const int q0 = blockIdx.y * 16;
+  if (threadIdx.x < 32) {
+    const int qi = q0 + (threadIdx.x >> 1);
+    if (qi < nq) qs[threadIdx.x >> 1][threadIdx.x & 1] = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16 * (threadIdx.x & 1));
+  }
+  __syncthreads();
+  const int ti = blockIdx.x * 256 + threadIdx.x;
+  if (ti >= nt) return;
+  const uint4 b0 = *reinterpret_cast<const uint4*>(t + (size_t)ti * 32);
+  const uint4 b1 = *reinterpret_cast<const uint4*>(t + (size_t)ti * 32 + 16);
+  for (int k = 0; k < 16 && q0 + k < nq; k++) dist[(size_t)(q0 + k) * nt + ti] = popc256(qs[k][0], qs[k][1], b0, b1);
+}
+
+__global__ __launch_bounds__(256) void hamming_best2_kernel(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t,
+                                                           int nt, int* __restrict__ out4) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= nq) return;
+  const uint4 a0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
+  const uint4 a1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16);
+  Top2 tt;
+  tt.k1 = tt.k2 = 0xFFFFFFFFu; tt.i1 = tt.i2 = -1;
+  for (int j = lane; j < nt; j += 64) {
+    const uint4 b0 = *reinterpret_cast<const uint4*>(t + (size_t)j * 32);
+    const uint4 b1 = *reinterpret_cast<const uint4*>(t + (size_t)j * 32 + 16);
+    top2_insert(tt, ((unsigned)popc256(a0, a1, b0, b1) << 20) | (unsigned)j, j);
+  }
+  top2_wave_merge(tt);
+  if (lane == 0) {
+    out4[4 * qi] = tt.i1 >= 0 ? (int)(tt.k1 >> 20) : 256; out4[4 * qi + 1] = tt.i1;
+    out4[4 * qi + 2] = tt.i2 >= 0 ? (int)(tt.k2 >> 20) : 256; out4[4 * qi + 3] = tt.i2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host helpers
+
+void make_pose(const float* T, PoseF* P) {
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) P->R[3 * i + j] = T[4 * i + j];
+    P->t[i] = T[4 * i + 3];
+  }
+  for (int i = 0; i < 3; i++) {      // mOw = -mRcw.t()*mtcw, general gemm path: double accumulation
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)P->R[3 * k + i] * (double)P->t[k];
+    P->Ow[i] = (float)(-s);
+  }
+}
+
+// ORBmatcher::ComputeThreeMaxima, S/ORBmatcher.cc:2312-2353
+void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+inline int rot_bin(float a1, float a2) {   // factor = 1/HISTO_LENGTH
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// frame object
+
+struct orbm_frame {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2] = {};
+  int cap = 0;
+  FrameParams fp;
+  bool has_uright = false;
+  DevBuf<orbx_keypoint> d_kps;
+  DevBuf<uint8_t> d_desc;
+  DevBuf<float> d_uright, d_depth;
+  DevBuf<int> d_cell_of, d_cell_start, d_cell_items, d_assigned_mp, d_assigned_obs;
+  std::vector<orbx_keypoint> h_kps;      // host mirror (octave / angle for the serial commit)
+  // query-side scratch
+  DevBuf<uint8_t> d_q_u8[4];
+  DevBuf<float> d_q_f32[8];
+  DevBuf<int> d_q_i32[4];
+  DevBuf<int> d_counter;
+  PinnedBuf<uint32_t> list;
+  PinnedBuf<QResult> results;
+  PinnedBuf<int> h_counter;
+  DevBuf<BowJob> d_jobs;
+  DevBuf<uint32_t> d_fidx;
+  float last_ms = 0;
+};
+
+static int frame_set_params(orbm_frame* f, const orbm_frame_view* v, int n) {
+  if (v->n_levels < 1 || v->n_levels > ORBG_MAX_LEVELS) return ORBG_BAD_ARG;
+  FrameParams& p = f->fp;
+  p.n = n;
+  p.min_x = v->min_x; p.max_x = v->max_x; p.min_y = v->min_y; p.max_y = v->max_y;
+  p.w_inv = static_cast<float>(ORBG_GRID_COLS) / static_cast<float>(v->max_x - v->min_x);
+  p.h_inv = static_cast<float>(ORBG_GRID_ROWS) / static_cast<float>(v->max_y - v->min_y);
+  p.fx = v->fx; p.fy = v->fy; p.cx = v->cx; p.cy = v->cy; p.bf = v->bf; p.b = v->b;
+  p.n_levels = v->n_levels;
+  p.log_sf = std::log(v->scale_factor);
+  p.scale[0] = 1.0f;
+  for (int i = 1; i < v->n_levels; i++) p.scale[i] = p.scale[i - 1] * v->scale_factor;
+  for (int i = v->n_levels; i < ORBG_MAX_LEVELS; i++) p.scale[i] = 0;
+  return ORBG_OK;
+}
+
+static int frame_reserve(orbm_frame* f, int n) {
+  int rc;
+  const size_t c = (size_t)std::max(n, 1);
+  if ((rc = f->d_kps.reserve(c)) || (rc = f->d_desc.reserve(c * 32)) || (rc = f->d_uright.reserve(c)) ||
+      (rc = f->d_depth.reserve(c)) || (rc = f->d_cell_of.reserve(c)) || (rc = f->d_cell_start.reserve(kCells + 1)) ||
+      (rc = f->d_cell_items.reserve(c)) || (rc = f->d_assigned_mp.reserve(c)) || (rc = f->d_assigned_obs.reserve(c)) ||
+      (rc = f->d_counter.reserve(4)) || (rc = f->h_counter.reserve(4)))
+    return rc;
+  return ORBG_OK;
+}
+
+static int frame_build_grid(orbm_frame* f) {
+  hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, f->stream, f->d_kps.p, f->fp, f->d_cell_of.p,
+                     f->d_cell_start.p, f->d_cell_items.p);
+  ORBG_HIP(hipGetLastError());
+  return ORBG_OK;
+}
+
+extern "C" int orbm_frame_create(int device, int cap_features, orbm_frame** out) {
+  if (!out || cap_features < 0) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  orbm_frame* f = new orbm_frame();
+  f->device = device;
+  f->cap = cap_features;
+  memset(&f->fp, 0, sizeof(f->fp));
+  if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return ORBG_HIP_ERROR; }
+  for (auto& e : f->ev) if (hipEventCreate(&e) != hipSuccess) { delete f; return ORBG_HIP_ERROR; }
+  if ((rc = frame_reserve(f, cap_features))) { delete f; return rc; }
+  *out = f;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_frame_destroy(orbm_frame* f) {
+  if (!f) return ORBG_BAD_ARG;
+  (void)hipSetDevice(f->device);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  f->d_kps.release(); f->d_desc.release(); f->d_uright.release(); f->d_depth.release(); f->d_cell_of.release();
+  f->d_cell_start.release(); f->d_cell_items.release(); f->d_assigned_mp.release(); f->d_assigned_obs.release();
+  for (auto& b : f->d_q_u8) b.release();
+  for (auto& b : f->d_q_f32) b.release();
+  for (auto& b : f->d_q_i32) b.release();
+  f->d_counter.release(); f->list.release(); f->results.release(); f->h_counter.release(); f->d_jobs.release(); f->d_fidx.release();
+  for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
+  if (f->stream) (void)hipStreamDestroy(f->stream);
+  delete f;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_frame_upload(orbm_frame* f, const orbm_frame_view* v) {
+  if (!f || !v || v->n < 0 || (v->n > 0 && (!v->kps || !v->desc))) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  if ((rc = frame_set_params(f, v, v->n))) return rc;
+  if ((rc = frame_reserve(f, v->n))) return rc;
+  const int n = v->n;
+  f->h_kps.assign(v->kps, v->kps + n);
+  f->has_uright = v->uright != nullptr;
+  if (n > 0) {
+    ORBG_HIP(hipMemcpyAsync(f->d_kps.p, v->kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, f->stream));
+    ORBG_HIP(hipMemcpyAsync(f->d_desc.p, v->desc, (size_t)n * 32, hipMemcpyHostToDevice, f->stream));
+    if (v->uright) ORBG_HIP(hipMemcpyAsync(f->d_uright.p, v->uright, (size_t)n * 4, hipMemcpyHostToDevice, f->stream));
+    if (v->depth) ORBG_HIP(hipMemcpyAsync(f->d_depth.p, v->depth, (size_t)n * 4, hipMemcpyHostToDevice, f->stream));
+  }
+  if ((rc = frame_build_grid(f))) return rc;
+  ORBG_HIP(hipStreamSynchronize(f->stream));
+  return ORBG_OK;
+}
+
+extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v) {
+  if (!f || !h || !v) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; int n; hipStream_t xs;
+  if ((rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &n, &xs))) return rc;
+  if (v->n >= 0 && v->n != n) return ORBG_BAD_ARG;
+  if ((rc = frame_set_params(f, v, n))) return rc;
+  if ((rc = frame_reserve(f, n))) return rc;
+  f->has_uright = true;
+  f->h_kps.resize(n);
+  if (n > 0) {
+    ORBG_HIP(hipStreamSynchronize(xs));    // extractor stream -> frame stream hand-over
+    ORBG_HIP(hipMemcpyAsync(f->d_kps.p, dk, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToDevice, f->stream));
+    ORBG_HIP(hipMemcpyAsync(f->d_desc.p, dd, (size_t)n * 32, hipMemcpyDeviceToDevice, f->stream));
+    ORBG_HIP(hipMemcpyAsync(f->d_uright.p, du, (size_t)n * 4, hipMemcpyDeviceToDevice, f->stream));
+    ORBG_HIP(hipMemcpyAsync(f->d_depth.p, dz, (size_t)n * 4, hipMemcpyDeviceToDevice, f->stream));
+    ORBG_HIP(hipMemcpyAsync(f->h_kps.data(), dk, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, f->stream));
+  }
+  if ((rc = frame_build_grid(f))) return rc;
+  ORBG_HIP(hipStreamSynchronize(f->stream));
+  return ORBG_OK;
+}
+
+extern "C" int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start, int32_t* cell_items) {
+  if (!f || !cell_start) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  ORBG_HIP(hipMemcpy(cell_start, f->d_cell_start.p, (kCells + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  const int total = cell_start[kCells];
+  if (cell_items && total > 0) ORBG_HIP(hipMemcpy(cell_items, f->d_cell_items.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+  return ORBG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// raw Hamming entry points
+
+static int hamming_common(int device, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out, bool matrix) {
+  if (nq < 0 || nt < 0 || !out || (nq > 0 && !q) || (nt > 0 && !t)) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  if (nq == 0) return ORBG_OK;
+  uint8_t *dq = nullptr, *dt = nullptr;
+  int* dout = nullptr;
+  const size_t out_n = matrix ? (size_t)nq * nt : (size_t)nq * 4;
+  ORBG_HIP(hipMalloc((void**)&dq, (size_t)nq * 32));
+  ORBG_HIP(hipMalloc((void**)&dt, (size_t)std::max(nt, 1) * 32));
+  ORBG_HIP(hipMalloc((void**)&dout, std::max<size_t>(out_n, 1) * sizeof(int)));
+  ORBG_HIP(hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice));
+  if (nt > 0) ORBG_HIP(hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice));
+  if (matrix) {
+    if (nt > 0) hipLaunchKernelGGL(hamming_matrix_kernel, dim3((nt + 255) / 256, (nq + 15) / 16), dim3(256), 0, 0, dq, nq, dt, nt, dout);
+  } else {
+    hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + 3) / 4), dim3(256), 0, 0, dq, nq, dt, nt, dout);
+  }
+  ORBG_HIP(hipGetLastError());
+  ORBG_HIP(hipDeviceSynchronize());
+  if (out_n > 0) ORBG_HIP(hipMemcpy(out, dout, out_n * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(dout);
+  return ORBG_OK;
+}
+
+extern "C" int orbm_hamming_matrix(int device, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* dist) {
+  return hamming_common(device, q, nq, t, nt, dist, true);
+}
+extern "C" int orbm_hamming_best2(int device, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out4) {
+  return hamming_common(device, q, nq, t, nt, out4, false);
+}
+
+// ------------------------------------------------------------------------------------------------
+// isInFrustum entry point + map object
+
+struct orbm_map {
+  int device = 0;
+  int m = 0;
+  DevBuf<float> pos, normal, min_dist, max_dist;
+  DevBuf<uint8_t> desc, bad, skip;
+  std::vector<int> n_obs;
+  std::vector<uint8_t> h_bad;
+  // device track fields
+  DevBuf<uint8_t> t_in_view;
+  DevBuf<float> t_px, t_py, t_pxr, t_depth, t_vc;
+  DevBuf<int> t_level;
+};
+
+static int map_reserve(orbm_map* m, int n) {
+  const size_t c = (size_t)std::max(n, 1);
+  int rc;
+  if ((rc = m->pos.reserve(3 * c)) || (rc = m->normal.reserve(3 * c)) || (rc = m->min_dist.reserve(c)) || (rc = m->max_dist.reserve(c)) ||
+      (rc = m->desc.reserve(32 * c)) || (rc = m->bad.reserve(c)) || (rc = m->skip.reserve(c)) || (rc = m->t_in_view.reserve(c)) ||
+      (rc = m->t_px.reserve(c)) || (rc = m->t_py.reserve(c)) || (rc = m->t_pxr.reserve(c)) || (rc = m->t_depth.reserve(c)) ||
+      (rc = m->t_vc.reserve(c)) || (rc = m->t_level.reserve(c)))
+    return rc;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_map_create(int device, int cap_points, orbm_map** out) {
+  if (!out || cap_points < 0) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  orbm_map* m = new orbm_map();
+  m->device = device;
+  if ((rc = map_reserve(m, cap_points))) { delete m; return rc; }
+  *out = m;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_map_destroy(orbm_map* m) {
+  if (!m) return ORBG_BAD_ARG;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  m->pos.release(); m->normal.release(); m->min_dist.release(); m->max_dist.release(); m->desc.release(); m->bad.release();
+  m->skip.release(); m->t_in_view.release(); m->t_px.release(); m->t_py.release(); m->t_pxr.release(); m->t_depth.release();
+  m->t_vc.release(); m->t_level.release();
+  delete m;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* p) {
+  if (!m || !p || p->m < 0) return ORBG_BAD_ARG;
+  if (p->m > 0 && (!p->pos || !p->normal || !p->min_dist || !p->max_dist || !p->desc || !p->n_obs || !p->bad)) return ORBG_BAD_ARG;
+  int rc = select_device(m->device);
+  if (rc) return rc;
+  if ((rc = map_reserve(m, p->m))) return rc;
+  const size_t n = (size_t)p->m;
+  m->m = p->m;
+  m->n_obs.assign(p->n_obs, p->n_obs + n);
+  m->h_bad.assign(p->bad, p->bad + n);
+  if (n > 0) {
+    ORBG_HIP(hipMemcpy(m->pos.p, p->pos, n * 12, hipMemcpyHostToDevice));
+    ORBG_HIP(hipMemcpy(m->normal.p, p->normal, n * 12, hipMemcpyHostToDevice));
+    ORBG_HIP(hipMemcpy(m->min_dist.p, p->min_dist, n * 4, hipMemcpyHostToDevice));
+    ORBG_HIP(hipMemcpy(m->max_dist.p, p->max_dist, n * 4, hipMemcpyHostToDevice));
+    ORBG_HIP(hipMemcpy(m->desc.p, p->desc, n * 32, hipMemcpyHostToDevice));
+    ORBG_HIP(hipMemcpy(m->bad.p, p->bad, n, hipMemcpyHostToDevice));
+    if (p->skip) ORBG_HIP(hipMemcpy(m->skip.p, p->skip, n, hipMemcpyHostToDevice));
+    else ORBG_HIP(hipMemset(m->skip.p, 0, n));
+  }
+  return ORBG_OK;
+}
+
+static WorldPtsDev map_dev(const orbm_map* m) {
+  WorldPtsDev w;
+  w.m = m->m; w.pos = m->pos.p; w.normal = m->normal.p; w.min_dist = m->min_dist.p; w.max_dist = m->max_dist.p;
+  w.desc = m->desc.p; w.bad = m->bad.p; w.skip = m->skip.p;
+  return w;
+}
+static TrackDev map_track(const orbm_map* m) {
+  TrackDev t;
+  t.in_view = m->t_in_view.p; t.px = m->t_px.p; t.py = m->t_py.p; t.pxr = m->t_pxr.p; t.depth = m->t_depth.p;
+  t.level = m->t_level.p; t.view_cos = m->t_vc.p;
+  return t;
+}
+
+extern "C" int orbm_is_in_frustum(orbm_frame* f, const float* Tcw, const orbm_worldpoints_view* pts, float limit,
+                                  uint8_t* track_in_view, float* proj_x, float* proj_y, float* proj_xr, float* track_depth,
+                                  int32_t* scale_level, float* view_cos) {
+  if (!f || !Tcw || !pts) return ORBG_BAD_ARG;
+  orbm_map* m = nullptr;
+  int rc = orbm_map_create(f->device, pts->m, &m);
+  if (rc) return rc;
+  // only the geometric fields are needed here
+  orbm_worldpoints_view p = *pts;
+  std::vector<int> zeros_i(std::max(pts->m, 1), 0);
+  std::vector<uint8_t> zeros_u((size_t)std::max(pts->m, 1) * 32, 0);
+  if (!p.n_obs) p.n_obs = zeros_i.data();
+  if (!p.bad) p.bad = zeros_u.data();
+  if (!p.desc) p.desc = zeros_u.data();
+  if ((rc = orbm_map_upload(m, &p))) { orbm_map_destroy(m); return rc; }
+  PoseF P;
+  make_pose(Tcw, &P);
+  const int n = pts->m;
+  if (n > 0) {
+    hipLaunchKernelGGL(frustum_kernel, dim3((n + 255) / 256), dim3(256), 0, f->stream, f->fp, P, map_dev(m), limit, map_track(m));
+    hipError_t e = hipStreamSynchronize(f->stream);
+    if (e != hipSuccess) { orbm_map_destroy(m); return ORBG_HIP_ERROR; }
+    (void)hipMemcpy(track_in_view, m->t_in_view.p, n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(proj_x, m->t_px.p, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(proj_y, m->t_py.p, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(proj_xr, m->t_pxr.p, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(track_depth, m->t_depth.p, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(scale_level, m->t_level.p, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(view_cos, m->t_vc.p, n * 4, hipMemcpyDeviceToHost);
+  }
+  orbm_map_destroy(m);
+  return ORBG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search drivers
+
+static FrameDev frame_dev(orbm_frame* f) {
+  FrameDev F;
+  F.kps = f->d_kps.p; F.desc = f->d_desc.p; F.uright = f->has_uright ? f->d_uright.p : nullptr;
+  F.cell_start = f->d_cell_start.p; F.cell_items = f->d_cell_items.p;
+  F.assigned_mp = f->d_assigned_mp.p; F.assigned_obs = f->d_assigned_obs.p;
+  return F;
+}
+
+static int upload_assigned(orbm_frame* f, const int32_t* amp, const int32_t* aob) {
+  const int n = f->fp.n;
+  if (n > 0) {
+    ORBG_HIP(hipMemcpyAsync(f->d_assigned_mp.p, amp, (size_t)n * 4, hipMemcpyHostToDevice, f->stream));
+    ORBG_HIP(hipMemcpyAsync(f->d_assigned_obs.p, aob, (size_t)n * 4, hipMemcpyHostToDevice, f->stream));
+  }
+  return ORBG_OK;
+}
+
+// Launches `launch(list_cap)` until the candidate list fits; leaves results + list in pinned memory.
+template <typename LaunchFn>
+static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
+  int rc;
+  if ((rc = f->results.reserve((size_t)std::max(n_queries, 1)))) return rc;
+  if (f->list.cap == 0 && (rc = f->list.reserve(1 << 18))) return rc;
+  for (int attempt = 0; attempt < 3; attempt++) {
+    ORBG_HIP(hipMemsetAsync(f->d_counter.p, 0, sizeof(int), f->stream));
+    ORBG_HIP(hipEventRecord(f->ev[0], f->stream));
+    launch((int)f->list.cap);
+    ORBG_HIP(hipGetLastError());
+    ORBG_HIP(hipEventRecord(f->ev[1], f->stream));
+    ORBG_HIP(hipMemcpyAsync(f->h_counter.h, f->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+    ORBG_HIP(hipStreamSynchronize(f->stream));
+    float ms;
+    if (hipEventElapsedTime(&ms, f->ev[0], f->ev[1]) == hipSuccess) f->last_ms = ms;
+    const int total = f->h_counter.h[0];
+    if ((size_t)total <= f->list.cap) return ORBG_OK;
+    if ((rc = f->list.reserve((size_t)total + total / 4))) return rc;
+  }
+  return ORBG_CAP_EXCEEDED;
+}
+
+// Serial commit of SearchByProjection(Frame, MapPoints): S/ORBmatcher.cc:85-141 replayed on the GPU results.
+static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio, int32_t* amp, int32_t* aob, int* nmatches_out) {
+  const int n = f->fp.n;
+  std::vector<uint8_t> claimed(std::max(n, 1), 0);   // features newly assigned in this call to an MP with Observations()>0
+  int nmatches = 0;
+  const QResult* R = f->results.h;
+  const uint32_t* list = f->list.h;
+  for (int i = 0; i < m; i++) {
+    const QResult& r = R[i];
+    if (r.count == 0 || r.best_idx < 0) continue;
+    int bestDist = r.best_dist, bestIdx = r.best_idx, bestDist2 = r.second_dist, idx2 = r.second_idx;
+    if (claimed[bestIdx] || (idx2 >= 0 && claimed[idx2])) {
+      // re-scan in the reference's order, skipping features claimed since the kernel ran
+      bestDist = 256; bestDist2 = 256; bestIdx = -1; idx2 = -1;
+      for (int k = 0; k < r.count; k++) {
+        const uint32_t e = list[r.base + k];
+        if (e == 0xFFFFFFFFu) continue;
+        const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
+        if (claimed[idx]) continue;
+        if (dist < bestDist) { bestDist2 = bestDist; idx2 = bestIdx; bestDist = dist; bestIdx = idx; }
+        else if (dist < bestDist2) { bestDist2 = dist; idx2 = idx; }
+      }
+      if (bestIdx < 0) continue;
+    }
+    const int bestLevel = f->h_kps[bestIdx].octave;
+    const int bestLevel2 = idx2 >= 0 ? f->h_kps[idx2].octave : -1;
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+        amp[bestIdx] = i;
+        aob[bestIdx] = n_obs[i];
+        if (n_obs[i] > 0) claimed[bestIdx] = 1;
+        nmatches++;
+      }
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
+static int ensure_q(orbm_frame* f, int m) {
+  int rc;
+  const size_t c = (size_t)std::max(m, 1);
+  for (int i = 0; i < 4; i++) if ((rc = f->d_q_u8[i].reserve(i == 2 ? c * 32 : c))) return rc;
+  for (int i = 0; i < 8; i++) if ((rc = f->d_q_f32[i].reserve(i == 7 ? 3 * c : c))) return rc;
+  for (int i = 0; i < 4; i++) if ((rc = f->d_q_i32[i].reserve(c))) return rc;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_search_by_projection_mps(orbm_frame* f, const orbm_mappoints_view* mps, float th, int far_points,
+                                             float th_far_points, float nnratio, int32_t* assigned_mp, int32_t* assigned_obs,
+                                             int* nmatches) {
+  if (!f || !mps || !assigned_mp || !assigned_obs || mps->m < 0) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int m = mps->m;
+  if (nmatches) *nmatches = 0;
+  if (m == 0) return ORBG_OK;
+  if ((rc = ensure_q(f, m))) return rc;
+  if ((rc = upload_assigned(f, assigned_mp, assigned_obs))) return rc;
+  hipStream_t st = f->stream;
+  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[0].p, mps->track_in_view, m, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[1].p, mps->bad, m, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[2].p, mps->desc, (size_t)m * 32, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[0].p, mps->proj_x, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[1].p, mps->proj_y, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[2].p, mps->proj_xr, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[3].p, mps->track_depth, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[4].p, mps->view_cos, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_i32[0].p, mps->scale_level, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  MpsDev mp;
+  mp.m = m; mp.in_view = f->d_q_u8[0].p; mp.bad = f->d_q_u8[1].p; mp.px = f->d_q_f32[0].p; mp.py = f->d_q_f32[1].p;
+  mp.pxr = f->d_q_f32[2].p; mp.depth = f->d_q_f32[3].p; mp.level = f->d_q_i32[0].p; mp.view_cos = f->d_q_f32[4].p;
+  mp.desc = f->d_q_u8[2].p;
+  rc = run_search(f, m, [&](int list_cap) {
+    hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), mp, th, far_points,
+                       th_far_points, f->d_counter.p, f->list.d, list_cap, f->results.d);
+  });
+  if (rc) return rc;
+  return commit_mps(f, m, mps->n_obs, nnratio, assigned_mp, assigned_obs, nmatches);
+}
+
+__global__ __launch_bounds__(256) void mask_track_kernel(uint8_t* in_view, const uint8_t* bad, const uint8_t* skip_map,
+                                                        const uint8_t* skip_call, int m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  if (bad[i] || skip_map[i] || (skip_call && skip_call[i])) in_view[i] = 0;
+}
+
+extern "C" int orbm_search_local_points(orbm_frame* f, orbm_map* mp, const float* Tcw, const uint8_t* skip, float th,
+                                        int far_points, float th_far_points, float nnratio, int32_t* assigned_mp,
+                                        int32_t* assigned_obs, int* nmatches) {
+  if (!f || !mp || !Tcw || !assigned_mp || !assigned_obs || f->device != mp->device) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int m = mp->m;
+  if (nmatches) *nmatches = 0;
+  if (m == 0) return ORBG_OK;
+  if ((rc = ensure_q(f, m))) return rc;
+  if ((rc = upload_assigned(f, assigned_mp, assigned_obs))) return rc;
+  hipStream_t st = f->stream;
+  PoseF P;
+  make_pose(Tcw, &P);
+  const uint8_t* d_skip_call = nullptr;
+  if (skip) {
+    ORBG_HIP(hipMemcpyAsync(f->d_q_u8[3].p, skip, m, hipMemcpyHostToDevice, st));
+    d_skip_call = f->d_q_u8[3].p;
+  }
+  hipLaunchKernelGGL(frustum_kernel, dim3((m + 255) / 256), dim3(256), 0, st, f->fp, P, map_dev(mp), 0.5f, map_track(mp));
+  hipLaunchKernelGGL(mask_track_kernel, dim3((m + 255) / 256), dim3(256), 0, st, mp->t_in_view.p, mp->bad.p, mp->skip.p, d_skip_call, m);
+  MpsDev q;
+  q.m = m; q.in_view = mp->t_in_view.p; q.bad = mp->bad.p; q.px = mp->t_px.p; q.py = mp->t_py.p; q.pxr = mp->t_pxr.p;
+  q.depth = mp->t_depth.p; q.level = mp->t_level.p; q.view_cos = mp->t_vc.p; q.desc = mp->desc.p;
+  rc = run_search(f, m, [&](int list_cap) {
+    hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), q, th, far_points,
+                       th_far_points, f->d_counter.p, f->list.d, list_cap, f->results.d);
+  });
+  if (rc) return rc;
+  return commit_mps(f, m, mp->n_obs.data(), nnratio, assigned_mp, assigned_obs, nmatches);
+}
+
+extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_cur, const orbm_lastframe_view* last, float th,
+                                               int mono, int check_orientation, int32_t* assigned_mp, int32_t* assigned_obs,
+                                               int* nmatches_out) {
+  if (!f || !Tcw_cur || !last || !assigned_mp || !assigned_obs || last->n < 0) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int m = last->n;
+  if (nmatches_out) *nmatches_out = 0;
+  if (m == 0) return ORBG_OK;
+  if ((rc = ensure_q(f, m))) return rc;
+  if ((rc = upload_assigned(f, assigned_mp, assigned_obs))) return rc;
+  hipStream_t st = f->stream;
+  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[0].p, last->mp_valid, m, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[1].p, last->outlier, m, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[2].p, last->desc, (size_t)m * 32, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[7].p, last->world_pos, (size_t)m * 12, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_i32[0].p, last->octave, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  PoseF Pc, Pl;
+  make_pose(Tcw_cur, &Pc);
+  make_pose(last->Tcw, &Pl);
+  // tlc = Rlw*twc + tlw (S/ORBmatcher.cc:1983-1991)
+  float tlc[3];
+  for (int i = 0; i < 3; i++) {
+    const float t0 = Pl.R[3 * i] * Pc.Ow[0] + Pl.R[3 * i + 1] * Pc.Ow[1] + Pl.R[3 * i + 2] * Pc.Ow[2];
+    tlc[i] = t0 + Pl.t[i];
+  }
+  const int forward = tlc[2] > f->fp.b && !mono;
+  const int backward = -tlc[2] > f->fp.b && !mono;
+  LastDev L;
+  L.n = m; L.mp_valid = f->d_q_u8[0].p; L.outlier = f->d_q_u8[1].p; L.world_pos = f->d_q_f32[7].p; L.desc = f->d_q_u8[2].p;
+  L.octave = f->d_q_i32[0].p;
+  rc = run_search(f, m, [&](int list_cap) {
+    hipLaunchKernelGGL(search_frame_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), L, Pc, th, forward, backward,
+                       f->d_counter.p, f->list.d, list_cap, f->results.d);
+  });
+  if (rc) return rc;
+  // serial commit (S/ORBmatcher.cc:2041-2091) + rotation consistency (:2164-2183)
+  const int n = f->fp.n;
+  std::vector<uint8_t> claimed(std::max(n, 1), 0);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  const QResult* R = f->results.h;
+  const uint32_t* list = f->list.h;
+  for (int i = 0; i < m; i++) {
+    const QResult& r = R[i];
+    if (r.count == 0 || r.best_idx < 0) continue;
+    int bestDist = r.best_dist, bestIdx = r.best_idx;
+    if (claimed[bestIdx]) {
+      bestDist = 256; bestIdx = -1;
+      for (int k = 0; k < r.count; k++) {
+        const uint32_t e = list[r.base + k];
+        if (e == 0xFFFFFFFFu) continue;
+        const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
+        if (claimed[idx]) continue;
+        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+      }
+      if (bestIdx < 0) continue;
+    }
+    if (bestDist <= TH_HIGH) {
+      assigned_mp[bestIdx] = i;
+      assigned_obs[bestIdx] = last->n_obs[i];
+      if (last->n_obs[i] > 0) claimed[bestIdx] = 1;
+      nmatches++;
+      if (check_orientation) rotHist[rot_bin(last->angle[i], f->h_kps[bestIdx].angle)].push_back(bestIdx);
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) { assigned_mp[idx] = -1; assigned_obs[idx] = 0; nmatches--; }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t* kf_desc, int nkf,
+                                  const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fvK, float nnratio,
+                                  int check_orientation, int32_t* matches, int* nmatches_out) {
+  if (!f || !fvF || !fvK || !kf_desc || !kf_mp_valid || !kf_angle || !matches || nkf < 0) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int n = f->fp.n;
+  for (int i = 0; i < n; i++) matches[i] = -1;
+  if (nmatches_out) *nmatches_out = 0;
+  // merge-join of the two sorted feature vectors (S/ORBmatcher.cc:290-448) -> one job per valid KF feature
+  std::vector<BowJob> jobs;
+  {
+    int k = 0, ff = 0;
+    while (k < fvK->n_nodes && ff < fvF->n_nodes) {
+      if (fvK->node_id[k] == fvF->node_id[ff]) {
+        for (uint32_t a = fvK->start[k]; a < fvK->start[k + 1]; a++) {
+          const uint32_t kfi = fvK->feat_idx[a];
+          if ((int)kfi >= nkf) return ORBG_BAD_ARG;
+          if (!kf_mp_valid[kfi]) continue;
+          jobs.push_back(BowJob{(int)kfi, (int)fvF->start[ff], (int)fvF->start[ff + 1]});
+        }
+        k++; ff++;
+      } else if (fvK->node_id[k] < fvF->node_id[ff]) {
+        k = (int)(std::lower_bound(fvK->node_id, fvK->node_id + fvK->n_nodes, fvF->node_id[ff]) - fvK->node_id);
+      } else {
+        ff = (int)(std::lower_bound(fvF->node_id, fvF->node_id + fvF->n_nodes, fvK->node_id[k]) - fvF->node_id);
+      }
+    }
+  }
+  const int nj = (int)jobs.size();
+  if (nj == 0) return ORBG_OK;
+  const int nfi = (int)fvF->start[fvF->n_nodes];
+  if ((rc = f->d_jobs.reserve(nj)) || (rc = f->d_fidx.reserve(std::max(nfi, 1))) || (rc = ensure_q(f, nkf))) return rc;
+  hipStream_t st = f->stream;
+  ORBG_HIP(hipMemcpyAsync(f->d_jobs.p, jobs.data(), (size_t)nj * sizeof(BowJob), hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_fidx.p, fvF->feat_idx, (size_t)nfi * 4, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[2].p, kf_desc, (size_t)nkf * 32, hipMemcpyHostToDevice, st));
+  rc = run_search(f, nj, [&](int list_cap) {
+    hipLaunchKernelGGL(search_bow_kernel, dim3((nj + 3) / 4), dim3(256), 0, st, f->d_desc.p, f->d_fidx.p, f->d_q_u8[2].p,
+                       f->d_jobs.p, nj, f->d_counter.p, f->list.d, list_cap, f->results.d);
+  });
+  if (rc) return rc;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  const QResult* R = f->results.h;
+  const uint32_t* list = f->list.h;
+  for (int j = 0; j < nj; j++) {
+    const QResult& r = R[j];
+    if (r.best_idx < 0) continue;
+    int bestDist1 = r.best_dist, bestIdxF = r.best_idx, bestDist2 = r.second_dist;
+    const bool dirty = matches[bestIdxF] >= 0 || (r.second_idx >= 0 && matches[r.second_idx] >= 0);
+    if (dirty) {
+      bestDist1 = 256; bestDist2 = 256; bestIdxF = -1;
+      for (int k = 0; k < r.count; k++) {
+        const uint32_t e = list[r.base + k];
+        const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
+        if (matches[idx] >= 0) continue;                       // :324-325
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = idx; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+      if (bestIdxF < 0) continue;
+    }
+    if (bestDist1 <= TH_LOW) {
+      if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+        matches[bestIdxF] = jobs[j].kf_idx;
+        if (check_orientation) rotHist[rot_bin(kf_angle[jobs[j].kf_idx], f->h_kps[bestIdxF].angle)].push_back(bestIdxF);
+        nmatches++;
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { matches[idx] = -1; nmatches--; }
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}

@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: the HIP library loads, exports every symbol include/orbgpu.h declares,
+and fails loudly (ORBG_NO_DEVICE) instead of falling back when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from multi_orbslam3_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    hdr = open(os.path.join(ROOT, "include", "orbgpu.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+((?:orbx|orbm|lba|orbg)_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.orbg_version()
+    assert lib.orbg_strerror(capi.ORBG_NO_DEVICE).startswith(b"no usable HIP device")
+
+
+def test_struct_layouts_match_header():
+    assert capi.KEYPOINT_DTYPE.itemsize == 24 and capi.EDGE_DTYPE.itemsize == 24
+    assert C.sizeof(capi.OrbxConfig) == 36
+    assert C.sizeof(capi.LbaProblem) % 8 == 0 and capi.LbaProblem.lambda_init.offset % 8 == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    lib = capi.load()
+    if lib.orbg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg = capi.OrbxConfig(1000, 1.2, 8, 20, 7, 640, 480, 1, 0)
+    h = C.c_void_p()
+    assert lib.orbx_create(C.byref(cfg), C.byref(h)) == capi.ORBG_NO_DEVICE
+    f = C.c_void_p()
+    assert lib.orbm_frame_create(0, 100, C.byref(f)) == capi.ORBG_NO_DEVICE
+    q = np.zeros((1, 32), np.uint8); d = np.zeros((1, 1), np.int32)
+    assert lib.orbm_hamming_matrix(0, C.c_void_p(q.ctypes.data), 1, C.c_void_p(q.ctypes.data), 1, C.c_void_p(d.ctypes.data)) == capi.ORBG_NO_DEVICE
+    from multi_orbslam3_amd import api
+    with pytest.raises(capi.OrbGpuError):
+        api.ORBextractor()
+
+
+def test_product_never_references_the_oracle():
+    """The product package and C sources must not import / include anything under oracle/."""
+    pkg = os.path.join(ROOT, "multi_orbslam3_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h", ".sh")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+                assert not re.search(r'#include\s+"[^"]*oracle/', txt), fn

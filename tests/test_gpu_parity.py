@@ -1,0 +1,223 @@
+"""GPU parity tests: the HIP path (through the C-ABI of liborbgpu.so) against the CPU oracle on the same seeded
+inputs.  Bit-exact for pyramid bytes, FAST candidates, keypoints, angles, descriptors, Hamming distances, stereo
+matches and matcher outputs; <= 1e-4 for LBA poses / points after float32 write-back (tolerance from
+BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from multi_orbslam3_amd import _capi as capi
+from multi_orbslam3_amd import api, synth, views
+from oracle import binding as ob
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_extract_equal(g, o, what):
+    gk, gd = g
+    ok, od = o
+    assert len(gk) == len(ok), "%s: count %d vs %d" % (what, len(gk), len(ok))
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(gk[f], ok[f]), "%s: field %s differs" % (what, f)
+    assert np.array_equal(gd, od), "%s: descriptors differ" % what
+
+
+@pytest.mark.parametrize("k", [0, 7])
+def test_extractor_mono_bit_exact(scene, k):
+    L, R, _ = scene.stereo_pair(k)
+    ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=1)
+    oe = ob.Extractor(n_features=1000)
+    nm, kps, desc = ex(L, (0, 0))
+    rc, okps, odesc, onm = oe.extract(L)
+    for l in range(8):
+        assert np.array_equal(ex.level(0, l), oe.level(l)), "pyramid level %d" % l
+        assert np.array_equal(ex.candidates(0, l), oe.candidates(l)), "FAST candidates level %d" % l
+    _assert_extract_equal((kps, desc), (okps, odesc), "mono")
+    assert nm == onm == len(kps)
+    # mono Frame ctor path: lapping {0,1000} reverses the order (S/Frame.cc:289)
+    nm2, k2, d2 = ex(L, (0, 1000))
+    rc, ok2, od2, onm2 = oe.extract(L, lap=(0, 1000))
+    assert nm2 == onm2 == 0
+    _assert_extract_equal((k2, d2), (ok2, od2), "mono-lapping")
+
+
+def test_extractor_empty_image():
+    ex = api.ORBextractor(100, 1.2, 8, 20, 7, 320, 240)
+    nm, kps, desc = ex(None)
+    assert nm == -1 and len(kps) == 0
+
+
+def test_extractor_stereo_batched_and_size_change(scene, small_scene):
+    ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
+    for sc, nf in ((scene, 1000), (small_scene, 1000), (scene, 1000)):
+        L, R, _ = sc.stereo_pair(3)
+        (kl, dl), (kr, dr) = ex.extract_stereo(L, R)
+        ol = ob.Extractor(n_features=nf, max_width=sc.W, max_height=sc.H)
+        orr = ob.Extractor(n_features=nf, max_width=sc.W, max_height=sc.H)
+        rc, okl, odl, _ = ol.extract(L)
+        rc, okr, odr, _ = orr.extract(R)
+        _assert_extract_equal((kl, dl), (okl, odl), "left %dx%d" % (sc.W, sc.H))
+        _assert_extract_equal((kr, dr), (okr, odr), "right %dx%d" % (sc.W, sc.H))
+        for l in (0, 4, 7):
+            assert np.array_equal(ex.level(1, l), orr.level(l))
+
+
+def test_extractor_low_texture_uses_min_threshold():
+    """Cells without a single iniTh corner fall back to minTh (S/ORBextractor.cc:825-829)."""
+    rng = np.random.RandomState(5)
+    img = (120 + rng.randint(-6, 7, (240, 320))).astype(np.uint8)       # weak texture: only minTh corners
+    img[60:180, 80:240] = (100 + rng.randint(0, 120, (120, 160))).astype(np.uint8)
+    ex = api.ORBextractor(500, 1.2, 8, 20, 7, 320, 240)
+    oe = ob.Extractor(n_features=500, max_width=320, max_height=240)
+    nm, kps, desc = ex(img)
+    rc, okps, odesc, _ = oe.extract(img)
+    for l in range(8):
+        assert np.array_equal(ex.candidates(0, l), oe.candidates(l)), "level %d" % l
+    _assert_extract_equal((kps, desc), (okps, odesc), "low-texture")
+    assert (okps["response"] < 20).any() and (okps["response"] >= 20).any()
+
+
+def test_stereo_match_bit_exact(scene):
+    fr = helpers.oracle_stereo_frame(scene, 2)
+    ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
+    (kl, dl), (kr, dr) = ex.extract_stereo(fr["L"], fr["R"])
+    assert np.array_equal(kl, fr["kps"]) and np.array_equal(dr, fr["desc_r"])
+    ur, dp = ex.ComputeStereoMatches(float(scene.cam["bf"]), float(scene.cam["b"]), n_left=len(kl))
+    assert (fr["uright"] > 0).sum() > 200
+    assert np.array_equal(ur.view(np.uint32), fr["uright"].view(np.uint32))
+    assert np.array_equal(dp.view(np.uint32), fr["depth"].view(np.uint32))
+
+
+def test_hamming_kernels():
+    rng = np.random.RandomState(1)
+    q = rng.randint(0, 256, (301, 32)).astype(np.uint8)
+    t = np.repeat(rng.randint(0, 256, (257, 32)).astype(np.uint8), 2, axis=0)[rng.permutation(514)]
+    m = api.ORBmatcher()
+    assert np.array_equal(m.DescriptorDistance(q, t), ob.hamming_matrix(q, t))
+    assert np.array_equal(m.best2(q, t), ob.hamming_best2(q, t))
+    z = np.zeros((1, 32), np.uint8); o = np.full((1, 32), 255, np.uint8)
+    assert m.DescriptorDistance(z, o)[0, 0] == 256 and m.DescriptorDistance(z, z)[0, 0] == 0
+    assert m.best2(q[:3], t[:1])[0, 3] == -1 and m.best2(q[:3], t[:1])[0, 2] == 256   # ragged: one candidate only
+
+
+def test_grid_and_frustum(scene):
+    fr = helpers.oracle_stereo_frame(scene, 1)
+    fv, keep = helpers.frame_view_of(scene, fr)
+    F = api.Frame().upload(fv, keep)
+    gs, gi = F.grid()
+    os_, oi = ob.build_grid(fv)
+    assert np.array_equal(gs, os_) and np.array_equal(gi, oi)
+    mp = helpers.local_map_from(scene, [fr, helpers.oracle_stereo_frame(scene, 6)], np.random.RandomState(3))
+    wv, keep2 = helpers.world_view_of(mp)
+    T = synth.perturb_pose(scene.pose(3), np.random.RandomState(4)).astype(np.float32)
+    g = F.isInFrustum(T, wv)
+    o = ob.is_in_frustum(fv, T, wv)
+    assert o["track_in_view"].sum() > 100
+    for k in o:
+        a, b = g[k], o[k]
+        if a.dtype == np.float32:
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+        else:
+            assert np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("th", [1.0, 3.0, 15.0])
+def test_search_by_projection_map(scene, th):
+    rng = np.random.RandomState(11)
+    f0, f1, f2 = [helpers.oracle_stereo_frame(scene, k) for k in (0, 4, 8)]
+    cur = helpers.oracle_stereo_frame(scene, 5)
+    mp = helpers.local_map_from(scene, [f0, f1, f2], rng)
+    fv, keep = helpers.frame_view_of(scene, cur)
+    wv, keep2 = helpers.world_view_of(mp)
+    T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+    n = len(cur["kps"])
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    pre = rng.rand(n) < 0.1                   # some features already matched by the motion model
+    amp0[pre] = 7; aob0[pre] = rng.randint(0, 3, pre.sum())
+    # (a) pre-projected view: exactly SearchByProjection(F, vpMapPoints, th, bFar, thFar)
+    tr = ob.is_in_frustum(fv, T, wv)
+    mv, keep3 = views.mappoints_view(tr["track_in_view"], mp["bad"], tr["proj_x"], tr["proj_y"], tr["proj_xr"], tr["track_depth"],
+                                     tr["scale_level"], tr["view_cos"], mp["desc"], mp["n_obs"])
+    F = api.Frame().upload(fv, keep)
+    m = api.ORBmatcher(0.8)
+    g = m.SearchByProjection(F, mv, th, True, 4.0, amp0, aob0)
+    o = ob.search_by_projection_mps(fv, mv, th, True, 4.0, 0.8, amp0, aob0)
+    assert o[2] > 50
+    assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    # (b) fused isInFrustum + search with the map resident on the device
+    skip = (rng.rand(len(mp["pos"])) < 0.05).astype(np.uint8)
+    LM = api.LocalMap().upload(wv)
+    g2 = m.SearchLocalPoints(F, LM, T, th, False, 0.0, amp0, aob0, skip)
+    wv2, keep4 = helpers.world_view_of(mp, skip)
+    o2 = ob.search_local_points(fv, wv2, T, th, False, 0.0, 0.8, amp0, aob0)
+    assert g2[2] == o2[2] and np.array_equal(g2[0], o2[0]) and np.array_equal(g2[1], o2[1])
+
+
+@pytest.mark.parametrize("th,mono", [(7.0, False), (15.0, True), (14.0, False)])
+def test_search_by_projection_frame(scene, th, mono):
+    rng = np.random.RandomState(13)
+    last = helpers.oracle_stereo_frame(scene, 10)
+    cur = helpers.oracle_stereo_frame(scene, 11)
+    fv, keep = helpers.frame_view_of(scene, cur, with_stereo=not mono)
+    lv, keep2 = helpers.make_lastframe(scene, last, rng)
+    T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+    n = len(cur["kps"])
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    F = api.Frame().upload(fv, keep)
+    m = api.ORBmatcher(0.9, True)
+    g = m.SearchByProjectionFrame(F, T, lv, th, mono, amp0, aob0)
+    o = ob.search_by_projection_frame(fv, T, lv, th, mono, True, amp0, aob0)
+    assert o[2] > 100
+    assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+
+
+def test_search_by_bow(scene):
+    kf = helpers.oracle_stereo_frame(scene, 20)
+    cur = helpers.oracle_stereo_frame(scene, 21)
+    fv, keep = helpers.frame_view_of(scene, cur)
+    # stand-in vocabulary (ORBvoc.txt is absent from the reference tree): node id = first 5 descriptor bits + octave/4
+    node = lambda d, k: (d[:, 0].astype(np.int64) >> 3) * 2 + (k["octave"] // 4)
+    fvF, kF = views.featvec_view(*views.featvec_from_nodes(node(cur["desc"], cur["kps"])))
+    fvK, kK = views.featvec_view(*views.featvec_from_nodes(node(kf["desc"], kf["kps"])))
+    valid = (kf["depth"] > 0).astype(np.uint8)
+    F = api.Frame().upload(fv, keep)
+    m = api.ORBmatcher(0.7, True)
+    g = m.SearchByBoW(F, fvF, kf["desc"], valid, kf["kps"]["angle"], fvK)
+    o = ob.search_by_bow(fv, fvF, kf["desc"], valid, kf["kps"]["angle"], fvK, 0.7, True)
+    assert o[1] > 20
+    assert g[1] == o[1] and np.array_equal(g[0], o[0])
+
+
+@pytest.mark.parametrize("shape", [(4, 2, 60), (20, 10, 2000)])
+def test_lba_parity(shape):
+    nf, nx, npts = shape
+    prob = synth.make_lba_problem(n_free=nf, n_fixed=nx, n_points=npts, mono_frac=0.1)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    g = api.Optimizer().LocalBundleAdjustment(p)
+    o = ob.lba_solve(p)
+    assert g.status == o.status == capi.LBA_APPLIED
+    assert g.iters == o.iters
+    assert np.abs(g.poses - o.poses).max() <= 1e-4          # tolerance stated by north_star
+    assert np.abs(g.points - o.points).max() <= 1e-4
+    assert np.array_equal(g.edge_outlier, o.edge_outlier)
+    assert np.array_equal(g.edge_depth_pos, o.edge_depth_pos)
+    tg, to = g.trace_rows(), o.trace_rows()
+    assert tg.shape == to.shape
+    assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9) and np.array_equal(tg[:, 2], to[:, 2])
+    assert g.chi2[1] < g.chi2[0]
+    # bit-reproducible run to run (fixed-order reductions)
+    g2 = api.Optimizer().LocalBundleAdjustment(p)
+    assert np.array_equal(g.poses, g2.poses) and np.array_equal(g.points, g2.points)
+
+
+def test_lba_stop_flag_and_outlier_rejection():
+    prob = synth.make_lba_problem(n_free=4, n_fixed=2, n_points=80)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    stop = np.ones(1, np.int32)
+    g = api.Optimizer().LocalBundleAdjustment(p, stop)
+    assert g.status == capi.LBA_ABORTED_BEFORE_OPT and np.array_equal(g.poses, prob["poses"])
+    bad = synth.make_lba_problem(n_free=4, n_fixed=2, n_points=80, outlier_frac=0.9)
+    p2, keep2 = views.lba_problem(bad["poses"], bad["pose_fixed"], bad["points"], bad["edges"], bad["cam"])
+    g2 = api.Optimizer().LocalBundleAdjustment(p2)
+    o2 = ob.lba_solve(p2)
+    assert g2.status == o2.status
