@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric):
+"tracking+localBA frames/sec per agent, 640x480 stereo, 1/2/4/8 agents".
+
+One STEP = one stereo frame of one agent through the hot path, inputs already resident in HBM:
+  extract L+R (pyramid, FAST, quad-tree, angle, rBRIEF)  ->  ComputeStereoMatches  ->  feature grid
+  ->  SearchByProjection(cur, last)  ->  SearchLocalPoints (isInFrustum + SearchByProjection over the local map)
+and, every FRAMES_PER_KF-th step (a keyframe), one Local Bundle Adjustment (20 free + 10 fixed KFs, 2000 points)
+plus the upload of the refreshed local map.  fps = steps / time, i.e. 1 / (t_frontend + t_LBA / FRAMES_PER_KF).
+
+Agents shard one per GPU with no data-path collective -> weak scaling; `value` is the
+aggregate over all ranks.  Launch for N>1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES_PER_KF = 5
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak is ~6300 GB/s
+# algorithmic bytes of the FAST kernel per launch: every pyramid pixel of both cameras read once
+PYR_PIXELS_640x480 = 950532
+
+
+def build_workload(scene, n_frames, api, views, synth, device):
+    """Run the pipeline once per distinct frame to cache the host-side views a Tracking thread would hold
+    (last-frame view, local-map chunks, pose guesses).  Not timed."""
+    import torch
+    from multi_orbslam3_amd import _capi as capi
+    cam = scene.cam
+    W, H = scene.W, scene.H
+    ex = api.ORBextractor(1000, 1.2, 8, 20, 7, W, H, n_cams=2, device=device)
+    rng = np.random.RandomState(1234)
+    frames = []
+    imgs = []
+    for k in range(n_frames):
+        L, R, Tcw = scene.stereo_pair(k)
+        dL = torch.from_numpy(L).to("cuda:%d" % device)
+        dR = torch.from_numpy(R).to("cuda:%d" % device)
+        imgs.append((dL, dR))
+        nl, nr, kl, dl = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W, download_left=True)
+        ur, dp = ex.ComputeStereoMatches(float(cam["bf"]), float(cam["b"]), n_left=nl)
+        kl, dl, ur, dp = kl.copy(), dl.copy(), ur.copy(), dp.copy()
+        Pw, valid = synth.unproject_to_world(kl, dp, Tcw, cam)
+        lv, keep = views.lastframe_view(valid.astype(np.uint8), np.zeros(nl, np.uint8), Pw, dl, kl["octave"], kl["angle"],
+                                        np.full(nl, 3, np.int32), Tcw.astype(np.float32))
+        chunk = synth.map_from_frame(kl, dl, dp, Tcw, cam)
+        frames.append(dict(Tcw=Tcw, guess=synth.perturb_pose(Tcw, rng).astype(np.float32), last_view=(lv, keep), chunk=chunk,
+                           n=nl, stereo=int((ur > 0).sum())))
+    return ex, imgs, frames
+
+
+def local_map_for(frames, k, n_kf=6):
+    """Union of the map points created by the last n_kf keyframes before frame k (keyframe = every FRAMES_PER_KF-th)."""
+    ids = [((k // FRAMES_PER_KF) - j) * FRAMES_PER_KF for j in range(1, n_kf + 1)]
+    ids = [i % len(frames) for i in ids]
+    parts = [frames[i]["chunk"] for i in ids]
+    return {key: np.concatenate([p[key] for p in parts]) for key in parts[0]}
+
+
+def cpu_baseline(scene, synth, views, n_frames=12, n_lba=3):
+    """The CPU oracle (a restatement of the reference path, 1 thread) on a bounded sample of the same workload."""
+    from oracle import binding as ob
+    cam = scene.cam
+    exL = ob.Extractor(n_features=1000, max_width=scene.W, max_height=scene.H)
+    exR = ob.Extractor(n_features=1000, max_width=scene.W, max_height=scene.H)
+    p = scene.frame_view_params()
+    rng = np.random.RandomState(1234)
+    last = None
+    chunks = []
+    t_front = 0.0
+    done = 0
+    for k in range(n_frames + 2):
+        L, R, Tcw = scene.stereo_pair(k)
+        t0 = time.perf_counter()
+        rc, kl, dl, _ = exL.extract(L)
+        rc, kr, dr, _ = exR.extract(R)
+        ur, dp = ob.stereo_match(exL, exR, kl, dl, kr, dr, float(cam["bf"]), float(cam["b"]))
+        fv, keep = views.frame_view(kl, dl, ur, dp, p["bounds"], p["cam"], 8, 1.2)
+        n = len(kl)
+        amp = np.full(n, -1, np.int32); aob = np.zeros(n, np.int32)
+        guess = synth.perturb_pose(Tcw, rng).astype(np.float32)
+        if last is not None and len(chunks) >= 2:
+            amp, aob, nm1 = ob.search_by_projection_frame(fv, guess, last[0], 7.0, False, True, amp, aob)
+            mp = {key: np.concatenate([c[key] for c in chunks[-6:]]) for key in chunks[0]}
+            wv, keep2 = views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
+            amp, aob, nm2 = ob.search_local_points(fv, wv, guess, 1.0, False, 0.0, 0.8, amp, aob)
+            t_front += time.perf_counter() - t0
+            done += 1
+        Pw, valid = synth.unproject_to_world(kl, dp, Tcw, cam)
+        last = views.lastframe_view(valid.astype(np.uint8), np.zeros(n, np.uint8), Pw, dl, kl["octave"], kl["angle"],
+                                    np.full(n, 3, np.int32), Tcw.astype(np.float32))
+        chunks.append(synth.map_from_frame(kl, dl, dp, Tcw, cam))
+    prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000)
+    lp, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    t0 = time.perf_counter()
+    for _ in range(n_lba):
+        ob.lba_solve(lp)
+    t_lba = (time.perf_counter() - t0) / n_lba
+    t_f = t_front / max(done, 1)
+    fps = 1.0 / (t_f + t_lba / FRAMES_PER_KF)
+    return dict(value=round(fps, 3), unit="frames/s", cores=1, kind="port",
+                sample="%d stereo frames front-end (%.1f ms/frame) + %d LBA calls (%.1f ms/call), 1 thread; "
+                       "the reference would use 2 threads for L/R extraction" % (done, 1e3 * t_f, n_lba, 1e3 * t_lba))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=16, help="distinct synthetic stereo frames (ping-pong sequence)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from multi_orbslam3_amd import _capi as capi
+    from multi_orbslam3_amd import api, synth, views
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    device = local_rank
+    torch.cuda.set_device(device)
+
+    W, H = 640, 480
+    scene = synth.Scene(W, H, seed=synth.SEED_IMAGES + rank)      # one agent per GPU, distinct seeds
+    cam = scene.cam
+    ex, imgs, frames = build_workload(scene, args.frames, api, views, synth, device)
+    p = scene.frame_view_params()
+    fv, fv_keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
+    F = api.Frame(4096, device)
+    LM = api.LocalMap(16384, device)
+    m_frame = api.ORBmatcher(0.9, True, device)
+    m_map = api.ORBmatcher(0.8, True, device)
+    opt = api.Optimizer(device)
+    prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000, seed=synth.SEED_LBA + rank)
+    lp, lp_keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"], device=device)
+    nF = len(frames)
+    seq = list(range(nF)) + list(range(nF - 2, 0, -1))             # ping-pong: consecutive frames stay adjacent
+    stage = dict(extract=0.0, stereo=0.0, grid=0.0, match_frame=0.0, match_map=0.0, lba=0.0, map_upload=0.0)
+    kern = dict(pyramid_ms=0.0, fast_kernel_ms=0.0, fast_ms=0.0, desc_ms=0.0, stereo_ms=0.0, octree_host_ms=0.0)
+    stats = dict(kp=0, stereo=0, m_frame=0, m_map=0, lba_iters=0, lba_calls=0)
+
+    def step(i, timed):
+        k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
+        fr = frames[k]
+        dL, dR = imgs[k]
+        t0 = time.perf_counter()
+        nl, nr = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W)[:2]
+        t1 = time.perf_counter()
+        ex.ComputeStereoMatches(float(cam["bf"]), float(cam["b"]), download=False)
+        t2 = time.perf_counter()
+        F.from_extractor(ex, fv, nl)
+        t3 = time.perf_counter()
+        amp = np.full(nl, -1, np.int32); aob = np.zeros(nl, np.int32)
+        amp, aob, n1 = m_frame.SearchByProjectionFrame(F, fr["guess"], frames[k_last]["last_view"][0], 7.0, False, amp, aob)
+        t4 = time.perf_counter()
+        amp, aob, n2 = m_map.SearchLocalPoints(F, LM, fr["guess"], 1.0, False, 0.0, amp, aob, None)
+        t5 = time.perf_counter()
+        t6 = t7 = t5
+        if i % FRAMES_PER_KF == 0:
+            mp = local_map_for(frames, k)
+            wv, keep = views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
+            LM.upload(wv)
+            t6 = time.perf_counter()
+            out = opt.LocalBundleAdjustment(lp)
+            t7 = time.perf_counter()
+            if timed:
+                stats["lba_iters"] += sum(out.iters); stats["lba_calls"] += 1
+        if timed:
+            for key, dt in (("extract", t1 - t0), ("stereo", t2 - t1), ("grid", t3 - t2), ("match_frame", t4 - t3),
+                            ("match_map", t5 - t4), ("map_upload", t6 - t5), ("lba", t7 - t6)):
+                stage[key] += dt
+            tm = ex.timings()
+            for key in kern:
+                kern[key] += tm[key]
+            stats["kp"] += nl + nr; stats["m_frame"] += n1; stats["m_map"] += n2
+
+    # local map must exist before the first frame
+    mp0 = local_map_for(frames, 0)
+    wv0, keep0 = views.worldpoints_view(mp0["pos"], mp0["normal"], mp0["min_dist"], mp0["max_dist"], mp0["desc"], mp0["n_obs"], mp0["bad"])
+    LM.upload(wv0)
+    for i in range(args.warmup):
+        step(i, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        K = args.steps
+        ms_per_step = 1e3 * elapsed / K
+        fast_ms = kern["fast_kernel_ms"] / K
+        fast_bytes = 2 * PYR_PIXELS_640x480 + (stats["kp"] / K) * 4.0     # both cameras' pyramid pixels + packed candidates
+        achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
+        line = {
+            "metric": "tracking+localBA frames/sec (aggregate over agents; 1 agent per GPU)",
+            "value": round(world * K / elapsed, 3),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32 (ORB front-end, Hamming), f64 (local BA)",
+            "data": "synthetic",
+            "config": {"workload": "C2: 1 client stereo 640x480 synthetic, 1000 ORB feat/frame, 20-KF local BA window "
+                                   "(20 free + 10 fixed KFs, 2000 points), 1 LBA per %d frames" % FRAMES_PER_KF,
+                       "per_agent_fps": round(K / elapsed, 3), "frames_per_keyframe": FRAMES_PER_KF,
+                       "stage_ms_per_frame": {k2: round(1e3 * v / K, 4) for k2, v in stage.items()},
+                       "device_ms_per_frame": {k2: round(v / K, 4) for k2, v in kern.items()},
+                       "avg_keypoints_per_stereo_frame": round(stats["kp"] / K, 1),
+                       "avg_matches_frame": round(stats["m_frame"] / K, 1), "avg_matches_map": round(stats["m_map"] / K, 1),
+                       "lba_ms_per_call": round(1e3 * stage["lba"] / max(stats["lba_calls"], 1), 3),
+                       "lba_lm_iterations_per_call": round(stats["lba_iters"] / max(stats["lba_calls"], 1), 2)},
+            "roofline": {"kernel": "fast_cells_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(fast_bytes), "avg_launch_ms": round(fast_ms, 5),
+                         "note": "per-frame work is a few MB: the path is launch/latency bound, not bandwidth bound (SURVEY.md 0-10)"},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene, synth, views)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,12 +88,21 @@ class ORBextractor:
             return nl.value, nr.value
         return (kl[: nl.value].copy(), dl[: nl.value].copy()), (kr[: nr.value].copy(), dr[: nr.value].copy())
 
-    def extract_stereo_dev(self, d_left, d_right, width, height, stride):
-        """Images already in HBM (raw device pointers, e.g. torch tensor .data_ptr()); results stay on the device."""
+    def extract_stereo_dev(self, d_left, d_right, width, height, stride, download_left=False):
+        """Images already in HBM (raw device pointers, e.g. torch tensor .data_ptr()).  Right-camera features always
+        stay on the device; the left ones are also copied to the host when download_left is set."""
         nl, nr = C.c_int(0), C.c_int(0)
+        kl = dl = None
+        if download_left:
+            if not hasattr(self, "_kl"):
+                self._kl = np.zeros(self.cap, capi.KEYPOINT_DTYPE)
+                self._dl = np.zeros((self.cap, 32), np.uint8)
+            kl, dl = self._kl, self._dl
         rc = self.lib.orbx_extract_stereo_dev(self.h, C.c_void_p(d_left), C.c_void_p(d_right), width, height, stride,
-                                              None, None, 0, C.byref(nl), None, None, 0, C.byref(nr))
+                                              _vp(kl), _vp(dl), self.cap, C.byref(nl), None, None, 0, C.byref(nr))
         capi.check(rc, "orbx_extract_stereo_dev")
+        if download_left:
+            return nl.value, nr.value, kl[: nl.value], dl[: nl.value]
         return nl.value, nr.value
 
     def level(self, cam, level):
@@ -126,7 +135,7 @@ class ORBextractor:
         t = np.zeros(8, np.float32)
         capi.check(self.lib.orbx_get_timings(self.h, _vp(t)))
         return dict(pyramid_ms=float(t[0]), fast_ms=float(t[1]), octree_host_ms=float(t[2]), desc_ms=float(t[3]),
-                    stereo_ms=float(t[4]))
+                    stereo_ms=float(t[4]), fast_kernel_ms=float(t[5]))
 
 
 class Frame:
@@ -156,8 +165,11 @@ class Frame:
         self.n = fv.n
         return self
 
-    def from_extractor(self, extractor, fv):
+    def from_extractor(self, extractor, fv, n_left):
+        """Features, uRight and depth are taken device-to-device from the extractor's left camera."""
+        fv.n = int(n_left)
         capi.check(self.lib.orbm_frame_from_extractor(self.h, extractor.h, C.byref(fv)), "orbm_frame_from_extractor")
+        self.n = int(n_left)
         return self
 
     def grid(self):

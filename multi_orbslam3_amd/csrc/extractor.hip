@@ -699,7 +699,7 @@ struct orbx_handle {
   orbx_config cfg;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[8] = {};
+  hipEvent_t ev[12] = {};
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> feats_per_level;
   UMax umax;
@@ -942,6 +942,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   if (n_cells > 0) {
     hipLaunchKernelGGL(fast_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
                        std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
+    ORBG_HIP(hipEventRecord(h->ev[7], st));
     hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
                        h->d_cells.p, n_cells, ncams, h->hdr.d, h->cand.d, h->cand_cap);
   }
@@ -1031,6 +1032,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->timings[1] = ms;   // FAST + gather
   h->timings[2] = std::chrono::duration<float, std::milli>(t_host1 - t_host0).count();  // host quad-tree
   if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->timings[3] = ms;   // orientation + descriptors
+  if (n_cells > 0 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) h->timings[5] = ms;   // fast_cells_kernel alone
   return ORBG_OK;
 }
 
