@@ -25,8 +25,14 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 using namespace orbg;
 
@@ -502,27 +508,36 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
 }
 
 // median-of-SAD outlier rejection (:949-962): one workgroup; rank counting gives the element
-// vDistIdx[size/2].first of the sorted list without sorting.
+// vDistIdx[size/2].first of the sorted list without sorting (SAD values staged in LDS, 128-bit broadcast reads).
 __global__ __launch_bounds__(1024) void stereo_finalize_kernel(float* __restrict__ uright, float* __restrict__ depth,
                                                               const int* __restrict__ best_sad, int nl) {
+  constexpr int kCap = 8192;
+  __shared__ int4 s_sad4[kCap / 4];
   __shared__ int s_cnt, s_median;
+  int* s_sad = reinterpret_cast<int*>(s_sad4);
   if (threadIdx.x == 0) { s_cnt = 0; s_median = -1; }
   __syncthreads();
+  const int npad = min((nl + 3) & ~3, kCap);
   int local = 0;
-  for (int i = threadIdx.x; i < nl; i += 1024) local += best_sad[i] >= 0;
+  for (int i = threadIdx.x; i < npad; i += 1024) {
+    const int v = i < nl ? best_sad[i] : -1;
+    s_sad[i] = v;
+    local += v >= 0;
+  }
   if (local) atomicAdd(&s_cnt, local);
   __syncthreads();
   const int n = s_cnt;
-  if (n == 0) return;
+  if (n == 0 || nl > kCap) return;     // nl > kCap cannot happen: the handle caps features well below (orbx_create)
   const int kth = n / 2;
-  // value v is the kth order statistic iff  #(x < v) <= kth < #(x <= v)
+  // value v is the kth order statistic iff  #(x < v) <= kth < #(x <= v); invalid entries are -1 and never counted
   for (int i = threadIdx.x; i < nl; i += 1024) {
-    const int v = best_sad[i];
+    const int v = s_sad[i];
     if (v < 0) continue;
     int lt = 0, le = 0;
-    for (int j = 0; j < nl; j++) {
-      const int x = best_sad[j];
-      if (x >= 0) { lt += x < v; le += x <= v; }
+    for (int j = 0; j < npad / 4; j++) {
+      const int4 x = s_sad4[j];
+      lt += ((x.x >= 0) & (x.x < v)) + ((x.y >= 0) & (x.y < v)) + ((x.z >= 0) & (x.z < v)) + ((x.w >= 0) & (x.w < v));
+      le += ((x.x >= 0) & (x.x <= v)) + ((x.y >= 0) & (x.y <= v)) + ((x.z >= 0) & (x.z <= v)) + ((x.w >= 0) & (x.w <= v));
     }
     if (lt <= kth && kth < le) s_median = v;     // every writer writes the same value
   }
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(1024) void stereo_finalize_kernel(float* __restrict
   const float median = (float)s_median;
   const float thDist = 1.5f * 1.4f * median;
   for (int i = threadIdx.x; i < nl; i += 1024) {
-    const int v = best_sad[i];
+    const int v = s_sad[i];
     if (v >= 0 && !((float)v < thDist)) { uright[i] = -1; depth[i] = -1; }
   }
 }
@@ -690,6 +705,63 @@ class QuadTree {
   std::vector<int> scratch_;
 };
 
+// Small persistent worker pool for the per-(camera, level) quad-trees (16 independent serial problems per stereo
+// frame).  The calling thread takes part, so pool size 0 degenerates to a plain loop.
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n) {
+    for (int i = 0; i < n; i++) threads_.emplace_back([this, i] { worker(i); });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  int size() const { return (int)threads_.size(); }
+  void run(int ntasks, const std::function<void(int, int)>& fn) {
+    if (ntasks <= 0) return;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; ntasks_ = ntasks; next_.store(0); pending_.store(ntasks); gen_++;
+    }
+    if (!threads_.empty()) cv_.notify_all();
+    work((int)threads_.size());
+    while (pending_.load(std::memory_order_acquire) != 0 || active_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+  }
+
+ private:
+  void work(int wid) {
+    for (;;) {
+      const int t = next_.fetch_add(1);
+      if (t >= ntasks_) break;
+      (*fn_)(t, wid);
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void worker(int wid) {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        active_.fetch_add(1);
+      }
+      work(wid);
+      active_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  const std::function<void(int, int)>* fn_ = nullptr;
+  int ntasks_ = 0;
+  std::atomic<int> next_{0}, pending_{0}, active_{0};
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -726,7 +798,9 @@ struct orbx_handle {
   int cand_cap = 0;
   // per-level candidate views of the last extraction (for orbx_get_candidates)
   std::vector<Cand> last_cands[2][ORBG_MAX_LEVELS];
-  QuadTree qt;
+  std::vector<SelKp> level_sel[2][ORBG_MAX_LEVELS];
+  std::vector<QuadTree> qts;               // one per pool thread + the caller
+  std::unique_ptr<WorkerPool> pool;
   float timings[8] = {0};
 };
 
@@ -833,7 +907,7 @@ static int setup_geometry(orbx_handle* h, int w, int hgt) {
 extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
   if (!cfg || !out) return ORBG_BAD_ARG;
   if (cfg->n_levels < 1 || cfg->n_levels > ORBG_MAX_LEVELS || cfg->n_features < 1 || cfg->n_cams < 1 || cfg->n_cams > 2 ||
-      !(cfg->scale_factor > 1.0f) || cfg->max_width > 4000 || cfg->max_height > 4000)
+      !(cfg->scale_factor > 1.0f) || cfg->max_width > 4000 || cfg->max_height > 4000 || cfg->n_features > 3500)
     return ORBG_BAD_ARG;
   int rc = select_device(cfg->device);
   if (rc) return rc;
@@ -869,6 +943,12 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
       ++v0;
     }
     for (int i = 0; i < 16; i++) h->umax.v[i] = um[i];
+  }
+  {
+    int nthreads = 3;
+    if (const char* env = getenv("ORBG_OCTREE_THREADS")) nthreads = std::max(0, std::min(atoi(env), 15));
+    h->pool.reset(new WorkerPool(nthreads));
+    h->qts.resize(nthreads + 1);
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   for (auto& e : h->ev)
@@ -961,34 +1041,42 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     ORBG_HIP(hipStreamSynchronize(st));
   }
   int n_sel_total = 0;
-  std::vector<int> keep;
+  // one task per (camera, level), biggest levels first; results land in level_sel[cam][level]
+  const int n_tasks = ncams * nl;
+  auto octree_task = [&](int task, int wid) {
+    const int cam = task % ncams, l = task / ncams;
+    std::vector<Cand>& cv = h->last_cands[cam][l];
+    std::vector<SelKp>& out = h->level_sel[cam][l];
+    cv.clear();
+    out.clear();
+    const LevelGeom& L = g.lv[l];
+    if (L.cell_end == L.cell_begin) return;
+    const int b = h->hdr.h[cam * ORBG_MAX_LEVELS + l];
+    int e;
+    int nlv = l + 1;
+    while (nlv < nl && g.lv[nlv].cell_end == g.lv[nlv].cell_begin) nlv++;
+    if (nlv < nl) e = h->hdr.h[cam * ORBG_MAX_LEVELS + nlv];
+    else e = h->hdr.h[2 * ORBG_MAX_LEVELS + 1 + cam];
+    cv.resize(e - b);
+    for (int i = b; i < e; i++) {
+      const uint32_t p = h->cand.h[i];
+      cv[i - b] = Cand{(int)(p & 0xFFF), (int)((p >> 12) & 0xFFF), (int)(p >> 24)};
+    }
+    const int minB = kEdge - 3;
+    std::vector<int> keep;
+    h->qts[wid].run(cv.data(), (int)cv.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, h->feats_per_level[l], keep);
+    out.reserve(keep.size());
+    for (int k : keep) {
+      SelKp s;
+      s.x = (short)(cv[k].x + minB); s.y = (short)(cv[k].y + minB);
+      s.level = (short)l; s.cam = (short)cam; s.out_idx = 0; s.response = (float)cv[k].score;
+      out.push_back(s);
+    }
+  };
+  h->pool->run(n_tasks, octree_task);
   for (int cam = 0; cam < ncams; cam++) {
     std::vector<SelKp> level_kps;   // in level order, octree list order
-    for (int l = 0; l < nl; l++) {
-      std::vector<Cand>& cv = h->last_cands[cam][l];
-      cv.clear();
-      const LevelGeom& L = g.lv[l];
-      if (L.cell_end == L.cell_begin) continue;
-      const int b = h->hdr.h[cam * ORBG_MAX_LEVELS + l];
-      int e;
-      int nlv = l + 1;
-      while (nlv < nl && g.lv[nlv].cell_end == g.lv[nlv].cell_begin) nlv++;
-      if (nlv < nl) e = h->hdr.h[cam * ORBG_MAX_LEVELS + nlv];
-      else e = h->hdr.h[2 * ORBG_MAX_LEVELS + 1 + cam];
-      cv.resize(e - b);
-      for (int i = b; i < e; i++) {
-        const uint32_t p = h->cand.h[i];
-        cv[i - b] = Cand{(int)(p & 0xFFF), (int)((p >> 12) & 0xFFF), (int)(p >> 24)};
-      }
-      const int minB = kEdge - 3;
-      h->qt.run(cv.data(), (int)cv.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, h->feats_per_level[l], keep);
-      for (int k : keep) {
-        SelKp s;
-        s.x = (short)(cv[k].x + minB); s.y = (short)(cv[k].y + minB);
-        s.level = (short)l; s.cam = (short)cam; s.out_idx = 0; s.response = (float)cv[k].score;
-        level_kps.push_back(s);
-      }
-    }
+    for (int l = 0; l < nl; l++) level_kps.insert(level_kps.end(), h->level_sel[cam][l].begin(), h->level_sel[cam][l].end());
     const int nk = (int)level_kps.size();
     h->n_kp[cam] = nk;
     if (n_out[cam]) *n_out[cam] = nk;
@@ -1014,9 +1102,11 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   }
   ORBG_HIP(hipEventRecord(h->ev[4], st));
   const bool want_out = kps_out[0] || desc_out[0] || kps_out[1] || desc_out[1];
-  if (want_out && n_sel_total > 0) {
+  if (n_sel_total > 0) {
+    // the keypoints are always mirrored into pinned host memory: the matchers' serial commit needs octave / angle
     ORBG_HIP(hipMemcpyAsync(h->h_kps.h, h->d_kps.p, (size_t)n_sel_total * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, st));
-    ORBG_HIP(hipMemcpyAsync(h->h_desc.h, h->d_desc.p, (size_t)n_sel_total * 32, hipMemcpyDeviceToHost, st));
+    if (desc_out[0] || desc_out[1])
+      ORBG_HIP(hipMemcpyAsync(h->h_desc.h, h->d_desc.p, (size_t)n_sel_total * 32, hipMemcpyDeviceToHost, st));
   }
   ORBG_HIP(hipStreamSynchronize(st));
   if (want_out) {
@@ -1154,9 +1244,10 @@ extern "C" int orbx_get_timings(orbx_handle* h, float* ms) {
 // accessors for matcher.hip (device-resident hand-over, same shared object)
 extern "C++" {
 int orbx_internal_left_features(orbx_handle* h, const orbx_keypoint** d_kps, const uint8_t** d_desc, const float** d_uright,
-                                const float** d_depth, int* n, hipStream_t* stream) {
+                                const float** d_depth, const orbx_keypoint** h_kps, int* n, hipStream_t* stream) {
   if (!h) return ORBG_BAD_ARG;
   *d_kps = h->d_kps.p; *d_desc = h->d_desc.p; *d_uright = h->d_uright.p; *d_depth = h->d_depth.p; *n = h->n_kp[0];
+  *h_kps = h->h_kps.h;
   *stream = h->stream;
   return ORBG_OK;
 }

@@ -10,13 +10,12 @@
 //   k_errors        thread/edge : residual, chi2, Huber rho        (+ fixed-order block partial sums)
 //   k_linearize     thread/edge : analytic Jacobians, weighted J^T W J blocks (Hpl 6x3, pose 21+6, point 6+3)
 //   k_reduce_points thread/point: Hll, bl   = ordered sum over the point's edges
-//   k_reduce_poses  block/pose  : Hpp, bp   = tree sum over the pose's edges
+//   k_lin_poses     block/pose  : Hpp, bp   rebuilt from the pose's edges on the fly, wave+block tree sum
 //   k_schur         block/pose-pair: S_ij = [i==j](Hpp_i + lambda I) - sum_l Hpl_il (Hll_l+lambda I)^-1 Hpl_jl^T,
 //                   gathered over the points both poses observe (structure built once per call); diagonal pairs
 //                   also produce b_s,i = bp_i - sum_l Hpl_il Dinv_l bl_l
-//   k_ldlt          one workgroup: blocked (6x6 pose blocks) dense LDL^T of the reduced camera matrix in LDS + solve
-//   k_backsub       thread/point: x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i)
-//   k_update        thread/vertex: trial state = exp(x_p) * T  /  X + x_l
+//   k_ldlt_blk      one workgroup: register-blocked (one 6x6 block per thread) dense LDL^T of the reduced camera matrix + solve
+//   k_update        thread/vertex: x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i); trial state = exp(x_p) * T  /  X + x_l
 //   k_finish        one workgroup: robust chi2, computeScale, max-diagonal -> pinned host record
 // The reduced camera system is tiny (6P x 6P, P <= a few tens): the path is latency bound, not FLOP bound.
 // Parity: poses/points within 1e-4 of the oracle after float32 write-back, identical outlier sets.
@@ -122,13 +121,22 @@ __device__ inline void pose_oplus(const PoseQ& T, const double* u, PoseQ* out) {
   quat_normalize(out->q);
 }
 
+// 1/d to ~1 ulp: hardware seed + two Newton-Raphson steps
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = x * (2.0 - d * x);
+  x = x * (2.0 - d * x);
+  return x;
+}
+
 __device__ inline void edge_error(const PoseQ& T, const double* X, const Cam& c, const lba_edge& e, double* err, double* Xc) {
   double r[3];
   quat_rotate(T.q, X, r);
   Xc[0] = r[0] + T.t[0]; Xc[1] = r[1] + T.t[1]; Xc[2] = r[2] + T.t[2];
   if (e.ur < 0) {
-    err[0] = (double)e.u - (c.fx * Xc[0] / Xc[2] + c.cx);
-    err[1] = (double)e.v - (c.fy * Xc[1] / Xc[2] + c.cy);
+    const double iz = 1.0 / Xc[2];
+    err[0] = (double)e.u - (c.fx * Xc[0] * iz + c.cx);
+    err[1] = (double)e.v - (c.fy * Xc[1] * iz + c.cy);
     err[2] = 0;
   } else {
     const float invz = (float)(1.0 / Xc[2]);                 // cam_project: float invz (types_six_dof_expmap.cpp:191)
@@ -178,29 +186,16 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// per-edge blocks: EB[k*54 + ...] = Hpl(18) | poseH upper (21) | poseB (6) | pointH upper (6) | pointB (3)
-constexpr int kEB = 54;
+// per-edge blocks: EB[k*27 + ...] = Hpl (6x3, 18) | pointH upper (6) | pointB (3)
+constexpr int kEB = 27;
 
-__global__ __launch_bounds__(256) void k_linearize(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                                  const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
-                                                  const double* __restrict__ chi2, const int* __restrict__ pose_col,
-                                                  const int* __restrict__ point_col, double* __restrict__ EB) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n_edges) return;
-  const lba_edge e = edges[k];
-  double* out = EB + (size_t)k * kEB;
-  const PoseQ T = poses[e.pose];
-  const double* X = points + 3 * (size_t)e.point;
-  double r[3];
-  quat_rotate(T.q, X, r);
-  const double x = r[0] + T.t[0], y = r[1] + T.t[1], z = r[2] + T.t[2];
+// Jacobians of one edge (stereo: G/types/types_six_dof_expmap.cpp:228-274; mono: S/OptimizableTypes.cpp:139-160)
+__device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double z, const Cam& c, bool mono, double* A, double* B) {
   double R[9];
   quat_to_R(T.q, R);
-  double A[9], B[18];
-  const bool mono = e.ur < 0;
-  const int D = mono ? 2 : 3;
-  if (mono) {                                     // S/OptimizableTypes.cpp:139-160
-    const double J[6] = {-(c.fx / z), -0.0, -(-c.fx * x / (z * z)), -0.0, -(c.fy / z), -(-c.fy * y / (z * z))};
+  const double iz = 1.0 / z, iz2 = iz * iz;     // one division per edge; the reference divides term by term (<= 2 ulp apart)
+  if (mono) {
+    const double J[6] = {-(c.fx * iz), -0.0, c.fx * x * iz2, -0.0, -(c.fy * iz), c.fy * y * iz2};
     for (int i = 0; i < 2; i++)
       for (int j = 0; j < 3; j++) A[3 * i + j] = J[3 * i] * R[j] + J[3 * i + 1] * R[3 + j] + J[3 * i + 2] * R[6 + j];
     const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
@@ -208,53 +203,124 @@ __global__ __launch_bounds__(256) void k_linearize(int n_edges, const lba_edge* 
       for (int j = 0; j < 6; j++) B[6 * i + j] = J[3 * i] * S[j] + J[3 * i + 1] * S[6 + j] + J[3 * i + 2] * S[12 + j];
     for (int j = 0; j < 3; j++) A[6 + j] = 0;
     for (int j = 0; j < 6; j++) B[12 + j] = 0;
-  } else {                                        // G/types/types_six_dof_expmap.cpp:228-274
-    const double z_2 = z * z;
+  } else {
     for (int j = 0; j < 3; j++) {
-      A[j] = -c.fx * R[j] / z + c.fx * x * R[6 + j] / z_2;
-      A[3 + j] = -c.fy * R[3 + j] / z + c.fy * y * R[6 + j] / z_2;
-      A[6 + j] = A[j] - c.bf * R[6 + j] / z_2;
+      A[j] = -c.fx * R[j] * iz + c.fx * x * R[6 + j] * iz2;
+      A[3 + j] = -c.fy * R[3 + j] * iz + c.fy * y * R[6 + j] * iz2;
+      A[6 + j] = A[j] - c.bf * R[6 + j] * iz2;
     }
-    B[0] = x * y / z_2 * c.fx; B[1] = -(1 + (x * x / z_2)) * c.fx; B[2] = y / z * c.fx; B[3] = -1. / z * c.fx; B[4] = 0; B[5] = x / z_2 * c.fx;
-    B[6] = (1 + y * y / z_2) * c.fy; B[7] = -x * y / z_2 * c.fy; B[8] = -x / z * c.fy; B[9] = 0; B[10] = -1. / z * c.fy; B[11] = y / z_2 * c.fy;
-    B[12] = B[0] - c.bf * y / z_2; B[13] = B[1] + c.bf * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - c.bf / z_2;
+    B[0] = x * y * iz2 * c.fx; B[1] = -(1 + (x * x * iz2)) * c.fx; B[2] = y * iz * c.fx; B[3] = -iz * c.fx; B[4] = 0; B[5] = x * iz2 * c.fx;
+    B[6] = (1 + y * y * iz2) * c.fy; B[7] = -x * y * iz2 * c.fy; B[8] = -x * iz * c.fy; B[9] = 0; B[10] = -iz * c.fy; B[11] = y * iz2 * c.fy;
+    B[12] = B[0] - c.bf * y * iz2; B[13] = B[1] + c.bf * x * iz2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - c.bf * iz2;
   }
-  double rho0, rho1;
-  huber(chi2[k], mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
-  const double om = (double)e.inv_sigma2;
-  const double wom = rho1 * om;
-  double omega_r[3];
-  for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * err[3 * (size_t)k + i]) * rho1 : 0.0;
-  const bool pf = pose_col[e.pose] >= 0, lf = point_col[e.point] >= 0;
-  // Hpl = B^T (w Omega) A   (6x3)
-  for (int a = 0; a < 6; a++)
-    for (int cidx = 0; cidx < 3; cidx++) {
-      double h = 0;
-      for (int i = 0; i < D; i++) h += B[6 * i + a] * wom * A[3 * i + cidx];
-      out[3 * a + cidx] = (pf && lf) ? h : 0.0;
+}
+
+// thread per edge; the 256 x 27 block of results is staged in LDS and written as ONE contiguous, coalesced chunk
+__global__ __launch_bounds__(256) void k_linearize(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+                                                  const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
+                                                  const double* __restrict__ chi2, const int* __restrict__ pose_col,
+                                                  const int* __restrict__ point_col, double* __restrict__ EB) {
+  __shared__ double stage[256 * kEB];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n_edges) {
+    const lba_edge e = edges[k];
+    double* out = stage + threadIdx.x * kEB;
+    const PoseQ T = poses[e.pose];
+    const double* X = points + 3 * (size_t)e.point;
+    double r[3];
+    quat_rotate(T.q, X, r);
+    const bool mono = e.ur < 0;
+    const int D = mono ? 2 : 3;
+    double A[9], B[18];
+    edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
+    double rho0, rho1;
+    huber(chi2[k], mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
+    const double om = (double)e.inv_sigma2;
+    const double wom = rho1 * om;
+    double omega_r[3];
+    for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * err[3 * (size_t)k + i]) * rho1 : 0.0;
+    const bool pf = pose_col[e.pose] >= 0, lf = point_col[e.point] >= 0;
+    for (int a = 0; a < 6; a++)          // Hpl = B^T (w Omega) A   (6x3)
+      for (int cidx = 0; cidx < 3; cidx++) {
+        double h = 0;
+        for (int i = 0; i < D; i++) h += B[6 * i + a] * wom * A[3 * i + cidx];
+        out[3 * a + cidx] = (pf && lf) ? h : 0.0;
+      }
+    int o = 18;
+    for (int a = 0; a < 3; a++)
+      for (int b2 = a; b2 < 3; b2++) {
+        double h = 0;
+        for (int i = 0; i < D; i++) h += A[3 * i + a] * wom * A[3 * i + b2];
+        out[o++] = lf ? h : 0.0;
+      }
+    for (int a = 0; a < 3; a++) {
+      double sacc = 0;
+      for (int i = 0; i < D; i++) sacc += A[3 * i + a] * omega_r[i];
+      out[o++] = lf ? sacc : 0.0;
     }
-  int o = 18;
-  for (int a = 0; a < 6; a++)
-    for (int b = a; b < 6; b++) {
-      double h = 0;
-      for (int i = 0; i < D; i++) h += B[6 * i + a] * wom * B[6 * i + b];
-      out[o++] = pf ? h : 0.0;
-    }
-  for (int a = 0; a < 6; a++) {
-    double s = 0;
-    for (int i = 0; i < D; i++) s += B[6 * i + a] * omega_r[i];
-    out[o++] = pf ? s : 0.0;
   }
-  for (int a = 0; a < 3; a++)
-    for (int b = a; b < 3; b++) {
-      double h = 0;
-      for (int i = 0; i < D; i++) h += A[3 * i + a] * wom * A[3 * i + b];
-      out[o++] = lf ? h : 0.0;
+  __syncthreads();
+  const int valid = min(256, n_edges - blockIdx.x * 256);
+  double* dst = EB + (size_t)blockIdx.x * 256 * kEB;
+  for (int i = threadIdx.x; i < valid * kEB; i += 256) dst[i] = stage[i];
+}
+
+// Hpp (21 upper) + bp (6) of one free pose: block per pose, threads stride over the pose's edges and rebuild the
+// pose Jacobian on the fly (no per-edge 27-double round trip through HBM); fixed-order wave + block reduction.
+__global__ __launch_bounds__(256) void k_lin_poses(const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
+                                                  const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+                                                  const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
+                                                  const double* __restrict__ chi2, double* __restrict__ Hpp, double* __restrict__ bp) {
+  __shared__ double wpart[4][27];
+  const int p = blockIdx.x;
+  const int b = ps_start[p], e_end = ps_start[p + 1];
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; i++) acc[i] = 0;
+  for (int j = b + threadIdx.x; j < e_end; j += 256) {
+    const int k = ps_edges[j];
+    const lba_edge e = edges[k];
+    const PoseQ T = poses[e.pose];
+    const double* X = points + 3 * (size_t)e.point;
+    double r[3];
+    quat_rotate(T.q, X, r);
+    const bool mono = e.ur < 0;
+    const int D = mono ? 2 : 3;
+    double A[9], B[18];
+    edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
+    double rho0, rho1;
+    huber(chi2[k], mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
+    const double om = (double)e.inv_sigma2;
+    const double wom = rho1 * om;
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b2 = a; b2 < 6; b2++) {
+        double h = 0;
+        for (int i = 0; i < D; i++) h += B[6 * i + a] * wom * B[6 * i + b2];
+        acc[o++] += h;
+      }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      double sacc = 0;
+      for (int i = 0; i < D; i++) sacc += B[6 * i + a] * (-(om * err[3 * (size_t)k + i]) * rho1);
+      acc[o++] += sacc;
     }
-  for (int a = 0; a < 3; a++) {
-    double s = 0;
-    for (int i = 0; i < D; i++) s += A[3 * i + a] * omega_r[i];
-    out[o++] = lf ? s : 0.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 27; i++) {
+    double v = acc[i];
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
+    if (lane == 0) wpart[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const double v = ((wpart[0][threadIdx.x] + wpart[1][threadIdx.x]) + wpart[2][threadIdx.x]) + wpart[3][threadIdx.x];
+    if (threadIdx.x < 21) Hpp[21 * (size_t)p + threadIdx.x] = v;
+    else bp[6 * (size_t)p + threadIdx.x - 21] = v;
   }
 }
 
@@ -266,33 +332,11 @@ __global__ __launch_bounds__(256) void k_reduce_points(int nL, const int* __rest
   double acc[9];
   for (int i = 0; i < 9; i++) acc[i] = 0;
   for (int j = pt_start[l]; j < pt_start[l + 1]; j++) {
-    const double* eb = EB + (size_t)pt_edges[j] * kEB + 45;
+    const double* eb = EB + (size_t)pt_edges[j] * kEB + 18;
     for (int i = 0; i < 9; i++) acc[i] += eb[i];
   }
   for (int i = 0; i < 6; i++) Hll[6 * (size_t)l + i] = acc[i];
   for (int i = 0; i < 3; i++) bl[3 * (size_t)l + i] = acc[6 + i];
-}
-
-// Hpp (21 upper) + bp (6) per free pose: one 256-thread block per pose, strided partials + tree
-__global__ __launch_bounds__(256) void k_reduce_poses(const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
-                                                     const double* __restrict__ EB, double* __restrict__ Hpp, double* __restrict__ bp) {
-  __shared__ double red[27][65];
-  const int p = blockIdx.x;
-  const int b = ps_start[p], e = ps_start[p + 1];
-  // thread = (component c in 0..26, slice s in 0..8): 27*9 = 243 threads active
-  const int c = threadIdx.x % 27, s = threadIdx.x / 27;
-  if (s < 9) {
-    double acc = 0;
-    for (int j = b + s; j < e; j += 9) acc += EB[(size_t)ps_edges[j] * kEB + 18 + c];
-    red[c][s] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x < 27) {
-    double acc = 0;
-    for (int s2 = 0; s2 < 9; s2++) acc += red[threadIdx.x][s2];
-    if (threadIdx.x < 21) Hpp[21 * (size_t)p + threadIdx.x] = acc;
-    else bp[6 * (size_t)p + threadIdx.x - 21] = acc;
-  }
 }
 
 __device__ inline void inv3_sym(const double* h6, double lambda, double* o) {
@@ -436,40 +480,198 @@ __global__ __launch_bounds__(1024) void k_ldlt(int n, double* S, const double* _
   if (tid == 0) *ok_flag = s_ok;
 }
 
-// x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i)
-__global__ __launch_bounds__(256) void k_backsub(int nL, int nP, const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
-                                                const int* __restrict__ pf_col, const double* __restrict__ EB,
-                                                const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
-                                                double* __restrict__ x) {
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= nL) return;
-  double cl[3] = {bl[3 * (size_t)l], bl[3 * (size_t)l + 1], bl[3 * (size_t)l + 2]};
-  for (int j = pf_start[l]; j < pf_start[l + 1]; j++) {
-    const double* Bi = EB + (size_t)pf_edges[j] * kEB;
-    const double* xp = x + 6 * (size_t)pf_col[j];
-    for (int c = 0; c < 3; c++)
-      for (int a = 0; a < 6; a++) cl[c] -= Bi[3 * a + c] * xp[a];
+// Register-blocked dense LDL^T + solve of the reduced camera system: thread t owns the 6x6 block (i,k), i >= k, of the
+// lower triangle in registers for the whole factorisation; per block column j: (1) the diagonal owner factors its block
+// and forward-substitutes y_j, (2) panel owners compute L_ij = A_ij L_jj^-T D_j^-1 and fold L_ij y_j into the running
+// rhs, (3) every trailing owner applies the rank-6 update A_ik -= L_ij (L_kj D_j)^T from the LDS-staged panel.  Two
+// barriers per block column forward, two backward; no pivoting; zero / non-finite pivot => ok = 0.
+constexpr int kPanStride = 74;   // doubles per panel row-block: L (36, padded to 37) + W (36, padded to 37): conflict-free b64 reads
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ldlt_blk(int nb, const double* __restrict__ S, const double* __restrict__ b,
+                                                 double* __restrict__ x, int* __restrict__ ok_flag) {
+  extern __shared__ double sh[];
+  double* Ljj = sh;            // 36
+  double* Dj = sh + 36;        // 6 (reciprocals of the block's pivots)
+  double* yj = sh + 42;        // 6 (forward: y_j, backward: x_i)
+  double* r = sh + 48;         // 6*nb running rhs
+  double* pan = r + 6 * nb;    // 2 * nb * kPanStride
+  __shared__ int s_ok;
+  const int t = threadIdx.x;
+  const int n = 6 * nb;
+  const int nblk = nb * (nb + 1) / 2;
+  int bi = -1, bk = -1;
+  if (t < nblk) {
+    bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= t) bi++;
+    while (bi * (bi + 1) / 2 > t) bi--;
+    bk = t - bi * (bi + 1) / 2;
   }
-  double Dinv[9];
-  inv3_sym(Hll + 6 * (size_t)l, lambda, Dinv);
-  for (int a = 0; a < 3; a++) x[6 * (size_t)nP + 3 * (size_t)l + a] = Dinv[3 * a] * cl[0] + Dinv[3 * a + 1] * cl[1] + Dinv[3 * a + 2] * cl[2];
+  double a[36];
+  if (bi >= 0) {
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) a[6 * rr + c] = S[(size_t)(6 * bi + rr) * n + 6 * bk + c];
+  }
+  for (int i = t; i < n; i += NT) r[i] = b[i];
+  if (t == 0) s_ok = 1;
+  __syncthreads();
+  for (int j = 0; j < nb; j++) {
+    double* P = pan + (size_t)(j & 1) * nb * kPanStride;
+    if (bi == j && bk == j) {
+      // in-register LDL^T of the 6x6 diagonal block: a[rr][c] (rr > c) <- L, a[c][c] <- d_c
+      bool good = true;
+      double inv_d[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double d = a[7 * c];
+#pragma unroll
+        for (int m = 0; m < c; m++) d -= a[6 * c + m] * a[6 * c + m] * a[7 * m];
+        if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
+        a[7 * c] = d;
+        const double id = fast_rcp(d);
+        inv_d[c] = id;
+#pragma unroll
+        for (int rr = c + 1; rr < 6; rr++) {
+          double v = a[6 * rr + c];
+#pragma unroll
+          for (int m = 0; m < c; m++) v -= a[6 * rr + m] * a[6 * c + m] * a[7 * m];
+          a[6 * rr + c] = v * id;
+        }
+      }
+      if (!good) s_ok = 0;
+      // y_j = L_jj^-1 r_j ; z_j = y_j / d (kept in r_j for the backward pass)
+      double y[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double v = r[6 * j + c];
+#pragma unroll
+        for (int m = 0; m < c; m++) v -= a[6 * c + m] * y[m];
+        y[c] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        yj[c] = y[c];
+        Dj[c] = inv_d[c];                 // panel owners only need 1/d
+        r[6 * j + c] = y[c] * inv_d[c];
+#pragma unroll
+        for (int m = 0; m < 6; m++) Ljj[6 * c + m] = a[6 * c + m];
+      }
+    }
+    __syncthreads();
+    if (!s_ok) break;
+    if (bk == j && bi > j) {
+      // W = A_ij L_jj^-T  (W L_jj^T = A_ij), L_ij = W D^-1
+      double* Lp = P + (size_t)bi * kPanStride;
+      double* Wp = Lp + 37;
+      double d[6], yv[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) { d[c] = Dj[c]; yv[c] = yj[c]; }
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++) {
+        double w[6];
+        double racc = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double v = a[6 * rr + c];
+#pragma unroll
+          for (int m = 0; m < c; m++) v -= w[m] * Ljj[6 * c + m];
+          w[c] = v;
+          const double l = v * d[c];      // d[] holds 1/d_c
+          a[6 * rr + c] = l;
+          Wp[6 * rr + c] = v;
+          Lp[6 * rr + c] = l;
+          racc += l * yv[c];
+        }
+        r[6 * bi + rr] -= racc;
+      }
+    }
+    __syncthreads();
+    if (bk > j && bi >= bk) {
+      const double* Lp = P + (size_t)bi * kPanStride;        // L_ij
+      const double* Wp = P + (size_t)bk * kPanStride + 37;   // W_kj = L_kj D_j
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        double lc[6], wc[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) { lc[q] = Lp[6 * q + m]; wc[q] = Wp[6 * q + m]; }
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) a[6 * rr + c] -= lc[rr] * wc[c];
+      }
+    }
+  }
+  const int ok = s_ok;
+  if (ok) {
+    // backward: x_i = L_ii^-T r_i ; r_k -= L_ik^T x_i for k < i
+    for (int i = nb - 1; i >= 0; i--) {
+      if (bi == i && bk == i) {
+        double xv[6];
+#pragma unroll
+        for (int c = 5; c >= 0; c--) {
+          double v = r[6 * i + c];
+#pragma unroll
+          for (int m = c + 1; m < 6; m++) v -= a[6 * m + c] * xv[m];
+          xv[c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) { yj[c] = xv[c]; x[6 * i + c] = xv[c]; }
+      }
+      __syncthreads();
+      if (bi == i && bk < i) {
+        double xv[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) xv[c] = yj[c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double acc = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++) acc += a[6 * rr + c] * xv[rr];
+          r[6 * bk + c] -= acc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t == 0) *ok_flag = ok;
 }
 
-// trial state = oplus(current, x) for active vertices, copy for the rest
+// trial state = oplus(current, x): poses exp(x_p) * T; points X + x_l with the landmark back-substitution
+// x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i) folded in (x_l is also stored for computeScale)
 __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int nP, const int* __restrict__ pose_col,
                                                const int* __restrict__ point_col, const PoseQ* __restrict__ poses,
-                                               const double* __restrict__ points, const double* __restrict__ x,
+                                               const double* __restrict__ points, double* __restrict__ x,
+                                               const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
+                                               const int* __restrict__ pf_col, const double* __restrict__ EB,
+                                               const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
                                                PoseQ* __restrict__ poses_out, double* __restrict__ points_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_poses) {
-    const int c = pose_col[i];
-    if (c >= 0) pose_oplus(poses[i], x + 6 * (size_t)c, &poses_out[i]);
-    else poses_out[i] = poses[i];
-  } else if (i < n_poses + n_points) {
-    const int p = i - n_poses;
-    const int c = point_col[p];
-    for (int a = 0; a < 3; a++)
-      points_out[3 * (size_t)p + a] = points[3 * (size_t)p + a] + (c >= 0 ? x[6 * (size_t)nP + 3 * (size_t)c + a] : 0.0);
+  if (i < n_points) {
+    const int l = point_col[i];
+    double dx[3] = {0, 0, 0};
+    if (l >= 0) {
+      double cl[3] = {bl[3 * (size_t)l], bl[3 * (size_t)l + 1], bl[3 * (size_t)l + 2]};
+      for (int j = pf_start[l]; j < pf_start[l + 1]; j++) {
+        const double* Bi = EB + (size_t)pf_edges[j] * kEB;
+        const double* xp = x + 6 * (size_t)pf_col[j];
+        for (int c = 0; c < 3; c++)
+          for (int a = 0; a < 6; a++) cl[c] -= Bi[3 * a + c] * xp[a];
+      }
+      double Dinv[9];
+      inv3_sym(Hll + 6 * (size_t)l, lambda, Dinv);
+      for (int a = 0; a < 3; a++) {
+        dx[a] = Dinv[3 * a] * cl[0] + Dinv[3 * a + 1] * cl[1] + Dinv[3 * a + 2] * cl[2];
+        x[6 * (size_t)nP + 3 * (size_t)l + a] = dx[a];
+      }
+    }
+    for (int a = 0; a < 3; a++) points_out[3 * (size_t)i + a] = points[3 * (size_t)i + a] + dx[a];
+  } else if (i < n_points + n_poses) {
+    const int p = i - n_points;
+    const int c = pose_col[p];
+    if (c >= 0) pose_oplus(poses[p], x + 6 * (size_t)c, &poses_out[p]);
+    else poses_out[p] = poses[p];
   }
 }
 
@@ -692,6 +894,10 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
   }
 
+  const size_t blk_lds = (48 + 6 * (size_t)nP + 2 * (size_t)nP * kPanStride) * sizeof(double);
+  if (blk_lds > 64 * 1024) {
+    ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_blk<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds));
+  }
   int cur = 0;   // index of the buffer holding the current estimate
   auto launch_errors = [&](int buf) {
     if (NE > 0)
@@ -709,12 +915,15 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   double lambda = -1, ni = 2;
   int nBad = 0;
   bool first_chi = true;
+  bool err_valid = false;          // d_err / d_chi2 hold the residuals of the CURRENT estimate
+  double currentChi = 0;
   auto optimize = [&](int iterations, int* done_out) -> int {
     int done = 0;
     bool ok = true;
     for (int it = 0; it < iterations && !terminate() && ok; it++) {
-      // computeActiveErrors + buildSystem
-      launch_errors(cur);
+      // computeActiveErrors (skipped when the residuals of the current estimate are already on the device:
+      // recomputing them would reproduce the same bits) + buildSystem
+      if (!err_valid) { launch_errors(cur); err_valid = true; }
       if (NE > 0)
         hipLaunchKernelGGL(k_linearize, dim3(n_blocks_e), dim3(256), 0, st, NE, h->d_edges.p, h->d_poses[cur].p, h->d_points[cur].p, cam, hb,
                            h->d_err.p, h->d_chi2.p, h->d_pose_col.p, h->d_point_col.p, h->d_EB.p);
@@ -722,17 +931,19 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, h->d_pt_start.p, h->d_pt_edges.p, h->d_EB.p,
                            h->d_Hll.p, h->d_bl.p);
       if (nP > 0)
-        hipLaunchKernelGGL(k_reduce_poses, dim3(nP), dim3(256), 0, st, h->d_ps_start.p, h->d_ps_edges.p, h->d_EB.p, h->d_Hpp.p, h->d_bp.p);
-      int rc2 = finish(0.0, 0, it == 0, false);
-      if (rc2) return rc2;
-      double currentChi = h->rec.h->chi2;
-      if (first_chi) { r->chi2_initial = currentChi; first_chi = false; }
-      double tempChi = currentChi;
-      const double iniChi = currentChi;
-      if (it == 0) {                                   // computeLambdaInit (levenberg.cpp:171-185)
+        hipLaunchKernelGGL(k_lin_poses, dim3(nP), dim3(256), 0, st, h->d_ps_start.p, h->d_ps_edges.p, h->d_edges.p, h->d_poses[cur].p,
+                           h->d_points[cur].p, cam, hb, h->d_err.p, h->d_chi2.p, h->d_Hpp.p, h->d_bp.p);
+      int rc2;
+      if (it == 0) {
+        // the only place the host needs chi2 / max diagonal before the first trial (computeLambdaInit)
+        if ((rc2 = finish(0.0, 0, 1, false))) return rc2;
+        currentChi = h->rec.h->chi2;
         lambda = p->lambda_init > 0 ? p->lambda_init : 1e-5 * h->rec.h->maxdiag;
         ni = 2; nBad = 0;
       }
+      if (first_chi) { r->chi2_initial = currentChi; first_chi = false; }
+      double tempChi = currentChi;
+      const double iniChi = currentChi;
       double rho = 0;
       int qmax = 0;
       do {
@@ -740,15 +951,18 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         if (nP > 0) {
           hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(64), 0, st, nP, h->d_pair_i1.p, h->d_pair_i2.p, h->d_pair_start.p, h->d_items.p,
                              h->d_EB.p, h->d_Hll.p, h->d_bl.p, h->d_Hpp.p, h->d_bp.p, lambda, h->d_S.p, h->d_bs.p);
-          hipLaunchKernelGGL(k_ldlt, dim3(1), dim3(1024), lds_need, st, n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_lds ? 1 : 0);
+          if (nP <= 22)
+            hipLaunchKernelGGL(k_ldlt_blk<256>, dim3(1), dim3(256), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
+          else if (nP <= 44)
+            hipLaunchKernelGGL(k_ldlt_blk<1024>, dim3(1), dim3(1024), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
+          else
+            hipLaunchKernelGGL(k_ldlt, dim3(1), dim3(1024), lds_need, st, n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_lds ? 1 : 0);
         } else {
           ORBG_HIP(hipMemsetAsync(h->d_ok.p, 0xFF, sizeof(int), st));   // nothing to solve: ok
         }
-        if (nL > 0)
-          hipLaunchKernelGGL(k_backsub, dim3((nL + 255) / 256), dim3(256), 0, st, nL, nP, h->d_pf_start.p, h->d_pf_edges.p, h->d_pf_col.p,
-                             h->d_EB.p, h->d_Hll.p, h->d_bl.p, lambda, h->d_x.p);
         hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, h->d_pose_col.p, h->d_point_col.p,
-                           h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, h->d_poses[trial].p, h->d_points[trial].p);
+                           h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, h->d_pf_start.p, h->d_pf_edges.p, h->d_pf_col.p, h->d_EB.p,
+                           h->d_Hll.p, h->d_bl.p, lambda, h->d_poses[trial].p, h->d_points[trial].p);
         launch_errors(trial);
         if ((rc2 = finish(lambda, 1, 0, true))) return rc2;
         const bool ok2 = h->rec.h->ok != 0;
@@ -766,9 +980,11 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           ni = 2;
           currentChi = tempChi;
           cur = trial;                                // discardTop(): keep the trial state
+          err_valid = true;
         } else {
           lambda *= ni;
           ni *= 2;                                    // pop(): current buffer untouched
+          err_valid = false;                          // d_err now belongs to the rejected trial
         }
         qmax++;
       } while (rho < 0 && qmax < 10 && !terminate());

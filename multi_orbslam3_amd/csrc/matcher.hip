@@ -25,7 +25,7 @@
 using namespace orbg;
 
 int orbx_internal_left_features(orbx_handle* h, const orbx_keypoint** d_kps, const uint8_t** d_desc, const float** d_uright,
-                                const float** d_depth, int* n, hipStream_t* stream);
+                                const float** d_depth, const orbx_keypoint** h_kps, int* n, hipStream_t* stream);
 
 namespace {
 
@@ -225,9 +225,11 @@ struct Query { int valid; float x, y, r; int min_level, max_level; float ur_ref;
 
 // GetFeaturesInArea (S/Frame.cc:628-697) + the candidate loop of the projection searches.
 // Emits the candidate list [base, base+count) (entry = idx | dist<<16, or 0xFFFFFFFF when filtered).
+constexpr int kSlot = 16;
+
 __device__ __forceinline__ void window_search(const FrameParams& fp, const FrameDev& F, const Query& q, const uint8_t* qdesc,
-                                              int* __restrict__ list_counter, uint32_t* __restrict__ list, int list_cap,
-                                              QResult* __restrict__ out) {
+                                              int qid, int n_queries, int* __restrict__ list_counter,
+                                              uint32_t* __restrict__ list, int list_cap, QResult* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   QResult res;
   res.base = 0; res.count = 0; res.best_idx = -1; res.best_dist = 256; res.second_idx = -1; res.second_dist = 256;
@@ -260,9 +262,13 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
     if (lane == 0) *out = res;
     return;
   }
-  int base = 0;
-  if (lane == 0) base = atomicAdd(list_counter, total);
-  base = __shfl(base, 0, 64);
+  // short lists (the common case) live in a fixed slot of kSlot entries per query; only longer ones take a segment of
+  // the shared overflow region behind the slots -- one device-scope atomic word saturates at ~88 ops/us on MI355X.
+  int base = qid * kSlot;
+  if (total > kSlot) {
+    if (lane == 0) base = n_queries * kSlot + atomicAdd(list_counter, total);
+    base = __shfl(base, 0, 64);
+  }
   const uint4 a0 = *reinterpret_cast<const uint4*>(qdesc);
   const uint4 a1 = *reinterpret_cast<const uint4*>(qdesc + 16);
   const bool bCheckLevels = (q.min_level > 0) || (q.max_level >= 0);
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) void search_mps_kernel(FrameParams fp, FrameDe
     q.min_level = lvl - 1; q.max_level = lvl;
     q.ur_ref = mp.pxr[i];
   }
-  window_search(fp, F, q, mp.desc + (size_t)i * 32, list_counter, list, list_cap, results + i);
+  window_search(fp, F, q, mp.desc + (size_t)i * 32, i, mp.m, list_counter, list, list_cap, results + i);
 }
 
 // MODE 2: SearchByProjection(CurrentFrame, LastFrame) (S/ORBmatcher.cc:1993-2066)
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, Frame
       }
     }
   }
-  window_search(fp, F, q, L.desc + (size_t)i * 32, list_counter, list, list_cap, results + i);
+  window_search(fp, F, q, L.desc + (size_t)i * 32, i, L.n, list_counter, list, list_cap, results + i);
 }
 
 // SearchByBoW inner loops (S/ORBmatcher.cc:297-371): one wavefront per keyframe feature of a shared node.
@@ -409,9 +415,11 @@ __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restri
   QResult res;
   res.base = 0; res.count = total; res.best_idx = -1; res.best_dist = 256; res.second_idx = -1; res.second_dist = 256;
   res.u = res.v = 0;
-  int base = 0;
-  if (lane == 0 && total > 0) base = atomicAdd(list_counter, total);
-  base = __shfl(base, 0, 64);
+  int base = j * kSlot;
+  if (total > kSlot) {
+    if (lane == 0) base = n_jobs * kSlot + atomicAdd(list_counter, total);
+    base = __shfl(base, 0, 64);
+  }
   const uint4 a0 = *reinterpret_cast<const uint4*>(kf_desc + (size_t)job.kf_idx * 32);
   const uint4 a1 = *reinterpret_cast<const uint4*>(kf_desc + (size_t)job.kf_idx * 32 + 16);
   Top2 t;
@@ -525,18 +533,24 @@ struct orbm_frame {
   DevBuf<orbx_keypoint> d_kps;
   DevBuf<uint8_t> d_desc;
   DevBuf<float> d_uright, d_depth;
-  DevBuf<int> d_cell_of, d_cell_start, d_cell_items, d_assigned_mp, d_assigned_obs;
-  std::vector<orbx_keypoint> h_kps;      // host mirror (octave / angle for the serial commit)
+  DevBuf<int> d_cell_of, d_cell_start, d_cell_items;
+  // features the kernels read: own buffers after orbm_frame_upload, the extractor's after orbm_frame_from_extractor
+  const orbx_keypoint* kps_p = nullptr;
+  const uint8_t* desc_p = nullptr;
+  const float* uright_p = nullptr;
+  const float* depth_p = nullptr;
+  std::vector<orbx_keypoint> h_kps_own;
+  const orbx_keypoint* hk = nullptr;     // host mirror (octave / angle for the serial commit)
+  // per-call inputs are packed into ONE pinned staging block and moved with ONE H2D copy
+  PinnedBuf<uint8_t> stage;
+  DevBuf<uint8_t> d_stage;
+  size_t stage_off = 0;
+  const int* d_assigned_mp = nullptr;
+  const int* d_assigned_obs = nullptr;
   // query-side scratch
-  DevBuf<uint8_t> d_q_u8[4];
-  DevBuf<float> d_q_f32[8];
-  DevBuf<int> d_q_i32[4];
   DevBuf<int> d_counter;
   PinnedBuf<uint32_t> list;
   PinnedBuf<QResult> results;
-  PinnedBuf<int> h_counter;
-  DevBuf<BowJob> d_jobs;
-  DevBuf<uint32_t> d_fidx;
   float last_ms = 0;
 };
 
@@ -561,14 +575,13 @@ static int frame_reserve(orbm_frame* f, int n) {
   const size_t c = (size_t)std::max(n, 1);
   if ((rc = f->d_kps.reserve(c)) || (rc = f->d_desc.reserve(c * 32)) || (rc = f->d_uright.reserve(c)) ||
       (rc = f->d_depth.reserve(c)) || (rc = f->d_cell_of.reserve(c)) || (rc = f->d_cell_start.reserve(kCells + 1)) ||
-      (rc = f->d_cell_items.reserve(c)) || (rc = f->d_assigned_mp.reserve(c)) || (rc = f->d_assigned_obs.reserve(c)) ||
-      (rc = f->d_counter.reserve(4)) || (rc = f->h_counter.reserve(4)))
+      (rc = f->d_cell_items.reserve(c)) || (rc = f->d_counter.reserve(4)))
     return rc;
   return ORBG_OK;
 }
 
 static int frame_build_grid(orbm_frame* f) {
-  hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, f->stream, f->d_kps.p, f->fp, f->d_cell_of.p,
+  hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, f->stream, f->kps_p, f->fp, f->d_cell_of.p,
                      f->d_cell_start.p, f->d_cell_items.p);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;
@@ -594,11 +607,8 @@ extern "C" int orbm_frame_destroy(orbm_frame* f) {
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   f->d_kps.release(); f->d_desc.release(); f->d_uright.release(); f->d_depth.release(); f->d_cell_of.release();
-  f->d_cell_start.release(); f->d_cell_items.release(); f->d_assigned_mp.release(); f->d_assigned_obs.release();
-  for (auto& b : f->d_q_u8) b.release();
-  for (auto& b : f->d_q_f32) b.release();
-  for (auto& b : f->d_q_i32) b.release();
-  f->d_counter.release(); f->list.release(); f->results.release(); f->h_counter.release(); f->d_jobs.release(); f->d_fidx.release();
+  f->d_cell_start.release(); f->d_cell_items.release(); f->stage.release(); f->d_stage.release();
+  f->d_counter.release(); f->list.release(); f->results.release();
   for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   delete f;
@@ -612,7 +622,9 @@ extern "C" int orbm_frame_upload(orbm_frame* f, const orbm_frame_view* v) {
   if ((rc = frame_set_params(f, v, v->n))) return rc;
   if ((rc = frame_reserve(f, v->n))) return rc;
   const int n = v->n;
-  f->h_kps.assign(v->kps, v->kps + n);
+  f->h_kps_own.assign(v->kps, v->kps + n);
+  f->hk = f->h_kps_own.data();
+  f->kps_p = f->d_kps.p; f->desc_p = f->d_desc.p; f->uright_p = f->d_uright.p; f->depth_p = f->d_depth.p;
   f->has_uright = v->uright != nullptr;
   if (n > 0) {
     ORBG_HIP(hipMemcpyAsync(f->d_kps.p, v->kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, f->stream));
@@ -629,24 +641,17 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
   if (!f || !h || !v) return ORBG_BAD_ARG;
   int rc = select_device(f->device);
   if (rc) return rc;
-  const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; int n; hipStream_t xs;
-  if ((rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &n, &xs))) return rc;
+  const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n; hipStream_t xs;
+  if ((rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n, &xs))) return rc;
   if (v->n >= 0 && v->n != n) return ORBG_BAD_ARG;
   if ((rc = frame_set_params(f, v, n))) return rc;
   if ((rc = frame_reserve(f, n))) return rc;
+  // Zero-copy hand-over: the frame aliases the extractor's device-resident left features (valid until the next
+  // extraction on that handle) and its pinned host mirror of the keypoints.  Every orbx_* entry point synchronises
+  // its stream before returning, so the data is complete here.
   f->has_uright = true;
-  f->h_kps.resize(n);
-  if (n > 0) {
-    ORBG_HIP(hipStreamSynchronize(xs));    // extractor stream -> frame stream hand-over
-    ORBG_HIP(hipMemcpyAsync(f->d_kps.p, dk, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToDevice, f->stream));
-    ORBG_HIP(hipMemcpyAsync(f->d_desc.p, dd, (size_t)n * 32, hipMemcpyDeviceToDevice, f->stream));
-    ORBG_HIP(hipMemcpyAsync(f->d_uright.p, du, (size_t)n * 4, hipMemcpyDeviceToDevice, f->stream));
-    ORBG_HIP(hipMemcpyAsync(f->d_depth.p, dz, (size_t)n * 4, hipMemcpyDeviceToDevice, f->stream));
-    ORBG_HIP(hipMemcpyAsync(f->h_kps.data(), dk, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, f->stream));
-  }
-  if ((rc = frame_build_grid(f))) return rc;
-  ORBG_HIP(hipStreamSynchronize(f->stream));
-  return ORBG_OK;
+  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk;
+  return frame_build_grid(f);      // asynchronous on the frame's stream; the searches run on the same stream
 }
 
 extern "C" int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start, int32_t* cell_items) {
@@ -818,18 +823,30 @@ extern "C" int orbm_is_in_frustum(orbm_frame* f, const float* Tcw, const orbm_wo
 
 static FrameDev frame_dev(orbm_frame* f) {
   FrameDev F;
-  F.kps = f->d_kps.p; F.desc = f->d_desc.p; F.uright = f->has_uright ? f->d_uright.p : nullptr;
+  F.kps = f->kps_p; F.desc = f->desc_p; F.uright = f->has_uright ? f->uright_p : nullptr;
   F.cell_start = f->d_cell_start.p; F.cell_items = f->d_cell_items.p;
-  F.assigned_mp = f->d_assigned_mp.p; F.assigned_obs = f->d_assigned_obs.p;
+  F.assigned_mp = f->d_assigned_mp; F.assigned_obs = f->d_assigned_obs;
   return F;
 }
 
-static int upload_assigned(orbm_frame* f, const int32_t* amp, const int32_t* aob) {
-  const int n = f->fp.n;
-  if (n > 0) {
-    ORBG_HIP(hipMemcpyAsync(f->d_assigned_mp.p, amp, (size_t)n * 4, hipMemcpyHostToDevice, f->stream));
-    ORBG_HIP(hipMemcpyAsync(f->d_assigned_obs.p, aob, (size_t)n * 4, hipMemcpyHostToDevice, f->stream));
-  }
+// ---- staging: pack every per-call host array into one pinned block, one H2D copy
+static int stage_begin(orbm_frame* f, size_t total_bytes) {
+  int rc;
+  const size_t need = total_bytes + 64 * 16;
+  if ((rc = f->stage.reserve(need)) || (rc = f->d_stage.reserve(need))) return rc;
+  f->stage_off = 0;
+  return ORBG_OK;
+}
+template <typename T>
+static const T* stage_add(orbm_frame* f, const T* src, size_t count) {
+  f->stage_off = (f->stage_off + 15) & ~(size_t)15;
+  if (count) memcpy(f->stage.h + f->stage_off, src, count * sizeof(T));
+  const T* dev = reinterpret_cast<const T*>(f->d_stage.p + f->stage_off);
+  f->stage_off += count * sizeof(T);
+  return dev;
+}
+static int stage_commit(orbm_frame* f) {
+  if (f->stage_off) ORBG_HIP(hipMemcpyAsync(f->d_stage.p, f->stage.h, f->stage_off, hipMemcpyHostToDevice, f->stream));
   return ORBG_OK;
 }
 
@@ -838,20 +855,23 @@ template <typename LaunchFn>
 static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
   int rc;
   if ((rc = f->results.reserve((size_t)std::max(n_queries, 1)))) return rc;
-  if (f->list.cap == 0 && (rc = f->list.reserve(1 << 18))) return rc;
+  const size_t slots = (size_t)n_queries * kSlot;
+  if (f->list.cap < slots + (1 << 16) && (rc = f->list.reserve(slots + (1 << 18)))) return rc;
   for (int attempt = 0; attempt < 3; attempt++) {
     ORBG_HIP(hipMemsetAsync(f->d_counter.p, 0, sizeof(int), f->stream));
     ORBG_HIP(hipEventRecord(f->ev[0], f->stream));
     launch((int)f->list.cap);
     ORBG_HIP(hipGetLastError());
     ORBG_HIP(hipEventRecord(f->ev[1], f->stream));
-    ORBG_HIP(hipMemcpyAsync(f->h_counter.h, f->d_counter.p, sizeof(int), hipMemcpyDeviceToHost, f->stream));
     ORBG_HIP(hipStreamSynchronize(f->stream));
     float ms;
     if (hipEventElapsedTime(&ms, f->ev[0], f->ev[1]) == hipSuccess) f->last_ms = ms;
-    const int total = f->h_counter.h[0];
-    if ((size_t)total <= f->list.cap) return ORBG_OK;
-    if ((rc = f->list.reserve((size_t)total + total / 4))) return rc;
+    // the end of the furthest list segment tells whether the overflow region was large enough
+    size_t total = 0;
+    const QResult* R = f->results.h;
+    for (int i = 0; i < n_queries; i++) total = std::max(total, (size_t)R[i].base + (size_t)R[i].count);
+    if (total <= f->list.cap) return ORBG_OK;
+    if ((rc = f->list.reserve(total + total / 4))) return rc;
   }
   return ORBG_CAP_EXCEEDED;
 }
@@ -880,8 +900,8 @@ static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio,
       }
       if (bestIdx < 0) continue;
     }
-    const int bestLevel = f->h_kps[bestIdx].octave;
-    const int bestLevel2 = idx2 >= 0 ? f->h_kps[idx2].octave : -1;
+    const int bestLevel = f->hk[bestIdx].octave;
+    const int bestLevel2 = idx2 >= 0 ? f->hk[idx2].octave : -1;
     if (bestDist <= TH_HIGH) {
       if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
       if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
@@ -896,15 +916,6 @@ static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio,
   return ORBG_OK;
 }
 
-static int ensure_q(orbm_frame* f, int m) {
-  int rc;
-  const size_t c = (size_t)std::max(m, 1);
-  for (int i = 0; i < 4; i++) if ((rc = f->d_q_u8[i].reserve(i == 2 ? c * 32 : c))) return rc;
-  for (int i = 0; i < 8; i++) if ((rc = f->d_q_f32[i].reserve(i == 7 ? 3 * c : c))) return rc;
-  for (int i = 0; i < 4; i++) if ((rc = f->d_q_i32[i].reserve(c))) return rc;
-  return ORBG_OK;
-}
-
 extern "C" int orbm_search_by_projection_mps(orbm_frame* f, const orbm_mappoints_view* mps, float th, int far_points,
                                              float th_far_points, float nnratio, int32_t* assigned_mp, int32_t* assigned_obs,
                                              int* nmatches) {
@@ -914,22 +925,19 @@ extern "C" int orbm_search_by_projection_mps(orbm_frame* f, const orbm_mappoints
   const int m = mps->m;
   if (nmatches) *nmatches = 0;
   if (m == 0) return ORBG_OK;
-  if ((rc = ensure_q(f, m))) return rc;
-  if ((rc = upload_assigned(f, assigned_mp, assigned_obs))) return rc;
+  const int n = f->fp.n;
+  if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 6 * 4)))) return rc;
   hipStream_t st = f->stream;
-  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[0].p, mps->track_in_view, m, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[1].p, mps->bad, m, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[2].p, mps->desc, (size_t)m * 32, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[0].p, mps->proj_x, (size_t)m * 4, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[1].p, mps->proj_y, (size_t)m * 4, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[2].p, mps->proj_xr, (size_t)m * 4, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[3].p, mps->track_depth, (size_t)m * 4, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[4].p, mps->view_cos, (size_t)m * 4, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_i32[0].p, mps->scale_level, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  f->d_assigned_mp = stage_add(f, assigned_mp, n);
+  f->d_assigned_obs = stage_add(f, assigned_obs, n);
   MpsDev mp;
-  mp.m = m; mp.in_view = f->d_q_u8[0].p; mp.bad = f->d_q_u8[1].p; mp.px = f->d_q_f32[0].p; mp.py = f->d_q_f32[1].p;
-  mp.pxr = f->d_q_f32[2].p; mp.depth = f->d_q_f32[3].p; mp.level = f->d_q_i32[0].p; mp.view_cos = f->d_q_f32[4].p;
-  mp.desc = f->d_q_u8[2].p;
+  mp.m = m;
+  mp.in_view = stage_add(f, mps->track_in_view, m); mp.bad = stage_add(f, mps->bad, m);
+  mp.desc = stage_add(f, mps->desc, (size_t)m * 32);
+  mp.px = stage_add(f, mps->proj_x, m); mp.py = stage_add(f, mps->proj_y, m); mp.pxr = stage_add(f, mps->proj_xr, m);
+  mp.depth = stage_add(f, mps->track_depth, m); mp.view_cos = stage_add(f, mps->view_cos, m);
+  mp.level = stage_add(f, mps->scale_level, m);
+  if ((rc = stage_commit(f))) return rc;
   rc = run_search(f, m, [&](int list_cap) {
     hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), mp, th, far_points,
                        th_far_points, f->d_counter.p, f->list.d, list_cap, f->results.d);
@@ -954,16 +962,15 @@ extern "C" int orbm_search_local_points(orbm_frame* f, orbm_map* mp, const float
   const int m = mp->m;
   if (nmatches) *nmatches = 0;
   if (m == 0) return ORBG_OK;
-  if ((rc = ensure_q(f, m))) return rc;
-  if ((rc = upload_assigned(f, assigned_mp, assigned_obs))) return rc;
+  const int n = f->fp.n;
+  if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m))) return rc;
   hipStream_t st = f->stream;
+  f->d_assigned_mp = stage_add(f, assigned_mp, n);
+  f->d_assigned_obs = stage_add(f, assigned_obs, n);
   PoseF P;
   make_pose(Tcw, &P);
-  const uint8_t* d_skip_call = nullptr;
-  if (skip) {
-    ORBG_HIP(hipMemcpyAsync(f->d_q_u8[3].p, skip, m, hipMemcpyHostToDevice, st));
-    d_skip_call = f->d_q_u8[3].p;
-  }
+  const uint8_t* d_skip_call = skip ? stage_add(f, skip, m) : nullptr;
+  if ((rc = stage_commit(f))) return rc;
   hipLaunchKernelGGL(frustum_kernel, dim3((m + 255) / 256), dim3(256), 0, st, f->fp, P, map_dev(mp), 0.5f, map_track(mp));
   hipLaunchKernelGGL(mask_track_kernel, dim3((m + 255) / 256), dim3(256), 0, st, mp->t_in_view.p, mp->bad.p, mp->skip.p, d_skip_call, m);
   MpsDev q;
@@ -986,14 +993,18 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
   const int m = last->n;
   if (nmatches_out) *nmatches_out = 0;
   if (m == 0) return ORBG_OK;
-  if ((rc = ensure_q(f, m))) return rc;
-  if ((rc = upload_assigned(f, assigned_mp, assigned_obs))) return rc;
+  const int n = f->fp.n;
+  if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 12 + 4)))) return rc;
   hipStream_t st = f->stream;
-  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[0].p, last->mp_valid, m, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[1].p, last->outlier, m, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[2].p, last->desc, (size_t)m * 32, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_f32[7].p, last->world_pos, (size_t)m * 12, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_i32[0].p, last->octave, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  f->d_assigned_mp = stage_add(f, assigned_mp, n);
+  f->d_assigned_obs = stage_add(f, assigned_obs, n);
+  LastDev L;
+  L.n = m;
+  L.mp_valid = stage_add(f, last->mp_valid, m); L.outlier = stage_add(f, last->outlier, m);
+  L.desc = stage_add(f, last->desc, (size_t)m * 32);
+  L.world_pos = stage_add(f, last->world_pos, (size_t)m * 3);
+  L.octave = stage_add(f, last->octave, m);
+  if ((rc = stage_commit(f))) return rc;
   PoseF Pc, Pl;
   make_pose(Tcw_cur, &Pc);
   make_pose(last->Tcw, &Pl);
@@ -1005,16 +1016,12 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
   }
   const int forward = tlc[2] > f->fp.b && !mono;
   const int backward = -tlc[2] > f->fp.b && !mono;
-  LastDev L;
-  L.n = m; L.mp_valid = f->d_q_u8[0].p; L.outlier = f->d_q_u8[1].p; L.world_pos = f->d_q_f32[7].p; L.desc = f->d_q_u8[2].p;
-  L.octave = f->d_q_i32[0].p;
   rc = run_search(f, m, [&](int list_cap) {
     hipLaunchKernelGGL(search_frame_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), L, Pc, th, forward, backward,
                        f->d_counter.p, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
   // serial commit (S/ORBmatcher.cc:2041-2091) + rotation consistency (:2164-2183)
-  const int n = f->fp.n;
   std::vector<uint8_t> claimed(std::max(n, 1), 0);
   std::vector<int> rotHist[HISTO_LENGTH];
   int nmatches = 0;
@@ -1040,7 +1047,7 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
       assigned_obs[bestIdx] = last->n_obs[i];
       if (last->n_obs[i] > 0) claimed[bestIdx] = 1;
       nmatches++;
-      if (check_orientation) rotHist[rot_bin(last->angle[i], f->h_kps[bestIdx].angle)].push_back(bestIdx);
+      if (check_orientation) rotHist[rot_bin(last->angle[i], f->hk[bestIdx].angle)].push_back(bestIdx);
     }
   }
   if (check_orientation) {
@@ -1086,14 +1093,15 @@ extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, c
   const int nj = (int)jobs.size();
   if (nj == 0) return ORBG_OK;
   const int nfi = (int)fvF->start[fvF->n_nodes];
-  if ((rc = f->d_jobs.reserve(nj)) || (rc = f->d_fidx.reserve(std::max(nfi, 1))) || (rc = ensure_q(f, nkf))) return rc;
+  if ((rc = stage_begin(f, (size_t)nj * sizeof(BowJob) + (size_t)nfi * 4 + (size_t)nkf * 32))) return rc;
   hipStream_t st = f->stream;
-  ORBG_HIP(hipMemcpyAsync(f->d_jobs.p, jobs.data(), (size_t)nj * sizeof(BowJob), hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_fidx.p, fvF->feat_idx, (size_t)nfi * 4, hipMemcpyHostToDevice, st));
-  ORBG_HIP(hipMemcpyAsync(f->d_q_u8[2].p, kf_desc, (size_t)nkf * 32, hipMemcpyHostToDevice, st));
+  const BowJob* d_jobs = stage_add(f, jobs.data(), nj);
+  const uint32_t* d_fidx = stage_add(f, fvF->feat_idx, nfi);
+  const uint8_t* d_kfdesc = stage_add(f, kf_desc, (size_t)nkf * 32);
+  if ((rc = stage_commit(f))) return rc;
   rc = run_search(f, nj, [&](int list_cap) {
-    hipLaunchKernelGGL(search_bow_kernel, dim3((nj + 3) / 4), dim3(256), 0, st, f->d_desc.p, f->d_fidx.p, f->d_q_u8[2].p,
-                       f->d_jobs.p, nj, f->d_counter.p, f->list.d, list_cap, f->results.d);
+    hipLaunchKernelGGL(search_bow_kernel, dim3((nj + 3) / 4), dim3(256), 0, st, f->desc_p, d_fidx, d_kfdesc,
+                       d_jobs, nj, f->d_counter.p, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
   std::vector<int> rotHist[HISTO_LENGTH];
@@ -1119,7 +1127,7 @@ extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, c
     if (bestDist1 <= TH_LOW) {
       if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
         matches[bestIdxF] = jobs[j].kf_idx;
-        if (check_orientation) rotHist[rot_bin(kf_angle[jobs[j].kf_idx], f->h_kps[bestIdxF].angle)].push_back(bestIdxF);
+        if (check_orientation) rotHist[rot_bin(kf_angle[jobs[j].kf_idx], f->hk[bestIdxF].angle)].push_back(bestIdxF);
         nmatches++;
       }
     }
