@@ -507,45 +507,51 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
   if (lane == 0) { uright[iL] = out_u; depth[iL] = out_d; best_sad[iL] = out_sad; }
 }
 
-// median-of-SAD outlier rejection (:949-962): one workgroup; rank counting gives the element
-// vDistIdx[size/2].first of the sorted list without sorting (SAD values staged in LDS, 128-bit broadcast reads).
-__global__ __launch_bounds__(1024) void stereo_finalize_kernel(float* __restrict__ uright, float* __restrict__ depth,
-                                                              const int* __restrict__ best_sad, int nl) {
-  constexpr int kCap = 8192;
-  __shared__ int4 s_sad4[kCap / 4];
-  __shared__ int s_cnt, s_median;
-  int* s_sad = reinterpret_cast<int*>(s_sad4);
-  if (threadIdx.x == 0) { s_cnt = 0; s_median = -1; }
+// median-of-SAD outlier rejection (:949-962), one 256-thread workgroup: the element vDistIdx[size/2].first of the
+// sorted list is found by a two-level (high byte / low byte) histogram select -- SAD <= 121*510 < 2^16 -- instead
+// of sorting; then every match whose SAD is not below 1.5f*1.4f*median is dropped.
+__global__ __launch_bounds__(256) void stereo_finalize_kernel(float* __restrict__ uright, float* __restrict__ depth,
+                                                             const int* __restrict__ best_sad, int nl) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned wsum[4];
+  __shared__ int s_bin, s_before;
+  const int tid = threadIdx.x;
+  // ---- pass 0: histogram of the high byte -> bin holding the element of rank kth = n/2
+  hist[tid] = 0;
+  if (tid == 0) { s_bin = -1; s_before = 0; }
   __syncthreads();
-  const int npad = min((nl + 3) & ~3, kCap);
-  int local = 0;
-  for (int i = threadIdx.x; i < npad; i += 1024) {
-    const int v = i < nl ? best_sad[i] : -1;
-    s_sad[i] = v;
-    local += v >= 0;
-  }
-  if (local) atomicAdd(&s_cnt, local);
-  __syncthreads();
-  const int n = s_cnt;
-  if (n == 0 || nl > kCap) return;     // nl > kCap cannot happen: the handle caps features well below (orbx_create)
-  const int kth = n / 2;
-  // value v is the kth order statistic iff  #(x < v) <= kth < #(x <= v); invalid entries are -1 and never counted
-  for (int i = threadIdx.x; i < nl; i += 1024) {
-    const int v = s_sad[i];
-    if (v < 0) continue;
-    int lt = 0, le = 0;
-    for (int j = 0; j < npad / 4; j++) {
-      const int4 x = s_sad4[j];
-      lt += ((x.x >= 0) & (x.x < v)) + ((x.y >= 0) & (x.y < v)) + ((x.z >= 0) & (x.z < v)) + ((x.w >= 0) & (x.w < v));
-      le += ((x.x >= 0) & (x.x <= v)) + ((x.y >= 0) & (x.y <= v)) + ((x.z >= 0) & (x.z <= v)) + ((x.w >= 0) & (x.w <= v));
-    }
-    if (lt <= kth && kth < le) s_median = v;     // every writer writes the same value
+  for (int i = tid; i < nl; i += 256) {
+    const int v = best_sad[i];
+    if (v >= 0) atomicAdd(&hist[(v >> 8) & 255], 1u);
   }
   __syncthreads();
-  const float median = (float)s_median;
-  const float thDist = 1.5f * 1.4f * median;
-  for (int i = threadIdx.x; i < nl; i += 1024) {
-    const int v = s_sad[i];
+  unsigned total;
+  unsigned mine = hist[tid];
+  unsigned excl = block_excl_scan_256(mine, &total, wsum);
+  if (total == 0) return;                           // no stereo match at all (uniform exit)
+  const unsigned kth = total / 2;
+  if (excl <= kth && kth < excl + mine) { s_bin = tid; s_before = (int)excl; }
+  __syncthreads();
+  const int hi = s_bin;
+  const unsigned before = (unsigned)s_before;
+  __syncthreads();
+  // ---- pass 1: histogram of the low byte inside that bin
+  hist[tid] = 0;
+  if (tid == 0) s_bin = -1;
+  __syncthreads();
+  for (int i = tid; i < nl; i += 256) {
+    const int v = best_sad[i];
+    if (v >= 0 && (v >> 8) == hi) atomicAdd(&hist[v & 255], 1u);
+  }
+  __syncthreads();
+  mine = hist[tid];
+  excl = block_excl_scan_256(mine, &total, wsum);
+  if (before + excl <= kth && kth < before + excl + mine) s_bin = tid;
+  __syncthreads();
+  const int median = (hi << 8) | s_bin;
+  const float thDist = 1.5f * 1.4f * (float)median;
+  for (int i = tid; i < nl; i += 256) {
+    const int v = best_sad[i];
     if (v >= 0 && !((float)v < thDist)) { uright[i] = -1; depth[i] = -1; }
   }
 }
@@ -1220,7 +1226,7 @@ extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* urigh
   if (nl > 0) {
     hipLaunchKernelGGL(stereo_match_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, h->d_pyr.p, h->geom, h->d_kps.p, h->d_desc.p,
                        nl, h->d_kps.p + nl, h->d_desc.p + (size_t)nl * 32, nr, bf, b, h->d_uright.p, h->d_depth.p, h->d_sad.p);
-    hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(1024), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl);
+    hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(256), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl);
   }
   ORBG_HIP(hipEventRecord(h->ev[6], st));
   if (nl > 0 && (uright || depth)) {

@@ -53,25 +53,31 @@ __host__ __device__ inline void quat_to_R(const double* q, double* R) {
 }
 
 __host__ __device__ inline void quat_from_R(const double* m, double* q) {
+  // Eigen::Quaterniond(Matrix3d); the three "largest diagonal" cases are spelled out so that no local array is
+  // indexed at run time (which would put it in scratch memory on the GPU)
   double t = m[0] + m[4] + m[8];
   if (t > 0) {
     t = sqrt(t + 1.0);
     q[3] = 0.5 * t;
     t = 0.5 / t;
     q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
-  } else {
-    int i = 0;
-    if (m[4] > m[0]) i = 1;
-    if (m[8] > m[4 * i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
-    double v[3];
-    v[i] = 0.5 * t;
-    t = 0.5 / t;
-    q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
-    v[j] = (m[3 * j + i] + m[3 * i + j]) * t;
-    v[k] = (m[3 * k + i] + m[3 * i + k]) * t;
-    q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+    return;
+  }
+  int i = 0;
+  if (m[4] > m[0]) i = 1;
+  if (m[8] > (i == 0 ? m[0] : m[4])) i = 2;
+  if (i == 0) {          // j = 1, k = 2
+    t = sqrt(m[0] - m[4] - m[8] + 1.0);
+    q[0] = 0.5 * t; t = 0.5 / t;
+    q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+  } else if (i == 1) {   // j = 2, k = 0
+    t = sqrt(m[4] - m[8] - m[0] + 1.0);
+    q[1] = 0.5 * t; t = 0.5 / t;
+    q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+  } else {               // j = 0, k = 1
+    t = sqrt(m[8] - m[0] - m[4] + 1.0);
+    q[2] = 0.5 * t; t = 0.5 / t;
+    q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
   }
 }
 
@@ -196,14 +202,21 @@ __device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double
   const double iz = 1.0 / z, iz2 = iz * iz;     // one division per edge; the reference divides term by term (<= 2 ulp apart)
   if (mono) {
     const double J[6] = {-(c.fx * iz), -0.0, c.fx * x * iz2, -0.0, -(c.fy * iz), c.fy * y * iz2};
+#pragma unroll
     for (int i = 0; i < 2; i++)
+#pragma unroll
       for (int j = 0; j < 3; j++) A[3 * i + j] = J[3 * i] * R[j] + J[3 * i + 1] * R[3 + j] + J[3 * i + 2] * R[6 + j];
     const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+#pragma unroll
     for (int i = 0; i < 2; i++)
+#pragma unroll
       for (int j = 0; j < 6; j++) B[6 * i + j] = J[3 * i] * S[j] + J[3 * i + 1] * S[6 + j] + J[3 * i + 2] * S[12 + j];
+#pragma unroll
     for (int j = 0; j < 3; j++) A[6 + j] = 0;
+#pragma unroll
     for (int j = 0; j < 6; j++) B[12 + j] = 0;
   } else {
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       A[j] = -c.fx * R[j] * iz + c.fx * x * R[6 + j] * iz2;
       A[3 + j] = -c.fy * R[3 + j] * iz + c.fy * y * R[6 + j] * iz2;
@@ -237,25 +250,36 @@ __global__ __launch_bounds__(256) void k_linearize(int n_edges, const lba_edge* 
     huber(chi2[k], mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
     const double om = (double)e.inv_sigma2;
     const double wom = rho1 * om;
+    // rows >= D of A/B/omega_r are exact zeros for monocular edges, so every loop runs a constant 3 rows and
+    // unrolls completely (no run-time indexed local arrays => no scratch memory)
     double omega_r[3];
+#pragma unroll
     for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * err[3 * (size_t)k + i]) * rho1 : 0.0;
     const bool pf = pose_col[e.pose] >= 0, lf = point_col[e.point] >= 0;
+#pragma unroll
     for (int a = 0; a < 6; a++)          // Hpl = B^T (w Omega) A   (6x3)
+#pragma unroll
       for (int cidx = 0; cidx < 3; cidx++) {
         double h = 0;
-        for (int i = 0; i < D; i++) h += B[6 * i + a] * wom * A[3 * i + cidx];
+#pragma unroll
+        for (int i = 0; i < 3; i++) h += B[6 * i + a] * wom * A[3 * i + cidx];
         out[3 * a + cidx] = (pf && lf) ? h : 0.0;
       }
     int o = 18;
+#pragma unroll
     for (int a = 0; a < 3; a++)
+#pragma unroll
       for (int b2 = a; b2 < 3; b2++) {
         double h = 0;
-        for (int i = 0; i < D; i++) h += A[3 * i + a] * wom * A[3 * i + b2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) h += A[3 * i + a] * wom * A[3 * i + b2];
         out[o++] = lf ? h : 0.0;
       }
+#pragma unroll
     for (int a = 0; a < 3; a++) {
       double sacc = 0;
-      for (int i = 0; i < D; i++) sacc += A[3 * i + a] * omega_r[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) sacc += A[3 * i + a] * omega_r[i];
       out[o++] = lf ? sacc : 0.0;
     }
   }
@@ -292,19 +316,24 @@ __global__ __launch_bounds__(256) void k_lin_poses(const int* __restrict__ ps_st
     huber(chi2[k], mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
     const double om = (double)e.inv_sigma2;
     const double wom = rho1 * om;
+    double omega_r[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * err[3 * (size_t)k + i]) * rho1 : 0.0;
     int o = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
       for (int b2 = a; b2 < 6; b2++) {
         double h = 0;
-        for (int i = 0; i < D; i++) h += B[6 * i + a] * wom * B[6 * i + b2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) h += B[6 * i + a] * wom * B[6 * i + b2];
         acc[o++] += h;
       }
 #pragma unroll
     for (int a = 0; a < 6; a++) {
       double sacc = 0;
-      for (int i = 0; i < D; i++) sacc += B[6 * i + a] * (-(om * err[3 * (size_t)k + i]) * rho1);
+#pragma unroll
+      for (int i = 0; i < 3; i++) sacc += B[6 * i + a] * omega_r[i];
       acc[o++] += sacc;
     }
   }
@@ -683,9 +712,16 @@ __global__ __launch_bounds__(256) void k_finish(int n_partial, const double* __r
                                                const double* __restrict__ Hpp, const double* __restrict__ Hll, double lambda,
                                                const int* __restrict__ ok_flag, int want_scale, int want_maxdiag, HostRec* __restrict__ rec) {
   __shared__ double red[256];
+  __shared__ double parts[1024];
   const int tid = threadIdx.x;
+  // all partials are fetched in parallel (one memory latency), then summed by one thread in a fixed order
+  for (int i = tid; i < n_partial && i < 1024; i += 256) parts[i] = partial[i];
+  __syncthreads();
   double chi = 0;
-  if (tid == 0) for (int i = 0; i < n_partial; i++) chi += partial[i];
+  if (tid == 0) {
+    for (int i = 0; i < n_partial && i < 1024; i++) chi += parts[i];
+    for (int i = 1024; i < n_partial; i++) chi += partial[i];
+  }
   double sc = 0;
   if (want_scale) {
     const int n6 = 6 * nP, n3 = 3 * nL;
