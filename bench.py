@@ -128,18 +128,13 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     from multi_orbslam3_amd import _capi as capi
-    from multi_orbslam3_amd import api, synth, views
+    from multi_orbslam3_amd import api, harness, synth, views
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    grp = harness.AgentGroup("nccl")
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     device = local_rank
     torch.cuda.set_device(device)
 
@@ -230,21 +225,13 @@ def main():
     for i in range(args.warmup):
         step(i, False)
     lba_q.join()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, True)
-    lba_q.join()                                       # every LBA triggered inside the timed region has finished
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def sync():
+        lba_q.join()                                   # every LBA triggered inside the timed region has finished
+        torch.cuda.synchronize()
+
+    # barrier + synchronize, exactly K steps, synchronize + barrier, MAX over ranks (harness.AgentGroup.timed)
+    elapsed = grp.timed(lambda i: step(args.warmup + i, True), args.steps, sync)
     if rank == 0:
         K = args.steps
         ms_per_step = 1e3 * elapsed / K
@@ -280,8 +267,7 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, synth, views)
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

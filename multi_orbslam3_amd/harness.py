@@ -1,0 +1,68 @@
+"""Multi-agent harness: one process per GPU / agent, no data-path collective.
+
+`torch.distributed` is only the control plane here: a barrier on both sides of the timed region and the MAX over
+ranks of the elapsed time.  backend "nccl" is RCCL on ROCm; the CPU tests use "gloo".
+"""
+import os
+import time
+
+
+class AgentGroup:
+    def __init__(self, backend=None, device_index=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.backend = backend
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            self.backend = backend
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", self.local_rank if device_index is None else device_index)
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            self.dist = dist
+
+    def agent_seed(self, base):
+        """Agents are independent clients: distinct seeds, no shared state."""
+        return base + self.rank
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, steps, sync=None):
+        """barrier + sync, exactly `steps` calls of fn(i), sync + barrier; returns MAX-over-ranks seconds."""
+        self.barrier()
+        if sync:
+            sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        if sync:
+            sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def aggregate_rate(self, steps, seconds):
+        """Whole-job throughput: every rank did `steps` units in the (max) time."""
+        return self.world * steps / seconds
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None

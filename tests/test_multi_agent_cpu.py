@@ -1,0 +1,65 @@
+"""N>1 path of the harness on CPU: 2 gloo ranks (world_size 2).  Agents are independent units -- one process per
+agent, no data-path collective; torch.distributed only provides the barriers and the MAX over
+ranks of the elapsed time.  The per-agent work here is the CPU oracle on a tiny image (the HIP path needs a GPU)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import json, os, sys, time, hashlib
+    sys.path.insert(0, %r)
+    import numpy as np
+    from multi_orbslam3_amd import harness, synth
+    from oracle import binding as ob
+    grp = harness.AgentGroup("gloo")
+    seed = grp.agent_seed(synth.SEED_IMAGES)
+    sc = synth.Scene(160, 120, seed=seed, tex_size=(400, 300), px_per_m=50.0)
+    ex = ob.Extractor(n_features=200, n_levels=4, max_width=160, max_height=120)
+    imgs = [sc.stereo_pair(k)[0] for k in range(3)]
+    digest = hashlib.sha256()
+    def step(i):
+        rc, k, d, _ = ex.extract(imgs[i %% 3])
+        digest.update(k.tobytes()); digest.update(d.tobytes())
+        if grp.rank == 1:
+            time.sleep(0.02)          # a slower agent: the job time must be the MAX over ranks
+    elapsed = grp.timed(step, 6)
+    out = dict(rank=grp.rank, world=grp.world, seed=seed, elapsed=elapsed, rate=grp.aggregate_rate(6, elapsed),
+               digest=digest.hexdigest())
+    print("RESULT " + json.dumps(out), flush=True)
+    grp.close()
+''') % ROOT
+
+
+def _run_ranks(world, port):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=240)
+        assert p.returncode == 0, se[-2000:]
+        line = [l for l in so.splitlines() if l.startswith("RESULT ")][-1]
+        outs.append(json.loads(line[7:]))
+    return sorted(outs, key=lambda o: o["rank"])
+
+
+def test_two_agents_gloo_no_cross_talk_and_max_time():
+    two = _run_ranks(2, 29611)
+    assert [o["world"] for o in two] == [2, 2]
+    assert two[0]["seed"] != two[1]["seed"] and two[0]["digest"] != two[1]["digest"]      # distinct agents
+    # both ranks report the same job time (MAX over ranks) and it includes the slow agent's sleeps
+    assert abs(two[0]["elapsed"] - two[1]["elapsed"]) < 1e-9
+    assert two[0]["elapsed"] >= 6 * 0.02
+    assert abs(two[0]["rate"] - 2 * 6 / two[0]["elapsed"]) < 1e-9                         # whole-job aggregate
+    # an agent's outputs do not depend on how many other agents run: rank 0 alone == rank 0 of the pair
+    one = _run_ranks(1, 29612)
+    assert one[0]["world"] == 1 and one[0]["digest"] == two[0]["digest"]

@@ -1,0 +1,305 @@
+"""First-principles checks that pin the oracle's matcher / stereo / LBA restatement.
+Independent (slow, straightforward) Python models are compared with the C++ oracle on small seeded inputs."""
+import numpy as np
+import pytest
+
+from multi_orbslam3_amd import _capi as capi
+from multi_orbslam3_amd import synth, views
+from oracle import binding as ob
+import helpers
+
+
+# ---------------------------------------------------------------- grid / GetFeaturesInArea / isInFrustum
+def _scales(n=8, sf=1.2):
+    s = [np.float32(1.0)]
+    for _ in range(1, n):
+        s.append(np.float32(s[-1] * np.float32(sf)))
+    return np.array(s, np.float32)
+
+
+def test_grid_matches_round_assignment(small_scene):
+    fr = helpers.oracle_stereo_frame(small_scene, 0, 500)
+    fv, keep = helpers.frame_view_of(small_scene, fr)
+    start, items = ob.build_grid(fv)
+    W, H = small_scene.W, small_scene.H
+    winv, hinv = np.float32(64) / np.float32(W), np.float32(48) / np.float32(H)
+    cells = {}
+    for i, kp in enumerate(fr["kps"]):
+        px = int(np.floor(np.float32(kp["x"] * winv) + np.float32(0.5)))      # round() for non-negative values
+        py = int(np.floor(np.float32(kp["y"] * hinv) + np.float32(0.5)))
+        if 0 <= px < 64 and 0 <= py < 48:
+            cells.setdefault(px * 48 + py, []).append(i)
+    for c in range(64 * 48):
+        assert list(items[start[c]:start[c + 1]]) == cells.get(c, [])
+    assert start[-1] == sum(len(v) for v in cells.values())
+
+
+def test_features_in_area_bruteforce(small_scene):
+    fr = helpers.oracle_stereo_frame(small_scene, 1, 500)
+    fv, keep = helpers.frame_view_of(small_scene, fr)
+    rng = np.random.RandomState(0)
+    k = fr["kps"]
+    for _ in range(60):
+        x, y = np.float32(rng.uniform(-20, small_scene.W + 20)), np.float32(rng.uniform(-20, small_scene.H + 20))
+        r = np.float32(rng.uniform(2, 60))
+        lo, hi = rng.choice([-1, 0, 2, 4]), rng.choice([-1, 3, 7])
+        got = set(ob.features_in_area(fv, x, y, r, int(lo), int(hi)).tolist())
+        check = (lo > 0) or (hi >= 0)
+        exp = set()
+        for i in range(len(k)):
+            if check and (k["octave"][i] < lo or (hi >= 0 and k["octave"][i] > hi)):
+                continue
+            if abs(np.float32(k["x"][i] - x)) < r and abs(np.float32(k["y"][i] - y)) < r:
+                exp.add(i)
+        # the grid query can only MISS features whose (rounded) cell lies outside the floor/ceil cell window
+        assert got <= exp
+        assert len(exp - got) <= max(2, len(exp) // 10)
+
+
+def test_is_in_frustum_against_float64_model(small_scene):
+    fr = helpers.oracle_stereo_frame(small_scene, 0, 500)
+    fv, keep = helpers.frame_view_of(small_scene, fr)
+    mp = helpers.local_map_from(small_scene, [fr])
+    wv, keep2 = helpers.world_view_of(mp)
+    T = small_scene.pose(2)
+    o = ob.is_in_frustum(fv, T.astype(np.float32), wv)
+    cam = small_scene.cam
+    R, t = T[:3, :3], T[:3, 3]
+    Pc = mp["pos"].astype(np.float64) @ R.T + t
+    u = float(cam["fx"]) * Pc[:, 0] / Pc[:, 2] + float(cam["cx"])
+    v = float(cam["fy"]) * Pc[:, 1] / Pc[:, 2] + float(cam["cy"])
+    vis = o["track_in_view"] > 0
+    assert vis.sum() > 50
+    assert np.abs(o["proj_x"][vis] - u[vis]).max() < 1e-2 and np.abs(o["proj_y"][vis] - v[vis]).max() < 1e-2
+    assert np.abs(o["proj_xr"][vis] - (u[vis] - float(cam["bf"]) / Pc[vis, 2])).max() < 1e-2
+    Ow = -R.T @ t
+    dist = np.linalg.norm(mp["pos"] - Ow, axis=1)
+    lvl = np.clip(np.ceil(np.log(mp["max_dist"] / dist) / np.log(1.2)), 0, 7)
+    assert (np.abs(o["scale_level"][vis] - lvl[vis]) <= 1).all() and (o["scale_level"][vis] == lvl[vis]).mean() > 0.98
+    inside = (Pc[:, 2] > 0) & (u >= 0) & (u <= small_scene.W) & (v >= 0) & (v <= small_scene.H)
+    assert not (vis & ~inside).any()
+
+
+# ---------------------------------------------------------------- matchers vs straightforward Python loops
+def _py_search_mps(fv_np, mv_np, th, nnratio, amp, aob, scales):
+    """Direct transliteration of the reference loop semantics in Python over an explicit candidate enumerator."""
+    kps, desc, uright, fvs = fv_np
+    amp, aob = amp.copy(), aob.copy()
+    nm = 0
+    for i in range(len(mv_np["track_in_view"])):
+        if not mv_np["track_in_view"][i] or mv_np["bad"][i]:
+            continue
+        lvl = int(mv_np["scale_level"][i])
+        r = np.float32(2.5) if np.float64(mv_np["view_cos"][i]) > 0.998 else np.float32(4.0)
+        if th != 1.0:
+            r = np.float32(r * np.float32(th))
+        rr = np.float32(r * scales[lvl])
+        cand = ob.features_in_area(fvs, mv_np["proj_x"][i], mv_np["proj_y"][i], rr, lvl - 1, lvl)
+        best, best2, bl, bl2, bi = 256, 256, -1, -1, -1
+        for idx in cand:
+            if amp[idx] >= 0 and aob[idx] > 0:
+                continue
+            if uright[idx] > 0 and abs(np.float32(mv_np["proj_xr"][i] - uright[idx])) > rr:
+                continue
+            d = int(np.unpackbits(mv_np["desc"][i] ^ desc[idx]).sum())
+            if d < best:
+                best2, bl2, best, bl, bi = best, bl, d, int(kps["octave"][idx]), idx
+            elif d < best2:
+                bl2, best2 = int(kps["octave"][idx]), d
+        if best <= 100:
+            if bl == bl2 and best > np.float32(nnratio) * np.float32(best2):
+                continue
+            amp[bi] = i; aob[bi] = mv_np["n_obs"][i]; nm += 1
+    return amp, aob, nm
+
+
+@pytest.mark.parametrize("th", [1.0, 5.0])
+def test_search_by_projection_mps_vs_python(small_scene, th):
+    rng = np.random.RandomState(3)
+    f0, f1 = helpers.oracle_stereo_frame(small_scene, 0, 400), helpers.oracle_stereo_frame(small_scene, 3, 400)
+    mp = helpers.local_map_from(small_scene, [f0], rng)
+    fv, keep = helpers.frame_view_of(small_scene, f1)
+    wv, keep2 = helpers.world_view_of(mp)
+    T = synth.perturb_pose(f1["Tcw"], rng).astype(np.float32)
+    tr = ob.is_in_frustum(fv, T, wv)
+    mvd = dict(tr, bad=mp["bad"], desc=mp["desc"], n_obs=mp["n_obs"])
+    mv, keep3 = views.mappoints_view(tr["track_in_view"], mp["bad"], tr["proj_x"], tr["proj_y"], tr["proj_xr"], tr["track_depth"],
+                                     tr["scale_level"], tr["view_cos"], mp["desc"], mp["n_obs"])
+    n = len(f1["kps"])
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    amp0[::7] = 3; aob0[::7] = rng.randint(0, 2, len(amp0[::7]))
+    o = ob.search_by_projection_mps(fv, mv, th, False, 0.0, 0.8, amp0, aob0)
+    p = _py_search_mps((f1["kps"], f1["desc"], f1["uright"], fv), mvd, th, 0.8, amp0, aob0, _scales())
+    assert o[2] == p[2] and o[2] > 20
+    assert np.array_equal(o[0], p[0]) and np.array_equal(o[1], p[1])
+
+
+def test_search_frame_orientation_filter_is_a_subset(small_scene):
+    rng = np.random.RandomState(5)
+    last, cur = helpers.oracle_stereo_frame(small_scene, 4, 400), helpers.oracle_stereo_frame(small_scene, 5, 400)
+    fv, keep = helpers.frame_view_of(small_scene, cur)
+    lv, keep2 = helpers.make_lastframe(small_scene, last, rng)
+    T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+    n = len(cur["kps"])
+    a0, b0 = np.full(n, -1, np.int32), np.zeros(n, np.int32)
+    with_ori = ob.search_by_projection_frame(fv, T, lv, 7.0, False, True, a0, b0)
+    no_ori = ob.search_by_projection_frame(fv, T, lv, 7.0, False, False, a0, b0)
+    assert 0 < with_ori[2] <= no_ori[2]
+    kept = with_ori[0] >= 0
+    assert np.array_equal(with_ori[0][kept], no_ori[0][kept])
+    # matched pairs are true correspondences: world point of the last-frame feature reprojects near the matched keypoint
+    idx = np.nonzero(kept)[0]
+    assert (np.abs(cur["kps"]["octave"][idx] - last["kps"]["octave"][with_ori[0][idx]]) <= 1).all()
+
+
+def test_search_by_bow_vs_python(small_scene):
+    kf, cur = helpers.oracle_stereo_frame(small_scene, 2, 400), helpers.oracle_stereo_frame(small_scene, 3, 400)
+    fv, keep = helpers.frame_view_of(small_scene, cur)
+    node = lambda d: (d[:, 0].astype(np.int64) >> 4)
+    nF, sF, iF = views.featvec_from_nodes(node(cur["desc"]))
+    nK, sK, iK = views.featvec_from_nodes(node(kf["desc"]))
+    fvF, k1 = views.featvec_view(nF, sF, iF)
+    fvK, k2 = views.featvec_view(nK, sK, iK)
+    valid = (kf["depth"] > 0).astype(np.uint8)
+    o = ob.search_by_bow(fv, fvF, kf["desc"], valid, kf["kps"]["angle"], fvK, 0.7, False)
+    matches = np.full(len(cur["kps"]), -1, np.int32)
+    nm = 0
+    for a, nid in enumerate(nK):
+        w = np.nonzero(nF == nid)[0]
+        if len(w) == 0:
+            continue
+        b = w[0]
+        for kfi in iK[sK[a]:sK[a + 1]]:
+            if not valid[kfi]:
+                continue
+            best, best2, bi = 256, 256, -1
+            for fi in iF[sF[b]:sF[b + 1]]:
+                if matches[fi] >= 0:
+                    continue
+                d = int(np.unpackbits(kf["desc"][kfi] ^ cur["desc"][fi]).sum())
+                if d < best:
+                    best2, best, bi = best, d, fi
+                elif d < best2:
+                    best2 = d
+            if best <= 50 and np.float32(best) < np.float32(0.7) * np.float32(best2):
+                matches[bi] = kfi; nm += 1
+    assert nm == o[1] and nm > 10 and np.array_equal(matches, o[0])
+
+
+def test_stereo_match_recovers_plane_depth(small_scene):
+    fr = helpers.oracle_stereo_frame(small_scene, 0, 500)
+    ok = fr["uright"] > 0
+    assert ok.sum() > 100
+    disp = fr["kps"]["x"][ok] - fr["uright"][ok]
+    assert (disp > 0).all() and np.allclose(fr["depth"][ok], float(small_scene.cam["bf"]) / disp, rtol=1e-6)
+    Pw, valid = synth.unproject_to_world(fr["kps"], fr["depth"], fr["Tcw"], small_scene.cam)
+    assert np.median(np.abs(Pw[ok][:, 2])) < 0.35          # the scene is the plane z = 0 (7-px disparities at 320x240)
+
+
+# ---------------------------------------------------------------- D-8 SE3 exp, D-7 LBA
+def _quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def test_se3_exp_against_rodrigues_and_small_angle_branch():
+    from scipy.spatial.transform import Rotation
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        u = rng.randn(6) * 0.3
+        q, t = ob.se3_exp(u)
+        assert abs(np.linalg.norm(q) - 1) < 1e-14 and q[3] >= 0
+        assert np.allclose(_quat_to_R(q), Rotation.from_rotvec(u[:3]).as_matrix(), atol=1e-13)
+        th = np.linalg.norm(u[:3]); K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+        assert np.allclose(t, V @ u[3:], atol=1e-13)
+    for th in (0.9e-5, 1.1e-5):                     # both sides of the theta < 1e-5 branch agree to O(theta^2)
+        u = np.array([th, 0, 0, 0.1, 0.2, 0.3])
+        q, t = ob.se3_exp(u)
+        assert np.allclose(_quat_to_R(q), Rotation.from_rotvec(u[:3]).as_matrix(), atol=1e-9)
+        assert np.allclose(t, u[3:], atol=1e-5)
+    q, t = ob.se3_exp(np.zeros(6))
+    assert np.allclose(q, [0, 0, 0, 1]) and np.allclose(t, 0)
+
+
+def _compose(dq, dt, q, t):
+    """exp(d) * T in numpy (quaternion x,y,z,w)."""
+    R = _quat_to_R(dq)
+    x1, y1, z1, w1 = dq; x2, y2, z2, w2 = q
+    qq = np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2,
+                   w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
+    return qq / np.linalg.norm(qq), dt + R @ t
+
+
+@pytest.mark.parametrize("stereo", [True, False])
+def test_analytic_jacobians_match_central_differences(stereo):
+    rng = np.random.RandomState(1)
+    cam = np.array([390.3, 390.3, 320, 240, 40.77], np.float32)
+    q, t = ob.se3_exp(rng.randn(6) * 0.2)
+    X = np.array([0.3, -0.2, 4.0]) + rng.randn(3) * 0.1
+    e = np.zeros(1, capi.EDGE_DTYPE)
+    e[0] = (0, 0, 321.5, 238.25, 310.0 if stereo else -1.0, 0.69)
+    err, A, B = ob.lba_edge_eval(q, t, X, cam, e)
+    D = 3 if stereo else 2
+    # the stereo error evaluates 1/z in float32 (types_six_dof_expmap.cpp:191): its quantisation (~6e-8 relative)
+    # forces a larger step and a looser tolerance than the all-double monocular edge
+    h = 1e-3 if stereo else 1e-6
+    tol = 5e-4 if stereo else 1e-6
+    for j in range(3):
+        d = np.zeros(3); d[j] = h
+        ep, _, _ = ob.lba_edge_eval(q, t, X + d, cam, e)
+        em, _, _ = ob.lba_edge_eval(q, t, X - d, cam, e)
+        assert np.allclose((ep - em)[:D] / (2 * h), A[:D, j], atol=tol * max(1, np.abs(A).max()))
+    for j in range(6):
+        d = np.zeros(6); d[j] = h
+        qp, tp = _compose(*ob.se3_exp(d), q, t)
+        qm, tm = _compose(*ob.se3_exp(-d), q, t)
+        ep, _, _ = ob.lba_edge_eval(qp, tp, X, cam, e)
+        em, _, _ = ob.lba_edge_eval(qm, tm, X, cam, e)
+        assert np.allclose((ep - em)[:D] / (2 * h), B[:D, j], atol=tol * max(1, np.abs(B).max()))
+
+
+def test_lba_noise_free_converges_and_monotone():
+    prob = synth.make_lba_problem(n_free=2, n_fixed=2, n_points=8, outlier_frac=0.0, min_obs=4, max_obs=4, seed=7)
+    # rebuild noise-free observations from the true geometry
+    fx, fy, cx, cy, bf = prob["cam"]
+    E = prob["edges"].copy()
+    for k, ed in enumerate(E):
+        T = prob["poses_true"][ed["pose"]]
+        Xc = T[:3, :3] @ prob["points_true"][ed["point"]] + T[:3, 3]
+        u = fx * Xc[0] / Xc[2] + cx
+        E[k]["u"] = u; E[k]["v"] = fy * Xc[1] / Xc[2] + cy; E[k]["ur"] = u - bf / Xc[2]
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], E, prob["cam"])
+    o = ob.lba_solve(p)
+    assert o.status == capi.LBA_APPLIED
+    tr = o.trace_rows()
+    assert (np.diff(tr[:, 1]) <= 1e-9).all()                  # chi2 never increases across accepted iterations
+    assert o.chi2[1] < 1e-3 * o.chi2[0] and o.chi2[1] < 0.05
+    assert o.n_outliers == 0
+    Tt = prob["poses_true"].reshape(-1, 16)
+    free = prob["pose_fixed"] == 0
+    assert np.abs(o.poses[free] - Tt[free]).max() < 5e-3
+    assert np.allclose(o.poses[~free], prob["poses"][~free].reshape(-1, 16), atol=1e-6)   # fixed poses: R->q->R round trip only
+
+
+def test_lba_huber_boundary_and_statuses():
+    prob = synth.make_lba_problem(n_free=3, n_fixed=2, n_points=40, seed=11)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    o = ob.lba_solve(p)
+    thr = np.where(prob["edges"]["ur"] < 0, 5.991, 7.815)
+    assert np.array_equal(o.edge_outlier.astype(bool), (o.edge_chi2 > thr) | (o.edge_depth_pos == 0))
+    stop = np.ones(1, np.int32)
+    o2 = ob.lba_solve(p, stop)
+    assert o2.status == capi.LBA_ABORTED_BEFORE_OPT and np.array_equal(o2.poses, prob["poses"])
+    bad = synth.make_lba_problem(n_free=3, n_fixed=2, n_points=40, outlier_frac=0.95, seed=11)
+    p3, keep3 = views.lba_problem(bad["poses"], bad["pose_fixed"], bad["points"], bad["edges"], bad["cam"])
+    assert ob.lba_solve(p3).status == capi.LBA_REJECTED_OUTLIERS
+    # a point without any free observer and a pose without edges stay untouched and do not break the solve
+    prob2 = synth.make_lba_problem(n_free=3, n_fixed=2, n_points=40, seed=11)
+    poses = np.concatenate([prob2["poses"], prob2["poses"][-1:]])          # extra free pose, no edges
+    fixed = np.concatenate([prob2["pose_fixed"], [0]]).astype(np.uint8)
+    p4, keep4 = views.lba_problem(poses, fixed, prob2["points"], prob2["edges"], prob2["cam"])
+    o4 = ob.lba_solve(p4)
+    assert o4.status == capi.LBA_APPLIED and np.allclose(o4.poses[-1], poses[-1], atol=1e-6)   # R->q->R round trip only
