@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic stereo frames (ping-pong sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-stages", action="store_true",
+                    help="bracket every extractor stage with HIP events (more API calls per frame); by default only "
+                         "fast_cells_kernel (the roofline kernel) is bracketed")
     ap.add_argument("--lba-mode", choices=["thread", "inline"], default="thread",
                     help="thread: LBA runs on its own host thread + HIP stream concurrently with tracking, as the reference's "
                          "LocalMapping thread does (S/ClientSystem.cc:105-106); inline: LBA blocks the frame loop")
@@ -154,7 +157,10 @@ def main():
     nF = len(frames)
     seq = list(range(nF)) + list(range(nF - 2, 0, -1))             # ping-pong: consecutive frames stay adjacent
     stage = dict(extract=0.0, stereo=0.0, grid=0.0, match_frame=0.0, match_map=0.0, lba=0.0, map_upload=0.0)
-    kern = dict(pyramid_ms=0.0, fast_kernel_ms=0.0, fast_ms=0.0, desc_ms=0.0, stereo_ms=0.0, octree_host_ms=0.0)
+    ex.set_profiling(2 if args.profile_stages else 1)
+    kern = dict(fast_kernel_ms=0.0, octree_host_ms=0.0)
+    if args.profile_stages:
+        kern.update(pyramid_ms=0.0, fast_ms=0.0, desc_ms=0.0, stereo_ms=0.0)
     stats = dict(kp=0, stereo=0, m_frame=0, m_map=0, lba_iters=0, lba_calls=0, lba_s=0.0)
 
     import queue

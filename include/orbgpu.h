@@ -300,7 +300,11 @@ int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile int32_t* sto
 const char* orbg_version(void);
 const char* orbg_strerror(int code);
 int orbg_device_count(void);
-/* Last per-stage device timings (ms, hipEvent) of a handle's most recent call, for bench.py. */
+/* Device timings (ms, hipEvent on the handle's stream) of the most recent call, for bench.py.
+ * ms[0] pyramid, [1] FAST+gather, [2] host quad-trees (wall), [3] orientation+descriptors, [4] stereo match,
+ * [5] fast_cells_kernel alone.  orbx_set_profiling: 0 = record nothing, 1 = only [2] and [5] (default),
+ * 2 = every stage (more hipEventRecord calls per frame). */
+int orbx_set_profiling(orbx_handle* h, int level);
 int orbx_get_timings(orbx_handle* h, float* ms /*8*/);
 
 #ifdef __cplusplus

@@ -98,7 +98,7 @@ EXPORTED_SYMBOLS = [
     "orbm_search_by_projection_mps", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
     "orbm_search_local_points", "orbm_search_by_projection_frame", "orbm_search_by_bow",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h",
-    "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings",
+    "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_set_profiling",
 ]
 
 _lib = None

@@ -131,6 +131,9 @@ class ORBextractor:
             return ur[:n_left], dp[:n_left]
         return ur, dp
 
+    def set_profiling(self, level):
+        capi.check(self.lib.orbx_set_profiling(self.h, int(level)))
+
     def timings(self):
         t = np.zeros(8, np.float32)
         capi.check(self.lib.orbx_get_timings(self.h, _vp(t)))

@@ -170,7 +170,16 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restri
   __shared__ uint8_t tile[kTile * kTileStride];
   __shared__ uint8_t score[(kTile + 2) * kTileStride];   // +1 apron of zeros all around the detection area
   __shared__ unsigned wsum[4];
-  const int cell = blockIdx.x, cam = blockIdx.y;
+  // XCD-aware block -> cell map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD), so
+  // XCD k is given a CONTIGUOUS run of cells: neighbouring cells (which share a 6-px halo and cache lines) hit the
+  // same XCD's L2 instead of eight different ones.  Placement only affects speed, never results.
+  const int cam = blockIdx.y;
+  int cell;
+  {
+    const int b = blockIdx.x, per = (n_cells + 7) >> 3;
+    cell = (b & 7) * per + (b >> 3);
+    if (cell >= n_cells || (b >> 3) >= per) return;      // grid is rounded up to 8 * per
+  }
   const CellRec c = cells[cell];
   const LevelGeom L = g.lv[c.level];
   const uint8_t* src = pyr + (size_t)cam * g.cam_stride + L.off + (size_t)(kEdge + c.y0) * L.stride + (kEdge + c.x0);
@@ -184,8 +193,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restri
   __syncthreads();
   const int wd = cw - 6, hd = ch - 6;       // detection area [3,cw-3) x [3,ch-3)
   const int npix = wd > 0 && hd > 0 ? wd * hd : 0;
-  for (int p = threadIdx.x; p < npix; p += 256) {
-    const int y = p / wd, x = p - y * wd;
+  // (x, y) of pixel p advance incrementally: one integer division per thread instead of one per pixel
+  const int wdiv = max(wd, 1);
+  const int step_y = 256 / wdiv, step_x = 256 - step_y * wdiv;
+  int y = (int)threadIdx.x / wdiv, x = (int)threadIdx.x - y * wdiv;
+  for (int p = threadIdx.x; p < npix; p += 256, x += step_x, y += step_y) {
+    if (x >= wd) { x -= wd; y++; }
     const uint8_t* q = &tile[(y + 3) * kTileStride + (x + 3)];
     const int v = q[0];
     int d[16];
@@ -208,8 +221,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restri
   const int K = (npix + 255) >> 8;
   const int p0 = threadIdx.x * K, p1 = min(p0 + K, npix);
   unsigned keep_ini = 0, keep_min = 0;
-  for (int p = p0; p < p1; p++) {
-    const int y = p / wd, x = p - y * wd;
+  const int y0 = p0 / wdiv, x0 = p0 - y0 * wdiv;
+  y = y0; x = x0;
+  for (int p = p0; p < p1; p++, x++) {
+    if (x >= wd) { x = 0; y++; }
     const uint8_t* s = &score[(y + 1) * kTileStride + (x + 1)];
     const int v = s[0];
     if (v >= min_th) {
@@ -231,10 +246,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restri
   while (mask) {
     const int b = __ffs(mask) - 1;
     mask &= mask - 1;
-    const int p = p0 + b;
-    const int y = p / wd, x = p - y * wd;
-    const unsigned sc = score[(y + 1) * kTileStride + (x + 1)];
-    out[pos++] = (unsigned)(x + 3 + c.offx) | ((unsigned)(y + 3 + c.offy) << 12) | (sc << 24);
+    int xx = x0 + b, yy = y0;
+    while (xx >= wd) { xx -= wd; yy++; }
+    const unsigned sc = score[(yy + 1) * kTileStride + (xx + 1)];
+    out[pos++] = (unsigned)(xx + 3 + c.offx) | ((unsigned)(yy + 3 + c.offy) << 12) | (sc << 24);
   }
   if (threadIdx.x == 0) counts[cam * n_cells + cell] = use_min ? (total >> 16) : (total & 0xFFFFu);
 }
@@ -712,7 +727,9 @@ class QuadTree {
 };
 
 // Small persistent worker pool for the per-(camera, level) quad-trees (16 independent serial problems per stereo
-// frame).  The calling thread takes part, so pool size 0 degenerates to a plain loop.
+// frame).  The calling thread takes part, so pool size 0 degenerates to a plain loop.  prepare() wakes the workers
+// ahead of time: they spin (bounded) until run() publishes the tasks, which hides the condition-variable wake-up
+// latency behind the GPU phase that precedes the quad-trees.
 class WorkerPool {
  public:
   explicit WorkerPool(int n) {
@@ -724,15 +741,22 @@ class WorkerPool {
     for (auto& t : threads_) t.join();
   }
   int size() const { return (int)threads_.size(); }
+  void prepare() {
+    if (threads_.empty()) return;
+    { std::lock_guard<std::mutex> lk(m_); arm_id_.fetch_add(1, std::memory_order_release); }
+    cv_.notify_all();
+  }
   void run(int ntasks, const std::function<void(int, int)>& fn) {
     if (ntasks <= 0) return;
     {
-      std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; ntasks_ = ntasks; next_.store(0); pending_.store(ntasks); gen_++;
+      std::unique_lock<std::mutex> lk(m_);
+      while (active_.load(std::memory_order_acquire) != 0) { lk.unlock(); std::this_thread::yield(); lk.lock(); }
+      fn_ = &fn; ntasks_ = ntasks; next_.store(0); pending_.store(ntasks);
+      run_id_.fetch_add(1, std::memory_order_release);
     }
     if (!threads_.empty()) cv_.notify_all();
     work((int)threads_.size());
-    while (pending_.load(std::memory_order_acquire) != 0 || active_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
   }
 
  private:
@@ -745,13 +769,22 @@ class WorkerPool {
     }
   }
   void worker(int wid) {
-    unsigned long long seen = 0;
+    unsigned long long done = 0, seen_arm = 0;
     for (;;) {
       {
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        cv_.wait(lk, [&] { return stop_ || run_id_.load() != done || arm_id_.load() != seen_arm; });
         if (stop_) return;
-        seen = gen_;
+        seen_arm = arm_id_.load();
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      while (run_id_.load(std::memory_order_acquire) == done) {       // armed: spin until the tasks are published
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+      }
+      if (run_id_.load(std::memory_order_acquire) == done) continue;  // nothing came: sleep again (run() also notifies)
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        done = run_id_.load();
         active_.fetch_add(1);
       }
       work(wid);
@@ -764,7 +797,7 @@ class WorkerPool {
   const std::function<void(int, int)>* fn_ = nullptr;
   int ntasks_ = 0;
   std::atomic<int> next_{0}, pending_{0}, active_{0};
-  unsigned long long gen_ = 0;
+  std::atomic<unsigned long long> run_id_{0}, arm_id_{0};
   bool stop_ = false;
 };
 
@@ -808,6 +841,7 @@ struct orbx_handle {
   std::vector<QuadTree> qts;               // one per pool thread + the caller
   std::unique_ptr<WorkerPool> pool;
   float timings[8] = {0};
+  int profile = 1;   // 0: no events, 1: only the FAST kernel is bracketed (bench roofline), 2: every stage
 };
 
 static int setup_geometry(orbx_handle* h, int w, int hgt) {
@@ -951,7 +985,7 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     for (int i = 0; i < 16; i++) h->umax.v[i] = um[i];
   }
   {
-    int nthreads = 3;
+    int nthreads = 5;
     if (const char* env = getenv("ORBG_OCTREE_THREADS")) nthreads = std::max(0, std::min(atoi(env), 15));
     h->pool.reset(new WorkerPool(nthreads));
     h->qts.resize(nthreads + 1);
@@ -1013,7 +1047,9 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   if (cams_mask == 2) return ORBG_BAD_ARG;
   const int n_cells = (int)h->cells.size();
   hipStream_t st = h->stream;
-  ORBG_HIP(hipEventRecord(h->ev[0], st));
+  const int prof = h->profile;
+  h->pool->prepare();
+  if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[0], st));
   {
     const LevelGeom& L0 = g.lv[0];
     dim3 grid((L0.w + 2 * kEdge + 63) / 64, (L0.h + 2 * kEdge + 3) / 4, ncams);
@@ -1024,15 +1060,15 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       hipLaunchKernelGGL(pyr_resize_kernel, gr, dim3(256), 0, st, h->d_pyr.p, g, l, h->d_xtab.p, h->d_ytab.p);
     }
   }
-  ORBG_HIP(hipEventRecord(h->ev[1], st));
+  if (prof >= 1) ORBG_HIP(hipEventRecord(h->ev[1], st));
   if (n_cells > 0) {
-    hipLaunchKernelGGL(fast_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
+    hipLaunchKernelGGL(fast_cells_kernel, dim3(8 * ((n_cells + 7) / 8), ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
                        std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
-    ORBG_HIP(hipEventRecord(h->ev[7], st));
+    if (prof >= 1) ORBG_HIP(hipEventRecord(h->ev[7], st));
     hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
                        h->d_cells.p, n_cells, ncams, h->hdr.d, h->cand.d, h->cand_cap);
   }
-  ORBG_HIP(hipEventRecord(h->ev[2], st));
+  if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[2], st));
   ORBG_HIP(hipStreamSynchronize(st));
   const auto t_host0 = std::chrono::steady_clock::now();
   // ---- host: quad-tree per (camera, level), lapping order (:1104-1146)
@@ -1101,12 +1137,12 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   if (ncams == 1) h->n_kp[1] = 0;
   const auto t_host1 = std::chrono::steady_clock::now();
   // ---- GPU phase 2: orientation + descriptors, written in final order
-  ORBG_HIP(hipEventRecord(h->ev[3], st));
+  if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[3], st));
   if (n_sel_total > 0) {
     hipLaunchKernelGGL(orient_desc_kernel, dim3((n_sel_total + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st,
                        h->d_pyr.p, g, h->sel.d, n_sel_total, h->umax, h->n_kp[0], h->d_kps.p, h->d_desc.p);
   }
-  ORBG_HIP(hipEventRecord(h->ev[4], st));
+  if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[4], st));
   const bool want_out = kps_out[0] || desc_out[0] || kps_out[1] || desc_out[1];
   if (n_sel_total > 0) {
     // the keypoints are always mirrored into pinned host memory: the matchers' serial commit needs octave / angle
@@ -1124,11 +1160,13 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     }
   }
   float ms;
-  if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->timings[0] = ms;   // pyramid
-  if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->timings[1] = ms;   // FAST + gather
   h->timings[2] = std::chrono::duration<float, std::milli>(t_host1 - t_host0).count();  // host quad-tree
-  if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->timings[3] = ms;   // orientation + descriptors
-  if (n_cells > 0 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) h->timings[5] = ms;   // fast_cells_kernel alone
+  if (prof >= 2) {
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->timings[0] = ms;   // pyramid
+    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->timings[1] = ms;   // FAST + gather
+    if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->timings[3] = ms;   // orientation + descriptors
+  }
+  if (prof >= 1 && n_cells > 0 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) h->timings[5] = ms;   // fast_cells_kernel alone
   return ORBG_OK;
 }
 
@@ -1222,13 +1260,13 @@ extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* urigh
   if (rc) return rc;
   const int nl = h->n_kp[0], nr = h->n_kp[1];
   hipStream_t st = h->stream;
-  ORBG_HIP(hipEventRecord(h->ev[5], st));
+  if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[5], st));
   if (nl > 0) {
     hipLaunchKernelGGL(stereo_match_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, h->d_pyr.p, h->geom, h->d_kps.p, h->d_desc.p,
                        nl, h->d_kps.p + nl, h->d_desc.p + (size_t)nl * 32, nr, bf, b, h->d_uright.p, h->d_depth.p, h->d_sad.p);
     hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(256), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl);
   }
-  ORBG_HIP(hipEventRecord(h->ev[6], st));
+  if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[6], st));
   if (nl > 0 && (uright || depth)) {
     ORBG_HIP(hipMemcpyAsync(h->h_stereo.h, h->d_uright.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));
     ORBG_HIP(hipMemcpyAsync(h->h_stereo.h + nl, h->d_depth.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));
@@ -1237,7 +1275,13 @@ extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* urigh
   if (nl > 0 && uright) memcpy(uright, h->h_stereo.h, (size_t)nl * 4);
   if (nl > 0 && depth) memcpy(depth, h->h_stereo.h + nl, (size_t)nl * 4);
   float ms;
-  if (hipEventElapsedTime(&ms, h->ev[5], h->ev[6]) == hipSuccess) h->timings[4] = ms;
+  if (h->profile >= 2 && hipEventElapsedTime(&ms, h->ev[5], h->ev[6]) == hipSuccess) h->timings[4] = ms;
+  return ORBG_OK;
+}
+
+extern "C" int orbx_set_profiling(orbx_handle* h, int level) {
+  if (!h || level < 0 || level > 2) return ORBG_BAD_ARG;
+  h->profile = level;
   return ORBG_OK;
 }
 

@@ -859,13 +859,9 @@ static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
   if (f->list.cap < slots + (1 << 16) && (rc = f->list.reserve(slots + (1 << 18)))) return rc;
   for (int attempt = 0; attempt < 3; attempt++) {
     ORBG_HIP(hipMemsetAsync(f->d_counter.p, 0, sizeof(int), f->stream));
-    ORBG_HIP(hipEventRecord(f->ev[0], f->stream));
     launch((int)f->list.cap);
     ORBG_HIP(hipGetLastError());
-    ORBG_HIP(hipEventRecord(f->ev[1], f->stream));
     ORBG_HIP(hipStreamSynchronize(f->stream));
-    float ms;
-    if (hipEventElapsedTime(&ms, f->ev[0], f->ev[1]) == hipSuccess) f->last_ms = ms;
     // the end of the furthest list segment tells whether the overflow region was large enough
     size_t total = 0;
     const QResult* R = f->results.h;
