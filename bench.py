@@ -3,7 +3,7 @@
 "tracking+localBA frames/sec per agent, 640x480 stereo, 1/2/4/8 agents".
 
 One STEP = one stereo frame of one agent through the hot path, inputs already resident in HBM:
-  extract L+R (pyramid, FAST, quad-tree, angle, rBRIEF)  ->  ComputeStereoMatches  ->  feature grid
+  [Frame ctor: extract L+R (pyramid, FAST, quad-tree, angle, rBRIEF) -> ComputeStereoMatches -> feature grid]
   ->  SearchByProjection(cur, last)  ->  SearchLocalPoints (isInFrustum + SearchByProjection over the local map)
 and, every FRAMES_PER_KF-th step (a keyframe), one Local Bundle Adjustment (20 free + 10 fixed KFs, 2000 points)
 plus the upload of the refreshed local map.  By default the LBA runs on its own host thread and HIP stream,
@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic stereo frames (ping-pong sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="call extract / ComputeStereoMatches / grid as three entry points instead of the fused "
+                         "Frame-constructor entry point orbx_frame_stereo_dev")
     ap.add_argument("--profile-stages", action="store_true",
                     help="bracket every extractor stage with HIP events (more API calls per frame); by default only "
                          "fast_cells_kernel (the roofline kernel) is bracketed")
@@ -154,6 +157,7 @@ def main():
     opt = api.Optimizer(device)
     prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000, seed=synth.SEED_LBA + rank)
     lp, lp_keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"], device=device)
+    bf, bb = float(cam["bf"]), float(cam["b"])
     nF = len(frames)
     seq = list(range(nF)) + list(range(nF - 2, 0, -1))             # ping-pong: consecutive frames stay adjacent
     stage = dict(extract=0.0, stereo=0.0, grid=0.0, match_frame=0.0, match_map=0.0, lba=0.0, map_upload=0.0)
@@ -190,11 +194,16 @@ def main():
         fr = frames[k]
         dL, dR = imgs[k]
         t0 = time.perf_counter()
-        nl, nr = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W)[:2]
-        t1 = time.perf_counter()
-        ex.ComputeStereoMatches(float(cam["bf"]), float(cam["b"]), download=False)
-        t2 = time.perf_counter()
-        F.from_extractor(ex, fv, nl)
+        if args.separate_calls:
+            nl, nr = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W)[:2]
+            t1 = time.perf_counter()
+            ex.ComputeStereoMatches(bf, bb, download=False)
+            t2 = time.perf_counter()
+            F.from_extractor(ex, fv, nl)
+        else:
+            # Frame::Frame(stereo): extraction + ComputeStereoMatches + grid in ONE submission / ONE final sync
+            nl, nr = ex.frame_stereo_dev(F, fv, dL.data_ptr(), dR.data_ptr(), W, H, W, bf, bb)
+            t1 = t2 = time.perf_counter()
         t3 = time.perf_counter()
         amp = np.full(nl, -1, np.int32); aob = np.zeros(nl, np.int32)
         amp, aob, n1 = m_frame.SearchByProjectionFrame(F, fr["guess"], frames[k_last]["last_view"][0], 7.0, False, amp, aob)

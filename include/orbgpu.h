@@ -146,6 +146,19 @@ int orbm_frame_upload(orbm_frame* f, const orbm_frame_view* view);
  * camera (no host round trip); view->kps/desc/uright/depth are ignored, view->n must be the
  * left feature count or -1. */
 int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const orbm_frame_view* view);
+/* Frame::Frame(imLeft, imRight, ...) (S/Frame.cc:71-172) as ONE submission with ONE final synchronisation: both
+ * ExtractORB calls (:92-95), ComputeStereoMatches (:117) and AssignFeaturesToGrid (:160).  Images are host u8 gray;
+ * `frame` (may be NULL) afterwards views the left features on the device exactly as after
+ * orbm_frame_from_extractor.  Host outputs (kps_left, desc_left, uright, depth: cap_left entries) may be NULL. */
+int orbx_frame_stereo(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
+                      const uint8_t* img_right, int width, int height, int stride, float bf, float b,
+                      orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
+                      int* n_left, int* n_right);
+/* Same with the two images already in device memory. */
+int orbx_frame_stereo_dev(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* d_img_left,
+                          const uint8_t* d_img_right, int width, int height, int stride, float bf, float b,
+                          orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
+                          int* n_left, int* n_right);
 /* Grid as CSR for tests: cell id = ix*48+iy, items in keypoint-index order (Appendix E-2). */
 int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start /*64*48+1*/, int32_t* cell_items /*n*/);
 

@@ -105,6 +105,39 @@ class ORBextractor:
             return nl.value, nr.value, kl[: nl.value], dl[: nl.value]
         return nl.value, nr.value
 
+    def frame_stereo(self, frame, fv, im_left, im_right, bf, b, download=True):
+        """Host-image variant of frame_stereo_dev (the actual Frame ctor hands over cv::Mat images)."""
+        im_left = np.ascontiguousarray(im_left, np.uint8)
+        im_right = np.ascontiguousarray(im_right, np.uint8)
+        self._host_imgs = (im_left, im_right)
+        return self.frame_stereo_dev(frame, fv, im_left.ctypes.data, im_right.ctypes.data, im_left.shape[1], im_left.shape[0],
+                                     im_left.strides[0], bf, b, download, _fn=self.lib.orbx_frame_stereo)
+
+    def frame_stereo_dev(self, frame, fv, d_left, d_right, width, height, stride, bf, b, download=False, _fn=None):
+        """Frame::Frame(stereo) (S/Frame.cc:71-172) in one submission: extract L+R, ComputeStereoMatches and the
+        feature grid, one final sync; `frame` views the left features on the device afterwards."""
+        nl, nr = C.c_int(0), C.c_int(0)
+        kl = dl = ur = dp = None
+        if download:
+            if not hasattr(self, "_kl"):
+                self._kl = np.zeros(self.cap, capi.KEYPOINT_DTYPE)
+                self._dl = np.zeros((self.cap, 32), np.uint8)
+            if not hasattr(self, "_ur"):
+                self._ur = np.zeros(self.cap, np.float32)
+                self._dp = np.zeros(self.cap, np.float32)
+            kl, dl, ur, dp = self._kl, self._dl, self._ur, self._dp
+        fn = _fn if _fn is not None else self.lib.orbx_frame_stereo_dev
+        rc = fn(self.h, frame.h if frame is not None else None, C.byref(fv), C.c_void_p(d_left),
+                C.c_void_p(d_right), width, height, stride, C.c_float(bf), C.c_float(b), _vp(kl),
+                _vp(dl), _vp(ur), _vp(dp), self.cap, C.byref(nl), C.byref(nr))
+        capi.check(rc, "orbx_frame_stereo_dev")
+        if frame is not None:
+            frame.n = nl.value
+        if download:
+            n = nl.value
+            return n, nr.value, kl[:n], dl[:n], ur[:n], dp[:n]
+        return nl.value, nr.value
+
     def level(self, cam, level):
         """mvImagePyramid[level] (I/ORBextractor.h:87) of the last extraction."""
         w, h = C.c_int(0), C.c_int(0)

@@ -1035,10 +1035,23 @@ extern "C" int orbx_get_tables(const orbx_handle* h, float* scale, float* inv_sc
   return ORBG_OK;
 }
 
+// Work chained behind the descriptor kernel on the same stream, before the single final synchronisation:
+// the rest of the stereo Frame constructor (S/Frame.cc:117 ComputeStereoMatches, :160 AssignFeaturesToGrid).
+struct PostOps {
+  bool stereo = false;
+  float bf = 0, b = 0;
+  float* uright = nullptr;
+  float* depth = nullptr;
+  orbm_frame* frame = nullptr;
+  const orbm_frame_view* view = nullptr;
+};
+int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream);
+static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st);
+
 // Core: cams_mask selects which cameras of the rig are processed; d_img are device pointers.
 static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img0, const uint8_t* d_img1, int w, int hgt,
                         int stride, const int lap[2][2], orbx_keypoint* kps_out[2], uint8_t* desc_out[2], const int cap[2],
-                        int* n_out[2], int* n_mono_out[2]) {
+                        int* n_out[2], int* n_mono_out[2], const PostOps* post = nullptr) {
   int rc = setup_geometry(h, w, hgt);
   if (rc) return rc;
   const PyrGeom& g = h->geom;
@@ -1143,6 +1156,18 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
                        h->d_pyr.p, g, h->sel.d, n_sel_total, h->umax, h->n_kp[0], h->d_kps.p, h->d_desc.p);
   }
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[4], st));
+  bool stereo_out = false;
+  if (post) {
+    if (post->stereo && ncams == 2) {
+      if ((rc = launch_stereo(h, post->bf, post->b, st))) return rc;
+      if (h->n_kp[0] > 0 && (post->uright || post->depth)) {
+        ORBG_HIP(hipMemcpyAsync(h->h_stereo.h, h->d_uright.p, (size_t)h->n_kp[0] * 4, hipMemcpyDeviceToHost, st));
+        ORBG_HIP(hipMemcpyAsync(h->h_stereo.h + h->n_kp[0], h->d_depth.p, (size_t)h->n_kp[0] * 4, hipMemcpyDeviceToHost, st));
+        stereo_out = true;
+      }
+    }
+    if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st))) return rc;
+  }
   const bool want_out = kps_out[0] || desc_out[0] || kps_out[1] || desc_out[1];
   if (n_sel_total > 0) {
     // the keypoints are always mirrored into pinned host memory: the matchers' serial commit needs octave / angle
@@ -1158,6 +1183,10 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       if (desc_out[cam]) memcpy(desc_out[cam], h->h_desc.h + (size_t)base * 32, (size_t)h->n_kp[cam] * 32);
       base += h->n_kp[cam];
     }
+  }
+  if (stereo_out) {
+    if (post->uright) memcpy(post->uright, h->h_stereo.h, (size_t)h->n_kp[0] * 4);
+    if (post->depth) memcpy(post->depth, h->h_stereo.h + h->n_kp[0], (size_t)h->n_kp[0] * 4);
   }
   float ms;
   h->timings[2] = std::chrono::duration<float, std::milli>(t_host1 - t_host0).count();  // host quad-tree
@@ -1232,6 +1261,53 @@ extern "C" int orbx_extract_stereo_dev(orbx_handle* h, const uint8_t* d_img_left
                              kps_right, desc_right, cap_right, n_right);
 }
 
+static int frame_stereo_impl(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
+                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b,
+                             orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
+                             int* n_left, int* n_right) {
+  if (!h || h->cfg.n_cams != 2 || !n_left) return ORBG_BAD_ARG;
+  if (frame && !view) return ORBG_BAD_ARG;
+  if (!img_left || !img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
+  if (stride < width) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  const uint8_t* d_img_left = img_left;
+  const uint8_t* d_img_right = img_right;
+  if (!on_device) {
+    if ((rc = setup_geometry(h, width, height))) return rc;
+    if ((rc = upload_image(h, 0, img_left, width, height, stride))) return rc;
+    if ((rc = upload_image(h, 1, img_right, width, height, stride))) return rc;
+    d_img_left = h->d_img.p;
+    d_img_right = h->d_img.p + (size_t)width * height;
+    stride = width;
+  }
+  PostOps post;
+  post.stereo = true; post.bf = bf; post.b = b; post.uright = uright; post.depth = depth; post.frame = frame; post.view = view;
+  const int lap[2][2] = {{0, 0}, {0, 0}};
+  orbx_keypoint* ko[2] = {kps_left, nullptr};
+  uint8_t* dout[2] = {desc_left, nullptr};
+  const int caps[2] = {cap_left, 0};
+  int* no[2] = {n_left, n_right};
+  int* nm[2] = {nullptr, nullptr};
+  return extract_core(h, 3, d_img_left, d_img_right, width, height, stride, lap, ko, dout, caps, no, nm, &post);
+}
+
+extern "C" int orbx_frame_stereo_dev(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* d_img_left,
+                                     const uint8_t* d_img_right, int width, int height, int stride, float bf, float b,
+                                     orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
+                                     int* n_left, int* n_right) {
+  return frame_stereo_impl(h, frame, view, d_img_left, d_img_right, true, width, height, stride, bf, b, kps_left, desc_left, uright,
+                           depth, cap_left, n_left, n_right);
+}
+
+extern "C" int orbx_frame_stereo(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
+                                 const uint8_t* img_right, int width, int height, int stride, float bf, float b,
+                                 orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
+                                 int* n_left, int* n_right) {
+  return frame_stereo_impl(h, frame, view, img_left, img_right, false, width, height, stride, bf, b, kps_left, desc_left, uright,
+                           depth, cap_left, n_left, n_right);
+}
+
 extern "C" int orbx_get_level(orbx_handle* h, int cam, int level, uint8_t* host_out, int* width, int* height) {
   if (!h || cam < 0 || cam >= h->cfg.n_cams || level < 0 || level >= h->cfg.n_levels || h->cur_w == 0) return ORBG_BAD_ARG;
   const LevelGeom& L = h->geom.lv[level];
@@ -1254,12 +1330,8 @@ extern "C" int orbx_get_candidates(orbx_handle* h, int cam, int level, int32_t* 
   return *n > cap ? ORBG_CAP_EXCEEDED : ORBG_OK;
 }
 
-extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* uright, float* depth) {
-  if (!h || h->cfg.n_cams != 2 || h->cur_w == 0) return ORBG_BAD_ARG;
-  int rc = select_device(h->device);
-  if (rc) return rc;
+static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st) {
   const int nl = h->n_kp[0], nr = h->n_kp[1];
-  hipStream_t st = h->stream;
   if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[5], st));
   if (nl > 0) {
     hipLaunchKernelGGL(stereo_match_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, h->d_pyr.p, h->geom, h->d_kps.p, h->d_desc.p,
@@ -1267,6 +1339,16 @@ extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* urigh
     hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(256), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl);
   }
   if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[6], st));
+  return ORBG_OK;
+}
+
+extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* uright, float* depth) {
+  if (!h || h->cfg.n_cams != 2 || h->cur_w == 0) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  const int nl = h->n_kp[0];
+  hipStream_t st = h->stream;
+  if ((rc = launch_stereo(h, bf, b, st))) return rc;
   if (nl > 0 && (uright || depth)) {
     ORBG_HIP(hipMemcpyAsync(h->h_stereo.h, h->d_uright.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));
     ORBG_HIP(hipMemcpyAsync(h->h_stereo.h + nl, h->d_depth.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));

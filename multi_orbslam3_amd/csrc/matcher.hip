@@ -654,6 +654,23 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
   return frame_build_grid(f);      // asynchronous on the frame's stream; the searches run on the same stream
 }
 
+// Used by orbx_frame_stereo_dev (extractor.hip): alias the extractor's left features and launch the grid build on the
+// EXTRACTOR's stream, behind the descriptor / stereo kernels; the caller synchronises that stream once.
+int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream) {
+  if (!f || !h || !v) return ORBG_BAD_ARG;
+  const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n0; hipStream_t xs;
+  int rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n0, &xs);
+  if (rc) return rc;
+  if ((rc = frame_set_params(f, v, n))) return rc;
+  if ((rc = frame_reserve(f, n))) return rc;
+  f->has_uright = true;
+  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk;
+  hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
+                     f->d_cell_items.p);
+  ORBG_HIP(hipGetLastError());
+  return ORBG_OK;
+}
+
 extern "C" int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start, int32_t* cell_items) {
   if (!f || !cell_start) return ORBG_BAD_ARG;
   int rc = select_device(f->device);

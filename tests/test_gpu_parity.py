@@ -88,6 +88,32 @@ def test_stereo_match_bit_exact(scene):
     assert np.array_equal(dp.view(np.uint32), fr["depth"].view(np.uint32))
 
 
+def test_fused_stereo_frame_constructor(scene):
+    """orbx_frame_stereo_dev = Frame::Frame(stereo): extraction + ComputeStereoMatches + grid in one submission."""
+    fr = helpers.oracle_stereo_frame(scene, 9)
+    last = helpers.oracle_stereo_frame(scene, 8)
+    ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
+    fv, keep = helpers.frame_view_of(scene, fr)
+    F = api.Frame()
+    cam = scene.cam
+    for _ in range(2):          # second pass re-uses every buffer
+        n, nr, kl, dl, ur, dp = ex.frame_stereo(F, fv, fr["L"], fr["R"], float(cam["bf"]), float(cam["b"]), download=True)
+        assert n == len(fr["kps"]) and nr == len(fr["kps_r"])
+        assert np.array_equal(kl, fr["kps"]) and np.array_equal(dl, fr["desc"])
+        assert np.array_equal(ur.view(np.uint32), fr["uright"].view(np.uint32))
+        assert np.array_equal(dp.view(np.uint32), fr["depth"].view(np.uint32))
+        gs, gi = F.grid()
+        os_, oi = ob.build_grid(fv)
+        assert np.array_equal(gs, os_) and np.array_equal(gi, oi)
+        rng = np.random.RandomState(2)
+        lv, keep2 = helpers.make_lastframe(scene, last, rng)
+        T = synth.perturb_pose(fr["Tcw"], rng).astype(np.float32)
+        a0, b0 = np.full(n, -1, np.int32), np.zeros(n, np.int32)
+        g = api.ORBmatcher(0.9, True).SearchByProjectionFrame(F, T, lv, 7.0, False, a0, b0)
+        o = ob.search_by_projection_frame(fv, T, lv, 7.0, False, True, a0, b0)
+        assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+
+
 def test_hamming_kernels():
     rng = np.random.RandomState(1)
     q = rng.randint(0, 256, (301, 32)).astype(np.uint8)
