@@ -281,6 +281,259 @@ __global__ __launch_bounds__(256) void gather_cells_kernel(const uint32_t* __res
     if (base + i < out_cap) out_cand[base + i] = in[i];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// DistributeOctTree on the GPU (S/ORBextractor.cc:479-761): one 512-thread workgroup per (camera, level).
+//
+// The reference's std::list bookkeeping has a closed form.  One pass splits a set P of nodes in a processing order
+// p_1..p_m; children (non-empty only, order n1..n4) are pushed to the FRONT, parents erased, so
+//     new list = reverse(children(p_1) ++ ... ++ children(p_m))  ++  (old list minus P, order kept).
+// Phase 1 ("while not finished"): P = every node with more than one key, in list order, no early exit.
+// Phase 2 (entered once size + 3*nToExpand > N): P = the nodes with more than one key in DESCENDING (key count,
+// creation order), cut after the first node that brings the list to >= N nodes (the reference's `break`), which is a
+// prefix sum over the children counts.  Termination: size >= N or a pass that did not change the size.
+// Keys do not need to stay ordered inside a node: the per-leaf winner "first maximum response in arrival order" is
+// the key with the largest response and, among equals, the smallest candidate index (arrival order is always the
+// candidate order) -- one packed atomicMax.  Everything lives in LDS; results are bit-identical to the host
+// implementation above (same pinned tie-break).
+constexpr int kOctThreads = 512;
+constexpr int kOctKeyCap = 4096;     // candidates per (camera, level)
+constexpr int kOctListCap = 2048;    // nodes alive at once (<= 4*N + 8)
+#define OCT_CC(p, q) ((int)((cc2[(p)][(q) >> 1] >> (((q) & 1) * 16)) & 0xFFFFu))
+
+struct OctCfg {
+  int n_levels, n_cams;
+  int n_target[ORBG_MAX_LEVELS];     // mnFeaturesPerLevel
+  int reg_off[2][ORBG_MAX_LEVELS];   // start of the (camera, level) region in the selection buffer
+  int reg_cap[ORBG_MAX_LEVELS];
+};
+
+struct OctSel { short x, y; float response; };   // level coordinates (border offset added)
+
+// exclusive prefix sum of v[0..n) (int, LDS) in place; returns the total.  All kOctThreads threads must call.
+__device__ inline int oct_scan_excl(int* v, int n, int* wsum /*LDS[8]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + kOctThreads - 1) / kOctThreads;
+  const int b = min(tid * per, n), e = min(b + per, n);
+  int s = 0;
+  for (int i = b; i < e; i++) s += v[i];
+  int inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kOctThreads / 64; w++) {
+    const int x = wsum[w];
+    if (w < wave) base += x;
+    total += x;
+  }
+  int run = base + inc - s;
+  for (int i = b; i < e; i++) { const int t = v[i]; v[i] = run; run += t; }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __restrict__ cand, const int* __restrict__ hdr,
+                                                            PyrGeom g, OctCfg cfg, OctSel* __restrict__ sel_out,
+                                                            int* __restrict__ lvl_count, int* __restrict__ overflow) {
+  __shared__ unsigned short node_of[kOctKeyCap];
+  __shared__ unsigned short kx[kOctKeyCap], ky[kOctKeyCap];
+  __shared__ unsigned char kr[kOctKeyCap], kq[kOctKeyCap];
+  __shared__ short bx0[2][kOctListCap], by0[2][kOctListCap], bx1[2][kOctListCap], by1[2][kOctListCap];
+  __shared__ unsigned short ncnt[2][kOctListCap], nseq[2][kOctListCap];
+  __shared__ unsigned short ord[kOctListCap], pos_of_ord[kOctListCap], new_pos[kOctListCap];
+  __shared__ unsigned cc2[kOctListCap][2];     // children key counts, two u16 packed per word: [q>>1] >> 16*(q&1)
+  __shared__ unsigned short child_pos[kOctListCap][4];
+  __shared__ int scanA[kOctListCap], scanB[kOctListCap];
+  __shared__ unsigned best[kOctListCap];
+  __shared__ int wsum[8];
+  __shared__ int s_n, s_cut, s_flag;
+  const int tid = threadIdx.x;
+  const int task = blockIdx.x;
+  const int cam = task % cfg.n_cams, level = task / cfg.n_cams;
+  const LevelGeom L = g.lv[level];
+  const int N = cfg.n_target[level];
+  int* out_count = lvl_count + cam * ORBG_MAX_LEVELS + level;
+  if (L.cell_end == L.cell_begin) { if (tid == 0) *out_count = 0; return; }
+  // candidate range of this (camera, level): next level that has cells, or the camera end
+  const int cb = hdr[cam * ORBG_MAX_LEVELS + level];
+  int nlv = level + 1;
+  while (nlv < cfg.n_levels && g.lv[nlv].cell_end == g.lv[nlv].cell_begin) nlv++;
+  const int ce = nlv < cfg.n_levels ? hdr[cam * ORBG_MAX_LEVELS + nlv] : hdr[2 * ORBG_MAX_LEVELS + 1 + cam];
+  const int nk = ce - cb;
+  if (nk <= 0) { if (tid == 0) *out_count = 0; return; }
+  if (nk > kOctKeyCap || 4 * N + 8 > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+  const int minB = kEdge - 3;
+  const int W = (L.w - kEdge + 3) - minB, H = (L.h - kEdge + 3) - minB;   // maxX-minX, maxY-minY
+  int nIni = (int)roundf((float)W / (float)H);
+  if (nIni < 1) nIni = 1;
+  const float hX = (float)W / (float)nIni;
+  // ---- roots (:541-583)
+  for (int i = tid; i < nIni; i += kOctThreads) scanA[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < nk; k += kOctThreads) {
+    const uint32_t p = cand[cb + k];
+    const int x = p & 0xFFF, y = (p >> 12) & 0xFFF;
+    kx[k] = (unsigned short)x; ky[k] = (unsigned short)y; kr[k] = (unsigned char)(p >> 24);
+    int r = (int)((float)x / hX);
+    if (r >= nIni) r = nIni - 1;
+    node_of[k] = (unsigned short)r;          // provisional: root index
+    atomicAdd(&scanA[r], 1);
+  }
+  __syncthreads();
+  // one thread per root: list position = number of non-empty roots before it (empty roots are dropped, :579-580)
+  for (int r = tid; r < nIni; r += kOctThreads) {
+    const int c = scanA[r];
+    int rank = 0;
+    for (int q = 0; q < r; q++) rank += scanA[q] > 0;
+    scanB[r] = c > 0 ? rank : -1;
+    if (c > 0) {
+      bx0[0][rank] = (short)(int)(hX * (float)r); bx1[0][rank] = (short)(int)(hX * (float)(r + 1));
+      by0[0][rank] = 0; by1[0][rank] = (short)H;
+      ncnt[0][rank] = (unsigned short)c; nseq[0][rank] = (unsigned short)rank;
+    }
+    if (r == nIni - 1) s_n = rank + (c > 0);
+  }
+  __syncthreads();
+  for (int k = tid; k < nk; k += kOctThreads) node_of[k] = (unsigned short)scanB[node_of[k]];
+  __syncthreads();
+  int cur = 0, n = s_n, mode = 1;
+  for (int pass = 0; pass < 64; pass++) {
+    const int prev = n;
+    // ---- A. expandable nodes and their processing order
+    for (int i = tid; i < n; i += kOctThreads) scanA[i] = ncnt[cur][i] > 1 ? 1 : 0;
+    __syncthreads();
+    int m;
+    if (mode == 1) {
+      m = oct_scan_excl(scanA, n, wsum);                      // ord = rank in list order
+      for (int i = tid; i < n; i += kOctThreads)
+        if (ncnt[cur][i] > 1) { ord[i] = (unsigned short)scanA[i]; pos_of_ord[scanA[i]] = (unsigned short)i; }
+    } else {
+      // descending (count, creation seq): rank by counting
+      m = 0;
+      for (int i = tid; i < n; i += kOctThreads) {
+        if (ncnt[cur][i] > 1) {
+          const unsigned key = ((unsigned)ncnt[cur][i] << 16) | nseq[cur][i];
+          int r = 0;
+          for (int j = 0; j < n; j++)
+            if (ncnt[cur][j] > 1) r += ((((unsigned)ncnt[cur][j] << 16) | nseq[cur][j]) > key);
+          ord[i] = (unsigned short)r; pos_of_ord[r] = (unsigned short)i;
+        }
+      }
+      __syncthreads();
+      m = oct_scan_excl(scanA, n, wsum);                      // only the total is needed here
+    }
+    __syncthreads();
+    if (m == 0) break;                                        // every node holds one key: size unchanged -> finished
+    // ---- B. children counts
+    for (int i = tid; i < n; i += kOctThreads) { cc2[i][0] = 0; cc2[i][1] = 0; }
+    __syncthreads();
+    for (int k = tid; k < nk; k += kOctThreads) {
+      const int p = node_of[k];
+      if (ncnt[cur][p] > 1) {
+        const int mx = bx0[cur][p] + ((bx1[cur][p] - bx0[cur][p] + 1) >> 1);     // UL.x + ceil((UR.x-UL.x)/2)
+        const int my = by0[cur][p] + ((by1[cur][p] - by0[cur][p] + 1) >> 1);
+        const int q = ((int)kx[k] < mx ? 0 : 1) + ((int)ky[k] < my ? 0 : 2);
+        kq[k] = (unsigned char)q;
+        atomicAdd(&cc2[p][q >> 1], q & 1 ? 0x10000u : 1u);                     // packed u16 pair add (counts < 65536)
+      }
+    }
+    __syncthreads();
+    // ---- C/D. children per processed node (in processing order), cut for phase 2
+    for (int o = tid; o < m; o += kOctThreads) {
+      const int p = pos_of_ord[o];
+      const int k4 = (OCT_CC(p, 0) > 0) + (OCT_CC(p, 1) > 0) + (OCT_CC(p, 2) > 0) + (OCT_CC(p, 3) > 0);
+      scanA[o] = k4;
+    }
+    __syncthreads();
+    if (tid == 0) s_cut = m - 1;
+    const int totalK_all = oct_scan_excl(scanA, m, wsum);     // scanA[o] = children created before node o
+    (void)totalK_all;
+    if (mode == 2) {
+      for (int o = tid; o < m; o += kOctThreads) {
+        const int p = pos_of_ord[o];
+        const int k4 = (OCT_CC(p, 0) > 0) + (OCT_CC(p, 1) > 0) + (OCT_CC(p, 2) > 0) + (OCT_CC(p, 3) > 0);
+        const int size_after = n + (scanA[o] + k4) - (o + 1);
+        if (size_after >= N) atomicMin(&s_cut, o);
+      }
+    }
+    __syncthreads();
+    const int cut = s_cut;
+    int C, nexp;
+    {
+      const int p = pos_of_ord[cut];
+      const int k4 = (OCT_CC(p, 0) > 0) + (OCT_CC(p, 1) > 0) + (OCT_CC(p, 2) > 0) + (OCT_CC(p, 3) > 0);
+      C = scanA[cut] + k4;                                    // children created by nodes 0..cut
+    }
+    // ---- E. survivors keep their order behind the children
+    for (int i = tid; i < n; i += kOctThreads) scanB[i] = (ncnt[cur][i] > 1 && ord[i] <= cut) ? 0 : 1;
+    __syncthreads();
+    const int nsurv = oct_scan_excl(scanB, n, wsum);
+    const int n_new = C + nsurv;
+    if (n_new > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+    const int nxt = cur ^ 1;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    int my_exp = 0;
+    for (int i = tid; i < n; i += kOctThreads) {
+      if (ncnt[cur][i] > 1 && ord[i] <= cut) {
+        const int o = ord[i];
+        const int mx = bx0[cur][i] + ((bx1[cur][i] - bx0[cur][i] + 1) >> 1);
+        const int my = by0[cur][i] + ((by1[cur][i] - by0[cur][i] + 1) >> 1);
+        int ci = scanA[o];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int c = OCT_CC(i, q);
+          if (c == 0) continue;
+          const int np = C - 1 - ci;                          // children end up reversed at the front
+          bx0[nxt][np] = (short)((q & 1) ? mx : bx0[cur][i]); bx1[nxt][np] = (short)((q & 1) ? bx1[cur][i] : mx);
+          by0[nxt][np] = (short)((q & 2) ? my : by0[cur][i]); by1[nxt][np] = (short)((q & 2) ? by1[cur][i] : my);
+          ncnt[nxt][np] = (unsigned short)c; nseq[nxt][np] = (unsigned short)ci;
+          child_pos[i][q] = (unsigned short)np;
+          my_exp += c > 1;
+          ci++;
+        }
+      } else {
+        const int np = C + scanB[i];
+        bx0[nxt][np] = bx0[cur][i]; bx1[nxt][np] = bx1[cur][i]; by0[nxt][np] = by0[cur][i]; by1[nxt][np] = by1[cur][i];
+        ncnt[nxt][np] = ncnt[cur][i]; nseq[nxt][np] = nseq[cur][i];
+        new_pos[i] = (unsigned short)np;
+      }
+    }
+    if (my_exp) atomicAdd(&s_flag, my_exp);                   // nToExpand of this pass
+    __syncthreads();
+    // ---- F. keys follow their node
+    for (int k = tid; k < nk; k += kOctThreads) {
+      const int p = node_of[k];
+      node_of[k] = (ncnt[cur][p] > 1 && ord[p] <= cut) ? child_pos[p][kq[k]] : new_pos[p];
+    }
+    nexp = s_flag;
+    __syncthreads();
+    cur = nxt; n = n_new;
+    if (n >= N || n == prev) break;                           // :667 / :732
+    if (mode == 1 && n + 3 * nexp > N) mode = 2;              // :671
+  }
+  // ---- retain the best key of every node, in list order (:742-758)
+  for (int i = tid; i < n; i += kOctThreads) best[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < nk; k += kOctThreads) atomicMax(&best[node_of[k]], ((unsigned)kr[k] << 16) | (unsigned)(0xFFFF - k));
+  __syncthreads();
+  if (n > cfg.reg_cap[level]) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+  OctSel* out = sel_out + cfg.reg_off[cam][level];
+  for (int i = tid; i < n; i += kOctThreads) {
+    const int k = 0xFFFF - (int)(best[i] & 0xFFFF);
+    OctSel o;
+    o.x = (short)(kx[k] + minB); o.y = (short)(ky[k] + minB); o.response = (float)kr[k];
+    out[i] = o;
+  }
+  if (tid == 0) *out_count = n;
+}
+
 // ------------------------------------------------------------------------------------------------
 // orientation + blur + rBRIEF, one wavefront per keypoint
 // (IC_Angle S/ORBextractor.cc:75-102, GaussianBlur :1114-1115 / Appendix A-4, computeOrbDescriptor :106-145)
@@ -322,21 +575,14 @@ constexpr int kHS = 38;              // row-pass stride (u16)
 constexpr int kBS = 40;              // blurred stride
 constexpr int kKpPerBlock = 4;
 
-__global__ __launch_bounds__(256) void orient_desc_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
-                                                         const SelKp* __restrict__ sel, int n_sel, UMax um, int cam1_base,
-                                                         orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
-  __shared__ uint8_t raw_s[kKpPerBlock][kPW * kPS];
-  __shared__ unsigned short hrow_s[kKpPerBlock][kPW * kHS];
-  __shared__ uint8_t blur_s[kKpPerBlock][kBW * kBS];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int k = blockIdx.x * kKpPerBlock + wv;
-  if (k >= n_sel) return;            // whole wavefront exits together; no block-wide barrier below
-  uint8_t* raw = raw_s[wv];
-  unsigned short* hrow = hrow_s[wv];
-  uint8_t* blur = blur_s[wv];
-  const SelKp kp = sel[k];
-  const LevelGeom L = g.lv[kp.level];
-  const uint8_t* src = pyr + (size_t)kp.cam * g.cam_stride + L.off + (size_t)(kEdge + kp.y - kPR) * L.stride + (kEdge + kp.x - kPR);
+// One wavefront: orientation + blur + descriptor of the keypoint (cam, level, x, y) -> slot `out`.
+__device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr, const PyrGeom& g, int cam, int level, int kx_, int ky_,
+                                                 float response, const UMax& um, size_t out, uint8_t* raw, unsigned short* hrow,
+                                                 uint8_t* blur, orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                 orbx_keypoint* __restrict__ kps_host, uint8_t* __restrict__ desc_host) {
+  const int lane = threadIdx.x & 63;
+  const LevelGeom L = g.lv[level];
+  const uint8_t* src = pyr + (size_t)cam * g.cam_stride + L.off + (size_t)(kEdge + ky_ - kPR) * L.stride + (kEdge + kx_ - kPR);
   for (int i = lane; i < kPW * kPS; i += 64) {
     const int y = i / kPS, x = i - y * kPS;
     if (x < kPW) raw[i] = src[(size_t)y * L.stride + x];
@@ -399,19 +645,71 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const uint8_t* __restr
     nib |= (unsigned)(val[0] < val[1]) << t;
   }
   const unsigned hi = __shfl_down(nib, 1, 64);
-  const size_t out = (size_t)(kp.cam ? cam1_base : 0) + kp.out_idx;
-  if ((lane & 1) == 0) desc[out * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
-  if (lane == 0) {
-    const float s = g.scale[kp.level];
-    orbx_keypoint o;
-    o.x = kp.level ? (float)kp.x * s : (float)kp.x;    // keypoint->pt *= scale  (:1131-1133)
-    o.y = kp.level ? (float)kp.y * s : (float)kp.y;
-    o.size = (float)(int)((float)kPatch * s);           // scaledPatchSize (:862,871)
-    o.angle = angle;
-    o.response = kp.response;
-    o.octave = kp.level;
-    kps[out] = o;
+  if ((lane & 1) == 0) {
+    const uint8_t byte = (uint8_t)(nib | (hi << 4));
+    desc[out * 32 + (lane >> 1)] = byte;
+    if (desc_host) desc_host[out * 32 + (lane >> 1)] = byte;
   }
+  if (lane == 0) {
+    const float s = g.scale[level];
+    orbx_keypoint o;
+    o.x = level ? (float)kx_ * s : (float)kx_;        // keypoint->pt *= scale  (:1131-1133)
+    o.y = level ? (float)ky_ * s : (float)ky_;
+    o.size = (float)(int)((float)kPatch * s);         // scaledPatchSize (:862,871)
+    o.angle = angle;
+    o.response = response;
+    o.octave = level;
+    kps[out] = o;
+    if (kps_host) kps_host[out] = o;
+  }
+}
+
+// front-end 1: keypoints chosen by the host quad-trees (SelKp records in final order)
+__global__ __launch_bounds__(256) void orient_desc_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
+                                                         const SelKp* __restrict__ sel, int n_sel, UMax um, int cam1_base,
+                                                         orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
+  __shared__ uint8_t raw_s[kKpPerBlock][kPW * kPS];
+  __shared__ unsigned short hrow_s[kKpPerBlock][kPW * kHS];
+  __shared__ uint8_t blur_s[kKpPerBlock][kBW * kBS];
+  const int wv = threadIdx.x >> 6;
+  const int k = blockIdx.x * kKpPerBlock + wv;
+  if (k >= n_sel) return;            // whole wavefront exits together; no block-wide barrier below
+  const SelKp kp = sel[k];
+  const size_t out = (size_t)(kp.cam ? cam1_base : 0) + kp.out_idx;
+  orient_desc_wave(pyr, g, kp.cam, kp.level, kp.x, kp.y, kp.response, um, out, raw_s[wv], hrow_s[wv], blur_s[wv], kps, desc, nullptr, nullptr);
+}
+
+// front-end 2: keypoints chosen by octree_kernel.  Wavefront w of the (over-sized) grid finds its (camera, level,
+// position) from the per-level counts; slot = keypoints before it in (camera, level) order -- or the mirror of it when
+// the whole image lies in the lapping area (mono Frame ctor, S/Frame.cc:289).  Also publishes the keypoint totals.
+__global__ __launch_bounds__(256) void orient_desc_gpu_kernel(const uint8_t* __restrict__ pyr, PyrGeom g, OctCfg cfg,
+                                                             const OctSel* __restrict__ sel, const int* __restrict__ lvl_count,
+                                                             UMax um, int reverse0, int reverse1, orbx_keypoint* __restrict__ kps,
+                                                             uint8_t* __restrict__ desc, orbx_keypoint* __restrict__ kps_host,
+                                                             uint8_t* __restrict__ desc_host, int* __restrict__ d_nkp,
+                                                             int* __restrict__ h_nkp) {
+  __shared__ uint8_t raw_s[kKpPerBlock][kPW * kPS];
+  __shared__ unsigned short hrow_s[kKpPerBlock][kPW * kHS];
+  __shared__ uint8_t blur_s[kKpPerBlock][kBW * kBS];
+  const int wv = threadIdx.x >> 6;
+  const int w = blockIdx.x * kKpPerBlock + wv;
+  int n0 = 0, n1 = 0;
+  for (int l = 0; l < cfg.n_levels; l++) { n0 += lvl_count[l]; if (cfg.n_cams > 1) n1 += lvl_count[ORBG_MAX_LEVELS + l]; }
+  if (w == 0 && (threadIdx.x & 63) == 0) { d_nkp[0] = n0; d_nkp[1] = n1; h_nkp[0] = n0; h_nkp[1] = n1; }
+  if (w >= n0 + n1) return;
+  const int cam = w >= n0 ? 1 : 0;
+  int s = cam ? w - n0 : w, level = 0;
+  for (; level < cfg.n_levels; level++) {
+    const int c = lvl_count[cam * ORBG_MAX_LEVELS + level];
+    if (s < c) break;
+    s -= c;
+  }
+  const OctSel kp = sel[cfg.reg_off[cam][level] + s];
+  const int seq = cam ? w - n0 : w;                       // index in (level, list) order within the camera
+  const int ncam = cam ? n1 : n0;
+  const int slot = (cam ? reverse1 : reverse0) ? ncam - 1 - seq : seq;
+  const size_t out = (size_t)(cam ? n0 : 0) + slot;
+  orient_desc_wave(pyr, g, cam, level, kp.x, kp.y, kp.response, um, out, raw_s[wv], hrow_s[wv], blur_s[wv], kps, desc, kps_host, desc_host);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -426,11 +724,15 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
 // Hamming, wavefront min on the (dist, iR) key = "first minimum wins"), then the 11x11 SAD over 11 offsets.
 __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
                                                           const orbx_keypoint* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
-                                                          const orbx_keypoint* __restrict__ kr, const uint8_t* __restrict__ dr, int nr,
+                                                          const orbx_keypoint* kr, const uint8_t* dr, int nr,
                                                           float bf, float b, float* __restrict__ uright, float* __restrict__ depth,
-                                                          int* __restrict__ best_sad) {
+                                                          int* __restrict__ best_sad, const int* __restrict__ d_nkp) {
   const int lane = threadIdx.x & 63;
   const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d_nkp) {        // counts produced on the device (GPU quad-tree path): right camera starts behind the left one
+    nl = d_nkp[0]; nr = d_nkp[1];
+    kr = kl + nl; dr = dl + (size_t)nl * 32;
+  }
   if (iL >= nl) return;
   const orbx_keypoint kpL = kl[iL];
   float out_u = -1.0f, out_d = -1.0f;
@@ -526,8 +828,10 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
 // sorted list is found by a two-level (high byte / low byte) histogram select -- SAD <= 121*510 < 2^16 -- instead
 // of sorting; then every match whose SAD is not below 1.5f*1.4f*median is dropped.
 __global__ __launch_bounds__(256) void stereo_finalize_kernel(float* __restrict__ uright, float* __restrict__ depth,
-                                                             const int* __restrict__ best_sad, int nl) {
+                                                             const int* __restrict__ best_sad, int nl, const int* __restrict__ d_nkp,
+                                                             float* __restrict__ host_out) {
   __shared__ unsigned hist[256];
+  if (d_nkp) nl = d_nkp[0];
   __shared__ unsigned wsum[4];
   __shared__ int s_bin, s_before;
   const int tid = threadIdx.x;
@@ -543,7 +847,10 @@ __global__ __launch_bounds__(256) void stereo_finalize_kernel(float* __restrict_
   unsigned total;
   unsigned mine = hist[tid];
   unsigned excl = block_excl_scan_256(mine, &total, wsum);
-  if (total == 0) return;                           // no stereo match at all (uniform exit)
+  if (total == 0) {                                 // no stereo match at all (uniform exit)
+    if (host_out) for (int i = tid; i < nl; i += 256) { host_out[i] = uright[i]; host_out[nl + i] = depth[i]; }
+    return;
+  }
   const unsigned kth = total / 2;
   if (excl <= kth && kth < excl + mine) { s_bin = tid; s_before = (int)excl; }
   __syncthreads();
@@ -567,7 +874,9 @@ __global__ __launch_bounds__(256) void stereo_finalize_kernel(float* __restrict_
   const float thDist = 1.5f * 1.4f * (float)median;
   for (int i = tid; i < nl; i += 256) {
     const int v = best_sad[i];
-    if (v >= 0 && !((float)v < thDist)) { uright[i] = -1; depth[i] = -1; }
+    float u = uright[i], d = depth[i];
+    if (v >= 0 && !((float)v < thDist)) { u = -1; d = -1; uright[i] = u; depth[i] = d; }
+    if (host_out) { host_out[i] = u; host_out[nl + i] = d; }     // mirror into mapped pinned memory: [uRight | depth]
   }
 }
 
@@ -840,6 +1149,15 @@ struct orbx_handle {
   std::vector<SelKp> level_sel[2][ORBG_MAX_LEVELS];
   std::vector<QuadTree> qts;               // one per pool thread + the caller
   std::unique_ptr<WorkerPool> pool;
+  // GPU quad-tree path
+  DevBuf<uint32_t> d_cand;
+  DevBuf<int> d_hdr, d_lvlcount, d_nkp, d_overflow;
+  DevBuf<OctSel> d_selreg;
+  PinnedBuf<int> h_nkp;          // [0] n left, [1] n right, [2] overflow flag
+  OctCfg octcfg;
+  int sel_bound = 0;             // upper bound of selected keypoints (sum of region capacities)
+  bool gpu_octree = true;
+  bool last_was_gpu = false;
   float timings[8] = {0};
   int profile = 1;   // 0: no events, 1: only the FAST kernel is bracketed (bench roofline), 2: every stage
 };
@@ -937,6 +1255,33 @@ static int setup_geometry(orbx_handle* h, int w, int hgt) {
   h->cand_cap = (int)std::min<size_t>(h->cells.size() * (size_t)nc * 64 + 4096, (size_t)1 << 22);
   if ((rc = h->cand.reserve(h->cand_cap))) return rc;
   if ((rc = h->hdr.reserve(2 * ORBG_MAX_LEVELS + 4))) return rc;
+  {
+    OctCfg& oc = h->octcfg;
+    oc.n_levels = nl; oc.n_cams = nc;
+    int roff = 0;
+    bool fits = true;
+    for (int l = 0; l < nl; l++) {
+      oc.n_target[l] = h->feats_per_level[l];
+      oc.reg_cap[l] = std::min(4 * h->feats_per_level[l] + 8, kOctListCap);
+      if (4 * h->feats_per_level[l] + 8 > kOctListCap) fits = false;
+    }
+    for (int c = 0; c < 2; c++)
+      for (int l = 0; l < nl; l++) { oc.reg_off[c][l] = roff; if (c < nc) roff += oc.reg_cap[l]; }
+    h->sel_bound = roff;
+    if (!fits) h->gpu_octree = false;          // per-level quota too large for the LDS-resident quad-tree
+    if ((rc = h->d_cand.reserve(h->cand_cap)) || (rc = h->d_hdr.reserve(2 * ORBG_MAX_LEVELS + 4)) ||
+        (rc = h->d_lvlcount.reserve(2 * ORBG_MAX_LEVELS)) || (rc = h->d_nkp.reserve(4)) || (rc = h->d_overflow.reserve(4)) ||
+        (rc = h->d_selreg.reserve(std::max(roff, 1))) || (rc = h->h_nkp.reserve(4)))
+      return rc;
+    ORBG_HIP(hipMemset(h->d_lvlcount.p, 0, 2 * ORBG_MAX_LEVELS * sizeof(int)));
+    ORBG_HIP(hipMemset(h->d_overflow.p, 0, sizeof(int)));
+    // output buffers must hold the worst case of the device-side selection
+    const size_t need = (size_t)roff + 64;
+    if ((rc = h->d_kps.reserve(need)) || (rc = h->d_desc.reserve(need * 32)) || (rc = h->h_kps.reserve(need)) ||
+        (rc = h->h_desc.reserve(need * 32)) || (rc = h->d_uright.reserve(need)) || (rc = h->d_depth.reserve(need)) ||
+        (rc = h->d_sad.reserve(need)) || (rc = h->h_stereo.reserve(2 * need)))
+      return rc;
+  }
   if (!xtab.empty()) ORBG_HIP(hipMemcpy(h->d_xtab.p, xtab.data(), xtab.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
   if (!ytab.empty()) ORBG_HIP(hipMemcpy(h->d_ytab.p, ytab.data(), ytab.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
   if (!h->cells.empty()) ORBG_HIP(hipMemcpy(h->d_cells.p, h->cells.data(), h->cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
@@ -987,6 +1332,7 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
   {
     int nthreads = 5;
     if (const char* env = getenv("ORBG_OCTREE_THREADS")) nthreads = std::max(0, std::min(atoi(env), 15));
+    if (const char* env = getenv("ORBG_HOST_OCTREE")) h->gpu_octree = atoi(env) == 0;
     h->pool.reset(new WorkerPool(nthreads));
     h->qts.resize(nthreads + 1);
   }
@@ -1016,6 +1362,8 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   h->d_slots.release(); h->d_counts.release(); h->hdr.release(); h->cand.release(); h->sel.release();
   h->d_kps.release(); h->d_desc.release(); h->h_kps.release(); h->h_desc.release();
   h->d_uright.release(); h->d_depth.release(); h->d_sad.release(); h->h_stereo.release();
+  h->d_cand.release(); h->d_hdr.release(); h->d_lvlcount.release(); h->d_nkp.release(); h->d_overflow.release();
+  h->d_selreg.release(); h->h_nkp.release();
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1045,13 +1393,14 @@ struct PostOps {
   orbm_frame* frame = nullptr;
   const orbm_frame_view* view = nullptr;
 };
-int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream);
-static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st);
+int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n);
+void orbm_internal_set_n(orbm_frame* f, int n);
+static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror);
 
 // Core: cams_mask selects which cameras of the rig are processed; d_img are device pointers.
 static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img0, const uint8_t* d_img1, int w, int hgt,
                         int stride, const int lap[2][2], orbx_keypoint* kps_out[2], uint8_t* desc_out[2], const int cap[2],
-                        int* n_out[2], int* n_mono_out[2], const PostOps* post = nullptr) {
+                        int* n_out[2], int* n_mono_out[2], const PostOps* post = nullptr, bool force_host = false) {
   int rc = setup_geometry(h, w, hgt);
   if (rc) return rc;
   const PyrGeom& g = h->geom;
@@ -1074,12 +1423,71 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     }
   }
   if (prof >= 1) ORBG_HIP(hipEventRecord(h->ev[1], st));
+  // The quad-trees run on the GPU unless the lapping area splits an image (only the fisheye-stereo path does that):
+  // reverse = whole image inside [lap0, lap1] (mono Frame ctor), plain = nothing inside.
+  bool use_gpu = h->gpu_octree && n_cells > 0 && !force_host;
+  int reverse[2] = {0, 0};
+  for (int c = 0; c < ncams && use_gpu; c++) {
+    const float xmin = (float)kEdge, xmax = (float)w;          // keypoint x range in level-0 pixels: [19, w)
+    if ((float)lap[c][1] < xmin || (float)lap[c][0] > xmax) reverse[c] = 0;
+    else if ((float)lap[c][0] <= xmin && (float)lap[c][1] >= xmax) reverse[c] = 1;
+    else use_gpu = false;
+  }
+  h->last_was_gpu = use_gpu;
   if (n_cells > 0) {
     hipLaunchKernelGGL(fast_cells_kernel, dim3(8 * ((n_cells + 7) / 8), ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
                        std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
     if (prof >= 1) ORBG_HIP(hipEventRecord(h->ev[7], st));
     hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
-                       h->d_cells.p, n_cells, ncams, h->hdr.d, h->cand.d, h->cand_cap);
+                       h->d_cells.p, n_cells, ncams, use_gpu ? h->d_hdr.p : h->hdr.d, use_gpu ? h->d_cand.p : h->cand.d, h->cand_cap);
+  }
+  if (use_gpu) {
+    // ---- everything stays on the device: quad-trees -> descriptors -> (stereo, grid) -> ONE synchronisation
+    OctCfg oc = h->octcfg;
+    oc.n_cams = ncams;                          // cameras processed by THIS call (a rig handle may extract one image)
+    hipLaunchKernelGGL(octree_kernel, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
+                       h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p);
+    const bool want_desc = desc_out[0] || desc_out[1];
+    hipLaunchKernelGGL(orient_desc_gpu_kernel, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
+                       oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,
+                       want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d);
+    bool stereo_out = false;
+    if (post) {
+      if (post->stereo && ncams == 2) {
+        stereo_out = post->uright || post->depth;
+        if ((rc = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr))) return rc;
+      }
+      if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p))) return rc;
+    }
+    ORBG_HIP(hipMemcpyAsync(h->h_nkp.h + 2, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ORBG_HIP(hipGetLastError());
+    ORBG_HIP(hipStreamSynchronize(st));
+    if (h->h_nkp.h[2]) {
+      // a level had more candidates / nodes than the LDS-resident quad-tree holds: redo this frame with the host trees
+      ORBG_HIP(hipMemset(h->d_overflow.p, 0, sizeof(int)));
+      return extract_core(h, cams_mask, d_img0, d_img1, w, hgt, stride, lap, kps_out, desc_out, cap, n_out, n_mono_out, post, true);
+    }
+    h->n_kp[0] = h->h_nkp.h[0];
+    h->n_kp[1] = ncams == 2 ? h->h_nkp.h[1] : 0;
+    int base = 0;
+    for (int cam = 0; cam < ncams; cam++) {
+      const int nk = h->n_kp[cam];
+      if (n_out[cam]) *n_out[cam] = nk;
+      if (n_mono_out[cam]) *n_mono_out[cam] = reverse[cam] ? 0 : nk;
+      if ((kps_out[cam] || desc_out[cam]) && nk > cap[cam]) return ORBG_CAP_EXCEEDED;
+      if (kps_out[cam]) memcpy(kps_out[cam], h->h_kps.h + base, (size_t)nk * sizeof(orbx_keypoint));
+      if (desc_out[cam]) memcpy(desc_out[cam], h->h_desc.h + (size_t)base * 32, (size_t)nk * 32);
+      base += nk;
+    }
+    if (post && post->frame) orbm_internal_set_n(post->frame, h->n_kp[0]);
+    if (stereo_out) {
+      if (post->uright) memcpy(post->uright, h->h_stereo.h, (size_t)h->n_kp[0] * 4);
+      if (post->depth) memcpy(post->depth, h->h_stereo.h + h->n_kp[0], (size_t)h->n_kp[0] * 4);
+    }
+    float ms;
+    h->timings[2] = 0;
+    if (prof >= 1 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) h->timings[5] = ms;   // fast_cells_kernel alone
+    return ORBG_OK;
   }
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[2], st));
   ORBG_HIP(hipStreamSynchronize(st));
@@ -1159,14 +1567,14 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   bool stereo_out = false;
   if (post) {
     if (post->stereo && ncams == 2) {
-      if ((rc = launch_stereo(h, post->bf, post->b, st))) return rc;
+      if ((rc = launch_stereo(h, post->bf, post->b, st, false, nullptr))) return rc;
       if (h->n_kp[0] > 0 && (post->uright || post->depth)) {
         ORBG_HIP(hipMemcpyAsync(h->h_stereo.h, h->d_uright.p, (size_t)h->n_kp[0] * 4, hipMemcpyDeviceToHost, st));
         ORBG_HIP(hipMemcpyAsync(h->h_stereo.h + h->n_kp[0], h->d_depth.p, (size_t)h->n_kp[0] * 4, hipMemcpyDeviceToHost, st));
         stereo_out = true;
       }
     }
-    if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st))) return rc;
+    if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st, nullptr))) return rc;
   }
   const bool want_out = kps_out[0] || desc_out[0] || kps_out[1] || desc_out[1];
   if (n_sel_total > 0) {
@@ -1324,19 +1732,40 @@ extern "C" int orbx_get_level(orbx_handle* h, int cam, int level, uint8_t* host_
 
 extern "C" int orbx_get_candidates(orbx_handle* h, int cam, int level, int32_t* xys, int cap, int* n) {
   if (!h || cam < 0 || cam >= h->cfg.n_cams || level < 0 || level >= h->cfg.n_levels || !n) return ORBG_BAD_ARG;
+  if (h->last_was_gpu) {
+    // device-resident candidate list of the last extraction: fetch and decode on demand
+    int rc = select_device(h->device);
+    if (rc) return rc;
+    std::vector<int> hdr(2 * ORBG_MAX_LEVELS + 4);
+    ORBG_HIP(hipMemcpy(hdr.data(), h->d_hdr.p, hdr.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const PyrGeom& g = h->geom;
+    const int nl = g.n_levels;
+    std::vector<Cand>& cvw = h->last_cands[cam][level];
+    cvw.clear();
+    if (g.lv[level].cell_end != g.lv[level].cell_begin) {
+      const int b = hdr[cam * ORBG_MAX_LEVELS + level];
+      int nlv = level + 1;
+      while (nlv < nl && g.lv[nlv].cell_end == g.lv[nlv].cell_begin) nlv++;
+      const int e = nlv < nl ? hdr[cam * ORBG_MAX_LEVELS + nlv] : hdr[2 * ORBG_MAX_LEVELS + 1 + cam];
+      std::vector<uint32_t> raw(std::max(e - b, 0));
+      if (e > b) ORBG_HIP(hipMemcpy(raw.data(), h->d_cand.p + b, (size_t)(e - b) * 4, hipMemcpyDeviceToHost));
+      for (uint32_t pk : raw) cvw.push_back(Cand{(int)(pk & 0xFFF), (int)((pk >> 12) & 0xFFF), (int)(pk >> 24)});
+    }
+  }
   const std::vector<Cand>& cv = h->last_cands[cam][level];
   *n = (int)cv.size();
   for (int i = 0; i < *n && i < cap; i++) { xys[3 * i] = cv[i].x; xys[3 * i + 1] = cv[i].y; xys[3 * i + 2] = cv[i].score; }
   return *n > cap ? ORBG_CAP_EXCEEDED : ORBG_OK;
 }
 
-static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st) {
-  const int nl = h->n_kp[0], nr = h->n_kp[1];
+static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror) {
+  const int nl = device_counts ? h->sel_bound : h->n_kp[0], nr = h->n_kp[1];
   if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[5], st));
   if (nl > 0) {
+    const int* dn = device_counts ? h->d_nkp.p : nullptr;
     hipLaunchKernelGGL(stereo_match_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, h->d_pyr.p, h->geom, h->d_kps.p, h->d_desc.p,
-                       nl, h->d_kps.p + nl, h->d_desc.p + (size_t)nl * 32, nr, bf, b, h->d_uright.p, h->d_depth.p, h->d_sad.p);
-    hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(256), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl);
+                       nl, h->d_kps.p + nl, h->d_desc.p + (size_t)nl * 32, nr, bf, b, h->d_uright.p, h->d_depth.p, h->d_sad.p, dn);
+    hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(256), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl, dn, host_mirror);
   }
   if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[6], st));
   return ORBG_OK;
@@ -1348,7 +1777,7 @@ extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* urigh
   if (rc) return rc;
   const int nl = h->n_kp[0];
   hipStream_t st = h->stream;
-  if ((rc = launch_stereo(h, bf, b, st))) return rc;
+  if ((rc = launch_stereo(h, bf, b, st, false, nullptr))) return rc;
   if (nl > 0 && (uright || depth)) {
     ORBG_HIP(hipMemcpyAsync(h->h_stereo.h, h->d_uright.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));
     ORBG_HIP(hipMemcpyAsync(h->h_stereo.h + nl, h->d_depth.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));

@@ -77,8 +77,9 @@ __device__ __forceinline__ float norm3d(const float* v) {
 
 __global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* __restrict__ kps, FrameParams fp,
                                                          int* __restrict__ cell_of, int* __restrict__ cell_start,
-                                                         int* __restrict__ cell_items) {
+                                                         int* __restrict__ cell_items, const int* __restrict__ d_n) {
   __shared__ int cnt[kCells];
+  if (d_n) fp.n = *d_n;               // feature count produced on the device (GPU quad-tree path)
   __shared__ int wsum[16];
   const int tid = threadIdx.x;
   for (int c = tid; c < kCells; c += 1024) cnt[c] = 0;
@@ -582,7 +583,7 @@ static int frame_reserve(orbm_frame* f, int n) {
 
 static int frame_build_grid(orbm_frame* f) {
   hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, f->stream, f->kps_p, f->fp, f->d_cell_of.p,
-                     f->d_cell_start.p, f->d_cell_items.p);
+                     f->d_cell_start.p, f->d_cell_items.p, (const int*)nullptr);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;
 }
@@ -656,20 +657,23 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
 
 // Used by orbx_frame_stereo_dev (extractor.hip): alias the extractor's left features and launch the grid build on the
 // EXTRACTOR's stream, behind the descriptor / stereo kernels; the caller synchronises that stream once.
-int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream) {
+int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n) {
   if (!f || !h || !v) return ORBG_BAD_ARG;
   const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n0; hipStream_t xs;
   int rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n0, &xs);
   if (rc) return rc;
-  if ((rc = frame_set_params(f, v, n))) return rc;
-  if ((rc = frame_reserve(f, n))) return rc;
+  // n < 0: the count only exists on the device yet (d_n); buffers are sized for the frame's capacity
+  if ((rc = frame_set_params(f, v, n < 0 ? 0 : n))) return rc;
+  if ((rc = frame_reserve(f, n < 0 ? std::max(f->cap, 4096) : n))) return rc;
   f->has_uright = true;
   f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk;
   hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
-                     f->d_cell_items.p);
+                     f->d_cell_items.p, d_n);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;
 }
+
+void orbm_internal_set_n(orbm_frame* f, int n) { f->fp.n = n; }
 
 extern "C" int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start, int32_t* cell_items) {
   if (!f || !cell_start) return ORBG_BAD_ARG;

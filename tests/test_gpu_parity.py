@@ -114,6 +114,32 @@ def test_fused_stereo_frame_constructor(scene):
         assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
 
 
+def test_gpu_and_host_quadtree_paths_agree(scene, small_scene, monkeypatch):
+    """The LDS-resident GPU quad-tree and the host implementation (ORBG_HOST_OCTREE=1; also the overflow / partial-
+    lapping fallback) give identical keypoints; a partial lapping area forces the host path transparently."""
+    for sc in (scene, small_scene):
+        L, R, _ = sc.stereo_pair(5)
+        monkeypatch.delenv("ORBG_HOST_OCTREE", raising=False)
+        ex_gpu = api.ORBextractor(1000, 1.2, 8, 20, 7, sc.W, sc.H, n_cams=2)
+        monkeypatch.setenv("ORBG_HOST_OCTREE", "1")
+        ex_host = api.ORBextractor(1000, 1.2, 8, 20, 7, sc.W, sc.H, n_cams=2)
+        monkeypatch.delenv("ORBG_HOST_OCTREE", raising=False)
+        a = ex_gpu.extract_stereo(L, R)
+        b = ex_host.extract_stereo(L, R)
+        for cam in (0, 1):
+            _assert_extract_equal(a[cam], b[cam], "gpu-vs-host quad-tree cam %d" % cam)
+        for l in (0, 3, 7):
+            assert np.array_equal(ex_gpu.candidates(1, l), ex_host.candidates(1, l))
+    # partial lapping area (fisheye-stereo style): front part natural order, lapping part from the back
+    ex = api.ORBextractor(500, 1.2, 8, 20, 7, 640, 480)
+    oe = ob.Extractor(n_features=500)
+    L, _, _ = scene.stereo_pair(6)
+    nm, k, d = ex(L, (200, 400))
+    rc, ok, od, onm = oe.extract(L, lap=(200, 400))
+    assert nm == onm and 0 < nm < len(k)
+    _assert_extract_equal((k, d), (ok, od), "partial lapping")
+
+
 def test_hamming_kernels():
     rng = np.random.RandomState(1)
     q = rng.randint(0, 256, (301, 32)).astype(np.uint8)
