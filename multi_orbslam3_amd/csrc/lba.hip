@@ -667,6 +667,199 @@ __global__ __launch_bounds__(NT) void k_ldlt_blk(int nb, const double* __restric
   if (t == 0) *ok_flag = ok;
 }
 
+// Row-pair variant of the register-blocked LDL^T: a 6x6 block is owned by THREE threads (two rows each), which cuts
+// the per-step trailing update (the longest phase) and the panel solve to a third, and every thread of block column j
+// factors the 6x6 diagonal block redundantly from an LDS copy, so no barrier is needed between "factor" and "panel":
+// two barriers per block column.  L is kept (LDS, or in the storage of S for large systems) for the back-substitution.
+// R = row pairs per thread (R = 1: up to 341 blocks = 25 poses with 1024 threads).
+template <int NT, int R>
+__global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S, const double* __restrict__ b,
+                                                  double* __restrict__ x, int* __restrict__ ok_flag, int l_in_lds) {
+  extern __shared__ double sh[];
+  double* rr_ = sh;                    // 6*nb running rhs (forward)
+  double* zz = rr_ + 6 * nb;           // 6*nb z = D^-1 L^-1 b, then running rhs of the backward pass
+  double* Ajj = zz + 6 * nb;           // 36 current diagonal block
+  double* xs = Ajj + 36;               // 6
+  double* pan = xs + 6;                // 2 * nb * kPanStride
+  double* Lall = l_in_lds ? pan + 2 * (size_t)nb * kPanStride : S;   // nblk * 36
+  __shared__ int s_ok;
+  const int t = threadIdx.x;
+  const int n = 6 * nb;
+  const int nblk = nb * (nb + 1) / 2;
+  const int units = 3 * nblk;
+  int ubi[R], ubk[R], upr[R], ublk[R];
+  double a[R][12];
+#pragma unroll
+  for (int s = 0; s < R; s++) {
+    const int u = t + s * NT;
+    ubi[s] = -1; ubk[s] = -1; upr[s] = 0; ublk[s] = 0;
+    if (u < units) {
+      const int blk = u / 3;
+      int bi = (int)((sqrtf(8.f * (float)blk + 1.f) - 1.f) * 0.5f);
+      while ((bi + 1) * (bi + 2) / 2 <= blk) bi++;
+      while (bi * (bi + 1) / 2 > blk) bi--;
+      ubi[s] = bi; ubk[s] = blk - bi * (bi + 1) / 2; upr[s] = u - 3 * blk; ublk[s] = blk;
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) a[s][6 * q + c] = S[(size_t)(6 * bi + 2 * upr[s] + q) * n + 6 * ubk[s] + c];
+    }
+  }
+  for (int i = t; i < n; i += NT) { rr_[i] = b[i]; zz[i] = 0; }
+  if (t == 0) s_ok = 1;
+  __syncthreads();            // S fully consumed before Lall (which may alias S) is written
+#pragma unroll
+  for (int s = 0; s < R; s++)
+    if (ubi[s] == 0 && ubk[s] == 0)
+#pragma unroll
+      for (int q = 0; q < 12; q++) Ajj[12 * upr[s] + q] = a[s][q];
+  for (int j = 0; j < nb; j++) {
+    __syncthreads();          // barrier X: Ajj + running rhs of column j complete
+    double* P = pan + (size_t)(j & 1) * nb * kPanStride;
+    bool in_col = false;
+#pragma unroll
+    for (int s = 0; s < R; s++) in_col |= (ubk[s] == j);
+    if (in_col) {
+      // redundant in-register LDL^T of the diagonal block
+      double L[36], dinv[6], y[6];
+#pragma unroll
+      for (int q = 0; q < 36; q++) L[q] = Ajj[q];
+      bool good = true;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double d = L[7 * c];
+#pragma unroll
+        for (int m = 0; m < c; m++) d -= L[6 * c + m] * L[6 * c + m] * L[7 * m];
+        if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
+        L[7 * c] = d;
+        const double id = fast_rcp(d);
+        dinv[c] = id;
+#pragma unroll
+        for (int q = c + 1; q < 6; q++) {
+          double v = L[6 * q + c];
+#pragma unroll
+          for (int m = 0; m < c; m++) v -= L[6 * q + m] * L[6 * c + m] * L[7 * m];
+          L[6 * q + c] = v * id;
+        }
+      }
+      if (!good) s_ok = 0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double v = rr_[6 * j + c];
+#pragma unroll
+        for (int m = 0; m < c; m++) v -= L[6 * c + m] * y[m];
+        y[c] = v;
+      }
+#pragma unroll
+      for (int s = 0; s < R; s++) {
+        if (ubk[s] != j) continue;
+        const int row0 = 2 * upr[s];
+        double* Lg = Lall + (size_t)ublk[s] * 36;
+        if (ubi[s] == j) {
+#pragma unroll
+          for (int pr = 0; pr < 3; pr++)          // compile-time row indices: L stays in registers
+            if (upr[s] == pr) {
+#pragma unroll
+              for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) Lg[6 * (2 * pr + q) + c] = L[6 * (2 * pr + q) + c];
+            }
+          if (upr[s] == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) zz[6 * j + c] = y[c] * dinv[c];
+          }
+        } else {
+          double* Lp = P + (size_t)ubi[s] * kPanStride;
+          double* Wp = Lp + 37;
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            double w[6];
+            double racc = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+              double v = a[s][6 * q + c];
+#pragma unroll
+              for (int m = 0; m < c; m++) v -= w[m] * L[6 * c + m];
+              w[c] = v;
+              const double l = v * dinv[c];
+              Wp[6 * (row0 + q) + c] = v;
+              Lp[6 * (row0 + q) + c] = l;
+              Lg[6 * (row0 + q) + c] = l;
+              racc += l * y[c];
+            }
+            rr_[6 * ubi[s] + row0 + q] -= racc;
+          }
+        }
+      }
+    }
+    __syncthreads();          // barrier Z: panel of column j published
+    if (!s_ok) break;
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      if (ubk[s] > j && ubi[s] >= ubk[s]) {
+        const double* Lp = P + (size_t)ubi[s] * kPanStride + 6 * (2 * upr[s]);   // two rows of L_ij
+        const double* Wp = P + (size_t)ubk[s] * kPanStride + 37;                 // W_kj = L_kj D_j
+        double l0[6], l1[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) { l0[m] = Lp[m]; l1[m] = Lp[6 + m]; }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double w[6];
+#pragma unroll
+          for (int m = 0; m < 6; m++) w[m] = Wp[6 * c + m];
+          double s0 = 0, s1 = 0;
+#pragma unroll
+          for (int m = 0; m < 6; m++) { s0 += l0[m] * w[m]; s1 += l1[m] * w[m]; }
+          a[s][c] -= s0;
+          a[s][6 + c] -= s1;
+        }
+        if (ubi[s] == j + 1 && ubk[s] == j + 1)
+#pragma unroll
+          for (int q = 0; q < 12; q++) Ajj[12 * upr[s] + q] = a[s][q];
+      }
+    }
+  }
+  __syncthreads();
+  const int ok = s_ok;
+  if (ok) {
+    // backward on whole blocks (pair-0 owners), L read back from Lall: x_i = L_ii^-T z_i ; z_k -= L_ik^T x_i
+    for (int i = nb - 1; i >= 0; i--) {
+#pragma unroll
+      for (int s = 0; s < R; s++) {
+        if (ubi[s] == i && ubk[s] == i && upr[s] == 0) {
+          const double* Lg = Lall + (size_t)ublk[s] * 36;
+          double xv[6];
+#pragma unroll
+          for (int c = 5; c >= 0; c--) {
+            double v = zz[6 * i + c];
+#pragma unroll
+            for (int m = c + 1; m < 6; m++) v -= Lg[6 * m + c] * xv[m];
+            xv[c] = v;
+          }
+#pragma unroll
+          for (int c = 0; c < 6; c++) { xs[c] = xv[c]; x[6 * i + c] = xv[c]; }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < R; s++) {
+        if (ubi[s] == i && ubk[s] < i && upr[s] == 0) {
+          const double* Lg = Lall + (size_t)ublk[s] * 36;
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            double acc = 0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) acc += Lg[6 * q + c] * xs[q];
+            zz[6 * ubk[s] + c] -= acc;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t == 0) *ok_flag = ok;
+}
+
 // trial state = oplus(current, x): poses exp(x_p) * T; points X + x_l with the landmark back-substitution
 // x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i) folded in (x_l is also stored for computeScale)
 __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int nP, const int* __restrict__ pose_col,
@@ -934,6 +1127,27 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   if (blk_lds > 64 * 1024) {
     ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_blk<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds));
   }
+  // row-pair LDL^T: R row pairs per thread, L kept in LDS when it fits next to the panels
+  int rows_R = 0, rows_l_in_lds = 0;
+  bool rows_small = false;
+  size_t rows_lds = 0;
+  {
+    const size_t units = 3 * (size_t)nP * (nP + 1) / 2;
+    rows_small = units <= 640;
+    if (units <= 1024) rows_R = 1; else if (units <= 2048) rows_R = 2; else if (units <= 4096) rows_R = 4;
+    if (getenv("ORBG_LDLT_BLK")) rows_R = 0;        // A/B switch: one-thread-per-block variant
+    const size_t base = (12 * (size_t)nP + 42 + 2 * (size_t)nP * kPanStride) * sizeof(double);
+    const size_t lall = (size_t)nP * (nP + 1) / 2 * 36 * sizeof(double);
+    rows_l_in_lds = base + lall <= 150 * 1024;
+    rows_lds = base + (rows_l_in_lds ? lall : 0);
+    if (rows_R && rows_lds > 64 * 1024) {
+      const void* fn = (rows_R == 1 && rows_small) ? reinterpret_cast<const void*>(k_ldlt_rows<640, 1>)
+                     : rows_R == 1 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 1>)
+                     : rows_R == 2 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 2>)
+                                   : reinterpret_cast<const void*>(k_ldlt_rows<1024, 4>);
+      ORBG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+    }
+  }
   int cur = 0;   // index of the buffer holding the current estimate
   auto launch_errors = [&](int buf) {
     if (NE > 0)
@@ -987,7 +1201,15 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         if (nP > 0) {
           hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(64), 0, st, nP, h->d_pair_i1.p, h->d_pair_i2.p, h->d_pair_start.p, h->d_items.p,
                              h->d_EB.p, h->d_Hll.p, h->d_bl.p, h->d_Hpp.p, h->d_bp.p, lambda, h->d_S.p, h->d_bs.p);
-          if (nP <= 22)
+          if (rows_R == 1 && rows_small)
+            hipLaunchKernelGGL((k_ldlt_rows<640, 1>), dim3(1), dim3(640), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
+          else if (rows_R == 1)
+            hipLaunchKernelGGL((k_ldlt_rows<1024, 1>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
+          else if (rows_R == 2)
+            hipLaunchKernelGGL((k_ldlt_rows<1024, 2>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
+          else if (rows_R == 4)
+            hipLaunchKernelGGL((k_ldlt_rows<1024, 4>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
+          else if (nP <= 22)
             hipLaunchKernelGGL(k_ldlt_blk<256>, dim3(1), dim3(256), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
           else if (nP <= 44)
             hipLaunchKernelGGL(k_ldlt_blk<1024>, dim3(1), dim3(1024), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);

@@ -273,3 +273,28 @@ def test_lba_stop_flag_and_outlier_rejection():
     g2 = api.Optimizer().LocalBundleAdjustment(p2)
     o2 = ob.lba_solve(p2)
     assert g2.status == o2.status
+
+
+def test_c4_sizes_1280x720_2000_features_and_50kf_lba():
+    """BASELINE.json configs[3] sizes: 1280x720, 2000 features/frame, 50 free + 20 fixed keyframes, 8000 points."""
+    sc = synth.Scene(1280, 720, tex_size=(3200, 1800), px_per_m=400.0)
+    L, R, _ = sc.stereo_pair(0)
+    ex = api.ORBextractor(2000, 1.2, 8, 20, 7, 1280, 720, n_cams=2)
+    (kl, dl), (kr, dr) = ex.extract_stereo(L, R)
+    ol = ob.Extractor(n_features=2000, max_width=1280, max_height=720)
+    orr = ob.Extractor(n_features=2000, max_width=1280, max_height=720)
+    rc, okl, odl, _ = ol.extract(L)
+    rc, okr, odr, _ = orr.extract(R)
+    assert len(okl) >= 1900
+    _assert_extract_equal((kl, dl), (okl, odl), "C4 left")
+    _assert_extract_equal((kr, dr), (okr, odr), "C4 right")
+    ur, dp = ex.ComputeStereoMatches(float(sc.cam["bf"]), float(sc.cam["b"]), n_left=len(kl))
+    our, odp = ob.stereo_match(ol, orr, okl, odl, okr, odr, float(sc.cam["bf"]), float(sc.cam["b"]))
+    assert np.array_equal(ur.view(np.uint32), our.view(np.uint32)) and np.array_equal(dp.view(np.uint32), odp.view(np.uint32))
+    prob = synth.make_lba_problem(n_free=50, n_fixed=20, n_points=8000, width=1280, height=720)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    g = api.Optimizer().LocalBundleAdjustment(p)
+    o = ob.lba_solve(p)
+    assert g.status == o.status == capi.LBA_APPLIED and g.iters == o.iters
+    assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4
+    assert np.array_equal(g.edge_outlier, o.edge_outlier)
