@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void gather_cells_kernel(const uint32_t* __res
 // the key with the largest response and, among equals, the smallest candidate index (arrival order is always the
 // candidate order) -- one packed atomicMax.  Everything lives in LDS; results are bit-identical to the host
 // implementation above (same pinned tie-break).
-constexpr int kOctThreads = 512;
+constexpr int kOctThreads = 256;
 constexpr int kOctKeyCap = 4096;     // candidates per (camera, level)
 constexpr int kOctListCap = 2048;    // nodes alive at once (<= 4*N + 8)
 #define OCT_CC(p, q) ((int)((cc2[(p)][(q) >> 1] >> (((q) & 1) * 16)) & 0xFFFFu))
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   __shared__ unsigned short ord[kOctListCap], pos_of_ord[kOctListCap], new_pos[kOctListCap];
   __shared__ unsigned cc2[kOctListCap][2];     // children key counts, two u16 packed per word: [q>>1] >> 16*(q&1)
   __shared__ unsigned short child_pos[kOctListCap][4];
-  __shared__ int scanA[kOctListCap], scanB[kOctListCap];
+  __shared__ __attribute__((aligned(16))) int scanA[kOctListCap];
+  __shared__ __attribute__((aligned(16))) int scanB[kOctListCap];
   __shared__ unsigned best[kOctListCap];
   __shared__ int wsum[8];
   __shared__ int s_n, s_cut, s_flag;
@@ -405,7 +406,75 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   int cur = 0, n = s_n, mode = 1;
   for (int pass = 0; pass < 64; pass++) {
     const int prev = n;
-    // ---- A. expandable nodes and their processing order
+    if (mode == 1) {
+      // ---- phase-1 fast path: processing order == list order, so ONE packed prefix sum (expandable | children<<12)
+      // yields the children positions, the survivors' positions and both totals; 7 barriers per pass.
+      for (int i = tid; i < n; i += kOctThreads) { cc2[i][0] = 0; cc2[i][1] = 0; }
+      if (tid == 0) s_flag = 0;
+      __syncthreads();
+      for (int k = tid; k < nk; k += kOctThreads) {
+        const int p = node_of[k];
+        if (ncnt[cur][p] > 1) {
+          const int mx = bx0[cur][p] + ((bx1[cur][p] - bx0[cur][p] + 1) >> 1);
+          const int my = by0[cur][p] + ((by1[cur][p] - by0[cur][p] + 1) >> 1);
+          const int q = ((int)kx[k] < mx ? 0 : 1) + ((int)ky[k] < my ? 0 : 2);
+          kq[k] = (unsigned char)q;
+          atomicAdd(&cc2[p][q >> 1], q & 1 ? 0x10000u : 1u);
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += kOctThreads) {
+        int v = 0;
+        if (ncnt[cur][i] > 1) v = 1 | (((OCT_CC(i, 0) > 0) + (OCT_CC(i, 1) > 0) + (OCT_CC(i, 2) > 0) + (OCT_CC(i, 3) > 0)) << 12);
+        scanA[i] = v;
+      }
+      __syncthreads();
+      const int tot = oct_scan_excl(scanA, n, wsum);
+      const int m1 = tot & 0xFFF, C1 = tot >> 12;
+      if (m1 == 0) break;
+      const int n_new1 = C1 + (n - m1);
+      if (n_new1 > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+      const int nxt1 = cur ^ 1;
+      int my_exp1 = 0;
+      for (int i = tid; i < n; i += kOctThreads) {
+        const int pe = scanA[i] & 0xFFF, pk = scanA[i] >> 12;     // expandable / children before node i
+        if (ncnt[cur][i] > 1) {
+          const int mx = bx0[cur][i] + ((bx1[cur][i] - bx0[cur][i] + 1) >> 1);
+          const int my = by0[cur][i] + ((by1[cur][i] - by0[cur][i] + 1) >> 1);
+          int ci = pk;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int c = OCT_CC(i, q);
+            if (c == 0) continue;
+            const int np = C1 - 1 - ci;
+            bx0[nxt1][np] = (short)((q & 1) ? mx : bx0[cur][i]); bx1[nxt1][np] = (short)((q & 1) ? bx1[cur][i] : mx);
+            by0[nxt1][np] = (short)((q & 2) ? my : by0[cur][i]); by1[nxt1][np] = (short)((q & 2) ? by1[cur][i] : my);
+            ncnt[nxt1][np] = (unsigned short)c; nseq[nxt1][np] = (unsigned short)ci;
+            child_pos[i][q] = (unsigned short)np;
+            my_exp1 += c > 1;
+            ci++;
+          }
+        } else {
+          const int np = C1 + (i - pe);
+          bx0[nxt1][np] = bx0[cur][i]; bx1[nxt1][np] = bx1[cur][i]; by0[nxt1][np] = by0[cur][i]; by1[nxt1][np] = by1[cur][i];
+          ncnt[nxt1][np] = ncnt[cur][i]; nseq[nxt1][np] = nseq[cur][i];
+          new_pos[i] = (unsigned short)np;
+        }
+      }
+      if (my_exp1) atomicAdd(&s_flag, my_exp1);
+      __syncthreads();
+      for (int k = tid; k < nk; k += kOctThreads) {
+        const int p = node_of[k];
+        node_of[k] = ncnt[cur][p] > 1 ? child_pos[p][kq[k]] : new_pos[p];
+      }
+      const int nexp1 = s_flag;
+      __syncthreads();
+      cur = nxt1; n = n_new1;
+      if (n >= N || n == prev) break;
+      if (n + 3 * nexp1 > N) mode = 2;
+      continue;
+    }
+    // ---- general path (phase 2): A. expandable nodes and their processing order
     for (int i = tid; i < n; i += kOctThreads) scanA[i] = ncnt[cur][i] > 1 ? 1 : 0;
     __syncthreads();
     int m;
@@ -414,14 +483,22 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
       for (int i = tid; i < n; i += kOctThreads)
         if (ncnt[cur][i] > 1) { ord[i] = (unsigned short)scanA[i]; pos_of_ord[scanA[i]] = (unsigned short)i; }
     } else {
-      // descending (count, creation seq): rank by counting
+      // descending (count, creation seq): rank by counting over packed keys (count<<16 | seq, 0 = not expandable),
+      // read four at a time from LDS
+      const int n4 = (n + 3) & ~3;
+      for (int i = tid; i < n4; i += kOctThreads)
+        scanB[i] = (i < n && ncnt[cur][i] > 1) ? (int)(((unsigned)ncnt[cur][i] << 16) | nseq[cur][i]) : 0;
+      __syncthreads();
       m = 0;
       for (int i = tid; i < n; i += kOctThreads) {
-        if (ncnt[cur][i] > 1) {
-          const unsigned key = ((unsigned)ncnt[cur][i] << 16) | nseq[cur][i];
+        const unsigned key = (unsigned)scanB[i];
+        if (key) {
           int r = 0;
-          for (int j = 0; j < n; j++)
-            if (ncnt[cur][j] > 1) r += ((((unsigned)ncnt[cur][j] << 16) | nseq[cur][j]) > key);
+          const uint4* k4p = reinterpret_cast<const uint4*>(scanB);
+          for (int j = 0; j < n4 / 4; j++) {
+            const uint4 kk = k4p[j];
+            r += (kk.x > key) + (kk.y > key) + (kk.z > key) + (kk.w > key);
+          }
           ord[i] = (unsigned short)r; pos_of_ord[r] = (unsigned short)i;
         }
       }
