@@ -253,6 +253,17 @@ def main():
         fast_ms = kern["fast_kernel_ms"] / K
         fast_bytes = 2 * PYR_PIXELS_640x480 + (stats["kp"] / K) * 4.0     # both cameras' pyramid pixels + packed candidates
         achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
+        # HBM-side traffic of the roofline kernel: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this
+        # same command, KB per launch), committed under profiles/; byte-wide loads are not the "wide coalesced" case for
+        # which gfx950 halves FETCH_SIZE, so no x2 correction is applied (calibration: profiles/README.md)
+        traffic, traffic_src = None, None
+        try:
+            pj = os.path.join(ROOT, "profiles", "r1_i_pmc_fetch_write_per_kernel.json")
+            pm = json.load(open(pj))["fast_cells_kernel"]
+            traffic = int(1024 * (pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]))
+            traffic_src = "profiles/r1_i_pmc_fetch_write_per_kernel.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         line = {
             "metric": "tracking+localBA frames/sec (aggregate over agents; 1 agent per GPU)",
             "value": round(world * K / elapsed, 3),
@@ -275,7 +286,7 @@ def main():
                                                              stats["lba_s"] / max(stats["lba_calls"], 1) / FRAMES_PER_KF), 3),
                        "lba_lm_iterations_per_call": round(stats["lba_iters"] / max(stats["lba_calls"], 1), 2)},
             "roofline": {"kernel": "fast_cells_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(fast_bytes), "avg_launch_ms": round(fast_ms, 5),
                          "note": "per-frame work is a few MB: the path is launch/latency bound, not bandwidth bound (SURVEY.md 0-10)"},
         }
