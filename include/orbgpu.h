@@ -309,6 +309,37 @@ int lba_create(int device, int cap_poses, int cap_points, int cap_edges, lba_han
 int lba_destroy(lba_handle* h);
 int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
 
+/* ---------------------------------------------------------------- pose-only optimisation */
+
+/* Everything Optimizer::PoseOptimization(Frame*) reads (S/Optimizer.cc:964-1278, mpCamera2 == NULL): one entry per
+ * feature that holds a map point. */
+typedef struct pose_opt_problem {
+  int32_t n;               /* nInitialCorrespondences */
+  const float* Xw;         /* n x 3, pMP->GetWorldPos() */
+  const float* u;          /* mvKeysUn[i].pt.x */
+  const float* v;          /* mvKeysUn[i].pt.y */
+  const float* ur;         /* mvuRight[i]; < 0 => monocular edge */
+  const float* inv_sigma2; /* mvInvLevelSigma2[octave] */
+  float fx, fy, cx, cy, bf;
+  float Tcw[16];           /* pFrame->mTcw (row-major), the estimate every round restarts from */
+  int32_t device;
+} pose_opt_problem;
+
+typedef struct pose_opt_result {
+  float    Tcw[16];        /* optimised pose (pFrame->SetPose) */
+  uint8_t* outlier;        /* n, pFrame->mvbOutlier for the correspondences (caller-allocated) */
+  int32_t  n_inliers;      /* return value: nInitialCorrespondences - nBad (0 if n < 3) */
+  int32_t  n_bad;
+  int32_t  iters[4];       /* LM iterations run in each of the 4 rounds */
+  double   chi2[4];        /* robustified chi2 at the end of each round (active edges) */
+} pose_opt_result;
+
+/* int Optimizer::PoseOptimization(Frame *pFrame), S/Optimizer.cc:964-1278: 4 rounds x 10 LM iterations on one SE3
+ * vertex with unary reprojection edges (I/OptimizableTypes.h:31-57, G/types/types_six_dof_expmap.h:208-236), outliers
+ * re-classified after every round (chi2 > 5.991 / 7.815), Huber kernels dropped for the last round.  The whole solve
+ * runs in ONE kernel launch (LM control flow on the device). */
+int pose_optimize(const pose_opt_problem* p, pose_opt_result* r);
+
 /* ---------------------------------------------------------------- misc */
 const char* orbg_version(void);
 const char* orbg_strerror(int code);

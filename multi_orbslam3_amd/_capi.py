@@ -81,6 +81,17 @@ class LbaResult(C.Structure):
                 ("trace_cap", C.c_int32), ("trace_len", C.c_int32)]
 
 
+class PoseOptProblem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("Xw", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("ur", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("bf", C.c_float), ("Tcw", C.c_float * 16), ("device", C.c_int32)]
+
+
+class PoseOptResult(C.Structure):
+    _fields_ = [("Tcw", C.c_float * 16), ("outlier", C.c_void_p), ("n_inliers", C.c_int32), ("n_bad", C.c_int32),
+                ("iters", C.c_int32 * 4), ("chi2", C.c_double * 4)]
+
+
 def ptr(a):
     """void* of a C-contiguous numpy array (or None)."""
     if a is None:
@@ -97,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "orbm_frame_get_grid", "orbm_hamming_matrix", "orbm_hamming_best2", "orbm_is_in_frustum",
     "orbm_search_by_projection_mps", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
     "orbm_search_local_points", "orbm_search_by_projection_frame", "orbm_search_by_bow",
-    "lba_solve", "lba_create", "lba_destroy", "lba_solve_h",
+    "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "pose_optimize",
     "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_set_profiling",
 ]
 

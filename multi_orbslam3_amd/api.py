@@ -345,6 +345,12 @@ class Optimizer:
         except Exception:
             pass
 
+    def PoseOptimization(self, problem):
+        """int Optimizer::PoseOptimization(Frame*) (S/Optimizer.cc:964-1278); problem: views.pose_opt_problem(...)[0]."""
+        out = views.PoseOptOutput(problem.n)
+        capi.check(self.lib.pose_optimize(C.byref(problem), C.byref(out.c)), "pose_optimize")
+        return out
+
     def LocalBundleAdjustment(self, problem, pbStopFlag=None, trace_cap=64):
         """problem: views.lba_problem(...)[0]; pbStopFlag: np.int32[1] polled between LM iterations."""
         out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)

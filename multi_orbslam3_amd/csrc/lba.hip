@@ -1308,3 +1308,369 @@ extern "C" int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag
   lba_destroy(h);
   return rc;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer::PoseOptimization(Frame*) (S/Optimizer.cc:964-1278) -- the WHOLE solve in one kernel launch.
+//
+// One 256-thread workgroup; thread t owns correspondences t, t+256, ...  The four rounds, the Levenberg-Marquardt
+// iterations and their accept/reject trials all run on the device: thread 0 holds the 6x6 system, lambda and the
+// control flow, everything else is broadcast through LDS.  Reductions are fixed-order (wavefront shuffle tree, then
+// the four wavefront partials in order), so the result is bit-reproducible.  A host-driven version would need one
+// synchronisation per LM trial (~40-60 per call); this needs one.
+namespace {
+
+struct PoCtl {            // LDS broadcast block
+  PoseQ T;                // pose under evaluation
+  int cont, accept;
+};
+
+constexpr int kPoThreads = 256;
+constexpr int kPoMaxPer = 16;      // correspondences per thread (n <= 4096)
+
+__device__ inline void po_block_reduce(double* vals, int nv, double (*wpart)[28], double* out) {
+  // vals[0..nv) per thread -> out[0..nv) (valid in thread 0..nv-1 after the call: every thread reads out[] from LDS)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = 0; i < nv; i++) {
+    double v = vals[i];
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
+    if (lane == 0) wpart[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < nv) out[threadIdx.x] = ((wpart[0][threadIdx.x] + wpart[1][threadIdx.x]) + wpart[2][threadIdx.x]) + wpart[3][threadIdx.x];
+  __syncthreads();
+}
+
+__device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, float v, float ur, const Cam& c, double* err, double* Xc) {
+  const double Xd[3] = {X[0], X[1], X[2]};
+  double r[3];
+  quat_rotate(T.q, Xd, r);
+  Xc[0] = r[0] + T.t[0]; Xc[1] = r[1] + T.t[1]; Xc[2] = r[2] + T.t[2];
+  if (ur < 0) {
+    const double iz = 1.0 / Xc[2];
+    err[0] = (double)u - (c.fx * Xc[0] * iz + c.cx);
+    err[1] = (double)v - (c.fy * Xc[1] * iz + c.cy);
+    err[2] = 0;
+  } else {
+    const float invz = (float)(1.0 / Xc[2]);                 // float invz (types_six_dof_expmap.cpp:340)
+    const double r0 = Xc[0] * invz * c.fx + c.cx;
+    const double r1 = Xc[1] * invz * c.fy + c.cy;
+    err[0] = (double)u - r0; err[1] = (double)v - r1; err[2] = (double)ur - (r0 - c.bf * invz);   // double bf*invz (:344)
+  }
+}
+
+__global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float* __restrict__ Xw, const float* __restrict__ ou,
+                                                             const float* __restrict__ ov, const float* __restrict__ our,
+                                                             const float* __restrict__ oinv, Cam cam, PoseQ T0,
+                                                             PoseQ* __restrict__ T_out, uint8_t* __restrict__ outlier_out,
+                                                             int* __restrict__ stats /*n_bad, iters[4]*/, double* __restrict__ chi_out) {
+  __shared__ double wpart[4][28];
+  __shared__ double red[28];
+  __shared__ PoCtl ctl;
+  const int tid = threadIdx.x;
+  const double dM = (float)sqrt(5.991), dS = (float)sqrt(7.815);
+  const double dsqM = dM * dM, dsqS = dS * dS;
+  // per-thread correspondence state (registers): outlier flag, level, last evaluated chi2
+  unsigned out_mask = 0;                 // mvbOutlier
+  double chi2v[kPoMaxPer];
+#pragma unroll
+  for (int s = 0; s < kPoMaxPer; s++) chi2v[s] = 0;
+  // thread-0 LM state
+  double H[21], b[6], x[6] = {0, 0, 0, 0, 0, 0};
+  double lambda = 0, ni = 2, currentChi = 0;
+  int nBadLM = 0;
+  bool robust = true;
+  PoseQ T = T0;
+  int nBad = 0;
+  if (tid == 0) { for (int i = 0; i < 8; i++) stats[i] = 0; for (int i = 0; i < 4; i++) chi_out[i] = 0; }
+  for (int round = 0; round < 4; round++) {
+    T = T0;                                                   // setEstimate(toSE3Quat(mTcw)) every round (:1191)
+    int n_active_local = 0;
+#pragma unroll
+    for (int s = 0; s < kPoMaxPer; s++) { const int i = tid + s * kPoThreads; if (i < n && !((out_mask >> s) & 1)) n_active_local++; }
+    double cnt = n_active_local;
+    po_block_reduce(&cnt, 1, wpart, red);
+    const int n_active = (int)red[0];
+    int done = 0;
+    bool ok = n_active > 0;
+    for (int it = 0; it < 10 && ok; it++) {
+      // ---- computeActiveErrors + buildSystem at T
+      double acc[28];
+#pragma unroll
+      for (int i = 0; i < 28; i++) acc[i] = 0;
+#pragma unroll
+      for (int s = 0; s < kPoMaxPer; s++) {
+        const int i = tid + s * kPoThreads;
+        if (i >= n || ((out_mask >> s) & 1)) continue;
+        const float ur = our[i];
+        const bool mono = ur < 0;
+        double err[3], Xc[3];
+        po_edge_error(T, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
+        const double om = (double)oinv[i];
+        const double c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
+        chi2v[s] = c2;
+        double rho0 = c2, rho1 = 1.0;
+        if (robust) huber(c2, mono ? dM : dS, mono ? dsqM : dsqS, &rho0, &rho1);
+        acc[27] += rho0;
+        // Jacobian (D x 6): mono S/OptimizableTypes.cpp:49-63, stereo types_six_dof_expmap.cpp:375-404
+        const double xx = Xc[0], yy = Xc[1], iz = 1.0 / Xc[2], iz2 = iz * iz;
+        double J[18];
+        J[0] = xx * yy * iz2 * cam.fx; J[1] = -(1 + (xx * xx * iz2)) * cam.fx; J[2] = yy * iz * cam.fx; J[3] = -iz * cam.fx; J[4] = 0; J[5] = xx * iz2 * cam.fx;
+        J[6] = (1 + yy * yy * iz2) * cam.fy; J[7] = -xx * yy * iz2 * cam.fy; J[8] = -xx * iz * cam.fy; J[9] = 0; J[10] = -iz * cam.fy; J[11] = yy * iz2 * cam.fy;
+        if (mono) {
+#pragma unroll
+          for (int q = 12; q < 18; q++) J[q] = 0;
+        } else {
+          J[12] = J[0] - cam.bf * yy * iz2; J[13] = J[1] + cam.bf * xx * iz2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - cam.bf * iz2;
+        }
+        const double wom = rho1 * om;
+        double orr[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) orr[k] = -(om * err[k]) * rho1;
+        int o = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = a; c < 6; c++) {
+            double h = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) h += J[6 * k + a] * wom * J[6 * k + c];
+            acc[o++] += h;
+          }
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          double sacc = 0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) sacc += J[6 * k + a] * orr[k];
+          acc[o++] += sacc;
+        }
+      }
+      po_block_reduce(acc, 28, wpart, red);
+      double iniChi = 0;
+      if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) H[i] = red[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) b[i] = red[21 + i];
+        currentChi = red[27];
+        iniChi = currentChi;
+        if (it == 0) {
+          const int di[6] = {0, 6, 11, 15, 18, 20};
+          double mx = 0;
+#pragma unroll
+          for (int j = 0; j < 6; j++) mx = fmax(mx, fabs(H[di[j]]));
+          lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
+        }
+      }
+      // ---- LM trials
+      double rho = 0;
+      int qmax = 0;
+      for (;;) {
+        bool ok2 = true;
+        if (tid == 0) {
+          // (H + lambda I) x = b by LDL^T without pivoting; "ok" only if every pivot is positive (Eigen::LDLT::isPositive)
+          double A[36];
+          {
+            int o = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+              for (int c = a; c < 6; c++) { const double v = H[o++] + (a == c ? lambda : 0.0); A[6 * a + c] = v; A[6 * c + a] = v; }
+          }
+          double D[6];
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            double d = A[7 * j];
+#pragma unroll
+            for (int k = 0; k < j; k++) d -= A[6 * j + k] * A[6 * j + k] * D[k];
+            if (!(d > 0.0) || fabs(d) == INFINITY) ok2 = false;
+            D[j] = d;
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) {
+              double sv = A[6 * i + j];
+#pragma unroll
+              for (int k = 0; k < j; k++) sv -= A[6 * i + k] * A[6 * j + k] * D[k];
+              A[6 * i + j] = sv / d;
+            }
+          }
+          if (ok2) {
+            double y[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { double v = b[i];
+#pragma unroll
+              for (int k = 0; k < i; k++) v -= A[6 * i + k] * y[k];
+              y[i] = v; }
+#pragma unroll
+            for (int i = 0; i < 6; i++) y[i] /= D[i];
+#pragma unroll
+            for (int i = 5; i >= 0; i--) { double v = y[i];
+#pragma unroll
+              for (int k = i + 1; k < 6; k++) v -= A[6 * k + i] * x[k];
+              x[i] = v; }
+          }
+          pose_oplus(T, x, &ctl.T);                       // update with whatever x holds, as g2o does
+        }
+        __syncthreads();
+        const PoseQ Tt = ctl.T;
+        double tchi = 0;
+        double tmp_chi[kPoMaxPer];
+#pragma unroll
+        for (int s = 0; s < kPoMaxPer; s++) {
+          tmp_chi[s] = chi2v[s];
+          const int i = tid + s * kPoThreads;
+          if (i >= n || ((out_mask >> s) & 1)) continue;
+          const float ur = our[i];
+          const bool mono = ur < 0;
+          double err[3], Xc[3];
+          po_edge_error(Tt, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
+          const double om = (double)oinv[i];
+          const double c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
+          tmp_chi[s] = c2;
+          double rho0 = c2, rho1;
+          if (robust) huber(c2, mono ? dM : dS, mono ? dsqM : dsqS, &rho0, &rho1);
+          tchi += rho0;
+        }
+        // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
+#pragma unroll
+        for (int s = 0; s < kPoMaxPer; s++) chi2v[s] = tmp_chi[s];
+        po_block_reduce(&tchi, 1, wpart, red);
+        if (tid == 0) {
+          double tempChi = red[0];
+          if (!ok2) tempChi = 1.7976931348623157e308;
+          rho = currentChi - tempChi;
+          double scale = 0;
+#pragma unroll
+          for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+          scale += 1e-3;
+          rho /= scale;
+          int accept = 0;
+          if (rho > 0 && fabs(tempChi) != INFINITY && tempChi == tempChi) {
+            double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+            alpha = fmin(alpha, 2. / 3.);
+            lambda *= fmax(1. / 3., alpha);
+            ni = 2;
+            currentChi = tempChi;
+            T = ctl.T;
+            accept = 1;
+          } else {
+            lambda *= ni; ni *= 2;
+          }
+          qmax++;
+          ctl.accept = accept;
+          ctl.cont = (rho < 0 && qmax < 10) ? 1 : 0;
+        }
+        __syncthreads();
+        const int cont = ctl.cont;
+        if (ctl.accept) T = ctl.T;
+        __syncthreads();
+        if (!cont) break;
+      }
+      done++;
+      if (tid == 0) {
+        int okf = 1;
+        if (qmax == 10 || rho == 0) okf = 0;
+        else {
+          if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+          if (nBadLM >= 3) okf = 0;
+        }
+        ctl.cont = okf;
+      }
+      __syncthreads();
+      ok = ctl.cont != 0;
+      __syncthreads();
+    }
+    if (tid == 0) { stats[1 + round] = done; chi_out[round] = currentChi; }
+    // ---- classification (:1196-1270): excluded edges get a fresh residual at the final pose, active ones keep the last one
+    int bad_local = 0;
+#pragma unroll
+    for (int s = 0; s < kPoMaxPer; s++) {
+      const int i = tid + s * kPoThreads;
+      if (i >= n) continue;
+      const float ur = our[i];
+      const bool mono = ur < 0;
+      if ((out_mask >> s) & 1) {
+        double err[3], Xc[3];
+        po_edge_error(T, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
+        const double om = (double)oinv[i];
+        chi2v[s] = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
+      }
+      const float c2f = (float)chi2v[s];
+      if (c2f > (mono ? 5.991f : 7.815f)) { out_mask |= 1u << s; bad_local++; }
+      else out_mask &= ~(1u << s);
+    }
+    double bl = bad_local;
+    po_block_reduce(&bl, 1, wpart, red);
+    nBad = (int)red[0];
+    if (round == 2) robust = false;                          // setRobustKernel(0)
+    if (n < 10) break;                                        // optimizer.edges().size() < 10
+  }
+#pragma unroll
+  for (int s = 0; s < kPoMaxPer; s++) { const int i = tid + s * kPoThreads; if (i < n) outlier_out[i] = (out_mask >> s) & 1; }
+  if (tid == 0) { *T_out = T; stats[0] = nBad; }
+}
+
+}  // namespace
+
+extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
+  if (!p || !r || p->n < 0 || (p->n > 0 && (!p->Xw || !p->u || !p->v || !p->ur || !p->inv_sigma2 || !r->outlier))) return ORBG_BAD_ARG;
+  if (p->n > kPoThreads * kPoMaxPer) return ORBG_CAP_EXCEEDED;
+  int rc = select_device(p->device);
+  if (rc) return rc;
+  const int n = p->n;
+  memcpy(r->Tcw, p->Tcw, sizeof(float) * 16);
+  r->n_inliers = 0; r->n_bad = 0;
+  for (int i = 0; i < 4; i++) { r->iters[i] = 0; r->chi2[i] = 0; }
+  for (int i = 0; i < n; i++) r->outlier[i] = 0;
+  if (n < 3) return ORBG_OK;                                  // S/Optimizer.cc:1180-1181
+  // one pinned staging block: inputs in, results out (a per-thread cache keeps the allocation across calls)
+  struct Scratch { PinnedBuf<uint8_t> stage; DevBuf<uint8_t> dev; int device = -1; };
+  static thread_local Scratch sc;
+  if (sc.device != p->device) { sc.stage.release(); sc.dev.release(); sc.device = p->device; }
+  const size_t in_bytes = ((size_t)n * 7 * 4 + 15) & ~(size_t)15;
+  const size_t out_off = in_bytes;
+  const size_t out_bytes = sizeof(PoseQ) + 8 * sizeof(int) + 4 * sizeof(double) + (size_t)n + 64;
+  if ((rc = sc.stage.reserve(in_bytes + out_bytes + 64)) || (rc = sc.dev.reserve(in_bytes + out_bytes + 64))) return rc;
+  float* hs = reinterpret_cast<float*>(sc.stage.h);
+  memcpy(hs, p->Xw, (size_t)n * 12);
+  memcpy(hs + 3 * (size_t)n, p->u, (size_t)n * 4);
+  memcpy(hs + 4 * (size_t)n, p->v, (size_t)n * 4);
+  memcpy(hs + 5 * (size_t)n, p->ur, (size_t)n * 4);
+  memcpy(hs + 6 * (size_t)n, p->inv_sigma2, (size_t)n * 4);
+  ORBG_HIP(hipMemcpyAsync(sc.dev.p, sc.stage.h, in_bytes, hipMemcpyHostToDevice, 0));
+  const float* dX = reinterpret_cast<const float*>(sc.dev.p);
+  uint8_t* dout = sc.dev.p + out_off;
+  PoseQ* dT = reinterpret_cast<PoseQ*>(dout);
+  double* dchi = reinterpret_cast<double*>(dout + sizeof(PoseQ));
+  int* dstats = reinterpret_cast<int*>(dout + sizeof(PoseQ) + 4 * sizeof(double));
+  uint8_t* dflag = dout + sizeof(PoseQ) + 4 * sizeof(double) + 8 * sizeof(int);
+  PoseQ T0;
+  {
+    const float* T = p->Tcw;
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    quat_from_R(R, T0.q);
+    quat_normalize(T0.q);
+    T0.t[0] = T[3]; T0.t[1] = T[7]; T0.t[2] = T[11];
+  }
+  Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
+  hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, 0, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n, dX + 5 * (size_t)n,
+                     dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi);
+  ORBG_HIP(hipGetLastError());
+  ORBG_HIP(hipMemcpyAsync(sc.stage.h + out_off, dout, out_bytes, hipMemcpyDeviceToHost, 0));
+  ORBG_HIP(hipStreamSynchronize(0));
+  const uint8_t* ho = sc.stage.h + out_off;
+  PoseQ Tf;
+  memcpy(&Tf, ho, sizeof(PoseQ));
+  memcpy(r->chi2, ho + sizeof(PoseQ), 4 * sizeof(double));
+  int stats[8];
+  memcpy(stats, ho + sizeof(PoseQ) + 4 * sizeof(double), sizeof(stats));
+  memcpy(r->outlier, ho + sizeof(PoseQ) + 4 * sizeof(double) + 8 * sizeof(int), (size_t)n);
+  r->n_bad = stats[0];
+  for (int i = 0; i < 4; i++) r->iters[i] = stats[1 + i];
+  r->n_inliers = n - r->n_bad;
+  double R[9];
+  quat_to_R(Tf.q, R);
+  for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) r->Tcw[4 * a + c] = (float)R[3 * a + c]; r->Tcw[4 * a + 3] = (float)Tf.t[a]; }
+  r->Tcw[12] = 0; r->Tcw[13] = 0; r->Tcw[14] = 0; r->Tcw[15] = 1;
+  return ORBG_OK;
+}

@@ -225,3 +225,32 @@ def make_lba_problem(n_free=20, n_fixed=10, n_points=2000, seed=SEED_LBA, width=
     points0 = (points_true + rng.randn(n_points, 3) * 0.02).astype(np.float32)
     return dict(poses=poses0, pose_fixed=fixed, points=points0, edges=E, cam=(fx, fy, cx, cy, bf),
                 poses_true=poses_true, points_true=points_true)
+
+
+def make_pose_opt_problem(n=500, seed=0xF00D, width=640, height=480, outlier_frac=0.1, mono_frac=0.2, sigma_rot_deg=0.5,
+                          sigma_t=0.02):
+    """Correspondences of one frame for Optimizer::PoseOptimization: points in front of a camera, observations with
+    1 px * scale noise, gross outliers, initial pose = truth perturbed."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    cam = camera_for(width, height)
+    fx, fy, cx, cy, bf = [float(cam[k]) for k in ("fx", "fy", "cx", "cy", "bf")]
+    T_true = np.eye(4)
+    T_true[:3, :3] = _rot(0.05, -0.03, 0.02)
+    T_true[:3, 3] = [0.1, -0.05, 0.2]
+    z = rng.uniform(1.5, 9.0, n)
+    uu = rng.uniform(30, width - 30, n); vv = rng.uniform(30, height - 30, n)
+    Pc = np.stack([(uu - cx) * z / fx, (vv - cy) * z / fy, z], 1)
+    Xw = (Pc - T_true[:3, 3]) @ T_true[:3, :3]
+    sc = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sc[i] = np.float32(sc[i - 1] * np.float32(1.2))
+    octv = rng.randint(0, 8, n)
+    s = sc[octv].astype(np.float64)
+    u = uu + rng.randn(n) * s; v = vv + rng.randn(n) * s; ur = uu - bf / z + rng.randn(n) * s
+    bad = rng.rand(n) < outlier_frac
+    u[bad] += rng.choice([-25, 25], bad.sum()); v[bad] += rng.choice([-25, 25], bad.sum())
+    ur[rng.rand(n) < mono_frac] = -1.0
+    inv_s2 = (np.float32(1.0) / (sc * sc)).astype(np.float32)[octv]
+    T0 = perturb_pose(T_true, rng, sigma_rot_deg, sigma_t)
+    return dict(Xw=Xw.astype(np.float32), u=u.astype(np.float32), v=v.astype(np.float32), ur=ur.astype(np.float32),
+                inv_sigma2=inv_s2, cam=(fx, fy, cx, cy, bf), Tcw=T0.astype(np.float32), T_true=T_true, bad=bad)

@@ -132,3 +132,46 @@ class LbaOutput:
 
     def trace_rows(self):
         return self.trace[: self.c.trace_len].copy()
+
+
+def pose_opt_problem(Xw, u, v, ur, inv_sigma2, cam, Tcw, device=0):
+    """cam = (fx, fy, cx, cy, bf); Tcw = pFrame->mTcw (4x4)."""
+    arrs = [_c(np.asarray(Xw, np.float32).reshape(-1, 3), np.float32), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32),
+            _c(inv_sigma2, np.float32)]
+    p = capi.PoseOptProblem()
+    p.n = len(arrs[1])
+    p.Xw, p.u, p.v, p.ur, p.inv_sigma2 = [capi.ptr(a) for a in arrs]
+    p.fx, p.fy, p.cx, p.cy, p.bf = [float(c) for c in cam]
+    T = np.asarray(Tcw, np.float32).reshape(16)
+    for i in range(16):
+        p.Tcw[i] = float(T[i])
+    p.device = int(device)
+    return p, arrs
+
+
+class PoseOptOutput:
+    def __init__(self, n):
+        self.outlier = np.zeros(max(n, 1), np.uint8)
+        self.c = capi.PoseOptResult()
+        self.c.outlier = capi.ptr(self.outlier)
+        self.n = n
+
+    @property
+    def Tcw(self):
+        return np.array(list(self.c.Tcw), np.float32).reshape(4, 4)
+
+    @property
+    def n_inliers(self):
+        return self.c.n_inliers
+
+    @property
+    def iters(self):
+        return tuple(self.c.iters)
+
+    @property
+    def chi2(self):
+        return tuple(self.c.chi2)
+
+    @property
+    def outliers(self):
+        return self.outlier[: self.n].copy()

@@ -296,3 +296,9 @@ def lba_edge_eval(q, t, X, cam5, edge):
                                C.c_void_p(cam.ctypes.data), C.c_void_p(e.ctypes.data), C.c_void_p(err.ctypes.data),
                                C.c_void_p(A.ctypes.data), C.c_void_p(B.ctypes.data))
     return err, A.reshape(3, 3), B.reshape(3, 6)
+
+
+def pose_optimize(problem):
+    out = views.PoseOptOutput(problem.n)
+    _chk(lib().oracle_pose_optimize(C.byref(problem), C.byref(out.c)))
+    return out

@@ -575,3 +575,225 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
   write_back();
   return ORBG_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer::PoseOptimization(Frame*) -- S/Optimizer.cc:964-1278 (mpCamera2 == NULL branch): one SE3 vertex,
+// unary edges EdgeSE3ProjectXYZOnlyPose (I/OptimizableTypes.h:31-57, S/OptimizableTypes.cpp:49-63) and
+// g2o::EdgeStereoSE3ProjectXYZOnlyPose (G/types/types_six_dof_expmap.{h:208-236,cpp:339-346,375-404}),
+// BlockSolver_6_3 over LinearSolverDense (Eigen::LDLT, must be positive: G/solvers/linear_solver_dense.h:105-110),
+// Levenberg-Marquardt as in oracle_lba_solve.
+namespace {
+
+struct PoEdge { double X[3]; double u, v, ur; double om; bool mono; };
+
+// error of a pose-only edge; stereo: invz is float32, bf*invz is a DOUBLE product here (bf is a double member,
+// unlike the binary stereo edge whose cam_project takes `const float &bf`)
+void po_error(const PoseQ& T, const PoEdge& e, const Cam& c, double err[3], double Xc[3]) {
+  double r[3];
+  quat_rotate(T.q, e.X, r);
+  for (int i = 0; i < 3; i++) Xc[i] = r[i] + T.t[i];
+  if (e.mono) {
+    err[0] = e.u - (c.fx * Xc[0] / Xc[2] + c.cx);
+    err[1] = e.v - (c.fy * Xc[1] / Xc[2] + c.cy);
+    err[2] = 0;
+  } else {
+    const float invz = (float)(1.0f / Xc[2]);
+    const double r0 = Xc[0] * invz * c.fx + c.cx;
+    const double r1 = Xc[1] * invz * c.fy + c.cy;
+    err[0] = e.u - r0; err[1] = e.v - r1; err[2] = e.ur - (r0 - c.bf * invz);
+  }
+}
+
+void po_jacobian(const double Xc[3], const PoEdge& e, const Cam& c, double J[18]) {
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+  if (e.mono) {
+    const double P[6] = {-(c.fx / z), -0.0, -(-c.fx * x / (z * z)), -0.0, -(c.fy / z), -(-c.fy * y / (z * z))};
+    const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 6; j++) J[6 * i + j] = P[3 * i] * S[j] + P[3 * i + 1] * S[6 + j] + P[3 * i + 2] * S[12 + j];
+    for (int j = 0; j < 6; j++) J[12 + j] = 0;
+  } else {
+    const double invz = 1.0 / z, invz_2 = invz * invz;
+    J[0] = x * y * invz_2 * c.fx; J[1] = -(1 + (x * x * invz_2)) * c.fx; J[2] = y * invz * c.fx; J[3] = -invz * c.fx; J[4] = 0; J[5] = x * invz_2 * c.fx;
+    J[6] = (1 + y * y * invz_2) * c.fy; J[7] = -x * y * invz_2 * c.fy; J[8] = -x * invz * c.fy; J[9] = 0; J[10] = -invz * c.fy; J[11] = y * invz_2 * c.fy;
+    J[12] = J[0] - c.bf * y * invz_2; J[13] = J[1] + c.bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - c.bf * invz_2;
+  }
+}
+
+// 6x6 LDL^T solve; false unless every pivot is positive (Eigen::LDLT::isPositive)
+bool solve6_pd(const double H[36], const double b[6], double x[6]) {
+  double L[36] = {0}, D[6];
+  for (int j = 0; j < 6; j++) {
+    double d = H[7 * j];
+    for (int k = 0; k < j; k++) d -= L[6 * j + k] * L[6 * j + k] * D[k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    D[j] = d;
+    for (int i = j + 1; i < 6; i++) {
+      double s = H[6 * i + j];
+      for (int k = 0; k < j; k++) s -= L[6 * i + k] * L[6 * j + k] * D[k];
+      L[6 * i + j] = s / d;
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) { y[i] = b[i]; for (int k = 0; k < i; k++) y[i] -= L[6 * i + k] * y[k]; }
+  for (int i = 0; i < 6; i++) y[i] /= D[i];
+  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[6 * k + i] * x[k]; x[i] = s; }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
+  if (!p || !r || p->n < 0 || (p->n > 0 && (!p->Xw || !p->u || !p->v || !p->ur || !p->inv_sigma2 || !r->outlier))) return ORBG_BAD_ARG;
+  const int n = p->n;
+  std::memcpy(r->Tcw, p->Tcw, sizeof(float) * 16);
+  r->n_inliers = 0; r->n_bad = 0;
+  for (int i = 0; i < 4; i++) { r->iters[i] = 0; r->chi2[i] = 0; }
+  for (int i = 0; i < n; i++) r->outlier[i] = 0;                              // mvbOutlier[i] = false   (:1015,1046)
+  if (n < 3) return ORBG_OK;                                                   // :1180-1181
+  Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
+  const double deltaMono = (float)std::sqrt(5.991), deltaStereo = (float)std::sqrt(7.815);   // :1001-1002
+  std::vector<PoEdge> E(n);
+  for (int i = 0; i < n; i++) {
+    E[i].X[0] = p->Xw[3 * i]; E[i].X[1] = p->Xw[3 * i + 1]; E[i].X[2] = p->Xw[3 * i + 2];
+    E[i].u = p->u[i]; E[i].v = p->v[i]; E[i].ur = p->ur[i]; E[i].om = p->inv_sigma2[i]; E[i].mono = p->ur[i] < 0;
+  }
+  PoseQ T0;
+  {
+    const float* T = p->Tcw;
+    double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    T0.q = quat_from_R(R);
+    normalize_rotation(T0.q);
+    T0.t[0] = T[3]; T0.t[1] = T[7]; T0.t[2] = T[11];
+  }
+  std::vector<double> err(3 * (size_t)n, 0.0), chi2(n, 0.0);
+  std::vector<uint8_t> level(n, 0);          // e->level(): 1 = excluded from the optimisation
+  PoseQ T = T0;
+  bool robust = true;
+  const float chi2Mono = 5.991f, chi2Stereo = 7.815f;                          // :1183-1184 (same value every round)
+  int nBad = 0;
+  auto compute_errors = [&](const PoseQ& Tc) {                                  // active edges only
+    for (int i = 0; i < n; i++) {
+      if (level[i]) continue;
+      double Xc[3];
+      po_error(Tc, E[i], cam, &err[3 * i], Xc);
+      double c = 0;
+      const int D = E[i].mono ? 2 : 3;
+      for (int k = 0; k < D; k++) c += err[3 * i + k] * (E[i].om * err[3 * i + k]);
+      chi2[i] = c;
+    }
+  };
+  auto robust_chi2 = [&]() {
+    double s = 0;
+    for (int i = 0; i < n; i++) {
+      if (level[i]) continue;
+      if (robust) { double rho[2]; const double d = E[i].mono ? deltaMono : deltaStereo; huber(chi2[i], d, d * d, rho); s += rho[0]; }
+      else s += chi2[i];
+    }
+    return s;
+  };
+  for (int it4 = 0; it4 < 4; it4++) {
+    T = T0;                                                                     // vSE3->setEstimate(toSE3Quat(mTcw)) :1191
+    double lambda = 0, ni = 2;
+    int nBadLM = 0, done = 0;
+    bool ok = true;
+    int n_active = 0;
+    for (int i = 0; i < n; i++) n_active += !level[i];
+    double currentChi = 0;
+    for (int it = 0; it < 10 && ok && n_active > 0; it++) {
+      compute_errors(T);
+      currentChi = robust_chi2();
+      double tempChi = currentChi;
+      const double iniChi = currentChi;
+      double H[36] = {0}, b[6] = {0};
+      for (int i = 0; i < n; i++) {
+        if (level[i]) continue;
+        double Xc[3], r3[3];
+        quat_rotate(T.q, E[i].X, r3);
+        for (int k = 0; k < 3; k++) Xc[k] = r3[k] + T.t[k];
+        double J[18];
+        po_jacobian(Xc, E[i], cam, J);
+        const int D = E[i].mono ? 2 : 3;
+        double w = 1.0;
+        if (robust) { double rho[2]; const double d = E[i].mono ? deltaMono : deltaStereo; huber(chi2[i], d, d * d, rho); w = rho[1]; }
+        for (int a = 0; a < 6; a++) {
+          double s = 0;
+          for (int k = 0; k < D; k++) s += J[6 * k + a] * (-(E[i].om * err[3 * i + k]) * w);
+          b[a] += s;
+          for (int c = 0; c < 6; c++) {
+            double h = 0;
+            for (int k = 0; k < D; k++) h += J[6 * k + a] * (w * E[i].om) * J[6 * k + c];
+            H[6 * a + c] += h;
+          }
+        }
+      }
+      if (it == 0) {
+        double mx = 0;
+        for (int j = 0; j < 6; j++) mx = std::max(std::fabs(H[7 * j]), mx);
+        lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
+      }
+      double rho = 0;
+      int qmax = 0;
+      double x[6] = {0, 0, 0, 0, 0, 0};
+      do {
+        const PoseQ backup = T;
+        double Hl[36];
+        for (int k = 0; k < 36; k++) Hl[k] = H[k] + (k % 7 == 0 ? lambda : 0.0);
+        const bool ok2 = solve6_pd(Hl, b, x);
+        pose_oplus(T, x);
+        compute_errors(T);
+        tempChi = robust_chi2();
+        if (!ok2) tempChi = std::numeric_limits<double>::max();
+        rho = currentChi - tempChi;
+        double scale = 0;
+        for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+        } else {
+          lambda *= ni; ni *= 2;
+          T = backup;
+        }
+        qmax++;
+      } while (rho < 0 && qmax < 10);
+      done++;
+      if (qmax == 10 || rho == 0) { ok = false; continue; }
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+      if (nBadLM >= 3) ok = false;
+    }
+    r->iters[it4] = done;
+    r->chi2[it4] = currentChi;
+    // :1196-1270 -- excluded edges get a fresh error, active ones keep the LAST evaluated one
+    nBad = 0;
+    for (int i = 0; i < n; i++) {
+      if (r->outlier[i]) {
+        double Xc[3];
+        po_error(T, E[i], cam, &err[3 * i], Xc);
+        double c = 0;
+        const int D = E[i].mono ? 2 : 3;
+        for (int k = 0; k < D; k++) c += err[3 * i + k] * (E[i].om * err[3 * i + k]);
+        chi2[i] = c;
+      }
+      const float c2 = (float)chi2[i];
+      if (c2 > (E[i].mono ? chi2Mono : chi2Stereo)) { r->outlier[i] = 1; level[i] = 1; nBad++; }
+      else { r->outlier[i] = 0; level[i] = 0; }
+    }
+    if (it4 == 2) robust = false;                                              // e->setRobustKernel(0) :1219,1245,1268
+    if (n < 10) break;                                                          // optimizer.edges().size() < 10 :1272
+  }
+  {
+    double R[9];
+    quat_to_R(T.q, R);
+    for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) r->Tcw[4 * a + c] = (float)R[3 * a + c]; r->Tcw[4 * a + 3] = (float)T.t[a]; }
+    r->Tcw[12] = 0; r->Tcw[13] = 0; r->Tcw[14] = 0; r->Tcw[15] = 1;
+  }
+  r->n_bad = nBad;
+  r->n_inliers = n - nBad;
+  return ORBG_OK;
+}

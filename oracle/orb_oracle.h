@@ -86,6 +86,7 @@ int oracle_search_by_bow(const orbm_frame_view* view, const orbm_featvec_view* f
 
 /* ---- LBA (S/Optimizer.cc:1810-2410 + vendored g2o) */
 int oracle_lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
+int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* r);
 /* pieces for the known-answer tests */
 void oracle_se3_exp(const double* upd6 /*omega,upsilon*/, double* q4_xyzw, double* t3);
 void oracle_lba_edge_eval(const double* q4_xyzw, const double* t3, const double* X3, const float* cam5 /*fx fy cx cy bf*/,

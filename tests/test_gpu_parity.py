@@ -298,3 +298,18 @@ def test_c4_sizes_1280x720_2000_features_and_50kf_lba():
     assert g.status == o.status == capi.LBA_APPLIED and g.iters == o.iters
     assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4
     assert np.array_equal(g.edge_outlier, o.edge_outlier)
+
+
+@pytest.mark.parametrize("n,of,mono", [(500, 0.1, 0.2), (900, 0.3, 0.0), (40, 0.0, 1.0), (8, 0.0, 0.0), (2, 0.0, 0.0)])
+def test_pose_optimization_parity(n, of, mono):
+    """Optimizer::PoseOptimization (row f-2): whole solve in one launch vs. the oracle."""
+    pr = synth.make_pose_opt_problem(n=n, outlier_frac=of, mono_frac=mono, seed=100 + n)
+    p, keep = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"])
+    g = api.Optimizer().PoseOptimization(p)
+    o = ob.pose_optimize(p)
+    assert g.iters == o.iters and g.n_inliers == o.n_inliers
+    assert np.array_equal(g.outliers, o.outliers)
+    assert np.abs(g.Tcw - o.Tcw).max() <= 1e-4
+    assert np.allclose(g.chi2, o.chi2, rtol=1e-8, atol=1e-9)
+    g2 = api.Optimizer().PoseOptimization(p)
+    assert np.array_equal(g.Tcw, g2.Tcw)

@@ -303,3 +303,40 @@ def test_lba_huber_boundary_and_statuses():
     p4, keep4 = views.lba_problem(poses, fixed, prob2["points"], prob2["edges"], prob2["cam"])
     o4 = ob.lba_solve(p4)
     assert o4.status == capi.LBA_APPLIED and np.allclose(o4.poses[-1], poses[-1], atol=1e-6)   # R->q->R round trip only
+
+
+# ---------------------------------------------------------------- PoseOptimization (row f-2)
+def _po(pr):
+    return views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"])
+
+
+def test_pose_optimization_recovers_pose_and_flags_outliers():
+    pr = synth.make_pose_opt_problem(n=400, outlier_frac=0.15, mono_frac=0.3, seed=5)
+    p, keep = _po(pr)
+    o = ob.pose_optimize(p)
+    e0 = np.abs(pr["Tcw"][:3, 3] - pr["T_true"][:3, 3]).max()
+    e1 = np.abs(o.Tcw[:3, 3] - pr["T_true"][:3, 3]).max()
+    assert e1 < 0.25 * e0 and e1 < 5e-3
+    flagged = o.outliers.astype(bool)
+    assert flagged[pr["bad"]].mean() > 0.97            # gross outliers are caught
+    assert flagged[~pr["bad"]].mean() < 0.12           # ~5 % false alarms of a chi2 test at 95 %
+    assert o.n_inliers == 400 - flagged.sum()
+    assert all(1 <= it <= 10 for it in o.iters)
+    # noise-free: converges to the true pose, nothing flagged
+    pr0 = synth.make_pose_opt_problem(n=100, outlier_frac=0.0, seed=6)
+    T = pr0["T_true"]; fx, fy, cx, cy, bf = pr0["cam"]
+    Pc = pr0["Xw"].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    pr0["u"] = (fx * Pc[:, 0] / Pc[:, 2] + cx).astype(np.float32); pr0["v"] = (fy * Pc[:, 1] / Pc[:, 2] + cy).astype(np.float32)
+    st = pr0["ur"] >= 0
+    pr0["ur"] = np.where(st, pr0["u"] - bf / Pc[:, 2], -1).astype(np.float32)
+    o0 = ob.pose_optimize(_po(pr0)[0])
+    assert o0.outliers.sum() == 0 and np.abs(o0.Tcw - T.astype(np.float32)).max() < 2e-4
+
+
+def test_pose_optimization_small_problem_rules():
+    pr = synth.make_pose_opt_problem(n=2, outlier_frac=0.0)
+    o = ob.pose_optimize(_po(pr)[0])
+    assert o.n_inliers == 0 and np.array_equal(o.Tcw, pr["Tcw"]) and o.iters == (0, 0, 0, 0)      # < 3 correspondences
+    pr = synth.make_pose_opt_problem(n=8, outlier_frac=0.0)
+    o = ob.pose_optimize(_po(pr)[0])
+    assert o.iters[0] > 0 and o.iters[1:] == (0, 0, 0)                                            # < 10 edges: one round
