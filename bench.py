@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--separate-calls", action="store_true",
                     help="call extract / ComputeStereoMatches / grid as three entry points instead of the fused "
                          "Frame-constructor entry point orbx_frame_stereo_dev")
+    ap.add_argument("--pose-opt", action="store_true",
+                    help="also run Optimizer::PoseOptimization (SURVEY row f-2) after each of the two searches, as "
+                         "Tracking does; off by default so that the metric stays the one SURVEY.md 8(d) defines")
     ap.add_argument("--profile-stages", action="store_true",
                     help="bracket every extractor stage with HIP events (more API calls per frame); by default only "
                          "fast_cells_kernel (the roofline kernel) is bracketed")
@@ -160,7 +163,13 @@ def main():
     bf, bb = float(cam["bf"]), float(cam["b"])
     nF = len(frames)
     seq = list(range(nF)) + list(range(nF - 2, 0, -1))             # ping-pong: consecutive frames stay adjacent
-    stage = dict(extract=0.0, stereo=0.0, grid=0.0, match_frame=0.0, match_map=0.0, lba=0.0, map_upload=0.0)
+    stage = dict(extract=0.0, stereo=0.0, grid=0.0, match_frame=0.0, match_map=0.0, lba=0.0, map_upload=0.0, pose_opt=0.0)
+    po_prob = synth.make_pose_opt_problem(n=450, seed=77 + rank)
+    po1, po1_keep = views.pose_opt_problem(po_prob["Xw"], po_prob["u"], po_prob["v"], po_prob["ur"], po_prob["inv_sigma2"],
+                                          po_prob["cam"], po_prob["Tcw"], device=device)
+    po_prob2 = synth.make_pose_opt_problem(n=650, seed=78 + rank)
+    po2, po2_keep = views.pose_opt_problem(po_prob2["Xw"], po_prob2["u"], po_prob2["v"], po_prob2["ur"], po_prob2["inv_sigma2"],
+                                          po_prob2["cam"], po_prob2["Tcw"], device=device)
     ex.set_profiling(2 if args.profile_stages else 1)
     kern = dict(fast_kernel_ms=0.0, octree_host_ms=0.0)
     if args.profile_stages:
@@ -210,6 +219,15 @@ def main():
         t4 = time.perf_counter()
         amp, aob, n2 = m_map.SearchLocalPoints(F, LM, fr["guess"], 1.0, False, 0.0, amp, aob, None)
         t5 = time.perf_counter()
+        if args.pose_opt:
+            # TrackWithMotionModel / TrackLocalMap call PoseOptimization after each search (S/Tracking.cc:2649,2712);
+            # ~450 and ~650 correspondences as the two searches produce here
+            opt.PoseOptimization(po1)
+            opt.PoseOptimization(po2)
+            tpo = time.perf_counter()
+            if timed:
+                stage["pose_opt"] += tpo - t5
+            t5 = tpo
         t6 = t7 = t5
         if i % FRAMES_PER_KF == 0:
             mp = local_map_for(frames, k)
@@ -247,6 +265,13 @@ def main():
 
     # barrier + synchronize, exactly K steps, synchronize + barrier, MAX over ranks (harness.AgentGroup.timed)
     elapsed = grp.timed(lambda i: step(args.warmup + i, True), args.steps, sync)
+    # informational: one PoseOptimization call (not part of `value` unless --pose-opt)
+    for _ in range(5):
+        opt.PoseOptimization(po1)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        opt.PoseOptimization(po1)
+    pose_opt_ms = 1e3 * (time.perf_counter() - t0) / 20
     if rank == 0:
         K = args.steps
         ms_per_step = 1e3 * elapsed / K
@@ -280,7 +305,8 @@ def main():
                        "device_ms_per_frame": {k2: round(v / K, 4) for k2, v in kern.items()},
                        "avg_keypoints_per_stereo_frame": round(stats["kp"] / K, 1),
                        "avg_matches_frame": round(stats["m_frame"] / K, 1), "avg_matches_map": round(stats["m_map"] / K, 1),
-                       "lba_mode": args.lba_mode,
+                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt),
+                       "pose_opt_ms_per_call_450_correspondences": round(pose_opt_ms, 4),
                        "lba_ms_per_call": round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3),
                        "sequential_fps_formula": round(1.0 / (sum(v for k2, v in stage.items() if k2 != "lba") / K +
                                                              stats["lba_s"] / max(stats["lba_calls"], 1) / FRAMES_PER_KF), 3),

@@ -1320,26 +1320,75 @@ extern "C" int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag
 // synchronisation per LM trial (~40-60 per call); this needs one.
 namespace {
 
-struct PoCtl {            // LDS broadcast block
-  PoseQ T;                // pose under evaluation
-  int cont, accept;
-};
-
 constexpr int kPoThreads = 256;
 constexpr int kPoMaxPer = 16;      // correspondences per thread (n <= 4096)
+constexpr int kPoRow = 8 * 33;     // one reduction row: 8 segments of 32 values, padded against LDS bank conflicts
 
-__device__ inline void po_block_reduce(double* vals, int nv, double (*wpart)[28], double* out) {
-  // vals[0..nv) per thread -> out[0..nv) (valid in thread 0..nv-1 after the call: every thread reads out[] from LDS)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = 0; i < nv; i++) {
-    double v = vals[i];
+// Block-wide sums of NV per-thread values in a fixed order: transpose through LDS, 8 threads per value add 32
+// entries each, one thread per value adds the 8 partials.  out[0..NV) is valid for every thread afterwards.
+template <int NV>
+__device__ inline void po_block_reduce(const double* vals, double* s_acc, double* s_part, double* out) {
+  const int tid = threadIdx.x;
+  const int col = (tid >> 5) * 33 + (tid & 31);
 #pragma unroll
-    for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
-    if (lane == 0) wpart[wave][i] = v;
+  for (int v = 0; v < NV; v++) s_acc[v * kPoRow + col] = vals[v];
+  __syncthreads();
+  if (tid < NV * 8) {
+    const double* p = s_acc + (tid >> 3) * kPoRow + (tid & 7) * 33;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { a0 += p[4 * j]; a1 += p[4 * j + 1]; a2 += p[4 * j + 2]; a3 += p[4 * j + 3]; }
+    s_part[tid] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
-  if (threadIdx.x < nv) out[threadIdx.x] = ((wpart[0][threadIdx.x] + wpart[1][threadIdx.x]) + wpart[2][threadIdx.x]) + wpart[3][threadIdx.x];
+  if (tid < NV) {
+    const double* p = s_part + tid * 8;
+    out[tid] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  }
   __syncthreads();
+}
+
+__device__ __forceinline__ double po_readlane(double v, int lane) {   // lane must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// (H + lambda I) x = b by LDL^T without pivoting, spread over lanes 0..5 of a wave: lane `li` holds row li.  Every
+// subtraction happens in the order of a scalar left-looking factorisation (ascending k), so the factors are the
+// same bits a serial solve would produce.  Returns false unless every pivot is positive (Eigen::LDLT::isPositive),
+// in which case x is left untouched.  x[] comes out wave-uniform.
+__device__ inline bool po_solve6(const double* Hrow, double b_li, int li, double lambda, double* x) {
+  double A[6], D[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) A[j] = Hrow[j] + (j == li ? lambda : 0.0);
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double d = po_readlane(A[k], k);
+    if (!(d > 0.0) || fabs(d) == INFINITY) ok = false;
+    D[k] = d;
+    const double Lik = A[k] / d;
+#pragma unroll
+    for (int j = k + 1; j < 6; j++) { const double Ljk = po_readlane(Lik, j); A[j] -= (Lik * Ljk) * d; }
+    A[k] = Lik;
+  }
+  if (!ok) return false;
+  double y = b_li;
+#pragma unroll
+  for (int k = 0; k < 5; k++) { const double yk = po_readlane(y, k); if (li > k) y -= A[k] * yk; }
+  double Di = D[0];
+#pragma unroll
+  for (int k = 1; k < 6; k++) Di = (li == k) ? D[k] : Di;
+  y /= Di;
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double sv = po_readlane(y, i);
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) sv -= po_readlane(A[i], k) * x[k];
+    x[i] = sv;
+  }
+  return true;
 }
 
 __device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, float v, float ur, const Cam& c, double* err, double* Xc) {
@@ -1360,37 +1409,39 @@ __device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, fl
   }
 }
 
+// Optimizer::PoseOptimization (S/Optimizer.cc:992-1290) in ONE launch of one workgroup: 4 rounds x up to 10
+// Levenberg-Marquardt iterations (g2o OptimizationAlgorithmLevenberg semantics), outlier re-classification after
+// each round.  The LM state (pose, lambda, gains) is kept identically in every thread -- all of them read the same
+// block sums from LDS and run the same arithmetic -- so the control flow needs no broadcast; the 6x6 solve runs on
+// lanes 0..5 of each wave.
 __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float* __restrict__ Xw, const float* __restrict__ ou,
                                                              const float* __restrict__ ov, const float* __restrict__ our,
                                                              const float* __restrict__ oinv, Cam cam, PoseQ T0,
                                                              PoseQ* __restrict__ T_out, uint8_t* __restrict__ outlier_out,
                                                              int* __restrict__ stats /*n_bad, iters[4]*/, double* __restrict__ chi_out) {
-  __shared__ double wpart[4][28];
+  __shared__ double s_acc[28 * kPoRow];
+  __shared__ double s_part[28 * 8];
   __shared__ double red[28];
-  __shared__ PoCtl ctl;
+  __shared__ double s_chi2[kPoThreads * kPoMaxPer];      // last evaluated chi2 of every correspondence
+  __shared__ uint8_t s_out[kPoThreads * kPoMaxPer];      // mvbOutlier
   const int tid = threadIdx.x;
+  const int li = min(tid & 63, 5);
   const double dM = (float)sqrt(5.991), dS = (float)sqrt(7.815);
   const double dsqM = dM * dM, dsqS = dS * dS;
-  // per-thread correspondence state (registers): outlier flag, level, last evaluated chi2
-  unsigned out_mask = 0;                 // mvbOutlier
-  double chi2v[kPoMaxPer];
-#pragma unroll
-  for (int s = 0; s < kPoMaxPer; s++) chi2v[s] = 0;
-  // thread-0 LM state
-  double H[21], b[6], x[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < n; i += kPoThreads) { s_chi2[i] = 0; s_out[i] = 0; }
+  double x[6] = {0, 0, 0, 0, 0, 0};
   double lambda = 0, ni = 2, currentChi = 0;
   int nBadLM = 0;
   bool robust = true;
   PoseQ T = T0;
   int nBad = 0;
   if (tid == 0) { for (int i = 0; i < 8; i++) stats[i] = 0; for (int i = 0; i < 4; i++) chi_out[i] = 0; }
+  __syncthreads();
   for (int round = 0; round < 4; round++) {
     T = T0;                                                   // setEstimate(toSE3Quat(mTcw)) every round (:1191)
-    int n_active_local = 0;
-#pragma unroll
-    for (int s = 0; s < kPoMaxPer; s++) { const int i = tid + s * kPoThreads; if (i < n && !((out_mask >> s) & 1)) n_active_local++; }
-    double cnt = n_active_local;
-    po_block_reduce(&cnt, 1, wpart, red);
+    double cnt = 0;
+    for (int i = tid; i < n; i += kPoThreads) cnt += !s_out[i];
+    po_block_reduce<1>(&cnt, s_acc, s_part, red);
     const int n_active = (int)red[0];
     int done = 0;
     bool ok = n_active > 0;
@@ -1399,17 +1450,15 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
       double acc[28];
 #pragma unroll
       for (int i = 0; i < 28; i++) acc[i] = 0;
-#pragma unroll
-      for (int s = 0; s < kPoMaxPer; s++) {
-        const int i = tid + s * kPoThreads;
-        if (i >= n || ((out_mask >> s) & 1)) continue;
+      for (int i = tid; i < n; i += kPoThreads) {
+        if (s_out[i]) continue;
         const float ur = our[i];
         const bool mono = ur < 0;
         double err[3], Xc[3];
         po_edge_error(T, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
         const double om = (double)oinv[i];
         const double c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
-        chi2v[s] = c2;
+        s_chi2[i] = c2;
         double rho0 = c2, rho1 = 1.0;
         if (robust) huber(c2, mono ? dM : dS, mono ? dsqM : dsqS, &rho0, &rho1);
         acc[27] += rho0;
@@ -1446,167 +1495,96 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
           acc[o++] += sacc;
         }
       }
-      po_block_reduce(acc, 28, wpart, red);
-      double iniChi = 0;
-      if (tid == 0) {
+      po_block_reduce<28>(acc, s_acc, s_part, red);
+      // every thread takes its own copy of the system: row li of H (upper triangle packed row-major in red[0..21)), b
+      double Hrow[6], b[6];
 #pragma unroll
-        for (int i = 0; i < 21; i++) H[i] = red[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) b[i] = red[21 + i];
-        currentChi = red[27];
-        iniChi = currentChi;
-        if (it == 0) {
-          const int di[6] = {0, 6, 11, 15, 18, 20};
-          double mx = 0;
-#pragma unroll
-          for (int j = 0; j < 6; j++) mx = fmax(mx, fabs(H[di[j]]));
-          lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
-        }
+      for (int j = 0; j < 6; j++) {
+        const int a = min(li, j), c = max(li, j);
+        Hrow[j] = red[a * 6 - (a * (a - 1)) / 2 + (c - a)];
+        b[j] = red[21 + j];
+      }
+      const double b_li = red[21 + li];
+      currentChi = red[27];
+      const double iniChi = currentChi;
+      if (it == 0) {
+        const double mx = fmax(fmax(fmax(fabs(red[0]), fabs(red[6])), fmax(fabs(red[11]), fabs(red[15]))), fmax(fabs(red[18]), fabs(red[20])));
+        lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
       }
       // ---- LM trials
       double rho = 0;
       int qmax = 0;
       for (;;) {
-        bool ok2 = true;
-        if (tid == 0) {
-          // (H + lambda I) x = b by LDL^T without pivoting; "ok" only if every pivot is positive (Eigen::LDLT::isPositive)
-          double A[36];
-          {
-            int o = 0;
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-              for (int c = a; c < 6; c++) { const double v = H[o++] + (a == c ? lambda : 0.0); A[6 * a + c] = v; A[6 * c + a] = v; }
-          }
-          double D[6];
-#pragma unroll
-          for (int j = 0; j < 6; j++) {
-            double d = A[7 * j];
-#pragma unroll
-            for (int k = 0; k < j; k++) d -= A[6 * j + k] * A[6 * j + k] * D[k];
-            if (!(d > 0.0) || fabs(d) == INFINITY) ok2 = false;
-            D[j] = d;
-#pragma unroll
-            for (int i = j + 1; i < 6; i++) {
-              double sv = A[6 * i + j];
-#pragma unroll
-              for (int k = 0; k < j; k++) sv -= A[6 * i + k] * A[6 * j + k] * D[k];
-              A[6 * i + j] = sv / d;
-            }
-          }
-          if (ok2) {
-            double y[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) { double v = b[i];
-#pragma unroll
-              for (int k = 0; k < i; k++) v -= A[6 * i + k] * y[k];
-              y[i] = v; }
-#pragma unroll
-            for (int i = 0; i < 6; i++) y[i] /= D[i];
-#pragma unroll
-            for (int i = 5; i >= 0; i--) { double v = y[i];
-#pragma unroll
-              for (int k = i + 1; k < 6; k++) v -= A[6 * k + i] * x[k];
-              x[i] = v; }
-          }
-          pose_oplus(T, x, &ctl.T);                       // update with whatever x holds, as g2o does
-        }
-        __syncthreads();
-        const PoseQ Tt = ctl.T;
+        const bool ok2 = po_solve6(Hrow, b_li, li, lambda, x);
+        PoseQ Tt;
+        pose_oplus(T, x, &Tt);                              // update with whatever x holds, as g2o does
         double tchi = 0;
-        double tmp_chi[kPoMaxPer];
-#pragma unroll
-        for (int s = 0; s < kPoMaxPer; s++) {
-          tmp_chi[s] = chi2v[s];
-          const int i = tid + s * kPoThreads;
-          if (i >= n || ((out_mask >> s) & 1)) continue;
+        // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
+        for (int i = tid; i < n; i += kPoThreads) {
+          if (s_out[i]) continue;
           const float ur = our[i];
           const bool mono = ur < 0;
           double err[3], Xc[3];
           po_edge_error(Tt, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
           const double om = (double)oinv[i];
           const double c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
-          tmp_chi[s] = c2;
+          s_chi2[i] = c2;
           double rho0 = c2, rho1;
           if (robust) huber(c2, mono ? dM : dS, mono ? dsqM : dsqS, &rho0, &rho1);
           tchi += rho0;
         }
-        // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
+        po_block_reduce<1>(&tchi, s_acc, s_part, red);
+        double tempChi = red[0];
+        if (!ok2) tempChi = 1.7976931348623157e308;
+        rho = currentChi - tempChi;
+        double scale = 0;
 #pragma unroll
-        for (int s = 0; s < kPoMaxPer; s++) chi2v[s] = tmp_chi[s];
-        po_block_reduce(&tchi, 1, wpart, red);
-        if (tid == 0) {
-          double tempChi = red[0];
-          if (!ok2) tempChi = 1.7976931348623157e308;
-          rho = currentChi - tempChi;
-          double scale = 0;
-#pragma unroll
-          for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
-          scale += 1e-3;
-          rho /= scale;
-          int accept = 0;
-          if (rho > 0 && fabs(tempChi) != INFINITY && tempChi == tempChi) {
-            double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
-            alpha = fmin(alpha, 2. / 3.);
-            lambda *= fmax(1. / 3., alpha);
-            ni = 2;
-            currentChi = tempChi;
-            T = ctl.T;
-            accept = 1;
-          } else {
-            lambda *= ni; ni *= 2;
-          }
-          qmax++;
-          ctl.accept = accept;
-          ctl.cont = (rho < 0 && qmax < 10) ? 1 : 0;
+        for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && fabs(tempChi) != INFINITY && tempChi == tempChi) {
+          double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+          alpha = fmin(alpha, 2. / 3.);
+          lambda *= fmax(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+          T = Tt;
+        } else {
+          lambda *= ni; ni *= 2;
         }
-        __syncthreads();
-        const int cont = ctl.cont;
-        if (ctl.accept) T = ctl.T;
-        __syncthreads();
-        if (!cont) break;
+        qmax++;
+        if (!(rho < 0 && qmax < 10)) break;
       }
       done++;
-      if (tid == 0) {
-        int okf = 1;
-        if (qmax == 10 || rho == 0) okf = 0;
-        else {
-          if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
-          if (nBadLM >= 3) okf = 0;
-        }
-        ctl.cont = okf;
+      if (qmax == 10 || rho == 0) ok = false;
+      else {
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+        if (nBadLM >= 3) ok = false;
       }
-      __syncthreads();
-      ok = ctl.cont != 0;
-      __syncthreads();
     }
     if (tid == 0) { stats[1 + round] = done; chi_out[round] = currentChi; }
     // ---- classification (:1196-1270): excluded edges get a fresh residual at the final pose, active ones keep the last one
-    int bad_local = 0;
-#pragma unroll
-    for (int s = 0; s < kPoMaxPer; s++) {
-      const int i = tid + s * kPoThreads;
-      if (i >= n) continue;
+    double bl = 0;
+    for (int i = tid; i < n; i += kPoThreads) {
       const float ur = our[i];
       const bool mono = ur < 0;
-      if ((out_mask >> s) & 1) {
+      if (s_out[i]) {
         double err[3], Xc[3];
         po_edge_error(T, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
         const double om = (double)oinv[i];
-        chi2v[s] = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
+        s_chi2[i] = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
       }
-      const float c2f = (float)chi2v[s];
-      if (c2f > (mono ? 5.991f : 7.815f)) { out_mask |= 1u << s; bad_local++; }
-      else out_mask &= ~(1u << s);
+      const float c2f = (float)s_chi2[i];
+      const bool bad = c2f > (mono ? 5.991f : 7.815f);
+      s_out[i] = bad;
+      bl += bad;
     }
-    double bl = bad_local;
-    po_block_reduce(&bl, 1, wpart, red);
+    po_block_reduce<1>(&bl, s_acc, s_part, red);
     nBad = (int)red[0];
     if (round == 2) robust = false;                          // setRobustKernel(0)
     if (n < 10) break;                                        // optimizer.edges().size() < 10
   }
-#pragma unroll
-  for (int s = 0; s < kPoMaxPer; s++) { const int i = tid + s * kPoThreads; if (i < n) outlier_out[i] = (out_mask >> s) & 1; }
+  for (int i = tid; i < n; i += kPoThreads) outlier_out[i] = s_out[i];
   if (tid == 0) { *T_out = T; stats[0] = nBad; }
 }
 
