@@ -258,6 +258,28 @@ int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fv_frame,
                        const orbm_featvec_view* fv_kf, float nnratio, int check_orientation,
                        int32_t* matches, int* nmatches);
 
+/* Server-side KeyFrame matchers.  A KeyFrame carries the same undistorted keypoints, descriptors
+ * and 64x48 grid as the Frame it was made from (S/KeyFrame.cc:889-940 copies mGrid), so it is an orbm_frame here.
+ *
+ * int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
+ *                                    vector<MapPoint*>& vpMatched, int th, float ratioHamming), S/ORBmatcher.cc:473-587
+ *   -> camera_project = 1 (projects with pKF->mpCamera->project)
+ * and the overload with vpPointsKFs / vpMatchedKF, :589-700 -> camera_project = 0 (float invz projection); the adapter
+ * fills vpMatchedKF[idx] = vpPointsKFs[matched[idx]].
+ * pts: candidate points resident on the device (pts.skip/bad exclude); already_found[m] (may be NULL) = point is already
+ * in vpMatched on entry.  matched[n] in/out: -1 = NULL; entries written are indices into pts. */
+int orbm_search_by_projection_sim3(orbm_frame* kf, orbm_map* pts, const float* Scw /*16, row-major Sim3*/,
+                                   const uint8_t* already_found, int th, float ratio_hamming, int camera_project,
+                                   int32_t* matched, int* nmatches);
+
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), S/ORBmatcher.cc:819-959.
+ * kf2 = pKF2 with its feature vector fv2 and mp_valid2[i] = (MapPoint present and not bad); the pKF1 side is flattened
+ * as for orbm_search_by_bow.  matches12[n1] out: feature index in pKF2 (-> vpMapPoints2[idx]) or -1. */
+int orbm_search_by_bow_kf(orbm_frame* kf2, const orbm_featvec_view* fv2, const uint8_t* mp_valid2,
+                          const uint8_t* desc1, int n1, const uint8_t* mp_valid1, const float* angle1,
+                          const orbm_featvec_view* fv1, float nnratio, int check_orientation,
+                          int32_t* matches12, int* nmatches);
+
 /* ---------------------------------------------------------------- local bundle adjustment */
 
 /* One reprojection edge (S/Optimizer.cc:2021-2084): mono if ur < 0, stereo otherwise. */

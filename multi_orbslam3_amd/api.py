@@ -325,6 +325,33 @@ class ORBmatcher:
         return matches[: F.n].copy(), n.value
 
 
+    def SearchByProjectionSim3(self, pKF, Scw, points, vpMatched, th, ratioHamming=1.0, already_found=None, with_kfs=False):
+        """(KeyFrame*, Scw, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming): S/ORBmatcher.cc:473-587
+        (with_kfs=False) and :589-700 (with_kfs=True).  points: LocalMap resident on the device."""
+        matched = np.ascontiguousarray(vpMatched, np.int32).copy()
+        S = np.ascontiguousarray(Scw, np.float32).reshape(16)
+        af = None if already_found is None else np.ascontiguousarray(already_found, np.uint8)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_projection_sim3(pKF.h, points.h, _vp(S), _vp(af), int(th), C.c_float(ratioHamming),
+                                                           0 if with_kfs else 1, _vp(matched), C.byref(n)),
+                   "orbm_search_by_projection_sim3")
+        return matched, n.value
+
+    def SearchByBoWKF(self, pKF2, fv2, mp_valid2, desc1, mp_valid1, angle1, fv1):
+        """(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12): S/ORBmatcher.cc:819-959; returns matches12 (indices into pKF2)."""
+        desc1 = np.ascontiguousarray(desc1, np.uint8)
+        mp_valid1 = np.ascontiguousarray(mp_valid1, np.uint8)
+        mp_valid2 = np.ascontiguousarray(mp_valid2, np.uint8)
+        angle1 = np.ascontiguousarray(angle1, np.float32)
+        matches = np.zeros(max(len(desc1), 1), np.int32)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_bow_kf(pKF2.h, C.byref(fv2), _vp(mp_valid2), _vp(desc1), len(desc1), _vp(mp_valid1),
+                                                  _vp(angle1), C.byref(fv1), C.c_float(self.mfNNratio),
+                                                  int(self.mbCheckOrientation), _vp(matches), C.byref(n)),
+                   "orbm_search_by_bow_kf")
+        return matches[: len(desc1)].copy(), n.value
+
+
 class Optimizer:
     """ORB_SLAM3::Optimizer (I/Optimizer.h:30-113): LocalBundleAdjustment numerical core."""
 

@@ -308,7 +308,7 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
         }
         const float distx = kp.x - q.x, disty = kp.y - q.y;
         if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) ok = false;
-        if (ok && F.assigned_mp[idx] >= 0 && F.assigned_obs[idx] > 0) ok = false;
+        if (ok && F.assigned_mp[idx] >= 0 && (!F.assigned_obs || F.assigned_obs[idx] > 0)) ok = false;
         if (ok && F.uright) {
           const float ur = F.uright[idx];
           if (ur > 0) {
@@ -365,6 +365,55 @@ __global__ __launch_bounds__(256) void search_mps_kernel(FrameParams fp, FrameDe
   window_search(fp, F, q, mp.desc + (size_t)i * 32, i, mp.m, list_counter, list, list_cap, results + i);
 }
 
+
+// SearchByProjection(KeyFrame*, Scw, ...) candidate tests (S/ORBmatcher.cc:495-548 / :612-667) fused with the window search
+__global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameDev F, WorldPtsDev w, const uint8_t* __restrict__ found,
+                                                         PoseF P, int camera_project, int th, int* list_counter, uint32_t* list,
+                                                         int list_cap, QResult* results) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= w.m) return;
+  Query q;
+  q.valid = 0; q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
+  if (!(w.bad[i] || w.skip[i] || (found && found[i]))) {
+    const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
+    float Pc[3];
+    pose_map(P, X, Pc);
+    if (!(Pc[2] < 0.0f)) {
+      float u, v;
+      if (camera_project) {
+        u = fp.fx * Pc[0] / Pc[2] + fp.cx;
+        v = fp.fy * Pc[1] / Pc[2] + fp.cy;
+      } else {
+        const float invz = 1.0f / Pc[2];
+        const float x = Pc[0] * invz, y = Pc[1] * invz;
+        u = fp.fx * x + fp.cx;
+        v = fp.fy * y + fp.cy;
+      }
+      if (u >= fp.min_x && u < fp.max_x && v >= fp.min_y && v < fp.max_y) {           // KeyFrame::IsInImage
+        const float max_raw = w.max_dist[i];
+        const float maxDistance = 1.2f * max_raw, minDistance = 0.8f * w.min_dist[i];
+        const float PO[3] = {X[0] - P.Ow[0], X[1] - P.Ow[1], X[2] - P.Ow[2]};
+        const float dist = norm3d(PO);
+        if (!(dist < minDistance || dist > maxDistance)) {
+          const double dot = (double)PO[0] * w.normal[3 * i] + (double)PO[1] * w.normal[3 * i + 1] + (double)PO[2] * w.normal[3 * i + 2];
+          if (!(dot < 0.5 * (double)dist)) {
+            const float ratio = max_raw / dist;                                        // PredictScale(dist, pKF)
+            const float lg = (float)log((double)ratio);
+            int lvl = (int)ceilf(lg / fp.log_sf);
+            if (lvl < 0) lvl = 0;
+            else if (lvl >= fp.n_levels) lvl = fp.n_levels - 1;
+            q.valid = 1;
+            q.x = u; q.y = v;
+            q.r = (float)th * fp.scale[lvl];
+            q.min_level = lvl - 1; q.max_level = lvl;
+          }
+        }
+      }
+    }
+  }
+  window_search(fp, F, q, w.desc + (size_t)i * 32, i, w.m, list_counter, list, list_cap, results + i);
+}
+
 // MODE 2: SearchByProjection(CurrentFrame, LastFrame) (S/ORBmatcher.cc:1993-2066)
 struct LastDev {
   int n;
@@ -405,6 +454,7 @@ __global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, Frame
 struct BowJob { int kf_idx; int f_begin, f_end; };   // frame-side bucket [f_begin,f_end) in fvF.feat_idx
 
 __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restrict__ fdesc, const uint32_t* __restrict__ f_feat_idx,
+                                                        const uint8_t* __restrict__ tvalid /*target eligibility or NULL*/,
                                                         const uint8_t* __restrict__ kf_desc, const BowJob* __restrict__ jobs,
                                                         int n_jobs, int* list_counter, uint32_t* list, int list_cap,
                                                         QResult* results) {
@@ -427,11 +477,15 @@ __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restri
   t.k1 = t.k2 = 0xFFFFFFFFu; t.i1 = t.i2 = -1;
   for (int p = lane; p < total; p += 64) {
     const int idx = (int)f_feat_idx[job.f_begin + p];
-    const uint4 b0 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32);
-    const uint4 b1 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32 + 16);
-    const int d = popc256(a0, a1, b0, b1);
-    top2_insert(t, ((unsigned)d << 20) | (unsigned)p, idx);
-    if (base + p < list_cap) list[base + p] = (unsigned)idx | ((unsigned)d << 16);
+    unsigned entry = 0xFFFFFFFFu;
+    if (!tvalid || tvalid[idx]) {
+      const uint4 b0 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32);
+      const uint4 b1 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32 + 16);
+      const int d = popc256(a0, a1, b0, b1);
+      top2_insert(t, ((unsigned)d << 20) | (unsigned)p, idx);
+      entry = (unsigned)idx | ((unsigned)d << 16);
+    }
+    if (base + p < list_cap) list[base + p] = entry;
   }
   top2_wave_merge(t);
   if (lane == 0) {
@@ -1078,14 +1132,16 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
   return ORBG_OK;
 }
 
-extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t* kf_desc, int nkf,
-                                  const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fvK, float nnratio,
-                                  int check_orientation, int32_t* matches, int* nmatches_out) {
-  if (!f || !fvF || !fvK || !kf_desc || !kf_mp_valid || !kf_angle || !matches || nkf < 0) return ORBG_BAD_ARG;
+// Shared body of SearchByBoW(KeyFrame*, Frame&) (S/ORBmatcher.cc:269-471, by_query = false) and
+// SearchByBoW(KeyFrame*, KeyFrame*) (:819-959, by_query = true).  Queries = the flattened pKF / pKF1 side; targets = f.
+static int bow_common(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t* t_valid, const uint8_t* kf_desc, int nkf,
+                      const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fvK, float nnratio,
+                      int check_orientation, bool by_query, int32_t* matches, int* nmatches_out) {
   int rc = select_device(f->device);
   if (rc) return rc;
   const int n = f->fp.n;
-  for (int i = 0; i < n; i++) matches[i] = -1;
+  const int n_out = by_query ? nkf : n;
+  for (int i = 0; i < n_out; i++) matches[i] = -1;
   if (nmatches_out) *nmatches_out = 0;
   // merge-join of the two sorted feature vectors (S/ORBmatcher.cc:290-448) -> one job per valid KF feature
   std::vector<BowJob> jobs;
@@ -1110,18 +1166,22 @@ extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, c
   const int nj = (int)jobs.size();
   if (nj == 0) return ORBG_OK;
   const int nfi = (int)fvF->start[fvF->n_nodes];
-  if ((rc = stage_begin(f, (size_t)nj * sizeof(BowJob) + (size_t)nfi * 4 + (size_t)nkf * 32))) return rc;
+  for (int i = 0; i < nfi; i++)
+    if ((int)fvF->feat_idx[i] >= n) return ORBG_BAD_ARG;
+  if ((rc = stage_begin(f, (size_t)nj * sizeof(BowJob) + (size_t)nfi * 4 + (size_t)nkf * 32 + (size_t)n))) return rc;
   hipStream_t st = f->stream;
   const BowJob* d_jobs = stage_add(f, jobs.data(), nj);
   const uint32_t* d_fidx = stage_add(f, fvF->feat_idx, nfi);
   const uint8_t* d_kfdesc = stage_add(f, kf_desc, (size_t)nkf * 32);
+  const uint8_t* d_tvalid = t_valid ? stage_add(f, t_valid, n) : nullptr;
   if ((rc = stage_commit(f))) return rc;
   rc = run_search(f, nj, [&](int list_cap) {
-    hipLaunchKernelGGL(search_bow_kernel, dim3((nj + 3) / 4), dim3(256), 0, st, f->desc_p, d_fidx, d_kfdesc,
+    hipLaunchKernelGGL(search_bow_kernel, dim3((nj + 3) / 4), dim3(256), 0, st, f->desc_p, d_fidx, d_tvalid, d_kfdesc,
                        d_jobs, nj, f->d_counter.p, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
   std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<uint8_t> taken(std::max(n, 1), 0);          // vpMapPointMatches[idx] != NULL (:324) / vbMatched2[idx] (:872)
   int nmatches = 0;
   const QResult* R = f->results.h;
   const uint32_t* list = f->list.h;
@@ -1129,22 +1189,26 @@ extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, c
     const QResult& r = R[j];
     if (r.best_idx < 0) continue;
     int bestDist1 = r.best_dist, bestIdxF = r.best_idx, bestDist2 = r.second_dist;
-    const bool dirty = matches[bestIdxF] >= 0 || (r.second_idx >= 0 && matches[r.second_idx] >= 0);
+    const bool dirty = taken[bestIdxF] || (r.second_idx >= 0 && taken[r.second_idx]);
     if (dirty) {
       bestDist1 = 256; bestDist2 = 256; bestIdxF = -1;
       for (int k = 0; k < r.count; k++) {
         const uint32_t e = list[r.base + k];
+        if (e == 0xFFFFFFFFu) continue;
         const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
-        if (matches[idx] >= 0) continue;                       // :324-325
+        if (taken[idx]) continue;
         if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = idx; }
         else if (dist < bestDist2) bestDist2 = dist;
       }
       if (bestIdxF < 0) continue;
     }
-    if (bestDist1 <= TH_LOW) {
+    const bool low = by_query ? (bestDist1 < TH_LOW) : (bestDist1 <= TH_LOW);      // :898 vs :373
+    if (low) {
       if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
-        matches[bestIdxF] = jobs[j].kf_idx;
-        if (check_orientation) rotHist[rot_bin(kf_angle[jobs[j].kf_idx], f->hk[bestIdxF].angle)].push_back(bestIdxF);
+        const int q = jobs[j].kf_idx;
+        taken[bestIdxF] = 1;
+        if (by_query) matches[q] = bestIdxF; else matches[bestIdxF] = q;
+        if (check_orientation) rotHist[rot_bin(kf_angle[q], f->hk[bestIdxF].angle)].push_back(by_query ? q : bestIdxF);
         nmatches++;
       }
     }
@@ -1155,6 +1219,93 @@ extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, c
     for (int i = 0; i < HISTO_LENGTH; i++) {
       if (i == ind1 || i == ind2 || i == ind3) continue;
       for (int idx : rotHist[i]) { matches[idx] = -1; nmatches--; }
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t* kf_desc, int nkf,
+                                  const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fvK,
+                                  float nnratio, int check_orientation, int32_t* matches, int* nmatches_out) {
+  if (!f || !fvF || !fvK || !kf_desc || !kf_mp_valid || !matches || nkf < 0 || (check_orientation && !kf_angle)) return ORBG_BAD_ARG;
+  return bow_common(f, fvF, nullptr, kf_desc, nkf, kf_mp_valid, kf_angle, fvK, nnratio, check_orientation, false, matches,
+                    nmatches_out);
+}
+
+extern "C" int orbm_search_by_bow_kf(orbm_frame* kf2, const orbm_featvec_view* fv2, const uint8_t* mp_valid2,
+                                     const uint8_t* desc1, int n1, const uint8_t* mp_valid1, const float* angle1,
+                                     const orbm_featvec_view* fv1, float nnratio, int check_orientation,
+                                     int32_t* matches12, int* nmatches_out) {
+  if (!kf2 || !fv2 || !fv1 || !mp_valid2 || !desc1 || !mp_valid1 || !matches12 || n1 < 0 || (check_orientation && !angle1))
+    return ORBG_BAD_ARG;
+  return bow_common(kf2, fv2, mp_valid2, desc1, n1, mp_valid1, angle1, fv1, nnratio, check_orientation, true, matches12,
+                    nmatches_out);
+}
+
+// SearchByProjection(KeyFrame*, Scw, ...): Sim3 decomposition (S/ORBmatcher.cc:484-488) with the cv::Mat float conventions
+// spelled out in the oracle (scale by (float)(1/(double)scw)), then the candidate kernel and the serial commit (:556-583).
+extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const float* Scw, const uint8_t* already_found,
+                                              int th, float ratio_hamming, int camera_project, int32_t* matched,
+                                              int* nmatches_out) {
+  if (!f || !mp || !Scw || !matched || f->device != mp->device) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int m = mp->m;
+  if (nmatches_out) *nmatches_out = 0;
+  if (m == 0) return ORBG_OK;
+  const int n = f->fp.n;
+  if ((rc = stage_begin(f, (size_t)n * 4 + (size_t)m))) return rc;
+  hipStream_t st = f->stream;
+  f->d_assigned_mp = stage_add(f, matched, n);
+  f->d_assigned_obs = nullptr;
+  const uint8_t* d_found = already_found ? stage_add(f, already_found, m) : nullptr;
+  if ((rc = stage_commit(f))) return rc;
+  float T16[16];
+  {
+    double d = 0;
+    for (int k = 0; k < 3; k++) d += (double)Scw[k] * (double)Scw[k];
+    const float scw = (float)std::sqrt(d);
+    const float alpha = (float)(1.0 / (double)scw);
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) T16[4 * i + j] = Scw[4 * i + j] * alpha + 0.0f;
+      T16[4 * i + 3] = Scw[4 * i + 3] * alpha + 0.0f;
+    }
+    T16[12] = T16[13] = T16[14] = 0.f; T16[15] = 1.f;
+  }
+  PoseF P;
+  make_pose(T16, &P);
+  FrameDev F = frame_dev(f);
+  F.uright = nullptr;                                          // no stereo gate in the KeyFrame searches
+  rc = run_search(f, m, [&](int list_cap) {
+    hipLaunchKernelGGL(search_sim3_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P,
+                       camera_project, th, f->d_counter.p, f->list.d, list_cap, f->results.d);
+  });
+  if (rc) return rc;
+  std::vector<uint8_t> claimed(std::max(n, 1), 0);
+  int nmatches = 0;
+  const QResult* R = f->results.h;
+  const uint32_t* list = f->list.h;
+  const float low = TH_LOW * ratio_hamming;
+  for (int i = 0; i < m; i++) {
+    const QResult& r = R[i];
+    if (r.count == 0 || r.best_idx < 0) continue;
+    int bestDist = r.best_dist, bestIdx = r.best_idx;
+    if (claimed[bestIdx]) {
+      bestDist = 256; bestIdx = -1;
+      for (int k = 0; k < r.count; k++) {
+        const uint32_t e = list[r.base + k];
+        if (e == 0xFFFFFFFFu) continue;
+        const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
+        if (claimed[idx]) continue;
+        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+      }
+      if (bestIdx < 0) continue;
+    }
+    if (bestDist <= low) {
+      matched[bestIdx] = i;
+      claimed[bestIdx] = 1;
+      nmatches++;
     }
   }
   if (nmatches_out) *nmatches_out = nmatches;

@@ -267,6 +267,32 @@ def search_by_bow(fv, fvF, kf_desc, kf_mp_valid, kf_angle, fvK, nnratio, check_o
     return matches[: fv.n].copy(), n.value
 
 
+def search_by_projection_sim3(kf, pts, Scw, matched, th, ratio_hamming=1.0, already_found=None, with_kfs=False):
+    matched = np.ascontiguousarray(matched, np.int32).copy()
+    S = np.ascontiguousarray(Scw, np.float32).reshape(16)
+    af = None if already_found is None else np.ascontiguousarray(already_found, np.uint8)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_projection_sim3(C.byref(kf), C.byref(pts), C.c_void_p(S.ctypes.data),
+                                                None if af is None else C.c_void_p(af.ctypes.data), int(th),
+                                                C.c_float(ratio_hamming), 0 if with_kfs else 1,
+                                                C.c_void_p(matched.ctypes.data), C.byref(n)))
+    return matched, n.value
+
+
+def search_by_bow_kf(kf2, fv2, mp_valid2, desc1, mp_valid1, angle1, fv1, nnratio, check_ori):
+    desc1 = np.ascontiguousarray(desc1, np.uint8)
+    mp_valid1 = np.ascontiguousarray(mp_valid1, np.uint8)
+    mp_valid2 = np.ascontiguousarray(mp_valid2, np.uint8)
+    angle1 = np.ascontiguousarray(angle1, np.float32)
+    matches = np.zeros(max(len(desc1), 1), np.int32)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_bow_kf(C.byref(kf2), C.byref(fv2), C.c_void_p(mp_valid2.ctypes.data),
+                                       C.c_void_p(desc1.ctypes.data), len(desc1), C.c_void_p(mp_valid1.ctypes.data),
+                                       C.c_void_p(angle1.ctypes.data), C.byref(fv1), C.c_float(nnratio), int(check_ori),
+                                       C.c_void_p(matches.ctypes.data), C.byref(n)))
+    return matches[: len(desc1)].copy(), n.value
+
+
 # ---------------------------------------------------------------- LBA
 def lba_solve(problem, stop_flag=None, trace_cap=64):
     out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)

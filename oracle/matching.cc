@@ -440,6 +440,143 @@ extern "C" int oracle_search_by_bow(const orbm_frame_view* view, const orbm_feat
   return ORBG_OK;
 }
 
+// ---- server-side KeyFrame matchers
+//
+// Sim3 decomposition as S/ORBmatcher.cc:484-488 / :601-605 with cv::Mat float conventions:
+//   scw  = (float) sqrt( sum_k (double)s0k*(double)s0k )                      (Mat::dot accumulates in double)
+//   Rcw  = sRcw / scw  -> MatExpr scale by alpha = 1.0/(double)scw, evaluated by convertTo 32f->32f as
+//          dst = src * (float)alpha + 0.0f                                     (cvtScale_<float,float,float>)
+//   tcw  likewise;   Ow = -Rcw.t()*tcw through the gemm path (see file header)
+static void sim3_pose(const float* S, float* T16) {
+  double d = 0;
+  for (int k = 0; k < 3; k++) d += (double)S[k] * (double)S[k];
+  const float scw = (float)std::sqrt(d);
+  const float alpha = (float)(1.0 / (double)scw);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T16[4 * i + j] = S[4 * i + j] * alpha + 0.0f;
+    T16[4 * i + 3] = S[4 * i + 3] * alpha + 0.0f;
+  }
+  T16[12] = T16[13] = T16[14] = 0.f; T16[15] = 1.f;
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming)      S/ORBmatcher.cc:473-587
+// (camera_project = 1) and the overload carrying vpPointsKFs / vpMatchedKF                   :589-700 (camera_project = 0,
+// which projects with a float invz instead of Pinhole::project).  matched[idx] >= 0 means vpMatched[idx] != NULL on entry;
+// on exit newly matched features hold the index of the candidate point.  already_found[i] = 1 when vpPoints[i] is
+// a member of vpMatched on entry (spAlreadyFound, :491-492).
+extern "C" int oracle_search_by_projection_sim3(const orbm_frame_view* kf, const orbm_worldpoints_view* pts, const float* Scw,
+                                                const uint8_t* already_found, int th, float ratio_hamming,
+                                                int camera_project, int32_t* matched, int* nmatches_out) {
+  const ScaleTables st(kf);
+  const Grid g = build_grid(kf);
+  float T16[16];
+  sim3_pose(Scw, T16);
+  const Pose pose(T16);
+  int nmatches = 0;
+  std::vector<int> vIndices;
+  for (int iMP = 0; iMP < pts->m; iMP++) {
+    if (pts->bad[iMP] || (pts->skip && pts->skip[iMP]) || (already_found && already_found[iMP])) continue;
+    const float* p3Dw = pts->pos + 3 * (size_t)iMP;
+    float p3Dc[3];
+    pose.map(p3Dw, p3Dc);
+    if (p3Dc[2] < 0.0) continue;
+    float u, v;
+    if (camera_project) {                     // Pinhole::project(cv::Point3f)  S/CameraModels/Pinhole.cpp:28-31
+      u = kf->fx * p3Dc[0] / p3Dc[2] + kf->cx;
+      v = kf->fy * p3Dc[1] / p3Dc[2] + kf->cy;
+    } else {                                  // :631-635
+      const float invz = 1 / p3Dc[2];
+      const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+      u = kf->fx * x + kf->cx;
+      v = kf->fy * y + kf->cy;
+    }
+    if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y)) continue;   // KeyFrame::IsInImage
+    const float maxDistance = 1.2f * pts->max_dist[iMP], minDistance = 0.8f * pts->min_dist[iMP];
+    const float PO[3] = {p3Dw[0] - pose.Ow[0], p3Dw[1] - pose.Ow[1], p3Dw[2] - pose.Ow[2]};
+    const float dist = norm3(PO);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const float* Pn = pts->normal + 3 * (size_t)iMP;
+    const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+    if (dot < 0.5 * dist) continue;
+    const float ratio = pts->max_dist[iMP] / dist;                      // PredictScale(dist, pKF)  S/MapPoint.cc:629-644
+    int lvl = (int)std::ceil(std::log(ratio) / st.log_sf);
+    if (lvl < 0) lvl = 0;
+    else if (lvl >= kf->n_levels) lvl = kf->n_levels - 1;
+    const float radius = th * st.scale[lvl];
+    features_in_area(kf, g, u, v, radius, -1, -1, vIndices);            // KeyFrame::GetFeaturesInArea  S/KeyFrame.cc:889-940
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = pts->desc + 32 * (size_t)iMP;
+    int bestDist = 256, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (matched[idx] >= 0) continue;
+      const int kpLevel = kf->kps[idx].octave;
+      if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+      const int d = oracle_hamming(dMP, kf->desc + 32 * (size_t)idx);
+      if (d < bestDist) { bestDist = d; bestIdx = idx; }
+    }
+    if (bestIdx >= 0 && bestDist <= TH_LOW * ratio_hamming) {
+      matched[bestIdx] = iMP;
+      nmatches++;
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) -- S/ORBmatcher.cc:819-959.
+// kf2 = pKF2 (view + fv2 + mp_valid2 = "has a MapPoint that is not bad"); the pKF1 side comes flattened as descriptors,
+// validity, angles and fv1.  matches12[idx1] = idx2 (the adapter stores vpMapPoints2[idx2]) or -1.
+extern "C" int oracle_search_by_bow_kf(const orbm_frame_view* kf2, const orbm_featvec_view* fv2, const uint8_t* mp_valid2,
+                                       const uint8_t* desc1, int n1, const uint8_t* mp_valid1, const float* angle1,
+                                       const orbm_featvec_view* fv1, float nnratio, int check_ori,
+                                       int32_t* matches12, int* nmatches_out) {
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::vector<uint8_t> vbMatched2(std::max(kf2->n, 1), 0);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int a = 0, b = 0;
+  while (a < fv1->n_nodes && b < fv2->n_nodes) {
+    if (fv1->node_id[a] == fv2->node_id[b]) {
+      for (uint32_t i1 = fv1->start[a]; i1 < fv1->start[a + 1]; i1++) {
+        const uint32_t idx1 = fv1->feat_idx[i1];
+        if (!mp_valid1[idx1]) continue;
+        const uint8_t* d1 = desc1 + 32 * (size_t)idx1;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (uint32_t i2 = fv2->start[b]; i2 < fv2->start[b + 1]; i2++) {
+          const uint32_t idx2 = fv2->feat_idx[i2];
+          if (vbMatched2[idx2] || !mp_valid2[idx2]) continue;
+          const int dist = oracle_hamming(d1, kf2->desc + 32 * (size_t)idx2);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 < TH_LOW) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches12[idx1] = bestIdx2;
+            vbMatched2[bestIdx2] = 1;
+            if (check_ori) rotHist[rot_bin(angle1[idx1], kf2->kps[bestIdx2].angle)].push_back((int)idx1);
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (fv1->node_id[a] < fv2->node_id[b]) {
+      a = (int)(std::lower_bound(fv1->node_id, fv1->node_id + fv1->n_nodes, fv2->node_id[b]) - fv1->node_id);
+    } else {
+      b = (int)(std::lower_bound(fv2->node_id, fv2->node_id + fv2->n_nodes, fv1->node_id[a]) - fv2->node_id);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
 // Frame::ComputeStereoMatches -- S/Frame.cc:785-963.
 extern "C" int oracle_stereo_match(oracle_extractor* left, oracle_extractor* right,
                                    const orbx_keypoint* kps_l, const uint8_t* desc_l, int N,

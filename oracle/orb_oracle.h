@@ -84,6 +84,15 @@ int oracle_search_by_bow(const orbm_frame_view* view, const orbm_featvec_view* f
                          const orbm_featvec_view* fv_kf, float nnratio, int check_orientation,
                          int32_t* matches, int* nmatches);
 
+/* ---- server-side KeyFrame matchers */
+int oracle_search_by_projection_sim3(const orbm_frame_view* kf, const orbm_worldpoints_view* pts, const float* Scw,
+                                     const uint8_t* already_found, int th, float ratio_hamming, int camera_project,
+                                     int32_t* matched, int* nmatches);
+int oracle_search_by_bow_kf(const orbm_frame_view* kf2, const orbm_featvec_view* fv2, const uint8_t* mp_valid2,
+                            const uint8_t* desc1, int n1, const uint8_t* mp_valid1, const float* angle1,
+                            const orbm_featvec_view* fv1, float nnratio, int check_orientation,
+                            int32_t* matches12, int* nmatches);
+
 /* ---- LBA (S/Optimizer.cc:1810-2410 + vendored g2o) */
 int oracle_lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
 int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* r);

@@ -240,6 +240,60 @@ def test_search_by_bow(scene):
     assert g[1] == o[1] and np.array_equal(g[0], o[0])
 
 
+@pytest.mark.parametrize("th,ratio,with_kfs,scale", [(3, 1.5, False, 1.0), (8, 1.0, True, 1.7), (8, 1.5, False, 0.6)])
+def test_search_by_projection_sim3(scene, th, ratio, with_kfs, scale):
+    """Server-side SearchByProjection(KeyFrame*, Scw, ...), both overloads."""
+    rng = np.random.RandomState(21)
+    f0, f1 = [helpers.oracle_stereo_frame(scene, k) for k in (12, 16)]
+    kf = helpers.oracle_stereo_frame(scene, 14)
+    mp = helpers.local_map_from(scene, [f0, f1], rng)
+    fv, keep = helpers.frame_view_of(scene, kf)
+    T = synth.perturb_pose(kf["Tcw"], rng).astype(np.float32)
+    S = T.copy()
+    S[:3, :] *= np.float32(scale)                       # Scw = [s*R | s*t]
+    n = len(kf["kps"])
+    matched0 = np.full(n, -1, np.int32)
+    pre = rng.rand(n) < 0.15
+    matched0[pre] = 3
+    found = (rng.rand(len(mp["pos"])) < 0.1).astype(np.uint8)
+    skip = (rng.rand(len(mp["pos"])) < 0.05).astype(np.uint8)
+    wv, keep2 = helpers.world_view_of(mp, skip)
+    F = api.Frame().upload(fv, keep)
+    LM = api.LocalMap().upload(wv)
+    m = api.ORBmatcher(0.75, True)
+    g = m.SearchByProjectionSim3(F, S, LM, matched0, th, ratio, found, with_kfs)
+    o = ob.search_by_projection_sim3(fv, wv, S, matched0, th, ratio, found, with_kfs)
+    assert o[1] > 50
+    assert g[1] == o[1] and np.array_equal(g[0], o[0])
+    assert np.array_equal(g[0][pre], matched0[pre])     # occupied features are never overwritten
+    # no candidates at all
+    g0 = m.SearchByProjectionSim3(F, S, LM, matched0, th, ratio, np.ones(len(mp["pos"]), np.uint8), with_kfs)
+    assert g0[1] == 0 and np.array_equal(g0[0], matched0)
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow_kf(scene, check_ori):
+    """Server-side SearchByBoW(KeyFrame*, KeyFrame*)."""
+    rng = np.random.RandomState(22)
+    kf1 = helpers.oracle_stereo_frame(scene, 30)
+    kf2 = helpers.oracle_stereo_frame(scene, 31)
+    fv2v, keep = helpers.frame_view_of(scene, kf2)
+    node = lambda d, k: (d[:, 0].astype(np.int64) >> 3) * 2 + (k["octave"] // 4)
+    fv2, k2 = views.featvec_view(*views.featvec_from_nodes(node(kf2["desc"], kf2["kps"])))
+    fv1, k1 = views.featvec_view(*views.featvec_from_nodes(node(kf1["desc"], kf1["kps"])))
+    valid1 = ((kf1["depth"] > 0) & (rng.rand(len(kf1["kps"])) < 0.9)).astype(np.uint8)
+    valid2 = ((kf2["depth"] > 0) & (rng.rand(len(kf2["kps"])) < 0.9)).astype(np.uint8)
+    F2 = api.Frame().upload(fv2v, keep)
+    m = api.ORBmatcher(0.8, check_ori)
+    g = m.SearchByBoWKF(F2, fv2, valid2, kf1["desc"], valid1, kf1["kps"]["angle"], fv1)
+    o = ob.search_by_bow_kf(fv2v, fv2, valid2, kf1["desc"], valid1, kf1["kps"]["angle"], fv1, 0.8, check_ori)
+    assert o[1] > 20
+    assert g[1] == o[1] and np.array_equal(g[0], o[0])
+    sel = g[0] >= 0
+    assert valid1[sel].all() and valid2[g[0][sel]].all()
+    assert len(np.unique(g[0][sel])) == sel.sum()       # vbMatched2: a pKF2 feature is used at most once
+
+
 @pytest.mark.parametrize("shape", [(4, 2, 60), (20, 10, 2000)])
 def test_lba_parity(shape):
     nf, nx, npts = shape

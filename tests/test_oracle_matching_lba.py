@@ -186,6 +186,86 @@ def test_search_by_bow_vs_python(small_scene):
     assert nm == o[1] and nm > 10 and np.array_equal(matches, o[0])
 
 
+def test_search_by_bow_kf_vs_python(small_scene):
+    """SearchByBoW(KF, KF) (a16): strict < TH_LOW, vbMatched2 bookkeeping, output indexed by pKF1 feature."""
+    rng = np.random.RandomState(8)
+    kf1, kf2 = helpers.oracle_stereo_frame(small_scene, 2, 400), helpers.oracle_stereo_frame(small_scene, 3, 400)
+    fv2v, keep = helpers.frame_view_of(small_scene, kf2)
+    node = lambda d: (d[:, 0].astype(np.int64) >> 4)
+    n1, s1, i1 = views.featvec_from_nodes(node(kf1["desc"]))
+    n2, s2, i2 = views.featvec_from_nodes(node(kf2["desc"]))
+    fv1, k1 = views.featvec_view(n1, s1, i1)
+    fv2, k2 = views.featvec_view(n2, s2, i2)
+    v1 = ((kf1["depth"] > 0) & (rng.rand(len(kf1["kps"])) < 0.9)).astype(np.uint8)
+    v2 = ((kf2["depth"] > 0) & (rng.rand(len(kf2["kps"])) < 0.9)).astype(np.uint8)
+    o = ob.search_by_bow_kf(fv2v, fv2, v2, kf1["desc"], v1, kf1["kps"]["angle"], fv1, 0.7, False)
+    m12 = np.full(len(kf1["kps"]), -1, np.int32)
+    used2 = np.zeros(len(kf2["kps"]), bool)
+    nm = 0
+    for a, nid in enumerate(n1):
+        w = np.nonzero(n2 == nid)[0]
+        if len(w) == 0:
+            continue
+        b = w[0]
+        for q in i1[s1[a]:s1[a + 1]]:
+            if not v1[q]:
+                continue
+            best, best2, bi = 256, 256, -1
+            for t in i2[s2[b]:s2[b + 1]]:
+                if used2[t] or not v2[t]:
+                    continue
+                d = int(np.unpackbits(kf1["desc"][q] ^ kf2["desc"][t]).sum())
+                if d < best:
+                    best2, best, bi = best, d, t
+                elif d < best2:
+                    best2 = d
+            if best < 50 and np.float32(best) < np.float32(0.7) * np.float32(best2):
+                m12[q] = bi; used2[bi] = True; nm += 1
+    assert nm == o[1] and nm > 10 and np.array_equal(m12, o[0])
+    # orientation filter keeps a subset
+    o2 = ob.search_by_bow_kf(fv2v, fv2, v2, kf1["desc"], v1, kf1["kps"]["angle"], fv1, 0.7, True)
+    kept = o2[0] >= 0
+    assert 0 < o2[1] <= o[1] and np.array_equal(o2[0][kept], o[0][kept])
+
+
+def test_search_by_projection_sim3_properties(small_scene):
+    """SearchByProjection(KF, Scw, ...) (a16): scale invariance of the Sim3 decomposition, occupancy and gating rules."""
+    rng = np.random.RandomState(9)
+    f0, kf = helpers.oracle_stereo_frame(small_scene, 0, 400), helpers.oracle_stereo_frame(small_scene, 2, 400)
+    mp = helpers.local_map_from(small_scene, [f0], rng)
+    fv, keep = helpers.frame_view_of(small_scene, kf)
+    wv, keep2 = helpers.world_view_of(mp)
+    T = kf["Tcw"].astype(np.float32)
+    n = len(kf["kps"])
+    free = np.full(n, -1, np.int32)
+    a = ob.search_by_projection_sim3(fv, wv, T, free, 4, 1.5)
+    assert a[1] > 30
+    sel = a[0] >= 0
+    assert a[1] == sel.sum() and len(np.unique(a[0][sel])) == sel.sum()          # each point matched at most once
+    # every match satisfies the acceptance rule and the level window
+    d = np.unpackbits(kf["desc"][sel] ^ mp["desc"][a[0][sel]], axis=1).sum(1)
+    assert (d <= 75).all()
+    # a power-of-two Sim3 scale leaves Rcw, tcw bit-identical after the division => identical matches
+    S = T.copy(); S[:3, :] *= np.float32(2.0)
+    b = ob.search_by_projection_sim3(fv, wv, S, free, 4, 1.5)
+    assert b[1] == a[1] and np.array_equal(a[0], b[0])
+    # occupied features are skipped, never overwritten; already-found points are not matched again
+    occ = free.copy(); occ[np.nonzero(sel)[0][::2]] = 10 ** 6
+    c = ob.search_by_projection_sim3(fv, wv, T, occ, 4, 1.5)
+    assert np.array_equal(c[0][occ >= 0], occ[occ >= 0])
+    found = np.zeros(len(mp["pos"]), np.uint8); found[a[0][sel]] = 1
+    e = ob.search_by_projection_sim3(fv, wv, T, free, 4, 1.5, found)
+    assert not np.isin(e[0][e[0] >= 0], a[0][sel]).any()
+    # stricter Hamming ratio can only lose matches; points behind the camera are never matched
+    f = ob.search_by_projection_sim3(fv, wv, T, free, 4, 0.5)
+    assert f[1] <= a[1]
+    Tb = T.copy(); Tb[2, :] *= -1; Tb[0, :] *= -1                                 # look the other way
+    assert ob.search_by_projection_sim3(fv, wv, Tb, free, 4, 1.5)[1] == 0
+    # the second overload differs only in how it rounds the projection
+    g = ob.search_by_projection_sim3(fv, wv, T, free, 4, 1.5, None, True)
+    assert abs(g[1] - a[1]) <= 2
+
+
 def test_stereo_match_recovers_plane_depth(small_scene):
     fr = helpers.oracle_stereo_frame(small_scene, 0, 500)
     ok = fr["uright"] > 0
