@@ -23,6 +23,7 @@
 // Compile with -ffp-contract=off (strict f32 for fastAtan2 and the pattern rotation).
 
 #include "common.hpp"
+#include "wave.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -78,6 +79,7 @@ struct SelKp {     // keypoint chosen by the quad-tree, in final output order
 
 constexpr int kTile = 66;         // max sub-image side is 65 (wCell,hCell <= 59, +6)
 constexpr int kTileStride = 68;
+constexpr int kQueuePerWave = (59 * 59 + 255) / 256 * 64;   // a wavefront tests at most 64 pixels per 256-pixel stride
 constexpr int kCellCap = 1024;    // >= ceil(59/2)^2 = 900 survivors of a strict 3x3 NMS
 
 __device__ __forceinline__ int reflect101(int p, int n) {
@@ -145,12 +147,7 @@ __device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
 // Packed (iniTh count | minTh count << 16) exclusive scan over a 256-thread workgroup.
 __device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned* total, unsigned* wsum /*LDS[4]*/) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    unsigned n = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += n;
-  }
+  const unsigned inc = wave_incl_scan_add(v);
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
   unsigned base = 0, tot = 0;
@@ -167,9 +164,11 @@ __device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned* to
 __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
                                                         const CellRec* __restrict__ cells, int n_cells, int ini_th,
                                                         int min_th, uint32_t* __restrict__ slots, int* __restrict__ counts) {
-  __shared__ uint8_t tile[kTile * kTileStride];
-  __shared__ uint8_t score[(kTile + 2) * kTileStride];   // +1 apron of zeros all around the detection area
+  __shared__ __attribute__((aligned(16))) uint8_t tile_raw[kTile * kTileStride];
+  __shared__ __attribute__((aligned(16))) uint8_t score[(kTile + 2) * kTileStride];   // +1 apron of zeros all around the detection area
   __shared__ unsigned wsum[4];
+  __shared__ unsigned short queue[4 * kQueuePerWave];
+  __shared__ int qcount[4];
   // XCD-aware block -> cell map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD), so
   // XCD k is given a CONTIGUOUS run of cells: neighbouring cells (which share a 6-px halo and cache lines) hit the
   // same XCD's L2 instead of eight different ones.  Placement only affects speed, never results.
@@ -184,11 +183,36 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restri
   const LevelGeom L = g.lv[c.level];
   const uint8_t* src = pyr + (size_t)cam * g.cam_stride + L.off + (size_t)(kEdge + c.y0) * L.stride + (kEdge + c.x0);
   const int cw = c.cw, ch = c.ch;
-  for (int i = threadIdx.x; i < (kTile + 2) * kTileStride; i += 256) score[i] = 0;
-  // stage the sub-image: consecutive lanes read consecutive bytes of a row
-  for (int i = threadIdx.x; i < ch * kTileStride; i += 256) {
-    const int y = i / kTileStride, x = i - y * kTileStride;
-    if (x < cw) tile[i] = src[(size_t)y * L.stride + x];
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(score);
+    for (int i = threadIdx.x; i < (kTile + 2) * kTileStride / 4; i += 256) z[i] = 0;
+  }
+  // stage the sub-image with aligned dword loads, all issued before the first LDS store (one memory round trip per
+  // workgroup instead of one per row): the tile keeps the source's alignment, i.e. its column 0 sits at byte xs
+  const int xs = (kEdge + c.x0) & 3;
+  const uint8_t* tl = tile_raw + xs;
+  {
+    const uint8_t* src_al = src - xs;                       // 4-byte aligned: level offsets and strides are multiples of 64
+    const int ndw = (xs + cw + 3) >> 2;                     // <= 17 = kTileStride / 4
+    const int total = ch * ndw;                             // <= 65 * 17 = 1105 < 5 * 256
+    uint32_t v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int i = threadIdx.x + k * 256;
+      if (i < total) {
+        const int r = i / ndw, cdw = i - r * ndw;
+        v[k] = *reinterpret_cast<const uint32_t*>(src_al + (size_t)r * L.stride + 4 * cdw);
+      }
+    }
+    uint32_t* t32 = reinterpret_cast<uint32_t*>(tile_raw);
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int i = threadIdx.x + k * 256;
+      if (i < total) {
+        const int r = i / ndw, cdw = i - r * ndw;
+        t32[r * (kTileStride / 4) + cdw] = v[k];
+      }
+    }
   }
   __syncthreads();
   const int wd = cw - 6, hd = ch - 6;       // detection area [3,cw-3) x [3,ch-3)
@@ -197,9 +221,36 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restri
   const int wdiv = max(wd, 1);
   const int step_y = 256 / wdiv, step_x = 256 - step_y * wdiv;
   int y = (int)threadIdx.x / wdiv, x = (int)threadIdx.x - y * wdiv;
-  for (int p = threadIdx.x; p < npix; p += 256, x += step_x, y += step_y) {
-    if (x >= wd) { x -= wd; y++; }
-    const uint8_t* q = &tile[(y + 3) * kTileStride + (x + 3)];
+  // Pass A -- the segment test's necessary condition on the 4 compass points of the ring (any 9-arc holds one pixel of
+  // every opposite pair): ~92 % of all pixels fail it and keep score 0, which is what cv::FAST's score buffer holds for
+  // them too (scores below the threshold can neither become keypoints nor suppress one).  Survivors are queued in LDS.
+  const int qt = min(min_th, ini_th);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned short* wq = queue + wave * kQueuePerWave;          // each wavefront appends to its own segment: the ballot is
+  int wn = 0;                                                  // wave-uniform, so no atomic and no shuffle is needed
+  for (int p0 = 0; p0 < npix; p0 += 256, x += step_x, y += step_y) {
+    const int p = p0 + threadIdx.x;
+    bool pass = false;
+    if (p < npix) {
+      if (x >= wd) { x -= wd; y++; }
+      const uint8_t* q = &tl[(y + 3) * kTileStride + (x + 3)];
+      const int v = q[0];
+      const int d0 = v - q[3 * kTileStride], d8 = v - q[-3 * kTileStride], d4 = v - q[3], d12 = v - q[-3];
+      pass = ((d0 > qt || d8 > qt) && (d4 > qt || d12 > qt)) || ((d0 < -qt || d8 < -qt) && (d4 < -qt || d12 < -qt));
+    }
+    const unsigned long long bal = __ballot(pass);
+    if (pass) wq[wn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 8));
+    wn += __popcll(bal);
+  }
+  if (lane == 0) qcount[wave] = wn;
+  __syncthreads();
+  // Pass B -- full cornerScore<16> of the queued pixels (order is irrelevant: results land by position)
+  const int n0 = qcount[0], n1 = n0 + qcount[1], n2 = n1 + qcount[2], nq = n2 + qcount[3];
+  for (int i = threadIdx.x; i < nq; i += 256) {
+    const int e = i < n0 ? queue[i] : i < n1 ? queue[kQueuePerWave + i - n0] : i < n2 ? queue[2 * kQueuePerWave + i - n1]
+                                                                                      : queue[3 * kQueuePerWave + i - n2];
+    const int ex = e & 255, ey = e >> 8;
+    const uint8_t* q = &tl[(ey + 3) * kTileStride + (ex + 3)];
     const int v = q[0];
     int d[16];
     d[0] = v - q[3 * kTileStride];          d[1] = v - q[3 * kTileStride + 1];
@@ -212,9 +263,9 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restri
     d[14] = v - q[2 * kTileStride - 2];     d[15] = v - q[3 * kTileStride - 1];
     int nd[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) nd[i] = -d[i];
-    const int s = max(arc9_maxmin(d), arc9_maxmin(nd)) - 1;   // cornerScore<16>: largest passing threshold
-    score[(y + 1) * kTileStride + (x + 1)] = (uint8_t)max(s, 0);
+    for (int k = 0; k < 16; k++) nd[k] = -d[k];
+    const int sc = max(arc9_maxmin(d), arc9_maxmin(nd)) - 1;   // cornerScore<16>: largest passing threshold
+    score[(ey + 1) * kTileStride + (ex + 1)] = (uint8_t)max(sc, 0);
   }
   __syncthreads();
   // NMS + threshold decision + ordered compaction; thread t owns pixels [t*K, (t+1)*K) in row-major order
@@ -264,8 +315,7 @@ __global__ __launch_bounds__(256) void gather_cells_kernel(const uint32_t* __res
   const int gidx = cam * n_cells + cell;
   int s = 0;
   for (int i = threadIdx.x; i < gidx; i += 256) s += counts[i];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
   __syncthreads();
   const int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -317,12 +367,7 @@ __device__ inline int oct_scan_excl(int* v, int n, int* wsum /*LDS[8]*/) {
   const int b = min(tid * per, n), e = min(b + per, n);
   int s = 0;
   for (int i = b; i < e; i++) s += v[i];
-  int inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
+  const int inc = wave_incl_scan_add(s);
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
   int base = 0, total = 0;
@@ -645,7 +690,7 @@ struct UMax { int v[16]; };
 
 constexpr int kPR = 21;              // patch radius: 18 (max rotated pattern reach) + 3 (blur)
 constexpr int kPW = 2 * kPR + 1;     // 43
-constexpr int kPS = 44;              // raw row stride
+constexpr int kPS = 48;              // raw row stride: 12 dwords hold 43 bytes at any source alignment
 constexpr int kBR = 18;
 constexpr int kBW = 2 * kBR + 1;     // 37
 constexpr int kHS = 38;              // row-pass stride (u16)
@@ -654,16 +699,32 @@ constexpr int kKpPerBlock = 4;
 
 // One wavefront: orientation + blur + descriptor of the keypoint (cam, level, x, y) -> slot `out`.
 __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr, const PyrGeom& g, int cam, int level, int kx_, int ky_,
-                                                 float response, const UMax& um, size_t out, uint8_t* raw, unsigned short* hrow,
+                                                 float response, const UMax& um, size_t out, uint8_t* raw_al, unsigned short* hrow,
                                                  uint8_t* blur, orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                  orbx_keypoint* __restrict__ kps_host, uint8_t* __restrict__ desc_host) {
   const int lane = threadIdx.x & 63;
   const LevelGeom L = g.lv[level];
   const uint8_t* src = pyr + (size_t)cam * g.cam_stride + L.off + (size_t)(kEdge + ky_ - kPR) * L.stride + (kEdge + kx_ - kPR);
-  for (int i = lane; i < kPW * kPS; i += 64) {
-    const int y = i / kPS, x = i - y * kPS;
-    if (x < kPW) raw[i] = src[(size_t)y * L.stride + x];
+  // stage the 43x43 patch with aligned dword loads, all in flight before the first LDS store; the LDS copy keeps the
+  // source alignment (column 0 at byte xs of each 48-byte row)
+  const int xs = (kEdge + kx_ - kPR) & 3;                   // level offsets and strides are multiples of 64
+  {
+    const uint8_t* src_al = src - xs;
+    constexpr int kDw = kPS / 4, kTot = kPW * kDw, kPer = (kTot + 63) / 64;
+    uint32_t v[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int i = lane + 64 * k;
+      if (i < kTot) v[k] = *reinterpret_cast<const uint32_t*>(src_al + (size_t)(i / kDw) * L.stride + 4 * (i % kDw));
+    }
+    uint32_t* r32 = reinterpret_cast<uint32_t*>(raw_al);
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int i = lane + 64 * k;
+      if (i < kTot) r32[i] = v[k];
+    }
   }
+  const uint8_t* raw = raw_al + xs;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
   // --- intensity centroid (exact integer sums -> order independent)
@@ -679,8 +740,7 @@ __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr
         m01 += v * val;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m01 += __shfl_xor(m01, o, 64); m10 += __shfl_xor(m10, o, 64); }
+    m01 = wave_sum(m01); m10 = wave_sum(m10);
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   // --- separable 7x7 Gaussian, Q8 taps {18,34,49,55,49,34,18}: row pass fits u16 (257*255 = 65535)
@@ -745,7 +805,7 @@ __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr
 __global__ __launch_bounds__(256) void orient_desc_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
                                                          const SelKp* __restrict__ sel, int n_sel, UMax um, int cam1_base,
                                                          orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
-  __shared__ uint8_t raw_s[kKpPerBlock][kPW * kPS];
+  __shared__ __attribute__((aligned(16))) uint8_t raw_s[kKpPerBlock][kPW * kPS];
   __shared__ unsigned short hrow_s[kKpPerBlock][kPW * kHS];
   __shared__ uint8_t blur_s[kKpPerBlock][kBW * kBS];
   const int wv = threadIdx.x >> 6;
@@ -765,7 +825,7 @@ __global__ __launch_bounds__(256) void orient_desc_gpu_kernel(const uint8_t* __r
                                                              uint8_t* __restrict__ desc, orbx_keypoint* __restrict__ kps_host,
                                                              uint8_t* __restrict__ desc_host, int* __restrict__ d_nkp,
                                                              int* __restrict__ h_nkp) {
-  __shared__ uint8_t raw_s[kKpPerBlock][kPW * kPS];
+  __shared__ __attribute__((aligned(16))) uint8_t raw_s[kKpPerBlock][kPW * kPS];
   __shared__ unsigned short hrow_s[kKpPerBlock][kPW * kHS];
   __shared__ uint8_t blur_s[kKpPerBlock][kBW * kBS];
   const int wv = threadIdx.x >> 6;
@@ -837,8 +897,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
       bestKey = min(bestKey, key);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) bestKey = min(bestKey, (unsigned)__shfl_xor((int)bestKey, o, 64));
+  bestKey = wave_min(bestKey);
   const int bestDist = bestKey == 0xFFFFFFFFu ? 100 : (int)(bestKey >> 16);
   // bestDist starts at TH_HIGH = 100 with a strict '<' (:841,862); accepted below (100+50)/2 = 75 (:790,871)
   if (bestDist < 75) {
@@ -871,10 +930,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
         }
       }
 #pragma unroll
-      for (int o = 0; o < 11; o++) {
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) sad[o] += __shfl_xor(sad[o], s, 64);
-      }
+      for (int o = 0; o < 11; o++) sad[o] = wave_sum(sad[o]);
       int bestS = 0x7FFFFFFF, bestinc = 0;
 #pragma unroll
       for (int o = 0; o < 11; o++)
