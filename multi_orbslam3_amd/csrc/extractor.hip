@@ -127,6 +127,137 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(uint8_t* __restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole pyramid in ONE launch ("tower" per level-0 tile).  The cascade level l <- level l-1 is a pure function of four
+// source pixels, so a workgroup that holds a level-0 tile plus a small halo in LDS can derive "its" pixels of every
+// level without waiting for other workgroups: ownership of a level-l pixel is inherited from the level-(l-1) pixel its
+// first tap reads (per axis, so owned sets are rectangles), and the extra pixels the bilinear footprints reach beyond a
+// tile (1 px per level, growing by the scale factor downwards: ~17 px at level 0 for 8 levels x 1.2) are recomputed
+// locally.  Same taps, same integer arithmetic as pyr_resize_kernel -> identical bytes; 8 dependent launches of a few
+// microseconds each become one.  The host precomputes, per tile and axis, the owned and the needed pixel range of each
+// level (TowerAxis); the reflect-101 border copies are written by the owner of the interior pixel they mirror.
+constexpr int kTwSide = 64;        // largest needed extent per axis and level a workgroup can hold
+constexpr int kTwThreads = 1024;   // 16 wavefronts: the level chain is latency bound, rows are spread as thin as possible
+constexpr int kTwWaves = kTwThreads / 64;
+
+struct TowerAxis { short own_lo[ORBG_MAX_LEVELS], own_hi[ORBG_MAX_LEVELS], need_lo[ORBG_MAX_LEVELS], need_hi[ORBG_MAX_LEVELS]; };
+struct TowerTap { short i0, i1, a0, a1; };   // source indices relative to the previous level's LDS block + weights
+
+__device__ __forceinline__ void tower_emit(uint8_t* __restrict__ lvl, const LevelGeom& L, int dx, int dy, uint8_t v) {
+  // interior position plus the border positions that mirror (dx, dy) under REFLECT_101 (19-px border)
+  const int xa = kEdge + dx, ya = kEdge + dy;
+  const int xb = (dx >= 1 && dx <= kEdge) ? kEdge - dx : -1;
+  const int xc = (dx >= L.w - 1 - kEdge && dx <= L.w - 2) ? kEdge + 2 * (L.w - 1) - dx : -1;
+  const int yb = (dy >= 1 && dy <= kEdge) ? kEdge - dy : -1;
+  const int yc = (dy >= L.h - 1 - kEdge && dy <= L.h - 2) ? kEdge + 2 * (L.h - 1) - dy : -1;
+  uint8_t* r = lvl + (size_t)ya * L.stride;
+  r[xa] = v;
+  if (xb >= 0) r[xb] = v;
+  if (xc >= 0) r[xc] = v;
+  if (yb >= 0) {
+    r = lvl + (size_t)yb * L.stride;
+    r[xa] = v;
+    if (xb >= 0) r[xb] = v;
+    if (xc >= 0) r[xc] = v;
+  }
+  if (yc >= 0) {
+    r = lvl + (size_t)yc * L.stride;
+    r[xa] = v;
+    if (xb >= 0) r[xb] = v;
+    if (xc >= 0) r[xc] = v;
+  }
+}
+
+__global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int img_stride,
+                                                       uint8_t* __restrict__ pyr, PyrGeom g, const ResizeTap* __restrict__ xtab,
+                                                       const ResizeTap* __restrict__ ytab, const TowerAxis* __restrict__ tax,
+                                                       const TowerAxis* __restrict__ tay) {
+  __shared__ __attribute__((aligned(16))) uint8_t buf[2][kTwSide * kTwSide];
+  __shared__ TowerTap s_xt[ORBG_MAX_LEVELS][kTwSide], s_yt[ORBG_MAX_LEVELS][kTwSide];
+  __shared__ TowerAxis s_ax, s_ay;
+  __shared__ LevelGeom s_lv[ORBG_MAX_LEVELS];   // kernel arguments sit in cold memory: each first touch of a cache line costs
+                                                // a full miss, so the per-level geometry is fetched once, up front
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cam = blockIdx.z;
+  const int nl = g.n_levels;
+  {
+    constexpr int kWords = (int)sizeof(TowerAxis) / 4;
+    if (tid < kWords) reinterpret_cast<int*>(&s_ax)[tid] = reinterpret_cast<const int*>(tax + blockIdx.x)[tid];
+    else if (tid < 2 * kWords) reinterpret_cast<int*>(&s_ay)[tid - kWords] = reinterpret_cast<const int*>(tay + blockIdx.y)[tid - kWords];
+    constexpr int kLvWords = (int)sizeof(LevelGeom) / 4;
+    const int j = tid - 2 * kWords;
+    if (j >= 0 && j < nl * kLvWords) reinterpret_cast<int*>(s_lv)[j] = reinterpret_cast<const int*>(g.lv)[j];
+  }
+  __syncthreads();
+  // level-0 block: image -> registers (all loads in flight), then LDS + the owned part to the pyramid
+  const int x0 = s_ax.need_lo[0], nw0 = s_ax.need_hi[0] - x0, y0 = s_ay.need_lo[0], nh0 = s_ay.need_hi[0] - y0;
+  const uint8_t* img = cam ? img1 : img0;
+  uint8_t px[kTwSide / kTwWaves];
+#pragma unroll
+  for (int k = 0; k < kTwSide / kTwWaves; k++) {
+    const int yy = wave + kTwWaves * k;
+    // clamped, unconditional: a predicated load makes hipcc branch around it and wait for each one separately
+    px[k] = img[(size_t)(y0 + min(yy, nh0 - 1)) * img_stride + x0 + min(lane, nw0 - 1)];
+  }
+  // taps of every level for this tile's ranges, source indices made relative to the previous level's block
+  for (int l0 = 1; l0 < nl; l0 += kTwWaves / 2) {
+    const int l = l0 + (wave >> 1);               // waves 2j, 2j+1: x and y taps of level l0+j
+    if (l < nl) {
+      const bool is_y = wave & 1;
+      const LevelGeom D = s_lv[l], S = s_lv[l - 1];
+      const TowerAxis& A = is_y ? s_ay : s_ax;
+      const int lo = A.need_lo[l], n = A.need_hi[l] - lo, plo = A.need_lo[l - 1];
+      if (lane < n) {
+        const ResizeTap t = is_y ? ytab[D.yt_off + lo + lane] : xtab[D.xt_off + lo + lane];
+        int i0, i1;
+        if (is_y) { i0 = min(max((int)t.ofs, 0), S.h - 1); i1 = min(max((int)t.ofs + 1, 0), S.h - 1); }
+        else { i0 = t.ofs; i1 = min(i0 + 1, S.w - 1); }
+        TowerTap o;
+        o.i0 = (short)(i0 - plo); o.i1 = (short)(i1 - plo); o.a0 = t.a0; o.a1 = t.a1;
+        if (is_y) s_yt[l][lane] = o; else s_xt[l][lane] = o;
+      }
+    }
+  }
+  uint8_t* cbase = pyr + (size_t)cam * g.cam_stride;
+  {
+    const LevelGeom L = s_lv[0];
+    const int ohx = s_ax.own_hi[0], ohy = s_ay.own_hi[0];
+#pragma unroll
+    for (int k = 0; k < kTwSide / kTwWaves; k++) {
+      const int yy = wave + kTwWaves * k;
+      if (yy < nh0 && lane < nw0) {
+        buf[0][yy * kTwSide + lane] = px[k];
+        if (x0 + lane < ohx && y0 + yy < ohy) tower_emit(cbase + L.off, L, x0 + lane, y0 + yy, px[k]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int l = 1; l < nl; l++) {
+    const int lox = s_ax.need_lo[l], nw = s_ax.need_hi[l] - lox, loy = s_ay.need_lo[l], nh = s_ay.need_hi[l] - loy;
+    if (nw > 0 && nh > 0) {
+      const LevelGeom L = s_lv[l];
+      const uint8_t* src = buf[(l - 1) & 1];
+      uint8_t* dst = buf[l & 1];
+      const int olx = s_ax.own_lo[l], ohx = s_ax.own_hi[l], oly = s_ay.own_lo[l], ohy = s_ay.own_hi[l];
+      if (lane < nw) {
+        const TowerTap tx = s_xt[l][lane];
+        for (int yy = wave; yy < nh; yy += kTwWaves) {
+          const TowerTap ty = s_yt[l][yy];
+          const uint8_t* r0 = src + ty.i0 * kTwSide;
+          const uint8_t* r1 = src + ty.i1 * kTwSide;
+          const int t0 = r0[tx.i0] * tx.a0 + r0[tx.i1] * tx.a1;
+          const int t1 = r1[tx.i0] * tx.a0 + r1[tx.i1] * tx.a1;
+          const int v = ((((int)ty.a0 * (t0 >> 4)) >> 16) + (((int)ty.a1 * (t1 >> 4)) >> 16) + 2) >> 2;
+          dst[yy * kTwSide + lane] = (uint8_t)v;
+          const int dx = lox + lane, dy = loy + yy;
+          if (dx >= olx && dx < ohx && dy >= oly && dy < ohy) tower_emit(cbase + L.off, L, dx, dy, (uint8_t)v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FAST-9/16 per cell  (cv::FAST via S/ORBextractor.cc:808-841)
 
 // max over the 16 arcs of 9 contiguous ring pixels of min(d) -- sliding-window minimum by doubling.
@@ -1262,6 +1393,8 @@ struct orbx_handle {
   std::vector<CellRec> cells;
   DevBuf<uint8_t> d_pyr, d_img;
   DevBuf<ResizeTap> d_xtab, d_ytab;
+  DevBuf<TowerAxis> d_tower_x, d_tower_y;    // per level-0 tile ranges of pyr_tower_kernel
+  int tower_T = 0, tower_ntx = 0, tower_nty = 0;   // tile side (0 = halo too large: one launch per level instead)
   DevBuf<CellRec> d_cells;
   DevBuf<uint32_t> d_slots;
   DevBuf<int> d_counts;
@@ -1294,6 +1427,45 @@ struct orbx_handle {
   float timings[8] = {0};
   int profile = 1;   // 0: no events, 1: only the FAST kernel is bracketed (bench roofline), 2: every stage
 };
+
+// Owned / needed pixel ranges of every level for the level-0 tiles of one axis (see pyr_tower_kernel).
+// s0[l][d], s1[l][d]: the two source indices (level l-1) the taps of pixel d of level l read.  Returns the largest
+// needed extent.
+static int build_tower_axis(int T, int nl, const int* size, const std::vector<std::vector<int>>& s0,
+                            const std::vector<std::vector<int>>& s1, std::vector<TowerAxis>& out) {
+  const int nt = (size[0] + T - 1) / T;
+  out.assign(nt, TowerAxis{});
+  std::vector<int> owner_prev(size[0]), owner;
+  for (int d = 0; d < size[0]; d++) owner_prev[d] = d / T;
+  for (int t = 0; t < nt; t++) { out[t].own_lo[0] = (short)(t * T); out[t].own_hi[0] = (short)std::min((t + 1) * T, size[0]); }
+  for (int l = 1; l < nl; l++) {
+    owner.assign(size[l], 0);
+    for (int t = 0; t < nt; t++) { out[t].own_lo[l] = 0; out[t].own_hi[l] = 0; }
+    std::vector<char> seen(nt, 0);
+    for (int d = 0; d < size[l]; d++) {
+      const int t = owner_prev[s0[l][d]];
+      owner[d] = t;
+      if (!seen[t]) { seen[t] = 1; out[t].own_lo[l] = (short)d; }
+      out[t].own_hi[l] = (short)(d + 1);
+    }
+    owner_prev.swap(owner);
+  }
+  int max_need = 0;
+  for (int t = 0; t < nt; t++) {
+    TowerAxis& A = out[t];
+    A.need_lo[nl - 1] = A.own_lo[nl - 1]; A.need_hi[nl - 1] = A.own_hi[nl - 1];
+    for (int l = nl - 1; l >= 1; l--) {
+      int lo = A.own_lo[l - 1], hi = A.own_hi[l - 1];
+      if (A.need_hi[l] > A.need_lo[l]) {
+        const int a = s0[l][A.need_lo[l]], b = s1[l][A.need_hi[l] - 1] + 1;
+        if (hi > lo) { lo = std::min(lo, a); hi = std::max(hi, b); } else { lo = a; hi = b; }
+      }
+      A.need_lo[l - 1] = (short)lo; A.need_hi[l - 1] = (short)hi;
+    }
+    for (int l = 0; l < nl; l++) max_need = std::max(max_need, A.need_hi[l] - A.need_lo[l]);
+  }
+  return max_need;
+}
 
 static int setup_geometry(orbx_handle* h, int w, int hgt) {
   if (w == h->cur_w && hgt == h->cur_h) return ORBG_OK;
@@ -1415,6 +1587,31 @@ static int setup_geometry(orbx_handle* h, int w, int hgt) {
         (rc = h->d_sad.reserve(need)) || (rc = h->h_stereo.reserve(2 * need)))
       return rc;
   }
+  // one-launch pyramid: largest level-0 tile whose halo still fits the LDS blocks of pyr_tower_kernel
+  h->tower_T = 0;
+  if (!getenv("ORBG_NO_TOWER")) {
+    std::vector<std::vector<int>> sx0(nl), sx1(nl), sy0(nl), sy1(nl);
+    int ws[ORBG_MAX_LEVELS], hs[ORBG_MAX_LEVELS];
+    for (int l = 0; l < nl; l++) { ws[l] = g.lv[l].w; hs[l] = g.lv[l].h; }
+    for (int l = 1; l < nl; l++) {
+      const LevelGeom& D = g.lv[l]; const LevelGeom& S = g.lv[l - 1];
+      sx0[l].resize(D.w); sx1[l].resize(D.w); sy0[l].resize(D.h); sy1[l].resize(D.h);
+      for (int d = 0; d < D.w; d++) { const int o = xtab[D.xt_off + d].ofs; sx0[l][d] = o; sx1[l][d] = std::min(o + 1, S.w - 1); }
+      for (int d = 0; d < D.h; d++) {
+        const int o = ytab[D.yt_off + d].ofs;
+        sy0[l][d] = std::min(std::max(o, 0), S.h - 1); sy1[l][d] = std::min(std::max(o + 1, 0), S.h - 1);
+      }
+    }
+    for (int T = 56; T >= 16; T -= 4) {
+      std::vector<TowerAxis> ax, ay;
+      if (build_tower_axis(T, nl, ws, sx0, sx1, ax) > kTwSide || build_tower_axis(T, nl, hs, sy0, sy1, ay) > kTwSide) continue;
+      if ((rc = h->d_tower_x.reserve(ax.size())) || (rc = h->d_tower_y.reserve(ay.size()))) return rc;
+      ORBG_HIP(hipMemcpy(h->d_tower_x.p, ax.data(), ax.size() * sizeof(TowerAxis), hipMemcpyHostToDevice));
+      ORBG_HIP(hipMemcpy(h->d_tower_y.p, ay.data(), ay.size() * sizeof(TowerAxis), hipMemcpyHostToDevice));
+      h->tower_T = T; h->tower_ntx = (int)ax.size(); h->tower_nty = (int)ay.size();
+      break;
+    }
+  }
   if (!xtab.empty()) ORBG_HIP(hipMemcpy(h->d_xtab.p, xtab.data(), xtab.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
   if (!ytab.empty()) ORBG_HIP(hipMemcpy(h->d_ytab.p, ytab.data(), ytab.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
   if (!h->cells.empty()) ORBG_HIP(hipMemcpy(h->d_cells.p, h->cells.data(), h->cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
@@ -1491,7 +1688,7 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   if (!h) return ORBG_BAD_ARG;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  h->d_pyr.release(); h->d_img.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_cells.release();
+  h->d_pyr.release(); h->d_img.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_tower_x.release(); h->d_tower_y.release(); h->d_cells.release();
   h->d_slots.release(); h->d_counts.release(); h->hdr.release(); h->cand.release(); h->sel.release();
   h->d_kps.release(); h->d_desc.release(); h->h_kps.release(); h->h_desc.release();
   h->d_uright.release(); h->d_depth.release(); h->d_sad.release(); h->h_stereo.release();
@@ -1546,13 +1743,18 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   h->pool->prepare();
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[0], st));
   {
-    const LevelGeom& L0 = g.lv[0];
-    dim3 grid((L0.w + 2 * kEdge + 63) / 64, (L0.h + 2 * kEdge + 3) / 4, ncams);
-    hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, d_img0, d_img1 ? d_img1 : d_img0, stride, h->d_pyr.p, g);
-    for (int l = 1; l < nl; l++) {
-      const LevelGeom& L = g.lv[l];
-      dim3 gr((L.w + 2 * kEdge + 63) / 64, (L.h + 2 * kEdge + 3) / 4, ncams);
-      hipLaunchKernelGGL(pyr_resize_kernel, gr, dim3(256), 0, st, h->d_pyr.p, g, l, h->d_xtab.p, h->d_ytab.p);
+    if (h->tower_T > 0) {
+      hipLaunchKernelGGL(pyr_tower_kernel, dim3(h->tower_ntx, h->tower_nty, ncams), dim3(kTwThreads), 0, st, d_img0, d_img1 ? d_img1 : d_img0,
+                         stride, h->d_pyr.p, g, h->d_xtab.p, h->d_ytab.p, h->d_tower_x.p, h->d_tower_y.p);
+    } else {
+      const LevelGeom& L0 = g.lv[0];
+      dim3 grid((L0.w + 2 * kEdge + 63) / 64, (L0.h + 2 * kEdge + 3) / 4, ncams);
+      hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, d_img0, d_img1 ? d_img1 : d_img0, stride, h->d_pyr.p, g);
+      for (int l = 1; l < nl; l++) {
+        const LevelGeom& L = g.lv[l];
+        dim3 gr((L.w + 2 * kEdge + 63) / 64, (L.h + 2 * kEdge + 3) / 4, ncams);
+        hipLaunchKernelGGL(pyr_resize_kernel, gr, dim3(256), 0, st, h->d_pyr.p, g, l, h->d_xtab.p, h->d_ytab.p);
+      }
     }
   }
   if (prof >= 1) ORBG_HIP(hipEventRecord(h->ev[1], st));
