@@ -109,6 +109,9 @@ int orbx_extract_stereo_dev(orbx_handle* h, const uint8_t* d_img_left, const uin
 /* mvImagePyramid[level] (public member read by Frame::ComputeStereoMatches, I/ORBextractor.h:87):
  * dimensions, and a copy of the level (without its 19-px border) into host memory (may be NULL). */
 int orbx_get_level(orbx_handle* h, int cam, int level, uint8_t* host_out, int* width, int* height);
+/* Same level together with the 19-px REFLECT_101 border copyMakeBorder puts around it (S/ORBextractor.cc:1167-1173):
+ * (width+38) x (height+38) bytes, tightly packed.  *width / *height still report the level size without border. */
+int orbx_get_level_bordered(orbx_handle* h, int cam, int level, uint8_t* host_out, int* width, int* height);
 
 /* Test/diagnostic view of ComputeKeyPointsOctTree's vToDistributeKeys (S/ORBextractor.cc:776-853)
  * for the last extraction: per level, FAST candidates in the reference's cell-major order,

@@ -138,12 +138,14 @@ class ORBextractor:
             return n, nr.value, kl[:n], dl[:n], ur[:n], dp[:n]
         return nl.value, nr.value
 
-    def level(self, cam, level):
-        """mvImagePyramid[level] (I/ORBextractor.h:87) of the last extraction."""
+    def level(self, cam, level, border=False):
+        """mvImagePyramid[level] (I/ORBextractor.h:87) of the last extraction; border=True includes the 19-px border."""
         w, h = C.c_int(0), C.c_int(0)
-        capi.check(self.lib.orbx_get_level(self.h, cam, level, None, C.byref(w), C.byref(h)))
-        out = np.zeros((h.value, w.value), np.uint8)
-        capi.check(self.lib.orbx_get_level(self.h, cam, level, _vp(out), C.byref(w), C.byref(h)))
+        fn = self.lib.orbx_get_level_bordered if border else self.lib.orbx_get_level
+        capi.check(fn(self.h, cam, level, None, C.byref(w), C.byref(h)))
+        e = 38 if border else 0
+        out = np.zeros((h.value + e, w.value + e), np.uint8)
+        capi.check(fn(self.h, cam, level, _vp(out), C.byref(w), C.byref(h)))
         return out
 
     def candidates(self, cam, level, cap=1 << 18):

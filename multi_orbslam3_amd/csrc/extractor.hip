@@ -2065,6 +2065,20 @@ extern "C" int orbx_get_level(orbx_handle* h, int cam, int level, uint8_t* host_
   return ORBG_OK;
 }
 
+extern "C" int orbx_get_level_bordered(orbx_handle* h, int cam, int level, uint8_t* host_out, int* width, int* height) {
+  if (!h || cam < 0 || cam >= h->cfg.n_cams || level < 0 || level >= h->cfg.n_levels || h->cur_w == 0) return ORBG_BAD_ARG;
+  const LevelGeom& L = h->geom.lv[level];
+  if (width) *width = L.w;
+  if (height) *height = L.h;
+  if (host_out) {
+    int rc = select_device(h->device);
+    if (rc) return rc;
+    const uint8_t* src = h->d_pyr.p + (size_t)cam * h->geom.cam_stride + L.off;
+    ORBG_HIP(hipMemcpy2D(host_out, L.w + 2 * kEdge, src, L.stride, L.w + 2 * kEdge, L.h + 2 * kEdge, hipMemcpyDeviceToHost));
+  }
+  return ORBG_OK;
+}
+
 extern "C" int orbx_get_candidates(orbx_handle* h, int cam, int level, int32_t* xys, int cap, int* n) {
   if (!h || cam < 0 || cam >= h->cfg.n_cams || level < 0 || level >= h->cfg.n_levels || !n) return ORBG_BAD_ARG;
   if (h->last_was_gpu) {

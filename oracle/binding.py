@@ -140,11 +140,13 @@ class Extractor:
                                   C.byref(n), C.byref(nm))
         return rc, kps[: n.value].copy(), desc[: n.value].copy(), nm.value
 
-    def level(self, l):
+    def level(self, l, border=False):
         w, h = C.c_int(0), C.c_int(0)
-        _chk(lib().oracle_get_level(self.h, l, None, C.byref(w), C.byref(h)))
-        out = np.zeros((h.value, w.value), np.uint8)
-        _chk(lib().oracle_get_level(self.h, l, C.c_void_p(out.ctypes.data), C.byref(w), C.byref(h)))
+        fn = lib().oracle_get_level_bordered if border else lib().oracle_get_level
+        _chk(fn(self.h, l, None, C.byref(w), C.byref(h)))
+        e = 38 if border else 0
+        out = np.zeros((h.value + e, w.value + e), np.uint8)
+        _chk(fn(self.h, l, C.c_void_p(out.ctypes.data), C.byref(w), C.byref(h)))
         return out
 
     def candidates(self, l, cap=1 << 18):

@@ -630,6 +630,16 @@ extern "C" int oracle_get_level(oracle_extractor* e, int level, uint8_t* host_ou
   return ORBG_OK;
 }
 
+extern "C" int oracle_get_level_bordered(oracle_extractor* e, int level, uint8_t* host_out, int* width, int* height) {
+  if (!e || level < 0 || level >= e->cfg.n_levels || e->pyr[level].empty()) return ORBG_BAD_ARG;
+  if (width) *width = e->lw[level];
+  if (height) *height = e->lh[level];
+  const int bw = e->lw[level] + 2 * kEdge, bh = e->lh[level] + 2 * kEdge;
+  if (host_out)
+    for (int y = 0; y < bh; y++) std::memcpy(host_out + (size_t)y * bw, e->pyr[level].data() + (size_t)y * e->lstride[level], bw);
+  return ORBG_OK;
+}
+
 extern "C" int oracle_get_candidates(oracle_extractor* e, int level, int32_t* xys, int cap, int* n) {
   if (!e || level < 0 || level >= e->cfg.n_levels || !n) return ORBG_BAD_ARG;
   *n = (int)e->cands[level].size();

@@ -49,6 +49,7 @@ int oracle_get_umax(const oracle_extractor* e, int32_t* umax16);
 int oracle_extract(oracle_extractor* e, const uint8_t* img, int width, int height, int stride,
                    int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n, int* n_mono);
 int oracle_get_level(oracle_extractor* e, int level, uint8_t* host_out, int* width, int* height);
+int oracle_get_level_bordered(oracle_extractor* e, int level, uint8_t* host_out, int* width, int* height);
 int oracle_get_candidates(oracle_extractor* e, int level, int32_t* xys, int cap, int* n);
 /* DistributeOctTree alone (S/ORBextractor.cc:537-761): in = n x {x,y,score} (relative coords),
  * out = kept candidates in list order. */

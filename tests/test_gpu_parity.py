@@ -41,6 +41,27 @@ def test_extractor_mono_bit_exact(scene, k):
     _assert_extract_equal((k2, d2), (ok2, od2), "mono-lapping")
 
 
+@pytest.mark.parametrize("shape,scale,levels", [((480, 640), 1.2, 8), ((241, 323), 1.2, 8), ((480, 640), 1.1, 12), ((300, 400), 2.0, 4)])
+def test_pyramid_one_launch_and_per_level_paths(monkeypatch, shape, scale, levels):
+    """Every pyramid level, border included: the one-launch tile tower, the per-level launches it falls back to when the
+    halo does not fit (scale 2.0), odd sizes and other scale factors -- all against the oracle's cv::resize cascade."""
+    rng = np.random.RandomState(shape[0] + levels)
+    img = rng.randint(0, 256, shape).astype(np.uint8)
+    img[::7, ::5] = 255
+    H, W = shape
+    oe = ob.Extractor(n_features=300, scale_factor=scale, n_levels=levels, max_width=W, max_height=H)
+    oe.extract(img)
+    for no_tower in ("", "1"):
+        if no_tower:
+            monkeypatch.setenv("ORBG_NO_TOWER", "1")
+        else:
+            monkeypatch.delenv("ORBG_NO_TOWER", raising=False)
+        ex = api.ORBextractor(300, scale, levels, 20, 7, W, H, n_cams=1)
+        ex(img, (0, 0))
+        for l in range(levels):
+            assert np.array_equal(ex.level(0, l, border=True), oe.level(l, border=True)), "level %d (no_tower=%r)" % (l, no_tower)
+
+
 def test_extractor_empty_image():
     ex = api.ORBextractor(100, 1.2, 8, 20, 7, 320, 240)
     nm, kps, desc = ex(None)
