@@ -6,9 +6,10 @@ One STEP = one stereo frame of one agent through the hot path, inputs already re
   [Frame ctor: extract L+R (pyramid, FAST, quad-tree, angle, rBRIEF) -> ComputeStereoMatches -> feature grid]
   ->  SearchByProjection(cur, last)  ->  SearchLocalPoints (isInFrustum + SearchByProjection over the local map)
 and, every FRAMES_PER_KF-th step (a keyframe), one Local Bundle Adjustment (20 free + 10 fixed KFs, 2000 points)
-plus the upload of the refreshed local map.  By default the LBA runs on its own host thread and HIP stream,
-concurrently with the frame loop, exactly as the reference runs LocalMapping next to Tracking
-(S/ClientSystem.cc:105-106); every LBA triggered in the timed region is joined before the clock stops.
+plus the upload of the refreshed local map.  By default (--lba-mode async) the LBA runs on the library's own worker
+thread and HIP stream (lba_solve_async / lba_wait), concurrently with the frame loop, exactly as the reference runs
+LocalMapping next to Tracking (S/ClientSystem.cc:105-106); every LBA triggered in the timed region is waited for
+before the clock stops.  `--lba-mode thread` does the same from a Python thread (pays for GIL hand-overs).
 `--lba-mode inline` gives the serial accounting fps = 1 / (t_frontend + t_LBA / FRAMES_PER_KF), which is also
 reported as config.sequential_fps_formula.
 
@@ -131,9 +132,10 @@ def main():
     ap.add_argument("--profile-stages", action="store_true",
                     help="bracket every extractor stage with HIP events (more API calls per frame); by default only "
                          "fast_cells_kernel (the roofline kernel) is bracketed")
-    ap.add_argument("--lba-mode", choices=["thread", "inline"], default="thread",
-                    help="thread: LBA runs on its own host thread + HIP stream concurrently with tracking, as the reference's "
-                         "LocalMapping thread does (S/ClientSystem.cc:105-106); inline: LBA blocks the frame loop")
+    ap.add_argument("--lba-mode", choices=["async", "thread", "inline"], default="async",
+                    help="async: LBA runs on the library's worker thread + its own HIP stream concurrently with tracking, as the "
+                         "reference's LocalMapping thread does (S/ClientSystem.cc:105-106); thread: the same from a Python "
+                         "thread; inline: LBA blocks the frame loop")
     args = ap.parse_args()
 
     import torch
@@ -180,6 +182,8 @@ def main():
     import threading
     lba_q = queue.Queue()
 
+    lba_out = views.LbaOutput(lp.n_poses, lp.n_points, lp.n_edges)      # result arrays are allocated once, like a SLAM system would
+
     def lba_worker():
         while True:
             job = lba_q.get()
@@ -187,16 +191,29 @@ def main():
                 lba_q.task_done()
                 return
             t0 = time.perf_counter()
-            out = opt.LocalBundleAdjustment(lp)
+            out = opt.LocalBundleAdjustment(lp, out=lba_out)
             dt = time.perf_counter() - t0
             if job:
                 stats["lba_iters"] += sum(out.iters); stats["lba_calls"] += 1; stats["lba_s"] += dt
             lba_q.task_done()
 
+    async_state = dict(t0=None, timed=False)
+
+    def collect_async():
+        if async_state["t0"] is None:
+            return
+        out = opt.wait()
+        if async_state["timed"]:
+            stats["lba_iters"] += sum(out.iters); stats["lba_calls"] += 1
+            stats["lba_s"] += opt.last_solve_ms * 1e-3
+        async_state["t0"] = None
+
     worker = None
     if args.lba_mode == "thread":
         worker = threading.Thread(target=lba_worker, daemon=True)
         worker.start()
+
+    amp_buf = np.full(8192, -1, np.int32); aob_buf = np.zeros(8192, np.int32)
 
     def step(i, timed):
         k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
@@ -214,10 +231,11 @@ def main():
             nl, nr = ex.frame_stereo_dev(F, fv, dL.data_ptr(), dR.data_ptr(), W, H, W, bf, bb)
             t1 = t2 = time.perf_counter()
         t3 = time.perf_counter()
-        amp = np.full(nl, -1, np.int32); aob = np.zeros(nl, np.int32)
-        amp, aob, n1 = m_frame.SearchByProjectionFrame(F, fr["guess"], frames[k_last]["last_view"][0], 7.0, False, amp, aob)
+        amp = amp_buf[:nl]; aob = aob_buf[:nl]
+        amp.fill(-1); aob.fill(0)                         # F.mvpMapPoints starts empty (S/Frame.cc:113)
+        amp, aob, n1 = m_frame.SearchByProjectionFrame(F, fr["guess"], frames[k_last]["last_view"][0], 7.0, False, amp, aob, inplace=True)
         t4 = time.perf_counter()
-        amp, aob, n2 = m_map.SearchLocalPoints(F, LM, fr["guess"], 1.0, False, 0.0, amp, aob, None)
+        amp, aob, n2 = m_map.SearchLocalPoints(F, LM, fr["guess"], 1.0, False, 0.0, amp, aob, None, inplace=True)
         t5 = time.perf_counter()
         if args.pose_opt:
             # TrackWithMotionModel / TrackLocalMap call PoseOptimization after each search (S/Tracking.cc:2649,2712);
@@ -234,11 +252,16 @@ def main():
             wv, keep = views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
             LM.upload(wv)
             t6 = time.perf_counter()
-            if worker is not None:
+            if args.lba_mode == "async":
+                collect_async()                        # the previous keyframe's LBA (long finished in steady state)
+                async_state["t0"], async_state["timed"] = time.perf_counter(), timed
+                opt.LocalBundleAdjustmentAsync(lp, lba_out)
+                t7 = time.perf_counter()
+            elif worker is not None:
                 lba_q.put(timed)                       # LocalMapping thread picks the keyframe up
                 t7 = t6
             else:
-                out = opt.LocalBundleAdjustment(lp)
+                out = opt.LocalBundleAdjustment(lp, out=lba_out)
                 t7 = time.perf_counter()
                 if timed:
                     stats["lba_iters"] += sum(out.iters); stats["lba_calls"] += 1; stats["lba_s"] += t7 - t6
@@ -258,9 +281,11 @@ def main():
     for i in range(args.warmup):
         step(i, False)
     lba_q.join()
+    collect_async()
 
     def sync():
         lba_q.join()                                   # every LBA triggered inside the timed region has finished
+        collect_async()
         torch.cuda.synchronize()
 
     # barrier + synchronize, exactly K steps, synchronize + barrier, MAX over ranks (harness.AgentGroup.timed)

@@ -333,6 +333,12 @@ typedef struct lba_handle lba_handle;
 int lba_create(int device, int cap_poses, int cap_points, int cap_edges, lba_handle** out);
 int lba_destroy(lba_handle* h);
 int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
+/* The same solve on a worker thread owned by the handle, as the reference runs it on its LocalMapping thread next to
+ * Tracking (S/ClientSystem.cc:105-106).  lba_solve_async returns immediately; lba_wait blocks until the solve is done
+* and returns its status (ORBG_OK when nothing was submitted).  problem / stop_flag / result must stay valid until then;
+ * one solve in flight per handle (a second lba_solve_async before lba_wait returns ORBG_BAD_ARG). */
+int lba_solve_async(lba_handle* h, const lba_problem* problem, const volatile int32_t* stop_flag, lba_result* result);
+int lba_wait(lba_handle* h, double* solve_ms /* wall time of that solve on the worker, may be NULL */);
 
 /* ---------------------------------------------------------------- pose-only optimisation */
 

@@ -291,10 +291,9 @@ class ORBmatcher:
         return amp, aob, n.value
 
     def SearchLocalPoints(self, F, local_map, Tcw, th=1.0, bFarPoints=False, thFarPoints=50.0, assigned_mp=None,
-                          assigned_obs=None, skip=None):
+                          assigned_obs=None, skip=None, inplace=False):
         """Fused Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153)."""
-        amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
-        aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+        amp, aob = self._state(assigned_mp, assigned_obs, inplace)
         T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
         sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
         n = C.c_int(0)
@@ -303,10 +302,17 @@ class ORBmatcher:
                                                      C.byref(n)), "orbm_search_local_points")
         return amp, aob, n.value
 
-    def SearchByProjectionFrame(self, CurrentFrame, Tcw_cur, lv, th, bMono, assigned_mp, assigned_obs):
+    @staticmethod
+    def _state(assigned_mp, assigned_obs, inplace):
+        """F.mvpMapPoints flattened; inplace=True updates the caller's int32 arrays (as the C ABI does) instead of copies."""
+        if inplace:
+            assert assigned_mp.dtype == np.int32 and assigned_obs.dtype == np.int32
+            return assigned_mp, assigned_obs
+        return np.ascontiguousarray(assigned_mp, np.int32).copy(), np.ascontiguousarray(assigned_obs, np.int32).copy()
+
+    def SearchByProjectionFrame(self, CurrentFrame, Tcw_cur, lv, th, bMono, assigned_mp, assigned_obs, inplace=False):
         """(Frame &CurrentFrame, const Frame &LastFrame, th, bMono): S/ORBmatcher.cc:1970-2186."""
-        amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
-        aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+        amp, aob = self._state(assigned_mp, assigned_obs, inplace)
         T = np.ascontiguousarray(Tcw_cur, np.float32).reshape(16)
         n = C.c_int(0)
         capi.check(self.lib.orbm_search_by_projection_frame(CurrentFrame.h, _vp(T), C.byref(lv), C.c_float(th), int(bMono),
@@ -374,15 +380,33 @@ class Optimizer:
         except Exception:
             pass
 
+    def LocalBundleAdjustmentAsync(self, problem, out, pbStopFlag=None):
+        """Submit the solve to the handle's own LocalMapping thread (lba_solve_async); collect with wait()."""
+        out.c.trace_len = 0
+        self._async_keep = (problem, out, pbStopFlag)
+        sp = None if pbStopFlag is None else C.c_void_p(pbStopFlag.ctypes.data)
+        capi.check(self.lib.lba_solve_async(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_async")
+
+    def wait(self):
+        ms = C.c_double(0.0)
+        capi.check(self.lib.lba_wait(self.h, C.byref(ms)), "lba_wait")
+        self.last_solve_ms = ms.value
+        keep, self._async_keep = getattr(self, "_async_keep", None), None
+        return keep[1] if keep else None
+
     def PoseOptimization(self, problem):
         """int Optimizer::PoseOptimization(Frame*) (S/Optimizer.cc:964-1278); problem: views.pose_opt_problem(...)[0]."""
         out = views.PoseOptOutput(problem.n)
         capi.check(self.lib.pose_optimize(C.byref(problem), C.byref(out.c)), "pose_optimize")
         return out
 
-    def LocalBundleAdjustment(self, problem, pbStopFlag=None, trace_cap=64):
-        """problem: views.lba_problem(...)[0]; pbStopFlag: np.int32[1] polled between LM iterations."""
-        out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)
+    def LocalBundleAdjustment(self, problem, pbStopFlag=None, trace_cap=64, out=None):
+        """problem: views.lba_problem(...)[0]; pbStopFlag: np.int32[1] polled between LM iterations.
+        out: a views.LbaOutput of matching size to reuse (the result arrays are the caller's, as in the C ABI)."""
+        if out is None:
+            out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)
+        else:
+            out.c.trace_len = 0
         sp = None if pbStopFlag is None else C.c_void_p(pbStopFlag.ctypes.data)
         capi.check(self.lib.lba_solve_h(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_h")
         return out

@@ -20,6 +20,12 @@
 // The reduced camera system is tiny (6P x 6P, P <= a few tens): the path is latency bound, not FLOP bound.
 // Parity: poses/points within 1e-4 of the oracle after float32 write-back, identical outlier sets.
 
+#include <time.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "common.hpp"
 
 #include <algorithm>
@@ -968,6 +974,14 @@ struct lba_handle {
   DevBuf<PairItem> d_items;
   PinnedBuf<HostRec> rec;
   float last_ms = 0;
+  // lba_solve_async: the library-owned "LocalMapping" thread of this handle
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool quit = false, job_pending = false, job_running = false;
+  const lba_problem* job_p = nullptr; const volatile int32_t* job_stop = nullptr; lba_result* job_r = nullptr;
+  int job_status = ORBG_OK;
+  double job_ms = 0;
 };
 
 extern "C" int lba_create(int device, int cap_poses, int cap_points, int cap_edges, lba_handle** out) {
@@ -985,6 +999,11 @@ extern "C" int lba_create(int device, int cap_poses, int cap_points, int cap_edg
 
 extern "C" int lba_destroy(lba_handle* h) {
   if (!h) return ORBG_BAD_ARG;
+  if (h->worker.joinable()) {
+    { std::lock_guard<std::mutex> lk(h->mu); h->quit = true; }
+    h->cv.notify_all();
+    h->worker.join();
+  }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->d_edges.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release();
@@ -1297,6 +1316,48 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   }
   for (size_t i = 0; i < points.size(); i++) r->points[i] = (float)points[i];
   return ORBG_OK;
+}
+
+// Optimizer::LocalBundleAdjustment runs on the LocalMapping thread, concurrently with Tracking (S/ClientSystem.cc:105-106,
+// S/LocalMapping.cc:114-133).  lba_solve_async hands the problem to a worker thread owned by the handle and returns at once;
+// lba_wait blocks until that solve has finished and returns its status.  problem / stop_flag / result must stay valid
+// until lba_wait returns; one solve in flight per handle.
+extern "C" int lba_solve_async(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
+  if (!h || !p || !r) return ORBG_BAD_ARG;
+  std::unique_lock<std::mutex> lk(h->mu);
+  if (h->job_pending || h->job_running) return ORBG_BAD_ARG;
+  if (!h->worker.joinable()) {
+    h->worker = std::thread([h]() {
+      std::unique_lock<std::mutex> lk(h->mu);
+      for (;;) {
+        h->cv.wait(lk, [h]() { return h->quit || h->job_pending; });
+        if (h->quit) return;
+        h->job_pending = false; h->job_running = true;
+        const lba_problem* p = h->job_p; const volatile int32_t* st = h->job_stop; lba_result* r = h->job_r;
+        lk.unlock();
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        const int rc = lba_solve_h(h, p, st, r);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        lk.lock();
+        h->job_ms = 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec);
+        h->job_status = rc; h->job_running = false;
+        h->cv.notify_all();
+      }
+    });
+  }
+  h->job_p = p; h->job_stop = stop_flag; h->job_r = r; h->job_pending = true;
+  lk.unlock();
+  h->cv.notify_all();
+  return ORBG_OK;
+}
+
+extern "C" int lba_wait(lba_handle* h, double* solve_ms) {
+  if (!h) return ORBG_BAD_ARG;
+  std::unique_lock<std::mutex> lk(h->mu);
+  h->cv.wait(lk, [h]() { return !h->job_pending && !h->job_running; });
+  if (solve_ms) *solve_ms = h->job_ms;
+  return h->job_status;
 }
 
 extern "C" int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {

@@ -18,6 +18,7 @@
 // Compile with -ffp-contract=off.
 
 #include "common.hpp"
+#include "wave.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -48,10 +49,12 @@ struct PoseF {   // Tcw split as the reference does (S/Frame.cc:439-445)
   float R[9], t[3], Ow[3];
 };
 
-struct QResult {   // per query, written to mapped pinned memory
-  int base, count;          // candidate list segment (count entries incl. filtered ones marked invalid)
-  int best_idx, best_dist, second_idx, second_dist;
-  float u, v;               // projection (frame-frame variant needs nothing else on the host)
+struct QResult {   // per query, written by the kernel into mapped pinned memory (24 B)
+  unsigned base;            // its segment of the candidate list (device memory; fetched only if the top-4 cannot decide)
+  unsigned short count;     // entries in the segment, filtered ones included
+  unsigned short n_top;     // valid entries below (4 = there may be more candidates than listed here)
+  unsigned short idx[4];    // the four best candidates in the order a sequential strict-'<' scan ranks them
+  unsigned short dist[4];
 };
 
 __device__ __forceinline__ int popc256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
@@ -199,42 +202,77 @@ __global__ __launch_bounds__(256) void frustum_kernel(FrameParams fp, PoseF P, W
 // ------------------------------------------------------------------------------------------------
 // window search: one wavefront per query
 
-struct Top2 { unsigned k1, k2; int i1, i2; };   // keys = dist<<20 | pos, k1 <= k2
+struct Top4 { unsigned k[4]; int i[4]; };   // keys = dist<<20 | pos, ascending; 0xFFFFFFFF = empty
 
-__device__ __forceinline__ void top2_insert(Top2& t, unsigned key, int idx) {
-  if (key < t.k1) { t.k2 = t.k1; t.i2 = t.i1; t.k1 = key; t.i1 = idx; }
-  else if (key < t.k2) { t.k2 = key; t.i2 = idx; }
+__device__ __forceinline__ void top4_init(Top4& t) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) { t.k[j] = 0xFFFFFFFFu; t.i[j] = -1; }
 }
 
-__device__ __forceinline__ void top2_wave_merge(Top2& t) {
+__device__ __forceinline__ void top4_insert(Top4& t, unsigned key, int idx) {
+  if (key >= t.k[3]) return;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned ok1 = (unsigned)__shfl_xor((int)t.k1, o, 64), ok2 = (unsigned)__shfl_xor((int)t.k2, o, 64);
-    const int oi1 = __shfl_xor(t.i1, o, 64), oi2 = __shfl_xor(t.i2, o, 64);
-    top2_insert(t, ok1, oi1);
-    top2_insert(t, ok2, oi2);
+  for (int j = 3; j >= 0; j--) {
+    const bool shift = j > 0 && key < t.k[j - 1];
+    if (shift) { t.k[j] = t.k[j - 1]; t.i[j] = t.i[j - 1]; }
+    else { t.k[j] = key; t.i[j] = idx; break; }
   }
 }
 
+// The four smallest keys over the wavefront (each lane holds its own four smallest): four rounds of "wave minimum of the
+// lane heads, owner pops".  Keys are unique (pos is), so the owner is unique.  All 64 lanes must be active.
+__device__ __forceinline__ void top4_wave_emit(Top4& t, QResult& res) {
+  res.n_top = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    res.idx[r] = 0xFFFF; res.dist[r] = 256;
+    const unsigned m = wave_min(t.k[0]);
+    if (m != 0xFFFFFFFFu) {
+      const bool own = t.k[0] == m;
+      const int owner = __ffsll((unsigned long long)__ballot(own)) - 1;
+      const int idx = __builtin_amdgcn_readlane(t.i[0], owner);
+      res.idx[r] = (unsigned short)idx; res.dist[r] = (unsigned short)(m >> 20);
+      res.n_top = (unsigned short)(r + 1);
+      if (own) {
+        t.k[0] = t.k[1]; t.i[0] = t.i[1]; t.k[1] = t.k[2]; t.i[1] = t.i[2]; t.k[2] = t.k[3]; t.i[2] = t.i[3];
+        t.k[3] = 0xFFFFFFFFu; t.i[3] = -1;
+      }
+    }
+  }
+}
+
+constexpr int kOccBits = 4096;
 struct FrameDev {
   const orbx_keypoint* kps; const uint8_t* desc; const float* uright;   // uright may be NULL
   const int* cell_start; const int* cell_items;
-  const int* assigned_mp; const int* assigned_obs;                       // state at entry
+  // "feature already holds a map point" at entry: for frames of up to kOccBits features the flags travel as a bitmask
+  // inside the kernel arguments (no upload, no copy command); larger frames read the two arrays from device memory
+  const int* assigned_mp; const int* assigned_obs;
+  int use_mask;
+  uint32_t occ[kOccBits / 32];
 };
+
+__device__ __forceinline__ bool feature_occupied(const FrameDev& F, int idx) {
+  if (F.use_mask) return (F.occ[idx >> 5] >> (idx & 31)) & 1u;
+  return F.assigned_mp[idx] >= 0 && (!F.assigned_obs || F.assigned_obs[idx] > 0);
+}
 
 struct Query { int valid; float x, y, r; int min_level, max_level; float ur_ref; };
 
 // GetFeaturesInArea (S/Frame.cc:628-697) + the candidate loop of the projection searches.
 // Emits the candidate list [base, base+count) (entry = idx | dist<<16, or 0xFFFFFFFF when filtered).
 constexpr int kSlot = 16;
+constexpr int kListStage = 64;
 
 __device__ __forceinline__ void window_search(const FrameParams& fp, const FrameDev& F, const Query& q, const uint8_t* qdesc,
                                               int qid, int n_queries, int* __restrict__ list_counter,
-                                              uint32_t* __restrict__ list, int list_cap, QResult* __restrict__ out) {
+                                              uint32_t* __restrict__ list, int list_cap, QResult* __restrict__ out,
+                                              uint32_t* __restrict__ s_list /*LDS, kListStage entries of this wavefront*/) {
   const int lane = threadIdx.x & 63;
   QResult res;
-  res.base = 0; res.count = 0; res.best_idx = -1; res.best_dist = 256; res.second_idx = -1; res.second_dist = 256;
-  res.u = q.x; res.v = q.y;
+  res.base = 0; res.count = 0; res.n_top = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { res.idx[j] = 0xFFFF; res.dist[j] = 256; }
   bool empty = !q.valid;
   int nMinCellX = 0, nMaxCellX = -1, nMinCellY = 0, nMaxCellY = -1;
   if (!empty) {
@@ -257,8 +295,7 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
     const int cell = ix * ORBG_GRID_ROWS + iy;
     total += F.cell_start[cell + 1] - F.cell_start[cell];
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+  total = wave_sum(total);
   if (total == 0) {
     if (lane == 0) *out = res;
     return;
@@ -273,8 +310,8 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
   const uint4 a0 = *reinterpret_cast<const uint4*>(qdesc);
   const uint4 a1 = *reinterpret_cast<const uint4*>(qdesc + 16);
   const bool bCheckLevels = (q.min_level > 0) || (q.max_level >= 0);
-  Top2 t;
-  t.k1 = t.k2 = 0xFFFFFFFFu; t.i1 = t.i2 = -1;
+  Top4 t;
+  top4_init(t);
   int run = 0;   // candidates before the current chunk of 64 cells
   for (int c0 = 0; c0 < ncell; c0 += 64) {
     const int c = c0 + lane;
@@ -285,17 +322,10 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
       s = F.cell_start[cell];
       n = F.cell_start[cell + 1] - s;
     }
-    int inc = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += v;
-    }
-    const int chunk_total = __shfl(inc, 63, 64);
+    const int inc = wave_incl_scan_add(n);
+    const int chunk_total = __builtin_amdgcn_readlane(inc, 63);
     const int my_pos0 = run + inc - n;
-    int nmax = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    const int nmax = wave_max(n);
     for (int j = 0; j < nmax; j++) {
       if (j < n) {
         const int idx = F.cell_items[s + j];
@@ -308,7 +338,7 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
         }
         const float distx = kp.x - q.x, disty = kp.y - q.y;
         if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) ok = false;
-        if (ok && F.assigned_mp[idx] >= 0 && (!F.assigned_obs || F.assigned_obs[idx] > 0)) ok = false;
+        if (ok && feature_occupied(F, idx)) ok = false;
         if (ok && F.uright) {
           const float ur = F.uright[idx];
           if (ur > 0) {
@@ -321,19 +351,21 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
           const uint4 b0 = *reinterpret_cast<const uint4*>(F.desc + (size_t)idx * 32);
           const uint4 b1 = *reinterpret_cast<const uint4*>(F.desc + (size_t)idx * 32 + 16);
           const int d = popc256(a0, a1, b0, b1);
-          top2_insert(t, ((unsigned)d << 20) | (unsigned)pos, idx);
+          top4_insert(t, ((unsigned)d << 20) | (unsigned)pos, idx);
           entry = (unsigned)idx | ((unsigned)d << 16);
         }
-        if (base + pos < list_cap) list[base + pos] = entry;
+        // the head of the list is staged in LDS and leaves as ONE contiguous burst (the list lives in host memory)
+        if (pos < kListStage) s_list[pos] = entry;
+        else if (base + pos < list_cap) list[base + pos] = entry;
       }
     }
     run += chunk_total;
   }
-  top2_wave_merge(t);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < min(total, kListStage) && base + lane < list_cap) list[base + lane] = s_list[lane];
+  top4_wave_emit(t, res);
   if (lane == 0) {
-    res.base = base; res.count = total;
-    if (t.i1 >= 0) { res.best_idx = t.i1; res.best_dist = (int)(t.k1 >> 20); }
-    if (t.i2 >= 0) { res.second_idx = t.i2; res.second_dist = (int)(t.k2 >> 20); }
+    res.base = (unsigned)base; res.count = (unsigned short)min(total, 65535);
     *out = res;
   }
 }
@@ -346,8 +378,10 @@ struct MpsDev {
 };
 
 __global__ __launch_bounds__(256) void search_mps_kernel(FrameParams fp, FrameDev F, MpsDev mp, float th, int far_points,
-                                                        float th_far, int* list_counter, uint32_t* list, int list_cap,
+                                                        float th_far, int* list_counter, int* counter_next, uint32_t* list, int list_cap,
                                                         QResult* results) {
+  __shared__ uint32_t s_stage[4][kListStage];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;   // the overflow counter the NEXT search on this frame will use
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= mp.m) return;
   Query q;
@@ -362,14 +396,44 @@ __global__ __launch_bounds__(256) void search_mps_kernel(FrameParams fp, FrameDe
     q.min_level = lvl - 1; q.max_level = lvl;
     q.ur_ref = mp.pxr[i];
   }
-  window_search(fp, F, q, mp.desc + (size_t)i * 32, i, mp.m, list_counter, list, list_cap, results + i);
+  window_search(fp, F, q, mp.desc + (size_t)i * 32, i, mp.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
 
+// Tracking::SearchLocalPoints in one launch: isInFrustum(pMP, 0.5) (S/Frame.cc:466-543) for the wavefront's own point,
+// then the query of search_mps_kernel -- the track fields never leave registers.
+__global__ __launch_bounds__(256) void search_local_kernel(FrameParams fp, FrameDev F, WorldPtsDev w, const uint8_t* __restrict__ skip_call,
+                                                          PoseF P, float th, int far_points, float th_far, int* list_counter,
+                                                          int* counter_next, uint32_t* list, int list_cap, QResult* results) {
+  __shared__ uint32_t s_stage[4][kListStage];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= w.m) return;
+  Query q;
+  q.valid = 0; q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
+  if (!(w.bad[i] || w.skip[i] || (skip_call && skip_call[i]))) {
+    const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
+    const float N[3] = {w.normal[3 * i], w.normal[3 * i + 1], w.normal[3 * i + 2]};
+    const TrackFields t = frustum_check(fp, P, X, N, w.min_dist[i], w.max_dist[i], 0.5f);
+    if (t.in_view && !(far_points && t.depth > th_far)) {
+      float r = (t.view_cos > 0.998) ? 2.5f : 4.0f;        // RadiusByViewingCos, S/ORBmatcher.cc:216-222
+      if (th != 1.0) r *= th;
+      q.valid = 1;
+      q.x = t.px; q.y = t.py;
+      q.r = r * fp.scale[t.level];
+      q.min_level = t.level - 1; q.max_level = t.level;
+      q.ur_ref = t.pxr;
+    }
+  }
+  window_search(fp, F, q, w.desc + (size_t)i * 32, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
+}
+
 // SearchByProjection(KeyFrame*, Scw, ...) candidate tests (S/ORBmatcher.cc:495-548 / :612-667) fused with the window search
 __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameDev F, WorldPtsDev w, const uint8_t* __restrict__ found,
-                                                         PoseF P, int camera_project, int th, int* list_counter, uint32_t* list,
+                                                         PoseF P, int camera_project, int th, int* list_counter, int* counter_next, uint32_t* list,
                                                          int list_cap, QResult* results) {
+  __shared__ uint32_t s_stage[4][kListStage];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;   // the overflow counter the NEXT search on this frame will use
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= w.m) return;
   Query q;
@@ -411,7 +475,7 @@ __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameD
       }
     }
   }
-  window_search(fp, F, q, w.desc + (size_t)i * 32, i, w.m, list_counter, list, list_cap, results + i);
+  window_search(fp, F, q, w.desc + (size_t)i * 32, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
 // MODE 2: SearchByProjection(CurrentFrame, LastFrame) (S/ORBmatcher.cc:1993-2066)
@@ -421,8 +485,10 @@ struct LastDev {
 };
 
 __global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, FrameDev F, LastDev L, PoseF Pc, float th,
-                                                          int forward, int backward, int* list_counter, uint32_t* list,
+                                                          int forward, int backward, int* list_counter, int* counter_next, uint32_t* list,
                                                           int list_cap, QResult* results) {
+  __shared__ uint32_t s_stage[4][kListStage];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;   // the overflow counter the NEXT search on this frame will use
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= L.n) return;
   Query q;
@@ -447,7 +513,7 @@ __global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, Frame
       }
     }
   }
-  window_search(fp, F, q, L.desc + (size_t)i * 32, i, L.n, list_counter, list, list_cap, results + i);
+  window_search(fp, F, q, L.desc + (size_t)i * 32, i, L.n, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
 // SearchByBoW inner loops (S/ORBmatcher.cc:297-371): one wavefront per keyframe feature of a shared node.
@@ -456,16 +522,15 @@ struct BowJob { int kf_idx; int f_begin, f_end; };   // frame-side bucket [f_beg
 __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restrict__ fdesc, const uint32_t* __restrict__ f_feat_idx,
                                                         const uint8_t* __restrict__ tvalid /*target eligibility or NULL*/,
                                                         const uint8_t* __restrict__ kf_desc, const BowJob* __restrict__ jobs,
-                                                        int n_jobs, int* list_counter, uint32_t* list, int list_cap,
+                                                        int n_jobs, int* list_counter, int* counter_next, uint32_t* list, int list_cap,
                                                         QResult* results) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;   // the overflow counter the NEXT search on this frame will use
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= n_jobs) return;
   const BowJob job = jobs[j];
   const int total = job.f_end - job.f_begin;
   QResult res;
-  res.base = 0; res.count = total; res.best_idx = -1; res.best_dist = 256; res.second_idx = -1; res.second_dist = 256;
-  res.u = res.v = 0;
   int base = j * kSlot;
   if (total > kSlot) {
     if (lane == 0) base = n_jobs * kSlot + atomicAdd(list_counter, total);
@@ -473,8 +538,8 @@ __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restri
   }
   const uint4 a0 = *reinterpret_cast<const uint4*>(kf_desc + (size_t)job.kf_idx * 32);
   const uint4 a1 = *reinterpret_cast<const uint4*>(kf_desc + (size_t)job.kf_idx * 32 + 16);
-  Top2 t;
-  t.k1 = t.k2 = 0xFFFFFFFFu; t.i1 = t.i2 = -1;
+  Top4 t;
+  top4_init(t);
   for (int p = lane; p < total; p += 64) {
     const int idx = (int)f_feat_idx[job.f_begin + p];
     unsigned entry = 0xFFFFFFFFu;
@@ -482,16 +547,14 @@ __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restri
       const uint4 b0 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32);
       const uint4 b1 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32 + 16);
       const int d = popc256(a0, a1, b0, b1);
-      top2_insert(t, ((unsigned)d << 20) | (unsigned)p, idx);
+      top4_insert(t, ((unsigned)d << 20) | (unsigned)p, idx);
       entry = (unsigned)idx | ((unsigned)d << 16);
     }
     if (base + p < list_cap) list[base + p] = entry;
   }
-  top2_wave_merge(t);
+  top4_wave_emit(t, res);
   if (lane == 0) {
-    res.base = base;
-    if (t.i1 >= 0) { res.best_idx = t.i1; res.best_dist = (int)(t.k1 >> 20); }
-    if (t.i2 >= 0) { res.second_idx = t.i2; res.second_dist = (int)(t.k2 >> 20); }
+    res.base = (unsigned)base; res.count = (unsigned short)min(total, 65535);
     results[j] = res;
   }
 }
@@ -522,17 +585,25 @@ __global__ __launch_bounds__(256) void hamming_best2_kernel(const uint8_t* __res
   if (qi >= nq) return;
   const uint4 a0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
   const uint4 a1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16);
-  Top2 tt;
-  tt.k1 = tt.k2 = 0xFFFFFFFFu; tt.i1 = tt.i2 = -1;
+  Top4 tt;
+  top4_init(tt);
   for (int j = lane; j < nt; j += 64) {
     const uint4 b0 = *reinterpret_cast<const uint4*>(t + (size_t)j * 32);
     const uint4 b1 = *reinterpret_cast<const uint4*>(t + (size_t)j * 32 + 16);
-    top2_insert(tt, ((unsigned)popc256(a0, a1, b0, b1) << 20) | (unsigned)j, j);
+    top4_insert(tt, ((unsigned)popc256(a0, a1, b0, b1) << 20) | (unsigned)j, j);
   }
-  top2_wave_merge(tt);
+  int od[2] = {256, 256}, oi[2] = {-1, -1};
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const unsigned m = wave_min(tt.k[0]);
+    if (m != 0xFFFFFFFFu) {
+      od[r] = (int)(m >> 20); oi[r] = (int)(m & 0xFFFFFu);
+      if (tt.k[0] == m) { tt.k[0] = tt.k[1]; tt.k[1] = tt.k[2]; tt.k[2] = tt.k[3]; tt.k[3] = 0xFFFFFFFFu; }
+    }
+  }
   if (lane == 0) {
-    out4[4 * qi] = tt.i1 >= 0 ? (int)(tt.k1 >> 20) : 256; out4[4 * qi + 1] = tt.i1;
-    out4[4 * qi + 2] = tt.i2 >= 0 ? (int)(tt.k2 >> 20) : 256; out4[4 * qi + 3] = tt.i2;
+    out4[4 * qi] = od[0]; out4[4 * qi + 1] = oi[0];
+    out4[4 * qi + 2] = od[1]; out4[4 * qi + 3] = oi[1];
   }
 }
 
@@ -602,9 +673,14 @@ struct orbm_frame {
   size_t stage_off = 0;
   const int* d_assigned_mp = nullptr;
   const int* d_assigned_obs = nullptr;
+  bool occ_mask = false;                 // occupancy travels in the kernel arguments (frames of <= kOccBits features)
+  uint32_t occ[kOccBits / 32];
+  size_t copy_lo = 0, copy_hi = 0;       // part of the staging block that needs a device copy
+  unsigned search_seq = 0;               // selects the overflow counter; the kernel clears the other one
   // query-side scratch
   DevBuf<int> d_counter;
-  PinnedBuf<uint32_t> list;
+  PinnedBuf<uint32_t> list;              // candidate lists: written by the kernels (one coalesced burst per query) into
+                                         // mapped pinned memory, read by the host only when a query's top-4 cannot decide
   PinnedBuf<QResult> results;
   float last_ms = 0;
 };
@@ -630,8 +706,12 @@ static int frame_reserve(orbm_frame* f, int n) {
   const size_t c = (size_t)std::max(n, 1);
   if ((rc = f->d_kps.reserve(c)) || (rc = f->d_desc.reserve(c * 32)) || (rc = f->d_uright.reserve(c)) ||
       (rc = f->d_depth.reserve(c)) || (rc = f->d_cell_of.reserve(c)) || (rc = f->d_cell_start.reserve(kCells + 1)) ||
-      (rc = f->d_cell_items.reserve(c)) || (rc = f->d_counter.reserve(4)))
+      (rc = f->d_cell_items.reserve(c)))
     return rc;
+  if (!f->d_counter.p) {                        // both overflow counters start at zero; from then on the kernels keep them so
+    if ((rc = f->d_counter.reserve(4))) return rc;
+    ORBG_HIP(hipMemset(f->d_counter.p, 0, f->d_counter.cap * sizeof(int)));
+  }
   return ORBG_OK;
 }
 
@@ -901,6 +981,8 @@ static FrameDev frame_dev(orbm_frame* f) {
   F.kps = f->kps_p; F.desc = f->desc_p; F.uright = f->has_uright ? f->uright_p : nullptr;
   F.cell_start = f->d_cell_start.p; F.cell_items = f->d_cell_items.p;
   F.assigned_mp = f->d_assigned_mp; F.assigned_obs = f->d_assigned_obs;
+  F.use_mask = f->occ_mask;
+  if (f->occ_mask) memcpy(F.occ, f->occ, sizeof(F.occ));
   return F;
 }
 
@@ -910,19 +992,41 @@ static int stage_begin(orbm_frame* f, size_t total_bytes) {
   const size_t need = total_bytes + 64 * 16;
   if ((rc = f->stage.reserve(need)) || (rc = f->d_stage.reserve(need))) return rc;
   f->stage_off = 0;
+  f->copy_lo = f->copy_hi = 0;
   return ORBG_OK;
 }
+// Packs a per-call input into the pinned staging block.  Inputs every query reads ONCE (descriptors, projections, flags)
+// are read by the kernel straight from that block (it is mapped into the device address space): no copy command at all.
+// Inputs that are re-read by many queries ask for a device copy (dev_copy): one H2D over their contiguous range.
 template <typename T>
-static const T* stage_add(orbm_frame* f, const T* src, size_t count) {
+static const T* stage_add(orbm_frame* f, const T* src, size_t count, bool dev_copy = false) {
   f->stage_off = (f->stage_off + 15) & ~(size_t)15;
   if (count) memcpy(f->stage.h + f->stage_off, src, count * sizeof(T));
-  const T* dev = reinterpret_cast<const T*>(f->d_stage.p + f->stage_off);
+  const T* dev = reinterpret_cast<const T*>((dev_copy ? f->d_stage.p : f->stage.d) + f->stage_off);
+  if (dev_copy && count) {
+    if (f->copy_hi == f->copy_lo) f->copy_lo = f->stage_off;
+    f->copy_hi = f->stage_off + count * sizeof(T);
+  }
   f->stage_off += count * sizeof(T);
   return dev;
 }
 static int stage_commit(orbm_frame* f) {
-  if (f->stage_off) ORBG_HIP(hipMemcpyAsync(f->d_stage.p, f->stage.h, f->stage_off, hipMemcpyHostToDevice, f->stream));
+  if (f->copy_hi > f->copy_lo)
+    ORBG_HIP(hipMemcpyAsync(f->d_stage.p + f->copy_lo, f->stage.h + f->copy_lo, f->copy_hi - f->copy_lo, hipMemcpyHostToDevice, f->stream));
   return ORBG_OK;
+}
+// F.mvpMapPoints occupancy at entry (S/ORBmatcher.cc:89-91 / :556): bitmask in the kernel arguments, or device arrays
+static void stage_occupancy(orbm_frame* f, const int32_t* amp, const int32_t* aob, int n) {
+  f->occ_mask = n <= kOccBits;
+  if (f->occ_mask) {
+    memset(f->occ, 0, sizeof(f->occ));
+    for (int i = 0; i < n; i++)
+      if (amp[i] >= 0 && (!aob || aob[i] > 0)) f->occ[i >> 5] |= 1u << (i & 31);
+    f->d_assigned_mp = nullptr; f->d_assigned_obs = nullptr;
+  } else {
+    f->d_assigned_mp = stage_add(f, amp, n, true);
+    f->d_assigned_obs = aob ? stage_add(f, aob, n, true) : nullptr;
+  }
 }
 
 // Launches `launch(list_cap)` until the candidate list fits; leaves results + list in pinned memory.
@@ -933,8 +1037,11 @@ static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
   const size_t slots = (size_t)n_queries * kSlot;
   if (f->list.cap < slots + (1 << 16) && (rc = f->list.reserve(slots + (1 << 18)))) return rc;
   for (int attempt = 0; attempt < 3; attempt++) {
-    ORBG_HIP(hipMemsetAsync(f->d_counter.p, 0, sizeof(int), f->stream));
-    launch((int)f->list.cap);
+    // two overflow counters take turns: every search kernel clears the one its successor will use
+    int* cur = f->d_counter.p + (f->search_seq & 1);
+    int* nxt = f->d_counter.p + ((f->search_seq + 1) & 1);
+    f->search_seq++;
+    launch((int)std::min<size_t>(f->list.cap, (size_t)1 << 30), cur, nxt);
     ORBG_HIP(hipGetLastError());
     ORBG_HIP(hipStreamSynchronize(f->stream));
     // the end of the furthest list segment tells whether the overflow region was large enough
@@ -947,30 +1054,51 @@ static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
   return ORBG_CAP_EXCEEDED;
 }
 
+// The two (or one) best candidates of query r that have not been claimed since the kernel ran, in the order the
+// reference's sequential scan would find them.  The kernel's top-4 decides whenever it can (it holds every candidate,
+// or enough unclaimed ones); otherwise the query's full list is re-scanned.
+struct Pick { int idx1 = -1, dist1 = 256, idx2 = -1, dist2 = 256; };
+template <typename ClaimedFn>
+static int pick_unclaimed(orbm_frame* f, const QResult& r, int want, ClaimedFn claimed, Pick* out) {
+  Pick p;
+  int found = 0;
+  for (int k = 0; k < r.n_top && found < want; k++) {
+    const int idx = r.idx[k];
+    if (claimed(idx)) continue;
+    if (found == 0) { p.idx1 = idx; p.dist1 = r.dist[k]; } else { p.idx2 = idx; p.dist2 = r.dist[k]; }
+    found++;
+  }
+  if (found < want && r.n_top == 4) {
+    p = Pick();
+    const uint32_t* list = f->list.h + r.base;
+    for (int k = 0; k < r.count; k++) {
+      const uint32_t e = list[k];
+      if (e == 0xFFFFFFFFu) continue;
+      const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
+      if (claimed(idx)) continue;
+      if (dist < p.dist1) { p.dist2 = p.dist1; p.idx2 = p.idx1; p.dist1 = dist; p.idx1 = idx; }
+      else if (dist < p.dist2) { p.dist2 = dist; p.idx2 = idx; }
+    }
+  }
+  *out = p;
+  return ORBG_OK;
+}
+
 // Serial commit of SearchByProjection(Frame, MapPoints): S/ORBmatcher.cc:85-141 replayed on the GPU results.
 static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio, int32_t* amp, int32_t* aob, int* nmatches_out) {
   const int n = f->fp.n;
   std::vector<uint8_t> claimed(std::max(n, 1), 0);   // features newly assigned in this call to an MP with Observations()>0
   int nmatches = 0;
   const QResult* R = f->results.h;
-  const uint32_t* list = f->list.h;
+  auto is_claimed = [&](int idx) { return claimed[idx] != 0; };
   for (int i = 0; i < m; i++) {
     const QResult& r = R[i];
-    if (r.count == 0 || r.best_idx < 0) continue;
-    int bestDist = r.best_dist, bestIdx = r.best_idx, bestDist2 = r.second_dist, idx2 = r.second_idx;
-    if (claimed[bestIdx] || (idx2 >= 0 && claimed[idx2])) {
-      // re-scan in the reference's order, skipping features claimed since the kernel ran
-      bestDist = 256; bestDist2 = 256; bestIdx = -1; idx2 = -1;
-      for (int k = 0; k < r.count; k++) {
-        const uint32_t e = list[r.base + k];
-        if (e == 0xFFFFFFFFu) continue;
-        const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
-        if (claimed[idx]) continue;
-        if (dist < bestDist) { bestDist2 = bestDist; idx2 = bestIdx; bestDist = dist; bestIdx = idx; }
-        else if (dist < bestDist2) { bestDist2 = dist; idx2 = idx; }
-      }
-      if (bestIdx < 0) continue;
-    }
+    if (r.n_top == 0) continue;
+    Pick pk;
+    int rc = pick_unclaimed(f, r, 2, is_claimed, &pk);   // features claimed since the kernel ran are skipped (:89-91)
+    if (rc) return rc;
+    if (pk.idx1 < 0) continue;
+    const int bestDist = pk.dist1, bestIdx = pk.idx1, bestDist2 = pk.dist2, idx2 = pk.idx2;
     const int bestLevel = f->hk[bestIdx].octave;
     const int bestLevel2 = idx2 >= 0 ? f->hk[idx2].octave : -1;
     if (bestDist <= TH_HIGH) {
@@ -999,8 +1127,7 @@ extern "C" int orbm_search_by_projection_mps(orbm_frame* f, const orbm_mappoints
   const int n = f->fp.n;
   if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 6 * 4)))) return rc;
   hipStream_t st = f->stream;
-  f->d_assigned_mp = stage_add(f, assigned_mp, n);
-  f->d_assigned_obs = stage_add(f, assigned_obs, n);
+  stage_occupancy(f, assigned_mp, assigned_obs, n);
   MpsDev mp;
   mp.m = m;
   mp.in_view = stage_add(f, mps->track_in_view, m); mp.bad = stage_add(f, mps->bad, m);
@@ -1009,19 +1136,12 @@ extern "C" int orbm_search_by_projection_mps(orbm_frame* f, const orbm_mappoints
   mp.depth = stage_add(f, mps->track_depth, m); mp.view_cos = stage_add(f, mps->view_cos, m);
   mp.level = stage_add(f, mps->scale_level, m);
   if ((rc = stage_commit(f))) return rc;
-  rc = run_search(f, m, [&](int list_cap) {
+  rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), mp, th, far_points,
-                       th_far_points, f->d_counter.p, f->list.d, list_cap, f->results.d);
+                       th_far_points, cnt, cnt_next, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
   return commit_mps(f, m, mps->n_obs, nnratio, assigned_mp, assigned_obs, nmatches);
-}
-
-__global__ __launch_bounds__(256) void mask_track_kernel(uint8_t* in_view, const uint8_t* bad, const uint8_t* skip_map,
-                                                        const uint8_t* skip_call, int m) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
-  if (bad[i] || skip_map[i] || (skip_call && skip_call[i])) in_view[i] = 0;
 }
 
 extern "C" int orbm_search_local_points(orbm_frame* f, orbm_map* mp, const float* Tcw, const uint8_t* skip, float th,
@@ -1036,20 +1156,15 @@ extern "C" int orbm_search_local_points(orbm_frame* f, orbm_map* mp, const float
   const int n = f->fp.n;
   if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m))) return rc;
   hipStream_t st = f->stream;
-  f->d_assigned_mp = stage_add(f, assigned_mp, n);
-  f->d_assigned_obs = stage_add(f, assigned_obs, n);
+  stage_occupancy(f, assigned_mp, assigned_obs, n);
   PoseF P;
   make_pose(Tcw, &P);
   const uint8_t* d_skip_call = skip ? stage_add(f, skip, m) : nullptr;
   if ((rc = stage_commit(f))) return rc;
-  hipLaunchKernelGGL(frustum_kernel, dim3((m + 255) / 256), dim3(256), 0, st, f->fp, P, map_dev(mp), 0.5f, map_track(mp));
-  hipLaunchKernelGGL(mask_track_kernel, dim3((m + 255) / 256), dim3(256), 0, st, mp->t_in_view.p, mp->bad.p, mp->skip.p, d_skip_call, m);
-  MpsDev q;
-  q.m = m; q.in_view = mp->t_in_view.p; q.bad = mp->bad.p; q.px = mp->t_px.p; q.py = mp->t_py.p; q.pxr = mp->t_pxr.p;
-  q.depth = mp->t_depth.p; q.level = mp->t_level.p; q.view_cos = mp->t_vc.p; q.desc = mp->desc.p;
-  rc = run_search(f, m, [&](int list_cap) {
-    hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), q, th, far_points,
-                       th_far_points, f->d_counter.p, f->list.d, list_cap, f->results.d);
+  const WorldPtsDev w = map_dev(mp);
+  rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
+    hipLaunchKernelGGL(search_local_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), w, d_skip_call, P, th, far_points,
+                       th_far_points, cnt, cnt_next, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
   return commit_mps(f, m, mp->n_obs.data(), nnratio, assigned_mp, assigned_obs, nmatches);
@@ -1067,8 +1182,7 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
   const int n = f->fp.n;
   if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 12 + 4)))) return rc;
   hipStream_t st = f->stream;
-  f->d_assigned_mp = stage_add(f, assigned_mp, n);
-  f->d_assigned_obs = stage_add(f, assigned_obs, n);
+  stage_occupancy(f, assigned_mp, assigned_obs, n);
   LastDev L;
   L.n = m;
   L.mp_valid = stage_add(f, last->mp_valid, m); L.outlier = stage_add(f, last->outlier, m);
@@ -1087,9 +1201,9 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
   }
   const int forward = tlc[2] > f->fp.b && !mono;
   const int backward = -tlc[2] > f->fp.b && !mono;
-  rc = run_search(f, m, [&](int list_cap) {
+  rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_frame_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), L, Pc, th, forward, backward,
-                       f->d_counter.p, f->list.d, list_cap, f->results.d);
+                       cnt, cnt_next, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
   // serial commit (S/ORBmatcher.cc:2041-2091) + rotation consistency (:2164-2183)
@@ -1097,22 +1211,14 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
   std::vector<int> rotHist[HISTO_LENGTH];
   int nmatches = 0;
   const QResult* R = f->results.h;
-  const uint32_t* list = f->list.h;
+  auto is_claimed = [&](int idx) { return claimed[idx] != 0; };
   for (int i = 0; i < m; i++) {
     const QResult& r = R[i];
-    if (r.count == 0 || r.best_idx < 0) continue;
-    int bestDist = r.best_dist, bestIdx = r.best_idx;
-    if (claimed[bestIdx]) {
-      bestDist = 256; bestIdx = -1;
-      for (int k = 0; k < r.count; k++) {
-        const uint32_t e = list[r.base + k];
-        if (e == 0xFFFFFFFFu) continue;
-        const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
-        if (claimed[idx]) continue;
-        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
-      }
-      if (bestIdx < 0) continue;
-    }
+    if (r.n_top == 0) continue;
+    Pick pk;
+    if ((rc = pick_unclaimed(f, r, 1, is_claimed, &pk))) return rc;
+    if (pk.idx1 < 0) continue;
+    const int bestDist = pk.dist1, bestIdx = pk.idx1;
     if (bestDist <= TH_HIGH) {
       assigned_mp[bestIdx] = i;
       assigned_obs[bestIdx] = last->n_obs[i];
@@ -1170,38 +1276,28 @@ static int bow_common(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t
     if ((int)fvF->feat_idx[i] >= n) return ORBG_BAD_ARG;
   if ((rc = stage_begin(f, (size_t)nj * sizeof(BowJob) + (size_t)nfi * 4 + (size_t)nkf * 32 + (size_t)n))) return rc;
   hipStream_t st = f->stream;
+  const uint32_t* d_fidx = stage_add(f, fvF->feat_idx, nfi, true);
+  const uint8_t* d_tvalid = t_valid ? stage_add(f, t_valid, n, true) : nullptr;
   const BowJob* d_jobs = stage_add(f, jobs.data(), nj);
-  const uint32_t* d_fidx = stage_add(f, fvF->feat_idx, nfi);
   const uint8_t* d_kfdesc = stage_add(f, kf_desc, (size_t)nkf * 32);
-  const uint8_t* d_tvalid = t_valid ? stage_add(f, t_valid, n) : nullptr;
   if ((rc = stage_commit(f))) return rc;
-  rc = run_search(f, nj, [&](int list_cap) {
+  rc = run_search(f, nj, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_bow_kernel, dim3((nj + 3) / 4), dim3(256), 0, st, f->desc_p, d_fidx, d_tvalid, d_kfdesc,
-                       d_jobs, nj, f->d_counter.p, f->list.d, list_cap, f->results.d);
+                       d_jobs, nj, cnt, cnt_next, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
   std::vector<int> rotHist[HISTO_LENGTH];
   std::vector<uint8_t> taken(std::max(n, 1), 0);          // vpMapPointMatches[idx] != NULL (:324) / vbMatched2[idx] (:872)
   int nmatches = 0;
   const QResult* R = f->results.h;
-  const uint32_t* list = f->list.h;
+  auto is_taken = [&](int idx) { return taken[idx] != 0; };
   for (int j = 0; j < nj; j++) {
     const QResult& r = R[j];
-    if (r.best_idx < 0) continue;
-    int bestDist1 = r.best_dist, bestIdxF = r.best_idx, bestDist2 = r.second_dist;
-    const bool dirty = taken[bestIdxF] || (r.second_idx >= 0 && taken[r.second_idx]);
-    if (dirty) {
-      bestDist1 = 256; bestDist2 = 256; bestIdxF = -1;
-      for (int k = 0; k < r.count; k++) {
-        const uint32_t e = list[r.base + k];
-        if (e == 0xFFFFFFFFu) continue;
-        const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
-        if (taken[idx]) continue;
-        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = idx; }
-        else if (dist < bestDist2) bestDist2 = dist;
-      }
-      if (bestIdxF < 0) continue;
-    }
+    if (r.n_top == 0) continue;
+    Pick pk;
+    if ((rc = pick_unclaimed(f, r, 2, is_taken, &pk))) return rc;
+    if (pk.idx1 < 0) continue;
+    const int bestDist1 = pk.dist1, bestIdxF = pk.idx1, bestDist2 = pk.dist2;
     const bool low = by_query ? (bestDist1 < TH_LOW) : (bestDist1 <= TH_LOW);      // :898 vs :373
     if (low) {
       if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
@@ -1257,8 +1353,7 @@ extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const
   const int n = f->fp.n;
   if ((rc = stage_begin(f, (size_t)n * 4 + (size_t)m))) return rc;
   hipStream_t st = f->stream;
-  f->d_assigned_mp = stage_add(f, matched, n);
-  f->d_assigned_obs = nullptr;
+  stage_occupancy(f, matched, nullptr, n);
   const uint8_t* d_found = already_found ? stage_add(f, already_found, m) : nullptr;
   if ((rc = stage_commit(f))) return rc;
   float T16[16];
@@ -1277,31 +1372,23 @@ extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const
   make_pose(T16, &P);
   FrameDev F = frame_dev(f);
   F.uright = nullptr;                                          // no stereo gate in the KeyFrame searches
-  rc = run_search(f, m, [&](int list_cap) {
+  rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_sim3_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P,
-                       camera_project, th, f->d_counter.p, f->list.d, list_cap, f->results.d);
+                       camera_project, th, cnt, cnt_next, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
   std::vector<uint8_t> claimed(std::max(n, 1), 0);
   int nmatches = 0;
   const QResult* R = f->results.h;
-  const uint32_t* list = f->list.h;
   const float low = TH_LOW * ratio_hamming;
+  auto is_claimed = [&](int idx) { return claimed[idx] != 0; };
   for (int i = 0; i < m; i++) {
     const QResult& r = R[i];
-    if (r.count == 0 || r.best_idx < 0) continue;
-    int bestDist = r.best_dist, bestIdx = r.best_idx;
-    if (claimed[bestIdx]) {
-      bestDist = 256; bestIdx = -1;
-      for (int k = 0; k < r.count; k++) {
-        const uint32_t e = list[r.base + k];
-        if (e == 0xFFFFFFFFu) continue;
-        const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
-        if (claimed[idx]) continue;
-        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
-      }
-      if (bestIdx < 0) continue;
-    }
+    if (r.n_top == 0) continue;
+    Pick pk;
+    if ((rc = pick_unclaimed(f, r, 1, is_claimed, &pk))) return rc;
+    if (pk.idx1 < 0) continue;
+    const int bestDist = pk.dist1, bestIdx = pk.idx1;
     if (bestDist <= low) {
       matched[bestIdx] = i;
       claimed[bestIdx] = 1;

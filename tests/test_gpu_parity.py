@@ -388,3 +388,21 @@ def test_pose_optimization_parity(n, of, mono):
     assert np.allclose(g.chi2, o.chi2, rtol=1e-8, atol=1e-9)
     g2 = api.Optimizer().PoseOptimization(p)
     assert np.array_equal(g.Tcw, g2.Tcw)
+
+
+def test_lba_async_matches_blocking_call():
+    """lba_solve_async / lba_wait (the library's LocalMapping thread) give the blocking call's result bit for bit."""
+    prob = synth.make_lba_problem(n_free=6, n_fixed=3, n_points=300)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    opt = api.Optimizer()
+    ref = opt.LocalBundleAdjustment(p)
+    out = views.LbaOutput(p.n_poses, p.n_points, p.n_edges)
+    for _ in range(3):                                       # the worker is reused across submissions
+        opt.LocalBundleAdjustmentAsync(p, out)
+        with pytest.raises(capi.OrbGpuError):
+            opt.LocalBundleAdjustmentAsync(p, out)           # one solve in flight per handle
+        got = opt.wait()
+        assert got is out and out.status == capi.LBA_APPLIED and opt.last_solve_ms > 0
+        assert np.array_equal(out.poses, ref.poses) and np.array_equal(out.points, ref.points)
+        assert np.array_equal(out.edge_outlier, ref.edge_outlier) and out.iters == ref.iters
+    assert opt.wait() is None                                # nothing in flight
