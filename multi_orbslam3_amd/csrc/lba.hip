@@ -169,6 +169,21 @@ struct Huber { double delta_mono, dsqr_mono, delta_stereo, dsqr_stereo; };
 // ---------------------------------------------------------------------------------------------- kernels
 
 // residuals + chi2 + robust rho (computeActiveErrors + activeRobustChi2); block partial sums in fixed order
+// per edge: bit 0 = isDepthPositive() with the current estimate, bit 1 = outlier (chi2 > 5.991 / 7.815 or depth <= 0)
+__global__ __launch_bounds__(256) void k_edge_flags(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+                                                   const double* __restrict__ points, const double* __restrict__ chi2,
+                                                   uint8_t* __restrict__ flags) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_edges) return;
+  const lba_edge e = edges[k];
+  double rr[3];
+  quat_rotate(poses[e.pose].q, points + 3 * (size_t)e.point, rr);
+  const bool depth_pos = rr[2] + poses[e.pose].t[2] > 0.0;
+  const double thr = e.ur < 0 ? 5.991 : 7.815;
+  const bool outlier = chi2[k] > thr || !depth_pos;
+  flags[k] = (uint8_t)((depth_pos ? 1 : 0) | (outlier ? 2 : 0));
+}
+
 __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                const double* __restrict__ points, Cam cam, Huber hb, double* __restrict__ err,
                                                double* __restrict__ chi2, double* __restrict__ partial) {
@@ -700,11 +715,19 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
     const int u = t + s * NT;
     ubi[s] = -1; ubk[s] = -1; upr[s] = 0; ublk[s] = 0;
     if (u < units) {
-      const int blk = u / 3;
-      int bi = (int)((sqrtf(8.f * (float)blk + 1.f) - 1.f) * 0.5f);
-      while ((bi + 1) * (bi + 2) / 2 <= blk) bi++;
-      while (bi * (bi + 1) / 2 > blk) bi--;
-      ubi[s] = bi; ubk[s] = blk - bi * (bi + 1) / 2; upr[s] = u - 3 * blk; ublk[s] = blk;
+      // Units are numbered COLUMN-major over the lower block triangle: the 3(nb-j) units of block column j are
+      // consecutive threads, so the diagonal factorisation + panel of a column occupies one or two wavefronts instead of
+      // a few lanes of every wavefront (the phase is issue bound: ~350 FP64 instructions per wavefront that enters it).
+      const int cb = u / 3;                                  // column-major block number
+      // column k starts at C(k) = k*nb - k(k-1)/2; invert with a float guess + fix-up
+      const float fnb = (float)nb + 0.5f;
+      int bk = (int)(fnb - sqrtf(fmaxf(fnb * fnb - 2.f * (float)cb, 0.f)));
+      if (bk < 0) bk = 0;
+      if (bk > nb - 1) bk = nb - 1;
+      while (bk > 0 && bk * nb - bk * (bk - 1) / 2 > cb) bk--;
+      while (bk + 1 < nb && (bk + 1) * nb - (bk + 1) * bk / 2 <= cb) bk++;
+      const int bi = bk + (cb - (bk * nb - bk * (bk - 1) / 2));
+      ubi[s] = bi; ubk[s] = bk; upr[s] = u - 3 * cb; ublk[s] = bi * (bi + 1) / 2 + bk;   // storage stays row-major
 #pragma unroll
       for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -726,34 +749,48 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
 #pragma unroll
     for (int s = 0; s < R; s++) in_col |= (ubk[s] == j);
     if (in_col) {
-      // redundant in-register LDL^T of the diagonal block
-      double L[36], dinv[6], y[6];
+      // Redundant in-register LDL^T of the diagonal block, arranged for DEPTH: right-looking updates (all independent
+      // inside a pivot step), then the explicit inverse X = L_jj^-1 of the unit-triangular factor, so that the panel rows
+      // and the rhs become plain dot products instead of dependent forward substitutions.  The chain per block column
+      // is ~6 x (reciprocal + 3) + ~10 operations instead of ~250.
+      double A[6][6], dinv[6], y[6];
 #pragma unroll
-      for (int q = 0; q < 36; q++) L[q] = Ajj[q];
+      for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int c = 0; c <= q; c++) A[q][c] = Ajj[6 * q + c];
       bool good = true;
 #pragma unroll
       for (int c = 0; c < 6; c++) {
-        double d = L[7 * c];
-#pragma unroll
-        for (int m = 0; m < c; m++) d -= L[6 * c + m] * L[6 * c + m] * L[7 * m];
+        const double d = A[c][c];
         if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
-        L[7 * c] = d;
         const double id = fast_rcp(d);
         dinv[c] = id;
+        double W[6];
 #pragma unroll
-        for (int q = c + 1; q < 6; q++) {
-          double v = L[6 * q + c];
+        for (int q = c + 1; q < 6; q++) { W[q] = A[q][c]; A[q][c] = W[q] * id; }       // A[q][c] now holds L[q][c]
 #pragma unroll
-          for (int m = 0; m < c; m++) v -= L[6 * q + m] * L[6 * c + m] * L[7 * m];
-          L[6 * q + c] = v * id;
-        }
+        for (int q = c + 1; q < 6; q++)
+#pragma unroll
+          for (int r = c + 1; r <= q; r++) A[q][r] -= A[q][c] * W[r];
       }
       if (!good) s_ok = 0;
+      // X = L^-1 (unit lower triangular), column by column; the six columns are independent chains
+      double X[6][6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+#pragma unroll
+        for (int q = c + 1; q < 6; q++) {
+          double v = -A[q][c];
+#pragma unroll
+          for (int m = c + 1; m < q; m++) v -= A[q][m] * X[m][c];
+          X[q][c] = v;
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         double v = rr_[6 * j + c];
 #pragma unroll
-        for (int m = 0; m < c; m++) v -= L[6 * c + m] * y[m];
+        for (int m = 0; m < c; m++) v += X[c][m] * rr_[6 * j + m];
         y[c] = v;
       }
 #pragma unroll
@@ -763,12 +800,13 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
         double* Lg = Lall + (size_t)ublk[s] * 36;
         if (ubi[s] == j) {
 #pragma unroll
-          for (int pr = 0; pr < 3; pr++)          // compile-time row indices: L stays in registers
+          for (int pr = 0; pr < 3; pr++)          // compile-time row indices: the factor stays in registers
             if (upr[s] == pr) {
 #pragma unroll
               for (int q = 0; q < 2; q++)
 #pragma unroll
-                for (int c = 0; c < 6; c++) Lg[6 * (2 * pr + q) + c] = L[6 * (2 * pr + q) + c];
+                for (int c = 0; c < 6; c++)   // lower: L_jj; strict upper: (L_jj^-1)^T for the backward pass
+                  Lg[6 * (2 * pr + q) + c] = c < 2 * pr + q ? A[2 * pr + q][c] : (c > 2 * pr + q ? X[c][2 * pr + q] : 1.0);
             }
           if (upr[s] == 0) {
 #pragma unroll
@@ -779,14 +817,12 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
           double* Wp = Lp + 37;
 #pragma unroll
           for (int q = 0; q < 2; q++) {
-            double w[6];
             double racc = 0;
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-              double v = a[s][6 * q + c];
+              double v = a[s][6 * q + c];                    // w = a L^-T : w[c] = a[c] + sum_{m<c} a[m] X[c][m]
 #pragma unroll
-              for (int m = 0; m < c; m++) v -= w[m] * L[6 * c + m];
-              w[c] = v;
+              for (int m = 0; m < c; m++) v += a[s][6 * q + m] * X[c][m];
               const double l = v * dinv[c];
               Wp[6 * (row0 + q) + c] = v;
               Lp[6 * (row0 + q) + c] = l;
@@ -827,40 +863,35 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
   }
   __syncthreads();
   const int ok = s_ok;
-  if (ok) {
-    // backward on whole blocks (pair-0 owners), L read back from Lall: x_i = L_ii^-T z_i ; z_k -= L_ik^T x_i
+  if (ok && t < 64) {
+    // Backward substitution by ONE wavefront, no workgroup barriers: x_i = L_ii^-T z_i as six dot products with the stored
+    // inverse, then z_k -= L_ik^T x_i for all k < i spread over the lanes (lane -> (k, c)); LDS accesses of a wavefront
+    // are ordered, so the steps chain without synchronisation.
     for (int i = nb - 1; i >= 0; i--) {
+      const double* Lii = Lall + (size_t)(i * (i + 1) / 2 + i) * 36;
+      double zi[6], xv[6];
 #pragma unroll
-      for (int s = 0; s < R; s++) {
-        if (ubi[s] == i && ubk[s] == i && upr[s] == 0) {
-          const double* Lg = Lall + (size_t)ublk[s] * 36;
-          double xv[6];
+      for (int c = 0; c < 6; c++) zi[c] = zz[6 * i + c];
 #pragma unroll
-          for (int c = 5; c >= 0; c--) {
-            double v = zz[6 * i + c];
+      for (int c = 0; c < 6; c++) {
+        double v = zi[c];
 #pragma unroll
-            for (int m = c + 1; m < 6; m++) v -= Lg[6 * m + c] * xv[m];
-            xv[c] = v;
-          }
-#pragma unroll
-          for (int c = 0; c < 6; c++) { xs[c] = xv[c]; x[6 * i + c] = xv[c]; }
-        }
+        for (int q = c + 1; q < 6; q++) v += Lii[6 * c + q] * zi[q];
+        xv[c] = v;
       }
-      __syncthreads();
+      if (t < 6) {
 #pragma unroll
-      for (int s = 0; s < R; s++) {
-        if (ubi[s] == i && ubk[s] < i && upr[s] == 0) {
-          const double* Lg = Lall + (size_t)ublk[s] * 36;
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            double acc = 0;
-#pragma unroll
-            for (int q = 0; q < 6; q++) acc += Lg[6 * q + c] * xs[q];
-            zz[6 * ubk[s] + c] -= acc;
-          }
-        }
+        for (int c = 0; c < 6; c++) if (t == c) x[6 * i + c] = xv[c];
       }
-      __syncthreads();
+      for (int o = t; o < 6 * i; o += 64) {
+        const int k = o / 6, c = o - 6 * k;
+        const double* Lik = Lall + (size_t)(i * (i + 1) / 2 + k) * 36;
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc += Lik[6 * q + c] * xv[q];
+        zz[o] -= acc;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (t == 0) *ok_flag = ok;
@@ -973,6 +1004,10 @@ struct lba_handle {
   DevBuf<int> d_pair_i1, d_pair_i2, d_pair_start, d_ok;
   DevBuf<PairItem> d_items;
   PinnedBuf<HostRec> rec;
+  PinnedBuf<uint8_t> up_h, dl_h;               // per-call upload block (built in place) / download block
+  DevBuf<uint8_t> up_d;
+  DevBuf<uint8_t> d_flags;
+  std::vector<int> s_pose_deg, s_point_deg, s_pose_col, s_point_col, s_pf_deg, s_f1, s_f2, s_f3, s_fill;   // host scratch kept across calls
   float last_ms = 0;
   // lba_solve_async: the library-owned "LocalMapping" thread of this handle
   std::thread worker;
@@ -1011,7 +1046,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release();
   h->d_pose_col.release(); h->d_point_col.release(); h->d_pt_start.release(); h->d_pt_edges.release(); h->d_ps_start.release();
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
-  h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release();
+  h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ORBG_OK;
@@ -1048,58 +1083,99 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     return ORBG_OK;
   }
   hipStream_t st = h->stream;
-  // ---- structure (the analogue of BlockSolver::buildStructure, G/core/block_solver.hpp:143-295), host side
-  std::vector<int> pose_deg(NP, 0), point_deg(NX, 0);
+  // ---- structure (the analogue of BlockSolver::buildStructure, G/core/block_solver.hpp:143-295), host side.
+  // Every array the kernels need is built IN PLACE inside one pinned block and goes to the device with ONE copy.
+  std::vector<int>& pose_deg = h->s_pose_deg; std::vector<int>& point_deg = h->s_point_deg;
+  pose_deg.assign(NP, 0); point_deg.assign(NX, 0);
   for (int k = 0; k < NE; k++) { pose_deg[p->edges[k].pose]++; point_deg[p->edges[k].point]++; }
-  std::vector<int> pose_col(NP, -1), point_col(NX, -1);
+  std::vector<int>& pose_col_v = h->s_pose_col; std::vector<int>& point_col_v = h->s_point_col;
+  pose_col_v.assign(NP, -1); point_col_v.assign(NX, -1);
   int nP = 0, nL = 0;
-  for (int i = 0; i < NP; i++) if (!p->pose_fixed[i] && pose_deg[i] > 0) pose_col[i] = nP++;
-  for (int i = 0; i < NX; i++) if (point_deg[i] > 0) point_col[i] = nL++;
+  for (int i = 0; i < NP; i++) if (!p->pose_fixed[i] && pose_deg[i] > 0) pose_col_v[i] = nP++;
+  for (int i = 0; i < NX; i++) if (point_deg[i] > 0) point_col_v[i] = nL++;
+  // free-pose degree of every active point -> number of (pose pair, landmark) items
+  std::vector<int>& pf_deg = h->s_pf_deg;
+  pf_deg.assign(nL + 1, 0);
+  int n_free_edges = 0;
+  for (int k = 0; k < NE; k++)
+    if (pose_col_v[p->edges[k].pose] >= 0) { pf_deg[point_col_v[p->edges[k].point]]++; n_free_edges++; }
+  size_t n_items = 0;
+  for (int l = 0; l < nL; l++) n_items += (size_t)pf_deg[l] * (pf_deg[l] + 1) / 2;
+  const int n_pairs_all = nP * (nP + 1) / 2;
+  // arena layout
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 63) & ~(size_t)63; return o; };
+  const size_t o_edges = take(sizeof(lba_edge) * (size_t)NE), o_poses = take(sizeof(PoseQ) * (size_t)NP), o_points = take(24 * (size_t)NX);
+  const size_t o_pose_col = take(4 * (size_t)NP), o_point_col = take(4 * (size_t)NX), o_pt_start = take(4 * ((size_t)nL + 1));
+  const size_t o_pt_edges = take(4 * (size_t)NE), o_ps_start = take(4 * ((size_t)nP + 1)), o_ps_edges = take(4 * (size_t)n_free_edges);
+  const size_t o_pf_start = take(4 * ((size_t)nL + 1)), o_pf_edges = take(4 * (size_t)n_free_edges), o_pf_col = take(4 * (size_t)n_free_edges);
+  const size_t o_pair_i1 = take(4 * (size_t)n_pairs_all), o_pair_i2 = take(4 * (size_t)n_pairs_all), o_pair_start = take(4 * ((size_t)n_pairs_all + 1));
+  const size_t o_items = take(sizeof(PairItem) * n_items);
+  if ((rc = h->up_h.reserve(off + 64)) || (rc = h->up_d.reserve(off + 64))) return rc;
+  uint8_t* H = h->up_h.h;
+  lba_edge* edges = reinterpret_cast<lba_edge*>(H + o_edges);
+  PoseQ* poses = reinterpret_cast<PoseQ*>(H + o_poses);
+  double* points = reinterpret_cast<double*>(H + o_points);
+  int* pose_col = reinterpret_cast<int*>(H + o_pose_col); int* point_col = reinterpret_cast<int*>(H + o_point_col);
+  int* pt_start = reinterpret_cast<int*>(H + o_pt_start); int* pt_edges = reinterpret_cast<int*>(H + o_pt_edges);
+  int* ps_start = reinterpret_cast<int*>(H + o_ps_start); int* ps_edges = reinterpret_cast<int*>(H + o_ps_edges);
+  int* pf_start = reinterpret_cast<int*>(H + o_pf_start); int* pf_edges = reinterpret_cast<int*>(H + o_pf_edges);
+  int* pf_col = reinterpret_cast<int*>(H + o_pf_col);
+  int* pair_i1 = reinterpret_cast<int*>(H + o_pair_i1); int* pair_i2 = reinterpret_cast<int*>(H + o_pair_i2);
+  int* pair_start = reinterpret_cast<int*>(H + o_pair_start);
+  PairItem* items = reinterpret_cast<PairItem*>(H + o_items);
+  memcpy(edges, p->edges, sizeof(lba_edge) * (size_t)NE);
+  memcpy(pose_col, pose_col_v.data(), 4 * (size_t)NP);
+  memcpy(point_col, point_col_v.data(), 4 * (size_t)NX);
   // CSR: edges per active point (creation order); per free pose; per active point restricted to free poses (sorted by col)
-  std::vector<int> pt_start(nL + 1, 0), ps_start(nP + 1, 0), pf_start(nL + 1, 0);
+  for (int i = 0; i <= nL; i++) pt_start[i] = 0;
+  for (int i = 0; i <= nP; i++) ps_start[i] = 0;
   for (int k = 0; k < NE; k++) {
     const int lc = point_col[p->edges[k].point], pc = pose_col[p->edges[k].pose];
     pt_start[lc + 1]++;
-    if (pc >= 0) { ps_start[pc + 1]++; pf_start[lc + 1]++; }
+    if (pc >= 0) ps_start[pc + 1]++;
   }
-  for (int i = 0; i < nL; i++) { pt_start[i + 1] += pt_start[i]; pf_start[i + 1] += pf_start[i]; }
+  pf_start[0] = 0;
+  for (int i = 0; i < nL; i++) { pt_start[i + 1] += pt_start[i]; pf_start[i + 1] = pf_start[i] + pf_deg[i]; }
   for (int i = 0; i < nP; i++) ps_start[i + 1] += ps_start[i];
-  std::vector<int> pt_edges(pt_start[nL]), ps_edges(ps_start[nP]), pf_edges(pf_start[nL]), pf_col(pf_start[nL]);
   {
-    std::vector<int> f1(pt_start.begin(), pt_start.end() - 1), f2(ps_start.begin(), ps_start.end() - 1), f3(pf_start.begin(), pf_start.end() - 1);
+    std::vector<int>& f1 = h->s_f1; std::vector<int>& f2 = h->s_f2; std::vector<int>& f3 = h->s_f3;
+    f1.assign(pt_start, pt_start + nL); f2.assign(ps_start, ps_start + nP); f3.assign(pf_start, pf_start + nL);
     for (int k = 0; k < NE; k++) {
       const int lc = point_col[p->edges[k].point], pc = pose_col[p->edges[k].pose];
       pt_edges[f1[lc]++] = k;
       if (pc >= 0) { ps_edges[f2[pc]++] = k; pf_edges[f3[lc]++] = k; }
     }
     for (int l = 0; l < nL; l++) {
-      std::stable_sort(pf_edges.begin() + pf_start[l], pf_edges.begin() + pf_start[l + 1],
-                       [&](int a, int b) { return pose_col[p->edges[a].pose] < pose_col[p->edges[b].pose]; });
+      // stable insertion sort by pose column (a handful of observations per landmark)
+      for (int a2 = pf_start[l] + 1; a2 < pf_start[l + 1]; a2++) {
+        const int e = pf_edges[a2], key = pose_col[p->edges[e].pose];
+        int b2 = a2 - 1;
+        while (b2 >= pf_start[l] && pose_col[p->edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
+        pf_edges[b2 + 1] = e;
+      }
       for (int j = pf_start[l]; j < pf_start[l + 1]; j++) pf_col[j] = pose_col[p->edges[pf_edges[j]].pose];
     }
   }
   // pose pairs (i1 <= i2) and their landmark items, grouped by pair (counting sort keeps landmark order)
-  const int n_pairs_all = nP * (nP + 1) / 2;
   auto pair_id = [&](int i1, int i2) { return i1 * nP - i1 * (i1 - 1) / 2 + (i2 - i1); };
-  std::vector<int> pair_cnt(n_pairs_all + 1, 0);
+  for (int i = 0; i <= n_pairs_all; i++) pair_start[i] = 0;
   for (int l = 0; l < nL; l++)
-    for (int a = pf_start[l]; a < pf_start[l + 1]; a++)
-      for (int b = a; b < pf_start[l + 1]; b++) pair_cnt[pair_id(pf_col[a], pf_col[b]) + 1]++;
-  for (int i = 0; i < n_pairs_all; i++) pair_cnt[i + 1] += pair_cnt[i];
-  std::vector<PairItem> items(pair_cnt[n_pairs_all]);
+    for (int a2 = pf_start[l]; a2 < pf_start[l + 1]; a2++)
+      for (int b2 = a2; b2 < pf_start[l + 1]; b2++) pair_start[pair_id(pf_col[a2], pf_col[b2]) + 1]++;
+  for (int i = 0; i < n_pairs_all; i++) pair_start[i + 1] += pair_start[i];
   {
-    std::vector<int> fill(pair_cnt.begin(), pair_cnt.end() - 1);
+    std::vector<int>& fill = h->s_fill;
+    fill.assign(pair_start, pair_start + n_pairs_all);
     for (int l = 0; l < nL; l++)
-      for (int a = pf_start[l]; a < pf_start[l + 1]; a++)
-        for (int b = a; b < pf_start[l + 1]; b++) items[fill[pair_id(pf_col[a], pf_col[b])]++] = PairItem{pf_edges[a], pf_edges[b], l};
+      for (int a2 = pf_start[l]; a2 < pf_start[l + 1]; a2++)
+        for (int b2 = a2; b2 < pf_start[l + 1]; b2++) items[fill[pair_id(pf_col[a2], pf_col[b2])]++] = PairItem{pf_edges[a2], pf_edges[b2], l};
   }
   // keep every pair (diagonals always; off-diagonals even if empty so that S is fully written)
-  std::vector<int> pair_i1(n_pairs_all), pair_i2(n_pairs_all), pair_start(pair_cnt);
   for (int i1 = 0; i1 < nP; i1++)
     for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
 
   // ---- initial state: Converter::toSE3Quat (S/Converter.cc:33-43)
-  std::vector<PoseQ> poses(NP);
   for (int i = 0; i < NP; i++) {
     const float* T = p->poses + 16 * (size_t)i;
     const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
@@ -1107,19 +1183,32 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     quat_normalize(poses[i].q);
     poses[i].t[0] = T[3]; poses[i].t[1] = T[7]; poses[i].t[2] = T[11];
   }
-  std::vector<double> points(3 * (size_t)NX);
-  for (size_t i = 0; i < points.size(); i++) points[i] = p->points[i];
-  std::vector<lba_edge> edges(p->edges, p->edges + NE);
+  for (size_t i = 0; i < 3 * (size_t)NX; i++) points[i] = p->points[i];
 
   const int n = 6 * nP;
   const int n_blocks_e = (NE + 255) / 256;
-  if ((rc = upload(h->d_edges, edges, st)) || (rc = upload(h->d_poses[0], poses, st)) || (rc = upload(h->d_points[0], points, st)) ||
-      (rc = upload(h->d_pose_col, pose_col, st)) || (rc = upload(h->d_point_col, point_col, st)) || (rc = upload(h->d_pt_start, pt_start, st)) ||
-      (rc = upload(h->d_pt_edges, pt_edges, st)) || (rc = upload(h->d_ps_start, ps_start, st)) || (rc = upload(h->d_ps_edges, ps_edges, st)) ||
-      (rc = upload(h->d_pf_start, pf_start, st)) || (rc = upload(h->d_pf_edges, pf_edges, st)) || (rc = upload(h->d_pf_col, pf_col, st)) ||
-      (rc = upload(h->d_pair_i1, pair_i1, st)) || (rc = upload(h->d_pair_i2, pair_i2, st)) || (rc = upload(h->d_pair_start, pair_start, st)) ||
-      (rc = upload(h->d_items, items, st)))
-    return rc;
+  if (off) ORBG_HIP(hipMemcpyAsync(h->up_d.p, H, off, hipMemcpyHostToDevice, st));
+  struct {
+    const lba_edge* edges; const int *pose_col, *point_col, *pt_start, *pt_edges, *ps_start, *ps_edges, *pf_start, *pf_edges, *pf_col,
+        *pair_i1, *pair_i2, *pair_start;
+    const PairItem* items;
+  } D;
+  {
+    const uint8_t* B = h->up_d.p;
+    D.edges = reinterpret_cast<const lba_edge*>(B + o_edges);
+    D.pose_col = reinterpret_cast<const int*>(B + o_pose_col); D.point_col = reinterpret_cast<const int*>(B + o_point_col);
+    D.pt_start = reinterpret_cast<const int*>(B + o_pt_start); D.pt_edges = reinterpret_cast<const int*>(B + o_pt_edges);
+    D.ps_start = reinterpret_cast<const int*>(B + o_ps_start); D.ps_edges = reinterpret_cast<const int*>(B + o_ps_edges);
+    D.pf_start = reinterpret_cast<const int*>(B + o_pf_start); D.pf_edges = reinterpret_cast<const int*>(B + o_pf_edges);
+    D.pf_col = reinterpret_cast<const int*>(B + o_pf_col);
+    D.pair_i1 = reinterpret_cast<const int*>(B + o_pair_i1); D.pair_i2 = reinterpret_cast<const int*>(B + o_pair_i2);
+    D.pair_start = reinterpret_cast<const int*>(B + o_pair_start);
+    D.items = reinterpret_cast<const PairItem*>(B + o_items);
+  }
+  // the two state buffers (current / trial estimate) are separate allocations: buffer 0 starts as a copy of the upload
+  if ((rc = h->d_poses[0].reserve(std::max(NP, 1))) || (rc = h->d_points[0].reserve(std::max<size_t>(3 * (size_t)NX, 1)))) return rc;
+  if (NP > 0) ORBG_HIP(hipMemcpyAsync(h->d_poses[0].p, h->up_d.p + o_poses, sizeof(PoseQ) * (size_t)NP, hipMemcpyDeviceToDevice, st));
+  if (NX > 0) ORBG_HIP(hipMemcpyAsync(h->d_points[0].p, h->up_d.p + o_points, 24 * (size_t)NX, hipMemcpyDeviceToDevice, st));
   if ((rc = h->d_poses[1].reserve(std::max(NP, 1))) || (rc = h->d_points[1].reserve(std::max<size_t>(3 * (size_t)NX, 1))) ||
       (rc = h->d_err.reserve(std::max<size_t>(3 * (size_t)NE, 1))) || (rc = h->d_chi2.reserve(std::max(NE, 1))) ||
       (rc = h->d_partial.reserve(std::max(n_blocks_e, 1))) || (rc = h->d_EB.reserve(std::max<size_t>((size_t)NE * kEB, 1))) ||
@@ -1170,7 +1259,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int cur = 0;   // index of the buffer holding the current estimate
   auto launch_errors = [&](int buf) {
     if (NE > 0)
-      hipLaunchKernelGGL(k_errors, dim3(n_blocks_e), dim3(256), 0, st, NE, h->d_edges.p, h->d_poses[buf].p, h->d_points[buf].p, cam, hb,
+      hipLaunchKernelGGL(k_errors, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, h->d_poses[buf].p, h->d_points[buf].p, cam, hb,
                          h->d_err.p, h->d_chi2.p, h->d_partial.p);
   };
   auto finish = [&](double lambda, int want_scale, int want_maxdiag, bool with_ok) -> int {
@@ -1194,13 +1283,13 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       // recomputing them would reproduce the same bits) + buildSystem
       if (!err_valid) { launch_errors(cur); err_valid = true; }
       if (NE > 0)
-        hipLaunchKernelGGL(k_linearize, dim3(n_blocks_e), dim3(256), 0, st, NE, h->d_edges.p, h->d_poses[cur].p, h->d_points[cur].p, cam, hb,
-                           h->d_err.p, h->d_chi2.p, h->d_pose_col.p, h->d_point_col.p, h->d_EB.p);
+        hipLaunchKernelGGL(k_linearize, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, h->d_poses[cur].p, h->d_points[cur].p, cam, hb,
+                           h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, h->d_EB.p);
       if (nL > 0)
-        hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, h->d_pt_start.p, h->d_pt_edges.p, h->d_EB.p,
+        hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, D.pt_start, D.pt_edges, h->d_EB.p,
                            h->d_Hll.p, h->d_bl.p);
       if (nP > 0)
-        hipLaunchKernelGGL(k_lin_poses, dim3(nP), dim3(256), 0, st, h->d_ps_start.p, h->d_ps_edges.p, h->d_edges.p, h->d_poses[cur].p,
+        hipLaunchKernelGGL(k_lin_poses, dim3(nP), dim3(256), 0, st, D.ps_start, D.ps_edges, D.edges, h->d_poses[cur].p,
                            h->d_points[cur].p, cam, hb, h->d_err.p, h->d_chi2.p, h->d_Hpp.p, h->d_bp.p);
       int rc2;
       if (it == 0) {
@@ -1218,7 +1307,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       do {
         const int trial = cur ^ 1;
         if (nP > 0) {
-          hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(64), 0, st, nP, h->d_pair_i1.p, h->d_pair_i2.p, h->d_pair_start.p, h->d_items.p,
+          hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(64), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                              h->d_EB.p, h->d_Hll.p, h->d_bl.p, h->d_Hpp.p, h->d_bp.p, lambda, h->d_S.p, h->d_bs.p);
           if (rows_R == 1 && rows_small)
             hipLaunchKernelGGL((k_ldlt_rows<640, 1>), dim3(1), dim3(640), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
@@ -1237,8 +1326,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         } else {
           ORBG_HIP(hipMemsetAsync(h->d_ok.p, 0xFF, sizeof(int), st));   // nothing to solve: ok
         }
-        hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, h->d_pose_col.p, h->d_point_col.p,
-                           h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, h->d_pf_start.p, h->d_pf_edges.p, h->d_pf_col.p, h->d_EB.p,
+        hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, D.pose_col, D.point_col,
+                           h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, h->d_EB.p,
                            h->d_Hll.p, h->d_bl.p, lambda, h->d_poses[trial].p, h->d_points[trial].p);
         launch_errors(trial);
         if ((rc2 = finish(lambda, 1, 0, true))) return rc2;
@@ -1286,35 +1375,43 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     if ((rc = optimize(p->its_round2 > 0 ? p->its_round2 : 10, &done))) return rc;
     r->iters_round2 = done;
   }
-  // ---- results: chi2 of the LAST error evaluation (d_chi2), depth test with the current estimate
-  std::vector<double> chi2(NE);
-  if (NE > 0) ORBG_HIP(hipMemcpyAsync(chi2.data(), h->d_chi2.p, (size_t)NE * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (NP > 0) ORBG_HIP(hipMemcpyAsync(poses.data(), h->d_poses[cur].p, (size_t)NP * sizeof(PoseQ), hipMemcpyDeviceToHost, st));
-  if (NX > 0) ORBG_HIP(hipMemcpyAsync(points.data(), h->d_points[cur].p, 3 * (size_t)NX * sizeof(double), hipMemcpyDeviceToHost, st));
+  // ---- results: chi2 of the LAST error evaluation (d_chi2), depth test with the current estimate (S/Optimizer.cc:2131-2166):
+  // flags computed on the device, everything comes back through one pinned block
+  size_t doff = 0;
+  auto dtake = [&](size_t bytes) { const size_t o = doff; doff = (doff + bytes + 63) & ~(size_t)63; return o; };
+  const size_t d_poses_o = dtake(sizeof(PoseQ) * (size_t)NP), d_points_o = dtake(24 * (size_t)NX), d_flags_o = dtake((size_t)NE);
+  const size_t d_chi_o = dtake(r->edge_chi2 ? 8 * (size_t)NE : 0);
+  if ((rc = h->dl_h.reserve(doff + 64)) || (rc = h->d_flags.reserve(std::max(NE, 1)))) return rc;
+  if (NE > 0) {
+    hipLaunchKernelGGL(k_edge_flags, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, h->d_poses[cur].p, h->d_points[cur].p, h->d_chi2.p,
+                       h->d_flags.p);
+    ORBG_HIP(hipMemcpyAsync(h->dl_h.h + d_flags_o, h->d_flags.p, (size_t)NE, hipMemcpyDeviceToHost, st));
+    if (r->edge_chi2) ORBG_HIP(hipMemcpyAsync(h->dl_h.h + d_chi_o, h->d_chi2.p, 8 * (size_t)NE, hipMemcpyDeviceToHost, st));
+  }
+  if (NP > 0) ORBG_HIP(hipMemcpyAsync(h->dl_h.h + d_poses_o, h->d_poses[cur].p, (size_t)NP * sizeof(PoseQ), hipMemcpyDeviceToHost, st));
+  if (NX > 0) ORBG_HIP(hipMemcpyAsync(h->dl_h.h + d_points_o, h->d_points[cur].p, 24 * (size_t)NX, hipMemcpyDeviceToHost, st));
   ORBG_HIP(hipStreamSynchronize(st));
+  const PoseQ* rposes = reinterpret_cast<const PoseQ*>(h->dl_h.h + d_poses_o);
+  const double* rpoints = reinterpret_cast<const double*>(h->dl_h.h + d_points_o);
+  const uint8_t* rflags = h->dl_h.h + d_flags_o;
   int n_out = 0;
   for (int k = 0; k < NE; k++) {
-    const lba_edge& e = p->edges[k];
-    double rr[3];
-    quat_rotate(poses[e.pose].q, &points[3 * (size_t)e.point], rr);
-    const bool depth_pos = rr[2] + poses[e.pose].t[2] > 0.0;
-    const double thr = e.ur < 0 ? 5.991 : 7.815;
-    const bool outlier = chi2[k] > thr || !depth_pos;
-    if (r->edge_chi2) r->edge_chi2[k] = chi2[k];
+    const bool depth_pos = rflags[k] & 1, outlier = rflags[k] & 2;
     if (r->edge_depth_pos) r->edge_depth_pos[k] = depth_pos;
     if (r->edge_outlier) r->edge_outlier[k] = outlier;
     n_out += outlier;
   }
+  if (r->edge_chi2 && NE > 0) memcpy(r->edge_chi2, h->dl_h.h + d_chi_o, 8 * (size_t)NE);
   r->n_outliers = n_out;
   if (NE > 0 && n_out >= NE * 0.5) r->status = LBA_REJECTED_OUTLIERS;
   for (int i = 0; i < NP; i++) {                       // Converter::toCvMat(SE3Quat)
     double R[9];
-    quat_to_R(poses[i].q, R);
+    quat_to_R(rposes[i].q, R);
     float* T = r->poses + 16 * (size_t)i;
-    for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) T[4 * a + c] = (float)R[3 * a + c]; T[4 * a + 3] = (float)poses[i].t[a]; }
+    for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) T[4 * a + c] = (float)R[3 * a + c]; T[4 * a + 3] = (float)rposes[i].t[a]; }
     T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
   }
-  for (size_t i = 0; i < points.size(); i++) r->points[i] = (float)points[i];
+  for (size_t i = 0; i < 3 * (size_t)NX; i++) r->points[i] = (float)rpoints[i];
   return ORBG_OK;
 }
 
