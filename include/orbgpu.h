@@ -381,6 +381,9 @@ int orbg_device_count(void);
  * 2 = every stage (more hipEventRecord calls per frame). */
 int orbx_set_profiling(orbx_handle* h, int level);
 int orbx_get_timings(orbx_handle* h, float* ms /*8*/);
+/* Average elapsed time of an EMPTY event pair on the handle's stream: the constant the profiling brackets add to a
+ * bracketed kernel's duration (bench.py reports the bracketed time both raw and net of this). */
+int orbx_event_overhead(orbx_handle* h, int reps, float* ms);
 
 #ifdef __cplusplus
 }

@@ -153,12 +153,47 @@ class FrameOnDevice {
     check(orbm_frame_from_extractor(f_, ex.handle(), &v), "orbm_frame_from_extractor");
     n_ = n_left;
   }
+  // Frame::Frame(imLeft, imRight, ...) numerical part (S/Frame.cc:71-172): ExtractORB(L) || ExtractORB(R) ->
+  // ComputeStereoMatches -> AssignFeaturesToGrid with ONE submission and ONE host sync; the features stay on the device.
+  // Host copies are optional (pass empty vectors' data() == nullptr to skip them).
+  int StereoCtor(ORBextractor& ex, orbm_frame_view v, const uint8_t* left, const uint8_t* right, int width, int height, int stride,
+                 std::vector<orbx_keypoint>* mvKeys = nullptr, std::vector<uint8_t>* mDescriptors = nullptr,
+                 std::vector<float>* mvuRight = nullptr, std::vector<float>* mvDepth = nullptr, int cap = 4096) {
+    if (mvKeys) mvKeys->resize(cap);
+    if (mDescriptors) mDescriptors->resize((size_t)cap * 32);
+    if (mvuRight) mvuRight->resize(cap);
+    if (mvDepth) mvDepth->resize(cap);
+    int nl = 0, nr = 0;
+    check(orbx_frame_stereo(ex.handle(), f_, &v, left, right, width, height, stride, v.bf, v.b, mvKeys ? mvKeys->data() : nullptr,
+                            mDescriptors ? mDescriptors->data() : nullptr, mvuRight ? mvuRight->data() : nullptr,
+                            mvDepth ? mvDepth->data() : nullptr, cap, &nl, &nr), "orbx_frame_stereo");
+    if (mvKeys) mvKeys->resize(nl);
+    if (mDescriptors) mDescriptors->resize((size_t)nl * 32);
+    if (mvuRight) mvuRight->resize(nl);
+    if (mvDepth) mvDepth->resize(nl);
+    n_ = nl;
+    return nl;
+  }
   int N() const { return n_; }
   orbm_frame* handle() const { return f_; }
 
  private:
   orbm_frame* f_ = nullptr;
   int n_ = 0;
+};
+
+// Map points kept resident on the device (the local map of Tracking, or the candidate points of a server search).
+class MapPointsOnDevice {
+ public:
+  explicit MapPointsOnDevice(int cap_points = 16384, int device = 0) { check(orbm_map_create(device, cap_points, &m_), "orbm_map_create"); }
+  ~MapPointsOnDevice() { if (m_) orbm_map_destroy(m_); }
+  MapPointsOnDevice(const MapPointsOnDevice&) = delete;
+  MapPointsOnDevice& operator=(const MapPointsOnDevice&) = delete;
+  void Upload(const orbm_worldpoints_view& v) { check(orbm_map_upload(m_, &v), "orbm_map_upload"); }
+  orbm_map* handle() const { return m_; }
+
+ private:
+  orbm_map* m_ = nullptr;
 };
 
 class ORBmatcher {
@@ -182,6 +217,35 @@ class ORBmatcher {
     int n = 0;
     check(orbm_search_by_projection_frame(CurrentFrame.handle(), Tcw_current, &LastFrame, th, bMono, mbCheckOrientation,
                                           assigned_mp.data(), assigned_obs.data(), &n), "orbm_search_by_projection_frame");
+    return n;
+  }
+  // Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153): isInFrustum(pMP, 0.5) for every candidate + the search
+  // above in one launch, map points resident on the device.  skip[i] = 1 for points already matched in this frame.
+  int SearchLocalPoints(FrameOnDevice& F, MapPointsOnDevice& vpLocalMapPoints, const float* Tcw, const uint8_t* skip,
+                        std::vector<int32_t>& assigned_mp, std::vector<int32_t>& assigned_obs, const float th = 1,
+                        const bool bFarPoints = false, const float thFarPoints = 50.0f) {
+    int n = 0;
+    check(orbm_search_local_points(F.handle(), vpLocalMapPoints.handle(), Tcw, skip, th, bFarPoints, thFarPoints, mfNNratio,
+                                   assigned_mp.data(), assigned_obs.data(), &n), "orbm_search_local_points");
+    return n;
+  }
+  // int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th,
+  //                        float ratioHamming), :473-587 (bWithKFs = false) and the overload with vpPointsKFs / vpMatchedKF,
+  // :589-700 (bWithKFs = true; the caller sets vpMatchedKF[idx] = vpPointsKFs[vpMatched[idx]] for the entries written).
+  int SearchByProjection(FrameOnDevice& pKF, const float* Scw, MapPointsOnDevice& vpPoints, const uint8_t* already_found,
+                         std::vector<int32_t>& vpMatched, int th, float ratioHamming = 1.0f, bool bWithKFs = false) {
+    int n = 0;
+    check(orbm_search_by_projection_sim3(pKF.handle(), vpPoints.handle(), Scw, already_found, th, ratioHamming, bWithKFs ? 0 : 1,
+                                         vpMatched.data(), &n), "orbm_search_by_projection_sim3");
+    return n;
+  }
+  // int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), :819-959.  vpMatches12[idx1] = idx2.
+  int SearchByBoW(FrameOnDevice& pKF2, const orbm_featvec_view& fv2, const uint8_t* mp_valid2, const uint8_t* desc1, int n1,
+                  const uint8_t* mp_valid1, const float* angle1, const orbm_featvec_view& fv1, std::vector<int32_t>& vpMatches12) {
+    int n = 0;
+    vpMatches12.assign(n1, -1);
+    check(orbm_search_by_bow_kf(pKF2.handle(), &fv2, mp_valid2, desc1, n1, mp_valid1, angle1, &fv1, mfNNratio, mbCheckOrientation,
+                                vpMatches12.data(), &n), "orbm_search_by_bow_kf");
     return n;
   }
   // int SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), :269-471.
@@ -210,6 +274,33 @@ class Optimizer {
     check(lba_solve(&problem, pbStopFlag, &result), "lba_solve");
     return result.status;
   }
+  // int static PoseOptimization(Frame* pFrame), I/Optimizer.h:47, S/Optimizer.cc:964-1278: returns nInitialCorrespondences -
+  // nBad; result.Tcw is what the reference writes with pFrame->SetPose, result.outlier[i] is pFrame->mvbOutlier.
+  static int PoseOptimization(const pose_opt_problem& problem, pose_opt_result& result) {
+    check(pose_optimize(&problem, &result), "pose_optimize");
+    return result.n_inliers;
+  }
+};
+
+// LocalMapping-side handle: keeps the device buffers across keyframes and can run the solve on its own worker thread
+// next to Tracking (S/ClientSystem.cc:105-106), as the reference's LocalMapping thread does.
+class LocalBA {
+ public:
+  explicit LocalBA(int device = 0) { check(lba_create(device, 0, 0, 0, &h_), "lba_create"); }
+  ~LocalBA() { if (h_) lba_destroy(h_); }
+  LocalBA(const LocalBA&) = delete;
+  LocalBA& operator=(const LocalBA&) = delete;
+  int Run(const lba_problem& problem, const volatile int32_t* pbStopFlag, lba_result& result) {
+    check(lba_solve_h(h_, &problem, pbStopFlag, &result), "lba_solve_h");
+    return result.status;
+  }
+  void Submit(const lba_problem& problem, const volatile int32_t* pbStopFlag, lba_result& result) {
+    check(lba_solve_async(h_, &problem, pbStopFlag, &result), "lba_solve_async");
+  }
+  void Wait(double* solve_ms = nullptr) { check(lba_wait(h_, solve_ms), "lba_wait"); }
+
+ private:
+  lba_handle* h_ = nullptr;
 };
 
 }  // namespace orbgpu

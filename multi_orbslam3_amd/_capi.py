@@ -110,7 +110,7 @@ EXPORTED_SYMBOLS = [
     "orbm_search_local_points", "orbm_search_by_projection_frame", "orbm_search_by_bow",
     "orbm_search_by_projection_sim3", "orbm_search_by_bow_kf",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "lba_solve_async", "lba_wait", "pose_optimize",
-    "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_set_profiling",
+    "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_event_overhead", "orbx_set_profiling",
 ]
 
 _lib = None

@@ -169,6 +169,11 @@ class ORBextractor:
     def set_profiling(self, level):
         capi.check(self.lib.orbx_set_profiling(self.h, int(level)))
 
+    def event_overhead_ms(self, reps=50):
+        ms = C.c_float(0.0)
+        capi.check(self.lib.orbx_event_overhead(self.h, int(reps), C.byref(ms)), "orbx_event_overhead")
+        return ms.value
+
     def timings(self):
         t = np.zeros(8, np.float32)
         capi.check(self.lib.orbx_get_timings(self.h, _vp(t)))

@@ -2145,6 +2145,24 @@ extern "C" int orbx_set_profiling(orbx_handle* h, int level) {
   return ORBG_OK;
 }
 
+// Cost of an empty hipEventRecord pair on the handle's stream (what the profiling brackets add to a measured kernel time)
+extern "C" int orbx_event_overhead(orbx_handle* h, int reps, float* ms) {
+  if (!h || !ms || reps < 1) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  double acc = 0;
+  for (int i = 0; i < reps; i++) {
+    ORBG_HIP(hipEventRecord(h->ev[1], h->stream));
+    ORBG_HIP(hipEventRecord(h->ev[7], h->stream));
+    ORBG_HIP(hipStreamSynchronize(h->stream));
+    float e = 0;
+    ORBG_HIP(hipEventElapsedTime(&e, h->ev[1], h->ev[7]));
+    acc += e;
+  }
+  *ms = (float)(acc / reps);
+  return ORBG_OK;
+}
+
 extern "C" int orbx_get_timings(orbx_handle* h, float* ms) {
   if (!h || !ms) return ORBG_BAD_ARG;
   for (int i = 0; i < 8; i++) ms[i] = h->timings[i];
