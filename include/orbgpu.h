@@ -283,6 +283,46 @@ int orbm_search_by_bow_kf(orbm_frame* kf2, const orbm_featvec_view* fv2, const u
                           const orbm_featvec_view* fv1, float nnratio, int check_orientation,
                           int32_t* matches12, int* nmatches);
 
+/* ---------------------------------------------------------------- bag of words */
+
+/* DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> flattened (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:60-130,
+ * m_nodes): node 0 is the root; the children of node i are child_ids[child_start[i] .. child_start[i+1]) in the order of
+ * m_nodes[i].children; a node without children is a leaf (= word). */
+enum { ORBV_TF_IDF = 0, ORBV_TF = 1, ORBV_IDF = 2, ORBV_BINARY = 3 };           /* WeightingType, BowVector.h:24-30 */
+enum { ORBV_NORM_NONE = 0, ORBV_NORM_L1 = 1, ORBV_NORM_L2 = 2 };                /* what mustNormalize() reports (ORBvoc: L1) */
+typedef struct orbv_vocab_view {
+  int32_t n_nodes;
+  int32_t L;                    /* m_L */
+  int32_t weighting;            /* ORBV_TF_IDF for ORBvoc.txt */
+  int32_t scoring_norm;         /* ORBV_NORM_L1 for ORBvoc.txt (L1_NORM scoring) */
+  const int32_t* child_start;   /* n_nodes + 1 */
+  const int32_t* child_ids;     /* child_start[n_nodes] node ids */
+  const uint8_t* desc;          /* n_nodes x 32, m_nodes[i].descriptor (the root's is unused) */
+  const double* weight;         /* n_nodes, m_nodes[i].weight */
+  const int32_t* word_id;       /* n_nodes, m_nodes[i].word_id (meaningful for leaves) */
+} orbv_vocab_view;
+typedef struct orbv_vocab orbv_vocab;
+int orbv_vocab_create(int device, const orbv_vocab_view* view, orbv_vocab** out);
+int orbv_vocab_destroy(orbv_vocab* v);
+/* void transform(const TDescriptor& feature, WordId&, WordValue&, NodeId* nid, int levelsup), TemplatedVocabulary.h:1214-1260,
+ * for n descriptors (host memory, n x 32): word_id[n], node_id[n] (node at level L - levelsup; 0 = root when that level is
+ * <= 0 or -- pinned, the reference leaves it uninitialised -- when a leaf is reached above it), weight[n]. */
+int orbv_transform(orbv_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* word_id, int32_t* node_id, double* weight);
+/* the same for the features resident in a device frame (orbm_frame_upload / orbm_frame_from_extractor / orbx_frame_stereo) */
+int orbv_transform_frame(orbv_vocab* v, orbm_frame* f, int levelsup, int32_t* word_id, int32_t* node_id, double* weight);
+/* void transform(const vector<TDescriptor>&, BowVector&, FeatureVector&, int levelsup), :1127-1199, second half: BowVector
+ * (ascending word ids, values weighted / normalised as the vocabulary prescribes) and FeatureVector (orbm_featvec_view layout)
+ * from the per-feature outputs above.  Output arrays hold up to n entries (fv_start: n + 1). */
+int orbv_bow_assemble(const orbv_vocab* v, const int32_t* word_id, const int32_t* node_id, const double* weight, int n,
+                      int32_t* bow_word, double* bow_value, int32_t* n_words,
+                      uint32_t* fv_node, uint32_t* fv_start, uint32_t* fv_feat, int32_t* n_fv_nodes);
+
+/* void MapPoint::ComputeDistinctiveDescriptors(), S/MapPoint.cc:448-522, for m map points at once: the descriptors of point p's
+ * observations are desc[start[p] .. start[p+1]) (x 32 bytes, in the order the reference pushes them into vDescriptors);
+ * best[p] = index inside that list of the descriptor with the least median Hamming distance to the others (first one on
+ * ties), or -1 for a point without observations (the reference returns early and keeps the old descriptor). */
+int orbm_distinctive_descriptors(int device, const uint8_t* desc, const int32_t* start, int m, int32_t* best);
+
 /* ---------------------------------------------------------------- local bundle adjustment */
 
 /* One reprojection edge (S/Optimizer.cc:2021-2084): mono if ur < 0, stereo otherwise. */

@@ -65,6 +65,16 @@ class FeatVecView(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("start", C.c_void_p), ("feat_idx", C.c_void_p)]
 
 
+class VocabView(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("L", C.c_int32), ("weighting", C.c_int32), ("scoring_norm", C.c_int32),
+                ("child_start", C.c_void_p), ("child_ids", C.c_void_p), ("desc", C.c_void_p), ("weight", C.c_void_p),
+                ("word_id", C.c_void_p)]
+
+
+ORBV_TF_IDF, ORBV_TF, ORBV_IDF, ORBV_BINARY = 0, 1, 2, 3
+ORBV_NORM_NONE, ORBV_NORM_L1, ORBV_NORM_L2 = 0, 1, 2
+
+
 class LbaProblem(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p), ("edges", C.c_void_p),
@@ -109,6 +119,8 @@ EXPORTED_SYMBOLS = [
     "orbm_search_by_projection_mps", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
     "orbm_search_local_points", "orbm_search_by_projection_frame", "orbm_search_by_bow",
     "orbm_search_by_projection_sim3", "orbm_search_by_bow_kf",
+    "orbv_vocab_create", "orbv_vocab_destroy", "orbv_transform", "orbv_transform_frame", "orbv_bow_assemble",
+    "orbm_distinctive_descriptors",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "lba_solve_async", "lba_wait", "pose_optimize",
     "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_event_overhead", "orbx_set_profiling",
 ]

@@ -365,6 +365,65 @@ class ORBmatcher:
         return matches[: len(desc1)].copy(), n.value
 
 
+class ORBVocabulary:
+    """DBoW2 ORBVocabulary (I/ORBVocabulary.h:30) on the device: transform() of descriptors into BowVector / FeatureVector."""
+
+    def __init__(self, view, keep=None, device=0):
+        self.lib = capi.load()
+        self.h = C.c_void_p()
+        self._keep = keep
+        capi.check(self.lib.orbv_vocab_create(device, C.byref(view), C.byref(self.h)), "orbv_vocab_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orbv_vocab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transform_features(self, desc=None, levelsup=4, frame=None):
+        """Per feature (word_id, node_id, weight): transform(feature, id, w, &nid, levelsup)."""
+        if frame is not None:
+            n = frame.n
+        else:
+            desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+            n = len(desc)
+        wid = np.zeros(max(n, 1), np.int32); nid = np.zeros(max(n, 1), np.int32); w = np.zeros(max(n, 1), np.float64)
+        if frame is not None:
+            capi.check(self.lib.orbv_transform_frame(self.h, frame.h, int(levelsup), _vp(wid), _vp(nid), _vp(w)), "orbv_transform_frame")
+        else:
+            capi.check(self.lib.orbv_transform(self.h, _vp(desc), n, int(levelsup), _vp(wid), _vp(nid), _vp(w)), "orbv_transform")
+        return wid[:n], nid[:n], w[:n]
+
+    def transform(self, desc=None, levelsup=4, frame=None):
+        """transform(features, BowVector&, FeatureVector&, levelsup): ((words, values), (node_id, start, feat_idx))."""
+        wid, nid, w = self.transform_features(desc, levelsup, frame)
+        n = len(wid)
+        bw = np.zeros(max(n, 1), np.int32); bv = np.zeros(max(n, 1), np.float64)
+        fn = np.zeros(max(n, 1), np.uint32); fs = np.zeros(n + 1, np.uint32); ff = np.zeros(max(n, 1), np.uint32)
+        nw, nn = C.c_int32(0), C.c_int32(0)
+        capi.check(self.lib.orbv_bow_assemble(self.h, _vp(wid), _vp(nid), _vp(w), n, _vp(bw), _vp(bv), C.byref(nw), _vp(fn), _vp(fs),
+                                              _vp(ff), C.byref(nn)), "orbv_bow_assemble")
+        k = nn.value
+        return (bw[: nw.value].copy(), bv[: nw.value].copy()), (fn[:k].copy(), fs[: k + 1].copy(), ff[: int(fs[k]) if k else 0].copy())
+
+
+def ComputeDistinctiveDescriptors(desc, start, device=0):
+    """MapPoint::ComputeDistinctiveDescriptors (S/MapPoint.cc:448-522) for a batch of map points (CSR lists of descriptors)."""
+    lib = capi.load()
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    start = np.ascontiguousarray(start, np.int32)
+    m = len(start) - 1
+    best = np.zeros(max(m, 1), np.int32)
+    capi.check(lib.orbm_distinctive_descriptors(int(device), _vp(desc) if len(desc) else None, _vp(start), m, _vp(best)),
+               "orbm_distinctive_descriptors")
+    return best[:m]
+
+
 class Optimizer:
     """ORB_SLAM3::Optimizer (I/Optimizer.h:30-113): LocalBundleAdjustment numerical core."""
 

@@ -1,0 +1,275 @@
+// liborbgpu -- bag-of-words side of the hot path, hand-written HIP for gfx950:
+//   * DBoW2::TemplatedVocabulary<FORB>::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1260): every
+//     descriptor walks the vocabulary tree (first minimum of FORB::distance among the children, FORB.cpp:83-103) to its
+//     word; BowVector / FeatureVector are assembled from the per-feature (word, node, weight) on the host, in the
+//     reference's insertion order;
+//   * MapPoint::ComputeDistinctiveDescriptors (S/MapPoint.cc:448-522) for a batch of map points: N x N Hamming
+//     distances per point, median of every row, first row with the least median.
+#include "common.hpp"
+#include "wave.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+using namespace orbg;
+
+int orbm_internal_features(orbm_frame* f, const uint8_t** d_desc, int* n, hipStream_t* stream);
+
+namespace {
+
+__device__ __forceinline__ int hamming32(const uint32_t* a, const uint32_t* b) {
+  int d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d += __popc(a[i] ^ b[i]);
+  return d;
+}
+
+// One thread per feature: the walk is a chain of L dependent "k children" comparisons -- pure latency, so the only
+// thing that matters is that all features walk concurrently.
+__global__ __launch_bounds__(256) void vocab_transform_kernel(const uint8_t* __restrict__ feat, int n, const int* __restrict__ child_start,
+                                                             const int* __restrict__ child_ids, const uint8_t* __restrict__ node_desc,
+                                                             const int* __restrict__ node_word, const double* __restrict__ node_weight,
+                                                             int nid_level, int32_t* __restrict__ word_id, int32_t* __restrict__ node_id,
+                                                             double* __restrict__ weight) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t f[8];
+  {
+    const uint4 f0 = *reinterpret_cast<const uint4*>(feat + (size_t)i * 32), f1 = *reinterpret_cast<const uint4*>(feat + (size_t)i * 32 + 16);
+    f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
+  }
+  int nid = 0;                    // root when nid_level <= 0 (:1224); also the pinned value when a leaf comes earlier
+  int final_id = 0, level = 0;
+  int cs = child_start[0], ce = child_start[1];
+  while (ce > cs) {               // do { ... } while (!isLeaf()) -- the root of a usable vocabulary has children
+    ++level;
+    int best = child_ids[cs];
+    int best_d;
+    {
+      const uint4 d0 = *reinterpret_cast<const uint4*>(node_desc + (size_t)best * 32), d1 = *reinterpret_cast<const uint4*>(node_desc + (size_t)best * 32 + 16);
+      const uint32_t nd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      best_d = hamming32(f, nd);
+    }
+    for (int c = cs + 1; c < ce; c++) {
+      const int id = child_ids[c];
+      const uint4 d0 = *reinterpret_cast<const uint4*>(node_desc + (size_t)id * 32), d1 = *reinterpret_cast<const uint4*>(node_desc + (size_t)id * 32 + 16);
+      const uint32_t nd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      const int d = hamming32(f, nd);
+      if (d < best_d) { best_d = d; best = id; }      // strict '<': first minimum wins (:1240-1244)
+    }
+    final_id = best;
+    if (level == nid_level) nid = final_id;
+    cs = child_start[final_id]; ce = child_start[final_id + 1];
+  }
+  word_id[i] = node_word[final_id];
+  node_id[i] = nid;
+  weight[i] = node_weight[final_id];
+}
+
+// One wavefront per map point.  Rows are kept in LDS (u16) while N <= kDdMax; the median of row i is found by rank
+// counting (no sort): the element whose rank interval [#smaller, #smaller + #equal) holds k = (int)(0.5*(N-1)).
+constexpr int kDdMax = 128;
+
+__global__ __launch_bounds__(64) void distinctive_kernel(const uint8_t* __restrict__ desc, const int* __restrict__ start, int m,
+                                                        int32_t* __restrict__ best_out) {
+  __shared__ unsigned short dist[kDdMax * kDdMax];
+  const int p = blockIdx.x, lane = threadIdx.x;
+  if (p >= m) return;
+  const int s = start[p], N = start[p + 1] - s;
+  if (N <= 0) { if (lane == 0) best_out[p] = -1; return; }
+  const uint32_t* D = reinterpret_cast<const uint32_t*>(desc) + (size_t)s * 8;
+  const int k = (int)(0.5 * (double)(N - 1));
+  unsigned best_key = 0xFFFFFFFFu;                 // (median << 16) | row : the minimum = least median, first row
+  if (N <= kDdMax) {
+    for (int e = lane; e < N * N; e += 64) {
+      const int i = e / N, j = e - i * N;
+      dist[i * kDdMax + j] = (unsigned short)(i == j ? 0 : hamming32(D + 8 * (size_t)i, D + 8 * (size_t)j));
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int i = lane; i < N; i += 64) {
+      const unsigned short* row = dist + i * kDdMax;
+      int median = 0;
+      for (int j = 0; j < N; j++) {
+        const int v = row[j];
+        int less = 0, eq = 0;
+        for (int l = 0; l < N; l++) { less += row[l] < v; eq += row[l] == v; }
+        if (less <= k && k < less + eq) { median = v; break; }
+      }
+      best_key = min(best_key, ((unsigned)median << 16) | (unsigned)i);
+    }
+  } else {
+    // more observations than the LDS block holds: distances are recomputed on the fly (rare, O(N^3))
+    for (int i = lane; i < N; i += 64) {
+      int median = 0;
+      for (int j = 0; j < N; j++) {
+        const int v = i == j ? 0 : hamming32(D + 8 * (size_t)i, D + 8 * (size_t)j);
+        int less = 0, eq = 0;
+        for (int l = 0; l < N; l++) {
+          const int w = i == l ? 0 : hamming32(D + 8 * (size_t)i, D + 8 * (size_t)l);
+          less += w < v; eq += w == v;
+        }
+        if (less <= k && k < less + eq) { median = v; break; }
+      }
+      best_key = min(best_key, ((unsigned)median << 16) | (unsigned)(i & 0xFFFF));
+    }
+  }
+  best_key = wave_min(best_key);
+  if (lane == 0) best_out[p] = (int)(best_key & 0xFFFFu);
+}
+
+}  // namespace
+
+struct orbv_vocab {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_nodes = 0, L = 0, weighting = 0, scoring_norm = 1;
+  DevBuf<int> d_child_start, d_child_ids, d_word;
+  DevBuf<uint8_t> d_desc;
+  DevBuf<double> d_weight;
+  DevBuf<uint8_t> d_feat;                 // staging for host descriptors
+  DevBuf<int> d_out_word, d_out_node;
+  DevBuf<double> d_out_weight;
+  PinnedBuf<uint8_t> pin;
+};
+
+extern "C" int orbv_vocab_create(int device, const orbv_vocab_view* v, orbv_vocab** out) {
+  if (!v || !out || v->n_nodes < 1 || !v->child_start || !v->desc || !v->weight || !v->word_id) return ORBG_BAD_ARG;
+  const int nn = v->n_nodes;
+  const int nc = v->child_start[nn];
+  if (v->child_start[0] != 0 || nc < 0 || (nc > 0 && !v->child_ids)) return ORBG_BAD_ARG;
+  for (int i = 0; i < nn; i++) if (v->child_start[i + 1] < v->child_start[i]) return ORBG_BAD_ARG;
+  for (int i = 0; i < nn; i++)                  // children are created after their parent (m_nodes.push_back): ids grow downwards,
+    for (int c = v->child_start[i]; c < v->child_start[i + 1]; c++)   // which also guarantees that every walk terminates
+      if (v->child_ids[c] <= i || v->child_ids[c] >= nn) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  orbv_vocab* h = new orbv_vocab();
+  h->device = device; h->n_nodes = nn; h->L = v->L; h->weighting = v->weighting; h->scoring_norm = v->scoring_norm;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
+  if ((rc = h->d_child_start.reserve(nn + 1)) || (rc = h->d_child_ids.reserve(std::max(nc, 1))) || (rc = h->d_word.reserve(nn)) ||
+      (rc = h->d_desc.reserve((size_t)nn * 32)) || (rc = h->d_weight.reserve(nn))) { orbv_vocab_destroy(h); return rc; }
+  ORBG_HIP(hipMemcpy(h->d_child_start.p, v->child_start, (size_t)(nn + 1) * 4, hipMemcpyHostToDevice));
+  if (nc > 0) ORBG_HIP(hipMemcpy(h->d_child_ids.p, v->child_ids, (size_t)nc * 4, hipMemcpyHostToDevice));
+  ORBG_HIP(hipMemcpy(h->d_word.p, v->word_id, (size_t)nn * 4, hipMemcpyHostToDevice));
+  ORBG_HIP(hipMemcpy(h->d_desc.p, v->desc, (size_t)nn * 32, hipMemcpyHostToDevice));
+  ORBG_HIP(hipMemcpy(h->d_weight.p, v->weight, (size_t)nn * 8, hipMemcpyHostToDevice));
+  *out = h;
+  return ORBG_OK;
+}
+
+extern "C" int orbv_vocab_destroy(orbv_vocab* h) {
+  if (!h) return ORBG_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  h->d_child_start.release(); h->d_child_ids.release(); h->d_word.release(); h->d_desc.release(); h->d_weight.release();
+  h->d_feat.release(); h->d_out_word.release(); h->d_out_node.release(); h->d_out_weight.release(); h->pin.release();
+  delete h;
+  return ORBG_OK;
+}
+
+static int transform_common(orbv_vocab* h, const uint8_t* d_feat, int n, int levelsup, hipStream_t wait_on, int32_t* word_id,
+                            int32_t* node_id, double* weight) {
+  int rc;
+  if ((rc = h->d_out_word.reserve(std::max(n, 1))) || (rc = h->d_out_node.reserve(std::max(n, 1))) ||
+      (rc = h->d_out_weight.reserve(std::max(n, 1))) || (rc = h->pin.reserve((size_t)std::max(n, 1) * 16)))
+    return rc;
+  if (wait_on && wait_on != h->stream) ORBG_HIP(hipStreamSynchronize(wait_on));     // features produced on another handle's stream
+  hipLaunchKernelGGL(vocab_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_feat, n, h->d_child_start.p,
+                     h->d_child_ids.p, h->d_desc.p, h->d_word.p, h->d_weight.p, h->L - levelsup, h->d_out_word.p, h->d_out_node.p,
+                     h->d_out_weight.p);
+  ORBG_HIP(hipGetLastError());
+  uint8_t* P = h->pin.h;
+  ORBG_HIP(hipMemcpyAsync(P, h->d_out_weight.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  ORBG_HIP(hipMemcpyAsync(P + (size_t)n * 8, h->d_out_word.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  ORBG_HIP(hipMemcpyAsync(P + (size_t)n * 12, h->d_out_node.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  ORBG_HIP(hipStreamSynchronize(h->stream));
+  memcpy(weight, P, (size_t)n * 8);
+  memcpy(word_id, P + (size_t)n * 8, (size_t)n * 4);
+  memcpy(node_id, P + (size_t)n * 12, (size_t)n * 4);
+  return ORBG_OK;
+}
+
+extern "C" int orbv_transform(orbv_vocab* h, const uint8_t* desc, int n, int levelsup, int32_t* word_id, int32_t* node_id, double* weight) {
+  if (!h || n < 0 || (n > 0 && (!desc || !word_id || !node_id || !weight))) return ORBG_BAD_ARG;
+  if (n == 0) return ORBG_OK;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  if ((rc = h->d_feat.reserve((size_t)n * 32))) return rc;
+  ORBG_HIP(hipMemcpyAsync(h->d_feat.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
+  return transform_common(h, h->d_feat.p, n, levelsup, nullptr, word_id, node_id, weight);
+}
+
+extern "C" int orbv_transform_frame(orbv_vocab* h, orbm_frame* f, int levelsup, int32_t* word_id, int32_t* node_id, double* weight) {
+  if (!h || !f || !word_id || !node_id || !weight) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  const uint8_t* d_desc = nullptr; int n = 0; hipStream_t fs = nullptr;
+  if ((rc = orbm_internal_features(f, &d_desc, &n, &fs))) return rc;
+  if (n == 0) return ORBG_OK;
+  return transform_common(h, d_desc, n, levelsup, fs, word_id, node_id, weight);
+}
+
+// transform(features, BowVector&, FeatureVector&, levelsup) bookkeeping (TemplatedVocabulary.h:1127-1199) on the host: the
+// std::map insertions of the reference replayed in feature order, so sums and ordering are the reference's.
+extern "C" int orbv_bow_assemble(const orbv_vocab* h, const int32_t* word_id, const int32_t* node_id, const double* weight, int n,
+                                 int32_t* bow_word, double* bow_value, int32_t* n_words, uint32_t* fv_node, uint32_t* fv_start,
+                                 uint32_t* fv_feat, int32_t* n_fv_nodes) {
+  if (!h || n < 0 || !n_words || !n_fv_nodes || (n > 0 && (!word_id || !node_id || !weight || !bow_word || !bow_value || !fv_node ||
+                                                           !fv_start || !fv_feat)))
+    return ORBG_BAD_ARG;
+  std::map<int32_t, double> v;
+  std::map<uint32_t, std::vector<uint32_t>> fv;
+  const bool tf = h->weighting == ORBV_TF_IDF || h->weighting == ORBV_TF;
+  for (int i = 0; i < n; i++) {
+    const double w = weight[i];
+    if (!(w > 0)) continue;                                         // stopped word (:1159)
+    if (tf) v[word_id[i]] += w;                                     // BowVector::addWeight
+    else v.emplace(word_id[i], w);                                  // BowVector::addIfNotExist
+    fv[(uint32_t)node_id[i]].push_back((uint32_t)i);                // FeatureVector::addFeature
+  }
+  const bool must = h->scoring_norm != ORBV_NORM_NONE;
+  if (tf && !v.empty() && !must) {
+    const double nd = (double)v.size();
+    for (auto& kv : v) kv.second /= nd;
+  }
+  if (must) {                                                       // BowVector::normalize (BowVector.cpp:62-84)
+    double norm = 0.0;
+    if (h->scoring_norm == ORBV_NORM_L1) for (auto& kv : v) norm += std::fabs(kv.second);
+    else { for (auto& kv : v) norm += kv.second * kv.second; norm = std::sqrt(norm); }
+    if (norm > 0.0) for (auto& kv : v) kv.second /= norm;
+  }
+  int k = 0;
+  for (auto& kv : v) { bow_word[k] = kv.first; bow_value[k] = kv.second; k++; }
+  *n_words = k;
+  int nn = 0; uint32_t off = 0;
+  for (auto& kv : fv) {
+    fv_node[nn] = kv.first; fv_start[nn] = off;
+    for (uint32_t fi : kv.second) fv_feat[off++] = fi;
+    nn++;
+  }
+  if (n > 0) fv_start[nn] = off;
+  *n_fv_nodes = nn;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_distinctive_descriptors(int device, const uint8_t* desc, const int32_t* start, int m, int32_t* best) {
+  if (m < 0 || (m > 0 && (!start || !best))) return ORBG_BAD_ARG;
+  if (m == 0) return ORBG_OK;
+  const int total = start[m];
+  if (start[0] != 0 || total < 0 || (total > 0 && !desc)) return ORBG_BAD_ARG;
+  for (int i = 0; i < m; i++) if (start[i + 1] < start[i] || start[i + 1] - start[i] > 65535) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  struct Scratch { DevBuf<uint8_t> d_desc; DevBuf<int> d_start, d_best; int device = -1; };
+  static thread_local Scratch sc;
+  if (sc.device != device) { sc.d_desc.release(); sc.d_start.release(); sc.d_best.release(); sc.device = device; }
+  if ((rc = sc.d_desc.reserve((size_t)std::max(total, 1) * 32)) || (rc = sc.d_start.reserve(m + 1)) || (rc = sc.d_best.reserve(m))) return rc;
+  if (total > 0) ORBG_HIP(hipMemcpyAsync(sc.d_desc.p, desc, (size_t)total * 32, hipMemcpyHostToDevice, 0));
+  ORBG_HIP(hipMemcpyAsync(sc.d_start.p, start, (size_t)(m + 1) * 4, hipMemcpyHostToDevice, 0));
+  hipLaunchKernelGGL(distinctive_kernel, dim3(m), dim3(64), 0, 0, sc.d_desc.p, sc.d_start.p, m, sc.d_best.p);
+  ORBG_HIP(hipGetLastError());
+  ORBG_HIP(hipMemcpy(best, sc.d_best.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+  return ORBG_OK;
+}

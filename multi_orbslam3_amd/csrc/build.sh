@@ -7,13 +7,13 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
 mkdir -p "$HERE/obj"
 pids=()
-for f in extractor matcher lba; do
-  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/orbgpu.h" -nt "$HERE/obj/$f.o" ]; then
+for f in extractor matcher lba bow; do
+  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/wave.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/orbgpu.h" -nt "$HERE/obj/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC $FLAGS -x hip -c "$HERE/misc.cpp" -o "$HERE/obj/misc.o"
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/extractor.o" "$HERE/obj/matcher.o" "$HERE/obj/lba.o" "$HERE/obj/misc.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/extractor.o" "$HERE/obj/matcher.o" "$HERE/obj/lba.o" "$HERE/obj/bow.o" "$HERE/obj/misc.o"
 echo "built $OUT"

@@ -809,6 +809,13 @@ int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v
 
 void orbm_internal_set_n(orbm_frame* f, int n) { f->fp.n = n; }
 
+// device-resident descriptors of the frame's features (for the vocabulary transform in bow.hip)
+int orbm_internal_features(orbm_frame* f, const uint8_t** d_desc, int* n, hipStream_t* stream) {
+  if (!f || !f->desc_p) return ORBG_BAD_ARG;
+  *d_desc = f->desc_p; *n = f->fp.n; *stream = f->stream;
+  return ORBG_OK;
+}
+
 extern "C" int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start, int32_t* cell_items) {
   if (!f || !cell_start) return ORBG_BAD_ARG;
   int rc = select_device(f->device);

@@ -254,3 +254,42 @@ def make_pose_opt_problem(n=500, seed=0xF00D, width=640, height=480, outlier_fra
     T0 = perturb_pose(T_true, rng, sigma_rot_deg, sigma_t)
     return dict(Xw=Xw.astype(np.float32), u=u.astype(np.float32), v=v.astype(np.float32), ur=ur.astype(np.float32),
                 inv_sigma2=inv_s2, cam=(fx, fy, cx, cy, bf), Tcw=T0.astype(np.float32), T_true=T_true, bad=bad)
+
+
+# ---------------------------------------------------------------- synthetic vocabulary (ORBvoc.txt is not in the reference tree)
+def make_vocabulary(k=10, L=3, seed=0xB0C, stop_frac=0.03, descriptors=None):
+    """A k-ary tree of depth L in DBoW2's node layout (node ids in creation order, children after parents): node descriptors are
+    drawn from `descriptors` (if given, so that real features spread over the words) or at random; leaf weights play the idf
+    (a few are 0 = stopped words).  Returns the arrays of views.vocab_view."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    child_lists = [[]]
+    level_of = [0]
+    frontier = [0]
+    for lvl in range(1, L + 1):
+        nxt = []
+        for parent in frontier:
+            kk = k if lvl < L or rng.rand() > 0.2 else max(2, k - 3)          # a few ragged leaf groups
+            for _ in range(kk):
+                child_lists.append([])
+                level_of.append(lvl)
+                child_lists[parent].append(len(child_lists) - 1)
+                nxt.append(len(child_lists) - 1)
+        frontier = nxt
+    n = len(child_lists)
+    child_start = np.zeros(n + 1, np.int32)
+    for i, c in enumerate(child_lists):
+        child_start[i + 1] = child_start[i] + len(c)
+    child_ids = np.array([c for cl in child_lists for c in cl], np.int32)
+    if descriptors is not None and len(descriptors) > 0:
+        desc = np.ascontiguousarray(descriptors[rng.randint(0, len(descriptors), n)], np.uint8)
+        flip = rng.randint(0, 256, desc.shape).astype(np.uint8) & rng.randint(0, 256, desc.shape).astype(np.uint8) & rng.randint(0, 256, desc.shape).astype(np.uint8)
+        desc = desc ^ flip
+    else:
+        desc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    word_id = np.full(n, -1, np.int32)
+    weight = np.zeros(n, np.float64)
+    leaves = [i for i in range(n) if not child_lists[i]]
+    for w, i in enumerate(leaves):
+        word_id[i] = w
+        weight[i] = 0.0 if rng.rand() < stop_frac else float(np.log(1.0 + 50.0 * rng.rand() + 1.0))
+    return dict(child_start=child_start, child_ids=child_ids, desc=desc, weight=weight, word_id=word_id, L=L, k=k)

@@ -82,6 +82,16 @@ def featvec_from_nodes(node_of_feature):
     return nodes.astype(np.uint32), start, order.astype(np.uint32)
 
 
+def vocab_view(child_start, child_ids, desc, weight, word_id, L, weighting=capi.ORBV_TF_IDF, scoring_norm=capi.ORBV_NORM_L1):
+    """DBoW2 vocabulary tree flattened (include/orbgpu.h: orbv_vocab_view)."""
+    arrs = [_c(child_start, np.int32), _c(child_ids, np.int32), _c(desc, np.uint8), _c(weight, np.float64), _c(word_id, np.int32)]
+    v = capi.VocabView()
+    v.n_nodes = len(arrs[0]) - 1
+    v.L, v.weighting, v.scoring_norm = int(L), int(weighting), int(scoring_norm)
+    v.child_start, v.child_ids, v.desc, v.weight, v.word_id = [capi.ptr(a) for a in arrs]
+    return v, arrs
+
+
 def lba_problem(poses, pose_fixed, points, edges, cam, lambda_init=0.0, its=(5, 10), device=0):
     """poses: (P,16) or (P,4,4) float32; edges: structured EDGE_DTYPE; cam = (fx, fy, cx, cy, bf)."""
     poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 16))

@@ -295,6 +295,39 @@ def search_by_bow_kf(kf2, fv2, mp_valid2, desc1, mp_valid1, angle1, fv1, nnratio
     return matches[: len(desc1)].copy(), n.value
 
 
+# ---------------------------------------------------------------- bag of words
+def vocab_transform(voc, desc, levelsup=4):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(desc)
+    wid = np.zeros(max(n, 1), np.int32); nid = np.zeros(max(n, 1), np.int32); w = np.zeros(max(n, 1), np.float64)
+    _chk(lib().oracle_vocab_transform(C.byref(voc), C.c_void_p(desc.ctypes.data), n, int(levelsup), C.c_void_p(wid.ctypes.data),
+                                      C.c_void_p(nid.ctypes.data), C.c_void_p(w.ctypes.data)))
+    return wid[:n], nid[:n], w[:n]
+
+
+def vocab_bow(voc, desc, levelsup=4):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(desc)
+    bw = np.zeros(max(n, 1), np.int32); bv = np.zeros(max(n, 1), np.float64)
+    fn = np.zeros(max(n, 1), np.uint32); fs = np.zeros(n + 1, np.uint32); ff = np.zeros(max(n, 1), np.uint32)
+    nw, nn = C.c_int32(0), C.c_int32(0)
+    _chk(lib().oracle_vocab_bow(C.byref(voc), C.c_void_p(desc.ctypes.data), n, int(levelsup), C.c_void_p(bw.ctypes.data),
+                                C.c_void_p(bv.ctypes.data), C.byref(nw), C.c_void_p(fn.ctypes.data), C.c_void_p(fs.ctypes.data),
+                                C.c_void_p(ff.ctypes.data), C.byref(nn)))
+    k = nn.value
+    return (bw[: nw.value].copy(), bv[: nw.value].copy()), (fn[:k].copy(), fs[: k + 1].copy(), ff[: int(fs[k]) if k else 0].copy())
+
+
+def distinctive_descriptors(desc, start):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    start = np.ascontiguousarray(start, np.int32)
+    m = len(start) - 1
+    best = np.zeros(max(m, 1), np.int32)
+    _chk(lib().oracle_distinctive_descriptors(C.c_void_p(desc.ctypes.data) if len(desc) else None, C.c_void_p(start.ctypes.data), m,
+                                              C.c_void_p(best.ctypes.data)))
+    return best[:m]
+
+
 # ---------------------------------------------------------------- LBA
 def lba_solve(problem, stop_flag=None, trace_cap=64):
     out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)

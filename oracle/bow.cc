@@ -1,0 +1,114 @@
+// ORACLE (test infrastructure, not product code) -- see orb_oracle.h for status: parity unpinned.
+//
+// CPU restatement of the bag-of-words pieces next to the hot path:
+//   DBoW2::TemplatedVocabulary<FORB>::transform  (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1260, FORB.cpp:83-103,
+//   BowVector.cpp:26-84, FeatureVector.cpp:31-45) and MapPoint::ComputeDistinctiveDescriptors (S/MapPoint.cc:448-522).
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <map>
+#include <vector>
+
+// void transform(const TDescriptor &feature, WordId &word_id, WordValue &weight, NodeId *nid, int levelsup) -- :1214-1260
+extern "C" int oracle_vocab_transform(const orbv_vocab_view* v, const uint8_t* desc, int n, int levelsup, int32_t* word_id,
+                                      int32_t* node_id, double* weight) {
+  if (!v || n < 0) return ORBG_BAD_ARG;
+  const int nid_level = v->L - levelsup;
+  for (int i = 0; i < n; i++) {
+    const uint8_t* f = desc + 32 * (size_t)i;
+    int nid = 0;                                   // "if(nid_level <= 0 && nid != NULL) *nid = 0" (:1224); pinned to 0 otherwise too
+    int final_id = 0, current_level = 0;
+    while (v->child_start[final_id + 1] > v->child_start[final_id]) {
+      ++current_level;
+      const int cs = v->child_start[final_id], ce = v->child_start[final_id + 1];
+      final_id = v->child_ids[cs];
+      double best_d = oracle_hamming(f, v->desc + 32 * (size_t)final_id);
+      for (int c = cs + 1; c < ce; c++) {
+        const int id = v->child_ids[c];
+        const double d = oracle_hamming(f, v->desc + 32 * (size_t)id);
+        if (d < best_d) { best_d = d; final_id = id; }
+      }
+      if (current_level == nid_level) nid = final_id;
+    }
+    word_id[i] = v->word_id[final_id];
+    weight[i] = v->weight[final_id];
+    node_id[i] = nid;
+  }
+  return ORBG_OK;
+}
+
+// void transform(const vector<TDescriptor>& features, BowVector &v, FeatureVector &fv, int levelsup) -- :1127-1199
+extern "C" int oracle_vocab_bow(const orbv_vocab_view* voc, const uint8_t* desc, int n, int levelsup, int32_t* bow_word,
+                                double* bow_value, int32_t* n_words, uint32_t* fv_node, uint32_t* fv_start, uint32_t* fv_feat,
+                                int32_t* n_fv_nodes) {
+  std::vector<int32_t> wid(std::max(n, 1)), nid(std::max(n, 1));
+  std::vector<double> w(std::max(n, 1));
+  int rc = oracle_vocab_transform(voc, desc, n, levelsup, wid.data(), nid.data(), w.data());
+  if (rc) return rc;
+  std::map<int32_t, double> v;                              // BowVector: std::map<WordId, WordValue>
+  std::map<uint32_t, std::vector<uint32_t>> fv;             // FeatureVector: std::map<NodeId, std::vector<unsigned int>>
+  const bool tf = voc->weighting == ORBV_TF_IDF || voc->weighting == ORBV_TF;
+  for (int i = 0; i < n; i++) {
+    if (!(w[i] > 0)) continue;                              // "if(w > 0) // not stopped"
+    if (tf) {                                               // BowVector::addWeight
+      auto it = v.lower_bound(wid[i]);
+      if (it != v.end() && !(v.key_comp()(wid[i], it->first))) it->second += w[i];
+      else v.insert(it, std::make_pair(wid[i], w[i]));
+    } else {                                                // BowVector::addIfNotExist
+      auto it = v.lower_bound(wid[i]);
+      if (it == v.end() || v.key_comp()(wid[i], it->first)) v.insert(it, std::make_pair(wid[i], w[i]));
+    }
+    fv[(uint32_t)nid[i]].push_back((uint32_t)i);            // FeatureVector::addFeature
+  }
+  const bool must = voc->scoring_norm != ORBV_NORM_NONE;
+  if (tf && !v.empty() && !must) {
+    const double nd = (double)v.size();
+    for (auto& kv : v) kv.second /= nd;
+  }
+  if (must) {
+    double norm = 0.0;
+    if (voc->scoring_norm == ORBV_NORM_L1) { for (auto& kv : v) norm += std::fabs(kv.second); }
+    else { for (auto& kv : v) norm += kv.second * kv.second; norm = std::sqrt(norm); }
+    if (norm > 0.0) for (auto& kv : v) kv.second /= norm;
+  }
+  int k = 0;
+  for (auto& kv : v) { bow_word[k] = kv.first; bow_value[k] = kv.second; k++; }
+  *n_words = k;
+  int nn = 0; uint32_t off = 0;
+  for (auto& kv : fv) {
+    fv_node[nn] = kv.first; fv_start[nn] = off;
+    for (uint32_t fi : kv.second) fv_feat[off++] = fi;
+    nn++;
+  }
+  fv_start[nn] = off;
+  *n_fv_nodes = nn;
+  return ORBG_OK;
+}
+
+// MapPoint::ComputeDistinctiveDescriptors -- S/MapPoint.cc:448-522, batched over m points (CSR lists of descriptors)
+extern "C" int oracle_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int m, int32_t* best) {
+  for (int p = 0; p < m; p++) {
+    const int N = start[p + 1] - start[p];
+    if (N <= 0) { best[p] = -1; continue; }                 // vDescriptors.empty(): return
+    const uint8_t* D = desc + 32 * (size_t)start[p];
+    std::vector<float> Distances((size_t)N * N);            // float Distances[N][N]
+    for (int i = 0; i < N; i++) {
+      Distances[(size_t)i * N + i] = 0;
+      for (int j = i + 1; j < N; j++) {
+        const int dij = oracle_hamming(D + 32 * (size_t)i, D + 32 * (size_t)j);
+        Distances[(size_t)i * N + j] = dij; Distances[(size_t)j * N + i] = dij;
+      }
+    }
+    int BestMedian = INT_MAX, BestIdx = 0;
+    for (int i = 0; i < N; i++) {
+      std::vector<int> vDists(Distances.begin() + (size_t)i * N, Distances.begin() + (size_t)(i + 1) * N);
+      std::sort(vDists.begin(), vDists.end());
+      const int median = vDists[(size_t)(0.5 * (N - 1))];
+      if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+    }
+    best[p] = BestIdx;
+  }
+  return ORBG_OK;
+}

@@ -94,6 +94,13 @@ int oracle_search_by_bow_kf(const orbm_frame_view* kf2, const orbm_featvec_view*
                             const orbm_featvec_view* fv1, float nnratio, int check_orientation,
                             int32_t* matches12, int* nmatches);
 
+/* ---- bag of words (Thirdparty/DBoW2, S/MapPoint.cc:448-522) */
+int oracle_vocab_transform(const orbv_vocab_view* v, const uint8_t* desc, int n, int levelsup, int32_t* word_id, int32_t* node_id,
+                           double* weight);
+int oracle_vocab_bow(const orbv_vocab_view* v, const uint8_t* desc, int n, int levelsup, int32_t* bow_word, double* bow_value,
+                     int32_t* n_words, uint32_t* fv_node, uint32_t* fv_start, uint32_t* fv_feat, int32_t* n_fv_nodes);
+int oracle_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int m, int32_t* best);
+
 /* ---- LBA (S/Optimizer.cc:1810-2410 + vendored g2o) */
 int oracle_lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
 int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* r);

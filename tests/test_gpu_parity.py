@@ -406,3 +406,48 @@ def test_lba_async_matches_blocking_call():
         assert np.array_equal(out.poses, ref.poses) and np.array_equal(out.points, ref.points)
         assert np.array_equal(out.edge_outlier, ref.edge_outlier) and out.iters == ref.iters
     assert opt.wait() is None                                # nothing in flight
+
+
+@pytest.mark.parametrize("k,L,levelsup", [(10, 3, 2), (10, 4, 4), (5, 6, 4)])
+def test_vocabulary_transform_parity(scene, k, L, levelsup):
+    """DBoW2 transform (row f-3): per-feature walk on the device, BowVector / FeatureVector bookkeeping vs the oracle."""
+    fr = helpers.oracle_stereo_frame(scene, 2)
+    v = synth.make_vocabulary(k=k, L=L, seed=31 + L, descriptors=fr["desc"])
+    vv, keep = views.vocab_view(v["child_start"], v["child_ids"], v["desc"], v["weight"], v["word_id"], L)
+    voc = api.ORBVocabulary(vv, keep)
+    g = voc.transform_features(fr["desc"], levelsup)
+    o = ob.vocab_transform(vv, fr["desc"], levelsup)
+    for a, b in zip(g, o):
+        assert np.array_equal(a, b)
+    assert len(np.unique(o[0])) > 20
+    (gw, gv), (gn, gs, gf) = voc.transform(fr["desc"], levelsup)
+    (ow, ov), (on, os_, of) = ob.vocab_bow(vv, fr["desc"], levelsup)
+    assert np.array_equal(gw, ow) and np.array_equal(gv, ov)            # same accumulation order -> identical doubles
+    assert np.array_equal(gn, on) and np.array_equal(gs, os_) and np.array_equal(gf, of)
+    # features that are already resident on the device (no descriptor upload)
+    fv, keep2 = helpers.frame_view_of(scene, fr)
+    F = api.Frame().upload(fv, keep2)
+    g2 = voc.transform_features(frame=F, levelsup=levelsup)
+    for a, b in zip(g2, o):
+        assert np.array_equal(a, b)
+    assert voc.transform_features(np.zeros((0, 32), np.uint8), levelsup)[0].shape == (0,)
+
+
+def test_distinctive_descriptors_parity(scene):
+    """MapPoint::ComputeDistinctiveDescriptors (row f-3) for a batch of map points, incl. empty, single, tied and >128 lists."""
+    rng = np.random.RandomState(4)
+    fr = helpers.oracle_stereo_frame(scene, 5)
+    lists, start = [], [0]
+    for p in range(300):
+        N = [0, 1, 2, 3, 5, 9, 16, 40, 129, 7][p % 10]
+        base = fr["desc"][rng.randint(0, len(fr["desc"]))]
+        noise = rng.randint(0, 256, (N, 32)).astype(np.uint8) & rng.randint(0, 256, (N, 32)).astype(np.uint8) & rng.randint(0, 256, (N, 32)).astype(np.uint8)
+        d = np.repeat(base[None], N, 0) ^ noise
+        if N >= 3:
+            d[2] = d[0]
+        lists.append(d); start.append(start[-1] + N)
+    desc = np.concatenate(lists)
+    g = api.ComputeDistinctiveDescriptors(desc, start)
+    o = ob.distinctive_descriptors(desc, start)
+    assert np.array_equal(g, o)
+    assert (g[::10] == -1).all() and (g[1::10] == 0).all()
