@@ -169,25 +169,39 @@ struct Huber { double delta_mono, dsqr_mono, delta_stereo, dsqr_stereo; };
 // ---------------------------------------------------------------------------------------------- kernels
 
 // residuals + chi2 + robust rho (computeActiveErrors + activeRobustChi2); block partial sums in fixed order
-// per edge: bit 0 = isDepthPositive() with the current estimate, bit 1 = outlier (chi2 > 5.991 / 7.815 or depth <= 0)
-__global__ __launch_bounds__(256) void k_edge_flags(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                                   const double* __restrict__ points, const double* __restrict__ chi2,
-                                                   uint8_t* __restrict__ flags) {
+struct HostRec { double chi2, scale, maxdiag; int ok; int pad; };   // what the host reads per LM trial (mapped pinned memory)
+
+// Results of a solve, written by the GPU straight into the caller-visible pinned block (no copy commands): per edge a flag
+// byte (bit 0 = isDepthPositive() with the final estimate, bit 1 = outlier: chi2 > 5.991 / 7.815 or depth <= 0,
+// S/Optimizer.cc:2131-2166) and optionally its chi2; the final poses and points.
+__global__ __launch_bounds__(256) void k_export(int n_edges, int n_poses, int n_points, const lba_edge* __restrict__ edges,
+                                               const PoseQ* __restrict__ poses, const double* __restrict__ points,
+                                               const double* __restrict__ chi2, uint8_t* __restrict__ out_flags,
+                                               double* __restrict__ out_chi2, PoseQ* __restrict__ out_poses,
+                                               double* __restrict__ out_points) {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n_edges) return;
-  const lba_edge e = edges[k];
-  double rr[3];
-  quat_rotate(poses[e.pose].q, points + 3 * (size_t)e.point, rr);
-  const bool depth_pos = rr[2] + poses[e.pose].t[2] > 0.0;
-  const double thr = e.ur < 0 ? 5.991 : 7.815;
-  const bool outlier = chi2[k] > thr || !depth_pos;
-  flags[k] = (uint8_t)((depth_pos ? 1 : 0) | (outlier ? 2 : 0));
+  if (k < n_edges) {
+    const lba_edge e = edges[k];
+    double rr[3];
+    quat_rotate(poses[e.pose].q, points + 3 * (size_t)e.point, rr);
+    const bool depth_pos = rr[2] + poses[e.pose].t[2] > 0.0;
+    const double thr = e.ur < 0 ? 5.991 : 7.815;
+    const double c = chi2[k];
+    const bool outlier = c > thr || !depth_pos;
+    out_flags[k] = (uint8_t)((depth_pos ? 1 : 0) | (outlier ? 2 : 0));
+    if (out_chi2) out_chi2[k] = c;
+  }
+  if (k < n_poses) out_poses[k] = poses[k];
+  if (k < 3 * n_points) out_points[k] = points[k];
 }
 
 __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                const double* __restrict__ points, Cam cam, Huber hb, double* __restrict__ err,
-                                               double* __restrict__ chi2, double* __restrict__ partial) {
+                                               double* __restrict__ chi2, double* __restrict__ partial,
+                                               int final_mode, unsigned* __restrict__ ticket, const double* __restrict__ scale_partial,
+                                               int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec) {
   __shared__ double red[256];
+  __shared__ int s_last;
   const int k = blockIdx.x * 256 + threadIdx.x;
   double rho0 = 0;
   if (k < n_edges) {
@@ -211,6 +225,37 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
     __syncthreads();
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+  if (!final_mode) return;
+  // The block that finishes last adds up the partial sums in index order (deterministic whoever is last) and publishes
+  // robust chi2 / scale / solver flag to the host record: what used to be a separate one-block kernel per LM trial.
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const int np = (int)gridDim.x;
+  // all partials are fetched in parallel, then summed by one thread in index order
+  __shared__ double parts[1024];
+  const int tot = min(np + n_scale_partial, 1024);
+  for (int i = threadIdx.x; i < tot; i += 256)
+    parts[i] = __hip_atomic_load(i < np ? &partial[i] : &scale_partial[i - np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double chi = 0, scale = 0;
+    for (int i = 0; i < np; i++) chi += i < 1024 ? parts[i] : __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < n_scale_partial; i++)
+      scale += np + i < 1024 ? parts[np + i] : __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rec->chi2 = chi; rec->scale = scale; rec->maxdiag = 0; rec->ok = ok_flag ? *ok_flag : 1;
+    *ticket = 0;
+  }
 }
 
 // per-edge blocks: EB[k*27 + ...] = Hpl (6x3, 18) | pointH upper (6) | pointB (3)
@@ -250,12 +295,12 @@ __device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double
 }
 
 // thread per edge; the 256 x 27 block of results is staged in LDS and written as ONE contiguous, coalesced chunk
-__global__ __launch_bounds__(256) void k_linearize(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+__device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                   const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
                                                   const double* __restrict__ chi2, const int* __restrict__ pose_col,
                                                   const int* __restrict__ point_col, double* __restrict__ EB) {
   __shared__ double stage[256 * kEB];
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int k = bid * 256 + threadIdx.x;
   if (k < n_edges) {
     const lba_edge e = edges[k];
     double* out = stage + threadIdx.x * kEB;
@@ -305,19 +350,19 @@ __global__ __launch_bounds__(256) void k_linearize(int n_edges, const lba_edge* 
     }
   }
   __syncthreads();
-  const int valid = min(256, n_edges - blockIdx.x * 256);
-  double* dst = EB + (size_t)blockIdx.x * 256 * kEB;
+  const int valid = min(256, n_edges - bid * 256);
+  double* dst = EB + (size_t)bid * 256 * kEB;
   for (int i = threadIdx.x; i < valid * kEB; i += 256) dst[i] = stage[i];
 }
 
 // Hpp (21 upper) + bp (6) of one free pose: block per pose, threads stride over the pose's edges and rebuild the
 // pose Jacobian on the fly (no per-edge 27-double round trip through HBM); fixed-order wave + block reduction.
-__global__ __launch_bounds__(256) void k_lin_poses(const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
+__device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
                                                   const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                   const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
                                                   const double* __restrict__ chi2, double* __restrict__ Hpp, double* __restrict__ bp) {
   __shared__ double wpart[4][27];
-  const int p = blockIdx.x;
+  const int p = bid;
   const int b = ps_start[p], e_end = ps_start[p + 1];
   double acc[27];
 #pragma unroll
@@ -372,6 +417,19 @@ __global__ __launch_bounds__(256) void k_lin_poses(const int* __restrict__ ps_st
     if (threadIdx.x < 21) Hpp[21 * (size_t)p + threadIdx.x] = v;
     else bp[6 * (size_t)p + threadIdx.x - 21] = v;
   }
+}
+
+
+// buildSystem in ONE launch: the first nP workgroups build Hpp / b_p of "their" pose from its edges (the longer job, so it
+// starts first), the remaining ones linearise 256 edges each (Hpl and the point parts).  The two jobs are independent.
+__global__ __launch_bounds__(256) void k_lin_all(int nP, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+                                                const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
+                                                const double* __restrict__ chi2, const int* __restrict__ pose_col,
+                                                const int* __restrict__ point_col, double* __restrict__ EB,
+                                                const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
+                                                double* __restrict__ Hpp, double* __restrict__ bp) {
+  if ((int)blockIdx.x < nP) lin_poses_block(blockIdx.x, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
+  else linearize_block(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB);
 }
 
 // Hll (6 upper) + bl (3) per active point: ordered sum over the point's edges
@@ -905,8 +963,11 @@ __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int n
                                                const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
                                                const int* __restrict__ pf_col, const double* __restrict__ EB,
                                                const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
-                                               PoseQ* __restrict__ poses_out, double* __restrict__ points_out) {
+                                               PoseQ* __restrict__ poses_out, double* __restrict__ points_out,
+                                               const double* __restrict__ bp, double* __restrict__ scale_partial) {
+  __shared__ double red[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
+  double sc = 0;                     // this thread's share of computeScale(): sum x (lambda x + b)  (levenberg.cpp:187-194)
   if (i < n_points) {
     const int l = point_col[i];
     double dx[3] = {0, 0, 0};
@@ -923,20 +984,31 @@ __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int n
       for (int a = 0; a < 3; a++) {
         dx[a] = Dinv[3 * a] * cl[0] + Dinv[3 * a + 1] * cl[1] + Dinv[3 * a + 2] * cl[2];
         x[6 * (size_t)nP + 3 * (size_t)l + a] = dx[a];
+        sc += dx[a] * (lambda * dx[a] + bl[3 * (size_t)l + a]);
       }
     }
     for (int a = 0; a < 3; a++) points_out[3 * (size_t)i + a] = points[3 * (size_t)i + a] + dx[a];
   } else if (i < n_points + n_poses) {
     const int p = i - n_points;
     const int c = pose_col[p];
-    if (c >= 0) pose_oplus(poses[p], x + 6 * (size_t)c, &poses_out[p]);
-    else poses_out[p] = poses[p];
+    if (c >= 0) {
+      pose_oplus(poses[p], x + 6 * (size_t)c, &poses_out[p]);
+      for (int a = 0; a < 6; a++) { const double xv = x[6 * (size_t)c + a]; sc += xv * (lambda * xv + bp[6 * (size_t)c + a]); }
+    } else {
+      poses_out[p] = poses[p];
+    }
   }
+  // fixed-order block sum -> one partial per block (the last block of the following k_errors adds them up in index order)
+  red[threadIdx.x] = sc;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scale_partial[blockIdx.x] = red[0];
 }
 
 // one workgroup: chi2 = sum partial[] (fixed order), scale = sum x (lambda x + b), maxdiag; -> pinned record
-struct HostRec { double chi2, scale, maxdiag; int ok; int pad; };
-
 __global__ __launch_bounds__(256) void k_finish(int n_partial, const double* __restrict__ partial, int nP, int nL,
                                                const double* __restrict__ x, const double* __restrict__ bp, const double* __restrict__ bl,
                                                const double* __restrict__ Hpp, const double* __restrict__ Hll, double lambda,
@@ -1007,6 +1079,8 @@ struct lba_handle {
   PinnedBuf<uint8_t> up_h, dl_h;               // per-call upload block (built in place) / download block
   DevBuf<uint8_t> up_d;
   DevBuf<uint8_t> d_flags;
+  DevBuf<double> d_scale_partial;
+  DevBuf<unsigned> d_ticket;
   std::vector<int> s_pose_deg, s_point_deg, s_pose_col, s_point_col, s_pf_deg, s_f1, s_f2, s_f3, s_fill;   // host scratch kept across calls
   float last_ms = 0;
   // lba_solve_async: the library-owned "LocalMapping" thread of this handle
@@ -1046,11 +1120,25 @@ extern "C" int lba_destroy(lba_handle* h) {
   h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release();
   h->d_pose_col.release(); h->d_point_col.release(); h->d_pt_start.release(); h->d_pt_edges.release(); h->d_ps_start.release();
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
-  h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release();
+  h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release(); h->d_scale_partial.release(); h->d_ticket.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ORBG_OK;
 }
+
+// ORBG_TRACE=1: average host-side time of the phases of lba_solve_h, printed when the library unloads
+struct TraceAcc {
+  double t[8] = {0}; long n = 0; const char* name;
+  explicit TraceAcc(const char* nm) : name(nm) {}
+  ~TraceAcc() {
+    if (n && getenv("ORBG_TRACE")) {
+      fprintf(stderr, "[orbgpu trace] %s n=%ld:", name, n);
+      for (int i = 0; i < 8; i++) fprintf(stderr, " %.1f", t[i] / n * 1e6);
+      fprintf(stderr, " us\n");
+    }
+  }
+};
+static inline double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 template <typename T>
 static int upload(DevBuf<T>& b, const std::vector<T>& v, hipStream_t st) {
@@ -1082,6 +1170,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     }
     return ORBG_OK;
   }
+  static TraceAcc tr("lba_solve_h structure / upload submit / LM loop / download+sync / write-back");
+  const double t_a = now_s();
   hipStream_t st = h->stream;
   // ---- structure (the analogue of BlockSolver::buildStructure, G/core/block_solver.hpp:143-295), host side.
   // Every array the kernels need is built IN PLACE inside one pinned block and goes to the device with ONE copy.
@@ -1187,6 +1277,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
 
   const int n = 6 * nP;
   const int n_blocks_e = (NE + 255) / 256;
+  const double t_b = now_s();
   if (off) ORBG_HIP(hipMemcpyAsync(h->up_d.p, H, off, hipMemcpyHostToDevice, st));
   struct {
     const lba_edge* edges; const int *pose_col, *point_col, *pt_start, *pt_edges, *ps_start, *ps_edges, *pf_start, *pf_edges, *pf_col,
@@ -1219,6 +1310,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     return rc;
   ORBG_HIP(hipMemsetAsync(h->d_x.p, 0, ((size_t)n + 3 * (size_t)nL) * sizeof(double), st));
 
+  const double t_c = now_s();
   Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
   Huber hb;
   hb.delta_mono = (float)std::sqrt(5.991); hb.dsqr_mono = hb.delta_mono * hb.delta_mono;          // S/Optimizer.cc:1991-1992
@@ -1257,10 +1349,18 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     }
   }
   int cur = 0;   // index of the buffer holding the current estimate
-  auto launch_errors = [&](int buf) {
+  const int n_blocks_u = (NP + NX + 255) / 256;
+  if ((rc = h->d_scale_partial.reserve(std::max(n_blocks_u, 1)))) return rc;
+  if (!h->d_ticket.p) {
+    if ((rc = h->d_ticket.reserve(4))) return rc;
+    ORBG_HIP(hipMemsetAsync(h->d_ticket.p, 0, 4 * sizeof(unsigned), st));
+  }
+  // final_mode: the last block also publishes {robust chi2, computeScale(), solver flag} to the host record
+  auto launch_errors = [&](int buf, int final_mode) {
     if (NE > 0)
       hipLaunchKernelGGL(k_errors, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, h->d_poses[buf].p, h->d_points[buf].p, cam, hb,
-                         h->d_err.p, h->d_chi2.p, h->d_partial.p);
+                         h->d_err.p, h->d_chi2.p, h->d_partial.p, final_mode, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u,
+                         h->d_ok.p, h->rec.d);
   };
   auto finish = [&](double lambda, int want_scale, int want_maxdiag, bool with_ok) -> int {
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, h->d_bp.p, h->d_bl.p, h->d_Hpp.p,
@@ -1281,16 +1381,14 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     for (int it = 0; it < iterations && !terminate() && ok; it++) {
       // computeActiveErrors (skipped when the residuals of the current estimate are already on the device:
       // recomputing them would reproduce the same bits) + buildSystem
-      if (!err_valid) { launch_errors(cur); err_valid = true; }
-      if (NE > 0)
-        hipLaunchKernelGGL(k_linearize, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, h->d_poses[cur].p, h->d_points[cur].p, cam, hb,
-                           h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, h->d_EB.p);
+      if (!err_valid) { launch_errors(cur, 0); err_valid = true; }
+      if (NE > 0 || nP > 0)
+        hipLaunchKernelGGL(k_lin_all, dim3(nP + (NE > 0 ? n_blocks_e : 0)), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[cur].p,
+                           h->d_points[cur].p, cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, h->d_EB.p, D.ps_start,
+                           D.ps_edges, h->d_Hpp.p, h->d_bp.p);
       if (nL > 0)
         hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, D.pt_start, D.pt_edges, h->d_EB.p,
                            h->d_Hll.p, h->d_bl.p);
-      if (nP > 0)
-        hipLaunchKernelGGL(k_lin_poses, dim3(nP), dim3(256), 0, st, D.ps_start, D.ps_edges, D.edges, h->d_poses[cur].p,
-                           h->d_points[cur].p, cam, hb, h->d_err.p, h->d_chi2.p, h->d_Hpp.p, h->d_bp.p);
       int rc2;
       if (it == 0) {
         // the only place the host needs chi2 / max diagonal before the first trial (computeLambdaInit)
@@ -1328,9 +1426,14 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         }
         hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, D.pose_col, D.point_col,
                            h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, h->d_EB.p,
-                           h->d_Hll.p, h->d_bl.p, lambda, h->d_poses[trial].p, h->d_points[trial].p);
-        launch_errors(trial);
-        if ((rc2 = finish(lambda, 1, 0, true))) return rc2;
+                           h->d_Hll.p, h->d_bl.p, lambda, h->d_poses[trial].p, h->d_points[trial].p, h->d_bp.p, h->d_scale_partial.p);
+        if (NE > 0) {
+          launch_errors(trial, 1);
+          ORBG_HIP(hipGetLastError());
+          ORBG_HIP(hipStreamSynchronize(st));
+        } else if ((rc2 = finish(lambda, 1, 0, true))) {
+          return rc2;
+        }
         const bool ok2 = h->rec.h->ok != 0;
         tempChi = h->rec.h->chi2;
         if (!ok2) tempChi = std::numeric_limits<double>::max();
@@ -1375,22 +1478,25 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     if ((rc = optimize(p->its_round2 > 0 ? p->its_round2 : 10, &done))) return rc;
     r->iters_round2 = done;
   }
+  const double t_d = now_s();
   // ---- results: chi2 of the LAST error evaluation (d_chi2), depth test with the current estimate (S/Optimizer.cc:2131-2166):
   // flags computed on the device, everything comes back through one pinned block
   size_t doff = 0;
   auto dtake = [&](size_t bytes) { const size_t o = doff; doff = (doff + bytes + 63) & ~(size_t)63; return o; };
   const size_t d_poses_o = dtake(sizeof(PoseQ) * (size_t)NP), d_points_o = dtake(24 * (size_t)NX), d_flags_o = dtake((size_t)NE);
   const size_t d_chi_o = dtake(r->edge_chi2 ? 8 * (size_t)NE : 0);
-  if ((rc = h->dl_h.reserve(doff + 64)) || (rc = h->d_flags.reserve(std::max(NE, 1)))) return rc;
-  if (NE > 0) {
-    hipLaunchKernelGGL(k_edge_flags, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, h->d_poses[cur].p, h->d_points[cur].p, h->d_chi2.p,
-                       h->d_flags.p);
-    ORBG_HIP(hipMemcpyAsync(h->dl_h.h + d_flags_o, h->d_flags.p, (size_t)NE, hipMemcpyDeviceToHost, st));
-    if (r->edge_chi2) ORBG_HIP(hipMemcpyAsync(h->dl_h.h + d_chi_o, h->d_chi2.p, 8 * (size_t)NE, hipMemcpyDeviceToHost, st));
+  if ((rc = h->dl_h.reserve(doff + 64))) return rc;
+  {
+    const int n_thr = std::max(std::max(NE, NP), 3 * NX);
+    if (n_thr > 0) {
+      hipLaunchKernelGGL(k_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, NE, NP, NX, D.edges, h->d_poses[cur].p, h->d_points[cur].p,
+                         h->d_chi2.p, h->dl_h.d + d_flags_o, r->edge_chi2 ? reinterpret_cast<double*>(h->dl_h.d + d_chi_o) : (double*)nullptr,
+                         reinterpret_cast<PoseQ*>(h->dl_h.d + d_poses_o), reinterpret_cast<double*>(h->dl_h.d + d_points_o));
+      ORBG_HIP(hipGetLastError());
+    }
   }
-  if (NP > 0) ORBG_HIP(hipMemcpyAsync(h->dl_h.h + d_poses_o, h->d_poses[cur].p, (size_t)NP * sizeof(PoseQ), hipMemcpyDeviceToHost, st));
-  if (NX > 0) ORBG_HIP(hipMemcpyAsync(h->dl_h.h + d_points_o, h->d_points[cur].p, 24 * (size_t)NX, hipMemcpyDeviceToHost, st));
   ORBG_HIP(hipStreamSynchronize(st));
+  const double t_e = now_s();
   const PoseQ* rposes = reinterpret_cast<const PoseQ*>(h->dl_h.h + d_poses_o);
   const double* rpoints = reinterpret_cast<const double*>(h->dl_h.h + d_points_o);
   const uint8_t* rflags = h->dl_h.h + d_flags_o;
@@ -1412,6 +1518,10 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
   }
   for (size_t i = 0; i < 3 * (size_t)NX; i++) r->points[i] = (float)rpoints[i];
+  {
+    const double t_f = now_s();
+    tr.t[0] += t_b - t_a; tr.t[1] += t_c - t_b; tr.t[2] += t_d - t_c; tr.t[3] += t_e - t_d; tr.t[4] += t_f - t_e; tr.n++;
+  }
   return ORBG_OK;
 }
 
