@@ -34,6 +34,7 @@ constexpr int TH_HIGH = 100;      // S/ORBmatcher.cc:36
 constexpr int TH_LOW = 50;        // :37
 constexpr int HISTO_LENGTH = 30;  // :38
 constexpr int kCells = ORBG_GRID_COLS * ORBG_GRID_ROWS;
+constexpr int kGridLdsItems = 4096;
 
 struct FrameParams {
   int n;
@@ -82,12 +83,19 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* _
                                                          int* __restrict__ cell_of, int* __restrict__ cell_start,
                                                          int* __restrict__ cell_items, const int* __restrict__ d_n) {
   __shared__ int cnt[kCells];
+  __shared__ int s_items[kGridLdsItems];   // cell_items staged in LDS (frames of up to kGridLdsItems features): fill + per-cell
+                                           // sort without a global-memory round trip per step
   if (d_n) fp.n = *d_n;               // feature count produced on the device (GPU quad-tree path)
   __shared__ int wsum[16];
+  __shared__ int s_total;
   const int tid = threadIdx.x;
+  const bool in_lds = fp.n <= kGridLdsItems;
   for (int c = tid; c < kCells; c += 1024) cnt[c] = 0;
   __syncthreads();
-  for (int i = tid; i < fp.n; i += 1024) {
+  int my_cell[kGridLdsItems / 1024];     // cells of this thread's features (register copy; cell_of[] is still written for the API)
+#pragma unroll
+  for (int q = 0; q < kGridLdsItems / 1024; q++) my_cell[q] = -1;
+  for (int i = tid, q = 0; i < fp.n; i += 1024, q++) {
     const int px = (int)roundf((kps[i].x - fp.min_x) * fp.w_inv);
     const int py = (int)roundf((kps[i].y - fp.min_y) * fp.h_inv);
     int c = -1;
@@ -96,43 +104,63 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* _
       atomicAdd(&cnt[c], 1);
     }
     cell_of[i] = c;
+#pragma unroll
+    for (int z = 0; z < kGridLdsItems / 1024; z++) if (z == q) my_cell[z] = c;
   }
   __syncthreads();
   // exclusive scan of 3072 counts: 3 per thread
   const int c0 = tid * 3;
   const int a = cnt[c0], b = cnt[c0 + 1], c = cnt[c0 + 2];
-  int inc = a + b + c;
   const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int n = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += n;
-  }
+  const int inc = wave_incl_scan_add(a + b + c);
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
   int base = 0;
   for (int w = 0; w < wave; w++) base += wsum[w];
   const int excl = base + inc - (a + b + c);
   cell_start[c0] = excl; cell_start[c0 + 1] = excl + a; cell_start[c0 + 2] = excl + a + b;
-  if (tid == 1023) cell_start[kCells] = excl + a + b + c;
+  if (tid == 1023) { cell_start[kCells] = excl + a + b + c; s_total = excl + a + b + c; }
   __syncthreads();
+  const int n_items = s_total;
   cnt[c0] = excl; cnt[c0 + 1] = excl + a; cnt[c0 + 2] = excl + a + b;   // running fill cursors
   __syncthreads();
+  if (in_lds) {
+#pragma unroll
+    for (int q = 0; q < kGridLdsItems / 1024; q++) {
+      const int i = tid + 1024 * q;
+      if (i < fp.n && my_cell[q] >= 0) s_items[atomicAdd(&cnt[my_cell[q]], 1)] = i;
+    }
+    __syncthreads();
+    // restore insertion (= keypoint index) order inside every cell
+    for (int q = 0; q < 3; q++) {
+      const int cc = c0 + q;
+      const int s0 = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
+      const int e = cnt[cc];
+      for (int i = s0 + 1; i < e; i++) {
+        const int key = s_items[i];
+        int j = i - 1;
+        while (j >= s0 && s_items[j] > key) { s_items[j + 1] = s_items[j]; j--; }
+        s_items[j + 1] = key;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_items; i += 1024) cell_items[i] = s_items[i];
+    return;
+  }
   for (int i = tid; i < fp.n; i += 1024) {
     const int cc = cell_of[i];
     if (cc >= 0) cell_items[atomicAdd(&cnt[cc], 1)] = i;
   }
   __syncthreads();
   __threadfence_block();
-  // restore insertion (= keypoint index) order inside every cell
   for (int q = 0; q < 3; q++) {
     const int cc = c0 + q;
-    const int s = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
+    const int s0 = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
     const int e = cnt[cc];
-    for (int i = s + 1; i < e; i++) {
+    for (int i = s0 + 1; i < e; i++) {
       const int key = cell_items[i];
       int j = i - 1;
-      while (j >= s && cell_items[j] > key) { cell_items[j + 1] = cell_items[j]; j--; }
+      while (j >= s0 && cell_items[j] > key) { cell_items[j + 1] = cell_items[j]; j--; }
       cell_items[j + 1] = key;
     }
   }
@@ -867,8 +895,11 @@ extern "C" int orbm_hamming_best2(int device, const uint8_t* q, int nq, const ui
 struct orbm_map {
   int device = 0;
   int m = 0;
-  DevBuf<float> pos, normal, min_dist, max_dist;
-  DevBuf<uint8_t> desc, bad, skip;
+  // point fields: ONE device block filled by ONE copy from a pinned staging block (offsets below, all 16-byte aligned)
+  DevBuf<uint8_t> arena;
+  PinnedBuf<uint8_t> stage;
+  hipStream_t stream = nullptr;
+  size_t o_pos = 0, o_normal = 0, o_min = 0, o_max = 0, o_desc = 0, o_bad = 0, o_skip = 0, arena_bytes = 0;
   std::vector<int> n_obs;
   std::vector<uint8_t> h_bad;
   // device track fields
@@ -880,8 +911,10 @@ struct orbm_map {
 static int map_reserve(orbm_map* m, int n) {
   const size_t c = (size_t)std::max(n, 1);
   int rc;
-  if ((rc = m->pos.reserve(3 * c)) || (rc = m->normal.reserve(3 * c)) || (rc = m->min_dist.reserve(c)) || (rc = m->max_dist.reserve(c)) ||
-      (rc = m->desc.reserve(32 * c)) || (rc = m->bad.reserve(c)) || (rc = m->skip.reserve(c)) || (rc = m->t_in_view.reserve(c)) ||
+  const size_t c16 = (c + 15) & ~(size_t)15;
+  m->o_pos = 0; m->o_normal = m->o_pos + 12 * c16; m->o_min = m->o_normal + 12 * c16; m->o_max = m->o_min + 4 * c16;
+  m->o_desc = m->o_max + 4 * c16; m->o_bad = m->o_desc + 32 * c16; m->o_skip = m->o_bad + c16; m->arena_bytes = m->o_skip + c16;
+  if ((rc = m->arena.reserve(m->arena_bytes)) || (rc = m->stage.reserve(m->arena_bytes)) || (rc = m->t_in_view.reserve(c)) ||
       (rc = m->t_px.reserve(c)) || (rc = m->t_py.reserve(c)) || (rc = m->t_pxr.reserve(c)) || (rc = m->t_depth.reserve(c)) ||
       (rc = m->t_vc.reserve(c)) || (rc = m->t_level.reserve(c)))
     return rc;
@@ -894,7 +927,8 @@ extern "C" int orbm_map_create(int device, int cap_points, orbm_map** out) {
   if (rc) return rc;
   orbm_map* m = new orbm_map();
   m->device = device;
-  if ((rc = map_reserve(m, cap_points))) { delete m; return rc; }
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return ORBG_HIP_ERROR; }
+  if ((rc = map_reserve(m, cap_points))) { orbm_map_destroy(m); return rc; }
   *out = m;
   return ORBG_OK;
 }
@@ -903,8 +937,9 @@ extern "C" int orbm_map_destroy(orbm_map* m) {
   if (!m) return ORBG_BAD_ARG;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
-  m->pos.release(); m->normal.release(); m->min_dist.release(); m->max_dist.release(); m->desc.release(); m->bad.release();
-  m->skip.release(); m->t_in_view.release(); m->t_px.release(); m->t_py.release(); m->t_pxr.release(); m->t_depth.release();
+  m->arena.release(); m->stage.release();
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  m->t_in_view.release(); m->t_px.release(); m->t_py.release(); m->t_pxr.release(); m->t_depth.release();
   m->t_vc.release(); m->t_level.release();
   delete m;
   return ORBG_OK;
@@ -921,22 +956,23 @@ extern "C" int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* p) {
   m->n_obs.assign(p->n_obs, p->n_obs + n);
   m->h_bad.assign(p->bad, p->bad + n);
   if (n > 0) {
-    ORBG_HIP(hipMemcpy(m->pos.p, p->pos, n * 12, hipMemcpyHostToDevice));
-    ORBG_HIP(hipMemcpy(m->normal.p, p->normal, n * 12, hipMemcpyHostToDevice));
-    ORBG_HIP(hipMemcpy(m->min_dist.p, p->min_dist, n * 4, hipMemcpyHostToDevice));
-    ORBG_HIP(hipMemcpy(m->max_dist.p, p->max_dist, n * 4, hipMemcpyHostToDevice));
-    ORBG_HIP(hipMemcpy(m->desc.p, p->desc, n * 32, hipMemcpyHostToDevice));
-    ORBG_HIP(hipMemcpy(m->bad.p, p->bad, n, hipMemcpyHostToDevice));
-    if (p->skip) ORBG_HIP(hipMemcpy(m->skip.p, p->skip, n, hipMemcpyHostToDevice));
-    else ORBG_HIP(hipMemset(m->skip.p, 0, n));
+    uint8_t* S = m->stage.h;
+    memcpy(S + m->o_pos, p->pos, n * 12); memcpy(S + m->o_normal, p->normal, n * 12);
+    memcpy(S + m->o_min, p->min_dist, n * 4); memcpy(S + m->o_max, p->max_dist, n * 4);
+    memcpy(S + m->o_desc, p->desc, n * 32); memcpy(S + m->o_bad, p->bad, n);
+    if (p->skip) memcpy(S + m->o_skip, p->skip, n); else memset(S + m->o_skip, 0, n);
+    ORBG_HIP(hipMemcpyAsync(m->arena.p, S, m->arena_bytes, hipMemcpyHostToDevice, m->stream));
+    ORBG_HIP(hipStreamSynchronize(m->stream));
   }
   return ORBG_OK;
 }
 
 static WorldPtsDev map_dev(const orbm_map* m) {
   WorldPtsDev w;
-  w.m = m->m; w.pos = m->pos.p; w.normal = m->normal.p; w.min_dist = m->min_dist.p; w.max_dist = m->max_dist.p;
-  w.desc = m->desc.p; w.bad = m->bad.p; w.skip = m->skip.p;
+  const uint8_t* A = m->arena.p;
+  w.m = m->m; w.pos = reinterpret_cast<const float*>(A + m->o_pos); w.normal = reinterpret_cast<const float*>(A + m->o_normal);
+  w.min_dist = reinterpret_cast<const float*>(A + m->o_min); w.max_dist = reinterpret_cast<const float*>(A + m->o_max);
+  w.desc = A + m->o_desc; w.bad = A + m->o_bad; w.skip = A + m->o_skip;
   return w;
 }
 static TrackDev map_track(const orbm_map* m) {
