@@ -1740,7 +1740,6 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   const int n_cells = (int)h->cells.size();
   hipStream_t st = h->stream;
   const int prof = h->profile;
-  h->pool->prepare();
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[0], st));
   {
     if (h->tower_T > 0) {
@@ -1769,6 +1768,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     else use_gpu = false;
   }
   h->last_was_gpu = use_gpu;
+  if (!use_gpu) h->pool->prepare();              // wake the host quad-tree workers only when they will be used
   if (n_cells > 0) {
     hipLaunchKernelGGL(fast_cells_kernel, dim3(8 * ((n_cells + 7) / 8), ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
                        std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
