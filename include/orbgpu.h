@@ -323,6 +323,25 @@ int orbv_bow_assemble(const orbv_vocab* v, const int32_t* word_id, const int32_t
  * ties), or -1 for a point without observations (the reference returns early and keeps the old descriptor). */
 int orbm_distinctive_descriptors(int device, const uint8_t* desc, const int32_t* start, int m, int32_t* best);
 
+/* double L1Scoring::score(v1, v2) (Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68) of one query BowVector against m candidates
+ * (the inner loop of KeyFrameDatabase::DetectNBestCandidates, S/KeyFrameDatabase.cc:594-761): candidates as CSR over
+ * ascending word ids.  score[m] in [0, 1]. */
+int orbv_score_l1(int device, const int32_t* q_word, const double* q_value, int nq, const int32_t* cand_start,
+                  const int32_t* cand_word, const double* cand_value, int m, double* score);
+
+/* ---------------------------------------------------------------- KeyFrame wire blocks */
+
+/* What a client sends per keyframe feature in orb_slam3_ros/KF (R/msg/KF.msg:29-31): CvKeyPoint {f32 x, f32 y, u8 size, f32 angle,
+ * u8 response, i8 octave} (R/msg/CvKeyPoint.msg:1-9, 15 bytes packed) and Descriptor {u8[32]}, as one block [N x 15 | N x 32]
+ * with the conversions of Converter::toCvKeyPointMsg / fromCvKeyPointMsg (S/Converter.cc:217-245).  The blocks are what agents
+ * exchange (RCCL all-gather on device memory, see multi_orbslam3_amd/harness.py) so that a server GPU can run the KeyFrame
+ * matchers on other agents' keyframes. */
+int orbk_wire_bytes(int n);                                              /* 47 * n */
+int orbk_pack_frame(orbm_frame* f, uint8_t* wire, int wire_on_device);
+int orbk_frame_from_wire(orbm_frame* f, const orbm_frame_view* view, const uint8_t* wire, int n, int wire_on_device);
+/* host copies of a device-resident frame's features */
+int orbm_frame_download(orbm_frame* f, orbx_keypoint* kps, uint8_t* desc);
+
 /* ---------------------------------------------------------------- local bundle adjustment */
 
 /* One reprojection edge (S/Optimizer.cc:2021-2084): mono if ur < 0, stereo otherwise. */

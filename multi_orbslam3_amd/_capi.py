@@ -120,7 +120,8 @@ EXPORTED_SYMBOLS = [
     "orbm_search_local_points", "orbm_search_by_projection_frame", "orbm_search_by_bow",
     "orbm_search_by_projection_sim3", "orbm_search_by_bow_kf",
     "orbv_vocab_create", "orbv_vocab_destroy", "orbv_transform", "orbv_transform_frame", "orbv_bow_assemble",
-    "orbm_distinctive_descriptors",
+    "orbm_distinctive_descriptors", "orbv_score_l1", "orbk_wire_bytes", "orbk_pack_frame", "orbk_frame_from_wire",
+    "orbm_frame_download",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "lba_solve_async", "lba_wait", "pose_optimize",
     "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_event_overhead", "orbx_set_profiling",
 ]

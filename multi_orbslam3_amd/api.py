@@ -215,6 +215,31 @@ class Frame:
         self.n = int(n_left)
         return self
 
+    # ---- KeyFrame wire blocks (orb_slam3_ros/KF: N x CvKeyPoint 15 B + N x Descriptor 32 B)
+    def pack_wire(self, device_ptr=None):
+        """Features -> wire block; into device memory at device_ptr (for the RCCL exchange) or returned as a numpy array."""
+        if device_ptr is not None:
+            capi.check(self.lib.orbk_pack_frame(self.h, C.c_void_p(int(device_ptr)), 1), "orbk_pack_frame")
+            return None
+        wire = np.zeros(max(47 * self.n, 1), np.uint8)
+        capi.check(self.lib.orbk_pack_frame(self.h, _vp(wire), 0), "orbk_pack_frame")
+        return wire[: 47 * self.n]
+
+    def from_wire(self, fv, wire=None, n=0, device_ptr=None):
+        """KeyFrame received as a wire block (numpy bytes or device pointer) -> device-resident frame with its grid."""
+        if device_ptr is not None:
+            capi.check(self.lib.orbk_frame_from_wire(self.h, C.byref(fv), C.c_void_p(int(device_ptr)), int(n), 1), "orbk_frame_from_wire")
+        else:
+            wire = np.ascontiguousarray(wire, np.uint8)
+            capi.check(self.lib.orbk_frame_from_wire(self.h, C.byref(fv), _vp(wire), int(n), 0), "orbk_frame_from_wire")
+        self.n = int(n)
+        return self
+
+    def download(self):
+        kps = np.zeros(max(self.n, 1), capi.KEYPOINT_DTYPE); desc = np.zeros((max(self.n, 1), 32), np.uint8)
+        capi.check(self.lib.orbm_frame_download(self.h, _vp(kps), _vp(desc)), "orbm_frame_download")
+        return kps[: self.n], desc[: self.n]
+
     def grid(self):
         start = np.zeros(capi.GRID_COLS * capi.GRID_ROWS + 1, np.int32)
         items = np.zeros(max(self.n, 1), np.int32)
@@ -410,6 +435,17 @@ class ORBVocabulary:
                                               _vp(ff), C.byref(nn)), "orbv_bow_assemble")
         k = nn.value
         return (bw[: nw.value].copy(), bv[: nw.value].copy()), (fn[:k].copy(), fs[: k + 1].copy(), ff[: int(fs[k]) if k else 0].copy())
+
+
+def BowScoreL1(q_word, q_value, cand_start, cand_word, cand_value, device=0):
+    """L1Scoring::score of one query BowVector against m candidate BowVectors (CSR): DetectNBestCandidates' inner loop."""
+    lib = capi.load()
+    qw = np.ascontiguousarray(q_word, np.int32); qv = np.ascontiguousarray(q_value, np.float64)
+    cs = np.ascontiguousarray(cand_start, np.int32); cw = np.ascontiguousarray(cand_word, np.int32); cv = np.ascontiguousarray(cand_value, np.float64)
+    m = len(cs) - 1
+    out = np.zeros(max(m, 1), np.float64)
+    capi.check(lib.orbv_score_l1(int(device), _vp(qw), _vp(qv), len(qw), _vp(cs), _vp(cw), _vp(cv), m, _vp(out)), "orbv_score_l1")
+    return out[:m]
 
 
 def ComputeDistinctiveDescriptors(desc, start, device=0):

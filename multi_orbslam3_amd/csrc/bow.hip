@@ -119,6 +119,25 @@ __global__ __launch_bounds__(64) void distinctive_kernel(const uint8_t* __restri
   if (lane == 0) best_out[p] = (int)(best_key & 0xFFFFu);
 }
 
+// double L1Scoring::score(v1, v2) (ScoringObject.cpp:23-68) of ONE query BowVector against m candidates (CSR), one thread per
+// candidate: the merge walk and the accumulation order are the reference's, so the doubles are too.
+__global__ __launch_bounds__(64) void bow_score_l1_kernel(const int* __restrict__ qw, const double* __restrict__ qv, int nq,
+                                                         const int* __restrict__ cstart, const int* __restrict__ cw,
+                                                         const double* __restrict__ cv, int m, double* __restrict__ score) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= m) return;
+  int i = 0, j = cstart[c];
+  const int je = cstart[c + 1];
+  double s = 0;
+  while (i < nq && j < je) {
+    const int a = qw[i], b = cw[j];
+    if (a == b) { const double vi = qv[i], wi = cv[j]; s += fabs(vi - wi) - fabs(vi) - fabs(wi); ++i; ++j; }
+    else if (a < b) ++i;        // lower_bound(b) on a sorted list = advance to the first element >= b
+    else ++j;
+  }
+  score[c] = -s / 2.0;
+}
+
 }  // namespace
 
 struct orbv_vocab {
@@ -271,5 +290,34 @@ extern "C" int orbm_distinctive_descriptors(int device, const uint8_t* desc, con
   hipLaunchKernelGGL(distinctive_kernel, dim3(m), dim3(64), 0, 0, sc.d_desc.p, sc.d_start.p, m, sc.d_best.p);
   ORBG_HIP(hipGetLastError());
   ORBG_HIP(hipMemcpy(best, sc.d_best.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+  return ORBG_OK;
+}
+
+extern "C" int orbv_score_l1(int device, const int32_t* q_word, const double* q_value, int nq, const int32_t* cand_start,
+                             const int32_t* cand_word, const double* cand_value, int m, double* score) {
+  if (nq < 0 || m < 0 || (m > 0 && (!cand_start || !score)) || (nq > 0 && (!q_word || !q_value))) return ORBG_BAD_ARG;
+  if (m == 0) return ORBG_OK;
+  const int total = cand_start[m];
+  if (cand_start[0] != 0 || total < 0 || (total > 0 && (!cand_word || !cand_value))) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  struct Scratch { DevBuf<int> qw, cs, cw; DevBuf<double> qv, cv, sc; int device = -1; };
+  static thread_local Scratch t;
+  if (t.device != device) { t.qw.release(); t.cs.release(); t.cw.release(); t.qv.release(); t.cv.release(); t.sc.release(); t.device = device; }
+  if ((rc = t.qw.reserve(std::max(nq, 1))) || (rc = t.qv.reserve(std::max(nq, 1))) || (rc = t.cs.reserve(m + 1)) ||
+      (rc = t.cw.reserve(std::max(total, 1))) || (rc = t.cv.reserve(std::max(total, 1))) || (rc = t.sc.reserve(m)))
+    return rc;
+  if (nq > 0) {
+    ORBG_HIP(hipMemcpyAsync(t.qw.p, q_word, (size_t)nq * 4, hipMemcpyHostToDevice, 0));
+    ORBG_HIP(hipMemcpyAsync(t.qv.p, q_value, (size_t)nq * 8, hipMemcpyHostToDevice, 0));
+  }
+  ORBG_HIP(hipMemcpyAsync(t.cs.p, cand_start, (size_t)(m + 1) * 4, hipMemcpyHostToDevice, 0));
+  if (total > 0) {
+    ORBG_HIP(hipMemcpyAsync(t.cw.p, cand_word, (size_t)total * 4, hipMemcpyHostToDevice, 0));
+    ORBG_HIP(hipMemcpyAsync(t.cv.p, cand_value, (size_t)total * 8, hipMemcpyHostToDevice, 0));
+  }
+  hipLaunchKernelGGL(bow_score_l1_kernel, dim3((m + 63) / 64), dim3(64), 0, 0, t.qw.p, t.qv.p, nq, t.cs.p, t.cw.p, t.cv.p, m, t.sc.p);
+  ORBG_HIP(hipGetLastError());
+  ORBG_HIP(hipMemcpy(score, t.sc.p, (size_t)m * 8, hipMemcpyDeviceToHost));
   return ORBG_OK;
 }

@@ -636,6 +636,57 @@ __global__ __launch_bounds__(256) void hamming_best2_kernel(const uint8_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// KeyFrame wire block: what orb_slam3_ros/KF carries per feature -- CvKeyPoint (R/msg/CvKeyPoint.msg:1-9,
+// serialised packed: f32 x, f32 y, u8 size, f32 angle, u8 response, i8 octave = 15 bytes) and Descriptor (u8[32]) -- as ONE
+// contiguous byte block [N x 15 | N x 32].  Conversions as Converter::toCvKeyPointMsg / fromCvKeyPointMsg (S/Converter.cc:217-245):
+// size and response travel as (u_int8_t) casts and come back as floats.
+constexpr int kWireKp = 15, kWireDesc = 32;
+
+__device__ __forceinline__ void wire_put_f32(uint8_t* p, float v) {
+  const unsigned u = __float_as_uint(v);
+  p[0] = (uint8_t)u; p[1] = (uint8_t)(u >> 8); p[2] = (uint8_t)(u >> 16); p[3] = (uint8_t)(u >> 24);
+}
+__device__ __forceinline__ float wire_get_f32(const uint8_t* p) {
+  return __uint_as_float((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));
+}
+
+__global__ __launch_bounds__(256) void wire_pack_kernel(const orbx_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int n,
+                                                       uint8_t* __restrict__ wire) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const orbx_keypoint k = kps[i];
+  uint8_t* p = wire + (size_t)i * kWireKp;
+  wire_put_f32(p, k.x); wire_put_f32(p + 4, k.y);
+  p[8] = (uint8_t)k.size;
+  wire_put_f32(p + 9, k.angle);
+  p[13] = (uint8_t)k.response;
+  p[14] = (uint8_t)(int8_t)k.octave;
+  const uint4* s = reinterpret_cast<const uint4*>(desc + (size_t)i * 32);
+  uint8_t* d = wire + (size_t)n * kWireKp + (size_t)i * kWireDesc;     // byte-aligned destination (15 n is odd for odd n)
+  const uint4 a = s[0], b = s[1];
+  const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int q = 0; q < 8; q++) { d[4 * q] = (uint8_t)w[q]; d[4 * q + 1] = (uint8_t)(w[q] >> 8); d[4 * q + 2] = (uint8_t)(w[q] >> 16); d[4 * q + 3] = (uint8_t)(w[q] >> 24); }
+}
+
+__global__ __launch_bounds__(256) void wire_unpack_kernel(const uint8_t* __restrict__ wire, int n, orbx_keypoint* __restrict__ kps,
+                                                         uint8_t* __restrict__ desc, orbx_keypoint* __restrict__ kps_host) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* p = wire + (size_t)i * kWireKp;
+  orbx_keypoint k;
+  k.x = wire_get_f32(p); k.y = wire_get_f32(p + 4);
+  k.size = (float)p[8];
+  k.angle = wire_get_f32(p + 9);
+  k.response = (float)p[13];
+  k.octave = (int)(int8_t)p[14];
+  kps[i] = k;
+  if (kps_host) kps_host[i] = k;
+  const uint8_t* d = wire + (size_t)n * kWireKp + (size_t)i * kWireDesc;
+  for (int q = 0; q < 32; q++) desc[(size_t)i * 32 + q] = d[q];
+}
+
+// ------------------------------------------------------------------------------------------------
 // host helpers
 
 void make_pose(const float* T, PoseF* P) {
@@ -851,6 +902,71 @@ extern "C" int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start, int32_t* 
   ORBG_HIP(hipMemcpy(cell_start, f->d_cell_start.p, (kCells + 1) * sizeof(int), hipMemcpyDeviceToHost));
   const int total = cell_start[kCells];
   if (cell_items && total > 0) ORBG_HIP(hipMemcpy(cell_items, f->d_cell_items.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+  return ORBG_OK;
+}
+
+extern "C" int orbk_wire_bytes(int n) { return n < 0 ? ORBG_BAD_ARG : n * (kWireKp + kWireDesc); }
+
+// Frame / KeyFrame features -> wire block.  `wire` is device memory (for the RCCL exchange) when wire_on_device != 0,
+// otherwise host memory.
+extern "C" int orbk_pack_frame(orbm_frame* f, uint8_t* wire, int wire_on_device) {
+  if (!f || !f->kps_p || (f->fp.n > 0 && !wire)) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int n = f->fp.n;
+  if (n == 0) return ORBG_OK;
+  const size_t bytes = (size_t)n * (kWireKp + kWireDesc);
+  uint8_t* d_wire = wire;
+  if (!wire_on_device) {
+    if ((rc = f->d_stage.reserve(bytes))) return rc;
+    d_wire = f->d_stage.p;
+  }
+  hipLaunchKernelGGL(wire_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, f->stream, f->kps_p, f->desc_p, n, d_wire);
+  ORBG_HIP(hipGetLastError());
+  if (!wire_on_device) ORBG_HIP(hipMemcpyAsync(wire, d_wire, bytes, hipMemcpyDeviceToHost, f->stream));
+  ORBG_HIP(hipStreamSynchronize(f->stream));
+  return ORBG_OK;
+}
+
+// Wire block -> device-resident KeyFrame (features + grid), ready for the KeyFrame matchers.  view supplies what the KF message
+// carries next to the features (bounds, calibration, scale pyramid; view->n / kps / desc are ignored).
+extern "C" int orbk_frame_from_wire(orbm_frame* f, const orbm_frame_view* v, const uint8_t* wire, int n, int wire_on_device) {
+  if (!f || !v || n < 0 || (n > 0 && !wire)) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  if ((rc = frame_set_params(f, v, n))) return rc;
+  if ((rc = frame_reserve(f, n))) return rc;
+  f->kps_p = f->d_kps.p; f->desc_p = f->d_desc.p; f->uright_p = f->d_uright.p; f->depth_p = f->d_depth.p;
+  f->has_uright = false;
+  f->h_kps_own.resize((size_t)std::max(n, 1));
+  f->hk = f->h_kps_own.data();
+  if (n > 0) {
+    const size_t bytes = (size_t)n * (kWireKp + kWireDesc);
+    const uint8_t* d_wire = wire;
+    if (!wire_on_device) {
+      if ((rc = f->d_stage.reserve(bytes))) return rc;
+      ORBG_HIP(hipMemcpyAsync(f->d_stage.p, wire, bytes, hipMemcpyHostToDevice, f->stream));
+      d_wire = f->d_stage.p;
+    }
+    hipLaunchKernelGGL(wire_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, f->stream, d_wire, n, f->d_kps.p, f->d_desc.p,
+                       (orbx_keypoint*)nullptr);
+    ORBG_HIP(hipGetLastError());
+    ORBG_HIP(hipMemcpyAsync(f->h_kps_own.data(), f->d_kps.p, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, f->stream));
+  }
+  if ((rc = frame_build_grid(f))) return rc;
+  ORBG_HIP(hipStreamSynchronize(f->stream));
+  return ORBG_OK;
+}
+
+// host copies of a device-resident frame's features (e.g. after orbk_frame_from_wire)
+extern "C" int orbm_frame_download(orbm_frame* f, orbx_keypoint* kps, uint8_t* desc) {
+  if (!f || !f->kps_p) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int n = f->fp.n;
+  if (n > 0 && kps) ORBG_HIP(hipMemcpyAsync(kps, f->kps_p, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, f->stream));
+  if (n > 0 && desc) ORBG_HIP(hipMemcpyAsync(desc, f->desc_p, (size_t)n * 32, hipMemcpyDeviceToHost, f->stream));
+  ORBG_HIP(hipStreamSynchronize(f->stream));
   return ORBG_OK;
 }
 

@@ -1,7 +1,10 @@
-"""Multi-agent harness: one process per GPU / agent, no data-path collective.
+"""Multi-agent harness: one process per GPU / agent, no data-path collective on the per-frame hot path.
 
-`torch.distributed` is only the control plane here: a barrier on both sides of the timed region and the MAX over
-ranks of the elapsed time.  backend "nccl" is RCCL on ROCm; the CPU tests use "gloo".
+`torch.distributed` is the control plane: a barrier on both sides of the timed region and the MAX over ranks of the elapsed
+time.  The ONE exchange the system has -- keyframe wire blocks going to the server-side matcher (row f-4, configs 3/5) -- is
+`all_gather_keyframes`: an all-gather of the agents' new KF blocks (47 bytes per feature, a few blocks per server tick, well
+under 1 MB: latency bound, so a single padded all-gather and no ring tuning).  backend "nccl" is RCCL over xGMI on ROCm; the CPU
+tests use "gloo".
 """
 import os
 import time
@@ -61,6 +64,26 @@ class AgentGroup:
     def aggregate_rate(self, steps, seconds):
         """Whole-job throughput: every rank did `steps` units in the (max) time."""
         return self.world * steps / seconds
+
+    def all_gather_keyframes(self, wire, n_features):
+        """Every agent contributes one keyframe wire block (torch uint8 tensor of 47 * n_features bytes, on the GPU with the
+        nccl backend, on the CPU with gloo); returns [(n_features_r, block_r)] for all ranks r, block_r a view into the
+        gathered buffer on the same device.  Two collectives: the feature counts (8 bytes per rank), then the blocks padded to
+        the largest one."""
+        import torch
+        dev = wire.device
+        if self.dist is None:
+            return [(int(n_features), wire[: 47 * int(n_features)])]
+        counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([int(n_features)], dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(counts, mine)
+        counts = [int(c) for c in counts.cpu()]
+        pad = 47 * max(max(counts), 1)
+        send = torch.zeros(pad, dtype=torch.uint8, device=dev)
+        send[: 47 * int(n_features)] = wire[: 47 * int(n_features)]
+        recv = torch.empty(self.world * pad, dtype=torch.uint8, device=dev)
+        self.dist.all_gather_into_tensor(recv, send)
+        return [(counts[r], recv[r * pad: r * pad + 47 * counts[r]]) for r in range(self.world)]
 
     def close(self):
         if self.dist is not None:

@@ -328,6 +328,31 @@ def distinctive_descriptors(desc, start):
     return best[:m]
 
 
+def score_l1(q_word, q_value, cand_start, cand_word, cand_value):
+    qw = np.ascontiguousarray(q_word, np.int32); qv = np.ascontiguousarray(q_value, np.float64)
+    cs = np.ascontiguousarray(cand_start, np.int32); cw = np.ascontiguousarray(cand_word, np.int32); cv = np.ascontiguousarray(cand_value, np.float64)
+    m = len(cs) - 1
+    out = np.zeros(max(m, 1), np.float64)
+    _chk(lib().oracle_score_l1(C.c_void_p(qw.ctypes.data), C.c_void_p(qv.ctypes.data), len(qw), C.c_void_p(cs.ctypes.data),
+                               C.c_void_p(cw.ctypes.data), C.c_void_p(cv.ctypes.data), m, C.c_void_p(out.ctypes.data)))
+    return out[:m]
+
+
+def wire_pack(kps, desc):
+    kps = np.ascontiguousarray(kps, capi.KEYPOINT_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(kps)
+    wire = np.zeros(47 * n, np.uint8)
+    _chk(lib().oracle_wire_pack(C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), n, C.c_void_p(wire.ctypes.data)))
+    return wire
+
+
+def wire_unpack(wire, n):
+    wire = np.ascontiguousarray(wire, np.uint8)
+    kps = np.zeros(n, capi.KEYPOINT_DTYPE); desc = np.zeros((n, 32), np.uint8)
+    _chk(lib().oracle_wire_unpack(C.c_void_p(wire.ctypes.data), n, C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data)))
+    return kps, desc
+
+
 # ---------------------------------------------------------------- LBA
 def lba_solve(problem, stop_flag=None, trace_cap=64):
     out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -109,6 +110,53 @@ extern "C" int oracle_distinctive_descriptors(const uint8_t* desc, const int32_t
       if (median < BestMedian) { BestMedian = median; BestIdx = i; }
     }
     best[p] = BestIdx;
+  }
+  return ORBG_OK;
+}
+
+// double L1Scoring::score(const BowVector &v1, const BowVector &v2) -- Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68
+extern "C" int oracle_score_l1(const int32_t* q_word, const double* q_value, int nq, const int32_t* cand_start,
+                               const int32_t* cand_word, const double* cand_value, int m, double* score_out) {
+  for (int c = 0; c < m; c++) {
+    const int32_t* w2 = cand_word + cand_start[c];
+    const double* v2 = cand_value + cand_start[c];
+    const int n2 = cand_start[c + 1] - cand_start[c];
+    int i = 0, j = 0;
+    double score = 0;
+    while (i < nq && j < n2) {
+      const double vi = q_value[i], wi = v2[j];
+      if (q_word[i] == w2[j]) { score += std::fabs(vi - wi) - std::fabs(vi) - std::fabs(wi); ++i; ++j; }
+      else if (q_word[i] < w2[j]) i = (int)(std::lower_bound(q_word + i, q_word + nq, w2[j]) - q_word);
+      else j = (int)(std::lower_bound(w2 + j, w2 + n2, q_word[i]) - w2);
+    }
+    score_out[c] = -score / 2.0;
+  }
+  return ORBG_OK;
+}
+
+// KF wire block: Converter::toCvKeyPointMsg / fromCvKeyPointMsg (S/Converter.cc:217-245), R/msg/CvKeyPoint.msg, R/msg/Descriptor.msg
+extern "C" int oracle_wire_pack(const orbx_keypoint* kps, const uint8_t* desc, int n, uint8_t* wire) {
+  for (int i = 0; i < n; i++) {
+    uint8_t* p = wire + (size_t)i * 15;
+    std::memcpy(p, &kps[i].x, 4); std::memcpy(p + 4, &kps[i].y, 4);
+    p[8] = (uint8_t)kps[i].size;                  // Msg.size = (u_int8_t)kp.size
+    std::memcpy(p + 9, &kps[i].angle, 4);
+    p[13] = (uint8_t)kps[i].response;             // Msg.response = (u_int8_t)kp.response
+    p[14] = (uint8_t)(int8_t)kps[i].octave;       // int8 octave
+    std::memcpy(wire + (size_t)n * 15 + (size_t)i * 32, desc + (size_t)i * 32, 32);
+  }
+  return ORBG_OK;
+}
+
+extern "C" int oracle_wire_unpack(const uint8_t* wire, int n, orbx_keypoint* kps, uint8_t* desc) {
+  for (int i = 0; i < n; i++) {
+    const uint8_t* p = wire + (size_t)i * 15;
+    std::memcpy(&kps[i].x, p, 4); std::memcpy(&kps[i].y, p + 4, 4);
+    kps[i].size = (float)p[8];
+    std::memcpy(&kps[i].angle, p + 9, 4);
+    kps[i].response = (float)p[13];
+    kps[i].octave = (int)(int8_t)p[14];
+    std::memcpy(desc + (size_t)i * 32, wire + (size_t)n * 15 + (size_t)i * 32, 32);
   }
   return ORBG_OK;
 }

@@ -100,6 +100,10 @@ int oracle_vocab_transform(const orbv_vocab_view* v, const uint8_t* desc, int n,
 int oracle_vocab_bow(const orbv_vocab_view* v, const uint8_t* desc, int n, int levelsup, int32_t* bow_word, double* bow_value,
                      int32_t* n_words, uint32_t* fv_node, uint32_t* fv_start, uint32_t* fv_feat, int32_t* n_fv_nodes);
 int oracle_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int m, int32_t* best);
+int oracle_score_l1(const int32_t* q_word, const double* q_value, int nq, const int32_t* cand_start, const int32_t* cand_word,
+                    const double* cand_value, int m, double* score);
+int oracle_wire_pack(const orbx_keypoint* kps, const uint8_t* desc, int n, uint8_t* wire);
+int oracle_wire_unpack(const uint8_t* wire, int n, orbx_keypoint* kps, uint8_t* desc);
 
 /* ---- LBA (S/Optimizer.cc:1810-2410 + vendored g2o) */
 int oracle_lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     lib = capi.load()
     hdr = open(os.path.join(ROOT, "include", "orbgpu.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+((?:orbx|orbm|orbv|lba|orbg|pose)_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|const char\*)\s+((?:orbx|orbm|orbv|orbk|lba|orbg|pose)_\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s

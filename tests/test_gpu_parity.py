@@ -451,3 +451,53 @@ def test_distinctive_descriptors_parity(scene):
     o = ob.distinctive_descriptors(desc, start)
     assert np.array_equal(g, o)
     assert (g[::10] == -1).all() and (g[1::10] == 0).all()
+
+
+def test_keyframe_wire_blocks_and_l1_score(scene):
+    """Row f-4: device pack / unpack of KF wire blocks, a KeyFrame rebuilt from a block serves the KeyFrame matcher, L1 BoW score."""
+    rng = np.random.RandomState(17)
+    kf = helpers.oracle_stereo_frame(scene, 14)
+    fv, keep = helpers.frame_view_of(scene, kf)
+    F = api.Frame().upload(fv, keep)
+    wire = F.pack_wire()
+    assert np.array_equal(wire, ob.wire_pack(kf["kps"], kf["desc"]))
+    n = len(kf["kps"])
+    K = api.Frame().from_wire(fv, wire, n)
+    k2, d2 = K.download()
+    ok, od = ob.wire_unpack(wire, n)
+    assert np.array_equal(d2, od) and all(np.array_equal(k2[f], ok[f]) for f in ("x", "y", "size", "angle", "response", "octave"))
+    assert np.array_equal(K.grid()[0], F.grid()[0]) and np.array_equal(K.grid()[1], F.grid()[1])
+    # the received KeyFrame gives the same Sim3 projection matches as the original one (size / response are not used by matching)
+    mp = helpers.local_map_from(scene, [helpers.oracle_stereo_frame(scene, 12)], rng)
+    wv, keep2 = helpers.world_view_of(mp)
+    LM = api.LocalMap().upload(wv)
+    m = api.ORBmatcher(0.75, True)
+    free = np.full(n, -1, np.int32)
+    T = kf["Tcw"].astype(np.float32)
+    a = m.SearchByProjectionSim3(F, T, LM, free, 4, 1.5)
+    b = m.SearchByProjectionSim3(K, T, LM, free, 4, 1.5)
+    assert a[1] > 30 and a[1] == b[1] and np.array_equal(a[0], b[0])
+    # device-to-device path (what the RCCL exchange uses)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")          # plain HIP runtime calls (torch must not initialise HIP after the library did)
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(47 * n)) == 0
+    F.pack_wire(device_ptr=dptr.value)
+    back = np.zeros(47 * n, np.uint8)
+    assert hip.hipMemcpy(ctypes.c_void_p(back.ctypes.data), dptr, ctypes.c_size_t(47 * n), 2) == 0     # hipMemcpyDeviceToHost
+    assert np.array_equal(back, wire)
+    K2 = api.Frame().from_wire(fv, n=n, device_ptr=dptr.value)
+    assert np.array_equal(K2.download()[1], od)
+    hip.hipFree(dptr)
+    # L1 BoW score
+    def bow(nw):
+        w = np.sort(rng.choice(20000, nw, replace=False)).astype(np.int32)
+        v = rng.rand(nw); v /= v.sum()
+        return w, v
+    qw, qv = bow(400)
+    cands = [bow(k) for k in rng.randint(0, 900, 200)] + [(qw, qv)]
+    cs = np.cumsum([0] + [len(c[0]) for c in cands]).astype(np.int32)
+    cw = np.concatenate([c[0] for c in cands]); cv = np.concatenate([c[1] for c in cands])
+    g = api.BowScoreL1(qw, qv, cs, cw, cv)
+    o = ob.score_l1(qw, qv, cs, cw, cv)
+    assert np.array_equal(g, o) and abs(g[-1] - 1.0) < 1e-12

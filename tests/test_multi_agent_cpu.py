@@ -63,3 +63,47 @@ def test_two_agents_gloo_no_cross_talk_and_max_time():
     # an agent's outputs do not depend on how many other agents run: rank 0 alone == rank 0 of the pair
     one = _run_ranks(1, 29612)
     assert one[0]["world"] == 1 and one[0]["digest"] == two[0]["digest"]
+
+
+EXCHANGE_WORKER = textwrap.dedent('''
+    import json, os, sys, hashlib
+    sys.path.insert(0, %r)
+    import numpy as np, torch
+    from multi_orbslam3_amd import harness, synth
+    from oracle import binding as ob
+    grp = harness.AgentGroup("gloo")
+    sc = synth.Scene(160, 120, seed=grp.agent_seed(synth.SEED_IMAGES), tex_size=(400, 300), px_per_m=50.0)
+    ex = ob.Extractor(n_features=150 + 60 * grp.rank, n_levels=4, max_width=160, max_height=120)      # ragged block sizes
+    rc, k, d, _ = ex.extract(sc.stereo_pair(1)[0])
+    wire = ob.wire_pack(k, d)
+    got = grp.all_gather_keyframes(torch.from_numpy(wire.copy()), len(k))
+    out = dict(rank=grp.rank, n=len(k), own=hashlib.sha256(wire.tobytes()).hexdigest(), blocks=[])
+    for r, (n_r, blk) in enumerate(got):
+        blk = blk.numpy()
+        kk, dd = ob.wire_unpack(blk, n_r)
+        out["blocks"].append(dict(n=n_r, sha=hashlib.sha256(blk.tobytes()).hexdigest(), octaves=int(kk["octave"].sum()),
+                                  desc=hashlib.sha256(dd.tobytes()).hexdigest()))
+    if grp.rank == 0:
+        out["roundtrip_ok"] = bool(np.array_equal(got[0][1].numpy(), wire))
+    print("RESULT " + json.dumps(out), flush=True)
+    grp.close()
+''') % ROOT
+
+
+def test_keyframe_blocks_all_gather_gloo():
+    """The one exchange of the system (row f-4 / 8e): every agent receives every agent's keyframe wire block, ragged sizes."""
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
+        procs.append(subprocess.Popen([sys.executable, "-c", EXCHANGE_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=240)
+        assert p.returncode == 0, se[-2000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    outs.sort(key=lambda o: o["rank"])
+    assert outs[0]["n"] != outs[1]["n"] and min(o["n"] for o in outs) > 30
+    for o in outs:                                   # both ranks hold both blocks, byte-identical to what their owners packed
+        assert [b["n"] for b in o["blocks"]] == [outs[0]["n"], outs[1]["n"]]
+        assert [b["sha"] for b in o["blocks"]] == [outs[0]["own"], outs[1]["own"]]
+    assert outs[0]["blocks"] == outs[1]["blocks"] and outs[0]["roundtrip_ok"]

@@ -105,3 +105,47 @@ def test_distinctive_descriptor_vs_python():
         D = np.array([[_ham(d[i], d[j]) for j in range(N)] for i in range(N)])
         med = [int(np.sort(D[i])[int(0.5 * (N - 1))]) for i in range(N)]
         assert best[p] == int(np.argmin(med)), p
+
+
+def test_wire_block_layout_and_conversions():
+    """KF wire block = N x {f32 x, f32 y, u8 size, f32 angle, u8 response, i8 octave} + N x u8[32] (KF.msg / CvKeyPoint.msg)."""
+    import struct
+    rng = np.random.RandomState(2)
+    n = 7
+    kps = np.zeros(n, capi.KEYPOINT_DTYPE)
+    kps["x"] = rng.rand(n) * 600; kps["y"] = rng.rand(n) * 400; kps["size"] = 31 * 1.2 ** rng.randint(0, 8, n)
+    kps["angle"] = rng.rand(n) * 360; kps["response"] = rng.randint(7, 256, n) + 0.0; kps["octave"] = rng.randint(0, 8, n)
+    desc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    wire = ob.wire_pack(kps, desc)
+    assert wire.shape == (47 * n,)
+    for i in range(n):
+        x, y, size, angle, resp, octv = struct.unpack_from("<ffBfBb", wire.tobytes(), 15 * i)
+        assert (np.float32(x), np.float32(y), np.float32(angle)) == (kps["x"][i], kps["y"][i], kps["angle"][i])
+        assert size == int(kps["size"][i]) and resp == int(kps["response"][i]) and octv == kps["octave"][i]   # (u_int8_t) casts truncate
+        assert np.array_equal(wire[15 * n + 32 * i: 15 * n + 32 * (i + 1)], desc[i])
+    k2, d2 = ob.wire_unpack(wire, n)
+    assert np.array_equal(d2, desc)
+    for f in ("x", "y", "angle", "octave"):
+        assert np.array_equal(k2[f], kps[f])
+    assert np.array_equal(k2["size"], np.floor(kps["size"])) and np.array_equal(k2["response"], kps["response"])
+
+
+def test_l1_score_vs_python():
+    rng = np.random.RandomState(6)
+    def bow(nw):
+        w = np.sort(rng.choice(5000, nw, replace=False)).astype(np.int32)
+        v = rng.rand(nw); v /= v.sum()
+        return w, v
+    qw, qv = bow(300)
+    cands = [bow(n) for n in (0, 1, 50, 300, 800)] + [(qw.copy(), qv.copy())]
+    cs = np.cumsum([0] + [len(c[0]) for c in cands]).astype(np.int32)
+    cw = np.concatenate([c[0] for c in cands]); cv = np.concatenate([c[1] for c in cands])
+    s = ob.score_l1(qw, qv, cs, cw, cv)
+    for c, (w, v) in enumerate(cands):
+        common = np.intersect1d(qw, w)
+        acc = 0.0
+        for word in common:                                          # ascending word order, as the merge walk visits them
+            vi = float(qv[np.searchsorted(qw, word)]); wi = float(v[np.searchsorted(w, word)])
+            acc += abs(vi - wi) - abs(vi) - abs(wi)
+        assert s[c] == -acc / 2.0
+    assert s[0] == 0.0 and abs(s[-1] - 1.0) < 1e-12                  # nothing in common -> 0, identical vectors -> 1
