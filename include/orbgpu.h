@@ -443,6 +443,10 @@ int orbx_get_timings(orbx_handle* h, float* ms /*8*/);
 /* Average elapsed time of an EMPTY event pair on the handle's stream: the constant the profiling brackets add to a
  * bracketed kernel's duration (bench.py reports the bracketed time both raw and net of this). */
 int orbx_event_overhead(orbx_handle* h, int reps, float* ms);
+/* Profiling level 1 brackets fast_cells_kernel with an event pair; with interval k only every k-th extraction is bracketed.
+ * The bracket times accumulate in the handle (sum in ms, number of samples) until reset. */
+int orbx_set_profile_interval(orbx_handle* h, int interval, int reset);
+int orbx_get_fast_kernel_stats(orbx_handle* h, double* sum_ms, int64_t* n);
 
 #ifdef __cplusplus
 }

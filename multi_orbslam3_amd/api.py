@@ -169,6 +169,14 @@ class ORBextractor:
     def set_profiling(self, level):
         capi.check(self.lib.orbx_set_profiling(self.h, int(level)))
 
+    def set_profile_interval(self, interval, reset=True):
+        capi.check(self.lib.orbx_set_profile_interval(self.h, int(interval), int(bool(reset))), "orbx_set_profile_interval")
+
+    def fast_kernel_stats(self):
+        s, n = C.c_double(0.0), C.c_int64(0)
+        capi.check(self.lib.orbx_get_fast_kernel_stats(self.h, C.byref(s), C.byref(n)), "orbx_get_fast_kernel_stats")
+        return s.value, n.value
+
     def event_overhead_ms(self, reps=50):
         ms = C.c_float(0.0)
         capi.check(self.lib.orbx_event_overhead(self.h, int(reps), C.byref(ms)), "orbx_event_overhead")

@@ -1426,6 +1426,9 @@ struct orbx_handle {
   bool last_was_gpu = false;
   float timings[8] = {0};
   int profile = 1;   // 0: no events, 1: only the FAST kernel is bracketed (bench roofline), 2: every stage
+  int profile_interval = 1;         // level-1 brackets on every k-th extraction only (an event pair costs ~5 us of stream time)
+  unsigned long long extract_calls = 0;
+  double fast_ms_sum = 0; long fast_ms_n = 0;   // accumulated bracket times of fast_cells_kernel
 };
 
 // Owned / needed pixel ranges of every level for the level-0 tiles of one axis (see pyr_tower_kernel).
@@ -1739,7 +1742,9 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   if (cams_mask == 2) return ORBG_BAD_ARG;
   const int n_cells = (int)h->cells.size();
   hipStream_t st = h->stream;
-  const int prof = h->profile;
+  int prof = h->profile;
+  if (prof == 1 && h->profile_interval > 1 && (h->extract_calls % (unsigned)h->profile_interval) != 0) prof = 0;
+  h->extract_calls++;
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[0], st));
   {
     if (h->tower_T > 0) {
@@ -1821,7 +1826,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     }
     float ms;
     h->timings[2] = 0;
-    if (prof >= 1 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) h->timings[5] = ms;   // fast_cells_kernel alone
+    if (prof >= 1 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) { h->timings[5] = ms; h->fast_ms_sum += ms; h->fast_ms_n++; }
     return ORBG_OK;
   }
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[2], st));
@@ -1938,7 +1943,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->timings[1] = ms;   // FAST + gather
     if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->timings[3] = ms;   // orientation + descriptors
   }
-  if (prof >= 1 && n_cells > 0 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) h->timings[5] = ms;   // fast_cells_kernel alone
+  if (prof >= 1 && n_cells > 0 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) { h->timings[5] = ms; h->fast_ms_sum += ms; h->fast_ms_n++; }
   return ORBG_OK;
 }
 
@@ -2136,6 +2141,20 @@ extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* urigh
   if (nl > 0 && depth) memcpy(depth, h->h_stereo.h + nl, (size_t)nl * 4);
   float ms;
   if (h->profile >= 2 && hipEventElapsedTime(&ms, h->ev[5], h->ev[6]) == hipSuccess) h->timings[4] = ms;
+  return ORBG_OK;
+}
+
+// level-1 brackets on every `interval`-th extraction; reset = 1 clears the accumulated fast_cells_kernel statistics
+extern "C" int orbx_set_profile_interval(orbx_handle* h, int interval, int reset) {
+  if (!h || interval < 1) return ORBG_BAD_ARG;
+  h->profile_interval = interval;
+  if (reset) { h->fast_ms_sum = 0; h->fast_ms_n = 0; h->extract_calls = 0; }
+  return ORBG_OK;
+}
+
+extern "C" int orbx_get_fast_kernel_stats(orbx_handle* h, double* sum_ms, int64_t* n) {
+  if (!h || !sum_ms || !n) return ORBG_BAD_ARG;
+  *sum_ms = h->fast_ms_sum; *n = (int64_t)h->fast_ms_n;
   return ORBG_OK;
 }
 
