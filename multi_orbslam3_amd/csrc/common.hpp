@@ -61,6 +61,19 @@ struct PinnedBuf {
   void release() { if (h) { (void)hipHostFree(h); h = nullptr; d = nullptr; cap = 0; } }
 };
 
+// Completion signal without the runtime's wake-up path: a one-thread kernel at the tail of a stream writes a sequence number
+// into mapped pinned memory (everything launched before it on that stream has completed and is visible by then), the host
+// spins on that word.  Falls back to hipStreamSynchronize if the word does not arrive.
+struct StreamSignal {
+  PinnedBuf<unsigned> word;
+  unsigned seq = 0;
+  int init() { int rc = word.reserve(16); if (rc) return rc; word.h[0] = 0; return ORBG_OK; }
+  void release() { word.release(); }
+  int post(hipStream_t st);      // enqueue the signal kernel (misc.cpp)
+  int wait(hipStream_t st);      // spin until the posted signal arrives (misc.cpp)
+  int sync(hipStream_t st) { int rc = post(st); return rc ? rc : wait(st); }
+};
+
 inline int select_device(int device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);

@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void orient_desc_gpu_kernel(const uint8_t* __r
                                                              UMax um, int reverse0, int reverse1, orbx_keypoint* __restrict__ kps,
                                                              uint8_t* __restrict__ desc, orbx_keypoint* __restrict__ kps_host,
                                                              uint8_t* __restrict__ desc_host, int* __restrict__ d_nkp,
-                                                             int* __restrict__ h_nkp) {
+                                                             int* __restrict__ h_nkp, const int* __restrict__ d_overflow) {
   __shared__ __attribute__((aligned(16))) uint8_t raw_s[kKpPerBlock][kPW * kPS];
   __shared__ unsigned short hrow_s[kKpPerBlock][kPW * kHS];
   __shared__ uint8_t blur_s[kKpPerBlock][kBW * kBS];
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void orient_desc_gpu_kernel(const uint8_t* __r
   const int w = blockIdx.x * kKpPerBlock + wv;
   int n0 = 0, n1 = 0;
   for (int l = 0; l < cfg.n_levels; l++) { n0 += lvl_count[l]; if (cfg.n_cams > 1) n1 += lvl_count[ORBG_MAX_LEVELS + l]; }
-  if (w == 0 && (threadIdx.x & 63) == 0) { d_nkp[0] = n0; d_nkp[1] = n1; h_nkp[0] = n0; h_nkp[1] = n1; }
+  if (w == 0 && (threadIdx.x & 63) == 0) { d_nkp[0] = n0; d_nkp[1] = n1; h_nkp[0] = n0; h_nkp[1] = n1; h_nkp[2] = *d_overflow; }
   if (w >= n0 + n1) return;
   const int cam = w >= n0 ? 1 : 0;
   int s = cam ? w - n0 : w, level = 0;
@@ -1420,6 +1420,7 @@ struct orbx_handle {
   DevBuf<int> d_hdr, d_lvlcount, d_nkp, d_overflow;
   DevBuf<OctSel> d_selreg;
   PinnedBuf<int> h_nkp;          // [0] n left, [1] n right, [2] overflow flag
+  StreamSignal sig;
   OctCfg octcfg;
   int sel_bound = 0;             // upper bound of selected keypoints (sum of region capacities)
   bool gpu_octree = true;
@@ -1696,7 +1697,7 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   h->d_kps.release(); h->d_desc.release(); h->h_kps.release(); h->h_desc.release();
   h->d_uright.release(); h->d_depth.release(); h->d_sad.release(); h->h_stereo.release();
   h->d_cand.release(); h->d_hdr.release(); h->d_lvlcount.release(); h->d_nkp.release(); h->d_overflow.release();
-  h->d_selreg.release(); h->h_nkp.release();
+  h->d_selreg.release(); h->h_nkp.release(); h->sig.release();
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1790,7 +1791,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     const bool want_desc = desc_out[0] || desc_out[1];
     hipLaunchKernelGGL(orient_desc_gpu_kernel, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
                        oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,
-                       want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d);
+                       want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d, h->d_overflow.p);
     bool stereo_out = false;
     if (post) {
       if (post->stereo && ncams == 2) {
@@ -1799,9 +1800,8 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       }
       if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p))) return rc;
     }
-    ORBG_HIP(hipMemcpyAsync(h->h_nkp.h + 2, h->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, st));
     ORBG_HIP(hipGetLastError());
-    ORBG_HIP(hipStreamSynchronize(st));
+    if ((rc = h->sig.sync(st))) return rc;          // completion word in pinned memory; the overflow flag came with the keypoint counts
     if (h->h_nkp.h[2]) {
       // a level had more candidates / nodes than the LDS-resident quad-tree holds: redo this frame with the host trees
       ORBG_HIP(hipMemset(h->d_overflow.p, 0, sizeof(int)));

@@ -169,7 +169,7 @@ struct Huber { double delta_mono, dsqr_mono, delta_stereo, dsqr_stereo; };
 // ---------------------------------------------------------------------------------------------- kernels
 
 // residuals + chi2 + robust rho (computeActiveErrors + activeRobustChi2); block partial sums in fixed order
-struct HostRec { double chi2, scale, maxdiag; int ok; int pad; };   // what the host reads per LM trial (mapped pinned memory)
+struct HostRec { double chi2, scale, maxdiag; int ok; unsigned seq; };   // seq is written last: the host spins on it   // what the host reads per LM trial (mapped pinned memory)
 
 // Results of a solve, written by the GPU straight into the caller-visible pinned block (no copy commands): per edge a flag
 // byte (bit 0 = isDepthPositive() with the final estimate, bit 1 = outlier: chi2 > 5.991 / 7.815 or depth <= 0,
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
                                                const double* __restrict__ points, Cam cam, Huber hb, double* __restrict__ err,
                                                double* __restrict__ chi2, double* __restrict__ partial,
                                                int final_mode, unsigned* __restrict__ ticket, const double* __restrict__ scale_partial,
-                                               int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec) {
+                                               int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec,
+                                               unsigned seq) {
   __shared__ double red[256];
   __shared__ int s_last;
   const int k = blockIdx.x * 256 + threadIdx.x;
@@ -255,6 +256,9 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
       scale += np + i < 1024 ? parts[np + i] : __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     rec->chi2 = chi; rec->scale = scale; rec->maxdiag = 0; rec->ok = ok_flag ? *ok_flag : 1;
     *ticket = 0;
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned*>(&rec->seq) = seq;       // the host polls this word instead of hipStreamSynchronize
+    __threadfence_system();
   }
 }
 
@@ -1076,6 +1080,7 @@ struct lba_handle {
   DevBuf<int> d_pair_i1, d_pair_i2, d_pair_start, d_ok;
   DevBuf<PairItem> d_items;
   PinnedBuf<HostRec> rec;
+  unsigned rec_seq = 0;
   PinnedBuf<uint8_t> up_h, dl_h;               // per-call upload block (built in place) / download block
   DevBuf<uint8_t> up_d;
   DevBuf<uint8_t> d_flags;
@@ -1101,6 +1106,7 @@ extern "C" int lba_create(int device, int cap_poses, int cap_points, int cap_edg
   h->device = device;
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   if ((rc = h->rec.reserve(4)) || (rc = h->d_ok.reserve(4))) { delete h; return rc; }
+  memset(h->rec.h, 0, 4 * sizeof(HostRec));
   (void)cap_poses; (void)cap_points; (void)cap_edges;   // buffers grow on first use and are kept
   *out = h;
   return ORBG_OK;
@@ -1360,7 +1366,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     if (NE > 0)
       hipLaunchKernelGGL(k_errors, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, h->d_poses[buf].p, h->d_points[buf].p, cam, hb,
                          h->d_err.p, h->d_chi2.p, h->d_partial.p, final_mode, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u,
-                         h->d_ok.p, h->rec.d);
+                         h->d_ok.p, h->rec.d, final_mode ? ++h->rec_seq : 0u);
   };
   auto finish = [&](double lambda, int want_scale, int want_maxdiag, bool with_ok) -> int {
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, h->d_bp.p, h->d_bl.p, h->d_Hpp.p,
@@ -1430,7 +1436,25 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         if (NE > 0) {
           launch_errors(trial, 1);
           ORBG_HIP(hipGetLastError());
-          ORBG_HIP(hipStreamSynchronize(st));
+          {
+            // the last workgroup of k_errors publishes the record and then its sequence number: spin on that word (the
+            // runtime's completion path costs ~10 us per LM trial); fall back to a stream sync if it does not arrive
+            volatile unsigned* w = &h->rec.h->seq;
+            const unsigned want = h->rec_seq;
+            bool got = false;
+            if (!getenv("ORBG_NO_POLL")) {
+              timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+              for (unsigned spins = 0; !got; spins++) {
+                if (*w == want) { got = true; break; }
+                if ((spins & 0xFFFF) == 0xFFFF) {
+                  timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+                  if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 50.0) break;
+                }
+              }
+              __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
+            if (!got) ORBG_HIP(hipStreamSynchronize(st));
+          }
         } else if ((rc2 = finish(lambda, 1, 0, true))) {
           return rc2;
         }
@@ -1590,6 +1614,7 @@ namespace {
 
 constexpr int kPoThreads = 256;
 constexpr int kPoMaxPer = 16;      // correspondences per thread (n <= 4096)
+constexpr int kPoLdsN = 1024;      // correspondences whose inputs are staged in LDS
 constexpr int kPoRow = 8 * 33;     // one reduction row: 8 segments of 32 values, padded against LDS bank conflicts
 
 // Block-wide sums of NV per-thread values in a fixed order: transpose through LDS, 8 threads per value add 32
@@ -1682,11 +1707,12 @@ __device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, fl
 // each round.  The LM state (pose, lambda, gains) is kept identically in every thread -- all of them read the same
 // block sums from LDS and run the same arithmetic -- so the control flow needs no broadcast; the 6x6 solve runs on
 // lanes 0..5 of each wave.
-__global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float* __restrict__ Xw, const float* __restrict__ ou,
-                                                             const float* __restrict__ ov, const float* __restrict__ our,
-                                                             const float* __restrict__ oinv, Cam cam, PoseQ T0,
+__global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float* Xw, const float* ou, const float* ov, const float* our,
+                                                             const float* oinv, Cam cam, PoseQ T0,
                                                              PoseQ* __restrict__ T_out, uint8_t* __restrict__ outlier_out,
-                                                             int* __restrict__ stats /*n_bad, iters[4]*/, double* __restrict__ chi_out) {
+                                                             int* __restrict__ stats /*n_bad, iters[4], .., [7] = seq*/,
+                                                             double* __restrict__ chi_out, unsigned seq) {
+  __shared__ float s_in[7 * kPoLdsN];                    // correspondences staged once (they are re-read ~36 times)
   __shared__ double s_acc[28 * kPoRow];
   __shared__ double s_part[28 * 8];
   __shared__ double red[28];
@@ -1697,13 +1723,19 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   const double dM = (float)sqrt(5.991), dS = (float)sqrt(7.815);
   const double dsqM = dM * dM, dsqS = dS * dS;
   for (int i = tid; i < n; i += kPoThreads) { s_chi2[i] = 0; s_out[i] = 0; }
+  if (n <= kPoLdsN) {
+    // the inputs may sit in mapped host memory (zero-copy): read them exactly once
+    for (int i = tid; i < 3 * n; i += kPoThreads) s_in[i] = Xw[i];
+    for (int i = tid; i < n; i += kPoThreads) { s_in[3 * n + i] = ou[i]; s_in[4 * n + i] = ov[i]; s_in[5 * n + i] = our[i]; s_in[6 * n + i] = oinv[i]; }
+    Xw = s_in; ou = s_in + 3 * n; ov = s_in + 4 * n; our = s_in + 5 * n; oinv = s_in + 6 * n;
+  }
   double x[6] = {0, 0, 0, 0, 0, 0};
   double lambda = 0, ni = 2, currentChi = 0;
   int nBadLM = 0;
   bool robust = true;
   PoseQ T = T0;
   int nBad = 0;
-  if (tid == 0) { for (int i = 0; i < 8; i++) stats[i] = 0; for (int i = 0; i < 4; i++) chi_out[i] = 0; }
+  if (tid == 0) { for (int i = 0; i < 7; i++) stats[i] = 0; for (int i = 0; i < 4; i++) chi_out[i] = 0; }
   __syncthreads();
   for (int round = 0; round < 4; round++) {
     T = T0;                                                   // setEstimate(toSE3Quat(mTcw)) every round (:1191)
@@ -1854,6 +1886,9 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   }
   for (int i = tid; i < n; i += kPoThreads) outlier_out[i] = s_out[i];
   if (tid == 0) { *T_out = T; stats[0] = nBad; }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) { *reinterpret_cast<volatile int*>(&stats[7]) = (int)seq; __threadfence_system(); }   // results are complete: the host spins on this word
 }
 
 }  // namespace
@@ -1883,9 +1918,15 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   memcpy(hs + 4 * (size_t)n, p->v, (size_t)n * 4);
   memcpy(hs + 5 * (size_t)n, p->ur, (size_t)n * 4);
   memcpy(hs + 6 * (size_t)n, p->inv_sigma2, (size_t)n * 4);
-  ORBG_HIP(hipMemcpyAsync(sc.dev.p, sc.stage.h, in_bytes, hipMemcpyHostToDevice, 0));
-  const float* dX = reinterpret_cast<const float*>(sc.dev.p);
-  uint8_t* dout = sc.dev.p + out_off;
+  // small problems: the kernel reads its inputs straight from this pinned block (once, into LDS); large ones get a device copy.
+  // Results always land in the pinned block, followed by a sequence number the host spins on.
+  const float* dX;
+  if (n <= kPoLdsN) dX = reinterpret_cast<const float*>(sc.stage.d);
+  else {
+    ORBG_HIP(hipMemcpyAsync(sc.dev.p, sc.stage.h, in_bytes, hipMemcpyHostToDevice, 0));
+    dX = reinterpret_cast<const float*>(sc.dev.p);
+  }
+  uint8_t* dout = sc.stage.d + out_off;
   PoseQ* dT = reinterpret_cast<PoseQ*>(dout);
   double* dchi = reinterpret_cast<double*>(dout + sizeof(PoseQ));
   int* dstats = reinterpret_cast<int*>(dout + sizeof(PoseQ) + 4 * sizeof(double));
@@ -1899,11 +1940,29 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
     T0.t[0] = T[3]; T0.t[1] = T[7]; T0.t[2] = T[11];
   }
   Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
+  static thread_local unsigned po_seq = 0;
+  po_seq = (po_seq + 1) & 0x7FFFFFFFu;
+  if (po_seq == 0) po_seq = 1;
+  volatile int* seq_word = reinterpret_cast<volatile int*>(sc.stage.h + out_off + sizeof(PoseQ) + 4 * sizeof(double)) + 7;
+  *seq_word = 0;
   hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, 0, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n, dX + 5 * (size_t)n,
-                     dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi);
+                     dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
   ORBG_HIP(hipGetLastError());
-  ORBG_HIP(hipMemcpyAsync(sc.stage.h + out_off, dout, out_bytes, hipMemcpyDeviceToHost, 0));
-  ORBG_HIP(hipStreamSynchronize(0));
+  {
+    bool got = false;
+    if (!getenv("ORBG_NO_POLL")) {
+      timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (unsigned spins = 0; !got; spins++) {
+        if (*seq_word == (int)po_seq) { got = true; break; }
+        if ((spins & 0xFFFF) == 0xFFFF) {
+          timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+          if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 100.0) break;
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (!got) ORBG_HIP(hipStreamSynchronize(0));
+  }
   const uint8_t* ho = sc.stage.h + out_off;
   PoseQ Tf;
   memcpy(&Tf, ho, sizeof(PoseQ));

@@ -756,6 +756,7 @@ struct orbm_frame {
   uint32_t occ[kOccBits / 32];
   size_t copy_lo = 0, copy_hi = 0;       // part of the staging block that needs a device copy
   unsigned search_seq = 0;               // selects the overflow counter; the kernel clears the other one
+  StreamSignal sig;                      // completion word in pinned memory (host spins instead of hipStreamSynchronize)
   // query-side scratch
   DevBuf<int> d_counter;
   PinnedBuf<uint32_t> list;              // candidate lists: written by the kernels (one coalesced burst per query) into
@@ -822,7 +823,7 @@ extern "C" int orbm_frame_destroy(orbm_frame* f) {
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   f->d_kps.release(); f->d_desc.release(); f->d_uright.release(); f->d_depth.release(); f->d_cell_of.release();
   f->d_cell_start.release(); f->d_cell_items.release(); f->stage.release(); f->d_stage.release();
-  f->d_counter.release(); f->list.release(); f->results.release();
+  f->d_counter.release(); f->list.release(); f->results.release(); f->sig.release();
   for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   delete f;
@@ -1202,7 +1203,7 @@ static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
     f->search_seq++;
     launch((int)std::min<size_t>(f->list.cap, (size_t)1 << 30), cur, nxt);
     ORBG_HIP(hipGetLastError());
-    ORBG_HIP(hipStreamSynchronize(f->stream));
+    if ((rc = f->sig.sync(f->stream))) return rc;
     // the end of the furthest list segment tells whether the overflow region was large enough
     size_t total = 0;
     const QResult* R = f->results.h;

@@ -21,3 +21,48 @@ extern "C" int orbg_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+// ---- StreamSignal (common.hpp)
+#include <time.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace orbg {
+
+__global__ void orbg_signal_kernel(volatile unsigned* flag, unsigned seq) {
+  *flag = seq;
+  __threadfence_system();
+}
+
+int StreamSignal::post(hipStream_t st) {
+  if (!word.h) { int rc = init(); if (rc) return rc; }
+  seq++;
+  hipLaunchKernelGGL(orbg_signal_kernel, dim3(1), dim3(1), 0, st, (volatile unsigned*)word.d, seq);
+  ORBG_HIP(hipGetLastError());
+  return ORBG_OK;
+}
+
+int StreamSignal::wait(hipStream_t st) {
+  static const bool use_poll = getenv("ORBG_NO_POLL") == nullptr;
+  if (use_poll) {
+    volatile unsigned* w = word.h;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0;; spins++) {
+      if (*w == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return ORBG_OK; }
+#if defined(__x86_64__)
+      _mm_pause();
+#endif
+      if ((spins & 0x3FFF) == 0x3FFF) {           // every ~16k spins: give up on polling after 50 ms (error or very long kernel)
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 50.0) break;
+      }
+    }
+  }
+  ORBG_HIP(hipStreamSynchronize(st));
+  return ORBG_OK;
+}
+
+}  // namespace orbg
