@@ -1086,7 +1086,7 @@ struct lba_handle {
   DevBuf<uint8_t> d_flags;
   DevBuf<double> d_scale_partial;
   DevBuf<unsigned> d_ticket;
-  std::vector<int> s_pose_deg, s_point_deg, s_pose_col, s_point_col, s_pf_deg, s_f1, s_f2, s_f3, s_fill;   // host scratch kept across calls
+  std::vector<int> s_pose_deg, s_point_deg, s_pose_col, s_point_col, s_pf_deg, s_f1, s_f2, s_f3, s_fill, s_row_off;   // host scratch kept across calls
   float last_ms = 0;
   // lba_solve_async: the library-owned "LocalMapping" thread of this handle
   std::thread worker;
@@ -1190,11 +1190,15 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   for (int i = 0; i < NP; i++) if (!p->pose_fixed[i] && pose_deg[i] > 0) pose_col_v[i] = nP++;
   for (int i = 0; i < NX; i++) if (point_deg[i] > 0) point_col_v[i] = nL++;
   // free-pose degree of every active point -> number of (pose pair, landmark) items
-  std::vector<int>& pf_deg = h->s_pf_deg;
-  pf_deg.assign(nL + 1, 0);
+  // one pass over the edges: free-pose degree of every active point, edges per active point, edges per free pose
+  std::vector<int>& pf_deg = h->s_pf_deg; std::vector<int>& pt_cnt = h->s_f1; std::vector<int>& ps_cnt = h->s_f2;
+  pf_deg.assign(nL + 1, 0); pt_cnt.assign(nL + 1, 0); ps_cnt.assign(nP + 1, 0);
   int n_free_edges = 0;
-  for (int k = 0; k < NE; k++)
-    if (pose_col_v[p->edges[k].pose] >= 0) { pf_deg[point_col_v[p->edges[k].point]]++; n_free_edges++; }
+  for (int k = 0; k < NE; k++) {
+    const int lc = point_col_v[p->edges[k].point], pc = pose_col_v[p->edges[k].pose];
+    pt_cnt[lc]++;
+    if (pc >= 0) { pf_deg[lc]++; ps_cnt[pc]++; n_free_edges++; }
+  }
   size_t n_items = 0;
   for (int l = 0; l < nL; l++) n_items += (size_t)pf_deg[l] * (pf_deg[l] + 1) / 2;
   const int n_pairs_all = nP * (nP + 1) / 2;
@@ -1224,16 +1228,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   memcpy(pose_col, pose_col_v.data(), 4 * (size_t)NP);
   memcpy(point_col, point_col_v.data(), 4 * (size_t)NX);
   // CSR: edges per active point (creation order); per free pose; per active point restricted to free poses (sorted by col)
-  for (int i = 0; i <= nL; i++) pt_start[i] = 0;
-  for (int i = 0; i <= nP; i++) ps_start[i] = 0;
-  for (int k = 0; k < NE; k++) {
-    const int lc = point_col[p->edges[k].point], pc = pose_col[p->edges[k].pose];
-    pt_start[lc + 1]++;
-    if (pc >= 0) ps_start[pc + 1]++;
-  }
-  pf_start[0] = 0;
-  for (int i = 0; i < nL; i++) { pt_start[i + 1] += pt_start[i]; pf_start[i + 1] = pf_start[i] + pf_deg[i]; }
-  for (int i = 0; i < nP; i++) ps_start[i + 1] += ps_start[i];
+  pt_start[0] = 0; pf_start[0] = 0; ps_start[0] = 0;
+  for (int i = 0; i < nL; i++) { pt_start[i + 1] = pt_start[i] + pt_cnt[i]; pf_start[i + 1] = pf_start[i] + pf_deg[i]; }
+  for (int i = 0; i < nP; i++) ps_start[i + 1] = ps_start[i] + ps_cnt[i];
   {
     std::vector<int>& f1 = h->s_f1; std::vector<int>& f2 = h->s_f2; std::vector<int>& f3 = h->s_f3;
     f1.assign(pt_start, pt_start + nL); f2.assign(ps_start, ps_start + nP); f3.assign(pf_start, pf_start + nL);
@@ -1242,30 +1239,41 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       pt_edges[f1[lc]++] = k;
       if (pc >= 0) { ps_edges[f2[pc]++] = k; pf_edges[f3[lc]++] = k; }
     }
+    // per landmark: stable insertion sort of its free observations by pose column (a handful each), then count its
+    // (pose pair) items; pair id = row_off[i1] + i2
+    std::vector<int>& row_off = h->s_row_off;
+    row_off.resize(std::max(nP, 1));
+    for (int i1 = 0; i1 < nP; i1++) row_off[i1] = i1 * nP - i1 * (i1 - 1) / 2 - i1;
+    for (int i = 0; i <= n_pairs_all; i++) pair_start[i] = 0;
     for (int l = 0; l < nL; l++) {
-      // stable insertion sort by pose column (a handful of observations per landmark)
-      for (int a2 = pf_start[l] + 1; a2 < pf_start[l + 1]; a2++) {
+      const int b0 = pf_start[l], e0 = pf_start[l + 1];
+      for (int a2 = b0 + 1; a2 < e0; a2++) {
         const int e = pf_edges[a2], key = pose_col[p->edges[e].pose];
         int b2 = a2 - 1;
-        while (b2 >= pf_start[l] && pose_col[p->edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
+        while (b2 >= b0 && pose_col[p->edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
         pf_edges[b2 + 1] = e;
       }
-      for (int j = pf_start[l]; j < pf_start[l + 1]; j++) pf_col[j] = pose_col[p->edges[pf_edges[j]].pose];
+      for (int j = b0; j < e0; j++) pf_col[j] = pose_col[p->edges[pf_edges[j]].pose];
+      for (int a2 = b0; a2 < e0; a2++) {
+        const int ro = row_off[pf_col[a2]] + 1;
+        for (int b2 = a2; b2 < e0; b2++) pair_start[ro + pf_col[b2]]++;
+      }
     }
   }
   // pose pairs (i1 <= i2) and their landmark items, grouped by pair (counting sort keeps landmark order)
   auto pair_id = [&](int i1, int i2) { return i1 * nP - i1 * (i1 - 1) / 2 + (i2 - i1); };
-  for (int i = 0; i <= n_pairs_all; i++) pair_start[i] = 0;
-  for (int l = 0; l < nL; l++)
-    for (int a2 = pf_start[l]; a2 < pf_start[l + 1]; a2++)
-      for (int b2 = a2; b2 < pf_start[l + 1]; b2++) pair_start[pair_id(pf_col[a2], pf_col[b2]) + 1]++;
   for (int i = 0; i < n_pairs_all; i++) pair_start[i + 1] += pair_start[i];
   {
     std::vector<int>& fill = h->s_fill;
     fill.assign(pair_start, pair_start + n_pairs_all);
-    for (int l = 0; l < nL; l++)
-      for (int a2 = pf_start[l]; a2 < pf_start[l + 1]; a2++)
-        for (int b2 = a2; b2 < pf_start[l + 1]; b2++) items[fill[pair_id(pf_col[a2], pf_col[b2])]++] = PairItem{pf_edges[a2], pf_edges[b2], l};
+    const std::vector<int>& row_off = h->s_row_off;
+    for (int l = 0; l < nL; l++) {
+      const int b0 = pf_start[l], e0 = pf_start[l + 1];
+      for (int a2 = b0; a2 < e0; a2++) {
+        const int ro = row_off[pf_col[a2]], ea = pf_edges[a2];
+        for (int b2 = a2; b2 < e0; b2++) items[fill[ro + pf_col[b2]]++] = PairItem{ea, pf_edges[b2], l};
+      }
+    }
   }
   // keep every pair (diagonals always; off-diagonals even if empty so that S is fully written)
   for (int i1 = 0; i1 < nP; i1++)
