@@ -247,8 +247,9 @@ def main():
             tpo = time.perf_counter()
             if timed:
                 stage["pose_opt"] += tpo - t5
-            t5 = tpo
-        t6 = t7 = t5
+        else:
+            tpo = t5
+        t6 = t7 = tpo
         if i % FRAMES_PER_KF == 0:
             mp = local_map_for(frames, k)
             wv, keep = views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
@@ -269,7 +270,7 @@ def main():
                     stats["lba_iters"] += sum(out.iters); stats["lba_calls"] += 1; stats["lba_s"] += t7 - t6
         if timed:
             for key, dt in (("extract", t1 - t0), ("stereo", t2 - t1), ("grid", t3 - t2), ("match_frame", t4 - t3),
-                            ("match_map", t5 - t4), ("map_upload", t6 - t5), ("lba", t7 - t6)):
+                            ("match_map", t5 - t4), ("map_upload", t6 - tpo), ("lba", t7 - t6)):
                 stage[key] += dt
             if args.profile_stages:
                 tm = ex.timings()
