@@ -44,8 +44,7 @@ int StreamSignal::post(hipStream_t st) {
 }
 
 int StreamSignal::wait(hipStream_t st) {
-  static const bool use_poll = getenv("ORBG_NO_POLL") == nullptr;
-  if (use_poll) {
+  if (!getenv("ORBG_NO_POLL")) {
     volatile unsigned* w = word.h;
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -501,3 +501,31 @@ def test_keyframe_wire_blocks_and_l1_score(scene):
     g = api.BowScoreL1(qw, qv, cs, cw, cv)
     o = ob.score_l1(qw, qv, cs, cw, cv)
     assert np.array_equal(g, o) and abs(g[-1] - 1.0) < 1e-12
+
+
+def test_completion_fallback_path_gives_same_results(scene, monkeypatch):
+    """ORBG_NO_POLL=1 switches every completion wait back to hipStreamSynchronize: results must not depend on the wait."""
+    L, R, _ = scene.stereo_pair(4)
+    p = scene.frame_view_params()
+    fv, keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
+    prob = synth.make_lba_problem(n_free=5, n_fixed=2, n_points=200)
+    lp, keep2 = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    pr = synth.make_pose_opt_problem(n=300, outlier_frac=0.1, mono_frac=0.2, seed=9)
+    pp, keep3 = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"])
+    outs = []
+    for no_poll in (False, True):
+        if no_poll:
+            monkeypatch.setenv("ORBG_NO_POLL", "1")
+        else:
+            monkeypatch.delenv("ORBG_NO_POLL", raising=False)
+        ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
+        F = api.Frame()
+        res = ex.frame_stereo(F, fv, L, R, float(scene.cam["bf"]), float(scene.cam["b"]))
+        opt = api.Optimizer()
+        lo = opt.LocalBundleAdjustment(lp)
+        po = opt.PoseOptimization(pp)
+        outs.append((res, lo.poses.copy(), lo.iters, po.Tcw.copy(), po.outliers))
+    a, b = outs
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
