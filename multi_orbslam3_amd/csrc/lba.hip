@@ -27,6 +27,7 @@
 #include <thread>
 
 #include "common.hpp"
+#include "wave.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -131,6 +132,57 @@ __device__ inline void pose_oplus(const PoseQ& T, const double* u, PoseQ* out) {
   out->q[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
   out->q[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
   quat_normalize(out->q);
+}
+
+// pose_oplus with the divisions hoisted (one reciprocal of theta, one per normalisation) and sincos(): the same formulas as
+// SE3Quat::exp / operator* / normalizeRotation, fewer dependent FP64 divisions.  Used where the update runs on the critical
+// path of a single workgroup (PoseOptimization); results differ from pose_oplus in the last bits only.
+__device__ inline void pose_oplus_fast(const PoseQ& T, const double* u, PoseQ* out) {
+  const double om0 = u[0], om1 = u[1], om2 = u[2];
+  const double th2 = om0 * om0 + om1 * om1 + om2 * om2;
+  const double theta = sqrt(th2);
+  const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+  double O2[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+  double R[9], V[9];
+  if (theta < 0.00001) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+  } else {
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    const double it = 1.0 / theta, it2 = it * it;
+    const double a = sn * it, b = (1 - cs) * it2, cc = (theta - sn) * (it2 * it);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const double I = (i % 4 == 0 ? 1.0 : 0.0);
+      R[i] = I + a * O[i] + b * O2[i];
+      V[i] = I + b * O[i] + cc * O2[i];
+    }
+  }
+  double eq[4], et[3];
+  quat_from_R(R, eq);
+#pragma unroll
+  for (int i = 0; i < 3; i++) et[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+  {
+    if (eq[3] < 0) { eq[0] = -eq[0]; eq[1] = -eq[1]; eq[2] = -eq[2]; eq[3] = -eq[3]; }
+    const double in = 1.0 / sqrt(eq[0] * eq[0] + eq[1] * eq[1] + eq[2] * eq[2] + eq[3] * eq[3]);
+    eq[0] *= in; eq[1] *= in; eq[2] *= in; eq[3] *= in;
+  }
+  double rt[3];
+  quat_rotate(eq, T.t, rt);
+  out->t[0] = et[0] + rt[0]; out->t[1] = et[1] + rt[1]; out->t[2] = et[2] + rt[2];
+  const double* a2 = eq; const double* b2 = T.q;
+  double q3 = a2[3] * b2[3] - a2[0] * b2[0] - a2[1] * b2[1] - a2[2] * b2[2];
+  double q0 = a2[3] * b2[0] + a2[0] * b2[3] + a2[1] * b2[2] - a2[2] * b2[1];
+  double q1 = a2[3] * b2[1] + a2[1] * b2[3] + a2[2] * b2[0] - a2[0] * b2[2];
+  double q2 = a2[3] * b2[2] + a2[2] * b2[3] + a2[0] * b2[1] - a2[1] * b2[0];
+  if (q3 < 0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
+  const double in = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  out->q[0] = q0 * in; out->q[1] = q1 * in; out->q[2] = q2 * in; out->q[3] = q3 * in;
 }
 
 // 1/d to ~1 ulp: hardware seed + two Newton-Raphson steps
@@ -1649,6 +1701,15 @@ __device__ inline void po_block_reduce(const double* vals, double* s_acc, double
   __syncthreads();
 }
 
+// Block-wide sum of ONE double per thread: DPP tree inside each wavefront, the four wave totals through LDS, added in wave
+// order by every thread (one barrier; `slot` alternates between consecutive calls so that no second barrier is needed).
+__device__ __forceinline__ double po_block_sum(double v, double (*wsum)[4], int slot) {
+  const double w = wave_sum_f64(v);
+  if ((threadIdx.x & 63) == 0) wsum[slot][threadIdx.x >> 6] = w;
+  __syncthreads();
+  return ((wsum[slot][0] + wsum[slot][1]) + wsum[slot][2]) + wsum[slot][3];
+}
+
 __device__ __forceinline__ double po_readlane(double v, int lane) {   // lane must be wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -1724,6 +1785,8 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   __shared__ double s_acc[28 * kPoRow];
   __shared__ double s_part[28 * 8];
   __shared__ double red[28];
+  __shared__ double s_wsum[2][4];
+  int sum_slot = 0;
   __shared__ double s_chi2[kPoThreads * kPoMaxPer];      // last evaluated chi2 of every correspondence
   __shared__ uint8_t s_out[kPoThreads * kPoMaxPer];      // mvbOutlier
   const int tid = threadIdx.x;
@@ -1749,8 +1812,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
     T = T0;                                                   // setEstimate(toSE3Quat(mTcw)) every round (:1191)
     double cnt = 0;
     for (int i = tid; i < n; i += kPoThreads) cnt += !s_out[i];
-    po_block_reduce<1>(&cnt, s_acc, s_part, red);
-    const int n_active = (int)red[0];
+    const int n_active = (int)po_block_sum(cnt, s_wsum, sum_slot); sum_slot ^= 1;
     int done = 0;
     bool ok = n_active > 0;
     for (int it = 0; it < 10 && ok; it++) {
@@ -1825,7 +1887,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
       for (;;) {
         const bool ok2 = po_solve6(Hrow, b_li, li, lambda, x);
         PoseQ Tt;
-        pose_oplus(T, x, &Tt);                              // update with whatever x holds, as g2o does
+        pose_oplus_fast(T, x, &Tt);                         // update with whatever x holds, as g2o does
         double tchi = 0;
         // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
         for (int i = tid; i < n; i += kPoThreads) {
@@ -1841,8 +1903,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
           if (robust) huber(c2, mono ? dM : dS, mono ? dsqM : dsqS, &rho0, &rho1);
           tchi += rho0;
         }
-        po_block_reduce<1>(&tchi, s_acc, s_part, red);
-        double tempChi = red[0];
+        double tempChi = po_block_sum(tchi, s_wsum, sum_slot); sum_slot ^= 1;
         if (!ok2) tempChi = 1.7976931348623157e308;
         rho = currentChi - tempChi;
         double scale = 0;
@@ -1887,8 +1948,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
       s_out[i] = bad;
       bl += bad;
     }
-    po_block_reduce<1>(&bl, s_acc, s_part, red);
-    nBad = (int)red[0];
+    nBad = (int)po_block_sum(bl, s_wsum, sum_slot); sum_slot ^= 1;
     if (round == 2) robust = false;                          // setRobustKernel(0)
     if (n < 10) break;                                        // optimizer.edges().size() < 10
   }

@@ -47,4 +47,17 @@ __device__ __forceinline__ unsigned wave_min(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// FP64 sum over the lanes in a fixed (tree) order, returned in every lane: each DPP step moves the two 32-bit halves
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#define ORBG_DPP64(ctrl, rmask)                                                                    \
+  {                                                                                                \
+    const int lo = ORBG_DPP(0, __double2loint(v), ctrl, rmask), hi = ORBG_DPP(0, __double2hiint(v), ctrl, rmask); \
+    v += __hiloint2double(hi, lo);                                                                 \
+  }
+  ORBG_DPP64(0x111, 0xF) ORBG_DPP64(0x112, 0xF) ORBG_DPP64(0x114, 0xF) ORBG_DPP64(0x118, 0xF) ORBG_DPP64(0x142, 0xA) ORBG_DPP64(0x143, 0xC)
+#undef ORBG_DPP64
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
 }  // namespace orbg
