@@ -46,6 +46,50 @@ def main():
                         out_poses=o.poses, out_points=o.points, out_outlier=o.edge_outlier, out_chi2=o.edge_chi2,
                         trace=o.trace_rows(), iters=np.array(o.iters), status=np.array([o.status]))
     print("kps", len(kl), len(kr), "stereo", int((ur > 0).sum()), "lba iters", o.iters, "edges", p.n_edges)
+    make_matching_pose_bow(sc)
+
+
+def make_matching_pose_bow(sc):
+    """Matchers (frame / KeyFrame variants), PoseOptimization, bag-of-words pieces, KeyFrame wire block: inputs + oracle outputs."""
+    rng = np.random.RandomState(7)
+    f0, f1, kf = [helpers.oracle_stereo_frame(sc, k, 300) for k in (0, 2, 1)]
+    mp = helpers.local_map_from(sc, [f0], rng)
+    n = len(kf["kps"])
+    T = synth.perturb_pose(kf["Tcw"], rng).astype(np.float32)
+    fvp = sc.frame_view_params()
+    fv, keep = helpers.frame_view_of(sc, kf)
+    wv, keep2 = helpers.world_view_of(mp)
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    loc = ob.search_local_points(fv, wv, T, 3.0, False, 0.0, 0.8, amp0, aob0)
+    S = T.copy(); S[:3, :] *= np.float32(1.3)
+    sim = ob.search_by_projection_sim3(fv, wv, S, amp0, 5, 1.5)
+    node = lambda d: (d[:, 0].astype(np.int64) >> 4)
+    n1, s1, i1 = views.featvec_from_nodes(node(f1["desc"])); n2, s2, i2 = views.featvec_from_nodes(node(kf["desc"]))
+    fv1, k1 = views.featvec_view(n1, s1, i1); fv2, k2 = views.featvec_view(n2, s2, i2)
+    v1 = (f1["depth"] > 0).astype(np.uint8); v2 = (kf["depth"] > 0).astype(np.uint8)
+    bow = ob.search_by_bow_kf(fv, fv2, v2, f1["desc"], v1, f1["kps"]["angle"], fv1, 0.8, True)
+    pr = synth.make_pose_opt_problem(n=200, outlier_frac=0.1, mono_frac=0.25, seed=21)
+    pp, keep3 = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"])
+    po = ob.pose_optimize(pp)
+    voc = synth.make_vocabulary(k=6, L=3, seed=3, descriptors=kf["desc"])
+    vv, keep4 = views.vocab_view(voc["child_start"], voc["child_ids"], voc["desc"], voc["weight"], voc["word_id"], 3)
+    (bw, bv), (fn, fs, ff) = ob.vocab_bow(vv, kf["desc"], 1)
+    dd_start = np.array([0, 1, 4, 4, 11, 30], np.int32)
+    dd = ob.distinctive_descriptors(kf["desc"][:30], dd_start)
+    wire = ob.wire_pack(kf["kps"], kf["desc"])
+    np.savez_compressed(os.path.join(OUT, "matching_pose_bow.npz"),
+                        kf_kps=kf["kps"], kf_desc=kf["desc"], kf_uright=kf["uright"], kf_depth=kf["depth"],
+                        bounds=np.array(fvp["bounds"], np.float32), cam=np.array(fvp["cam"], np.float32), T=T, S=S,
+                        mp_pos=mp["pos"], mp_normal=mp["normal"], mp_min=mp["min_dist"], mp_max=mp["max_dist"], mp_desc=mp["desc"],
+                        mp_nobs=mp["n_obs"], mp_bad=mp["bad"],
+                        loc_amp=loc[0], loc_aob=loc[1], loc_n=np.array([loc[2]]), sim_matched=sim[0], sim_n=np.array([sim[1]]),
+                        f1_desc=f1["desc"], f1_angle=f1["kps"]["angle"], v1=v1, v2=v2, n1=n1, s1=s1, i1=i1, n2=n2, s2=s2, i2=i2,
+                        bow_m12=bow[0], bow_n=np.array([bow[1]]),
+                        po_Xw=pr["Xw"], po_u=pr["u"], po_v=pr["v"], po_ur=pr["ur"], po_w=pr["inv_sigma2"], po_cam=np.array(pr["cam"], np.float32),
+                        po_T0=pr["Tcw"], po_T=po.Tcw, po_out=po.outliers, po_iters=np.array(po.iters), po_inl=np.array([po.n_inliers]),
+                        voc_cs=voc["child_start"], voc_ci=voc["child_ids"], voc_desc=voc["desc"], voc_w=voc["weight"], voc_word=voc["word_id"],
+                        bow_word=bw, bow_value=bv, fv_node=fn, fv_start=fs, fv_feat=ff, dd_start=dd_start, dd_best=dd, wire=wire)
+    print("local", loc[2], "sim3", sim[1], "bow_kf", bow[1], "pose_opt", po.iters, po.n_inliers, "words", len(bw))
 
 
 if __name__ == "__main__":

@@ -68,3 +68,60 @@ def test_gpu_reproduces_golden():
     assert o.status == int(b["status"][0]) and tuple(o.iters) == tuple(b["iters"])
     assert np.abs(o.poses - b["out_poses"]).max() <= 1e-4 and np.abs(o.points - b["out_points"]).max() <= 1e-4
     assert np.array_equal(o.edge_outlier, b["out_outlier"])
+
+
+def _fixture_views(g):
+    from multi_orbslam3_amd import views as V
+    fv, k1 = V.frame_view(g["kf_kps"], g["kf_desc"], g["kf_uright"], g["kf_depth"], tuple(g["bounds"]), tuple(g["cam"]), 8, 1.2)
+    wv, k2 = V.worldpoints_view(g["mp_pos"], g["mp_normal"], g["mp_min"], g["mp_max"], g["mp_desc"], g["mp_nobs"], g["mp_bad"])
+    fv1, k3 = V.featvec_view(g["n1"], g["s1"], g["i1"]); fv2, k4 = V.featvec_view(g["n2"], g["s2"], g["i2"])
+    pp, k5 = V.pose_opt_problem(g["po_Xw"], g["po_u"], g["po_v"], g["po_ur"], g["po_w"], tuple(g["po_cam"]), g["po_T0"])
+    vv, k6 = V.vocab_view(g["voc_cs"], g["voc_ci"], g["voc_desc"], g["voc_w"], g["voc_word"], 3)
+    return fv, wv, fv1, fv2, pp, vv, (k1, k2, k3, k4, k5, k6)
+
+
+def test_oracle_reproduces_golden_matching_pose_bow():
+    g = _load("matching_pose_bow.npz")
+    fv, wv, fv1, fv2, pp, vv, keep = _fixture_views(g)
+    n = len(g["kf_kps"])
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    loc = ob.search_local_points(fv, wv, g["T"], 3.0, False, 0.0, 0.8, amp0, aob0)
+    assert loc[2] == int(g["loc_n"][0]) and np.array_equal(loc[0], g["loc_amp"]) and np.array_equal(loc[1], g["loc_aob"])
+    sim = ob.search_by_projection_sim3(fv, wv, g["S"], amp0, 5, 1.5)
+    assert sim[1] == int(g["sim_n"][0]) and np.array_equal(sim[0], g["sim_matched"])
+    bow = ob.search_by_bow_kf(fv, fv2, g["v2"], g["f1_desc"], g["v1"], g["f1_angle"], fv1, 0.8, True)
+    assert bow[1] == int(g["bow_n"][0]) and np.array_equal(bow[0], g["bow_m12"])
+    po = ob.pose_optimize(pp)
+    assert tuple(po.iters) == tuple(g["po_iters"]) and po.n_inliers == int(g["po_inl"][0]) and np.array_equal(po.outliers, g["po_out"])
+    assert np.allclose(po.Tcw, g["po_T"], atol=1e-6)
+    (bw, bv), (fn, fs, ff) = ob.vocab_bow(vv, g["kf_desc"], 1)
+    assert np.array_equal(bw, g["bow_word"]) and np.array_equal(bv, g["bow_value"])
+    assert np.array_equal(fn, g["fv_node"]) and np.array_equal(fs, g["fv_start"]) and np.array_equal(ff, g["fv_feat"])
+    assert np.array_equal(ob.distinctive_descriptors(g["kf_desc"][:30], g["dd_start"]), g["dd_best"])
+    assert np.array_equal(ob.wire_pack(g["kf_kps"], g["kf_desc"]), g["wire"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_matching_pose_bow():
+    from multi_orbslam3_amd import api
+    g = _load("matching_pose_bow.npz")
+    fv, wv, fv1, fv2, pp, vv, keep = _fixture_views(g)
+    n = len(g["kf_kps"])
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    F = api.Frame().upload(fv, keep)
+    LM = api.LocalMap().upload(wv)
+    loc = api.ORBmatcher(0.8).SearchLocalPoints(F, LM, g["T"], 3.0, False, 0.0, amp0, aob0)
+    assert loc[2] == int(g["loc_n"][0]) and np.array_equal(loc[0], g["loc_amp"]) and np.array_equal(loc[1], g["loc_aob"])
+    sim = api.ORBmatcher(0.8).SearchByProjectionSim3(F, g["S"], LM, amp0, 5, 1.5)
+    assert sim[1] == int(g["sim_n"][0]) and np.array_equal(sim[0], g["sim_matched"])
+    bow = api.ORBmatcher(0.8, True).SearchByBoWKF(F, fv2, g["v2"], g["f1_desc"], g["v1"], g["f1_angle"], fv1)
+    assert bow[1] == int(g["bow_n"][0]) and np.array_equal(bow[0], g["bow_m12"])
+    po = api.Optimizer().PoseOptimization(pp)
+    assert tuple(po.iters) == tuple(g["po_iters"]) and po.n_inliers == int(g["po_inl"][0]) and np.array_equal(po.outliers, g["po_out"])
+    assert np.abs(po.Tcw - g["po_T"]).max() <= 1e-4
+    voc = api.ORBVocabulary(vv, keep)
+    (bw, bv), (fn, fs, ff) = voc.transform(g["kf_desc"], 1)
+    assert np.array_equal(bw, g["bow_word"]) and np.array_equal(bv, g["bow_value"])
+    assert np.array_equal(fn, g["fv_node"]) and np.array_equal(fs, g["fv_start"]) and np.array_equal(ff, g["fv_feat"])
+    assert np.array_equal(api.ComputeDistinctiveDescriptors(g["kf_desc"][:30], g["dd_start"]), g["dd_best"])
+    assert np.array_equal(F.pack_wire(), g["wire"])
