@@ -807,9 +807,14 @@ __global__ __launch_bounds__(NT) void k_ldlt_blk(int nb, const double* __restric
 // factors the 6x6 diagonal block redundantly from an LDS copy, so no barrier is needed between "factor" and "panel":
 // two barriers per block column.  L is kept (LDS, or in the storage of S for large systems) for the back-substitution.
 // R = row pairs per thread (R = 1: up to 341 blocks = 25 poses with 1024 threads).
+// Block sparsity of the factor (symbolic elimination on the host, fill-in included): bit i of m[j] = block L_ij is
+// structurally non-zero.  The reference exploits the same sparsity through Eigen::SimplicialLDLT (G/solvers/linear_solver_eigen.h);
+// here it prunes the trailing update: a block (i,k) is touched at step j only if both L_ij and L_kj exist.
+struct LdltNz { unsigned m[64]; };
+
 template <int NT, int R>
 __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S, const double* __restrict__ b,
-                                                  double* __restrict__ x, int* __restrict__ ok_flag, int l_in_lds) {
+                                                  double* __restrict__ x, int* __restrict__ ok_flag, int l_in_lds, LdltNz nz) {
   extern __shared__ double sh[];
   double* rr_ = sh;                    // 6*nb running rhs (forward)
   double* zz = rr_ + 6 * nb;           // 6*nb z = D^-1 L^-1 b, then running rhs of the backward pass
@@ -950,9 +955,10 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
     }
     __syncthreads();          // barrier Z: panel of column j published
     if (!s_ok) break;
+    const unsigned nzj = nb <= 32 ? nz.m[j] : 0xFFFFFFFFu;      // rows with a non-zero block in column j
 #pragma unroll
     for (int s = 0; s < R; s++) {
-      if (ubk[s] > j && ubi[s] >= ubk[s]) {
+      if (ubk[s] > j && ubi[s] >= ubk[s] && ((nzj >> (ubk[s] & 31)) & 1u) && ((nzj >> (ubi[s] & 31)) & 1u)) {
         const double* Lp = P + (size_t)ubi[s] * kPanStride + 6 * (2 * upr[s]);   // two rows of L_ij
         const double* Wp = P + (size_t)ubk[s] * kPanStride + 37;                 // W_kj = L_kj D_j
         double l0[6], l1[6];
@@ -1327,6 +1333,24 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       }
     }
   }
+  // symbolic elimination of the reduced camera system: which blocks of L are structurally non-zero (fill-in included)
+  LdltNz ldlt_nz;
+  for (int j = 0; j < 64; j++) ldlt_nz.m[j] = 0xFFFFFFFFu;
+  if (nP <= 32 && !getenv("ORBG_LDLT_DENSE")) {
+    unsigned col[32];                                   // col[j]: rows i > j with S_ij != 0, then with fill-in
+    for (int j = 0; j < nP; j++) {
+      unsigned mcol = 0;
+      for (int i = j + 1; i < nP; i++)
+        if (pair_start[pair_id(j, i) + 1] > pair_start[pair_id(j, i)]) mcol |= 1u << i;
+      col[j] = mcol;
+    }
+    for (int j = 0; j < nP; j++) {
+      const unsigned rows = col[j];
+      for (int k = j + 1; k < nP; k++)
+        if ((rows >> k) & 1u) col[k] |= rows & ~((2u << k) - 1u);     // rows below k of column j fill column k
+      ldlt_nz.m[j] = rows;
+    }
+  }
   // keep every pair (diagonals always; off-diagonals even if empty so that S is fully written)
   for (int i1 = 0; i1 < nP; i1++)
     for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
@@ -1474,13 +1498,13 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(64), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                              h->d_EB.p, h->d_Hll.p, h->d_bl.p, h->d_Hpp.p, h->d_bp.p, lambda, h->d_S.p, h->d_bs.p);
           if (rows_R == 1 && rows_small)
-            hipLaunchKernelGGL((k_ldlt_rows<640, 1>), dim3(1), dim3(640), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
+            hipLaunchKernelGGL((k_ldlt_rows<640, 1>), dim3(1), dim3(640), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
           else if (rows_R == 1)
-            hipLaunchKernelGGL((k_ldlt_rows<1024, 1>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
+            hipLaunchKernelGGL((k_ldlt_rows<1024, 1>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
           else if (rows_R == 2)
-            hipLaunchKernelGGL((k_ldlt_rows<1024, 2>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
+            hipLaunchKernelGGL((k_ldlt_rows<1024, 2>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
           else if (rows_R == 4)
-            hipLaunchKernelGGL((k_ldlt_rows<1024, 4>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds);
+            hipLaunchKernelGGL((k_ldlt_rows<1024, 4>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
           else if (nP <= 22)
             hipLaunchKernelGGL(k_ldlt_blk<256>, dim3(1), dim3(256), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
           else if (nP <= 44)
