@@ -462,9 +462,7 @@ __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 27; i++) {
-    double v = acc[i];
-#pragma unroll
-    for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
+    const double v = wave_sum_f64(acc[i]);            // DPP tree, fixed order
     if (lane == 0) wpart[wave][i] = v;
   }
   __syncthreads();
@@ -517,22 +515,28 @@ __device__ inline void inv3_sym(const double* h6, double lambda, double* o) {
 // Schur complement block (i1 <= i2) and, on diagonal pairs, the reduced rhs.
 struct PairItem { int ea, eb, l; };   // edges (pose i1 / pose i2) of landmark l
 
-__global__ __launch_bounds__(64) void k_schur(int nP, const int* __restrict__ pair_i1, const int* __restrict__ pair_i2,
-                                             const int* __restrict__ pair_start, const PairItem* __restrict__ items,
-                                             const double* __restrict__ EB, const double* __restrict__ Hll, const double* __restrict__ bl,
-                                             const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda,
-                                             double* __restrict__ S, double* __restrict__ bs) {
-  __shared__ double red[37][65];
+constexpr int kSchurThreads = 256;
+
+__global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __restrict__ pair_i1, const int* __restrict__ pair_i2,
+                                                        const int* __restrict__ pair_start, const PairItem* __restrict__ items,
+                                                        const double* __restrict__ EB, const double* __restrict__ Hll,
+                                                        const double* __restrict__ bl, const double* __restrict__ Hpp,
+                                                        const double* __restrict__ bp, double lambda, double* __restrict__ S,
+                                                        double* __restrict__ bs) {
+  // one workgroup per pose pair, one thread per shared landmark (the diagonal pairs hold every landmark of the pose:
+  // ~550 at C2, so 256 threads keep their item loop at 3 rounds); sums in a fixed order: per thread, then 4 x 64, then 4
+  __shared__ double red[42][kSchurThreads + 1];
+  __shared__ double part[42][4];
   const int pr = blockIdx.x;
   const int i1 = pair_i1[pr], i2 = pair_i2[pr];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   double acc[36], cacc[6];
 #pragma unroll
   for (int i = 0; i < 36; i++) acc[i] = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) cacc[i] = 0;
   const bool diag = i1 == i2;
-  for (int j = pair_start[pr] + lane; j < pair_start[pr + 1]; j += 64) {
+  for (int j = pair_start[pr] + tid; j < pair_start[pr + 1]; j += kSchurThreads) {
     const PairItem it = items[j];
     double Dinv[9];
     inv3_sym(Hll + 6 * (size_t)it.l, lambda, Dinv);
@@ -553,15 +557,23 @@ __global__ __launch_bounds__(64) void k_schur(int nP, const int* __restrict__ pa
       for (int a = 0; a < 6; a++) cacc[a] += BD[3 * a] * b[0] + BD[3 * a + 1] * b[1] + BD[3 * a + 2] * b[2];
     }
   }
-  // fixed-order reduction over the 64 lanes
 #pragma unroll
-  for (int i = 0; i < 36; i++) red[i][lane] = acc[i];
+  for (int i = 0; i < 36; i++) red[i][tid] = acc[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) red[36 + i][tid] = cacc[i];
+  __syncthreads();
+  const int nval = diag ? 42 : 36;
+  if (tid < 4 * nval) {
+    const int o = tid >> 2, q = tid & 3;
+    double s = 0;
+    for (int k = 0; k < 64; k++) s += red[o][64 * q + k];
+    part[o][q] = s;
+  }
   __syncthreads();
   const int n = 6 * nP;
-  if (lane < 36) {
-    double s = 0;
-    for (int k = 0; k < 64; k++) s += red[lane][k];
-    const int a = lane / 6, c = lane % 6;
+  if (tid < 36) {
+    const double s = ((part[tid][0] + part[tid][1]) + part[tid][2]) + part[tid][3];
+    const int a = tid / 6, c = tid % 6;
     double v = -s;
     if (diag) {
       const int lo = a < c ? a : c, hi = a < c ? c : a;
@@ -570,17 +582,10 @@ __global__ __launch_bounds__(64) void k_schur(int nP, const int* __restrict__ pa
     }
     S[(size_t)(6 * i1 + a) * n + 6 * i2 + c] = v;
     if (!diag) S[(size_t)(6 * i2 + c) * n + 6 * i1 + a] = v;
-  }
-  __syncthreads();
-  if (diag) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) red[i][lane] = cacc[i];
-    __syncthreads();
-    if (lane < 6) {
-      double s = 0;
-      for (int k = 0; k < 64; k++) s += red[lane][k];
-      bs[6 * i1 + lane] = bp[6 * (size_t)i1 + lane] - s;
-    }
+  } else if (diag && tid < 42) {
+    const int a = tid - 36;
+    const double s = ((part[tid][0] + part[tid][1]) + part[tid][2]) + part[tid][3];
+    bs[6 * i1 + a] = bp[6 * (size_t)i1 + a] - s;
   }
 }
 
@@ -1495,7 +1500,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       do {
         const int trial = cur ^ 1;
         if (nP > 0) {
-          hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(64), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
+          hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                              h->d_EB.p, h->d_Hll.p, h->d_bl.p, h->d_Hpp.p, h->d_bp.p, lambda, h->d_S.p, h->d_bs.p);
           if (rows_R == 1 && rows_small)
             hipLaunchKernelGGL((k_ldlt_rows<640, 1>), dim3(1), dim3(640), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
