@@ -492,10 +492,28 @@ __global__ __launch_bounds__(256) void k_reduce_points(int nL, const int* __rest
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= nL) return;
   double acc[9];
+#pragma unroll
   for (int i = 0; i < 9; i++) acc[i] = 0;
-  for (int j = pt_start[l]; j < pt_start[l + 1]; j++) {
-    const double* eb = EB + (size_t)pt_edges[j] * kEB + 18;
-    for (int i = 0; i < 9; i++) acc[i] += eb[i];
+  // the edge list is walked in chunks of 4 whose indices, then blocks, are all requested before the first use: two memory
+  // round trips per chunk instead of two per edge (the chain of dependent loads is what this kernel costs); same sum order
+  const int jb = pt_start[l], je = pt_start[l + 1];
+  for (int j0 = jb; j0 < je; j0 += 4) {
+    int id[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) id[q] = pt_edges[min(j0 + q, je - 1)];
+    double v[4][9];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double* eb = EB + (size_t)id[q] * kEB + 18;
+#pragma unroll
+      for (int i = 0; i < 9; i++) v[q][i] = eb[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (j0 + q < je) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) acc[i] += v[q][i];
+      }
   }
   for (int i = 0; i < 6; i++) Hll[6 * (size_t)l + i] = acc[i];
   for (int i = 0; i < 3; i++) bl[3 * (size_t)l + i] = acc[6 + i];
