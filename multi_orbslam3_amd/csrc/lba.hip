@@ -833,7 +833,7 @@ __global__ __launch_bounds__(NT) void k_ldlt_blk(int nb, const double* __restric
 // Block sparsity of the factor (symbolic elimination on the host, fill-in included): bit i of m[j] = block L_ij is
 // structurally non-zero.  The reference exploits the same sparsity through Eigen::SimplicialLDLT (G/solvers/linear_solver_eigen.h);
 // here it prunes the trailing update: a block (i,k) is touched at step j only if both L_ij and L_kj exist.
-struct LdltNz { unsigned m[64]; };
+struct LdltNz { unsigned long long m[64]; };
 
 template <int NT, int R>
 __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S, const double* __restrict__ b,
@@ -978,10 +978,10 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
     }
     __syncthreads();          // barrier Z: panel of column j published
     if (!s_ok) break;
-    const unsigned nzj = nb <= 32 ? nz.m[j] : 0xFFFFFFFFu;      // rows with a non-zero block in column j
+    const unsigned long long nzj = nb <= 64 ? nz.m[j] : ~0ull;   // rows with a non-zero block in column j
 #pragma unroll
     for (int s = 0; s < R; s++) {
-      if (ubk[s] > j && ubi[s] >= ubk[s] && ((nzj >> (ubk[s] & 31)) & 1u) && ((nzj >> (ubi[s] & 31)) & 1u)) {
+      if (ubk[s] > j && ubi[s] >= ubk[s] && ((nzj >> (ubk[s] & 63)) & 1ull) && ((nzj >> (ubi[s] & 63)) & 1ull)) {
         const double* Lp = P + (size_t)ubi[s] * kPanStride + 6 * (2 * upr[s]);   // two rows of L_ij
         const double* Wp = P + (size_t)ubk[s] * kPanStride + 37;                 // W_kj = L_kj D_j
         double l0[6], l1[6];
@@ -1358,19 +1358,19 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   }
   // symbolic elimination of the reduced camera system: which blocks of L are structurally non-zero (fill-in included)
   LdltNz ldlt_nz;
-  for (int j = 0; j < 64; j++) ldlt_nz.m[j] = 0xFFFFFFFFu;
-  if (nP <= 32 && !getenv("ORBG_LDLT_DENSE")) {
-    unsigned col[32];                                   // col[j]: rows i > j with S_ij != 0, then with fill-in
+  for (int j = 0; j < 64; j++) ldlt_nz.m[j] = ~0ull;
+  if (nP <= 64 && !getenv("ORBG_LDLT_DENSE")) {
+    unsigned long long col[64];                         // col[j]: rows i > j with S_ij != 0, then with fill-in
     for (int j = 0; j < nP; j++) {
-      unsigned mcol = 0;
+      unsigned long long mcol = 0;
       for (int i = j + 1; i < nP; i++)
-        if (pair_start[pair_id(j, i) + 1] > pair_start[pair_id(j, i)]) mcol |= 1u << i;
+        if (pair_start[pair_id(j, i) + 1] > pair_start[pair_id(j, i)]) mcol |= 1ull << i;
       col[j] = mcol;
     }
     for (int j = 0; j < nP; j++) {
-      const unsigned rows = col[j];
+      const unsigned long long rows = col[j];
       for (int k = j + 1; k < nP; k++)
-        if ((rows >> k) & 1u) col[k] |= rows & ~((2u << k) - 1u);     // rows below k of column j fill column k
+        if ((rows >> k) & 1ull) col[k] |= k < 63 ? (rows & ~((2ull << k) - 1ull)) : 0ull;   // rows below k of column j fill column k
       ldlt_nz.m[j] = rows;
     }
   }
