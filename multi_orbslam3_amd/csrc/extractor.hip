@@ -516,7 +516,7 @@ __device__ inline int oct_scan_excl(int* v, int n, int* wsum /*LDS[8]*/) {
 
 __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __restrict__ cand, const int* __restrict__ hdr,
                                                             PyrGeom g, OctCfg cfg, OctSel* __restrict__ sel_out,
-                                                            int* __restrict__ lvl_count, int* __restrict__ overflow) {
+                                                            int* __restrict__ lvl_count, int* __restrict__ overflow, int cand_cap) {
   __shared__ unsigned short node_of[kOctKeyCap];
   __shared__ unsigned short kx[kOctKeyCap], ky[kOctKeyCap];
   __shared__ unsigned char kr[kOctKeyCap], kq[kOctKeyCap];
@@ -544,7 +544,8 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   const int ce = nlv < cfg.n_levels ? hdr[cam * ORBG_MAX_LEVELS + nlv] : hdr[2 * ORBG_MAX_LEVELS + 1 + cam];
   const int nk = ce - cb;
   if (nk <= 0) { if (tid == 0) *out_count = 0; return; }
-  if (nk > kOctKeyCap || 4 * N + 8 > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+  // ce > cand_cap: gather_cells_kernel dropped the tail of the list, the host path regrows the buffer and redoes the frame
+  if (nk > kOctKeyCap || 4 * N + 8 > kOctListCap || ce > cand_cap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
   const int minB = kEdge - 3;
   const int W = (L.w - kEdge + 3) - minB, H = (L.h - kEdge + 3) - minB;   // maxX-minX, maxY-minY
   int nIni = (int)roundf((float)W / (float)H);
@@ -963,8 +964,12 @@ __global__ __launch_bounds__(256) void orient_desc_gpu_kernel(const uint8_t* __r
   const int w = blockIdx.x * kKpPerBlock + wv;
   int n0 = 0, n1 = 0;
   for (int l = 0; l < cfg.n_levels; l++) { n0 += lvl_count[l]; if (cfg.n_cams > 1) n1 += lvl_count[ORBG_MAX_LEVELS + l]; }
-  if (w == 0 && (threadIdx.x & 63) == 0) { d_nkp[0] = n0; d_nkp[1] = n1; h_nkp[0] = n0; h_nkp[1] = n1; h_nkp[2] = *d_overflow; }
-  if (w >= n0 + n1) return;
+  const int ovf = *d_overflow;
+  if (w == 0 && (threadIdx.x & 63) == 0) {
+    d_nkp[0] = ovf ? 0 : n0; d_nkp[1] = ovf ? 0 : n1;     // zero counts keep the chained stereo / grid kernels idle on overflow
+    h_nkp[0] = n0; h_nkp[1] = n1; h_nkp[2] = ovf;
+  }
+  if (ovf || w >= n0 + n1) return;                        // overflow: the host redoes the frame, nothing here is kept
   const int cam = w >= n0 ? 1 : 0;
   int s = cam ? w - n0 : w, level = 0;
   for (; level < cfg.n_levels; level++) {
@@ -1787,7 +1792,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     OctCfg oc = h->octcfg;
     oc.n_cams = ncams;                          // cameras processed by THIS call (a rig handle may extract one image)
     hipLaunchKernelGGL(octree_kernel, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
-                       h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p);
+                       h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap);
     const bool want_desc = desc_out[0] || desc_out[1];
     hipLaunchKernelGGL(orient_desc_gpu_kernel, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
                        oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,

@@ -62,6 +62,29 @@ def test_pyramid_one_launch_and_per_level_paths(monkeypatch, shape, scale, level
             assert np.array_equal(ex.level(0, l, border=True), oe.level(l, border=True)), "level %d (no_tower=%r)" % (l, no_tower)
 
 
+def test_extractor_dense_noise_overflows_to_host_trees(scene):
+    """A noise image has more FAST candidates per level than the LDS-resident quad-tree (and the candidate buffer) holds:
+    the device pass must flag the overflow without touching anything out of range -- recycled, non-zero device memory
+    included -- and the host quad-trees redo the frame with the same result as the oracle."""
+    L, R, _ = scene.stereo_pair(2)
+    warm = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
+    warm.extract_stereo(L, R)
+    del warm                                                            # its buffers are recycled by the next handle
+    rng = np.random.RandomState(488)
+    img = rng.randint(0, 256, (480, 640)).astype(np.uint8)
+    oe = ob.Extractor(n_features=300, max_width=640, max_height=480)
+    rc, okps, odesc, onm = oe.extract(img)
+    assert sum(len(oe.candidates(l)) for l in range(8)) > 60000
+    for n_cams in (1, 2):
+        ex = api.ORBextractor(300, 1.2, 8, 20, 7, 640, 480, n_cams=n_cams)
+        for _ in range(2):
+            nm, kps, desc = ex(img, (0, 0))
+            _assert_extract_equal((kps, desc), (okps, odesc), "dense noise")
+    (kl, dl), (kr, dr) = ex.extract_stereo(img, img)
+    _assert_extract_equal((kl, dl), (okps, odesc), "dense noise stereo L")
+    _assert_extract_equal((kr, dr), (okps, odesc), "dense noise stereo R")
+
+
 def test_extractor_empty_image():
     ex = api.ORBextractor(100, 1.2, 8, 20, 7, 320, 240)
     nm, kps, desc = ex(None)
