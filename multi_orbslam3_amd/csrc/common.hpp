@@ -27,6 +27,10 @@ constexpr int kEdge = 19;        // EDGE_THRESHOLD  S/ORBextractor.cc:72
 constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE S/ORBextractor.cc:71
 constexpr int kPatch = 31;       // PATCH_SIZE      S/ORBextractor.cc:70
 
+// ORBG_POISON=1 fills every new buffer with 0xA5 so that a kernel consuming memory nobody wrote shows up in the parity
+// tests (fresh HIP allocations are often zero, recycled ones are not).  Test aid; allocations are outside the timed path.
+inline bool poison_allocations() { static const bool on = getenv("ORBG_POISON") != nullptr; return on; }
+
 // Growable device buffer (never shrinks); all allocations happen outside the timed/launch path once sizes settle.
 template <typename T>
 struct DevBuf {
@@ -37,6 +41,7 @@ struct DevBuf {
     if (p) { ORBG_HIP(hipFree(p)); p = nullptr; cap = 0; }
     size_t want = n + n / 4 + 64;
     ORBG_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+    if (poison_allocations()) ORBG_HIP(hipMemset(p, 0xA5, want * sizeof(T)));
     cap = want;
     return ORBG_OK;
   }
@@ -55,6 +60,7 @@ struct PinnedBuf {
     size_t want = n + n / 4 + 64;
     ORBG_HIP(hipHostMalloc((void**)&h, want * sizeof(T), hipHostMallocMapped));
     ORBG_HIP(hipHostGetDevicePointer((void**)&d, h, 0));
+    if (poison_allocations()) memset(h, 0xA5, want * sizeof(T));
     cap = want;
     return ORBG_OK;
   }
