@@ -188,8 +188,8 @@ __device__ inline void pose_oplus_fast(const PoseQ& T, const double* u, PoseQ* o
 // 1/d to ~1 ulp: hardware seed + two Newton-Raphson steps
 __device__ __forceinline__ double fast_rcp(double d) {
   double x = __builtin_amdgcn_rcp(d);
-  x = x * (2.0 - d * x);
-  x = x * (2.0 - d * x);
+  x = __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
+  x = __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
   return x;
 }
 
@@ -835,32 +835,62 @@ __global__ __launch_bounds__(NT) void k_ldlt_blk(int nb, const double* __restric
 // here it prunes the trailing update: a block (i,k) is touched at step j only if both L_ij and L_kj exist.
 struct LdltNz { unsigned long long m[64]; };
 
-template <int NT, int R>
+// L_IN_LDS is a template parameter so that the factor's pointer has ONE address space per instantiation: a run-time
+// "LDS or global" select makes every access to L a flat_* instruction (aperture check, both wait counters).
+//
+// Schedule per block column j (two workgroup barriers):
+//   barrier X | panel: the threads of column j read the factored diagonal block F_j = {X = L_jj^-1, 1/d, y} from LDS and
+//             | turn their two rows of A_ij into L_ij, W_ij = L_ij D_j and the rhs update
+//   barrier Z | trailing update A_ik -= L_ij W_kj^T; then the ONE wavefront that owns block (j+1, j+1) factors it
+//             | (look-ahead of the diagonal only: its ~130-instruction dependent chain overlaps the other wavefronts'
+//             | trailing updates instead of sitting between two barriers in front of every wavefront)
+// A wavefront holds 21 blocks x 3 threads (lane 63 idles) so that the three owners of a block always share a wavefront
+// and can exchange its rows through LDS without a workgroup barrier.
+constexpr int kBlkPerWave = 21;
+constexpr int kPanW = 37;            // offset of W inside a panel row-block (odd: conflict-free 64-bit reads across blocks)
+typedef double ldlt_d2 __attribute__((ext_vector_type(2)));
+// N doubles (N even) from / to a 16-byte aligned address as 128-bit accesses: an LDS instruction costs ~3 cycles of the
+// CU's LDS pipe per wavefront for 8 bytes per lane and ~4 for 16, and the trailing update is bound by exactly that
+template <int N>
+__device__ __forceinline__ void ld_pairs(const double* __restrict__ p, double* out) {
+  const ldlt_d2* q = reinterpret_cast<const ldlt_d2*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+  for (int i = 0; i < N / 2; i++) { const ldlt_d2 v = q[i]; out[2 * i] = v.x; out[2 * i + 1] = v.y; }
+}
+template <int N>
+__device__ __forceinline__ void st_pairs(double* __restrict__ p, const double* in) {
+  ldlt_d2* q = reinterpret_cast<ldlt_d2*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+  for (int i = 0; i < N / 2; i++) { ldlt_d2 v; v.x = in[2 * i]; v.y = in[2 * i + 1]; q[i] = v; }
+}
+
+template <int NT, int R, bool L_IN_LDS>
 __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S, const double* __restrict__ b,
-                                                  double* __restrict__ x, int* __restrict__ ok_flag, int l_in_lds, LdltNz nz) {
-  extern __shared__ double sh[];
+                                                  double* __restrict__ x, int* __restrict__ ok_flag, LdltNz nz) {
+#pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared: fused multiply-adds halve the FP64 chain
+  extern __shared__ __attribute__((aligned(16))) double sh[];
   double* rr_ = sh;                    // 6*nb running rhs (forward)
   double* zz = rr_ + 6 * nb;           // 6*nb z = D^-1 L^-1 b, then running rhs of the backward pass
-  double* Ajj = zz + 6 * nb;           // 36 current diagonal block
-  double* xs = Ajj + 36;               // 6
-  double* pan = xs + 6;                // 2 * nb * kPanStride
-  double* Lall = l_in_lds ? pan + 2 * (size_t)nb * kPanStride : S;   // nblk * 36
+  double* Ajj = zz + 6 * nb;           // 36 next diagonal block (rows exchanged between its three owners)
+  double* Fjj = Ajj + 36;              // 32 (12 used): 1/d (6), y (6) of the factored diagonal block
+  double* pan = Fjj + 32;              // 2 * nb * kPanStride
+  double* Lall;                        // nblk * 36
+  if constexpr (L_IN_LDS) Lall = pan + 2 * (size_t)nb * kPanStride; else Lall = S;
   __shared__ int s_ok;
   const int t = threadIdx.x;
   const int n = 6 * nb;
   const int nblk = nb * (nb + 1) / 2;
-  const int units = 3 * nblk;
   int ubi[R], ubk[R], upr[R], ublk[R];
   double a[R][12];
 #pragma unroll
   for (int s = 0; s < R; s++) {
     const int u = t + s * NT;
+    const int lane = u & 63;
+    const int cb = (u >> 6) * kBlkPerWave + lane / 3;        // column-major block number
     ubi[s] = -1; ubk[s] = -1; upr[s] = 0; ublk[s] = 0;
-    if (u < units) {
-      // Units are numbered COLUMN-major over the lower block triangle: the 3(nb-j) units of block column j are
-      // consecutive threads, so the diagonal factorisation + panel of a column occupies one or two wavefronts instead of
-      // a few lanes of every wavefront (the phase is issue bound: ~350 FP64 instructions per wavefront that enters it).
-      const int cb = u / 3;                                  // column-major block number
+    if (lane < 3 * kBlkPerWave && cb < nblk) {
+      // Blocks are numbered COLUMN-major over the lower block triangle: the threads of block column j are consecutive,
+      // so the panel of a column occupies one or two wavefronts instead of a few lanes of every wavefront.
       // column k starts at C(k) = k*nb - k(k-1)/2; invert with a float guess + fix-up
       const float fnb = (float)nb + 0.5f;
       int bk = (int)(fnb - sqrtf(fmaxf(fnb * fnb - 2.f * (float)cb, 0.f)));
@@ -869,7 +899,7 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
       while (bk > 0 && bk * nb - bk * (bk - 1) / 2 > cb) bk--;
       while (bk + 1 < nb && (bk + 1) * nb - (bk + 1) * bk / 2 <= cb) bk++;
       const int bi = bk + (cb - (bk * nb - bk * (bk - 1) / 2));
-      ubi[s] = bi; ubk[s] = bk; upr[s] = u - 3 * cb; ublk[s] = bi * (bi + 1) / 2 + bk;   // storage stays row-major
+      ubi[s] = bi; ubk[s] = bk; upr[s] = lane - 3 * (lane / 3); ublk[s] = bi * (bi + 1) / 2 + bk;   // storage stays row-major
 #pragma unroll
       for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -878,115 +908,148 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
   }
   for (int i = t; i < n; i += NT) { rr_[i] = b[i]; zz[i] = 0; }
   if (t == 0) s_ok = 1;
-  __syncthreads();            // S fully consumed before Lall (which may alias S) is written
+  __syncthreads();            // S fully consumed before Lall (which may alias S) is written; rhs in LDS
+
+  // Factor the diagonal block jn, executed by its three owners (one wavefront): rows -> LDS -> everyone reads the lower
+  // triangle; right-looking LDL^T arranged for depth, explicit inverse X of the unit-triangular factor, y = X r_jn.
+  // Publishes F (for the panel threads of column jn), the diagonal block of the stored factor and z_jn.
+  auto factor_diag = [&](int jn, int sd) {
+    int pr_d = 0;
 #pragma unroll
-  for (int s = 0; s < R; s++)
-    if (ubi[s] == 0 && ubk[s] == 0)
-#pragma unroll
-      for (int q = 0; q < 12; q++) Ajj[12 * upr[s] + q] = a[s][q];
-  for (int j = 0; j < nb; j++) {
-    __syncthreads();          // barrier X: Ajj + running rhs of column j complete
-    double* P = pan + (size_t)(j & 1) * nb * kPanStride;
-    bool in_col = false;
-#pragma unroll
-    for (int s = 0; s < R; s++) in_col |= (ubk[s] == j);
-    if (in_col) {
-      // Redundant in-register LDL^T of the diagonal block, arranged for DEPTH: right-looking updates (all independent
-      // inside a pivot step), then the explicit inverse X = L_jj^-1 of the unit-triangular factor, so that the panel rows
-      // and the rhs become plain dot products instead of dependent forward substitutions.  The chain per block column
-      // is ~6 x (reciprocal + 3) + ~10 operations instead of ~250.
-      double A[6][6], dinv[6], y[6];
+    for (int s = 0; s < R; s++)
+      if (s == sd) {
+        pr_d = upr[s];
+        st_pairs<12>(Ajj + 12 * upr[s], a[s]);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();       // LDS operations of one wavefront complete in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double A[6][6], dinv[6], y[6], rj[6];
+    {
+      double flat[36];
+      ld_pairs<36>(Ajj, flat);
 #pragma unroll
       for (int q = 0; q < 6; q++)
 #pragma unroll
-        for (int c = 0; c <= q; c++) A[q][c] = Ajj[6 * q + c];
-      bool good = true;
+        for (int c = 0; c <= q; c++) A[q][c] = flat[6 * q + c];
+    }
+    ld_pairs<6>(rr_ + 6 * jn, rj);
+    bool good = true;
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const double d = A[c][c];
-        if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
-        const double id = fast_rcp(d);
-        dinv[c] = id;
-        double W[6];
+    for (int c = 0; c < 6; c++) {
+      const double d = A[c][c];
+      if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
+      const double id = fast_rcp(d);
+      dinv[c] = id;
+      double W[6];
 #pragma unroll
-        for (int q = c + 1; q < 6; q++) { W[q] = A[q][c]; A[q][c] = W[q] * id; }       // A[q][c] now holds L[q][c]
+      for (int q = c + 1; q < 6; q++) { W[q] = A[q][c]; A[q][c] = W[q] * id; }       // A[q][c] now holds L[q][c]
 #pragma unroll
-        for (int q = c + 1; q < 6; q++)
+      for (int q = c + 1; q < 6; q++)
 #pragma unroll
-          for (int r = c + 1; r <= q; r++) A[q][r] -= A[q][c] * W[r];
-      }
-      if (!good) s_ok = 0;
-      // X = L^-1 (unit lower triangular), column by column; the six columns are independent chains
-      double X[6][6];
+        for (int r = c + 1; r <= q; r++) A[q][r] -= A[q][c] * W[r];
+    }
+    if (!good) s_ok = 0;
+    // X = L^-1 (unit lower triangular), column by column; the six columns are independent chains
+    double X[6][6];
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
+    for (int c = 0; c < 6; c++) {
 #pragma unroll
-        for (int q = c + 1; q < 6; q++) {
-          double v = -A[q][c];
+      for (int q = c + 1; q < 6; q++) {
+        double v = -A[q][c];
 #pragma unroll
-          for (int m = c + 1; m < q; m++) v -= A[q][m] * X[m][c];
-          X[q][c] = v;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double v = rr_[6 * j + c];
-#pragma unroll
-        for (int m = 0; m < c; m++) v += X[c][m] * rr_[6 * j + m];
-        y[c] = v;
-      }
-#pragma unroll
-      for (int s = 0; s < R; s++) {
-        if (ubk[s] != j) continue;
-        const int row0 = 2 * upr[s];
-        double* Lg = Lall + (size_t)ublk[s] * 36;
-        if (ubi[s] == j) {
-#pragma unroll
-          for (int pr = 0; pr < 3; pr++)          // compile-time row indices: the factor stays in registers
-            if (upr[s] == pr) {
-#pragma unroll
-              for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int c = 0; c < 6; c++)   // lower: L_jj; strict upper: (L_jj^-1)^T for the backward pass
-                  Lg[6 * (2 * pr + q) + c] = c < 2 * pr + q ? A[2 * pr + q][c] : (c > 2 * pr + q ? X[c][2 * pr + q] : 1.0);
-            }
-          if (upr[s] == 0) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) zz[6 * j + c] = y[c] * dinv[c];
-          }
-        } else {
-          double* Lp = P + (size_t)ubi[s] * kPanStride;
-          double* Wp = Lp + 37;
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-            double racc = 0;
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-              double v = a[s][6 * q + c];                    // w = a L^-T : w[c] = a[c] + sum_{m<c} a[m] X[c][m]
-#pragma unroll
-              for (int m = 0; m < c; m++) v += a[s][6 * q + m] * X[c][m];
-              const double l = v * dinv[c];
-              Wp[6 * (row0 + q) + c] = v;
-              Lp[6 * (row0 + q) + c] = l;
-              Lg[6 * (row0 + q) + c] = l;
-              racc += l * y[c];
-            }
-            rr_[6 * ubi[s] + row0 + q] -= racc;
-          }
-        }
+        for (int m = c + 1; m < q; m++) v -= A[q][m] * X[m][c];
+        X[q][c] = v;
       }
     }
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      double v = rj[c];
+#pragma unroll
+      for (int m = 0; m < c; m++) v += X[c][m] * rj[m];
+      y[c] = v;
+    }
+    // One lane publishes the results (an LDS store costs ~16-28 cycles of the wavefront's issue time whatever the number
+    // of active lanes): X row-packed into the diagonal block of the stored factor (read by the panel threads of column
+    // jn and by the backward pass), 1/d and y into F, z_jn.  L_jj itself is not needed by anyone.
+    if (pr_d == 0) {
+      double xs[16], dz[18];
+#pragma unroll
+      for (int c = 1; c < 6; c++)
+#pragma unroll
+        for (int m = 0; m < c; m++) xs[c * (c - 1) / 2 + m] = X[c][m];
+      xs[15] = 0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) { dz[c] = dinv[c]; dz[6 + c] = y[c]; dz[12 + c] = y[c] * dinv[c]; }
+      st_pairs<16>(Lall + (size_t)(jn * (jn + 1) / 2 + jn) * 36, xs);
+      st_pairs<12>(Fjj, dz);
+      st_pairs<6>(zz + 6 * jn, dz + 12);
+    }
+  };
+
+  {
+    int sd = -1;
+#pragma unroll
+    for (int s = 0; s < R; s++) if (ubi[s] == 0 && ubk[s] == 0) sd = s;
+    if (sd >= 0) factor_diag(0, sd);
+  }
+  for (int j = 0; j < nb; j++) {
+    __syncthreads();          // barrier X: F_j + running rhs of column j complete
+    if (!s_ok) break;         // uniform: s_ok is only written between barrier Z and the next barrier X
+    double* P = pan + (size_t)(j & 1) * nb * kPanStride;
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      if (ubk[s] != j || ubi[s] == j) continue;
+      double X[6][6], dinv[6], y[6];
+      {
+        double f[16], g[12];
+        ld_pairs<16>(Lall + (size_t)(j * (j + 1) / 2 + j) * 36, f);
+        ld_pairs<12>(Fjj, g);
+#pragma unroll
+        for (int c = 1; c < 6; c++)
+#pragma unroll
+          for (int m = 0; m < c; m++) X[c][m] = f[c * (c - 1) / 2 + m];
+#pragma unroll
+        for (int c = 0; c < 6; c++) { dinv[c] = g[c]; y[c] = g[6 + c]; }
+      }
+      const int row0 = 2 * upr[s];
+      double* Lg = Lall + (size_t)ublk[s] * 36;
+      double* Lp = P + (size_t)ubi[s] * kPanStride;
+      double* Wp = Lp + kPanW;
+      // the running rhs is read before the panel is stored (LDS operations complete in order)
+      double rhs[2];
+      ld_pairs<2>(rr_ + 6 * ubi[s] + row0, rhs);
+      double racc[2] = {0, 0}, wv[12], lv[12];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double v = a[s][6 * q + c];                    // w = a L^-T : w[c] = a[c] + sum_{m<c} a[m] X[c][m]
+#pragma unroll
+          for (int m = 0; m < c; m++) v += a[s][6 * q + m] * X[c][m];
+          const double l = v * dinv[c];
+          wv[6 * q + c] = v;
+          lv[6 * q + c] = l;
+          racc[q] += l * y[c];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 12; q++) { Wp[6 * row0 + q] = wv[q]; Lp[6 * row0 + q] = lv[q]; }
+      st_pairs<12>(Lg + 6 * row0, lv);
+      rhs[0] -= racc[0]; rhs[1] -= racc[1];
+      st_pairs<2>(rr_ + 6 * ubi[s] + row0, rhs);
+    }
     __syncthreads();          // barrier Z: panel of column j published
-    if (!s_ok) break;
     const unsigned long long nzj = nb <= 64 ? nz.m[j] : ~0ull;   // rows with a non-zero block in column j
+    int sd = -1;
 #pragma unroll
     for (int s = 0; s < R; s++) {
       if (ubk[s] > j && ubi[s] >= ubk[s] && ((nzj >> (ubk[s] & 63)) & 1ull) && ((nzj >> (ubi[s] & 63)) & 1ull)) {
         const double* Lp = P + (size_t)ubi[s] * kPanStride + 6 * (2 * upr[s]);   // two rows of L_ij
-        const double* Wp = P + (size_t)ubk[s] * kPanStride + 37;                 // W_kj = L_kj D_j
-        double l0[6], l1[6];
+        const double* Wp = P + (size_t)ubk[s] * kPanStride + kPanW;              // W_kj = L_kj D_j
+        double l01[12];
 #pragma unroll
-        for (int m = 0; m < 6; m++) { l0[m] = Lp[m]; l1[m] = Lp[6 + m]; }
+        for (int m = 0; m < 12; m++) l01[m] = Lp[m];
 #pragma unroll
         for (int c = 0; c < 6; c++) {
           double w[6];
@@ -994,19 +1057,62 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
           for (int m = 0; m < 6; m++) w[m] = Wp[6 * c + m];
           double s0 = 0, s1 = 0;
 #pragma unroll
-          for (int m = 0; m < 6; m++) { s0 += l0[m] * w[m]; s1 += l1[m] * w[m]; }
+          for (int m = 0; m < 6; m++) { s0 += l01[m] * w[m]; s1 += l01[6 + m] * w[m]; }
           a[s][c] -= s0;
           a[s][6 + c] -= s1;
         }
-        if (ubi[s] == j + 1 && ubk[s] == j + 1)
-#pragma unroll
-          for (int q = 0; q < 12; q++) Ajj[12 * upr[s] + q] = a[s][q];
       }
+      if (ubi[s] == j + 1 && ubk[s] == j + 1) sd = s;
     }
+    if (sd >= 0) factor_diag(j + 1, sd);
   }
   __syncthreads();
   const int ok = s_ok;
-  if (ok && t < 64) {
+  if (ok && t < 64 && nb <= 20) {
+    // Backward substitution by ONE wavefront with z in registers: per step the six entries of z_i are broadcast with
+    // v_readlane, every lane forms x_i = X_i^T z_i from the stored inverse and updates its own entries
+    // z_k -= L_ik^T x_i.  No LDS stores in the loop, so the loads of L (which do not depend on the chain) are issued ahead
+    // of it.  The phase is bound by the instruction issue of this single wavefront (~5 cycles per instruction).
+    // lane o < 60 holds z[o] (block rows 0..9) and z[60 + o] (block rows 10..19): a block row never straddles the two
+    double z0 = t < 60 && t < n ? zz[t] : 0.0, z1 = t < 60 && t + 60 < n ? zz[t + 60] : 0.0;
+    const int kk = t / 6, cc = t - 6 * kk;             // lane -> (block row kk or kk + 10, component cc)
+    for (int i = nb - 1; i >= 0; i--) {
+      const double* Lrow = Lall + (size_t)(i * (i + 1) / 2) * 36;
+      const double* Xp = Lrow + (size_t)i * 36;        // X_i row-packed: X[q][c] at q(q-1)/2 + c
+      double xp[16], l0[6], l1[6];
+      ld_pairs<16>(Xp, xp);
+      const bool on0 = t < 60 && kk < i, on1 = t < 60 && kk + 10 < i;
+      const double* L0 = Lrow + (size_t)(on0 ? kk : 0) * 36 + cc;
+      const double* L1 = Lrow + (size_t)(on1 ? kk + 10 : 0) * 36 + cc;
+#pragma unroll
+      for (int q = 0; q < 6; q++) { l0[q] = L0[6 * q]; l1[q] = L1[6 * q]; }
+      const double src = i < 10 ? z0 : z1;             // uniform select
+      const int lb = 6 * (i < 10 ? i : i - 10);
+      double zi[6], xv[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) & 0xFFFFFFFFll), lb + c);
+        const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) >> 32), lb + c);
+        zi[c] = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {                    // x_i = X_i^T z_i: x[c] = z[c] + sum_{q>c} X[q][c] z[q], two partial sums
+        double va = zi[c], vb = 0;
+#pragma unroll
+        for (int q = c + 1; q < 6; q++) { if ((q - c) & 1) va += xp[q * (q - 1) / 2 + c] * zi[q]; else vb += xp[q * (q - 1) / 2 + c] * zi[q]; }
+        xv[c] = va + vb;
+      }
+      const double a0 = (l0[0] * xv[0] + l0[1] * xv[1]) + (l0[2] * xv[2] + l0[3] * xv[3]) + (l0[4] * xv[4] + l0[5] * xv[5]);
+      const double a1 = (l1[0] * xv[0] + l1[1] * xv[1]) + (l1[2] * xv[2] + l1[3] * xv[3]) + (l1[4] * xv[4] + l1[5] * xv[5]);
+      const double xs_ = cc == 0 ? xv[0] : cc == 1 ? xv[1] : cc == 2 ? xv[2] : cc == 3 ? xv[3] : cc == 4 ? xv[4] : xv[5];
+      z0 = on0 ? z0 - a0 : (kk == i ? xs_ : z0);       // the solved block row replaces z in place
+      z1 = on1 ? z1 - a1 : (kk + 10 == i ? xs_ : z1);
+    }
+    if (t < 60) {
+      if (t < n) x[t] = z0;
+      if (t + 60 < n) x[t + 60] = z1;
+    }
+  } else if (ok && t < 64) {
     // Backward substitution by ONE wavefront, no workgroup barriers: x_i = L_ii^-T z_i as six dot products with the stored
     // inverse, then z_k -= L_ik^T x_i for all k < i spread over the lanes (lane -> (k, c)); LDS accesses of a wavefront
     // are ordered, so the steps chain without synchronisation.
@@ -1019,7 +1125,7 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
       for (int c = 0; c < 6; c++) {
         double v = zi[c];
 #pragma unroll
-        for (int q = c + 1; q < 6; q++) v += Lii[6 * c + q] * zi[q];
+        for (int q = c + 1; q < 6; q++) v += Lii[q * (q - 1) / 2 + c] * zi[q];     // X_i row-packed
         xv[c] = v;
       }
       if (t < 6) {
@@ -1445,19 +1551,26 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   bool rows_small = false;
   size_t rows_lds = 0;
   {
-    const size_t units = 3 * (size_t)nP * (nP + 1) / 2;
-    rows_small = units <= 640;
-    if (units <= 1024) rows_R = 1; else if (units <= 2048) rows_R = 2; else if (units <= 4096) rows_R = 4;
+    const size_t nblk = (size_t)nP * (nP + 1) / 2;            // a wavefront holds kBlkPerWave blocks (3 threads each)
+    rows_small = nblk <= 10 * kBlkPerWave;
+    if (nblk <= 16 * kBlkPerWave) rows_R = 1; else if (nblk <= 32 * kBlkPerWave) rows_R = 2; else if (nblk <= 64 * kBlkPerWave) rows_R = 4;
     if (getenv("ORBG_LDLT_BLK")) rows_R = 0;        // A/B switch: one-thread-per-block variant
-    const size_t base = (12 * (size_t)nP + 42 + 2 * (size_t)nP * kPanStride) * sizeof(double);
+    const size_t base = (12 * (size_t)nP + 36 + 32 + 2 * (size_t)nP * kPanStride) * sizeof(double);
     const size_t lall = (size_t)nP * (nP + 1) / 2 * 36 * sizeof(double);
     rows_l_in_lds = base + lall <= 150 * 1024;
     rows_lds = base + (rows_l_in_lds ? lall : 0);
     if (rows_R && rows_lds > 64 * 1024) {
-      const void* fn = (rows_R == 1 && rows_small) ? reinterpret_cast<const void*>(k_ldlt_rows<640, 1>)
-                     : rows_R == 1 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 1>)
-                     : rows_R == 2 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 2>)
-                                   : reinterpret_cast<const void*>(k_ldlt_rows<1024, 4>);
+      const void* fn;
+      if (rows_l_in_lds)
+        fn = (rows_R == 1 && rows_small) ? reinterpret_cast<const void*>(k_ldlt_rows<640, 1, true>)
+           : rows_R == 1 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 1, true>)
+           : rows_R == 2 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 2, true>)
+                         : reinterpret_cast<const void*>(k_ldlt_rows<1024, 4, true>);
+      else
+        fn = (rows_R == 1 && rows_small) ? reinterpret_cast<const void*>(k_ldlt_rows<640, 1, false>)
+           : rows_R == 1 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 1, false>)
+           : rows_R == 2 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 2, false>)
+                         : reinterpret_cast<const void*>(k_ldlt_rows<1024, 4, false>);
       ORBG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
     }
   }
@@ -1520,14 +1633,22 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         if (nP > 0) {
           hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                              h->d_EB.p, h->d_Hll.p, h->d_bl.p, h->d_Hpp.p, h->d_bp.p, lambda, h->d_S.p, h->d_bs.p);
-          if (rows_R == 1 && rows_small)
-            hipLaunchKernelGGL((k_ldlt_rows<640, 1>), dim3(1), dim3(640), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
-          else if (rows_R == 1)
-            hipLaunchKernelGGL((k_ldlt_rows<1024, 1>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
-          else if (rows_R == 2)
-            hipLaunchKernelGGL((k_ldlt_rows<1024, 2>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
-          else if (rows_R == 4)
-            hipLaunchKernelGGL((k_ldlt_rows<1024, 4>), dim3(1), dim3(1024), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, rows_l_in_lds, ldlt_nz);
+          if (rows_R) {
+            auto go = [&](auto kern, int nt) {
+              hipLaunchKernelGGL(kern, dim3(1), dim3(nt), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz);
+            };
+            if (rows_l_in_lds) {
+              if (rows_R == 1 && rows_small) go(k_ldlt_rows<640, 1, true>, 640);
+              else if (rows_R == 1) go(k_ldlt_rows<1024, 1, true>, 1024);
+              else if (rows_R == 2) go(k_ldlt_rows<1024, 2, true>, 1024);
+              else go(k_ldlt_rows<1024, 4, true>, 1024);
+            } else {
+              if (rows_R == 1 && rows_small) go(k_ldlt_rows<640, 1, false>, 640);
+              else if (rows_R == 1) go(k_ldlt_rows<1024, 1, false>, 1024);
+              else if (rows_R == 2) go(k_ldlt_rows<1024, 2, false>, 1024);
+              else go(k_ldlt_rows<1024, 4, false>, 1024);
+            }
+          }
           else if (nP <= 22)
             hipLaunchKernelGGL(k_ldlt_blk<256>, dim3(1), dim3(256), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
           else if (nP <= 44)
