@@ -714,6 +714,31 @@ void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, in
   else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
+// Rotation histogram without per-call allocations: bin counts + one reusable (bin, index) list in push order.
+struct RotHist {
+  int cnt[HISTO_LENGTH];
+  std::vector<uint32_t>& e;
+  explicit RotHist(std::vector<uint32_t>& store) : e(store) { for (int& c : cnt) c = 0; e.clear(); }
+  void add(int bin, int idx) { cnt[bin]++; e.push_back(((uint32_t)bin << 24) | (uint32_t)idx); }
+  // ORBmatcher::ComputeThreeMaxima, S/ORBmatcher.cc:2312-2353, on the bin sizes; calls drop(idx) for every entry outside
+  template <typename DropFn>
+  void reject_outside_three_maxima(DropFn drop) const {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int s = cnt[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    for (const uint32_t v : e) {
+      const int bin = (int)(v >> 24);
+      if (bin != ind1 && bin != ind2 && bin != ind3) drop((int)(v & 0xFFFFFFu));
+    }
+  }
+};
+
 inline int rot_bin(float a1, float a2) {   // factor = 1/HISTO_LENGTH
   const float factor = 1.0f / HISTO_LENGTH;
   float rot = a1 - a2;
@@ -729,6 +754,14 @@ inline int rot_bin(float a1, float a2) {   // factor = 1/HISTO_LENGTH (SURVEY.md
 // frame object
 
 struct orbm_frame {
+  std::vector<uint8_t> claimed_buf;      // reusable host scratch of the serial commits
+  std::vector<uint32_t> rot_entries;
+  // octave / angle of the frame's keypoints in ordinary (cached) host memory: the serial commits index them at random,
+  // and the pinned mirror the GPU has just written costs a DRAM round trip per touched line
+  std::vector<float> hk_angle;
+  std::vector<int8_t> hk_oct;
+  const orbx_keypoint* hk_cached_from = nullptr;
+  int hk_cached_n = -1;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[2] = {};
@@ -838,7 +871,7 @@ extern "C" int orbm_frame_upload(orbm_frame* f, const orbm_frame_view* v) {
   if ((rc = frame_reserve(f, v->n))) return rc;
   const int n = v->n;
   f->h_kps_own.assign(v->kps, v->kps + n);
-  f->hk = f->h_kps_own.data();
+  f->hk = f->h_kps_own.data(); f->hk_cached_n = -1;
   f->kps_p = f->d_kps.p; f->desc_p = f->d_desc.p; f->uright_p = f->d_uright.p; f->depth_p = f->d_depth.p;
   f->has_uright = v->uright != nullptr;
   if (n > 0) {
@@ -865,7 +898,7 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
   // extraction on that handle) and its pinned host mirror of the keypoints.  Every orbx_* entry point synchronises
   // its stream before returning, so the data is complete here.
   f->has_uright = true;
-  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk;
+  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
   return frame_build_grid(f);      // asynchronous on the frame's stream; the searches run on the same stream
 }
 
@@ -880,14 +913,14 @@ int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v
   if ((rc = frame_set_params(f, v, n < 0 ? 0 : n))) return rc;
   if ((rc = frame_reserve(f, n < 0 ? std::max(f->cap, 4096) : n))) return rc;
   f->has_uright = true;
-  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk;
+  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
   hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
                      f->d_cell_items.p, d_n);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;
 }
 
-void orbm_internal_set_n(orbm_frame* f, int n) { f->fp.n = n; }
+void orbm_internal_set_n(orbm_frame* f, int n) { f->fp.n = n; f->hk_cached_n = -1; }
 
 // device-resident descriptors of the frame's features (for the vocabulary transform in bow.hip)
 int orbm_internal_features(orbm_frame* f, const uint8_t** d_desc, int* n, hipStream_t* stream) {
@@ -940,7 +973,7 @@ extern "C" int orbk_frame_from_wire(orbm_frame* f, const orbm_frame_view* v, con
   f->kps_p = f->d_kps.p; f->desc_p = f->d_desc.p; f->uright_p = f->d_uright.p; f->depth_p = f->d_depth.p;
   f->has_uright = false;
   f->h_kps_own.resize((size_t)std::max(n, 1));
-  f->hk = f->h_kps_own.data();
+  f->hk = f->h_kps_own.data(); f->hk_cached_n = -1;
   if (n > 0) {
     const size_t bytes = (size_t)n * (kWireKp + kWireDesc);
     const uint8_t* d_wire = wire;
@@ -1147,6 +1180,16 @@ static FrameDev frame_dev(orbm_frame* f) {
 }
 
 // ---- staging: pack every per-call host array into one pinned block, one H2D copy
+// (re)builds the cached octave / angle arrays; `fresh` forces it (a new frame was attached to the same buffers)
+static void cache_keypoint_fields(orbm_frame* f) {
+  const int n = f->fp.n;
+  if (f->hk_cached_from == f->hk && f->hk_cached_n == n) return;
+  f->hk_angle.resize((size_t)std::max(n, 1));
+  f->hk_oct.resize((size_t)std::max(n, 1));
+  for (int i = 0; i < n; i++) { f->hk_angle[i] = f->hk[i].angle; f->hk_oct[i] = (int8_t)f->hk[i].octave; }
+  f->hk_cached_from = f->hk; f->hk_cached_n = n;
+}
+
 static int stage_begin(orbm_frame* f, size_t total_bytes) {
   int rc;
   const size_t need = total_bytes + 64 * 16;
@@ -1247,11 +1290,14 @@ static int pick_unclaimed(orbm_frame* f, const QResult& r, int want, ClaimedFn c
 // Serial commit of SearchByProjection(Frame, MapPoints): S/ORBmatcher.cc:85-141 replayed on the GPU results.
 static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio, int32_t* amp, int32_t* aob, int* nmatches_out) {
   const int n = f->fp.n;
-  std::vector<uint8_t> claimed(std::max(n, 1), 0);   // features newly assigned in this call to an MP with Observations()>0
+  cache_keypoint_fields(f);
+  f->claimed_buf.assign((size_t)std::max(n, 1), 0);  // features newly assigned in this call to an MP with Observations()>0
+  uint8_t* claimed = f->claimed_buf.data();
   int nmatches = 0;
   const QResult* R = f->results.h;
   auto is_claimed = [&](int idx) { return claimed[idx] != 0; };
   for (int i = 0; i < m; i++) {
+    __builtin_prefetch(&R[i + 16]);                     // results sit in pinned memory the GPU has just written
     const QResult& r = R[i];
     if (r.n_top == 0) continue;
     Pick pk;
@@ -1259,8 +1305,8 @@ static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio,
     if (rc) return rc;
     if (pk.idx1 < 0) continue;
     const int bestDist = pk.dist1, bestIdx = pk.idx1, bestDist2 = pk.dist2, idx2 = pk.idx2;
-    const int bestLevel = f->hk[bestIdx].octave;
-    const int bestLevel2 = idx2 >= 0 ? f->hk[idx2].octave : -1;
+    const int bestLevel = f->hk_oct[bestIdx];
+    const int bestLevel2 = idx2 >= 0 ? f->hk_oct[idx2] : -1;
     if (bestDist <= TH_HIGH) {
       if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
       if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
@@ -1367,12 +1413,15 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
   });
   if (rc) return rc;
   // serial commit (S/ORBmatcher.cc:2041-2091) + rotation consistency (:2164-2183)
-  std::vector<uint8_t> claimed(std::max(n, 1), 0);
-  std::vector<int> rotHist[HISTO_LENGTH];
+  cache_keypoint_fields(f);
+  f->claimed_buf.assign((size_t)std::max(n, 1), 0);
+  uint8_t* claimed = f->claimed_buf.data();
+  RotHist rotHist(f->rot_entries);
   int nmatches = 0;
   const QResult* R = f->results.h;
   auto is_claimed = [&](int idx) { return claimed[idx] != 0; };
   for (int i = 0; i < m; i++) {
+    __builtin_prefetch(&R[i + 16]);                     // results sit in pinned memory the GPU has just written
     const QResult& r = R[i];
     if (r.n_top == 0) continue;
     Pick pk;
@@ -1384,16 +1433,11 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
       assigned_obs[bestIdx] = last->n_obs[i];
       if (last->n_obs[i] > 0) claimed[bestIdx] = 1;
       nmatches++;
-      if (check_orientation) rotHist[rot_bin(last->angle[i], f->hk[bestIdx].angle)].push_back(bestIdx);
+      if (check_orientation) rotHist.add(rot_bin(last->angle[i], f->hk_angle[bestIdx]), bestIdx);
     }
   }
-  if (check_orientation) {
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < HISTO_LENGTH; i++)
-      if (i != ind1 && i != ind2 && i != ind3)
-        for (int idx : rotHist[i]) { assigned_mp[idx] = -1; assigned_obs[idx] = 0; nmatches--; }
-  }
+  if (check_orientation)
+    rotHist.reject_outside_three_maxima([&](int idx) { assigned_mp[idx] = -1; assigned_obs[idx] = 0; nmatches--; });
   if (nmatches_out) *nmatches_out = nmatches;
   return ORBG_OK;
 }
@@ -1446,12 +1490,15 @@ static int bow_common(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t
                        d_jobs, nj, cnt, cnt_next, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
-  std::vector<int> rotHist[HISTO_LENGTH];
-  std::vector<uint8_t> taken(std::max(n, 1), 0);          // vpMapPointMatches[idx] != NULL (:324) / vbMatched2[idx] (:872)
+  cache_keypoint_fields(f);
+  RotHist rotHist(f->rot_entries);
+  f->claimed_buf.assign((size_t)std::max(n, 1), 0);       // vpMapPointMatches[idx] != NULL (:324) / vbMatched2[idx] (:872)
+  uint8_t* taken = f->claimed_buf.data();
   int nmatches = 0;
   const QResult* R = f->results.h;
   auto is_taken = [&](int idx) { return taken[idx] != 0; };
   for (int j = 0; j < nj; j++) {
+    __builtin_prefetch(&R[j + 16]);
     const QResult& r = R[j];
     if (r.n_top == 0) continue;
     Pick pk;
@@ -1464,19 +1511,12 @@ static int bow_common(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t
         const int q = jobs[j].kf_idx;
         taken[bestIdxF] = 1;
         if (by_query) matches[q] = bestIdxF; else matches[bestIdxF] = q;
-        if (check_orientation) rotHist[rot_bin(kf_angle[q], f->hk[bestIdxF].angle)].push_back(by_query ? q : bestIdxF);
+        if (check_orientation) rotHist.add(rot_bin(kf_angle[q], f->hk_angle[bestIdxF]), by_query ? q : bestIdxF);
         nmatches++;
       }
     }
   }
-  if (check_orientation) {
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-      if (i == ind1 || i == ind2 || i == ind3) continue;
-      for (int idx : rotHist[i]) { matches[idx] = -1; nmatches--; }
-    }
-  }
+  if (check_orientation) rotHist.reject_outside_three_maxima([&](int idx) { matches[idx] = -1; nmatches--; });
   if (nmatches_out) *nmatches_out = nmatches;
   return ORBG_OK;
 }
@@ -1543,6 +1583,7 @@ extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const
   const float low = TH_LOW * ratio_hamming;
   auto is_claimed = [&](int idx) { return claimed[idx] != 0; };
   for (int i = 0; i < m; i++) {
+    __builtin_prefetch(&R[i + 16]);                     // results sit in pinned memory the GPU has just written
     const QResult& r = R[i];
     if (r.n_top == 0) continue;
     Pick pk;
