@@ -221,7 +221,7 @@ struct Huber { double delta_mono, dsqr_mono, delta_stereo, dsqr_stereo; };
 // ---------------------------------------------------------------------------------------------- kernels
 
 // residuals + chi2 + robust rho (computeActiveErrors + activeRobustChi2); block partial sums in fixed order
-struct HostRec { double chi2, scale, maxdiag; int ok; unsigned seq; };   // seq is written last: the host spins on it   // what the host reads per LM trial (mapped pinned memory)
+struct HostRec { double chi2, scale, maxdiag, chi2_init; int ok; unsigned seq; };   // seq is written last: the host spins on it   // what the host reads per LM trial (mapped pinned memory)
 
 // Results of a solve, written by the GPU straight into the caller-visible pinned block (no copy commands): per edge a flag
 // byte (bit 0 = isDepthPositive() with the final estimate, bit 1 = outlier: chi2 > 5.991 / 7.815 or depth <= 0,
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
     for (int i = 0; i < np; i++) chi += i < 1024 ? parts[i] : __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = 0; i < n_scale_partial; i++)
       scale += np + i < 1024 ? parts[np + i] : __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    rec->chi2 = chi; rec->scale = scale; rec->maxdiag = 0; rec->ok = ok_flag ? *ok_flag : 1;
+    rec->chi2 = chi; rec->scale = scale; rec->ok = ok_flag ? *ok_flag : 1;     // maxdiag / chi2_init stay as k_finish left them
     *ticket = 0;
     __threadfence_system();
     *reinterpret_cast<volatile unsigned*>(&rec->seq) = seq;       // the host polls this word instead of hipStreamSynchronize
@@ -539,8 +539,9 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
                                                         const int* __restrict__ pair_start, const PairItem* __restrict__ items,
                                                         const double* __restrict__ EB, const double* __restrict__ Hll,
                                                         const double* __restrict__ bl, const double* __restrict__ Hpp,
-                                                        const double* __restrict__ bp, double lambda, double* __restrict__ S,
-                                                        double* __restrict__ bs) {
+                                                        const double* __restrict__ bp, double lambda_v, double* __restrict__ S,
+                                                        double* __restrict__ bs, const double* __restrict__ lambda_p) {
+  const double lambda = lambda_p ? *lambda_p : lambda_v;      // first trial of a round: lambda was computed on the device
   // one workgroup per pose pair, one thread per shared landmark (the diagonal pairs hold every landmark of the pose:
   // ~550 at C2, so 256 threads keep their item loop at 3 rounds); sums in a fixed order: per thread, then 4 x 64, then 4
   __shared__ double red[42][kSchurThreads + 1];
@@ -1153,9 +1154,11 @@ __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int n
                                                const double* __restrict__ points, double* __restrict__ x,
                                                const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
                                                const int* __restrict__ pf_col, const double* __restrict__ EB,
-                                               const double* __restrict__ Hll, const double* __restrict__ bl, double lambda,
+                                               const double* __restrict__ Hll, const double* __restrict__ bl, double lambda_v,
                                                PoseQ* __restrict__ poses_out, double* __restrict__ points_out,
-                                               const double* __restrict__ bp, double* __restrict__ scale_partial) {
+                                               const double* __restrict__ bp, double* __restrict__ scale_partial,
+                                               const double* __restrict__ lambda_p) {
+  const double lambda = lambda_p ? *lambda_p : lambda_v;
   __shared__ double red[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
   double sc = 0;                     // this thread's share of computeScale(): sum x (lambda x + b)  (levenberg.cpp:187-194)
@@ -1203,7 +1206,8 @@ __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int n
 __global__ __launch_bounds__(256) void k_finish(int n_partial, const double* __restrict__ partial, int nP, int nL,
                                                const double* __restrict__ x, const double* __restrict__ bp, const double* __restrict__ bl,
                                                const double* __restrict__ Hpp, const double* __restrict__ Hll, double lambda,
-                                               const int* __restrict__ ok_flag, int want_scale, int want_maxdiag, HostRec* __restrict__ rec) {
+                                               const int* __restrict__ ok_flag, int want_scale, int want_maxdiag, HostRec* __restrict__ rec,
+                                               double lambda_init, double* __restrict__ lambda0_out) {
   __shared__ double red[256];
   __shared__ double parts[1024];
   const int tid = threadIdx.x;
@@ -1248,7 +1252,14 @@ __global__ __launch_bounds__(256) void k_finish(int n_partial, const double* __r
     __syncthreads();
   }
   if (tid == 0) {
-    rec->chi2 = chi; rec->scale = scale; rec->maxdiag = red[0]; rec->ok = ok_flag ? *ok_flag : 1;
+    if (lambda0_out) {
+      // start of an LM round (computeLambdaInit, levenberg.cpp:177-185): the first trial reads lambda from device memory, the
+      // host picks chi2 / max diagonal up together with that trial's record -- no synchronisation in between
+      rec->chi2_init = chi; rec->maxdiag = red[0];
+      *lambda0_out = lambda_init > 0 ? lambda_init : 1e-5 * red[0];
+    } else {
+      rec->chi2 = chi; rec->scale = scale; rec->maxdiag = red[0]; rec->ok = ok_flag ? *ok_flag : 1;
+    }
   }
 }
 
@@ -1263,6 +1274,7 @@ struct lba_handle {
   DevBuf<PoseQ> d_poses[2];
   DevBuf<double> d_points[2];
   DevBuf<double> d_err, d_chi2, d_partial, d_EB, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_x;
+  DevBuf<double> d_EB2, d_Hll2, d_bl2, d_Hpp2, d_bp2, d_lambda0;   // second linearisation set (speculative next iteration)
   DevBuf<int> d_pose_col, d_point_col, d_pt_start, d_pt_edges, d_ps_start, d_ps_edges, d_pf_start, d_pf_edges, d_pf_col;
   DevBuf<int> d_pair_i1, d_pair_i2, d_pair_start, d_ok;
   DevBuf<PairItem> d_items;
@@ -1311,6 +1323,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   h->d_edges.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release();
   h->d_err.release(); h->d_chi2.release(); h->d_partial.release(); h->d_EB.release(); h->d_Hll.release(); h->d_bl.release();
   h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release();
+  h->d_EB2.release(); h->d_Hll2.release(); h->d_bl2.release(); h->d_Hpp2.release(); h->d_bp2.release(); h->d_lambda0.release();
   h->d_pose_col.release(); h->d_point_col.release(); h->d_pt_start.release(); h->d_pt_edges.release(); h->d_ps_start.release();
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
   h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release(); h->d_scale_partial.release(); h->d_ticket.release();
@@ -1524,6 +1537,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       (rc = h->d_partial.reserve(std::max(n_blocks_e, 1))) || (rc = h->d_EB.reserve(std::max<size_t>((size_t)NE * kEB, 1))) ||
       (rc = h->d_Hll.reserve(std::max<size_t>(6 * (size_t)nL, 1))) || (rc = h->d_bl.reserve(std::max<size_t>(3 * (size_t)nL, 1))) ||
       (rc = h->d_Hpp.reserve(std::max<size_t>(21 * (size_t)nP, 1))) || (rc = h->d_bp.reserve(std::max<size_t>(6 * (size_t)nP, 1))) ||
+      (rc = h->d_EB2.reserve(std::max<size_t>((size_t)NE * kEB, 1))) || (rc = h->d_Hll2.reserve(std::max<size_t>(6 * (size_t)nL, 1))) ||
+      (rc = h->d_bl2.reserve(std::max<size_t>(3 * (size_t)nL, 1))) || (rc = h->d_Hpp2.reserve(std::max<size_t>(21 * (size_t)nP, 1))) ||
+      (rc = h->d_bp2.reserve(std::max<size_t>(6 * (size_t)nP, 1))) || (rc = h->d_lambda0.reserve(2)) ||
       (rc = h->d_S.reserve(std::max<size_t>((size_t)n * n, 1))) || (rc = h->d_bs.reserve(std::max(n, 1))) ||
       (rc = h->d_x.reserve(std::max<size_t>((size_t)n + 3 * (size_t)nL, 1))))
     return rc;
@@ -1588,11 +1604,49 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
                          h->d_err.p, h->d_chi2.p, h->d_partial.p, final_mode, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u,
                          h->d_ok.p, h->rec.d, final_mode ? ++h->rec_seq : 0u);
   };
+  // two sets of linearisation outputs: while the host waits for the verdict on a trial, the linearisation of the TRIAL
+  // state (= the next iteration's, if the trial is accepted -- the usual case) is already running into the other set
+  double* const EBs[2] = {h->d_EB.p, h->d_EB2.p};
+  double* const Hlls[2] = {h->d_Hll.p, h->d_Hll2.p};
+  double* const bls[2] = {h->d_bl.p, h->d_bl2.p};
+  double* const Hpps[2] = {h->d_Hpp.p, h->d_Hpp2.p};
+  double* const bps[2] = {h->d_bp.p, h->d_bp2.p};
+  int ls = 0;                      // linearisation set of the current iteration
+  bool spec_ready = false;         // set ls^1 holds the linearisation of the current estimate
+  auto launch_linearise = [&](int buf, int set) {
+    if (NE > 0 || nP > 0)
+      hipLaunchKernelGGL(k_lin_all, dim3(nP + (NE > 0 ? n_blocks_e : 0)), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[buf].p,
+                         h->d_points[buf].p, cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
+                         D.ps_edges, Hpps[set], bps[set]);
+    if (nL > 0)
+      hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, D.pt_start, D.pt_edges, EBs[set],
+                         Hlls[set], bls[set]);
+  };
   auto finish = [&](double lambda, int want_scale, int want_maxdiag, bool with_ok) -> int {
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, h->d_bp.p, h->d_bl.p, h->d_Hpp.p,
-                       h->d_Hll.p, lambda, with_ok ? h->d_ok.p : (int*)nullptr, want_scale, want_maxdiag, h->rec.d);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, bps[ls], bls[ls], Hpps[ls],
+                       Hlls[ls], lambda, with_ok ? h->d_ok.p : (int*)nullptr, want_scale, want_maxdiag, h->rec.d, 0.0, (double*)nullptr);
     ORBG_HIP(hipGetLastError());
     ORBG_HIP(hipStreamSynchronize(st));
+    return ORBG_OK;
+  };
+  auto poll_record = [&]() -> int {
+    // the last workgroup of k_errors publishes the record and then its sequence number: spin on that word (the
+    // runtime's completion path costs ~10 us per LM trial); fall back to a stream sync if it does not arrive
+    volatile unsigned* w = &h->rec.h->seq;
+    const unsigned want = h->rec_seq;
+    bool got = false;
+    if (!getenv("ORBG_NO_POLL")) {
+      timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (unsigned spins = 0; !got; spins++) {
+        if (*w == want) { got = true; break; }
+        if ((spins & 0xFFFF) == 0xFFFF) {
+          timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+          if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 50.0) break;
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (!got) ORBG_HIP(hipStreamSynchronize(st));
     return ORBG_OK;
   };
 
@@ -1601,38 +1655,46 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   bool first_chi = true;
   bool err_valid = false;          // d_err / d_chi2 hold the residuals of the CURRENT estimate
   double currentChi = 0;
+  bool last_round = false;
   auto optimize = [&](int iterations, int* done_out) -> int {
     int done = 0;
     bool ok = true;
     for (int it = 0; it < iterations && !terminate() && ok; it++) {
       // computeActiveErrors (skipped when the residuals of the current estimate are already on the device:
-      // recomputing them would reproduce the same bits) + buildSystem
-      if (!err_valid) { launch_errors(cur, 0); err_valid = true; }
-      if (NE > 0 || nP > 0)
-        hipLaunchKernelGGL(k_lin_all, dim3(nP + (NE > 0 ? n_blocks_e : 0)), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[cur].p,
-                           h->d_points[cur].p, cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, h->d_EB.p, D.ps_start,
-                           D.ps_edges, h->d_Hpp.p, h->d_bp.p);
-      if (nL > 0)
-        hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, D.pt_start, D.pt_edges, h->d_EB.p,
-                           h->d_Hll.p, h->d_bl.p);
+      // recomputing them would reproduce the same bits) + buildSystem (skipped when the speculative set holds it)
+      if (spec_ready) {
+        ls ^= 1;
+        spec_ready = false;
+      } else {
+        if (!err_valid) { launch_errors(cur, 0); err_valid = true; }
+        launch_linearise(cur, ls);
+      }
       int rc2;
+      bool lambda_on_device = false;
       if (it == 0) {
-        // the only place the host needs chi2 / max diagonal before the first trial (computeLambdaInit)
-        if ((rc2 = finish(0.0, 0, 1, false))) return rc2;
-        currentChi = h->rec.h->chi2;
-        lambda = p->lambda_init > 0 ? p->lambda_init : 1e-5 * h->rec.h->maxdiag;
+        if (NE > 0) {
+          // computeLambdaInit without a host round trip: k_finish leaves lambda in device memory for the first trial
+          hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, bps[ls], bls[ls], Hpps[ls],
+                             Hlls[ls], 0.0, (int*)nullptr, 0, 1, h->rec.d, p->lambda_init, h->d_lambda0.p);
+          lambda_on_device = true;
+        } else {
+          if ((rc2 = finish(0.0, 0, 1, false))) return rc2;
+          currentChi = h->rec.h->chi2;
+          lambda = p->lambda_init > 0 ? p->lambda_init : 1e-5 * h->rec.h->maxdiag;
+        }
         ni = 2; nBad = 0;
       }
-      if (first_chi) { r->chi2_initial = currentChi; first_chi = false; }
+      if (!lambda_on_device && first_chi) { r->chi2_initial = currentChi; first_chi = false; }
       double tempChi = currentChi;
-      const double iniChi = currentChi;
+      double iniChi = currentChi;
       double rho = 0;
       int qmax = 0;
       do {
         const int trial = cur ^ 1;
+        const double* lam_p = lambda_on_device ? h->d_lambda0.p : (const double*)nullptr;
         if (nP > 0) {
           hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
-                             h->d_EB.p, h->d_Hll.p, h->d_bl.p, h->d_Hpp.p, h->d_bp.p, lambda, h->d_S.p, h->d_bs.p);
+                             EBs[ls], Hlls[ls], bls[ls], Hpps[ls], bps[ls], lambda, h->d_S.p, h->d_bs.p, lam_p);
           if (rows_R) {
             auto go = [&](auto kern, int nt) {
               hipLaunchKernelGGL(kern, dim3(1), dim3(nt), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz);
@@ -1659,32 +1721,26 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           ORBG_HIP(hipMemsetAsync(h->d_ok.p, 0xFF, sizeof(int), st));   // nothing to solve: ok
         }
         hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, D.pose_col, D.point_col,
-                           h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, h->d_EB.p,
-                           h->d_Hll.p, h->d_bl.p, lambda, h->d_poses[trial].p, h->d_points[trial].p, h->d_bp.p, h->d_scale_partial.p);
+                           h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
+                           Hlls[ls], bls[ls], lambda, h->d_poses[trial].p, h->d_points[trial].p, bps[ls], h->d_scale_partial.p, lam_p);
         if (NE > 0) {
           launch_errors(trial, 1);
+          // speculate on acceptance: linearise the trial state into the other set while the host waits for the verdict
+          // (not after the very last iteration that can run)
+          const bool may_continue = !(last_round && it + 1 >= iterations);
+          if (may_continue) launch_linearise(trial, ls ^ 1);
           ORBG_HIP(hipGetLastError());
-          {
-            // the last workgroup of k_errors publishes the record and then its sequence number: spin on that word (the
-            // runtime's completion path costs ~10 us per LM trial); fall back to a stream sync if it does not arrive
-            volatile unsigned* w = &h->rec.h->seq;
-            const unsigned want = h->rec_seq;
-            bool got = false;
-            if (!getenv("ORBG_NO_POLL")) {
-              timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
-              for (unsigned spins = 0; !got; spins++) {
-                if (*w == want) { got = true; break; }
-                if ((spins & 0xFFFF) == 0xFFFF) {
-                  timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-                  if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 50.0) break;
-                }
-              }
-              __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            }
-            if (!got) ORBG_HIP(hipStreamSynchronize(st));
-          }
+          if ((rc2 = poll_record())) return rc2;
         } else if ((rc2 = finish(lambda, 1, 0, true))) {
           return rc2;
+        }
+        if (lambda_on_device) {
+          // the round's initial chi2 / lambda, as the device computed them before this first trial
+          currentChi = h->rec.h->chi2_init;
+          lambda = p->lambda_init > 0 ? p->lambda_init : 1e-5 * h->rec.h->maxdiag;
+          lambda_on_device = false;
+          if (first_chi) { r->chi2_initial = currentChi; first_chi = false; }
+          tempChi = currentChi; iniChi = currentChi;
         }
         const bool ok2 = h->rec.h->ok != 0;
         tempChi = h->rec.h->chi2;
@@ -1702,10 +1758,12 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           currentChi = tempChi;
           cur = trial;                                // discardTop(): keep the trial state
           err_valid = true;
+          spec_ready = NE > 0 && !(last_round && it + 1 >= iterations);
         } else {
           lambda *= ni;
           ni *= 2;                                    // pop(): current buffer untouched
           err_valid = false;                          // d_err now belongs to the rejected trial
+          spec_ready = false;
         }
         qmax++;
       } while (rho < 0 && qmax < 10 && !terminate());
@@ -1727,6 +1785,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   if ((rc = optimize(p->its_round1 > 0 ? p->its_round1 : 5, &done))) return rc;
   r->iters_round1 = done;
   if (!terminate()) {
+    last_round = true;
     if ((rc = optimize(p->its_round2 > 0 ? p->its_round2 : 10, &done))) return rc;
     r->iters_round2 = done;
   }
