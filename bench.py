@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--profile-stages", action="store_true",
                     help="bracket every extractor stage with HIP events (more API calls per frame); by default only "
                          "fast_cells_kernel (the roofline kernel) is bracketed")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="construct every frame synchronously before it is tracked; by default frame t+1's constructor "
+                         "(orbx_frame_stereo_dev_submit on a second extractor handle) runs while frame t is tracked")
     ap.add_argument("--lba-mode", choices=["async", "thread", "inline"], default="async",
                     help="async: LBA runs on the library's worker thread + its own HIP stream concurrently with tracking, as the "
                          "reference's LocalMapping thread does (S/ClientSystem.cc:105-106); thread: the same from a Python "
@@ -184,6 +187,11 @@ def main():
     p = scene.frame_view_params()
     fv, fv_keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
     F = api.Frame(4096, device)
+    pipeline = not (args.no_pipeline or args.separate_calls)
+    # frame t+1 is constructed (second extractor handle, second frame object) while frame t is tracked
+    exs = [ex, api.ORBextractor(1000, 1.2, 8, 20, 7, W, H, n_cams=2, device=device)] if pipeline else [ex]
+    Fs = [F, api.Frame(4096, device)] if pipeline else [F]
+    in_flight = [False, False]
     LM = api.LocalMap(16384, device)
     m_frame = api.ORBmatcher(0.9, True, device)
     m_map = api.ORBmatcher(0.8, True, device)
@@ -200,7 +208,8 @@ def main():
     po_prob2 = synth.make_pose_opt_problem(n=650, seed=78 + rank)
     po2, po2_keep = views.pose_opt_problem(po_prob2["Xw"], po_prob2["u"], po_prob2["v"], po_prob2["ur"], po_prob2["inv_sigma2"],
                                           po_prob2["cam"], po_prob2["Tcw"], device=device)
-    ex.set_profiling(2 if args.profile_stages else 1)
+    for e in exs:
+        e.set_profiling(2 if args.profile_stages else 1)
     ev_overhead_ms = ex.event_overhead_ms(100)
     FAST_BRACKET_EVERY = 1 if args.profile_stages else 4         # the event pair costs ~5 us of stream time: sample every 4th frame
     kern = dict(fast_kernel_ms=0.0, octree_host_ms=0.0)
@@ -250,7 +259,19 @@ def main():
         fr = frames[k]
         dL, dR = imgs[k]
         t0 = time.perf_counter()
-        if args.separate_calls:
+        Fc, exc = F, ex
+        if pipeline:
+            c = i & 1
+            Fc, exc = Fs[c], exs[c]
+            if not in_flight[c]:                          # first step only: nothing was submitted ahead
+                exc.frame_stereo_dev_submit(Fc, fv, dL.data_ptr(), dR.data_ptr(), W, H, W, bf, bb)
+            nl, nr = exc.frame_stereo_dev_wait()
+            in_flight[c] = False
+            nxt = imgs[seq[(i + 1) % len(seq)]]           # Frame::Frame(t+1) runs during the tracking of frame t
+            exs[c ^ 1].frame_stereo_dev_submit(Fs[c ^ 1], fv, nxt[0].data_ptr(), nxt[1].data_ptr(), W, H, W, bf, bb)
+            in_flight[c ^ 1] = True
+            t1 = t2 = time.perf_counter()
+        elif args.separate_calls:
             nl, nr = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W)[:2]
             t1 = time.perf_counter()
             ex.ComputeStereoMatches(bf, bb, download=False)
@@ -263,9 +284,9 @@ def main():
         t3 = time.perf_counter()
         amp = amp_buf[:nl]; aob = aob_buf[:nl]
         amp.fill(-1); aob.fill(0)                         # F.mvpMapPoints starts empty (S/Frame.cc:113)
-        amp, aob, n1 = m_frame.SearchByProjectionFrame(F, fr["guess"], frames[k_last]["last_view"][0], 7.0, False, amp, aob, inplace=True)
+        amp, aob, n1 = m_frame.SearchByProjectionFrame(Fc, fr["guess"], frames[k_last]["last_view"][0], 7.0, False, amp, aob, inplace=True)
         t4 = time.perf_counter()
-        amp, aob, n2 = m_map.SearchLocalPoints(F, LM, fr["guess"], 1.0, False, 0.0, amp, aob, None, inplace=True)
+        amp, aob, n2 = m_map.SearchLocalPoints(Fc, LM, fr["guess"], 1.0, False, 0.0, amp, aob, None, inplace=True)
         t5 = time.perf_counter()
         if args.pose_opt:
             # TrackWithMotionModel / TrackLocalMap call PoseOptimization after each search (S/Tracking.cc:2649,2712);
@@ -301,7 +322,7 @@ def main():
                             ("match_map", t5 - t4), ("map_upload", t6 - tpo), ("lba", t7 - t6)):
                 stage[key] += dt
             if args.profile_stages:
-                tm = ex.timings()
+                tm = exc.timings()
                 for key in kern:
                     kern[key] += tm[key]
             stats["kp"] += nl + nr; stats["m_frame"] += n1; stats["m_map"] += n2
@@ -318,9 +339,14 @@ def main():
     def sync():
         lba_q.join()                                   # every LBA triggered inside the timed region has finished
         collect_async()
+        for c in range(len(exs)):                      # ... and so has the frame constructor submitted by the last step
+            if pipeline and in_flight[c]:
+                exs[c].frame_stereo_dev_wait()
+                in_flight[c] = False
         torch.cuda.synchronize()
 
-    ex.set_profile_interval(FAST_BRACKET_EVERY, reset=True)
+    for e in exs:
+        e.set_profile_interval(max(FAST_BRACKET_EVERY // len(exs), 1), reset=True)
     # barrier + synchronize, exactly K steps, synchronize + barrier, MAX over ranks (harness.AgentGroup.timed)
     elapsed = grp.timed(lambda i: step(args.warmup + i, True), args.steps, sync)
     # informational: one PoseOptimization call (not part of `value` unless --pose-opt)
@@ -336,7 +362,10 @@ def main():
         # fast_cells_kernel is bracketed by a HIP event pair on the extractor's stream in every timed step; an EMPTY pair on
         # that stream already measures ev_overhead_ms (event-record commands are not free), so the kernel's launch
         # duration is the bracket minus that constant -- this is the figure that agrees with rocprofv3's kernel trace
-        fast_sum, fast_n = ex.fast_kernel_stats()              # bracket times accumulated inside the library over the timed region
+        fast_sum, fast_n = 0.0, 0                              # bracket times accumulated inside the library over the timed region
+        for e in exs:
+            fs_, fn_ = e.fast_kernel_stats()
+            fast_sum += fs_; fast_n += fn_
         fast_ms_raw = fast_sum / max(fast_n, 1)
         fast_ms = max(fast_ms_raw - ev_overhead_ms, 1e-6)
         fast_bytes = 2 * PYR_PIXELS_640x480 + (stats["kp"] / K) * 4.0     # both cameras' pyramid pixels + packed candidates
@@ -370,6 +399,9 @@ def main():
                        "avg_keypoints_per_stereo_frame": round(stats["kp"] / K, 1),
                        "avg_matches_frame": round(stats["m_frame"] / K, 1), "avg_matches_map": round(stats["m_map"] / K, 1),
                        "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt),
+                       "frame_ctor": ("pipelined: Frame(t+1) is submitted on a second extractor handle before frame t is tracked and "
+                                      "collected at the start of step t+1; the constructor left in flight by the last timed step is "
+                                      "waited for inside the timed region") if pipeline else "synchronous",
                        "pose_opt_ms_per_call_450_correspondences": round(pose_opt_ms, 4),
                        "lba_ms_per_call": round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3),
                        "sequential_fps_formula": round(1.0 / (sum(v for k2, v in stage.items() if k2 != "lba") / K +

@@ -162,6 +162,14 @@ int orbx_frame_stereo_dev(orbx_handle* h, orbm_frame* frame, const orbm_frame_vi
                           const uint8_t* d_img_right, int width, int height, int stride, float bf, float b,
                           orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
                           int* n_left, int* n_right);
+/* The same constructor in two halves: _submit enqueues the whole chain (pyramids .. grid) on the handle's stream and
+ * returns, _wait completes it (redoing the frame with the host quad-trees if a device list overflowed) and returns the
+ * feature counts.  Between the two calls the handle, `frame` and the images must be left alone; work on OTHER handles /
+ * frames (the searches of the previous frame, S/Tracking.cc:2629-2735) may run meanwhile and overlaps on the GPU.
+ * One submission per handle at a time; no host copies of the features in this form. */
+int orbx_frame_stereo_dev_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* d_img_left,
+                                 const uint8_t* d_img_right, int width, int height, int stride, float bf, float b);
+int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_right);
 /* Grid as CSR for tests: cell id = ix*48+iy, items in keypoint-index order (Appendix E-2). */
 int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start /*64*48+1*/, int32_t* cell_items /*n*/);
 

@@ -113,6 +113,23 @@ class ORBextractor:
         return self.frame_stereo_dev(frame, fv, im_left.ctypes.data, im_right.ctypes.data, im_left.shape[1], im_left.shape[0],
                                      im_left.strides[0], bf, b, download, _fn=self.lib.orbx_frame_stereo)
 
+    def frame_stereo_dev_submit(self, frame, fv, d_left, d_right, width, height, stride, bf, b):
+        """First half of frame_stereo_dev: enqueue the Frame constructor and return; other handles / frames may be used
+        until frame_stereo_dev_wait (the chain overlaps with their kernels on the GPU)."""
+        self._pending = (frame, fv)                    # keep the view alive
+        rc = self.lib.orbx_frame_stereo_dev_submit(self.h, frame.h if frame is not None else None, C.byref(fv), C.c_void_p(d_left),
+                                                   C.c_void_p(d_right), width, height, stride, C.c_float(bf), C.c_float(b))
+        capi.check(rc, "orbx_frame_stereo_dev_submit")
+
+    def frame_stereo_dev_wait(self):
+        nl, nr = C.c_int(0), C.c_int(0)
+        capi.check(self.lib.orbx_frame_stereo_dev_wait(self.h, C.byref(nl), C.byref(nr)), "orbx_frame_stereo_dev_wait")
+        frame = self._pending[0] if getattr(self, "_pending", None) else None
+        if frame is not None:
+            frame.n = nl.value
+        self._pending = None
+        return nl.value, nr.value
+
     def frame_stereo_dev(self, frame, fv, d_left, d_right, width, height, stride, bf, b, download=False, _fn=None):
         """Frame::Frame(stereo) (S/Frame.cc:71-172) in one submission: extract L+R, ComputeStereoMatches and the
         feature grid, one final sync; `frame` views the left features on the device afterwards."""

@@ -1430,6 +1430,7 @@ struct orbx_handle {
   int sel_bound = 0;             // upper bound of selected keypoints (sum of region capacities)
   bool gpu_octree = true;
   bool last_was_gpu = false;
+  struct ExtractPending* pending = nullptr;    // orbx_frame_stereo_dev_submit .. _wait
   float timings[8] = {0};
   int profile = 1;   // 0: no events, 1: only the FAST kernel is bracketed (bench roofline), 2: every stage
   int profile_interval = 1;         // level-1 brackets on every k-th extraction only (an event pair costs ~5 us of stream time)
@@ -1705,6 +1706,7 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   h->d_selreg.release(); h->h_nkp.release(); h->sig.release();
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h->pending;
   delete h;
   return ORBG_OK;
 }
@@ -1732,6 +1734,26 @@ struct PostOps {
   orbm_frame* frame = nullptr;
   const orbm_frame_view* view = nullptr;
 };
+// Everything the second half of a GPU-path extraction needs (it runs either right away or in orbx_frame_stereo_dev_wait)
+struct ExtractPending {
+  bool active = false;           // submitted, not yet waited for
+  bool finished = false;         // the submission ran synchronously (host quad-trees): results are already in n_res
+  unsigned cams_mask = 0;
+  const uint8_t* d_img0 = nullptr; const uint8_t* d_img1 = nullptr;
+  int w = 0, hgt = 0, stride = 0, ncams = 0, prof = 0;
+  int lap[2][2] = {{0, 0}, {0, 0}};
+  orbx_keypoint* kps_out[2] = {nullptr, nullptr};
+  uint8_t* desc_out[2] = {nullptr, nullptr};
+  int cap[2] = {0, 0};
+  int* n_out[2] = {nullptr, nullptr};
+  int* n_mono_out[2] = {nullptr, nullptr};
+  bool has_post = false;
+  PostOps post;
+  orbm_frame_view view_copy;     // the caller's view may be gone by the time of the wait
+  int reverse[2] = {0, 0};
+  bool stereo_out = false;
+  int n_res[2] = {0, 0};
+};
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n);
 void orbm_internal_set_n(orbm_frame* f, int n);
 static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror);
@@ -1739,7 +1761,13 @@ static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool
 // Core: cams_mask selects which cameras of the rig are processed; d_img are device pointers.
 static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img0, const uint8_t* d_img1, int w, int hgt,
                         int stride, const int lap[2][2], orbx_keypoint* kps_out[2], uint8_t* desc_out[2], const int cap[2],
-                        int* n_out[2], int* n_mono_out[2], const PostOps* post = nullptr, bool force_host = false) {
+                        int* n_out[2], int* n_mono_out[2], const PostOps* post = nullptr, bool force_host = false,
+                        bool submit_only = false);
+static int extract_finish_gpu(orbx_handle* h, ExtractPending& c);
+
+static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img0, const uint8_t* d_img1, int w, int hgt,
+                        int stride, const int lap[2][2], orbx_keypoint* kps_out[2], uint8_t* desc_out[2], const int cap[2],
+                        int* n_out[2], int* n_mono_out[2], const PostOps* post, bool force_host, bool submit_only) {
   int rc = setup_geometry(h, w, hgt);
   if (rc) return rc;
   const PyrGeom& g = h->geom;
@@ -1806,33 +1834,25 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p))) return rc;
     }
     ORBG_HIP(hipGetLastError());
-    if ((rc = h->sig.sync(st))) return rc;          // completion word in pinned memory; the overflow flag came with the keypoint counts
-    if (h->h_nkp.h[2]) {
-      // a level had more candidates / nodes than the LDS-resident quad-tree holds: redo this frame with the host trees
-      ORBG_HIP(hipMemset(h->d_overflow.p, 0, sizeof(int)));
-      return extract_core(h, cams_mask, d_img0, d_img1, w, hgt, stride, lap, kps_out, desc_out, cap, n_out, n_mono_out, post, true);
+    if ((rc = h->sig.post(st))) return rc;          // completion word in pinned memory
+    ExtractPending local;
+    if (submit_only && !h->pending) h->pending = new ExtractPending();
+    ExtractPending& c = submit_only ? *h->pending : local;
+    c.active = submit_only; c.finished = false;
+    c.cams_mask = cams_mask; c.d_img0 = d_img0; c.d_img1 = d_img1; c.w = w; c.hgt = hgt; c.stride = stride; c.ncams = ncams; c.prof = prof;
+    for (int a = 0; a < 2; a++) {
+      c.lap[a][0] = lap[a][0]; c.lap[a][1] = lap[a][1];
+      c.kps_out[a] = kps_out[a]; c.desc_out[a] = desc_out[a]; c.cap[a] = cap[a]; c.n_out[a] = n_out[a]; c.n_mono_out[a] = n_mono_out[a];
+      c.reverse[a] = reverse[a];
     }
-    h->n_kp[0] = h->h_nkp.h[0];
-    h->n_kp[1] = ncams == 2 ? h->h_nkp.h[1] : 0;
-    int base = 0;
-    for (int cam = 0; cam < ncams; cam++) {
-      const int nk = h->n_kp[cam];
-      if (n_out[cam]) *n_out[cam] = nk;
-      if (n_mono_out[cam]) *n_mono_out[cam] = reverse[cam] ? 0 : nk;
-      if ((kps_out[cam] || desc_out[cam]) && nk > cap[cam]) return ORBG_CAP_EXCEEDED;
-      if (kps_out[cam]) memcpy(kps_out[cam], h->h_kps.h + base, (size_t)nk * sizeof(orbx_keypoint));
-      if (desc_out[cam]) memcpy(desc_out[cam], h->h_desc.h + (size_t)base * 32, (size_t)nk * 32);
-      base += nk;
+    c.has_post = post != nullptr;
+    if (post) {
+      c.post = *post;
+      if (post->view) { c.view_copy = *post->view; c.post.view = &c.view_copy; }
     }
-    if (post && post->frame) orbm_internal_set_n(post->frame, h->n_kp[0]);
-    if (stereo_out) {
-      if (post->uright) memcpy(post->uright, h->h_stereo.h, (size_t)h->n_kp[0] * 4);
-      if (post->depth) memcpy(post->depth, h->h_stereo.h + h->n_kp[0], (size_t)h->n_kp[0] * 4);
-    }
-    float ms;
-    h->timings[2] = 0;
-    if (prof >= 1 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) { h->timings[5] = ms; h->fast_ms_sum += ms; h->fast_ms_n++; }
-    return ORBG_OK;
+    c.stereo_out = stereo_out;
+    if (submit_only) return ORBG_OK;
+    return extract_finish_gpu(h, c);
   }
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[2], st));
   ORBG_HIP(hipStreamSynchronize(st));
@@ -2053,6 +2073,49 @@ extern "C" int orbx_frame_stereo_dev(orbx_handle* h, orbm_frame* frame, const or
                            depth, cap_left, n_left, n_right);
 }
 
+// Frame constructor split in two so that the caller can overlap it with work on other streams (tracking of the previous
+// frame): submit enqueues the whole chain and returns, wait completes it.
+extern "C" int orbx_frame_stereo_dev_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* d_img_left,
+                                            const uint8_t* d_img_right, int width, int height, int stride, float bf, float b) {
+  if (!h || h->cfg.n_cams != 2) return ORBG_BAD_ARG;
+  if (frame && !view) return ORBG_BAD_ARG;
+  if (!d_img_left || !d_img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
+  if (stride < width) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  if (!h->pending) h->pending = new ExtractPending();
+  ExtractPending& P = *h->pending;
+  if (P.active || P.finished) return ORBG_BAD_ARG;      // the previous submission has not been collected
+  PostOps post;
+  post.stereo = true; post.bf = bf; post.b = b; post.frame = frame; post.view = view;
+  const int lap[2][2] = {{0, 0}, {0, 0}};
+  orbx_keypoint* ko[2] = {nullptr, nullptr};
+  uint8_t* dout[2] = {nullptr, nullptr};
+  const int caps[2] = {0, 0};
+  int* no[2] = {&P.n_res[0], &P.n_res[1]};
+  int* nm[2] = {nullptr, nullptr};
+  rc = extract_core(h, 3, d_img_left, d_img_right, width, height, stride, lap, ko, dout, caps, no, nm, &post, false, true);
+  if (rc) { P.active = false; return rc; }
+  if (!P.active) P.finished = true;                      // host quad-tree path: it ran to completion inside the call
+  return ORBG_OK;
+}
+
+extern "C" int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_right) {
+  if (!h || !h->pending || !(h->pending->active || h->pending->finished)) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  ExtractPending& P = *h->pending;
+  if (P.active) {
+    P.active = false;
+    rc = extract_finish_gpu(h, P);
+  }
+  P.finished = false;
+  if (rc) return rc;
+  if (n_left) *n_left = P.n_res[0];
+  if (n_right) *n_right = P.n_res[1];
+  return ORBG_OK;
+}
+
 extern "C" int orbx_frame_stereo(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
                                  const uint8_t* img_right, int width, int height, int stride, float bf, float b,
                                  orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
@@ -2115,6 +2178,43 @@ extern "C" int orbx_get_candidates(orbx_handle* h, int cam, int level, int32_t* 
   *n = (int)cv.size();
   for (int i = 0; i < *n && i < cap; i++) { xys[3 * i] = cv[i].x; xys[3 * i + 1] = cv[i].y; xys[3 * i + 2] = cv[i].score; }
   return *n > cap ? ORBG_CAP_EXCEEDED : ORBG_OK;
+}
+
+// Second half of the GPU-path extraction: wait for the completion word, fall back to the host quad-trees if a level
+// overflowed the device lists, hand the counts (and the optional host copies) over.
+static int extract_finish_gpu(orbx_handle* h, ExtractPending& c) {
+  int rc;
+  hipStream_t st = h->stream;
+  if ((rc = h->sig.wait(st))) return rc;            // the overflow flag came with the keypoint counts
+  const PostOps* post = c.has_post ? &c.post : nullptr;
+  if (h->h_nkp.h[2]) {
+    // a level had more candidates / nodes than the LDS-resident quad-tree holds: redo this frame with the host trees
+    ORBG_HIP(hipMemset(h->d_overflow.p, 0, sizeof(int)));
+    return extract_core(h, c.cams_mask, c.d_img0, c.d_img1, c.w, c.hgt, c.stride, c.lap, c.kps_out, c.desc_out, c.cap, c.n_out, c.n_mono_out,
+                        post, true, false);
+  }
+  const int ncams = c.ncams;
+  h->n_kp[0] = h->h_nkp.h[0];
+  h->n_kp[1] = ncams == 2 ? h->h_nkp.h[1] : 0;
+  int base = 0;
+  for (int cam = 0; cam < ncams; cam++) {
+    const int nk = h->n_kp[cam];
+    if (c.n_out[cam]) *c.n_out[cam] = nk;
+    if (c.n_mono_out[cam]) *c.n_mono_out[cam] = c.reverse[cam] ? 0 : nk;
+    if ((c.kps_out[cam] || c.desc_out[cam]) && nk > c.cap[cam]) return ORBG_CAP_EXCEEDED;
+    if (c.kps_out[cam]) memcpy(c.kps_out[cam], h->h_kps.h + base, (size_t)nk * sizeof(orbx_keypoint));
+    if (c.desc_out[cam]) memcpy(c.desc_out[cam], h->h_desc.h + (size_t)base * 32, (size_t)nk * 32);
+    base += nk;
+  }
+  if (post && post->frame) orbm_internal_set_n(post->frame, h->n_kp[0]);
+  if (c.stereo_out) {
+    if (post->uright) memcpy(post->uright, h->h_stereo.h, (size_t)h->n_kp[0] * 4);
+    if (post->depth) memcpy(post->depth, h->h_stereo.h + h->n_kp[0], (size_t)h->n_kp[0] * 4);
+  }
+  float ms;
+  h->timings[2] = 0;
+  if (c.prof >= 1 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) { h->timings[5] = ms; h->fast_ms_sum += ms; h->fast_ms_n++; }
+  return ORBG_OK;
 }
 
 static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror) {

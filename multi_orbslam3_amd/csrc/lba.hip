@@ -1147,6 +1147,228 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
   if (t == 0) *ok_flag = ok;
 }
 
+// Dataflow variant of the row-pair block LDL^T for systems whose factor AND W = L D fit in LDS (nb <= 20 poses):
+// no workgroup barriers inside the factorisation.  Every block column lives in ONE wavefront (FlowMap, packed by the
+// host), which applies the updates of the earlier columns to its blocks as their panels appear, then factors its diagonal
+// block (every lane of the column redundantly -- free in SIMD, and nothing has to be published for the panel), computes
+// its panel and raises the column counter.  The other wavefronts apply a column's update whenever they get to it, so the
+// critical path per column is one update + factor + panel of a single wavefront (~2.9k cycles) instead of two
+// barrier-separated phases of the whole workgroup (~4.4k).
+struct FlowMap { unsigned char c0[16], c1[16]; };      // wavefront w owns block columns [c0[w], c1[w])
+
+__global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__ S, const double* __restrict__ b,
+                                                    double* __restrict__ x, int* __restrict__ ok_flag, LdltNz nz, FlowMap map) {
+#pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int nblk = nb * (nb + 1) / 2;
+  double* rr_ = sh;                    // 6*nb running rhs (forward)
+  double* zz = rr_ + 6 * nb;           // 6*nb z = D^-1 L^-1 b
+  // factor: one record of kPanStride doubles per block, COLUMN-major block order (consecutive lanes <-> consecutive
+  // records: 64-bit accesses of a wavefront spread over the banks): L_ij at +0 (the diagonal records hold X row-packed),
+  // W_ij = L_ij D_j at +37
+  double* Pan = zz + 6 * nb;
+  double* Aex = Pan + (size_t)nblk * kPanStride;   // 16 x 36: diagonal-block row exchange, one slot per wavefront
+  auto rec = [nb](int i, int k_) { return (size_t)(k_ * nb - k_ * (k_ - 1) / 2 + (i - k_)) * kPanStride; };
+  __shared__ int s_ok;
+  __shared__ int s_done;               // number of block columns whose panel is complete
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int n = 6 * nb;
+  const int c0 = map.c0[wv], c1 = map.c1[wv];
+  // lane -> block of this wavefront's columns (column-major), three lanes per block
+  int bi = -1, bk = -1;
+  const int pr = lane - 3 * (lane / 3);
+  {
+    int q = lane / 3;
+    if (lane < 63)
+      for (int c = c0; c < c1; c++) {
+        const int len = nb - c;
+        if (q < len) { bk = c; bi = c + q; break; }
+        q -= len;
+      }
+  }
+  const size_t blk = bi >= 0 ? rec(bi, bk) : 0;
+  double a[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++) a[q] = 0;
+  if (bi >= 0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) a[6 * q + c] = S[(size_t)(6 * bi + 2 * pr + q) * n + 6 * bk + c];
+  }
+  for (int i = t; i < n; i += 1024) { rr_[i] = b[i]; zz[i] = 0; }
+  if (t == 0) { s_ok = 1; s_done = 0; }
+  __syncthreads();
+  if (c0 == 0 && c1 > 0) __builtin_amdgcn_s_setprio(3);
+  double* Ajj = Aex + 36 * wv;
+  volatile int* done = &s_done;
+  for (int j = 0; j < c1; j++) {       // a wavefront is finished once its last column is factored
+    // the wavefront whose column comes next is on the critical path: it must not share its SIMD's issue slots evenly with
+    // wavefronts that are merely catching up on trailing updates
+    if (j + 1 == c0) __builtin_amdgcn_s_setprio(3);
+    if (j >= c0) {
+      // ---- this wavefront owns column j: all earlier updates are applied (loop order)
+      if (bk == j && bi == j) st_pairs<12>(Ajj + 12 * pr, a);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (bk == j) {
+        double A[6][6], dinv[6], y[6], rj[6];
+        {
+          double flat[36];
+          ld_pairs<36>(Ajj, flat);
+#pragma unroll
+          for (int q = 0; q < 6; q++)
+#pragma unroll
+            for (int c = 0; c <= q; c++) A[q][c] = flat[6 * q + c];
+        }
+        ld_pairs<6>(rr_ + 6 * j, rj);
+        bool good = true;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const double d = A[c][c];
+          if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
+          const double id = fast_rcp(d);
+          dinv[c] = id;
+          double W[6];
+#pragma unroll
+          for (int q = c + 1; q < 6; q++) { W[q] = A[q][c]; A[q][c] = W[q] * id; }
+#pragma unroll
+          for (int q = c + 1; q < 6; q++)
+#pragma unroll
+            for (int r = c + 1; r <= q; r++) A[q][r] -= A[q][c] * W[r];
+        }
+        if (!good) s_ok = 0;
+        double X[6][6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+#pragma unroll
+          for (int q = c + 1; q < 6; q++) {
+            double v = -A[q][c];
+#pragma unroll
+            for (int m = c + 1; m < q; m++) v -= A[q][m] * X[m][c];
+            X[q][c] = v;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double v = rj[c];
+#pragma unroll
+          for (int m = 0; m < c; m++) v += X[c][m] * rj[m];
+          y[c] = v;
+        }
+        if (bi == j) {
+          if (pr == 0) {                 // X row-packed (panel-independent; read by the backward pass) and z_j
+            double xs[16], zs[6];
+#pragma unroll
+            for (int c = 1; c < 6; c++)
+#pragma unroll
+              for (int m = 0; m < c; m++) xs[c * (c - 1) / 2 + m] = X[c][m];
+            xs[15] = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) zs[c] = y[c] * dinv[c];
+            st_pairs<16>(Pan + blk, xs);
+            st_pairs<6>(zz + 6 * j, zs);
+          }
+        } else {
+          double rhs[2];
+          ld_pairs<2>(rr_ + 6 * bi + 2 * pr, rhs);
+          double racc[2] = {0, 0}, wv_[12], lv[12];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+              double v = a[6 * q + c];                    // w = a L^-T : w[c] = a[c] + sum_{m<c} a[m] X[c][m]
+#pragma unroll
+              for (int m = 0; m < c; m++) v += a[6 * q + m] * X[c][m];
+              const double l = v * dinv[c];
+              wv_[6 * q + c] = v;
+              lv[6 * q + c] = l;
+              racc[q] += l * y[c];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 12; q++) Pan[blk + 37 + 12 * pr + q] = wv_[q];
+          st_pairs<12>(Pan + blk + 12 * pr, lv);
+          rhs[0] -= racc[0]; rhs[1] -= racc[1];
+          st_pairs<2>(rr_ + 6 * bi + 2 * pr, rhs);
+        }
+      }
+      // publish: every LDS store of this wavefront is complete before the counter moves
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) *done = j + 1;
+    } else {
+      // ---- wait for the panel of column j (uniform spin on the LDS counter)
+      while (*done <= j) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    // ---- trailing update with column j for this wavefront's blocks right of it
+    const unsigned long long nzj = nz.m[j];
+    if (bk > j && ((nzj >> (bk & 63)) & 1ull) && ((nzj >> (bi & 63)) & 1ull)) {
+      const double* Lp = Pan + rec(bi, j) + 12 * pr;     // two rows of L_ij
+      const double* Wp = Pan + rec(bk, j) + 37;          // W_kj = L_kj D_j
+      double l01[12];
+#pragma unroll
+      for (int m = 0; m < 12; m++) l01[m] = Lp[m];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double w[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) w[m] = Wp[6 * c + m];
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int m = 0; m < 6; m++) { s0 += l01[m] * w[m]; s1 += l01[6 + m] * w[m]; }
+        a[c] -= s0;
+        a[6 + c] -= s1;
+      }
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+  __syncthreads();
+  const int ok = s_ok;
+  if (ok && t < 64) {
+    // backward substitution by one wavefront with z in registers (see k_ldlt_rows)
+    double z0 = t < 60 && t < n ? zz[t] : 0.0, z1 = t < 60 && t + 60 < n ? zz[t + 60] : 0.0;
+    const int kk = t / 6, cc = t - 6 * kk;
+    for (int i = nb - 1; i >= 0; i--) {
+      const double* Xp = Pan + rec(i, i);
+      double xp[16], l0[6], l1[6];
+      ld_pairs<16>(Xp, xp);
+      const bool on0 = t < 60 && kk < i, on1 = t < 60 && kk + 10 < i;
+      const double* L0 = Pan + rec(i, on0 ? kk : 0) + cc;
+      const double* L1 = Pan + rec(i, on1 ? kk + 10 : 0) + cc;
+#pragma unroll
+      for (int q = 0; q < 6; q++) { l0[q] = L0[6 * q]; l1[q] = L1[6 * q]; }
+      const double src = i < 10 ? z0 : z1;
+      const int lb = 6 * (i < 10 ? i : i - 10);
+      double zi[6], xv[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) & 0xFFFFFFFFll), lb + c);
+        const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) >> 32), lb + c);
+        zi[c] = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double va = zi[c], vb = 0;
+#pragma unroll
+        for (int q = c + 1; q < 6; q++) { if ((q - c) & 1) va += xp[q * (q - 1) / 2 + c] * zi[q]; else vb += xp[q * (q - 1) / 2 + c] * zi[q]; }
+        xv[c] = va + vb;
+      }
+      const double a0 = (l0[0] * xv[0] + l0[1] * xv[1]) + (l0[2] * xv[2] + l0[3] * xv[3]) + (l0[4] * xv[4] + l0[5] * xv[5]);
+      const double a1 = (l1[0] * xv[0] + l1[1] * xv[1]) + (l1[2] * xv[2] + l1[3] * xv[3]) + (l1[4] * xv[4] + l1[5] * xv[5]);
+      const double xs_ = cc == 0 ? xv[0] : cc == 1 ? xv[1] : cc == 2 ? xv[2] : cc == 3 ? xv[3] : cc == 4 ? xv[4] : xv[5];
+      z0 = on0 ? z0 - a0 : (kk == i ? xs_ : z0);
+      z1 = on1 ? z1 - a1 : (kk + 10 == i ? xs_ : z1);
+    }
+    if (t < 60) {
+      if (t < n) x[t] = z0;
+      if (t + 60 < n) x[t + 60] = z1;
+    }
+  }
+  if (t == 0) *ok_flag = ok;
+}
+
 // trial state = oplus(current, x): poses exp(x_p) * T; points X + x_l with the landmark back-substitution
 // x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i) folded in (x_l is also stored for computeScale)
 __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int nP, const int* __restrict__ pose_col,
@@ -1360,8 +1582,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int rc = select_device(h->device);
   if (rc) return rc;
   const int NP = p->n_poses, NX = p->n_points, NE = p->n_edges;
-  for (int k = 0; k < NE; k++)
-    if (p->edges[k].pose < 0 || p->edges[k].pose >= NP || p->edges[k].point < 0 || p->edges[k].point >= NX) return ORBG_BAD_ARG;
   auto terminate = [&]() { return stop_flag && *stop_flag; };
   r->status = LBA_APPLIED; r->iters_round1 = r->iters_round2 = 0; r->n_outliers = 0; r->trace_len = 0;
   r->chi2_initial = r->chi2_final = 0;
@@ -1383,7 +1603,11 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   // Every array the kernels need is built IN PLACE inside one pinned block and goes to the device with ONE copy.
   std::vector<int>& pose_deg = h->s_pose_deg; std::vector<int>& point_deg = h->s_point_deg;
   pose_deg.assign(NP, 0); point_deg.assign(NX, 0);
-  for (int k = 0; k < NE; k++) { pose_deg[p->edges[k].pose]++; point_deg[p->edges[k].point]++; }
+  for (int k = 0; k < NE; k++) {                       // validation and degrees in one pass over the edges
+    const unsigned ep = (unsigned)p->edges[k].pose, ex = (unsigned)p->edges[k].point;
+    if (ep >= (unsigned)NP || ex >= (unsigned)NX) return ORBG_BAD_ARG;
+    pose_deg[ep]++; point_deg[ex]++;
+  }
   std::vector<int>& pose_col_v = h->s_pose_col; std::vector<int>& point_col_v = h->s_point_col;
   pose_col_v.assign(NP, -1); point_col_v.assign(NX, -1);
   int nP = 0, nL = 0;
@@ -1424,6 +1648,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int* pair_i1 = reinterpret_cast<int*>(H + o_pair_i1); int* pair_i2 = reinterpret_cast<int*>(H + o_pair_i2);
   int* pair_start = reinterpret_cast<int*>(H + o_pair_start);
   PairItem* items = reinterpret_cast<PairItem*>(H + o_items);
+  const double t_s1 = now_s();
   memcpy(edges, p->edges, sizeof(lba_edge) * (size_t)NE);
   memcpy(pose_col, pose_col_v.data(), 4 * (size_t)NP);
   memcpy(point_col, point_col_v.data(), 4 * (size_t)NX);
@@ -1460,43 +1685,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       }
     }
   }
-  // pose pairs (i1 <= i2) and their landmark items, grouped by pair (counting sort keeps landmark order)
-  auto pair_id = [&](int i1, int i2) { return i1 * nP - i1 * (i1 - 1) / 2 + (i2 - i1); };
-  for (int i = 0; i < n_pairs_all; i++) pair_start[i + 1] += pair_start[i];
-  {
-    std::vector<int>& fill = h->s_fill;
-    fill.assign(pair_start, pair_start + n_pairs_all);
-    const std::vector<int>& row_off = h->s_row_off;
-    for (int l = 0; l < nL; l++) {
-      const int b0 = pf_start[l], e0 = pf_start[l + 1];
-      for (int a2 = b0; a2 < e0; a2++) {
-        const int ro = row_off[pf_col[a2]], ea = pf_edges[a2];
-        for (int b2 = a2; b2 < e0; b2++) items[fill[ro + pf_col[b2]]++] = PairItem{ea, pf_edges[b2], l};
-      }
-    }
-  }
-  // symbolic elimination of the reduced camera system: which blocks of L are structurally non-zero (fill-in included)
+  const double t_s2 = now_s();
   LdltNz ldlt_nz;
   for (int j = 0; j < 64; j++) ldlt_nz.m[j] = ~0ull;
-  if (nP <= 64 && !getenv("ORBG_LDLT_DENSE")) {
-    unsigned long long col[64];                         // col[j]: rows i > j with S_ij != 0, then with fill-in
-    for (int j = 0; j < nP; j++) {
-      unsigned long long mcol = 0;
-      for (int i = j + 1; i < nP; i++)
-        if (pair_start[pair_id(j, i) + 1] > pair_start[pair_id(j, i)]) mcol |= 1ull << i;
-      col[j] = mcol;
-    }
-    for (int j = 0; j < nP; j++) {
-      const unsigned long long rows = col[j];
-      for (int k = j + 1; k < nP; k++)
-        if ((rows >> k) & 1ull) col[k] |= k < 63 ? (rows & ~((2ull << k) - 1ull)) : 0ull;   // rows below k of column j fill column k
-      ldlt_nz.m[j] = rows;
-    }
-  }
-  // keep every pair (diagonals always; off-diagonals even if empty so that S is fully written)
-  for (int i1 = 0; i1 < nP; i1++)
-    for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
-
   // ---- initial state: Converter::toSE3Quat (S/Converter.cc:33-43)
   for (int i = 0; i < NP; i++) {
     const float* T = p->poses + 16 * (size_t)i;
@@ -1510,7 +1701,10 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const int n = 6 * nP;
   const int n_blocks_e = (NE + 255) / 256;
   const double t_b = now_s();
-  if (off) ORBG_HIP(hipMemcpyAsync(h->up_d.p, H, off, hipMemcpyHostToDevice, st));
+  // part A of the arena (edges, state, the CSR lists the error / linearisation kernels read) goes up now; the pair items
+  // the Schur kernel needs are built while the device already computes the first residuals and Jacobians
+  const size_t off_a = o_pf_start;
+  if (off_a) ORBG_HIP(hipMemcpyAsync(h->up_d.p, H, off_a, hipMemcpyHostToDevice, st));
   struct {
     const lba_edge* edges; const int *pose_col, *point_col, *pt_start, *pt_edges, *ps_start, *ps_edges, *pf_start, *pf_edges, *pf_col,
         *pair_i1, *pair_i2, *pair_start;
@@ -1588,6 +1782,40 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
            : rows_R == 2 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 2, false>)
                          : reinterpret_cast<const void*>(k_ldlt_rows<1024, 4, false>);
       ORBG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+    }
+  }
+  // dataflow LDL^T (k_ldlt_flow): whole block columns per wavefront, packed greedily in column order
+  FlowMap flow_map;
+  bool use_flow = false;
+  size_t flow_lds = 0;
+  if (nP >= 1 && nP <= 20 && !getenv("ORBG_LDLT_ROWS") && !getenv("ORBG_LDLT_BLK")) {
+    int w = 0, fill = 0;
+    for (int i = 0; i < 16; i++) { flow_map.c0[i] = 0; flow_map.c1[i] = 0; }
+    bool fits = true;
+    flow_map.c0[0] = 0;
+    for (int c = 0; c < nP; c++) {
+      const int len = nP - c;
+      if (fill + len > kBlkPerWave) {
+        flow_map.c1[w] = (unsigned char)c;
+        if (++w >= 16) { fits = false; break; }
+        flow_map.c0[w] = (unsigned char)c;
+        fill = 0;
+      }
+      fill += len;
+    }
+    if (fits) {
+      flow_map.c1[w] = (unsigned char)nP;
+      for (int i = w + 1; i < 16; i++) { flow_map.c0[i] = 0; flow_map.c1[i] = 0; }          // idle wavefronts skip the loop
+      const size_t nblk = (size_t)nP * (nP + 1) / 2;
+      flow_lds = (12 * (size_t)nP + nblk * kPanStride + 16 * 36) * sizeof(double);
+      use_flow = flow_lds <= 150 * 1024;
+      if (use_flow && flow_lds > 64 * 1024) {
+        static size_t flow_attr = 0;
+        if (flow_attr < flow_lds) {
+          ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds));
+          flow_attr = flow_lds;
+        }
+      }
     }
   }
   int cur = 0;   // index of the buffer holding the current estimate
@@ -1695,7 +1923,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         if (nP > 0) {
           hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                              EBs[ls], Hlls[ls], bls[ls], Hpps[ls], bps[ls], lambda, h->d_S.p, h->d_bs.p, lam_p);
-          if (rows_R) {
+          if (use_flow) {
+            hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
+          } else if (rows_R) {
             auto go = [&](auto kern, int nt) {
               hipLaunchKernelGGL(kern, dim3(1), dim3(nt), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz);
             };
@@ -1781,6 +2011,51 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     return ORBG_OK;
   };
 
+  // first residuals + linearisation are launched before the host has finished the structure
+  if (!terminate()) {
+    launch_errors(cur, 0); err_valid = true;
+    launch_linearise(cur, ls ^ 1);
+    spec_ready = true;
+    ORBG_HIP(hipGetLastError());
+  }
+  const double t_s2b = now_s();
+  // pose pairs (i1 <= i2) and their landmark items, grouped by pair (counting sort keeps landmark order)
+  auto pair_id = [&](int i1, int i2) { return i1 * nP - i1 * (i1 - 1) / 2 + (i2 - i1); };
+  for (int i = 0; i < n_pairs_all; i++) pair_start[i + 1] += pair_start[i];
+  {
+    std::vector<int>& fill = h->s_fill;
+    fill.assign(pair_start, pair_start + n_pairs_all);
+    const std::vector<int>& row_off = h->s_row_off;
+    for (int l = 0; l < nL; l++) {
+      const int b0 = pf_start[l], e0 = pf_start[l + 1];
+      for (int a2 = b0; a2 < e0; a2++) {
+        const int ro = row_off[pf_col[a2]], ea = pf_edges[a2];
+        for (int b2 = a2; b2 < e0; b2++) items[fill[ro + pf_col[b2]]++] = PairItem{ea, pf_edges[b2], l};
+      }
+    }
+  }
+  // symbolic elimination of the reduced camera system: which blocks of L are structurally non-zero (fill-in included)
+  if (nP <= 64 && !getenv("ORBG_LDLT_DENSE")) {
+    unsigned long long col[64];                         // col[j]: rows i > j with S_ij != 0, then with fill-in
+    for (int j = 0; j < nP; j++) {
+      unsigned long long mcol = 0;
+      for (int i = j + 1; i < nP; i++)
+        if (pair_start[pair_id(j, i) + 1] > pair_start[pair_id(j, i)]) mcol |= 1ull << i;
+      col[j] = mcol;
+    }
+    for (int j = 0; j < nP; j++) {
+      const unsigned long long rows = col[j];
+      for (int k = j + 1; k < nP; k++)
+        if ((rows >> k) & 1ull) col[k] |= k < 63 ? (rows & ~((2ull << k) - 1ull)) : 0ull;   // rows below k of column j fill column k
+      ldlt_nz.m[j] = rows;
+    }
+  }
+  // keep every pair (diagonals always; off-diagonals even if empty so that S is fully written)
+  for (int i1 = 0; i1 < nP; i1++)
+    for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
+
+  if (off > off_a) ORBG_HIP(hipMemcpyAsync(h->up_d.p + off_a, H + off_a, off - off_a, hipMemcpyHostToDevice, st));
+  const double t_s3b = now_s();
   int done = 0;
   if ((rc = optimize(p->its_round1 > 0 ? p->its_round1 : 5, &done))) return rc;
   r->iters_round1 = done;
@@ -1831,7 +2106,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   for (size_t i = 0; i < 3 * (size_t)NX; i++) r->points[i] = (float)rpoints[i];
   {
     const double t_f = now_s();
-    tr.t[0] += t_b - t_a; tr.t[1] += t_c - t_b; tr.t[2] += t_d - t_c; tr.t[3] += t_e - t_d; tr.t[4] += t_f - t_e; tr.n++;
+    tr.t[0] += t_b - t_a; tr.t[1] += t_c - t_b; tr.t[2] += t_d - t_c; tr.t[3] += t_e - t_d; tr.t[4] += t_f - t_e; tr.t[5] += t_s1 - t_a; tr.t[6] += t_s2 - t_s1; tr.t[7] += t_s3b - t_s2b; tr.n++;
   }
   return ORBG_OK;
 }

@@ -158,6 +158,56 @@ def test_fused_stereo_frame_constructor(scene):
         assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
 
 
+def test_frame_constructor_submit_wait_pipelines_across_frames(scene):
+    """orbx_frame_stereo_dev_submit / _wait: frame t+1 is constructed on one handle while frame t (other handle, other
+    frame object) is being tracked; every frame's features, grid and matches equal the synchronous path / the oracle."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    cam = scene.cam
+    bf, bb = float(cam["bf"]), float(cam["b"])
+    ids = [3, 4, 5, 6]
+    orc = [helpers.oracle_stereo_frame(scene, i) for i in ids]
+    ex = [api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2) for _ in range(2)]
+    Fr = [api.Frame(), api.Frame()]
+    dimg = []
+    for fr in orc:
+        pair = []
+        for im in (fr["L"], fr["R"]):
+            im = np.ascontiguousarray(im, np.uint8)
+            d = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(im.size)) == 0
+            assert hip.hipMemcpy(d, ctypes.c_void_p(im.ctypes.data), ctypes.c_size_t(im.size), 1) == 0     # HostToDevice
+            pair.append(d)
+        dimg.append(pair)
+    fvs = [helpers.frame_view_of(scene, fr) for fr in orc]
+    m = api.ORBmatcher(0.9, True)
+    rng = np.random.RandomState(4)
+    with pytest.raises(Exception):
+        ex[0].frame_stereo_dev_wait()                                   # nothing submitted
+    ex[0].frame_stereo_dev_submit(Fr[0], fvs[0][0], dimg[0][0].value, dimg[0][1].value, 640, 480, 640, bf, bb)
+    for t in range(len(ids)):
+        cur = t & 1
+        n, nr = ex[cur].frame_stereo_dev_wait()
+        if t + 1 < len(ids):                                            # next frame's constructor runs during this frame's tracking
+            ex[cur ^ 1].frame_stereo_dev_submit(Fr[cur ^ 1], fvs[t + 1][0], dimg[t + 1][0].value, dimg[t + 1][1].value, 640, 480, 640, bf, bb)
+        fr, (fv, keep) = orc[t], fvs[t]
+        assert n == len(fr["kps"]) and nr == len(fr["kps_r"])
+        kd, dd = Fr[cur].download()[:2]
+        assert np.array_equal(kd, fr["kps"]) and np.array_equal(dd, fr["desc"])
+        gs, gi = Fr[cur].grid()
+        os_, oi = ob.build_grid(fv)
+        assert np.array_equal(gs, os_) and np.array_equal(gi, oi)
+        lv, keep2 = helpers.make_lastframe(scene, helpers.oracle_stereo_frame(scene, ids[t] - 1), rng)
+        T = synth.perturb_pose(fr["Tcw"], rng).astype(np.float32)
+        a0, b0 = np.full(n, -1, np.int32), np.zeros(n, np.int32)
+        g = m.SearchByProjectionFrame(Fr[cur], T, lv, 7.0, False, a0, b0)
+        o = ob.search_by_projection_frame(fv, T, lv, 7.0, False, True, a0, b0)
+        assert g[2] == o[2] and g[2] > 50 and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    for pair in dimg:
+        for d in pair:
+            hip.hipFree(d)
+
+
 def test_gpu_and_host_quadtree_paths_agree(scene, small_scene, monkeypatch):
     """The LDS-resident GPU quad-tree and the host implementation (ORBG_HOST_OCTREE=1; also the overflow / partial-
     lapping fallback) give identical keypoints; a partial lapping area forces the host path transparently."""
