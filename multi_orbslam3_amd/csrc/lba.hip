@@ -1507,6 +1507,7 @@ struct lba_handle {
   DevBuf<uint8_t> d_flags;
   DevBuf<double> d_scale_partial;
   DevBuf<unsigned> d_ticket;
+  StreamSignal sig;              // completion word behind k_export (polled instead of hipStreamSynchronize)
   std::vector<int> s_pose_deg, s_point_deg, s_pose_col, s_point_col, s_pf_deg, s_f1, s_f2, s_f3, s_fill, s_row_off;   // host scratch kept across calls
   float last_ms = 0;
   // lba_solve_async: the library-owned "LocalMapping" thread of this handle
@@ -1548,7 +1549,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   h->d_EB2.release(); h->d_Hll2.release(); h->d_bl2.release(); h->d_Hpp2.release(); h->d_bp2.release(); h->d_lambda0.release();
   h->d_pose_col.release(); h->d_point_col.release(); h->d_pt_start.release(); h->d_pt_edges.release(); h->d_ps_start.release();
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
-  h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release(); h->d_scale_partial.release(); h->d_ticket.release();
+  h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release(); h->d_scale_partial.release(); h->d_ticket.release(); h->sig.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ORBG_OK;
@@ -1953,12 +1954,14 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, D.pose_col, D.point_col,
                            h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
                            Hlls[ls], bls[ls], lambda, h->d_poses[trial].p, h->d_points[trial].p, bps[ls], h->d_scale_partial.p, lam_p);
+        bool speculated = false;
         if (NE > 0) {
           launch_errors(trial, 1);
           // speculate on acceptance: linearise the trial state into the other set while the host waits for the verdict
           // (not after the very last iteration that can run)
-          const bool may_continue = !(last_round && it + 1 >= iterations);
-          if (may_continue) launch_linearise(trial, ls ^ 1);
+          // ... nor when two iterations in a row barely improved chi2: a third one ends the round (nBad >= 3)
+          const bool may_continue = !(last_round && (it + 1 >= iterations || nBad >= 2));
+          if (may_continue) { launch_linearise(trial, ls ^ 1); speculated = true; }
           ORBG_HIP(hipGetLastError());
           if ((rc2 = poll_record())) return rc2;
         } else if ((rc2 = finish(lambda, 1, 0, true))) {
@@ -1988,7 +1991,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           currentChi = tempChi;
           cur = trial;                                // discardTop(): keep the trial state
           err_valid = true;
-          spec_ready = NE > 0 && !(last_round && it + 1 >= iterations);
+          spec_ready = speculated;
         } else {
           lambda *= ni;
           ni *= 2;                                    // pop(): current buffer untouched
@@ -2081,7 +2084,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       ORBG_HIP(hipGetLastError());
     }
   }
-  ORBG_HIP(hipStreamSynchronize(st));
+  if ((rc = h->sig.sync(st))) return rc;
   const double t_e = now_s();
   const PoseQ* rposes = reinterpret_cast<const PoseQ*>(h->dl_h.h + d_poses_o);
   const double* rpoints = reinterpret_cast<const double*>(h->dl_h.h + d_points_o);
