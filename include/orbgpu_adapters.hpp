@@ -174,6 +174,21 @@ class FrameOnDevice {
     n_ = nl;
     return nl;
   }
+  // The same constructor in two halves for images that are already in device memory: Submit enqueues the chain and
+  // returns, Wait completes it.  Between the two calls `ex` and this frame are busy; other extractors / frames (the
+  // tracking of the previous frame) may be used and overlap on the GPU.
+  void StereoCtorSubmit(ORBextractor& ex, orbm_frame_view v, const uint8_t* d_left, const uint8_t* d_right, int width, int height,
+                        int stride) {
+    check(orbx_frame_stereo_dev_submit(ex.handle(), f_, &v, d_left, d_right, width, height, stride, v.bf, v.b),
+          "orbx_frame_stereo_dev_submit");
+  }
+  int StereoCtorWait(ORBextractor& ex, int* n_right = nullptr) {
+    int nl = 0, nr = 0;
+    check(orbx_frame_stereo_dev_wait(ex.handle(), &nl, &nr), "orbx_frame_stereo_dev_wait");
+    if (n_right) *n_right = nr;
+    n_ = nl;
+    return nl;
+  }
   int N() const { return n_; }
   orbm_frame* handle() const { return f_; }
 
