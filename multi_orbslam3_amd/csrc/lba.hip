@@ -1493,6 +1493,7 @@ struct lba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   DevBuf<lba_edge> d_edges;
+  PinnedBuf<lba_edge> edges_pin;       // the caller's edge list, copied (and validated, counted) in ONE pass
   DevBuf<PoseQ> d_poses[2];
   DevBuf<double> d_points[2];
   DevBuf<double> d_err, d_chi2, d_partial, d_EB, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_x;
@@ -1543,7 +1544,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  h->d_edges.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release();
+  h->d_edges.release(); h->edges_pin.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release();
   h->d_err.release(); h->d_chi2.release(); h->d_partial.release(); h->d_EB.release(); h->d_Hll.release(); h->d_bl.release();
   h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release();
   h->d_EB2.release(); h->d_Hll2.release(); h->d_bl2.release(); h->d_Hpp2.release(); h->d_bp2.release(); h->d_lambda0.release();
@@ -1604,11 +1605,18 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   // Every array the kernels need is built IN PLACE inside one pinned block and goes to the device with ONE copy.
   std::vector<int>& pose_deg = h->s_pose_deg; std::vector<int>& point_deg = h->s_point_deg;
   pose_deg.assign(NP, 0); point_deg.assign(NX, 0);
-  for (int k = 0; k < NE; k++) {                       // validation and degrees in one pass over the edges
-    const unsigned ep = (unsigned)p->edges[k].pose, ex = (unsigned)p->edges[k].point;
+  // ONE pass over the caller's edges (360 KB at C2, cold): copy into pinned memory, validate, count degrees; the copy
+  // goes to the device at once and every later pass reads the warm pinned copy
+  if ((rc = h->edges_pin.reserve(std::max(NE, 1))) || (rc = h->d_edges.reserve(std::max(NE, 1)))) return rc;
+  lba_edge* const edges = h->edges_pin.h;
+  for (int k = 0; k < NE; k++) {
+    const lba_edge e = p->edges[k];
+    edges[k] = e;
+    const unsigned ep = (unsigned)e.pose, ex = (unsigned)e.point;
     if (ep >= (unsigned)NP || ex >= (unsigned)NX) return ORBG_BAD_ARG;
     pose_deg[ep]++; point_deg[ex]++;
   }
+  if (NE > 0) ORBG_HIP(hipMemcpyAsync(h->d_edges.p, edges, sizeof(lba_edge) * (size_t)NE, hipMemcpyHostToDevice, st));
   std::vector<int>& pose_col_v = h->s_pose_col; std::vector<int>& point_col_v = h->s_point_col;
   pose_col_v.assign(NP, -1); point_col_v.assign(NX, -1);
   int nP = 0, nL = 0;
@@ -1620,7 +1628,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   pf_deg.assign(nL + 1, 0); pt_cnt.assign(nL + 1, 0); ps_cnt.assign(nP + 1, 0);
   int n_free_edges = 0;
   for (int k = 0; k < NE; k++) {
-    const int lc = point_col_v[p->edges[k].point], pc = pose_col_v[p->edges[k].pose];
+    const int lc = point_col_v[edges[k].point], pc = pose_col_v[edges[k].pose];
     pt_cnt[lc]++;
     if (pc >= 0) { pf_deg[lc]++; ps_cnt[pc]++; n_free_edges++; }
   }
@@ -1630,7 +1638,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   // arena layout
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 63) & ~(size_t)63; return o; };
-  const size_t o_edges = take(sizeof(lba_edge) * (size_t)NE), o_poses = take(sizeof(PoseQ) * (size_t)NP), o_points = take(24 * (size_t)NX);
+  const size_t o_poses = take(sizeof(PoseQ) * (size_t)NP), o_points = take(24 * (size_t)NX);
   const size_t o_pose_col = take(4 * (size_t)NP), o_point_col = take(4 * (size_t)NX), o_pt_start = take(4 * ((size_t)nL + 1));
   const size_t o_pt_edges = take(4 * (size_t)NE), o_ps_start = take(4 * ((size_t)nP + 1)), o_ps_edges = take(4 * (size_t)n_free_edges);
   const size_t o_pf_start = take(4 * ((size_t)nL + 1)), o_pf_edges = take(4 * (size_t)n_free_edges), o_pf_col = take(4 * (size_t)n_free_edges);
@@ -1638,7 +1646,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const size_t o_items = take(sizeof(PairItem) * n_items);
   if ((rc = h->up_h.reserve(off + 64)) || (rc = h->up_d.reserve(off + 64))) return rc;
   uint8_t* H = h->up_h.h;
-  lba_edge* edges = reinterpret_cast<lba_edge*>(H + o_edges);
   PoseQ* poses = reinterpret_cast<PoseQ*>(H + o_poses);
   double* points = reinterpret_cast<double*>(H + o_points);
   int* pose_col = reinterpret_cast<int*>(H + o_pose_col); int* point_col = reinterpret_cast<int*>(H + o_point_col);
@@ -1650,7 +1657,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int* pair_start = reinterpret_cast<int*>(H + o_pair_start);
   PairItem* items = reinterpret_cast<PairItem*>(H + o_items);
   const double t_s1 = now_s();
-  memcpy(edges, p->edges, sizeof(lba_edge) * (size_t)NE);
   memcpy(pose_col, pose_col_v.data(), 4 * (size_t)NP);
   memcpy(point_col, point_col_v.data(), 4 * (size_t)NX);
   // CSR: edges per active point (creation order); per free pose; per active point restricted to free poses (sorted by col)
@@ -1661,7 +1667,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     std::vector<int>& f1 = h->s_f1; std::vector<int>& f2 = h->s_f2; std::vector<int>& f3 = h->s_f3;
     f1.assign(pt_start, pt_start + nL); f2.assign(ps_start, ps_start + nP); f3.assign(pf_start, pf_start + nL);
     for (int k = 0; k < NE; k++) {
-      const int lc = point_col[p->edges[k].point], pc = pose_col[p->edges[k].pose];
+      const int lc = point_col[edges[k].point], pc = pose_col[edges[k].pose];
       pt_edges[f1[lc]++] = k;
       if (pc >= 0) { ps_edges[f2[pc]++] = k; pf_edges[f3[lc]++] = k; }
     }
@@ -1674,12 +1680,12 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     for (int l = 0; l < nL; l++) {
       const int b0 = pf_start[l], e0 = pf_start[l + 1];
       for (int a2 = b0 + 1; a2 < e0; a2++) {
-        const int e = pf_edges[a2], key = pose_col[p->edges[e].pose];
+        const int e = pf_edges[a2], key = pose_col[edges[e].pose];
         int b2 = a2 - 1;
-        while (b2 >= b0 && pose_col[p->edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
+        while (b2 >= b0 && pose_col[edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
         pf_edges[b2 + 1] = e;
       }
-      for (int j = b0; j < e0; j++) pf_col[j] = pose_col[p->edges[pf_edges[j]].pose];
+      for (int j = b0; j < e0; j++) pf_col[j] = pose_col[edges[pf_edges[j]].pose];
       for (int a2 = b0; a2 < e0; a2++) {
         const int ro = row_off[pf_col[a2]] + 1;
         for (int b2 = a2; b2 < e0; b2++) pair_start[ro + pf_col[b2]]++;
@@ -1713,7 +1719,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   } D;
   {
     const uint8_t* B = h->up_d.p;
-    D.edges = reinterpret_cast<const lba_edge*>(B + o_edges);
+    D.edges = h->d_edges.p;
     D.pose_col = reinterpret_cast<const int*>(B + o_pose_col); D.point_col = reinterpret_cast<const int*>(B + o_point_col);
     D.pt_start = reinterpret_cast<const int*>(B + o_pt_start); D.pt_edges = reinterpret_cast<const int*>(B + o_pt_edges);
     D.ps_start = reinterpret_cast<const int*>(B + o_ps_start); D.ps_edges = reinterpret_cast<const int*>(B + o_ps_edges);
@@ -1840,6 +1846,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   double* const bls[2] = {h->d_bl.p, h->d_bl2.p};
   double* const Hpps[2] = {h->d_Hpp.p, h->d_Hpp2.p};
   double* const bps[2] = {h->d_bp.p, h->d_bp2.p};
+  const bool no_spec = getenv("ORBG_NO_SPEC") != nullptr;   // A/B switch: no speculative linearisation
   int ls = 0;                      // linearisation set of the current iteration
   bool spec_ready = false;         // set ls^1 holds the linearisation of the current estimate
   auto launch_linearise = [&](int buf, int set) {
@@ -1960,7 +1967,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           // speculate on acceptance: linearise the trial state into the other set while the host waits for the verdict
           // (not after the very last iteration that can run)
           // ... nor when two iterations in a row barely improved chi2: a third one ends the round (nBad >= 3)
-          const bool may_continue = !(last_round && (it + 1 >= iterations || nBad >= 2));
+          const bool may_continue = !(last_round && (it + 1 >= iterations || nBad >= 2)) && !no_spec;
           if (may_continue) { launch_linearise(trial, ls ^ 1); speculated = true; }
           ORBG_HIP(hipGetLastError());
           if ((rc2 = poll_record())) return rc2;

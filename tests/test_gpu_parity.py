@@ -410,6 +410,55 @@ def test_lba_parity(shape):
     assert np.array_equal(g.poses, g2.poses) and np.array_equal(g.points, g2.points)
 
 
+@pytest.mark.parametrize("nf", [1, 2, 3, 7, 13, 19, 20, 21, 26])
+def test_lba_window_sizes_cover_both_ldlt_kernels(nf, monkeypatch):
+    """Free-pose counts on both sides of the dataflow LDL^T's limit (20 poses: wavefront packing with 1..13 active
+    wavefronts, odd sizes) and the barrier kernel beyond it; the barrier kernel is also forced for the small sizes."""
+    prob = synth.make_lba_problem(n_free=nf, n_fixed=3, n_points=40 * nf + 60, mono_frac=0.2, seed=100 + nf)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    o = ob.lba_solve(p)
+    for force_rows in ("", "1"):
+        if force_rows:
+            monkeypatch.setenv("ORBG_LDLT_ROWS", "1")
+        else:
+            monkeypatch.delenv("ORBG_LDLT_ROWS", raising=False)
+        g = api.Optimizer().LocalBundleAdjustment(p)
+        assert g.status == o.status and g.iters == o.iters, (nf, force_rows)
+        assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4
+        assert np.array_equal(g.edge_outlier, o.edge_outlier)
+        tg, to = g.trace_rows(), o.trace_rows()
+        assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2])
+        assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9)
+
+
+@pytest.mark.parametrize("seed,noise,lam", [(10, 3.0, 0.0), (9, 3.0, 0.0), (11, 3.0, 0.0), (10, 1.0, 1e-12)])
+def test_lba_rejected_trials_discard_the_speculative_linearisation(seed, noise, lam):
+    """Far-off initial estimates make g2o's LM reject trials (qmax up to 10 in the trace, rounds that end on qmax == 10):
+    the linearisation that was launched for a rejected trial state must be dropped, the retry must use the old one, and
+    the next round must start from freshly computed residuals."""
+    prob = synth.make_lba_problem(n_free=6, n_fixed=2, n_points=150, outlier_frac=0.1, seed=seed)
+    rng = np.random.RandomState(seed)
+    poses = prob["poses"].copy().reshape(-1, 4, 4)
+    for i in range(len(poses)):
+        if not prob["pose_fixed"][i]:
+            poses[i][:3, 3] += (noise * rng.randn(3)).astype(np.float32)
+    poses = poses.reshape(prob["poses"].shape)
+    pts = prob["points"] + (0.5 * noise * rng.randn(*prob["points"].shape)).astype(np.float32)
+    p, keep = views.lba_problem(poses, prob["pose_fixed"], pts, prob["edges"], prob["cam"], lambda_init=lam)
+    o = ob.lba_solve(p)
+    g = api.Optimizer().LocalBundleAdjustment(p)
+    tg, to = g.trace_rows(), o.trace_rows()
+    assert (to[:, 2] > 1).any(), "no LM trial was rejected: the case does not exercise the discard path"
+    assert g.status == o.status and g.iters == o.iters
+    assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2])
+    # these start several metres off: the discrete LM flow (accept / reject sequence) must be identical; lambda, chi2 and
+    # the poorly constrained far points are compared relatively (the reciprocal-based LDL^T differs from the oracle's
+    # divisions in the last bits and the rejected trials amplify that)
+    assert np.allclose(tg[:, 0], to[:, 0], rtol=1e-5) and np.allclose(tg[:, 1], to[:, 1], rtol=1e-6)
+    assert np.abs(g.poses - o.poses).max() <= 1e-4
+    assert np.allclose(g.points, o.points, rtol=1e-4, atol=1e-4)
+
+
 def test_lba_stop_flag_and_outlier_rejection():
     prob = synth.make_lba_problem(n_free=4, n_fixed=2, n_points=80)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
