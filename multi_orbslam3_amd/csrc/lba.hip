@@ -544,7 +544,10 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
   const double lambda = lambda_p ? *lambda_p : lambda_v;      // first trial of a round: lambda was computed on the device
   // one workgroup per pose pair, one thread per shared landmark (the diagonal pairs hold every landmark of the pose:
   // ~550 at C2, so 256 threads keep their item loop at 3 rounds); sums in a fixed order: per thread, then 4 x 64, then 4
-  __shared__ double red[42][kSchurThreads + 1];
+  // per value one row of 4 segments of 64 + 1 doubles: in the second phase lane (o, q) walks segment q of row o, and without
+  // the per-segment pad the four q-lanes of a row hit the same bank on every read (SQ_LDS_BANK_CONFLICT: 371 k cycles)
+  constexpr int kSeg = 65, kRow = 4 * kSeg + 1;
+  __shared__ double red[42 * kRow];
   __shared__ double part[42][4];
   const int pr = blockIdx.x;
   const int i1 = pair_i1[pr], i2 = pair_i2[pr];
@@ -576,16 +579,17 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
       for (int a = 0; a < 6; a++) cacc[a] += BD[3 * a] * b[0] + BD[3 * a + 1] * b[1] + BD[3 * a + 2] * b[2];
     }
   }
+  const int slot = (tid >> 6) * kSeg + (tid & 63);
 #pragma unroll
-  for (int i = 0; i < 36; i++) red[i][tid] = acc[i];
+  for (int i = 0; i < 36; i++) red[i * kRow + slot] = acc[i];
 #pragma unroll
-  for (int i = 0; i < 6; i++) red[36 + i][tid] = cacc[i];
+  for (int i = 0; i < 6; i++) red[(36 + i) * kRow + slot] = cacc[i];
   __syncthreads();
   const int nval = diag ? 42 : 36;
   if (tid < 4 * nval) {
     const int o = tid >> 2, q = tid & 3;
     double s = 0;
-    for (int k = 0; k < 64; k++) s += red[o][64 * q + k];
+    for (int k = 0; k < 64; k++) s += red[o * kRow + q * kSeg + k];
     part[o][q] = s;
   }
   __syncthreads();
