@@ -1622,7 +1622,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     }
     return ORBG_OK;
   }
-  static TraceAcc tr("lba_solve_h structure / upload submit / LM loop / download+sync / write-back");
+  static TraceAcc tr("lba_solve_h structure (before the first launch) / upload submit / LM loop incl. pair items / export+wait / write-back / "
+                     "of the structure: edge pass + layout / CSR lists / of the LM loop: pair items + symbolic + upload");
   const double t_a = now_s();
   hipStream_t st = h->stream;
   // ---- structure (the analogue of BlockSolver::buildStructure, G/core/block_solver.hpp:143-295), host side.
