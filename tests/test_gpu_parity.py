@@ -459,6 +459,25 @@ def test_lba_rejected_trials_discard_the_speculative_linearisation(seed, noise, 
     assert np.allclose(g.points, o.points, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.timeout(120)
+def test_lba_degenerate_inputs_end_like_the_oracle():
+    """A free pose with a single observation (rank-deficient pose block) and a NaN landmark: the barrier-free LDL^T must
+    not hang on a bad pivot, and status / iteration counts must be the oracle's."""
+    prob = synth.make_lba_problem(n_free=5, n_fixed=2, n_points=60, seed=3)
+    edges = prob["edges"]
+    keep = np.ones(len(edges), bool)
+    idx = np.where(edges["pose"] == edges["pose"].max())[0]
+    keep[idx[1:]] = False
+    e2 = edges[keep]
+    pts_nan = prob["points"].copy()
+    pts_nan.reshape(-1)[5] = np.nan
+    for pts in (prob["points"], pts_nan):
+        p, k = views.lba_problem(prob["poses"], prob["pose_fixed"], pts, e2, prob["cam"])
+        o = ob.lba_solve(p)
+        g = api.Optimizer().LocalBundleAdjustment(p)
+        assert g.status == o.status and g.iters == o.iters
+
+
 def test_lba_stop_flag_and_outlier_rejection():
     prob = synth.make_lba_problem(n_free=4, n_fixed=2, n_points=80)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
