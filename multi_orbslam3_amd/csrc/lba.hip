@@ -1155,10 +1155,17 @@ __global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S
 // no workgroup barriers inside the factorisation.  Every block column lives in ONE wavefront (FlowMap, packed by the
 // host), which applies the updates of the earlier columns to its blocks as their panels appear, then factors its diagonal
 // block (every lane of the column redundantly -- free in SIMD, and nothing has to be published for the panel), computes
-// its panel and raises the column counter.  The other wavefronts apply a column's update whenever they get to it, so the
+// its panel and raises the column counter.  The rows of the diagonal block reach the column's lanes through v_readlane
+// (their owners are the first three lanes of the column's lane range), not through LDS, and the diagonal lane stores its
+// own results (X for the backward pass, z_j) only after the counter has moved.  The other wavefronts apply a column's update whenever they get to it, so the
 // critical path per column is one update + factor + panel of a single wavefront (~2.9k cycles) instead of two
 // barrier-separated phases of the whole workgroup (~4.4k).
 struct FlowMap { unsigned char c0[16], c1[16]; };      // wavefront w owns block columns [c0[w], c1[w])
+__device__ __forceinline__ double po_readlane_any(double v, int lane) {   // lane must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 
 __global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__ S, const double* __restrict__ b,
                                                     double* __restrict__ x, int* __restrict__ ok_flag, LdltNz nz, FlowMap map) {
@@ -1169,9 +1176,8 @@ __global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__
   double* zz = rr_ + 6 * nb;           // 6*nb z = D^-1 L^-1 b
   // factor: one record of kPanStride doubles per block, COLUMN-major block order (consecutive lanes <-> consecutive
   // records: 64-bit accesses of a wavefront spread over the banks): L_ij at +0 (the diagonal records hold X row-packed),
-  // W_ij = L_ij D_j at +37
+  // W_ij = L_ij D_j at +38 (16-byte aligned: 128-bit accesses; a single wavefront pays 25-40 cycles per LDS INSTRUCTION)
   double* Pan = zz + 6 * nb;
-  double* Aex = Pan + (size_t)nblk * kPanStride;   // 16 x 36: diagonal-block row exchange, one slot per wavefront
   auto rec = [nb](int i, int k_) { return (size_t)(k_ * nb - k_ * (k_ - 1) / 2 + (i - k_)) * kPanStride; };
   __shared__ int s_ok;
   __shared__ int s_done;               // number of block columns whose panel is complete
@@ -1204,28 +1210,24 @@ __global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__
   if (t == 0) { s_ok = 1; s_done = 0; }
   __syncthreads();
   if (c0 == 0 && c1 > 0) __builtin_amdgcn_s_setprio(3);
-  double* Ajj = Aex + 36 * wv;
-  volatile int* done = &s_done;
+  // the column counter is accessed through the __shared__ object itself: a generic `volatile int*` turns the poll and the
+  // publish into flat_load / flat_store with sc0 sc1 and a vmcnt(0) wait -- a ~1.5 k-cycle round trip per hand-over
   for (int j = 0; j < c1; j++) {       // a wavefront is finished once its last column is factored
     // the wavefront whose column comes next is on the critical path: it must not share its SIMD's issue slots evenly with
     // wavefronts that are merely catching up on trailing updates
     if (j + 1 == c0) __builtin_amdgcn_s_setprio(3);
     if (j >= c0) {
       // ---- this wavefront owns column j: all earlier updates are applied (loop order)
-      if (bk == j && bi == j) st_pairs<12>(Ajj + 12 * pr, a);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // the diagonal block's rows sit in the first three lanes of this column's lane range: broadcast the lower triangle
+      // with v_readlane (42 scalar-broadcast instructions, no LDS round trip: an LDS exchange costs ~1.5 k cycles here)
+      int l0 = 0;
+      for (int c = c0; c < j; c++) l0 += 3 * (nb - c);
+      double A[6][6], dinv[6], y[6], rj[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int c = 0; c <= q; c++) A[q][c] = po_readlane_any(a[6 * (q & 1) + c], l0 + (q >> 1));
       if (bk == j) {
-        double A[6][6], dinv[6], y[6], rj[6];
-        {
-          double flat[36];
-          ld_pairs<36>(Ajj, flat);
-#pragma unroll
-          for (int q = 0; q < 6; q++)
-#pragma unroll
-            for (int c = 0; c <= q; c++) A[q][c] = flat[6 * q + c];
-        }
         ld_pairs<6>(rr_ + 6 * j, rj);
         bool good = true;
 #pragma unroll
@@ -1261,20 +1263,7 @@ __global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__
           for (int m = 0; m < c; m++) v += X[c][m] * rj[m];
           y[c] = v;
         }
-        if (bi == j) {
-          if (pr == 0) {                 // X row-packed (panel-independent; read by the backward pass) and z_j
-            double xs[16], zs[6];
-#pragma unroll
-            for (int c = 1; c < 6; c++)
-#pragma unroll
-              for (int m = 0; m < c; m++) xs[c * (c - 1) / 2 + m] = X[c][m];
-            xs[15] = 0;
-#pragma unroll
-            for (int c = 0; c < 6; c++) zs[c] = y[c] * dinv[c];
-            st_pairs<16>(Pan + blk, xs);
-            st_pairs<6>(zz + 6 * j, zs);
-          }
-        } else {
+        if (bi != j) {
           double rhs[2];
           ld_pairs<2>(rr_ + 6 * bi + 2 * pr, rhs);
           double racc[2] = {0, 0}, wv_[12], lv[12];
@@ -1291,26 +1280,39 @@ __global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__
               racc[q] += l * y[c];
             }
           }
-#pragma unroll
-          for (int q = 0; q < 12; q++) Pan[blk + 37 + 12 * pr + q] = wv_[q];
+          st_pairs<12>(Pan + blk + 38 + 12 * pr, wv_);
           st_pairs<12>(Pan + blk + 12 * pr, lv);
           rhs[0] -= racc[0]; rhs[1] -= racc[1];
           st_pairs<2>(rr_ + 6 * bi + 2 * pr, rhs);
         }
+        // publish: every LDS store of this wavefront is complete before the counter moves
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (bi == j && pr == 0) {
+          __hip_atomic_store(&s_done, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // the diagonal lane's own results (X row-packed for the backward pass, z_j) are not needed by the next column:
+          // they are stored after the counter has moved
+          double xs[16], zs[6];
+#pragma unroll
+          for (int c = 1; c < 6; c++)
+#pragma unroll
+            for (int m = 0; m < c; m++) xs[c * (c - 1) / 2 + m] = X[c][m];
+          xs[15] = 0;
+#pragma unroll
+          for (int c = 0; c < 6; c++) zs[c] = y[c] * dinv[c];
+          st_pairs<16>(Pan + blk, xs);
+          st_pairs<6>(zz + 6 * j, zs);
+        }
       }
-      // publish: every LDS store of this wavefront is complete before the counter moves
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) *done = j + 1;
     } else {
       // ---- wait for the panel of column j (uniform spin on the LDS counter)
-      while (*done <= j) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     // ---- trailing update with column j for this wavefront's blocks right of it
     const unsigned long long nzj = nz.m[j];
     if (bk > j && ((nzj >> (bk & 63)) & 1ull) && ((nzj >> (bi & 63)) & 1ull)) {
       const double* Lp = Pan + rec(bi, j) + 12 * pr;     // two rows of L_ij
-      const double* Wp = Pan + rec(bk, j) + 37;          // W_kj = L_kj D_j
+      const double* Wp = Pan + rec(bk, j) + 38;          // W_kj = L_kj D_j
       double l01[12];
 #pragma unroll
       for (int m = 0; m < 12; m++) l01[m] = Lp[m];
@@ -1839,7 +1841,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       flow_map.c1[w] = (unsigned char)nP;
       for (int i = w + 1; i < 16; i++) { flow_map.c0[i] = 0; flow_map.c1[i] = 0; }          // idle wavefronts skip the loop
       const size_t nblk = (size_t)nP * (nP + 1) / 2;
-      flow_lds = (12 * (size_t)nP + nblk * kPanStride + 16 * 36) * sizeof(double);
+      flow_lds = (12 * (size_t)nP + nblk * kPanStride) * sizeof(double);
       use_flow = flow_lds <= 150 * 1024;
       if (use_flow && flow_lds > 64 * 1024) {
         static size_t flow_attr = 0;
