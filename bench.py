@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--profile-stages", action="store_true",
                     help="bracket every extractor stage with HIP events (more API calls per frame); by default only "
                          "fast_cells_kernel (the roofline kernel) is bracketed")
+    ap.add_argument("--no-numa-pin", action="store_true",
+                    help="do not restrict the process to the CPUs of the GPU's NUMA node (default: like numactl --cpunodebind)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="construct every frame synchronously before it is tracked; by default frame t+1's constructor "
                          "(orbx_frame_stereo_dev_submit on a second extractor handle) runs while frame t is tracked")
@@ -169,6 +171,27 @@ def main():
                          "thread; inline: LBA blocks the frame loop")
     args = ap.parse_args()
 
+    # The agent keeps six HIP streams busy (two extractor handles, two frames, the local map, the local BA).  The ROCm
+    # runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 4, the search kernels sometimes
+    # share a queue with the local BA's chain (bimodal 4200 / 4950 frames/s run to run); with 6 every stream has its own
+    # (stable 4930-5040); 8 and 12 are slower again (4500).  Must be set before the runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+    # Every agent keeps two threads spinning on completion words (tracking thread, local-BA worker).  If the container's CPU
+    # quota cannot feed that for all ranks of this node (cgroup cpu.max), fall back to the runtime's blocking waits
+    # (ORBG_NO_POLL=1: ~6-10 us more latency per wait, a fraction of a CPU per rank) instead of being throttled.
+    wait_mode = "polling"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+            if float(q) / float(per) < 3.0 * ranks_here:
+                os.environ.setdefault("ORBG_NO_POLL", "1")
+                wait_mode = "runtime waits (cpu quota %.1f for %d ranks)" % (float(q) / float(per), ranks_here)
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("ORBG_NO_POLL"):
+        wait_mode = "runtime waits" if wait_mode == "polling" else wait_mode
     import torch
     from multi_orbslam3_amd import _capi as capi
     from multi_orbslam3_amd import api, harness, synth, views
@@ -179,6 +202,8 @@ def main():
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     device = local_rank
     torch.cuda.set_device(device)
+    cpu_affinity = None if args.no_numa_pin else harness.pin_to_gpu_numa_node(device)
+    core_pair = None if args.no_numa_pin else harness.core_pair_for_agent(device, local_rank)
 
     W, H = 640, 480
     scene = synth.Scene(W, H, seed=synth.SEED_IMAGES + rank)      # one agent per GPU, distinct seeds
@@ -199,6 +224,13 @@ def main():
     prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000, seed=synth.SEED_LBA + rank)
     lp, lp_keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"], device=device)
     bf, bb = float(cam["bf"]), float(cam["b"])
+    if core_pair is not None and args.lba_mode == "async":
+        # the library's local-BA worker inherits the affinity of the thread that makes the first asynchronous call
+        os.sched_setaffinity(0, core_pair[1])
+        opt.LocalBundleAdjustmentAsync(lp, views.LbaOutput(lp.n_poses, lp.n_points, lp.n_edges))
+        opt.wait()
+        os.sched_setaffinity(0, core_pair[0])
+        cpu_affinity = "%s; tracking thread on cpus %s, local-BA worker on cpus %s" % (cpu_affinity, sorted(core_pair[0]), sorted(core_pair[1]))
     nF = len(frames)
     seq = list(range(nF)) + list(range(nF - 2, 0, -1))             # ping-pong: consecutive frames stay adjacent
     stage = dict(extract=0.0, stereo=0.0, grid=0.0, match_frame=0.0, match_map=0.0, lba=0.0, map_upload=0.0, pose_opt=0.0)
@@ -398,7 +430,8 @@ def main():
                        "device_ms_per_frame": dict({k2: round(v / K, 4) for k2, v in kern.items()}, fast_kernel_ms=round(fast_ms_raw, 4)),
                        "avg_keypoints_per_stereo_frame": round(stats["kp"] / K, 1),
                        "avg_matches_frame": round(stats["m_frame"] / K, 1), "avg_matches_map": round(stats["m_map"] / K, 1),
-                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt),
+                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt), "cpu_affinity": cpu_affinity,
+                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
                        "frame_ctor": ("pipelined: Frame(t+1) is submitted on a second extractor handle before frame t is tracked and "
                                       "collected at the start of step t+1; the constructor left in flight by the last timed step is "
                                       "waited for inside the timed region") if pipeline else "synchronous",

@@ -754,6 +754,11 @@ inline int rot_bin(float a1, float a2) {   // factor = 1/HISTO_LENGTH (SURVEY.md
 // frame object
 
 struct orbm_frame {
+  // `stream` is the stream the frame's work is enqueued on: its own one, or -- while it views an extractor's features -- that
+  // extractor's (the features were produced there, so no cross-stream ordering is needed, and the agent keeps fewer
+  // streams busy: the runtime multiplexes streams onto a handful of hardware queues, and a search kernel that shares a queue
+  // with the local BA's chain waits behind 48 us solves)
+  hipStream_t own_stream = nullptr;
   std::vector<uint8_t> claimed_buf;      // reusable host scratch of the serial commits
   std::vector<uint32_t> rot_entries;
   // octave / angle of the frame's keypoints in ordinary (cached) host memory: the serial commits index them at random,
@@ -843,7 +848,8 @@ extern "C" int orbm_frame_create(int device, int cap_features, orbm_frame** out)
   f->device = device;
   f->cap = cap_features;
   memset(&f->fp, 0, sizeof(f->fp));
-  if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return ORBG_HIP_ERROR; }
+  if (hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking) != hipSuccess) { delete f; return ORBG_HIP_ERROR; }
+  f->stream = f->own_stream;
   for (auto& e : f->ev) if (hipEventCreate(&e) != hipSuccess) { delete f; return ORBG_HIP_ERROR; }
   if ((rc = frame_reserve(f, cap_features))) { delete f; return rc; }
   *out = f;
@@ -854,11 +860,12 @@ extern "C" int orbm_frame_destroy(orbm_frame* f) {
   if (!f) return ORBG_BAD_ARG;
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
+  if (f->own_stream && f->own_stream != f->stream) (void)hipStreamSynchronize(f->own_stream);
   f->d_kps.release(); f->d_desc.release(); f->d_uright.release(); f->d_depth.release(); f->d_cell_of.release();
   f->d_cell_start.release(); f->d_cell_items.release(); f->stage.release(); f->d_stage.release();
   f->d_counter.release(); f->list.release(); f->results.release(); f->sig.release();
   for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
-  if (f->stream) (void)hipStreamDestroy(f->stream);
+  if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
   delete f;
   return ORBG_OK;
 }
@@ -872,6 +879,7 @@ extern "C" int orbm_frame_upload(orbm_frame* f, const orbm_frame_view* v) {
   const int n = v->n;
   f->h_kps_own.assign(v->kps, v->kps + n);
   f->hk = f->h_kps_own.data(); f->hk_cached_n = -1;
+  f->stream = f->own_stream;       // features of its own: back on the frame's own stream
   f->kps_p = f->d_kps.p; f->desc_p = f->d_desc.p; f->uright_p = f->d_uright.p; f->depth_p = f->d_depth.p;
   f->has_uright = v->uright != nullptr;
   if (n > 0) {
@@ -899,7 +907,8 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
   // its stream before returning, so the data is complete here.
   f->has_uright = true;
   f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
-  return frame_build_grid(f);      // asynchronous on the frame's stream; the searches run on the same stream
+  f->stream = xs;                  // work on this frame is enqueued on the extractor's stream from now on
+  return frame_build_grid(f);      // asynchronous on that stream; the searches run on the same stream
 }
 
 // Used by orbx_frame_stereo_dev (extractor.hip): alias the extractor's left features and launch the grid build on the
@@ -914,6 +923,7 @@ int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v
   if ((rc = frame_reserve(f, n < 0 ? std::max(f->cap, 4096) : n))) return rc;
   f->has_uright = true;
   f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
+  f->stream = stream;              // the extractor's stream: searches on this frame follow its constructor in order
   hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
                      f->d_cell_items.p, d_n);
   ORBG_HIP(hipGetLastError());
@@ -974,6 +984,7 @@ extern "C" int orbk_frame_from_wire(orbm_frame* f, const orbm_frame_view* v, con
   f->has_uright = false;
   f->h_kps_own.resize((size_t)std::max(n, 1));
   f->hk = f->h_kps_own.data(); f->hk_cached_n = -1;
+  f->stream = f->own_stream;       // features of its own: back on the frame's own stream
   if (n > 0) {
     const size_t bytes = (size_t)n * (kWireKp + kWireDesc);
     const uint8_t* d_wire = wire;

@@ -10,6 +10,75 @@ import os
 import time
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa_node(device_index):
+    """Restrict this process (and the threads it creates afterwards: the library's LBA worker) to the CPUs of the NUMA node
+    the GPU hangs off -- what `numactl --cpunodebind` does for a deployed agent.  The per-frame path spins on words in pinned
+    host memory and rings PCIe doorbells; from the other socket every one of those is a cross-socket round trip (measured
+    on the 2-socket bench box: searches 47 -> 65-74 us per call when the scheduler places the thread there).
+    Returns a short description, or None when the topology is not visible (containers without sysfs, single-node hosts)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            cpus = _parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return "numa node %d of GPU %s (%d cpus)" % (node, bdf, len(allowed))
+    except Exception:                                     # topology not visible: run unpinned
+        return None
+
+
+def core_pair_for_agent(device_index, slot):
+    """Two distinct physical cores (each returned with its SMT siblings) on the GPU's NUMA node for agent number `slot` on
+    that node: one for the tracking thread, one for the library's local-BA worker.  Both threads spin on completion words;
+    when the scheduler happens to put them on the two hardware threads of one core each runs at about half speed
+    (searches 47 -> 65-74 us per call, observed in roughly one run out of five).  Returns (main_cpus, worker_cpus) or None."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            node = 0
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            cpus = _parse_cpulist(f.read()) & os.sched_getaffinity(0)
+        cores, seen = [], set()
+        for c in sorted(cpus):
+            if c in seen:
+                continue
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                sib = _parse_cpulist(f.read()) & cpus
+            seen |= sib
+            cores.append(sib)
+        if len(cores) < 2:
+            return None
+        # leave core 0 of the node to the OS; agents take consecutive pairs
+        base = 1 + 2 * (slot % max((len(cores) - 1) // 2, 1))
+        if base + 1 >= len(cores):
+            base = 0
+        return cores[base], cores[base + 1]
+    except Exception:
+        return None
+
+
 class AgentGroup:
     def __init__(self, backend=None, device_index=None):
         self.rank = int(os.environ.get("RANK", "0"))
