@@ -175,7 +175,9 @@ def main():
     # runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 4, the search kernels sometimes
     # share a queue with the local BA's chain (bimodal 4200 / 4950 frames/s run to run); with 6 every stream has its own
     # (stable 4930-5040); 8 and 12 are slower again (4500).  Must be set before the runtime initialises.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+    # (Without the pipelined constructor the agent has three busy streams and the default of 4 is the good setting: 4600 vs
+    # 3000 frames/s with 6 or 8 -- more hardware queues than busy streams cost dispatch latency on every one of them.)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if (args.no_pipeline or args.separate_calls) else "6")
     # Every agent keeps two threads spinning on completion words (tracking thread, local-BA worker).  If the container's CPU
     # quota cannot feed that for all ranks of this node (cgroup cpu.max), fall back to the runtime's blocking waits
     # (ORBG_NO_POLL=1: ~6-10 us more latency per wait, a fraction of a CPU per rank) instead of being throttled.

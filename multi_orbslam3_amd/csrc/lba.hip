@@ -23,6 +23,7 @@
 #include <time.h>
 
 #include <condition_variable>
+#include <atomic>
 #include <mutex>
 #include <thread>
 
@@ -1541,7 +1542,11 @@ struct lba_handle {
   std::thread worker;
   std::mutex mu;
   std::condition_variable cv;
-  bool quit = false, job_pending = false, job_running = false;
+  std::atomic<bool> quit{false};
+  // 0 = idle, 1 = a job is waiting for the worker, 2 = the worker is solving.  Changed under `mu` (the condition variable
+  // stays the fallback), but both sides first SPIN on it: a futex wake-up costs 10-60 us (more from a deep C-state), and in
+  // steady state the worker gets its next keyframe tens of microseconds after it delivered the last one.
+  std::atomic<int> job_state{0};
   const lba_problem* job_p = nullptr; const volatile int32_t* job_stop = nullptr; lba_result* job_r = nullptr;
   int job_status = ORBG_OK;
   double job_ms = 0;
@@ -2152,40 +2157,73 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
 // S/LocalMapping.cc:114-133).  lba_solve_async hands the problem to a worker thread owned by the handle and returns at once;
 // lba_wait blocks until that solve has finished and returns its status.  problem / stop_flag / result must stay valid
 // until lba_wait returns; one solve in flight per handle.
+static inline bool lba_spin_allowed() { static const bool off = getenv("ORBG_NO_POLL") != nullptr; return !off; }
+// spins until pred() or `limit_us` have passed; returns pred()
+template <typename Pred>
+static inline bool lba_spin_until(Pred pred, double limit_us) {
+  if (!lba_spin_allowed()) return pred();
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned spins = 0;; spins++) {
+    if (pred()) return true;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+    if ((spins & 0xFF) == 0xFF) {
+      timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3 > limit_us) return pred();
+    }
+  }
+}
+
 extern "C" int lba_solve_async(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
   if (!h || !p || !r) return ORBG_BAD_ARG;
   std::unique_lock<std::mutex> lk(h->mu);
-  if (h->job_pending || h->job_running) return ORBG_BAD_ARG;
+  if (h->job_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;
   if (!h->worker.joinable()) {
     h->worker = std::thread([h]() {
-      std::unique_lock<std::mutex> lk(h->mu);
       for (;;) {
-        h->cv.wait(lk, [h]() { return h->quit || h->job_pending; });
-        if (h->quit) return;
-        h->job_pending = false; h->job_running = true;
-        const lba_problem* p = h->job_p; const volatile int32_t* st = h->job_stop; lba_result* r = h->job_r;
-        lk.unlock();
+        // next job: spin briefly (the tracking thread usually submits within tens of microseconds), then sleep
+        if (!lba_spin_until([h]() { return h->quit || h->job_state.load(std::memory_order_acquire) == 1; }, 400.0)) {
+          std::unique_lock<std::mutex> lk(h->mu);
+          h->cv.wait(lk, [h]() { return h->quit || h->job_state.load(std::memory_order_acquire) == 1; });
+        }
+        const lba_problem* p; const volatile int32_t* st; lba_result* r;
+        {
+          std::unique_lock<std::mutex> lk(h->mu);
+          if (h->quit) return;
+          h->job_state.store(2, std::memory_order_release);
+          p = h->job_p; st = h->job_stop; r = h->job_r;
+        }
         timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         const int rc = lba_solve_h(h, p, st, r);
         clock_gettime(CLOCK_MONOTONIC, &t1);
-        lk.lock();
-        h->job_ms = 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec);
-        h->job_status = rc; h->job_running = false;
+        {
+          std::unique_lock<std::mutex> lk(h->mu);
+          h->job_ms = 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec);
+          h->job_status = rc;
+          h->job_state.store(0, std::memory_order_release);
+        }
         h->cv.notify_all();
       }
     });
   }
-  h->job_p = p; h->job_stop = stop_flag; h->job_r = r; h->job_pending = true;
+  h->job_p = p; h->job_stop = stop_flag; h->job_r = r;
+  h->job_state.store(1, std::memory_order_release);
   lk.unlock();
   h->cv.notify_all();
   return ORBG_OK;
 }
-
 extern "C" int lba_wait(lba_handle* h, double* solve_ms) {
   if (!h) return ORBG_BAD_ARG;
+  // the caller is usually a few tens of microseconds early: spin, then sleep on the condition variable
+  if (!lba_spin_until([h]() { return h->job_state.load(std::memory_order_acquire) == 0; }, 3000.0)) {
+    std::unique_lock<std::mutex> lk(h->mu);
+    h->cv.wait(lk, [h]() { return h->job_state.load(std::memory_order_acquire) == 0; });
+  }
   std::unique_lock<std::mutex> lk(h->mu);
-  h->cv.wait(lk, [h]() { return !h->job_pending && !h->job_running; });
   if (solve_ms) *solve_ms = h->job_ms;
   return h->job_status;
 }
