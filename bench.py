@@ -204,6 +204,7 @@ def main():
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     device = local_rank
     torch.cuda.set_device(device)
+    affinity_at_start = os.sched_getaffinity(0)
     cpu_affinity = None if args.no_numa_pin else harness.pin_to_gpu_numa_node(device)
     core_pair = None if args.no_numa_pin else harness.core_pair_for_agent(device, local_rank)
 
@@ -450,6 +451,7 @@ def main():
                          "note": "per-frame work is a few MB: the path is launch/latency bound, not bandwidth bound (SURVEY.md 0-10)"},
         }
         if not args.no_cpu_baseline:
+            os.sched_setaffinity(0, affinity_at_start)     # the CPU baseline's three threads get the whole machine again
             line["cpu_baseline"] = cpu_baseline(scene, synth, views)
         print(json.dumps(line))
     grp.close()

@@ -70,8 +70,9 @@ def core_pair_for_agent(device_index, slot):
             cores.append(sib)
         if len(cores) < 2:
             return None
-        # leave core 0 of the node to the OS; agents take consecutive pairs
-        base = 1 + 2 * (slot % max((len(cores) - 1) // 2, 1))
+        # the first cores of a node serve interrupts and housekeeping: agents take consecutive pairs from the upper half
+        half = len(cores) // 2
+        base = half + 2 * (slot % max((len(cores) - half) // 2, 1))
         if base + 1 >= len(cores):
             base = 0
         return cores[base], cores[base + 1]
