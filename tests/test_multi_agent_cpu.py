@@ -107,3 +107,12 @@ def test_keyframe_blocks_all_gather_gloo():
         assert [b["n"] for b in o["blocks"]] == [outs[0]["n"], outs[1]["n"]]
         assert [b["sha"] for b in o["blocks"]] == [outs[0]["own"], outs[1]["own"]]
     assert outs[0]["blocks"] == outs[1]["blocks"] and outs[0]["roundtrip_ok"]
+
+
+def test_cpu_list_parsing_and_pinning_helpers_degrade_without_a_gpu():
+    from multi_orbslam3_amd import harness
+    assert harness._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert harness._parse_cpulist("") == set()
+    # no GPU / no sysfs topology here: both helpers report "not available" instead of raising
+    assert harness.pin_to_gpu_numa_node(0) is None
+    assert harness.core_pair_for_agent(0, 0) is None
