@@ -1918,6 +1918,25 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     return ORBG_OK;
   };
 
+  // results block (one pinned allocation the export kernel writes straight into) and its launcher: also used speculatively
+  size_t doff = 0;
+  auto dtake = [&](size_t bytes) { const size_t o = doff; doff = (doff + bytes + 63) & ~(size_t)63; return o; };
+  const size_t d_poses_o = dtake(sizeof(PoseQ) * (size_t)NP), d_points_o = dtake(24 * (size_t)NX), d_flags_o = dtake((size_t)NE);
+  const size_t d_chi_o = dtake(r->edge_chi2 ? 8 * (size_t)NE : 0);
+  if ((rc = h->dl_h.reserve(doff + 64))) return rc;
+  auto launch_export = [&](int buf) {
+    const int n_thr = std::max(std::max(NE, NP), 3 * NX);
+    if (n_thr > 0)
+      hipLaunchKernelGGL(k_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, NE, NP, NX, D.edges, h->d_poses[buf].p, h->d_points[buf].p,
+                         h->d_chi2.p, h->dl_h.d + d_flags_o, r->edge_chi2 ? reinterpret_cast<double*>(h->dl_h.d + d_chi_o) : (double*)nullptr,
+                         reinterpret_cast<PoseQ*>(h->dl_h.d + d_poses_o), reinterpret_cast<double*>(h->dl_h.d + d_points_o));
+  };
+  // Speculation beyond the next linearisation: `version` counts LM trials; work launched for "this trial gets accepted and
+  // ends the round / the solve" is valid only if no later trial ran and the trial's buffer became the current one.
+  int version = 0;
+  int fin_version = -1;            // k_finish (lambda init of the NEXT round) already ran on the speculative set
+  int exp_version = -1, exp_buf = -1;   // k_export of the trial state already in flight (completion word posted)
+
   double lambda = -1, ni = 2;
   int nBad = 0;
   bool first_chi = true;
@@ -1930,6 +1949,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     for (int it = 0; it < iterations && !terminate() && ok; it++) {
       // computeActiveErrors (skipped when the residuals of the current estimate are already on the device:
       // recomputing them would reproduce the same bits) + buildSystem (skipped when the speculative set holds it)
+      const bool used_spec = spec_ready;
       if (spec_ready) {
         ls ^= 1;
         spec_ready = false;
@@ -1942,8 +1962,10 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       if (it == 0) {
         if (NE > 0) {
           // computeLambdaInit without a host round trip: k_finish leaves lambda in device memory for the first trial
-          hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, bps[ls], bls[ls], Hpps[ls],
-                             Hlls[ls], 0.0, (int*)nullptr, 0, 1, h->rec.d, p->lambda_init, h->d_lambda0.p);
+          // (it may already have run, speculatively, behind the last trial of the previous round)
+          if (!(used_spec && fin_version == version))
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, bps[ls], bls[ls], Hpps[ls],
+                               Hlls[ls], 0.0, (int*)nullptr, 0, 1, h->rec.d, p->lambda_init, h->d_lambda0.p);
           lambda_on_device = true;
         } else {
           if ((rc2 = finish(0.0, 0, 1, false))) return rc2;
@@ -1959,6 +1981,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       int qmax = 0;
       do {
         const int trial = cur ^ 1;
+        version++;
         const double* lam_p = lambda_on_device ? h->d_lambda0.p : (const double*)nullptr;
         if (nP > 0) {
           hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
@@ -2001,6 +2024,19 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           // ... nor when two iterations in a row barely improved chi2: a third one ends the round (nBad >= 3)
           const bool may_continue = !(last_round && (it + 1 >= iterations || nBad >= 2)) && !no_spec;
           if (may_continue) { launch_linearise(trial, ls ^ 1); speculated = true; }
+          const bool round_may_end = it + 1 >= iterations || nBad >= 2;
+          if (speculated && !last_round && round_may_end && !lambda_on_device) {
+            // ... and if this trial ends the round, the next round's lambda init as well
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, bps[ls ^ 1], bls[ls ^ 1],
+                               Hpps[ls ^ 1], Hlls[ls ^ 1], 0.0, (int*)nullptr, 0, 1, h->rec.d, p->lambda_init, h->d_lambda0.p);
+            fin_version = version;
+          }
+          if (last_round && round_may_end && !no_spec && !lambda_on_device) {
+            // ... or, in the last round, the export of the trial state (dropped if the trial is rejected or the round goes on)
+            launch_export(trial);
+            if ((rc2 = h->sig.post(st))) return rc2;
+            exp_version = version; exp_buf = trial;
+          }
           ORBG_HIP(hipGetLastError());
           if ((rc2 = poll_record())) return rc2;
         } else if ((rc2 = finish(lambda, 1, 0, true))) {
@@ -2109,21 +2145,13 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const double t_d = now_s();
   // ---- results: chi2 of the LAST error evaluation (d_chi2), depth test with the current estimate (S/Optimizer.cc:2131-2166):
   // flags computed on the device, everything comes back through one pinned block
-  size_t doff = 0;
-  auto dtake = [&](size_t bytes) { const size_t o = doff; doff = (doff + bytes + 63) & ~(size_t)63; return o; };
-  const size_t d_poses_o = dtake(sizeof(PoseQ) * (size_t)NP), d_points_o = dtake(24 * (size_t)NX), d_flags_o = dtake((size_t)NE);
-  const size_t d_chi_o = dtake(r->edge_chi2 ? 8 * (size_t)NE : 0);
-  if ((rc = h->dl_h.reserve(doff + 64))) return rc;
-  {
-    const int n_thr = std::max(std::max(NE, NP), 3 * NX);
-    if (n_thr > 0) {
-      hipLaunchKernelGGL(k_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, NE, NP, NX, D.edges, h->d_poses[cur].p, h->d_points[cur].p,
-                         h->d_chi2.p, h->dl_h.d + d_flags_o, r->edge_chi2 ? reinterpret_cast<double*>(h->dl_h.d + d_chi_o) : (double*)nullptr,
-                         reinterpret_cast<PoseQ*>(h->dl_h.d + d_poses_o), reinterpret_cast<double*>(h->dl_h.d + d_points_o));
-      ORBG_HIP(hipGetLastError());
-    }
+  if (exp_version == version && exp_buf == cur) {
+    if ((rc = h->sig.wait(st))) return rc;              // the speculative export is the final one
+  } else {
+    launch_export(cur);
+    ORBG_HIP(hipGetLastError());
+    if ((rc = h->sig.sync(st))) return rc;
   }
-  if ((rc = h->sig.sync(st))) return rc;
   const double t_e = now_s();
   const PoseQ* rposes = reinterpret_cast<const PoseQ*>(h->dl_h.h + d_poses_o);
   const double* rpoints = reinterpret_cast<const double*>(h->dl_h.h + d_points_o);
