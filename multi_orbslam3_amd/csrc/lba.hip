@@ -248,6 +248,46 @@ __global__ __launch_bounds__(256) void k_export(int n_edges, int n_poses, int n_
   if (k < 3 * n_points) out_points[k] = points[k];
 }
 
+// The workgroup (of n_edge_blocks that call this) that finishes last adds up the partial sums in index order (deterministic
+// whoever is last) and publishes robust chi2 / scale / solver flag to the host record: what used to be a separate one-block
+// kernel per LM trial.  Every calling workgroup has written partial[its index] before.
+__device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                     const double* __restrict__ scale_partial, int n_scale_partial,
+                                                     const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq) {
+  __shared__ int s_last;
+  __shared__ double parts[1024];
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (unsigned)n_edge_blocks - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const int np = n_edge_blocks;
+  // all partials are fetched in parallel, then summed by one thread in index order
+  const int tot = min(np + n_scale_partial, 1024);
+  for (int i = threadIdx.x; i < tot; i += 256)
+    parts[i] = __hip_atomic_load(i < np ? &partial[i] : &scale_partial[i - np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double chi = 0, scale = 0;
+    for (int i = 0; i < np; i++) chi += i < 1024 ? parts[i] : __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < n_scale_partial; i++)
+      scale += np + i < 1024 ? parts[np + i] : __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rec->chi2 = chi; rec->scale = scale; rec->ok = ok_flag ? *ok_flag : 1;     // maxdiag / chi2_init stay as k_finish left them
+    *ticket = 0;
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned*>(&rec->seq) = seq;       // the host polls this word instead of hipStreamSynchronize
+    __threadfence_system();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                const double* __restrict__ points, Cam cam, Huber hb, double* __restrict__ err,
                                                double* __restrict__ chi2, double* __restrict__ partial,
@@ -255,7 +295,6 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
                                                int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec,
                                                unsigned seq) {
   __shared__ double red[256];
-  __shared__ int s_last;
   const int k = blockIdx.x * 256 + threadIdx.x;
   double rho0 = 0;
   if (k < n_edges) {
@@ -280,39 +319,7 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
   if (!final_mode) return;
-  // The block that finishes last adds up the partial sums in index order (deterministic whoever is last) and publishes
-  // robust chi2 / scale / solver flag to the host record: what used to be a separate one-block kernel per LM trial.
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == gridDim.x - 1);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  const int np = (int)gridDim.x;
-  // all partials are fetched in parallel, then summed by one thread in index order
-  __shared__ double parts[1024];
-  const int tot = min(np + n_scale_partial, 1024);
-  for (int i = threadIdx.x; i < tot; i += 256)
-    parts[i] = __hip_atomic_load(i < np ? &partial[i] : &scale_partial[i - np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double chi = 0, scale = 0;
-    for (int i = 0; i < np; i++) chi += i < 1024 ? parts[i] : __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = 0; i < n_scale_partial; i++)
-      scale += np + i < 1024 ? parts[np + i] : __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    rec->chi2 = chi; rec->scale = scale; rec->ok = ok_flag ? *ok_flag : 1;     // maxdiag / chi2_init stay as k_finish left them
-    *ticket = 0;
-    __threadfence_system();
-    *reinterpret_cast<volatile unsigned*>(&rec->seq) = seq;       // the host polls this word instead of hipStreamSynchronize
-    __threadfence_system();
-  }
+  publish_trial_record((int)gridDim.x, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq);
 }
 
 // per-edge blocks: EB[k*27 + ...] = Hpl (6x3, 18) | pointH upper (6) | pointB (3)
@@ -352,12 +359,17 @@ __device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double
 }
 
 // thread per edge; the 256 x 27 block of results is staged in LDS and written as ONE contiguous, coalesced chunk
+// FUSED: the residuals are computed here (and stored, with their chi2 and the workgroup's robust partial sum) instead of being
+// read back from a preceding k_errors launch -- same functions, same inputs, same bits.
+template <bool FUSED>
 __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                                  const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
-                                                  const double* __restrict__ chi2, const int* __restrict__ pose_col,
-                                                  const int* __restrict__ point_col, double* __restrict__ EB) {
+                                                  const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ err,
+                                                  double* __restrict__ chi2, const int* __restrict__ pose_col,
+                                                  const int* __restrict__ point_col, double* __restrict__ EB, double* __restrict__ partial) {
   __shared__ double stage[256 * kEB];
+  __shared__ double red_f[256];
   const int k = bid * 256 + threadIdx.x;
+  double rho0 = 0;
   if (k < n_edges) {
     const lba_edge e = edges[k];
     double* out = stage + threadIdx.x * kEB;
@@ -367,17 +379,30 @@ __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_
     quat_rotate(T.q, X, r);
     const bool mono = e.ur < 0;
     const int D = mono ? 2 : 3;
+    double er[3], chi_k;
+    if constexpr (FUSED) {
+      double Xc[3];
+      edge_error(T, X, c, e, er, Xc);
+      const double om0 = (double)e.inv_sigma2;
+      chi_k = 0;
+      for (int i = 0; i < D; i++) chi_k += er[i] * (om0 * er[i]);
+      err[3 * (size_t)k] = er[0]; err[3 * (size_t)k + 1] = er[1]; err[3 * (size_t)k + 2] = er[2];
+      chi2[k] = chi_k;
+    } else {
+      er[0] = err[3 * (size_t)k]; er[1] = err[3 * (size_t)k + 1]; er[2] = err[3 * (size_t)k + 2];
+      chi_k = chi2[k];
+    }
     double A[9], B[18];
     edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
-    double rho0, rho1;
-    huber(chi2[k], mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
+    double rho1;
+    huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
     const double om = (double)e.inv_sigma2;
     const double wom = rho1 * om;
     // rows >= D of A/B/omega_r are exact zeros for monocular edges, so every loop runs a constant 3 rows and
     // unrolls completely (no run-time indexed local arrays => no scratch memory)
     double omega_r[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * err[3 * (size_t)k + i]) * rho1 : 0.0;
+    for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * er[i]) * rho1 : 0.0;
     const bool pf = pose_col[e.pose] >= 0, lf = point_col[e.point] >= 0;
 #pragma unroll
     for (int a = 0; a < 6; a++)          // Hpl = B^T (w Omega) A   (6x3)
@@ -406,14 +431,24 @@ __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_
       out[o++] = lf ? sacc : 0.0;
     }
   }
+  if constexpr (FUSED) red_f[threadIdx.x] = k < n_edges ? rho0 : 0.0;
   __syncthreads();
   const int valid = min(256, n_edges - bid * 256);
   double* dst = EB + (size_t)bid * 256 * kEB;
   for (int i = threadIdx.x; i < valid * kEB; i += 256) dst[i] = stage[i];
+  if constexpr (FUSED) {
+    // the workgroup's robust chi2 partial, same tree as k_errors
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if ((int)threadIdx.x < s2) red_f[threadIdx.x] += red_f[threadIdx.x + s2];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[bid] = red_f[0];
+  }
 }
 
 // Hpp (21 upper) + bp (6) of one free pose: block per pose, threads stride over the pose's edges and rebuild the
 // pose Jacobian on the fly (no per-edge 27-double round trip through HBM); fixed-order wave + block reduction.
+template <bool FUSED>
 __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
                                                   const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                   const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
@@ -433,15 +468,26 @@ __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__
     quat_rotate(T.q, X, r);
     const bool mono = e.ur < 0;
     const int D = mono ? 2 : 3;
+    double er[3], chi_k;
+    if constexpr (FUSED) {             // the edge workgroups of this launch are computing the same residuals concurrently
+      double Xc[3];
+      edge_error(T, X, c, e, er, Xc);
+      const double om0 = (double)e.inv_sigma2;
+      chi_k = 0;
+      for (int i = 0; i < D; i++) chi_k += er[i] * (om0 * er[i]);
+    } else {
+      er[0] = err[3 * (size_t)k]; er[1] = err[3 * (size_t)k + 1]; er[2] = err[3 * (size_t)k + 2];
+      chi_k = chi2[k];
+    }
     double A[9], B[18];
     edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
     double rho0, rho1;
-    huber(chi2[k], mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
+    huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
     const double om = (double)e.inv_sigma2;
     const double wom = rho1 * om;
     double omega_r[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * err[3 * (size_t)k + i]) * rho1 : 0.0;
+    for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * er[i]) * rho1 : 0.0;
     int o = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++)
@@ -483,8 +529,28 @@ __global__ __launch_bounds__(256) void k_lin_all(int nP, int n_edges, const lba_
                                                 const int* __restrict__ point_col, double* __restrict__ EB,
                                                 const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
                                                 double* __restrict__ Hpp, double* __restrict__ bp) {
-  if ((int)blockIdx.x < nP) lin_poses_block(blockIdx.x, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
-  else linearize_block(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB);
+  if ((int)blockIdx.x < nP) lin_poses_block<false>(blockIdx.x, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
+  else linearize_block<false>(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, const_cast<double*>(err), const_cast<double*>(chi2),
+                              pose_col, point_col, EB, nullptr);
+}
+
+// k_errors (final mode) + k_lin_all in one launch, for the speculative path of the LM driver: residuals, chi2 and the robust
+// partial sums of the TRIAL state, its linearisation into the other set of buffers, and -- by the edge workgroup that
+// finishes last -- the record the host is waiting for.  One launch floor (~5 us) less per accepted trial.
+__global__ __launch_bounds__(256) void k_errlin(int nP, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+                                               const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ err,
+                                               double* __restrict__ chi2, const int* __restrict__ pose_col,
+                                               const int* __restrict__ point_col, double* __restrict__ EB,
+                                               const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
+                                               double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ partial,
+                                               unsigned* __restrict__ ticket, const double* __restrict__ scale_partial, int n_scale_partial,
+                                               const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq) {
+  if ((int)blockIdx.x < nP) {
+    lin_poses_block<true>(blockIdx.x, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
+  } else {
+    linearize_block<true>(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB, partial);
+    publish_trial_record((int)gridDim.x - nP, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq);
+  }
 }
 
 // Hll (6 upper) + bl (3) per active point: ordered sum over the point's edges
@@ -2018,12 +2084,24 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
                            Hlls[ls], bls[ls], lambda, h->d_poses[trial].p, h->d_points[trial].p, bps[ls], h->d_scale_partial.p, lam_p);
         bool speculated = false;
         if (NE > 0) {
-          launch_errors(trial, 1);
           // speculate on acceptance: linearise the trial state into the other set while the host waits for the verdict
           // (not after the very last iteration that can run)
           // ... nor when two iterations in a row barely improved chi2: a third one ends the round (nBad >= 3)
           const bool may_continue = !(last_round && (it + 1 >= iterations || nBad >= 2)) && !no_spec;
-          if (may_continue) { launch_linearise(trial, ls ^ 1); speculated = true; }
+          if (may_continue && !getenv("ORBG_NO_FUSE")) {
+            // residuals + record + linearisation of the trial state in ONE launch
+            const int set = ls ^ 1;
+            hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[trial].p, h->d_points[trial].p,
+                               cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start, D.ps_edges, Hpps[set],
+                               bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u, h->d_ok.p, h->rec.d, ++h->rec_seq);
+            if (nL > 0)
+              hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, D.pt_start, D.pt_edges, EBs[set],
+                                 Hlls[set], bls[set]);
+            speculated = true;
+          } else {
+            launch_errors(trial, 1);
+            if (may_continue) { launch_linearise(trial, ls ^ 1); speculated = true; }
+          }
           const bool round_may_end = it + 1 >= iterations || nBad >= 2;
           if (speculated && !last_round && round_may_end && !lambda_on_device) {
             // ... and if this trial ends the round, the next round's lambda init as well
