@@ -360,31 +360,39 @@ __device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double
 
 // thread per edge; the 256 x 27 block of results is staged in LDS and written as ONE contiguous, coalesced chunk
 // FUSED: the residuals are computed here (and stored, with their chi2 and the workgroup's robust partial sum) instead of being
-// read back from a preceding k_errors launch -- same functions, same inputs, same bits.
+// read back from a preceding k_errors launch -- same functions, same inputs, same bits.  The partial sum is written, and the
+// trial record published by the last workgroup, BEFORE the Jacobians: the host gets its verdict ~5 us earlier and its
+// decision latency hides behind the rest of this kernel and k_reduce_points.
+struct TrialPublish {
+  double* partial; unsigned* ticket; const double* scale_partial; int n_scale_partial; const int* ok_flag; HostRec* rec; unsigned seq;
+  int n_edge_blocks;
+};
+__device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                     const double* __restrict__ scale_partial, int n_scale_partial,
+                                                     const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq);
+
 template <bool FUSED>
 __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                   const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ err,
                                                   double* __restrict__ chi2, const int* __restrict__ pose_col,
-                                                  const int* __restrict__ point_col, double* __restrict__ EB, double* __restrict__ partial) {
+                                                  const int* __restrict__ point_col, double* __restrict__ EB, const TrialPublish pub) {
   __shared__ double stage[256 * kEB];
   __shared__ double red_f[256];
   const int k = bid * 256 + threadIdx.x;
-  double rho0 = 0;
-  if (k < n_edges) {
-    const lba_edge e = edges[k];
-    double* out = stage + threadIdx.x * kEB;
-    const PoseQ T = poses[e.pose];
-    const double* X = points + 3 * (size_t)e.point;
-    double r[3];
-    quat_rotate(T.q, X, r);
-    const bool mono = e.ur < 0;
-    const int D = mono ? 2 : 3;
-    double er[3], chi_k;
+  const bool live = k < n_edges;
+  lba_edge e;
+  e.pose = 0; e.point = 0; e.u = 0; e.v = 0; e.ur = -1; e.inv_sigma2 = 0;
+  if (live) e = edges[k];
+  const PoseQ T = poses[e.pose];
+  const double* X = points + 3 * (size_t)e.point;
+  const bool mono = e.ur < 0;
+  const int D = mono ? 2 : 3;
+  double er[3] = {0, 0, 0}, chi_k = 0, rho0 = 0, rho1 = 0;
+  if (live) {
     if constexpr (FUSED) {
       double Xc[3];
       edge_error(T, X, c, e, er, Xc);
       const double om0 = (double)e.inv_sigma2;
-      chi_k = 0;
       for (int i = 0; i < D; i++) chi_k += er[i] * (om0 * er[i]);
       err[3 * (size_t)k] = er[0]; err[3 * (size_t)k + 1] = er[1]; err[3 * (size_t)k + 2] = er[2];
       chi2[k] = chi_k;
@@ -392,10 +400,25 @@ __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_
       er[0] = err[3 * (size_t)k]; er[1] = err[3 * (size_t)k + 1]; er[2] = err[3 * (size_t)k + 2];
       chi_k = chi2[k];
     }
+    huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
+  }
+  if constexpr (FUSED) {
+    // the workgroup's robust chi2 partial (same tree as k_errors), then the record if this is the last workgroup
+    red_f[threadIdx.x] = live ? rho0 : 0.0;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if ((int)threadIdx.x < s2) red_f[threadIdx.x] += red_f[threadIdx.x + s2];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) pub.partial[bid] = red_f[0];
+    publish_trial_record(pub.n_edge_blocks, pub.partial, pub.ticket, pub.scale_partial, pub.n_scale_partial, pub.ok_flag, pub.rec, pub.seq);
+  }
+  if (live) {
+    double* out = stage + threadIdx.x * kEB;
+    double r[3];
+    quat_rotate(T.q, X, r);
     double A[9], B[18];
     edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
-    double rho1;
-    huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
     const double om = (double)e.inv_sigma2;
     const double wom = rho1 * om;
     // rows >= D of A/B/omega_r are exact zeros for monocular edges, so every loop runs a constant 3 rows and
@@ -431,23 +454,11 @@ __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_
       out[o++] = lf ? sacc : 0.0;
     }
   }
-  if constexpr (FUSED) red_f[threadIdx.x] = k < n_edges ? rho0 : 0.0;
   __syncthreads();
   const int valid = min(256, n_edges - bid * 256);
   double* dst = EB + (size_t)bid * 256 * kEB;
   for (int i = threadIdx.x; i < valid * kEB; i += 256) dst[i] = stage[i];
-  if constexpr (FUSED) {
-    // the workgroup's robust chi2 partial, same tree as k_errors
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-      if ((int)threadIdx.x < s2) red_f[threadIdx.x] += red_f[threadIdx.x + s2];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[bid] = red_f[0];
-  }
 }
-
-// Hpp (21 upper) + bp (6) of one free pose: block per pose, threads stride over the pose's edges and rebuild the
-// pose Jacobian on the fly (no per-edge 27-double round trip through HBM); fixed-order wave + block reduction.
 template <bool FUSED>
 __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
                                                   const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(256) void k_lin_all(int nP, int n_edges, const lba_
                                                 double* __restrict__ Hpp, double* __restrict__ bp) {
   if ((int)blockIdx.x < nP) lin_poses_block<false>(blockIdx.x, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
   else linearize_block<false>(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, const_cast<double*>(err), const_cast<double*>(chi2),
-                              pose_col, point_col, EB, nullptr);
+                              pose_col, point_col, EB, TrialPublish{});
 }
 
 // k_errors (final mode) + k_lin_all in one launch, for the speculative path of the LM driver: residuals, chi2 and the robust
@@ -548,8 +559,8 @@ __global__ __launch_bounds__(256) void k_errlin(int nP, int n_edges, const lba_e
   if ((int)blockIdx.x < nP) {
     lin_poses_block<true>(blockIdx.x, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
   } else {
-    linearize_block<true>(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB, partial);
-    publish_trial_record((int)gridDim.x - nP, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq);
+    linearize_block<true>(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB,
+                          TrialPublish{partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, (int)gridDim.x - nP});
   }
 }
 
@@ -602,12 +613,54 @@ struct PairItem { int ea, eb, l; };   // edges (pose i1 / pose i2) of landmark l
 
 constexpr int kSchurThreads = 256;
 
+// Pose-pair -> shared-landmark items built on the device (windows of up to 64 free poses): one workgroup per pose pair
+// walks the landmarks in index order, keeps those whose pose mask has both bits (ballot + popcount scan: the items come out
+// in landmark order, exactly as the host's counting sort produces them, so the Schur sums keep their order and bits) and
+// looks the two edges up in the landmark's short, sorted observation list.  Pair p owns items[p * cap, p * cap + count[p]).
+// Replaces ~30 us of host loops and a 0.5 MB upload per solve that sat between the first kernels and the first k_schur.
+__global__ __launch_bounds__(256) void k_build_items(int nP, int nL, const unsigned long long* __restrict__ lm_mask,
+                                                    const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
+                                                    const int* __restrict__ pf_col, PairItem* __restrict__ items, int cap,
+                                                    int* __restrict__ pair_count) {
+  __shared__ int wcount[4];
+  const int pr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int i1 = 0, rem = pr;
+  while (rem >= nP - i1) { rem -= nP - i1; i1++; }
+  const int i2 = i1 + rem;
+  const unsigned long long need = (1ull << i1) | (1ull << i2);
+  PairItem* out = items + (size_t)pr * cap;
+  int running = 0;
+  for (int l0 = 0; l0 < nL; l0 += 256) {
+    const int l = l0 + tid;
+    const unsigned long long m = l < nL ? lm_mask[l] : 0ull;
+    const bool has = (m & need) == need;
+    const unsigned long long bal = __ballot(has);
+    if (lane == 0) wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const int c = wcount[w]; if (w < wv) before += c; total += c; }
+    if (has) {
+      const int pos = running + before + __popcll(bal & ((1ull << lane) - 1ull));
+      // the landmark's observations are sorted by pose column: the k-th set bit of its mask is its k-th list entry
+      const int b0 = pf_start[l];
+      const int ea = pf_edges[b0 + __popcll(m & ((1ull << i1) - 1ull))];
+      const int eb = pf_edges[b0 + __popcll(m & ((1ull << i2) - 1ull))];
+      out[pos] = PairItem{ea, eb, l};
+    }
+    running += total;
+    __syncthreads();
+  }
+  if (tid == 0) pair_count[pr] = running;
+}
+
 __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __restrict__ pair_i1, const int* __restrict__ pair_i2,
                                                         const int* __restrict__ pair_start, const PairItem* __restrict__ items,
                                                         const double* __restrict__ EB, const double* __restrict__ Hll,
                                                         const double* __restrict__ bl, const double* __restrict__ Hpp,
                                                         const double* __restrict__ bp, double lambda_v, double* __restrict__ S,
-                                                        double* __restrict__ bs, const double* __restrict__ lambda_p) {
+                                                        double* __restrict__ bs, const double* __restrict__ lambda_p, int item_cap,
+                                                        const int* __restrict__ pair_count) {
   const double lambda = lambda_p ? *lambda_p : lambda_v;      // first trial of a round: lambda was computed on the device
   // one workgroup per pose pair, one thread per shared landmark (the diagonal pairs hold every landmark of the pose:
   // ~550 at C2, so 256 threads keep their item loop at 3 rounds); sums in a fixed order: per thread, then 4 x 64, then 4
@@ -625,7 +678,10 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
 #pragma unroll
   for (int i = 0; i < 6; i++) cacc[i] = 0;
   const bool diag = i1 == i2;
-  for (int j = pair_start[pr] + tid; j < pair_start[pr + 1]; j += kSchurThreads) {
+  // items of this pair: CSR offsets from the host build, or a fixed-capacity segment filled by k_build_items
+  const int j0 = pair_start ? pair_start[pr] : pr * item_cap;
+  const int j1 = pair_start ? pair_start[pr + 1] : j0 + pair_count[pr];
+  for (int j = j0 + tid; j < j1; j += kSchurThreads) {
     const PairItem it = items[j];
     double Dinv[9];
     inv3_sym(Hll + 6 * (size_t)it.l, lambda, Dinv);
@@ -1587,6 +1643,8 @@ struct lba_handle {
   hipStream_t stream = nullptr;
   DevBuf<lba_edge> d_edges;
   PinnedBuf<lba_edge> edges_pin;       // the caller's edge list, copied (and validated, counted) in ONE pass
+  DevBuf<PairItem> d_items_dev;        // pair items built by k_build_items (fixed-capacity segment per pose pair)
+  DevBuf<int> d_pair_count;
   DevBuf<PoseQ> d_poses[2];
   DevBuf<double> d_points[2];
   DevBuf<double> d_err, d_chi2, d_partial, d_EB, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_x;
@@ -1641,7 +1699,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  h->d_edges.release(); h->edges_pin.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release();
+  h->d_edges.release(); h->edges_pin.release(); h->d_items_dev.release(); h->d_pair_count.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release();
   h->d_err.release(); h->d_chi2.release(); h->d_partial.release(); h->d_EB.release(); h->d_Hll.release(); h->d_bl.release();
   h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release();
   h->d_EB2.release(); h->d_Hll2.release(); h->d_bl2.release(); h->d_Hpp2.release(); h->d_bp2.release(); h->d_lambda0.release();
@@ -1740,8 +1798,12 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const size_t o_pose_col = take(4 * (size_t)NP), o_point_col = take(4 * (size_t)NX), o_pt_start = take(4 * ((size_t)nL + 1));
   const size_t o_pt_edges = take(4 * (size_t)NE), o_ps_start = take(4 * ((size_t)nP + 1)), o_ps_edges = take(4 * (size_t)n_free_edges);
   const size_t o_pf_start = take(4 * ((size_t)nL + 1)), o_pf_edges = take(4 * (size_t)n_free_edges), o_pf_col = take(4 * (size_t)n_free_edges);
+  // pair items on the device when the pose masks fit one word and the fixed-capacity segments stay small
+  const bool dev_items = nP >= 1 && nP <= 64 && (size_t)n_pairs_all * (size_t)std::max(nL, 1) * sizeof(PairItem) <= ((size_t)32 << 20) &&
+                         !getenv("ORBG_HOST_ITEMS");
+  const size_t o_lm_mask = take(8 * (size_t)nL);
   const size_t o_pair_i1 = take(4 * (size_t)n_pairs_all), o_pair_i2 = take(4 * (size_t)n_pairs_all), o_pair_start = take(4 * ((size_t)n_pairs_all + 1));
-  const size_t o_items = take(sizeof(PairItem) * n_items);
+  const size_t o_items = take(dev_items ? 0 : sizeof(PairItem) * n_items);
   if ((rc = h->up_h.reserve(off + 64)) || (rc = h->up_d.reserve(off + 64))) return rc;
   uint8_t* H = h->up_h.h;
   PoseQ* poses = reinterpret_cast<PoseQ*>(H + o_poses);
@@ -1753,6 +1815,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int* pf_col = reinterpret_cast<int*>(H + o_pf_col);
   int* pair_i1 = reinterpret_cast<int*>(H + o_pair_i1); int* pair_i2 = reinterpret_cast<int*>(H + o_pair_i2);
   int* pair_start = reinterpret_cast<int*>(H + o_pair_start);
+  unsigned long long* lm_mask = reinterpret_cast<unsigned long long*>(H + o_lm_mask);
+  unsigned long long adj[64];                            // adj[i]: poses sharing a landmark with pose i (dev_items)
+  for (int i = 0; i < 64; i++) adj[i] = 0;
   PairItem* items = reinterpret_cast<PairItem*>(H + o_items);
   const double t_s1 = now_s();
   memcpy(pose_col, pose_col_v.data(), 4 * (size_t)NP);
@@ -1784,9 +1849,16 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         pf_edges[b2 + 1] = e;
       }
       for (int j = b0; j < e0; j++) pf_col[j] = pose_col[edges[pf_edges[j]].pose];
-      for (int a2 = b0; a2 < e0; a2++) {
-        const int ro = row_off[pf_col[a2]] + 1;
-        for (int b2 = a2; b2 < e0; b2++) pair_start[ro + pf_col[b2]]++;
+      if (dev_items) {
+        unsigned long long m = 0;
+        for (int j = b0; j < e0; j++) m |= 1ull << pf_col[j];
+        lm_mask[l] = m;
+        for (int j = b0; j < e0; j++) adj[pf_col[j]] |= m;
+      } else {
+        for (int a2 = b0; a2 < e0; a2++) {
+          const int ro = row_off[pf_col[a2]] + 1;
+          for (int b2 = a2; b2 < e0; b2++) pair_start[ro + pf_col[b2]]++;
+        }
       }
     }
   }
@@ -1808,7 +1880,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const double t_b = now_s();
   // part A of the arena (edges, state, the CSR lists the error / linearisation kernels read) goes up now; the pair items
   // the Schur kernel needs are built while the device already computes the first residuals and Jacobians
-  const size_t off_a = o_pf_start;
+  const size_t off_a = dev_items ? o_pair_i1 : o_pf_start;    // with device-built items the pf lists and pose masks go up first
   if (off_a) ORBG_HIP(hipMemcpyAsync(h->up_d.p, H, off_a, hipMemcpyHostToDevice, st));
   struct {
     const lba_edge* edges; const int *pose_col, *point_col, *pt_start, *pt_edges, *ps_start, *ps_edges, *pf_start, *pf_edges, *pf_col,
@@ -1824,8 +1896,13 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     D.pf_start = reinterpret_cast<const int*>(B + o_pf_start); D.pf_edges = reinterpret_cast<const int*>(B + o_pf_edges);
     D.pf_col = reinterpret_cast<const int*>(B + o_pf_col);
     D.pair_i1 = reinterpret_cast<const int*>(B + o_pair_i1); D.pair_i2 = reinterpret_cast<const int*>(B + o_pair_i2);
-    D.pair_start = reinterpret_cast<const int*>(B + o_pair_start);
-    D.items = reinterpret_cast<const PairItem*>(B + o_items);
+    D.pair_start = dev_items ? (const int*)nullptr : reinterpret_cast<const int*>(B + o_pair_start);
+    D.items = dev_items ? (const PairItem*)nullptr : reinterpret_cast<const PairItem*>(B + o_items);
+  }
+  const int item_cap = std::max(nL, 1);
+  if (dev_items) {
+    if ((rc = h->d_items_dev.reserve((size_t)n_pairs_all * item_cap)) || (rc = h->d_pair_count.reserve(std::max(n_pairs_all, 1)))) return rc;
+    D.items = h->d_items_dev.p;
   }
   // the two state buffers (current / trial estimate) are separate allocations: buffer 0 starts as a copy of the upload
   if ((rc = h->d_poses[0].reserve(std::max(NP, 1))) || (rc = h->d_points[0].reserve(std::max<size_t>(3 * (size_t)NX, 1)))) return rc;
@@ -2051,7 +2128,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         const double* lam_p = lambda_on_device ? h->d_lambda0.p : (const double*)nullptr;
         if (nP > 0) {
           hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
-                             EBs[ls], Hlls[ls], bls[ls], Hpps[ls], bps[ls], lambda, h->d_S.p, h->d_bs.p, lam_p);
+                             EBs[ls], Hlls[ls], bls[ls], Hpps[ls], bps[ls], lambda, h->d_S.p, h->d_bs.p, lam_p, item_cap,
+                             dev_items ? h->d_pair_count.p : (const int*)nullptr);
           if (use_flow) {
             hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
           } else if (rows_R) {
@@ -2172,13 +2250,17 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     launch_errors(cur, 0); err_valid = true;
     launch_linearise(cur, ls ^ 1);
     spec_ready = true;
+    if (dev_items && nL > 0)
+      hipLaunchKernelGGL(k_build_items, dim3(n_pairs_all), dim3(256), 0, st, nP, nL,
+                         reinterpret_cast<const unsigned long long*>(h->up_d.p + o_lm_mask), D.pf_start, D.pf_edges, D.pf_col,
+                         h->d_items_dev.p, item_cap, h->d_pair_count.p);
     ORBG_HIP(hipGetLastError());
   }
   const double t_s2b = now_s();
   // pose pairs (i1 <= i2) and their landmark items, grouped by pair (counting sort keeps landmark order)
   auto pair_id = [&](int i1, int i2) { return i1 * nP - i1 * (i1 - 1) / 2 + (i2 - i1); };
-  for (int i = 0; i < n_pairs_all; i++) pair_start[i + 1] += pair_start[i];
-  {
+  if (!dev_items) {
+    for (int i = 0; i < n_pairs_all; i++) pair_start[i + 1] += pair_start[i];
     std::vector<int>& fill = h->s_fill;
     fill.assign(pair_start, pair_start + n_pairs_all);
     const std::vector<int>& row_off = h->s_row_off;
@@ -2196,7 +2278,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     for (int j = 0; j < nP; j++) {
       unsigned long long mcol = 0;
       for (int i = j + 1; i < nP; i++)
-        if (pair_start[pair_id(j, i) + 1] > pair_start[pair_id(j, i)]) mcol |= 1ull << i;
+        if (dev_items ? ((adj[j] >> i) & 1ull) != 0 : pair_start[pair_id(j, i) + 1] > pair_start[pair_id(j, i)]) mcol |= 1ull << i;
       col[j] = mcol;
     }
     for (int j = 0; j < nP; j++) {
