@@ -1834,33 +1834,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       pt_edges[f1[lc]++] = k;
       if (pc >= 0) { ps_edges[f2[pc]++] = k; pf_edges[f3[lc]++] = k; }
     }
-    // per landmark: stable insertion sort of its free observations by pose column (a handful each), then count its
-    // (pose pair) items; pair id = row_off[i1] + i2
-    std::vector<int>& row_off = h->s_row_off;
-    row_off.resize(std::max(nP, 1));
-    for (int i1 = 0; i1 < nP; i1++) row_off[i1] = i1 * nP - i1 * (i1 - 1) / 2 - i1;
-    for (int i = 0; i <= n_pairs_all; i++) pair_start[i] = 0;
-    for (int l = 0; l < nL; l++) {
-      const int b0 = pf_start[l], e0 = pf_start[l + 1];
-      for (int a2 = b0 + 1; a2 < e0; a2++) {
-        const int e = pf_edges[a2], key = pose_col[edges[e].pose];
-        int b2 = a2 - 1;
-        while (b2 >= b0 && pose_col[edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
-        pf_edges[b2 + 1] = e;
-      }
-      for (int j = b0; j < e0; j++) pf_col[j] = pose_col[edges[pf_edges[j]].pose];
-      if (dev_items) {
-        unsigned long long m = 0;
-        for (int j = b0; j < e0; j++) m |= 1ull << pf_col[j];
-        lm_mask[l] = m;
-        for (int j = b0; j < e0; j++) adj[pf_col[j]] |= m;
-      } else {
-        for (int a2 = b0; a2 < e0; a2++) {
-          const int ro = row_off[pf_col[a2]] + 1;
-          for (int b2 = a2; b2 < e0; b2++) pair_start[ro + pf_col[b2]]++;
-        }
-      }
-    }
   }
   const double t_s2 = now_s();
   LdltNz ldlt_nz;
@@ -1880,7 +1853,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const double t_b = now_s();
   // part A of the arena (edges, state, the CSR lists the error / linearisation kernels read) goes up now; the pair items
   // the Schur kernel needs are built while the device already computes the first residuals and Jacobians
-  const size_t off_a = dev_items ? o_pair_i1 : o_pf_start;    // with device-built items the pf lists and pose masks go up first
+  const size_t off_a = o_pf_start;
   if (off_a) ORBG_HIP(hipMemcpyAsync(h->up_d.p, H, off_a, hipMemcpyHostToDevice, st));
   struct {
     const lba_edge* edges; const int *pose_col, *point_col, *pt_start, *pt_edges, *ps_start, *ps_edges, *pf_start, *pf_edges, *pf_col,
@@ -2250,13 +2223,50 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     launch_errors(cur, 0); err_valid = true;
     launch_linearise(cur, ls ^ 1);
     spec_ready = true;
-    if (dev_items && nL > 0)
+    ORBG_HIP(hipGetLastError());
+  }
+  const double t_s2b = now_s();
+  // while those run: the landmarks' free observations sorted by pose column, their pose masks / the pair counts
+  {
+    // per landmark: stable insertion sort of its free observations by pose column (a handful each), then count its
+    // (pose pair) items; pair id = row_off[i1] + i2
+    std::vector<int>& row_off = h->s_row_off;
+    row_off.resize(std::max(nP, 1));
+    for (int i1 = 0; i1 < nP; i1++) row_off[i1] = i1 * nP - i1 * (i1 - 1) / 2 - i1;
+    for (int i = 0; i <= n_pairs_all; i++) pair_start[i] = 0;
+    for (int l = 0; l < nL; l++) {
+      const int b0 = pf_start[l], e0 = pf_start[l + 1];
+      for (int a2 = b0 + 1; a2 < e0; a2++) {
+        const int e = pf_edges[a2], key = pose_col[edges[e].pose];
+        int b2 = a2 - 1;
+        while (b2 >= b0 && pose_col[edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
+        pf_edges[b2 + 1] = e;
+      }
+      for (int j = b0; j < e0; j++) pf_col[j] = pose_col[edges[pf_edges[j]].pose];
+      if (dev_items) {
+        unsigned long long m = 0;
+        for (int j = b0; j < e0; j++) m |= 1ull << pf_col[j];
+        lm_mask[l] = m;
+        for (int j = b0; j < e0; j++) adj[pf_col[j]] |= m;
+      } else {
+        for (int a2 = b0; a2 < e0; a2++) {
+          const int ro = row_off[pf_col[a2]] + 1;
+          for (int b2 = a2; b2 < e0; b2++) pair_start[ro + pf_col[b2]]++;
+        }
+      }
+    }
+  }
+  size_t off_b = off_a;
+  if (dev_items && !terminate()) {
+    // the pf lists and pose masks go up next and the device builds the pair items behind the first linearisation
+    off_b = o_pair_i1;
+    ORBG_HIP(hipMemcpyAsync(h->up_d.p + off_a, H + off_a, off_b - off_a, hipMemcpyHostToDevice, st));
+    if (nL > 0)
       hipLaunchKernelGGL(k_build_items, dim3(n_pairs_all), dim3(256), 0, st, nP, nL,
                          reinterpret_cast<const unsigned long long*>(h->up_d.p + o_lm_mask), D.pf_start, D.pf_edges, D.pf_col,
                          h->d_items_dev.p, item_cap, h->d_pair_count.p);
     ORBG_HIP(hipGetLastError());
   }
-  const double t_s2b = now_s();
   // pose pairs (i1 <= i2) and their landmark items, grouped by pair (counting sort keeps landmark order)
   auto pair_id = [&](int i1, int i2) { return i1 * nP - i1 * (i1 - 1) / 2 + (i2 - i1); };
   if (!dev_items) {
@@ -2292,7 +2302,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   for (int i1 = 0; i1 < nP; i1++)
     for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
 
-  if (off > off_a) ORBG_HIP(hipMemcpyAsync(h->up_d.p + off_a, H + off_a, off - off_a, hipMemcpyHostToDevice, st));
+  if (off > off_b) ORBG_HIP(hipMemcpyAsync(h->up_d.p + off_b, H + off_b, off - off_b, hipMemcpyHostToDevice, st));
   const double t_s3b = now_s();
   int done = 0;
   if ((rc = optimize(p->its_round1 > 0 ? p->its_round1 : 5, &done))) return rc;
