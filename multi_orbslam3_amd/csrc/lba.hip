@@ -2223,6 +2223,12 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     launch_errors(cur, 0); err_valid = true;
     launch_linearise(cur, ls ^ 1);
     spec_ready = true;
+    if (NE > 0) {
+      // the first round's lambda init needs nothing the host is still building: it goes right behind the linearisation
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, h->d_x.p, bps[ls ^ 1], bls[ls ^ 1],
+                         Hpps[ls ^ 1], Hlls[ls ^ 1], 0.0, (int*)nullptr, 0, 1, h->rec.d, p->lambda_init, h->d_lambda0.p);
+      fin_version = version;
+    }
     ORBG_HIP(hipGetLastError());
   }
   const double t_s2b = now_s();
