@@ -1768,6 +1768,8 @@ static int extract_finish_gpu(orbx_handle* h, ExtractPending& c);
 static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img0, const uint8_t* d_img1, int w, int hgt,
                         int stride, const int lap[2][2], orbx_keypoint* kps_out[2], uint8_t* desc_out[2], const int cap[2],
                         int* n_out[2], int* n_mono_out[2], const PostOps* post, bool force_host, bool submit_only) {
+  // a submitted Frame constructor owns the handle (stream, pyramid, feature buffers) until it has been waited for
+  if (h->pending && h->pending->active) return ORBG_BAD_ARG;
   int rc = setup_geometry(h, w, hgt);
   if (rc) return rc;
   const PyrGeom& g = h->geom;

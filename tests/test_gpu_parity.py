@@ -185,6 +185,10 @@ def test_frame_constructor_submit_wait_pipelines_across_frames(scene):
     with pytest.raises(Exception):
         ex[0].frame_stereo_dev_wait()                                   # nothing submitted
     ex[0].frame_stereo_dev_submit(Fr[0], fvs[0][0], dimg[0][0].value, dimg[0][1].value, 640, 480, 640, bf, bb)
+    with pytest.raises(Exception):
+        ex[0].extract_stereo(orc[0]["L"], orc[0]["R"])                  # the handle is busy until the wait
+    with pytest.raises(Exception):
+        ex[0].frame_stereo_dev_submit(Fr[0], fvs[0][0], dimg[0][0].value, dimg[0][1].value, 640, 480, 640, bf, bb)
     for t in range(len(ids)):
         cur = t & 1
         n, nr = ex[cur].frame_stereo_dev_wait()
