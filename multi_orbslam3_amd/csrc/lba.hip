@@ -534,6 +534,77 @@ __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__
 
 // buildSystem in ONE launch: the first nP workgroups build Hpp / b_p of "their" pose from its edges (the longer job, so it
 // starts first), the remaining ones linearise 256 edges each (Hpl and the point parts).  The two jobs are independent.
+// Point workgroups of the fused launch: Hll and b_l of "their" landmark straight from its edges (residual, Huber weight and
+// the 3x3 point Jacobian recomputed with the functions the edge workgroups use -- same bits as summing their per-edge
+// blocks in k_reduce_points, in the same edge order), so that no separate reduction launch is needed.
+__device__ __forceinline__ void lin_points_block(int bid, int nL, const int* __restrict__ pt_start, const int* __restrict__ pt_edges,
+                                                   const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+                                                   const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ Hll,
+                                                   double* __restrict__ bl) {
+  const int l = bid * 256 + threadIdx.x;
+  if (l >= nL) return;
+  double acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) acc[i] = 0;
+  const int jb = pt_start[l], je = pt_start[l + 1];
+  for (int j0 = jb; j0 < je; j0 += 4) {
+    // indices, then edges, then poses of a chunk of four are requested before the first use
+    int id[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) id[q] = pt_edges[min(j0 + q, je - 1)];
+    lba_edge ev[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) ev[q] = edges[id[q]];
+    PoseQ Tv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) Tv[q] = poses[ev[q].pose];
+    const double* X = points + 3 * (size_t)ev[0].point;       // every edge of the list observes this landmark
+    const double Xl[3] = {X[0], X[1], X[2]};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (j0 + q < je) {
+        const lba_edge e = ev[q];
+        const PoseQ T = Tv[q];
+        const bool mono = e.ur < 0;
+        const int D = mono ? 2 : 3;
+        double er[3], Xc[3];
+        edge_error(T, Xl, c, e, er, Xc);
+        const double om = (double)e.inv_sigma2;
+        double chi_k = 0;
+        for (int i = 0; i < D; i++) chi_k += er[i] * (om * er[i]);
+        double rho0, rho1;
+        huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
+        double r[3];
+        quat_rotate(T.q, Xl, r);
+        double A[9], B[18];
+        edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
+        const double wom = rho1 * om;
+        double omega_r[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * er[i]) * rho1 : 0.0;
+        int o = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b2 = a; b2 < 3; b2++) {
+            double h = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) h += A[3 * i + a] * wom * A[3 * i + b2];
+            acc[o++] += h;
+          }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          double sacc = 0;
+#pragma unroll
+          for (int i = 0; i < 3; i++) sacc += A[3 * i + a] * omega_r[i];
+          acc[o++] += sacc;
+        }
+      }
+  }
+  for (int i = 0; i < 6; i++) Hll[6 * (size_t)l + i] = acc[i];
+  for (int i = 0; i < 3; i++) bl[3 * (size_t)l + i] = acc[6 + i];
+}
+
 __global__ __launch_bounds__(256) void k_lin_all(int nP, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                 const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
                                                 const double* __restrict__ chi2, const int* __restrict__ pose_col,
@@ -555,12 +626,17 @@ __global__ __launch_bounds__(256) void k_errlin(int nP, int n_edges, const lba_e
                                                const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
                                                double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ partial,
                                                unsigned* __restrict__ ticket, const double* __restrict__ scale_partial, int n_scale_partial,
-                                               const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq) {
-  if ((int)blockIdx.x < nP) {
-    lin_poses_block<true>(blockIdx.x, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
+                                               const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq, int n_edge_blocks,
+                                               int nL, const int* __restrict__ pt_start, const int* __restrict__ pt_edges,
+                                               double* __restrict__ Hll, double* __restrict__ bl) {
+  const int bid = (int)blockIdx.x;
+  if (bid < nP) {
+    lin_poses_block<true>(bid, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
+  } else if (bid < nP + n_edge_blocks) {
+    linearize_block<true>(bid - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB,
+                          TrialPublish{partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, n_edge_blocks});
   } else {
-    linearize_block<true>(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB,
-                          TrialPublish{partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, (int)gridDim.x - nP});
+    lin_points_block(bid - nP - n_edge_blocks, nL, pt_start, pt_edges, edges, poses, points, c, hb, Hll, bl);
   }
 }
 
@@ -2142,12 +2218,11 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           if (may_continue && !getenv("ORBG_NO_FUSE")) {
             // residuals + record + linearisation of the trial state in ONE launch
             const int set = ls ^ 1;
-            hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[trial].p, h->d_points[trial].p,
-                               cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start, D.ps_edges, Hpps[set],
-                               bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u, h->d_ok.p, h->rec.d, ++h->rec_seq);
-            if (nL > 0)
-              hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, D.pt_start, D.pt_edges, EBs[set],
-                                 Hlls[set], bls[set]);
+            const int n_blocks_l = (nL + 255) / 256;       // the landmark reduction rides in the same launch (point workgroups)
+            hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[trial].p,
+                               h->d_points[trial].p, cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
+                               D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u, h->d_ok.p,
+                               h->rec.d, ++h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set]);
             speculated = true;
           } else {
             launch_errors(trial, 1);
