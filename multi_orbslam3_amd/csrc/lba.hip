@@ -251,9 +251,14 @@ __global__ __launch_bounds__(256) void k_export(int n_edges, int n_poses, int n_
 // The workgroup (of n_edge_blocks that call this) that finishes last adds up the partial sums in index order (deterministic
 // whoever is last) and publishes robust chi2 / scale / solver flag to the host record: what used to be a separate one-block
 // kernel per LM trial.  Every calling workgroup has written partial[its index] before.
+// What the LM step needs to know on the device to prepare the NEXT solve before the host has spoken: the chi2 and lambda the
+// trial started from (by value, or from device memory at the start of a round) and where to leave lambda for the accepted case.
+struct LmIn { double cur_chi, lambda; const double* chi_p; const double* lambda_p; double* lambda_next; };
+
 __device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const double* __restrict__ partial, unsigned* __restrict__ ticket,
                                                      const double* __restrict__ scale_partial, int n_scale_partial,
-                                                     const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq) {
+                                                     const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq,
+                                                     const LmIn lm = LmIn{0, 0, nullptr, nullptr, nullptr}) {
   __shared__ int s_last;
   __shared__ double parts[1024];
   if (threadIdx.x == 0) {
@@ -280,7 +285,21 @@ __device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const do
     for (int i = 0; i < np; i++) chi += i < 1024 ? parts[i] : __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = 0; i < n_scale_partial; i++)
       scale += np + i < 1024 ? parts[np + i] : __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    rec->chi2 = chi; rec->scale = scale; rec->ok = ok_flag ? *ok_flag : 1;     // maxdiag / chi2_init stay as k_finish left them
+    const int okv = ok_flag ? *ok_flag : 1;
+    rec->chi2 = chi; rec->scale = scale; rec->ok = okv;     // maxdiag / chi2_init stay as k_finish left them
+    if (lm.lambda_next) {
+      // lambda of the NEXT iteration if this trial is accepted -- the host's arithmetic (levenberg.cpp:116-141), operation for
+      // operation, so that a solve launched speculatively with it is the solve the host would have launched
+      const double cur = lm.chi_p ? *lm.chi_p : lm.cur_chi;
+      const double lam = lm.lambda_p ? *lm.lambda_p : lm.lambda;
+      const double tempChi = okv ? chi : 1.7976931348623157e308;
+      double rho = cur - tempChi;
+      rho /= scale + 1e-3;
+      const double c3 = 2 * rho - 1;
+      double alpha = 1. - c3 * c3 * c3;
+      alpha = fmin(alpha, 2. / 3.);
+      *lm.lambda_next = lam * fmax(1. / 3., alpha);
+    }
     *ticket = 0;
     __threadfence_system();
     *reinterpret_cast<volatile unsigned*>(&rec->seq) = seq;       // the host polls this word instead of hipStreamSynchronize
@@ -366,10 +385,8 @@ __device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double
 struct TrialPublish {
   double* partial; unsigned* ticket; const double* scale_partial; int n_scale_partial; const int* ok_flag; HostRec* rec; unsigned seq;
   int n_edge_blocks;
+  LmIn lm;
 };
-__device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const double* __restrict__ partial, unsigned* __restrict__ ticket,
-                                                     const double* __restrict__ scale_partial, int n_scale_partial,
-                                                     const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq);
 
 template <bool FUSED>
 __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
@@ -411,7 +428,8 @@ __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_
       __syncthreads();
     }
     if (threadIdx.x == 0) pub.partial[bid] = red_f[0];
-    publish_trial_record(pub.n_edge_blocks, pub.partial, pub.ticket, pub.scale_partial, pub.n_scale_partial, pub.ok_flag, pub.rec, pub.seq);
+    publish_trial_record(pub.n_edge_blocks, pub.partial, pub.ticket, pub.scale_partial, pub.n_scale_partial, pub.ok_flag, pub.rec, pub.seq,
+                         pub.lm);
   }
   if (live) {
     double* out = stage + threadIdx.x * kEB;
@@ -613,7 +631,7 @@ __global__ __launch_bounds__(256) void k_lin_all(int nP, int n_edges, const lba_
                                                 double* __restrict__ Hpp, double* __restrict__ bp) {
   if ((int)blockIdx.x < nP) lin_poses_block<false>(blockIdx.x, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
   else linearize_block<false>(blockIdx.x - nP, n_edges, edges, poses, points, c, hb, const_cast<double*>(err), const_cast<double*>(chi2),
-                              pose_col, point_col, EB, TrialPublish{});
+                              pose_col, point_col, EB, TrialPublish{nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0u, 0, LmIn{0, 0, nullptr, nullptr, nullptr}});
 }
 
 // k_errors (final mode) + k_lin_all in one launch, for the speculative path of the LM driver: residuals, chi2 and the robust
@@ -628,13 +646,13 @@ __global__ __launch_bounds__(256) void k_errlin(int nP, int n_edges, const lba_e
                                                unsigned* __restrict__ ticket, const double* __restrict__ scale_partial, int n_scale_partial,
                                                const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq, int n_edge_blocks,
                                                int nL, const int* __restrict__ pt_start, const int* __restrict__ pt_edges,
-                                               double* __restrict__ Hll, double* __restrict__ bl) {
+                                               double* __restrict__ Hll, double* __restrict__ bl, LmIn lm) {
   const int bid = (int)blockIdx.x;
   if (bid < nP) {
     lin_poses_block<true>(bid, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
   } else if (bid < nP + n_edge_blocks) {
     linearize_block<true>(bid - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB,
-                          TrialPublish{partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, n_edge_blocks});
+                          TrialPublish{partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, n_edge_blocks, lm});
   } else {
     lin_points_block(bid - nP - n_edge_blocks, nL, pt_start, pt_edges, edges, poses, points, c, hb, Hll, bl);
   }
@@ -1703,7 +1721,8 @@ __global__ __launch_bounds__(256) void k_finish(int n_partial, const double* __r
       // start of an LM round (computeLambdaInit, levenberg.cpp:177-185): the first trial reads lambda from device memory, the
       // host picks chi2 / max diagonal up together with that trial's record -- no synchronisation in between
       rec->chi2_init = chi; rec->maxdiag = red[0];
-      *lambda0_out = lambda_init > 0 ? lambda_init : 1e-5 * red[0];
+      lambda0_out[0] = lambda_init > 0 ? lambda_init : 1e-5 * red[0];
+      lambda0_out[2] = chi;                          // [1] = lambda of the next iteration (publish_trial_record), [2] = chi2 the round starts from
     } else {
       rec->chi2 = chi; rec->scale = scale; rec->maxdiag = red[0]; rec->ok = ok_flag ? *ok_flag : 1;
     }
@@ -1964,7 +1983,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       (rc = h->d_Hpp.reserve(std::max<size_t>(21 * (size_t)nP, 1))) || (rc = h->d_bp.reserve(std::max<size_t>(6 * (size_t)nP, 1))) ||
       (rc = h->d_EB2.reserve(std::max<size_t>((size_t)NE * kEB, 1))) || (rc = h->d_Hll2.reserve(std::max<size_t>(6 * (size_t)nL, 1))) ||
       (rc = h->d_bl2.reserve(std::max<size_t>(3 * (size_t)nL, 1))) || (rc = h->d_Hpp2.reserve(std::max<size_t>(21 * (size_t)nP, 1))) ||
-      (rc = h->d_bp2.reserve(std::max<size_t>(6 * (size_t)nP, 1))) || (rc = h->d_lambda0.reserve(2)) ||
+      (rc = h->d_bp2.reserve(std::max<size_t>(6 * (size_t)nP, 1))) || (rc = h->d_lambda0.reserve(4)) ||
       (rc = h->d_S.reserve(std::max<size_t>((size_t)n * n, 1))) || (rc = h->d_bs.reserve(std::max(n, 1))) ||
       (rc = h->d_x.reserve(std::max<size_t>((size_t)n + 3 * (size_t)nL, 1))))
     return rc;
@@ -2129,6 +2148,41 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int fin_version = -1;            // k_finish (lambda init of the NEXT round) already ran on the speculative set
   int exp_version = -1, exp_buf = -1;   // k_export of the trial state already in flight (completion word posted)
 
+  int solve_version = -1;          // Schur complement + LDL^T of the NEXT trial already launched (speculatively) at this trial number
+  auto launch_solve = [&](int set_, double lam_, const double* lamp_) -> int {
+    if (nP > 0) {
+      hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
+                         EBs[set_], Hlls[set_], bls[set_], Hpps[set_], bps[set_], lam_, h->d_S.p, h->d_bs.p, lamp_, item_cap,
+                         dev_items ? h->d_pair_count.p : (const int*)nullptr);
+      if (use_flow) {
+        hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
+      } else if (rows_R) {
+        auto go = [&](auto kern, int nt) {
+          hipLaunchKernelGGL(kern, dim3(1), dim3(nt), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz);
+        };
+        if (rows_l_in_lds) {
+          if (rows_R == 1 && rows_small) go(k_ldlt_rows<640, 1, true>, 640);
+          else if (rows_R == 1) go(k_ldlt_rows<1024, 1, true>, 1024);
+          else if (rows_R == 2) go(k_ldlt_rows<1024, 2, true>, 1024);
+          else go(k_ldlt_rows<1024, 4, true>, 1024);
+        } else {
+          if (rows_R == 1 && rows_small) go(k_ldlt_rows<640, 1, false>, 640);
+          else if (rows_R == 1) go(k_ldlt_rows<1024, 1, false>, 1024);
+          else if (rows_R == 2) go(k_ldlt_rows<1024, 2, false>, 1024);
+          else go(k_ldlt_rows<1024, 4, false>, 1024);
+        }
+      }
+      else if (nP <= 22)
+        hipLaunchKernelGGL(k_ldlt_blk<256>, dim3(1), dim3(256), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
+      else if (nP <= 44)
+        hipLaunchKernelGGL(k_ldlt_blk<1024>, dim3(1), dim3(1024), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
+      else
+        hipLaunchKernelGGL(k_ldlt, dim3(1), dim3(1024), lds_need, st, n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_lds ? 1 : 0);
+    } else {
+      ORBG_HIP(hipMemsetAsync(h->d_ok.p, 0xFF, sizeof(int), st));   // nothing to solve: ok
+    }
+    return ORBG_OK;
+  };
   double lambda = -1, ni = 2;
   int nBad = 0;
   bool first_chi = true;
@@ -2175,37 +2229,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         const int trial = cur ^ 1;
         version++;
         const double* lam_p = lambda_on_device ? h->d_lambda0.p : (const double*)nullptr;
-        if (nP > 0) {
-          hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
-                             EBs[ls], Hlls[ls], bls[ls], Hpps[ls], bps[ls], lambda, h->d_S.p, h->d_bs.p, lam_p, item_cap,
-                             dev_items ? h->d_pair_count.p : (const int*)nullptr);
-          if (use_flow) {
-            hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
-          } else if (rows_R) {
-            auto go = [&](auto kern, int nt) {
-              hipLaunchKernelGGL(kern, dim3(1), dim3(nt), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz);
-            };
-            if (rows_l_in_lds) {
-              if (rows_R == 1 && rows_small) go(k_ldlt_rows<640, 1, true>, 640);
-              else if (rows_R == 1) go(k_ldlt_rows<1024, 1, true>, 1024);
-              else if (rows_R == 2) go(k_ldlt_rows<1024, 2, true>, 1024);
-              else go(k_ldlt_rows<1024, 4, true>, 1024);
-            } else {
-              if (rows_R == 1 && rows_small) go(k_ldlt_rows<640, 1, false>, 640);
-              else if (rows_R == 1) go(k_ldlt_rows<1024, 1, false>, 1024);
-              else if (rows_R == 2) go(k_ldlt_rows<1024, 2, false>, 1024);
-              else go(k_ldlt_rows<1024, 4, false>, 1024);
-            }
-          }
-          else if (nP <= 22)
-            hipLaunchKernelGGL(k_ldlt_blk<256>, dim3(1), dim3(256), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
-          else if (nP <= 44)
-            hipLaunchKernelGGL(k_ldlt_blk<1024>, dim3(1), dim3(1024), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
-          else
-            hipLaunchKernelGGL(k_ldlt, dim3(1), dim3(1024), lds_need, st, n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_lds ? 1 : 0);
-        } else {
-          ORBG_HIP(hipMemsetAsync(h->d_ok.p, 0xFF, sizeof(int), st));   // nothing to solve: ok
-        }
+        // the solve of this trial may already be running: it was launched, with the lambda the device computed for the accepted
+        // case, behind the previous trial's residual / linearisation kernel
+        if (!(solve_version == version - 1 && qmax == 0 && used_spec) && (rc2 = launch_solve(ls, lambda, lam_p))) return rc2;
         hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, D.pose_col, D.point_col,
                            h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
                            Hlls[ls], bls[ls], lambda, h->d_poses[trial].p, h->d_points[trial].p, bps[ls], h->d_scale_partial.p, lam_p);
@@ -2222,8 +2248,16 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
             hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[trial].p,
                                h->d_points[trial].p, cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                                D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u, h->d_ok.p,
-                               h->rec.d, ++h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set]);
+                               h->rec.d, ++h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
+                               LmIn{currentChi, lambda, lambda_on_device ? h->d_lambda0.p + 2 : (const double*)nullptr,
+                                    lambda_on_device ? h->d_lambda0.p : (const double*)nullptr, h->d_lambda0.p + 1});
             speculated = true;
+            // ... and, when the next trial belongs to the same round, its Schur complement + LDL^T with the lambda the device
+            // has just computed for the accepted case: the host's verdict then arrives while they run
+            if (it + 1 < iterations && nBad < 2 && nP > 0) {
+              if ((rc2 = launch_solve(set, 0.0, h->d_lambda0.p + 1))) return rc2;
+              solve_version = version;
+            }
           } else {
             launch_errors(trial, 1);
             if (may_continue) { launch_linearise(trial, ls ^ 1); speculated = true; }
@@ -2262,7 +2296,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         scale += 1e-3;
         rho /= scale;
         if (rho > 0 && std::isfinite(tempChi)) {
-          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          const double c3 = 2 * rho - 1;               // (2 rho - 1)^3 as two multiplications: publish_trial_record does the same
+          double alpha = 1. - c3 * c3 * c3;            // arithmetic on the device for the speculative next solve
           alpha = std::min(alpha, 2. / 3.);
           const double scaleFactor = std::max(1. / 3., alpha);
           lambda *= scaleFactor;
