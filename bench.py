@@ -147,8 +147,8 @@ def cpu_baseline(scene, synth, views, n_frames=300, n_distinct=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic stereo frames (ping-pong sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--separate-calls", action="store_true",
