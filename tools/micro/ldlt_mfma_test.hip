@@ -1,0 +1,127 @@
+// Stand-alone check + timing of csrc/ldlt_mfma.hpp (the FP64-MFMA LDL^T of the reduced camera system).
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o ldlt_mfma_test ldlt_mfma_test.hip && ./ldlt_mfma_test
+// 1. probes the operand / accumulator lane layout of v_mfma_f64_16x16x4_f64 with asymmetric integer data,
+// 2. solves random SPD systems of the sizes the local BA produces and compares with a long-double host LDL^T,
+// 3. checks the zero-pivot failure flag, 4. times the kernel (HIP events over back-to-back launches).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define LDLTM_PROFILE 1
+#include "../../multi_orbslam3_amd/csrc/ldlt_mfma.hpp"
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); exit(2); } } while (0)
+
+__global__ void k_probe(const double* A /*16x4*/, const double* B /*4x16*/, double* D /*16x16*/) {
+  const int l = threadIdx.x;
+  ldltm::d4 c = {0, 0, 0, 0};
+  c = ldltm::mfma(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], c);
+  for (int g = 0; g < 4; g++) D[((l >> 4) + 4 * g) * 16 + (l & 15)] = c[g];
+}
+
+static bool host_solve(int n, const std::vector<double>& S, const std::vector<double>& b, std::vector<double>& x) {
+  std::vector<long double> a(S.begin(), S.end()), y(b.begin(), b.end());
+  for (int j = 0; j < n; j++) {
+    const long double d = a[(size_t)j * n + j];
+    if (d == 0) return false;
+    for (int i = j + 1; i < n; i++) {
+      const long double l = a[(size_t)i * n + j] / d;
+      for (int c = j + 1; c <= i; c++) a[(size_t)i * n + c] -= l * a[(size_t)c * n + j];   // rows c >= j+1 still unscaled below
+    }
+    for (int i = j + 1; i < n; i++) a[(size_t)i * n + j] /= d;
+  }
+  for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) y[i] -= a[(size_t)i * n + j] * y[j];
+  for (int i = 0; i < n; i++) y[i] /= a[(size_t)i * n + i];
+  for (int i = n - 1; i >= 0; i--) for (int j = i + 1; j < n; j++) y[i] -= a[(size_t)j * n + i] * y[j];
+  x.assign(n, 0.0);
+  for (int i = 0; i < n; i++) x[i] = (double)y[i];
+  return true;
+}
+
+int main(int argc, char** argv) {
+  int fails = 0;
+  {   // ---- 1. layout probe
+    std::vector<double> A(64), B(64), D(256), ref(256, 0.0);
+    for (int i = 0; i < 16; i++) for (int k = 0; k < 4; k++) A[i * 4 + k] = 1 + i * 7 + k * 3;
+    for (int k = 0; k < 4; k++) for (int j = 0; j < 16; j++) B[k * 16 + j] = 2 + k * 11 + j * 5 + (j * j) % 3;
+    for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) for (int k = 0; k < 4; k++) ref[i * 16 + j] += A[i * 4 + k] * B[k * 16 + j];
+    double *dA, *dB, *dD;
+    CK(hipMalloc(&dA, 64 * 8)); CK(hipMalloc(&dB, 64 * 8)); CK(hipMalloc(&dD, 256 * 8));
+    CK(hipMemcpy(dA, A.data(), 64 * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), 64 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    CK(hipMemcpy(D.data(), dD, 256 * 8, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < 256; i++) bad += D[i] != ref[i];
+    printf("mfma_f64_16x16x4 layout probe: %s (%d mismatches)\n", bad ? "FAIL" : "ok", bad);
+    fails += bad != 0;
+  }
+  std::mt19937_64 rng(12345);
+  std::normal_distribution<double> N01(0.0, 1.0);
+  const int sizes[] = {6, 12, 18, 60, 96, 114, 120, 126, 132, 138, 150, 204, 240, 300};
+  for (int n : sizes) {
+    if (!ldltm::supports(n)) { printf("n=%d unsupported\n", n); continue; }
+    std::vector<double> M((size_t)n * n), S((size_t)n * n), b(n), x(n), xr;
+    for (auto& v : M) v = N01(rng);
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j <= i; j++) {
+        double s = 0;
+        for (int k = 0; k < n; k++) s += M[(size_t)i * n + k] * M[(size_t)j * n + k];
+        if (i == j) s += 0.05 * n;
+        S[(size_t)i * n + j] = S[(size_t)j * n + i] = s;
+      }
+    for (auto& v : b) v = N01(rng);
+    host_solve(n, S, b, xr);
+    const ldltm::Geo g = ldltm::make_geo(n);
+    double *dS, *db, *dx, *dw; int* dok;
+    CK(hipMalloc(&dS, S.size() * 8)); CK(hipMalloc(&db, n * 8)); CK(hipMalloc(&dx, n * 8)); CK(hipMalloc(&dok, 4));
+    CK(hipMalloc(&dw, ldltm::wglob_doubles(g) * 8));
+    CK(hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(dx, 0, n * 8)); CK(hipMemset(dok, 0xFF, 4));
+    CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
+    CK(hipDeviceSynchronize());
+    int ok = -7;
+    CK(hipMemcpy(x.data(), dx, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost));
+    double err = 0, mx = 0;
+    for (int i = 0; i < n; i++) { err = std::max(err, std::fabs(x[i] - xr[i])); mx = std::max(mx, std::fabs(xr[i])); }
+    const bool good = ok == 1 && err <= 1e-10 * std::max(mx, 1.0);
+    // timing
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 200;
+    for (int i = 0; i < 10; i++) CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; i++) CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (n == 120 || n == 300) {
+      long long pr[256];
+      CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltm::g_prof), sizeof(pr)));
+      printf("  prof n=%d (cycles from kernel start): loaded %lld  factor_done %lld  sync %lld  end %lld\n", n, pr[1] - pr[0], pr[2] - pr[0], pr[3] - pr[0], pr[4] - pr[0]);
+      for (int k = 0; k < g.Tp; k++) {
+        const long long* e = pr + 8 + 8 * k;
+        printf("   row %2d: factor start %7lld  pivots %6lld  publish %5lld | panel(k,k+1) start %7lld dur %5lld | upd(k+1,k+1) done %7lld\n", k, e[0] - pr[0], e[1] - e[0], e[2] - e[1], e[3] - pr[0], e[4] - e[3], e[5] - pr[0]);
+      }
+    }
+    printf("n=%3d T=%2d ok=%d max|dx|=%.3e (max|x|=%.3e) %s   %.2f us/launch\n", n, g.T, ok, err, mx, good ? "ok" : "FAIL", 1000.0 * ms / reps);
+    fails += !good;
+    if (n == 120) {   // zero pivot -> ok = 0
+      std::vector<double> S2 = S;
+      for (int i = 0; i < n; i++) S2[i] = S2[(size_t)i * n] = 0.0;
+      CK(hipMemcpy(dS, S2.data(), S2.size() * 8, hipMemcpyHostToDevice));
+      CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost));
+      printf("zero pivot: ok=%d %s\n", ok, ok == 0 ? "ok" : "FAIL");
+      fails += ok != 0;
+    }
+    CK(hipFree(dS)); CK(hipFree(db)); CK(hipFree(dx)); CK(hipFree(dok)); CK(hipFree(dw));
+  }
+  printf(fails ? "FAILED (%d)\n" : "ALL OK\n", fails);
+  return fails ? 1 : 0;
+}
