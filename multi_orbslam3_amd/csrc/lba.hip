@@ -14,7 +14,9 @@
 //   k_schur         block/pose-pair: S_ij = [i==j](Hpp_i + lambda I) - sum_l Hpl_il (Hll_l+lambda I)^-1 Hpl_jl^T,
 //                   gathered over the points both poses observe (structure built once per call); diagonal pairs
 //                   also produce b_s,i = bp_i - sum_l Hpl_il Dinv_l bl_l
-//   k_ldlt_blk      one workgroup: register-blocked (one 6x6 block per thread) dense LDL^T of the reduced camera matrix + solve
+//   ldlt_mfma.hpp   one workgroup: dense LDL^T + solve of the reduced camera system on the FP64 matrix cores
+//                   (v_mfma_f64_16x16x4_f64; 16x16 tiles in registers, dataflow between wavefronts); k_ldlt_flow /
+//                   k_ldlt_rows / k_ldlt are the vector-ALU kernels for windows it does not cover (> 50 free poses)
 //   k_update        thread/vertex: x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i); trial state = exp(x_p) * T  /  X + x_l
 //   k_finish        one workgroup: robust chi2, computeScale, max-diagonal -> pinned host record
 // The reduced camera system is tiny (6P x 6P, P <= a few tens): the path is latency bound, not FLOP bound.
@@ -36,6 +38,8 @@
 #include <numeric>
 
 using namespace orbg;
+
+#include "ldlt_mfma.hpp"
 
 namespace {
 
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
                                                         const double* __restrict__ bl, const double* __restrict__ Hpp,
                                                         const double* __restrict__ bp, double lambda_v, double* __restrict__ S,
                                                         double* __restrict__ bs, const double* __restrict__ lambda_p, int item_cap,
-                                                        const int* __restrict__ pair_count) {
+                                                        const int* __restrict__ pair_count, double* __restrict__ St) {
   const double lambda = lambda_p ? *lambda_p : lambda_v;      // first trial of a round: lambda was computed on the device
   // one workgroup per pose pair, one thread per shared landmark (the diagonal pairs hold every landmark of the pose:
   // ~550 at C2, so 256 threads keep their item loop at 3 rounds); sums in a fixed order: per thread, then 4 x 64, then 4
@@ -820,8 +824,17 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
       const int u = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);        // index into the 21 upper entries
       v += Hpp[21 * (size_t)i1 + u] + (a == c ? lambda : 0.0);
     }
-    S[(size_t)(6 * i1 + a) * n + 6 * i2 + c] = v;
-    if (!diag) S[(size_t)(6 * i2 + c) * n + 6 * i1 + a] = v;
+    if (St) {
+      // the matrix-core LDL^T reads the matrix as a tile image (ldlt_mfma.hpp): upper-triangle tiles only, the diagonal
+      // tiles with both triangles
+      const int r = 6 * i1 + a, cc = 6 * i2 + c;
+      const int p0 = ldltm::tile_image_pos(r, cc), p1 = ldltm::tile_image_pos(cc, r);
+      if (p0 >= 0) St[p0] = v;
+      if (p1 >= 0 && r != cc) St[p1] = v;
+    } else {
+      S[(size_t)(6 * i1 + a) * n + 6 * i2 + c] = v;
+      if (!diag) S[(size_t)(6 * i2 + c) * n + 6 * i1 + a] = v;
+    }
   } else if (diag && tid < 42) {
     const int a = tid - 36;
     const double s = ((part[tid][0] + part[tid][1]) + part[tid][2]) + part[tid][3];
@@ -896,156 +909,6 @@ __global__ __launch_bounds__(1024) void k_ldlt(int n, double* S, const double* _
 // barriers per block column forward, two backward; no pivoting; zero / non-finite pivot => ok = 0.
 constexpr int kPanStride = 74;   // doubles per panel row-block: L (36, padded to 37) + W (36, padded to 37): conflict-free b64 reads
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_ldlt_blk(int nb, const double* __restrict__ S, const double* __restrict__ b,
-                                                 double* __restrict__ x, int* __restrict__ ok_flag) {
-  extern __shared__ double sh[];
-  double* Ljj = sh;            // 36
-  double* Dj = sh + 36;        // 6 (reciprocals of the block's pivots)
-  double* yj = sh + 42;        // 6 (forward: y_j, backward: x_i)
-  double* r = sh + 48;         // 6*nb running rhs
-  double* pan = r + 6 * nb;    // 2 * nb * kPanStride
-  __shared__ int s_ok;
-  const int t = threadIdx.x;
-  const int n = 6 * nb;
-  const int nblk = nb * (nb + 1) / 2;
-  int bi = -1, bk = -1;
-  if (t < nblk) {
-    bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-    while ((bi + 1) * (bi + 2) / 2 <= t) bi++;
-    while (bi * (bi + 1) / 2 > t) bi--;
-    bk = t - bi * (bi + 1) / 2;
-  }
-  double a[36];
-  if (bi >= 0) {
-#pragma unroll
-    for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) a[6 * rr + c] = S[(size_t)(6 * bi + rr) * n + 6 * bk + c];
-  }
-  for (int i = t; i < n; i += NT) r[i] = b[i];
-  if (t == 0) s_ok = 1;
-  __syncthreads();
-  for (int j = 0; j < nb; j++) {
-    double* P = pan + (size_t)(j & 1) * nb * kPanStride;
-    if (bi == j && bk == j) {
-      // in-register LDL^T of the 6x6 diagonal block: a[rr][c] (rr > c) <- L, a[c][c] <- d_c
-      bool good = true;
-      double inv_d[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double d = a[7 * c];
-#pragma unroll
-        for (int m = 0; m < c; m++) d -= a[6 * c + m] * a[6 * c + m] * a[7 * m];
-        if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
-        a[7 * c] = d;
-        const double id = fast_rcp(d);
-        inv_d[c] = id;
-#pragma unroll
-        for (int rr = c + 1; rr < 6; rr++) {
-          double v = a[6 * rr + c];
-#pragma unroll
-          for (int m = 0; m < c; m++) v -= a[6 * rr + m] * a[6 * c + m] * a[7 * m];
-          a[6 * rr + c] = v * id;
-        }
-      }
-      if (!good) s_ok = 0;
-      // y_j = L_jj^-1 r_j ; z_j = y_j / d (kept in r_j for the backward pass)
-      double y[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double v = r[6 * j + c];
-#pragma unroll
-        for (int m = 0; m < c; m++) v -= a[6 * c + m] * y[m];
-        y[c] = v;
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        yj[c] = y[c];
-        Dj[c] = inv_d[c];                 // panel owners only need 1/d
-        r[6 * j + c] = y[c] * inv_d[c];
-#pragma unroll
-        for (int m = 0; m < 6; m++) Ljj[6 * c + m] = a[6 * c + m];
-      }
-    }
-    __syncthreads();
-    if (!s_ok) break;
-    if (bk == j && bi > j) {
-      // W = A_ij L_jj^-T  (W L_jj^T = A_ij), L_ij = W D^-1
-      double* Lp = P + (size_t)bi * kPanStride;
-      double* Wp = Lp + 37;
-      double d[6], yv[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) { d[c] = Dj[c]; yv[c] = yj[c]; }
-#pragma unroll
-      for (int rr = 0; rr < 6; rr++) {
-        double w[6];
-        double racc = 0;
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          double v = a[6 * rr + c];
-#pragma unroll
-          for (int m = 0; m < c; m++) v -= w[m] * Ljj[6 * c + m];
-          w[c] = v;
-          const double l = v * d[c];      // d[] holds 1/d_c
-          a[6 * rr + c] = l;
-          Wp[6 * rr + c] = v;
-          Lp[6 * rr + c] = l;
-          racc += l * yv[c];
-        }
-        r[6 * bi + rr] -= racc;
-      }
-    }
-    __syncthreads();
-    if (bk > j && bi >= bk) {
-      const double* Lp = P + (size_t)bi * kPanStride;        // L_ij
-      const double* Wp = P + (size_t)bk * kPanStride + 37;   // W_kj = L_kj D_j
-#pragma unroll
-      for (int m = 0; m < 6; m++) {
-        double lc[6], wc[6];
-#pragma unroll
-        for (int q = 0; q < 6; q++) { lc[q] = Lp[6 * q + m]; wc[q] = Wp[6 * q + m]; }
-#pragma unroll
-        for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-          for (int c = 0; c < 6; c++) a[6 * rr + c] -= lc[rr] * wc[c];
-      }
-    }
-  }
-  const int ok = s_ok;
-  if (ok) {
-    // backward: x_i = L_ii^-T r_i ; r_k -= L_ik^T x_i for k < i
-    for (int i = nb - 1; i >= 0; i--) {
-      if (bi == i && bk == i) {
-        double xv[6];
-#pragma unroll
-        for (int c = 5; c >= 0; c--) {
-          double v = r[6 * i + c];
-#pragma unroll
-          for (int m = c + 1; m < 6; m++) v -= a[6 * m + c] * xv[m];
-          xv[c] = v;
-        }
-#pragma unroll
-        for (int c = 0; c < 6; c++) { yj[c] = xv[c]; x[6 * i + c] = xv[c]; }
-      }
-      __syncthreads();
-      if (bi == i && bk < i) {
-        double xv[6];
-#pragma unroll
-        for (int c = 0; c < 6; c++) xv[c] = yj[c];
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          double acc = 0;
-#pragma unroll
-          for (int rr = 0; rr < 6; rr++) acc += a[6 * rr + c] * xv[rr];
-          r[6 * bk + c] -= acc;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (t == 0) *ok_flag = ok;
-}
 
 // Row-pair variant of the register-blocked LDL^T: a 6x6 block is owned by THREE threads (two rows each), which cuts
 // the per-step trailing update (the longest phase) and the panel solve to a third, and every thread of block column j
@@ -1743,6 +1606,7 @@ struct lba_handle {
   DevBuf<PoseQ> d_poses[2];
   DevBuf<double> d_points[2];
   DevBuf<double> d_err, d_chi2, d_partial, d_EB, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_x;
+  DevBuf<double> d_St, d_wfac;         // reduced camera matrix as a tile image / factor scratch of the matrix-core LDL^T (ldlt_mfma.hpp)
   DevBuf<double> d_EB2, d_Hll2, d_bl2, d_Hpp2, d_bp2, d_lambda0;   // second linearisation set (speculative next iteration)
   DevBuf<int> d_pose_col, d_point_col, d_pt_start, d_pt_edges, d_ps_start, d_ps_edges, d_pf_start, d_pf_edges, d_pf_col;
   DevBuf<int> d_pair_i1, d_pair_i2, d_pair_start, d_ok;
@@ -1796,7 +1660,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->d_edges.release(); h->edges_pin.release(); h->d_items_dev.release(); h->d_pair_count.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release();
   h->d_err.release(); h->d_chi2.release(); h->d_partial.release(); h->d_EB.release(); h->d_Hll.release(); h->d_bl.release();
-  h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release();
+  h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release(); h->d_St.release(); h->d_wfac.release();
   h->d_EB2.release(); h->d_Hll2.release(); h->d_bl2.release(); h->d_Hpp2.release(); h->d_bp2.release(); h->d_lambda0.release();
   h->d_pose_col.release(); h->d_point_col.release(); h->d_pt_start.release(); h->d_pt_edges.release(); h->d_ps_start.release();
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
@@ -2002,10 +1866,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
   }
 
-  const size_t blk_lds = (48 + 6 * (size_t)nP + 2 * (size_t)nP * kPanStride) * sizeof(double);
-  if (blk_lds > 64 * 1024) {
-    ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_blk<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds));
-  }
   // row-pair LDL^T: R row pairs per thread, L kept in LDS when it fits next to the panels
   int rows_R = 0, rows_l_in_lds = 0;
   bool rows_small = false;
@@ -2014,7 +1874,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     const size_t nblk = (size_t)nP * (nP + 1) / 2;            // a wavefront holds kBlkPerWave blocks (3 threads each)
     rows_small = nblk <= 10 * kBlkPerWave;
     if (nblk <= 16 * kBlkPerWave) rows_R = 1; else if (nblk <= 32 * kBlkPerWave) rows_R = 2; else if (nblk <= 64 * kBlkPerWave) rows_R = 4;
-    if (getenv("ORBG_LDLT_BLK")) rows_R = 0;        // A/B switch: one-thread-per-block variant
     const size_t base = (12 * (size_t)nP + 36 + 32 + 2 * (size_t)nP * kPanStride) * sizeof(double);
     const size_t lall = (size_t)nP * (nP + 1) / 2 * 36 * sizeof(double);
     rows_l_in_lds = base + lall <= 150 * 1024;
@@ -2038,7 +1897,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   FlowMap flow_map;
   bool use_flow = false;
   size_t flow_lds = 0;
-  if (nP >= 1 && nP <= 20 && !getenv("ORBG_LDLT_ROWS") && !getenv("ORBG_LDLT_BLK")) {
+  if (nP >= 1 && nP <= 20 && !getenv("ORBG_LDLT_ROWS")) {
     int w = 0, fill = 0;
     for (int i = 0; i < 16; i++) { flow_map.c0[i] = 0; flow_map.c1[i] = 0; }
     bool fits = true;
@@ -2067,6 +1926,11 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         }
       }
     }
+  }
+  // FP64 matrix-core LDL^T (ldlt_mfma.hpp): up to 50 free poses; ORBG_LDLT_VALU=1 switches back to the vector-ALU kernels
+  const bool use_mfma = nP >= 1 && ldltm::supports(n) && !getenv("ORBG_LDLT_VALU");
+  if (use_mfma) {
+    if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
   }
   int cur = 0;   // index of the buffer holding the current estimate
   const int n_blocks_u = (NP + NX + 255) / 256;
@@ -2153,8 +2017,10 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     if (nP > 0) {
       hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                          EBs[set_], Hlls[set_], bls[set_], Hpps[set_], bps[set_], lam_, h->d_S.p, h->d_bs.p, lamp_, item_cap,
-                         dev_items ? h->d_pair_count.p : (const int*)nullptr);
-      if (use_flow) {
+                         dev_items ? h->d_pair_count.p : (const int*)nullptr, use_mfma ? h->d_St.p : (double*)nullptr);
+      if (use_mfma) {
+        ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
+      } else if (use_flow) {
         hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
       } else if (rows_R) {
         auto go = [&](auto kern, int nt) {
@@ -2172,10 +2038,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           else go(k_ldlt_rows<1024, 4, false>, 1024);
         }
       }
-      else if (nP <= 22)
-        hipLaunchKernelGGL(k_ldlt_blk<256>, dim3(1), dim3(256), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
-      else if (nP <= 44)
-        hipLaunchKernelGGL(k_ldlt_blk<1024>, dim3(1), dim3(1024), blk_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p);
       else
         hipLaunchKernelGGL(k_ldlt, dim3(1), dim3(1024), lds_need, st, n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_lds ? 1 : 0);
     } else {

@@ -26,6 +26,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace ldltm {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -54,10 +57,25 @@ __host__ __device__ inline Geo make_geo(int n) {
 // doubles of dynamic LDS
 __host__ __device__ inline size_t lds_doubles(const Geo& g, bool wlds) {
   size_t d = (size_t)2 * g.T * 512 + 2 * 16 * kGld + 32;
-  if (wlds) d += (size_t)g.N * (g.N - 1) / 2 + 64;
+  if (wlds) d += (size_t)g.N * (g.N - 1) / 2 + 256;
   return d;
 }
-__host__ inline size_t wglob_doubles(const Geo& g) { return (size_t)g.N * (g.N - 1) / 2 + 64; }
+__host__ inline size_t wglob_doubles(const Geo& g) { return (size_t)g.N * (g.N - 1) / 2 + 512; }
+
+// Input layout shared by the kernels below ("tile image"): the upper triangle's 16x16 tiles, tile (i, j), i <= j, at
+// t = j(j+1)/2 + i, 256 doubles each, lane-major: element (row 16i + (l>>4) + 4g, column 16j + (l&15)) at
+// t*256 + 4*l + g -- a lane's four accumulator values are 32 contiguous bytes (two 16-byte loads, fully coalesced:
+// one CU pulls 8-byte strided loads of a row-major matrix at ~11 GB/s, 16-byte ones at ~100 GB/s).  Diagonal tiles
+// hold both triangles.  Entries outside the n x n matrix are never read (the kernels synthesise padding and border).
+__host__ __device__ inline size_t tile_image_doubles(int n) { const Geo g = make_geo(n); return (size_t)g.ntiles * 256; }
+__host__ __device__ inline int tile_index(int i, int j) { return j * (j + 1) / 2 + i; }
+// position of matrix element (r, c) in the tile image, or -1 if it lies in a lower-triangle tile
+__host__ __device__ inline int tile_image_pos(int r, int c) {
+  const int i = r >> 4, j = c >> 4;
+  if (i > j) return -1;
+  const int l = ((r & 15) & 3) * 16 + (c & 15), g = (r & 15) >> 2;
+  return tile_index(i, j) * 256 + 4 * l + g;
+}
 
 __device__ __forceinline__ double rdlane(double v, int l) {   // l must be wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -72,8 +90,11 @@ __device__ __forceinline__ double rcp2(double d) {            // 1/d to ~1 ulp: 
   return x;
 }
 
+#ifndef LDLTM_SLEEP
+#define LDLTM_SLEEP 1
+#endif
 #ifdef LDLTM_PROFILE
-__device__ long long g_prof[256];
+__device__ long long g_prof[512];
 #define LDLTM_T(slot) do { if (lane == 0) g_prof[slot] = clock64(); } while (0)
 #else
 #define LDLTM_T(slot) do { } while (0)
@@ -82,7 +103,7 @@ __device__ long long g_prof[256];
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 template <int NS, int NY, bool WLDS>
-__global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __restrict__ S, const double* __restrict__ b,
+__global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __restrict__ St, const double* __restrict__ b,
                                                         double* __restrict__ x, int* __restrict__ ok_flag,
                                                         double* __restrict__ wglob) {
 #pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
@@ -100,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
   double* const Dv = Gb + 2 * 16 * kGld;                // [2][16]
   double* const Wl = Dv + 32;                           // factor store in LDS (WLDS)
   auto wm_store = [&](int I, int J, double v) {         // entry (I, J), I < J, of the unit upper factor; column-packed
-    const size_t o = (size_t)J * (J - 1) / 2 + I;
+    const int o = J * (J - 1) / 2 + I;
     if constexpr (WLDS) Wl[o] = v; else wglob[o] = v;
   };
   if (wv == 0) LDLTM_T(0);
@@ -121,34 +142,54 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
       i = t - j * (j + 1) / 2;
     }
     ti[s] = i; tj[s] = j;
-    d4 v = {0.0, 0.0, 0.0, 0.0};
-    if (t < G.ntiles) {
-      const int c = 16 * j + lc;
+  }
+  // two 16-byte loads per lane and tile from the tile image; wave-uniform conditions only (hipcc waits for a
+  // lane-predicated load before it issues the next one)
+  {
+    d4 sv[NS];
+    double bv[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      // no branch around the loads (hipcc drains the memory counter at every join): slots past the end re-read the last tile
+      const int t = min(s * kWaves + wv, G.ntiles - 1);
+      sv[s] = *reinterpret_cast<const d4*>(St + (size_t)t * 256 + 4 * lane);
+      const bool bt = tj[s] == (cb >> 4);
+      const int c = 16 * min(tj[s], T - 1) + lc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) bv[s][g] = b[bt ? min(min(16 * min(ti[s], T - 1) + lr + 4 * g, c), n - 1) : 0];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const int c = 16 * tj[s] + lc;
+      d4 v;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const int r = 16 * i + lr + 4 * g;
+        const int r = 16 * ti[s] + lr + 4 * g;
         double e = 0.0;
-        if (r < n && c < n) e = S[(size_t)r * n + c];
+        if (r < n && c < n) e = sv[s][g];
         else if (r == c) e = r < n_pad ? 1.0 : 0.0;
-        else if (c == cb && r < n) e = b[r];
-        else if (r == cb && c < n) e = b[c];
-        v[g] = e;
+        else if ((c == cb && r < n) || (r == cb && c < n)) e = bv[s][g];
+        v[g] = (tj[s] < T) ? e : 0.0;
       }
+      acc[s] = v;
     }
-    acc[s] = v;
   }
   __syncthreads();
   if (wv == 0) LDLTM_T(1);
 
   auto wait_gt = [&](int* w, int k) {
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k) __builtin_amdgcn_s_sleep(1);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k) __builtin_amdgcn_s_sleep(LDLTM_SLEEP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
   auto wait_free = [&](int k) {   // the LDS buffers of parity k&1 were last used by tile row k-2
     if (k >= 2) wait_gt(&s_rowdone[k - 2], kWaves - 1);
   };
 
-  // ---- the 16 (or fewer, last row) pivots of diagonal tile k
+  // ---- the 16 (or fewer, last row) pivots of diagonal tile k.  Per pivot j: C -= u (r u)^T as ONE matrix instruction
+  // (u = row j = column j of the symmetric tile: register j>>2 in the lanes of group j&3 is at once the A operand and,
+  // scaled, the B operand), the same update on a copy of the identity (-> G = L^-1).  The reciprocal of the NEXT pivot
+  // is computed on the vector ALU while the matrix instruction runs:  d_{j+1} = c_{j+1,j+1} - r_j c_{j,j+1}^2  from the
+  // operand copies, so the chain per pivot is one matrix instruction + one multiply, not instruction + readlane + rcp.
   auto factor = [&](int k) {
     LDLTM_T(8 + 8 * k + 0);
     d4 C = {0.0, 0.0, 0.0, 0.0};
@@ -160,41 +201,67 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
     for (int g = 0; g < 4; g++) E[g] = (lr + 4 * g == lc) ? 1.0 : 0.0;
     Gc = E;
     double dvv = 1.0;
-    bool good = true;
     const int npiv = min(16, n_pad - 16 * k);
+    double d = rdlane(C[0], 0);
+    bool good = !(d == 0.0 || !(fabs(d) < INFINITY));
+    double r = rcp2(d);
+#ifdef LDLTM_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
     for (int j = 0; j < 16; j++) {
+      if (j == 8) LDLTM_T(8 + 8 * k + 6);
       if (j < npiv) {
         const int g = j >> 2, q = j & 3;
-        const double d = rdlane(C[g], q * 16 + j);
-        if (d == 0.0 || !(fabs(d) < INFINITY)) good = false;
-        const double r = rcp2(d);
         const bool in = lr == q;
         const double rm = in ? -r : 0.0;
-        const double u = C[g];
-        const double wc = u * rm, we = E[g] * rm;
-        Wc[g] -= wc;                           // row j of the unit upper factor (lanes of group q), others unchanged
-        Gc[g] = in ? E[g] : Gc[g];             // row j of L^-1
-        if (lane == j) dvv = r;
+        double u = C[g];
+        asm volatile("" : "+v"(u));              // own registers: the instruction below then updates C in place
+        double un = u;
+        if (j < 15 && ((j + 1) >> 2) != g) { un = C[(j + 1) >> 2]; asm volatile("" : "+v"(un)); }
+        const double wc = u * rm;
         C = mfma(u, wc, C);
+        __builtin_amdgcn_sched_barrier(0);     // the tile's instruction first: it heads the dependency chain
+        double a = 0.0, bb = 0.0;
+        if (j < 15) {
+          a = rdlane(un, ((j + 1) & 3) * 16 + j + 1);   // c_{j+1,j+1} and c_{j,j+1} before this update
+          bb = rdlane(u, q * 16 + j + 1);
+        }
+        const double eg = E[g];
+        const double we = eg * rm;
+        Gc[g] = in ? eg : Gc[g];               // row j of L^-1 (final before its own pivot)
+        Wc[g] -= wc;                           // row j of the unit upper factor (lanes of group q), others unchanged
+        if (lane == j) dvv = r;
+        if (j + 1 < npiv) d = __builtin_fma(-r * bb, bb, a);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef LDLTM_NO_E
         E = mfma(u, we, E);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < npiv) {
+          if (d == 0.0 || !(fabs(d) < INFINITY)) good = false;
+          r = rcp2(d);
+        }
       }
     }
+#ifdef LDLTM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     LDLTM_T(8 + 8 * k + 1);
     wait_free(k);
     const int par = k & 1;
 #pragma unroll
     for (int g = 0; g < 4; g++) Gb[par * 16 * kGld + lc * kGld + lr + 4 * g] = Gc[g];
     if (lane < 16) Dv[par * 16 + lane] = dvv;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int I = 16 * k + lr + 4 * g, J = 16 * k + lc;
-      if (I < J && I < n_pad && J <= cb) wm_store(I, J, Wc[g]);
-    }
     if (!good) s_ok = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_store(&s_diag, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     LDLTM_T(8 + 8 * k + 2);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {              // the factor's rows are not needed before the back-substitution
+      const int I = 16 * k + lr + 4 * g, J = 16 * k + lc;
+      if (I < J && I < n_pad && J <= cb) wm_store(I, J, Wc[g]);
+    }
   };
 
   auto owns_diag = [&](int k) { return (k * (k + 1) / 2 + k) % kWaves == wv; };
@@ -226,45 +293,62 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
         R0 = mfma(Gf[1], X[1], R0);
         R1 = mfma(Gf[3], X[3], R1);
         const int j = tj[s];
-        double* const pb = Pan + ((size_t)(par * T + j) * 2) * 256 + lane;
+        double* const pb = Pan + ((par * T + j) * 2) * 256 + lane;
+        double w4[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-          const double r = R0[g] + R1[g];
-          const double w = r * dv4[g];
-          pb[g * 64] = -r;
-          pb[256 + g * 64] = w;
-          const int J = 16 * j + lc;
-          if (J <= cb) wm_store(16 * k + lr + 4 * g, J, w);
+          const double rr = R0[g] + R1[g];
+          w4[g] = rr * dv4[g];
+          pb[g * 64] = -rr;
+          pb[256 + g * 64] = w4[g];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(&s_panel[j], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (j == k + 1) LDLTM_T(8 + 8 * k + 4);
+        const int J = 16 * j + lc;
+        if (J <= cb) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, w4[g]);
+        }
       }
     }
-    // ---- trailing update with row k: tiles of row k+1 first, then (early) the next diagonal tile, then the rest
-    auto trail = [&](bool next_row) {
+    // ---- trailing update with row k.  Order: the next diagonal tile (then its pivots at once), the other tiles of
+    // row k+1 (the next panel), the rest.
+    auto trail = [&](int pass) {
 #pragma unroll
       for (int s = 0; s < NS; s++) {
         const int i = ti[s], j = tj[s];
-        if (i > k && i < (1 << 20) && ((i == k + 1) == next_row)) {
+        const int cls = (i == k + 1) ? (j == k + 1 ? 0 : 1) : 2;
+        if (i > k && i < (1 << 20) && cls == pass) {
           wait_gt(&s_panel[i], k);
           if (j != i) wait_gt(&s_panel[j], k);
-          const double* const pa = Pan + ((size_t)(par * T + i) * 2) * 256 + lane;
-          const double* const pw = Pan + ((size_t)(par * T + j) * 2 + 1) * 256 + lane;
+          const double* const pa = Pan + ((par * T + i) * 2) * 256 + lane;
+          const double* const pw = Pan + ((par * T + j) * 2 + 1) * 256 + lane;
           double a[4], w[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) { a[q] = pa[q * 64]; w[q] = pw[q * 64]; }
           d4 c = acc[s];
+          if (pass == 0) {                       // two chains of two: this tile is on the critical path
+            d4 t2 = {0.0, 0.0, 0.0, 0.0};
+            c = mfma(a[0], w[0], c);
+            t2 = mfma(a[2], w[2], t2);
+            c = mfma(a[1], w[1], c);
+            t2 = mfma(a[3], w[3], t2);
+            c += t2;
+          } else {
 #pragma unroll
-          for (int q = 0; q < 4; q++) c = mfma(a[q], w[q], c);
+            for (int q = 0; q < 4; q++) c = mfma(a[q], w[q], c);
+          }
           acc[s] = c;
-          if (i == k + 1 && j == k + 1) LDLTM_T(8 + 8 * k + 5);
+          if (pass == 0) LDLTM_T(8 + 8 * k + 5);
         }
       }
     };
-    trail(true);
-    if (k + 1 < G.Tp && owns_diag(k + 1)) factor(k + 1);
-    trail(false);
+    const bool next_diag = k + 1 < G.Tp && owns_diag(k + 1);
+    if (next_diag) { trail(0); factor(k + 1); }
+    trail(1);
+    if (!next_diag) trail(0);                    // a diagonal tile that holds no pivots (border only)
+    trail(2);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_fetch_add(&s_rowdone[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
@@ -273,12 +357,15 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
   __syncthreads();
   if (wv == 0) LDLTM_T(3);
   const int ok = s_ok;
-  // ---- back-substitution  L^T x = y  on one wavefront: x in registers, one column per step
+  // ---- back-substitution  L^T x = y  on one wavefront: x in registers, one column per step (v_readlane broadcast);
+  // the factor's columns are read four at a time, one group ahead, with unconditional loads (entries on or below the
+  // diagonal are masked after the load)
   if (wv == 0 && ok) {
-    auto wm_load = [&](int I, int J) -> double {        // 0 outside the strict upper triangle
-      if (I >= J) return 0.0;
-      const size_t o = (size_t)J * (J - 1) / 2 + I;
-      if constexpr (WLDS) return Wl[o]; else return __builtin_nontemporal_load(wglob + o);
+    auto wm_load = [&](int I, int J) -> double {
+      const int o = J * (J - 1) / 2 + I;
+      double v;
+      if constexpr (WLDS) v = Wl[o]; else v = __builtin_nontemporal_load(wglob + o);
+      return I < J ? v : 0.0;
     };
     double y[NY];
 #pragma unroll
@@ -286,28 +373,31 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
 #pragma unroll
     for (int rg = NY - 1; rg >= 0; rg--) {
       const int lo = rg * 64, hi = min(n_pad, lo + 64);
-      if (hi <= lo) continue;
-      double cur[4][NY], nxt[4][NY];
-      auto load_group = [&](int J0, double (*buf)[NY]) {
+      if (hi > lo) {
+        double cur[4][NY], nxt[4][NY];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
-          for (int r2 = 0; r2 < NY; r2++) buf[c][r2] = r2 <= rg ? wm_load(r2 * 64 + lane, J0 + c) : 0.0;
-      };
-      load_group(hi - 4, cur);
-      for (int J0 = hi - 4; J0 >= lo; J0 -= 4) {
-        if (J0 - 4 >= lo) load_group(J0 - 4, nxt);
+          for (int r2 = 0; r2 < NY; r2++) { cur[c][r2] = r2 <= rg ? wm_load(r2 * 64 + lane, hi - 4 + c) : 0.0; nxt[c][r2] = 0.0; }
+        for (int J0 = hi - 4; J0 >= lo; J0 -= 4) {
+          const int Jn = max(J0 - 4, lo);        // the last group re-reads itself (harmless) instead of branching
 #pragma unroll
-        for (int c = 3; c >= 0; c--) {
-          const double xJ = rdlane(y[rg], J0 + c - lo);
+          for (int c = 0; c < 4; c++)
 #pragma unroll
-          for (int r2 = 0; r2 < NY; r2++)
-            if (r2 <= rg) y[r2] -= cur[c][r2] * xJ;
+            for (int r2 = 0; r2 < NY; r2++)
+              if (r2 <= rg) nxt[c][r2] = wm_load(r2 * 64 + lane, Jn + c);
+#pragma unroll
+          for (int c = 3; c >= 0; c--) {
+            const double xJ = rdlane(y[rg], J0 + c - lo);
+#pragma unroll
+            for (int r2 = 0; r2 < NY; r2++)
+              if (r2 <= rg) y[r2] -= cur[c][r2] * xJ;
+          }
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r2 = 0; r2 < NY; r2++) cur[c][r2] = nxt[c][r2];
         }
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-          for (int r2 = 0; r2 < NY; r2++) cur[c][r2] = nxt[c][r2];
       }
     }
 #pragma unroll
@@ -317,14 +407,360 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
   if (tid == 0) *ok_flag = ok;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Column variant for up to 8 tile rows (windows of <= 20 free poses, the C2 workload): tile column j lives in
+// wavefront j.  Measured on MI355X (tools/micro/mfma_f64_latency.hip): an FP64 matrix instruction and FP64 vector
+// instructions of the same SIMD do NOT overlap (the 16x16x4 instruction holds the FP64 pipe for 64 cycles), so a
+// pivot costs its owner  readlane + rcp + one instruction = ~170 cycles  and every further instruction per pivot
+// (the identity copy of the general kernel) another ~66.  Here the diagonal wavefront therefore does nothing but its
+// own tile: it streams every pivot (the row u and 1/d) through LDS and the owners of the panel tiles (k, j) REPLAY the
+// rank-1 updates on their tile one step behind (one instruction per pivot on another SIMD), collecting R and W row by
+// row.  Wavefront k+1 holds both (k, k+1) and (k+1, k+1): it folds R^T W into its diagonal tile four pivots at a time
+// straight from registers, so the next diagonal tile is complete one instruction after the last replayed pivot.
+// Only R goes through LDS for the remaining trailing tiles (W stays in the owner's registers).
+constexpr int kColT = 8;
+constexpr int kPivRing = 4;                                   // tile rows of streamed pivots kept in LDS
+constexpr int kColPanels = kColT * (kColT - 1) / 2;           // one R image per panel tile: never overwritten
+
+// factor store of the column kernel: columns in pairs, (I, J) at  2p(p+1) + 2I + (J&1),  p = J>>1, rows I <= 2p+1;
+// entries on / below the diagonal inside a pair are stored as zeros, so the back-substitution reads two columns with
+// one 128-bit LDS load per lane and needs no per-entry mask
+__host__ __device__ inline size_t lds_doubles_cols(const Geo& g) {
+  const size_t pairs = (size_t)g.N / 2;
+  return (size_t)kPivRing * 16 * 64 + (size_t)kPivRing * 16 + (size_t)kColPanels * 256 + 2 * pairs * (pairs + 1) + 512;
+}
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+// explicit LDS pointers for volatile reads (a volatile generic pointer becomes flat_load); volatile because hipcc
+// otherwise sinks a look-ahead read into the place that uses it and waits for it there
+typedef __attribute__((address_space(3))) const volatile d2* lds_vd2p;
+typedef __attribute__((address_space(3))) const volatile double* lds_vdp;
+
+__global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __restrict__ St, const double* __restrict__ b,
+                                                        double* __restrict__ x, int* __restrict__ ok_flag) {
+#pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  __shared__ int s_piv;                // pivots published so far (16 k + pv + 1)
+  __shared__ int s_rflag[kColT];       // per tile column j: rows k whose R_kj is published
+  __shared__ int s_rowdone[kColT];     // per tile row: wavefronts that finished it
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const Geo G = make_geo(n);
+  const int T = G.T, n_pad = G.n_pad, cb = G.cb;
+  double* const Piv = sh;                               // [4][16][64]  per pivot the A operand -L[:, pv] (zero outside its lane group)
+  double* const Rcp = Piv + kPivRing * 16 * 64;         // [4][16]      1/d, written four pivots at a time
+  double* const Rb = Rcp + kPivRing * 16;               // [28][256]    -W_kj register images, tile (k, j) at k(15-k)/2 + j-k-1
+  double* const Wl = Rb + kColPanels * 256;             // unit upper factor, pair-packed
+  if (wv == 0) LDLTM_T(0);
+  if (tid == 0) { s_piv = 0; s_ok = 1; }
+  if (tid < kColT) { s_rflag[tid] = 0; s_rowdone[tid] = 0; }
+  __syncthreads();                     // the only barrier before the back-substitution: from here on the wavefronts run on flags
+
+  // ---- tile (i, wv) in slot i, two 16-byte loads per lane and tile, all in flight before the first use.  Wave-uniform
+  // conditions only around the loads (hipcc waits for a lane-predicated load before it issues the next one); a
+  // wavefront starts as soon as ITS column has arrived: wavefront 0 factors its single tile while the long columns
+  // are still streaming in
+  d4 acc[kColT];
+  {
+    d4 sv[kColT];
+    double bv[kColT][4];
+    const int c = 16 * wv + lc;
+    const bool border = wv == (cb >> 4);                // the column that holds the right-hand side
+    // no branch at all around the loads (even a wave-uniform one makes hipcc drain the memory counter at the join:
+    // the column then arrives one tile per memory round trip); slots past the column re-read its last tile
+    const int wc_ = min(wv, T - 1);
+#pragma unroll
+    for (int i = 0; i < kColT; i++) {
+      sv[i] = *reinterpret_cast<const d4*>(St + (size_t)tile_index(min(i, wc_), wc_) * 256 + 4 * lane);
+#pragma unroll
+      for (int g = 0; g < 4; g++) bv[i][g] = b[border ? min(min(16 * i + lr + 4 * g, c), n - 1) : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < kColT; i++) {
+      d4 v;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int r = 16 * i + lr + 4 * g;
+        double e = 0.0;
+        if (r < n && c < n) e = sv[i][g];
+        else if (r == c) e = r < n_pad ? 1.0 : 0.0;
+        else if ((c == cb && r < n) || (r == cb && c < n)) e = bv[i][g];
+        v[g] = (i <= wv && wv < T) ? e : 0.0;
+      }
+      acc[i] = v;
+    }
+  }
+  if (wv == 0) LDLTM_T(1);
+
+  auto poll_gt = [&](int* w, int k) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k) { }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  auto wait_free = [&](int k) {   // the pivot ring's slot k&3 was last used by tile row k-4 (T-1-(k-4) wavefronts replayed it)
+    if (k >= kPivRing) poll_gt(&s_rowdone[k - kPivRing], T - 1 - (k - kPivRing) - 1);
+  };
+  auto wm_store = [&](int I, int J, double v) { const int p2 = J >> 1; Wl[2 * p2 * (p2 + 1) + 2 * I + (J & 1)] = v; };
+  auto rb_of = [&](int k, int j) { return Rb + (k * (15 - k) / 2 + j - k - 1) * 256 + lane; };
+  auto row_done = [&](int k) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&s_rowdone[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  if (wv < T) {
+    d4 nWlast = {0.0, 0.0, 0.0, 0.0};   // -W of this wavefront's last panel tile: stored after its diagonal tile is factored
+    for (int k = 0; k <= wv && k < G.Tp; k++) {
+      const int par = k & (kPivRing - 1);
+      const int npiv = min(16, n_pad - 16 * k);          // a multiple of 4
+      if (k == wv) {
+        // ---- diagonal tile: pivot by pivot, each one streamed to the replaying wavefronts.  Everything that is not
+        // on the pivot chain is kept out of the loop (tools/micro/pivot_variants.hip: chain 173 cycles, +13 for a
+        // finite check, +26 for a branch, +16 for an accumulate, +37 for the two LDS stores -- per pivot, all serial):
+        // one branch per four pivots, the factor's rows stay in their registers until the loop is over, a zero pivot
+        // is detected from the last one (it poisons everything after it).
+        LDLTM_T(8 + 8 * k + 0);
+        d4 C = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < kColT; s++)
+          if (s == k) C = acc[s];
+        double wcs[16];
+#pragma unroll
+        for (int pv = 0; pv < 16; pv++) wcs[pv] = 0.0;
+        double dlast = 1.0;
+        double r4[4] = {1.0, 1.0, 1.0, 1.0};
+        bool anyzero = false;
+        wait_free(k);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (g == 2) LDLTM_T(8 + 8 * k + 6);
+          if (4 * g < npiv) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int pv = 4 * g + q;
+              const double d = rdlane(C[g], q * 16 + pv);
+              const double r = rcp2(d);
+              r4[q] = r;
+              double u = C[g];
+              asm volatile("" : "+v"(u));          // own registers: the instruction below then updates C in place
+              // the A operand of this pivot for everybody: -L[:, pv] = -r u in the lanes of group q, zero elsewhere (the
+              // B operand is then simply the tile's register g, unmasked: the other groups meet zeros).  ONE data store
+              // per pivot (a lone wavefront pays ~30 cycles per LDS instruction); LDS executes a wavefront's
+              // instructions in order, so the counter (same value from every lane: no exec juggling) becomes visible
+              // after the row
+              const double t = u * -r;
+              const double um = (lr == q) ? t : 0.0;
+              Piv[(par * 16 + pv) * 64 + lane] = um;
+              if (q == 3) Rcp[par * 16 + 4 * g + (lane & 3)] = (lane & 3) == 0 ? r4[0] : (lane & 3) == 1 ? r4[1] : (lane & 3) == 2 ? r4[2] : r4[3];
+              asm volatile("" ::: "memory");
+              __hip_atomic_store(&s_piv, 16 * k + pv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              wcs[pv] = um;                        // row pv of the unit upper factor (negated), lanes of group q
+              if (q == 3) { dlast = d; if (d == 0.0) anyzero = true; }
+              if (pv < 15) C = mfma(um, u, C);     // after the 16th pivot nothing of the tile is read again
+            }
+          }
+        }
+        LDLTM_T(8 + 8 * k + 1);
+        if (anyzero || !(fabs(dlast) < INFINITY)) s_ok = 0;
+        if (k > 0) {                               // the deferred stores of the panel tile (k-1, k)
+          const int J = 16 * wv + lc;
+          if (J <= cb) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) wm_store(16 * (k - 1) + lr + 4 * g, J, -nWlast[g]);
+          }
+          row_done(k - 1);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const double w = -((wcs[4 * g] + wcs[4 * g + 1]) + (wcs[4 * g + 2] + wcs[4 * g + 3]));
+          const int I = 16 * k + lr + 4 * g, J = 16 * k + lc;
+          if (I <= (J | 1) && I < n_pad && J <= cb) wm_store(I, J, I < J ? w : 0.0);
+        }
+        LDLTM_T(8 + 8 * k + 2);
+      } else {
+        // ---- panel tile (k, wv): replay the pivots one step behind the diagonal wavefront
+        d4 X = {0.0, 0.0, 0.0, 0.0}, D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < kColT; s++) {
+          if (s == k) X = acc[s];
+          if (s == wv) D = acc[s];
+        }
+        if (wv == k + 1) LDLTM_T(8 + 8 * k + 3);
+        LDLTM_T(80 + wv * 24 + 3 * k);
+        d4 Rc = {0.0, 0.0, 0.0, 0.0}, nW = {0.0, 0.0, 0.0, 0.0};
+        // The row of pivot pv+1 is read (counter first, then the row: LDS keeps a wavefront's order) while pivot pv is
+        // applied; the read is valid if the counter it saw already covered pv+1, otherwise the row is polled for.
+        // A wavefront that follows the diagonal closely takes the poll path, one that replays a finished row never waits.
+        // (compiler barriers keep hipcc from hoisting the row read above the counter read: a relaxed atomic orders nothing)
+        int cnt_raw = __hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // consumed one step later
+        asm volatile("" ::: "memory");
+        const lds_vdp pivr = (lds_vdp)(Piv) + par * 16 * 64 + lane;
+        double u_s = pivr[0];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (4 * g < npiv) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int pv = 4 * g + q;
+              const int want = 16 * k + pv;
+              double u = u_s;
+              if (__builtin_amdgcn_readfirstlane(cnt_raw) <= want) {
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= want) { }
+                asm volatile("" ::: "memory");
+                u = pivr[pv * 64];
+              }
+              if (pv < 15) {
+                asm volatile("" ::: "memory");
+                cnt_raw = __hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+                u_s = pivr[(pv + 1) * 64];
+              }
+              double xg = X[g];
+              asm volatile("" : "+v"(xg));         // own registers: X is then updated in place
+              Rc[g] = (lr == q) ? xg : Rc[g];      // row pv of R
+              if (pv < 15) X = mfma(u, xg, X);     // X -= L[:, pv] R[pv, :]; the tile is dead after its 16th row
+              if (q == 3) {                        // four rows complete: -W = -D^-1 R and the own diagonal tile (wv, wv) -= R^T W
+                nW[g] = Rc[g] * -Rcp[par * 16 + 4 * g + lr];
+                D = mfma(Rc[g], nW[g], D);
+              }
+              __builtin_amdgcn_sched_barrier(0);   // the look-ahead counter is consumed AFTER the instruction is issued
+            }
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < kColT; s++)
+          if (s == wv) acc[s] = D;
+        if (wv == k + 1) LDLTM_T(8 + 8 * k + 4);
+        LDLTM_T(80 + wv * 24 + 3 * k + 1);
+        // publish -W for the trailing tiles of the other columns (their B operand is their own unscaled R)
+        double* const rb = rb_of(k, wv);
+#pragma unroll
+        for (int g = 0; g < 4; g++) rb[g * 64] = nW[g];
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(&s_rflag[wv], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wv == k + 1) LDLTM_T(8 + 8 * k + 5);
+        if (wv == k + 1) {
+          nWlast = nW;                             // next: this wavefront's own pivots; the factor store can wait
+        } else {
+          // ---- trailing tiles (i, wv), k < i < wv:  -= W_ki^T R_k,wv
+#pragma unroll
+          for (int s = 0; s < kColT; s++) {
+            if (s > k && s < wv) {
+              poll_gt(&s_rflag[s], k);
+              const double* const pa = rb_of(k, s);
+              double a[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) a[q] = pa[q * 64];
+              d4 c = acc[s];
+#pragma unroll
+              for (int q = 0; q < 4; q++) c = mfma(a[q], Rc[q], c);
+              acc[s] = c;
+            }
+          }
+          const int J = 16 * wv + lc;
+          if (J <= cb) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, -nW[g]);
+          }
+          LDLTM_T(80 + wv * 24 + 3 * k + 2);
+          row_done(k);
+        }
+      }
+    }
+    // a column without pivots of its own (the border column when n_pad is a multiple of 16) never reaches the branch
+    // above that stores its last panel tile
+    if (wv >= G.Tp && wv > 0) {
+      const int J = 16 * wv + lc;
+      if (J <= cb) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) wm_store(16 * (wv - 1) + lr + 4 * g, J, -nWlast[g]);
+      }
+      row_done(wv - 1);
+    }
+  }
+  if (wv == 0) LDLTM_T(2);
+  __syncthreads();
+  if (wv == 0) LDLTM_T(3);
+  const int ok = s_ok;
+  // ---- back-substitution  L^T x = y  on one wavefront (n_pad <= 124: two registers of x per lane), two columns per
+  // 128-bit load, one pair ahead; lanes past the pair's rows are switched off (they hold finished x)
+  if (wv == 0 && ok) {
+    // volatile: hipcc otherwise sinks the look-ahead load into the iteration that uses it (and then waits for it there)
+    const lds_vd2p W2 = (lds_vd2p)(Wl) + lane;   // entry pair (I, 2p..2p+1) at p(p+1) + I
+    double y0, y1;
+    {
+      const int pb = (cb >> 1) * ((cb >> 1) + 1);
+      const d2 a0 = W2[pb], a1 = W2[pb + 64];
+      y0 = lane < n_pad ? a0[0] : 0.0; y1 = 64 + lane < n_pad ? a1[0] : 0.0;
+    }
+    const int np = n_pad >> 1;
+    // pairs 32 .. np-1: the diagonal sits in y1, y0 takes part in full.  Four pairs are in flight (an LDS round trip
+    // is ~130 cycles, a pair's two dependent steps ~60): slot i of the ring is refilled right after its use
+    if (np > 32) {
+      d2 c0[4], c1[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const int pi = max(np - 1 - i, 32); c0[i] = W2[pi * (pi + 1)]; c1[i] = W2[pi * (pi + 1) + 64]; }
+      for (int pb = np - 1; pb >= 32; pb -= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int p2 = pb - i;
+          if (p2 >= 32) {
+            const bool on = 64 + lane <= 2 * p2 + 1;
+            const double x1 = rdlane(y1, 2 * p2 + 1 - 64);
+            y1 -= (on ? c1[i][1] : 0.0) * x1;
+            y0 -= c0[i][1] * x1;
+            const double x0 = rdlane(y1, 2 * p2 - 64);
+            y1 -= (on ? c1[i][0] : 0.0) * x0;
+            y0 -= c0[i][0] * x0;
+            const int pn = max(p2 - 4, 32);          // past the end: re-read a valid pair instead of branching
+            c0[i] = W2[pn * (pn + 1)]; c1[i] = W2[pn * (pn + 1) + 64];
+          }
+        }
+      }
+    }
+    {
+      const int ps = min(np, 32) - 1;
+      if (ps >= 0) {
+        d2 c0[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int pi = max(ps - i, 0); c0[i] = W2[pi * (pi + 1)]; }
+        for (int pb = ps; pb >= 0; pb -= 4) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int p2 = pb - i;
+            if (p2 >= 0) {
+              const bool on = lane <= 2 * p2 + 1;
+              const double x1 = rdlane(y0, 2 * p2 + 1);
+              y0 -= (on ? c0[i][1] : 0.0) * x1;
+              const double x0 = rdlane(y0, 2 * p2);
+              y0 -= (on ? c0[i][0] : 0.0) * x0;
+              const int pn = max(p2 - 4, 0);
+              c0[i] = W2[pn * (pn + 1)];
+            }
+          }
+        }
+      }
+    }
+    if (lane < n) x[lane] = y0;
+    if (64 + lane < n) x[64 + lane] = y1;
+  }
+  if (wv == 0) LDLTM_T(4);
+  if (tid == 0) *ok_flag = ok;
+}
+
 // true if k_ldlt_mfma covers a system of n unknowns (n = 6 * free poses)
 __host__ inline bool supports(int n) { return n >= 1 && make_geo(n).T <= 19; }
 
-struct Launch { const void* fn; size_t lds; bool wlds; };
+struct Launch { const void* fn; size_t lds; bool wlds; bool cols; };
 
 __host__ inline Launch pick(int n) {
   const Geo g = make_geo(n);
   Launch L;
+  if (g.T <= kColT && !getenv("ORBG_LDLT_TILES")) {
+    L.fn = reinterpret_cast<const void*>(k_ldlt_cols); L.wlds = true; L.cols = true;
+    L.lds = lds_doubles_cols(g) * sizeof(double);
+    return L;
+  }
+  L.cols = false;
   if (g.T <= 9) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
   else if (g.T <= 13) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<12, 4, false>); L.wlds = false; }
   else { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<24, 5, false>); L.wlds = false; }
@@ -332,17 +768,18 @@ __host__ inline Launch pick(int n) {
   return L;
 }
 
-__host__ inline hipError_t launch(int n, const double* S, const double* b, double* x, int* ok, double* wglob, hipStream_t st) {
+// St: the matrix as a tile image (tile_image_pos), b: right-hand side, x: solution, wglob: wglob_doubles() of scratch
+__host__ inline hipError_t launch(int n, const double* St, const double* b, double* x, int* ok, double* wglob, hipStream_t st) {
   const Launch L = pick(n);
-  static size_t attr[3] = {0, 0, 0};
+  static size_t attr[4] = {0, 0, 0, 0};
   const Geo g = make_geo(n);
-  const int which = g.T <= 9 ? 0 : g.T <= 13 ? 1 : 2;
+  const int which = L.cols ? 3 : g.T <= 9 ? 0 : g.T <= 13 ? 1 : 2;
   if (L.lds > 64 * 1024 && attr[which] < L.lds) {
     hipError_t e = hipFuncSetAttribute(L.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
     if (e != hipSuccess) return e;
     attr[which] = L.lds;
   }
-  void* args[] = {(void*)&n, (void*)&S, (void*)&b, (void*)&x, (void*)&ok, (void*)&wglob};
+  void* args[] = {(void*)&n, (void*)&St, (void*)&b, (void*)&x, (void*)&ok, (void*)&wglob};   // the column kernel ignores wglob
   return hipLaunchKernel(L.fn, dim3(1), dim3(kThreads), args, L.lds, st);
 }
 

@@ -11,7 +11,9 @@
 #include <random>
 #include <vector>
 
+#ifndef NO_PROFILE
 #define LDLTM_PROFILE 1
+#endif
 #include "../../multi_orbslam3_amd/csrc/ldlt_mfma.hpp"
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); exit(2); } } while (0)
@@ -61,8 +63,13 @@ int main(int argc, char** argv) {
   }
   std::mt19937_64 rng(12345);
   std::normal_distribution<double> N01(0.0, 1.0);
-  const int sizes[] = {6, 12, 18, 60, 96, 114, 120, 126, 132, 138, 150, 204, 240, 300};
-  for (int n : sizes) {
+  const int sizes_all[] = {6, 12, 18, 60, 96, 114, 120, 126, 132, 138, 150, 204, 240, 300};
+  const int sizes_q[] = {120};   // quick mode: the C2 window only
+  const bool quick = argc > 1;
+  const int* sizes = quick ? sizes_q : sizes_all;
+  const int nsizes = quick ? 1 : 14;
+  for (int si = 0; si < nsizes; si++) {
+    const int n = sizes[si];
     if (!ldltm::supports(n)) { printf("n=%d unsupported\n", n); continue; }
     std::vector<double> M((size_t)n * n), S((size_t)n * n), b(n), x(n), xr;
     for (auto& v : M) v = N01(rng);
@@ -79,7 +86,14 @@ int main(int argc, char** argv) {
     double *dS, *db, *dx, *dw; int* dok;
     CK(hipMalloc(&dS, S.size() * 8)); CK(hipMalloc(&db, n * 8)); CK(hipMalloc(&dx, n * 8)); CK(hipMalloc(&dok, 4));
     CK(hipMalloc(&dw, ldltm::wglob_doubles(g) * 8));
-    CK(hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice));
+    auto to_image = [&](const std::vector<double>& M2) {     // the kernels read the matrix as a tile image; poison the rest
+      std::vector<double> im(ldltm::tile_image_doubles(n), std::nan(""));
+      for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { const int pos = ldltm::tile_image_pos(r, c); if (pos >= 0) im[pos] = M2[(size_t)r * n + c]; }
+      return im;
+    };
+    std::vector<double> im = to_image(S);
+    CK(hipFree(dS)); CK(hipMalloc(&dS, im.size() * 8));
+    CK(hipMemcpy(dS, im.data(), im.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice));
     CK(hipMemset(dx, 0, n * 8)); CK(hipMemset(dok, 0xFF, 4));
     CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
     CK(hipDeviceSynchronize());
@@ -87,6 +101,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(x.data(), dx, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost));
     double err = 0, mx = 0;
     for (int i = 0; i < n; i++) { err = std::max(err, std::fabs(x[i] - xr[i])); mx = std::max(mx, std::fabs(xr[i])); }
+    if (n == 6 && getenv("LDLT_DEBUG")) { for (int i = 0; i < n; i++) printf("   x[%d] = % .6e  ref % .6e\n", i, x[i], xr[i]); }
     const bool good = ok == 1 && err <= 1e-10 * std::max(mx, 1.0);
     // timing
     hipEvent_t e0, e1;
@@ -99,21 +114,33 @@ int main(int argc, char** argv) {
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
+#ifdef LDLTM_PROFILE
     if (n == 120 || n == 300) {
-      long long pr[256];
+      long long pr[512];
       CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltm::g_prof), sizeof(pr)));
       printf("  prof n=%d (cycles from kernel start): loaded %lld  factor_done %lld  sync %lld  end %lld\n", n, pr[1] - pr[0], pr[2] - pr[0], pr[3] - pr[0], pr[4] - pr[0]);
       for (int k = 0; k < g.Tp; k++) {
         const long long* e = pr + 8 + 8 * k;
-        printf("   row %2d: factor start %7lld  pivots %6lld  publish %5lld | panel(k,k+1) start %7lld dur %5lld | upd(k+1,k+1) done %7lld\n", k, e[0] - pr[0], e[1] - e[0], e[2] - e[1], e[3] - pr[0], e[4] - e[3], e[5] - pr[0]);
+        printf("   row %2d: factor start %7lld  pivots %6lld (first 8: %5lld) publish %5lld | panel(k,k+1) start %7lld dur %5lld | upd(k+1,k+1) done %7lld\n", k, e[0] - pr[0], e[1] - e[0], e[6] - e[0], e[2] - e[1], e[3] - pr[0], e[4] - e[3], e[5] - pr[0]);
       }
     }
+    if (n == 120) {
+      long long pr[512];
+      CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltm::g_prof), sizeof(pr)));
+      for (int w = 1; w < 8; w++) {
+        printf("   wave %d:", w);
+        for (int k = 0; k < w; k++) printf(" r%d[%lld %lld %lld]", k, pr[80 + w * 24 + 3 * k] - pr[0], pr[80 + w * 24 + 3 * k + 1] - pr[0], k + 1 < w ? pr[80 + w * 24 + 3 * k + 2] - pr[0] : 0);
+        printf("\n");
+      }
+    }
+#endif
     printf("n=%3d T=%2d ok=%d max|dx|=%.3e (max|x|=%.3e) %s   %.2f us/launch\n", n, g.T, ok, err, mx, good ? "ok" : "FAIL", 1000.0 * ms / reps);
     fails += !good;
     if (n == 120) {   // zero pivot -> ok = 0
       std::vector<double> S2 = S;
       for (int i = 0; i < n; i++) S2[i] = S2[(size_t)i * n] = 0.0;
-      CK(hipMemcpy(dS, S2.data(), S2.size() * 8, hipMemcpyHostToDevice));
+      std::vector<double> im2 = to_image(S2);
+      CK(hipMemcpy(dS, im2.data(), im2.size() * 8, hipMemcpyHostToDevice));
       CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost));
