@@ -45,6 +45,9 @@ enum {
 #define ORBG_DESC_BYTES 32
 #define ORBG_GRID_COLS 64      /* FRAME_GRID_COLS, I/Frame.h:39 */
 #define ORBG_GRID_ROWS 48      /* FRAME_GRID_ROWS, I/Frame.h:38 */
+/* Feature indices travel in 16 bits inside the matchers and the stereo matcher (0xFFFF = none): frames / keypoint sets of
+ * this many features or more are refused with ORBG_CAP_EXCEEDED (the reference runs with 1000-2000 features per image). */
+#define ORBG_MAX_FRAME_FEATURES 65535
 
 /* ---------------------------------------------------------------- ORB extractor */
 

@@ -507,10 +507,13 @@ class Optimizer:
 
     def LocalBundleAdjustmentAsync(self, problem, out, pbStopFlag=None):
         """Submit the solve to the handle's own LocalMapping thread (lba_solve_async); collect with wait()."""
+        if getattr(self, "_async_keep", None) is not None:
+            # a solve is in flight: its problem / result arrays must stay referenced until wait()
+            raise RuntimeError("LocalBundleAdjustmentAsync: the previous solve has not been collected with wait()")
         out.c.trace_len = 0
-        self._async_keep = (problem, out, pbStopFlag)
         sp = None if pbStopFlag is None else C.c_void_p(pbStopFlag.ctypes.data)
         capi.check(self.lib.lba_solve_async(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_async")
+        self._async_keep = (problem, out, pbStopFlag)      # only once the library has accepted the job
 
     def wait(self):
         ms = C.c_double(0.0)

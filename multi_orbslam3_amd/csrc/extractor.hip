@@ -1756,6 +1756,7 @@ struct ExtractPending {
 };
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n);
 void orbm_internal_set_n(orbm_frame* f, int n);
+int orbx_internal_kp_capacity(orbx_handle* h);
 static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror);
 
 // Core: cams_mask selects which cameras of the rig are processed; d_img are device pointers.
@@ -2221,6 +2222,9 @@ static int extract_finish_gpu(orbx_handle* h, ExtractPending& c) {
 
 static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror) {
   const int nl = device_counts ? h->sel_bound : h->n_kp[0], nr = h->n_kp[1];
+  // the stereo key packs the right keypoint's index into 16 bits (dist << 16 | iR)
+  if (nl >= ORBG_MAX_FRAME_FEATURES || nr >= ORBG_MAX_FRAME_FEATURES || (device_counts && orbx_internal_kp_capacity(h) >= 2 * ORBG_MAX_FRAME_FEATURES))
+    return ORBG_CAP_EXCEEDED;
   if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[5], st));
   if (nl > 0) {
     const int* dn = device_counts ? h->d_nkp.p : nullptr;
@@ -2297,6 +2301,9 @@ extern "C" int orbx_get_timings(orbx_handle* h, float* ms) {
 
 // accessors for matcher.hip (device-resident hand-over, same shared object)
 extern "C++" {
+// capacity (keypoints, both cameras) of the device feature buffers: the bound of any device-side keypoint count
+int orbx_internal_kp_capacity(orbx_handle* h) { return h ? (int)std::min<size_t>(h->d_kps.cap, 0x7fffffff) : 0; }
+
 int orbx_internal_left_features(orbx_handle* h, const orbx_keypoint** d_kps, const uint8_t** d_desc, const float** d_uright,
                                 const float** d_depth, const orbx_keypoint** h_kps, int* n, hipStream_t* stream) {
   if (!h) return ORBG_BAD_ARG;

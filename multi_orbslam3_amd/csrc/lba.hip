@@ -2726,9 +2726,16 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   for (int i = 0; i < n; i++) r->outlier[i] = 0;
   if (n < 3) return ORBG_OK;                                  // S/Optimizer.cc:1180-1181
   // one pinned staging block: inputs in, results out (a per-thread cache keeps the allocation across calls)
-  struct Scratch { PinnedBuf<uint8_t> stage; DevBuf<uint8_t> dev; int device = -1; };
+  // per-thread scratch with its own non-blocking stream (the legacy null stream would synchronise with every blocking
+  // stream of the process -- torch / RCCL -- and serialise concurrent callers); released when the thread exits
+  struct Scratch {
+    PinnedBuf<uint8_t> stage; DevBuf<uint8_t> dev; int device = -1; hipStream_t stream = nullptr;
+    void drop() { stage.release(); dev.release(); if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; } }
+    ~Scratch() { drop(); }
+  };
   static thread_local Scratch sc;
-  if (sc.device != p->device) { sc.stage.release(); sc.dev.release(); sc.device = p->device; }
+  if (sc.device != p->device) { sc.drop(); sc.device = p->device; }
+  if (!sc.stream) ORBG_HIP(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
   const size_t in_bytes = ((size_t)n * 7 * 4 + 15) & ~(size_t)15;
   const size_t out_off = in_bytes;
   const size_t out_bytes = sizeof(PoseQ) + 8 * sizeof(int) + 4 * sizeof(double) + (size_t)n + 64;
@@ -2744,7 +2751,7 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   const float* dX;
   if (n <= kPoLdsN) dX = reinterpret_cast<const float*>(sc.stage.d);
   else {
-    ORBG_HIP(hipMemcpyAsync(sc.dev.p, sc.stage.h, in_bytes, hipMemcpyHostToDevice, 0));
+    ORBG_HIP(hipMemcpyAsync(sc.dev.p, sc.stage.h, in_bytes, hipMemcpyHostToDevice, sc.stream));
     dX = reinterpret_cast<const float*>(sc.dev.p);
   }
   uint8_t* dout = sc.stage.d + out_off;
@@ -2766,7 +2773,7 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   if (po_seq == 0) po_seq = 1;
   volatile int* seq_word = reinterpret_cast<volatile int*>(sc.stage.h + out_off + sizeof(PoseQ) + 4 * sizeof(double)) + 7;
   *seq_word = 0;
-  hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, 0, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n, dX + 5 * (size_t)n,
+  hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n, dX + 5 * (size_t)n,
                      dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
   ORBG_HIP(hipGetLastError());
   {
@@ -2782,7 +2789,7 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
       }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
-    if (!got) ORBG_HIP(hipStreamSynchronize(0));
+    if (!got) ORBG_HIP(hipStreamSynchronize(sc.stream));
   }
   const uint8_t* ho = sc.stage.h + out_off;
   PoseQ Tf;

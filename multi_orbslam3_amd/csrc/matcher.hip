@@ -805,6 +805,8 @@ struct orbm_frame {
 
 static int frame_set_params(orbm_frame* f, const orbm_frame_view* v, int n) {
   if (v->n_levels < 1 || v->n_levels > ORBG_MAX_LEVELS) return ORBG_BAD_ARG;
+  // feature indices travel in 16 bits (candidate lists idx | dist << 16, QResult.idx with 0xFFFF = none)
+  if (n >= ORBG_MAX_FRAME_FEATURES) return ORBG_CAP_EXCEEDED;
   FrameParams& p = f->fp;
   p.n = n;
   p.min_x = v->min_x; p.max_x = v->max_x; p.min_y = v->min_y; p.max_y = v->max_y;
@@ -913,14 +915,18 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
 
 // Used by orbx_frame_stereo_dev (extractor.hip): alias the extractor's left features and launch the grid build on the
 // EXTRACTOR's stream, behind the descriptor / stereo kernels; the caller synchronises that stream once.
+int orbx_internal_kp_capacity(orbx_handle* h);   // extractor.hip
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n) {
   if (!f || !h || !v) return ORBG_BAD_ARG;
   const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n0; hipStream_t xs;
   int rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n0, &xs);
   if (rc) return rc;
-  // n < 0: the count only exists on the device yet (d_n); buffers are sized for the frame's capacity
+  // n < 0: the count only exists on the device yet (d_n): the grid buffers are sized for the most keypoints the
+  // extractor's own buffers can hold (grid_build_kernel writes cell_of[i] / cell_items[i] for every i < *d_n)
   if ((rc = frame_set_params(f, v, n < 0 ? 0 : n))) return rc;
-  if ((rc = frame_reserve(f, n < 0 ? std::max(f->cap, 4096) : n))) return rc;
+  const int xcap = orbx_internal_kp_capacity(h);
+  if (n < 0 && xcap >= ORBG_MAX_FRAME_FEATURES) return ORBG_CAP_EXCEEDED;
+  if ((rc = frame_reserve(f, n < 0 ? std::max(std::max(f->cap, 4096), xcap) : n))) return rc;
   f->has_uright = true;
   f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
   f->stream = stream;              // the extractor's stream: searches on this frame follow its constructor in order
