@@ -2,20 +2,28 @@
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric):
 "tracking+localBA frames/sec per agent, 640x480 stereo, 1/2/4/8 agents".
 
-One STEP = one stereo frame of one agent through the hot path, inputs already resident in HBM:
+One STEP = one frame of one agent through the hot path, inputs already resident in HBM:
   [Frame ctor: extract L+R (pyramid, FAST, quad-tree, angle, rBRIEF) -> ComputeStereoMatches -> feature grid]
   ->  SearchByProjection(cur, last)  ->  SearchLocalPoints (isInFrustum + SearchByProjection over the local map)
-and, every FRAMES_PER_KF-th step (a keyframe), one Local Bundle Adjustment (20 free + 10 fixed KFs, 2000 points)
-plus the upload of the refreshed local map.  By default (--lba-mode async) the LBA runs on the library's own worker
-thread and HIP stream (lba_solve_async / lba_wait), concurrently with the frame loop, exactly as the reference runs
-LocalMapping next to Tracking (S/ClientSystem.cc:105-106); every LBA triggered in the timed region is waited for
-before the clock stops.  `--lba-mode thread` does the same from a Python thread (pays for GIL hand-overs).
-`--lba-mode inline` gives the serial accounting fps = 1 / (t_frontend + t_LBA / FRAMES_PER_KF), which is also
-reported as config.sequential_fps_formula.
+and, every FRAMES_PER_KF-th step (a keyframe), one Local Bundle Adjustment plus the upload of the refreshed local map.
+By default (--lba-mode async) the LBA runs on the library's own worker thread and HIP stream (lba_solve_async /
+lba_wait), concurrently with the frame loop, exactly as the reference runs LocalMapping next to Tracking
+(S/ClientSystem.cc:105-106); every LBA triggered in the timed region is waited for before the clock stops.
+`--lba-mode inline` gives the serial accounting fps = 1 / (t_frontend + t_LBA / FRAMES_PER_KF).
+
+--config selects the workload: C2 (BASELINE.json configs[1], the metric's configuration, default), C4 (configs[3]'s
+single-GPU part: 1280x720, 2000 features, 50-KF local BA) or mono (the monocular agents of configs[4]: host image ->
+ORBextractor::operator() with the lapping area of S/Frame.cc:289 -> Frame upload -> the two searches -> mono-edge LBA).
+
+Besides `value` the line carries value_host_images (the Frame constructor takes host images: H2D included) and
+value_with_pose_opt (the two PoseOptimization calls of Tracking per frame included), each from a shorter timed region,
+p50 / p95 of the per-step times, the measured device-copy bandwidth, and the host CPU.
 
 Agents shard one per GPU with no data-path collective -> weak scaling; `value` is the
 aggregate over all ranks.  Launch for N>1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+--server-tick adds the server-side exchange of configs[2]/[4] (not part of `value`): RCCL all-gather of KeyFrame wire
+blocks -> KeyFrame rebuilt on the device -> SearchByProjection(KF, Scw, map points), microseconds per tick.
 """
 import argparse
 import json
@@ -29,37 +37,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FRAMES_PER_KF = 5
-HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak is ~6300 GB/s
-# algorithmic bytes of the FAST kernel per launch: every pyramid pixel of both cameras read once
-PYR_PIXELS_640x480 = 950532
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (dense); measured issue rate of v_mfma_f64_16x16x4_f64:
+#                                 one per 66 cycles per SIMD = 31 FLOP/clk/SIMD (tools/micro/mfma_f64_latency.hip) = 76 TF
+
+CONFIGS = {
+    "C2": dict(W=640, H=480, stereo=True, n_features=1000, lba=(20, 10, 2000), mono_frac=0.0, frame_cap=4096, map_cap=16384,
+               label="C2: 1 client stereo 640x480 synthetic, 1000 ORB feat/frame, 20-KF local BA window "
+                     "(20 free + 10 fixed KFs, 2000 points)"),
+    "C4": dict(W=1280, H=720, stereo=True, n_features=2000, lba=(50, 20, 8000), mono_frac=0.0, frame_cap=8192, map_cap=32768,
+               label="C4 (single-GPU part of configs[3]): 1 client stereo 1280x720 synthetic, 2000 ORB feat/frame, 50-KF local BA "
+                     "window (50 free + 20 fixed KFs, 8000 points); visual edges only (IMU types are out of scope)"),
+    "mono": dict(W=640, H=480, stereo=False, n_features=1000, lba=(20, 10, 2000), mono_frac=1.0, frame_cap=4096, map_cap=16384,
+                 label="mono agent of configs[4]: 1 client mono 640x480 synthetic (host image -> operator() with lapping area "
+                       "{0,1000}, S/Frame.cc:289), 1000 ORB feat/frame, 20-KF local BA of monocular edges"),
+}
 
 
-def build_workload(scene, n_frames, api, views, synth, device):
+def build_workload(scene, cfg, n_frames, api, views, synth, device):
     """Run the pipeline once per distinct frame to cache the host-side views a Tracking thread would hold
     (last-frame view, local-map chunks, pose guesses).  Not timed."""
     import torch
-    from multi_orbslam3_amd import _capi as capi
     cam = scene.cam
     W, H = scene.W, scene.H
-    ex = api.ORBextractor(1000, 1.2, 8, 20, 7, W, H, n_cams=2, device=device)
+    ex = api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, W, H, n_cams=2 if cfg["stereo"] else 1, device=device)
     rng = np.random.RandomState(1234)
-    frames = []
-    imgs = []
+    frames, imgs, host_imgs = [], [], []
     for k in range(n_frames):
         L, R, Tcw = scene.stereo_pair(k)
-        dL = torch.from_numpy(L).to("cuda:%d" % device)
-        dR = torch.from_numpy(R).to("cuda:%d" % device)
-        imgs.append((dL, dR))
-        nl, nr, kl, dl = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W, download_left=True)
-        ur, dp = ex.ComputeStereoMatches(float(cam["bf"]), float(cam["b"]), n_left=nl)
-        kl, dl, ur, dp = kl.copy(), dl.copy(), ur.copy(), dp.copy()
+        host_imgs.append((L, R))
+        if cfg["stereo"]:
+            dL = torch.from_numpy(L).to("cuda:%d" % device)
+            dR = torch.from_numpy(R).to("cuda:%d" % device)
+            imgs.append((dL, dR))
+            nl, nr, kl, dl = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W, download_left=True)
+            ur, dp = ex.ComputeStereoMatches(float(cam["bf"]), float(cam["b"]), n_left=nl)
+            kl, dl, ur, dp = kl.copy(), dl.copy(), ur.copy(), dp.copy()
+        else:
+            imgs.append((None, None))
+            nm, kl, dl = ex(L, (0, 1000))
+            nl = len(kl)
+            dp = scene.depth_at(kl, Tcw)             # a mono agent's map comes from triangulation; here: scene geometry
+            ur = np.full(nl, -1.0, np.float32)
         Pw, valid = synth.unproject_to_world(kl, dp, Tcw, cam)
         lv, keep = views.lastframe_view(valid.astype(np.uint8), np.zeros(nl, np.uint8), Pw, dl, kl["octave"], kl["angle"],
                                         np.full(nl, 3, np.int32), Tcw.astype(np.float32))
         chunk = synth.map_from_frame(kl, dl, dp, Tcw, cam)
         frames.append(dict(Tcw=Tcw, guess=synth.perturb_pose(Tcw, rng).astype(np.float32), last_view=(lv, keep), chunk=chunk,
                            n=nl, stereo=int((ur > 0).sum())))
-    return ex, imgs, frames
+    return ex, imgs, host_imgs, frames
 
 
 def local_map_for(frames, k, n_kf=6):
@@ -70,22 +96,40 @@ def local_map_for(frames, k, n_kf=6):
     return {key: np.concatenate([p[key] for p in parts]) for key in parts[0]}
 
 
-def cpu_baseline(scene, synth, views, n_frames=300, n_distinct=16):
-    """The CPU oracle (a restatement of the reference path) on a bounded sample of the same workload, with the reference's
-    threading: left / right extraction on two threads (S/Frame.cc:92-95), the tracking steps on the calling thread, local
-    BA on its own thread next to tracking (S/ClientSystem.cc:105-106) -- at most 3 busy cores."""
+def host_cpu():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(nproc=os.cpu_count(), model=model, affinity_cpus=len(os.sched_getaffinity(0)))
+
+
+def cpu_baseline(scene, cfg, synth, views, n_frames):
+    """The CPU oracle (a restatement of the reference path), rebuilt -O3 -march=native for this host, on a bounded sample of
+    the same workload with the reference's threading: left / right extraction on two threads (S/Frame.cc:92-95), the
+    tracking steps on the calling thread, local BA on its own thread next to tracking (S/ClientSystem.cc:105-106) -- at
+    most 3 busy cores."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as ob
+    lib_path = ob.use_native()
     cam = scene.cam
-    exL = ob.Extractor(n_features=1000, max_width=scene.W, max_height=scene.H)
-    exR = ob.Extractor(n_features=1000, max_width=scene.W, max_height=scene.H)
+    n_distinct = 16
+    nf = cfg["n_features"]
+    exL = ob.Extractor(n_features=nf, max_width=scene.W, max_height=scene.H)
+    exR = ob.Extractor(n_features=nf, max_width=scene.W, max_height=scene.H)
     p = scene.frame_view_params()
     rng = np.random.RandomState(1234)
     imgs = [scene.stereo_pair(k) for k in range(n_distinct)]
     seq = list(range(n_distinct)) + list(range(n_distinct - 2, 0, -1))
-    prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000)
+    nfree, nfix, npts = cfg["lba"]
+    prob = synth.make_lba_problem(n_free=nfree, n_fixed=nfix, n_points=npts, width=scene.W, height=scene.H, mono_frac=cfg["mono_frac"])
     lp, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
     pool = ThreadPoolExecutor(2)
     q = queue.Queue()
@@ -106,20 +150,25 @@ def cpu_baseline(scene, synth, views, n_frames=300, n_distinct=16):
     chunks = []
     t_start = None
     done = 0
+    th_frame, mono = (7.0, False) if cfg["stereo"] else (15.0, True)
     for i in range(n_frames + 8):
         L, R, Tcw = imgs[seq[i % len(seq)]]
         if i == 8:                                        # the first frames only fill the last-frame view / local map
             t_start = time.perf_counter()
-        fl, fr = pool.submit(exL.extract, L), pool.submit(exR.extract, R)
-        rc, kl, dl, _ = fl.result()
-        rc, kr, dr, _ = fr.result()
-        ur, dp = ob.stereo_match(exL, exR, kl, dl, kr, dr, float(cam["bf"]), float(cam["b"]))
-        fv, keep1 = views.frame_view(kl, dl, ur, dp, p["bounds"], p["cam"], 8, 1.2)
+        if cfg["stereo"]:
+            fl, fr = pool.submit(exL.extract, L), pool.submit(exR.extract, R)
+            rc, kl, dl, _ = fl.result()
+            rc, kr, dr, _ = fr.result()
+            ur, dp = ob.stereo_match(exL, exR, kl, dl, kr, dr, float(cam["bf"]), float(cam["b"]))
+        else:
+            rc, kl, dl, _ = exL.extract(L, (0, 1000))
+            ur, dp = None, scene.depth_at(kl, Tcw)
+        fv, keep1 = views.frame_view(kl, dl, ur, dp if cfg["stereo"] else None, p["bounds"], p["cam"], 8, 1.2)
         n = len(kl)
         amp = np.full(n, -1, np.int32); aob = np.zeros(n, np.int32)
         guess = synth.perturb_pose(Tcw, rng).astype(np.float32)
         if last is not None and len(chunks) >= 2:
-            amp, aob, nm1 = ob.search_by_projection_frame(fv, guess, last[0], 7.0, False, True, amp, aob)
+            amp, aob, nm1 = ob.search_by_projection_frame(fv, guess, last[0], th_frame, mono, True, amp, aob)
             mp = {key: np.concatenate([c[key] for c in chunks[-6:]]) for key in chunks[0]}
             wv, keep2 = views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
             amp, aob, nm2 = ob.search_local_points(fv, wv, guess, 1.0, False, 0.0, 0.8, amp, aob)
@@ -138,10 +187,28 @@ def cpu_baseline(scene, synth, views, n_frames=300, n_distinct=16):
     wall = time.perf_counter() - t_start
     pool.shutdown()
     fps = done / wall
-    return dict(value=round(fps, 3), unit="frames/s", cores=3, kind="port",
-                sample="%d stereo frames (L/R extraction on 2 threads) + %d local BAs of %.1f ms on their own thread, %.1f s wall; "
-                       "threads as in the reference (S/Frame.cc:92-95, S/ClientSystem.cc:105-106)"
-                       % (done, len(lba_times), 1e3 * float(np.mean(lba_times)) if lba_times else 0.0, wall))
+    native = lib_path.endswith(os.path.join("_native", "liboracle.so"))
+    return dict(value=round(fps, 3), unit="frames/s", cores=3 if cfg["stereo"] else 2, kind="port",
+                build="g++ -O3 -march=native -ffp-contract=off, built on this host" if native else "g++ -O3 -msse4.2 (portable build)",
+                sample="%d frames (%s) + %d local BAs of %.1f ms on their own thread, %.1f s wall; threads as in the "
+                       "reference (S/Frame.cc:92-95, S/ClientSystem.cc:105-106)"
+                       % (done, "L/R extraction on 2 threads" if cfg["stereo"] else "mono extraction on the tracking thread",
+                          len(lba_times), 1e3 * float(np.mean(lba_times)) if lba_times else 0.0, wall))
+
+
+def copy_bandwidth_gbs(torch, device, mib=512, reps=10):
+    """Device-to-device copy of `mib` MiB (read + write counted): the second denominator SURVEY.md 8(d) asks for."""
+    a = torch.empty(mib << 20, dtype=torch.uint8, device="cuda:%d" % device)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * (mib << 20) * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -149,35 +216,43 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--frames", type=int, default=16, help="distinct synthetic stereo frames (ping-pong sequence)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
+    ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames (ping-pong sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the value_host_images / value_with_pose_opt regions")
+    ap.add_argument("--secondary-steps", type=int, default=300)
     ap.add_argument("--separate-calls", action="store_true",
                     help="call extract / ComputeStereoMatches / grid as three entry points instead of the fused "
                          "Frame-constructor entry point orbx_frame_stereo_dev")
     ap.add_argument("--pose-opt", action="store_true",
-                    help="also run Optimizer::PoseOptimization (SURVEY row f-2) after each of the two searches, as "
-                         "Tracking does; off by default so that the metric stays the one SURVEY.md 8(d) defines")
-    ap.add_argument("--profile-stages", action="store_true",
-                    help="bracket every extractor stage with HIP events (more API calls per frame); by default only "
-                         "fast_cells_kernel (the roofline kernel) is bracketed")
+                    help="also run Optimizer::PoseOptimization (SURVEY row f-2) after each of the two searches in the MAIN "
+                         "timed region; by default that accounting is reported as value_with_pose_opt")
+    ap.add_argument("--host-images", action="store_true",
+                    help="hand host images to the Frame constructor in the MAIN timed region (H2D inside); by default that "
+                         "accounting is reported as value_host_images")
+    ap.add_argument("--profile-stages", action="store_true", help="bracket every extractor stage with HIP events")
     ap.add_argument("--no-numa-pin", action="store_true",
                     help="do not restrict the process to the CPUs of the GPU's NUMA node (default: like numactl --cpunodebind)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="construct every frame synchronously before it is tracked; by default frame t+1's constructor "
                          "(orbx_frame_stereo_dev_submit on a second extractor handle) runs while frame t is tracked")
-    ap.add_argument("--lba-mode", choices=["async", "thread", "inline"], default="async",
+    ap.add_argument("--lba-mode", choices=["async", "inline"], default="async",
                     help="async: LBA runs on the library's worker thread + its own HIP stream concurrently with tracking, as the "
-                         "reference's LocalMapping thread does (S/ClientSystem.cc:105-106); thread: the same from a Python "
-                         "thread; inline: LBA blocks the frame loop")
+                         "reference's LocalMapping thread does (S/ClientSystem.cc:105-106); inline: LBA blocks the frame loop")
+    ap.add_argument("--server-tick", action="store_true",
+                    help="also time the server-side exchange (RCCL all-gather of KF wire blocks -> rebuilt KeyFrame -> "
+                         "SearchByProjection(KF, Scw, map)) for 2 and 8 KF blocks; reported under config.server_tick")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    stereo = cfg["stereo"]
 
     # The agent keeps six HIP streams busy (two extractor handles, two frames, the local map, the local BA).  The ROCm
     # runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 4, the search kernels sometimes
-    # share a queue with the local BA's chain (bimodal 4200 / 4950 frames/s run to run); with 6 every stream has its own
-    # (stable 4930-5040); 8 and 12 are slower again (4500).  Must be set before the runtime initialises.
-    # (Without the pipelined constructor the agent has three busy streams and the default of 4 is the good setting: 4600 vs
-    # 3000 frames/s with 6 or 8 -- more hardware queues than busy streams cost dispatch latency on every one of them.)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if (args.no_pipeline or args.separate_calls) else "6")
+    # share a queue with the local BA's chain; with 6 every stream has its own; 8 and 12 are slower again.  Must be set
+    # before the runtime initialises.  (Without the pipelined constructor the agent has three busy streams and the default
+    # of 4 is the good setting -- more hardware queues than busy streams cost dispatch latency on every one of them.)
+    pipeline = stereo and not (args.no_pipeline or args.separate_calls or args.host_images)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "6" if pipeline else "4")
     # Every agent keeps two threads spinning on completion words (tracking thread, local-BA worker).  If the container's CPU
     # quota cannot feed that for all ranks of this node (cgroup cpu.max), fall back to the runtime's blocking waits
     # (ORBG_NO_POLL=1: ~6-10 us more latency per wait, a fraction of a CPU per rank) instead of being throttled.
@@ -200,7 +275,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    grp = harness.AgentGroup("nccl")
+    # --server-tick on one GPU still goes through RCCL: a single-rank process group, created before any other GPU call
+    grp = harness.AgentGroup("nccl", force_group=args.server_tick)
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     device = local_rank
     torch.cuda.set_device(device)
@@ -208,23 +284,24 @@ def main():
     cpu_affinity = None if args.no_numa_pin else harness.pin_to_gpu_numa_node(device)
     core_pair = None if args.no_numa_pin else harness.core_pair_for_agent(device, local_rank)
 
-    W, H = 640, 480
+    W, H = cfg["W"], cfg["H"]
     scene = synth.Scene(W, H, seed=synth.SEED_IMAGES + rank)      # one agent per GPU, distinct seeds
     cam = scene.cam
-    ex, imgs, frames = build_workload(scene, args.frames, api, views, synth, device)
+    ex, imgs, host_imgs, frames = build_workload(scene, cfg, args.frames, api, views, synth, device)
     p = scene.frame_view_params()
     fv, fv_keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
-    F = api.Frame(4096, device)
-    pipeline = not (args.no_pipeline or args.separate_calls)
+    F = api.Frame(cfg["frame_cap"], device)
     # frame t+1 is constructed (second extractor handle, second frame object) while frame t is tracked
-    exs = [ex, api.ORBextractor(1000, 1.2, 8, 20, 7, W, H, n_cams=2, device=device)] if pipeline else [ex]
-    Fs = [F, api.Frame(4096, device)] if pipeline else [F]
+    exs = [ex, api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, W, H, n_cams=2, device=device)] if pipeline else [ex]
+    Fs = [F, api.Frame(cfg["frame_cap"], device)] if pipeline else [F]
     in_flight = [False, False]
-    LM = api.LocalMap(16384, device)
+    LM = api.LocalMap(cfg["map_cap"], device)
     m_frame = api.ORBmatcher(0.9, True, device)
     m_map = api.ORBmatcher(0.8, True, device)
     opt = api.Optimizer(device)
-    prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000, seed=synth.SEED_LBA + rank)
+    nfree, nfix, npts = cfg["lba"]
+    prob = synth.make_lba_problem(n_free=nfree, n_fixed=nfix, n_points=npts, seed=synth.SEED_LBA + rank, width=W, height=H,
+                                  mono_frac=cfg["mono_frac"])
     lp, lp_keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"], device=device)
     bf, bb = float(cam["bf"]), float(cam["b"])
     if core_pair is not None and args.lba_mode == "async":
@@ -236,7 +313,6 @@ def main():
         cpu_affinity = "%s; tracking thread on cpus %s, local-BA worker on cpus %s" % (cpu_affinity, sorted(core_pair[0]), sorted(core_pair[1]))
     nF = len(frames)
     seq = list(range(nF)) + list(range(nF - 2, 0, -1))             # ping-pong: consecutive frames stay adjacent
-    stage = dict(extract=0.0, stereo=0.0, grid=0.0, match_frame=0.0, match_map=0.0, lba=0.0, map_upload=0.0, pose_opt=0.0)
     po_prob = synth.make_pose_opt_problem(n=450, seed=77 + rank)
     po1, po1_keep = views.pose_opt_problem(po_prob["Xw"], po_prob["u"], po_prob["v"], po_prob["ur"], po_prob["inv_sigma2"],
                                           po_prob["cam"], po_prob["Tcw"], device=device)
@@ -246,56 +322,49 @@ def main():
     for e in exs:
         e.set_profiling(2 if args.profile_stages else 1)
     ev_overhead_ms = ex.event_overhead_ms(100)
+    lba_ev_overhead_ms = opt.event_overhead_ms(100)
+    opt.set_profiling(True, reset=True)
     FAST_BRACKET_EVERY = 1 if args.profile_stages else 4         # the event pair costs ~5 us of stream time: sample every 4th frame
-    kern = dict(fast_kernel_ms=0.0, octree_host_ms=0.0)
-    if args.profile_stages:
-        kern.update(pyramid_ms=0.0, fast_ms=0.0, desc_ms=0.0, stereo_ms=0.0)
-    stats = dict(kp=0, stereo=0, m_frame=0, m_map=0, lba_iters=0, lba_calls=0, lba_s=0.0)
-
-    import queue
-    import threading
-    lba_q = queue.Queue()
+    th_frame, mono_flag = (7.0, False) if stereo else (15.0, True)
 
     lba_out = views.LbaOutput(lp.n_poses, lp.n_points, lp.n_edges)      # result arrays are allocated once, like a SLAM system would
+    amp_buf = np.full(2 * cfg["frame_cap"], -1, np.int32); aob_buf = np.zeros(2 * cfg["frame_cap"], np.int32)
 
-    def lba_worker():
-        while True:
-            job = lba_q.get()
-            if job is None:
-                lba_q.task_done()
-                return
-            t0 = time.perf_counter()
-            out = opt.LocalBundleAdjustment(lp, out=lba_out)
-            dt = time.perf_counter() - t0
-            if job:
-                stats["lba_iters"] += sum(out.iters); stats["lba_calls"] += 1; stats["lba_s"] += dt
-            lba_q.task_done()
+    class Region:
+        """Accumulators of one timed region."""
+        def __init__(self, n):
+            self.stage = dict(extract=0.0, stereo=0.0, grid=0.0, match_frame=0.0, match_map=0.0, lba=0.0, map_upload=0.0, pose_opt=0.0)
+            self.kern = dict(fast_kernel_ms=0.0, octree_host_ms=0.0)
+            if args.profile_stages:
+                self.kern.update(pyramid_ms=0.0, fast_ms=0.0, desc_ms=0.0, stereo_ms=0.0)
+            self.stats = dict(kp=0, stereo=0, m_frame=0, m_map=0, lba_iters=0, lba_calls=0, lba_s=0.0)
+            self.step_s = np.zeros(max(n, 1))
+            self.async_t0 = None
+            self.async_timed = False
 
-    async_state = dict(t0=None, timed=False)
-
-    def collect_async():
-        if async_state["t0"] is None:
+    def collect_async(reg):
+        if reg.async_t0 is None:
             return
         out = opt.wait()
-        if async_state["timed"]:
-            stats["lba_iters"] += sum(out.iters); stats["lba_calls"] += 1
-            stats["lba_s"] += opt.last_solve_ms * 1e-3
-        async_state["t0"] = None
+        if reg.async_timed:
+            reg.stats["lba_iters"] += sum(out.iters); reg.stats["lba_calls"] += 1
+            reg.stats["lba_s"] += opt.last_solve_ms * 1e-3
+        reg.async_t0 = None
 
-    worker = None
-    if args.lba_mode == "thread":
-        worker = threading.Thread(target=lba_worker, daemon=True)
-        worker.start()
-
-    amp_buf = np.full(8192, -1, np.int32); aob_buf = np.zeros(8192, np.int32)
-
-    def step(i, timed):
+    def step(i, reg, timed, pose_opt, host_images, pipelined, slot=None):
         k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
         fr = frames[k]
         dL, dR = imgs[k]
         t0 = time.perf_counter()
         Fc, exc = F, ex
-        if pipeline:
+        if not stereo:
+            # mono agent: Frame::Frame(mono) = ExtractORB(0, im, 0, 1000) (S/Frame.cc:289) + grid; host image in, features out
+            nm, kl, dl = ex(host_imgs[k][0], (0, 1000))
+            nl, nr = len(kl), 0
+            t1 = t2 = time.perf_counter()
+            fvm, keepm = views.frame_view(kl, dl, None, None, p["bounds"], p["cam"], 8, 1.2)
+            F.upload(fvm, keepm)
+        elif pipelined:
             c = i & 1
             Fc, exc = Fs[c], exs[c]
             if not in_flight[c]:                          # first step only: nothing was submitted ahead
@@ -305,6 +374,10 @@ def main():
             nxt = imgs[seq[(i + 1) % len(seq)]]           # Frame::Frame(t+1) runs during the tracking of frame t
             exs[c ^ 1].frame_stereo_dev_submit(Fs[c ^ 1], fv, nxt[0].data_ptr(), nxt[1].data_ptr(), W, H, W, bf, bb)
             in_flight[c ^ 1] = True
+            t1 = t2 = time.perf_counter()
+        elif host_images:
+            # the reference's constructor takes host images (cv::Mat): the two H2D copies are inside the step
+            nl, nr = ex.frame_stereo(F, fv, host_imgs[k][0], host_imgs[k][1], bf, bb, download=False)
             t1 = t2 = time.perf_counter()
         elif args.separate_calls:
             nl, nr = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W)[:2]
@@ -319,18 +392,16 @@ def main():
         t3 = time.perf_counter()
         amp = amp_buf[:nl]; aob = aob_buf[:nl]
         amp.fill(-1); aob.fill(0)                         # F.mvpMapPoints starts empty (S/Frame.cc:113)
-        amp, aob, n1 = m_frame.SearchByProjectionFrame(Fc, fr["guess"], frames[k_last]["last_view"][0], 7.0, False, amp, aob, inplace=True)
+        amp, aob, n1 = m_frame.SearchByProjectionFrame(Fc, fr["guess"], frames[k_last]["last_view"][0], th_frame, mono_flag, amp, aob, inplace=True)
         t4 = time.perf_counter()
         amp, aob, n2 = m_map.SearchLocalPoints(Fc, LM, fr["guess"], 1.0, False, 0.0, amp, aob, None, inplace=True)
         t5 = time.perf_counter()
-        if args.pose_opt:
+        if pose_opt:
             # TrackWithMotionModel / TrackLocalMap call PoseOptimization after each search (S/Tracking.cc:2649,2712);
             # ~450 and ~650 correspondences as the two searches produce here
             opt.PoseOptimization(po1)
             opt.PoseOptimization(po2)
             tpo = time.perf_counter()
-            if timed:
-                stage["pose_opt"] += tpo - t5
         else:
             tpo = t5
         t6 = t7 = tpo
@@ -340,83 +411,126 @@ def main():
             LM.upload(wv)
             t6 = time.perf_counter()
             if args.lba_mode == "async":
-                collect_async()                        # the previous keyframe's LBA (long finished in steady state)
-                async_state["t0"], async_state["timed"] = time.perf_counter(), timed
+                collect_async(reg)                     # the previous keyframe's LBA (long finished in steady state)
+                reg.async_t0, reg.async_timed = time.perf_counter(), timed
                 opt.LocalBundleAdjustmentAsync(lp, lba_out)
                 t7 = time.perf_counter()
-            elif worker is not None:
-                lba_q.put(timed)                       # LocalMapping thread picks the keyframe up
-                t7 = t6
             else:
                 out = opt.LocalBundleAdjustment(lp, out=lba_out)
                 t7 = time.perf_counter()
                 if timed:
-                    stats["lba_iters"] += sum(out.iters); stats["lba_calls"] += 1; stats["lba_s"] += t7 - t6
+                    reg.stats["lba_iters"] += sum(out.iters); reg.stats["lba_calls"] += 1; reg.stats["lba_s"] += t7 - t6
         if timed:
+            st = reg.stage
             for key, dt in (("extract", t1 - t0), ("stereo", t2 - t1), ("grid", t3 - t2), ("match_frame", t4 - t3),
-                            ("match_map", t5 - t4), ("map_upload", t6 - tpo), ("lba", t7 - t6)):
-                stage[key] += dt
+                            ("match_map", t5 - t4), ("pose_opt", tpo - t5), ("map_upload", t6 - tpo), ("lba", t7 - t6)):
+                st[key] += dt
             if args.profile_stages:
                 tm = exc.timings()
-                for key in kern:
-                    kern[key] += tm[key]
-            stats["kp"] += nl + nr; stats["m_frame"] += n1; stats["m_map"] += n2
+                for key in reg.kern:
+                    reg.kern[key] += tm[key]
+            reg.stats["kp"] += nl + nr; reg.stats["m_frame"] += n1; reg.stats["m_map"] += n2
+            if slot is not None:
+                reg.step_s[slot] = time.perf_counter() - t0
 
     # local map must exist before the first frame
     mp0 = local_map_for(frames, 0)
     wv0, keep0 = views.worldpoints_view(mp0["pos"], mp0["normal"], mp0["min_dist"], mp0["max_dist"], mp0["desc"], mp0["n_obs"], mp0["bad"])
     LM.upload(wv0)
-    for i in range(args.warmup):
-        step(i, False)
-    lba_q.join()
-    collect_async()
 
-    def sync():
-        lba_q.join()                                   # every LBA triggered inside the timed region has finished
-        collect_async()
-        for c in range(len(exs)):                      # ... and so has the frame constructor submitted by the last step
-            if pipeline and in_flight[c]:
-                exs[c].frame_stereo_dev_wait()
-                in_flight[c] = False
-        torch.cuda.synchronize()
+    def run_region(n_steps, n_warm, pose_opt, host_images, pipelined, first_index):
+        """W untimed steps, then exactly n_steps timed ones between barrier + synchronize on both sides; MAX over ranks."""
+        reg = Region(n_steps)
+
+        def sync():
+            collect_async(reg)                         # every LBA triggered inside the timed region has finished
+            for c in range(len(exs)):                  # ... and so has the frame constructor submitted by the last step
+                if in_flight[c]:
+                    exs[c].frame_stereo_dev_wait()
+                    in_flight[c] = False
+            torch.cuda.synchronize()
+
+        for i in range(n_warm):
+            step(first_index + i, reg, False, pose_opt, host_images, pipelined)
+        collect_async(reg)
+        base = first_index + n_warm
+        elapsed = grp.timed(lambda i: step(base + i, reg, True, pose_opt, host_images, pipelined, slot=i), n_steps, sync)
+        return reg, elapsed
 
     for e in exs:
         e.set_profile_interval(max(FAST_BRACKET_EVERY // len(exs), 1), reset=True)
-    # barrier + synchronize, exactly K steps, synchronize + barrier, MAX over ranks (harness.AgentGroup.timed)
-    elapsed = grp.timed(lambda i: step(args.warmup + i, True), args.steps, sync)
-    # informational: one PoseOptimization call (not part of `value` unless --pose-opt)
+    reg, elapsed = run_region(args.steps, args.warmup, args.pose_opt, args.host_images, pipeline, 0)
+    solver_sum_ms, solver_n, solver_unknowns, solver_mfma = opt.solver_stats()
+    fast_sum, fast_n = 0.0, 0                              # bracket times accumulated inside the library over the timed region
+    for e in exs:
+        fs_, fn_ = e.fast_kernel_stats()
+        fast_sum += fs_; fast_n += fn_
+    opt.set_profiling(False, reset=False)
+    for e in exs:
+        e.set_profiling(0)
+
+    secondary = {}
+    if not args.no_secondary:
+        ns = max(min(args.secondary_steps, args.steps), 1)
+        nw = max(min(args.warmup, 40), 1)
+        if stereo and not args.host_images:
+            r2, e2 = run_region(ns, nw, False, True, False, 10000)
+            secondary["value_host_images"] = round(world * ns / e2, 3)
+            secondary["value_host_images_note"] = ("orbx_frame_stereo: pageable host images handed to the Frame constructor (two H2D "
+                                                   "copies inside the step, synchronous constructor), %d timed steps" % ns)
+        if not args.pose_opt:
+            r3, e3 = run_region(ns, nw, True, args.host_images, pipeline, 20000)
+            secondary["value_with_pose_opt"] = round(world * ns / e3, 3)
+            secondary["value_with_pose_opt_note"] = ("the two PoseOptimization calls of Tracking per frame inside the step "
+                                                     "(S/Tracking.cc:2649,2712; 450 / 650 correspondences), %d timed steps" % ns)
+
+    # informational: one PoseOptimization call
     for _ in range(5):
         opt.PoseOptimization(po1)
     t0 = time.perf_counter()
     for _ in range(20):
         opt.PoseOptimization(po1)
     pose_opt_ms = 1e3 * (time.perf_counter() - t0) / 20
+
+    server_tick = None
+    if args.server_tick:
+        server_tick = run_server_tick(grp, api, views, torch, device, frames, fv, LM, scene)
+
+    copy_gbs = copy_bandwidth_gbs(torch, device) if rank == 0 else None
+
     if rank == 0:
         K = args.steps
+        stage, kern, stats = reg.stage, reg.kern, reg.stats
         ms_per_step = 1e3 * elapsed / K
-        # fast_cells_kernel is bracketed by a HIP event pair on the extractor's stream in every timed step; an EMPTY pair on
-        # that stream already measures ev_overhead_ms (event-record commands are not free), so the kernel's launch
-        # duration is the bracket minus that constant -- this is the figure that agrees with rocprofv3's kernel trace
-        fast_sum, fast_n = 0.0, 0                              # bracket times accumulated inside the library over the timed region
-        for e in exs:
-            fs_, fn_ = e.fast_kernel_stats()
-            fast_sum += fs_; fast_n += fn_
+        # fast_cells_kernel (the frame path's HBM-streaming kernel) is bracketed by a HIP event pair on the extractor's stream;
+        # an EMPTY pair on that stream already measures ev_overhead_ms, so the launch duration is the bracket minus that
         fast_ms_raw = fast_sum / max(fast_n, 1)
         fast_ms = max(fast_ms_raw - ev_overhead_ms, 1e-6)
-        fast_bytes = 2 * PYR_PIXELS_640x480 + (stats["kp"] / K) * 4.0     # both cameras' pyramid pixels + packed candidates
-        achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
-        # HBM-side traffic of the roofline kernel: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this
-        # same command, KB per launch), committed under profiles/; byte-wide loads are not the "wide coalesced" case for
-        # which gfx950 halves FETCH_SIZE, so no x2 correction is applied (calibration: profiles/README.md)
+        pyr_px = sum(int(round(W / 1.2 ** l)) * int(round(H / 1.2 ** l)) for l in range(8))   # ~ the reference's float32 level sizes
+        fast_bytes = (2 if stereo else 1) * pyr_px + (stats["kp"] / K) * 4.0
+        fast_gbs = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_n else 0.0
+        # the DOMINANT kernel of the step (top row of profiles/r2_*_kernel_stats: 8 launches per local BA): the LDL^T + solve of
+        # the reduced camera system on the FP64 matrix cores.  Algorithmic FLOPs n^3/3 + 2 n^2 (SURVEY.md 8d: dense LDL^T),
+        # duration from a HIP event pair on the local BA's stream (one bracketed launch per solve) minus the empty-pair cost
+        n_unk = solver_unknowns
+        ldlt_flops = n_unk ** 3 / 3.0 + 2.0 * n_unk ** 2
+        ldlt_ms_raw = solver_sum_ms / max(solver_n, 1)
+        ldlt_ms = max(ldlt_ms_raw - lba_ev_overhead_ms, 1e-6)
+        ldlt_tflops = ldlt_flops / (ldlt_ms * 1e-3) / 1e12 if solver_n else 0.0
+        # HBM-side traffic of that kernel: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this same
+        # command, KB per launch), committed under profiles/ (newest round)
         traffic, traffic_src = None, None
         try:
             import glob
-            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_per_kernel.json")))[-1]   # newest round
-            pm = json.load(open(pj))["fast_cells_kernel"]
-            traffic = int(1024 * (pm["FETCH_SIZE_KB_avg"] + pm["WRITE_SIZE_KB_avg"]))
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_per_kernel.json")))[-1]
+            pm = json.load(open(pj))
+            key = [k2 for k2 in pm if "k_ldlt" in k2][0]
+            traffic = int(1024 * (pm[key]["FETCH_SIZE_KB_avg"] + pm[key]["WRITE_SIZE_KB_avg"]))
             traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)" % os.path.basename(pj)
         except Exception:
             pass
+        step_ms = 1e3 * reg.step_s
+        total_bytes_per_step = fast_bytes * 6.8 + 3.9e6 * (stats["lba_iters"] / max(stats["lba_calls"], 1)) / FRAMES_PER_KF   # SURVEY 8(d)
         line = {
             "metric": "tracking+localBA frames/sec (aggregate over agents; 1 agent per GPU)",
             "value": round(world * K / elapsed, 3),
@@ -426,15 +540,17 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (ORB front-end, Hamming), f64 (local BA)",
             "data": "synthetic",
-            "config": {"workload": "C2: 1 client stereo 640x480 synthetic, 1000 ORB feat/frame, 20-KF local BA window "
-                                   "(20 free + 10 fixed KFs, 2000 points), 1 LBA per %d frames" % FRAMES_PER_KF,
+            "timed_region_s": round(elapsed, 4),
+            "step_ms_p50": round(float(np.percentile(step_ms, 50)), 4), "step_ms_p95": round(float(np.percentile(step_ms, 95)), 4),
+            "step_ms_max": round(float(step_ms.max()), 4),
+            "config": {"workload": cfg["label"] + ", 1 LBA per %d frames" % FRAMES_PER_KF, "name": args.config,
                        "per_agent_fps": round(K / elapsed, 3), "frames_per_keyframe": FRAMES_PER_KF,
                        "stage_ms_per_frame": {k2: round(1e3 * v / K, 4) for k2, v in stage.items()},
                        "device_ms_per_frame": dict({k2: round(v / K, 4) for k2, v in kern.items()}, fast_kernel_ms=round(fast_ms_raw, 4)),
-                       "avg_keypoints_per_stereo_frame": round(stats["kp"] / K, 1),
+                       "avg_keypoints_per_frame": round(stats["kp"] / K, 1),
                        "avg_matches_frame": round(stats["m_frame"] / K, 1), "avg_matches_map": round(stats["m_map"] / K, 1),
-                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt), "cpu_affinity": cpu_affinity,
-                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
+                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt), "host_images_in_step": bool(args.host_images or not stereo),
+                       "cpu_affinity": cpu_affinity, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
                        "frame_ctor": ("pipelined: Frame(t+1) is submitted on a second extractor handle before frame t is tracked and "
                                       "collected at the start of step t+1; the constructor left in flight by the last timed step is "
                                       "waited for inside the timed region") if pipeline else "synchronous",
@@ -442,19 +558,98 @@ def main():
                        "lba_ms_per_call": round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3),
                        "sequential_fps_formula": round(1.0 / (sum(v for k2, v in stage.items() if k2 != "lba") / K +
                                                              stats["lba_s"] / max(stats["lba_calls"], 1) / FRAMES_PER_KF), 3),
-                       "lba_lm_iterations_per_call": round(stats["lba_iters"] / max(stats["lba_calls"], 1), 2)},
-            "roofline": {"kernel": "fast_cells_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(fast_bytes), "avg_launch_ms": round(fast_ms, 5),
-                         "avg_launch_ms_event_bracket_raw": round(fast_ms_raw, 5), "event_pair_overhead_ms": round(ev_overhead_ms, 5),
-                         "bracketed_launches": int(fast_n), "bracket_every_nth_frame": FAST_BRACKET_EVERY,
-                         "note": "per-frame work is a few MB: the path is launch/latency bound, not bandwidth bound (SURVEY.md 0-10)"},
+                       "lba_lm_iterations_per_call": round(stats["lba_iters"] / max(stats["lba_calls"], 1), 2),
+                       "whole_step_hbm": {"algorithmic_bytes_per_step": int(total_bytes_per_step),
+                                          "achieved_GBps": round(total_bytes_per_step / (ms_per_step * 1e-3) / 1e9, 2),
+                                          "frac_of_hbm_peak": round(total_bytes_per_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                          "note": "SURVEY.md 8(d): 6.5 MB per image + 3.9 MB per LM step; the step is launch / latency bound"},
+                       "frame_path_kernel": {"kernel": "fast_cells_kernel", "bound": "hbm", "achieved_GBps": round(fast_gbs, 2),
+                                             "frac_of_hbm_peak": round(fast_gbs / HBM_PEAK_GBS, 5), "avg_launch_ms": round(fast_ms, 5),
+                                             "event_pair_overhead_ms": round(ev_overhead_ms, 5), "bracketed_launches": int(fast_n)},
+                       "device_copy_GBps_measured": round(copy_gbs, 1), "host_cpu": host_cpu()},
+            "roofline": {"kernel": ("ldltm::k_ldlt_cols" if n_unk <= 124 else "ldltm::k_ldlt_mfma") if solver_mfma else "k_ldlt_flow / k_ldlt_rows",
+                         "bound": "mfma", "achieved": round(ldlt_tflops, 6), "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ldlt_tflops / FP64_MATRIX_PEAK_TFLOPS, 8), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_flops_per_launch": int(ldlt_flops), "unknowns": int(n_unk), "launches_per_local_ba": round(stats["lba_iters"] / max(stats["lba_calls"], 1), 2),
+                         "avg_launch_ms": round(ldlt_ms, 5), "avg_launch_ms_event_bracket_raw": round(ldlt_ms_raw, 5),
+                         "event_pair_overhead_ms": round(lba_ev_overhead_ms, 5), "bracketed_launches": int(solver_n),
+                         "peak_source": "AMD MI355X spec sheet, FP64 matrix 78.6 TF (MI355X_MICROARCH.md has no FP64 row); measured issue rate "
+                                        "of v_mfma_f64_16x16x4_f64: 1 per 66 cycles per SIMD = 76 TF at 2.4 GHz (tools/micro/mfma_f64_latency.hip)",
+                         "note": "a 120 x 120 LDL^T + solve is 0.6 MFLOP on a dependent chain of 120 pivots (one workgroup): "
+                                 "time-to-solution is the figure of merit, the FLOP fraction is reported as the contract asks"},
         }
+        line.update(secondary)
+        if server_tick is not None:
+            line["config"]["server_tick"] = server_tick
         if not args.no_cpu_baseline:
             os.sched_setaffinity(0, affinity_at_start)     # the CPU baseline's three threads get the whole machine again
-            line["cpu_baseline"] = cpu_baseline(scene, synth, views)
+            n_base = 300 if args.config != "C4" else 60
+            line["cpu_baseline"] = cpu_baseline(scene, cfg, synth, views, n_base)
+            line["cpu_baseline"]["host_cpu"] = host_cpu()
         print(json.dumps(line))
     grp.close()
+
+
+def run_server_tick(grp, api, views, torch, device, frames, fv, LM, scene, reps=50):
+    """Server tick of configs[2]/[4] (S/Communicator.cc:124-146 hand-over, S/LoopClosing.cc:657,769,795 matching): every
+    agent contributes KeyFrame wire blocks (R/msg/KF.msg:29-31) over RCCL, the server rebuilds each KeyFrame on the device
+    (orbk_frame_from_wire) and runs SearchByProjection(KF, Scw, map points).  With fewer ranks than blocks, every rank
+    contributes several keyframes (one all-gather per keyframe round)."""
+    from multi_orbslam3_amd import _capi as capi
+    import ctypes as C
+    p = scene.frame_view_params()
+    kfs = []
+    for k in (3, 8, 11, 14):
+        fr = frames[k % len(frames)]
+        src = fr["last_view"]
+        kfs.append(fr)
+    # wire blocks of this rank's keyframes, device resident
+    blocks = []
+    Ftmp = api.Frame(8192, device)
+    lib = capi.load()
+    for fr in kfs:
+        ch = fr["chunk"]
+        n = len(ch["src_idx"])
+        kps = np.zeros(n, capi.KEYPOINT_DTYPE)
+        kps["x"] = 100.0 + (np.arange(n) % 400); kps["y"] = 80.0 + (np.arange(n) // 400) * 7.0
+        kps["size"] = 31.0; kps["angle"] = 0.0; kps["response"] = 20.0; kps["octave"] = 0
+        fvk, keepk = views.frame_view(kps, ch["desc"], None, None, p["bounds"], p["cam"], 8, 1.2)
+        Ftmp.upload(fvk, keepk)
+        w = torch.zeros(47 * n, dtype=torch.uint8, device="cuda:%d" % device)
+        Ftmp.pack_wire(device_ptr=w.data_ptr())
+        blocks.append((n, w))
+    torch.cuda.synchronize()
+    m = api.ORBmatcher(0.75, True, device)
+    K = api.Frame(8192, device)
+    out = {}
+    for n_blocks in (2, 8):
+        rounds = max((n_blocks + grp.world - 1) // grp.world, 1)
+        free = np.full(8192, -1, np.int32)
+
+        def tick():
+            done = 0
+            for r in range(rounds):
+                n, w = blocks[r % len(blocks)]
+                got = grp.all_gather_keyframes(w, n)
+                for (nr, blk) in got:
+                    if done >= n_blocks:
+                        break
+                    K.from_wire(fv, n=nr, device_ptr=blk.data_ptr())
+                    m.SearchByProjectionSim3(K, kfs[r % len(kfs)]["Tcw"].astype(np.float32), LM, free[:nr], 4, 1.5)
+                    done += 1
+            return done
+        for _ in range(5):
+            tick()
+        torch.cuda.synchronize(); grp.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            done = tick()
+        torch.cuda.synchronize(); grp.barrier()
+        dt = grp.max_over_ranks(time.perf_counter() - t0)
+        out["%d_kf_blocks_us" % n_blocks] = round(1e6 * dt / reps, 1)
+    out["note"] = ("per tick: RCCL all-gather of the KeyFrame wire blocks (47 B/feature, backend nccl, %d rank%s) + "
+                   "orbk_frame_from_wire + SearchByProjection(KF, Scw, map points) per block" % (grp.world, "" if grp.world == 1 else "s"))
+    return out
 
 
 if __name__ == "__main__":

@@ -409,6 +409,13 @@ int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile int32_t* sto
  * one solve in flight per handle (a second lba_solve_async before lba_wait returns ORBG_BAD_ARG). */
 int lba_solve_async(lba_handle* h, const lba_problem* problem, const volatile int32_t* stop_flag, lba_result* result);
 int lba_wait(lba_handle* h, double* solve_ms /* wall time of that solve on the worker, may be NULL */);
+/* Measurement hooks (bench.py roofline): with profiling on, one launch per solve of the reduced-camera-system LDL^T
+ * (G/solvers/linear_solver_eigen.h:94-124 behind G/core/block_solver.hpp:447) is bracketed by a HIP event pair on the
+ * handle's stream; the stats are the summed bracket time, the number of brackets, the unknowns of the last system
+ * (6 x free poses) and whether the FP64 matrix-core kernel solved it.  lba_event_overhead: cost of an empty pair. */
+int lba_set_profiling(lba_handle* h, int on, int reset);
+int lba_get_solver_stats(lba_handle* h, double* sum_ms, int64_t* n_brackets, int32_t* n_unknowns, int32_t* matrix_core);
+int lba_event_overhead(lba_handle* h, int reps, float* ms);
 
 /* ---------------------------------------------------------------- pose-only optimisation */
 

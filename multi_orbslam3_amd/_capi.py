@@ -123,6 +123,7 @@ EXPORTED_SYMBOLS = [
     "orbm_distinctive_descriptors", "orbv_score_l1", "orbk_wire_bytes", "orbk_pack_frame", "orbk_frame_from_wire",
     "orbm_frame_download",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "lba_solve_async", "lba_wait", "pose_optimize",
+    "lba_set_profiling", "lba_get_solver_stats", "lba_event_overhead",
     "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_event_overhead", "orbx_set_profile_interval", "orbx_get_fast_kernel_stats", "orbx_set_profiling",
 ]
 

@@ -515,6 +515,21 @@ class Optimizer:
         capi.check(self.lib.lba_solve_async(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_async")
         self._async_keep = (problem, out, pbStopFlag)      # only once the library has accepted the job
 
+    def set_profiling(self, on=True, reset=True):
+        """Bracket one LDL^T launch per solve with a HIP event pair on the handle's stream (bench.py roofline)."""
+        capi.check(self.lib.lba_set_profiling(self.h, int(bool(on)), int(bool(reset))), "lba_set_profiling")
+
+    def solver_stats(self):
+        """(sum of bracket times in ms, brackets, unknowns of the system, solved on the FP64 matrix cores?)"""
+        s, n, nu, mc = C.c_double(0.0), C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        capi.check(self.lib.lba_get_solver_stats(self.h, C.byref(s), C.byref(n), C.byref(nu), C.byref(mc)), "lba_get_solver_stats")
+        return s.value, n.value, nu.value, bool(mc.value)
+
+    def event_overhead_ms(self, reps=100):
+        ms = C.c_float(0.0)
+        capi.check(self.lib.lba_event_overhead(self.h, int(reps), C.byref(ms)), "lba_event_overhead")
+        return ms.value
+
     def wait(self):
         ms = C.c_double(0.0)
         capi.check(self.lib.lba_wait(self.h, C.byref(ms)), "lba_wait")

@@ -1621,6 +1621,10 @@ struct lba_handle {
   StreamSignal sig;              // completion word behind k_export (polled instead of hipStreamSynchronize)
   std::vector<int> s_pose_deg, s_point_deg, s_pose_col, s_point_col, s_pf_deg, s_f1, s_f2, s_f3, s_fill, s_row_off;   // host scratch kept across calls
   float last_ms = 0;
+  // live measurement of the dominant kernel (the LDL^T launch): one HIP event pair per solve on the handle's stream
+  int prof_on = 0;
+  hipEvent_t prof_ev[2] = {nullptr, nullptr};
+  double prof_sum_ms = 0; long long prof_n = 0; int prof_n_unknowns = 0;
   // lba_solve_async: the library-owned "LocalMapping" thread of this handle
   std::thread worker;
   std::mutex mu;
@@ -1665,6 +1669,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   h->d_pose_col.release(); h->d_point_col.release(); h->d_pt_start.release(); h->d_pt_edges.release(); h->d_ps_start.release();
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
   h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release(); h->d_scale_partial.release(); h->d_ticket.release(); h->sig.release();
+  for (auto& e : h->prof_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ORBG_OK;
@@ -2013,11 +2018,14 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int exp_version = -1, exp_buf = -1;   // k_export of the trial state already in flight (completion word posted)
 
   int solve_version = -1;          // Schur complement + LDL^T of the NEXT trial already launched (speculatively) at this trial number
+  bool prof_pending = false;       // an event pair brackets one LDL^T launch of this call
   auto launch_solve = [&](int set_, double lam_, const double* lamp_) -> int {
     if (nP > 0) {
       hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                          EBs[set_], Hlls[set_], bls[set_], Hpps[set_], bps[set_], lam_, h->d_S.p, h->d_bs.p, lamp_, item_cap,
                          dev_items ? h->d_pair_count.p : (const int*)nullptr, use_mfma ? h->d_St.p : (double*)nullptr);
+      const bool bracket = h->prof_on && !prof_pending;
+      if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
       if (use_mfma) {
         ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
       } else if (use_flow) {
@@ -2040,6 +2048,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       }
       else
         hipLaunchKernelGGL(k_ldlt, dim3(1), dim3(1024), lds_need, st, n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_lds ? 1 : 0);
+      if (bracket) { ORBG_HIP(hipEventRecord(h->prof_ev[1], st)); prof_pending = true; }
     } else {
       ORBG_HIP(hipMemsetAsync(h->d_ok.p, 0xFF, sizeof(int), st));   // nothing to solve: ok
     }
@@ -2301,6 +2310,10 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     if ((rc = h->sig.sync(st))) return rc;
   }
   const double t_e = now_s();
+  if (prof_pending) {                                   // the stream is idle here: both events have completed
+    float ems = 0;
+    if (hipEventElapsedTime(&ems, h->prof_ev[0], h->prof_ev[1]) == hipSuccess) { h->prof_sum_ms += ems; h->prof_n++; h->prof_n_unknowns = n; }
+  }
   const PoseQ* rposes = reinterpret_cast<const PoseQ*>(h->dl_h.h + d_poses_o);
   const double* rpoints = reinterpret_cast<const double*>(h->dl_h.h + d_points_o);
   const uint8_t* rflags = h->dl_h.h + d_flags_o;
@@ -2326,6 +2339,46 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     const double t_f = now_s();
     tr.t[0] += t_b - t_a; tr.t[1] += t_c - t_b; tr.t[2] += t_d - t_c; tr.t[3] += t_e - t_d; tr.t[4] += t_f - t_e; tr.t[5] += t_s1 - t_a; tr.t[6] += t_s2 - t_s1; tr.t[7] += t_s3b - t_s2b; tr.n++;
   }
+  return ORBG_OK;
+}
+
+// Live measurement for bench.py's roofline: with profiling on, ONE launch of the reduced-camera-system LDL^T per solve is
+// bracketed by a HIP event pair on the handle's stream.  lba_get_solver_stats returns the accumulated bracket time, the
+// number of brackets, the size of the system and which kernel ran; lba_event_overhead measures an empty pair.
+extern "C" int lba_set_profiling(lba_handle* h, int on, int reset) {
+  if (!h) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  if (on && !h->prof_ev[0]) { ORBG_HIP(hipEventCreate(&h->prof_ev[0])); ORBG_HIP(hipEventCreate(&h->prof_ev[1])); }
+  h->prof_on = on;
+  if (reset) { h->prof_sum_ms = 0; h->prof_n = 0; }
+  return ORBG_OK;
+}
+
+extern "C" int lba_get_solver_stats(lba_handle* h, double* sum_ms, int64_t* n_brackets, int32_t* n_unknowns, int32_t* matrix_core) {
+  if (!h || !sum_ms || !n_brackets) return ORBG_BAD_ARG;
+  *sum_ms = h->prof_sum_ms; *n_brackets = h->prof_n;
+  if (n_unknowns) *n_unknowns = h->prof_n_unknowns;
+  if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !getenv("ORBG_LDLT_VALU");
+  return ORBG_OK;
+}
+
+extern "C" int lba_event_overhead(lba_handle* h, int reps, float* ms) {
+  if (!h || !ms || reps < 1) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  if ((rc = lba_set_profiling(h, h->prof_on, 0))) return rc;
+  if (!h->prof_ev[0]) { ORBG_HIP(hipEventCreate(&h->prof_ev[0])); ORBG_HIP(hipEventCreate(&h->prof_ev[1])); }
+  double acc = 0;
+  for (int i = 0; i < reps; i++) {
+    ORBG_HIP(hipEventRecord(h->prof_ev[0], h->stream));
+    ORBG_HIP(hipEventRecord(h->prof_ev[1], h->stream));
+    ORBG_HIP(hipStreamSynchronize(h->stream));
+    float e = 0;
+    ORBG_HIP(hipEventElapsedTime(&e, h->prof_ev[0], h->prof_ev[1]));
+    acc += e;
+  }
+  *ms = (float)(acc / reps);
   return ORBG_OK;
 }
 

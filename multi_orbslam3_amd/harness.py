@@ -81,13 +81,15 @@ def core_pair_for_agent(device_index, slot):
 
 
 class AgentGroup:
-    def __init__(self, backend=None, device_index=None):
+    def __init__(self, backend=None, device_index=None, force_group=False):
+        """force_group: create the process group even for a single rank (exercises the RCCL path of
+        all_gather_keyframes on one GPU; must then be constructed before any other GPU call of the process)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.backend = backend
-        if self.world > 1:
+        if self.world > 1 or force_group:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

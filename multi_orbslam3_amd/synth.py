@@ -106,6 +106,18 @@ class Scene:
         Tr[0, 3] -= float(self.cam["b"])     # x_right = x_left - b
         return self._render(Tl), self._render(Tr), Tl
 
+    def depth_at(self, kps, Tcw):
+        """Camera-frame depth of the plane z = 0 along the ray of every keypoint (mono agents have no stereo depth:
+        the benchmark's last-frame / map views are seeded from the scene geometry instead)."""
+        c = self.cam
+        d = np.stack([(kps["x"].astype(np.float64) - float(c["cx"])) / float(c["fx"]),
+                      (kps["y"].astype(np.float64) - float(c["cy"])) / float(c["fy"]), np.ones(len(kps))], axis=1)
+        R, t = Tcw[:3, :3], Tcw[:3, 3]
+        Ow = -R.T @ t
+        dw = d @ R                                  # R^T d per row
+        z = -Ow[2] / dw[:, 2]                       # Ow + z * dw hits world z = 0
+        return np.where(np.isfinite(z) & (z > 0), z, -1.0).astype(np.float32)
+
     def frame_view_params(self):
         c = self.cam
         return dict(bounds=(0.0, float(self.W), 0.0, float(self.H)),

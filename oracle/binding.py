@@ -28,10 +28,25 @@ def build(force=False):
     return LIB_PATH
 
 
+def use_native():
+    """Rebuild the oracle with -march=native for THIS host (bench.py's cpu_baseline on the GPU box) and use that build.
+    Must be called before the first oracle call of the process; falls back to the portable build if the compiler fails."""
+    global LIB_PATH, _lib
+    if _lib is not None:
+        return LIB_PATH
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "_native/liboracle.so"])
+        LIB_PATH = os.path.join(_HERE, "_native", "liboracle.so")
+    except (subprocess.CalledProcessError, OSError):
+        pass
+    return LIB_PATH
+
+
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not LIB_PATH.endswith(os.path.join("_native", "liboracle.so")):
+            build()
         _lib = C.CDLL(LIB_PATH)
         _lib.oracle_fast_atan2.restype = C.c_float
         _lib.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
