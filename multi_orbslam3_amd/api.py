@@ -507,13 +507,13 @@ class Optimizer:
 
     def LocalBundleAdjustmentAsync(self, problem, out, pbStopFlag=None):
         """Submit the solve to the handle's own LocalMapping thread (lba_solve_async); collect with wait()."""
-        if getattr(self, "_async_keep", None) is not None:
-            # a solve is in flight: its problem / result arrays must stay referenced until wait()
-            raise RuntimeError("LocalBundleAdjustmentAsync: the previous solve has not been collected with wait()")
-        out.c.trace_len = 0
+        # a refused submission (one solve in flight per handle -> ORBG_BAD_ARG) must not drop the references that keep the
+        # in-flight problem / result arrays alive: they are replaced only once the library has accepted the new job
         sp = None if pbStopFlag is None else C.c_void_p(pbStopFlag.ctypes.data)
+        if getattr(self, "_async_keep", None) is None:
+            out.c.trace_len = 0
         capi.check(self.lib.lba_solve_async(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_async")
-        self._async_keep = (problem, out, pbStopFlag)      # only once the library has accepted the job
+        self._async_keep = (problem, out, pbStopFlag)
 
     def set_profiling(self, on=True, reset=True):
         """Bracket one LDL^T launch per solve with a HIP event pair on the handle's stream (bench.py roofline)."""
