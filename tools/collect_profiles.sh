@@ -1,23 +1,39 @@
 #!/bin/bash
 # Collects the evidence files of a build on the GPU box: rocprofv3 kernel stats (inline LBA so that every kernel is in one
-# trace), the two PMC passes, and the bench lines.  Usage (on the box): bash tools/collect_profiles.sh <tag>   e.g. r1_o
+# trace), the PMC passes (FETCH_SIZE / WRITE_SIZE for HBM traffic, the FP64-MFMA counters for the matrix-core LDL^T; one
+# rocprofv3 run per counter group, no trace domains) and the bench lines.
+# Usage (on the box): bash tools/collect_profiles.sh <tag>   e.g. r2_a
 # Results land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
 TAG=${1:-rX}
-OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"
+R="$GRAFT_REPO_ROOT"
+OUT="$R/gpurun_out/$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --lba-mode inline --no-pipeline > $OUT/stats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_async -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_async.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --lba-mode inline --no-pipeline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --lba-mode inline --no-pipeline > $OUT/pmc_write.log 2>&1
-cd "$GRAFT_REPO_ROOT"
-python3 bench.py --steps 400 --warmup 40 2>/dev/null | tail -1 > $OUT/bench_line_async_pipelined.json
-python3 bench.py --steps 400 --warmup 40 --no-pipeline --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_line_async_sync_ctor.json
-python3 bench.py --steps 400 --warmup 40 --lba-mode inline --no-pipeline --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_line_inline.json
-python3 bench.py --steps 400 --warmup 40 --pose-opt --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_line_async_poseopt.json
-python3 tools/lba_gaps.py $OUT/stats/run_kernel_trace.csv > $OUT/lba_gaps.txt 2>&1
-find $OUT -name "*_kernel_trace.csv" -size +8M -delete
-ls -la $OUT $OUT/stats | head -30
-for f in $OUT/bench_line_*.json; do python3 -c "import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], d['value'], d['config']['lba_ms_per_call'], d['config']['stage_ms_per_frame'])"; done
+INL="--steps 100 --warmup 10 --no-cpu-baseline --no-secondary --lba-mode inline --no-pipeline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$R/bench.py" $INL > "$OUT/stats.log" 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_async" -o run -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --no-secondary > "$OUT/stats_async.log" 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -o run -- python3 "$R/bench.py" --config C4 --steps 40 --warmup 5 --no-cpu-baseline --no-secondary --lba-mode inline --no-pipeline > "$OUT/stats_c4.log" 2>&1 || true
+PMC="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --lba-mode inline --no-pipeline"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_fetch.log" 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_write.log" 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_mfma.log" 2>&1 || true
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_sq" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_sq.log" 2>&1 || true
+cd "$R"
+python3 bench.py --steps 2000 --warmup 100 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_default.json" || true
+python3 bench.py --steps 400 --warmup 40 --no-pipeline --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_sync_ctor.json" || true
+python3 bench.py --steps 400 --warmup 40 --lba-mode inline --no-pipeline --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_inline.json" || true
+python3 bench.py --config C4 --steps 200 --warmup 20 --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_c4.json" || true
+python3 bench.py --config mono --steps 400 --warmup 40 --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_mono.json" || true
+python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-secondary --server-tick 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_server_tick.json" || true
+python3 tools/lba_gaps.py "$OUT/stats/run_kernel_trace.csv" > "$OUT/lba_gaps.txt" 2>&1 || true
+f=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
+if [ -n "$f" ] && [ -n "$w" ]; then python3 profiles/pmc_aggregate.py FETCH_SIZE="$f" WRITE_SIZE="$w" > "$OUT/pmc_fetch_write_per_kernel.json" || true; fi
+for grp in pmc_mfma pmc_sq; do
+  c=$(find "$OUT/$grp" -name "*counter_collection.csv" | head -1)
+  if [ -n "$c" ]; then python3 profiles/pmc_counters.py "$c" > "$OUT/${grp}_per_kernel.txt" || true; fi
+done
+find "$OUT" -name "*_kernel_trace.csv" -size +8M -delete
+find "$OUT" -name "*counter_collection.csv" -size +8M -delete
+ls -la "$OUT" | head -40

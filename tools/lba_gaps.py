@@ -9,7 +9,7 @@ for r in rows:
     nm = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
     ks.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), nm))
 ks.sort()
-lba = [k for k in ks if k[2].startswith('k_')]
+lba = [k for k in ks if k[2].startswith('k_') or k[2].startswith('ldltm::')]
 gaps = collections.defaultdict(list)
 for a, b in zip(lba, lba[1:]):
     g = (b[0] - a[1]) / 1e3
