@@ -395,7 +395,9 @@ typedef struct lba_result {
 /* void Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int&, int) numerical core,
  * S/Optimizer.cc:1917-2267 + 2321-2396 (state write-back into result).  stop_flag may be NULL;
  * it is polled between LM iterations/trials exactly where g2o polls forceStopFlag
- * (G/core/sparse_optimizer.cpp:376, G/core/optimization_algorithm_levenberg.cpp:149). */
+ * (G/core/sparse_optimizer.cpp:376, G/core/optimization_algorithm_levenberg.cpp:149).  A positive value is the
+ * reference's `true` (raised by Tracking, S/LocalMapping.cc:381-386).  A NEGATIVE value -k is a deterministic form for
+ * tests: the flag reads as raised once k Levenberg-Marquardt trials have been evaluated, whatever the timing. */
 int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
 
 /* Persistent LBA workspace variant: avoids per-call device allocation. */

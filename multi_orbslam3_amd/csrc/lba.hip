@@ -1703,7 +1703,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int rc = select_device(h->device);
   if (rc) return rc;
   const int NP = p->n_poses, NX = p->n_points, NE = p->n_edges;
-  auto terminate = [&]() { return stop_flag && *stop_flag; };
+  // > 0: stop (the reference's bool); < 0: stop once that many LM trials have been evaluated (deterministic test hook, orbgpu.h)
+  int trials_done = 0;
+  auto terminate = [&]() { if (!stop_flag) return false; const int v = *stop_flag; return v > 0 || (v < 0 && trials_done >= -v); };
   r->status = LBA_APPLIED; r->iters_round1 = r->iters_round2 = 0; r->n_outliers = 0; r->trace_len = 0;
   r->chi2_initial = r->chi2_final = 0;
   if (terminate()) {                                   // S/Optimizer.cc:2127-2129
@@ -2184,6 +2186,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           spec_ready = false;
         }
         qmax++;
+        trials_done++;
       } while (rho < 0 && qmax < 10 && !terminate());
       done++;
       r->chi2_final = currentChi;

@@ -268,7 +268,8 @@ struct Lba {
   std::vector<double> x;               // 6nP + 3nL
   double delta_mono, delta_stereo, dsqr_mono, dsqr_stereo;
   const volatile int32_t* stop;
-  bool terminate() const { return stop && *stop; }
+  int trials_done = 0;        // LM trials evaluated so far: a negative flag value -k means "stop once k trials are done" (orbgpu.h)
+  bool terminate() const { if (!stop) return false; const int v = *stop; return v > 0 || (v < 0 && trials_done >= -v); }
 
   void compute_errors() {
     for (int k = 0; k < p->n_edges; k++) {
@@ -536,6 +537,7 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
           s.points = backup_points;
         }
         qmax++;
+        s.trials_done++;
       } while (rho < 0 && qmax < 10 && !s.terminate());
       done++;
       r->chi2_final = currentChi;

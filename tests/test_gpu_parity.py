@@ -414,25 +414,99 @@ def test_lba_parity(shape):
     assert np.array_equal(g.poses, g2.poses) and np.array_equal(g.points, g2.points)
 
 
-@pytest.mark.parametrize("nf", [1, 2, 3, 7, 13, 19, 20, 21, 26])
-def test_lba_window_sizes_cover_both_ldlt_kernels(nf, monkeypatch):
-    """Free-pose counts on both sides of the dataflow LDL^T's limit (20 poses: wavefront packing with 1..13 active
-    wavefronts, odd sizes) and the barrier kernel beyond it; the barrier kernel is also forced for the small sizes."""
+@pytest.mark.parametrize("nf", [1, 2, 3, 7, 13, 19, 20, 21, 22, 26, 31, 40])
+def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
+    """Free-pose counts around every kernel boundary of the reduced-camera-system solve: the matrix-core column kernel
+    (<= 20 poses, 1..8 tile columns), the matrix-core tile kernel in its three instantiations (<= 22 / <= 34 / <= 50 poses;
+    forced for the small sizes too), and the vector-ALU kernels behind ORBG_LDLT_VALU (dataflow <= 20 poses, barrier kernel)."""
     prob = synth.make_lba_problem(n_free=nf, n_fixed=3, n_points=40 * nf + 60, mono_frac=0.2, seed=100 + nf)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
     o = ob.lba_solve(p)
-    for force_rows in ("", "1"):
-        if force_rows:
-            monkeypatch.setenv("ORBG_LDLT_ROWS", "1")
-        else:
-            monkeypatch.delenv("ORBG_LDLT_ROWS", raising=False)
+    variants = [{}, {"ORBG_LDLT_TILES": "1"}, {"ORBG_LDLT_VALU": "1"}, {"ORBG_LDLT_VALU": "1", "ORBG_LDLT_ROWS": "1"}]
+    for env in variants:
+        for key in ("ORBG_LDLT_TILES", "ORBG_LDLT_VALU", "ORBG_LDLT_ROWS"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
         g = api.Optimizer().LocalBundleAdjustment(p)
-        assert g.status == o.status and g.iters == o.iters, (nf, force_rows)
-        assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4
+        assert g.status == o.status and g.iters == o.iters, (nf, env)
+        assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4, (nf, env)
         assert np.array_equal(g.edge_outlier, o.edge_outlier)
         tg, to = g.trace_rows(), o.trace_rows()
-        assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2])
-        assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9)
+        assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]), (nf, env)
+        assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), (nf, env)
+
+
+@pytest.mark.parametrize("k_trials", [1, 2, 3, "round1", "round1+1", 100])
+def test_lba_abort_at_a_given_trial_matches_the_oracle(k_trials):
+    """*pbStopFlag raised by Tracking while the solve runs (S/LocalMapping.cc:381-386 -> G/core/optimization_algorithm_
+    levenberg.cpp:149, G/core/sparse_optimizer.cpp:376, S/Optimizer.cc:2135-2139).  The deterministic form of the flag (-k:
+    raised once k LM trials are evaluated) puts the product and the oracle at the same poll point: iteration counts, status
+    and the written-back state must agree although the product had speculative launches in flight when it saw the flag."""
+    prob = synth.make_lba_problem(n_free=8, n_fixed=3, n_points=400, mono_frac=0.1, seed=321)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    full = ob.lba_solve(p)
+    trials_round1 = int(full.trace_rows()[: full.iters[0], 2].sum())
+    k = {"round1": trials_round1, "round1+1": trials_round1 + 1}.get(k_trials, k_trials)
+    stop_o, stop_g = np.array([-k], np.int32), np.array([-k], np.int32)
+    o = ob.lba_solve(p, stop_flag=stop_o)
+    opt = api.Optimizer()
+    g = opt.LocalBundleAdjustment(p, pbStopFlag=stop_g)
+    assert g.status == o.status and g.iters == o.iters, (k, g.iters, o.iters)
+    if k < int(full.trace_rows()[:, 2].sum()):
+        assert tuple(o.iters) != tuple(full.iters)             # the flag really cut the solve short
+    assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4
+    assert np.array_equal(g.edge_outlier, o.edge_outlier) and np.array_equal(g.edge_depth_pos, o.edge_depth_pos)
+    tg, to = g.trace_rows(), o.trace_rows()
+    assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]) and np.allclose(tg[:, 1], to[:, 1], rtol=1e-9)
+    # the handle is clean afterwards: the next (uninterrupted) solve is the full one, bit for bit as on a fresh handle
+    again = opt.LocalBundleAdjustment(p)
+    fresh = api.Optimizer().LocalBundleAdjustment(p)
+    assert again.iters == fresh.iters == full.iters and np.array_equal(again.poses, fresh.poses) and np.array_equal(again.points, fresh.points)
+
+
+def test_lba_abort_from_another_thread_leaves_the_results_alone():
+    """A real asynchronous abort: Tracking raises the flag at an arbitrary moment while the library's LocalMapping thread
+    solves (speculative linearisations / solves / exports may be in flight).  After lba_wait the caller-visible arrays must be
+    final -- nothing launched on speculation may still write into them -- and the result must be one the solver can
+    legitimately return: a prefix of the uninterrupted iteration sequence."""
+    import threading
+    import time as _time
+    prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000, seed=77)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    opt = api.Optimizer()
+    full = opt.LocalBundleAdjustment(p)
+    out = views.LbaOutput(p.n_poses, p.n_points, p.n_edges)
+    seen = set()
+    for rep in range(24):
+        stop = np.zeros(1, np.int32)
+        delay = 1e-6 * (20 + 45 * rep)                         # 20 us .. 1.1 ms: before, inside and after the solve (~0.8 ms)
+
+        def raiser():
+            t_end = _time.perf_counter() + delay
+            while _time.perf_counter() < t_end:
+                pass
+            stop[0] = 1
+
+        th = threading.Thread(target=raiser)
+        opt.LocalBundleAdjustmentAsync(p, out, pbStopFlag=stop)
+        th.start()
+        got = opt.wait()
+        th.join()
+        snap = (out.poses.copy(), out.points.copy(), out.edge_outlier.copy(), out.edge_chi2.copy() if out.edge_chi2 is not None else None)
+        assert got is out and out.status in (capi.LBA_APPLIED, capi.LBA_ABORTED_BEFORE_OPT, capi.LBA_REJECTED_OUTLIERS)
+        it = tuple(out.iters)
+        seen.add(it)
+        assert it[0] <= full.iters[0] and it[1] <= full.iters[1] and (it[1] == 0 or it[0] == full.iters[0])
+        assert np.isfinite(out.poses).all() and np.isfinite(out.points).all()
+        if it == tuple(full.iters):
+            assert np.array_equal(out.poses, full.poses) and np.array_equal(out.points, full.points)
+        _time.sleep(0.003)                                     # anything still running on the device would show up now
+        assert np.array_equal(out.poses, snap[0]) and np.array_equal(out.points, snap[1]) and np.array_equal(out.edge_outlier, snap[2])
+    assert len(seen) >= 2, seen                                # the sweep hit the solve at different poll points
+    again = opt.LocalBundleAdjustment(p)
+    assert again.iters == full.iters and np.array_equal(again.poses, full.poses) and np.array_equal(again.points, full.points)
+
 
 
 @pytest.mark.parametrize("seed,noise,lam", [(10, 3.0, 0.0), (9, 3.0, 0.0), (11, 3.0, 0.0), (10, 1.0, 1e-12)])
