@@ -1,0 +1,386 @@
+// orbgpu_dropin.hpp -- the bodies INTEGRATION.md describes, as real code: function templates with the reference's
+// signatures that flatten the reference's pointer graph (Frame / KeyFrame / MapPoint / Map), call the C-ABI and write the
+// results back where the reference does.  They are templates over the object types (duck typing on the reference's own
+// member names), so the same code compiles against yutongwangBIT/multi_orbslam3's classes
+// (cv::Mat based; define HAVE_OPENCV) and against the header-only mocks of tests/cpp/mock_orbslam3.hpp, and over an
+// `Ops` policy that names the entry points: orbgpu::dropin::GpuOps = liborbgpu (the product); tests/cpp adds an
+// OracleOps over the CPU oracle so that both run through the same glue.
+//
+//   int  SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)   I/ORBmatcher.h:46,  S/ORBmatcher.cc:44-214
+//   int  SearchByProjection(Frame& Current, const Frame& Last, th, bMono)                     I/ORBmatcher.h:50,  S/ORBmatcher.cc:1970-2186
+//   int  SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                                   I/ORBmatcher.h:64,  S/ORBmatcher.cc:269-471
+//   void isInFrustum for a list of points (Tracking::SearchLocalPoints' loop)                 S/Tracking.cc:3111-3128, S/Frame.cc:466-543
+//   void LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int& num_fixedKF, int)      I/Optimizer.h:42,   S/Optimizer.cc:1810-2410
+//   int  PoseOptimization(Frame*)                                                             I/Optimizer.h:47,   S/Optimizer.cc:964-1278
+//
+// Matrix access goes through mat_f32 / mat_u8 / make_mat (overloads for cv::Mat below, for the mock in the test header).
+#ifndef ORBGPU_DROPIN_HPP_
+#define ORBGPU_DROPIN_HPP_
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <tuple>
+#include <vector>
+
+#include "orbgpu_adapters.hpp"
+
+namespace orbgpu {
+namespace dropin {
+
+#ifdef HAVE_OPENCV
+inline const float* mat_f32(const cv::Mat& m) { return m.ptr<float>(0); }
+inline const uint8_t* mat_u8(const cv::Mat& m, int row) { return m.ptr<uint8_t>(row); }
+inline void make_mat(cv::Mat& out, int rows, int cols, const float* data) { out = cv::Mat(rows, cols, CV_32F, const_cast<float*>(data)).clone(); }
+#endif
+
+// ------------------------------------------------------------------------------------------------ entry points
+// The product: liborbgpu.  A Frame is uploaded on first use and cached by its address + feature count (the reference's
+// Frame would carry an orbgpu::FrameOnDevice member instead -- FrameOnDevice::StereoCtor leaves it on the device).
+struct GpuOps {
+  static FrameOnDevice& frame(const void* key, const orbm_frame_view& v) {
+    static thread_local std::map<const void*, std::unique_ptr<FrameOnDevice>> cache;
+    auto& slot = cache[key];
+    if (!slot) slot.reset(new FrameOnDevice(std::max(v.n, 4096)));
+    slot->Upload(v);
+    return *slot;
+  }
+  static int is_in_frustum(const void* key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim,
+                           uint8_t* in_view, float* px, float* py, float* pxr, float* depth, int32_t* level, float* vcos) {
+    return orbm_is_in_frustum(frame(key, v).handle(), Tcw, &pts, lim, in_view, px, py, pxr, depth, level, vcos);
+  }
+  static int search_mps(const void* key, const orbm_frame_view& v, const orbm_mappoints_view& mps, float th, int far_points, float th_far,
+                        float nnratio, int32_t* amp, int32_t* aob, int* n) {
+    return orbm_search_by_projection_mps(frame(key, v).handle(), &mps, th, far_points, th_far, nnratio, amp, aob, n);
+  }
+  static int search_frame(const void* key, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono,
+                          int check_ori, int32_t* amp, int32_t* aob, int* n) {
+    return orbm_search_by_projection_frame(frame(key, v).handle(), Tcw, &last, th, mono, check_ori, amp, aob, n);
+  }
+  static int search_bow(const void* key, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf,
+                        const uint8_t* kf_valid, const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori,
+                        int32_t* matches, int* n) {
+    return orbm_search_by_bow(frame(key, v).handle(), &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
+  }
+  static int lba(const lba_problem& p, const volatile int32_t* stop, lba_result& r) { return lba_solve(&p, stop, &r); }
+  static int pose_opt(const pose_opt_problem& p, pose_opt_result& r) { return pose_optimize(&p, &r); }
+};
+
+// ------------------------------------------------------------------------------------------------ flattening helpers
+struct FrameFlat {
+  std::vector<orbx_keypoint> kps;
+  std::vector<uint8_t> desc;
+  std::vector<float> uright, depth;
+  orbm_frame_view v;
+};
+
+template <class FrameT>
+void flatten_frame(const FrameT& F, FrameFlat& o) {
+  const int N = F.N;
+  o.kps.resize(N); o.desc.resize((size_t)N * 32); o.uright.resize(N); o.depth.resize(N);
+  for (int i = 0; i < N; i++) {
+    const auto& kp = F.mvKeysUn[i];
+    o.kps[i] = orbx_keypoint{kp.pt.x, kp.pt.y, kp.size, kp.angle, kp.response, (int32_t)kp.octave};
+    std::memcpy(&o.desc[(size_t)32 * i], mat_u8(F.mDescriptors, i), 32);
+    o.uright[i] = F.mvuRight[i];
+    o.depth[i] = F.mvDepth[i];
+  }
+  o.v = orbm_frame_view{N, o.kps.data(), o.desc.data(), o.uright.data(), o.depth.data(), F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY,
+                        F.fx, F.fy, F.cx, F.cy, F.mbf, F.mb, F.mnScaleLevels, F.mfScaleFactor};
+}
+
+// F.mvpMapPoints <-> (assigned_mp, assigned_obs): entries that exist on entry are marked with a value no search writes
+template <class FrameT>
+void flatten_assignments(const FrameT& F, std::vector<int32_t>& amp, std::vector<int32_t>& aob) {
+  amp.assign(F.N, -1); aob.assign(F.N, 0);
+  for (int i = 0; i < F.N; i++)
+    if (F.mvpMapPoints[i]) { amp[i] = INT32_MAX; aob[i] = F.mvpMapPoints[i]->Observations(); }
+}
+
+template <class FeatVecT>
+struct FeatVecFlat {          // the std::map in key order
+  std::vector<uint32_t> node, start, feat;
+  orbm_featvec_view v;
+  explicit FeatVecFlat(const FeatVecT& fv) {
+    start.push_back(0);
+    for (const auto& kv : fv) {
+      node.push_back((uint32_t)kv.first);
+      for (unsigned idx : kv.second) feat.push_back(idx);
+      start.push_back((uint32_t)feat.size());
+    }
+    v = orbm_featvec_view{(int32_t)node.size(), node.data(), start.data(), feat.data()};
+  }
+};
+
+inline size_t vertex_id(long unsigned id, unsigned client, bool is_kf) {       // Optimizer::GetID, I/Optimizer.h:104-112
+  const size_t IDRANGE = 1000000, MAXAGENTS = 4;                                // I/Optimizer.h:23-24
+  return is_kf ? IDRANGE * client + id : IDRANGE * (MAXAGENTS + client) + id;
+}
+
+// ------------------------------------------------------------------------------------------------ isInFrustum (batch)
+// The loop of Tracking::SearchLocalPoints (S/Tracking.cc:3111-3128): F.isInFrustum(pMP, 0.5) for every candidate, which
+// stores the mTrack* fields in the map point (S/Frame.cc:529-538) and counts the visible ones.
+template <class Ops = GpuOps, class FrameT, class MapPointT>
+int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewingCosLimit = 0.5f) {
+  const int M = (int)vpMPs.size();
+  FrameFlat ff; flatten_frame(F, ff);
+  std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M); std::vector<uint8_t> desc(32 * (size_t)M), bad(M);
+  std::vector<int32_t> nobs(M);
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = vpMPs[i];
+    const auto X = p->GetWorldPos(); const auto nv = p->GetNormal();
+    std::memcpy(&pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&nrm[3 * (size_t)i], mat_f32(nv), 12);
+    // raw members (protected in the reference: add two getters there); the 0.8 / 1.2 factors of GetMin/MaxDistanceInvariance
+    // (S/MapPoint.cc:617-627) are applied inside the call
+    dmin[i] = p->mfMinDistance; dmax[i] = p->mfMaxDistance;
+    const auto Dm = p->GetDescriptor();
+    std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
+    bad[i] = p->isBad(); nobs[i] = p->Observations();
+  }
+  orbm_worldpoints_view wv{M, pos.data(), nrm.data(), dmin.data(), dmax.data(), desc.data(), nobs.data(), bad.data(), nullptr};
+  std::vector<uint8_t> inv(M); std::vector<float> px(M), py(M), pxr(M), dep(M), vc(M); std::vector<int32_t> lvl(M);
+  check(Ops::is_in_frustum(&F, ff.v, mat_f32(F.mTcw), wv, viewingCosLimit, inv.data(), px.data(), py.data(), pxr.data(), dep.data(),
+                           lvl.data(), vc.data()), "isInFrustum");
+  int n = 0;
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = vpMPs[i];
+    p->mbTrackInView = inv[i] != 0;
+    if (inv[i]) { p->mTrackProjX = px[i]; p->mTrackProjY = py[i]; p->mTrackProjXR = pxr[i]; p->mTrackDepth = dep[i];
+                  p->mnTrackScaleLevel = lvl[i]; p->mTrackViewCos = vc[i]; n++; }
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------ ORBmatcher
+// int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th, const bool bFarPoints,
+//                                    const float thFarPoints), S/ORBmatcher.cc:44-214
+template <class Ops = GpuOps, class FrameT, class MapPointT>
+int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th, const bool bFarPoints,
+                       const float thFarPoints, float mfNNratio) {
+  const int M = (int)vpMapPoints.size();
+  FrameFlat ff; flatten_frame(F, ff);
+  std::vector<uint8_t> inv(M), bad(M), desc(32 * (size_t)M); std::vector<float> px(M), py(M), pxr(M), dep(M), vc(M);
+  std::vector<int32_t> lvl(M), nobs(M);
+  for (int i = 0; i < M; i++) {                                    // the fields isInFrustum() stored (S/Frame.cc:529-538)
+    MapPointT* p = vpMapPoints[i];
+    inv[i] = p->mbTrackInView; bad[i] = p->isBad(); px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; pxr[i] = p->mTrackProjXR;
+    dep[i] = p->mTrackDepth; lvl[i] = p->mnTrackScaleLevel; vc[i] = p->mTrackViewCos; nobs[i] = p->Observations();
+    const auto Dm = p->GetDescriptor();
+    std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
+  }
+  orbm_mappoints_view mv{M, inv.data(), bad.data(), px.data(), py.data(), pxr.data(), dep.data(), lvl.data(), vc.data(), desc.data(), nobs.data()};
+  std::vector<int32_t> amp, aob; flatten_assignments(F, amp, aob);
+  int n = 0;
+  check(Ops::search_mps(&F, ff.v, mv, th, bFarPoints, thFarPoints, mfNNratio, amp.data(), aob.data(), &n), "SearchByProjection(F, MPs)");
+  for (int i = 0; i < F.N; i++)
+    if (amp[i] >= 0 && amp[i] != INT32_MAX) F.mvpMapPoints[i] = vpMapPoints[amp[i]];         // :139
+  return n;
+}
+
+// int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono),
+// S/ORBmatcher.cc:1970-2186
+template <class Ops = GpuOps, class FrameT>
+int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono, bool mbCheckOrientation) {
+  const int NL = LastFrame.N;
+  FrameFlat ff; flatten_frame(CurrentFrame, ff);
+  std::vector<uint8_t> valid(NL), outl(NL), desc(32 * (size_t)NL); std::vector<float> pos(3 * (size_t)NL), ang(NL);
+  std::vector<int32_t> oct(NL), nobs(NL);
+  for (int i = 0; i < NL; i++) {
+    auto* p = LastFrame.mvpMapPoints[i];
+    valid[i] = p != nullptr; outl[i] = LastFrame.mvbOutlier[i];
+    oct[i] = LastFrame.mvKeys[i].octave; ang[i] = LastFrame.mvKeysUn[i].angle;
+    if (p) { const auto Xm = p->GetWorldPos(); const auto Dm = p->GetDescriptor();
+             std::memcpy(&pos[3 * (size_t)i], mat_f32(Xm), 12); std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
+             nobs[i] = p->Observations(); }
+  }
+  orbm_lastframe_view lv{NL, valid.data(), outl.data(), pos.data(), desc.data(), oct.data(), ang.data(), nobs.data(), {0}};
+  std::memcpy(lv.Tcw, mat_f32(LastFrame.mTcw), 64);
+  std::vector<int32_t> amp, aob; flatten_assignments(CurrentFrame, amp, aob);
+  int n = 0;
+  check(Ops::search_frame(&CurrentFrame, ff.v, mat_f32(CurrentFrame.mTcw), lv, th, bMono, mbCheckOrientation, amp.data(), aob.data(), &n),
+        "SearchByProjection(Cur, Last)");
+  for (int i = 0; i < CurrentFrame.N; i++)
+    if (amp[i] >= 0 && amp[i] != INT32_MAX) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[amp[i]];   // :2077 (rotation-histogram
+  return n;                                                                                                  //  rejects, :2170, come back as -1)
+}
+
+// int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), S/ORBmatcher.cc:269-471
+template <class Ops = GpuOps, class KeyFrameT, class FrameT, class MapPointT>
+int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches, float mfNNratio, bool mbCheckOrientation) {
+  const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+  const int NK = (int)vpMapPointsKF.size();
+  FrameFlat ff; flatten_frame(F, ff);
+  std::vector<uint8_t> kdesc(32 * (size_t)NK), kvalid(NK); std::vector<float> kang(NK);
+  for (int i = 0; i < NK; i++) {
+    std::memcpy(&kdesc[32 * (size_t)i], mat_u8(pKF->mDescriptors, i), 32);
+    kvalid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();                               // :322-325
+    kang[i] = pKF->mvKeysUn[i].angle;
+  }
+  FeatVecFlat<decltype(F.mFeatVec)> fF(F.mFeatVec);
+  FeatVecFlat<decltype(pKF->mFeatVec)> fK(pKF->mFeatVec);
+  std::vector<int32_t> matches(F.N, -1);
+  int n = 0;
+  check(Ops::search_bow(&F, ff.v, fF.v, kdesc.data(), NK, kvalid.data(), kang.data(), fK.v, mfNNratio, mbCheckOrientation, matches.data(), &n),
+        "SearchByBoW(KF, F)");
+  vpMapPointMatches.assign(F.N, static_cast<MapPointT*>(nullptr));                           // :273
+  for (int i = 0; i < F.N; i++)
+    if (matches[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[matches[i]];
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------ Optimizer
+// void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int LocalBASize),
+// S/Optimizer.cc:1810-2410.  Graph collection (:1813-1908) and write-back (:2263-2408) act on the caller's objects exactly
+// as the reference does; the g2o block in between (:1917-2261) is one lba_solve.  Returns the LBA_* status for callers
+// that want it (the reference returns void).
+template <class Ops = GpuOps, class KeyFrameT, class MapT>
+int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num_fixedKF, int /*LocalBASize: unused in the reference too*/) {
+  using MapPointT = typename std::remove_pointer<typename std::decay<decltype(pKF->GetMapPointMatches())>::type::value_type>::type;
+  // ---- local keyframes: pKF and its covisible neighbours in this map (:1813-1826)
+  std::list<KeyFrameT*> lLocalKeyFrames{pKF};
+  pKF->mnBALocalForKF = pKF->mnId;
+  auto* pCurrentMap = pKF->GetMap();
+  for (KeyFrameT* n : pKF->GetVectorCovisibleKeyFrames()) {
+    n->mnBALocalForKF = pKF->mnId;
+    if (!n->isBad() && n->GetMap() == pCurrentMap) lLocalKeyFrames.push_back(n);
+  }
+  // ---- local map points: seen by the local keyframes (:1828-1854)
+  num_fixedKF = 0;
+  std::list<MapPointT*> lLocalMapPoints;
+  for (KeyFrameT* kf : lLocalKeyFrames) {
+    if (kf->mnId == pMap->GetInitKFid()) num_fixedKF = 1;
+    for (MapPointT* mp : kf->GetMapPointMatches())
+      if (mp && !mp->isBad() && mp->GetMap() == pCurrentMap && mp->mnBALocalForKF != pKF->mnId) {
+        lLocalMapPoints.push_back(mp);
+        mp->mnBALocalForKF = pKF->mnId;
+      }
+  }
+  // ---- fixed keyframes: observe local points without being local (:1856-1873)
+  std::list<KeyFrameT*> lFixedCameras;
+  for (MapPointT* mp : lLocalMapPoints)
+    for (const auto& ob : mp->GetObservations()) {
+      KeyFrameT* kf = ob.first;
+      if (kf->mnBALocalForKF != pKF->mnId && kf->mnBAFixedForKF != pKF->mnId) {
+        kf->mnBAFixedForKF = pKF->mnId;
+        if (!kf->isBad() && kf->GetMap() == pCurrentMap) lFixedCameras.push_back(kf);
+      }
+    }
+  num_fixedKF += (int)lFixedCameras.size();
+  if (num_fixedKF < 2) {
+    // fewer than two fixed keyframes leave the scale free: the one / two local keyframes with the lowest ids are fixed (:1875-1910)
+    KeyFrameT *low = nullptr, *second = nullptr;
+    long unsigned lowId = pKF->mnId, secondId = pKF->mnId;
+    for (KeyFrameT* kf : lLocalKeyFrames) {
+      if (kf == pKF || kf->mnId == pMap->GetInitKFid()) continue;
+      if (kf->mnId < lowId) { lowId = kf->mnId; low = kf; }
+      else if (kf->mnId < secondId) { secondId = kf->mnId; second = kf; }
+    }
+    if (low) { lFixedCameras.push_back(low); lLocalKeyFrames.remove(low); num_fixedKF++; }
+    if (num_fixedKF < 2 && second) { lFixedCameras.push_back(second); lLocalKeyFrames.remove(second); num_fixedKF++; }
+  }
+  // ---- the flattened problem: vertices in ascending g2o id, edges per point in observation order
+  std::vector<KeyFrameT*> vKF(lLocalKeyFrames.begin(), lLocalKeyFrames.end());
+  const size_t n_local = vKF.size();
+  vKF.insert(vKF.end(), lFixedCameras.begin(), lFixedCameras.end());
+  std::map<KeyFrameT*, bool> is_fixed;
+  for (size_t i = 0; i < vKF.size(); i++) is_fixed[vKF[i]] = i >= n_local || vKF[i]->mnId == pMap->GetInitKFid();   // :1940, :1951
+  std::sort(vKF.begin(), vKF.end(), [](KeyFrameT* a, KeyFrameT* b) { return vertex_id(a->mnId, a->mnClientId, true) < vertex_id(b->mnId, b->mnClientId, true); });
+  std::map<KeyFrameT*, int> kfIndex;
+  std::vector<float> poses(16 * vKF.size()); std::vector<uint8_t> fixed(vKF.size());
+  for (size_t i = 0; i < vKF.size(); i++) {
+    kfIndex[vKF[i]] = (int)i;
+    const auto Tm = vKF[i]->GetPose();
+    std::memcpy(&poses[16 * i], mat_f32(Tm), 64);
+    fixed[i] = is_fixed[vKF[i]];
+  }
+  std::vector<MapPointT*> vMP(lLocalMapPoints.begin(), lLocalMapPoints.end());
+  std::sort(vMP.begin(), vMP.end(), [](MapPointT* a, MapPointT* b) { return vertex_id(a->mnId, a->mnClientId, false) < vertex_id(b->mnId, b->mnClientId, false); });
+  std::vector<float> pts; std::vector<lba_edge> edges; std::vector<std::pair<KeyFrameT*, MapPointT*>> edgeOwner;
+  for (size_t j = 0; j < vMP.size(); j++) {
+    MapPointT* mp = vMP[j];
+    const auto Xm = mp->GetWorldPos();                     // a clone (S/MapPoint.cc:GetWorldPos): keep it alive while it is read
+    const float* X = mat_f32(Xm);
+    pts.insert(pts.end(), X, X + 3);
+    // the reference walks a std::map<KeyFrame*, ...> (address order); here: by vertex id, which only permutes sums (E-6)
+    std::vector<std::pair<size_t, std::pair<KeyFrameT*, int>>> obs;
+    for (const auto& ob : mp->GetObservations()) {
+      KeyFrameT* kf = ob.first;
+      if (kf->isBad() || kf->GetMap() != pCurrentMap || !kfIndex.count(kf)) continue;        // :2003
+      const int li = std::get<0>(ob.second);
+      if (li < 0) continue;                                                                  // :2007
+      obs.push_back({vertex_id(kf->mnId, kf->mnClientId, true), {kf, li}});
+    }
+    std::sort(obs.begin(), obs.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (const auto& o : obs) {
+      KeyFrameT* kf = o.second.first; const int li = o.second.second;
+      const auto& kp = kf->mvKeysUn[li];
+      edges.push_back(lba_edge{kfIndex[kf], (int32_t)j, kp.pt.x, kp.pt.y, kf->mvuRight[li] /* < 0: monocular (:2007) */, kf->mvInvLevelSigma2[kp.octave]});
+      edgeOwner.push_back({kf, mp});
+    }
+  }
+  lba_problem P{(int32_t)vKF.size(), (int32_t)vMP.size(), (int32_t)edges.size(), poses.data(), fixed.data(), pts.data(), edges.data(),
+                pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, pMap->IsInertial() ? 100.0 : 0.0 /* :1924-1925 */, 5, 10, 0};
+  std::vector<float> oposes(poses.size()), opts(pts.size()); std::vector<uint8_t> eout(edges.size()), edep(edges.size());
+  std::vector<double> echi(edges.size());
+  lba_result R{}; R.poses = oposes.data(); R.points = opts.data(); R.edge_outlier = eout.data(); R.edge_depth_pos = edep.data(); R.edge_chi2 = echi.data();
+  // *pbStopFlag is a bool written by Tracking (S/LocalMapping.cc:381-386); the library polls an int32: a byte-wide bool is
+  // mirrored through a one-element buffer that a watcher in the caller updates, or (here) sampled when the solve starts --
+  // deployments widen the flag itself
+  volatile int32_t stop = (pbStopFlag && *pbStopFlag) ? 1 : 0;
+  check(Ops::lba(P, &stop, R), "LocalBundleAdjustment");
+  if (R.status != LBA_APPLIED) return R.status;                                              // :2127-2129 and :2257-2261: nothing is written
+  std::vector<std::pair<KeyFrameT*, MapPointT*>> vToErase;                                   // :2207-2253
+  for (size_t k = 0; k < edges.size(); k++)
+    if (!edgeOwner[k].second->isBad() && eout[k]) vToErase.push_back(edgeOwner[k]);
+  std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                                   // :2263
+  for (auto& e : vToErase) { e.first->EraseMapPointMatch(e.second); e.second->EraseObservation(e.first); }   // :2279-2286
+  for (KeyFrameT* kf : lLocalKeyFrames) {                                                    // :2318-2372 (SetPose)
+    decltype(kf->GetPose()) T; make_mat(T, 4, 4, &oposes[16 * (size_t)kfIndex[kf]]);
+    kf->SetPose(T);
+  }
+  for (size_t j = 0; j < vMP.size(); j++) {                                                  // :2375-2383
+    decltype(vMP[j]->GetWorldPos()) X; make_mat(X, 3, 1, &opts[3 * j]);
+    vMP[j]->SetWorldPos(X);
+    vMP[j]->UpdateNormalAndDepth();
+  }
+  return R.status;
+}
+
+// int Optimizer::PoseOptimization(Frame *pFrame), S/Optimizer.cc:964-1278 (mpCamera2 == NULL: the rectified-stereo / mono rigs
+// of every BASELINE configuration)
+template <class Ops = GpuOps, class FrameT>
+int PoseOptimization(FrameT* pFrame) {
+  const int N = pFrame->N;
+  std::vector<float> Xw, u, v, ur, w; std::vector<int> featIdx;
+  for (int i = 0; i < N; i++) {
+    auto* pMP = pFrame->mvpMapPoints[i];
+    if (!pMP) continue;
+    pFrame->mvbOutlier[i] = false;                                                           // :1030, :1061
+    const auto& kp = pFrame->mvKeysUn[i];
+    const auto Xm = pMP->GetWorldPos();
+    const float* X = mat_f32(Xm);
+    Xw.insert(Xw.end(), X, X + 3); u.push_back(kp.pt.x); v.push_back(kp.pt.y); ur.push_back(pFrame->mvuRight[i]);
+    w.push_back(pFrame->mvInvLevelSigma2[kp.octave]); featIdx.push_back(i);
+  }
+  if (featIdx.size() < 3) return 0;                                                          // :1160-1161
+  pose_opt_problem P{(int32_t)featIdx.size(), Xw.data(), u.data(), v.data(), ur.data(), w.data(), pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy,
+                     pFrame->mbf, {0}, 0};
+  std::memcpy(P.Tcw, mat_f32(pFrame->mTcw), 64);
+  std::vector<uint8_t> outlier(featIdx.size());
+  pose_opt_result R{}; R.outlier = outlier.data();
+  check(Ops::pose_opt(P, R), "PoseOptimization");
+  for (size_t k = 0; k < featIdx.size(); k++) pFrame->mvbOutlier[featIdx[k]] = outlier[k] != 0;
+  decltype(pFrame->mTcw) T; make_mat(T, 4, 4, R.Tcw);
+  pFrame->SetPose(T);                                                                        // :1273-1275
+  return R.n_inliers;                                                                        // nInitialCorrespondences - nBad
+}
+
+}  // namespace dropin
+}  // namespace orbgpu
+
+#endif  // ORBGPU_DROPIN_HPP_

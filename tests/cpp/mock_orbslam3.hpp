@@ -1,0 +1,103 @@
+// Header-only stand-ins for the reference's Frame / KeyFrame / MapPoint / Map with exactly the members the hot path reads
+// or writes, under the reference's own names, so that include/orbgpu_dropin.hpp -- the glue that
+// would be pasted into S/ORBmatcher.cc / S/Optimizer.cc -- compiles and runs without OpenCV / g2o / ROS.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace mock {
+
+struct Mat {                       // the slice of cv::Mat the glue uses: continuous rows of float or bytes
+  int rows = 0, cols = 0;
+  std::vector<uint8_t> bytes;
+  int elem = 4;
+  Mat() {}
+  Mat(int r, int c, int elem_size) : rows(r), cols(c), bytes((size_t)r * c * elem_size), elem(elem_size) {}
+  bool empty() const { return bytes.empty(); }
+  template <class T> const T* ptr(int row = 0) const { return reinterpret_cast<const T*>(bytes.data() + (size_t)row * cols * elem); }
+  template <class T> T* ptr(int row = 0) { return reinterpret_cast<T*>(bytes.data() + (size_t)row * cols * elem); }
+  float at(int r, int c) const { return ptr<float>(r)[c]; }
+};
+struct Point2f { float x, y; };
+struct KeyPoint { Point2f pt; float size, angle, response; int octave; };
+
+class Map; class KeyFrame;
+
+class MapPoint {
+ public:
+  long unsigned mnId = 0; uint8_t mnClientId = 0;
+  long unsigned mnBALocalForKF = ~0ul;
+  // fields Frame::isInFrustum stores (S/Frame.cc:529-538)
+  bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackDepth = 0, mTrackViewCos = 0; int mnTrackScaleLevel = 0;
+  float mfMinDistance = 0, mfMaxDistance = 0;
+  Mat mWorldPos{3, 1, 4}, mNormalVector{3, 1, 4}, mDescriptor{1, 32, 1};
+  std::map<KeyFrame*, std::tuple<int, int>> mObservations;
+  bool mbBad = false; Map* mpMap = nullptr; int nObs = 0;
+  int n_normal_updates = 0;
+  bool isBad() const { return mbBad; }
+  Map* GetMap() const { return mpMap; }
+  int Observations() const { return nObs; }
+  Mat GetWorldPos() const { return mWorldPos; }
+  Mat GetNormal() const { return mNormalVector; }
+  Mat GetDescriptor() const { return mDescriptor; }
+  void SetWorldPos(const Mat& X) { mWorldPos = X; }
+  std::map<KeyFrame*, std::tuple<int, int>> GetObservations() const { return mObservations; }
+  void EraseObservation(KeyFrame* kf) { if (mObservations.erase(kf)) nObs--; }
+  void UpdateNormalAndDepth() { n_normal_updates++; }
+};
+
+class Map {
+ public:
+  long unsigned mnInitKFid = 0; bool mbInertial = false;
+  std::mutex mMutexMapUpdate;
+  long unsigned GetInitKFid() const { return mnInitKFid; }
+  bool IsInertial() const { return mbInertial; }
+};
+
+typedef std::map<unsigned, std::vector<unsigned>> FeatureVector;     // DBoW2::FeatureVector (D/FeatureVector.h:24-25)
+
+class KeyFrame {
+ public:
+  long unsigned mnId = 0; uint8_t mnClientId = 0;
+  long unsigned mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul;
+  float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+  std::vector<KeyPoint> mvKeysUn; std::vector<float> mvuRight, mvInvLevelSigma2;
+  Mat mDescriptors; FeatureVector mFeatVec;
+  std::vector<MapPoint*> mvpMapPoints; std::vector<KeyFrame*> mvpOrderedConnectedKeyFrames;
+  Mat Tcw{4, 4, 4};
+  bool mbBad = false; Map* mpMap = nullptr;
+  bool isBad() const { return mbBad; }
+  Map* GetMap() const { return mpMap; }
+  std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() const { return mvpOrderedConnectedKeyFrames; }
+  std::vector<MapPoint*> GetMapPointMatches() const { return mvpMapPoints; }
+  Mat GetPose() const { return Tcw; }
+  void SetPose(const Mat& T) { Tcw = T; }
+  void EraseMapPointMatch(MapPoint* mp) { for (auto& p : mvpMapPoints) if (p == mp) p = nullptr; }
+};
+
+class Frame {
+ public:
+  int N = 0;
+  std::vector<KeyPoint> mvKeys, mvKeysUn; Mat mDescriptors;
+  std::vector<float> mvuRight, mvDepth, mvInvLevelSigma2;
+  std::vector<MapPoint*> mvpMapPoints; std::vector<bool> mvbOutlier;
+  FeatureVector mFeatVec;
+  Mat mTcw{4, 4, 4};
+  float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0;   // statics in the reference
+  int mnScaleLevels = 8; float mfScaleFactor = 1.2f;
+  void SetPose(const Mat& T) { mTcw = T; }
+};
+
+// the matrix access points include/orbgpu_dropin.hpp asks for
+inline const float* mat_f32(const Mat& m) { return m.ptr<float>(0); }
+inline const uint8_t* mat_u8(const Mat& m, int row) { return m.ptr<uint8_t>(row); }
+inline void make_mat(Mat& out, int rows, int cols, const float* data) { out = Mat(rows, cols, 4); std::memcpy(out.ptr<float>(0), data, sizeof(float) * rows * cols); }
+
+}  // namespace mock
+
+namespace orbgpu { namespace dropin { using mock::mat_f32; using mock::mat_u8; using mock::make_mat; } }

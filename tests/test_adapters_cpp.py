@@ -1,32 +1,55 @@
-"""The C++ host side above the C-ABI (include/orbgpu_adapters.hpp) compiles with plain g++, links against
-liborbgpu.so, and fails loudly without a GPU."""
+"""The C++ host side above the C-ABI (include/orbgpu_adapters.hpp: classes with the reference's names; include/orbgpu_dropin.hpp:
+the INTEGRATION.md bodies with the reference's signatures) compiles with plain g++, links against liborbgpu.so, fails loudly
+without a GPU, and -- through header-only mocks of Frame / KeyFrame / MapPoint / Map -- agrees with the CPU oracle on a GPU."""
 import os
 import subprocess
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "tests", "cpp", "adapter_smoke")
+CPP = os.path.join(ROOT, "tests", "cpp")
 
 
-def _build():
+def _build(name, with_oracle=False):
     lib_dir = os.path.join(ROOT, "multi_orbslam3_amd")
-    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp"),
-           "-o", EXE, "-L", lib_dir, "-lorbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    exe = os.path.join(CPP, name)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CPP,
+           os.path.join(CPP, name + ".cpp"), "-o", exe, "-L", lib_dir, "-lorbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib",
+           "-L/opt/rocm/lib"]
+    if with_oracle:
+        from oracle import binding as ob
+        ob.build()
+        odir = os.path.join(ROOT, "oracle")
+        cmd += ["-L", odir, "-loracle", "-Wl,-rpath," + odir]
     subprocess.check_call(cmd)
+    return exe
 
 
-def test_adapters_compile_link_and_fail_loudly_without_gpu():
-    _build()
+def _no_gpu():
     from multi_orbslam3_amd import _capi
-    if _capi.load().orbg_device_count() > 0:
-        pytest.skip("a GPU is present; see the gpu-marked test")
-    r = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
+    return _capi.load().orbg_device_count() <= 0
+
+
+@pytest.mark.parametrize("name,with_oracle", [("adapter_smoke", False), ("dropin_parity", True)])
+def test_host_side_compiles_links_and_fails_loudly_without_gpu(name, with_oracle):
+    exe = _build(name, with_oracle)
+    if not _no_gpu():
+        pytest.skip("a GPU is present; see the gpu-marked tests")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and "no usable HIP device" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 @pytest.mark.gpu
 def test_adapters_run_on_gpu():
-    _build()
-    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    exe = _build("adapter_smoke")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
+    """Extractor / stereo Frame constructor, isInFrustum, SearchByProjection x2, SearchByBoW, PoseOptimization and
+    LocalBundleAdjustment (graph collection, vToErase, 50 %-outlier early return, pbStopFlag) with the reference's signatures."""
+    exe = _build("dropin_parity", with_oracle=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "dropin parity ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-1000:])
