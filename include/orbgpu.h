@@ -340,6 +340,40 @@ int orbm_distinctive_descriptors(int device, const uint8_t* desc, const int32_t*
 int orbv_score_l1(int device, const int32_t* q_word, const double* q_value, int nq, const int32_t* cand_start,
                   const int32_t* cand_word, const double* cand_value, int m, double* score);
 
+/* ---------------------------------------------------------------- place recognition database */
+
+/* What KeyFrameDatabase::DetectNBestCandidates (S/KeyFrameDatabase.cc:594-761) reads, flattened; keyframes are indices
+ * 0 .. n_kfs-1 (the caller's KeyFrame* table). */
+typedef struct orbd_database_view {
+  int32_t n_kfs, n_words;
+  const int32_t* inv_start;    /* n_words + 1: CSR over words */
+  const int32_t* inv_kf;       /* mvInvertedFile[word] (I/KeyFrameDatabase.h:82): keyframes in insertion order */
+  const int32_t* bow_start;    /* n_kfs + 1 */
+  const int32_t* bow_word;     /* pKFi->mBowVec, ascending word ids */
+  const double*  bow_value;
+  const int32_t* covis_start;  /* n_kfs + 1 */
+  const int32_t* covis_kf;     /* pKFi->GetBestCovisibilityKeyFrames(10), best first (:682) */
+  const int32_t* map_id;       /* n_kfs: pKFi->GetMap() as an id */
+  const uint8_t* bad;          /* n_kfs: pKFi->isBad() */
+  const uint8_t* map_bad;      /* n_kfs: pKFi->GetMap()->IsBad() */
+} orbd_database_view;
+typedef struct orbd_database orbd_database;
+int orbd_database_create(int device, const orbd_database_view* view, orbd_database** out);   /* uploads the view */
+int orbd_database_destroy(orbd_database* d);
+/* void KeyFrameDatabase::DetectNBestCandidates(KeyFrame* pKF, vector<KeyFrame*>& vpLoopCand, vector<KeyFrame*>& vpMergeCand,
+ *                                              int nNumCandidates), S/KeyFrameDatabase.cc:594-761, for the query keyframe's
+ * BowVector (q_word ascending / q_value), its connected keyframes (connected[n_kfs] = spConnectedKF.count, :603,618) and its
+ * map.  On the device: the inverted-file walk with the common-word counts (:605-633), the 0.8 * max filter (:638-646), the
+ * L1 scores (:652-663) and the covisibility accumulation (:673-701); the ranking (stable sort by accumulated score, :705)
+ * and the selection (:713-735) run on the host over the few scored keyframes.  place_score[n_kfs] is
+ * pKFi->mPlaceRecognitionScore, in/out: keyframes that share a word without reaching the word threshold keep the score of
+ * an earlier query, and the accumulation reads it (the reference does).  Pinned: a bad keyframe is skipped in the selection
+ * (the reference's `continue` at :718-719 does not advance its iterator and never terminates).
+ * loop_cand / merge_cand: up to n_candidates keyframe indices each. */
+int orbd_detect_n_best_candidates(orbd_database* d, const int32_t* q_word, const double* q_value, int nq, const uint8_t* connected,
+                                  int32_t query_map_id, int n_candidates, float* place_score, int32_t* loop_cand, int32_t* n_loop,
+                                  int32_t* merge_cand, int32_t* n_merge);
+
 /* ---------------------------------------------------------------- KeyFrame wire blocks */
 
 /* What a client sends per keyframe feature in orb_slam3_ros/KF (R/msg/KF.msg:29-31): CvKeyPoint {f32 x, f32 y, u8 size, f32 angle,

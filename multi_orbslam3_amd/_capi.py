@@ -97,6 +97,12 @@ class PoseOptProblem(C.Structure):
                 ("bf", C.c_float), ("Tcw", C.c_float * 16), ("device", C.c_int32)]
 
 
+class DatabaseView(C.Structure):
+    _fields_ = [("n_kfs", C.c_int32), ("n_words", C.c_int32), ("inv_start", C.c_void_p), ("inv_kf", C.c_void_p),
+                ("bow_start", C.c_void_p), ("bow_word", C.c_void_p), ("bow_value", C.c_void_p), ("covis_start", C.c_void_p),
+                ("covis_kf", C.c_void_p), ("map_id", C.c_void_p), ("bad", C.c_void_p), ("map_bad", C.c_void_p)]
+
+
 class PoseOptResult(C.Structure):
     _fields_ = [("Tcw", C.c_float * 16), ("outlier", C.c_void_p), ("n_inliers", C.c_int32), ("n_bad", C.c_int32),
                 ("iters", C.c_int32 * 4), ("chi2", C.c_double * 4)]
@@ -124,6 +130,7 @@ EXPORTED_SYMBOLS = [
     "orbm_frame_download",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "lba_solve_async", "lba_wait", "pose_optimize",
     "lba_set_profiling", "lba_get_solver_stats", "lba_event_overhead",
+    "orbd_database_create", "orbd_database_destroy", "orbd_detect_n_best_candidates",
     "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_event_overhead", "orbx_set_profile_interval", "orbx_get_fast_kernel_stats", "orbx_set_profiling",
 ]
 

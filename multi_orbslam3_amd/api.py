@@ -553,3 +553,38 @@ class Optimizer:
         sp = None if pbStopFlag is None else C.c_void_p(pbStopFlag.ctypes.data)
         capi.check(self.lib.lba_solve_h(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_h")
         return out
+
+
+class KeyFrameDatabase:
+    """Device-resident place-recognition database (inverted file, BowVectors, covisibility lists): the compute side of
+    KeyFrameDatabase::DetectNBestCandidates (S/KeyFrameDatabase.cc:594-761).  view: views.database_view(...)."""
+
+    def __init__(self, view, keep=None, device=0):
+        self.lib = capi.load()
+        self.h = C.c_void_p()
+        self._keep = keep
+        self.n_kfs = view.n_kfs
+        capi.check(self.lib.orbd_database_create(device, C.byref(view), C.byref(self.h)), "orbd_database_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orbd_database_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def DetectNBestCandidates(self, q_word, q_value, connected, query_map_id, nNumCandidates, place_score):
+        """-> (vpLoopCand, vpMergeCand) as keyframe indices; place_score (float32[n_kfs]) is updated in place."""
+        qw = np.ascontiguousarray(q_word, np.int32); qv = np.ascontiguousarray(q_value, np.float64)
+        con = np.ascontiguousarray(connected, np.uint8)
+        assert place_score.dtype == np.float32 and place_score.flags["C_CONTIGUOUS"] and len(place_score) == self.n_kfs
+        loop = np.zeros(max(nNumCandidates, 1), np.int32); merge = np.zeros(max(nNumCandidates, 1), np.int32)
+        nl, nm = C.c_int32(0), C.c_int32(0)
+        capi.check(self.lib.orbd_detect_n_best_candidates(self.h, _vp(qw), _vp(qv), len(qw), _vp(con), int(query_map_id), int(nNumCandidates),
+                                                          _vp(place_score), _vp(loop), C.byref(nl), _vp(merge), C.byref(nm)),
+                   "orbd_detect_n_best_candidates")
+        return loop[: nl.value].copy(), merge[: nm.value].copy()

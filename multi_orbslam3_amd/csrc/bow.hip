@@ -138,6 +138,87 @@ __global__ __launch_bounds__(64) void bow_score_l1_kernel(const int* __restrict_
   score[c] = -s / 2.0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// KeyFrameDatabase::DetectNBestCandidates (S/KeyFrameDatabase.cc:594-761) on the flattened database.
+// db_walk_kernel: one workgroup per query word walks mvInvertedFile[word]: common-word count per keyframe (integer atomics:
+// the result does not depend on the order) and the position of the keyframe's FIRST encounter (query word rank, list
+// position) -- the order of lKFsSharingWords, which decides ties of the final stable sort.
+__global__ __launch_bounds__(256) void db_walk_kernel(const int* __restrict__ qw, int nq, const int* __restrict__ inv_start,
+                                                     const int* __restrict__ inv_kf, int n_words, int* __restrict__ words,
+                                                     unsigned long long* __restrict__ first_key) {
+  const int r = blockIdx.x;
+  const int w = qw[r];
+  if (w < 0 || w >= n_words) return;
+  const int b0 = inv_start[w], e0 = inv_start[w + 1];
+  for (int p = b0 + threadIdx.x; p < e0; p += 256) {
+    const int kf = inv_kf[p];
+    atomicAdd(&words[kf], 1);
+    atomicMin(&first_key[kf], ((unsigned long long)r << 32) | (unsigned)(p - b0));
+  }
+}
+
+// one workgroup: maxCommonWords over the keyframes that are not connected to the query (:636-644), minCommonWords =
+// int(max * 0.8f) (:646), selection flags
+__global__ __launch_bounds__(1024) void db_select_kernel(int n_kfs, const int* __restrict__ words, const uint8_t* __restrict__ connected,
+                                                        uint8_t* __restrict__ shares, uint8_t* __restrict__ sel, int* __restrict__ out2) {
+  __shared__ int s_max[16];
+  int m = 0;
+  for (int i = threadIdx.x; i < n_kfs; i += 1024)
+    if (!connected[i] && words[i] > m) m = words[i];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  int mx = 0;
+  for (int w = 0; w < 16; w++) mx = max(mx, s_max[w]);
+  const int minw = (int)(mx * 0.8f);
+  int cnt = 0;
+  for (int i = threadIdx.x; i < n_kfs; i += 1024) {
+    const bool sh = !connected[i] && words[i] > 0;
+    const bool se = sh && words[i] > minw;
+    shares[i] = sh; sel[i] = se; cnt += se;
+  }
+  if (threadIdx.x == 0) { out2[0] = mx; out2[1] = minw; }
+}
+
+// float si = mpVoc->score(pKF->mBowVec, pKFi->mBowVec) for the selected keyframes (:652-663), the walk of bow_score_l1_kernel
+__global__ __launch_bounds__(64) void db_score_kernel(int n_kfs, const uint8_t* __restrict__ sel, const int* __restrict__ qw,
+                                                     const double* __restrict__ qv, int nq, const int* __restrict__ bstart,
+                                                     const int* __restrict__ bw, const double* __restrict__ bv, float* __restrict__ place_score) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n_kfs || !sel[c]) return;
+  int i = 0, j = bstart[c];
+  const int je = bstart[c + 1];
+  double s = 0;
+  while (i < nq && j < je) {
+    const int a = qw[i], b = bw[j];
+    if (a == b) { const double vi = qv[i], wi = bv[j]; s += fabs(vi - wi) - fabs(vi) - fabs(wi); ++i; ++j; }
+    else if (a < b) ++i;
+    else ++j;
+  }
+  place_score[c] = (float)(-s / 2.0);
+}
+
+// covisibility accumulation (:673-701): the keyframe's own score plus those of its best-covisibility neighbours that share a
+// word with the query (float sums in list order); the best-scoring keyframe of the group represents it
+__global__ __launch_bounds__(64) void db_accumulate_kernel(int n_kfs, const uint8_t* __restrict__ sel, const uint8_t* __restrict__ shares,
+                                                          const int* __restrict__ cstart, const int* __restrict__ ckf,
+                                                          const float* __restrict__ place_score, float* __restrict__ acc_out,
+                                                          int* __restrict__ best_out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n_kfs || !sel[c]) return;
+  float best = place_score[c], acc = best;
+  int bk = c;
+  for (int p = cstart[c]; p < cstart[c + 1]; p++) {
+    const int k2 = ckf[p];
+    if (!shares[k2]) continue;                        // pKF2->mnPlaceRecognitionQuery != pKF->mnId
+    const float s2 = place_score[k2];
+    acc += s2;
+    if (s2 > best) { bk = k2; best = s2; }
+  }
+  acc_out[c] = acc; best_out[c] = bk;
+}
+
 }  // namespace
 
 struct orbv_vocab {
@@ -319,5 +400,124 @@ extern "C" int orbv_score_l1(int device, const int32_t* q_word, const double* q_
   hipLaunchKernelGGL(bow_score_l1_kernel, dim3((m + 63) / 64), dim3(64), 0, 0, t.qw.p, t.qv.p, nq, t.cs.p, t.cw.p, t.cv.p, m, t.sc.p);
   ORBG_HIP(hipGetLastError());
   ORBG_HIP(hipMemcpy(score, t.sc.p, (size_t)m * 8, hipMemcpyDeviceToHost));
+  return ORBG_OK;
+}
+
+
+// ---------------------------------------------------------------- place recognition database
+struct orbd_database {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_kfs = 0, n_words = 0;
+  DevBuf<int> inv_start, inv_kf, bow_start, bow_word, covis_start, covis_kf, words, best, out2, qw;
+  DevBuf<double> bow_value, qv;
+  DevBuf<uint8_t> connected, shares, sel;
+  DevBuf<unsigned long long> first_key;
+  DevBuf<float> place_score, acc;
+  std::vector<int> map_id;
+  std::vector<uint8_t> bad, map_bad;
+  std::vector<int> h_words, h_best;
+  std::vector<unsigned long long> h_key;
+  std::vector<uint8_t> h_sel;
+  std::vector<float> h_acc;
+};
+
+extern "C" int orbd_database_create(int device, const orbd_database_view* v, orbd_database** out) {
+  if (!v || !out || v->n_kfs < 0 || v->n_words < 0) return ORBG_BAD_ARG;
+  const int K = v->n_kfs, Wn = v->n_words;
+  if ((Wn > 0 && !v->inv_start) || (K > 0 && (!v->bow_start || !v->covis_start || !v->map_id || !v->bad || !v->map_bad))) return ORBG_BAD_ARG;
+  const int n_inv = Wn > 0 ? v->inv_start[Wn] : 0, n_bow = K > 0 ? v->bow_start[K] : 0, n_cov = K > 0 ? v->covis_start[K] : 0;
+  if (n_inv < 0 || n_bow < 0 || n_cov < 0 || (n_inv > 0 && !v->inv_kf) || (n_bow > 0 && (!v->bow_word || !v->bow_value)) || (n_cov > 0 && !v->covis_kf))
+    return ORBG_BAD_ARG;
+  for (int i = 0; i < n_inv; i++) if (v->inv_kf[i] < 0 || v->inv_kf[i] >= K) return ORBG_BAD_ARG;
+  for (int i = 0; i < n_cov; i++) if (v->covis_kf[i] < 0 || v->covis_kf[i] >= K) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  orbd_database* d = new orbd_database;
+  d->device = device; d->n_kfs = K; d->n_words = Wn;
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { delete d; return ORBG_HIP_ERROR; }
+  auto up = [&](auto& buf, const auto* src, size_t n) -> int {
+    int r = buf.reserve(std::max<size_t>(n, 1));
+    if (r) return r;
+    if (n > 0) ORBG_HIP(hipMemcpyAsync(buf.p, src, n * sizeof(*src), hipMemcpyHostToDevice, d->stream));
+    return ORBG_OK;
+  };
+  if ((rc = up(d->inv_start, v->inv_start, Wn > 0 ? (size_t)Wn + 1 : 0)) || (rc = up(d->inv_kf, v->inv_kf, n_inv)) ||
+      (rc = up(d->bow_start, v->bow_start, K > 0 ? (size_t)K + 1 : 0)) || (rc = up(d->bow_word, v->bow_word, n_bow)) ||
+      (rc = up(d->bow_value, v->bow_value, n_bow)) || (rc = up(d->covis_start, v->covis_start, K > 0 ? (size_t)K + 1 : 0)) ||
+      (rc = up(d->covis_kf, v->covis_kf, n_cov)) || (rc = d->words.reserve(std::max(K, 1))) || (rc = d->best.reserve(std::max(K, 1))) ||
+      (rc = d->out2.reserve(4)) || (rc = d->connected.reserve(std::max(K, 1))) || (rc = d->shares.reserve(std::max(K, 1))) ||
+      (rc = d->sel.reserve(std::max(K, 1))) || (rc = d->first_key.reserve(std::max(K, 1))) || (rc = d->place_score.reserve(std::max(K, 1))) ||
+      (rc = d->acc.reserve(std::max(K, 1)))) {
+    orbd_database_destroy(d);
+    return rc;
+  }
+  d->map_id.assign(v->map_id, v->map_id + K); d->bad.assign(v->bad, v->bad + K); d->map_bad.assign(v->map_bad, v->map_bad + K);
+  if (hipStreamSynchronize(d->stream) != hipSuccess) { orbd_database_destroy(d); return ORBG_HIP_ERROR; }
+  *out = d;
+  return ORBG_OK;
+}
+
+extern "C" int orbd_database_destroy(orbd_database* d) {
+  if (!d) return ORBG_OK;
+  (void)hipSetDevice(d->device);
+  d->inv_start.release(); d->inv_kf.release(); d->bow_start.release(); d->bow_word.release(); d->covis_start.release(); d->covis_kf.release();
+  d->words.release(); d->best.release(); d->out2.release(); d->qw.release(); d->bow_value.release(); d->qv.release(); d->connected.release();
+  d->shares.release(); d->sel.release(); d->first_key.release(); d->place_score.release(); d->acc.release();
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+  return ORBG_OK;
+}
+
+extern "C" int orbd_detect_n_best_candidates(orbd_database* d, const int32_t* q_word, const double* q_value, int nq, const uint8_t* connected,
+                                             int32_t query_map_id, int n_candidates, float* place_score, int32_t* loop_cand, int32_t* n_loop,
+                                             int32_t* merge_cand, int32_t* n_merge) {
+  if (!d || nq < 0 || (nq > 0 && (!q_word || !q_value)) || n_candidates < 0 || !n_loop || !n_merge || (n_candidates > 0 && (!loop_cand || !merge_cand)))
+    return ORBG_BAD_ARG;
+  const int K = d->n_kfs;
+  if (K > 0 && (!connected || !place_score)) return ORBG_BAD_ARG;
+  *n_loop = 0; *n_merge = 0;
+  if (K == 0 || nq == 0) return ORBG_OK;
+  int rc = select_device(d->device);
+  if (rc) return rc;
+  hipStream_t st = d->stream;
+  if ((rc = d->qw.reserve(nq)) || (rc = d->qv.reserve(nq))) return rc;
+  ORBG_HIP(hipMemcpyAsync(d->qw.p, q_word, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(d->qv.p, q_value, (size_t)nq * 8, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(d->connected.p, connected, (size_t)K, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemcpyAsync(d->place_score.p, place_score, (size_t)K * 4, hipMemcpyHostToDevice, st));
+  ORBG_HIP(hipMemsetAsync(d->words.p, 0, (size_t)K * 4, st));
+  ORBG_HIP(hipMemsetAsync(d->first_key.p, 0xFF, (size_t)K * 8, st));
+  hipLaunchKernelGGL(db_walk_kernel, dim3(nq), dim3(256), 0, st, d->qw.p, nq, d->inv_start.p, d->inv_kf.p, d->n_words, d->words.p, d->first_key.p);
+  hipLaunchKernelGGL(db_select_kernel, dim3(1), dim3(1024), 0, st, K, d->words.p, d->connected.p, d->shares.p, d->sel.p, d->out2.p);
+  hipLaunchKernelGGL(db_score_kernel, dim3((K + 63) / 64), dim3(64), 0, st, K, d->sel.p, d->qw.p, d->qv.p, nq, d->bow_start.p, d->bow_word.p,
+                     d->bow_value.p, d->place_score.p);
+  hipLaunchKernelGGL(db_accumulate_kernel, dim3((K + 63) / 64), dim3(64), 0, st, K, d->sel.p, d->shares.p, d->covis_start.p, d->covis_kf.p,
+                     d->place_score.p, d->acc.p, d->best.p);
+  ORBG_HIP(hipGetLastError());
+  d->h_sel.resize(K); d->h_acc.resize(K); d->h_best.resize(K); d->h_key.resize(K);
+  ORBG_HIP(hipMemcpyAsync(d->h_sel.data(), d->sel.p, (size_t)K, hipMemcpyDeviceToHost, st));
+  ORBG_HIP(hipMemcpyAsync(d->h_acc.data(), d->acc.p, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+  ORBG_HIP(hipMemcpyAsync(d->h_best.data(), d->best.p, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+  ORBG_HIP(hipMemcpyAsync(d->h_key.data(), d->first_key.p, (size_t)K * 8, hipMemcpyDeviceToHost, st));
+  ORBG_HIP(hipMemcpyAsync(place_score, d->place_score.p, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+  ORBG_HIP(hipStreamSynchronize(st));
+  // lScoreAndMatch order = order of first encounter in the inverted-file walk; list::sort(compFirst) is a stable sort
+  struct Ent { unsigned long long key; float acc; int best; };
+  std::vector<Ent> ents;
+  for (int i = 0; i < K; i++)
+    if (d->h_sel[i]) ents.push_back(Ent{d->h_key[i], d->h_acc[i], d->h_best[i]});
+  std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.acc > b.acc; });
+  std::vector<uint8_t> added(K, 0);
+  for (const Ent& e : ents) {
+    if (!(*n_loop < n_candidates || *n_merge < n_candidates)) break;              // :714
+    const int k = e.best;
+    if (d->bad[k]) continue;                                                       // pinned: skipped (see orbgpu.h)
+    if (added[k]) continue;
+    if (d->map_id[k] == query_map_id && *n_loop < n_candidates) loop_cand[(*n_loop)++] = k;
+    else if (d->map_id[k] != query_map_id && *n_merge < n_candidates && !d->map_bad[k]) merge_cand[(*n_merge)++] = k;
+    added[k] = 1;
+  }
   return ORBG_OK;
 }

@@ -185,3 +185,26 @@ class PoseOptOutput:
     @property
     def outliers(self):
         return self.outlier[: self.n].copy()
+
+
+def database_view(inverted_file, bow_vectors, covisible, map_id, bad, map_bad, n_words):
+    """orbd_database_view (KeyFrameDatabase flattened, S/KeyFrameDatabase.cc:594-761): inverted_file = {word: [kf, ...]} in
+    insertion order, bow_vectors[kf] = (words ascending, values), covisible[kf] = GetBestCovisibilityKeyFrames(10) as indices."""
+    K = len(bow_vectors)
+    inv_start = np.zeros(n_words + 1, np.int32)
+    for w, lst in inverted_file.items():
+        inv_start[w + 1] = len(lst)
+    inv_start = np.cumsum(inv_start).astype(np.int32)
+    inv_kf = np.zeros(max(int(inv_start[-1]), 1), np.int32)
+    for w, lst in inverted_file.items():
+        inv_kf[inv_start[w]: inv_start[w] + len(lst)] = lst
+    bow_start = np.cumsum([0] + [len(b[0]) for b in bow_vectors]).astype(np.int32)
+    bow_word = _c(np.concatenate([b[0] for b in bow_vectors]) if K else np.zeros(1), np.int32)
+    bow_value = _c(np.concatenate([b[1] for b in bow_vectors]) if K else np.zeros(1), np.float64)
+    covis_start = np.cumsum([0] + [len(c) for c in covisible]).astype(np.int32)
+    covis_kf = _c(np.concatenate([np.asarray(c, np.int32) for c in covisible] + [np.zeros(0, np.int32)]), np.int32)
+    if covis_kf.size == 0:
+        covis_kf = np.zeros(1, np.int32)
+    arrs = [inv_start, inv_kf, bow_start, bow_word, bow_value, covis_start, covis_kf, _c(map_id, np.int32), _c(bad, np.uint8), _c(map_bad, np.uint8)]
+    v = capi.DatabaseView(K, n_words, *[capi.ptr(a) for a in arrs])
+    return v, arrs

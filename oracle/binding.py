@@ -18,7 +18,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("extractor.cc", "matching.cc", "lba.cc", "orb_oracle.h",
+    srcs = [os.path.join(_HERE, f) for f in ("extractor.cc", "matching.cc", "lba.cc", "bow.cc", "orb_oracle.h",
                                              "orb_pattern_data.inc", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "orbgpu.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(
@@ -403,3 +403,16 @@ def pose_optimize(problem):
     out = views.PoseOptOutput(problem.n)
     _chk(lib().oracle_pose_optimize(C.byref(problem), C.byref(out.c)))
     return out
+
+
+def detect_n_best_candidates(view, q_word, q_value, connected, query_map_id, n_candidates, place_score):
+    """KeyFrameDatabase::DetectNBestCandidates (S/KeyFrameDatabase.cc:594-761) on views.database_view; place_score in/out."""
+    qw = np.ascontiguousarray(q_word, np.int32); qv = np.ascontiguousarray(q_value, np.float64)
+    con = np.ascontiguousarray(connected, np.uint8)
+    loop = np.zeros(max(n_candidates, 1), np.int32); merge = np.zeros(max(n_candidates, 1), np.int32)
+    nl, nm = C.c_int32(0), C.c_int32(0)
+    _chk(lib().oracle_detect_n_best_candidates(C.byref(view), C.c_void_p(qw.ctypes.data), C.c_void_p(qv.ctypes.data), len(qw),
+                                               C.c_void_p(con.ctypes.data), int(query_map_id), int(n_candidates),
+                                               C.c_void_p(place_score.ctypes.data), C.c_void_p(loop.ctypes.data), C.byref(nl),
+                                               C.c_void_p(merge.ctypes.data), C.byref(nm)))
+    return loop[: nl.value].copy(), merge[: nm.value].copy()

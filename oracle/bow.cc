@@ -6,6 +6,8 @@
 #include "orb_oracle.h"
 
 #include <algorithm>
+#include <list>
+#include <set>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -157,6 +159,76 @@ extern "C" int oracle_wire_unpack(const uint8_t* wire, int n, orbx_keypoint* kps
     kps[i].response = (float)p[13];
     kps[i].octave = (int)(int8_t)p[14];
     std::memcpy(desc + (size_t)i * 32, wire + (size_t)n * 15 + (size_t)i * 32, 32);
+  }
+  return ORBG_OK;
+}
+
+
+// void KeyFrameDatabase::DetectNBestCandidates(KeyFrame* pKF, vector<KeyFrame*>& vpLoopCand, vector<KeyFrame*>& vpMergeCand,
+//                                              int nNumCandidates) -- S/KeyFrameDatabase.cc:594-761, on the flattened database
+// (orbd_database_view, keyframes = indices).  Per-keyframe members of the reference become arrays: mnPlaceRecognitionQuery
+// -> `queried` (every query has a fresh id), mnPlaceRecognitionWords -> `words`, mPlaceRecognitionScore -> place_score
+// (in/out: it survives from query to query in the reference and the covisibility accumulation reads stale values, :688).
+extern "C" int oracle_detect_n_best_candidates(const orbd_database_view* v, const int32_t* q_word, const double* q_value, int nq,
+                                               const uint8_t* connected, int32_t query_map_id, int n_candidates, float* place_score,
+                                               int32_t* loop_cand, int32_t* n_loop, int32_t* merge_cand, int32_t* n_merge) {
+  *n_loop = 0; *n_merge = 0;
+  const int K = v->n_kfs;
+  std::vector<uint8_t> queried(K, 0);
+  std::vector<int> words(K, 0);
+  std::list<int> lKFsSharingWords;
+  for (int r = 0; r < nq; r++) {                                                  // :605-633
+    const int w = q_word[r];
+    if (w < 0 || w >= v->n_words) continue;
+    for (int p = v->inv_start[w]; p < v->inv_start[w + 1]; p++) {
+      const int kf = v->inv_kf[p];
+      if (!queried[kf]) {
+        words[kf] = 0;
+        if (!connected[kf]) { queried[kf] = 1; lKFsSharingWords.push_back(kf); }
+      }
+      words[kf]++;
+    }
+  }
+  if (lKFsSharingWords.empty()) return ORBG_OK;
+  int maxCommonWords = 0;                                                          // :636-644
+  for (int kf : lKFsSharingWords) if (words[kf] > maxCommonWords) maxCommonWords = words[kf];
+  const int minCommonWords = (int)(maxCommonWords * 0.8f);                         // :646
+  std::list<std::pair<float, int>> lScoreAndMatch;
+  for (int kf : lKFsSharingWords) {                                                // :652-663
+    if (words[kf] > minCommonWords) {
+      double sc = 0;
+      const int one[2] = {0, v->bow_start[kf + 1] - v->bow_start[kf]};
+      oracle_score_l1(q_word, q_value, nq, one, v->bow_word + v->bow_start[kf], v->bow_value + v->bow_start[kf], 1, &sc);
+      const float si = (float)sc;
+      place_score[kf] = si;
+      lScoreAndMatch.push_back(std::make_pair(si, kf));
+    }
+  }
+  if (lScoreAndMatch.empty()) return ORBG_OK;
+  std::list<std::pair<float, int>> lAccScoreAndMatch;
+  for (const auto& it : lScoreAndMatch) {                                          // :673-701
+    const int kf = it.second;
+    float bestScore = it.first, accScore = bestScore;
+    int best = kf;
+    for (int p = v->covis_start[kf]; p < v->covis_start[kf + 1]; p++) {
+      const int k2 = v->covis_kf[p];
+      if (!queried[k2]) continue;
+      accScore += place_score[k2];
+      if (place_score[k2] > bestScore) { best = k2; bestScore = place_score[k2]; }
+    }
+    lAccScoreAndMatch.push_back(std::make_pair(accScore, best));
+  }
+  lAccScoreAndMatch.sort([](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });   // :705, compFirst :588-591
+  std::set<int> added;
+  for (const auto& it : lAccScoreAndMatch) {                                       // :713-735
+    if (!(*n_loop < n_candidates || *n_merge < n_candidates)) break;
+    const int kf = it.second;
+    if (v->bad[kf]) continue;       // pinned: the reference's `continue` (:718-719) skips the iterator increment and spins forever
+    if (!added.count(kf)) {
+      if (v->map_id[kf] == query_map_id && *n_loop < n_candidates) loop_cand[(*n_loop)++] = kf;
+      else if (v->map_id[kf] != query_map_id && *n_merge < n_candidates && !v->map_bad[kf]) merge_cand[(*n_merge)++] = kf;
+      added.insert(kf);
+    }
   }
   return ORBG_OK;
 }

@@ -102,6 +102,9 @@ int oracle_vocab_bow(const orbv_vocab_view* v, const uint8_t* desc, int n, int l
 int oracle_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int m, int32_t* best);
 int oracle_score_l1(const int32_t* q_word, const double* q_value, int nq, const int32_t* cand_start, const int32_t* cand_word,
                     const double* cand_value, int m, double* score);
+int oracle_detect_n_best_candidates(const orbd_database_view* v, const int32_t* q_word, const double* q_value, int nq,
+                                    const uint8_t* connected, int32_t query_map_id, int n_candidates, float* place_score,
+                                    int32_t* loop_cand, int32_t* n_loop, int32_t* merge_cand, int32_t* n_merge);
 int oracle_wire_pack(const orbx_keypoint* kps, const uint8_t* desc, int n, uint8_t* wire);
 int oracle_wire_unpack(const uint8_t* wire, int n, orbx_keypoint* kps, uint8_t* desc);
 

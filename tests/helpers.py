@@ -59,3 +59,29 @@ def make_lastframe(scene, fr, rng):
     lv, keep = views.lastframe_view(valid.astype(np.uint8), outlier, Pw, fr["desc"], fr["kps"]["octave"], fr["kps"]["angle"],
                                     n_obs, fr["Tcw"].astype(np.float32))
     return lv, keep
+
+
+def random_database(rng, n_kfs=300, n_words=4000, words_per_kf=(60, 260), n_maps=2, bad_frac=0.05):
+    """A synthetic KeyFrameDatabase: keyframes cluster around a few "places" (shared word pools) so that queries find groups of
+    similar keyframes; inverted file in keyframe-insertion order, L1-normalised BowVectors, covisibility = neighbours in id."""
+    import numpy as np
+    places = [rng.choice(n_words, 500, replace=False) for _ in range(12)]
+    bows, inv = [], {}
+    for k in range(n_kfs):
+        pool = places[(k // 7) % len(places)]
+        nw = rng.randint(*words_per_kf)
+        w = np.unique(np.concatenate([rng.choice(pool, int(nw * 0.8)), rng.choice(n_words, nw - int(nw * 0.8))])).astype(np.int32)
+        v = rng.rand(len(w)) + 0.05
+        v /= v.sum()
+        bows.append((w, v))
+        for x in w:
+            inv.setdefault(int(x), []).append(k)
+    covis = []
+    for k in range(n_kfs):
+        c = [j for j in (k - 1, k + 1, k - 2, k + 2, k - 3, k + 7, k - 7, k + 14) if 0 <= j < n_kfs]
+        rng.shuffle(c)
+        covis.append(c[: rng.randint(0, 9)])
+    map_id = (np.arange(n_kfs) * n_maps // n_kfs).astype(np.int32)
+    bad = (rng.rand(n_kfs) < bad_frac).astype(np.uint8)
+    map_bad = np.zeros(n_kfs, np.uint8)
+    return dict(inv=inv, bows=bows, covis=covis, map_id=map_id, bad=bad, map_bad=map_bad, n_words=n_words)

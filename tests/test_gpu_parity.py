@@ -748,3 +748,32 @@ def test_completion_fallback_path_gives_same_results(scene, monkeypatch):
     for x, y in zip(a[0], b[0]):
         assert np.array_equal(np.asarray(x), np.asarray(y))
     assert np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_detect_n_best_candidates_parity():
+    """Row f-4: KeyFrameDatabase::DetectNBestCandidates on the device-resident database (inverted-file walk, common-word counts,
+    0.8 * max filter, L1 scores, covisibility accumulation) vs the oracle, over a sequence of queries that share the
+    per-keyframe score state; candidate lists identical, scores bit-identical."""
+    rng = np.random.RandomState(11)
+    db = helpers.random_database(rng, n_kfs=600, n_words=6000)
+    db["n_words"] += 1                                           # one word no keyframe contains
+    v, keep = views.database_view(db["inv"], db["bows"], db["covis"], db["map_id"], db["bad"], db["map_bad"], db["n_words"])
+    D = api.KeyFrameDatabase(v, keep)
+    K = len(db["bows"])
+    pg, po = np.zeros(K, np.float32), np.zeros(K, np.float32)
+    total = 0
+    for q in range(25):
+        kq = rng.randint(K)
+        qw, qv = db["bows"][kq]
+        if q == 7:                                               # a query that shares no word with anybody
+            unused = [w for w in range(db["n_words"]) if w not in db["inv"]]
+            qw, qv = np.array(unused[:1], np.int32), np.array([1.0])
+        con = np.zeros(K, np.uint8)
+        con[max(kq - 3, 0): kq + 4] = 1
+        n_c = int(rng.choice([1, 3, 5]))
+        gl, gm = D.DetectNBestCandidates(qw, qv, con, int(db["map_id"][kq]), n_c, pg)
+        ol, om = ob.detect_n_best_candidates(v, qw, qv, con, int(db["map_id"][kq]), n_c, po)
+        assert np.array_equal(gl, ol) and np.array_equal(gm, om), (q, gl, ol, gm, om)
+        assert np.array_equal(pg.view(np.uint32), po.view(np.uint32)), q
+        total += len(gl) + len(gm)
+    assert total > 40
