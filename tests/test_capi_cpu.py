@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     lib = capi.load()
     hdr = open(os.path.join(ROOT, "include", "orbgpu.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+((?:orbx|orbm|orbv|orbk|lba|orbg|pose)_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|const char\*)\s+((?:orbx|orbm|orbv|orbk|orbd|lba|orbg|pose)_\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
@@ -38,6 +38,8 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert lib.orbx_create(C.byref(cfg), C.byref(h)) == capi.ORBG_NO_DEVICE
     f = C.c_void_p()
     assert lib.orbm_frame_create(0, 100, C.byref(f)) == capi.ORBG_NO_DEVICE
+    dv = capi.DatabaseView(0, 0, *([None] * 10))
+    assert lib.orbd_database_create(0, C.byref(dv), C.byref(f)) == capi.ORBG_NO_DEVICE
     q = np.zeros((1, 32), np.uint8); d = np.zeros((1, 1), np.int32)
     assert lib.orbm_hamming_matrix(0, C.c_void_p(q.ctypes.data), 1, C.c_void_p(q.ctypes.data), 1, C.c_void_p(d.ctypes.data)) == capi.ORBG_NO_DEVICE
     from multi_orbslam3_amd import api
