@@ -63,6 +63,17 @@ typedef struct orbx_config {
   int32_t max_height;
   int32_t n_cams;         /* 1 = mono, 2 = stereo rig (left = cam 0, right = cam 1) */
   int32_t device;         /* HIP device ordinal (1 agent <-> 1 GPU) */
+  /* Deployment variants for the two places where the reference's output depends on its build, not on its source
+   * (all zero = the defaults the parity tests pin):
+   * gauss_taps: outer-to-centre half of the 7-tap Q8 kernel cv::GaussianBlur(7x7, sigma 2) uses on CV_8U
+   *   {18,34,49,55} (sum 257, default): OpenCV <= 3.4.1, and the 3.4.2 - 4.4 fixed-point path (each tap rounded on its own);
+   *   {18,34,48,56} (sum 256): OpenCV >= 4.5 (getGaussianKernelFixedPoint_ED: rounding error diffused, centre = remainder).
+   *   Any taps with 2 (t0+t1+t2) + t3 <= 257 are accepted.
+   * octree_oldest_first: DistributeOctTree sorts (size, ExtractorNode*) and splits from the back (S/ORBextractor.cc:679-682):
+   *   among equally populated nodes the heap address decides.  0 (default): the most recently created node first
+   *   (addresses grow with allocation order); 1: the oldest first (allocators that hand out descending addresses). */
+  int32_t gauss_taps[4];
+  int32_t octree_oldest_first;
 } orbx_config;
 
 /* The cv::KeyPoint fields the reference sets/uses. 24 bytes. */

@@ -31,7 +31,8 @@ assert KEYPOINT_DTYPE.itemsize == 24 and EDGE_DTYPE.itemsize == 24
 class OrbxConfig(C.Structure):
     _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_width", C.c_int32),
-                ("max_height", C.c_int32), ("n_cams", C.c_int32), ("device", C.c_int32)]
+                ("max_height", C.c_int32), ("n_cams", C.c_int32), ("device", C.c_int32),
+                ("gauss_taps", C.c_int32 * 4), ("octree_oldest_first", C.c_int32)]
 
 
 class FrameView(C.Structure):

@@ -21,10 +21,11 @@ class ORBextractor:
     """ORB_SLAM3::ORBextractor (I/ORBextractor.h:47-113).  n_cams=2 gives the batched stereo rig."""
 
     def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, max_width=640,
-                 max_height=480, n_cams=1, device=0):
+                 max_height=480, n_cams=1, device=0, gauss_taps=None, octree_oldest_first=False):
+        """gauss_taps / octree_oldest_first: the two deployment variants of orbx_config (OpenCV >= 4.5: (18, 34, 48, 56))."""
         self.lib = capi.load()
         self.cfg = capi.OrbxConfig(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width, max_height,
-                                   n_cams, device)
+                                   n_cams, device, (C.c_int32 * 4)(*(gauss_taps or (0, 0, 0, 0))), int(bool(octree_oldest_first)))
         self.h = C.c_void_p()
         capi.check(self.lib.orbx_create(C.byref(self.cfg), C.byref(self.h)), "orbx_create")
         self.cap = 2 * nfeatures + 256

@@ -15,10 +15,12 @@
 //     lookups read LDS; the orientation moments use the same staged patch;
 //   * small, latency-bound hand-offs (candidate lists, selected keypoints) go through mapped pinned
 //     host memory written/read directly by the kernels -- no extra memcpy launches.
-// The quad-tree (DistributeOctTree) runs on the host between the two GPU phases (serial, pointer-chasing
-// in the reference; here an index/range based implementation with a pinned deterministic tie-break).
+// The quad-tree (DistributeOctTree; serial and pointer-chasing in the reference) runs on the device too: octree_kernel, an
+// LDS-resident closed form of the std::list bookkeeping per (camera, level) with a pinned deterministic tie-break
+// (orbx_config.octree_oldest_first selects the other order).  An index/range based host implementation with the same
+// tie-break remains for partial lapping areas and for frames whose candidate lists overflow the device buffers.
 //
-// Bit-exactness contract (tests/test_gpu_extractor.py): pyramid bytes, FAST candidate lists, kept
+// Bit-exactness contract (tests/test_gpu_parity.py): pyramid bytes, FAST candidate lists, kept
 // keypoints, angles (f32 bits) and descriptors are identical to the CPU oracle.
 // Compile with -ffp-contract=off (strict f32 for fastAtan2 and the pattern rotation).
 
@@ -484,6 +486,7 @@ constexpr int kOctListCap = 2048;    // nodes alive at once (<= 4*N + 8)
 
 struct OctCfg {
   int n_levels, n_cams;
+  int oldest_first;                  // quad-tree tie-break variant (orbx_config.octree_oldest_first)
   int n_target[ORBG_MAX_LEVELS];     // mnFeaturesPerLevel
   int reg_off[2][ORBG_MAX_LEVELS];   // start of the (camera, level) region in the selection buffer
   int reg_cap[ORBG_MAX_LEVELS];
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
       // read four at a time from LDS
       const int n4 = (n + 3) & ~3;
       for (int i = tid; i < n4; i += kOctThreads)
-        scanB[i] = (i < n && ncnt[cur][i] > 1) ? (int)(((unsigned)ncnt[cur][i] << 16) | nseq[cur][i]) : 0;
+        scanB[i] = (i < n && ncnt[cur][i] > 1) ? (int)(((unsigned)ncnt[cur][i] << 16) | (cfg.oldest_first ? 0xFFFFu - nseq[cur][i] : nseq[cur][i])) : 0;
       __syncthreads();
       m = 0;
       for (int i = tid; i < n; i += kOctThreads) {
@@ -818,7 +821,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-struct UMax { int v[16]; };
+struct UMax { int v[16]; int gauss[4]; };   // circle table of IC_Angle + the blur taps (orbx_config.gauss_taps)
 
 constexpr int kPR = 21;              // patch radius: 18 (max rotated pattern reach) + 3 (blur)
 constexpr int kPW = 2 * kPR + 1;     // 43
@@ -875,11 +878,11 @@ __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr
     m01 = wave_sum(m01); m10 = wave_sum(m10);
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // --- separable 7x7 Gaussian, Q8 taps {18,34,49,55,49,34,18}: row pass fits u16 (257*255 = 65535)
+  // --- separable 7x7 Gaussian, Q8 taps (default {18,34,49,55,49,34,18}; orbx_config.gauss_taps): the row pass fits u16 (257*255 = 65535)
   for (int i = lane; i < kPW * kBW; i += 64) {
     const int y = i / kBW, x = i - y * kBW;
     const uint8_t* r = raw + y * kPS + x;       // x is already offset by -3 relative to the blurred column
-    const int acc = 18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 49 * (r[2] + r[4]) + 55 * r[3];
+    const int acc = um.gauss[0] * (r[0] + r[6]) + um.gauss[1] * (r[1] + r[5]) + um.gauss[2] * (r[2] + r[4]) + um.gauss[3] * r[3];
     hrow[y * kHS + x] = (unsigned short)acc;
   }
   __builtin_amdgcn_wave_barrier();
@@ -887,7 +890,8 @@ __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr
   for (int i = lane; i < kBW * kBW; i += 64) {
     const int y = i / kBW, x = i - y * kBW;
     const unsigned short* r = hrow + y * kHS + x;
-    const int acc = 18 * ((int)r[0] + r[6 * kHS]) + 34 * ((int)r[kHS] + r[5 * kHS]) + 49 * ((int)r[2 * kHS] + r[4 * kHS]) + 55 * (int)r[3 * kHS];
+    const int acc = um.gauss[0] * ((int)r[0] + r[6 * kHS]) + um.gauss[1] * ((int)r[kHS] + r[5 * kHS]) + um.gauss[2] * ((int)r[2 * kHS] + r[4 * kHS]) +
+                    um.gauss[3] * (int)r[3 * kHS];
     const int v = (acc + 32768) >> 16;
     blur[y * kBS + x] = (uint8_t)min(v, 255);
   }
@@ -1220,7 +1224,9 @@ class QuadTree {
           const int prev = size_;
           prev_work_.swap(work_);
           work_.clear();
-          std::sort(prev_work_.begin(), prev_work_.end());   // (size, node id) ascending; id == creation order
+          // (size, node id) ascending, walked from the back; id == creation order (oldest_first_: ids descending within a size)
+          if (oldest_first_) std::sort(prev_work_.begin(), prev_work_.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first != b.first ? a.first < b.first : a.second > b.second; });
+          else std::sort(prev_work_.begin(), prev_work_.end());
           for (int j = (int)prev_work_.size() - 1; j >= 0; j--) {
             const int id = prev_work_[j].second;
             split(id, nullptr);
@@ -1247,6 +1253,9 @@ class QuadTree {
   std::vector<Node> nodes_;
   std::vector<int> keys_, tmp_, root_of_;
   std::vector<std::pair<int, int>> work_, prev_work_;
+ public:
+  bool oldest_first_ = false;        // orbx_config.octree_oldest_first
+ private:
   int head_ = -1, tail_ = -1, size_ = 0;
 
   int new_node(const Node& n) { nodes_.push_back(n); return (int)nodes_.size() - 1; }
@@ -1573,6 +1582,7 @@ static int setup_geometry(orbx_handle* h, int w, int hgt) {
   {
     OctCfg& oc = h->octcfg;
     oc.n_levels = nl; oc.n_cams = nc;
+    oc.oldest_first = h->cfg.octree_oldest_first != 0;
     int roff = 0;
     bool fits = true;
     for (int l = 0; l < nl; l++) {
@@ -1638,6 +1648,12 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
   if (rc) return rc;
   orbx_handle* h = new orbx_handle();
   h->cfg = *cfg;
+  {
+    // blur taps: all zero selects the default kernel; the row pass of the descriptor kernel is a u16 (sum * 255 <= 65535)
+    int* t = h->cfg.gauss_taps;
+    if (t[0] == 0 && t[1] == 0 && t[2] == 0 && t[3] == 0) { t[0] = 18; t[1] = 34; t[2] = 49; t[3] = 55; }
+    if (t[0] < 0 || t[1] < 0 || t[2] < 0 || t[3] < 1 || 2 * (t[0] + t[1] + t[2]) + t[3] > 257) { delete h; return ORBG_BAD_ARG; }
+  }
   h->device = cfg->device;
   const int nl = cfg->n_levels;
   // ORBextractor::ORBextractor (S/ORBextractor.cc:413-468)
@@ -1668,6 +1684,7 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
       ++v0;
     }
     for (int i = 0; i < 16; i++) h->umax.v[i] = um[i];
+    for (int i = 0; i < 4; i++) h->umax.gauss[i] = h->cfg.gauss_taps[i];
   }
   {
     int nthreads = 5;
@@ -1675,6 +1692,7 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     if (const char* env = getenv("ORBG_HOST_OCTREE")) h->gpu_octree = atoi(env) == 0;
     h->pool.reset(new WorkerPool(nthreads));
     h->qts.resize(nthreads + 1);
+    for (auto& q : h->qts) q.oldest_first_ = cfg->octree_oldest_first != 0;
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   for (auto& e : h->ev)

@@ -109,8 +109,9 @@ def hamming(a, b):
 
 # ---------------------------------------------------------------- extractor
 def make_config(n_features=1000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7, max_width=640, max_height=480,
-                n_cams=1, device=0):
-    return capi.OrbxConfig(n_features, scale_factor, n_levels, ini_th, min_th, max_width, max_height, n_cams, device)
+                n_cams=1, device=0, gauss_taps=None, octree_oldest_first=False):
+    return capi.OrbxConfig(n_features, scale_factor, n_levels, ini_th, min_th, max_width, max_height, n_cams, device,
+                           (C.c_int32 * 4)(*(gauss_taps or (0, 0, 0, 0))), int(bool(octree_oldest_first)))
 
 
 class Extractor:

@@ -177,8 +177,9 @@ extern "C" int oracle_fast_detect(const uint8_t* img, int w, int h, int stride, 
 // cv::GaussianBlur(m, m, Size(7,7), 2, 2, BORDER_REFLECT_101) on CV_8UC1 -- Appendix A-4, OpenCV <= 3.4.1
 // fixed-point separable path: Q8 taps [18,34,49,55,49,34,18] (sum 257), row pass in int32,
 // column pass (sum + 32768) >> 16, saturated.  Called at S/ORBextractor.cc:1115.
-extern "C" void oracle_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
-  static const int K[7] = {18, 34, 49, 55, 49, 34, 18};
+// taps4 = outer-to-centre half of the kernel (orbx_config.gauss_taps): {18,34,49,55} or, for OpenCV >= 4.5, {18,34,48,56}
+extern "C" void oracle_gaussian_blur7_taps(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, const int* taps4) {
+  const int K[7] = {taps4[0], taps4[1], taps4[2], taps4[3], taps4[2], taps4[1], taps4[0]};
   std::vector<int> tmp((size_t)w * h);
   for (int y = 0; y < h; y++) {
     const uint8_t* S = src + (size_t)y * sstride;
@@ -196,6 +197,11 @@ extern "C" void oracle_gaussian_blur7(const uint8_t* src, int w, int h, int sstr
       D[x] = sat_u8((acc + 32768) >> 16);
     }
   }
+}
+
+extern "C" void oracle_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+  static const int K4[4] = {18, 34, 49, 55};
+  oracle_gaussian_blur7_taps(src, w, h, sstride, dst, dstride, K4);
 }
 
 // cv::fastAtan2(y, x) in degrees -- Appendix A-5 (OpenCV 3.x core/src/mathfuncs_core.cpp, scalar path).
@@ -242,6 +248,9 @@ extern "C" int oracle_extractor_create(const orbx_config* cfg, oracle_extractor*
   if (!cfg || !out || cfg->n_levels < 1 || cfg->n_levels > ORBG_MAX_LEVELS || cfg->n_features < 1) return ORBG_BAD_ARG;
   auto* e = new oracle_extractor();
   e->cfg = *cfg;
+  if (e->cfg.gauss_taps[0] == 0 && e->cfg.gauss_taps[1] == 0 && e->cfg.gauss_taps[2] == 0 && e->cfg.gauss_taps[3] == 0) {
+    e->cfg.gauss_taps[0] = 18; e->cfg.gauss_taps[1] = 34; e->cfg.gauss_taps[2] = 49; e->cfg.gauss_taps[3] = 55;
+  }
   const int nl = cfg->n_levels;
   e->scale.resize(nl); e->inv_scale.resize(nl); e->sigma2.resize(nl); e->inv_sigma2.resize(nl);
   e->scale[0] = 1.0f; e->sigma2[0] = 1.0f;
@@ -390,7 +399,7 @@ void divide_node(const OctNode& p, const std::vector<OracleCand>& c, OctNode ch[
   for (int i = 0; i < 4; i++) if (ch[i].keys.size() == 1) ch[i].no_more = true;
 }
 
-std::vector<int> distribute_octree(const std::vector<OracleCand>& c, int minX, int maxX, int minY, int maxY, int N) {
+std::vector<int> distribute_octree(const std::vector<OracleCand>& c, int minX, int maxX, int minY, int maxY, int N, bool oldest_first = false) {
   std::vector<int> result;
   if (c.empty()) return result;
   int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));   // :541
@@ -451,7 +460,7 @@ std::vector<int> distribute_octree(const std::vector<OracleCand>& c, int minX, i
         // sort(pair<int, ExtractorNode*>): pinned tie-break = creation sequence (== pool id order)
         std::sort(prev.begin(), prev.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& b) {
           if (a.first != b.first) return a.first < b.first;
-          return L.pool[a.second].seq < L.pool[b.second].seq;
+          return oldest_first ? L.pool[a.second].seq > L.pool[b.second].seq : L.pool[a.second].seq < L.pool[b.second].seq;
         });
         for (int j = (int)prev.size() - 1; j >= 0; j--) {
           OctNode ch[4];
@@ -570,8 +579,8 @@ extern "C" int oracle_extract(oracle_extractor* e, const uint8_t* img, int width
           cand.push_back({cell[3 * k] + j * wCell, cell[3 * k + 1] + i * hCell, cell[3 * k + 2]});
       }
     }
-    std::vector<int> keep = distribute_octree(cand, minBorderX, maxBorderX, minBorderY, maxBorderY,
-                                              e->feats_per_level[level]);
+    std::vector<int> keep = distribute_octree(cand, minBorderX, maxBorderX, minBorderY, maxBorderY, e->feats_per_level[level],
+                                              e->cfg.octree_oldest_first != 0);
     all[level].reserve(keep.size());
     for (int k : keep) {                                                                          // :862-872
       LevelKp kp;
@@ -599,7 +608,7 @@ extern "C" int oracle_extract(oracle_extractor* e, const uint8_t* img, int width
     std::vector<uint8_t> work((size_t)lw * lh), blur((size_t)lw * lh);
     for (int y = 0; y < lh; y++)
       std::memcpy(work.data() + (size_t)y * lw, e->level_ptr(level) + (size_t)y * e->lstride[level], lw);
-    oracle_gaussian_blur7(work.data(), lw, lh, lw, blur.data(), lw);
+    oracle_gaussian_blur7_taps(work.data(), lw, lh, lw, blur.data(), lw, e->cfg.gauss_taps);
     const float scale = e->scale[level];
     const int scaledPatchSize = (int)(kPatch * e->scale[level]);                                  // :862
     for (auto& kp : all[level]) {

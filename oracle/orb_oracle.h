@@ -37,6 +37,7 @@ int  oracle_fast_score(const uint8_t* img, int stride, int x, int y);
 int  oracle_fast_detect(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax,
                         int32_t* xys, int cap);
 void oracle_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+void oracle_gaussian_blur7_taps(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, const int* taps4);
 float oracle_fast_atan2(float y, float x);
 int  oracle_hamming(const uint8_t* a, const uint8_t* b);
 

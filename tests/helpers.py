@@ -44,12 +44,6 @@ def local_map_from(scene, frames, rng=None):
     return out
 
 
-def lastframe_view_of(fr, rng=None):
-    """LastFrame view: every stereo-matched feature carries a map point at its unprojected position."""
-    from multi_orbslam3_amd import synth as s
-    return fr
-
-
 def make_lastframe(scene, fr, rng):
     Pw, valid = synth.unproject_to_world(fr["kps"], fr["depth"], fr["Tcw"], scene.cam)
     n = len(fr["kps"])

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert capi.KEYPOINT_DTYPE.itemsize == 24 and capi.EDGE_DTYPE.itemsize == 24
-    assert C.sizeof(capi.OrbxConfig) == 36
+    assert C.sizeof(capi.OrbxConfig) == 56
     assert C.sizeof(capi.LbaProblem) % 8 == 0 and capi.LbaProblem.lambda_init.offset % 8 == 0
 
 

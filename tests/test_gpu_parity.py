@@ -85,6 +85,29 @@ def test_extractor_dense_noise_overflows_to_host_trees(scene):
     _assert_extract_equal((kr, dr), (okps, odesc), "dense noise stereo R")
 
 
+@pytest.mark.parametrize("variant", [dict(gauss_taps=(18, 34, 48, 56)), dict(octree_oldest_first=True),
+                                     dict(gauss_taps=(18, 34, 48, 56), octree_oldest_first=True)])
+def test_extractor_deployment_variants(scene, variant):
+    """The two places where the reference's output depends on its build (OpenCV's Gaussian taps, the heap-address tie-break of
+    DistributeOctTree) are switchable in orbx_config: every variant is bit-exact against the oracle's same variant, on the device
+    quad-tree path (stereo rig) and the host quad-tree path (mono with a partial lapping area), and differs from the default."""
+    L, R, _ = scene.stereo_pair(5)
+    ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2, **variant)
+    (kl, dl), (kr, dr) = ex.extract_stereo(L, R)
+    ol, orr = ob.Extractor(n_features=1000, **variant), ob.Extractor(n_features=1000, **variant)
+    rc, okl, odl, _ = ol.extract(L)
+    rc, okr, odr, _ = orr.extract(R)
+    _assert_extract_equal((kl, dl), (okl, odl), "variant %r left" % (variant,))
+    _assert_extract_equal((kr, dr), (okr, odr), "variant %r right" % (variant,))
+    exm = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=1, **variant)
+    nm, km, dm = exm(L, (200, 400))                                   # partial lapping area -> host quad-trees
+    rc, okm, odm, onm = ol.extract(L, lap=(200, 400))
+    assert nm == onm
+    _assert_extract_equal((km, dm), (okm, odm), "variant %r mono" % (variant,))
+    rc, dk, dd, _ = ob.Extractor(n_features=1000).extract(L)          # the default build
+    assert len(dk) != len(okl) or not np.array_equal(dd, odl)
+
+
 def test_extractor_empty_image():
     ex = api.ORBextractor(100, 1.2, 8, 20, 7, 320, 240)
     nm, kps, desc = ex(None)

@@ -169,6 +169,23 @@ def test_gaussian_impulse_response():
     assert (ob.gaussian_blur7(np.full((9, 9), 100, np.uint8)) == ((100 * 257 * 257 + 32768) >> 16)).all()
 
 
+def test_gaussian_taps_variant_of_newer_opencv():
+    """orbx_config.gauss_taps = (18, 34, 48, 56): the kernel sums to 256, so flat areas keep their value exactly and the
+    impulse response is the outer product of the taps."""
+    import ctypes as C
+    img = np.zeros((15, 15), np.uint8)
+    img[7, 7] = 255
+    out = np.zeros_like(img)
+    taps = (C.c_int * 4)(18, 34, 48, 56)
+    ob.lib().oracle_gaussian_blur7_taps(C.c_void_p(img.ctypes.data), 15, 15, 15, C.c_void_p(out.ctypes.data), 15, taps)
+    k = np.array([18, 34, 48, 56, 48, 34, 18])
+    assert np.array_equal(out[4:11, 4:11], (255 * np.outer(k, k) + 32768) >> 16)
+    flat = np.full((9, 9), 137, np.uint8)
+    out2 = np.zeros_like(flat)
+    ob.lib().oracle_gaussian_blur7_taps(C.c_void_p(flat.ctypes.data), 9, 9, 9, C.c_void_p(out2.ctypes.data), 9, taps)
+    assert (out2 == 137).all()
+
+
 def test_gaussian_reflect101_border():
     rng = np.random.RandomState(11)
     img = rng.randint(0, 256, (12, 15)).astype(np.uint8)
