@@ -587,43 +587,31 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
         if (wv == k + 1) LDLTM_T(8 + 8 * k + 3);
         LDLTM_T(80 + wv * 24 + 3 * k);
         d4 Rc = {0.0, 0.0, 0.0, 0.0}, nW = {0.0, 0.0, 0.0, 0.0};
-        // The row of pivot pv+1 is read (counter first, then the row: LDS keeps a wavefront's order) while pivot pv is
-        // applied; the read is valid if the counter it saw already covered pv+1, otherwise the row is polled for.
-        // A wavefront that follows the diagonal closely takes the poll path, one that replays a finished row never waits.
-        // (compiler barriers keep hipcc from hoisting the row read above the counter read: a relaxed atomic orders nothing)
-        int cnt_raw = __hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // consumed one step later
-        asm volatile("" ::: "memory");
+        // Four pivots at a time: one poll of the counter, the four rows and their 1/d in flight together, then four dependent
+        // instructions.  (Per-pivot hand-over with a look-ahead read was measured at ~270 cycles per pivot -- an LDS round trip
+        // per step on top of the instruction -- and let the long columns fall behind the diagonal; the group form costs the
+        // wavefront that holds the next diagonal tile ~150 cycles more at the end of a row and halves everybody's replay.)
         const lds_vdp pivr = (lds_vdp)(Piv) + par * 16 * 64 + lane;
-        double u_s = pivr[0];
+        const lds_vdp rcpr = (lds_vdp)(Rcp) + par * 16 + lr;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           if (4 * g < npiv) {
+            poll_gt(&s_piv, 16 * k + 4 * g + 3);
+            double u4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) u4[q] = pivr[(4 * g + q) * 64];
+            const double rsel = rcpr[4 * g];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               const int pv = 4 * g + q;
-              const int want = 16 * k + pv;
-              double u = u_s;
-              if (__builtin_amdgcn_readfirstlane(cnt_raw) <= want) {
-                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= want) { }
-                asm volatile("" ::: "memory");
-                u = pivr[pv * 64];
-              }
-              if (pv < 15) {
-                asm volatile("" ::: "memory");
-                cnt_raw = __hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                asm volatile("" ::: "memory");
-                u_s = pivr[(pv + 1) * 64];
-              }
               double xg = X[g];
               asm volatile("" : "+v"(xg));         // own registers: X is then updated in place
               Rc[g] = (lr == q) ? xg : Rc[g];      // row pv of R
-              if (pv < 15) X = mfma(u, xg, X);     // X -= L[:, pv] R[pv, :]; the tile is dead after its 16th row
-              if (q == 3) {                        // four rows complete: -W = -D^-1 R and the own diagonal tile (wv, wv) -= R^T W
-                nW[g] = Rc[g] * -Rcp[par * 16 + 4 * g + lr];
-                D = mfma(Rc[g], nW[g], D);
-              }
-              __builtin_amdgcn_sched_barrier(0);   // the look-ahead counter is consumed AFTER the instruction is issued
+              if (pv < 15) X = mfma(u4[q], xg, X); // X -= L[:, pv] R[pv, :]; the tile is dead after its 16th row
             }
+            // four rows complete: -W = -D^-1 R and the own diagonal tile (wv, wv) -= R^T W
+            nW[g] = Rc[g] * -rsel;
+            D = mfma(Rc[g], nW[g], D);
           }
         }
 #pragma unroll
