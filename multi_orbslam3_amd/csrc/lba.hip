@@ -838,7 +838,9 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
   } else if (diag && tid < 42) {
     const int a = tid - 36;
     const double s = ((part[tid][0] + part[tid][1]) + part[tid][2]) + part[tid][3];
-    bs[6 * i1 + a] = bp[6 * (size_t)i1 + a] - s;
+    const double v = bp[6 * (size_t)i1 + a] - s;
+    bs[6 * i1 + a] = v;
+    if (St) ldltm::image_put_rhs(St, n, 6 * i1 + a, v);     // the solver reads the right-hand side as the matrix' border column
   }
 }
 
@@ -1938,6 +1940,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const bool use_mfma = nP >= 1 && ldltm::supports(n) && !getenv("ORBG_LDLT_VALU");
   if (use_mfma) {
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
+    // padding and zeros of the bordered image: they depend on n only, k_schur never touches them -- once per call
+    ORBG_HIP(ldltm::launch_image_pad(n, h->d_St.p, st));
   }
   int cur = 0;   // index of the buffer holding the current estimate
   const int n_blocks_u = (NP + NX + 255) / 256;
@@ -2029,7 +2033,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       const bool bracket = h->prof_on && !prof_pending;
       if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
       if (use_mfma) {
-        ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
+        ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
       } else if (use_flow) {
         hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
       } else if (rows_R) {

@@ -77,10 +77,54 @@ __host__ __device__ inline int tile_image_pos(int r, int c) {
   return tile_index(i, j) * 256 + 4 * l + g;
 }
 
+// The image holds the BORDERED matrix the kernels factor, N = 16 T rows and columns:  S in rows/columns < n, ones on the
+// diagonal of the padding rows n .. n_pad-1, the right-hand side in column cb = n_pad (rows < n; mirrored into row cb
+// inside the last diagonal tile), zeros everywhere else.  The kernels load tiles and nothing else (synthesising padding
+// and border per element cost every wavefront ~1100 vector instructions before its first pivot).  Producers write S and,
+// per row, image_put_rhs(); everything that does not depend on the values is written once per geometry by k_image_pad.
+__host__ __device__ inline void image_put_rhs(double* St, int n, int r, double v) {
+  const Geo g = make_geo(n);
+  St[tile_image_pos(r, g.cb)] = v;
+  const int m = tile_image_pos(g.cb, r);
+  if (m >= 0) St[m] = v;
+}
+// value of image element (r, c) outside S and the right-hand side, or -1.0 if (r, c) is not such an element
+__host__ __device__ inline double image_pad_value(const Geo& g, int n, int r, int c) {
+  if (r < n && c < n) return -1.0;
+  if ((c == g.cb && r < n) || (r == g.cb && c < n)) return -1.0;
+  return (r == c && r < g.n_pad) ? 1.0 : 0.0;
+}
+__global__ void k_image_pad(int n, double* __restrict__ St) {
+  const Geo g = make_geo(n);
+  const int j0 = n >> 4;                         // tile columns j0 .. T-1 hold everything outside S
+  const int t0 = tile_index(0, j0), cnt = (g.ntiles - t0) * 256;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += gridDim.x * blockDim.x) {
+    const int t = t0 + (e >> 8), w = e & 255, l = w >> 2, gg = w & 3;
+    int j = j0;
+    while (tile_index(0, j + 1) <= t) j++;
+    const int i = t - tile_index(0, j);
+    const double v = image_pad_value(g, n, 16 * i + (l >> 4) + 4 * gg, 16 * j + (l & 15));
+    if (v >= 0.0) St[(size_t)t0 * 256 + e] = v;
+  }
+}
+__host__ inline hipError_t launch_image_pad(int n, double* St, hipStream_t st) {
+  hipLaunchKernelGGL(k_image_pad, dim3(8), dim3(256), 0, st, n, St);
+  return hipGetLastError();
+}
+
 __device__ __forceinline__ double rdlane(double v, int l) {   // l must be wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
+}
+
+// lanes of the odd 16-lane groups receive the value held by the even group below them (gfx950 v_permlane16_swap:
+// swaps the odd rows of its first operand with the even rows of its second; both operands are copies of v here)
+__device__ __forceinline__ double row_even_to_odd(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]);
 }
 
 __device__ __forceinline__ double rcp2(double d) {            // 1/d to ~1 ulp: hardware seed + two Newton steps
@@ -103,8 +147,7 @@ __device__ long long g_prof[512];
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 template <int NS, int NY, bool WLDS>
-__global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __restrict__ St, const double* __restrict__ b,
-                                                        double* __restrict__ x, int* __restrict__ ok_flag,
+__global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag,
                                                         double* __restrict__ wglob) {
 #pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
   extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -147,31 +190,17 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
   // lane-predicated load before it issues the next one)
   {
     d4 sv[NS];
-    double bv[NS][4];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       // no branch around the loads (hipcc drains the memory counter at every join): slots past the end re-read the last tile
       const int t = min(s * kWaves + wv, G.ntiles - 1);
       sv[s] = *reinterpret_cast<const d4*>(St + (size_t)t * 256 + 4 * lane);
-      const bool bt = tj[s] == (cb >> 4);
-      const int c = 16 * min(tj[s], T - 1) + lc;
-#pragma unroll
-      for (int g = 0; g < 4; g++) bv[s][g] = b[bt ? min(min(16 * min(ti[s], T - 1) + lr + 4 * g, c), n - 1) : 0];
     }
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-      const int c = 16 * tj[s] + lc;
-      d4 v;
+      const bool on = tj[s] < T;
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int r = 16 * ti[s] + lr + 4 * g;
-        double e = 0.0;
-        if (r < n && c < n) e = sv[s][g];
-        else if (r == c) e = r < n_pad ? 1.0 : 0.0;
-        else if ((c == cb && r < n) || (r == cb && c < n)) e = bv[s][g];
-        v[g] = (tj[s] < T) ? e : 0.0;
-      }
-      acc[s] = v;
+      for (int g = 0; g < 4; g++) acc[s][g] = on ? sv[s][g] : 0.0;
     }
   }
   __syncthreads();
@@ -436,8 +465,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const volatile d2* lds_vd2p;
 typedef __attribute__((address_space(3))) const volatile double* lds_vdp;
 
-__global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __restrict__ St, const double* __restrict__ b,
-                                                        double* __restrict__ x, int* __restrict__ ok_flag) {
+__global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag) {
 #pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ int s_piv;                // pivots published so far (16 k + pv + 1)
@@ -456,6 +484,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
   if (tid == 0) { s_piv = 0; s_ok = 1; }
   if (tid < kColT) { s_rflag[tid] = 0; s_rowdone[tid] = 0; }
   __syncthreads();                     // the only barrier before the back-substitution: from here on the wavefronts run on flags
+  LDLTM_T(310 + wv);
 
   // ---- tile (i, wv) in slot i, two 16-byte loads per lane and tile, all in flight before the first use.  Wave-uniform
   // conditions only around the loads (hipcc waits for a lane-predicated load before it issues the next one); a
@@ -464,34 +493,20 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
   d4 acc[kColT];
   {
     d4 sv[kColT];
-    double bv[kColT][4];
-    const int c = 16 * wv + lc;
-    const bool border = wv == (cb >> 4);                // the column that holds the right-hand side
     // no branch at all around the loads (even a wave-uniform one makes hipcc drain the memory counter at the join:
     // the column then arrives one tile per memory round trip); slots past the column re-read its last tile
     const int wc_ = min(wv, T - 1);
 #pragma unroll
-    for (int i = 0; i < kColT; i++) {
-      sv[i] = *reinterpret_cast<const d4*>(St + (size_t)tile_index(min(i, wc_), wc_) * 256 + 4 * lane);
-#pragma unroll
-      for (int g = 0; g < 4; g++) bv[i][g] = b[border ? min(min(16 * i + lr + 4 * g, c), n - 1) : 0];
-    }
+    for (int i = 0; i < kColT; i++) sv[i] = *reinterpret_cast<const d4*>(St + (size_t)tile_index(min(i, wc_), wc_) * 256 + 4 * lane);
 #pragma unroll
     for (int i = 0; i < kColT; i++) {
-      d4 v;
+      const bool on = i <= wv && wv < T;
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int r = 16 * i + lr + 4 * g;
-        double e = 0.0;
-        if (r < n && c < n) e = sv[i][g];
-        else if (r == c) e = r < n_pad ? 1.0 : 0.0;
-        else if ((c == cb && r < n) || (r == cb && c < n)) e = bv[i][g];
-        v[g] = (i <= wv && wv < T) ? e : 0.0;
-      }
-      acc[i] = v;
+      for (int g = 0; g < 4; g++) acc[i][g] = on ? sv[i][g] : 0.0;
     }
   }
   if (wv == 0) LDLTM_T(1);
+  LDLTM_T(300 + wv);
 
   auto poll_gt = [&](int* w, int k) {
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k) { }
@@ -523,9 +538,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
 #pragma unroll
         for (int s = 0; s < kColT; s++)
           if (s == k) C = acc[s];
-        double wcs[16];
-#pragma unroll
-        for (int pv = 0; pv < 16; pv++) wcs[pv] = 0.0;
+        double wrow[4] = {0.0, 0.0, 0.0, 0.0};   // rows of the unit upper factor (negated), row 4g + lr in register g
         double dlast = 1.0;
         double r4[4] = {1.0, 1.0, 1.0, 1.0};
         bool anyzero = false;
@@ -535,27 +548,41 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
           if (g == 2) LDLTM_T(8 + 8 * k + 6);
           if (4 * g < npiv) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int pv = 4 * g + q;
-              const double d = rdlane(C[g], q * 16 + pv);
-              const double r = rcp2(d);
-              r4[q] = r;
+            for (int h = 0; h < 2; h++) {
+              // TWO pivots per matrix instruction: rows p0, p1 = p0 + 1 sit in lane groups q0, q0 + 1 of register g.
+              // With  [c00 c01; c01 c11]  the leading 2x2 block:  r0 = 1/c00,  l10 = c01 r0,  1/d1 = c00 / det,
+              // row1' = row1 - l10 row0  (row0 copied into the lanes of group q0+1 by one v_permlane16_swap per half),
+              // and the rank-2 update  C -= r0 row0^T row0 + (1/d1) row1'^T row1'  is ONE instruction with
+              // A = [-r0 row0 | -(1/d1) row1'] in groups q0, q0+1 (zero elsewhere), B = [row0; row1'].
+              // The two reciprocals are independent (det form), so the serial chain per PAIR is
+              // readlane, 2 fma, rcp, mul, fma, mul, select, instruction  (~2/3 of what two single pivots cost).
+              const int q0 = 2 * h, p0 = 4 * g + q0, p1 = p0 + 1;
               double u = C[g];
               asm volatile("" : "+v"(u));          // own registers: the instruction below then updates C in place
-              // the A operand of this pivot for everybody: -L[:, pv] = -r u in the lanes of group q, zero elsewhere (the
-              // B operand is then simply the tile's register g, unmasked: the other groups meet zeros).  ONE data store
-              // per pivot (a lone wavefront pays ~30 cycles per LDS instruction); LDS executes a wavefront's
-              // instructions in order, so the counter (same value from every lane: no exec juggling) becomes visible
-              // after the row
-              const double t = u * -r;
-              const double um = (lr == q) ? t : 0.0;
-              Piv[(par * 16 + pv) * 64 + lane] = um;
-              if (q == 3) Rcp[par * 16 + 4 * g + (lane & 3)] = (lane & 3) == 0 ? r4[0] : (lane & 3) == 1 ? r4[1] : (lane & 3) == 2 ? r4[2] : r4[3];
+              const double c00 = rdlane(u, q0 * 16 + p0), c01 = rdlane(u, q0 * 16 + p1), c11 = rdlane(u, (q0 + 1) * 16 + p1);
+              const double det = __builtin_fma(c00, c11, -(c01 * c01));
+              const double r0 = rcp2(c00);
+              const double rdet = rcp2(det);
+              const double r1 = c00 * rdet;
+              const double nl10 = -(c01 * r0);
+              const double u0b = row_even_to_odd(u);
+              const double u1 = __builtin_fma(nl10, u0b, u);          // row1' in the lanes of group q0 + 1
+              const bool in0 = lr == q0, in1 = lr == q0 + 1;
+              const double bv = in1 ? u1 : u;
+              // the A operand of this pair for everybody (the replaying wavefronts read -l10 out of it: element p1 of
+              // its first column).  ONE data store per pair (a lone wavefront pays ~30 cycles per LDS instruction); LDS
+              // executes a wavefront's instructions in order, so the counter (same value from every lane: no exec
+              // juggling) becomes visible after the data
+              const double av = in0 ? u * -r0 : in1 ? u1 * -r1 : 0.0;
+              Piv[(par * 8 + 2 * g + h) * 64 + lane] = av;
+              r4[q0] = r0; r4[q0 + 1] = r1;
+              if (h == 1) Rcp[par * 16 + 4 * g + (lane & 3)] = (lane & 3) == 0 ? r4[0] : (lane & 3) == 1 ? r4[1] : (lane & 3) == 2 ? r4[2] : r4[3];
               asm volatile("" ::: "memory");
-              __hip_atomic_store(&s_piv, 16 * k + pv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              wcs[pv] = um;                        // row pv of the unit upper factor (negated), lanes of group q
-              if (q == 3) { dlast = d; if (d == 0.0) anyzero = true; }
-              if (pv < 15) C = mfma(um, u, C);     // after the 16th pivot nothing of the tile is read again
+              __hip_atomic_store(&s_piv, 16 * k + p1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              wrow[g] += av;                       // disjoint lane groups: a select spelled as an add
+              anyzero |= (c00 == 0.0) | (det == 0.0);
+              dlast = det;
+              if (p1 < 15) C = mfma(av, bv, C);    // after the 16th pivot nothing of the tile is read again
             }
           }
         }
@@ -571,7 +598,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
         }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-          const double w = -((wcs[4 * g] + wcs[4 * g + 1]) + (wcs[4 * g + 2] + wcs[4 * g + 3]));
+          const double w = -wrow[g];
           const int I = 16 * k + lr + 4 * g, J = 16 * k + lc;
           if (I <= (J | 1) && I < n_pad && J <= cb) wm_store(I, J, I < J ? w : 0.0);
         }
@@ -587,29 +614,30 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
         if (wv == k + 1) LDLTM_T(8 + 8 * k + 3);
         LDLTM_T(80 + wv * 24 + 3 * k);
         d4 Rc = {0.0, 0.0, 0.0, 0.0}, nW = {0.0, 0.0, 0.0, 0.0};
-        // Four pivots at a time: one poll of the counter, the four rows and their 1/d in flight together, then four dependent
-        // instructions.  (Per-pivot hand-over with a look-ahead read was measured at ~270 cycles per pivot -- an LDS round trip
-        // per step on top of the instruction -- and let the long columns fall behind the diagonal; the group form costs the
-        // wavefront that holds the next diagonal tile ~150 cycles more at the end of a row and halves everybody's replay.)
-        const lds_vdp pivr = (lds_vdp)(Piv) + par * 16 * 64 + lane;
+        // One poll per pair: the pair's A operand comes from LDS, -l10 is read out of it, the second row is reduced by
+        // the first exactly as on the diagonal, then ONE instruction applies both pivots (~110 cycles per pair against
+        // ~230 on the diagonal wavefront, so the columns keep up and the wavefront that holds the next diagonal tile
+        // finishes one pair's work after the last pivot is published).
+        const lds_vdp pivr = (lds_vdp)(Piv) + par * 8 * 64 + lane;
         const lds_vdp rcpr = (lds_vdp)(Rcp) + par * 16 + lr;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           if (4 * g < npiv) {
-            poll_gt(&s_piv, 16 * k + 4 * g + 3);
-            double u4[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) u4[q] = pivr[(4 * g + q) * 64];
-            const double rsel = rcpr[4 * g];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int pv = 4 * g + q;
+            for (int h = 0; h < 2; h++) {
+              const int q0 = 2 * h, p1 = 4 * g + q0 + 1;
+              poll_gt(&s_piv, 16 * k + p1);
+              const double a = pivr[(2 * g + h) * 64];
               double xg = X[g];
               asm volatile("" : "+v"(xg));         // own registers: X is then updated in place
-              Rc[g] = (lr == q) ? xg : Rc[g];      // row pv of R
-              if (pv < 15) X = mfma(u4[q], xg, X); // X -= L[:, pv] R[pv, :]; the tile is dead after its 16th row
+              const double x0b = row_even_to_odd(xg);
+              const double nl10 = rdlane(a, q0 * 16 + p1);
+              const double rrow = (lr == q0 + 1) ? __builtin_fma(nl10, x0b, xg) : xg;   // rows p0, p1 of R in groups q0, q0+1
+              Rc[g] = (h == 0 || lr >= 2) ? rrow : Rc[g];
+              if (p1 < 15) X = mfma(a, rrow, X);   // X -= L[:, p0] R[p0, :] + L[:, p1] R[p1, :]; dead after its 16th row
             }
             // four rows complete: -W = -D^-1 R and the own diagonal tile (wv, wv) -= R^T W
+            const double rsel = rcpr[4 * g];
             nW[g] = Rc[g] * -rsel;
             D = mfma(Rc[g], nW[g], D);
           }
@@ -756,8 +784,8 @@ __host__ inline Launch pick(int n) {
   return L;
 }
 
-// St: the matrix as a tile image (tile_image_pos), b: right-hand side, x: solution, wglob: wglob_doubles() of scratch
-__host__ inline hipError_t launch(int n, const double* St, const double* b, double* x, int* ok, double* wglob, hipStream_t st) {
+// St: the bordered matrix as a tile image (see image_put_rhs / k_image_pad), x: solution, wglob: wglob_doubles() of scratch
+__host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st) {
   const Launch L = pick(n);
   static size_t attr[4] = {0, 0, 0, 0};
   const Geo g = make_geo(n);
@@ -767,7 +795,7 @@ __host__ inline hipError_t launch(int n, const double* St, const double* b, doub
     if (e != hipSuccess) return e;
     attr[which] = L.lds;
   }
-  void* args[] = {(void*)&n, (void*)&St, (void*)&b, (void*)&x, (void*)&ok, (void*)&wglob};   // the column kernel ignores wglob
+  void* args[] = {(void*)&n, (void*)&St, (void*)&x, (void*)&ok, (void*)&wglob};   // the column kernel ignores wglob
   return hipLaunchKernel(L.fn, dim3(1), dim3(kThreads), args, L.lds, st);
 }
 

@@ -89,13 +89,15 @@ int main(int argc, char** argv) {
     auto to_image = [&](const std::vector<double>& M2) {     // the kernels read the matrix as a tile image; poison the rest
       std::vector<double> im(ldltm::tile_image_doubles(n), std::nan(""));
       for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { const int pos = ldltm::tile_image_pos(r, c); if (pos >= 0) im[pos] = M2[(size_t)r * n + c]; }
+      for (int r = 0; r < n; r++) ldltm::image_put_rhs(im.data(), n, r, b[r]);      // the padding is left to k_image_pad
       return im;
     };
     std::vector<double> im = to_image(S);
     CK(hipFree(dS)); CK(hipMalloc(&dS, im.size() * 8));
     CK(hipMemcpy(dS, im.data(), im.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice));
+    CK(ldltm::launch_image_pad(n, dS, 0));
     CK(hipMemset(dx, 0, n * 8)); CK(hipMemset(dok, 0xFF, 4));
-    CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
+    CK(ldltm::launch(n, dS, dx, dok, dw, 0));
     CK(hipDeviceSynchronize());
     int ok = -7;
     CK(hipMemcpy(x.data(), dx, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost));
@@ -107,9 +109,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 200;
-    for (int i = 0; i < 10; i++) CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
+    for (int i = 0; i < 10; i++) CK(ldltm::launch(n, dS, dx, dok, dw, 0));
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; i++) CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
+    for (int i = 0; i < reps; i++) CK(ldltm::launch(n, dS, dx, dok, dw, 0));
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -127,6 +129,9 @@ int main(int argc, char** argv) {
     if (n == 120) {
       long long pr[512];
       CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltm::g_prof), sizeof(pr)));
+      printf("   columns loaded (start -> ready):");
+      for (int w = 0; w < 8; w++) printf(" %lld->%lld", pr[310 + w] - pr[0], pr[300 + w] - pr[0]);
+      printf("\n");
       for (int w = 1; w < 8; w++) {
         printf("   wave %d:", w);
         for (int k = 0; k < w; k++) printf(" r%d[%lld %lld %lld]", k, pr[80 + w * 24 + 3 * k] - pr[0], pr[80 + w * 24 + 3 * k + 1] - pr[0], k + 1 < w ? pr[80 + w * 24 + 3 * k + 2] - pr[0] : 0);
@@ -141,7 +146,8 @@ int main(int argc, char** argv) {
       for (int i = 0; i < n; i++) S2[i] = S2[(size_t)i * n] = 0.0;
       std::vector<double> im2 = to_image(S2);
       CK(hipMemcpy(dS, im2.data(), im2.size() * 8, hipMemcpyHostToDevice));
-      CK(ldltm::launch(n, dS, db, dx, dok, dw, 0));
+      CK(ldltm::launch_image_pad(n, dS, 0));
+      CK(ldltm::launch(n, dS, dx, dok, dw, 0));
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost));
       printf("zero pivot: ok=%d %s\n", ok, ok == 0 ? "ok" : "FAIL");
