@@ -134,6 +134,11 @@ __device__ __forceinline__ double rcp2(double d) {            // 1/d to ~1 ulp: 
   return x;
 }
 
+__device__ __forceinline__ double rcp1(double d) {            // hardware seed (4.5e-8) + one Newton step: 2e-15 relative
+  const double x = __builtin_amdgcn_rcp(d);                   // (tools/micro/fp64_latency.hip); 0 -> NaN, NaN -> NaN
+  return __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
+}
+
 #ifndef LDLTM_SLEEP
 #define LDLTM_SLEEP 1
 #endif
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
 #pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ int s_piv;                // pivots published so far (16 k + pv + 1)
-  __shared__ int s_rflag[kColT];       // per tile column j: rows k whose R_kj is published
+  __shared__ int s_rbits[kColT];       // per tile row k: bit j set once -W_kj is published
   __shared__ int s_rowdone[kColT];     // per tile row: wavefronts that finished it
   __shared__ int s_ok;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -482,34 +487,33 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
   double* const Wl = Rb + kColPanels * 256;             // unit upper factor, pair-packed
   if (wv == 0) LDLTM_T(0);
   if (tid == 0) { s_piv = 0; s_ok = 1; }
-  if (tid < kColT) { s_rflag[tid] = 0; s_rowdone[tid] = 0; }
+  if (tid < kColT) { s_rbits[tid] = 0; s_rowdone[tid] = 0; }
   __syncthreads();                     // the only barrier before the back-substitution: from here on the wavefronts run on flags
   LDLTM_T(310 + wv);
 
-  // ---- tile (i, wv) in slot i, two 16-byte loads per lane and tile, all in flight before the first use.  Wave-uniform
-  // conditions only around the loads (hipcc waits for a lane-predicated load before it issues the next one); a
-  // wavefront starts as soon as ITS column has arrived: wavefront 0 factors its single tile while the long columns
-  // are still streaming in
-  d4 acc[kColT];
+  // ---- the column's tiles, two 16-byte loads per lane and tile, all in flight before the first use, no branch around
+  // the loads (even a wave-uniform one makes hipcc drain the memory counter at the join: the column then arrives one
+  // tile per memory round trip; slots past the column re-read its first tile and are never used).
+  // Rt[j] is tile (k + j, wv) while tile row k is worked on: the trailing update of tile k+j writes its result into
+  // slot j-1 (a matrix instruction's destination need not be its accumulator), so the panel tile of the current row is
+  // always Rt[0] and no register is ever indexed at run time (hipcc turns that into 56 selects or into scratch memory).
+  // The diagonal tile (wv, wv) has registers of its own.
+  d4 Rt[kColT - 1], Dg;
   {
-    d4 sv[kColT];
-    // no branch at all around the loads (even a wave-uniform one makes hipcc drain the memory counter at the join:
-    // the column then arrives one tile per memory round trip); slots past the column re-read its last tile
     const int wc_ = min(wv, T - 1);
+    Dg = *reinterpret_cast<const d4*>(St + (size_t)tile_index(wc_, wc_) * 256 + 4 * lane);
 #pragma unroll
-    for (int i = 0; i < kColT; i++) sv[i] = *reinterpret_cast<const d4*>(St + (size_t)tile_index(min(i, wc_), wc_) * 256 + 4 * lane);
-#pragma unroll
-    for (int i = 0; i < kColT; i++) {
-      const bool on = i <= wv && wv < T;
-#pragma unroll
-      for (int g = 0; g < 4; g++) acc[i][g] = on ? sv[i][g] : 0.0;
-    }
+    for (int i = 0; i < kColT - 1; i++) Rt[i] = *reinterpret_cast<const d4*>(St + (size_t)tile_index(i < wc_ ? i : 0, wc_) * 256 + 4 * lane);
   }
   if (wv == 0) LDLTM_T(1);
   LDLTM_T(300 + wv);
 
   auto poll_gt = [&](int* w, int k) {
+#ifdef LDLTM_COLSLEEP
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k) __builtin_amdgcn_s_sleep(LDLTM_COLSLEEP);
+#else
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k) { }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
   auto wait_free = [&](int k) {   // the pivot ring's slot k&3 was last used by tile row k-4 (T-1-(k-4) wavefronts replayed it)
@@ -534,15 +538,18 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
         // one branch per four pivots, the factor's rows stay in their registers until the loop is over, a zero pivot
         // is detected from the last one (it poisons everything after it).
         LDLTM_T(8 + 8 * k + 0);
-        d4 C = {0.0, 0.0, 0.0, 0.0};
+        d4 C = Dg;
+        // Every FP64 vector instruction costs this wavefront 8 cycles whether anything depends on it or not (and the
+        // matrix instruction shares their pipe), so the loop holds only what the next pivot needs: the rows of the
+        // factor stay in registers until it is over, and a zero pivot is not tested for -- 1/0 becomes NaN in the
+        // Newton step and NaN reaches every later pivot of the matrix, so the LAST pair's reciprocals tell.
+        double wav[8];                           // the pairs' A operands = rows of the unit upper factor (negated)
 #pragma unroll
-        for (int s = 0; s < kColT; s++)
-          if (s == k) C = acc[s];
-        double wrow[4] = {0.0, 0.0, 0.0, 0.0};   // rows of the unit upper factor (negated), row 4g + lr in register g
-        double dlast = 1.0;
-        double r4[4] = {1.0, 1.0, 1.0, 1.0};
-        bool anyzero = false;
+        for (int i = 0; i < 8; i++) wav[i] = 0.0;
+        double rlast = 1.0;
+#ifndef LDLTM_ALONE
         wait_free(k);
+#endif
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           if (g == 2) LDLTM_T(8 + 8 * k + 6);
@@ -554,15 +561,13 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
               // row1' = row1 - l10 row0  (row0 copied into the lanes of group q0+1 by one v_permlane16_swap per half),
               // and the rank-2 update  C -= r0 row0^T row0 + (1/d1) row1'^T row1'  is ONE instruction with
               // A = [-r0 row0 | -(1/d1) row1'] in groups q0, q0+1 (zero elsewhere), B = [row0; row1'].
-              // The two reciprocals are independent (det form), so the serial chain per PAIR is
-              // readlane, 2 fma, rcp, mul, fma, mul, select, instruction  (~2/3 of what two single pivots cost).
               const int q0 = 2 * h, p0 = 4 * g + q0, p1 = p0 + 1;
               double u = C[g];
               asm volatile("" : "+v"(u));          // own registers: the instruction below then updates C in place
               const double c00 = rdlane(u, q0 * 16 + p0), c01 = rdlane(u, q0 * 16 + p1), c11 = rdlane(u, (q0 + 1) * 16 + p1);
               const double det = __builtin_fma(c00, c11, -(c01 * c01));
-              const double r0 = rcp2(c00);
-              const double rdet = rcp2(det);
+              const double r0 = rcp1(c00);
+              const double rdet = rcp1(det);
               const double r1 = c00 * rdet;
               const double nl10 = -(c01 * r0);
               const double u0b = row_even_to_odd(u);
@@ -570,24 +575,22 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
               const bool in0 = lr == q0, in1 = lr == q0 + 1;
               const double bv = in1 ? u1 : u;
               // the A operand of this pair for everybody (the replaying wavefronts read -l10 out of it: element p1 of
-              // its first column).  ONE data store per pair (a lone wavefront pays ~30 cycles per LDS instruction); LDS
+              // its first column) and the two reciprocals.  A lone wavefront pays ~30 cycles per LDS instruction; LDS
               // executes a wavefront's instructions in order, so the counter (same value from every lane: no exec
               // juggling) becomes visible after the data
               const double av = in0 ? u * -r0 : in1 ? u1 * -r1 : 0.0;
               Piv[(par * 8 + 2 * g + h) * 64 + lane] = av;
-              r4[q0] = r0; r4[q0 + 1] = r1;
-              if (h == 1) Rcp[par * 16 + 4 * g + (lane & 3)] = (lane & 3) == 0 ? r4[0] : (lane & 3) == 1 ? r4[1] : (lane & 3) == 2 ? r4[2] : r4[3];
+              Rcp[par * 16 + p0 + (lane & 1)] = (lane & 1) ? r1 : r0;
               asm volatile("" ::: "memory");
               __hip_atomic_store(&s_piv, 16 * k + p1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              wrow[g] += av;                       // disjoint lane groups: a select spelled as an add
-              anyzero |= (c00 == 0.0) | (det == 0.0);
-              dlast = det;
+              wav[2 * g + h] = av;
+              if (h == 1) rlast = r0 + r1;       // the loop ends on a group of four
               if (p1 < 15) C = mfma(av, bv, C);    // after the 16th pivot nothing of the tile is read again
             }
           }
         }
         LDLTM_T(8 + 8 * k + 1);
-        if (anyzero || !(fabs(dlast) < INFINITY)) s_ok = 0;
+        if (!(fabs(rlast) < INFINITY)) s_ok = 0;
         if (k > 0) {                               // the deferred stores of the panel tile (k-1, k)
           const int J = 16 * wv + lc;
           if (J <= cb) {
@@ -598,53 +601,81 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
         }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-          const double w = -wrow[g];
+          const double w = -(wav[2 * g] + wav[2 * g + 1]);       // disjoint lane groups
           const int I = 16 * k + lr + 4 * g, J = 16 * k + lc;
           if (I <= (J | 1) && I < n_pad && J <= cb) wm_store(I, J, I < J ? w : 0.0);
         }
         LDLTM_T(8 + 8 * k + 2);
       } else {
-        // ---- panel tile (k, wv): replay the pivots one step behind the diagonal wavefront
-        d4 X = {0.0, 0.0, 0.0, 0.0}, D = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < kColT; s++) {
-          if (s == k) X = acc[s];
-          if (s == wv) D = acc[s];
-        }
+#ifdef LDLTM_ALONE
+        continue;                                  // timing experiment: nobody replays (results are garbage)
+#endif
+        // ---- panel tile (k, wv): replay the pivots behind the diagonal wavefront.
+        // Per pair: its A operand comes from LDS, -l10 is read out of it, the second row is reduced by the first exactly as
+        // on the diagonal, then ONE instruction applies both pivots (~200 cycles per pair with the update of the own
+        // diagonal tile, tools/micro/replay_chain.hip; the diagonal wavefront needs ~400).  An LDS round trip costs a lone
+        // wavefront 120-200 cycles and an LDS instruction ~25, so every wait reads what it waits for in the SAME round
+        // trip: the counter first, then speculatively all eight operands and the reciprocals -- LDS executes this
+        // wavefront's reads in order and the diagonal's writes in order, so whatever the counter value covers is the
+        // published data.  Pairs it does not cover are read again, counter first, one round trip per try.
+        d4 X = Rt[0];
+        d4 D = Dg;
         if (wv == k + 1) LDLTM_T(8 + 8 * k + 3);
         LDLTM_T(80 + wv * 24 + 3 * k);
         d4 Rc = {0.0, 0.0, 0.0, 0.0}, nW = {0.0, 0.0, 0.0, 0.0};
-        // One poll per pair: the pair's A operand comes from LDS, -l10 is read out of it, the second row is reduced by
-        // the first exactly as on the diagonal, then ONE instruction applies both pivots (~110 cycles per pair against
-        // ~230 on the diagonal wavefront, so the columns keep up and the wavefront that holds the next diagonal tile
-        // finishes one pair's work after the last pivot is published).
         const lds_vdp pivr = (lds_vdp)(Piv) + par * 8 * 64 + lane;
         const lds_vdp rcpr = (lds_vdp)(Rcp) + par * 16 + lr;
+        auto pair_step = [&](const int g, const int h, const double a) {
+          const int q0 = 2 * h, p1 = 4 * g + q0 + 1;
+          double xg = X[g];
+          asm volatile("" : "+v"(xg));         // own registers: X is then updated in place
+          const double x0b = row_even_to_odd(xg);
+          const double nl10 = rdlane(a, q0 * 16 + p1);
+          const double rrow = (lr == q0 + 1) ? __builtin_fma(nl10, x0b, xg) : xg;   // rows p0, p1 of R in groups q0, q0+1
+          Rc[g] = (h == 0 || lr >= 2) ? rrow : Rc[g];
+          if (p1 < 15) X = mfma(a, rrow, X);   // X -= L[:, p0] R[p0, :] + L[:, p1] R[p1, :]; dead after its 16th row
+        };
+        double a8[8], rs[4];
+        const int c0 = __hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; i++) a8[i] = pivr[i * 64];
+#pragma unroll
+        for (int g = 0; g < 4; g++) rs[g] = rcpr[4 * g];
+        const int seen = __builtin_amdgcn_readfirstlane(c0);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           if (4 * g < npiv) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-              const int q0 = 2 * h, p1 = 4 * g + q0 + 1;
-              poll_gt(&s_piv, 16 * k + p1);
-              const double a = pivr[(2 * g + h) * 64];
-              double xg = X[g];
-              asm volatile("" : "+v"(xg));         // own registers: X is then updated in place
-              const double x0b = row_even_to_odd(xg);
-              const double nl10 = rdlane(a, q0 * 16 + p1);
-              const double rrow = (lr == q0 + 1) ? __builtin_fma(nl10, x0b, xg) : xg;   // rows p0, p1 of R in groups q0, q0+1
-              Rc[g] = (h == 0 || lr >= 2) ? rrow : Rc[g];
-              if (p1 < 15) X = mfma(a, rrow, X);   // X -= L[:, p0] R[p0, :] + L[:, p1] R[p1, :]; dead after its 16th row
+              const int need = 16 * k + 4 * g + 2 * h + 1;       // the counter exceeds this once the pair is published
+              if (seen <= need) {
+                for (;;) {
+                  const int c = __hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  asm volatile("" ::: "memory");
+                  a8[2 * g + h] = pivr[(2 * g + h) * 64];
+                  if (h == 1) rs[g] = rcpr[4 * g];
+                  if (__builtin_amdgcn_readfirstlane(c) > need) break;
+                }
+              }
+              pair_step(g, h, a8[2 * g + h]);
             }
             // four rows complete: -W = -D^-1 R and the own diagonal tile (wv, wv) -= R^T W
-            const double rsel = rcpr[4 * g];
-            nW[g] = Rc[g] * -rsel;
+            nW[g] = Rc[g] * -rs[g];
             D = mfma(Rc[g], nW[g], D);
+            if (g == 0 && k > 0) {
+              // the factor store of the PREVIOUS tile row (for the back-substitution) and its completion count (frees the
+              // pivot ring four rows later) are nobody's next step: issued here, where a wavefront that keeps up waits anyway
+              const int J = 16 * wv + lc;
+              if (J <= cb) {
+#pragma unroll
+                for (int g2 = 0; g2 < 4; g2++) wm_store(16 * (k - 1) + lr + 4 * g2, J, -nWlast[g2]);
+              }
+              row_done(k - 1);
+            }
           }
         }
-#pragma unroll
-        for (int s = 0; s < kColT; s++)
-          if (s == wv) acc[s] = D;
+        Dg = D;
         if (wv == k + 1) LDLTM_T(8 + 8 * k + 4);
         LDLTM_T(80 + wv * 24 + 3 * k + 1);
         // publish -W for the trailing tiles of the other columns (their B operand is their own unscaled R)
@@ -652,33 +683,38 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
 #pragma unroll
         for (int g = 0; g < 4; g++) rb[g * 64] = nW[g];
         asm volatile("" ::: "memory");
-        __hip_atomic_store(&s_rflag[wv], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_or(&s_rbits[k], 1 << wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (wv == k + 1) LDLTM_T(8 + 8 * k + 5);
-        if (wv == k + 1) {
-          nWlast = nW;                             // next: this wavefront's own pivots; the factor store can wait
-        } else {
-          // ---- trailing tiles (i, wv), k < i < wv:  -= W_ki^T R_k,wv
+        nWlast = nW;
+        if (wv > k + 1) {
+          // ---- trailing tiles (k + j, wv), 0 < j < wv - k:  -= W_k,k+j^T R_k,wv.  The row's publication bits and every
+          // operand in one round trip (the same speculation as above), then the instructions
+          const int nt = wv - k - 1;
+          const int want = ((1 << wv) - 1) & ~((2 << k) - 1);       // columns k+1 .. wv-1
+          double ta[kColT - 2][4];
+          for (;;) {
+            const int f = __hip_atomic_load(&s_rbits[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
 #pragma unroll
-          for (int s = 0; s < kColT; s++) {
-            if (s > k && s < wv) {
-              poll_gt(&s_rflag[s], k);
-              const double* const pa = rb_of(k, s);
-              double a[4];
+            for (int j = 1; j < kColT - 1; j++) {
+              if (j <= nt) {
+                const lds_vdp pa = (lds_vdp)rb_of(k, k + j);
 #pragma unroll
-              for (int q = 0; q < 4; q++) a[q] = pa[q * 64];
-              d4 c = acc[s];
+                for (int q = 0; q < 4; q++) ta[j - 1][q] = pa[q * 64];
+              }
+            }
+            if ((__builtin_amdgcn_readfirstlane(f) & want) == want) break;
+          }
 #pragma unroll
-              for (int q = 0; q < 4; q++) c = mfma(a[q], Rc[q], c);
-              acc[s] = c;
+          for (int j = 1; j < kColT - 1; j++) {
+            if (j <= nt) {
+              d4 c = Rt[j];
+#pragma unroll
+              for (int q = 0; q < 4; q++) c = mfma(ta[j - 1][q], Rc[q], c);
+              Rt[j - 1] = c;
             }
           }
-          const int J = 16 * wv + lc;
-          if (J <= cb) {
-#pragma unroll
-            for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, -nW[g]);
-          }
           LDLTM_T(80 + wv * 24 + 3 * k + 2);
-          row_done(k);
         }
       }
     }
