@@ -688,31 +688,42 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
         nWlast = nW;
         if (wv > k + 1) {
           // ---- trailing tiles (k + j, wv), 0 < j < wv - k:  -= W_k,k+j^T R_k,wv.  The row's publication bits and every
-          // operand in one round trip (the same speculation as above), then the instructions
-          const int nt = wv - k - 1;
+          // operand in one round trip (the same speculation as above), then the instructions, the tiles' chains
+          // interleaved (a dependent matrix instruction waits 82 cycles, an independent one issues after 66).  One
+          // straight-line variant per tile count: with a condition per tile hipcc carries every slot through ~100 register
+          // copies per tile row.
           const int want = ((1 << wv) - 1) & ~((2 << k) - 1);       // columns k+1 .. wv-1
-          double ta[kColT - 2][4];
-          for (;;) {
-            const int f = __hip_atomic_load(&s_rbits[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
+          auto trailing = [&](auto ntc) {
+            constexpr int NT = decltype(ntc)::value;
+            double ta[NT][4];
+            for (;;) {
+              const int f = __hip_atomic_load(&s_rbits[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              asm volatile("" ::: "memory");
 #pragma unroll
-            for (int j = 1; j < kColT - 1; j++) {
-              if (j <= nt) {
-                const lds_vdp pa = (lds_vdp)rb_of(k, k + j);
+              for (int j = 0; j < NT; j++) {
+                const lds_vdp pa = (lds_vdp)rb_of(k, k + 1 + j);
 #pragma unroll
-                for (int q = 0; q < 4; q++) ta[j - 1][q] = pa[q * 64];
+                for (int q = 0; q < 4; q++) ta[j][q] = pa[q * 64];
               }
+              if ((__builtin_amdgcn_readfirstlane(f) & want) == want) break;
             }
-            if ((__builtin_amdgcn_readfirstlane(f) & want) == want) break;
-          }
+            d4 c[NT];
 #pragma unroll
-          for (int j = 1; j < kColT - 1; j++) {
-            if (j <= nt) {
-              d4 c = Rt[j];
+            for (int j = 0; j < NT; j++) c[j] = Rt[j + 1];
 #pragma unroll
-              for (int q = 0; q < 4; q++) c = mfma(ta[j - 1][q], Rc[q], c);
-              Rt[j - 1] = c;
-            }
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+              for (int j = 0; j < NT; j++) c[j] = mfma(ta[j][q], Rc[q], c[j]);
+#pragma unroll
+            for (int j = 0; j < NT; j++) Rt[j] = c[j];
+          };
+          switch (wv - k - 1) {
+            case 1: trailing(std::integral_constant<int, 1>{}); break;
+            case 2: trailing(std::integral_constant<int, 2>{}); break;
+            case 3: trailing(std::integral_constant<int, 3>{}); break;
+            case 4: trailing(std::integral_constant<int, 4>{}); break;
+            case 5: trailing(std::integral_constant<int, 5>{}); break;
+            default: trailing(std::integral_constant<int, 6>{}); break;
           }
           LDLTM_T(80 + wv * 24 + 3 * k + 2);
         }
