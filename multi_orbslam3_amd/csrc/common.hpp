@@ -76,6 +76,12 @@ struct StreamSignal {
   int init() { int rc = word.reserve(16); if (rc) return rc; word.h[0] = 0; return ORBG_OK; }
   void release() { word.release(); }
   int post(hipStream_t st);      // enqueue the signal kernel (misc.cpp)
+  // for kernels that post the signal themselves (DoneSig below): next sequence number + the word's device address
+  int arm(unsigned* seq_out, volatile unsigned** flag_out) {
+    if (!word.h) { int rc = init(); if (rc) return rc; }
+    *seq_out = ++seq; *flag_out = (volatile unsigned*)word.d;
+    return ORBG_OK;
+  }
   int wait(hipStream_t st);      // spin until the posted signal arrives (misc.cpp)
   int sync(hipStream_t st) { int rc = post(st); return rc ? rc : wait(st); }
 };

@@ -1772,7 +1772,8 @@ struct ExtractPending {
   bool stereo_out = false;
   int n_res[2] = {0, 0};
 };
-int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n);
+int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
+                         volatile unsigned* done_flag, unsigned done_seq);
 void orbm_internal_set_n(orbm_frame* f, int n);
 int orbx_internal_kp_capacity(orbx_handle* h);
 static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror);
@@ -1846,16 +1847,22 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     hipLaunchKernelGGL(orient_desc_gpu_kernel, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
                        oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,
                        want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d, h->d_overflow.p);
-    bool stereo_out = false;
+    bool stereo_out = false, posted = false;
     if (post) {
       if (post->stereo && ncams == 2) {
         stereo_out = post->uright || post->depth;
         if ((rc = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr))) return rc;
       }
-      if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p))) return rc;
+      if (post->frame) {
+        // the grid build is the last kernel of the chain: it posts the completion word itself (no signal kernel)
+        unsigned seq; volatile unsigned* flag;
+        if ((rc = h->sig.arm(&seq, &flag))) return rc;
+        if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq))) return rc;
+        posted = true;
+      }
     }
     ORBG_HIP(hipGetLastError());
-    if ((rc = h->sig.post(st))) return rc;          // completion word in pinned memory
+    if (!posted && (rc = h->sig.post(st))) return rc;          // completion word in pinned memory
     ExtractPending local;
     if (submit_only && !h->pending) h->pending = new ExtractPending();
     ExtractPending& c = submit_only ? *h->pending : local;
@@ -1960,7 +1967,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
         stereo_out = true;
       }
     }
-    if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st, nullptr))) return rc;
+    if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st, nullptr, nullptr, 0u))) return rc;
   }
   const bool want_out = kps_out[0] || desc_out[0] || kps_out[1] || desc_out[1];
   if (n_sel_total > 0) {

@@ -79,9 +79,9 @@ __device__ __forceinline__ float norm3d(const float* v) {
 // ------------------------------------------------------------------------------------------------
 // grid  (Frame::AssignFeaturesToGrid / PosInGrid, S/Frame.cc:360-391,699-709); CSR, cell = ix*48+iy
 
-__global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* __restrict__ kps, FrameParams fp,
-                                                         int* __restrict__ cell_of, int* __restrict__ cell_start,
-                                                         int* __restrict__ cell_items, const int* __restrict__ d_n) {
+__device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict__ kps, FrameParams fp,
+                                                int* __restrict__ cell_of, int* __restrict__ cell_start,
+                                                int* __restrict__ cell_items, const int* __restrict__ d_n) {
   __shared__ int cnt[kCells];
   __shared__ int s_items[kGridLdsItems];   // cell_items staged in LDS (frames of up to kGridLdsItems features): fill + per-cell
                                            // sort without a global-memory round trip per step
@@ -163,6 +163,19 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* _
       while (j >= s0 && cell_items[j] > key) { cell_items[j + 1] = cell_items[j]; j--; }
       cell_items[j + 1] = key;
     }
+  }
+}
+
+// done_flag != nullptr: the Frame constructor's completion word.  The last kernel of the chain posts it itself: everything the
+// earlier kernels wrote for the host is complete at their end, and nothing this kernel writes is read by the host.
+__global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* __restrict__ kps, FrameParams fp,
+                                                         int* __restrict__ cell_of, int* __restrict__ cell_start,
+                                                         int* __restrict__ cell_items, const int* __restrict__ d_n,
+                                                         volatile unsigned* done_flag, unsigned done_seq) {
+  grid_build_body(kps, fp, cell_of, cell_start, cell_items, d_n);
+  if (done_flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) *done_flag = done_seq;
   }
 }
 
@@ -824,7 +837,7 @@ static int frame_reserve(orbm_frame* f, int n) {
 
 static int frame_build_grid(orbm_frame* f) {
   hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, f->stream, f->kps_p, f->fp, f->d_cell_of.p,
-                     f->d_cell_start.p, f->d_cell_items.p, (const int*)nullptr);
+                     f->d_cell_start.p, f->d_cell_items.p, (const int*)nullptr, (volatile unsigned*)nullptr, 0u);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;
 }
@@ -903,7 +916,8 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
 // Used by orbx_frame_stereo_dev (extractor.hip): alias the extractor's left features and launch the grid build on the
 // EXTRACTOR's stream, behind the descriptor / stereo kernels; the caller synchronises that stream once.
 int orbx_internal_kp_capacity(orbx_handle* h);   // extractor.hip
-int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n) {
+int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
+                         volatile unsigned* done_flag, unsigned done_seq) {
   if (!f || !h || !v) return ORBG_BAD_ARG;
   const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n0; hipStream_t xs;
   int rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n0, &xs);
@@ -918,7 +932,7 @@ int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v
   f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
   f->stream = stream;              // the extractor's stream: searches on this frame follow its constructor in order
   hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
-                     f->d_cell_items.p, d_n);
+                     f->d_cell_items.p, d_n, done_flag, done_seq);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;
 }
@@ -1250,6 +1264,9 @@ static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
     f->search_seq++;
     launch((int)std::min<size_t>(f->list.cap, (size_t)1 << 30), cur, nxt);
     ORBG_HIP(hipGetLastError());
+    // (the completion word cannot be posted by the search kernel itself: its results go to pinned memory from wavefronts on
+    // eight XCDs, and only a system-scope release per wavefront -- a whole-L2 write-back each, 2.5x on the kernel -- orders
+    // them before the word; a drained memory counter does not: measured, the host saw the word before the results)
     if ((rc = f->sig.sync(f->stream))) return rc;
     // the end of the furthest list segment tells whether the overflow region was large enough
     size_t total = 0;
