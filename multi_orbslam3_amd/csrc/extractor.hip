@@ -1445,6 +1445,7 @@ struct orbx_handle {
   int profile_interval = 1;         // level-1 brackets on every k-th extraction only (an event pair costs ~5 us of stream time)
   unsigned long long extract_calls = 0;
   double fast_ms_sum = 0; long fast_ms_n = 0;   // accumulated bracket times of fast_cells_kernel
+  struct CtorGraph* cgraph = nullptr;          // captured kernel chain of the device-resident Frame constructor
 };
 
 // Owned / needed pixel ranges of every level for the level-0 tiles of one axis (see pyr_tower_kernel).
@@ -1712,10 +1713,13 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
   return ORBG_OK;
 }
 
+static void ctor_graph_free(struct CtorGraph* g);
+
 extern "C" int orbx_destroy(orbx_handle* h) {
   if (!h) return ORBG_BAD_ARG;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  ctor_graph_free(h->cgraph);
   h->d_pyr.release(); h->d_img.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_tower_x.release(); h->d_tower_y.release(); h->d_cells.release();
   h->d_slots.release(); h->d_counts.release(); h->hdr.release(); h->cand.release(); h->sel.release();
   h->d_kps.release(); h->d_desc.release(); h->h_kps.release(); h->h_desc.release();
@@ -1778,6 +1782,42 @@ void orbm_internal_set_n(orbm_frame* f, int n);
 int orbx_internal_kp_capacity(orbx_handle* h);
 static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror);
 
+// The device-resident Frame constructor is a fixed chain of kernels (pyramid, FAST, gather, quad-trees, descriptors, stereo):
+// only the image pointers change from call to call.  Submitting it as one executable graph costs the tracking thread one
+// launch instead of seven (~3.2 us of host time each: 22.5 us for the chain, measured inside this function).  The chain is captured from the stream the second time a call repeats
+// the previous one's configuration (the first pass sizes every buffer; nothing may allocate during capture); any change of
+// a launch parameter -- a regrown buffer, another image size -- drops the graph.  ORBG_CTOR_GRAPH=1 enables it (see below).
+struct CtorKey {
+  const void* ptrs[24];
+  int ints[16];
+  float flts[2];
+};
+struct CtorGraph {
+  CtorKey key{};            // configuration of the previous call
+  bool key_valid = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipGraphNode_t first = nullptr;   // the pyramid kernel: the only node with per-call arguments (the images)
+  // argument block of that node
+  const uint8_t* a_img0 = nullptr; const uint8_t* a_img1 = nullptr; int a_stride = 0; uint8_t* a_pyr = nullptr; PyrGeom a_g{};
+  const ResizeTap* a_xtab = nullptr; const ResizeTap* a_ytab = nullptr; const TowerAxis* a_tx = nullptr; const TowerAxis* a_ty = nullptr;
+  dim3 grid{1, 1, 1};
+  void drop() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    exec = nullptr; graph = nullptr; first = nullptr;
+  }
+};
+// Measured on MI355X / ROCm 7.2 (bench.py C2, 3 x 3000 steps each way): hipGraphLaunch of the seven-kernel chain costs the
+// host what the seven launches cost (extract stage 45.4-46.0 us with, 45.3-46.2 us without), so it is off unless asked for.
+static const bool g_ctor_graph = getenv("ORBG_CTOR_GRAPH") && atoi(getenv("ORBG_CTOR_GRAPH")) != 0;
+
+static long g_cg_replays = 0, g_cg_captures = 0, g_cg_misses = 0, g_cg_ineligible = 0;
+static void ctor_graph_free(CtorGraph* g) {
+  if (getenv("ORBG_CTOR_GRAPH_STATS")) fprintf(stderr, "[orbgpu] ctor graph: %ld replays, %ld captures, %ld key changes, %ld ineligible calls\n", g_cg_replays, g_cg_captures, g_cg_misses, g_cg_ineligible);
+  if (g) { g->drop(); delete g; }
+}
+
 // Core: cams_mask selects which cameras of the rig are processed; d_img are device pointers.
 static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img0, const uint8_t* d_img1, int w, int hgt,
                         int stride, const int lap[2][2], orbx_keypoint* kps_out[2], uint8_t* desc_out[2], const int cap[2],
@@ -1801,23 +1841,6 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   int prof = h->profile;
   if (prof == 1 && h->profile_interval > 1 && (h->extract_calls % (unsigned)h->profile_interval) != 0) prof = 0;
   h->extract_calls++;
-  if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[0], st));
-  {
-    if (h->tower_T > 0) {
-      hipLaunchKernelGGL(pyr_tower_kernel, dim3(h->tower_ntx, h->tower_nty, ncams), dim3(kTwThreads), 0, st, d_img0, d_img1 ? d_img1 : d_img0,
-                         stride, h->d_pyr.p, g, h->d_xtab.p, h->d_ytab.p, h->d_tower_x.p, h->d_tower_y.p);
-    } else {
-      const LevelGeom& L0 = g.lv[0];
-      dim3 grid((L0.w + 2 * kEdge + 63) / 64, (L0.h + 2 * kEdge + 3) / 4, ncams);
-      hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, d_img0, d_img1 ? d_img1 : d_img0, stride, h->d_pyr.p, g);
-      for (int l = 1; l < nl; l++) {
-        const LevelGeom& L = g.lv[l];
-        dim3 gr((L.w + 2 * kEdge + 63) / 64, (L.h + 2 * kEdge + 3) / 4, ncams);
-        hipLaunchKernelGGL(pyr_resize_kernel, gr, dim3(256), 0, st, h->d_pyr.p, g, l, h->d_xtab.p, h->d_ytab.p);
-      }
-    }
-  }
-  if (prof >= 1) ORBG_HIP(hipEventRecord(h->ev[1], st));
   // The quad-trees run on the GPU unless the lapping area splits an image (only the fisheye-stereo path does that):
   // reverse = whole image inside [lap0, lap1] (mono Frame ctor), plain = nothing inside.
   bool use_gpu = h->gpu_octree && n_cells > 0 && !force_host;
@@ -1830,29 +1853,117 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   }
   h->last_was_gpu = use_gpu;
   if (!use_gpu) h->pool->prepare();              // wake the host quad-tree workers only when they will be used
-  if (n_cells > 0) {
-    hipLaunchKernelGGL(fast_cells_kernel, dim3(8 * ((n_cells + 7) / 8), ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
-                       std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
-    if (prof >= 1) ORBG_HIP(hipEventRecord(h->ev[7], st));
-    hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
-                       h->d_cells.p, n_cells, ncams, use_gpu ? h->d_hdr.p : h->hdr.d, use_gpu ? h->d_cand.p : h->cand.d, h->cand_cap);
-  }
-  if (use_gpu) {
-    // ---- everything stays on the device: quad-trees -> descriptors -> (stereo, grid) -> ONE synchronisation
-    OctCfg oc = h->octcfg;
-    oc.n_cams = ncams;                          // cameras processed by THIS call (a rig handle may extract one image)
-    hipLaunchKernelGGL(octree_kernel, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
-                       h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap);
-    const bool want_desc = desc_out[0] || desc_out[1];
-    hipLaunchKernelGGL(orient_desc_gpu_kernel, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
-                       oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,
-                       want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d, h->d_overflow.p);
-    bool stereo_out = false, posted = false;
-    if (post) {
-      if (post->stereo && ncams == 2) {
-        stereo_out = post->uright || post->depth;
-        if ((rc = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr))) return rc;
+  const bool want_desc = desc_out[0] || desc_out[1];
+  const bool do_stereo = use_gpu && post && post->stereo && ncams == 2;
+  const bool stereo_out = do_stereo && (post->uright || post->depth);
+  OctCfg oc = h->octcfg;
+  oc.n_cams = ncams;                          // cameras processed by THIS call (a rig handle may extract one image)
+  const uint8_t* const img1 = d_img1 ? d_img1 : d_img0;
+  // every launch of the chain up to (not including) the grid build; prof_ > 0 adds the event brackets
+  auto launch_chain = [&](int prof_) -> int {
+    if (prof_ >= 2) ORBG_HIP(hipEventRecord(h->ev[0], st));
+    if (h->tower_T > 0) {
+      hipLaunchKernelGGL(pyr_tower_kernel, dim3(h->tower_ntx, h->tower_nty, ncams), dim3(kTwThreads), 0, st, d_img0, img1,
+                         stride, h->d_pyr.p, g, h->d_xtab.p, h->d_ytab.p, h->d_tower_x.p, h->d_tower_y.p);
+    } else {
+      const LevelGeom& L0 = g.lv[0];
+      dim3 grid((L0.w + 2 * kEdge + 63) / 64, (L0.h + 2 * kEdge + 3) / 4, ncams);
+      hipLaunchKernelGGL(pyr_level0_kernel, grid, dim3(256), 0, st, d_img0, img1, stride, h->d_pyr.p, g);
+      for (int l = 1; l < nl; l++) {
+        const LevelGeom& L = g.lv[l];
+        dim3 gr((L.w + 2 * kEdge + 63) / 64, (L.h + 2 * kEdge + 3) / 4, ncams);
+        hipLaunchKernelGGL(pyr_resize_kernel, gr, dim3(256), 0, st, h->d_pyr.p, g, l, h->d_xtab.p, h->d_ytab.p);
       }
+    }
+    if (prof_ >= 1) ORBG_HIP(hipEventRecord(h->ev[1], st));
+    if (n_cells > 0) {
+      hipLaunchKernelGGL(fast_cells_kernel, dim3(8 * ((n_cells + 7) / 8), ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
+                         std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
+      if (prof_ >= 1) ORBG_HIP(hipEventRecord(h->ev[7], st));
+      hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
+                         h->d_cells.p, n_cells, ncams, use_gpu ? h->d_hdr.p : h->hdr.d, use_gpu ? h->d_cand.p : h->cand.d, h->cand_cap);
+    }
+    if (use_gpu) {
+      // ---- everything stays on the device: quad-trees -> descriptors -> (stereo, grid) -> ONE synchronisation
+      hipLaunchKernelGGL(octree_kernel, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
+                         h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap);
+      hipLaunchKernelGGL(orient_desc_gpu_kernel, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
+                         oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,
+                         want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d, h->d_overflow.p);
+      if (do_stereo) {
+        const int rcs = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr);
+        if (rcs) return rcs;
+      }
+    }
+    return ORBG_OK;
+  };
+  bool replayed = false;
+  if (g_ctor_graph && use_gpu && prof == 0 && h->profile < 2 && h->tower_T > 0) {
+    CtorKey key;
+    memset(&key, 0, sizeof(key));
+    const void* kp[] = {h->d_pyr.p, h->d_xtab.p, h->d_ytab.p, h->d_tower_x.p, h->d_tower_y.p, h->d_cells.p, h->d_slots.p, h->d_counts.p,
+                        h->d_hdr.p, h->d_cand.p, h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->d_kps.p, h->d_desc.p, h->h_kps.d,
+                        want_desc ? h->h_desc.d : nullptr, h->d_nkp.p, h->h_nkp.d, h->d_uright.p, h->d_depth.p, h->d_sad.p,
+                        stereo_out ? h->h_stereo.d : nullptr};
+    static_assert(sizeof(kp) <= sizeof(key.ptrs), "CtorKey::ptrs too small");
+    memcpy(key.ptrs, kp, sizeof(kp));
+    const int ki[] = {w, hgt, stride, ncams, n_cells, h->cfg.ini_th_fast, h->cfg.min_th_fast, h->cand_cap, h->sel_bound, reverse[0],
+                      reverse[1], (int)do_stereo, h->tower_ntx, h->tower_nty, nl};
+    static_assert(sizeof(ki) <= sizeof(key.ints), "CtorKey::ints too small");
+    memcpy(key.ints, ki, sizeof(ki));
+    key.flts[0] = do_stereo ? post->bf : 0.f; key.flts[1] = do_stereo ? post->b : 0.f;
+    if (!h->cgraph) h->cgraph = new CtorGraph();
+    CtorGraph& cg = *h->cgraph;
+    if (!(cg.key_valid && memcmp(&cg.key, &key, sizeof(key)) == 0)) {
+      cg.drop();                                  // first call with this configuration: plain launches below
+      g_cg_misses++;
+      cg.key = key; cg.key_valid = true;
+    } else {
+      if (!cg.exec) {
+        // second call in a row with the same configuration: record the chain (nothing executes during the capture)
+        hipGraph_t gr = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int rcc = launch_chain(0);
+          const hipError_t ee = hipStreamEndCapture(st, &gr);
+          hipGraphExec_t ex = nullptr;
+          hipGraphNode_t root = nullptr;
+          size_t n_root = 1;
+          if (rcc == ORBG_OK && ee == hipSuccess && gr && hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess &&
+              hipGraphGetRootNodes(gr, &root, &n_root) == hipSuccess && n_root == 1) {
+            cg.graph = gr; cg.exec = ex; cg.first = root;
+            g_cg_captures++;
+            cg.a_img0 = d_img0; cg.a_img1 = img1; cg.a_stride = stride; cg.a_pyr = h->d_pyr.p; cg.a_g = g;
+            cg.a_xtab = h->d_xtab.p; cg.a_ytab = h->d_ytab.p; cg.a_tx = h->d_tower_x.p; cg.a_ty = h->d_tower_y.p;
+            cg.grid = dim3(h->tower_ntx, h->tower_nty, ncams);
+          } else {
+            if (ex) (void)hipGraphExecDestroy(ex);
+            if (gr) (void)hipGraphDestroy(gr);
+            (void)hipGetLastError();
+            cg.key_valid = false;                 // try again later; this call launches directly
+          }
+        }
+      }
+      if (cg.exec) {
+        if (cg.a_img0 != d_img0 || cg.a_img1 != img1) {
+          cg.a_img0 = d_img0; cg.a_img1 = img1;
+          void* args[] = {&cg.a_img0, &cg.a_img1, &cg.a_stride, &cg.a_pyr, &cg.a_g, &cg.a_xtab, &cg.a_ytab, &cg.a_tx, &cg.a_ty};
+          hipKernelNodeParams np;
+          memset(&np, 0, sizeof(np));
+          np.func = reinterpret_cast<void*>(pyr_tower_kernel);
+          np.gridDim = cg.grid; np.blockDim = dim3(kTwThreads); np.sharedMemBytes = 0; np.kernelParams = args; np.extra = nullptr;
+          ORBG_HIP(hipGraphExecKernelNodeSetParams(cg.exec, cg.first, &np));
+        }
+        ORBG_HIP(hipGraphLaunch(cg.exec, st));
+        replayed = true;
+        g_cg_replays++;
+      }
+    }
+  }
+  if (!replayed) g_cg_ineligible++;
+  if (!replayed && (rc = launch_chain(prof))) return rc;
+  if (use_gpu) {
+    bool posted = false;
+    if (post) {
       if (post->frame) {
         // the grid build is the last kernel of the chain: it posts the completion word itself (no signal kernel)
         unsigned seq; volatile unsigned* flag;
@@ -1957,14 +2068,14 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
                        h->d_pyr.p, g, h->sel.d, n_sel_total, h->umax, h->n_kp[0], h->d_kps.p, h->d_desc.p);
   }
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[4], st));
-  bool stereo_out = false;
+  bool stereo_out_host = false;
   if (post) {
     if (post->stereo && ncams == 2) {
       if ((rc = launch_stereo(h, post->bf, post->b, st, false, nullptr))) return rc;
       if (h->n_kp[0] > 0 && (post->uright || post->depth)) {
         ORBG_HIP(hipMemcpyAsync(h->h_stereo.h, h->d_uright.p, (size_t)h->n_kp[0] * 4, hipMemcpyDeviceToHost, st));
         ORBG_HIP(hipMemcpyAsync(h->h_stereo.h + h->n_kp[0], h->d_depth.p, (size_t)h->n_kp[0] * 4, hipMemcpyDeviceToHost, st));
-        stereo_out = true;
+        stereo_out_host = true;
       }
     }
     if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st, nullptr, nullptr, 0u))) return rc;
@@ -1985,7 +2096,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       base += h->n_kp[cam];
     }
   }
-  if (stereo_out) {
+  if (stereo_out_host) {
     if (post->uright) memcpy(post->uright, h->h_stereo.h, (size_t)h->n_kp[0] * 4);
     if (post->depth) memcpy(post->depth, h->h_stereo.h + h->n_kp[0], (size_t)h->n_kp[0] * 4);
   }

@@ -2,6 +2,10 @@
 inputs.  Bit-exact for pyramid bytes, FAST candidates, keypoints, angles, descriptors, Hamming distances, stereo
 matches and matcher outputs; <= 1e-4 for LBA poses / points after float32 write-back (tolerance from
 BASELINE.json north_star)."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -188,9 +192,13 @@ def test_frame_constructor_submit_wait_pipelines_across_frames(scene):
     hip = ctypes.CDLL("libamdhip64.so")
     cam = scene.cam
     bf, bb = float(cam["bf"]), float(cam["b"])
-    ids = [3, 4, 5, 6]
+    graph_run = os.environ.get("ORBG_CTOR_GRAPH") == "1"      # see test_frame_constructor_as_an_executable_graph
+    ids = [3, 4, 5, 6, 7, 8, 9, 10] if graph_run else [3, 4, 5, 6]
     orc = [helpers.oracle_stereo_frame(scene, i) for i in ids]
     ex = [api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2) for _ in range(2)]
+    if graph_run:
+        for e in ex:
+            e.set_profiling(0)                                      # event brackets keep a call out of the graph
     Fr = [api.Frame(), api.Frame()]
     dimg = []
     for fr in orc:
@@ -233,6 +241,20 @@ def test_frame_constructor_submit_wait_pipelines_across_frames(scene):
     for pair in dimg:
         for d in pair:
             hip.hipFree(d)
+
+
+def test_frame_constructor_as_an_executable_graph():
+    """ORBG_CTOR_GRAPH=1: the constructor's kernel chain is captured into a hipGraph the second time a handle repeats a
+    configuration and replayed from then on (only the image pointers are patched).  Same test as above, eight frames, in a
+    process that has the variable set; the library reports how many constructors went through the graph."""
+    env = dict(os.environ, ORBG_CTOR_GRAPH="1", ORBG_CTOR_GRAPH_STATS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", os.path.abspath(__file__) +
+                        "::test_frame_constructor_submit_wait_pipelines_across_frames"], capture_output=True, text=True, timeout=900,
+                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    import re
+    m = re.search(r"ctor graph: (\d+) replays, (\d+) captures", r.stdout + r.stderr)
+    assert m and int(m.group(2)) == 2 and int(m.group(1)) >= 6, (r.stdout[-1500:], r.stderr[-1500:])
 
 
 def test_gpu_and_host_quadtree_paths_agree(scene, small_scene, monkeypatch):
