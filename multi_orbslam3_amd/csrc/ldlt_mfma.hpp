@@ -219,11 +219,11 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
     if (k >= 2) wait_gt(&s_rowdone[k - 2], kWaves - 1);
   };
 
-  // ---- the 16 (or fewer, last row) pivots of diagonal tile k.  Per pivot j: C -= u (r u)^T as ONE matrix instruction
-  // (u = row j = column j of the symmetric tile: register j>>2 in the lanes of group j&3 is at once the A operand and,
-  // scaled, the B operand), the same update on a copy of the identity (-> G = L^-1).  The reciprocal of the NEXT pivot
-  // is computed on the vector ALU while the matrix instruction runs:  d_{j+1} = c_{j+1,j+1} - r_j c_{j,j+1}^2  from the
-  // operand copies, so the chain per pivot is one matrix instruction + one multiply, not instruction + readlane + rcp.
+  // ---- the 16 (or fewer, last row) pivots of diagonal tile k, TWO per matrix instruction (see the diagonal loop of
+  // k_ldlt_cols below for the derivation): rows p0, p1 of register g sit in lane groups q0, q0+1; with r0 = 1/c00,
+  // l10 = c01 r0, 1/d1 = c00 / det the rank-2 update is C -= A B with A = [-r0 row0 | -(1/d1) row1'], B = [row0; row1'],
+  // row1' = row1 - l10 row0.  The same two pivots are replayed on a copy of the identity (-> G = L^-1, needed by the
+  // panel owners): its second row is reduced by its first with the same l10, then one instruction with the same A.
   auto factor = [&](int k) {
     LDLTM_T(8 + 8 * k + 0);
     d4 C = {0.0, 0.0, 0.0, 0.0};
@@ -235,49 +235,46 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
     for (int g = 0; g < 4; g++) E[g] = (lr + 4 * g == lc) ? 1.0 : 0.0;
     Gc = E;
     double dvv = 1.0;
-    const int npiv = min(16, n_pad - 16 * k);
-    double d = rdlane(C[0], 0);
-    bool good = !(d == 0.0 || !(fabs(d) < INFINITY));
-    double r = rcp2(d);
+    const int npiv = min(16, n_pad - 16 * k);          // a multiple of 4
+    double rlast = 1.0;
 #ifdef LDLTM_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      if (j == 8) LDLTM_T(8 + 8 * k + 6);
-      if (j < npiv) {
-        const int g = j >> 2, q = j & 3;
-        const bool in = lr == q;
-        const double rm = in ? -r : 0.0;
-        double u = C[g];
-        asm volatile("" : "+v"(u));              // own registers: the instruction below then updates C in place
-        double un = u;
-        if (j < 15 && ((j + 1) >> 2) != g) { un = C[(j + 1) >> 2]; asm volatile("" : "+v"(un)); }
-        const double wc = u * rm;
-        C = mfma(u, wc, C);
-        __builtin_amdgcn_sched_barrier(0);     // the tile's instruction first: it heads the dependency chain
-        double a = 0.0, bb = 0.0;
-        if (j < 15) {
-          a = rdlane(un, ((j + 1) & 3) * 16 + j + 1);   // c_{j+1,j+1} and c_{j,j+1} before this update
-          bb = rdlane(u, q * 16 + j + 1);
-        }
-        const double eg = E[g];
-        const double we = eg * rm;
-        Gc[g] = in ? eg : Gc[g];               // row j of L^-1 (final before its own pivot)
-        Wc[g] -= wc;                           // row j of the unit upper factor (lanes of group q), others unchanged
-        if (lane == j) dvv = r;
-        if (j + 1 < npiv) d = __builtin_fma(-r * bb, bb, a);
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef LDLTM_NO_E
-        E = mfma(u, we, E);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 1 < npiv) {
-          if (d == 0.0 || !(fabs(d) < INFINITY)) good = false;
-          r = rcp2(d);
+    for (int g = 0; g < 4; g++) {
+      if (g == 2) LDLTM_T(8 + 8 * k + 6);
+      if (4 * g < npiv) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int q0 = 2 * h, p0 = 4 * g + q0, p1 = p0 + 1;
+          double u = C[g];
+          asm volatile("" : "+v"(u));              // own registers: the instruction below then updates C in place
+          const double c00 = rdlane(u, q0 * 16 + p0), c01 = rdlane(u, q0 * 16 + p1), c11 = rdlane(u, (q0 + 1) * 16 + p1);
+          const double det = __builtin_fma(c00, c11, -(c01 * c01));
+          const double r0 = rcp1(c00);
+          const double rdet = rcp1(det);
+          const double r1 = c00 * rdet;
+          const double nl10 = -(c01 * r0);
+          const double u0b = row_even_to_odd(u);
+          const double u1 = __builtin_fma(nl10, u0b, u);          // row1' in the lanes of group q0 + 1
+          const bool in0 = lr == q0, in1 = lr == q0 + 1;
+          const double bv = in1 ? u1 : u;
+          const double av = in0 ? u * -r0 : in1 ? u1 * -r1 : 0.0;
+          if (p1 < 15) C = mfma(av, bv, C);        // after the 16th pivot nothing of the tile is read again
+          // the identity copy: rows p0, p1 of L^-1 are final before their own pivots
+          double eg = E[g];
+          asm volatile("" : "+v"(eg));
+          const double e0b = row_even_to_odd(eg);
+          const double erow = in1 ? __builtin_fma(nl10, e0b, eg) : eg;
+          Gc[g] = (in0 || in1) ? erow : Gc[g];
+          if (p1 < 15) E = mfma(av, erow, E);
+          Wc[g] -= av;                             // rows p0, p1 of the unit upper factor (their two lane groups)
+          dvv = lane == p0 ? r0 : lane == p1 ? r1 : dvv;
+          if (h == 1) rlast = r0 + r1;             // a zero or non-finite pivot turns every later reciprocal into NaN
         }
       }
     }
+    const bool good = fabs(rlast) < INFINITY;
 #ifdef LDLTM_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
