@@ -511,6 +511,14 @@ int orbx_event_overhead(orbx_handle* h, int reps, float* ms);
 /* Profiling level 1 brackets fast_cells_kernel with an event pair; with interval k only every k-th extraction is bracketed.
  * The bracket times accumulate in the handle (sum in ms, number of samples) until reset. */
 int orbx_set_profile_interval(orbx_handle* h, int interval, int reset);
+/* Which kernel of the Frame-constructor chain the level-1 event pair brackets (default: fast_cells_kernel); the
+   accumulated times are read with orbx_get_fast_kernel_stats and reset by this call.  For bench.py's roofline line,
+   which has to describe whichever kernel dominates the step. */
+#define ORBX_PROF_FAST 0
+#define ORBX_PROF_OCTREE 1
+#define ORBX_PROF_ORIENT_DESC 2
+#define ORBX_PROF_PYRAMID 3
+int orbx_set_profile_kernel(orbx_handle* h, int which);
 int orbx_get_fast_kernel_stats(orbx_handle* h, double* sum_ms, int64_t* n);
 
 #ifdef __cplusplus

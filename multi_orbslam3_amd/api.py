@@ -190,6 +190,12 @@ class ORBextractor:
     def set_profile_interval(self, interval, reset=True):
         capi.check(self.lib.orbx_set_profile_interval(self.h, int(interval), int(bool(reset))), "orbx_set_profile_interval")
 
+    PROF_KERNELS = {"fast_cells_kernel": 0, "octree_kernel": 1, "orient_desc_gpu_kernel": 2, "pyr_tower_kernel": 3}
+
+    def set_profile_kernel(self, name):
+        """Which kernel of the constructor chain the level-1 event pair brackets (resets the accumulated times)."""
+        capi.check(self.lib.orbx_set_profile_kernel(self.h, self.PROF_KERNELS[name]), "orbx_set_profile_kernel")
+
     def fast_kernel_stats(self):
         s, n = C.c_double(0.0), C.c_int64(0)
         capi.check(self.lib.orbx_get_fast_kernel_stats(self.h, C.byref(s), C.byref(n)), "orbx_get_fast_kernel_stats")

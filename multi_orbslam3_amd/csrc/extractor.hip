@@ -1444,7 +1444,8 @@ struct orbx_handle {
   int profile = 1;   // 0: no events, 1: only the FAST kernel is bracketed (bench roofline), 2: every stage
   int profile_interval = 1;         // level-1 brackets on every k-th extraction only (an event pair costs ~5 us of stream time)
   unsigned long long extract_calls = 0;
-  double fast_ms_sum = 0; long fast_ms_n = 0;   // accumulated bracket times of fast_cells_kernel
+  double fast_ms_sum = 0; long fast_ms_n = 0;   // accumulated bracket times of the bracketed kernel (fast_cells_kernel by default)
+  int prof_kernel = 0;              // which kernel of the chain the level-1 event pair brackets: ORBX_PROF_*
   struct CtorGraph* cgraph = nullptr;          // captured kernel chain of the device-resident Frame constructor
 };
 
@@ -1862,6 +1863,10 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   // every launch of the chain up to (not including) the grid build; prof_ > 0 adds the event brackets
   auto launch_chain = [&](int prof_) -> int {
     if (prof_ >= 2) ORBG_HIP(hipEventRecord(h->ev[0], st));
+    const int pk = h->prof_kernel;
+    auto br0 = [&](int which) -> int { if (prof_ >= 1 && pk == which) ORBG_HIP(hipEventRecord(h->ev[1], st)); return ORBG_OK; };
+    auto br1 = [&](int which) -> int { if (prof_ >= 1 && pk == which) ORBG_HIP(hipEventRecord(h->ev[7], st)); return ORBG_OK; };
+    if (br0(ORBX_PROF_PYRAMID)) return ORBG_HIP_ERROR;
     if (h->tower_T > 0) {
       hipLaunchKernelGGL(pyr_tower_kernel, dim3(h->tower_ntx, h->tower_nty, ncams), dim3(kTwThreads), 0, st, d_img0, img1,
                          stride, h->d_pyr.p, g, h->d_xtab.p, h->d_ytab.p, h->d_tower_x.p, h->d_tower_y.p);
@@ -1875,21 +1880,27 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
         hipLaunchKernelGGL(pyr_resize_kernel, gr, dim3(256), 0, st, h->d_pyr.p, g, l, h->d_xtab.p, h->d_ytab.p);
       }
     }
-    if (prof_ >= 1) ORBG_HIP(hipEventRecord(h->ev[1], st));
+    if (br1(ORBX_PROF_PYRAMID)) return ORBG_HIP_ERROR;
+    if (prof_ >= 2 && pk != ORBX_PROF_FAST) ORBG_HIP(hipEventRecord(h->ev[8], st));      // end of the pyramid for the stage timings
     if (n_cells > 0) {
+      if (br0(ORBX_PROF_FAST)) return ORBG_HIP_ERROR;
       hipLaunchKernelGGL(fast_cells_kernel, dim3(8 * ((n_cells + 7) / 8), ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
                          std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
-      if (prof_ >= 1) ORBG_HIP(hipEventRecord(h->ev[7], st));
+      if (br1(ORBX_PROF_FAST)) return ORBG_HIP_ERROR;
       hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
                          h->d_cells.p, n_cells, ncams, use_gpu ? h->d_hdr.p : h->hdr.d, use_gpu ? h->d_cand.p : h->cand.d, h->cand_cap);
     }
     if (use_gpu) {
       // ---- everything stays on the device: quad-trees -> descriptors -> (stereo, grid) -> ONE synchronisation
+      if (br0(ORBX_PROF_OCTREE)) return ORBG_HIP_ERROR;
       hipLaunchKernelGGL(octree_kernel, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
                          h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap);
+      if (br1(ORBX_PROF_OCTREE)) return ORBG_HIP_ERROR;
+      if (br0(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
       hipLaunchKernelGGL(orient_desc_gpu_kernel, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
                          oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,
                          want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d, h->d_overflow.p);
+      if (br1(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
       if (do_stereo) {
         const int rcs = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr);
         if (rcs) return rcs;
@@ -2103,8 +2114,9 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   float ms;
   h->timings[2] = std::chrono::duration<float, std::milli>(t_host1 - t_host0).count();  // host quad-tree
   if (prof >= 2) {
-    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->timings[0] = ms;   // pyramid
-    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->timings[1] = ms;   // FAST + gather
+    hipEvent_t pyr_end = h->prof_kernel == ORBX_PROF_FAST ? h->ev[1] : h->ev[8];
+    if (hipEventElapsedTime(&ms, h->ev[0], pyr_end) == hipSuccess) h->timings[0] = ms;   // pyramid
+    if (hipEventElapsedTime(&ms, pyr_end, h->ev[2]) == hipSuccess) h->timings[1] = ms;    // FAST + gather
     if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->timings[3] = ms;   // orientation + descriptors
   }
   if (prof >= 1 && n_cells > 0 && hipEventElapsedTime(&ms, h->ev[1], h->ev[7]) == hipSuccess) { h->timings[5] = ms; h->fast_ms_sum += ms; h->fast_ms_n++; }
@@ -2392,6 +2404,13 @@ extern "C" int orbx_stereo_match(orbx_handle* h, float bf, float b, float* urigh
 }
 
 // level-1 brackets on every `interval`-th extraction; reset = 1 clears the accumulated fast_cells_kernel statistics
+extern "C" int orbx_set_profile_kernel(orbx_handle* h, int which) {
+  if (!h || which < ORBX_PROF_FAST || which > ORBX_PROF_PYRAMID) return ORBG_BAD_ARG;
+  h->prof_kernel = which;
+  h->fast_ms_sum = 0; h->fast_ms_n = 0;
+  return ORBG_OK;
+}
+
 extern "C" int orbx_set_profile_interval(orbx_handle* h, int interval, int reset) {
   if (!h || interval < 1) return ORBG_BAD_ARG;
   h->profile_interval = interval;

@@ -72,12 +72,20 @@ def test_roofline_kernel_is_the_top_row_of_a_fresh_kernel_trace():
     rows = list(csv.DictReader(open(stats[0])))
     # PoseOptimization runs only in the informational tail of bench.py (not in a step): leave it out of the ranking
     rows = [x for x in rows if "pose_opt_kernel" not in x["Name"]]
+    # copies are not kernels of the library
+    rows = [x for x in rows if "__amd_rocclr" not in x["Name"]]
     rows.sort(key=lambda x: -float(x["TotalDurationNs"]))
-    top = rows[0]["Name"]
-    assert d["roofline"]["kernel"].split("::")[-1] in top, (d["roofline"]["kernel"], [x["Name"][:60] for x in rows[:4]])
+    # bench.py picks the subject from its own event brackets; two kernels within 15 % of each other in total time (at the
+    # moment octree_kernel and the LDL^T) may swap places between two runs, so the subject has to be the top row or tied with it
+    name = d["roofline"]["kernel"].split("::")[-1]
+    mine = [x for x in rows if name in x["Name"]]
+    assert mine, (name, [x["Name"][:60] for x in rows[:4]])
+    assert float(mine[0]["TotalDurationNs"]) >= 0.85 * float(rows[0]["TotalDurationNs"]), (name, [(x["Name"][:50], x["TotalDurationNs"]) for x in rows[:4]])
     # and the live event-bracket duration agrees with the trace's average for that kernel
-    avg_us = float(rows[0]["AverageNs"]) / 1e3
+    avg_us = float(mine[0]["AverageNs"]) / 1e3
     assert abs(1e3 * d["roofline"]["avg_launch_ms"] - avg_us) < 0.25 * avg_us, (d["roofline"]["avg_launch_ms"], avg_us)
+    per = d["config"]["device_ms_per_step_by_kernel"]
+    assert list(per)[0].split("::")[-1] == name and len(per) >= 5
     shutil.rmtree(out, ignore_errors=True)
 
 
