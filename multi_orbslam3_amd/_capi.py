@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbgpu.so")
+LIB_PATH = os.environ.get("ORBG_LIB") or os.path.join(_HERE, "liborbgpu.so")   # ORBG_LIB: an experimental build (tools/micro/variants)
 
 ORBG_OK, ORBG_EMPTY, ORBG_BAD_ARG, ORBG_CAP_EXCEEDED, ORBG_HIP_ERROR, ORBG_NO_DEVICE, ORBG_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 LBA_APPLIED, LBA_ABORTED_BEFORE_OPT, LBA_REJECTED_OUTLIERS = 0, 1, 2

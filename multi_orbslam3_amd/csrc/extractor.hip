@@ -833,6 +833,11 @@ constexpr int kBS = 40;              // blurred stride
 constexpr int kKpPerBlock = 4;
 
 // One wavefront: orientation + blur + descriptor of the keypoint (cam, level, x, y) -> slot `out`.
+// TAPS selects the blur kernel at compile time: 0 = {18,34,49,55} (OpenCV < 4.5, the reference's), 1 = {18,34,48,56}
+// (OpenCV >= 4.5), 2 = the values of orbx_config.gauss_taps at run time.  With run-time taps the two blur passes lose the
+// constant-multiplier forms and the kernel takes 27 instead of 20 us (bench.py census, pipelined step), so the two known
+// variants are instantiated.
+template <int TAPS>
 __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr, const PyrGeom& g, int cam, int level, int kx_, int ky_,
                                                  float response, const UMax& um, size_t out, uint8_t* raw_al, unsigned short* hrow,
                                                  uint8_t* blur, orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
@@ -879,10 +884,12 @@ __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   // --- separable 7x7 Gaussian, Q8 taps (default {18,34,49,55,49,34,18}; orbx_config.gauss_taps): the row pass fits u16 (257*255 = 65535)
+  const int t0 = TAPS == 2 ? um.gauss[0] : 18, t1 = TAPS == 2 ? um.gauss[1] : 34;
+  const int t2 = TAPS == 2 ? um.gauss[2] : TAPS == 1 ? 48 : 49, t3 = TAPS == 2 ? um.gauss[3] : TAPS == 1 ? 56 : 55;
   for (int i = lane; i < kPW * kBW; i += 64) {
     const int y = i / kBW, x = i - y * kBW;
     const uint8_t* r = raw + y * kPS + x;       // x is already offset by -3 relative to the blurred column
-    const int acc = um.gauss[0] * (r[0] + r[6]) + um.gauss[1] * (r[1] + r[5]) + um.gauss[2] * (r[2] + r[4]) + um.gauss[3] * r[3];
+    const int acc = t0 * (r[0] + r[6]) + t1 * (r[1] + r[5]) + t2 * (r[2] + r[4]) + t3 * r[3];
     hrow[y * kHS + x] = (unsigned short)acc;
   }
   __builtin_amdgcn_wave_barrier();
@@ -890,8 +897,7 @@ __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr
   for (int i = lane; i < kBW * kBW; i += 64) {
     const int y = i / kBW, x = i - y * kBW;
     const unsigned short* r = hrow + y * kHS + x;
-    const int acc = um.gauss[0] * ((int)r[0] + r[6 * kHS]) + um.gauss[1] * ((int)r[kHS] + r[5 * kHS]) + um.gauss[2] * ((int)r[2 * kHS] + r[4 * kHS]) +
-                    um.gauss[3] * (int)r[3 * kHS];
+    const int acc = t0 * ((int)r[0] + r[6 * kHS]) + t1 * ((int)r[kHS] + r[5 * kHS]) + t2 * ((int)r[2 * kHS] + r[4 * kHS]) + t3 * (int)r[3 * kHS];
     const int v = (acc + 32768) >> 16;
     blur[y * kBS + x] = (uint8_t)min(v, 255);
   }
@@ -938,6 +944,7 @@ __device__ __forceinline__ void orient_desc_wave(const uint8_t* __restrict__ pyr
 }
 
 // front-end 1: keypoints chosen by the host quad-trees (SelKp records in final order)
+template <int TAPS>
 __global__ __launch_bounds__(256) void orient_desc_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
                                                          const SelKp* __restrict__ sel, int n_sel, UMax um, int cam1_base,
                                                          orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
@@ -949,12 +956,13 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const uint8_t* __restr
   if (k >= n_sel) return;            // whole wavefront exits together; no block-wide barrier below
   const SelKp kp = sel[k];
   const size_t out = (size_t)(kp.cam ? cam1_base : 0) + kp.out_idx;
-  orient_desc_wave(pyr, g, kp.cam, kp.level, kp.x, kp.y, kp.response, um, out, raw_s[wv], hrow_s[wv], blur_s[wv], kps, desc, nullptr, nullptr);
+  orient_desc_wave<TAPS>(pyr, g, kp.cam, kp.level, kp.x, kp.y, kp.response, um, out, raw_s[wv], hrow_s[wv], blur_s[wv], kps, desc, nullptr, nullptr);
 }
 
 // front-end 2: keypoints chosen by octree_kernel.  Wavefront w of the (over-sized) grid finds its (camera, level,
 // position) from the per-level counts; slot = keypoints before it in (camera, level) order -- or the mirror of it when
 // the whole image lies in the lapping area (mono Frame ctor, S/Frame.cc:289).  Also publishes the keypoint totals.
+template <int TAPS>
 __global__ __launch_bounds__(256) void orient_desc_gpu_kernel(const uint8_t* __restrict__ pyr, PyrGeom g, OctCfg cfg,
                                                              const OctSel* __restrict__ sel, const int* __restrict__ lvl_count,
                                                              UMax um, int reverse0, int reverse1, orbx_keypoint* __restrict__ kps,
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(256) void orient_desc_gpu_kernel(const uint8_t* __r
   const int ncam = cam ? n1 : n0;
   const int slot = (cam ? reverse1 : reverse0) ? ncam - 1 - seq : seq;
   const size_t out = (size_t)(cam ? n0 : 0) + slot;
-  orient_desc_wave(pyr, g, cam, level, kp.x, kp.y, kp.response, um, out, raw_s[wv], hrow_s[wv], blur_s[wv], kps, desc, kps_host, desc_host);
+  orient_desc_wave<TAPS>(pyr, g, cam, level, kp.x, kp.y, kp.response, um, out, raw_s[wv], hrow_s[wv], blur_s[wv], kps, desc, kps_host, desc_host);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1445,6 +1453,7 @@ struct orbx_handle {
   int profile_interval = 1;         // level-1 brackets on every k-th extraction only (an event pair costs ~5 us of stream time)
   unsigned long long extract_calls = 0;
   double fast_ms_sum = 0; long fast_ms_n = 0;   // accumulated bracket times of the bracketed kernel (fast_cells_kernel by default)
+  int taps_variant = 0;             // 0 / 1: one of the two compiled-in blur kernels, 2: run-time taps (orient_desc_wave)
   int prof_kernel = 0;              // which kernel of the chain the level-1 event pair brackets: ORBX_PROF_*
   struct CtorGraph* cgraph = nullptr;          // captured kernel chain of the device-resident Frame constructor
 };
@@ -1687,6 +1696,8 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     }
     for (int i = 0; i < 16; i++) h->umax.v[i] = um[i];
     for (int i = 0; i < 4; i++) h->umax.gauss[i] = h->cfg.gauss_taps[i];
+    const int* gt = h->cfg.gauss_taps;
+    h->taps_variant = (gt[0] == 18 && gt[1] == 34 && gt[2] == 49 && gt[3] == 55) ? 0 : (gt[0] == 18 && gt[1] == 34 && gt[2] == 48 && gt[3] == 56) ? 1 : 2;
   }
   {
     int nthreads = 5;
@@ -1897,9 +1908,14 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
                          h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap);
       if (br1(ORBX_PROF_OCTREE)) return ORBG_HIP_ERROR;
       if (br0(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
-      hipLaunchKernelGGL(orient_desc_gpu_kernel, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
-                         oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,
-                         want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d, h->d_overflow.p);
+      auto launch_od = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((h->sel_bound + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st, h->d_pyr.p, g,
+                           oc, h->d_selreg.p, h->d_lvlcount.p, h->umax, reverse[0], reverse[1], h->d_kps.p, h->d_desc.p, h->h_kps.d,
+                           want_desc ? h->h_desc.d : (uint8_t*)nullptr, h->d_nkp.p, h->h_nkp.d, h->d_overflow.p);
+      };
+      if (h->taps_variant == 0) launch_od(orient_desc_gpu_kernel<0>);
+      else if (h->taps_variant == 1) launch_od(orient_desc_gpu_kernel<1>);
+      else launch_od(orient_desc_gpu_kernel<2>);
       if (br1(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
       if (do_stereo) {
         const int rcs = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr);
@@ -2075,8 +2091,13 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   // ---- GPU phase 2: orientation + descriptors, written in final order
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[3], st));
   if (n_sel_total > 0) {
-    hipLaunchKernelGGL(orient_desc_kernel, dim3((n_sel_total + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st,
-                       h->d_pyr.p, g, h->sel.d, n_sel_total, h->umax, h->n_kp[0], h->d_kps.p, h->d_desc.p);
+    auto launch_odh = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3((n_sel_total + kKpPerBlock - 1) / kKpPerBlock), dim3(256), 0, st,
+                         h->d_pyr.p, g, h->sel.d, n_sel_total, h->umax, h->n_kp[0], h->d_kps.p, h->d_desc.p);
+    };
+    if (h->taps_variant == 0) launch_odh(orient_desc_kernel<0>);
+    else if (h->taps_variant == 1) launch_odh(orient_desc_kernel<1>);
+    else launch_odh(orient_desc_kernel<2>);
   }
   if (prof >= 2) ORBG_HIP(hipEventRecord(h->ev[4], st));
   bool stereo_out_host = false;

@@ -89,7 +89,7 @@ def test_extractor_dense_noise_overflows_to_host_trees(scene):
     _assert_extract_equal((kr, dr), (okps, odesc), "dense noise stereo R")
 
 
-@pytest.mark.parametrize("variant", [dict(gauss_taps=(18, 34, 48, 56)), dict(octree_oldest_first=True),
+@pytest.mark.parametrize("variant", [dict(gauss_taps=(18, 34, 48, 56)), dict(octree_oldest_first=True), dict(gauss_taps=(16, 32, 48, 64)),
                                      dict(gauss_taps=(18, 34, 48, 56), octree_oldest_first=True)])
 def test_extractor_deployment_variants(scene, variant):
     """The two places where the reference's output depends on its build (OpenCV's Gaussian taps, the heap-address tie-break of
