@@ -179,12 +179,24 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
   __shared__ LevelGeom s_lv[ORBG_MAX_LEVELS];   // kernel arguments sit in cold memory: each first touch of a cache line costs
                                                 // a full miss, so the per-level geometry is fetched once, up front
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cam = blockIdx.z;
+  // XCD-aware workgroup -> tile map: workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with an L2 of
+  // its own.  Horizontally adjacent tiles write the two halves of the cache lines that straddle their border; on different
+  // XCDs every such line is written back twice as a partial line.  Logical tile L = (id % 8) * (total / 8) + id / 8 gives
+  // every XCD a contiguous run of tiles (x fastest), so those lines are completed in one L2.
+  int bx = blockIdx.x, by = blockIdx.y, cam = blockIdx.z;
+  {
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 7) == 0) {
+      const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int L = (id & 7) * (total >> 3) + (id >> 3);
+      bx = L % gridDim.x; by = (L / gridDim.x) % gridDim.y; cam = L / (gridDim.x * gridDim.y);
+    }
+  }
   const int nl = g.n_levels;
   {
     constexpr int kWords = (int)sizeof(TowerAxis) / 4;
-    if (tid < kWords) reinterpret_cast<int*>(&s_ax)[tid] = reinterpret_cast<const int*>(tax + blockIdx.x)[tid];
-    else if (tid < 2 * kWords) reinterpret_cast<int*>(&s_ay)[tid - kWords] = reinterpret_cast<const int*>(tay + blockIdx.y)[tid - kWords];
+    if (tid < kWords) reinterpret_cast<int*>(&s_ax)[tid] = reinterpret_cast<const int*>(tax + bx)[tid];
+    else if (tid < 2 * kWords) reinterpret_cast<int*>(&s_ay)[tid - kWords] = reinterpret_cast<const int*>(tay + by)[tid - kWords];
     constexpr int kLvWords = (int)sizeof(LevelGeom) / 4;
     const int j = tid - 2 * kWords;
     if (j >= 0 && j < nl * kLvWords) reinterpret_cast<int*>(s_lv)[j] = reinterpret_cast<const int*>(g.lv)[j];

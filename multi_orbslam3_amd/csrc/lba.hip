@@ -767,7 +767,14 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
   constexpr int kSeg = 65, kRow = 4 * kSeg + 1;
   __shared__ double red[42 * kRow];
   __shared__ double part[42][4];
-  const int pr = blockIdx.x;
+  // XCD-aware workgroup -> pair map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2;
+  // consecutive pairs share a pose and with it that pose's edge blocks, so every XCD takes a contiguous run of the pair list
+  // (the b/8-th workgroup of XCD k gets the k-th run's b/8-th pair)
+  int pr;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, k = blockIdx.x & 7;
+    pr = k * q + min(k, r) + (blockIdx.x >> 3);
+  }
   const int i1 = pair_i1[pr], i2 = pair_i2[pr];
   const int tid = threadIdx.x;
   double acc[36], cacc[6];
