@@ -494,7 +494,6 @@ __global__ __launch_bounds__(256) void gather_cells_kernel(const uint32_t* __res
 constexpr int kOctThreads = 256;
 constexpr int kOctKeyCap = 4096;     // candidates per (camera, level)
 constexpr int kOctListCap = 2048;    // nodes alive at once (<= 4*N + 8)
-#define OCT_CC(p, q) ((int)((cc2[(p)][(q) >> 1] >> (((q) & 1) * 16)) & 0xFFFFu))
 
 struct OctCfg {
   int n_levels, n_cams;
@@ -506,45 +505,49 @@ struct OctCfg {
 
 struct OctSel { short x, y; float response; };   // level coordinates (border offset added)
 
-// exclusive prefix sum of v[0..n) (int, LDS) in place; returns the total.  All kOctThreads threads must call.
-__device__ inline int oct_scan_excl(int* v, int n, int* wsum /*LDS[8]*/) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n + kOctThreads - 1) / kOctThreads;
-  const int b = min(tid * per, n), e = min(b + per, n);
-  int s = 0;
-  for (int i = b; i < e; i++) s += v[i];
+// Exclusive prefix over the workgroup (thread order) of one value per thread, and the total.  One barrier; `wsum` must not
+// be the array the previous call on this path used (callers rotate through four).
+__device__ __forceinline__ int oct_block_excl(int s, int* total, int* wsum /*LDS[4]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int inc = wave_incl_scan_add(s);
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  int base = 0, total = 0;
+  int base = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < kOctThreads / 64; w++) {
     const int x = wsum[w];
     if (w < wave) base += x;
-    total += x;
+    tot += x;
   }
-  int run = base + inc - s;
-  for (int i = b; i < e; i++) { const int t = v[i]; v[i] = run; run += t; }
-  __syncthreads();
-  return total;
+  *total = tot;
+  return base + inc - s;
 }
+
+// Execution model (round 2; the closed form above is unchanged).  A pass used to be 9-14 workgroup barriers over LDS arrays,
+// every phase a chain of dependent LDS round trips of four wavefronts: 8 k cycles per pass even for a one-node list, 73 k
+// cycles (30 us) for level 0.  Now
+//   * a thread keeps its keys (<= 16: candidate word, list position, quadrant) in registers; a node is ONE 16-byte LDS
+//     record (bounds, key count, creation number);
+//   * the nodes are dealt to the threads in contiguous chunks of the list, so the prefix sums of a pass (children before a
+//     node, survivors before a node) are a thread-local walk plus one wave scan and one barrier, and the thread that scanned
+//     a node creates its children without reading the scan back;
+//   * "keys follow their node" of pass p and "count the children's keys" of pass p+1 are one phase; the children-count
+//     words of the next list are zeroed by whoever creates a node.
+// A first-phase pass is three barriers, a second-phase pass six.
+constexpr int kOctKPT = kOctKeyCap / kOctThreads;     // keys per thread
 
 __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __restrict__ cand, const int* __restrict__ hdr,
                                                             PyrGeom g, OctCfg cfg, OctSel* __restrict__ sel_out,
                                                             int* __restrict__ lvl_count, int* __restrict__ overflow, int cand_cap) {
-  __shared__ unsigned short node_of[kOctKeyCap];
-  __shared__ unsigned short kx[kOctKeyCap], ky[kOctKeyCap];
-  __shared__ unsigned char kr[kOctKeyCap], kq[kOctKeyCap];
-  __shared__ short bx0[2][kOctListCap], by0[2][kOctListCap], bx1[2][kOctListCap], by1[2][kOctListCap];
-  __shared__ unsigned short ncnt[2][kOctListCap], nseq[2][kOctListCap];
-  __shared__ unsigned short ord[kOctListCap], pos_of_ord[kOctListCap], new_pos[kOctListCap];
-  __shared__ unsigned cc2[kOctListCap][2];     // children key counts, two u16 packed per word: [q>>1] >> 16*(q&1)
+  __shared__ uint4 node[2][kOctListCap];          // x0 | x1 << 16, y0 | y1 << 16, key count | creation number << 16, -
+  __shared__ unsigned cc2[2][kOctListCap][2];     // children key counts, two u16 packed per word: [q>>1] >> 16*(q&1)
   __shared__ unsigned short child_pos[kOctListCap][4];
+  __shared__ unsigned short new_pos[kOctListCap], ord[kOctListCap], pos_of_ord[kOctListCap];
   __shared__ __attribute__((aligned(16))) int scanA[kOctListCap];
   __shared__ __attribute__((aligned(16))) int scanB[kOctListCap];
   __shared__ unsigned best[kOctListCap];
-  __shared__ int wsum[8];
-  __shared__ int s_n, s_cut, s_flag;
+  __shared__ int wsum[4][4];
+  __shared__ int s_n, s_cut, s_m, s_flag[2];
   const int tid = threadIdx.x;
   const int task = blockIdx.x;
   const int cam = task % cfg.n_cams, level = task / cfg.n_cams;
@@ -561,22 +564,32 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   if (nk <= 0) { if (tid == 0) *out_count = 0; return; }
   // ce > cand_cap: gather_cells_kernel dropped the tail of the list, the host path regrows the buffer and redoes the frame
   if (nk > kOctKeyCap || 4 * N + 8 > kOctListCap || ce > cand_cap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+  // ---- this thread's keys: k = tid, tid + 256, ...  (kw: x | y << 12 | response << 24;  kn: list position | quadrant << 16 |
+  // "its node is being split" << 18)
+  uint32_t kw[kOctKPT];
+  unsigned kn[kOctKPT];
+#pragma unroll
+  for (int m = 0; m < kOctKPT; m++) kw[m] = cand[cb + min(tid + kOctThreads * m, nk - 1)];
   const int minB = kEdge - 3;
   const int W = (L.w - kEdge + 3) - minB, H = (L.h - kEdge + 3) - minB;   // maxX-minX, maxY-minY
   int nIni = (int)roundf((float)W / (float)H);
   if (nIni < 1) nIni = 1;
   const float hX = (float)W / (float)nIni;
+  auto nonzero4 = [](unsigned c01, unsigned c23) { return (int)((c01 & 0xFFFFu) != 0) + (int)((c01 >> 16) != 0) + (int)((c23 & 0xFFFFu) != 0) + (int)((c23 >> 16) != 0); };
   // ---- roots (:541-583)
   for (int i = tid; i < nIni; i += kOctThreads) scanA[i] = 0;
   __syncthreads();
-  for (int k = tid; k < nk; k += kOctThreads) {
-    const uint32_t p = cand[cb + k];
-    const int x = p & 0xFFF, y = (p >> 12) & 0xFFF;
-    kx[k] = (unsigned short)x; ky[k] = (unsigned short)y; kr[k] = (unsigned char)(p >> 24);
-    int r = (int)((float)x / hX);
-    if (r >= nIni) r = nIni - 1;
-    node_of[k] = (unsigned short)r;          // provisional: root index
-    atomicAdd(&scanA[r], 1);
+#pragma unroll
+  for (int m = 0; m < kOctKPT; m++) {
+    if (tid + kOctThreads * m < nk) {
+      const int x = kw[m] & 0xFFF;
+      int r = (int)((float)x / hX);
+      if (r >= nIni) r = nIni - 1;
+      kn[m] = (unsigned)r;                    // provisional: root index
+      atomicAdd(&scanA[r], 1);
+    } else {
+      kn[m] = 0;
+    }
   }
   __syncthreads();
   // one thread per root: list position = number of non-empty roots before it (empty roots are dropped, :579-580)
@@ -586,219 +599,224 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
     for (int q = 0; q < r; q++) rank += scanA[q] > 0;
     scanB[r] = c > 0 ? rank : -1;
     if (c > 0) {
-      bx0[0][rank] = (short)(int)(hX * (float)r); bx1[0][rank] = (short)(int)(hX * (float)(r + 1));
-      by0[0][rank] = 0; by1[0][rank] = (short)H;
-      ncnt[0][rank] = (unsigned short)c; nseq[0][rank] = (unsigned short)rank;
+      const unsigned x0 = (unsigned)(unsigned short)(short)(int)(hX * (float)r), x1 = (unsigned)(unsigned short)(short)(int)(hX * (float)(r + 1));
+      node[0][rank] = make_uint4(x0 | (x1 << 16), 0u | ((unsigned)(unsigned short)(short)H << 16), (unsigned)c | ((unsigned)rank << 16), 0u);
+      cc2[0][rank][0] = 0; cc2[0][rank][1] = 0;
     }
     if (r == nIni - 1) s_n = rank + (c > 0);
   }
   __syncthreads();
-  for (int k = tid; k < nk; k += kOctThreads) node_of[k] = (unsigned short)scanB[node_of[k]];
-  __syncthreads();
-  int cur = 0, n = s_n, mode = 1;
+#pragma unroll
+  for (int m = 0; m < kOctKPT; m++) kn[m] = tid + kOctThreads * m < nk ? (unsigned)scanB[kn[m]] : 0u;
+  int cur = 0, n = s_n, mode = 1, par = 0, ws = 0;
+  // loop invariant: node[cur][0..n) is the list, cc2[cur][0..n) is zero, kn[m] & 0xFFFF is the position of key m's node
   for (int pass = 0; pass < 64; pass++) {
     const int prev = n;
-    if (mode == 1) {
-      // ---- phase-1 fast path: processing order == list order, so ONE packed prefix sum (expandable | children<<12)
-      // yields the children positions, the survivors' positions and both totals; 7 barriers per pass.
-      for (int i = tid; i < n; i += kOctThreads) { cc2[i][0] = 0; cc2[i][1] = 0; }
-      if (tid == 0) s_flag = 0;
-      __syncthreads();
-      for (int k = tid; k < nk; k += kOctThreads) {
-        const int p = node_of[k];
-        if (ncnt[cur][p] > 1) {
-          const int mx = bx0[cur][p] + ((bx1[cur][p] - bx0[cur][p] + 1) >> 1);
-          const int my = by0[cur][p] + ((by1[cur][p] - by0[cur][p] + 1) >> 1);
-          const int q = ((int)kx[k] < mx ? 0 : 1) + ((int)ky[k] < my ? 0 : 2);
-          kq[k] = (unsigned char)q;
-          atomicAdd(&cc2[p][q >> 1], q & 1 ? 0x10000u : 1u);
+    const int nxt = cur ^ 1;
+    // ---- keys: children key counts of every node with more than one key (:601-640 / :686-727 split the node's keys)
+#pragma unroll
+    for (int m = 0; m < kOctKPT; m++) {
+      if (kOctThreads * m < nk) {              // uniform
+        if (tid + kOctThreads * m < nk) {
+          const unsigned p = kn[m] & 0xFFFFu;
+          const uint4 rec = node[cur][p];
+          if ((rec.z & 0xFFFFu) > 1u) {
+            const int x0 = rec.x & 0xFFFF, x1 = rec.x >> 16, y0 = rec.y & 0xFFFF, y1 = rec.y >> 16;
+            const int mx = x0 + ((x1 - x0 + 1) >> 1);             // UL.x + ceil((UR.x-UL.x)/2)
+            const int my = y0 + ((y1 - y0 + 1) >> 1);
+            const int kx = kw[m] & 0xFFF, ky = (kw[m] >> 12) & 0xFFF;
+            const int q = (kx < mx ? 0 : 1) + (ky < my ? 0 : 2);
+            atomicAdd(&cc2[cur][p][q >> 1], q & 1 ? 0x10000u : 1u);          // packed u16 pair add (counts < 65536)
+            kn[m] = p | ((unsigned)q << 16) | (1u << 18);
+          } else {
+            kn[m] = p;
+          }
         }
       }
-      __syncthreads();
-      for (int i = tid; i < n; i += kOctThreads) {
-        int v = 0;
-        if (ncnt[cur][i] > 1) v = 1 | (((OCT_CC(i, 0) > 0) + (OCT_CC(i, 1) > 0) + (OCT_CC(i, 2) > 0) + (OCT_CC(i, 3) > 0)) << 12);
-        scanA[i] = v;
+    }
+    if (mode == 2) {
+      // ranking keys of the expandable nodes: count << 16 | creation number (0 = not expandable), padded to a multiple of 4
+      const int n4 = (n + 3) & ~3;
+      for (int i = tid; i < n4; i += kOctThreads) {
+        unsigned key = 0;
+        if (i < n) {
+          const unsigned cs = node[cur][i].z;
+          if ((cs & 0xFFFFu) > 1u) key = ((cs & 0xFFFFu) << 16) | (cfg.oldest_first ? 0xFFFFu - (cs >> 16) : (cs >> 16));
+        }
+        scanB[i] = (int)key;
       }
-      __syncthreads();
-      const int tot = oct_scan_excl(scanA, n, wsum);
+    }
+    if (tid == 0) { s_flag[par] = 0; s_cut = 0x7fffffff; s_m = 0; }
+    __syncthreads();
+    // contiguous chunk of the list for this thread
+    const int per = (n + kOctThreads - 1) / kOctThreads;
+    const int b = min(tid * per, n), e = min(b + per, n);
+    int n_new, nexp;
+    if (mode == 1) {
+      // ---- phase 1: every node with more than one key splits, in list order.  One packed scan (expandable | children << 12)
+      int sv = 0;
+      for (int i = b; i < e; i++)
+        if ((node[cur][i].z & 0xFFFFu) > 1u) sv += 1 | (nonzero4(cc2[cur][i][0], cc2[cur][i][1]) << 12);
+      int tot;
+      const int ex = oct_block_excl(sv, &tot, wsum[ws]); ws = (ws + 1) & 3;
       const int m1 = tot & 0xFFF, C1 = tot >> 12;
       if (m1 == 0) break;
-      const int n_new1 = C1 + (n - m1);
-      if (n_new1 > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
-      const int nxt1 = cur ^ 1;
-      int my_exp1 = 0;
-      for (int i = tid; i < n; i += kOctThreads) {
-        const int pe = scanA[i] & 0xFFF, pk = scanA[i] >> 12;     // expandable / children before node i
-        if (ncnt[cur][i] > 1) {
-          const int mx = bx0[cur][i] + ((bx1[cur][i] - bx0[cur][i] + 1) >> 1);
-          const int my = by0[cur][i] + ((by1[cur][i] - by0[cur][i] + 1) >> 1);
-          int ci = pk;
+      n_new = C1 + (n - m1);
+      if (n_new > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+      int pe = ex & 0xFFF, ci = ex >> 12, my_exp = 0;         // expandable nodes / children before node i
+      for (int i = b; i < e; i++) {
+        const uint4 rec = node[cur][i];
+        if ((rec.z & 0xFFFFu) > 1u) {
+          const int x0 = rec.x & 0xFFFF, x1 = rec.x >> 16, y0 = rec.y & 0xFFFF, y1 = rec.y >> 16;
+          const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+          const unsigned c01 = cc2[cur][i][0], c23 = cc2[cur][i][1];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const int c = OCT_CC(i, q);
+            const unsigned c = ((q & 2 ? c23 : c01) >> ((q & 1) * 16)) & 0xFFFFu;
             if (c == 0) continue;
-            const int np = C1 - 1 - ci;
-            bx0[nxt1][np] = (short)((q & 1) ? mx : bx0[cur][i]); bx1[nxt1][np] = (short)((q & 1) ? bx1[cur][i] : mx);
-            by0[nxt1][np] = (short)((q & 2) ? my : by0[cur][i]); by1[nxt1][np] = (short)((q & 2) ? by1[cur][i] : my);
-            ncnt[nxt1][np] = (unsigned short)c; nseq[nxt1][np] = (unsigned short)ci;
+            const int np = C1 - 1 - ci;                      // children end up reversed at the front
+            node[nxt][np] = make_uint4((unsigned)((q & 1) ? mx : x0) | ((unsigned)((q & 1) ? x1 : mx) << 16),
+                                       (unsigned)((q & 2) ? my : y0) | ((unsigned)((q & 2) ? y1 : my) << 16), c | ((unsigned)ci << 16), 0u);
+            cc2[nxt][np][0] = 0; cc2[nxt][np][1] = 0;
             child_pos[i][q] = (unsigned short)np;
-            my_exp1 += c > 1;
+            my_exp += c > 1;
             ci++;
           }
+          pe++;
         } else {
           const int np = C1 + (i - pe);
-          bx0[nxt1][np] = bx0[cur][i]; bx1[nxt1][np] = bx1[cur][i]; by0[nxt1][np] = by0[cur][i]; by1[nxt1][np] = by1[cur][i];
-          ncnt[nxt1][np] = ncnt[cur][i]; nseq[nxt1][np] = nseq[cur][i];
+          node[nxt][np] = rec;
+          cc2[nxt][np][0] = 0; cc2[nxt][np][1] = 0;
           new_pos[i] = (unsigned short)np;
         }
       }
-      if (my_exp1) atomicAdd(&s_flag, my_exp1);
+      if (my_exp) atomicAdd(&s_flag[par], my_exp);
       __syncthreads();
-      for (int k = tid; k < nk; k += kOctThreads) {
-        const int p = node_of[k];
-        node_of[k] = ncnt[cur][p] > 1 ? child_pos[p][kq[k]] : new_pos[p];
-      }
-      const int nexp1 = s_flag;
-      __syncthreads();
-      cur = nxt1; n = n_new1;
-      if (n >= N || n == prev) break;
-      if (n + 3 * nexp1 > N) mode = 2;
-      continue;
-    }
-    // ---- general path (phase 2): A. expandable nodes and their processing order
-    for (int i = tid; i < n; i += kOctThreads) scanA[i] = ncnt[cur][i] > 1 ? 1 : 0;
-    __syncthreads();
-    int m;
-    if (mode == 1) {
-      m = oct_scan_excl(scanA, n, wsum);                      // ord = rank in list order
-      for (int i = tid; i < n; i += kOctThreads)
-        if (ncnt[cur][i] > 1) { ord[i] = (unsigned short)scanA[i]; pos_of_ord[scanA[i]] = (unsigned short)i; }
-    } else {
-      // descending (count, creation seq): rank by counting over packed keys (count<<16 | seq, 0 = not expandable),
-      // read four at a time from LDS
-      const int n4 = (n + 3) & ~3;
-      for (int i = tid; i < n4; i += kOctThreads)
-        scanB[i] = (i < n && ncnt[cur][i] > 1) ? (int)(((unsigned)ncnt[cur][i] << 16) | (cfg.oldest_first ? 0xFFFFu - nseq[cur][i] : nseq[cur][i])) : 0;
-      __syncthreads();
-      m = 0;
-      for (int i = tid; i < n; i += kOctThreads) {
-        const unsigned key = (unsigned)scanB[i];
-        if (key) {
-          int r = 0;
-          const uint4* k4p = reinterpret_cast<const uint4*>(scanB);
-          for (int j = 0; j < n4 / 4; j++) {
-            const uint4 kk = k4p[j];
-            r += (kk.x > key) + (kk.y > key) + (kk.z > key) + (kk.w > key);
-          }
-          ord[i] = (unsigned short)r; pos_of_ord[r] = (unsigned short)i;
-        }
-      }
-      __syncthreads();
-      m = oct_scan_excl(scanA, n, wsum);                      // only the total is needed here
-    }
-    __syncthreads();
-    if (m == 0) break;                                        // every node holds one key: size unchanged -> finished
-    // ---- B. children counts
-    for (int i = tid; i < n; i += kOctThreads) { cc2[i][0] = 0; cc2[i][1] = 0; }
-    __syncthreads();
-    for (int k = tid; k < nk; k += kOctThreads) {
-      const int p = node_of[k];
-      if (ncnt[cur][p] > 1) {
-        const int mx = bx0[cur][p] + ((bx1[cur][p] - bx0[cur][p] + 1) >> 1);     // UL.x + ceil((UR.x-UL.x)/2)
-        const int my = by0[cur][p] + ((by1[cur][p] - by0[cur][p] + 1) >> 1);
-        const int q = ((int)kx[k] < mx ? 0 : 1) + ((int)ky[k] < my ? 0 : 2);
-        kq[k] = (unsigned char)q;
-        atomicAdd(&cc2[p][q >> 1], q & 1 ? 0x10000u : 1u);                     // packed u16 pair add (counts < 65536)
-      }
-    }
-    __syncthreads();
-    // ---- C/D. children per processed node (in processing order), cut for phase 2
-    for (int o = tid; o < m; o += kOctThreads) {
-      const int p = pos_of_ord[o];
-      const int k4 = (OCT_CC(p, 0) > 0) + (OCT_CC(p, 1) > 0) + (OCT_CC(p, 2) > 0) + (OCT_CC(p, 3) > 0);
-      scanA[o] = k4;
-    }
-    __syncthreads();
-    if (tid == 0) s_cut = m - 1;
-    const int totalK_all = oct_scan_excl(scanA, m, wsum);     // scanA[o] = children created before node o
-    (void)totalK_all;
-    if (mode == 2) {
-      for (int o = tid; o < m; o += kOctThreads) {
-        const int p = pos_of_ord[o];
-        const int k4 = (OCT_CC(p, 0) > 0) + (OCT_CC(p, 1) > 0) + (OCT_CC(p, 2) > 0) + (OCT_CC(p, 3) > 0);
-        const int size_after = n + (scanA[o] + k4) - (o + 1);
-        if (size_after >= N) atomicMin(&s_cut, o);
-      }
-    }
-    __syncthreads();
-    const int cut = s_cut;
-    int C, nexp;
-    {
-      const int p = pos_of_ord[cut];
-      const int k4 = (OCT_CC(p, 0) > 0) + (OCT_CC(p, 1) > 0) + (OCT_CC(p, 2) > 0) + (OCT_CC(p, 3) > 0);
-      C = scanA[cut] + k4;                                    // children created by nodes 0..cut
-    }
-    // ---- E. survivors keep their order behind the children
-    for (int i = tid; i < n; i += kOctThreads) scanB[i] = (ncnt[cur][i] > 1 && ord[i] <= cut) ? 0 : 1;
-    __syncthreads();
-    const int nsurv = oct_scan_excl(scanB, n, wsum);
-    const int n_new = C + nsurv;
-    if (n_new > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
-    const int nxt = cur ^ 1;
-    if (tid == 0) s_flag = 0;
-    __syncthreads();
-    int my_exp = 0;
-    for (int i = tid; i < n; i += kOctThreads) {
-      if (ncnt[cur][i] > 1 && ord[i] <= cut) {
-        const int o = ord[i];
-        const int mx = bx0[cur][i] + ((bx1[cur][i] - bx0[cur][i] + 1) >> 1);
-        const int my = by0[cur][i] + ((by1[cur][i] - by0[cur][i] + 1) >> 1);
-        int ci = scanA[o];
+      nexp = s_flag[par];
+      // keys follow their node
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int c = OCT_CC(i, q);
-          if (c == 0) continue;
-          const int np = C - 1 - ci;                          // children end up reversed at the front
-          bx0[nxt][np] = (short)((q & 1) ? mx : bx0[cur][i]); bx1[nxt][np] = (short)((q & 1) ? bx1[cur][i] : mx);
-          by0[nxt][np] = (short)((q & 2) ? my : by0[cur][i]); by1[nxt][np] = (short)((q & 2) ? by1[cur][i] : my);
-          ncnt[nxt][np] = (unsigned short)c; nseq[nxt][np] = (unsigned short)ci;
-          child_pos[i][q] = (unsigned short)np;
-          my_exp += c > 1;
-          ci++;
+      for (int m = 0; m < kOctKPT; m++) {
+        if (tid + kOctThreads * m < nk) {
+          const unsigned p = kn[m] & 0xFFFFu;
+          kn[m] = (kn[m] >> 18) & 1u ? child_pos[p][(kn[m] >> 16) & 3u] : new_pos[p];
         }
-      } else {
-        const int np = C + scanB[i];
-        bx0[nxt][np] = bx0[cur][i]; bx1[nxt][np] = bx1[cur][i]; by0[nxt][np] = by0[cur][i]; by1[nxt][np] = by1[cur][i];
-        ncnt[nxt][np] = ncnt[cur][i]; nseq[nxt][np] = nseq[cur][i];
-        new_pos[i] = (unsigned short)np;
+      }
+    } else {
+      // ---- phase 2: processing order = descending (key count, creation number): rank by counting, four keys per LDS read
+      {
+        const int n4 = (n + 3) & ~3;
+        for (int i = tid; i < n; i += kOctThreads) {
+          const unsigned key = (unsigned)scanB[i];
+          if (key) {
+            int r = 0;
+            const uint4* k4p = reinterpret_cast<const uint4*>(scanB);
+            for (int j = 0; j < n4 / 4; j++) {
+              const uint4 kk = k4p[j];
+              r += (kk.x > key) + (kk.y > key) + (kk.z > key) + (kk.w > key);
+            }
+            ord[i] = (unsigned short)r; pos_of_ord[r] = (unsigned short)i;
+            atomicMax(&s_m, r + 1);
+          }
+        }
+      }
+      __syncthreads();
+      const int m = s_m;
+      if (m == 0) break;                                      // every node holds one key: size unchanged -> finished
+      // children created before each processed node (processing order, chunks), and the cut of the reference's `break`
+      const int pero = (m + kOctThreads - 1) / kOctThreads;
+      const int bo = min(tid * pero, m), eo = min(bo + pero, m);
+      int so = 0;
+      for (int o = bo; o < eo; o++) { const int p = pos_of_ord[o]; so += nonzero4(cc2[cur][p][0], cc2[cur][p][1]); }
+      int totK;
+      int before = oct_block_excl(so, &totK, wsum[ws]); ws = (ws + 1) & 3;
+      (void)totK;
+      for (int o = bo; o < eo; o++) {
+        const int p = pos_of_ord[o];
+        const int k4 = nonzero4(cc2[cur][p][0], cc2[cur][p][1]);
+        scanA[o] = before;
+        if (n + (before + k4) - (o + 1) >= N) atomicMin(&s_cut, o);
+        before += k4;
+      }
+      __syncthreads();
+      const int cut = min(s_cut, m - 1);
+      int C;
+      {
+        const int p = pos_of_ord[cut];
+        C = scanA[cut] + nonzero4(cc2[cur][p][0], cc2[cur][p][1]);      // children created by nodes 0..cut
+      }
+      // survivors keep their order behind the children
+      int ss = 0;
+      for (int i = b; i < e; i++) ss += ((node[cur][i].z & 0xFFFFu) > 1u && ord[i] <= cut) ? 0 : 1;
+      int nsurv;
+      int sb = oct_block_excl(ss, &nsurv, wsum[ws]); ws = (ws + 1) & 3;
+      n_new = C + nsurv;
+      if (n_new > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+      int my_exp = 0;
+      for (int i = b; i < e; i++) {
+        const uint4 rec = node[cur][i];
+        if ((rec.z & 0xFFFFu) > 1u && ord[i] <= cut) {
+          const int x0 = rec.x & 0xFFFF, x1 = rec.x >> 16, y0 = rec.y & 0xFFFF, y1 = rec.y >> 16;
+          const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+          const unsigned c01 = cc2[cur][i][0], c23 = cc2[cur][i][1];
+          int ci = scanA[ord[i]];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const unsigned c = ((q & 2 ? c23 : c01) >> ((q & 1) * 16)) & 0xFFFFu;
+            if (c == 0) continue;
+            const int np = C - 1 - ci;
+            node[nxt][np] = make_uint4((unsigned)((q & 1) ? mx : x0) | ((unsigned)((q & 1) ? x1 : mx) << 16),
+                                       (unsigned)((q & 2) ? my : y0) | ((unsigned)((q & 2) ? y1 : my) << 16), c | ((unsigned)ci << 16), 0u);
+            cc2[nxt][np][0] = 0; cc2[nxt][np][1] = 0;
+            child_pos[i][q] = (unsigned short)np;
+            my_exp += c > 1;
+            ci++;
+          }
+        } else {
+          const int np = C + sb;
+          sb++;
+          node[nxt][np] = rec;
+          cc2[nxt][np][0] = 0; cc2[nxt][np][1] = 0;
+          new_pos[i] = (unsigned short)np;
+        }
+      }
+      if (my_exp) atomicAdd(&s_flag[par], my_exp);
+      __syncthreads();
+      nexp = s_flag[par];
+#pragma unroll
+      for (int m2 = 0; m2 < kOctKPT; m2++) {
+        if (tid + kOctThreads * m2 < nk) {
+          const unsigned p = kn[m2] & 0xFFFFu;
+          kn[m2] = ((kn[m2] >> 18) & 1u) && ord[p] <= cut ? child_pos[p][(kn[m2] >> 16) & 3u] : new_pos[p];
+        }
       }
     }
-    if (my_exp) atomicAdd(&s_flag, my_exp);                   // nToExpand of this pass
-    __syncthreads();
-    // ---- F. keys follow their node
-    for (int k = tid; k < nk; k += kOctThreads) {
-      const int p = node_of[k];
-      node_of[k] = (ncnt[cur][p] > 1 && ord[p] <= cut) ? child_pos[p][kq[k]] : new_pos[p];
-    }
-    nexp = s_flag;
-    __syncthreads();
-    cur = nxt; n = n_new;
+    cur = nxt; n = n_new; par ^= 1;
     if (n >= N || n == prev) break;                           // :667 / :732
     if (mode == 1 && n + 3 * nexp > N) mode = 2;              // :671
   }
-  // ---- retain the best key of every node, in list order (:742-758)
+  // ---- retain the best key of every node, in list order (:742-758): largest response, among equals the first candidate
+  if (n > cfg.reg_cap[level]) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+  __syncthreads();                                            // a thread that left the loop early may still be read above
   for (int i = tid; i < n; i += kOctThreads) best[i] = 0;
   __syncthreads();
-  for (int k = tid; k < nk; k += kOctThreads) atomicMax(&best[node_of[k]], ((unsigned)kr[k] << 16) | (unsigned)(0xFFFF - k));
+  unsigned kv[kOctKPT];
+#pragma unroll
+  for (int m = 0; m < kOctKPT; m++) {
+    kv[m] = 0;
+    if (tid + kOctThreads * m < nk) {
+      kv[m] = ((kw[m] >> 24) << 16) | (unsigned)(0xFFFF - (tid + kOctThreads * m));
+      atomicMax(&best[kn[m] & 0xFFFFu], kv[m]);
+    }
+  }
   __syncthreads();
-  if (n > cfg.reg_cap[level]) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
   OctSel* out = sel_out + cfg.reg_off[cam][level];
-  for (int i = tid; i < n; i += kOctThreads) {
-    const int k = 0xFFFF - (int)(best[i] & 0xFFFF);
-    OctSel o;
-    o.x = (short)(kx[k] + minB); o.y = (short)(ky[k] + minB); o.response = (float)kr[k];
-    out[i] = o;
+#pragma unroll
+  for (int m = 0; m < kOctKPT; m++) {
+    if (tid + kOctThreads * m < nk && best[kn[m] & 0xFFFFu] == kv[m]) {
+      OctSel o;
+      o.x = (short)((int)(kw[m] & 0xFFF) + minB); o.y = (short)((int)((kw[m] >> 12) & 0xFFF) + minB); o.response = (float)(kw[m] >> 24);
+      out[kn[m] & 0xFFFFu] = o;
+    }
   }
   if (tid == 0) *out_count = n;
 }

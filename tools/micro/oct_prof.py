@@ -3,14 +3,14 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from multi_orbslam3_amd import _capi
-_capi.LIB_PATH = os.path.join(ROOT, "tools", "micro", "variants", "liborbgpu_octprof.so")
+os.environ["ORBG_LIB"] = os.path.join(ROOT, "tools", "micro", "variants", "liborbgpu_octprof.so")
 from multi_orbslam3_amd import api, synth
 sc = synth.Scene(640, 480)
 L, R, _ = sc.stereo_pair(5)
 ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
 for _ in range(3):
     ex.extract_stereo(L, R)
+from multi_orbslam3_amd import _capi
 lib = _capi.load()
 buf = (C.c_longlong * (32 * 48))()
 lib.orbx_debug_oct_prof.argtypes = [C.c_void_p]
@@ -26,3 +26,8 @@ for b in range(16):
         line += "[n=%d m%d %d] " % (p[b, 5 + 2 * k] >> 2, p[b, 5 + 2 * k] & 3, nxt - p[b, 4 + 2 * k])
         k += 1
     print(line)
+
+for b in (0, 2):
+    print("blk %d pass 2 (mode 1): keys %d | barrier %d | scan %d | children %d | barrier %d | follow %d" % (b, p[b,30]-p[b,8], p[b,31]-p[b,30], p[b,32]-p[b,31], p[b,33]-p[b,32], p[b,34]-p[b,33], p[b,35]-p[b,34]))
+b = 0
+print("blk 0 pass 4 (mode 2): keys+rankkeys %d | barrier %d | rank %d | barrier %d | order scan+cut %d | (barrier+C+surv scan) %d | children %d | barrier+follow %d" % (p[b,36]-p[b,12], p[b,37]-p[b,36], p[b,38]-p[b,37], p[b,39]-p[b,38], p[b,40]-p[b,39], p[b,41]-p[b,40], p[b,42]-p[b,41], p[b,43]-p[b,42]))
