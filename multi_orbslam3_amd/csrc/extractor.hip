@@ -535,6 +535,13 @@ __device__ __forceinline__ int oct_block_excl(int s, int* total, int* wsum /*LDS
 //     words of the next list are zeroed by whoever creates a node.
 // A first-phase pass is three barriers, a second-phase pass six.
 constexpr int kOctKPT = kOctKeyCap / kOctThreads;     // keys per thread
+// -DOCT_PROFILE: s_memtime stamps of thread 0 per workgroup (tools/micro/oct_prof.py prints them)
+#ifdef OCT_PROFILE
+__device__ long long g_oct_prof[32][48];
+#define OCT_T(slot) do { if (threadIdx.x == 0 && (slot) < 48) g_oct_prof[blockIdx.x][slot] = clock64(); } while (0)
+#else
+#define OCT_T(slot) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __restrict__ cand, const int* __restrict__ hdr,
                                                             PyrGeom g, OctCfg cfg, OctSel* __restrict__ sel_out,
@@ -550,6 +557,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   __shared__ int s_n, s_cut, s_m, s_flag[2];
   const int tid = threadIdx.x;
   const int task = blockIdx.x;
+  OCT_T(0);
   const int cam = task % cfg.n_cams, level = task / cfg.n_cams;
   const LevelGeom L = g.lv[level];
   const int N = cfg.n_target[level];
@@ -610,9 +618,14 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   for (int m = 0; m < kOctKPT; m++) kn[m] = tid + kOctThreads * m < nk ? (unsigned)scanB[kn[m]] : 0u;
   int cur = 0, n = s_n, mode = 1, par = 0, ws = 0;
   // loop invariant: node[cur][0..n) is the list, cc2[cur][0..n) is zero, kn[m] & 0xFFFF is the position of key m's node
+  OCT_T(1);
   for (int pass = 0; pass < 64; pass++) {
     const int prev = n;
     const int nxt = cur ^ 1;
+    OCT_T(4 + 2 * pass);
+#ifdef OCT_PROFILE
+    if (tid == 0 && 5 + 2 * pass < 30) g_oct_prof[blockIdx.x][5 + 2 * pass] = n * 4 + mode;
+#endif
     // ---- keys: children key counts of every node with more than one key (:601-640 / :686-727 split the node's keys)
 #pragma unroll
     for (int m = 0; m < kOctKPT; m++) {
@@ -647,7 +660,11 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
       }
     }
     if (tid == 0) { s_flag[par] = 0; s_cut = 0x7fffffff; s_m = 0; }
+    if (pass == 2) OCT_T(30);
+    if (pass == 4) OCT_T(36);
     __syncthreads();
+    if (pass == 2) OCT_T(31);
+    if (pass == 4) OCT_T(37);
     // contiguous chunk of the list for this thread
     const int per = (n + kOctThreads - 1) / kOctThreads;
     const int b = min(tid * per, n), e = min(b + per, n);
@@ -659,6 +676,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
         if ((node[cur][i].z & 0xFFFFu) > 1u) sv += 1 | (nonzero4(cc2[cur][i][0], cc2[cur][i][1]) << 12);
       int tot;
       const int ex = oct_block_excl(sv, &tot, wsum[ws]); ws = (ws + 1) & 3;
+      if (pass == 2) OCT_T(32);
       const int m1 = tot & 0xFFF, C1 = tot >> 12;
       if (m1 == 0) break;
       n_new = C1 + (n - m1);
@@ -691,7 +709,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
         }
       }
       if (my_exp) atomicAdd(&s_flag[par], my_exp);
+      if (pass == 2) OCT_T(33);
       __syncthreads();
+      if (pass == 2) OCT_T(34);
       nexp = s_flag[par];
       // keys follow their node
 #pragma unroll
@@ -719,7 +739,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
           }
         }
       }
+      if (pass == 4) OCT_T(38);
       __syncthreads();
+      if (pass == 4) OCT_T(39);
       const int m = s_m;
       if (m == 0) break;                                      // every node holds one key: size unchanged -> finished
       // children created before each processed node (processing order, chunks), and the cut of the reference's `break`
@@ -737,6 +759,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
         if (n + (before + k4) - (o + 1) >= N) atomicMin(&s_cut, o);
         before += k4;
       }
+      if (pass == 4) OCT_T(40);
       __syncthreads();
       const int cut = min(s_cut, m - 1);
       int C;
@@ -749,6 +772,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
       for (int i = b; i < e; i++) ss += ((node[cur][i].z & 0xFFFFu) > 1u && ord[i] <= cut) ? 0 : 1;
       int nsurv;
       int sb = oct_block_excl(ss, &nsurv, wsum[ws]); ws = (ws + 1) & 3;
+      if (pass == 4) OCT_T(41);
       n_new = C + nsurv;
       if (n_new > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
       int my_exp = 0;
@@ -780,6 +804,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
         }
       }
       if (my_exp) atomicAdd(&s_flag[par], my_exp);
+      if (pass == 4) OCT_T(42);
       __syncthreads();
       nexp = s_flag[par];
 #pragma unroll
@@ -790,10 +815,16 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
         }
       }
     }
+    if (pass == 2) OCT_T(35);
+    if (pass == 4) OCT_T(43);
     cur = nxt; n = n_new; par ^= 1;
     if (n >= N || n == prev) break;                           // :667 / :732
     if (mode == 1 && n + 3 * nexp > N) mode = 2;              // :671
   }
+  OCT_T(2);
+#ifdef OCT_PROFILE
+  if (tid == 0) g_oct_prof[blockIdx.x][46] = nk * 65536 + n;
+#endif
   // ---- retain the best key of every node, in list order (:742-758): largest response, among equals the first candidate
   if (n > cfg.reg_cap[level]) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
   __syncthreads();                                            // a thread that left the loop early may still be read above
@@ -819,7 +850,11 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
     }
   }
   if (tid == 0) *out_count = n;
+  OCT_T(3);
 }
+#ifdef OCT_PROFILE
+extern "C" int orbx_debug_oct_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_prof), sizeof(g_oct_prof)) == hipSuccess ? 0 : -1; }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // orientation + blur + rBRIEF, one wavefront per keypoint
