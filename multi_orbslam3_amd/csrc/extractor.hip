@@ -563,11 +563,14 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   const int N = cfg.n_target[level];
   int* out_count = lvl_count + cam * ORBG_MAX_LEVELS + level;
   if (L.cell_end == L.cell_begin) { if (tid == 0) *out_count = 0; return; }
-  // candidate range of this (camera, level): next level that has cells, or the camera end
-  const int cb = hdr[cam * ORBG_MAX_LEVELS + level];
+  // candidate range of this (camera, level): next level that has cells, or the camera end.  Both header words come from ONE
+  // fetch (lane l reads word l of the 2 x 16 + 3 word header; picking them by two dependent loads cost a memory round trip more)
+  static_assert(2 * ORBG_MAX_LEVELS + 3 <= 64, "header does not fit one wavefront-wide load");
+  const int hword = hdr[min(tid & 63, 2 * ORBG_MAX_LEVELS + 2)];
   int nlv = level + 1;
   while (nlv < cfg.n_levels && g.lv[nlv].cell_end == g.lv[nlv].cell_begin) nlv++;
-  const int ce = nlv < cfg.n_levels ? hdr[cam * ORBG_MAX_LEVELS + nlv] : hdr[2 * ORBG_MAX_LEVELS + 1 + cam];
+  const int cb = __builtin_amdgcn_readlane(hword, cam * ORBG_MAX_LEVELS + level);
+  const int ce = __builtin_amdgcn_readlane(hword, nlv < cfg.n_levels ? cam * ORBG_MAX_LEVELS + nlv : 2 * ORBG_MAX_LEVELS + 1 + cam);
   const int nk = ce - cb;
   if (nk <= 0) { if (tid == 0) *out_count = 0; return; }
   // ce > cand_cap: gather_cells_kernel dropped the tail of the list, the host path regrows the buffer and redoes the frame
@@ -626,23 +629,32 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
 #ifdef OCT_PROFILE
     if (tid == 0 && 5 + 2 * pass < 30) g_oct_prof[blockIdx.x][5 + 2 * pass] = n * 4 + mode;
 #endif
-    // ---- keys: children key counts of every node with more than one key (:601-640 / :686-727 split the node's keys)
+    // ---- keys: children key counts of every node with more than one key (:601-640 / :686-727 split the node's keys).
+    // The records of four keys are requested before the first is used: the phases of this kernel are chains of dependent LDS
+    // round trips (200-300 cycles each with four wavefronts doing the same), so independent reads are issued together.
 #pragma unroll
-    for (int m = 0; m < kOctKPT; m++) {
-      if (kOctThreads * m < nk) {              // uniform
-        if (tid + kOctThreads * m < nk) {
-          const unsigned p = kn[m] & 0xFFFFu;
-          const uint4 rec = node[cur][p];
-          if ((rec.z & 0xFFFFu) > 1u) {
-            const int x0 = rec.x & 0xFFFF, x1 = rec.x >> 16, y0 = rec.y & 0xFFFF, y1 = rec.y >> 16;
-            const int mx = x0 + ((x1 - x0 + 1) >> 1);             // UL.x + ceil((UR.x-UL.x)/2)
-            const int my = y0 + ((y1 - y0 + 1) >> 1);
-            const int kx = kw[m] & 0xFFF, ky = (kw[m] >> 12) & 0xFFF;
-            const int q = (kx < mx ? 0 : 1) + (ky < my ? 0 : 2);
-            atomicAdd(&cc2[cur][p][q >> 1], q & 1 ? 0x10000u : 1u);          // packed u16 pair add (counts < 65536)
-            kn[m] = p | ((unsigned)q << 16) | (1u << 18);
-          } else {
-            kn[m] = p;
+    for (int m0 = 0; m0 < kOctKPT; m0 += 4) {
+      if (kOctThreads * m0 < nk) {             // uniform
+        uint4 rec4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rec4[u] = node[cur][kn[m0 + u] & 0xFFFFu];      // inactive keys sit on position 0
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int m = m0 + u;
+          if (tid + kOctThreads * m < nk) {
+            const unsigned p = kn[m] & 0xFFFFu;
+            const uint4 rec = rec4[u];
+            if ((rec.z & 0xFFFFu) > 1u) {
+              const int x0 = rec.x & 0xFFFF, x1 = rec.x >> 16, y0 = rec.y & 0xFFFF, y1 = rec.y >> 16;
+              const int mx = x0 + ((x1 - x0 + 1) >> 1);             // UL.x + ceil((UR.x-UL.x)/2)
+              const int my = y0 + ((y1 - y0 + 1) >> 1);
+              const int kx = kw[m] & 0xFFF, ky = (kw[m] >> 12) & 0xFFF;
+              const int q = (kx < mx ? 0 : 1) + (ky < my ? 0 : 2);
+              atomicAdd(&cc2[cur][p][q >> 1], q & 1 ? 0x10000u : 1u);          // packed u16 pair add (counts < 65536)
+              kn[m] = p | ((unsigned)q << 16) | (1u << 18);
+            } else {
+              kn[m] = p;
+            }
           }
         }
       }
@@ -715,22 +727,52 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
       nexp = s_flag[par];
       // keys follow their node
 #pragma unroll
-      for (int m = 0; m < kOctKPT; m++) {
-        if (tid + kOctThreads * m < nk) {
-          const unsigned p = kn[m] & 0xFFFFu;
-          kn[m] = (kn[m] >> 18) & 1u ? child_pos[p][(kn[m] >> 16) & 3u] : new_pos[p];
+      for (int m0 = 0; m0 < kOctKPT; m0 += 4) {
+        if (kOctThreads * m0 < nk) {
+          unsigned short cp[4], npv[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const unsigned p = kn[m0 + u] & 0xFFFFu; cp[u] = child_pos[p][(kn[m0 + u] >> 16) & 3u]; npv[u] = new_pos[p]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) kn[m0 + u] = tid + kOctThreads * (m0 + u) < nk ? ((kn[m0 + u] >> 18) & 1u ? cp[u] : npv[u]) : 0u;
         }
       }
     } else {
-      // ---- phase 2: processing order = descending (key count, creation number): rank by counting, four keys per LDS read
-      {
+      // ---- phase 2: processing order = descending (key count, creation number): rank by counting.  Every wavefront takes the
+      // whole key list into registers (lane l: keys l, l+64, ...) and broadcasts it lane by lane (v_readlane): n compares per
+      // node without a single further LDS access (n/4 128-bit LDS reads per node before: 7 k cycles at n = 174)
+      if (n <= kOctThreads) {
+        // one node per thread (the usual case: n <= N + 3, N <= 250 for up to ~1150 features per image)
+        const int lane = tid & 63;
+        const int nreg = (n + 63) >> 6;
+        const unsigned mykey = tid < n ? (unsigned)scanB[tid] : 0u;
+        int myrank = 0;
+        for (int rg = 0; rg < nreg; rg++) {
+          const int idx = rg * 64 + lane;
+          const unsigned kreg = idx < n ? (unsigned)scanB[idx] : 0u;
+#pragma unroll
+          for (int l = 0; l < 64; l++) myrank += (unsigned)__builtin_amdgcn_readlane((int)kreg, l) > mykey;
+        }
+        if (mykey) {
+          ord[tid] = (unsigned short)myrank; pos_of_ord[myrank] = (unsigned short)tid;
+          atomicMax(&s_m, myrank + 1);
+        }
+      } else {
         const int n4 = (n + 3) & ~3;
         for (int i = tid; i < n; i += kOctThreads) {
           const unsigned key = (unsigned)scanB[i];
           if (key) {
             int r = 0;
             const uint4* k4p = reinterpret_cast<const uint4*>(scanB);
-            for (int j = 0; j < n4 / 4; j++) {
+            const int nq = n4 / 4;
+            int j = 0;
+            for (; j + 8 <= nq; j += 8) {                     // eight reads in flight (an LDS round trip each otherwise)
+              uint4 kk[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) kk[u] = k4p[j + u];
+#pragma unroll
+              for (int u = 0; u < 8; u++) r += (kk[u].x > key) + (kk[u].y > key) + (kk[u].z > key) + (kk[u].w > key);
+            }
+            for (; j < nq; j++) {
               const uint4 kk = k4p[j];
               r += (kk.x > key) + (kk.y > key) + (kk.z > key) + (kk.w > key);
             }
@@ -748,13 +790,17 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
       const int pero = (m + kOctThreads - 1) / kOctThreads;
       const int bo = min(tid * pero, m), eo = min(bo + pero, m);
       int so = 0;
-      for (int o = bo; o < eo; o++) { const int p = pos_of_ord[o]; so += nonzero4(cc2[cur][p][0], cc2[cur][p][1]); }
+      unsigned k4pack = 0;                                    // the chunk's children counts, 3 bits each (chunks are <= 8 long)
+      for (int o = bo; o < eo; o++) {
+        const int p = pos_of_ord[o];
+        const int k4 = nonzero4(cc2[cur][p][0], cc2[cur][p][1]);
+        so += k4; k4pack |= (unsigned)k4 << (3 * (o - bo));
+      }
       int totK;
       int before = oct_block_excl(so, &totK, wsum[ws]); ws = (ws + 1) & 3;
       (void)totK;
       for (int o = bo; o < eo; o++) {
-        const int p = pos_of_ord[o];
-        const int k4 = nonzero4(cc2[cur][p][0], cc2[cur][p][1]);
+        const int k4 = (k4pack >> (3 * (o - bo))) & 7;
         scanA[o] = before;
         if (n + (before + k4) - (o + 1) >= N) atomicMin(&s_cut, o);
         before += k4;
@@ -808,10 +854,13 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
       __syncthreads();
       nexp = s_flag[par];
 #pragma unroll
-      for (int m2 = 0; m2 < kOctKPT; m2++) {
-        if (tid + kOctThreads * m2 < nk) {
-          const unsigned p = kn[m2] & 0xFFFFu;
-          kn[m2] = ((kn[m2] >> 18) & 1u) && ord[p] <= cut ? child_pos[p][(kn[m2] >> 16) & 3u] : new_pos[p];
+      for (int m0 = 0; m0 < kOctKPT; m0 += 4) {
+        if (kOctThreads * m0 < nk) {
+          unsigned short cp[4], npv[4], od[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const unsigned p = kn[m0 + u] & 0xFFFFu; cp[u] = child_pos[p][(kn[m0 + u] >> 16) & 3u]; npv[u] = new_pos[p]; od[u] = ord[p]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) kn[m0 + u] = tid + kOctThreads * (m0 + u) < nk ? (((kn[m0 + u] >> 18) & 1u) && (int)od[u] <= cut ? cp[u] : npv[u]) : 0u;
         }
       }
     }
