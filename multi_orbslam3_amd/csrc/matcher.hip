@@ -1074,7 +1074,20 @@ struct orbm_map {
   DevBuf<uint8_t> t_in_view;
   DevBuf<float> t_px, t_py, t_pxr, t_depth, t_vc;
   DevBuf<int> t_level;
+  // the upload is asynchronous: the copy is followed by an event the consumers' streams wait for (no host wait per upload;
+  // UpdateLocalMap runs once per keyframe, the next search on another stream follows ~100 us later)
+  hipEvent_t up_ev = nullptr;
+  bool up_pending = false;
 };
+
+// Orders the kernels enqueued on `st` after the map's last upload.  Host cost: one hipStreamWaitEvent while an upload is pending.
+static int map_sync_to(orbm_map* m, hipStream_t st) {
+  if (!m->up_pending) return ORBG_OK;
+  if (hipEventQuery(m->up_ev) == hipSuccess) { m->up_pending = false; return ORBG_OK; }
+  (void)hipGetLastError();                       // hipErrorNotReady is not an error here
+  ORBG_HIP(hipStreamWaitEvent(st, m->up_ev, 0));
+  return ORBG_OK;
+}
 
 static int map_reserve(orbm_map* m, int n) {
   const size_t c = (size_t)std::max(n, 1);
@@ -1096,6 +1109,7 @@ extern "C" int orbm_map_create(int device, int cap_points, orbm_map** out) {
   orbm_map* m = new orbm_map();
   m->device = device;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return ORBG_HIP_ERROR; }
+  if (hipEventCreateWithFlags(&m->up_ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(m->stream); delete m; return ORBG_HIP_ERROR; }
   if ((rc = map_reserve(m, cap_points))) { orbm_map_destroy(m); return rc; }
   *out = m;
   return ORBG_OK;
@@ -1106,6 +1120,7 @@ extern "C" int orbm_map_destroy(orbm_map* m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   m->arena.release(); m->stage.release();
+  if (m->up_ev) (void)hipEventDestroy(m->up_ev);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   m->t_in_view.release(); m->t_px.release(); m->t_py.release(); m->t_pxr.release(); m->t_depth.release();
   m->t_vc.release(); m->t_level.release();
@@ -1118,6 +1133,8 @@ extern "C" int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* p) {
   if (p->m > 0 && (!p->pos || !p->normal || !p->min_dist || !p->max_dist || !p->desc || !p->n_obs || !p->bad)) return ORBG_BAD_ARG;
   int rc = select_device(m->device);
   if (rc) return rc;
+  // the staging block (and, if the buffers grow, the arena) must not be touched while the previous copy is in flight
+  if (m->up_pending) { ORBG_HIP(hipEventSynchronize(m->up_ev)); m->up_pending = false; }
   if ((rc = map_reserve(m, p->m))) return rc;
   const size_t n = (size_t)p->m;
   m->m = p->m;
@@ -1130,7 +1147,8 @@ extern "C" int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* p) {
     memcpy(S + m->o_desc, p->desc, n * 32); memcpy(S + m->o_bad, p->bad, n);
     if (p->skip) memcpy(S + m->o_skip, p->skip, n); else memset(S + m->o_skip, 0, n);
     ORBG_HIP(hipMemcpyAsync(m->arena.p, S, m->arena_bytes, hipMemcpyHostToDevice, m->stream));
-    ORBG_HIP(hipStreamSynchronize(m->stream));
+    ORBG_HIP(hipEventRecord(m->up_ev, m->stream));
+    m->up_pending = true;
   }
   return ORBG_OK;
 }
@@ -1169,6 +1187,7 @@ extern "C" int orbm_is_in_frustum(orbm_frame* f, const float* Tcw, const orbm_wo
   make_pose(Tcw, &P);
   const int n = pts->m;
   if (n > 0) {
+    if ((rc = map_sync_to(m, f->stream))) { orbm_map_destroy(m); return rc; }
     hipLaunchKernelGGL(frustum_kernel, dim3((n + 255) / 256), dim3(256), 0, f->stream, f->fp, P, map_dev(m), limit, map_track(m));
     hipError_t e = hipStreamSynchronize(f->stream);
     if (e != hipSuccess) { orbm_map_destroy(m); return ORBG_HIP_ERROR; }
@@ -1388,6 +1407,7 @@ extern "C" int orbm_search_local_points(orbm_frame* f, orbm_map* mp, const float
   make_pose(Tcw, &P);
   const uint8_t* d_skip_call = skip ? stage_add(f, skip, m) : nullptr;
   if ((rc = stage_commit(f))) return rc;
+  if ((rc = map_sync_to(mp, st))) return rc;       // the map's last upload may still be in flight on its own stream
   const WorldPtsDev w = map_dev(mp);
   rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_local_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), w, d_skip_call, P, th, far_points,
@@ -1593,6 +1613,7 @@ extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const
   make_pose(T16, &P);
   FrameDev F = frame_dev(f);
   F.uright = nullptr;                                          // no stereo gate in the KeyFrame searches
+  if ((rc = map_sync_to(mp, st))) return rc;
   rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_sim3_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P,
                        camera_project, th, cnt, cnt_next, f->list.d, list_cap, f->results.d);
