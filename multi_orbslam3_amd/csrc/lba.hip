@@ -190,6 +190,45 @@ __device__ inline void pose_oplus_fast(const PoseQ& T, const double* u, PoseQ* o
   out->q[0] = q0 * in; out->q[1] = q1 * in; out->q[2] = q2 * in; out->q[3] = q3 * in;
 }
 
+// 1/sqrt(d): hardware seed + two Newton-Raphson steps
+__device__ __forceinline__ double fast_rsqrt(double d) {
+  double x = __builtin_amdgcn_rsq(d);
+  x = x * __builtin_fma(-0.5 * d * x, x, 1.5);
+  x = x * __builtin_fma(-0.5 * d * x, x, 1.5);
+  return x;
+}
+
+// exp(u) * T for the increments of PoseOptimization's trial loop (|omega| < 0.3 rad; anything larger takes pose_oplus_fast):
+// the four functions of theta the exponential needs -- sin(theta/2)/theta, cos(theta/2), (1-cos theta)/theta^2,
+// (theta - sin theta)/theta^3 -- are even power series in theta, six terms of each are exact to 1e-17 in that range; no
+// sqrt, sincos or division (the library sincos alone is ~300 FP64 instructions, and every instruction of this kernel costs
+// the workgroup 8 cycles on the critical path), and no cancellation in (1 - cos theta) for the small angles LM steps have.
+__device__ inline void pose_oplus_series(const PoseQ& T, const double* u, PoseQ* out) {
+  const double om0 = u[0], om1 = u[1], om2 = u[2];
+  const double t = om0 * om0 + om1 * om1 + om2 * om2;
+  if (t > 0.09) { pose_oplus_fast(T, u, out); return; }
+  const double s = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 81749606400.0, 1.0 / 185794560.0), -1.0 / 645120.0), 1.0 / 3840.0), -1.0 / 48.0), 0.5);
+  const double c = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 3715891200.0, 1.0 / 10321920.0), -1.0 / 46080.0), 1.0 / 384.0), -0.125), 1.0);
+  const double b = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 479001600.0, 1.0 / 3628800.0), -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0), 0.5);
+  const double cc = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 6227020800.0, 1.0 / 39916800.0), -1.0 / 362880.0), 1.0 / 5040.0), -1.0 / 120.0), 1.0 / 6.0);
+  // V u_t = u_t + b (omega x u_t) + cc (omega x (omega x u_t))
+  const double w0 = om1 * u[5] - om2 * u[4], w1 = om2 * u[3] - om0 * u[5], w2 = om0 * u[4] - om1 * u[3];
+  const double z0 = om1 * w2 - om2 * w1, z1 = om2 * w0 - om0 * w2, z2 = om0 * w1 - om1 * w0;
+  const double et[3] = {u[3] + b * w0 + cc * z0, u[4] + b * w1 + cc * z1, u[5] + b * w2 + cc * z2};
+  const double eq[4] = {om0 * s, om1 * s, om2 * s, c};          // unit up to rounding, w > 0
+  double rt[3];
+  quat_rotate(eq, T.t, rt);
+  out->t[0] = et[0] + rt[0]; out->t[1] = et[1] + rt[1]; out->t[2] = et[2] + rt[2];
+  const double* b2 = T.q;
+  double q3 = eq[3] * b2[3] - eq[0] * b2[0] - eq[1] * b2[1] - eq[2] * b2[2];
+  double q0 = eq[3] * b2[0] + eq[0] * b2[3] + eq[1] * b2[2] - eq[2] * b2[1];
+  double q1 = eq[3] * b2[1] + eq[1] * b2[3] + eq[2] * b2[0] - eq[0] * b2[2];
+  double q2 = eq[3] * b2[2] + eq[2] * b2[3] + eq[0] * b2[1] - eq[1] * b2[0];
+  if (q3 < 0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
+  const double in = fast_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  out->q[0] = q0 * in; out->q[1] = q1 * in; out->q[2] = q2 * in; out->q[3] = q3 * in;
+}
+
 // 1/d to ~1 ulp: hardware seed + two Newton-Raphson steps
 __device__ __forceinline__ double fast_rcp(double d) {
   double x = __builtin_amdgcn_rcp(d);
@@ -2574,6 +2613,9 @@ __device__ inline bool po_solve6(const double* Hrow, double b_li, int li, double
 }
 
 __device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, float v, float ur, const Cam& c, double* err, double* Xc) {
+  // the same operations in the same order as the oracle's edge error: the LM loop's accept / reject and termination tests sit
+  // on differences of chi2 sums at convergence, where one changed rounding flips a decision (tried: rotation matrix instead of
+  // the quaternion sandwich and Newton reciprocals instead of divisions -- 20 % fewer cycles here, different iteration counts)
   const double Xd[3] = {X[0], X[1], X[2]};
   double r[3];
   quat_rotate(T.q, Xd, r);
@@ -2596,6 +2638,15 @@ __device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, fl
 // each round.  The LM state (pose, lambda, gains) is kept identically in every thread -- all of them read the same
 // block sums from LDS and run the same arithmetic -- so the control flow needs no broadcast; the 6x6 solve runs on
 // lanes 0..5 of each wave.
+// -DPO_PROFILE: cycles of thread 0 per phase, summed over the call (build, reduce, solve, trial evaluation, trial sum, rest)
+#ifdef PO_PROFILE
+__device__ long long g_po_prof[8];
+#define PO_T0() long long po_t = clock64()
+#define PO_ACC(slot) do { const long long po_n = clock64(); if (threadIdx.x == 0) g_po_prof[slot] += po_n - po_t; po_t = po_n; } while (0)
+#else
+#define PO_T0() do { } while (0)
+#define PO_ACC(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float* Xw, const float* ou, const float* ov, const float* our,
                                                              const float* oinv, Cam cam, PoseQ T0,
                                                              PoseQ* __restrict__ T_out, uint8_t* __restrict__ outlier_out,
@@ -2628,6 +2679,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   int nBad = 0;
   if (tid == 0) { for (int i = 0; i < 7; i++) stats[i] = 0; for (int i = 0; i < 4; i++) chi_out[i] = 0; }
   __syncthreads();
+  PO_T0();
   for (int round = 0; round < 4; round++) {
     T = T0;                                                   // setEstimate(toSE3Quat(mTcw)) every round (:1191)
     double cnt = 0;
@@ -2696,7 +2748,9 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
           acc[o++] += sacc;
         }
       }
+      PO_ACC(0);
       po_block_reduce<28>(acc, s_acc, s_part, red);
+      PO_ACC(1);
       // every thread takes its own copy of the system: row li of H (upper triangle packed row-major in red[0..21)), b
       double Hrow[6], b[6];
 #pragma unroll
@@ -2716,9 +2770,11 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
       double rho = 0;
       int qmax = 0;
       for (;;) {
+        PO_ACC(5);
         const bool ok2 = po_solve6(Hrow, b_li, li, lambda, x);
         PoseQ Tt;
-        pose_oplus_fast(T, x, &Tt);                         // update with whatever x holds, as g2o does
+        pose_oplus_series(T, x, &Tt);                       // update with whatever x holds, as g2o does
+        PO_ACC(2);
         double tchi = 0;
         // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
         for (int i = tid; i < n; i += kPoThreads) {
@@ -2734,7 +2790,9 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
           if (robust) huber(c2, mono ? dM : dS, mono ? dsqM : dsqS, &rho0, &rho1);
           tchi += rho0;
         }
+        PO_ACC(3);
         double tempChi = po_block_sum(tchi, s_wsum, sum_slot); sum_slot ^= 1;
+        PO_ACC(4);
         if (!ok2) tempChi = 1.7976931348623157e308;
         rho = currentChi - tempChi;
         double scale = 0;
@@ -2783,6 +2841,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
     if (round == 2) robust = false;                          // setRobustKernel(0)
     if (n < 10) break;                                        // optimizer.edges().size() < 10
   }
+  PO_ACC(5);
   for (int i = tid; i < n; i += kPoThreads) outlier_out[i] = s_out[i];
   if (tid == 0) { *T_out = T; stats[0] = nBad; }
   __threadfence_system();
@@ -2791,6 +2850,14 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
 }
 
 }  // namespace
+
+#ifdef PO_PROFILE
+extern "C" int pose_opt_debug_prof(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_po_prof), sizeof(g_po_prof)) != hipSuccess) return -1;
+  if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_po_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   if (!p || !r || p->n < 0 || (p->n > 0 && (!p->Xw || !p->u || !p->v || !p->ur || !p->inv_sigma2 || !r->outlier))) return ORBG_BAD_ARG;
