@@ -305,7 +305,16 @@ struct Query { int valid; float x, y, r; int min_level, max_level; float ur_ref;
 constexpr int kSlot = 16;
 constexpr int kListStage = 64;
 
-__device__ __forceinline__ void window_search(const FrameParams& fp, const FrameDev& F, const Query& q, const uint8_t* qdesc,
+struct QDesc { uint4 a0, a1; };
+// a query's descriptor: requested at the top of a kernel, together with its other fields (for the frame search they sit in
+// pinned host memory: every dependent access there is a ~2 us PCIe round trip)
+__device__ __forceinline__ QDesc load_qdesc(const uint8_t* p) {
+  QDesc d;
+  d.a0 = *reinterpret_cast<const uint4*>(p); d.a1 = *reinterpret_cast<const uint4*>(p + 16);
+  return d;
+}
+
+__device__ __forceinline__ void window_search(const FrameParams& fp, const FrameDev& F, const Query& q, const QDesc& qd,
                                               int qid, int n_queries, int* __restrict__ list_counter,
                                               uint32_t* __restrict__ list, int list_cap, QResult* __restrict__ out,
                                               uint32_t* __restrict__ s_list /*LDS, kListStage entries of this wavefront*/) {
@@ -348,8 +357,7 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
     if (lane == 0) base = n_queries * kSlot + atomicAdd(list_counter, total);
     base = __shfl(base, 0, 64);
   }
-  const uint4 a0 = *reinterpret_cast<const uint4*>(qdesc);
-  const uint4 a1 = *reinterpret_cast<const uint4*>(qdesc + 16);
+  const uint4 a0 = qd.a0, a1 = qd.a1;
   const bool bCheckLevels = (q.min_level > 0) || (q.max_level >= 0);
   Top4 t;
   top4_init(t);
@@ -367,11 +375,19 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
     const int chunk_total = __builtin_amdgcn_readlane(inc, 63);
     const int my_pos0 = run + inc - n;
     const int nmax = wave_max(n);
+    // The candidate loop is a chain of dependent loads (item -> keypoint -> right coordinate -> descriptor, ~0.3 us each from
+    // the L2): the next item's index is fetched one step ahead, and a candidate's keypoint, right coordinate and descriptor
+    // are requested together (the descriptor of a candidate the gates reject is then simply not used)
+    int idx_next = n > 0 ? F.cell_items[s] : 0;
     for (int j = 0; j < nmax; j++) {
+      const int idx = idx_next;
+      if (j + 1 < n) idx_next = F.cell_items[s + j + 1];
       if (j < n) {
-        const int idx = F.cell_items[s + j];
         const int pos = my_pos0 + j;
         const orbx_keypoint kp = F.kps[idx];
+        const float ur_c = F.uright ? F.uright[idx] : 0.f;
+        const uint4 b0 = *reinterpret_cast<const uint4*>(F.desc + (size_t)idx * 32);
+        const uint4 b1 = *reinterpret_cast<const uint4*>(F.desc + (size_t)idx * 32 + 16);
         bool ok = true;
         if (bCheckLevels) {
           if (kp.octave < q.min_level) ok = false;
@@ -381,7 +397,7 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
         if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) ok = false;
         if (ok && feature_occupied(F, idx)) ok = false;
         if (ok && F.uright) {
-          const float ur = F.uright[idx];
+          const float ur = ur_c;
           if (ur > 0) {
             const float er = fabsf(q.ur_ref - ur);
             if (er > q.r) ok = false;
@@ -389,8 +405,6 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
         }
         unsigned entry = 0xFFFFFFFFu;
         if (ok) {
-          const uint4 b0 = *reinterpret_cast<const uint4*>(F.desc + (size_t)idx * 32);
-          const uint4 b1 = *reinterpret_cast<const uint4*>(F.desc + (size_t)idx * 32 + 16);
           const int d = popc256(a0, a1, b0, b1);
           top4_insert(t, ((unsigned)d << 20) | (unsigned)pos, idx);
           entry = (unsigned)idx | ((unsigned)d << 16);
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(256) void search_mps_kernel(FrameParams fp, FrameDe
     q.min_level = lvl - 1; q.max_level = lvl;
     q.ur_ref = mp.pxr[i];
   }
-  window_search(fp, F, q, mp.desc + (size_t)i * 32, i, mp.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
+  window_search(fp, F, q, load_qdesc(mp.desc + (size_t)i * 32), i, mp.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
 
@@ -452,10 +466,14 @@ __global__ __launch_bounds__(256) void search_local_kernel(FrameParams fp, Frame
   if (i >= w.m) return;
   Query q;
   q.valid = 0; q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
-  if (!(w.bad[i] || w.skip[i] || (skip_call && skip_call[i]))) {
-    const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
-    const float N[3] = {w.normal[3 * i], w.normal[3 * i + 1], w.normal[3 * i + 2]};
-    const TrackFields t = frustum_check(fp, P, X, N, w.min_dist[i], w.max_dist[i], 0.5f);
+  // the point's fields and its descriptor are requested together (flags -> position -> distances -> descriptor were dependent)
+  const uint8_t w_bad = w.bad[i], w_skip = w.skip[i], c_skip = skip_call ? skip_call[i] : (uint8_t)0;
+  const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
+  const float N[3] = {w.normal[3 * i], w.normal[3 * i + 1], w.normal[3 * i + 2]};
+  const float w_min = w.min_dist[i], w_max = w.max_dist[i];
+  const QDesc qd = load_qdesc(w.desc + (size_t)i * 32);
+  if (!(w_bad || w_skip || c_skip)) {
+    const TrackFields t = frustum_check(fp, P, X, N, w_min, w_max, 0.5f);
     if (t.in_view && !(far_points && t.depth > th_far)) {
       float r = (t.view_cos > 0.998) ? 2.5f : 4.0f;        // RadiusByViewingCos, S/ORBmatcher.cc:216-222
       if (th != 1.0) r *= th;
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(256) void search_local_kernel(FrameParams fp, Frame
       q.ur_ref = t.pxr;
     }
   }
-  window_search(fp, F, q, w.desc + (size_t)i * 32, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
+  window_search(fp, F, q, qd, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
 // SearchByProjection(KeyFrame*, Scw, ...) candidate tests (S/ORBmatcher.cc:495-548 / :612-667) fused with the window search
@@ -479,6 +497,7 @@ __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameD
   if (i >= w.m) return;
   Query q;
   q.valid = 0; q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
+  const QDesc qd = load_qdesc(w.desc + (size_t)i * 32);
   if (!(w.bad[i] || w.skip[i] || (found && found[i]))) {
     const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
     float Pc[3];
@@ -516,7 +535,7 @@ __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameD
       }
     }
   }
-  window_search(fp, F, q, w.desc + (size_t)i * 32, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
+  window_search(fp, F, q, qd, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
 // MODE 2: SearchByProjection(CurrentFrame, LastFrame) (S/ORBmatcher.cc:1993-2066)
@@ -534,8 +553,12 @@ __global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, Frame
   if (i >= L.n) return;
   Query q;
   q.valid = 0; q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
-  if (L.mp_valid[i] && !L.outlier[i]) {
-    const float X[3] = {L.world_pos[3 * i], L.world_pos[3 * i + 1], L.world_pos[3 * i + 2]};
+  // every field of the query in ONE trip to host memory (valid -> position -> octave -> descriptor were four)
+  const uint8_t l_valid = L.mp_valid[i], l_outlier = L.outlier[i];
+  const float X[3] = {L.world_pos[3 * i], L.world_pos[3 * i + 1], L.world_pos[3 * i + 2]};
+  const int l_oct = L.octave[i];
+  const QDesc qd = load_qdesc(L.desc + (size_t)i * 32);
+  if (l_valid && !l_outlier) {
     float x3Dc[3];
     pose_map(Pc, X, x3Dc);
     const float invzc = (float)(1.0 / (double)x3Dc[2]);
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, Frame
       const float u = fp.fx * x3Dc[0] / x3Dc[2] + fp.cx;
       const float v = fp.fy * x3Dc[1] / x3Dc[2] + fp.cy;
       if (!(u < fp.min_x || u > fp.max_x) && !(v < fp.min_y || v > fp.max_y)) {
-        const int oct = L.octave[i];
+        const int oct = l_oct;
         q.valid = 1;
         q.x = u; q.y = v;
         q.r = th * fp.scale[oct];
@@ -554,7 +577,7 @@ __global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, Frame
       }
     }
   }
-  window_search(fp, F, q, L.desc + (size_t)i * 32, i, L.n, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
+  window_search(fp, F, q, qd, i, L.n, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
 // SearchByBoW inner loops (S/ORBmatcher.cc:297-371): one wavefront per keyframe feature of a shared node.
