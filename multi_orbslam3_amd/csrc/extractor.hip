@@ -1146,8 +1146,11 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
   if (!(maxU < 0) && row >= 0 && row < nRows) {
     const uint4 a0 = *reinterpret_cast<const uint4*>(dl + (size_t)iL * 32);
     const uint4 a1 = *reinterpret_cast<const uint4*>(dl + (size_t)iL * 32 + 16);
+    // the right keypoint of the NEXT round is requested before this round's gates and descriptor (each a dependent trip to the L2)
+    orbx_keypoint kpN = kr[min(lane, nr - 1)];
     for (int iR = lane; iR < nr; iR += 64) {
-      const orbx_keypoint kpR = kr[iR];
+      const orbx_keypoint kpR = kpN;
+      kpN = kr[min(iR + 64, nr - 1)];
       const float r = 2.0f * g.scale[kpR.octave];
       const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);   // vRowIndices band (:806-811)
       if (row < minr || row > maxr) continue;
