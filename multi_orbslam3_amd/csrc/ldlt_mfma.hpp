@@ -7,9 +7,9 @@
 // triangle's tiles are dealt cyclically to the wavefronts and stay in REGISTERS for the whole factorisation, in the
 // accumulator layout of the instruction (lane l, register g <-> row (l>>4)+4g, column l&15).  Per tile row k:
 //
-//   diag    the owner of tile (k,k) eliminates its 16 pivots one by one; every pivot is ONE matrix instruction on the
-//           tile (rank-1 update  C -= u (r u)^T: the instruction's operand broadcast replaces the LDS / readlane
-//           exchange a VALU update needs) and one on a copy of the identity, which collects G = L_kk^-1.
+//   diag    the owner of tile (k,k) eliminates its 16 pivots TWO at a time; every pair is ONE matrix instruction on the
+//           tile (rank-2 update: the instruction's operand broadcast replaces the LDS / readlane exchange a VALU
+//           update needs) and one on a copy of the identity, which collects G = L_kk^-1.
 //           Row j of a symmetric tile in accumulator layout IS column j in A-operand layout, so no data moves.
 //   panel   the owners of tiles (k,j), j>k: R = G X (4 instructions), W = D^-1 R; -R and W are published in LDS in
 //           operand layout, W also goes to the factor store (the unit upper-triangular factor L^T, row blocks).
@@ -440,15 +440,16 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
 
 // ---------------------------------------------------------------------------------------------------------------
 // Column variant for up to 8 tile rows (windows of <= 20 free poses, the C2 workload): tile column j lives in
-// wavefront j.  Measured on MI355X (tools/micro/mfma_f64_latency.hip): an FP64 matrix instruction and FP64 vector
-// instructions of the same SIMD do NOT overlap (the 16x16x4 instruction holds the FP64 pipe for 64 cycles), so a
-// pivot costs its owner  readlane + rcp + one instruction = ~170 cycles  and every further instruction per pivot
-// (the identity copy of the general kernel) another ~66.  Here the diagonal wavefront therefore does nothing but its
-// own tile: it streams every pivot (the row u and 1/d) through LDS and the owners of the panel tiles (k, j) REPLAY the
-// rank-1 updates on their tile one step behind (one instruction per pivot on another SIMD), collecting R and W row by
-// row.  Wavefront k+1 holds both (k, k+1) and (k+1, k+1): it folds R^T W into its diagonal tile four pivots at a time
-// straight from registers, so the next diagonal tile is complete one instruction after the last replayed pivot.
-// Only R goes through LDS for the remaining trailing tiles (W stays in the owner's registers).
+// wavefront j.  Measured on MI355X (tools/micro/): an FP64 matrix instruction and FP64 vector instructions of the same
+// SIMD do NOT overlap (the 16x16x4 instruction holds the FP64 pipe for 64 cycles), every FP64 vector instruction costs a
+// wavefront 8 cycles of issue, and a pair of pivots costs its owner ~340 cycles in isolation (readlanes, two reciprocals,
+// the row reduction, one instruction) -- every further instruction on the diagonal wavefront is added serially.  Here
+// the diagonal wavefront therefore does nothing but its own tile: it streams every pair (its A operand and the two
+// reciprocals) through LDS and the owners of the panel tiles (k, j) REPLAY the pairs on their tile (one instruction per
+// pair on another SIMD), collecting R and W row by row.  Wavefront k+1 holds both (k, k+1) and (k+1, k+1): it folds
+// R^T W into its diagonal tile four rows at a time straight from registers, so the next diagonal tile is complete one
+// instruction after the last replayed pair.  Only -W goes through LDS for the remaining trailing tiles (their B operand
+// is the owner's own unscaled R, which stays in registers).
 constexpr int kColT = 8;
 constexpr int kPivRing = 4;                                   // tile rows of streamed pivots kept in LDS
 constexpr int kColPanels = kColT * (kColT - 1) / 2;           // one R image per panel tile: never overwritten
@@ -478,8 +479,8 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
   const int lr = lane >> 4, lc = lane & 15;
   const Geo G = make_geo(n);
   const int T = G.T, n_pad = G.n_pad, cb = G.cb;
-  double* const Piv = sh;                               // [4][16][64]  per pivot the A operand -L[:, pv] (zero outside its lane group)
-  double* const Rcp = Piv + kPivRing * 16 * 64;         // [4][16]      1/d, written four pivots at a time
+  double* const Piv = sh;                               // [4][8][64]   per pivot pair the A operand (-L[:, p0] | -L[:, p1] in their lane groups, zero elsewhere)
+  double* const Rcp = Piv + kPivRing * 16 * 64;         // [4][16]      1/d, written pair by pair
   double* const Rb = Rcp + kPivRing * 16;               // [28][256]    -W_kj register images, tile (k, j) at k(15-k)/2 + j-k-1
   double* const Wl = Rb + kColPanels * 256;             // unit upper factor, pair-packed
   if (wv == 0) LDLTM_T(0);
