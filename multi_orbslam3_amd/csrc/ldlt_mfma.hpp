@@ -468,6 +468,47 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const volatile d2* lds_vd2p;
 typedef __attribute__((address_space(3))) const volatile double* lds_vdp;
 
+// Back-substitution of the column kernel with every pair index known at compile time (NP = n_pad / 2 pairs of columns):
+// lane selects of v_readlane, LDS offsets and the bounds of the look-ahead ring become immediates, the address arithmetic and
+// the loop control of the run-time form (about half of its ~35 instructions per pair) disappear.  Instantiated for the
+// window size local BA runs at (20 free poses: n_pad = 120); other sizes take the loops in the kernel.
+template <int NP>
+__device__ __forceinline__ void backsub_pairs_unrolled(const lds_vd2p W2, double& y0, double& y1, const int lane) {
+  if constexpr (NP > 32) {
+    d2 c0[4], c1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int pi = NP - 1 - i > 32 ? NP - 1 - i : 32; c0[i] = W2[pi * (pi + 1)]; c1[i] = W2[pi * (pi + 1) + 64]; }
+#pragma unroll
+    for (int p2 = NP - 1; p2 >= 32; p2--) {
+      const int i = (NP - 1 - p2) & 3;
+      const bool on = 64 + lane <= 2 * p2 + 1;
+      const double x1 = rdlane(y1, 2 * p2 + 1 - 64);
+      y1 -= (on ? c1[i][1] : 0.0) * x1;
+      y0 -= c0[i][1] * x1;
+      const double x0 = rdlane(y1, 2 * p2 - 64);
+      y1 -= (on ? c1[i][0] : 0.0) * x0;
+      y0 -= c0[i][0] * x0;
+      if (p2 - 4 >= 32) { c0[i] = W2[(p2 - 4) * (p2 - 3)]; c1[i] = W2[(p2 - 4) * (p2 - 3) + 64]; }
+    }
+  }
+  {
+    constexpr int ps = (NP < 32 ? NP : 32) - 1;
+    d2 c0[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int pi = ps - i > 0 ? ps - i : 0; c0[i] = W2[pi * (pi + 1)]; }
+#pragma unroll
+    for (int p2 = ps; p2 >= 0; p2--) {
+      const int i = (ps - p2) & 3;
+      const bool on = lane <= 2 * p2 + 1;
+      const double x1 = rdlane(y0, 2 * p2 + 1);
+      y0 -= (on ? c0[i][1] : 0.0) * x1;
+      const double x0 = rdlane(y0, 2 * p2);
+      y0 -= (on ? c0[i][0] : 0.0) * x0;
+      if (p2 - 4 >= 0) c0[i] = W2[(p2 - 4) * (p2 - 3)];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag) {
 #pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
   extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -754,6 +795,11 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
       y0 = lane < n_pad ? a0[0] : 0.0; y1 = 64 + lane < n_pad ? a1[0] : 0.0;
     }
     const int np = n_pad >> 1;
+    if (np == 60) backsub_pairs_unrolled<60>(W2, y0, y1, lane);          // 20 free poses
+    else if (np == 58) backsub_pairs_unrolled<58>(W2, y0, y1, lane);     // 19
+    else if (np == 54) backsub_pairs_unrolled<54>(W2, y0, y1, lane);     // 18
+    else if (np == 48) backsub_pairs_unrolled<48>(W2, y0, y1, lane);     // 16
+    else {
     // pairs 32 .. np-1: the diagonal sits in y1, y0 takes part in full.  Four pairs are in flight (an LDS round trip
     // is ~130 cycles, a pair's two dependent steps ~60): slot i of the ring is refilled right after its use
     if (np > 32) {
@@ -800,6 +846,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
           }
         }
       }
+    }
     }
     if (lane < n) x[lane] = y0;
     if (64 + lane < n) x[64 + lane] = y1;
