@@ -474,6 +474,10 @@ typedef __attribute__((address_space(3))) const volatile double* lds_vdp;
 // window size local BA runs at (20 free poses: n_pad = 120); other sizes take the loops in the kernel.
 template <int NP>
 __device__ __forceinline__ void backsub_pairs_unrolled(const lds_vd2p W2, double& y0, double& y1, const int lane) {
+  // No masks on the factor's columns: a lane whose x is final is not protected from the entries past its pair's rows (they
+  // belong to the next pair's storage: finite numbers), its x is simply kept aside the moment it becomes final (one select
+  // per pair instead of two per column); nothing reads a final lane of y again.
+  double x0f = y0, x1f = y1;
   if constexpr (NP > 32) {
     d2 c0[4], c1[4];
 #pragma unroll
@@ -481,12 +485,12 @@ __device__ __forceinline__ void backsub_pairs_unrolled(const lds_vd2p W2, double
 #pragma unroll
     for (int p2 = NP - 1; p2 >= 32; p2--) {
       const int i = (NP - 1 - p2) & 3;
-      const bool on = 64 + lane <= 2 * p2 + 1;
       const double x1 = rdlane(y1, 2 * p2 + 1 - 64);
-      y1 -= (on ? c1[i][1] : 0.0) * x1;
+      y1 -= c1[i][1] * x1;                       // entries on / below the diagonal inside the pair are stored as zeros
       y0 -= c0[i][1] * x1;
       const double x0 = rdlane(y1, 2 * p2 - 64);
-      y1 -= (on ? c1[i][0] : 0.0) * x0;
+      x1f = (lane >> 1) == p2 - 32 ? y1 : x1f;   // lanes 2 p2 - 64 and 2 p2 - 63 are final now
+      y1 -= c1[i][0] * x0;
       y0 -= c0[i][0] * x0;
       if (p2 - 4 >= 32) { c0[i] = W2[(p2 - 4) * (p2 - 3)]; c1[i] = W2[(p2 - 4) * (p2 - 3) + 64]; }
     }
@@ -499,14 +503,15 @@ __device__ __forceinline__ void backsub_pairs_unrolled(const lds_vd2p W2, double
 #pragma unroll
     for (int p2 = ps; p2 >= 0; p2--) {
       const int i = (ps - p2) & 3;
-      const bool on = lane <= 2 * p2 + 1;
       const double x1 = rdlane(y0, 2 * p2 + 1);
-      y0 -= (on ? c0[i][1] : 0.0) * x1;
+      y0 -= c0[i][1] * x1;
       const double x0 = rdlane(y0, 2 * p2);
-      y0 -= (on ? c0[i][0] : 0.0) * x0;
+      x0f = (lane >> 1) == p2 ? y0 : x0f;
+      y0 -= c0[i][0] * x0;
       if (p2 - 4 >= 0) c0[i] = W2[(p2 - 4) * (p2 - 3)];
     }
   }
+  y0 = x0f; y1 = x1f;
 }
 
 __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag) {
@@ -527,9 +532,6 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
   if (wv == 0) LDLTM_T(0);
   if (tid == 0) { s_piv = 0; s_ok = 1; }
   if (tid < kColT) { s_rbits[tid] = 0; s_rowdone[tid] = 0; }
-  __syncthreads();                     // the only barrier before the back-substitution: from here on the wavefronts run on flags
-  LDLTM_T(310 + wv);
-
   // ---- the column's tiles, two 16-byte loads per lane and tile, all in flight before the first use, no branch around
   // the loads (even a wave-uniform one makes hipcc drain the memory counter at the join: the column then arrives one
   // tile per memory round trip; slots past the column re-read its first tile and are never used).
@@ -544,6 +546,9 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
 #pragma unroll
     for (int i = 0; i < kColT - 1; i++) Rt[i] = *reinterpret_cast<const d4*>(St + (size_t)tile_index(i < wc_ ? i : 0, wc_) * 256 + 4 * lane);
   }
+  __syncthreads();                     // the only barrier before the back-substitution (the tile loads above are in flight across
+                                       // it): from here on the wavefronts run on flags
+  LDLTM_T(310 + wv);
   if (wv == 0) LDLTM_T(1);
   LDLTM_T(300 + wv);
 
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
         for (int i = 0; i < 8; i++) a8[i] = pivr[i * 64];
 #pragma unroll
         for (int g = 0; g < 4; g++) rs[g] = rcpr[4 * g];
-        const int seen = __builtin_amdgcn_readfirstlane(c0);
+        int seen = __builtin_amdgcn_readfirstlane(c0);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           if (4 * g < npiv) {
@@ -689,12 +694,18 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
             for (int h = 0; h < 2; h++) {
               const int need = 16 * k + 4 * g + 2 * h + 1;       // the counter exceeds this once the pair is published
               if (seen <= need) {
+                // a wait also fetches the FOLLOWING pair's operand: the diagonal needs ~400 cycles per pair, a wait is a
+                // round trip of ~200, so the next pair is often published by the time this one's wait returns and the
+                // wavefront that will factor the next diagonal tile stays one pair behind instead of two
                 for (;;) {
                   const int c = __hip_atomic_load(&s_piv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                   asm volatile("" ::: "memory");
                   a8[2 * g + h] = pivr[(2 * g + h) * 64];
-                  if (h == 1) rs[g] = rcpr[4 * g];
-                  if (__builtin_amdgcn_readfirstlane(c) > need) break;
+                  if (2 * g + h + 1 < 8) a8[2 * g + h + 1] = pivr[(2 * g + h + 1) * 64];
+                  rs[g] = rcpr[4 * g];
+                  if (h == 1 && g + 1 < 4) rs[g + 1] = rcpr[4 * (g + 1)];
+                  const int cv = __builtin_amdgcn_readfirstlane(c);
+                  if (cv > need) { seen = min(cv, need + 3); break; }     // this read covers this pair and, if published, the next
                 }
               }
               pair_step(g, h, a8[2 * g + h]);
