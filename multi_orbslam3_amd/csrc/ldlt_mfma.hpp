@@ -521,10 +521,21 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
   __shared__ int s_rbits[kColT];       // per tile row k: bit j set once -W_kj is published
   __shared__ int s_rowdone[kColT];     // per tile row: wavefronts that finished it
   __shared__ int s_ok;
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, hwv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
   const Geo G = make_geo(n);
   const int T = G.T, n_pad = G.n_pad, cb = G.cb;
+  // Tile column <-> wavefront.  Wavefronts w and w + 4 of a workgroup share a SIMD (tools/micro/wave_simd_map.hip), and a
+  // long column's trailing updates take the FP64 pipe away from whoever shares its SIMD: columns 0..3 go to wavefronts
+  // 0..3, the rest in DESCENDING order to wavefronts 4..7, i.e. column w is paired with column T-1-w.  Every SIMD then carries
+  // about the same number of matrix instructions, and from the middle of the factorisation on the diagonal wavefront's
+  // partner has already finished (19.7 -> 19.2 us at 120 unknowns against the identity map; pairing 2w with 2w+1 puts the
+  // wavefront that replays for the NEXT diagonal tile next to the diagonal: 22.3 us).
+#ifdef LDLTM_IDMAP
+  const int wv = hwv;
+#else
+  const int wv = hwv < 4 ? hwv : (T - 1 - (hwv - 4) >= 4 ? T - 1 - (hwv - 4) : kColT + hwv);      // >= T: no column
+#endif
   double* const Piv = sh;                               // [4][8][64]   per pivot pair the A operand (-L[:, p0] | -L[:, p1] in their lane groups, zero elsewhere)
   double* const Rcp = Piv + kPivRing * 16 * 64;         // [4][16]      1/d, written pair by pair
   double* const Rb = Rcp + kPivRing * 16;               // [28][256]    -W_kj register images, tile (k, j) at k(15-k)/2 + j-k-1
@@ -594,6 +605,9 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
 #ifndef LDLTM_ALONE
         wait_free(k);
 #endif
+#ifdef LDLTM_COLPRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           if (g == 2) LDLTM_T(8 + 8 * k + 6);
@@ -633,6 +647,9 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
             }
           }
         }
+#ifdef LDLTM_COLPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         LDLTM_T(8 + 8 * k + 1);
         if (!(fabs(rlast) < INFINITY)) s_ok = 0;
         if (k > 0) {                               // the deferred stores of the panel tile (k-1, k)
