@@ -535,6 +535,12 @@ __device__ __forceinline__ int oct_block_excl(int s, int* total, int* wsum /*LDS
 //     words of the next list are zeroed by whoever creates a node.
 // A first-phase pass is three barriers, a second-phase pass six.
 constexpr int kOctKPT = kOctKeyCap / kOctThreads;     // keys per thread
+// One LDS atomic per WAVEFRONT on a workgroup-wide word: hipcc's atomic optimiser turns a per-lane atomicMax / atomicMin on
+// one address into a scalar loop over the active lanes (s_ff1 + v_readlane per lane: ~3 k cycles for a full wavefront);
+// a DPP reduction first and a single lane's atomic is ~150.
+__device__ __forceinline__ void oct_wave_atomic_add(int* w, int v) { const int s = wave_sum(v); if ((threadIdx.x & 63) == 0 && s) atomicAdd(w, s); }
+__device__ __forceinline__ void oct_wave_atomic_max(int* w, int v) { const int s = wave_max(v); if ((threadIdx.x & 63) == 0) atomicMax(w, s); }
+__device__ __forceinline__ void oct_wave_atomic_min(int* w, int v) { const int s = -wave_max(-v); if ((threadIdx.x & 63) == 0) atomicMin(w, s); }
 // -DOCT_PROFILE: s_memtime stamps of thread 0 per workgroup (tools/micro/oct_prof.py prints them)
 #ifdef OCT_PROFILE
 __device__ long long g_oct_prof[32][48];
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
           new_pos[i] = (unsigned short)np;
         }
       }
-      if (my_exp) atomicAdd(&s_flag[par], my_exp);
+      oct_wave_atomic_add(&s_flag[par], my_exp);
       if (pass == 2) OCT_T(33);
       __syncthreads();
       if (pass == 2) OCT_T(34);
@@ -752,12 +758,11 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
 #pragma unroll
           for (int l = 0; l < 64; l++) myrank += (unsigned)__builtin_amdgcn_readlane((int)kreg, l) > mykey;
         }
-        if (mykey) {
-          ord[tid] = (unsigned short)myrank; pos_of_ord[myrank] = (unsigned short)tid;
-          atomicMax(&s_m, myrank + 1);
-        }
+        if (mykey) { ord[tid] = (unsigned short)myrank; pos_of_ord[myrank] = (unsigned short)tid; }
+        oct_wave_atomic_max(&s_m, mykey ? myrank + 1 : 0);
       } else {
         const int n4 = (n + 3) & ~3;
+        int mloc = 0;
         for (int i = tid; i < n; i += kOctThreads) {
           const unsigned key = (unsigned)scanB[i];
           if (key) {
@@ -777,9 +782,10 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
               r += (kk.x > key) + (kk.y > key) + (kk.z > key) + (kk.w > key);
             }
             ord[i] = (unsigned short)r; pos_of_ord[r] = (unsigned short)i;
-            atomicMax(&s_m, r + 1);
+            mloc = max(mloc, r + 1);
           }
         }
+        oct_wave_atomic_max(&s_m, mloc);
       }
       if (pass == 4) OCT_T(38);
       __syncthreads();
@@ -799,12 +805,14 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
       int totK;
       int before = oct_block_excl(so, &totK, wsum[ws]); ws = (ws + 1) & 3;
       (void)totK;
+      int cutloc = 0x7fffffff;
       for (int o = bo; o < eo; o++) {
         const int k4 = (k4pack >> (3 * (o - bo))) & 7;
         scanA[o] = before;
-        if (n + (before + k4) - (o + 1) >= N) atomicMin(&s_cut, o);
+        if (n + (before + k4) - (o + 1) >= N) cutloc = min(cutloc, o);
         before += k4;
       }
+      oct_wave_atomic_min(&s_cut, cutloc);
       if (pass == 4) OCT_T(40);
       __syncthreads();
       const int cut = min(s_cut, m - 1);
@@ -849,7 +857,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
           new_pos[i] = (unsigned short)np;
         }
       }
-      if (my_exp) atomicAdd(&s_flag[par], my_exp);
+      oct_wave_atomic_add(&s_flag[par], my_exp);
       if (pass == 4) OCT_T(42);
       __syncthreads();
       nexp = s_flag[par];
