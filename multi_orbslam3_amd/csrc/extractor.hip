@@ -169,6 +169,13 @@ __device__ __forceinline__ void tower_emit(uint8_t* __restrict__ lvl, const Leve
   }
 }
 
+// -DTW_PROFILE: s_memtime stamps of thread 0 of workgroup (1, 1, 0) (tools/micro/tw_prof.py prints them)
+#ifdef TW_PROFILE
+__device__ long long g_tw_prof[32];
+#define TW_T(slot) do { if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0) g_tw_prof[slot] = clock64(); } while (0)
+#else
+#define TW_T(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int img_stride,
                                                        uint8_t* __restrict__ pyr, PyrGeom g, const ResizeTap* __restrict__ xtab,
                                                        const ResizeTap* __restrict__ ytab, const TowerAxis* __restrict__ tax,
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
   __shared__ LevelGeom s_lv[ORBG_MAX_LEVELS];   // kernel arguments sit in cold memory: each first touch of a cache line costs
                                                 // a full miss, so the per-level geometry is fetched once, up front
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TW_T(0);
   // XCD-aware workgroup -> tile map: workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with an L2 of
   // its own.  Horizontally adjacent tiles write the two halves of the cache lines that straddle their border; on different
   // XCDs every such line is written back twice as a partial line.  Logical tile L = (id % 8) * (total / 8) + id / 8 gives
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
     if (j >= 0 && j < nl * kLvWords) reinterpret_cast<int*>(s_lv)[j] = reinterpret_cast<const int*>(g.lv)[j];
   }
   __syncthreads();
+  TW_T(1);
   // level-0 block: image -> registers (all loads in flight), then LDS + the owned part to the pyramid
   const int x0 = s_ax.need_lo[0], nw0 = s_ax.need_hi[0] - x0, y0 = s_ay.need_lo[0], nh0 = s_ay.need_hi[0] - y0;
   const uint8_t* img = cam ? img1 : img0;
@@ -232,6 +241,7 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
     }
   }
   uint8_t* cbase = pyr + (size_t)cam * g.cam_stride;
+  TW_T(2);
   {
     const LevelGeom L = s_lv[0];
     const int ohx = s_ax.own_hi[0], ohy = s_ay.own_hi[0];
@@ -245,6 +255,7 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
     }
   }
   __syncthreads();
+  TW_T(3);
   for (int l = 1; l < nl; l++) {
     const int lox = s_ax.need_lo[l], nw = s_ax.need_hi[l] - lox, loy = s_ay.need_lo[l], nh = s_ay.need_hi[l] - loy;
     if (nw > 0 && nh > 0) {
@@ -268,8 +279,12 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
       }
     }
     __syncthreads();
+    TW_T(3 + l);
   }
 }
+#ifdef TW_PROFILE
+extern "C" int orbx_debug_tw_prof(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tw_prof), sizeof(g_tw_prof)) == hipSuccess ? 0 : -1; }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 per cell  (cv::FAST via S/ORBextractor.cc:808-841)
