@@ -245,12 +245,16 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
   {
     const LevelGeom L = s_lv[0];
     const int ohx = s_ax.own_hi[0], ohy = s_ay.own_hi[0];
+    const bool plain0 = s_ax.own_lo[0] > kEdge && ohx - 1 < L.w - 1 - kEdge && s_ay.own_lo[0] > kEdge && ohy - 1 < L.h - 1 - kEdge;
 #pragma unroll
     for (int k = 0; k < kTwSide / kTwWaves; k++) {
       const int yy = wave + kTwWaves * k;
       if (yy < nh0 && lane < nw0) {
         buf[0][yy * kTwSide + lane] = px[k];
-        if (x0 + lane < ohx && y0 + yy < ohy) tower_emit(cbase + L.off, L, x0 + lane, y0 + yy, px[k]);
+        if (x0 + lane < ohx && y0 + yy < ohy) {
+          if (plain0) (cbase + L.off)[(size_t)(kEdge + y0 + yy) * L.stride + kEdge + x0 + lane] = px[k];
+          else tower_emit(cbase + L.off, L, x0 + lane, y0 + yy, px[k]);
+        }
       }
     }
   }
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
       const uint8_t* src = buf[(l - 1) & 1];
       uint8_t* dst = buf[l & 1];
       const int olx = s_ax.own_lo[l], ohx = s_ax.own_hi[l], oly = s_ay.own_lo[l], ohy = s_ay.own_hi[l];
+      const bool plain = olx > kEdge && ohx - 1 < L.w - 1 - kEdge && oly > kEdge && ohy - 1 < L.h - 1 - kEdge;   // workgroup-uniform
       if (lane < nw) {
         const TowerTap tx = s_xt[l][lane];
         for (int yy = wave; yy < nh; yy += kTwWaves) {
@@ -274,7 +279,12 @@ __global__ __launch_bounds__(kTwThreads) void pyr_tower_kernel(const uint8_t* __
           const int v = ((((int)ty.a0 * (t0 >> 4)) >> 16) + (((int)ty.a1 * (t1 >> 4)) >> 16) + 2) >> 2;
           dst[yy * kTwSide + lane] = (uint8_t)v;
           const int dx = lox + lane, dy = loy + yy;
-          if (dx >= olx && dx < ohx && dy >= oly && dy < ohy) tower_emit(cbase + L.off, L, dx, dy, (uint8_t)v);
+          if (dx >= olx && dx < ohx && dy >= oly && dy < ohy) {
+            // a tile whose owned range stays clear of the bands that REFLECT_101 mirrors into the border (most tiles) writes
+            // the interior byte only: the eight conditional mirror stores of tower_emit are ~60 instructions per pixel
+            if (plain) (cbase + L.off)[(size_t)(kEdge + dy) * L.stride + kEdge + dx] = (uint8_t)v;
+            else tower_emit(cbase + L.off, L, dx, dy, (uint8_t)v);
+          }
         }
       }
     }
