@@ -143,7 +143,7 @@ __device__ __forceinline__ double rcp1(double d) {            // hardware seed (
 #define LDLTM_SLEEP 1
 #endif
 #ifdef LDLTM_PROFILE
-__device__ long long g_prof[512];
+__device__ long long g_prof[2048];
 #define LDLTM_T(slot) do { if (lane == 0) g_prof[slot] = clock64(); } while (0)
 #else
 #define LDLTM_T(slot) do { } while (0)
@@ -436,6 +436,539 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_mfma(int n, const double* __r
   }
   if (wv == 0) LDLTM_T(4);
   if (tid == 0) *ok_flag = ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Variant for 10 .. 19 tile rows (windows of 25 .. 50 free poses, the C4 workload): FOUR wavefronts, one per SIMD, up to
+// 48 tiles each.  With eight wavefronts a SIMD's 512 registers are split in two: 24 tiles fill 192 of a wavefront's 256
+// and hipcc parks tiles in scratch memory; with one wavefront per SIMD the same 384 tile registers leave 128 for
+// everything else, the eliminating wavefront has the FP64 pipe of its SIMD to itself (a neighbour's matrix instruction
+// between two dependent FP64 instructions holds the pipe for 64 cycles: 860 instead of 400 cycles per pair of pivots),
+// and the latency a second wavefront would hide is hidden by updating four tiles at a time instead.
+//
+// Tiles are dealt in ROW-major order (t = rowstart(i) + j - i, owner t % 4, slot t / 4): the tiles that still change after
+// tile row k are a suffix of every wavefront's slots, so the bulk of a trailing update is a run over consecutive slots with
+// no per-tile test, and a wavefront's tiles of one row (a panel) are consecutive slots too.  Register arrays cannot be
+// indexed at run time: the slot is a compile-time constant inside the cases of a switch (slot_switch).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// (the empty statements differ from case to case: hipcc otherwise merges the cases' moves into one access with a computed
+// index, and an array that is indexed at run time lives in scratch memory)
+#define LDLTM_CASE(c) case c: if constexpr (c < N) { asm volatile("" :: "n"(c)); f(std::integral_constant<int, c>{}); asm volatile("" :: "n"(c)); } break;
+template <int N, class F>
+__device__ __forceinline__ void slot_switch(int s, F&& f) {     // f(integral_constant<int, s>), s < N <= 48
+  switch (s) {
+    LDLTM_CASE(0) LDLTM_CASE(1) LDLTM_CASE(2) LDLTM_CASE(3) LDLTM_CASE(4) LDLTM_CASE(5) LDLTM_CASE(6) LDLTM_CASE(7)
+    LDLTM_CASE(8) LDLTM_CASE(9) LDLTM_CASE(10) LDLTM_CASE(11) LDLTM_CASE(12) LDLTM_CASE(13) LDLTM_CASE(14) LDLTM_CASE(15)
+    LDLTM_CASE(16) LDLTM_CASE(17) LDLTM_CASE(18) LDLTM_CASE(19) LDLTM_CASE(20) LDLTM_CASE(21) LDLTM_CASE(22) LDLTM_CASE(23)
+    LDLTM_CASE(24) LDLTM_CASE(25) LDLTM_CASE(26) LDLTM_CASE(27) LDLTM_CASE(28) LDLTM_CASE(29) LDLTM_CASE(30) LDLTM_CASE(31)
+    LDLTM_CASE(32) LDLTM_CASE(33) LDLTM_CASE(34) LDLTM_CASE(35) LDLTM_CASE(36) LDLTM_CASE(37) LDLTM_CASE(38) LDLTM_CASE(39)
+    LDLTM_CASE(40) LDLTM_CASE(41) LDLTM_CASE(42) LDLTM_CASE(43) LDLTM_CASE(44) LDLTM_CASE(45) LDLTM_CASE(46) LDLTM_CASE(47)
+    default: break;
+  }
+}
+#undef LDLTM_CASE
+
+// Tile store of k_ldlt_big: tile S < 32 lives in the accumulation registers a[8S : 8S+7], tile S >= 32 in the vector registers
+// v[128 + 8(S-32) : ...], all addressed from inline assembly; matrix instructions update a tile in place, 8 moves copy it
+// out.  hipcc never sees these registers as values (a tile array of its own ends up as hundreds of moves at every join
+// of the row loop, or in scratch memory).  To keep its own values out of them: the kernel with 48 tiles is limited to 128
+// registers of each kind (amdgpu_num_vgpr: v128.. and a128.. are then reserved), and every assembly statement names the
+// accumulation registers hipcc may still use as clobbered -- accumulation and vector registers are one allocatable class on
+// this part, and hipcc does park long-lived values there.
+#define LDLTM_AGPR_LO \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", \
+  "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", \
+  "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", \
+  "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", \
+  "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", \
+  "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", \
+  "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", \
+  "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", \
+  "a125", "a126", "a127"
+#define LDLTM_AGPR_HI \
+  "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", \
+  "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", \
+  "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", \
+  "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", \
+  "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", \
+  "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", \
+  "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", \
+  "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+  "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", \
+  "a254", "a255"
+typedef int i8v __attribute__((ext_vector_type(8)));
+#define LDLTM_ASM(V, text, outs, ins)                                   \
+  do {                                                                  \
+    if constexpr (V) { asm volatile(text : outs : ins : LDLTM_AGPR_LO); } \
+    else { asm volatile(text : outs : ins : LDLTM_AGPR_LO, LDLTM_AGPR_HI); } \
+  } while (0)
+#define LDLTM_COMMA ,
+constexpr int tile_reg(int S) { return S < 32 ? 8 * S : 128 + 8 * (S - 32); }
+template <int S, bool V>
+__device__ __forceinline__ d4 tile_get_r() {
+  int x0, x1, x2, x3, x4, x5, x6, x7;
+  constexpr int R = tile_reg(S);
+  // (18 wait states between a matrix instruction's write and a read of its result; assembly is opaque to the hazard pass)
+  if constexpr (S < 32) {
+    LDLTM_ASM(V, "s_nop 15\n\ts_nop 7\n\t"
+                 "v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%9]\n\tv_accvgpr_read_b32 %2, a[%10]\n\tv_accvgpr_read_b32 %3, a[%11]\n\t"
+                 "v_accvgpr_read_b32 %4, a[%12]\n\tv_accvgpr_read_b32 %5, a[%13]\n\tv_accvgpr_read_b32 %6, a[%14]\n\tv_accvgpr_read_b32 %7, a[%15]",
+              "=v"(x0) LDLTM_COMMA "=v"(x1) LDLTM_COMMA "=v"(x2) LDLTM_COMMA "=v"(x3) LDLTM_COMMA "=v"(x4) LDLTM_COMMA "=v"(x5) LDLTM_COMMA "=v"(x6) LDLTM_COMMA "=v"(x7),
+              "n"(R) LDLTM_COMMA "n"(R + 1) LDLTM_COMMA "n"(R + 2) LDLTM_COMMA "n"(R + 3) LDLTM_COMMA "n"(R + 4) LDLTM_COMMA "n"(R + 5) LDLTM_COMMA "n"(R + 6) LDLTM_COMMA "n"(R + 7));
+  } else {
+    LDLTM_ASM(V, "s_nop 15\n\ts_nop 7\n\t"
+                 "v_mov_b32 %0, v[%8]\n\tv_mov_b32 %1, v[%9]\n\tv_mov_b32 %2, v[%10]\n\tv_mov_b32 %3, v[%11]\n\t"
+                 "v_mov_b32 %4, v[%12]\n\tv_mov_b32 %5, v[%13]\n\tv_mov_b32 %6, v[%14]\n\tv_mov_b32 %7, v[%15]",
+              "=v"(x0) LDLTM_COMMA "=v"(x1) LDLTM_COMMA "=v"(x2) LDLTM_COMMA "=v"(x3) LDLTM_COMMA "=v"(x4) LDLTM_COMMA "=v"(x5) LDLTM_COMMA "=v"(x6) LDLTM_COMMA "=v"(x7),
+              "n"(R) LDLTM_COMMA "n"(R + 1) LDLTM_COMMA "n"(R + 2) LDLTM_COMMA "n"(R + 3) LDLTM_COMMA "n"(R + 4) LDLTM_COMMA "n"(R + 5) LDLTM_COMMA "n"(R + 6) LDLTM_COMMA "n"(R + 7));
+  }
+  const i8v v = {x0, x1, x2, x3, x4, x5, x6, x7};
+  return __builtin_bit_cast(d4, v);
+}
+template <int S, bool V>
+__device__ __forceinline__ void tile_put_r(d4 c) {
+  const i8v v = __builtin_bit_cast(i8v, c);
+  constexpr int R = tile_reg(S);
+  if constexpr (S < 32) {
+    LDLTM_ASM(V, "v_accvgpr_write_b32 a[%8], %0\n\tv_accvgpr_write_b32 a[%9], %1\n\tv_accvgpr_write_b32 a[%10], %2\n\tv_accvgpr_write_b32 a[%11], %3\n\t"
+                 "v_accvgpr_write_b32 a[%12], %4\n\tv_accvgpr_write_b32 a[%13], %5\n\tv_accvgpr_write_b32 a[%14], %6\n\tv_accvgpr_write_b32 a[%15], %7\n\ts_nop 3", ,
+              "v"(v[0]) LDLTM_COMMA "v"(v[1]) LDLTM_COMMA "v"(v[2]) LDLTM_COMMA "v"(v[3]) LDLTM_COMMA "v"(v[4]) LDLTM_COMMA "v"(v[5]) LDLTM_COMMA "v"(v[6]) LDLTM_COMMA "v"(v[7]) LDLTM_COMMA
+              "n"(R) LDLTM_COMMA "n"(R + 1) LDLTM_COMMA "n"(R + 2) LDLTM_COMMA "n"(R + 3) LDLTM_COMMA "n"(R + 4) LDLTM_COMMA "n"(R + 5) LDLTM_COMMA "n"(R + 6) LDLTM_COMMA "n"(R + 7));
+  } else {
+    LDLTM_ASM(V, "v_mov_b32 v[%8], %0\n\tv_mov_b32 v[%9], %1\n\tv_mov_b32 v[%10], %2\n\tv_mov_b32 v[%11], %3\n\t"
+                 "v_mov_b32 v[%12], %4\n\tv_mov_b32 v[%13], %5\n\tv_mov_b32 v[%14], %6\n\tv_mov_b32 v[%15], %7\n\ts_nop 3", ,
+              "v"(v[0]) LDLTM_COMMA "v"(v[1]) LDLTM_COMMA "v"(v[2]) LDLTM_COMMA "v"(v[3]) LDLTM_COMMA "v"(v[4]) LDLTM_COMMA "v"(v[5]) LDLTM_COMMA "v"(v[6]) LDLTM_COMMA "v"(v[7]) LDLTM_COMMA
+              "n"(R) LDLTM_COMMA "n"(R + 1) LDLTM_COMMA "n"(R + 2) LDLTM_COMMA "n"(R + 3) LDLTM_COMMA "n"(R + 4) LDLTM_COMMA "n"(R + 5) LDLTM_COMMA "n"(R + 6) LDLTM_COMMA "n"(R + 7));
+  }
+}
+// tile S -= A^T W in place: four dependent matrix instructions
+template <int S, bool V>
+__device__ __forceinline__ void tile_mfma4(const double (&a)[4], const double (&w)[4]) {
+  constexpr int R = tile_reg(S);
+#define LDLTM_M4(F)                                                                                                                     \
+  LDLTM_ASM(V, "v_mfma_f64_16x16x4_f64 " F "[%8:%9], %0, %1, " F "[%8:%9]\n\tv_mfma_f64_16x16x4_f64 " F "[%8:%9], %2, %3, " F "[%8:%9]\n\t"   \
+               "v_mfma_f64_16x16x4_f64 " F "[%8:%9], %4, %5, " F "[%8:%9]\n\tv_mfma_f64_16x16x4_f64 " F "[%8:%9], %6, %7, " F "[%8:%9]", ,       \
+            "v"(a[0]) LDLTM_COMMA "v"(w[0]) LDLTM_COMMA "v"(a[1]) LDLTM_COMMA "v"(w[1]) LDLTM_COMMA "v"(a[2]) LDLTM_COMMA "v"(w[2]) LDLTM_COMMA \
+            "v"(a[3]) LDLTM_COMMA "v"(w[3]) LDLTM_COMMA "n"(R) LDLTM_COMMA "n"(R + 7))
+  if constexpr (S < 32) { LDLTM_M4("a"); } else { LDLTM_M4("v"); }
+#undef LDLTM_M4
+}
+// tiles S and S+1 (S even), the two chains interleaved (an independent matrix instruction issues after 66 cycles, a dependent
+// one after 82)
+template <int S, bool V>
+__device__ __forceinline__ void tile_mfma4x2(const double (&a0)[4], const double (&w0)[4], const double (&a1)[4], const double (&w1)[4]) {
+  constexpr int R = tile_reg(S);
+#define LDLTM_M8(F)                                                                                                                     \
+  LDLTM_ASM(V, "v_mfma_f64_16x16x4_f64 " F "[%16:%17], %0, %1, " F "[%16:%17]\n\tv_mfma_f64_16x16x4_f64 " F "[%18:%19], %8, %9, " F "[%18:%19]\n\t"     \
+               "v_mfma_f64_16x16x4_f64 " F "[%16:%17], %2, %3, " F "[%16:%17]\n\tv_mfma_f64_16x16x4_f64 " F "[%18:%19], %10, %11, " F "[%18:%19]\n\t"   \
+               "v_mfma_f64_16x16x4_f64 " F "[%16:%17], %4, %5, " F "[%16:%17]\n\tv_mfma_f64_16x16x4_f64 " F "[%18:%19], %12, %13, " F "[%18:%19]\n\t"   \
+               "v_mfma_f64_16x16x4_f64 " F "[%16:%17], %6, %7, " F "[%16:%17]\n\tv_mfma_f64_16x16x4_f64 " F "[%18:%19], %14, %15, " F "[%18:%19]", ,       \
+            "v"(a0[0]) LDLTM_COMMA "v"(w0[0]) LDLTM_COMMA "v"(a0[1]) LDLTM_COMMA "v"(w0[1]) LDLTM_COMMA "v"(a0[2]) LDLTM_COMMA "v"(w0[2]) LDLTM_COMMA \
+            "v"(a0[3]) LDLTM_COMMA "v"(w0[3]) LDLTM_COMMA "v"(a1[0]) LDLTM_COMMA "v"(w1[0]) LDLTM_COMMA "v"(a1[1]) LDLTM_COMMA "v"(w1[1]) LDLTM_COMMA \
+            "v"(a1[2]) LDLTM_COMMA "v"(w1[2]) LDLTM_COMMA "v"(a1[3]) LDLTM_COMMA "v"(w1[3]) LDLTM_COMMA                                       \
+            "n"(R) LDLTM_COMMA "n"(R + 7) LDLTM_COMMA "n"(R + 8) LDLTM_COMMA "n"(R + 15))
+  if constexpr (S < 32) { LDLTM_M8("a"); } else { LDLTM_M8("v"); }
+#undef LDLTM_M8
+}
+
+// Matrix instruction on compiler-allocated vector registers, for k_ldlt_big (the builtin lets hipcc place the result in an
+// accumulation register of its choice).  Assembly is opaque to the hazard pass: two wait states cover a vector-ALU write
+// of an operand just before, 18 a vector-ALU read of the result right after.
+template <bool V>
+__device__ __forceinline__ d4 mfma_v(double a, double b, d4 c) {
+  LDLTM_ASM(V, "s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 2", "+v"(c), "v"(a) LDLTM_COMMA "v"(b));
+  return c;
+}
+
+constexpr int kBigWaves = 4;
+constexpr int kBigThreads = 64 * kBigWaves;
+
+template <int NS, int NY>
+__device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag,
+                                              double* __restrict__ wglob) {
+#pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  __shared__ int s_diag;               // tile rows whose G / D^-1 are published
+  __shared__ int s_panel[kMaxT + 4];   // per tile column j: rows k for which -R_kj / W_kj are published
+  __shared__ int s_pcount[kMaxT + 4];  // per tile row: panel tiles published
+  __shared__ int s_rowdone[kMaxT + 4]; // per tile row: wavefronts that finished its trailing update
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const Geo G = make_geo(n);
+  const int T = G.T, n_pad = G.n_pad, cb = G.cb;
+  double* const Pan = sh;                               // [2][T][2][256]
+  double* const Gb = Pan + (size_t)2 * T * 512;         // [2][16 * kGld]
+  double* const Dv = Gb + 2 * 16 * kGld;                // [2][16]
+  auto wm_store = [&](int I, int J, double v) { wglob[J * (J - 1) / 2 + I] = v; };   // entry (I, J), I < J, of the unit upper factor
+  if (wv == 0) LDLTM_T(0);
+  if (tid == 0) { s_diag = 0; s_ok = 1; }
+  if (tid < kMaxT + 4) { s_panel[tid] = 0; s_rowdone[tid] = 0; s_pcount[tid] = 0; }
+
+  auto rowstart = [&](int i) -> int { return i * T - i * (i - 1) / 2; };
+  // slot of tile (i, j), i <= j, if this wavefront owns it, else -1
+  auto my_slot = [&](int i, int j) -> int {
+    const int t = rowstart(i) + j - i;
+    return (t & (kBigWaves - 1)) == wv ? t >> 2 : -1;
+  };
+  // first slot of this wavefront whose tile lies in row i or below
+  auto first_slot_from_row = [&](int i) -> int { return (rowstart(i) - wv + kBigWaves - 1) >> 2; };
+  const int my_count = first_slot_from_row(T);          // rowstart(T) = number of tiles
+
+  // The tiles.  A register array can only be indexed by constants, and code specialised per slot does not fit the
+  // instruction cache (a wavefront then fetches every tile update from the L2: ~3000 cycles per tile measured), so the work
+  // on a tile is generic code; per slot there is only a case of a switch with the tile's registers in it: four matrix
+  // instructions (update in place) or eight moves (copy out for the panel / the elimination).
+  constexpr bool V = NS > 32;                           // tiles in v128..v255 as well
+  if constexpr (V) { asm volatile("" ::: "a0", "a255", "v255"); } else { asm volatile("" ::: "a0", "a255"); }   // (the register allocation of the kernel)
+  auto tile_get = [&](int sl) -> d4 {
+    d4 c = {0.0, 0.0, 0.0, 0.0};
+    slot_switch<NS>(sl, [&](auto sc) { c = tile_get_r<decltype(sc)::value, V>(); });
+    return c;
+  };
+  // U -= R^T W on the tile in slot sl, operands in a[], w[]
+  auto tile_update = [&](int sl, const double (&a)[4], const double (&w)[4]) {
+    slot_switch<NS>(sl, [&](auto sc) { tile_mfma4<decltype(sc)::value, V>(a, w); });
+  };
+  // ... on the tiles in slots sl (even) and sl + 1, chains interleaved
+  auto pair_update = [&](int sl, const double (&a0)[4], const double (&w0)[4], const double (&a1)[4], const double (&w1)[4]) {
+    slot_switch<NS / 2>(sl >> 1, [&](auto gc) { tile_mfma4x2<2 * decltype(gc)::value, V>(a0, w0, a1, w1); });
+  };
+  // two 16-byte loads per lane and tile from the tile image (column-major tile order there), 8 or 16 tiles in flight
+  auto tile_addr = [&](int sl) -> const d4* {
+    const int t = min(sl * kBigWaves + wv, G.ntiles - 1);
+    const float bq = (float)(2 * T + 1);
+    int i = (int)((bq - sqrtf(bq * bq - 8.0f * (float)t)) * 0.5f);
+    i = max(0, min(T - 1, i));
+    if (i + 1 < T && rowstart(i + 1) <= t) i++;
+    if (rowstart(i) > t) i--;
+    const int j = i + t - rowstart(i);
+    return reinterpret_cast<const d4*>(St + (size_t)tile_index(i, j) * 256 + 4 * lane);
+  };
+  constexpr int LC = V ? 8 : 16;                        // tiles in flight per round
+  static_for<0, (NS + LC - 1) / LC>([&](auto cc) {
+    constexpr int c0 = LC * decltype(cc)::value;
+    d4 tmp[LC];
+    static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (c0 + u < NS) tmp[u] = *tile_addr(c0 + u); });
+    static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (c0 + u < NS) tile_put_r<c0 + u, V>(tmp[u]); });
+  });
+  __syncthreads();
+  if (wv == 0) LDLTM_T(1);
+
+  // Signalling goes through LDS only, and the LDS unit executes a wavefront's accesses in program order: a flag written
+  // after the data is seen after the data, a read issued after the flag read returns sees what the flag announces.  The
+  // hand-overs need a compiler barrier, not a fence (a release fence would also wait for the factor's global stores).
+  auto ld_flag = [&](int* w) -> int {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  };
+  auto wait_gt = [&](int* w, int k) {
+    while (ld_flag(w) <= k) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  auto wait_free = [&](int k) {   // the LDS buffers of parity k&1 were last used by tile row k-2
+    if (k >= 2) wait_gt(&s_rowdone[k - 2], kBigWaves - 1);
+  };
+  auto post = [&](int* w, int v) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto post_add = [&](int* w) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  // ---- the pivots of diagonal tile k, two per matrix instruction (k_ldlt_mfma::factor above; here the two rows of
+  // G = L^-1 that a pair completes go to LDS at once)
+  auto factor = [&](d4 C, int k) {
+    LDLTM_T(8 + 8 * k + 0);
+    wait_free(k);
+    const int par = k & 1;
+    d4 E, Wc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; g++) E[g] = (lr + 4 * g == lc) ? 1.0 : 0.0;
+    double dvv = 1.0;
+    const int npiv = min(16, n_pad - 16 * k);          // a multiple of 4
+    double rlast = 1.0;
+    double* const gcol = Gb + par * 16 * kGld + lc * kGld + lr;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (g == 2) LDLTM_T(8 + 8 * k + 6);
+      if (4 * g < npiv) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int q0 = 2 * h, p0 = 4 * g + q0, p1 = p0 + 1;
+          double u = C[g];
+          asm volatile("" : "+v"(u));              // own registers: the instruction below then updates C in place
+          const double c00 = rdlane(u, q0 * 16 + p0), c01 = rdlane(u, q0 * 16 + p1), c11 = rdlane(u, (q0 + 1) * 16 + p1);
+          const double det = __builtin_fma(c00, c11, -(c01 * c01));
+          const double r0 = rcp1(c00);
+          const double rdet = rcp1(det);
+          const double r1 = c00 * rdet;
+          const double nl10 = -(c01 * r0);
+          const double u0b = row_even_to_odd(u);
+          const double u1 = __builtin_fma(nl10, u0b, u);          // row1' in the lanes of group q0 + 1
+          const bool in0 = lr == q0, in1 = lr == q0 + 1;
+          const double bv = in1 ? u1 : u;
+          const double av = in0 ? u * -r0 : in1 ? u1 * -r1 : 0.0;
+          if (p1 < 15) C = mfma_v<V>(av, bv, C);        // after the 16th pivot nothing of the tile is read again
+          double eg = E[g];
+          asm volatile("" : "+v"(eg));
+          const double e0b = row_even_to_odd(eg);
+          const double erow = in1 ? __builtin_fma(nl10, e0b, eg) : eg;
+          if (in0 || in1) gcol[4 * g] = erow;      // rows p0, p1 of L^-1 are final before their own pivots
+          if (p1 < 15) E = mfma_v<V>(av, erow, E);
+          Wc[g] -= av;                             // rows p0, p1 of the unit upper factor (their two lane groups)
+          dvv = lane == p0 ? r0 : lane == p1 ? r1 : dvv;
+          if (h == 1) rlast = r0 + r1;             // a zero or non-finite pivot turns every later reciprocal into NaN
+        }
+      } else {
+        gcol[4 * g] = E[g];                        // rows without pivots (last tile row): identity
+      }
+    }
+    const bool good = fabs(rlast) < INFINITY;
+    LDLTM_T(8 + 8 * k + 1);
+    if (lane < 16) Dv[par * 16 + lane] = dvv;
+    if (!good) s_ok = 0;
+    post(&s_diag, k + 1);
+    LDLTM_T(8 + 8 * k + 2);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {              // the factor's rows are not needed before the back-substitution
+      const int I = 16 * k + lr + 4 * g, J = 16 * k + lc;
+      if (I < J && I < n_pad && J <= cb) wm_store(I, J, Wc[g]);
+    }
+  };
+
+  // ---- panel tile (k, j), j > k: R = G X, W = D^-1 R; -R and W to LDS in operand layout
+  auto panel_tile = [&](const d4 X, int k, int j, const double (&Gf)[4], const double (&dv4)[4]) {
+    const int par = k & 1;
+    if (j == k + 1) LDLTM_T(8 + 8 * k + 3);
+    d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
+    R0 = mfma_v<V>(Gf[0], X[0], R0);
+    R1 = mfma_v<V>(Gf[2], X[2], R1);
+    R0 = mfma_v<V>(Gf[1], X[1], R0);
+    R1 = mfma_v<V>(Gf[3], X[3], R1);
+    double* const pb = Pan + ((par * T + j) * 2) * 256 + lane;
+    double w4[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const double rr = R0[g] + R1[g];
+      w4[g] = rr * dv4[g];
+      pb[g * 64] = -rr;
+      pb[256 + g * 64] = w4[g];
+    }
+    post(&s_panel[j], k + 1);
+    post_add(&s_pcount[k]);
+    if (j == k + 1) LDLTM_T(8 + 8 * k + 4);
+    const int J = 16 * j + lc;
+    if (J <= cb) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, w4[g]);
+    }
+  };
+  // ---- U_ij -= R_ki^T W_kj (4 instructions, operands straight from LDS)
+  auto update1 = [&](d4 c, int i, int j, int k, bool two_chains) -> d4 {
+    const int par = k & 1;
+    const double* const pa = Pan + ((par * T + i) * 2) * 256 + lane;
+    const double* const pw = Pan + ((par * T + j) * 2 + 1) * 256 + lane;
+    double a[4], w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { a[q] = pa[q * 64]; w[q] = pw[q * 64]; }
+    if (two_chains) {                        // two chains of two: this tile is on the critical path
+      d4 t2 = {0.0, 0.0, 0.0, 0.0};
+      c = mfma_v<V>(a[0], w[0], c);
+      t2 = mfma_v<V>(a[2], w[2], t2);
+      c = mfma_v<V>(a[1], w[1], c);
+      t2 = mfma_v<V>(a[3], w[3], t2);
+      c += t2;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) c = mfma_v<V>(a[q], w[q], c);
+    }
+    return c;
+  };
+  // next tile of this wavefront in row-major order
+  auto advance = [&](int& i, int& j) {
+    j += kBigWaves;
+    while (j >= T && i + 1 < T) { i++; j = j - T + i; }
+  };
+
+  auto ld_ops = [&](int k, int i, int j, double (&av)[4], double (&wv4)[4]) {
+    const int par = k & 1;
+    const double* const pa = Pan + ((par * T + i) * 2) * 256 + lane;
+    const double* const pw = Pan + ((par * T + j) * 2 + 1) * 256 + lane;
+    av[0] = pa[0]; av[1] = pa[64]; av[2] = pa[128]; av[3] = pa[192];
+    wv4[0] = pw[0]; wv4[1] = pw[64]; wv4[2] = pw[128]; wv4[3] = pw[192];
+  };
+  // four consecutive slots (sl a multiple of 4): every operand read is in flight before the first instruction
+  auto quad_update = [&](int sl, int k, int& bi, int& bj) {
+    double a0[4], w0[4], a1[4], w1[4], a2[4], w2[4], a3[4], w3[4];
+    ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
+    ld_ops(k, bi, bj, a1, w1); advance(bi, bj);
+    ld_ops(k, bi, bj, a2, w2); advance(bi, bj);
+    ld_ops(k, bi, bj, a3, w3); advance(bi, bj);
+    slot_switch<NS / 4>(sl >> 2, [&](auto gc) {
+      constexpr int s0 = 4 * decltype(gc)::value;
+      tile_mfma4x2<s0, V>(a0, w0, a1, w1);
+      tile_mfma4x2<s0 + 2, V>(a2, w2, a3, w3);
+    });
+  };
+
+  // Row program.  For tile row k (k = -1: nothing to update yet):
+  //   stage 0  the tile (k+1,k+1), if it is mine, gets row k's update and is eliminated at once;
+  //   stage 1  my other tiles of row k+1 (the next panel) get row k's update;
+  //   stage 2  my remaining live tiles, four consecutive slots per step where possible; between two steps the wavefront
+  //            looks whether tile (k+1,k+1) has been published meanwhile and, if so, turns to its panel tiles of row k+1
+  //            FIRST -- the chain diag -> panel -> update -> diag never waits for bulk work.
+  for (int k = -1; k < G.Tp; k++) {
+    LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 0);
+    if (k + 1 < T) {
+      const int sd = my_slot(k + 1, k + 1);
+      if (sd >= 0) {
+        d4 C = tile_get(sd);
+        if (k >= 0) {
+          wait_gt(&s_panel[k + 1], k);
+          C = update1(C, k + 1, k + 1, k, true);
+          LDLTM_T(8 + 8 * k + 5);
+        }
+        if (k + 1 < G.Tp) factor(C, k + 1);
+      }
+    }
+    LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 1);
+    int sl = 0, se = 0, bi = 0, bj = 0;
+    if (k >= 0) {
+      int s1 = first_slot_from_row(k + 1);
+      const int s2 = min(first_slot_from_row(k + 2), my_count);
+      int j = k + 1 + (s1 * kBigWaves + wv - rowstart(k + 1));
+      if (s1 < s2 && j == k + 1) { s1++; j += kBigWaves; }
+      for (; s1 < s2; s1++, j += kBigWaves) {
+        wait_gt(&s_panel[k + 1], k);
+        wait_gt(&s_panel[j], k);
+        double a0[4], w0[4];
+        ld_ops(k, k + 1, j, a0, w0);
+        tile_update(s1, a0, w0);
+      }
+      LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 2);
+      wait_gt(&s_pcount[k], T - 2 - k);            // every panel tile of row k is published: no flag checks in the bulk
+      sl = s2; se = my_count;
+      bi = k + 2; bj = k + 2 + (sl * kBigWaves + wv - rowstart(k + 2));
+      while (bj >= T && bi + 1 < T) { bi++; bj = bj - T + bi; }
+    }
+    LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 3);
+    const int seA = se;
+    bool pdone = !(k + 1 < G.Tp);
+    for (;;) {
+      if (!pdone) {
+        const int kk = k + 1;
+        if (ld_flag(&s_diag) > kk && (kk < 2 || ld_flag(&s_rowdone[kk - 2]) >= kBigWaves)) {
+          asm volatile("" ::: "memory");
+          LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 5);
+          // my panel tiles (kk, j) (consecutive slots, every fourth j)
+          const int par = kk & 1;
+          int ps = first_slot_from_row(kk);
+          const int pe = min(first_slot_from_row(kk + 1), my_count);
+          int pj = kk + (ps * kBigWaves + wv - rowstart(kk));
+          if (ps < pe && pj == kk) { ps++; pj += kBigWaves; }
+          if (ps < pe) {
+            double Gf[4], dv4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              Gf[q] = Gb[par * 16 * kGld + (4 * q + lr) * kGld + lc];
+              dv4[q] = Dv[par * 16 + lr + 4 * q];
+            }
+            for (; ps < pe; ps++, pj += kBigWaves) panel_tile(tile_get(ps), kk, pj, Gf, dv4);
+          }
+          pdone = true;
+          LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 6);
+        }
+      }
+      if (sl < seA) {
+        if (!V && (sl & 3) == 0 && sl + 4 <= seA) { quad_update(sl, k, bi, bj); sl += 4; }   // (V: 128 vector registers, no room for 32 operands)
+        else if ((sl & 1) == 0 && sl + 2 <= seA) {
+          double a0[4], w0[4], a1[4], w1[4];
+          ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
+          ld_ops(k, bi, bj, a1, w1); advance(bi, bj);
+          pair_update(sl, a0, w0, a1, w1);
+          sl += 2;
+        } else {
+          double a0[4], w0[4];
+          ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
+          tile_update(sl, a0, w0);
+          sl++;
+        }
+      } else if (pdone) {
+        break;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (k >= 0) post_add(&s_rowdone[k]);
+    LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 4);
+  }
+  __threadfence();
+  if (wv == 0) LDLTM_T(2);
+  __syncthreads();
+  if (wv == 0) LDLTM_T(3);
+  const int ok = s_ok;
+  // ---- back-substitution  L^T x = y  on one wavefront: x in registers, one column per step (v_readlane broadcast);
+  // the factor's columns are read four at a time, one group ahead, with unconditional loads (entries on or below the
+  // diagonal are masked after the load)
+  if (wv == 0 && ok) {
+    auto wm_load = [&](int I, int J) -> double {
+      const double v = __builtin_nontemporal_load(wglob + (J * (J - 1) / 2 + I));
+      return I < J ? v : 0.0;
+    };
+    double y[NY];
+#pragma unroll
+    for (int r = 0; r < NY; r++) { const int I = r * 64 + lane; y[r] = I < n_pad ? wm_load(I, cb) : 0.0; }
+#pragma unroll
+    for (int rg = NY - 1; rg >= 0; rg--) {
+      const int lo = rg * 64, hi = min(n_pad, lo + 64);
+      if (hi > lo) {
+        double cur[4][NY], nxt[4][NY];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+          for (int r2 = 0; r2 < NY; r2++) { cur[c][r2] = r2 <= rg ? wm_load(r2 * 64 + lane, hi - 4 + c) : 0.0; nxt[c][r2] = 0.0; }
+        for (int J0 = hi - 4; J0 >= lo; J0 -= 4) {
+          const int Jn = max(J0 - 4, lo);        // the last group re-reads itself (harmless) instead of branching
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r2 = 0; r2 < NY; r2++)
+              if (r2 <= rg) nxt[c][r2] = wm_load(r2 * 64 + lane, Jn + c);
+#pragma unroll
+          for (int c = 3; c >= 0; c--) {
+            const double xJ = rdlane(y[rg], J0 + c - lo);
+#pragma unroll
+            for (int r2 = 0; r2 < NY; r2++)
+              if (r2 <= rg) y[r2] -= cur[c][r2] * xJ;
+          }
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r2 = 0; r2 < NY; r2++) cur[c][r2] = nxt[c][r2];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NY; r++) { const int I = r * 64 + lane; if (I < n) x[I] = y[r]; }
+  }
+  if (wv == 0) LDLTM_T(4);
+  if (tid == 0) *ok_flag = ok;
+}
+
+template <int NS, int NY>
+__global__ __launch_bounds__(kBigThreads) void k_ldlt_big(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag,
+                                                          double* __restrict__ wglob) {
+  ldlt_big_body<NS, NY>(n, St, x, ok_flag, wglob);
+}
+// 48 tiles per wavefront: hipcc keeps to v0..v127
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_num_vgpr(128))) void k_ldlt_big48(int n, const double* __restrict__ St, double* __restrict__ x,
+                                                                                                int* __restrict__ ok_flag, double* __restrict__ wglob) {
+  ldlt_big_body<48, 5>(n, St, x, ok_flag, wglob);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -886,20 +1419,29 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
 // true if k_ldlt_mfma covers a system of n unknowns (n = 6 * free poses)
 __host__ inline bool supports(int n) { return n >= 1 && make_geo(n).T <= 19; }
 
-struct Launch { const void* fn; size_t lds; bool wlds; bool cols; };
+struct Launch { const void* fn; size_t lds; bool wlds; bool cols; int threads; };
 
 __host__ inline Launch pick(int n) {
   const Geo g = make_geo(n);
   Launch L;
   if (g.T <= kColT && !getenv("ORBG_LDLT_TILES")) {
-    L.fn = reinterpret_cast<const void*>(k_ldlt_cols); L.wlds = true; L.cols = true;
+    L.fn = reinterpret_cast<const void*>(k_ldlt_cols); L.wlds = true; L.cols = true; L.threads = kThreads;
     L.lds = lds_doubles_cols(g) * sizeof(double);
     return L;
   }
   L.cols = false;
+  L.threads = kThreads;
   if (g.T <= 9) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
-  else if (g.T <= 13) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<12, 4, false>); L.wlds = false; }
-  else { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<24, 5, false>); L.wlds = false; }
+  else if (getenv("ORBG_LDLT_8W")) {
+    if (g.T <= 13) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<12, 4, false>); L.wlds = false; }
+    else { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<24, 5, false>); L.wlds = false; }
+  } else {
+    L.threads = kBigThreads; L.wlds = false;
+    if (g.T <= 10) L.fn = reinterpret_cast<const void*>(k_ldlt_big<16, 4>);
+    else if (g.T <= 13) L.fn = reinterpret_cast<const void*>(k_ldlt_big<24, 4>);
+    else if (g.T <= 15) L.fn = reinterpret_cast<const void*>(k_ldlt_big<32, 4>);
+    else L.fn = reinterpret_cast<const void*>(k_ldlt_big48);
+  }
   L.lds = lds_doubles(g, L.wlds) * sizeof(double);
   return L;
 }
@@ -907,16 +1449,16 @@ __host__ inline Launch pick(int n) {
 // St: the bordered matrix as a tile image (see image_put_rhs / k_image_pad), x: solution, wglob: wglob_doubles() of scratch
 __host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st) {
   const Launch L = pick(n);
-  static size_t attr[4] = {0, 0, 0, 0};
+  static size_t attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const Geo g = make_geo(n);
-  const int which = L.cols ? 3 : g.T <= 9 ? 0 : g.T <= 13 ? 1 : 2;
+  const int which = L.cols ? 3 : g.T <= 9 ? 0 : (g.T <= 13 ? 1 : 2) + (L.threads == kBigThreads ? (g.T <= 10 ? 5 : 3) : 0);
   if (L.lds > 64 * 1024 && attr[which] < L.lds) {
     hipError_t e = hipFuncSetAttribute(L.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
     if (e != hipSuccess) return e;
     attr[which] = L.lds;
   }
   void* args[] = {(void*)&n, (void*)&St, (void*)&x, (void*)&ok, (void*)&wglob};   // the column kernel ignores wglob
-  return hipLaunchKernel(L.fn, dim3(1), dim3(kThreads), args, L.lds, st);
+  return hipLaunchKernel(L.fn, dim3(1), dim3(L.threads), args, L.lds, st);
 }
 
 }  // namespace ldltm

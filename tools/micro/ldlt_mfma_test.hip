@@ -126,6 +126,22 @@ int main(int argc, char** argv) {
         printf("   row %2d: factor start %7lld  pivots %6lld (first 8: %5lld) publish %5lld | panel(k,k+1) start %7lld dur %5lld | upd(k+1,k+1) done %7lld\n", k, e[0] - pr[0], e[1] - e[0], e[6] - e[0], e[2] - e[1], e[3] - pr[0], e[4] - e[3], e[5] - pr[0]);
       }
     }
+    if (getenv("LDLT_WAVES") && atoi(getenv("LDLT_WAVES")) == n) {
+      long long pr[2048];
+      CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltm::g_prof), sizeof(pr)));
+      printf("  n=%d: loaded %lld factor_done %lld end %lld\n", n, pr[1] - pr[0], pr[2] - pr[0], pr[4] - pr[0]);
+      printf("   wave 0 items (kind*100+row : cycles to next):");
+      for (int i = 0; i + 1 < 400 && pr[1100 + 2 * i + 2] > 0; i++) printf(" %lld:%lld", pr[1101 + 2 * i], pr[1100 + 2 * i + 2] - pr[1100 + 2 * i]);
+      printf("\n");
+      for (int k = -1; k < g.Tp; k++) {
+        printf("   row %2d:", k);
+        for (int w = 0; w < 4; w++) {
+          const long long* e = pr + 512 + ((k + 1) * 4 + w) * 8;
+          printf(" w%d[%lld d%lld n%lld w%lld b%lld | p@%lld +%lld]", w, e[0] - pr[0], e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3], e[5] - pr[0], e[6] - e[5]);
+        }
+        printf("\n");
+      }
+    }
     if (n == 120) {
       long long pr[512];
       CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltm::g_prof), sizeof(pr)));
