@@ -583,6 +583,49 @@ __device__ __forceinline__ d4 mfma_v(double a, double b, d4 c) {
   return c;
 }
 
+#include "ldlt_jump_tables.inc"
+// run-time slot -> the tile's registers: a computed jump into a table of equally sized cases (tools/gen/gen_ldlt_jump_tables.py);
+// hipcc lowers a switch over the slot to a chain of up to 48 compare-and-branch blocks, 500-900 cycles per dispatch
+template <bool V>
+__device__ __forceinline__ d4 tile_get_jt(int sl) {
+  int x0, x1, x2, x3, x4, x5, x6, x7, tmp;
+  if constexpr (V) {
+    asm volatile(LDLTM_JT_GET_48 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=&s"(tmp) : "s"(sl)
+                 : "vcc", "scc", LDLTM_AGPR_LO);
+  } else {
+    asm volatile(LDLTM_JT_GET_32 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=&s"(tmp) : "s"(sl)
+                 : "vcc", "scc", LDLTM_AGPR_LO, LDLTM_AGPR_HI);
+  }
+  const i8v v = {x0, x1, x2, x3, x4, x5, x6, x7};
+  return __builtin_bit_cast(d4, v);
+}
+template <bool V>
+__device__ __forceinline__ void tile_mfma4_jt(int sl, const double (&a)[4], const double (&w)[4]) {
+  int tmp;
+  if constexpr (V) {
+    asm volatile(LDLTM_JT_MFMA4_48 : "=&s"(tmp) : "v"(a[0]), "v"(w[0]), "v"(a[1]), "v"(w[1]), "v"(a[2]), "v"(w[2]), "v"(a[3]), "v"(w[3]), "s"(sl)
+                 : "vcc", "scc", LDLTM_AGPR_LO);
+  } else {
+    asm volatile(LDLTM_JT_MFMA4_32 : "=&s"(tmp) : "v"(a[0]), "v"(w[0]), "v"(a[1]), "v"(w[1]), "v"(a[2]), "v"(w[2]), "v"(a[3]), "v"(w[3]), "s"(sl)
+                 : "vcc", "scc", LDLTM_AGPR_LO, LDLTM_AGPR_HI);
+  }
+}
+template <bool V>
+__device__ __forceinline__ void tile_mfma8_jt(int pair, const double (&a0)[4], const double (&w0)[4], const double (&a1)[4], const double (&w1)[4]) {
+  int tmp;
+  if constexpr (V) {
+    asm volatile(LDLTM_JT_MFMA8_48 : "=&s"(tmp)
+                 : "v"(a0[0]), "v"(w0[0]), "v"(a0[1]), "v"(w0[1]), "v"(a0[2]), "v"(w0[2]), "v"(a0[3]), "v"(w0[3]),
+                   "v"(a1[0]), "v"(w1[0]), "v"(a1[1]), "v"(w1[1]), "v"(a1[2]), "v"(w1[2]), "v"(a1[3]), "v"(w1[3]), "s"(pair)
+                 : "vcc", "scc", LDLTM_AGPR_LO);
+  } else {
+    asm volatile(LDLTM_JT_MFMA8_32 : "=&s"(tmp)
+                 : "v"(a0[0]), "v"(w0[0]), "v"(a0[1]), "v"(w0[1]), "v"(a0[2]), "v"(w0[2]), "v"(a0[3]), "v"(w0[3]),
+                   "v"(a1[0]), "v"(w1[0]), "v"(a1[1]), "v"(w1[1]), "v"(a1[2]), "v"(w1[2]), "v"(a1[3]), "v"(w1[3]), "s"(pair)
+                 : "vcc", "scc", LDLTM_AGPR_LO, LDLTM_AGPR_HI);
+  }
+}
+
 constexpr int kBigWaves = 4;
 constexpr int kBigThreads = 64 * kBigWaves;
 
@@ -624,20 +667,14 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
   // instructions (update in place) or eight moves (copy out for the panel / the elimination).
   constexpr bool V = NS > 32;                           // tiles in v128..v255 as well
   if constexpr (V) { asm volatile("" ::: "a0", "a255", "v255"); } else { asm volatile("" ::: "a0", "a255"); }   // (the register allocation of the kernel)
-  auto tile_get = [&](int sl) -> d4 {
-    d4 c = {0.0, 0.0, 0.0, 0.0};
-    slot_switch<NS>(sl, [&](auto sc) { c = tile_get_r<decltype(sc)::value, V>(); });
-    return c;
-  };
+  auto tile_get = [&](int sl) -> d4 { return tile_get_jt<V>(sl); };
   // U -= R^T W on the tile in slot sl, operands in a[], w[]
-  auto tile_update = [&](int sl, const double (&a)[4], const double (&w)[4]) {
-    slot_switch<NS>(sl, [&](auto sc) { tile_mfma4<decltype(sc)::value, V>(a, w); });
-  };
+  auto tile_update = [&](int sl, const double (&a)[4], const double (&w)[4]) { tile_mfma4_jt<V>(sl, a, w); };
   // ... on the tiles in slots sl (even) and sl + 1, chains interleaved
   auto pair_update = [&](int sl, const double (&a0)[4], const double (&w0)[4], const double (&a1)[4], const double (&w1)[4]) {
-    slot_switch<NS / 2>(sl >> 1, [&](auto gc) { tile_mfma4x2<2 * decltype(gc)::value, V>(a0, w0, a1, w1); });
+    tile_mfma8_jt<V>(sl >> 1, a0, w0, a1, w1);
   };
-  // two 16-byte loads per lane and tile from the tile image (column-major tile order there), 8 or 16 tiles in flight
+  // two 16-byte loads per lane and tile from the tile image (column-major tile order there)
   auto tile_addr = [&](int sl) -> const d4* {
     const int t = min(sl * kBigWaves + wv, G.ntiles - 1);
     const float bq = (float)(2 * T + 1);
@@ -648,13 +685,18 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     const int j = i + t - rowstart(i);
     return reinterpret_cast<const d4*>(St + (size_t)tile_index(i, j) * 256 + 4 * lane);
   };
-  constexpr int LC = V ? 8 : 16;                        // tiles in flight per round
-  static_for<0, (NS + LC - 1) / LC>([&](auto cc) {
-    constexpr int c0 = LC * decltype(cc)::value;
-    d4 tmp[LC];
-    static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (c0 + u < NS) tmp[u] = *tile_addr(c0 + u); });
-    static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (c0 + u < NS) tile_put_r<c0 + u, V>(tmp[u]); });
-  });
+  // rounds of LC tiles; round r+1 is requested before round r is moved into the tile store
+  constexpr int LC = V ? 4 : 8, NR = (NS + LC - 1) / LC;
+  {
+    d4 buf[2][LC];
+    static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (u < NS) buf[0][u] = *tile_addr(u); });
+    static_for<0, NR>([&](auto rr) {
+      constexpr int r = decltype(rr)::value, c0 = LC * r, pb = r & 1;
+      if constexpr (r + 1 < NR)
+        static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (c0 + LC + u < NS) buf[pb ^ 1][u] = *tile_addr(c0 + LC + u); });
+      static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (c0 + u < NS) tile_put_r<c0 + u, V>(buf[pb][u]); });
+    });
+  }
   __syncthreads();
   if (wv == 0) LDLTM_T(1);
 
@@ -809,11 +851,8 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     ld_ops(k, bi, bj, a1, w1); advance(bi, bj);
     ld_ops(k, bi, bj, a2, w2); advance(bi, bj);
     ld_ops(k, bi, bj, a3, w3); advance(bi, bj);
-    slot_switch<NS / 4>(sl >> 2, [&](auto gc) {
-      constexpr int s0 = 4 * decltype(gc)::value;
-      tile_mfma4x2<s0, V>(a0, w0, a1, w1);
-      tile_mfma4x2<s0 + 2, V>(a2, w2, a3, w3);
-    });
+    tile_mfma8_jt<V>(sl >> 1, a0, w0, a1, w1);
+    tile_mfma8_jt<V>((sl >> 1) + 1, a2, w2, a3, w3);
   };
 
   // Row program.  For tile row k (k = -1: nothing to update yet):
@@ -843,8 +882,23 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
       const int s2 = min(first_slot_from_row(k + 2), my_count);
       int j = k + 1 + (s1 * kBigWaves + wv - rowstart(k + 1));
       if (s1 < s2 && j == k + 1) { s1++; j += kBigWaves; }
-      for (; s1 < s2; s1++, j += kBigWaves) {
-        wait_gt(&s_panel[k + 1], k);
+      if (s1 < s2) wait_gt(&s_panel[k + 1], k);
+      if (s1 < s2 && (s1 & 1)) {
+        wait_gt(&s_panel[j], k);
+        double a0[4], w0[4];
+        ld_ops(k, k + 1, j, a0, w0);
+        tile_update(s1, a0, w0);
+        s1++; j += kBigWaves;
+      }
+      for (; s1 + 2 <= s2; s1 += 2, j += 2 * kBigWaves) {
+        wait_gt(&s_panel[j], k);
+        wait_gt(&s_panel[j + kBigWaves], k);
+        double a0[4], w0[4], a1[4], w1[4];
+        ld_ops(k, k + 1, j, a0, w0);
+        ld_ops(k, k + 1, j + kBigWaves, a1, w1);
+        pair_update(s1, a0, w0, a1, w1);
+      }
+      if (s1 < s2) {
         wait_gt(&s_panel[j], k);
         double a0[4], w0[4];
         ld_ops(k, k + 1, j, a0, w0);
