@@ -548,7 +548,10 @@ def main():
             pass
         # ---- which kernel dominates the step?  device time per step = average launch x launches per step
         lm_per_ba = stats["lba_iters"] / max(stats["lba_calls"], 1)
-        ldlt_name = ("ldltm::k_ldlt_cols" if n_unk <= 124 else "ldltm::k_ldlt_mfma") if solver_mfma else "k_ldlt_flow / k_ldlt_rows"
+        # the variant ldltm::pick() chooses for this many unknowns (tile rows T of the bordered matrix)
+        ldlt_T = ((((n_unk + 3) & ~3) + 1) + 15) // 16
+        ldlt_name = (("ldltm::k_ldlt_cols" if ldlt_T <= 8 else "ldltm::k_ldlt_mfma" if ldlt_T <= 9 else
+                      "ldltm::k_ldlt_big" if ldlt_T <= 15 else "ldltm::k_ldlt_big48") if solver_mfma else "k_ldlt_flow / k_ldlt_rows")
         per_step = {ldlt_name: ldlt_ms * lm_per_ba / FRAMES_PER_KF if solver_n else 0.0, "fast_cells_kernel": fast_ms if fast_n else 0.0}
         for kname, (kms, kn) in chain_ms.items():
             per_step[kname] = kms

@@ -666,7 +666,12 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
   // on a tile is generic code; per slot there is only a case of a switch with the tile's registers in it: four matrix
   // instructions (update in place) or eight moves (copy out for the panel / the elimination).
   constexpr bool V = NS > 32;                           // tiles in v128..v255 as well
-  if constexpr (V) { asm volatile("" ::: "a0", "a255", "v255"); } else { asm volatile("" ::: "a0", "a255"); }   // (the register allocation of the kernel)
+  // (the register allocation of the kernel: hipcc counts what assembly statements name as clobbered, not what their text uses;
+  // in the 48-tile kernel these registers are reserved -- which is the point -- and naming them draws a warning)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  if constexpr (V) { asm volatile("" ::: "a0", "a255", "v255"); } else { asm volatile("" ::: "a0", "a255"); }
+#pragma clang diagnostic pop
   auto tile_get = [&](int sl) -> d4 { return tile_get_jt<V>(sl); };
   // U -= R^T W on the tile in slot sl, operands in a[], w[]
   auto tile_update = [&](int sl, const double (&a)[4], const double (&w)[4]) { tile_mfma4_jt<V>(sl, a, w); };

@@ -96,7 +96,7 @@ def test_other_configurations_produce_a_line(name):
     assert d["config"]["name"] == name and d["value"] > 0 and d["config"]["lba_ms_per_call"] > 0
     assert d["roofline"]["bracketed_launches"] >= 1
     if name == "C4":
-        assert d["roofline"]["unknowns"] == 300 and "k_ldlt_mfma" in d["roofline"]["kernel"]
+        assert d["roofline"]["unknowns"] == 300 and "k_ldlt_big48" in d["roofline"]["kernel"]
     else:
         assert d["config"]["host_images_in_step"] is True
 

@@ -459,17 +459,20 @@ def test_lba_parity(shape):
     assert np.array_equal(g.poses, g2.poses) and np.array_equal(g.points, g2.points)
 
 
-@pytest.mark.parametrize("nf", [1, 2, 3, 7, 13, 19, 20, 21, 22, 26, 31, 40])
+@pytest.mark.parametrize("nf", [1, 2, 3, 7, 13, 19, 20, 21, 22, 26, 31, 36, 40, 47])
 def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
     """Free-pose counts around every kernel boundary of the reduced-camera-system solve: the matrix-core column kernel
-    (<= 20 poses, 1..8 tile columns), the matrix-core tile kernel in its three instantiations (<= 22 / <= 34 / <= 50 poses;
-    forced for the small sizes too), and the vector-ALU kernels behind ORBG_LDLT_VALU (dataflow <= 20 poses, barrier kernel)."""
+    (<= 20 poses, 1..8 tile columns), the eight-wavefront tile kernel (9 tile rows: 21..23 poses; forced for the small sizes
+    by ORBG_LDLT_TILES and for the large ones by ORBG_LDLT_8W), the four-wavefront kernel with its tile store in the
+    accumulation / high vector registers in its four instantiations (10 / 11..13 / 14..15 / 16..19 tile rows: <= 26 / 34 / 39 /
+    50 poses), and the vector-ALU kernels behind ORBG_LDLT_VALU (dataflow <= 20 poses, barrier kernel)."""
     prob = synth.make_lba_problem(n_free=nf, n_fixed=3, n_points=40 * nf + 60, mono_frac=0.2, seed=100 + nf)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
     o = ob.lba_solve(p)
-    variants = [{}, {"ORBG_LDLT_TILES": "1"}, {"ORBG_LDLT_VALU": "1"}, {"ORBG_LDLT_VALU": "1", "ORBG_LDLT_ROWS": "1"}]
+    variants = [{}, {"ORBG_LDLT_TILES": "1"}, {"ORBG_LDLT_TILES": "1", "ORBG_LDLT_8W": "1"}, {"ORBG_LDLT_VALU": "1"},
+                {"ORBG_LDLT_VALU": "1", "ORBG_LDLT_ROWS": "1"}]
     for env in variants:
-        for key in ("ORBG_LDLT_TILES", "ORBG_LDLT_VALU", "ORBG_LDLT_ROWS"):
+        for key in ("ORBG_LDLT_TILES", "ORBG_LDLT_8W", "ORBG_LDLT_VALU", "ORBG_LDLT_ROWS"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
