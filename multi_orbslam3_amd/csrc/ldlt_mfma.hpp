@@ -944,7 +944,25 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
         }
       }
       if (sl < seA) {
-        if (!V && (sl & 3) == 0 && sl + 4 <= seA) { quad_update(sl, k, bi, bj); sl += 4; }   // (V: 128 vector registers, no room for 32 operands)
+        if (V && pdone && (sl & 1) == 0) {
+          // nothing left to look out for in this row: the remaining pairs in a loop of their own (one branch per pair)
+          for (; sl + 2 <= seA; sl += 2) {
+            double a0[4], w0[4], a1[4], w1[4];
+            ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
+            ld_ops(k, bi, bj, a1, w1); advance(bi, bj);
+            pair_update(sl, a0, w0, a1, w1);
+          }
+          if (sl < seA) {
+            double a0[4], w0[4];
+            ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
+            tile_update(sl, a0, w0);
+            sl++;
+          }
+        }
+        else if (!V && pdone && (sl & 3) == 0 && sl + 4 <= seA) {
+          for (; sl + 4 <= seA; sl += 4) quad_update(sl, k, bi, bj);
+        }
+        else if (!V && (sl & 3) == 0 && sl + 4 <= seA) { quad_update(sl, k, bi, bj); sl += 4; }   // (V: 128 vector registers, no room for 32 operands)
         else if ((sl & 1) == 0 && sl + 2 <= seA) {
           double a0[4], w0[4], a1[4], w1[4];
           ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
