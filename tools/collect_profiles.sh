@@ -20,6 +20,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- pyt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_write.log" 2>&1 || true
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_mfma.log" 2>&1 || true
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_sq" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_sq.log" 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma_c4" -o run -- python3 "$R/bench.py" --config C4 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --lba-mode inline --no-pipeline > "$OUT/pmc_mfma_c4.log" 2>&1 || true
 cd "$R"
 python3 bench.py --steps 2000 --warmup 100 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_default.json" || true
 python3 bench.py --steps 400 --warmup 40 --no-pipeline --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_sync_ctor.json" || true
@@ -30,7 +31,7 @@ python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-secondary --serv
 python3 tools/lba_gaps.py "$OUT/stats/run_kernel_trace.csv" > "$OUT/lba_gaps.txt" 2>&1 || true
 f=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 profiles/pmc_aggregate.py FETCH_SIZE="$f" WRITE_SIZE="$w" > "$OUT/pmc_fetch_write_per_kernel.json" || true; fi
-for grp in pmc_mfma pmc_sq; do
+for grp in pmc_mfma pmc_sq pmc_mfma_c4; do
   c=$(find "$OUT/$grp" -name "*counter_collection.csv" | head -1)
   if [ -n "$c" ]; then python3 profiles/pmc_counters.py "$c" > "$OUT/${grp}_per_kernel.txt" || true; fi
 done
