@@ -577,10 +577,23 @@ __device__ __forceinline__ void tile_mfma4x2(const double (&a0)[4], const double
 // Matrix instruction on compiler-allocated vector registers, for k_ldlt_big (the builtin lets hipcc place the result in an
 // accumulation register of its choice).  Assembly is opaque to the hazard pass: two wait states cover a vector-ALU write
 // of an operand just before, 18 a vector-ALU read of the result right after.
-template <bool V>
+// (A wait state is one issue slot of the wavefront -- four cycles: the 18 after every instruction cost a panel tile 300 of its
+// 570 cycles of matrix work and the elimination 150 of 660 per pivot pair.  WAIT = false where the next reader is another
+// matrix instruction on the same registers, which the hardware interlocks, or provably far away; mfma_wait() before a
+// vector-ALU read otherwise.)
+template <bool V, bool WAIT = true>
 __device__ __forceinline__ d4 mfma_v(double a, double b, d4 c) {
-  LDLTM_ASM(V, "s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 2", "+v"(c), "v"(a) LDLTM_COMMA "v"(b));
+  if constexpr (WAIT) {
+    LDLTM_ASM(V, "s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 2", "+v"(c), "v"(a) LDLTM_COMMA "v"(b));
+  } else {
+    LDLTM_ASM(V, "s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0", "+v"(c), "v"(a) LDLTM_COMMA "v"(b));
+  }
   return c;
+}
+// 18 wait states for the results in c0 (and c1); the operands tie the statement to the instructions that produce them
+template <bool V>
+__device__ __forceinline__ void mfma_wait(d4& c0, d4& c1) {
+  LDLTM_ASM(V, "s_nop 15\n\ts_nop 2", "+v"(c0) LDLTM_COMMA "+v"(c1), );
 }
 
 #include "ldlt_jump_tables.inc"
@@ -748,7 +761,9 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
         for (int h = 0; h < 2; h++) {
           const int q0 = 2 * h, p0 = 4 * g + q0, p1 = p0 + 1;
           double u = C[g];
-          asm volatile("" : "+v"(u));              // own registers: the instruction below then updates C in place
+          // own registers: the instruction below then updates C in place.  (The previous pair's instruction on C was issued
+          // before its instruction on E, which held the pipe for 64 cycles: with these 8 wait states more than the 18 required.)
+          asm volatile("s_nop 7" : "+v"(u));
           const double c00 = rdlane(u, q0 * 16 + p0), c01 = rdlane(u, q0 * 16 + p1), c11 = rdlane(u, (q0 + 1) * 16 + p1);
           const double det = __builtin_fma(c00, c11, -(c01 * c01));
           const double r0 = rcp1(c00);
@@ -760,13 +775,13 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
           const bool in0 = lr == q0, in1 = lr == q0 + 1;
           const double bv = in1 ? u1 : u;
           const double av = in0 ? u * -r0 : in1 ? u1 * -r1 : 0.0;
-          if (p1 < 15) C = mfma_v<V>(av, bv, C);        // after the 16th pivot nothing of the tile is read again
+          if (p1 < 15) C = mfma_v<V, false>(av, bv, C);   // after the 16th pivot nothing of the tile is read again
           double eg = E[g];
           asm volatile("" : "+v"(eg));
           const double e0b = row_even_to_odd(eg);
           const double erow = in1 ? __builtin_fma(nl10, e0b, eg) : eg;
           if (in0 || in1) gcol[4 * g] = erow;      // rows p0, p1 of L^-1 are final before their own pivots
-          if (p1 < 15) E = mfma_v<V>(av, erow, E);
+          if (p1 < 15) E = mfma_v<V, false>(av, erow, E);  // (read again after the next pair's chain of reciprocals: > 200 cycles)
           Wc[g] -= av;                             // rows p0, p1 of the unit upper factor (their two lane groups)
           dvv = lane == p0 ? r0 : lane == p1 ? r1 : dvv;
           if (h == 1) rlast = r0 + r1;             // a zero or non-finite pivot turns every later reciprocal into NaN
@@ -793,10 +808,11 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     const int par = k & 1;
     if (j == k + 1) LDLTM_T(8 + 8 * k + 3);
     d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
-    R0 = mfma_v<V>(Gf[0], X[0], R0);
-    R1 = mfma_v<V>(Gf[2], X[2], R1);
-    R0 = mfma_v<V>(Gf[1], X[1], R0);
-    R1 = mfma_v<V>(Gf[3], X[3], R1);
+    R0 = mfma_v<V, false>(Gf[0], X[0], R0);
+    R1 = mfma_v<V, false>(Gf[2], X[2], R1);
+    R0 = mfma_v<V, false>(Gf[1], X[1], R0);
+    R1 = mfma_v<V, false>(Gf[3], X[3], R1);
+    mfma_wait<V>(R0, R1);
     double* const pb = Pan + ((par * T + j) * 2) * 256 + lane;
     double w4[4];
 #pragma unroll
@@ -823,16 +839,18 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     double a[4], w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) { a[q] = pa[q * 64]; w[q] = pw[q * 64]; }
+    d4 t2 = {0.0, 0.0, 0.0, 0.0};
     if (two_chains) {                        // two chains of two: this tile is on the critical path
-      d4 t2 = {0.0, 0.0, 0.0, 0.0};
-      c = mfma_v<V>(a[0], w[0], c);
-      t2 = mfma_v<V>(a[2], w[2], t2);
-      c = mfma_v<V>(a[1], w[1], c);
-      t2 = mfma_v<V>(a[3], w[3], t2);
+      c = mfma_v<V, false>(a[0], w[0], c);
+      t2 = mfma_v<V, false>(a[2], w[2], t2);
+      c = mfma_v<V, false>(a[1], w[1], c);
+      t2 = mfma_v<V, false>(a[3], w[3], t2);
+      mfma_wait<V>(c, t2);
       c += t2;
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; q++) c = mfma_v<V>(a[q], w[q], c);
+      for (int q = 0; q < 4; q++) c = mfma_v<V, false>(a[q], w[q], c);
+      mfma_wait<V>(c, t2);
     }
     return c;
   };
