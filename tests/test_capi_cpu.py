@@ -56,3 +56,20 @@ def test_product_never_references_the_oracle():
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
                 assert not re.search(r'#include\s+"[^"]*oracle/', txt), fn
+
+
+def test_generated_jump_tables_are_current():
+    """csrc/ldlt_jump_tables.inc (the per-tile dispatch tables of ldltm::k_ldlt_big) is generated: the committed file must be
+    what tools/gen/gen_ldlt_jump_tables.py writes, and every case of a table must have the stride the computed jump assumes
+    (4 matrix instructions = 32 bytes + s_branch + one s_nop = 40; 8 = 64 + 4 + 4 = 72)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_jt", os.path.join(root, "tools", "gen", "gen_ldlt_jump_tables.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(gen.DST).read() == gen.render()
+    for n in (32, 48):
+        lines = gen.mfma4(n)
+        assert sum(1 for l in lines if l.startswith("v_mfma")) == 4 * n and sum(1 for l in lines if l.startswith("s_branch")) == n
+        lines = gen.get(n)
+        assert sum(1 for l in lines if l.startswith("s_branch")) == n
