@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "wave.hpp"
+#include "stereo_finalize.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -312,23 +313,6 @@ __device__ __forceinline__ int arc9_maxmin(const int (&d)[16]) {
 #pragma unroll
   for (int i = 0; i < 16; i++) best = max(best, min(m8[i], d[(i + 8) & 15]));
   return best;
-}
-
-// Packed (iniTh count | minTh count << 16) exclusive scan over a 256-thread workgroup.
-__device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned* total, unsigned* wsum /*LDS[4]*/) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned inc = wave_incl_scan_add(v);
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  unsigned base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const unsigned s = wsum[w];
-    if (w < wave) base += s;
-    tot += s;
-  }
-  *total = tot;
-  return base + inc - v;
 }
 
 __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
@@ -1255,60 +1239,11 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
   if (lane == 0) { uright[iL] = out_u; depth[iL] = out_d; best_sad[iL] = out_sad; }
 }
 
-// median-of-SAD outlier rejection (:949-962), one 256-thread workgroup: the element vDistIdx[size/2].first of the
-// sorted list is found by a two-level (high byte / low byte) histogram select -- SAD <= 121*510 < 2^16 -- instead
-// of sorting; then every match whose SAD is not below 1.5f*1.4f*median is dropped.
+// (stereo_finalize_body: stereo_finalize.hpp)
 __global__ __launch_bounds__(256) void stereo_finalize_kernel(float* __restrict__ uright, float* __restrict__ depth,
                                                              const int* __restrict__ best_sad, int nl, const int* __restrict__ d_nkp,
                                                              float* __restrict__ host_out) {
-  __shared__ unsigned hist[256];
-  if (d_nkp) nl = d_nkp[0];
-  __shared__ unsigned wsum[4];
-  __shared__ int s_bin, s_before;
-  const int tid = threadIdx.x;
-  // ---- pass 0: histogram of the high byte -> bin holding the element of rank kth = n/2
-  hist[tid] = 0;
-  if (tid == 0) { s_bin = -1; s_before = 0; }
-  __syncthreads();
-  for (int i = tid; i < nl; i += 256) {
-    const int v = best_sad[i];
-    if (v >= 0) atomicAdd(&hist[(v >> 8) & 255], 1u);
-  }
-  __syncthreads();
-  unsigned total;
-  unsigned mine = hist[tid];
-  unsigned excl = block_excl_scan_256(mine, &total, wsum);
-  if (total == 0) {                                 // no stereo match at all (uniform exit)
-    if (host_out) for (int i = tid; i < nl; i += 256) { host_out[i] = uright[i]; host_out[nl + i] = depth[i]; }
-    return;
-  }
-  const unsigned kth = total / 2;
-  if (excl <= kth && kth < excl + mine) { s_bin = tid; s_before = (int)excl; }
-  __syncthreads();
-  const int hi = s_bin;
-  const unsigned before = (unsigned)s_before;
-  __syncthreads();
-  // ---- pass 1: histogram of the low byte inside that bin
-  hist[tid] = 0;
-  if (tid == 0) s_bin = -1;
-  __syncthreads();
-  for (int i = tid; i < nl; i += 256) {
-    const int v = best_sad[i];
-    if (v >= 0 && (v >> 8) == hi) atomicAdd(&hist[v & 255], 1u);
-  }
-  __syncthreads();
-  mine = hist[tid];
-  excl = block_excl_scan_256(mine, &total, wsum);
-  if (before + excl <= kth && kth < before + excl + mine) s_bin = tid;
-  __syncthreads();
-  const int median = (hi << 8) | s_bin;
-  const float thDist = 1.5f * 1.4f * (float)median;
-  for (int i = tid; i < nl; i += 256) {
-    const int v = best_sad[i];
-    float u = uright[i], d = depth[i];
-    if (v >= 0 && !((float)v < thDist)) { u = -1; d = -1; uright[i] = u; depth[i] = d; }
-    if (host_out) { host_out[i] = u; host_out[nl + i] = d; }     // mirror into mapped pinned memory: [uRight | depth]
-  }
+  stereo_finalize_body(uright, depth, best_sad, nl, d_nkp, host_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1760,7 +1695,7 @@ static int setup_geometry(orbx_handle* h, int w, int hgt) {
         (rc = h->d_selreg.reserve(std::max(roff, 1))) || (rc = h->h_nkp.reserve(4)))
       return rc;
     ORBG_HIP(hipMemset(h->d_lvlcount.p, 0, 2 * ORBG_MAX_LEVELS * sizeof(int)));
-    ORBG_HIP(hipMemset(h->d_overflow.p, 0, sizeof(int)));
+    ORBG_HIP(hipMemset(h->d_overflow.p, 0, 4 * sizeof(int)));   // [0] overflow flag, [2] ticket of the constructor's last launch
     // output buffers must hold the worst case of the device-side selection
     const size_t need = (size_t)roff + 64;
     if ((rc = h->d_kps.reserve(need)) || (rc = h->d_desc.reserve(need * 32)) || (rc = h->h_kps.reserve(need)) ||
@@ -1939,10 +1874,11 @@ struct ExtractPending {
   int n_res[2] = {0, 0};
 };
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
-                         volatile unsigned* done_flag, unsigned done_seq);
+                         volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin);
 void orbm_internal_set_n(orbm_frame* f, int n);
 int orbx_internal_kp_capacity(orbx_handle* h);
-static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror);
+static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror,
+                         StereoFinalizeArgs* defer_finalize = nullptr);
 
 // The device-resident Frame constructor is a fixed chain of kernels (pyramid, FAST, gather, quad-trees, descriptors, stereo):
 // only the image pointers change from call to call.  Submitting it as one executable graph costs the tracking thread one
@@ -2068,7 +2004,10 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       else launch_od(orient_desc_gpu_kernel<2>);
       if (br1(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
       if (do_stereo) {
-        const int rcs = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr);
+        // with a device frame to build, the median rejection runs as the second workgroup of the grid build (one launch less)
+        StereoFinalizeArgs unused;
+        const int rcs = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr,
+                                      post->frame ? &unused : nullptr);
         if (rcs) return rcs;
       }
     }
@@ -2145,7 +2084,12 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
         // the grid build is the last kernel of the chain: it posts the completion word itself (no signal kernel)
         unsigned seq; volatile unsigned* flag;
         if ((rc = h->sig.arm(&seq, &flag))) return rc;
-        if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq))) return rc;
+        StereoFinalizeArgs fin{};
+        const bool with_fin = do_stereo && h->sel_bound > 0;
+        if (with_fin)
+          fin = StereoFinalizeArgs{h->d_uright.p, h->d_depth.p, h->d_sad.p, h->sel_bound, h->d_nkp.p, stereo_out ? h->h_stereo.d : nullptr,
+                                   reinterpret_cast<unsigned*>(h->d_overflow.p + 2)};
+        if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq, with_fin ? &fin : nullptr))) return rc;
         posted = true;
       }
     }
@@ -2260,7 +2204,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
         stereo_out_host = true;
       }
     }
-    if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st, nullptr, nullptr, 0u))) return rc;
+    if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st, nullptr, nullptr, 0u, nullptr))) return rc;
   }
   const bool want_out = kps_out[0] || desc_out[0] || kps_out[1] || desc_out[1];
   if (n_sel_total > 0) {
@@ -2539,7 +2483,9 @@ static int extract_finish_gpu(orbx_handle* h, ExtractPending& c) {
   return ORBG_OK;
 }
 
-static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror) {
+// defer_finalize: do not launch the median rejection; hand its arguments back (it then runs next to the grid build)
+static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror,
+                         StereoFinalizeArgs* defer_finalize) {
   const int nl = device_counts ? h->sel_bound : h->n_kp[0], nr = h->n_kp[1];
   // the stereo key packs the right keypoint's index into 16 bits (dist << 16 | iR)
   if (nl >= ORBG_MAX_FRAME_FEATURES || nr >= ORBG_MAX_FRAME_FEATURES || (device_counts && orbx_internal_kp_capacity(h) >= 2 * ORBG_MAX_FRAME_FEATURES))
@@ -2549,7 +2495,8 @@ static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool
     const int* dn = device_counts ? h->d_nkp.p : nullptr;
     hipLaunchKernelGGL(stereo_match_kernel, dim3((nl + 3) / 4), dim3(256), 0, st, h->d_pyr.p, h->geom, h->d_kps.p, h->d_desc.p,
                        nl, h->d_kps.p + nl, h->d_desc.p + (size_t)nl * 32, nr, bf, b, h->d_uright.p, h->d_depth.p, h->d_sad.p, dn);
-    hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(256), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl, dn, host_mirror);
+    if (defer_finalize) *defer_finalize = StereoFinalizeArgs{h->d_uright.p, h->d_depth.p, h->d_sad.p, nl, dn, host_mirror, nullptr};
+    else hipLaunchKernelGGL(stereo_finalize_kernel, dim3(1), dim3(256), 0, st, h->d_uright.p, h->d_depth.p, h->d_sad.p, nl, dn, host_mirror);
   }
   if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[6], st));
   return ORBG_OK;

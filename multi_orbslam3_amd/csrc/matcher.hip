@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "wave.hpp"
+#include "stereo_finalize.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -176,6 +177,32 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* _
   if (done_flag) {
     __syncthreads();
     if (threadIdx.x == 0) *done_flag = done_seq;
+  }
+}
+
+// Last launch of the stereo Frame constructor: workgroup 0 builds the grid, workgroup 1 (its first four wavefronts; the
+// others leave at once) runs the median rejection of ComputeStereoMatches -- the two do not depend on each other, and as two
+// launches they cost the tracking thread a submission and the stream a kernel boundary more.  The rejection mirrors its
+// result into pinned host memory, so its wavefronts release to system scope before they take the ticket; the workgroup
+// that takes it second posts the constructor's completion word.
+__global__ __launch_bounds__(1024) void grid_build_finalize_kernel(const orbx_keypoint* __restrict__ kps, FrameParams fp,
+                                                                  int* __restrict__ cell_of, int* __restrict__ cell_start,
+                                                                  int* __restrict__ cell_items, const int* __restrict__ d_n,
+                                                                  volatile unsigned* done_flag, unsigned done_seq, StereoFinalizeArgs fin) {
+  if (blockIdx.x == 0) {
+    grid_build_body(kps, fp, cell_of, cell_start, cell_items, d_n);
+  } else {
+    if (threadIdx.x >= 256) return;              // (whole wavefronts: a barrier only counts wavefronts that are still alive)
+    stereo_finalize_body(fin.uright, fin.depth, fin.best_sad, fin.nl, fin.d_nkp, fin.host_out);
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == 1u) {
+      __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done_flag) *done_flag = done_seq;
+    }
   }
 }
 
@@ -940,7 +967,7 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
 // EXTRACTOR's stream, behind the descriptor / stereo kernels; the caller synchronises that stream once.
 int orbx_internal_kp_capacity(orbx_handle* h);   // extractor.hip
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
-                         volatile unsigned* done_flag, unsigned done_seq) {
+                         volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin) {
   if (!f || !h || !v) return ORBG_BAD_ARG;
   const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n0; hipStream_t xs;
   int rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n0, &xs);
@@ -954,8 +981,12 @@ int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v
   f->has_uright = true;
   f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
   f->stream = stream;              // the extractor's stream: searches on this frame follow its constructor in order
-  hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
-                     f->d_cell_items.p, d_n, done_flag, done_seq);
+  if (fin)
+    hipLaunchKernelGGL(grid_build_finalize_kernel, dim3(2), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
+                       f->d_cell_items.p, d_n, done_flag, done_seq, *fin);
+  else
+    hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
+                       f->d_cell_items.p, d_n, done_flag, done_seq);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;
 }
