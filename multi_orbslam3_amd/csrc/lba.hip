@@ -1774,7 +1774,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   // ---- structure (the analogue of BlockSolver::buildStructure, G/core/block_solver.hpp:143-295), host side.
   // Every array the kernels need is built IN PLACE inside one pinned block and goes to the device with ONE copy.
   std::vector<int>& pose_deg = h->s_pose_deg; std::vector<int>& point_deg = h->s_point_deg;
-  pose_deg.assign(NP, 0); point_deg.assign(NX, 0);
+  std::vector<int>& pf_raw = h->s_f3;                      // per point: observations from poses that are not fixed
+  pose_deg.assign(NP, 0); point_deg.assign(NX, 0); pf_raw.assign(NX, 0);
   // ONE pass over the caller's edges (360 KB at C2, cold): copy into pinned memory, validate, count degrees; the copy
   // goes to the device at once and every later pass reads the warm pinned copy
   if ((rc = h->edges_pin.reserve(std::max(NE, 1))) || (rc = h->d_edges.reserve(std::max(NE, 1)))) return rc;
@@ -1785,6 +1786,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     const unsigned ep = (unsigned)e.pose, ex = (unsigned)e.point;
     if (ep >= (unsigned)NP || ex >= (unsigned)NX) return ORBG_BAD_ARG;
     pose_deg[ep]++; point_deg[ex]++;
+    pf_raw[ex] += p->pose_fixed[ep] ? 0 : 1;
   }
   if (NE > 0) ORBG_HIP(hipMemcpyAsync(h->d_edges.p, edges, sizeof(lba_edge) * (size_t)NE, hipMemcpyHostToDevice, st));
   std::vector<int>& pose_col_v = h->s_pose_col; std::vector<int>& point_col_v = h->s_point_col;
@@ -1792,16 +1794,14 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   int nP = 0, nL = 0;
   for (int i = 0; i < NP; i++) if (!p->pose_fixed[i] && pose_deg[i] > 0) pose_col_v[i] = nP++;
   for (int i = 0; i < NX; i++) if (point_deg[i] > 0) point_col_v[i] = nL++;
-  // free-pose degree of every active point -> number of (pose pair, landmark) items
-  // one pass over the edges: free-pose degree of every active point, edges per active point, edges per free pose
+  // free-pose degree of every active point (-> number of (pose pair, landmark) items), edges per active point, edges per
+  // free pose: all of them follow from the degrees counted in the pass above (a pose with an edge has pose_deg > 0, so
+  // "not fixed" is "free" there)
   std::vector<int>& pf_deg = h->s_pf_deg; std::vector<int>& pt_cnt = h->s_f1; std::vector<int>& ps_cnt = h->s_f2;
   pf_deg.assign(nL + 1, 0); pt_cnt.assign(nL + 1, 0); ps_cnt.assign(nP + 1, 0);
   int n_free_edges = 0;
-  for (int k = 0; k < NE; k++) {
-    const int lc = point_col_v[edges[k].point], pc = pose_col_v[edges[k].pose];
-    pt_cnt[lc]++;
-    if (pc >= 0) { pf_deg[lc]++; ps_cnt[pc]++; n_free_edges++; }
-  }
+  for (int i = 0; i < NX; i++) { const int lc = point_col_v[i]; if (lc >= 0) { pt_cnt[lc] = point_deg[i]; pf_deg[lc] = pf_raw[i]; } }
+  for (int i = 0; i < NP; i++) { const int pc = pose_col_v[i]; if (pc >= 0) { ps_cnt[pc] = pose_deg[i]; n_free_edges += pose_deg[i]; } }
   size_t n_items = 0;
   for (int l = 0; l < nL; l++) n_items += (size_t)pf_deg[l] * (pf_deg[l] + 1) / 2;
   const int n_pairs_all = nP * (nP + 1) / 2;
@@ -1891,10 +1891,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     if ((rc = h->d_items_dev.reserve((size_t)n_pairs_all * item_cap)) || (rc = h->d_pair_count.reserve(std::max(n_pairs_all, 1)))) return rc;
     D.items = h->d_items_dev.p;
   }
-  // the two state buffers (current / trial estimate) are separate allocations: buffer 0 starts as a copy of the upload
-  if ((rc = h->d_poses[0].reserve(std::max(NP, 1))) || (rc = h->d_points[0].reserve(std::max<size_t>(3 * (size_t)NX, 1)))) return rc;
-  if (NP > 0) ORBG_HIP(hipMemcpyAsync(h->d_poses[0].p, h->up_d.p + o_poses, sizeof(PoseQ) * (size_t)NP, hipMemcpyDeviceToDevice, st));
-  if (NX > 0) ORBG_HIP(hipMemcpyAsync(h->d_points[0].p, h->up_d.p + o_points, 24 * (size_t)NX, hipMemcpyDeviceToDevice, st));
+  // the two state buffers (current / trial estimate): buffer 0 IS the uploaded state inside the arena (part A is not written
+  // again during the solve; two device-to-device copies of a few KB cost the stream ~10 us each before the first residuals),
+  // buffer 1 an allocation of its own
   if ((rc = h->d_poses[1].reserve(std::max(NP, 1))) || (rc = h->d_points[1].reserve(std::max<size_t>(3 * (size_t)NX, 1))) ||
       (rc = h->d_err.reserve(std::max<size_t>(3 * (size_t)NE, 1))) || (rc = h->d_chi2.reserve(std::max(NE, 1))) ||
       (rc = h->d_partial.reserve(std::max(n_blocks_e, 1))) || (rc = h->d_EB.reserve(std::max<size_t>((size_t)NE * kEB, 1))) ||
@@ -1906,6 +1905,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       (rc = h->d_S.reserve(std::max<size_t>((size_t)n * n, 1))) || (rc = h->d_bs.reserve(std::max(n, 1))) ||
       (rc = h->d_x.reserve(std::max<size_t>((size_t)n + 3 * (size_t)nL, 1))))
     return rc;
+  PoseQ* const posesB[2] = {reinterpret_cast<PoseQ*>(h->up_d.p + o_poses), h->d_poses[1].p};
+  double* const pointsB[2] = {reinterpret_cast<double*>(h->up_d.p + o_points), h->d_points[1].p};
   ORBG_HIP(hipMemsetAsync(h->d_x.p, 0, ((size_t)n + 3 * (size_t)nL) * sizeof(double), st));
 
   const double t_c = now_s();
@@ -1999,7 +2000,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   // final_mode: the last block also publishes {robust chi2, computeScale(), solver flag} to the host record
   auto launch_errors = [&](int buf, int final_mode) {
     if (NE > 0)
-      hipLaunchKernelGGL(k_errors, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, h->d_poses[buf].p, h->d_points[buf].p, cam, hb,
+      hipLaunchKernelGGL(k_errors, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, posesB[buf], pointsB[buf], cam, hb,
                          h->d_err.p, h->d_chi2.p, h->d_partial.p, final_mode, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u,
                          h->d_ok.p, h->rec.d, final_mode ? ++h->rec_seq : 0u);
   };
@@ -2015,8 +2016,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   bool spec_ready = false;         // set ls^1 holds the linearisation of the current estimate
   auto launch_linearise = [&](int buf, int set) {
     if (NE > 0 || nP > 0)
-      hipLaunchKernelGGL(k_lin_all, dim3(nP + (NE > 0 ? n_blocks_e : 0)), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[buf].p,
-                         h->d_points[buf].p, cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
+      hipLaunchKernelGGL(k_lin_all, dim3(nP + (NE > 0 ? n_blocks_e : 0)), dim3(256), 0, st, nP, NE, D.edges, posesB[buf],
+                         pointsB[buf], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                          D.ps_edges, Hpps[set], bps[set]);
     if (nL > 0)
       hipLaunchKernelGGL(k_reduce_points, dim3((nL + 255) / 256), dim3(256), 0, st, nL, D.pt_start, D.pt_edges, EBs[set],
@@ -2059,7 +2060,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   auto launch_export = [&](int buf) {
     const int n_thr = std::max(std::max(NE, NP), 3 * NX);
     if (n_thr > 0)
-      hipLaunchKernelGGL(k_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, NE, NP, NX, D.edges, h->d_poses[buf].p, h->d_points[buf].p,
+      hipLaunchKernelGGL(k_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, NE, NP, NX, D.edges, posesB[buf], pointsB[buf],
                          h->d_chi2.p, h->dl_h.d + d_flags_o, r->edge_chi2 ? reinterpret_cast<double*>(h->dl_h.d + d_chi_o) : (double*)nullptr,
                          reinterpret_cast<PoseQ*>(h->dl_h.d + d_poses_o), reinterpret_cast<double*>(h->dl_h.d + d_points_o));
   };
@@ -2156,8 +2157,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         // case, behind the previous trial's residual / linearisation kernel
         if (!(solve_version == version - 1 && qmax == 0 && used_spec) && (rc2 = launch_solve(ls, lambda, lam_p))) return rc2;
         hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, D.pose_col, D.point_col,
-                           h->d_poses[cur].p, h->d_points[cur].p, h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
-                           Hlls[ls], bls[ls], lambda, h->d_poses[trial].p, h->d_points[trial].p, bps[ls], h->d_scale_partial.p, lam_p);
+                           posesB[cur], pointsB[cur], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
+                           Hlls[ls], bls[ls], lambda, posesB[trial], pointsB[trial], bps[ls], h->d_scale_partial.p, lam_p);
         bool speculated = false;
         if (NE > 0) {
           // speculate on acceptance: linearise the trial state into the other set while the host waits for the verdict
@@ -2168,8 +2169,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
             // residuals + record + linearisation of the trial state in ONE launch
             const int set = ls ^ 1;
             const int n_blocks_l = (nL + 255) / 256;       // the landmark reduction rides in the same launch (point workgroups)
-            hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, h->d_poses[trial].p,
-                               h->d_points[trial].p, cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
+            hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[trial],
+                               pointsB[trial], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                                D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u, h->d_ok.p,
                                h->rec.d, ++h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
                                LmIn{currentChi, lambda, lambda_on_device ? h->d_lambda0.p + 2 : (const double*)nullptr,
