@@ -1925,7 +1925,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     return rc;
   PoseQ* const posesB[2] = {reinterpret_cast<PoseQ*>(h->up_d.p + o_poses), h->d_poses[1].p};
   double* const pointsB[2] = {reinterpret_cast<double*>(h->up_d.p + o_points), h->d_points[1].p};
-  ORBG_HIP(hipMemsetAsync(h->d_x.p, 0, ((size_t)n + 3 * (size_t)nL) * sizeof(double), st));
 
   const double t_c = now_s();
   Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
@@ -2005,8 +2004,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const bool use_mfma = nP >= 1 && ldltm::supports(n) && !getenv("ORBG_LDLT_VALU");
   if (use_mfma) {
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
-    // padding and zeros of the bordered image: they depend on n only, k_schur never touches them -- once per call
-    ORBG_HIP(ldltm::launch_image_pad(n, h->d_St.p, st));
   }
   int cur = 0;   // index of the buffer holding the current estimate
   const int n_blocks_u = (NP + NX + 255) / 256;
@@ -2273,8 +2270,21 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
 
   // first residuals + linearisation are launched before the host has finished the structure
   if (!terminate()) {
-    launch_errors(cur, 0); err_valid = true;
-    launch_linearise(cur, ls ^ 1);
+    if (NE > 0 && !getenv("ORBG_NO_FUSE")) {
+      // residuals + linearisation of the initial estimate in the fused kernel of the later trials (its record is not waited
+      // for: it carries the sequence number the host has already seen)
+      const int set = ls ^ 1;
+      const int n_blocks_l = (nL + 255) / 256;
+      hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
+                         pointsB[cur], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
+                         D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, 0, (const int*)nullptr,
+                         h->rec.d, h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
+                         LmIn{0.0, 0.0, (const double*)nullptr, (const double*)nullptr, (double*)nullptr});
+    } else {
+      launch_errors(cur, 0);
+      launch_linearise(cur, ls ^ 1);
+    }
+    err_valid = true;
     spec_ready = true;
     if (NE > 0) {
       // the first round's lambda init needs nothing the host is still building: it goes right behind the linearisation
@@ -2284,6 +2294,10 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     }
     ORBG_HIP(hipGetLastError());
   }
+  // not needed before the first Schur complement: the zeroed step vector and the padding / zeros of the bordered tile image
+  // (they depend on n only, k_schur never touches them -- once per call) go behind the first linearisation
+  ORBG_HIP(hipMemsetAsync(h->d_x.p, 0, ((size_t)n + 3 * (size_t)nL) * sizeof(double), st));
+  if (use_mfma) ORBG_HIP(ldltm::launch_image_pad(n, h->d_St.p, st));
   const double t_s2b = now_s();
   // while those run: the landmarks' free observations sorted by pose column, their pose masks / the pair counts
   {
