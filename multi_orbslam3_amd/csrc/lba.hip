@@ -2330,9 +2330,13 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     }
   }
   size_t off_b = off_a;
+  auto pair_id = [&](int i1, int i2) { return i1 * nP - i1 * (i1 - 1) / 2 + (i2 - i1); };
   if (dev_items && !terminate()) {
-    // the pf lists and pose masks go up next and the device builds the pair items behind the first linearisation
-    off_b = o_pair_i1;
+    // the pf lists and pose masks go up next and the device builds the pair items behind the first linearisation; the pair
+    // table (a function of nP alone) rides along, so nothing is left for a third upload
+    for (int i1 = 0; i1 < nP; i1++)
+      for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
+    off_b = o_pair_start;
     if ((rc = upload_arena(h, off_a, off_b, st, blit))) return rc;
     if (nL > 0)
       hipLaunchKernelGGL(k_build_items, dim3(n_pairs_all), dim3(256), 0, st, nP, nL,
@@ -2341,7 +2345,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     ORBG_HIP(hipGetLastError());
   }
   // pose pairs (i1 <= i2) and their landmark items, grouped by pair (counting sort keeps landmark order)
-  auto pair_id = [&](int i1, int i2) { return i1 * nP - i1 * (i1 - 1) / 2 + (i2 - i1); };
   if (!dev_items) {
     for (int i = 0; i < n_pairs_all; i++) pair_start[i + 1] += pair_start[i];
     std::vector<int>& fill = h->s_fill;
@@ -2375,7 +2378,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   for (int i1 = 0; i1 < nP; i1++)
     for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
 
-  if ((rc = upload_arena(h, off_b, off, st, blit))) return rc;
+  if (!dev_items && (rc = upload_arena(h, off_b, off, st, blit))) return rc;
   const double t_s3b = now_s();
   int done = 0;
   if ((rc = optimize(p->its_round1 > 0 ? p->its_round1 : 5, &done))) return rc;
