@@ -1805,7 +1805,15 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     pose_deg[ep]++; point_deg[ex]++;
     pf_raw[ex] += p->pose_fixed[ep] ? 0 : 1;
   }
-  if (NE > 0) ORBG_HIP(hipMemcpyAsync(h->d_edges.p, edges, sizeof(lba_edge) * (size_t)NE, hipMemcpyHostToDevice, st));
+  if (NE > 0) {
+    if (getenv("ORBG_LBA_BLIT")) {
+      ORBG_HIP(hipMemcpyAsync(h->d_edges.p, edges, sizeof(lba_edge) * (size_t)NE, hipMemcpyHostToDevice, st));
+    } else {                                               // (k_upload16 below: the runtime's blit takes ~50 us for these 190 KB)
+      const unsigned n16 = (unsigned)((sizeof(lba_edge) * (size_t)NE + 15) / 16);
+      hipLaunchKernelGGL(k_upload16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(h->edges_pin.d),
+                         reinterpret_cast<uint4*>(h->d_edges.p), n16);
+    }
+  }
   std::vector<int>& pose_col_v = h->s_pose_col; std::vector<int>& point_col_v = h->s_point_col;
   pose_col_v.assign(NP, -1); point_col_v.assign(NX, -1);
   int nP = 0, nL = 0;
