@@ -750,6 +750,61 @@ struct PairItem { int ea, eb, l; };   // edges (pose i1 / pose i2) of landmark l
 
 constexpr int kSchurThreads = 256;
 
+// Per landmark: its free observations sorted by pose column (stable: the order the host's insertion sort produces), their
+// columns and the landmark's pose mask -- the inputs of k_build_items and k_update.  One thread per landmark; the list (a
+// handful of entries, at most one per free pose) is sorted in LDS.  Replaces ~25 us of host loops per solve during which the
+// device sat idle between the first linearisation and the first Schur complement.
+constexpr int kSortPfThreads = 64, kSortPfCap = 64;
+__device__ __forceinline__ void sort_pf_block(int bid, int nL, const int* __restrict__ pf_start, int* __restrict__ pf_edges,
+                                              int* __restrict__ pf_col, unsigned long long* __restrict__ lm_mask,
+                                              const lba_edge* __restrict__ edges, const int* __restrict__ pose_col) {
+  __shared__ int s_e[kSortPfThreads][kSortPfCap + 1];      // (+1: rows start on different banks)
+  __shared__ int s_c[kSortPfThreads][kSortPfCap + 1];
+  const int l = bid * kSortPfThreads + threadIdx.x;
+  if (l >= nL) return;
+  const int b0 = pf_start[l], cnt = pf_start[l + 1] - b0;
+  unsigned long long m = 0;
+  if (cnt <= kSortPfCap) {
+    int* const se = s_e[threadIdx.x];
+    int* const sc = s_c[threadIdx.x];
+    for (int j = 0; j < cnt; j++) se[j] = pf_edges[b0 + j];
+    for (int j = 0; j < cnt; j++) sc[j] = pose_col[edges[se[j]].pose];
+    for (int a2 = 1; a2 < cnt; a2++) {
+      const int e = se[a2], key = sc[a2];
+      int b2 = a2 - 1;
+      while (b2 >= 0 && sc[b2] > key) { se[b2 + 1] = se[b2]; sc[b2 + 1] = sc[b2]; b2--; }
+      se[b2 + 1] = e; sc[b2 + 1] = key;
+    }
+    for (int j = 0; j < cnt; j++) { pf_edges[b0 + j] = se[j]; pf_col[b0 + j] = sc[j]; m |= 1ull << sc[j]; }
+  } else {                                                 // (more observations than free poses: repeated edges) in place
+    for (int a2 = b0 + 1; a2 < b0 + cnt; a2++) {
+      const int e = pf_edges[a2], key = pose_col[edges[e].pose];
+      int b2 = a2 - 1;
+      while (b2 >= b0 && pose_col[edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
+      pf_edges[b2 + 1] = e;
+    }
+    for (int j = b0; j < b0 + cnt; j++) { const int c = pose_col[edges[pf_edges[j]].pose]; pf_col[j] = c; m |= 1ull << c; }
+  }
+  lm_mask[l] = m;
+}
+
+// k_sort_pf, the padding of the bordered tile image (ldltm::k_image_pad) and the zeroing of the step vector in ONE launch:
+// at the start of a solve the worker thread issues a dozen launches back to back and the device waits for each of them.
+__global__ __launch_bounds__(kSortPfThreads) void k_prep(int n_sort_blocks, int nL, const int* __restrict__ pf_start, int* __restrict__ pf_edges,
+                                                        int* __restrict__ pf_col, unsigned long long* __restrict__ lm_mask,
+                                                        const lba_edge* __restrict__ edges, const int* __restrict__ pose_col,
+                                                        int n, double* __restrict__ St, double* __restrict__ xzero, int n_zero) {
+  constexpr int kPadBlocks = 32;
+  const int bid = (int)blockIdx.x;
+  if (bid < n_sort_blocks) { sort_pf_block(bid, nL, pf_start, pf_edges, pf_col, lm_mask, edges, pose_col); return; }
+  if (bid < n_sort_blocks + kPadBlocks) {
+    if (St) ldltm::image_pad_range(n, St, (bid - n_sort_blocks) * kSortPfThreads + (int)threadIdx.x, kPadBlocks * kSortPfThreads);
+    return;
+  }
+  const int nz = (int)gridDim.x - n_sort_blocks - kPadBlocks;
+  for (int i = (bid - n_sort_blocks - kPadBlocks) * kSortPfThreads + (int)threadIdx.x; i < n_zero; i += nz * kSortPfThreads) xzero[i] = 0.0;
+}
+
 // Pose-pair -> shared-landmark items built on the device (windows of up to 64 free poses): one workgroup per pose pair
 // walks the landmarks in index order, keeps those whose pose mask has both bits (ballot + popcount scan: the items come out
 // in landmark order, exactly as the host's counting sort produces them, so the Schur sums keep their order and bits) and
@@ -814,7 +869,13 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, k = blockIdx.x & 7;
     pr = k * q + min(k, r) + (blockIdx.x >> 3);
   }
-  const int i1 = pair_i1[pr], i2 = pair_i2[pr];
+  int i1, i2;
+  if (pair_i1) { i1 = pair_i1[pr]; i2 = pair_i2[pr]; }
+  else {                                                   // pair id = i1 nP - i1 (i1 - 1) / 2 + (i2 - i1), rows in order
+    int rem = pr; i1 = 0;
+    while (rem >= nP - i1) { rem -= nP - i1; i1++; }
+    i2 = i1 + rem;
+  }
   const int tid = threadIdx.x;
   double acc[36], cacc[6];
 #pragma unroll
@@ -1892,7 +1953,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const double t_b = now_s();
   // part A of the arena (edges, state, the CSR lists the error / linearisation kernels read) goes up now; the pair items
   // the Schur kernel needs are built while the device already computes the first residuals and Jacobians
-  const size_t off_a = o_pf_start;
+  // (the lists of free observations per landmark, still in edge order, go along when the device sorts them: k_sort_pf)
+  const bool dev_lists = dev_items && nP >= 1 && ldltm::supports(6 * nP) && !getenv("ORBG_LDLT_VALU") && !getenv("ORBG_HOST_LISTS");
+  const size_t off_a = dev_lists ? o_pf_col : o_pf_start;
   const bool blit = getenv("ORBG_LBA_BLIT") != nullptr;       // A/B switch: the runtime's copies
   if ((rc = upload_arena(h, 0, off_a, st, blit))) return rc;
   struct {
@@ -1909,6 +1972,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     D.pf_start = reinterpret_cast<const int*>(B + o_pf_start); D.pf_edges = reinterpret_cast<const int*>(B + o_pf_edges);
     D.pf_col = reinterpret_cast<const int*>(B + o_pf_col);
     D.pair_i1 = reinterpret_cast<const int*>(B + o_pair_i1); D.pair_i2 = reinterpret_cast<const int*>(B + o_pair_i2);
+    if (dev_lists) { D.pair_i1 = nullptr; D.pair_i2 = nullptr; }
     D.pair_start = dev_items ? (const int*)nullptr : reinterpret_cast<const int*>(B + o_pair_start);
     D.items = dev_items ? (const PairItem*)nullptr : reinterpret_cast<const PairItem*>(B + o_items);
   }
@@ -2304,9 +2368,20 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   }
   // not needed before the first Schur complement: the zeroed step vector and the padding / zeros of the bordered tile image
   // (they depend on n only, k_schur never touches them -- once per call) go behind the first linearisation
-  ORBG_HIP(hipMemsetAsync(h->d_x.p, 0, ((size_t)n + 3 * (size_t)nL) * sizeof(double), st));
-  if (use_mfma) ORBG_HIP(ldltm::launch_image_pad(n, h->d_St.p, st));
+  const int n_zero = n + 3 * nL;
+  if (dev_lists) {
+    // ... in one launch with the per-landmark lists (k_prep)
+    const int nsb = (nL + kSortPfThreads - 1) / kSortPfThreads;
+    hipLaunchKernelGGL(k_prep, dim3(nsb + 32 + 8), dim3(kSortPfThreads), 0, st, nsb, nL, D.pf_start, const_cast<int*>(D.pf_edges),
+                       const_cast<int*>(D.pf_col), reinterpret_cast<unsigned long long*>(h->up_d.p + o_lm_mask), D.edges, D.pose_col,
+                       n, use_mfma ? h->d_St.p : (double*)nullptr, h->d_x.p, n_zero);
+    ORBG_HIP(hipGetLastError());
+  } else {
+    ORBG_HIP(hipMemsetAsync(h->d_x.p, 0, (size_t)n_zero * sizeof(double), st));
+    if (use_mfma) ORBG_HIP(ldltm::launch_image_pad(n, h->d_St.p, st));
+  }
   const double t_s2b = now_s();
+  if (!dev_lists)
   // while those run: the landmarks' free observations sorted by pose column, their pose masks / the pair counts
   {
     // per landmark: stable insertion sort of its free observations by pose column (a handful each), then count its
@@ -2345,7 +2420,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     for (int i1 = 0; i1 < nP; i1++)
       for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
     off_b = o_pair_start;
-    if ((rc = upload_arena(h, off_a, off_b, st, blit))) return rc;
+    if (!dev_lists && (rc = upload_arena(h, off_a, off_b, st, blit))) return rc;      // (dev_lists: k_schur derives the pair from its index)
     if (nL > 0)
       hipLaunchKernelGGL(k_build_items, dim3(n_pairs_all), dim3(256), 0, st, nP, nL,
                          reinterpret_cast<const unsigned long long*>(h->up_d.p + o_lm_mask), D.pf_start, D.pf_edges, D.pf_col,
@@ -2367,7 +2442,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     }
   }
   // symbolic elimination of the reduced camera system: which blocks of L are structurally non-zero (fill-in included)
-  if (nP <= 64 && !getenv("ORBG_LDLT_DENSE")) {
+  if (nP <= 64 && !getenv("ORBG_LDLT_DENSE") && !dev_lists) {     // (only the vector-ALU kernels read it; dev_lists implies the matrix-core solver)
     unsigned long long col[64];                         // col[j]: rows i > j with S_ij != 0, then with fill-in
     for (int j = 0; j < nP; j++) {
       unsigned long long mcol = 0;

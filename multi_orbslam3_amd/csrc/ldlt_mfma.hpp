@@ -94,11 +94,12 @@ __host__ __device__ inline double image_pad_value(const Geo& g, int n, int r, in
   if ((c == g.cb && r < n) || (r == g.cb && c < n)) return -1.0;
   return (r == c && r < g.n_pad) ? 1.0 : 0.0;
 }
-__global__ void k_image_pad(int n, double* __restrict__ St) {
+// (thread `me` of `nthreads`; also called from lba.hip's k_prep)
+__device__ __forceinline__ void image_pad_range(int n, double* __restrict__ St, int me, int nthreads) {
   const Geo g = make_geo(n);
   const int j0 = n >> 4;                         // tile columns j0 .. T-1 hold everything outside S
   const int t0 = tile_index(0, j0), cnt = (g.ntiles - t0) * 256;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += gridDim.x * blockDim.x) {
+  for (int e = me; e < cnt; e += nthreads) {
     const int t = t0 + (e >> 8), w = e & 255, l = w >> 2, gg = w & 3;
     int j = j0;
     while (tile_index(0, j + 1) <= t) j++;
@@ -106,6 +107,9 @@ __global__ void k_image_pad(int n, double* __restrict__ St) {
     const double v = image_pad_value(g, n, 16 * i + (l >> 4) + 4 * gg, 16 * j + (l & 15));
     if (v >= 0.0) St[(size_t)t0 * 256 + e] = v;
   }
+}
+__global__ void k_image_pad(int n, double* __restrict__ St) {
+  image_pad_range(n, St, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 __host__ inline hipError_t launch_image_pad(int n, double* St, hipStream_t st) {
   hipLaunchKernelGGL(k_image_pad, dim3(8), dim3(256), 0, st, n, St);
