@@ -485,6 +485,30 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
         assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), (nf, env)
 
 
+@pytest.mark.parametrize("env", [{"ORBG_HOST_LISTS": "1"}, {"ORBG_LBA_BLIT": "1"}, {"ORBG_HOST_ITEMS": "1"}, {"ORBG_NO_FUSE": "1"}])
+def test_lba_start_up_variants_agree_with_the_oracle(env, monkeypatch):
+    """The start of a solve has device-side and host-side forms (per-landmark observation lists sorted by k_prep or by the host,
+    uploads through k_upload16 or the runtime's copies, pair items built on the device or on the host, the initial estimate
+    through the fused k_errlin or through k_errors + k_lin_all + k_reduce_points): every form must give the oracle's solve."""
+    prob = synth.make_lba_problem(n_free=12, n_fixed=4, n_points=700, mono_frac=0.15, seed=4242)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    o = ob.lba_solve(p)
+    for key in ("ORBG_HOST_LISTS", "ORBG_LBA_BLIT", "ORBG_HOST_ITEMS", "ORBG_NO_FUSE"):
+        monkeypatch.delenv(key, raising=False)
+    base = api.Optimizer().LocalBundleAdjustment(p)
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    g = api.Optimizer().LocalBundleAdjustment(p)
+    for r in (base, g):
+        assert r.status == o.status and r.iters == o.iters, env
+        assert np.abs(r.poses - o.poses).max() <= 1e-4 and np.abs(r.points - o.points).max() <= 1e-4, env
+        assert np.array_equal(r.edge_outlier, o.edge_outlier)
+        tg, to = r.trace_rows(), o.trace_rows()
+        assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]) and np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), env
+    # the forms differ in where a list is built, not in the arithmetic: same bits
+    assert np.array_equal(base.poses, g.poses) and np.array_equal(base.points, g.points), env
+
+
 @pytest.mark.parametrize("k_trials", [1, 2, 3, "round1", "round1+1", 100])
 def test_lba_abort_at_a_given_trial_matches_the_oracle(k_trials):
     """*pbStopFlag raised by Tracking while the solve runs (S/LocalMapping.cc:381-386 -> G/core/optimization_algorithm_
