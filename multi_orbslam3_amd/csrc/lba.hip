@@ -350,14 +350,16 @@ __device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const do
   }
 }
 
-__global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                               const double* __restrict__ points, Cam cam, Huber hb, double* __restrict__ err,
-                                               double* __restrict__ chi2, double* __restrict__ partial,
+// (returns this thread's chi2 -- the caller may go on with it: k_errors_export)
+__device__ __forceinline__ double errors_block(int bid, int n_edge_blocks, int n_edges, const lba_edge* __restrict__ edges,
+                                               const PoseQ* __restrict__ poses, const double* __restrict__ points, Cam cam, Huber hb,
+                                               double* __restrict__ err, double* __restrict__ chi2, double* __restrict__ partial,
                                                int final_mode, unsigned* __restrict__ ticket, const double* __restrict__ scale_partial,
                                                int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec,
                                                unsigned seq) {
   __shared__ double red[256];
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int k = bid * 256 + threadIdx.x;
+  double c_out = 0;
   double rho0 = 0;
   if (k < n_edges) {
     const lba_edge e = edges[k];
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
     for (int i = 0; i < D; i++) c += er[i] * (om * er[i]);
     err[3 * (size_t)k] = er[0]; err[3 * (size_t)k + 1] = er[1]; err[3 * (size_t)k + 2] = er[2];
     chi2[k] = c;
+    c_out = c;
     double rho1;
     const bool mono = D == 2;
     huber(c, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
@@ -379,9 +382,51 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-  if (!final_mode) return;
-  publish_trial_record((int)gridDim.x, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq);
+  if (threadIdx.x == 0) partial[bid] = red[0];
+  if (final_mode) publish_trial_record(n_edge_blocks, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq);
+  return c_out;
+}
+__global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+                                               const double* __restrict__ points, Cam cam, Huber hb, double* __restrict__ err,
+                                               double* __restrict__ chi2, double* __restrict__ partial,
+                                               int final_mode, unsigned* __restrict__ ticket, const double* __restrict__ scale_partial,
+                                               int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec,
+                                               unsigned seq) {
+  errors_block((int)blockIdx.x, (int)gridDim.x, n_edges, edges, poses, points, cam, hb, err, chi2, partial, final_mode, ticket, scale_partial,
+               n_scale_partial, ok_flag, rec, seq);
+}
+// The last evaluation of a solve and the export of the state it evaluated (speculative: dropped if the trial is rejected) in
+// one launch: the export needs nothing of the other workgroups (an edge's flags follow from its own chi2).
+__global__ __launch_bounds__(256) void k_errors_export(int n_edge_blocks, int n_edges, const lba_edge* __restrict__ edges,
+                                                      const PoseQ* __restrict__ poses, const double* __restrict__ points, Cam cam, Huber hb,
+                                                      double* __restrict__ err, double* __restrict__ chi2, double* __restrict__ partial,
+                                                      unsigned* __restrict__ ticket, const double* __restrict__ scale_partial,
+                                                      int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec,
+                                                      unsigned seq, int n_poses, int n_points, uint8_t* __restrict__ out_flags,
+                                                      double* __restrict__ out_chi2, PoseQ* __restrict__ out_poses,
+                                                      double* __restrict__ out_points) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  // export first (the record's publication ends with returns inside errors_block)
+  if (k < n_poses) out_poses[k] = poses[k];
+  if (k < 3 * n_points) out_points[k] = points[k];
+  if ((int)blockIdx.x >= n_edge_blocks) return;
+  bool depth_pos = false; double thr = 0;
+  if (k < n_edges) {
+    const lba_edge e = edges[k];
+    double rr[3];
+    quat_rotate(poses[e.pose].q, points + 3 * (size_t)e.point, rr);
+    depth_pos = rr[2] + poses[e.pose].t[2] > 0.0;
+    thr = e.ur < 0 ? 5.991 : 7.815;
+  }
+  // the flags need this edge's chi2: computed below, so the residual part runs first for the values and the flags are
+  // written from its return value
+  const double c = errors_block((int)blockIdx.x, n_edge_blocks, n_edges, edges, poses, points, cam, hb, err, chi2, partial, 1, ticket,
+                                scale_partial, n_scale_partial, ok_flag, rec, seq);
+  if (k < n_edges) {
+    const bool outlier = c > thr || !depth_pos;
+    out_flags[k] = (uint8_t)((depth_pos ? 1 : 0) | (outlier ? 2 : 0));
+    if (out_chi2) out_chi2[k] = c;
+  }
 }
 
 // per-edge blocks: EB[k*27 + ...] = Hpl (6x3, 18) | pointH upper (6) | pointB (3)
@@ -701,6 +746,7 @@ __global__ __launch_bounds__(256) void k_errlin(int nP, int n_edges, const lba_e
   }
 }
 
+
 // Hll (6 upper) + bl (3) per active point: ordered sum over the point's edges
 __global__ __launch_bounds__(256) void k_reduce_points(int nL, const int* __restrict__ pt_start, const int* __restrict__ pt_edges,
                                                       const double* __restrict__ EB, double* __restrict__ Hll, double* __restrict__ bl) {
@@ -755,16 +801,17 @@ constexpr int kSchurThreads = 256;
 // handful of entries, at most one per free pose) is sorted in LDS.  Replaces ~25 us of host loops per solve during which the
 // device sat idle between the first linearisation and the first Schur complement.
 constexpr int kSortPfThreads = 64, kSortPfCap = 64;
+template <int NT, int CAP>
 __device__ __forceinline__ void sort_pf_block(int bid, int nL, const int* __restrict__ pf_start, int* __restrict__ pf_edges,
                                               int* __restrict__ pf_col, unsigned long long* __restrict__ lm_mask,
                                               const lba_edge* __restrict__ edges, const int* __restrict__ pose_col) {
-  __shared__ int s_e[kSortPfThreads][kSortPfCap + 1];      // (+1: rows start on different banks)
-  __shared__ int s_c[kSortPfThreads][kSortPfCap + 1];
-  const int l = bid * kSortPfThreads + threadIdx.x;
+  __shared__ int s_e[NT][CAP + 1];      // (+1: rows start on different banks)
+  __shared__ int s_c[NT][CAP + 1];
+  const int l = bid * NT + threadIdx.x;
   if (l >= nL) return;
   const int b0 = pf_start[l], cnt = pf_start[l + 1] - b0;
   unsigned long long m = 0;
-  if (cnt <= kSortPfCap) {
+  if (cnt <= CAP) {
     int* const se = s_e[threadIdx.x];
     int* const sc = s_c[threadIdx.x];
     for (int j = 0; j < cnt; j++) se[j] = pf_edges[b0 + j];
@@ -788,6 +835,45 @@ __device__ __forceinline__ void sort_pf_block(int bid, int nL, const int* __rest
   lm_mask[l] = m;
 }
 
+// First launch of a solve: the linearisation of the initial estimate and, in further workgroups, everything else that needs
+// only the first upload -- the per-landmark observation lists (256 landmarks per workgroup, lists of up to 16 entries sorted
+// in LDS), the padding of the tile image, the zeroed step vector.  (Two launches: 12 + 6.6 us one after the other.)
+constexpr int kPrep256Cap = 16, kPrep256Pad = 8, kPrep256Zero = 4;
+__global__ __launch_bounds__(256) void k_errlin_prep(int n_errlin_blocks, int n_sort_blocks, int* __restrict__ pf_edges_w, int* __restrict__ pf_col_w,
+                                                    const int* __restrict__ pf_start, unsigned long long* __restrict__ lm_mask,
+                                                    int n_unknowns, double* __restrict__ St, double* __restrict__ xzero, int n_zero,
+                                                    int nP, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
+                                               const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ err,
+                                               double* __restrict__ chi2, const int* __restrict__ pose_col,
+                                               const int* __restrict__ point_col, double* __restrict__ EB,
+                                               const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
+                                               double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ partial,
+                                               unsigned* __restrict__ ticket, const double* __restrict__ scale_partial, int n_scale_partial,
+                                               const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq, int n_edge_blocks,
+                                               int nL, const int* __restrict__ pt_start, const int* __restrict__ pt_edges,
+                                               double* __restrict__ Hll, double* __restrict__ bl, LmIn lm) {
+  int bid = (int)blockIdx.x;
+  if (bid >= n_errlin_blocks) {
+    bid -= n_errlin_blocks;
+    if (bid < n_sort_blocks) { sort_pf_block<256, kPrep256Cap>(bid, nL, pf_start, pf_edges_w, pf_col_w, lm_mask, edges, pose_col); return; }
+    bid -= n_sort_blocks;
+    if (bid < kPrep256Pad) { if (St) ldltm::image_pad_range(n_unknowns, St, bid * 256 + (int)threadIdx.x, kPrep256Pad * 256); return; }
+    bid -= kPrep256Pad;
+    for (int i = bid * 256 + (int)threadIdx.x; i < n_zero; i += kPrep256Zero * 256) xzero[i] = 0.0;
+    return;
+  }
+
+  
+  if (bid < nP) {
+    lin_poses_block<true>(bid, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
+  } else if (bid < nP + n_edge_blocks) {
+    linearize_block<true>(bid - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB,
+                          TrialPublish{partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, n_edge_blocks, lm});
+  } else {
+    lin_points_block(bid - nP - n_edge_blocks, nL, pt_start, pt_edges, edges, poses, points, c, hb, Hll, bl);
+  }
+}
+
 // k_sort_pf, the padding of the bordered tile image (ldltm::k_image_pad) and the zeroing of the step vector in ONE launch:
 // at the start of a solve the worker thread issues a dozen launches back to back and the device waits for each of them.
 __global__ __launch_bounds__(kSortPfThreads) void k_prep(int n_sort_blocks, int nL, const int* __restrict__ pf_start, int* __restrict__ pf_edges,
@@ -796,7 +882,7 @@ __global__ __launch_bounds__(kSortPfThreads) void k_prep(int n_sort_blocks, int 
                                                         int n, double* __restrict__ St, double* __restrict__ xzero, int n_zero) {
   constexpr int kPadBlocks = 32;
   const int bid = (int)blockIdx.x;
-  if (bid < n_sort_blocks) { sort_pf_block(bid, nL, pf_start, pf_edges, pf_col, lm_mask, edges, pose_col); return; }
+  if (bid < n_sort_blocks) { sort_pf_block<kSortPfThreads, kSortPfCap>(bid, nL, pf_start, pf_edges, pf_col, lm_mask, edges, pose_col); return; }
   if (bid < n_sort_blocks + kPadBlocks) {
     if (St) ldltm::image_pad_range(n, St, (bid - n_sort_blocks) * kSortPfThreads + (int)threadIdx.x, kPadBlocks * kSortPfThreads);
     return;
@@ -810,12 +896,12 @@ __global__ __launch_bounds__(kSortPfThreads) void k_prep(int n_sort_blocks, int 
 // in landmark order, exactly as the host's counting sort produces them, so the Schur sums keep their order and bits) and
 // looks the two edges up in the landmark's short, sorted observation list.  Pair p owns items[p * cap, p * cap + count[p]).
 // Replaces ~30 us of host loops and a 0.5 MB upload per solve that sat between the first kernels and the first k_schur.
-__global__ __launch_bounds__(256) void k_build_items(int nP, int nL, const unsigned long long* __restrict__ lm_mask,
-                                                    const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
-                                                    const int* __restrict__ pf_col, PairItem* __restrict__ items, int cap,
-                                                    int* __restrict__ pair_count) {
+__device__ __forceinline__ void build_items_block(int pr, int nP, int nL, const unsigned long long* __restrict__ lm_mask,
+                                                  const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
+                                                  const int* __restrict__ pf_col, PairItem* __restrict__ items, int cap,
+                                                  int* __restrict__ pair_count) {
   __shared__ int wcount[4];
-  const int pr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int i1 = 0, rem = pr;
   while (rem >= nP - i1) { rem -= nP - i1; i1++; }
   const int i2 = i1 + rem;
@@ -844,6 +930,12 @@ __global__ __launch_bounds__(256) void k_build_items(int nP, int nL, const unsig
     __syncthreads();
   }
   if (tid == 0) pair_count[pr] = running;
+}
+__global__ __launch_bounds__(256) void k_build_items(int nP, int nL, const unsigned long long* __restrict__ lm_mask,
+                                                    const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
+                                                    const int* __restrict__ pf_col, PairItem* __restrict__ items, int cap,
+                                                    int* __restrict__ pair_count) {
+  build_items_block((int)blockIdx.x, nP, nL, lm_mask, pf_start, pf_edges, pf_col, items, cap, pair_count);
 }
 
 __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __restrict__ pair_i1, const int* __restrict__ pair_i2,
@@ -1640,11 +1732,11 @@ __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int n
 }
 
 // one workgroup: chi2 = sum partial[] (fixed order), scale = sum x (lambda x + b), maxdiag; -> pinned record
-__global__ __launch_bounds__(256) void k_finish(int n_partial, const double* __restrict__ partial, int nP, int nL,
-                                               const double* __restrict__ x, const double* __restrict__ bp, const double* __restrict__ bl,
-                                               const double* __restrict__ Hpp, const double* __restrict__ Hll, double lambda,
-                                               const int* __restrict__ ok_flag, int want_scale, int want_maxdiag, HostRec* __restrict__ rec,
-                                               double lambda_init, double* __restrict__ lambda0_out) {
+__device__ __forceinline__ void finish_block(int n_partial, const double* __restrict__ partial, int nP, int nL,
+                                             const double* __restrict__ x, const double* __restrict__ bp, const double* __restrict__ bl,
+                                             const double* __restrict__ Hpp, const double* __restrict__ Hll, double lambda,
+                                             const int* __restrict__ ok_flag, int want_scale, int want_maxdiag, HostRec* __restrict__ rec,
+                                             double lambda_init, double* __restrict__ lambda0_out) {
   __shared__ double red[256];
   __shared__ double parts[1024];
   const int tid = threadIdx.x;
@@ -1700,6 +1792,27 @@ __global__ __launch_bounds__(256) void k_finish(int n_partial, const double* __r
     }
   }
 }
+__global__ __launch_bounds__(256) void k_finish(int n_partial, const double* __restrict__ partial, int nP, int nL,
+                                               const double* __restrict__ x, const double* __restrict__ bp, const double* __restrict__ bl,
+                                               const double* __restrict__ Hpp, const double* __restrict__ Hll, double lambda,
+                                               const int* __restrict__ ok_flag, int want_scale, int want_maxdiag, HostRec* __restrict__ rec,
+                                               double lambda_init, double* __restrict__ lambda0_out) {
+  finish_block(n_partial, partial, nP, nL, x, bp, bl, Hpp, Hll, lambda, ok_flag, want_scale, want_maxdiag, rec, lambda_init, lambda0_out);
+}
+// First iteration of a solve: the lambda init (workgroup 0) and the pose-pair items (one workgroup per pair) wait for different
+// things of the launch before -- the linearisation and the sorted observation lists -- and not for each other: one launch.
+__global__ __launch_bounds__(256) void k_finish_items(int n_partial, const double* __restrict__ partial, int nP, int nL,
+                                                     const double* __restrict__ bp, const double* __restrict__ bl,
+                                                     const double* __restrict__ Hpp, const double* __restrict__ Hll, HostRec* __restrict__ rec,
+                                                     double lambda_init, double* __restrict__ lambda0_out,
+                                                     const unsigned long long* __restrict__ lm_mask, const int* __restrict__ pf_start,
+                                                     const int* __restrict__ pf_edges, const int* __restrict__ pf_col,
+                                                     PairItem* __restrict__ items, int cap, int* __restrict__ pair_count) {
+  if (blockIdx.x == 0)
+    finish_block(n_partial, partial, nP, nL, nullptr, bp, bl, Hpp, Hll, 0.0, nullptr, 0, 1, rec, lambda_init, lambda0_out);
+  else
+    build_items_block((int)blockIdx.x - 1, nP, nL, lm_mask, pf_start, pf_edges, pf_col, items, cap, pair_count);
+}
 
 }  // namespace
 
@@ -1734,6 +1847,7 @@ struct lba_handle {
   int prof_on = 0;
   hipEvent_t prof_ev[2] = {nullptr, nullptr};
   double prof_sum_ms = 0; long long prof_n = 0; int prof_n_unknowns = 0;
+  long long prof_solves = 0;       // solves since profiling was switched on / reset: every fourth one carries the event pair
   // lba_solve_async: the library-owned "LocalMapping" thread of this handle
   std::thread worker;
   std::mutex mu;
@@ -2159,12 +2273,14 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
 
   int solve_version = -1;          // Schur complement + LDL^T of the NEXT trial already launched (speculatively) at this trial number
   bool prof_pending = false;       // an event pair brackets one LDL^T launch of this call
+  const bool prof_this_solve = h->prof_on && (h->prof_solves++ & 3) == 0;
   auto launch_solve = [&](int set_, double lam_, const double* lamp_) -> int {
     if (nP > 0) {
       hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                          EBs[set_], Hlls[set_], bls[set_], Hpps[set_], bps[set_], lam_, h->d_S.p, h->d_bs.p, lamp_, item_cap,
                          dev_items ? h->d_pair_count.p : (const int*)nullptr, use_mfma ? h->d_St.p : (double*)nullptr);
-      const bool bracket = h->prof_on && !prof_pending;
+      // (two event records and an elapsed-time query cost the solve ~8 us: one solve in four is enough for an average)
+      const bool bracket = h->prof_on && !prof_pending && prof_this_solve;
       if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
       if (use_mfma) {
         ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
@@ -2246,7 +2362,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
         hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, D.pose_col, D.point_col,
                            posesB[cur], pointsB[cur], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
                            Hlls[ls], bls[ls], lambda, posesB[trial], pointsB[trial], bps[ls], h->d_scale_partial.p, lam_p);
-        bool speculated = false;
+        bool speculated = false, fused_export = false;
         if (NE > 0) {
           // speculate on acceptance: linearise the trial state into the other set while the host waits for the verdict
           // (not after the very last iteration that can run)
@@ -2270,7 +2386,19 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
               solve_version = version;
             }
           } else {
-            launch_errors(trial, 1);
+            // the last evaluation that can run in the last round goes together with the (speculative) export of its state
+            fused_export = !may_continue && last_round && (it + 1 >= iterations || nBad >= 2) && !no_spec && !lambda_on_device &&
+                           !getenv("ORBG_NO_FUSE") && !getenv("ORBG_NO_EXPORT_FUSE");
+            if (fused_export) {
+              const int n_thr = std::max(std::max(NE, NP), 3 * NX);
+              hipLaunchKernelGGL(k_errors_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, n_blocks_e, NE, D.edges, posesB[trial],
+                                 pointsB[trial], cam, hb, h->d_err.p, h->d_chi2.p, h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p,
+                                 n_blocks_u, h->d_ok.p, h->rec.d, ++h->rec_seq, NP, NX, h->dl_h.d + d_flags_o,
+                                 r->edge_chi2 ? reinterpret_cast<double*>(h->dl_h.d + d_chi_o) : (double*)nullptr,
+                                 reinterpret_cast<PoseQ*>(h->dl_h.d + d_poses_o), reinterpret_cast<double*>(h->dl_h.d + d_points_o));
+            } else {
+              launch_errors(trial, 1);
+            }
             if (may_continue) { launch_linearise(trial, ls ^ 1); speculated = true; }
           }
           const bool round_may_end = it + 1 >= iterations || nBad >= 2;
@@ -2282,7 +2410,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
           }
           if (last_round && round_may_end && !no_spec && !lambda_on_device) {
             // ... or, in the last round, the export of the trial state (dropped if the trial is rejected or the round goes on)
-            launch_export(trial);
+            if (!fused_export) launch_export(trial);
             if ((rc2 = h->sig.post(st))) return rc2;
             exp_version = version; exp_buf = trial;
           }
@@ -2341,7 +2469,27 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   };
 
   // first residuals + linearisation are launched before the host has finished the structure
-  if (!terminate()) {
+  const int n_zero = n + 3 * nL;
+  // first iteration in two launches (k_errlin_prep, k_finish_items) where the observation lists are sorted on the device
+  const bool first2 = dev_lists && NE > 0 && nL > 0 && !getenv("ORBG_NO_FUSE") && !getenv("ORBG_NO_FIRST2") && !terminate();
+  if (first2) {
+    const int set = ls ^ 1;
+    const int n_blocks_l = (nL + 255) / 256, n_err = nP + n_blocks_e + n_blocks_l, nsb = (nL + 255) / 256;
+    hipLaunchKernelGGL(k_errlin_prep, dim3(n_err + nsb + kPrep256Pad + kPrep256Zero), dim3(256), 0, st, n_err, nsb,
+                       const_cast<int*>(D.pf_edges), const_cast<int*>(D.pf_col), D.pf_start,
+                       reinterpret_cast<unsigned long long*>(h->up_d.p + o_lm_mask), n, use_mfma ? h->d_St.p : (double*)nullptr,
+                       h->d_x.p, n_zero,
+                       nP, NE, D.edges, posesB[cur], pointsB[cur], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set],
+                       D.ps_start, D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, 0,
+                       (const int*)nullptr, h->rec.d, h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
+                       LmIn{0.0, 0.0, (const double*)nullptr, (const double*)nullptr, (double*)nullptr});
+    hipLaunchKernelGGL(k_finish_items, dim3(1 + n_pairs_all), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, bps[set], bls[set],
+                       Hpps[set], Hlls[set], h->rec.d, p->lambda_init, h->d_lambda0.p,
+                       reinterpret_cast<const unsigned long long*>(h->up_d.p + o_lm_mask), D.pf_start, D.pf_edges, D.pf_col,
+                       h->d_items_dev.p, item_cap, h->d_pair_count.p);
+    ORBG_HIP(hipGetLastError());
+    err_valid = true; spec_ready = true; fin_version = version;
+  } else if (!terminate()) {
     if (NE > 0 && !getenv("ORBG_NO_FUSE")) {
       // residuals + linearisation of the initial estimate in the fused kernel of the later trials (its record is not waited
       // for: it carries the sequence number the host has already seen)
@@ -2368,8 +2516,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   }
   // not needed before the first Schur complement: the zeroed step vector and the padding / zeros of the bordered tile image
   // (they depend on n only, k_schur never touches them -- once per call) go behind the first linearisation
-  const int n_zero = n + 3 * nL;
-  if (dev_lists) {
+  if (first2) {
+    // (done by k_errlin_prep)
+  } else if (dev_lists) {
     // ... in one launch with the per-landmark lists (k_prep)
     const int nsb = (nL + kSortPfThreads - 1) / kSortPfThreads;
     hipLaunchKernelGGL(k_prep, dim3(nsb + 32 + 8), dim3(kSortPfThreads), 0, st, nsb, nL, D.pf_start, const_cast<int*>(D.pf_edges),
@@ -2421,7 +2570,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
     off_b = o_pair_start;
     if (!dev_lists && (rc = upload_arena(h, off_a, off_b, st, blit))) return rc;      // (dev_lists: k_schur derives the pair from its index)
-    if (nL > 0)
+    if (nL > 0 && !first2)
       hipLaunchKernelGGL(k_build_items, dim3(n_pairs_all), dim3(256), 0, st, nP, nL,
                          reinterpret_cast<const unsigned long long*>(h->up_d.p + o_lm_mask), D.pf_start, D.pf_edges, D.pf_col,
                          h->d_items_dev.p, item_cap, h->d_pair_count.p);
@@ -2523,7 +2672,7 @@ extern "C" int lba_set_profiling(lba_handle* h, int on, int reset) {
   if (rc) return rc;
   if (on && !h->prof_ev[0]) { ORBG_HIP(hipEventCreate(&h->prof_ev[0])); ORBG_HIP(hipEventCreate(&h->prof_ev[1])); }
   h->prof_on = on;
-  if (reset) { h->prof_sum_ms = 0; h->prof_n = 0; }
+  if (reset) { h->prof_sum_ms = 0; h->prof_n = 0; h->prof_solves = 0; }
   return ORBG_OK;
 }
 

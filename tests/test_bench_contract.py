@@ -44,7 +44,7 @@ def test_bench_line_has_the_contract_fields():
     for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "bracketed_launches"):
         assert key in rf, key
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
-    assert rf["bracketed_launches"] >= 4 and 0.002 < rf["avg_launch_ms"] < 1.0
+    assert rf["bracketed_launches"] >= 2 and 0.002 < rf["avg_launch_ms"] < 1.0      # (one solve in four carries the event pair)
     cb = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample", "build", "host_cpu"):
         assert key in cb, key
