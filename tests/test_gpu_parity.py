@@ -485,7 +485,8 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
         assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), (nf, env)
 
 
-@pytest.mark.parametrize("env", [{"ORBG_HOST_LISTS": "1"}, {"ORBG_LBA_BLIT": "1"}, {"ORBG_HOST_ITEMS": "1"}, {"ORBG_NO_FUSE": "1"}])
+@pytest.mark.parametrize("env", [{"ORBG_HOST_LISTS": "1"}, {"ORBG_LBA_BLIT": "1"}, {"ORBG_HOST_ITEMS": "1"}, {"ORBG_NO_FUSE": "1"},
+                                 {"ORBG_NO_FIRST2": "1"}, {"ORBG_NO_EXPORT_FUSE": "1"}])
 def test_lba_start_up_variants_agree_with_the_oracle(env, monkeypatch):
     """The start of a solve has device-side and host-side forms (per-landmark observation lists sorted by k_prep or by the host,
     uploads through k_upload16 or the runtime's copies, pair items built on the device or on the host, the initial estimate
@@ -493,7 +494,7 @@ def test_lba_start_up_variants_agree_with_the_oracle(env, monkeypatch):
     prob = synth.make_lba_problem(n_free=12, n_fixed=4, n_points=700, mono_frac=0.15, seed=4242)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
     o = ob.lba_solve(p)
-    for key in ("ORBG_HOST_LISTS", "ORBG_LBA_BLIT", "ORBG_HOST_ITEMS", "ORBG_NO_FUSE"):
+    for key in ("ORBG_HOST_LISTS", "ORBG_LBA_BLIT", "ORBG_HOST_ITEMS", "ORBG_NO_FUSE", "ORBG_NO_FIRST2", "ORBG_NO_EXPORT_FUSE"):
         monkeypatch.delenv(key, raising=False)
     base = api.Optimizer().LocalBundleAdjustment(p)
     for key, val in env.items():
