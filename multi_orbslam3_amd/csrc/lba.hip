@@ -2639,11 +2639,15 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const double* rpoints = reinterpret_cast<const double*>(h->dl_h.h + d_points_o);
   const uint8_t* rflags = h->dl_h.h + d_flags_o;
   int n_out = 0;
-  for (int k = 0; k < NE; k++) {
-    const bool depth_pos = rflags[k] & 1, outlier = rflags[k] & 2;
-    if (r->edge_depth_pos) r->edge_depth_pos[k] = depth_pos;
-    if (r->edge_outlier) r->edge_outlier[k] = outlier;
-    n_out += outlier;
+  {
+    // (restrict-qualified locals and no branch in the bodies: the loops vectorise; as one loop with the two tests inside they
+    // cost ~1 ns per edge)
+    const uint8_t* __restrict__ rf = rflags;
+    uint8_t* __restrict__ odp = reinterpret_cast<uint8_t*>(r->edge_depth_pos);
+    uint8_t* __restrict__ oout = reinterpret_cast<uint8_t*>(r->edge_outlier);
+    if (odp) for (int k = 0; k < NE; k++) odp[k] = rf[k] & 1;
+    if (oout) for (int k = 0; k < NE; k++) oout[k] = (rf[k] >> 1) & 1;
+    for (int k = 0; k < NE; k++) n_out += (rf[k] >> 1) & 1;
   }
   if (r->edge_chi2 && NE > 0) memcpy(r->edge_chi2, h->dl_h.h + d_chi_o, 8 * (size_t)NE);
   r->n_outliers = n_out;
