@@ -20,5 +20,5 @@ for k, v in sorted(gaps.items(), key=lambda kv: -sum(kv[1])):
     if len(v) > 5:
         print("%-22s -> %-22s n=%4d avg gap %6.2f us  total %8.1f us" % (k[0], k[1], len(v), sum(v) / len(v), sum(v)))
         tot += sum(v)
-n_solves = sum(1 for k in lba if k[2].startswith('k_export'))
+n_solves = sum(1 for k in lba if k[2].startswith('k_export') or k[2].startswith('k_errors_export'))
 print("solves %d, gap time per solve %.1f us, kernel time per solve %.1f us" % (n_solves, tot / max(n_solves, 1), sum(k[1] - k[0] for k in lba) / 1e3 / max(n_solves, 1)))
