@@ -924,12 +924,12 @@ __device__ __forceinline__ void build_items_block(int pr, int nP, int nL, const 
       const int b0 = pf_start[l];
       const int ea = pf_edges[b0 + __popcll(m & ((1ull << i1) - 1ull))];
       const int eb = pf_edges[b0 + __popcll(m & ((1ull << i2) - 1ull))];
-      out[pos] = PairItem{ea, eb, l};
+      if (pos < cap) out[pos] = PairItem{ea, eb, l};        // (cap = edges of the busiest pose: cannot overflow unless a pose observes a landmark twice)
     }
     running += total;
     __syncthreads();
   }
-  if (tid == 0) pair_count[pr] = running;
+  if (tid == 0) pair_count[pr] = min(running, cap);
 }
 __global__ __launch_bounds__(256) void k_build_items(int nP, int nL, const unsigned long long* __restrict__ lm_mask,
                                                     const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
@@ -2013,7 +2013,12 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const size_t o_pt_edges = take(4 * (size_t)NE), o_ps_start = take(4 * ((size_t)nP + 1)), o_ps_edges = take(4 * (size_t)n_free_edges);
   const size_t o_pf_start = take(4 * ((size_t)nL + 1)), o_pf_edges = take(4 * (size_t)n_free_edges), o_pf_col = take(4 * (size_t)n_free_edges);
   // pair items on the device when the pose masks fit one word and the fixed-capacity segments stay small
-  const bool dev_items = nP >= 1 && nP <= 64 && (size_t)n_pairs_all * (size_t)std::max(nL, 1) * sizeof(PairItem) <= ((size_t)32 << 20) &&
+  // (a pair's items are landmarks both poses observe: never more than the edges of either pose -- a far smaller segment than
+  // one entry per landmark, which kept the 50-keyframe window of C4 on the host path)
+  int max_pose_edges = 1;
+  for (int i = 0; i < nP; i++) max_pose_edges = std::max(max_pose_edges, ps_cnt[i]);
+  const int item_cap = std::min(std::max(nL, 1), max_pose_edges);
+  const bool dev_items = nP >= 1 && nP <= 64 && (size_t)n_pairs_all * (size_t)item_cap * sizeof(PairItem) <= ((size_t)64 << 20) &&
                          !getenv("ORBG_HOST_ITEMS");
   const size_t o_lm_mask = take(8 * (size_t)nL);
   const size_t o_pair_i1 = take(4 * (size_t)n_pairs_all), o_pair_i2 = take(4 * (size_t)n_pairs_all), o_pair_start = take(4 * ((size_t)n_pairs_all + 1));
@@ -2090,7 +2095,6 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     D.pair_start = dev_items ? (const int*)nullptr : reinterpret_cast<const int*>(B + o_pair_start);
     D.items = dev_items ? (const PairItem*)nullptr : reinterpret_cast<const PairItem*>(B + o_items);
   }
-  const int item_cap = std::max(nL, 1);
   if (dev_items) {
     if ((rc = h->d_items_dev.reserve((size_t)n_pairs_all * item_cap)) || (rc = h->d_pair_count.reserve(std::max(n_pairs_all, 1)))) return rc;
     D.items = h->d_items_dev.p;
