@@ -801,7 +801,9 @@ constexpr int kSchurThreads = 256;
 // handful of entries, at most one per free pose) is sorted in LDS.  Replaces ~25 us of host loops per solve during which the
 // device sat idle between the first linearisation and the first Schur complement.
 constexpr int kSortPfThreads = 64, kSortPfCap = 64;
-template <int NT, int CAP>
+// BY_EDGE: the input list is in no particular order (atomic fill): order by (column, edge index); otherwise the input is
+// in edge order and a stable sort by column gives the same
+template <int NT, int CAP, bool BY_EDGE = false>
 __device__ __forceinline__ void sort_pf_block(int bid, int nL, const int* __restrict__ pf_start, int* __restrict__ pf_edges,
                                               int* __restrict__ pf_col, unsigned long long* __restrict__ lm_mask,
                                               const lba_edge* __restrict__ edges, const int* __restrict__ pose_col) {
@@ -819,7 +821,7 @@ __device__ __forceinline__ void sort_pf_block(int bid, int nL, const int* __rest
     for (int a2 = 1; a2 < cnt; a2++) {
       const int e = se[a2], key = sc[a2];
       int b2 = a2 - 1;
-      while (b2 >= 0 && sc[b2] > key) { se[b2 + 1] = se[b2]; sc[b2 + 1] = sc[b2]; b2--; }
+      while (b2 >= 0 && (sc[b2] > key || (BY_EDGE && sc[b2] == key && se[b2] > e))) { se[b2 + 1] = se[b2]; sc[b2 + 1] = sc[b2]; b2--; }
       se[b2 + 1] = e; sc[b2 + 1] = key;
     }
     for (int j = 0; j < cnt; j++) { pf_edges[b0 + j] = se[j]; pf_col[b0 + j] = sc[j]; m |= 1ull << sc[j]; }
@@ -827,7 +829,8 @@ __device__ __forceinline__ void sort_pf_block(int bid, int nL, const int* __rest
     for (int a2 = b0 + 1; a2 < b0 + cnt; a2++) {
       const int e = pf_edges[a2], key = pose_col[edges[e].pose];
       int b2 = a2 - 1;
-      while (b2 >= b0 && pose_col[edges[pf_edges[b2]].pose] > key) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
+      while (b2 >= b0 && (pose_col[edges[pf_edges[b2]].pose] > key ||
+                          (BY_EDGE && pose_col[edges[pf_edges[b2]].pose] == key && pf_edges[b2] > e))) { pf_edges[b2 + 1] = pf_edges[b2]; b2--; }
       pf_edges[b2 + 1] = e;
     }
     for (int j = b0; j < b0 + cnt; j++) { const int c = pose_col[edges[pf_edges[j]].pose]; pf_col[j] = c; m |= 1ull << c; }
@@ -835,10 +838,106 @@ __device__ __forceinline__ void sort_pf_block(int bid, int nL, const int* __rest
   lm_mask[l] = m;
 }
 
+// CSR lists on the device (edges per active point, per free pose, per active point restricted to free poses).  The host
+// counts degrees while it copies the edges, so the list STARTS are known; the fill is one atomic cursor per list (k_csr_fill),
+// and because the kernels sum over a list in list order -- and that order has to be the edge order of the oracle -- every
+// list is then sorted by edge index (k_csr_sort: a point's handful of entries by its thread in LDS, a pose's few hundred to
+// few thousand by a workgroup's bitonic network).  Replaces a host pass of 29 us (C2) / 84 us (C4) during which the device
+// had nothing to do.
+__global__ __launch_bounds__(256) void k_csr_fill(int n_edges, const lba_edge* __restrict__ edges, const int* __restrict__ pose_col,
+                                                 const int* __restrict__ point_col, int* __restrict__ cur_pt, int* __restrict__ cur_ps,
+                                                 int* __restrict__ cur_pf, int* __restrict__ pt_edges, int* __restrict__ ps_edges,
+                                                 int* __restrict__ pf_edges) {
+  // (the pose cursors are few and hot: a workgroup first ranks its edges per pose in LDS and takes one range per pose)
+  __shared__ int s_cnt[64], s_base[64];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int lc = -1, pc = -1, my = 0;
+  if (k < n_edges) {
+    const lba_edge e = edges[k];
+    lc = point_col[e.point]; pc = pose_col[e.pose];
+    pt_edges[atomicAdd(&cur_pt[lc], 1)] = k;
+    if (pc >= 0) { pf_edges[atomicAdd(&cur_pf[lc], 1)] = k; my = atomicAdd(&s_cnt[pc], 1); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&cur_ps[threadIdx.x], s_cnt[threadIdx.x]);
+  __syncthreads();
+  if (pc >= 0) ps_edges[s_base[pc] + my] = k;
+}
+constexpr int kPrep256Cap = 16, kPrep256Pad = 8, kPrep256Zero = 4;
+constexpr int kCsrPoseCap = 4096, kCsrPtCap = 16;
+__global__ __launch_bounds__(256) void k_csr_sort(int nP, int nL, const int* __restrict__ ps_start, int* __restrict__ ps_edges,
+                                                 const int* __restrict__ pt_start, int* __restrict__ pt_edges,
+                                                 const int* __restrict__ pf_start, int* __restrict__ pf_edges, int* __restrict__ pf_col,
+                                                 unsigned long long* __restrict__ lm_mask, const lba_edge* __restrict__ edges,
+                                                 const int* __restrict__ pose_col, int n_unknowns, double* __restrict__ St,
+                                                 double* __restrict__ xzero, int n_zero) {
+  __shared__ int s_pose[kCsrPoseCap];
+  __shared__ int s_pt[256][kCsrPtCap + 1];
+  int bid = (int)blockIdx.x;
+  const int tid = threadIdx.x;
+  if (bid < nP) {
+    // one free pose: its edge list ascending (bitonic network over the next power of two, padded with INT_MAX)
+    const int b0 = ps_start[bid], cnt = ps_start[bid + 1] - b0;
+    int m = 1;
+    while (m < cnt) m <<= 1;
+    for (int i = tid; i < m; i += 256) s_pose[i] = i < cnt ? ps_edges[b0 + i] : 0x7FFFFFFF;
+    __syncthreads();
+    for (int k2 = 2; k2 <= m; k2 <<= 1)
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < m; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const int a = s_pose[i], c = s_pose[ixj];
+            const bool up = (i & k2) == 0;
+            if ((a > c) == up) { s_pose[i] = c; s_pose[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = tid; i < cnt; i += 256) ps_edges[b0 + i] = s_pose[i];
+    return;
+  }
+  bid -= nP;
+  const int n_pt_blocks = (nL + 255) / 256;
+  if (bid < n_pt_blocks) {
+    const int l = bid * 256 + tid;
+    if (l < nL) {
+      // the point's edges ascending
+      const int b0 = pt_start[l], cnt = pt_start[l + 1] - b0;
+      if (cnt <= kCsrPtCap) {
+        int* const se = s_pt[tid];
+        for (int j = 0; j < cnt; j++) se[j] = pt_edges[b0 + j];
+        for (int a2 = 1; a2 < cnt; a2++) {
+          const int e = se[a2];
+          int b2 = a2 - 1;
+          while (b2 >= 0 && se[b2] > e) { se[b2 + 1] = se[b2]; b2--; }
+          se[b2 + 1] = e;
+        }
+        for (int j = 0; j < cnt; j++) pt_edges[b0 + j] = se[j];
+      } else {
+        for (int a2 = b0 + 1; a2 < b0 + cnt; a2++) {
+          const int e = pt_edges[a2];
+          int b2 = a2 - 1;
+          while (b2 >= b0 && pt_edges[b2] > e) { pt_edges[b2 + 1] = pt_edges[b2]; b2--; }
+          pt_edges[b2 + 1] = e;
+        }
+      }
+    }
+    // its free observations by (pose column, edge index), their columns and the pose mask
+    sort_pf_block<256, kCsrPtCap, true>(bid, nL, pf_start, pf_edges, pf_col, lm_mask, edges, pose_col);
+    return;
+  }
+  bid -= n_pt_blocks;
+  if (bid < kPrep256Pad) { if (St) ldltm::image_pad_range(n_unknowns, St, bid * 256 + tid, kPrep256Pad * 256); return; }
+  bid -= kPrep256Pad;
+  for (int i = bid * 256 + tid; i < n_zero; i += kPrep256Zero * 256) xzero[i] = 0.0;
+}
+
 // First launch of a solve: the linearisation of the initial estimate and, in further workgroups, everything else that needs
 // only the first upload -- the per-landmark observation lists (256 landmarks per workgroup, lists of up to 16 entries sorted
 // in LDS), the padding of the tile image, the zeroed step vector.  (Two launches: 12 + 6.6 us one after the other.)
-constexpr int kPrep256Cap = 16, kPrep256Pad = 8, kPrep256Zero = 4;
 __global__ __launch_bounds__(256) void k_errlin_prep(int n_errlin_blocks, int n_sort_blocks, int* __restrict__ pf_edges_w, int* __restrict__ pf_col_w,
                                                     const int* __restrict__ pf_start, unsigned long long* __restrict__ lm_mask,
                                                     int n_unknowns, double* __restrict__ St, double* __restrict__ xzero, int n_zero,
@@ -2009,9 +2108,12 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 63) & ~(size_t)63; return o; };
   const size_t o_poses = take(sizeof(PoseQ) * (size_t)NP), o_points = take(24 * (size_t)NX);
+  // (what the host fills first; then the lists the device may fill itself: see off_a below)
   const size_t o_pose_col = take(4 * (size_t)NP), o_point_col = take(4 * (size_t)NX), o_pt_start = take(4 * ((size_t)nL + 1));
-  const size_t o_pt_edges = take(4 * (size_t)NE), o_ps_start = take(4 * ((size_t)nP + 1)), o_ps_edges = take(4 * (size_t)n_free_edges);
-  const size_t o_pf_start = take(4 * ((size_t)nL + 1)), o_pf_edges = take(4 * (size_t)n_free_edges), o_pf_col = take(4 * (size_t)n_free_edges);
+  const size_t o_ps_start = take(4 * ((size_t)nP + 1)), o_pf_start = take(4 * ((size_t)nL + 1));
+  const size_t o_cur_pt = take(4 * (size_t)nL), o_cur_ps = take(4 * (size_t)nP), o_cur_pf = take(4 * (size_t)nL);   // fill cursors (k_csr_fill)
+  const size_t o_pt_edges = take(4 * (size_t)NE), o_ps_edges = take(4 * (size_t)n_free_edges);
+  const size_t o_pf_edges = take(4 * (size_t)n_free_edges), o_pf_col = take(4 * (size_t)n_free_edges);
   // pair items on the device when the pose masks fit one word and the fixed-capacity segments stay small
   // (a pair's items are landmarks both poses observe: never more than the edges of either pose -- a far smaller segment than
   // one entry per landmark, which kept the 50-keyframe window of C4 on the host path)
@@ -2020,6 +2122,13 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const int item_cap = std::min(std::max(nL, 1), max_pose_edges);
   const bool dev_items = nP >= 1 && nP <= 64 && (size_t)n_pairs_all * (size_t)item_cap * sizeof(PairItem) <= ((size_t)64 << 20) &&
                          !getenv("ORBG_HOST_ITEMS");
+  // (the lists of free observations per landmark, still in edge order, go along when the device sorts them: k_prep / k_errlin_prep)
+  const bool dev_lists = dev_items && nP >= 1 && ldltm::supports(6 * nP) && !getenv("ORBG_LDLT_VALU") && !getenv("ORBG_HOST_LISTS");
+  // ... and the device fills the lists itself (k_csr_fill / k_csr_sort) when a pose's list fits the sorting workgroup
+  // (measured: a wash at C2 -- 7.7 + 15.2 us of kernels for a 29 us host pass -- and -20 us at C4: used from 16 k edges on;
+  // ORBG_DEV_CSR=1 forces it, ORBG_HOST_CSR=1 forbids it)
+  const bool dev_csr = dev_lists && NE > 0 && nL > 0 && max_pose_edges <= kCsrPoseCap && !getenv("ORBG_NO_FUSE") && !getenv("ORBG_NO_FIRST2") &&
+                       !getenv("ORBG_HOST_CSR") && (NE >= 16384 || getenv("ORBG_DEV_CSR"));
   const size_t o_lm_mask = take(8 * (size_t)nL);
   const size_t o_pair_i1 = take(4 * (size_t)n_pairs_all), o_pair_i2 = take(4 * (size_t)n_pairs_all), o_pair_start = take(4 * ((size_t)n_pairs_all + 1));
   const size_t o_items = take(dev_items ? 0 : sizeof(PairItem) * n_items);
@@ -2045,7 +2154,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   pt_start[0] = 0; pf_start[0] = 0; ps_start[0] = 0;
   for (int i = 0; i < nL; i++) { pt_start[i + 1] = pt_start[i] + pt_cnt[i]; pf_start[i + 1] = pf_start[i] + pf_deg[i]; }
   for (int i = 0; i < nP; i++) ps_start[i + 1] = ps_start[i] + ps_cnt[i];
-  {
+  if (dev_csr) {
+    memcpy(H + o_cur_pt, pt_start, 4 * (size_t)nL); memcpy(H + o_cur_ps, ps_start, 4 * (size_t)nP); memcpy(H + o_cur_pf, pf_start, 4 * (size_t)nL);
+  } else {
     std::vector<int>& f1 = h->s_f1; std::vector<int>& f2 = h->s_f2; std::vector<int>& f3 = h->s_f3;
     f1.assign(pt_start, pt_start + nL); f2.assign(ps_start, ps_start + nP); f3.assign(pf_start, pf_start + nL);
     for (int k = 0; k < NE; k++) {
@@ -2072,9 +2183,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const double t_b = now_s();
   // part A of the arena (edges, state, the CSR lists the error / linearisation kernels read) goes up now; the pair items
   // the Schur kernel needs are built while the device already computes the first residuals and Jacobians
-  // (the lists of free observations per landmark, still in edge order, go along when the device sorts them: k_sort_pf)
-  const bool dev_lists = dev_items && nP >= 1 && ldltm::supports(6 * nP) && !getenv("ORBG_LDLT_VALU") && !getenv("ORBG_HOST_LISTS");
-  const size_t off_a = dev_lists ? o_pf_col : o_pf_start;
+  // part A: host-filled arrays; + the point / pose lists when the host fills them; + the unsorted free-observation lists when
+  // the device only sorts
+  const size_t off_a = dev_csr ? o_pt_edges : dev_lists ? o_pf_col : o_pf_edges;
   const bool blit = getenv("ORBG_LBA_BLIT") != nullptr;       // A/B switch: the runtime's copies
   if ((rc = upload_arena(h, 0, off_a, st, blit))) return rc;
   struct {
@@ -2476,7 +2587,29 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   const int n_zero = n + 3 * nL;
   // first iteration in two launches (k_errlin_prep, k_finish_items) where the observation lists are sorted on the device
   const bool first2 = dev_lists && NE > 0 && nL > 0 && !getenv("ORBG_NO_FUSE") && !getenv("ORBG_NO_FIRST2") && !terminate();
-  if (first2) {
+  if (first2 && dev_csr) {
+    const int set = ls ^ 1;
+    const int n_blocks_l = (nL + 255) / 256;
+    uint8_t* const B = h->up_d.p;
+    hipLaunchKernelGGL(k_csr_fill, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, D.pose_col, D.point_col, reinterpret_cast<int*>(B + o_cur_pt),
+                       reinterpret_cast<int*>(B + o_cur_ps), reinterpret_cast<int*>(B + o_cur_pf), const_cast<int*>(D.pt_edges),
+                       const_cast<int*>(D.ps_edges), const_cast<int*>(D.pf_edges));
+    hipLaunchKernelGGL(k_csr_sort, dim3(nP + n_blocks_l + kPrep256Pad + kPrep256Zero), dim3(256), 0, st, nP, nL, D.ps_start,
+                       const_cast<int*>(D.ps_edges), D.pt_start, const_cast<int*>(D.pt_edges), D.pf_start, const_cast<int*>(D.pf_edges),
+                       const_cast<int*>(D.pf_col), reinterpret_cast<unsigned long long*>(B + o_lm_mask), D.edges, D.pose_col, n,
+                       use_mfma ? h->d_St.p : (double*)nullptr, h->d_x.p, n_zero);
+    hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
+                       pointsB[cur], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
+                       D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, 0, (const int*)nullptr,
+                       h->rec.d, h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
+                       LmIn{0.0, 0.0, (const double*)nullptr, (const double*)nullptr, (double*)nullptr});
+    hipLaunchKernelGGL(k_finish_items, dim3(1 + n_pairs_all), dim3(256), 0, st, n_blocks_e, h->d_partial.p, nP, nL, bps[set], bls[set],
+                       Hpps[set], Hlls[set], h->rec.d, p->lambda_init, h->d_lambda0.p,
+                       reinterpret_cast<const unsigned long long*>(B + o_lm_mask), D.pf_start, D.pf_edges, D.pf_col,
+                       h->d_items_dev.p, item_cap, h->d_pair_count.p);
+    ORBG_HIP(hipGetLastError());
+    err_valid = true; spec_ready = true; fin_version = version;
+  } else if (first2) {
     const int set = ls ^ 1;
     const int n_blocks_l = (nL + 255) / 256, n_err = nP + n_blocks_e + n_blocks_l, nsb = (nL + 255) / 256;
     hipLaunchKernelGGL(k_errlin_prep, dim3(n_err + nsb + kPrep256Pad + kPrep256Zero), dim3(256), 0, st, n_err, nsb,

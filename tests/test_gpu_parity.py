@@ -486,15 +486,16 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"ORBG_HOST_LISTS": "1"}, {"ORBG_LBA_BLIT": "1"}, {"ORBG_HOST_ITEMS": "1"}, {"ORBG_NO_FUSE": "1"},
-                                 {"ORBG_NO_FIRST2": "1"}, {"ORBG_NO_EXPORT_FUSE": "1"}])
+                                 {"ORBG_NO_FIRST2": "1"}, {"ORBG_NO_EXPORT_FUSE": "1"}, {"ORBG_DEV_CSR": "1"}])
 def test_lba_start_up_variants_agree_with_the_oracle(env, monkeypatch):
     """The start of a solve has device-side and host-side forms (per-landmark observation lists sorted by k_prep or by the host,
-    uploads through k_upload16 or the runtime's copies, pair items built on the device or on the host, the initial estimate
+    uploads through k_upload16 or the runtime's copies, pair items built on the device or on the host, the CSR lists filled by the
+    host or by k_csr_fill / k_csr_sort (used from 16 k edges on, forced here), the initial estimate
     through the fused k_errlin or through k_errors + k_lin_all + k_reduce_points): every form must give the oracle's solve."""
     prob = synth.make_lba_problem(n_free=12, n_fixed=4, n_points=700, mono_frac=0.15, seed=4242)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
     o = ob.lba_solve(p)
-    for key in ("ORBG_HOST_LISTS", "ORBG_LBA_BLIT", "ORBG_HOST_ITEMS", "ORBG_NO_FUSE", "ORBG_NO_FIRST2", "ORBG_NO_EXPORT_FUSE"):
+    for key in ("ORBG_HOST_LISTS", "ORBG_LBA_BLIT", "ORBG_HOST_ITEMS", "ORBG_NO_FUSE", "ORBG_NO_FIRST2", "ORBG_NO_EXPORT_FUSE", "ORBG_DEV_CSR"):
         monkeypatch.delenv(key, raising=False)
     base = api.Optimizer().LocalBundleAdjustment(p)
     for key, val in env.items():
