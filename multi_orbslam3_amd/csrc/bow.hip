@@ -172,11 +172,10 @@ __global__ __launch_bounds__(1024) void db_select_kernel(int n_kfs, const int* _
   int mx = 0;
   for (int w = 0; w < 16; w++) mx = max(mx, s_max[w]);
   const int minw = (int)(mx * 0.8f);
-  int cnt = 0;
   for (int i = threadIdx.x; i < n_kfs; i += 1024) {
     const bool sh = !connected[i] && words[i] > 0;
     const bool se = sh && words[i] > minw;
-    shares[i] = sh; sel[i] = se; cnt += se;
+    shares[i] = sh; sel[i] = se;
   }
   if (threadIdx.x == 0) { out2[0] = mx; out2[1] = minw; }
 }

@@ -1542,6 +1542,7 @@ struct orbx_handle {
   int prof_kernel = 0;              // which kernel of the chain the level-1 event pair brackets: ORBX_PROF_*
   struct CtorGraph* cgraph = nullptr;          // captured kernel chain of the device-resident Frame constructor
 };
+static void delete_pending(struct ExtractPending* p);   // (defined behind the type)
 
 // Owned / needed pixel ranges of every level for the level-0 tiles of one axis (see pyr_tower_kernel).
 // s0[l][d], s1[l][d]: the two source indices (level l-1) the taps of pixel d of level l read.  Returns the largest
@@ -1825,7 +1826,7 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   h->d_selreg.release(); h->h_nkp.release(); h->sig.release();
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
-  delete h->pending;
+  delete_pending(h->pending);
   delete h;
   return ORBG_OK;
 }
@@ -1873,6 +1874,7 @@ struct ExtractPending {
   bool stereo_out = false;
   int n_res[2] = {0, 0};
 };
+static void delete_pending(ExtractPending* p) { delete p; }
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
                          volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin);
 void orbm_internal_set_n(orbm_frame* f, int n);

@@ -1551,7 +1551,6 @@ __global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__
                                                     double* __restrict__ x, int* __restrict__ ok_flag, LdltNz nz, FlowMap map) {
 #pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int nblk = nb * (nb + 1) / 2;
   double* rr_ = sh;                    // 6*nb running rhs (forward)
   double* zz = rr_ + 6 * nb;           // 6*nb z = D^-1 L^-1 b
   // factor: one record of kPanStride doubles per block, COLUMN-major block order (consecutive lanes <-> consecutive
