@@ -73,3 +73,42 @@ def test_generated_jump_tables_are_current():
         assert sum(1 for l in lines if l.startswith("v_mfma")) == 4 * n and sum(1 for l in lines if l.startswith("s_branch")) == n
         lines = gen.get(n)
         assert sum(1 for l in lines if l.startswith("s_branch")) == n
+
+
+def test_big_ldlt_kernel_keeps_the_compiler_out_of_its_tile_registers(tmp_path):
+    """ldltm::k_ldlt_big48 keeps its 48 tiles in a0..a255 and v128..v255, addressed from inline assembly only; hipcc is kept out
+    of them by amdgpu_num_vgpr(128) and clobber lists.  Guard: in the device assembly of lba.hip no instruction OUTSIDE the
+    assembly statements touches an accumulation register or a vector register >= 128, nothing is spilled to scratch, and the
+    kernel's allocation is the whole register file (512)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "lba_dev.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                    "-fhip-fp32-correctly-rounded-divide-sqrt", "--cuda-device-only", "-S", "-o", str(out),
+                    os.path.join(root, "multi_orbslam3_amd", "csrc", "lba.hip")], check=True, stderr=subprocess.DEVNULL, timeout=600)
+    text = out.read_text()
+    m = re.search(r"^(_ZN5ldltm12k_ldlt_big48\w*):", text, re.M)
+    assert m, "kernel not found"
+    name = m.group(1)
+    body = text[m.start():text.index("s_endpgm", m.start())]
+    assert "scratch_" not in body
+    in_asm, bad = False, []
+    for line in body.splitlines():
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        if in_asm:
+            continue
+        code = line.split(";")[0]
+        if "v_accvgpr" in code or re.search(r"\ba\[?\d", code) or any(int(x) >= 128 for x in re.findall(r"\bv\[?(\d+)", code)):
+            bad.append(line.strip())
+    assert not bad, bad[:5]
+    desc = text[text.index(".amdhsa_kernel " + name):]
+    assert re.search(r"\.amdhsa_next_free_vgpr\s+512", desc[:3000]) and re.search(r"\.amdhsa_accum_offset\s+256", desc[:3000])
