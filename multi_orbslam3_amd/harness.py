@@ -45,6 +45,21 @@ def pin_to_gpu_numa_node(device_index):
         return None
 
 
+def _pick_core_pair(cores, slot, n_local):
+    """cores: the physical cores of the node (sets of hardware threads), in order.  The first cores of a node serve
+    interrupts and housekeeping, so agents take consecutive pairs from the upper half.  Two agents must never get the same
+    pair (four spinning threads on two cores): when the node has fewer pairs than the launch has local ranks (all of which
+    may sit on this node) every core is used, and when that is not enough either nothing is pinned."""
+    n_local = max(n_local, slot + 1)
+    half = len(cores) // 2
+    if (len(cores) - half) // 2 < n_local:
+        half = 0
+    if (len(cores) - half) // 2 < n_local:
+        return None
+    base = half + 2 * slot
+    return cores[base], cores[base + 1]
+
+
 def core_pair_for_agent(device_index, slot):
     """Two distinct physical cores (each returned with its SMT siblings) on the GPU's NUMA node for agent number `slot` on
     that node: one for the tracking thread, one for the library's local-BA worker.  Both threads spin on completion words;
@@ -68,14 +83,7 @@ def core_pair_for_agent(device_index, slot):
                 sib = _parse_cpulist(f.read()) & cpus
             seen |= sib
             cores.append(sib)
-        if len(cores) < 2:
-            return None
-        # the first cores of a node serve interrupts and housekeeping: agents take consecutive pairs from the upper half
-        half = len(cores) // 2
-        base = half + 2 * (slot % max((len(cores) - half) // 2, 1))
-        if base + 1 >= len(cores):
-            base = 0
-        return cores[base], cores[base + 1]
+        return _pick_core_pair(cores, slot, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     except Exception:
         return None
 

@@ -116,3 +116,20 @@ def test_cpu_list_parsing_and_pinning_helpers_degrade_without_a_gpu():
     # no GPU / no sysfs topology here: both helpers report "not available" instead of raising
     assert harness.pin_to_gpu_numa_node(0) is None
     assert harness.core_pair_for_agent(0, 0) is None
+
+
+def test_agents_of_one_node_never_share_a_core_pair():
+    from multi_orbslam3_amd import harness
+    for ncores in (2, 3, 8, 16, 17, 64, 96):
+        cores = [{c, c + 128} for c in range(ncores)]
+        for n_local in (1, 2, 4, 8):
+            got = [harness._pick_core_pair(cores, slot, n_local) for slot in range(n_local)]
+            if ncores // 2 < n_local:
+                assert all(g is None for g in got)
+                continue
+            flat = [frozenset(c) for g in got for c in g]
+            assert len(set(flat)) == 2 * n_local                     # all distinct physical cores
+            if (ncores - ncores // 2) // 2 >= n_local:                  # room in the upper half: housekeeping cores stay free
+                assert min(min(c) for c in flat) >= ncores // 2
+    # a single agent on a big node gets the first pair of the upper half
+    assert harness._pick_core_pair([{c} for c in range(64)], 0, 1) == ({32}, {33})
