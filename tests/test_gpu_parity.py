@@ -485,6 +485,22 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
         assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), (nf, env)
 
 
+def test_lba_every_window_size_up_to_50_free_poses():
+    """Default kernel choice at EVERY free-pose count 1..50 (the sizes the test above leaves out included): each count pads the
+    reduced camera system's last tile row differently (6 n mod 16 takes all eight even residues), and the four-wavefront
+    kernel's tile -> register map differs per tile-row count."""
+    for nf in range(1, 51):
+        prob = synth.make_lba_problem(n_free=nf, n_fixed=2, n_points=12 * nf + 40, mono_frac=0.25, seed=7000 + nf)
+        p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+        o = ob.lba_solve(p)
+        g = api.Optimizer().LocalBundleAdjustment(p)
+        assert g.status == o.status and g.iters == o.iters, nf
+        assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4, nf
+        assert np.array_equal(g.edge_outlier, o.edge_outlier), nf
+        tg, to = g.trace_rows(), o.trace_rows()
+        assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]) and np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), nf
+
+
 @pytest.mark.parametrize("env", [{"ORBG_HOST_LISTS": "1"}, {"ORBG_LBA_BLIT": "1"}, {"ORBG_HOST_ITEMS": "1"}, {"ORBG_NO_FUSE": "1"},
                                  {"ORBG_NO_FIRST2": "1"}, {"ORBG_NO_EXPORT_FUSE": "1"}, {"ORBG_DEV_CSR": "1"}])
 def test_lba_start_up_variants_agree_with_the_oracle(env, monkeypatch):
