@@ -54,12 +54,13 @@ enum {
 /* ORBextractor ctor arguments (S/ORBextractor.cc:408-411, values from ORBParameters I/Datatypes.h:43-55)
  * plus the sizes the handle pre-allocates for. */
 typedef struct orbx_config {
-  int32_t n_features;     /* nfeatures   */
+  int32_t n_features;     /* nfeatures, 1 .. 3500 (the reference's settings use 1000 - 2000); more: ORBG_BAD_ARG */
   float   scale_factor;   /* scaleFactor */
   int32_t n_levels;       /* nlevels (<= ORBG_MAX_LEVELS) */
   int32_t ini_th_fast;    /* iniThFAST   */
   int32_t min_th_fast;    /* minThFAST   */
-  int32_t max_width;      /* largest image the handle will be given */
+  int32_t max_width;      /* largest image the handle will be given (<= 4000 x 4000); every pyramid level of an image
+                           * must stay larger than the 19-pixel border (else ORBG_BAD_ARG from the extract call) */
   int32_t max_height;
   int32_t n_cams;         /* 1 = mono, 2 = stereo rig (left = cam 0, right = cam 1) */
   int32_t device;         /* HIP device ordinal (1 agent <-> 1 GPU) */

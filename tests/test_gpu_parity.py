@@ -112,10 +112,52 @@ def test_extractor_deployment_variants(scene, variant):
     assert len(dk) != len(okl) or not np.array_equal(dd, odl)
 
 
+@pytest.mark.parametrize("W,H,nf,kind", [(752, 480, 1200, "scene"), (1241, 376, 2000, "scene"), (323, 241, 500, "scene"),
+                                          (131, 97, 300, "noise"), (70, 70, 100, "noise"), (641, 479, 1000, "blocks"),
+                                          (1000, 333, 777, "blocks"), (320, 240, 3500, "noise")])
+def test_extractor_image_sizes_and_feature_counts_bit_exact(W, H, nf, kind):
+    """Image shapes whose pyramid levels have odd widths / heights and partial 30-pixel cells at the borders (EuRoC 752x480,
+    KITTI 1241x376, shapes that are no multiple of anything), images barely larger than the 2 x 19-pixel border at the top
+    levels, more requested features than the image has corners, three kinds of content -- keypoints and descriptors of every
+    one against the oracle, mono with and without lapping."""
+    rng = np.random.RandomState(W * 1000 + H)
+    if kind == "scene":
+        img = synth.Scene(W, H, tex_size=(max(2 * W, 800), max(2 * H, 600)), px_per_m=100.0).stereo_pair(2)[0]
+    elif kind == "noise":
+        img = rng.randint(0, 256, (H, W)).astype(np.uint8)
+    else:
+        # random rectangles on a ramp: strong isolated corners, large flat areas (cells that fall back to minThFAST or stay empty)
+        img = np.tile((np.arange(W) * 40 // W + 60).astype(np.uint8), (H, 1))
+        for _ in range(60):
+            x0, y0 = rng.randint(0, W - 8), rng.randint(0, H - 8)
+            img[y0:y0 + rng.randint(4, 60), x0:x0 + rng.randint(4, 80)] = rng.randint(0, 256)
+    img = np.ascontiguousarray(img)
+    ex = api.ORBextractor(nf, 1.2, 8, 20, 7, W, H, n_cams=1)
+    oe = ob.Extractor(n_features=nf, max_width=W, max_height=H)
+    for lap in ((0, 0), (0, 1000), (W // 3, 2 * W // 3)):
+        nm, kps, desc = ex(img, lap)
+        rc, okps, odesc, onm = oe.extract(img, lap=lap)
+        _assert_extract_equal((kps, desc), (okps, odesc), "%dx%d %s lap %s" % (W, H, kind, lap))
+        assert nm == onm
+    for l in range(8):
+        assert np.array_equal(ex.level(0, l), oe.level(l)), "pyramid level %d" % l
+
+
 def test_extractor_empty_image():
     ex = api.ORBextractor(100, 1.2, 8, 20, 7, 320, 240)
     nm, kps, desc = ex(None)
     assert nm == -1 and len(kps) == 0
+
+
+def test_extractor_refuses_what_the_header_says_it_refuses():
+    with pytest.raises(capi.OrbGpuError):                   # include/orbgpu.h: n_features 1 .. 3500
+        api.ORBextractor(5000, 1.2, 8, 20, 7, 320, 240)
+    with pytest.raises(capi.OrbGpuError):
+        api.ORBextractor(1000, 1.0, 8, 20, 7, 320, 240)     # scale factor must exceed 1
+    ex = api.ORBextractor(100, 1.2, 8, 20, 7, 320, 240)
+    with pytest.raises(capi.OrbGpuError):                   # the top level of a 64 x 64 image is 18 pixels: inside the border
+        ex(np.zeros((64, 64), np.uint8), (0, 0))
+    assert len(ex(np.zeros((240, 320), np.uint8), (0, 0))[1]) == 0      # ... and the handle is still usable
 
 
 def test_extractor_stereo_batched_and_size_change(scene, small_scene):
