@@ -227,6 +227,28 @@ def test_fused_stereo_frame_constructor(scene):
         assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
 
 
+@pytest.mark.parametrize("W,H,nf", [(752, 480, 1200), (1241, 376, 2000), (323, 241, 600)])
+def test_fused_stereo_frame_constructor_image_shapes(W, H, nf):
+    """Frame::Frame(stereo) in one submission on EuRoC / KITTI / odd image shapes: both feature sets, the stereo matches
+    (row bands and sliding windows clipped by a width that is no multiple of anything) and the grid against the oracle, twice
+    on one handle."""
+    sc = synth.Scene(W, H, tex_size=(max(2 * W, 800), max(2 * H, 600)), px_per_m=100.0)
+    ex = api.ORBextractor(nf, 1.2, 8, 20, 7, W, H, n_cams=2)
+    F = api.Frame()
+    for k in (1, 6):
+        fr = helpers.oracle_stereo_frame(sc, k, n_features=nf)
+        fv, keep = helpers.frame_view_of(sc, fr)
+        n, nr, kl, dl, ur, dp = ex.frame_stereo(F, fv, fr["L"], fr["R"], float(sc.cam["bf"]), float(sc.cam["b"]), download=True)
+        assert n == len(fr["kps"]) and nr == len(fr["kps_r"]), (W, H, k)
+        assert np.array_equal(kl, fr["kps"]) and np.array_equal(dl, fr["desc"]), (W, H, k)
+        assert np.array_equal(ur.view(np.uint32), fr["uright"].view(np.uint32)), (W, H, k)
+        assert np.array_equal(dp.view(np.uint32), fr["depth"].view(np.uint32)), (W, H, k)
+        assert (fr["uright"] > 0).sum() > 50
+        gs, gi = F.grid()
+        os_, oi = ob.build_grid(fv)
+        assert np.array_equal(gs, os_) and np.array_equal(gi, oi), (W, H, k)
+
+
 def test_frame_constructor_submit_wait_pipelines_across_frames(scene):
     """orbx_frame_stereo_dev_submit / _wait: frame t+1 is constructed on one handle while frame t (other handle, other
     frame object) is being tracked; every frame's features, grid and matches equal the synchronous path / the oracle."""
