@@ -412,6 +412,53 @@ def test_search_by_projection_map(scene, th):
     assert g2[2] == o2[2] and np.array_equal(g2[0], o2[0]) and np.array_equal(g2[1], o2[1])
 
 
+def test_projection_searches_on_empty_far_and_crowded_maps(scene):
+    """The map side of TrackLocalMap at its edges: no map points at all; every point bad; a camera looking away from the map
+    (nothing in the frustum); a crowded map (each point eight times, so that every feature has tied candidates and the
+    best / second-best bookkeeping decides); a last frame without map points."""
+    rng = np.random.RandomState(21)
+    f0, f1 = [helpers.oracle_stereo_frame(scene, k) for k in (2, 6)]
+    cur = helpers.oracle_stereo_frame(scene, 4)
+    mp = helpers.local_map_from(scene, [f0, f1], rng)
+    fv, keep = helpers.frame_view_of(scene, cur)
+    n = len(cur["kps"])
+    T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+    F = api.Frame().upload(fv, keep)
+    m = api.ORBmatcher(0.8)
+
+    def check(mpx, Tx, what, expect_some=None):
+        amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+        wv, keep2 = helpers.world_view_of(mpx)
+        LM = api.LocalMap().upload(wv)
+        g = m.SearchLocalPoints(F, LM, Tx, 3.0, False, 0.0, amp0, aob0, None)
+        o = ob.search_local_points(fv, wv, Tx, 3.0, False, 0.0, 0.8, amp0, aob0)
+        assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1]), what
+        if expect_some is not None:
+            assert (o[2] > 0) == expect_some, (what, o[2])
+
+    check({k: v[:0] for k, v in mp.items()}, T, "empty map", False)
+    allbad = dict(mp); allbad["bad"] = np.ones_like(mp["bad"])
+    check(allbad, T, "all bad", False)
+    Taway = T.copy(); Taway[:3, :3] = T[:3, :3] @ np.diag([-1.0, 1.0, -1.0]).astype(np.float32)     # half a turn about y
+    check(mp, Taway, "looking away", False)
+    crowded = {k: np.concatenate([v] * 8) for k, v in mp.items()}
+    check(crowded, T, "crowded", True)
+    # last frame without a single map point: SearchByProjection(CurrentFrame, LastFrame) finds nothing, touches nothing
+    last = helpers.oracle_stereo_frame(scene, 3)
+    Pw, valid = synth.unproject_to_world(last["kps"], last["depth"], last["Tcw"], scene.cam)
+    nl = len(last["kps"])
+    lv0, keep3 = views.lastframe_view(np.zeros(nl, np.uint8), np.zeros(nl, np.uint8), Pw, last["desc"], last["kps"]["octave"],
+                                      last["kps"]["angle"], np.full(nl, 2, np.int32), last["Tcw"].astype(np.float32))
+    lv1, keep4 = views.lastframe_view(valid.astype(np.uint8), np.ones(nl, np.uint8), Pw, last["desc"], last["kps"]["octave"],
+                                      last["kps"]["angle"], np.full(nl, 2, np.int32), last["Tcw"].astype(np.float32))
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    for lvx in (lv0, lv1):                                 # no map points; every map point an outlier of the last frame
+        g = api.ORBmatcher(0.9, True).SearchByProjectionFrame(F, T, lvx, 7.0, False, amp0, aob0)
+        o = ob.search_by_projection_frame(fv, T, lvx, 7.0, False, True, amp0, aob0)
+        assert o[2] == 0
+        assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+
+
 @pytest.mark.parametrize("th,mono", [(7.0, False), (15.0, True), (14.0, False)])
 def test_search_by_projection_frame(scene, th, mono):
     rng = np.random.RandomState(13)
