@@ -821,7 +821,8 @@ def test_c4_sizes_1280x720_2000_features_and_50kf_lba():
     assert np.array_equal(g.edge_outlier, o.edge_outlier)
 
 
-@pytest.mark.parametrize("n,of,mono", [(500, 0.1, 0.2), (900, 0.3, 0.0), (40, 0.0, 1.0), (8, 0.0, 0.0), (2, 0.0, 0.0)])
+@pytest.mark.parametrize("n,of,mono", [(500, 0.1, 0.2), (900, 0.3, 0.0), (40, 0.0, 1.0), (8, 0.0, 0.0), (2, 0.0, 0.0), (1, 0.0, 0.0),
+                                       (2000, 0.2, 0.1), (3500, 0.05, 0.5), (257, 0.6, 0.3), (513, 0.0, 1.0)])
 def test_pose_optimization_parity(n, of, mono):
     """Optimizer::PoseOptimization (row f-2): whole solve in one launch vs. the oracle."""
     pr = synth.make_pose_opt_problem(n=n, outlier_frac=of, mono_frac=mono, seed=100 + n)
