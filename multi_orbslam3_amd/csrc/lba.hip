@@ -1202,6 +1202,144 @@ __global__ __launch_bounds__(1024) void k_ldlt(int n, double* S, const double* _
   if (tid == 0) *ok_flag = s_ok;
 }
 
+// ---- Blocked LDL^T + solve over MANY workgroups, for windows beyond the single-workgroup kernels (more than 51 free poses:
+// the matrix-core kernels hold <= 19 tile rows in one CU's registers, the row-pair kernel <= 1344 blocks).  Right-looking,
+// 16-column blocks, dense row-major S in global memory (L2-resident), two launches per block column:
+//   k_wide_panel(kb):  every workgroup factors the 16 x 16 diagonal block itself (no hand-over between workgroups);
+//                      workgroup 0 stores it and forward-substitutes the right-hand side's block, workgroup g >= 1 turns
+//                      row block kb + g into L = A L_kk^-T D^-1 (in place) and W = L D (kept in the mirrored upper block);
+//   k_wide_update(kb): A_ij -= W_ik L_jk^T for every trailing block, and the right-hand side as one more row;
+// then k_wide_back: x = L^-T z in one workgroup.  Same failure rule as k_ldlt: a zero / non-finite pivot clears the flag.
+__global__ __launch_bounds__(256) void k_wide_panel(int n, int kb, double* S, const double* __restrict__ b, double* yw, double* z,
+                                                    int* __restrict__ ok_flag) {
+  __shared__ double Lk[16][17];
+  __shared__ double Aw[16][17];
+  const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+  const int k0 = 16 * kb;
+  {
+    const int gr = k0 + r, gc = k0 + c;
+    Lk[r][c] = (gr < n && gc < n) ? S[(size_t)gr * n + gc] : (r == c ? 1.0 : 0.0);
+  }
+  if (blockIdx.x == 0 && kb == 0 && tid == 0) *ok_flag = 1;
+  __syncthreads();
+  bool bad = false;
+  for (int j = 0; j < 16; j++) {
+    const double d = Lk[j][j];
+    if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) bad = true;
+    const bool below = r > j, upd = below && c > j && c <= r;
+    double v = 0.0, wc = 0.0;
+    if (below) v = Lk[r][j];
+    if (upd) wc = Lk[c][j];
+    __syncthreads();
+    const double l = v / d;
+    if (upd) Lk[r][c] -= l * wc;
+    if (below && c == j) Lk[r][j] = l;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    if (bad && tid == 0) *ok_flag = 0;
+    const int gr = k0 + r, gc = k0 + c;
+    if (gr < n && gc < n && c <= r) S[(size_t)gr * n + gc] = Lk[r][c];
+    if (tid == 0) {
+      // the right-hand side as a row: w = b_k^T L_kk^-T (kept for the trailing update), z = w / D
+      const double* src = kb == 0 ? b : yw;
+      double w[16];
+      for (int cc = 0; cc < 16; cc++) {
+        double a = k0 + cc < n ? src[k0 + cc] : 0.0;
+        for (int m = 0; m < cc; m++) a -= w[m] * Lk[cc][m];
+        w[cc] = a;
+      }
+      for (int cc = 0; cc < 16; cc++)
+        if (k0 + cc < n) { yw[k0 + cc] = w[cc]; z[k0 + cc] = w[cc] / Lk[cc][cc]; }
+    }
+    return;
+  }
+  const int i0 = 16 * (kb + (int)blockIdx.x);
+  Aw[r][c] = i0 + r < n ? S[(size_t)(i0 + r) * n + k0 + c] : 0.0;
+  __syncthreads();
+  for (int m = 0; m < 15; m++) {
+    if (c > m) Aw[r][c] -= Aw[r][m] * Lk[c][m];
+    __syncthreads();
+  }
+  if (i0 + r < n) {
+    const double w = Aw[r][c];
+    S[(size_t)(i0 + r) * n + k0 + c] = w / Lk[c][c];
+    S[(size_t)(k0 + c) * n + i0 + r] = w;
+  }
+}
+
+// grid (m, m + 1), m = trailing row blocks: block (jj, ii) updates tile (kb+1+ii, kb+1+jj), ii >= jj; row ii == m is the right-hand side
+__global__ __launch_bounds__(256) void k_wide_update(int n, int kb, double* S, const double* __restrict__ b, double* yw) {
+  const int m_blocks = gridDim.x, jj = blockIdx.x, ii = blockIdx.y;
+  if (ii < m_blocks && ii < jj) return;
+  __shared__ double Wt[16][17];
+  __shared__ double Lj[16][17];
+  const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+  const int k0 = 16 * kb, j0 = 16 * (kb + 1 + jj);
+  Lj[r][c] = j0 + r < n ? S[(size_t)(j0 + r) * n + k0 + c] : 0.0;               // L_jk[r][c]
+  if (ii == m_blocks) {
+    if (r == 0) Wt[0][c] = yw[k0 + c];
+    __syncthreads();
+    if (r == 0 && j0 + c < n) {
+      double acc = 0.0;
+      for (int m = 0; m < 16; m++) acc += Wt[0][m] * Lj[c][m];
+      yw[j0 + c] = (kb == 0 ? b[j0 + c] : yw[j0 + c]) - acc;
+    }
+    return;
+  }
+  const int i0 = 16 * (kb + 1 + ii);
+  Wt[c][r] = i0 + c < n ? S[(size_t)(k0 + r) * n + i0 + c] : 0.0;               // W_ik[c][r], read along the mirrored block's rows
+  __syncthreads();
+  if (i0 + r < n && j0 + c < n) {
+    double acc = 0.0;
+    for (int m = 0; m < 16; m++) acc += Wt[r][m] * Lj[c][m];
+    S[(size_t)(i0 + r) * n + j0 + c] -= acc;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_wide_back(int n, const double* __restrict__ S, const double* __restrict__ z, double* __restrict__ x,
+                                                    const int* __restrict__ ok_flag) {
+  extern __shared__ double xs[];
+  __shared__ double Lk[16][17];
+  if (*ok_flag == 0) return;
+  const int tid = threadIdx.x, T = (n + 15) / 16;
+  for (int i = tid; i < n; i += 1024) xs[i] = z[i];
+  __syncthreads();
+  for (int kb = T - 1; kb >= 0; kb--) {
+    const int k0 = 16 * kb, w = min(16, n - k0);
+    if (tid < 256) {
+      const int r = tid >> 4, c = tid & 15;
+      Lk[r][c] = (r < w && c < r) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0)
+      for (int j = w - 1; j > 0; j--) {
+        const double xj = xs[k0 + j];
+        for (int i = 0; i < j; i++) xs[k0 + i] -= Lk[j][i] * xj;
+      }
+    __syncthreads();
+    for (int i = tid; i < k0; i += 1024) {
+      double acc = 0.0;
+      for (int cc = 0; cc < w; cc++) acc += S[(size_t)(k0 + cc) * n + i] * xs[k0 + cc];
+      xs[i] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 1024) x[i] = xs[i];
+}
+
+static void launch_ldlt_wide(int n, double* S, const double* b, double* x, int* ok, double* scratch, hipStream_t st) {
+  const int T = (n + 15) / 16;
+  double* yw = scratch;
+  double* z = scratch + n;
+  for (int kb = 0; kb < T; kb++) {
+    hipLaunchKernelGGL(k_wide_panel, dim3(T - kb), dim3(256), 0, st, n, kb, S, b, yw, z, ok);
+    const int m = T - kb - 1;
+    if (m > 0) hipLaunchKernelGGL(k_wide_update, dim3(m, m + 1), dim3(256), 0, st, n, kb, S, b, yw);
+  }
+  hipLaunchKernelGGL(k_wide_back, dim3(1), dim3(1024), (size_t)n * sizeof(double), st, n, S, z, x, ok);
+}
+
 // Register-blocked dense LDL^T + solve of the reduced camera system: thread t owns the 6x6 block (i,k), i >= k, of the
 // lower triangle in registers for the whole factorisation; per block column j: (1) the diagonal owner factors its block
 // and forward-substitutes y_j, (2) panel owners compute L_ij = A_ij L_jj^-T D_j^-1 and fold L_ij y_j into the running
@@ -1926,6 +2064,7 @@ struct lba_handle {
   DevBuf<PoseQ> d_poses[2];
   DevBuf<double> d_points[2];
   DevBuf<double> d_err, d_chi2, d_partial, d_EB, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_x;
+  DevBuf<double> d_wide;               // running / scaled right-hand side of the many-workgroup LDL^T (k_wide_*)
   DevBuf<double> d_St, d_wfac;         // reduced camera matrix as a tile image / factor scratch of the matrix-core LDL^T (ldlt_mfma.hpp)
   DevBuf<double> d_EB2, d_Hll2, d_bl2, d_Hpp2, d_bp2, d_lambda0;   // second linearisation set (speculative next iteration)
   DevBuf<int> d_pose_col, d_point_col, d_pt_start, d_pt_edges, d_ps_start, d_ps_edges, d_pf_start, d_pf_edges, d_pf_col;
@@ -2301,7 +2440,11 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     }
   }
   // FP64 matrix-core LDL^T (ldlt_mfma.hpp): up to 50 free poses; ORBG_LDLT_VALU=1 switches back to the vector-ALU kernels
-  const bool use_mfma = nP >= 1 && ldltm::supports(n) && !getenv("ORBG_LDLT_VALU");
+  const bool force_wide = getenv("ORBG_LDLT_WIDE") != nullptr;          // A/B and test switch: k_wide_* at any size
+  const bool use_mfma = nP >= 1 && ldltm::supports(n) && !getenv("ORBG_LDLT_VALU") && !force_wide;
+  // windows beyond every single-workgroup kernel (more than 51 free poses): blocked LDL^T over many workgroups
+  const bool use_wide = nP >= 1 && (force_wide || (!use_mfma && !use_flow && !rows_R));
+  if (use_wide && (rc = h->d_wide.reserve(2 * (size_t)n + 32))) return rc;
   if (use_mfma) {
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
   }
@@ -2398,6 +2541,8 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
       if (use_mfma) {
         ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
+      } else if (use_wide) {
+        launch_ldlt_wide(n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wide.p, st);
       } else if (use_flow) {
         hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
       } else if (rows_R) {
@@ -2820,7 +2965,7 @@ extern "C" int lba_get_solver_stats(lba_handle* h, double* sum_ms, int64_t* n_br
   if (!h || !sum_ms || !n_brackets) return ORBG_BAD_ARG;
   *sum_ms = h->prof_sum_ms; *n_brackets = h->prof_n;
   if (n_unknowns) *n_unknowns = h->prof_n_unknowns;
-  if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !getenv("ORBG_LDLT_VALU");
+  if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !getenv("ORBG_LDLT_VALU") && !getenv("ORBG_LDLT_WIDE");
   return ORBG_OK;
 }
 

@@ -576,14 +576,15 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
     (<= 20 poses, 1..8 tile columns), the eight-wavefront tile kernel (9 tile rows: 21..23 poses; forced for the small sizes
     by ORBG_LDLT_TILES and for the large ones by ORBG_LDLT_8W), the four-wavefront kernel with its tile store in the
     accumulation / high vector registers in its four instantiations (10 / 11..13 / 14..15 / 16..19 tile rows: <= 26 / 34 / 39 /
-    50 poses), and the vector-ALU kernels behind ORBG_LDLT_VALU (dataflow <= 20 poses, barrier kernel)."""
+    50 poses), the vector-ALU kernels behind ORBG_LDLT_VALU (dataflow <= 20 poses, barrier kernel), and the many-workgroup
+    blocked kernels of windows with more than 51 free poses (forced here by ORBG_LDLT_WIDE)."""
     prob = synth.make_lba_problem(n_free=nf, n_fixed=3, n_points=40 * nf + 60, mono_frac=0.2, seed=100 + nf)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
     o = ob.lba_solve(p)
     variants = [{}, {"ORBG_LDLT_TILES": "1"}, {"ORBG_LDLT_TILES": "1", "ORBG_LDLT_8W": "1"}, {"ORBG_LDLT_VALU": "1"},
-                {"ORBG_LDLT_VALU": "1", "ORBG_LDLT_ROWS": "1"}]
+                {"ORBG_LDLT_VALU": "1", "ORBG_LDLT_ROWS": "1"}, {"ORBG_LDLT_WIDE": "1"}]
     for env in variants:
-        for key in ("ORBG_LDLT_TILES", "ORBG_LDLT_8W", "ORBG_LDLT_VALU", "ORBG_LDLT_ROWS"):
+        for key in ("ORBG_LDLT_TILES", "ORBG_LDLT_8W", "ORBG_LDLT_VALU", "ORBG_LDLT_ROWS", "ORBG_LDLT_WIDE"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
@@ -594,6 +595,22 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
         tg, to = g.trace_rows(), o.trace_rows()
         assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]), (nf, env)
         assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), (nf, env)
+
+
+@pytest.mark.parametrize("nf", [51, 52, 56, 64, 65, 83, 120])
+def test_lba_windows_beyond_the_benchmark_sizes(nf):
+    """More than 50 free poses (a covisibility window of ORB-SLAM3 is not bounded): 51 is the last size of the single-workgroup
+    row kernel, from 52 on the reduced camera system is factorised by the many-workgroup blocked kernels (k_wide_*); beyond 64
+    free poses the pair items come from the host (the pose masks no longer fit one word)."""
+    prob = synth.make_lba_problem(n_free=nf, n_fixed=3, n_points=25 * nf, mono_frac=0.2, seed=300 + nf)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    o = ob.lba_solve(p)
+    g = api.Optimizer().LocalBundleAdjustment(p)
+    assert g.status == o.status and g.iters == o.iters
+    assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4
+    assert np.array_equal(g.edge_outlier, o.edge_outlier)
+    tg, to = g.trace_rows(), o.trace_rows()
+    assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]) and np.allclose(tg[:, 1], to[:, 1], rtol=1e-9)
 
 
 def test_lba_every_window_size_up_to_50_free_poses():
