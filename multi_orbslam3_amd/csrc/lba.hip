@@ -1240,18 +1240,15 @@ __global__ __launch_bounds__(256) void k_wide_panel(int n, int kb, double* S, co
     if (bad && tid == 0) *ok_flag = 0;
     const int gr = k0 + r, gc = k0 + c;
     if (gr < n && gc < n && c <= r) S[(size_t)gr * n + gc] = Lk[r][c];
-    if (tid == 0) {
-      // the right-hand side as a row: w = b_k^T L_kk^-T (kept for the trailing update), z = w / D
-      const double* src = kb == 0 ? b : yw;
-      double w[16];
-      for (int cc = 0; cc < 16; cc++) {
-        double a = k0 + cc < n ? src[k0 + cc] : 0.0;
-        for (int m = 0; m < cc; m++) a -= w[m] * Lk[cc][m];
-        w[cc] = a;
-      }
-      for (int cc = 0; cc < 16; cc++)
-        if (k0 + cc < n) { yw[k0 + cc] = w[cc]; z[k0 + cc] = w[cc] / Lk[cc][cc]; }
+    // the right-hand side as a one-row block: w = b_k^T L_kk^-T (kept for the trailing update), z = w / D
+    const double* src = kb == 0 ? b : yw;
+    Aw[r][c] = (r == 0 && k0 + c < n) ? src[k0 + c] : 0.0;
+    __syncthreads();
+    for (int m = 0; m < 15; m++) {
+      if (r == 0 && c > m) Aw[0][c] -= Aw[0][m] * Lk[c][m];
+      __syncthreads();
     }
+    if (r == 0 && k0 + c < n) { const double w = Aw[0][c]; yw[k0 + c] = w; z[k0 + c] = w / Lk[c][c]; }
     return;
   }
   const int i0 = 16 * (kb + (int)blockIdx.x);
@@ -1300,23 +1297,26 @@ __global__ __launch_bounds__(256) void k_wide_update(int n, int kb, double* S, c
 __global__ __launch_bounds__(1024) void k_wide_back(int n, const double* __restrict__ S, const double* __restrict__ z, double* __restrict__ x,
                                                     const int* __restrict__ ok_flag) {
   extern __shared__ double xs[];
-  __shared__ double Lk[16][17];
   if (*ok_flag == 0) return;
   const int tid = threadIdx.x, T = (n + 15) / 16;
   for (int i = tid; i < n; i += 1024) xs[i] = z[i];
   __syncthreads();
   for (int kb = T - 1; kb >= 0; kb--) {
     const int k0 = 16 * kb, w = min(16, n - k0);
-    if (tid < 256) {
-      const int r = tid >> 4, c = tid & 15;
-      Lk[r][c] = (r < w && c < r) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0;
-    }
-    __syncthreads();
-    if (tid == 0)
-      for (int j = w - 1; j > 0; j--) {
-        const double xj = xs[k0 + j];
-        for (int i = 0; i < j; i++) xs[k0 + i] -= Lk[j][i] * xj;
+    if (tid < 64) {
+      // the diagonal block: lane i < 16 holds x_i and column i of L_kk; x_j goes round by a lane read, 15 steps in registers
+      const int i = tid & 15;
+      double lcol[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) lcol[j] = (j > i && j < w) ? S[(size_t)(k0 + j) * n + k0 + i] : 0.0;
+      double xv = i < w ? xs[k0 + i] : 0.0;
+#pragma unroll
+      for (int j = 15; j > 0; j--) {
+        const double xj = __shfl(xv, j, 16);
+        xv -= lcol[j] * xj;
       }
+      if (tid < w) xs[k0 + tid] = xv;
+    }
     __syncthreads();
     for (int i = tid; i < k0; i += 1024) {
       double acc = 0.0;
