@@ -1022,3 +1022,37 @@ def test_detect_n_best_candidates_parity():
         assert np.array_equal(pg.view(np.uint32), po.view(np.uint32)), q
         total += len(gl) + len(gm)
     assert total > 40
+
+
+@pytest.mark.parametrize("case", ["one_kf", "all_bad", "all_connected", "other_maps_bad", "large"])
+def test_detect_n_best_candidates_edge_databases(case):
+    """The database at its edges: a single keyframe; every keyframe bad; every keyframe connected to the query (nothing may be
+    returned); every other map bad (no merge candidates); 3000 keyframes over 20 000 words."""
+    rng = np.random.RandomState({"one_kf": 1, "all_bad": 2, "all_connected": 3, "other_maps_bad": 4, "large": 5}[case])
+    if case == "one_kf":
+        db = helpers.random_database(rng, n_kfs=1, n_words=500)
+    elif case == "large":
+        db = helpers.random_database(rng, n_kfs=3000, n_words=20000)
+    else:
+        db = helpers.random_database(rng, n_kfs=120, n_words=2000)
+    if case == "all_bad":
+        db["bad"][:] = 1
+    if case == "other_maps_bad":
+        db["map_bad"][1:] = 1
+    v, keep = views.database_view(db["inv"], db["bows"], db["covis"], db["map_id"], db["bad"], db["map_bad"], db["n_words"])
+    D = api.KeyFrameDatabase(v, keep)
+    K = len(db["bows"])
+    pg, po = np.zeros(K, np.float32), np.zeros(K, np.float32)
+    for q in range(6):
+        kq = rng.randint(K)
+        qw, qv = db["bows"][kq]
+        con = np.ones(K, np.uint8) if case == "all_connected" else np.zeros(K, np.uint8)
+        con[kq] = 1
+        gl, gm = D.DetectNBestCandidates(qw, qv, con, int(db["map_id"][kq]), 3, pg)
+        ol, om = ob.detect_n_best_candidates(v, qw, qv, con, int(db["map_id"][kq]), 3, po)
+        assert np.array_equal(gl, ol) and np.array_equal(gm, om), (case, q, gl, ol, gm, om)
+        assert np.array_equal(pg.view(np.uint32), po.view(np.uint32)), (case, q)
+        if case in ("one_kf", "all_bad", "all_connected"):
+            assert len(ol) == 0 and len(om) == 0
+        if case == "other_maps_bad":
+            assert len(om) == 0
