@@ -494,6 +494,39 @@ def test_search_by_bow(scene):
     assert g[1] == o[1] and np.array_equal(g[0], o[0])
 
 
+@pytest.mark.parametrize("case", ["disjoint_nodes", "no_valid_points", "one_node", "coarse_nodes", "no_orientation_check"])
+def test_search_by_bow_edge_cases(scene, case):
+    """SearchByBoW(KF, F) when the two feature vectors share no node; when the keyframe has no map point; when every feature
+    falls into ONE node (every keyframe point is compared with every frame feature: the longest candidate lists); with 4 coarse
+    nodes; without the rotation histogram."""
+    kf = helpers.oracle_stereo_frame(scene, 14)
+    cur = helpers.oracle_stereo_frame(scene, 15)
+    fv, keep = helpers.frame_view_of(scene, cur)
+    if case == "one_node":
+        node = lambda d, k: np.zeros(len(d), np.int64)
+    elif case == "coarse_nodes":
+        node = lambda d, k: d[:, 0].astype(np.int64) >> 6
+    else:
+        node = lambda d, k: (d[:, 0].astype(np.int64) >> 3) * 2 + (k["octave"] // 4)
+    nF, nK = node(cur["desc"], cur["kps"]), node(kf["desc"], kf["kps"])
+    if case == "disjoint_nodes":
+        nK = nK + 1000
+    fvF, kF = views.featvec_view(*views.featvec_from_nodes(nF))
+    fvK, kK = views.featvec_view(*views.featvec_from_nodes(nK))
+    valid = (kf["depth"] > 0).astype(np.uint8)
+    if case == "no_valid_points":
+        valid[:] = 0
+    check = case != "no_orientation_check"
+    F = api.Frame().upload(fv, keep)
+    g = api.ORBmatcher(0.7, check).SearchByBoW(F, fvF, kf["desc"], valid, kf["kps"]["angle"], fvK)
+    o = ob.search_by_bow(fv, fvF, kf["desc"], valid, kf["kps"]["angle"], fvK, 0.7, check)
+    assert g[1] == o[1] and np.array_equal(g[0], o[0]), case
+    if case in ("disjoint_nodes", "no_valid_points"):
+        assert o[1] == 0
+    else:
+        assert o[1] > 10
+
+
 @pytest.mark.parametrize("th,ratio,with_kfs,scale", [(3, 1.5, False, 1.0), (8, 1.0, True, 1.7), (8, 1.5, False, 0.6)])
 def test_search_by_projection_sim3(scene, th, ratio, with_kfs, scale):
     """Server-side SearchByProjection(KeyFrame*, Scw, ...), both overloads."""
