@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(1024) void k_ldlt(int n, double* S, const double* _
   if (tid == 0) *ok_flag = s_ok;
 }
 
-// ---- Blocked LDL^T + solve over MANY workgroups, for windows beyond the single-workgroup kernels (more than 51 free poses:
+// ---- Blocked LDL^T + solve over MANY workgroups, for windows beyond the matrix-core kernels (more than 50 free poses:
 // the matrix-core kernels hold <= 19 tile rows in one CU's registers, the row-pair kernel <= 1344 blocks).  Right-looking,
 // 16-column blocks, dense row-major S in global memory (L2-resident), two launches per block column:
 //   k_wide_panel(kb):  every workgroup factors the 16 x 16 diagonal block itself (no hand-over between workgroups);
@@ -2442,8 +2442,9 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   // FP64 matrix-core LDL^T (ldlt_mfma.hpp): up to 50 free poses; ORBG_LDLT_VALU=1 switches back to the vector-ALU kernels
   const bool force_wide = getenv("ORBG_LDLT_WIDE") != nullptr;          // A/B and test switch: k_wide_* at any size
   const bool use_mfma = nP >= 1 && ldltm::supports(n) && !getenv("ORBG_LDLT_VALU") && !force_wide;
-  // windows beyond every single-workgroup kernel (more than 51 free poses): blocked LDL^T over many workgroups
-  const bool use_wide = nP >= 1 && (force_wide || (!use_mfma && !use_flow && !rows_R));
+  // windows beyond the matrix-core kernels (more than 50 free poses): blocked LDL^T over many workgroups
+  // (51 free poses still fit the row-pair kernel, which stays reachable through ORBG_LDLT_VALU; the blocked form is faster there: 2.7 vs 3.4 ms)
+  const bool use_wide = nP >= 1 && (force_wide || (!use_mfma && !use_flow && (!rows_R || (nP > 50 && !getenv("ORBG_LDLT_VALU")))));
   if (use_wide && (rc = h->d_wide.reserve(2 * (size_t)n + 32))) return rc;
   if (use_mfma) {
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;

@@ -632,8 +632,8 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
 
 @pytest.mark.parametrize("nf", [51, 52, 56, 64, 65, 83, 120])
 def test_lba_windows_beyond_the_benchmark_sizes(nf):
-    """More than 50 free poses (a covisibility window of ORB-SLAM3 is not bounded): 51 is the last size of the single-workgroup
-    row kernel, from 52 on the reduced camera system is factorised by the many-workgroup blocked kernels (k_wide_*); beyond 64
+    """More than 50 free poses (a covisibility window of ORB-SLAM3 is not bounded): from 51 on the reduced camera system is
+    factorised by the many-workgroup blocked kernels (k_wide_*; 51 is also the last size of the row-pair kernel); beyond 64
     free poses the pair items come from the host (the pose masks no longer fit one word)."""
     prob = synth.make_lba_problem(n_free=nf, n_fixed=3, n_points=25 * nf, mono_frac=0.2, seed=300 + nf)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
