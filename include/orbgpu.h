@@ -443,19 +443,27 @@ typedef struct lba_result {
  * it is polled between LM iterations/trials exactly where g2o polls forceStopFlag
  * (G/core/sparse_optimizer.cpp:376, G/core/optimization_algorithm_levenberg.cpp:149).  A positive value is the
  * reference's `true` (raised by Tracking, S/LocalMapping.cc:381-386).  A NEGATIVE value -k is a deterministic form for
- * tests: the flag reads as raised once k Levenberg-Marquardt trials have been evaluated, whatever the timing. */
+ * tests: the flag reads as raised once k Levenberg-Marquardt trials have been evaluated, whatever the timing (INT32_MIN:
+ * k = 0, i.e. raised right after the check that precedes optimize(), S/Optimizer.cc:2127-2129). */
 int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
+/* The same solve polling the reference's OWN flag: `bool* pbStopFlag` (I/Optimizer.h:42) points at LocalMapping::mbAbortBA,
+ * a one-byte bool that LocalMapping::InterruptBA sets from the Tracking thread while the solve runs (S/LocalMapping.cc:381-386,
+ * :118 hands &mbAbortBA to the optimiser).  stop_bool is that address, passed through unchanged (any non-zero byte = raised);
+ * it is read -- never written -- at exactly the poll points above, so the reference's InterruptBA() needs no change. */
+int lba_solve_b(const lba_problem* p, const volatile uint8_t* stop_bool, lba_result* r);
 
 /* Persistent LBA workspace variant: avoids per-call device allocation. */
 typedef struct lba_handle lba_handle;
 int lba_create(int device, int cap_poses, int cap_points, int cap_edges, lba_handle** out);
 int lba_destroy(lba_handle* h);
 int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
+int lba_solve_hb(lba_handle* h, const lba_problem* p, const volatile uint8_t* stop_bool, lba_result* r);   /* bool flag, see lba_solve_b */
 /* The same solve on a worker thread owned by the handle, as the reference runs it on its LocalMapping thread next to
  * Tracking (S/ClientSystem.cc:105-106).  lba_solve_async returns immediately; lba_wait blocks until the solve is done
 * and returns its status (ORBG_OK when nothing was submitted).  problem / stop_flag / result must stay valid until then;
  * one solve in flight per handle (a second lba_solve_async before lba_wait returns ORBG_BAD_ARG). */
 int lba_solve_async(lba_handle* h, const lba_problem* problem, const volatile int32_t* stop_flag, lba_result* result);
+int lba_solve_async_b(lba_handle* h, const lba_problem* problem, const volatile uint8_t* stop_bool, lba_result* result);
 int lba_wait(lba_handle* h, double* solve_ms /* wall time of that solve on the worker, may be NULL */);
 /* Measurement hooks (bench.py roofline): with profiling on, one launch per solve of the reduced-camera-system LDL^T
  * (G/solvers/linear_solver_eigen.h:94-124 behind G/core/block_solver.hpp:447) is bracketed by a HIP event pair on the

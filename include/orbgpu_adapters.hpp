@@ -289,6 +289,16 @@ class Optimizer {
     check(lba_solve(&problem, pbStopFlag, &result), "lba_solve");
     return result.status;
   }
+  // ... with the reference's own flag: LocalMapping hands &mbAbortBA, a one-byte bool that InterruptBA() sets while the solve
+  // runs (S/LocalMapping.cc:245,381-386); the library polls that byte where g2o polls it, nothing on the reference side changes
+  static int LocalBundleAdjustment(const lba_problem& problem, const volatile bool* pbStopFlag, lba_result& result) {
+    check(lba_solve_b(&problem, stop_byte(pbStopFlag), &result), "lba_solve_b");
+    return result.status;
+  }
+  static const volatile uint8_t* stop_byte(const volatile bool* pbStopFlag) {
+    static_assert(sizeof(bool) == 1, "bool* pbStopFlag is polled as one byte");
+    return reinterpret_cast<const volatile uint8_t*>(pbStopFlag);
+  }
   // int static PoseOptimization(Frame* pFrame), I/Optimizer.h:47, S/Optimizer.cc:964-1278: returns nInitialCorrespondences -
   // nBad; result.Tcw is what the reference writes with pFrame->SetPose, result.outlier[i] is pFrame->mvbOutlier.
   static int PoseOptimization(const pose_opt_problem& problem, pose_opt_result& result) {
@@ -311,6 +321,14 @@ class LocalBA {
   }
   void Submit(const lba_problem& problem, const volatile int32_t* pbStopFlag, lba_result& result) {
     check(lba_solve_async(h_, &problem, pbStopFlag, &result), "lba_solve_async");
+  }
+  // the reference's bool flag (&LocalMapping::mbAbortBA), polled in place
+  int Run(const lba_problem& problem, const volatile bool* pbStopFlag, lba_result& result) {
+    check(lba_solve_hb(h_, &problem, Optimizer::stop_byte(pbStopFlag), &result), "lba_solve_hb");
+    return result.status;
+  }
+  void Submit(const lba_problem& problem, const volatile bool* pbStopFlag, lba_result& result) {
+    check(lba_solve_async_b(h_, &problem, Optimizer::stop_byte(pbStopFlag), &result), "lba_solve_async_b");
   }
   void Wait(double* solve_ms = nullptr) { check(lba_wait(h_, solve_ms), "lba_wait"); }
 

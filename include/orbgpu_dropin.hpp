@@ -40,15 +40,33 @@ inline void make_mat(cv::Mat& out, int rows, int cols, const float* data) { out 
 #endif
 
 // ------------------------------------------------------------------------------------------------ entry points
-// The product: liborbgpu.  A Frame is uploaded on first use and cached by its address + feature count (the reference's
-// Frame would carry an orbgpu::FrameOnDevice member instead -- FrameOnDevice::StereoCtor leaves it on the device).
+// The product: liborbgpu.  A Frame is uploaded on first use into one of a few device frames the calling thread keeps
+// (least recently used first: Tracking works on mCurrentFrame / mLastFrame / a relocalisation candidate at a time; the
+// reference's Frame would carry an orbgpu::FrameOnDevice member instead -- FrameOnDevice::StereoCtor leaves it on the
+// device).  The local BA keeps ONE handle per calling thread (the LocalMapping thread), so device buffers, pinned staging
+// and the stream survive from keyframe to keyframe.  GpuOps::release() drops everything the calling thread holds (call it
+// before the thread ends if the HIP runtime may be torn down first).
 struct GpuOps {
+  static constexpr int kFrameSlots = 4;
+  struct ThreadState {
+    struct Slot { const void* key = nullptr; unsigned long long used = 0; std::unique_ptr<FrameOnDevice> dev; };
+    Slot slots[kFrameSlots];
+    unsigned long long tick = 0;
+    std::unique_ptr<LocalBA> ba;
+  };
+  static ThreadState& state() { static thread_local ThreadState s; return s; }
+  static void release() { ThreadState& s = state(); for (auto& sl : s.slots) { sl.dev.reset(); sl.key = nullptr; sl.used = 0; } s.ba.reset(); }
   static FrameOnDevice& frame(const void* key, const orbm_frame_view& v) {
-    static thread_local std::map<const void*, std::unique_ptr<FrameOnDevice>> cache;
-    auto& slot = cache[key];
-    if (!slot) slot.reset(new FrameOnDevice(std::max(v.n, 4096)));
-    slot->Upload(v);
-    return *slot;
+    ThreadState& s = state();
+    ThreadState::Slot* hit = nullptr; ThreadState::Slot* lru = &s.slots[0];
+    for (auto& sl : s.slots) {
+      if (sl.key == key && sl.dev) hit = &sl;
+      if (sl.used < lru->used) lru = &sl;
+    }
+    if (!hit) { hit = lru; hit->key = key; if (!hit->dev) hit->dev.reset(new FrameOnDevice(std::max(v.n, 4096))); }
+    hit->used = ++s.tick;
+    hit->dev->Upload(v);
+    return *hit->dev;
   }
   static int is_in_frustum(const void* key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim,
                            uint8_t* in_view, float* px, float* py, float* pxr, float* depth, int32_t* level, float* vcos) {
@@ -67,7 +85,13 @@ struct GpuOps {
                         int32_t* matches, int* n) {
     return orbm_search_by_bow(frame(key, v).handle(), &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
   }
-  static int lba(const lba_problem& p, const volatile int32_t* stop, lba_result& r) { return lba_solve(&p, stop, &r); }
+  // pbStopFlag goes through as it is: the library polls the caller's bool (lba_solve_hb)
+  static int lba(const lba_problem& p, const volatile bool* stop, lba_result& r) {
+    ThreadState& s = state();
+    if (!s.ba) s.ba.reset(new LocalBA(p.device));
+    s.ba->Run(p, stop, r);
+    return ORBG_OK;
+  }
   static int pose_opt(const pose_opt_problem& p, pose_opt_result& r) { return pose_optimize(&p, &r); }
 };
 
@@ -328,11 +352,10 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   std::vector<float> oposes(poses.size()), opts(pts.size()); std::vector<uint8_t> eout(edges.size()), edep(edges.size());
   std::vector<double> echi(edges.size());
   lba_result R{}; R.poses = oposes.data(); R.points = opts.data(); R.edge_outlier = eout.data(); R.edge_depth_pos = edep.data(); R.edge_chi2 = echi.data();
-  // *pbStopFlag is a bool written by Tracking (S/LocalMapping.cc:381-386); the library polls an int32: a byte-wide bool is
-  // mirrored through a one-element buffer that a watcher in the caller updates, or (here) sampled when the solve starts --
-  // deployments widen the flag itself
-  volatile int32_t stop = (pbStopFlag && *pbStopFlag) ? 1 : 0;
-  check(Ops::lba(P, &stop, R), "LocalBundleAdjustment");
+  // *pbStopFlag is LocalMapping::mbAbortBA, a bool Tracking raises through InterruptBA() while this runs (S/LocalMapping.cc:381-386):
+  // the pointer goes to the library unchanged and is polled there between LM iterations / trials, where g2o polls it
+  // (G/core/sparse_optimizer.cpp:376, G/core/optimization_algorithm_levenberg.cpp:149) and for bDoMore (:2135-2139)
+  check(Ops::lba(P, pbStopFlag, R), "LocalBundleAdjustment");
   if (R.status != LBA_APPLIED) return R.status;                                              // :2127-2129 and :2257-2261: nothing is written
   std::vector<std::pair<KeyFrameT*, MapPointT*>> vToErase;                                   // :2207-2253
   for (size_t k = 0; k < edges.size(); k++)
@@ -341,13 +364,14 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   for (auto& e : vToErase) { e.first->EraseMapPointMatch(e.second); e.second->EraseObservation(e.first); }   // :2279-2286
   for (KeyFrameT* kf : lLocalKeyFrames) {                                                    // :2318-2372 (SetPose)
     decltype(kf->GetPose()) T; make_mat(T, 4, 4, &oposes[16 * (size_t)kfIndex[kf]]);
-    kf->SetPose(T);
+    kf->SetPose(T, true);                                                                    // :2327 (bLock: mbPoseLock on the server)
   }
   for (size_t j = 0; j < vMP.size(); j++) {                                                  // :2375-2383
     decltype(vMP[j]->GetWorldPos()) X; make_mat(X, 3, 1, &opts[3 * j]);
-    vMP[j]->SetWorldPos(X);
+    vMP[j]->SetWorldPos(X, true);                                                            // :2386
     vMP[j]->UpdateNormalAndDepth();
   }
+  pMap->IncreaseChangeIndex();                                                               // :2397 (Tracking reads it: mbMapUpdated)
   return R.status;
 }
 

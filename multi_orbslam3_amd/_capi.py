@@ -130,6 +130,7 @@ EXPORTED_SYMBOLS = [
     "orbm_distinctive_descriptors", "orbv_score_l1", "orbk_wire_bytes", "orbk_pack_frame", "orbk_frame_from_wire",
     "orbm_frame_download",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "lba_solve_async", "lba_wait", "pose_optimize",
+    "lba_solve_b", "lba_solve_hb", "lba_solve_async_b",
     "lba_set_profiling", "lba_get_solver_stats", "lba_event_overhead",
     "orbd_database_create", "orbd_database_destroy", "orbd_detect_n_best_candidates",
     "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_event_overhead", "orbx_set_profile_interval", "orbx_set_profile_kernel", "orbx_get_fast_kernel_stats", "orbx_set_profiling",

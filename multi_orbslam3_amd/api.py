@@ -519,8 +519,20 @@ class Optimizer:
         sp = None if pbStopFlag is None else C.c_void_p(pbStopFlag.ctypes.data)
         if getattr(self, "_async_keep", None) is None:
             out.c.trace_len = 0
-        capi.check(self.lib.lba_solve_async(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_async")
+        fn = self.lib.lba_solve_async_b if self._is_bool_flag(pbStopFlag) else self.lib.lba_solve_async
+        capi.check(fn(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_async")
         self._async_keep = (problem, out, pbStopFlag)
+
+    @staticmethod
+    def _is_bool_flag(flag):
+        """np.bool_ / np.uint8 flag = the reference's `bool* pbStopFlag` (polled as one byte, lba_solve_hb); np.int32 = the
+        C-ABI's int32 flag with its deterministic test forms."""
+        if flag is None:
+            return False
+        if flag.dtype in (np.bool_, np.uint8):
+            return True
+        assert flag.dtype == np.int32, "pbStopFlag must be a bool / uint8 / int32 array of one element"
+        return False
 
     def set_profiling(self, on=True, reset=True):
         """Bracket one LDL^T launch per solve with a HIP event pair on the handle's stream (bench.py roofline)."""
@@ -551,14 +563,16 @@ class Optimizer:
         return out
 
     def LocalBundleAdjustment(self, problem, pbStopFlag=None, trace_cap=64, out=None):
-        """problem: views.lba_problem(...)[0]; pbStopFlag: np.int32[1] polled between LM iterations.
+        """problem: views.lba_problem(...)[0]; pbStopFlag: np.bool_[1] (the reference's bool) or np.int32[1], polled between LM
+        iterations / trials.
         out: a views.LbaOutput of matching size to reuse (the result arrays are the caller's, as in the C ABI)."""
         if out is None:
             out = views.LbaOutput(problem.n_poses, problem.n_points, problem.n_edges, trace_cap)
         else:
             out.c.trace_len = 0
         sp = None if pbStopFlag is None else C.c_void_p(pbStopFlag.ctypes.data)
-        capi.check(self.lib.lba_solve_h(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_h")
+        fn = self.lib.lba_solve_hb if self._is_bool_flag(pbStopFlag) else self.lib.lba_solve_h
+        capi.check(fn(self.h, C.byref(problem), sp, C.byref(out.c)), "lba_solve_h")
         return out
 
 

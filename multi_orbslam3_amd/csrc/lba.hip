@@ -1205,8 +1205,11 @@ __global__ __launch_bounds__(1024) void k_ldlt(int n, double* S, const double* _
 // ---- Blocked LDL^T + solve over MANY workgroups, for windows beyond the matrix-core kernels (more than 50 free poses:
 // the matrix-core kernels hold <= 19 tile rows in one CU's registers, the row-pair kernel <= 1344 blocks).  Right-looking,
 // 16-column blocks, dense row-major S in global memory (L2-resident), two launches per block column:
-//   k_wide_panel(kb):  every workgroup factors the 16 x 16 diagonal block itself (no hand-over between workgroups);
-//                      workgroup 0 stores it and forward-substitutes the right-hand side's block, workgroup g >= 1 turns
+//   k_wide_panel(kb):  every workgroup factors the 16 x 16 diagonal block itself (no hand-over between workgroups).  The
+//                      block is READ from its diagonal and upper triangle only and workgroup 0 WRITES the strictly lower
+//                      triangle only (L_kk for the back-substitution), so a workgroup that is dispatched after workgroup 0
+//                      has finished still factors the unfactored block: no location is input and output of one launch;
+//                      workgroup 0 also forward-substitutes the right-hand side's block, workgroup g >= 1 turns
 //                      row block kb + g into L = A L_kk^-T D^-1 (in place) and W = L D (kept in the mirrored upper block);
 //   k_wide_update(kb): A_ij -= W_ik L_jk^T for every trailing block, and the right-hand side as one more row;
 // then k_wide_back: x = L^-T z in one workgroup.  Same failure rule as k_ldlt: a zero / non-finite pivot clears the flag.
@@ -1218,7 +1221,8 @@ __global__ __launch_bounds__(256) void k_wide_panel(int n, int kb, double* S, co
   const int k0 = 16 * kb;
   {
     const int gr = k0 + r, gc = k0 + c;
-    Lk[r][c] = (gr < n && gc < n) ? S[(size_t)gr * n + gc] : (r == c ? 1.0 : 0.0);
+    const int lo = gr < gc ? gr : gc, hi = gr < gc ? gc : gr;
+    Lk[r][c] = (gr < n && gc < n) ? S[(size_t)lo * n + hi] : (r == c ? 1.0 : 0.0);
   }
   if (blockIdx.x == 0 && kb == 0 && tid == 0) *ok_flag = 1;
   __syncthreads();
@@ -1239,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_wide_panel(int n, int kb, double* S, co
   if (blockIdx.x == 0) {
     if (bad && tid == 0) *ok_flag = 0;
     const int gr = k0 + r, gc = k0 + c;
-    if (gr < n && gc < n && c <= r) S[(size_t)gr * n + gc] = Lk[r][c];
+    if (gr < n && gc < n && c < r) S[(size_t)gr * n + gc] = Lk[r][c];
     // the right-hand side as a one-row block: w = b_k^T L_kk^-T (kept for the trailing update), z = w / D
     const double* src = kb == 0 ? b : yw;
     Aw[r][c] = (r == 0 && k0 + c < n) ? src[k0 + c] : 0.0;
@@ -1328,7 +1332,9 @@ __global__ __launch_bounds__(1024) void k_wide_back(int n, const double* __restr
   for (int i = tid; i < n; i += 1024) x[i] = xs[i];
 }
 
-static void launch_ldlt_wide(int n, double* S, const double* b, double* x, int* ok, double* scratch, hipStream_t st) {
+constexpr int kWideMaxUnknowns = 8192;   // k_wide_back keeps x in LDS: n * 8 bytes <= 64 KB (1365 free poses)
+static hipError_t launch_ldlt_wide(int n, double* S, const double* b, double* x, int* ok, double* scratch, hipStream_t st) {
+  if (n > kWideMaxUnknowns) return hipErrorInvalidValue;
   const int T = (n + 15) / 16;
   double* yw = scratch;
   double* z = scratch + n;
@@ -1338,6 +1344,7 @@ static void launch_ldlt_wide(int n, double* S, const double* b, double* x, int* 
     if (m > 0) hipLaunchKernelGGL(k_wide_update, dim3(m, m + 1), dim3(256), 0, st, n, kb, S, b, yw);
   }
   hipLaunchKernelGGL(k_wide_back, dim3(1), dim3(1024), (size_t)n * sizeof(double), st, n, S, z, x, ok);
+  return hipGetLastError();
 }
 
 // Register-blocked dense LDL^T + solve of the reduced camera system: thread t owns the 6x6 block (i,k), i >= k, of the
@@ -2054,6 +2061,12 @@ __global__ __launch_bounds__(256) void k_finish_items(int n_partial, const doubl
 
 // ---------------------------------------------------------------------------------------------- handle
 
+// The abort flag as the caller owns it: the C-ABI's int32 (with its deterministic test forms) or the reference's own
+// one-byte bool (LocalMapping::mbAbortBA behind Optimizer::LocalBundleAdjustment's bool* pbStopFlag, S/LocalMapping.cc:381-386)
+struct StopRef {
+  const volatile int32_t* i32 = nullptr;
+  const volatile uint8_t* u8 = nullptr;
+};
 struct lba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -2094,7 +2107,7 @@ struct lba_handle {
   // stays the fallback), but both sides first SPIN on it: a futex wake-up costs 10-60 us (more from a deep C-state), and in
   // steady state the worker gets its next keyframe tens of microseconds after it delivered the last one.
   std::atomic<int> job_state{0};
-  const lba_problem* job_p = nullptr; const volatile int32_t* job_stop = nullptr; lba_result* job_r = nullptr;
+  const lba_problem* job_p = nullptr; StopRef job_stop; lba_result* job_r = nullptr;
   int job_status = ORBG_OK;
   double job_ms = 0;
 };
@@ -2174,15 +2187,23 @@ static int upload_arena(lba_handle* h, size_t off0, size_t off1, hipStream_t st,
   return ORBG_OK;
 }
 
-extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
+static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r) {
   if (!h || !p || !r || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0) return ORBG_BAD_ARG;
   if (!r->poses || !r->points) return ORBG_BAD_ARG;
   int rc = select_device(h->device);
   if (rc) return rc;
   const int NP = p->n_poses, NX = p->n_points, NE = p->n_edges;
   // > 0: stop (the reference's bool); < 0: stop once that many LM trials have been evaluated (deterministic test hook, orbgpu.h)
+  // INT32_MIN: raised right after the check that precedes optimize() (the -k form with k = 0)
   int trials_done = 0;
-  auto terminate = [&]() { if (!stop_flag) return false; const int v = *stop_flag; return v > 0 || (v < 0 && trials_done >= -v); };
+  bool past_precheck = false;
+  auto terminate = [&]() {
+    if (stop_ref.u8) return *stop_ref.u8 != 0;
+    if (!stop_ref.i32) return false;
+    const int v = *stop_ref.i32;
+    if (v == INT32_MIN) return past_precheck;
+    return v > 0 || (v < 0 && trials_done >= -v);
+  };
   r->status = LBA_APPLIED; r->iters_round1 = r->iters_round2 = 0; r->n_outliers = 0; r->trace_len = 0;
   r->chi2_initial = r->chi2_final = 0;
   if (terminate()) {                                   // S/Optimizer.cc:2127-2129
@@ -2196,6 +2217,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
     }
     return ORBG_OK;
   }
+  past_precheck = true;
   static TraceAcc tr("lba_solve_h structure (before the first launch) / upload submit / LM loop incl. pair items / export+wait / write-back / "
                      "of the structure: edge pass + layout / CSR lists / of the LM loop: pair items + symbolic + upload");
   const double t_a = now_s();
@@ -2445,6 +2467,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
   // windows beyond the matrix-core kernels (more than 50 free poses): blocked LDL^T over many workgroups
   // (51 free poses still fit the row-pair kernel, which stays reachable through ORBG_LDLT_VALU; the blocked form is faster there: 2.7 vs 3.4 ms)
   const bool use_wide = nP >= 1 && (force_wide || (!use_mfma && !use_flow && (!rows_R || (nP > 50 && !getenv("ORBG_LDLT_VALU")))));
+  if (use_wide && n > kWideMaxUnknowns) return ORBG_CAP_EXCEEDED;      // (k_wide_back's x lives in LDS)
   if (use_wide && (rc = h->d_wide.reserve(2 * (size_t)n + 32))) return rc;
   if (use_mfma) {
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
@@ -2543,7 +2566,7 @@ extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile i
       if (use_mfma) {
         ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
       } else if (use_wide) {
-        launch_ldlt_wide(n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wide.p, st);
+        ORBG_HIP(launch_ldlt_wide(n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wide.p, st));
       } else if (use_flow) {
         hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
       } else if (rows_R) {
@@ -3013,7 +3036,16 @@ static inline bool lba_spin_until(Pred pred, double limit_us) {
   }
 }
 
-extern "C" int lba_solve_async(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
+extern "C" int lba_solve_h(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
+  StopRef s; s.i32 = stop_flag;
+  return lba_solve_impl(h, p, s, r);
+}
+extern "C" int lba_solve_hb(lba_handle* h, const lba_problem* p, const volatile uint8_t* stop_bool, lba_result* r) {
+  StopRef s; s.u8 = stop_bool;
+  return lba_solve_impl(h, p, s, r);
+}
+
+static int lba_solve_async_impl(lba_handle* h, const lba_problem* p, StopRef stop_flag, lba_result* r) {
   if (!h || !p || !r) return ORBG_BAD_ARG;
   std::unique_lock<std::mutex> lk(h->mu);
   if (h->job_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;
@@ -3025,7 +3057,7 @@ extern "C" int lba_solve_async(lba_handle* h, const lba_problem* p, const volati
           std::unique_lock<std::mutex> lk(h->mu);
           h->cv.wait(lk, [h]() { return h->quit || h->job_state.load(std::memory_order_acquire) == 1; });
         }
-        const lba_problem* p; const volatile int32_t* st; lba_result* r;
+        const lba_problem* p; StopRef st; lba_result* r;
         {
           std::unique_lock<std::mutex> lk(h->mu);
           if (h->quit) return;
@@ -3034,7 +3066,7 @@ extern "C" int lba_solve_async(lba_handle* h, const lba_problem* p, const volati
         }
         timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        const int rc = lba_solve_h(h, p, st, r);
+        const int rc = lba_solve_impl(h, p, st, r);
         clock_gettime(CLOCK_MONOTONIC, &t1);
         {
           std::unique_lock<std::mutex> lk(h->mu);
@@ -3052,6 +3084,14 @@ extern "C" int lba_solve_async(lba_handle* h, const lba_problem* p, const volati
   h->cv.notify_all();
   return ORBG_OK;
 }
+extern "C" int lba_solve_async(lba_handle* h, const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
+  StopRef s; s.i32 = stop_flag;
+  return lba_solve_async_impl(h, p, s, r);
+}
+extern "C" int lba_solve_async_b(lba_handle* h, const lba_problem* p, const volatile uint8_t* stop_bool, lba_result* r) {
+  StopRef s; s.u8 = stop_bool;
+  return lba_solve_async_impl(h, p, s, r);
+}
 extern "C" int lba_wait(lba_handle* h, double* solve_ms) {
   if (!h) return ORBG_BAD_ARG;
   // the caller is usually a few tens of microseconds early: spin, then sleep on the condition variable
@@ -3064,14 +3104,22 @@ extern "C" int lba_wait(lba_handle* h, double* solve_ms) {
   return h->job_status;
 }
 
-extern "C" int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
+static int lba_solve_once(const lba_problem* p, StopRef stop, lba_result* r) {
   if (!p) return ORBG_BAD_ARG;
   lba_handle* h = nullptr;
   int rc = lba_create(p->device, p->n_poses, p->n_points, p->n_edges, &h);
   if (rc) return rc;
-  rc = lba_solve_h(h, p, stop_flag, r);
+  rc = lba_solve_impl(h, p, stop, r);
   lba_destroy(h);
   return rc;
+}
+extern "C" int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
+  StopRef s; s.i32 = stop_flag;
+  return lba_solve_once(p, s, r);
+}
+extern "C" int lba_solve_b(const lba_problem* p, const volatile uint8_t* stop_bool, lba_result* r) {
+  StopRef s; s.u8 = stop_bool;
+  return lba_solve_once(p, s, r);
 }
 
 

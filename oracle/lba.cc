@@ -18,7 +18,9 @@
 #include "orb_oracle.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -269,7 +271,13 @@ struct Lba {
   double delta_mono, delta_stereo, dsqr_mono, dsqr_stereo;
   const volatile int32_t* stop;
   int trials_done = 0;        // LM trials evaluated so far: a negative flag value -k means "stop once k trials are done" (orbgpu.h)
-  bool terminate() const { if (!stop) return false; const int v = *stop; return v > 0 || (v < 0 && trials_done >= -v); }
+  bool past_precheck = false; // INT32_MIN: raised right after the check that precedes optimize() (the -k form with k = 0)
+  bool terminate() const {
+    if (!stop) return false;
+    const int v = *stop;
+    if (v == INT32_MIN) return past_precheck;
+    return v > 0 || (v < 0 && trials_done >= -v);
+  }
 
   void compute_errors() {
     for (int k = 0; k < p->n_edges; k++) {
@@ -488,6 +496,7 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
     for (int k = 0; k < p->n_edges; k++) { if (r->edge_chi2) r->edge_chi2[k] = 0; if (r->edge_depth_pos) r->edge_depth_pos[k] = 1; if (r->edge_outlier) r->edge_outlier[k] = 0; }
     return ORBG_OK;
   }
+  s.past_precheck = true;
 
   double lambda = -1, ni = 2;
   int nBad = 0;

@@ -4,11 +4,16 @@
 //   extractor + stereo Frame constructor, isInFrustum, the three tracking matchers, LocalBundleAdjustment (graph collection,
 //   vToErase, the 50 %-outlier early return, *pbStopFlag) and PoseOptimization.
 // Exit code 0 = every stage agrees; 3 = no GPU (the glue must fail loudly); anything else = a mismatch (printed).
+#include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <set>
+#include <thread>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "mock_orbslam3.hpp"
@@ -35,9 +40,40 @@ struct OracleOps {       // the same entry points over the CPU oracle: views ins
                         const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori, int32_t* matches, int* n) {
     return oracle_search_by_bow(&v, &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
   }
-  static int lba(const lba_problem& p, const volatile int32_t* stop, lba_result& r) { return oracle_lba_solve(&p, stop, &r); }
+  // (the oracle polls an int32: the bool is sampled -- the cases that raise it DURING the solve go through OracleAtTrialOps)
+  static int lba(const lba_problem& p, const volatile bool* stop, lba_result& r) {
+    volatile int32_t s = (stop && *stop) ? 1 : 0;
+    return oracle_lba_solve(&p, &s, &r);
+  }
   static int pose_opt(const pose_opt_problem& p, pose_opt_result& r) { return oracle_pose_optimize(&p, &r); }
 };
+
+// The product's entry points with a tap on the solver's report: LM iterations per round and the number of LM trials that
+// had been evaluated when the solve ended (= when it saw the flag, for an aborted one).
+struct GpuTapOps : od::GpuOps {
+  static int iters[2], trials, status;
+  static int lba(const lba_problem& p, const volatile bool* stop, lba_result& r) {
+    static double trace[3 * 64];
+    r.trace = trace; r.trace_cap = 64; r.trace_len = 0;
+    const int rc = od::GpuOps::lba(p, stop, r);
+    iters[0] = r.iters_round1; iters[1] = r.iters_round2; status = r.status; trials = 0;
+    for (int i = 0; i < r.trace_len; i++) trials += (int)trace[3 * i + 2];
+    r.trace = nullptr; r.trace_cap = r.trace_len = 0;
+    return rc;
+  }
+};
+int GpuTapOps::iters[2] = {0, 0}; int GpuTapOps::trials = 0; int GpuTapOps::status = 0;
+// The oracle stopped at a given poll point: "the flag reads as raised once k LM trials have been evaluated" (orbgpu.h)
+struct OracleAtTrialOps : OracleOps {
+  static int k, iters[2];
+  static int lba(const lba_problem& p, const volatile bool*, lba_result& r) {
+    volatile int32_t s = k == 0 ? INT32_MIN : -k;
+    const int rc = oracle_lba_solve(&p, &s, &r);
+    iters[0] = r.iters_round1; iters[1] = r.iters_round2;
+    return rc;
+  }
+};
+int OracleAtTrialOps::k = 0; int OracleAtTrialOps::iters[2] = {0, 0};
 
 // ------------------------------------------------------------------------------------------------ synthetic agent
 static unsigned g_seed = 1;
@@ -210,10 +246,12 @@ static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_
 }
 
 // ------------------------------------------------------------------------------------------------ local BA scenario
-struct BaOut { int status, num_fixed, erased; std::vector<float> poses, points; std::vector<int> normal_updates; };
+struct BaOut { int status, num_fixed, erased, change_index, locked_poses, locked_points; std::vector<float> poses, points; std::vector<int> normal_updates; };
 
+// raise_after_us >= 0: a second thread (Tracking calling LocalMapping::InterruptBA, S/LocalMapping.cc:381-386) sets the bool
+// that many microseconds after the call starts
 template <class Ops>
-static BaOut run_lba(int n_local, int n_far, int n_pts, double outlier_frac, bool stop, unsigned seed) {
+static BaOut run_lba(int n_local, int n_far, int n_pts, double outlier_frac, bool stop, unsigned seed, double raise_after_us = -1.0) {
   g_seed = seed;
   Agent A; BaOut o;
   const int P = n_local + n_far;
@@ -265,9 +303,19 @@ static BaOut run_lba(int n_local, int n_far, int n_pts, double outlier_frac, boo
     }
     A.points.push_back(std::move(mp));
   }
-  bool flag = stop;
-  o.status = od::LocalBundleAdjustment<Ops>(cur, &flag, &A.map, o.num_fixed, 0);
-  o.erased = 0;
+  bool mbAbortBA = stop;                                            // I/LocalMapping.h:155
+  std::thread tracking;
+  if (raise_after_us >= 0)
+    tracking = std::thread([&mbAbortBA, raise_after_us]() {
+      const auto t_end = std::chrono::steady_clock::now() + std::chrono::nanoseconds((long long)(raise_after_us * 1e3));
+      while (std::chrono::steady_clock::now() < t_end) {}
+      *const_cast<volatile bool*>(&mbAbortBA) = true;
+    });
+  o.status = od::LocalBundleAdjustment<Ops>(cur, &mbAbortBA, &A.map, o.num_fixed, 0);
+  if (tracking.joinable()) tracking.join();
+  o.erased = 0; o.change_index = A.map.GetMapChangeIndex(); o.locked_poses = o.locked_points = 0;
+  for (auto& kf : A.kfs) o.locked_poses += kf->n_locked_pose_writes;
+  for (auto& p : A.points) o.locked_points += p->n_locked_pos_writes;
   for (auto& kf : A.kfs) { o.poses.insert(o.poses.end(), kf->Tcw.ptr<float>(0), kf->Tcw.ptr<float>(0) + 16); for (auto* p : kf->mvpMapPoints) o.erased += p == nullptr; }
   for (auto& p : A.points) { o.points.insert(o.points.end(), p->mWorldPos.ptr<float>(0), p->mWorldPos.ptr<float>(0) + 3); o.normal_updates.push_back(p->n_normal_updates); }
   return o;
@@ -313,8 +361,49 @@ int main() {
       EXPECT(max_abs_diff(bg.poses, bc.poses) <= 1e-4f && max_abs_diff(bg.points, bc.points) <= 1e-4f, "state differs: poses %g points %g",
              max_abs_diff(bg.poses, bc.poses), max_abs_diff(bg.points, bc.points));
       EXPECT(bg.normal_updates == bc.normal_updates, "UpdateNormalAndDepth calls differ");
-      if (cs.want_status == LBA_APPLIED) EXPECT(bg.erased > 0 && bg.normal_updates[0] == 1, "an applied LBA erases outliers and refreshes the points");
-      else EXPECT(bg.erased == 0 && bg.normal_updates[0] == 0, "a rejected / aborted LBA must not touch the map");
+      if (cs.want_status == LBA_APPLIED) {
+        EXPECT(bg.erased > 0 && bg.normal_updates[0] == 1, "an applied LBA erases outliers and refreshes the points");
+        // SetPose(T, true) for every local keyframe, SetWorldPos(X, true) for every local point, then pMap->IncreaseChangeIndex()
+        // (S/Optimizer.cc:2327,2386,2397)
+        EXPECT(bg.change_index == 1 && bg.locked_poses >= cs.n_local - 2 && bg.locked_poses <= cs.n_local && bg.locked_points > 0,
+               "write-back: change index %d, %d locked pose writes, %d locked point writes", bg.change_index, bg.locked_poses, bg.locked_points);
+      } else {
+        EXPECT(bg.erased == 0 && bg.normal_updates[0] == 0, "a rejected / aborted LBA must not touch the map");
+        EXPECT(bg.change_index == 0 && bg.locked_poses == 0 && bg.locked_points == 0, "a rejected / aborted LBA must not bump the change index");
+      }
+      EXPECT(bg.change_index == bc.change_index && bg.locked_poses == bc.locked_poses && bg.locked_points == bc.locked_points, "write-back calls differ");
+    }
+    // ---- InterruptBA() DURING the solve: Tracking sets LocalMapping::mbAbortBA -- the very bool behind pbStopFlag -- from a
+    // second thread at an arbitrary moment.  Wherever the product saw it (it reports how many LM trials it had evaluated),
+    // the oracle stopped at that same poll point must give the same iteration counts, status and written-back state.
+    {
+      std::set<std::pair<int, int>> seen;
+      const BaOut full = run_lba<GpuTapOps>(8, 4, 500, 0.03, false, 99);
+      const int full_it[2] = {GpuTapOps::iters[0], GpuTapOps::iters[1]};
+      int n_cut = 0;
+      for (int rep = 0; rep < 36; rep++) {
+        const BaOut bg = run_lba<GpuTapOps>(8, 4, 500, 0.03, false, 99, 25.0 * rep);
+        const int it0 = GpuTapOps::iters[0], it1 = GpuTapOps::iters[1], k = GpuTapOps::trials;
+        seen.insert({it0, it1});
+        BaOut bc;
+        if (bg.status == LBA_ABORTED_BEFORE_OPT) {
+          bc = run_lba<OracleOps>(8, 4, 500, 0.03, true, 99);
+        } else {
+          OracleAtTrialOps::k = k;
+          bc = run_lba<OracleAtTrialOps>(8, 4, 500, 0.03, false, 99);
+          EXPECT(it0 == OracleAtTrialOps::iters[0] && it1 == OracleAtTrialOps::iters[1], "flag after %d us, seen after %d trials: iterations %d+%d vs oracle %d+%d",
+                 25 * rep, k, it0, it1, OracleAtTrialOps::iters[0], OracleAtTrialOps::iters[1]);
+        }
+        n_cut += it0 != full_it[0] || it1 != full_it[1];
+        EXPECT(bg.status == bc.status && bg.erased == bc.erased && bg.change_index == bc.change_index, "flag after %d us: status %d vs %d, erased %d vs %d",
+               25 * rep, bg.status, bc.status, bg.erased, bc.erased);
+        EXPECT(max_abs_diff(bg.poses, bc.poses) <= 1e-4f && max_abs_diff(bg.points, bc.points) <= 1e-4f, "flag after %d us (%d trials): state differs: poses %g points %g",
+               25 * rep, k, max_abs_diff(bg.poses, bc.poses), max_abs_diff(bg.points, bc.points));
+      }
+      std::printf("InterruptBA during the solve: %zu distinct (round 1, round 2) iteration counts over 36 delays, %d solves cut short (uninterrupted: %d+%d)\n",
+                  seen.size(), n_cut, full_it[0], full_it[1]);
+      EXPECT(seen.size() >= 2 && n_cut >= 1, "the sweep never interrupted a running solve");
+      (void)full;
     }
     if (g_fail) { std::printf("dropin parity: %d mismatches\n", g_fail); return 1; }
     std::printf("dropin parity ok\n");

@@ -45,7 +45,8 @@ class MapPoint {
   Mat GetWorldPos() const { return mWorldPos; }
   Mat GetNormal() const { return mNormalVector; }
   Mat GetDescriptor() const { return mDescriptor; }
-  void SetWorldPos(const Mat& X) { mWorldPos = X; }
+  int n_locked_pos_writes = 0;
+  void SetWorldPos(const Mat& X, bool bLock = false, bool /*bLockSend*/ = false) { mWorldPos = X; n_locked_pos_writes += bLock; }   // I/MapPoint.h:126
   std::map<KeyFrame*, std::tuple<int, int>> GetObservations() const { return mObservations; }
   void EraseObservation(KeyFrame* kf) { if (mObservations.erase(kf)) nObs--; }
   void UpdateNormalAndDepth() { n_normal_updates++; }
@@ -55,6 +56,9 @@ class Map {
  public:
   long unsigned mnInitKFid = 0; bool mbInertial = false;
   std::mutex mMutexMapUpdate;
+  int mnMapChange = 0;
+  void IncreaseChangeIndex() { mnMapChange++; }                       // I/Map.h:100-101
+  int GetMapChangeIndex() const { return mnMapChange; }
   long unsigned GetInitKFid() const { return mnInitKFid; }
   bool IsInertial() const { return mbInertial; }
 };
@@ -76,7 +80,8 @@ class KeyFrame {
   std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() const { return mvpOrderedConnectedKeyFrames; }
   std::vector<MapPoint*> GetMapPointMatches() const { return mvpMapPoints; }
   Mat GetPose() const { return Tcw; }
-  void SetPose(const Mat& T) { Tcw = T; }
+  int n_locked_pose_writes = 0;
+  void SetPose(const Mat& T, bool bLock = false, bool /*bLockSend*/ = false) { Tcw = T; n_locked_pose_writes += bLock; }          // I/KeyFrame.h:276
   void EraseMapPointMatch(MapPoint* mp) { for (auto& p : mvpMapPoints) if (p == mp) p = nullptr; }
 };
 

@@ -14,7 +14,7 @@ def _build(name, with_oracle=False):
     lib_dir = os.path.join(ROOT, "multi_orbslam3_amd")
     exe = os.path.join(CPP, name)
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CPP,
-           os.path.join(CPP, name + ".cpp"), "-o", exe, "-L", lib_dir, "-lorbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib",
+           os.path.join(CPP, name + ".cpp"), "-o", exe, "-pthread", "-L", lib_dir, "-lorbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib",
            "-L/opt/rocm/lib"]
     if with_oracle:
         from oracle import binding as ob
@@ -49,7 +49,9 @@ def test_adapters_run_on_gpu():
 @pytest.mark.gpu
 def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
     """Extractor / stereo Frame constructor, isInFrustum, SearchByProjection x2, SearchByBoW, PoseOptimization and
-    LocalBundleAdjustment (graph collection, vToErase, 50 %-outlier early return, pbStopFlag) with the reference's signatures."""
+    LocalBundleAdjustment (graph collection, vToErase, 50 %-outlier early return, pbStopFlag raised before AND -- by a second
+    thread, through the reference's own bool -- during the solve, SetPose / SetWorldPos lock flags, Map change index) with the
+    reference's signatures."""
     exe = _build("dropin_parity", with_oracle=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "dropin parity ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-1000:])
