@@ -185,6 +185,19 @@ int orbx_frame_stereo_dev(orbx_handle* h, orbm_frame* frame, const orbm_frame_vi
 int orbx_frame_stereo_dev_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* d_img_left,
                                  const uint8_t* d_img_right, int width, int height, int stride, float bf, float b);
 int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_right);
+/* The two-halves constructor with HOST images (cv::Mat data, any host memory): Frame::Frame(imLeft, imRight, ...)
+ * (S/Frame.cc:71-172) as Tracking::GrabImageStereo (S/Tracking.cc:1014-1083) receives them.  _submit packs the rows into the
+ * handle's pinned staging slot, enqueues one copy kernel (host -> HBM over PCIe, ordered before the pyramid on the handle's
+ * stream, overlapping the kernels of other handles) and the constructor chain; _wait is orbx_frame_stereo_dev_wait.  The
+ * images may be reused as soon as _submit returns with flags == 0.  With ORBX_SUBMIT_ASYNC the packing and the launches are
+ * done by the library's ingest thread (one per process, created by the first such call; it inherits that caller's CPU
+ * affinity): the call returns at once and the images must stay valid until _wait.  Typical use: the image grabber / camera
+ * thread submits frame t+1 (flags 0) while Tracking works on frame t, or Tracking itself submits with ORBX_SUBMIT_ASYNC.
+ * One submission per handle at a time (ORBG_BAD_ARG otherwise). */
+#define ORBX_SUBMIT_ASYNC 1
+int orbx_frame_stereo_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
+                             const uint8_t* img_right, int width, int height, int stride, float bf, float b, int flags);
+int orbx_frame_stereo_wait(orbx_handle* h, int* n_left, int* n_right);
 /* Grid as CSR for tests: cell id = ix*48+iy, items in keypoint-index order (Appendix E-2). */
 int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start /*64*48+1*/, int32_t* cell_items /*n*/);
 

@@ -122,6 +122,19 @@ class ORBextractor:
                                                    C.c_void_p(d_right), width, height, stride, C.c_float(bf), C.c_float(b))
         capi.check(rc, "orbx_frame_stereo_dev_submit")
 
+    def frame_stereo_submit(self, frame, fv, im_left, im_right, bf, b, async_ingest=False):
+        """First half of the Frame constructor with HOST images (orbx_frame_stereo_submit): rows packed into the handle's
+        pinned staging slot, one copy kernel + the constructor chain enqueued; collect with frame_stereo_dev_wait().  With
+        async_ingest the packing and the launches run on the library's ingest thread and the call returns at once (the
+        images are kept alive here until the wait)."""
+        assert im_left.dtype == np.uint8 and im_right.dtype == np.uint8 and im_left.shape == im_right.shape
+        assert im_left.strides[1] == 1 and im_right.strides == im_left.strides
+        self._pending = (frame, fv, im_left, im_right)
+        rc = self.lib.orbx_frame_stereo_submit(self.h, frame.h if frame is not None else None, C.byref(fv), C.c_void_p(im_left.ctypes.data),
+                                               C.c_void_p(im_right.ctypes.data), im_left.shape[1], im_left.shape[0], im_left.strides[0],
+                                               C.c_float(bf), C.c_float(b), 1 if async_ingest else 0)
+        capi.check(rc, "orbx_frame_stereo_submit")
+
     def frame_stereo_dev_wait(self):
         nl, nr = C.c_int(0), C.c_int(0)
         capi.check(self.lib.orbx_frame_stereo_dev_wait(self.h, C.byref(nl), C.byref(nr)), "orbx_frame_stereo_dev_wait")

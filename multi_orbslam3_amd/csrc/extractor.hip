@@ -1541,6 +1541,11 @@ struct orbx_handle {
   int taps_variant = 0;             // 0 / 1: one of the two compiled-in blur kernels, 2: run-time taps (orient_desc_wave)
   int prof_kernel = 0;              // which kernel of the chain the level-1 event pair brackets: ORBX_PROF_*
   struct CtorGraph* cgraph = nullptr;          // captured kernel chain of the device-resident Frame constructor
+  // host images (orbx_frame_stereo_submit / orbx_frame_stereo / orbx_extract*): one pinned staging slot per handle -- a handle
+  // has one submission in flight, and the slot is free again when that submission has been waited for
+  PinnedBuf<uint8_t> h_img;
+  std::atomic<int> ingest_state{0};            // 0 idle, 1 handed to the ingest thread, 2 submitted by it (ingest_rc valid)
+  int ingest_rc = 0;
 };
 static void delete_pending(struct ExtractPending* p);   // (defined behind the type)
 
@@ -1816,9 +1821,10 @@ static void ctor_graph_free(struct CtorGraph* g);
 extern "C" int orbx_destroy(orbx_handle* h) {
   if (!h) return ORBG_BAD_ARG;
   (void)hipSetDevice(h->device);
+  while (h->ingest_state.load(std::memory_order_acquire) == 1) std::this_thread::yield();   // an asynchronous submission is being enqueued
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   ctor_graph_free(h->cgraph);
-  h->d_pyr.release(); h->d_img.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_tower_x.release(); h->d_tower_y.release(); h->d_cells.release();
+  h->d_pyr.release(); h->d_img.release(); h->h_img.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_tower_x.release(); h->d_tower_y.release(); h->d_cells.release();
   h->d_slots.release(); h->d_counts.release(); h->hdr.release(); h->cand.release(); h->sel.release();
   h->d_kps.release(); h->d_desc.release(); h->h_kps.release(); h->h_desc.release();
   h->d_uright.release(); h->d_depth.release(); h->d_sad.release(); h->h_stereo.release();
@@ -2240,9 +2246,41 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   return ORBG_OK;
 }
 
-static int upload_image(orbx_handle* h, int slot, const uint8_t* img, int w, int hgt, int stride) {
-  // pageable host -> device; rows are packed on the device (stride = w)
-  ORBG_HIP(hipMemcpy2DAsync(h->d_img.p + (size_t)slot * w * hgt, w, img, stride, w, hgt, hipMemcpyHostToDevice, h->stream));
+// Host images reach the device through the handle's pinned staging slot: the rows are packed into it by the calling (or the
+// ingest) thread and ONE copy kernel on the extractor's stream moves the slot into HBM -- every PCIe read of the transfer is in
+// flight at once, the copy is ordered before the pyramid kernel by the stream, and it overlaps whatever other streams run
+// (the runtime's pageable-memory copy stages through its own buffers synchronously: ~35 us of the calling thread for two
+// 640 x 480 images, and its blit kernel takes ~26 us for what this kernel moves in a few).  ORBG_IMG_RUNTIME_COPY=1 keeps
+// the runtime's path (hipMemcpy2DAsync from the caller's memory).
+__global__ __launch_bounds__(256) void img_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+static const bool g_img_runtime_copy = getenv("ORBG_IMG_RUNTIME_COPY") != nullptr;
+
+// a submitted Frame constructor owns the handle (stream, staging slot, pyramid, feature buffers) until it has been waited for
+static inline bool handle_busy(const orbx_handle* h) {
+  return h->ingest_state.load(std::memory_order_acquire) != 0 || (h->pending && (h->pending->active || h->pending->finished));
+}
+
+// images[c] for c < n_img -> h->d_img (packed rows, image c at c * w * hgt)
+static int stage_images(orbx_handle* h, const uint8_t* const* images, int n_img, int w, int hgt, int stride) {
+  const size_t per = (size_t)w * hgt, total = per * n_img;
+  if (g_img_runtime_copy) {
+    for (int c = 0; c < n_img; c++)
+      ORBG_HIP(hipMemcpy2DAsync(h->d_img.p + c * per, w, images[c], stride, w, hgt, hipMemcpyHostToDevice, h->stream));
+    return ORBG_OK;
+  }
+  int rc;
+  if ((rc = h->h_img.reserve(total + 16)) || (rc = h->d_img.reserve(total + 16))) return rc;
+  for (int c = 0; c < n_img; c++) {
+    uint8_t* dst = h->h_img.h + c * per;
+    if (stride == w) memcpy(dst, images[c], per);
+    else for (int y = 0; y < hgt; y++) memcpy(dst + (size_t)y * w, images[c] + (size_t)y * stride, w);
+  }
+  const int n16 = (int)((total + 15) / 16);
+  hipLaunchKernelGGL(img_upload_kernel, dim3((n16 + 255) / 256), dim3(256), 0, h->stream, reinterpret_cast<const uint4*>(h->h_img.d),
+                     reinterpret_cast<uint4*>(h->d_img.p), n16);
   return ORBG_OK;
 }
 
@@ -2251,10 +2289,11 @@ extern "C" int orbx_extract(orbx_handle* h, int cam, const uint8_t* img, int wid
   if (!h || !n) return ORBG_BAD_ARG;
   if (!img || width <= 0 || height <= 0) return ORBG_EMPTY;     // S/ORBextractor.cc:1072-1073
   if (cam != 0 || stride < width) return ORBG_BAD_ARG;          // one camera per call goes through slot 0
+  if (handle_busy(h)) return ORBG_BAD_ARG;
   int rc = select_device(h->device);
   if (rc) return rc;
   if ((rc = setup_geometry(h, width, height))) return rc;
-  if ((rc = upload_image(h, 0, img, width, height, stride))) return rc;
+  if ((rc = stage_images(h, &img, 1, width, height, stride))) return rc;
   const int lap[2][2] = {{lap0, lap1}, {0, 0}};
   orbx_keypoint* ko[2] = {kps, nullptr};
   uint8_t* dout[2] = {desc, nullptr};
@@ -2280,12 +2319,12 @@ extern "C" int orbx_extract_stereo(orbx_handle* h, const uint8_t* img_left, cons
                                    orbx_keypoint* kps_right, uint8_t* desc_right, int cap_right, int* n_right) {
   if (!h || h->cfg.n_cams != 2) return ORBG_BAD_ARG;
   if (!img_left || !img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
-  if (stride < width) return ORBG_BAD_ARG;
+  if (stride < width || handle_busy(h)) return ORBG_BAD_ARG;
   int rc = select_device(h->device);
   if (rc) return rc;
   if ((rc = setup_geometry(h, width, height))) return rc;
-  if ((rc = upload_image(h, 0, img_left, width, height, stride))) return rc;
-  if ((rc = upload_image(h, 1, img_right, width, height, stride))) return rc;
+  const uint8_t* const both[2] = {img_left, img_right};
+  if ((rc = stage_images(h, both, 2, width, height, stride))) return rc;
   return extract_stereo_impl(h, h->d_img.p, h->d_img.p + (size_t)width * height, width, height, width, kps_left, desc_left,
                              cap_left, n_left, kps_right, desc_right, cap_right, n_right);
 }
@@ -2309,15 +2348,15 @@ static int frame_stereo_impl(orbx_handle* h, orbm_frame* frame, const orbm_frame
   if (!h || h->cfg.n_cams != 2 || !n_left) return ORBG_BAD_ARG;
   if (frame && !view) return ORBG_BAD_ARG;
   if (!img_left || !img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
-  if (stride < width) return ORBG_BAD_ARG;
+  if (stride < width || handle_busy(h)) return ORBG_BAD_ARG;
   int rc = select_device(h->device);
   if (rc) return rc;
   const uint8_t* d_img_left = img_left;
   const uint8_t* d_img_right = img_right;
   if (!on_device) {
     if ((rc = setup_geometry(h, width, height))) return rc;
-    if ((rc = upload_image(h, 0, img_left, width, height, stride))) return rc;
-    if ((rc = upload_image(h, 1, img_right, width, height, stride))) return rc;
+    const uint8_t* const both[2] = {img_left, img_right};
+    if ((rc = stage_images(h, both, 2, width, height, stride))) return rc;
     d_img_left = h->d_img.p;
     d_img_right = h->d_img.p + (size_t)width * height;
     stride = width;
@@ -2343,17 +2382,23 @@ extern "C" int orbx_frame_stereo_dev(orbx_handle* h, orbm_frame* frame, const or
 
 // Frame constructor split in two so that the caller can overlap it with work on other streams (tracking of the previous
 // frame): submit enqueues the whole chain and returns, wait completes it.
-extern "C" int orbx_frame_stereo_dev_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* d_img_left,
-                                            const uint8_t* d_img_right, int width, int height, int stride, float bf, float b) {
-  if (!h || h->cfg.n_cams != 2) return ORBG_BAD_ARG;
-  if (frame && !view) return ORBG_BAD_ARG;
-  if (!d_img_left || !d_img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
-  if (stride < width) return ORBG_BAD_ARG;
+static int frame_submit_impl(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
+                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b) {
   int rc = select_device(h->device);
   if (rc) return rc;
   if (!h->pending) h->pending = new ExtractPending();
   ExtractPending& P = *h->pending;
   if (P.active || P.finished) return ORBG_BAD_ARG;      // the previous submission has not been collected
+  const uint8_t* d_img_left = img_left;
+  const uint8_t* d_img_right = img_right;
+  if (!on_device) {
+    if ((rc = setup_geometry(h, width, height))) return rc;
+    const uint8_t* const both[2] = {img_left, img_right};
+    if ((rc = stage_images(h, both, 2, width, height, stride))) return rc;
+    d_img_left = h->d_img.p;
+    d_img_right = h->d_img.p + (size_t)width * height;
+    stride = width;
+  }
   PostOps post;
   post.stereo = true; post.bf = bf; post.b = b; post.frame = frame; post.view = view;
   const int lap[2][2] = {{0, 0}, {0, 0}};
@@ -2368,10 +2413,115 @@ extern "C" int orbx_frame_stereo_dev_submit(orbx_handle* h, orbm_frame* frame, c
   return ORBG_OK;
 }
 
-extern "C" int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_right) {
-  if (!h || !h->pending || !(h->pending->active || h->pending->finished)) return ORBG_BAD_ARG;
-  int rc = select_device(h->device);
+extern "C" int orbx_frame_stereo_dev_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* d_img_left,
+                                            const uint8_t* d_img_right, int width, int height, int stride, float bf, float b) {
+  if (!h || h->cfg.n_cams != 2) return ORBG_BAD_ARG;
+  if (frame && !view) return ORBG_BAD_ARG;
+  if (!d_img_left || !d_img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
+  if (stride < width) return ORBG_BAD_ARG;
+  if (h->ingest_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;
+  return frame_submit_impl(h, frame, view, d_img_left, d_img_right, true, width, height, stride, bf, b);
+}
+
+// ---- the ingest thread: ONE per process, shared by every extractor handle.  A camera driver / image-grabber thread of a
+// deployment plays this role itself (it calls orbx_frame_stereo_submit with flags 0 when a stereo pair arrives); for callers
+// that hand images over on their tracking thread, ORBX_SUBMIT_ASYNC moves the staging copy (~0.6 MB at 640 x 480) and the
+// launches of the constructor chain off that thread.  The thread is created by the first asynchronous submission and
+// inherits that caller's CPU affinity.
+namespace {
+struct IngestJob {
+  orbx_handle* h; orbm_frame* frame; orbm_frame_view view; bool has_view; const uint8_t* L; const uint8_t* R; int w, hgt, stride; float bf, b;
+};
+struct IngestWorker {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<IngestJob> q;
+  std::atomic<int> queued{0};
+  bool quit = false;
+  std::thread th;
+  static bool spin_ok() { static const bool off = getenv("ORBG_NO_POLL") != nullptr; return !off; }
+  void run() {
+    for (;;) {
+      // the next pair usually arrives within a frame time: spin for a while, then sleep
+      bool have = false;
+      if (spin_ok()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+          if (queued.load(std::memory_order_acquire) > 0) { have = true; break; }
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+          if ((spins & 0xFF) == 0xFF && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+        }
+      }
+      IngestJob job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!have) cv.wait(lk, [this]() { return quit || !q.empty(); });
+        if (quit && q.empty()) return;
+        if (q.empty()) continue;
+        job = q.front();
+        q.erase(q.begin());
+        queued.fetch_sub(1, std::memory_order_acq_rel);
+      }
+      job.h->ingest_rc = frame_submit_impl(job.h, job.frame, job.has_view ? &job.view : nullptr, job.L, job.R, false, job.w, job.hgt,
+                                           job.stride, job.bf, job.b);
+      job.h->ingest_state.store(2, std::memory_order_release);
+    }
+  }
+  void push(const IngestJob& j) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      if (!th.joinable()) th = std::thread([this]() { run(); });
+      q.push_back(j);
+      queued.fetch_add(1, std::memory_order_acq_rel);
+    }
+    cv.notify_one();
+  }
+  ~IngestWorker() {
+    { std::unique_lock<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+IngestWorker& ingest_worker() { static IngestWorker w; return w; }
+}  // namespace
+
+extern "C" int orbx_frame_stereo_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
+                                        const uint8_t* img_right, int width, int height, int stride, float bf, float b, int flags) {
+  if (!h || h->cfg.n_cams != 2) return ORBG_BAD_ARG;
+  if (frame && !view) return ORBG_BAD_ARG;
+  if (!img_left || !img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
+  if (stride < width || width > h->cfg.max_width || height > h->cfg.max_height) return ORBG_BAD_ARG;
+  if (h->ingest_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;       // one submission per handle at a time
+  if (h->pending && (h->pending->active || h->pending->finished)) return ORBG_BAD_ARG;
+  if (!(flags & ORBX_SUBMIT_ASYNC)) return frame_submit_impl(h, frame, view, img_left, img_right, false, width, height, stride, bf, b);
+  int rc = select_device(h->device);                    // a missing device is reported by the call, not by the wait
   if (rc) return rc;
+  IngestJob j{h, frame, orbm_frame_view{}, view != nullptr, img_left, img_right, width, height, stride, bf, b};
+  if (view) j.view = *view;
+  h->ingest_state.store(1, std::memory_order_release);
+  ingest_worker().push(j);
+  return ORBG_OK;
+}
+
+extern "C" int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_right) {
+  if (!h) return ORBG_BAD_ARG;
+  int rc;
+  if (h->ingest_state.load(std::memory_order_acquire) != 0) {
+    // handed to the ingest thread: wait until it has enqueued the chain (it is usually done long before)
+    for (unsigned spins = 0; h->ingest_state.load(std::memory_order_acquire) != 2; spins++) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+      if (!IngestWorker::spin_ok() || (spins & 0xFFFF) == 0xFFFF) std::this_thread::yield();
+    }
+    rc = h->ingest_rc;
+    h->ingest_state.store(0, std::memory_order_release);
+    if (rc) return rc;
+  }
+  if (!h->pending || !(h->pending->active || h->pending->finished)) return ORBG_BAD_ARG;
+  if ((rc = select_device(h->device))) return rc;
   ExtractPending& P = *h->pending;
   if (P.active) {
     P.active = false;
@@ -2383,6 +2533,7 @@ extern "C" int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_ri
   if (n_right) *n_right = P.n_res[1];
   return ORBG_OK;
 }
+extern "C" int orbx_frame_stereo_wait(orbx_handle* h, int* n_left, int* n_right) { return orbx_frame_stereo_dev_wait(h, n_left, n_right); }
 
 extern "C" int orbx_frame_stereo(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
                                  const uint8_t* img_right, int width, int height, int stride, float bf, float b,

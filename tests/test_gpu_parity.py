@@ -307,6 +307,57 @@ def test_frame_constructor_submit_wait_pipelines_across_frames(scene):
             hip.hipFree(d)
 
 
+@pytest.mark.parametrize("async_ingest", [False, True])
+def test_frame_constructor_submit_with_host_images(scene, async_ingest):
+    """orbx_frame_stereo_submit / _wait: the pipelined constructor fed with HOST images (what Tracking::GrabImageStereo holds,
+    S/Tracking.cc:1014-1083) through the pinned staging slot + copy kernel -- on the calling thread and on the library's ingest
+    thread.  Features, stereo matches and grid equal the oracle's for every frame; images with a row stride; the staging slot
+    is private to a handle, so with flags == 0 the caller's image may be overwritten right after the submit."""
+    cam = scene.cam
+    bf, bb = float(cam["bf"]), float(cam["b"])
+    ids = [3, 4, 5, 6, 7]
+    orc = [helpers.oracle_stereo_frame(scene, i) for i in ids]
+    ex = [api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2) for _ in range(2)]
+    Fr = [api.Frame(), api.Frame()]
+    fvs = [helpers.frame_view_of(scene, fr) for fr in orc]
+
+    def host_pair(t):
+        fr = orc[t]
+        if t % 2 == 1:                                   # odd frames: rows inside a wider buffer (cv::Mat ROI: stride > width)
+            big = [np.full((480, 704), 77, np.uint8), np.full((480, 704), 78, np.uint8)]
+            big[0][:, 32:672] = fr["L"]; big[1][:, 32:672] = fr["R"]
+            return big[0][:, 32:672], big[1][:, 32:672]
+        return np.array(fr["L"], np.uint8, order="C"), np.array(fr["R"], np.uint8, order="C")
+
+    with pytest.raises(Exception):
+        ex[0].frame_stereo_dev_wait()                                   # nothing submitted
+    pair = host_pair(0)
+    ex[0].frame_stereo_submit(Fr[0], fvs[0][0], pair[0], pair[1], bf, bb, async_ingest=async_ingest)
+    with pytest.raises(Exception):
+        ex[0].extract_stereo(orc[0]["L"], orc[0]["R"])                  # the handle is busy until the wait
+    with pytest.raises(Exception):
+        ex[0].frame_stereo_submit(Fr[0], fvs[0][0], pair[0], pair[1], bf, bb, async_ingest=async_ingest)
+    for t in range(len(ids)):
+        cur = t & 1
+        n, nr = ex[cur].frame_stereo_dev_wait()
+        if t + 1 < len(ids):
+            pair = host_pair(t + 1)
+            ex[cur ^ 1].frame_stereo_submit(Fr[cur ^ 1], fvs[t + 1][0], pair[0], pair[1], bf, bb, async_ingest=async_ingest)
+            if not async_ingest:
+                pair[0][...] = 0; pair[1][...] = 255                    # the rows were packed into the staging slot by the call
+        fr, (fv, keep) = orc[t], fvs[t]
+        assert n == len(fr["kps"]) and nr == len(fr["kps_r"]), (t, n, nr)
+        kd, dd = Fr[cur].download()[:2]
+        assert np.array_equal(kd, fr["kps"]) and np.array_equal(dd, fr["desc"])
+        gs, gi = Fr[cur].grid()
+        os_, oi = ob.build_grid(fv)
+        assert np.array_equal(gs, os_) and np.array_equal(gi, oi)
+    # the synchronous host-image constructor goes through the same staging path
+    n, nr, kl, dl, ur, dp = ex[0].frame_stereo(Fr[0], fvs[2][0], orc[2]["L"], orc[2]["R"], bf, bb)
+    assert np.array_equal(kl[:n], orc[2]["kps"]) and np.array_equal(dl[:n], orc[2]["desc"])
+    assert np.array_equal(ur[:n], orc[2]["uright"]) and np.array_equal(dp[:n], orc[2]["depth"])
+
+
 def test_frame_constructor_as_an_executable_graph():
     """ORBG_CTOR_GRAPH=1: the constructor's kernel chain is captured into a hipGraph the second time a handle repeats a
     configuration and replayed from then on (only the image pointers are patched).  Same test as above, eight frames, in a
