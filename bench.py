@@ -2,7 +2,10 @@
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric):
 "tracking+localBA frames/sec per agent, 640x480 stereo, 1/2/4/8 agents".
 
-One STEP = one frame of one agent through the hot path, inputs already resident in HBM:
+One STEP = one frame of one agent through the hot path.  The frame's two images are HOST arrays (what Tracking::GrabImageStereo
+holds, S/Tracking.cc:1014-1083): the pipelined Frame constructor packs them into pinned staging and copies them to HBM on
+the extractor's stream while the previous frame is tracked (`value`; --device-images gives the accounting with images already
+resident in HBM, reported as value_device_images):
   [Frame ctor: extract L+R (pyramid, FAST, quad-tree, angle, rBRIEF) -> ComputeStereoMatches -> feature grid]
   ->  SearchByProjection(cur, last)  ->  SearchLocalPoints (isInFrustum + SearchByProjection over the local map)
 and, every FRAMES_PER_KF-th step (a keyframe), one Local Bundle Adjustment plus the upload of the refreshed local map.
@@ -15,9 +18,11 @@ lba_wait), concurrently with the frame loop, exactly as the reference runs Local
 single-GPU part: 1280x720, 2000 features, 50-KF local BA) or mono (the monocular agents of configs[4]: host image ->
 ORBextractor::operator() with the lapping area of S/Frame.cc:289 -> Frame upload -> the two searches -> mono-edge LBA).
 
-Besides `value` the line carries value_host_images (the Frame constructor takes host images: H2D included) and
-value_with_pose_opt (the two PoseOptimization calls of Tracking per frame included), each from a shorter timed region,
-p50 / p95 of the per-step times, the measured device-copy bandwidth, and the host CPU.
+Besides `value` the line carries value_device_images (images already in HBM), value_sync_ctor_host_images (the constructor an
+UNCHANGED Tracking thread calls: synchronous, host images), value_with_pose_opt (the two PoseOptimization calls of Tracking
+per frame included) and fps_formula (BASELINE.md's 1/(t_frontend + t_LBA/K)), each from a shorter timed region,
+p50 / p95 of the per-step times, the measured device-copy bandwidth, and the host CPU.  An internal untimed pre-warm
+(>= 200 steps and >= 50 ms, `prewarm_steps`) precedes --warmup so that a short driver run is at steady state.
 
 Agents shard one per GPU with no data-path collective -> weak scaling; `value` is the
 aggregate over all ranks.  Launch for N>1:
@@ -42,36 +47,44 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (dense); measured
 #                                 one per 66 cycles per SIMD = 31 FLOP/clk/SIMD (tools/micro/mfma_f64_latency.hip) = 76 TF
 
 CONFIGS = {
-    "C2": dict(W=640, H=480, stereo=True, n_features=1000, lba=(20, 10, 2000), mono_frac=0.0, frame_cap=4096, map_cap=16384,
+    "C2": dict(W=640, H=480, stereo=True, n_features=1000, lba=(20, 10, 2000), mono_frac=0.0, frame_cap=4096, map_cap=32768, local_kfs=20,
                label="C2: 1 client stereo 640x480 synthetic, 1000 ORB feat/frame, 20-KF local BA window "
                      "(20 free + 10 fixed KFs, 2000 points)"),
-    "C4": dict(W=1280, H=720, stereo=True, n_features=2000, lba=(50, 20, 8000), mono_frac=0.0, frame_cap=8192, map_cap=32768,
+    "C4": dict(W=1280, H=720, stereo=True, n_features=2000, lba=(50, 20, 8000), mono_frac=0.0, frame_cap=8192, map_cap=131072, local_kfs=50,
                label="C4 (single-GPU part of configs[3]): 1 client stereo 1280x720 synthetic, 2000 ORB feat/frame, 50-KF local BA "
                      "window (50 free + 20 fixed KFs, 8000 points); visual edges only (IMU types are out of scope)"),
-    "mono": dict(W=640, H=480, stereo=False, n_features=1000, lba=(20, 10, 2000), mono_frac=1.0, frame_cap=4096, map_cap=16384,
+    "mono": dict(W=640, H=480, stereo=False, n_features=1000, lba=(20, 10, 2000), mono_frac=1.0, frame_cap=4096, map_cap=32768, local_kfs=20,
                  label="mono agent of configs[4]: 1 client mono 640x480 synthetic (host image -> operator() with lapping area "
                        "{0,1000}, S/Frame.cc:289), 1000 ORB feat/frame, 20-KF local BA of monocular edges"),
 }
 
 
 def build_workload(scene, cfg, n_frames, api, views, synth, device):
-    """Run the pipeline once per distinct frame to cache the host-side views a Tracking thread would hold
-    (last-frame view, local-map chunks, pose guesses).  Not timed."""
+    """Run the pipeline once per distinct frame to cache the host-side views a Tracking thread would hold (last-frame view,
+    pose guesses) and to build the map a LocalMapping thread would have built: every FRAMES_PER_KF-th frame is a keyframe
+    that adds map points for its features with depth that did NOT match a point of the local map of the keyframes before it
+    (SearchLocalPoints with the true pose -- what Tracking + LocalMapping::CreateNewMapPoints leave behind).  Not timed."""
     import torch
     cam = scene.cam
     W, H = scene.W, scene.H
+    p = scene.frame_view_params()
     ex = api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, W, H, n_cams=2 if cfg["stereo"] else 1, device=device)
     rng = np.random.RandomState(1234)
+    F = api.Frame(cfg["frame_cap"], device)
+    LM = api.LocalMap(cfg["map_cap"], device)
+    m_dedupe = api.ORBmatcher(0.8, True, device)
+    fv0, _keep0 = views.frame_view(np.zeros(1, capi_dtype()), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
     frames, imgs, host_imgs = [], [], []
+    kf_chunks = {}
     for k in range(n_frames):
         L, R, Tcw = scene.stereo_pair(k)
-        host_imgs.append((L, R))
+        host_imgs.append((np.ascontiguousarray(L), np.ascontiguousarray(R)))
         if cfg["stereo"]:
             dL = torch.from_numpy(L).to("cuda:%d" % device)
             dR = torch.from_numpy(R).to("cuda:%d" % device)
             imgs.append((dL, dR))
-            nl, nr, kl, dl = ex.extract_stereo_dev(dL.data_ptr(), dR.data_ptr(), W, H, W, download_left=True)
-            ur, dp = ex.ComputeStereoMatches(float(cam["bf"]), float(cam["b"]), n_left=nl)
+            nl, nr, kl, dl, ur, dp = ex.frame_stereo_dev(F, fv0, dL.data_ptr(), dR.data_ptr(), W, H, W, float(cam["bf"]), float(cam["b"]),
+                                                         download=True)
             kl, dl, ur, dp = kl.copy(), dl.copy(), ur.copy(), dp.copy()
         else:
             imgs.append((None, None))
@@ -79,21 +92,70 @@ def build_workload(scene, cfg, n_frames, api, views, synth, device):
             nl = len(kl)
             dp = scene.depth_at(kl, Tcw)             # a mono agent's map comes from triangulation; here: scene geometry
             ur = np.full(nl, -1.0, np.float32)
+            fvm, keepm = views.frame_view(kl, dl, None, None, p["bounds"], p["cam"], 8, 1.2)
+            F.upload(fvm, keepm)
         Pw, valid = synth.unproject_to_world(kl, dp, Tcw, cam)
         lv, keep = views.lastframe_view(valid.astype(np.uint8), np.zeros(nl, np.uint8), Pw, dl, kl["octave"], kl["angle"],
                                         np.full(nl, 3, np.int32), Tcw.astype(np.float32))
-        chunk = synth.map_from_frame(kl, dl, dp, Tcw, cam)
-        frames.append(dict(Tcw=Tcw, guess=synth.perturb_pose(Tcw, rng).astype(np.float32), last_view=(lv, keep), chunk=chunk,
+        if k % FRAMES_PER_KF == 0:
+            dp_new = dp.copy()
+            prev = [kf_chunks[j] for j in sorted(kf_chunks) if j >= k - FRAMES_PER_KF * (cfg["local_kfs"] - 1)]
+            if prev:
+                mp = {key: np.concatenate([c[key] for c in prev]) for key in prev[0]}
+                wv, keep_w = views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
+                LM.upload(wv)
+                amp = np.full(nl, -1, np.int32); aob = np.zeros(nl, np.int32)
+                amp, aob, nmatch = m_dedupe.SearchLocalPoints(F, LM, Tcw.astype(np.float32), 1.0, False, 0.0, amp, aob, None)
+                dp_new[amp >= 0] = -1.0                  # the feature already observes a map point
+            kf_chunks[k] = synth.map_from_frame(kl, dl, dp_new, Tcw, cam)
+        frames.append(dict(Tcw=Tcw, guess=synth.perturb_pose(Tcw, rng).astype(np.float32), last_view=(lv, keep),
                            n=nl, stereo=int((ur > 0).sum())))
-    return ex, imgs, host_imgs, frames
+    return ex, imgs, host_imgs, frames, kf_chunks
 
 
-def local_map_for(frames, k, n_kf=6):
-    """Union of the map points created by the last n_kf keyframes before frame k (keyframe = every FRAMES_PER_KF-th)."""
-    ids = [((k // FRAMES_PER_KF) - j) * FRAMES_PER_KF for j in range(1, n_kf + 1)]
-    ids = [i % len(frames) for i in ids]
-    parts = [frames[i]["chunk"] for i in ids]
-    return {key: np.concatenate([p[key] for p in parts]) for key in parts[0]}
+def capi_dtype():
+    from multi_orbslam3_amd import _capi
+    return _capi.KEYPOINT_DTYPE
+
+
+class LocalMaps:
+    """The local map of the Tracking thread: all map points created by the last `n_kf` DISTINCT keyframes visited (SURVEY.md
+    8d: 20 keyframes at C2, 50 at C4).  The flattened views are cached per keyframe set (a SLAM system keeps them as the
+    point list of its local map; flattening 5-20 k points in Python inside the timed loop would measure numpy)."""
+
+    def __init__(self, kf_chunks, n_kf, views):
+        self.chunks, self.n_kf, self.views = kf_chunks, n_kf, views
+        self.recent = []                  # keyframe ids, most recent last, unique
+        self.cache = {}
+        self.sizes = []
+
+    def prefill(self, seq, first_step):
+        """The keyframes the sequence passed before step `first_step` (oldest first)."""
+        back, j = [], first_step - 1
+        while len(back) < self.n_kf and j > first_step - 1 - 2 * len(seq):
+            k = seq[j % len(seq)]
+            if k % FRAMES_PER_KF == 0 and k not in back:
+                back.append(k)
+            j -= 1
+        for k in reversed(back):
+            self.visit(k)
+
+    def visit(self, kf_id):
+        if kf_id in self.recent:
+            self.recent.remove(kf_id)
+        self.recent.append(kf_id)
+        self.recent = self.recent[-self.n_kf:]
+
+    def view(self):
+        key = tuple(sorted(self.recent))
+        got = self.cache.get(key)
+        if got is None:
+            parts = [self.chunks[j] for j in key]
+            mp = {k2: np.concatenate([c[k2] for c in parts]) for k2 in parts[0]}
+            got = self.views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
+            self.cache[key] = got
+            self.sizes.append(int(got[0].m))
+        return got[0]
 
 
 def host_cpu():
@@ -109,25 +171,25 @@ def host_cpu():
     return dict(nproc=os.cpu_count(), model=model, affinity_cpus=len(os.sched_getaffinity(0)))
 
 
-def cpu_baseline(scene, cfg, synth, views, n_frames):
+def cpu_baseline(scene, cfg, synth, views, n_frames, host_imgs, frames, kf_chunks, seq, cpus=None):
     """The CPU oracle (a restatement of the reference path), rebuilt -O3 -march=native for this host, on a bounded sample of
-    the same workload with the reference's threading: left / right extraction on two threads (S/Frame.cc:92-95), the
-    tracking steps on the calling thread, local BA on its own thread next to tracking (S/ClientSystem.cc:105-106) -- at
-    most 3 busy cores."""
+    the same workload (same images, same sequence, same local maps) with the reference's threading: left / right extraction
+    on two threads (S/Frame.cc:92-95), the tracking steps on the calling thread, local BA on its own thread next to tracking
+    (S/ClientSystem.cc:105-106) -- at most 3 busy cores.  cpus: restrict the sample's threads to these CPUs (per-agent
+    baselines of a multi-GPU run use disjoint core triples)."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as ob
     lib_path = ob.use_native()
+    if cpus:
+        os.sched_setaffinity(0, cpus)                     # threads created below inherit it
     cam = scene.cam
-    n_distinct = 16
     nf = cfg["n_features"]
     exL = ob.Extractor(n_features=nf, max_width=scene.W, max_height=scene.H)
     exR = ob.Extractor(n_features=nf, max_width=scene.W, max_height=scene.H)
     p = scene.frame_view_params()
     rng = np.random.RandomState(1234)
-    imgs = [scene.stereo_pair(k) for k in range(n_distinct)]
-    seq = list(range(n_distinct)) + list(range(n_distinct - 2, 0, -1))
     nfree, nfix, npts = cfg["lba"]
     prob = synth.make_lba_problem(n_free=nfree, n_fixed=nfix, n_points=npts, width=scene.W, height=scene.H, mono_frac=cfg["mono_frac"])
     lp, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
@@ -146,14 +208,20 @@ def cpu_baseline(scene, cfg, synth, views, n_frames):
 
     worker = threading.Thread(target=lba_worker, daemon=True)
     worker.start()
+    maps = LocalMaps(kf_chunks, cfg["local_kfs"], views)
+    n_fill = 2 * FRAMES_PER_KF                            # the first frames only fill the last-frame view
+    maps.prefill(seq, 0)                                  # the map of the keyframes before the sample's first frame
+    wv = maps.view()
     last = None
-    chunks = []
     t_start = None
     done = 0
+    n_map = []
     th_frame, mono = (7.0, False) if cfg["stereo"] else (15.0, True)
-    for i in range(n_frames + 8):
-        L, R, Tcw = imgs[seq[i % len(seq)]]
-        if i == 8:                                        # the first frames only fill the last-frame view / local map
+    for i in range(n_frames + n_fill):
+        k = seq[i % len(seq)]
+        L, R = host_imgs[k]
+        Tcw = frames[k]["Tcw"]
+        if i == n_fill:
             t_start = time.perf_counter()
         if cfg["stereo"]:
             fl, fr = pool.submit(exL.extract, L), pool.submit(exR.extract, R)
@@ -167,21 +235,21 @@ def cpu_baseline(scene, cfg, synth, views, n_frames):
         n = len(kl)
         amp = np.full(n, -1, np.int32); aob = np.zeros(n, np.int32)
         guess = synth.perturb_pose(Tcw, rng).astype(np.float32)
-        if last is not None and len(chunks) >= 2:
+        if last is not None:
             amp, aob, nm1 = ob.search_by_projection_frame(fv, guess, last[0], th_frame, mono, True, amp, aob)
-            mp = {key: np.concatenate([c[key] for c in chunks[-6:]]) for key in chunks[0]}
-            wv, keep2 = views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
             amp, aob, nm2 = ob.search_local_points(fv, wv, guess, 1.0, False, 0.0, 0.8, amp, aob)
-        if i >= 8:
-            done += 1
-            if done % FRAMES_PER_KF == 0:
+        if k % FRAMES_PER_KF == 0:
+            maps.visit(k)
+        if i % FRAMES_PER_KF == 0:
+            wv = maps.view()
+            n_map.append(int(wv.m))
+            if i >= n_fill:
                 q.put(1)
+        if i >= n_fill:
+            done += 1
         Pw, valid = synth.unproject_to_world(kl, dp, Tcw, cam)
         last = views.lastframe_view(valid.astype(np.uint8), np.zeros(n, np.uint8), Pw, dl, kl["octave"], kl["angle"],
                                     np.full(n, 3, np.int32), Tcw.astype(np.float32))
-        if i < 8 or i % FRAMES_PER_KF == 0:
-            chunks.append(synth.map_from_frame(kl, dl, dp, Tcw, cam))
-            chunks = chunks[-6:]
     q.put(None)
     worker.join()                                         # every LBA triggered by the sample has finished
     wall = time.perf_counter() - t_start
@@ -190,10 +258,10 @@ def cpu_baseline(scene, cfg, synth, views, n_frames):
     native = lib_path.endswith(os.path.join("_native", "liboracle.so"))
     return dict(value=round(fps, 3), unit="frames/s", cores=3 if cfg["stereo"] else 2, kind="port",
                 build="g++ -O3 -march=native -ffp-contract=off, built on this host" if native else "g++ -O3 -msse4.2 (portable build)",
-                sample="%d frames (%s) + %d local BAs of %.1f ms on their own thread, %.1f s wall; threads as in the "
-                       "reference (S/Frame.cc:92-95, S/ClientSystem.cc:105-106)"
+                sample="%d frames (%s) + %d local BAs of %.1f ms on their own thread, local map of %d points on average, %.1f s wall; "
+                       "threads as in the reference (S/Frame.cc:92-95, S/ClientSystem.cc:105-106)"
                        % (done, "L/R extraction on 2 threads" if cfg["stereo"] else "mono extraction on the tracking thread",
-                          len(lba_times), 1e3 * float(np.mean(lba_times)) if lba_times else 0.0, wall))
+                          len(lba_times), 1e3 * float(np.mean(lba_times)) if lba_times else 0.0, int(np.mean(n_map)) if n_map else 0, wall))
 
 
 def copy_bandwidth_gbs(torch, device, mib=512, reps=10):
@@ -217,7 +285,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
-    ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames (ping-pong sequence)")
+    ap.add_argument("--frames", type=int, default=100,
+                    help="distinct synthetic frames; the sequence is their ping-pong, 2 * frames - 2 steps long (SURVEY.md 8d: 200 frames)")
+    ap.add_argument("--prewarm-steps", type=int, default=200,
+                    help="untimed steps before --warmup (at least this many and at least 50 ms): first-use allocations, clocks, "
+                         "hardware queues -- so that a short timed region is at steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the value_host_images / value_with_pose_opt regions")
     ap.add_argument("--secondary-steps", type=int, default=300)
@@ -227,9 +299,12 @@ def main():
     ap.add_argument("--pose-opt", action="store_true",
                     help="also run Optimizer::PoseOptimization (SURVEY row f-2) after each of the two searches in the MAIN "
                          "timed region; by default that accounting is reported as value_with_pose_opt")
-    ap.add_argument("--host-images", action="store_true",
-                    help="hand host images to the Frame constructor in the MAIN timed region (H2D inside); by default that "
-                         "accounting is reported as value_host_images")
+    ap.add_argument("--device-images", action="store_true",
+                    help="MAIN timed region with the images already resident in HBM (no host staging / PCIe copy); by default that "
+                         "accounting is reported as value_device_images")
+    ap.add_argument("--ingest", choices=["thread", "inline"], default="thread",
+                    help="host images: thread = the library's ingest thread packs the rows into pinned staging and enqueues the "
+                         "constructor (orbx_frame_stereo_submit, ORBX_SUBMIT_ASYNC); inline = the tracking thread does")
     ap.add_argument("--profile-stages", action="store_true", help="bracket every extractor stage with HIP events")
     ap.add_argument("--no-numa-pin", action="store_true",
                     help="do not restrict the process to the CPUs of the GPU's NUMA node (default: like numactl --cpunodebind)")
@@ -251,7 +326,8 @@ def main():
     # share a queue with the local BA's chain; with 6 every stream has its own; 8 and 12 are slower again.  Must be set
     # before the runtime initialises.  (Without the pipelined constructor the agent has three busy streams and the default
     # of 4 is the good setting -- more hardware queues than busy streams cost dispatch latency on every one of them.)
-    pipeline = stereo and not (args.no_pipeline or args.separate_calls or args.host_images)
+    pipeline = stereo and not (args.no_pipeline or args.separate_calls)
+    host_images = not args.device_images and not args.separate_calls
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "6" if pipeline else "4")
     # Every agent keeps two threads spinning on completion words (tracking thread, local-BA worker).  If the container's CPU
     # quota cannot feed that for all ranks of this node (cgroup cpu.max), fall back to the runtime's blocking waits
@@ -282,12 +358,12 @@ def main():
     torch.cuda.set_device(device)
     affinity_at_start = os.sched_getaffinity(0)
     cpu_affinity = None if args.no_numa_pin else harness.pin_to_gpu_numa_node(device)
-    core_pair = None if args.no_numa_pin else harness.core_pair_for_agent(device, local_rank)
+    core_pair = None if args.no_numa_pin else harness.cores_for_agent(device, local_rank, per_agent=3)
 
     W, H = cfg["W"], cfg["H"]
     scene = synth.Scene(W, H, seed=synth.SEED_IMAGES + rank)      # one agent per GPU, distinct seeds
     cam = scene.cam
-    ex, imgs, host_imgs, frames = build_workload(scene, cfg, args.frames, api, views, synth, device)
+    ex, imgs, host_imgs, frames, kf_chunks = build_workload(scene, cfg, args.frames, api, views, synth, device)
     p = scene.frame_view_params()
     fv, fv_keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
     F = api.Frame(cfg["frame_cap"], device)
@@ -311,6 +387,16 @@ def main():
         opt.wait()
         os.sched_setaffinity(0, core_pair[0])
         cpu_affinity = "%s; tracking thread on cpus %s, local-BA worker on cpus %s" % (cpu_affinity, sorted(core_pair[0]), sorted(core_pair[1]))
+    if pipeline and args.ingest == "thread":
+        # the library's ingest thread is created by the first asynchronous submission and inherits that caller's affinity
+        if core_pair is not None and len(core_pair) >= 3:
+            os.sched_setaffinity(0, core_pair[2])
+        exs[1].frame_stereo_submit(Fs[1], fv, host_imgs[0][0], host_imgs[0][1], bf, bb, async_ingest=True)
+        exs[1].frame_stereo_dev_wait()
+        if core_pair is not None:
+            os.sched_setaffinity(0, core_pair[0])
+            if len(core_pair) >= 3:
+                cpu_affinity = "%s, image-ingest thread on cpus %s" % (cpu_affinity, sorted(core_pair[2]))
     nF = len(frames)
     seq = list(range(nF)) + list(range(nF - 2, 0, -1))             # ping-pong: consecutive frames stay adjacent
     po_prob = synth.make_pose_opt_problem(n=450, seed=77 + rank)
@@ -351,6 +437,16 @@ def main():
             reg.stats["lba_s"] += opt.last_solve_ms * 1e-3
         reg.async_t0 = None
 
+    maps = LocalMaps(kf_chunks, cfg["local_kfs"], views)
+    maps.prefill(seq, 0)
+    ingest_async = args.ingest == "thread"
+
+    def submit_ctor(c, k_img, host_images):
+        if host_images:
+            exs[c].frame_stereo_submit(Fs[c], fv, host_imgs[k_img][0], host_imgs[k_img][1], bf, bb, async_ingest=ingest_async)
+        else:
+            exs[c].frame_stereo_dev_submit(Fs[c], fv, imgs[k_img][0].data_ptr(), imgs[k_img][1].data_ptr(), W, H, W, bf, bb)
+
     def step(i, reg, timed, pose_opt, host_images, pipelined, slot=None):
         k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
         fr = frames[k]
@@ -368,11 +464,10 @@ def main():
             c = i & 1
             Fc, exc = Fs[c], exs[c]
             if not in_flight[c]:                          # first step only: nothing was submitted ahead
-                exc.frame_stereo_dev_submit(Fc, fv, dL.data_ptr(), dR.data_ptr(), W, H, W, bf, bb)
+                submit_ctor(c, k, host_images)
             nl, nr = exc.frame_stereo_dev_wait()
             in_flight[c] = False
-            nxt = imgs[seq[(i + 1) % len(seq)]]           # Frame::Frame(t+1) runs during the tracking of frame t
-            exs[c ^ 1].frame_stereo_dev_submit(Fs[c ^ 1], fv, nxt[0].data_ptr(), nxt[1].data_ptr(), W, H, W, bf, bb)
+            submit_ctor(c ^ 1, seq[(i + 1) % len(seq)], host_images)   # Frame::Frame(t+1) runs during the tracking of frame t
             in_flight[c ^ 1] = True
             t1 = t2 = time.perf_counter()
         elif host_images:
@@ -405,10 +500,10 @@ def main():
         else:
             tpo = t5
         t6 = t7 = tpo
+        if k % FRAMES_PER_KF == 0:
+            maps.visit(k)                              # this frame's map points joined the map when it was a keyframe
         if i % FRAMES_PER_KF == 0:
-            mp = local_map_for(frames, k)
-            wv, keep = views.worldpoints_view(mp["pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["n_obs"], mp["bad"])
-            LM.upload(wv)
+            LM.upload(maps.view())                     # Tracking::UpdateLocalMap: points of the last 20 / 50 keyframes
             t6 = time.perf_counter()
             if args.lba_mode == "async":
                 collect_async(reg)                     # the previous keyframe's LBA (long finished in steady state)
@@ -434,9 +529,7 @@ def main():
                 reg.step_s[slot] = time.perf_counter() - t0
 
     # local map must exist before the first frame
-    mp0 = local_map_for(frames, 0)
-    wv0, keep0 = views.worldpoints_view(mp0["pos"], mp0["normal"], mp0["min_dist"], mp0["max_dist"], mp0["desc"], mp0["n_obs"], mp0["bad"])
-    LM.upload(wv0)
+    LM.upload(maps.view())
 
     def run_region(n_steps, n_warm, pose_opt, host_images, pipelined, first_index):
         """W untimed steps, then exactly n_steps timed ones between barrier + synchronize on both sides; MAX over ranks."""
@@ -457,9 +550,18 @@ def main():
         elapsed = grp.timed(lambda i: step(base + i, reg, True, pose_opt, host_images, pipelined, slot=i), n_steps, sync)
         return reg, elapsed
 
+    # internal pre-warm, independent of --warmup: at least --prewarm-steps steps AND at least 50 ms of the main configuration
+    prewarm_done = 0
+    t_pw = time.perf_counter()
+    scratch = Region(1)
+    while prewarm_done < args.prewarm_steps or time.perf_counter() - t_pw < 0.05:
+        step(prewarm_done, scratch, False, args.pose_opt, host_images, pipeline)
+        prewarm_done += 1
+    collect_async(scratch)
     for e in exs:
         e.set_profile_interval(max(FAST_BRACKET_EVERY // len(exs), 1), reset=True)
-    reg, elapsed = run_region(args.steps, args.warmup, args.pose_opt, args.host_images, pipeline, 0)
+    opt.set_profiling(True, reset=True)
+    reg, elapsed = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, prewarm_done)
     solver_sum_ms, solver_n, solver_unknowns, solver_mfma = opt.solver_stats()
     fast_sum, fast_n = 0.0, 0                              # bracket times accumulated inside the library over the timed region
     for e in exs:
@@ -473,7 +575,7 @@ def main():
             for e in exs:
                 e.set_profile_kernel(kname)
                 e.set_profile_interval(1, reset=True)
-            run_region(max(min(40, args.steps), 4), 4, False, args.host_images, pipeline, 30000)
+            run_region(max(min(40, args.steps), 4), 4, False, host_images, pipeline, 30000)
             cs, cn = 0.0, 0
             for e in exs:
                 s_, n_ = e.fast_kernel_stats()
@@ -490,13 +592,19 @@ def main():
     if not args.no_secondary:
         ns = max(min(args.secondary_steps, args.steps), 1)
         nw = max(min(args.warmup, 40), 1)
-        if stereo and not args.host_images:
-            r2, e2 = run_region(ns, nw, False, True, False, 10000)
-            secondary["value_host_images"] = round(world * ns / e2, 3)
-            secondary["value_host_images_note"] = ("orbx_frame_stereo: pageable host images handed to the Frame constructor (two H2D "
-                                                   "copies inside the step, synchronous constructor), %d timed steps" % ns)
+        if stereo and host_images and pipeline:
+            r2, e2 = run_region(ns, nw, False, False, True, 10000)
+            secondary["value_device_images"] = round(world * ns / e2, 3)
+            secondary["value_device_images_note"] = ("the two images already resident in HBM (orbx_frame_stereo_dev_submit): no host "
+                                                     "staging, no PCIe copy; pipelined constructor, %d timed steps" % ns)
+        if stereo and pipeline:
+            r4, e4 = run_region(ns, nw, False, True, False, 15000)
+            secondary["value_sync_ctor_host_images"] = round(world * ns / e4, 3)
+            secondary["value_sync_ctor_host_images_note"] = ("orbx_frame_stereo: the constructor an UNCHANGED Tracking thread calls -- host "
+                                                             "images in, synchronous, nothing overlaps the tracking of the previous frame; "
+                                                             "%d timed steps" % ns)
         if not args.pose_opt:
-            r3, e3 = run_region(ns, nw, True, args.host_images, pipeline, 20000)
+            r3, e3 = run_region(ns, nw, True, host_images, pipeline, 20000)
             secondary["value_with_pose_opt"] = round(world * ns / e3, 3)
             secondary["value_with_pose_opt_note"] = ("the two PoseOptimization calls of Tracking per frame inside the step "
                                                      "(S/Tracking.cc:2649,2712; 450 / 650 correspondences), %d timed steps" % ns)
@@ -511,7 +619,7 @@ def main():
 
     server_tick = None
     if args.server_tick:
-        server_tick = run_server_tick(grp, api, views, torch, device, frames, fv, LM, scene)
+        server_tick = run_server_tick(grp, api, views, torch, device, frames, kf_chunks, fv, LM, scene)
 
     copy_gbs = copy_bandwidth_gbs(torch, device) if rank == 0 else None
 
@@ -574,18 +682,28 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (ORB front-end, Hamming), f64 (local BA)",
             "data": "synthetic",
-            "timed_region_s": round(elapsed, 4),
+            "timed_region_s": round(elapsed, 4), "prewarm_steps": int(prewarm_done),
+            "fps_formula": round(1.0 / (sum(v for k2, v in stage.items() if k2 != "lba") / K +
+                                        stats["lba_s"] / max(stats["lba_calls"], 1) / FRAMES_PER_KF), 3),
+            "fps_formula_note": "BASELINE.md protocol: 1 / (t_frontend + t_LBA / K), K = %d frames per keyframe; t_frontend = host wall "
+                                "time of the frame path per step, t_LBA = wall time of one local BA (both from the main timed region)" % FRAMES_PER_KF,
             "step_ms_p50": round(float(np.percentile(step_ms, 50)), 4), "step_ms_p95": round(float(np.percentile(step_ms, 95)), 4),
             "step_ms_max": round(float(step_ms.max()), 4),
-            "config": {"workload": cfg["label"] + ", 1 LBA per %d frames" % FRAMES_PER_KF, "name": args.config,
+            "config": {"workload": cfg["label"] + ", 1 LBA per %d frames; local map = map points of the last %d keyframes (%d on average), "
+                                   "%d-frame ping-pong sequence of %d distinct frames"
+                                   % (FRAMES_PER_KF, cfg["local_kfs"], int(np.mean(maps.sizes)) if maps.sizes else 0, len(seq), nF), "name": args.config,
                        "per_agent_fps": round(K / elapsed, 3), "frames_per_keyframe": FRAMES_PER_KF,
                        "stage_ms_per_frame": {k2: round(1e3 * v / K, 4) for k2, v in stage.items()},
                        "device_ms_per_frame": dict({k2: round(v / K, 4) for k2, v in kern.items()}, fast_kernel_ms=round(fast_ms_raw, 4)),
                        "avg_keypoints_per_frame": round(stats["kp"] / K, 1),
                        "avg_matches_frame": round(stats["m_frame"] / K, 1), "avg_matches_map": round(stats["m_map"] / K, 1),
-                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt), "host_images_in_step": bool(args.host_images or not stereo),
+                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt), "host_images_in_step": bool(host_images or not stereo),
+                       "image_ingest": ("host images -> pinned staging slot (%s) -> copy kernel on the extractor's stream -> HBM"
+                                        % ("library ingest thread" if pipeline and ingest_async else "calling thread")) if host_images else "images resident in HBM",
+                       "local_map_points_avg": int(np.mean(maps.sizes)) if maps.sizes else 0, "local_map_keyframes": cfg["local_kfs"],
+                       "sequence_frames": len(seq),
                        "cpu_affinity": cpu_affinity, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
-                       "frame_ctor": ("pipelined: Frame(t+1) is submitted on a second extractor handle before frame t is tracked and "
+                       "frame_ctor": ("pipelined: Frame(t+1) is submitted (host images: orbx_frame_stereo_submit) on a second extractor handle before frame t is tracked and "
                                       "collected at the start of step t+1; the constructor left in flight by the last timed step is "
                                       "waited for inside the timed region") if pipeline else "synchronous",
                        "pose_opt_ms_per_call_450_correspondences": round(pose_opt_ms, 4),
@@ -639,61 +757,69 @@ def main():
         line.update(secondary)
         if server_tick is not None:
             line["config"]["server_tick"] = server_tick
-        if not args.no_cpu_baseline:
-            os.sched_setaffinity(0, affinity_at_start)     # the CPU baseline's three threads get the whole machine again
-            n_base = 300 if args.config != "C4" else 60
-            line["cpu_baseline"] = cpu_baseline(scene, cfg, synth, views, n_base)
-            line["cpu_baseline"]["host_cpu"] = host_cpu()
+    # CPU baseline: every rank (= agent) runs its own sample on its own three physical cores ("for A agents run A
+    # independent baseline processes pinned to disjoint cores"); rank 0 reports its sample and min / median over the ranks
+    if not args.no_cpu_baseline:
+        n_base = 300 if args.config != "C4" else 60
+        own = None
+        if core_pair is not None and world > 1:
+            own = set().union(*core_pair)
+        else:
+            os.sched_setaffinity(0, affinity_at_start)     # one agent: the baseline's three threads get the whole machine again
+        base = cpu_baseline(scene, cfg, synth, views, n_base, host_imgs, frames, kf_chunks, seq, cpus=own)
+        per_rank = grp.gather_floats(base["value"])
+        if rank == 0:
+            base["host_cpu"] = host_cpu()
+            base["per_agent"] = {"values": [round(v, 3) for v in per_rank], "min": round(min(per_rank), 3),
+                                 "median": round(float(np.median(per_rank)), 3),
+                                 "pinning": "each agent's sample on its own physical cores %s" % (sorted(own) if own else "(unpinned: one agent)")}
+            line["cpu_baseline"] = base
+    if rank == 0:
         print(json.dumps(line))
     grp.close()
 
 
-def run_server_tick(grp, api, views, torch, device, frames, fv, LM, scene, reps=50):
+def run_server_tick(grp, api, views, torch, device, frames, kf_chunks, fv, LM, scene, reps=50):
     """Server tick of configs[2]/[4] (S/Communicator.cc:124-146 hand-over, S/LoopClosing.cc:657,769,795 matching): every
-    agent contributes KeyFrame wire blocks (R/msg/KF.msg:29-31) over RCCL, the server rebuilds each KeyFrame on the device
-    (orbk_frame_from_wire) and runs SearchByProjection(KF, Scw, map points).  With fewer ranks than blocks, every rank
-    contributes several keyframes (one all-gather per keyframe round)."""
+    agent contributes ALL its new KeyFrame wire blocks (R/msg/KF.msg:29-31) in ONE RCCL all-gather per tick
+    (AgentGroup.all_gather_keyframe_blocks: fixed-size buffers, feature counts in the header), the server rebuilds each
+    KeyFrame on the device (orbk_frame_from_wire) and runs SearchByProjection(KF, Scw, map points) on it.  2 and 8 blocks per
+    tick in total: with fewer ranks than blocks every rank contributes several keyframes to the same collective."""
     from multi_orbslam3_amd import _capi as capi
-    import ctypes as C
     p = scene.frame_view_params()
-    kfs = []
-    for k in (3, 8, 11, 14):
-        fr = frames[k % len(frames)]
-        src = fr["last_view"]
-        kfs.append(fr)
-    # wire blocks of this rank's keyframes, device resident
+    kf_ids = sorted(kf_chunks)[:8]
     blocks = []
     Ftmp = api.Frame(8192, device)
-    lib = capi.load()
-    for fr in kfs:
-        ch = fr["chunk"]
-        n = len(ch["src_idx"])
+    for k in kf_ids:
+        ch = kf_chunks[k]
+        n = min(len(ch["src_idx"]), 2000)
         kps = np.zeros(n, capi.KEYPOINT_DTYPE)
         kps["x"] = 100.0 + (np.arange(n) % 400); kps["y"] = 80.0 + (np.arange(n) // 400) * 7.0
         kps["size"] = 31.0; kps["angle"] = 0.0; kps["response"] = 20.0; kps["octave"] = 0
-        fvk, keepk = views.frame_view(kps, ch["desc"], None, None, p["bounds"], p["cam"], 8, 1.2)
+        fvk, keepk = views.frame_view(kps, ch["desc"][:n], None, None, p["bounds"], p["cam"], 8, 1.2)
         Ftmp.upload(fvk, keepk)
         w = torch.zeros(47 * n, dtype=torch.uint8, device="cuda:%d" % device)
         Ftmp.pack_wire(device_ptr=w.data_ptr())
-        blocks.append((n, w))
+        blocks.append((n, w, frames[k]["Tcw"].astype(np.float32)))
     torch.cuda.synchronize()
     m = api.ORBmatcher(0.75, True, device)
     K = api.Frame(8192, device)
+    bufs = grp.tick_buffers(max_features=2048, device="cuda:%d" % device, max_blocks=8)
     out = {}
     for n_blocks in (2, 8):
-        rounds = max((n_blocks + grp.world - 1) // grp.world, 1)
+        per_rank = max((n_blocks + grp.world - 1) // grp.world, 1)
+        mine = [(n, w) for (n, w, T) in blocks[:per_rank]]
         free = np.full(8192, -1, np.int32)
 
         def tick():
             done = 0
-            for r in range(rounds):
-                n, w = blocks[r % len(blocks)]
-                got = grp.all_gather_keyframes(w, n)
-                for (nr, blk) in got:
+            got = grp.all_gather_keyframe_blocks(bufs, mine)          # ONE collective + one header read-back per tick
+            for lst in got:
+                for j, (nr, blk) in enumerate(lst):
                     if done >= n_blocks:
                         break
                     K.from_wire(fv, n=nr, device_ptr=blk.data_ptr())
-                    m.SearchByProjectionSim3(K, kfs[r % len(kfs)]["Tcw"].astype(np.float32), LM, free[:nr], 4, 1.5)
+                    m.SearchByProjectionSim3(K, blocks[j][2], LM, free[:nr], 4, 1.5)
                     done += 1
             return done
         for _ in range(5):
@@ -705,8 +831,17 @@ def run_server_tick(grp, api, views, torch, device, frames, fv, LM, scene, reps=
         torch.cuda.synchronize(); grp.barrier()
         dt = grp.max_over_ranks(time.perf_counter() - t0)
         out["%d_kf_blocks_us" % n_blocks] = round(1e6 * dt / reps, 1)
-    out["note"] = ("per tick: RCCL all-gather of the KeyFrame wire blocks (47 B/feature, backend nccl, %d rank%s) + "
-                   "orbk_frame_from_wire + SearchByProjection(KF, Scw, map points) per block" % (grp.world, "" if grp.world == 1 else "s"))
+    # the collective alone (8 blocks)
+    mine = [(n, w) for (n, w, T) in blocks[:max((8 + grp.world - 1) // grp.world, 1)]]
+    torch.cuda.synchronize(); grp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        grp.all_gather_keyframe_blocks(bufs, mine)
+    torch.cuda.synchronize(); grp.barrier()
+    out["exchange_only_8_blocks_us"] = round(1e6 * grp.max_over_ranks(time.perf_counter() - t0) / reps, 1)
+    out["note"] = ("per tick: ONE RCCL all-gather of every agent's new KeyFrame wire blocks (47 B/feature, fixed-size buffers of %d bytes, "
+                   "backend nccl, %d rank%s) + one read-back of the headers, then orbk_frame_from_wire + SearchByProjection(KF, Scw, map "
+                   "points) per block" % (bufs["cap"], grp.world, "" if grp.world == 1 else "s"))
     return out
 
 

@@ -45,47 +45,67 @@ def pin_to_gpu_numa_node(device_index):
         return None
 
 
-def _pick_core_pair(cores, slot, n_local):
+def _pick_cores(cores, slot, n_local, per_agent):
     """cores: the physical cores of the node (sets of hardware threads), in order.  The first cores of a node serve
-    interrupts and housekeeping, so agents take consecutive pairs from the upper half.  Two agents must never get the same
-    pair (four spinning threads on two cores): when the node has fewer pairs than the launch has local ranks (all of which
-    may sit on this node) every core is used, and when that is not enough either nothing is pinned."""
+    interrupts and housekeeping, so agents take consecutive runs of `per_agent` cores from the upper half.  Two agents must
+    never share a core (their spinning threads would halve each other): when the node has fewer runs than the launch has
+    local ranks (all of which may sit on this node) every core is used, and when that is not enough either nothing is pinned."""
     n_local = max(n_local, slot + 1)
     half = len(cores) // 2
-    if (len(cores) - half) // 2 < n_local:
+    if (len(cores) - half) // per_agent < n_local:
         half = 0
-    if (len(cores) - half) // 2 < n_local:
+    if (len(cores) - half) // per_agent < n_local:
         return None
-    base = half + 2 * slot
-    return cores[base], cores[base + 1]
+    base = half + per_agent * slot
+    return tuple(cores[base + i] for i in range(per_agent))
+
+
+def _pick_core_pair(cores, slot, n_local):
+    return _pick_cores(cores, slot, n_local, 2)
+
+
+def _physical_cores_of_gpu_node(device_index):
+    import torch
+    pr = torch.cuda.get_device_properties(device_index)
+    bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+        node = int(f.read().strip())
+    if node < 0:
+        node = 0
+    with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+        cpus = _parse_cpulist(f.read()) & os.sched_getaffinity(0)
+    cores, seen = [], set()
+    for c in sorted(cpus):
+        if c in seen:
+            continue
+        with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+            sib = _parse_cpulist(f.read()) & cpus
+        seen |= sib
+        cores.append(sib)
+    return cores
+
+
+def cores_for_agent(device_index, slot, per_agent=3):
+    """`per_agent` distinct physical cores (each returned with its SMT siblings) on the GPU's NUMA node for agent number
+    `slot` on that node: tracking thread, the library's local-BA worker, the library's image-ingest thread.  All three spin
+    on completion / hand-over words; when the scheduler happens to put two of them on the hardware threads of one core each
+    runs at about half speed (searches 47 -> 65-74 us per call, observed in roughly one run out of five).  Falls back to a
+    pair (the ingest thread then floats on the node) and returns None when the topology is not visible."""
+    try:
+        cores = _physical_cores_of_gpu_node(device_index)
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        got = _pick_cores(cores, slot, n_local, per_agent)
+        if got is None and per_agent > 2:
+            got = _pick_cores(cores, slot, n_local, 2)
+        return got
+    except Exception:
+        return None
 
 
 def core_pair_for_agent(device_index, slot):
-    """Two distinct physical cores (each returned with its SMT siblings) on the GPU's NUMA node for agent number `slot` on
-    that node: one for the tracking thread, one for the library's local-BA worker.  Both threads spin on completion words;
-    when the scheduler happens to put them on the two hardware threads of one core each runs at about half speed
-    (searches 47 -> 65-74 us per call, observed in roughly one run out of five).  Returns (main_cpus, worker_cpus) or None."""
-    try:
-        import torch
-        pr = torch.cuda.get_device_properties(device_index)
-        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
-        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
-            node = int(f.read().strip())
-        if node < 0:
-            node = 0
-        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
-            cpus = _parse_cpulist(f.read()) & os.sched_getaffinity(0)
-        cores, seen = [], set()
-        for c in sorted(cpus):
-            if c in seen:
-                continue
-            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
-                sib = _parse_cpulist(f.read()) & cpus
-            seen |= sib
-            cores.append(sib)
-        return _pick_core_pair(cores, slot, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    except Exception:
-        return None
+    """Two distinct physical cores for agent `slot` (tracking thread, local-BA worker); see cores_for_agent."""
+    got = cores_for_agent(device_index, slot, per_agent=2)
+    return None if got is None else (got[0], got[1])
 
 
 class AgentGroup:
@@ -128,6 +148,17 @@ class AgentGroup:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_floats(self, value):
+        """One float per rank -> list over ranks (on every rank)."""
+        if self.dist is None:
+            return [float(value)]
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        out = torch.zeros(self.world, dtype=torch.float64, device=dev)
+        self.dist.all_gather_into_tensor(out, mine)
+        return [float(v) for v in out.cpu()]
+
     def timed(self, fn, steps, sync=None):
         """barrier + sync, exactly `steps` calls of fn(i), sync + barrier; returns MAX-over-ranks seconds."""
         self.barrier()
@@ -164,6 +195,59 @@ class AgentGroup:
         recv = torch.empty(self.world * pad, dtype=torch.uint8, device=dev)
         self.dist.all_gather_into_tensor(recv, send)
         return [(counts[r], recv[r * pad: r * pad + 47 * counts[r]]) for r in range(self.world)]
+
+    # ---- server tick: ONE collective per tick, whatever the number of ranks and of new keyframes
+    TICK_MAX_BLOCKS = 15                     # new keyframes one agent can contribute per tick
+    TICK_HEADER_BYTES = 64                   # int32[16]: number of blocks, then the feature count of each block
+
+    def tick_buffers(self, max_features, device, max_blocks=8):
+        """Persistent send / receive buffers of a server tick for up to `max_blocks` keyframes of up to `max_features`
+        features per agent: [64-byte header | the agent's wire blocks back to back].  The size is fixed for the group's life,
+        so a tick needs no size exchange."""
+        import torch
+        assert 1 <= max_blocks <= self.TICK_MAX_BLOCKS
+        cap = self.TICK_HEADER_BYTES + 47 * int(max_features) * int(max_blocks)
+        cap = (cap + 255) & ~255
+        send = torch.zeros(cap, dtype=torch.uint8, device=device)
+        recv = torch.zeros(self.world * cap, dtype=torch.uint8, device=device)
+        return dict(cap=cap, send=send, recv=recv, max_blocks=int(max_blocks), max_features=int(max_features))
+
+    def all_gather_keyframe_blocks(self, bufs, blocks):
+        """One server tick: every agent contributes ALL its new keyframe wire blocks -- `blocks` = [(n_features, uint8 tensor
+        of 47 * n_features bytes)], possibly empty -- in ONE all-gather of the fixed-size tick buffers (RCCL over xGMI on GPU
+        tensors, gloo on CPU tensors; < 1 MB per agent: latency bound).  The per-block feature counts travel in the buffer's
+        header, so there is no second collective and no host round trip between collectives; the headers of all agents are read
+        back with one small copy.  Returns [[(n_features, block view), ...] for every rank]."""
+        import numpy as np
+        import torch
+        cap, send, recv = bufs["cap"], bufs["send"], bufs["recv"]
+        assert len(blocks) <= bufs["max_blocks"]
+        hdr = np.zeros(self.TICK_HEADER_BYTES // 4, np.int32)
+        hdr[0] = len(blocks)
+        off = self.TICK_HEADER_BYTES
+        for b, (n, w) in enumerate(blocks):
+            n = int(n)
+            assert n <= bufs["max_features"]
+            hdr[1 + b] = n
+            send[off: off + 47 * n] = w[: 47 * n]
+            off += 47 * n
+        send[: self.TICK_HEADER_BYTES] = torch.from_numpy(hdr.view(np.uint8)).to(send.device, non_blocking=True)
+        if self.dist is None:
+            recv[:cap] = send
+        else:
+            self.dist.all_gather_into_tensor(recv, send)
+        heads = recv.view(self.world, cap)[:, : self.TICK_HEADER_BYTES].cpu().numpy().view(np.int32)      # the tick's one read-back
+        out = []
+        for r in range(self.world):
+            nb = int(heads[r, 0])
+            off = r * cap + self.TICK_HEADER_BYTES
+            lst = []
+            for b in range(nb):
+                n = int(heads[r, 1 + b])
+                lst.append((n, recv[off: off + 47 * n]))
+                off += 47 * n
+            out.append(lst)
+        return out
 
     def close(self):
         if self.dist is not None:

@@ -28,15 +28,19 @@ def test_bench_line_has_the_contract_fields():
     d = _bench("--steps", "40", "--warmup", "10", "--secondary-steps", "20")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "timed_region_s", "step_ms_p50", "step_ms_p95",
-                "value_host_images", "value_with_pose_opt"):
+                "value_device_images", "value_sync_ctor_host_images", "value_with_pose_opt", "fps_formula", "prewarm_steps"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 10
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
     assert abs(d["timed_region_s"] - 40 * d["ms_per_step"] * 1e-3) < 0.02 * d["timed_region_s"]
     assert 0 < d["step_ms_p50"] <= d["step_ms_p95"]
-    assert 0 < d["value_host_images"] and 0 < d["value_with_pose_opt"] < d["value"] * 1.2
+    assert 0 < d["value_sync_ctor_host_images"] and 0 < d["value_device_images"] and 0 < d["value_with_pose_opt"] < d["value"] * 1.2
+    assert d["prewarm_steps"] >= 200 and d["fps_formula"] > 0
     cfgd = d["config"]
+    # `value` is the host-image accounting: the images enter through pinned staging + a PCIe copy inside the step
+    assert cfgd["host_images_in_step"] is True and "pinned staging" in cfgd["image_ingest"]
+    assert cfgd["local_map_keyframes"] == 20 and 3000 <= cfgd["local_map_points_avg"] <= 12000 and cfgd["sequence_frames"] >= 190
     assert d["data"] == "synthetic" and "workload" in cfgd and "model" not in cfgd and cfgd["name"] == "C2"
     assert cfgd["device_copy_GBps_measured"] > 500 and cfgd["host_cpu"]["nproc"] >= 1 and cfgd["host_cpu"]["model"]
     assert cfgd["whole_step_hbm"]["achieved_GBps"] > 0
@@ -106,3 +110,4 @@ def test_server_tick_goes_through_rccl_on_one_rank():
     d = _bench("--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary", "--server-tick")
     st = d["config"]["server_tick"]
     assert st["2_kf_blocks_us"] > 0 and st["8_kf_blocks_us"] > st["2_kf_blocks_us"] and "nccl" in st["note"]
+    assert 0 < st["exchange_only_8_blocks_us"] < st["8_kf_blocks_us"] and "ONE RCCL all-gather" in st["note"]

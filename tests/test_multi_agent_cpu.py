@@ -85,6 +85,22 @@ EXCHANGE_WORKER = textwrap.dedent('''
                                   desc=hashlib.sha256(dd.tobytes()).hexdigest()))
     if grp.rank == 0:
         out["roundtrip_ok"] = bool(np.array_equal(got[0][1].numpy(), wire))
+    # one server tick with SEVERAL new keyframes per agent (rank r contributes r + 2 blocks of different sizes) in ONE collective
+    mine = []
+    for j in range(grp.rank + 2):
+        rc, kj, dj, _ = ex.extract(sc.stereo_pair(2 + j)[0])
+        mine.append((len(kj), torch.from_numpy(ob.wire_pack(kj, dj).copy())))
+    calls = []
+    real = grp.dist.all_gather_into_tensor
+    grp.dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    bufs = grp.tick_buffers(max_features=400, device="cpu", max_blocks=4)
+    tick = grp.all_gather_keyframe_blocks(bufs, mine)
+    tick2 = grp.all_gather_keyframe_blocks(bufs, mine[:1])          # the buffers are reused tick after tick
+    grp.dist.all_gather_into_tensor = real
+    out["tick_collectives"] = len(calls)
+    out["tick_own"] = [[n, hashlib.sha256(w.numpy().tobytes()).hexdigest()] for n, w in mine]
+    out["tick"] = [[[n, hashlib.sha256(b.numpy().tobytes()).hexdigest()] for n, b in lst] for lst in tick]
+    out["tick2_counts"] = [len(lst) for lst in tick2]
     print("RESULT " + json.dumps(out), flush=True)
     grp.close()
 ''') % ROOT
@@ -107,6 +123,12 @@ def test_keyframe_blocks_all_gather_gloo():
         assert [b["n"] for b in o["blocks"]] == [outs[0]["n"], outs[1]["n"]]
         assert [b["sha"] for b in o["blocks"]] == [outs[0]["own"], outs[1]["own"]]
     assert outs[0]["blocks"] == outs[1]["blocks"] and outs[0]["roundtrip_ok"]
+    # the batched tick: 2 + 3 blocks, ONE all-gather per tick, every rank holds every block byte for byte
+    for o in outs:
+        assert o["tick_collectives"] == 2                                  # two ticks, one collective each
+        assert o["tick"] == [outs[0]["tick_own"], outs[1]["tick_own"]]
+        assert o["tick2_counts"] == [1, 1]
+    assert [len(o["tick_own"]) for o in outs] == [2, 3]
 
 
 def test_cpu_list_parsing_and_pinning_helpers_degrade_without_a_gpu():
