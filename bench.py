@@ -302,6 +302,8 @@ def main():
     ap.add_argument("--device-images", action="store_true",
                     help="MAIN timed region with the images already resident in HBM (no host staging / PCIe copy); by default that "
                          "accounting is reported as value_device_images")
+    ap.add_argument("--submit-order", choices=["before-wait", "after-wait"], default="before-wait",
+                    help="pipelined constructor: hand frame t+1 over before or after frame t's constructor is collected")
     ap.add_argument("--ingest", choices=["thread", "inline"], default="thread",
                     help="host images: thread = the library's ingest thread packs the rows into pinned staging and enqueues the "
                          "constructor (orbx_frame_stereo_submit, ORBX_SUBMIT_ASYNC); inline = the tracking thread does")
@@ -440,6 +442,7 @@ def main():
     maps = LocalMaps(kf_chunks, cfg["local_kfs"], views)
     maps.prefill(seq, 0)
     ingest_async = args.ingest == "thread"
+    submit_first = args.submit_order == "before-wait"
 
     def submit_ctor(c, k_img, host_images):
         if host_images:
@@ -447,7 +450,7 @@ def main():
         else:
             exs[c].frame_stereo_dev_submit(Fs[c], fv, imgs[k_img][0].data_ptr(), imgs[k_img][1].data_ptr(), W, H, W, bf, bb)
 
-    def step(i, reg, timed, pose_opt, host_images, pipelined, slot=None):
+    def step(i, reg, timed, pose_opt, host_images, pipelined, slot=None, last=False):
         k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
         fr = frames[k]
         dL, dR = imgs[k]
@@ -465,10 +468,17 @@ def main():
             Fc, exc = Fs[c], exs[c]
             if not in_flight[c]:                          # first step only: nothing was submitted ahead
                 submit_ctor(c, k, host_images)
+            if submit_first and not last:
+                # Frame::Frame(t+1) is handed over (other handle, other frame object) BEFORE frame t is collected: its staging
+                # copy and launches overlap the tail of frame t's constructor; the image pair t+1 is needed at the same
+                # moment either way (the start of step t)
+                submit_ctor(c ^ 1, seq[(i + 1) % len(seq)], host_images)
+                in_flight[c ^ 1] = True
             nl, nr = exc.frame_stereo_dev_wait()
             in_flight[c] = False
-            submit_ctor(c ^ 1, seq[(i + 1) % len(seq)], host_images)   # Frame::Frame(t+1) runs during the tracking of frame t
-            in_flight[c ^ 1] = True
+            if not submit_first and not last:
+                submit_ctor(c ^ 1, seq[(i + 1) % len(seq)], host_images)   # Frame::Frame(t+1) runs during the tracking of frame t
+                in_flight[c ^ 1] = True
             t1 = t2 = time.perf_counter()
         elif host_images:
             # the reference's constructor takes host images (cv::Mat): the two H2D copies are inside the step
@@ -547,7 +557,8 @@ def main():
             step(first_index + i, reg, False, pose_opt, host_images, pipelined)
         collect_async(reg)
         base = first_index + n_warm
-        elapsed = grp.timed(lambda i: step(base + i, reg, True, pose_opt, host_images, pipelined, slot=i), n_steps, sync)
+        # (the last timed step does not hand a further frame over: the region holds exactly n_steps constructors)
+        elapsed = grp.timed(lambda i: step(base + i, reg, True, pose_opt, host_images, pipelined, slot=i, last=(i == n_steps - 1)), n_steps, sync)
         return reg, elapsed
 
     # internal pre-warm, independent of --warmup: at least --prewarm-steps steps AND at least 50 ms of the main configuration
@@ -704,8 +715,8 @@ def main():
                        "sequence_frames": len(seq),
                        "cpu_affinity": cpu_affinity, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
                        "frame_ctor": ("pipelined: Frame(t+1) is submitted (host images: orbx_frame_stereo_submit) on a second extractor handle before frame t is tracked and "
-                                      "collected at the start of step t+1; the constructor left in flight by the last timed step is "
-                                      "waited for inside the timed region") if pipeline else "synchronous",
+                                      "collected at the start of step t+1; the timed region holds exactly K constructors (the first step "
+                                      "submits its own, the last one hands no further frame over)") if pipeline else "synchronous",
                        "pose_opt_ms_per_call_450_correspondences": round(pose_opt_ms, 4),
                        "lba_ms_per_call": round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3),
                        "sequential_fps_formula": round(1.0 / (sum(v for k2, v in stage.items() if k2 != "lba") / K +

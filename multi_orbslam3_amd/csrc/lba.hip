@@ -2950,11 +2950,23 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     const uint8_t* __restrict__ rf = rflags;
     uint8_t* __restrict__ odp = reinterpret_cast<uint8_t*>(r->edge_depth_pos);
     uint8_t* __restrict__ oout = reinterpret_cast<uint8_t*>(r->edge_outlier);
-    if (odp) for (int k = 0; k < NE; k++) odp[k] = rf[k] & 1;
-    if (oout) for (int k = 0; k < NE; k++) oout[k] = (rf[k] >> 1) & 1;
-    for (int k = 0; k < NE; k++) n_out += (rf[k] >> 1) & 1;
+    if (version == 0) {
+      // the flag was raised between the check that precedes optimize() and the first iteration: g2o never evaluated a
+      // residual (e->chi2() reads an edge's never-written _error: pinned as zero, as in the oracle), so only the depth test
+      // of the unchanged estimate can make an outlier (S/Optimizer.cc:2219-2253)
+      if (odp) for (int k = 0; k < NE; k++) odp[k] = rf[k] & 1;
+      if (oout) for (int k = 0; k < NE; k++) oout[k] = (rf[k] & 1) ^ 1;
+      for (int k = 0; k < NE; k++) n_out += (rf[k] & 1) ^ 1;
+    } else {
+      if (odp) for (int k = 0; k < NE; k++) odp[k] = rf[k] & 1;
+      if (oout) for (int k = 0; k < NE; k++) oout[k] = (rf[k] >> 1) & 1;
+      for (int k = 0; k < NE; k++) n_out += (rf[k] >> 1) & 1;
+    }
   }
-  if (r->edge_chi2 && NE > 0) memcpy(r->edge_chi2, h->dl_h.h + d_chi_o, 8 * (size_t)NE);
+  if (r->edge_chi2 && NE > 0) {
+    if (version == 0) memset(r->edge_chi2, 0, 8 * (size_t)NE);
+    else memcpy(r->edge_chi2, h->dl_h.h + d_chi_o, 8 * (size_t)NE);
+  }
   r->n_outliers = n_out;
   if (NE > 0 && n_out >= NE * 0.5) r->status = LBA_REJECTED_OUTLIERS;
   for (int i = 0; i < NP; i++) {                       // Converter::toCvMat(SE3Quat)

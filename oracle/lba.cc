@@ -566,7 +566,8 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
   if (bDoMore) r->iters_round2 = optimize(p->its_round2 > 0 ? p->its_round2 : 10);   // :2202-2203 (outliers kept, Appendix C-6)
 
   // :2207-2261 -- e->chi2() uses the errors of the LAST computeActiveErrors (possibly a rejected trial);
-  // isDepthPositive() uses the current estimates.
+  // isDepthPositive() uses the current estimates.  If the flag was raised before the first iteration no residual was ever
+  // evaluated: g2o's BaseEdge leaves _error uninitialised (G/core/base_edge.h:50-58) -- pinned here as zero (s.chi2 starts zeroed).
   int n_out = 0;
   for (int k = 0; k < p->n_edges; k++) {
     const lba_edge& e = p->edges[k];

@@ -40,7 +40,7 @@ def test_bench_line_has_the_contract_fields():
     cfgd = d["config"]
     # `value` is the host-image accounting: the images enter through pinned staging + a PCIe copy inside the step
     assert cfgd["host_images_in_step"] is True and "pinned staging" in cfgd["image_ingest"]
-    assert cfgd["local_map_keyframes"] == 20 and 3000 <= cfgd["local_map_points_avg"] <= 12000 and cfgd["sequence_frames"] >= 190
+    assert cfgd["local_map_keyframes"] == 20 and 2000 <= cfgd["local_map_points_avg"] <= 12000 and cfgd["sequence_frames"] >= 190
     assert d["data"] == "synthetic" and "workload" in cfgd and "model" not in cfgd and cfgd["name"] == "C2"
     assert cfgd["device_copy_GBps_measured"] > 500 and cfgd["host_cpu"]["nproc"] >= 1 and cfgd["host_cpu"]["model"]
     assert cfgd["whole_step_hbm"]["achieved_GBps"] > 0
