@@ -307,6 +307,9 @@ def main():
     ap.add_argument("--ingest", choices=["thread", "inline"], default="thread",
                     help="host images: thread = the library's ingest thread packs the rows into pinned staging and enqueues the "
                          "constructor (orbx_frame_stereo_submit, ORBX_SUBMIT_ASYNC); inline = the tracking thread does")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip tests/cpp/dropin_bench (the per-frame path and the local BA timed through the reference-signature glue "
+                         "over mock Frame / KeyFrame / MapPoint objects; reported as value_dropin)")
     ap.add_argument("--profile-stages", action="store_true", help="bracket every extractor stage with HIP events")
     ap.add_argument("--no-numa-pin", action="store_true",
                     help="do not restrict the process to the CPUs of the GPU's NUMA node (default: like numactl --cpunodebind)")
@@ -633,6 +636,7 @@ def main():
         server_tick = run_server_tick(grp, api, views, torch, device, frames, kf_chunks, fv, LM, scene)
 
     copy_gbs = copy_bandwidth_gbs(torch, device) if rank == 0 else None
+    dropin = run_dropin_bench() if (rank == 0 and not args.no_dropin and args.config == "C2") else None
 
     if rank == 0:
         K = args.steps
@@ -766,6 +770,13 @@ def main():
                                         "reported as the contract asks" if dominant == "octree_kernel" else
                                         "one launch per Frame constructor (both cameras)"}
         line.update(secondary)
+        if dropin is not None:
+            line["value_dropin"] = dropin.get("frames_per_s_frame_path")
+            line["value_dropin_note"] = ("tests/cpp/dropin_bench: Frame::Frame(stereo, host images) + SearchByProjection(Cur, Last) + SearchLocalPoints "
+                                         "called through the reference-signature glue (include/orbgpu_dropin.hpp) on mock Frame / MapPoint "
+                                         "objects, synchronous constructor, one thread: frames/s of that frame path; per-call glue / upload / "
+                                         "C-ABI microseconds under config.dropin")
+            line["config"]["dropin"] = dropin
         if server_tick is not None:
             line["config"]["server_tick"] = server_tick
     # CPU baseline: every rank (= agent) runs its own sample on its own three physical cores ("for A agents run A
@@ -788,6 +799,22 @@ def main():
     if rank == 0:
         print(json.dumps(line))
     grp.close()
+
+
+def run_dropin_bench():
+    """tests/cpp/dropin_bench (built by __graft_entry__.build(); rebuilt here if missing): the path through the reference-side glue."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_bench")
+    try:
+        if not os.path.exists(exe):
+            import __graft_entry__ as ge
+            ge.build_dropin_bench()
+        r = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": "dropin_bench exit code %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:                                # the headline does not depend on it
+        return {"error": repr(e)[:300]}
 
 
 def run_server_tick(grp, api, views, torch, device, frames, kf_chunks, fv, LM, scene, reps=50):

@@ -182,6 +182,14 @@ class FrameOnDevice {
     check(orbx_frame_stereo_dev_submit(ex.handle(), f_, &v, d_left, d_right, width, height, stride, v.bf, v.b),
           "orbx_frame_stereo_dev_submit");
   }
+  // ... and for HOST images (the cv::Mat data Tracking::GrabImageStereo holds): Submit packs the rows into the extractor's pinned
+  // staging slot and enqueues copy + chain; with async_ingest the library's ingest thread does that and the images must stay
+  // valid until StereoCtorWait.
+  void StereoCtorSubmitHost(ORBextractor& ex, orbm_frame_view v, const uint8_t* left, const uint8_t* right, int width, int height,
+                            int stride, bool async_ingest = false) {
+    check(orbx_frame_stereo_submit(ex.handle(), f_, &v, left, right, width, height, stride, v.bf, v.b, async_ingest ? ORBX_SUBMIT_ASYNC : 0),
+          "orbx_frame_stereo_submit");
+  }
   int StereoCtorWait(ORBextractor& ex, int* n_right = nullptr) {
     int nl = 0, nr = 0;
     check(orbx_frame_stereo_dev_wait(ex.handle(), &nl, &nr), "orbx_frame_stereo_dev_wait");

@@ -1,0 +1,193 @@
+// Synthetic agent shared by tests/cpp/dropin_parity.cpp and tests/cpp/dropin_bench.cpp: a textured plane seen by a moving stereo
+// rig, Frames built through the extractor adapter, map points as LocalMapping creates them, and a local-BA window -- all held in
+// the header-only mocks of Frame / KeyFrame / MapPoint / Map (mock_orbslam3.hpp).
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+#include "mock_orbslam3.hpp"
+#include "orbgpu_dropin.hpp"
+
+using namespace mock;
+
+// ------------------------------------------------------------------------------------------------ synthetic agent
+static unsigned g_seed = 1;
+static unsigned rnd() { g_seed = g_seed * 1664525u + 1013904223u; return g_seed >> 8; }
+static double urand() { return (rnd() & 0xFFFFFF) / double(0x1000000); }
+static double nrand() { double a = urand() + 1e-12, b = urand(); return std::sqrt(-2 * std::log(a)) * std::cos(6.283185307179586 * b); }
+
+static const int W = 640, H = 480, TW = 1600, TH = 1200;
+static const float FX = 458.654f * 640 / 752, CX = 320.f, CY = 240.f, BF = 47.90639384423901f * 640 / 752, BB = BF / FX;
+
+static std::vector<uint8_t> make_texture() {
+  std::vector<float> t((size_t)TW * TH, 110.f);
+  for (int cell = 128; cell >= 4; cell /= 2) {                    // value noise octaves
+    const int gw = TW / cell + 2, gh = TH / cell + 2;
+    std::vector<float> g((size_t)gw * gh);
+    for (auto& x : g) x = (float)(urand() - 0.5) * cell * 0.9f;
+    for (int y = 0; y < TH; y++)
+      for (int x = 0; x < TW; x++) {
+        const int gx = x / cell, gy = y / cell; const float fx = (x % cell) / (float)cell, fy = (y % cell) / (float)cell;
+        t[(size_t)y * TW + x] += (g[gy * gw + gx] * (1 - fx) + g[gy * gw + gx + 1] * fx) * (1 - fy) + (g[(gy + 1) * gw + gx] * (1 - fx) + g[(gy + 1) * gw + gx + 1] * fx) * fy;
+      }
+  }
+  for (int k = 0; k < 700; k++) {                                // dark / bright rectangles: plenty of FAST corners
+    const int x0 = rnd() % (TW - 60), y0 = rnd() % (TH - 60), w = 8 + rnd() % 50, h = 8 + rnd() % 50; const float val = (rnd() & 1) ? 225.f : 30.f;
+    for (int y = y0; y < y0 + h; y++) for (int x = x0; x < x0 + w; x++) t[(size_t)y * TW + x] = val + (float)((x * 7 + y * 13) % 9);
+  }
+  std::vector<uint8_t> out(t.size());
+  for (size_t i = 0; i < t.size(); i++) out[i] = (uint8_t)std::min(255.f, std::max(0.f, t[i]));
+  return out;
+}
+
+static void rot(double rx, double ry, double rz, double R[9]) {
+  const double cx = std::cos(rx), sx = std::sin(rx), cy = std::cos(ry), sy = std::sin(ry), cz = std::cos(rz), sz = std::sin(rz);
+  const double Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx}, Ry[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy}, Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+  double T[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T[3 * i + j] = 0; for (int k = 0; k < 3; k++) T[3 * i + j] += Ry[3 * i + k] * Rx[3 * k + j]; }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[3 * i + j] = 0; for (int k = 0; k < 3; k++) R[3 * i + j] += Rz[3 * i + k] * T[3 * k + j]; }
+}
+static void pose_of(int k, double T[16]) {                       // left camera: drift + tilt over the plane z = 0
+  const double t = 0.02 * k; double R[9];
+  rot(0.32 + 0.04 * std::sin(0.7 * t + 0.3), -0.22 + 0.05 * std::sin(0.5 * t), 0.03 * std::sin(0.9 * t), R);
+  const double C[3] = {3.75 + 0.6 * t, 3.0 + 0.15 * std::sin(0.8 * t), -2.8 - 0.1 * std::sin(0.6 * t)};
+  for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0) ? 1 : 0;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * i + j]; T[4 * i + 3] = -(R[3 * i] * C[0] + R[3 * i + 1] * C[1] + R[3 * i + 2] * C[2]); }
+}
+static std::vector<uint8_t> render(const std::vector<uint8_t>& tex, const double T[16]) {
+  std::vector<uint8_t> im((size_t)W * H);
+  double Ow[3];
+  for (int i = 0; i < 3; i++) Ow[i] = -(T[i] * T[3] + T[4 + i] * T[7] + T[8 + i] * T[11]);
+  for (int v = 0; v < H; v++)
+    for (int u = 0; u < W; u++) {
+      const double d[3] = {(u - CX) / FX, (v - CY) / FX, 1.0};
+      double dw[3];
+      for (int i = 0; i < 3; i++) dw[i] = T[i] * d[0] + T[4 + i] * d[1] + T[8 + i] * d[2];
+      const double s = -Ow[2] / dw[2];
+      const double X = (Ow[0] + s * dw[0]) * 200.0, Y = (Ow[1] + s * dw[1]) * 200.0;
+      const double tx = std::min(std::max(X, 0.0), TW - 1.001), ty = std::min(std::max(Y, 0.0), TH - 1.001);
+      const int x0 = (int)tx, y0 = (int)ty; const double fx = tx - x0, fy = ty - y0;
+      const double val = (tex[(size_t)y0 * TW + x0] * (1 - fx) + tex[(size_t)y0 * TW + x0 + 1] * fx) * (1 - fy) +
+                         (tex[(size_t)(y0 + 1) * TW + x0] * (1 - fx) + tex[(size_t)(y0 + 1) * TW + x0 + 1] * fx) * fy;
+      im[(size_t)v * W + u] = (uint8_t)std::lrint(std::min(255.0, std::max(0.0, val)));
+    }
+  return im;
+}
+
+static Mat mat44(const double T[16]) { Mat m(4, 4, 4); for (int i = 0; i < 16; i++) m.ptr<float>(0)[i] = (float)T[i]; return m; }
+
+struct Agent {          // everything one run (one Ops) owns: frames, map points, keyframes
+  std::vector<std::unique_ptr<Frame>> frames;
+  std::vector<std::unique_ptr<MapPoint>> points;
+  std::vector<std::unique_ptr<KeyFrame>> kfs;
+  Map map;
+};
+
+// Frame::Frame(stereo) through the adapter: extraction L+R, ComputeStereoMatches, grid -- and the host copies the mocks hold
+static void make_frame(Agent& A, orbgpu::ORBextractor& rig, const std::vector<uint8_t>& tex, int k) {
+  double T[16], Tr[16]; pose_of(k, T);
+  for (int i = 0; i < 16; i++) Tr[i] = T[i];
+  Tr[3] -= BB;
+  const std::vector<uint8_t> L = render(tex, T), R = render(tex, Tr);
+  std::unique_ptr<Frame> F(new Frame);
+  F->mnMinX = 0; F->mnMaxX = W; F->mnMinY = 0; F->mnMaxY = H; F->fx = FX; F->fy = FX; F->cx = CX; F->cy = CY; F->mbf = BF; F->mb = BB;
+  orbm_frame_view v{0, nullptr, nullptr, nullptr, nullptr, 0, (float)W, 0, (float)H, FX, FX, CX, CY, BF, BB, 8, 1.2f};
+  orbgpu::FrameOnDevice dev(4096);
+  std::vector<orbx_keypoint> keys; std::vector<uint8_t> desc; std::vector<float> ur, dp;
+  const int N = dev.StereoCtor(rig, v, L.data(), R.data(), W, H, W, &keys, &desc, &ur, &dp);
+  F->N = N; F->mvKeys.resize(N); F->mDescriptors = Mat(N, 32, 1); F->mvuRight = ur; F->mvDepth = dp;
+  for (int i = 0; i < N; i++) F->mvKeys[i] = KeyPoint{{keys[i].x, keys[i].y}, keys[i].size, keys[i].angle, keys[i].response, keys[i].octave};
+  F->mvKeysUn = F->mvKeys;                                        // k1 == 0: no undistortion (S/Frame.cc:723-727)
+  std::memcpy(F->mDescriptors.ptr<uint8_t>(0), desc.data(), desc.size());
+  F->mvpMapPoints.assign(N, nullptr); F->mvbOutlier.assign(N, false);
+  F->mvInvLevelSigma2 = rig.GetInverseScaleSigmaSquares();
+  F->mTcw = mat44(T);
+  { int ns = 0; for (int i = 0; i < N; i++) ns += dp[i] > 0; std::fprintf(stderr, "frame %d: %d keypoints, %d with stereo depth\n", k, N, ns); }
+  for (int i = 0; i < N; i++) F->mFeatVec[(desc[32 * (size_t)i] | (desc[32 * (size_t)i + 1] << 8)) & 0x3FF].push_back(i);   // stand-in vocabulary: 10 descriptor bits = node id
+  A.frames.push_back(std::move(F));
+}
+
+// map points as LocalMapping creates them from a stereo keyframe (S/LocalMapping.cc CreateNewMapPoints / MapPoint::UpdateNormalAndDepth)
+static void make_points_from(Agent& A, const Frame& F, std::vector<MapPoint*>& out, std::vector<int>& feat_of) {
+  const float* T = F.mTcw.ptr<float>(0);
+  float Ow[3];
+  for (int i = 0; i < 3; i++) Ow[i] = -(T[i] * T[3] + T[4 + i] * T[7] + T[8 + i] * T[11]);
+  float sf[8]; sf[0] = 1.f; for (int l = 1; l < 8; l++) sf[l] = sf[l - 1] * 1.2f;
+  for (int i = 0; i < F.N; i++) {
+    const float z = F.mvDepth[i];
+    if (!(z > 0)) continue;
+    const float xc = (F.mvKeysUn[i].pt.x - CX) * z / FX, yc = (F.mvKeysUn[i].pt.y - CY) * z / FX;
+    const float Pc[3] = {xc - T[3], yc - T[7], z - T[11]};
+    std::unique_ptr<MapPoint> p(new MapPoint);
+    float* X = p->mWorldPos.ptr<float>(0);
+    for (int a = 0; a < 3; a++) X[a] = T[a] * Pc[0] + T[4 + a] * Pc[1] + T[8 + a] * Pc[2];
+    float PO[3] = {X[0] - Ow[0], X[1] - Ow[1], X[2] - Ow[2]};
+    const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    for (int a = 0; a < 3; a++) p->mNormalVector.ptr<float>(0)[a] = PO[a] / dist;
+    p->mfMaxDistance = dist * sf[F.mvKeysUn[i].octave]; p->mfMinDistance = p->mfMaxDistance / sf[7];
+    std::memcpy(p->mDescriptor.ptr<uint8_t>(0), F.mDescriptors.ptr<uint8_t>(i), 32);
+    p->mnId = A.points.size(); p->nObs = 3; p->mpMap = &A.map;
+    out.push_back(p.get()); feat_of.push_back(i);
+    A.points.push_back(std::move(p));
+  }
+}
+
+// The window Optimizer::LocalBundleAdjustment works on: n_local covisible keyframes (the last one is the new keyframe), n_far older
+// ones that only observe shared points (they become the fixed cameras), n_pts points seen by runs of 3-7 keyframes, pixel noise,
+// gross outliers.  Returns the new keyframe.
+static KeyFrame* build_lba_scene(Agent& A, int n_local, int n_far, int n_pts, double outlier_frac, unsigned seed) {
+  g_seed = seed;
+  const int P = n_local + n_far;
+  std::vector<std::vector<double>> Tt(P, std::vector<double>(16));
+  float isig[8]; { float s = 1.f; for (int l = 0; l < 8; l++) { isig[l] = 1.f / (s * s); s *= 1.2f; } }
+  for (int k = 0; k < P; k++) {
+    double R[9]; rot(0.02 * std::sin(0.3 * k), 0.03 * std::sin(0.2 * k + 1.0), 0.01 * std::sin(0.5 * k), R);
+    const double C[3] = {0.12 * k, 0.02 * std::sin(0.4 * k), 0.03 * std::cos(0.3 * k)};
+    for (int i = 0; i < 16; i++) Tt[k][i] = (i % 5 == 0) ? 1 : 0;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tt[k][4 * i + j] = R[3 * i + j]; Tt[k][4 * i + 3] = -(R[3 * i] * C[0] + R[3 * i + 1] * C[1] + R[3 * i + 2] * C[2]); }
+    std::unique_ptr<KeyFrame> kf(new KeyFrame);
+    kf->mnId = 10 + k; kf->fx = FX; kf->fy = FX; kf->cx = CX; kf->cy = CY; kf->mbf = BF; kf->mpMap = &A.map;
+    kf->mvInvLevelSigma2.assign(isig, isig + 8);
+    double Tn[16]; for (int i = 0; i < 16; i++) Tn[i] = Tt[k][i];
+    Tn[3] += 0.01 * nrand(); Tn[7] += 0.01 * nrand(); Tn[11] += 0.01 * nrand();       // initial estimate: truth + 1 cm
+    kf->Tcw = mat44(Tn);
+    A.kfs.push_back(std::move(kf));
+  }
+  A.map.mnInitKFid = 0;                                            // the initial keyframe is not in the window
+  KeyFrame* cur = A.kfs[P - 1].get();                              // the new keyframe: covisible with the n_local - 1 before it
+  // (covisibility order: ascending ids here -- with descending ids the reference's "two lowest ids" scan, S/Optimizer.cc:1886-1899,
+  //  never finds a second keyframe and reads an uninitialised pointer; the glue then fixes only one)
+  for (int k = n_far; k <= P - 2; k++) cur->mvpOrderedConnectedKeyFrames.push_back(A.kfs[k].get());
+  for (int j = 0; j < n_pts; j++) {
+    const int nobs = std::min(3 + (int)(rnd() % 5), P), k0 = rnd() % (P - nobs + 1), kc = std::min(k0 + nobs / 2, P - 1);
+    const double z = 2.0 + 7.0 * urand(), u = 60 + (W - 120) * urand(), v = 60 + (H - 120) * urand();
+    const double Pc[3] = {(u - CX) * z / FX, (v - CY) * z / FX, z};
+    const double* T = Tt[kc].data();
+    double Xw[3];
+    for (int a = 0; a < 3; a++) Xw[a] = T[a] * (Pc[0] - T[3]) + T[4 + a] * (Pc[1] - T[7]) + T[8 + a] * (Pc[2] - T[11]);
+    std::unique_ptr<MapPoint> mp(new MapPoint);
+    mp->mnId = 100 + j; mp->mpMap = &A.map;
+    for (int a = 0; a < 3; a++) mp->mWorldPos.ptr<float>(0)[a] = (float)(Xw[a] + 0.02 * nrand());
+    for (int k = k0; k < k0 + nobs; k++) {
+      const double* Tk = Tt[k].data();
+      double Xc[3];
+      for (int a = 0; a < 3; a++) Xc[a] = Tk[4 * a] * Xw[0] + Tk[4 * a + 1] * Xw[1] + Tk[4 * a + 2] * Xw[2] + Tk[4 * a + 3];
+      if (Xc[2] < 0.3) continue;
+      const int oct = rnd() % 4; const double sig = std::pow(1.2, oct);
+      double pu = FX * Xc[0] / Xc[2] + CX + sig * nrand(), pv = FX * Xc[1] / Xc[2] + CY + sig * nrand();
+      if (urand() < outlier_frac) { pu += (urand() < 0.5 ? -1 : 1) * (15 + 20 * urand()); pv += (urand() < 0.5 ? -1 : 1) * (15 + 20 * urand()); }
+      KeyFrame* kf = A.kfs[k].get();
+      const int li = (int)kf->mvKeysUn.size();
+      kf->mvKeysUn.push_back(KeyPoint{{(float)pu, (float)pv}, 31.f, 0.f, 20.f, oct});
+      kf->mvuRight.push_back((rnd() % 10 == 0) ? -1.f : (float)(pu - BF / Xc[2] + sig * nrand()));     // one in ten observations is monocular
+      kf->mvpMapPoints.push_back(mp.get());
+      mp->mObservations[kf] = std::make_tuple(li, -1);
+      mp->nObs++;
+    }
+    A.points.push_back(std::move(mp));
+  }
+  return cur;
+}
+

@@ -30,7 +30,7 @@ def _no_gpu():
     return _capi.load().orbg_device_count() <= 0
 
 
-@pytest.mark.parametrize("name,with_oracle", [("adapter_smoke", False), ("dropin_parity", True)])
+@pytest.mark.parametrize("name,with_oracle", [("adapter_smoke", False), ("dropin_parity", True), ("dropin_bench", False)])
 def test_host_side_compiles_links_and_fails_loudly_without_gpu(name, with_oracle):
     exe = _build(name, with_oracle)
     if not _no_gpu():
@@ -55,3 +55,18 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
     exe = _build("dropin_parity", with_oracle=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "dropin parity ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-1000:])
+
+
+@pytest.mark.gpu
+def test_dropin_bench_times_the_path_through_the_glue():
+    """tests/cpp/dropin_bench: every call of the per-frame path and the local BA through the reference-signature glue over the
+    mocks at C2 sizes; glue / upload / C-ABI time per call as one JSON line (bench.py surfaces it as value_dropin)."""
+    import json
+    exe = _build("dropin_bench")
+    r = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rows = d["dropin_bench"]
+    assert len(rows) == 5 and d["frames_per_s_frame_path"] > 0 and d["local_map_points"] > 2000
+    for name, row in rows.items():
+        assert row["total_us"] > 0 and row["c_abi_us"] > 0 and 0 <= row["glue_frac"] < 1.0, (name, row)
