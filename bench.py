@@ -568,7 +568,9 @@ def main():
     prewarm_done = 0
     t_pw = time.perf_counter()
     scratch = Region(1)
-    while prewarm_done < args.prewarm_steps or time.perf_counter() - t_pw < 0.05:
+    # (... and such that the first TIMED step is a keyframe step: the region then holds exactly K / FRAMES_PER_KF local BAs, the
+    # last of them submitted FRAMES_PER_KF steps before the clock stops, whatever K and --warmup are)
+    while (prewarm_done < args.prewarm_steps or time.perf_counter() - t_pw < 0.05 or (prewarm_done + args.warmup) % FRAMES_PER_KF != 0):
         step(prewarm_done, scratch, False, args.pose_opt, host_images, pipeline)
         prewarm_done += 1
     collect_async(scratch)

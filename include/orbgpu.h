@@ -259,6 +259,11 @@ int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* pts);
 int orbm_search_local_points(orbm_frame* f, orbm_map* m, const float* Tcw, const uint8_t* skip /*m or NULL*/,
                              float th, int far_points, float th_far_points, float nnratio,
                              int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+/* Same, and in_frustum[m] (may be NULL) reports for which points isInFrustum() returned true -- the points the loop of
+ * Tracking::SearchLocalPoints calls IncreaseVisible() for and counts in nToMatch (S/Tracking.cc:3118-3122). */
+int orbm_search_local_points_vis(orbm_frame* f, orbm_map* m, const float* Tcw, const uint8_t* skip /*m or NULL*/,
+                                 float th, int far_points, float th_far_points, float nnratio,
+                                 int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches, uint8_t* in_frustum /*m or NULL*/);
 
 /* LastFrame fields read by SearchByProjection(Frame &Cur, const Frame &Last, th, bMono)
  * (SURVEY.md Appendix E-4). SoA, n entries (= LastFrame.N). */

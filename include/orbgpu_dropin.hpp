@@ -10,6 +10,7 @@
 //   int  SearchByProjection(Frame& Current, const Frame& Last, th, bMono)                     I/ORBmatcher.h:50,  S/ORBmatcher.cc:1970-2186
 //   int  SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                                   I/ORBmatcher.h:64,  S/ORBmatcher.cc:269-471
 //   void isInFrustum for a list of points (Tracking::SearchLocalPoints' loop)                 S/Tracking.cc:3111-3128, S/Frame.cc:466-543
+//   void Tracking::SearchLocalPoints() body: the loop above + the matcher call as ONE device pass  S/Tracking.cc:3083-3155
 //   void LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int& num_fixedKF, int)      I/Optimizer.h:42,   S/Optimizer.cc:1810-2410
 //   int  PoseOptimization(Frame*)                                                             I/Optimizer.h:47,   S/Optimizer.cc:964-1278
 //
@@ -39,6 +40,17 @@ inline const uint8_t* mat_u8(const cv::Mat& m, int row) { return m.ptr<uint8_t>(
 inline void make_mat(cv::Mat& out, int rows, int cols, const float* data) { out = cv::Mat(rows, cols, CV_32F, const_cast<float*>(data)).clone(); }
 #endif
 
+// What an entry-point set gets to identify the Frame a call works on: its address and, if the Frame carries one, the
+// device-resident copy its constructor left behind (FrameOnDevice::StereoCtor / StereoCtorSubmitHost: features, stereo matches
+// and grid are already on the device, nothing is flattened or uploaded).  A Frame type opts in by having a member
+// `void* mpGpuFrame` (an orbgpu::FrameOnDevice*, nullptr = none).
+struct FrameKey {
+  const void* id = nullptr;
+  FrameOnDevice* resident = nullptr;
+};
+template <class FrameT> auto resident_frame_of(const FrameT& F, int) -> decltype(static_cast<FrameOnDevice*>(F.mpGpuFrame)) { return static_cast<FrameOnDevice*>(F.mpGpuFrame); }
+template <class FrameT> FrameOnDevice* resident_frame_of(const FrameT&, long) { return nullptr; }
+
 // ------------------------------------------------------------------------------------------------ entry points
 // The product: liborbgpu.  A Frame is uploaded on first use into one of a few device frames the calling thread keeps
 // (least recently used first: Tracking works on mCurrentFrame / mLastFrame / a relocalisation candidate at a time; the
@@ -53,10 +65,14 @@ struct GpuOps {
     Slot slots[kFrameSlots];
     unsigned long long tick = 0;
     std::unique_ptr<LocalBA> ba;
+    std::unique_ptr<MapPointsOnDevice> local_map;      // Tracking's local map, re-uploaded by every SearchLocalPoints
   };
   static ThreadState& state() { static thread_local ThreadState s; return s; }
-  static void release() { ThreadState& s = state(); for (auto& sl : s.slots) { sl.dev.reset(); sl.key = nullptr; sl.used = 0; } s.ba.reset(); }
-  static FrameOnDevice& frame(const void* key, const orbm_frame_view& v) {
+  static void release() { ThreadState& s = state(); for (auto& sl : s.slots) { sl.dev.reset(); sl.key = nullptr; sl.used = 0; } s.ba.reset(); s.local_map.reset(); }
+  static constexpr bool kUsesResidentFrame = true;
+  static FrameOnDevice& frame(const FrameKey& fk, const orbm_frame_view& v) {
+    if (fk.resident) return *fk.resident;
+    const void* key = fk.id;
     ThreadState& s = state();
     ThreadState::Slot* hit = nullptr; ThreadState::Slot* lru = &s.slots[0];
     for (auto& sl : s.slots) {
@@ -68,19 +84,28 @@ struct GpuOps {
     hit->dev->Upload(v);
     return *hit->dev;
   }
-  static int is_in_frustum(const void* key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim,
+  static int is_in_frustum(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim,
                            uint8_t* in_view, float* px, float* py, float* pxr, float* depth, int32_t* level, float* vcos) {
     return orbm_is_in_frustum(frame(key, v).handle(), Tcw, &pts, lim, in_view, px, py, pxr, depth, level, vcos);
   }
-  static int search_mps(const void* key, const orbm_frame_view& v, const orbm_mappoints_view& mps, float th, int far_points, float th_far,
+  static int search_mps(const FrameKey& key, const orbm_frame_view& v, const orbm_mappoints_view& mps, float th, int far_points, float th_far,
                         float nnratio, int32_t* amp, int32_t* aob, int* n) {
     return orbm_search_by_projection_mps(frame(key, v).handle(), &mps, th, far_points, th_far, nnratio, amp, aob, n);
   }
-  static int search_frame(const void* key, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono,
+  static int search_frame(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono,
                           int check_ori, int32_t* amp, int32_t* aob, int* n) {
     return orbm_search_by_projection_frame(frame(key, v).handle(), Tcw, &last, th, mono, check_ori, amp, aob, n);
   }
-  static int search_bow(const void* key, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf,
+  // isInFrustum(., 0.5) for every non-skipped point + SearchByProjection(F, points) in one device pass; in_frustum[m] out
+  static int search_local(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float th,
+                          int far_points, float th_far, float nnratio, int32_t* amp, int32_t* aob, int* n, uint8_t* in_frustum) {
+    ThreadState& s = state();
+    if (!s.local_map) s.local_map.reset(new MapPointsOnDevice(std::max(pts.m, 16384)));
+    s.local_map->Upload(pts);
+    return orbm_search_local_points_vis(frame(key, v).handle(), s.local_map->handle(), Tcw, nullptr, th, far_points, th_far, nnratio, amp, aob, n,
+                                        in_frustum);
+  }
+  static int search_bow(const FrameKey& key, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf,
                         const uint8_t* kf_valid, const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori,
                         int32_t* matches, int* n) {
     return orbm_search_by_bow(frame(key, v).handle(), &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
@@ -101,11 +126,20 @@ struct FrameFlat {
   std::vector<uint8_t> desc;
   std::vector<float> uright, depth;
   orbm_frame_view v;
+  FrameKey key;
 };
 
-template <class FrameT>
+template <class Ops, class FrameT>
 void flatten_frame(const FrameT& F, FrameFlat& o) {
   const int N = F.N;
+  o.key.id = &F;
+  o.key.resident = Ops::kUsesResidentFrame ? resident_frame_of(F, 0) : nullptr;
+  if (o.key.resident) {
+    // the features are on the device already: only the scalars of the view are needed
+    o.v = orbm_frame_view{N, nullptr, nullptr, nullptr, nullptr, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY,
+                          F.fx, F.fy, F.cx, F.cy, F.mbf, F.mb, F.mnScaleLevels, F.mfScaleFactor};
+    return;
+  }
   o.kps.resize(N); o.desc.resize((size_t)N * 32); o.uright.resize(N); o.depth.resize(N);
   for (int i = 0; i < N; i++) {
     const auto& kp = F.mvKeysUn[i];
@@ -152,7 +186,7 @@ inline size_t vertex_id(long unsigned id, unsigned client, bool is_kf) {       /
 template <class Ops = GpuOps, class FrameT, class MapPointT>
 int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewingCosLimit = 0.5f) {
   const int M = (int)vpMPs.size();
-  FrameFlat ff; flatten_frame(F, ff);
+  FrameFlat ff; flatten_frame<Ops>(F, ff);
   std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M); std::vector<uint8_t> desc(32 * (size_t)M), bad(M);
   std::vector<int32_t> nobs(M);
   for (int i = 0; i < M; i++) {
@@ -168,7 +202,7 @@ int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewin
   }
   orbm_worldpoints_view wv{M, pos.data(), nrm.data(), dmin.data(), dmax.data(), desc.data(), nobs.data(), bad.data(), nullptr};
   std::vector<uint8_t> inv(M); std::vector<float> px(M), py(M), pxr(M), dep(M), vc(M); std::vector<int32_t> lvl(M);
-  check(Ops::is_in_frustum(&F, ff.v, mat_f32(F.mTcw), wv, viewingCosLimit, inv.data(), px.data(), py.data(), pxr.data(), dep.data(),
+  check(Ops::is_in_frustum(ff.key, ff.v, mat_f32(F.mTcw), wv, viewingCosLimit, inv.data(), px.data(), py.data(), pxr.data(), dep.data(),
                            lvl.data(), vc.data()), "isInFrustum");
   int n = 0;
   for (int i = 0; i < M; i++) {
@@ -180,6 +214,59 @@ int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewin
   return n;
 }
 
+// ------------------------------------------------------------------------------------------------ Tracking::SearchLocalPoints
+// void Tracking::SearchLocalPoints(), S/Tracking.cc:3083-3155, with mCurrentFrame = F and mvpLocalMapPoints = vpLocalMapPoints:
+// the first loop (points the frame already holds: drop bad ones, IncreaseVisible, mnLastFrameSeen) runs here as it does there;
+// the second loop (isInFrustum per point) and matcher.SearchByProjection(F, points, th, bFarPoints, thFarPoints) are ONE device
+// pass over the flattened points (world position, normal, distance range, descriptor, flags -- one GetWorldPos / GetNormal /
+// GetDescriptor clone per point, as the reference's isInFrustum + SearchByProjection take).  Side effects kept: IncreaseVisible()
+// and mbTrackInView for the points in the frustum (the other mTrack* fields are only read by the search itself and, for the
+// viewer, through F.mmProjectPoints: call isInFrustumAll instead when they are needed).  `th` is the value the reference
+// derives from the sensor / IMU / relocalisation state (:3131-3151).  Returns the number of matches (nToMatch == 0: 0).
+template <class Ops = GpuOps, class FrameT, class MapPointT>
+int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints, float th, bool bFarPoints, float thFarPoints, float mfNNratio = 0.8f) {
+  for (auto& pMP : F.mvpMapPoints) {                                                          // :3086-3103
+    if (!pMP) continue;
+    if (pMP->isBad()) { pMP = nullptr; continue; }
+    pMP->IncreaseVisible();
+    pMP->mnLastFrameSeen = F.mnId;
+    pMP->mbTrackInView = false;
+  }
+  const int M = (int)vpLocalMapPoints.size();
+  if (M == 0) return 0;
+  FrameFlat ff; flatten_frame<Ops>(F, ff);
+  std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M); std::vector<uint8_t> desc(32 * (size_t)M), bad(M), skip(M);
+  std::vector<int32_t> nobs(M);
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = vpLocalMapPoints[i];
+    skip[i] = p->mnLastFrameSeen == F.mnId;                                                   // :3112-3113
+    bad[i] = p->isBad();                                                                      // :3114-3115
+    if (skip[i] || bad[i]) continue;
+    const auto X = p->GetWorldPos(); const auto nv = p->GetNormal(); const auto Dm = p->GetDescriptor();
+    std::memcpy(&pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&nrm[3 * (size_t)i], mat_f32(nv), 12);
+    dmin[i] = p->mfMinDistance; dmax[i] = p->mfMaxDistance;
+    std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
+    nobs[i] = p->Observations();
+  }
+  orbm_worldpoints_view wv{M, pos.data(), nrm.data(), dmin.data(), dmax.data(), desc.data(), nobs.data(), bad.data(), skip.data()};
+  std::vector<int32_t> amp, aob; flatten_assignments(F, amp, aob);
+  std::vector<uint8_t> vis(M);
+  int n = 0;
+  check(Ops::search_local(ff.key, ff.v, mat_f32(F.mTcw), wv, th, bFarPoints, thFarPoints, mfNNratio, amp.data(), aob.data(), &n, vis.data()),
+        "SearchLocalPoints");
+  int nToMatch = 0;
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = vpLocalMapPoints[i];
+    if (skip[i] || bad[i]) continue;
+    p->mbTrackInView = vis[i] != 0;                                                           // S/Frame.cc:468,529
+    if (vis[i]) { p->IncreaseVisible(); nToMatch++; }                                         // :3118-3122
+  }
+  if (nToMatch == 0) return 0;                                                                // :3129 (nothing was written: no query was valid)
+  for (int i = 0; i < F.N; i++)
+    if (amp[i] >= 0 && amp[i] != INT32_MAX) F.mvpMapPoints[i] = vpLocalMapPoints[amp[i]];       // S/ORBmatcher.cc:139
+  return n;
+}
+
 // ------------------------------------------------------------------------------------------------ ORBmatcher
 // int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th, const bool bFarPoints,
 //                                    const float thFarPoints), S/ORBmatcher.cc:44-214
@@ -187,7 +274,7 @@ template <class Ops = GpuOps, class FrameT, class MapPointT>
 int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th, const bool bFarPoints,
                        const float thFarPoints, float mfNNratio) {
   const int M = (int)vpMapPoints.size();
-  FrameFlat ff; flatten_frame(F, ff);
+  FrameFlat ff; flatten_frame<Ops>(F, ff);
   std::vector<uint8_t> inv(M), bad(M), desc(32 * (size_t)M); std::vector<float> px(M), py(M), pxr(M), dep(M), vc(M);
   std::vector<int32_t> lvl(M), nobs(M);
   for (int i = 0; i < M; i++) {                                    // the fields isInFrustum() stored (S/Frame.cc:529-538)
@@ -200,7 +287,7 @@ int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, co
   orbm_mappoints_view mv{M, inv.data(), bad.data(), px.data(), py.data(), pxr.data(), dep.data(), lvl.data(), vc.data(), desc.data(), nobs.data()};
   std::vector<int32_t> amp, aob; flatten_assignments(F, amp, aob);
   int n = 0;
-  check(Ops::search_mps(&F, ff.v, mv, th, bFarPoints, thFarPoints, mfNNratio, amp.data(), aob.data(), &n), "SearchByProjection(F, MPs)");
+  check(Ops::search_mps(ff.key, ff.v, mv, th, bFarPoints, thFarPoints, mfNNratio, amp.data(), aob.data(), &n), "SearchByProjection(F, MPs)");
   for (int i = 0; i < F.N; i++)
     if (amp[i] >= 0 && amp[i] != INT32_MAX) F.mvpMapPoints[i] = vpMapPoints[amp[i]];         // :139
   return n;
@@ -211,7 +298,7 @@ int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, co
 template <class Ops = GpuOps, class FrameT>
 int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono, bool mbCheckOrientation) {
   const int NL = LastFrame.N;
-  FrameFlat ff; flatten_frame(CurrentFrame, ff);
+  FrameFlat ff; flatten_frame<Ops>(CurrentFrame, ff);
   std::vector<uint8_t> valid(NL), outl(NL), desc(32 * (size_t)NL); std::vector<float> pos(3 * (size_t)NL), ang(NL);
   std::vector<int32_t> oct(NL), nobs(NL);
   for (int i = 0; i < NL; i++) {
@@ -226,7 +313,7 @@ int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const floa
   std::memcpy(lv.Tcw, mat_f32(LastFrame.mTcw), 64);
   std::vector<int32_t> amp, aob; flatten_assignments(CurrentFrame, amp, aob);
   int n = 0;
-  check(Ops::search_frame(&CurrentFrame, ff.v, mat_f32(CurrentFrame.mTcw), lv, th, bMono, mbCheckOrientation, amp.data(), aob.data(), &n),
+  check(Ops::search_frame(ff.key, ff.v, mat_f32(CurrentFrame.mTcw), lv, th, bMono, mbCheckOrientation, amp.data(), aob.data(), &n),
         "SearchByProjection(Cur, Last)");
   for (int i = 0; i < CurrentFrame.N; i++)
     if (amp[i] >= 0 && amp[i] != INT32_MAX) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[amp[i]];   // :2077 (rotation-histogram
@@ -238,7 +325,7 @@ template <class Ops = GpuOps, class KeyFrameT, class FrameT, class MapPointT>
 int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches, float mfNNratio, bool mbCheckOrientation) {
   const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
   const int NK = (int)vpMapPointsKF.size();
-  FrameFlat ff; flatten_frame(F, ff);
+  FrameFlat ff; flatten_frame<Ops>(F, ff);
   std::vector<uint8_t> kdesc(32 * (size_t)NK), kvalid(NK); std::vector<float> kang(NK);
   for (int i = 0; i < NK; i++) {
     std::memcpy(&kdesc[32 * (size_t)i], mat_u8(pKF->mDescriptors, i), 32);
@@ -249,7 +336,7 @@ int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMa
   FeatVecFlat<decltype(pKF->mFeatVec)> fK(pKF->mFeatVec);
   std::vector<int32_t> matches(F.N, -1);
   int n = 0;
-  check(Ops::search_bow(&F, ff.v, fF.v, kdesc.data(), NK, kvalid.data(), kang.data(), fK.v, mfNNratio, mbCheckOrientation, matches.data(), &n),
+  check(Ops::search_bow(ff.key, ff.v, fF.v, kdesc.data(), NK, kvalid.data(), kang.data(), fK.v, mfNNratio, mbCheckOrientation, matches.data(), &n),
         "SearchByBoW(KF, F)");
   vpMapPointMatches.assign(F.N, static_cast<MapPointT*>(nullptr));                           // :273
   for (int i = 0; i < F.N; i++)

@@ -124,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_upload", "orbm_frame_from_extractor", "orbx_frame_stereo_dev", "orbx_frame_stereo", "orbx_frame_stereo_dev_submit", "orbx_frame_stereo_dev_wait", "orbx_frame_stereo_submit", "orbx_frame_stereo_wait",
     "orbm_frame_get_grid", "orbm_hamming_matrix", "orbm_hamming_best2", "orbm_is_in_frustum",
     "orbm_search_by_projection_mps", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
-    "orbm_search_local_points", "orbm_search_by_projection_frame", "orbm_search_by_bow",
+    "orbm_search_local_points", "orbm_search_local_points_vis", "orbm_search_by_projection_frame", "orbm_search_by_bow",
     "orbm_search_by_projection_sim3", "orbm_search_by_bow_kf",
     "orbv_vocab_create", "orbv_vocab_destroy", "orbv_transform", "orbv_transform_frame", "orbv_bow_assemble",
     "orbm_distinctive_descriptors", "orbv_score_l1", "orbk_wire_bytes", "orbk_pack_frame", "orbk_frame_from_wire",

@@ -51,9 +51,11 @@ struct PoseF {   // Tcw split as the reference does (S/Frame.cc:439-445)
   float R[9], t[3], Ow[3];
 };
 
+constexpr unsigned short kQCountMask = 0x7FFF;   // QResult.count: entries of the list segment (capped) ...
+constexpr unsigned short kQVisible = 0x8000;     // ... and, from search_local_kernel, "isInFrustum() returned true for this point"
 struct QResult {   // per query, written by the kernel into mapped pinned memory (24 B)
   unsigned base;            // its segment of the candidate list (device memory; fetched only if the top-4 cannot decide)
-  unsigned short count;     // entries in the segment, filtered ones included
+  unsigned short count;     // entries in the segment, filtered ones included (& kQCountMask); bit 15: kQVisible
   unsigned short n_top;     // valid entries below (4 = there may be more candidates than listed here)
   unsigned short idx[4];    // the four best candidates in the order a sequential strict-'<' scan ranks them
   unsigned short dist[4];
@@ -344,10 +346,11 @@ __device__ __forceinline__ QDesc load_qdesc(const uint8_t* p) {
 __device__ __forceinline__ void window_search(const FrameParams& fp, const FrameDev& F, const Query& q, const QDesc& qd,
                                               int qid, int n_queries, int* __restrict__ list_counter,
                                               uint32_t* __restrict__ list, int list_cap, QResult* __restrict__ out,
-                                              uint32_t* __restrict__ s_list /*LDS, kListStage entries of this wavefront*/) {
+                                              uint32_t* __restrict__ s_list /*LDS, kListStage entries of this wavefront*/,
+                                              unsigned short flags = 0) {
   const int lane = threadIdx.x & 63;
   QResult res;
-  res.base = 0; res.count = 0; res.n_top = 0;
+  res.base = 0; res.count = flags; res.n_top = 0;
 #pragma unroll
   for (int j = 0; j < 4; j++) { res.idx[j] = 0xFFFF; res.dist[j] = 256; }
   bool empty = !q.valid;
@@ -447,7 +450,7 @@ __device__ __forceinline__ void window_search(const FrameParams& fp, const Frame
   if (lane < min(total, kListStage) && base + lane < list_cap) list[base + lane] = s_list[lane];
   top4_wave_emit(t, res);
   if (lane == 0) {
-    res.base = (unsigned)base; res.count = (unsigned short)min(total, 65535);
+    res.base = (unsigned)base; res.count = (unsigned short)(min(total, (int)kQCountMask) | flags);
     *out = res;
   }
 }
@@ -499,8 +502,10 @@ __global__ __launch_bounds__(256) void search_local_kernel(FrameParams fp, Frame
   const float N[3] = {w.normal[3 * i], w.normal[3 * i + 1], w.normal[3 * i + 2]};
   const float w_min = w.min_dist[i], w_max = w.max_dist[i];
   const QDesc qd = load_qdesc(w.desc + (size_t)i * 32);
+  unsigned short vis = 0;
   if (!(w_bad || w_skip || c_skip)) {
     const TrackFields t = frustum_check(fp, P, X, N, w_min, w_max, 0.5f);
+    if (t.in_view) vis = kQVisible;                        // what Tracking::SearchLocalPoints counts (IncreaseVisible, nToMatch)
     if (t.in_view && !(far_points && t.depth > th_far)) {
       float r = (t.view_cos > 0.998) ? 2.5f : 4.0f;        // RadiusByViewingCos, S/ORBmatcher.cc:216-222
       if (th != 1.0) r *= th;
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256) void search_local_kernel(FrameParams fp, Frame
       q.ur_ref = t.pxr;
     }
   }
-  window_search(fp, F, q, qd, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
+  window_search(fp, F, q, qd, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6], vis);
 }
 
 // SearchByProjection(KeyFrame*, Scw, ...) candidate tests (S/ORBmatcher.cc:495-548 / :612-667) fused with the window search
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restri
   }
   top4_wave_emit(t, res);
   if (lane == 0) {
-    res.base = (unsigned)base; res.count = (unsigned short)min(total, 65535);
+    res.base = (unsigned)base; res.count = (unsigned short)min(total, (int)kQCountMask);
     results[j] = res;
   }
 }
@@ -1222,39 +1227,22 @@ static TrackDev map_track(const orbm_map* m) {
   return t;
 }
 
+// Stand-alone isInFrustum for a list of points (the loop of Tracking::SearchLocalPoints): inputs and outputs travel through the
+// frame's pinned staging block, which the kernel reads and writes in place (every field is touched once): no allocation, no
+// copy command, one launch and one completion word per call.  Defined behind the staging helpers.
+static int frustum_zero_copy(orbm_frame* f, const float* Tcw, const orbm_worldpoints_view* pts, float limit, uint8_t* track_in_view,
+                             float* proj_x, float* proj_y, float* proj_xr, float* track_depth, int32_t* scale_level, float* view_cos);
 extern "C" int orbm_is_in_frustum(orbm_frame* f, const float* Tcw, const orbm_worldpoints_view* pts, float limit,
                                   uint8_t* track_in_view, float* proj_x, float* proj_y, float* proj_xr, float* track_depth,
                                   int32_t* scale_level, float* view_cos) {
-  if (!f || !Tcw || !pts) return ORBG_BAD_ARG;
-  orbm_map* m = nullptr;
-  int rc = orbm_map_create(f->device, pts->m, &m);
+  if (!f || !Tcw || !pts || pts->m < 0) return ORBG_BAD_ARG;
+  if (pts->m > 0 && (!pts->pos || !pts->normal || !pts->min_dist || !pts->max_dist || !track_in_view || !proj_x || !proj_y || !proj_xr ||
+                     !track_depth || !scale_level || !view_cos))
+    return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
   if (rc) return rc;
-  // only the geometric fields are needed here
-  orbm_worldpoints_view p = *pts;
-  std::vector<int> zeros_i(std::max(pts->m, 1), 0);
-  std::vector<uint8_t> zeros_u((size_t)std::max(pts->m, 1) * 32, 0);
-  if (!p.n_obs) p.n_obs = zeros_i.data();
-  if (!p.bad) p.bad = zeros_u.data();
-  if (!p.desc) p.desc = zeros_u.data();
-  if ((rc = orbm_map_upload(m, &p))) { orbm_map_destroy(m); return rc; }
-  PoseF P;
-  make_pose(Tcw, &P);
-  const int n = pts->m;
-  if (n > 0) {
-    if ((rc = map_sync_to(m, f->stream))) { orbm_map_destroy(m); return rc; }
-    hipLaunchKernelGGL(frustum_kernel, dim3((n + 255) / 256), dim3(256), 0, f->stream, f->fp, P, map_dev(m), limit, map_track(m));
-    hipError_t e = hipStreamSynchronize(f->stream);
-    if (e != hipSuccess) { orbm_map_destroy(m); return ORBG_HIP_ERROR; }
-    (void)hipMemcpy(track_in_view, m->t_in_view.p, n, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(proj_x, m->t_px.p, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(proj_y, m->t_py.p, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(proj_xr, m->t_pxr.p, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(track_depth, m->t_depth.p, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(scale_level, m->t_level.p, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(view_cos, m->t_vc.p, n * 4, hipMemcpyDeviceToHost);
-  }
-  orbm_map_destroy(m);
-  return ORBG_OK;
+  if (pts->m == 0) return ORBG_OK;
+  return frustum_zero_copy(f, Tcw, pts, limit, track_in_view, proj_x, proj_y, proj_xr, track_depth, scale_level, view_cos);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1309,6 +1297,36 @@ static int stage_commit(orbm_frame* f) {
     ORBG_HIP(hipMemcpyAsync(f->d_stage.p + f->copy_lo, f->stage.h + f->copy_lo, f->copy_hi - f->copy_lo, hipMemcpyHostToDevice, f->stream));
   return ORBG_OK;
 }
+static int frustum_zero_copy(orbm_frame* f, const float* Tcw, const orbm_worldpoints_view* pts, float limit, uint8_t* track_in_view,
+                             float* proj_x, float* proj_y, float* proj_xr, float* track_depth, int32_t* scale_level, float* view_cos) {
+  const size_t n = (size_t)pts->m;
+  int rc;
+  if ((rc = stage_begin(f, n * (32 + 25) + 16 * 16))) return rc;
+  WorldPtsDev w;
+  w.m = pts->m;
+  w.pos = stage_add(f, pts->pos, 3 * n); w.normal = stage_add(f, pts->normal, 3 * n);
+  w.min_dist = stage_add(f, pts->min_dist, n); w.max_dist = stage_add(f, pts->max_dist, n);
+  w.desc = nullptr; w.bad = nullptr; w.skip = nullptr;
+  // outputs: regions of the same block
+  auto out_region = [&](size_t bytes) { f->stage_off = (f->stage_off + 15) & ~(size_t)15; const size_t o = f->stage_off; f->stage_off += bytes; return o; };
+  const size_t o_iv = out_region(n), o_px = out_region(4 * n), o_py = out_region(4 * n), o_pxr = out_region(4 * n), o_dep = out_region(4 * n),
+               o_lvl = out_region(4 * n), o_vc = out_region(4 * n);
+  uint8_t* D = f->stage.d;
+  TrackDev t;
+  t.in_view = D + o_iv; t.px = reinterpret_cast<float*>(D + o_px); t.py = reinterpret_cast<float*>(D + o_py);
+  t.pxr = reinterpret_cast<float*>(D + o_pxr); t.depth = reinterpret_cast<float*>(D + o_dep); t.level = reinterpret_cast<int*>(D + o_lvl);
+  t.view_cos = reinterpret_cast<float*>(D + o_vc);
+  PoseF P;
+  make_pose(Tcw, &P);
+  hipLaunchKernelGGL(frustum_kernel, dim3((pts->m + 255) / 256), dim3(256), 0, f->stream, f->fp, P, w, limit, t);
+  ORBG_HIP(hipGetLastError());
+  if ((rc = f->sig.sync(f->stream))) return rc;
+  const uint8_t* Hh = f->stage.h;
+  memcpy(track_in_view, Hh + o_iv, n); memcpy(proj_x, Hh + o_px, 4 * n); memcpy(proj_y, Hh + o_py, 4 * n); memcpy(proj_xr, Hh + o_pxr, 4 * n);
+  memcpy(track_depth, Hh + o_dep, 4 * n); memcpy(scale_level, Hh + o_lvl, 4 * n); memcpy(view_cos, Hh + o_vc, 4 * n);
+  return ORBG_OK;
+}
+
 // F.mvpMapPoints occupancy at entry (S/ORBmatcher.cc:89-91 / :556): bitmask in the kernel arguments, or device arrays
 static void stage_occupancy(orbm_frame* f, const int32_t* amp, const int32_t* aob, int n) {
   f->occ_mask = n <= kOccBits;
@@ -1344,7 +1362,7 @@ static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
     // the end of the furthest list segment tells whether the overflow region was large enough
     size_t total = 0;
     const QResult* R = f->results.h;
-    for (int i = 0; i < n_queries; i++) total = std::max(total, (size_t)R[i].base + (size_t)R[i].count);
+    for (int i = 0; i < n_queries; i++) total = std::max(total, (size_t)R[i].base + (size_t)(R[i].count & kQCountMask));
     if (total <= f->list.cap) return ORBG_OK;
     if ((rc = f->list.reserve(total + total / 4))) return rc;
   }
@@ -1368,7 +1386,7 @@ static int pick_unclaimed(orbm_frame* f, const QResult& r, int want, ClaimedFn c
   if (found < want && r.n_top == 4) {
     p = Pick();
     const uint32_t* list = f->list.h + r.base;
-    for (int k = 0; k < r.count; k++) {
+    for (int k = 0; k < (r.count & kQCountMask); k++) {
       const uint32_t e = list[k];
       if (e == 0xFFFFFFFFu) continue;
       const int idx = (int)(e & 0xFFFF), dist = (int)(e >> 16);
@@ -1447,6 +1465,12 @@ extern "C" int orbm_search_by_projection_mps(orbm_frame* f, const orbm_mappoints
 extern "C" int orbm_search_local_points(orbm_frame* f, orbm_map* mp, const float* Tcw, const uint8_t* skip, float th,
                                         int far_points, float th_far_points, float nnratio, int32_t* assigned_mp,
                                         int32_t* assigned_obs, int* nmatches) {
+  return orbm_search_local_points_vis(f, mp, Tcw, skip, th, far_points, th_far_points, nnratio, assigned_mp, assigned_obs, nmatches, nullptr);
+}
+
+extern "C" int orbm_search_local_points_vis(orbm_frame* f, orbm_map* mp, const float* Tcw, const uint8_t* skip, float th,
+                                            int far_points, float th_far_points, float nnratio, int32_t* assigned_mp,
+                                            int32_t* assigned_obs, int* nmatches, uint8_t* in_frustum) {
   if (!f || !mp || !Tcw || !assigned_mp || !assigned_obs || f->device != mp->device) return ORBG_BAD_ARG;
   int rc = select_device(f->device);
   if (rc) return rc;
@@ -1468,6 +1492,10 @@ extern "C" int orbm_search_local_points(orbm_frame* f, orbm_map* mp, const float
                        th_far_points, cnt, cnt_next, f->list.d, list_cap, f->results.d);
   });
   if (rc) return rc;
+  if (in_frustum) {
+    const QResult* R = f->results.h;
+    for (int i = 0; i < m; i++) in_frustum[i] = (R[i].count & kQVisible) ? 1 : 0;
+  }
   return commit_mps(f, m, mp->n_obs.data(), nnratio, assigned_mp, assigned_obs, nmatches);
 }
 

@@ -22,14 +22,15 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 // The product's entry points with two stop-watches: time inside the C-ABI call proper, and time spent uploading the flattened
 // Frame (a Frame that carries an orbgpu::FrameOnDevice member, as the Frame constructor adapter leaves it, skips that part).
 struct TimedOps {
+  static constexpr bool kUsesResidentFrame = true;
   static double t_call, t_upload;
-  static orbgpu::FrameOnDevice& frame(const void* key, const orbm_frame_view& v) {
+  static orbgpu::FrameOnDevice& frame(const od::FrameKey& key, const orbm_frame_view& v) {
     const double t0 = now_us();
     orbgpu::FrameOnDevice& f = od::GpuOps::frame(key, v);
     t_upload += now_us() - t0;
     return f;
   }
-  static int is_in_frustum(const void* key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim,
+  static int is_in_frustum(const od::FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim,
                            uint8_t* in_view, float* px, float* py, float* pxr, float* depth, int32_t* level, float* vcos) {
     orbm_frame* f = frame(key, v).handle();
     const double t0 = now_us();
@@ -37,7 +38,7 @@ struct TimedOps {
     t_call += now_us() - t0;
     return rc;
   }
-  static int search_mps(const void* key, const orbm_frame_view& v, const orbm_mappoints_view& mps, float th, int far_points, float th_far,
+  static int search_mps(const od::FrameKey& key, const orbm_frame_view& v, const orbm_mappoints_view& mps, float th, int far_points, float th_far,
                         float nnratio, int32_t* amp, int32_t* aob, int* n) {
     orbm_frame* f = frame(key, v).handle();
     const double t0 = now_us();
@@ -45,7 +46,7 @@ struct TimedOps {
     t_call += now_us() - t0;
     return rc;
   }
-  static int search_frame(const void* key, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono,
+  static int search_frame(const od::FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono,
                           int check_ori, int32_t* amp, int32_t* aob, int* n) {
     orbm_frame* f = frame(key, v).handle();
     const double t0 = now_us();
@@ -53,7 +54,18 @@ struct TimedOps {
     t_call += now_us() - t0;
     return rc;
   }
-  static int search_bow(const void* key, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf,
+  static int search_local(const od::FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float th, int far_points,
+                          float th_far, float nnratio, int32_t* amp, int32_t* aob, int* n, uint8_t* in_frustum) {
+    orbm_frame* f = frame(key, v).handle();
+    od::GpuOps::ThreadState& s = od::GpuOps::state();
+    const double t0 = now_us();
+    if (!s.local_map) s.local_map.reset(new orbgpu::MapPointsOnDevice(std::max(pts.m, 16384)));
+    s.local_map->Upload(pts);
+    const int rc = orbm_search_local_points_vis(f, s.local_map->handle(), Tcw, nullptr, th, far_points, th_far, nnratio, amp, aob, n, in_frustum);
+    t_call += now_us() - t0;
+    return rc;
+  }
+  static int search_bow(const od::FrameKey& key, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf,
                         const uint8_t* kf_valid, const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori,
                         int32_t* matches, int* n) {
     orbm_frame* f = frame(key, v).handle();
@@ -101,7 +113,8 @@ int main(int argc, char** argv) {
     const std::vector<uint8_t> tex = make_texture();
     orbgpu::ORBextractor rig(1000, 1.2f, 8, 20, 7, W, H, /*n_cams*/ 2);
     Agent A;
-    for (int k = 0; k <= 7; k++) make_frame(A, rig, tex, k);
+    for (int k = 0; k <= 7; k++) make_frame(A, rig, tex, k, /*Tracking's current frame stays on the device*/ k == 7);
+    orbgpu::ORBextractor rig2(1000, 1.2f, 8, 20, 7, W, H, /*n_cams*/ 2);      // (the constructor row must not disturb the frame `rig` holds)
     Frame& Last = *A.frames[6];
     Frame& Cur = *A.frames[7];
     // local map: the points the keyframes 0..5 created (a few thousand, as bench.py's local map of 20 keyframes)
@@ -127,7 +140,7 @@ int main(int argc, char** argv) {
       Frame F;
       rows.push_back(measure("Frame::Frame(stereo, host images)", reps, 5, []() {}, [&]() {
         const double t0 = now_us();
-        const int N = dev.StereoCtor(rig, v, L.data(), R.data(), W, H, W, &keys, &desc, &ur, &dp);
+        const int N = dev.StereoCtor(rig2, v, L.data(), R.data(), W, H, W, &keys, &desc, &ur, &dp);
         TimedOps::t_call += now_us() - t0;
         // what the reference's constructor leaves in the Frame (S/Frame.cc:97-160): mvKeys / mvKeysUn, mDescriptors, mvuRight, mvDepth
         F.N = N; F.mvKeys.resize(N); F.mDescriptors = Mat(N, 32, 1); F.mvuRight = ur; F.mvDepth = dp;
@@ -145,7 +158,11 @@ int main(int argc, char** argv) {
     od::SearchByProjection<TimedOps>(Cur, Last, 7.0f, false, true);
     const std::vector<MapPoint*> after_frame = Cur.mvpMapPoints;
     auto reset_local = [&]() { Cur.mvpMapPoints = after_frame; Cur.mTcw = Tguess; };
-    rows.push_back(measure("SearchLocalPoints (isInFrustum + SearchByProjection(F, MPs))", reps, 5, reset_local, [&]() {
+    Cur.mnId = 7;
+    auto reset_fused = [&]() { reset_local(); for (auto* p : local) p->mnLastFrameSeen = ~0ul; };
+    rows.push_back(measure("SearchLocalPoints (fused: map upload + isInFrustum + search in one pass)", reps, 5, reset_fused,
+                           [&]() { return od::SearchLocalPoints<TimedOps>(Cur, local, 1.0f, false, 50.0f, 0.8f); }));
+    rows.push_back(measure("SearchLocalPoints as two calls (isInFrustum loop + SearchByProjection(F, MPs))", reps, 5, reset_fused, [&]() {
       od::isInFrustumAll<TimedOps>(Cur, local, 0.5f);
       return od::SearchByProjection<TimedOps>(Cur, local, 1.0f, false, 50.0f, 0.8f);
     }));
@@ -188,7 +205,7 @@ int main(int argc, char** argv) {
       std::snprintf(buf, sizeof(buf), "%s\"%s\": {\"total_us\": %.1f, \"c_abi_us\": %.1f, \"frame_upload_us\": %.1f, \"glue_us\": %.1f, \"glue_frac\": %.3f, \"work\": %d}",
                     i ? ", " : "", r.name.c_str(), r.total, r.call, r.upload, glue, glue / r.total, r.work);
       js += buf;
-      if (i < 3) frame_path += r.total;
+      if (i < 3) frame_path += r.total;      // constructor + SearchByProjection(Cur, Last) + fused SearchLocalPoints
     }
     char tail[512];
     std::snprintf(tail, sizeof(tail), "}, \"frame_path_us\": %.1f, \"frames_per_s_frame_path\": %.1f, \"local_map_points\": %zu, \"reps\": %d}", frame_path, 1e6 / frame_path,

@@ -24,21 +24,31 @@ using namespace mock;
 namespace od = orbgpu::dropin;
 
 struct OracleOps {       // the same entry points over the CPU oracle: views instead of device handles
-  static int is_in_frustum(const void*, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim, uint8_t* in_view,
+  static constexpr bool kUsesResidentFrame = false;
+  static int is_in_frustum(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim, uint8_t* in_view,
                            float* px, float* py, float* pxr, float* depth, int32_t* level, float* vcos) {
     return oracle_is_in_frustum(&v, Tcw, &pts, lim, in_view, px, py, pxr, depth, level, vcos);
   }
-  static int search_mps(const void*, const orbm_frame_view& v, const orbm_mappoints_view& mps, float th, int far_points, float th_far, float nnratio,
+  static int search_mps(const od::FrameKey&, const orbm_frame_view& v, const orbm_mappoints_view& mps, float th, int far_points, float th_far, float nnratio,
                         int32_t* amp, int32_t* aob, int* n) {
     return oracle_search_by_projection_mps(&v, &mps, th, far_points, th_far, nnratio, amp, aob, n);
   }
-  static int search_frame(const void*, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono, int check_ori,
+  static int search_frame(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono, int check_ori,
                           int32_t* amp, int32_t* aob, int* n) {
     return oracle_search_by_projection_frame(&v, Tcw, &last, th, mono, check_ori, amp, aob, n);
   }
-  static int search_bow(const void*, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf, const uint8_t* kf_valid,
+  static int search_bow(const od::FrameKey&, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf, const uint8_t* kf_valid,
                         const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori, int32_t* matches, int* n) {
     return oracle_search_by_bow(&v, &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
+  }
+  static int search_local(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float th, int far_points,
+                          float th_far, float nnratio, int32_t* amp, int32_t* aob, int* n, uint8_t* in_frustum) {
+    const int m = pts.m;
+    std::vector<float> px(m), py(m), pxr(m), dep(m), vc(m); std::vector<int32_t> lvl(m);
+    oracle_is_in_frustum(&v, Tcw, &pts, 0.5f, in_frustum, px.data(), py.data(), pxr.data(), dep.data(), lvl.data(), vc.data());
+    for (int i = 0; i < m; i++)
+      if ((pts.skip && pts.skip[i]) || pts.bad[i]) in_frustum[i] = 0;
+    return oracle_search_local_points(&v, &pts, Tcw, th, far_points, th_far, nnratio, amp, aob, n);
   }
   // (the oracle polls an int32: the bool is sampled -- the cases that raise it DURING the solve go through OracleAtTrialOps)
   static int lba(const lba_problem& p, const volatile bool* stop, lba_result& r) {
@@ -89,12 +99,12 @@ static std::vector<int> assignment_ids(const Frame& F, const std::vector<MapPoin
   return out;
 }
 
-struct TrackOut { int n_visible, n_map, n_frame, n_bow, n_pose; std::vector<int> a_map, a_frame, a_bow; std::vector<bool> outl; std::vector<float> pose; };
+struct TrackOut { int n_visible, n_map, n_frame, n_bow, n_pose, n_fused, vis_sum; std::vector<int> a_map, a_frame, a_bow, a_fused; std::vector<bool> outl; std::vector<float> pose; };
 
 template <class Ops>
 static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_t>& tex) {
   Agent A; TrackOut o;
-  for (int k : {4, 5, 6}) make_frame(A, rig, tex, k);
+  for (int k : {4, 5, 6}) make_frame(A, rig, tex, k, /*the frame being tracked stays on the device (product run)*/ k == 6);
   Frame &F0 = *A.frames[0], &F1 = *A.frames[1], &F2 = *A.frames[2];
   // ---- Tracking::SearchLocalPoints: isInFrustum + SearchByProjection(F, local map points)
   std::vector<MapPoint*> local; std::vector<int> src;
@@ -102,6 +112,21 @@ static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_
   o.n_visible = od::isInFrustumAll<Ops>(F2, local, 0.5f);
   o.n_map = od::SearchByProjection<Ops>(F2, local, 3.0f, false, 50.0f, 0.8f);
   o.a_map = assignment_ids(F2, local);
+  // ---- the same through the fused body of Tracking::SearchLocalPoints: some features already hold a point (those points are
+  // skipped through mnLastFrameSeen), one of them is bad (dropped from the frame), a few local points are bad
+  {
+    std::fill(F2.mvpMapPoints.begin(), F2.mvpMapPoints.end(), nullptr);
+    F2.mnId = 77;
+    for (size_t j = 0; j < local.size(); j++) { local[j]->mbTrackInView = false; local[j]->mnVisible = 1; local[j]->mnLastFrameSeen = ~0ul; local[j]->mbBad = (j % 41) == 7; }
+    int held = 0;
+    for (int i = 0; i < F2.N && held < 60; i++) if (o.a_map[i] >= 0) { F2.mvpMapPoints[i] = local[o.a_map[i]]; held++; }
+    o.n_fused = od::SearchLocalPoints<Ops>(F2, local, 3.0f, false, 50.0f, 0.8f);
+    o.a_fused = assignment_ids(F2, local);
+    o.vis_sum = 0;
+    for (auto* p : local) o.vis_sum += p->mnVisible + 1000 * (int)p->mbTrackInView;
+    for (auto* p : local) p->mbBad = false;
+    std::fill(F2.mvpMapPoints.begin(), F2.mvpMapPoints.end(), nullptr);
+  }
   // ---- TrackWithMotionModel: SearchByProjection(Current, Last) with the last frame's map points, then PoseOptimization
   std::vector<MapPoint*> lastpts; std::vector<int> lastfeat;
   make_points_from(A, F1, lastpts, lastfeat);
@@ -171,6 +196,8 @@ int main() {
     EXPECT(g.n_visible == c.n_visible && g.n_visible > 300, "isInFrustum %d vs %d", g.n_visible, c.n_visible);
     EXPECT(g.n_map == c.n_map && g.a_map == c.a_map && g.n_map > 100, "SearchByProjection(F, MPs) %d vs %d", g.n_map, c.n_map);
     EXPECT(g.n_frame == c.n_frame && g.a_frame == c.a_frame && g.n_frame > 100, "SearchByProjection(Cur, Last) %d vs %d", g.n_frame, c.n_frame);
+    EXPECT(g.n_fused == c.n_fused && g.a_fused == c.a_fused && g.vis_sum == c.vis_sum && g.n_fused > 100, "SearchLocalPoints (fused) %d vs %d, visible sums %d vs %d",
+           g.n_fused, c.n_fused, g.vis_sum, c.vis_sum);
     EXPECT(g.n_bow == c.n_bow && g.a_bow == c.a_bow && g.n_bow > 20, "SearchByBoW %d vs %d", g.n_bow, c.n_bow);
     EXPECT(g.n_pose == c.n_pose && g.outl == c.outl && g.n_pose > 50, "PoseOptimization inliers %d vs %d", g.n_pose, c.n_pose);
     EXPECT(max_abs_diff(g.pose, c.pose) <= 1e-4f, "PoseOptimization pose differs by %g", max_abs_diff(g.pose, c.pose));

@@ -39,6 +39,8 @@ class MapPoint {
   std::map<KeyFrame*, std::tuple<int, int>> mObservations;
   bool mbBad = false; Map* mpMap = nullptr; int nObs = 0;
   int n_normal_updates = 0;
+  long unsigned mnLastFrameSeen = ~0ul; int mnVisible = 1;
+  void IncreaseVisible(int n = 1) { mnVisible += n; }                   // S/MapPoint.cc:427-431
   bool isBad() const { return mbBad; }
   Map* GetMap() const { return mpMap; }
   int Observations() const { return nObs; }
@@ -87,6 +89,8 @@ class KeyFrame {
 
 class Frame {
  public:
+  long unsigned mnId = 0;
+  void* mpGpuFrame = nullptr;           // the device-resident copy the constructor adapter left (an orbgpu::FrameOnDevice*), or none
   int N = 0;
   std::vector<KeyPoint> mvKeys, mvKeysUn; Mat mDescriptors;
   std::vector<float> mvuRight, mvDepth, mvInvLevelSigma2;

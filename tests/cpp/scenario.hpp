@@ -79,6 +79,7 @@ static std::vector<uint8_t> render(const std::vector<uint8_t>& tex, const double
 static Mat mat44(const double T[16]) { Mat m(4, 4, 4); for (int i = 0; i < 16; i++) m.ptr<float>(0)[i] = (float)T[i]; return m; }
 
 struct Agent {          // everything one run (one Ops) owns: frames, map points, keyframes
+  std::vector<std::unique_ptr<orbgpu::FrameOnDevice>> dev_frames;
   std::vector<std::unique_ptr<Frame>> frames;
   std::vector<std::unique_ptr<MapPoint>> points;
   std::vector<std::unique_ptr<KeyFrame>> kfs;
@@ -86,7 +87,8 @@ struct Agent {          // everything one run (one Ops) owns: frames, map points
 };
 
 // Frame::Frame(stereo) through the adapter: extraction L+R, ComputeStereoMatches, grid -- and the host copies the mocks hold
-static void make_frame(Agent& A, orbgpu::ORBextractor& rig, const std::vector<uint8_t>& tex, int k) {
+// keep_on_device: the Frame keeps the device-resident copy its constructor produced (mpGpuFrame) -- valid until `rig` extracts again
+static void make_frame(Agent& A, orbgpu::ORBextractor& rig, const std::vector<uint8_t>& tex, int k, bool keep_on_device = false) {
   double T[16], Tr[16]; pose_of(k, T);
   for (int i = 0; i < 16; i++) Tr[i] = T[i];
   Tr[3] -= BB;
@@ -94,9 +96,11 @@ static void make_frame(Agent& A, orbgpu::ORBextractor& rig, const std::vector<ui
   std::unique_ptr<Frame> F(new Frame);
   F->mnMinX = 0; F->mnMaxX = W; F->mnMinY = 0; F->mnMaxY = H; F->fx = FX; F->fy = FX; F->cx = CX; F->cy = CY; F->mbf = BF; F->mb = BB;
   orbm_frame_view v{0, nullptr, nullptr, nullptr, nullptr, 0, (float)W, 0, (float)H, FX, FX, CX, CY, BF, BB, 8, 1.2f};
-  orbgpu::FrameOnDevice dev(4096);
+  std::unique_ptr<orbgpu::FrameOnDevice> devp(new orbgpu::FrameOnDevice(4096));
+  orbgpu::FrameOnDevice& dev = *devp;
   std::vector<orbx_keypoint> keys; std::vector<uint8_t> desc; std::vector<float> ur, dp;
   const int N = dev.StereoCtor(rig, v, L.data(), R.data(), W, H, W, &keys, &desc, &ur, &dp);
+  if (keep_on_device) { F->mpGpuFrame = devp.get(); A.dev_frames.push_back(std::move(devp)); }
   F->N = N; F->mvKeys.resize(N); F->mDescriptors = Mat(N, 32, 1); F->mvuRight = ur; F->mvDepth = dp;
   for (int i = 0; i < N; i++) F->mvKeys[i] = KeyPoint{{keys[i].x, keys[i].y}, keys[i].size, keys[i].angle, keys[i].response, keys[i].octave};
   F->mvKeysUn = F->mvKeys;                                        // k1 == 0: no undistortion (S/Frame.cc:723-727)
