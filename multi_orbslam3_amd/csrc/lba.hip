@@ -3226,25 +3226,91 @@ __device__ inline bool po_solve6(const double* Hrow, double b_li, int li, double
   return true;
 }
 
-__device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, float v, float ur, const Cam& c, double* err, double* Xc) {
-  // the same operations in the same order as the oracle's edge error: the LM loop's accept / reject and termination tests sit
-  // on differences of chi2 sums at convergence, where one changed rounding flips a decision (tried: rotation matrix instead of
-  // the quaternion sandwich and Newton reciprocals instead of divisions -- 20 % fewer cycles here, different iteration counts)
-  const double Xd[3] = {X[0], X[1], X[2]};
-  double r[3];
-  quat_rotate(T.q, Xd, r);
+// ---- two correspondences side by side.  A lone wavefront issues a DEPENDENT FP64 instruction every ~9 cycles and an independent
+// one every ~5.4 (tools/micro/fp64_latency; the pipe itself takes one per 4.2), and hipcc keeps the arithmetic of one
+// correspondence together when it is written as a scalar function called twice.  The per-correspondence arithmetic is therefore
+// written ONCE over a value type V that is either double (one correspondence) or D2 (the thread's correspondences i and i + 256,
+// element-wise): every operation of the pair stands next to its twin in the instruction stream, the operations and their order per
+// correspondence are exactly the scalar ones -- the same bits, which the LM loop's accept / reject and termination decisions need
+// (tried: rotation matrix instead of the quaternion sandwich, Newton reciprocals instead of divisions: different iteration counts).
+struct D2 { double a, b; };
+struct B2 { bool a, b; };
+__device__ __forceinline__ D2 operator+(D2 x, D2 y) { return D2{x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ D2 operator-(D2 x, D2 y) { return D2{x.a - y.a, x.b - y.b}; }
+__device__ __forceinline__ D2 operator*(D2 x, D2 y) { return D2{x.a * y.a, x.b * y.b}; }
+__device__ __forceinline__ D2 operator-(D2 x) { return D2{-x.a, -x.b}; }
+__device__ __forceinline__ D2 operator+(D2 x, double y) { return D2{x.a + y, x.b + y}; }
+__device__ __forceinline__ D2 operator+(double x, D2 y) { return D2{x + y.a, x + y.b}; }
+__device__ __forceinline__ D2 operator-(D2 x, double y) { return D2{x.a - y, x.b - y}; }
+__device__ __forceinline__ D2 operator-(double x, D2 y) { return D2{x - y.a, x - y.b}; }
+__device__ __forceinline__ D2 operator*(D2 x, double y) { return D2{x.a * y, x.b * y}; }
+__device__ __forceinline__ D2 operator*(double x, D2 y) { return D2{x * y.a, x * y.b}; }
+__device__ __forceinline__ D2 operator/(double x, D2 y) { return D2{x / y.a, x / y.b}; }
+__device__ __forceinline__ D2 operator/(D2 x, D2 y) { return D2{x.a / y.a, x.b / y.b}; }
+__device__ __forceinline__ double po_f32round(double x) { return (double)(float)x; }
+__device__ __forceinline__ D2 po_f32round(D2 x) { return D2{(double)(float)x.a, (double)(float)x.b}; }
+__device__ __forceinline__ double po_sel(bool c, double x, double y) { return c ? x : y; }
+__device__ __forceinline__ D2 po_sel(B2 c, D2 x, D2 y) { return D2{c.a ? x.a : y.a, c.b ? x.b : y.b}; }
+__device__ __forceinline__ bool po_neg(double x) { return x < 0; }
+__device__ __forceinline__ B2 po_neg(D2 x) { return B2{x.a < 0, x.b < 0}; }
+__device__ __forceinline__ double po_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ D2 po_sqrt(D2 x) { return D2{sqrt(x.a), sqrt(x.b)}; }
+__device__ __forceinline__ bool po_any_gt(double e, double d) { return !(e <= d); }
+__device__ __forceinline__ bool po_any_gt(D2 e, D2 d) { return !(e.a <= d.a) || !(e.b <= d.b); }
+__device__ __forceinline__ bool po_le(double e, double d) { return e <= d; }
+__device__ __forceinline__ B2 po_le(D2 e, D2 d) { return B2{e.a <= d.a, e.b <= d.b}; }
+template <class V> __device__ __forceinline__ V po_c(double x);
+template <> __device__ __forceinline__ double po_c<double>(double x) { return x; }
+template <> __device__ __forceinline__ D2 po_c<D2>(double x) { return D2{x, x}; }
+template <class V> struct PoMask;
+template <> struct PoMask<double> { typedef bool type; };
+template <> struct PoMask<D2> { typedef B2 type; };
+
+// quat_rotate (above) over V
+template <class V>
+__device__ __forceinline__ void po_quat_rotate(const double* q, const V* v, V* out) {
+  const V uv0 = 2 * (q[1] * v[2] - q[2] * v[1]), uv1 = 2 * (q[2] * v[0] - q[0] * v[2]), uv2 = 2 * (q[0] * v[1] - q[1] * v[0]);
+  out[0] = v[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
+  out[1] = v[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
+  out[2] = v[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
+}
+// camera-frame point and 1 / z, then the edge error: mono I/OptimizableTypes.h:44-48 (Pinhole::project in double), stereo
+// G/types/types_six_dof_expmap.cpp:339-346 (float invz, double bf * invz).  Both forms are evaluated and one is selected.
+template <class V>
+__device__ __forceinline__ void po_cam_point(const PoseQ& T, const V* X, V* Xc, V* iz) {
+  V r[3];
+  po_quat_rotate(T.q, X, r);
   Xc[0] = r[0] + T.t[0]; Xc[1] = r[1] + T.t[1]; Xc[2] = r[2] + T.t[2];
-  if (ur < 0) {
-    const double iz = 1.0 / Xc[2];
-    err[0] = (double)u - (c.fx * Xc[0] * iz + c.cx);
-    err[1] = (double)v - (c.fy * Xc[1] * iz + c.cy);
-    err[2] = 0;
-  } else {
-    const float invz = (float)(1.0 / Xc[2]);                 // float invz (types_six_dof_expmap.cpp:340)
-    const double r0 = Xc[0] * invz * c.fx + c.cx;
-    const double r1 = Xc[1] * invz * c.fy + c.cy;
-    err[0] = (double)u - r0; err[1] = (double)v - r1; err[2] = (double)ur - (r0 - c.bf * invz);   // double bf*invz (:344)
+  *iz = 1.0 / Xc[2];
+}
+template <class V, class M>
+__device__ __forceinline__ void po_residual(const V* Xc, V iz, V u, V v, V ur, M mono, const Cam& c, V* err) {
+  const V m0 = u - (c.fx * Xc[0] * iz + c.cx);
+  const V m1 = v - (c.fy * Xc[1] * iz + c.cy);
+  const V invz = po_f32round(iz);
+  const V r0 = Xc[0] * invz * c.fx + c.cx;
+  const V r1 = Xc[1] * invz * c.fy + c.cy;
+  const V s2 = ur - (r0 - c.bf * invz);
+  err[0] = po_sel(mono, m0, u - r0);
+  err[1] = po_sel(mono, m1, v - r1);
+  err[2] = po_sel(mono, po_c<V>(0.0), s2);
+}
+// rho0 / rho1 of RobustKernelHuber::robustify (G/core/robust_kernel_impl.cpp:78-91); the square root only where e > dsqr
+template <class V>
+__device__ __forceinline__ void po_huber(bool robust, V e, V delta, V dsqr, V one, V* rho0, V* rho1) {
+  *rho0 = e; *rho1 = one;
+  if (robust && po_any_gt(e, dsqr)) {
+    const V sq = po_sqrt(e);
+    const auto in = po_le(e, dsqr);
+    *rho0 = po_sel(in, e, 2 * sq * delta - dsqr);
+    *rho1 = po_sel(in, one, delta / sq);
   }
+}
+__device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, float v, float ur, const Cam& c, double* err, double* Xc) {
+  const double Xd[3] = {X[0], X[1], X[2]};
+  double iz;
+  po_cam_point<double>(T, Xd, Xc, &iz);
+  po_residual<double, bool>(Xc, iz, (double)u, (double)v, (double)ur, ur < 0, c, err);
 }
 
 // Optimizer::PoseOptimization (S/Optimizer.cc:992-1290) in ONE launch of one workgroup: 4 rounds x up to 10
@@ -3261,8 +3327,10 @@ __device__ long long g_po_prof[8];
 #define PO_T0() do { } while (0)
 #define PO_ACC(slot) do { } while (0)
 #endif
-__global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float* Xw, const float* ou, const float* ov, const float* our,
-                                                             const float* oinv, Cam cam, PoseQ T0,
+template <bool LDS_IN>      // LDS_IN: n <= kPoLdsN, the correspondences are staged in LDS (typed LDS accesses: a pointer that may be LDS or
+                            // global at run time turns every load into a flat_load with a full wait behind it)
+__global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float* g_Xw, const float* g_ou, const float* g_ov, const float* g_our,
+                                                             const float* g_oinv, Cam cam, PoseQ T0,
                                                              PoseQ* __restrict__ T_out, uint8_t* __restrict__ outlier_out,
                                                              int* __restrict__ stats /*n_bad, iters[4], .., [7] = seq*/,
                                                              double* __restrict__ chi_out, unsigned seq) {
@@ -3279,12 +3347,17 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   const double dM = (float)sqrt(5.991), dS = (float)sqrt(7.815);
   const double dsqM = dM * dM, dsqS = dS * dS;
   for (int i = tid; i < n; i += kPoThreads) { s_chi2[i] = 0; s_out[i] = 0; }
-  if (n <= kPoLdsN) {
+  if (LDS_IN) {
     // the inputs may sit in mapped host memory (zero-copy): read them exactly once
-    for (int i = tid; i < 3 * n; i += kPoThreads) s_in[i] = Xw[i];
-    for (int i = tid; i < n; i += kPoThreads) { s_in[3 * n + i] = ou[i]; s_in[4 * n + i] = ov[i]; s_in[5 * n + i] = our[i]; s_in[6 * n + i] = oinv[i]; }
-    Xw = s_in; ou = s_in + 3 * n; ov = s_in + 4 * n; our = s_in + 5 * n; oinv = s_in + 6 * n;
+    for (int i = tid; i < 3 * n; i += kPoThreads) s_in[i] = g_Xw[i];
+    for (int i = tid; i < n; i += kPoThreads) { s_in[3 * n + i] = g_ou[i]; s_in[4 * n + i] = g_ov[i]; s_in[5 * n + i] = g_our[i]; s_in[6 * n + i] = g_oinv[i]; }
   }
+  const float* const Xw = LDS_IN ? s_in : g_Xw;
+  const float* const ou = LDS_IN ? s_in + 3 * n : g_ou;
+  const float* const ov = LDS_IN ? s_in + 4 * n : g_ov;
+  const float* const our = LDS_IN ? s_in + 5 * n : g_our;
+  const float* const oinv = LDS_IN ? s_in + 6 * n : g_oinv;
+  const D2 dM2{dM, dM}, dS2{dS, dS}, dsqM2{dsqM, dsqM}, dsqS2{dsqS, dsqS}, one2{1.0, 1.0};
   double x[6] = {0, 0, 0, 0, 0, 0};
   double lambda = 0, ni = 2, currentChi = 0;
   int nBadLM = 0;
@@ -3306,60 +3379,78 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
       double acc[28];
 #pragma unroll
       for (int i = 0; i < 28; i++) acc[i] = 0;
-      for (int i = tid; i < n; i += kPoThreads) {
-        if (s_out[i]) continue;
-        const float ur = our[i];
-        const bool mono = ur < 0;
-        double err[3], Xc[3];
-        po_edge_error(T, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
-        const double om = (double)oinv[i];
-        const double c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
-        s_chi2[i] = c2;
-        double rho0 = c2, rho1 = 1.0;
-        if (robust) huber(c2, mono ? dM : dS, mono ? dsqM : dsqS, &rho0, &rho1);
-        acc[27] += rho0;
+      // a thread's correspondences i, i + 256 are linearised side by side (D2: one instruction stream per correspondence, the
+      // two interleaved) and accumulated in the order i, i + 256, ... as a scalar loop would: same sums, bit for bit
+      for (int i0 = tid; i0 < n; i0 += 2 * kPoThreads) {
+        const int i1r = i0 + kPoThreads;
+        const bool in1 = i1r < n;
+        const int i1 = in1 ? i1r : i0;
+        const bool act0 = !s_out[i0], act1 = in1 && !s_out[i1];
+        if (!(act0 || act1)) continue;                             // (both excluded is rare)
+        const D2 X[3] = {D2{(double)Xw[3 * i0], (double)Xw[3 * i1]}, D2{(double)Xw[3 * i0 + 1], (double)Xw[3 * i1 + 1]},
+                         D2{(double)Xw[3 * i0 + 2], (double)Xw[3 * i1 + 2]}};
+        const D2 uu{(double)ou[i0], (double)ou[i1]}, vv{(double)ov[i0], (double)ov[i1]}, ur{(double)our[i0], (double)our[i1]};
+        const D2 om{(double)oinv[i0], (double)oinv[i1]};
+        const B2 mono = po_neg(ur);
+        D2 Xc[3], iz, err[3];
+        po_cam_point<D2>(T, X, Xc, &iz);
+        po_residual<D2, B2>(Xc, iz, uu, vv, ur, mono, cam, err);
+        const D2 c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + po_sel(mono, D2{0.0, 0.0}, err[2] * (om * err[2]));
+        D2 rho0, rho1;
+        po_huber<D2>(robust, c2, po_sel(mono, dM2, dS2), po_sel(mono, dsqM2, dsqS2), one2, &rho0, &rho1);
         // Jacobian (D x 6): mono S/OptimizableTypes.cpp:49-63, stereo types_six_dof_expmap.cpp:375-404
-        const double xx = Xc[0], yy = Xc[1], iz = 1.0 / Xc[2], iz2 = iz * iz;
-        double J[18];
-        J[0] = xx * yy * iz2 * cam.fx; J[1] = -(1 + (xx * xx * iz2)) * cam.fx; J[2] = yy * iz * cam.fx; J[3] = -iz * cam.fx; J[4] = 0; J[5] = xx * iz2 * cam.fx;
-        J[6] = (1 + yy * yy * iz2) * cam.fy; J[7] = -xx * yy * iz2 * cam.fy; J[8] = -xx * iz * cam.fy; J[9] = 0; J[10] = -iz * cam.fy; J[11] = yy * iz2 * cam.fy;
-        if (mono) {
-#pragma unroll
-          for (int q = 12; q < 18; q++) J[q] = 0;
-        } else {
-          J[12] = J[0] - cam.bf * yy * iz2; J[13] = J[1] + cam.bf * xx * iz2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - cam.bf * iz2;
-        }
-        const double wom = rho1 * om;
-        double orr[3];
+        const D2 xx = Xc[0], yy = Xc[1], iz2 = iz * iz;
+        const D2 zero2{0.0, 0.0};
+        D2 J[18];
+        J[0] = xx * yy * iz2 * cam.fx; J[1] = -(1 + (xx * xx * iz2)) * cam.fx; J[2] = yy * iz * cam.fx; J[3] = -iz * cam.fx; J[4] = zero2; J[5] = xx * iz2 * cam.fx;
+        J[6] = (1 + yy * yy * iz2) * cam.fy; J[7] = -xx * yy * iz2 * cam.fy; J[8] = -xx * iz * cam.fy; J[9] = zero2; J[10] = -iz * cam.fy; J[11] = yy * iz2 * cam.fy;
+        J[12] = po_sel(mono, zero2, J[0] - cam.bf * yy * iz2); J[13] = po_sel(mono, zero2, J[1] + cam.bf * xx * iz2); J[14] = po_sel(mono, zero2, J[2]);
+        J[15] = po_sel(mono, zero2, J[3]); J[16] = zero2; J[17] = po_sel(mono, zero2, J[5] - cam.bf * iz2);
+        const D2 wom = rho1 * om;
+        D2 orr[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) orr[k] = -(om * err[k]) * rho1;
         // J^T (w Omega) J with the weighted rows formed once and the structural zeros of the Jacobian (column 4 of rows 0 and
-        // 2, column 3 of row 1) left out: 15 + 45 + 15 multiply-adds per correspondence instead of 126 + 36 -- the kernel is
-        // bound by the FP64 issue rate of one CU (8 cycles per instruction), so instructions are what counts
+        // 2, column 3 of row 1) left out: 15 + 45 + 15 multiply-adds per correspondence instead of 126 + 36
         constexpr int kZeroCol[3] = {4, 3, 4};
-        double wJ[18];
+        D2 wJ[18];
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-          for (int a = 0; a < 6; a++) wJ[6 * k + a] = a == kZeroCol[k] ? 0.0 : wom * J[6 * k + a];
-        int o = 0;
+          for (int a2 = 0; a2 < 6; a2++) wJ[6 * k + a2] = a2 == kZeroCol[k] ? zero2 : wom * J[6 * k + a2];
+        D2 hh[27];
+        {
+          int o = 0;
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+          for (int a2 = 0; a2 < 6; a2++)
 #pragma unroll
-          for (int c = a; c < 6; c++) {
-            double h = 0;
+            for (int c3 = a2; c3 < 6; c3++) {
+              D2 h = zero2;
+#pragma unroll
+              for (int k = 0; k < 3; k++)
+                if (a2 != kZeroCol[k] && c3 != kZeroCol[k]) h = h + J[6 * k + a2] * wJ[6 * k + c3];
+              hh[o++] = h;
+            }
+#pragma unroll
+          for (int a2 = 0; a2 < 6; a2++) {
+            D2 sacc = zero2;
 #pragma unroll
             for (int k = 0; k < 3; k++)
-              if (a != kZeroCol[k] && c != kZeroCol[k]) h += J[6 * k + a] * wJ[6 * k + c];
-            acc[o++] += h;
+              if (a2 != kZeroCol[k]) sacc = sacc + J[6 * k + a2] * orr[k];
+            hh[o++] = sacc;
           }
+        }
+        if (act0) {
+          s_chi2[i0] = c2.a;
+          acc[27] += rho0.a;
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-          double sacc = 0;
+          for (int o = 0; o < 27; o++) acc[o] += hh[o].a;
+        }
+        if (act1) {
+          s_chi2[i1] = c2.b;
+          acc[27] += rho0.b;
 #pragma unroll
-          for (int k = 0; k < 3; k++)
-            if (a != kZeroCol[k]) sacc += J[6 * k + a] * orr[k];
-          acc[o++] += sacc;
+          for (int o = 0; o < 27; o++) acc[o] += hh[o].b;
         }
       }
       PO_ACC(0);
@@ -3391,18 +3482,25 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
         PO_ACC(2);
         double tchi = 0;
         // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
-        for (int i = tid; i < n; i += kPoThreads) {
-          if (s_out[i]) continue;
-          const float ur = our[i];
-          const bool mono = ur < 0;
-          double err[3], Xc[3];
-          po_edge_error(Tt, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
-          const double om = (double)oinv[i];
-          const double c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
-          s_chi2[i] = c2;
-          double rho0 = c2, rho1;
-          if (robust) huber(c2, mono ? dM : dS, mono ? dsqM : dsqS, &rho0, &rho1);
-          tchi += rho0;
+        for (int i0 = tid; i0 < n; i0 += 2 * kPoThreads) {
+          const int i1r = i0 + kPoThreads;
+          const bool in1 = i1r < n;
+          const int i1 = in1 ? i1r : i0;
+          const bool act0 = !s_out[i0], act1 = in1 && !s_out[i1];
+          if (!(act0 || act1)) continue;
+          const D2 X[3] = {D2{(double)Xw[3 * i0], (double)Xw[3 * i1]}, D2{(double)Xw[3 * i0 + 1], (double)Xw[3 * i1 + 1]},
+                           D2{(double)Xw[3 * i0 + 2], (double)Xw[3 * i1 + 2]}};
+          const D2 uu{(double)ou[i0], (double)ou[i1]}, vv{(double)ov[i0], (double)ov[i1]}, ur{(double)our[i0], (double)our[i1]};
+          const D2 om{(double)oinv[i0], (double)oinv[i1]};
+          const B2 mono = po_neg(ur);
+          D2 Xc[3], iz, err[3];
+          po_cam_point<D2>(Tt, X, Xc, &iz);
+          po_residual<D2, B2>(Xc, iz, uu, vv, ur, mono, cam, err);
+          const D2 c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + po_sel(mono, D2{0.0, 0.0}, err[2] * (om * err[2]));
+          D2 rho0, rho1;
+          po_huber<D2>(robust, c2, po_sel(mono, dM2, dS2), po_sel(mono, dsqM2, dsqS2), one2, &rho0, &rho1);
+          if (act0) { s_chi2[i0] = c2.a; tchi += rho0.a; }
+          if (act1) { s_chi2[i1] = c2.b; tchi += rho0.b; }
         }
         PO_ACC(3);
         double tempChi = po_block_sum(tchi, s_wsum, sum_slot); sum_slot ^= 1;
@@ -3532,8 +3630,12 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   if (po_seq == 0) po_seq = 1;
   volatile int* seq_word = reinterpret_cast<volatile int*>(sc.stage.h + out_off + sizeof(PoseQ) + 4 * sizeof(double)) + 7;
   *seq_word = 0;
-  hipLaunchKernelGGL(pose_opt_kernel, dim3(1), dim3(kPoThreads), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n, dX + 5 * (size_t)n,
-                     dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
+  if (n <= kPoLdsN)
+    hipLaunchKernelGGL(pose_opt_kernel<true>, dim3(1), dim3(kPoThreads), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n,
+                       dX + 5 * (size_t)n, dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
+  else
+    hipLaunchKernelGGL(pose_opt_kernel<false>, dim3(1), dim3(kPoThreads), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n,
+                       dX + 5 * (size_t)n, dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
   ORBG_HIP(hipGetLastError());
   {
     bool got = false;

@@ -11,16 +11,14 @@ __global__ void k_lat(double* out, long long* cyc, double seed, int lanes_active
   // 1) dependent FMA chain
   t0 = clock64();
 #pragma unroll
-  for (int i = 0; i < 256; i++) a = __builtin_fma(a, b, c);
-  asm volatile("" :: "v"(a));
+  for (int i = 0; i < 256; i++) { a = __builtin_fma(a, b, c); asm volatile("" : "+v"(a)); }
   t1 = clock64();
   if (t == 0) cyc[0] = t1 - t0;
   // 2) 4 independent FMA chains
   double a0 = a, a1 = a + 1, a2 = a + 2, a3 = a + 3;
   t0 = clock64();
 #pragma unroll
-  for (int i = 0; i < 64; i++) { a0 = __builtin_fma(a0, b, c); a1 = __builtin_fma(a1, b, c); a2 = __builtin_fma(a2, b, c); a3 = __builtin_fma(a3, b, c); }
-  asm volatile("" :: "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+  for (int i = 0; i < 64; i++) { a0 = __builtin_fma(a0, b, c); a1 = __builtin_fma(a1, b, c); a2 = __builtin_fma(a2, b, c); a3 = __builtin_fma(a3, b, c); asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
   t1 = clock64();
   if (t == 0) cyc[1] = t1 - t0;
   a = a0 + a1 + a2 + a3;
@@ -68,11 +66,21 @@ __global__ void k_issue(double* out, long long* cyc, double seed) {
   __syncthreads();
   long long t0 = clock64();
 #pragma unroll
-  for (int i = 0; i < 256; i++) { a0 = __builtin_fma(a0, b, c); a1 = __builtin_fma(a1, b, c); a2 = __builtin_fma(a2, b, c); a3 = __builtin_fma(a3, b, c); }
-  asm volatile("" :: "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+  for (int i = 0; i < 256; i++) {
+    a0 = __builtin_fma(a0, b, c); a1 = __builtin_fma(a1, b, c); a2 = __builtin_fma(a2, b, c); a3 = __builtin_fma(a3, b, c);
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+  }
   __syncthreads();
   long long t1 = clock64();
   if (t == 0) cyc[0] = t1 - t0;
+  // ONE dependent chain per wavefront (what a serial solve looks like)
+  __syncthreads();
+  t0 = clock64();
+#pragma unroll
+  for (int i = 0; i < 512; i++) { a0 = __builtin_fma(a0, b, c); asm volatile("" : "+v"(a0)); }
+  __syncthreads();
+  t1 = clock64();
+  if (t == 0) cyc[2] = t1 - t0;
   __syncthreads();
   t0 = clock64();
 #pragma unroll
@@ -106,8 +114,9 @@ int main() {
     long long h[8];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     const double per_simd = nw <= 4 ? 1.0 : nw / 4.0;      // wavefronts sharing the busiest SIMD
-    printf("%2d wavefronts in the workgroup (%.0f per SIMD): FMA %.2f cycles per instruction per wavefront, %.2f per instruction per SIMD | unfused mul/add %.2f per wavefront, %.2f per SIMD\n",
-           nw, per_simd, h[0] / 1024.0, h[0] / 1024.0 / per_simd, h[1] / 1024.0, h[1] / 1024.0 / per_simd);
+    printf("%2d wavefronts in the workgroup (%.0f per SIMD): 4 independent FMA chains %.2f cycles per instruction per wavefront, %.2f per SIMD | "
+           "4 independent unfused mul/add chains %.2f per wavefront, %.2f per SIMD | one dependent FMA chain %.2f per wavefront, %.2f per SIMD\n",
+           nw, per_simd, h[0] / 1024.0, h[0] / 1024.0 / per_simd, h[1] / 1024.0, h[1] / 1024.0 / per_simd, h[2] / 512.0, h[2] / 512.0 / per_simd);
   }
   return 0;
 }
