@@ -302,6 +302,10 @@ def main():
     ap.add_argument("--device-images", action="store_true",
                     help="MAIN timed region with the images already resident in HBM (no host staging / PCIe copy); by default that "
                          "accounting is reported as value_device_images")
+    ap.add_argument("--loop", choices=["cxx", "python"], default="cxx",
+                    help="cxx: the Tracking-thread loop is libagentloop.so (multi_orbslam3_amd/csrc/agent_loop.cpp: C++ above the C-ABI, as the "
+                         "reference's Tracking.cc is); python: the same steps from this script through the ctypes wrappers (mono / "
+                         "--separate-calls / --profile-stages always use it)")
     ap.add_argument("--submit-order", choices=["before-wait", "after-wait"], default="before-wait",
                     help="pipelined constructor: hand frame t+1 over before or after frame t's constructor is collected")
     ap.add_argument("--ingest", choices=["thread", "inline"], default="thread",
@@ -544,8 +548,59 @@ def main():
     # local map must exist before the first frame
     LM.upload(maps.view())
 
+    # ---- the same loop in C++ (libagentloop.so): the per-frame host work of a client is C++ in the reference (Tracking.cc)
+    use_cxx = args.loop == "cxx" and stereo and not args.separate_calls and not args.profile_stages
+    loop = None
+    if use_cxx:
+        from multi_orbslam3_amd import agent as agent_mod
+        # the local map uploaded at keyframe step i is periodic in i (sequence length x frames per keyframe): one view per keyframe
+        # step of the period, taken from the second pass (the first one starts from the prefill)
+        period = int(np.lcm(len(seq), FRAMES_PER_KF))
+        sim = LocalMaps(kf_chunks, cfg["local_kfs"], views)
+        sim.prefill(seq, 0)
+        kf_views = []
+        for i in range(2 * period):
+            kk = seq[i % len(seq)]
+            if kk % FRAMES_PER_KF == 0:
+                sim.visit(kk)
+            if i % FRAMES_PER_KF == 0 and i >= period:
+                kf_views.append(sim.view())
+        maps.sizes = list(sim.sizes)
+        frames_in = [dict(host=host_imgs[k], dev=(imgs[k][0].data_ptr(), imgs[k][1].data_ptr()),
+                          guess=np.ascontiguousarray(frames[k]["guess"], np.float32).reshape(16), last_view=frames[k]["last_view"][0])
+                     for k in range(nF)]
+        loop = agent_mod.AgentLoop(exs, Fs, LM, opt, fv, W, H, W, bf, bb, frames_in, seq, kf_views, lp, lba_out, [po1, po2], FRAMES_PER_KF,
+                                   2 * cfg["frame_cap"], th_frame, mono_flag)
+
+    def run_region_cxx(n_steps, n_warm, pose_opt, host_images, pipelined, first_index):
+        reg = Region(n_steps)
+        loop.configure(pipelined, host_images, ingest_async, submit_first, args.lba_mode == "async", pose_opt)
+        st = agent_mod.Stats()
+
+        def sync():
+            loop.drain(st, True)
+            torch.cuda.synchronize()
+
+        loop.run(first_index, n_warm)
+        loop.drain()
+        base = first_index + n_warm
+        step_s = np.zeros(max(n_steps, 1))
+        grp.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop.run(base, n_steps, last_is_final=True, timed=True, step_s=step_s, stats=st)
+        sync()
+        grp.barrier()
+        elapsed = grp.max_over_ranks(time.perf_counter() - t0)
+        for key, j in (("extract", 0), ("match_frame", 1), ("match_map", 2), ("pose_opt", 3), ("map_upload", 4), ("lba", 5)):
+            reg.stage[key] = st.stage_s[j]
+        reg.stats.update(kp=st.kp, m_frame=st.m_frame, m_map=st.m_map, lba_iters=st.lba_iters, lba_calls=st.lba_calls, lba_s=st.lba_s)
+        reg.step_s = step_s
+        return reg, elapsed
+
     def run_region(n_steps, n_warm, pose_opt, host_images, pipelined, first_index):
         """W untimed steps, then exactly n_steps timed ones between barrier + synchronize on both sides; MAX over ranks."""
+        if use_cxx:
+            return run_region_cxx(n_steps, n_warm, pose_opt, host_images, pipelined, first_index)
         reg = Region(n_steps)
 
         def sync():
@@ -570,9 +625,16 @@ def main():
     scratch = Region(1)
     # (... and such that the first TIMED step is a keyframe step: the region then holds exactly K / FRAMES_PER_KF local BAs, the
     # last of them submitted FRAMES_PER_KF steps before the clock stops, whatever K and --warmup are)
+    if use_cxx:
+        loop.configure(pipeline, host_images, ingest_async, submit_first, args.lba_mode == "async", args.pose_opt)
     while (prewarm_done < args.prewarm_steps or time.perf_counter() - t_pw < 0.05 or (prewarm_done + args.warmup) % FRAMES_PER_KF != 0):
-        step(prewarm_done, scratch, False, args.pose_opt, host_images, pipeline)
+        if use_cxx:
+            loop.run(prewarm_done, 1)
+        else:
+            step(prewarm_done, scratch, False, args.pose_opt, host_images, pipeline)
         prewarm_done += 1
+    if use_cxx:
+        loop.drain()
     collect_async(scratch)
     for e in exs:
         e.set_profile_interval(max(FAST_BRACKET_EVERY // len(exs), 1), reset=True)
@@ -714,7 +776,9 @@ def main():
                        "device_ms_per_frame": dict({k2: round(v / K, 4) for k2, v in kern.items()}, fast_kernel_ms=round(fast_ms_raw, 4)),
                        "avg_keypoints_per_frame": round(stats["kp"] / K, 1),
                        "avg_matches_frame": round(stats["m_frame"] / K, 1), "avg_matches_map": round(stats["m_map"] / K, 1),
-                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt), "host_images_in_step": bool(host_images or not stereo),
+                       "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt),
+                       "tracking_loop": ("libagentloop.so (multi_orbslam3_amd/csrc/agent_loop.cpp): the per-frame loop is C++ above the C-ABI, timed as one call "
+                                         "of K steps" if use_cxx else "python (ctypes wrappers, one step per call)"), "host_images_in_step": bool(host_images or not stereo),
                        "image_ingest": ("host images -> pinned staging slot (%s) -> copy kernel on the extractor's stream -> HBM"
                                         % ("library ingest thread" if pipeline and ingest_async else "calling thread")) if host_images else "images resident in HBM",
                        "local_map_points_avg": int(np.mean(maps.sizes)) if maps.sizes else 0, "local_map_keyframes": cfg["local_kfs"],

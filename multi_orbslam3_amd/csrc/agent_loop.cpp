@@ -1,0 +1,186 @@
+// libagentloop -- the Tracking thread of one client, in C++ above the C-ABI of liborbgpu (include/orbgpu.h).
+//
+// The reference's per-frame path is C++: ClientNode::ImageCallbackStereo -> ClientSystem::TrackStereo -> Tracking::GrabImageStereo
+// (Frame constructor, S/Tracking.cc:1014-1083) -> Tracking::Track: TrackWithMotionModel (SearchByProjection(Current, Last) +
+// PoseOptimization, :2592-2660) and TrackLocalMap (UpdateLocalMap, SearchLocalPoints + PoseOptimization, :2700-2735), with
+// LocalMapping running Optimizer::LocalBundleAdjustment on its own thread for every keyframe (S/LocalMapping.cc:114-133,245).
+// This file is that loop over flat inputs, calling ONLY the C-ABI (no kernels, no HIP calls of its own): bench.py prepares the
+// handles and the per-frame views once and times agent_run(); a deployment has Tracking.cc in this place.
+//
+//   step(i):  frame k = seq[i % n_seq]
+//     pipelined:   [submit Frame(t+1) on the other extractor handle]  wait Frame(t)         (orbx_frame_stereo_submit / _dev_submit / _wait)
+//     synchronous: Frame(t) = orbx_frame_stereo / orbx_frame_stereo_dev
+//     SearchByProjection(Current, Last)  [PoseOptimization]  SearchLocalPoints  [PoseOptimization]
+//     keyframe step (i % frames_per_kf == 0): local map refresh (orbm_map_upload), wait for the previous local BA, submit the next
+//
+// Build: g++ -O2 -shared -fPIC agent_loop.cpp -I include -L. -lorbgpu  (multi_orbslam3_amd/csrc/build.sh)
+#include <time.h>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/orbgpu.h"
+
+extern "C" {
+
+typedef struct agent_frame_in {            // what Tracking holds for one frame of the sequence
+  const uint8_t* host_left; const uint8_t* host_right;       // cv::Mat data of the stereo pair
+  const uint8_t* dev_left; const uint8_t* dev_right;         // the same images resident in HBM (device-image accounting)
+  const float* Tcw_guess;                                    // 16 floats: motion-model prediction (mCurrentFrame.mTcw)
+  const orbm_lastframe_view* last_view;                      // this frame AS the last frame of its successor (mLastFrame)
+} agent_frame_in;
+
+typedef struct agent_cfg {
+  orbx_handle* ex[2]; orbm_frame* fr[2];                     // ping-pong: Frame(t+1) is built on the other pair
+  orbm_map* local_map; lba_handle* lba;
+  const orbm_frame_view* frame_view;                         // intrinsics / bounds (features come from the constructor)
+  int width, height, stride; float bf, b;
+  const agent_frame_in* frames; int n_frames;
+  const int32_t* seq; int n_seq;                             // frame index per step (ping-pong over the distinct frames)
+  const orbm_worldpoints_view* const* kf_maps; int n_kf_maps; // local map to upload at keyframe step i: kf_maps[(i / frames_per_kf) % n_kf_maps]
+  const lba_problem* lba_prob; lba_result* lba_out;
+  const pose_opt_problem* po[2]; pose_opt_result* po_out[2]; // the two PoseOptimization calls of a frame (NULL: skipped)
+  int frames_per_kf;
+  int pipelined, host_images, ingest_async, submit_first, lba_async, pose_opt;
+  float th_frame; int mono; float nn_frame, nn_map;
+  int32_t* amp; int32_t* aob; int cap;                       // F.mvpMapPoints as (assigned_mp, assigned_obs), cap entries each
+  int32_t in_flight[2];                                      // pipelined constructor submitted on ex[c] and not yet collected (state across calls)
+  int32_t lba_in_flight;                                     // a local BA submitted and not yet collected
+} agent_cfg;
+
+typedef struct agent_stats {
+  double stage_s[8];       // extract(wait / ctor), match_frame, match_map, pose_opt, map_upload, lba, (spare)
+  double lba_s; int64_t lba_calls, lba_iters;
+  int64_t kp, m_frame, m_map;
+  int32_t error, error_step;
+} agent_stats;
+
+// struct sizes for the binding's layout check (multi_orbslam3_amd/agent.py)
+int agent_sizeof(int which) { return which == 0 ? (int)sizeof(agent_cfg) : which == 1 ? (int)sizeof(agent_stats) : (int)sizeof(agent_frame_in); }
+
+static inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+static int submit_ctor(agent_cfg* c, int slot, int k) {
+  const agent_frame_in& f = c->frames[k];
+  if (c->host_images)
+    return orbx_frame_stereo_submit(c->ex[slot], c->fr[slot], c->frame_view, f.host_left, f.host_right, c->width, c->height, c->stride, c->bf, c->b,
+                                    c->ingest_async ? ORBX_SUBMIT_ASYNC : 0);
+  return orbx_frame_stereo_dev_submit(c->ex[slot], c->fr[slot], c->frame_view, f.dev_left, f.dev_right, c->width, c->height, c->stride, c->bf, c->b);
+}
+
+// Collects the local BA in flight (if any); its wall time and iteration counts go to the statistics when `timed`.
+static int collect_lba(agent_cfg* c, agent_stats* st, int timed) {
+  if (!c->lba_in_flight) return ORBG_OK;
+  double ms = 0;
+  const int rc = lba_wait(c->lba, &ms);
+  c->lba_in_flight = 0;
+  if (rc) return rc;
+  if (timed && st) { st->lba_s += 1e-3 * ms; st->lba_calls++; st->lba_iters += c->lba_out->iters_round1 + c->lba_out->iters_round2; }
+  return ORBG_OK;
+}
+
+// Runs steps first_step .. first_step + n_steps - 1.  last_is_final: the last step hands no further frame over (a timed region
+// holds exactly n_steps constructors).  step_s (n_steps doubles, may be NULL) receives the wall time of every step.  State that
+// lives across calls (constructors / local BA in flight) is kept in cfg.
+int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, int timed, double* step_s, agent_stats* st) {
+  if (!c || !st || n_steps < 0) return ORBG_BAD_ARG;
+  int rc = ORBG_OK, s_done = 0;
+  for (int s = 0; s < n_steps && rc == ORBG_OK; s++) {
+    s_done = s;
+    const int64_t i = first_step + s;
+    const int k = c->seq[i % c->n_seq], k_last = c->seq[(i + c->n_seq - 1) % c->n_seq];
+    const agent_frame_in& fin = c->frames[k];
+    const bool last = last_is_final && s == n_steps - 1;
+    const double t0 = now_s();
+    int nl = 0, nr = 0, cur = 0;
+    if (c->pipelined) {
+      cur = (int)(i & 1);
+      if (!c->in_flight[cur]) { if ((rc = submit_ctor(c, cur, k))) break; c->in_flight[cur] = 1; }     // first step only
+      if (c->submit_first && !last) {
+        // Frame(t+1) is handed over (other handle, other frame object) BEFORE frame t is collected: its staging copy and its
+        // launches overlap the tail of frame t's constructor; the image pair t+1 is needed at the same moment either way
+        if ((rc = submit_ctor(c, cur ^ 1, c->seq[(i + 1) % c->n_seq]))) break;
+        c->in_flight[cur ^ 1] = 1;
+      }
+      if ((rc = orbx_frame_stereo_dev_wait(c->ex[cur], &nl, &nr))) break;
+      c->in_flight[cur] = 0;
+      if (!c->submit_first && !last) {
+        if ((rc = submit_ctor(c, cur ^ 1, c->seq[(i + 1) % c->n_seq]))) break;
+        c->in_flight[cur ^ 1] = 1;
+      }
+    } else if (c->host_images) {
+      rc = orbx_frame_stereo(c->ex[0], c->fr[0], c->frame_view, fin.host_left, fin.host_right, c->width, c->height, c->stride, c->bf, c->b,
+                             nullptr, nullptr, nullptr, nullptr, 0, &nl, &nr);
+    } else {
+      rc = orbx_frame_stereo_dev(c->ex[0], c->fr[0], c->frame_view, fin.dev_left, fin.dev_right, c->width, c->height, c->stride, c->bf, c->b,
+                                 nullptr, nullptr, nullptr, nullptr, 0, &nl, &nr);
+    }
+    if (rc) break;
+    if (nl > c->cap) { rc = ORBG_CAP_EXCEEDED; break; }
+    orbm_frame* F = c->fr[cur];
+    const double t1 = now_s();
+    // F.mvpMapPoints starts empty (S/Frame.cc:113)
+    for (int j = 0; j < nl; j++) c->amp[j] = -1;
+    memset(c->aob, 0, sizeof(int32_t) * (size_t)nl);
+    int n1 = 0, n2 = 0;
+    if ((rc = orbm_search_by_projection_frame(F, fin.Tcw_guess, c->frames[k_last].last_view, c->th_frame, c->mono, 1, c->amp, c->aob, &n1))) break;
+    const double t2 = now_s();
+    double t_po = 0;
+    if (c->pose_opt && c->po[0]) {                                 // TrackWithMotionModel: Optimizer::PoseOptimization(&mCurrentFrame), :2649
+      const double a = now_s();
+      if ((rc = pose_optimize(c->po[0], c->po_out[0]))) break;
+      t_po += now_s() - a;
+    }
+    const double t2b = now_s();
+    if ((rc = orbm_search_local_points(F, c->local_map, fin.Tcw_guess, nullptr, 1.0f, 0, 0.0f, c->nn_map, c->amp, c->aob, &n2))) break;
+    const double t3 = now_s();
+    if (c->pose_opt && c->po[1]) {                                 // TrackLocalMap: Optimizer::PoseOptimization(&mCurrentFrame), :2712
+      const double a = now_s();
+      if ((rc = pose_optimize(c->po[1], c->po_out[1]))) break;
+      t_po += now_s() - a;
+    }
+    const double t4 = now_s();
+    double t5 = t4, t6 = t4;
+    if (i % c->frames_per_kf == 0) {
+      // keyframe: Tracking::UpdateLocalMap (the points of the last 20 / 50 keyframes), LocalMapping gets a new keyframe
+      if ((rc = orbm_map_upload(c->local_map, c->kf_maps[(i / c->frames_per_kf) % c->n_kf_maps]))) break;
+      t5 = now_s();
+      if (c->lba_async) {
+        if ((rc = collect_lba(c, st, timed))) break;               // the previous keyframe's local BA (long finished in steady state)
+        if ((rc = lba_solve_async(c->lba, c->lba_prob, nullptr, c->lba_out))) break;
+        c->lba_in_flight = 1;
+      } else {
+        const double a = now_s();
+        if ((rc = lba_solve_h(c->lba, c->lba_prob, nullptr, c->lba_out))) break;
+        if (timed) { st->lba_s += now_s() - a; st->lba_calls++; st->lba_iters += c->lba_out->iters_round1 + c->lba_out->iters_round2; }
+      }
+      t6 = now_s();
+    }
+    if (timed) {
+      st->stage_s[0] += t1 - t0; st->stage_s[1] += t2 - t1; st->stage_s[2] += t3 - t2b; st->stage_s[3] += t_po;
+      st->stage_s[4] += t5 - t4; st->stage_s[5] += t6 - t5;
+      st->kp += nl + nr; st->m_frame += n1; st->m_map += n2;
+      if (step_s) step_s[s] = now_s() - t0;
+    }
+  }
+  st->error = rc;
+  if (rc) st->error_step = (int32_t)s_done;
+  return rc;
+}
+
+// End of a region: every local BA triggered in it has finished and every constructor handed over has been collected.
+int agent_drain(agent_cfg* c, agent_stats* st, int timed) {
+  if (!c) return ORBG_BAD_ARG;
+  int rc = collect_lba(c, st, timed);
+  for (int s = 0; s < 2; s++)
+    if (c->in_flight[s]) {
+      int nl, nr;
+      const int r2 = orbx_frame_stereo_dev_wait(c->ex[s], &nl, &nr);
+      c->in_flight[s] = 0;
+      if (!rc) rc = r2;
+    }
+  return rc;
+}
+
+}  // extern "C"

@@ -112,3 +112,11 @@ def test_big_ldlt_kernel_keeps_the_compiler_out_of_its_tile_registers(tmp_path):
     assert not bad, bad[:5]
     desc = text[text.index(".amdhsa_kernel " + name):]
     assert re.search(r"\.amdhsa_next_free_vgpr\s+512", desc[:3000]) and re.search(r"\.amdhsa_accum_offset\s+256", desc[:3000])
+
+
+def test_agent_loop_library_loads_and_its_structures_match_the_binding():
+    """libagentloop.so (the Tracking-thread loop above the C-ABI) links against liborbgpu.so; the ctypes mirror of agent_cfg /
+    agent_stats / agent_frame_in has the C sizes (checked inside load())."""
+    from multi_orbslam3_amd import agent
+    lib = agent.load()
+    assert lib.agent_sizeof(0) > 200 and hasattr(lib, "agent_run") and hasattr(lib, "agent_drain")

@@ -922,6 +922,55 @@ def test_c4_sizes_1280x720_2000_features_and_50kf_lba():
     assert np.array_equal(g.edge_outlier, o.edge_outlier)
 
 
+def test_c4_sizes_matchers_2000_features_8k_map_points():
+    """The tracking searches at BASELINE.json configs[3] sizes: 1280x720 frames of ~2000 features against a local map of ~8 k map
+    points (seven keyframes' worth, shuffled, with bad / zero-observation points): SearchLocalPoints (fused isInFrustum +
+    SearchByProjection(F, MPs)), the stand-alone isInFrustum + SearchByProjection(F, MPs) pair, SearchByProjection(Cur, Last) and
+    SearchByBoW(KF, F) -- match arrays and counts identical to the oracle's."""
+    sc = synth.Scene(1280, 720, tex_size=(3200, 1800), px_per_m=400.0)
+    rng = np.random.RandomState(44)
+    frs = [helpers.oracle_stereo_frame(sc, k, n_features=2000) for k in (0, 2, 4, 6, 8, 10, 12, 13, 14)]
+    cur, last = frs[-1], frs[-2]
+    assert len(cur["kps"]) >= 1900
+    mp = helpers.local_map_from(sc, frs[:7], rng)
+    assert 7000 <= len(mp["pos"]) <= 12000, len(mp["pos"])
+    fv, keep = helpers.frame_view_of(sc, cur)
+    F = api.Frame(8192).upload(fv, keep)
+    n = len(cur["kps"])
+    T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+    # ---- SearchByProjection(Cur, Last), then SearchLocalPoints on top of its assignments (as Tracking does)
+    lv, keep2 = helpers.make_lastframe(sc, last, rng)
+    a0, b0 = np.full(n, -1, np.int32), np.zeros(n, np.int32)
+    g1 = api.ORBmatcher(0.9, True).SearchByProjectionFrame(F, T, lv, 7.0, False, a0, b0)
+    o1 = ob.search_by_projection_frame(fv, T, lv, 7.0, False, True, a0, b0)
+    assert o1[2] > 300 and g1[2] == o1[2] and np.array_equal(g1[0], o1[0]) and np.array_equal(g1[1], o1[1])
+    wv, keep3 = helpers.world_view_of(mp)
+    LM = api.LocalMap(16384)
+    LM.upload(wv)
+    g2 = api.ORBmatcher(0.8, True).SearchLocalPoints(F, LM, T, 1.0, False, 0.0, o1[0].copy(), o1[1].copy(), None)
+    o2 = ob.search_local_points(fv, wv, T, 1.0, False, 0.0, 0.8, o1[0].copy(), o1[1].copy())
+    assert o2[2] > 300 and g2[2] == o2[2] and np.array_equal(g2[0], o2[0]) and np.array_equal(g2[1], o2[1])
+    # ---- the two-call form: isInFrustum for every point, then SearchByProjection(F, MPs) on the stored track fields
+    trk = F.isInFrustum(T, wv, 0.5)
+    otrk = ob.is_in_frustum(fv, T, wv, 0.5)
+    for key in otrk:
+        assert np.array_equal(np.asarray(trk[key]).view(np.uint8), np.asarray(otrk[key]).view(np.uint8)), key
+    assert int(np.asarray(otrk["track_in_view"]).sum()) > 1500
+    mv, keep4 = views.mappoints_view(otrk["track_in_view"], mp["bad"], otrk["proj_x"], otrk["proj_y"], otrk["proj_xr"], otrk["track_depth"],
+                                     otrk["scale_level"], otrk["view_cos"], mp["desc"], mp["n_obs"])
+    g3 = api.ORBmatcher(0.8, True).SearchByProjection(F, mv, 3.0, True, 40.0, np.full(n, -1, np.int32), np.zeros(n, np.int32))
+    o3 = ob.search_by_projection_mps(fv, mv, 3.0, True, 40.0, 0.8, np.full(n, -1, np.int32), np.zeros(n, np.int32))
+    assert o3[2] > 300 and g3[2] == o3[2] and np.array_equal(g3[0], o3[0]) and np.array_equal(g3[1], o3[1])
+    # ---- SearchByBoW(KF, F) with 2000-feature sides
+    node = lambda d, k: (d[:, 0].astype(np.int64) >> 2) * 2 + (k["octave"] // 4)
+    fvF, kF = views.featvec_view(*views.featvec_from_nodes(node(cur["desc"], cur["kps"])))
+    fvK, kK = views.featvec_view(*views.featvec_from_nodes(node(last["desc"], last["kps"])))
+    valid = (last["depth"] > 0).astype(np.uint8)
+    g4 = api.ORBmatcher(0.7, True).SearchByBoW(F, fvF, last["desc"], valid, last["kps"]["angle"], fvK)
+    o4 = ob.search_by_bow(fv, fvF, last["desc"], valid, last["kps"]["angle"], fvK, 0.7, True)
+    assert o4[1] > 100 and g4[1] == o4[1] and np.array_equal(g4[0], o4[0])
+
+
 @pytest.mark.parametrize("n,of,mono", [(500, 0.1, 0.2), (900, 0.3, 0.0), (40, 0.0, 1.0), (8, 0.0, 0.0), (2, 0.0, 0.0), (1, 0.0, 0.0),
                                        (2000, 0.2, 0.1), (3500, 0.05, 0.5), (257, 0.6, 0.3), (513, 0.0, 1.0)])
 def test_pose_optimization_parity(n, of, mono):
