@@ -1901,7 +1901,8 @@ __global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__
 
 // trial state = oplus(current, x): poses exp(x_p) * T; points X + x_l with the landmark back-substitution
 // x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i) folded in (x_l is also stored for computeScale)
-__global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int nP, const int* __restrict__ pose_col,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_update(int n_poses, int n_points, int nP, const int* __restrict__ pose_col,
                                                const int* __restrict__ point_col, const PoseQ* __restrict__ poses,
                                                const double* __restrict__ points, double* __restrict__ x,
                                                const int* __restrict__ pf_start, const int* __restrict__ pf_edges,
@@ -1911,8 +1912,8 @@ __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int n
                                                const double* __restrict__ bp, double* __restrict__ scale_partial,
                                                const double* __restrict__ lambda_p) {
   const double lambda = lambda_p ? *lambda_p : lambda_v;
-  __shared__ double red[256];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double red[NT];
+  const int i = blockIdx.x * NT + threadIdx.x;
   double sc = 0;                     // this thread's share of computeScale(): sum x (lambda x + b)  (levenberg.cpp:187-194)
   if (i < n_points) {
     const int l = point_col[i];
@@ -1967,7 +1968,7 @@ __global__ __launch_bounds__(256) void k_update(int n_poses, int n_points, int n
   // fixed-order block sum -> one partial per block (the last block of the following k_errors adds them up in index order)
   red[threadIdx.x] = sc;
   __syncthreads();
-  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+  for (int s2 = NT / 2; s2 > 0; s2 >>= 1) {
     if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
     __syncthreads();
   }
@@ -2473,7 +2474,11 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
   }
   int cur = 0;   // index of the buffer holding the current estimate
-  const int n_blocks_u = (NP + NX + 255) / 256;
+  // k_update's workgroup size: the kernel is a chain of dependent memory round trips per landmark; smaller workgroups spread the
+  // same wavefronts over more compute units (ORBG_UPD_THREADS = 64 / 128 / 256 for experiments)
+  // measured (tools/lba_time.py, C2): 256 threads 0.499 ms per solve, 128: 0.488, 64: 0.484
+  static const int upd_threads = []() { const char* e = getenv("ORBG_UPD_THREADS"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
+  const int n_blocks_u = (NP + NX + upd_threads - 1) / upd_threads;
   if ((rc = h->d_scale_partial.reserve(std::max(n_blocks_u, 1)))) return rc;
   if (!h->d_ticket.p) {
     if ((rc = h->d_ticket.reserve(4))) return rc;
@@ -2642,9 +2647,14 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
         // the solve of this trial may already be running: it was launched, with the lambda the device computed for the accepted
         // case, behind the previous trial's residual / linearisation kernel
         if (!(solve_version == version - 1 && qmax == 0 && used_spec) && (rc2 = launch_solve(ls, lambda, lam_p))) return rc2;
-        hipLaunchKernelGGL(k_update, dim3((NP + NX + 255) / 256), dim3(256), 0, st, NP, NX, nP, D.pose_col, D.point_col,
-                           posesB[cur], pointsB[cur], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
-                           Hlls[ls], bls[ls], lambda, posesB[trial], pointsB[trial], bps[ls], h->d_scale_partial.p, lam_p);
+        {
+          auto upd = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(n_blocks_u), dim3(upd_threads), 0, st, NP, NX, nP, D.pose_col, D.point_col,
+                               posesB[cur], pointsB[cur], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
+                               Hlls[ls], bls[ls], lambda, posesB[trial], pointsB[trial], bps[ls], h->d_scale_partial.p, lam_p);
+          };
+          if (upd_threads == 64) upd(k_update<64>); else if (upd_threads == 128) upd(k_update<128>); else upd(k_update<256>);
+        }
         bool speculated = false, fused_export = false;
         if (NE > 0) {
           // speculate on acceptance: linearise the trial state into the other set while the host waits for the verdict
@@ -3339,6 +3349,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   __shared__ double s_part[28 * 8];
   __shared__ double red[28];
   __shared__ double s_wsum[2][4];
+  __shared__ double s_cand[4][14];                       // LM trial candidates of the current iteration: x[6], pose q[4] t[3], solve ok
   int sum_slot = 0;
   __shared__ double s_chi2[kPoThreads * kPoMaxPer];      // last evaluated chi2 of every correspondence
   __shared__ uint8_t s_out[kPoThreads * kPoMaxPer];      // mvbOutlier
@@ -3471,14 +3482,48 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
         const double mx = fmax(fmax(fmax(fabs(red[0]), fabs(red[6])), fmax(fabs(red[11]), fabs(red[15]))), fmax(fabs(red[18]), fabs(red[20])));
         lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
       }
-      // ---- LM trials
+      // ---- LM trials.  The damping values a run of REJECTED trials goes through are known in advance (lambda *= ni, ni *= 2 per
+      // rejection, levenberg.cpp:139-146), and H, b do not change inside an iteration: the four wavefronts solve
+      // (H + lambda_c I) x = b and form the trial pose for candidates c = 0..3 at the same time (each on its own SIMD -- they used
+      // to repeat the SAME solve four times), hand them over through LDS, and trial q picks up candidate q.  A rejected trial then
+      // costs no solve (23 of the 41 trials of a typical call).  Same operations per candidate as the sequential loop: same bits.
       double rho = 0;
       int qmax = 0;
       for (;;) {
         PO_ACC(5);
-        const bool ok2 = po_solve6(Hrow, b_li, li, lambda, x);
+        const int cslot = qmax & 3;
+        if (cslot == 0) {
+          double lam_c = lambda, ni_c = ni;
+          const int wv = tid >> 6;
+          for (int cc = 0; cc < wv; cc++) { lam_c *= ni_c; ni_c *= 2; }
+          double xc[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
+          const bool okc = po_solve6(Hrow, b_li, li, lam_c, xc);
+          PoseQ Tc;
+          pose_oplus_series(T, xc, &Tc);
+          if ((tid & 63) == 0) {
+            double* sc = s_cand[wv];
+#pragma unroll
+            for (int j = 0; j < 6; j++) sc[j] = xc[j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) sc[6 + j] = Tc.q[j];
+#pragma unroll
+            for (int j = 0; j < 3; j++) sc[10 + j] = Tc.t[j];
+            sc[13] = okc ? 1.0 : 0.0;
+          }
+          __syncthreads();
+        }
+        const bool ok2 = s_cand[cslot][13] != 0.0;
         PoseQ Tt;
-        pose_oplus_series(T, x, &Tt);                       // update with whatever x holds, as g2o does
+        if (ok2) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) x[j] = s_cand[cslot][j];
+#pragma unroll
+          for (int j = 0; j < 4; j++) Tt.q[j] = s_cand[cslot][6 + j];
+#pragma unroll
+          for (int j = 0; j < 3; j++) Tt.t[j] = s_cand[cslot][10 + j];
+        } else {
+          pose_oplus_series(T, x, &Tt);                     // the solve failed: update with whatever x holds, as g2o does
+        }
         PO_ACC(2);
         double tchi = 0;
         // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
