@@ -1920,16 +1920,18 @@ __global__ __launch_bounds__(NT) void k_update(int n_poses, int n_points, int nP
     double dx[3] = {0, 0, 0};
     if (l >= 0) {
       double cl[3] = {bl[3 * (size_t)l], bl[3 * (size_t)l + 1], bl[3 * (size_t)l + 2]};
-      // the point's observations in chunks of 4: indices, then all blocks of the chunk, are requested before the first use
-      // (one memory round trip per chunk instead of two per observation); the subtraction order is unchanged
+      // the point's observations in chunks of kUpdChunk: indices, then all blocks of the chunk, are requested before the first
+      // use (one memory round trip per chunk instead of two per observation; with 8 per chunk a point of up to 8 observations --
+      // nearly all of them -- costs two round trips in all); the subtraction order is unchanged
+      constexpr int kUpdChunk = 8;
       const int j1 = pf_start[l + 1];
-      for (int j0 = pf_start[l]; j0 < j1; j0 += 4) {
-        int eid[4], col[4];
+      for (int j0 = pf_start[l]; j0 < j1; j0 += kUpdChunk) {
+        int eid[kUpdChunk], col[kUpdChunk];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int j = min(j0 + u, j1 - 1); eid[u] = pf_edges[j]; col[u] = pf_col[j]; }
-        double Bv[4][18], xv[4][6];
+        for (int u = 0; u < kUpdChunk; u++) { const int j = min(j0 + u, j1 - 1); eid[u] = pf_edges[j]; col[u] = pf_col[j]; }
+        double Bv[kUpdChunk][18], xv[kUpdChunk][6];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kUpdChunk; u++) {
           const double* Bi = EB + (size_t)eid[u] * kEB;
           const double* xp = x + 6 * (size_t)col[u];
 #pragma unroll
@@ -1938,7 +1940,7 @@ __global__ __launch_bounds__(NT) void k_update(int n_poses, int n_points, int nP
           for (int a = 0; a < 6; a++) xv[u][a] = xp[a];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < kUpdChunk; u++)
           if (j0 + u < j1) {
 #pragma unroll
             for (int c = 0; c < 3; c++)

@@ -838,6 +838,7 @@ struct orbm_frame {
   const float* uright_p = nullptr;
   const float* depth_p = nullptr;
   std::vector<orbx_keypoint> h_kps_own;
+  PinnedBuf<orbx_keypoint> h_kps_pin;    // host mirror written by the unpack kernel itself (orbk_frame_from_wire)
   const orbx_keypoint* hk = nullptr;     // host mirror (octave / angle for the serial commit)
   // per-call inputs are packed into ONE pinned staging block and moved with ONE H2D copy
   PinnedBuf<uint8_t> stage;
@@ -920,7 +921,7 @@ extern "C" int orbm_frame_destroy(orbm_frame* f) {
   if (f->own_stream && f->own_stream != f->stream) (void)hipStreamSynchronize(f->own_stream);
   f->d_kps.release(); f->d_desc.release(); f->d_uright.release(); f->d_depth.release(); f->d_cell_of.release();
   f->d_cell_start.release(); f->d_cell_items.release(); f->stage.release(); f->d_stage.release();
-  f->d_counter.release(); f->list.release(); f->results.release(); f->sig.release();
+  f->d_counter.release(); f->list.release(); f->results.release(); f->sig.release(); f->h_kps_pin.release();
   for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
   if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
   delete f;
@@ -1048,8 +1049,11 @@ extern "C" int orbk_frame_from_wire(orbm_frame* f, const orbm_frame_view* v, con
   if ((rc = frame_reserve(f, n))) return rc;
   f->kps_p = f->d_kps.p; f->desc_p = f->d_desc.p; f->uright_p = f->d_uright.p; f->depth_p = f->d_depth.p;
   f->has_uright = false;
-  f->h_kps_own.resize((size_t)std::max(n, 1));
-  f->hk = f->h_kps_own.data(); f->hk_cached_n = -1;
+  // the host mirror of the keypoints (octave / angle for the serial commits) is written by the unpack kernel straight into
+  // pinned memory: no copy command, and -- for a block that is already on the device -- no wait here at all: whatever uses the
+  // frame next is enqueued on the same stream, and the commits read the mirror only after their own search has completed
+  if ((rc = f->h_kps_pin.reserve((size_t)std::max(n, 1)))) return rc;
+  f->hk = f->h_kps_pin.h; f->hk_cached_n = -1; f->hk_cached_from = nullptr;
   f->stream = f->own_stream;       // features of its own: back on the frame's own stream
   if (n > 0) {
     const size_t bytes = (size_t)n * (kWireKp + kWireDesc);
@@ -1060,12 +1064,11 @@ extern "C" int orbk_frame_from_wire(orbm_frame* f, const orbm_frame_view* v, con
       d_wire = f->d_stage.p;
     }
     hipLaunchKernelGGL(wire_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, f->stream, d_wire, n, f->d_kps.p, f->d_desc.p,
-                       (orbx_keypoint*)nullptr);
+                       f->h_kps_pin.d);
     ORBG_HIP(hipGetLastError());
-    ORBG_HIP(hipMemcpyAsync(f->h_kps_own.data(), f->d_kps.p, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, f->stream));
   }
   if ((rc = frame_build_grid(f))) return rc;
-  ORBG_HIP(hipStreamSynchronize(f->stream));
+  if (!wire_on_device) ORBG_HIP(hipStreamSynchronize(f->stream));     // the caller's host block may go away
   return ORBG_OK;
 }
 
