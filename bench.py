@@ -337,9 +337,9 @@ def main():
     # of 4 is the good setting -- more hardware queues than busy streams cost dispatch latency on every one of them.)
     pipeline = stereo and not (args.no_pipeline or args.separate_calls)
     host_images = not args.device_images and not args.separate_calls
-    # (--server-tick measures the SERVER's exchange + matching, which a deployment runs in the server process: that run keeps the
-    # runtime's default of 4 queues -- with 6, the tick's streams share hardware queues erratically: 8 blocks 354 us vs 1470 us)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "6" if (pipeline and not args.server_tick) else "4")
+    # Measured this round (3 / 4 / 5 / 6 / 8 queues: 5550 / 8290 / 8270 / 8240 / 4380 frames/s): the runtime's default of 4 is as good
+    # as 5 or 6 now, and the server tick (--server-tick) needs it (with 6 its streams share queues erratically: 8 blocks 354 us vs 1470)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
     # Every agent keeps two threads spinning on completion words (tracking thread, local-BA worker).  If the container's CPU
     # quota cannot feed that for all ranks of this node (cgroup cpu.max), fall back to the runtime's blocking waits
     # (ORBG_NO_POLL=1: ~6-10 us more latency per wait, a fraction of a CPU per rank) instead of being throttled.

@@ -366,15 +366,18 @@ class ORBmatcher:
         return amp, aob, n.value
 
     def SearchLocalPoints(self, F, local_map, Tcw, th=1.0, bFarPoints=False, thFarPoints=50.0, assigned_mp=None,
-                          assigned_obs=None, skip=None, inplace=False):
-        """Fused Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153)."""
+                          assigned_obs=None, skip=None, inplace=False, in_frustum=None):
+        """Fused Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153).  in_frustum: optional uint8[m] output, 1 where
+        isInFrustum() returned true (the points the reference calls IncreaseVisible() for)."""
         amp, aob = self._state(assigned_mp, assigned_obs, inplace)
         T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
         sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
         n = C.c_int(0)
-        capi.check(self.lib.orbm_search_local_points(F.h, local_map.h, _vp(T), _vp(sk), C.c_float(th), int(bFarPoints),
-                                                     C.c_float(thFarPoints), C.c_float(self.mfNNratio), _vp(amp), _vp(aob),
-                                                     C.byref(n)), "orbm_search_local_points")
+        if in_frustum is not None:
+            assert in_frustum.dtype == np.uint8 and in_frustum.flags["C_CONTIGUOUS"]
+        capi.check(self.lib.orbm_search_local_points_vis(F.h, local_map.h, _vp(T), _vp(sk), C.c_float(th), int(bFarPoints),
+                                                         C.c_float(thFarPoints), C.c_float(self.mfNNratio), _vp(amp), _vp(aob),
+                                                         C.byref(n), _vp(in_frustum)), "orbm_search_local_points")
         return amp, aob, n.value
 
     @staticmethod

@@ -519,6 +519,102 @@ __global__ __launch_bounds__(256) void search_local_kernel(FrameParams fp, Frame
   window_search(fp, F, q, qd, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6], vis);
 }
 
+// ---- large local maps (a merged server map: tens of thousands of points, a few per cent of them in view).  One wavefront per
+// map point -- what search_local_kernel does -- spends its time on points that fail isInFrustum (26 ns per point at 76 k points).
+// Here the frustum test runs one THREAD per point (cull_count_kernel), the points that become queries are compacted in point
+// order (cull_fill_kernel: slot -> point index, on the device and mirrored for the host), and the window search runs one
+// wavefront per SLOT (search_culled_kernel).  The results are the ones search_local_kernel gives for the same points: the same
+// frustum_check, the same window_search, the commit walks the slots in ascending point order.
+__device__ __forceinline__ bool local_query_of(const FrameParams& fp, const WorldPtsDev& w, const uint8_t* __restrict__ skip_call,
+                                               const PoseF& P, float th, int far_points, float th_far, int i, Query* q, bool* in_view) {
+  q->valid = 0; q->x = q->y = q->r = 0; q->min_level = q->max_level = 0; q->ur_ref = 0;
+  *in_view = false;
+  const uint8_t w_bad = w.bad[i], w_skip = w.skip[i], c_skip = skip_call ? skip_call[i] : (uint8_t)0;
+  const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
+  const float N[3] = {w.normal[3 * i], w.normal[3 * i + 1], w.normal[3 * i + 2]};
+  const float w_min = w.min_dist[i], w_max = w.max_dist[i];
+  if (w_bad || w_skip || c_skip) return false;
+  const TrackFields t = frustum_check(fp, P, X, N, w_min, w_max, 0.5f);
+  *in_view = t.in_view != 0;
+  if (!(t.in_view && !(far_points && t.depth > th_far))) return false;
+  float r = (t.view_cos > 0.998) ? 2.5f : 4.0f;            // RadiusByViewingCos, S/ORBmatcher.cc:216-222
+  if (th != 1.0) r *= th;
+  q->valid = 1;
+  q->x = t.px; q->y = t.py;
+  q->r = r * fp.scale[t.level];
+  q->min_level = t.level - 1; q->max_level = t.level;
+  q->ur_ref = t.pxr;
+  return true;
+}
+
+// pass 1: per point "becomes a query" (flag byte, device) and "isInFrustum" (byte, host mirror, optional); per block the count
+__global__ __launch_bounds__(256) void cull_count_kernel(FrameParams fp, WorldPtsDev w, const uint8_t* __restrict__ skip_call, PoseF P, float th,
+                                                        int far_points, float th_far, uint8_t* __restrict__ qflag,
+                                                        uint8_t* __restrict__ vis_host, int* __restrict__ blk_cnt) {
+  __shared__ int wcnt[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool valid = false, vis = false;
+  if (i < w.m) {
+    Query q;
+    valid = local_query_of(fp, w, skip_call, P, th, far_points, th_far, i, &q, &vis);
+    qflag[i] = valid ? 1 : 0;
+    if (vis_host) vis_host[i] = vis ? 1 : 0;
+  }
+  const int c = __popcll(__ballot(valid));
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// pass 2: order-preserving compaction.  Block b's first slot = the counts of the blocks before it; inside the block by ballot rank.
+__global__ __launch_bounds__(256) void cull_fill_kernel(int m, const uint8_t* __restrict__ qflag, const int* __restrict__ blk_cnt,
+                                                       int* __restrict__ slot_pt, int* __restrict__ slot_pt_host, int* __restrict__ total_dev,
+                                                       int* __restrict__ total_host) {
+  __shared__ int red[4];
+  __shared__ int wcnt[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int sacc = 0;
+  for (int j = threadIdx.x; j < b; j += 256) sacc += blk_cnt[j];
+  sacc = wave_sum(sacc);
+  const int i = b * 256 + threadIdx.x;
+  const bool valid = i < m && qflag[i] != 0;
+  const unsigned long long bal = __ballot(valid);
+  if (lane == 0) { red[wave] = sacc; wcnt[wave] = __popcll(bal); }
+  __syncthreads();
+  const int base = red[0] + red[1] + red[2] + red[3];
+  int woff = 0;
+  for (int k = 0; k < wave; k++) woff += wcnt[k];
+  if (valid) {
+    const int s = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+    slot_pt[s] = i;
+    slot_pt_host[s] = i;
+  }
+  if (b == (int)gridDim.x - 1 && threadIdx.x == 0) {
+    const int tot = base + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    *total_dev = tot;
+    *total_host = tot;
+  }
+}
+
+// pass 3: one wavefront per compacted query (grid-stride over the slots); query id = slot
+__global__ __launch_bounds__(256) void search_culled_kernel(FrameParams fp, FrameDev F, WorldPtsDev w, const uint8_t* __restrict__ skip_call, PoseF P,
+                                                           float th, int far_points, float th_far, const int* __restrict__ slot_pt,
+                                                           const int* __restrict__ total_p, int slot_cap, int* list_counter, int* counter_next,
+                                                           uint32_t* list, int list_cap, QResult* results) {
+  __shared__ uint32_t s_stage[4][kListStage];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;
+  const int total = min(*total_p, slot_cap);
+  const int nwaves = (int)gridDim.x * 4;
+  for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < total; s += nwaves) {
+    const int i = slot_pt[s];
+    Query q;
+    bool vis;
+    local_query_of(fp, w, skip_call, P, th, far_points, th_far, i, &q, &vis);
+    const QDesc qd = load_qdesc(w.desc + (size_t)i * 32);
+    window_search(fp, F, q, qd, s, slot_cap, list_counter, list, list_cap, results + s, s_stage[threadIdx.x >> 6], vis ? kQVisible : (unsigned short)0);
+  }
+}
+
 // SearchByProjection(KeyFrame*, Scw, ...) candidate tests (S/ORBmatcher.cc:495-548 / :612-667) fused with the window search
 __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameDev F, WorldPtsDev w, const uint8_t* __restrict__ found,
                                                          PoseF P, int camera_project, int th, int* list_counter, int* counter_next, uint32_t* list,
@@ -839,6 +935,11 @@ struct orbm_frame {
   const float* depth_p = nullptr;
   std::vector<orbx_keypoint> h_kps_own;
   PinnedBuf<orbx_keypoint> h_kps_pin;    // host mirror written by the unpack kernel itself (orbk_frame_from_wire)
+  // large-map path of SearchLocalPoints (cull_* kernels)
+  DevBuf<uint8_t> d_qflag;
+  DevBuf<int> d_blk_cnt, d_slot_pt, d_total;
+  PinnedBuf<int> h_slot_pt;              // [0] = number of queries, [4 ..] slot -> point index
+  PinnedBuf<uint8_t> h_vis;
   const orbx_keypoint* hk = nullptr;     // host mirror (octave / angle for the serial commit)
   // per-call inputs are packed into ONE pinned staging block and moved with ONE H2D copy
   PinnedBuf<uint8_t> stage;
@@ -921,7 +1022,7 @@ extern "C" int orbm_frame_destroy(orbm_frame* f) {
   if (f->own_stream && f->own_stream != f->stream) (void)hipStreamSynchronize(f->own_stream);
   f->d_kps.release(); f->d_desc.release(); f->d_uright.release(); f->d_depth.release(); f->d_cell_of.release();
   f->d_cell_start.release(); f->d_cell_items.release(); f->stage.release(); f->d_stage.release();
-  f->d_counter.release(); f->list.release(); f->results.release(); f->sig.release(); f->h_kps_pin.release();
+  f->d_counter.release(); f->list.release(); f->results.release(); f->sig.release(); f->h_kps_pin.release(); f->d_qflag.release(); f->d_blk_cnt.release(); f->d_slot_pt.release(); f->d_total.release(); f->h_slot_pt.release(); f->h_vis.release();
   for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
   if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
   delete f;
@@ -1345,8 +1446,9 @@ static void stage_occupancy(orbm_frame* f, const int32_t* amp, const int32_t* ao
 }
 
 // Launches `launch(list_cap)` until the candidate list fits; leaves results + list in pinned memory.
+// n_scan_host: the number of queries that actually ran is written by the launch into pinned memory (large-map path); NULL: n_queries
 template <typename LaunchFn>
-static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
+static int run_search(orbm_frame* f, int n_queries, LaunchFn launch, const volatile int* n_scan_host = nullptr) {
   int rc;
   if ((rc = f->results.reserve((size_t)std::max(n_queries, 1)))) return rc;
   const size_t slots = (size_t)n_queries * kSlot;
@@ -1365,7 +1467,8 @@ static int run_search(orbm_frame* f, int n_queries, LaunchFn launch) {
     // the end of the furthest list segment tells whether the overflow region was large enough
     size_t total = 0;
     const QResult* R = f->results.h;
-    for (int i = 0; i < n_queries; i++) total = std::max(total, (size_t)R[i].base + (size_t)(R[i].count & kQCountMask));
+    const int n_scan = n_scan_host ? std::min((int)*n_scan_host, n_queries) : n_queries;
+    for (int i = 0; i < n_scan; i++) total = std::max(total, (size_t)R[i].base + (size_t)(R[i].count & kQCountMask));
     if (total <= f->list.cap) return ORBG_OK;
     if ((rc = f->list.reserve(total + total / 4))) return rc;
   }
@@ -1403,7 +1506,9 @@ static int pick_unclaimed(orbm_frame* f, const QResult& r, int want, ClaimedFn c
 }
 
 // Serial commit of SearchByProjection(Frame, MapPoints): S/ORBmatcher.cc:85-141 replayed on the GPU results.
-static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio, int32_t* amp, int32_t* aob, int* nmatches_out) {
+// slot_pt: the queries are a compacted subset of the points (large-map path), R[s] belongs to point slot_pt[s]; NULL: R[i] is point i
+static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio, int32_t* amp, int32_t* aob, int* nmatches_out,
+                      const int* slot_pt = nullptr) {
   const int n = f->fp.n;
   cache_keypoint_fields(f);
   f->claimed_buf.assign((size_t)std::max(n, 1), 0);  // features newly assigned in this call to an MP with Observations()>0
@@ -1411,10 +1516,11 @@ static int commit_mps(orbm_frame* f, int m, const int32_t* n_obs, float nnratio,
   int nmatches = 0;
   const QResult* R = f->results.h;
   auto is_claimed = [&](int idx) { return claimed[idx] != 0; };
-  for (int i = 0; i < m; i++) {
-    __builtin_prefetch(&R[i + 16]);                     // results sit in pinned memory the GPU has just written
-    const QResult& r = R[i];
+  for (int s = 0; s < m; s++) {
+    __builtin_prefetch(&R[s + 16]);                     // results sit in pinned memory the GPU has just written
+    const QResult& r = R[s];
     if (r.n_top == 0) continue;
+    const int i = slot_pt ? slot_pt[s] : s;
     Pick pk;
     int rc = pick_unclaimed(f, r, 2, is_claimed, &pk);   // features claimed since the kernel ran are skipped (:89-91)
     if (rc) return rc;
@@ -1490,6 +1596,27 @@ extern "C" int orbm_search_local_points_vis(orbm_frame* f, orbm_map* mp, const f
   if ((rc = stage_commit(f))) return rc;
   if ((rc = map_sync_to(mp, st))) return rc;       // the map's last upload may still be in flight on its own stream
   const WorldPtsDev w = map_dev(mp);
+  // large maps: frustum test one thread per point, compaction, window search only for the points that become queries
+  static const int cull_min = []() { const char* e = getenv("ORBG_CULL_MIN"); return e ? atoi(e) : 8192; }();
+  if (m >= cull_min) {
+    const int nb = (m + 255) / 256;
+    if ((rc = f->d_qflag.reserve((size_t)m)) || (rc = f->d_blk_cnt.reserve((size_t)nb)) || (rc = f->d_slot_pt.reserve((size_t)m)) ||
+        (rc = f->d_total.reserve(4)) || (rc = f->h_slot_pt.reserve((size_t)m + 4)) || (in_frustum && (rc = f->h_vis.reserve((size_t)m))))
+      return rc;
+    const int grid_search = std::min((m + 3) / 4, 2048);
+    rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
+      hipLaunchKernelGGL(cull_count_kernel, dim3(nb), dim3(256), 0, st, f->fp, w, d_skip_call, P, th, far_points, th_far_points, f->d_qflag.p,
+                         in_frustum ? f->h_vis.d : (uint8_t*)nullptr, f->d_blk_cnt.p);
+      hipLaunchKernelGGL(cull_fill_kernel, dim3(nb), dim3(256), 0, st, m, f->d_qflag.p, f->d_blk_cnt.p, f->d_slot_pt.p, f->h_slot_pt.d + 4,
+                         f->d_total.p, f->h_slot_pt.d);
+      hipLaunchKernelGGL(search_culled_kernel, dim3(grid_search), dim3(256), 0, st, f->fp, frame_dev(f), w, d_skip_call, P, th, far_points,
+                         th_far_points, f->d_slot_pt.p, f->d_total.p, m, cnt, cnt_next, f->list.d, list_cap, f->results.d);
+    }, f->h_slot_pt.h);
+    if (rc) return rc;
+    const int total = std::min(f->h_slot_pt.h[0], m);
+    if (in_frustum) memcpy(in_frustum, f->h_vis.h, (size_t)m);
+    return commit_mps(f, total, mp->n_obs.data(), nnratio, assigned_mp, assigned_obs, nmatches, f->h_slot_pt.h + 4);
+  }
   rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_local_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), w, d_skip_call, P, th, far_points,
                        th_far_points, cnt, cnt_next, f->list.d, list_cap, f->results.d);

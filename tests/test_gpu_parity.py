@@ -922,6 +922,45 @@ def test_c4_sizes_1280x720_2000_features_and_50kf_lba():
     assert np.array_equal(g.edge_outlier, o.edge_outlier)
 
 
+@pytest.mark.parametrize("far", [False, True])
+def test_search_local_points_on_a_large_merged_map(scene, far):
+    """A server-size map (about 30 k points: eight copies of a local map shifted out of view, one jittered copy in view, bad and
+    zero-observation points, skip flags) takes the large-map path of SearchLocalPoints -- frustum test per thread, ordered
+    compaction, window search per surviving point -- and must give what the per-point path and the oracle give: identical
+    assignments, identical in-frustum flags."""
+    rng = np.random.RandomState(71)
+    frs = [helpers.oracle_stereo_frame(scene, k) for k in (2, 6, 9)]
+    cur = helpers.oracle_stereo_frame(scene, 4)
+    base = helpers.local_map_from(scene, frs, rng)
+    parts = []
+    for c in range(17):
+        p = {k: v.copy() for k, v in base.items()}
+        if c % 2 == 0:
+            p["pos"] = p["pos"] + np.array([40.0 * (c + 1), -25.0 * c, 3.0 * c], np.float32)      # far outside the frustum
+        else:
+            p["pos"] = (p["pos"] + rng.randn(*p["pos"].shape) * 0.01).astype(np.float32)          # jittered copy in view
+        parts.append(p)
+    big = {k: np.concatenate([p[k] for p in parts]) for k in base}
+    m = len(big["pos"])
+    assert m > 25000
+    skip = (rng.rand(m) < 0.1).astype(np.uint8)
+    wv, keep2 = helpers.world_view_of(big, skip)
+    fv, keep = helpers.frame_view_of(scene, cur)
+    F = api.Frame().upload(fv, keep)
+    n = len(cur["kps"])
+    T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    amp0[::7] = 5; aob0[::7] = 2                                     # some features already hold a point
+    LM = api.LocalMap(65536).upload(wv)
+    vis = np.zeros(m, np.uint8)
+    g = api.ORBmatcher(0.8, True).SearchLocalPoints(F, LM, T, 3.0, far, 4.5, amp0, aob0, None, in_frustum=vis)
+    o = ob.search_local_points(fv, wv, T, 3.0, far, 4.5, 0.8, amp0, aob0)
+    assert o[2] > 100 and g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    otrk = ob.is_in_frustum(fv, T, wv, 0.5)
+    want_vis = np.asarray(otrk["track_in_view"]).astype(np.uint8) * (1 - skip) * (1 - big["bad"])
+    assert np.array_equal(vis, want_vis) and 1000 < int(vis.sum()) < m // 2
+
+
 def test_c4_sizes_matchers_2000_features_8k_map_points():
     """The tracking searches at BASELINE.json configs[3] sizes: 1280x720 frames of ~2000 features against a local map of ~8 k map
     points (seven keyframes' worth, shuffled, with bad / zero-observation points): SearchLocalPoints (fused isInFrustum +
