@@ -31,6 +31,16 @@
 
 #include "orbgpu_adapters.hpp"
 
+#ifdef ORBGPU_GLUE_TRACE
+#include <chrono>
+#include <cstdio>
+#define ORBGPU_GLUE_T(label) do { const auto _n = std::chrono::steady_clock::now(); std::fprintf(stderr, "  [glue] %-28s %8.1f us\n", label, std::chrono::duration<double, std::micro>(_n - _glue_t).count()); _glue_t = _n; } while (0)
+#define ORBGPU_GLUE_T0() auto _glue_t = std::chrono::steady_clock::now()
+#else
+#define ORBGPU_GLUE_T(label) do { } while (0)
+#define ORBGPU_GLUE_T0() do { } while (0)
+#endif
+
 namespace orbgpu {
 namespace dropin {
 
@@ -352,6 +362,7 @@ int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMa
 template <class Ops = GpuOps, class KeyFrameT, class MapT>
 int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num_fixedKF, int /*LocalBASize: unused in the reference too*/) {
   using MapPointT = typename std::remove_pointer<typename std::decay<decltype(pKF->GetMapPointMatches())>::type::value_type>::type;
+  ORBGPU_GLUE_T0();
   // ---- local keyframes: pKF and its covisible neighbours in this map (:1813-1826)
   std::list<KeyFrameT*> lLocalKeyFrames{pKF};
   pKF->mnBALocalForKF = pKF->mnId;
@@ -371,16 +382,25 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
         mp->mnBALocalForKF = pKF->mnId;
       }
   }
-  // ---- fixed keyframes: observe local points without being local (:1856-1873)
+  ORBGPU_GLUE_T("local keyframes + points");
+  // ---- fixed keyframes: observe local points without being local (:1856-1873).  GetObservations() hands out a COPY of the
+  // point's std::map (under the point's mutex): it is taken once per point and kept for the edge pass below
+  using ObsMap = typename std::decay<decltype(std::declval<MapPointT>().GetObservations())>::type;
+  struct LocalPoint { MapPointT* mp; ObsMap obs; size_t vid; };
+  std::vector<LocalPoint> vLP;
+  vLP.reserve(lLocalMapPoints.size());
   std::list<KeyFrameT*> lFixedCameras;
-  for (MapPointT* mp : lLocalMapPoints)
-    for (const auto& ob : mp->GetObservations()) {
+  for (MapPointT* mp : lLocalMapPoints) {
+    vLP.push_back(LocalPoint{mp, mp->GetObservations(), vertex_id(mp->mnId, mp->mnClientId, false)});
+    for (const auto& ob : vLP.back().obs) {
       KeyFrameT* kf = ob.first;
       if (kf->mnBALocalForKF != pKF->mnId && kf->mnBAFixedForKF != pKF->mnId) {
         kf->mnBAFixedForKF = pKF->mnId;
         if (!kf->isBad() && kf->GetMap() == pCurrentMap) lFixedCameras.push_back(kf);
       }
     }
+  }
+  ORBGPU_GLUE_T("observations + fixed cameras");
   num_fixedKF += (int)lFixedCameras.size();
   if (num_fixedKF < 2) {
     // fewer than two fixed keyframes leave the scale free: the one / two local keyframes with the lowest ids are fixed (:1875-1910)
@@ -398,42 +418,68 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   std::vector<KeyFrameT*> vKF(lLocalKeyFrames.begin(), lLocalKeyFrames.end());
   const size_t n_local = vKF.size();
   vKF.insert(vKF.end(), lFixedCameras.begin(), lFixedCameras.end());
-  std::map<KeyFrameT*, bool> is_fixed;
-  for (size_t i = 0; i < vKF.size(); i++) is_fixed[vKF[i]] = i >= n_local || vKF[i]->mnId == pMap->GetInitKFid();   // :1940, :1951
-  std::sort(vKF.begin(), vKF.end(), [](KeyFrameT* a, KeyFrameT* b) { return vertex_id(a->mnId, a->mnClientId, true) < vertex_id(b->mnId, b->mnClientId, true); });
-  std::map<KeyFrameT*, int> kfIndex;
+  std::vector<std::pair<KeyFrameT*, bool>> kf_fixed(vKF.size());
+  for (size_t i = 0; i < vKF.size(); i++) kf_fixed[i] = {vKF[i], i >= n_local || vKF[i]->mnId == pMap->GetInitKFid()};   // :1940, :1951
+  std::sort(kf_fixed.begin(), kf_fixed.end(), [](const auto& a, const auto& b) {
+    return vertex_id(a.first->mnId, a.first->mnClientId, true) < vertex_id(b.first->mnId, b.first->mnClientId, true); });
+  // keyframe -> index in the flattened problem: a few dozen keyframes, looked up once per observation: a small open-addressing
+  // table keyed by the keyframe's address
+  size_t tab_size = 64;
+  while (tab_size < 4 * vKF.size()) tab_size *= 2;
+  std::vector<std::pair<KeyFrameT*, int>> kfTab(tab_size, std::pair<KeyFrameT*, int>(nullptr, -1));
+  auto kf_slot = [&](KeyFrameT* kf) { return ((reinterpret_cast<uintptr_t>(kf) >> 4) * 0x9E3779B97F4A7C15ull >> 20) & (tab_size - 1); };
   std::vector<float> poses(16 * vKF.size()); std::vector<uint8_t> fixed(vKF.size());
   for (size_t i = 0; i < vKF.size(); i++) {
-    kfIndex[vKF[i]] = (int)i;
+    vKF[i] = kf_fixed[i].first;
+    size_t h = kf_slot(vKF[i]);
+    while (kfTab[h].first) h = (h + 1) & (tab_size - 1);
+    kfTab[h] = {vKF[i], (int)i};
     const auto Tm = vKF[i]->GetPose();
     std::memcpy(&poses[16 * i], mat_f32(Tm), 64);
-    fixed[i] = is_fixed[vKF[i]];
+    fixed[i] = kf_fixed[i].second;
   }
-  std::vector<MapPointT*> vMP(lLocalMapPoints.begin(), lLocalMapPoints.end());
-  std::sort(vMP.begin(), vMP.end(), [](MapPointT* a, MapPointT* b) { return vertex_id(a->mnId, a->mnClientId, false) < vertex_id(b->mnId, b->mnClientId, false); });
+  auto kf_index = [&](KeyFrameT* kf) -> int {
+    for (size_t h = kf_slot(kf);; h = (h + 1) & (tab_size - 1)) {
+      if (kfTab[h].first == kf) return kfTab[h].second;
+      if (!kfTab[h].first) return -1;
+    }
+  };
+  ORBGPU_GLUE_T("keyframe table");
+  // the points in ascending vertex id: a permutation is sorted, not the records (each holds a std::map)
+  std::vector<std::pair<size_t, uint32_t>> order(vLP.size());
+  for (size_t j = 0; j < vLP.size(); j++) order[j] = {vLP[j].vid, (uint32_t)j};
+  std::sort(order.begin(), order.end());
+  ORBGPU_GLUE_T("sort points");
+  std::vector<MapPointT*> vMP(vLP.size());
   std::vector<float> pts; std::vector<lba_edge> edges; std::vector<std::pair<KeyFrameT*, MapPointT*>> edgeOwner;
-  for (size_t j = 0; j < vMP.size(); j++) {
-    MapPointT* mp = vMP[j];
+  pts.reserve(3 * vLP.size()); edges.reserve(8 * vLP.size()); edgeOwner.reserve(8 * vLP.size());
+  struct ObsRef { size_t vid; KeyFrameT* kf; int li; int col; };
+  std::vector<ObsRef> obs;
+  for (size_t j = 0; j < vLP.size(); j++) {
+    const LocalPoint& lp = vLP[order[j].second];
+    MapPointT* mp = lp.mp;
+    vMP[j] = mp;
     const auto Xm = mp->GetWorldPos();                     // a clone (S/MapPoint.cc:GetWorldPos): keep it alive while it is read
     const float* X = mat_f32(Xm);
     pts.insert(pts.end(), X, X + 3);
     // the reference walks a std::map<KeyFrame*, ...> (address order); here: by vertex id, which only permutes sums (E-6)
-    std::vector<std::pair<size_t, std::pair<KeyFrameT*, int>>> obs;
-    for (const auto& ob : mp->GetObservations()) {
+    obs.clear();
+    for (const auto& ob : lp.obs) {
       KeyFrameT* kf = ob.first;
-      if (kf->isBad() || kf->GetMap() != pCurrentMap || !kfIndex.count(kf)) continue;        // :2003
+      const int col = kf_index(kf);
+      if (col < 0 || kf->isBad() || kf->GetMap() != pCurrentMap) continue;                   // :2003
       const int li = std::get<0>(ob.second);
       if (li < 0) continue;                                                                  // :2007
-      obs.push_back({vertex_id(kf->mnId, kf->mnClientId, true), {kf, li}});
+      obs.push_back(ObsRef{vertex_id(kf->mnId, kf->mnClientId, true), kf, li, col});
     }
-    std::sort(obs.begin(), obs.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-    for (const auto& o : obs) {
-      KeyFrameT* kf = o.second.first; const int li = o.second.second;
-      const auto& kp = kf->mvKeysUn[li];
-      edges.push_back(lba_edge{kfIndex[kf], (int32_t)j, kp.pt.x, kp.pt.y, kf->mvuRight[li] /* < 0: monocular (:2007) */, kf->mvInvLevelSigma2[kp.octave]});
-      edgeOwner.push_back({kf, mp});
+    std::sort(obs.begin(), obs.end(), [](const ObsRef& a, const ObsRef& b) { return a.vid < b.vid; });
+    for (const ObsRef& o : obs) {
+      const auto& kp = o.kf->mvKeysUn[o.li];
+      edges.push_back(lba_edge{o.col, (int32_t)j, kp.pt.x, kp.pt.y, o.kf->mvuRight[o.li] /* < 0: monocular (:2007) */, o.kf->mvInvLevelSigma2[kp.octave]});
+      edgeOwner.push_back({o.kf, mp});
     }
   }
+  ORBGPU_GLUE_T("points + edges");
   lba_problem P{(int32_t)vKF.size(), (int32_t)vMP.size(), (int32_t)edges.size(), poses.data(), fixed.data(), pts.data(), edges.data(),
                 pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, pMap->IsInertial() ? 100.0 : 0.0 /* :1924-1925 */, 5, 10, 0};
   std::vector<float> oposes(poses.size()), opts(pts.size()); std::vector<uint8_t> eout(edges.size()), edep(edges.size());
@@ -442,7 +488,9 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   // *pbStopFlag is LocalMapping::mbAbortBA, a bool Tracking raises through InterruptBA() while this runs (S/LocalMapping.cc:381-386):
   // the pointer goes to the library unchanged and is polled there between LM iterations / trials, where g2o polls it
   // (G/core/sparse_optimizer.cpp:376, G/core/optimization_algorithm_levenberg.cpp:149) and for bDoMore (:2135-2139)
+  ORBGPU_GLUE_T("result buffers");
   check(Ops::lba(P, pbStopFlag, R), "LocalBundleAdjustment");
+  ORBGPU_GLUE_T("solve (Ops::lba)");
   if (R.status != LBA_APPLIED) return R.status;                                              // :2127-2129 and :2257-2261: nothing is written
   std::vector<std::pair<KeyFrameT*, MapPointT*>> vToErase;                                   // :2207-2253
   for (size_t k = 0; k < edges.size(); k++)
@@ -450,7 +498,7 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                                   // :2263
   for (auto& e : vToErase) { e.first->EraseMapPointMatch(e.second); e.second->EraseObservation(e.first); }   // :2279-2286
   for (KeyFrameT* kf : lLocalKeyFrames) {                                                    // :2318-2372 (SetPose)
-    decltype(kf->GetPose()) T; make_mat(T, 4, 4, &oposes[16 * (size_t)kfIndex[kf]]);
+    decltype(kf->GetPose()) T; make_mat(T, 4, 4, &oposes[16 * (size_t)kf_index(kf)]);
     kf->SetPose(T, true);                                                                    // :2327 (bLock: mbPoseLock on the server)
   }
   for (size_t j = 0; j < vMP.size(); j++) {                                                  // :2375-2383
@@ -459,6 +507,7 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
     vMP[j]->UpdateNormalAndDepth();
   }
   pMap->IncreaseChangeIndex();                                                               // :2397 (Tracking reads it: mbMapUpdated)
+  ORBGPU_GLUE_T("write-back");
   return R.status;
 }
 
