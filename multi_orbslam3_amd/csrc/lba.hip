@@ -576,51 +576,71 @@ __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0;
-  for (int j = b + threadIdx.x; j < e_end; j += 256) {
-    const int k = ps_edges[j];
-    const lba_edge e = edges[k];
-    const PoseQ T = poses[e.pose];
-    const double* X = points + 3 * (size_t)e.point;
-    double r[3];
-    quat_rotate(T.q, X, r);
-    const bool mono = e.ur < 0;
-    const int D = mono ? 2 : 3;
-    double er[3], chi_k;
-    if constexpr (FUSED) {             // the edge workgroups of this launch are computing the same residuals concurrently
-      double Xc[3];
-      edge_error(T, X, c, e, er, Xc);
-      const double om0 = (double)e.inv_sigma2;
-      chi_k = 0;
-      for (int i = 0; i < D; i++) chi_k += er[i] * (om0 * er[i]);
-    } else {
-      er[0] = err[3 * (size_t)k]; er[1] = err[3 * (size_t)k + 1]; er[2] = err[3 * (size_t)k + 2];
-      chi_k = chi2[k];
+  // Every edge of the list observes pose p.  A thread's edges (j, j + 256, ...) are fetched in chunks of
+  // three -- indices, then edge records, then landmark positions, each level requested for the whole chunk before the first use
+  // (three memory round trips per chunk instead of three per edge) -- and accumulated in the order of the plain loop: same bits.
+  constexpr int kCh = 3;
+  for (int j0 = b + threadIdx.x; j0 < e_end; j0 += 256 * kCh) {
+    int kk[kCh];
+#pragma unroll
+    for (int u = 0; u < kCh; u++) kk[u] = ps_edges[min(j0 + 256 * u, e_end - 1)];
+    lba_edge ev[kCh];
+#pragma unroll
+    for (int u = 0; u < kCh; u++) ev[u] = edges[kk[u]];
+    double Xv[kCh][3];
+#pragma unroll
+    for (int u = 0; u < kCh; u++) {
+      const double* Xp = points + 3 * (size_t)ev[u].point;
+      Xv[u][0] = Xp[0]; Xv[u][1] = Xp[1]; Xv[u][2] = Xp[2];
     }
-    double A[9], B[18];
-    edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
-    double rho0, rho1;
-    huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
-    const double om = (double)e.inv_sigma2;
-    const double wom = rho1 * om;
-    double omega_r[3];
+    const PoseQ T = poses[ev[0].pose];                     // (the same pose for every edge of the list: requested with the landmarks)
 #pragma unroll
-    for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * er[i]) * rho1 : 0.0;
-    int o = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int b2 = a; b2 < 6; b2++) {
-        double h = 0;
-#pragma unroll
-        for (int i = 0; i < 3; i++) h += B[6 * i + a] * wom * B[6 * i + b2];
-        acc[o++] += h;
+    for (int u = 0; u < kCh; u++) {
+      if (j0 + 256 * u >= e_end) continue;
+      const int k = kk[u];
+      const lba_edge e = ev[u];
+      const double* X = Xv[u];
+      double r[3];
+      quat_rotate(T.q, X, r);
+      const bool mono = e.ur < 0;
+      const int D = mono ? 2 : 3;
+      double er[3], chi_k;
+      if constexpr (FUSED) {             // the edge workgroups of this launch are computing the same residuals concurrently
+        double Xc[3];
+        edge_error(T, X, c, e, er, Xc);
+        const double om0 = (double)e.inv_sigma2;
+        chi_k = 0;
+        for (int i = 0; i < D; i++) chi_k += er[i] * (om0 * er[i]);
+      } else {
+        er[0] = err[3 * (size_t)k]; er[1] = err[3 * (size_t)k + 1]; er[2] = err[3 * (size_t)k + 2];
+        chi_k = chi2[k];
       }
+      double A[9], B[18];
+      edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
+      double rho0, rho1;
+      huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
+      const double om = (double)e.inv_sigma2;
+      const double wom = rho1 * om;
+      double omega_r[3];
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
-      double sacc = 0;
+      for (int i = 0; i < 3; i++) omega_r[i] = i < D ? -(om * er[i]) * rho1 : 0.0;
+      int o = 0;
 #pragma unroll
-      for (int i = 0; i < 3; i++) sacc += B[6 * i + a] * omega_r[i];
-      acc[o++] += sacc;
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b2 = a; b2 < 6; b2++) {
+          double h = 0;
+#pragma unroll
+          for (int i = 0; i < 3; i++) h += B[6 * i + a] * wom * B[6 * i + b2];
+          acc[o++] += h;
+        }
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+        double sacc = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) sacc += B[6 * i + a] * omega_r[i];
+        acc[o++] += sacc;
+      }
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

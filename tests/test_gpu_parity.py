@@ -837,6 +837,99 @@ def test_lba_abort_from_another_thread_leaves_the_results_alone():
 
 
 
+def test_lba_abort_through_the_references_bool_flag():
+    """`bool* pbStopFlag` as the reference owns it (LocalMapping::mbAbortBA, one byte, raised by Tracking through InterruptBA while
+    the solve runs: S/LocalMapping.cc:381-386): the library polls that byte (lba_solve_hb / lba_solve_async_b).  Wherever a solve
+    saw the flag -- it reports the LM trials it had evaluated -- the oracle stopped at that poll point gives the same result."""
+    import threading
+    import time as _time
+    prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000, seed=78)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    opt = api.Optimizer()
+    full = opt.LocalBundleAdjustment(p)
+    flag = np.ones(1, np.bool_)                                   # raised before the call: S/Optimizer.cc:2127-2129
+    g0 = opt.LocalBundleAdjustment(p, pbStopFlag=flag)
+    assert g0.status == capi.LBA_ABORTED_BEFORE_OPT and g0.iters == (0, 0)
+    out = views.LbaOutput(p.n_poses, p.n_points, p.n_edges)
+    seen = set()
+    for rep in range(20):
+        flag = np.zeros(1, np.uint8)
+        delay = 1e-6 * (30 + 40 * rep)
+
+        def raiser():
+            t_end = _time.perf_counter() + delay
+            while _time.perf_counter() < t_end:
+                pass
+            flag[0] = 1
+
+        th = threading.Thread(target=raiser)
+        opt.LocalBundleAdjustmentAsync(p, out, pbStopFlag=flag)
+        th.start()
+        got = opt.wait()
+        th.join()
+        it = tuple(got.iters)
+        seen.add(it)
+        if got.status == capi.LBA_ABORTED_BEFORE_OPT:
+            continue
+        k = int(got.trace_rows()[:, 2].sum())
+        stop_o = np.array([-k if k > 0 else np.iinfo(np.int32).min], np.int32)
+        o = ob.lba_solve(p, stop_flag=stop_o)
+        assert got.status == o.status and it == tuple(o.iters), (rep, k, it, o.iters)
+        assert np.abs(got.poses - o.poses).max() <= 1e-4 and np.abs(got.points - o.points).max() <= 1e-4, (rep, k)
+        assert np.array_equal(got.edge_outlier, o.edge_outlier), (rep, k)
+    assert len(seen) >= 2, seen
+    again = opt.LocalBundleAdjustment(p)
+    assert again.iters == full.iters and np.array_equal(again.poses, full.poses)
+
+
+def test_blocked_ldlt_is_deterministic_next_to_a_busy_gpu():
+    """The many-workgroup blocked LDL^T (windows of more than 50 free poses) re-reads the diagonal block in every panel workgroup:
+    a workgroup that is dispatched late must still see the unfactored block.  Other streams keep every compute unit busy while the
+    solve runs; results must be the bits of the solve on an idle GPU (and the oracle's, to tolerance)."""
+    import torch
+    prob = synth.make_lba_problem(n_free=64, n_fixed=3, n_points=1600, mono_frac=0.2, seed=364)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    opt = api.Optimizer()
+    idle = opt.LocalBundleAdjustment(p)
+    o = ob.lba_solve(p)
+    assert idle.iters == o.iters and np.abs(idle.poses - o.poses).max() <= 1e-4
+    a = torch.randn(4096, 4096, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for rep in range(6):
+        for st in streams:                                        # ~10 ms of large GEMMs on three streams
+            with torch.cuda.stream(st):
+                b = a
+                for _ in range(6):
+                    b = b @ a
+        busy = opt.LocalBundleAdjustment(p)
+        assert busy.iters == idle.iters, rep
+        assert np.array_equal(busy.poses, idle.poses) and np.array_equal(busy.points, idle.points), rep
+        assert np.array_equal(busy.trace_rows(), idle.trace_rows()), rep
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("W,H,nf", [(752, 480, 1200), (323, 241, 600)])
+def test_host_image_submit_on_other_image_shapes(W, H, nf):
+    """orbx_frame_stereo_submit through the library's ingest thread on EuRoC / odd image shapes (an image size that is no multiple
+    of 16 bytes, rows inside a wider buffer): features, stereo matches and grid equal the oracle's."""
+    sc = synth.Scene(W, H, tex_size=(max(2 * W, 800), max(2 * H, 600)), px_per_m=100.0)
+    ex = api.ORBextractor(nf, 1.2, 8, 20, 7, W, H, n_cams=2)
+    F = api.Frame()
+    for k in (2, 5):
+        fr = helpers.oracle_stereo_frame(sc, k, n_features=nf)
+        fv, keep = helpers.frame_view_of(sc, fr)
+        big = [np.full((H, W + 37), 9, np.uint8), np.full((H, W + 37), 200, np.uint8)]
+        big[0][:, 5:5 + W] = fr["L"]; big[1][:, 5:5 + W] = fr["R"]
+        ex.frame_stereo_submit(F, fv, big[0][:, 5:5 + W], big[1][:, 5:5 + W], float(sc.cam["bf"]), float(sc.cam["b"]), async_ingest=True)
+        n, nr = ex.frame_stereo_dev_wait()
+        assert n == len(fr["kps"]) and nr == len(fr["kps_r"]), (W, H, k)
+        kd, dd = F.download()[:2]
+        assert np.array_equal(kd, fr["kps"]) and np.array_equal(dd, fr["desc"]), (W, H, k)
+        gs, gi = F.grid()
+        os_, oi = ob.build_grid(fv)
+        assert np.array_equal(gs, os_) and np.array_equal(gi, oi), (W, H, k)
+
+
 @pytest.mark.parametrize("seed,noise,lam", [(10, 3.0, 0.0), (9, 3.0, 0.0), (11, 3.0, 0.0), (10, 1.0, 1e-12)])
 def test_lba_rejected_trials_discard_the_speculative_linearisation(seed, noise, lam):
     """Far-off initial estimates make g2o's LM reject trials (qmax up to 10 in the trace, rounds that end on qmax == 10):

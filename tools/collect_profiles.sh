@@ -11,23 +11,31 @@ R="$GRAFT_REPO_ROOT"
 OUT="$R/gpurun_out/$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-INL="--steps 100 --warmup 10 --no-cpu-baseline --no-secondary --lba-mode inline --no-pipeline"
+INL="--steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-dropin --lba-mode inline --no-pipeline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$R/bench.py" $INL > "$OUT/stats.log" 2>&1 || true
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_async" -o run -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --no-secondary > "$OUT/stats_async.log" 2>&1 || true
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -o run -- python3 "$R/bench.py" --config C4 --steps 40 --warmup 5 --no-cpu-baseline --no-secondary --lba-mode inline --no-pipeline > "$OUT/stats_c4.log" 2>&1 || true
-PMC="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --lba-mode inline --no-pipeline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_async" -o run -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-dropin > "$OUT/stats_async.log" 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -o run -- python3 "$R/bench.py" --config C4 --steps 40 --warmup 5 --no-cpu-baseline --no-secondary --no-dropin --lba-mode inline --no-pipeline > "$OUT/stats_c4.log" 2>&1 || true
+PMC="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-dropin --lba-mode inline --no-pipeline"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_fetch.log" 2>&1 || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_write.log" 2>&1 || true
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_mfma.log" 2>&1 || true
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_sq" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_sq.log" 2>&1 || true
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma_c4" -o run -- python3 "$R/bench.py" --config C4 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --lba-mode inline --no-pipeline > "$OUT/pmc_mfma_c4.log" 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma_c4" -o run -- python3 "$R/bench.py" --config C4 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-dropin --lba-mode inline --no-pipeline > "$OUT/pmc_mfma_c4.log" 2>&1 || true
 cd "$R"
 python3 bench.py --steps 2000 --warmup 100 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_default.json" || true
-python3 bench.py --steps 400 --warmup 40 --no-pipeline --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_sync_ctor.json" || true
-python3 bench.py --steps 400 --warmup 40 --lba-mode inline --no-pipeline --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_inline.json" || true
-python3 bench.py --config C4 --steps 200 --warmup 20 --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_c4.json" || true
-python3 bench.py --config mono --steps 400 --warmup 40 --no-secondary 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_mono.json" || true
-python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-secondary --server-tick 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_server_tick.json" || true
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_driver_20_steps.json" || true
+python3 bench.py --steps 400 --warmup 40 --no-pipeline --no-cpu-baseline --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_sync_ctor.json" || true
+python3 bench.py --steps 400 --warmup 40 --lba-mode inline --no-pipeline --no-cpu-baseline --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_inline.json" || true
+python3 bench.py --config C4 --steps 200 --warmup 20 --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_c4.json" || true
+python3 bench.py --config mono --steps 400 --warmup 40 --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_mono.json" || true
+python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-secondary --no-dropin --server-tick 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_server_tick.json" || true
+tests/cpp/dropin_bench 40 > "$OUT/dropin_bench.json" 2> "$OUT/dropin_bench.txt" || true
+tools/micro/fp64_latency > "$OUT/micro_fp64_issue.txt" 2>&1 || true
+python3 tools/search_large_map.py 1 8 32 128 > "$OUT/search_large_map.txt" 2>&1 || true
+python3 tools/po_time.py > "$OUT/pose_opt_time.txt" 2>&1 || true
+python3 tools/micro/po_prof.py > "$OUT/pose_opt_phases.txt" 2>&1 || true
+python3 tools/lba_time.py C2 200 > "$OUT/lba_time.txt" 2>&1 || true
+python3 tools/lba_time.py C4 40 >> "$OUT/lba_time.txt" 2>&1 || true
 python3 tools/lba_gaps.py "$OUT/stats/run_kernel_trace.csv" > "$OUT/lba_gaps.txt" 2>&1 || true
 f=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 profiles/pmc_aggregate.py FETCH_SIZE="$f" WRITE_SIZE="$w" > "$OUT/pmc_fetch_write_per_kernel.json" || true; fi
