@@ -1997,6 +1997,164 @@ __global__ __launch_bounds__(NT) void k_update(int n_poses, int n_points, int nP
   if (threadIdx.x == 0) scale_partial[blockIdx.x] = red[0];
 }
 
+// ---- the solve and the update in ONE launch (windows of <= 20 free poses: the column LDL^T).  Workgroup 0 is ldltm::ldlt_cols_body
+// (19 us on one compute unit); the other workgroups are k_update's work for 512 vertices each: they request everything that does
+// not depend on the solution -- a landmark's right-hand side, its first four Hpl blocks, Hll; a pose's state -- and then wait for
+// workgroup 0 to publish "x is ready" (a sequence number, release / acquire at agent scope: the workgroups sit on different XCDs).
+// What is left after the wait is arithmetic and one short round trip for x: the ~8 us of dependent loads of k_update and one
+// kernel boundary disappear from every LM iteration.  Same operations and order per vertex as k_update; the per-block partial sums
+// of computeScale() are over 512 threads here.
+struct UpdArgs {
+  int n_poses, n_points, nP;
+  const int* pose_col; const int* point_col; const PoseQ* poses; const double* points; double* x;
+  const int* pf_start; const int* pf_edges; const int* pf_col; const double* EB; const double* Hll; const double* bl; double lambda_v;
+  PoseQ* poses_out; double* points_out; const double* bp; double* scale_partial; const double* lambda_p;
+};
+constexpr int kFusedUpdThreads = ldltm::kThreads;
+
+__device__ __forceinline__ void update_after_solve_block(int ub, const UpdArgs& a, const unsigned* __restrict__ x_ready, unsigned seq) {
+  extern __shared__ __attribute__((aligned(16))) double upd_sh[];     // the launch's dynamic LDS (the LDL^T workgroup's store): 4 KB of it
+  double* const red = upd_sh;
+  const int i = ub * kFusedUpdThreads + (int)threadIdx.x;
+  const bool is_point = i < a.n_points, is_pose = !is_point && i < a.n_points + a.n_poses;
+  // ---- before the solution exists
+  int l = -1, j0 = 0, j1 = 0, c = -1;
+  double cl[3] = {0, 0, 0}, h6[6] = {1, 0, 0, 1, 0, 1}, Xin[3] = {0, 0, 0}, blv[3] = {0, 0, 0}, bpv[6] = {0, 0, 0, 0, 0, 0};
+  int eid[4] = {0, 0, 0, 0}, col[4] = {0, 0, 0, 0}, eid2[4] = {0, 0, 0, 0}, col2[4] = {0, 0, 0, 0};
+  double Bv[4][18];
+  PoseQ Tin;
+  if (is_point) {
+    l = a.point_col[i];
+    Xin[0] = a.points[3 * (size_t)i]; Xin[1] = a.points[3 * (size_t)i + 1]; Xin[2] = a.points[3 * (size_t)i + 2];
+    if (l >= 0) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) { blv[q] = a.bl[3 * (size_t)l + q]; cl[q] = blv[q]; }
+#pragma unroll
+      for (int q = 0; q < 6; q++) h6[q] = a.Hll[6 * (size_t)l + q];
+      j0 = a.pf_start[l]; j1 = a.pf_start[l + 1];
+      if (j1 > j0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = min(j0 + u, j1 - 1); eid[u] = a.pf_edges[j]; col[u] = a.pf_col[j]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = min(j0 + 4 + u, j1 - 1); eid2[u] = a.pf_edges[j]; col2[u] = a.pf_col[j]; }   // (indices only)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const double* Bi = a.EB + (size_t)eid[u] * kEB;
+#pragma unroll
+          for (int q = 0; q < 18; q++) Bv[u][q] = Bi[q];
+        }
+      }
+    }
+  } else if (is_pose) {
+    const int p = i - a.n_points;
+    c = a.pose_col[p];
+    Tin = a.poses[p];
+    if (c >= 0) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) bpv[q] = a.bp[6 * (size_t)c + q];
+    }
+  }
+  const double lambda = a.lambda_p ? *a.lambda_p : a.lambda_v;
+  // ---- wait for workgroup 0
+  while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(x_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != (int)seq) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (x is read with agent-scope loads below: no cache invalidation needed)
+  auto ldx = [&](size_t k) { return __hip_atomic_load(&a.x[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // ---- after
+  double sc = 0;
+  if (is_point) {
+    double dx[3] = {0, 0, 0};
+    if (l >= 0) {
+      if (j1 > j0) {
+        double xv[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+          for (int q = 0; q < 6; q++) xv[u][q] = ldx(6 * (size_t)col[u] + q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (j0 + u < j1) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+              for (int q = 0; q < 6; q++) cl[cc] -= Bv[u][3 * q + cc] * xv[u][q];
+          }
+      }
+      for (int jb = j0 + 4; jb < j1; jb += 4) {                   // landmarks with more than four free observations
+        int e2[4], c2[4];
+        if (jb == j0 + 4) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) { e2[u] = eid2[u]; c2[u] = col2[u]; }       // observations 4..7: indices came in before the wait
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int j = min(jb + u, j1 - 1); e2[u] = a.pf_edges[j]; c2[u] = a.pf_col[j]; }
+        }
+        double B2[4][18], x2[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const double* Bi = a.EB + (size_t)e2[u] * kEB;
+#pragma unroll
+          for (int q = 0; q < 18; q++) B2[u][q] = Bi[q];
+#pragma unroll
+          for (int q = 0; q < 6; q++) x2[u][q] = ldx(6 * (size_t)c2[u] + q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (jb + u < j1) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+              for (int q = 0; q < 6; q++) cl[cc] -= B2[u][3 * q + cc] * x2[u][q];
+          }
+      }
+      double Dinv[9];
+      inv3_sym(h6, lambda, Dinv);
+      for (int q = 0; q < 3; q++) {
+        dx[q] = Dinv[3 * q] * cl[0] + Dinv[3 * q + 1] * cl[1] + Dinv[3 * q + 2] * cl[2];
+        a.x[6 * (size_t)a.nP + 3 * (size_t)l + q] = dx[q];
+        sc += dx[q] * (lambda * dx[q] + blv[q]);
+      }
+    }
+    for (int q = 0; q < 3; q++) a.points_out[3 * (size_t)i + q] = Xin[q] + dx[q];
+  } else if (is_pose) {
+    const int p = i - a.n_points;
+    if (c >= 0) {
+      double xc6[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) xc6[q] = ldx(6 * (size_t)c + q);
+      pose_oplus(Tin, xc6, &a.poses_out[p]);
+      for (int q = 0; q < 6; q++) sc += xc6[q] * (lambda * xc6[q] + bpv[q]);
+    } else {
+      a.poses_out[p] = Tin;
+    }
+  }
+  // fixed-order block sum: DPP tree per wavefront, the eight wave totals in wave order
+  const double wsum = wave_sum_f64(sc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0;
+    for (int w2 = 0; w2 < kFusedUpdThreads / 64; w2++) tot += red[w2];
+    a.scale_partial[ub] = tot;
+  }
+}
+
+__global__ __launch_bounds__(ldltm::kThreads) void k_ldlt_cols_update(int n, const double* __restrict__ St, double* __restrict__ x,
+                                                                      int* __restrict__ ok_flag, unsigned* __restrict__ x_ready, unsigned seq,
+                                                                      UpdArgs ua) {
+  if (blockIdx.x == 0) {
+    ldltm::ldlt_cols_body<true>(n, St, x, ok_flag);      // x leaves through agent-scope stores of wavefront 0
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // thread 0 belongs to the wavefront that stored x: its stores are complete (memory counter drained) before the word goes out
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __hip_atomic_store(x_ready, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  update_after_solve_block((int)blockIdx.x - 1, ua, x_ready, seq);
+}
+
 // one workgroup: chi2 = sum partial[] (fixed order), scale = sum x (lambda x + b), maxdiag; -> pinned record
 __device__ __forceinline__ void finish_block(int n_partial, const double* __restrict__ partial, int nP, int nL,
                                              const double* __restrict__ x, const double* __restrict__ bp, const double* __restrict__ bl,
@@ -2099,6 +2257,8 @@ struct lba_handle {
   DevBuf<int> d_pair_count;
   DevBuf<PoseQ> d_poses[2];
   DevBuf<double> d_points[2];
+  DevBuf<unsigned> d_xready;           // "x is ready" sequence word of the fused LDL^T + update launch
+  unsigned xseq = 0;
   DevBuf<double> d_err, d_chi2, d_partial, d_EB, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_x;
   DevBuf<double> d_wide;               // running / scaled right-hand side of the many-workgroup LDL^T (k_wide_*)
   DevBuf<double> d_St, d_wfac;         // reduced camera matrix as a tile image / factor scratch of the matrix-core LDL^T (ldlt_mfma.hpp)
@@ -2158,7 +2318,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  h->d_edges.release(); h->edges_pin.release(); h->d_items_dev.release(); h->d_pair_count.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release();
+  h->d_edges.release(); h->edges_pin.release(); h->d_items_dev.release(); h->d_pair_count.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release(); h->d_xready.release();
   h->d_err.release(); h->d_chi2.release(); h->d_partial.release(); h->d_EB.release(); h->d_Hll.release(); h->d_bl.release();
   h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release(); h->d_St.release(); h->d_wfac.release();
   h->d_EB2.release(); h->d_Hll2.release(); h->d_bl2.release(); h->d_Hpp2.release(); h->d_bp2.release(); h->d_lambda0.release();
@@ -2393,10 +2553,12 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     if ((rc = h->d_items_dev.reserve((size_t)n_pairs_all * item_cap)) || (rc = h->d_pair_count.reserve(std::max(n_pairs_all, 1)))) return rc;
     D.items = h->d_items_dev.p;
   }
-  // the two state buffers (current / trial estimate): buffer 0 IS the uploaded state inside the arena (part A is not written
-  // again during the solve; two device-to-device copies of a few KB cost the stream ~10 us each before the first residuals),
-  // buffer 1 an allocation of its own
+  // the three state buffers (current / trial estimate / the trial after it, written on speculation by the fused solve + update
+  // launch): buffer 0 IS the uploaded state inside the arena (part A is not written again during the solve; two device-to-device
+  // copies of a few KB cost the stream ~10 us each before the first residuals), buffers 1 and 2 allocations of their own.
+  // They rotate: trial = (cur + 1) % 3, and an accepted trial becomes the current estimate.
   if ((rc = h->d_poses[1].reserve(std::max(NP, 1))) || (rc = h->d_points[1].reserve(std::max<size_t>(3 * (size_t)NX, 1))) ||
+      (rc = h->d_poses[0].reserve(std::max(NP, 1))) || (rc = h->d_points[0].reserve(std::max<size_t>(3 * (size_t)NX, 1))) ||
       (rc = h->d_err.reserve(std::max<size_t>(3 * (size_t)NE, 1))) || (rc = h->d_chi2.reserve(std::max(NE, 1))) ||
       (rc = h->d_partial.reserve(std::max(n_blocks_e, 1))) || (rc = h->d_EB.reserve(std::max<size_t>((size_t)NE * kEB, 1))) ||
       (rc = h->d_Hll.reserve(std::max<size_t>(6 * (size_t)nL, 1))) || (rc = h->d_bl.reserve(std::max<size_t>(3 * (size_t)nL, 1))) ||
@@ -2407,8 +2569,15 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       (rc = h->d_S.reserve(std::max<size_t>((size_t)n * n, 1))) || (rc = h->d_bs.reserve(std::max(n, 1))) ||
       (rc = h->d_x.reserve(std::max<size_t>((size_t)n + 3 * (size_t)nL, 1))))
     return rc;
-  PoseQ* const posesB[2] = {reinterpret_cast<PoseQ*>(h->up_d.p + o_poses), h->d_poses[1].p};
-  double* const pointsB[2] = {reinterpret_cast<double*>(h->up_d.p + o_points), h->d_points[1].p};
+  if (!h->d_xready.p) {
+    // the "x is ready" word starts at zero (a recycled allocation may hold another handle's last sequence number); sequence
+    // numbers start at 1
+    if ((rc = h->d_xready.reserve(4))) return rc;
+    ORBG_HIP(hipMemsetAsync(h->d_xready.p, 0, 4 * sizeof(unsigned), h->stream));
+    h->xseq = 0;
+  }
+  PoseQ* const posesB[3] = {reinterpret_cast<PoseQ*>(h->up_d.p + o_poses), h->d_poses[1].p, h->d_poses[0].p};
+  double* const pointsB[3] = {reinterpret_cast<double*>(h->up_d.p + o_points), h->d_points[1].p, h->d_points[0].p};
 
   const double t_c = now_s();
   Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
@@ -2500,8 +2669,22 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // same wavefronts over more compute units (ORBG_UPD_THREADS = 64 / 128 / 256 for experiments)
   // measured (tools/lba_time.py, C2): 256 threads 0.499 ms per solve, 128: 0.488, 64: 0.484
   static const int upd_threads = []() { const char* e = getenv("ORBG_UPD_THREADS"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
-  const int n_blocks_u = (NP + NX + upd_threads - 1) / upd_threads;
+  // ORBG_FUSE_UPDATE=1: windows the column LDL^T covers run the solve and the update as ONE launch (k_ldlt_cols_update).  Off by
+  // default -- measured at C2 (tools/lba_time.py): 0.4865 ms per solve fused, 0.4868-0.4911 as two launches.  The update workgroups
+  // do overlap their dependent loads with the LDL^T, but they sit on other XCDs than the LDL^T workgroup: the "x is ready" word and
+  // x itself reach them through memory (agent-scope stores / loads, ~2 us each way), which costs what the kernel boundary and
+  // k_update's own loads cost.  (A same-XCD placement checked through the XCC_ID register would make the hand-over an L2 round trip.)
+  const bool fuse_upd = use_mfma && ldltm::pick(n).cols && getenv("ORBG_FUSE_UPDATE") && atoi(getenv("ORBG_FUSE_UPDATE")) != 0;
+  const int n_blocks_u = fuse_upd ? (NP + NX + kFusedUpdThreads - 1) / kFusedUpdThreads : (NP + NX + upd_threads - 1) / upd_threads;
   if ((rc = h->d_scale_partial.reserve(std::max(n_blocks_u, 1)))) return rc;
+  if (fuse_upd) {
+    static bool attr_set = false;
+    const size_t lds = ldltm::pick(n).lds;
+    if (!attr_set && lds > 48 * 1024) {
+      ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_cols_update), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+      attr_set = true;
+    }
+  }
   if (!h->d_ticket.p) {
     if ((rc = h->d_ticket.reserve(4))) return rc;
     ORBG_HIP(hipMemsetAsync(h->d_ticket.p, 0, 4 * sizeof(unsigned), st));
@@ -2582,7 +2765,8 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   int solve_version = -1;          // Schur complement + LDL^T of the NEXT trial already launched (speculatively) at this trial number
   bool prof_pending = false;       // an event pair brackets one LDL^T launch of this call
   const bool prof_this_solve = h->prof_on && (h->prof_solves++ & 3) == 0;
-  auto launch_solve = [&](int set_, double lam_, const double* lamp_) -> int {
+  // in_buf / out_buf: with the fused launch the trial state posesB[out_buf] = posesB[in_buf] (+) x is written by the same launch
+  auto launch_solve = [&](int set_, double lam_, const double* lamp_, int in_buf, int out_buf) -> int {
     if (nP > 0) {
       hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                          EBs[set_], Hlls[set_], bls[set_], Hpps[set_], bps[set_], lam_, h->d_S.p, h->d_bs.p, lamp_, item_cap,
@@ -2590,7 +2774,13 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       // (two event records and an elapsed-time query cost the solve ~8 us: one solve in four is enough for an average)
       const bool bracket = h->prof_on && !prof_pending && prof_this_solve;
       if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
-      if (use_mfma) {
+      if (fuse_upd) {
+        UpdArgs ua{NP, NX, nP, D.pose_col, D.point_col, posesB[in_buf], pointsB[in_buf], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[set_],
+                   Hlls[set_], bls[set_], lam_, posesB[out_buf], pointsB[out_buf], bps[set_], h->d_scale_partial.p, lamp_};
+        h->xseq = h->xseq == 0x7FFFFFFFu ? 1u : h->xseq + 1u;
+        hipLaunchKernelGGL(k_ldlt_cols_update, dim3(1 + n_blocks_u), dim3(ldltm::kThreads), ldltm::pick(n).lds, st, n, h->d_St.p, h->d_x.p,
+                           h->d_ok.p, h->d_xready.p, h->xseq, ua);
+      } else if (use_mfma) {
         ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
       } else if (use_wide) {
         ORBG_HIP(launch_ldlt_wide(n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wide.p, st));
@@ -2663,13 +2853,13 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       double rho = 0;
       int qmax = 0;
       do {
-        const int trial = cur ^ 1;
+        const int trial = (cur + 1) % 3;
         version++;
         const double* lam_p = lambda_on_device ? h->d_lambda0.p : (const double*)nullptr;
         // the solve of this trial may already be running: it was launched, with the lambda the device computed for the accepted
-        // case, behind the previous trial's residual / linearisation kernel
-        if (!(solve_version == version - 1 && qmax == 0 && used_spec) && (rc2 = launch_solve(ls, lambda, lam_p))) return rc2;
-        {
+        // case, behind the previous trial's residual / linearisation kernel (with the fused launch: its update into `trial` too)
+        if (!(solve_version == version - 1 && qmax == 0 && used_spec) && (rc2 = launch_solve(ls, lambda, lam_p, cur, trial))) return rc2;
+        if (!fuse_upd) {
           auto upd = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(n_blocks_u), dim3(upd_threads), 0, st, NP, NX, nP, D.pose_col, D.point_col,
                                posesB[cur], pointsB[cur], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
@@ -2697,7 +2887,9 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
             // ... and, when the next trial belongs to the same round, its Schur complement + LDL^T with the lambda the device
             // has just computed for the accepted case: the host's verdict then arrives while they run
             if (it + 1 < iterations && nBad < 2 && nP > 0) {
-              if ((rc2 = launch_solve(set, 0.0, h->d_lambda0.p + 1))) return rc2;
+              // (fused launch: the update of the trial AFTER this one, into the third buffer -- this trial's state stays intact
+              // in case it is rejected, the current estimate in case it is not)
+              if ((rc2 = launch_solve(set, 0.0, h->d_lambda0.p + 1, trial, (trial + 1) % 3))) return rc2;
               solve_version = version;
             }
           } else {

@@ -1146,7 +1146,11 @@ __device__ __forceinline__ void backsub_pairs_unrolled(const lds_vd2p W2, double
   y0 = x0f; y1 = x1f;
 }
 
-__global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag) {
+// (a device function so that the local BA can launch it as workgroup 0 of a larger grid: lba.hip, k_ldlt_cols_update.  AGENT_X:
+// the solution is stored with agent-scope atomic stores -- write-through to the level every XCD sees -- because workgroups of the
+// SAME launch on other XCDs read it; a release fence at agent scope would write the whole L2 back instead)
+template <bool AGENT_X>
+__device__ __forceinline__ void ldlt_cols_body(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag) {
 #pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ int s_piv;                // pivots published so far (16 k + pv + 1)
@@ -1508,11 +1512,20 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __r
       }
     }
     }
-    if (lane < n) x[lane] = y0;
-    if (64 + lane < n) x[64 + lane] = y1;
+    if constexpr (AGENT_X) {
+      if (lane < n) __hip_atomic_store(&x[lane], y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (64 + lane < n) __hip_atomic_store(&x[64 + lane], y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane < n) x[lane] = y0;
+      if (64 + lane < n) x[64 + lane] = y1;
+    }
   }
   if (wv == 0) LDLTM_T(4);
   if (tid == 0) *ok_flag = ok;
+}
+
+__global__ __launch_bounds__(kThreads) void k_ldlt_cols(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag) {
+  ldlt_cols_body<false>(n, St, x, ok_flag);
 }
 
 // true if k_ldlt_mfma covers a system of n unknowns (n = 6 * free poses)

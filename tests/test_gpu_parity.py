@@ -930,6 +930,36 @@ def test_host_image_submit_on_other_image_shapes(W, H, nf):
         assert np.array_equal(gs, os_) and np.array_equal(gi, oi), (W, H, k)
 
 
+def test_lba_with_the_solve_and_the_update_in_one_launch():
+    """ORBG_FUSE_UPDATE=1 (off by default): the LDL^T workgroup and k_update's work as ONE launch -- the update
+    workgroups prefetch, wait for "x is ready" and finish the trial state; with speculative solves the trial after the next one is
+    written into a third state buffer.  Same decisions, trace and results as the oracle, for every window size the column kernel
+    covers, and the rejected-trial paths."""
+    code = (
+        "import numpy as np\n"
+        "from multi_orbslam3_amd import api, synth, views\n"
+        "from oracle import binding as ob\n"
+        "for nf, seed, noise in [(n, 7000 + n, 1.0) for n in range(1, 21)] + [(12, 10, 3.0), (20, 9, 3.0), (8, 11, 3.0)]:\n"
+        "    prob = synth.make_lba_problem(n_free=nf, n_fixed=2, n_points=12 * nf + 40, mono_frac=0.25, seed=seed)\n"
+        "    if noise != 1.0:\n"
+        "        prob['points'] = (prob['points'] + np.random.RandomState(seed).randn(*prob['points'].shape) * 0.05 * noise).astype(np.float32)\n"
+        "    p, keep = views.lba_problem(prob['poses'], prob['pose_fixed'], prob['points'], prob['edges'], prob['cam'])\n"
+        "    o = ob.lba_solve(p)\n"
+        "    opt = api.Optimizer()\n"
+        "    for rep in range(2):\n"
+        "        g = opt.LocalBundleAdjustment(p)\n"
+        "        assert g.status == o.status and g.iters == o.iters, (nf, g.iters, o.iters)\n"
+        "        assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4, nf\n"
+        "        assert np.array_equal(g.edge_outlier, o.edge_outlier), nf\n"
+        "        tg, to = g.trace_rows(), o.trace_rows()\n"
+        "        assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]) and np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), nf\n"
+        "print('fused ok')\n")
+    env = dict(os.environ, ORBG_FUSE_UPDATE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "fused ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 @pytest.mark.parametrize("seed,noise,lam", [(10, 3.0, 0.0), (9, 3.0, 0.0), (11, 3.0, 0.0), (10, 1.0, 1e-12)])
 def test_lba_rejected_trials_discard_the_speculative_linearisation(seed, noise, lam):
     """Far-off initial estimates make g2o's LM reject trials (qmax up to 10 in the trace, rounds that end on qmax == 10):
