@@ -111,3 +111,78 @@ def test_server_tick_goes_through_rccl_on_one_rank():
     st = d["config"]["server_tick"]
     assert st["2_kf_blocks_us"] > 0 and st["8_kf_blocks_us"] > st["2_kf_blocks_us"] and "nccl" in st["note"]
     assert 0 < st["exchange_only_8_blocks_us"] < st["8_kf_blocks_us"] and "ONE RCCL all-gather" in st["note"]
+
+
+@pytest.mark.gpu
+def test_cxx_tracking_loop_does_the_work_of_the_python_loop():
+    """bench.py times libagentloop.so (csrc/agent_loop.cpp).  On a short sequence the C++ loop and the step-by-step Python loop over
+    the same handles must do the same work: identical keypoint and match totals per region for the pipelined host-image,
+    pipelined device-image and synchronous constructors, and the same number of local BAs with the same LM iterations."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from multi_orbslam3_amd import _capi as capi, agent, api, synth, views
+    cfg = dict(bench.CONFIGS["C2"])
+    scene = synth.Scene(640, 480, seed=synth.SEED_IMAGES)
+    n_frames = 12
+    ex, imgs, host_imgs, frames, kf_chunks = bench.build_workload(scene, cfg, n_frames, api, views, synth, 0)
+    p = scene.frame_view_params()
+    fv, _k = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
+    exs = [ex, api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, 640, 480, n_cams=2)]
+    Fs = [api.Frame(cfg["frame_cap"]), api.Frame(cfg["frame_cap"])]
+    LM = api.LocalMap(cfg["map_cap"])
+    opt = api.Optimizer()
+    prob = synth.make_lba_problem(n_free=6, n_fixed=3, n_points=300, seed=5)
+    lp, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    lba_out = views.LbaOutput(lp.n_poses, lp.n_points, lp.n_edges)
+    seq = list(range(n_frames)) + list(range(n_frames - 2, 0, -1))
+    K = bench.FRAMES_PER_KF
+    period = int(np.lcm(len(seq), K))
+    sim = bench.LocalMaps(kf_chunks, cfg["local_kfs"], views)
+    sim.prefill(seq, 0)
+    kf_views = []
+    for i in range(2 * period):
+        if seq[i % len(seq)] % K == 0:
+            sim.visit(seq[i % len(seq)])
+        if i % K == 0 and i >= period:
+            kf_views.append(sim.view())
+    bf, bb = float(scene.cam["bf"]), float(scene.cam["b"])
+    frames_in = [dict(host=host_imgs[k], dev=(imgs[k][0].data_ptr(), imgs[k][1].data_ptr()),
+                      guess=np.ascontiguousarray(frames[k]["guess"], np.float32).reshape(16), last_view=frames[k]["last_view"][0]) for k in range(n_frames)]
+    po = synth.make_pose_opt_problem(n=100, seed=3)
+    po1, kp = views.pose_opt_problem(po["Xw"], po["u"], po["v"], po["ur"], po["inv_sigma2"], po["cam"], po["Tcw"])
+    loop = agent.AgentLoop(exs, Fs, LM, opt, fv, 640, 480, 640, bf, bb, frames_in, seq, kf_views, lp, lba_out, [po1, po1], K, 2 * cfg["frame_cap"], 7.0, False)
+    m_frame, m_map = api.ORBmatcher(0.9, True), api.ORBmatcher(0.8, True)
+    n_steps = 23
+
+    def python_region(pipelined, host):
+        kp = mf = mm = 0
+        amp = np.full(2 * cfg["frame_cap"], -1, np.int32); aob = np.zeros(2 * cfg["frame_cap"], np.int32)
+        LM.upload(kf_views[0])
+        for i in range(n_steps):
+            k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
+            c = i & 1 if pipelined else 0
+            if host:
+                nl, nr = exs[c].frame_stereo(Fs[c], fv, host_imgs[k][0], host_imgs[k][1], bf, bb, download=False)
+            else:
+                nl, nr = exs[c].frame_stereo_dev(Fs[c], fv, imgs[k][0].data_ptr(), imgs[k][1].data_ptr(), 640, 480, 640, bf, bb)
+            a, b = amp[:nl], aob[:nl]
+            a.fill(-1); b.fill(0)
+            a, b, n1 = m_frame.SearchByProjectionFrame(Fs[c], frames[k]["guess"], frames[k_last]["last_view"][0], 7.0, False, a, b, inplace=True)
+            a, b, n2 = m_map.SearchLocalPoints(Fs[c], LM, frames[k]["guess"], 1.0, False, 0.0, a, b, None, inplace=True)
+            if i % K == 0:
+                LM.upload(kf_views[(i // K) % len(kf_views)])
+            kp += nl + nr; mf += n1; mm += n2
+        return kp, mf, mm
+
+    for pipelined, host in ((True, True), (True, False), (False, True)):
+        LM.upload(kf_views[0])
+        loop.configure(pipelined, host, ingest_async=host, submit_first=True, lba_async=True, pose_opt=False)
+        st = loop.run(0, n_steps, last_is_final=True, timed=True)
+        loop.drain(st, True)
+        torch.cuda.synchronize()
+        want = python_region(pipelined, host)
+        assert (st.kp, st.m_frame, st.m_map) == want, (pipelined, host, (st.kp, st.m_frame, st.m_map), want)
+        assert st.lba_calls == (n_steps + K - 1) // K and st.lba_iters == st.lba_calls * sum(lba_out.iters)
+        assert st.m_frame > 100 * n_steps // 2 and st.kp > 1500 * n_steps
