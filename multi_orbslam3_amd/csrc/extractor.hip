@@ -2273,14 +2273,18 @@ static int stage_images(orbx_handle* h, const uint8_t* const* images, int n_img,
   }
   int rc;
   if ((rc = h->h_img.reserve(total + 16)) || (rc = h->d_img.reserve(total + 16))) return rc;
+  // one copy kernel per image, launched as soon as that image is packed: the device copies the left image while the host packs the
+  // right one.  A launch moves the 16-byte blocks that cover its image: the few bytes it shares with a neighbour's blocks are either
+  // already staged (the image before) or rewritten by the next launch (the image after), which runs behind it on the stream.
   for (int c = 0; c < n_img; c++) {
     uint8_t* dst = h->h_img.h + c * per;
     if (stride == w) memcpy(dst, images[c], per);
     else for (int y = 0; y < hgt; y++) memcpy(dst + (size_t)y * w, images[c] + (size_t)y * stride, w);
+    const size_t b0 = (c * per) / 16, b1 = ((c + 1) * per + 15) / 16;
+    const int n16 = (int)(b1 - b0);
+    hipLaunchKernelGGL(img_upload_kernel, dim3((n16 + 255) / 256), dim3(256), 0, h->stream, reinterpret_cast<const uint4*>(h->h_img.d) + b0,
+                       reinterpret_cast<uint4*>(h->d_img.p) + b0, n16);
   }
-  const int n16 = (int)((total + 15) / 16);
-  hipLaunchKernelGGL(img_upload_kernel, dim3((n16 + 255) / 256), dim3(256), 0, h->stream, reinterpret_cast<const uint4*>(h->h_img.d),
-                     reinterpret_cast<uint4*>(h->d_img.p), n16);
   return ORBG_OK;
 }
 

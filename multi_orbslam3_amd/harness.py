@@ -85,6 +85,50 @@ def _physical_cores_of_gpu_node(device_index):
     return cores
 
 
+def _cpu_busy(interval=0.12):
+    """Busy fraction of every hardware thread over `interval` seconds (two readings of /proc/stat)."""
+    def read():
+        out = {}
+        with open("/proc/stat") as f:
+            for line in f:
+                if line.startswith("cpu") and line[3].isdigit():
+                    p = line.split()
+                    v = [int(x) for x in p[1:9]]
+                    out[int(p[0][3:])] = (sum(v), v[3] + v[4])
+        return out
+    a = read()
+    time.sleep(interval)
+    b = read()
+    busy = {}
+    for c, (tot, idle) in a.items():
+        dt = b[c][0] - tot
+        busy[c] = 0.0 if dt <= 0 else 1.0 - (b[c][1] - idle) / dt
+    return busy
+
+
+def _pick_idle_cores(cores, busy, per_agent, group=8):
+    """A lone agent on a SHARED host (the bench boxes run four tenants on one 2-socket machine) takes the `per_agent` least
+    busy physical cores of the least busy group of `group` consecutive cores (one L3 slice: the three threads hand words to
+    each other) instead of a fixed run: a neighbour's job sitting on the fixed run costs a third of the frame rate
+    (8270-8340 frames/s on six runs of one box, 5650 on a seventh with the local BA worker sharing a core).  `cores`: sets of
+    hardware threads per physical core, in order; `busy`: hardware thread -> busy fraction.  Returns None when there are
+    fewer than `per_agent` cores."""
+    if len(cores) < per_agent:
+        return None
+    load = [max(busy.get(t, 0.0) for t in c) for c in cores]
+    best = None
+    for g0 in range(0, len(cores), group):
+        idx = sorted(range(g0, min(g0 + group, len(cores))), key=lambda i: (load[i], i))[:per_agent]
+        if len(idx) < per_agent:
+            continue
+        key = (round(sum(load[i] for i in idx), 2), -g0)             # ties: the upper groups (the first cores serve interrupts)
+        if best is None or key < best[0]:
+            best = (key, idx)
+    if best is None:
+        return None
+    return tuple(cores[i] for i in sorted(best[1]))
+
+
 def cores_for_agent(device_index, slot, per_agent=3):
     """`per_agent` distinct physical cores (each returned with its SMT siblings) on the GPU's NUMA node for agent number
     `slot` on that node: tracking thread, the library's local-BA worker, the library's image-ingest thread.  All three spin
@@ -94,6 +138,10 @@ def cores_for_agent(device_index, slot, per_agent=3):
     try:
         cores = _physical_cores_of_gpu_node(device_index)
         n_local = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        if n_local == 1 and slot == 0 and os.environ.get("ORBG_FIXED_CORES", "0") != "1":
+            got = _pick_idle_cores(cores, _cpu_busy(), per_agent)
+            if got is not None:
+                return got
         got = _pick_cores(cores, slot, n_local, per_agent)
         if got is None and per_agent > 2:
             got = _pick_cores(cores, slot, n_local, 2)

@@ -155,3 +155,22 @@ def test_agents_of_one_node_never_share_a_core_pair():
                 assert min(min(c) for c in flat) >= ncores // 2
     # a single agent on a big node gets the first pair of the upper half
     assert harness._pick_core_pair([{c} for c in range(64)], 0, 1) == ({32}, {33})
+
+
+def test_a_lone_agent_takes_the_idle_cores_of_one_l3_slice():
+    from multi_orbslam3_amd import harness
+    cores = [{c, c + 64} for c in range(32)]
+    # idle machine: the last slice, its first three cores
+    got = harness._pick_idle_cores(cores, {}, 3)
+    assert got == ({24, 88}, {25, 89}, {26, 90})
+    # a neighbour spins on the sibling thread of core 25 and on core 26: the slice is still the best one with three idle cores
+    busy = {89: 0.95, 26: 0.9}
+    got = harness._pick_idle_cores(cores, busy, 3)
+    assert got == ({24, 88}, {27, 91}, {28, 92})
+    # the whole upper slice busy: the next idle slice is taken; cores stay inside ONE slice
+    busy = {c: 0.8 for c in range(24, 32)}
+    got = harness._pick_idle_cores(cores, busy, 3)
+    assert got == ({16, 80}, {17, 81}, {18, 82})
+    assert harness._pick_idle_cores(cores[:2], {}, 3) is None
+    b = harness._cpu_busy(0.02)
+    assert b and all(0.0 <= v <= 1.0 for v in b.values())
