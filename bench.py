@@ -574,6 +574,20 @@ def main():
         loop = agent_mod.AgentLoop(exs, Fs, LM, opt, fv, W, H, W, bf, bb, frames_in, seq, kf_views, lp, lba_out, [po1, po2], FRAMES_PER_KF,
                                    2 * cfg["frame_cap"], th_frame, mono_flag)
 
+    def ctxt_switches():
+        """Involuntary context switches of every thread of this process so far: a spinning thread that loses its core to a
+        neighbour's job shows up here (the bench boxes are shared hosts)."""
+        tot = 0
+        try:
+            for t in os.listdir("/proc/self/task"):
+                with open("/proc/self/task/%s/status" % t) as f:
+                    for line in f:
+                        if line.startswith("nonvoluntary_ctxt_switches"):
+                            tot += int(line.split()[1])
+        except OSError:
+            return None
+        return tot
+
     def run_region_cxx(n_steps, n_warm, pose_opt, host_images, pipelined, first_index):
         reg = Region(n_steps)
         loop.configure(pipelined, host_images, ingest_async, submit_first, args.lba_mode == "async", pose_opt)
@@ -588,11 +602,14 @@ def main():
         base = first_index + n_warm
         step_s = np.zeros(max(n_steps, 1))
         grp.barrier(); torch.cuda.synchronize()
+        cs0 = ctxt_switches()
         t0 = time.perf_counter()
         loop.run(base, n_steps, last_is_final=True, timed=True, step_s=step_s, stats=st)
         sync()
         grp.barrier()
         elapsed = grp.max_over_ranks(time.perf_counter() - t0)
+        cs1 = ctxt_switches()
+        reg.stats["nonvoluntary_ctxt_switches"] = None if cs0 is None or cs1 is None else cs1 - cs0
         for key, j in (("extract", 0), ("match_frame", 1), ("match_map", 2), ("pose_opt", 3), ("map_upload", 4), ("lba", 5)):
             reg.stage[key] = st.stage_s[j]
         reg.stats.update(kp=st.kp, m_frame=st.m_frame, m_map=st.m_map, lba_iters=st.lba_iters, lba_calls=st.lba_calls, lba_s=st.lba_s)
@@ -642,6 +659,15 @@ def main():
         e.set_profile_interval(max(FAST_BRACKET_EVERY // len(exs), 1), reset=True)
     opt.set_profiling(True, reset=True)
     reg, elapsed = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, prewarm_done)
+    # what the shared host did to the region: involuntary context switches of this process's threads inside it, and how busy
+    # OTHER tenants keep the hardware threads of the agent's cores right after it (this process sleeps during the sample)
+    host_noise = {"nonvoluntary_ctxt_switches_in_region": reg.stats.get("nonvoluntary_ctxt_switches")}
+    if core_pair is not None:
+        try:
+            busy = harness._cpu_busy(0.1)
+            host_noise["agent_cores_busy_after_region"] = {str(t): round(busy.get(t, 0.0), 2) for c in core_pair for t in sorted(c)}
+        except OSError:
+            pass
     solver_sum_ms, solver_n, solver_unknowns, solver_mfma = opt.solver_stats()
     fast_sum, fast_n = 0.0, 0                              # bracket times accumulated inside the library over the timed region
     for e in exs:
@@ -785,7 +811,7 @@ def main():
                                         % ("library ingest thread" if pipeline and ingest_async else "calling thread")) if host_images else "images resident in HBM",
                        "local_map_points_avg": int(np.mean(maps.sizes)) if maps.sizes else 0, "local_map_keyframes": cfg["local_kfs"],
                        "sequence_frames": len(seq),
-                       "cpu_affinity": cpu_affinity, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
+                       "cpu_affinity": cpu_affinity, "host_noise": host_noise, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
                        "frame_ctor": ("pipelined: Frame(t+1) is submitted (host images: orbx_frame_stereo_submit) on a second extractor handle before frame t is tracked and "
                                       "collected at the start of step t+1; the timed region holds exactly K constructors (the first step "
                                       "submits its own, the last one hands no further frame over)") if pipeline else "synchronous",

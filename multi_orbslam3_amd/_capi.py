@@ -158,6 +158,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("liborbgpu.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(expected at %s). There is no CPU fallback." % LIB_PATH)
+    # ONE HIP / HSA runtime per process: PyTorch-ROCm ships its own libamdhip64 + libhsa-runtime64 and loads them by path even when
+    # the system's are mapped already (the library's own dependency resolves to /opt/rocm); the second runtime then finds no
+    # GPU ("No HIP GPUs are available" from the first torch.cuda call of a process that used this library before importing
+    # torch).  With torch imported first the library's NEEDED entry resolves to the runtime torch mapped.  A C++ deployment
+    # (no torch in the process) has the system runtime only.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.orbg_version.restype = C.c_char_p
     lib.orbg_strerror.restype = C.c_char_p

@@ -246,7 +246,7 @@ extern "C" int orbv_vocab_create(int device, const orbv_vocab_view* v, orbv_voca
   if (rc) return rc;
   orbv_vocab* h = new orbv_vocab();
   h->device = device; h->n_nodes = nn; h->L = v->L; h->weighting = v->weighting; h->scoring_norm = v->scoring_norm;
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
+  if (orbg::create_stream(&h->stream, "bow") != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   if ((rc = h->d_child_start.reserve(nn + 1)) || (rc = h->d_child_ids.reserve(std::max(nc, 1))) || (rc = h->d_word.reserve(nn)) ||
       (rc = h->d_desc.reserve((size_t)nn * 32)) || (rc = h->d_weight.reserve(nn))) { orbv_vocab_destroy(h); return rc; }
   ORBG_HIP(hipMemcpy(h->d_child_start.p, v->child_start, (size_t)(nn + 1) * 4, hipMemcpyHostToDevice));
@@ -261,7 +261,7 @@ extern "C" int orbv_vocab_create(int device, const orbv_vocab_view* v, orbv_voca
 extern "C" int orbv_vocab_destroy(orbv_vocab* h) {
   if (!h) return ORBG_BAD_ARG;
   (void)hipSetDevice(h->device);
-  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  (void)hipStreamSynchronize(h->stream); orbg::release_stream(h->stream);     // (a null h->stream is the null stream)
   h->d_child_start.release(); h->d_child_ids.release(); h->d_word.release(); h->d_desc.release(); h->d_weight.release();
   h->d_feat.release(); h->d_out_word.release(); h->d_out_node.release(); h->d_out_weight.release(); h->pin.release();
   delete h;
@@ -434,7 +434,7 @@ extern "C" int orbd_database_create(int device, const orbd_database_view* v, orb
   if (rc) return rc;
   orbd_database* d = new orbd_database;
   d->device = device; d->n_kfs = K; d->n_words = Wn;
-  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { delete d; return ORBG_HIP_ERROR; }
+  if (orbg::create_stream(&d->stream, "db") != hipSuccess) { delete d; return ORBG_HIP_ERROR; }
   auto up = [&](auto& buf, const auto* src, size_t n) -> int {
     int r = buf.reserve(std::max<size_t>(n, 1));
     if (r) return r;
@@ -463,7 +463,7 @@ extern "C" int orbd_database_destroy(orbd_database* d) {
   d->inv_start.release(); d->inv_kf.release(); d->bow_start.release(); d->bow_word.release(); d->covis_start.release(); d->covis_kf.release();
   d->words.release(); d->best.release(); d->out2.release(); d->qw.release(); d->bow_value.release(); d->qv.release(); d->connected.release();
   d->shares.release(); d->sel.release(); d->first_key.release(); d->place_score.release(); d->acc.release();
-  if (d->stream) (void)hipStreamDestroy(d->stream);
+  (void)hipStreamSynchronize(d->stream); orbg::release_stream(d->stream);
   delete d;
   return ORBG_OK;
 }

@@ -86,6 +86,24 @@ struct StreamSignal {
   int sync(hipStream_t st) { int rc = post(st); return rc ? rc : wait(st); }
 };
 
+// Streams of the library's handles.  HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4): the
+// first four streams get a queue each, every further one joins the queue with the fewest users, ties broken by the queues'
+// ADDRESSES -- i.e. differently from run to run.  Streams that share a hardware queue are serialised: with one stream per handle
+// (two extractors, two frames, the local map, the local BA, PoseOptimization, the null stream = 8) the local BA landed on the queue of
+// an extractor in about one process out of three: 0.79 instead of 0.59 ms per solve and 5600 instead of 8400 frames/s for the
+// whole run, same cores, no host noise.  The library therefore owns THREE streams per device, created
+// together by the first handle so that each gets a hardware queue of its own next to the null stream's:
+//   "lba"                      -> L        (local BA handles; nothing else ever)
+//   "ex"                       -> E0 / E1  (extractor handles, alternating: Frame(t+1) is built next to the searches on frame t)
+//   "fr"                       -> M, E0, E1 in turn (a frame built by the constructor adopts its extractor's stream anyway)
+//   "map", "po", "bow", "db"   -> M = the null stream (uploads, PoseOptimization, vocabulary / database work)
+// Handles that share a stream stay correct -- every completion signal is enqueued behind the handle's own work on an in-order
+// stream -- they merely do not overlap.  ORBG_STREAM_POOL=0 gives every handle a stream of its own again (ORBG_PRIO_<ROLE> =
+// -1 / 1 then picks a HIP stream priority for the role: priorities open further hardware queues and were slower in every
+// combination tried).  Implemented in misc.cpp (one registry for all translation units).
+hipError_t create_stream(hipStream_t* st, const char* role);
+void release_stream(hipStream_t st);       // destroys a stream of its own; pool streams live as long as the process
+
 inline int select_device(int device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);

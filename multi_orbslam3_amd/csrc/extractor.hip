@@ -1590,6 +1590,9 @@ static int build_tower_axis(int T, int nl, const int* size, const std::vector<st
 
 static int setup_geometry(orbx_handle* h, int w, int hgt) {
   if (w == h->cur_w && hgt == h->cur_h) return ORBG_OK;
+  // the geometry is rebuilt in place: until the rebuild has succeeded the handle has NO valid geometry (a refused size -- a
+  // pyramid level inside the border -- must not leave the tables of two image sizes mixed behind the old cur_w / cur_h)
+  h->cur_w = h->cur_h = 0;
   const int nl = h->cfg.n_levels;
   PyrGeom& g = h->geom;
   g.n_levels = nl;
@@ -1798,7 +1801,7 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     h->qts.resize(nthreads + 1);
     for (auto& q : h->qts) q.oldest_first_ = cfg->octree_oldest_first != 0;
   }
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
+  if (orbg::create_stream(&h->stream, "ex") != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   for (auto& e : h->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   const int cap = 2 * (cfg->n_features + 4 * nl + 64);
@@ -1822,7 +1825,7 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   if (!h) return ORBG_BAD_ARG;
   (void)hipSetDevice(h->device);
   while (h->ingest_state.load(std::memory_order_acquire) == 1) std::this_thread::yield();   // an asynchronous submission is being enqueued
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->stream);
   ctor_graph_free(h->cgraph);
   h->d_pyr.release(); h->d_img.release(); h->h_img.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_tower_x.release(); h->d_tower_y.release(); h->d_cells.release();
   h->d_slots.release(); h->d_counts.release(); h->hdr.release(); h->cand.release(); h->sel.release();
@@ -1831,7 +1834,7 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   h->d_cand.release(); h->d_hdr.release(); h->d_lvlcount.release(); h->d_nkp.release(); h->d_overflow.release();
   h->d_selreg.release(); h->h_nkp.release(); h->sig.release();
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  orbg::release_stream(h->stream);
   delete_pending(h->pending);
   delete h;
   return ORBG_OK;

@@ -2301,7 +2301,7 @@ extern "C" int lba_create(int device, int cap_poses, int cap_points, int cap_edg
   if (rc) return rc;
   lba_handle* h = new lba_handle();
   h->device = device;
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
+  if (orbg::create_stream(&h->stream, "lba") != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   if ((rc = h->rec.reserve(4)) || (rc = h->d_ok.reserve(4))) { delete h; return rc; }
   memset(h->rec.h, 0, 4 * sizeof(HostRec));
   (void)cap_poses; (void)cap_points; (void)cap_edges;   // buffers grow on first use and are kept
@@ -2317,7 +2317,7 @@ extern "C" int lba_destroy(lba_handle* h) {
     h->worker.join();
   }
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->stream);
   h->d_edges.release(); h->edges_pin.release(); h->d_items_dev.release(); h->d_pair_count.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release(); h->d_xready.release();
   h->d_err.release(); h->d_chi2.release(); h->d_partial.release(); h->d_EB.release(); h->d_Hll.release(); h->d_bl.release();
   h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release(); h->d_St.release(); h->d_wfac.release();
@@ -2326,7 +2326,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
   h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release(); h->d_scale_partial.release(); h->d_ticket.release(); h->sig.release();
   for (auto& e : h->prof_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  orbg::release_stream(h->stream);
   delete h;
   return ORBG_OK;
 }
@@ -3842,16 +3842,17 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   for (int i = 0; i < n; i++) r->outlier[i] = 0;
   if (n < 3) return ORBG_OK;                                  // S/Optimizer.cc:1180-1181
   // one pinned staging block: inputs in, results out (a per-thread cache keeps the allocation across calls)
-  // per-thread scratch with its own non-blocking stream (the legacy null stream would synchronise with every blocking
-  // stream of the process -- torch / RCCL -- and serialise concurrent callers); released when the thread exits
+  // per-thread scratch; the stream comes from the library's pool (common.hpp: role "po" = the null stream, which keeps the
+  // hardware queues of the extractor and local-BA streams to themselves; the library's own streams are non-blocking, so nothing
+  // of the agent synchronises with it implicitly); released when the thread exits
   struct Scratch {
-    PinnedBuf<uint8_t> stage; DevBuf<uint8_t> dev; int device = -1; hipStream_t stream = nullptr;
-    void drop() { stage.release(); dev.release(); if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; } }
+    PinnedBuf<uint8_t> stage; DevBuf<uint8_t> dev; int device = -1; hipStream_t stream = nullptr; bool have_stream = false;
+    void drop() { stage.release(); dev.release(); if (have_stream) { orbg::release_stream(stream); stream = nullptr; have_stream = false; } }
     ~Scratch() { drop(); }
   };
   static thread_local Scratch sc;
   if (sc.device != p->device) { sc.drop(); sc.device = p->device; }
-  if (!sc.stream) ORBG_HIP(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
+  if (!sc.have_stream) { ORBG_HIP(orbg::create_stream(&sc.stream, "po")); sc.have_stream = true; }      // (the null stream is a null pointer)
   const size_t in_bytes = ((size_t)n * 7 * 4 + 15) & ~(size_t)15;
   const size_t out_off = in_bytes;
   const size_t out_bytes = sizeof(PoseQ) + 8 * sizeof(int) + 4 * sizeof(double) + (size_t)n + 64;

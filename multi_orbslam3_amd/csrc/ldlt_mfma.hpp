@@ -1109,39 +1109,42 @@ __device__ __forceinline__ void backsub_pairs_unrolled(const lds_vd2p W2, double
   // No masks on the factor's columns: a lane whose x is final is not protected from the entries past its pair's rows (they
   // belong to the next pair's storage: finite numbers), its x is simply kept aside the moment it becomes final (one select
   // per pair instead of two per column); nothing reads a final lane of y again.
+  // Both unknowns of a pair come from ONE state of y:  x1 = y[2p+1],  x0 = y[2p] - w01 x1  with w01 = W(2p, 2p+1) read out of the
+  // column itself ahead of time -- one lane read on the dependent chain per pair instead of two.
+  // ONE ring of four pairs in flight over both halves (rows >= 64 live in y1 and need the second 128-bit load per pair).  The
+  // scheduling barrier after every pair keeps the refill where it is written: hipcc otherwise moves two pairs of arithmetic in
+  // front of it and the wait in front of a pair then covers a load issued ONE pair earlier (93 cycles per pair, an LDS round trip
+  // of a lone wavefront is ~130).
   double x0f = y0, x1f = y1;
-  if constexpr (NP > 32) {
-    d2 c0[4], c1[4];
+  d2 c0[4], c1[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { const int pi = NP - 1 - i > 32 ? NP - 1 - i : 32; c0[i] = W2[pi * (pi + 1)]; c1[i] = W2[pi * (pi + 1) + 64]; }
-#pragma unroll
-    for (int p2 = NP - 1; p2 >= 32; p2--) {
-      const int i = (NP - 1 - p2) & 3;
-      const double x1 = rdlane(y1, 2 * p2 + 1 - 64);
-      y1 -= c1[i][1] * x1;                       // entries on / below the diagonal inside the pair are stored as zeros
-      y0 -= c0[i][1] * x1;
-      const double x0 = rdlane(y1, 2 * p2 - 64);
-      x1f = (lane >> 1) == p2 - 32 ? y1 : x1f;   // lanes 2 p2 - 64 and 2 p2 - 63 are final now
-      y1 -= c1[i][0] * x0;
-      y0 -= c0[i][0] * x0;
-      if (p2 - 4 >= 32) { c0[i] = W2[(p2 - 4) * (p2 - 3)]; c1[i] = W2[(p2 - 4) * (p2 - 3) + 64]; }
-    }
+  for (int i = 0; i < 4; i++) {
+    const int pi = NP - 1 - i > 0 ? NP - 1 - i : 0;
+    c0[i] = W2[pi * (pi + 1)];
+    c1[i] = pi >= 32 ? W2[pi * (pi + 1) + 64] : c0[i];
   }
-  {
-    constexpr int ps = (NP < 32 ? NP : 32) - 1;
-    d2 c0[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { const int pi = ps - i > 0 ? ps - i : 0; c0[i] = W2[pi * (pi + 1)]; }
-#pragma unroll
-    for (int p2 = ps; p2 >= 0; p2--) {
-      const int i = (ps - p2) & 3;
-      const double x1 = rdlane(y0, 2 * p2 + 1);
-      y0 -= c0[i][1] * x1;
-      const double x0 = rdlane(y0, 2 * p2);
+  for (int p2 = NP - 1; p2 >= 0; p2--) {
+    const int i = (NP - 1 - p2) & 3;
+    if (p2 >= 32) {
+      const double w01 = rdlane(c1[i][1], 2 * p2 - 64);
+      const double x1 = rdlane(y1, 2 * p2 + 1 - 64), y0r = rdlane(y1, 2 * p2 - 64);
+      const double x0 = __builtin_fma(-w01, x1, y0r);
+      y1 = __builtin_fma(-c1[i][0], x0, __builtin_fma(-c1[i][1], x1, y1));   // entries on / below the diagonal inside the pair are stored as zeros
+      y0 = __builtin_fma(-c0[i][0], x0, __builtin_fma(-c0[i][1], x1, y0));
+      x1f = (lane >> 1) == p2 - 32 ? y1 : x1f;   // lanes 2 p2 - 64 and 2 p2 - 63 are final now
+    } else {
+      const double w01 = rdlane(c0[i][1], 2 * p2);
+      const double x1 = rdlane(y0, 2 * p2 + 1), y0r = rdlane(y0, 2 * p2);
+      const double x0 = __builtin_fma(-w01, x1, y0r);
+      y0 = __builtin_fma(-c0[i][0], x0, __builtin_fma(-c0[i][1], x1, y0));
       x0f = (lane >> 1) == p2 ? y0 : x0f;
-      y0 -= c0[i][0] * x0;
-      if (p2 - 4 >= 0) c0[i] = W2[(p2 - 4) * (p2 - 3)];
     }
+    if (p2 - 4 >= 0) {
+      c0[i] = W2[(p2 - 4) * (p2 - 3)];
+      if (p2 - 4 >= 32) c1[i] = W2[(p2 - 4) * (p2 - 3) + 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   y0 = x0f; y1 = x1f;
 }

@@ -1007,7 +1007,7 @@ extern "C" int orbm_frame_create(int device, int cap_features, orbm_frame** out)
   f->device = device;
   f->cap = cap_features;
   memset(&f->fp, 0, sizeof(f->fp));
-  if (hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking) != hipSuccess) { delete f; return ORBG_HIP_ERROR; }
+  if (orbg::create_stream(&f->own_stream, "fr") != hipSuccess) { delete f; return ORBG_HIP_ERROR; }
   f->stream = f->own_stream;
   for (auto& e : f->ev) if (hipEventCreate(&e) != hipSuccess) { delete f; return ORBG_HIP_ERROR; }
   if ((rc = frame_reserve(f, cap_features))) { delete f; return rc; }
@@ -1018,13 +1018,13 @@ extern "C" int orbm_frame_create(int device, int cap_features, orbm_frame** out)
 extern "C" int orbm_frame_destroy(orbm_frame* f) {
   if (!f) return ORBG_BAD_ARG;
   (void)hipSetDevice(f->device);
-  if (f->stream) (void)hipStreamSynchronize(f->stream);
-  if (f->own_stream && f->own_stream != f->stream) (void)hipStreamSynchronize(f->own_stream);
+  (void)hipStreamSynchronize(f->stream);
+  if (f->own_stream != f->stream) (void)hipStreamSynchronize(f->own_stream);
   f->d_kps.release(); f->d_desc.release(); f->d_uright.release(); f->d_depth.release(); f->d_cell_of.release();
   f->d_cell_start.release(); f->d_cell_items.release(); f->stage.release(); f->d_stage.release();
   f->d_counter.release(); f->list.release(); f->results.release(); f->sig.release(); f->h_kps_pin.release(); f->d_qflag.release(); f->d_blk_cnt.release(); f->d_slot_pt.release(); f->d_total.release(); f->h_slot_pt.release(); f->h_vis.release();
   for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
-  if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
+  orbg::release_stream(f->own_stream);
   delete f;
   return ORBG_OK;
 }
@@ -1271,8 +1271,8 @@ extern "C" int orbm_map_create(int device, int cap_points, orbm_map** out) {
   if (rc) return rc;
   orbm_map* m = new orbm_map();
   m->device = device;
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return ORBG_HIP_ERROR; }
-  if (hipEventCreateWithFlags(&m->up_ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(m->stream); delete m; return ORBG_HIP_ERROR; }
+  if (orbg::create_stream(&m->stream, "map") != hipSuccess) { delete m; return ORBG_HIP_ERROR; }
+  if (hipEventCreateWithFlags(&m->up_ev, hipEventDisableTiming) != hipSuccess) { orbg::release_stream(m->stream); delete m; return ORBG_HIP_ERROR; }
   if ((rc = map_reserve(m, cap_points))) { orbm_map_destroy(m); return rc; }
   *out = m;
   return ORBG_OK;
@@ -1284,7 +1284,7 @@ extern "C" int orbm_map_destroy(orbm_map* m) {
   (void)hipDeviceSynchronize();
   m->arena.release(); m->stage.release();
   if (m->up_ev) (void)hipEventDestroy(m->up_ev);
-  if (m->stream) (void)hipStreamDestroy(m->stream);
+  orbg::release_stream(m->stream);
   m->t_in_view.release(); m->t_px.release(); m->t_py.release(); m->t_pxr.release(); m->t_depth.release();
   m->t_vc.release(); m->t_level.release();
   delete m;

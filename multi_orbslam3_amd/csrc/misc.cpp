@@ -28,7 +28,62 @@ extern "C" int orbg_device_count(void) {
 #include <immintrin.h>
 #endif
 
+#include <mutex>
+
 namespace orbg {
+
+namespace {
+struct DevicePool { bool made = false; hipStream_t L = nullptr, E[2] = {nullptr, nullptr}; unsigned n_ex = 0, n_fr = 0; };
+std::mutex g_pool_mu;
+DevicePool g_pool[64];
+bool pool_enabled() { static const bool on = [] { const char* e = getenv("ORBG_STREAM_POOL"); return !(e && e[0] == '0'); }(); return on; }
+
+hipError_t create_own(hipStream_t* st, const char* role) {
+  char name[32];
+  snprintf(name, sizeof name, "ORBG_PRIO_%s", role);
+  for (char* c = name; *c; c++) if (*c >= 'a' && *c <= 'z') *c = (char)(*c - 'a' + 'A');
+  const char* e = getenv(name);
+  const int prio = e ? atoi(e) : 0;
+  if (prio == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  int lo = 0, hi = 0;                                   // numerically hi <= lo; hi is the greatest priority
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio < 0 ? hi : lo);
+}
+}  // namespace
+
+hipError_t create_stream(hipStream_t* st, const char* role) {
+  if (!pool_enabled()) return create_own(st, role);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return create_own(st, role);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  DevicePool& P = g_pool[dev];
+  if (!P.made) {
+    hipStream_t s3[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; i++)
+      if ((e = hipStreamCreateWithFlags(&s3[i], hipStreamNonBlocking)) != hipSuccess) {
+        for (int j = 0; j < i; j++) (void)hipStreamDestroy(s3[j]);
+        return e;
+      }
+    P.L = s3[0]; P.E[0] = s3[1]; P.E[1] = s3[2]; P.made = true;
+  }
+  if (!strcmp(role, "lba")) *st = P.L;
+  else if (!strcmp(role, "ex")) *st = P.E[P.n_ex++ & 1];
+  else if (!strcmp(role, "fr")) { const unsigned k = P.n_fr++ % 3; *st = k == 0 ? (hipStream_t) nullptr : P.E[k - 1]; }
+  else *st = nullptr;                                   // the null stream (its explicit handle hipStreamLegacy crashes hipStreamWaitEvent on events recorded on it: ROCm 7.2)
+  return hipSuccess;
+}
+
+void release_stream(hipStream_t st) {
+  if (!st) return;
+  if (pool_enabled()) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (const DevicePool& P : g_pool)
+      if (P.made && (st == P.L || st == P.E[0] || st == P.E[1])) return;
+  }
+  (void)hipStreamDestroy(st);
+}
 
 __global__ void orbg_signal_kernel(volatile unsigned* flag, unsigned seq) {
   *flag = seq;

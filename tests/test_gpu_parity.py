@@ -149,7 +149,7 @@ def test_extractor_empty_image():
     assert nm == -1 and len(kps) == 0
 
 
-def test_extractor_refuses_what_the_header_says_it_refuses():
+def test_extractor_refuses_what_the_header_says_it_refuses(small_scene):
     with pytest.raises(capi.OrbGpuError):                   # include/orbgpu.h: n_features 1 .. 3500
         api.ORBextractor(5000, 1.2, 8, 20, 7, 320, 240)
     with pytest.raises(capi.OrbGpuError):
@@ -157,7 +157,14 @@ def test_extractor_refuses_what_the_header_says_it_refuses():
     ex = api.ORBextractor(100, 1.2, 8, 20, 7, 320, 240)
     with pytest.raises(capi.OrbGpuError):                   # the top level of a 64 x 64 image is 18 pixels: inside the border
         ex(np.zeros((64, 64), np.uint8), (0, 0))
-    assert len(ex(np.zeros((240, 320), np.uint8), (0, 0))[1]) == 0      # ... and the handle is still usable
+    assert len(ex(np.zeros((240, 320), np.uint8), (0, 0))[1]) == 0      # ... and the handle is still usable:
+    L = small_scene.stereo_pair(1)[0]                                   # the refused size left nothing of its geometry behind
+    nm, kps, desc = ex(L, (0, 0))
+    oe = ob.Extractor(n_features=100)
+    rc, okps, odesc, onm = oe.extract(L)
+    _assert_extract_equal((kps, desc), (okps, odesc), "after a refused image size")
+    for l in range(8):
+        assert np.array_equal(ex.level(0, l), oe.level(l)), "pyramid level %d after a refused image size" % l
 
 
 def test_extractor_stereo_batched_and_size_change(scene, small_scene):
@@ -1351,3 +1358,34 @@ def test_detect_n_best_candidates_edge_databases(case):
             assert len(ol) == 0 and len(om) == 0
         if case == "other_maps_bad":
             assert len(om) == 0
+
+
+def test_library_and_torch_share_one_hip_runtime_whatever_the_import_order():
+    """PyTorch-ROCm maps its own HIP / HSA runtime even when the system's is mapped already; a second runtime in the process
+    finds no GPU.  `_capi.load()` therefore imports torch before it maps liborbgpu.so: a process that uses the library first and
+    torch afterwards (this file does, test by test) must still get the GPU from torch, and only one libamdhip64 may be mapped."""
+    code = ("from multi_orbslam3_amd import api\n"
+            "opt = api.Optimizer()\n"
+            "import torch\n"
+            "a = torch.ones(8, device='cuda')\n"
+            "assert float(a.sum().item()) == 8.0\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+            "assert len(libs) == 1, libs\n"
+            "print('one runtime:', libs[0])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "one runtime:" in r.stdout
+
+
+def test_one_stream_per_handle_is_still_a_working_configuration():
+    """ORBG_STREAM_POOL=0: every handle creates a stream of its own (the layout before the library pooled its streams into three
+    hardware-queue-sized ones, csrc/common.hpp).  The frame constructor, the matchers and the local BA agree with the oracle
+    there as well."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORBG_STREAM_POOL="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "test_fused_stereo_frame_constructor or test_search_by_projection or test_lba_parity or test_lba_async or test_pose_optimization_parity"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
