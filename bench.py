@@ -635,7 +635,10 @@ def main():
         collect_async(reg)
         base = first_index + n_warm
         # (the last timed step does not hand a further frame over: the region holds exactly n_steps constructors)
+        cs0 = ctxt_switches()
         elapsed = grp.timed(lambda i: step(base + i, reg, True, pose_opt, host_images, pipelined, slot=i, last=(i == n_steps - 1)), n_steps, sync)
+        cs1 = ctxt_switches()
+        reg.stats["nonvoluntary_ctxt_switches"] = None if cs0 is None or cs1 is None else cs1 - cs0
         return reg, elapsed
 
     # internal pre-warm, independent of --warmup: at least --prewarm-steps steps AND at least 50 ms of the main configuration

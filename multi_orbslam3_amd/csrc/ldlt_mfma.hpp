@@ -1462,6 +1462,7 @@ __device__ __forceinline__ void ldlt_cols_body(int n, const double* __restrict__
       y0 = lane < n_pad ? a0[0] : 0.0; y1 = 64 + lane < n_pad ? a1[0] : 0.0;
     }
     const int np = n_pad >> 1;
+    LDLTM_T(5);
     if (np == 60) backsub_pairs_unrolled<60>(W2, y0, y1, lane);          // 20 free poses
     else if (np == 58) backsub_pairs_unrolled<58>(W2, y0, y1, lane);     // 19
     else if (np == 54) backsub_pairs_unrolled<54>(W2, y0, y1, lane);     // 18
@@ -1515,6 +1516,7 @@ __device__ __forceinline__ void ldlt_cols_body(int n, const double* __restrict__
       }
     }
     }
+    LDLTM_T(6);
     if constexpr (AGENT_X) {
       if (lane < n) __hip_atomic_store(&x[lane], y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (64 + lane < n) __hip_atomic_store(&x[64 + lane], y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

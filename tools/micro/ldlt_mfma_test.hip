@@ -120,7 +120,9 @@ int main(int argc, char** argv) {
     if (n == 120 || n == 300) {
       long long pr[512];
       CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltm::g_prof), sizeof(pr)));
-      printf("  prof n=%d (cycles from kernel start): loaded %lld  factor_done %lld  sync %lld  end %lld\n", n, pr[1] - pr[0], pr[2] - pr[0], pr[3] - pr[0], pr[4] - pr[0]);
+      printf("  prof n=%d (cycles from kernel start): loaded %lld  factor_done %lld  sync %lld  end %lld", n, pr[1] - pr[0], pr[2] - pr[0], pr[3] - pr[0], pr[4] - pr[0]);
+      if (n == 120) printf("  (back-substitution: first column loaded %lld, pairs %lld, store %lld)", pr[5] - pr[3], pr[6] - pr[5], pr[4] - pr[6]);
+      printf("\n");
       for (int k = 0; k < g.Tp; k++) {
         const long long* e = pr + 8 + 8 * k;
         printf("   row %2d: factor start %7lld  pivots %6lld (first 8: %5lld) publish %5lld | panel(k,k+1) start %7lld dur %5lld | upd(k+1,k+1) done %7lld\n", k, e[0] - pr[0], e[1] - e[0], e[6] - e[0], e[2] - e[1], e[3] - pr[0], e[4] - e[3], e[5] - pr[0]);
