@@ -32,6 +32,11 @@
 namespace ldltm {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+// explicit LDS pointers for volatile reads (a volatile generic pointer becomes flat_load); volatile because hipcc
+// otherwise sinks a look-ahead read into the place that uses it and waits for it there
+typedef __attribute__((address_space(3))) const volatile d2* lds_vd2p;
+typedef __attribute__((address_space(3))) const volatile double* lds_vdp;
 
 constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;
@@ -697,25 +702,38 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     tile_mfma8_jt<V>(sl >> 1, a0, w0, a1, w1);
   };
   // two 16-byte loads per lane and tile from the tile image (column-major tile order there)
-  auto tile_addr = [&](int sl) -> const d4* {
+  auto tile_ij = [&](int sl, int& i, int& j) {       // the tile in slot sl of this wavefront
     const int t = min(sl * kBigWaves + wv, G.ntiles - 1);
     const float bq = (float)(2 * T + 1);
-    int i = (int)((bq - sqrtf(bq * bq - 8.0f * (float)t)) * 0.5f);
+    i = (int)((bq - sqrtf(bq * bq - 8.0f * (float)t)) * 0.5f);
     i = max(0, min(T - 1, i));
     if (i + 1 < T && rowstart(i + 1) <= t) i++;
     if (rowstart(i) > t) i--;
-    const int j = i + t - rowstart(i);
-    return reinterpret_cast<const d4*>(St + (size_t)tile_index(i, j) * 256 + 4 * lane);
+    j = i + t - rowstart(i);
   };
-  // rounds of LC tiles; round r+1 is requested before round r is moved into the tile store
-  constexpr int LC = V ? 4 : 8, NR = (NS + LC - 1) / LC;
+  // lane s holds the coordinates of slot s (i | j << 8): the bulk loop gets a tile's operand addresses with one v_readlane
+  // instead of stepping (i, j) through the triangle -- between two groups of matrix instructions every scalar instruction counts,
+  // the wavefront issues them while the matrix pipe is idle -- and the loads below get their addresses without 75 instructions
+  // of index arithmetic per tile (48 tiles: 18 k of the 21 k cycles the loading took)
+  int vtab;
+  { int ti, tj; tile_ij(lane, ti, tj); vtab = ti | (tj << 8); }
+  auto tile_addr = [&](int sl) -> const d4* {
+    const int ij = __builtin_amdgcn_readlane(vtab, sl);
+    return reinterpret_cast<const d4*>(St + (size_t)tile_index(ij & 255, ij >> 8) * 256 + 4 * lane);
+  };
+  // rounds of LC tiles; rounds r+1 .. r+LD-1 are requested before round r is moved into the tile store (a round is one memory
+  // round trip of ~1800 cycles: with one round ahead the 48-tile kernel spent 21 k cycles = 9 us loading)
+  constexpr int LC = V ? 4 : 8, LD = V ? 3 : 2, NR = (NS + LC - 1) / LC;
   {
-    d4 buf[2][LC];
-    static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (u < NS) buf[0][u] = *tile_addr(u); });
+    d4 buf[LD][LC];
+    static_for<0, LD - 1>([&](auto dd) {
+      constexpr int d = decltype(dd)::value;
+      static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (d * LC + u < NS) buf[d][u] = *tile_addr(d * LC + u); });
+    });
     static_for<0, NR>([&](auto rr) {
-      constexpr int r = decltype(rr)::value, c0 = LC * r, pb = r & 1;
-      if constexpr (r + 1 < NR)
-        static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (c0 + LC + u < NS) buf[pb ^ 1][u] = *tile_addr(c0 + LC + u); });
+      constexpr int r = decltype(rr)::value, c0 = LC * r, pb = r % LD, nb = (r + LD - 1) % LD, n0 = c0 + (LD - 1) * LC;
+      if constexpr (r + LD - 1 < NR)
+        static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (n0 + u < NS) buf[nb][u] = *tile_addr(n0 + u); });
       static_for<0, LC>([&](auto uu) { constexpr int u = decltype(uu)::value; if constexpr (c0 + u < NS) tile_put_r<c0 + u, V>(buf[pb][u]); });
     });
   }
@@ -817,15 +835,18 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     R0 = mfma_v<V, false>(Gf[1], X[1], R0);
     R1 = mfma_v<V, false>(Gf[3], X[3], R1);
     mfma_wait<V>(R0, R1);
-    double* const pb = Pan + ((par * T + j) * 2) * 256 + lane;
-    double w4[4];
+    // operand images in LDS: a lane's four values as two 16-byte halves, [half][lane][2] -- two 128-bit accesses per operand
+    // with a 16-byte lane stride (no bank conflicts) instead of four 64-bit ones
+    d2* const pb = reinterpret_cast<d2*>(Pan + ((par * T + j) * 2) * 256) + lane;
+    double w4[4], nr[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const double rr = R0[g] + R1[g];
       w4[g] = rr * dv4[g];
-      pb[g * 64] = -rr;
-      pb[256 + g * 64] = w4[g];
+      nr[g] = -rr;
     }
+    pb[0] = d2{nr[0], nr[1]}; pb[64] = d2{nr[2], nr[3]};
+    pb[128] = d2{w4[0], w4[1]}; pb[192] = d2{w4[2], w4[3]};
     post(&s_panel[j], k + 1);
     post_add(&s_pcount[k]);
     if (j == k + 1) LDLTM_T(8 + 8 * k + 4);
@@ -838,11 +859,11 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
   // ---- U_ij -= R_ki^T W_kj (4 instructions, operands straight from LDS)
   auto update1 = [&](d4 c, int i, int j, int k, bool two_chains) -> d4 {
     const int par = k & 1;
-    const double* const pa = Pan + ((par * T + i) * 2) * 256 + lane;
-    const double* const pw = Pan + ((par * T + j) * 2 + 1) * 256 + lane;
+    const d2* const pa = reinterpret_cast<const d2*>(Pan + ((par * T + i) * 2) * 256) + lane;
+    const d2* const pw = reinterpret_cast<const d2*>(Pan + ((par * T + j) * 2 + 1) * 256) + lane;
     double a[4], w[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) { a[q] = pa[q * 64]; w[q] = pw[q * 64]; }
+    { const d2 a01 = pa[0], a23 = pa[64], w01 = pw[0], w23 = pw[64];
+      a[0] = a01[0]; a[1] = a01[1]; a[2] = a23[0]; a[3] = a23[1]; w[0] = w01[0]; w[1] = w01[1]; w[2] = w23[0]; w[3] = w23[1]; }
     d4 t2 = {0.0, 0.0, 0.0, 0.0};
     if (two_chains) {                        // two chains of two: this tile is on the critical path
       c = mfma_v<V, false>(a[0], w[0], c);
@@ -858,26 +879,26 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     }
     return c;
   };
-  // next tile of this wavefront in row-major order
-  auto advance = [&](int& i, int& j) {
-    j += kBigWaves;
-    while (j >= T && i + 1 < T) { i++; j = j - T + i; }
-  };
-
   auto ld_ops = [&](int k, int i, int j, double (&av)[4], double (&wv4)[4]) {
     const int par = k & 1;
-    const double* const pa = Pan + ((par * T + i) * 2) * 256 + lane;
-    const double* const pw = Pan + ((par * T + j) * 2 + 1) * 256 + lane;
-    av[0] = pa[0]; av[1] = pa[64]; av[2] = pa[128]; av[3] = pa[192];
-    wv4[0] = pw[0]; wv4[1] = pw[64]; wv4[2] = pw[128]; wv4[3] = pw[192];
+    // volatile LDS reads: they stay where they are written (the look-ahead of the bulk loop below)
+    const lds_vd2p pa = (lds_vd2p)(Pan + ((par * T + i) * 2) * 256) + lane;
+    const lds_vd2p pw = (lds_vd2p)(Pan + ((par * T + j) * 2 + 1) * 256) + lane;
+    const d2 a01 = pa[0], a23 = pa[64], w01 = pw[0], w23 = pw[64];
+    av[0] = a01[0]; av[1] = a01[1]; av[2] = a23[0]; av[3] = a23[1];
+    wv4[0] = w01[0]; wv4[1] = w01[1]; wv4[2] = w23[0]; wv4[3] = w23[1];
+  };
+  auto ld_ops_slot = [&](int k, int slot, double (&av)[4], double (&wv4)[4]) {
+    const int ij = __builtin_amdgcn_readlane(vtab, slot);
+    ld_ops(k, ij & 255, ij >> 8, av, wv4);
   };
   // four consecutive slots (sl a multiple of 4): every operand read is in flight before the first instruction
-  auto quad_update = [&](int sl, int k, int& bi, int& bj) {
+  auto quad_update = [&](int sl, int k) {
     double a0[4], w0[4], a1[4], w1[4], a2[4], w2[4], a3[4], w3[4];
-    ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
-    ld_ops(k, bi, bj, a1, w1); advance(bi, bj);
-    ld_ops(k, bi, bj, a2, w2); advance(bi, bj);
-    ld_ops(k, bi, bj, a3, w3); advance(bi, bj);
+    ld_ops_slot(k, sl, a0, w0);
+    ld_ops_slot(k, sl + 1, a1, w1);
+    ld_ops_slot(k, sl + 2, a2, w2);
+    ld_ops_slot(k, sl + 3, a3, w3);
     tile_mfma8_jt<V>(sl >> 1, a0, w0, a1, w1);
     tile_mfma8_jt<V>((sl >> 1) + 1, a2, w2, a3, w3);
   };
@@ -903,7 +924,7 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
       }
     }
     LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 1);
-    int sl = 0, se = 0, bi = 0, bj = 0;
+    int sl = 0, se = 0;
     if (k >= 0) {
       int s1 = first_slot_from_row(k + 1);
       const int s2 = min(first_slot_from_row(k + 2), my_count);
@@ -934,8 +955,6 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
       LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 2);
       wait_gt(&s_pcount[k], T - 2 - k);            // every panel tile of row k is published: no flag checks in the bulk
       sl = s2; se = my_count;
-      bi = k + 2; bj = k + 2 + (sl * kBigWaves + wv - rowstart(k + 2));
-      while (bj >= T && bi + 1 < T) { bi++; bj = bj - T + bi; }
     }
     LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 3);
     const int seA = se;
@@ -968,32 +987,50 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
       if (sl < seA) {
         if (V && pdone && (sl & 1) == 0) {
           // nothing left to look out for in this row: the remaining pairs in a loop of their own (one branch per pair)
-          for (; sl + 2 <= seA; sl += 2) {
-            double a0[4], w0[4], a1[4], w1[4];
-            ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
-            ld_ops(k, bi, bj, a1, w1); advance(bi, bj);
-            pair_update(sl, a0, w0, a1, w1);
+          // two operand sets take turns: the reads of the pair after this one are in flight while this pair's eight
+          // instructions run (before: 16 LDS reads, a round trip, THEN the instructions -- 580 cycles per tile for 264 of them)
+          if (sl + 2 <= seA) {
+            // (the look-ahead reads are unconditional -- past the last pair they fetch the last slots again -- and nothing but the
+            // loop's own back edge lies between them and the instructions: a branch in between makes hipcc wait for all of them)
+            double a0[4], w0[4], a1[4], w1[4], b0[4], x0[4], b1[4], x1[4];
+            const int last = seA - 1;
+            ld_ops_slot(k, sl, a0, w0);
+            ld_ops_slot(k, sl + 1, a1, w1);
+            for (;;) {
+              ld_ops_slot(k, min(sl + 2, last), b0, x0);
+              ld_ops_slot(k, min(sl + 3, last), b1, x1);
+              __builtin_amdgcn_sched_barrier(0);
+              pair_update(sl, a0, w0, a1, w1);
+              sl += 2;
+              if (sl + 2 > seA) break;
+              ld_ops_slot(k, min(sl + 2, last), a0, w0);
+              ld_ops_slot(k, min(sl + 3, last), a1, w1);
+              __builtin_amdgcn_sched_barrier(0);
+              pair_update(sl, b0, x0, b1, x1);
+              sl += 2;
+              if (sl + 2 > seA) break;
+            }
           }
           if (sl < seA) {
             double a0[4], w0[4];
-            ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
+            ld_ops_slot(k, sl, a0, w0);
             tile_update(sl, a0, w0);
             sl++;
           }
         }
         else if (!V && pdone && (sl & 3) == 0 && sl + 4 <= seA) {
-          for (; sl + 4 <= seA; sl += 4) quad_update(sl, k, bi, bj);
+          for (; sl + 4 <= seA; sl += 4) quad_update(sl, k);
         }
-        else if (!V && (sl & 3) == 0 && sl + 4 <= seA) { quad_update(sl, k, bi, bj); sl += 4; }   // (V: 128 vector registers, no room for 32 operands)
+        else if (!V && (sl & 3) == 0 && sl + 4 <= seA) { quad_update(sl, k); sl += 4; }   // (V: 128 vector registers, no room for 32 operands)
         else if ((sl & 1) == 0 && sl + 2 <= seA) {
           double a0[4], w0[4], a1[4], w1[4];
-          ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
-          ld_ops(k, bi, bj, a1, w1); advance(bi, bj);
+          ld_ops_slot(k, sl, a0, w0);
+          ld_ops_slot(k, sl + 1, a1, w1);
           pair_update(sl, a0, w0, a1, w1);
           sl += 2;
         } else {
           double a0[4], w0[4];
-          ld_ops(k, bi, bj, a0, w0); advance(bi, bj);
+          ld_ops_slot(k, sl, a0, w0);
           tile_update(sl, a0, w0);
           sl++;
         }
@@ -1015,43 +1052,44 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
   // the factor's columns are read four at a time, one group ahead, with unconditional loads (entries on or below the
   // diagonal are masked after the load)
   if (wv == 0 && ok) {
-    auto wm_load = [&](int I, int J) -> double {
-      const double v = __builtin_nontemporal_load(wglob + (J * (J - 1) / 2 + I));
-      return I < J ? v : 0.0;
-    };
+    // (raw loads: only the column's own row group holds entries on or below the diagonal, and they are masked where they are
+    // USED -- masking them where they arrive, and copying the look-ahead registers, made every group wait for its own loads:
+    // a memory round trip per four columns.  Two register sets take turns instead.)
+    auto wm_raw = [&](int I, int J) -> double { return __builtin_nontemporal_load(wglob + (J * (J - 1) / 2 + I)); };
     double y[NY];
 #pragma unroll
-    for (int r = 0; r < NY; r++) { const int I = r * 64 + lane; y[r] = I < n_pad ? wm_load(I, cb) : 0.0; }
-#pragma unroll
-    for (int rg = NY - 1; rg >= 0; rg--) {
+    for (int r = 0; r < NY; r++) { const int I = r * 64 + lane; y[r] = I < n_pad ? wm_raw(I, cb) : 0.0; }
+    static_for<0, NY>([&](auto rr) {
+      constexpr int rg = NY - 1 - decltype(rr)::value;
       const int lo = rg * 64, hi = min(n_pad, lo + 64);
       if (hi > lo) {
-        double cur[4][NY], nxt[4][NY];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-          for (int r2 = 0; r2 < NY; r2++) { cur[c][r2] = r2 <= rg ? wm_load(r2 * 64 + lane, hi - 4 + c) : 0.0; nxt[c][r2] = 0.0; }
-        for (int J0 = hi - 4; J0 >= lo; J0 -= 4) {
-          const int Jn = max(J0 - 4, lo);        // the last group re-reads itself (harmless) instead of branching
+        double A[4][rg + 1], B[4][rg + 1];
+        auto fetch = [&](double (&dst)[4][rg + 1], int J0) {
+          const int Jc = max(J0, lo);            // past the row group's first column: a valid group again, never used
 #pragma unroll
           for (int c = 0; c < 4; c++)
 #pragma unroll
-            for (int r2 = 0; r2 < NY; r2++)
-              if (r2 <= rg) nxt[c][r2] = wm_load(r2 * 64 + lane, Jn + c);
+            for (int r2 = 0; r2 <= rg; r2++) dst[c][r2] = wm_raw(r2 * 64 + lane, Jc + c);
+        };
+        auto apply = [&](const double (&src)[4][rg + 1], int J0) {
 #pragma unroll
           for (int c = 3; c >= 0; c--) {
             const double xJ = rdlane(y[rg], J0 + c - lo);
 #pragma unroll
-            for (int r2 = 0; r2 < NY; r2++)
-              if (r2 <= rg) y[r2] -= cur[c][r2] * xJ;
+            for (int r2 = 0; r2 < rg; r2++) y[r2] -= src[c][r2] * xJ;
+            y[rg] -= (lo + lane < J0 + c ? src[c][rg] : 0.0) * xJ;
           }
-#pragma unroll
-          for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int r2 = 0; r2 < NY; r2++) cur[c][r2] = nxt[c][r2];
+        };
+        fetch(A, hi - 4);
+        for (int J0 = hi - 4; J0 >= lo; J0 -= 8) {
+          fetch(B, J0 - 4);
+          apply(A, J0);
+          if (J0 - 4 < lo) break;
+          fetch(A, J0 - 8);
+          apply(B, J0 - 4);
         }
       }
-    }
+    });
 #pragma unroll
     for (int r = 0; r < NY; r++) { const int I = r * 64 + lane; if (I < n) x[I] = y[r]; }
   }
@@ -1094,11 +1132,6 @@ __host__ __device__ inline size_t lds_doubles_cols(const Geo& g) {
   return (size_t)kPivRing * 16 * 64 + (size_t)kPivRing * 16 + (size_t)kColPanels * 256 + 2 * pairs * (pairs + 1) + 512;
 }
 
-typedef double d2 __attribute__((ext_vector_type(2)));
-// explicit LDS pointers for volatile reads (a volatile generic pointer becomes flat_load); volatile because hipcc
-// otherwise sinks a look-ahead read into the place that uses it and waits for it there
-typedef __attribute__((address_space(3))) const volatile d2* lds_vd2p;
-typedef __attribute__((address_space(3))) const volatile double* lds_vdp;
 
 // Back-substitution of the column kernel with every pair index known at compile time (NP = n_pad / 2 pairs of columns):
 // lane selects of v_readlane, LDS offsets and the bounds of the look-ahead ring become immediates, the address arithmetic and
