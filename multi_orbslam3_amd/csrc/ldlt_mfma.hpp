@@ -608,14 +608,21 @@ __device__ __forceinline__ void mfma_wait(d4& c0, d4& c1) {
 #include "ldlt_jump_tables.inc"
 // run-time slot -> the tile's registers: a computed jump into a table of equally sized cases (tools/gen/gen_ldlt_jump_tables.py);
 // hipcc lowers a switch over the slot to a chain of up to 48 compare-and-branch blocks, 500-900 cycles per dispatch
-template <bool V>
+// (WAIT = false: without the 24 wait states in front -- for a tile whose last matrix instruction is known to be far away)
+template <bool V, bool WAIT = true>
 __device__ __forceinline__ d4 tile_get_jt(int sl) {
   int x0, x1, x2, x3, x4, x5, x6, x7, tmp;
-  if constexpr (V) {
+  if constexpr (V && WAIT) {
     asm volatile(LDLTM_JT_GET_48 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=&s"(tmp) : "s"(sl)
                  : "vcc", "scc", LDLTM_AGPR_LO);
-  } else {
+  } else if constexpr (V) {
+    asm volatile(LDLTM_JT_GETNW_48 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=&s"(tmp) : "s"(sl)
+                 : "vcc", "scc", LDLTM_AGPR_LO);
+  } else if constexpr (WAIT) {
     asm volatile(LDLTM_JT_GET_32 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=&s"(tmp) : "s"(sl)
+                 : "vcc", "scc", LDLTM_AGPR_LO, LDLTM_AGPR_HI);
+  } else {
+    asm volatile(LDLTM_JT_GETNW_32 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7), "=&s"(tmp) : "s"(sl)
                  : "vcc", "scc", LDLTM_AGPR_LO, LDLTM_AGPR_HI);
   }
   const i8v v = {x0, x1, x2, x3, x4, x5, x6, x7};
@@ -645,6 +652,27 @@ __device__ __forceinline__ void tile_mfma8_jt(int pair, const double (&a0)[4], c
                  : "v"(a0[0]), "v"(w0[0]), "v"(a0[1]), "v"(w0[1]), "v"(a0[2]), "v"(w0[2]), "v"(a0[3]), "v"(w0[3]),
                    "v"(a1[0]), "v"(w1[0]), "v"(a1[1]), "v"(w1[1]), "v"(a1[2]), "v"(w1[2]), "v"(a1[3]), "v"(w1[3]), "s"(pair)
                  : "vcc", "scc", LDLTM_AGPR_LO, LDLTM_AGPR_HI);
+  }
+}
+
+// The trailing update's steady state (ldlt_jump_tables.inc, BULK): `pairs` consecutive pairs of tiles starting at the EVEN pair
+// `first`, everything else between the matrix instructions.  vtab: slot -> tile coordinates (one lane per slot); addr_r / addr_w:
+// this lane's LDS byte addresses inside the -R / W operand images of column 0 of the row's parity.  The operand sets and the
+// address registers are v60..v127 (named as clobbered: hipcc keeps its own values below).
+#define LDLTM_VGPR_60_127 \
+  "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", \
+  "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", \
+  "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", \
+  "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+template <bool V>
+__device__ __forceinline__ void tile_bulk_pairs(int first, int pairs, int vtab, unsigned addr_r, unsigned addr_w) {
+  int t0, t1, t2, t3;
+  if constexpr (V) {
+    asm volatile(LDLTM_JT_BULK_48 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "v"(vtab), "v"(addr_r), "v"(addr_w), "s"(first), "s"(pairs)
+                 : "vcc", "scc", "memory", LDLTM_VGPR_60_127, LDLTM_AGPR_LO);
+  } else {
+    asm volatile(LDLTM_JT_BULK_32 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "v"(vtab), "v"(addr_r), "v"(addr_w), "s"(first), "s"(pairs)
+                 : "vcc", "scc", "memory", LDLTM_VGPR_60_127, LDLTM_AGPR_LO, LDLTM_AGPR_HI);
   }
 }
 
@@ -768,6 +796,12 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     LDLTM_T(8 + 8 * k + 0);
     wait_free(k);
     const int par = k & 1;
+    // (the lane-derived values of this function are recomputed from an opaque copy of the lane number: hoisted out of the row loop
+    // they are live across the bulk update's assembly block, which leaves hipcc 60 vector registers, and were spilled to scratch
+    // memory -- reloaded here, on the critical chain)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int lr = lane_o >> 4, lc = lane_o & 15;
     d4 E, Wc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int g = 0; g < 4; g++) E[g] = (lr + 4 * g == lc) ? 1.0 : 0.0;
@@ -847,8 +881,7 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     }
     pb[0] = d2{nr[0], nr[1]}; pb[64] = d2{nr[2], nr[3]};
     pb[128] = d2{w4[0], w4[1]}; pb[192] = d2{w4[2], w4[3]};
-    post(&s_panel[j], k + 1);
-    post_add(&s_pcount[k]);
+    if (j == k + 1) post(&s_panel[j], k + 1);    // the one tile somebody waits for by itself (the next diagonal tile's update)
     if (j == k + 1) LDLTM_T(8 + 8 * k + 4);
     const int J = 16 * j + lc;
     if (J <= cb) {
@@ -892,17 +925,6 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
     const int ij = __builtin_amdgcn_readlane(vtab, slot);
     ld_ops(k, ij & 255, ij >> 8, av, wv4);
   };
-  // four consecutive slots (sl a multiple of 4): every operand read is in flight before the first instruction
-  auto quad_update = [&](int sl, int k) {
-    double a0[4], w0[4], a1[4], w1[4], a2[4], w2[4], a3[4], w3[4];
-    ld_ops_slot(k, sl, a0, w0);
-    ld_ops_slot(k, sl + 1, a1, w1);
-    ld_ops_slot(k, sl + 2, a2, w2);
-    ld_ops_slot(k, sl + 3, a3, w3);
-    tile_mfma8_jt<V>(sl >> 1, a0, w0, a1, w1);
-    tile_mfma8_jt<V>((sl >> 1) + 1, a2, w2, a3, w3);
-  };
-
   // Row program.  For tile row k (k = -1: nothing to update yet):
   //   stage 0  the tile (k+1,k+1), if it is mine, gets row k's update and is eliminated at once;
   //   stage 1  my other tiles of row k+1 (the next panel) get row k's update;
@@ -924,43 +946,20 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
       }
     }
     LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 1);
-    int sl = 0, se = 0;
+    // my live tiles from row k+1 on (consecutive slots; the eliminated diagonal tile's slot, if it is mine, is swept along: it is
+    // dead).  The tiles of row k+1 -- the next panel -- come first in slot order and must have row k's update before this
+    // wavefront computes its panel tiles of row k+1 (sl >= s2 below).
+    int sl = 0, se = 0, s2 = 0;
     if (k >= 0) {
-      int s1 = first_slot_from_row(k + 1);
-      const int s2 = min(first_slot_from_row(k + 2), my_count);
-      int j = k + 1 + (s1 * kBigWaves + wv - rowstart(k + 1));
-      if (s1 < s2 && j == k + 1) { s1++; j += kBigWaves; }
-      if (s1 < s2) wait_gt(&s_panel[k + 1], k);
-      if (s1 < s2 && (s1 & 1)) {
-        wait_gt(&s_panel[j], k);
-        double a0[4], w0[4];
-        ld_ops(k, k + 1, j, a0, w0);
-        tile_update(s1, a0, w0);
-        s1++; j += kBigWaves;
-      }
-      for (; s1 + 2 <= s2; s1 += 2, j += 2 * kBigWaves) {
-        wait_gt(&s_panel[j], k);
-        wait_gt(&s_panel[j + kBigWaves], k);
-        double a0[4], w0[4], a1[4], w1[4];
-        ld_ops(k, k + 1, j, a0, w0);
-        ld_ops(k, k + 1, j + kBigWaves, a1, w1);
-        pair_update(s1, a0, w0, a1, w1);
-      }
-      if (s1 < s2) {
-        wait_gt(&s_panel[j], k);
-        double a0[4], w0[4];
-        ld_ops(k, k + 1, j, a0, w0);
-        tile_update(s1, a0, w0);
-      }
-      LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 2);
-      wait_gt(&s_pcount[k], T - 2 - k);            // every panel tile of row k is published: no flag checks in the bulk
-      sl = s2; se = my_count;
+      wait_gt(&s_pcount[k], T - 2 - k);            // every panel tile of row k is published: no flag checks in the update
+      sl = first_slot_from_row(k + 1); s2 = min(first_slot_from_row(k + 2), my_count); se = my_count;
     }
     LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 3);
     const int seA = se;
+    const unsigned lbase = (unsigned)(unsigned long)(lds_vdp)Pan + (((unsigned)(k & 1) * (unsigned)T) << 12) + 16u * (unsigned)lane;
     bool pdone = !(k + 1 < G.Tp);
     for (;;) {
-      if (!pdone) {
+      if (!pdone && sl >= s2) {
         const int kk = k + 1;
         if (ld_flag(&s_diag) > kk && (kk < 2 || ld_flag(&s_rowdone[kk - 2]) >= kBigWaves)) {
           asm volatile("" ::: "memory");
@@ -978,51 +977,27 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
               Gf[q] = Gb[par * 16 * kGld + (4 * q + lr) * kGld + lc];
               dv4[q] = Dv[par * 16 + lr + 4 * q];
             }
-            for (; ps < pe; ps++, pj += kBigWaves) panel_tile(tile_get(ps), kk, pj, Gf, dv4);
+            // (the first read of a tile waits out a matrix instruction that may just have written it; while that tile is worked
+            // on the bulk update's last instructions drain, the later tiles are read without the wait states)
+            const int np_mine = pe - ps;
+            panel_tile(tile_get(ps), kk, pj, Gf, dv4);
+            for (ps++, pj += kBigWaves; ps < pe; ps++, pj += kBigWaves) panel_tile(tile_get_jt<V, false>(ps), kk, pj, Gf, dv4);
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&s_pcount[kk], np_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           pdone = true;
           LDLTM_T(512 + ((k + 1) * 4 + wv) * 8 + 6);
         }
       }
       if (sl < seA) {
-        if (V && pdone && (sl & 1) == 0) {
-          // nothing left to look out for in this row: the remaining pairs in a loop of their own (one branch per pair)
-          // two operand sets take turns: the reads of the pair after this one are in flight while this pair's eight
-          // instructions run (before: 16 LDS reads, a round trip, THEN the instructions -- 580 cycles per tile for 264 of them)
-          if (sl + 2 <= seA) {
-            // (the look-ahead reads are unconditional -- past the last pair they fetch the last slots again -- and nothing but the
-            // loop's own back edge lies between them and the instructions: a branch in between makes hipcc wait for all of them)
-            double a0[4], w0[4], a1[4], w1[4], b0[4], x0[4], b1[4], x1[4];
-            const int last = seA - 1;
-            ld_ops_slot(k, sl, a0, w0);
-            ld_ops_slot(k, sl + 1, a1, w1);
-            for (;;) {
-              ld_ops_slot(k, min(sl + 2, last), b0, x0);
-              ld_ops_slot(k, min(sl + 3, last), b1, x1);
-              __builtin_amdgcn_sched_barrier(0);
-              pair_update(sl, a0, w0, a1, w1);
-              sl += 2;
-              if (sl + 2 > seA) break;
-              ld_ops_slot(k, min(sl + 2, last), a0, w0);
-              ld_ops_slot(k, min(sl + 3, last), a1, w1);
-              __builtin_amdgcn_sched_barrier(0);
-              pair_update(sl, b0, x0, b1, x1);
-              sl += 2;
-              if (sl + 2 > seA) break;
-            }
-          }
-          if (sl < seA) {
-            double a0[4], w0[4];
-            ld_ops_slot(k, sl, a0, w0);
-            tile_update(sl, a0, w0);
-            sl++;
-          }
-        }
-        else if (!V && pdone && (sl & 3) == 0 && sl + 4 <= seA) {
-          for (; sl + 4 <= seA; sl += 4) quad_update(sl, k);
-        }
-        else if (!V && (sl & 3) == 0 && sl + 4 <= seA) { quad_update(sl, k); sl += 4; }   // (V: 128 vector registers, no room for 32 operands)
-        else if ((sl & 1) == 0 && sl + 2 <= seA) {
+        if ((sl & 3) == 0 && sl + 2 <= seA) {
+          // consecutive pairs as one block of straight-line code (tile_bulk_pairs, entered at an even pair); while the next
+          // diagonal tile is still being eliminated the block is left every four pairs (~2000 cycles) to look for it
+          int np = (seA - sl) >> 1;
+          if (!pdone) np = min(np, 4);
+          tile_bulk_pairs<V>(sl >> 1, np, vtab, lbase, lbase + 2048u);
+          sl += 2 * np;
+        } else if ((sl & 1) == 0 && sl + 2 <= seA) {
           double a0[4], w0[4], a1[4], w1[4];
           ld_ops_slot(k, sl, a0, w0);
           ld_ops_slot(k, sl + 1, a1, w1);
