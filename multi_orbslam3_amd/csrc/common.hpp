@@ -95,7 +95,8 @@ struct StreamSignal {
 // together by the first handle so that each gets a hardware queue of its own next to the null stream's:
 //   "lba"                      -> L        (local BA handles; nothing else ever)
 //   "ex"                       -> E0 / E1  (extractor handles, alternating: Frame(t+1) is built next to the searches on frame t)
-//   "fr"                       -> M, E0, E1 in turn (a frame built by the constructor adopts its extractor's stream anyway)
+//   "fr"                       -> M in a process that has extractors (a frame built by the constructor adopts its extractor's
+//                                 stream anyway); M, E0, E1 in turn in a process without (the server's KeyFrame matchers)
 //   "map", "po", "bow", "db"   -> M = the null stream (uploads, PoseOptimization, vocabulary / database work)
 // Handles that share a stream stay correct -- every completion signal is enqueued behind the handle's own work on an in-order
 // stream -- they merely do not overlap.  ORBG_STREAM_POOL=0 gives every handle a stream of its own again (ORBG_PRIO_<ROLE> =

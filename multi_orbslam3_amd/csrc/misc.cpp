@@ -70,7 +70,13 @@ hipError_t create_stream(hipStream_t* st, const char* role) {
   }
   if (!strcmp(role, "lba")) *st = P.L;
   else if (!strcmp(role, "ex")) *st = P.E[P.n_ex++ & 1];
-  else if (!strcmp(role, "fr")) { const unsigned k = P.n_fr++ % 3; *st = k == 0 ? (hipStream_t) nullptr : P.E[k - 1]; }
+  else if (!strcmp(role, "fr")) {
+    // a frame's OWN stream (host-built frames: KeyFrames on the server, uploaded frames of the glue).  In a process with
+    // extractors -- an agent -- E0 / E1 belong to the constructor chains and the searches of the tracking thread: other frames
+    // go to the null stream.  A process without extractors (the server's matcher threads) spreads its frames over all three.
+    const unsigned k = P.n_ex ? 0 : P.n_fr++ % 3;
+    *st = k == 0 ? (hipStream_t) nullptr : P.E[k - 1];
+  }
   else *st = nullptr;                                   // the null stream (its explicit handle hipStreamLegacy crashes hipStreamWaitEvent on events recorded on it: ROCm 7.2)
   return hipSuccess;
 }
