@@ -1057,6 +1057,7 @@ __global__ __launch_bounds__(256) void k_build_items(int nP, int nL, const unsig
   build_items_block((int)blockIdx.x, nP, nL, lm_mask, pf_start, pf_edges, pf_col, items, cap, pair_count);
 }
 
+template <int PASSES>      // 1: all 42 values in one transpose (88 KB of LDS: one workgroup per compute unit), 2: two passes of 21 (44 KB: three)
 __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __restrict__ pair_i1, const int* __restrict__ pair_i2,
                                                         const int* __restrict__ pair_start, const PairItem* __restrict__ items,
                                                         const double* __restrict__ EB, const double* __restrict__ Hll,
@@ -1069,8 +1070,12 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
   // ~550 at C2, so 256 threads keep their item loop at 3 rounds); sums in a fixed order: per thread, then 4 x 64, then 4
   // per value one row of 4 segments of 64 + 1 doubles: in the second phase lane (o, q) walks segment q of row o, and without
   // the per-segment pad the four q-lanes of a row hit the same bank on every read (SQ_LDS_BANK_CONFLICT: 371 k cycles)
-  constexpr int kSeg = 65, kRow = 4 * kSeg + 1;
-  __shared__ double red[42 * kRow];
+  // With more pairs than compute units (C4: 50 poses, 1275 pairs) the 42 values go through the transpose in TWO passes of 21:
+  // 44 KB of LDS per workgroup instead of 88 -- three workgroups per compute unit instead of one (the kernel ran five rounds of
+  // one four-wavefront workgroup per compute unit, each the latency of its dependent loads, item -> landmark / edge blocks:
+  // 35 -> 28 us).  The additions and their order are the same in both forms: the same bits.
+  constexpr int kSeg = 65, kRow = 4 * kSeg + 1, kPass = 42 / PASSES;
+  __shared__ double red[kPass * kRow];
   __shared__ double part[42][4];
   // XCD-aware workgroup -> pair map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2;
   // consecutive pairs share a pose and with it that pose's edge blocks, so every XCD takes a contiguous run of the pair list
@@ -1119,17 +1124,23 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
     }
   }
   const int slot = (tid >> 6) * kSeg + (tid & 63);
-#pragma unroll
-  for (int i = 0; i < 36; i++) red[i * kRow + slot] = acc[i];
-#pragma unroll
-  for (int i = 0; i < 6; i++) red[(36 + i) * kRow + slot] = cacc[i];
-  __syncthreads();
   const int nval = diag ? 42 : 36;
-  if (tid < 4 * nval) {
-    const int o = tid >> 2, q = tid & 3;
-    double s = 0;
-    for (int k = 0; k < 64; k++) s += red[o * kRow + q * kSeg + k];
-    part[o][q] = s;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ps++) {
+    if (ps == 1) __syncthreads();                                   // the first pass' sums have been read
+#pragma unroll
+    for (int i = 0; i < kPass; i++) {
+      const int v = ps * kPass + i;                                 // compile-time
+      red[i * kRow + slot] = v < 36 ? acc[v < 36 ? v : 0] : cacc[v >= 36 ? v - 36 : 0];
+    }
+    __syncthreads();
+    if (tid < 4 * kPass && ps * kPass + (tid >> 2) < nval) {
+      const int o = tid >> 2, q = tid & 3;
+      const double* r = red + o * kRow + q * kSeg;
+      double s = 0;
+      for (int k = 0; k < 64; k++) s += r[k];
+      part[ps * kPass + o][q] = s;
+    }
   }
   __syncthreads();
   const int n = 6 * nP;
@@ -2768,7 +2779,9 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // in_buf / out_buf: with the fused launch the trial state posesB[out_buf] = posesB[in_buf] (+) x is written by the same launch
   auto launch_solve = [&](int set_, double lam_, const double* lamp_, int in_buf, int out_buf) -> int {
     if (nP > 0) {
-      hipLaunchKernelGGL(k_schur, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
+      // (more pose pairs than compute units: the two-pass form, three workgroups per compute unit)
+      const auto schur_fn = n_pairs_all > 256 ? k_schur<2> : k_schur<1>;
+      hipLaunchKernelGGL(schur_fn, dim3(n_pairs_all), dim3(kSchurThreads), 0, st, nP, D.pair_i1, D.pair_i2, D.pair_start, D.items,
                          EBs[set_], Hlls[set_], bls[set_], Hpps[set_], bps[set_], lam_, h->d_S.p, h->d_bs.p, lamp_, item_cap,
                          dev_items ? h->d_pair_count.p : (const int*)nullptr, use_mfma ? h->d_St.p : (double*)nullptr);
       // (two event records and an elapsed-time query cost the solve ~8 us: one solve in four is enough for an average)
