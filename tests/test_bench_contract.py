@@ -44,6 +44,8 @@ def test_bench_line_has_the_contract_fields():
     assert d["data"] == "synthetic" and "workload" in cfgd and "model" not in cfgd and cfgd["name"] == "C2"
     assert cfgd["device_copy_GBps_measured"] > 500 and cfgd["host_cpu"]["nproc"] >= 1 and cfgd["host_cpu"]["model"]
     assert cfgd["whole_step_hbm"]["achieved_GBps"] > 0
+    # what the (shared) host did to the region: involuntary context switches of the process's threads, neighbours on the agent's cores
+    assert "nonvoluntary_ctxt_switches_in_region" in cfgd["host_noise"]
     rf = d["roofline"]
     for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "bracketed_launches"):
         assert key in rf, key
