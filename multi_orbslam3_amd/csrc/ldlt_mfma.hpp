@@ -794,7 +794,10 @@ __device__ __forceinline__ void ldlt_big_body(int n, const double* __restrict__ 
   // G = L^-1 that a pair completes go to LDS at once)
   auto factor = [&](d4 C, int k) {
     LDLTM_T(8 + 8 * k + 0);
-    wait_free(k);
+    // (no wait for the buffers of this parity: G and D^-1 of tile row k-2 were read by that row's panel tiles, and this wavefront
+    // itself waited for ALL of them -- s_pcount[k-2] -- before it started row k-2's update, one loop iteration ago.  Waiting for
+    // the row's UPDATE to finish everywhere, as the panel images need, put the slowest wavefront's bulk work of row k-2 on the
+    // diagonal chain: 10-12 k cycles per late tile row instead of ~6.5 k.)
     const int par = k & 1;
     // (the lane-derived values of this function are recomputed from an opaque copy of the lane number: hoisted out of the row loop
     // they are live across the bulk update's assembly block, which leaves hipcc 60 vector registers, and were spilled to scratch
