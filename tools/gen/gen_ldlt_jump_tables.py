@@ -88,7 +88,9 @@ def bulk(n):
         f = fetch(nxt)
         B = [".p2align 8", f".Lblk{p}_%=:", "s_waitcnt lgkmcnt(0)",
              f"v_readlane_b32 %0, %4, {2*p+2}", f"v_readlane_b32 %1, %4, {2*p+3}", m[0]]
-        B += addr_math("%0", 0) + [m[1]] + addr_math("%1", 1) + [m[2]] + f[0:2] + [m[3]] + f[2:4] + [m[4]] + f[4:6] + [m[5]] + f[6:8]
+        # (the reads early in the block: issued behind the fifth matrix instruction the last of them were still in flight when the
+        # next block asked for them -- ~100 cycles per pair with four wavefronts on the LDS)
+        B += addr_math("%0", 0) + addr_math("%1", 1) + [m[1]] + f[0:3] + [m[2]] + f[3:6] + [m[3]] + f[6:8] + [m[4], m[5]]
         B += [m[6], "s_sub_u32 %3, %3, 1", "s_cmp_eq_u32 %3, 0", m[7], "s_cbranch_scc1 .Lend_%="]
         if p + 1 < npairs:
             B.append(f"s_branch .Lblk{p+1}_%=")
