@@ -1389,3 +1389,22 @@ def test_one_stream_per_handle_is_still_a_working_configuration():
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
+
+
+def test_ldlt_kernels_against_a_long_double_host_factorisation():
+    """tools/micro/ldlt_mfma_test: every LDL^T kernel of csrc/ldlt_mfma.hpp (column kernel, 8-wavefront tile kernel, the four forms
+    of the 4-wavefront kernel) on random SPD systems of 6 ... 300 unknowns against a long-double factorisation on the host
+    (|dx| <= 1e-10 max|x|), the operand layout probe of v_mfma_f64_16x16x4_f64 and the zero-pivot flag.  Built without the
+    in-kernel timeline (-DNO_PROFILE: the code the library ships)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tools", "micro", "ldlt_mfma_test.hip")
+    exe = os.path.join(root, "tools", "micro", "ldlt_mfma_test_np")
+    hdr = os.path.join(root, "multi_orbslam3_amd", "csrc", "ldlt_mfma.hpp")
+    inc = os.path.join(root, "multi_orbslam3_amd", "csrc", "ldlt_jump_tables.inc")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in (src, hdr, inc)):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-DNO_PROFILE", "-o", exe, src],
+                              timeout=900)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL OK" in r.stdout and "FAIL" not in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+    sizes = [ln for ln in r.stdout.splitlines() if ln.startswith("n=")]
+    assert len(sizes) == 14, sizes
