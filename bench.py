@@ -362,10 +362,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    # --server-tick on one GPU still goes through RCCL: a single-rank process group, created before any other GPU call
-    grp = harness.AgentGroup("nccl", force_group=args.server_tick)
+    # --server-tick on one GPU still goes through RCCL: a single-rank process group
+    # control plane on gloo, the RCCL group of the server tick is created by its first collective (harness.AgentGroup)
+    grp = harness.AgentGroup("nccl", force_group=args.server_tick, device_index=(
+        int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1) if os.environ.get("ORBG_BENCH_SHARE_GPU") == "1" else None))
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     device = local_rank
+    if os.environ.get("ORBG_BENCH_SHARE_GPU") == "1":
+        # test aid: several ranks on the GPUs that exist (a 2-rank launch on a 1-GPU box exercises the multi-rank code path of this
+        # file -- barriers, MAX over ranks, per-agent statistics; the rate it prints says nothing)
+        device = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
     affinity_at_start = os.sched_getaffinity(0)
     cpu_affinity = None if args.no_numa_pin else harness.pin_to_gpu_numa_node(device)

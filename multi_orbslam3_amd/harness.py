@@ -159,7 +159,7 @@ def core_pair_for_agent(device_index, slot):
 class AgentGroup:
     def __init__(self, backend=None, device_index=None, force_group=False):
         """force_group: create the process group even for a single rank (exercises the RCCL path of
-        all_gather_keyframes on one GPU; must then be constructed before any other GPU call of the process)."""
+        all_gather_keyframes on one GPU)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,11 +173,25 @@ class AgentGroup:
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             self.backend = backend
-            kw = {}
-            if backend == "nccl":
-                kw["device_id"] = torch.device("cuda", self.local_rank if device_index is None else device_index)
-            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            # Control plane (barriers around the timed region, MAX of the elapsed times, per-agent statistics) on gloo, always:
+            # agents have no data-path collective, and an RCCL communicator in the process -- its streams and hardware queues --
+            # costs an agent a third of its frame rate from the first barrier on (8400 -> 5450 frames/s with a 1-rank nccl group
+            # that only ever ran barriers; csrc/common.hpp on hardware queues).  The RCCL group is the DATA plane of the server
+            # tick and is created by its first collective (data_group()).
+            self._device_index = self.local_rank if device_index is None else device_index
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             self.dist = dist
+            self._data_group = None
+
+    def data_group(self):
+        """The group of the data-path exchange (keyframe wire blocks): RCCL over xGMI for GPU tensors, created -- collectively --
+        by the first exchange; the default gloo group when the agents run on CPU tensors (tests)."""
+        if self.dist is None or self.backend != "nccl":
+            return None
+        if self._data_group is None:
+            import torch
+            self._data_group = self.dist.new_group(backend="nccl", device_id=torch.device("cuda", self._device_index))
+        return self._data_group
 
     def agent_seed(self, base):
         """Agents are independent clients: distinct seeds, no shared state."""
@@ -191,8 +205,7 @@ class AgentGroup:
         if self.dist is None:
             return seconds
         import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        t = torch.tensor([seconds], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -201,11 +214,10 @@ class AgentGroup:
         if self.dist is None:
             return [float(value)]
         import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-        out = torch.zeros(self.world, dtype=torch.float64, device=dev)
-        self.dist.all_gather_into_tensor(out, mine)
-        return [float(v) for v in out.cpu()]
+        mine = torch.tensor([float(value)], dtype=torch.float64)
+        out = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [float(v[0]) for v in out]
 
     def timed(self, fn, steps, sync=None):
         """barrier + sync, exactly `steps` calls of fn(i), sync + barrier; returns MAX-over-ranks seconds."""
@@ -235,13 +247,13 @@ class AgentGroup:
             return [(int(n_features), wire[: 47 * int(n_features)])]
         counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
         mine = torch.tensor([int(n_features)], dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(counts, mine)
+        self.dist.all_gather_into_tensor(counts, mine, group=self.data_group() if dev.type == "cuda" else None)
         counts = [int(c) for c in counts.cpu()]
         pad = 47 * max(max(counts), 1)
         send = torch.zeros(pad, dtype=torch.uint8, device=dev)
         send[: 47 * int(n_features)] = wire[: 47 * int(n_features)]
         recv = torch.empty(self.world * pad, dtype=torch.uint8, device=dev)
-        self.dist.all_gather_into_tensor(recv, send)
+        self.dist.all_gather_into_tensor(recv, send, group=self.data_group() if dev.type == "cuda" else None)
         return [(counts[r], recv[r * pad: r * pad + 47 * counts[r]]) for r in range(self.world)]
 
     # ---- server tick: ONE collective per tick, whatever the number of ranks and of new keyframes
@@ -283,7 +295,7 @@ class AgentGroup:
         if self.dist is None:
             recv[:cap] = send
         else:
-            self.dist.all_gather_into_tensor(recv, send)
+            self.dist.all_gather_into_tensor(recv, send, group=self.data_group() if send.device.type == "cuda" else None)
         heads = recv.view(self.world, cap)[:, : self.TICK_HEADER_BYTES].cpu().numpy().view(np.int32)      # the tick's one read-back
         out = []
         for r in range(self.world):

@@ -188,3 +188,23 @@ def test_cxx_tracking_loop_does_the_work_of_the_python_loop():
         assert (st.kp, st.m_frame, st.m_map) == want, (pipelined, host, (st.kp, st.m_frame, st.m_map), want)
         assert st.lba_calls == (n_steps + K - 1) // K and st.lba_iters == st.lba_calls * sum(lba_out.iters)
         assert st.m_frame > 100 * n_steps // 2 and st.kp > 1500 * n_steps
+
+
+@pytest.mark.gpu
+def test_two_ranks_produce_one_aggregate_line():
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one process per rank), here with both ranks on
+    the box's one GPU (ORBG_BENCH_SHARE_GPU=1: the rate is meaningless, the code path is the real one): gloo control plane, barrier
+    on both sides of the timed region, MAX over ranks, rank 0 prints ONE line whose value is the aggregate over the agents and
+    which carries every agent's CPU baseline."""
+    port = 29500 + (os.getpid() % 400)
+    env = dict(os.environ, ORBG_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "10",
+                        "--no-secondary", "--no-dropin"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]          # whole-job aggregate = 2 agents x steps / max time
+    assert len(d["cpu_baseline"]["per_agent"]["values"]) == 2
