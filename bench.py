@@ -612,8 +612,9 @@ def main():
         t0 = time.perf_counter()
         loop.run(base, n_steps, last_is_final=True, timed=True, step_s=step_s, stats=st)
         sync()
-        grp.barrier()
-        elapsed = grp.max_over_ranks(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0             # this rank's K steps, everything it launched complete; the job's time is the
+        grp.barrier()                             # MAX over ranks (they started together) -- the barrier's own latency (gloo:
+        elapsed = grp.max_over_ranks(dt)          # TCP, a few hundred microseconds against a 2.7 ms region) is not step time
         cs1 = ctxt_switches()
         reg.stats["nonvoluntary_ctxt_switches"] = None if cs0 is None or cs1 is None else cs1 - cs0
         for key, j in (("extract", 0), ("match_frame", 1), ("match_map", 2), ("pose_opt", 3), ("map_upload", 4), ("lba", 5)):

@@ -229,8 +229,9 @@ class AgentGroup:
             fn(i)
         if sync:
             sync()
+        dt = time.perf_counter() - t0          # (the closing barrier's own latency is not step time: MAX over ranks of the ranks' times)
         self.barrier()
-        return self.max_over_ranks(time.perf_counter() - t0)
+        return self.max_over_ranks(dt)
 
     def aggregate_rate(self, steps, seconds):
         """Whole-job throughput: every rank did `steps` units in the (max) time."""
