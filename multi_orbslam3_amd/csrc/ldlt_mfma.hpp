@@ -1253,7 +1253,7 @@ __device__ __forceinline__ void ldlt_cols_body(int n, const double* __restrict__
         for (int i = 0; i < 8; i++) wav[i] = 0.0;
         double rlast = 1.0;
 #ifndef LDLTM_ALONE
-        wait_free(k);
+        if (k == 0) wait_free(k);       // (later rows: checked while this wavefront replayed row k-1, off the diagonal chain)
 #endif
 #ifdef LDLTM_COLPRIO
         __builtin_amdgcn_s_setprio(3);
@@ -1331,6 +1331,9 @@ __device__ __forceinline__ void ldlt_cols_body(int n, const double* __restrict__
         // published data.  Pairs it does not cover are read again, counter first, one round trip per try.
         d4 X = Rt[0];
         d4 D = Dg;
+        // the pivot ring's slot of the row this wavefront will eliminate next: an LDS round trip that has no business between the
+        // last replayed pair and the first pivot
+        if (wv == k + 1) wait_free(k + 1);
         if (wv == k + 1) LDLTM_T(8 + 8 * k + 3);
         LDLTM_T(80 + wv * 24 + 3 * k);
         d4 Rc = {0.0, 0.0, 0.0, 0.0}, nW = {0.0, 0.0, 0.0, 0.0};
@@ -1396,6 +1399,8 @@ __device__ __forceinline__ void ldlt_cols_body(int n, const double* __restrict__
         if (wv == k + 1) LDLTM_T(8 + 8 * k + 4);
         LDLTM_T(80 + wv * 24 + 3 * k + 1);
         // publish -W for the trailing tiles of the other columns (their B operand is their own unscaled R)
+        // (measured: deferring this behind the first pivot pair for the wavefront that eliminates next -- to get ~150 cycles of
+        // LDS issue off the diagonal chain -- is slower, 19.8 vs 19.2 us: the readers' late start costs more)
         double* const rb = rb_of(k, wv);
 #pragma unroll
         for (int g = 0; g < 4; g++) rb[g * 64] = nW[g];
