@@ -1564,7 +1564,7 @@ __host__ inline Launch pick(int n) {
   }
   L.cols = false;
   L.threads = kThreads;
-  if (g.T <= 9) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
+  if (g.T <= 9 && !getenv("ORBG_LDLT_T9_4W")) {   // (the 4-wavefront kernel is as fast at 9 tile rows: 39.5-42.7 vs 37.0-43.9 us) L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
   else if (getenv("ORBG_LDLT_8W")) {
     if (g.T <= 13) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<12, 4, false>); L.wlds = false; }
     else { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<24, 5, false>); L.wlds = false; }
@@ -1582,13 +1582,16 @@ __host__ inline Launch pick(int n) {
 // St: the bordered matrix as a tile image (see image_put_rhs / k_image_pad), x: solution, wglob: wglob_doubles() of scratch
 __host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st) {
   const Launch L = pick(n);
-  static size_t attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const Geo g = make_geo(n);
-  const int which = L.cols ? 3 : g.T <= 9 ? 0 : (g.T <= 13 ? 1 : 2) + (L.threads == kBigThreads ? (g.T <= 10 ? 5 : 3) : 0);
-  if (L.lds > 64 * 1024 && attr[which] < L.lds) {
-    hipError_t e = hipFuncSetAttribute(L.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
-    if (e != hipSuccess) return e;
-    attr[which] = L.lds;
+  // dynamic LDS beyond 64 KB has to be allowed per kernel, once (and again if a larger system comes along)
+  static struct { const void* fn; size_t lds; } attr[12] = {};
+  if (L.lds > 64 * 1024) {
+    int w = 0;
+    while (w < 11 && attr[w].fn && attr[w].fn != L.fn) w++;
+    if (attr[w].fn != L.fn || attr[w].lds < L.lds) {
+      hipError_t e = hipFuncSetAttribute(L.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
+      if (e != hipSuccess) return e;
+      attr[w].fn = L.fn; attr[w].lds = L.lds;
+    }
   }
   void* args[] = {(void*)&n, (void*)&St, (void*)&x, (void*)&ok, (void*)&wglob};   // the column kernel ignores wglob
   return hipLaunchKernel(L.fn, dim3(1), dim3(L.threads), args, L.lds, st);
