@@ -1564,7 +1564,8 @@ __host__ inline Launch pick(int n) {
   }
   L.cols = false;
   L.threads = kThreads;
-  if (g.T <= 9 && !getenv("ORBG_LDLT_T9_4W")) {   // (the 4-wavefront kernel is as fast at 9 tile rows: 39.5-42.7 vs 37.0-43.9 us) L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
+  // (9 tile rows: the 4-wavefront kernel is as fast as the 8-wavefront one, 39.5-42.7 vs 37.0-43.9 us; ORBG_LDLT_T9_4W=1 selects it)
+  if (g.T <= 9 && !getenv("ORBG_LDLT_T9_4W")) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
   else if (getenv("ORBG_LDLT_8W")) {
     if (g.T <= 13) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<12, 4, false>); L.wlds = false; }
     else { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<24, 5, false>); L.wlds = false; }
