@@ -2685,7 +2685,9 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // do overlap their dependent loads with the LDL^T, but they sit on other XCDs than the LDL^T workgroup: the "x is ready" word and
   // x itself reach them through memory (agent-scope stores / loads, ~2 us each way), which costs what the kernel boundary and
   // k_update's own loads cost.  (A same-XCD placement checked through the XCC_ID register would make the hand-over an L2 round trip.)
-  const bool fuse_upd = use_mfma && ldltm::pick(n).cols && getenv("ORBG_FUSE_UPDATE") && atoi(getenv("ORBG_FUSE_UPDATE")) != 0;
+  // (on by default since the end of round 3: alone on the GPU the fused launch is a wash -- 0.488 vs 0.486 ms per solve -- but next to
+  // the tracking chains every dispatch less counts: 0.586 vs 0.597 ms, 8490 vs 8360 frames/s; ORBG_FUSE_UPDATE=0: two launches)
+  const bool fuse_upd = use_mfma && ldltm::pick(n).cols && !(getenv("ORBG_FUSE_UPDATE") && atoi(getenv("ORBG_FUSE_UPDATE")) == 0);
   const int n_blocks_u = fuse_upd ? (NP + NX + kFusedUpdThreads - 1) / kFusedUpdThreads : (NP + NX + upd_threads - 1) / upd_threads;
   if ((rc = h->d_scale_partial.reserve(std::max(n_blocks_u, 1)))) return rc;
   if (fuse_upd) {

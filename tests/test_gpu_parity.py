@@ -937,11 +937,12 @@ def test_host_image_submit_on_other_image_shapes(W, H, nf):
         assert np.array_equal(gs, os_) and np.array_equal(gi, oi), (W, H, k)
 
 
-def test_lba_with_the_solve_and_the_update_in_one_launch():
-    """ORBG_FUSE_UPDATE=1 (off by default): the LDL^T workgroup and k_update's work as ONE launch -- the update
-    workgroups prefetch, wait for "x is ready" and finish the trial state; with speculative solves the trial after the next one is
-    written into a third state buffer.  Same decisions, trace and results as the oracle, for every window size the column kernel
-    covers, and the rejected-trial paths."""
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_lba_with_the_solve_and_the_update_in_one_launch(fuse):
+    """ORBG_FUSE_UPDATE (on by default since the end of round 3; "0": two launches): the LDL^T workgroup and
+    k_update's work as ONE launch -- the update workgroups prefetch, wait for "x is ready" and finish the trial state; with
+    speculative solves the trial after the next one is written into a third state buffer.  Same decisions, trace and results as
+    the oracle in both forms, for every window size the column kernel covers, and the rejected-trial paths."""
     code = (
         "import numpy as np\n"
         "from multi_orbslam3_amd import api, synth, views\n"
@@ -961,7 +962,7 @@ def test_lba_with_the_solve_and_the_update_in_one_launch():
         "        tg, to = g.trace_rows(), o.trace_rows()\n"
         "        assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]) and np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), nf\n"
         "print('fused ok')\n")
-    env = dict(os.environ, ORBG_FUSE_UPDATE="1")
+    env = dict(os.environ, ORBG_FUSE_UPDATE=fuse)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "fused ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
