@@ -756,6 +756,16 @@ def main():
         # duration from a HIP event pair on the local BA's stream (one bracketed launch per solve) minus the empty-pair cost
         n_unk = solver_unknowns
         ldlt_flops = n_unk ** 3 / 3.0 + 2.0 * n_unk ** 2
+        # windows of <= 20 free poses: the LDL^T workgroup and the state update's workgroups are ONE launch (k_ldlt_cols_update,
+        # the default since the end of round 3; ORBG_FUSE_UPDATE=0: two launches) -- the bracket then times both, and the launch's
+        # algorithmic FLOPs are the solve's plus the update's (per observation of a free pose H_pl^T dx: 72; per landmark a 3 x 3 solve: ~60)
+        fused_update = bool(solver_mfma) and (((((n_unk + 3) & ~3) + 1) + 15) // 16) <= 8 and os.environ.get("ORBG_FUSE_UPDATE", "1") != "0"
+        upd_flops = 0.0
+        if fused_update:
+            free = np.asarray(prob["pose_fixed"]) == 0
+            upd_flops = 72.0 * float(free[np.asarray(prob["edges"]["pose"])].sum()) + 60.0 * len(prob["points"])
+        ldlt_only_flops = ldlt_flops
+        ldlt_flops = ldlt_flops + upd_flops
         ldlt_ms_raw = solver_sum_ms / max(solver_n, 1)
         ldlt_ms = max(ldlt_ms_raw - lba_ev_overhead_ms, 1e-6)
         ldlt_tflops = ldlt_flops / (ldlt_ms * 1e-3) / 1e12 if solver_n else 0.0
@@ -775,7 +785,7 @@ def main():
         lm_per_ba = stats["lba_iters"] / max(stats["lba_calls"], 1)
         # the variant ldltm::pick() chooses for this many unknowns (tile rows T of the bordered matrix)
         ldlt_T = ((((n_unk + 3) & ~3) + 1) + 15) // 16
-        ldlt_name = (("ldltm::k_ldlt_cols" if ldlt_T <= 8 else "ldltm::k_ldlt_mfma" if ldlt_T <= 9 else
+        ldlt_name = (("k_ldlt_cols_update" if fused_update else "ldltm::k_ldlt_cols" if ldlt_T <= 8 else "ldltm::k_ldlt_mfma" if ldlt_T <= 9 else
                       "ldltm::k_ldlt_big" if ldlt_T <= 15 else "ldltm::k_ldlt_big48") if solver_mfma else "k_ldlt_flow / k_ldlt_rows")
         per_step = {ldlt_name: ldlt_ms * lm_per_ba / FRAMES_PER_KF if solver_n else 0.0, "fast_cells_kernel": fast_ms if fast_n else 0.0}
         for kname, (kms, kn) in chain_ms.items():
@@ -841,13 +851,17 @@ def main():
             "roofline": {"kernel": ldlt_name,
                          "bound": "mfma", "achieved": round(ldlt_tflops, 6), "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ldlt_tflops / FP64_MATRIX_PEAK_TFLOPS, 8), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_flops_per_launch": int(ldlt_flops), "unknowns": int(n_unk), "launches_per_local_ba": round(stats["lba_iters"] / max(stats["lba_calls"], 1), 2),
+                         "algorithmic_flops_per_launch": int(ldlt_flops), "ldlt_flops": int(ldlt_only_flops), "state_update_flops": int(upd_flops),
+                         "unknowns": int(n_unk), "launches_per_local_ba": round(stats["lba_iters"] / max(stats["lba_calls"], 1), 2),
                          "avg_launch_ms": round(ldlt_ms, 5), "avg_launch_ms_event_bracket_raw": round(ldlt_ms_raw, 5),
                          "event_pair_overhead_ms": round(lba_ev_overhead_ms, 5), "bracketed_launches": int(solver_n),
                          "peak_source": "AMD MI355X spec sheet, FP64 matrix 78.6 TF (MI355X_MICROARCH.md has no FP64 row); measured issue rate "
                                         "of v_mfma_f64_16x16x4_f64: 1 per 66 cycles per SIMD = 76 TF at 2.4 GHz (tools/micro/mfma_f64_latency.hip)",
                          "note": "a 120 x 120 LDL^T + solve is 0.6 MFLOP on a dependent chain of 120 pivots (one workgroup): "
-                                 "time-to-solution is the figure of merit, the FLOP fraction is reported as the contract asks"},
+                                 "time-to-solution is the figure of merit, the FLOP fraction is reported as the contract asks"
+                                 + ("; the launch is k_ldlt_cols_update: the LDL^T workgroup (19.2 us alone, tools/micro/ldlt_neighbours) plus "
+                                    "the state update's workgroups, which start with it and finish after x is published -- one dispatch "
+                                    "less per LM iteration; ORBG_FUSE_UPDATE=0 gives the two launches of the earlier rounds' lines" if fused_update else "")},
         }
         line["config"]["device_ms_per_step_by_kernel"] = {k2: round(v, 5) for k2, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
         if dominant != ldlt_name:
