@@ -311,6 +311,9 @@ def main():
     ap.add_argument("--ingest", choices=["thread", "inline"], default="thread",
                     help="host images: thread = the library's ingest thread packs the rows into pinned staging and enqueues the "
                          "constructor (orbx_frame_stereo_submit, ORBX_SUBMIT_ASYNC); inline = the tracking thread does")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the main K-step region is run this many times back to back; value = the FIRST one, value_min / _median / _max "
+                         "over all of them are reported next to it (1: no repeats)")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip tests/cpp/dropin_bench (the per-frame path and the local BA timed through the reference-signature glue "
                          "over mock Frame / KeyFrame / MapPoint objects; reported as value_dropin)")
@@ -444,6 +447,7 @@ def main():
             self.step_s = np.zeros(max(n, 1))
             self.async_t0 = None
             self.async_timed = False
+            self.timeline = np.zeros((0, 5), np.float32)     # per constructor: queue / pack / enqueue / wait / latency [us] (orbx_get_ctor_timeline)
 
     def collect_async(reg):
         if reg.async_t0 is None:
@@ -608,6 +612,8 @@ def main():
         base = first_index + n_warm
         step_s = np.zeros(max(n_steps, 1))
         grp.barrier(); torch.cuda.synchronize()
+        for e in exs:
+            e.ctor_timeline(reset=True)
         cs0 = ctxt_switches()
         t0 = time.perf_counter()
         loop.run(base, n_steps, last_is_final=True, timed=True, step_s=step_s, stats=st)
@@ -621,6 +627,7 @@ def main():
             reg.stage[key] = st.stage_s[j]
         reg.stats.update(kp=st.kp, m_frame=st.m_frame, m_map=st.m_map, lba_iters=st.lba_iters, lba_calls=st.lba_calls, lba_s=st.lba_s)
         reg.step_s = step_s
+        reg.timeline = np.concatenate([e.ctor_timeline() for e in exs]) if stereo else np.zeros((0, 5), np.float32)
         return reg, elapsed
 
     def run_region(n_steps, n_warm, pose_opt, host_images, pipelined, first_index):
@@ -642,10 +649,13 @@ def main():
         collect_async(reg)
         base = first_index + n_warm
         # (the last timed step does not hand a further frame over: the region holds exactly n_steps constructors)
+        for e in exs:
+            e.ctor_timeline(reset=True)
         cs0 = ctxt_switches()
         elapsed = grp.timed(lambda i: step(base + i, reg, True, pose_opt, host_images, pipelined, slot=i, last=(i == n_steps - 1)), n_steps, sync)
         cs1 = ctxt_switches()
         reg.stats["nonvoluntary_ctxt_switches"] = None if cs0 is None or cs1 is None else cs1 - cs0
+        reg.timeline = np.concatenate([e.ctor_timeline() for e in exs]) if stereo else np.zeros((0, 5), np.float32)
         return reg, elapsed
 
     # internal pre-warm, independent of --warmup: at least --prewarm-steps steps AND at least 50 ms of the main configuration
@@ -678,6 +688,15 @@ def main():
             host_noise["agent_cores_busy_after_region"] = {str(t): round(busy.get(t, 0.0), 2) for c in core_pair for t in sorted(c)}
         except OSError:
             pass
+    # the same K-step region four more times, back to back (same configuration, same clock brackets): `value` stays the FIRST
+    # region, literally; min / median / max over the five say how much of it is the draw of one 3 ms window on a shared host
+    repeat_values = [world * args.steps / elapsed]
+    if not args.no_secondary and args.repeats > 1:
+        for rep in range(1, args.repeats):
+            first = prewarm_done + rep * (args.steps + args.warmup + FRAMES_PER_KF)
+            first += (-(first + args.warmup)) % FRAMES_PER_KF                # the first timed step is a keyframe step again
+            rr, er = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, first)
+            repeat_values.append(world * args.steps / er)
     solver_sum_ms, solver_n, solver_unknowns, solver_mfma = opt.solver_stats()
     fast_sum, fast_n = 0.0, 0                              # bracket times accumulated inside the library over the timed region
     for e in exs:
@@ -738,7 +757,11 @@ def main():
         server_tick = run_server_tick(grp, api, views, torch, device, frames, kf_chunks, fv, LM, scene)
 
     copy_gbs = copy_bandwidth_gbs(torch, device) if rank == 0 else None
-    dropin = run_dropin_bench() if (rank == 0 and not args.no_dropin and args.config == "C2") else None
+    # The drop-in child is a separate dynamically linked program: under a profiler (its preloaded library has initialised the GPU in
+    # this process, and the child would inherit the preload) that fork + exec is the hop this pool forbids -- never from a profiled run.
+    under_profiler = any(k.startswith(("ROCP", "ROCPROF", "ROCTRACER")) for k in os.environ) or \
+        any(t in os.environ.get("LD_PRELOAD", "") for t in ("rocprof", "roctracer", "rocprofiler"))
+    dropin = run_dropin_bench() if (rank == 0 and not args.no_dropin and not under_profiler and args.config == "C2") else None
 
     if rank == 0:
         K = args.steps
@@ -863,6 +886,21 @@ def main():
                                     "the state update's workgroups, which start with it and finish after x is published -- one dispatch "
                                     "less per LM iteration; ORBG_FUSE_UPDATE=0 gives the two launches of the earlier rounds' lines" if fused_update else "")},
         }
+        # ---- the diagnosis of THIS run as top-level scalars (nested objects do not survive into the driver's record)
+        line["value_min"] = round(min(repeat_values), 3); line["value_median"] = round(float(np.median(repeat_values)), 3)
+        line["value_max"] = round(max(repeat_values), 3); line["value_regions"] = len(repeat_values)
+        line["host_noise_ctxt_switches"] = host_noise.get("nonvoluntary_ctxt_switches_in_region")
+        busy_after = host_noise.get("agent_cores_busy_after_region") or {}
+        line["host_noise_max_core_busy"] = max(busy_after.values()) if busy_after else None
+        tl = reg.timeline
+        if len(tl):
+            for j, nm in enumerate(("ingest_queue_us", "ingest_pack_us", "ctor_enqueue_us", "ctor_wait_us", "ctor_latency_us")):
+                line[nm + "_p50"] = round(float(np.percentile(tl[:, j], 50)), 1)
+                line[nm + "_max"] = round(float(tl[:, j].max()), 1)
+        for k2, v in stage.items():
+            if k2 in ("extract", "match_frame", "match_map", "map_upload", "lba"):
+                line["stage_%s_us" % k2] = round(1e6 * v / K, 1)
+        line["lba_ms_per_call"] = round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3)
         line["config"]["device_ms_per_step_by_kernel"] = {k2: round(v, 5) for k2, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
         if dominant != ldlt_name:
             # a kernel of the constructor chain holds more device time per step than the LDL^T: it is the roofline's subject
@@ -899,7 +937,7 @@ def main():
             line["config"]["server_tick"] = server_tick
     # CPU baseline: every rank (= agent) runs its own sample on its own three physical cores ("for A agents run A
     # independent baseline processes pinned to disjoint cores"); rank 0 reports its sample and min / median over the ranks
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and not under_profiler:      # (the baseline builds the oracle -march=native: g++ children)
         n_base = 300 if args.config != "C4" else 60
         own = None
         if core_pair is not None and world > 1:
@@ -960,6 +998,7 @@ def run_server_tick(grp, api, views, torch, device, frames, kf_chunks, fv, LM, s
     torch.cuda.synchronize()
     m = api.ORBmatcher(0.75, True, device)
     K = api.Frame(8192, device)
+    grp.open_data_plane()                                                  # collective: the RCCL group of the exchange, outside every timed rep
     bufs = grp.tick_buffers(max_features=2048, device="cuda:%d" % device, max_blocks=8)
     out = {}
     for n_blocks in (2, 8):

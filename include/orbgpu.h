@@ -522,6 +522,39 @@ typedef struct pose_opt_result {
  * runs in ONE kernel launch (LM control flow on the device). */
 int pose_optimize(const pose_opt_problem* p, pose_opt_result* r);
 
+/* ---------------------------------------------------------------- streams, hardware queues, host threads
+ * Streams.  Every handle enqueues its work on ONE HIP stream.  By default that stream comes from a per-device pool the library
+ * creates with its first handle: four hipStreamNonBlocking streams -- L (local BA handles), E0 / E1 (extractor handles,
+ * alternating; a frame built by a constructor stays on its extractor's stream), M (map uploads, PoseOptimization, vocabulary and
+ * database handles, host-built frames, the stand-alone utilities).  None of them is the legacy null stream: nothing the library
+ * launches joins, or is joined by, the blocking streams of the application (SURVEY.md 8(b) "no hidden global state": the pool is the
+ * one piece of per-device state the handles share, and it can be replaced).  *_set_stream hands a handle the CALLER's stream instead
+ * (a hipStream_t passed as void*; never the null stream -- NULL means "back to the pool"); the handle must be idle, its old stream
+ * is drained first, and the caller's stream is never destroyed by the library.  ORBG_STREAM_POOL=0 in the environment gives every
+ * handle a private stream.
+ * Hardware queues.  The ROCm runtime multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 by default); the
+ * streams that share a queue are serialised.  The pool's four streams are created together so that they occupy the four default
+ * queues.  An application that keeps further streams of its own busy next to the library should start with GPU_MAX_HW_QUEUES =
+ * 4 + its own busy streams in the environment (it is read when the runtime initialises; measured here: 4, 5 and 6 are equally good
+ * for an agent, 3 costs a third of the frame rate, 8 half of it).
+ * Host threads.  A synchronous call blocks its caller by SPINNING on a completion word in pinned memory for up to a bounded time
+ * (then it falls back to the runtime's blocking wait); the asynchronous forms own one thread each -- lba_solve_async: one worker per
+ * handle, ORBX_SUBMIT_ASYNC: one ingest thread per process -- which spin for a few hundred microseconds between jobs before they
+ * sleep.  An agent that uses all three therefore keeps up to three cores busy (tracking thread, local-BA worker, ingest thread);
+ * ORBG_NO_POLL=1 switches every wait to the runtime's blocking form (6-10 us more latency per wait, no spinning).
+ * Cameras.  The fused Frame constructors (orbx_frame_stereo*) build the grid from the extracted keypoints as they are, i.e. they
+ * implement Frame::UndistortKeyPoints for mDistCoef[0] == 0 (rectified stereo: mvKeysUn = mvKeys, S/Frame.cc:723-727).  The
+ * reference's image bounds are exactly the image rectangle in that case (S/Frame.cc:775-783) and the undistorted corners otherwise
+ * (:753-773): a view whose bounds are not (0, width, 0, height) is refused with ORBG_BAD_ARG.  Distorted cameras (the mono agents
+ * with EuRoC intrinsics) go through orbx_extract + the caller's cv::undistortPoints + orbm_frame_upload. */
+int orbx_set_stream(orbx_handle* h, void* hip_stream);
+int orbm_frame_set_stream(orbm_frame* f, void* hip_stream);
+int orbm_map_set_stream(orbm_map* m, void* hip_stream);
+int lba_set_stream(lba_handle* h, void* hip_stream);
+int orbv_vocab_set_stream(orbv_vocab* v, void* hip_stream);
+int orbd_database_set_stream(orbd_database* d, void* hip_stream);
+int pose_opt_set_stream(int device, void* hip_stream);      /* the calling thread's pose_optimize calls on `device` */
+
 /* ---------------------------------------------------------------- misc */
 const char* orbg_version(void);
 const char* orbg_strerror(int code);
@@ -546,6 +579,12 @@ int orbx_set_profile_interval(orbx_handle* h, int interval, int reset);
 #define ORBX_PROF_ORIENT_DESC 2
 #define ORBX_PROF_PYRAMID 3
 int orbx_set_profile_kernel(orbx_handle* h, int which);
+/* Host-side timeline of the handle's last Frame constructors (<= 512 kept), oldest first: out[i * 5 + f] in microseconds,
+ * f = 0 queue (hand-over to the ingest thread -> it starts; 0 for synchronous submissions), 1 pack (rows copied into the pinned
+ * staging slot), 2 enqueue (host time of the launches), 3 wait (time the collecting thread was blocked), 4 latency (hand-over ->
+ * constructor complete, as the collecting thread sees it; the synchronous orbx_frame_stereo records pack and latency only).
+ * *n = entries written; reset != 0 forgets them.  For bench.py's per-step diagnosis of a shared host. */
+int orbx_get_ctor_timeline(orbx_handle* h, float* out, int cap, int* n, int reset);
 int orbx_get_fast_kernel_stats(orbx_handle* h, double* sum_ms, int64_t* n);
 
 #ifdef __cplusplus

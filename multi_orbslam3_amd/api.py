@@ -197,6 +197,14 @@ class ORBextractor:
             return ur[:n_left], dp[:n_left]
         return ur, dp
 
+    def ctor_timeline(self, reset=False):
+        """Host-side timeline of the last Frame constructors of this handle: array [n, 5] of microseconds
+        (queue, pack, enqueue, wait, latency), oldest first (orbx_get_ctor_timeline)."""
+        out = np.zeros((512, 5), np.float32)
+        n = C.c_int(0)
+        capi.check(self.lib.orbx_get_ctor_timeline(self.h, _vp(out), 512, C.byref(n), int(bool(reset))), "orbx_get_ctor_timeline")
+        return out[: n.value].copy()
+
     def set_profiling(self, level):
         capi.check(self.lib.orbx_set_profiling(self.h, int(level)))
 

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(64) void db_accumulate_kernel(int n_kfs, const uint
 struct orbv_vocab {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool ext_stream = false;
   int n_nodes = 0, L = 0, weighting = 0, scoring_norm = 1;
   DevBuf<int> d_child_start, d_child_ids, d_word;
   DevBuf<uint8_t> d_desc;
@@ -258,10 +259,18 @@ extern "C" int orbv_vocab_create(int device, const orbv_vocab_view* v, orbv_voca
   return ORBG_OK;
 }
 
+extern "C" int orbv_vocab_set_stream(orbv_vocab* h, void* hip_stream) {
+  if (!h) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  return orbg::swap_stream(&h->stream, &h->ext_stream, hip_stream, "bow");
+}
+
 extern "C" int orbv_vocab_destroy(orbv_vocab* h) {
   if (!h) return ORBG_BAD_ARG;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream); orbg::release_stream(h->stream);     // (a null h->stream is the null stream)
+  (void)hipStreamSynchronize(h->stream);
+  if (!h->ext_stream) orbg::release_stream(h->stream);
   h->d_child_start.release(); h->d_child_ids.release(); h->d_word.release(); h->d_desc.release(); h->d_weight.release();
   h->d_feat.release(); h->d_out_word.release(); h->d_out_node.release(); h->d_out_weight.release(); h->pin.release();
   delete h;
@@ -365,11 +374,14 @@ extern "C" int orbm_distinctive_descriptors(int device, const uint8_t* desc, con
   static thread_local Scratch sc;
   if (sc.device != device) { sc.d_desc.release(); sc.d_start.release(); sc.d_best.release(); sc.device = device; }
   if ((rc = sc.d_desc.reserve((size_t)std::max(total, 1) * 32)) || (rc = sc.d_start.reserve(m + 1)) || (rc = sc.d_best.reserve(m))) return rc;
-  if (total > 0) ORBG_HIP(hipMemcpyAsync(sc.d_desc.p, desc, (size_t)total * 32, hipMemcpyHostToDevice, 0));
-  ORBG_HIP(hipMemcpyAsync(sc.d_start.p, start, (size_t)(m + 1) * 4, hipMemcpyHostToDevice, 0));
-  hipLaunchKernelGGL(distinctive_kernel, dim3(m), dim3(64), 0, 0, sc.d_desc.p, sc.d_start.p, m, sc.d_best.p);
+  orbg::MiscStream ms;                                 // the library's M stream (never the legacy null stream)
+  if ((rc = ms.open())) return rc;
+  if (total > 0) ORBG_HIP(hipMemcpyAsync(sc.d_desc.p, desc, (size_t)total * 32, hipMemcpyHostToDevice, ms.s));
+  ORBG_HIP(hipMemcpyAsync(sc.d_start.p, start, (size_t)(m + 1) * 4, hipMemcpyHostToDevice, ms.s));
+  hipLaunchKernelGGL(distinctive_kernel, dim3(m), dim3(64), 0, ms.s, sc.d_desc.p, sc.d_start.p, m, sc.d_best.p);
   ORBG_HIP(hipGetLastError());
-  ORBG_HIP(hipMemcpy(best, sc.d_best.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+  ORBG_HIP(hipMemcpyAsync(best, sc.d_best.p, (size_t)m * 4, hipMemcpyDeviceToHost, ms.s));
+  ORBG_HIP(hipStreamSynchronize(ms.s));
   return ORBG_OK;
 }
 
@@ -387,18 +399,21 @@ extern "C" int orbv_score_l1(int device, const int32_t* q_word, const double* q_
   if ((rc = t.qw.reserve(std::max(nq, 1))) || (rc = t.qv.reserve(std::max(nq, 1))) || (rc = t.cs.reserve(m + 1)) ||
       (rc = t.cw.reserve(std::max(total, 1))) || (rc = t.cv.reserve(std::max(total, 1))) || (rc = t.sc.reserve(m)))
     return rc;
+  orbg::MiscStream ms;
+  if ((rc = ms.open())) return rc;
   if (nq > 0) {
-    ORBG_HIP(hipMemcpyAsync(t.qw.p, q_word, (size_t)nq * 4, hipMemcpyHostToDevice, 0));
-    ORBG_HIP(hipMemcpyAsync(t.qv.p, q_value, (size_t)nq * 8, hipMemcpyHostToDevice, 0));
+    ORBG_HIP(hipMemcpyAsync(t.qw.p, q_word, (size_t)nq * 4, hipMemcpyHostToDevice, ms.s));
+    ORBG_HIP(hipMemcpyAsync(t.qv.p, q_value, (size_t)nq * 8, hipMemcpyHostToDevice, ms.s));
   }
-  ORBG_HIP(hipMemcpyAsync(t.cs.p, cand_start, (size_t)(m + 1) * 4, hipMemcpyHostToDevice, 0));
+  ORBG_HIP(hipMemcpyAsync(t.cs.p, cand_start, (size_t)(m + 1) * 4, hipMemcpyHostToDevice, ms.s));
   if (total > 0) {
-    ORBG_HIP(hipMemcpyAsync(t.cw.p, cand_word, (size_t)total * 4, hipMemcpyHostToDevice, 0));
-    ORBG_HIP(hipMemcpyAsync(t.cv.p, cand_value, (size_t)total * 8, hipMemcpyHostToDevice, 0));
+    ORBG_HIP(hipMemcpyAsync(t.cw.p, cand_word, (size_t)total * 4, hipMemcpyHostToDevice, ms.s));
+    ORBG_HIP(hipMemcpyAsync(t.cv.p, cand_value, (size_t)total * 8, hipMemcpyHostToDevice, ms.s));
   }
-  hipLaunchKernelGGL(bow_score_l1_kernel, dim3((m + 63) / 64), dim3(64), 0, 0, t.qw.p, t.qv.p, nq, t.cs.p, t.cw.p, t.cv.p, m, t.sc.p);
+  hipLaunchKernelGGL(bow_score_l1_kernel, dim3((m + 63) / 64), dim3(64), 0, ms.s, t.qw.p, t.qv.p, nq, t.cs.p, t.cw.p, t.cv.p, m, t.sc.p);
   ORBG_HIP(hipGetLastError());
-  ORBG_HIP(hipMemcpy(score, t.sc.p, (size_t)m * 8, hipMemcpyDeviceToHost));
+  ORBG_HIP(hipMemcpyAsync(score, t.sc.p, (size_t)m * 8, hipMemcpyDeviceToHost, ms.s));
+  ORBG_HIP(hipStreamSynchronize(ms.s));
   return ORBG_OK;
 }
 
@@ -407,6 +422,7 @@ extern "C" int orbv_score_l1(int device, const int32_t* q_word, const double* q_
 struct orbd_database {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool ext_stream = false;
   int n_kfs = 0, n_words = 0;
   DevBuf<int> inv_start, inv_kf, bow_start, bow_word, covis_start, covis_kf, words, best, out2, qw;
   DevBuf<double> bow_value, qv;
@@ -457,13 +473,21 @@ extern "C" int orbd_database_create(int device, const orbd_database_view* v, orb
   return ORBG_OK;
 }
 
+extern "C" int orbd_database_set_stream(orbd_database* d, void* hip_stream) {
+  if (!d) return ORBG_BAD_ARG;
+  int rc = select_device(d->device);
+  if (rc) return rc;
+  return orbg::swap_stream(&d->stream, &d->ext_stream, hip_stream, "db");
+}
+
 extern "C" int orbd_database_destroy(orbd_database* d) {
   if (!d) return ORBG_OK;
   (void)hipSetDevice(d->device);
   d->inv_start.release(); d->inv_kf.release(); d->bow_start.release(); d->bow_word.release(); d->covis_start.release(); d->covis_kf.release();
   d->words.release(); d->best.release(); d->out2.release(); d->qw.release(); d->bow_value.release(); d->qv.release(); d->connected.release();
   d->shares.release(); d->sel.release(); d->first_key.release(); d->place_score.release(); d->acc.release();
-  (void)hipStreamSynchronize(d->stream); orbg::release_stream(d->stream);
+  (void)hipStreamSynchronize(d->stream);
+  if (!d->ext_stream) orbg::release_stream(d->stream);
   delete d;
   return ORBG_OK;
 }

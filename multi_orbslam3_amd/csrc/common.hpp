@@ -31,6 +31,10 @@ constexpr int kPatch = 31;       // PATCH_SIZE      S/ORBextractor.cc:70
 // tests (fresh HIP allocations are often zero, recycled ones are not).  Test aid; allocations are outside the timed path.
 inline bool poison_allocations() { static const bool on = getenv("ORBG_POISON") != nullptr; return on; }
 
+// ORBG_NO_POLL=1: every completion wait of the library goes through the runtime's blocking waits instead of spinning on a word in
+// pinned memory (read once per process; bench.py sets it when the container's CPU quota cannot feed the spinning threads).
+inline bool poll_allowed() { static const bool off = getenv("ORBG_NO_POLL") != nullptr; return !off; }
+
 // Growable device buffer (never shrinks); all allocations happen outside the timed/launch path once sizes settle.
 template <typename T>
 struct DevBuf {
@@ -86,24 +90,46 @@ struct StreamSignal {
   int sync(hipStream_t st) { int rc = post(st); return rc ? rc : wait(st); }
 };
 
-// Streams of the library's handles.  HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4): the
-// first four streams get a queue each, every further one joins the queue with the fewest users, ties broken by the queues'
-// ADDRESSES -- i.e. differently from run to run.  Streams that share a hardware queue are serialised: with one stream per handle
-// (two extractors, two frames, the local map, the local BA, PoseOptimization, the null stream = 8) the local BA landed on the queue of
-// an extractor in about one process out of three: 0.79 instead of 0.59 ms per solve and 5600 instead of 8400 frames/s for the
-// whole run, same cores, no host noise.  The library therefore owns THREE streams per device, created
-// together by the first handle so that each gets a hardware queue of its own next to the null stream's:
-//   "lba"                      -> L        (local BA handles; nothing else ever)
-//   "ex"                       -> E0 / E1  (extractor handles, alternating: Frame(t+1) is built next to the searches on frame t)
-//   "fr"                       -> M in a process that has extractors (a frame built by the constructor adopts its extractor's
-//                                 stream anyway); M, E0, E1 in turn in a process without (the server's KeyFrame matchers)
-//   "map", "po", "bow", "db"   -> M = the null stream (uploads, PoseOptimization, vocabulary / database work)
+// Streams of the library's handles.  HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 unless the
+// environment says otherwise): the first four streams get a queue each, every further one joins the queue with the fewest users,
+// ties broken by the queues' ADDRESSES -- i.e. differently from run to run.  Streams that share a hardware queue are serialised: with
+// one stream per handle (two extractors, two frames, the local map, the local BA, PoseOptimization = 7) the local BA landed on the
+// queue of an extractor in about one process out of three: 0.79 instead of 0.59 ms per solve and 5600 instead of 8400 frames/s for
+// the whole run, same cores, no host noise.  The library therefore owns FOUR non-blocking streams per device,
+// created together by the first handle so that each gets a hardware queue of its own:
+//   "lba"                              -> L        (local BA handles; nothing else ever)
+//   "ex"                               -> E0 / E1  (extractor handles, alternating: Frame(t+1) is built next to the searches on frame t)
+//   "fr"                               -> M in a process that has extractors (a frame built by the constructor adopts its extractor's
+//                                         stream anyway); M, E0, E1 in turn in a process without (the server's KeyFrame matchers)
+//   "map", "po", "bow", "db", "misc"   -> M        (map uploads, PoseOptimization, vocabulary / database work, stand-alone utilities)
+// None of them is the legacy null stream: nothing the library launches joins (or is joined by) the blocking streams of the
+// application it is embedded in.  An application that itself keeps streams busy should run with GPU_MAX_HW_QUEUES >= 4 + its own
+// (include/orbgpu.h, "Streams"), or hand the library its streams: every handle type has a *_set_stream entry point.
 // Handles that share a stream stay correct -- every completion signal is enqueued behind the handle's own work on an in-order
 // stream -- they merely do not overlap.  ORBG_STREAM_POOL=0 gives every handle a stream of its own again (ORBG_PRIO_<ROLE> =
 // -1 / 1 then picks a HIP stream priority for the role: priorities open further hardware queues and were slower in every
 // combination tried).  Implemented in misc.cpp (one registry for all translation units).
 hipError_t create_stream(hipStream_t* st, const char* role);
 void release_stream(hipStream_t st);       // destroys a stream of its own; pool streams live as long as the process
+bool is_library_stream(hipStream_t st);    // one of the pool's streams (shared between handles: never capture on it, never destroy it)
+
+// *_set_stream (include/orbgpu.h, "Streams"): the handle's work goes to the caller's stream from now on; NULL = back to the library's
+// stream of the role.  The handle must be idle; its old stream is drained first.  A caller's stream is never destroyed by the library.
+inline int swap_stream(hipStream_t* slot, bool* external, void* user, const char* role) {
+  if (*slot) ORBG_HIP(hipStreamSynchronize(*slot));
+  if (!*external) release_stream(*slot);
+  *slot = nullptr;
+  if (user) { *slot = (hipStream_t)user; *external = true; }
+  else { *external = false; ORBG_HIP(create_stream(slot, role)); }
+  return ORBG_OK;
+}
+
+// the M stream of the current device for a stand-alone utility call (a stream of its own, destroyed on scope exit, when the pool is off)
+struct MiscStream {
+  hipStream_t s = nullptr;
+  int open() { ORBG_HIP(create_stream(&s, "misc")); return ORBG_OK; }
+  ~MiscStream() { if (s) { (void)hipStreamSynchronize(s); release_stream(s); } }
+};
 
 inline int select_device(int device) {
   int n = 0;

@@ -1486,7 +1486,12 @@ class WorkerPool {
 // ------------------------------------------------------------------------------------------------
 // handle
 
+static inline double host_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec; }
+// Measured on MI355X / ROCm 7.2: hipGraphLaunch of the constructor chain costs the host what its launches cost: off unless asked for
+static const bool g_ctor_graph = getenv("ORBG_CTOR_GRAPH") && atoi(getenv("ORBG_CTOR_GRAPH")) != 0;
+
 struct orbx_handle {
+  bool ext_stream = false;                    // `stream` was handed in through orbx_set_stream (never destroyed here)
   orbx_config cfg;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -1546,6 +1551,22 @@ struct orbx_handle {
   PinnedBuf<uint8_t> h_img;
   std::atomic<int> ingest_state{0};            // 0 idle, 1 handed to the ingest thread, 2 submitted by it (ingest_rc valid)
   int ingest_rc = 0;
+  // host-side timeline of the last submissions (orbx_get_ctor_timeline): per submission, microseconds
+  //   [0] queue   hand-over to the ingest thread -> it starts (0 for synchronous submissions)
+  //   [1] pack    rows copied into the pinned staging slot (both images)
+  //   [2] enqueue the launches of the copy kernels + constructor chain (host time, pack excluded)
+  //   [3] wait    time the collecting thread was blocked in the wait
+  //   [4] latency hand-over -> constructor complete as seen by the collecting thread
+  static constexpr int kTlCap = 512, kTlFields = 5;
+  float tl[kTlCap][kTlFields] = {};
+  unsigned long long tl_n = 0;                 // submissions recorded so far (ring index = tl_n % kTlCap)
+  double tl_t_handover = 0, tl_pack_acc = 0, tl_queue = 0, tl_enqueue = 0;   // scratch of the submission in flight
+  void tl_begin() { tl_t_handover = host_now_us(); tl_pack_acc = 0; tl_queue = 0; tl_enqueue = 0; }
+  void tl_commit(double wait_us) {
+    float* e = tl[tl_n % kTlCap];
+    e[0] = (float)tl_queue; e[1] = (float)tl_pack_acc; e[2] = (float)tl_enqueue; e[3] = (float)wait_us; e[4] = (float)(host_now_us() - tl_t_handover);
+    tl_n++;
+  }
 };
 static void delete_pending(struct ExtractPending* p);   // (defined behind the type)
 
@@ -1801,7 +1822,8 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     h->qts.resize(nthreads + 1);
     for (auto& q : h->qts) q.oldest_first_ = cfg->octree_oldest_first != 0;
   }
-  if (orbg::create_stream(&h->stream, "ex") != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
+  // (ORBG_CTOR_GRAPH=1 captures the constructor chain on the handle's stream: that stream must not be shared with other handles)
+  if ((g_ctor_graph ? hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) : orbg::create_stream(&h->stream, "ex")) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   for (auto& e : h->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   const int cap = 2 * (cfg->n_features + 4 * nl + 64);
@@ -1821,6 +1843,7 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
 
 static void ctor_graph_free(struct CtorGraph* g);
 
+
 extern "C" int orbx_destroy(orbx_handle* h) {
   if (!h) return ORBG_BAD_ARG;
   (void)hipSetDevice(h->device);
@@ -1834,7 +1857,7 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   h->d_cand.release(); h->d_hdr.release(); h->d_lvlcount.release(); h->d_nkp.release(); h->d_overflow.release();
   h->d_selreg.release(); h->h_nkp.release(); h->sig.release();
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
-  orbg::release_stream(h->stream);
+  if (!h->ext_stream) orbg::release_stream(h->stream);
   delete_pending(h->pending);
   delete h;
   return ORBG_OK;
@@ -1919,7 +1942,6 @@ struct CtorGraph {
 };
 // Measured on MI355X / ROCm 7.2 (bench.py C2, 3 x 3000 steps each way): hipGraphLaunch of the seven-kernel chain costs the
 // host what the seven launches cost (extract stage 45.4-46.0 us with, 45.3-46.2 us without), so it is off unless asked for.
-static const bool g_ctor_graph = getenv("ORBG_CTOR_GRAPH") && atoi(getenv("ORBG_CTOR_GRAPH")) != 0;
 
 static long g_cg_replays = 0, g_cg_captures = 0, g_cg_misses = 0, g_cg_ineligible = 0;
 static void ctor_graph_free(CtorGraph* g) {
@@ -2281,8 +2303,10 @@ static int stage_images(orbx_handle* h, const uint8_t* const* images, int n_img,
   // already staged (the image before) or rewritten by the next launch (the image after), which runs behind it on the stream.
   for (int c = 0; c < n_img; c++) {
     uint8_t* dst = h->h_img.h + c * per;
+    const double tp0 = host_now_us();
     if (stride == w) memcpy(dst, images[c], per);
     else for (int y = 0; y < hgt; y++) memcpy(dst + (size_t)y * w, images[c] + (size_t)y * stride, w);
+    h->tl_pack_acc += host_now_us() - tp0;
     const size_t b0 = (c * per) / 16, b1 = ((c + 1) * per + 15) / 16;
     const int n16 = (int)(b1 - b0);
     hipLaunchKernelGGL(img_upload_kernel, dim3((n16 + 255) / 256), dim3(256), 0, h->stream, reinterpret_cast<const uint4*>(h->h_img.d) + b0,
@@ -2348,12 +2372,20 @@ extern "C" int orbx_extract_stereo_dev(orbx_handle* h, const uint8_t* d_img_left
                              kps_right, desc_right, cap_right, n_right);
 }
 
+// The fused constructors feed the extracted keypoints straight into the grid: mvKeysUn = mvKeys, i.e. mDistCoef[0] == 0
+// (S/Frame.cc:723-727).  The reference's bounds are the image rectangle exactly then (S/Frame.cc:775-783); anything else is a
+// distorted camera, which this entry point does not undistort: refused.
+static inline bool view_is_undistorted(const orbm_frame_view* v, int width, int height) {
+  return v->min_x == 0.0f && v->min_y == 0.0f && v->max_x == (float)width && v->max_y == (float)height;
+}
+
 static int frame_stereo_impl(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
                              const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b,
                              orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
                              int* n_left, int* n_right) {
   if (!h || h->cfg.n_cams != 2 || !n_left) return ORBG_BAD_ARG;
   if (frame && !view) return ORBG_BAD_ARG;
+  if (frame && width > 0 && height > 0 && !view_is_undistorted(view, width, height)) return ORBG_BAD_ARG;
   if (!img_left || !img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
   if (stride < width || handle_busy(h)) return ORBG_BAD_ARG;
   int rc = select_device(h->device);
@@ -2389,7 +2421,17 @@ extern "C" int orbx_frame_stereo_dev(orbx_handle* h, orbm_frame* frame, const or
 
 // Frame constructor split in two so that the caller can overlap it with work on other streams (tracking of the previous
 // frame): submit enqueues the whole chain and returns, wait completes it.
+static int frame_submit_core(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
+                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b);
 static int frame_submit_impl(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
+                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b) {
+  const double t0 = host_now_us();
+  h->tl_queue = t0 - h->tl_t_handover;
+  const int rc = frame_submit_core(h, frame, view, img_left, img_right, on_device, width, height, stride, bf, b);
+  h->tl_enqueue = host_now_us() - t0 - h->tl_pack_acc;
+  return rc;
+}
+static int frame_submit_core(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
                              const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b) {
   int rc = select_device(h->device);
   if (rc) return rc;
@@ -2426,7 +2468,9 @@ extern "C" int orbx_frame_stereo_dev_submit(orbx_handle* h, orbm_frame* frame, c
   if (frame && !view) return ORBG_BAD_ARG;
   if (!d_img_left || !d_img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
   if (stride < width) return ORBG_BAD_ARG;
+  if (frame && !view_is_undistorted(view, width, height)) return ORBG_BAD_ARG;
   if (h->ingest_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;
+  h->tl_begin();
   return frame_submit_impl(h, frame, view, d_img_left, d_img_right, true, width, height, stride, bf, b);
 }
 
@@ -2446,7 +2490,7 @@ struct IngestWorker {
   std::atomic<int> queued{0};
   bool quit = false;
   std::thread th;
-  static bool spin_ok() { static const bool off = getenv("ORBG_NO_POLL") != nullptr; return !off; }
+  static bool spin_ok() { return orbg::poll_allowed(); }
   void run() {
     for (;;) {
       // the next pair usually arrives within a frame time: spin for a while, then sleep
@@ -2500,8 +2544,10 @@ extern "C" int orbx_frame_stereo_submit(orbx_handle* h, orbm_frame* frame, const
   if (frame && !view) return ORBG_BAD_ARG;
   if (!img_left || !img_right || width <= 0 || height <= 0) return ORBG_EMPTY;
   if (stride < width || width > h->cfg.max_width || height > h->cfg.max_height) return ORBG_BAD_ARG;
+  if (frame && !view_is_undistorted(view, width, height)) return ORBG_BAD_ARG;
   if (h->ingest_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;       // one submission per handle at a time
   if (h->pending && (h->pending->active || h->pending->finished)) return ORBG_BAD_ARG;
+  h->tl_begin();
   if (!(flags & ORBX_SUBMIT_ASYNC)) return frame_submit_impl(h, frame, view, img_left, img_right, false, width, height, stride, bf, b);
   int rc = select_device(h->device);                    // a missing device is reported by the call, not by the wait
   if (rc) return rc;
@@ -2515,6 +2561,7 @@ extern "C" int orbx_frame_stereo_submit(orbx_handle* h, orbm_frame* frame, const
 extern "C" int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_right) {
   if (!h) return ORBG_BAD_ARG;
   int rc;
+  const double t_wait0 = host_now_us();
   if (h->ingest_state.load(std::memory_order_acquire) != 0) {
     // handed to the ingest thread: wait until it has enqueued the chain (it is usually done long before)
     for (unsigned spins = 0; h->ingest_state.load(std::memory_order_acquire) != 2; spins++) {
@@ -2536,18 +2583,46 @@ extern "C" int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_ri
   }
   P.finished = false;
   if (rc) return rc;
+  h->tl_commit(host_now_us() - t_wait0);
   if (n_left) *n_left = P.n_res[0];
   if (n_right) *n_right = P.n_res[1];
   return ORBG_OK;
 }
+
+// Host-side timeline of the handle's last submissions, oldest first: out[i * 5 + f], f = queue / pack / enqueue / wait / latency in
+// microseconds (see orbx_handle::tl); *n = entries written (<= cap, <= 512).  reset != 0 forgets them afterwards.
+extern "C" int orbx_get_ctor_timeline(orbx_handle* h, float* out, int cap, int* n, int reset) {
+  if (!h || !n || cap < 0 || (cap > 0 && !out)) return ORBG_BAD_ARG;
+  const unsigned long long have = std::min<unsigned long long>(h->tl_n, orbx_handle::kTlCap);
+  const int take = (int)std::min<unsigned long long>(have, (unsigned long long)cap);
+  for (int i = 0; i < take; i++) {
+    const float* e = h->tl[(h->tl_n - take + i) % orbx_handle::kTlCap];
+    for (int f = 0; f < orbx_handle::kTlFields; f++) out[i * orbx_handle::kTlFields + f] = e[f];
+  }
+  *n = take;
+  if (reset) h->tl_n = 0;
+  return ORBG_OK;
+}
+extern "C" int orbx_set_stream(orbx_handle* h, void* hip_stream) {
+  if (!h) return ORBG_BAD_ARG;
+  if (h->ingest_state.load(std::memory_order_acquire) != 0 || (h->pending && (h->pending->active || h->pending->finished))) return ORBG_BAD_ARG;
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  if (h->cgraph) { ctor_graph_free(h->cgraph); h->cgraph = nullptr; }      // a captured chain belongs to the stream it was captured on
+  return orbg::swap_stream(&h->stream, &h->ext_stream, hip_stream, "ex");
+}
+
 extern "C" int orbx_frame_stereo_wait(orbx_handle* h, int* n_left, int* n_right) { return orbx_frame_stereo_dev_wait(h, n_left, n_right); }
 
 extern "C" int orbx_frame_stereo(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
                                  const uint8_t* img_right, int width, int height, int stride, float bf, float b,
                                  orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left,
                                  int* n_left, int* n_right) {
-  return frame_stereo_impl(h, frame, view, img_left, img_right, false, width, height, stride, bf, b, kps_left, desc_left, uright,
-                           depth, cap_left, n_left, n_right);
+  if (h) h->tl_begin();
+  const int rc = frame_stereo_impl(h, frame, view, img_left, img_right, false, width, height, stride, bf, b, kps_left, desc_left, uright,
+                                   depth, cap_left, n_left, n_right);
+  if (h && rc == ORBG_OK) h->tl_commit(0.0);            // synchronous: queue / enqueue / wait are not separated, latency = the call
+  return rc;
 }
 
 extern "C" int orbx_get_level(orbx_handle* h, int cam, int level, uint8_t* host_out, int* width, int* height) {

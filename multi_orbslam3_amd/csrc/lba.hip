@@ -2068,7 +2068,7 @@ __device__ __forceinline__ void update_after_solve_block(int ub, const UpdArgs& 
   const double lambda = a.lambda_p ? *a.lambda_p : a.lambda_v;
   // ---- wait for workgroup 0
   while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(x_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != (int)seq) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (x is read with agent-scope loads below: no cache invalidation needed)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // pairs with workgroup 0's agent-scope release (x itself is also read with agent-scope loads below)
   auto ldx = [&](size_t k) { return __hip_atomic_load(&a.x[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   // ---- after
   double sc = 0;
@@ -2157,9 +2157,10 @@ __global__ __launch_bounds__(ldltm::kThreads) void k_ldlt_cols_update(int n, con
     ldltm::ldlt_cols_body<true>(n, St, x, ok_flag);      // x leaves through agent-scope stores of wavefront 0
     __syncthreads();
     if (threadIdx.x == 0) {
-      // thread 0 belongs to the wavefront that stored x: its stores are complete (memory counter drained) before the word goes out
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __hip_atomic_store(x_ready, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // thread 0 belongs to the wavefront that stored x.  Agent-scope RELEASE on the publication: the compiler emits the L2
+      // write-back and s_waitcnt vmcnt(0) in front of the word's store, so that x is visible to every XCD before the word is
+      // (a workgroup-scope fence compiles to lgkmcnt(0) only; x and the word live in different allocations = different channels)
+      __hip_atomic_store(x_ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
@@ -2259,9 +2260,34 @@ struct StopRef {
   const volatile int32_t* i32 = nullptr;
   const volatile uint8_t* u8 = nullptr;
 };
+// A/B, test and experiment switches of the solve (ORBG_* environment variables): read ONCE, when the handle is created -- the solve
+// path itself never calls getenv.  A test that wants another variant creates another handle.
+struct LbaSwitches {
+  bool blit = false, host_items = false, host_lists = false, no_fuse = false, no_first2 = false, host_csr = false, dev_csr = false;
+  bool ldlt_valu = false, ldlt_rows = false, ldlt_wide = false, ldlt_dense = false, fuse_update = true, no_spec = false, no_poll = false;
+  bool no_export_fuse = false;
+  int upd_threads = 64;              // k_update's workgroup size (ORBG_UPD_THREADS = 64 / 128 / 256)
+  ldltm::Switches ldlt;              // which matrix-core kernel a size gets (ORBG_LDLT_TILES / _T9_4W / _8W)
+  static LbaSwitches from_env() {
+    LbaSwitches w;
+    auto on = [](const char* k) { return getenv(k) != nullptr; };
+    w.blit = on("ORBG_LBA_BLIT"); w.host_items = on("ORBG_HOST_ITEMS"); w.host_lists = on("ORBG_HOST_LISTS"); w.no_fuse = on("ORBG_NO_FUSE");
+    w.no_first2 = on("ORBG_NO_FIRST2"); w.host_csr = on("ORBG_HOST_CSR"); w.dev_csr = on("ORBG_DEV_CSR"); w.ldlt_valu = on("ORBG_LDLT_VALU");
+    w.ldlt_rows = on("ORBG_LDLT_ROWS"); w.ldlt_wide = on("ORBG_LDLT_WIDE"); w.ldlt_dense = on("ORBG_LDLT_DENSE"); w.no_spec = on("ORBG_NO_SPEC");
+    w.no_poll = !orbg::poll_allowed(); w.no_export_fuse = on("ORBG_NO_EXPORT_FUSE");
+    if (const char* e = getenv("ORBG_FUSE_UPDATE")) w.fuse_update = atoi(e) != 0;
+    if (const char* e = getenv("ORBG_UPD_THREADS")) { const int v = atoi(e); w.upd_threads = (v == 256 || v == 128) ? v : 64; }
+    w.ldlt = ldltm::Switches::from_env();
+    return w;
+  }
+};
 struct lba_handle {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool ext_stream = false;             // `stream` was handed in through lba_set_stream (never destroyed here)
+  LbaSwitches sw;
+  ldltm::AttrCache ldlt_attr;          // which kernels of THIS handle's device already allow their dynamic LDS size
+  size_t flow_attr = 0, fused_attr = 0;
   DevBuf<lba_edge> d_edges;
   PinnedBuf<lba_edge> edges_pin;       // the caller's edge list, copied (and validated, counted) in ONE pass
   DevBuf<PairItem> d_items_dev;        // pair items built by k_build_items (fixed-capacity segment per pose pair)
@@ -2312,12 +2338,21 @@ extern "C" int lba_create(int device, int cap_poses, int cap_points, int cap_edg
   if (rc) return rc;
   lba_handle* h = new lba_handle();
   h->device = device;
+  h->sw = LbaSwitches::from_env();
   if (orbg::create_stream(&h->stream, "lba") != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   if ((rc = h->rec.reserve(4)) || (rc = h->d_ok.reserve(4))) { delete h; return rc; }
   memset(h->rec.h, 0, 4 * sizeof(HostRec));
   (void)cap_poses; (void)cap_points; (void)cap_edges;   // buffers grow on first use and are kept
   *out = h;
   return ORBG_OK;
+}
+
+extern "C" int lba_set_stream(lba_handle* h, void* hip_stream) {
+  if (!h) return ORBG_BAD_ARG;
+  if (h->job_state.load() != 0) return ORBG_BAD_ARG;        // a solve is in flight on the worker
+  int rc = select_device(h->device);
+  if (rc) return rc;
+  return orbg::swap_stream(&h->stream, &h->ext_stream, hip_stream, "lba");
 }
 
 extern "C" int lba_destroy(lba_handle* h) {
@@ -2337,7 +2372,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
   h->d_pair_i2.release(); h->d_pair_start.release(); h->d_ok.release(); h->d_items.release(); h->rec.release(); h->up_h.release(); h->dl_h.release(); h->up_d.release(); h->d_flags.release(); h->d_scale_partial.release(); h->d_ticket.release(); h->sig.release();
   for (auto& e : h->prof_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-  orbg::release_stream(h->stream);
+  if (!h->ext_stream) orbg::release_stream(h->stream);
   delete h;
   return ORBG_OK;
 }
@@ -2382,6 +2417,8 @@ static int upload_arena(lba_handle* h, size_t off0, size_t off1, hipStream_t st,
 }
 
 static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r) {
+  if (!h) return ORBG_BAD_ARG;
+  const LbaSwitches& sw = h->sw;
   if (!h || !p || !r || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0) return ORBG_BAD_ARG;
   if (!r->poses || !r->points) return ORBG_BAD_ARG;
   int rc = select_device(h->device);
@@ -2434,7 +2471,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     pf_raw[ex] += p->pose_fixed[ep] ? 0 : 1;
   }
   if (NE > 0) {
-    if (getenv("ORBG_LBA_BLIT")) {
+    if (sw.blit) {
       ORBG_HIP(hipMemcpyAsync(h->d_edges.p, edges, sizeof(lba_edge) * (size_t)NE, hipMemcpyHostToDevice, st));
     } else {                                               // (k_upload16 below: the runtime's blit takes ~50 us for these 190 KB)
       const unsigned n16 = (unsigned)((sizeof(lba_edge) * (size_t)NE + 15) / 16);
@@ -2475,14 +2512,14 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   for (int i = 0; i < nP; i++) max_pose_edges = std::max(max_pose_edges, ps_cnt[i]);
   const int item_cap = std::min(std::max(nL, 1), max_pose_edges);
   const bool dev_items = nP >= 1 && nP <= 64 && (size_t)n_pairs_all * (size_t)item_cap * sizeof(PairItem) <= ((size_t)64 << 20) &&
-                         !getenv("ORBG_HOST_ITEMS");
+                         !sw.host_items;
   // (the lists of free observations per landmark, still in edge order, go along when the device sorts them: k_prep / k_errlin_prep)
-  const bool dev_lists = dev_items && nP >= 1 && ldltm::supports(6 * nP) && !getenv("ORBG_LDLT_VALU") && !getenv("ORBG_HOST_LISTS");
+  const bool dev_lists = dev_items && nP >= 1 && ldltm::supports(6 * nP) && !sw.ldlt_valu && !sw.host_lists;
   // ... and the device fills the lists itself (k_csr_fill / k_csr_sort) when a pose's list fits the sorting workgroup
   // (measured: a wash at C2 -- 7.7 + 15.2 us of kernels for a 29 us host pass -- and -20 us at C4: used from 16 k edges on;
   // ORBG_DEV_CSR=1 forces it, ORBG_HOST_CSR=1 forbids it)
-  const bool dev_csr = dev_lists && NE > 0 && nL > 0 && max_pose_edges <= kCsrPoseCap && !getenv("ORBG_NO_FUSE") && !getenv("ORBG_NO_FIRST2") &&
-                       !getenv("ORBG_HOST_CSR") && (NE >= 16384 || getenv("ORBG_DEV_CSR"));
+  const bool dev_csr = dev_lists && NE > 0 && nL > 0 && max_pose_edges <= kCsrPoseCap && !sw.no_fuse && !sw.no_first2 &&
+                       !sw.host_csr && (NE >= 16384 || sw.dev_csr);
   const size_t o_lm_mask = take(8 * (size_t)nL);
   const size_t o_pair_i1 = take(4 * (size_t)n_pairs_all), o_pair_i2 = take(4 * (size_t)n_pairs_all), o_pair_start = take(4 * ((size_t)n_pairs_all + 1));
   const size_t o_items = take(dev_items ? 0 : sizeof(PairItem) * n_items);
@@ -2540,7 +2577,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // part A: host-filled arrays; + the point / pose lists when the host fills them; + the unsorted free-observation lists when
   // the device only sorts
   const size_t off_a = dev_csr ? o_pt_edges : dev_lists ? o_pf_col : o_pf_edges;
-  const bool blit = getenv("ORBG_LBA_BLIT") != nullptr;       // A/B switch: the runtime's copies
+  const bool blit = sw.blit;       // A/B switch: the runtime's copies
   if ((rc = upload_arena(h, 0, off_a, st, blit))) return rc;
   struct {
     const lba_edge* edges; const int *pose_col, *point_col, *pt_start, *pt_edges, *ps_start, *ps_edges, *pf_start, *pf_edges, *pf_col,
@@ -2634,7 +2671,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   FlowMap flow_map;
   bool use_flow = false;
   size_t flow_lds = 0;
-  if (nP >= 1 && nP <= 20 && !getenv("ORBG_LDLT_ROWS")) {
+  if (nP >= 1 && nP <= 20 && !sw.ldlt_rows) {
     int w = 0, fill = 0;
     for (int i = 0; i < 16; i++) { flow_map.c0[i] = 0; flow_map.c1[i] = 0; }
     bool fits = true;
@@ -2656,20 +2693,19 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       flow_lds = (12 * (size_t)nP + nblk * kPanStride) * sizeof(double);
       use_flow = flow_lds <= 150 * 1024;
       if (use_flow && flow_lds > 64 * 1024) {
-        static size_t flow_attr = 0;
-        if (flow_attr < flow_lds) {
+        if (h->flow_attr < flow_lds) {            // (per handle = per device; a handle is used by one thread at a time)
           ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds));
-          flow_attr = flow_lds;
+          h->flow_attr = flow_lds;
         }
       }
     }
   }
   // FP64 matrix-core LDL^T (ldlt_mfma.hpp): up to 50 free poses; ORBG_LDLT_VALU=1 switches back to the vector-ALU kernels
-  const bool force_wide = getenv("ORBG_LDLT_WIDE") != nullptr;          // A/B and test switch: k_wide_* at any size
-  const bool use_mfma = nP >= 1 && ldltm::supports(n) && !getenv("ORBG_LDLT_VALU") && !force_wide;
+  const bool force_wide = sw.ldlt_wide;          // A/B and test switch: k_wide_* at any size
+  const bool use_mfma = nP >= 1 && ldltm::supports(n) && !sw.ldlt_valu && !force_wide;
   // windows beyond the matrix-core kernels (more than 50 free poses): blocked LDL^T over many workgroups
   // (51 free poses still fit the row-pair kernel, which stays reachable through ORBG_LDLT_VALU; the blocked form is faster there: 2.7 vs 3.4 ms)
-  const bool use_wide = nP >= 1 && (force_wide || (!use_mfma && !use_flow && (!rows_R || (nP > 50 && !getenv("ORBG_LDLT_VALU")))));
+  const bool use_wide = nP >= 1 && (force_wide || (!use_mfma && !use_flow && (!rows_R || (nP > 50 && !sw.ldlt_valu))));
   if (use_wide && n > kWideMaxUnknowns) return ORBG_CAP_EXCEEDED;      // (k_wide_back's x lives in LDS)
   if (use_wide && (rc = h->d_wide.reserve(2 * (size_t)n + 32))) return rc;
   if (use_mfma) {
@@ -2679,7 +2715,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // k_update's workgroup size: the kernel is a chain of dependent memory round trips per landmark; smaller workgroups spread the
   // same wavefronts over more compute units (ORBG_UPD_THREADS = 64 / 128 / 256 for experiments)
   // measured (tools/lba_time.py, C2): 256 threads 0.499 ms per solve, 128: 0.488, 64: 0.484
-  static const int upd_threads = []() { const char* e = getenv("ORBG_UPD_THREADS"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
+  const int upd_threads = sw.upd_threads;
   // ORBG_FUSE_UPDATE=1: windows the column LDL^T covers run the solve and the update as ONE launch (k_ldlt_cols_update).  Off by
   // default -- measured at C2 (tools/lba_time.py): 0.4865 ms per solve fused, 0.4868-0.4911 as two launches.  The update workgroups
   // do overlap their dependent loads with the LDL^T, but they sit on other XCDs than the LDL^T workgroup: the "x is ready" word and
@@ -2687,15 +2723,14 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // k_update's own loads cost.  (A same-XCD placement checked through the XCC_ID register would make the hand-over an L2 round trip.)
   // (on by default since the end of round 3: alone on the GPU the fused launch is a wash -- 0.488 vs 0.486 ms per solve -- but next to
   // the tracking chains every dispatch less counts: 0.586 vs 0.597 ms, 8490 vs 8360 frames/s; ORBG_FUSE_UPDATE=0: two launches)
-  const bool fuse_upd = use_mfma && ldltm::pick(n).cols && !(getenv("ORBG_FUSE_UPDATE") && atoi(getenv("ORBG_FUSE_UPDATE")) == 0);
+  const bool fuse_upd = use_mfma && ldltm::pick(n, sw.ldlt).cols && sw.fuse_update;
   const int n_blocks_u = fuse_upd ? (NP + NX + kFusedUpdThreads - 1) / kFusedUpdThreads : (NP + NX + upd_threads - 1) / upd_threads;
   if ((rc = h->d_scale_partial.reserve(std::max(n_blocks_u, 1)))) return rc;
   if (fuse_upd) {
-    static bool attr_set = false;
-    const size_t lds = ldltm::pick(n).lds;
-    if (!attr_set && lds > 48 * 1024) {
+    const size_t lds = ldltm::pick(n, sw.ldlt).lds;
+    if (h->fused_attr < lds && lds > 48 * 1024) {
       ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_cols_update), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-      attr_set = true;
+      h->fused_attr = 160 * 1024 - 8 * 1024;
     }
   }
   if (!h->d_ticket.p) {
@@ -2716,7 +2751,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   double* const bls[2] = {h->d_bl.p, h->d_bl2.p};
   double* const Hpps[2] = {h->d_Hpp.p, h->d_Hpp2.p};
   double* const bps[2] = {h->d_bp.p, h->d_bp2.p};
-  const bool no_spec = getenv("ORBG_NO_SPEC") != nullptr;   // A/B switch: no speculative linearisation
+  const bool no_spec = sw.no_spec;   // A/B switch: no speculative linearisation
   int ls = 0;                      // linearisation set of the current iteration
   bool spec_ready = false;         // set ls^1 holds the linearisation of the current estimate
   auto launch_linearise = [&](int buf, int set) {
@@ -2741,7 +2776,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     volatile unsigned* w = &h->rec.h->seq;
     const unsigned want = h->rec_seq;
     bool got = false;
-    if (!getenv("ORBG_NO_POLL")) {
+    if (!sw.no_poll) {
       timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
       for (unsigned spins = 0; !got; spins++) {
         if (*w == want) { got = true; break; }
@@ -2793,10 +2828,10 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
         UpdArgs ua{NP, NX, nP, D.pose_col, D.point_col, posesB[in_buf], pointsB[in_buf], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[set_],
                    Hlls[set_], bls[set_], lam_, posesB[out_buf], pointsB[out_buf], bps[set_], h->d_scale_partial.p, lamp_};
         h->xseq = h->xseq == 0x7FFFFFFFu ? 1u : h->xseq + 1u;
-        hipLaunchKernelGGL(k_ldlt_cols_update, dim3(1 + n_blocks_u), dim3(ldltm::kThreads), ldltm::pick(n).lds, st, n, h->d_St.p, h->d_x.p,
+        hipLaunchKernelGGL(k_ldlt_cols_update, dim3(1 + n_blocks_u), dim3(ldltm::kThreads), ldltm::pick(n, sw.ldlt).lds, st, n, h->d_St.p, h->d_x.p,
                            h->d_ok.p, h->d_xready.p, h->xseq, ua);
       } else if (use_mfma) {
-        ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st));
+        ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st, sw.ldlt, &h->ldlt_attr));
       } else if (use_wide) {
         ORBG_HIP(launch_ldlt_wide(n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wide.p, st));
       } else if (use_flow) {
@@ -2888,7 +2923,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
           // (not after the very last iteration that can run)
           // ... nor when two iterations in a row barely improved chi2: a third one ends the round (nBad >= 3)
           const bool may_continue = !(last_round && (it + 1 >= iterations || nBad >= 2)) && !no_spec;
-          if (may_continue && !getenv("ORBG_NO_FUSE")) {
+          if (may_continue && !sw.no_fuse) {
             // residuals + record + linearisation of the trial state in ONE launch
             const int set = ls ^ 1;
             const int n_blocks_l = (nL + 255) / 256;       // the landmark reduction rides in the same launch (point workgroups)
@@ -2910,7 +2945,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
           } else {
             // the last evaluation that can run in the last round goes together with the (speculative) export of its state
             fused_export = !may_continue && last_round && (it + 1 >= iterations || nBad >= 2) && !no_spec && !lambda_on_device &&
-                           !getenv("ORBG_NO_FUSE") && !getenv("ORBG_NO_EXPORT_FUSE");
+                           !sw.no_fuse && !sw.no_export_fuse;
             if (fused_export) {
               const int n_thr = std::max(std::max(NE, NP), 3 * NX);
               hipLaunchKernelGGL(k_errors_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, n_blocks_e, NE, D.edges, posesB[trial],
@@ -2993,7 +3028,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // first residuals + linearisation are launched before the host has finished the structure
   const int n_zero = n + 3 * nL;
   // first iteration in two launches (k_errlin_prep, k_finish_items) where the observation lists are sorted on the device
-  const bool first2 = dev_lists && NE > 0 && nL > 0 && !getenv("ORBG_NO_FUSE") && !getenv("ORBG_NO_FIRST2") && !terminate();
+  const bool first2 = dev_lists && NE > 0 && nL > 0 && !sw.no_fuse && !sw.no_first2 && !terminate();
   if (first2 && dev_csr) {
     const int set = ls ^ 1;
     const int n_blocks_l = (nL + 255) / 256;
@@ -3034,7 +3069,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     ORBG_HIP(hipGetLastError());
     err_valid = true; spec_ready = true; fin_version = version;
   } else if (!terminate()) {
-    if (NE > 0 && !getenv("ORBG_NO_FUSE")) {
+    if (NE > 0 && !sw.no_fuse) {
       // residuals + linearisation of the initial estimate in the fused kernel of the later trials (its record is not waited
       // for: it carries the sequence number the host has already seen)
       const int set = ls ^ 1;
@@ -3135,7 +3170,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     }
   }
   // symbolic elimination of the reduced camera system: which blocks of L are structurally non-zero (fill-in included)
-  if (nP <= 64 && !getenv("ORBG_LDLT_DENSE") && !dev_lists) {     // (only the vector-ALU kernels read it; dev_lists implies the matrix-core solver)
+  if (nP <= 64 && !sw.ldlt_dense && !dev_lists) {     // (only the vector-ALU kernels read it; dev_lists implies the matrix-core solver)
     unsigned long long col[64];                         // col[j]: rows i > j with S_ij != 0, then with fill-in
     for (int j = 0; j < nP; j++) {
       unsigned long long mcol = 0;
@@ -3240,7 +3275,7 @@ extern "C" int lba_get_solver_stats(lba_handle* h, double* sum_ms, int64_t* n_br
   if (!h || !sum_ms || !n_brackets) return ORBG_BAD_ARG;
   *sum_ms = h->prof_sum_ms; *n_brackets = h->prof_n;
   if (n_unknowns) *n_unknowns = h->prof_n_unknowns;
-  if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !getenv("ORBG_LDLT_VALU") && !getenv("ORBG_LDLT_WIDE");
+  if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !h->sw.ldlt_valu && !h->sw.ldlt_wide;
   return ORBG_OK;
 }
 
@@ -3267,7 +3302,7 @@ extern "C" int lba_event_overhead(lba_handle* h, int reps, float* ms) {
 // S/LocalMapping.cc:114-133).  lba_solve_async hands the problem to a worker thread owned by the handle and returns at once;
 // lba_wait blocks until that solve has finished and returns its status.  problem / stop_flag / result must stay valid
 // until lba_wait returns; one solve in flight per handle.
-static inline bool lba_spin_allowed() { static const bool off = getenv("ORBG_NO_POLL") != nullptr; return !off; }
+static inline bool lba_spin_allowed() { return orbg::poll_allowed(); }
 // spins until pred() or `limit_us` have passed; returns pred()
 template <typename Pred>
 static inline bool lba_spin_until(Pred pred, double limit_us) {
@@ -3845,6 +3880,29 @@ extern "C" int pose_opt_debug_prof(long long* out, int reset) {
 }
 #endif
 
+// per-thread scratch of pose_optimize (PoseOptimization has no handle: the reference calls a static member); released when the thread exits
+namespace {
+struct PoScratch {
+  PinnedBuf<uint8_t> stage; DevBuf<uint8_t> dev; int device = -1; hipStream_t stream = nullptr; bool ext_stream = false;
+  void drop_stream() { if (stream && !ext_stream) orbg::release_stream(stream); stream = nullptr; ext_stream = false; }
+  void drop() { stage.release(); dev.release(); drop_stream(); }
+  ~PoScratch() { drop(); }
+};
+PoScratch& po_scratch() { static thread_local PoScratch sc; return sc; }
+}  // namespace
+
+// the calling thread's pose_optimize calls on `device` use the caller's stream from now on (NULL: the library's M stream again)
+extern "C" int pose_opt_set_stream(int device, void* hip_stream) {
+  int rc = select_device(device);
+  if (rc) return rc;
+  PoScratch& sc = po_scratch();
+  if (sc.device != device) { sc.drop(); sc.device = device; }
+  if (sc.stream) ORBG_HIP(hipStreamSynchronize(sc.stream));
+  sc.drop_stream();
+  if (hip_stream) { sc.stream = (hipStream_t)hip_stream; sc.ext_stream = true; }
+  return ORBG_OK;
+}
+
 extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   if (!p || !r || p->n < 0 || (p->n > 0 && (!p->Xw || !p->u || !p->v || !p->ur || !p->inv_sigma2 || !r->outlier))) return ORBG_BAD_ARG;
   if (p->n > kPoThreads * kPoMaxPer) return ORBG_CAP_EXCEEDED;
@@ -3856,18 +3914,11 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   for (int i = 0; i < 4; i++) { r->iters[i] = 0; r->chi2[i] = 0; }
   for (int i = 0; i < n; i++) r->outlier[i] = 0;
   if (n < 3) return ORBG_OK;                                  // S/Optimizer.cc:1180-1181
-  // one pinned staging block: inputs in, results out (a per-thread cache keeps the allocation across calls)
-  // per-thread scratch; the stream comes from the library's pool (common.hpp: role "po" = the null stream, which keeps the
-  // hardware queues of the extractor and local-BA streams to themselves; the library's own streams are non-blocking, so nothing
-  // of the agent synchronises with it implicitly); released when the thread exits
-  struct Scratch {
-    PinnedBuf<uint8_t> stage; DevBuf<uint8_t> dev; int device = -1; hipStream_t stream = nullptr; bool have_stream = false;
-    void drop() { stage.release(); dev.release(); if (have_stream) { orbg::release_stream(stream); stream = nullptr; have_stream = false; } }
-    ~Scratch() { drop(); }
-  };
-  static thread_local Scratch sc;
+  // one pinned staging block: inputs in, results out (a per-thread cache keeps the allocation across calls); the stream comes from
+  // the library's pool (common.hpp: role "po" = M, non-blocking like all of the library's streams) or from pose_opt_set_stream
+  PoScratch& sc = po_scratch();
   if (sc.device != p->device) { sc.drop(); sc.device = p->device; }
-  if (!sc.have_stream) { ORBG_HIP(orbg::create_stream(&sc.stream, "po")); sc.have_stream = true; }      // (the null stream is a null pointer)
+  if (!sc.stream) { ORBG_HIP(orbg::create_stream(&sc.stream, "po")); sc.ext_stream = false; }
   const size_t in_bytes = ((size_t)n * 7 * 4 + 15) & ~(size_t)15;
   const size_t out_off = in_bytes;
   const size_t out_bytes = sizeof(PoseQ) + 8 * sizeof(int) + 4 * sizeof(double) + (size_t)n + 64;
@@ -3914,7 +3965,7 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   ORBG_HIP(hipGetLastError());
   {
     bool got = false;
-    if (!getenv("ORBG_NO_POLL")) {
+    if (orbg::poll_allowed()) {
       timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
       for (unsigned spins = 0; !got; spins++) {
         if (*seq_word == (int)po_seq) { got = true; break; }

@@ -1554,10 +1554,22 @@ __host__ inline bool supports(int n) { return n >= 1 && make_geo(n).T <= 19; }
 
 struct Launch { const void* fn; size_t lds; bool wlds; bool cols; int threads; };
 
-__host__ inline Launch pick(int n) {
+// kernel-selection switches (A/B and test): the caller reads them once (lba_create) and hands them to pick() / launch()
+struct Switches {
+  bool tiles = false, t9_4w = false, w8 = false;
+  static Switches from_env() {
+    Switches s;
+    s.tiles = getenv("ORBG_LDLT_TILES") != nullptr; s.t9_4w = getenv("ORBG_LDLT_T9_4W") != nullptr; s.w8 = getenv("ORBG_LDLT_8W") != nullptr;
+    return s;
+  }
+};
+// dynamic LDS beyond 64 KB has to be allowed per kernel and per DEVICE: the owner of a device context (an lba handle) keeps one
+struct AttrCache { struct { const void* fn; size_t lds; } e[12] = {}; };
+
+__host__ inline Launch pick(int n, const Switches& sw) {
   const Geo g = make_geo(n);
   Launch L;
-  if (g.T <= kColT && !getenv("ORBG_LDLT_TILES")) {
+  if (g.T <= kColT && !sw.tiles) {
     L.fn = reinterpret_cast<const void*>(k_ldlt_cols); L.wlds = true; L.cols = true; L.threads = kThreads;
     L.lds = lds_doubles_cols(g) * sizeof(double);
     return L;
@@ -1565,8 +1577,8 @@ __host__ inline Launch pick(int n) {
   L.cols = false;
   L.threads = kThreads;
   // (9 tile rows: the 4-wavefront kernel is as fast as the 8-wavefront one, 39.5-42.7 vs 37.0-43.9 us; ORBG_LDLT_T9_4W=1 selects it)
-  if (g.T <= 9 && !getenv("ORBG_LDLT_T9_4W")) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
-  else if (getenv("ORBG_LDLT_8W")) {
+  if (g.T <= 9 && !sw.t9_4w) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
+  else if (sw.w8) {
     if (g.T <= 13) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<12, 4, false>); L.wlds = false; }
     else { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<24, 5, false>); L.wlds = false; }
   } else {
@@ -1581,10 +1593,12 @@ __host__ inline Launch pick(int n) {
 }
 
 // St: the bordered matrix as a tile image (see image_put_rhs / k_image_pad), x: solution, wglob: wglob_doubles() of scratch
-__host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st) {
-  const Launch L = pick(n);
-  // dynamic LDS beyond 64 KB has to be allowed per kernel, once (and again if a larger system comes along)
-  static struct { const void* fn; size_t lds; } attr[12] = {};
+__host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st, const Switches& sw,
+                                  AttrCache* cache) {
+  const Launch L = pick(n, sw);
+  // dynamic LDS beyond 64 KB has to be allowed per kernel, once per device (and again if a larger system comes along)
+  AttrCache local;
+  auto& attr = (cache ? cache : &local)->e;
   if (L.lds > 64 * 1024) {
     int w = 0;
     while (w < 11 && attr[w].fn && attr[w].fn != L.fn) w++;
@@ -1596,6 +1610,13 @@ __host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, d
   }
   void* args[] = {(void*)&n, (void*)&St, (void*)&x, (void*)&ok, (void*)&wglob};   // the column kernel ignores wglob
   return hipLaunchKernel(L.fn, dim3(1), dim3(L.threads), args, L.lds, st);
+}
+
+// stand-alone tools (tools/micro): one device, switches from the environment of the process
+__host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st) {
+  static const Switches sw = Switches::from_env();
+  static AttrCache cache;
+  return launch(n, St, x, ok, wglob, st, sw, &cache);
 }
 
 }  // namespace ldltm

@@ -910,6 +910,7 @@ struct orbm_frame {
   // streams busy: the runtime multiplexes streams onto a handful of hardware queues, and a search kernel that shares a queue
   // with the local BA's chain waits behind 48 us solves)
   hipStream_t own_stream = nullptr;
+  bool ext_stream = false;               // own_stream was handed in through orbm_frame_set_stream (never destroyed here)
   std::vector<uint8_t> claimed_buf;      // reusable host scratch of the serial commits
   std::vector<uint32_t> rot_entries;
   // octave / angle of the frame's keypoints in ordinary (cached) host memory: the serial commits index them at random,
@@ -1024,8 +1025,19 @@ extern "C" int orbm_frame_destroy(orbm_frame* f) {
   f->d_cell_start.release(); f->d_cell_items.release(); f->stage.release(); f->d_stage.release();
   f->d_counter.release(); f->list.release(); f->results.release(); f->sig.release(); f->h_kps_pin.release(); f->d_qflag.release(); f->d_blk_cnt.release(); f->d_slot_pt.release(); f->d_total.release(); f->h_slot_pt.release(); f->h_vis.release();
   for (auto& e : f->ev) if (e) (void)hipEventDestroy(e);
-  orbg::release_stream(f->own_stream);
+  if (!f->ext_stream) orbg::release_stream(f->own_stream);
   delete f;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_frame_set_stream(orbm_frame* f, void* hip_stream) {
+  if (!f) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const bool on_own = f->stream == f->own_stream;         // (a frame that views an extractor's features stays on that extractor's stream)
+  if (!on_own) ORBG_HIP(hipStreamSynchronize(f->stream));
+  if ((rc = orbg::swap_stream(&f->own_stream, &f->ext_stream, hip_stream, "fr"))) return rc;
+  if (on_own) f->stream = f->own_stream;
   return ORBG_OK;
 }
 
@@ -1199,16 +1211,18 @@ static int hamming_common(int device, const uint8_t* q, int nq, const uint8_t* t
   ORBG_HIP(hipMalloc((void**)&dq, (size_t)nq * 32));
   ORBG_HIP(hipMalloc((void**)&dt, (size_t)std::max(nt, 1) * 32));
   ORBG_HIP(hipMalloc((void**)&dout, std::max<size_t>(out_n, 1) * sizeof(int)));
-  ORBG_HIP(hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice));
-  if (nt > 0) ORBG_HIP(hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice));
+  orbg::MiscStream ms;                                 // the library's M stream (never the legacy null stream)
+  if ((rc = ms.open())) return rc;
+  ORBG_HIP(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ms.s));
+  if (nt > 0) ORBG_HIP(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ms.s));
   if (matrix) {
-    if (nt > 0) hipLaunchKernelGGL(hamming_matrix_kernel, dim3((nt + 255) / 256, (nq + 15) / 16), dim3(256), 0, 0, dq, nq, dt, nt, dout);
+    if (nt > 0) hipLaunchKernelGGL(hamming_matrix_kernel, dim3((nt + 255) / 256, (nq + 15) / 16), dim3(256), 0, ms.s, dq, nq, dt, nt, dout);
   } else {
-    hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + 3) / 4), dim3(256), 0, 0, dq, nq, dt, nt, dout);
+    hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + 3) / 4), dim3(256), 0, ms.s, dq, nq, dt, nt, dout);
   }
   ORBG_HIP(hipGetLastError());
-  ORBG_HIP(hipDeviceSynchronize());
-  if (out_n > 0) ORBG_HIP(hipMemcpy(out, dout, out_n * sizeof(int), hipMemcpyDeviceToHost));
+  if (out_n > 0) ORBG_HIP(hipMemcpyAsync(out, dout, out_n * sizeof(int), hipMemcpyDeviceToHost, ms.s));
+  ORBG_HIP(hipStreamSynchronize(ms.s));
   (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(dout);
   return ORBG_OK;
 }
@@ -1230,6 +1244,7 @@ struct orbm_map {
   DevBuf<uint8_t> arena;
   PinnedBuf<uint8_t> stage;
   hipStream_t stream = nullptr;
+  bool ext_stream = false;
   size_t o_pos = 0, o_normal = 0, o_min = 0, o_max = 0, o_desc = 0, o_bad = 0, o_skip = 0, arena_bytes = 0;
   std::vector<int> n_obs;
   std::vector<uint8_t> h_bad;
@@ -1278,13 +1293,20 @@ extern "C" int orbm_map_create(int device, int cap_points, orbm_map** out) {
   return ORBG_OK;
 }
 
+extern "C" int orbm_map_set_stream(orbm_map* m, void* hip_stream) {
+  if (!m) return ORBG_BAD_ARG;
+  int rc = select_device(m->device);
+  if (rc) return rc;
+  return orbg::swap_stream(&m->stream, &m->ext_stream, hip_stream, "map");
+}
+
 extern "C" int orbm_map_destroy(orbm_map* m) {
   if (!m) return ORBG_BAD_ARG;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   m->arena.release(); m->stage.release();
   if (m->up_ev) (void)hipEventDestroy(m->up_ev);
-  orbg::release_stream(m->stream);
+  if (!m->ext_stream) orbg::release_stream(m->stream);
   m->t_in_view.release(); m->t_px.release(); m->t_py.release(); m->t_pxr.release(); m->t_depth.release();
   m->t_vc.release(); m->t_level.release();
   delete m;

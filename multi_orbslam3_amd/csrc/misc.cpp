@@ -33,7 +33,7 @@ extern "C" int orbg_device_count(void) {
 namespace orbg {
 
 namespace {
-struct DevicePool { bool made = false; hipStream_t L = nullptr, E[2] = {nullptr, nullptr}; unsigned n_ex = 0, n_fr = 0; };
+struct DevicePool { bool made = false; hipStream_t L = nullptr, E[2] = {nullptr, nullptr}, M = nullptr; unsigned n_ex = 0, n_fr = 0; };
 std::mutex g_pool_mu;
 DevicePool g_pool[64];
 bool pool_enabled() { static const bool on = [] { const char* e = getenv("ORBG_STREAM_POOL"); return !(e && e[0] == '0'); }(); return on; }
@@ -49,6 +49,21 @@ hipError_t create_own(hipStream_t* st, const char* role) {
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
   return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio < 0 ? hi : lo);
 }
+
+// the four streams of a device, created together (g_pool_mu held)
+hipError_t make_pool(DevicePool& P) {
+  if (P.made) return hipSuccess;
+  hipStream_t s4[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < 4; i++) {
+    const hipError_t e = hipStreamCreateWithFlags(&s4[i], hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      for (int j = 0; j < i; j++) (void)hipStreamDestroy(s4[j]);
+      return e;
+    }
+  }
+  P.L = s4[0]; P.E[0] = s4[1]; P.E[1] = s4[2]; P.M = s4[3]; P.made = true;
+  return hipSuccess;
+}
 }  // namespace
 
 hipError_t create_stream(hipStream_t* st, const char* role) {
@@ -59,25 +74,17 @@ hipError_t create_stream(hipStream_t* st, const char* role) {
   if (dev < 0 || dev >= 64) return create_own(st, role);
   std::lock_guard<std::mutex> lk(g_pool_mu);
   DevicePool& P = g_pool[dev];
-  if (!P.made) {
-    hipStream_t s3[3] = {nullptr, nullptr, nullptr};
-    for (int i = 0; i < 3; i++)
-      if ((e = hipStreamCreateWithFlags(&s3[i], hipStreamNonBlocking)) != hipSuccess) {
-        for (int j = 0; j < i; j++) (void)hipStreamDestroy(s3[j]);
-        return e;
-      }
-    P.L = s3[0]; P.E[0] = s3[1]; P.E[1] = s3[2]; P.made = true;
-  }
+  if ((e = make_pool(P)) != hipSuccess) return e;
   if (!strcmp(role, "lba")) *st = P.L;
   else if (!strcmp(role, "ex")) *st = P.E[P.n_ex++ & 1];
   else if (!strcmp(role, "fr")) {
     // a frame's OWN stream (host-built frames: KeyFrames on the server, uploaded frames of the glue).  In a process with
     // extractors -- an agent -- E0 / E1 belong to the constructor chains and the searches of the tracking thread: other frames
-    // go to the null stream.  A process without extractors (the server's matcher threads) spreads its frames over all three.
+    // go to M.  A process without extractors (the server's matcher threads) spreads its frames over M, E0, E1.
     const unsigned k = P.n_ex ? 0 : P.n_fr++ % 3;
-    *st = k == 0 ? (hipStream_t) nullptr : P.E[k - 1];
+    *st = k == 0 ? P.M : P.E[k - 1];
   }
-  else *st = nullptr;                                   // the null stream (its explicit handle hipStreamLegacy crashes hipStreamWaitEvent on events recorded on it: ROCm 7.2)
+  else *st = P.M;                                       // "map", "po", "bow", "db", "misc"
   return hipSuccess;
 }
 
@@ -86,9 +93,17 @@ void release_stream(hipStream_t st) {
   if (pool_enabled()) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (const DevicePool& P : g_pool)
-      if (P.made && (st == P.L || st == P.E[0] || st == P.E[1])) return;
+      if (P.made && (st == P.L || st == P.E[0] || st == P.E[1] || st == P.M)) return;
   }
   (void)hipStreamDestroy(st);
+}
+
+bool is_library_stream(hipStream_t st) {
+  if (!st || !pool_enabled()) return false;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (const DevicePool& P : g_pool)
+    if (P.made && (st == P.L || st == P.E[0] || st == P.E[1] || st == P.M)) return true;
+  return false;
 }
 
 __global__ void orbg_signal_kernel(volatile unsigned* flag, unsigned seq) {
@@ -105,7 +120,7 @@ int StreamSignal::post(hipStream_t st) {
 }
 
 int StreamSignal::wait(hipStream_t st) {
-  if (!getenv("ORBG_NO_POLL")) {
+  if (poll_allowed()) {
     volatile unsigned* w = word.h;
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -164,7 +164,8 @@ class AgentGroup:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
-        self.backend = backend
+        self.data_backend = backend          # backend of the DATA plane (keyframe exchange); the control plane is gloo, always
+        self._data_group = None
         if self.world > 1 or force_group:
             import torch
             import torch.distributed as dist
@@ -172,25 +173,47 @@ class AgentGroup:
             os.environ.setdefault("MASTER_PORT", "29531")
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
-            self.backend = backend
+            self.data_backend = backend
             # Control plane (barriers around the timed region, MAX of the elapsed times, per-agent statistics) on gloo, always:
             # agents have no data-path collective, and an RCCL communicator in the process -- its streams and hardware queues --
             # costs an agent a third of its frame rate from the first barrier on (8400 -> 5450 frames/s with a 1-rank nccl group
             # that only ever ran barriers; csrc/common.hpp on hardware queues).  The RCCL group is the DATA plane of the server
-            # tick and is created by its first collective (data_group()).
+            # tick and is created by open_data_plane() -- a collective of its own, called by every rank before the first exchange.
             self._device_index = self.local_rank if device_index is None else device_index
             dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             self.dist = dist
             self._data_group = None
 
-    def data_group(self):
-        """The group of the data-path exchange (keyframe wire blocks): RCCL over xGMI for GPU tensors, created -- collectively --
-        by the first exchange; the default gloo group when the agents run on CPU tensors (tests)."""
-        if self.dist is None or self.backend != "nccl":
+    @property
+    def backend(self):                       # (kept for callers of the earlier name)
+        return self.data_backend
+
+    def open_data_plane(self):
+        """COLLECTIVE: creates the group of the data-path exchange (keyframe wire blocks) -- RCCL over xGMI when the data backend
+        is "nccl"; with "gloo" (CPU tests) the exchange uses the default group and this is a barrier.  Every rank must call it,
+        before its first exchange and outside any timed region (communicator set-up takes hundreds of milliseconds); the
+        exchanges themselves never create a group, so a rank that skips one exchange cannot hang the others in new_group."""
+        if self.dist is None:
             return None
-        if self._data_group is None:
+        if self.data_backend == "nccl" and self._data_group is None:
             import torch
             self._data_group = self.dist.new_group(backend="nccl", device_id=torch.device("cuda", self._device_index))
+        self.dist.barrier()
+        return self._data_group
+
+    def data_group(self, tensor=None):
+        """The group an exchange of `tensor` goes through: the RCCL group for GPU tensors (open_data_plane() must have been
+        called), the default gloo group for CPU tensors.  GPU tensors without an RCCL data plane are an error, not a silent
+        fall-through to gloo."""
+        if self.dist is None:
+            return None
+        on_gpu = tensor is not None and tensor.device.type == "cuda"
+        if not on_gpu:
+            return None
+        if self.data_backend != "nccl":
+            raise RuntimeError("GPU tensors need the nccl (RCCL) data plane; this group was created with data backend %r" % (self.data_backend,))
+        if self._data_group is None:
+            raise RuntimeError("call AgentGroup.open_data_plane() on every rank before the first keyframe exchange")
         return self._data_group
 
     def agent_seed(self, base):
@@ -248,13 +271,13 @@ class AgentGroup:
             return [(int(n_features), wire[: 47 * int(n_features)])]
         counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
         mine = torch.tensor([int(n_features)], dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(counts, mine, group=self.data_group() if dev.type == "cuda" else None)
+        self.dist.all_gather_into_tensor(counts, mine, group=self.data_group(mine))
         counts = [int(c) for c in counts.cpu()]
         pad = 47 * max(max(counts), 1)
         send = torch.zeros(pad, dtype=torch.uint8, device=dev)
         send[: 47 * int(n_features)] = wire[: 47 * int(n_features)]
         recv = torch.empty(self.world * pad, dtype=torch.uint8, device=dev)
-        self.dist.all_gather_into_tensor(recv, send, group=self.data_group() if dev.type == "cuda" else None)
+        self.dist.all_gather_into_tensor(recv, send, group=self.data_group(send))
         return [(counts[r], recv[r * pad: r * pad + 47 * counts[r]]) for r in range(self.world)]
 
     # ---- server tick: ONE collective per tick, whatever the number of ranks and of new keyframes
@@ -296,7 +319,7 @@ class AgentGroup:
         if self.dist is None:
             recv[:cap] = send
         else:
-            self.dist.all_gather_into_tensor(recv, send, group=self.data_group() if send.device.type == "cuda" else None)
+            self.dist.all_gather_into_tensor(recv, send, group=self.data_group(send))
         heads = recv.view(self.world, cap)[:, : self.TICK_HEADER_BYTES].cpu().numpy().view(np.int32)      # the tick's one read-back
         out = []
         for r in range(self.world):

@@ -915,6 +915,127 @@ def test_blocked_ldlt_is_deterministic_next_to_a_busy_gpu():
     torch.cuda.synchronize()
 
 
+def test_handles_run_on_caller_supplied_streams(scene):
+    """*_set_stream (include/orbgpu.h, "Streams"): every handle type takes the caller's hipStream_t instead of the library's pooled
+    stream, results are unchanged, the caller's stream is not destroyed with the handle, and NULL returns to the pool."""
+    import ctypes as C
+    import torch
+    lib = capi.load()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    sp = [C.c_void_p(s.cuda_stream) for s in streams]
+    L, R, _ = scene.stereo_pair(3)
+    p = scene.frame_view_params()
+    fv, keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
+    prob = synth.make_lba_problem(n_free=6, n_fixed=2, n_points=240, seed=31)
+    lp, keep2 = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    pr = synth.make_pose_opt_problem(n=300, outlier_frac=0.1, mono_frac=0.2, seed=9)
+    pp, keep3 = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"])
+    bf, b = float(scene.cam["bf"]), float(scene.cam["b"])
+
+    def run(own):
+        ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
+        F = api.Frame()
+        opt = api.Optimizer()
+        if own:
+            capi.check(lib.orbx_set_stream(ex.h, sp[0]), "orbx_set_stream")
+            capi.check(lib.orbm_frame_set_stream(F.h, sp[1]), "orbm_frame_set_stream")
+            capi.check(lib.lba_set_stream(opt.h, sp[2]), "lba_set_stream")
+            capi.check(lib.pose_opt_set_stream(0, sp[3]), "pose_opt_set_stream")
+        res = ex.frame_stereo(F, fv, L, R, bf, b)
+        kd, dd = F.download()[:2]
+        lo = opt.LocalBundleAdjustment(lp)
+        po = opt.PoseOptimization(pp)
+        if own:
+            # back to the pool and once more on the pool's streams
+            capi.check(lib.orbx_set_stream(ex.h, None), "orbx_set_stream")
+            capi.check(lib.lba_set_stream(opt.h, None), "lba_set_stream")
+            capi.check(lib.pose_opt_set_stream(0, None), "pose_opt_set_stream")
+            lo2 = opt.LocalBundleAdjustment(lp)
+            assert np.array_equal(lo2.poses, lo.poses)
+        out = ([np.asarray(x) for x in res], kd.copy(), dd.copy(), lo.poses.copy(), lo.iters, po.Tcw.copy(), np.asarray(po.outliers).copy())
+        ex.close(); F.close(); opt.close()
+        return out
+
+    a, bres = run(False), run(True)
+    for x, y in zip(a[0], bres[0]):
+        assert np.array_equal(x, y)
+    for i in (1, 2, 3, 5, 6):
+        assert np.array_equal(a[i], bres[i]), i
+    assert a[4] == bres[4]
+    for s in streams:              # the caller's streams are alive and usable after the handles are gone
+        with torch.cuda.stream(s):
+            t = torch.ones(16, device="cuda") * 2
+        s.synchronize()
+        assert float(t.sum()) == 32.0
+
+
+def test_fused_constructor_refuses_a_distorted_camera_view(scene):
+    """orbx_frame_stereo* feed mvKeys straight into the grid (mDistCoef[0] == 0, S/Frame.cc:723-727): a view whose image bounds are
+    not the image rectangle -- what ComputeImageBounds yields for a distorted camera, S/Frame.cc:753-773 -- is refused, not mis-gridded."""
+    L, R, _ = scene.stereo_pair(3)
+    p = scene.frame_view_params()
+    ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
+    F = api.Frame()
+    bf, b = float(scene.cam["bf"]), float(scene.cam["b"])
+    bad_bounds = (-21.7, 655.2, -14.3, 497.9)          # EuRoC-like undistorted corners
+    fv, keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, bad_bounds, p["cam"], 8, 1.2)
+    with pytest.raises(capi.OrbGpuError) as e:
+        ex.frame_stereo(F, fv, L, R, bf, b)
+    assert e.value.code == capi.ORBG_BAD_ARG
+    with pytest.raises(capi.OrbGpuError) as e:
+        ex.frame_stereo_submit(F, fv, L, R, bf, b, async_ingest=True)
+    assert e.value.code == capi.ORBG_BAD_ARG
+    fv2, keep2 = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
+    res = ex.frame_stereo(F, fv2, L, R, bf, b)          # the handle is still usable
+    assert res is not None
+
+
+def test_fused_solve_and_update_launch_is_deterministic_next_to_a_busy_gpu():
+    """The default local BA launch of windows of <= 20 free poses (k_ldlt_cols_update): workgroups 1..n wait for the word that
+    workgroup 0 publishes with an agent-scope release behind the solution x.  Three streams of large GEMMs keep every compute unit
+    busy while the solves run, so that the update workgroups are dispatched late, early, and on other XCDs than workgroup 0: results
+    must be the bits of the solve on an idle GPU and the oracle's to tolerance; a lost hand-over would hang (the subprocess has a
+    timeout) or change the trial state."""
+    code = (
+        "import numpy as np, torch\n"
+        "from multi_orbslam3_amd import api, synth, views\n"
+        "from oracle import binding as ob\n"
+        "probs = []\n"
+        "for nf, seed in [(20, 501), (20, 502), (13, 503), (6, 504)]:\n"
+        "    prob = synth.make_lba_problem(n_free=nf, n_fixed=10 if nf == 20 else 3, n_points=2000 if nf == 20 else 60 * nf, mono_frac=0.2, seed=seed)\n"
+        "    p, keep = views.lba_problem(prob['poses'], prob['pose_fixed'], prob['points'], prob['edges'], prob['cam'])\n"
+        "    probs.append((p, keep, ob.lba_solve(p)))\n"
+        "opt = api.Optimizer()\n"
+        "idle = []\n"
+        "for p, keep, o in probs:\n"
+        "    g = opt.LocalBundleAdjustment(p)\n"
+        "    assert g.status == o.status and g.iters == o.iters\n"
+        "    assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4\n"
+        "    assert np.array_equal(g.edge_outlier, o.edge_outlier)\n"
+        "    idle.append((g.iters, g.poses.copy(), g.points.copy(), g.trace_rows().copy()))\n"
+        "a = torch.randn(4096, 4096, device='cuda')\n"
+        "streams = [torch.cuda.Stream() for _ in range(3)]\n"
+        "n = 0\n"
+        "for rep in range(8):\n"
+        "    for st in streams:\n"
+        "        with torch.cuda.stream(st):\n"
+        "            b = a\n"
+        "            for _ in range(8):\n"
+        "                b = b @ a\n"
+        "    for (p, keep, o), (it, po, pt, tr) in zip(probs, idle):\n"
+        "        g = opt.LocalBundleAdjustment(p)\n"
+        "        assert g.iters == it, (rep, g.iters, it)\n"
+        "        assert np.array_equal(g.poses, po) and np.array_equal(g.points, pt), rep\n"
+        "        assert np.array_equal(g.trace_rows(), tr), rep\n"
+        "        n += 1\n"
+        "torch.cuda.synchronize()\n"
+        "print('fused busy ok', n)\n")
+    env = dict(os.environ, ORBG_FUSE_UPDATE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "fused busy ok 32" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 @pytest.mark.parametrize("W,H,nf", [(752, 480, 1200), (323, 241, 600)])
 def test_host_image_submit_on_other_image_shapes(W, H, nf):
     """orbx_frame_stereo_submit through the library's ingest thread on EuRoC / odd image shapes (an image size that is no multiple
@@ -1270,32 +1391,50 @@ def test_keyframe_wire_blocks_and_l1_score(scene):
     assert np.array_equal(g, o) and abs(g[-1] - 1.0) < 1e-12
 
 
-def test_completion_fallback_path_gives_same_results(scene, monkeypatch):
-    """ORBG_NO_POLL=1 switches every completion wait back to hipStreamSynchronize: results must not depend on the wait."""
-    L, R, _ = scene.stereo_pair(4)
-    p = scene.frame_view_params()
-    fv, keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
-    prob = synth.make_lba_problem(n_free=5, n_fixed=2, n_points=200)
-    lp, keep2 = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
-    pr = synth.make_pose_opt_problem(n=300, outlier_frac=0.1, mono_frac=0.2, seed=9)
-    pp, keep3 = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"])
+def test_completion_fallback_path_gives_same_results(tmp_path):
+    """ORBG_NO_POLL=1 switches every completion wait back to the runtime's blocking waits (the switch is read once per process, so
+    each form runs in a process of its own): results must not depend on the wait."""
+    code = (
+        "import sys, numpy as np\n"
+        "from multi_orbslam3_amd import _capi as capi, api, synth, views\n"
+        "scene = synth.Scene(640, 480)\n"
+        "L, R, _ = scene.stereo_pair(4)\n"
+        "p = scene.frame_view_params()\n"
+        "fv, keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p['bounds'], p['cam'], 8, 1.2)\n"
+        "prob = synth.make_lba_problem(n_free=5, n_fixed=2, n_points=200)\n"
+        "lp, keep2 = views.lba_problem(prob['poses'], prob['pose_fixed'], prob['points'], prob['edges'], prob['cam'])\n"
+        "pr = synth.make_pose_opt_problem(n=300, outlier_frac=0.1, mono_frac=0.2, seed=9)\n"
+        "pp, keep3 = views.pose_opt_problem(pr['Xw'], pr['u'], pr['v'], pr['ur'], pr['inv_sigma2'], pr['cam'], pr['Tcw'])\n"
+        "ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)\n"
+        "F = api.Frame()\n"
+        "res = ex.frame_stereo(F, fv, L, R, float(scene.cam['bf']), float(scene.cam['b']))\n"
+        "ex.frame_stereo_submit(F, fv, L, R, float(scene.cam['bf']), float(scene.cam['b']), async_ingest=True)\n"
+        "n2 = ex.frame_stereo_dev_wait()\n"
+        "opt = api.Optimizer()\n"
+        "lo = opt.LocalBundleAdjustment(lp)\n"
+        "opt.LocalBundleAdjustmentAsync(lp, views.LbaOutput(lp.n_poses, lp.n_points, lp.n_edges))\n"
+        "lo2 = opt.wait()\n"
+        "po = opt.PoseOptimization(pp)\n"
+        "out = {'r%d' % i: np.asarray(x) for i, x in enumerate(res)}\n"
+        "out.update(n2=np.asarray(n2), lba_poses=lo.poses, lba_iters=np.asarray(lo.iters), lba2_poses=lo2.poses, po_T=po.Tcw, po_out=np.asarray(po.outliers))\n"
+        "np.savez(sys.argv[1], **out)\n"
+        "print('ok')\n")
     outs = []
     for no_poll in (False, True):
+        env = dict(os.environ)
+        env.pop("ORBG_NO_POLL", None)
         if no_poll:
-            monkeypatch.setenv("ORBG_NO_POLL", "1")
-        else:
-            monkeypatch.delenv("ORBG_NO_POLL", raising=False)
-        ex = api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2)
-        F = api.Frame()
-        res = ex.frame_stereo(F, fv, L, R, float(scene.cam["bf"]), float(scene.cam["b"]))
-        opt = api.Optimizer()
-        lo = opt.LocalBundleAdjustment(lp)
-        po = opt.PoseOptimization(pp)
-        outs.append((res, lo.poses.copy(), lo.iters, po.Tcw.copy(), po.outliers))
+            env["ORBG_NO_POLL"] = "1"
+        f = str(tmp_path / ("poll%d.npz" % no_poll))
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+        outs.append(dict(np.load(f)))
     a, b = outs
-    for x, y in zip(a[0], b[0]):
-        assert np.array_equal(np.asarray(x), np.asarray(y))
-    assert np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["lba_poses"], a["lba2_poses"])
 
 
 def test_detect_n_best_candidates_parity():

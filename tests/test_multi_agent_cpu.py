@@ -93,6 +93,7 @@ EXCHANGE_WORKER = textwrap.dedent('''
     calls = []
     real = grp.dist.all_gather_into_tensor
     grp.dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    assert grp.open_data_plane() is None                  # gloo data plane: the default group (and a barrier on every rank)
     bufs = grp.tick_buffers(max_features=400, device="cpu", max_blocks=4)
     tick = grp.all_gather_keyframe_blocks(bufs, mine)
     tick2 = grp.all_gather_keyframe_blocks(bufs, mine[:1])          # the buffers are reused tick after tick

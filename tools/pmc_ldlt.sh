@@ -7,7 +7,7 @@ OUT="$GRAFT_REPO_ROOT/gpurun_out/pmc_ldlt"
 rm -rf "$OUT"; mkdir -p "$OUT"
 for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_ANY"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/$tag -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --lba-mode inline --no-pipeline > $OUT/$tag.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/$tag -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin --lba-mode inline --no-pipeline > $OUT/$tag.log 2>&1
   f=$(find $OUT/$tag -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python3 - "$f" <<'PY'

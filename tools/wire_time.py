@@ -32,6 +32,7 @@ print("from_wire %.1f us, search_sim3 %.1f us, both %.1f us (n=%d, m=%d)" % (5e3
 # the same through the one-collective tick (1-rank RCCL group)
 from multi_orbslam3_amd import harness
 grp = harness.AgentGroup("nccl", force_group=True)
+grp.open_data_plane()
 bufs = grp.tick_buffers(max_features=2048, device="cuda:0", max_blocks=8)
 blocks = [(n, w)] * 8
 def tick(nb, do_search=True, do_wire=True):
