@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "wave.hpp"
 #include "stereo_finalize.hpp"
+#include "grid_build.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -558,9 +559,18 @@ __device__ long long g_oct_prof[32][48];
 #define OCT_T(slot) do { } while (0)
 #endif
 
+// FROM_SLOTS (round 4, the default): the workgroup takes its candidates straight from fast_cells_kernel's per-cell slots -- the
+// cells of a (camera, level) are a contiguous run, cell-major order IS the candidate order -- instead of from the compacted list
+// gather_cells_kernel wrote (one launch less per constructor).  A thread owns a contiguous chunk of the level's cells: it requests
+// their counts and, in the same trip to memory, the first eight slot entries of each (most cells hold fewer); a workgroup scan of
+// the counts gives every cell its place in an LDS staging array (the not-yet-used second node list), the entries go there, and
+// the keys are then dealt to the threads from LDS exactly as they were from the compacted list.
+constexpr int kOctSpecCells = 4;     // cells per thread whose first entries are requested before their counts are known
+template <bool FROM_SLOTS>
 __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __restrict__ cand, const int* __restrict__ hdr,
                                                             PyrGeom g, OctCfg cfg, OctSel* __restrict__ sel_out,
-                                                            int* __restrict__ lvl_count, int* __restrict__ overflow, int cand_cap) {
+                                                            int* __restrict__ lvl_count, int* __restrict__ overflow, int cand_cap,
+                                                            const uint32_t* __restrict__ slots, const int* __restrict__ counts, int n_cells) {
   __shared__ uint4 node[2][kOctListCap];          // x0 | x1 << 16, y0 | y1 << 16, key count | creation number << 16, -
   __shared__ unsigned cc2[2][kOctListCap][2];     // children key counts, two u16 packed per word: [q>>1] >> 16*(q&1)
   __shared__ unsigned short child_pos[kOctListCap][4];
@@ -578,6 +588,60 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   const int N = cfg.n_target[level];
   int* out_count = lvl_count + cam * ORBG_MAX_LEVELS + level;
   if (L.cell_end == L.cell_begin) { if (tid == 0) *out_count = 0; return; }
+  uint32_t kw[kOctKPT];
+  unsigned kn[kOctKPT];
+  int nk;
+  if constexpr (FROM_SLOTS) {
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(&node[1][0]);     // 32 KB, first written by the first pass (behind barriers)
+    static_assert(sizeof(uint4) * kOctListCap >= sizeof(uint32_t) * kOctKeyCap, "staging does not fit the second node list");
+    const int nc = L.cell_end - L.cell_begin;
+    const int cpt = (nc + kOctThreads - 1) / kOctThreads;               // cells per thread (1-2 at 640 x 480, 4 at 1280 x 720)
+    const int c0 = min(tid * cpt, nc), c1 = min(c0 + cpt, nc);
+    const int* cnt_p = counts + (size_t)cam * n_cells + L.cell_begin;
+    const uint32_t* slot_p = slots + ((size_t)cam * n_cells + L.cell_begin) * kCellCap;
+    int cn[kOctSpecCells];
+    uint4 sp[kOctSpecCells][2];
+#pragma unroll
+    for (int q = 0; q < kOctSpecCells; q++) {
+      const int c = min(c0 + q, nc - 1);
+      cn[q] = cnt_p[c];
+      const uint4* row = reinterpret_cast<const uint4*>(slot_p + (size_t)c * kCellCap);
+      sp[q][0] = row[0]; sp[q][1] = row[1];
+    }
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < kOctSpecCells; q++) { if (c0 + q >= c1) cn[q] = 0; mine += cn[q]; }
+    for (int c = c0 + kOctSpecCells; c < c1; c++) mine += cnt_p[c];     // (images with more than 1024 cells per level)
+    int total;
+    int base = oct_block_excl(mine, &total, wsum[3]);
+    nk = total;
+    if (nk <= 0) { if (tid == 0) *out_count = 0; return; }
+    if (nk > kOctKeyCap || 4 * N + 8 > kOctListCap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
+#pragma unroll
+    for (int q = 0; q < kOctSpecCells; q++) {
+      const int n_c = cn[q];
+      if (n_c > 0) {
+        const uint32_t e8[8] = {sp[q][0].x, sp[q][0].y, sp[q][0].z, sp[q][0].w, sp[q][1].x, sp[q][1].y, sp[q][1].z, sp[q][1].w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j < n_c) stage[base + j] = e8[j];
+        if (n_c > 8) {
+          const uint32_t* row = slot_p + (size_t)(c0 + q) * kCellCap;
+          for (int j = 8; j < n_c; j++) stage[base + j] = row[j];
+        }
+        base += n_c;
+      }
+    }
+    for (int c = c0 + kOctSpecCells; c < c1; c++) {
+      const int n_c = cnt_p[c];
+      const uint32_t* row = slot_p + (size_t)c * kCellCap;
+      for (int j = 0; j < n_c; j++) stage[base + j] = row[j];
+      base += n_c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kOctKPT; m++) kw[m] = stage[min(tid + kOctThreads * m, nk - 1)];
+    // (the first pass writes node[1] only behind the barriers of the root set-up below)
+  } else {
   // candidate range of this (camera, level): next level that has cells, or the camera end.  Both header words come from ONE
   // fetch (lane l reads word l of the 2 x 16 + 3 word header; picking them by two dependent loads cost a memory round trip more)
   static_assert(2 * ORBG_MAX_LEVELS + 3 <= 64, "header does not fit one wavefront-wide load");
@@ -586,16 +650,15 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   while (nlv < cfg.n_levels && g.lv[nlv].cell_end == g.lv[nlv].cell_begin) nlv++;
   const int cb = __builtin_amdgcn_readlane(hword, cam * ORBG_MAX_LEVELS + level);
   const int ce = __builtin_amdgcn_readlane(hword, nlv < cfg.n_levels ? cam * ORBG_MAX_LEVELS + nlv : 2 * ORBG_MAX_LEVELS + 1 + cam);
-  const int nk = ce - cb;
+  nk = ce - cb;
   if (nk <= 0) { if (tid == 0) *out_count = 0; return; }
   // ce > cand_cap: gather_cells_kernel dropped the tail of the list, the host path regrows the buffer and redoes the frame
   if (nk > kOctKeyCap || 4 * N + 8 > kOctListCap || ce > cand_cap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
   // ---- this thread's keys: k = tid, tid + 256, ...  (kw: x | y << 12 | response << 24;  kn: list position | quadrant << 16 |
   // "its node is being split" << 18)
-  uint32_t kw[kOctKPT];
-  unsigned kn[kOctKPT];
 #pragma unroll
   for (int m = 0; m < kOctKPT; m++) kw[m] = cand[cb + min(tid + kOctThreads * m, nk - 1)];
+  }
   const int minB = kEdge - 3;
   const int W = (L.w - kEdge + 3) - minB, H = (L.h - kEdge + 3) - minB;   // maxX-minX, maxY-minY
   int nIni = (int)roundf((float)W / (float)H);
@@ -1138,13 +1201,13 @@ __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const 
 
 // One wavefront per left keypoint: lanes sweep all right keypoints (row band + octave + disparity gates,
 // Hamming, wavefront min on the (dist, iR) key = "first minimum wins"), then the 11x11 SAD over 11 offsets.
-__global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
-                                                          const orbx_keypoint* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
-                                                          const orbx_keypoint* kr, const uint8_t* dr, int nr,
-                                                          float bf, float b, float* __restrict__ uright, float* __restrict__ depth,
-                                                          int* __restrict__ best_sad, const int* __restrict__ d_nkp) {
+// the wavefront's left keypoint iL (one wavefront per keypoint; no LDS, no barriers)
+__device__ __forceinline__ void stereo_match_wave(const int iL, const uint8_t* __restrict__ pyr, const PyrGeom& g,
+                                                  const orbx_keypoint* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
+                                                  const orbx_keypoint* kr, const uint8_t* dr, int nr,
+                                                  float bf, float b, float* __restrict__ uright, float* __restrict__ depth,
+                                                  int* __restrict__ best_sad, const int* __restrict__ d_nkp) {
   const int lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d_nkp) {        // counts produced on the device (GPU quad-tree path): right camera starts behind the left one
     nl = d_nkp[0]; nr = d_nkp[1];
     kr = kl + nl; dr = dl + (size_t)nl * 32;
@@ -1237,6 +1300,69 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
     }
   }
   if (lane == 0) { uright[iL] = out_u; depth[iL] = out_d; best_sad[iL] = out_sad; }
+}
+
+__global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
+                                                          const orbx_keypoint* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
+                                                          const orbx_keypoint* kr, const uint8_t* dr, int nr,
+                                                          float bf, float b, float* __restrict__ uright, float* __restrict__ depth,
+                                                          int* __restrict__ best_sad, const int* __restrict__ d_nkp) {
+  stereo_match_wave(blockIdx.x * 4 + (threadIdx.x >> 6), pyr, g, kl, dl, nl, kr, dr, nr, bf, b, uright, depth, best_sad, d_nkp);
+}
+
+// Tail of the fused stereo Frame constructor as ONE launch of 1024-thread workgroups (round 4; before: stereo_match_kernel, then
+// grid_build_finalize_kernel):
+//   workgroups 0 .. n_match-1   ComputeStereoMatches, 16 left keypoints each (one wavefront per keypoint)
+//   workgroup  n_match          the feature grid of the left image (it needs the keypoints only: independent of the matching)
+// The match workgroups take a ticket when their results are out; the one that takes the LAST ticket runs the median rejection
+// (S/Frame.cc:949-962: it needs every match) on its first four wavefronts.  That workgroup and the grid workgroup then take the
+// constructor's two-party ticket; whoever is second posts the completion word the host spins on.
+// Hand-over through device memory between workgroups on different XCDs: every wavefront drains its own stores (vmcnt(0)) before
+// the workgroup barrier, thread 0 then takes the ticket with an agent-scope acq_rel (L2 write-back in front of it, invalidate
+// behind it); the rejection mirrors its result into pinned host memory, so its workgroup releases to system scope before the
+// second ticket.
+constexpr int kSgThreads = 1024;
+__global__ __launch_bounds__(kSgThreads) void stereo_grid_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
+                                                                 const orbx_keypoint* __restrict__ kl, const uint8_t* __restrict__ dl, int nl_bound,
+                                                                 float bf, float b, float* __restrict__ uright, float* __restrict__ depth,
+                                                                 int* __restrict__ best_sad, const int* __restrict__ d_nkp, int n_match,
+                                                                 orbg::GridLaunchArgs ga, volatile unsigned* done_flag, unsigned done_seq,
+                                                                 float* __restrict__ host_mirror, unsigned* __restrict__ tickets /*[0] match, [1] final*/) {
+  __shared__ int s_last;
+  bool second_party = false;
+  if ((int)blockIdx.x == n_match) {
+    orbg::grid_build_body(ga.kps, ga.fp, ga.cell_of, ga.cell_start, ga.cell_items, d_nkp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    second_party = true;
+  } else {
+    stereo_match_wave(blockIdx.x * (kSgThreads / 64) + (threadIdx.x >> 6), pyr, g, kl, dl, nl_bound, nullptr, nullptr, 0, bf, b, uright, depth,
+                      best_sad, d_nkp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // RELEASE only: an acquire here would invalidate this XCD's L2 under the match workgroups that are still running on it;
+      // the one workgroup that goes on to read the others' results acquires below
+      const unsigned before = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = before == (unsigned)(n_match - 1);
+      if (s_last) __hip_atomic_store(&tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x >= 256) return;              // (whole wavefronts leave: the barriers below count the four that stay)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    stereo_finalize_body(uright, depth, best_sad, nl_bound, d_nkp, host_mirror);
+    __threadfence_system();
+    __syncthreads();
+    second_party = true;
+  }
+  if (second_party && threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add(&tickets[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == 1u) {
+      __hip_atomic_store(&tickets[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done_flag) *done_flag = done_seq;
+    }
+  }
 }
 
 // (stereo_finalize_body: stereo_finalize.hpp)
@@ -1486,6 +1612,8 @@ class WorkerPool {
 // ------------------------------------------------------------------------------------------------
 // handle
 
+static const bool g_oct_gather = getenv("ORBG_OCT_GATHER") && atoi(getenv("ORBG_OCT_GATHER")) != 0;
+static const bool g_ctor_split_tail = getenv("ORBG_CTOR_SPLIT_TAIL") && atoi(getenv("ORBG_CTOR_SPLIT_TAIL")) != 0;
 static inline double host_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec; }
 // Measured on MI355X / ROCm 7.2: hipGraphLaunch of the constructor chain costs the host what its launches cost: off unless asked for
 static const bool g_ctor_graph = getenv("ORBG_CTOR_GRAPH") && atoi(getenv("ORBG_CTOR_GRAPH")) != 0;
@@ -1549,6 +1677,8 @@ struct orbx_handle {
   // host images (orbx_frame_stereo_submit / orbx_frame_stereo / orbx_extract*): one pinned staging slot per handle -- a handle
   // has one submission in flight, and the slot is free again when that submission has been waited for
   PinnedBuf<uint8_t> h_img;
+  PinnedBuf<unsigned> up_ready;                // [0] "second image packed" word of img_upload_pair_kernel, [8] its error word
+  unsigned up_seq = 0;
   std::atomic<int> ingest_state{0};            // 0 idle, 1 handed to the ingest thread, 2 submitted by it (ingest_rc valid)
   int ingest_rc = 0;
   // host-side timeline of the last submissions (orbx_get_ctor_timeline): per submission, microseconds
@@ -1850,7 +1980,7 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   while (h->ingest_state.load(std::memory_order_acquire) == 1) std::this_thread::yield();   // an asynchronous submission is being enqueued
   (void)hipStreamSynchronize(h->stream);
   ctor_graph_free(h->cgraph);
-  h->d_pyr.release(); h->d_img.release(); h->h_img.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_tower_x.release(); h->d_tower_y.release(); h->d_cells.release();
+  h->d_pyr.release(); h->d_img.release(); h->h_img.release(); h->up_ready.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_tower_x.release(); h->d_tower_y.release(); h->d_cells.release();
   h->d_slots.release(); h->d_counts.release(); h->hdr.release(); h->cand.release(); h->sel.release();
   h->d_kps.release(); h->d_desc.release(); h->h_kps.release(); h->h_desc.release();
   h->d_uright.release(); h->d_depth.release(); h->d_sad.release(); h->h_stereo.release();
@@ -1907,6 +2037,7 @@ struct ExtractPending {
   int n_res[2] = {0, 0};
 };
 static void delete_pending(ExtractPending* p) { delete p; }
+int orbm_internal_attach_prepare(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, hipStream_t stream, orbg::GridLaunchArgs* out);   // matcher.hip
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
                          volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin);
 void orbm_internal_set_n(orbm_frame* f, int n);
@@ -1987,6 +2118,9 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   const bool want_desc = desc_out[0] || desc_out[1];
   const bool do_stereo = use_gpu && post && post->stereo && ncams == 2;
   const bool stereo_out = do_stereo && (post->uright || post->depth);
+  // stereo matching, median rejection, feature grid and the completion word as ONE launch (stereo_grid_kernel) when a device frame
+  // is built; ORBG_CTOR_SPLIT_TAIL=1 keeps the two launches of round 3 (stereo_match_kernel, grid_build_finalize_kernel)
+  const bool fused_tail = do_stereo && post->frame && h->sel_bound > 0 && !g_ctor_split_tail;
   OctCfg oc = h->octcfg;
   oc.n_cams = ncams;                          // cameras processed by THIS call (a rig handle may extract one image)
   const uint8_t* const img1 = d_img1 ? d_img1 : d_img0;
@@ -2017,14 +2151,21 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       hipLaunchKernelGGL(fast_cells_kernel, dim3(8 * ((n_cells + 7) / 8), ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
                          std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
       if (br1(ORBX_PROF_FAST)) return ORBG_HIP_ERROR;
-      hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
-                         h->d_cells.p, n_cells, ncams, use_gpu ? h->d_hdr.p : h->hdr.d, use_gpu ? h->d_cand.p : h->cand.d, h->cand_cap);
+      // the GPU quad-trees take the candidates from the per-cell slots themselves (octree_kernel<true>): the compacted list is only
+      // built for the host quad-trees (and, on demand, for orbx_get_candidates); ORBG_OCT_GATHER=1: the round-3 chain
+      if (!use_gpu || g_oct_gather)
+        hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
+                           h->d_cells.p, n_cells, ncams, use_gpu ? h->d_hdr.p : h->hdr.d, use_gpu ? h->d_cand.p : h->cand.d, h->cand_cap);
     }
     if (use_gpu) {
       // ---- everything stays on the device: quad-trees -> descriptors -> (stereo, grid) -> ONE synchronisation
       if (br0(ORBX_PROF_OCTREE)) return ORBG_HIP_ERROR;
-      hipLaunchKernelGGL(octree_kernel, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
-                         h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap);
+      if (g_oct_gather)
+        hipLaunchKernelGGL(octree_kernel<false>, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
+                           h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap, h->d_slots.p, h->d_counts.p, n_cells);
+      else
+        hipLaunchKernelGGL(octree_kernel<true>, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
+                           h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap, h->d_slots.p, h->d_counts.p, n_cells);
       if (br1(ORBX_PROF_OCTREE)) return ORBG_HIP_ERROR;
       if (br0(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
       auto launch_od = [&](auto kern) {
@@ -2036,7 +2177,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       else if (h->taps_variant == 1) launch_od(orient_desc_gpu_kernel<1>);
       else launch_od(orient_desc_gpu_kernel<2>);
       if (br1(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
-      if (do_stereo) {
+      if (do_stereo && !fused_tail) {
         // with a device frame to build, the median rejection runs as the second workgroup of the grid build (one launch less)
         StereoFinalizeArgs unused;
         const int rcs = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr,
@@ -2119,10 +2260,23 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
         if ((rc = h->sig.arm(&seq, &flag))) return rc;
         StereoFinalizeArgs fin{};
         const bool with_fin = do_stereo && h->sel_bound > 0;
-        if (with_fin)
-          fin = StereoFinalizeArgs{h->d_uright.p, h->d_depth.p, h->d_sad.p, h->sel_bound, h->d_nkp.p, stereo_out ? h->h_stereo.d : nullptr,
-                                   reinterpret_cast<unsigned*>(h->d_overflow.p + 2)};
-        if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq, with_fin ? &fin : nullptr))) return rc;
+        if (fused_tail) {
+          const int nlb = h->sel_bound;
+          if (nlb >= ORBG_MAX_FRAME_FEATURES || orbx_internal_kp_capacity(h) >= 2 * ORBG_MAX_FRAME_FEATURES) return ORBG_CAP_EXCEEDED;
+          orbg::GridLaunchArgs ga;
+          if ((rc = orbm_internal_attach_prepare(post->frame, h, post->view, st, &ga))) return rc;
+          if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[5], st));
+          const int n_match = (nlb + kSgThreads / 64 - 1) / (kSgThreads / 64);
+          hipLaunchKernelGGL(stereo_grid_kernel, dim3(n_match + 1), dim3(kSgThreads), 0, st, h->d_pyr.p, h->geom, h->d_kps.p, h->d_desc.p, nlb,
+                             post->bf, post->b, h->d_uright.p, h->d_depth.p, h->d_sad.p, h->d_nkp.p, n_match, ga, flag, seq,
+                             stereo_out ? h->h_stereo.d : (float*)nullptr, reinterpret_cast<unsigned*>(h->d_overflow.p + 2));
+          if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[6], st));
+        } else {
+          if (with_fin)
+            fin = StereoFinalizeArgs{h->d_uright.p, h->d_depth.p, h->d_sad.p, h->sel_bound, h->d_nkp.p, stereo_out ? h->h_stereo.d : nullptr,
+                                     reinterpret_cast<unsigned*>(h->d_overflow.p + 2)};
+          if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq, with_fin ? &fin : nullptr))) return rc;
+        }
         posted = true;
       }
     }
@@ -2283,6 +2437,43 @@ __global__ __launch_bounds__(256) void img_upload_kernel(const uint4* __restrict
 }
 static const bool g_img_runtime_copy = getenv("ORBG_IMG_RUNTIME_COPY") != nullptr;
 
+// Round 4: ONE copy kernel per stereo constructor, launched when the FIRST image is in the staging slot.  Its first workgroups copy
+// that image at once; the others belong to the second image: their first thread polls one word in pinned memory, which the host
+// writes (the submission's sequence number) when the second image is packed, and then they copy -- four 16-byte blocks per thread,
+// every read in flight before the first store.  The word is written once, behind the pack, and is the only host memory the device
+// reads while the host is still packing (a first form that polled a word per 38 KB chunk from a kernel launched before the pack was
+// measured at 64 us per pair: the device's reads of lines the host was writing slowed the pack itself to 21-47 us).  A poll that does
+// not see its word within ~100 ms (the packing thread died) raises the handle's error word instead of hanging the device.
+constexpr int kUpThreads = 256, kUpPerThread = 4;
+__global__ __launch_bounds__(kUpThreads) void img_upload_pair_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int first16, int total16,
+                                                                     int wg_first, const unsigned* ready, unsigned seq, unsigned* err) {
+  __shared__ int s_ok;
+  int b0, b1, wg;
+  if ((int)blockIdx.x < wg_first) { b0 = 0; b1 = first16; wg = blockIdx.x; }
+  else {
+    b0 = first16; b1 = total16; wg = blockIdx.x - wg_first;
+    if (threadIdx.x == 0) {
+      int ok = 0;
+      for (int spin = 0; spin < (1 << 16); spin++) {
+        if (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (!ok) __hip_atomic_store(err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // (system scope: the image is read after the word)
+  }
+  const int i0 = b0 + (wg * kUpPerThread) * kUpThreads + (int)threadIdx.x;
+  uint4 v[kUpPerThread];
+#pragma unroll
+  for (int q = 0; q < kUpPerThread; q++) { const int i = i0 + q * kUpThreads; if (i < b1) v[q] = src[i]; }
+#pragma unroll
+  for (int q = 0; q < kUpPerThread; q++) { const int i = i0 + q * kUpThreads; if (i < b1) dst[i] = v[q]; }
+}
+static const bool g_img_two_uploads = getenv("ORBG_IMG_TWO_UPLOADS") != nullptr;     // A/B switch: the round-3 form (one copy kernel per image, after its pack)
+
 // a submitted Frame constructor owns the handle (stream, staging slot, pyramid, feature buffers) until it has been waited for
 static inline bool handle_busy(const orbx_handle* h) {
   return h->ingest_state.load(std::memory_order_acquire) != 0 || (h->pending && (h->pending->active || h->pending->finished));
@@ -2298,12 +2489,39 @@ static int stage_images(orbx_handle* h, const uint8_t* const* images, int n_img,
   }
   int rc;
   if ((rc = h->h_img.reserve(total + 16)) || (rc = h->d_img.reserve(total + 16))) return rc;
+  if (!g_img_two_uploads && n_img == 2) {
+    if ((rc = h->up_ready.reserve(16))) return rc;
+    if (!h->up_seq) memset(h->up_ready.h, 0, 16 * sizeof(unsigned));
+    const unsigned seq = ++h->up_seq;
+    // blocks of 16 bytes: the first image's blocks end at the block that holds its last byte; that block (shared with the second
+    // image when the image size is no multiple of 16) belongs to the SECOND range, which is copied once both images are packed
+    const int first16 = (int)(per / 16), total16 = (int)((total + 15) / 16);
+    const int per_wg = kUpThreads * kUpPerThread;
+    const int wg_first = (first16 + per_wg - 1) / per_wg, wg_second = (total16 - first16 + per_wg - 1) / per_wg;
+    double tp0 = host_now_us();
+    auto pack = [&](int c) {
+      uint8_t* dst = h->h_img.h + c * per;
+      if (stride == w) memcpy(dst, images[c], per);
+      else for (int y = 0; y < hgt; y++) memcpy(dst + (size_t)y * w, images[c] + (size_t)y * stride, w);
+    };
+    pack(0);
+    h->tl_pack_acc += host_now_us() - tp0;
+    hipLaunchKernelGGL(img_upload_pair_kernel, dim3(wg_first + wg_second), dim3(kUpThreads), 0, h->stream, reinterpret_cast<const uint4*>(h->h_img.d),
+                       reinterpret_cast<uint4*>(h->d_img.p), first16, total16, wg_first, h->up_ready.d, seq, h->up_ready.d + 8);
+    ORBG_HIP(hipGetLastError());
+    tp0 = host_now_us();
+    pack(1);
+    __atomic_store_n(&h->up_ready.h[0], seq, __ATOMIC_RELEASE);
+    h->tl_pack_acc += host_now_us() - tp0;
+    return ORBG_OK;
+  }
   // one copy kernel per image, launched as soon as that image is packed: the device copies the left image while the host packs the
   // right one.  A launch moves the 16-byte blocks that cover its image: the few bytes it shares with a neighbour's blocks are either
   // already staged (the image before) or rewritten by the next launch (the image after), which runs behind it on the stream.
   for (int c = 0; c < n_img; c++) {
     uint8_t* dst = h->h_img.h + c * per;
     const double tp0 = host_now_us();
+    // (non-temporal stores were measured, round 4: under memory pressure from the same L3 slice 106 vs 112 us per pair, quiet 16.9 vs 16.9)
     if (stride == w) memcpy(dst, images[c], per);
     else for (int y = 0; y < hgt; y++) memcpy(dst + (size_t)y * w, images[c] + (size_t)y * stride, w);
     h->tl_pack_acc += host_now_us() - tp0;
@@ -2659,6 +2877,15 @@ extern "C" int orbx_get_candidates(orbx_handle* h, int cam, int level, int32_t* 
     // device-resident candidate list of the last extraction: fetch and decode on demand
     int rc = select_device(h->device);
     if (rc) return rc;
+    if (!g_oct_gather && !h->cells.empty()) {
+      // the constructor chain no longer builds the compacted list (the quad-trees read the per-cell slots): build it now from the
+      // slots of the last extraction, which stay valid until the next one
+      const int ncams = h->cfg.n_cams, n_cells = (int)h->cells.size();
+      hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, h->stream, h->d_slots.p, h->d_counts.p, h->geom,
+                         h->d_cells.p, n_cells, ncams, h->d_hdr.p, h->d_cand.p, h->cand_cap);
+      ORBG_HIP(hipGetLastError());
+      ORBG_HIP(hipStreamSynchronize(h->stream));
+    }
     std::vector<int> hdr(2 * ORBG_MAX_LEVELS + 4);
     ORBG_HIP(hipMemcpy(hdr.data(), h->d_hdr.p, hdr.size() * sizeof(int), hipMemcpyDeviceToHost));
     const PyrGeom& g = h->geom;
@@ -2687,6 +2914,8 @@ static int extract_finish_gpu(orbx_handle* h, ExtractPending& c) {
   int rc;
   hipStream_t st = h->stream;
   if ((rc = h->sig.wait(st))) return rc;            // the overflow flag came with the keypoint counts
+  // (img_upload_pair_kernel gave up waiting for the host's pack: the images never reached the device)
+  if (h->up_seq && h->up_ready.h && h->up_ready.h[8] == h->up_seq) return ORBG_INTERNAL;
   const PostOps* post = c.has_post ? &c.post : nullptr;
   if (h->h_nkp.h[2]) {
     // a level had more candidates / nodes than the LDS-resident quad-tree holds: redo this frame with the host trees

@@ -1,0 +1,121 @@
+// Shared by matcher.hip and extractor.hip: the frame parameters a kernel reads and the feature grid build
+// (Frame::AssignFeaturesToGrid / PosInGrid, S/Frame.cc:360-391,699-709; CSR, cell = ix*48+iy) as a 1024-thread workgroup body.
+// matcher.hip launches it as a kernel of its own (host-built frames); extractor.hip runs it as one more workgroup of the stereo
+// match launch of the fused Frame constructor (stereo_grid_kernel).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/orbgpu.h"
+#include "wave.hpp"
+
+namespace orbg {
+
+constexpr int kCells = ORBG_GRID_COLS * ORBG_GRID_ROWS;
+constexpr int kGridLdsItems = 4096;
+
+struct FrameParams {
+  int n;
+  float min_x, max_x, min_y, max_y;
+  float w_inv, h_inv;               // mfGridElementWidthInv / HeightInv (S/Frame.cc:127-144)
+  float fx, fy, cx, cy, bf, b;
+  int n_levels;
+  float log_sf;
+  float scale[ORBG_MAX_LEVELS];
+};
+
+
+__device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict__ kps, FrameParams fp,
+                                                int* __restrict__ cell_of, int* __restrict__ cell_start,
+                                                int* __restrict__ cell_items, const int* __restrict__ d_n) {
+  __shared__ int cnt[kCells];
+  __shared__ int s_items[kGridLdsItems];   // cell_items staged in LDS (frames of up to kGridLdsItems features): fill + per-cell
+                                           // sort without a global-memory round trip per step
+  if (d_n) fp.n = *d_n;               // feature count produced on the device (GPU quad-tree path)
+  __shared__ int wsum[16];
+  __shared__ int s_total;
+  const int tid = threadIdx.x;
+  const bool in_lds = fp.n <= kGridLdsItems;
+  for (int c = tid; c < kCells; c += 1024) cnt[c] = 0;
+  __syncthreads();
+  int my_cell[kGridLdsItems / 1024];     // cells of this thread's features (register copy; cell_of[] is still written for the API)
+#pragma unroll
+  for (int q = 0; q < kGridLdsItems / 1024; q++) my_cell[q] = -1;
+  for (int i = tid, q = 0; i < fp.n; i += 1024, q++) {
+    const int px = (int)roundf((kps[i].x - fp.min_x) * fp.w_inv);
+    const int py = (int)roundf((kps[i].y - fp.min_y) * fp.h_inv);
+    int c = -1;
+    if (!(px < 0 || px >= ORBG_GRID_COLS || py < 0 || py >= ORBG_GRID_ROWS)) {
+      c = px * ORBG_GRID_ROWS + py;
+      atomicAdd(&cnt[c], 1);
+    }
+    cell_of[i] = c;
+#pragma unroll
+    for (int z = 0; z < kGridLdsItems / 1024; z++) if (z == q) my_cell[z] = c;
+  }
+  __syncthreads();
+  // exclusive scan of 3072 counts: 3 per thread
+  const int c0 = tid * 3;
+  const int a = cnt[c0], b = cnt[c0 + 1], c = cnt[c0 + 2];
+  const int lane = tid & 63, wave = tid >> 6;
+  const int inc = wave_incl_scan_add(a + b + c);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  const int excl = base + inc - (a + b + c);
+  cell_start[c0] = excl; cell_start[c0 + 1] = excl + a; cell_start[c0 + 2] = excl + a + b;
+  if (tid == 1023) { cell_start[kCells] = excl + a + b + c; s_total = excl + a + b + c; }
+  __syncthreads();
+  const int n_items = s_total;
+  cnt[c0] = excl; cnt[c0 + 1] = excl + a; cnt[c0 + 2] = excl + a + b;   // running fill cursors
+  __syncthreads();
+  if (in_lds) {
+#pragma unroll
+    for (int q = 0; q < kGridLdsItems / 1024; q++) {
+      const int i = tid + 1024 * q;
+      if (i < fp.n && my_cell[q] >= 0) s_items[atomicAdd(&cnt[my_cell[q]], 1)] = i;
+    }
+    __syncthreads();
+    // restore insertion (= keypoint index) order inside every cell
+    for (int q = 0; q < 3; q++) {
+      const int cc = c0 + q;
+      const int s0 = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
+      const int e = cnt[cc];
+      for (int i = s0 + 1; i < e; i++) {
+        const int key = s_items[i];
+        int j = i - 1;
+        while (j >= s0 && s_items[j] > key) { s_items[j + 1] = s_items[j]; j--; }
+        s_items[j + 1] = key;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_items; i += 1024) cell_items[i] = s_items[i];
+    return;
+  }
+  for (int i = tid; i < fp.n; i += 1024) {
+    const int cc = cell_of[i];
+    if (cc >= 0) cell_items[atomicAdd(&cnt[cc], 1)] = i;
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int q = 0; q < 3; q++) {
+    const int cc = c0 + q;
+    const int s0 = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
+    const int e = cnt[cc];
+    for (int i = s0 + 1; i < e; i++) {
+      const int key = cell_items[i];
+      int j = i - 1;
+      while (j >= s0 && cell_items[j] > key) { cell_items[j + 1] = cell_items[j]; j--; }
+      cell_items[j + 1] = key;
+    }
+  }
+}
+
+
+// What extractor.hip needs to launch the grid build of a frame next to its own kernels (filled by orbm_internal_attach_prepare)
+struct GridLaunchArgs {
+  const orbx_keypoint* kps; FrameParams fp; int* cell_of; int* cell_start; int* cell_items;
+};
+
+}  // namespace orbg

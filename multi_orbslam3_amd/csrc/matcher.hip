@@ -29,24 +29,13 @@ using namespace orbg;
 int orbx_internal_left_features(orbx_handle* h, const orbx_keypoint** d_kps, const uint8_t** d_desc, const float** d_uright,
                                 const float** d_depth, const orbx_keypoint** h_kps, int* n, hipStream_t* stream);
 
+#include "grid_build.hpp"
+
 namespace {
 
 constexpr int TH_HIGH = 100;      // S/ORBmatcher.cc:36
 constexpr int TH_LOW = 50;        // :37
 constexpr int HISTO_LENGTH = 30;  // :38
-constexpr int kCells = ORBG_GRID_COLS * ORBG_GRID_ROWS;
-constexpr int kGridLdsItems = 4096;
-
-struct FrameParams {
-  int n;
-  float min_x, max_x, min_y, max_y;
-  float w_inv, h_inv;               // mfGridElementWidthInv / HeightInv (S/Frame.cc:127-144)
-  float fx, fy, cx, cy, bf, b;
-  int n_levels;
-  float log_sf;
-  float scale[ORBG_MAX_LEVELS];
-};
-
 struct PoseF {   // Tcw split as the reference does (S/Frame.cc:439-445)
   float R[9], t[3], Ow[3];
 };
@@ -81,93 +70,6 @@ __device__ __forceinline__ float norm3d(const float* v) {
 
 // ------------------------------------------------------------------------------------------------
 // grid  (Frame::AssignFeaturesToGrid / PosInGrid, S/Frame.cc:360-391,699-709); CSR, cell = ix*48+iy
-
-__device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict__ kps, FrameParams fp,
-                                                int* __restrict__ cell_of, int* __restrict__ cell_start,
-                                                int* __restrict__ cell_items, const int* __restrict__ d_n) {
-  __shared__ int cnt[kCells];
-  __shared__ int s_items[kGridLdsItems];   // cell_items staged in LDS (frames of up to kGridLdsItems features): fill + per-cell
-                                           // sort without a global-memory round trip per step
-  if (d_n) fp.n = *d_n;               // feature count produced on the device (GPU quad-tree path)
-  __shared__ int wsum[16];
-  __shared__ int s_total;
-  const int tid = threadIdx.x;
-  const bool in_lds = fp.n <= kGridLdsItems;
-  for (int c = tid; c < kCells; c += 1024) cnt[c] = 0;
-  __syncthreads();
-  int my_cell[kGridLdsItems / 1024];     // cells of this thread's features (register copy; cell_of[] is still written for the API)
-#pragma unroll
-  for (int q = 0; q < kGridLdsItems / 1024; q++) my_cell[q] = -1;
-  for (int i = tid, q = 0; i < fp.n; i += 1024, q++) {
-    const int px = (int)roundf((kps[i].x - fp.min_x) * fp.w_inv);
-    const int py = (int)roundf((kps[i].y - fp.min_y) * fp.h_inv);
-    int c = -1;
-    if (!(px < 0 || px >= ORBG_GRID_COLS || py < 0 || py >= ORBG_GRID_ROWS)) {
-      c = px * ORBG_GRID_ROWS + py;
-      atomicAdd(&cnt[c], 1);
-    }
-    cell_of[i] = c;
-#pragma unroll
-    for (int z = 0; z < kGridLdsItems / 1024; z++) if (z == q) my_cell[z] = c;
-  }
-  __syncthreads();
-  // exclusive scan of 3072 counts: 3 per thread
-  const int c0 = tid * 3;
-  const int a = cnt[c0], b = cnt[c0 + 1], c = cnt[c0 + 2];
-  const int lane = tid & 63, wave = tid >> 6;
-  const int inc = wave_incl_scan_add(a + b + c);
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; w++) base += wsum[w];
-  const int excl = base + inc - (a + b + c);
-  cell_start[c0] = excl; cell_start[c0 + 1] = excl + a; cell_start[c0 + 2] = excl + a + b;
-  if (tid == 1023) { cell_start[kCells] = excl + a + b + c; s_total = excl + a + b + c; }
-  __syncthreads();
-  const int n_items = s_total;
-  cnt[c0] = excl; cnt[c0 + 1] = excl + a; cnt[c0 + 2] = excl + a + b;   // running fill cursors
-  __syncthreads();
-  if (in_lds) {
-#pragma unroll
-    for (int q = 0; q < kGridLdsItems / 1024; q++) {
-      const int i = tid + 1024 * q;
-      if (i < fp.n && my_cell[q] >= 0) s_items[atomicAdd(&cnt[my_cell[q]], 1)] = i;
-    }
-    __syncthreads();
-    // restore insertion (= keypoint index) order inside every cell
-    for (int q = 0; q < 3; q++) {
-      const int cc = c0 + q;
-      const int s0 = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
-      const int e = cnt[cc];
-      for (int i = s0 + 1; i < e; i++) {
-        const int key = s_items[i];
-        int j = i - 1;
-        while (j >= s0 && s_items[j] > key) { s_items[j + 1] = s_items[j]; j--; }
-        s_items[j + 1] = key;
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < n_items; i += 1024) cell_items[i] = s_items[i];
-    return;
-  }
-  for (int i = tid; i < fp.n; i += 1024) {
-    const int cc = cell_of[i];
-    if (cc >= 0) cell_items[atomicAdd(&cnt[cc], 1)] = i;
-  }
-  __syncthreads();
-  __threadfence_block();
-  for (int q = 0; q < 3; q++) {
-    const int cc = c0 + q;
-    const int s0 = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
-    const int e = cnt[cc];
-    for (int i = s0 + 1; i < e; i++) {
-      const int key = cell_items[i];
-      int j = i - 1;
-      while (j >= s0 && cell_items[j] > key) { cell_items[j + 1] = cell_items[j]; j--; }
-      cell_items[j + 1] = key;
-    }
-  }
-}
 
 // done_flag != nullptr: the Frame constructor's completion word.  The last kernel of the chain posts it itself: everything the
 // earlier kernels wrote for the host is complete at their end, and nothing this kernel writes is read by the host.
@@ -1107,6 +1009,24 @@ int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v
     hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
                        f->d_cell_items.p, d_n, done_flag, done_seq);
   ORBG_HIP(hipGetLastError());
+  return ORBG_OK;
+}
+
+// The same set-up WITHOUT the launch: the fused stereo constructor runs the grid build as one more workgroup of its stereo match
+// launch (extractor.hip, stereo_grid_kernel) and needs the frame's buffers for that.
+int orbm_internal_attach_prepare(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, hipStream_t stream, orbg::GridLaunchArgs* out) {
+  if (!f || !h || !v || !out) return ORBG_BAD_ARG;
+  const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n0; hipStream_t xs;
+  int rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n0, &xs);
+  if (rc) return rc;
+  if ((rc = frame_set_params(f, v, 0))) return rc;               // the count only exists on the device yet
+  const int xcap = orbx_internal_kp_capacity(h);
+  if (xcap >= ORBG_MAX_FRAME_FEATURES) return ORBG_CAP_EXCEEDED;
+  if ((rc = frame_reserve(f, std::max(std::max(f->cap, 4096), xcap)))) return rc;
+  f->has_uright = true;
+  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
+  f->stream = stream;
+  out->kps = f->kps_p; out->fp = f->fp; out->cell_of = f->d_cell_of.p; out->cell_start = f->d_cell_start.p; out->cell_items = f->d_cell_items.p;
   return ORBG_OK;
 }
 

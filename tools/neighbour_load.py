@@ -8,8 +8,10 @@ fixed run of cores this script computed the neighbours of, instead of looking fo
 the load processes it started (by PID).
 
 modes (combine with commas):
-  siblings   one spinning process on EACH hardware thread of the agent's three cores (the agent's threads share their core with a
-             neighbour's job wherever the scheduler puts them)
+  siblings   one spinning process on the SECOND hardware thread of each of the agent's three cores (SMT sharing: the agent's thread
+             keeps a hardware thread of its own and shares the core's execution units)
+  timeslice  one spinning process on EACH hardware thread of the agent's three cores (the agent's threads have no hardware thread
+             of their own left: the scheduler time-slices them against the load)
   l3         memory-streaming processes on both hardware threads of the other cores of the agent's L3 slice (8 cores)
   membw      N memory-streaming processes spread over the rest of the GPU's NUMA node (default N = 16; membw:32 for 32)
   everywhere one spinning process on one hardware thread of every other core of the NUMA node
@@ -94,6 +96,10 @@ def main():
         if name == "none":
             pass
         elif name == "siblings":
+            for c in agent:
+                if len(c) > 1:
+                    start(spin, [sorted(c)[-1]])
+        elif name == "timeslice":
             for c in agent:
                 for t in sorted(c):
                     start(spin, [t])
