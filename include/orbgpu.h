@@ -256,6 +256,11 @@ typedef struct orbm_map orbm_map;
 int orbm_map_create(int device, int cap_points, orbm_map** out);
 int orbm_map_destroy(orbm_map* m);
 int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* pts);
+/* MapPoint::Observations() of the points of the last upload, refreshed without re-uploading the map (host side only: the serial commit
+ * reads it, S/ORBmatcher.cc:89-91).  With it a local map stays resident across frames: its static fields (position, normal, distance
+ * range, descriptor) are uploaded when Tracking::UpdateLocalPoints / the local BA's write-back changed them, the per-frame exclusions
+ * (points the frame already holds, points that became bad) go through `skip`. */
+int orbm_map_set_observations(orbm_map* m, const int32_t* n_obs /* m */);
 int orbm_search_local_points(orbm_frame* f, orbm_map* m, const float* Tcw, const uint8_t* skip /*m or NULL*/,
                              float th, int far_points, float th_far_points, float nnratio,
                              int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);

@@ -213,6 +213,8 @@ class MapPointsOnDevice {
   MapPointsOnDevice(const MapPointsOnDevice&) = delete;
   MapPointsOnDevice& operator=(const MapPointsOnDevice&) = delete;
   void Upload(const orbm_worldpoints_view& v) { check(orbm_map_upload(m_, &v), "orbm_map_upload"); }
+  // the resident map stays as it is; only MapPoint::Observations() of its points is refreshed (host side, no device traffic)
+  void SetObservations(const int32_t* n_obs) { check(orbm_map_set_observations(m_, n_obs), "orbm_map_set_observations"); }
   orbm_map* handle() const { return m_; }
 
  private:

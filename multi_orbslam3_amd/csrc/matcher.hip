@@ -1258,6 +1258,15 @@ extern "C" int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* p) {
   return ORBG_OK;
 }
 
+// Per-frame refresh of the one field of an uploaded map that lives on the HOST side of the search (MapPoint::Observations(), read by
+// the serial commit: S/ORBmatcher.cc:89-91): no device traffic.  For callers that keep a local map resident across frames and pass
+// the per-frame exclusions (already matched / became bad) through the `skip` argument of orbm_search_local_points*.
+extern "C" int orbm_map_set_observations(orbm_map* m, const int32_t* n_obs) {
+  if (!m || (m->m > 0 && !n_obs)) return ORBG_BAD_ARG;
+  m->n_obs.assign(n_obs, n_obs + m->m);
+  return ORBG_OK;
+}
+
 static WorldPtsDev map_dev(const orbm_map* m) {
   WorldPtsDev w;
   const uint8_t* A = m->arena.p;

@@ -99,7 +99,8 @@ static std::vector<int> assignment_ids(const Frame& F, const std::vector<MapPoin
   return out;
 }
 
-struct TrackOut { int n_visible, n_map, n_frame, n_bow, n_pose, n_fused, vis_sum; std::vector<int> a_map, a_frame, a_bow, a_fused; std::vector<bool> outl; std::vector<float> pose; };
+struct TrackOut { int n_visible, n_map, n_frame, n_bow, n_pose, n_fused, vis_sum; std::vector<int> a_map, a_frame, a_bow, a_fused; std::vector<bool> outl; std::vector<float> pose;
+                  std::vector<int> a_cached, a_stale, a_moved, a_delta, a_delta_fresh; };
 
 template <class Ops>
 static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_t>& tex) {
@@ -124,6 +125,36 @@ static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_
     o.a_fused = assignment_ids(F2, local);
     o.vis_sum = 0;
     for (auto* p : local) o.vis_sum += p->mnVisible + 1000 * (int)p->mbTrackInView;
+    // ---- the glue's cache of the flattened local map (round 4): the same call again (same pointers, same change index: statics and
+    // device map reused), points moved WITHOUT the map's change index (the cache may not notice: the documented staleness until the
+    // next write-back), the change index moved (everything re-read), another pointer sequence (known points copied, new ones read)
+    auto again = [&](const std::vector<MapPoint*>& pts, unsigned long id) {
+      std::fill(F2.mvpMapPoints.begin(), F2.mvpMapPoints.end(), nullptr);
+      F2.mnId = id;
+      for (auto* p : local) { p->mbTrackInView = false; p->mnVisible = 1; }
+      int held2 = 0;
+      for (int i = 0; i < F2.N && held2 < 60; i++) if (o.a_map[i] >= 0) { F2.mvpMapPoints[i] = local[o.a_map[i]]; held2++; }
+      od::SearchLocalPoints<Ops>(F2, pts, 3.0f, false, 50.0f, 0.8f);
+      return assignment_ids(F2, local);
+    };
+    o.a_cached = again(local, 78);
+    std::vector<Mat> saved;
+    for (size_t j = 0; j < local.size(); j += 3) { saved.push_back(local[j]->mWorldPos); local[j]->mWorldPos.ptr<float>(0)[2] += 40.0f; }
+    o.a_stale = again(local, 79);
+    A.map.IncreaseChangeIndex();
+    o.a_moved = again(local, 80);
+    { size_t q = 0; for (size_t j = 0; j < local.size(); j += 3) local[j]->mWorldPos = saved[q++]; }
+    A.map.IncreaseChangeIndex();
+    again(local, 81);
+    std::vector<MapPoint*> other(local.begin() + 100, local.end());
+    std::swap(other[3], other[200]); std::swap(other[10], other[11]);
+    std::vector<MapPoint*> extra; std::vector<int> extra_src;
+    make_points_from(A, F1, extra, extra_src);
+    other.insert(other.begin() + 50, extra.begin(), extra.begin() + 40);
+    auto ids_in = [&](const std::vector<MapPoint*>& pts) { std::vector<int> r(F2.N, -1); for (int i = 0; i < F2.N; i++) if (F2.mvpMapPoints[i]) r[i] = (int)(std::find(pts.begin(), pts.end(), F2.mvpMapPoints[i]) - pts.begin()); return r; };
+    again(other, 82); o.a_delta = ids_in(other);
+    od::local_map_cache<Ops>().invalidate();
+    again(other, 83); o.a_delta_fresh = ids_in(other);
     for (auto* p : local) p->mbBad = false;
     std::fill(F2.mvpMapPoints.begin(), F2.mvpMapPoints.end(), nullptr);
   }
@@ -198,6 +229,18 @@ int main() {
     EXPECT(g.n_frame == c.n_frame && g.a_frame == c.a_frame && g.n_frame > 100, "SearchByProjection(Cur, Last) %d vs %d", g.n_frame, c.n_frame);
     EXPECT(g.n_fused == c.n_fused && g.a_fused == c.a_fused && g.vis_sum == c.vis_sum && g.n_fused > 100, "SearchLocalPoints (fused) %d vs %d, visible sums %d vs %d",
            g.n_fused, c.n_fused, g.vis_sum, c.vis_sum);
+    {
+      auto ndiff = [](const std::vector<int>& a, const std::vector<int>& b) { int d = (int)(a.size() != b.size()); for (size_t i = 0; i < a.size() && i < b.size(); i++) d += a[i] != b[i]; return d; };
+      EXPECT(g.a_cached == g.a_fused && c.a_cached == c.a_fused, "SearchLocalPoints on the cached local map differs from the first call (%d / %d features)",
+             ndiff(g.a_cached, g.a_fused), ndiff(c.a_cached, c.a_fused));
+      EXPECT(g.a_stale == g.a_fused, "moved points were noticed without a change of the map's change index (%d features)", ndiff(g.a_stale, g.a_fused));
+      EXPECT(g.a_moved == c.a_moved && ndiff(g.a_moved, g.a_fused) > 20, "after IncreaseChangeIndex: %d features differ between the entry-point sets, %d from the unmoved map",
+             ndiff(g.a_moved, c.a_moved), ndiff(g.a_moved, g.a_fused));
+      EXPECT(g.a_delta == g.a_delta_fresh && c.a_delta == c.a_delta_fresh && g.a_delta == c.a_delta, "another pointer sequence: patched cache vs fresh read %d / %d, GPU vs oracle %d",
+             ndiff(g.a_delta, g.a_delta_fresh), ndiff(c.a_delta, c.a_delta_fresh), ndiff(g.a_delta, c.a_delta));
+      int nd = 0; for (int v : g.a_delta) nd += v >= 0;
+      EXPECT(nd > 100, "the patched local map matched only %d features", nd);
+    }
     EXPECT(g.n_bow == c.n_bow && g.a_bow == c.a_bow && g.n_bow > 20, "SearchByBoW %d vs %d", g.n_bow, c.n_bow);
     EXPECT(g.n_pose == c.n_pose && g.outl == c.outl && g.n_pose > 50, "PoseOptimization inliers %d vs %d", g.n_pose, c.n_pose);
     EXPECT(max_abs_diff(g.pose, c.pose) <= 1e-4f, "PoseOptimization pose differs by %g", max_abs_diff(g.pose, c.pose));

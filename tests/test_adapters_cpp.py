@@ -67,6 +67,10 @@ def test_dropin_bench_times_the_path_through_the_glue():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     rows = d["dropin_bench"]
-    assert len(rows) == 6 and d["frames_per_s_frame_path"] > 0 and d["local_map_points"] > 2000
+    assert len(rows) == 7 and d["frames_per_s_frame_path"] > 0 and d["local_map_points"] > 2000
+    # the glue's cache of the flattened local map: on a frame whose local map is the previous frame's nothing is cloned or uploaded
+    cached = [r for n, r in rows.items() if "unchanged since the last frame" in n][0]
+    fresh = [r for n, r in rows.items() if "after a keyframe" in n][0]
+    assert cached["glue_us"] < 0.5 * fresh["glue_us"], (cached, fresh)
     for name, row in rows.items():
         assert row["total_us"] > 0 and row["c_abi_us"] > 0 and 0 <= row["glue_frac"] < 1.0, (name, row)
