@@ -324,6 +324,16 @@ int orbm_search_by_projection_sim3(orbm_frame* kf, orbm_map* pts, const float* S
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), S/ORBmatcher.cc:819-959.
  * kf2 = pKF2 with its feature vector fv2 and mp_valid2[i] = (MapPoint present and not bad); the pKF1 side is flattened
  * as for orbm_search_by_bow.  matches12[n1] out: feature index in pKF2 (-> vpMapPoints2[idx]) or -1. */
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
+ * const int ORBdist) -- the relocalisation overload, I/ORBmatcher.h:54, S/ORBmatcher.cc:2188-2310 (Tracking::Relocalization,
+ * S/Tracking.cc:3372-3410: th = 10 / ORBdist = 100, then th = 3 / ORBdist = 64).  kf_points: pKF->GetMapPointMatches() uploaded
+ * feature by feature with orbm_map_upload (m = pKF->N; bad[i] = 1 where the keyframe has no point or the point isBad());
+ * already_found[i] = sAlreadyFound.count(pMP) (NULL: none); kf_angle[i] = pKF->mvKeysUn[i].angle (read when check_orientation).
+ * assigned_mp (f's N entries) in: >= 0 where CurrentFrame.mvpMapPoints[idx] != NULL -- here ANY map point blocks a feature
+ * (:2246-2247); out: newly matched features hold the index i of the keyframe feature whose point they took. */
+int orbm_search_by_projection_reloc(orbm_frame* cur, orbm_map* kf_points, const float* Tcw_cur /*16*/, const uint8_t* already_found /*m or NULL*/,
+                                    const float* kf_angle /*m*/, float th, int orb_dist, int check_orientation,
+                                    int32_t* assigned_mp, int* nmatches);
 int orbm_search_by_bow_kf(orbm_frame* kf2, const orbm_featvec_view* fv2, const uint8_t* mp_valid2,
                           const uint8_t* desc1, int n1, const uint8_t* mp_valid1, const float* angle1,
                           const orbm_featvec_view* fv1, float nnratio, int check_orientation,

@@ -8,6 +8,7 @@
 //
 //   int  SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)   I/ORBmatcher.h:46,  S/ORBmatcher.cc:44-214
 //   int  SearchByProjection(Frame& Current, const Frame& Last, th, bMono)                     I/ORBmatcher.h:50,  S/ORBmatcher.cc:1970-2186
+//   int  SearchByProjection(Frame& Current, KeyFrame*, const set<MapPoint*>&, th, ORBdist)     I/ORBmatcher.h:54,  S/ORBmatcher.cc:2188-2310
 //   int  SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                                   I/ORBmatcher.h:64,  S/ORBmatcher.cc:269-471
 //   void isInFrustum for a list of points (Tracking::SearchLocalPoints' loop)                 S/Tracking.cc:3111-3128, S/Frame.cc:466-543
 //   void Tracking::SearchLocalPoints() body: the loop above + the matcher call as ONE device pass  S/Tracking.cc:3083-3155
@@ -79,9 +80,10 @@ struct GpuOps {
     std::unique_ptr<LocalBA> ba;
     std::unique_ptr<MapPointsOnDevice> local_map;      // Tracking's local map: resident from one SearchLocalPoints to the next while its
     bool local_map_loaded = false;                     // static fields do not change (search_local_resident)
+    std::unique_ptr<MapPointsOnDevice> reloc_map;      // the candidate keyframe's points of SearchByProjection(F, pKF, sAlreadyFound, ..)
   };
   static ThreadState& state() { static thread_local ThreadState s; return s; }
-  static void release() { ThreadState& s = state(); for (auto& sl : s.slots) { sl.dev.reset(); sl.key = nullptr; sl.used = 0; } s.ba.reset(); s.local_map.reset(); s.local_map_loaded = false; }
+  static void release() { ThreadState& s = state(); for (auto& sl : s.slots) { sl.dev.reset(); sl.key = nullptr; sl.used = 0; } s.ba.reset(); s.local_map.reset(); s.local_map_loaded = false; s.reloc_map.reset(); }
   static constexpr bool kUsesResidentFrame = true;
   static FrameOnDevice& frame(const FrameKey& fk, const orbm_frame_view& v) {
     if (fk.resident) return *fk.resident;
@@ -138,6 +140,14 @@ struct GpuOps {
                         const uint8_t* kf_valid, const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori,
                         int32_t* matches, int* n) {
     return orbm_search_by_bow(frame(key, v).handle(), &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
+  }
+  // the relocalisation overload: the keyframe's points go up as a map of their own (a candidate keyframe is searched once or twice)
+  static int search_reloc(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
+                          const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
+    ThreadState& s = state();
+    if (!s.reloc_map) s.reloc_map.reset(new MapPointsOnDevice(std::max(kf_pts.m, 4096)));
+    s.reloc_map->Upload(kf_pts);
+    return orbm_search_by_projection_reloc(frame(key, v).handle(), s.reloc_map->handle(), Tcw, found, kf_angle, th, orb_dist, check_ori, amp, n);
   }
   // pbStopFlag goes through as it is: the library polls the caller's bool (lba_solve_hb)
   static int lba(const lba_problem& p, const volatile bool* stop, lba_result& r) {
@@ -423,6 +433,40 @@ int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const floa
   for (int i = 0; i < CurrentFrame.N; i++)
     if (amp[i] >= 0 && amp[i] != INT32_MAX) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[amp[i]];   // :2077 (rotation-histogram
   return n;                                                                                                  //  rejects, :2170, come back as -1)
+}
+
+// int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
+//                                    const int ORBdist), S/ORBmatcher.cc:2188-2310 -- Tracking::Relocalization's guided search
+template <class Ops = GpuOps, class FrameT, class KeyFrameT, class MapPointT>
+int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*>& sAlreadyFound, const float th, const int ORBdist,
+                       bool mbCheckOrientation) {
+  const std::vector<MapPointT*> vpMPs = pKF->GetMapPointMatches();                            // :2203
+  const int NK = (int)vpMPs.size();
+  FrameFlat ff; flatten_frame<Ops>(CurrentFrame, ff);
+  std::vector<float> pos(3 * (size_t)NK), nrm(3 * (size_t)NK, 0.f), dmin(NK, 0.f), dmax(NK, 1.f), ang(NK);
+  std::vector<uint8_t> desc(32 * (size_t)NK), bad(NK, 1), found(NK, 0);
+  std::vector<int32_t> nobs(NK, 0);
+  for (int i = 0; i < NK; i++) {
+    ang[i] = pKF->mvKeysUn[i].angle;                                                          // :2261
+    MapPointT* p = vpMPs[i];
+    if (!p || p->isBad()) continue;                                                           // :2209-2211
+    bad[i] = 0;
+    found[i] = sAlreadyFound.count(p) ? 1 : 0;                                                // :2211
+    if (found[i]) continue;
+    const auto X = p->GetWorldPos(); const auto Dm = p->GetDescriptor();
+    std::memcpy(&pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
+    dmin[i] = p->mfMinDistance; dmax[i] = p->mfMaxDistance;                                   // raw members: the 0.8 / 1.2 factors are applied inside
+  }
+  orbm_worldpoints_view wv{NK, pos.data(), nrm.data(), dmin.data(), dmax.data(), desc.data(), nobs.data(), bad.data(), nullptr};
+  // CurrentFrame.mvpMapPoints[i2] != NULL blocks feature i2, whatever the point's observations (:2246-2247)
+  std::vector<int32_t> amp(CurrentFrame.N);
+  for (int i = 0; i < CurrentFrame.N; i++) amp[i] = CurrentFrame.mvpMapPoints[i] ? INT32_MAX : -1;
+  int n = 0;
+  check(Ops::search_reloc(ff.key, ff.v, mat_f32(CurrentFrame.mTcw), wv, found.data(), ang.data(), th, ORBdist, mbCheckOrientation, amp.data(), &n),
+        "SearchByProjection(Cur, KF, sAlreadyFound)");
+  for (int i = 0; i < CurrentFrame.N; i++)
+    if (amp[i] >= 0 && amp[i] != INT32_MAX) CurrentFrame.mvpMapPoints[i] = vpMPs[amp[i]];      // :2267 (rotation-vote rejects come back as -1, :2300)
+  return n;
 }
 
 // int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), S/ORBmatcher.cc:269-471

@@ -431,6 +431,20 @@ class ORBmatcher:
                    "orbm_search_by_projection_sim3")
         return matched, n.value
 
+    def SearchByProjectionReloc(self, CurrentFrame, Tcw, kf_points, kf_angle, assigned_mp, th, ORBdist, already_found=None):
+        """(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist): the relocalisation overload,
+        S/ORBmatcher.cc:2188-2310.  kf_points: the keyframe's map point matches, feature by feature, as a LocalMap resident on the
+        device (bad = no point / isBad()); kf_angle: pKF->mvKeysUn[i].angle; assigned_mp >= 0 where the frame already holds a point."""
+        amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        ang = np.ascontiguousarray(kf_angle, np.float32)
+        af = None if already_found is None else np.ascontiguousarray(already_found, np.uint8)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_projection_reloc(CurrentFrame.h, kf_points.h, _vp(T), _vp(af), _vp(ang), C.c_float(th), int(ORBdist),
+                                                            int(self.mbCheckOrientation), _vp(amp), C.byref(n)),
+                   "orbm_search_by_projection_reloc")
+        return amp, n.value
+
     def SearchByBoWKF(self, pKF2, fv2, mp_valid2, desc1, mp_valid1, angle1, fv1):
         """(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12): S/ORBmatcher.cc:819-959; returns matches12 (indices into pKF2)."""
         desc1 = np.ascontiguousarray(desc1, np.uint8)

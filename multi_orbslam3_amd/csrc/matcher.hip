@@ -568,6 +568,49 @@ __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameD
   window_search(fp, F, q, qd, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
+// SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) -- the relocalisation overload,
+// S/ORBmatcher.cc:2188-2310: one wavefront per feature of the keyframe.  No depth-sign test in front of Pinhole::project (:2214-2217),
+// bounds inclusive on both sides (:2219-2222), distance range with the 0.8 / 1.2 invariance factors (:2228-2233), PredictScale on
+// the FRAME's scale tables (:2235), window th * scale, levels nPredictedLevel - 1 .. + 1 (:2238-2240); a feature that holds ANY map
+// point is not a candidate (:2246-2247: the occupancy the host stages has no "observations > 0" condition here).
+__global__ __launch_bounds__(256) void search_reloc_kernel(FrameParams fp, FrameDev F, WorldPtsDev w, const uint8_t* __restrict__ found,
+                                                          PoseF P, float th, int* list_counter, int* counter_next, uint32_t* list,
+                                                          int list_cap, QResult* results) {
+  __shared__ uint32_t s_stage[4][kListStage];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;   // the overflow counter the NEXT search on this frame will use
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= w.m) return;
+  Query q;
+  q.valid = 0; q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
+  const uint8_t w_bad = w.bad[i], w_skip = w.skip[i], w_found = found ? found[i] : (uint8_t)0;
+  const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
+  const float max_raw = w.max_dist[i], min_raw = w.min_dist[i];
+  const QDesc qd = load_qdesc(w.desc + (size_t)i * 32);
+  if (!(w_bad || w_skip || w_found)) {
+    float Pc[3];
+    pose_map(P, X, Pc);
+    const float u = fp.fx * Pc[0] / Pc[2] + fp.cx;
+    const float v = fp.fy * Pc[1] / Pc[2] + fp.cy;
+    if (!(u < fp.min_x || u > fp.max_x) && !(v < fp.min_y || v > fp.max_y)) {
+      const float maxDistance = 1.2f * max_raw, minDistance = 0.8f * min_raw;
+      const float PO[3] = {X[0] - P.Ow[0], X[1] - P.Ow[1], X[2] - P.Ow[2]};
+      const float dist = norm3d(PO);
+      if (!(dist < minDistance || dist > maxDistance)) {
+        const float ratio = max_raw / dist;                                        // PredictScale(dist3D, &CurrentFrame)
+        const float lg = (float)log((double)ratio);
+        int lvl = (int)ceilf(lg / fp.log_sf);
+        if (lvl < 0) lvl = 0;
+        else if (lvl >= fp.n_levels) lvl = fp.n_levels - 1;
+        q.valid = 1;
+        q.x = u; q.y = v;
+        q.r = th * fp.scale[lvl];
+        q.min_level = lvl - 1; q.max_level = lvl + 1;
+      }
+    }
+  }
+  window_search(fp, F, q, qd, i, w.m, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
+}
+
 // MODE 2: SearchByProjection(CurrentFrame, LastFrame) (S/ORBmatcher.cc:1993-2066)
 struct LastDev {
   int n;
@@ -1801,6 +1844,62 @@ extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const
       nmatches++;
     }
   }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
+// SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist), S/ORBmatcher.cc:2188-2310:
+// the candidate kernel above, then the serial commit (:2265-2281: a feature taken by an earlier point of this call is no candidate
+// for a later one) and the rotation-consistency vote (:2284-2306).  kf_points: the keyframe's GetMapPointMatches() uploaded feature
+// by feature (orbm_map_upload: bad[i] = no point or isBad()); kf_angle[i] = pKF->mvKeysUn[i].angle.
+extern "C" int orbm_search_by_projection_reloc(orbm_frame* f, orbm_map* mp, const float* Tcw, const uint8_t* already_found,
+                                               const float* kf_angle, float th, int orb_dist, int check_orientation,
+                                               int32_t* assigned_mp, int* nmatches_out) {
+  if (!f || !mp || !Tcw || !assigned_mp || f->device != mp->device || (check_orientation && !kf_angle)) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int m = mp->m;
+  if (nmatches_out) *nmatches_out = 0;
+  if (m == 0) return ORBG_OK;
+  const int n = f->fp.n;
+  if ((rc = stage_begin(f, (size_t)n * 4 + (size_t)m))) return rc;
+  hipStream_t st = f->stream;
+  stage_occupancy(f, assigned_mp, nullptr, n);                   // any map point blocks a feature (:2246-2247)
+  const uint8_t* d_found = already_found ? stage_add(f, already_found, m) : nullptr;
+  if ((rc = stage_commit(f))) return rc;
+  PoseF P;
+  make_pose(Tcw, &P);
+  FrameDev F = frame_dev(f);
+  F.uright = nullptr;                                          // no stereo gate in this overload
+  if ((rc = map_sync_to(mp, st))) return rc;
+  rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
+    hipLaunchKernelGGL(search_reloc_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P, th, cnt, cnt_next,
+                       f->list.d, list_cap, f->results.d);
+  });
+  if (rc) return rc;
+  cache_keypoint_fields(f);
+  f->claimed_buf.assign((size_t)std::max(n, 1), 0);
+  uint8_t* claimed = f->claimed_buf.data();
+  RotHist rotHist(f->rot_entries);
+  int nmatches = 0;
+  const QResult* R = f->results.h;
+  auto is_claimed = [&](int idx) { return claimed[idx] != 0; };
+  for (int i = 0; i < m; i++) {
+    __builtin_prefetch(&R[i + 16]);
+    const QResult& r = R[i];
+    if (r.n_top == 0) continue;
+    Pick pk;
+    if ((rc = pick_unclaimed(f, r, 1, is_claimed, &pk))) return rc;
+    if (pk.idx1 < 0) continue;
+    if (pk.dist1 <= orb_dist) {
+      assigned_mp[pk.idx1] = i;
+      claimed[pk.idx1] = 1;
+      nmatches++;
+      if (check_orientation) rotHist.add(rot_bin(kf_angle[i], f->hk_angle[pk.idx1]), pk.idx1);
+    }
+  }
+  if (check_orientation)
+    rotHist.reject_outside_three_maxima([&](int idx) { assigned_mp[idx] = -1; nmatches--; });
   if (nmatches_out) *nmatches_out = nmatches;
   return ORBG_OK;
 }

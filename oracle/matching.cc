@@ -523,6 +523,67 @@ extern "C" int oracle_search_by_projection_sim3(const orbm_frame_view* kf, const
   return ORBG_OK;
 }
 
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+// -- S/ORBmatcher.cc:2188-2310, the relocalisation overload (Tracking::Relocalization, S/Tracking.cc:3372-3410).
+// pts = pKF->GetMapPointMatches() flattened feature by feature (m = pKF->N): bad[i] = "no map point, or isBad()" (:2209-2211),
+// already_found[i] = sAlreadyFound.count(pMP) (:2211), kf_angle[i] = pKF->mvKeysUn[i].angle (:2261).  assigned_mp[idx] >= 0 means
+// CurrentFrame.mvpMapPoints[idx] != NULL on entry (ANY map point blocks the feature here, :2246-2247 -- the other projection
+// searches only respect points with observations); on exit newly matched features hold the index i of the keyframe's point.
+// Quirks kept: no depth-sign test before Pinhole::project (:2214-2217), bounds inclusive on both sides (:2219-2222), levels
+// nPredictedLevel-1 .. nPredictedLevel+1 (:2240), no viewing-angle test, no stereo gate.
+extern "C" int oracle_search_by_projection_reloc(const orbm_frame_view* cur, const float* Tcw_cur, const orbm_worldpoints_view* pts,
+                                                 const uint8_t* already_found, const float* kf_angle, float th, int orb_dist,
+                                                 int check_ori, int32_t* assigned_mp, int* nmatches_out) {
+  const ScaleTables st(cur);
+  const Grid g = build_grid(cur);
+  const Pose pose(Tcw_cur);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> vIndices2;
+  for (int i = 0; i < pts->m; i++) {
+    if (pts->bad[i] || (pts->skip && pts->skip[i]) || (already_found && already_found[i])) continue;
+    const float* x3Dw = pts->pos + 3 * (size_t)i;
+    float x3Dc[3];
+    pose.map(x3Dw, x3Dc);                                               // Rcw*x3Dw+tcw
+    const float u = cur->fx * x3Dc[0] / x3Dc[2] + cur->cx;              // Pinhole::project(cv::Point3f)
+    const float v = cur->fy * x3Dc[1] / x3Dc[2] + cur->cy;
+    if (u < cur->min_x || u > cur->max_x) continue;
+    if (v < cur->min_y || v > cur->max_y) continue;
+    const float PO[3] = {x3Dw[0] - pose.Ow[0], x3Dw[1] - pose.Ow[1], x3Dw[2] - pose.Ow[2]};
+    const float dist3D = norm3(PO);
+    const float maxDistance = 1.2f * pts->max_dist[i], minDistance = 0.8f * pts->min_dist[i];   // Get{Max,Min}DistanceInvariance
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float ratio = pts->max_dist[i] / dist3D;                      // PredictScale(dist3D, &CurrentFrame)  S/MapPoint.cc:646-661
+    int lvl = (int)std::ceil(std::log(ratio) / st.log_sf);
+    if (lvl < 0) lvl = 0;
+    else if (lvl >= cur->n_levels) lvl = cur->n_levels - 1;
+    const float radius = th * st.scale[lvl];
+    features_in_area(cur, g, u, v, radius, lvl - 1, lvl + 1, vIndices2);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = pts->desc + 32 * (size_t)i;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (assigned_mp[i2] >= 0) continue;                               // :2246-2247
+      const int dist = oracle_hamming(dMP, cur->desc + 32 * (size_t)i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= orb_dist && bestIdx2 >= 0) {
+      assigned_mp[bestIdx2] = i;
+      nmatches++;
+      if (check_ori) rotHist[rot_bin(kf_angle[i], cur->kps[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (check_ori) {                                                      // :2284-2306
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int b = 0; b < HISTO_LENGTH; b++)
+      if (b != ind1 && b != ind2 && b != ind3)
+        for (int idx : rotHist[b]) { assigned_mp[idx] = -1; nmatches--; }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
 // ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) -- S/ORBmatcher.cc:819-959.
 // kf2 = pKF2 (view + fv2 + mp_valid2 = "has a MapPoint that is not bad"); the pKF1 side comes flattened as descriptors,
 // validity, angles and fv1.  matches12[idx1] = idx2 (the adapter stores vpMapPoints2[idx2]) or -1.

@@ -87,6 +87,9 @@ int oracle_search_by_bow(const orbm_frame_view* view, const orbm_featvec_view* f
                          int32_t* matches, int* nmatches);
 
 /* ---- server-side KeyFrame matchers */
+int oracle_search_by_projection_reloc(const orbm_frame_view* cur, const float* Tcw_cur, const orbm_worldpoints_view* pts,
+                                      const uint8_t* already_found, const float* kf_angle, float th, int orb_dist,
+                                      int check_ori, int32_t* assigned_mp, int* nmatches_out);
 int oracle_search_by_projection_sim3(const orbm_frame_view* kf, const orbm_worldpoints_view* pts, const float* Scw,
                                      const uint8_t* already_found, int th, float ratio_hamming, int camera_project,
                                      int32_t* matched, int* nmatches);

@@ -37,6 +37,10 @@ struct OracleOps {       // the same entry points over the CPU oracle: views ins
                           int32_t* amp, int32_t* aob, int* n) {
     return oracle_search_by_projection_frame(&v, Tcw, &last, th, mono, check_ori, amp, aob, n);
   }
+  static int search_reloc(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
+                          const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
+    return oracle_search_by_projection_reloc(&v, Tcw, &kf_pts, found, kf_angle, th, orb_dist, check_ori, amp, n);
+  }
   static int search_bow(const od::FrameKey&, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf, const uint8_t* kf_valid,
                         const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori, int32_t* matches, int* n) {
     return oracle_search_by_bow(&v, &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
@@ -100,7 +104,8 @@ static std::vector<int> assignment_ids(const Frame& F, const std::vector<MapPoin
 }
 
 struct TrackOut { int n_visible, n_map, n_frame, n_bow, n_pose, n_fused, vis_sum; std::vector<int> a_map, a_frame, a_bow, a_fused; std::vector<bool> outl; std::vector<float> pose;
-                  std::vector<int> a_cached, a_stale, a_moved, a_delta, a_delta_fresh; };
+                  std::vector<int> a_cached, a_stale, a_moved, a_delta, a_delta_fresh;
+                  int n_reloc1 = 0, n_reloc2 = 0; std::vector<int> a_reloc; };
 
 template <class Ops>
 static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_t>& tex) {
@@ -178,6 +183,20 @@ static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_
   o.n_bow = od::SearchByBoW<Ops>(kf.get(), F2, bow, 0.7f, true);
   Frame tmp; tmp.N = F2.N; tmp.mvpMapPoints = bow;
   o.a_bow = assignment_ids(tmp, lastpts);
+  // ---- Tracking::Relocalization (S/Tracking.cc:3372-3410): the BoW matches stay in the frame, SearchByProjection(F, pKF, sFound, 10, 100)
+  // adds more, then a narrower pass (3, 64) with the enlarged set
+  {
+    F2.mvpMapPoints = bow;
+    for (auto* p : lastpts) p->mbBad = false;
+    for (size_t j = 5; j < lastpts.size(); j += 37) lastpts[j]->mbBad = true;
+    std::set<MapPoint*> sFound;
+    for (auto* p : F2.mvpMapPoints) if (p) sFound.insert(p);
+    o.n_reloc1 = od::SearchByProjection<Ops>(F2, kf.get(), sFound, 10.0f, 100, true);
+    for (auto* p : F2.mvpMapPoints) if (p) sFound.insert(p);
+    o.n_reloc2 = od::SearchByProjection<Ops>(F2, kf.get(), sFound, 3.0f, 64, true);
+    o.a_reloc = assignment_ids(F2, lastpts);
+    for (auto* p : lastpts) p->mbBad = false;
+  }
   return o;
 }
 
@@ -242,6 +261,8 @@ int main() {
       EXPECT(nd > 100, "the patched local map matched only %d features", nd);
     }
     EXPECT(g.n_bow == c.n_bow && g.a_bow == c.a_bow && g.n_bow > 20, "SearchByBoW %d vs %d", g.n_bow, c.n_bow);
+    EXPECT(g.n_reloc1 == c.n_reloc1 && g.n_reloc2 == c.n_reloc2 && g.a_reloc == c.a_reloc && g.n_reloc1 > 20,
+           "SearchByProjection(F, KF, sAlreadyFound): %d / %d vs %d / %d new matches", g.n_reloc1, g.n_reloc2, c.n_reloc1, c.n_reloc2);
     EXPECT(g.n_pose == c.n_pose && g.outl == c.outl && g.n_pose > 50, "PoseOptimization inliers %d vs %d", g.n_pose, c.n_pose);
     EXPECT(max_abs_diff(g.pose, c.pose) <= 1e-4f, "PoseOptimization pose differs by %g", max_abs_diff(g.pose, c.pose));
     int n_out = 0; for (bool b : g.outl) n_out += b;

@@ -616,6 +616,44 @@ def test_search_by_projection_sim3(scene, th, ratio, with_kfs, scale):
     assert g0[1] == 0 and np.array_equal(g0[0], matched0)
 
 
+@pytest.mark.parametrize("th,orb_dist,check_ori", [(10.0, 100, True), (3.0, 64, True), (10.0, 100, False), (1.0, 50, True)])
+def test_search_by_projection_relocalisation_overload(scene, th, orb_dist, check_ori):
+    """SearchByProjection(Frame&, KeyFrame*, set<MapPoint*>&, th, ORBdist) (S/ORBmatcher.cc:2188-2310; Tracking::Relocalization calls
+    it with 10 / 100 and 3 / 64): the keyframe's map points feature by feature (some features without a point, some points bad, some
+    in sAlreadyFound), a current frame that already holds points (any of them blocks its feature), a perturbed pose."""
+    rng = np.random.RandomState(23)
+    kf = helpers.oracle_stereo_frame(scene, 18)
+    cur = helpers.oracle_stereo_frame(scene, 20)
+    mp = synth.map_from_frame(kf["kps"], kf["desc"], kf["depth"], kf["Tcw"], scene.cam)        # points the keyframe created (stereo features)
+    nk = len(kf["kps"])
+    # feature-by-feature view of pKF->GetMapPointMatches(): features without depth have no point (bad = 1)
+    pos = np.zeros((nk, 3), np.float32); nrm = np.zeros((nk, 3), np.float32); dmin = np.zeros(nk, np.float32); dmax = np.ones(nk, np.float32)
+    desc = np.zeros((nk, 32), np.uint8); bad = np.ones(nk, np.uint8)
+    idx = mp["src_idx"]
+    pos[idx] = mp["pos"]; nrm[idx] = mp["normal"]; dmin[idx] = mp["min_dist"]; dmax[idx] = mp["max_dist"]; desc[idx] = mp["desc"]; bad[idx] = 0
+    bad[idx[rng.rand(len(idx)) < 0.05]] = 1                                                        # isBad()
+    found = np.zeros(nk, np.uint8); found[idx[rng.rand(len(idx)) < 0.1]] = 1                      # sAlreadyFound
+    wv, keep2 = views.worldpoints_view(pos, nrm, dmin, dmax, desc, np.full(nk, 2, np.int32), bad, None)
+    fv, keep = helpers.frame_view_of(scene, cur)
+    n = len(cur["kps"])
+    amp0 = np.full(n, -1, np.int32)
+    pre = rng.rand(n) < 0.1
+    amp0[pre] = 2 ** 31 - 1
+    T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+    F = api.Frame().upload(fv, keep)
+    KP = api.LocalMap().upload(wv)
+    m = api.ORBmatcher(0.75, check_ori)
+    g = m.SearchByProjectionReloc(F, T, KP, kf["kps"]["angle"], amp0, th, orb_dist, found)
+    o = ob.search_by_projection_reloc(fv, T, wv, kf["kps"]["angle"], amp0, th, orb_dist, check_ori, found)
+    assert o[1] > (60 if th >= 3 else 10), o[1]
+    assert g[1] == o[1] and np.array_equal(g[0], o[0])
+    assert np.array_equal(g[0][pre], amp0[pre])                 # features that hold a point are never taken
+    newly = (g[0] >= 0) & ~pre
+    assert not found[g[0][newly]].any() and not bad[g[0][newly]].any()
+    g0 = m.SearchByProjectionReloc(F, T, KP, kf["kps"]["angle"], amp0, th, orb_dist, np.ones(nk, np.uint8))
+    assert g0[1] == 0 and np.array_equal(g0[0], amp0)
+
+
 @pytest.mark.parametrize("check_ori", [True, False])
 def test_search_by_bow_kf(scene, check_ori):
     """Server-side SearchByBoW(KeyFrame*, KeyFrame*)."""

@@ -266,6 +266,104 @@ def test_search_by_projection_sim3_properties(small_scene):
     assert abs(g[1] - a[1]) <= 2
 
 
+def _py_search_reloc(fr, cam, bounds, Tcw, pos, dmin, dmax, desc, bad, found, kf_angle, amp, th, orb_dist, check_ori):
+    """S/ORBmatcher.cc:2188-2310 line by line in float32 numpy (a brute-force window scan stands in for the grid query, restricted
+    to the features the oracle's GetFeaturesInArea returns so that the cell-window quirk of SURVEY.md C-4 is the same)."""
+    f32 = np.float32
+    fx, fy, cx, cy = [f32(cam[k]) for k in ("fx", "fy", "cx", "cy")]
+    R = Tcw[:3, :3].astype(f32); t = Tcw[:3, 3].astype(f32)
+    Ow = (-(R.T.astype(np.float32) @ t)).astype(f32)
+    sc = _scales()
+    log_sf = f32(np.log(f32(1.2)))
+    amp = amp.copy()
+    k = fr["kps"]
+    hist = [[] for _ in range(30)]
+    n = 0
+    for i in range(len(pos)):
+        if bad[i] or found[i]:
+            continue
+        X = pos[i].astype(f32)
+        Xc = np.array([f32(f32(f32(R[r, 0] * X[0]) + f32(R[r, 1] * X[1])) + f32(R[r, 2] * X[2])) + t[r] for r in range(3)], f32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = f32(f32(fx * Xc[0]) / Xc[2]) + cx
+            v = f32(f32(fy * Xc[1]) / Xc[2]) + cy
+        if u < bounds[0] or u > bounds[1] or v < bounds[2] or v > bounds[3]:
+            continue
+        PO = (X - Ow).astype(f32)
+        dist = f32(np.sqrt(np.float64(PO[0]) ** 2 + np.float64(PO[1]) ** 2 + np.float64(PO[2]) ** 2))
+        if dist < f32(0.8) * dmin[i] or dist > f32(1.2) * dmax[i]:
+            continue
+        lvl = int(np.ceil(f32(np.log(np.float64(f32(dmax[i] / dist)))) / log_sf))
+        lvl = min(max(lvl, 0), 7)
+        r = f32(th) * sc[lvl]
+        best, bi = 256, -1
+        for j in fr["_area"](u, v, r, lvl - 1, lvl + 1):
+            if amp[j] >= 0:
+                continue
+            d = int(np.unpackbits(desc[i] ^ fr["desc"][j]).sum())
+            if d < best:
+                best, bi = d, j
+        if best <= orb_dist and bi >= 0:
+            amp[bi] = i
+            n += 1
+            if check_ori:
+                rot = f32(kf_angle[i]) - f32(k["angle"][bi])
+                if rot < 0:
+                    rot = f32(rot + f32(360.0))
+                b = int(np.floor(np.float64(f32(rot * f32(1.0 / 30))) + 0.5))
+                hist[0 if b == 30 else b].append(bi)
+    if check_ori:
+        sizes = [len(h) for h in hist]
+        m1 = m2 = m3 = 0; i1 = i2 = i3 = -1
+        for b, sz in enumerate(sizes):
+            if sz > m1:
+                m3, m2, m1, i3, i2, i1 = m2, m1, sz, i2, i1, b
+            elif sz > m2:
+                m3, m2, i3, i2 = m2, sz, i2, b
+            elif sz > m3:
+                m3, i3 = sz, b
+        if m2 < 0.1 * m1:
+            i2 = i3 = -1
+        elif m3 < 0.1 * m1:
+            i3 = -1
+        for b in range(30):
+            if b not in (i1, i2, i3):
+                for j in hist[b]:
+                    amp[j] = -1
+                    n -= 1
+    return amp, n
+
+
+@pytest.mark.parametrize("th,orb_dist,check_ori", [(10.0, 100, True), (3.0, 64, False)])
+def test_search_by_projection_reloc_vs_python(small_scene, th, orb_dist, check_ori):
+    """The relocalisation overload of SearchByProjection (S/ORBmatcher.cc:2188-2310) against a line-by-line Python model: points
+    without a map point / bad / already found are skipped, ANY assigned feature is blocked, th * scale window over levels l-1..l+1,
+    bestDist <= ORBdist, rotation vote."""
+    rng = np.random.RandomState(31)
+    kf, cur = helpers.oracle_stereo_frame(small_scene, 3, 400), helpers.oracle_stereo_frame(small_scene, 4, 400)
+    mp = synth.map_from_frame(kf["kps"], kf["desc"], kf["depth"], kf["Tcw"], small_scene.cam)
+    nk, idx = len(kf["kps"]), mp["src_idx"]
+    pos = np.zeros((nk, 3), np.float32); nrm = np.zeros((nk, 3), np.float32); dmin = np.zeros(nk, np.float32); dmax = np.ones(nk, np.float32)
+    desc = np.zeros((nk, 32), np.uint8); bad = np.ones(nk, np.uint8)
+    pos[idx] = mp["pos"]; nrm[idx] = mp["normal"]; dmin[idx] = mp["min_dist"]; dmax[idx] = mp["max_dist"]; desc[idx] = mp["desc"]; bad[idx] = 0
+    bad[idx[rng.rand(len(idx)) < 0.05]] = 1
+    found = np.zeros(nk, np.uint8); found[idx[rng.rand(len(idx)) < 0.1]] = 1
+    wv, keep2 = views.worldpoints_view(pos, nrm, dmin, dmax, desc, np.full(nk, 2, np.int32), bad, None)
+    fv, keep = helpers.frame_view_of(small_scene, cur)
+    n = len(cur["kps"])
+    amp0 = np.full(n, -1, np.int32); amp0[rng.rand(n) < 0.1] = 7
+    T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+    got, ng = ob.search_by_projection_reloc(fv, T, wv, kf["kps"]["angle"], amp0, th, orb_dist, check_ori, found)
+    cur = dict(cur); cur["_area"] = lambda u, v, r, lo, hi: ob.features_in_area(fv, np.float32(u), np.float32(v), np.float32(r), int(lo), int(hi)).tolist()
+    p = small_scene.frame_view_params()
+    exp, ne = _py_search_reloc(cur, small_scene.cam, p["bounds"], T, pos, dmin, dmax, desc, bad, found, kf["kps"]["angle"], amp0, th, orb_dist, check_ori)
+    assert ng == ne and ng > 40, (ng, ne)
+    assert np.array_equal(got, exp)
+    # every newly matched feature took a distinct, admissible point
+    new = (got >= 0) & (amp0 < 0)
+    assert len(np.unique(got[new])) == new.sum() and not bad[got[new]].any() and not found[got[new]].any()
+
+
 def test_stereo_match_recovers_plane_depth(small_scene):
     fr = helpers.oracle_stereo_frame(small_scene, 0, 500)
     ok = fr["uright"] > 0
