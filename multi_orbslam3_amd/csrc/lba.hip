@@ -3468,6 +3468,8 @@ __device__ __forceinline__ double po_readlane(double v, int lane) {   // lane mu
 // same bits a serial solve would produce.  Returns false unless every pivot is positive (Eigen::LDLT::isPositive),
 // in which case x is left untouched.  x[] comes out wave-uniform.
 __device__ inline bool po_solve6(const double* Hrow, double b_li, int li, double lambda, double* x) {
+  // (round 4, measured and dropped: the seven divisions as products with 1/d from the hardware seed + two Newton steps -- no
+  // measurable gain, 162 vs 158-164 us at 450 correspondences, and one of the twelve parity cases changed an iteration count)
   double A[6], D[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) A[j] = Hrow[j] + (j == li ? lambda : 0.0);
@@ -3587,6 +3589,60 @@ __device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, fl
   po_residual<double, bool>(Xc, iz, (double)u, (double)v, (double)ur, ur < 0, c, err);
 }
 
+// ---- the per-correspondence arithmetic of the LM loop, written once over V (double: one correspondence, D2: the thread's pair)
+// PoEval: everything an evaluation at a pose produces for a correspondence
+template <class V> struct PoEval { V Xc[3], iz, err[3], c2, rho0, rho1; };
+template <class V, class M>
+__device__ __forceinline__ void po_eval(const PoseQ& T, const V* X, V uu, V vv, V ur, V om, M mono, bool robust, const Cam& cam,
+                                        double dM, double dS, double dsqM, double dsqS, PoEval<V>* e) {
+  po_cam_point<V>(T, X, e->Xc, &e->iz);
+  po_residual<V, M>(e->Xc, e->iz, uu, vv, ur, mono, cam, e->err);
+  e->c2 = e->err[0] * (om * e->err[0]) + e->err[1] * (om * e->err[1]) + po_sel(mono, po_c<V>(0.0), e->err[2] * (om * e->err[2]));
+  po_huber<V>(robust, e->c2, po_sel(mono, po_c<V>(dM), po_c<V>(dS)), po_sel(mono, po_c<V>(dsqM), po_c<V>(dsqS)), po_c<V>(1.0), &e->rho0, &e->rho1);
+}
+// J^T (w Omega) J (21 entries, upper triangle row-major) and J^T (w Omega) r (6) of one evaluation -> hh[27]
+template <class V, class M>
+__device__ __forceinline__ void po_hessian(const PoEval<V>& e, V om, M mono, const Cam& cam, V* hh) {
+  // Jacobian (D x 6): mono S/OptimizableTypes.cpp:49-63, stereo types_six_dof_expmap.cpp:375-404
+  const V xx = e.Xc[0], yy = e.Xc[1], iz = e.iz, iz2 = iz * iz;
+  const V zero = po_c<V>(0.0);
+  V J[18];
+  J[0] = xx * yy * iz2 * cam.fx; J[1] = -(1 + (xx * xx * iz2)) * cam.fx; J[2] = yy * iz * cam.fx; J[3] = -iz * cam.fx; J[4] = zero; J[5] = xx * iz2 * cam.fx;
+  J[6] = (1 + yy * yy * iz2) * cam.fy; J[7] = -xx * yy * iz2 * cam.fy; J[8] = -xx * iz * cam.fy; J[9] = zero; J[10] = -iz * cam.fy; J[11] = yy * iz2 * cam.fy;
+  J[12] = po_sel(mono, zero, J[0] - cam.bf * yy * iz2); J[13] = po_sel(mono, zero, J[1] + cam.bf * xx * iz2); J[14] = po_sel(mono, zero, J[2]);
+  J[15] = po_sel(mono, zero, J[3]); J[16] = zero; J[17] = po_sel(mono, zero, J[5] - cam.bf * iz2);
+  const V wom = e.rho1 * om;
+  V orr[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) orr[k] = -(om * e.err[k]) * e.rho1;
+  // J^T (w Omega) J with the weighted rows formed once and the structural zeros of the Jacobian (column 4 of rows 0 and
+  // 2, column 3 of row 1) left out: 15 + 45 + 15 multiply-adds per correspondence instead of 126 + 36
+  constexpr int kZeroCol[3] = {4, 3, 4};
+  V wJ[18];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int a2 = 0; a2 < 6; a2++) wJ[6 * k + a2] = a2 == kZeroCol[k] ? zero : wom * J[6 * k + a2];
+  int o = 0;
+#pragma unroll
+  for (int a2 = 0; a2 < 6; a2++)
+#pragma unroll
+    for (int c3 = a2; c3 < 6; c3++) {
+      V h = zero;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        if (a2 != kZeroCol[k] && c3 != kZeroCol[k]) h = h + J[6 * k + a2] * wJ[6 * k + c3];
+      hh[o++] = h;
+    }
+#pragma unroll
+  for (int a2 = 0; a2 < 6; a2++) {
+    V sacc = zero;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (a2 != kZeroCol[k]) sacc = sacc + J[6 * k + a2] * orr[k];
+    hh[o++] = sacc;
+  }
+}
 // Optimizer::PoseOptimization (S/Optimizer.cc:992-1290) in ONE launch of one workgroup: 4 rounds x up to 10
 // Levenberg-Marquardt iterations (g2o OptimizationAlgorithmLevenberg semantics), outlier re-classification after
 // each round.  The LM state (pose, lambda, gains) is kept identically in every thread -- all of them read the same
@@ -3632,7 +3688,6 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   const float* const ov = LDS_IN ? s_in + 4 * n : g_ov;
   const float* const our = LDS_IN ? s_in + 5 * n : g_our;
   const float* const oinv = LDS_IN ? s_in + 6 * n : g_oinv;
-  const D2 dM2{dM, dM}, dS2{dS, dS}, dsqM2{dsqM, dsqM}, dsqS2{dsqS, dsqS}, one2{1.0, 1.0};
   double x[6] = {0, 0, 0, 0, 0, 0};
   double lambda = 0, ni = 2, currentChi = 0;
   int nBadLM = 0;
@@ -3655,75 +3710,54 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
 #pragma unroll
       for (int i = 0; i < 28; i++) acc[i] = 0;
       // a thread's correspondences i, i + 256 are linearised side by side (D2: one instruction stream per correspondence, the
-      // two interleaved) and accumulated in the order i, i + 256, ... as a scalar loop would: same sums, bit for bit
+      // two interleaved) and accumulated in the order i, i + 256, ... as a scalar loop would: same sums, bit for bit.  A pass whose
+      // second halves all lie beyond n (n <= 256, 512 < n <= 768: the third correspondence of a thread) runs the one-correspondence
+      // form of the same arithmetic.  (Measured and dropped, round 4: keeping the accepted trial's evaluation -- camera point, 1/z,
+      // residual, Huber terms -- for the next buildSystem: bit-identical and a quarter of buildSystem's arithmetic less, but the 80
+      // registers it holds go to the accumulation registers as spills (36 -> 109): 158 -> 164 us at 450 correspondences.)
       for (int i0 = tid; i0 < n; i0 += 2 * kPoThreads) {
+        if ((i0 - tid) + kPoThreads >= n) {
+          // ---- single correspondences (uniform: no thread has a partner in this pass)
+          if (s_out[i0]) continue;
+          const double X[3] = {(double)Xw[3 * i0], (double)Xw[3 * i0 + 1], (double)Xw[3 * i0 + 2]};
+          const double ur1 = (double)our[i0], om1 = (double)oinv[i0];
+          const bool mono1 = po_neg(ur1);
+          PoEval<double> e1;
+          po_eval<double, bool>(T, X, (double)ou[i0], (double)ov[i0], ur1, om1, mono1, robust, cam, dM, dS, dsqM, dsqS, &e1);
+          double h1[27];
+          po_hessian<double, bool>(e1, om1, mono1, cam, h1);
+          s_chi2[i0] = e1.c2;
+          acc[27] += e1.rho0;
+#pragma unroll
+          for (int o = 0; o < 27; o++) acc[o] += h1[o];
+          continue;
+        }
         const int i1r = i0 + kPoThreads;
         const bool in1 = i1r < n;
         const int i1 = in1 ? i1r : i0;
         const bool act0 = !s_out[i0], act1 = in1 && !s_out[i1];
         if (!(act0 || act1)) continue;                             // (both excluded is rare)
-        const D2 X[3] = {D2{(double)Xw[3 * i0], (double)Xw[3 * i1]}, D2{(double)Xw[3 * i0 + 1], (double)Xw[3 * i1 + 1]},
-                         D2{(double)Xw[3 * i0 + 2], (double)Xw[3 * i1 + 2]}};
-        const D2 uu{(double)ou[i0], (double)ou[i1]}, vv{(double)ov[i0], (double)ov[i1]}, ur{(double)our[i0], (double)our[i1]};
         const D2 om{(double)oinv[i0], (double)oinv[i1]};
+        const D2 ur{(double)our[i0], (double)our[i1]};
         const B2 mono = po_neg(ur);
-        D2 Xc[3], iz, err[3];
-        po_cam_point<D2>(T, X, Xc, &iz);
-        po_residual<D2, B2>(Xc, iz, uu, vv, ur, mono, cam, err);
-        const D2 c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + po_sel(mono, D2{0.0, 0.0}, err[2] * (om * err[2]));
-        D2 rho0, rho1;
-        po_huber<D2>(robust, c2, po_sel(mono, dM2, dS2), po_sel(mono, dsqM2, dsqS2), one2, &rho0, &rho1);
-        // Jacobian (D x 6): mono S/OptimizableTypes.cpp:49-63, stereo types_six_dof_expmap.cpp:375-404
-        const D2 xx = Xc[0], yy = Xc[1], iz2 = iz * iz;
-        const D2 zero2{0.0, 0.0};
-        D2 J[18];
-        J[0] = xx * yy * iz2 * cam.fx; J[1] = -(1 + (xx * xx * iz2)) * cam.fx; J[2] = yy * iz * cam.fx; J[3] = -iz * cam.fx; J[4] = zero2; J[5] = xx * iz2 * cam.fx;
-        J[6] = (1 + yy * yy * iz2) * cam.fy; J[7] = -xx * yy * iz2 * cam.fy; J[8] = -xx * iz * cam.fy; J[9] = zero2; J[10] = -iz * cam.fy; J[11] = yy * iz2 * cam.fy;
-        J[12] = po_sel(mono, zero2, J[0] - cam.bf * yy * iz2); J[13] = po_sel(mono, zero2, J[1] + cam.bf * xx * iz2); J[14] = po_sel(mono, zero2, J[2]);
-        J[15] = po_sel(mono, zero2, J[3]); J[16] = zero2; J[17] = po_sel(mono, zero2, J[5] - cam.bf * iz2);
-        const D2 wom = rho1 * om;
-        D2 orr[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) orr[k] = -(om * err[k]) * rho1;
-        // J^T (w Omega) J with the weighted rows formed once and the structural zeros of the Jacobian (column 4 of rows 0 and
-        // 2, column 3 of row 1) left out: 15 + 45 + 15 multiply-adds per correspondence instead of 126 + 36
-        constexpr int kZeroCol[3] = {4, 3, 4};
-        D2 wJ[18];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-#pragma unroll
-          for (int a2 = 0; a2 < 6; a2++) wJ[6 * k + a2] = a2 == kZeroCol[k] ? zero2 : wom * J[6 * k + a2];
-        D2 hh[27];
+        PoEval<D2> e2;
         {
-          int o = 0;
-#pragma unroll
-          for (int a2 = 0; a2 < 6; a2++)
-#pragma unroll
-            for (int c3 = a2; c3 < 6; c3++) {
-              D2 h = zero2;
-#pragma unroll
-              for (int k = 0; k < 3; k++)
-                if (a2 != kZeroCol[k] && c3 != kZeroCol[k]) h = h + J[6 * k + a2] * wJ[6 * k + c3];
-              hh[o++] = h;
-            }
-#pragma unroll
-          for (int a2 = 0; a2 < 6; a2++) {
-            D2 sacc = zero2;
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-              if (a2 != kZeroCol[k]) sacc = sacc + J[6 * k + a2] * orr[k];
-            hh[o++] = sacc;
-          }
+          const D2 X[3] = {D2{(double)Xw[3 * i0], (double)Xw[3 * i1]}, D2{(double)Xw[3 * i0 + 1], (double)Xw[3 * i1 + 1]},
+                           D2{(double)Xw[3 * i0 + 2], (double)Xw[3 * i1 + 2]}};
+          const D2 uu{(double)ou[i0], (double)ou[i1]}, vv{(double)ov[i0], (double)ov[i1]};
+          po_eval<D2, B2>(T, X, uu, vv, ur, om, mono, robust, cam, dM, dS, dsqM, dsqS, &e2);
         }
+        D2 hh[27];
+        po_hessian<D2, B2>(e2, om, mono, cam, hh);
         if (act0) {
-          s_chi2[i0] = c2.a;
-          acc[27] += rho0.a;
+          s_chi2[i0] = e2.c2.a;
+          acc[27] += e2.rho0.a;
 #pragma unroll
           for (int o = 0; o < 27; o++) acc[o] += hh[o].a;
         }
         if (act1) {
-          s_chi2[i1] = c2.b;
-          acc[27] += rho0.b;
+          s_chi2[i1] = e2.c2.b;
+          acc[27] += e2.rho0.b;
 #pragma unroll
           for (int o = 0; o < 27; o++) acc[o] += hh[o].b;
         }
@@ -3792,6 +3826,15 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
         double tchi = 0;
         // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
         for (int i0 = tid; i0 < n; i0 += 2 * kPoThreads) {
+          if ((i0 - tid) + kPoThreads >= n) {
+            if (s_out[i0]) continue;
+            const double X[3] = {(double)Xw[3 * i0], (double)Xw[3 * i0 + 1], (double)Xw[3 * i0 + 2]};
+            const double ur1 = (double)our[i0];
+            PoEval<double> e1;
+            po_eval<double, bool>(Tt, X, (double)ou[i0], (double)ov[i0], ur1, (double)oinv[i0], po_neg(ur1), robust, cam, dM, dS, dsqM, dsqS, &e1);
+            s_chi2[i0] = e1.c2; tchi += e1.rho0;
+            continue;
+          }
           const int i1r = i0 + kPoThreads;
           const bool in1 = i1r < n;
           const int i1 = in1 ? i1r : i0;
@@ -3801,15 +3844,10 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
                            D2{(double)Xw[3 * i0 + 2], (double)Xw[3 * i1 + 2]}};
           const D2 uu{(double)ou[i0], (double)ou[i1]}, vv{(double)ov[i0], (double)ov[i1]}, ur{(double)our[i0], (double)our[i1]};
           const D2 om{(double)oinv[i0], (double)oinv[i1]};
-          const B2 mono = po_neg(ur);
-          D2 Xc[3], iz, err[3];
-          po_cam_point<D2>(Tt, X, Xc, &iz);
-          po_residual<D2, B2>(Xc, iz, uu, vv, ur, mono, cam, err);
-          const D2 c2 = err[0] * (om * err[0]) + err[1] * (om * err[1]) + po_sel(mono, D2{0.0, 0.0}, err[2] * (om * err[2]));
-          D2 rho0, rho1;
-          po_huber<D2>(robust, c2, po_sel(mono, dM2, dS2), po_sel(mono, dsqM2, dsqS2), one2, &rho0, &rho1);
-          if (act0) { s_chi2[i0] = c2.a; tchi += rho0.a; }
-          if (act1) { s_chi2[i1] = c2.b; tchi += rho0.b; }
+          PoEval<D2> e2;
+          po_eval<D2, B2>(Tt, X, uu, vv, ur, om, po_neg(ur), robust, cam, dM, dS, dsqM, dsqS, &e2);
+          if (act0) { s_chi2[i0] = e2.c2.a; tchi += e2.rho0.a; }
+          if (act1) { s_chi2[i1] = e2.c2.b; tchi += e2.rho0.b; }
         }
         PO_ACC(3);
         double tempChi = po_block_sum(tchi, s_wsum, sum_slot); sum_slot ^= 1;
