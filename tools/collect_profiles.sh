@@ -37,6 +37,11 @@ python3 tools/micro/po_prof.py > "$OUT/pose_opt_phases.txt" 2>&1 || true
 python3 tools/lba_time.py C2 200 > "$OUT/lba_time.txt" 2>&1 || true
 python3 tools/lba_time.py C4 40 >> "$OUT/lba_time.txt" 2>&1 || true
 python3 tools/lba_gaps.py "$OUT/stats/run_kernel_trace.csv" > "$OUT/lba_gaps.txt" 2>&1 || true
+python3 tools/ctor_gaps.py "$OUT/stats/run_kernel_trace.csv" > "$OUT/ctor_gaps.txt" 2>&1 || true
+SPREAD=0 python3 tools/search_large_map.py 1 8 32 128 > "$OUT/search_large_map_dense.txt" 2>&1 || true
+python3 tools/po_sweep.py 500 > "$OUT/pose_opt_sweep.txt" 2>&1 || true
+bash tools/noise_matrix.sh none none siblings l3 membw everywhere > "$OUT/noise_matrix.txt" 2>&1 || true
+bash tools/bench_driver_repeat.sh 5 > "$OUT/bench_driver_repeat.txt" 2>&1 || true
 f=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 profiles/pmc_aggregate.py FETCH_SIZE="$f" WRITE_SIZE="$w" > "$OUT/pmc_fetch_write_per_kernel.json" || true; fi
 for grp in pmc_mfma pmc_sq pmc_mfma_c4; do
