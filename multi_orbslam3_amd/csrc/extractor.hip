@@ -1310,8 +1310,8 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
   stereo_match_wave(blockIdx.x * 4 + (threadIdx.x >> 6), pyr, g, kl, dl, nl, kr, dr, nr, bf, b, uright, depth, best_sad, d_nkp);
 }
 
-// Tail of the fused stereo Frame constructor as ONE launch of 1024-thread workgroups (round 4; before: stereo_match_kernel, then
-// grid_build_finalize_kernel):
+// Tail of the fused stereo Frame constructor as ONE launch of 1024-thread workgroups (round 4, ORBG_CTOR_FUSED_TAIL=1; the default
+// stays stereo_match_kernel, then grid_build_finalize_kernel -- see extract_core for the measurements):
 //   workgroups 0 .. n_match-1   ComputeStereoMatches, 16 left keypoints each (one wavefront per keypoint)
 //   workgroup  n_match          the feature grid of the left image (it needs the keypoints only: independent of the matching)
 // The match workgroups take a ticket when their results are out; the one that takes the LAST ticket runs the median rejection
@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(kSgThreads) void stereo_grid_kernel(const uint8_t* 
   __shared__ int s_last;
   bool second_party = false;
   if ((int)blockIdx.x == n_match) {
-    orbg::grid_build_body(ga.kps, ga.fp, ga.cell_of, ga.cell_start, ga.cell_items, d_nkp);
+    orbg::grid_build_body<kSgThreads>(ga.kps, ga.fp, ga.cell_of, ga.cell_start, ga.cell_items, d_nkp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     second_party = true;
@@ -1613,7 +1613,7 @@ class WorkerPool {
 // handle
 
 static const bool g_oct_gather = getenv("ORBG_OCT_GATHER") && atoi(getenv("ORBG_OCT_GATHER")) != 0;
-static const bool g_ctor_split_tail = getenv("ORBG_CTOR_SPLIT_TAIL") && atoi(getenv("ORBG_CTOR_SPLIT_TAIL")) != 0;
+static const bool g_ctor_fused_tail = getenv("ORBG_CTOR_FUSED_TAIL") && atoi(getenv("ORBG_CTOR_FUSED_TAIL")) != 0;
 static inline double host_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec; }
 // Measured on MI355X / ROCm 7.2: hipGraphLaunch of the constructor chain costs the host what its launches cost: off unless asked for
 static const bool g_ctor_graph = getenv("ORBG_CTOR_GRAPH") && atoi(getenv("ORBG_CTOR_GRAPH")) != 0;
@@ -2118,9 +2118,12 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   const bool want_desc = desc_out[0] || desc_out[1];
   const bool do_stereo = use_gpu && post && post->stereo && ncams == 2;
   const bool stereo_out = do_stereo && (post->uright || post->depth);
-  // stereo matching, median rejection, feature grid and the completion word as ONE launch (stereo_grid_kernel) when a device frame
-  // is built; ORBG_CTOR_SPLIT_TAIL=1 keeps the two launches of round 3 (stereo_match_kernel, grid_build_finalize_kernel)
-  const bool fused_tail = do_stereo && post->frame && h->sel_bound > 0 && !g_ctor_split_tail;
+  // ORBG_CTOR_FUSED_TAIL=1: stereo matching, median rejection, feature grid and the completion word as ONE launch
+  // (stereo_grid_kernel) when a device frame is built.  Off by default: alone on the GPU the launch takes what the two launches of
+  // round 3 take (22.6 us vs stereo_match_kernel 12.0 + grid_build_finalize_kernel 9.1 + 0.8 between them), next to the searches and
+  // the local BA it takes longer (31.6 vs 26.1 us; with 256-thread workgroups 54.8: one agent-scope release + ticket per workgroup),
+  // and the constructor's latency is half of the pipelined step: 7200 vs 6900 frames/s on the driver's command.
+  const bool fused_tail = do_stereo && post->frame && h->sel_bound > 0 && g_ctor_fused_tail;
   OctCfg oc = h->octcfg;
   oc.n_cams = ncams;                          // cameras processed by THIS call (a rig handle may extract one image)
   const uint8_t* const img1 = d_img1 ? d_img1 : d_img0;

@@ -1,5 +1,5 @@
 // Shared by matcher.hip and extractor.hip: the frame parameters a kernel reads and the feature grid build
-// (Frame::AssignFeaturesToGrid / PosInGrid, S/Frame.cc:360-391,699-709; CSR, cell = ix*48+iy) as a 1024-thread workgroup body.
+// (Frame::AssignFeaturesToGrid / PosInGrid, S/Frame.cc:360-391,699-709; CSR, cell = ix*48+iy) as a workgroup body.
 // matcher.hip launches it as a kernel of its own (host-built frames); extractor.hip runs it as one more workgroup of the stereo
 // match launch of the fused Frame constructor (stereo_grid_kernel).
 #pragma once
@@ -25,9 +25,14 @@ struct FrameParams {
 };
 
 
+// NT threads per workgroup (1024 as a kernel of its own; 256 as one more workgroup of the 256-thread stereo match launch): a thread
+// owns kCells / NT consecutive cells of the scan and kGridLdsItems / NT strided features.  The result does not depend on NT.
+template <int NT>
 __device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict__ kps, FrameParams fp,
                                                 int* __restrict__ cell_of, int* __restrict__ cell_start,
                                                 int* __restrict__ cell_items, const int* __restrict__ d_n) {
+  constexpr int IPT = kGridLdsItems / NT, CPT = kCells / NT, NW = NT / 64;
+  static_assert(kCells % NT == 0 && kGridLdsItems % NT == 0 && NT % 64 == 0 && NW <= 16, "grid_build_body: unsupported workgroup size");
   __shared__ int cnt[kCells];
   __shared__ int s_items[kGridLdsItems];   // cell_items staged in LDS (frames of up to kGridLdsItems features): fill + per-cell
                                            // sort without a global-memory round trip per step
@@ -36,12 +41,12 @@ __device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict_
   __shared__ int s_total;
   const int tid = threadIdx.x;
   const bool in_lds = fp.n <= kGridLdsItems;
-  for (int c = tid; c < kCells; c += 1024) cnt[c] = 0;
+  for (int c = tid; c < kCells; c += NT) cnt[c] = 0;
   __syncthreads();
-  int my_cell[kGridLdsItems / 1024];     // cells of this thread's features (register copy; cell_of[] is still written for the API)
+  int my_cell[IPT];     // cells of this thread's features (register copy; cell_of[] is still written for the API)
 #pragma unroll
-  for (int q = 0; q < kGridLdsItems / 1024; q++) my_cell[q] = -1;
-  for (int i = tid, q = 0; i < fp.n; i += 1024, q++) {
+  for (int q = 0; q < IPT; q++) my_cell[q] = -1;
+  for (int i = tid, q = 0; i < fp.n; i += NT, q++) {
     const int px = (int)roundf((kps[i].x - fp.min_x) * fp.w_inv);
     const int py = (int)roundf((kps[i].y - fp.min_y) * fp.h_inv);
     int c = -1;
@@ -51,37 +56,46 @@ __device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict_
     }
     cell_of[i] = c;
 #pragma unroll
-    for (int z = 0; z < kGridLdsItems / 1024; z++) if (z == q) my_cell[z] = c;
+    for (int z = 0; z < IPT; z++) if (z == q) my_cell[z] = c;
   }
   __syncthreads();
-  // exclusive scan of 3072 counts: 3 per thread
-  const int c0 = tid * 3;
-  const int a = cnt[c0], b = cnt[c0 + 1], c = cnt[c0 + 2];
+  // exclusive scan of the 3072 counts: CPT per thread
+  const int c0 = tid * CPT;
+  int cv[CPT];
+  int mine = 0;
+#pragma unroll
+  for (int k = 0; k < CPT; k++) { cv[k] = cnt[c0 + k]; mine += cv[k]; }
   const int lane = tid & 63, wave = tid >> 6;
-  const int inc = wave_incl_scan_add(a + b + c);
+  const int inc = wave_incl_scan_add(mine);
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
   int base = 0;
   for (int w = 0; w < wave; w++) base += wsum[w];
-  const int excl = base + inc - (a + b + c);
-  cell_start[c0] = excl; cell_start[c0 + 1] = excl + a; cell_start[c0 + 2] = excl + a + b;
-  if (tid == 1023) { cell_start[kCells] = excl + a + b + c; s_total = excl + a + b + c; }
+  const int excl = base + inc - mine;
+  int st[CPT];
+  {
+    int run = excl;
+#pragma unroll
+    for (int k = 0; k < CPT; k++) { st[k] = run; cell_start[c0 + k] = run; run += cv[k]; }
+    if (tid == NT - 1) { cell_start[kCells] = run; s_total = run; }
+  }
   __syncthreads();
   const int n_items = s_total;
-  cnt[c0] = excl; cnt[c0 + 1] = excl + a; cnt[c0 + 2] = excl + a + b;   // running fill cursors
+#pragma unroll
+  for (int k = 0; k < CPT; k++) cnt[c0 + k] = st[k];   // running fill cursors
   __syncthreads();
   if (in_lds) {
 #pragma unroll
-    for (int q = 0; q < kGridLdsItems / 1024; q++) {
-      const int i = tid + 1024 * q;
+    for (int q = 0; q < IPT; q++) {
+      const int i = tid + NT * q;
       if (i < fp.n && my_cell[q] >= 0) s_items[atomicAdd(&cnt[my_cell[q]], 1)] = i;
     }
     __syncthreads();
     // restore insertion (= keypoint index) order inside every cell
-    for (int q = 0; q < 3; q++) {
-      const int cc = c0 + q;
-      const int s0 = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
-      const int e = cnt[cc];
+#pragma unroll
+    for (int q = 0; q < CPT; q++) {
+      const int s0 = st[q];
+      const int e = cnt[c0 + q];
       for (int i = s0 + 1; i < e; i++) {
         const int key = s_items[i];
         int j = i - 1;
@@ -90,19 +104,19 @@ __device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict_
       }
     }
     __syncthreads();
-    for (int i = tid; i < n_items; i += 1024) cell_items[i] = s_items[i];
+    for (int i = tid; i < n_items; i += NT) cell_items[i] = s_items[i];
     return;
   }
-  for (int i = tid; i < fp.n; i += 1024) {
+  for (int i = tid; i < fp.n; i += NT) {
     const int cc = cell_of[i];
     if (cc >= 0) cell_items[atomicAdd(&cnt[cc], 1)] = i;
   }
   __syncthreads();
   __threadfence_block();
-  for (int q = 0; q < 3; q++) {
-    const int cc = c0 + q;
-    const int s0 = q == 0 ? excl : (q == 1 ? excl + a : excl + a + b);
-    const int e = cnt[cc];
+#pragma unroll
+  for (int q = 0; q < CPT; q++) {
+    const int s0 = st[q];
+    const int e = cnt[c0 + q];
     for (int i = s0 + 1; i < e; i++) {
       const int key = cell_items[i];
       int j = i - 1;
@@ -111,7 +125,6 @@ __device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict_
     }
   }
 }
-
 
 // What extractor.hip needs to launch the grid build of a frame next to its own kernels (filled by orbm_internal_attach_prepare)
 struct GridLaunchArgs {

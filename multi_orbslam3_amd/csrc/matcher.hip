@@ -77,7 +77,7 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* _
                                                          int* __restrict__ cell_of, int* __restrict__ cell_start,
                                                          int* __restrict__ cell_items, const int* __restrict__ d_n,
                                                          volatile unsigned* done_flag, unsigned done_seq) {
-  grid_build_body(kps, fp, cell_of, cell_start, cell_items, d_n);
+  grid_build_body<1024>(kps, fp, cell_of, cell_start, cell_items, d_n);
   if (done_flag) {
     __syncthreads();
     if (threadIdx.x == 0) *done_flag = done_seq;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(1024) void grid_build_finalize_kernel(const orbx_ke
                                                                   int* __restrict__ cell_items, const int* __restrict__ d_n,
                                                                   volatile unsigned* done_flag, unsigned done_seq, StereoFinalizeArgs fin) {
   if (blockIdx.x == 0) {
-    grid_build_body(kps, fp, cell_of, cell_start, cell_items, d_n);
+    grid_build_body<1024>(kps, fp, cell_of, cell_start, cell_items, d_n);
   } else {
     if (threadIdx.x >= 256) return;              // (whole wavefronts: a barrier only counts wavefronts that are still alive)
     stereo_finalize_body(fin.uright, fin.depth, fin.best_sad, fin.nl, fin.d_nkp, fin.host_out);

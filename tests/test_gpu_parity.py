@@ -379,6 +379,20 @@ def test_frame_constructor_as_an_executable_graph():
     assert m and int(m.group(2)) == 2 and int(m.group(1)) >= 6, (r.stdout[-1500:], r.stderr[-1500:])
 
 
+@pytest.mark.parametrize("switch", ["ORBG_CTOR_FUSED_TAIL", "ORBG_OCT_GATHER", "ORBG_IMG_TWO_UPLOADS"])
+def test_frame_constructor_chain_variants(switch):
+    """The A/B forms of the constructor chain (read once per process): stereo match + median rejection + grid + completion word as ONE
+    launch (stereo_grid_kernel: last-workgroup ticket, agent-scope hand-over), quad-trees fed by gather_cells_kernel's compacted list
+    instead of FAST's per-cell slots, one copy kernel per image instead of the pair kernel.  The constructor parity tests -- features,
+    stereo matches, grid against the oracle; host images through the ingest thread on odd shapes -- in a process that has the switch."""
+    env = dict(os.environ, **{switch: "1"})
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", here + "::test_frame_constructor_submit_wait_pipelines_across_frames",
+                        here + "::test_host_image_submit_on_other_image_shapes", here + "::test_fused_stereo_frame_constructor", here + "::test_frame_constructor_submit_with_host_images"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_gpu_and_host_quadtree_paths_agree(scene, small_scene, monkeypatch):
     """The LDS-resident GPU quad-tree and the host implementation (ORBG_HOST_OCTREE=1; also the overflow / partial-
     lapping fallback) give identical keypoints; a partial lapping area forces the host path transparently."""
