@@ -3714,7 +3714,9 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
       // second halves all lie beyond n (n <= 256, 512 < n <= 768: the third correspondence of a thread) runs the one-correspondence
       // form of the same arithmetic.  (Measured and dropped, round 4: keeping the accepted trial's evaluation -- camera point, 1/z,
       // residual, Huber terms -- for the next buildSystem: bit-identical and a quarter of buildSystem's arithmetic less, but the 80
-      // registers it holds go to the accumulation registers as spills (36 -> 109): 158 -> 164 us at 450 correspondences.)
+      // registers it holds go to the accumulation registers as spills (36 -> 109): 158 -> 164 us at 450 correspondences; adding every
+      // Hessian entry to its accumulator as soon as it exists instead of forming the pair's 27 first: spills 36 -> 12, but the
+      // accumulators become two-deep dependency chains: 162 -> 169 us.)
       for (int i0 = tid; i0 < n; i0 += 2 * kPoThreads) {
         if ((i0 - tid) + kPoThreads >= n) {
           // ---- single correspondences (uniform: no thread has a partner in this pass)
