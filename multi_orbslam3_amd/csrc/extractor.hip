@@ -2447,6 +2447,9 @@ static const bool g_img_runtime_copy = getenv("ORBG_IMG_RUNTIME_COPY") != nullpt
 // reads while the host is still packing (a first form that polled a word per 38 KB chunk from a kernel launched before the pack was
 // measured at 64 us per pair: the device's reads of lines the host was writing slowed the pack itself to 21-47 us).  A poll that does
 // not see its word within ~100 ms (the packing thread died) raises the handle's error word instead of hanging the device.
+// (Also measured, round 4: the right image packed by the SUBMITTING thread while the ingest thread packs the left one -- the ingest
+// thread's pack halves, 15 -> 8 us, the constructor's latency does not move, 147 vs 146 us: next to the searches and the local BA the
+// chain is not waiting for the second image.)
 constexpr int kUpThreads = 256, kUpPerThread = 4;
 __global__ __launch_bounds__(kUpThreads) void img_upload_pair_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int first16, int total16,
                                                                      int wg_first, const unsigned* ready, unsigned seq, unsigned* err) {
