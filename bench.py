@@ -312,6 +312,10 @@ def main():
     ap.add_argument("--ingest", choices=["thread", "inline"], default="thread",
                     help="host images: thread = the library's ingest thread packs the rows into pinned staging and enqueues the "
                          "constructor (orbx_frame_stereo_submit, ORBX_SUBMIT_ASYNC); inline = the tracking thread does")
+    ap.add_argument("--last-frame-view", choices=["resident", "inplace"], default="resident",
+                    help="SearchByProjection(Current, Last): resident = mLastFrame's view is uploaded when the tracking of that frame ends "
+                         "(orbm_lastview_upload, inside the step) and the next frame's search reads it from HBM; inplace = the search kernel "
+                         "reads the view from pinned host memory over PCIe (the form of rounds 1-3)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the main K-step region is run this many times back to back; value = the FIRST one, value_min / _median / _max "
                          "over all of them are reported next to it (1: no repeats)")
@@ -582,8 +586,9 @@ def main():
         frames_in = [dict(host=host_imgs[k], dev=(imgs[k][0].data_ptr(), imgs[k][1].data_ptr()),
                           guess=np.ascontiguousarray(frames[k]["guess"], np.float32).reshape(16), last_view=frames[k]["last_view"][0])
                      for k in range(nF)]
+        last_dev = api.LastFrameOnDevice(2 * cfg["frame_cap"], device) if args.last_frame_view == "resident" else None
         loop = agent_mod.AgentLoop(exs, Fs, LM, opt, fv, W, H, W, bf, bb, frames_in, seq, kf_views, lp, lba_out, [po1, po2], FRAMES_PER_KF,
-                                   2 * cfg["frame_cap"], th_frame, mono_flag)
+                                   2 * cfg["frame_cap"], th_frame, mono_flag, last_view=last_dev)
 
     def ctxt_switches():
         """Involuntary context switches of every thread of this process so far: a spinning thread that loses its core to a
@@ -624,7 +629,7 @@ def main():
         elapsed = grp.max_over_ranks(dt)          # TCP, a few hundred microseconds against a 2.7 ms region) is not step time
         cs1 = ctxt_switches()
         reg.stats["nonvoluntary_ctxt_switches"] = None if cs0 is None or cs1 is None else cs1 - cs0
-        for key, j in (("extract", 0), ("match_frame", 1), ("match_map", 2), ("pose_opt", 3), ("map_upload", 4), ("lba", 5)):
+        for key, j in (("extract", 0), ("match_frame", 1), ("match_map", 2), ("pose_opt", 3), ("map_upload", 4), ("lba", 5), ("last_view_upload", 6)):
             reg.stage[key] = st.stage_s[j]
         reg.stats.update(kp=st.kp, m_frame=st.m_frame, m_map=st.m_map, lba_iters=st.lba_iters, lba_calls=st.lba_calls, lba_s=st.lba_s)
         reg.step_s = step_s
@@ -874,6 +879,8 @@ def main():
                                          "of K steps" if use_cxx else "python (ctypes wrappers, one step per call)"), "host_images_in_step": bool(host_images or not stereo),
                        "image_ingest": ("host images -> pinned staging slot (%s) -> copy kernel on the extractor's stream -> HBM"
                                         % ("library ingest thread" if pipeline and ingest_async else "calling thread")) if host_images else "images resident in HBM",
+                       "last_frame_view": ("resident: uploaded at the end of the frame's tracking (inside the step), read from HBM by the next frame's search"
+                                           if (use_cxx and args.last_frame_view == "resident") else "read in place from pinned host memory"),
                        "local_map_points_avg": int(np.mean(maps.sizes)) if maps.sizes else 0, "local_map_keyframes": cfg["local_kfs"],
                        "sequence_frames": len(seq),
                        "cpu_affinity": cpu_affinity, "host_noise": host_noise, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
@@ -920,7 +927,7 @@ def main():
                 line[nm + "_p50"] = round(float(np.percentile(tl[:, j], 50)), 1)
                 line[nm + "_max"] = round(float(tl[:, j].max()), 1)
         for k2, v in stage.items():
-            if k2 in ("extract", "match_frame", "match_map", "map_upload", "lba"):
+            if k2 in ("extract", "match_frame", "match_map", "map_upload", "lba", "last_view_upload"):
                 line["stage_%s_us" % k2] = round(1e6 * v / K, 1)
         line["lba_ms_per_call"] = round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3)
         line["config"]["device_ms_per_step_by_kernel"] = {k2: round(v, 5) for k2, v in sorted(per_step.items(), key=lambda kv: -kv[1])}

@@ -291,6 +291,19 @@ int orbm_search_by_projection_frame(orbm_frame* cur, const float* Tcw_cur, const
                                     float th, int mono, int check_orientation,
                                     int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
 
+/* The same search with the last frame's view RESIDENT on the device.  Tracking knows mLastFrame's map points when it has finished
+ * tracking that frame (mLastFrame = Frame(mCurrentFrame), S/Tracking.cc:2086-2090) -- a frame time before the next
+ * SearchByProjection(Current, Last) reads them: orbm_lastview_upload takes the view then (one packed copy on the library's M stream,
+ * asynchronous; the view's arrays may be reused as soon as it returns), orbm_search_by_projection_frame_resident reads it from HBM
+ * instead of from pinned host memory over PCIe at the moment the next constructor's images cross it.  Same results as
+ * orbm_search_by_projection_frame on the same view. */
+typedef struct orbm_lastview orbm_lastview;
+int orbm_lastview_create(int device, int cap_features, orbm_lastview** out);
+int orbm_lastview_destroy(orbm_lastview* v);
+int orbm_lastview_upload(orbm_lastview* v, const orbm_lastframe_view* last);
+int orbm_search_by_projection_frame_resident(orbm_frame* cur, const float* Tcw_cur, orbm_lastview* last, float th, int mono,
+                                             int check_orientation, int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+
 /* DBoW2::FeatureVector flattened: sorted node ids, CSR feature lists. */
 typedef struct orbm_featvec_view {
   int32_t n_nodes;

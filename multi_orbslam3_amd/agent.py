@@ -25,7 +25,7 @@ class Cfg(C.Structure):
                 ("pipelined", C.c_int), ("host_images", C.c_int), ("ingest_async", C.c_int), ("submit_first", C.c_int),
                 ("lba_async", C.c_int), ("pose_opt", C.c_int), ("th_frame", C.c_float), ("mono", C.c_int), ("nn_frame", C.c_float),
                 ("nn_map", C.c_float), ("amp", C.c_void_p), ("aob", C.c_void_p), ("cap", C.c_int), ("in_flight", C.c_int32 * 2),
-                ("lba_in_flight", C.c_int32)]
+                ("lba_in_flight", C.c_int32), ("last_view_dev", C.c_void_p), ("last_view_frame", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -58,7 +58,7 @@ class AgentLoop:
     """Holds the agent_cfg (and everything it points to) of one client."""
 
     def __init__(self, exs, frs, local_map, opt, frame_view, width, height, stride, bf, b, frames, seq, kf_map_views, lba_prob, lba_out,
-                 po_probs, frames_per_kf, cap, th_frame, mono, nn_map=0.8):
+                 po_probs, frames_per_kf, cap, th_frame, mono, nn_map=0.8, last_view=None):
         self.lib = load()
         self.keep = [exs, frs, local_map, opt, frame_view, frames, kf_map_views, lba_prob, lba_out, po_probs]
         c = Cfg()
@@ -94,6 +94,9 @@ class AgentLoop:
         self.aob = np.zeros(cap, np.int32)
         c.amp, c.aob, c.cap = self.amp.ctypes.data, self.aob.ctypes.data, cap
         c.th_frame, c.mono, c.nn_frame, c.nn_map = th_frame, int(mono), 0.9, nn_map
+        self.keep.append(last_view)
+        c.last_view_dev = last_view.h.value if last_view is not None else None      # api.LastFrameOnDevice: the last frame's view resident on the device
+        c.last_view_frame = -1
         self.c = c
 
     def configure(self, pipelined, host_images, ingest_async, submit_first, lba_async, pose_opt):

@@ -337,6 +337,31 @@ class LocalMap:
         return self
 
 
+class LastFrameOnDevice:
+    """mLastFrame's view for SearchByProjection(Current, Last), resident on the device (orbm_lastview_*): uploaded when the tracking
+    of that frame has finished, read from HBM by the next frame's search."""
+
+    def __init__(self, cap_features=4096, device=0):
+        self.lib = capi.load()
+        self.h = C.c_void_p()
+        capi.check(self.lib.orbm_lastview_create(device, cap_features, C.byref(self.h)), "orbm_lastview_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.orbm_lastview_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, lv):
+        capi.check(self.lib.orbm_lastview_upload(self.h, C.byref(lv)), "orbm_lastview_upload")
+        return self
+
+
 class ORBmatcher:
     """ORB_SLAM3::ORBmatcher (I/ORBmatcher.h:35-108), hot-path searches only."""
 
@@ -404,6 +429,16 @@ class ORBmatcher:
         capi.check(self.lib.orbm_search_by_projection_frame(CurrentFrame.h, _vp(T), C.byref(lv), C.c_float(th), int(bMono),
                                                             int(self.mbCheckOrientation), _vp(amp), _vp(aob), C.byref(n)),
                    "orbm_search_by_projection_frame")
+        return amp, aob, n.value
+
+    def SearchByProjectionFrameResident(self, CurrentFrame, Tcw_cur, last_on_device, th, bMono, assigned_mp, assigned_obs):
+        """SearchByProjection(Current, Last) on a LastFrameOnDevice (orbm_search_by_projection_frame_resident)."""
+        amp, aob = self._state(assigned_mp, assigned_obs, False)
+        T = np.ascontiguousarray(Tcw_cur, np.float32).reshape(16)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_projection_frame_resident(CurrentFrame.h, _vp(T), last_on_device.h, C.c_float(th), int(bool(bMono)),
+                                                                     int(self.mbCheckOrientation), _vp(amp), _vp(aob), C.byref(n)),
+                   "orbm_search_by_projection_frame_resident")
         return amp, aob, n.value
 
     def SearchByBoW(self, F, fvF, kf_desc, kf_mp_valid, kf_angle, fvK):

@@ -47,10 +47,12 @@ typedef struct agent_cfg {
   int32_t* amp; int32_t* aob; int cap;                       // F.mvpMapPoints as (assigned_mp, assigned_obs), cap entries each
   int32_t in_flight[2];                                      // pipelined constructor submitted on ex[c] and not yet collected (state across calls)
   int32_t lba_in_flight;                                     // a local BA submitted and not yet collected
+  orbm_lastview* last_view_dev;                              // NULL: SearchByProjection(Current, Last) reads the view in place (pinned memory)
+  int32_t last_view_frame;                                   // frame whose view is resident in last_view_dev (-1: none)
 } agent_cfg;
 
 typedef struct agent_stats {
-  double stage_s[8];       // extract(wait / ctor), match_frame, match_map, pose_opt, map_upload, lba, (spare)
+  double stage_s[8];       // extract(wait / ctor), match_frame, match_map, pose_opt, map_upload, lba, last-frame view upload, (spare)
   double lba_s; int64_t lba_calls, lba_iters;
   int64_t kp, m_frame, m_map;
   int32_t error, error_step;
@@ -124,7 +126,15 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
     for (int j = 0; j < nl; j++) c->amp[j] = -1;
     memset(c->aob, 0, sizeof(int32_t) * (size_t)nl);
     int n1 = 0, n2 = 0;
-    if ((rc = orbm_search_by_projection_frame(F, fin.Tcw_guess, c->frames[k_last].last_view, c->th_frame, c->mono, 1, c->amp, c->aob, &n1))) break;
+    if (c->last_view_dev) {
+      // mLastFrame's view is resident: it went up when the tracking of that frame ended (below); only the first step after a change
+      // of the sequence position uploads here
+      if (c->last_view_frame != k_last) {
+        if ((rc = orbm_lastview_upload(c->last_view_dev, c->frames[k_last].last_view))) break;
+        c->last_view_frame = k_last;
+      }
+      if ((rc = orbm_search_by_projection_frame_resident(F, fin.Tcw_guess, c->last_view_dev, c->th_frame, c->mono, 1, c->amp, c->aob, &n1))) break;
+    } else if ((rc = orbm_search_by_projection_frame(F, fin.Tcw_guess, c->frames[k_last].last_view, c->th_frame, c->mono, 1, c->amp, c->aob, &n1))) break;
     const double t2 = now_s();
     double t_po = 0;
     if (c->pose_opt && c->po[0]) {                                 // TrackWithMotionModel: Optimizer::PoseOptimization(&mCurrentFrame), :2649
@@ -139,6 +149,15 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
       const double a = now_s();
       if ((rc = pose_optimize(c->po[1], c->po_out[1]))) break;
       t_po += now_s() - a;
+    }
+    double t_lv = 0;
+    if (c->last_view_dev) {
+      // end of Track(): mLastFrame = Frame(mCurrentFrame) (S/Tracking.cc:2086-2090) -- this frame's map points are known now, the next
+      // frame's SearchByProjection(Current, Last) reads them a frame time later: the view goes to the device while nothing else crosses PCIe
+      const double a = now_s();
+      if ((rc = orbm_lastview_upload(c->last_view_dev, fin.last_view))) break;
+      c->last_view_frame = k;
+      t_lv = now_s() - a;
     }
     const double t4 = now_s();
     double t5 = t4, t6 = t4;
@@ -159,7 +178,7 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
     }
     if (timed) {
       st->stage_s[0] += t1 - t0; st->stage_s[1] += t2 - t1; st->stage_s[2] += t3 - t2b; st->stage_s[3] += t_po;
-      st->stage_s[4] += t5 - t4; st->stage_s[5] += t6 - t5;
+      st->stage_s[4] += t5 - t4; st->stage_s[5] += t6 - t5; st->stage_s[6] += t_lv;
       st->kp += nl + nr; st->m_frame += n1; st->m_map += n2;
       if (step_s) step_s[s] = now_s() - t0;
     }

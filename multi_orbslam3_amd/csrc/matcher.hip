@@ -1623,29 +1623,17 @@ extern "C" int orbm_search_local_points_vis(orbm_frame* f, orbm_map* mp, const f
   return commit_mps(f, m, mp->n_obs.data(), nnratio, assigned_mp, assigned_obs, nmatches);
 }
 
-extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_cur, const orbm_lastframe_view* last, float th,
-                                               int mono, int check_orientation, int32_t* assigned_mp, int32_t* assigned_obs,
-                                               int* nmatches_out) {
-  if (!f || !Tcw_cur || !last || !assigned_mp || !assigned_obs || last->n < 0) return ORBG_BAD_ARG;
-  int rc = select_device(f->device);
-  if (rc) return rc;
-  const int m = last->n;
-  if (nmatches_out) *nmatches_out = 0;
-  if (m == 0) return ORBG_OK;
+// Common part of the two entry points below.  `stage_view`: the view is packed into the frame's pinned staging block and read there
+// by the kernel (one PCIe trip per query); otherwise L already points at a device-resident copy (orbm_lastview_upload).
+static int search_frame_common(orbm_frame* f, const float* Tcw_cur, const float* Tcw_last, int m, LastDev L, const int32_t* n_obs_last,
+                               const float* angle_last, hipEvent_t wait_ev, float th, int mono, int check_orientation,
+                               int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches_out) {
+  int rc;
   const int n = f->fp.n;
-  if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 12 + 4)))) return rc;
   hipStream_t st = f->stream;
-  stage_occupancy(f, assigned_mp, assigned_obs, n);
-  LastDev L;
-  L.n = m;
-  L.mp_valid = stage_add(f, last->mp_valid, m); L.outlier = stage_add(f, last->outlier, m);
-  L.desc = stage_add(f, last->desc, (size_t)m * 32);
-  L.world_pos = stage_add(f, last->world_pos, (size_t)m * 3);
-  L.octave = stage_add(f, last->octave, m);
-  if ((rc = stage_commit(f))) return rc;
   PoseF Pc, Pl;
   make_pose(Tcw_cur, &Pc);
-  make_pose(last->Tcw, &Pl);
+  make_pose(Tcw_last, &Pl);
   // tlc = Rlw*twc + tlw (S/ORBmatcher.cc:1983-1991)
   float tlc[3];
   for (int i = 0; i < 3; i++) {
@@ -1654,6 +1642,7 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
   }
   const int forward = tlc[2] > f->fp.b && !mono;
   const int backward = -tlc[2] > f->fp.b && !mono;
+  if (wait_ev) ORBG_HIP(hipStreamWaitEvent(st, wait_ev, 0));
   rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_frame_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, frame_dev(f), L, Pc, th, forward, backward,
                        cnt, cnt_next, f->list.d, list_cap, f->results.d);
@@ -1677,16 +1666,145 @@ extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_c
     const int bestDist = pk.dist1, bestIdx = pk.idx1;
     if (bestDist <= TH_HIGH) {
       assigned_mp[bestIdx] = i;
-      assigned_obs[bestIdx] = last->n_obs[i];
-      if (last->n_obs[i] > 0) claimed[bestIdx] = 1;
+      assigned_obs[bestIdx] = n_obs_last[i];
+      if (n_obs_last[i] > 0) claimed[bestIdx] = 1;
       nmatches++;
-      if (check_orientation) rotHist.add(rot_bin(last->angle[i], f->hk_angle[bestIdx]), bestIdx);
+      if (check_orientation) rotHist.add(rot_bin(angle_last[i], f->hk_angle[bestIdx]), bestIdx);
     }
   }
   if (check_orientation)
     rotHist.reject_outside_three_maxima([&](int idx) { assigned_mp[idx] = -1; assigned_obs[idx] = 0; nmatches--; });
   if (nmatches_out) *nmatches_out = nmatches;
   return ORBG_OK;
+}
+
+extern "C" int orbm_search_by_projection_frame(orbm_frame* f, const float* Tcw_cur, const orbm_lastframe_view* last, float th,
+                                               int mono, int check_orientation, int32_t* assigned_mp, int32_t* assigned_obs,
+                                               int* nmatches_out) {
+  if (!f || !Tcw_cur || !last || !assigned_mp || !assigned_obs || last->n < 0) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int m = last->n;
+  if (nmatches_out) *nmatches_out = 0;
+  if (m == 0) return ORBG_OK;
+  const int n = f->fp.n;
+  if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 12 + 4)))) return rc;
+  stage_occupancy(f, assigned_mp, assigned_obs, n);
+  LastDev L;
+  L.n = m;
+  L.mp_valid = stage_add(f, last->mp_valid, m); L.outlier = stage_add(f, last->outlier, m);
+  L.desc = stage_add(f, last->desc, (size_t)m * 32);
+  L.world_pos = stage_add(f, last->world_pos, (size_t)m * 3);
+  L.octave = stage_add(f, last->octave, m);
+  if ((rc = stage_commit(f))) return rc;
+  return search_frame_common(f, Tcw_cur, last->Tcw, m, L, last->n_obs, last->angle, nullptr, th, mono, check_orientation, assigned_mp,
+                             assigned_obs, nmatches_out);
+}
+
+// ---- the last frame's view resident on the device (round 4).  Tracking knows mLastFrame's map points when it has finished tracking
+// that frame (S/Tracking.cc:2086-2090: mLastFrame = Frame(mCurrentFrame)) -- a whole frame time before SearchByProjection(Current,
+// Last) reads them.  orbm_lastview_upload takes the view THEN: one packed copy on the library's M stream while nothing else crosses
+// PCIe; the search kernel of the next frame reads HBM.  Read in place (the form above) the queries cross PCIe at the start of the
+// step, together with the 614 KB image upload of the constructor that runs next to the search: 24 us per call on an idle GPU,
+// 44 us in the agent.
+struct orbm_lastview {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool ext_stream = false;
+  DevBuf<uint8_t> arena;
+  PinnedBuf<uint8_t> stage;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+  int n = 0;
+  size_t o_valid = 0, o_outl = 0, o_desc = 0, o_pos = 0, o_oct = 0, bytes = 0;
+  std::vector<int32_t> n_obs;
+  std::vector<float> angle;
+  float Tcw[16] = {0};
+};
+
+__global__ __launch_bounds__(256) void lastview_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
+extern "C" int orbm_lastview_create(int device, int cap_features, orbm_lastview** out) {
+  if (!out || cap_features < 0) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  orbm_lastview* v = new orbm_lastview();
+  v->device = device;
+  if (orbg::create_stream(&v->stream, "map") != hipSuccess) { delete v; return ORBG_HIP_ERROR; }
+  if (hipEventCreateWithFlags(&v->ev, hipEventDisableTiming) != hipSuccess) { orbg::release_stream(v->stream); delete v; return ORBG_HIP_ERROR; }
+  const size_t need = (size_t)std::max(cap_features, 16) * 64 + 256;
+  if ((rc = v->arena.reserve(need)) || (rc = v->stage.reserve(need))) { v->arena.release(); v->stage.release(); (void)hipEventDestroy(v->ev); orbg::release_stream(v->stream); delete v; return rc; }
+  *out = v;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_lastview_destroy(orbm_lastview* v) {
+  if (!v) return ORBG_BAD_ARG;
+  (void)hipSetDevice(v->device);
+  (void)hipStreamSynchronize(v->stream);
+  v->arena.release(); v->stage.release();
+  if (v->ev) (void)hipEventDestroy(v->ev);
+  if (!v->ext_stream) orbg::release_stream(v->stream);
+  delete v;
+  return ORBG_OK;
+}
+
+extern "C" int orbm_lastview_upload(orbm_lastview* v, const orbm_lastframe_view* last) {
+  if (!v || !last || last->n < 0) return ORBG_BAD_ARG;
+  const size_t m = (size_t)last->n;
+  if (m > 0 && (!last->mp_valid || !last->outlier || !last->world_pos || !last->desc || !last->octave || !last->angle || !last->n_obs)) return ORBG_BAD_ARG;
+  int rc = select_device(v->device);
+  if (rc) return rc;
+  if (v->pending) { ORBG_HIP(hipEventSynchronize(v->ev)); v->pending = false; }      // the staging block of the previous upload
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  v->o_valid = 0; v->o_outl = al(m); v->o_desc = v->o_outl + al(m); v->o_pos = v->o_desc + al(32 * m); v->o_oct = v->o_pos + al(12 * m);
+  v->bytes = v->o_oct + al(4 * m);
+  if ((rc = v->arena.reserve(v->bytes + 64)) || (rc = v->stage.reserve(v->bytes + 64))) return rc;
+  v->n = last->n;
+  v->n_obs.assign(last->n_obs, last->n_obs + m);
+  v->angle.assign(last->angle, last->angle + m);
+  memcpy(v->Tcw, last->Tcw, sizeof(v->Tcw));
+  if (m > 0) {
+    uint8_t* S = v->stage.h;
+    memcpy(S + v->o_valid, last->mp_valid, m); memcpy(S + v->o_outl, last->outlier, m); memcpy(S + v->o_desc, last->desc, 32 * m);
+    memcpy(S + v->o_pos, last->world_pos, 12 * m); memcpy(S + v->o_oct, last->octave, 4 * m);
+    const int n16 = (int)((v->bytes + 15) / 16);
+    hipLaunchKernelGGL(lastview_copy_kernel, dim3((n16 + 255) / 256), dim3(256), 0, v->stream, reinterpret_cast<const uint4*>(v->stage.d),
+                       reinterpret_cast<uint4*>(v->arena.p), n16);
+    ORBG_HIP(hipGetLastError());
+    ORBG_HIP(hipEventRecord(v->ev, v->stream));
+    v->pending = true;
+  }
+  return ORBG_OK;
+}
+
+extern "C" int orbm_search_by_projection_frame_resident(orbm_frame* f, const float* Tcw_cur, orbm_lastview* v, float th, int mono,
+                                                        int check_orientation, int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches_out) {
+  if (!f || !Tcw_cur || !v || !assigned_mp || !assigned_obs || f->device != v->device) return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  const int m = v->n;
+  if (nmatches_out) *nmatches_out = 0;
+  if (m == 0) return ORBG_OK;
+  const int n = f->fp.n;
+  if ((rc = stage_begin(f, (size_t)n * 8))) return rc;
+  stage_occupancy(f, assigned_mp, assigned_obs, n);
+  if ((rc = stage_commit(f))) return rc;
+  const uint8_t* A = v->arena.p;
+  LastDev L;
+  L.n = m;
+  L.mp_valid = A + v->o_valid; L.outlier = A + v->o_outl; L.desc = A + v->o_desc;
+  L.world_pos = reinterpret_cast<const float*>(A + v->o_pos); L.octave = reinterpret_cast<const int*>(A + v->o_oct);
+  hipEvent_t wait_ev = nullptr;
+  if (v->pending) {
+    if (hipEventQuery(v->ev) == hipSuccess) v->pending = false;
+    else { (void)hipGetLastError(); wait_ev = v->ev; }
+  }
+  return search_frame_common(f, Tcw_cur, v->Tcw, m, L, v->n_obs.data(), v->angle.data(), wait_ev, th, mono, check_orientation, assigned_mp,
+                             assigned_obs, nmatches_out);
 }
 
 // Shared body of SearchByBoW(KeyFrame*, Frame&) (S/ORBmatcher.cc:269-471, by_query = false) and

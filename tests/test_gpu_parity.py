@@ -630,6 +630,31 @@ def test_search_by_projection_sim3(scene, th, ratio, with_kfs, scale):
     assert g0[1] == 0 and np.array_equal(g0[0], matched0)
 
 
+@pytest.mark.parametrize("th,mono", [(7.0, False), (15.0, True)])
+def test_search_by_projection_frame_with_a_resident_last_frame_view(scene, th, mono):
+    """orbm_lastview_upload + orbm_search_by_projection_frame_resident: the last frame's view on the device (uploaded a frame time
+    before it is read) gives what the in-place form and the oracle give, across re-uploads of views of different sizes."""
+    rng = np.random.RandomState(41)
+    m = api.ORBmatcher(0.9, True)
+    LV = api.LastFrameOnDevice(1024)                       # smaller than the views: the buffers grow
+    for k in (3, 4, 5):
+        last, cur = helpers.oracle_stereo_frame(scene, k), helpers.oracle_stereo_frame(scene, k + 1)
+        lv, keep_lv = helpers.make_lastframe(scene, last, rng)
+        fv, keep = helpers.frame_view_of(scene, cur, with_stereo=not mono)
+        F = api.Frame().upload(fv, keep)
+        n = len(cur["kps"])
+        amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+        amp0[::11] = 3; aob0[::11] = 1
+        T = synth.perturb_pose(cur["Tcw"], rng).astype(np.float32)
+        LV.upload(lv)
+        g = m.SearchByProjectionFrameResident(F, T, LV, th, mono, amp0, aob0)
+        h = m.SearchByProjectionFrame(F, T, lv, th, mono, amp0, aob0)
+        o = ob.search_by_projection_frame(fv, T, lv, th, mono, True, amp0, aob0)
+        assert o[2] > 100
+        for a, b in ((g, o), (h, o)):
+            assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), k
+
+
 @pytest.mark.parametrize("th,orb_dist,check_ori", [(10.0, 100, True), (3.0, 64, True), (10.0, 100, False), (1.0, 50, True)])
 def test_search_by_projection_relocalisation_overload(scene, th, orb_dist, check_ori):
     """SearchByProjection(Frame&, KeyFrame*, set<MapPoint*>&, th, ORBdist) (S/ORBmatcher.cc:2188-2310; Tracking::Relocalization calls
