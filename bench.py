@@ -452,6 +452,8 @@ def main():
             self.step_s = np.zeros(max(n, 1))
             self.async_t0 = None
             self.async_timed = False
+            self.sync_tail_s = 0.0                            # time spent inside the closing torch.cuda.synchronize()
+            self.tail = (0.0, 0.0, 0.0)
             self.timeline = np.zeros((0, 5), np.float32)     # per constructor: queue / pack / enqueue / wait / latency [us] (orbx_get_ctor_timeline)
 
     def collect_async(reg):
@@ -610,14 +612,21 @@ def main():
         st = agent_mod.Stats()
 
         def sync():
+            t_a = time.perf_counter()
             loop.drain(st, True)
-            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            capi.check(capi.load().orbg_quiesce(device), "orbg_quiesce")     # spin until the library's streams are empty ...
+            t_s = time.perf_counter()
+            torch.cuda.synchronize()                                          # ... so that the contract's synchronisation has nothing to block on
+            reg.sync_tail_s = time.perf_counter() - t_s
+            reg.tail = (t_b - t_a, t_s - t_b, reg.sync_tail_s)               # drain (last local BA), quiesce, runtime synchronisation
 
         loop.run(first_index, n_warm)
         loop.drain()
         base = first_index + n_warm
         step_s = np.zeros(max(n_steps, 1))
-        grp.barrier(); torch.cuda.synchronize()
+        capi.check(capi.load().orbg_quiesce(device), "orbg_quiesce")      # (the same bracket on both sides; also: nothing of the closing
+        grp.barrier(); torch.cuda.synchronize()                          # bracket is a first use inside the timed region)
         for e in exs:
             e.ctor_timeline(reset=True)
         cs0 = ctxt_switches()
@@ -648,7 +657,10 @@ def main():
                 if in_flight[c]:
                     exs[c].frame_stereo_dev_wait()
                     in_flight[c] = False
+            capi.check(capi.load().orbg_quiesce(device), "orbg_quiesce")
+            t_s = time.perf_counter()
             torch.cuda.synchronize()
+            reg.sync_tail_s = time.perf_counter() - t_s
 
         for i in range(n_warm):
             step(first_index + i, reg, False, pose_opt, host_images, pipelined)
@@ -717,12 +729,16 @@ def main():
     # the same K-step region four more times, back to back (same configuration, same clock brackets): `value` stays the FIRST
     # region, literally; min / median / max over the five say how much of it is the draw of one 3 ms window on a shared host
     repeat_values = [world * args.steps / elapsed]
+    repeat_detail = [(round(1e3 * elapsed, 4), round(1e3 * float(reg.step_s.sum()), 4), [round(1e6 * x, 1) for x in reg.tail],
+                      round(1e3 * reg.stats["lba_s"] / max(reg.stats["lba_calls"], 1), 3))]
     if not args.no_secondary and args.repeats > 1:
         for rep in range(1, args.repeats):
             first = prewarm_done + rep * (args.steps + args.warmup + FRAMES_PER_KF)
             first += (-(first + args.warmup)) % FRAMES_PER_KF                # the first timed step is a keyframe step again
             rr, er = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, first)
             repeat_values.append(world * args.steps / er)
+            repeat_detail.append((round(1e3 * er, 4), round(1e3 * float(rr.step_s.sum()), 4), [round(1e6 * x, 1) for x in rr.tail],
+                                  round(1e3 * rr.stats["lba_s"] / max(rr.stats["lba_calls"], 1), 3)))
     solver_sum_ms, solver_n, solver_unknowns, solver_mfma = opt.solver_stats()
     fast_sum, fast_n = 0.0, 0                              # bracket times accumulated inside the library over the timed region
     for e in exs:
@@ -930,6 +946,8 @@ def main():
             if k2 in ("extract", "match_frame", "match_map", "map_upload", "lba", "last_view_upload"):
                 line["stage_%s_us" % k2] = round(1e6 * v / K, 1)
         line["lba_ms_per_call"] = round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3)
+        line["sync_tail_us"] = round(1e6 * reg.sync_tail_s, 1)
+        line["config"]["regions_ms_elapsed__ms_in_steps__tail_us_drain_quiesce_sync__lba_ms"] = repeat_detail
         line["config"]["device_ms_per_step_by_kernel"] = {k2: round(v, 5) for k2, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
         if dominant != ldlt_name:
             # a kernel of the constructor chain holds more device time per step than the LDL^T: it is the roofline's subject

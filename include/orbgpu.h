@@ -587,6 +587,9 @@ int pose_opt_set_stream(int device, void* hip_stream);      /* the calling threa
 const char* orbg_version(void);
 const char* orbg_strerror(int code);
 int orbg_device_count(void);
+/* Spins until everything enqueued so far on the library's pooled streams of `device` has completed (handles on caller-supplied
+ * streams are the caller's to wait for).  After it, the runtime's own device synchronisation finds nothing outstanding. */
+int orbg_quiesce(int device);
 /* Device timings (ms, hipEvent on the handle's stream) of the most recent call, for bench.py.
  * ms[0] pyramid, [1] FAST+gather, [2] host quad-trees (wall), [3] orientation+descriptors, [4] stereo match,
  * [5] fast_cells_kernel alone.  orbx_set_profiling: 0 = record nothing, 1 = only [2] and [5] (default),
