@@ -129,6 +129,9 @@ extern "C" int orbg_quiesce(int device) {
   int rc;
   for (int i = 0; i < 4; i++) if ((rc = sig[i].post(st[i]))) return rc;
   for (int i = 0; i < 4; i++) if ((rc = sig[i].wait(st[i]))) return rc;
+  // let the runtime retire what has completed (non-blocking, ~3 us per stream): its own device synchronisation then has no command
+  // left to look at (measured: 57 -> 9 us inside the synchronisation for 13 us more here)
+  for (int i = 0; i < 4; i++) (void)hipStreamQuery(st[i]);
   return ORBG_OK;
 }
 
