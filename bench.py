@@ -454,6 +454,7 @@ def main():
             self.async_timed = False
             self.sync_tail_s = 0.0                            # time spent inside the closing torch.cuda.synchronize()
             self.tail = (0.0, 0.0, 0.0)
+            self.worst_step = None                           # (ms, [extract, match_frame, match_map, pose_opt, map_upload, lba, last_view] us) of the slowest step
             self.timeline = np.zeros((0, 5), np.float32)     # per constructor: queue / pack / enqueue / wait / latency [us] (orbx_get_ctor_timeline)
 
     def collect_async(reg):
@@ -642,6 +643,7 @@ def main():
             reg.stage[key] = st.stage_s[j]
         reg.stats.update(kp=st.kp, m_frame=st.m_frame, m_map=st.m_map, lba_iters=st.lba_iters, lba_calls=st.lba_calls, lba_s=st.lba_s)
         reg.step_s = step_s
+        reg.worst_step = (round(1e3 * st.worst_step_s, 3), [round(1e6 * st.worst_stage_s[q], 1) for q in range(7)])
         reg.timeline = np.concatenate([e.ctor_timeline() for e in exs]) if stereo else np.zeros((0, 5), np.float32)
         return reg, elapsed
 
@@ -730,7 +732,7 @@ def main():
     # region, literally; min / median / max over the five say how much of it is the draw of one 3 ms window on a shared host
     repeat_values = [world * args.steps / elapsed]
     repeat_detail = [(round(1e3 * elapsed, 4), round(1e3 * float(reg.step_s.sum()), 4), [round(1e6 * x, 1) for x in reg.tail],
-                      round(1e3 * reg.stats["lba_s"] / max(reg.stats["lba_calls"], 1), 3))]
+                      round(1e3 * reg.stats["lba_s"] / max(reg.stats["lba_calls"], 1), 3), reg.worst_step)]
     if not args.no_secondary and args.repeats > 1:
         for rep in range(1, args.repeats):
             first = prewarm_done + rep * (args.steps + args.warmup + FRAMES_PER_KF)
@@ -738,7 +740,7 @@ def main():
             rr, er = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, first)
             repeat_values.append(world * args.steps / er)
             repeat_detail.append((round(1e3 * er, 4), round(1e3 * float(rr.step_s.sum()), 4), [round(1e6 * x, 1) for x in rr.tail],
-                                  round(1e3 * rr.stats["lba_s"] / max(rr.stats["lba_calls"], 1), 3)))
+                                  round(1e3 * rr.stats["lba_s"] / max(rr.stats["lba_calls"], 1), 3), rr.worst_step))
     solver_sum_ms, solver_n, solver_unknowns, solver_mfma = opt.solver_stats()
     fast_sum, fast_n = 0.0, 0                              # bracket times accumulated inside the library over the timed region
     for e in exs:
@@ -947,7 +949,7 @@ def main():
                 line["stage_%s_us" % k2] = round(1e6 * v / K, 1)
         line["lba_ms_per_call"] = round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3)
         line["sync_tail_us"] = round(1e6 * reg.sync_tail_s, 1)
-        line["config"]["regions_ms_elapsed__ms_in_steps__tail_us_drain_quiesce_sync__lba_ms"] = repeat_detail
+        line["config"]["regions_ms_elapsed__ms_in_steps__tail_us_drain_quiesce_sync__lba_ms__worst_step"] = repeat_detail
         line["config"]["device_ms_per_step_by_kernel"] = {k2: round(v, 5) for k2, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
         if dominant != ldlt_name:
             # a kernel of the constructor chain holds more device time per step than the LDL^T: it is the roofline's subject

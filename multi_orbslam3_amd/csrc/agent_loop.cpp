@@ -56,6 +56,7 @@ typedef struct agent_stats {
   double lba_s; int64_t lba_calls, lba_iters;
   int64_t kp, m_frame, m_map;
   int32_t error, error_step;
+  double worst_step_s, worst_stage_s[8];   // the slowest timed step of the call and its stages (same order as stage_s)
 } agent_stats;
 
 // struct sizes for the binding's layout check (multi_orbslam3_amd/agent.py)
@@ -180,7 +181,13 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
       st->stage_s[0] += t1 - t0; st->stage_s[1] += t2 - t1; st->stage_s[2] += t3 - t2b; st->stage_s[3] += t_po;
       st->stage_s[4] += t5 - t4; st->stage_s[5] += t6 - t5; st->stage_s[6] += t_lv;
       st->kp += nl + nr; st->m_frame += n1; st->m_map += n2;
-      if (step_s) step_s[s] = now_s() - t0;
+      const double t_step = now_s() - t0;
+      if (step_s) step_s[s] = t_step;
+      if (t_step > st->worst_step_s) {
+        st->worst_step_s = t_step;
+        const double w[8] = {t1 - t0, t2 - t1, t3 - t2b, t_po, t5 - t4, t6 - t5, t_lv, 0.0};
+        for (int q = 0; q < 8; q++) st->worst_stage_s[q] = w[q];
+      }
     }
   }
   st->error = rc;

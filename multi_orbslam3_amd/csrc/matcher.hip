@@ -1276,6 +1276,13 @@ extern "C" int orbm_map_destroy(orbm_map* m) {
   return ORBG_OK;
 }
 
+// pinned staging block -> device arena, 16 bytes per thread, every PCIe read in flight at once (map uploads, last-frame views): the
+// runtime's hipMemcpyAsync takes ~26 us to move 150 KB (its blit kernel), this a few
+__global__ __launch_bounds__(256) void lastview_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
 extern "C" int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* p) {
   if (!m || !p || p->m < 0) return ORBG_BAD_ARG;
   if (p->m > 0 && (!p->pos || !p->normal || !p->min_dist || !p->max_dist || !p->desc || !p->n_obs || !p->bad)) return ORBG_BAD_ARG;
@@ -1294,7 +1301,10 @@ extern "C" int orbm_map_upload(orbm_map* m, const orbm_worldpoints_view* p) {
     memcpy(S + m->o_min, p->min_dist, n * 4); memcpy(S + m->o_max, p->max_dist, n * 4);
     memcpy(S + m->o_desc, p->desc, n * 32); memcpy(S + m->o_bad, p->bad, n);
     if (p->skip) memcpy(S + m->o_skip, p->skip, n); else memset(S + m->o_skip, 0, n);
-    ORBG_HIP(hipMemcpyAsync(m->arena.p, S, m->arena_bytes, hipMemcpyHostToDevice, m->stream));
+    const int n16 = (int)((m->arena_bytes + 15) / 16);
+    hipLaunchKernelGGL(lastview_copy_kernel, dim3((n16 + 255) / 256), dim3(256), 0, m->stream, reinterpret_cast<const uint4*>(m->stage.d),
+                       reinterpret_cast<uint4*>(m->arena.p), n16);
+    ORBG_HIP(hipGetLastError());
     ORBG_HIP(hipEventRecord(m->up_ev, m->stream));
     m->up_pending = true;
   }
@@ -1721,11 +1731,6 @@ struct orbm_lastview {
   std::vector<float> angle;
   float Tcw[16] = {0};
 };
-
-__global__ __launch_bounds__(256) void lastview_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n16) dst[i] = src[i];
-}
 
 extern "C" int orbm_lastview_create(int device, int cap_features, orbm_lastview** out) {
   if (!out || cap_features < 0) return ORBG_BAD_ARG;
