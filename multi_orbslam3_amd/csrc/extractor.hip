@@ -2446,7 +2446,7 @@ static const bool g_img_runtime_copy = getenv("ORBG_IMG_RUNTIME_COPY") != nullpt
 // every read in flight before the first store.  The word is written once, behind the pack, and is the only host memory the device
 // reads while the host is still packing (a first form that polled a word per 38 KB chunk from a kernel launched before the pack was
 // measured at 64 us per pair: the device's reads of lines the host was writing slowed the pack itself to 21-47 us).  A poll that does
-// not see its word within ~100 ms (the packing thread died) raises the handle's error word instead of hanging the device.
+// not see its word within ~2 s (the packing thread died) raises the handle's error word instead of hanging the device.
 // (Also measured, round 4: the right image packed by the SUBMITTING thread while the ingest thread packs the left one -- the ingest
 // thread's pack halves, 15 -> 8 us, the constructor's latency does not move, 147 vs 146 us: next to the searches and the local BA the
 // chain is not waiting for the second image.)
@@ -2460,7 +2460,7 @@ __global__ __launch_bounds__(kUpThreads) void img_upload_pair_kernel(const uint4
     b0 = first16; b1 = total16; wg = blockIdx.x - wg_first;
     if (threadIdx.x == 0) {
       int ok = 0;
-      for (int spin = 0; spin < (1 << 16); spin++) {
+      for (int spin = 0; spin < (1 << 20); spin++) {          // ~2 s: a packing thread that lost its core for a few time slices is no error
         if (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) { ok = 1; break; }
         __builtin_amdgcn_s_sleep(4);
       }
