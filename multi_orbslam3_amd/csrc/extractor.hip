@@ -508,6 +508,7 @@ constexpr int kOctListCap = 2048;    // nodes alive at once (<= 4*N + 8)
 struct OctCfg {
   int n_levels, n_cams;
   int oldest_first;                  // quad-tree tie-break variant (orbx_config.octree_oldest_first)
+  int jump;                          // 1: the first (up to three) uniform passes come from a three-level histogram (octree_kernel, "jump start")
   int n_target[ORBG_MAX_LEVELS];     // mnFeaturesPerLevel
   int reg_off[2][ORBG_MAX_LEVELS];   // start of the (camera, level) region in the selection buffer
   int reg_cap[ORBG_MAX_LEVELS];
@@ -667,6 +668,10 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   auto nonzero4 = [](unsigned c01, unsigned c23) { return (int)((c01 & 0xFFFFu) != 0) + (int)((c01 >> 16) != 0) + (int)((c23 & 0xFFFFu) != 0) + (int)((c23 >> 16) != 0); };
   // ---- roots (:541-583)
   for (int i = tid; i < nIni; i += kOctThreads) scanA[i] = 0;
+  // scratch of the jump start: h3[128] | h2[32] | h1[8] behind the root counts, the order masks in scanB
+  constexpr int kJ3 = 16, kJ2 = kJ3 + 128, kJ1 = kJ2 + 32, kJEnd = kJ1 + 8;
+  for (int i = kJ3 + tid; i < kJEnd; i += kOctThreads) scanA[i] = 0;
+  if (tid < 32) scanB[16 + tid] = 0;
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < kOctKPT; m++) {
@@ -681,7 +686,183 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
     }
   }
   __syncthreads();
+  // ---- jump start (round 4).  Phase-1 passes split EVERY node that holds more than one key, so the list after the first J of them
+  // (J <= 3: 1 -> 4 -> 16 -> 64 nodes per root, ~5.5 k cycles each for almost no work) is a function of the key counts of the
+  // 4 / 16 / 64 cells of a three-level quadrant grid per root:
+  //   * a depth-d cell is a node iff it holds keys and every ancestor holds more than one; it stops splitting when it holds one;
+  //   * creation order within pass j ("parents in list order, quadrants ascending", children then pushed to the front reversed):
+  //     depth 1: (root, q1) ascending; depth 2: (root, q1) DESCENDING then q2 ascending; depth 3: (root, q1) ascending, q2
+  //     descending, q3 ascending -- the permuted indices pi1 / pi2 / pi3 below;
+  //   * list after pass J = depth-J nodes in descending pi_J, then the one-key leaves of depth J-1 in descending pi_{J-1}, ...,
+  //     depth 1, then the one-key roots in root order (survivors keep their order behind the new children);
+  //   * after each pass the reference's rules decide (:667-671): size >= N or unchanged -> finished; size + 3 * expandable > N ->
+  //     phase 2.  They are evaluated on the counts, so J, the phase and "finished" come out exactly as the pass loop would find them.
+  // One histogram (an LDS atomic per key), bit masks of "node" / "one-key leaf" per depth in creation order, positions by popcount.
+  bool jumped = false, jump_finished = false;
+  int jump_n = 0, jump_mode = 1;
+  if (cfg.jump && nIni <= 2 && (scanA[0] > 1 || (nIni > 1 && scanA[1] > 1))) {
+    int* const h3 = scanA + kJ3; int* const h2 = scanA + kJ2; int* const h1 = scanA + kJ1;
+    unsigned* const EX3 = reinterpret_cast<unsigned*>(scanB) + 16; unsigned* const LF3 = EX3 + 4;          // [4] words each
+    unsigned* const EX2 = EX3 + 8; unsigned* const LF2 = EX3 + 9; unsigned* const EX1 = EX3 + 10; unsigned* const LF1 = EX3 + 11;
+    unsigned* const RLF = EX3 + 12;                                                                        // one-key roots (bit r)
+    auto root_box = [&](int r, int* x0, int* x1) { *x0 = (int)(short)(int)(hX * (float)r); *x1 = (int)(short)(int)(hX * (float)(r + 1)); };
+    auto child_of = [](int q, int* x0, int* x1, int* y0, int* y1) {
+      const int mx = *x0 + ((*x1 - *x0 + 1) >> 1), my = *y0 + ((*y1 - *y0 + 1) >> 1);
+      if (q & 1) *x0 = mx; else *x1 = mx;
+      if (q & 2) *y0 = my; else *y1 = my;
+    };
+    OCT_T(20);
+    unsigned code[kOctKPT];
+#pragma unroll
+    for (int m = 0; m < kOctKPT; m++) {
+      code[m] = 0;
+      if (tid + kOctThreads * m < nk) {
+        const int kx = kw[m] & 0xFFF, ky = (kw[m] >> 12) & 0xFFF;
+        int x0, x1, y0 = 0, y1 = H;
+        root_box((int)kn[m], &x0, &x1);
+        unsigned c = kn[m];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+          const int q = (kx < mx ? 0 : 1) + (ky < my ? 0 : 2);
+          child_of(q, &x0, &x1, &y0, &y1);
+          c = c * 4 + (unsigned)q;
+        }
+        code[m] = c;
+        atomicAdd(&h3[c], 1);
+      }
+    }
+    OCT_T(21);
+    __syncthreads();
+    OCT_T(22);
+    const int idmax1 = nIni * 4 - 1;
+    auto cnt0 = [&](int r) { return r < nIni ? scanA[r] : 0; };
+    auto pi2 = [&](int id2) { return (idmax1 - (id2 >> 2)) * 4 + (id2 & 3); };
+    auto pi3 = [](int id3) { return ((id3 >> 4) * 4 + (3 - ((id3 >> 2) & 3))) * 4 + (id3 & 3); };
+    // the masks by wavefront ballots (no LDS atomics on shared words): thread t of wavefronts 0 / 1 stands for the depth-3 cell
+    // whose creation-order index pi3 is t; wavefront 2: lanes 0..31 the depth-2 cell with pi2 = lane, lanes 32..39 the depth-1
+    // cells, lanes 40..41 the roots.  A thread sums the 16 depth-3 counts of its depth-1 cell itself (four 128-bit reads in
+    // flight): the counts of its parents need no pass of their own; the depth-2 / depth-1 threads leave theirs in h2 / h1.
+    {
+      const int lane = tid & 63, wv = tid >> 6;
+      bool is_node = false, one = false;
+      int id1 = -1, q2 = 0, q3 = 0, kind = -1;          // kind: 3 / 2 / 1 = depth of the thread's cell, 0 = root
+      if (wv < 2) { id1 = tid >> 4; q2 = 3 - ((tid >> 2) & 3); q3 = tid & 3; kind = 3; }                   // pi3^-1(t)
+      else if (wv == 2 && lane < 32) { id1 = idmax1 - (lane >> 2); q2 = lane & 3; kind = 2; }            // pi2^-1(lane)
+      else if (wv == 2 && lane < 40) { id1 = lane - 32; kind = 1; }
+      else if (wv == 2 && lane < 42) { kind = 0; }
+      if (kind >= 1 && id1 >= 0 && (id1 >> 2) < nIni) {
+        const int4* blk = reinterpret_cast<const int4*>(h3 + 16 * id1);
+        const int4 b0 = blk[0], b1 = blk[1], b2 = blk[2], b3 = blk[3];
+        const int s0 = b0.x + b0.y + b0.z + b0.w, s1 = b1.x + b1.y + b1.z + b1.w, s2 = b2.x + b2.y + b2.z + b2.w, s3 = b3.x + b3.y + b3.z + b3.w;
+        const int c1 = (s0 + s1) + (s2 + s3);
+        const int c2 = q2 == 0 ? s0 : q2 == 1 ? s1 : q2 == 2 ? s2 : s3;
+        const int4 bq = q2 == 0 ? b0 : q2 == 1 ? b1 : q2 == 2 ? b2 : b3;
+        const int c3 = q3 == 0 ? bq.x : q3 == 1 ? bq.y : q3 == 2 ? bq.z : bq.w;
+        const bool n1 = c1 > 0 && cnt0(id1 >> 2) > 1, n2 = c2 > 0 && n1 && c1 > 1, n3 = c3 > 0 && n2 && c2 > 1;
+        if (kind == 3) { is_node = n3; one = n3 && c3 == 1; }
+        else if (kind == 2) { is_node = n2; one = n2 && c2 == 1; h2[id1 * 4 + q2] = c2; }
+        else { is_node = n1; one = n1 && c1 == 1; h1[id1] = c1; }
+      } else if (kind == 0) {
+        const int r = lane - 40;
+        if (r < nIni && scanA[r] == 1) one = true;
+      }
+      const unsigned long long bn = __ballot(is_node), bo = __ballot(one);
+      if (lane == 0) {
+        if (wv < 2) { EX3[2 * wv] = (unsigned)bn; EX3[2 * wv + 1] = (unsigned)(bn >> 32); LF3[2 * wv] = (unsigned)bo; LF3[2 * wv + 1] = (unsigned)(bo >> 32); }
+        else if (wv == 2) {
+          *EX2 = (unsigned)bn; *LF2 = (unsigned)bo;
+          *EX1 = (unsigned)(bn >> 32) & 0xFFu; *LF1 = (unsigned)(bo >> 32) & 0xFFu;
+          *RLF = (unsigned)(bo >> 40) & 0x3u;
+        }
+      }
+    }
+    OCT_T(23);
+    __syncthreads();
+    OCT_T(24);
+    auto node1 = [&](int id1) { return h1[id1] > 0 && cnt0(id1 >> 2) > 1; };
+    auto node2 = [&](int id2) { return h2[id2] > 0 && node1(id2 >> 2) && h1[id2 >> 2] > 1; };
+    auto node3 = [&](int id3) { return h3[id3] > 0 && node2(id3 >> 2) && h2[id3 >> 2] > 1; };
+    const unsigned e3[4] = {EX3[0], EX3[1], EX3[2], EX3[3]}, f3[4] = {LF3[0], LF3[1], LF3[2], LF3[3]};
+    const unsigned e2 = *EX2, f2 = *LF2, e1 = *EX1, f1 = *LF1, rl = *RLF;
+    const int k1 = __popc(e1), l1 = __popc(f1), k2 = __popc(e2), l2 = __popc(f2);
+    const int k3 = __popc(e3[0]) + __popc(e3[1]) + __popc(e3[2]) + __popc(e3[3]);
+    const int l3 = __popc(f3[0]) + __popc(f3[1]) + __popc(f3[2]) + __popc(f3[3]);
+    const int l0 = __popc(rl), xr = (int)(cnt0(0) > 1) + (int)(cnt0(1) > 1), n0 = l0 + xr;
+    // the pass loop's decisions on the counts
+    int J = 1, nn = k1 + l0, prevn = n0, md = 1;
+    bool fin = false;
+    if (nn >= N || nn == prevn) fin = true;
+    else if (nn + 3 * (k1 - l1) > N) md = 2;
+    else if (k1 - l1 == 0) fin = true;                              // no node left to split: the next pass would leave at once
+    else {
+      J = 2; prevn = nn; nn = k2 + l1 + l0;
+      if (nn >= N || nn == prevn) fin = true;
+      else if (nn + 3 * (k2 - l2) > N) md = 2;
+      else if (k2 - l2 == 0) fin = true;
+      else {
+        J = 3; prevn = nn; nn = k3 + l2 + l1 + l0;
+        if (nn >= N || nn == prevn) fin = true;
+        else if (nn + 3 * (k3 - l3) > N) md = 2;
+      }
+    }
+    const int KJ = J == 1 ? k1 : J == 2 ? k2 : k3;
+    auto below128 = [&](const unsigned* w, int p) {                 // set bits of the 128-bit mask below bit p
+      int a = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) a += j < (p >> 5) ? __popc(w[j]) : j == (p >> 5) ? __popc(w[j] & ((1u << (p & 31)) - 1u)) : 0;
+      return a;
+    };
+    auto below32 = [](unsigned w, int p) { return __popc(w & ((1u << p) - 1u)); };
+    auto above32 = [](unsigned w, int p) { return p >= 31 ? 0 : __popc(w >> (p + 1)); };
+    // list position of: a depth-J node, a one-key leaf of depth d < J, a one-key root
+    const int off2 = KJ, off1 = KJ + (J > 2 ? l2 : 0), off0 = KJ + (J > 2 ? l2 : 0) + (J > 1 ? l1 : 0);
+    auto pos_d3 = [&](int id3) { return KJ - 1 - below128(e3, pi3(id3)); };
+    auto pos_d2 = [&](int id2) { const int p = pi2(id2); return J == 2 ? KJ - 1 - below32(e2, p) : off2 + above32(f2, p); };
+    auto pos_d1 = [&](int id1) { return J == 1 ? KJ - 1 - below32(e1, id1) : off1 + above32(f1, id1); };
+    auto pos_d0 = [&](int r) { return off0 + below32(rl, r); };
+    // ---- the nodes: one thread per cell that is in the list
+    {
+      int depth = -1, id = 0;
+      if (tid < 128) { depth = 3; id = tid; } else if (tid < 160) { depth = 2; id = tid - 128; } else if (tid < 168) { depth = 1; id = tid - 160; } else if (tid < 170) { depth = 0; id = tid - 168; }
+      const int r = depth < 0 ? nIni : id >> (2 * depth);
+      if (depth >= 0 && r < nIni) {
+        bool in_list; int pos = 0, cnt = 0, seq = 0;
+        if (depth == 3) { in_list = J == 3 && node3(id); if (in_list) { pos = pos_d3(id); cnt = h3[id]; seq = below128(e3, pi3(id)); } }
+        else if (depth == 2) { in_list = J >= 2 && node2(id) && (J == 2 || h2[id] == 1); if (in_list) { pos = pos_d2(id); cnt = h2[id]; seq = below32(e2, pi2(id)); } }
+        else if (depth == 1) { in_list = node1(id) && (J == 1 || h1[id] == 1); if (in_list) { pos = pos_d1(id); cnt = h1[id]; seq = below32(e1, id); } }
+        else { in_list = scanA[id] == 1; if (in_list) { pos = pos_d0(id); cnt = 1; seq = (id == 1 && scanA[0] > 0) ? 1 : 0; } }
+        if (in_list) {
+          int x0, x1, y0 = 0, y1 = H;
+          root_box(r, &x0, &x1);
+          for (int d = depth - 1; d >= 0; d--) child_of((id >> (2 * d)) & 3, &x0, &x1, &y0, &y1);
+          node[0][pos] = make_uint4((unsigned)(unsigned short)(short)x0 | ((unsigned)(unsigned short)(short)x1 << 16),
+                                    (unsigned)(unsigned short)(short)y0 | ((unsigned)(unsigned short)(short)y1 << 16), (unsigned)cnt | ((unsigned)seq << 16), 0u);
+          cc2[0][pos][0] = 0; cc2[0][pos][1] = 0;
+        }
+      }
+    }
+    OCT_T(25);
+    // ---- the keys: the deepest node on the key's path (it stops at the first cell that holds one key, or at depth J)
+#pragma unroll
+    for (int m = 0; m < kOctKPT; m++) {
+      unsigned pos = 0;
+      if (tid + kOctThreads * m < nk) {
+        const int id3 = (int)code[m], id2 = id3 >> 2, id1 = id3 >> 4, r = id3 >> 6;
+        if (scanA[r] == 1) pos = (unsigned)pos_d0(r);
+        else if (J == 1 || h1[id1] == 1) pos = (unsigned)pos_d1(id1);
+        else if (J == 2 || h2[id2] == 1) pos = (unsigned)pos_d2(id2);
+        else pos = (unsigned)pos_d3(id3);
+      }
+      kn[m] = pos;
+    }
+    jumped = true; jump_finished = fin; jump_n = nn; jump_mode = md;
+    OCT_T(26);
+    __syncthreads();
+    OCT_T(27);
+  }
   // one thread per root: list position = number of non-empty roots before it (empty roots are dropped, :579-580)
+  if (!jumped)
   for (int r = tid; r < nIni; r += kOctThreads) {
     const int c = scanA[r];
     int rank = 0;
@@ -695,12 +876,14 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
     if (r == nIni - 1) s_n = rank + (c > 0);
   }
   __syncthreads();
+  if (!jumped) {
 #pragma unroll
-  for (int m = 0; m < kOctKPT; m++) kn[m] = tid + kOctThreads * m < nk ? (unsigned)scanB[kn[m]] : 0u;
-  int cur = 0, n = s_n, mode = 1, par = 0, ws = 0;
+    for (int m = 0; m < kOctKPT; m++) kn[m] = tid + kOctThreads * m < nk ? (unsigned)scanB[kn[m]] : 0u;
+  }
+  int cur = 0, n = jumped ? jump_n : s_n, mode = jumped ? jump_mode : 1, par = 0, ws = 0;
   // loop invariant: node[cur][0..n) is the list, cc2[cur][0..n) is zero, kn[m] & 0xFFFF is the position of key m's node
   OCT_T(1);
-  for (int pass = 0; pass < 64; pass++) {
+  for (int pass = 0; pass < 64 && !jump_finished; pass++) {
     const int prev = n;
     const int nxt = cur ^ 1;
     OCT_T(4 + 2 * pass);
@@ -1839,6 +2022,7 @@ static int setup_geometry(orbx_handle* h, int w, int hgt) {
     OctCfg& oc = h->octcfg;
     oc.n_levels = nl; oc.n_cams = nc;
     oc.oldest_first = h->cfg.octree_oldest_first != 0;
+    oc.jump = getenv("ORBG_OCT_NO_JUMP") ? 0 : 1;      // (read when the geometry is set up: per handle)
     int roff = 0;
     bool fits = true;
     for (int l = 0; l < nl; l++) {

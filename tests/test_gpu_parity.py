@@ -379,7 +379,7 @@ def test_frame_constructor_as_an_executable_graph():
     assert m and int(m.group(2)) == 2 and int(m.group(1)) >= 6, (r.stdout[-1500:], r.stderr[-1500:])
 
 
-@pytest.mark.parametrize("switch", ["ORBG_CTOR_FUSED_TAIL", "ORBG_OCT_GATHER", "ORBG_IMG_TWO_UPLOADS"])
+@pytest.mark.parametrize("switch", ["ORBG_CTOR_FUSED_TAIL", "ORBG_OCT_GATHER", "ORBG_IMG_TWO_UPLOADS", "ORBG_OCT_NO_JUMP"])
 def test_frame_constructor_chain_variants(switch):
     """The A/B forms of the constructor chain (read once per process): stereo match + median rejection + grid + completion word as ONE
     launch (stereo_grid_kernel: last-workgroup ticket, agent-scope hand-over), quad-trees fed by gather_cells_kernel's compacted list

@@ -28,6 +28,10 @@ for b in range(16):
     print(line)
 
 for b in (0, 2):
+    if p[b, 27] > p[b, 20] > 0:
+        print("blk %d jump start: before %d | codes + histogram %d | barrier %d | masks %d | barrier %d | decisions + nodes %d | key positions %d | barrier %d" %
+              (b, p[b,20]-p[b,0], p[b,21]-p[b,20], p[b,22]-p[b,21], p[b,23]-p[b,22], p[b,24]-p[b,23], p[b,25]-p[b,24], p[b,26]-p[b,25], p[b,27]-p[b,26]))
+for b in (0, 2):
     print("blk %d pass 2 (mode 1): keys %d | barrier %d | scan %d | children %d | barrier %d | follow %d" % (b, p[b,30]-p[b,8], p[b,31]-p[b,30], p[b,32]-p[b,31], p[b,33]-p[b,32], p[b,34]-p[b,33], p[b,35]-p[b,34]))
 b = 0
 print("blk 0 pass 4 (mode 2): keys+rankkeys %d | barrier %d | rank %d | barrier %d | order scan+cut %d | (barrier+C+surv scan) %d | children %d | barrier+follow %d" % (p[b,36]-p[b,12], p[b,37]-p[b,36], p[b,38]-p[b,37], p[b,39]-p[b,38], p[b,40]-p[b,39], p[b,41]-p[b,40], p[b,42]-p[b,41], p[b,43]-p[b,42]))
