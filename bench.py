@@ -309,6 +309,9 @@ def main():
                          "--separate-calls / --profile-stages always use it)")
     ap.add_argument("--submit-order", choices=["before-wait", "after-wait"], default="before-wait",
                     help="pipelined constructor: hand frame t+1 over before or after frame t's constructor is collected")
+    ap.add_argument("--ctor-ahead", type=int, default=int(os.environ.get("ORBG_BENCH_CTOR_AHEAD", "2")), choices=[1, 2, 3],
+                    help="pipelined constructor: frames handed over ahead of the one being tracked (ring of N + 1 extractor handles / frame "
+                         "objects; the python loop supports 1)")
     ap.add_argument("--ingest", choices=["thread", "inline"], default="thread",
                     help="host images: thread = the library's ingest thread packs the rows into pinned staging and enqueues the "
                          "constructor (orbx_frame_stereo_submit, ORBX_SUBMIT_ASYNC); inline = the tracking thread does")
@@ -393,9 +396,11 @@ def main():
     fv, fv_keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
     F = api.Frame(cfg["frame_cap"], device)
     # frame t+1 is constructed (second extractor handle, second frame object) while frame t is tracked
-    exs = [ex, api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, W, H, n_cams=2, device=device)] if pipeline else [ex]
-    Fs = [F, api.Frame(cfg["frame_cap"], device)] if pipeline else [F]
-    in_flight = [False, False]
+    ctor_ahead = args.ctor_ahead if (args.loop == "cxx" and stereo and not args.separate_calls and not args.profile_stages) else 1
+    n_ring = 2 if ctor_ahead == 1 else 4        # an even ring: consecutive frames alternate between the two extractor streams
+    exs = [ex] + [api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, W, H, n_cams=2, device=device) for _ in range(n_ring - 1)] if pipeline else [ex]
+    Fs = [F] + [api.Frame(cfg["frame_cap"], device) for _ in range(n_ring - 1)] if pipeline else [F]
+    in_flight = [False] * 4
     LM = api.LocalMap(cfg["map_cap"], device)
     m_frame = api.ORBmatcher(0.9, True, device)
     m_map = api.ORBmatcher(0.8, True, device)
@@ -609,7 +614,7 @@ def main():
 
     def run_region_cxx(n_steps, n_warm, pose_opt, host_images, pipelined, first_index):
         reg = Region(n_steps)
-        loop.configure(pipelined, host_images, ingest_async, submit_first, args.lba_mode == "async", pose_opt)
+        loop.configure(pipelined, host_images, ingest_async, submit_first, args.lba_mode == "async", pose_opt, ahead=ctor_ahead)
         st = agent_mod.Stats()
 
         def sync():
@@ -685,7 +690,7 @@ def main():
     # (... and such that the first TIMED step is a keyframe step: the region then holds exactly K / FRAMES_PER_KF local BAs, the
     # last of them submitted FRAMES_PER_KF steps before the clock stops, whatever K and --warmup are)
     if use_cxx:
-        loop.configure(pipeline, host_images, ingest_async, submit_first, args.lba_mode == "async", args.pose_opt)
+        loop.configure(pipeline, host_images, ingest_async, submit_first, args.lba_mode == "async", args.pose_opt, ahead=ctor_ahead)
     # The pre-warm runs until the step rate is STATIONARY: chunks of 100 steps, until at least --prewarm-steps steps and 0.3 s have
     # passed and the last three chunks agree within 1.5 % (cap: 3 s).  Measured on fresh boxes: after 400 steps / 50 ms the first
     # K = 20 region was 4-7 % below the four that followed it (and 20 % on the driver's box in round 3); after 4000 steps it is
@@ -902,9 +907,11 @@ def main():
                        "local_map_points_avg": int(np.mean(maps.sizes)) if maps.sizes else 0, "local_map_keyframes": cfg["local_kfs"],
                        "sequence_frames": len(seq),
                        "cpu_affinity": cpu_affinity, "host_noise": host_noise, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
-                       "frame_ctor": ("pipelined: Frame(t+1) is submitted (host images: orbx_frame_stereo_submit) on a second extractor handle before frame t is tracked and "
-                                      "collected at the start of step t+1; the timed region holds exactly K constructors (the first step "
-                                      "submits its own, the last one hands no further frame over)") if pipeline else "synchronous",
+                       "frame_ctor": ("pipelined, %d frame(s) ahead: Frame(t+1 .. t+%d) are submitted (host images: orbx_frame_stereo_submit) on the other extractor "
+                                      "handles of a ring of %d before frame t is tracked, and collected at the start of their own steps; the timed region holds "
+                                      "exactly K constructors (the first step submits its own and the ones ahead, the last ones hand no further frame over)"
+                                      % (ctor_ahead, ctor_ahead, n_ring)) if pipeline else "synchronous",
+                       "frame_ctor_ahead": ctor_ahead if pipeline else 0,
                        "pose_opt_ms_per_call_450_correspondences": round(pose_opt_ms, 4),
                        "lba_ms_per_call": round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3),
                        "sequential_fps_formula": round(1.0 / (sum(v for k2, v in stage.items() if k2 != "lba") / K +

@@ -17,15 +17,15 @@ class FrameIn(C.Structure):
 
 
 class Cfg(C.Structure):
-    _fields_ = [("ex", C.c_void_p * 2), ("fr", C.c_void_p * 2), ("local_map", C.c_void_p), ("lba", C.c_void_p),
+    _fields_ = [("ex", C.c_void_p * 4), ("fr", C.c_void_p * 4), ("local_map", C.c_void_p), ("lba", C.c_void_p),
                 ("frame_view", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride", C.c_int), ("bf", C.c_float), ("b", C.c_float),
                 ("frames", C.c_void_p), ("n_frames", C.c_int), ("seq", C.c_void_p), ("n_seq", C.c_int),
                 ("kf_maps", C.c_void_p), ("n_kf_maps", C.c_int), ("lba_prob", C.c_void_p), ("lba_out", C.c_void_p),
                 ("po", C.c_void_p * 2), ("po_out", C.c_void_p * 2), ("frames_per_kf", C.c_int),
                 ("pipelined", C.c_int), ("host_images", C.c_int), ("ingest_async", C.c_int), ("submit_first", C.c_int),
                 ("lba_async", C.c_int), ("pose_opt", C.c_int), ("th_frame", C.c_float), ("mono", C.c_int), ("nn_frame", C.c_float),
-                ("nn_map", C.c_float), ("amp", C.c_void_p), ("aob", C.c_void_p), ("cap", C.c_int), ("in_flight", C.c_int32 * 2),
-                ("lba_in_flight", C.c_int32), ("last_view_dev", C.c_void_p), ("last_view_frame", C.c_int32)]
+                ("nn_map", C.c_float), ("amp", C.c_void_p), ("aob", C.c_void_p), ("cap", C.c_int), ("in_flight", C.c_int32 * 4),
+                ("ahead", C.c_int32), ("ring", C.c_int32), ("lba_in_flight", C.c_int32), ("last_view_dev", C.c_void_p), ("last_view_frame", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -63,9 +63,11 @@ class AgentLoop:
         self.lib = load()
         self.keep = [exs, frs, local_map, opt, frame_view, frames, kf_map_views, lba_prob, lba_out, po_probs]
         c = Cfg()
-        for j in range(2):
+        for j in range(4):
             c.ex[j] = exs[min(j, len(exs) - 1)].h.value
             c.fr[j] = frs[min(j, len(frs) - 1)].h.value
+        c.ring = max(min(len(exs), 4), 2)                  # ring of (handle, frame) pairs; frames handed over ahead: configure(ahead=)
+        c.ahead = 1
         c.local_map, c.lba = local_map.h.value, opt.h.value
         c.frame_view = C.addressof(frame_view)
         c.width, c.height, c.stride, c.bf, c.b = width, height, stride, bf, b
@@ -100,8 +102,9 @@ class AgentLoop:
         c.last_view_frame = -1
         self.c = c
 
-    def configure(self, pipelined, host_images, ingest_async, submit_first, lba_async, pose_opt):
+    def configure(self, pipelined, host_images, ingest_async, submit_first, lba_async, pose_opt, ahead=1):
         c = self.c
+        c.ahead = max(1, min(int(ahead), c.ring - 1))
         c.pipelined, c.host_images, c.ingest_async, c.submit_first = int(pipelined), int(host_images), int(ingest_async), int(submit_first)
         c.lba_async, c.pose_opt = int(lba_async), int(pose_opt)
 

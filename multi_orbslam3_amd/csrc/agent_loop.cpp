@@ -8,7 +8,7 @@
 // handles and the per-frame views once and times agent_run(); a deployment has Tracking.cc in this place.
 //
 //   step(i):  frame k = seq[i % n_seq]
-//     pipelined:   [submit Frame(t+1) on the other extractor handle]  wait Frame(t)         (orbx_frame_stereo_submit / _dev_submit / _wait)
+//     pipelined:   [submit Frame(t+1 .. t+ahead) on the other extractor handles]  wait Frame(t)   (orbx_frame_stereo_submit / _dev_submit / _wait)
 //     synchronous: Frame(t) = orbx_frame_stereo / orbx_frame_stereo_dev
 //     SearchByProjection(Current, Last)  [PoseOptimization]  SearchLocalPoints  [PoseOptimization]
 //     keyframe step (i % frames_per_kf == 0): local map refresh (orbm_map_upload), wait for the previous local BA, submit the next
@@ -32,7 +32,7 @@ typedef struct agent_frame_in {            // what Tracking holds for one frame 
 } agent_frame_in;
 
 typedef struct agent_cfg {
-  orbx_handle* ex[2]; orbm_frame* fr[2];                     // ping-pong: Frame(t+1) is built on the other pair
+  orbx_handle* ex[4]; orbm_frame* fr[4];                     // ring of (extractor handle, frame object) pairs: Frame(t+1 .. t+ahead) are built on the others
   orbm_map* local_map; lba_handle* lba;
   const orbm_frame_view* frame_view;                         // intrinsics / bounds (features come from the constructor)
   int width, height, stride; float bf, b;
@@ -45,7 +45,9 @@ typedef struct agent_cfg {
   int pipelined, host_images, ingest_async, submit_first, lba_async, pose_opt;
   float th_frame; int mono; float nn_frame, nn_map;
   int32_t* amp; int32_t* aob; int cap;                       // F.mvpMapPoints as (assigned_mp, assigned_obs), cap entries each
-  int32_t in_flight[2];                                      // pipelined constructor submitted on ex[c] and not yet collected (state across calls)
+  int32_t in_flight[4];                                      // pipelined constructor submitted on ex[c] and not yet collected (state across calls)
+  int32_t ahead, ring;                                       // pipelined: frames handed over ahead of the one being tracked (1 .. ring - 1), pairs in the ring (2 .. 4;
+                                                             // an even ring keeps consecutive frames on alternating extractor streams)
   int32_t lba_in_flight;                                     // a local BA submitted and not yet collected
   orbm_lastview* last_view_dev;                              // NULL: SearchByProjection(Current, Last) reads the view in place (pinned memory)
   int32_t last_view_frame;                                   // frame whose view is resident in last_view_dev (-1: none)
@@ -98,20 +100,26 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
     const double t0 = now_s();
     int nl = 0, nr = 0, cur = 0;
     if (c->pipelined) {
-      cur = (int)(i & 1);
-      if (!c->in_flight[cur]) { if ((rc = submit_ctor(c, cur, k))) break; c->in_flight[cur] = 1; }     // first step only
-      if (c->submit_first && !last) {
-        // Frame(t+1) is handed over (other handle, other frame object) BEFORE frame t is collected: its staging copy and its
-        // launches overlap the tail of frame t's constructor; the image pair t+1 is needed at the same moment either way
-        if ((rc = submit_ctor(c, cur ^ 1, c->seq[(i + 1) % c->n_seq]))) break;
-        c->in_flight[cur ^ 1] = 1;
-      }
-      if ((rc = orbx_frame_stereo_dev_wait(c->ex[cur], &nl, &nr))) break;
+      // ring of (handle, frame) pairs: frame t lives in pair t % ring.  Frame(t+1 .. t+ahead) are handed over (their
+      // staging copies and launches overlap frame t's constructor tail and tracking) either before or after frame t is collected;
+      // a final region hands nothing over beyond its last step, so it holds exactly n_steps constructors
+      const int ring = c->ring < 2 ? 2 : c->ring > 4 ? 4 : c->ring, ahead = c->ahead < 1 ? 1 : c->ahead > ring - 1 ? ring - 1 : c->ahead;
+      cur = (int)(i % ring);
+      auto submit_ahead = [&](int d0, int d1) -> int {
+        for (int d = d0; d <= d1; d++) {
+          const int slot = (int)((i + d) % ring);
+          if (c->in_flight[slot] || (last_is_final && s + d >= n_steps)) continue;
+          const int r = submit_ctor(c, slot, c->seq[(i + d) % c->n_seq]);
+          if (r) return r;
+          c->in_flight[slot] = 1;
+        }
+        return ORBG_OK;
+      };
+      if ((rc = submit_ahead(0, 0))) break;                    // the first step of a sequence only (nothing was handed over ahead)
+      if (!c->submit_first || (rc = submit_ahead(1, ahead)) == ORBG_OK) rc = orbx_frame_stereo_dev_wait(c->ex[cur], &nl, &nr);
+      if (rc) break;
       c->in_flight[cur] = 0;
-      if (!c->submit_first && !last) {
-        if ((rc = submit_ctor(c, cur ^ 1, c->seq[(i + 1) % c->n_seq]))) break;
-        c->in_flight[cur ^ 1] = 1;
-      }
+      if (!c->submit_first && (rc = submit_ahead(1, ahead))) break;
     } else if (c->host_images) {
       rc = orbx_frame_stereo(c->ex[0], c->fr[0], c->frame_view, fin.host_left, fin.host_right, c->width, c->height, c->stride, c->bf, c->b,
                              nullptr, nullptr, nullptr, nullptr, 0, &nl, &nr);
@@ -199,7 +207,7 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
 int agent_drain(agent_cfg* c, agent_stats* st, int timed) {
   if (!c) return ORBG_BAD_ARG;
   int rc = collect_lba(c, st, timed);
-  for (int s = 0; s < 2; s++)
+  for (int s = 0; s < 4; s++)
     if (c->in_flight[s]) {
       int nl, nr;
       const int r2 = orbx_frame_stereo_dev_wait(c->ex[s], &nl, &nr);

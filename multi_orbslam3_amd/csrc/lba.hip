@@ -2020,6 +2020,7 @@ struct UpdArgs {
   const int* pose_col; const int* point_col; const PoseQ* poses; const double* points; double* x;
   const int* pf_start; const int* pf_edges; const int* pf_col; const double* EB; const double* Hll; const double* bl; double lambda_v;
   PoseQ* poses_out; double* points_out; const double* bp; double* scale_partial; const double* lambda_p;
+  int ldlt_prio;
 };
 constexpr int kFusedUpdThreads = ldltm::kThreads;
 
@@ -2154,6 +2155,7 @@ __global__ __launch_bounds__(ldltm::kThreads) void k_ldlt_cols_update(int n, con
                                                                       int* __restrict__ ok_flag, unsigned* __restrict__ x_ready, unsigned seq,
                                                                       UpdArgs ua) {
   if (blockIdx.x == 0) {
+    if (ua.ldlt_prio) __builtin_amdgcn_s_setprio(3);     // the chain of dependent pivots: its wavefronts issue ahead of any neighbour's on the CU
     ldltm::ldlt_cols_body<true>(n, St, x, ok_flag);      // x leaves through agent-scope stores of wavefront 0
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2265,7 +2267,7 @@ struct StopRef {
 struct LbaSwitches {
   bool blit = false, host_items = false, host_lists = false, no_fuse = false, no_first2 = false, host_csr = false, dev_csr = false;
   bool ldlt_valu = false, ldlt_rows = false, ldlt_wide = false, ldlt_dense = false, fuse_update = true, no_spec = false, no_poll = false;
-  bool no_export_fuse = false;
+  bool no_export_fuse = false, ldlt_prio = false;
   int upd_threads = 64;              // k_update's workgroup size (ORBG_UPD_THREADS = 64 / 128 / 256)
   ldltm::Switches ldlt;              // which matrix-core kernel a size gets (ORBG_LDLT_TILES / _T9_4W / _8W)
   static LbaSwitches from_env() {
@@ -2274,7 +2276,7 @@ struct LbaSwitches {
     w.blit = on("ORBG_LBA_BLIT"); w.host_items = on("ORBG_HOST_ITEMS"); w.host_lists = on("ORBG_HOST_LISTS"); w.no_fuse = on("ORBG_NO_FUSE");
     w.no_first2 = on("ORBG_NO_FIRST2"); w.host_csr = on("ORBG_HOST_CSR"); w.dev_csr = on("ORBG_DEV_CSR"); w.ldlt_valu = on("ORBG_LDLT_VALU");
     w.ldlt_rows = on("ORBG_LDLT_ROWS"); w.ldlt_wide = on("ORBG_LDLT_WIDE"); w.ldlt_dense = on("ORBG_LDLT_DENSE"); w.no_spec = on("ORBG_NO_SPEC");
-    w.no_poll = !orbg::poll_allowed(); w.no_export_fuse = on("ORBG_NO_EXPORT_FUSE");
+    w.no_poll = !orbg::poll_allowed(); w.no_export_fuse = on("ORBG_NO_EXPORT_FUSE"); w.ldlt_prio = on("ORBG_LDLT_PRIO");
     if (const char* e = getenv("ORBG_FUSE_UPDATE")) w.fuse_update = atoi(e) != 0;
     if (const char* e = getenv("ORBG_UPD_THREADS")) { const int v = atoi(e); w.upd_threads = (v == 256 || v == 128) ? v : 64; }
     w.ldlt = ldltm::Switches::from_env();
@@ -2826,7 +2828,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
       if (fuse_upd) {
         UpdArgs ua{NP, NX, nP, D.pose_col, D.point_col, posesB[in_buf], pointsB[in_buf], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[set_],
-                   Hlls[set_], bls[set_], lam_, posesB[out_buf], pointsB[out_buf], bps[set_], h->d_scale_partial.p, lamp_};
+                   Hlls[set_], bls[set_], lam_, posesB[out_buf], pointsB[out_buf], bps[set_], h->d_scale_partial.p, lamp_, sw.ldlt_prio ? 1 : 0};
         h->xseq = h->xseq == 0x7FFFFFFFu ? 1u : h->xseq + 1u;
         hipLaunchKernelGGL(k_ldlt_cols_update, dim3(1 + n_blocks_u), dim3(ldltm::kThreads), ldltm::pick(n, sw.ldlt).lds, st, n, h->d_St.p, h->d_x.p,
                            h->d_ok.p, h->d_xready.p, h->xseq, ua);

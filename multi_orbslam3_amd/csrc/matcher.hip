@@ -979,7 +979,7 @@ extern "C" int orbm_frame_set_stream(orbm_frame* f, void* hip_stream) {
   if (!f) return ORBG_BAD_ARG;
   int rc = select_device(f->device);
   if (rc) return rc;
-  const bool on_own = f->stream == f->own_stream;         // (a frame that views an extractor's features stays on that extractor's stream)
+  const bool on_own = f->stream == f->own_stream;         // (a frame whose constructor is still in flight stays on that extractor's stream)
   if (!on_own) ORBG_HIP(hipStreamSynchronize(f->stream));
   if ((rc = orbg::swap_stream(&f->own_stream, &f->ext_stream, hip_stream, "fr"))) return rc;
   if (on_own) f->stream = f->own_stream;
@@ -1073,7 +1073,15 @@ int orbm_internal_attach_prepare(orbm_frame* f, orbx_handle* h, const orbm_frame
   return ORBG_OK;
 }
 
-void orbm_internal_set_n(orbm_frame* f, int n) { f->fp.n = n; f->hk_cached_n = -1; }
+// Called when the host has COLLECTED the constructor (completion word seen: every result of the chain is released to system scope).
+// From here on the frame's searches need no ordering against the extractor's stream, and they must not sit behind the constructors
+// of LATER frames that a pipelined caller has already enqueued there (two frames ahead: SearchLocalPoints waited 129 us behind
+// Frame(t+2)): the frame goes back to its own stream.  ORBG_FRAME_KEEP_CTOR_STREAM=1 keeps the extractor's stream (rounds 1-3).
+void orbm_internal_set_n(orbm_frame* f, int n) {
+  static const bool keep = [] { const char* e = getenv("ORBG_FRAME_KEEP_CTOR_STREAM"); return e && e[0] == '1'; }();
+  f->fp.n = n; f->hk_cached_n = -1;
+  if (!keep) f->stream = f->own_stream;
+}
 
 // device-resident descriptors of the frame's features (for the vocabulary transform in bow.hip)
 int orbm_internal_features(orbm_frame* f, const uint8_t** d_desc, int* n, hipStream_t* stream) {

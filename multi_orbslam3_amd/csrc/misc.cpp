@@ -54,8 +54,15 @@ hipError_t create_own(hipStream_t* st, const char* role) {
 hipError_t make_pool(DevicePool& P) {
   if (P.made) return hipSuccess;
   hipStream_t s4[4] = {nullptr, nullptr, nullptr, nullptr};
+  // ORBG_POOL_PRIO = four characters over (L, E0, E1, M): 'h' greatest priority, 'l' least, anything else default
+  const char* pr = getenv("ORBG_POOL_PRIO");
+  int lo = 0, hi = 0;
+  if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) pr = nullptr;
   for (int i = 0; i < 4; i++) {
-    const hipError_t e = hipStreamCreateWithFlags(&s4[i], hipStreamNonBlocking);
+    const char pc = (pr && strlen(pr) > (size_t)i) ? pr[i] : '-';
+    const hipError_t e = pc == 'h' ? hipStreamCreateWithPriority(&s4[i], hipStreamNonBlocking, hi)
+                       : pc == 'l' ? hipStreamCreateWithPriority(&s4[i], hipStreamNonBlocking, lo)
+                                   : hipStreamCreateWithFlags(&s4[i], hipStreamNonBlocking);
     if (e != hipSuccess) {
       for (int j = 0; j < i; j++) (void)hipStreamDestroy(s4[j]);
       return e;

@@ -131,8 +131,8 @@ def test_cxx_tracking_loop_does_the_work_of_the_python_loop():
     ex, imgs, host_imgs, frames, kf_chunks = bench.build_workload(scene, cfg, n_frames, api, views, synth, 0)
     p = scene.frame_view_params()
     fv, _k = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
-    exs = [ex, api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, 640, 480, n_cams=2)]
-    Fs = [api.Frame(cfg["frame_cap"]), api.Frame(cfg["frame_cap"])]
+    exs = [ex] + [api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, 640, 480, n_cams=2) for _ in range(3)]     # a ring of four (handle, frame) pairs
+    Fs = [api.Frame(cfg["frame_cap"]) for _ in range(4)]
     LM = api.LocalMap(cfg["map_cap"])
     opt = api.Optimizer()
     prob = synth.make_lba_problem(n_free=6, n_fixed=3, n_points=300, seed=5)
@@ -164,7 +164,7 @@ def test_cxx_tracking_loop_does_the_work_of_the_python_loop():
         LM.upload(kf_views[0])
         for i in range(n_steps):
             k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
-            c = i & 1 if pipelined else 0
+            c = i % 4 if pipelined else 0
             if host:
                 nl, nr = exs[c].frame_stereo(Fs[c], fv, host_imgs[k][0], host_imgs[k][1], bf, bb, download=False)
             else:
@@ -178,14 +178,23 @@ def test_cxx_tracking_loop_does_the_work_of_the_python_loop():
             kp += nl + nr; mf += n1; mm += n2
         return kp, mf, mm
 
-    for pipelined, host in ((True, True), (True, False), (False, True)):
+    # (frames handed over ahead of the tracked one: 1 = rounds 1-3, 2 = bench.py's default, 3 = the whole ring in flight; submit
+    # order before / after the collection of the current frame; a region split over two calls keeps its frames in flight across them)
+    for pipelined, host, ahead, first, split in ((True, True, 1, True, False), (True, True, 2, True, True), (True, True, 3, False, False),
+                                                 (True, False, 2, False, True), (True, False, 1, True, False), (False, True, 1, True, False)):
         LM.upload(kf_views[0])
-        loop.configure(pipelined, host, ingest_async=host, submit_first=True, lba_async=True, pose_opt=False)
-        st = loop.run(0, n_steps, last_is_final=True, timed=True)
+        loop.configure(pipelined, host, ingest_async=host, submit_first=first, lba_async=True, pose_opt=False, ahead=ahead)
+        if split:
+            st = loop.run(0, 9, last_is_final=False, timed=True)
+            assert sum(loop.c.in_flight) == (ahead if pipelined else 0)
+            st = loop.run(9, n_steps - 9, last_is_final=True, timed=True, stats=st)
+        else:
+            st = loop.run(0, n_steps, last_is_final=True, timed=True)
+        assert sum(loop.c.in_flight) == 0                 # a final region hands nothing over beyond its last step
         loop.drain(st, True)
         torch.cuda.synchronize()
         want = python_region(pipelined, host)
-        assert (st.kp, st.m_frame, st.m_map) == want, (pipelined, host, (st.kp, st.m_frame, st.m_map), want)
+        assert (st.kp, st.m_frame, st.m_map) == want, (pipelined, host, ahead, (st.kp, st.m_frame, st.m_map), want)
         assert st.lba_calls == (n_steps + K - 1) // K and st.lba_iters == st.lba_calls * sum(lba_out.iters)
         assert st.m_frame > 100 * n_steps // 2 and st.kp > 1500 * n_steps
 
