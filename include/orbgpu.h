@@ -553,7 +553,8 @@ int pose_optimize(const pose_opt_problem* p, pose_opt_result* r);
 /* ---------------------------------------------------------------- streams, hardware queues, host threads
  * Streams.  Every handle enqueues its work on ONE HIP stream.  By default that stream comes from a per-device pool the library
  * creates with its first handle: four hipStreamNonBlocking streams -- L (local BA handles), E0 / E1 (extractor handles,
- * alternating; a frame built by a constructor stays on its extractor's stream), M (map uploads, PoseOptimization, vocabulary and
+ * alternating; a frame built by a constructor is on its extractor's stream until the constructor has been COLLECTED -- from then on its
+ * searches run on the frame's own stream, M, and never queue behind constructors of later frames), M (map uploads, PoseOptimization, vocabulary and
  * database handles, host-built frames, the stand-alone utilities).  None of them is the legacy null stream: nothing the library
  * launches joins, or is joined by, the blocking streams of the application (SURVEY.md 8(b) "no hidden global state": the pool is the
  * one piece of per-device state the handles share, and it can be replaced).  *_set_stream hands a handle the CALLER's stream instead

@@ -99,8 +99,9 @@ struct StreamSignal {
 // created together by the first handle so that each gets a hardware queue of its own:
 //   "lba"                              -> L        (local BA handles; nothing else ever)
 //   "ex"                               -> E0 / E1  (extractor handles, alternating: Frame(t+1) is built next to the searches on frame t)
-//   "fr"                               -> M in a process that has extractors (a frame built by the constructor adopts its extractor's
-//                                         stream anyway); M, E0, E1 in turn in a process without (the server's KeyFrame matchers)
+//   "fr"                               -> M in a process that has extractors (a frame built by the constructor is on its extractor's
+//                                         stream until that constructor has been collected, then back on M: matcher.hip,
+//                                         orbm_internal_set_n); M, E0, E1 in turn in a process without (the server's KeyFrame matchers)
 //   "map", "po", "bow", "db", "misc"   -> M        (map uploads, PoseOptimization, vocabulary / database work, stand-alone utilities)
 // None of them is the legacy null stream: nothing the library launches joins (or is joined by) the blocking streams of the
 // application it is embedded in.  An application that itself keeps streams busy should run with GPU_MAX_HW_QUEUES >= 4 + its own

@@ -152,6 +152,9 @@ __global__ void orbg_signal_kernel(volatile unsigned* flag, unsigned seq) {
 int StreamSignal::post(hipStream_t st) {
   if (!word.h) { int rc = init(); if (rc) return rc; }
   seq++;
+  // ORBG_SIGNAL_WRITEVALUE=1: the stream's own write command (hipStreamWriteValue32: no kernel dispatch) instead of the signal kernel
+  static const bool wv = [] { const char* e = getenv("ORBG_SIGNAL_WRITEVALUE"); return e && e[0] == '1'; }();
+  if (wv) { ORBG_HIP(hipStreamWriteValue32(st, (void*)word.d, seq, 0)); return ORBG_OK; }
   hipLaunchKernelGGL(orbg_signal_kernel, dim3(1), dim3(1), 0, st, (volatile unsigned*)word.d, seq);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;
