@@ -828,10 +828,11 @@ def main():
         # duration from a HIP event pair on the local BA's stream (one bracketed launch per solve) minus the empty-pair cost
         n_unk = solver_unknowns
         ldlt_flops = n_unk ** 3 / 3.0 + 2.0 * n_unk ** 2
-        # windows of <= 20 free poses: the LDL^T workgroup and the state update's workgroups are ONE launch (k_ldlt_cols_update,
-        # the default since the end of round 3; ORBG_FUSE_UPDATE=0: two launches) -- the bracket then times both, and the launch's
+        # windows of <= 20 free poses, ORBG_FUSE_UPDATE=1: the LDL^T workgroup and the state update's workgroups are ONE launch
+        # (k_ldlt_cols_update; the default from the end of round 3 until the hand-over got its agent-scope release in round 4, which
+        # costs more than the kernel boundary it saves: two launches again) -- the bracket then times both, and the launch's
         # algorithmic FLOPs are the solve's plus the update's (per observation of a free pose H_pl^T dx: 72; per landmark a 3 x 3 solve: ~60)
-        fused_update = bool(solver_mfma) and (((((n_unk + 3) & ~3) + 1) + 15) // 16) <= 8 and os.environ.get("ORBG_FUSE_UPDATE", "1") != "0"
+        fused_update = bool(solver_mfma) and (((((n_unk + 3) & ~3) + 1) + 15) // 16) <= 8 and os.environ.get("ORBG_FUSE_UPDATE", "0") not in ("0", "")
         upd_flops = 0.0
         if fused_update:
             free = np.asarray(prob["pose_fixed"]) == 0

@@ -2266,7 +2266,7 @@ struct StopRef {
 // path itself never calls getenv.  A test that wants another variant creates another handle.
 struct LbaSwitches {
   bool blit = false, host_items = false, host_lists = false, no_fuse = false, no_first2 = false, host_csr = false, dev_csr = false;
-  bool ldlt_valu = false, ldlt_rows = false, ldlt_wide = false, ldlt_dense = false, fuse_update = true, no_spec = false, no_poll = false;
+  bool ldlt_valu = false, ldlt_rows = false, ldlt_wide = false, ldlt_dense = false, fuse_update = false, no_spec = false, no_poll = false;
   bool no_export_fuse = false, ldlt_prio = false;
   int upd_threads = 64;              // k_update's workgroup size (ORBG_UPD_THREADS = 64 / 128 / 256)
   ldltm::Switches ldlt;              // which matrix-core kernel a size gets (ORBG_LDLT_TILES / _T9_4W / _8W)

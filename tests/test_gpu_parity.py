@@ -1068,7 +1068,7 @@ def test_fused_constructor_refuses_a_distorted_camera_view(scene):
 
 
 def test_fused_solve_and_update_launch_is_deterministic_next_to_a_busy_gpu():
-    """The default local BA launch of windows of <= 20 free poses (k_ldlt_cols_update): workgroups 1..n wait for the word that
+    """The ONE-launch form of the local BA solve for windows of <= 20 free poses (k_ldlt_cols_update, ORBG_FUSE_UPDATE=1): workgroups 1..n wait for the word that
     workgroup 0 publishes with an agent-scope release behind the solution x.  Three streams of large GEMMs keep every compute unit
     busy while the solves run, so that the update workgroups are dispatched late, early, and on other XCDs than workgroup 0: results
     must be the bits of the solve on an idle GPU and the oracle's to tolerance; a lost hand-over would hang (the subprocess has a
@@ -1137,7 +1137,7 @@ def test_host_image_submit_on_other_image_shapes(W, H, nf):
 
 @pytest.mark.parametrize("fuse", ["1", "0"])
 def test_lba_with_the_solve_and_the_update_in_one_launch(fuse):
-    """ORBG_FUSE_UPDATE (on by default since the end of round 3; "0": two launches): the LDL^T workgroup and
+    """ORBG_FUSE_UPDATE ("1": one launch; "0", the default again since round 4, DESIGN.md 0: two launches): the LDL^T workgroup and
     k_update's work as ONE launch -- the update workgroups prefetch, wait for "x is ready" and finish the trial state; with
     speculative solves the trial after the next one is written into a third state buffer.  Same decisions, trace and results as
     the oracle in both forms, for every window size the column kernel covers, and the rejected-trial paths."""
