@@ -2267,7 +2267,7 @@ struct StopRef {
 struct LbaSwitches {
   bool blit = false, host_items = false, host_lists = false, no_fuse = false, no_first2 = false, host_csr = false, dev_csr = false;
   bool ldlt_valu = false, ldlt_rows = false, ldlt_wide = false, ldlt_dense = false, fuse_update = false, no_spec = false, no_poll = false;
-  bool no_export_fuse = false, ldlt_prio = false;
+  bool no_export_fuse = false, ldlt_prio = false, old_passes = false;
   int upd_threads = 64;              // k_update's workgroup size (ORBG_UPD_THREADS = 64 / 128 / 256)
   ldltm::Switches ldlt;              // which matrix-core kernel a size gets (ORBG_LDLT_TILES / _T9_4W / _8W)
   static LbaSwitches from_env() {
@@ -2276,7 +2276,7 @@ struct LbaSwitches {
     w.blit = on("ORBG_LBA_BLIT"); w.host_items = on("ORBG_HOST_ITEMS"); w.host_lists = on("ORBG_HOST_LISTS"); w.no_fuse = on("ORBG_NO_FUSE");
     w.no_first2 = on("ORBG_NO_FIRST2"); w.host_csr = on("ORBG_HOST_CSR"); w.dev_csr = on("ORBG_DEV_CSR"); w.ldlt_valu = on("ORBG_LDLT_VALU");
     w.ldlt_rows = on("ORBG_LDLT_ROWS"); w.ldlt_wide = on("ORBG_LDLT_WIDE"); w.ldlt_dense = on("ORBG_LDLT_DENSE"); w.no_spec = on("ORBG_NO_SPEC");
-    w.no_poll = !orbg::poll_allowed(); w.no_export_fuse = on("ORBG_NO_EXPORT_FUSE"); w.ldlt_prio = on("ORBG_LDLT_PRIO");
+    w.no_poll = !orbg::poll_allowed(); w.no_export_fuse = on("ORBG_NO_EXPORT_FUSE"); w.ldlt_prio = on("ORBG_LDLT_PRIO"); w.old_passes = on("ORBG_LBA_OLD_PASSES");
     if (const char* e = getenv("ORBG_FUSE_UPDATE")) w.fuse_update = atoi(e) != 0;
     if (const char* e = getenv("ORBG_UPD_THREADS")) { const int v = atoi(e); w.upd_threads = (v == 256 || v == 128) ? v : 64; }
     w.ldlt = ldltm::Switches::from_env();
@@ -2313,7 +2313,8 @@ struct lba_handle {
   DevBuf<double> d_scale_partial;
   DevBuf<unsigned> d_ticket;
   StreamSignal sig;              // completion word behind k_export (polled instead of hipStreamSynchronize)
-  std::vector<int> s_pose_deg, s_point_deg, s_pose_col, s_point_col, s_pf_deg, s_f1, s_f2, s_f3, s_fill, s_row_off;   // host scratch kept across calls
+  std::vector<int> s_pose_deg, s_point_deg, s_pose_col, s_point_col, s_pf_deg, s_f1, s_f2, s_f3, s_fill, s_row_off, s_junk;   // host scratch kept across calls
+  std::vector<unsigned> s_cnt4;
   float last_ms = 0;
   // live measurement of the dominant kernel (the LDL^T launch): one HIP event pair per solve on the handle's stream
   int prof_on = 0;
@@ -2464,13 +2465,48 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // goes to the device at once and every later pass reads the warm pinned copy
   if ((rc = h->edges_pin.reserve(std::max(NE, 1))) || (rc = h->d_edges.reserve(std::max(NE, 1)))) return rc;
   lba_edge* const edges = h->edges_pin.h;
-  for (int k = 0; k < NE; k++) {
-    const lba_edge e = p->edges[k];
-    edges[k] = e;
-    const unsigned ep = (unsigned)e.pose, ex = (unsigned)e.point;
-    if (ep >= (unsigned)NP || ex >= (unsigned)NX) return ORBG_BAD_ARG;
-    pose_deg[ep]++; point_deg[ex]++;
-    pf_raw[ex] += p->pose_fixed[ep] ? 0 : 1;
+  // Optimizer::LocalBundleAdjustment adds the edges landmark by landmark (S/Optimizer.cc:2007-2124): consecutive edges increment the
+  // SAME landmark's counters, and a read-modify-write of one word per edge is a chain of store-to-load forwards.  The landmark
+  // counters therefore rotate over four copies (k & 3: a run of up to four edges of one
+  // landmark touches four different words), both counts packed in one word (edges | edges of free poses << 16; fewer than 65536 edges);
+  // `runs` counts the changes of landmark along the list: equal to the number of observed landmarks <=> every landmark's edges are
+  // consecutive, which the list pass below exploits.
+  int runs = 0;
+  {
+    unsigned prev_pt = ~0u;
+    if (NE < 65536 && !sw.old_passes) {
+      std::vector<unsigned>& cnt4 = h->s_cnt4;
+      cnt4.assign(4 * (size_t)NX, 0u);
+      unsigned* const c4 = cnt4.data();
+      int* const pd = pose_deg.data();
+      const uint8_t* const fixed = p->pose_fixed;
+      for (int k = 0; k < NE; k++) {
+        const lba_edge e = p->edges[k];
+        edges[k] = e;
+        const unsigned ep = (unsigned)e.pose, ex = (unsigned)e.point;
+        if (ep >= (unsigned)NP || ex >= (unsigned)NX) return ORBG_BAD_ARG;
+        pd[ep]++;
+        c4[(size_t)(k & 3) * NX + ex] += 1u + ((fixed[ep] ? 0u : 1u) << 16);
+        runs += ex != prev_pt;
+        prev_pt = ex;
+      }
+      int* const pdeg = point_deg.data(); int* const pfr = pf_raw.data();
+      for (int i = 0; i < NX; i++) {
+        const unsigned sum = c4[i] + c4[(size_t)NX + i] + c4[2 * (size_t)NX + i] + c4[3 * (size_t)NX + i];
+        pdeg[i] = (int)(sum & 0xFFFFu); pfr[i] = (int)(sum >> 16);
+      }
+    } else {
+      for (int k = 0; k < NE; k++) {
+        const lba_edge e = p->edges[k];
+        edges[k] = e;
+        const unsigned ep = (unsigned)e.pose, ex = (unsigned)e.point;
+        if (ep >= (unsigned)NP || ex >= (unsigned)NX) return ORBG_BAD_ARG;
+        pose_deg[ep]++; point_deg[ex]++;
+        pf_raw[ex] += p->pose_fixed[ep] ? 0 : 1;
+        runs += ex != prev_pt;
+        prev_pt = ex;
+      }
+    }
   }
   if (NE > 0) {
     if (sw.blit) {
@@ -2551,11 +2587,37 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     memcpy(H + o_cur_pt, pt_start, 4 * (size_t)nL); memcpy(H + o_cur_ps, ps_start, 4 * (size_t)nP); memcpy(H + o_cur_pf, pf_start, 4 * (size_t)nL);
   } else {
     std::vector<int>& f1 = h->s_f1; std::vector<int>& f2 = h->s_f2; std::vector<int>& f3 = h->s_f3;
-    f1.assign(pt_start, pt_start + nL); f2.assign(ps_start, ps_start + nP); f3.assign(pf_start, pf_start + nL);
-    for (int k = 0; k < NE; k++) {
-      const int lc = point_col[edges[k].point], pc = pose_col[edges[k].pose];
-      pt_edges[f1[lc]++] = k;
-      if (pc >= 0) { ps_edges[f2[pc]++] = k; pf_edges[f3[lc]++] = k; }
+    if (runs == nL && !sw.old_passes) {
+      // every landmark's edges are consecutive (the reference's order): a landmark's list positions are carried in registers along
+      // its run instead of in per-landmark cursors (the same store-to-load chains as above), and the "pose is free" test selects
+      // the destination (a junk word for edges of fixed poses) instead of branching on a one-in-three condition
+      f2.assign(ps_start, ps_start + nP);
+      f2.push_back(0);                                       // [nP]: cursor of the edges of fixed poses, into junk
+      std::vector<int>& junk = h->s_junk;
+      if ((int)junk.size() < NE + 1) junk.resize((size_t)NE + 1);
+      int* const ps_base[2] = {junk.data(), ps_edges};
+      int* const f2p = f2.data();
+      int prev = -1, pt_pos = 0, pf_pos = 0;
+      for (int k = 0; k < NE; k++) {
+        const int ex = edges[k].point, lc = point_col[ex], pc = pose_col[edges[k].pose];
+        const bool ch = ex != prev;
+        prev = ex;
+        pt_pos = ch ? pt_start[lc] : pt_pos;
+        pf_pos = ch ? pf_start[lc] : pf_pos;
+        pt_edges[pt_pos++] = k;
+        const int fr = pc >= 0;
+        ps_base[fr][f2p[fr ? pc : nP]++] = k;
+        int* const pf_dst = fr ? pf_edges + pf_pos : junk.data() + NE;
+        *pf_dst = k;
+        pf_pos += fr;
+      }
+    } else {
+      f1.assign(pt_start, pt_start + nL); f2.assign(ps_start, ps_start + nP); f3.assign(pf_start, pf_start + nL);
+      for (int k = 0; k < NE; k++) {
+        const int lc = point_col[edges[k].point], pc = pose_col[edges[k].pose];
+        pt_edges[f1[lc]++] = k;
+        if (pc >= 0) { ps_edges[f2[pc]++] = k; pf_edges[f3[lc]++] = k; }
+      }
     }
   }
   const double t_s2 = now_s();

@@ -1166,6 +1166,50 @@ def test_lba_with_the_solve_and_the_update_in_one_launch(fuse):
     assert r.returncode == 0 and "fused ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
+@pytest.mark.parametrize("old", ["", "1"])
+def test_lba_structure_passes_on_grouped_and_scattered_edge_lists(old):
+    """The host's structure passes (csrc/lba.hip, lba_solve_impl): the reference adds a landmark's edges consecutively, and the passes
+    exploit that (rotating packed counters, list positions carried along a run); an edge list in ANY other order -- shuffled, two runs
+    per landmark, by pose -- takes the per-landmark cursors.  Every order against the oracle on the same list (sums follow the edge
+    order), both forms (ORBG_LBA_OLD_PASSES=1: cursors always) bit-equal to each other through the printed digest."""
+    code = (
+        "import hashlib, numpy as np\n"
+        "from multi_orbslam3_amd import api, synth, views\n"
+        "from oracle import binding as ob\n"
+        "dig = hashlib.sha256()\n"
+        "for nf, nfix, npts, seed in [(20, 10, 2000, 3), (7, 3, 300, 4), (1, 2, 40, 5), (12, 0, 500, 6)]:\n"
+        "    prob = synth.make_lba_problem(n_free=nf, n_fixed=nfix, n_points=npts, mono_frac=0.3, seed=seed)\n"
+        "    E = prob['edges']\n"
+        "    rng = np.random.RandomState(seed)\n"
+        "    half = np.concatenate([np.arange(0, len(E), 2), np.arange(1, len(E), 2)])          # two runs per landmark\n"
+        "    orders = [np.arange(len(E)), rng.permutation(len(E)), half, np.argsort(E['pose'], kind='stable')]\n"
+        "    for order in orders:\n"
+        "        pr = dict(prob, edges=np.ascontiguousarray(E[order]))\n"
+        "        p, keep = views.lba_problem(pr['poses'], pr['pose_fixed'], pr['points'], pr['edges'], pr['cam'])\n"
+        "        o = ob.lba_solve(p)\n"
+        "        g = api.Optimizer().LocalBundleAdjustment(p)\n"
+        "        assert g.status == o.status and g.iters == o.iters, (nf, g.iters, o.iters)\n"
+        "        assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4, nf\n"
+        "        assert np.array_equal(g.edge_outlier, o.edge_outlier), nf\n"
+        "        dig.update(np.ascontiguousarray(g.poses).tobytes()); dig.update(np.ascontiguousarray(g.points).tobytes())\n"
+        "        dig.update(np.ascontiguousarray(g.edge_chi2).tobytes())\n"
+        "print('structure ok', dig.hexdigest())\n")
+    env = dict(os.environ)
+    env.pop("ORBG_LBA_OLD_PASSES", None)
+    if old:
+        env["ORBG_LBA_OLD_PASSES"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "structure ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    digest = r.stdout.strip().split()[-1]
+    _STRUCTURE_DIGESTS[old] = digest
+    if len(_STRUCTURE_DIGESTS) == 2:
+        assert _STRUCTURE_DIGESTS[""] == _STRUCTURE_DIGESTS["1"], _STRUCTURE_DIGESTS
+
+
+_STRUCTURE_DIGESTS = {}
+
+
 @pytest.mark.parametrize("seed,noise,lam", [(10, 3.0, 0.0), (9, 3.0, 0.0), (11, 3.0, 0.0), (10, 1.0, 1e-12)])
 def test_lba_rejected_trials_discard_the_speculative_linearisation(seed, noise, lam):
     """Far-off initial estimates make g2o's LM reject trials (qmax up to 10 in the trace, rounds that end on qmax == 10):

@@ -2,7 +2,8 @@
 # Collects the evidence files of a build on the GPU box: rocprofv3 kernel stats (inline LBA so that every kernel is in one
 # trace), the PMC passes (FETCH_SIZE / WRITE_SIZE for HBM traffic, the FP64-MFMA counters for the matrix-core LDL^T; one
 # rocprofv3 run per counter group, no trace domains) and the bench lines.
-# Usage (on the box): bash tools/collect_profiles.sh <tag>   e.g. r2_a
+# Usage (on the box): bash tools/collect_profiles.sh <tag>   e.g. r2_a      (run tools/micro/build_variants.sh in the container first:
+# the phase tables come from the -DPO_PROFILE / -DOCT_PROFILE variants of the library, which must match the sources)
 # Results land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
@@ -38,6 +39,8 @@ python3 tools/lba_time.py C2 200 > "$OUT/lba_time.txt" 2>&1 || true
 python3 tools/lba_time.py C4 40 >> "$OUT/lba_time.txt" 2>&1 || true
 python3 tools/lba_gaps.py "$OUT/stats/run_kernel_trace.csv" > "$OUT/lba_gaps.txt" 2>&1 || true
 python3 tools/ctor_gaps.py "$OUT/stats/run_kernel_trace.csv" > "$OUT/ctor_gaps.txt" 2>&1 || true
+python3 tools/lba_timeline.py "$(find "$OUT/stats_async" -name "*kernel_trace.csv" | head -1)" > "$OUT/lba_timeline_agent.txt" 2>&1 || true
+python3 tools/micro/oct_prof.py > "$OUT/octree_phases.txt" 2>&1 || true
 SPREAD=0 python3 tools/search_large_map.py 1 8 32 128 > "$OUT/search_large_map_dense.txt" 2>&1 || true
 python3 tools/po_sweep.py 500 > "$OUT/pose_opt_sweep.txt" 2>&1 || true
 bash tools/noise_matrix.sh none none siblings l3 membw everywhere > "$OUT/noise_matrix.txt" 2>&1 || true
