@@ -721,7 +721,8 @@ def main():
         loop.drain()
     collect_async(scratch)
     for e in exs:
-        e.set_profile_interval(max(FAST_BRACKET_EVERY // len(exs), 1), reset=True)
+        e.set_profile_interval(FAST_BRACKET_EVERY, reset=True)       # every handle brackets every 4th of ITS frames: one frame in four overall,
+                                                                      # whatever the size of the ring (an event pair holds the stream for ~2 x 10 us)
     opt.set_profiling(True, reset=True)
     reg, elapsed = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, prewarm_done)
     # what the shared host did to the region: involuntary context switches of this process's threads inside it, and how busy
