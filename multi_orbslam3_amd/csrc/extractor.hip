@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(kSgThreads) void stereo_grid_kernel(const uint8_t* 
     if (threadIdx.x >= 256) return;              // (whole wavefronts leave: the barriers below count the four that stay)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     stereo_finalize_body(uright, depth, best_sad, nl_bound, d_nkp, host_mirror);
-    __threadfence_system();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system-scope release (no acquire half: no L2 invalidation)
     __syncthreads();
     second_party = true;
   }
@@ -2653,7 +2653,11 @@ __global__ __launch_bounds__(kUpThreads) void img_upload_pair_kernel(const uint4
     }
     __syncthreads();
     if (!s_ok) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // (system scope: the image is read after the word)
+    // The image is read after the word: the loads below are ISSUED after the spin loop has seen it (LDS hand-over + barrier), and the
+    // staging slot is coherent host memory (hipHostMallocMapped: uncached in the GPU's L2), so no cache line can hold an older
+    // copy.  A system-scope acquire fence here (round 4 until the end) invalidated the XCD's L2 once per wavefront of the right
+    // image's workgroups -- ~80 invalidations per frame under the local BA's kernels.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
   const int i0 = b0 + (wg * kUpPerThread) * kUpThreads + (int)threadIdx.x;
   uint4 v[kUpPerThread];

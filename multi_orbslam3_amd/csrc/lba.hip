@@ -344,9 +344,8 @@ __device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const do
       *lm.lambda_next = lam * fmax(1. / 3., alpha);
     }
     *ticket = 0;
-    __threadfence_system();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                  // system-scope release of the record (no acquire half: no L2 invalidation)
     *reinterpret_cast<volatile unsigned*>(&rec->seq) = seq;       // the host polls this word instead of hipStreamSynchronize
-    __threadfence_system();
   }
 }
 
@@ -3969,9 +3968,9 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   PO_ACC(5);
   for (int i = tid; i < n; i += kPoThreads) outlier_out[i] = s_out[i];
   if (tid == 0) { *T_out = T; stats[0] = nBad; }
-  __threadfence_system();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");              // system-scope release of every wavefront's results (no acquire half)
   __syncthreads();
-  if (tid == 0) { *reinterpret_cast<volatile int*>(&stats[7]) = (int)seq; __threadfence_system(); }   // results are complete: the host spins on this word
+  if (tid == 0) *reinterpret_cast<volatile int*>(&stats[7]) = (int)seq;   // results are complete: the host spins on this word
 }
 
 }  // namespace

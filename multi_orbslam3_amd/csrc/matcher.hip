@@ -98,7 +98,9 @@ __global__ __launch_bounds__(1024) void grid_build_finalize_kernel(const orbx_ke
   } else {
     if (threadIdx.x >= 256) return;              // (whole wavefronts: a barrier only counts wavefronts that are still alive)
     stereo_finalize_body(fin.uright, fin.depth, fin.best_sad, fin.nl, fin.d_nkp, fin.host_out);
-    __threadfence_system();
+    // system-scope RELEASE (write-back + wait), not __threadfence_system(): the acquire half of a full fence invalidates the XCD's L2
+    // under every kernel running next to this one (the local BA's: 0.583 -> 0.575 ms per solve with the invalidations gone)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -144,9 +144,10 @@ extern "C" int orbg_quiesce(int device) {
 
 namespace orbg {
 
+// (the word is ordered behind the work it signals by the kernel boundary in front of this launch; a fence BEHIND the store orders
+// nothing, and a full system fence invalidates the XCD's L2 under the kernels of the other streams)
 __global__ void orbg_signal_kernel(volatile unsigned* flag, unsigned seq) {
   *flag = seq;
-  __threadfence_system();
 }
 
 int StreamSignal::post(hipStream_t st) {
