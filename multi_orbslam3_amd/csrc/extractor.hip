@@ -2636,7 +2636,7 @@ static const bool g_img_runtime_copy = getenv("ORBG_IMG_RUNTIME_COPY") != nullpt
 // chain is not waiting for the second image.)
 constexpr int kUpThreads = 256, kUpPerThread = 4;
 __global__ __launch_bounds__(kUpThreads) void img_upload_pair_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int first16, int total16,
-                                                                     int wg_first, const unsigned* ready, unsigned seq, unsigned* err) {
+                                                                     int wg_first, int wg_stride, const unsigned* ready, unsigned seq, unsigned* err) {
   __shared__ int s_ok;
   int b0, b1, wg;
   if ((int)blockIdx.x < wg_first) { b0 = 0; b1 = first16; wg = blockIdx.x; }
@@ -2659,14 +2659,21 @@ __global__ __launch_bounds__(kUpThreads) void img_upload_pair_kernel(const uint4
     // image's workgroups -- ~80 invalidations per frame under the local BA's kernels.
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
-  const int i0 = b0 + (wg * kUpPerThread) * kUpThreads + (int)threadIdx.x;
-  uint4 v[kUpPerThread];
+  // a workgroup moves 16 KB per trip and then its next chunk (wg_stride workgroups per image): the reads in flight over PCIe are
+  // wg_stride x 16 KB per image instead of the whole image (see g_upload_wgs)
+  for (int c = wg;; c += wg_stride) {
+    const int i0 = b0 + (c * kUpPerThread) * kUpThreads + (int)threadIdx.x;
+    if (i0 - (int)threadIdx.x >= b1) break;
+    uint4 v[kUpPerThread];
 #pragma unroll
-  for (int q = 0; q < kUpPerThread; q++) { const int i = i0 + q * kUpThreads; if (i < b1) v[q] = src[i]; }
+    for (int q = 0; q < kUpPerThread; q++) { const int i = i0 + q * kUpThreads; if (i < b1) v[q] = src[i]; }
 #pragma unroll
-  for (int q = 0; q < kUpPerThread; q++) { const int i = i0 + q * kUpThreads; if (i < b1) dst[i] = v[q]; }
+    for (int q = 0; q < kUpPerThread; q++) { const int i = i0 + q * kUpThreads; if (i < b1) dst[i] = v[q]; }
+  }
 }
 static const bool g_img_two_uploads = getenv("ORBG_IMG_TWO_UPLOADS") != nullptr;     // A/B switch: the round-3 form (one copy kernel per image, after its pack)
+// workgroups per image of img_upload_pair_kernel (0: one per 16 KB chunk, every read of the pair in flight at once)
+static const int g_upload_wgs = [] { const char* e = getenv("ORBG_UPLOAD_WGS"); return e ? atoi(e) : 0; }();
 
 // a submitted Frame constructor owns the handle (stream, staging slot, pyramid, feature buffers) until it has been waited for
 static inline bool handle_busy(const orbx_handle* h) {
@@ -2691,7 +2698,9 @@ static int stage_images(orbx_handle* h, const uint8_t* const* images, int n_img,
     // image when the image size is no multiple of 16) belongs to the SECOND range, which is copied once both images are packed
     const int first16 = (int)(per / 16), total16 = (int)((total + 15) / 16);
     const int per_wg = kUpThreads * kUpPerThread;
-    const int wg_first = (first16 + per_wg - 1) / per_wg, wg_second = (total16 - first16 + per_wg - 1) / per_wg;
+    int wg_first = (first16 + per_wg - 1) / per_wg, wg_second = (total16 - first16 + per_wg - 1) / per_wg;
+    int wg_stride = std::max(wg_first, wg_second);
+    if (g_upload_wgs > 0 && g_upload_wgs < wg_stride) { wg_stride = g_upload_wgs; wg_first = std::min(wg_first, wg_stride); wg_second = std::min(wg_second, wg_stride); }
     double tp0 = host_now_us();
     auto pack = [&](int c) {
       uint8_t* dst = h->h_img.h + c * per;
@@ -2701,7 +2710,7 @@ static int stage_images(orbx_handle* h, const uint8_t* const* images, int n_img,
     pack(0);
     h->tl_pack_acc += host_now_us() - tp0;
     hipLaunchKernelGGL(img_upload_pair_kernel, dim3(wg_first + wg_second), dim3(kUpThreads), 0, h->stream, reinterpret_cast<const uint4*>(h->h_img.d),
-                       reinterpret_cast<uint4*>(h->d_img.p), first16, total16, wg_first, h->up_ready.d, seq, h->up_ready.d + 8);
+                       reinterpret_cast<uint4*>(h->d_img.p), first16, total16, wg_first, wg_stride, h->up_ready.d, seq, h->up_ready.d + 8);
     ORBG_HIP(hipGetLastError());
     tp0 = host_now_us();
     pack(1);
