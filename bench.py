@@ -436,10 +436,10 @@ def main():
     po2, po2_keep = views.pose_opt_problem(po_prob2["Xw"], po_prob2["u"], po_prob2["v"], po_prob2["ur"], po_prob2["inv_sigma2"],
                                           po_prob2["cam"], po_prob2["Tcw"], device=device)
     for e in exs:
-        e.set_profiling(2 if args.profile_stages else 1)
+        e.set_profiling(0 if os.environ.get("ORBG_BENCH_NO_BRACKETS") else 2 if args.profile_stages else 1)     # (experiment switch: no event brackets at all)
     ev_overhead_ms = ex.event_overhead_ms(100)
     lba_ev_overhead_ms = opt.event_overhead_ms(100)
-    opt.set_profiling(True, reset=True)
+    opt.set_profiling(not os.environ.get("ORBG_BENCH_NO_BRACKETS"), reset=True)
     FAST_BRACKET_EVERY = 1 if args.profile_stages else 4         # the event pair costs ~5 us of stream time: sample every 4th frame
     th_frame, mono_flag = (7.0, False) if stereo else (15.0, True)
 
@@ -723,7 +723,7 @@ def main():
     for e in exs:
         e.set_profile_interval(FAST_BRACKET_EVERY, reset=True)       # every handle brackets every 4th of ITS frames: one frame in four overall,
                                                                       # whatever the size of the ring (an event pair holds the stream for ~2 x 10 us)
-    opt.set_profiling(True, reset=True)
+    opt.set_profiling(not os.environ.get("ORBG_BENCH_NO_BRACKETS"), reset=True)
     reg, elapsed = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, prewarm_done)
     # what the shared host did to the region: involuntary context switches of this process's threads inside it, and how busy
     # OTHER tenants keep the hardware threads of the agent's cores right after it (this process sleeps during the sample)
