@@ -2784,8 +2784,11 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // do overlap their dependent loads with the LDL^T, but they sit on other XCDs than the LDL^T workgroup: the "x is ready" word and
   // x itself reach them through memory (agent-scope stores / loads, ~2 us each way), which costs what the kernel boundary and
   // k_update's own loads cost.  (A same-XCD placement checked through the XCC_ID register would make the hand-over an L2 round trip.)
-  // (on by default since the end of round 3: alone on the GPU the fused launch is a wash -- 0.488 vs 0.486 ms per solve -- but next to
-  // the tracking chains every dispatch less counts: 0.586 vs 0.597 ms, 8490 vs 8360 frames/s; ORBG_FUSE_UPDATE=0: two launches)
+  // (On by default from the end of round 3 -- next to the tracking chains the fused launch measured 0.586 vs 0.597 ms -- until the
+  // hand-over got the agent-scope RELEASE it needs, round 4: with the L2 write-back in front of the word the fused launch is 0.491
+  // vs 0.485 ms alone and 0.590 vs 0.584 ms next to the tracking chains.  Two launches are the default again.  Also measured in
+  // round 4: a landmark's dependent round trips are ~0.5 us each, a kernel's fixed cost 4-5 us -- a per-landmark record that halves
+  // k_update's round trips bought nothing alone and 3 us per solve in the agent: not kept.)
   const bool fuse_upd = use_mfma && ldltm::pick(n, sw.ldlt).cols && sw.fuse_update;
   const int n_blocks_u = fuse_upd ? (NP + NX + kFusedUpdThreads - 1) / kFusedUpdThreads : (NP + NX + upd_threads - 1) / upd_threads;
   if ((rc = h->d_scale_partial.reserve(std::max(n_blocks_u, 1)))) return rc;
