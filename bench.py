@@ -312,6 +312,9 @@ def main():
     ap.add_argument("--ctor-ahead", type=int, default=int(os.environ.get("ORBG_BENCH_CTOR_AHEAD", "2")), choices=[1, 2, 3],
                     help="pipelined constructor: frames handed over ahead of the one being tracked (ring of N + 1 extractor handles / frame "
                          "objects; the python loop supports 1)")
+    ap.add_argument("--no-host-features", action="store_true",
+                    help="pipelined constructor: leave the features in HBM (rounds 1-3); by default every frame's keypoints, descriptors, "
+                         "uRight and depth are delivered into host arrays when the constructor is collected (orbx_set_frame_outputs)")
     ap.add_argument("--ingest", choices=["thread", "inline"], default="thread",
                     help="host images: thread = the library's ingest thread packs the rows into pinned staging and enqueues the "
                          "constructor (orbx_frame_stereo_submit, ORBX_SUBMIT_ASYNC); inline = the tracking thread does")
@@ -401,6 +404,9 @@ def main():
     exs = [ex] + [api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, W, H, n_cams=2, device=device) for _ in range(n_ring - 1)] if pipeline else [ex]
     Fs = [F] + [api.Frame(cfg["frame_cap"], device) for _ in range(n_ring - 1)] if pipeline else [F]
     in_flight = [False] * 4
+    # the pipelined constructor delivers mvKeys / mDescriptors / mvuRight / mvDepth into host arrays at every _wait (orbx_set_frame_outputs):
+    # what an unchanged Tracking / KeyFrame / Communicator reads of a frame is on the host inside the timed step
+    feature_outputs = [e.set_frame_outputs(cfg["frame_cap"]) for e in exs] if (pipeline and not args.no_host_features) else None
     LM = api.LocalMap(cfg["map_cap"], device)
     m_frame = api.ORBmatcher(0.9, True, device)
     m_map = api.ORBmatcher(0.8, True, device)
@@ -914,6 +920,9 @@ def main():
                                       "exactly K constructors (the first step submits its own and the ones ahead, the last ones hand no further frame over)"
                                       % (ctor_ahead, ctor_ahead, n_ring)) if pipeline else "synchronous",
                        "frame_ctor_ahead": ctor_ahead if pipeline else 0,
+                       "features_on_host": ("every frame: mvKeys / mDescriptors / mvuRight / mvDepth of the left image are copied into host arrays when the "
+                                            "constructor is collected (orbx_set_frame_outputs), inside the step") if feature_outputs else
+                                           "no: the features stay in HBM (counts only)",
                        "pose_opt_ms_per_call_450_correspondences": round(pose_opt_ms, 4),
                        "lba_ms_per_call": round(1e3 * stats["lba_s"] / max(stats["lba_calls"], 1), 3),
                        "sequential_fps_formula": round(1.0 / (sum(v for k2, v in stage.items() if k2 != "lba") / K +

@@ -195,6 +195,12 @@ int orbx_frame_stereo_dev_wait(orbx_handle* h, int* n_left, int* n_right);
  * thread submits frame t+1 (flags 0) while Tracking works on frame t, or Tracking itself submits with ORBX_SUBMIT_ASYNC.
  * One submission per handle at a time (ORBG_BAD_ARG otherwise). */
 #define ORBX_SUBMIT_ASYNC 1
+/* Host arrays for the features of the two-halves constructor: from now on every _submit of this handle also delivers the LEFT image's
+ * mvKeys / mDescriptors / mvuRight / mvDepth -- what the output arguments of orbx_frame_stereo deliver for the synchronous
+ * constructor, S/Frame.cc:100-118 -- into these arrays (cap_left entries each; a NULL array is not delivered) by the time _wait
+ * returns; ORBG_CAP_EXCEEDED from _wait when the frame has more features.  The arrays belong to the caller and must stay valid while
+ * a submission is in flight; all NULL / cap 0 switches the delivery off again.  The handle must be idle. */
+int orbx_set_frame_outputs(orbx_handle* h, orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left);
 int orbx_frame_stereo_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
                              const uint8_t* img_right, int width, int height, int stride, float bf, float b, int flags);
 int orbx_frame_stereo_wait(orbx_handle* h, int* n_left, int* n_right);

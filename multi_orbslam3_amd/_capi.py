@@ -121,7 +121,7 @@ def ptr(a):
 EXPORTED_SYMBOLS = [
     "orbx_create", "orbx_destroy", "orbx_get_tables", "orbx_extract", "orbx_extract_stereo",
     "orbx_extract_stereo_dev", "orbx_get_level", "orbx_get_level_bordered", "orbx_get_candidates", "orbx_stereo_match",
-    "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_upload", "orbm_frame_from_extractor", "orbx_frame_stereo_dev", "orbx_frame_stereo", "orbx_frame_stereo_dev_submit", "orbx_frame_stereo_dev_wait", "orbx_frame_stereo_submit", "orbx_frame_stereo_wait",
+    "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_upload", "orbm_frame_from_extractor", "orbx_frame_stereo_dev", "orbx_frame_stereo", "orbx_frame_stereo_dev_submit", "orbx_frame_stereo_dev_wait", "orbx_frame_stereo_submit", "orbx_frame_stereo_wait", "orbx_set_frame_outputs",
     "orbm_frame_get_grid", "orbm_hamming_matrix", "orbm_hamming_best2", "orbm_is_in_frustum",
     "orbm_search_by_projection_mps", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
     "orbm_search_local_points", "orbm_search_local_points_vis", "orbm_search_by_projection_frame", "orbm_search_by_bow",

@@ -135,6 +135,21 @@ class ORBextractor:
                                                C.c_float(bf), C.c_float(b), 1 if async_ingest else 0)
         capi.check(rc, "orbx_frame_stereo_submit")
 
+    def set_frame_outputs(self, cap):
+        """orbx_set_frame_outputs: the two-halves constructor delivers mvKeys / mDescriptors / mvuRight / mvDepth of the left image
+        into host arrays owned by this object (returned) by the time frame_stereo_dev_wait() returns; cap = 0 switches it off."""
+        if cap <= 0:
+            capi.check(self.lib.orbx_set_frame_outputs(self.h, None, None, None, None, 0), "orbx_set_frame_outputs")
+            self._outputs = None
+            return None
+        out = dict(kps=np.zeros(cap, capi.KEYPOINT_DTYPE), desc=np.zeros((cap, 32), np.uint8), uright=np.zeros(cap, np.float32),
+                   depth=np.zeros(cap, np.float32))
+        capi.check(self.lib.orbx_set_frame_outputs(self.h, C.c_void_p(capi.ptr(out["kps"])), C.c_void_p(capi.ptr(out["desc"])),
+                                                   C.c_void_p(capi.ptr(out["uright"])), C.c_void_p(capi.ptr(out["depth"])), int(cap)),
+                   "orbx_set_frame_outputs")
+        self._outputs = out
+        return out
+
     def frame_stereo_dev_wait(self):
         nl, nr = C.c_int(0), C.c_int(0)
         capi.check(self.lib.orbx_frame_stereo_dev_wait(self.h, C.byref(nl), C.byref(nr)), "orbx_frame_stereo_dev_wait")

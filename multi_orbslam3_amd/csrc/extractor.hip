@@ -1862,6 +1862,8 @@ struct orbx_handle {
   PinnedBuf<uint8_t> h_img;
   PinnedBuf<unsigned> up_ready;                // [0] "second image packed" word of img_upload_pair_kernel, [8] its error word
   unsigned up_seq = 0;
+  // orbx_set_frame_outputs: host arrays the two-halves constructor delivers the left image's features into at _wait
+  orbx_keypoint* out_kps = nullptr; uint8_t* out_desc = nullptr; float* out_uright = nullptr; float* out_depth = nullptr; int out_cap = 0;
   std::atomic<int> ingest_state{0};            // 0 idle, 1 handed to the ingest thread, 2 submitted by it (ingest_rc valid)
   int ingest_rc = 0;
   // host-side timeline of the last submissions (orbx_get_ctor_timeline): per submission, microseconds
@@ -2871,15 +2873,24 @@ static int frame_submit_core(orbx_handle* h, orbm_frame* frame, const orbm_frame
   }
   PostOps post;
   post.stereo = true; post.bf = bf; post.b = b; post.frame = frame; post.view = view;
+  post.uright = h->out_uright; post.depth = h->out_depth;             // (orbx_set_frame_outputs: delivered by _wait)
   const int lap[2][2] = {{0, 0}, {0, 0}};
-  orbx_keypoint* ko[2] = {nullptr, nullptr};
-  uint8_t* dout[2] = {nullptr, nullptr};
-  const int caps[2] = {0, 0};
+  orbx_keypoint* ko[2] = {h->out_kps, nullptr};
+  uint8_t* dout[2] = {h->out_desc, nullptr};
+  const int caps[2] = {h->out_cap, 0};
   int* no[2] = {&P.n_res[0], &P.n_res[1]};
   int* nm[2] = {nullptr, nullptr};
   rc = extract_core(h, 3, d_img_left, d_img_right, width, height, stride, lap, ko, dout, caps, no, nm, &post, false, true);
   if (rc) { P.active = false; return rc; }
   if (!P.active) P.finished = true;                      // host quad-tree path: it ran to completion inside the call
+  return ORBG_OK;
+}
+
+// Host arrays for the features of the two-halves constructor (include/orbgpu.h): taken by every later _submit of this handle.
+extern "C" int orbx_set_frame_outputs(orbx_handle* h, orbx_keypoint* kps_left, uint8_t* desc_left, float* uright, float* depth, int cap_left) {
+  if (!h || cap_left < 0 || ((kps_left || desc_left || uright || depth) && cap_left == 0)) return ORBG_BAD_ARG;
+  if (handle_busy(h)) return ORBG_BAD_ARG;
+  h->out_kps = kps_left; h->out_desc = desc_left; h->out_uright = uright; h->out_depth = depth; h->out_cap = cap_left;
   return ORBG_OK;
 }
 
@@ -3140,6 +3151,7 @@ static int extract_finish_gpu(orbx_handle* h, ExtractPending& c) {
     base += nk;
   }
   if (post && post->frame) orbm_internal_set_n(post->frame, h->n_kp[0]);
+  if (c.stereo_out && h->n_kp[0] > c.cap[0]) return ORBG_CAP_EXCEEDED;      // uright / depth hold cap_left entries like the other outputs
   if (c.stereo_out) {
     if (post->uright) memcpy(post->uright, h->h_stereo.h, (size_t)h->n_kp[0] * 4);
     if (post->depth) memcpy(post->depth, h->h_stereo.h + h->n_kp[0], (size_t)h->n_kp[0] * 4);

@@ -379,6 +379,55 @@ def test_frame_constructor_as_an_executable_graph():
     assert m and int(m.group(2)) == 2 and int(m.group(1)) >= 6, (r.stdout[-1500:], r.stderr[-1500:])
 
 
+@pytest.mark.parametrize("async_ingest,device_images", [(False, False), (True, False), (False, True)])
+def test_two_halves_constructor_delivers_features_to_host(scene, async_ingest, device_images):
+    """orbx_set_frame_outputs: the pipelined constructor hands mvKeys / mDescriptors / mvuRight / mvDepth of the left image to host
+    arrays by the time _wait returns (what an unchanged Tracking / KeyFrame reads every frame, S/Frame.cc:100-118) -- equal to the
+    oracle's for every frame of a ping-pong over two handles, too small a capacity is refused by _wait, and switching the delivery
+    off leaves the arrays alone."""
+    import torch
+    cam = scene.cam
+    bf, bb = float(cam["bf"]), float(cam["b"])
+    ids = [3, 4, 5, 6]
+    orc = [helpers.oracle_stereo_frame(scene, i) for i in ids]
+    ex = [api.ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, n_cams=2) for _ in range(2)]
+    Fr = [api.Frame(), api.Frame()]
+    fvs = [helpers.frame_view_of(scene, fr) for fr in orc]
+    outs = [e.set_frame_outputs(2048) for e in ex]
+    dev = [(torch.from_numpy(np.ascontiguousarray(fr["L"])).cuda(), torch.from_numpy(np.ascontiguousarray(fr["R"])).cuda()) for fr in orc]
+    torch.cuda.synchronize()
+
+    def submit(c, t):
+        if device_images:
+            ex[c].frame_stereo_dev_submit(Fr[c], fvs[t][0], dev[t][0].data_ptr(), dev[t][1].data_ptr(), 640, 480, 640, bf, bb)
+        else:
+            ex[c].frame_stereo_submit(Fr[c], fvs[t][0], np.ascontiguousarray(orc[t]["L"]), np.ascontiguousarray(orc[t]["R"]), bf, bb, async_ingest=async_ingest)
+
+    submit(0, 0)
+    for t in range(len(ids)):
+        cur = t & 1
+        if t + 1 < len(ids):
+            submit(cur ^ 1, t + 1)
+        n, nr = ex[cur].frame_stereo_dev_wait()
+        fr, o = orc[t], outs[cur]
+        assert n == len(fr["kps"])
+        assert np.array_equal(o["kps"][:n], fr["kps"]) and np.array_equal(o["desc"][:n], fr["desc"]), t
+        assert np.array_equal(o["uright"][:n], fr["uright"]) and np.array_equal(o["depth"][:n], fr["depth"]), t
+    # a capacity below the frame's feature count: refused at _wait, the handle is usable afterwards
+    ex[0].set_frame_outputs(16)
+    submit(0, 0)
+    with pytest.raises(Exception):
+        ex[0].frame_stereo_dev_wait()
+    keep = ex[1]._outputs["kps"].copy()
+    ex[1].set_frame_outputs(0)
+    submit(1, 0)
+    n, nr = ex[1].frame_stereo_dev_wait()
+    assert n == len(orc[0]["kps"]) and np.array_equal(keep, outs[1]["kps"])            # delivery off: the old arrays are untouched
+    ex[0].set_frame_outputs(0)
+    submit(0, 1)
+    assert ex[0].frame_stereo_dev_wait()[0] == len(orc[1]["kps"])
+
+
 @pytest.mark.parametrize("switch", ["ORBG_CTOR_FUSED_TAIL", "ORBG_OCT_GATHER", "ORBG_IMG_TWO_UPLOADS", "ORBG_OCT_NO_JUMP"])
 def test_frame_constructor_chain_variants(switch):
     """The A/B forms of the constructor chain (read once per process): stereo match + median rejection + grid + completion word as ONE
