@@ -56,6 +56,12 @@ class ORBextractor {
   ORBextractor(const ORBextractor&) = delete;
   ORBextractor& operator=(const ORBextractor&) = delete;
 
+  // Host destinations of the two-halves stereo constructor (FrameOnDevice::StereoCtorSubmit* / StereoCtorWait below): the Frame's
+  // mvKeys / mDescriptors / mvuRight / mvDepth storage, cap entries each; StereoCtorWait fills them (orbx_set_frame_outputs).
+  void SetFrameOutputs(orbx_keypoint* mvKeys, uint8_t* mDescriptors, float* mvuRight, float* mvDepth, int cap) {
+    check(orbx_set_frame_outputs(h_, mvKeys, mDescriptors, mvuRight, mvDepth, cap), "orbx_set_frame_outputs");
+  }
+
   // int operator()(InputArray image, InputArray mask, vector<KeyPoint>& keypoints, OutputArray descriptors,
   //                vector<int>& vLappingArea), S/ORBextractor.cc:1068-1150 -- flattened: 8-bit gray image, row stride.
   // Returns monoIndex, or -1 for an empty image (:1072-1073).
