@@ -309,7 +309,7 @@ def main():
                          "--separate-calls / --profile-stages always use it)")
     ap.add_argument("--submit-order", choices=["before-wait", "after-wait"], default="before-wait",
                     help="pipelined constructor: hand frame t+1 over before or after frame t's constructor is collected")
-    ap.add_argument("--ctor-ahead", type=int, default=int(os.environ.get("ORBG_BENCH_CTOR_AHEAD", "2")), choices=[1, 2, 3],
+    ap.add_argument("--ctor-ahead", type=int, default=int(os.environ.get("ORBG_BENCH_CTOR_AHEAD", "1")), choices=[1, 2, 3],
                     help="pipelined constructor: frames handed over ahead of the one being tracked (ring of N + 1 extractor handles / frame "
                          "objects; the python loop supports 1)")
     ap.add_argument("--no-host-features", action="store_true",
