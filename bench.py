@@ -465,7 +465,7 @@ def main():
             self.async_timed = False
             self.sync_tail_s = 0.0                            # time spent inside the closing torch.cuda.synchronize()
             self.tail = (0.0, 0.0, 0.0)
-            self.worst_step = None                           # (ms, [extract, match_frame, match_map, pose_opt, map_upload, lba, last_view] us) of the slowest step
+            self.worst_step = None                           # (ms, [extract, match_frame, match_map, pose_opt, map_upload, lba, last_view] us, index in the region) of the slowest step
             self.timeline = np.zeros((0, 5), np.float32)     # per constructor: queue / pack / enqueue / wait / latency [us] (orbx_get_ctor_timeline)
 
     def collect_async(reg):
@@ -642,6 +642,7 @@ def main():
         for e in exs:
             e.ctor_timeline(reset=True)
         cs0 = ctxt_switches()
+        th0 = harness.cgroup_throttled()
         t0 = time.perf_counter()
         loop.run(base, n_steps, last_is_final=True, timed=True, step_s=step_s, stats=st)
         sync()
@@ -650,11 +651,13 @@ def main():
         elapsed = grp.max_over_ranks(dt)          # TCP, a few hundred microseconds against a 2.7 ms region) is not step time
         cs1 = ctxt_switches()
         reg.stats["nonvoluntary_ctxt_switches"] = None if cs0 is None or cs1 is None else cs1 - cs0
+        th1 = harness.cgroup_throttled()
+        reg.stats["cgroup_throttled_us"] = None if th0 is None or th1 is None else th1[1] - th0[1]
         for key, j in (("extract", 0), ("match_frame", 1), ("match_map", 2), ("pose_opt", 3), ("map_upload", 4), ("lba", 5), ("last_view_upload", 6)):
             reg.stage[key] = st.stage_s[j]
         reg.stats.update(kp=st.kp, m_frame=st.m_frame, m_map=st.m_map, lba_iters=st.lba_iters, lba_calls=st.lba_calls, lba_s=st.lba_s)
         reg.step_s = step_s
-        reg.worst_step = (round(1e3 * st.worst_step_s, 3), [round(1e6 * st.worst_stage_s[q], 1) for q in range(7)])
+        reg.worst_step = (round(1e3 * st.worst_step_s, 3), [round(1e6 * st.worst_stage_s[q], 1) for q in range(7)], int(st.worst_step_index - base))
         reg.timeline = np.concatenate([e.ctor_timeline() for e in exs]) if stereo else np.zeros((0, 5), np.float32)
         return reg, elapsed
 
@@ -733,7 +736,8 @@ def main():
     reg, elapsed = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, prewarm_done)
     # what the shared host did to the region: involuntary context switches of this process's threads inside it, and how busy
     # OTHER tenants keep the hardware threads of the agent's cores right after it (this process sleeps during the sample)
-    host_noise = {"nonvoluntary_ctxt_switches_in_region": reg.stats.get("nonvoluntary_ctxt_switches")}
+    host_noise = {"nonvoluntary_ctxt_switches_in_region": reg.stats.get("nonvoluntary_ctxt_switches"),
+                  "cgroup_throttled_us_in_region": reg.stats.get("cgroup_throttled_us"), "cgroup_cpu_quota": harness.cgroup_cpu_quota()}
     if core_pair is not None:
         try:
             busy = harness._cpu_busy(0.1)
@@ -955,6 +959,8 @@ def main():
         line["value_min"] = round(min(repeat_values), 3); line["value_median"] = round(float(np.median(repeat_values)), 3)
         line["value_max"] = round(max(repeat_values), 3); line["value_regions"] = len(repeat_values)
         line["host_noise_ctxt_switches"] = host_noise.get("nonvoluntary_ctxt_switches_in_region")
+        line["host_cgroup_cpu_quota"] = host_noise.get("cgroup_cpu_quota")                    # CPUs this container may use per 100 ms period (None: no quota)
+        line["host_noise_cgroup_throttled_us"] = host_noise.get("cgroup_throttled_us_in_region")   # > 0: the container spent its quota inside the region
         busy_after = host_noise.get("agent_cores_busy_after_region") or {}
         line["host_noise_max_core_busy"] = max(busy_after.values()) if busy_after else None
         tl = reg.timeline

@@ -31,7 +31,7 @@ class Cfg(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("stage_s", C.c_double * 8), ("lba_s", C.c_double), ("lba_calls", C.c_int64), ("lba_iters", C.c_int64),
                 ("kp", C.c_int64), ("m_frame", C.c_int64), ("m_map", C.c_int64), ("error", C.c_int32), ("error_step", C.c_int32),
-                ("worst_step_s", C.c_double), ("worst_stage_s", C.c_double * 8)]
+                ("worst_step_s", C.c_double), ("worst_stage_s", C.c_double * 8), ("worst_step_index", C.c_int64)]
 
 
 _lib = None

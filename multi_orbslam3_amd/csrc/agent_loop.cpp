@@ -59,6 +59,7 @@ typedef struct agent_stats {
   int64_t kp, m_frame, m_map;
   int32_t error, error_step;
   double worst_step_s, worst_stage_s[8];   // the slowest timed step of the call and its stages (same order as stage_s)
+  int64_t worst_step_index;                // ... and which step of the sequence it was (first_step + s)
 } agent_stats;
 
 // struct sizes for the binding's layout check (multi_orbslam3_amd/agent.py)
@@ -193,6 +194,7 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
       if (step_s) step_s[s] = t_step;
       if (t_step > st->worst_step_s) {
         st->worst_step_s = t_step;
+        st->worst_step_index = i;
         const double w[8] = {t1 - t0, t2 - t1, t3 - t2b, t_po, t5 - t4, t6 - t5, t_lv, 0.0};
         for (int q = 0; q < 8; q++) st->worst_stage_s[q] = w[q];
       }

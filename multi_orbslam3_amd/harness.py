@@ -337,3 +337,33 @@ class AgentGroup:
         if self.dist is not None:
             self.dist.destroy_process_group()
             self.dist = None
+
+
+def cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in CPUs (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), or None when unlimited / unreadable.
+    A container with a quota throttles ALL its threads for the rest of a 100 ms period once the quota is spent: three spinning
+    agent threads next to other busy processes of the same container show up as ~80 ms pauses (round 4: the bench boxes run the
+    command in a 16-CPU cgroup; tools/neighbour_load.py's `everywhere` mode exceeded it)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except (OSError, ValueError):
+        return None
+
+
+def cgroup_throttled():
+    """(periods throttled, microseconds throttled) of this process's cgroup so far, or None."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            d = dict(line.split()[:2] for line in open(path) if line.strip())
+            us = int(d["throttled_usec"]) if "throttled_usec" in d else int(d.get("throttled_time", 0)) // 1000
+            return int(d.get("nr_throttled", 0)), us
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
