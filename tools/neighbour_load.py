@@ -88,10 +88,10 @@ def main():
     procs = []
     # The load must stay INSIDE the container's CPU quota (cgroup cpu.max; 16 CPUs on the bench boxes): a cgroup that spends its quota
     # has ALL its threads stopped for the rest of the 100 ms period -- the benchmark's included.  Round 4 measured exactly that as
-    # "one 75-80 ms pause per region" under `everywhere` (63 spinners) before the quota was read here.  Five CPUs are left to the
+    # "one 75-80 ms pause per region" under `everywhere` (63 spinners) before the quota was read here.  Six CPUs are left to the
     # benchmark (three spinning agent threads, the interpreter, the runtime's helpers); ORBG_LOAD_IGNORE_QUOTA=1 starts everything.
     quota = harness.cgroup_cpu_quota()
-    budget = None if (quota is None or os.environ.get("ORBG_LOAD_IGNORE_QUOTA")) else max(int(quota) - 5, 0)
+    budget = None if (quota is None or os.environ.get("ORBG_LOAD_IGNORE_QUOTA")) else max(int(quota) - 6, 0)
     skipped = [0]
 
     def start(fn, cpus, *a):
