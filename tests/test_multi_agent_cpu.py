@@ -175,3 +175,36 @@ def test_a_lone_agent_takes_the_idle_cores_of_one_l3_slice():
     assert harness._pick_idle_cores(cores[:2], {}, 3) is None
     b = harness._cpu_busy(0.02)
     assert b and all(0.0 <= v <= 1.0 for v in b.values())
+
+
+def test_cgroup_quota_and_throttle_readers(monkeypatch, tmp_path):
+    """harness.cgroup_cpu_quota / cgroup_throttled: cgroup v2 `cpu.max` (`max 100000` = no quota, `1600000 100000` = 16 CPUs) and
+    `cpu.stat`; v1 files as the fall-back; unreadable files give None (bench.py then reports null, never fails)."""
+    import builtins
+    from multi_orbslam3_amd import harness
+    files = {}
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/sys/fs/cgroup"):
+            if path in files:
+                f = tmp_path / ("f%d" % (abs(hash(path)) % 100000))
+                f.write_text(files[path])
+                return real_open(f, *a, **k)
+            raise OSError("no such cgroup file")
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert harness.cgroup_cpu_quota() is None and harness.cgroup_throttled() is None
+    files["/sys/fs/cgroup/cpu.max"] = "max 100000\n"
+    assert harness.cgroup_cpu_quota() is None
+    files["/sys/fs/cgroup/cpu.max"] = "1600000 100000\n"
+    assert harness.cgroup_cpu_quota() == 16.0
+    files["/sys/fs/cgroup/cpu.stat"] = "usage_usec 5\nnr_periods 449\nnr_throttled 289\nthrottled_usec 1442068891\n"
+    assert harness.cgroup_throttled() == (289, 1442068891)
+    del files["/sys/fs/cgroup/cpu.max"], files["/sys/fs/cgroup/cpu.stat"]
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "250000\n"; files["/sys/fs/cgroup/cpu/cpu.cfs_period_us"] = "100000\n"
+    files["/sys/fs/cgroup/cpu/cpu.stat"] = "nr_periods 10\nnr_throttled 3\nthrottled_time 7000000\n"
+    assert harness.cgroup_cpu_quota() == 2.5 and harness.cgroup_throttled() == (3, 7000)
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "-1\n"
+    assert harness.cgroup_cpu_quota() is None
