@@ -45,7 +45,9 @@ struct DevBuf {
     if (p) { ORBG_HIP(hipFree(p)); p = nullptr; cap = 0; }
     size_t want = n + n / 4 + 64;
     ORBG_HIP(hipMalloc((void**)&p, want * sizeof(T)));
-    if (poison_allocations()) ORBG_HIP(hipMemset(p, 0xA5, want * sizeof(T)));
+    // (the fill runs on the null stream and hipMemset may return before it has finished; the library's streams are non-blocking
+    // since round 4 and do not join it: without the synchronisation the fill raced with the first kernels that write the buffer)
+    if (poison_allocations()) { ORBG_HIP(hipMemset(p, 0xA5, want * sizeof(T))); ORBG_HIP(hipDeviceSynchronize()); }
     cap = want;
     return ORBG_OK;
   }

@@ -379,6 +379,18 @@ def test_frame_constructor_as_an_executable_graph():
     assert m and int(m.group(2)) == 2 and int(m.group(1)) >= 6, (r.stdout[-1500:], r.stderr[-1500:])
 
 
+def test_parity_subset_with_poisoned_allocations():
+    """ORBG_POISON=1 fills every new device / pinned buffer with 0xA5 (fresh HIP allocations are usually zero, so a kernel that consumes
+    memory nobody wrote passes unnoticed): a constructor test, a search test and the local BA's window sizes in such a process."""
+    env = dict(os.environ, ORBG_POISON="1")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", here + "::test_fused_stereo_frame_constructor",
+                        here + "::test_frame_constructor_submit_wait_pipelines_across_frames", here + "::test_lba_window_sizes_cover_every_ldlt_kernel",
+                        here + "::test_lba_every_window_size_up_to_50_free_poses", here + "::test_pose_optimization_parity"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 @pytest.mark.parametrize("async_ingest,device_images", [(False, False), (True, False), (False, True)])
 def test_two_halves_constructor_delivers_features_to_host(scene, async_ingest, device_images):
     """orbx_set_frame_outputs: the pipelined constructor hands mvKeys / mDescriptors / mvuRight / mvDepth of the left image to host
