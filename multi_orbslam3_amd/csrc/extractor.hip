@@ -2040,8 +2040,10 @@ static int setup_geometry(orbx_handle* h, int w, int hgt) {
         (rc = h->d_lvlcount.reserve(2 * ORBG_MAX_LEVELS)) || (rc = h->d_nkp.reserve(4)) || (rc = h->d_overflow.reserve(4)) ||
         (rc = h->d_selreg.reserve(std::max(roff, 1))) || (rc = h->h_nkp.reserve(4)))
       return rc;
-    ORBG_HIP(hipMemset(h->d_lvlcount.p, 0, 2 * ORBG_MAX_LEVELS * sizeof(int)));
-    ORBG_HIP(hipMemset(h->d_overflow.p, 0, 4 * sizeof(int)));   // [0] overflow flag, [2] ticket of the constructor's last launch
+    // (on the handle's own stream, in front of everything that uses them: the null stream's hipMemset may return before the fill has
+    // run, and the library's non-blocking streams do not join the null stream)
+    ORBG_HIP(hipMemsetAsync(h->d_lvlcount.p, 0, 2 * ORBG_MAX_LEVELS * sizeof(int), h->stream));
+    ORBG_HIP(hipMemsetAsync(h->d_overflow.p, 0, 4 * sizeof(int), h->stream));   // [0] overflow flag, [2] ticket of the constructor's last launch
     // output buffers must hold the worst case of the device-side selection
     const size_t need = (size_t)roff + 64;
     if ((rc = h->d_kps.reserve(need)) || (rc = h->d_desc.reserve(need * 32)) || (rc = h->h_kps.reserve(need)) ||
@@ -3133,7 +3135,7 @@ static int extract_finish_gpu(orbx_handle* h, ExtractPending& c) {
   const PostOps* post = c.has_post ? &c.post : nullptr;
   if (h->h_nkp.h[2]) {
     // a level had more candidates / nodes than the LDS-resident quad-tree holds: redo this frame with the host trees
-    ORBG_HIP(hipMemset(h->d_overflow.p, 0, sizeof(int)));
+    ORBG_HIP(hipMemsetAsync(h->d_overflow.p, 0, sizeof(int), st));
     return extract_core(h, c.cams_mask, c.d_img0, c.d_img1, c.w, c.hgt, c.stride, c.lap, c.kps_out, c.desc_out, c.cap, c.n_out, c.n_mono_out,
                         post, true, false);
   }

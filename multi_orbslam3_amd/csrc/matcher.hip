@@ -935,7 +935,10 @@ static int frame_reserve(orbm_frame* f, int n) {
     return rc;
   if (!f->d_counter.p) {                        // both overflow counters start at zero; from then on the kernels keep them so
     if ((rc = f->d_counter.reserve(4))) return rc;
-    ORBG_HIP(hipMemset(f->d_counter.p, 0, f->d_counter.cap * sizeof(int)));
+    // (once per frame object, and complete before anything can use it: the null stream's hipMemset may return before the fill has run,
+    // and the library's non-blocking streams do not join the null stream)
+    ORBG_HIP(hipMemsetAsync(f->d_counter.p, 0, f->d_counter.cap * sizeof(int), f->stream));
+    ORBG_HIP(hipStreamSynchronize(f->stream));
   }
   return ORBG_OK;
 }
