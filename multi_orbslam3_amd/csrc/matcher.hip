@@ -1099,6 +1099,7 @@ extern "C" int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start, int32_t* 
   if (!f || !cell_start) return ORBG_BAD_ARG;
   int rc = select_device(f->device);
   if (rc) return rc;
+  ORBG_HIP(hipStreamSynchronize(f->stream));              // (the grid build may still be in flight on the frame's stream; the copies below use the null stream)
   ORBG_HIP(hipMemcpy(cell_start, f->d_cell_start.p, (kCells + 1) * sizeof(int), hipMemcpyDeviceToHost));
   const int total = cell_start[kCells];
   if (cell_items && total > 0) ORBG_HIP(hipMemcpy(cell_items, f->d_cell_items.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
