@@ -97,7 +97,6 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
     const int64_t i = first_step + s;
     const int k = c->seq[i % c->n_seq], k_last = c->seq[(i + c->n_seq - 1) % c->n_seq];
     const agent_frame_in& fin = c->frames[k];
-    const bool last = last_is_final && s == n_steps - 1;
     const double t0 = now_s();
     int nl = 0, nr = 0, cur = 0;
     if (c->pipelined) {
