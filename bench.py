@@ -265,6 +265,135 @@ def cpu_baseline(scene, cfg, synth, views, n_frames, host_imgs, frames, kf_chunk
                           len(lba_times), 1e3 * float(np.mean(lba_times)) if lba_times else 0.0, int(np.mean(n_map)) if n_map else 0, wall))
 
 
+def _bits_equal(a, b):
+    """Bit-for-bit equality of two arrays (structured or plain; -0.0 != 0.0, NaN == NaN of the same payload)."""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames, host_imgs, seq, map_view_of_step, lp, lba_out, th_frame, mono,
+                nn_map=0.8):
+    """SURVEY.md 8(d) "parity gates run in the same job": the frames the product loop has just been TIMED on, once more through
+    the same loop (`run_step(i)` = one step of libagentloop.so -- or of the Python loop -- configured as the main timed region, returning
+    what it left on the host: mvKeys / mDescriptors / mvuRight / mvDepth as delivered by the constructor, F.mvpMapPoints after
+    SearchByProjection(Current, Last) and after SearchLocalPoints), and the CPU oracle on the same images, pose guesses, last-frame
+    views and local maps.  Bit-exact: keypoints (24 B records), descriptors, uRight / depth (f32 bits), both match arrays and match
+    counts.  Local BA: the result the loop's last solve delivered against the oracle's solve of the same problem: status, LM
+    iterations of both rounds, outlier flags, |pose| / |point| difference <= 1e-4 after the float32 write-back, (lambda, chi2, trials)
+    trace within 1e-9 relative.  Outside every timed region.  Returns the `parity` object of the line; ok = every field true / <= 1e-4."""
+    from oracle import binding as ob
+    W, H = scene.W, scene.H
+    cam = scene.cam
+    p = scene.frame_view_params()
+    stereo = cfg["stereo"]
+    exL = ob.Extractor(n_features=cfg["n_features"], max_width=W, max_height=H)
+    exR = ob.Extractor(n_features=cfg["n_features"], max_width=W, max_height=H) if stereo else None
+    res = dict(frames=0, extract_bit_exact=True, stereo_bit_exact=True if stereo else None, match_frame_equal=True, match_map_equal=True,
+               keypoints_checked=0, matches_frame_checked=0, matches_map_checked=0, first_step=int(first_step))
+    bad = []
+    for i in range(first_step, first_step + n_gate):
+        k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
+        got = run_step(i)
+        L, R = host_imgs[k]
+        if stereo:
+            rc, okl, odl, _ = exL.extract(L)
+            rc, okr, odr, _ = exR.extract(R)
+            our, odp = ob.stereo_match(exL, exR, okl, odl, okr, odr, float(cam["bf"]), float(cam["b"]))
+        else:
+            rc, okl, odl, _ = exL.extract(L, (0, 1000))
+            our = odp = None
+        n = len(okl)
+        e_ok = got["nl"] == n and _bits_equal(got["kps"][:n], okl) and _bits_equal(got["desc"][:n], odl)
+        if stereo:
+            e_ok = e_ok and got["nr"] == len(okr)
+            s_ok = got["nl"] == n and _bits_equal(got["uright"][:n], our) and _bits_equal(got["depth"][:n], odp)
+            res["stereo_bit_exact"] = bool(res["stereo_bit_exact"] and s_ok)
+            if not s_ok:
+                bad.append("step %d (frame %d): uRight / depth differ from the oracle" % (i, k))
+        res["extract_bit_exact"] = bool(res["extract_bit_exact"] and e_ok)
+        if not e_ok:
+            bad.append("step %d (frame %d): keypoints / descriptors differ from the oracle (%d vs %d left)" % (i, k, got["nl"], n))
+            continue                                      # the searches of a frame with other features cannot agree
+        fv, keep1 = views.frame_view(okl, odl, our, odp, p["bounds"], p["cam"], 8, 1.2)
+        guess = frames[k]["guess"]
+        amp = np.full(n, -1, np.int32); aob = np.zeros(n, np.int32)
+        amp1, aob1, n1 = ob.search_by_projection_frame(fv, guess, frames[k_last]["last_view"][0], th_frame, mono, True, amp, aob)
+        f_ok = got["n1"] == n1 and np.array_equal(got["amp_frame"][:n], amp1)
+        amp2, aob2, n2 = ob.search_local_points(fv, map_view_of_step(i), guess, 1.0, False, 0.0, nn_map, amp1, aob1)
+        m_ok = got["n2"] == n2 and np.array_equal(got["amp"][:n], amp2) and np.array_equal(got["aob"][:n], aob2)
+        res["match_frame_equal"] = bool(res["match_frame_equal"] and f_ok)
+        res["match_map_equal"] = bool(res["match_map_equal"] and m_ok)
+        if not f_ok:
+            bad.append("step %d (frame %d): SearchByProjection(Current, Last) %d matches vs oracle %d" % (i, k, got["n1"], n1))
+        if not m_ok:
+            bad.append("step %d (frame %d): SearchLocalPoints %d matches vs oracle %d" % (i, k, got["n2"], n2))
+        res["frames"] += 1; res["keypoints_checked"] += n + (len(okr) if stereo else 0)
+        res["matches_frame_checked"] += int(n1); res["matches_map_checked"] += int(n2)
+    # ---- the local BA the loop ran last (every keyframe step solves the same problem) against the oracle's solve of it
+    finish()                                              # every local BA the gate's steps submitted has delivered its result
+    g = lba_out
+    o = ob.lba_solve(lp)
+    d_pose = float(np.abs(g.poses - o.poses).max()); d_pt = float(np.abs(g.points - o.points).max())
+    tg, to = g.trace_rows(), o.trace_rows()
+    tr_ok = tg.shape == to.shape and bool(np.array_equal(tg[:, 2], to[:, 2]))
+    tr_rel = float(np.max(np.abs(tg[:, :2] - to[:, :2]) / np.maximum(np.abs(to[:, :2]), 1e-300))) if tr_ok and len(to) else (0.0 if tr_ok else float("inf"))
+    res.update(lba_max_abs=max(d_pose, d_pt), lba_pose_max_abs=d_pose, lba_point_max_abs=d_pt,
+               lba_iters_equal=bool(g.status == o.status and tuple(g.iters) == tuple(o.iters)), lba_iters=[int(x) for x in g.iters],
+               lba_outliers_equal=bool(np.array_equal(g.edge_outlier, o.edge_outlier) and g.n_outliers == o.n_outliers),
+               lba_trace_trials_equal=tr_ok, lba_trace_max_rel=tr_rel, lba_edges=int(lp.n_edges))
+    if not res["lba_iters_equal"]:
+        bad.append("local BA: status / iterations %s %s vs oracle %s %s" % (g.status, tuple(g.iters), o.status, tuple(o.iters)))
+    if not (res["lba_max_abs"] <= 1e-4):
+        bad.append("local BA: |pose| %.3g |point| %.3g above 1e-4" % (d_pose, d_pt))
+    if not res["lba_outliers_equal"]:
+        bad.append("local BA: outlier sets differ")
+    if not (tr_ok and tr_rel <= 1e-9):
+        bad.append("local BA: (lambda, chi2, trials) trace differs (max rel %.3g)" % tr_rel)
+    res["ok"] = not bad
+    res["violations"] = bad[:8]
+    res["oracle"] = "oracle/ (CPU restatement of the reference path; parity unpinned by the reference, see DESIGN.md section 6)"
+    return res
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this same command (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, as torch.distributed.run sets them), rank 0 inheriting stdout -- it prints the ONE line.  The parent
+    never initialises the GPU (torch.cuda.device_count() does not on this image).  Returns the exit code: 0 when every rank returned 0;
+    2 when the node has fewer GPUs than ranks (ORBG_BENCH_SHARE_GPU=1, a test aid, lets ranks share the GPUs that exist)."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < n and os.environ.get("ORBG_BENCH_SHARE_GPU") != "1":
+        sys.stderr.write("bench.py: --gpus %d but this node has %d GPU%s (one agent per GPU; ORBG_BENCH_SHARE_GPU=1 shares them for a dry run)\n"
+                         % (n, n_dev, "" if n_dev == 1 else "s"))
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(range(n))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.remove(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for q in pending:
+                    procs[q].terminate()                   # (exactly the processes started above)
+        time.sleep(0.05)
+    return rc
+
+
 def copy_bandwidth_gbs(torch, device, mib=512, reps=10):
     """Device-to-device copy of `mib` MiB (read + write counted): the second denominator SURVEY.md 8(d) asks for."""
     a = torch.empty(mib << 20, dtype=torch.uint8, device="cuda:%d" % device)
@@ -292,6 +421,10 @@ def main():
                     help="untimed steps before --warmup (at least this many; the pre-warm runs until the step rate is stationary, "
                          "0.3 - 3 s): first-use allocations, clocks, hardware queues -- so that a short timed region is at steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-frames", type=int, default=20,
+                    help="in-job parity gate (SURVEY.md 8d): this many frames of the timed sequence go through the product loop once more, "
+                         "outside the timed region, and every output is compared with the CPU oracle; the process exits with code 3 on a "
+                         "violation (0: no gate, the line then carries parity: null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the value_host_images / value_with_pose_opt regions")
     ap.add_argument("--secondary-steps", type=int, default=300)
     ap.add_argument("--separate-calls", action="store_true",
@@ -341,6 +474,17 @@ def main():
                     help="also time the server-side exchange (RCCL all-gather of KF wire blocks -> rebuilt KeyFrame -> "
                          "SearchByProjection(KF, Scw, map)) for 2 and 8 KF blocks; reported under config.server_tick")
     args = ap.parse_args()
+    # ---- N > 1 launched the way the driver launches N = 1 (`python bench.py --gpus N`, no RANK in the environment): this process
+    # starts the N rank processes itself -- fresh children, decided BEFORE anything here touches the GPU -- and relays their exit code
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank%s (WORLD_SIZE): refusing to print a line whose n_gpus is not "
+                         "what was asked for\n" % (args.gpus, world_env, "" if world_env == 1 else "s"))
+        sys.exit(2)
     cfg = CONFIGS[args.config]
     stereo = cfg["stereo"]
 
@@ -354,22 +498,37 @@ def main():
     # Measured this round (3 / 4 / 5 / 6 / 8 queues: 5550 / 8290 / 8270 / 8240 / 4380 frames/s): the runtime's default of 4 is as good
     # as 5 or 6 now, and the server tick (--server-tick) needs it (with 6 its streams share queues erratically: 8 blocks 354 us vs 1470)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
-    # Every agent keeps two threads spinning on completion words (tracking thread, local-BA worker).  If the container's CPU
-    # quota cannot feed that for all ranks of this node (cgroup cpu.max), fall back to the runtime's blocking waits
-    # (ORBG_NO_POLL=1: ~6-10 us more latency per wait, a fraction of a CPU per rank) instead of being throttled.
-    wait_mode = "polling"
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q, per = f.read().split()
-        if q != "max":
-            ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-            if float(q) / float(per) < 3.0 * ranks_here:
-                os.environ.setdefault("ORBG_NO_POLL", "1")
-                wait_mode = "runtime waits (cpu quota %.1f for %d ranks)" % (float(q) / float(per), ranks_here)
-    except (OSError, ValueError):
-        pass
-    if os.environ.get("ORBG_NO_POLL"):
-        wait_mode = "runtime waits" if wait_mode == "polling" else wait_mode
+    # Every agent keeps up to three threads spinning on completion words (tracking thread, local-BA worker, image-ingest thread).  If
+    # the container's CPU quota (cgroup cpu.max) cannot feed that for all ranks of this node, the policy is per thread ROLE
+    # (orbg_set_wait_policy / ORBG_NO_POLL, include/orbgpu.h "Host threads"): the tracking thread keeps spinning -- it is on the frame's
+    # critical path -- and the local-BA worker and the ingest thread block (runtime waits / condition variables: 6-10 us more latency
+    # per wait, a fraction of a CPU each); only below one CPU per rank does the tracking thread block too.
+    wait_policy = {"caller": "spin", "lba": "spin", "ingest": "spin", "reason": "no cpu quota (or quota >= 3 cpus per rank)"}
+    ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if os.environ.get("ORBG_NO_POLL") is None:
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                q, per = f.read().split()
+            if q != "max":
+                cpus = float(q) / float(per)
+                if cpus < 1.0 * ranks_here:
+                    os.environ["ORBG_NO_POLL"] = "all"
+                elif cpus < 3.0 * ranks_here:
+                    os.environ["ORBG_NO_POLL"] = "lba,ingest"
+                wait_policy["reason"] = "cpu quota %.1f for %d rank%s" % (cpus, ranks_here, "" if ranks_here == 1 else "s")
+        except (OSError, ValueError):
+            pass
+    else:
+        wait_policy["reason"] = "ORBG_NO_POLL=%s in the environment" % os.environ["ORBG_NO_POLL"]
+    np_env = os.environ.get("ORBG_NO_POLL")
+    if np_env is not None:
+        every = np_env in ("", "1", "all") or not any(t in np_env for t in ("caller", "lba", "ingest"))
+        for role in ("caller", "lba", "ingest"):
+            if every or role in np_env:
+                wait_policy[role] = "block"
+    wait_mode = "polling" if all(wait_policy[r] == "spin" for r in ("caller", "lba", "ingest")) else \
+        "per role: tracking thread %ss, local-BA worker %ss, ingest thread %ss (%s)" % (wait_policy["caller"], wait_policy["lba"], wait_policy["ingest"],
+                                                                                       wait_policy["reason"])
     import torch
     from multi_orbslam3_amd import _capi as capi
     from multi_orbslam3_amd import api, harness, synth, views
@@ -488,7 +647,9 @@ def main():
         else:
             exs[c].frame_stereo_dev_submit(Fs[c], fv, imgs[k_img][0].data_ptr(), imgs[k_img][1].data_ptr(), W, H, W, bf, bb)
 
-    def step(i, reg, timed, pose_opt, host_images, pipelined, slot=None, last=False):
+    current_map_view = [None]                     # python loop: the view the last LM.upload() made resident
+
+    def step(i, reg, timed, pose_opt, host_images, pipelined, slot=None, last=False, capture=None):
         k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
         fr = frames[k]
         dL, dR = imgs[k]
@@ -537,8 +698,14 @@ def main():
         amp.fill(-1); aob.fill(0)                         # F.mvpMapPoints starts empty (S/Frame.cc:113)
         amp, aob, n1 = m_frame.SearchByProjectionFrame(Fc, fr["guess"], frames[k_last]["last_view"][0], th_frame, mono_flag, amp, aob, inplace=True)
         t4 = time.perf_counter()
+        if capture is not None:
+            capture["amp_frame"] = amp.copy()
         amp, aob, n2 = m_map.SearchLocalPoints(Fc, LM, fr["guess"], 1.0, False, 0.0, amp, aob, None, inplace=True)
         t5 = time.perf_counter()
+        if capture is not None:
+            capture.update(nl=nl, nr=nr, n1=n1, n2=n2, amp=amp.copy(), aob=aob.copy(), map_view=current_map_view[0])
+            if not stereo:
+                capture.update(kps=kl, desc=dl)
         if pose_opt:
             # TrackWithMotionModel / TrackLocalMap call PoseOptimization after each search (S/Tracking.cc:2649,2712);
             # ~450 and ~650 correspondences as the two searches produce here
@@ -551,7 +718,8 @@ def main():
         if k % FRAMES_PER_KF == 0:
             maps.visit(k)                              # this frame's map points joined the map when it was a keyframe
         if i % FRAMES_PER_KF == 0:
-            LM.upload(maps.view())                     # Tracking::UpdateLocalMap: points of the last 20 / 50 keyframes
+            current_map_view[0] = maps.view()
+            LM.upload(current_map_view[0])             # Tracking::UpdateLocalMap: points of the last 20 / 50 keyframes
             t6 = time.perf_counter()
             if args.lba_mode == "async":
                 collect_async(reg)                     # the previous keyframe's LBA (long finished in steady state)
@@ -577,7 +745,8 @@ def main():
                 reg.step_s[slot] = time.perf_counter() - t0
 
     # local map must exist before the first frame
-    LM.upload(maps.view())
+    current_map_view[0] = maps.view()
+    LM.upload(current_map_view[0])
 
     # ---- the same loop in C++ (libagentloop.so): the per-frame host work of a client is C++ in the reference (Tracking.cc)
     use_cxx = args.loop == "cxx" and stereo and not args.separate_calls and not args.profile_stages
@@ -918,7 +1087,7 @@ def main():
                                            if (use_cxx and args.last_frame_view == "resident") else "read in place from pinned host memory"),
                        "local_map_points_avg": int(np.mean(maps.sizes)) if maps.sizes else 0, "local_map_keyframes": cfg["local_kfs"],
                        "sequence_frames": len(seq),
-                       "cpu_affinity": cpu_affinity, "host_noise": host_noise, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode,
+                       "cpu_affinity": cpu_affinity, "host_noise": host_noise, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "completion_wait": wait_mode, "wait_policy": wait_policy,
                        "frame_ctor": ("pipelined, %d frame(s) ahead: Frame(t+1 .. t+%d) are submitted (host images: orbx_frame_stereo_submit) on the other extractor "
                                       "handles of a ring of %d before frame t is tracked, and collected at the start of their own steps; the timed region holds "
                                       "exactly K constructors (the first step submits its own and the ones ahead, the last ones hand no further frame over)"
@@ -1025,9 +1194,64 @@ def main():
                                  "median": round(float(np.median(per_rank)), 3),
                                  "pinning": "each agent's sample on its own physical cores %s" % (sorted(own) if own else "(unpinned: one agent)")}
             line["cpu_baseline"] = base
+    # ---- in-job parity gate (SURVEY.md 8d last row): frames of the TIMED sequence once more through the same loop, every output
+    # against the CPU oracle.  After the cpu_baseline leg (which selects the oracle build of this process), outside every timed region.
+    parity = None
+    if args.parity_frames > 0 and under_profiler:
+        parity = {"skipped": "under a profiler (the oracle library may have to be rebuilt: a child process)"}
+    elif args.parity_frames > 0:
+        K_ = FRAMES_PER_KF
+        gate_first = 40000                                   # (a multiple of FRAMES_PER_KF: the gate's first step is a keyframe step)
+        if use_cxx:
+            gate_pipelined = True                            # the main region's configuration (pipelined, host images, features on host)
+            if feature_outputs is None:
+                loop.drain()
+                feature_outputs = [e.set_frame_outputs(cfg["frame_cap"]) for e in exs]
+            loop.configure(gate_pipelined, True, ingest_async, submit_first, args.lba_mode == "async", False, ahead=ctor_ahead)
+            loop.capture_first_search(True)
+            loop.run(gate_first - K_, K_)                    # the keyframe step before the gate makes its local map resident
+
+            def run_step(i):
+                st = loop.run(i, 1)
+                out = feature_outputs[i % loop.c.ring]
+                return dict(nl=st.last_nl, nr=st.last_nr, n1=st.last_n1, n2=st.last_n2, kps=out["kps"], desc=out["desc"], uright=out["uright"],
+                            depth=out["depth"], amp_frame=loop.amp_after_frame, amp=loop.amp, aob=loop.aob)
+
+            def map_view_of_step(i):
+                return kf_views[((i // K_) - (1 if i % K_ == 0 else 0)) % len(kf_views)]
+        else:
+            scratch2 = Region(1)
+            for j in range(gate_first - K_, gate_first):
+                step(j, scratch2, False, False, host_images, pipeline)
+            gate_maps = {}
+
+            def run_step(i):
+                cap_ = {}
+                step(i, scratch2, False, False, host_images, pipeline, capture=cap_)
+                gate_maps[i] = cap_["map_view"]
+                return cap_
+
+            def map_view_of_step(i):
+                return gate_maps[i]
+        if use_cxx or not stereo:
+            parity = parity_gate(args.parity_frames, gate_first, run_step, (loop.drain if use_cxx else (lambda: collect_async(scratch2))), scene, cfg,
+                                 views, frames, host_imgs, seq, map_view_of_step, lp, lba_out, th_frame, mono_flag)
+            if use_cxx:
+                loop.capture_first_search(False)
+            parity["loop"] = "libagentloop.so, configured as the main timed region" if use_cxx else "python loop (ctypes wrappers)"
+        else:
+            parity = {"skipped": "the python loop of a stereo agent leaves its features in HBM (use the default --loop cxx)"}
+        oks = grp.gather_floats(1.0 if parity.get("ok", True) else 0.0)
+        parity["agents_ok"] = [bool(v) for v in oks]
+        if not all(parity["agents_ok"]):
+            parity["ok"] = False
     if rank == 0:
+        line["parity"] = parity
         print(json.dumps(line))
     grp.close()
+    if parity is not None and parity.get("ok") is False:
+        sys.stderr.write("bench.py: PARITY VIOLATION against the oracle: %s\n" % "; ".join(parity.get("violations", []) or ["(another agent)"]))
+        sys.exit(3)
 
 
 def run_dropin_bench():

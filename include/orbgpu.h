@@ -576,12 +576,20 @@ int pose_optimize(const pose_opt_problem* p, pose_opt_result* r);
  * (then it falls back to the runtime's blocking wait); the asynchronous forms own one thread each -- lba_solve_async: one worker per
  * handle, ORBX_SUBMIT_ASYNC: one ingest thread per process -- which spin for a few hundred microseconds between jobs before they
  * sleep.  An agent that uses all three therefore keeps up to three cores busy (tracking thread, local-BA worker, ingest thread);
- * ORBG_NO_POLL=1 switches every wait to the runtime's blocking form (6-10 us more latency per wait, no spinning).
+ * The policy is per ROLE of the waiting thread (orbg_set_wait_policy below): ORBG_ROLE_CALLER (any thread of the application that
+ * calls the library: Tracking), ORBG_ROLE_LBA_WORKER, ORBG_ROLE_INGEST.  A role that does not spin waits in the runtime's blocking
+ * form / on a condition variable (6-10 us more latency per wait, no busy core).  A host whose CPU quota cannot feed three spinning
+ * threads per agent keeps the tracking thread spinning (it is on the frame's critical path) and lets the other two block.
+ * ORBG_NO_POLL in the environment sets the start-up policy: "1" / "all" = no role spins; a comma list of caller / lba / ingest =
+ * those roles block.
  * Cameras.  The fused Frame constructors (orbx_frame_stereo*) build the grid from the extracted keypoints as they are, i.e. they
  * implement Frame::UndistortKeyPoints for mDistCoef[0] == 0 (rectified stereo: mvKeysUn = mvKeys, S/Frame.cc:723-727).  The
  * reference's image bounds are exactly the image rectangle in that case (S/Frame.cc:775-783) and the undistorted corners otherwise
  * (:753-773): a view whose bounds are not (0, width, 0, height) is refused with ORBG_BAD_ARG.  Distorted cameras (the mono agents
  * with EuRoC intrinsics) go through orbx_extract + the caller's cv::undistortPoints + orbm_frame_upload. */
+enum { ORBG_ROLE_CALLER = 0, ORBG_ROLE_LBA_WORKER = 1, ORBG_ROLE_INGEST = 2 };
+int orbg_set_wait_policy(int role, int spin);   /* spin != 0: waits of that role spin on completion words; 0: they block.  Process-wide, any time */
+int orbg_get_wait_policy(int role);             /* 1 = spins, 0 = blocks, ORBG_BAD_ARG for an unknown role */
 int orbx_set_stream(orbx_handle* h, void* hip_stream);
 int orbm_frame_set_stream(orbm_frame* f, void* hip_stream);
 int orbm_map_set_stream(orbm_map* m, void* hip_stream);

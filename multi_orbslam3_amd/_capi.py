@@ -135,7 +135,7 @@ EXPORTED_SYMBOLS = [
     "orbd_database_create", "orbd_database_destroy", "orbd_detect_n_best_candidates",
     "orbx_set_stream", "orbm_frame_set_stream", "orbm_map_set_stream", "lba_set_stream", "orbv_vocab_set_stream", "orbd_database_set_stream",
     "pose_opt_set_stream", "orbx_get_ctor_timeline", "orbm_map_set_observations", "orbm_search_by_projection_reloc", "orbm_lastview_create", "orbm_lastview_destroy", "orbm_lastview_upload",
-    "orbm_search_by_projection_frame_resident", "orbg_quiesce",
+    "orbm_search_by_projection_frame_resident", "orbg_quiesce", "orbg_set_wait_policy", "orbg_get_wait_policy",
     "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_event_overhead", "orbx_set_profile_interval", "orbx_set_profile_kernel", "orbx_get_fast_kernel_stats", "orbx_set_profiling",
 ]
 

@@ -25,13 +25,15 @@ class Cfg(C.Structure):
                 ("pipelined", C.c_int), ("host_images", C.c_int), ("ingest_async", C.c_int), ("submit_first", C.c_int),
                 ("lba_async", C.c_int), ("pose_opt", C.c_int), ("th_frame", C.c_float), ("mono", C.c_int), ("nn_frame", C.c_float),
                 ("nn_map", C.c_float), ("amp", C.c_void_p), ("aob", C.c_void_p), ("cap", C.c_int), ("in_flight", C.c_int32 * 4),
-                ("ahead", C.c_int32), ("ring", C.c_int32), ("lba_in_flight", C.c_int32), ("last_view_dev", C.c_void_p), ("last_view_frame", C.c_int32)]
+                ("ahead", C.c_int32), ("ring", C.c_int32), ("lba_in_flight", C.c_int32), ("last_view_dev", C.c_void_p), ("last_view_frame", C.c_int32),
+                ("amp_after_frame", C.c_void_p)]
 
 
 class Stats(C.Structure):
     _fields_ = [("stage_s", C.c_double * 8), ("lba_s", C.c_double), ("lba_calls", C.c_int64), ("lba_iters", C.c_int64),
                 ("kp", C.c_int64), ("m_frame", C.c_int64), ("m_map", C.c_int64), ("error", C.c_int32), ("error_step", C.c_int32),
-                ("worst_step_s", C.c_double), ("worst_stage_s", C.c_double * 8), ("worst_step_index", C.c_int64)]
+                ("worst_step_s", C.c_double), ("worst_stage_s", C.c_double * 8), ("worst_step_index", C.c_int64),
+                ("last_nl", C.c_int32), ("last_nr", C.c_int32), ("last_n1", C.c_int32), ("last_n2", C.c_int32)]
 
 
 _lib = None
@@ -100,7 +102,16 @@ class AgentLoop:
         self.keep.append(last_view)
         c.last_view_dev = last_view.h.value if last_view is not None else None      # api.LastFrameOnDevice: the last frame's view resident on the device
         c.last_view_frame = -1
+        c.amp_after_frame = None
+        self.amp_after_frame = None
         self.c = c
+
+    def capture_first_search(self, on=True):
+        """From now on every step also copies F.mvpMapPoints as SearchByProjection(Current, Last) left it into
+        self.amp_after_frame (bench.py's parity gate; off: no copy)."""
+        if on and self.amp_after_frame is None:
+            self.amp_after_frame = np.full(len(self.amp), -1, np.int32)
+        self.c.amp_after_frame = self.amp_after_frame.ctypes.data if on else None
 
     def configure(self, pipelined, host_images, ingest_async, submit_first, lba_async, pose_opt, ahead=1):
         c = self.c

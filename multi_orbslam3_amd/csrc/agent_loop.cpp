@@ -51,6 +51,8 @@ typedef struct agent_cfg {
   int32_t lba_in_flight;                                     // a local BA submitted and not yet collected
   orbm_lastview* last_view_dev;                              // NULL: SearchByProjection(Current, Last) reads the view in place (pinned memory)
   int32_t last_view_frame;                                   // frame whose view is resident in last_view_dev (-1: none)
+  int32_t* amp_after_frame;                                  // NULL, or cap entries: F.mvpMapPoints as SearchByProjection(Current, Last) left it
+                                                             // (bench.py's in-job parity gate compares both searches with the oracle)
 } agent_cfg;
 
 typedef struct agent_stats {
@@ -60,6 +62,7 @@ typedef struct agent_stats {
   int32_t error, error_step;
   double worst_step_s, worst_stage_s[8];   // the slowest timed step of the call and its stages (same order as stage_s)
   int64_t worst_step_index;                // ... and which step of the sequence it was (first_step + s)
+  int32_t last_nl, last_nr, last_n1, last_n2;   // the LAST step of the call: features left / right, matches of the two searches
 } agent_stats;
 
 // struct sizes for the binding's layout check (multi_orbslam3_amd/agent.py)
@@ -144,6 +147,7 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
       }
       if ((rc = orbm_search_by_projection_frame_resident(F, fin.Tcw_guess, c->last_view_dev, c->th_frame, c->mono, 1, c->amp, c->aob, &n1))) break;
     } else if ((rc = orbm_search_by_projection_frame(F, fin.Tcw_guess, c->frames[k_last].last_view, c->th_frame, c->mono, 1, c->amp, c->aob, &n1))) break;
+    if (c->amp_after_frame) memcpy(c->amp_after_frame, c->amp, sizeof(int32_t) * (size_t)nl);
     const double t2 = now_s();
     double t_po = 0;
     if (c->pose_opt && c->po[0]) {                                 // TrackWithMotionModel: Optimizer::PoseOptimization(&mCurrentFrame), :2649
@@ -185,6 +189,7 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
       }
       t6 = now_s();
     }
+    st->last_nl = nl; st->last_nr = nr; st->last_n1 = n1; st->last_n2 = n2;
     if (timed) {
       st->stage_s[0] += t1 - t0; st->stage_s[1] += t2 - t1; st->stage_s[2] += t3 - t2b; st->stage_s[3] += t_po;
       st->stage_s[4] += t5 - t4; st->stage_s[5] += t6 - t5; st->stage_s[6] += t_lv;

@@ -31,9 +31,14 @@ constexpr int kPatch = 31;       // PATCH_SIZE      S/ORBextractor.cc:70
 // tests (fresh HIP allocations are often zero, recycled ones are not).  Test aid; allocations are outside the timed path.
 inline bool poison_allocations() { static const bool on = getenv("ORBG_POISON") != nullptr; return on; }
 
-// ORBG_NO_POLL=1: every completion wait of the library goes through the runtime's blocking waits instead of spinning on a word in
-// pinned memory (read once per process; bench.py sets it when the container's CPU quota cannot feed the spinning threads).
-inline bool poll_allowed() { static const bool off = getenv("ORBG_NO_POLL") != nullptr; return !off; }
+// Wait policy per host-thread ROLE (include/orbgpu.h, "Host threads"): a wait either SPINS on a completion word in pinned memory or
+// goes through the runtime's blocking waits / a condition variable.  Roles: the caller's threads (Tracking), the local-BA worker of a
+// handle, the process's image-ingest thread.  ORBG_NO_POLL in the environment gives the start-up policy ("1" / "all": every role
+// blocks; a comma list of caller / lba / ingest: those roles block); orbg_set_wait_policy() changes it at run time.  Implemented in
+// misc.cpp (one state for all translation units); poll_allowed() is what every wait site asks -- an atomic load + a thread-local.
+enum { kRoleCaller = 0, kRoleLbaWorker = 1, kRoleIngest = 2, kRoleCount = 3 };
+bool poll_allowed();                 // may the CALLING thread spin?
+void set_thread_role(int role);      // called once by the library's own threads when they start
 
 // Growable device buffer (never shrinks); all allocations happen outside the timed/launch path once sizes settle.
 template <typename T>

@@ -2926,6 +2926,7 @@ struct IngestWorker {
   std::thread th;
   static bool spin_ok() { return orbg::poll_allowed(); }
   void run() {
+    orbg::set_thread_role(orbg::kRoleIngest);
     for (;;) {
       // the next pair usually arrives within a frame time: spin for a while, then sleep
       bool have = false;

@@ -2265,7 +2265,7 @@ struct StopRef {
 // path itself never calls getenv.  A test that wants another variant creates another handle.
 struct LbaSwitches {
   bool blit = false, host_items = false, host_lists = false, no_fuse = false, no_first2 = false, host_csr = false, dev_csr = false;
-  bool ldlt_valu = false, ldlt_rows = false, ldlt_wide = false, ldlt_dense = false, fuse_update = false, no_spec = false, no_poll = false;
+  bool ldlt_valu = false, ldlt_rows = false, ldlt_wide = false, ldlt_dense = false, fuse_update = false, no_spec = false;
   bool no_export_fuse = false, ldlt_prio = false, old_passes = false;
   int upd_threads = 64;              // k_update's workgroup size (ORBG_UPD_THREADS = 64 / 128 / 256)
   ldltm::Switches ldlt;              // which matrix-core kernel a size gets (ORBG_LDLT_TILES / _T9_4W / _8W)
@@ -2275,7 +2275,7 @@ struct LbaSwitches {
     w.blit = on("ORBG_LBA_BLIT"); w.host_items = on("ORBG_HOST_ITEMS"); w.host_lists = on("ORBG_HOST_LISTS"); w.no_fuse = on("ORBG_NO_FUSE");
     w.no_first2 = on("ORBG_NO_FIRST2"); w.host_csr = on("ORBG_HOST_CSR"); w.dev_csr = on("ORBG_DEV_CSR"); w.ldlt_valu = on("ORBG_LDLT_VALU");
     w.ldlt_rows = on("ORBG_LDLT_ROWS"); w.ldlt_wide = on("ORBG_LDLT_WIDE"); w.ldlt_dense = on("ORBG_LDLT_DENSE"); w.no_spec = on("ORBG_NO_SPEC");
-    w.no_poll = !orbg::poll_allowed(); w.no_export_fuse = on("ORBG_NO_EXPORT_FUSE"); w.ldlt_prio = on("ORBG_LDLT_PRIO"); w.old_passes = on("ORBG_LBA_OLD_PASSES");
+    w.no_export_fuse = on("ORBG_NO_EXPORT_FUSE"); w.ldlt_prio = on("ORBG_LDLT_PRIO"); w.old_passes = on("ORBG_LBA_OLD_PASSES");
     if (const char* e = getenv("ORBG_FUSE_UPDATE")) w.fuse_update = atoi(e) != 0;
     if (const char* e = getenv("ORBG_UPD_THREADS")) { const int v = atoi(e); w.upd_threads = (v == 256 || v == 128) ? v : 64; }
     w.ldlt = ldltm::Switches::from_env();
@@ -2842,7 +2842,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     volatile unsigned* w = &h->rec.h->seq;
     const unsigned want = h->rec_seq;
     bool got = false;
-    if (!sw.no_poll) {
+    if (orbg::poll_allowed()) {              // (the policy of the thread that runs the solve: caller or local-BA worker)
       timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
       for (unsigned spins = 0; !got; spins++) {
         if (*w == want) { got = true; break; }
@@ -3403,6 +3403,7 @@ static int lba_solve_async_impl(lba_handle* h, const lba_problem* p, StopRef sto
   if (h->job_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;
   if (!h->worker.joinable()) {
     h->worker = std::thread([h]() {
+      orbg::set_thread_role(orbg::kRoleLbaWorker);
       for (;;) {
         // next job: spin briefly (the tracking thread usually submits within tens of microseconds), then sleep
         if (!lba_spin_until([h]() { return h->quit || h->job_state.load(std::memory_order_acquire) == 1; }, 400.0)) {

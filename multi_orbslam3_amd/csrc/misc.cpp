@@ -28,9 +28,28 @@ extern "C" int orbg_device_count(void) {
 #include <immintrin.h>
 #endif
 
+#include <atomic>
 #include <mutex>
 
 namespace orbg {
+
+// ---- wait policy per thread role (common.hpp)
+namespace {
+unsigned block_mask_from_env() {
+  const char* e = getenv("ORBG_NO_POLL");
+  if (!e) return 0u;
+  if (!*e || !strcmp(e, "1") || !strcmp(e, "all")) return (1u << kRoleCount) - 1u;
+  unsigned m = 0;
+  if (strstr(e, "caller")) m |= 1u << kRoleCaller;
+  if (strstr(e, "lba")) m |= 1u << kRoleLbaWorker;
+  if (strstr(e, "ingest")) m |= 1u << kRoleIngest;
+  return m ? m : (1u << kRoleCount) - 1u;                  // anything else that is set: the round-4 meaning (every wait blocks)
+}
+std::atomic<unsigned>& block_mask() { static std::atomic<unsigned> m{block_mask_from_env()}; return m; }
+thread_local int t_role = kRoleCaller;
+}  // namespace
+bool poll_allowed() { return !((block_mask().load(std::memory_order_relaxed) >> t_role) & 1u); }
+void set_thread_role(int role) { if (role >= 0 && role < kRoleCount) t_role = role; }
 
 namespace {
 struct DevicePool { bool made = false; hipStream_t L = nullptr, E[2] = {nullptr, nullptr}, M = nullptr; unsigned n_ex = 0, n_fr = 0; };
@@ -114,6 +133,17 @@ bool is_library_stream(hipStream_t st) {
 }
 
 }  // namespace orbg
+
+extern "C" int orbg_set_wait_policy(int role, int spin) {
+  if (role < 0 || role >= orbg::kRoleCount) return ORBG_BAD_ARG;
+  if (spin) orbg::block_mask().fetch_and(~(1u << role), std::memory_order_relaxed);
+  else orbg::block_mask().fetch_or(1u << role, std::memory_order_relaxed);
+  return ORBG_OK;
+}
+extern "C" int orbg_get_wait_policy(int role) {
+  if (role < 0 || role >= orbg::kRoleCount) return ORBG_BAD_ARG;
+  return ((orbg::block_mask().load(std::memory_order_relaxed) >> role) & 1u) ? 0 : 1;
+}
 
 // Waits -- spinning on completion words, like every other wait of the library -- until everything enqueued so far on the library's
 // pooled streams of `device` has completed.  For a caller that brackets a region with the runtime's own device synchronisation

@@ -92,5 +92,44 @@ def make_matching_pose_bow(sc):
     print("local", loc[2], "sim3", sim[1], "bow_kf", bow[1], "pose_opt", po.iters, po.n_inliers, "words", len(bw))
 
 
+def make_appendix_f():
+    """SURVEY.md Appendix F's larger fixtures: the 96x72 and 640x480 extractions (per-level candidates, kept keypoints, angles,
+    descriptors, the constructor's tables) and the C2-sized local BA (20 free + 10 fixed keyframes, 2000 points) with its
+    per-iteration (lambda, chi2, trials) trace."""
+    # (Appendix F names 64 x 48; that size has NO FAST cell -- the detection window [16, h - 16) is 16 rows, nRows = 16 / 30 = 0, and
+    # the reference divides by it, S/ORBextractor.cc:779-782 -- so the smallest fixture is a 96 x 72 crop of the 640 x 480 frame)
+    sc = synth.Scene(640, 480)
+    L, R, Tcw = sc.stereo_pair(3)
+    crop = np.ascontiguousarray(L[200:272, 300:396])
+    ex = ob.Extractor(n_features=100, n_levels=3, max_width=96, max_height=72)
+    rc, kl, dl, nm = ex.extract(crop)
+    np.savez_compressed(os.path.join(OUT, "extract_96x72.npz"), L=crop, kps=kl, desc=dl, cand0=ex.candidates(0), cand1=ex.candidates(1),
+                        cand2=ex.candidates(2), level2=ex.level(2, border=True))
+    print("96x72: kps", len(kl))
+    sc = synth.Scene(640, 480)
+    L, R, Tcw = sc.stereo_pair(3)
+    ex = ob.Extractor(n_features=1000, max_width=640, max_height=480)
+    rc, kl, dl, nm = ex.extract(L)
+    cands = {"cand%d" % l: ex.candidates(l) for l in range(8)}
+    tabs = ex.tables()
+    rc, km, dm, nmono = ex.extract(L, (0, 1000))                # the monocular Frame constructor's lapping area (S/Frame.cc:289)
+    np.savez_compressed(os.path.join(OUT, "extract_640x480.npz"), L=L, kps=kl, desc=dl, kps_mono_order=km, desc_mono_order=dm,
+                        n_mono=np.array([nm, nmono]), level7=ex.level(7, border=True), scale=tabs[0], inv_scale=tabs[1], sigma2=tabs[2],
+                        inv_sigma2=tabs[3], features_per_level=tabs[4], **cands)
+    print("640x480: kps", len(kl), "candidates", [len(cands["cand%d" % l]) for l in range(8)], "monoIndex", nm, nmono)
+    prob = synth.make_lba_problem(n_free=20, n_fixed=10, n_points=2000, width=640, height=480, seed=synth.SEED_LBA)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    o = ob.lba_solve(p)
+    np.savez_compressed(os.path.join(OUT, "lba_20p10_2000.npz"), poses=prob["poses"], pose_fixed=prob["pose_fixed"], points=prob["points"],
+                        edges=prob["edges"], cam=np.array(prob["cam"], np.float32), out_poses=o.poses, out_points=o.points,
+                        out_outlier=o.edge_outlier, out_depth_pos=o.edge_depth_pos, out_chi2=o.edge_chi2, trace=o.trace_rows(),
+                        iters=np.array(o.iters), status=np.array([o.status]), chi2=np.array(o.chi2), n_outliers=np.array([o.n_outliers]))
+    print("lba 20+10/2000: edges", p.n_edges, "iters", o.iters, "trace rows", len(o.trace_rows()), "chi2", o.chi2, "outliers", o.n_outliers)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "appendix_f":
+        make_appendix_f()
+    else:
+        main()
+        make_appendix_f()

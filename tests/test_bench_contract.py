@@ -28,7 +28,7 @@ def test_bench_line_has_the_contract_fields():
     d = _bench("--steps", "40", "--warmup", "10", "--secondary-steps", "20")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "timed_region_s", "step_ms_p50", "step_ms_p95",
-                "value_device_images", "value_sync_ctor_host_images", "value_with_pose_opt", "fps_formula", "prewarm_steps"):
+                "value_device_images", "value_sync_ctor_host_images", "value_with_pose_opt", "fps_formula", "prewarm_steps", "parity"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 10
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -55,6 +55,10 @@ def test_bench_line_has_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample", "build", "host_cpu"):
         assert key in cb, key
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1
+    # the in-job parity gate: 20 frames of the timed sequence through libagentloop.so against the oracle
+    pr = d["parity"]
+    assert pr["ok"] is True and pr["frames"] == 20 and pr["extract_bit_exact"] and pr["stereo_bit_exact"] and pr["match_frame_equal"]
+    assert pr["match_map_equal"] and pr["lba_iters_equal"] and pr["lba_max_abs"] <= 1e-4 and "libagentloop" in pr["loop"]
 
 
 @pytest.mark.gpu
@@ -217,3 +221,40 @@ def test_two_ranks_produce_one_aggregate_line():
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]          # whole-job aggregate = 2 agents x steps / max time
     assert len(d["cpu_baseline"]["per_agent"]["values"]) == 2
+
+
+def test_gpus_flag_is_never_silently_ignored():
+    """`--gpus N` must produce a line with n_gpus == N or fail: without a launcher bench.py starts the N ranks itself (refused, rc 2,
+    when the node has fewer GPUs -- this container has none), and under a launcher whose WORLD_SIZE differs from --gpus it refuses too.
+    Both decisions are taken before anything touches a GPU, so they run here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ORBG_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    if r.returncode == 0:                                  # (a box with >= 2 GPUs: the line must say so)
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["n_gpus"] == 2
+    else:
+        assert r.returncode == 2 and "--gpus 2 but this node has" in r.stderr and not r.stdout.strip()
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env2)
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_self_launched_ranks_and_the_in_job_parity_gate():
+    """`python bench.py --gpus 2` with no launcher (how the driver starts N = 1): two rank processes on the box's one GPU
+    (ORBG_BENCH_SHARE_GPU=1), ONE line with n_gpus == 2, and the in-job parity gate green for both agents."""
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}, ORBG_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-secondary",
+                        "--no-dropin", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20
+    pr = d["parity"]
+    assert pr["ok"] is True and pr["agents_ok"] == [True, True] and pr["frames"] == 20
+    for key in ("extract_bit_exact", "stereo_bit_exact", "match_frame_equal", "match_map_equal", "lba_iters_equal", "lba_outliers_equal"):
+        assert pr[key] is True, key
+    assert pr["lba_max_abs"] <= 1e-4 and pr["lba_trace_max_rel"] <= 1e-9 and pr["keypoints_checked"] > 30000
