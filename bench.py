@@ -55,8 +55,14 @@ CONFIGS = {
                label="C4 (single-GPU part of configs[3]): 1 client stereo 1280x720 synthetic, 2000 ORB feat/frame, 50-KF local BA "
                      "window (50 free + 20 fixed KFs, 8000 points); visual edges only (IMU types are out of scope)"),
     "mono": dict(W=640, H=480, stereo=False, n_features=1000, lba=(20, 10, 2000), mono_frac=1.0, frame_cap=4096, map_cap=32768, local_kfs=20,
-                 label="mono agent of configs[4]: 1 client mono 640x480 synthetic (host image -> operator() with lapping area "
-                       "{0,1000}, S/Frame.cc:289), 1000 ORB feat/frame, 20-KF local BA of monocular edges"),
+                 label="mono agent of configs[4]: 1 client mono 640x480 synthetic (Frame::Frame(mono), S/Frame.cc:260-358: host image -> "
+                       "ExtractORB with lapping area {0,1000} -> grid, one fused submission), 1000 ORB feat/frame, 20-KF local BA of monocular edges"),
+    "mono_dist": dict(W=640, H=480, stereo=False, n_features=1000, lba=(20, 10, 2000), mono_frac=1.0, frame_cap=4096, map_cap=32768, local_kfs=20,
+                      dist=(-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0),
+                      label="mono agent with a DISTORTED camera (EuRoC's radial-tangential coefficients, R/ros/conf/EuRoC_mono_client.yaml, on the "
+                            "synthetic pinhole images: Frame::UndistortKeyPoints runs on the device inside the fused constructor; the arithmetic and "
+                            "the throughput are a distorted camera's, the match counts towards the image edges are lower than a real lens would give), "
+                            "640x480, 1000 ORB feat/frame, 20-KF local BA of monocular edges"),
 }
 
 
@@ -74,12 +80,14 @@ def build_workload(scene, cfg, n_frames, api, views, synth, device):
     F = api.Frame(cfg["frame_cap"], device)
     LM = api.LocalMap(cfg["map_cap"], device)
     m_dedupe = api.ORBmatcher(0.8, True, device)
-    fv0, _keep0 = views.frame_view(np.zeros(1, capi_dtype()), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
+    dist = cfg.get("dist")
+    bounds = p["bounds"] if dist is None else api.image_bounds(W, H, p["cam"][:4], dist, device)      # Frame::ComputeImageBounds
+    fv0, _keep0 = views.frame_view(np.zeros(1, capi_dtype()), np.zeros((1, 32), np.uint8), None, None, bounds, p["cam"], 8, 1.2)
     frames, imgs, host_imgs = [], [], []
     kf_chunks = {}
     for k in range(n_frames):
         L, R, Tcw = scene.stereo_pair(k)
-        host_imgs.append((np.ascontiguousarray(L), np.ascontiguousarray(R)))
+        host_imgs.append((np.ascontiguousarray(L), np.ascontiguousarray(R) if cfg["stereo"] else None))
         if cfg["stereo"]:
             dL = torch.from_numpy(L).to("cuda:%d" % device)
             dR = torch.from_numpy(R).to("cuda:%d" % device)
@@ -88,13 +96,11 @@ def build_workload(scene, cfg, n_frames, api, views, synth, device):
                                                          download=True)
             kl, dl, ur, dp = kl.copy(), dl.copy(), ur.copy(), dp.copy()
         else:
-            imgs.append((None, None))
-            nm, kl, dl = ex(L, (0, 1000))
-            nl = len(kl)
-            dp = scene.depth_at(kl, Tcw)             # a mono agent's map comes from triangulation; here: scene geometry
+            dL = torch.from_numpy(L).to("cuda:%d" % device)
+            imgs.append((dL, None))
+            nl, kraw, kl, dl = ex.frame_mono(F, fv0, L, dist)       # Frame::Frame(mono); kl = mvKeysUn (= mvKeys without distortion)
+            dp = scene.depth_at(kraw, Tcw)           # a mono agent's map comes from triangulation; here: scene geometry
             ur = np.full(nl, -1.0, np.float32)
-            fvm, keepm = views.frame_view(kl, dl, None, None, p["bounds"], p["cam"], 8, 1.2)
-            F.upload(fvm, keepm)
         Pw, valid = synth.unproject_to_world(kl, dp, Tcw, cam)
         lv, keep = views.lastframe_view(valid.astype(np.uint8), np.zeros(nl, np.uint8), Pw, dl, kl["octave"], kl["angle"],
                                         np.full(nl, 3, np.int32), Tcw.astype(np.float32))
@@ -111,7 +117,7 @@ def build_workload(scene, cfg, n_frames, api, views, synth, device):
             kf_chunks[k] = synth.map_from_frame(kl, dl, dp_new, Tcw, cam)
         frames.append(dict(Tcw=Tcw, guess=synth.perturb_pose(Tcw, rng).astype(np.float32), last_view=(lv, keep),
                            n=nl, stereo=int((ur > 0).sum())))
-    return ex, imgs, host_imgs, frames, kf_chunks
+    return ex, imgs, host_imgs, frames, kf_chunks, fv0, bounds
 
 
 def capi_dtype():
@@ -190,6 +196,7 @@ def cpu_baseline(scene, cfg, synth, views, n_frames, host_imgs, frames, kf_chunk
     exL = ob.Extractor(n_features=nf, max_width=scene.W, max_height=scene.H)
     exR = ob.Extractor(n_features=nf, max_width=scene.W, max_height=scene.H)
     p = scene.frame_view_params()
+    base_bounds = p["bounds"] if cfg.get("dist") is None else ob.image_bounds(scene.W, scene.H, p["cam"][:4], cfg["dist"])
     rng = np.random.RandomState(1234)
     nfree, nfix, npts = cfg["lba"]
     prob = synth.make_lba_problem(n_free=nfree, n_fixed=nfix, n_points=npts, width=scene.W, height=scene.H, mono_frac=cfg["mono_frac"])
@@ -232,7 +239,8 @@ def cpu_baseline(scene, cfg, synth, views, n_frames, host_imgs, frames, kf_chunk
         else:
             rc, kl, dl, _ = exL.extract(L, (0, 1000))
             ur, dp = None, scene.depth_at(kl, Tcw)
-        fv, keep1 = views.frame_view(kl, dl, ur, dp if cfg["stereo"] else None, p["bounds"], p["cam"], 8, 1.2)
+            kl = ob.undistort_keypoints(kl, p["cam"][:4], cfg.get("dist"))           # Frame::UndistortKeyPoints (a copy without distortion)
+        fv, keep1 = views.frame_view(kl, dl, ur, dp if cfg["stereo"] else None, base_bounds, p["cam"], 8, 1.2)
         n = len(kl)
         amp = np.full(n, -1, np.int32); aob = np.zeros(n, np.int32)
         guess = synth.perturb_pose(Tcw, rng).astype(np.float32)
@@ -272,7 +280,7 @@ def _bits_equal(a, b):
 
 
 def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames, host_imgs, seq, map_view_of_step, lp, lba_out, th_frame, mono,
-                nn_map=0.8):
+                nn_map=0.8, bounds=None):
     """SURVEY.md 8(d) "parity gates run in the same job": the frames the product loop has just been TIMED on, once more through
     the same loop (`run_step(i)` = one step of libagentloop.so -- or of the Python loop -- configured as the main timed region, returning
     what it left on the host: mvKeys / mDescriptors / mvuRight / mvDepth as delivered by the constructor, F.mvpMapPoints after
@@ -286,6 +294,12 @@ def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames,
     cam = scene.cam
     p = scene.frame_view_params()
     stereo = cfg["stereo"]
+    dist = cfg.get("dist")
+    if dist is not None:                                   # Frame::ComputeImageBounds: the product's bounds (device) against the oracle's
+        ob_bounds = ob.image_bounds(W, H, p["cam"][:4], dist)
+        if tuple(np.float32(bounds)) != tuple(np.float32(ob_bounds)):
+            return dict(ok=False, frames=0, violations=["image bounds %s differ from the oracle's %s" % (tuple(bounds), ob_bounds)])
+    bounds = p["bounds"] if bounds is None else bounds
     exL = ob.Extractor(n_features=cfg["n_features"], max_width=W, max_height=H)
     exR = ob.Extractor(n_features=cfg["n_features"], max_width=W, max_height=H) if stereo else None
     res = dict(frames=0, extract_bit_exact=True, stereo_bit_exact=True if stereo else None, match_frame_equal=True, match_map_equal=True,
@@ -304,6 +318,9 @@ def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames,
             our = odp = None
         n = len(okl)
         e_ok = got["nl"] == n and _bits_equal(got["kps"][:n], okl) and _bits_equal(got["desc"][:n], odl)
+        if not stereo:
+            okl = ob.undistort_keypoints(okl, p["cam"][:4], dist)         # mvKeysUn: what the grid and the searches read
+            e_ok = e_ok and _bits_equal(got["kps_un"][:n], okl)
         if stereo:
             e_ok = e_ok and got["nr"] == len(okr)
             s_ok = got["nl"] == n and _bits_equal(got["uright"][:n], our) and _bits_equal(got["depth"][:n], odp)
@@ -314,7 +331,7 @@ def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames,
         if not e_ok:
             bad.append("step %d (frame %d): keypoints / descriptors differ from the oracle (%d vs %d left)" % (i, k, got["nl"], n))
             continue                                      # the searches of a frame with other features cannot agree
-        fv, keep1 = views.frame_view(okl, odl, our, odp, p["bounds"], p["cam"], 8, 1.2)
+        fv, keep1 = views.frame_view(okl, odl, our, odp, bounds, p["cam"], 8, 1.2)
         guess = frames[k]["guess"]
         amp = np.full(n, -1, np.int32); aob = np.zeros(n, np.int32)
         amp1, aob1, n1 = ob.search_by_projection_frame(fv, guess, frames[k_last]["last_view"][0], th_frame, mono, True, amp, aob)
@@ -493,7 +510,7 @@ def main():
     # share a queue with the local BA's chain; with 6 every stream has its own; 8 and 12 are slower again.  Must be set
     # before the runtime initialises.  (Without the pipelined constructor the agent has three busy streams and the default
     # of 4 is the good setting -- more hardware queues than busy streams cost dispatch latency on every one of them.)
-    pipeline = stereo and not (args.no_pipeline or args.separate_calls)
+    pipeline = not (args.no_pipeline or args.separate_calls)
     host_images = not args.device_images and not args.separate_calls
     # Measured this round (3 / 4 / 5 / 6 / 8 queues: 5550 / 8290 / 8270 / 8240 / 4380 frames/s): the runtime's default of 4 is as good
     # as 5 or 6 now, and the server tick (--server-tick) needs it (with 6 its streams share queues erratically: 8 blocks 354 us vs 1470)
@@ -553,14 +570,15 @@ def main():
     W, H = cfg["W"], cfg["H"]
     scene = synth.Scene(W, H, seed=synth.SEED_IMAGES + rank)      # one agent per GPU, distinct seeds
     cam = scene.cam
-    ex, imgs, host_imgs, frames, kf_chunks = build_workload(scene, cfg, args.frames, api, views, synth, device)
+    ex, imgs, host_imgs, frames, kf_chunks, fv, frame_bounds = build_workload(scene, cfg, args.frames, api, views, synth, device)
     p = scene.frame_view_params()
-    fv, fv_keep = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
+    dist = cfg.get("dist")
+    dist_c = None if dist is None else capi.OrbxDistortion(*[float(v) for v in dist])
     F = api.Frame(cfg["frame_cap"], device)
     # frame t+1 is constructed (second extractor handle, second frame object) while frame t is tracked
-    ctor_ahead = args.ctor_ahead if (args.loop == "cxx" and stereo and not args.separate_calls and not args.profile_stages) else 1
+    ctor_ahead = args.ctor_ahead if (args.loop == "cxx" and not args.separate_calls and not args.profile_stages) else 1
     n_ring = 2 if ctor_ahead == 1 else 4        # an even ring: consecutive frames alternate between the two extractor streams
-    exs = [ex] + [api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, W, H, n_cams=2, device=device) for _ in range(n_ring - 1)] if pipeline else [ex]
+    exs = [ex] + [api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, W, H, n_cams=2 if stereo else 1, device=device) for _ in range(n_ring - 1)] if pipeline else [ex]
     Fs = [F] + [api.Frame(cfg["frame_cap"], device) for _ in range(n_ring - 1)] if pipeline else [F]
     in_flight = [False] * 4
     # the pipelined constructor delivers mvKeys / mDescriptors / mvuRight / mvDepth into host arrays at every _wait (orbx_set_frame_outputs):
@@ -586,7 +604,10 @@ def main():
         # the library's ingest thread is created by the first asynchronous submission and inherits that caller's affinity
         if core_pair is not None and len(core_pair) >= 3:
             os.sched_setaffinity(0, core_pair[2])
-        exs[1].frame_stereo_submit(Fs[1], fv, host_imgs[0][0], host_imgs[0][1], bf, bb, async_ingest=True)
+        if stereo:
+            exs[1].frame_stereo_submit(Fs[1], fv, host_imgs[0][0], host_imgs[0][1], bf, bb, async_ingest=True)
+        else:
+            exs[1].frame_mono_submit(Fs[1], fv, host_imgs[0][0], dist_c, async_ingest=True)
         exs[1].frame_stereo_dev_wait()
         if core_pair is not None:
             os.sched_setaffinity(0, core_pair[0])
@@ -642,7 +663,12 @@ def main():
     submit_first = args.submit_order == "before-wait"
 
     def submit_ctor(c, k_img, host_images):
-        if host_images:
+        if not stereo:
+            if host_images:
+                exs[c].frame_mono_submit(Fs[c], fv, host_imgs[k_img][0], dist_c, async_ingest=ingest_async)
+            else:
+                exs[c].frame_mono_submit(Fs[c], fv, None, dist_c, device_ptr=imgs[k_img][0].data_ptr(), size=(W, H, W))
+        elif host_images:
             exs[c].frame_stereo_submit(Fs[c], fv, host_imgs[k_img][0], host_imgs[k_img][1], bf, bb, async_ingest=ingest_async)
         else:
             exs[c].frame_stereo_dev_submit(Fs[c], fv, imgs[k_img][0].data_ptr(), imgs[k_img][1].data_ptr(), W, H, W, bf, bb)
@@ -655,13 +681,15 @@ def main():
         dL, dR = imgs[k]
         t0 = time.perf_counter()
         Fc, exc = F, ex
-        if not stereo:
-            # mono agent: Frame::Frame(mono) = ExtractORB(0, im, 0, 1000) (S/Frame.cc:289) + grid; host image in, features out
-            nm, kl, dl = ex(host_imgs[k][0], (0, 1000))
-            nl, nr = len(kl), 0
+        kl = kun = dl = None
+        if not stereo and not pipelined:
+            # mono agent: Frame::Frame(mono) = ExtractORB(0, im, 0, 1000) (S/Frame.cc:289) + UndistortKeyPoints + grid, one fused submission
+            if host_images:
+                nl, kl, kun, dl = ex.frame_mono(F, fv, host_imgs[k][0], dist_c)
+            else:
+                nl, kl, kun, dl = ex.frame_mono(F, fv, None, dist_c, device_ptr=imgs[k][0].data_ptr(), size=(W, H, W))
+            nr = 0
             t1 = t2 = time.perf_counter()
-            fvm, keepm = views.frame_view(kl, dl, None, None, p["bounds"], p["cam"], 8, 1.2)
-            F.upload(fvm, keepm)
         elif pipelined:
             c = i & 1
             Fc, exc = Fs[c], exs[c]
@@ -704,8 +732,11 @@ def main():
         t5 = time.perf_counter()
         if capture is not None:
             capture.update(nl=nl, nr=nr, n1=n1, n2=n2, amp=amp.copy(), aob=aob.copy(), map_view=current_map_view[0])
-            if not stereo:
-                capture.update(kps=kl, desc=dl)
+            if kl is not None:
+                capture.update(kps=kl, kps_un=kun, desc=dl)
+            elif feature_outputs is not None and pipelined:
+                o_ = feature_outputs[i & 1]
+                capture.update(kps=o_["kps"], kps_un=o_["kps_un"], desc=o_["desc"], uright=o_["uright"], depth=o_["depth"])
         if pose_opt:
             # TrackWithMotionModel / TrackLocalMap call PoseOptimization after each search (S/Tracking.cc:2649,2712);
             # ~450 and ~650 correspondences as the two searches produce here
@@ -749,7 +780,7 @@ def main():
     LM.upload(current_map_view[0])
 
     # ---- the same loop in C++ (libagentloop.so): the per-frame host work of a client is C++ in the reference (Tracking.cc)
-    use_cxx = args.loop == "cxx" and stereo and not args.separate_calls and not args.profile_stages
+    use_cxx = args.loop == "cxx" and not args.separate_calls and not args.profile_stages
     loop = None
     if use_cxx:
         from multi_orbslam3_amd import agent as agent_mod
@@ -766,12 +797,12 @@ def main():
             if i % FRAMES_PER_KF == 0 and i >= period:
                 kf_views.append(sim.view())
         maps.sizes = list(sim.sizes)
-        frames_in = [dict(host=host_imgs[k], dev=(imgs[k][0].data_ptr(), imgs[k][1].data_ptr()),
+        frames_in = [dict(host=host_imgs[k], dev=(imgs[k][0].data_ptr(), imgs[k][1].data_ptr() if stereo else None),
                           guess=np.ascontiguousarray(frames[k]["guess"], np.float32).reshape(16), last_view=frames[k]["last_view"][0])
                      for k in range(nF)]
         last_dev = api.LastFrameOnDevice(2 * cfg["frame_cap"], device) if args.last_frame_view == "resident" else None
         loop = agent_mod.AgentLoop(exs, Fs, LM, opt, fv, W, H, W, bf, bb, frames_in, seq, kf_views, lp, lba_out, [po1, po2], FRAMES_PER_KF,
-                                   2 * cfg["frame_cap"], th_frame, mono_flag, last_view=last_dev)
+                                   2 * cfg["frame_cap"], th_frame, mono_flag, last_view=last_dev, mono_agent=not stereo, dist=dist_c)
 
     def ctxt_switches():
         """Involuntary context switches of every thread of this process so far: a spinning thread that loses its core to a
@@ -827,7 +858,7 @@ def main():
         reg.stats.update(kp=st.kp, m_frame=st.m_frame, m_map=st.m_map, lba_iters=st.lba_iters, lba_calls=st.lba_calls, lba_s=st.lba_s)
         reg.step_s = step_s
         reg.worst_step = (round(1e3 * st.worst_step_s, 3), [round(1e6 * st.worst_stage_s[q], 1) for q in range(7)], int(st.worst_step_index - base))
-        reg.timeline = np.concatenate([e.ctor_timeline() for e in exs]) if stereo else np.zeros((0, 5), np.float32)
+        reg.timeline = np.concatenate([e.ctor_timeline() for e in exs])
         return reg, elapsed
 
     def run_region(n_steps, n_warm, pose_opt, host_images, pipelined, first_index):
@@ -858,7 +889,7 @@ def main():
         elapsed = grp.timed(lambda i: step(base + i, reg, True, pose_opt, host_images, pipelined, slot=i, last=(i == n_steps - 1)), n_steps, sync)
         cs1 = ctxt_switches()
         reg.stats["nonvoluntary_ctxt_switches"] = None if cs0 is None or cs1 is None else cs1 - cs0
-        reg.timeline = np.concatenate([e.ctor_timeline() for e in exs]) if stereo else np.zeros((0, 5), np.float32)
+        reg.timeline = np.concatenate([e.ctor_timeline() for e in exs])
         return reg, elapsed
 
     # internal pre-warm, independent of --warmup: at least --prewarm-steps steps AND at least 50 ms of the main configuration
@@ -956,15 +987,15 @@ def main():
     if not args.no_secondary:
         ns = max(min(args.secondary_steps, args.steps), 1)
         nw = max(min(args.warmup, 40), 1)
-        if stereo and host_images and pipeline:
+        if host_images and pipeline:
             r2, e2 = run_region(ns, nw, False, False, True, 10000)
             secondary["value_device_images"] = round(world * ns / e2, 3)
-            secondary["value_device_images_note"] = ("the two images already resident in HBM (orbx_frame_stereo_dev_submit): no host "
+            secondary["value_device_images_note"] = ("the image(s) already resident in HBM (orbx_frame_stereo_dev_submit / orbx_frame_mono_dev_submit): no host "
                                                      "staging, no PCIe copy; pipelined constructor, %d timed steps" % ns)
-        if stereo and pipeline:
+        if pipeline:
             r4, e4 = run_region(ns, nw, False, True, False, 15000)
             secondary["value_sync_ctor_host_images"] = round(world * ns / e4, 3)
-            secondary["value_sync_ctor_host_images_note"] = ("orbx_frame_stereo: the constructor an UNCHANGED Tracking thread calls -- host "
+            secondary["value_sync_ctor_host_images_note"] = ("orbx_frame_stereo / orbx_frame_mono: the constructor an UNCHANGED Tracking thread calls -- host "
                                                              "images in, synchronous, nothing overlaps the tracking of the previous frame; "
                                                              "%d timed steps" % ns)
         if not args.pose_opt:
@@ -1080,7 +1111,7 @@ def main():
                        "avg_matches_frame": round(stats["m_frame"] / K, 1), "avg_matches_map": round(stats["m_map"] / K, 1),
                        "lba_mode": args.lba_mode, "pose_opt_in_step": bool(args.pose_opt),
                        "tracking_loop": ("libagentloop.so (multi_orbslam3_amd/csrc/agent_loop.cpp): the per-frame loop is C++ above the C-ABI, timed as one call "
-                                         "of K steps" if use_cxx else "python (ctypes wrappers, one step per call)"), "host_images_in_step": bool(host_images or not stereo),
+                                         "of K steps" if use_cxx else "python (ctypes wrappers, one step per call)"), "host_images_in_step": bool(host_images),
                        "image_ingest": ("host images -> pinned staging slot (%s) -> copy kernel on the extractor's stream -> HBM"
                                         % ("library ingest thread" if pipeline and ingest_async else "calling thread")) if host_images else "images resident in HBM",
                        "last_frame_view": ("resident: uploaded at the end of the frame's tracking (inside the step), read from HBM by the next frame's search"
@@ -1214,8 +1245,8 @@ def main():
             def run_step(i):
                 st = loop.run(i, 1)
                 out = feature_outputs[i % loop.c.ring]
-                return dict(nl=st.last_nl, nr=st.last_nr, n1=st.last_n1, n2=st.last_n2, kps=out["kps"], desc=out["desc"], uright=out["uright"],
-                            depth=out["depth"], amp_frame=loop.amp_after_frame, amp=loop.amp, aob=loop.aob)
+                return dict(nl=st.last_nl, nr=st.last_nr, n1=st.last_n1, n2=st.last_n2, kps=out["kps"], kps_un=out["kps_un"], desc=out["desc"],
+                            uright=out["uright"], depth=out["depth"], amp_frame=loop.amp_after_frame, amp=loop.amp, aob=loop.aob)
 
             def map_view_of_step(i):
                 return kf_views[((i // K_) - (1 if i % K_ == 0 else 0)) % len(kf_views)]
@@ -1233,14 +1264,14 @@ def main():
 
             def map_view_of_step(i):
                 return gate_maps[i]
-        if use_cxx or not stereo:
+        if use_cxx or (pipeline and feature_outputs is not None) or (not stereo and not pipeline):
             parity = parity_gate(args.parity_frames, gate_first, run_step, (loop.drain if use_cxx else (lambda: collect_async(scratch2))), scene, cfg,
-                                 views, frames, host_imgs, seq, map_view_of_step, lp, lba_out, th_frame, mono_flag)
+                                 views, frames, host_imgs, seq, map_view_of_step, lp, lba_out, th_frame, mono_flag, bounds=frame_bounds)
             if use_cxx:
                 loop.capture_first_search(False)
             parity["loop"] = "libagentloop.so, configured as the main timed region" if use_cxx else "python loop (ctypes wrappers)"
         else:
-            parity = {"skipped": "the python loop of a stereo agent leaves its features in HBM (use the default --loop cxx)"}
+            parity = {"skipped": "this python-loop configuration leaves the features in HBM (use the default --loop cxx)"}
         oks = grp.gather_floats(1.0 if parity.get("ok", True) else 0.0)
         parity["agents_ok"] = [bool(v) for v in oks]
         if not all(parity["agents_ok"]):

@@ -204,6 +204,35 @@ int orbx_set_frame_outputs(orbx_handle* h, orbx_keypoint* kps_left, uint8_t* des
 int orbx_frame_stereo_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
                              const uint8_t* img_right, int width, int height, int stride, float bf, float b, int flags);
 int orbx_frame_stereo_wait(orbx_handle* h, int* n_left, int* n_right);
+/* ---- the monocular Frame constructor (mono agents of BASELINE configs 1 and 5)
+ * Frame::Frame(imGray, ..., pCamera, distCoef, ...), S/Frame.cc:260-358: ExtractORB(0, imGray, 0, 1000) (:289 -- the lapping area
+ * {0, 1000} covers every image up to 1000 px wide, so ALL keypoints are written from the back: reversed order, monoIndex = 0,
+ * S/ORBextractor.cc:1135-1144), UndistortKeyPoints (:301, :721-754), mvuRight = mvDepth = -1 (:303-304), AssignFeaturesToGrid (:344)
+ * as ONE submission with ONE final synchronisation, exactly like the stereo constructor above; `frame` views mvKeysUn + mDescriptors
+ * with its grid on the device afterwards.
+ * dist = mDistCoef {k1, k2, p1, p2, k3} (S/Tracking.cc:71-81); NULL or k1 == 0: mvKeysUn = mvKeys (S/Frame.cc:723-727) and the view's
+ * bounds must be the image rectangle.  Otherwise every keypoint goes through cv::undistortPoints(mat, mat, K, mDistCoef, Mat(), mK)
+ * (S/Frame.cc:740; K = mK = the view's fx, fy, cx, cy; OpenCV 3.2 cvUndistortPoints: 5 fixed-point iterations in double) on the
+ * device, and the view's bounds are the caller's ComputeImageBounds (S/Frame.cc:756-783: orbx_undistort_points of the four corners).
+ * Host outputs (cap entries each, any may be NULL): kps = mvKeys, kps_un = mvKeysUn, desc = mDescriptors. */
+typedef struct orbx_distortion { float k1, k2, p1, p2, k3; } orbx_distortion;
+int orbx_frame_mono(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, const uint8_t* img,
+                    int width, int height, int stride, orbx_keypoint* kps, orbx_keypoint* kps_un, uint8_t* desc, int cap, int* n);
+int orbx_frame_mono_dev(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, const uint8_t* d_img,
+                        int width, int height, int stride, orbx_keypoint* kps, orbx_keypoint* kps_un, uint8_t* desc, int cap, int* n);
+/* The two-halves form (see orbx_frame_stereo_submit): host image / image resident in HBM; _wait collects it (orbx_frame_stereo_dev_wait
+ * works too and reports n_right = 0).  orbx_set_frame_outputs' kps_left / desc_left arrays receive mvKeys / mDescriptors,
+ * orbx_set_frame_outputs_un's array receives mvKeysUn. */
+int orbx_frame_mono_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, const uint8_t* img,
+                           int width, int height, int stride, int flags);
+int orbx_frame_mono_dev_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist,
+                               const uint8_t* d_img, int width, int height, int stride);
+int orbx_frame_mono_wait(orbx_handle* h, int* n);
+int orbx_set_frame_outputs_un(orbx_handle* h, orbx_keypoint* kps_un /* cap_left of orbx_set_frame_outputs entries, or NULL */);
+/* cv::undistortPoints(pts, pts, K, mDistCoef, Mat(), K) for n points (xy_in / xy_out: n x {x, y} float32, host memory; in place
+ * allowed), on the device: what Frame::ComputeImageBounds (S/Frame.cc:756-783) runs on the four image corners. */
+int orbx_undistort_points(int device, const float* xy_in, int n, float fx, float fy, float cx, float cy, const orbx_distortion* dist,
+                          float* xy_out);
 /* Grid as CSR for tests: cell id = ix*48+iy, items in keypoint-index order (Appendix E-2). */
 int orbm_frame_get_grid(orbm_frame* f, int32_t* cell_start /*64*48+1*/, int32_t* cell_items /*n*/);
 
@@ -586,7 +615,7 @@ int pose_optimize(const pose_opt_problem* p, pose_opt_result* r);
  * implement Frame::UndistortKeyPoints for mDistCoef[0] == 0 (rectified stereo: mvKeysUn = mvKeys, S/Frame.cc:723-727).  The
  * reference's image bounds are exactly the image rectangle in that case (S/Frame.cc:775-783) and the undistorted corners otherwise
  * (:753-773): a view whose bounds are not (0, width, 0, height) is refused with ORBG_BAD_ARG.  Distorted cameras (the mono agents
- * with EuRoC intrinsics) go through orbx_extract + the caller's cv::undistortPoints + orbm_frame_upload. */
+ * with EuRoC intrinsics) use orbx_frame_mono*, which undistorts on the device. */
 enum { ORBG_ROLE_CALLER = 0, ORBG_ROLE_LBA_WORKER = 1, ORBG_ROLE_INGEST = 2 };
 int orbg_set_wait_policy(int role, int spin);   /* spin != 0: waits of that role spin on completion words; 0: they block.  Process-wide, any time */
 int orbg_get_wait_policy(int role);             /* 1 = spins, 0 = blocks, ORBG_BAD_ARG for an unknown role */

@@ -35,6 +35,11 @@ class OrbxConfig(C.Structure):
                 ("gauss_taps", C.c_int32 * 4), ("octree_oldest_first", C.c_int32)]
 
 
+class OrbxDistortion(C.Structure):
+    """orbx_distortion: mDistCoef {k1, k2, p1, p2, k3} (S/Tracking.cc:71-81)."""
+    _fields_ = [("k1", C.c_float), ("k2", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("k3", C.c_float)]
+
+
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("kps", C.c_void_p), ("desc", C.c_void_p), ("uright", C.c_void_p),
                 ("depth", C.c_void_p), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
@@ -136,6 +141,8 @@ EXPORTED_SYMBOLS = [
     "orbx_set_stream", "orbm_frame_set_stream", "orbm_map_set_stream", "lba_set_stream", "orbv_vocab_set_stream", "orbd_database_set_stream",
     "pose_opt_set_stream", "orbx_get_ctor_timeline", "orbm_map_set_observations", "orbm_search_by_projection_reloc", "orbm_lastview_create", "orbm_lastview_destroy", "orbm_lastview_upload",
     "orbm_search_by_projection_frame_resident", "orbg_quiesce", "orbg_set_wait_policy", "orbg_get_wait_policy",
+    "orbx_frame_mono", "orbx_frame_mono_dev", "orbx_frame_mono_submit", "orbx_frame_mono_dev_submit", "orbx_frame_mono_wait",
+    "orbx_set_frame_outputs_un", "orbx_undistort_points",
     "orbg_version", "orbg_strerror", "orbg_device_count", "orbx_get_timings", "orbx_event_overhead", "orbx_set_profile_interval", "orbx_set_profile_kernel", "orbx_get_fast_kernel_stats", "orbx_set_profiling",
 ]
 

@@ -26,7 +26,7 @@ class Cfg(C.Structure):
                 ("lba_async", C.c_int), ("pose_opt", C.c_int), ("th_frame", C.c_float), ("mono", C.c_int), ("nn_frame", C.c_float),
                 ("nn_map", C.c_float), ("amp", C.c_void_p), ("aob", C.c_void_p), ("cap", C.c_int), ("in_flight", C.c_int32 * 4),
                 ("ahead", C.c_int32), ("ring", C.c_int32), ("lba_in_flight", C.c_int32), ("last_view_dev", C.c_void_p), ("last_view_frame", C.c_int32),
-                ("amp_after_frame", C.c_void_p)]
+                ("amp_after_frame", C.c_void_p), ("mono_agent", C.c_int32), ("dist", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -61,7 +61,9 @@ class AgentLoop:
     """Holds the agent_cfg (and everything it points to) of one client."""
 
     def __init__(self, exs, frs, local_map, opt, frame_view, width, height, stride, bf, b, frames, seq, kf_map_views, lba_prob, lba_out,
-                 po_probs, frames_per_kf, cap, th_frame, mono, nn_map=0.8, last_view=None):
+                 po_probs, frames_per_kf, cap, th_frame, mono, nn_map=0.8, last_view=None, mono_agent=False, dist=None):
+        """mono_agent: a monocular client (frames carry one host / device image; Frame::Frame(mono) with lapping area {0, 1000});
+        dist: its capi.OrbxDistortion (mDistCoef) or None."""
         self.lib = load()
         self.keep = [exs, frs, local_map, opt, frame_view, frames, kf_map_views, lba_prob, lba_out, po_probs]
         c = Cfg()
@@ -76,7 +78,8 @@ class AgentLoop:
         self.frames_in = (FrameIn * len(frames))()
         for k, f in enumerate(frames):
             fi = self.frames_in[k]
-            fi.host_left, fi.host_right = f["host"][0].ctypes.data, f["host"][1].ctypes.data
+            fi.host_left = f["host"][0].ctypes.data
+            fi.host_right = None if f["host"][1] is None else f["host"][1].ctypes.data
             fi.dev_left, fi.dev_right = f["dev"]
             fi.Tcw_guess = f["guess"].ctypes.data
             fi.last_view = C.addressof(f["last_view"])
@@ -104,6 +107,9 @@ class AgentLoop:
         c.last_view_frame = -1
         c.amp_after_frame = None
         self.amp_after_frame = None
+        c.mono_agent = int(bool(mono_agent))
+        self.keep.append(dist)
+        c.dist = None if dist is None else C.addressof(dist)
         self.c = c
 
     def capture_first_search(self, on=True):

@@ -143,12 +143,63 @@ class ORBextractor:
             self._outputs = None
             return None
         out = dict(kps=np.zeros(cap, capi.KEYPOINT_DTYPE), desc=np.zeros((cap, 32), np.uint8), uright=np.zeros(cap, np.float32),
-                   depth=np.zeros(cap, np.float32))
+                   depth=np.zeros(cap, np.float32), kps_un=np.zeros(cap, capi.KEYPOINT_DTYPE))
         capi.check(self.lib.orbx_set_frame_outputs(self.h, C.c_void_p(capi.ptr(out["kps"])), C.c_void_p(capi.ptr(out["desc"])),
                                                    C.c_void_p(capi.ptr(out["uright"])), C.c_void_p(capi.ptr(out["depth"])), int(cap)),
                    "orbx_set_frame_outputs")
+        # (mvKeysUn: delivered by the monocular constructor only)
+        capi.check(self.lib.orbx_set_frame_outputs_un(self.h, C.c_void_p(capi.ptr(out["kps_un"]))), "orbx_set_frame_outputs_un")
         self._outputs = out
         return out
+
+    # ---- the monocular Frame constructor (S/Frame.cc:260-358)
+    @staticmethod
+    def _dist(dist):
+        """(k1, k2, p1, p2[, k3]) / capi.OrbxDistortion / None -> (keep-alive object, ctypes argument)"""
+        if dist is None:
+            return None, None
+        d = dist if isinstance(dist, capi.OrbxDistortion) else capi.OrbxDistortion(*([float(v) for v in dist] + [0.0] * (5 - len(dist))))
+        return d, C.byref(d)
+
+    def frame_mono(self, frame, fv, image, dist=None, download=True, device_ptr=None, size=None):
+        """Frame::Frame(mono): ExtractORB(0, im, 0, 1000) + UndistortKeyPoints + grid in ONE submission (orbx_frame_mono);
+        -> (n, mvKeys, mvKeysUn, mDescriptors) or n.  device_ptr/size=(w, h, stride): the image is resident in HBM."""
+        n = C.c_int(0)
+        kps = kun = desc = None
+        if download:
+            kps = np.zeros(self.cap, capi.KEYPOINT_DTYPE); kun = np.zeros(self.cap, capi.KEYPOINT_DTYPE); desc = np.zeros((self.cap, 32), np.uint8)
+        dk, darg = self._dist(dist)
+        if device_ptr is not None:
+            w, h, stride = size
+            rc = self.lib.orbx_frame_mono_dev(self.h, frame.h if frame is not None else None, C.byref(fv), darg, C.c_void_p(device_ptr), w, h, stride,
+                                              _vp(kps), _vp(kun), _vp(desc), self.cap, C.byref(n))
+        else:
+            image = np.ascontiguousarray(image, np.uint8)
+            rc = self.lib.orbx_frame_mono(self.h, frame.h if frame is not None else None, C.byref(fv), darg, _vp(image), image.shape[1],
+                                          image.shape[0], image.strides[0], _vp(kps), _vp(kun), _vp(desc), self.cap, C.byref(n))
+        capi.check(rc, "orbx_frame_mono")
+        if frame is not None:
+            frame.n = n.value
+        if download:
+            return n.value, kps[: n.value].copy(), kun[: n.value].copy(), desc[: n.value].copy()
+        return n.value
+
+    def frame_mono_submit(self, frame, fv, image, dist=None, async_ingest=False, device_ptr=None, size=None):
+        """First half of the monocular constructor (orbx_frame_mono_submit / _dev_submit); collect with frame_mono_wait()."""
+        dk, darg = self._dist(dist)
+        if device_ptr is not None:
+            w, h, stride = size
+            self._pending = (frame, fv, dk)
+            rc = self.lib.orbx_frame_mono_dev_submit(self.h, frame.h if frame is not None else None, C.byref(fv), darg, C.c_void_p(device_ptr), w, h, stride)
+        else:
+            assert image.dtype == np.uint8 and image.strides[1] == 1
+            self._pending = (frame, fv, dk, image)
+            rc = self.lib.orbx_frame_mono_submit(self.h, frame.h if frame is not None else None, C.byref(fv), darg, C.c_void_p(image.ctypes.data),
+                                                 image.shape[1], image.shape[0], image.strides[0], 1 if async_ingest else 0)
+        capi.check(rc, "orbx_frame_mono_submit")
+
+    def frame_mono_wait(self):
+        return self.frame_stereo_dev_wait()[0]
 
     def frame_stereo_dev_wait(self):
         nl, nr = C.c_int(0), C.c_int(0)
@@ -247,6 +298,25 @@ class ORBextractor:
         capi.check(self.lib.orbx_get_timings(self.h, _vp(t)))
         return dict(pyramid_ms=float(t[0]), fast_ms=float(t[1]), octree_host_ms=float(t[2]), desc_ms=float(t[3]),
                     stereo_ms=float(t[4]), fast_kernel_ms=float(t[5]))
+
+
+def undistort_points(xy, cam4, dist, device=0):
+    """cv::undistortPoints(pts, pts, K, mDistCoef, Mat(), K) on the device (orbx_undistort_points): xy n x 2 float32."""
+    lib = capi.load()
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    dk, darg = ORBextractor._dist(dist)
+    capi.check(lib.orbx_undistort_points(int(device), _vp(xy), len(xy), C.c_float(cam4[0]), C.c_float(cam4[1]), C.c_float(cam4[2]),
+                                         C.c_float(cam4[3]), darg, _vp(out)), "orbx_undistort_points")
+    return out
+
+
+def image_bounds(width, height, cam4, dist, device=0):
+    """Frame::ComputeImageBounds (S/Frame.cc:756-783) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    if dist is None or float(np.float32(dist[0] if not isinstance(dist, capi.OrbxDistortion) else dist.k1)) == 0.0:
+        return (0.0, float(width), 0.0, float(height))
+    m = undistort_points(np.array([[0, 0], [width, 0], [0, height], [width, height]], np.float32), cam4, dist, device)
+    return (float(min(m[0, 0], m[2, 0])), float(max(m[1, 0], m[3, 0])), float(min(m[0, 1], m[1, 1])), float(max(m[2, 1], m[3, 1])))
 
 
 class Frame:

@@ -8,7 +8,8 @@
 // handles and the per-frame views once and times agent_run(); a deployment has Tracking.cc in this place.
 //
 //   step(i):  frame k = seq[i % n_seq]
-//     pipelined:   [submit Frame(t+1 .. t+ahead) on the other extractor handles]  wait Frame(t)   (orbx_frame_stereo_submit / _dev_submit / _wait)
+//     pipelined:   [submit Frame(t+1 .. t+ahead) on the other extractor handles]  wait Frame(t)   (orbx_frame_stereo_submit / _dev_submit / _wait;
+//                  a monocular client: orbx_frame_mono_submit / _dev_submit)
 //     synchronous: Frame(t) = orbx_frame_stereo / orbx_frame_stereo_dev
 //     SearchByProjection(Current, Last)  [PoseOptimization]  SearchLocalPoints  [PoseOptimization]
 //     keyframe step (i % frames_per_kf == 0): local map refresh (orbm_map_upload), wait for the previous local BA, submit the next
@@ -53,6 +54,8 @@ typedef struct agent_cfg {
   int32_t last_view_frame;                                   // frame whose view is resident in last_view_dev (-1: none)
   int32_t* amp_after_frame;                                  // NULL, or cap entries: F.mvpMapPoints as SearchByProjection(Current, Last) left it
                                                              // (bench.py's in-job parity gate compares both searches with the oracle)
+  int32_t mono_agent;                                        // 1: a monocular client -- Frame::Frame(mono) (S/Frame.cc:260-358) from host_left / dev_left
+  const orbx_distortion* dist;                               // mono: mDistCoef (NULL: none), undistorted on the device by the constructor
 } agent_cfg;
 
 typedef struct agent_stats {
@@ -72,6 +75,12 @@ static inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); r
 
 static int submit_ctor(agent_cfg* c, int slot, int k) {
   const agent_frame_in& f = c->frames[k];
+  if (c->mono_agent) {
+    if (c->host_images)
+      return orbx_frame_mono_submit(c->ex[slot], c->fr[slot], c->frame_view, c->dist, f.host_left, c->width, c->height, c->stride,
+                                    c->ingest_async ? ORBX_SUBMIT_ASYNC : 0);
+    return orbx_frame_mono_dev_submit(c->ex[slot], c->fr[slot], c->frame_view, c->dist, f.dev_left, c->width, c->height, c->stride);
+  }
   if (c->host_images)
     return orbx_frame_stereo_submit(c->ex[slot], c->fr[slot], c->frame_view, f.host_left, f.host_right, c->width, c->height, c->stride, c->bf, c->b,
                                     c->ingest_async ? ORBX_SUBMIT_ASYNC : 0);
@@ -123,6 +132,11 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
       if (rc) break;
       c->in_flight[cur] = 0;
       if (!c->submit_first && (rc = submit_ahead(1, ahead))) break;
+    } else if (c->mono_agent) {
+      rc = c->host_images ? orbx_frame_mono(c->ex[0], c->fr[0], c->frame_view, c->dist, fin.host_left, c->width, c->height, c->stride, nullptr, nullptr,
+                                            nullptr, 0, &nl)
+                          : orbx_frame_mono_dev(c->ex[0], c->fr[0], c->frame_view, c->dist, fin.dev_left, c->width, c->height, c->stride, nullptr,
+                                                nullptr, nullptr, 0, &nl);
     } else if (c->host_images) {
       rc = orbx_frame_stereo(c->ex[0], c->fr[0], c->frame_view, fin.host_left, fin.host_right, c->width, c->height, c->stride, c->bf, c->b,
                              nullptr, nullptr, nullptr, nullptr, 0, &nl, &nr);

@@ -1829,6 +1829,8 @@ struct orbx_handle {
   PinnedBuf<orbx_keypoint> h_kps;
   PinnedBuf<uint8_t> h_desc;
   DevBuf<float> d_uright, d_depth;
+  DevBuf<orbx_keypoint> d_kps_un;   // mvKeysUn of the monocular constructor for a distorted camera (the frame views these)
+  PinnedBuf<orbx_keypoint> h_kps_un;
   DevBuf<int> d_sad;
   PinnedBuf<float> h_stereo;
   int n_kp[2] = {0, 0};
@@ -1864,6 +1866,7 @@ struct orbx_handle {
   unsigned up_seq = 0;
   // orbx_set_frame_outputs: host arrays the two-halves constructor delivers the left image's features into at _wait
   orbx_keypoint* out_kps = nullptr; uint8_t* out_desc = nullptr; float* out_uright = nullptr; float* out_depth = nullptr; int out_cap = 0;
+  orbx_keypoint* out_kps_un = nullptr;         // orbx_set_frame_outputs_un: mvKeysUn of the monocular constructor
   std::atomic<int> ingest_state{0};            // 0 idle, 1 handed to the ingest thread, 2 submitted by it (ingest_rc valid)
   int ingest_rc = 0;
   // host-side timeline of the last submissions (orbx_get_ctor_timeline): per submission, microseconds
@@ -2203,6 +2206,10 @@ struct PostOps {
   float* depth = nullptr;
   orbm_frame* frame = nullptr;
   const orbm_frame_view* view = nullptr;
+  // monocular constructor (S/Frame.cc:260-358): no stereo data; undist: Frame::UndistortKeyPoints on the device (:721-754)
+  bool mono = false, undist = false;
+  orbx_distortion dist{};
+  orbx_keypoint* kps_un_out = nullptr;       // host copy of mvKeysUn (cap[0] entries), may be NULL
 };
 // Everything the second half of a GPU-path extraction needs (it runs either right away or in orbx_frame_stereo_dev_wait)
 struct ExtractPending {
@@ -2227,7 +2234,21 @@ struct ExtractPending {
 static void delete_pending(ExtractPending* p) { delete p; }
 int orbm_internal_attach_prepare(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, hipStream_t stream, orbg::GridLaunchArgs* out);   // matcher.hip
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
-                         volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin);
+                         volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin, const orbg::UndistortArgs* un = nullptr,
+                         bool mono = false);
+// arguments of the undistortion in front of the grid build (the handle's mvKeysUn buffers are sized here)
+static int make_undistort_args(orbx_handle* h, const PostOps* post, orbg::UndistortArgs* ua) {
+  memset(ua, 0, sizeof(*ua));
+  if (!post || !post->undist) return ORBG_OK;
+  const size_t cap = h->d_kps.cap;
+  int rc;
+  if ((rc = h->d_kps_un.reserve(cap)) || (rc = h->h_kps_un.reserve(cap))) return rc;
+  ua->on = 1;
+  ua->fx = post->view->fx; ua->fy = post->view->fy; ua->cx = post->view->cx; ua->cy = post->view->cy;
+  ua->k1 = post->dist.k1; ua->k2 = post->dist.k2; ua->p1 = post->dist.p1; ua->p2 = post->dist.p2; ua->k3 = post->dist.k3;
+  ua->src = h->d_kps.p; ua->dst = h->d_kps_un.p; ua->dst_host = h->h_kps_un.d;
+  return ORBG_OK;
+}
 void orbm_internal_set_n(orbm_frame* f, int n);
 int orbx_internal_kp_capacity(orbx_handle* h);
 static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror,
@@ -2466,7 +2487,9 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
           if (with_fin)
             fin = StereoFinalizeArgs{h->d_uright.p, h->d_depth.p, h->d_sad.p, h->sel_bound, h->d_nkp.p, stereo_out ? h->h_stereo.d : nullptr,
                                      reinterpret_cast<unsigned*>(h->d_overflow.p + 2)};
-          if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq, with_fin ? &fin : nullptr))) return rc;
+          orbg::UndistortArgs ua;
+          if ((rc = make_undistort_args(h, post, &ua))) return rc;
+          if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq, with_fin ? &fin : nullptr, &ua, post->mono))) return rc;
         }
         posted = true;
       }
@@ -2582,7 +2605,11 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
         stereo_out_host = true;
       }
     }
-    if (post->frame && (rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st, nullptr, nullptr, 0u, nullptr))) return rc;
+    if (post->frame) {
+      orbg::UndistortArgs ua;
+      if ((rc = make_undistort_args(h, post, &ua))) return rc;
+      if ((rc = orbm_internal_attach(post->frame, h, post->view, h->n_kp[0], st, nullptr, nullptr, 0u, nullptr, &ua, post->mono))) return rc;
+    }
   }
   const bool want_out = kps_out[0] || desc_out[0] || kps_out[1] || desc_out[1];
   if (n_sel_total > 0) {
@@ -2603,6 +2630,10 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   if (stereo_out_host) {
     if (post->uright) memcpy(post->uright, h->h_stereo.h, (size_t)h->n_kp[0] * 4);
     if (post->depth) memcpy(post->depth, h->h_stereo.h + h->n_kp[0], (size_t)h->n_kp[0] * 4);
+  }
+  if (post && post->kps_un_out) {
+    if (h->n_kp[0] > cap[0]) return ORBG_CAP_EXCEEDED;
+    memcpy(post->kps_un_out, (post->undist && post->frame) ? h->h_kps_un.h : h->h_kps.h, (size_t)h->n_kp[0] * sizeof(orbx_keypoint));
   }
   float ms;
   h->timings[2] = std::chrono::duration<float, std::milli>(t_host1 - t_host0).count();  // host quad-tree
@@ -2846,18 +2877,30 @@ extern "C" int orbx_frame_stereo_dev(orbx_handle* h, orbm_frame* frame, const or
 
 // Frame constructor split in two so that the caller can overlap it with work on other streams (tracking of the previous
 // frame): submit enqueues the whole chain and returns, wait completes it.
+// mono: the monocular constructor (img_right unused; dist = mDistCoef or NULL)
 static int frame_submit_core(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
-                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b);
+                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b, bool mono,
+                             const orbx_distortion* dist);
 static int frame_submit_impl(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
-                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b) {
+                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b, bool mono = false,
+                             const orbx_distortion* dist = nullptr) {
   const double t0 = host_now_us();
   h->tl_queue = t0 - h->tl_t_handover;
-  const int rc = frame_submit_core(h, frame, view, img_left, img_right, on_device, width, height, stride, bf, b);
+  const int rc = frame_submit_core(h, frame, view, img_left, img_right, on_device, width, height, stride, bf, b, mono, dist);
   h->tl_enqueue = host_now_us() - t0 - h->tl_pack_acc;
   return rc;
 }
+// Frame::Frame(mono): ExtractORB(0, imGray, 0, 1000) (S/Frame.cc:289) -- camera 0 only, lapping area {0, 1000}
+static const int kMonoLap[2][2] = {{0, 1000}, {0, 0}};
+static inline bool dist_active(const orbx_distortion* d) { return d && d->k1 != 0.0f; }      // S/Frame.cc:723
+static void fill_mono_post(PostOps* post, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, orbx_keypoint* kps_un_out) {
+  post->stereo = false; post->mono = true; post->frame = frame; post->view = view; post->kps_un_out = kps_un_out;
+  post->undist = dist_active(dist) && frame != nullptr;
+  if (post->undist) post->dist = *dist;
+}
 static int frame_submit_core(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const uint8_t* img_left,
-                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b) {
+                             const uint8_t* img_right, bool on_device, int width, int height, int stride, float bf, float b, bool mono,
+                             const orbx_distortion* dist) {
   int rc = select_device(h->device);
   if (rc) return rc;
   if (!h->pending) h->pending = new ExtractPending();
@@ -2868,21 +2911,26 @@ static int frame_submit_core(orbx_handle* h, orbm_frame* frame, const orbm_frame
   if (!on_device) {
     if ((rc = setup_geometry(h, width, height))) return rc;
     const uint8_t* const both[2] = {img_left, img_right};
-    if ((rc = stage_images(h, both, 2, width, height, stride))) return rc;
+    if ((rc = stage_images(h, both, mono ? 1 : 2, width, height, stride))) return rc;
     d_img_left = h->d_img.p;
-    d_img_right = h->d_img.p + (size_t)width * height;
+    d_img_right = mono ? nullptr : h->d_img.p + (size_t)width * height;
     stride = width;
   }
   PostOps post;
-  post.stereo = true; post.bf = bf; post.b = b; post.frame = frame; post.view = view;
-  post.uright = h->out_uright; post.depth = h->out_depth;             // (orbx_set_frame_outputs: delivered by _wait)
-  const int lap[2][2] = {{0, 0}, {0, 0}};
+  if (mono) fill_mono_post(&post, frame, view, dist, h->out_kps_un);
+  else {
+    post.stereo = true; post.bf = bf; post.b = b; post.frame = frame; post.view = view;
+    post.uright = h->out_uright; post.depth = h->out_depth;             // (orbx_set_frame_outputs: delivered by _wait)
+  }
+  const int lap_stereo[2][2] = {{0, 0}, {0, 0}};
   orbx_keypoint* ko[2] = {h->out_kps, nullptr};
   uint8_t* dout[2] = {h->out_desc, nullptr};
   const int caps[2] = {h->out_cap, 0};
   int* no[2] = {&P.n_res[0], &P.n_res[1]};
   int* nm[2] = {nullptr, nullptr};
-  rc = extract_core(h, 3, d_img_left, d_img_right, width, height, stride, lap, ko, dout, caps, no, nm, &post, false, true);
+  P.n_res[1] = 0;
+  rc = extract_core(h, mono ? 1u : 3u, d_img_left, d_img_right, width, height, stride, mono ? kMonoLap : lap_stereo, ko, dout, caps, no, nm, &post,
+                    false, true);
   if (rc) { P.active = false; return rc; }
   if (!P.active) P.finished = true;                      // host quad-tree path: it ran to completion inside the call
   return ORBG_OK;
@@ -2893,6 +2941,7 @@ extern "C" int orbx_set_frame_outputs(orbx_handle* h, orbx_keypoint* kps_left, u
   if (!h || cap_left < 0 || ((kps_left || desc_left || uright || depth) && cap_left == 0)) return ORBG_BAD_ARG;
   if (handle_busy(h)) return ORBG_BAD_ARG;
   h->out_kps = kps_left; h->out_desc = desc_left; h->out_uright = uright; h->out_depth = depth; h->out_cap = cap_left;
+  if (cap_left == 0) h->out_kps_un = nullptr;               // (the mvKeysUn array shares the capacity: off together)
   return ORBG_OK;
 }
 
@@ -2916,6 +2965,7 @@ extern "C" int orbx_frame_stereo_dev_submit(orbx_handle* h, orbm_frame* frame, c
 namespace {
 struct IngestJob {
   orbx_handle* h; orbm_frame* frame; orbm_frame_view view; bool has_view; const uint8_t* L; const uint8_t* R; int w, hgt, stride; float bf, b;
+  bool mono = false, has_dist = false; orbx_distortion dist{};
 };
 struct IngestWorker {
   std::mutex mu;
@@ -2951,7 +3001,7 @@ struct IngestWorker {
         queued.fetch_sub(1, std::memory_order_acq_rel);
       }
       job.h->ingest_rc = frame_submit_impl(job.h, job.frame, job.has_view ? &job.view : nullptr, job.L, job.R, false, job.w, job.hgt,
-                                           job.stride, job.bf, job.b);
+                                           job.stride, job.bf, job.b, job.mono, job.has_dist ? &job.dist : nullptr);
       job.h->ingest_state.store(2, std::memory_order_release);
     }
   }
@@ -2986,7 +3036,9 @@ extern "C" int orbx_frame_stereo_submit(orbx_handle* h, orbm_frame* frame, const
   if (!(flags & ORBX_SUBMIT_ASYNC)) return frame_submit_impl(h, frame, view, img_left, img_right, false, width, height, stride, bf, b);
   int rc = select_device(h->device);                    // a missing device is reported by the call, not by the wait
   if (rc) return rc;
-  IngestJob j{h, frame, orbm_frame_view{}, view != nullptr, img_left, img_right, width, height, stride, bf, b};
+  IngestJob j;
+  j.h = h; j.frame = frame; j.has_view = view != nullptr; j.L = img_left; j.R = img_right; j.w = width; j.hgt = height; j.stride = stride;
+  j.bf = bf; j.b = b;
   if (view) j.view = *view;
   h->ingest_state.store(1, std::memory_order_release);
   ingest_worker().push(j);
@@ -3058,6 +3110,127 @@ extern "C" int orbx_frame_stereo(orbx_handle* h, orbm_frame* frame, const orbm_f
                                    depth, cap_left, n_left, n_right);
   if (h && rc == ORBG_OK) h->tl_commit(0.0);            // synchronous: queue / enqueue / wait are not separated, latency = the call
   return rc;
+}
+
+// ---- the monocular Frame constructor (include/orbgpu.h): camera 0, lapping area {0, 1000}, undistortion + grid as the chain's tail
+static int mono_args_ok(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, const uint8_t* img,
+                        int width, int height, int stride) {
+  if (!h) return ORBG_BAD_ARG;
+  if (frame && !view) return ORBG_BAD_ARG;
+  if (dist_active(dist) && !frame) return ORBG_BAD_ARG;          // mvKeysUn of a distorted camera exists as the frame's features
+  if (!img || width <= 0 || height <= 0) return ORBG_EMPTY;      // (the reference returns before it touches anything: S/Frame.cc:297-298)
+  if (stride < width || width > h->cfg.max_width || height > h->cfg.max_height) return ORBG_BAD_ARG;
+  // without distortion the reference's bounds are the image rectangle (S/Frame.cc:776-782); with it they are the undistorted corners
+  if (frame && !dist_active(dist) && !view_is_undistorted(view, width, height)) return ORBG_BAD_ARG;
+  if (frame && dist_active(dist) && !(view->fx > 0.0f && view->fy > 0.0f && view->max_x > view->min_x && view->max_y > view->min_y)) return ORBG_BAD_ARG;
+  return ORBG_OK;
+}
+
+static int frame_mono_impl(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, const uint8_t* img,
+                           bool on_device, int width, int height, int stride, orbx_keypoint* kps, orbx_keypoint* kps_un, uint8_t* desc, int cap,
+                           int* n) {
+  if (!n) return ORBG_BAD_ARG;
+  int rc = mono_args_ok(h, frame, view, dist, img, width, height, stride);
+  if (rc) return rc;
+  if (handle_busy(h)) return ORBG_BAD_ARG;
+  if ((rc = select_device(h->device))) return rc;
+  const uint8_t* d_img = img;
+  if (!on_device) {
+    if ((rc = setup_geometry(h, width, height))) return rc;
+    if ((rc = stage_images(h, &img, 1, width, height, stride))) return rc;
+    d_img = h->d_img.p;
+    stride = width;
+  }
+  PostOps post;
+  fill_mono_post(&post, frame, view, dist, kps_un);
+  orbx_keypoint* ko[2] = {kps, nullptr};
+  uint8_t* dout[2] = {desc, nullptr};
+  const int caps[2] = {cap, 0};
+  int* no[2] = {n, nullptr};
+  int* nm[2] = {nullptr, nullptr};
+  return extract_core(h, 1, d_img, nullptr, width, height, stride, kMonoLap, ko, dout, caps, no, nm, &post);
+}
+
+extern "C" int orbx_frame_mono(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, const uint8_t* img,
+                               int width, int height, int stride, orbx_keypoint* kps, orbx_keypoint* kps_un, uint8_t* desc, int cap, int* n) {
+  if (h) h->tl_begin();
+  const int rc = frame_mono_impl(h, frame, view, dist, img, false, width, height, stride, kps, kps_un, desc, cap, n);
+  if (h && rc == ORBG_OK) h->tl_commit(0.0);
+  return rc;
+}
+extern "C" int orbx_frame_mono_dev(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, const uint8_t* d_img,
+                                   int width, int height, int stride, orbx_keypoint* kps, orbx_keypoint* kps_un, uint8_t* desc, int cap, int* n) {
+  return frame_mono_impl(h, frame, view, dist, d_img, true, width, height, stride, kps, kps_un, desc, cap, n);
+}
+
+extern "C" int orbx_frame_mono_dev_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist,
+                                          const uint8_t* d_img, int width, int height, int stride) {
+  int rc = mono_args_ok(h, frame, view, dist, d_img, width, height, stride);
+  if (rc) return rc;
+  if (h->ingest_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;
+  h->tl_begin();
+  return frame_submit_impl(h, frame, view, d_img, nullptr, true, width, height, stride, 0.f, 0.f, true, dist);
+}
+
+extern "C" int orbx_frame_mono_submit(orbx_handle* h, orbm_frame* frame, const orbm_frame_view* view, const orbx_distortion* dist, const uint8_t* img,
+                                      int width, int height, int stride, int flags) {
+  int rc = mono_args_ok(h, frame, view, dist, img, width, height, stride);
+  if (rc) return rc;
+  if (h->ingest_state.load(std::memory_order_acquire) != 0) return ORBG_BAD_ARG;       // one submission per handle at a time
+  if (h->pending && (h->pending->active || h->pending->finished)) return ORBG_BAD_ARG;
+  h->tl_begin();
+  if (!(flags & ORBX_SUBMIT_ASYNC)) return frame_submit_impl(h, frame, view, img, nullptr, false, width, height, stride, 0.f, 0.f, true, dist);
+  if ((rc = select_device(h->device))) return rc;
+  IngestJob j;
+  j.h = h; j.frame = frame; j.has_view = view != nullptr; j.L = img; j.R = nullptr; j.w = width; j.hgt = height; j.stride = stride; j.bf = 0; j.b = 0;
+  if (view) j.view = *view;
+  j.mono = true; j.has_dist = dist != nullptr;
+  if (dist) j.dist = *dist;
+  h->ingest_state.store(1, std::memory_order_release);
+  ingest_worker().push(j);
+  return ORBG_OK;
+}
+
+extern "C" int orbx_frame_mono_wait(orbx_handle* h, int* n) { return orbx_frame_stereo_dev_wait(h, n, nullptr); }
+
+extern "C" int orbx_set_frame_outputs_un(orbx_handle* h, orbx_keypoint* kps_un) {
+  if (!h || (kps_un && h->out_cap == 0)) return ORBG_BAD_ARG;
+  if (handle_busy(h)) return ORBG_BAD_ARG;
+  h->out_kps_un = kps_un;
+  return ORBG_OK;
+}
+
+// cv::undistortPoints on n host points, on the device (Frame::ComputeImageBounds runs it on the four corners, S/Frame.cc:756-783)
+__global__ __launch_bounds__(256) void undistort_points_kernel(orbg::UndistortArgs ua, const float2* __restrict__ in, float2* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float2 p = in[i], q;
+  orbg::undistort_point(ua, p.x, p.y, &q.x, &q.y);
+  out[i] = q;
+}
+extern "C" int orbx_undistort_points(int device, const float* xy_in, int n, float fx, float fy, float cx, float cy, const orbx_distortion* dist,
+                                     float* xy_out) {
+  if (n < 0 || (n > 0 && (!xy_in || !xy_out))) return ORBG_BAD_ARG;
+  int rc = select_device(device);
+  if (rc) return rc;
+  if (n == 0) return ORBG_OK;
+  if (!dist_active(dist)) { if (xy_out != xy_in) memmove(xy_out, xy_in, (size_t)n * 8); return ORBG_OK; }     // S/Frame.cc:723-727
+  orbg::MiscStream ms;
+  if ((rc = ms.open())) return rc;
+  DevBuf<float2> d_in, d_out;
+  if ((rc = d_in.reserve(n)) || (rc = d_out.reserve(n))) { d_in.release(); d_out.release(); return rc; }
+  orbg::UndistortArgs ua;
+  memset(&ua, 0, sizeof(ua));
+  ua.on = 1; ua.fx = fx; ua.fy = fy; ua.cx = cx; ua.cy = cy; ua.k1 = dist->k1; ua.k2 = dist->k2; ua.p1 = dist->p1; ua.p2 = dist->p2; ua.k3 = dist->k3;
+  hipError_t e = hipMemcpyAsync(d_in.p, xy_in, (size_t)n * 8, hipMemcpyHostToDevice, ms.s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(undistort_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ms.s, ua, d_in.p, d_out.p, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(xy_out, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, ms.s);
+  if (e == hipSuccess) e = hipStreamSynchronize(ms.s);
+  d_in.release(); d_out.release();
+  return e == hipSuccess ? ORBG_OK : ORBG_HIP_ERROR;
 }
 
 extern "C" int orbx_get_level(orbx_handle* h, int cam, int level, uint8_t* host_out, int* width, int* height) {
@@ -3154,6 +3327,10 @@ static int extract_finish_gpu(orbx_handle* h, ExtractPending& c) {
     base += nk;
   }
   if (post && post->frame) orbm_internal_set_n(post->frame, h->n_kp[0]);
+  if (post && post->kps_un_out) {
+    if (h->n_kp[0] > c.cap[0]) return ORBG_CAP_EXCEEDED;
+    memcpy(post->kps_un_out, (post->undist && post->frame) ? h->h_kps_un.h : h->h_kps.h, (size_t)h->n_kp[0] * sizeof(orbx_keypoint));
+  }
   if (c.stereo_out && h->n_kp[0] > c.cap[0]) return ORBG_CAP_EXCEEDED;      // uright / depth hold cap_left entries like the other outputs
   if (c.stereo_out) {
     if (post->uright) memcpy(post->uright, h->h_stereo.h, (size_t)h->n_kp[0] * 4);

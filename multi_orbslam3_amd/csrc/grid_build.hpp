@@ -126,6 +126,39 @@ __device__ __forceinline__ void grid_build_body(const orbx_keypoint* __restrict_
   }
 }
 
+// Frame::UndistortKeyPoints (S/Frame.cc:721-754) for the fused monocular constructor: cv::undistortPoints(mat, mat, K, mDistCoef, Mat(), mK)
+// per keypoint, in double as OpenCV 3.2's cvUndistortPoints computes it (five fixed-point iterations; the operation order is the
+// oracle's, oracle/matching.cc oracle_undistort_points, and the translation unit is built with -ffp-contract=off: bit-equal results).
+struct UndistortArgs {
+  int on;                                    // 0: mvKeysUn = mvKeys (mDistCoef[0] == 0), nothing below is read
+  double fx, fy, cx, cy, k1, k2, p1, p2, k3;
+  const orbx_keypoint* src;                  // mvKeys on the device (the extractor's buffer)
+  orbx_keypoint* dst;                        // mvKeysUn on the device: what the frame's grid and searches read
+  orbx_keypoint* dst_host;                   // the same records in mapped pinned memory (delivered to the caller as mvKeysUn), may be NULL
+};
+
+__device__ __forceinline__ void undistort_point(const UndistortArgs& a, float u, float v, float* xo, float* yo) {
+  const double ifx = 1. / a.fx, ify = 1. / a.fy;
+  double x = (double)u, y = (double)v;
+  x = (x - a.cx) * ifx;
+  y = (y - a.cy) * ify;
+  const double x0 = x, y0 = y;
+#pragma unroll 1
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1. / (1 + ((a.k3 * r2 + a.k2) * r2 + a.k1) * r2);
+    const double deltaX = 2 * a.p1 * x * y + a.p2 * (r2 + 2 * x * x);
+    const double deltaY = a.p1 * (r2 + 2 * y * y) + 2 * a.p2 * x * y;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  const double xx = a.fx * x + 0. * y + a.cx;
+  const double yy = 0. * x + a.fy * y + a.cy;
+  const double ww = 1. / (0. * x + 0. * y + 1.);
+  *xo = (float)(xx * ww);
+  *yo = (float)(yy * ww);
+}
+
 // What extractor.hip needs to launch the grid build of a frame next to its own kernels (filled by orbm_internal_attach_prepare)
 struct GridLaunchArgs {
   const orbx_keypoint* kps; FrameParams fp; int* cell_of; int* cell_start; int* cell_items;

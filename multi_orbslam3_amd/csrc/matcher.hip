@@ -84,6 +84,31 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* _
   }
 }
 
+// Last launch of the MONOCULAR Frame constructor for a distorted camera (orbx_frame_mono*): Frame::UndistortKeyPoints (S/Frame.cc:721-754)
+// and AssignFeaturesToGrid (:344) in one workgroup -- a thread undistorts exactly the keypoints whose cells it then computes.  The
+// undistorted records also go to mapped pinned memory (mvKeysUn for the caller), so every wavefront releases to system scope before
+// the completion word is posted.
+__global__ __launch_bounds__(1024) void undistort_grid_kernel(orbg::UndistortArgs ua, FrameParams fp, int* __restrict__ cell_of,
+                                                             int* __restrict__ cell_start, int* __restrict__ cell_items,
+                                                             const int* __restrict__ d_n, volatile unsigned* done_flag, unsigned done_seq) {
+  const int n = d_n ? *d_n : fp.n;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    orbx_keypoint k = ua.src[i];
+    float xu, yu;
+    orbg::undistort_point(ua, k.x, k.y, &xu, &yu);
+    k.x = xu; k.y = yu;
+    ua.dst[i] = k;
+    if (ua.dst_host) ua.dst_host[i] = k;
+  }
+  // (grid_build_body's thread t reads the records t, t + 1024, ... -- the ones it has just written)
+  grid_build_body<1024>(ua.dst, fp, cell_of, cell_start, cell_items, d_n);
+  if (done_flag) {
+    if (ua.dst_host) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) *done_flag = done_seq;
+  }
+}
+
 // Last launch of the stereo Frame constructor: workgroup 0 builds the grid, workgroup 1 (its first four wavefronts; the
 // others leave at once) runs the median rejection of ComputeStereoMatches -- the two do not depend on each other, and as two
 // launches they cost the tracking thread a submission and the stream a kernel boundary more.  The rejection mirrors its
@@ -1036,7 +1061,8 @@ extern "C" int orbm_frame_from_extractor(orbm_frame* f, orbx_handle* h, const or
 // EXTRACTOR's stream, behind the descriptor / stereo kernels; the caller synchronises that stream once.
 int orbx_internal_kp_capacity(orbx_handle* h);   // extractor.hip
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
-                         volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin) {
+                         volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin, const orbg::UndistortArgs* un,
+                         bool mono) {
   if (!f || !h || !v) return ORBG_BAD_ARG;
   const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n0; hipStream_t xs;
   int rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n0, &xs);
@@ -1047,10 +1073,14 @@ int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v
   const int xcap = orbx_internal_kp_capacity(h);
   if (n < 0 && xcap >= ORBG_MAX_FRAME_FEATURES) return ORBG_CAP_EXCEEDED;
   if ((rc = frame_reserve(f, n < 0 ? std::max(std::max(f->cap, 4096), xcap) : n))) return rc;
-  f->has_uright = true;
-  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
+  f->has_uright = !mono;           // monocular frame: mvuRight = -1 for every feature (S/Frame.cc:303)
+  f->kps_p = (un && un->on) ? un->dst : dk;      // the grid and the searches read mvKeysUn
+  f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;      // (octave / angle of mvKeys == those of mvKeysUn)
   f->stream = stream;              // the extractor's stream: searches on this frame follow its constructor in order
-  if (fin)
+  if (un && un->on)
+    hipLaunchKernelGGL(undistort_grid_kernel, dim3(1), dim3(1024), 0, stream, *un, f->fp, f->d_cell_of.p, f->d_cell_start.p, f->d_cell_items.p,
+                       d_n, done_flag, done_seq);
+  else if (fin)
     hipLaunchKernelGGL(grid_build_finalize_kernel, dim3(2), dim3(1024), 0, stream, f->kps_p, f->fp, f->d_cell_of.p, f->d_cell_start.p,
                        f->d_cell_items.p, d_n, done_flag, done_seq, *fin);
   else

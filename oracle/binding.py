@@ -195,6 +195,34 @@ def stereo_match(ex_l, ex_r, kps_l, desc_l, kps_r, desc_r, bf, b):
 
 
 # ---------------------------------------------------------------- frame / matchers
+def undistort_points(xy, cam4, dist5):
+    """cv::undistortPoints(pts, pts, K, mDistCoef, Mat(), K) (S/Frame.cc:740,767): xy n x 2 float32; cam4 = (fx, fy, cx, cy);
+    dist5 = (k1, k2, p1, p2, k3) or None."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    d = None if dist5 is None else capi.OrbxDistortion(*[float(v) for v in dist5])
+    _chk(lib().oracle_undistort_points(C.c_void_p(xy.ctypes.data), len(xy), C.c_float(cam4[0]), C.c_float(cam4[1]), C.c_float(cam4[2]),
+                                       C.c_float(cam4[3]), None if d is None else C.byref(d), C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def undistort_keypoints(kps, cam4, dist5):
+    """Frame::UndistortKeyPoints (S/Frame.cc:721-754): mvKeysUn = mvKeys with pt replaced."""
+    un = kps.copy()
+    if len(kps):
+        xy = undistort_points(np.stack([kps["x"], kps["y"]], axis=1), cam4, dist5)
+        un["x"], un["y"] = xy[:, 0], xy[:, 1]
+    return un
+
+
+def image_bounds(width, height, cam4, dist5):
+    """Frame::ComputeImageBounds (S/Frame.cc:756-783) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    if dist5 is None or float(np.float32(dist5[0])) == 0.0:
+        return (0.0, float(width), 0.0, float(height))
+    m = undistort_points(np.array([[0, 0], [width, 0], [0, height], [width, height]], np.float32), cam4, dist5)
+    return (float(min(m[0, 0], m[2, 0])), float(max(m[1, 0], m[3, 0])), float(min(m[0, 1], m[1, 1])), float(max(m[2, 1], m[3, 1])))
+
+
 def build_grid(fv):
     start = np.zeros(capi.GRID_COLS * capi.GRID_ROWS + 1, np.int32)
     items = np.zeros(max(fv.n, 1), np.int32)

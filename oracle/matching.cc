@@ -223,6 +223,50 @@ extern "C" int oracle_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, 
   return ORBG_OK;
 }
 
+// Frame::UndistortKeyPoints (S/Frame.cc:721-754) / ComputeImageBounds (:756-783): cv::undistortPoints(mat, mat, toK(), mDistCoef,
+// cv::Mat(), mK) on CV_32FC2 points.  cv::undistortPoints is NOT in the reference tree (OpenCV, imgproc/src/undistort.cpp); restated
+// from the 3.2-era cvUndistortPoints the README's platform ships: camera matrix and coefficients widened float -> double, R = I,
+// RR = P * R with P = mK (products with an identity: exact), per point
+//     x = (u - cx) * ifx,  y = (v - cy) * ify            (ifx = 1. / fx)
+//     5 x { r2 = x*x + y*y;  icdist = (1 + ((k6*r2 + k5)*r2 + k4)*r2) / (1 + ((k3*r2 + k2)*r2 + k1)*r2);   [k4..k6 = 0 here]
+//           dX = 2*p1*x*y + p2*(r2 + 2*x*x);  dY = p1*(r2 + 2*y*y) + 2*p2*x*y;  x = (x0 - dX)*icdist;  y = (y0 - dY)*icdist }
+//     xx = RR00*x + RR01*y + RR02,  yy = RR10*x + RR11*y + RR12,  ww = 1. / (RR20*x + RR21*y + RR22);  out = (float)(xx*ww), (float)(yy*ww)
+// all in double, no contraction (the library is built without FMA for x86-64).  Later OpenCV versions (>= 3.4.2) add a
+// termination criterion whose default is the same 5 iterations and an early exit for icdist < 0, which no point inside an image of
+// a camera with EuRoC-like coefficients reaches.  PARITY UNPINNED, like every OpenCV restatement in this oracle.
+extern "C" int oracle_undistort_points(const float* xy_in, int n, float fx_, float fy_, float cx_, float cy_, const orbx_distortion* dist,
+                                       float* xy_out) {
+  if (n < 0 || (n > 0 && (!xy_in || !xy_out))) return ORBG_BAD_ARG;
+  if (!dist || dist->k1 == 0.0f) {                               // S/Frame.cc:723-727, :776-782
+    for (int i = 0; i < 2 * n; i++) xy_out[i] = xy_in[i];
+    return ORBG_OK;
+  }
+  const double fx = fx_, fy = fy_, cx = cx_, cy = cy_;
+  const double ifx = 1. / fx, ify = 1. / fy;
+  const double k0 = dist->k1, k1 = dist->k2, k2 = dist->p1, k3 = dist->p2, k4 = dist->k3;   // OpenCV's k[0..4] = k1 k2 p1 p2 k3
+  const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};
+  for (int i = 0; i < n; i++) {
+    double x = xy_in[2 * i], y = xy_in[2 * i + 1];
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+      const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x);
+      const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+    const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+    const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+    xy_out[2 * i] = (float)(xx * ww);
+    xy_out[2 * i + 1] = (float)(yy * ww);
+  }
+  return ORBG_OK;
+}
+
 extern "C" int oracle_build_grid(const orbm_frame_view* view, int32_t* cell_start, int32_t* cell_items) {
   Grid g = build_grid(view);
   std::memcpy(cell_start, g.start.data(), g.start.size() * sizeof(int32_t));

@@ -62,6 +62,9 @@ int oracle_stereo_match(oracle_extractor* left, oracle_extractor* right,
                         const orbx_keypoint* kps_l, const uint8_t* desc_l, int n_l,
                         const orbx_keypoint* kps_r, const uint8_t* desc_r, int n_r,
                         float bf, float b, float* uright, float* depth);
+/* cv::undistortPoints(src, dst, K, distCoeffs, Mat(), P = K) as Frame::UndistortKeyPoints / ComputeImageBounds call it
+ * (S/Frame.cc:740,767): xy = n x {x, y} float32, in place allowed.  dist NULL or k1 == 0: copy (S/Frame.cc:723-727). */
+int oracle_undistort_points(const float* xy_in, int n, float fx, float fy, float cx, float cy, const orbx_distortion* dist, float* xy_out);
 int oracle_build_grid(const orbm_frame_view* view, int32_t* cell_start, int32_t* cell_items);
 int oracle_features_in_area(const orbm_frame_view* view, float x, float y, float r, int min_level,
                             int max_level, int32_t* out_idx, int cap);

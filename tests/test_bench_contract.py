@@ -100,15 +100,18 @@ def test_roofline_kernel_is_the_top_row_of_a_fresh_kernel_trace():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["C4", "mono"])
+@pytest.mark.parametrize("name", ["C4", "mono", "mono_dist"])
 def test_other_configurations_produce_a_line(name):
     d = _bench("--config", name, "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--secondary-steps", "10")
     assert d["config"]["name"] == name and d["value"] > 0 and d["config"]["lba_ms_per_call"] > 0
     assert d["roofline"]["bracketed_launches"] >= 1
+    assert d["parity"]["ok"] is True and d["parity"]["frames"] == 20          # the in-job gate runs for every configuration
     if name == "C4":
         assert d["roofline"]["unknowns"] == 300 and "k_ldlt_big48" in d["roofline"]["kernel"]
     else:
-        assert d["config"]["host_images_in_step"] is True
+        # a monocular agent is a first-class agent: fused constructor, pipelined, the C++ loop
+        assert d["config"]["host_images_in_step"] is True and "libagentloop" in d["config"]["tracking_loop"]
+        assert d["config"]["frame_ctor_ahead"] >= 1 and d["parity"]["stereo_bit_exact"] is None
 
 
 @pytest.mark.gpu
@@ -132,7 +135,7 @@ def test_cxx_tracking_loop_does_the_work_of_the_python_loop():
     cfg = dict(bench.CONFIGS["C2"])
     scene = synth.Scene(640, 480, seed=synth.SEED_IMAGES)
     n_frames = 12
-    ex, imgs, host_imgs, frames, kf_chunks = bench.build_workload(scene, cfg, n_frames, api, views, synth, 0)
+    ex, imgs, host_imgs, frames, kf_chunks, _fv0, _bounds = bench.build_workload(scene, cfg, n_frames, api, views, synth, 0)
     p = scene.frame_view_params()
     fv, _k = views.frame_view(np.zeros(1, capi.KEYPOINT_DTYPE), np.zeros((1, 32), np.uint8), None, None, p["bounds"], p["cam"], 8, 1.2)
     exs = [ex] + [api.ORBextractor(cfg["n_features"], 1.2, 8, 20, 7, 640, 480, n_cams=2) for _ in range(3)]     # a ring of four (handle, frame) pairs

@@ -364,3 +364,86 @@ def test_octree_properties():
     two = np.array([[10, 10, 50], [11, 10, 90]], np.int32)
     out = ob.distribute_octree(two, 16, 464, 16, 464, 1)
     assert len(out) == 1 and out[0][2] == 90
+
+
+# ---- cv::undistortPoints as Frame::UndistortKeyPoints / ComputeImageBounds call it (S/Frame.cc:721-783)
+EUROC_CAM = (458.654, 457.296, 367.215, 248.375)                       # R/ros/conf/EuRoC_mono_client.yaml:9-12
+EUROC_DIST = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+
+
+def _undistort_model(xy, cam4, dist5):
+    """Line-by-line Python model of OpenCV 3.2's cvUndistortPoints for the call at S/Frame.cc:740 (Python floats are IEEE doubles and
+    the interpreter never contracts a * b + c): inputs widened from float32, 5 iterations, P = K."""
+    f32 = lambda v: float(np.float32(v))
+    fx, fy, cx, cy = [f32(v) for v in cam4]
+    k1, k2, p1, p2, k3 = [f32(v) for v in dist5]
+    ifx, ify = 1.0 / fx, 1.0 / fy
+    out = np.zeros((len(xy), 2), np.float32)
+    for i, (u, v) in enumerate(np.asarray(xy, np.float32)):
+        x = (float(u) - cx) * ifx
+        y = (float(v) - cy) * ify
+        x0, y0 = x, y
+        for _ in range(5):
+            r2 = x * x + y * y
+            icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x = (x0 - dx) * icdist
+            y = (y0 - dy) * icdist
+        xx = fx * x + 0.0 * y + cx
+        yy = 0.0 * x + fy * y + cy
+        ww = 1.0 / (0.0 * x + 0.0 * y + 1.0)
+        out[i] = (np.float32(xx * ww), np.float32(yy * ww))
+    return out
+
+
+def _distort_forward(xy_un, cam4, dist5):
+    """The forward Brown-Conrady model (what a lens does): undistorted pixel -> distorted pixel, in double."""
+    fx, fy, cx, cy = cam4
+    k1, k2, p1, p2, k3 = dist5
+    x = (np.asarray(xy_un, np.float64)[:, 0] - cx) / fx
+    y = (np.asarray(xy_un, np.float64)[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return np.stack([fx * xd + cx, fy * yd + cy], axis=1)
+
+
+def test_undistort_points_against_the_python_model_and_the_forward_lens_model():
+    rng = np.random.RandomState(3)
+    xy = np.concatenate([rng.uniform([0, 0], [752, 480], (4000, 2)), [[0, 0], [752, 0], [0, 480], [752, 480], [367.215, 248.375]]]).astype(np.float32)
+    for dist in (EUROC_DIST, (-0.3, 0.1, 0.001, -0.0005, -0.02), (0.05, 0.0, 0.0, 0.0, 0.0)):
+        got = ob.undistort_points(xy, EUROC_CAM, dist)
+        want = _undistort_model(xy, EUROC_CAM, dist)
+        assert got.tobytes() == want.tobytes(), dist                     # bit-exact against the model
+        # five fixed-point iterations invert the lens model to a fraction of a pixel inside the image (worst towards the corners:
+        # the iteration has not converged there -- that is what the reference computes with)
+        if dist[0] < -0.29:                                              # (a lens the fixed-point iteration does not invert at the corners:
+            continue                                                     #  the model check above is all that can be said)
+        back = _distort_forward(got.astype(np.float64), [float(np.float32(v)) for v in EUROC_CAM], [float(np.float32(v)) for v in dist])
+        err = np.abs(back - xy).max(axis=1)
+        assert np.median(err) < 0.02 and err.max() < 0.5, (dist, np.median(err), err.max())
+    # the principal point is a fixed point; k1 == 0 means "no distortion" whatever the other coefficients say (S/Frame.cc:723)
+    c = ob.undistort_points([[367.215, 248.375]], EUROC_CAM, EUROC_DIST)
+    assert np.abs(c - np.float32([367.215, 248.375])).max() < 1e-3
+    same = ob.undistort_points(xy, EUROC_CAM, (0.0, 0.5, 0.1, 0.1, 0.3))
+    assert same.tobytes() == xy.tobytes() and ob.undistort_points(xy, EUROC_CAM, None).tobytes() == xy.tobytes()
+    assert len(ob.undistort_points(np.zeros((0, 2), np.float32), EUROC_CAM, EUROC_DIST)) == 0
+
+
+def test_image_bounds_and_undistorted_keypoints():
+    """Frame::ComputeImageBounds (S/Frame.cc:756-783): with EuRoC's barrel distortion the undistorted corners lie OUTSIDE the image
+    rectangle; without distortion the bounds are the rectangle.  UndistortKeyPoints keeps every keypoint field but pt."""
+    b = ob.image_bounds(752, 480, EUROC_CAM, EUROC_DIST)
+    assert b[0] < -30 and b[1] > 752 + 30 and b[2] < -15 and b[3] > 480 + 15
+    m = _undistort_model(np.float32([[0, 0], [752, 0], [0, 480], [752, 480]]), EUROC_CAM, EUROC_DIST)
+    assert b == (float(min(m[0, 0], m[2, 0])), float(max(m[1, 0], m[3, 0])), float(min(m[0, 1], m[1, 1])), float(max(m[2, 1], m[3, 1])))
+    assert ob.image_bounds(752, 480, EUROC_CAM, None) == (0.0, 752.0, 0.0, 480.0)
+    kps = np.zeros(5, capi.KEYPOINT_DTYPE)
+    kps["x"] = [20, 100, 376, 700, 730]; kps["y"] = [25, 400, 240, 30, 460]; kps["size"] = 31; kps["angle"] = [1, 2, 3, 4, 5]
+    kps["response"] = 50; kps["octave"] = [0, 1, 2, 3, 4]
+    un = ob.undistort_keypoints(kps, EUROC_CAM, EUROC_DIST)
+    for f in ("size", "angle", "response", "octave"):
+        assert np.array_equal(un[f], kps[f])
+    assert un["x"][0] < kps["x"][0] and un["x"][4] > kps["x"][4] and abs(un["x"][2] - kps["x"][2]) < 0.1
