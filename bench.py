@@ -66,6 +66,17 @@ CONFIGS = {
 }
 
 
+CONFIGS["C3"] = dict(CONFIGS["C2"], server=dict(tick_every=2), expect_gpus=2,
+                     label="C3 (configs[2]): stereo clients 640x480 as C2, one per GPU, PLUS the server's place recognition in the same job -- every "
+                           "2 keyframes all agents all-gather their new KeyFrame wire blocks (RCCL over xGMI), the server (rank 0's GPU, a thread of "
+                           "its own) rebuilds each KeyFrame, computes its bag of words, queries DetectNBestCandidates and runs SearchByBoW(KF, KF) + "
+                           "SearchByProjection(KF, Scw, map points)")
+CONFIGS["C5"] = dict(per_rank=["C2", "mono"], server=dict(tick_every=2), expect_gpus=8,
+                     label="C5 (configs[4]): mixed clients, one per GPU -- even ranks stereo 640x480 (as C2), odd ranks monocular 640x480 (as mono) -- "
+                           "PLUS the server tick of C3 (RCCL all-gather of every agent's new KeyFrame blocks every 2 keyframes, place recognition "
+                           "and KeyFrame matching on rank 0's GPU)")
+
+
 def build_workload(scene, cfg, n_frames, api, views, synth, device):
     """Run the pipeline once per distinct frame to cache the host-side views a Tracking thread would hold (last-frame view,
     pose guesses) and to build the map a LocalMapping thread would have built: every FRAMES_PER_KF-th frame is a keyframe
@@ -116,7 +127,7 @@ def build_workload(scene, cfg, n_frames, api, views, synth, device):
                 dp_new[amp >= 0] = -1.0                  # the feature already observes a map point
             kf_chunks[k] = synth.map_from_frame(kl, dl, dp_new, Tcw, cam)
         frames.append(dict(Tcw=Tcw, guess=synth.perturb_pose(Tcw, rng).astype(np.float32), last_view=(lv, keep),
-                           n=nl, stereo=int((ur > 0).sum())))
+                           n=nl, stereo=int((ur > 0).sum()), kf_feats=(kl.copy(), dl.copy()) if k % FRAMES_PER_KF == 0 else None))
     return ex, imgs, host_imgs, frames, kf_chunks, fv0, bounds
 
 
@@ -178,7 +189,7 @@ def host_cpu():
     return dict(nproc=os.cpu_count(), model=model, affinity_cpus=len(os.sched_getaffinity(0)))
 
 
-def cpu_baseline(scene, cfg, synth, views, n_frames, host_imgs, frames, kf_chunks, seq, cpus=None):
+def cpu_baseline(scene, cfg, synth, views, n_frames, host_imgs, frames, kf_chunks, seq, cpus=None, build_native=True):
     """The CPU oracle (a restatement of the reference path), rebuilt -O3 -march=native for this host, on a bounded sample of
     the same workload (same images, same sequence, same local maps) with the reference's threading: left / right extraction
     on two threads (S/Frame.cc:92-95), the tracking steps on the calling thread, local BA on its own thread next to tracking
@@ -188,7 +199,7 @@ def cpu_baseline(scene, cfg, synth, views, n_frames, host_imgs, frames, kf_chunk
     import threading
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as ob
-    lib_path = ob.use_native()
+    lib_path = ob.use_native(build=build_native)
     if cpus:
         os.sched_setaffinity(0, cpus)                     # threads created below inherit it
     cam = scene.cam
@@ -305,9 +316,16 @@ def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames,
     res = dict(frames=0, extract_bit_exact=True, stereo_bit_exact=True if stereo else None, match_frame_equal=True, match_map_equal=True,
                keypoints_checked=0, matches_frame_checked=0, matches_map_checked=0, first_step=int(first_step))
     bad = []
+    import zlib
+    digest = 0
     for i in range(first_step, first_step + n_gate):
         k, k_last = seq[i % len(seq)], seq[(i - 1) % len(seq)]
         got = run_step(i)
+        # digest of everything this agent's loop delivered for the frame (multi-agent runs: equal to the 1-agent run of the same seed)
+        for key in ("kps", "kps_un", "desc", "uright", "depth", "amp_frame", "amp", "aob"):
+            if got.get(key) is not None:
+                a_ = np.ascontiguousarray(got[key][: got["nl"]])
+                digest = zlib.crc32(a_.tobytes(), digest)
         L, R = host_imgs[k]
         if stereo:
             rc, okl, odl, _ = exL.extract(L)
@@ -349,6 +367,8 @@ def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames,
     # ---- the local BA the loop ran last (every keyframe step solves the same problem) against the oracle's solve of it
     finish()                                              # every local BA the gate's steps submitted has delivered its result
     g = lba_out
+    digest = zlib.crc32(np.ascontiguousarray(g.points).tobytes(), zlib.crc32(np.ascontiguousarray(g.poses).tobytes(), digest))
+    res["agent_digest"] = int(digest)
     o = ob.lba_solve(lp)
     d_pose = float(np.abs(g.poses - o.poses).max()); d_pt = float(np.abs(g.points - o.points).max())
     tg, to = g.trace_rows(), o.trace_rows()
@@ -370,6 +390,42 @@ def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames,
     res["violations"] = bad[:8]
     res["oracle"] = "oracle/ (CPU restatement of the reference path; parity unpinned by the reference, see DESIGN.md section 6)"
     return res
+
+
+def server_tick_parity(server, views):
+    """The in-job gate, server side (rank 0): the LAST tick's blocks through the oracle -- wire unpack, bag of words,
+    DetectNBestCandidates (from the score state the tick started with), SearchByBoW(KF, KF), SearchByProjection(KF, Scw, points) --
+    against what the device produced inside the timed region."""
+    from oracle import binding as ob
+    if server is None or not server.is_server or not server.last:
+        return None
+    fv = server.fv
+    ok = dict(blocks=0, wire_equal=True, bow_equal=True, candidates_equal=True, bow_matches_equal=True, projection_matches_equal=True)
+    for r in server.last:
+        n = r["n"]
+        wire = r["wire"] if r["wire"] is not None else r["blk"].cpu().numpy()
+        kps, desc = ob.wire_unpack(np.ascontiguousarray(wire), n)
+        server.KF.from_wire(fv, wire=np.ascontiguousarray(wire), n=n)
+        gk, gd = server.KF.download()
+        ok["wire_equal"] &= bool(gk.tobytes() == kps.tobytes() and gd.tobytes() == desc.tobytes())
+        (bw, bv), (fn, fs, ff) = ob.vocab_bow(server.vocab_view, desc, server.LEVELS_UP)
+        ok["bow_equal"] &= bool(np.array_equal(bw, r["bow"][0]) and np.array_equal(bv, r["bow"][1]) and np.array_equal(fn, r["fv"][0])
+                                and np.array_equal(fs, r["fv"][1]) and np.array_equal(ff, r["fv"][2]))
+        score = r["before"].copy()
+        ol, om = ob.detect_n_best_candidates(server.db_view, bw, bv, r["con"], r["agent"], 3, score)
+        ok["candidates_equal"] &= bool(np.array_equal(ol, r["loop"]) and np.array_equal(om, r["merge"]))
+        c = server.db_kfs[r["cand"]]
+        fvk, keepk = views.frame_view(kps, desc, None, None, (fv.min_x, fv.max_x, fv.min_y, fv.max_y), (fv.fx, fv.fy, fv.cx, fv.cy, fv.bf, fv.b),
+                                      fv.n_levels, fv.scale_factor)
+        fvK, k1 = views.featvec_view(fn, fs, ff)
+        fv1, k2 = views.featvec_view(*c["fv"])
+        om12, onb = ob.search_by_bow_kf(fvk, fvK, np.ones(n, np.uint8), c["desc"], c["valid"], c["angle"], fv1, 0.9, True)
+        ok["bow_matches_equal"] &= bool(onb == r["nb"] and np.array_equal(om12, r["m12"]))
+        omt, onp = ob.search_by_projection_sim3(fvk, server.map_view, r["T"], server.free[:n], 8, 1.5)
+        ok["projection_matches_equal"] &= bool(onp == r["nproj"] and np.array_equal(omt, r["matched"]))
+        ok["blocks"] += 1
+    ok["ok"] = all(v for k, v in ok.items() if k != "blocks") and ok["blocks"] > 0
+    return ok
 
 
 def launch_ranks(n):
@@ -438,6 +494,9 @@ def main():
                     help="untimed steps before --warmup (at least this many; the pre-warm runs until the step rate is stationary, "
                          "0.3 - 3 s): first-use allocations, clocks, hardware queues -- so that a short timed region is at steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--first-agent", type=int, default=0,
+                    help="agent id of rank 0 (rank r runs agent first-agent + r: its own scene / local-BA seeds); a 1-rank run with --first-agent a "
+                         "reproduces agent a of a multi-rank run (tests compare parity.agent_digests)")
     ap.add_argument("--parity-frames", type=int, default=20,
                     help="in-job parity gate (SURVEY.md 8d): this many frames of the timed sequence go through the product loop once more, "
                          "outside the timed region, and every output is compared with the CPU oracle; the process exits with code 3 on a "
@@ -503,6 +562,11 @@ def main():
                          "what was asked for\n" % (args.gpus, world_env, "" if world_env == 1 else "s"))
         sys.exit(2)
     cfg = CONFIGS[args.config]
+    server_cfg = cfg.get("server")
+    if "per_rank" in cfg:
+        # mixed clients: the configuration of THIS rank's agent
+        sub = cfg["per_rank"][int(os.environ.get("RANK", "0")) % len(cfg["per_rank"])]
+        cfg = dict(CONFIGS[sub], server=server_cfg, label=cfg["label"] + " -- this rank: " + sub, agent_kind=sub)
     stereo = cfg["stereo"]
 
     # The agent keeps six HIP streams busy (two extractor handles, two frames, the local map, the local BA).  The ROCm
@@ -554,7 +618,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     # --server-tick on one GPU still goes through RCCL: a single-rank process group
     # control plane on gloo, the RCCL group of the server tick is created by its first collective (harness.AgentGroup)
-    grp = harness.AgentGroup("nccl", force_group=args.server_tick, device_index=(
+    grp = harness.AgentGroup("nccl", force_group=args.server_tick or server_cfg is not None, device_index=(
         int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1) if os.environ.get("ORBG_BENCH_SHARE_GPU") == "1" else None))
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     device = local_rank
@@ -568,7 +632,8 @@ def main():
     core_pair = None if args.no_numa_pin else harness.cores_for_agent(device, local_rank, per_agent=3)
 
     W, H = cfg["W"], cfg["H"]
-    scene = synth.Scene(W, H, seed=synth.SEED_IMAGES + rank)      # one agent per GPU, distinct seeds
+    agent_id = args.first_agent + rank
+    scene = synth.Scene(W, H, seed=synth.SEED_IMAGES + agent_id)      # one agent per GPU, distinct seeds
     cam = scene.cam
     ex, imgs, host_imgs, frames, kf_chunks, fv, frame_bounds = build_workload(scene, cfg, args.frames, api, views, synth, device)
     p = scene.frame_view_params()
@@ -589,7 +654,7 @@ def main():
     m_map = api.ORBmatcher(0.8, True, device)
     opt = api.Optimizer(device)
     nfree, nfix, npts = cfg["lba"]
-    prob = synth.make_lba_problem(n_free=nfree, n_fixed=nfix, n_points=npts, seed=synth.SEED_LBA + rank, width=W, height=H,
+    prob = synth.make_lba_problem(n_free=nfree, n_fixed=nfix, n_points=npts, seed=synth.SEED_LBA + agent_id, width=W, height=H,
                                   mono_frac=cfg["mono_frac"])
     lp, lp_keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"], device=device)
     bf, bb = float(cam["bf"]), float(cam["b"])
@@ -615,10 +680,10 @@ def main():
                 cpu_affinity = "%s, image-ingest thread on cpus %s" % (cpu_affinity, sorted(core_pair[2]))
     nF = len(frames)
     seq = list(range(nF)) + list(range(nF - 2, 0, -1))             # ping-pong: consecutive frames stay adjacent
-    po_prob = synth.make_pose_opt_problem(n=450, seed=77 + rank)
+    po_prob = synth.make_pose_opt_problem(n=450, seed=77 + agent_id)
     po1, po1_keep = views.pose_opt_problem(po_prob["Xw"], po_prob["u"], po_prob["v"], po_prob["ur"], po_prob["inv_sigma2"],
                                           po_prob["cam"], po_prob["Tcw"], device=device)
-    po_prob2 = synth.make_pose_opt_problem(n=650, seed=78 + rank)
+    po_prob2 = synth.make_pose_opt_problem(n=650, seed=78 + agent_id)
     po2, po2_keep = views.pose_opt_problem(po_prob2["Xw"], po_prob2["u"], po_prob2["v"], po_prob2["ur"], po_prob2["inv_sigma2"],
                                           po_prob2["cam"], po_prob2["Tcw"], device=device)
     for e in exs:
@@ -804,6 +869,19 @@ def main():
         loop = agent_mod.AgentLoop(exs, Fs, LM, opt, fv, W, H, W, bf, bb, frames_in, seq, kf_views, lp, lba_out, [po1, po2], FRAMES_PER_KF,
                                    2 * cfg["frame_cap"], th_frame, mono_flag, last_view=last_dev, mono_agent=not stereo, dist=dist_c)
 
+    # ---- C3 / C5: the server's place recognition runs in this job (harness.ServerTick; a collective constructor)
+    server = None
+    if server_cfg is not None:
+        if not use_cxx:
+            raise SystemExit("bench.py: --config %s needs the default C++ loop" % args.config)
+        agent_kfs = [(k, frames[k]["kf_feats"][0], frames[k]["kf_feats"][1], frames[k]["Tcw"]) for k in range(nF) if frames[k]["kf_feats"] is not None]
+        allp = {key: np.concatenate([kf_chunks[j][key] for j in sorted(kf_chunks)]) for key in kf_chunks[sorted(kf_chunks)[0]]}
+        server_map_view, server_map_keep = views.worldpoints_view(allp["pos"], allp["normal"], allp["min_dist"], allp["max_dist"], allp["desc"],
+                                                                  allp["n_obs"], allp["bad"])
+        server = harness.ServerTick(grp, api, views, synth, device, fv, server_map_view, agent_kfs, FRAMES_PER_KF,
+                                    tick_every=server_cfg["tick_every"], max_features=cfg["frame_cap"],
+                                    shared_gpu=os.environ.get("ORBG_BENCH_SHARE_GPU") == "1" and world > 1)
+
     def ctxt_switches():
         """Involuntary context switches of every thread of this process so far: a spinning thread that loses its core to a
         neighbour's job shows up here (the bench boxes are shared hosts)."""
@@ -844,7 +922,22 @@ def main():
         cs0 = ctxt_switches()
         th0 = harness.cgroup_throttled()
         t0 = time.perf_counter()
-        loop.run(base, n_steps, last_is_final=True, timed=True, step_s=step_s, stats=st)
+        if server is None:
+            loop.run(base, n_steps, last_is_final=True, timed=True, step_s=step_s, stats=st)
+        else:
+            # C3 / C5: the same K steps, handed to libagentloop in chunks that end with a keyframe step; after each the agent packs the
+            # keyframe into a wire block, and every tick_every-th keyframe ALL ranks meet in the server tick's all-gather
+            s_, ring_ = 0, loop.c.ring
+            while s_ < n_steps:
+                i_ = base + s_
+                n_ = min(((-i_) % FRAMES_PER_KF) + 1, n_steps - s_)
+                loop.run(i_, n_, last_is_final=(s_ + n_ == n_steps), timed=True, step_s=step_s[s_:], stats=st)
+                s_ += n_
+                last_ = base + s_ - 1
+                if last_ % FRAMES_PER_KF == 0:
+                    k_ = seq[last_ % len(seq)]
+                    server.on_keyframe(Fs[(last_ % ring_) if pipelined else 0], st.last_nl, k_, frames[k_]["Tcw"])
+            server.drain()                        # (rank 0) every tick exchanged in the region has been processed by the server thread
         sync()
         dt = time.perf_counter() - t0             # this rank's K steps, everything it launched complete; the job's time is the
         grp.barrier()                             # MAX over ranks (they started together) -- the barrier's own latency (gloo:
@@ -1217,7 +1310,12 @@ def main():
             own = set().union(*core_pair)
         else:
             os.sched_setaffinity(0, affinity_at_start)     # one agent: the baseline's three threads get the whole machine again
-        base = cpu_baseline(scene, cfg, synth, views, n_base, host_imgs, frames, kf_chunks, seq, cpus=own)
+        # one rank of the node builds the -march=native oracle, the others wait for the file (they must not all write it at once)
+        if local_rank == 0:
+            from oracle import binding as ob_
+            ob_.use_native()
+        grp.barrier()
+        base = cpu_baseline(scene, cfg, synth, views, n_base, host_imgs, frames, kf_chunks, seq, cpus=own, build_native=False)
         per_rank = grp.gather_floats(base["value"])
         if rank == 0:
             base["host_cpu"] = host_cpu()
@@ -1272,13 +1370,37 @@ def main():
             parity["loop"] = "libagentloop.so, configured as the main timed region" if use_cxx else "python loop (ctypes wrappers)"
         else:
             parity = {"skipped": "this python-loop configuration leaves the features in HBM (use the default --loop cxx)"}
+        if server is not None and "skipped" not in parity:
+            sp = server_tick_parity(server, views)
+            if sp is not None:
+                parity["server_tick"] = sp
+                if not sp["ok"]:
+                    parity["ok"] = False
+                    parity.setdefault("violations", []).append("server tick: %s" % {k2: v for k2, v in sp.items() if v is False})
         oks = grp.gather_floats(1.0 if parity.get("ok", True) else 0.0)
         parity["agents_ok"] = [bool(v) for v in oks]
+        parity["agent_digests"] = [int(v) for v in grp.gather_floats(float(parity.get("agent_digest", 0)))]
+        parity["agent_ids"] = [args.first_agent + r_ for r_ in range(world)]
         if not all(parity["agents_ok"]):
             parity["ok"] = False
+    kinds = grp.gather_floats(0.0 if stereo else 1.0)
+    pol = grp.gather_floats(float(sum(1 << j for j, r in enumerate(("caller", "lba", "ingest")) if wait_policy[r] == "block")))
+    server_report = server.report() if server is not None else None
     if rank == 0:
         line["parity"] = parity
-        print(json.dumps(line))
+        line["config"]["agents"] = ["stereo" if v == 0.0 else "mono" for v in kinds]
+        line["config"]["wait_policy_per_rank"] = ["".join(("b" if (int(v) >> j) & 1 else "s") for j in range(3)) + " (tracking / local-BA worker / ingest: s = spins, b = blocks)"
+                                                  for v in pol]
+        if server_report is not None:
+            line["config"]["server_tick_in_job"] = server_report
+        # (RCCL writes a version banner through C stdio, which is flushed at exit when stdout is a file: flush it now so that the
+        # JSON line is the LAST line of the output)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
     grp.close()
     if parity is not None and parity.get("ok") is False:
         sys.stderr.write("bench.py: PARITY VIOLATION against the oracle: %s\n" % "; ".join(parity.get("violations", []) or ["(another agent)"]))

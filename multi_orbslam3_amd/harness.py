@@ -283,6 +283,7 @@ class AgentGroup:
     # ---- server tick: ONE collective per tick, whatever the number of ranks and of new keyframes
     TICK_MAX_BLOCKS = 15                     # new keyframes one agent can contribute per tick
     TICK_HEADER_BYTES = 64                   # int32[16]: number of blocks, then the feature count of each block
+    TICK_POSE_BYTES = 64                     # float32[16] per block: the keyframe's Tcw (KF.msg carries the pose next to the features)
 
     def tick_buffers(self, max_features, device, max_blocks=8):
         """Persistent send / receive buffers of a server tick for up to `max_blocks` keyframes of up to `max_features`
@@ -290,45 +291,52 @@ class AgentGroup:
         so a tick needs no size exchange."""
         import torch
         assert 1 <= max_blocks <= self.TICK_MAX_BLOCKS
-        cap = self.TICK_HEADER_BYTES + 47 * int(max_features) * int(max_blocks)
+        cap = self.TICK_HEADER_BYTES + self.TICK_POSE_BYTES * int(max_blocks) + 47 * int(max_features) * int(max_blocks)
         cap = (cap + 255) & ~255
         send = torch.zeros(cap, dtype=torch.uint8, device=device)
         recv = torch.zeros(self.world * cap, dtype=torch.uint8, device=device)
         return dict(cap=cap, send=send, recv=recv, max_blocks=int(max_blocks), max_features=int(max_features))
 
-    def all_gather_keyframe_blocks(self, bufs, blocks):
+    def all_gather_keyframe_blocks(self, bufs, blocks, with_poses=False):
         """One server tick: every agent contributes ALL its new keyframe wire blocks -- `blocks` = [(n_features, uint8 tensor
-        of 47 * n_features bytes)], possibly empty -- in ONE all-gather of the fixed-size tick buffers (RCCL over xGMI on GPU
-        tensors, gloo on CPU tensors; < 1 MB per agent: latency bound).  The per-block feature counts travel in the buffer's
-        header, so there is no second collective and no host round trip between collectives; the headers of all agents are read
-        back with one small copy.  Returns [[(n_features, block view), ...] for every rank]."""
+        of 47 * n_features bytes[, Tcw as 16 float32])], possibly empty -- in ONE all-gather of the fixed-size tick buffers (RCCL
+        over xGMI on GPU tensors, gloo on CPU tensors; < 1 MB per agent: latency bound).  The per-block feature counts and poses
+        travel in the buffer's header, so there is no second collective and no host round trip between collectives; the headers of
+        all agents are read back with one small copy.  Returns [[(n_features, block view[, Tcw 4 x 4]), ...] for every rank]."""
         import numpy as np
         import torch
         cap, send, recv = bufs["cap"], bufs["send"], bufs["recv"]
-        assert len(blocks) <= bufs["max_blocks"]
-        hdr = np.zeros(self.TICK_HEADER_BYTES // 4, np.int32)
+        mb = bufs["max_blocks"]
+        assert len(blocks) <= mb
+        hb = self.TICK_HEADER_BYTES + self.TICK_POSE_BYTES * mb
+        hdr = np.zeros(hb // 4, np.int32)
         hdr[0] = len(blocks)
-        off = self.TICK_HEADER_BYTES
-        for b, (n, w) in enumerate(blocks):
-            n = int(n)
+        off = hb
+        for b, blk in enumerate(blocks):
+            n, w = int(blk[0]), blk[1]
             assert n <= bufs["max_features"]
             hdr[1 + b] = n
+            if len(blk) > 2 and blk[2] is not None:
+                hdr[16 + 16 * b: 32 + 16 * b] = np.ascontiguousarray(blk[2], np.float32).reshape(16).view(np.int32)
             send[off: off + 47 * n] = w[: 47 * n]
             off += 47 * n
-        send[: self.TICK_HEADER_BYTES] = torch.from_numpy(hdr.view(np.uint8)).to(send.device, non_blocking=True)
+        send[:hb] = torch.from_numpy(hdr.view(np.uint8)).to(send.device, non_blocking=True)
         if self.dist is None:
             recv[:cap] = send
         else:
             self.dist.all_gather_into_tensor(recv, send, group=self.data_group(send))
-        heads = recv.view(self.world, cap)[:, : self.TICK_HEADER_BYTES].cpu().numpy().view(np.int32)      # the tick's one read-back
+        heads = recv.view(self.world, cap)[:, :hb].cpu().numpy().view(np.int32)      # the tick's one read-back
         out = []
         for r in range(self.world):
             nb = int(heads[r, 0])
-            off = r * cap + self.TICK_HEADER_BYTES
+            off = r * cap + hb
             lst = []
             for b in range(nb):
                 n = int(heads[r, 1 + b])
-                lst.append((n, recv[off: off + 47 * n]))
+                if with_poses:
+                    lst.append((n, recv[off: off + 47 * n], heads[r, 16 + 16 * b: 32 + 16 * b].view(np.float32).reshape(4, 4).copy()))
+                else:
+                    lst.append((n, recv[off: off + 47 * n]))
                 off += 47 * n
             out.append(lst)
         return out
@@ -367,3 +375,239 @@ def cgroup_throttled():
         except (OSError, ValueError, KeyError):
             continue
     return None
+
+
+class ServerTick:
+    """The compute side of the server of BASELINE configs[2] / configs[4], running in the SAME job next to the agents
+    (S/ClientHandler.cc:100-129: one LoopClosing / place-recognition thread per client on the server; S/LoopClosing.cc:580-840
+    NewDetectCommonRegions; S/Communicator.cc:951-1149 keyframes arriving from the clients).
+
+    Every agent (= rank) packs each new keyframe into a wire block on its GPU (orbk_pack_frame, R/msg/KF.msg:29-31 layout); every
+    `tick_every` keyframes ALL ranks meet in ONE all-gather of the blocks (RCCL over xGMI on device tensors; gloo over host copies
+    when several ranks share one GPU, which RCCL refuses -- a test aid, flagged in the report).  The server lives on rank 0's GPU:
+    for every block received it rebuilds the KeyFrame on the device (orbk_frame_from_wire), computes its bag of words
+    (KeyFrame::ComputeBoW -> orbv_transform_frame + orbv_bow_assemble), asks the place-recognition database for loop / merge
+    candidates (KeyFrameDatabase::DetectNBestCandidates -> orbd_detect_n_best_candidates), matches the keyframe against the best
+    candidate by bag of words (ORBmatcher::SearchByBoW(KF, KF) -> orbm_search_by_bow_kf) and projects the server's map points into it
+    (ORBmatcher::SearchByProjection(KF, Scw, points) -> orbm_search_by_projection_sim3).  The Sim3 solver between the two matchers
+    is out of scope: the keyframe's own pose plays Scw.
+
+    The database is built before the timed region from every agent's keyframes of the sequence (what the server has received so
+    far): vocabulary = a synthetic DBoW2 tree over rank 0's descriptors (ORBvoc.txt is not in the reference tree), map id = agent."""
+
+    LEVELS_UP = 1
+
+    def __init__(self, grp, api, views, synth, device, fv, server_map_view, agent_kfs, frames_per_kf, tick_every=2, max_features=4096,
+                 shared_gpu=False):
+        """agent_kfs: this agent's keyframes of the sequence, [(frame id, keypoints, descriptors, Tcw)], host arrays; server_map_view:
+        the map points the server projects into incoming keyframes (rank 0: a worldpoints view, uploaded into a map handle of the
+        server's own).  COLLECTIVE: every rank constructs it at the same point (the keyframes travel to the server through the
+        tick's own exchange).  The server's work runs on a thread of its own on rank 0 (the reference's server is a separate process
+        with one place-recognition thread per client): the tracking thread only takes part in the exchange."""
+        import queue
+        import threading
+        import numpy as np
+        import torch
+        self.grp, self.api, self.views, self.fv = grp, api, views, fv
+        self.map_view = server_map_view
+        self.device, self.tick_every, self.K = device, int(tick_every), int(frames_per_kf)
+        self.shared_gpu = bool(shared_gpu)
+        self.is_server = grp.rank == 0
+        self.np, self.torch = np, torch
+        self.dev = "cpu" if self.shared_gpu else "cuda:%d" % device
+        self.max_features = int(max_features)
+        # two sets of tick buffers, used alternately: the server thread may still read tick t's blocks while tick t + 1 is exchanged
+        self.bufs2 = [grp.tick_buffers(max_features=self.max_features, device=self.dev, max_blocks=max(self.tick_every, 1)) for _ in range(2)]
+        self.bufs = self.bufs2[0]
+        self.busy = [None, None]                             # threading.Event per buffer set: set when the server thread is done with it
+        self.wire = [torch.zeros(47 * self.max_features, dtype=torch.uint8, device="cuda:%d" % device) for _ in range(max(self.tick_every, 1))]
+        self.pending = []                                    # [(n, wire tensor, Tcw)] packed since the last tick
+        self.stats = dict(ticks=0, blocks=0, loop_candidates=0, merge_candidates=0, bow_matches=0, projection_matches=0, exchange_s=0.0,
+                          server_s=0.0, pack_s=0.0)
+        self.last = None                                     # inputs / outputs of the last tick (rank 0) for the parity gate
+        self.n_agent_kfs = len(agent_kfs)
+        self.kf_slot = {int(k): j for j, (k, _a, _b, _c) in enumerate(agent_kfs)}
+        # ---- every agent's keyframes -> the server (host blocks over the control plane: set-up, untimed)
+        F = api.Frame(self.max_features, device)
+        self._F = F
+        setup_bufs = grp.tick_buffers(max_features=self.max_features, device="cpu", max_blocks=8)
+        mine = []
+        for (k, kps, desc, Tcw) in agent_kfs:
+            fvk, keepk = views.frame_view(kps, desc, None, None, (fv.min_x, fv.max_x, fv.min_y, fv.max_y),
+                                          (fv.fx, fv.fy, fv.cx, fv.cy, fv.bf, fv.b), fv.n_levels, fv.scale_factor)
+            F.upload(fvk, keepk)
+            mine.append((len(kps), torch.from_numpy(F.pack_wire().copy()), np.asarray(Tcw, np.float32)))
+        rounds = grp.max_over_ranks(float((len(mine) + 7) // 8))
+        received = [[] for _ in range(grp.world)]
+        for r in range(int(rounds)):
+            got = grp.all_gather_keyframe_blocks(setup_bufs, mine[8 * r: 8 * r + 8], with_poses=True)
+            for a in range(grp.world):
+                received[a] += [(n, blk.numpy().copy(), T) for (n, blk, T) in got[a]]
+        if grp.dist is not None and not self.shared_gpu:
+            grp.open_data_plane()                            # the RCCL group of the ticks (collective, outside every timed region)
+        elif grp.dist is not None:
+            grp.barrier()
+        if not self.is_server:
+            return
+        # ---- the server's state: vocabulary, database, the flattened keyframes the KeyFrame matcher reads
+        all_desc = np.concatenate([d for (_k, _p, d, _T) in agent_kfs]) if agent_kfs else np.zeros((1, 32), np.uint8)
+        voc = synth.make_vocabulary(k=10, L=3, seed=0xB0C, descriptors=all_desc)
+        self.voc_arrays = voc
+        vv, self._vkeep = views.vocab_view(voc["child_start"], voc["child_ids"], voc["desc"], voc["weight"], voc["word_id"], voc["L"])
+        self.vocab_view = vv
+        self.voc = api.ORBVocabulary(vv, self._vkeep, device)
+        self.n_words = int(voc["word_id"].max()) + 1
+        self.KF = api.Frame(self.max_features, device)       # the keyframe being processed
+        self.matcher_bow = api.ORBmatcher(0.9, True, device)     # S/LoopClosing.cc:605-606: matcherBoW(0.9, true), matcher(0.75, true)
+        self.matcher_proj = api.ORBmatcher(0.75, True, device)
+        bows, inv, covis, map_id, self.db_kfs = [], {}, [], [], []
+        for a in range(grp.world):
+            base = len(bows)
+            for j, (n, wire, T) in enumerate(received[a]):
+                self.KF.from_wire(fv, wire=wire, n=n)
+                (bw, bv), (fn, fs, ff) = self.voc.transform(frame=self.KF, levelsup=self.LEVELS_UP)
+                kps, desc = self.KF.download()
+                idx = len(bows)
+                bows.append((bw, bv))
+                for w in bw:
+                    inv.setdefault(int(w), []).append(idx)
+                map_id.append(a)
+                self.db_kfs.append(dict(desc=desc.copy(), angle=np.ascontiguousarray(kps["angle"]).copy(), fv=(fn, fs, ff), Tcw=T, agent=a, slot=j,
+                                        valid=np.ones(n, np.uint8)))
+            n_a = len(bows) - base
+            for j in range(n_a):
+                covis.append([base + q for q in (j - 1, j + 1, j - 2, j + 2, j - 3, j + 3) if 0 <= q < n_a])
+        self.agent_base = np.cumsum([0] + [len(received[a]) for a in range(grp.world)])
+        nk = len(bows)
+        self.db_arrays = dict(inv=inv, bows=bows, covis=covis, map_id=np.asarray(map_id, np.int32), bad=np.zeros(nk, np.uint8),
+                              map_bad=np.zeros(nk, np.uint8), n_words=self.n_words)
+        dv, self._dkeep = views.database_view(inv, bows, covis, self.db_arrays["map_id"], self.db_arrays["bad"], self.db_arrays["map_bad"], self.n_words)
+        self.db_view = dv
+        self.db = api.KeyFrameDatabase(dv, self._dkeep, device)
+        self.place_score = np.zeros(nk, np.float32)
+        self.free = np.full(self.max_features, -1, np.int32)
+        self.LM = api.LocalMap(max(int(server_map_view.m), 1) + 64, device)      # the server's own map handle (never the agent's)
+        self.LM.upload(server_map_view)
+        self.q = queue.Queue()
+        self.error = None
+        self.thread = threading.Thread(target=self._serve, daemon=True)
+        self.thread.start()
+
+    def _serve(self):
+        while True:
+            job = self.q.get()
+            try:
+                if job is None:
+                    return
+                if self.error is None:
+                    self._process(*job)
+            except Exception as e:                           # reported by drain(): a failing server must not hang the agents
+                self.error = e
+            finally:
+                self.q.task_done()
+
+    # ---- agent side
+    def on_keyframe(self, frame, n_features, frame_id, Tcw):
+        """The agent has just tracked a keyframe (device frame `frame`, still resident): pack it; every tick_every-th call is a tick."""
+        t0 = time.perf_counter()
+        w = self.wire[len(self.pending)]
+        frame.n = int(n_features)
+        frame.pack_wire(device_ptr=w.data_ptr())
+        self.pending.append((int(n_features), w, self.np.asarray(Tcw, self.np.float32), int(frame_id)))
+        self.stats["pack_s"] += time.perf_counter() - t0
+        if len(self.pending) >= self.tick_every:
+            self.tick()
+
+    def tick(self):
+        """COLLECTIVE: one all-gather of every agent's pending blocks, then the server's work on rank 0."""
+        np = self.np
+        t0 = time.perf_counter()
+        blocks = [((n, w.cpu(), T) if self.shared_gpu else (n, w, T)) for (n, w, T, _k) in self.pending]
+        self.pending = []
+        b = self.stats["ticks"] & 1
+        if self.busy[b] is not None:
+            self.busy[b].wait()                              # the server thread has finished with this buffer set (two ticks ago)
+        got = self.grp.all_gather_keyframe_blocks(self.bufs2[b], blocks, with_poses=True)
+        t1 = time.perf_counter()
+        self.stats["exchange_s"] += t1 - t0
+        self.stats["ticks"] += 1
+        if not self.is_server:
+            return
+        import threading
+        self.busy[b] = threading.Event()
+        self.q.put((got, self.busy[b]))
+
+    def _process(self, got, done):
+        np = self.np
+        t1 = time.perf_counter()
+        record = []
+        for a, lst in enumerate(got):
+            for (n, blk, T) in lst:
+                before = self.place_score.copy()
+                if self.shared_gpu:
+                    wire_host = blk.numpy().copy()
+                    self.KF.from_wire(self.fv, wire=wire_host, n=n)
+                else:
+                    wire_host = None
+                    self.KF.from_wire(self.fv, n=n, device_ptr=blk.data_ptr())
+                (bw, bv), (fn, fs, ff) = self.voc.transform(frame=self.KF, levelsup=self.LEVELS_UP)
+                # spConnectedKF: the database keyframes of the same agent that the new keyframe is covisible with (its neighbours in time)
+                con = np.zeros(len(self.place_score), np.uint8)
+                lo, hi = int(self.agent_base[a]), int(self.agent_base[a + 1])
+                j = self._nearest_db_slot(a, T)
+                con[max(lo, lo + j - 2): min(hi, lo + j + 3)] = 1
+                loop_c, merge_c = self.db.DetectNBestCandidates(bw, bv, con, a, 3, self.place_score)
+                cand = int(merge_c[0]) if len(merge_c) else int(loop_c[0]) if len(loop_c) else (lo + j + 5) % max(len(self.place_score), 1)
+                c = self.db_kfs[cand]
+                fvK, keepK = self.views.featvec_view(fn, fs, ff)
+                fv1, keep1 = self.views.featvec_view(*c["fv"])
+                m12, nb = self.matcher_bow.SearchByBoWKF(self.KF, fvK, np.ones(n, np.uint8), c["desc"], c["valid"], c["angle"], fv1)
+                matched, nproj = self.matcher_proj.SearchByProjectionSim3(self.KF, T, self.LM, self.free[:n], 8, 1.5)
+                self.stats["blocks"] += 1
+                self.stats["loop_candidates"] += len(loop_c); self.stats["merge_candidates"] += len(merge_c)
+                self.stats["bow_matches"] += int(nb); self.stats["projection_matches"] += int(nproj)
+                record.append(dict(agent=a, n=n, wire=wire_host, blk=blk, T=T, bow=(bw, bv), fv=(fn, fs, ff), con=con, before=before,
+                                   loop=loop_c, merge=merge_c, cand=cand, m12=m12, nb=nb, matched=matched, nproj=nproj))
+        self.last = record
+        self.stats["server_s"] += time.perf_counter() - t1
+        done.set()
+
+    def drain(self):
+        """Every tick exchanged so far has been processed by the server thread (rank 0; a no-op elsewhere)."""
+        if self.is_server:
+            self.q.join()
+            if self.error is not None:
+                raise self.error
+
+    def _nearest_db_slot(self, a, T):
+        """Index (within agent a's database keyframes) of the keyframe whose pose is nearest to T (the sequence revisits its frames)."""
+        np = self.np
+        lo, hi = int(self.agent_base[a]), int(self.agent_base[a + 1])
+        if hi <= lo:
+            return 0
+        d = [float(np.abs(self.db_kfs[q]["Tcw"] - T).sum()) for q in range(lo, hi)]
+        return int(np.argmin(d))
+
+    def flush(self):
+        """COLLECTIVE: a tick for whatever is pending (end of a region), so that every rank leaves with empty hands."""
+        n = self.grp.max_over_ranks(float(len(self.pending)))
+        if n > 0:
+            self.tick()
+
+    def report(self, wall_s=None):
+        s = dict(self.stats)
+        t = max(s["ticks"], 1)
+        out = dict(ticks=s["ticks"], keyframes_per_agent_per_tick=self.tick_every, exchange_us_per_tick=round(1e6 * s["exchange_s"] / t, 1),
+                   pack_us_per_keyframe=round(1e6 * s["pack_s"] / max(s["ticks"] * self.tick_every, 1), 1),
+                   exchange=("gloo over host copies (ranks share a GPU: RCCL refuses two ranks on one device; test aid)" if self.shared_gpu else
+                             ("RCCL all-gather on device memory, %d rank%s" % (self.grp.world, "" if self.grp.world == 1 else "s")) if self.grp.dist is not None
+                             else "single rank: device-to-device copy (no process group)"),
+                   bytes_per_agent_per_tick=int(self.bufs["cap"]),
+                   server_thread="rank 0, a thread of its own next to the agent's tracking thread (handles of its own: KeyFrame, vocabulary, "
+                                 "database, map)")
+        if self.is_server:
+            out.update(server_rank=0, server_us_per_tick=round(1e6 * s["server_s"] / t, 1), blocks=s["blocks"],
+                       database_keyframes=len(self.place_score), vocabulary_words=self.n_words,
+                       loop_candidates=s["loop_candidates"], merge_candidates=s["merge_candidates"], bow_matches=s["bow_matches"],
+                       projection_matches=s["projection_matches"])
+        return out

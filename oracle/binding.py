@@ -28,15 +28,22 @@ def build(force=False):
     return LIB_PATH
 
 
-def use_native():
+def use_native(build=True):
     """Rebuild the oracle with -march=native for THIS host (bench.py's cpu_baseline on the GPU box) and use that build.
-    Must be called before the first oracle call of the process; falls back to the portable build if the compiler fails."""
+    Must be called before the first oracle call of the process; falls back to the portable build if the compiler fails.
+    build=False: only select a native build that another process of this job has made (several ranks on one node must not
+    write the same file at once: local rank 0 builds, the others wait for it and select)."""
     global LIB_PATH, _lib
     if _lib is not None:
         return LIB_PATH
+    native = os.path.join(_HERE, "_native", "liboracle.so")
+    if not build:
+        if os.path.exists(native):
+            LIB_PATH = native
+        return LIB_PATH
     try:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "_native/liboracle.so"])
-        LIB_PATH = os.path.join(_HERE, "_native", "liboracle.so")
+        LIB_PATH = native
     except (subprocess.CalledProcessError, OSError):
         pass
     return LIB_PATH

@@ -261,3 +261,53 @@ def test_self_launched_ranks_and_the_in_job_parity_gate():
     for key in ("extract_bit_exact", "stereo_bit_exact", "match_frame_equal", "match_map_equal", "lba_iters_equal", "lba_outliers_equal"):
         assert pr[key] is True, key
     assert pr["lba_max_abs"] <= 1e-4 and pr["lba_trace_max_rel"] <= 1e-9 and pr["keypoints_checked"] > 30000
+
+
+def _last_json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    assert stdout.strip().splitlines()[-1].startswith("{"), "the JSON line must be the last line of the output"
+    return json.loads(lines[0])
+
+
+def _run_bench(args, share=False, timeout=1200):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ORBG_BENCH_SHARE_GPU")}
+    if share:
+        env["ORBG_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return _last_json_line(r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,agent1", [("C3", "C2"), ("C5", "mono")])
+def test_c3_and_c5_two_agents_with_the_server_tick_in_the_same_job(config, agent1):
+    """BASELINE configs[2] / configs[4] as runnable jobs, here with two ranks on the box's one GPU (ORBG_BENCH_SHARE_GPU=1: the exchange
+    then goes through gloo over host copies -- RCCL refuses two ranks on one device; the 1-rank run below goes through RCCL):
+    per-rank agent kinds, the server tick's collective inside the timed region, the server's outputs equal to the oracle's, and
+    SURVEY Appendix F "Multi-GPU": every agent's outputs equal the 1-rank run of the same agent (no cross-talk)."""
+    common = ["--steps", "40", "--warmup", "5", "--no-secondary", "--no-dropin", "--no-cpu-baseline", "--repeats", "1"]
+    d = _run_bench(["--config", config, "--gpus", "2"] + common, share=True)
+    assert d["n_gpus"] == 2 and d["config"]["name"] == config
+    assert d["config"]["agents"] == (["stereo", "stereo"] if config == "C3" else ["stereo", "mono"])
+    st = d["config"]["server_tick_in_job"]
+    assert st["ticks"] >= 4 and st["blocks"] == 2 * 2 * st["ticks"] and st["database_keyframes"] == 40 and "gloo" in st["exchange"]
+    pr = d["parity"]
+    assert pr["ok"] is True and pr["agents_ok"] == [True, True] and pr["server_tick"]["ok"] is True and pr["server_tick"]["blocks"] == 4
+    for key in ("wire_equal", "bow_equal", "candidates_equal", "bow_matches_equal", "projection_matches_equal"):
+        assert pr["server_tick"][key] is True, key
+    # each agent alone, same seed: identical outputs (the digest covers keypoints, descriptors, stereo data, both match arrays, the local BA)
+    d0 = _run_bench(["--config", "C2", "--first-agent", "0"] + common)
+    d1 = _run_bench(["--config", agent1, "--first-agent", "1"] + common)
+    assert pr["agent_digests"][0] == d0["parity"]["agent_digests"][0] and pr["agent_digests"][1] == d1["parity"]["agent_digests"][0]
+    assert pr["agent_digests"][0] != pr["agent_digests"][1]
+
+
+@pytest.mark.gpu
+def test_c3_server_tick_goes_through_rccl_in_the_timed_region():
+    """One rank: the tick's all-gather is an RCCL collective on device memory (a single-rank group), inside the timed region, next to the
+    agent; the server's results of the last tick equal the oracle's."""
+    d = _run_bench(["--config", "C3", "--steps", "60", "--warmup", "5", "--no-secondary", "--no-dropin", "--no-cpu-baseline", "--repeats", "1"])
+    st = d["config"]["server_tick_in_job"]
+    assert "RCCL" in st["exchange"] and st["ticks"] >= 6 and st["exchange_us_per_tick"] > 0 and st["server_us_per_tick"] > 0
+    assert d["parity"]["ok"] is True and d["parity"]["server_tick"]["ok"] is True and d["value"] > 0
