@@ -116,9 +116,15 @@ struct GpuOps {
                           int far_points, float th_far, float nnratio, int32_t* amp, int32_t* aob, int* n, uint8_t* in_frustum) {
     ThreadState& s = state();
     if (!s.local_map) s.local_map.reset(new MapPointsOnDevice(std::max(pts.m, 16384)));
-    s.local_map->Upload(pts);
+    // Only what does NOT depend on the frame is baked into the resident map: the static fields and isBad() (final once set).  The
+    // per-frame exclusion -- mnLastFrameSeen == F.mnId, S/Tracking.cc:3105-3109 -- belongs to THIS frame: it travels as the call's skip
+    // list, on the uploading call as on every later one (the kernels OR the map's flags with the call's: a skip flag uploaded with
+    // the map would exclude the uploading frame's matches from every later frame that reuses the map).
+    orbm_worldpoints_view up = pts;
+    up.skip = nullptr;
+    s.local_map->Upload(up);
     s.local_map_loaded = true;
-    return orbm_search_local_points_vis(frame(key, v).handle(), s.local_map->handle(), Tcw, nullptr, th, far_points, th_far, nnratio, amp, aob, n,
+    return orbm_search_local_points_vis(frame(key, v).handle(), s.local_map->handle(), Tcw, pts.skip, th, far_points, th_far, nnratio, amp, aob, n,
                                         in_frustum);
   }
   // The same when the STATIC fields of the points (position, normal, distance range, descriptor) are the ones of the previous call
@@ -274,10 +280,24 @@ int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewin
 // copied from the cache and only the new ones are cloned; another map or change index, or kLocalMapMaxAge calls without a refresh (a
 // keyframe whose local BA was aborted re-describes points without moving the index: the bound on that staleness) => everything is
 // read again.  The per-frame fields -- mnLastFrameSeen, isBad(), Observations() -- are read every call, as the reference does.
+//
+// Round 5 -- what the map's change index does NOT cover.  LocalMapping re-describes points WITHOUT moving the index: ProcessNewKeyFrame
+// (AddObservation + UpdateNormalAndDepth + ComputeDistinctiveDescriptors per point of the new keyframe, S/LocalMapping.cc:405-425),
+// SearchInNeighbors' fusions (:857-859, :968-969), Tracking's own new points (S/Tracking.cc:2295-2296, :4053-4055), and a local BA
+// that is aborted returns before IncreaseChangeIndex (S/Optimizer.cc:2127-2129).  Every one of them changes the point's OBSERVATIONS
+// first (the descriptor is the medoid of the observations' descriptors, normal / distance range are functions of the observing
+// keyframes) or its distance members.  So every call compares, per point, what it reads anyway -- Observations() -- and the two raw
+// distance members with the values cached next to the statics: a point whose count or range moved is re-read (three clones for that
+// point only) and the resident map is uploaded again for this call.  What remains assumed: a point's descriptor / normal do not
+// change while its observation count, its distance range and the map's change index all stay the same between two consecutive frames
+// (an erase + add pair on one point within one frame time); kLocalMapMaxAge calls bound even that.  Define
+// ORBGPU_DROPIN_EXACT_LOCAL_MAP to read every point's statics on every call (the reference's cost, no assumption).
+// A Map type without GetMapChangeIndex() does not compile here (there would be no signal for moved points at all).
 constexpr unsigned kLocalMapMaxAge = 30;
 struct LocalMapCache {
   std::vector<const void*> ptrs;
   std::vector<float> pos, nrm, dmin, dmax;
+  std::vector<int32_t> nobs_seen;                  // Observations() when the statics of point i were read
   std::vector<uint8_t> desc, have;                 // have[i]: the statics of point i were read (bad points are never read)
   const void* map = nullptr; long long change_index = -1;
   unsigned age = 0;
@@ -291,7 +311,16 @@ template <class MapPointT> auto change_index_of(MapPointT* p, int) -> decltype((
   auto* m = p->GetMap();
   return m ? (long long)m->GetMapChangeIndex() : 0;
 }
-template <class MapPointT> long long change_index_of(MapPointT*, long) { return 0; }
+// An entry-point set may ask for the reference's exact behaviour (every point's statics read on every call): `static constexpr bool
+// kExactLocalMap = true` (tests/cpp: the oracle's set, so that the product's cache is checked against uncached semantics)
+template <class Ops, class = void> struct exact_local_map : std::false_type {};
+template <class Ops> struct exact_local_map<Ops, typename std::enable_if<Ops::kExactLocalMap>::type> : std::true_type {};
+template <class MapPointT> struct no_change_index : std::false_type {};
+template <class MapPointT> long long change_index_of(MapPointT*, long) {
+  static_assert(no_change_index<MapPointT>::value, "orbgpu::dropin::SearchLocalPoints needs MapPoint::GetMap()->GetMapChangeIndex() (I/Map.h): without it "
+                                                   "nothing signals that the local BA moved the points");
+  return 0;
+}
 
 template <class Ops = GpuOps, class FrameT, class MapPointT>
 int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints, float th, bool bFarPoints, float thFarPoints, float mfNNratio = 0.8f) {
@@ -326,34 +355,49 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
     std::memcpy(&C.pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&C.nrm[3 * (size_t)i], mat_f32(nv), 12);
     C.dmin[i] = p->mfMinDistance; C.dmax[i] = p->mfMaxDistance;
     std::memcpy(&C.desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
+    C.nobs_seen[i] = nobs[i];
     C.have[i] = 1;
   };
-  const bool fresh = C.ptrs.empty() || C.map != map || C.change_index != ci || C.age >= kLocalMapMaxAge;
+  // a cached point is DIRTY when its observation count or its distance range is not what it was when its statics were read
+  auto dirty = [&](int i) {
+    const MapPointT* p = vpLocalMapPoints[i];
+    return C.nobs_seen[i] != nobs[i] || C.dmin[i] != p->mfMinDistance || C.dmax[i] != p->mfMaxDistance;
+  };
+#ifdef ORBGPU_DROPIN_EXACT_LOCAL_MAP
+  const bool fresh = true;
+#else
+  const bool fresh = exact_local_map<Ops>::value || C.ptrs.empty() || C.map != map || C.change_index != ci || C.age >= kLocalMapMaxAge;
+#endif
   bool statics_same = false;
   if (!fresh && (int)C.ptrs.size() == M && std::memcmp(C.ptrs.data(), vpLocalMapPoints.data(), sizeof(void*) * (size_t)M) == 0) {
     statics_same = true;
-    for (int i = 0; i < M; i++)                      // (a point that was bad when the cache was filled cannot come back: isBad is final)
-      if (!C.have[i] && !bad[i]) { read_statics(i); statics_same = false; }
+    for (int i = 0; i < M; i++) {                    // (a point that was bad when the cache was filled cannot come back: isBad is final)
+      if (bad[i]) continue;
+      if (!C.have[i] || dirty(i)) { read_statics(i); statics_same = false; }
+    }
     C.age++;
   } else if (!fresh) {
     // another pointer sequence on the same map state: keep what is known, read the new points
     if (!C.index_valid) { C.index.clear(); C.index.reserve(C.ptrs.size() * 2); for (size_t j = 0; j < C.ptrs.size(); j++) if (C.have[j]) C.index.emplace(C.ptrs[j], (int)j); }
     std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M); std::vector<uint8_t> desc(32 * (size_t)M), have(M, 0);
+    std::vector<int32_t> seen(M, 0);
     std::vector<int> todo;
     for (int i = 0; i < M; i++) {
       const auto it = C.index.find((const void*)vpLocalMapPoints[i]);
-      if (it != C.index.end()) {
-        const size_t j = (size_t)it->second;
+      const MapPointT* p = vpLocalMapPoints[i];
+      const size_t j = it != C.index.end() ? (size_t)it->second : 0;
+      if (it != C.index.end() && !bad[i] && C.nobs_seen[j] == nobs[i] && C.dmin[j] == p->mfMinDistance && C.dmax[j] == p->mfMaxDistance) {
         std::memcpy(&pos[3 * (size_t)i], &C.pos[3 * j], 12); std::memcpy(&nrm[3 * (size_t)i], &C.nrm[3 * j], 12);
-        dmin[i] = C.dmin[j]; dmax[i] = C.dmax[j]; std::memcpy(&desc[32 * (size_t)i], &C.desc[32 * j], 32); have[i] = 1;
+        dmin[i] = C.dmin[j]; dmax[i] = C.dmax[j]; std::memcpy(&desc[32 * (size_t)i], &C.desc[32 * j], 32); have[i] = 1; seen[i] = C.nobs_seen[j];
       } else if (!bad[i]) todo.push_back(i);
     }
-    C.pos.swap(pos); C.nrm.swap(nrm); C.dmin.swap(dmin); C.dmax.swap(dmax); C.desc.swap(desc); C.have.swap(have);
+    C.pos.swap(pos); C.nrm.swap(nrm); C.dmin.swap(dmin); C.dmax.swap(dmax); C.desc.swap(desc); C.have.swap(have); C.nobs_seen.swap(seen);
     C.ptrs.assign((const void* const*)vpLocalMapPoints.data(), (const void* const*)vpLocalMapPoints.data() + M);
     for (int i : todo) read_statics(i);
     C.index_valid = false; C.age++;
   } else {
     C.pos.assign(3 * (size_t)M, 0.f); C.nrm.assign(3 * (size_t)M, 0.f); C.dmin.assign(M, 0.f); C.dmax.assign(M, 0.f); C.desc.assign(32 * (size_t)M, 0); C.have.assign(M, 0);
+    C.nobs_seen.assign(M, 0);
     C.ptrs.assign((const void* const*)vpLocalMapPoints.data(), (const void* const*)vpLocalMapPoints.data() + M);
     for (int i = 0; i < M; i++) if (!bad[i]) read_statics(i);
     C.map = map; C.change_index = ci; C.age = 0; C.index_valid = false;

@@ -79,8 +79,15 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* _
                                                          volatile unsigned* done_flag, unsigned done_seq) {
   grid_build_body<1024>(kps, fp, cell_of, cell_start, cell_items, d_n);
   if (done_flag) {
+    // The host may act on the word BEFORE this kernel has ended (it launches the frame's searches on another stream): every
+    // wavefront's grid stores must have reached the L2 (vmcnt) and the L2 must have been written back (one agent-scope release by the
+    // posting thread: a search on another XCD reads the grid through ITS L2) before the word is written.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) *done_flag = done_seq;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      *done_flag = done_seq;
+    }
   }
 }
 
@@ -103,9 +110,13 @@ __global__ __launch_bounds__(1024) void undistort_grid_kernel(orbg::UndistortArg
   // (grid_build_body's thread t reads the records t, t + 1024, ... -- the ones it has just written)
   grid_build_body<1024>(ua.dst, fp, cell_of, cell_start, cell_items, d_n);
   if (done_flag) {
-    if (ua.dst_host) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (ua.dst_host) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // mvKeysUn for the host: system scope, every wavefront
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (see grid_build_kernel)
     __syncthreads();
-    if (threadIdx.x == 0) *done_flag = done_seq;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      *done_flag = done_seq;
+    }
   }
 }
 
@@ -120,6 +131,9 @@ __global__ __launch_bounds__(1024) void grid_build_finalize_kernel(const orbx_ke
                                                                   volatile unsigned* done_flag, unsigned done_seq, StereoFinalizeArgs fin) {
   if (blockIdx.x == 0) {
     grid_build_body<1024>(kps, fp, cell_of, cell_start, cell_items, d_n);
+    // every wavefront's grid stores have reached the L2 before thread 0's agent-scope release (the ticket below) writes it back: the
+    // host may launch the frame's searches -- on another stream, possibly another XCD -- as soon as it sees the completion word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     if (threadIdx.x >= 256) return;              // (whole wavefronts: a barrier only counts wavefronts that are still alive)
     stereo_finalize_body(fin.uright, fin.depth, fin.best_sad, fin.nl, fin.d_nkp, fin.host_out);

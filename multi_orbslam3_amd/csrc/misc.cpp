@@ -52,7 +52,12 @@ bool poll_allowed() { return !((block_mask().load(std::memory_order_relaxed) >> 
 void set_thread_role(int role) { if (role >= 0 && role < kRoleCount) t_role = role; }
 
 namespace {
-struct DevicePool { bool made = false; hipStream_t L = nullptr, E[2] = {nullptr, nullptr}, M = nullptr; unsigned n_ex = 0, n_fr = 0; };
+struct DevicePool {
+  bool made = false; hipStream_t L = nullptr, E[2] = {nullptr, nullptr}, M = nullptr; unsigned n_ex = 0, n_fr = 0;
+  // orbg_quiesce's completion words: per DEVICE (pinned words belong to the device that was current when they were allocated), one
+  // caller at a time (q_mu); they live as long as the pool
+  std::mutex q_mu; StreamSignal q_sig[4];
+};
 std::mutex g_pool_mu;
 DevicePool g_pool[64];
 bool pool_enabled() { static const bool on = [] { const char* e = getenv("ORBG_STREAM_POOL"); return !(e && e[0] == '0'); }(); return on; }
@@ -162,7 +167,9 @@ extern "C" int orbg_quiesce(int device) {
     st[0] = P.L; st[1] = P.E[0]; st[2] = P.E[1]; st[3] = P.M;
   }
   ORBG_HIP(hipSetDevice(device));
-  static thread_local StreamSignal sig[4];
+  DevicePool& Pq = g_pool[device];
+  std::lock_guard<std::mutex> qlk(Pq.q_mu);
+  StreamSignal* sig = Pq.q_sig;
   int rc;
   for (int i = 0; i < 4; i++) if ((rc = sig[i].post(st[i]))) return rc;
   for (int i = 0; i < 4; i++) if ((rc = sig[i].wait(st[i]))) return rc;

@@ -25,6 +25,7 @@ namespace od = orbgpu::dropin;
 
 struct OracleOps {       // the same entry points over the CPU oracle: views instead of device handles
   static constexpr bool kUsesResidentFrame = false;
+  static constexpr bool kExactLocalMap = true;      // the reference's semantics: every point's fields are read on every call (no cache)
   static int is_in_frustum(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim, uint8_t* in_view,
                            float* px, float* py, float* pxr, float* depth, int32_t* level, float* vcos) {
     return oracle_is_in_frustum(&v, Tcw, &pts, lim, in_view, px, py, pxr, depth, level, vcos);
@@ -104,6 +105,7 @@ static std::vector<int> assignment_ids(const Frame& F, const std::vector<MapPoin
 }
 
 struct TrackOut { int n_visible, n_map, n_frame, n_bow, n_pose, n_fused, vis_sum; std::vector<int> a_map, a_frame, a_bow, a_fused; std::vector<bool> outl; std::vector<float> pose;
+                  std::vector<std::vector<int>> a_varied; std::vector<int> vis_varied;
                   std::vector<int> a_cached, a_stale, a_moved, a_delta, a_delta_fresh;
                   int n_reloc1 = 0, n_reloc2 = 0; std::vector<int> a_reloc; };
 
@@ -143,6 +145,41 @@ static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_
       return assignment_ids(F2, local);
     };
     o.a_cached = again(local, 78);
+    // ---- per-frame state that CHANGES between the call that uploaded the resident map and the calls that reuse it (same pointers,
+    // same change index): other features hold points (the previous frame's exclusions must not stick to the map), points turn bad,
+    // Observations() move, and LocalMapping re-describes points without touching the change index (ProcessNewKeyFrame: observation
+    // + descriptor + distance range, S/LocalMapping.cc:405-425) -- each call against the oracle's set, which reads everything fresh
+    {
+      auto varied = [&](unsigned long id, int hold_from, int hold_to) {
+        std::fill(F2.mvpMapPoints.begin(), F2.mvpMapPoints.end(), nullptr);
+        F2.mnId = id;
+        for (auto* p : local) { p->mbTrackInView = false; p->mnVisible = 1; }
+        int seen = 0;
+        for (int i = 0; i < F2.N; i++) if (o.a_map[i] >= 0) { if (seen >= hold_from && seen < hold_to) F2.mvpMapPoints[i] = local[o.a_map[i]]; seen++; }
+        od::SearchLocalPoints<Ops>(F2, local, 3.0f, false, 50.0f, 0.8f);
+        o.a_varied.push_back(assignment_ids(F2, local));
+        int vs = 0;
+        for (auto* p : local) vs += p->mnVisible + 1000 * (int)p->mbTrackInView;
+        o.vis_varied.push_back(vs);
+      };
+      od::local_map_cache<Ops>().invalidate();
+      varied(90, 0, 60);                                   // uploads the map: features 0..59 of the matched ones hold their points
+      varied(91, 60, 120);                                 // cached map, OTHER held features: the first 60 points are candidates again
+      varied(92, 0, 0);                                    // nothing held
+      for (size_t j = 3; j < local.size(); j += 29) local[j]->mbBad = true;       // points culled by LocalMapping between two frames
+      varied(93, 30, 90);
+      for (size_t j = 1; j < local.size(); j += 7) local[j]->nObs = (local[j]->nObs + 1) % 3;     // Observations() moved (0 lets a feature be overwritten, S/ORBmatcher.cc:89-91)
+      varied(94, 30, 90);
+      for (size_t j = 2; j < local.size(); j += 5) {       // ProcessNewKeyFrame: one more observation, another medoid descriptor, a wider distance range
+        MapPoint* p = local[j], *q = local[(j + 11) % local.size()];
+        p->nObs += 1; p->mDescriptor = q->mDescriptor; p->mfMaxDistance *= 1.3f; p->mfMinDistance *= 0.8f;
+      }
+      varied(95, 10, 50);
+      varied(96, 50, 10);                                  // (nothing held) the re-described points once more, from the refreshed cache
+    }
+    od::local_map_cache<Ops>().invalidate();
+    for (auto* p : local) p->mbBad = false;
+    for (size_t j = 0; j < local.size(); j++) local[j]->mbBad = (j % 41) == 7;
     std::vector<Mat> saved;
     for (size_t j = 0; j < local.size(); j += 3) { saved.push_back(local[j]->mWorldPos); local[j]->mWorldPos.ptr<float>(0)[2] += 40.0f; }
     o.a_stale = again(local, 79);
@@ -252,6 +289,14 @@ int main() {
       auto ndiff = [](const std::vector<int>& a, const std::vector<int>& b) { int d = (int)(a.size() != b.size()); for (size_t i = 0; i < a.size() && i < b.size(); i++) d += a[i] != b[i]; return d; };
       EXPECT(g.a_cached == g.a_fused && c.a_cached == c.a_fused, "SearchLocalPoints on the cached local map differs from the first call (%d / %d features)",
              ndiff(g.a_cached, g.a_fused), ndiff(c.a_cached, c.a_fused));
+      EXPECT(g.a_varied.size() == 7 && c.a_varied.size() == 7, "varied-state calls missing");
+      for (size_t q = 0; q < g.a_varied.size() && q < c.a_varied.size(); q++) {
+        int nm = 0; for (int v : g.a_varied[q]) nm += v >= 0;
+        EXPECT(g.a_varied[q] == c.a_varied[q] && g.vis_varied[q] == c.vis_varied[q] && nm > 100,
+               "SearchLocalPoints with changing per-frame state, call %zu: %d features differ from the oracle's fresh read (visible sums %d vs %d, %d matched)", q,
+               ndiff(g.a_varied[q], c.a_varied[q]), g.vis_varied[q], c.vis_varied[q], nm);
+      }
+      EXPECT(ndiff(g.a_varied[0], g.a_varied[1]) > 0 && ndiff(g.a_varied[4], g.a_varied[5]) > 0, "the varied-state calls do not exercise anything");
       EXPECT(g.a_stale == g.a_fused, "moved points were noticed without a change of the map's change index (%d features)", ndiff(g.a_stale, g.a_fused));
       EXPECT(g.a_moved == c.a_moved && ndiff(g.a_moved, g.a_fused) > 20, "after IncreaseChangeIndex: %d features differ between the entry-point sets, %d from the unmoved map",
              ndiff(g.a_moved, c.a_moved), ndiff(g.a_moved, g.a_fused));
