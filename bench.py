@@ -518,7 +518,7 @@ def main():
                          "--separate-calls / --profile-stages always use it)")
     ap.add_argument("--submit-order", choices=["before-wait", "after-wait"], default="before-wait",
                     help="pipelined constructor: hand frame t+1 over before or after frame t's constructor is collected")
-    ap.add_argument("--ctor-ahead", type=int, default=int(os.environ.get("ORBG_BENCH_CTOR_AHEAD", "1")), choices=[1, 2, 3],
+    ap.add_argument("--ctor-ahead", type=int, default=1, choices=[1, 2, 3],
                     help="pipelined constructor: frames handed over ahead of the one being tracked (ring of N + 1 extractor handles / frame "
                          "objects; the python loop supports 1)")
     ap.add_argument("--no-host-features", action="store_true",
@@ -687,10 +687,10 @@ def main():
     po2, po2_keep = views.pose_opt_problem(po_prob2["Xw"], po_prob2["u"], po_prob2["v"], po_prob2["ur"], po_prob2["inv_sigma2"],
                                           po_prob2["cam"], po_prob2["Tcw"], device=device)
     for e in exs:
-        e.set_profiling(0 if os.environ.get("ORBG_BENCH_NO_BRACKETS") else 2 if args.profile_stages else 1)     # (experiment switch: no event brackets at all)
+        e.set_profiling(2 if args.profile_stages else 1)
     ev_overhead_ms = ex.event_overhead_ms(100)
     lba_ev_overhead_ms = opt.event_overhead_ms(100)
-    opt.set_profiling(not os.environ.get("ORBG_BENCH_NO_BRACKETS"), reset=True)
+    opt.set_profiling(True, reset=True)
     FAST_BRACKET_EVERY = 1 if args.profile_stages else 4         # the event pair costs ~5 us of stream time: sample every 4th frame
     th_frame, mono_flag = (7.0, False) if stereo else (15.0, True)
 
@@ -1025,7 +1025,7 @@ def main():
     for e in exs:
         e.set_profile_interval(FAST_BRACKET_EVERY, reset=True)       # every handle brackets every 4th of ITS frames: one frame in four overall,
                                                                       # whatever the size of the ring (an event pair holds the stream for ~2 x 10 us)
-    opt.set_profiling(not os.environ.get("ORBG_BENCH_NO_BRACKETS"), reset=True)
+    opt.set_profiling(True, reset=True)
     reg, elapsed = run_region(args.steps, args.warmup, args.pose_opt, host_images, pipeline, prewarm_done)
     # what the shared host did to the region: involuntary context switches of this process's threads inside it, and how busy
     # OTHER tenants keep the hardware threads of the agent's cores right after it (this process sleeps during the sample)
@@ -1132,17 +1132,6 @@ def main():
         # duration from a HIP event pair on the local BA's stream (one bracketed launch per solve) minus the empty-pair cost
         n_unk = solver_unknowns
         ldlt_flops = n_unk ** 3 / 3.0 + 2.0 * n_unk ** 2
-        # windows of <= 20 free poses, ORBG_FUSE_UPDATE=1: the LDL^T workgroup and the state update's workgroups are ONE launch
-        # (k_ldlt_cols_update; the default from the end of round 3 until the hand-over got its agent-scope release in round 4, which
-        # costs more than the kernel boundary it saves: two launches again) -- the bracket then times both, and the launch's
-        # algorithmic FLOPs are the solve's plus the update's (per observation of a free pose H_pl^T dx: 72; per landmark a 3 x 3 solve: ~60)
-        fused_update = bool(solver_mfma) and (((((n_unk + 3) & ~3) + 1) + 15) // 16) <= 8 and os.environ.get("ORBG_FUSE_UPDATE", "0") not in ("0", "")
-        upd_flops = 0.0
-        if fused_update:
-            free = np.asarray(prob["pose_fixed"]) == 0
-            upd_flops = 72.0 * float(free[np.asarray(prob["edges"]["pose"])].sum()) + 60.0 * len(prob["points"])
-        ldlt_only_flops = ldlt_flops
-        ldlt_flops = ldlt_flops + upd_flops
         ldlt_ms_raw = solver_sum_ms / max(solver_n, 1)
         ldlt_ms = max(ldlt_ms_raw - lba_ev_overhead_ms, 1e-6)
         ldlt_tflops = ldlt_flops / (ldlt_ms * 1e-3) / 1e12 if solver_n else 0.0
@@ -1162,8 +1151,8 @@ def main():
         lm_per_ba = stats["lba_iters"] / max(stats["lba_calls"], 1)
         # the variant ldltm::pick() chooses for this many unknowns (tile rows T of the bordered matrix)
         ldlt_T = ((((n_unk + 3) & ~3) + 1) + 15) // 16
-        ldlt_name = (("k_ldlt_cols_update" if fused_update else "ldltm::k_ldlt_cols" if ldlt_T <= 8 else "ldltm::k_ldlt_mfma" if ldlt_T <= 9 else
-                      "ldltm::k_ldlt_big" if ldlt_T <= 15 else "ldltm::k_ldlt_big48") if solver_mfma else "k_ldlt_flow / k_ldlt_rows")
+        ldlt_name = (("ldltm::k_ldlt_cols" if ldlt_T <= 8 else "ldltm::k_ldlt_mfma" if ldlt_T <= 9 else
+                      "ldltm::k_ldlt_big" if ldlt_T <= 15 else "ldltm::k_ldlt_big48") if solver_mfma else "k_wide_panel / k_wide_update")
         per_step = {ldlt_name: ldlt_ms * lm_per_ba / FRAMES_PER_KF if solver_n else 0.0, "fast_cells_kernel": fast_ms if fast_n else 0.0}
         for kname, (kms, kn) in chain_ms.items():
             per_step[kname] = kms
@@ -1236,17 +1225,14 @@ def main():
             "roofline": {"kernel": ldlt_name,
                          "bound": "mfma", "achieved": round(ldlt_tflops, 6), "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ldlt_tflops / FP64_MATRIX_PEAK_TFLOPS, 8), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_flops_per_launch": int(ldlt_flops), "ldlt_flops": int(ldlt_only_flops), "state_update_flops": int(upd_flops),
+                         "algorithmic_flops_per_launch": int(ldlt_flops),
                          "unknowns": int(n_unk), "launches_per_local_ba": round(stats["lba_iters"] / max(stats["lba_calls"], 1), 2),
                          "avg_launch_ms": round(ldlt_ms, 5), "avg_launch_ms_event_bracket_raw": round(ldlt_ms_raw, 5),
                          "event_pair_overhead_ms": round(lba_ev_overhead_ms, 5), "bracketed_launches": int(solver_n),
                          "peak_source": "AMD MI355X spec sheet, FP64 matrix 78.6 TF (MI355X_MICROARCH.md has no FP64 row); measured issue rate "
                                         "of v_mfma_f64_16x16x4_f64: 1 per 66 cycles per SIMD = 76 TF at 2.4 GHz (tools/micro/mfma_f64_latency.hip)",
                          "note": "a 120 x 120 LDL^T + solve is 0.6 MFLOP on a dependent chain of 120 pivots (one workgroup): "
-                                 "time-to-solution is the figure of merit, the FLOP fraction is reported as the contract asks"
-                                 + ("; the launch is k_ldlt_cols_update: the LDL^T workgroup (19.2 us alone, tools/micro/ldlt_neighbours) plus "
-                                    "the state update's workgroups, which start with it and finish after x is published -- one dispatch "
-                                    "less per LM iteration; ORBG_FUSE_UPDATE=0 gives the two launches of the earlier rounds' lines" if fused_update else "")},
+                                 "time-to-solution is the figure of merit, the FLOP fraction is reported as the contract asks"},
         }
         # ---- the diagnosis of THIS run as top-level scalars (nested objects do not survive into the driver's record)
         line["value_min"] = round(min(repeat_values), 3); line["value_median"] = round(float(np.median(repeat_values)), 3)

@@ -114,9 +114,8 @@ struct StreamSignal {
 // application it is embedded in.  An application that itself keeps streams busy should run with GPU_MAX_HW_QUEUES >= 4 + its own
 // (include/orbgpu.h, "Streams"), or hand the library its streams: every handle type has a *_set_stream entry point.
 // Handles that share a stream stay correct -- every completion signal is enqueued behind the handle's own work on an in-order
-// stream -- they merely do not overlap.  ORBG_STREAM_POOL=0 gives every handle a stream of its own again (ORBG_PRIO_<ROLE> =
-// -1 / 1 then picks a HIP stream priority for the role: priorities open further hardware queues and were slower in every
-// combination tried).  Implemented in misc.cpp (one registry for all translation units).
+// stream -- they merely do not overlap.  ORBG_STREAM_POOL=0 gives every handle a stream of its own again.  Implemented in misc.cpp
+// (one registry for all translation units).
 hipError_t create_stream(hipStream_t* st, const char* role);
 void release_stream(hipStream_t st);       // destroys a stream of its own; pool streams live as long as the process
 bool is_library_stream(hipStream_t st);    // one of the pool's streams (shared between handles: never capture on it, never destroy it)

@@ -560,14 +560,13 @@ __device__ long long g_oct_prof[32][48];
 #define OCT_T(slot) do { } while (0)
 #endif
 
-// FROM_SLOTS (round 4, the default): the workgroup takes its candidates straight from fast_cells_kernel's per-cell slots -- the
+// The workgroup takes its candidates straight from fast_cells_kernel's per-cell slots -- the
 // cells of a (camera, level) are a contiguous run, cell-major order IS the candidate order -- instead of from the compacted list
 // gather_cells_kernel wrote (one launch less per constructor).  A thread owns a contiguous chunk of the level's cells: it requests
 // their counts and, in the same trip to memory, the first eight slot entries of each (most cells hold fewer); a workgroup scan of
 // the counts gives every cell its place in an LDS staging array (the not-yet-used second node list), the entries go there, and
 // the keys are then dealt to the threads from LDS exactly as they were from the compacted list.
 constexpr int kOctSpecCells = 4;     // cells per thread whose first entries are requested before their counts are known
-template <bool FROM_SLOTS>
 __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __restrict__ cand, const int* __restrict__ hdr,
                                                             PyrGeom g, OctCfg cfg, OctSel* __restrict__ sel_out,
                                                             int* __restrict__ lvl_count, int* __restrict__ overflow, int cand_cap,
@@ -592,7 +591,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
   uint32_t kw[kOctKPT];
   unsigned kn[kOctKPT];
   int nk;
-  if constexpr (FROM_SLOTS) {
+  {
     uint32_t* const stage = reinterpret_cast<uint32_t*>(&node[1][0]);     // 32 KB, first written by the first pass (behind barriers)
     static_assert(sizeof(uint4) * kOctListCap >= sizeof(uint32_t) * kOctKeyCap, "staging does not fit the second node list");
     const int nc = L.cell_end - L.cell_begin;
@@ -642,23 +641,6 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const uint32_t* __r
 #pragma unroll
     for (int m = 0; m < kOctKPT; m++) kw[m] = stage[min(tid + kOctThreads * m, nk - 1)];
     // (the first pass writes node[1] only behind the barriers of the root set-up below)
-  } else {
-  // candidate range of this (camera, level): next level that has cells, or the camera end.  Both header words come from ONE
-  // fetch (lane l reads word l of the 2 x 16 + 3 word header; picking them by two dependent loads cost a memory round trip more)
-  static_assert(2 * ORBG_MAX_LEVELS + 3 <= 64, "header does not fit one wavefront-wide load");
-  const int hword = hdr[min(tid & 63, 2 * ORBG_MAX_LEVELS + 2)];
-  int nlv = level + 1;
-  while (nlv < cfg.n_levels && g.lv[nlv].cell_end == g.lv[nlv].cell_begin) nlv++;
-  const int cb = __builtin_amdgcn_readlane(hword, cam * ORBG_MAX_LEVELS + level);
-  const int ce = __builtin_amdgcn_readlane(hword, nlv < cfg.n_levels ? cam * ORBG_MAX_LEVELS + nlv : 2 * ORBG_MAX_LEVELS + 1 + cam);
-  nk = ce - cb;
-  if (nk <= 0) { if (tid == 0) *out_count = 0; return; }
-  // ce > cand_cap: gather_cells_kernel dropped the tail of the list, the host path regrows the buffer and redoes the frame
-  if (nk > kOctKeyCap || 4 * N + 8 > kOctListCap || ce > cand_cap) { if (tid == 0) { *overflow = 1; *out_count = 0; } return; }
-  // ---- this thread's keys: k = tid, tid + 256, ...  (kw: x | y << 12 | response << 24;  kn: list position | quadrant << 16 |
-  // "its node is being split" << 18)
-#pragma unroll
-  for (int m = 0; m < kOctKPT; m++) kw[m] = cand[cb + min(tid + kOctThreads * m, nk - 1)];
   }
   const int minB = kEdge - 3;
   const int W = (L.w - kEdge + 3) - minB, H = (L.h - kEdge + 3) - minB;   // maxX-minX, maxY-minY
@@ -1493,61 +1475,6 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const uint8_t* __rest
   stereo_match_wave(blockIdx.x * 4 + (threadIdx.x >> 6), pyr, g, kl, dl, nl, kr, dr, nr, bf, b, uright, depth, best_sad, d_nkp);
 }
 
-// Tail of the fused stereo Frame constructor as ONE launch of 1024-thread workgroups (round 4, ORBG_CTOR_FUSED_TAIL=1; the default
-// stays stereo_match_kernel, then grid_build_finalize_kernel -- see extract_core for the measurements):
-//   workgroups 0 .. n_match-1   ComputeStereoMatches, 16 left keypoints each (one wavefront per keypoint)
-//   workgroup  n_match          the feature grid of the left image (it needs the keypoints only: independent of the matching)
-// The match workgroups take a ticket when their results are out; the one that takes the LAST ticket runs the median rejection
-// (S/Frame.cc:949-962: it needs every match) on its first four wavefronts.  That workgroup and the grid workgroup then take the
-// constructor's two-party ticket; whoever is second posts the completion word the host spins on.
-// Hand-over through device memory between workgroups on different XCDs: every wavefront drains its own stores (vmcnt(0)) before
-// the workgroup barrier, thread 0 then takes the ticket with an agent-scope acq_rel (L2 write-back in front of it, invalidate
-// behind it); the rejection mirrors its result into pinned host memory, so its workgroup releases to system scope before the
-// second ticket.
-constexpr int kSgThreads = 1024;
-__global__ __launch_bounds__(kSgThreads) void stereo_grid_kernel(const uint8_t* __restrict__ pyr, PyrGeom g,
-                                                                 const orbx_keypoint* __restrict__ kl, const uint8_t* __restrict__ dl, int nl_bound,
-                                                                 float bf, float b, float* __restrict__ uright, float* __restrict__ depth,
-                                                                 int* __restrict__ best_sad, const int* __restrict__ d_nkp, int n_match,
-                                                                 orbg::GridLaunchArgs ga, volatile unsigned* done_flag, unsigned done_seq,
-                                                                 float* __restrict__ host_mirror, unsigned* __restrict__ tickets /*[0] match, [1] final*/) {
-  __shared__ int s_last;
-  bool second_party = false;
-  if ((int)blockIdx.x == n_match) {
-    orbg::grid_build_body<kSgThreads>(ga.kps, ga.fp, ga.cell_of, ga.cell_start, ga.cell_items, d_nkp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    second_party = true;
-  } else {
-    stereo_match_wave(blockIdx.x * (kSgThreads / 64) + (threadIdx.x >> 6), pyr, g, kl, dl, nl_bound, nullptr, nullptr, 0, bf, b, uright, depth,
-                      best_sad, d_nkp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      // RELEASE only: an acquire here would invalidate this XCD's L2 under the match workgroups that are still running on it;
-      // the one workgroup that goes on to read the others' results acquires below
-      const unsigned before = __hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = before == (unsigned)(n_match - 1);
-      if (s_last) __hip_atomic_store(&tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x >= 256) return;              // (whole wavefronts leave: the barriers below count the four that stay)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    stereo_finalize_body(uright, depth, best_sad, nl_bound, d_nkp, host_mirror);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system-scope release (no acquire half: no L2 invalidation)
-    __syncthreads();
-    second_party = true;
-  }
-  if (second_party && threadIdx.x == 0) {
-    const unsigned before = __hip_atomic_fetch_add(&tickets[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (before == 1u) {
-      __hip_atomic_store(&tickets[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (done_flag) *done_flag = done_seq;
-    }
-  }
-}
-
 // (stereo_finalize_body: stereo_finalize.hpp)
 __global__ __launch_bounds__(256) void stereo_finalize_kernel(float* __restrict__ uright, float* __restrict__ depth,
                                                              const int* __restrict__ best_sad, int nl, const int* __restrict__ d_nkp,
@@ -1795,11 +1722,7 @@ class WorkerPool {
 // ------------------------------------------------------------------------------------------------
 // handle
 
-static const bool g_oct_gather = getenv("ORBG_OCT_GATHER") && atoi(getenv("ORBG_OCT_GATHER")) != 0;
-static const bool g_ctor_fused_tail = getenv("ORBG_CTOR_FUSED_TAIL") && atoi(getenv("ORBG_CTOR_FUSED_TAIL")) != 0;
 static inline double host_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec; }
-// Measured on MI355X / ROCm 7.2: hipGraphLaunch of the constructor chain costs the host what its launches cost: off unless asked for
-static const bool g_ctor_graph = getenv("ORBG_CTOR_GRAPH") && atoi(getenv("ORBG_CTOR_GRAPH")) != 0;
 
 struct orbx_handle {
   bool ext_stream = false;                    // `stream` was handed in through orbx_set_stream (never destroyed here)
@@ -1858,7 +1781,6 @@ struct orbx_handle {
   double fast_ms_sum = 0; long fast_ms_n = 0;   // accumulated bracket times of the bracketed kernel (fast_cells_kernel by default)
   int taps_variant = 0;             // 0 / 1: one of the two compiled-in blur kernels, 2: run-time taps (orient_desc_wave)
   int prof_kernel = 0;              // which kernel of the chain the level-1 event pair brackets: ORBX_PROF_*
-  struct CtorGraph* cgraph = nullptr;          // captured kernel chain of the device-resident Frame constructor
   // host images (orbx_frame_stereo_submit / orbx_frame_stereo / orbx_extract*): one pinned staging slot per handle -- a handle
   // has one submission in flight, and the slot is free again when that submission has been waited for
   PinnedBuf<uint8_t> h_img;
@@ -2136,15 +2058,14 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     h->taps_variant = (gt[0] == 18 && gt[1] == 34 && gt[2] == 49 && gt[3] == 55) ? 0 : (gt[0] == 18 && gt[1] == 34 && gt[2] == 48 && gt[3] == 56) ? 1 : 2;
   }
   {
-    int nthreads = 5;
-    if (const char* env = getenv("ORBG_OCTREE_THREADS")) nthreads = std::max(0, std::min(atoi(env), 15));
+    const int nthreads = 5;                        // host quad-tree workers (the fallback path; they sleep unless it is taken)
     if (const char* env = getenv("ORBG_HOST_OCTREE")) h->gpu_octree = atoi(env) == 0;
     h->pool.reset(new WorkerPool(nthreads));
     h->qts.resize(nthreads + 1);
     for (auto& q : h->qts) q.oldest_first_ = cfg->octree_oldest_first != 0;
   }
   // (ORBG_CTOR_GRAPH=1 captures the constructor chain on the handle's stream: that stream must not be shared with other handles)
-  if ((g_ctor_graph ? hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) : orbg::create_stream(&h->stream, "ex")) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
+  if (orbg::create_stream(&h->stream, "ex") != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   for (auto& e : h->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete h; return ORBG_HIP_ERROR; }
   const int cap = 2 * (cfg->n_features + 4 * nl + 64);
@@ -2162,7 +2083,6 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_handle** out) {
   return ORBG_OK;
 }
 
-static void ctor_graph_free(struct CtorGraph* g);
 
 
 extern "C" int orbx_destroy(orbx_handle* h) {
@@ -2170,7 +2090,6 @@ extern "C" int orbx_destroy(orbx_handle* h) {
   (void)hipSetDevice(h->device);
   while (h->ingest_state.load(std::memory_order_acquire) == 1) std::this_thread::yield();   // an asynchronous submission is being enqueued
   (void)hipStreamSynchronize(h->stream);
-  ctor_graph_free(h->cgraph);
   h->d_pyr.release(); h->d_img.release(); h->h_img.release(); h->up_ready.release(); h->d_xtab.release(); h->d_ytab.release(); h->d_tower_x.release(); h->d_tower_y.release(); h->d_cells.release();
   h->d_slots.release(); h->d_counts.release(); h->hdr.release(); h->cand.release(); h->sel.release();
   h->d_kps.release(); h->d_desc.release(); h->h_kps.release(); h->h_desc.release();
@@ -2232,7 +2151,6 @@ struct ExtractPending {
   int n_res[2] = {0, 0};
 };
 static void delete_pending(ExtractPending* p) { delete p; }
-int orbm_internal_attach_prepare(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, hipStream_t stream, orbg::GridLaunchArgs* out);   // matcher.hip
 int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, int n, hipStream_t stream, const int* d_n,
                          volatile unsigned* done_flag, unsigned done_seq, const StereoFinalizeArgs* fin, const orbg::UndistortArgs* un = nullptr,
                          bool mono = false);
@@ -2253,41 +2171,6 @@ void orbm_internal_set_n(orbm_frame* f, int n);
 int orbx_internal_kp_capacity(orbx_handle* h);
 static int launch_stereo(orbx_handle* h, float bf, float b, hipStream_t st, bool device_counts, float* host_mirror,
                          StereoFinalizeArgs* defer_finalize = nullptr);
-
-// The device-resident Frame constructor is a fixed chain of kernels (pyramid, FAST, gather, quad-trees, descriptors, stereo):
-// only the image pointers change from call to call.  Submitting it as one executable graph costs the tracking thread one
-// launch instead of seven (~3.2 us of host time each: 22.5 us for the chain, measured inside this function).  The chain is captured from the stream the second time a call repeats
-// the previous one's configuration (the first pass sizes every buffer; nothing may allocate during capture); any change of
-// a launch parameter -- a regrown buffer, another image size -- drops the graph.  ORBG_CTOR_GRAPH=1 enables it (see below).
-struct CtorKey {
-  const void* ptrs[24];
-  int ints[16];
-  float flts[2];
-};
-struct CtorGraph {
-  CtorKey key{};            // configuration of the previous call
-  bool key_valid = false;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  hipGraphNode_t first = nullptr;   // the pyramid kernel: the only node with per-call arguments (the images)
-  // argument block of that node
-  const uint8_t* a_img0 = nullptr; const uint8_t* a_img1 = nullptr; int a_stride = 0; uint8_t* a_pyr = nullptr; PyrGeom a_g{};
-  const ResizeTap* a_xtab = nullptr; const ResizeTap* a_ytab = nullptr; const TowerAxis* a_tx = nullptr; const TowerAxis* a_ty = nullptr;
-  dim3 grid{1, 1, 1};
-  void drop() {
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    exec = nullptr; graph = nullptr; first = nullptr;
-  }
-};
-// Measured on MI355X / ROCm 7.2 (bench.py C2, 3 x 3000 steps each way): hipGraphLaunch of the seven-kernel chain costs the
-// host what the seven launches cost (extract stage 45.4-46.0 us with, 45.3-46.2 us without), so it is off unless asked for.
-
-static long g_cg_replays = 0, g_cg_captures = 0, g_cg_misses = 0, g_cg_ineligible = 0;
-static void ctor_graph_free(CtorGraph* g) {
-  if (getenv("ORBG_CTOR_GRAPH_STATS")) fprintf(stderr, "[orbgpu] ctor graph: %ld replays, %ld captures, %ld key changes, %ld ineligible calls\n", g_cg_replays, g_cg_captures, g_cg_misses, g_cg_ineligible);
-  if (g) { g->drop(); delete g; }
-}
 
 // Core: cams_mask selects which cameras of the rig are processed; d_img are device pointers.
 static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img0, const uint8_t* d_img1, int w, int hgt,
@@ -2327,12 +2210,6 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
   const bool want_desc = desc_out[0] || desc_out[1];
   const bool do_stereo = use_gpu && post && post->stereo && ncams == 2;
   const bool stereo_out = do_stereo && (post->uright || post->depth);
-  // ORBG_CTOR_FUSED_TAIL=1: stereo matching, median rejection, feature grid and the completion word as ONE launch
-  // (stereo_grid_kernel) when a device frame is built.  Off by default: alone on the GPU the launch takes what the two launches of
-  // round 3 take (22.6 us vs stereo_match_kernel 12.0 + grid_build_finalize_kernel 9.1 + 0.8 between them), next to the searches and
-  // the local BA it takes longer (31.6 vs 26.1 us; with 256-thread workgroups 54.8: one agent-scope release + ticket per workgroup),
-  // and the constructor's latency is half of the pipelined step: 7200 vs 6900 frames/s on the driver's command.
-  const bool fused_tail = do_stereo && post->frame && h->sel_bound > 0 && g_ctor_fused_tail;
   OctCfg oc = h->octcfg;
   oc.n_cams = ncams;                          // cameras processed by THIS call (a rig handle may extract one image)
   const uint8_t* const img1 = d_img1 ? d_img1 : d_img0;
@@ -2363,21 +2240,17 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       hipLaunchKernelGGL(fast_cells_kernel, dim3(8 * ((n_cells + 7) / 8), ncams), dim3(256), 0, st, h->d_pyr.p, g, h->d_cells.p, n_cells,
                          std::max(h->cfg.ini_th_fast, 1), std::max(h->cfg.min_th_fast, 1), h->d_slots.p, h->d_counts.p);
       if (br1(ORBX_PROF_FAST)) return ORBG_HIP_ERROR;
-      // the GPU quad-trees take the candidates from the per-cell slots themselves (octree_kernel<true>): the compacted list is only
-      // built for the host quad-trees (and, on demand, for orbx_get_candidates); ORBG_OCT_GATHER=1: the round-3 chain
-      if (!use_gpu || g_oct_gather)
+      // the GPU quad-trees take the candidates from the per-cell slots themselves (octree_kernel): the compacted list is only
+      // built for the host quad-trees (and, on demand, for orbx_get_candidates)
+      if (!use_gpu)
         hipLaunchKernelGGL(gather_cells_kernel, dim3(n_cells, ncams), dim3(256), 0, st, h->d_slots.p, h->d_counts.p, g,
                            h->d_cells.p, n_cells, ncams, use_gpu ? h->d_hdr.p : h->hdr.d, use_gpu ? h->d_cand.p : h->cand.d, h->cand_cap);
     }
     if (use_gpu) {
       // ---- everything stays on the device: quad-trees -> descriptors -> (stereo, grid) -> ONE synchronisation
       if (br0(ORBX_PROF_OCTREE)) return ORBG_HIP_ERROR;
-      if (g_oct_gather)
-        hipLaunchKernelGGL(octree_kernel<false>, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
-                           h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap, h->d_slots.p, h->d_counts.p, n_cells);
-      else
-        hipLaunchKernelGGL(octree_kernel<true>, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
-                           h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap, h->d_slots.p, h->d_counts.p, n_cells);
+      hipLaunchKernelGGL(octree_kernel, dim3(ncams * nl), dim3(kOctThreads), 0, st, h->d_cand.p, h->d_hdr.p, g, oc,
+                         h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->cand_cap, h->d_slots.p, h->d_counts.p, n_cells);
       if (br1(ORBX_PROF_OCTREE)) return ORBG_HIP_ERROR;
       if (br0(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
       auto launch_od = [&](auto kern) {
@@ -2389,7 +2262,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
       else if (h->taps_variant == 1) launch_od(orient_desc_gpu_kernel<1>);
       else launch_od(orient_desc_gpu_kernel<2>);
       if (br1(ORBX_PROF_ORIENT_DESC)) return ORBG_HIP_ERROR;
-      if (do_stereo && !fused_tail) {
+      if (do_stereo) {
         // with a device frame to build, the median rejection runs as the second workgroup of the grid build (one launch less)
         StereoFinalizeArgs unused;
         const int rcs = launch_stereo(h, post->bf, post->b, st, true, stereo_out ? h->h_stereo.d : nullptr,
@@ -2399,70 +2272,7 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
     }
     return ORBG_OK;
   };
-  bool replayed = false;
-  if (g_ctor_graph && use_gpu && prof == 0 && h->profile < 2 && h->tower_T > 0) {
-    CtorKey key;
-    memset(&key, 0, sizeof(key));
-    const void* kp[] = {h->d_pyr.p, h->d_xtab.p, h->d_ytab.p, h->d_tower_x.p, h->d_tower_y.p, h->d_cells.p, h->d_slots.p, h->d_counts.p,
-                        h->d_hdr.p, h->d_cand.p, h->d_selreg.p, h->d_lvlcount.p, h->d_overflow.p, h->d_kps.p, h->d_desc.p, h->h_kps.d,
-                        want_desc ? h->h_desc.d : nullptr, h->d_nkp.p, h->h_nkp.d, h->d_uright.p, h->d_depth.p, h->d_sad.p,
-                        stereo_out ? h->h_stereo.d : nullptr};
-    static_assert(sizeof(kp) <= sizeof(key.ptrs), "CtorKey::ptrs too small");
-    memcpy(key.ptrs, kp, sizeof(kp));
-    const int ki[] = {w, hgt, stride, ncams, n_cells, h->cfg.ini_th_fast, h->cfg.min_th_fast, h->cand_cap, h->sel_bound, reverse[0],
-                      reverse[1], (int)do_stereo, h->tower_ntx, h->tower_nty, nl};
-    static_assert(sizeof(ki) <= sizeof(key.ints), "CtorKey::ints too small");
-    memcpy(key.ints, ki, sizeof(ki));
-    key.flts[0] = do_stereo ? post->bf : 0.f; key.flts[1] = do_stereo ? post->b : 0.f;
-    if (!h->cgraph) h->cgraph = new CtorGraph();
-    CtorGraph& cg = *h->cgraph;
-    if (!(cg.key_valid && memcmp(&cg.key, &key, sizeof(key)) == 0)) {
-      cg.drop();                                  // first call with this configuration: plain launches below
-      g_cg_misses++;
-      cg.key = key; cg.key_valid = true;
-    } else {
-      if (!cg.exec) {
-        // second call in a row with the same configuration: record the chain (nothing executes during the capture)
-        hipGraph_t gr = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-          const int rcc = launch_chain(0);
-          const hipError_t ee = hipStreamEndCapture(st, &gr);
-          hipGraphExec_t ex = nullptr;
-          hipGraphNode_t root = nullptr;
-          size_t n_root = 1;
-          if (rcc == ORBG_OK && ee == hipSuccess && gr && hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess &&
-              hipGraphGetRootNodes(gr, &root, &n_root) == hipSuccess && n_root == 1) {
-            cg.graph = gr; cg.exec = ex; cg.first = root;
-            g_cg_captures++;
-            cg.a_img0 = d_img0; cg.a_img1 = img1; cg.a_stride = stride; cg.a_pyr = h->d_pyr.p; cg.a_g = g;
-            cg.a_xtab = h->d_xtab.p; cg.a_ytab = h->d_ytab.p; cg.a_tx = h->d_tower_x.p; cg.a_ty = h->d_tower_y.p;
-            cg.grid = dim3(h->tower_ntx, h->tower_nty, ncams);
-          } else {
-            if (ex) (void)hipGraphExecDestroy(ex);
-            if (gr) (void)hipGraphDestroy(gr);
-            (void)hipGetLastError();
-            cg.key_valid = false;                 // try again later; this call launches directly
-          }
-        }
-      }
-      if (cg.exec) {
-        if (cg.a_img0 != d_img0 || cg.a_img1 != img1) {
-          cg.a_img0 = d_img0; cg.a_img1 = img1;
-          void* args[] = {&cg.a_img0, &cg.a_img1, &cg.a_stride, &cg.a_pyr, &cg.a_g, &cg.a_xtab, &cg.a_ytab, &cg.a_tx, &cg.a_ty};
-          hipKernelNodeParams np;
-          memset(&np, 0, sizeof(np));
-          np.func = reinterpret_cast<void*>(pyr_tower_kernel);
-          np.gridDim = cg.grid; np.blockDim = dim3(kTwThreads); np.sharedMemBytes = 0; np.kernelParams = args; np.extra = nullptr;
-          ORBG_HIP(hipGraphExecKernelNodeSetParams(cg.exec, cg.first, &np));
-        }
-        ORBG_HIP(hipGraphLaunch(cg.exec, st));
-        replayed = true;
-        g_cg_replays++;
-      }
-    }
-  }
-  if (!replayed) g_cg_ineligible++;
-  if (!replayed && (rc = launch_chain(prof))) return rc;
+  if ((rc = launch_chain(prof))) return rc;
   if (use_gpu) {
     bool posted = false;
     if (post) {
@@ -2472,25 +2282,12 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
         if ((rc = h->sig.arm(&seq, &flag))) return rc;
         StereoFinalizeArgs fin{};
         const bool with_fin = do_stereo && h->sel_bound > 0;
-        if (fused_tail) {
-          const int nlb = h->sel_bound;
-          if (nlb >= ORBG_MAX_FRAME_FEATURES || orbx_internal_kp_capacity(h) >= 2 * ORBG_MAX_FRAME_FEATURES) return ORBG_CAP_EXCEEDED;
-          orbg::GridLaunchArgs ga;
-          if ((rc = orbm_internal_attach_prepare(post->frame, h, post->view, st, &ga))) return rc;
-          if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[5], st));
-          const int n_match = (nlb + kSgThreads / 64 - 1) / (kSgThreads / 64);
-          hipLaunchKernelGGL(stereo_grid_kernel, dim3(n_match + 1), dim3(kSgThreads), 0, st, h->d_pyr.p, h->geom, h->d_kps.p, h->d_desc.p, nlb,
-                             post->bf, post->b, h->d_uright.p, h->d_depth.p, h->d_sad.p, h->d_nkp.p, n_match, ga, flag, seq,
-                             stereo_out ? h->h_stereo.d : (float*)nullptr, reinterpret_cast<unsigned*>(h->d_overflow.p + 2));
-          if (h->profile >= 2) ORBG_HIP(hipEventRecord(h->ev[6], st));
-        } else {
-          if (with_fin)
-            fin = StereoFinalizeArgs{h->d_uright.p, h->d_depth.p, h->d_sad.p, h->sel_bound, h->d_nkp.p, stereo_out ? h->h_stereo.d : nullptr,
-                                     reinterpret_cast<unsigned*>(h->d_overflow.p + 2)};
-          orbg::UndistortArgs ua;
-          if ((rc = make_undistort_args(h, post, &ua))) return rc;
-          if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq, with_fin ? &fin : nullptr, &ua, post->mono))) return rc;
-        }
+        if (with_fin)
+          fin = StereoFinalizeArgs{h->d_uright.p, h->d_depth.p, h->d_sad.p, h->sel_bound, h->d_nkp.p, stereo_out ? h->h_stereo.d : nullptr,
+                                   reinterpret_cast<unsigned*>(h->d_overflow.p + 2)};
+        orbg::UndistortArgs ua;
+        if ((rc = make_undistort_args(h, post, &ua))) return rc;
+        if ((rc = orbm_internal_attach(post->frame, h, post->view, -1, st, h->d_nkp.p, flag, seq, with_fin ? &fin : nullptr, &ua, post->mono))) return rc;
         posted = true;
       }
     }
@@ -2651,13 +2448,11 @@ static int extract_core(orbx_handle* h, unsigned cams_mask, const uint8_t* d_img
 // ingest) thread and ONE copy kernel on the extractor's stream moves the slot into HBM -- every PCIe read of the transfer is in
 // flight at once, the copy is ordered before the pyramid kernel by the stream, and it overlaps whatever other streams run
 // (the runtime's pageable-memory copy stages through its own buffers synchronously: ~35 us of the calling thread for two
-// 640 x 480 images, and its blit kernel takes ~26 us for what this kernel moves in a few).  ORBG_IMG_RUNTIME_COPY=1 keeps
-// the runtime's path (hipMemcpy2DAsync from the caller's memory).
+// 640 x 480 images, and its blit kernel takes ~26 us for what this kernel moves in a few).
 __global__ __launch_bounds__(256) void img_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n16) dst[i] = src[i];
 }
-static const bool g_img_runtime_copy = getenv("ORBG_IMG_RUNTIME_COPY") != nullptr;
 
 // Round 4: ONE copy kernel per stereo constructor, launched when the FIRST image is in the staging slot.  Its first workgroups copy
 // that image at once; the others belong to the second image: their first thread polls one word in pinned memory, which the host
@@ -2706,9 +2501,6 @@ __global__ __launch_bounds__(kUpThreads) void img_upload_pair_kernel(const uint4
     for (int q = 0; q < kUpPerThread; q++) { const int i = i0 + q * kUpThreads; if (i < b1) dst[i] = v[q]; }
   }
 }
-static const bool g_img_two_uploads = getenv("ORBG_IMG_TWO_UPLOADS") != nullptr;     // A/B switch: the round-3 form (one copy kernel per image, after its pack)
-// workgroups per image of img_upload_pair_kernel (0: one per 16 KB chunk, every read of the pair in flight at once)
-static const int g_upload_wgs = [] { const char* e = getenv("ORBG_UPLOAD_WGS"); return e ? atoi(e) : 0; }();
 
 // a submitted Frame constructor owns the handle (stream, staging slot, pyramid, feature buffers) until it has been waited for
 static inline bool handle_busy(const orbx_handle* h) {
@@ -2718,14 +2510,9 @@ static inline bool handle_busy(const orbx_handle* h) {
 // images[c] for c < n_img -> h->d_img (packed rows, image c at c * w * hgt)
 static int stage_images(orbx_handle* h, const uint8_t* const* images, int n_img, int w, int hgt, int stride) {
   const size_t per = (size_t)w * hgt, total = per * n_img;
-  if (g_img_runtime_copy) {
-    for (int c = 0; c < n_img; c++)
-      ORBG_HIP(hipMemcpy2DAsync(h->d_img.p + c * per, w, images[c], stride, w, hgt, hipMemcpyHostToDevice, h->stream));
-    return ORBG_OK;
-  }
   int rc;
   if ((rc = h->h_img.reserve(total + 16)) || (rc = h->d_img.reserve(total + 16))) return rc;
-  if (!g_img_two_uploads && n_img == 2) {
+  if (n_img == 2) {
     if ((rc = h->up_ready.reserve(16))) return rc;
     if (!h->up_seq) memset(h->up_ready.h, 0, 16 * sizeof(unsigned));
     const unsigned seq = ++h->up_seq;
@@ -2735,7 +2522,6 @@ static int stage_images(orbx_handle* h, const uint8_t* const* images, int n_img,
     const int per_wg = kUpThreads * kUpPerThread;
     int wg_first = (first16 + per_wg - 1) / per_wg, wg_second = (total16 - first16 + per_wg - 1) / per_wg;
     int wg_stride = std::max(wg_first, wg_second);
-    if (g_upload_wgs > 0 && g_upload_wgs < wg_stride) { wg_stride = g_upload_wgs; wg_first = std::min(wg_first, wg_stride); wg_second = std::min(wg_second, wg_stride); }
     double tp0 = host_now_us();
     auto pack = [&](int c) {
       uint8_t* dst = h->h_img.h + c * per;
@@ -3095,7 +2881,6 @@ extern "C" int orbx_set_stream(orbx_handle* h, void* hip_stream) {
   if (h->ingest_state.load(std::memory_order_acquire) != 0 || (h->pending && (h->pending->active || h->pending->finished))) return ORBG_BAD_ARG;
   int rc = select_device(h->device);
   if (rc) return rc;
-  if (h->cgraph) { ctor_graph_free(h->cgraph); h->cgraph = nullptr; }      // a captured chain belongs to the stream it was captured on
   return orbg::swap_stream(&h->stream, &h->ext_stream, hip_stream, "ex");
 }
 
@@ -3267,7 +3052,7 @@ extern "C" int orbx_get_candidates(orbx_handle* h, int cam, int level, int32_t* 
     // device-resident candidate list of the last extraction: fetch and decode on demand
     int rc = select_device(h->device);
     if (rc) return rc;
-    if (!g_oct_gather && !h->cells.empty()) {
+    if (!h->cells.empty()) {
       // the constructor chain no longer builds the compacted list (the quad-trees read the per-cell slots): build it now from the
       // slots of the last extraction, which stay valid until the next one
       const int ncams = h->cfg.n_cams, n_cells = (int)h->cells.size();

@@ -1,7 +1,6 @@
 // Shared by matcher.hip and extractor.hip: the frame parameters a kernel reads and the feature grid build
 // (Frame::AssignFeaturesToGrid / PosInGrid, S/Frame.cc:360-391,699-709; CSR, cell = ix*48+iy) as a workgroup body.
-// matcher.hip launches it as a kernel of its own (host-built frames); extractor.hip runs it as one more workgroup of the stereo
-// match launch of the fused Frame constructor (stereo_grid_kernel).
+// matcher.hip launches it as a kernel of its own (host-built frames) and as the last launch of the fused Frame constructors.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -158,10 +157,5 @@ __device__ __forceinline__ void undistort_point(const UndistortArgs& a, float u,
   *xo = (float)(xx * ww);
   *yo = (float)(yy * ww);
 }
-
-// What extractor.hip needs to launch the grid build of a frame next to its own kernels (filled by orbm_internal_attach_prepare)
-struct GridLaunchArgs {
-  const orbx_keypoint* kps; FrameParams fp; int* cell_of; int* cell_start; int* cell_items;
-};
 
 }  // namespace orbg

@@ -15,8 +15,8 @@
 //                   gathered over the points both poses observe (structure built once per call); diagonal pairs
 //                   also produce b_s,i = bp_i - sum_l Hpl_il Dinv_l bl_l
 //   ldlt_mfma.hpp   one workgroup: dense LDL^T + solve of the reduced camera system on the FP64 matrix cores
-//                   (v_mfma_f64_16x16x4_f64; 16x16 tiles in registers, dataflow between wavefronts); k_ldlt_flow /
-//                   k_ldlt_rows / k_ldlt are the vector-ALU kernels for windows it does not cover (> 50 free poses)
+//                   (v_mfma_f64_16x16x4_f64; 16x16 tiles in registers, dataflow between wavefronts) up to 50 free poses;
+//                   k_wide_panel / k_wide_update / k_wide_back: the blocked many-workgroup LDL^T of larger windows
 //   k_update        thread/vertex: x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i); trial state = exp(x_p) * T  /  X + x_l
 //   k_finish        one workgroup: robust chi2, computeScale, max-diagonal -> pinned host record
 // The reduced camera system is tiny (6P x 6P, P <= a few tens): the path is latency bound, not FLOP bound.
@@ -40,202 +40,11 @@
 using namespace orbg;
 
 #include "ldlt_mfma.hpp"
+#include "se3.hpp"
+
+using namespace orbg_se3;
 
 namespace {
-
-struct Cam { double fx, fy, cx, cy, bf; float bf_f; };
-struct PoseQ { double q[4]; double t[3]; };   // quaternion x,y,z,w + translation (SE3Quat)
-
-// ---- SE3 / quaternion helpers shared by host and device (Eigen / g2o semantics, see oracle/lba.cc for citations)
-__host__ __device__ inline void quat_rotate(const double* q, const double* v, double* out) {
-  const double uv0 = 2 * (q[1] * v[2] - q[2] * v[1]), uv1 = 2 * (q[2] * v[0] - q[0] * v[2]), uv2 = 2 * (q[0] * v[1] - q[1] * v[0]);
-  out[0] = v[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
-  out[1] = v[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
-  out[2] = v[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
-}
-
-__host__ __device__ inline void quat_to_R(const double* q, double* R) {
-  const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
-  const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
-  const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
-  const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
-  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
-  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
-}
-
-__host__ __device__ inline void quat_from_R(const double* m, double* q) {
-  // Eigen::Quaterniond(Matrix3d); the three "largest diagonal" cases are spelled out so that no local array is
-  // indexed at run time (which would put it in scratch memory on the GPU)
-  double t = m[0] + m[4] + m[8];
-  if (t > 0) {
-    t = sqrt(t + 1.0);
-    q[3] = 0.5 * t;
-    t = 0.5 / t;
-    q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
-    return;
-  }
-  int i = 0;
-  if (m[4] > m[0]) i = 1;
-  if (m[8] > (i == 0 ? m[0] : m[4])) i = 2;
-  if (i == 0) {          // j = 1, k = 2
-    t = sqrt(m[0] - m[4] - m[8] + 1.0);
-    q[0] = 0.5 * t; t = 0.5 / t;
-    q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
-  } else if (i == 1) {   // j = 2, k = 0
-    t = sqrt(m[4] - m[8] - m[0] + 1.0);
-    q[1] = 0.5 * t; t = 0.5 / t;
-    q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
-  } else {               // j = 0, k = 1
-    t = sqrt(m[8] - m[0] - m[4] + 1.0);
-    q[2] = 0.5 * t; t = 0.5 / t;
-    q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
-  }
-}
-
-__host__ __device__ inline void quat_normalize(double* q) {   // SE3Quat::normalizeRotation
-  if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
-  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
-}
-
-// estimate = SE3Quat::exp(update) * estimate   (G/types/se3quat.h:225-260,102-110)
-__device__ inline void pose_oplus(const PoseQ& T, const double* u, PoseQ* out) {
-  const double om0 = u[0], om1 = u[1], om2 = u[2];
-  const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
-  const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
-  double O2[9];
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
-  double R[9], V[9];
-  if (theta < 0.00001) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
-  } else {
-    const double s = sin(theta), c = cos(theta);
-    const double a = s / theta, b = (1 - c) / (theta * theta), cc = (theta - s) / (theta * theta * theta);
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const double I = (i % 4 == 0 ? 1.0 : 0.0);
-      R[i] = I + a * O[i] + b * O2[i];
-      V[i] = I + b * O[i] + cc * O2[i];
-    }
-  }
-  double eq[4], et[3];
-  quat_from_R(R, eq);
-#pragma unroll
-  for (int i = 0; i < 3; i++) et[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
-  quat_normalize(eq);
-  double rt[3];
-  quat_rotate(eq, T.t, rt);
-  out->t[0] = et[0] + rt[0]; out->t[1] = et[1] + rt[1]; out->t[2] = et[2] + rt[2];
-  const double* a = eq; const double* b = T.q;
-  out->q[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-  out->q[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-  out->q[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-  out->q[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-  quat_normalize(out->q);
-}
-
-// pose_oplus with the divisions hoisted (one reciprocal of theta, one per normalisation) and sincos(): the same formulas as
-// SE3Quat::exp / operator* / normalizeRotation, fewer dependent FP64 divisions.  Used where the update runs on the critical
-// path of a single workgroup (PoseOptimization); results differ from pose_oplus in the last bits only.
-__device__ inline void pose_oplus_fast(const PoseQ& T, const double* u, PoseQ* out) {
-  const double om0 = u[0], om1 = u[1], om2 = u[2];
-  const double th2 = om0 * om0 + om1 * om1 + om2 * om2;
-  const double theta = sqrt(th2);
-  const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
-  double O2[9];
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
-  double R[9], V[9];
-  if (theta < 0.00001) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
-  } else {
-    double sn, cs;
-    sincos(theta, &sn, &cs);
-    const double it = 1.0 / theta, it2 = it * it;
-    const double a = sn * it, b = (1 - cs) * it2, cc = (theta - sn) * (it2 * it);
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const double I = (i % 4 == 0 ? 1.0 : 0.0);
-      R[i] = I + a * O[i] + b * O2[i];
-      V[i] = I + b * O[i] + cc * O2[i];
-    }
-  }
-  double eq[4], et[3];
-  quat_from_R(R, eq);
-#pragma unroll
-  for (int i = 0; i < 3; i++) et[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
-  {
-    if (eq[3] < 0) { eq[0] = -eq[0]; eq[1] = -eq[1]; eq[2] = -eq[2]; eq[3] = -eq[3]; }
-    const double in = 1.0 / sqrt(eq[0] * eq[0] + eq[1] * eq[1] + eq[2] * eq[2] + eq[3] * eq[3]);
-    eq[0] *= in; eq[1] *= in; eq[2] *= in; eq[3] *= in;
-  }
-  double rt[3];
-  quat_rotate(eq, T.t, rt);
-  out->t[0] = et[0] + rt[0]; out->t[1] = et[1] + rt[1]; out->t[2] = et[2] + rt[2];
-  const double* a2 = eq; const double* b2 = T.q;
-  double q3 = a2[3] * b2[3] - a2[0] * b2[0] - a2[1] * b2[1] - a2[2] * b2[2];
-  double q0 = a2[3] * b2[0] + a2[0] * b2[3] + a2[1] * b2[2] - a2[2] * b2[1];
-  double q1 = a2[3] * b2[1] + a2[1] * b2[3] + a2[2] * b2[0] - a2[0] * b2[2];
-  double q2 = a2[3] * b2[2] + a2[2] * b2[3] + a2[0] * b2[1] - a2[1] * b2[0];
-  if (q3 < 0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
-  const double in = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-  out->q[0] = q0 * in; out->q[1] = q1 * in; out->q[2] = q2 * in; out->q[3] = q3 * in;
-}
-
-// 1/sqrt(d): hardware seed + two Newton-Raphson steps
-__device__ __forceinline__ double fast_rsqrt(double d) {
-  double x = __builtin_amdgcn_rsq(d);
-  x = x * __builtin_fma(-0.5 * d * x, x, 1.5);
-  x = x * __builtin_fma(-0.5 * d * x, x, 1.5);
-  return x;
-}
-
-// exp(u) * T for the increments of PoseOptimization's trial loop (|omega| < 0.3 rad; anything larger takes pose_oplus_fast):
-// the four functions of theta the exponential needs -- sin(theta/2)/theta, cos(theta/2), (1-cos theta)/theta^2,
-// (theta - sin theta)/theta^3 -- are even power series in theta, six terms of each are exact to 1e-17 in that range; no
-// sqrt, sincos or division (the library sincos alone is ~300 FP64 instructions, and every instruction of this kernel costs
-// the workgroup 8 cycles on the critical path), and no cancellation in (1 - cos theta) for the small angles LM steps have.
-__device__ inline void pose_oplus_series(const PoseQ& T, const double* u, PoseQ* out) {
-  const double om0 = u[0], om1 = u[1], om2 = u[2];
-  const double t = om0 * om0 + om1 * om1 + om2 * om2;
-  if (t > 0.09) { pose_oplus_fast(T, u, out); return; }
-  const double s = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 81749606400.0, 1.0 / 185794560.0), -1.0 / 645120.0), 1.0 / 3840.0), -1.0 / 48.0), 0.5);
-  const double c = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 3715891200.0, 1.0 / 10321920.0), -1.0 / 46080.0), 1.0 / 384.0), -0.125), 1.0);
-  const double b = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 479001600.0, 1.0 / 3628800.0), -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0), 0.5);
-  const double cc = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, -1.0 / 6227020800.0, 1.0 / 39916800.0), -1.0 / 362880.0), 1.0 / 5040.0), -1.0 / 120.0), 1.0 / 6.0);
-  // V u_t = u_t + b (omega x u_t) + cc (omega x (omega x u_t))
-  const double w0 = om1 * u[5] - om2 * u[4], w1 = om2 * u[3] - om0 * u[5], w2 = om0 * u[4] - om1 * u[3];
-  const double z0 = om1 * w2 - om2 * w1, z1 = om2 * w0 - om0 * w2, z2 = om0 * w1 - om1 * w0;
-  const double et[3] = {u[3] + b * w0 + cc * z0, u[4] + b * w1 + cc * z1, u[5] + b * w2 + cc * z2};
-  const double eq[4] = {om0 * s, om1 * s, om2 * s, c};          // unit up to rounding, w > 0
-  double rt[3];
-  quat_rotate(eq, T.t, rt);
-  out->t[0] = et[0] + rt[0]; out->t[1] = et[1] + rt[1]; out->t[2] = et[2] + rt[2];
-  const double* b2 = T.q;
-  double q3 = eq[3] * b2[3] - eq[0] * b2[0] - eq[1] * b2[1] - eq[2] * b2[2];
-  double q0 = eq[3] * b2[0] + eq[0] * b2[3] + eq[1] * b2[2] - eq[2] * b2[1];
-  double q1 = eq[3] * b2[1] + eq[1] * b2[3] + eq[2] * b2[0] - eq[0] * b2[2];
-  double q2 = eq[3] * b2[2] + eq[2] * b2[3] + eq[0] * b2[1] - eq[1] * b2[0];
-  if (q3 < 0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
-  const double in = fast_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-  out->q[0] = q0 * in; out->q[1] = q1 * in; out->q[2] = q2 * in; out->q[3] = q3 * in;
-}
-
-// 1/d to ~1 ulp: hardware seed + two Newton-Raphson steps
-__device__ __forceinline__ double fast_rcp(double d) {
-  double x = __builtin_amdgcn_rcp(d);
-  x = __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
-  x = __builtin_fma(x, __builtin_fma(-d, x, 1.0), x);
-  return x;
-}
 
 __device__ inline void edge_error(const PoseQ& T, const double* X, const Cam& c, const lba_edge& e, double* err, double* Xc) {
   double r[3];
@@ -1172,66 +981,6 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
   }
 }
 
-// Dense LDL^T (no pivoting) + solve, one workgroup, matrix in global memory (L2-resident), row-major full n x n.
-// Fails (flag=0) on an exactly-zero / non-finite pivot, as Eigen::SimplicialLDLT would.
-__global__ __launch_bounds__(1024) void k_ldlt(int n, double* S, const double* __restrict__ b, double* __restrict__ x,
-                                              int* __restrict__ ok_flag, int use_lds) {
-  extern __shared__ double sh[];
-  double* D = sh;                 // n
-  double* y = sh + n;             // n
-  double* A = use_lds ? sh + 2 * (size_t)n : S;   // n*n in LDS when it fits one CU, else in place (L2-resident)
-  __shared__ int s_ok;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  if (use_lds)
-    for (int i = tid; i < n * n; i += nt) A[i] = S[i];
-  if (tid == 0) s_ok = 1;
-  __syncthreads();
-  for (int j = 0; j < n; j++) {
-    // pivot
-    if (tid == 0) {
-      const double d = A[(size_t)j * n + j];
-      if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) s_ok = 0;
-      D[j] = d;
-    }
-    __syncthreads();
-    if (!s_ok) break;
-    const double d = D[j];
-    // column j of L (stored below the diagonal, unscaled copy kept in y as scratch)
-    for (int i = j + 1 + tid; i < n; i += nt) {
-      const double v = A[(size_t)i * n + j];
-      y[i] = v;                       // L_ij * d
-      A[(size_t)i * n + j] = v / d;   // L_ij
-    }
-    __syncthreads();
-    // trailing update (lower triangle): A_ik -= L_ij * (L_kj * d)
-    const int m = n - j - 1;
-    for (int t = tid; t < m * m; t += nt) {
-      const int i = j + 1 + t / m, k = j + 1 + t % m;
-      if (k <= i) A[(size_t)i * n + k] -= A[(size_t)i * n + j] * y[k];
-    }
-    __syncthreads();
-  }
-  if (s_ok) {
-    // forward: L z = b ; z/D ; backward: L^T x = z   (serial over columns, parallel over rows)
-    for (int i = tid; i < n; i += nt) y[i] = b[i];
-    __syncthreads();
-    for (int j = 0; j < n; j++) {
-      const double yj = y[j];
-      for (int i = j + 1 + tid; i < n; i += nt) y[i] -= A[(size_t)i * n + j] * yj;
-      __syncthreads();
-    }
-    for (int i = tid; i < n; i += nt) y[i] /= D[i];
-    __syncthreads();
-    for (int j = n - 1; j >= 0; j--) {
-      const double xj = y[j];
-      for (int i = tid; i < j; i += nt) y[i] -= A[(size_t)j * n + i] * xj;
-      __syncthreads();
-    }
-    for (int i = tid; i < n; i += nt) x[i] = y[i];
-  }
-  if (tid == 0) *ok_flag = s_ok;
-}
-
 // ---- Blocked LDL^T + solve over MANY workgroups, for windows beyond the matrix-core kernels (more than 50 free poses:
 // the matrix-core kernels hold <= 19 tile rows in one CU's registers, the row-pair kernel <= 1344 blocks).  Right-looking,
 // 16-column blocks, dense row-major S in global memory (L2-resident), two launches per block column:
@@ -1377,558 +1126,6 @@ static hipError_t launch_ldlt_wide(int n, double* S, const double* b, double* x,
   return hipGetLastError();
 }
 
-// Register-blocked dense LDL^T + solve of the reduced camera system: thread t owns the 6x6 block (i,k), i >= k, of the
-// lower triangle in registers for the whole factorisation; per block column j: (1) the diagonal owner factors its block
-// and forward-substitutes y_j, (2) panel owners compute L_ij = A_ij L_jj^-T D_j^-1 and fold L_ij y_j into the running
-// rhs, (3) every trailing owner applies the rank-6 update A_ik -= L_ij (L_kj D_j)^T from the LDS-staged panel.  Two
-// barriers per block column forward, two backward; no pivoting; zero / non-finite pivot => ok = 0.
-constexpr int kPanStride = 74;   // doubles per panel row-block: L (36, padded to 37) + W (36, padded to 37): conflict-free b64 reads
-
-
-// Row-pair variant of the register-blocked LDL^T: a 6x6 block is owned by THREE threads (two rows each), which cuts
-// the per-step trailing update (the longest phase) and the panel solve to a third, and every thread of block column j
-// factors the 6x6 diagonal block redundantly from an LDS copy, so no barrier is needed between "factor" and "panel":
-// two barriers per block column.  L is kept (LDS, or in the storage of S for large systems) for the back-substitution.
-// R = row pairs per thread (R = 1: up to 341 blocks = 25 poses with 1024 threads).
-// Block sparsity of the factor (symbolic elimination on the host, fill-in included): bit i of m[j] = block L_ij is
-// structurally non-zero.  The reference exploits the same sparsity through Eigen::SimplicialLDLT (G/solvers/linear_solver_eigen.h);
-// here it prunes the trailing update: a block (i,k) is touched at step j only if both L_ij and L_kj exist.
-struct LdltNz { unsigned long long m[64]; };
-
-// L_IN_LDS is a template parameter so that the factor's pointer has ONE address space per instantiation: a run-time
-// "LDS or global" select makes every access to L a flat_* instruction (aperture check, both wait counters).
-//
-// Schedule per block column j (two workgroup barriers):
-//   barrier X | panel: the threads of column j read the factored diagonal block F_j = {X = L_jj^-1, 1/d, y} from LDS and
-//             | turn their two rows of A_ij into L_ij, W_ij = L_ij D_j and the rhs update
-//   barrier Z | trailing update A_ik -= L_ij W_kj^T; then the ONE wavefront that owns block (j+1, j+1) factors it
-//             | (look-ahead of the diagonal only: its ~130-instruction dependent chain overlaps the other wavefronts'
-//             | trailing updates instead of sitting between two barriers in front of every wavefront)
-// A wavefront holds 21 blocks x 3 threads (lane 63 idles) so that the three owners of a block always share a wavefront
-// and can exchange its rows through LDS without a workgroup barrier.
-constexpr int kBlkPerWave = 21;
-constexpr int kPanW = 37;            // offset of W inside a panel row-block (odd: conflict-free 64-bit reads across blocks)
-typedef double ldlt_d2 __attribute__((ext_vector_type(2)));
-// N doubles (N even) from / to a 16-byte aligned address as 128-bit accesses: an LDS instruction costs ~3 cycles of the
-// CU's LDS pipe per wavefront for 8 bytes per lane and ~4 for 16, and the trailing update is bound by exactly that
-template <int N>
-__device__ __forceinline__ void ld_pairs(const double* __restrict__ p, double* out) {
-  const ldlt_d2* q = reinterpret_cast<const ldlt_d2*>(__builtin_assume_aligned(p, 16));
-#pragma unroll
-  for (int i = 0; i < N / 2; i++) { const ldlt_d2 v = q[i]; out[2 * i] = v.x; out[2 * i + 1] = v.y; }
-}
-template <int N>
-__device__ __forceinline__ void st_pairs(double* __restrict__ p, const double* in) {
-  ldlt_d2* q = reinterpret_cast<ldlt_d2*>(__builtin_assume_aligned(p, 16));
-#pragma unroll
-  for (int i = 0; i < N / 2; i++) { ldlt_d2 v; v.x = in[2 * i]; v.y = in[2 * i + 1]; q[i] = v; }
-}
-
-template <int NT, int R, bool L_IN_LDS>
-__global__ __launch_bounds__(NT) void k_ldlt_rows(int nb, double* __restrict__ S, const double* __restrict__ b,
-                                                  double* __restrict__ x, int* __restrict__ ok_flag, LdltNz nz) {
-#pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared: fused multiply-adds halve the FP64 chain
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* rr_ = sh;                    // 6*nb running rhs (forward)
-  double* zz = rr_ + 6 * nb;           // 6*nb z = D^-1 L^-1 b, then running rhs of the backward pass
-  double* Ajj = zz + 6 * nb;           // 36 next diagonal block (rows exchanged between its three owners)
-  double* Fjj = Ajj + 36;              // 32 (12 used): 1/d (6), y (6) of the factored diagonal block
-  double* pan = Fjj + 32;              // 2 * nb * kPanStride
-  double* Lall;                        // nblk * 36
-  if constexpr (L_IN_LDS) Lall = pan + 2 * (size_t)nb * kPanStride; else Lall = S;
-  __shared__ int s_ok;
-  const int t = threadIdx.x;
-  const int n = 6 * nb;
-  const int nblk = nb * (nb + 1) / 2;
-  int ubi[R], ubk[R], upr[R], ublk[R];
-  double a[R][12];
-#pragma unroll
-  for (int s = 0; s < R; s++) {
-    const int u = t + s * NT;
-    const int lane = u & 63;
-    const int cb = (u >> 6) * kBlkPerWave + lane / 3;        // column-major block number
-    ubi[s] = -1; ubk[s] = -1; upr[s] = 0; ublk[s] = 0;
-    if (lane < 3 * kBlkPerWave && cb < nblk) {
-      // Blocks are numbered COLUMN-major over the lower block triangle: the threads of block column j are consecutive,
-      // so the panel of a column occupies one or two wavefronts instead of a few lanes of every wavefront.
-      // column k starts at C(k) = k*nb - k(k-1)/2; invert with a float guess + fix-up
-      const float fnb = (float)nb + 0.5f;
-      int bk = (int)(fnb - sqrtf(fmaxf(fnb * fnb - 2.f * (float)cb, 0.f)));
-      if (bk < 0) bk = 0;
-      if (bk > nb - 1) bk = nb - 1;
-      while (bk > 0 && bk * nb - bk * (bk - 1) / 2 > cb) bk--;
-      while (bk + 1 < nb && (bk + 1) * nb - (bk + 1) * bk / 2 <= cb) bk++;
-      const int bi = bk + (cb - (bk * nb - bk * (bk - 1) / 2));
-      ubi[s] = bi; ubk[s] = bk; upr[s] = lane - 3 * (lane / 3); ublk[s] = bi * (bi + 1) / 2 + bk;   // storage stays row-major
-#pragma unroll
-      for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) a[s][6 * q + c] = S[(size_t)(6 * bi + 2 * upr[s] + q) * n + 6 * ubk[s] + c];
-    }
-  }
-  for (int i = t; i < n; i += NT) { rr_[i] = b[i]; zz[i] = 0; }
-  if (t == 0) s_ok = 1;
-  __syncthreads();            // S fully consumed before Lall (which may alias S) is written; rhs in LDS
-
-  // Factor the diagonal block jn, executed by its three owners (one wavefront): rows -> LDS -> everyone reads the lower
-  // triangle; right-looking LDL^T arranged for depth, explicit inverse X of the unit-triangular factor, y = X r_jn.
-  // Publishes F (for the panel threads of column jn), the diagonal block of the stored factor and z_jn.
-  auto factor_diag = [&](int jn, int sd) {
-    int pr_d = 0;
-#pragma unroll
-    for (int s = 0; s < R; s++)
-      if (s == sd) {
-        pr_d = upr[s];
-        st_pairs<12>(Ajj + 12 * upr[s], a[s]);
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();       // LDS operations of one wavefront complete in order
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double A[6][6], dinv[6], y[6], rj[6];
-    {
-      double flat[36];
-      ld_pairs<36>(Ajj, flat);
-#pragma unroll
-      for (int q = 0; q < 6; q++)
-#pragma unroll
-        for (int c = 0; c <= q; c++) A[q][c] = flat[6 * q + c];
-    }
-    ld_pairs<6>(rr_ + 6 * jn, rj);
-    bool good = true;
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-      const double d = A[c][c];
-      if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
-      const double id = fast_rcp(d);
-      dinv[c] = id;
-      double W[6];
-#pragma unroll
-      for (int q = c + 1; q < 6; q++) { W[q] = A[q][c]; A[q][c] = W[q] * id; }       // A[q][c] now holds L[q][c]
-#pragma unroll
-      for (int q = c + 1; q < 6; q++)
-#pragma unroll
-        for (int r = c + 1; r <= q; r++) A[q][r] -= A[q][c] * W[r];
-    }
-    if (!good) s_ok = 0;
-    // X = L^-1 (unit lower triangular), column by column; the six columns are independent chains
-    double X[6][6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-#pragma unroll
-      for (int q = c + 1; q < 6; q++) {
-        double v = -A[q][c];
-#pragma unroll
-        for (int m = c + 1; m < q; m++) v -= A[q][m] * X[m][c];
-        X[q][c] = v;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-      double v = rj[c];
-#pragma unroll
-      for (int m = 0; m < c; m++) v += X[c][m] * rj[m];
-      y[c] = v;
-    }
-    // One lane publishes the results (an LDS store costs ~16-28 cycles of the wavefront's issue time whatever the number
-    // of active lanes): X row-packed into the diagonal block of the stored factor (read by the panel threads of column
-    // jn and by the backward pass), 1/d and y into F, z_jn.  L_jj itself is not needed by anyone.
-    if (pr_d == 0) {
-      double xs[16], dz[18];
-#pragma unroll
-      for (int c = 1; c < 6; c++)
-#pragma unroll
-        for (int m = 0; m < c; m++) xs[c * (c - 1) / 2 + m] = X[c][m];
-      xs[15] = 0;
-#pragma unroll
-      for (int c = 0; c < 6; c++) { dz[c] = dinv[c]; dz[6 + c] = y[c]; dz[12 + c] = y[c] * dinv[c]; }
-      st_pairs<16>(Lall + (size_t)(jn * (jn + 1) / 2 + jn) * 36, xs);
-      st_pairs<12>(Fjj, dz);
-      st_pairs<6>(zz + 6 * jn, dz + 12);
-    }
-  };
-
-  {
-    int sd = -1;
-#pragma unroll
-    for (int s = 0; s < R; s++) if (ubi[s] == 0 && ubk[s] == 0) sd = s;
-    if (sd >= 0) factor_diag(0, sd);
-  }
-  for (int j = 0; j < nb; j++) {
-    __syncthreads();          // barrier X: F_j + running rhs of column j complete
-    if (!s_ok) break;         // uniform: s_ok is only written between barrier Z and the next barrier X
-    double* P = pan + (size_t)(j & 1) * nb * kPanStride;
-#pragma unroll
-    for (int s = 0; s < R; s++) {
-      if (ubk[s] != j || ubi[s] == j) continue;
-      double X[6][6], dinv[6], y[6];
-      {
-        double f[16], g[12];
-        ld_pairs<16>(Lall + (size_t)(j * (j + 1) / 2 + j) * 36, f);
-        ld_pairs<12>(Fjj, g);
-#pragma unroll
-        for (int c = 1; c < 6; c++)
-#pragma unroll
-          for (int m = 0; m < c; m++) X[c][m] = f[c * (c - 1) / 2 + m];
-#pragma unroll
-        for (int c = 0; c < 6; c++) { dinv[c] = g[c]; y[c] = g[6 + c]; }
-      }
-      const int row0 = 2 * upr[s];
-      double* Lg = Lall + (size_t)ublk[s] * 36;
-      double* Lp = P + (size_t)ubi[s] * kPanStride;
-      double* Wp = Lp + kPanW;
-      // the running rhs is read before the panel is stored (LDS operations complete in order)
-      double rhs[2];
-      ld_pairs<2>(rr_ + 6 * ubi[s] + row0, rhs);
-      double racc[2] = {0, 0}, wv[12], lv[12];
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          double v = a[s][6 * q + c];                    // w = a L^-T : w[c] = a[c] + sum_{m<c} a[m] X[c][m]
-#pragma unroll
-          for (int m = 0; m < c; m++) v += a[s][6 * q + m] * X[c][m];
-          const double l = v * dinv[c];
-          wv[6 * q + c] = v;
-          lv[6 * q + c] = l;
-          racc[q] += l * y[c];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 12; q++) { Wp[6 * row0 + q] = wv[q]; Lp[6 * row0 + q] = lv[q]; }
-      st_pairs<12>(Lg + 6 * row0, lv);
-      rhs[0] -= racc[0]; rhs[1] -= racc[1];
-      st_pairs<2>(rr_ + 6 * ubi[s] + row0, rhs);
-    }
-    __syncthreads();          // barrier Z: panel of column j published
-    const unsigned long long nzj = nb <= 64 ? nz.m[j] : ~0ull;   // rows with a non-zero block in column j
-    int sd = -1;
-#pragma unroll
-    for (int s = 0; s < R; s++) {
-      if (ubk[s] > j && ubi[s] >= ubk[s] && ((nzj >> (ubk[s] & 63)) & 1ull) && ((nzj >> (ubi[s] & 63)) & 1ull)) {
-        const double* Lp = P + (size_t)ubi[s] * kPanStride + 6 * (2 * upr[s]);   // two rows of L_ij
-        const double* Wp = P + (size_t)ubk[s] * kPanStride + kPanW;              // W_kj = L_kj D_j
-        double l01[12];
-#pragma unroll
-        for (int m = 0; m < 12; m++) l01[m] = Lp[m];
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          double w[6];
-#pragma unroll
-          for (int m = 0; m < 6; m++) w[m] = Wp[6 * c + m];
-          double s0 = 0, s1 = 0;
-#pragma unroll
-          for (int m = 0; m < 6; m++) { s0 += l01[m] * w[m]; s1 += l01[6 + m] * w[m]; }
-          a[s][c] -= s0;
-          a[s][6 + c] -= s1;
-        }
-      }
-      if (ubi[s] == j + 1 && ubk[s] == j + 1) sd = s;
-    }
-    if (sd >= 0) factor_diag(j + 1, sd);
-  }
-  __syncthreads();
-  const int ok = s_ok;
-  if (ok && t < 64 && nb <= 20) {
-    // Backward substitution by ONE wavefront with z in registers: per step the six entries of z_i are broadcast with
-    // v_readlane, every lane forms x_i = X_i^T z_i from the stored inverse and updates its own entries
-    // z_k -= L_ik^T x_i.  No LDS stores in the loop, so the loads of L (which do not depend on the chain) are issued ahead
-    // of it.  The phase is bound by the instruction issue of this single wavefront (~5 cycles per instruction).
-    // lane o < 60 holds z[o] (block rows 0..9) and z[60 + o] (block rows 10..19): a block row never straddles the two
-    double z0 = t < 60 && t < n ? zz[t] : 0.0, z1 = t < 60 && t + 60 < n ? zz[t + 60] : 0.0;
-    const int kk = t / 6, cc = t - 6 * kk;             // lane -> (block row kk or kk + 10, component cc)
-    for (int i = nb - 1; i >= 0; i--) {
-      const double* Lrow = Lall + (size_t)(i * (i + 1) / 2) * 36;
-      const double* Xp = Lrow + (size_t)i * 36;        // X_i row-packed: X[q][c] at q(q-1)/2 + c
-      double xp[16], l0[6], l1[6];
-      ld_pairs<16>(Xp, xp);
-      const bool on0 = t < 60 && kk < i, on1 = t < 60 && kk + 10 < i;
-      const double* L0 = Lrow + (size_t)(on0 ? kk : 0) * 36 + cc;
-      const double* L1 = Lrow + (size_t)(on1 ? kk + 10 : 0) * 36 + cc;
-#pragma unroll
-      for (int q = 0; q < 6; q++) { l0[q] = L0[6 * q]; l1[q] = L1[6 * q]; }
-      const double src = i < 10 ? z0 : z1;             // uniform select
-      const int lb = 6 * (i < 10 ? i : i - 10);
-      double zi[6], xv[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) & 0xFFFFFFFFll), lb + c);
-        const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) >> 32), lb + c);
-        zi[c] = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) {                    // x_i = X_i^T z_i: x[c] = z[c] + sum_{q>c} X[q][c] z[q], two partial sums
-        double va = zi[c], vb = 0;
-#pragma unroll
-        for (int q = c + 1; q < 6; q++) { if ((q - c) & 1) va += xp[q * (q - 1) / 2 + c] * zi[q]; else vb += xp[q * (q - 1) / 2 + c] * zi[q]; }
-        xv[c] = va + vb;
-      }
-      const double a0 = (l0[0] * xv[0] + l0[1] * xv[1]) + (l0[2] * xv[2] + l0[3] * xv[3]) + (l0[4] * xv[4] + l0[5] * xv[5]);
-      const double a1 = (l1[0] * xv[0] + l1[1] * xv[1]) + (l1[2] * xv[2] + l1[3] * xv[3]) + (l1[4] * xv[4] + l1[5] * xv[5]);
-      const double xs_ = cc == 0 ? xv[0] : cc == 1 ? xv[1] : cc == 2 ? xv[2] : cc == 3 ? xv[3] : cc == 4 ? xv[4] : xv[5];
-      z0 = on0 ? z0 - a0 : (kk == i ? xs_ : z0);       // the solved block row replaces z in place
-      z1 = on1 ? z1 - a1 : (kk + 10 == i ? xs_ : z1);
-    }
-    if (t < 60) {
-      if (t < n) x[t] = z0;
-      if (t + 60 < n) x[t + 60] = z1;
-    }
-  } else if (ok && t < 64) {
-    // Backward substitution by ONE wavefront, no workgroup barriers: x_i = L_ii^-T z_i as six dot products with the stored
-    // inverse, then z_k -= L_ik^T x_i for all k < i spread over the lanes (lane -> (k, c)); LDS accesses of a wavefront
-    // are ordered, so the steps chain without synchronisation.
-    for (int i = nb - 1; i >= 0; i--) {
-      const double* Lii = Lall + (size_t)(i * (i + 1) / 2 + i) * 36;
-      double zi[6], xv[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) zi[c] = zz[6 * i + c];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double v = zi[c];
-#pragma unroll
-        for (int q = c + 1; q < 6; q++) v += Lii[q * (q - 1) / 2 + c] * zi[q];     // X_i row-packed
-        xv[c] = v;
-      }
-      if (t < 6) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) if (t == c) x[6 * i + c] = xv[c];
-      }
-      for (int o = t; o < 6 * i; o += 64) {
-        const int k = o / 6, c = o - 6 * k;
-        const double* Lik = Lall + (size_t)(i * (i + 1) / 2 + k) * 36;
-        double acc = 0;
-#pragma unroll
-        for (int q = 0; q < 6; q++) acc += Lik[6 * q + c] * xv[q];
-        zz[o] -= acc;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  if (t == 0) *ok_flag = ok;
-}
-
-// Dataflow variant of the row-pair block LDL^T for systems whose factor AND W = L D fit in LDS (nb <= 20 poses):
-// no workgroup barriers inside the factorisation.  Every block column lives in ONE wavefront (FlowMap, packed by the
-// host), which applies the updates of the earlier columns to its blocks as their panels appear, then factors its diagonal
-// block (every lane of the column redundantly -- free in SIMD, and nothing has to be published for the panel), computes
-// its panel and raises the column counter.  The rows of the diagonal block reach the column's lanes through v_readlane
-// (their owners are the first three lanes of the column's lane range), not through LDS, and the diagonal lane stores its
-// own results (X for the backward pass, z_j) only after the counter has moved.  The other wavefronts apply a column's update whenever they get to it, so the
-// critical path per column is one update + factor + panel of a single wavefront (~2.9k cycles) instead of two
-// barrier-separated phases of the whole workgroup (~4.4k).
-struct FlowMap { unsigned char c0[16], c1[16]; };      // wavefront w owns block columns [c0[w], c1[w])
-__device__ __forceinline__ double po_readlane_any(double v, int lane) {   // lane must be wave-uniform
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-__global__ __launch_bounds__(1024) void k_ldlt_flow(int nb, double* __restrict__ S, const double* __restrict__ b,
-                                                    double* __restrict__ x, int* __restrict__ ok_flag, LdltNz nz, FlowMap map) {
-#pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* rr_ = sh;                    // 6*nb running rhs (forward)
-  double* zz = rr_ + 6 * nb;           // 6*nb z = D^-1 L^-1 b
-  // factor: one record of kPanStride doubles per block, COLUMN-major block order (consecutive lanes <-> consecutive
-  // records: 64-bit accesses of a wavefront spread over the banks): L_ij at +0 (the diagonal records hold X row-packed),
-  // W_ij = L_ij D_j at +38 (16-byte aligned: 128-bit accesses; a single wavefront pays 25-40 cycles per LDS INSTRUCTION)
-  double* Pan = zz + 6 * nb;
-  auto rec = [nb](int i, int k_) { return (size_t)(k_ * nb - k_ * (k_ - 1) / 2 + (i - k_)) * kPanStride; };
-  __shared__ int s_ok;
-  __shared__ int s_done;               // number of block columns whose panel is complete
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int n = 6 * nb;
-  const int c0 = map.c0[wv], c1 = map.c1[wv];
-  // lane -> block of this wavefront's columns (column-major), three lanes per block
-  int bi = -1, bk = -1;
-  const int pr = lane - 3 * (lane / 3);
-  {
-    int q = lane / 3;
-    if (lane < 63)
-      for (int c = c0; c < c1; c++) {
-        const int len = nb - c;
-        if (q < len) { bk = c; bi = c + q; break; }
-        q -= len;
-      }
-  }
-  const size_t blk = bi >= 0 ? rec(bi, bk) : 0;
-  double a[12];
-#pragma unroll
-  for (int q = 0; q < 12; q++) a[q] = 0;
-  if (bi >= 0) {
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) a[6 * q + c] = S[(size_t)(6 * bi + 2 * pr + q) * n + 6 * bk + c];
-  }
-  for (int i = t; i < n; i += 1024) { rr_[i] = b[i]; zz[i] = 0; }
-  if (t == 0) { s_ok = 1; s_done = 0; }
-  __syncthreads();
-  if (c0 == 0 && c1 > 0) __builtin_amdgcn_s_setprio(3);
-  // the column counter is accessed through the __shared__ object itself: a generic `volatile int*` turns the poll and the
-  // publish into flat_load / flat_store with sc0 sc1 and a vmcnt(0) wait -- a ~1.5 k-cycle round trip per hand-over
-  for (int j = 0; j < c1; j++) {       // a wavefront is finished once its last column is factored
-    // the wavefront whose column comes next is on the critical path: it must not share its SIMD's issue slots evenly with
-    // wavefronts that are merely catching up on trailing updates
-    if (j + 1 == c0) __builtin_amdgcn_s_setprio(3);
-    if (j >= c0) {
-      // ---- this wavefront owns column j: all earlier updates are applied (loop order)
-      // the diagonal block's rows sit in the first three lanes of this column's lane range: broadcast the lower triangle
-      // with v_readlane (42 scalar-broadcast instructions, no LDS round trip: an LDS exchange costs ~1.5 k cycles here)
-      int l0 = 0;
-      for (int c = c0; c < j; c++) l0 += 3 * (nb - c);
-      double A[6][6], dinv[6], y[6], rj[6];
-#pragma unroll
-      for (int q = 0; q < 6; q++)
-#pragma unroll
-        for (int c = 0; c <= q; c++) A[q][c] = po_readlane_any(a[6 * (q & 1) + c], l0 + (q >> 1));
-      if (bk == j) {
-        ld_pairs<6>(rr_ + 6 * j, rj);
-        bool good = true;
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          const double d = A[c][c];
-          if (d == 0.0 || !(d == d) || fabs(d) == INFINITY) good = false;
-          const double id = fast_rcp(d);
-          dinv[c] = id;
-          double W[6];
-#pragma unroll
-          for (int q = c + 1; q < 6; q++) { W[q] = A[q][c]; A[q][c] = W[q] * id; }
-#pragma unroll
-          for (int q = c + 1; q < 6; q++)
-#pragma unroll
-            for (int r = c + 1; r <= q; r++) A[q][r] -= A[q][c] * W[r];
-        }
-        if (!good) s_ok = 0;
-        double X[6][6];
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-#pragma unroll
-          for (int q = c + 1; q < 6; q++) {
-            double v = -A[q][c];
-#pragma unroll
-            for (int m = c + 1; m < q; m++) v -= A[q][m] * X[m][c];
-            X[q][c] = v;
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          double v = rj[c];
-#pragma unroll
-          for (int m = 0; m < c; m++) v += X[c][m] * rj[m];
-          y[c] = v;
-        }
-        if (bi != j) {
-          double rhs[2];
-          ld_pairs<2>(rr_ + 6 * bi + 2 * pr, rhs);
-          double racc[2] = {0, 0}, wv_[12], lv[12];
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-              double v = a[6 * q + c];                    // w = a L^-T : w[c] = a[c] + sum_{m<c} a[m] X[c][m]
-#pragma unroll
-              for (int m = 0; m < c; m++) v += a[6 * q + m] * X[c][m];
-              const double l = v * dinv[c];
-              wv_[6 * q + c] = v;
-              lv[6 * q + c] = l;
-              racc[q] += l * y[c];
-            }
-          }
-          st_pairs<12>(Pan + blk + 38 + 12 * pr, wv_);
-          st_pairs<12>(Pan + blk + 12 * pr, lv);
-          rhs[0] -= racc[0]; rhs[1] -= racc[1];
-          st_pairs<2>(rr_ + 6 * bi + 2 * pr, rhs);
-        }
-        // publish: every LDS store of this wavefront is complete before the counter moves
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (bi == j && pr == 0) {
-          __hip_atomic_store(&s_done, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          // the diagonal lane's own results (X row-packed for the backward pass, z_j) are not needed by the next column:
-          // they are stored after the counter has moved
-          double xs[16], zs[6];
-#pragma unroll
-          for (int c = 1; c < 6; c++)
-#pragma unroll
-            for (int m = 0; m < c; m++) xs[c * (c - 1) / 2 + m] = X[c][m];
-          xs[15] = 0;
-#pragma unroll
-          for (int c = 0; c < 6; c++) zs[c] = y[c] * dinv[c];
-          st_pairs<16>(Pan + blk, xs);
-          st_pairs<6>(zz + 6 * j, zs);
-        }
-      }
-    } else {
-      // ---- wait for the panel of column j (uniform spin on the LDS counter)
-      while (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    // ---- trailing update with column j for this wavefront's blocks right of it
-    const unsigned long long nzj = nz.m[j];
-    if (bk > j && ((nzj >> (bk & 63)) & 1ull) && ((nzj >> (bi & 63)) & 1ull)) {
-      const double* Lp = Pan + rec(bi, j) + 12 * pr;     // two rows of L_ij
-      const double* Wp = Pan + rec(bk, j) + 38;          // W_kj = L_kj D_j
-      double l01[12];
-#pragma unroll
-      for (int m = 0; m < 12; m++) l01[m] = Lp[m];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double w[6];
-#pragma unroll
-        for (int m = 0; m < 6; m++) w[m] = Wp[6 * c + m];
-        double s0 = 0, s1 = 0;
-#pragma unroll
-        for (int m = 0; m < 6; m++) { s0 += l01[m] * w[m]; s1 += l01[6 + m] * w[m]; }
-        a[c] -= s0;
-        a[6 + c] -= s1;
-      }
-    }
-  }
-  __builtin_amdgcn_s_setprio(0);
-  __syncthreads();
-  const int ok = s_ok;
-  if (ok && t < 64) {
-    // backward substitution by one wavefront with z in registers (see k_ldlt_rows)
-    double z0 = t < 60 && t < n ? zz[t] : 0.0, z1 = t < 60 && t + 60 < n ? zz[t + 60] : 0.0;
-    const int kk = t / 6, cc = t - 6 * kk;
-    for (int i = nb - 1; i >= 0; i--) {
-      const double* Xp = Pan + rec(i, i);
-      double xp[16], l0[6], l1[6];
-      ld_pairs<16>(Xp, xp);
-      const bool on0 = t < 60 && kk < i, on1 = t < 60 && kk + 10 < i;
-      const double* L0 = Pan + rec(i, on0 ? kk : 0) + cc;
-      const double* L1 = Pan + rec(i, on1 ? kk + 10 : 0) + cc;
-#pragma unroll
-      for (int q = 0; q < 6; q++) { l0[q] = L0[6 * q]; l1[q] = L1[6 * q]; }
-      const double src = i < 10 ? z0 : z1;
-      const int lb = 6 * (i < 10 ? i : i - 10);
-      double zi[6], xv[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) & 0xFFFFFFFFll), lb + c);
-        const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) >> 32), lb + c);
-        zi[c] = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double va = zi[c], vb = 0;
-#pragma unroll
-        for (int q = c + 1; q < 6; q++) { if ((q - c) & 1) va += xp[q * (q - 1) / 2 + c] * zi[q]; else vb += xp[q * (q - 1) / 2 + c] * zi[q]; }
-        xv[c] = va + vb;
-      }
-      const double a0 = (l0[0] * xv[0] + l0[1] * xv[1]) + (l0[2] * xv[2] + l0[3] * xv[3]) + (l0[4] * xv[4] + l0[5] * xv[5]);
-      const double a1 = (l1[0] * xv[0] + l1[1] * xv[1]) + (l1[2] * xv[2] + l1[3] * xv[3]) + (l1[4] * xv[4] + l1[5] * xv[5]);
-      const double xs_ = cc == 0 ? xv[0] : cc == 1 ? xv[1] : cc == 2 ? xv[2] : cc == 3 ? xv[3] : cc == 4 ? xv[4] : xv[5];
-      z0 = on0 ? z0 - a0 : (kk == i ? xs_ : z0);
-      z1 = on1 ? z1 - a1 : (kk + 10 == i ? xs_ : z1);
-    }
-    if (t < 60) {
-      if (t < n) x[t] = z0;
-      if (t + 60 < n) x[t + 60] = z1;
-    }
-  }
-  if (t == 0) *ok_flag = ok;
-}
-
 // trial state = oplus(current, x): poses exp(x_p) * T; points X + x_l with the landmark back-substitution
 // x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i) folded in (x_l is also stored for computeScale)
 template <int NT>
@@ -2005,167 +1202,6 @@ __global__ __launch_bounds__(NT) void k_update(int n_poses, int n_points, int nP
     __syncthreads();
   }
   if (threadIdx.x == 0) scale_partial[blockIdx.x] = red[0];
-}
-
-// ---- the solve and the update in ONE launch (windows of <= 20 free poses: the column LDL^T).  Workgroup 0 is ldltm::ldlt_cols_body
-// (19 us on one compute unit); the other workgroups are k_update's work for 512 vertices each: they request everything that does
-// not depend on the solution -- a landmark's right-hand side, its first four Hpl blocks, Hll; a pose's state -- and then wait for
-// workgroup 0 to publish "x is ready" (a sequence number, release / acquire at agent scope: the workgroups sit on different XCDs).
-// What is left after the wait is arithmetic and one short round trip for x: the ~8 us of dependent loads of k_update and one
-// kernel boundary disappear from every LM iteration.  Same operations and order per vertex as k_update; the per-block partial sums
-// of computeScale() are over 512 threads here.
-struct UpdArgs {
-  int n_poses, n_points, nP;
-  const int* pose_col; const int* point_col; const PoseQ* poses; const double* points; double* x;
-  const int* pf_start; const int* pf_edges; const int* pf_col; const double* EB; const double* Hll; const double* bl; double lambda_v;
-  PoseQ* poses_out; double* points_out; const double* bp; double* scale_partial; const double* lambda_p;
-  int ldlt_prio;
-};
-constexpr int kFusedUpdThreads = ldltm::kThreads;
-
-__device__ __forceinline__ void update_after_solve_block(int ub, const UpdArgs& a, const unsigned* __restrict__ x_ready, unsigned seq) {
-  extern __shared__ __attribute__((aligned(16))) double upd_sh[];     // the launch's dynamic LDS (the LDL^T workgroup's store): 4 KB of it
-  double* const red = upd_sh;
-  const int i = ub * kFusedUpdThreads + (int)threadIdx.x;
-  const bool is_point = i < a.n_points, is_pose = !is_point && i < a.n_points + a.n_poses;
-  // ---- before the solution exists
-  int l = -1, j0 = 0, j1 = 0, c = -1;
-  double cl[3] = {0, 0, 0}, h6[6] = {1, 0, 0, 1, 0, 1}, Xin[3] = {0, 0, 0}, blv[3] = {0, 0, 0}, bpv[6] = {0, 0, 0, 0, 0, 0};
-  int eid[4] = {0, 0, 0, 0}, col[4] = {0, 0, 0, 0}, eid2[4] = {0, 0, 0, 0}, col2[4] = {0, 0, 0, 0};
-  double Bv[4][18];
-  PoseQ Tin;
-  if (is_point) {
-    l = a.point_col[i];
-    Xin[0] = a.points[3 * (size_t)i]; Xin[1] = a.points[3 * (size_t)i + 1]; Xin[2] = a.points[3 * (size_t)i + 2];
-    if (l >= 0) {
-#pragma unroll
-      for (int q = 0; q < 3; q++) { blv[q] = a.bl[3 * (size_t)l + q]; cl[q] = blv[q]; }
-#pragma unroll
-      for (int q = 0; q < 6; q++) h6[q] = a.Hll[6 * (size_t)l + q];
-      j0 = a.pf_start[l]; j1 = a.pf_start[l + 1];
-      if (j1 > j0) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int j = min(j0 + u, j1 - 1); eid[u] = a.pf_edges[j]; col[u] = a.pf_col[j]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int j = min(j0 + 4 + u, j1 - 1); eid2[u] = a.pf_edges[j]; col2[u] = a.pf_col[j]; }   // (indices only)
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const double* Bi = a.EB + (size_t)eid[u] * kEB;
-#pragma unroll
-          for (int q = 0; q < 18; q++) Bv[u][q] = Bi[q];
-        }
-      }
-    }
-  } else if (is_pose) {
-    const int p = i - a.n_points;
-    c = a.pose_col[p];
-    Tin = a.poses[p];
-    if (c >= 0) {
-#pragma unroll
-      for (int q = 0; q < 6; q++) bpv[q] = a.bp[6 * (size_t)c + q];
-    }
-  }
-  const double lambda = a.lambda_p ? *a.lambda_p : a.lambda_v;
-  // ---- wait for workgroup 0
-  while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(x_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != (int)seq) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // pairs with workgroup 0's agent-scope release (x itself is also read with agent-scope loads below)
-  auto ldx = [&](size_t k) { return __hip_atomic_load(&a.x[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  // ---- after
-  double sc = 0;
-  if (is_point) {
-    double dx[3] = {0, 0, 0};
-    if (l >= 0) {
-      if (j1 > j0) {
-        double xv[4][6];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-#pragma unroll
-          for (int q = 0; q < 6; q++) xv[u][q] = ldx(6 * (size_t)col[u] + q);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (j0 + u < j1) {
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++)
-#pragma unroll
-              for (int q = 0; q < 6; q++) cl[cc] -= Bv[u][3 * q + cc] * xv[u][q];
-          }
-      }
-      for (int jb = j0 + 4; jb < j1; jb += 4) {                   // landmarks with more than four free observations
-        int e2[4], c2[4];
-        if (jb == j0 + 4) {
-#pragma unroll
-          for (int u = 0; u < 4; u++) { e2[u] = eid2[u]; c2[u] = col2[u]; }       // observations 4..7: indices came in before the wait
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; u++) { const int j = min(jb + u, j1 - 1); e2[u] = a.pf_edges[j]; c2[u] = a.pf_col[j]; }
-        }
-        double B2[4][18], x2[4][6];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const double* Bi = a.EB + (size_t)e2[u] * kEB;
-#pragma unroll
-          for (int q = 0; q < 18; q++) B2[u][q] = Bi[q];
-#pragma unroll
-          for (int q = 0; q < 6; q++) x2[u][q] = ldx(6 * (size_t)c2[u] + q);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (jb + u < j1) {
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++)
-#pragma unroll
-              for (int q = 0; q < 6; q++) cl[cc] -= B2[u][3 * q + cc] * x2[u][q];
-          }
-      }
-      double Dinv[9];
-      inv3_sym(h6, lambda, Dinv);
-      for (int q = 0; q < 3; q++) {
-        dx[q] = Dinv[3 * q] * cl[0] + Dinv[3 * q + 1] * cl[1] + Dinv[3 * q + 2] * cl[2];
-        a.x[6 * (size_t)a.nP + 3 * (size_t)l + q] = dx[q];
-        sc += dx[q] * (lambda * dx[q] + blv[q]);
-      }
-    }
-    for (int q = 0; q < 3; q++) a.points_out[3 * (size_t)i + q] = Xin[q] + dx[q];
-  } else if (is_pose) {
-    const int p = i - a.n_points;
-    if (c >= 0) {
-      double xc6[6];
-#pragma unroll
-      for (int q = 0; q < 6; q++) xc6[q] = ldx(6 * (size_t)c + q);
-      pose_oplus(Tin, xc6, &a.poses_out[p]);
-      for (int q = 0; q < 6; q++) sc += xc6[q] * (lambda * xc6[q] + bpv[q]);
-    } else {
-      a.poses_out[p] = Tin;
-    }
-  }
-  // fixed-order block sum: DPP tree per wavefront, the eight wave totals in wave order
-  const double wsum = wave_sum_f64(sc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wsum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0;
-    for (int w2 = 0; w2 < kFusedUpdThreads / 64; w2++) tot += red[w2];
-    a.scale_partial[ub] = tot;
-  }
-}
-
-__global__ __launch_bounds__(ldltm::kThreads) void k_ldlt_cols_update(int n, const double* __restrict__ St, double* __restrict__ x,
-                                                                      int* __restrict__ ok_flag, unsigned* __restrict__ x_ready, unsigned seq,
-                                                                      UpdArgs ua) {
-  if (blockIdx.x == 0) {
-    if (ua.ldlt_prio) __builtin_amdgcn_s_setprio(3);     // the chain of dependent pivots: its wavefronts issue ahead of any neighbour's on the CU
-    ldltm::ldlt_cols_body<true>(n, St, x, ok_flag);      // x leaves through agent-scope stores of wavefront 0
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      // thread 0 belongs to the wavefront that stored x.  Agent-scope RELEASE on the publication: the compiler emits the L2
-      // write-back and s_waitcnt vmcnt(0) in front of the word's store, so that x is visible to every XCD before the word is
-      // (a workgroup-scope fence compiles to lgkmcnt(0) only; x and the word live in different allocations = different channels)
-      __hip_atomic_store(x_ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-  update_after_solve_block((int)blockIdx.x - 1, ua, x_ready, seq);
 }
 
 // one workgroup: chi2 = sum partial[] (fixed order), scale = sum x (lambda x + b), maxdiag; -> pinned record
@@ -2261,24 +1297,15 @@ struct StopRef {
   const volatile int32_t* i32 = nullptr;
   const volatile uint8_t* u8 = nullptr;
 };
-// A/B, test and experiment switches of the solve (ORBG_* environment variables): read ONCE, when the handle is created -- the solve
-// path itself never calls getenv.  A test that wants another variant creates another handle.
+// The one switch of the solve (read ONCE, when the handle is created -- the solve path itself never calls getenv):
+// ORBG_LDLT_WIDE=1 sends every window to the many-workgroup blocked LDL^T (k_wide_*: the solver of windows beyond 50 free poses) so
+// that tests can run it on small problems.  Round 5 removed the measured-slower variants of rounds 1-4 (vector-ALU LDL^T kernels,
+// the fused solve + update launch, the A/B forms of the start of a solve): docs/experiments.md keeps their numbers.
 struct LbaSwitches {
-  bool blit = false, host_items = false, host_lists = false, no_fuse = false, no_first2 = false, host_csr = false, dev_csr = false;
-  bool ldlt_valu = false, ldlt_rows = false, ldlt_wide = false, ldlt_dense = false, fuse_update = false, no_spec = false;
-  bool no_export_fuse = false, ldlt_prio = false, old_passes = false;
-  int upd_threads = 64;              // k_update's workgroup size (ORBG_UPD_THREADS = 64 / 128 / 256)
-  ldltm::Switches ldlt;              // which matrix-core kernel a size gets (ORBG_LDLT_TILES / _T9_4W / _8W)
+  bool ldlt_wide = false;
   static LbaSwitches from_env() {
     LbaSwitches w;
-    auto on = [](const char* k) { return getenv(k) != nullptr; };
-    w.blit = on("ORBG_LBA_BLIT"); w.host_items = on("ORBG_HOST_ITEMS"); w.host_lists = on("ORBG_HOST_LISTS"); w.no_fuse = on("ORBG_NO_FUSE");
-    w.no_first2 = on("ORBG_NO_FIRST2"); w.host_csr = on("ORBG_HOST_CSR"); w.dev_csr = on("ORBG_DEV_CSR"); w.ldlt_valu = on("ORBG_LDLT_VALU");
-    w.ldlt_rows = on("ORBG_LDLT_ROWS"); w.ldlt_wide = on("ORBG_LDLT_WIDE"); w.ldlt_dense = on("ORBG_LDLT_DENSE"); w.no_spec = on("ORBG_NO_SPEC");
-    w.no_export_fuse = on("ORBG_NO_EXPORT_FUSE"); w.ldlt_prio = on("ORBG_LDLT_PRIO"); w.old_passes = on("ORBG_LBA_OLD_PASSES");
-    if (const char* e = getenv("ORBG_FUSE_UPDATE")) w.fuse_update = atoi(e) != 0;
-    if (const char* e = getenv("ORBG_UPD_THREADS")) { const int v = atoi(e); w.upd_threads = (v == 256 || v == 128) ? v : 64; }
-    w.ldlt = ldltm::Switches::from_env();
+    w.ldlt_wide = getenv("ORBG_LDLT_WIDE") != nullptr;
     return w;
   }
 };
@@ -2288,15 +1315,12 @@ struct lba_handle {
   bool ext_stream = false;             // `stream` was handed in through lba_set_stream (never destroyed here)
   LbaSwitches sw;
   ldltm::AttrCache ldlt_attr;          // which kernels of THIS handle's device already allow their dynamic LDS size
-  size_t flow_attr = 0, fused_attr = 0;
   DevBuf<lba_edge> d_edges;
   PinnedBuf<lba_edge> edges_pin;       // the caller's edge list, copied (and validated, counted) in ONE pass
   DevBuf<PairItem> d_items_dev;        // pair items built by k_build_items (fixed-capacity segment per pose pair)
   DevBuf<int> d_pair_count;
   DevBuf<PoseQ> d_poses[2];
   DevBuf<double> d_points[2];
-  DevBuf<unsigned> d_xready;           // "x is ready" sequence word of the fused LDL^T + update launch
-  unsigned xseq = 0;
   DevBuf<double> d_err, d_chi2, d_partial, d_EB, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_x;
   DevBuf<double> d_wide;               // running / scaled right-hand side of the many-workgroup LDL^T (k_wide_*)
   DevBuf<double> d_St, d_wfac;         // reduced camera matrix as a tile image / factor scratch of the matrix-core LDL^T (ldlt_mfma.hpp)
@@ -2366,7 +1390,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   }
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  h->d_edges.release(); h->edges_pin.release(); h->d_items_dev.release(); h->d_pair_count.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release(); h->d_xready.release();
+  h->d_edges.release(); h->edges_pin.release(); h->d_items_dev.release(); h->d_pair_count.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release(); 
   h->d_err.release(); h->d_chi2.release(); h->d_partial.release(); h->d_EB.release(); h->d_Hll.release(); h->d_bl.release();
   h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release(); h->d_St.release(); h->d_wfac.release();
   h->d_EB2.release(); h->d_Hll2.release(); h->d_bl2.release(); h->d_Hpp2.release(); h->d_bp2.release(); h->d_lambda0.release();
@@ -2408,9 +1432,8 @@ __global__ __launch_bounds__(256) void k_upload16(const uint4* __restrict__ src,
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i < n16) dst[i] = src[i];
 }
-static int upload_arena(lba_handle* h, size_t off0, size_t off1, hipStream_t st, bool blit) {
+static int upload_arena(lba_handle* h, size_t off0, size_t off1, hipStream_t st) {
   if (off1 <= off0) return ORBG_OK;
-  if (blit) { ORBG_HIP(hipMemcpyAsync(h->up_d.p + off0, h->up_h.h + off0, off1 - off0, hipMemcpyHostToDevice, st)); return ORBG_OK; }
   const unsigned n16 = (unsigned)((off1 - off0 + 15) / 16);           // offsets are multiples of 64, the arena has 64 bytes of slack
   hipLaunchKernelGGL(k_upload16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(h->up_h.d + off0),
                      reinterpret_cast<uint4*>(h->up_d.p + off0), n16);
@@ -2473,7 +1496,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   int runs = 0;
   {
     unsigned prev_pt = ~0u;
-    if (NE < 65536 && !sw.old_passes) {
+    if (NE < 65536) {
       std::vector<unsigned>& cnt4 = h->s_cnt4;
       cnt4.assign(4 * (size_t)NX, 0u);
       unsigned* const c4 = cnt4.data();
@@ -2508,13 +1531,10 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     }
   }
   if (NE > 0) {
-    if (sw.blit) {
-      ORBG_HIP(hipMemcpyAsync(h->d_edges.p, edges, sizeof(lba_edge) * (size_t)NE, hipMemcpyHostToDevice, st));
-    } else {                                               // (k_upload16 below: the runtime's blit takes ~50 us for these 190 KB)
-      const unsigned n16 = (unsigned)((sizeof(lba_edge) * (size_t)NE + 15) / 16);
-      hipLaunchKernelGGL(k_upload16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(h->edges_pin.d),
-                         reinterpret_cast<uint4*>(h->d_edges.p), n16);
-    }
+    // (k_upload16: the runtime's blit kernel takes ~50 us for these 190 KB)
+    const unsigned n16 = (unsigned)((sizeof(lba_edge) * (size_t)NE + 15) / 16);
+    hipLaunchKernelGGL(k_upload16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(h->edges_pin.d),
+                       reinterpret_cast<uint4*>(h->d_edges.p), n16);
   }
   std::vector<int>& pose_col_v = h->s_pose_col; std::vector<int>& point_col_v = h->s_point_col;
   pose_col_v.assign(NP, -1); point_col_v.assign(NX, -1);
@@ -2548,15 +1568,12 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   int max_pose_edges = 1;
   for (int i = 0; i < nP; i++) max_pose_edges = std::max(max_pose_edges, ps_cnt[i]);
   const int item_cap = std::min(std::max(nL, 1), max_pose_edges);
-  const bool dev_items = nP >= 1 && nP <= 64 && (size_t)n_pairs_all * (size_t)item_cap * sizeof(PairItem) <= ((size_t)64 << 20) &&
-                         !sw.host_items;
+  const bool dev_items = nP >= 1 && nP <= 64 && (size_t)n_pairs_all * (size_t)item_cap * sizeof(PairItem) <= ((size_t)64 << 20);
   // (the lists of free observations per landmark, still in edge order, go along when the device sorts them: k_prep / k_errlin_prep)
-  const bool dev_lists = dev_items && nP >= 1 && ldltm::supports(6 * nP) && !sw.ldlt_valu && !sw.host_lists;
+  const bool dev_lists = dev_items && nP >= 1 && ldltm::supports(6 * nP);
   // ... and the device fills the lists itself (k_csr_fill / k_csr_sort) when a pose's list fits the sorting workgroup
-  // (measured: a wash at C2 -- 7.7 + 15.2 us of kernels for a 29 us host pass -- and -20 us at C4: used from 16 k edges on;
-  // ORBG_DEV_CSR=1 forces it, ORBG_HOST_CSR=1 forbids it)
-  const bool dev_csr = dev_lists && NE > 0 && nL > 0 && max_pose_edges <= kCsrPoseCap && !sw.no_fuse && !sw.no_first2 &&
-                       !sw.host_csr && (NE >= 16384 || sw.dev_csr);
+  // (measured: a wash at C2 -- 7.7 + 15.2 us of kernels for a 29 us host pass -- and -20 us at C4: used from 16 k edges on)
+  const bool dev_csr = dev_lists && NE > 0 && nL > 0 && max_pose_edges <= kCsrPoseCap && NE >= 16384;
   const size_t o_lm_mask = take(8 * (size_t)nL);
   const size_t o_pair_i1 = take(4 * (size_t)n_pairs_all), o_pair_i2 = take(4 * (size_t)n_pairs_all), o_pair_start = take(4 * ((size_t)n_pairs_all + 1));
   const size_t o_items = take(dev_items ? 0 : sizeof(PairItem) * n_items);
@@ -2572,8 +1589,6 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   int* pair_i1 = reinterpret_cast<int*>(H + o_pair_i1); int* pair_i2 = reinterpret_cast<int*>(H + o_pair_i2);
   int* pair_start = reinterpret_cast<int*>(H + o_pair_start);
   unsigned long long* lm_mask = reinterpret_cast<unsigned long long*>(H + o_lm_mask);
-  unsigned long long adj[64];                            // adj[i]: poses sharing a landmark with pose i (dev_items)
-  for (int i = 0; i < 64; i++) adj[i] = 0;
   PairItem* items = reinterpret_cast<PairItem*>(H + o_items);
   const double t_s1 = now_s();
   memcpy(pose_col, pose_col_v.data(), 4 * (size_t)NP);
@@ -2586,7 +1601,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     memcpy(H + o_cur_pt, pt_start, 4 * (size_t)nL); memcpy(H + o_cur_ps, ps_start, 4 * (size_t)nP); memcpy(H + o_cur_pf, pf_start, 4 * (size_t)nL);
   } else {
     std::vector<int>& f1 = h->s_f1; std::vector<int>& f2 = h->s_f2; std::vector<int>& f3 = h->s_f3;
-    if (runs == nL && !sw.old_passes) {
+    if (runs == nL) {
       // every landmark's edges are consecutive (the reference's order): a landmark's list positions are carried in registers along
       // its run instead of in per-landmark cursors (the same store-to-load chains as above), and the "pose is free" test selects
       // the destination (a junk word for edges of fixed poses) instead of branching on a one-in-three condition
@@ -2620,8 +1635,6 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     }
   }
   const double t_s2 = now_s();
-  LdltNz ldlt_nz;
-  for (int j = 0; j < 64; j++) ldlt_nz.m[j] = ~0ull;
   // ---- initial state: Converter::toSE3Quat (S/Converter.cc:33-43)
   for (int i = 0; i < NP; i++) {
     const float* T = p->poses + 16 * (size_t)i;
@@ -2640,8 +1653,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // part A: host-filled arrays; + the point / pose lists when the host fills them; + the unsorted free-observation lists when
   // the device only sorts
   const size_t off_a = dev_csr ? o_pt_edges : dev_lists ? o_pf_col : o_pf_edges;
-  const bool blit = sw.blit;       // A/B switch: the runtime's copies
-  if ((rc = upload_arena(h, 0, off_a, st, blit))) return rc;
+  if ((rc = upload_arena(h, 0, off_a, st))) return rc;
   struct {
     const lba_edge* edges; const int *pose_col, *point_col, *pt_start, *pt_edges, *ps_start, *ps_edges, *pf_start, *pf_edges, *pf_col,
         *pair_i1, *pair_i2, *pair_start;
@@ -2680,13 +1692,6 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       (rc = h->d_S.reserve(std::max<size_t>((size_t)n * n, 1))) || (rc = h->d_bs.reserve(std::max(n, 1))) ||
       (rc = h->d_x.reserve(std::max<size_t>((size_t)n + 3 * (size_t)nL, 1))))
     return rc;
-  if (!h->d_xready.p) {
-    // the "x is ready" word starts at zero (a recycled allocation may hold another handle's last sequence number); sequence
-    // numbers start at 1
-    if ((rc = h->d_xready.reserve(4))) return rc;
-    ORBG_HIP(hipMemsetAsync(h->d_xready.p, 0, 4 * sizeof(unsigned), h->stream));
-    h->xseq = 0;
-  }
   PoseQ* const posesB[3] = {reinterpret_cast<PoseQ*>(h->up_d.p + o_poses), h->d_poses[1].p, h->d_poses[0].p};
   double* const pointsB[3] = {reinterpret_cast<double*>(h->up_d.p + o_points), h->d_points[1].p, h->d_points[0].p};
 
@@ -2695,110 +1700,22 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   Huber hb;
   hb.delta_mono = (float)std::sqrt(5.991); hb.dsqr_mono = hb.delta_mono * hb.delta_mono;          // S/Optimizer.cc:1991-1992
   hb.delta_stereo = (float)std::sqrt(7.815); hb.dsqr_stereo = hb.delta_stereo * hb.delta_stereo;
-  // k_ldlt keeps the matrix in LDS when it fits (n*n + 2n doubles <= 160 KiB), otherwise works in place in L2
-  size_t lds_need = ((size_t)n * n + 2 * (size_t)n) * sizeof(double);
-  const bool ldlt_lds = lds_need <= 150 * 1024;
-  if (!ldlt_lds) lds_need = 2 * (size_t)n * sizeof(double);
-  if (lds_need > 64 * 1024) {
-    ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-  }
-
-  // row-pair LDL^T: R row pairs per thread, L kept in LDS when it fits next to the panels
-  int rows_R = 0, rows_l_in_lds = 0;
-  bool rows_small = false;
-  size_t rows_lds = 0;
-  {
-    const size_t nblk = (size_t)nP * (nP + 1) / 2;            // a wavefront holds kBlkPerWave blocks (3 threads each)
-    rows_small = nblk <= 10 * kBlkPerWave;
-    if (nblk <= 16 * kBlkPerWave) rows_R = 1; else if (nblk <= 32 * kBlkPerWave) rows_R = 2; else if (nblk <= 64 * kBlkPerWave) rows_R = 4;
-    const size_t base = (12 * (size_t)nP + 36 + 32 + 2 * (size_t)nP * kPanStride) * sizeof(double);
-    const size_t lall = (size_t)nP * (nP + 1) / 2 * 36 * sizeof(double);
-    rows_l_in_lds = base + lall <= 150 * 1024;
-    rows_lds = base + (rows_l_in_lds ? lall : 0);
-    if (rows_R && rows_lds > 64 * 1024) {
-      const void* fn;
-      if (rows_l_in_lds)
-        fn = (rows_R == 1 && rows_small) ? reinterpret_cast<const void*>(k_ldlt_rows<640, 1, true>)
-           : rows_R == 1 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 1, true>)
-           : rows_R == 2 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 2, true>)
-                         : reinterpret_cast<const void*>(k_ldlt_rows<1024, 4, true>);
-      else
-        fn = (rows_R == 1 && rows_small) ? reinterpret_cast<const void*>(k_ldlt_rows<640, 1, false>)
-           : rows_R == 1 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 1, false>)
-           : rows_R == 2 ? reinterpret_cast<const void*>(k_ldlt_rows<1024, 2, false>)
-                         : reinterpret_cast<const void*>(k_ldlt_rows<1024, 4, false>);
-      ORBG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
-    }
-  }
-  // dataflow LDL^T (k_ldlt_flow): whole block columns per wavefront, packed greedily in column order
-  FlowMap flow_map;
-  bool use_flow = false;
-  size_t flow_lds = 0;
-  if (nP >= 1 && nP <= 20 && !sw.ldlt_rows) {
-    int w = 0, fill = 0;
-    for (int i = 0; i < 16; i++) { flow_map.c0[i] = 0; flow_map.c1[i] = 0; }
-    bool fits = true;
-    flow_map.c0[0] = 0;
-    for (int c = 0; c < nP; c++) {
-      const int len = nP - c;
-      if (fill + len > kBlkPerWave) {
-        flow_map.c1[w] = (unsigned char)c;
-        if (++w >= 16) { fits = false; break; }
-        flow_map.c0[w] = (unsigned char)c;
-        fill = 0;
-      }
-      fill += len;
-    }
-    if (fits) {
-      flow_map.c1[w] = (unsigned char)nP;
-      for (int i = w + 1; i < 16; i++) { flow_map.c0[i] = 0; flow_map.c1[i] = 0; }          // idle wavefronts skip the loop
-      const size_t nblk = (size_t)nP * (nP + 1) / 2;
-      flow_lds = (12 * (size_t)nP + nblk * kPanStride) * sizeof(double);
-      use_flow = flow_lds <= 150 * 1024;
-      if (use_flow && flow_lds > 64 * 1024) {
-        if (h->flow_attr < flow_lds) {            // (per handle = per device; a handle is used by one thread at a time)
-          ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds));
-          h->flow_attr = flow_lds;
-        }
-      }
-    }
-  }
-  // FP64 matrix-core LDL^T (ldlt_mfma.hpp): up to 50 free poses; ORBG_LDLT_VALU=1 switches back to the vector-ALU kernels
-  const bool force_wide = sw.ldlt_wide;          // A/B and test switch: k_wide_* at any size
-  const bool use_mfma = nP >= 1 && ldltm::supports(n) && !sw.ldlt_valu && !force_wide;
+  // FP64 matrix-core LDL^T (ldlt_mfma.hpp): up to 50 free poses
+  const bool force_wide = sw.ldlt_wide;          // test switch: k_wide_* at any size
+  const bool use_mfma = nP >= 1 && ldltm::supports(n) && !force_wide;
   // windows beyond the matrix-core kernels (more than 50 free poses): blocked LDL^T over many workgroups
-  // (51 free poses still fit the row-pair kernel, which stays reachable through ORBG_LDLT_VALU; the blocked form is faster there: 2.7 vs 3.4 ms)
-  const bool use_wide = nP >= 1 && (force_wide || (!use_mfma && !use_flow && (!rows_R || (nP > 50 && !sw.ldlt_valu))));
+  const bool use_wide = nP >= 1 && !use_mfma;
   if (use_wide && n > kWideMaxUnknowns) return ORBG_CAP_EXCEEDED;      // (k_wide_back's x lives in LDS)
   if (use_wide && (rc = h->d_wide.reserve(2 * (size_t)n + 32))) return rc;
   if (use_mfma) {
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
   }
   int cur = 0;   // index of the buffer holding the current estimate
-  // k_update's workgroup size: the kernel is a chain of dependent memory round trips per landmark; smaller workgroups spread the
-  // same wavefronts over more compute units (ORBG_UPD_THREADS = 64 / 128 / 256 for experiments)
-  // measured (tools/lba_time.py, C2): 256 threads 0.499 ms per solve, 128: 0.488, 64: 0.484
-  const int upd_threads = sw.upd_threads;
-  // ORBG_FUSE_UPDATE=1: windows the column LDL^T covers run the solve and the update as ONE launch (k_ldlt_cols_update).  Off by
-  // default -- measured at C2 (tools/lba_time.py): 0.4865 ms per solve fused, 0.4868-0.4911 as two launches.  The update workgroups
-  // do overlap their dependent loads with the LDL^T, but they sit on other XCDs than the LDL^T workgroup: the "x is ready" word and
-  // x itself reach them through memory (agent-scope stores / loads, ~2 us each way), which costs what the kernel boundary and
-  // k_update's own loads cost.  (A same-XCD placement checked through the XCC_ID register would make the hand-over an L2 round trip.)
-  // (On by default from the end of round 3 -- next to the tracking chains the fused launch measured 0.586 vs 0.597 ms -- until the
-  // hand-over got the agent-scope RELEASE it needs, round 4: with the L2 write-back in front of the word the fused launch is 0.491
-  // vs 0.485 ms alone and 0.590 vs 0.584 ms next to the tracking chains.  Two launches are the default again.  Also measured in
-  // round 4: a landmark's dependent round trips are ~0.5 us each, a kernel's fixed cost 4-5 us -- a per-landmark record that halves
-  // k_update's round trips bought nothing alone and 3 us per solve in the agent: not kept.)
-  const bool fuse_upd = use_mfma && ldltm::pick(n, sw.ldlt).cols && sw.fuse_update;
-  const int n_blocks_u = fuse_upd ? (NP + NX + kFusedUpdThreads - 1) / kFusedUpdThreads : (NP + NX + upd_threads - 1) / upd_threads;
+  // k_update's workgroup size: the kernel is a chain of dependent memory round trips per landmark; small workgroups spread the same
+  // wavefronts over more compute units (measured at C2: 256 threads 0.499 ms per solve, 128: 0.488, 64: 0.484)
+  constexpr int upd_threads = 64;
+  const int n_blocks_u = (NP + NX + upd_threads - 1) / upd_threads;
   if ((rc = h->d_scale_partial.reserve(std::max(n_blocks_u, 1)))) return rc;
-  if (fuse_upd) {
-    const size_t lds = ldltm::pick(n, sw.ldlt).lds;
-    if (h->fused_attr < lds && lds > 48 * 1024) {
-      ORBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ldlt_cols_update), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-      h->fused_attr = 160 * 1024 - 8 * 1024;
-    }
-  }
   if (!h->d_ticket.p) {
     if ((rc = h->d_ticket.reserve(4))) return rc;
     ORBG_HIP(hipMemsetAsync(h->d_ticket.p, 0, 4 * sizeof(unsigned), st));
@@ -2817,7 +1734,6 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   double* const bls[2] = {h->d_bl.p, h->d_bl2.p};
   double* const Hpps[2] = {h->d_Hpp.p, h->d_Hpp2.p};
   double* const bps[2] = {h->d_bp.p, h->d_bp2.p};
-  const bool no_spec = sw.no_spec;   // A/B switch: no speculative linearisation
   int ls = 0;                      // linearisation set of the current iteration
   bool spec_ready = false;         // set ls^1 holds the linearisation of the current estimate
   auto launch_linearise = [&](int buf, int set) {
@@ -2890,36 +1806,11 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       // (two event records and an elapsed-time query cost the solve ~8 us: one solve in four is enough for an average)
       const bool bracket = h->prof_on && !prof_pending && prof_this_solve;
       if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
-      if (fuse_upd) {
-        UpdArgs ua{NP, NX, nP, D.pose_col, D.point_col, posesB[in_buf], pointsB[in_buf], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[set_],
-                   Hlls[set_], bls[set_], lam_, posesB[out_buf], pointsB[out_buf], bps[set_], h->d_scale_partial.p, lamp_, sw.ldlt_prio ? 1 : 0};
-        h->xseq = h->xseq == 0x7FFFFFFFu ? 1u : h->xseq + 1u;
-        hipLaunchKernelGGL(k_ldlt_cols_update, dim3(1 + n_blocks_u), dim3(ldltm::kThreads), ldltm::pick(n, sw.ldlt).lds, st, n, h->d_St.p, h->d_x.p,
-                           h->d_ok.p, h->d_xready.p, h->xseq, ua);
-      } else if (use_mfma) {
-        ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st, sw.ldlt, &h->ldlt_attr));
-      } else if (use_wide) {
+      if (use_mfma) {
+        ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st, &h->ldlt_attr));
+      } else {
         ORBG_HIP(launch_ldlt_wide(n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wide.p, st));
-      } else if (use_flow) {
-        hipLaunchKernelGGL(k_ldlt_flow, dim3(1), dim3(1024), flow_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz, flow_map);
-      } else if (rows_R) {
-        auto go = [&](auto kern, int nt) {
-          hipLaunchKernelGGL(kern, dim3(1), dim3(nt), rows_lds, st, nP, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_nz);
-        };
-        if (rows_l_in_lds) {
-          if (rows_R == 1 && rows_small) go(k_ldlt_rows<640, 1, true>, 640);
-          else if (rows_R == 1) go(k_ldlt_rows<1024, 1, true>, 1024);
-          else if (rows_R == 2) go(k_ldlt_rows<1024, 2, true>, 1024);
-          else go(k_ldlt_rows<1024, 4, true>, 1024);
-        } else {
-          if (rows_R == 1 && rows_small) go(k_ldlt_rows<640, 1, false>, 640);
-          else if (rows_R == 1) go(k_ldlt_rows<1024, 1, false>, 1024);
-          else if (rows_R == 2) go(k_ldlt_rows<1024, 2, false>, 1024);
-          else go(k_ldlt_rows<1024, 4, false>, 1024);
-        }
       }
-      else
-        hipLaunchKernelGGL(k_ldlt, dim3(1), dim3(1024), lds_need, st, n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, ldlt_lds ? 1 : 0);
       if (bracket) { ORBG_HIP(hipEventRecord(h->prof_ev[1], st)); prof_pending = true; }
     } else {
       ORBG_HIP(hipMemsetAsync(h->d_ok.p, 0xFF, sizeof(int), st));   // nothing to solve: ok
@@ -2975,21 +1866,16 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
         // the solve of this trial may already be running: it was launched, with the lambda the device computed for the accepted
         // case, behind the previous trial's residual / linearisation kernel (with the fused launch: its update into `trial` too)
         if (!(solve_version == version - 1 && qmax == 0 && used_spec) && (rc2 = launch_solve(ls, lambda, lam_p, cur, trial))) return rc2;
-        if (!fuse_upd) {
-          auto upd = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(n_blocks_u), dim3(upd_threads), 0, st, NP, NX, nP, D.pose_col, D.point_col,
-                               posesB[cur], pointsB[cur], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
-                               Hlls[ls], bls[ls], lambda, posesB[trial], pointsB[trial], bps[ls], h->d_scale_partial.p, lam_p);
-          };
-          if (upd_threads == 64) upd(k_update<64>); else if (upd_threads == 128) upd(k_update<128>); else upd(k_update<256>);
-        }
+        hipLaunchKernelGGL(k_update<upd_threads>, dim3(n_blocks_u), dim3(upd_threads), 0, st, NP, NX, nP, D.pose_col, D.point_col,
+                           posesB[cur], pointsB[cur], h->d_x.p, D.pf_start, D.pf_edges, D.pf_col, EBs[ls],
+                           Hlls[ls], bls[ls], lambda, posesB[trial], pointsB[trial], bps[ls], h->d_scale_partial.p, lam_p);
         bool speculated = false, fused_export = false;
         if (NE > 0) {
           // speculate on acceptance: linearise the trial state into the other set while the host waits for the verdict
           // (not after the very last iteration that can run)
           // ... nor when two iterations in a row barely improved chi2: a third one ends the round (nBad >= 3)
-          const bool may_continue = !(last_round && (it + 1 >= iterations || nBad >= 2)) && !no_spec;
-          if (may_continue && !sw.no_fuse) {
+          const bool may_continue = !(last_round && (it + 1 >= iterations || nBad >= 2));
+          if (may_continue) {
             // residuals + record + linearisation of the trial state in ONE launch
             const int set = ls ^ 1;
             const int n_blocks_l = (nL + 255) / 256;       // the landmark reduction rides in the same launch (point workgroups)
@@ -3010,8 +1896,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
             }
           } else {
             // the last evaluation that can run in the last round goes together with the (speculative) export of its state
-            fused_export = !may_continue && last_round && (it + 1 >= iterations || nBad >= 2) && !no_spec && !lambda_on_device &&
-                           !sw.no_fuse && !sw.no_export_fuse;
+            fused_export = last_round && (it + 1 >= iterations || nBad >= 2) && !lambda_on_device;
             if (fused_export) {
               const int n_thr = std::max(std::max(NE, NP), 3 * NX);
               hipLaunchKernelGGL(k_errors_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, n_blocks_e, NE, D.edges, posesB[trial],
@@ -3022,7 +1907,6 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
             } else {
               launch_errors(trial, 1);
             }
-            if (may_continue) { launch_linearise(trial, ls ^ 1); speculated = true; }
           }
           const bool round_may_end = it + 1 >= iterations || nBad >= 2;
           if (speculated && !last_round && round_may_end && !lambda_on_device) {
@@ -3031,7 +1915,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
                                Hpps[ls ^ 1], Hlls[ls ^ 1], 0.0, (int*)nullptr, 0, 1, h->rec.d, p->lambda_init, h->d_lambda0.p);
             fin_version = version;
           }
-          if (last_round && round_may_end && !no_spec && !lambda_on_device) {
+          if (last_round && round_may_end && !lambda_on_device) {
             // ... or, in the last round, the export of the trial state (dropped if the trial is rejected or the round goes on)
             if (!fused_export) launch_export(trial);
             if ((rc2 = h->sig.post(st))) return rc2;
@@ -3094,7 +1978,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   // first residuals + linearisation are launched before the host has finished the structure
   const int n_zero = n + 3 * nL;
   // first iteration in two launches (k_errlin_prep, k_finish_items) where the observation lists are sorted on the device
-  const bool first2 = dev_lists && NE > 0 && nL > 0 && !sw.no_fuse && !sw.no_first2 && !terminate();
+  const bool first2 = dev_lists && NE > 0 && nL > 0 && !terminate();
   if (first2 && dev_csr) {
     const int set = ls ^ 1;
     const int n_blocks_l = (nL + 255) / 256;
@@ -3135,7 +2019,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     ORBG_HIP(hipGetLastError());
     err_valid = true; spec_ready = true; fin_version = version;
   } else if (!terminate()) {
-    if (NE > 0 && !sw.no_fuse) {
+    if (NE > 0) {
       // residuals + linearisation of the initial estimate in the fused kernel of the later trials (its record is not waited
       // for: it carries the sequence number the host has already seen)
       const int set = ls ^ 1;
@@ -3145,9 +2029,6 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
                          D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, 0, (const int*)nullptr,
                          h->rec.d, h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
                          LmIn{0.0, 0.0, (const double*)nullptr, (const double*)nullptr, (double*)nullptr});
-    } else {
-      launch_errors(cur, 0);
-      launch_linearise(cur, ls ^ 1);
     }
     err_valid = true;
     spec_ready = true;
@@ -3197,7 +2078,6 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
         unsigned long long m = 0;
         for (int j = b0; j < e0; j++) m |= 1ull << pf_col[j];
         lm_mask[l] = m;
-        for (int j = b0; j < e0; j++) adj[pf_col[j]] |= m;
       } else {
         for (int a2 = b0; a2 < e0; a2++) {
           const int ro = row_off[pf_col[a2]] + 1;
@@ -3214,7 +2094,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     for (int i1 = 0; i1 < nP; i1++)
       for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
     off_b = o_pair_start;
-    if (!dev_lists && (rc = upload_arena(h, off_a, off_b, st, blit))) return rc;      // (dev_lists: k_schur derives the pair from its index)
+    if (!dev_lists && (rc = upload_arena(h, off_a, off_b, st))) return rc;      // (dev_lists: k_schur derives the pair from its index)
     if (nL > 0 && !first2)
       hipLaunchKernelGGL(k_build_items, dim3(n_pairs_all), dim3(256), 0, st, nP, nL,
                          reinterpret_cast<const unsigned long long*>(h->up_d.p + o_lm_mask), D.pf_start, D.pf_edges, D.pf_col,
@@ -3235,27 +2115,11 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       }
     }
   }
-  // symbolic elimination of the reduced camera system: which blocks of L are structurally non-zero (fill-in included)
-  if (nP <= 64 && !sw.ldlt_dense && !dev_lists) {     // (only the vector-ALU kernels read it; dev_lists implies the matrix-core solver)
-    unsigned long long col[64];                         // col[j]: rows i > j with S_ij != 0, then with fill-in
-    for (int j = 0; j < nP; j++) {
-      unsigned long long mcol = 0;
-      for (int i = j + 1; i < nP; i++)
-        if (dev_items ? ((adj[j] >> i) & 1ull) != 0 : pair_start[pair_id(j, i) + 1] > pair_start[pair_id(j, i)]) mcol |= 1ull << i;
-      col[j] = mcol;
-    }
-    for (int j = 0; j < nP; j++) {
-      const unsigned long long rows = col[j];
-      for (int k = j + 1; k < nP; k++)
-        if ((rows >> k) & 1ull) col[k] |= k < 63 ? (rows & ~((2ull << k) - 1ull)) : 0ull;   // rows below k of column j fill column k
-      ldlt_nz.m[j] = rows;
-    }
-  }
   // keep every pair (diagonals always; off-diagonals even if empty so that S is fully written)
   for (int i1 = 0; i1 < nP; i1++)
     for (int i2 = i1; i2 < nP; i2++) { pair_i1[pair_id(i1, i2)] = i1; pair_i2[pair_id(i1, i2)] = i2; }
 
-  if (!dev_items && (rc = upload_arena(h, off_b, off, st, blit))) return rc;
+  if (!dev_items && (rc = upload_arena(h, off_b, off, st))) return rc;
   const double t_s3b = now_s();
   int done = 0;
   if ((rc = optimize(p->its_round1 > 0 ? p->its_round1 : 5, &done))) return rc;
@@ -3341,7 +2205,7 @@ extern "C" int lba_get_solver_stats(lba_handle* h, double* sum_ms, int64_t* n_br
   if (!h || !sum_ms || !n_brackets) return ORBG_BAD_ARG;
   *sum_ms = h->prof_sum_ms; *n_brackets = h->prof_n;
   if (n_unknowns) *n_unknowns = h->prof_n_unknowns;
-  if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !h->sw.ldlt_valu && !h->sw.ldlt_wide;
+  if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !h->sw.ldlt_wide;
   return ORBG_OK;
 }
 
@@ -3473,631 +2337,4 @@ extern "C" int lba_solve(const lba_problem* p, const volatile int32_t* stop_flag
 extern "C" int lba_solve_b(const lba_problem* p, const volatile uint8_t* stop_bool, lba_result* r) {
   StopRef s; s.u8 = stop_bool;
   return lba_solve_once(p, s, r);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Optimizer::PoseOptimization(Frame*) (S/Optimizer.cc:964-1278) -- the WHOLE solve in one kernel launch.
-//
-// One 256-thread workgroup; thread t owns correspondences t, t+256, ...  The four rounds, the Levenberg-Marquardt
-// iterations and their accept/reject trials all run on the device: thread 0 holds the 6x6 system, lambda and the
-// control flow, everything else is broadcast through LDS.  Reductions are fixed-order (wavefront shuffle tree, then
-// the four wavefront partials in order), so the result is bit-reproducible.  A host-driven version would need one
-// synchronisation per LM trial (~40-60 per call); this needs one.
-namespace {
-
-constexpr int kPoThreads = 256;
-constexpr int kPoMaxPer = 16;      // correspondences per thread (n <= 4096)
-constexpr int kPoLdsN = 1024;      // correspondences whose inputs are staged in LDS
-constexpr int kPoRow = 8 * 33;     // one reduction row: 8 segments of 32 values, padded against LDS bank conflicts
-
-// Block-wide sums of NV per-thread values in a fixed order: transpose through LDS, 8 threads per value add 32
-// entries each, one thread per value adds the 8 partials.  out[0..NV) is valid for every thread afterwards.
-template <int NV>
-__device__ inline void po_block_reduce(const double* vals, double* s_acc, double* s_part, double* out) {
-  const int tid = threadIdx.x;
-  const int col = (tid >> 5) * 33 + (tid & 31);
-#pragma unroll
-  for (int v = 0; v < NV; v++) s_acc[v * kPoRow + col] = vals[v];
-  __syncthreads();
-  if (tid < NV * 8) {
-    const double* p = s_acc + (tid >> 3) * kPoRow + (tid & 7) * 33;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) { a0 += p[4 * j]; a1 += p[4 * j + 1]; a2 += p[4 * j + 2]; a3 += p[4 * j + 3]; }
-    s_part[tid] = (a0 + a1) + (a2 + a3);
-  }
-  __syncthreads();
-  if (tid < NV) {
-    const double* p = s_part + tid * 8;
-    out[tid] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-  }
-  __syncthreads();
-}
-
-// Block-wide sum of ONE double per thread: DPP tree inside each wavefront, the four wave totals through LDS, added in wave
-// order by every thread (one barrier; `slot` alternates between consecutive calls so that no second barrier is needed).
-__device__ __forceinline__ double po_block_sum(double v, double (*wsum)[4], int slot) {
-  const double w = wave_sum_f64(v);
-  if ((threadIdx.x & 63) == 0) wsum[slot][threadIdx.x >> 6] = w;
-  __syncthreads();
-  return ((wsum[slot][0] + wsum[slot][1]) + wsum[slot][2]) + wsum[slot][3];
-}
-
-__device__ __forceinline__ double po_readlane(double v, int lane) {   // lane must be wave-uniform
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// (H + lambda I) x = b by LDL^T without pivoting, spread over lanes 0..5 of a wave: lane `li` holds row li.  Every
-// subtraction happens in the order of a scalar left-looking factorisation (ascending k), so the factors are the
-// same bits a serial solve would produce.  Returns false unless every pivot is positive (Eigen::LDLT::isPositive),
-// in which case x is left untouched.  x[] comes out wave-uniform.
-__device__ inline bool po_solve6(const double* Hrow, double b_li, int li, double lambda, double* x) {
-  // (round 4, measured and dropped: the seven divisions as products with 1/d from the hardware seed + two Newton steps -- no
-  // measurable gain, 162 vs 158-164 us at 450 correspondences, and one of the twelve parity cases changed an iteration count)
-  double A[6], D[6];
-#pragma unroll
-  for (int j = 0; j < 6; j++) A[j] = Hrow[j] + (j == li ? lambda : 0.0);
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const double d = po_readlane(A[k], k);
-    if (!(d > 0.0) || fabs(d) == INFINITY) ok = false;
-    D[k] = d;
-    const double Lik = A[k] / d;
-#pragma unroll
-    for (int j = k + 1; j < 6; j++) { const double Ljk = po_readlane(Lik, j); A[j] -= (Lik * Ljk) * d; }
-    A[k] = Lik;
-  }
-  if (!ok) return false;
-  double y = b_li;
-#pragma unroll
-  for (int k = 0; k < 5; k++) { const double yk = po_readlane(y, k); if (li > k) y -= A[k] * yk; }
-  double Di = D[0];
-#pragma unroll
-  for (int k = 1; k < 6; k++) Di = (li == k) ? D[k] : Di;
-  y /= Di;
-#pragma unroll
-  for (int i = 5; i >= 0; i--) {
-    double sv = po_readlane(y, i);
-#pragma unroll
-    for (int k = i + 1; k < 6; k++) sv -= po_readlane(A[i], k) * x[k];
-    x[i] = sv;
-  }
-  return true;
-}
-
-// ---- two correspondences side by side.  A lone wavefront issues a DEPENDENT FP64 instruction every ~9 cycles and an independent
-// one every ~5.4 (tools/micro/fp64_latency; the pipe itself takes one per 4.2), and hipcc keeps the arithmetic of one
-// correspondence together when it is written as a scalar function called twice.  The per-correspondence arithmetic is therefore
-// written ONCE over a value type V that is either double (one correspondence) or D2 (the thread's correspondences i and i + 256,
-// element-wise): every operation of the pair stands next to its twin in the instruction stream, the operations and their order per
-// correspondence are exactly the scalar ones -- the same bits, which the LM loop's accept / reject and termination decisions need
-// (tried: rotation matrix instead of the quaternion sandwich, Newton reciprocals instead of divisions: different iteration counts).
-struct D2 { double a, b; };
-struct B2 { bool a, b; };
-__device__ __forceinline__ D2 operator+(D2 x, D2 y) { return D2{x.a + y.a, x.b + y.b}; }
-__device__ __forceinline__ D2 operator-(D2 x, D2 y) { return D2{x.a - y.a, x.b - y.b}; }
-__device__ __forceinline__ D2 operator*(D2 x, D2 y) { return D2{x.a * y.a, x.b * y.b}; }
-__device__ __forceinline__ D2 operator-(D2 x) { return D2{-x.a, -x.b}; }
-__device__ __forceinline__ D2 operator+(D2 x, double y) { return D2{x.a + y, x.b + y}; }
-__device__ __forceinline__ D2 operator+(double x, D2 y) { return D2{x + y.a, x + y.b}; }
-__device__ __forceinline__ D2 operator-(D2 x, double y) { return D2{x.a - y, x.b - y}; }
-__device__ __forceinline__ D2 operator-(double x, D2 y) { return D2{x - y.a, x - y.b}; }
-__device__ __forceinline__ D2 operator*(D2 x, double y) { return D2{x.a * y, x.b * y}; }
-__device__ __forceinline__ D2 operator*(double x, D2 y) { return D2{x * y.a, x * y.b}; }
-__device__ __forceinline__ D2 operator/(double x, D2 y) { return D2{x / y.a, x / y.b}; }
-__device__ __forceinline__ D2 operator/(D2 x, D2 y) { return D2{x.a / y.a, x.b / y.b}; }
-__device__ __forceinline__ double po_f32round(double x) { return (double)(float)x; }
-__device__ __forceinline__ D2 po_f32round(D2 x) { return D2{(double)(float)x.a, (double)(float)x.b}; }
-__device__ __forceinline__ double po_sel(bool c, double x, double y) { return c ? x : y; }
-__device__ __forceinline__ D2 po_sel(B2 c, D2 x, D2 y) { return D2{c.a ? x.a : y.a, c.b ? x.b : y.b}; }
-__device__ __forceinline__ bool po_neg(double x) { return x < 0; }
-__device__ __forceinline__ B2 po_neg(D2 x) { return B2{x.a < 0, x.b < 0}; }
-__device__ __forceinline__ double po_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ D2 po_sqrt(D2 x) { return D2{sqrt(x.a), sqrt(x.b)}; }
-__device__ __forceinline__ bool po_any_gt(double e, double d) { return !(e <= d); }
-__device__ __forceinline__ bool po_any_gt(D2 e, D2 d) { return !(e.a <= d.a) || !(e.b <= d.b); }
-__device__ __forceinline__ bool po_le(double e, double d) { return e <= d; }
-__device__ __forceinline__ B2 po_le(D2 e, D2 d) { return B2{e.a <= d.a, e.b <= d.b}; }
-template <class V> __device__ __forceinline__ V po_c(double x);
-template <> __device__ __forceinline__ double po_c<double>(double x) { return x; }
-template <> __device__ __forceinline__ D2 po_c<D2>(double x) { return D2{x, x}; }
-template <class V> struct PoMask;
-template <> struct PoMask<double> { typedef bool type; };
-template <> struct PoMask<D2> { typedef B2 type; };
-
-// quat_rotate (above) over V
-template <class V>
-__device__ __forceinline__ void po_quat_rotate(const double* q, const V* v, V* out) {
-  const V uv0 = 2 * (q[1] * v[2] - q[2] * v[1]), uv1 = 2 * (q[2] * v[0] - q[0] * v[2]), uv2 = 2 * (q[0] * v[1] - q[1] * v[0]);
-  out[0] = v[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
-  out[1] = v[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
-  out[2] = v[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
-}
-// camera-frame point and 1 / z, then the edge error: mono I/OptimizableTypes.h:44-48 (Pinhole::project in double), stereo
-// G/types/types_six_dof_expmap.cpp:339-346 (float invz, double bf * invz).  Both forms are evaluated and one is selected.
-template <class V>
-__device__ __forceinline__ void po_cam_point(const PoseQ& T, const V* X, V* Xc, V* iz) {
-  V r[3];
-  po_quat_rotate(T.q, X, r);
-  Xc[0] = r[0] + T.t[0]; Xc[1] = r[1] + T.t[1]; Xc[2] = r[2] + T.t[2];
-  *iz = 1.0 / Xc[2];
-}
-template <class V, class M>
-__device__ __forceinline__ void po_residual(const V* Xc, V iz, V u, V v, V ur, M mono, const Cam& c, V* err) {
-  const V m0 = u - (c.fx * Xc[0] * iz + c.cx);
-  const V m1 = v - (c.fy * Xc[1] * iz + c.cy);
-  const V invz = po_f32round(iz);
-  const V r0 = Xc[0] * invz * c.fx + c.cx;
-  const V r1 = Xc[1] * invz * c.fy + c.cy;
-  const V s2 = ur - (r0 - c.bf * invz);
-  err[0] = po_sel(mono, m0, u - r0);
-  err[1] = po_sel(mono, m1, v - r1);
-  err[2] = po_sel(mono, po_c<V>(0.0), s2);
-}
-// rho0 / rho1 of RobustKernelHuber::robustify (G/core/robust_kernel_impl.cpp:78-91); the square root only where e > dsqr
-template <class V>
-__device__ __forceinline__ void po_huber(bool robust, V e, V delta, V dsqr, V one, V* rho0, V* rho1) {
-  *rho0 = e; *rho1 = one;
-  if (robust && po_any_gt(e, dsqr)) {
-    const V sq = po_sqrt(e);
-    const auto in = po_le(e, dsqr);
-    *rho0 = po_sel(in, e, 2 * sq * delta - dsqr);
-    *rho1 = po_sel(in, one, delta / sq);
-  }
-}
-__device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, float v, float ur, const Cam& c, double* err, double* Xc) {
-  const double Xd[3] = {X[0], X[1], X[2]};
-  double iz;
-  po_cam_point<double>(T, Xd, Xc, &iz);
-  po_residual<double, bool>(Xc, iz, (double)u, (double)v, (double)ur, ur < 0, c, err);
-}
-
-// ---- the per-correspondence arithmetic of the LM loop, written once over V (double: one correspondence, D2: the thread's pair)
-// PoEval: everything an evaluation at a pose produces for a correspondence
-template <class V> struct PoEval { V Xc[3], iz, err[3], c2, rho0, rho1; };
-template <class V, class M>
-__device__ __forceinline__ void po_eval(const PoseQ& T, const V* X, V uu, V vv, V ur, V om, M mono, bool robust, const Cam& cam,
-                                        double dM, double dS, double dsqM, double dsqS, PoEval<V>* e) {
-  po_cam_point<V>(T, X, e->Xc, &e->iz);
-  po_residual<V, M>(e->Xc, e->iz, uu, vv, ur, mono, cam, e->err);
-  e->c2 = e->err[0] * (om * e->err[0]) + e->err[1] * (om * e->err[1]) + po_sel(mono, po_c<V>(0.0), e->err[2] * (om * e->err[2]));
-  po_huber<V>(robust, e->c2, po_sel(mono, po_c<V>(dM), po_c<V>(dS)), po_sel(mono, po_c<V>(dsqM), po_c<V>(dsqS)), po_c<V>(1.0), &e->rho0, &e->rho1);
-}
-// J^T (w Omega) J (21 entries, upper triangle row-major) and J^T (w Omega) r (6) of one evaluation -> hh[27]
-template <class V, class M>
-__device__ __forceinline__ void po_hessian(const PoEval<V>& e, V om, M mono, const Cam& cam, V* hh) {
-  // Jacobian (D x 6): mono S/OptimizableTypes.cpp:49-63, stereo types_six_dof_expmap.cpp:375-404
-  const V xx = e.Xc[0], yy = e.Xc[1], iz = e.iz, iz2 = iz * iz;
-  const V zero = po_c<V>(0.0);
-  V J[18];
-  J[0] = xx * yy * iz2 * cam.fx; J[1] = -(1 + (xx * xx * iz2)) * cam.fx; J[2] = yy * iz * cam.fx; J[3] = -iz * cam.fx; J[4] = zero; J[5] = xx * iz2 * cam.fx;
-  J[6] = (1 + yy * yy * iz2) * cam.fy; J[7] = -xx * yy * iz2 * cam.fy; J[8] = -xx * iz * cam.fy; J[9] = zero; J[10] = -iz * cam.fy; J[11] = yy * iz2 * cam.fy;
-  J[12] = po_sel(mono, zero, J[0] - cam.bf * yy * iz2); J[13] = po_sel(mono, zero, J[1] + cam.bf * xx * iz2); J[14] = po_sel(mono, zero, J[2]);
-  J[15] = po_sel(mono, zero, J[3]); J[16] = zero; J[17] = po_sel(mono, zero, J[5] - cam.bf * iz2);
-  const V wom = e.rho1 * om;
-  V orr[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) orr[k] = -(om * e.err[k]) * e.rho1;
-  // J^T (w Omega) J with the weighted rows formed once and the structural zeros of the Jacobian (column 4 of rows 0 and
-  // 2, column 3 of row 1) left out: 15 + 45 + 15 multiply-adds per correspondence instead of 126 + 36
-  constexpr int kZeroCol[3] = {4, 3, 4};
-  V wJ[18];
-#pragma unroll
-  for (int k = 0; k < 3; k++)
-#pragma unroll
-    for (int a2 = 0; a2 < 6; a2++) wJ[6 * k + a2] = a2 == kZeroCol[k] ? zero : wom * J[6 * k + a2];
-  int o = 0;
-#pragma unroll
-  for (int a2 = 0; a2 < 6; a2++)
-#pragma unroll
-    for (int c3 = a2; c3 < 6; c3++) {
-      V h = zero;
-#pragma unroll
-      for (int k = 0; k < 3; k++)
-        if (a2 != kZeroCol[k] && c3 != kZeroCol[k]) h = h + J[6 * k + a2] * wJ[6 * k + c3];
-      hh[o++] = h;
-    }
-#pragma unroll
-  for (int a2 = 0; a2 < 6; a2++) {
-    V sacc = zero;
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-      if (a2 != kZeroCol[k]) sacc = sacc + J[6 * k + a2] * orr[k];
-    hh[o++] = sacc;
-  }
-}
-// Optimizer::PoseOptimization (S/Optimizer.cc:992-1290) in ONE launch of one workgroup: 4 rounds x up to 10
-// Levenberg-Marquardt iterations (g2o OptimizationAlgorithmLevenberg semantics), outlier re-classification after
-// each round.  The LM state (pose, lambda, gains) is kept identically in every thread -- all of them read the same
-// block sums from LDS and run the same arithmetic -- so the control flow needs no broadcast; the 6x6 solve runs on
-// lanes 0..5 of each wave.
-// -DPO_PROFILE: cycles of thread 0 per phase, summed over the call (build, reduce, solve, trial evaluation, trial sum, rest)
-#ifdef PO_PROFILE
-__device__ long long g_po_prof[8];
-#define PO_T0() long long po_t = clock64()
-#define PO_ACC(slot) do { const long long po_n = clock64(); if (threadIdx.x == 0) g_po_prof[slot] += po_n - po_t; po_t = po_n; } while (0)
-#else
-#define PO_T0() do { } while (0)
-#define PO_ACC(slot) do { } while (0)
-#endif
-template <bool LDS_IN>      // LDS_IN: n <= kPoLdsN, the correspondences are staged in LDS (typed LDS accesses: a pointer that may be LDS or
-                            // global at run time turns every load into a flat_load with a full wait behind it)
-__global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float* g_Xw, const float* g_ou, const float* g_ov, const float* g_our,
-                                                             const float* g_oinv, Cam cam, PoseQ T0,
-                                                             PoseQ* __restrict__ T_out, uint8_t* __restrict__ outlier_out,
-                                                             int* __restrict__ stats /*n_bad, iters[4], .., [7] = seq*/,
-                                                             double* __restrict__ chi_out, unsigned seq) {
-  __shared__ float s_in[7 * kPoLdsN];                    // correspondences staged once (they are re-read ~36 times)
-  __shared__ double s_acc[28 * kPoRow];
-  __shared__ double s_part[28 * 8];
-  __shared__ double red[28];
-  __shared__ double s_wsum[2][4];
-  __shared__ double s_cand[4][14];                       // LM trial candidates of the current iteration: x[6], pose q[4] t[3], solve ok
-  int sum_slot = 0;
-  __shared__ double s_chi2[kPoThreads * kPoMaxPer];      // last evaluated chi2 of every correspondence
-  __shared__ uint8_t s_out[kPoThreads * kPoMaxPer];      // mvbOutlier
-  const int tid = threadIdx.x;
-  const int li = min(tid & 63, 5);
-  const double dM = (float)sqrt(5.991), dS = (float)sqrt(7.815);
-  const double dsqM = dM * dM, dsqS = dS * dS;
-  for (int i = tid; i < n; i += kPoThreads) { s_chi2[i] = 0; s_out[i] = 0; }
-  if (LDS_IN) {
-    // the inputs may sit in mapped host memory (zero-copy): read them exactly once
-    for (int i = tid; i < 3 * n; i += kPoThreads) s_in[i] = g_Xw[i];
-    for (int i = tid; i < n; i += kPoThreads) { s_in[3 * n + i] = g_ou[i]; s_in[4 * n + i] = g_ov[i]; s_in[5 * n + i] = g_our[i]; s_in[6 * n + i] = g_oinv[i]; }
-  }
-  const float* const Xw = LDS_IN ? s_in : g_Xw;
-  const float* const ou = LDS_IN ? s_in + 3 * n : g_ou;
-  const float* const ov = LDS_IN ? s_in + 4 * n : g_ov;
-  const float* const our = LDS_IN ? s_in + 5 * n : g_our;
-  const float* const oinv = LDS_IN ? s_in + 6 * n : g_oinv;
-  double x[6] = {0, 0, 0, 0, 0, 0};
-  double lambda = 0, ni = 2, currentChi = 0;
-  int nBadLM = 0;
-  bool robust = true;
-  PoseQ T = T0;
-  int nBad = 0;
-  if (tid == 0) { for (int i = 0; i < 7; i++) stats[i] = 0; for (int i = 0; i < 4; i++) chi_out[i] = 0; }
-  __syncthreads();
-  PO_T0();
-  for (int round = 0; round < 4; round++) {
-    T = T0;                                                   // setEstimate(toSE3Quat(mTcw)) every round (:1191)
-    double cnt = 0;
-    for (int i = tid; i < n; i += kPoThreads) cnt += !s_out[i];
-    const int n_active = (int)po_block_sum(cnt, s_wsum, sum_slot); sum_slot ^= 1;
-    int done = 0;
-    bool ok = n_active > 0;
-    for (int it = 0; it < 10 && ok; it++) {
-      // ---- computeActiveErrors + buildSystem at T
-      double acc[28];
-#pragma unroll
-      for (int i = 0; i < 28; i++) acc[i] = 0;
-      // a thread's correspondences i, i + 256 are linearised side by side (D2: one instruction stream per correspondence, the
-      // two interleaved) and accumulated in the order i, i + 256, ... as a scalar loop would: same sums, bit for bit.  A pass whose
-      // second halves all lie beyond n (n <= 256, 512 < n <= 768: the third correspondence of a thread) runs the one-correspondence
-      // form of the same arithmetic.  (Measured and dropped, round 4: keeping the accepted trial's evaluation -- camera point, 1/z,
-      // residual, Huber terms -- for the next buildSystem: bit-identical and a quarter of buildSystem's arithmetic less, but the 80
-      // registers it holds go to the accumulation registers as spills (36 -> 109): 158 -> 164 us at 450 correspondences; adding every
-      // Hessian entry to its accumulator as soon as it exists instead of forming the pair's 27 first: spills 36 -> 12, but the
-      // accumulators become two-deep dependency chains: 162 -> 169 us.)
-      for (int i0 = tid; i0 < n; i0 += 2 * kPoThreads) {
-        if ((i0 - tid) + kPoThreads >= n) {
-          // ---- single correspondences (uniform: no thread has a partner in this pass)
-          if (s_out[i0]) continue;
-          const double X[3] = {(double)Xw[3 * i0], (double)Xw[3 * i0 + 1], (double)Xw[3 * i0 + 2]};
-          const double ur1 = (double)our[i0], om1 = (double)oinv[i0];
-          const bool mono1 = po_neg(ur1);
-          PoEval<double> e1;
-          po_eval<double, bool>(T, X, (double)ou[i0], (double)ov[i0], ur1, om1, mono1, robust, cam, dM, dS, dsqM, dsqS, &e1);
-          double h1[27];
-          po_hessian<double, bool>(e1, om1, mono1, cam, h1);
-          s_chi2[i0] = e1.c2;
-          acc[27] += e1.rho0;
-#pragma unroll
-          for (int o = 0; o < 27; o++) acc[o] += h1[o];
-          continue;
-        }
-        const int i1r = i0 + kPoThreads;
-        const bool in1 = i1r < n;
-        const int i1 = in1 ? i1r : i0;
-        const bool act0 = !s_out[i0], act1 = in1 && !s_out[i1];
-        if (!(act0 || act1)) continue;                             // (both excluded is rare)
-        const D2 om{(double)oinv[i0], (double)oinv[i1]};
-        const D2 ur{(double)our[i0], (double)our[i1]};
-        const B2 mono = po_neg(ur);
-        PoEval<D2> e2;
-        {
-          const D2 X[3] = {D2{(double)Xw[3 * i0], (double)Xw[3 * i1]}, D2{(double)Xw[3 * i0 + 1], (double)Xw[3 * i1 + 1]},
-                           D2{(double)Xw[3 * i0 + 2], (double)Xw[3 * i1 + 2]}};
-          const D2 uu{(double)ou[i0], (double)ou[i1]}, vv{(double)ov[i0], (double)ov[i1]};
-          po_eval<D2, B2>(T, X, uu, vv, ur, om, mono, robust, cam, dM, dS, dsqM, dsqS, &e2);
-        }
-        D2 hh[27];
-        po_hessian<D2, B2>(e2, om, mono, cam, hh);
-        if (act0) {
-          s_chi2[i0] = e2.c2.a;
-          acc[27] += e2.rho0.a;
-#pragma unroll
-          for (int o = 0; o < 27; o++) acc[o] += hh[o].a;
-        }
-        if (act1) {
-          s_chi2[i1] = e2.c2.b;
-          acc[27] += e2.rho0.b;
-#pragma unroll
-          for (int o = 0; o < 27; o++) acc[o] += hh[o].b;
-        }
-      }
-      PO_ACC(0);
-      po_block_reduce<28>(acc, s_acc, s_part, red);
-      PO_ACC(1);
-      // every thread takes its own copy of the system: row li of H (upper triangle packed row-major in red[0..21)), b
-      double Hrow[6], b[6];
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        const int a = min(li, j), c = max(li, j);
-        Hrow[j] = red[a * 6 - (a * (a - 1)) / 2 + (c - a)];
-        b[j] = red[21 + j];
-      }
-      const double b_li = red[21 + li];
-      currentChi = red[27];
-      const double iniChi = currentChi;
-      if (it == 0) {
-        const double mx = fmax(fmax(fmax(fabs(red[0]), fabs(red[6])), fmax(fabs(red[11]), fabs(red[15]))), fmax(fabs(red[18]), fabs(red[20])));
-        lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
-      }
-      // ---- LM trials.  The damping values a run of REJECTED trials goes through are known in advance (lambda *= ni, ni *= 2 per
-      // rejection, levenberg.cpp:139-146), and H, b do not change inside an iteration: the four wavefronts solve
-      // (H + lambda_c I) x = b and form the trial pose for candidates c = 0..3 at the same time (each on its own SIMD -- they used
-      // to repeat the SAME solve four times), hand them over through LDS, and trial q picks up candidate q.  A rejected trial then
-      // costs no solve (23 of the 41 trials of a typical call).  Same operations per candidate as the sequential loop: same bits.
-      double rho = 0;
-      int qmax = 0;
-      for (;;) {
-        PO_ACC(5);
-        const int cslot = qmax & 3;
-        if (cslot == 0) {
-          double lam_c = lambda, ni_c = ni;
-          const int wv = tid >> 6;
-          for (int cc = 0; cc < wv; cc++) { lam_c *= ni_c; ni_c *= 2; }
-          double xc[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
-          const bool okc = po_solve6(Hrow, b_li, li, lam_c, xc);
-          PoseQ Tc;
-          pose_oplus_series(T, xc, &Tc);
-          if ((tid & 63) == 0) {
-            double* sc = s_cand[wv];
-#pragma unroll
-            for (int j = 0; j < 6; j++) sc[j] = xc[j];
-#pragma unroll
-            for (int j = 0; j < 4; j++) sc[6 + j] = Tc.q[j];
-#pragma unroll
-            for (int j = 0; j < 3; j++) sc[10 + j] = Tc.t[j];
-            sc[13] = okc ? 1.0 : 0.0;
-          }
-          __syncthreads();
-        }
-        const bool ok2 = s_cand[cslot][13] != 0.0;
-        PoseQ Tt;
-        if (ok2) {
-#pragma unroll
-          for (int j = 0; j < 6; j++) x[j] = s_cand[cslot][j];
-#pragma unroll
-          for (int j = 0; j < 4; j++) Tt.q[j] = s_cand[cslot][6 + j];
-#pragma unroll
-          for (int j = 0; j < 3; j++) Tt.t[j] = s_cand[cslot][10 + j];
-        } else {
-          pose_oplus_series(T, x, &Tt);                     // the solve failed: update with whatever x holds, as g2o does
-        }
-        PO_ACC(2);
-        double tchi = 0;
-        // the residuals of the LAST evaluation stay with the edges, accepted or not (:1196-1270 read e->chi2())
-        for (int i0 = tid; i0 < n; i0 += 2 * kPoThreads) {
-          if ((i0 - tid) + kPoThreads >= n) {
-            if (s_out[i0]) continue;
-            const double X[3] = {(double)Xw[3 * i0], (double)Xw[3 * i0 + 1], (double)Xw[3 * i0 + 2]};
-            const double ur1 = (double)our[i0];
-            PoEval<double> e1;
-            po_eval<double, bool>(Tt, X, (double)ou[i0], (double)ov[i0], ur1, (double)oinv[i0], po_neg(ur1), robust, cam, dM, dS, dsqM, dsqS, &e1);
-            s_chi2[i0] = e1.c2; tchi += e1.rho0;
-            continue;
-          }
-          const int i1r = i0 + kPoThreads;
-          const bool in1 = i1r < n;
-          const int i1 = in1 ? i1r : i0;
-          const bool act0 = !s_out[i0], act1 = in1 && !s_out[i1];
-          if (!(act0 || act1)) continue;
-          const D2 X[3] = {D2{(double)Xw[3 * i0], (double)Xw[3 * i1]}, D2{(double)Xw[3 * i0 + 1], (double)Xw[3 * i1 + 1]},
-                           D2{(double)Xw[3 * i0 + 2], (double)Xw[3 * i1 + 2]}};
-          const D2 uu{(double)ou[i0], (double)ou[i1]}, vv{(double)ov[i0], (double)ov[i1]}, ur{(double)our[i0], (double)our[i1]};
-          const D2 om{(double)oinv[i0], (double)oinv[i1]};
-          PoEval<D2> e2;
-          po_eval<D2, B2>(Tt, X, uu, vv, ur, om, po_neg(ur), robust, cam, dM, dS, dsqM, dsqS, &e2);
-          if (act0) { s_chi2[i0] = e2.c2.a; tchi += e2.rho0.a; }
-          if (act1) { s_chi2[i1] = e2.c2.b; tchi += e2.rho0.b; }
-        }
-        PO_ACC(3);
-        double tempChi = po_block_sum(tchi, s_wsum, sum_slot); sum_slot ^= 1;
-        PO_ACC(4);
-        if (!ok2) tempChi = 1.7976931348623157e308;
-        rho = currentChi - tempChi;
-        double scale = 0;
-#pragma unroll
-        for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
-        scale += 1e-3;
-        rho /= scale;
-        if (rho > 0 && fabs(tempChi) != INFINITY && tempChi == tempChi) {
-          double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
-          alpha = fmin(alpha, 2. / 3.);
-          lambda *= fmax(1. / 3., alpha);
-          ni = 2;
-          currentChi = tempChi;
-          T = Tt;
-        } else {
-          lambda *= ni; ni *= 2;
-        }
-        qmax++;
-        if (!(rho < 0 && qmax < 10)) break;
-      }
-      done++;
-      if (qmax == 10 || rho == 0) ok = false;
-      else {
-        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
-        if (nBadLM >= 3) ok = false;
-      }
-    }
-    if (tid == 0) { stats[1 + round] = done; chi_out[round] = currentChi; }
-    // ---- classification (:1196-1270): excluded edges get a fresh residual at the final pose, active ones keep the last one
-    double bl = 0;
-    for (int i = tid; i < n; i += kPoThreads) {
-      const float ur = our[i];
-      const bool mono = ur < 0;
-      if (s_out[i]) {
-        double err[3], Xc[3];
-        po_edge_error(T, Xw + 3 * (size_t)i, ou[i], ov[i], ur, cam, err, Xc);
-        const double om = (double)oinv[i];
-        s_chi2[i] = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono ? 0.0 : err[2] * (om * err[2]));
-      }
-      const float c2f = (float)s_chi2[i];
-      const bool bad = c2f > (mono ? 5.991f : 7.815f);
-      s_out[i] = bad;
-      bl += bad;
-    }
-    nBad = (int)po_block_sum(bl, s_wsum, sum_slot); sum_slot ^= 1;
-    if (round == 2) robust = false;                          // setRobustKernel(0)
-    if (n < 10) break;                                        // optimizer.edges().size() < 10
-  }
-  PO_ACC(5);
-  for (int i = tid; i < n; i += kPoThreads) outlier_out[i] = s_out[i];
-  if (tid == 0) { *T_out = T; stats[0] = nBad; }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");              // system-scope release of every wavefront's results (no acquire half)
-  __syncthreads();
-  if (tid == 0) *reinterpret_cast<volatile int*>(&stats[7]) = (int)seq;   // results are complete: the host spins on this word
-}
-
-}  // namespace
-
-#ifdef PO_PROFILE
-extern "C" int pose_opt_debug_prof(long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_po_prof), sizeof(g_po_prof)) != hipSuccess) return -1;
-  if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_po_prof), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-#endif
-
-// per-thread scratch of pose_optimize (PoseOptimization has no handle: the reference calls a static member); released when the thread exits
-namespace {
-struct PoScratch {
-  PinnedBuf<uint8_t> stage; DevBuf<uint8_t> dev; int device = -1; hipStream_t stream = nullptr; bool ext_stream = false;
-  void drop_stream() { if (stream && !ext_stream) orbg::release_stream(stream); stream = nullptr; ext_stream = false; }
-  void drop() { stage.release(); dev.release(); drop_stream(); }
-  ~PoScratch() { drop(); }
-};
-PoScratch& po_scratch() { static thread_local PoScratch sc; return sc; }
-}  // namespace
-
-// the calling thread's pose_optimize calls on `device` use the caller's stream from now on (NULL: the library's M stream again)
-extern "C" int pose_opt_set_stream(int device, void* hip_stream) {
-  int rc = select_device(device);
-  if (rc) return rc;
-  PoScratch& sc = po_scratch();
-  if (sc.device != device) { sc.drop(); sc.device = device; }
-  if (sc.stream) ORBG_HIP(hipStreamSynchronize(sc.stream));
-  sc.drop_stream();
-  if (hip_stream) { sc.stream = (hipStream_t)hip_stream; sc.ext_stream = true; }
-  return ORBG_OK;
-}
-
-extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
-  if (!p || !r || p->n < 0 || (p->n > 0 && (!p->Xw || !p->u || !p->v || !p->ur || !p->inv_sigma2 || !r->outlier))) return ORBG_BAD_ARG;
-  if (p->n > kPoThreads * kPoMaxPer) return ORBG_CAP_EXCEEDED;
-  int rc = select_device(p->device);
-  if (rc) return rc;
-  const int n = p->n;
-  memcpy(r->Tcw, p->Tcw, sizeof(float) * 16);
-  r->n_inliers = 0; r->n_bad = 0;
-  for (int i = 0; i < 4; i++) { r->iters[i] = 0; r->chi2[i] = 0; }
-  for (int i = 0; i < n; i++) r->outlier[i] = 0;
-  if (n < 3) return ORBG_OK;                                  // S/Optimizer.cc:1180-1181
-  // one pinned staging block: inputs in, results out (a per-thread cache keeps the allocation across calls); the stream comes from
-  // the library's pool (common.hpp: role "po" = M, non-blocking like all of the library's streams) or from pose_opt_set_stream
-  PoScratch& sc = po_scratch();
-  if (sc.device != p->device) { sc.drop(); sc.device = p->device; }
-  if (!sc.stream) { ORBG_HIP(orbg::create_stream(&sc.stream, "po")); sc.ext_stream = false; }
-  const size_t in_bytes = ((size_t)n * 7 * 4 + 15) & ~(size_t)15;
-  const size_t out_off = in_bytes;
-  const size_t out_bytes = sizeof(PoseQ) + 8 * sizeof(int) + 4 * sizeof(double) + (size_t)n + 64;
-  if ((rc = sc.stage.reserve(in_bytes + out_bytes + 64)) || (rc = sc.dev.reserve(in_bytes + out_bytes + 64))) return rc;
-  float* hs = reinterpret_cast<float*>(sc.stage.h);
-  memcpy(hs, p->Xw, (size_t)n * 12);
-  memcpy(hs + 3 * (size_t)n, p->u, (size_t)n * 4);
-  memcpy(hs + 4 * (size_t)n, p->v, (size_t)n * 4);
-  memcpy(hs + 5 * (size_t)n, p->ur, (size_t)n * 4);
-  memcpy(hs + 6 * (size_t)n, p->inv_sigma2, (size_t)n * 4);
-  // small problems: the kernel reads its inputs straight from this pinned block (once, into LDS); large ones get a device copy.
-  // Results always land in the pinned block, followed by a sequence number the host spins on.
-  const float* dX;
-  if (n <= kPoLdsN) dX = reinterpret_cast<const float*>(sc.stage.d);
-  else {
-    ORBG_HIP(hipMemcpyAsync(sc.dev.p, sc.stage.h, in_bytes, hipMemcpyHostToDevice, sc.stream));
-    dX = reinterpret_cast<const float*>(sc.dev.p);
-  }
-  uint8_t* dout = sc.stage.d + out_off;
-  PoseQ* dT = reinterpret_cast<PoseQ*>(dout);
-  double* dchi = reinterpret_cast<double*>(dout + sizeof(PoseQ));
-  int* dstats = reinterpret_cast<int*>(dout + sizeof(PoseQ) + 4 * sizeof(double));
-  uint8_t* dflag = dout + sizeof(PoseQ) + 4 * sizeof(double) + 8 * sizeof(int);
-  PoseQ T0;
-  {
-    const float* T = p->Tcw;
-    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
-    quat_from_R(R, T0.q);
-    quat_normalize(T0.q);
-    T0.t[0] = T[3]; T0.t[1] = T[7]; T0.t[2] = T[11];
-  }
-  Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
-  static thread_local unsigned po_seq = 0;
-  po_seq = (po_seq + 1) & 0x7FFFFFFFu;
-  if (po_seq == 0) po_seq = 1;
-  volatile int* seq_word = reinterpret_cast<volatile int*>(sc.stage.h + out_off + sizeof(PoseQ) + 4 * sizeof(double)) + 7;
-  *seq_word = 0;
-  if (n <= kPoLdsN)
-    hipLaunchKernelGGL(pose_opt_kernel<true>, dim3(1), dim3(kPoThreads), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n,
-                       dX + 5 * (size_t)n, dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
-  else
-    hipLaunchKernelGGL(pose_opt_kernel<false>, dim3(1), dim3(kPoThreads), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n,
-                       dX + 5 * (size_t)n, dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
-  ORBG_HIP(hipGetLastError());
-  {
-    bool got = false;
-    if (orbg::poll_allowed()) {
-      timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
-      for (unsigned spins = 0; !got; spins++) {
-        if (*seq_word == (int)po_seq) { got = true; break; }
-        if ((spins & 0xFFFF) == 0xFFFF) {
-          timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-          if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 100.0) break;
-        }
-      }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
-    if (!got) ORBG_HIP(hipStreamSynchronize(sc.stream));
-  }
-  const uint8_t* ho = sc.stage.h + out_off;
-  PoseQ Tf;
-  memcpy(&Tf, ho, sizeof(PoseQ));
-  memcpy(r->chi2, ho + sizeof(PoseQ), 4 * sizeof(double));
-  int stats[8];
-  memcpy(stats, ho + sizeof(PoseQ) + 4 * sizeof(double), sizeof(stats));
-  memcpy(r->outlier, ho + sizeof(PoseQ) + 4 * sizeof(double) + 8 * sizeof(int), (size_t)n);
-  r->n_bad = stats[0];
-  for (int i = 0; i < 4; i++) r->iters[i] = stats[1 + i];
-  r->n_inliers = n - r->n_bad;
-  double R[9];
-  quat_to_R(Tf.q, R);
-  for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) r->Tcw[4 * a + c] = (float)R[3 * a + c]; r->Tcw[4 * a + 3] = (float)Tf.t[a]; }
-  r->Tcw[12] = 0; r->Tcw[13] = 0; r->Tcw[14] = 0; r->Tcw[15] = 1;
-  return ORBG_OK;
 }

@@ -1554,34 +1554,24 @@ __host__ inline bool supports(int n) { return n >= 1 && make_geo(n).T <= 19; }
 
 struct Launch { const void* fn; size_t lds; bool wlds; bool cols; int threads; };
 
-// kernel-selection switches (A/B and test): the caller reads them once (lba_create) and hands them to pick() / launch()
-struct Switches {
-  bool tiles = false, t9_4w = false, w8 = false;
-  static Switches from_env() {
-    Switches s;
-    s.tiles = getenv("ORBG_LDLT_TILES") != nullptr; s.t9_4w = getenv("ORBG_LDLT_T9_4W") != nullptr; s.w8 = getenv("ORBG_LDLT_8W") != nullptr;
-    return s;
-  }
-};
 // dynamic LDS beyond 64 KB has to be allowed per kernel and per DEVICE: the owner of a device context (an lba handle) keeps one
 struct AttrCache { struct { const void* fn; size_t lds; } e[12] = {}; };
 
-__host__ inline Launch pick(int n, const Switches& sw) {
+// Which kernel a system of n unknowns gets (measured, tools/micro/ldlt_mfma_test): up to kColT tile rows the column kernel, 9 tile rows
+// the four-wavefront tile kernel with W in LDS, beyond that the 512-thread kernels (16 / 24 / 32 / 48 tiles per wavefront group).
+// (Rounds 2-4 kept an eight-wavefront tile kernel and a tile kernel for small windows behind switches: slower, removed in round 5.)
+__host__ inline Launch pick(int n) {
   const Geo g = make_geo(n);
   Launch L;
-  if (g.T <= kColT && !sw.tiles) {
+  if (g.T <= kColT) {
     L.fn = reinterpret_cast<const void*>(k_ldlt_cols); L.wlds = true; L.cols = true; L.threads = kThreads;
     L.lds = lds_doubles_cols(g) * sizeof(double);
     return L;
   }
   L.cols = false;
   L.threads = kThreads;
-  // (9 tile rows: the 4-wavefront kernel is as fast as the 8-wavefront one, 39.5-42.7 vs 37.0-43.9 us; ORBG_LDLT_T9_4W=1 selects it)
-  if (g.T <= 9 && !sw.t9_4w) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
-  else if (sw.w8) {
-    if (g.T <= 13) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<12, 4, false>); L.wlds = false; }
-    else { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<24, 5, false>); L.wlds = false; }
-  } else {
+  if (g.T <= 9) { L.fn = reinterpret_cast<const void*>(k_ldlt_mfma<6, 3, true>); L.wlds = true; }
+  else {
     L.threads = kBigThreads; L.wlds = false;
     if (g.T <= 10) L.fn = reinterpret_cast<const void*>(k_ldlt_big<16, 4>);
     else if (g.T <= 13) L.fn = reinterpret_cast<const void*>(k_ldlt_big<24, 4>);
@@ -1593,9 +1583,8 @@ __host__ inline Launch pick(int n, const Switches& sw) {
 }
 
 // St: the bordered matrix as a tile image (see image_put_rhs / k_image_pad), x: solution, wglob: wglob_doubles() of scratch
-__host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st, const Switches& sw,
-                                  AttrCache* cache) {
-  const Launch L = pick(n, sw);
+__host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st, AttrCache* cache) {
+  const Launch L = pick(n);
   // dynamic LDS beyond 64 KB has to be allowed per kernel, once per device (and again if a larger system comes along)
   AttrCache local;
   auto& attr = (cache ? cache : &local)->e;
@@ -1612,11 +1601,10 @@ __host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, d
   return hipLaunchKernel(L.fn, dim3(1), dim3(L.threads), args, L.lds, st);
 }
 
-// stand-alone tools (tools/micro): one device, switches from the environment of the process
+// stand-alone tools (tools/micro): one device
 __host__ inline hipError_t launch(int n, const double* St, double* x, int* ok, double* wglob, hipStream_t st) {
-  static const Switches sw = Switches::from_env();
   static AttrCache cache;
-  return launch(n, St, x, ok, wglob, st, sw, &cache);
+  return launch(n, St, x, ok, wglob, st, &cache);
 }
 
 }  // namespace ldltm

@@ -1104,32 +1104,13 @@ int orbm_internal_attach(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v
   return ORBG_OK;
 }
 
-// The same set-up WITHOUT the launch: the fused stereo constructor runs the grid build as one more workgroup of its stereo match
-// launch (extractor.hip, stereo_grid_kernel) and needs the frame's buffers for that.
-int orbm_internal_attach_prepare(orbm_frame* f, orbx_handle* h, const orbm_frame_view* v, hipStream_t stream, orbg::GridLaunchArgs* out) {
-  if (!f || !h || !v || !out) return ORBG_BAD_ARG;
-  const orbx_keypoint* dk; const uint8_t* dd; const float* du; const float* dz; const orbx_keypoint* hk; int n0; hipStream_t xs;
-  int rc = orbx_internal_left_features(h, &dk, &dd, &du, &dz, &hk, &n0, &xs);
-  if (rc) return rc;
-  if ((rc = frame_set_params(f, v, 0))) return rc;               // the count only exists on the device yet
-  const int xcap = orbx_internal_kp_capacity(h);
-  if (xcap >= ORBG_MAX_FRAME_FEATURES) return ORBG_CAP_EXCEEDED;
-  if ((rc = frame_reserve(f, std::max(std::max(f->cap, 4096), xcap)))) return rc;
-  f->has_uright = true;
-  f->kps_p = dk; f->desc_p = dd; f->uright_p = du; f->depth_p = dz; f->hk = hk; f->hk_cached_n = -1;
-  f->stream = stream;
-  out->kps = f->kps_p; out->fp = f->fp; out->cell_of = f->d_cell_of.p; out->cell_start = f->d_cell_start.p; out->cell_items = f->d_cell_items.p;
-  return ORBG_OK;
-}
-
 // Called when the host has COLLECTED the constructor (completion word seen: every result of the chain is released to system scope).
 // From here on the frame's searches need no ordering against the extractor's stream, and they must not sit behind the constructors
 // of LATER frames that a pipelined caller has already enqueued there (two frames ahead: SearchLocalPoints waited 129 us behind
-// Frame(t+2)): the frame goes back to its own stream.  ORBG_FRAME_KEEP_CTOR_STREAM=1 keeps the extractor's stream (rounds 1-3).
+// Frame(t+2)): the frame goes back to its own stream.
 void orbm_internal_set_n(orbm_frame* f, int n) {
-  static const bool keep = [] { const char* e = getenv("ORBG_FRAME_KEEP_CTOR_STREAM"); return e && e[0] == '1'; }();
   f->fp.n = n; f->hk_cached_n = -1;
-  if (!keep) f->stream = f->own_stream;
+  f->stream = f->own_stream;
 }
 
 // device-resident descriptors of the frame's features (for the vocabulary transform in bow.hip)

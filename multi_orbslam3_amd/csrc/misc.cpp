@@ -62,31 +62,15 @@ std::mutex g_pool_mu;
 DevicePool g_pool[64];
 bool pool_enabled() { static const bool on = [] { const char* e = getenv("ORBG_STREAM_POOL"); return !(e && e[0] == '0'); }(); return on; }
 
-hipError_t create_own(hipStream_t* st, const char* role) {
-  char name[32];
-  snprintf(name, sizeof name, "ORBG_PRIO_%s", role);
-  for (char* c = name; *c; c++) if (*c >= 'a' && *c <= 'z') *c = (char)(*c - 'a' + 'A');
-  const char* e = getenv(name);
-  const int prio = e ? atoi(e) : 0;
-  if (prio == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-  int lo = 0, hi = 0;                                   // numerically hi <= lo; hi is the greatest priority
-  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio < 0 ? hi : lo);
-}
+hipError_t create_own(hipStream_t* st, const char* /*role*/) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
 
 // the four streams of a device, created together (g_pool_mu held)
 hipError_t make_pool(DevicePool& P) {
   if (P.made) return hipSuccess;
   hipStream_t s4[4] = {nullptr, nullptr, nullptr, nullptr};
-  // ORBG_POOL_PRIO = four characters over (L, E0, E1, M): 'h' greatest priority, 'l' least, anything else default
-  const char* pr = getenv("ORBG_POOL_PRIO");
-  int lo = 0, hi = 0;
-  if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) pr = nullptr;
+  // (stream priorities were measured in rounds 3-4: they open further hardware queues and were slower in every combination)
   for (int i = 0; i < 4; i++) {
-    const char pc = (pr && strlen(pr) > (size_t)i) ? pr[i] : '-';
-    const hipError_t e = pc == 'h' ? hipStreamCreateWithPriority(&s4[i], hipStreamNonBlocking, hi)
-                       : pc == 'l' ? hipStreamCreateWithPriority(&s4[i], hipStreamNonBlocking, lo)
-                                   : hipStreamCreateWithFlags(&s4[i], hipStreamNonBlocking);
+    const hipError_t e = hipStreamCreateWithFlags(&s4[i], hipStreamNonBlocking);
     if (e != hipSuccess) {
       for (int j = 0; j < i; j++) (void)hipStreamDestroy(s4[j]);
       return e;
@@ -190,9 +174,7 @@ __global__ void orbg_signal_kernel(volatile unsigned* flag, unsigned seq) {
 int StreamSignal::post(hipStream_t st) {
   if (!word.h) { int rc = init(); if (rc) return rc; }
   seq++;
-  // ORBG_SIGNAL_WRITEVALUE=1: the stream's own write command (hipStreamWriteValue32: no kernel dispatch) instead of the signal kernel
-  static const bool wv = [] { const char* e = getenv("ORBG_SIGNAL_WRITEVALUE"); return e && e[0] == '1'; }();
-  if (wv) { ORBG_HIP(hipStreamWriteValue32(st, (void*)word.d, seq, 0)); return ORBG_OK; }
+  // (hipStreamWriteValue32 instead of a one-thread kernel: measured +2-3 us per search, round 4)
   hipLaunchKernelGGL(orbg_signal_kernel, dim3(1), dim3(1), 0, st, (volatile unsigned*)word.d, seq);
   ORBG_HIP(hipGetLastError());
   return ORBG_OK;

@@ -138,7 +138,7 @@ def cores_for_agent(device_index, slot, per_agent=3):
     try:
         cores = _physical_cores_of_gpu_node(device_index)
         n_local = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
-        if n_local == 1 and slot == 0 and os.environ.get("ORBG_FIXED_CORES", "0") != "1":
+        if n_local == 1 and slot == 0:
             got = _pick_idle_cores(cores, _cpu_busy(), per_agent)
             if got is not None:
                 return got

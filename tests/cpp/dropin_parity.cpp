@@ -162,6 +162,9 @@ static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_
         for (auto* p : local) vs += p->mnVisible + 1000 * (int)p->mbTrackInView;
         o.vis_varied.push_back(vs);
       };
+      struct Saved { int nObs; Mat desc; float dmin, dmax; };
+      std::vector<Saved> keep;
+      for (auto* p : local) keep.push_back(Saved{p->nObs, p->mDescriptor, p->mfMinDistance, p->mfMaxDistance});
       od::local_map_cache<Ops>().invalidate();
       varied(90, 0, 60);                                   // uploads the map: features 0..59 of the matched ones hold their points
       varied(91, 60, 120);                                 // cached map, OTHER held features: the first 60 points are candidates again
@@ -176,10 +179,11 @@ static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_
       }
       varied(95, 10, 50);
       varied(96, 50, 10);                                  // (nothing held) the re-described points once more, from the refreshed cache
+      for (size_t j = 0; j < local.size(); j++) { local[j]->nObs = keep[j].nObs; local[j]->mDescriptor = keep[j].desc; local[j]->mfMinDistance = keep[j].dmin; local[j]->mfMaxDistance = keep[j].dmax; }
     }
     od::local_map_cache<Ops>().invalidate();
-    for (auto* p : local) p->mbBad = false;
     for (size_t j = 0; j < local.size(); j++) local[j]->mbBad = (j % 41) == 7;
+    again(local, 78);                                      // (the cache is warm again, as after a_cached)
     std::vector<Mat> saved;
     for (size_t j = 0; j < local.size(); j += 3) { saved.push_back(local[j]->mWorldPos); local[j]->mWorldPos.ptr<float>(0)[2] += 40.0f; }
     o.a_stale = again(local, 79);
@@ -296,7 +300,9 @@ int main() {
                "SearchLocalPoints with changing per-frame state, call %zu: %d features differ from the oracle's fresh read (visible sums %d vs %d, %d matched)", q,
                ndiff(g.a_varied[q], c.a_varied[q]), g.vis_varied[q], c.vis_varied[q], nm);
       }
-      EXPECT(ndiff(g.a_varied[0], g.a_varied[1]) > 0 && ndiff(g.a_varied[4], g.a_varied[5]) > 0, "the varied-state calls do not exercise anything");
+      EXPECT(g.vis_varied[1] != g.vis_varied[2] && ndiff(g.a_varied[2], g.a_varied[3]) > 0 && ndiff(g.a_varied[4], g.a_varied[5]) + ndiff(g.a_varied[3], g.a_varied[4]) > 0,
+             "the varied-state calls do not exercise anything (visible sums %d %d; %d / %d / %d features differ between consecutive calls)", g.vis_varied[1],
+             g.vis_varied[2], ndiff(g.a_varied[2], g.a_varied[3]), ndiff(g.a_varied[3], g.a_varied[4]), ndiff(g.a_varied[4], g.a_varied[5]));
       EXPECT(g.a_stale == g.a_fused, "moved points were noticed without a change of the map's change index (%d features)", ndiff(g.a_stale, g.a_fused));
       EXPECT(g.a_moved == c.a_moved && ndiff(g.a_moved, g.a_fused) > 20, "after IncreaseChangeIndex: %d features differ between the entry-point sets, %d from the unmoved map",
              ndiff(g.a_moved, c.a_moved), ndiff(g.a_moved, g.a_fused));

@@ -120,3 +120,26 @@ def test_agent_loop_library_loads_and_its_structures_match_the_binding():
     from multi_orbslam3_amd import agent
     lib = agent.load()
     assert lib.agent_sizeof(0) > 200 and hasattr(lib, "agent_run") and hasattr(lib, "agent_drain")
+
+
+def test_wait_policy_per_thread_role():
+    """orbg_set_wait_policy / orbg_get_wait_policy (include/orbgpu.h "Host threads"): per role of the waiting thread, process-wide,
+    changeable at run time; the start-up policy comes from ORBG_NO_POLL.  No GPU involved."""
+    import subprocess
+    import sys
+    code = ("from multi_orbslam3_amd import _capi\n"
+            "lib = _capi.load()\n"
+            "print([lib.orbg_get_wait_policy(r) for r in range(3)], lib.orbg_get_wait_policy(3), lib.orbg_set_wait_policy(7, 1))\n"
+            "assert lib.orbg_set_wait_policy(1, 1) == 0 and lib.orbg_set_wait_policy(0, 0) == 0\n"
+            "print([lib.orbg_get_wait_policy(r) for r in range(3)])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_val, first in ((None, [1, 1, 1]), ("1", [0, 0, 0]), ("all", [0, 0, 0]), ("lba,ingest", [1, 0, 0]), ("caller", [0, 1, 1])):
+        env = {k: v for k, v in os.environ.items() if k != "ORBG_NO_POLL"}
+        if env_val is not None:
+            env["ORBG_NO_POLL"] = env_val
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-1500:]
+        lines = r.stdout.strip().splitlines()
+        assert lines[0] == "%s -2 -2" % first, (env_val, lines)
+        want = list(first); want[1] = 1; want[0] = 0
+        assert lines[1] == str(want), (env_val, lines)

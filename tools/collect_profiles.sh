@@ -28,7 +28,10 @@ python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' | tail -1 > "$OUT
 python3 bench.py --steps 400 --warmup 40 --no-pipeline --no-cpu-baseline --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_sync_ctor.json" || true
 python3 bench.py --steps 400 --warmup 40 --lba-mode inline --no-pipeline --no-cpu-baseline --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_inline.json" || true
 python3 bench.py --config C4 --steps 200 --warmup 20 --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_c4.json" || true
-python3 bench.py --config mono --steps 400 --warmup 40 --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_mono.json" || true
+python3 bench.py --config mono --steps 2000 --warmup 100 --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_mono.json" || true
+python3 bench.py --config mono_dist --steps 2000 --warmup 100 --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_mono_dist.json" || true
+python3 bench.py --config C3 --steps 2000 --warmup 100 --no-secondary --no-dropin 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_c3_1rank.json" || true
+ORBG_BENCH_SHARE_GPU=1 python3 bench.py --config C5 --gpus 2 --steps 200 --warmup 20 --no-secondary --no-dropin --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_c5_2ranks_shared_gpu.json" || true
 python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-secondary --no-dropin --server-tick 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_server_tick.json" || true
 tests/cpp/dropin_bench 40 > "$OUT/dropin_bench.json" 2> "$OUT/dropin_bench.txt" || true
 tools/micro/fp64_latency > "$OUT/micro_fp64_issue.txt" 2>&1 || true
@@ -43,7 +46,6 @@ python3 tools/lba_timeline.py "$(find "$OUT/stats_async" -name "*kernel_trace.cs
 python3 tools/micro/oct_prof.py > "$OUT/octree_phases.txt" 2>&1 || true
 SPREAD=0 python3 tools/search_large_map.py 1 8 32 128 > "$OUT/search_large_map_dense.txt" 2>&1 || true
 python3 tools/po_sweep.py 500 > "$OUT/pose_opt_sweep.txt" 2>&1 || true
-bash tools/noise_matrix.sh none none siblings l3 membw everywhere > "$OUT/noise_matrix.txt" 2>&1 || true
 bash tools/bench_driver_repeat.sh 5 > "$OUT/bench_driver_repeat.txt" 2>&1 || true
 f=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 profiles/pmc_aggregate.py FETCH_SIZE="$f" WRITE_SIZE="$w" > "$OUT/pmc_fetch_write_per_kernel.json" || true; fi
