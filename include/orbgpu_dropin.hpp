@@ -609,24 +609,28 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   // table keyed by the keyframe's address
   size_t tab_size = 64;
   while (tab_size < 4 * vKF.size()) tab_size *= 2;
-  std::vector<std::pair<KeyFrameT*, int>> kfTab(tab_size, std::pair<KeyFrameT*, int>(nullptr, -1));
+  // (per keyframe: its column, its vertex id and whether its observations make edges -- !isBad() && GetMap() == pCurrentMap, :2003 --
+  // evaluated once per call instead of once per observation: both are stable while this thread, LocalMapping, is in here)
+  struct KfRec { KeyFrameT* kf; int col; size_t vid; bool usable; };
+  std::vector<KfRec> kfTab(tab_size, KfRec{nullptr, -1, 0, false});
   auto kf_slot = [&](KeyFrameT* kf) { return ((reinterpret_cast<uintptr_t>(kf) >> 4) * 0x9E3779B97F4A7C15ull >> 20) & (tab_size - 1); };
   std::vector<float> poses(16 * vKF.size()); std::vector<uint8_t> fixed(vKF.size());
   for (size_t i = 0; i < vKF.size(); i++) {
     vKF[i] = kf_fixed[i].first;
     size_t h = kf_slot(vKF[i]);
-    while (kfTab[h].first) h = (h + 1) & (tab_size - 1);
-    kfTab[h] = {vKF[i], (int)i};
+    while (kfTab[h].kf) h = (h + 1) & (tab_size - 1);
+    kfTab[h] = KfRec{vKF[i], (int)i, vertex_id(vKF[i]->mnId, vKF[i]->mnClientId, true), !vKF[i]->isBad() && vKF[i]->GetMap() == pCurrentMap};
     const auto Tm = vKF[i]->GetPose();
     std::memcpy(&poses[16 * i], mat_f32(Tm), 64);
     fixed[i] = kf_fixed[i].second;
   }
-  auto kf_index = [&](KeyFrameT* kf) -> int {
+  auto kf_rec = [&](KeyFrameT* kf) -> const KfRec* {
     for (size_t h = kf_slot(kf);; h = (h + 1) & (tab_size - 1)) {
-      if (kfTab[h].first == kf) return kfTab[h].second;
-      if (!kfTab[h].first) return -1;
+      if (kfTab[h].kf == kf) return &kfTab[h];
+      if (!kfTab[h].kf) return nullptr;
     }
   };
+  auto kf_index = [&](KeyFrameT* kf) -> int { const KfRec* r = kf_rec(kf); return r ? r->col : -1; };
   ORBGPU_GLUE_T("keyframe table");
   // the points in ascending vertex id: a permutation is sorted, not the records (each holds a std::map)
   std::vector<std::pair<size_t, uint32_t>> order(vLP.size());
@@ -634,7 +638,11 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   std::sort(order.begin(), order.end());
   ORBGPU_GLUE_T("sort points");
   std::vector<MapPointT*> vMP(vLP.size());
-  std::vector<float> pts; std::vector<lba_edge> edges; std::vector<std::pair<KeyFrameT*, MapPointT*>> edgeOwner;
+  // (the flat arrays of a call live in the calling thread -- LocalMapping -- across calls: no allocation, no zero fill per keyframe)
+  static thread_local std::vector<float> pts, oposes, opts; static thread_local std::vector<lba_edge> edges;
+  static thread_local std::vector<uint8_t> eout, edep; static thread_local std::vector<double> echi;
+  std::vector<std::pair<KeyFrameT*, MapPointT*>> edgeOwner;
+  pts.clear(); edges.clear();
   pts.reserve(3 * vLP.size()); edges.reserve(8 * vLP.size()); edgeOwner.reserve(8 * vLP.size());
   struct ObsRef { size_t vid; KeyFrameT* kf; int li; int col; };
   std::vector<ObsRef> obs;
@@ -649,11 +657,11 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
     obs.clear();
     for (const auto& ob : lp.obs) {
       KeyFrameT* kf = ob.first;
-      const int col = kf_index(kf);
-      if (col < 0 || kf->isBad() || kf->GetMap() != pCurrentMap) continue;                   // :2003
+      const KfRec* kr = kf_rec(kf);
+      if (!kr || !kr->usable) continue;                                                      // :2003
       const int li = std::get<0>(ob.second);
       if (li < 0) continue;                                                                  // :2007
-      obs.push_back(ObsRef{vertex_id(kf->mnId, kf->mnClientId, true), kf, li, col});
+      obs.push_back(ObsRef{kr->vid, kf, li, kr->col});
     }
     std::sort(obs.begin(), obs.end(), [](const ObsRef& a, const ObsRef& b) { return a.vid < b.vid; });
     for (const ObsRef& o : obs) {
@@ -665,8 +673,7 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   ORBGPU_GLUE_T("points + edges");
   lba_problem P{(int32_t)vKF.size(), (int32_t)vMP.size(), (int32_t)edges.size(), poses.data(), fixed.data(), pts.data(), edges.data(),
                 pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, pMap->IsInertial() ? 100.0 : 0.0 /* :1924-1925 */, 5, 10, 0};
-  std::vector<float> oposes(poses.size()), opts(pts.size()); std::vector<uint8_t> eout(edges.size()), edep(edges.size());
-  std::vector<double> echi(edges.size());
+  oposes.resize(poses.size()); opts.resize(pts.size()); eout.resize(edges.size()); edep.resize(edges.size()); echi.resize(edges.size());
   lba_result R{}; R.poses = oposes.data(); R.points = opts.data(); R.edge_outlier = eout.data(); R.edge_depth_pos = edep.data(); R.edge_chi2 = echi.data();
   // *pbStopFlag is LocalMapping::mbAbortBA, a bool Tracking raises through InterruptBA() while this runs (S/LocalMapping.cc:381-386):
   // the pointer goes to the library unchanged and is polled there between LM iterations / trials, where g2o polls it
@@ -684,10 +691,14 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
     decltype(kf->GetPose()) T; make_mat(T, 4, 4, &oposes[16 * (size_t)kf_index(kf)]);
     kf->SetPose(T, true);                                                                    // :2327 (bLock: mbPoseLock on the server)
   }
-  for (size_t j = 0; j < vMP.size(); j++) {                                                  // :2375-2383
-    decltype(vMP[j]->GetWorldPos()) X; make_mat(X, 3, 1, &opts[3 * j]);
-    vMP[j]->SetWorldPos(X, true);                                                            // :2386
-    vMP[j]->UpdateNormalAndDepth();
+  if (!vMP.empty()) {                                                                        // :2375-2383
+    decltype(vMP[0]->GetWorldPos()) X; make_mat(X, 3, 1, &opts[0]);                          // ONE 3 x 1 matrix, refilled per point:
+    float* Xd = const_cast<float*>(mat_f32(X));                                              // SetWorldPos copies it (Pos.copyTo, S/MapPoint.cc:125)
+    for (size_t j = 0; j < vMP.size(); j++) {
+      Xd[0] = opts[3 * j]; Xd[1] = opts[3 * j + 1]; Xd[2] = opts[3 * j + 2];
+      vMP[j]->SetWorldPos(X, true);                                                          // :2386
+      vMP[j]->UpdateNormalAndDepth();
+    }
   }
   pMap->IncreaseChangeIndex();                                                               // :2397 (Tracking reads it: mbMapUpdated)
   ORBGPU_GLUE_T("write-back");

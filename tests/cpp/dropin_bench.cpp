@@ -60,9 +60,11 @@ struct TimedOps {
     od::GpuOps::ThreadState& s = od::GpuOps::state();
     const double t0 = now_us();
     if (!s.local_map) s.local_map.reset(new orbgpu::MapPointsOnDevice(std::max(pts.m, 16384)));
-    s.local_map->Upload(pts);
+    orbm_worldpoints_view up = pts;                    // (as GpuOps::search_local: the per-frame exclusions travel with the call)
+    up.skip = nullptr;
+    s.local_map->Upload(up);
     s.local_map_loaded = true;
-    const int rc = orbm_search_local_points_vis(f, s.local_map->handle(), Tcw, nullptr, th, far_points, th_far, nnratio, amp, aob, n, in_frustum);
+    const int rc = orbm_search_local_points_vis(f, s.local_map->handle(), Tcw, pts.skip, th, far_points, th_far, nnratio, amp, aob, n, in_frustum);
     t_call += now_us() - t0;
     return rc;
   }

@@ -13,7 +13,9 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 def _build(name, with_oracle=False):
     lib_dir = os.path.join(ROOT, "multi_orbslam3_amd")
     exe = os.path.join(CPP, name)
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CPP,
+    # (opencv_branches: the HAVE_OPENCV lines of the adapters against the signature-only stub of tests/cpp/opencv_stub)
+    stub = ["-I", os.path.join(CPP, "opencv_stub")] if name == "opencv_branches" else []
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CPP] + stub + [
            os.path.join(CPP, name + ".cpp"), "-o", exe, "-pthread", "-L", lib_dir, "-lorbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib",
            "-L/opt/rocm/lib"]
     if with_oracle:
@@ -30,13 +32,23 @@ def _no_gpu():
     return _capi.load().orbg_device_count() <= 0
 
 
-@pytest.mark.parametrize("name,with_oracle", [("adapter_smoke", False), ("dropin_parity", True), ("dropin_bench", False)])
+@pytest.mark.parametrize("name,with_oracle", [("adapter_smoke", False), ("dropin_parity", True), ("dropin_bench", False), ("opencv_branches", False)])
 def test_host_side_compiles_links_and_fails_loudly_without_gpu(name, with_oracle):
     exe = _build(name, with_oracle)
     if not _no_gpu():
         pytest.skip("a GPU is present; see the gpu-marked tests")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and "no usable HIP device" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_opencv_signature_branches_run_on_gpu():
+    """ORBextractor::operator()(cv::InputArray, cv::InputArray, vector<cv::KeyPoint>&, cv::OutputArray, vector<int>&) -- the reference's exact
+    signature, I/ORBextractor.h:61-63 -- and the cv::Mat helpers of the glue, compiled against tests/cpp/opencv_stub (no OpenCV in this
+    image; the stub pins nothing about OpenCV): same features as the pointer overload, -1 on an empty image."""
+    exe = _build("opencv_branches")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "identical to the pointer overload: 1" in r.stdout, (r.stdout, r.stderr)
 
 
 @pytest.mark.gpu
