@@ -1318,17 +1318,21 @@ def main():
         K_ = FRAMES_PER_KF
         gate_first = 40000                                   # (a multiple of FRAMES_PER_KF: the gate's first step is a keyframe step)
         if use_cxx:
-            gate_pipelined = True                            # the main region's configuration (pipelined, host images, features on host)
-            if feature_outputs is None:
-                loop.drain()
+            # the main region's configuration (pipelined or not, host or device images); the features come to the host through the
+            # constructor's own delivery (orbx_set_frame_outputs for the two-halves form, its output arguments for the synchronous one)
+            loop.drain()
+            sync_out = None
+            if pipeline and feature_outputs is None:
                 feature_outputs = [e.set_frame_outputs(cfg["frame_cap"]) for e in exs]
-            loop.configure(gate_pipelined, True, ingest_async, submit_first, args.lba_mode == "async", False, ahead=ctor_ahead)
+            if not pipeline:
+                sync_out = loop.set_sync_outputs(cfg["frame_cap"])
+            loop.configure(pipeline, host_images, ingest_async, submit_first, args.lba_mode == "async", False, ahead=ctor_ahead)
             loop.capture_first_search(True)
             loop.run(gate_first - K_, K_)                    # the keyframe step before the gate makes its local map resident
 
             def run_step(i):
                 st = loop.run(i, 1)
-                out = feature_outputs[i % loop.c.ring]
+                out = sync_out if sync_out is not None else feature_outputs[i % loop.c.ring]
                 return dict(nl=st.last_nl, nr=st.last_nr, n1=st.last_n1, n2=st.last_n2, kps=out["kps"], kps_un=out["kps_un"], desc=out["desc"],
                             uright=out["uright"], depth=out["depth"], amp_frame=loop.amp_after_frame, amp=loop.amp, aob=loop.aob)
 
@@ -1353,6 +1357,7 @@ def main():
                                  views, frames, host_imgs, seq, map_view_of_step, lp, lba_out, th_frame, mono_flag, bounds=frame_bounds)
             if use_cxx:
                 loop.capture_first_search(False)
+                loop.set_sync_outputs(0)
             parity["loop"] = "libagentloop.so, configured as the main timed region" if use_cxx else "python loop (ctypes wrappers)"
         else:
             parity = {"skipped": "this python-loop configuration leaves the features in HBM (use the default --loop cxx)"}

@@ -26,7 +26,9 @@ class Cfg(C.Structure):
                 ("lba_async", C.c_int), ("pose_opt", C.c_int), ("th_frame", C.c_float), ("mono", C.c_int), ("nn_frame", C.c_float),
                 ("nn_map", C.c_float), ("amp", C.c_void_p), ("aob", C.c_void_p), ("cap", C.c_int), ("in_flight", C.c_int32 * 4),
                 ("ahead", C.c_int32), ("ring", C.c_int32), ("lba_in_flight", C.c_int32), ("last_view_dev", C.c_void_p), ("last_view_frame", C.c_int32),
-                ("amp_after_frame", C.c_void_p), ("mono_agent", C.c_int32), ("dist", C.c_void_p)]
+                ("amp_after_frame", C.c_void_p), ("mono_agent", C.c_int32), ("dist", C.c_void_p),
+                ("sync_kps", C.c_void_p), ("sync_kps_un", C.c_void_p), ("sync_desc", C.c_void_p), ("sync_uright", C.c_void_p),
+                ("sync_depth", C.c_void_p), ("sync_cap", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -111,6 +113,22 @@ class AgentLoop:
         self.keep.append(dist)
         c.dist = None if dist is None else C.addressof(dist)
         self.c = c
+
+    def set_sync_outputs(self, cap):
+        """Host arrays the SYNCHRONOUS constructor of the loop delivers mvKeys / mvKeysUn / mDescriptors / mvuRight / mvDepth into
+        (cap = 0: off again).  Returns them as a dict (as ORBextractor.set_frame_outputs does for the two-halves constructor)."""
+        c = self.c
+        if cap <= 0:
+            c.sync_kps = c.sync_kps_un = c.sync_desc = c.sync_uright = c.sync_depth = None
+            c.sync_cap = 0
+            self._sync_out = None
+            return None
+        out = dict(kps=np.zeros(cap, capi.KEYPOINT_DTYPE), kps_un=np.zeros(cap, capi.KEYPOINT_DTYPE), desc=np.zeros((cap, 32), np.uint8),
+                   uright=np.zeros(cap, np.float32), depth=np.zeros(cap, np.float32))
+        c.sync_kps, c.sync_kps_un, c.sync_desc = out["kps"].ctypes.data, out["kps_un"].ctypes.data, out["desc"].ctypes.data
+        c.sync_uright, c.sync_depth, c.sync_cap = out["uright"].ctypes.data, out["depth"].ctypes.data, int(cap)
+        self._sync_out = out
+        return out
 
     def capture_first_search(self, on=True):
         """From now on every step also copies F.mvpMapPoints as SearchByProjection(Current, Last) left it into

@@ -56,6 +56,9 @@ typedef struct agent_cfg {
                                                              // (bench.py's in-job parity gate compares both searches with the oracle)
   int32_t mono_agent;                                        // 1: a monocular client -- Frame::Frame(mono) (S/Frame.cc:260-358) from host_left / dev_left
   const orbx_distortion* dist;                               // mono: mDistCoef (NULL: none), undistorted on the device by the constructor
+  // host arrays the SYNCHRONOUS constructor delivers the left features into (the output arguments of orbx_frame_stereo / orbx_frame_mono;
+  // the two-halves constructor delivers through orbx_set_frame_outputs); all NULL / 0: counts only
+  orbx_keypoint* sync_kps; orbx_keypoint* sync_kps_un; uint8_t* sync_desc; float* sync_uright; float* sync_depth; int32_t sync_cap;
 } agent_cfg;
 
 typedef struct agent_stats {
@@ -133,16 +136,16 @@ int agent_run(agent_cfg* c, int64_t first_step, int n_steps, int last_is_final, 
       c->in_flight[cur] = 0;
       if (!c->submit_first && (rc = submit_ahead(1, ahead))) break;
     } else if (c->mono_agent) {
-      rc = c->host_images ? orbx_frame_mono(c->ex[0], c->fr[0], c->frame_view, c->dist, fin.host_left, c->width, c->height, c->stride, nullptr, nullptr,
-                                            nullptr, 0, &nl)
-                          : orbx_frame_mono_dev(c->ex[0], c->fr[0], c->frame_view, c->dist, fin.dev_left, c->width, c->height, c->stride, nullptr,
-                                                nullptr, nullptr, 0, &nl);
+      rc = c->host_images ? orbx_frame_mono(c->ex[0], c->fr[0], c->frame_view, c->dist, fin.host_left, c->width, c->height, c->stride, c->sync_kps,
+                                            c->sync_kps_un, c->sync_desc, c->sync_cap, &nl)
+                          : orbx_frame_mono_dev(c->ex[0], c->fr[0], c->frame_view, c->dist, fin.dev_left, c->width, c->height, c->stride, c->sync_kps,
+                                                c->sync_kps_un, c->sync_desc, c->sync_cap, &nl);
     } else if (c->host_images) {
       rc = orbx_frame_stereo(c->ex[0], c->fr[0], c->frame_view, fin.host_left, fin.host_right, c->width, c->height, c->stride, c->bf, c->b,
-                             nullptr, nullptr, nullptr, nullptr, 0, &nl, &nr);
+                             c->sync_kps, c->sync_desc, c->sync_uright, c->sync_depth, c->sync_cap, &nl, &nr);
     } else {
       rc = orbx_frame_stereo_dev(c->ex[0], c->fr[0], c->frame_view, fin.dev_left, fin.dev_right, c->width, c->height, c->stride, c->bf, c->b,
-                                 nullptr, nullptr, nullptr, nullptr, 0, &nl, &nr);
+                                 c->sync_kps, c->sync_desc, c->sync_uright, c->sync_depth, c->sync_cap, &nl, &nr);
     }
     if (rc) break;
     if (nl > c->cap) { rc = ORBG_CAP_EXCEEDED; break; }
