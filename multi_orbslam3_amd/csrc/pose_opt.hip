@@ -513,6 +513,282 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
   if (tid == 0) *reinterpret_cast<volatile int*>(&stats[7]) = (int)seq;   // results are complete: the host spins on this word
 }
 
+
+// ---- The same solve with EIGHT wavefronts for up to 512 correspondences (what Tracking hands over: 300-700 per call at 1000-2000
+// features): one correspondence per thread, kept in registers, two wavefronts per SIMD.  A lone wavefront issues a dependent FP64
+// instruction every 8.3-9 cycles where the pipe takes one per 4.2 (tools/micro/fp64_latency): the per-correspondence phases
+// (linearisation, trial evaluation) of the four-wavefront kernel run at ~9 cycles per instruction; with a second wavefront on every
+// SIMD they share the issue slots.  What made round 3's eight-wavefront attempt slower is avoided: the LM trial solves (6 x 6 LDL^T
+// + exponential map, ~1200 FP64 instructions) run on wavefronts 0-3 only, one candidate each, while 4-7 wait at the barrier; and the
+// block sums keep the ORDER of the four-wavefront kernel -- correspondences t and t + 256 sit on neighbouring lanes, the even one adds
+// its neighbour's term behind its own (exactly what thread t did there), then the same tree over those 256 sums -- so every sum,
+// every LM decision and every result is bit-identical to pose_opt_kernel.
+constexpr int kPoWide = 512;
+// the value the neighbouring lane (lane ^ 1) holds: one DPP move per 32-bit half (quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ double po_lane_partner(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// Threads 2t and 2t + 1 hold the correspondences t and t + 256 of the four-wavefront kernel's thread t: the even lane adds its
+// neighbour's term behind its own (no LDS, no barrier) and plays thread t in that kernel's reduction.
+template <int NV>
+__device__ inline void po_block_reduce_wide(const double* vals, double* s_acc, double* s_part, double* out) {
+  const int tid = threadIdx.x, t = tid >> 1;
+  const int col = (t >> 5) * 33 + (t & 31);
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    const double sum = vals[v] + po_lane_partner(vals[v]);
+    if (!(tid & 1)) s_acc[v * kPoRow + col] = sum;
+  }
+  __syncthreads();
+  if (tid < NV * 8) {
+    const double* p = s_acc + (tid >> 3) * kPoRow + (tid & 7) * 33;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { a0 += p[4 * j]; a1 += p[4 * j + 1]; a2 += p[4 * j + 2]; a3 += p[4 * j + 3]; }
+    s_part[tid] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (tid < NV) {
+    const double* p = s_part + tid * 8;
+    out[tid] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  }
+  __syncthreads();
+}
+// sum of one term per thread in the four-wavefront kernel's order: (term of t) + (term of t + 256) on the even lane, then that
+// kernel's DPP tree over its threads 0..255 (wavefronts 0-3 here, through LDS) and the four wave totals in wave order
+__device__ __forceinline__ double po_block_sum_wide(double v, double* s_pair, double (*wsum)[4], int slot) {
+  const int tid = threadIdx.x;
+  const double pr = v + po_lane_partner(v);
+  if (!(tid & 1)) s_pair[tid >> 1] = pr;
+  __syncthreads();
+  if (tid < 256) {
+    const double w = wave_sum_f64(s_pair[tid]);
+    if ((tid & 63) == 0) wsum[slot][tid >> 6] = w;
+  }
+  __syncthreads();
+  return ((wsum[slot][0] + wsum[slot][1]) + wsum[slot][2]) + wsum[slot][3];
+}
+// exact count (every term 0 or 1): any order
+__device__ __forceinline__ double po_block_count_wide(double v, double* s_cnt) {
+  const double w = wave_sum_f64(v);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = w;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) s += s_cnt[k];
+  __syncthreads();
+  return s;
+}
+
+// NP = 1: n <= 512, one correspondence per thread; NP = 2: n <= 1024, lanes 2t / 2t + 1 hold (t, t + 512) / (t + 256, t + 768) and the
+// even lane collects the four-wavefront kernel's sum order ((h_t + h_t+256) + h_t+512) + h_t+768 with one neighbour exchange per pass.
+template <int NP>
+__global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const float* g_Xw, const float* g_ou, const float* g_ov, const float* g_our,
+                                                                const float* g_oinv, Cam cam, PoseQ T0, PoseQ* __restrict__ T_out,
+                                                                uint8_t* __restrict__ outlier_out, int* __restrict__ stats, double* __restrict__ chi_out,
+                                                                unsigned seq) {
+  __shared__ double s_acc[28 * kPoRow];
+  __shared__ double s_part[28 * 8];
+  __shared__ double red[28];
+  __shared__ double s_wsum[2][4];
+  __shared__ double s_cnt[8];
+  __shared__ double s_pair[256];
+  __shared__ double s_cand[4][14];
+  int sum_slot = 0;
+  const int tid = threadIdx.x;
+  const bool even = !(tid & 1);
+  const int li = min(tid & 63, 5);
+  const double dM = (float)sqrt(5.991), dS = (float)sqrt(7.815);
+  const double dsqM = dM * dM, dsqS = dS * dS;
+  // this thread's correspondences: read once (the inputs may sit in mapped host memory), kept in registers as the floats they are
+  bool have[NP], mono[NP], my_out[NP];
+  int idx[NP];
+  float Xf[NP][3], uf[NP], vf[NP], urf[NP], omf[NP];
+  double my_chi2[NP];                                        // last evaluated chi2 of the correspondence
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const int i_mine = (tid >> 1) + 256 * (tid & 1) + 512 * p;       // pass p: lanes 2t, 2t + 1 <-> correspondences t + 512 p, t + 256 + 512 p
+    have[p] = i_mine < n;
+    const int i = have[p] ? i_mine : 0;
+    idx[p] = i;
+    Xf[p][0] = g_Xw[3 * i]; Xf[p][1] = g_Xw[3 * i + 1]; Xf[p][2] = g_Xw[3 * i + 2];
+    uf[p] = g_ou[i]; vf[p] = g_ov[i]; urf[p] = g_our[i]; omf[p] = g_oinv[i];
+    mono[p] = urf[p] < 0;
+    my_out[p] = false; my_chi2[p] = 0;
+  }
+  double x[6] = {0, 0, 0, 0, 0, 0};
+  double lambda = 0, ni = 2, currentChi = 0;
+  int nBadLM = 0;
+  bool robust = true;
+  PoseQ T = T0;
+  int nBad = 0;
+  if (tid == 0) { for (int k = 0; k < 7; k++) stats[k] = 0; for (int k = 0; k < 4; k++) chi_out[k] = 0; }
+  PO_T0();
+  for (int round = 0; round < 4; round++) {
+    T = T0;                                                   // setEstimate(toSE3Quat(mTcw)) every round (:1191)
+    bool active[NP];
+    double cnt = 0;
+#pragma unroll
+    for (int p = 0; p < NP; p++) { active[p] = have[p] && !my_out[p]; cnt += active[p] ? 1.0 : 0.0; }
+    const int n_active = (int)po_block_count_wide(cnt, s_cnt);
+    int done = 0;
+    bool ok = n_active > 0;
+    for (int it = 0; it < 10 && ok; it++) {
+      // ---- computeActiveErrors + buildSystem at T
+      double acc[28];
+#pragma unroll
+      for (int k = 0; k < 28; k++) acc[k] = 0;
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        if (p > 0) {
+          // the even lane takes its neighbour's term of the pass before (it now holds what thread t held after correspondence
+          // t + 256 (p - 1) ... in the four-wavefront kernel), the odd lane starts the pass from zero
+#pragma unroll
+          for (int k = 0; k < 28; k++) { const double nb = po_lane_partner(acc[k]); acc[k] = even ? acc[k] + nb : 0.0; }
+        }
+        if (active[p]) {
+          const double X[3] = {(double)Xf[p][0], (double)Xf[p][1], (double)Xf[p][2]};
+          const double om = (double)omf[p];
+          PoEval<double> e1;
+          po_eval<double, bool>(T, X, (double)uf[p], (double)vf[p], (double)urf[p], om, mono[p], robust, cam, dM, dS, dsqM, dsqS, &e1);
+          double h1[27];
+          po_hessian<double, bool>(e1, om, mono[p], cam, h1);
+          my_chi2[p] = e1.c2;
+          acc[27] += e1.rho0;
+#pragma unroll
+          for (int o = 0; o < 27; o++) acc[o] += h1[o];
+        }
+      }
+      PO_ACC(0);
+      po_block_reduce_wide<28>(acc, s_acc, s_part, red);
+      PO_ACC(1);
+      double Hrow[6], b[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const int a = min(li, j), c = max(li, j);
+        Hrow[j] = red[a * 6 - (a * (a - 1)) / 2 + (c - a)];
+        b[j] = red[21 + j];
+      }
+      const double b_li = red[21 + li];
+      currentChi = red[27];
+      const double iniChi = currentChi;
+      if (it == 0) {
+        const double mx = fmax(fmax(fmax(fabs(red[0]), fabs(red[6])), fmax(fabs(red[11]), fabs(red[15]))), fmax(fabs(red[18]), fabs(red[20])));
+        lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
+      }
+      // ---- LM trials: wavefronts 0-3 solve the next four candidates of a run of rejections (see pose_opt_kernel), 4-7 wait
+      double rho = 0;
+      int qmax = 0;
+      for (;;) {
+        PO_ACC(5);
+        const int cslot = qmax & 3;
+        if (cslot == 0) {
+          if (tid < 256) {
+            double lam_c = lambda, ni_c = ni;
+            const int wv = tid >> 6;
+            for (int cc = 0; cc < wv; cc++) { lam_c *= ni_c; ni_c *= 2; }
+            double xc[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
+            const bool okc = po_solve6(Hrow, b_li, li, lam_c, xc);
+            PoseQ Tc;
+            pose_oplus_series(T, xc, &Tc);
+            if ((tid & 63) == 0) {
+              double* sc = s_cand[wv];
+#pragma unroll
+              for (int j = 0; j < 6; j++) sc[j] = xc[j];
+#pragma unroll
+              for (int j = 0; j < 4; j++) sc[6 + j] = Tc.q[j];
+#pragma unroll
+              for (int j = 0; j < 3; j++) sc[10 + j] = Tc.t[j];
+              sc[13] = okc ? 1.0 : 0.0;
+            }
+          }
+          __syncthreads();
+        }
+        const bool ok2 = s_cand[cslot][13] != 0.0;
+        PoseQ Tt;
+        if (ok2) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) x[j] = s_cand[cslot][j];
+#pragma unroll
+          for (int j = 0; j < 4; j++) Tt.q[j] = s_cand[cslot][6 + j];
+#pragma unroll
+          for (int j = 0; j < 3; j++) Tt.t[j] = s_cand[cslot][10 + j];
+        } else {
+          pose_oplus_series(T, x, &Tt);                     // the solve failed: update with whatever x holds, as g2o does
+        }
+        PO_ACC(2);
+        double tchi = 0;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          if (p > 0) { const double nb = po_lane_partner(tchi); tchi = even ? tchi + nb : 0.0; }
+          if (active[p]) {
+            const double X[3] = {(double)Xf[p][0], (double)Xf[p][1], (double)Xf[p][2]};
+            PoEval<double> e1;
+            po_eval<double, bool>(Tt, X, (double)uf[p], (double)vf[p], (double)urf[p], (double)omf[p], mono[p], robust, cam, dM, dS, dsqM, dsqS, &e1);
+            my_chi2[p] = e1.c2; tchi += e1.rho0;
+          }
+        }
+        PO_ACC(3);
+        double tempChi = po_block_sum_wide(tchi, s_pair, s_wsum, sum_slot); sum_slot ^= 1;
+        PO_ACC(4);
+        if (!ok2) tempChi = 1.7976931348623157e308;
+        rho = currentChi - tempChi;
+        double scale = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && fabs(tempChi) != INFINITY && tempChi == tempChi) {
+          double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+          alpha = fmin(alpha, 2. / 3.);
+          lambda *= fmax(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+          T = Tt;
+        } else {
+          lambda *= ni; ni *= 2;
+        }
+        qmax++;
+        if (!(rho < 0 && qmax < 10)) break;
+      }
+      done++;
+      if (qmax == 10 || rho == 0) ok = false;
+      else {
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+        if (nBadLM >= 3) ok = false;
+      }
+    }
+    if (tid == 0) { stats[1 + round] = done; chi_out[round] = currentChi; }
+    // ---- classification (:1196-1270): excluded edges get a fresh residual at the final pose, active ones keep the last one
+    double bl = 0;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      if (!have[p]) continue;
+      if (my_out[p]) {
+        double err[3], Xc[3];
+        po_edge_error(T, Xf[p], uf[p], vf[p], urf[p], cam, err, Xc);
+        const double om = (double)omf[p];
+        my_chi2[p] = err[0] * (om * err[0]) + err[1] * (om * err[1]) + (mono[p] ? 0.0 : err[2] * (om * err[2]));
+      }
+      const float c2f = (float)my_chi2[p];
+      my_out[p] = c2f > (mono[p] ? 5.991f : 7.815f);
+      bl += my_out[p] ? 1.0 : 0.0;
+    }
+    nBad = (int)po_block_count_wide(bl, s_cnt);
+    if (round == 2) robust = false;                          // setRobustKernel(0)
+    if (n < 10) break;                                        // optimizer.edges().size() < 10
+  }
+  PO_ACC(5);
+#pragma unroll
+  for (int p = 0; p < NP; p++) if (have[p]) outlier_out[idx[p]] = my_out[p] ? 1 : 0;
+  if (tid == 0) { *T_out = T; stats[0] = nBad; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");              // system-scope release of every wavefront's results (no acquire half)
+  __syncthreads();
+  if (tid == 0) *reinterpret_cast<volatile int*>(&stats[7]) = (int)seq;   // results are complete: the host spins on this word
+}
+
 }  // namespace
 
 #ifdef PO_PROFILE
@@ -599,7 +875,13 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   if (po_seq == 0) po_seq = 1;
   volatile int* seq_word = reinterpret_cast<volatile int*>(sc.stage.h + out_off + sizeof(PoseQ) + 4 * sizeof(double)) + 7;
   *seq_word = 0;
-  if (n <= kPoLdsN)
+  if (n <= kPoWide)
+    hipLaunchKernelGGL(pose_opt_wide_kernel<1>, dim3(1), dim3(kPoWide), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n,
+                       dX + 5 * (size_t)n, dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
+  else if (n <= 2 * kPoWide)
+    hipLaunchKernelGGL(pose_opt_wide_kernel<2>, dim3(1), dim3(kPoWide), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n,
+                       dX + 5 * (size_t)n, dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
+  else if (n <= kPoLdsN)
     hipLaunchKernelGGL(pose_opt_kernel<true>, dim3(1), dim3(kPoThreads), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n,
                        dX + 5 * (size_t)n, dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
   else
