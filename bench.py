@@ -388,7 +388,7 @@ def parity_gate(n_gate, first_step, run_step, finish, scene, cfg, views, frames,
         bad.append("local BA: (lambda, chi2, trials) trace differs (max rel %.3g)" % tr_rel)
     res["ok"] = not bad
     res["violations"] = bad[:8]
-    res["oracle"] = "oracle/ (CPU restatement of the reference path; parity unpinned by the reference, see DESIGN.md section 6)"
+    res["oracle"] = "oracle/ (CPU restatement of the reference path; parity unpinned by the reference, see DESIGN.md section 5)"
     return res
 
 
