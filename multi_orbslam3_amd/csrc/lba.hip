@@ -16,6 +16,7 @@
 //                   also produce b_s,i = bp_i - sum_l Hpl_il Dinv_l bl_l
 //   ldlt_mfma.hpp   one workgroup: dense LDL^T + solve of the reduced camera system on the FP64 matrix cores
 //                   (v_mfma_f64_16x16x4_f64; 16x16 tiles in registers, dataflow between wavefronts) up to 50 free poses;
+//   ldlt_xcd.hpp    the same on eight workgroups of one XCD (hand-overs through that XCD's L2) from 16 tile rows on (40+ free poses);
 //                   k_wide_panel / k_wide_update / k_wide_back: the blocked many-workgroup LDL^T of larger windows
 //   k_update        thread/vertex: x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i); trial state = exp(x_p) * T  /  X + x_l
 //   k_finish        one workgroup: robust chi2, computeScale, max-diagonal -> pinned host record
@@ -40,6 +41,7 @@
 using namespace orbg;
 
 #include "ldlt_mfma.hpp"
+#include "ldlt_xcd.hpp"
 #include "se3.hpp"
 
 using namespace orbg_se3;
@@ -1301,11 +1303,16 @@ struct StopRef {
 // ORBG_LDLT_WIDE=1 sends every window to the many-workgroup blocked LDL^T (k_wide_*: the solver of windows beyond 50 free poses) so
 // that tests can run it on small problems.  Round 5 removed the measured-slower variants of rounds 1-4 (vector-ALU LDL^T kernels,
 // the fused solve + update launch, the A/B forms of the start of a solve): docs/experiments.md keeps their numbers.
+// ORBG_LDLT_XCD=0 keeps windows of 40 .. 50 free poses on the one-workgroup kernel instead of the eight-workgroup one
+// (ldlt_xcd.hpp); =safe forces that kernel's agent-scope hand-overs (the path it takes by itself when its workgroups do not
+// share an XCD); =all uses it from 14 tile rows on (tests).
 struct LbaSwitches {
   bool ldlt_wide = false;
+  int ldlt_xcd = 1;                    // 0 off, 1 where it pays, 2 forced safe hand-overs, 3 wherever it can run
   static LbaSwitches from_env() {
     LbaSwitches w;
     w.ldlt_wide = getenv("ORBG_LDLT_WIDE") != nullptr;
+    if (const char* e = getenv("ORBG_LDLT_XCD")) w.ldlt_xcd = !strcmp(e, "0") ? 0 : !strcmp(e, "safe") ? 2 : !strcmp(e, "all") ? 3 : 1;
     return w;
   }
 };
@@ -1315,6 +1322,9 @@ struct lba_handle {
   bool ext_stream = false;             // `stream` was handed in through lba_set_stream (never destroyed here)
   LbaSwitches sw;
   ldltm::AttrCache ldlt_attr;          // which kernels of THIS handle's device already allow their dynamic LDS size
+  ldltx::Context ldlt_x;               // flags / scratch / launch counter of the eight-workgroup LDL^T
+  DevBuf<double> d_xscr;
+  DevBuf<unsigned> d_xflags;
   DevBuf<lba_edge> d_edges;
   PinnedBuf<lba_edge> edges_pin;       // the caller's edge list, copied (and validated, counted) in ONE pass
   DevBuf<PairItem> d_items_dev;        // pair items built by k_build_items (fixed-capacity segment per pose pair)
@@ -1392,7 +1402,7 @@ extern "C" int lba_destroy(lba_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   h->d_edges.release(); h->edges_pin.release(); h->d_items_dev.release(); h->d_pair_count.release(); h->d_poses[0].release(); h->d_poses[1].release(); h->d_points[0].release(); h->d_points[1].release(); 
   h->d_err.release(); h->d_chi2.release(); h->d_partial.release(); h->d_EB.release(); h->d_Hll.release(); h->d_bl.release();
-  h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release(); h->d_St.release(); h->d_wfac.release();
+  h->d_Hpp.release(); h->d_bp.release(); h->d_S.release(); h->d_bs.release(); h->d_x.release(); h->d_St.release(); h->d_wfac.release(); h->d_xscr.release(); h->d_xflags.release(); h->ldlt_x.scr = nullptr; h->ldlt_x.flags = nullptr;
   h->d_EB2.release(); h->d_Hll2.release(); h->d_bl2.release(); h->d_Hpp2.release(); h->d_bp2.release(); h->d_lambda0.release();
   h->d_pose_col.release(); h->d_point_col.release(); h->d_pt_start.release(); h->d_pt_edges.release(); h->d_ps_start.release();
   h->d_ps_edges.release(); h->d_pf_start.release(); h->d_pf_edges.release(); h->d_pf_col.release(); h->d_pair_i1.release();
@@ -1710,6 +1720,13 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   if (use_mfma) {
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
   }
+  // 40 .. 50 free poses: the same tile image, factored by eight workgroups of one XCD (ldlt_xcd.hpp)
+  const bool use_xcd = use_mfma && sw.ldlt_xcd != 0 && (sw.ldlt_xcd == 3 ? ldltx::supports(n) : ldltx::pays(n));
+  if (use_xcd && !h->ldlt_x.scr) {
+    if ((rc = h->d_xscr.reserve(ldltx::scratch_doubles())) || (rc = h->d_xflags.reserve(ldltx::kFlagWords))) return rc;
+    ORBG_HIP(hipMemsetAsync(h->d_xflags.p, 0, ldltx::kFlagWords * sizeof(unsigned), st));
+    h->ldlt_x.bind(h->d_xscr.p, h->d_xflags.p);
+  }
   int cur = 0;   // index of the buffer holding the current estimate
   // k_update's workgroup size: the kernel is a chain of dependent memory round trips per landmark; small workgroups spread the same
   // wavefronts over more compute units (measured at C2: 256 threads 0.499 ms per solve, 128: 0.488, 64: 0.484)
@@ -1806,7 +1823,9 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       // (two event records and an elapsed-time query cost the solve ~8 us: one solve in four is enough for an average)
       const bool bracket = h->prof_on && !prof_pending && prof_this_solve;
       if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
-      if (use_mfma) {
+      if (use_xcd) {
+        ORBG_HIP(ldltx::launch(h->ldlt_x, n, h->d_St.p, h->d_x.p, h->d_ok.p, st, ldltx::kMaxP, sw.ldlt_xcd == 2));
+      } else if (use_mfma) {
         ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st, &h->ldlt_attr));
       } else {
         ORBG_HIP(launch_ldlt_wide(n, h->d_S.p, h->d_bs.p, h->d_x.p, h->d_ok.p, h->d_wide.p, st));

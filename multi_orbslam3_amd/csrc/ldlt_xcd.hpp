@@ -1,0 +1,629 @@
+// Dense LDL^T + solve of the reduced camera system on SEVERAL workgroups of ONE XCD (round 5): the C4 window (50 free poses, 300
+// unknowns, 19 tile rows) takes 122 us on the one compute unit of ldltm::k_ldlt_big48, whose matrix-instruction floor is ~31 us
+// (4570 v_mfma_f64_16x16x4 / 4 SIMDs) and whose LDS operand feed runs at half the CU's bandwidth.  Here the 190 tiles are dealt to
+// kP x 8 wavefronts on kP compute units that share an L2; everything that ldltm::k_ldlt_mfma hands from wavefront to wavefront
+// through LDS (G = L_kk^-1 and D^-1 of a diagonal tile, the -R / W images of a panel tile, the "published" flags) goes through
+// global memory that stays in that L2:
+//   * stores are plain (the vector L1 writes through), s_waitcnt vmcnt(0), then a relaxed agent-scope store of the flag word;
+//   * flags and operands are read with relaxed agent-scope atomic loads (sc1: they miss in the CU's vector L1 and are served by the
+//     XCD's L2) -- measured 0.59 us per hand-over of a 2 KB tile (tools/micro/xcd_handover), against 0.93 / 1.25 us for an
+//     agent-scope release / acquire pair inside / across XCDs.  This is coherent ONLY because all participants share one L2.
+// Placement: 8 x kP workgroups are launched (the dispatcher deals workgroups round-robin over the 8 XCDs); every workgroup reads
+// HW_REG_XCC_ID and draws a ticket of its XCD; the first XCD that has kP tickets wins, its first kP workgroups take part, everybody
+// else leaves at once (pigeonhole: some XCD always gets kP).  Flags carry the launch's epoch, so nothing is cleared between launches.
+// Chain: tile (k, k+1) and tile (k+1, k+1) belong to the same wavefront, which goes G_k -> panel -> update from registers -> pivots
+// -> G_{k+1} with ONE hand-over per tile row; trailing tiles fetch their two operand images from the L2, all tiles of a wavefront
+// in flight at once.  Same arithmetic per tile as ldltm::k_ldlt_mfma (pivot pairs as rank-2 matrix instructions, G collected on an
+// identity copy); the back-substitution runs on one wavefront once every wavefront has reported.
+#pragma once
+
+#include <type_traits>
+
+#include "ldlt_mfma.hpp"
+
+namespace ldltx {
+
+using ldltm::d4;
+using ldltm::Geo;
+using ldltm::kGld;
+using ldltm::make_geo;
+using ldltm::mfma;
+using ldltm::rcp1;
+using ldltm::rdlane;
+using ldltm::row_even_to_odd;
+
+constexpr int kMaxP = 8;                    // participating workgroups (compute units of one XCD): 4 or 8
+constexpr int kWgWaves = 8, kThreads = 64 * kWgWaves;
+constexpr int kMaxW = kMaxP * kWgWaves;     // wavefronts that hold tiles
+constexpr int kChain = 4;                   // tiles of a column, from the diagonal up, that its chain wavefront holds
+constexpr int kMaxNS = 8;                   // tile slots per wavefront: 4 with 8 workgroups, 8 with 4
+constexpr int kMaxT = ldltm::kMaxT;
+constexpr int kNY = 5;                      // 64-lane groups of the solution vector (n_pad <= 320)
+// flag words
+constexpr int kFDiag = 0, kFPanel = 32, kFWave = kFPanel + kMaxT * kMaxT, kFElect = kFWave + 64, kFBad = kFElect + 8;
+constexpr int kFlagStride = 640;             // one copy of the flags per participant (its wavefronts poll that copy only)
+constexpr int kFlagWords = kFlagStride * kMaxP;
+// scratch (doubles)
+constexpr size_t kPanOff = 0, kPanDoubles = (size_t)kMaxT * kMaxT * 512;
+constexpr size_t kGbOff = kPanOff + kPanDoubles, kGbDoubles = (size_t)kMaxT * 16 * kGld;
+constexpr size_t kDvOff = kGbOff + kGbDoubles, kDvDoubles = (size_t)kMaxT * 16;
+constexpr size_t kWOff = kDvOff + kDvDoubles;
+__host__ inline size_t scratch_doubles() { return kWOff + ldltm::wglob_doubles(make_geo(16 * kMaxT - 20)) + 1024; }
+
+struct Plan { short tile[kMaxW][kMaxNS]; signed char chain[kMaxW]; int np, ns, force_safe; };       // tile index j(j+1)/2 + i per wavefront slot (-1: none), in processing order
+
+__host__ inline bool plan_fits(int n, int np, int ns);
+// the systems this kernel can take (tools/micro/ldlt_mfma_test: it is ahead of ldltm::k_ldlt_big48 from 16 tile rows on -- 75 / 88 /
+// 96 us against 81 / 99 / 111 us at 16 / 18 / 19 rows -- level at 15, behind below)
+__host__ inline bool supports(int n) { const Geo g = make_geo(n); return n >= 1 && g.T >= 14 && g.T <= kMaxT - 1 && g.n_pad <= 64 * kNY && plan_fits(n, kMaxP, 4); }
+__host__ inline bool pays(int n) { return supports(n) && make_geo(n).T >= 16; }
+
+// Tiles to wavefronts.  Column j's last three tiles -- (j-2, j), (j-1, j), (j, j) -- go to one "chain" wavefront (consecutive
+// columns on different compute units) that holds nothing else: it meets G_{j-2} and G_{j-1} polling, not in the middle of a
+// trailing update.  The other tiles go round to the remaining wavefronts (to the chain wavefronts too once those are full).
+// Slots are ordered by (row, column).
+__host__ inline Plan make_plan(int n, int np, int ns) {
+  const Geo g = make_geo(n);
+  const int W = np * kWgWaves;
+  Plan P;
+  P.np = np; P.ns = ns; P.force_safe = 0;
+  int cnt[kMaxW];
+  bool chain[kMaxW];
+  for (int w = 0; w < kMaxW; w++) { cnt[w] = 0; chain[w] = false; for (int s = 0; s < kMaxNS; s++) P.tile[w][s] = -1; }
+  auto put = [&](int w, int i, int j) { P.tile[w][cnt[w]++] = (short)ldltm::tile_index(i, j); };
+  auto chain_wave = [&](int j) { return (j % np) * kWgWaves + (j / np) % kWgWaves; };
+  for (int j = 0; j < g.T; j++) {           // (j-3, j) .. (j, j) in slots 0 .. 3 (-1 where there is none)
+    const int w = chain_wave(j);
+    chain[w] = true;
+    cnt[w] = kChain;
+    for (int q = 0; q < kChain; q++) P.tile[w][q] = j - (kChain - 1) + q >= 0 ? (short)ldltm::tile_index(j - (kChain - 1) + q, j) : (short)-1;
+  }
+  for (int j = kChain; j < g.T; j++)
+    for (int i = 0; i + kChain <= j; i++) {
+      int best = -1;
+      for (int w = 0; w < W; w++)
+        if (!chain[w] && cnt[w] < ns && (best < 0 || cnt[w] < cnt[best])) best = w;
+      put(best, i, j);
+    }
+  for (int w = 0; w < kMaxW; w++) P.chain[w] = chain[w];
+  for (int w = 0; w < W; w++) {             // order by (row, column); insertion sort of <= 8 entries
+    if (P.chain[w]) continue;
+    auto key = [&](short t) { int j = 0; while ((j + 1) * (j + 2) / 2 <= t) j++; const int i = t - j * (j + 1) / 2; return i * 64 + j; };
+    for (int a = 1; a < cnt[w]; a++) {
+      const short t = P.tile[w][a];
+      int b = a - 1;
+      while (b >= 0 && key(P.tile[w][b]) > key(t)) { P.tile[w][b + 1] = P.tile[w][b]; b--; }
+      P.tile[w][b + 1] = t;
+    }
+  }
+  return P;
+}
+__host__ inline bool plan_fits(int n, int np, int ns) {
+  const Geo g = make_geo(n);
+  int ct = 0;
+  for (int j = 0; j < g.T; j++) ct += j + 1 < kChain ? j + 1 : kChain;
+  return g.T <= np * kWgWaves && ns >= kChain && g.ntiles - ct <= (np * kWgWaves - g.T) * ns;
+}
+__host__ inline int plan_max_slots(const Plan& P) { int m = 0; for (int w = 0; w < kMaxW; w++) for (int s = 0; s < kMaxNS; s++) if (P.tile[w][s] >= 0 && s + 1 > m) m = s + 1; return m; }
+
+#ifdef LDLTX_PROFILE
+__device__ long long g_xprof[512];
+#define LDLTX_T(i) do { if (lane == 0) g_xprof[(i)] = wall_clock64(); } while (0)
+#else
+#define LDLTX_T(i) do { } while (0)
+#endif
+
+#ifdef LDLTX_WATCHDOG                       // (micro-benchmark builds: a wait that does not end reports where and lets the kernel finish)
+__device__ int g_xdog[16];
+#define LDLTX_DOG(where, a, b) do { if (++dog_ > (1 << 22)) { if (lane == 0 && atomicAdd(&g_xdog[0], 1) == 0) { g_xdog[1] = (where); g_xdog[2] = gw_; g_xdog[3] = (a); g_xdog[4] = (b); } bail_ = true; } } while (0)
+#else
+#define LDLTX_DOG(where, a, b) do { } while (0)
+#endif
+
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xF;
+}
+__device__ __forceinline__ double ld_l2(const double* p) {
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __restrict__ St, double* __restrict__ x, int* __restrict__ ok_flag,
+                                                       double* scr, unsigned* flags, unsigned epoch, Plan plan) {
+#pragma clang fp contract(fast)        // the solve is tolerance-checked (1e-4), not bit-compared
+  __shared__ __attribute__((aligned(32))) double s_x[64 * kNY];        // the solution, posted block by block during the back-substitution
+  __shared__ int s_xready;                 // column groups (from the last column down) whose x_J are posted
+  constexpr int kNS = 4;
+  const int kP = plan.np, kW = kP * kWgWaves;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  [[maybe_unused]] int dog_ = 0, gw_ = (int)(blockIdx.x >> 3) * kWgWaves + wv;
+  [[maybe_unused]] bool bail_ = false;
+#ifdef LDLTX_PROFILE
+  const long long t_enter = wall_clock64();
+#endif
+  // ---- which workgroups take part: block 8 r is participant r (the dispatcher deals a grid's workgroups round-robin over the 8
+  // XCDs, so these share one); the others leave at once.  Every participant posts its XCC id; if they differ after all (another
+  // partition mode, a changed dispatcher) `safe` turns the hand-overs into agent-scope release / acquire pairs -- slower, correct.
+  if ((blockIdx.x & 7u) != 0) return;
+  const int rank = blockIdx.x >> 3;
+  const unsigned my_xcc = xcc_id() & 0xFFu, ep = epoch & 0xFFFFFFu;
+  if (tid == 0) {
+    __hip_atomic_store(flags + kFElect + rank, (ep << 8) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_xready = 0;
+  }
+  __syncthreads();
+  const int gw = rank * kWgWaves + wv;
+#ifdef LDLTX_PROFILE
+  if (tid == 0) { atomicAdd((unsigned long long*)&g_xprof[1], 1ull); g_xprof[4 + rank] = t_enter; }
+#endif
+  const Geo G = make_geo(n);
+  const int T = G.T, n_pad = G.n_pad, cb = G.cb;
+  double* const Pan = scr + kPanOff;      // [T][T][2][256]: -R and W of panel tile (k, j), operand layout = accumulator layout
+  double* const Gb = scr + kGbOff;        // [T][16 * kGld]
+  double* const Dv = scr + kDvOff;        // [T][16]
+  double* const Wg = scr + kWOff;         // the unit upper factor, column-packed: entry (I, J), I < J, at J (J - 1) / 2 + I
+  // (every participant polls its own copy of the G / panel flags: sixty-four wavefronts polling one cache line queue up in the
+  // L2 channel that holds it -- an idle sweep took 3 us; the publisher writes the eight copies with one store instruction)
+  unsigned* const f_diag = flags + rank * kFlagStride + kFDiag;
+  unsigned* const f_panel = flags + rank * kFlagStride + kFPanel;
+  auto wm_store = [&](int I, int J, double v) { Wg[J * (J - 1) / 2 + I] = v; };
+
+  // ---- this wavefront's tiles
+  d4 acc[kNS];
+  int ti0[kNS], tj0[kNS];
+#pragma unroll
+  for (int s = 0; s < kNS; s++) {
+    const int t = __builtin_amdgcn_readfirstlane((int)plan.tile[gw][s]);
+    int i = 1 << 20, j = 1 << 20;
+    if (t >= 0) {
+      j = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while ((j + 1) * (j + 2) / 2 <= t) j++;
+      while (j * (j + 1) / 2 > t) j--;
+      i = t - j * (j + 1) / 2;
+    }
+    ti0[s] = i; tj0[s] = j;
+    const d4 v = *reinterpret_cast<const d4*>(St + (size_t)max(t, 0) * 256 + 4 * lane);
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc[s][g] = t >= 0 ? v[g] : 0.0;
+  }
+
+  bool safe;
+  for (;;) {
+    const unsigned f = ld_flag(flags + kFElect + min(lane, kP - 1));
+    if (__builtin_amdgcn_ballot_w64((f >> 8) != ep) == 0) { safe = plan.force_safe || __builtin_amdgcn_ballot_w64((f & 0xFFu) != my_xcc) != 0; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#ifdef LDLTX_PROFILE
+  if (gw == 0) { LDLTX_T(0); if (lane == 0) g_xprof[12] = safe; }
+#endif
+  auto publish = [&](int idx, bool copies) { // every store of this wavefront has reached the L2 (or, `safe`, the memory); then the flag
+    if (safe) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < (copies ? kMaxP : 1)) __hip_atomic_store(flags + lane * kFlagStride + idx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto acquire = [&]() { if (safe) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); };
+
+  // ---- the pivots of diagonal tile k, two per matrix instruction (ldltm::k_ldlt_mfma's `factor`), G and D^-1 to the L2
+  auto factor = [&](int k) {
+    LDLTX_T(16 + 8 * k + 0);
+    d4 C = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < kNS; s++)
+      if (ti0[s] == k && tj0[s] == k) C = acc[s];
+    d4 E, Gc, Wc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; g++) E[g] = (lr + 4 * g == lc) ? 1.0 : 0.0;
+    Gc = E;
+    double dvv = 1.0;
+    const int npiv = min(16, n_pad - 16 * k);          // a multiple of 4
+    double rlast = 1.0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (4 * g < npiv) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int q0 = 2 * h, p0 = 4 * g + q0, p1 = p0 + 1;
+          double u = C[g];
+          asm volatile("" : "+v"(u));
+          const double c00 = rdlane(u, q0 * 16 + p0), c01 = rdlane(u, q0 * 16 + p1), c11 = rdlane(u, (q0 + 1) * 16 + p1);
+          const double det = __builtin_fma(c00, c11, -(c01 * c01));
+          const double r0 = rcp1(c00);
+          const double rdet = rcp1(det);
+          const double r1 = c00 * rdet;
+          const double nl10 = -(c01 * r0);
+          const double u0b = row_even_to_odd(u);
+          const double u1 = __builtin_fma(nl10, u0b, u);
+          const bool in0 = lr == q0, in1 = lr == q0 + 1;
+          const double bv = in1 ? u1 : u;
+          const double av = in0 ? u * -r0 : in1 ? u1 * -r1 : 0.0;
+          if (p1 < 15) C = mfma(av, bv, C);
+          double eg = E[g];
+          asm volatile("" : "+v"(eg));
+          const double e0b = row_even_to_odd(eg);
+          const double erow = in1 ? __builtin_fma(nl10, e0b, eg) : eg;
+          Gc[g] = (in0 || in1) ? erow : Gc[g];
+          if (p1 < 15) E = mfma(av, erow, E);
+          Wc[g] -= av;
+          dvv = lane == p0 ? r0 : lane == p1 ? r1 : dvv;
+          if (h == 1) rlast = r0 + r1;
+        }
+      }
+    }
+    const bool good = fabs(rlast) < INFINITY;
+    LDLTX_T(16 + 8 * k + 1);
+    double* const gk = Gb + (size_t)k * 16 * kGld;
+#pragma unroll
+    for (int g = 0; g < 4; g++) gk[lc * kGld + lr + 4 * g] = Gc[g];
+    if (lane < 16) Dv[k * 16 + lane] = dvv;
+    if (!good && lane == 0) __hip_atomic_store(flags + kFBad, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    publish(kFDiag + k, true);
+    LDLTX_T(16 + 8 * k + 2);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {              // the factor's rows are not needed before the back-substitution
+      const int I = 16 * k + lr + 4 * g, J = 16 * k + lc;
+      if (I < J && I < n_pad && J <= cb) wm_store(I, J, Wc[g]);
+    }
+  };
+  // ---- dataflow.  Per slot: st = tile rows still to apply (0: every row applied -- the tile waits for G of its row, or, on the
+  // diagonal, for its pivots; -1: finished or empty), the addresses of the two flags and of the two operand images of the next
+  // row (they move by one tile row per applied row: no address arithmetic, and hardly a branch, in a sweep -- written with
+  // conditions on (i, j, rows applied) a sweep was ~100 scalar branches and took 2-3 us, idle ones included).
+  int st[kNS], left = 0;
+  const unsigned* fpa[kNS]; const unsigned* fpb[kNS]; const unsigned* fpd[kNS];
+  unsigned offa[kNS], offw[kNS];
+  bool isdiag[kNS];
+#pragma unroll
+  for (int s = 0; s < kNS; s++) {
+    const bool on = ti0[s] < (1 << 20);
+    const int i = on ? ti0[s] : 0, j = on ? tj0[s] : 0;
+    st[s] = on ? i : -1;
+    left += on;
+    isdiag[s] = on && i == j;
+    fpa[s] = f_panel + i; fpb[s] = f_panel + j; fpd[s] = f_diag + i;
+    offa[s] = (unsigned)i * 512u; offw[s] = (unsigned)j * 512u + 256u;
+  }
+  const unsigned row_words = (unsigned)T, row_doubles = (unsigned)T * 512u;
+  auto advance = [&](int s) { st[s]--; fpa[s] += row_words; fpb[s] += row_words; offa[s] += row_doubles; offw[s] += row_doubles; };
+  const bool chain_wave = plan.chain[gw] != 0;
+#ifdef LDLTX_PROFILE
+  long long sw_n = 0, sw_w = 0, sw_t0 = wall_clock64(), sw_upd = 0, sw_pan = 0, sw_tp = 0, sw_tu = 0, sw_tq = 0, sw_mark = 0;
+#endif
+  while (left > 0) {
+    // (opaque copies: everything derived from a slot's tile position is loop-invariant, and hoisted out of this loop it costs 64
+    // vector registers of store addresses and spills)
+    int ti[kNS], tj[kNS];
+#pragma unroll
+    for (int s = 0; s < kNS; s++) { ti[s] = ti0[s]; tj[s] = tj0[s]; asm volatile("" : "+s"(ti[s]), "+s"(tj[s])); }
+    // ---- a chain wavefront (tiles (j-3, j) .. (j, j) in slots 0 .. 3).  Once every row above the first unfinished tile (k, j) is
+    // applied to all its tiles it leaves the sweeps: it spins on G_k's flag, solves (k, j), updates the diagonal tile from
+    // registers and the tiles between with the -R images of (k, k+1) .., which the chain wavefronts of those columns publish at
+    // about the same time; for k = j - 1 the pivots of (j, j) follow at once.  One hand-over per tile row on the critical path,
+    // no sweep in it, and the wavefront is back spinning before the next G arrives.
+    if (chain_wave) {
+      bool took = false;
+      auto chain_step = [&](auto SC) {
+        constexpr int S = decltype(SC)::value;
+        constexpr int D = kChain - 1;              // the diagonal tile's slot
+        bool go = !took && st[S] == 0;
+#pragma unroll
+        for (int s1 = 0; s1 < S; s1++) go = go && st[s1] < 0;
+#pragma unroll
+        for (int s1 = S + 1; s1 <= D; s1++) go = go && st[s1] == s1 - S;
+        if (!go) return;
+        took = true;
+        const int k = ti[S], j = tj[S];
+        while (__builtin_amdgcn_readfirstlane(ld_flag(fpd[S])) != epoch && !bail_) { LDLTX_DOG(1, k, j); }
+        acquire();
+        if (S == D - 1) LDLTX_T(16 + 8 * k + 6);
+        double Gf[4], dv4[4];
+        const double* const gk = Gb + (size_t)k * 16 * kGld;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + k * 16 + lr + 4 * q); }
+        if (S == D - 1) LDLTX_T(16 + 8 * k + 3);
+        const d4 X = acc[S];
+        d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
+        R0 = mfma(Gf[0], X[0], R0);
+        R1 = mfma(Gf[2], X[2], R1);
+        R0 = mfma(Gf[1], X[1], R0);
+        R1 = mfma(Gf[3], X[3], R1);
+        double* const pb = Pan + ((size_t)(k * T + j) * 2) * 256 + lane;
+        double nR[4], w4[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const double rr = R0[g] + R1[g];
+          nR[g] = -rr;
+          w4[g] = rr * dv4[g];
+          pb[g * 64] = nR[g];
+          pb[256 + g * 64] = w4[g];
+        }
+        if (S == D - 1) LDLTX_T(16 + 8 * k + 4);
+        publish(kFPanel + k * T + j, true);
+        if (S == D - 1) LDLTX_T(16 + 8 * k + 5);
+        {                                          // (the same order of operations as every other tile update: results do not
+          d4 c = acc[D];                           // depend on which path applied a row)
+#pragma unroll
+          for (int q = 0; q < 4; q++) c = mfma(nR[q], w4[q], c);
+          acc[D] = c;
+        }
+        st[S] = -1; left--;
+        advance(D);
+        if (S == D - 1) {
+          LDLTX_T(16 + 8 * k + 7);
+          if (k + 1 < G.Tp) factor(k + 1);
+          st[D] = -1; left--;
+        }
+#pragma unroll
+        for (int s1 = S + 1; s1 < D; s1++) {       // tile (i, j), k < i < j: -R of (k, i) from the L2, W of (k, j) from registers
+          while (__builtin_amdgcn_readfirstlane(ld_flag(fpa[s1])) != epoch && !bail_) { LDLTX_DOG(6, k, s1); }
+          acquire();
+          const double* const pa = Pan + offa[s1] + lane;
+          double oa[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) oa[q] = ld_l2(pa + q * 64);
+          d4 c = acc[s1];
+#pragma unroll
+          for (int q = 0; q < 4; q++) c = mfma(oa[q], w4[q], c);
+          acc[s1] = c;
+          advance(s1);
+        }
+        const int J = 16 * j + lc;
+        if (J <= cb) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, w4[g]);
+        }
+      };
+      chain_step(std::integral_constant<int, 0>{});
+      chain_step(std::integral_constant<int, 1>{});
+      chain_step(std::integral_constant<int, 2>{});
+      if (took) continue;
+    }
+    // ---- one sweep: the flags every slot waits for -- the two panel images of its next row, G of its own row -- in one round
+    // trip; then the ready trailing updates (operand images of all slots in flight together); then the panel tiles whose last row
+    // is applied -- in THIS sweep, too: with panels first a column's tiles (k, j), (k+1, j) cost two sweeps a row and the
+    // wavefronts fall rows behind the chain
+#ifdef LDLTX_PROFILE
+    sw_mark = wall_clock64();
+#endif
+    bool upd[kNS], dg[kNS], any = false;
+    {
+      unsigned fa[kNS], fb[kNS], fd[kNS];
+#pragma unroll
+      for (int s = 0; s < kNS; s++) { fa[s] = ld_flag(fpa[s]); fb[s] = ld_flag(fpb[s]); fd[s] = ld_flag(fpd[s]); }
+#pragma unroll
+      for (int s = 0; s < kNS; s++) {
+        const unsigned a = __builtin_amdgcn_readfirstlane(fa[s]), b2 = __builtin_amdgcn_readfirstlane(fb[s]), d = __builtin_amdgcn_readfirstlane(fd[s]);
+        upd[s] = (st[s] > 0) & (a == epoch) & (b2 == epoch);
+        dg[s] = (d == epoch) & !isdiag[s];
+        any = any | upd[s];
+      }
+    }
+    acquire();
+    bool worked = false;
+#ifdef LDLTX_PROFILE
+    { const long long t = wall_clock64(); sw_tp += t - sw_mark; sw_mark = t; }
+    sw_n++;
+#pragma unroll
+    for (int s = 0; s < kNS; s++) { sw_upd += upd[s]; sw_pan += dg[s] && st[s] == 0; }
+#endif
+    // ---- trailing updates
+    if (any) {
+      double oa[kNS][4], ow[kNS][4];
+#pragma unroll
+      for (int s = 0; s < kNS; s++) {            // unconditional loads (a branch would drain the memory counter per slot)
+        const double* const pa = Pan + offa[s] + lane;
+        const double* const pw = Pan + offw[s] + lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { oa[s][q] = ld_l2(pa + q * 64); ow[s][q] = ld_l2(pw + q * 64); }
+      }
+#pragma unroll
+      for (int s = 0; s < kNS; s++) {
+        if (upd[s]) {
+          d4 c = acc[s];
+#pragma unroll
+          for (int q = 0; q < 4; q++) c = mfma(oa[s][q], ow[s][q], c);
+          acc[s] = c;
+          advance(s);
+        }
+      }
+      worked = true;
+    }
+#ifdef LDLTX_PROFILE
+    { const long long t = wall_clock64(); sw_tu += t - sw_mark; sw_mark = t; }
+#endif
+    // ---- panel tiles
+    int g_row = -1;
+    double Gf[4] = {0, 0, 0, 0}, dv4[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < kNS; s++) {
+      if (dg[s] && st[s] == 0) {
+        const int k = ti[s], j = tj[s];
+        if (g_row != k) {
+          const double* const gk = Gb + (size_t)k * 16 * kGld;
+#pragma unroll
+          for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + k * 16 + lr + 4 * q); }
+          g_row = k;
+        }
+        const d4 X = acc[s];
+        d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
+        R0 = mfma(Gf[0], X[0], R0);
+        R1 = mfma(Gf[2], X[2], R1);
+        R0 = mfma(Gf[1], X[1], R0);
+        R1 = mfma(Gf[3], X[3], R1);
+        double* const pb = Pan + ((size_t)(k * T + j) * 2) * 256 + lane;
+        double w4[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const double rr = R0[g] + R1[g];
+          w4[g] = rr * dv4[g];
+          pb[g * 64] = -rr;
+          pb[256 + g * 64] = w4[g];
+        }
+        publish(kFPanel + k * T + j, true);
+#ifdef LDLTX_PROFILE
+        if (lane == 0) { atomicMax((unsigned long long*)&g_xprof[400 + k], (unsigned long long)wall_clock64()); atomicMin((unsigned long long*)&g_xprof[430 + k], (unsigned long long)wall_clock64()); }
+#endif
+        const int J = 16 * j + lc;
+        if (J <= cb) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, w4[g]);
+        }
+        st[s] = -1; left--; worked = true;
+      }
+    }
+    // ---- a diagonal tile with every row above it applied that no chain step took (tile (0, 0)): its pivots
+    int fk = -1;
+#pragma unroll
+    for (int s = 0; s < kNS; s++) {
+      if (isdiag[s] && st[s] == 0) {
+        if (ti[s] < G.Tp) fk = ti[s];
+        st[s] = -1; left--; worked = true;
+      }
+    }
+    if (fk >= 0) factor(fk);
+#ifdef LDLTX_PROFILE
+    sw_w += worked;
+    { const long long t = wall_clock64(); sw_tq += t - sw_mark; sw_mark = t; }
+#endif
+    if (!worked) { __builtin_amdgcn_s_sleep(1); LDLTX_DOG(3, st[0] * 10000 + st[1] * 100 + st[2], ti0[0] * 10000 + ti0[1] * 100 + ti0[2]); if (bail_) break; }
+  }
+  // ---- every wavefront reports; participant 0 back-substitutes  L^T x = y.  Wavefront w owns rows 64 w .. 64 w + 63 (one per
+  // lane): it streams its rows of the factor's columns from the L2, four columns a group from the last column down, kDepth groups
+  // in flight; for the columns right of its block it subtracts W(I, J) x_J with x_J read from LDS, then it solves its own block
+  // column by column (v_readlane broadcast, ldltm::k_ldlt_mfma's loop restricted to one row group) and posts each group's four
+  // x_J.  The dependent chain is one readlane + one FMA per column and moves from wavefront to wavefront at block boundaries.
+  publish(kFWave + gw, false);
+#ifdef LDLTX_PROFILE
+  LDLTX_T(256 + gw);
+  if (lane == 0 && (gw == 5 || gw == 29 || gw == 62)) { long long* o = g_xprof + 460 + (gw == 5 ? 0 : gw == 29 ? 6 : 12); o[0] = sw_n; o[1] = sw_w; o[2] = wall_clock64() - sw_t0; o[3] = sw_upd; o[4] = sw_pan; long long* o2 = g_xprof + 480 + (gw == 5 ? 0 : gw == 29 ? 4 : 8); o2[0] = sw_tp; o2[1] = sw_tu; o2[2] = sw_tq; }
+#endif
+  if (rank != 0 || wv >= kNY || 64 * wv >= n_pad) return;
+  for (;;) {
+    const unsigned f = lane < kW ? ld_flag(&flags[kFWave + lane]) : epoch;
+    if (__builtin_amdgcn_ballot_w64(f != epoch) == 0 || bail_) break;
+    __builtin_amdgcn_s_sleep(1);
+    LDLTX_DOG(4, 0, 0);
+  }
+  acquire();
+  const int ok = ld_flag(flags + kFBad) != epoch;
+  if (wv == 0) LDLTX_T(2);
+  if (ok) {
+    const int I = 64 * wv + lane, lo = 64 * wv;
+    // (a column's start is wave-uniform and moves by J - 1 doubles from column J to J - 1: two scalar instructions and one load
+    // per value; entries on or below the diagonal are masked where the value is USED -- masked at the load, the select drags the
+    // wait for the load up to it)
+    const unsigned Iu = (unsigned)I;
+    auto col_ptr = [&](int J) -> const double* { return Wg + (size_t)(J * (J - 1) / 2); };
+    double y = I < n_pad ? ld_l2(col_ptr(cb) + Iu) : 0.0;
+    // Columns in groups of four from the last one down: group g = columns n_pad - 4 g - 4 .. n_pad - 4 g - 1.
+    const int hi = min(n_pad, lo + 64);
+    const int g_off = (n_pad - hi) >> 2;            // groups right of this block
+    const int ng_own = (hi - lo) >> 2;
+    // this block's own columns: in registers before anything else (the block's solve then is the bare readlane / FMA chain;
+    // streamed it ran at 130 cycles a column: branches, address arithmetic, waits)
+    double wown[64];
+    {
+      const double* cp = col_ptr(lo);
+#pragma unroll
+      for (int c = 0; c < 64; c++) { wown[c] = ld_l2(cp + Iu); cp += lo + c; }
+    }
+    // ---- the columns right of this block, eight a batch: one look at the count of posted groups, two 32-byte reads of x from
+    // LDS, eight FMAs; the next batch's loads in flight meanwhile
+    constexpr int kB = 2;                           // groups per batch
+    double bufA[4 * kB], bufB[4 * kB];
+    int Jld = n_pad - 1;                            // next column to load, going down
+    int avail = 0;                                  // posted groups, as last read (a lagging wavefront looks once per several batches)
+    const double* pld = col_ptr(Jld);
+    auto load_batch = [&](double (&b)[4 * kB]) {
+#pragma unroll
+      for (int q = 0; q < kB; q++)
+#pragma unroll
+        for (int c = 3; c >= 0; c--) { b[4 * q + c] = ld_l2(pld + Iu); Jld--; pld -= Jld; }
+    };
+    auto run_batch = [&](const double (&b)[4 * kB], int gs) {
+      if (gs >= g_off) return;
+      const int need = min(gs + kB, g_off);
+      // (no fences: a workgroup-scope fence also waits for the factor loads in flight; LDS operations of a wavefront execute in
+      // order, which is all the ordering the count and the values need)
+      while (avail < need && !bail_) { avail = __hip_atomic_load(&s_xready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); LDLTX_DOG(2, gs, 0); }
+      asm volatile("" ::: "memory");
+      double ya = 0.0, yb = 0.0;
+#pragma unroll
+      for (int q = 0; q < kB; q++) {
+        if (gs + q < g_off) {
+          const int J0 = n_pad - 4 - 4 * (gs + q);
+          const d4 xv = *reinterpret_cast<const d4*>(&s_x[J0]);
+          ya += b[4 * q + 3] * xv[3]; yb += b[4 * q + 2] * xv[2];       // (every row of this block is above these columns: no mask)
+          ya += b[4 * q + 1] * xv[1]; yb += b[4 * q + 0] * xv[0];
+        }
+      }
+      y -= ya + yb;
+    };
+    load_batch(bufA);
+    load_batch(bufB);
+    LDLTX_T(300 + 4 * wv);
+    for (int g0 = 0; g0 < g_off; g0 += 2 * kB) {
+      run_batch(bufA, g0);
+      load_batch(bufA);
+      run_batch(bufB, g0 + kB);
+      load_batch(bufB);
+    }
+    // ---- this block: one readlane + one FMA per column; the four x_J of a group are posted at once
+    LDLTX_T(300 + 4 * wv + 1);
+#ifdef LDLTX_PROFILE
+    if (lane == 0) g_xprof[330 + wv] = clock64();
+#endif
+#pragma unroll
+    for (int q = 15; q >= 0; q--) {
+      if (q < ng_own) {
+#pragma unroll
+        for (int c = 3; c >= 0; c--) y -= (lane < 4 * q + c ? wown[4 * q + c] : 0.0) * rdlane(y, 4 * q + c);
+        if ((lane >> 2) == q) s_x[lo + lane] = y;
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&s_xready, g_off + ng_own - q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    LDLTX_T(300 + 4 * wv + 2);
+#ifdef LDLTX_PROFILE
+    if (lane == 0) g_xprof[330 + wv] = clock64() - g_xprof[330 + wv];
+#endif
+    if (I < n) x[I] = y;
+  }
+  if (wv == 0) { LDLTX_T(3); if (lane == 0) *ok_flag = ok; }
+}
+
+// Host side: scratch + flags of one user (an lba handle); the epoch advances with every launch.  The memory is the caller's
+// (bind) or the context's own (ensure: the micro-benchmark).
+struct Context {
+  double* scr = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int plan_n = -1; Plan plan; bool owned = false;
+  void bind(double* scratch /* scratch_doubles() */, unsigned* zeroed_flags /* kFlagWords */) { scr = scratch; flags = zeroed_flags; owned = false; epoch = 0; }
+  hipError_t ensure() {
+    if (scr) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&scr, scratch_doubles() * sizeof(double));
+    if (e != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&flags, kFlagWords * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMemset(flags, 0, kFlagWords * sizeof(unsigned))) != hipSuccess) return e;
+    owned = true;
+    return hipDeviceSynchronize();
+  }
+  void release() { if (owned) { if (scr) (void)hipFree(scr); if (flags) (void)hipFree(flags); } scr = nullptr; flags = nullptr; }
+};
+__host__ inline hipError_t launch(Context& c, int n, const double* St, double* x, int* ok, hipStream_t st, int np = 8, bool force_safe = false) {
+  hipError_t e = c.ensure();
+  if (e != hipSuccess) return e;
+  const int ns = 4;
+  if (np != kMaxP || !plan_fits(n, np, ns)) return hipErrorInvalidValue;
+  if (c.plan_n != n) { c.plan = make_plan(n, np, ns); c.plan_n = n; }
+  c.plan.force_safe = force_safe;
+  c.epoch = (c.epoch + 1) & 0xFFFFFFu;
+  if (c.epoch == 0) {                        // once per 16 M launches: stale flags of the same epoch value must not survive the wrap
+    if ((e = hipMemsetAsync(c.flags, 0, kFlagWords * sizeof(unsigned), st)) != hipSuccess) return e;
+    c.epoch = 1;
+  }
+  hipLaunchKernelGGL(k_ldlt_xcd, dim3(8 * (np - 1) + 1), dim3(kThreads), 0, st, n, St, x, ok, c.scr, c.flags, c.epoch, c.plan);
+  return hipGetLastError();
+}
+
+}  // namespace ldltx

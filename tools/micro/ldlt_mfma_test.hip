@@ -14,7 +14,14 @@
 #ifndef NO_PROFILE
 #define LDLTM_PROFILE 1
 #endif
+#ifdef XPROFILE
+#define LDLTX_PROFILE 1
+#endif
+#ifdef XWATCHDOG
+#define LDLTX_WATCHDOG 1
+#endif
 #include "../../multi_orbslam3_amd/csrc/ldlt_mfma.hpp"
+#include "../../multi_orbslam3_amd/csrc/ldlt_xcd.hpp"
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -63,11 +70,11 @@ int main(int argc, char** argv) {
   }
   std::mt19937_64 rng(12345);
   std::normal_distribution<double> N01(0.0, 1.0);
-  const int sizes_all[] = {6, 12, 18, 60, 96, 114, 120, 126, 132, 138, 150, 204, 240, 300};
+  const int sizes_all[] = {6, 12, 18, 60, 96, 114, 120, 126, 132, 138, 150, 204, 222, 240, 270, 300};
   const int sizes_q[] = {120};   // quick mode: the C2 window only
   const bool quick = argc > 1;
   const int* sizes = quick ? sizes_q : sizes_all;
-  const int nsizes = quick ? 1 : 14;
+  const int nsizes = quick ? 1 : 16;
   for (int si = 0; si < nsizes; si++) {
     const int n = sizes[si];
     if (!ldltm::supports(n)) { printf("n=%d unsupported\n", n); continue; }
@@ -159,6 +166,94 @@ int main(int argc, char** argv) {
 #endif
     printf("n=%3d T=%2d ok=%d max|dx|=%.3e (max|x|=%.3e) %s   %.2f us/launch\n", n, g.T, ok, err, mx, good ? "ok" : "FAIL", 1000.0 * ms / reps);
     fails += !good;
+    for (int np = 8; np <= 8 && ldltx::supports(n); np += 4) {   // the same system on four / eight compute units of one XCD
+      static ldltx::Context cx;
+      if (!ldltx::plan_fits(n, np, 4)) continue;
+      CK(hipMemset(dx, 0, n * 8)); CK(hipMemset(dok, 0xFF, 4));
+      CK(ldltx::launch(cx, n, dS, dx, dok, 0, np));
+      CK(hipDeviceSynchronize());
+      int ok2 = -7;
+#ifdef LDLTX_WATCHDOG
+      {
+        int dg[16];
+        CK(hipMemcpyFromSymbol(dg, HIP_SYMBOL(ldltx::g_xdog), sizeof(dg)));
+        if (dg[0]) { printf("   WATCHDOG n=%d np=%d: %d waits gave up; first: where %d wave %d a %d b %d\n", n, np, dg[0], dg[1], dg[2], dg[3], dg[4]); return 3; }
+      }
+#endif
+      CK(hipMemcpy(x.data(), dx, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok2, dok, 4, hipMemcpyDeviceToHost));
+      double err2 = 0;
+      for (int i = 0; i < n; i++) err2 = std::max(err2, std::fabs(x[i] - xr[i]));
+      const bool good2 = ok2 == 1 && err2 <= 1e-10 * std::max(mx, 1.0);
+      for (int i = 0; i < 10; i++) CK(ldltx::launch(cx, n, dS, dx, dok, 0, np));
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < reps; i++) CK(ldltx::launch(cx, n, dS, dx, dok, 0, np));
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      CK(hipMemcpy(x.data(), dx, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok2, dok, 4, hipMemcpyDeviceToHost));
+      double err3 = 0;
+      for (int i = 0; i < n; i++) err3 = std::max(err3, std::fabs(x[i] - xr[i]));
+      const bool good3 = ok2 == 1 && err3 <= 1e-10 * std::max(mx, 1.0);
+      printf("   xcd (%d workgroups, %d slots): ok=%d max|dx|=%.3e %s; after %d launches %.3e %s   %.2f us/launch\n", np, ldltx::plan_max_slots(cx.plan), ok2, err2,
+             good2 ? "ok" : "FAIL", reps + 10, err3, good3 ? "ok" : "FAIL", 1000.0 * ms / reps);
+      fails += !good2 + !good3;
+      {   // the cross-XCD-safe hand-overs (agent-scope release / acquire), forced
+        CK(hipMemset(dx, 0, n * 8));
+        CK(ldltx::launch(cx, n, dS, dx, dok, 0, np, true));
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 20; i++) CK(ldltx::launch(cx, n, dS, dx, dok, 0, np, true));
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpy(x.data(), dx, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok2, dok, 4, hipMemcpyDeviceToHost));
+        double err4 = 0;
+        for (int i = 0; i < n; i++) err4 = std::max(err4, std::fabs(x[i] - xr[i]));
+        const bool good4 = ok2 == 1 && err4 <= 1e-10 * std::max(mx, 1.0);
+        printf("   xcd, agent-scope fences forced: ok=%d max|dx|=%.3e %s   %.2f us/launch\n", ok2, err4, good4 ? "ok" : "FAIL", 1000.0 * ms / 20);
+        fails += !good4;
+      }
+#ifdef LDLTX_PROFILE
+      {
+        long long z[512] = {0}, pr[512];
+        for (int q = 430; q < 460; q++) z[q] = 0x7fffffffffffffffll;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(ldltx::g_xprof), z, sizeof(z)));
+        CK(ldltx::launch(cx, n, dS, dx, dok, 0, np));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltx::g_xprof), sizeof(pr)));
+        long long t0 = pr[4];
+        for (int q = 1; q < np; q++) t0 = std::min(t0, pr[4 + q]);
+        auto us = [&](long long t) { return (t - t0) * 0.01; };
+        printf("   xcd prof: participants %lld safe %lld; placed %.2f; all waves done %.2f; end %.2f us\n", pr[1], pr[12], us(pr[0]), us(pr[2]), us(pr[3]));
+        printf("   back-substitution (start, own block from, to):");
+        for (int w = 0; w < 5; w++) printf("  w%d %.2f %.2f %.2f", w, us(pr[300 + 4 * w]), us(pr[301 + 4 * w]), us(pr[302 + 4 * w]));
+        printf("\n   own block in clock64() ticks:");
+        for (int w = 0; w < 5; w++) printf(" %lld", pr[330 + w]);
+        printf("\n");
+        printf("   wave done:");
+        for (int w = 0; w < 8 * np; w++) printf(" %.1f", us(pr[256 + w]));
+        printf("\n");
+        for (int k = 0; k < g.Tp; k++)
+          if (np == 8) printf("    row %2d: pivots start %.2f done %.2f published %.2f | chain panel: seen %.2f G loaded %.2f, computed %.2f published %.2f done %.2f\n", k, us(pr[16 + 8 * k + 0]), us(pr[16 + 8 * k + 1]), us(pr[16 + 8 * k + 2]), us(pr[16 + 8 * k + 6]), us(pr[16 + 8 * k + 3]), us(pr[16 + 8 * k + 4]), us(pr[16 + 8 * k + 5]), us(pr[16 + 8 * k + 7]));
+        for (int q = 0; q < 3; q++) printf("   generic wavefront %d: %lld sweeps, %lld with work, %.1f us (%.2f us a sweep), %lld tile updates, %lld panel tiles\n", q == 0 ? 5 : q == 1 ? 29 : 62, pr[460 + 6 * q], pr[461 + 6 * q], pr[462 + 6 * q] * 0.01, pr[462 + 6 * q] * 0.01 / std::max(1ll, pr[460 + 6 * q]), pr[463 + 6 * q], pr[464 + 6 * q]);
+        for (int q = 0; q < 3; q++) printf("      time in: flags %.1f us, trailing updates %.1f us, panel + pivots + idle sleep %.1f us\n", pr[480 + 4 * q] * 0.01, pr[481 + 4 * q] * 0.01, pr[482 + 4 * q] * 0.01);
+        printf("   generic panel tiles of a row published (first .. last) after its G: ");
+        for (int k = 0; k + 4 < g.Tp; k++) printf(" %.1f..%.1f", us(pr[430 + k]) - us(pr[16 + 8 * k + 2]), us(pr[400 + k]) - us(pr[16 + 8 * k + 2]));
+        printf("\n");
+      }
+#endif
+      if (n == 300 && np == 8) {
+        std::vector<double> S2 = S;
+        for (int i = 0; i < n; i++) S2[i] = S2[(size_t)i * n] = 0.0;
+        std::vector<double> im2 = to_image(S2);
+        CK(hipMemcpy(dS, im2.data(), im2.size() * 8, hipMemcpyHostToDevice));
+        CK(ldltm::launch_image_pad(n, dS, 0));
+        CK(ldltx::launch(cx, n, dS, dx, dok, 0, np));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(&ok2, dok, 4, hipMemcpyDeviceToHost));
+        printf("   xcd zero pivot: ok=%d %s\n", ok2, ok2 == 0 ? "ok" : "FAIL");
+        fails += ok2 != 0;
+      }
+    }
     if (n == 120) {   // zero pivot -> ok = 0
       std::vector<double> S2 = S;
       for (int i = 0; i < n; i++) S2[i] = S2[(size_t)i * n] = 0.0;
