@@ -267,149 +267,102 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
       if (I < J && I < n_pad && J <= cb) wm_store(I, J, Wc[g]);
     }
   };
-  // ---- dataflow.  Per slot: st = tile rows still to apply (0: every row applied -- the tile waits for G of its row, or, on the
-  // diagonal, for its pivots; -1: finished or empty), the addresses of the two flags and of the two operand images of the next
-  // row (they move by one tile row per applied row: no address arithmetic, and hardly a branch, in a sweep -- written with
-  // conditions on (i, j, rows applied) a sweep was ~100 scalar branches and took 2-3 us, idle ones included).
-  int st[kNS], left = 0;
-  const unsigned* fpa[kNS]; const unsigned* fpb[kNS]; const unsigned* fpd[kNS];
+  // ---- the schedule of a wavefront, row by row (no polling sweeps: a sweep over four slots was three dependent L2 round trips and
+  // took 2-3 us; a tile advanced one row per sweep and the wavefronts ran rows behind the chain).  For r = 0, 1, ..:
+  //   * its panel tiles of row r (those not held by a chain wavefront): wait for G_r, solve, publish;
+  //   * its tiles below row r: wait for the two panel images of row r of each, all operand images in flight together, update.
+  // Every wait is for something of row r published by wavefronts that have only rows < r behind them: no cycle.  A chain
+  // wavefront (tiles (j-3, j) .. (j, j) in slots 0 .. 3) does rows < j-3 like this, then per row k = j-3, j-2, j-1: spins on G_k's
+  // flag, solves (k, j), updates the diagonal tile from registers and the tiles between with the -R images of (k, k+1) ..,
+  // which the chain wavefronts of those columns publish at about the same time; for k = j - 1 the pivots of (j, j) follow at
+  // once.  One hand-over per tile row on the critical path.
+  const bool chain_wave = plan.chain[gw] != 0;
+  bool on[kNS], isdiag[kNS];
+  const unsigned* fpa[kNS]; const unsigned* fpb[kNS];
   unsigned offa[kNS], offw[kNS];
-  bool isdiag[kNS];
+  int r_end = 0;                           // rows the row loop runs over
 #pragma unroll
   for (int s = 0; s < kNS; s++) {
-    const bool on = ti0[s] < (1 << 20);
-    const int i = on ? ti0[s] : 0, j = on ? tj0[s] : 0;
-    st[s] = on ? i : -1;
-    left += on;
-    isdiag[s] = on && i == j;
-    fpa[s] = f_panel + i; fpb[s] = f_panel + j; fpd[s] = f_diag + i;
+    on[s] = ti0[s] < (1 << 20);
+    const int i = on[s] ? ti0[s] : 0, j = on[s] ? tj0[s] : 0;
+    isdiag[s] = on[s] && i == j;
+    fpa[s] = f_panel + i; fpb[s] = f_panel + j;
     offa[s] = (unsigned)i * 512u; offw[s] = (unsigned)j * 512u + 256u;
+    if (on[s]) r_end = max(r_end, i + 1);
+  }
+  if (chain_wave) {                        // the first row its chain steps take over
+    r_end = 1 << 20;
+#pragma unroll
+    for (int s = 0; s < kNS; s++) if (on[s]) r_end = min(r_end, ti0[s]);
   }
   const unsigned row_words = (unsigned)T, row_doubles = (unsigned)T * 512u;
-  auto advance = [&](int s) { st[s]--; fpa[s] += row_words; fpb[s] += row_words; offa[s] += row_doubles; offw[s] += row_doubles; };
-  const bool chain_wave = plan.chain[gw] != 0;
-#ifdef LDLTX_PROFILE
-  long long sw_n = 0, sw_w = 0, sw_t0 = wall_clock64(), sw_upd = 0, sw_pan = 0, sw_tp = 0, sw_tu = 0, sw_tq = 0, sw_mark = 0;
-#endif
-  while (left > 0) {
+  auto spin = [&](const unsigned* f, int where, int a2) {
+    while (__builtin_amdgcn_readfirstlane(ld_flag(f)) != epoch && !bail_) { LDLTX_DOG(where, a2, 0); }
+  };
+  for (int r = 0; r < r_end; r++) {
     // (opaque copies: everything derived from a slot's tile position is loop-invariant, and hoisted out of this loop it costs 64
     // vector registers of store addresses and spills)
     int ti[kNS], tj[kNS];
 #pragma unroll
     for (int s = 0; s < kNS; s++) { ti[s] = ti0[s]; tj[s] = tj0[s]; asm volatile("" : "+s"(ti[s]), "+s"(tj[s])); }
-    // ---- a chain wavefront (tiles (j-3, j) .. (j, j) in slots 0 .. 3).  Once every row above the first unfinished tile (k, j) is
-    // applied to all its tiles it leaves the sweeps: it spins on G_k's flag, solves (k, j), updates the diagonal tile from
-    // registers and the tiles between with the -R images of (k, k+1) .., which the chain wavefronts of those columns publish at
-    // about the same time; for k = j - 1 the pivots of (j, j) follow at once.  One hand-over per tile row on the critical path,
-    // no sweep in it, and the wavefront is back spinning before the next G arrives.
-    if (chain_wave) {
-      bool took = false;
-      auto chain_step = [&](auto SC) {
-        constexpr int S = decltype(SC)::value;
-        constexpr int D = kChain - 1;              // the diagonal tile's slot
-        bool go = !took && st[S] == 0;
+    // ---- panel tiles of row r
+    bool have_g = false;
+    double Gf[4] = {0, 0, 0, 0}, dv4[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int s1 = 0; s1 < S; s1++) go = go && st[s1] < 0;
+    for (int s = 0; s < kNS; s++) {
+      if (!chain_wave && on[s] && ti[s] == r && !isdiag[s]) {
+        const int j = tj[s];
+        if (!have_g) {
+          spin(f_diag + r, 1, r);
+          acquire();
+          const double* const gk = Gb + (size_t)r * 16 * kGld;
 #pragma unroll
-        for (int s1 = S + 1; s1 <= D; s1++) go = go && st[s1] == s1 - S;
-        if (!go) return;
-        took = true;
-        const int k = ti[S], j = tj[S];
-        while (__builtin_amdgcn_readfirstlane(ld_flag(fpd[S])) != epoch && !bail_) { LDLTX_DOG(1, k, j); }
-        acquire();
-        if (S == D - 1) LDLTX_T(16 + 8 * k + 6);
-        double Gf[4], dv4[4];
-        const double* const gk = Gb + (size_t)k * 16 * kGld;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + k * 16 + lr + 4 * q); }
-        if (S == D - 1) LDLTX_T(16 + 8 * k + 3);
-        const d4 X = acc[S];
+          for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + r * 16 + lr + 4 * q); }
+          have_g = true;
+        }
+        const d4 X = acc[s];
         d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
         R0 = mfma(Gf[0], X[0], R0);
         R1 = mfma(Gf[2], X[2], R1);
         R0 = mfma(Gf[1], X[1], R0);
         R1 = mfma(Gf[3], X[3], R1);
-        double* const pb = Pan + ((size_t)(k * T + j) * 2) * 256 + lane;
-        double nR[4], w4[4];
+        double* const pb = Pan + ((size_t)(r * T + j) * 2) * 256 + lane;
+        double w4[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           const double rr = R0[g] + R1[g];
-          nR[g] = -rr;
           w4[g] = rr * dv4[g];
-          pb[g * 64] = nR[g];
+          pb[g * 64] = -rr;
           pb[256 + g * 64] = w4[g];
         }
-        if (S == D - 1) LDLTX_T(16 + 8 * k + 4);
-        publish(kFPanel + k * T + j, true);
-        if (S == D - 1) LDLTX_T(16 + 8 * k + 5);
-        {                                          // (the same order of operations as every other tile update: results do not
-          d4 c = acc[D];                           // depend on which path applied a row)
-#pragma unroll
-          for (int q = 0; q < 4; q++) c = mfma(nR[q], w4[q], c);
-          acc[D] = c;
-        }
-        st[S] = -1; left--;
-        advance(D);
-        if (S == D - 1) {
-          LDLTX_T(16 + 8 * k + 7);
-          if (k + 1 < G.Tp) factor(k + 1);
-          st[D] = -1; left--;
-        }
-#pragma unroll
-        for (int s1 = S + 1; s1 < D; s1++) {       // tile (i, j), k < i < j: -R of (k, i) from the L2, W of (k, j) from registers
-          while (__builtin_amdgcn_readfirstlane(ld_flag(fpa[s1])) != epoch && !bail_) { LDLTX_DOG(6, k, s1); }
-          acquire();
-          const double* const pa = Pan + offa[s1] + lane;
-          double oa[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) oa[q] = ld_l2(pa + q * 64);
-          d4 c = acc[s1];
-#pragma unroll
-          for (int q = 0; q < 4; q++) c = mfma(oa[q], w4[q], c);
-          acc[s1] = c;
-          advance(s1);
-        }
+        publish(kFPanel + r * T + j, true);
+#ifdef LDLTX_PROFILE
+        if (lane == 0) { atomicMax((unsigned long long*)&g_xprof[400 + r], (unsigned long long)wall_clock64()); atomicMin((unsigned long long*)&g_xprof[430 + r], (unsigned long long)wall_clock64()); }
+#endif
         const int J = 16 * j + lc;
         if (J <= cb) {
 #pragma unroll
-          for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, w4[g]);
+          for (int g = 0; g < 4; g++) wm_store(16 * r + lr + 4 * g, J, w4[g]);
         }
-      };
-      chain_step(std::integral_constant<int, 0>{});
-      chain_step(std::integral_constant<int, 1>{});
-      chain_step(std::integral_constant<int, 2>{});
-      if (took) continue;
-    }
-    // ---- one sweep: the flags every slot waits for -- the two panel images of its next row, G of its own row -- in one round
-    // trip; then the ready trailing updates (operand images of all slots in flight together); then the panel tiles whose last row
-    // is applied -- in THIS sweep, too: with panels first a column's tiles (k, j), (k+1, j) cost two sweeps a row and the
-    // wavefronts fall rows behind the chain
-#ifdef LDLTX_PROFILE
-    sw_mark = wall_clock64();
-#endif
-    bool upd[kNS], dg[kNS], any = false;
-    {
-      unsigned fa[kNS], fb[kNS], fd[kNS];
-#pragma unroll
-      for (int s = 0; s < kNS; s++) { fa[s] = ld_flag(fpa[s]); fb[s] = ld_flag(fpb[s]); fd[s] = ld_flag(fpd[s]); }
-#pragma unroll
-      for (int s = 0; s < kNS; s++) {
-        const unsigned a = __builtin_amdgcn_readfirstlane(fa[s]), b2 = __builtin_amdgcn_readfirstlane(fb[s]), d = __builtin_amdgcn_readfirstlane(fd[s]);
-        upd[s] = (st[s] > 0) & (a == epoch) & (b2 == epoch);
-        dg[s] = (d == epoch) & !isdiag[s];
-        any = any | upd[s];
       }
     }
-    acquire();
-    bool worked = false;
-#ifdef LDLTX_PROFILE
-    { const long long t = wall_clock64(); sw_tp += t - sw_mark; sw_mark = t; }
-    sw_n++;
+    // ---- tiles below row r: all their flags, then all their operand images, then the updates
+    bool need[kNS], any = false;
 #pragma unroll
-    for (int s = 0; s < kNS; s++) { sw_upd += upd[s]; sw_pan += dg[s] && st[s] == 0; }
-#endif
-    // ---- trailing updates
+    for (int s = 0; s < kNS; s++) { need[s] = on[s] && ti[s] > r; any = any || need[s]; }
     if (any) {
+      for (;;) {
+        unsigned fa[kNS], fb[kNS];
+#pragma unroll
+        for (int s = 0; s < kNS; s++) { fa[s] = ld_flag(fpa[s]); fb[s] = ld_flag(fpb[s]); }
+        bool all = true;
+#pragma unroll
+        for (int s = 0; s < kNS; s++)
+          all = all && (!need[s] || (__builtin_amdgcn_readfirstlane(fa[s]) == epoch && __builtin_amdgcn_readfirstlane(fb[s]) == epoch));
+        if (all || bail_) break;
+        LDLTX_DOG(3, r, ti0[0] * 100 + tj0[0]);
+      }
+      acquire();
       double oa[kNS][4], ow[kNS][4];
 #pragma unroll
       for (int s = 0; s < kNS; s++) {            // unconditional loads (a branch would drain the memory counter per slot)
@@ -420,74 +373,88 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
       }
 #pragma unroll
       for (int s = 0; s < kNS; s++) {
-        if (upd[s]) {
+        if (need[s]) {
           d4 c = acc[s];
 #pragma unroll
           for (int q = 0; q < 4; q++) c = mfma(oa[s][q], ow[s][q], c);
           acc[s] = c;
-          advance(s);
         }
       }
-      worked = true;
     }
-#ifdef LDLTX_PROFILE
-    { const long long t = wall_clock64(); sw_tu += t - sw_mark; sw_mark = t; }
-#endif
-    // ---- panel tiles
-    int g_row = -1;
-    double Gf[4] = {0, 0, 0, 0}, dv4[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int s = 0; s < kNS; s++) {
-      if (dg[s] && st[s] == 0) {
-        const int k = ti[s], j = tj[s];
-        if (g_row != k) {
-          const double* const gk = Gb + (size_t)k * 16 * kGld;
+    for (int s = 0; s < kNS; s++) { fpa[s] += row_words; fpb[s] += row_words; offa[s] += row_doubles; offw[s] += row_doubles; }
+  }
+  if (chain_wave) {
+    int ti[kNS], tj[kNS];
 #pragma unroll
-          for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + k * 16 + lr + 4 * q); }
-          g_row = k;
-        }
-        const d4 X = acc[s];
-        d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
-        R0 = mfma(Gf[0], X[0], R0);
-        R1 = mfma(Gf[2], X[2], R1);
-        R0 = mfma(Gf[1], X[1], R0);
-        R1 = mfma(Gf[3], X[3], R1);
-        double* const pb = Pan + ((size_t)(k * T + j) * 2) * 256 + lane;
-        double w4[4];
+    for (int s = 0; s < kNS; s++) { ti[s] = ti0[s]; tj[s] = tj0[s]; asm volatile("" : "+s"(ti[s]), "+s"(tj[s])); }
+    constexpr int D = kChain - 1;                // the diagonal tile's slot
+    auto chain_step = [&](auto SC) {
+      constexpr int S = decltype(SC)::value;
+      if (!on[S]) return;
+      const int k = ti[S], j = tj[S];
+      spin(f_diag + k, 1, k);
+      acquire();
+      if (S == D - 1) LDLTX_T(16 + 8 * k + 6);
+      double Gf[4], dv4[4];
+      const double* const gk = Gb + (size_t)k * 16 * kGld;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const double rr = R0[g] + R1[g];
-          w4[g] = rr * dv4[g];
-          pb[g * 64] = -rr;
-          pb[256 + g * 64] = w4[g];
-        }
-        publish(kFPanel + k * T + j, true);
-#ifdef LDLTX_PROFILE
-        if (lane == 0) { atomicMax((unsigned long long*)&g_xprof[400 + k], (unsigned long long)wall_clock64()); atomicMin((unsigned long long*)&g_xprof[430 + k], (unsigned long long)wall_clock64()); }
-#endif
-        const int J = 16 * j + lc;
-        if (J <= cb) {
+      for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + k * 16 + lr + 4 * q); }
+      if (S == D - 1) LDLTX_T(16 + 8 * k + 3);
+      const d4 X = acc[S];
+      d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
+      R0 = mfma(Gf[0], X[0], R0);
+      R1 = mfma(Gf[2], X[2], R1);
+      R0 = mfma(Gf[1], X[1], R0);
+      R1 = mfma(Gf[3], X[3], R1);
+      double* const pb = Pan + ((size_t)(k * T + j) * 2) * 256 + lane;
+      double nR[4], w4[4];
 #pragma unroll
-          for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, w4[g]);
-        }
-        st[s] = -1; left--; worked = true;
+      for (int g = 0; g < 4; g++) {
+        const double rr = R0[g] + R1[g];
+        nR[g] = -rr;
+        w4[g] = rr * dv4[g];
+        pb[g * 64] = nR[g];
+        pb[256 + g * 64] = w4[g];
       }
-    }
-    // ---- a diagonal tile with every row above it applied that no chain step took (tile (0, 0)): its pivots
-    int fk = -1;
+      if (S == D - 1) LDLTX_T(16 + 8 * k + 4);
+      publish(kFPanel + k * T + j, true);
+      if (S == D - 1) LDLTX_T(16 + 8 * k + 5);
+      {                                            // (the same order of operations as every other tile update: results do not
+        d4 c = acc[D];                             // depend on who applied a row)
 #pragma unroll
-    for (int s = 0; s < kNS; s++) {
-      if (isdiag[s] && st[s] == 0) {
-        if (ti[s] < G.Tp) fk = ti[s];
-        st[s] = -1; left--; worked = true;
+        for (int q = 0; q < 4; q++) c = mfma(nR[q], w4[q], c);
+        acc[D] = c;
       }
-    }
-    if (fk >= 0) factor(fk);
-#ifdef LDLTX_PROFILE
-    sw_w += worked;
-    { const long long t = wall_clock64(); sw_tq += t - sw_mark; sw_mark = t; }
-#endif
-    if (!worked) { __builtin_amdgcn_s_sleep(1); LDLTX_DOG(3, st[0] * 10000 + st[1] * 100 + st[2], ti0[0] * 10000 + ti0[1] * 100 + ti0[2]); if (bail_) break; }
+      if (S == D - 1) {
+        LDLTX_T(16 + 8 * k + 7);
+        if (k + 1 < G.Tp) factor(k + 1);
+      }
+#pragma unroll
+      for (int s1 = S + 1; s1 < D; s1++) {         // tile (i, j), k < i < j: -R of (k, i) from the L2, W of (k, j) from registers
+        spin(fpa[s1], 6, k);
+        acquire();
+        const double* const pa = Pan + offa[s1] + lane;
+        double oa[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) oa[q] = ld_l2(pa + q * 64);
+        d4 c = acc[s1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) c = mfma(oa[q], w4[q], c);
+        acc[s1] = c;
+      }
+      const int J = 16 * j + lc;
+      if (J <= cb) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) wm_store(16 * k + lr + 4 * g, J, w4[g]);
+      }
+#pragma unroll
+      for (int s = 0; s < kNS; s++) { fpa[s] += row_words; offa[s] += row_doubles; }
+    };
+    if (!on[D - 1] && on[D] && ti[D] == 0 && G.Tp > 0) factor(0);      // column 0: the first pivots wait for nothing
+    chain_step(std::integral_constant<int, 0>{});
+    chain_step(std::integral_constant<int, 1>{});
+    chain_step(std::integral_constant<int, 2>{});
   }
   // ---- every wavefront reports; participant 0 back-substitutes  L^T x = y.  Wavefront w owns rows 64 w .. 64 w + 63 (one per
   // lane): it streams its rows of the factor's columns from the L2, four columns a group from the last column down, kDepth groups
@@ -497,7 +464,6 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   publish(kFWave + gw, false);
 #ifdef LDLTX_PROFILE
   LDLTX_T(256 + gw);
-  if (lane == 0 && (gw == 5 || gw == 29 || gw == 62)) { long long* o = g_xprof + 460 + (gw == 5 ? 0 : gw == 29 ? 6 : 12); o[0] = sw_n; o[1] = sw_w; o[2] = wall_clock64() - sw_t0; o[3] = sw_upd; o[4] = sw_pan; long long* o2 = g_xprof + 480 + (gw == 5 ? 0 : gw == 29 ? 4 : 8); o2[0] = sw_tp; o2[1] = sw_tu; o2[2] = sw_tq; }
 #endif
   if (rank != 0 || wv >= kNY || 64 * wv >= n_pad) return;
   for (;;) {

@@ -234,8 +234,6 @@ int main(int argc, char** argv) {
         printf("\n");
         for (int k = 0; k < g.Tp; k++)
           if (np == 8) printf("    row %2d: pivots start %.2f done %.2f published %.2f | chain panel: seen %.2f G loaded %.2f, computed %.2f published %.2f done %.2f\n", k, us(pr[16 + 8 * k + 0]), us(pr[16 + 8 * k + 1]), us(pr[16 + 8 * k + 2]), us(pr[16 + 8 * k + 6]), us(pr[16 + 8 * k + 3]), us(pr[16 + 8 * k + 4]), us(pr[16 + 8 * k + 5]), us(pr[16 + 8 * k + 7]));
-        for (int q = 0; q < 3; q++) printf("   generic wavefront %d: %lld sweeps, %lld with work, %.1f us (%.2f us a sweep), %lld tile updates, %lld panel tiles\n", q == 0 ? 5 : q == 1 ? 29 : 62, pr[460 + 6 * q], pr[461 + 6 * q], pr[462 + 6 * q] * 0.01, pr[462 + 6 * q] * 0.01 / std::max(1ll, pr[460 + 6 * q]), pr[463 + 6 * q], pr[464 + 6 * q]);
-        for (int q = 0; q < 3; q++) printf("      time in: flags %.1f us, trailing updates %.1f us, panel + pivots + idle sleep %.1f us\n", pr[480 + 4 * q] * 0.01, pr[481 + 4 * q] * 0.01, pr[482 + 4 * q] * 0.01);
         printf("   generic panel tiles of a row published (first .. last) after its G: ");
         for (int k = 0; k + 4 < g.Tp; k++) printf(" %.1f..%.1f", us(pr[430 + k]) - us(pr[16 + 8 * k + 2]), us(pr[400 + k]) - us(pr[16 + 8 * k + 2]));
         printf("\n");
