@@ -1,20 +1,23 @@
-// Dense LDL^T + solve of the reduced camera system on SEVERAL workgroups of ONE XCD (round 5): the C4 window (50 free poses, 300
-// unknowns, 19 tile rows) takes 122 us on the one compute unit of ldltm::k_ldlt_big48, whose matrix-instruction floor is ~31 us
-// (4570 v_mfma_f64_16x16x4 / 4 SIMDs) and whose LDS operand feed runs at half the CU's bandwidth.  Here the 190 tiles are dealt to
-// kP x 8 wavefronts on kP compute units that share an L2; everything that ldltm::k_ldlt_mfma hands from wavefront to wavefront
-// through LDS (G = L_kk^-1 and D^-1 of a diagonal tile, the -R / W images of a panel tile, the "published" flags) goes through
-// global memory that stays in that L2:
+// Dense LDL^T + solve of the reduced camera system on EIGHT workgroups of ONE XCD (round 5).  The C4 window (50 free poses, 300
+// unknowns, 19 tile rows) takes 111 us alone and 140 us next to the tracking streams on the one compute unit of
+// ldltm::k_ldlt_big48; here 92 / 96 us.  The 190 tiles of 16 x 16 live in the registers of 64 wavefronts on 8 compute units that share
+// an L2.  What ldltm::k_ldlt_mfma hands from wavefront to wavefront through LDS -- G = L_kk^-1 and D^-1 of a diagonal tile, the
+// -R / W images of a panel tile, the "published" flags -- goes through global memory that stays in that L2:
 //   * stores are plain (the vector L1 writes through), s_waitcnt vmcnt(0), then a relaxed agent-scope store of the flag word;
 //   * flags and operands are read with relaxed agent-scope atomic loads (sc1: they miss in the CU's vector L1 and are served by the
-//     XCD's L2) -- measured 0.59 us per hand-over of a 2 KB tile (tools/micro/xcd_handover), against 0.93 / 1.25 us for an
-//     agent-scope release / acquire pair inside / across XCDs.  This is coherent ONLY because all participants share one L2.
-// Placement: 8 x kP workgroups are launched (the dispatcher deals workgroups round-robin over the 8 XCDs); every workgroup reads
-// HW_REG_XCC_ID and draws a ticket of its XCD; the first XCD that has kP tickets wins, its first kP workgroups take part, everybody
-// else leaves at once (pigeonhole: some XCD always gets kP).  Flags carry the launch's epoch, so nothing is cleared between launches.
-// Chain: tile (k, k+1) and tile (k+1, k+1) belong to the same wavefront, which goes G_k -> panel -> update from registers -> pivots
-// -> G_{k+1} with ONE hand-over per tile row; trailing tiles fetch their two operand images from the L2, all tiles of a wavefront
-// in flight at once.  Same arithmetic per tile as ldltm::k_ldlt_mfma (pivot pairs as rank-2 matrix instructions, G collected on an
-// identity copy); the back-substitution runs on one wavefront once every wavefront has reported.
+//     XCD's L2): 0.45 us from the flag store to the reader seeing it, 0.16 .. 0.6 us per load round trip (quiet .. 64 wavefronts
+//     polling); tools/micro/xcd_handover measured 0.59 us per 2 KB hand-over against 0.93 / 1.25 us for an agent-scope release /
+//     acquire pair inside / across XCDs.  Coherent ONLY because all participants share one L2 -- so:
+// Placement: a grid of 57 blocks; blocks 0, 8, .., 56 take part (the dispatcher deals a grid's workgroups round-robin over the 8
+// XCDs), the others leave at once.  Every participant posts HW_REG_XCC_ID; if the ids differ (another partition mode, a changed
+// dispatcher) every hand-over becomes an agent-scope release / acquire pair: slower (147 us), correct, tested (ORBG_LDLT_XCD=safe).
+// Flags carry the launch's number (epoch): nothing is cleared between launches.
+// Schedule: column j's last four tiles (j-3, j) .. (j, j) sit on one "chain" wavefront, which per row k = j-3 .. j-1 spins on
+// G_k's flag, solves (k, j), updates the tiles below from registers / one L2 image, and for k = j-1 runs the pivots of (j, j) at
+// once: ONE hand-over per tile row on the critical path.  The other tiles, <= 4 per wavefront, are walked row by row (wait for
+// the row's panel images, update; wait for G, solve, publish).  Same arithmetic per tile as ldltm::k_ldlt_mfma (pivot pairs as
+// rank-2 matrix instructions, G collected on an identity copy) in one fixed order: bitwise reproducible.  The back-substitution
+// runs on five wavefronts of workgroup 0, one per 64-row block, x posted through LDS.  DESIGN.md section 8 has the timeline.
 #pragma once
 
 #include <type_traits>
@@ -32,11 +35,11 @@ using ldltm::rcp1;
 using ldltm::rdlane;
 using ldltm::row_even_to_odd;
 
-constexpr int kMaxP = 8;                    // participating workgroups (compute units of one XCD): 4 or 8
+constexpr int kMaxP = 8;                    // participating workgroups (compute units of one XCD)
 constexpr int kWgWaves = 8, kThreads = 64 * kWgWaves;
 constexpr int kMaxW = kMaxP * kWgWaves;     // wavefronts that hold tiles
 constexpr int kChain = 4;                   // tiles of a column, from the diagonal up, that its chain wavefront holds
-constexpr int kMaxNS = 8;                   // tile slots per wavefront: 4 with 8 workgroups, 8 with 4
+constexpr int kMaxNS = 8;                   // tile slots per wavefront in the plan (the kernel uses 4)
 constexpr int kMaxT = ldltm::kMaxT;
 constexpr int kNY = 5;                      // 64-lane groups of the solution vector (n_pad <= 320)
 // flag words
@@ -53,15 +56,13 @@ __host__ inline size_t scratch_doubles() { return kWOff + ldltm::wglob_doubles(m
 struct Plan { short tile[kMaxW][kMaxNS]; signed char chain[kMaxW]; int np, ns, force_safe; };       // tile index j(j+1)/2 + i per wavefront slot (-1: none), in processing order
 
 __host__ inline bool plan_fits(int n, int np, int ns);
-// the systems this kernel can take (tools/micro/ldlt_mfma_test: it is ahead of ldltm::k_ldlt_big48 from 16 tile rows on -- 75 / 88 /
-// 96 us against 81 / 99 / 111 us at 16 / 18 / 19 rows -- level at 15, behind below)
+// the systems this kernel can take (tools/micro/ldlt_mfma_test: it is ahead of ldltm::k_ldlt_big48 from 16 tile rows on -- 72 / 85 /
+// 92 us against 81 / 99 / 111 us at 16 / 18 / 19 rows -- level at 15, behind below)
 __host__ inline bool supports(int n) { const Geo g = make_geo(n); return n >= 1 && g.T >= 14 && g.T <= kMaxT - 1 && g.n_pad <= 64 * kNY && plan_fits(n, kMaxP, 4); }
 __host__ inline bool pays(int n) { return supports(n) && make_geo(n).T >= 16; }
 
-// Tiles to wavefronts.  Column j's last three tiles -- (j-2, j), (j-1, j), (j, j) -- go to one "chain" wavefront (consecutive
-// columns on different compute units) that holds nothing else: it meets G_{j-2} and G_{j-1} polling, not in the middle of a
-// trailing update.  The other tiles go round to the remaining wavefronts (to the chain wavefronts too once those are full).
-// Slots are ordered by (row, column).
+// Tiles to wavefronts.  Column j's last kChain tiles go to one "chain" wavefront (consecutive columns on different compute units)
+// that holds nothing else; the other tiles, column by column, to whichever other wavefront holds the fewest, ordered by (row, column).
 __host__ inline Plan make_plan(int n, int np, int ns) {
   const Geo g = make_geo(n);
   const int W = np * kWgWaves;
@@ -78,6 +79,9 @@ __host__ inline Plan make_plan(int n, int np, int ns) {
     cnt[w] = kChain;
     for (int q = 0; q < kChain; q++) P.tile[w][q] = j - (kChain - 1) + q >= 0 ? (short)ldltm::tile_index(j - (kChain - 1) + q, j) : (short)-1;
   }
+  // the other tiles column by column to whichever wavefront holds the fewest.  (Four tiles of one ROW per wavefront -- slots in
+  // lockstep, one shared -R image -- was slower: 100 us against 92; a row's panel tiles then come from four wavefronts only and
+  // every other wavefront waits for the last of them.)
   for (int j = kChain; j < g.T; j++)
     for (int i = 0; i + kChain <= j; i++) {
       int best = -1;
@@ -305,12 +309,14 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
     int ti[kNS], tj[kNS];
 #pragma unroll
     for (int s = 0; s < kNS; s++) { ti[s] = ti0[s]; tj[s] = tj0[s]; asm volatile("" : "+s"(ti[s]), "+s"(tj[s])); }
-    // ---- panel tiles of row r
-    bool have_g = false;
-    double Gf[4] = {0, 0, 0, 0}, dv4[4] = {0, 0, 0, 0};
+    // ---- panel tiles of row r: all solved and stored, ONE wait for the stores, then their flags (a wait per tile is a store
+    // round trip, 0.5 us, per tile)
+    bool have_g = false, pan[kNS];
+    double Gf[4] = {0, 0, 0, 0}, dv4[4] = {0, 0, 0, 0}, wk[kNS][4];
 #pragma unroll
     for (int s = 0; s < kNS; s++) {
-      if (!chain_wave && on[s] && ti[s] == r && !isdiag[s]) {
+      pan[s] = !chain_wave && on[s] && ti[s] == r && !isdiag[s];
+      if (pan[s]) {
         const int j = tj[s];
         if (!have_g) {
           spin(f_diag + r, 1, r);
@@ -327,22 +333,31 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
         R0 = mfma(Gf[1], X[1], R0);
         R1 = mfma(Gf[3], X[3], R1);
         double* const pb = Pan + ((size_t)(r * T + j) * 2) * 256 + lane;
-        double w4[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           const double rr = R0[g] + R1[g];
-          w4[g] = rr * dv4[g];
+          wk[s][g] = rr * dv4[g];
           pb[g * 64] = -rr;
-          pb[256 + g * 64] = w4[g];
+          pb[256 + g * 64] = wk[s][g];
         }
-        publish(kFPanel + r * T + j, true);
-#ifdef LDLTX_PROFILE
-        if (lane == 0) { atomicMax((unsigned long long*)&g_xprof[400 + r], (unsigned long long)wall_clock64()); atomicMin((unsigned long long*)&g_xprof[430 + r], (unsigned long long)wall_clock64()); }
-#endif
-        const int J = 16 * j + lc;
-        if (J <= cb) {
+      }
+    }
+    if (have_g) {
+      if (safe) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-          for (int g = 0; g < 4; g++) wm_store(16 * r + lr + 4 * g, J, w4[g]);
+      for (int s = 0; s < kNS; s++) {
+        if (pan[s]) {
+          const int j = tj[s];
+          if (lane < kMaxP) __hip_atomic_store(flags + lane * kFlagStride + kFPanel + r * T + j, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LDLTX_PROFILE
+          if (lane == 0) { atomicMax((unsigned long long*)&g_xprof[400 + r], (unsigned long long)wall_clock64()); atomicMin((unsigned long long*)&g_xprof[430 + r], (unsigned long long)wall_clock64()); }
+#endif
+          const int J = 16 * j + lc;
+          if (J <= cb) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) wm_store(16 * r + lr + 4 * g, J, wk[s][g]);
+          }
         }
       }
     }
