@@ -537,6 +537,66 @@ int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMa
   return n;
 }
 
+// ------------------------------------------------------------------------------------------------ local-BA window cache
+// Consecutive local-BA windows share ~95 % of their map points.  Reading a point costs the reference a std::map copy
+// (GetObservations) and a matrix clone (GetWorldPos), both under the point's mutexes, plus a sort of its observations: two thirds of
+// the glue's time.  A MapPoint type that carries a change counter
+//     long unsigned mnChangeStamp = 0;     // ++ in AddObservation, EraseObservation, SetWorldPos, SetBadFlag
+// lets the calling thread (LocalMapping) keep each point's flattened observation list and position from window to window and
+// re-read only the points whose counter moved -- by this function's own write-back, which knows what it wrote, or by anybody else.
+// Without the member the points are read as before; an entry-point set with `kNoLbaCache = true` also reads them as before (tests).
+template <class T, class = void> struct has_change_stamp : std::false_type {};
+template <class T> struct has_change_stamp<T, std::void_t<decltype(std::declval<T&>().mnChangeStamp)>> : std::true_type {};
+template <class Ops, class = void> struct lba_cache_off : std::false_type {};
+template <class Ops> struct lba_cache_off<Ops, std::void_t<decltype(Ops::kNoLbaCache)>> : std::integral_constant<bool, Ops::kNoLbaCache> {};
+
+template <class KeyFrameT, class MapPointT>
+struct LbaWindowCache {
+  struct Obs { KeyFrameT* kf; size_t kf_vid; int li; float u, v, ur, w; };
+  struct Rec {
+    MapPointT* mp = nullptr; long unsigned id = 0, stamp = 0, seen = 0; bool valid = false;
+    size_t vid = 0; float pos[3] = {0, 0, 0};
+    std::vector<Obs> obs;                    // every observation (li < 0 ones too: their keyframes still count as fixed cameras), by keyframe vertex id
+  };
+  std::vector<Rec> recs;
+  std::vector<int32_t> tab;                  // open addressing on the point's address -> index into recs
+  long unsigned call = 0;
+  static LbaWindowCache& instance() { static thread_local LbaWindowCache c; return c; }
+  size_t slot_of(const void* p) const { return ((reinterpret_cast<uintptr_t>(p) >> 4) * 0x9E3779B97F4A7C15ull >> 16) & (tab.size() - 1); }
+  void rebuild_table(size_t want) {
+    size_t n = 1024;
+    while (n < 2 * want) n *= 2;
+    tab.assign(n, -1);
+    for (size_t i = 0; i < recs.size(); i++) {
+      size_t h = slot_of(recs[i].mp);
+      while (tab[h] >= 0) h = (h + 1) & (tab.size() - 1);
+      tab[h] = (int32_t)i;
+    }
+  }
+  int32_t find_or_add(MapPointT* mp) {
+    if (tab.empty() || 2 * (recs.size() + 1) > tab.size()) rebuild_table(2 * (recs.size() + 1));
+    size_t h = slot_of(mp);
+    while (tab[h] >= 0) {
+      if (recs[tab[h]].mp == mp) return tab[h];
+      h = (h + 1) & (tab.size() - 1);
+    }
+    recs.emplace_back();
+    recs.back().mp = mp;
+    tab[h] = (int32_t)recs.size() - 1;
+    return tab[h];
+  }
+  // points that left the window stay until they outnumber the window four to one
+  void drop_unseen(size_t window) {
+    if (recs.size() <= 4 * window + 1024) return;
+    size_t k = 0;
+    for (size_t i = 0; i < recs.size(); i++)
+      if (recs[i].seen + 8 >= call) { if (k != i) recs[k] = std::move(recs[i]); k++; }
+    recs.resize(k);
+    rebuild_table(recs.size());
+  }
+  void clear() { recs.clear(); tab.clear(); }
+};
+
 // ------------------------------------------------------------------------------------------------ Optimizer
 // void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int LocalBASize),
 // S/Optimizer.cc:1810-2410.  Graph collection (:1813-1908) and write-back (:2263-2408) act on the caller's objects exactly
@@ -556,7 +616,8 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   }
   // ---- local map points: seen by the local keyframes (:1828-1854)
   num_fixedKF = 0;
-  std::list<MapPointT*> lLocalMapPoints;
+  static thread_local std::vector<MapPointT*> lLocalMapPoints;       // (a std::list in the reference: 2000 nodes allocated and freed per window)
+  lLocalMapPoints.clear();
   for (KeyFrameT* kf : lLocalKeyFrames) {
     if (kf->mnId == pMap->GetInitKFid()) num_fixedKF = 1;
     for (MapPointT* mp : kf->GetMapPointMatches())
@@ -567,20 +628,64 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   }
   ORBGPU_GLUE_T("local keyframes + points");
   // ---- fixed keyframes: observe local points without being local (:1856-1873).  GetObservations() hands out a COPY of the
-  // point's std::map (under the point's mutex): it is taken once per point and kept for the edge pass below
+  // point's std::map (under the point's mutex): it is taken once per point and kept for the edge pass below -- or, with the window
+  // cache, taken only for the points that changed since this thread's last window
+  constexpr bool kCached = has_change_stamp<MapPointT>::value && !lba_cache_off<Ops>::value;
+  using Cache = LbaWindowCache<KeyFrameT, MapPointT>;
   using ObsMap = typename std::decay<decltype(std::declval<MapPointT>().GetObservations())>::type;
   struct LocalPoint { MapPointT* mp; ObsMap obs; size_t vid; };
   std::vector<LocalPoint> vLP;
-  vLP.reserve(lLocalMapPoints.size());
+  std::vector<int32_t> vRec;                 // (cached path) the cache record of each local point
   std::list<KeyFrameT*> lFixedCameras;
-  for (MapPointT* mp : lLocalMapPoints) {
-    vLP.push_back(LocalPoint{mp, mp->GetObservations(), vertex_id(mp->mnId, mp->mnClientId, false)});
-    for (const auto& ob : vLP.back().obs) {
-      KeyFrameT* kf = ob.first;
-      if (kf->mnBALocalForKF != pKF->mnId && kf->mnBAFixedForKF != pKF->mnId) {
-        kf->mnBAFixedForKF = pKF->mnId;
-        if (!kf->isBad() && kf->GetMap() == pCurrentMap) lFixedCameras.push_back(kf);
+  auto note_camera = [&](KeyFrameT* kf) {
+    if (kf->mnBALocalForKF != pKF->mnId && kf->mnBAFixedForKF != pKF->mnId) {
+      kf->mnBAFixedForKF = pKF->mnId;
+      if (!kf->isBad() && kf->GetMap() == pCurrentMap) lFixedCameras.push_back(kf);
+    }
+  };
+  // (cached path) keyframes by vertex id relative to the window's keyframe: the marks of a keyframe are looked at once per window,
+  // not once per observation, and the edge pass finds a keyframe's column without hashing its address
+  constexpr size_t kVidSpan = 4096;
+  const size_t vid_hi = vertex_id(pKF->mnId, pKF->mnClientId, true);
+  static thread_local std::vector<uint8_t> kfSeen; static thread_local std::vector<int32_t> kfCol;
+  if constexpr (kCached) {
+    Cache& C = Cache::instance();
+    C.call++;
+    kfSeen.assign(kVidSpan, 0);
+    vRec.reserve(lLocalMapPoints.size());
+    for (MapPointT* mp : lLocalMapPoints) {
+      const int32_t ri = C.find_or_add(mp);
+      typename Cache::Rec& rc = C.recs[ri];
+      const long unsigned stamp = mp->mnChangeStamp;        // read BEFORE the point: a change during the read is seen next time
+      if (!rc.valid || rc.id != mp->mnId || rc.stamp != stamp) {
+        rc.id = mp->mnId; rc.stamp = stamp; rc.valid = true; rc.vid = vertex_id(mp->mnId, mp->mnClientId, false);
+        rc.obs.clear();
+        for (const auto& ob : mp->GetObservations()) {
+          KeyFrameT* kf = ob.first;
+          typename Cache::Obs o{kf, vertex_id(kf->mnId, kf->mnClientId, true), std::get<0>(ob.second), 0.f, 0.f, 0.f, 0.f};
+          if (o.li >= 0) {
+            const auto& kp = kf->mvKeysUn[o.li];
+            o.u = kp.pt.x; o.v = kp.pt.y; o.ur = kf->mvuRight[o.li]; o.w = kf->mvInvLevelSigma2[kp.octave];
+          }
+          rc.obs.push_back(o);
+        }
+        std::sort(rc.obs.begin(), rc.obs.end(), [](const typename Cache::Obs& a, const typename Cache::Obs& b) { return a.kf_vid < b.kf_vid; });
+        const auto Xm = mp->GetWorldPos();
+        std::memcpy(rc.pos, mat_f32(Xm), 12);
       }
+      rc.seen = C.call;
+      vRec.push_back(ri);
+      for (const auto& o : rc.obs) {
+        const size_t d = vid_hi - o.kf_vid;                  // (unsigned: a keyframe with a higher id, or of another client, wraps past the span)
+        if (d < kVidSpan) { if (kfSeen[d]) continue; kfSeen[d] = 1; }
+        note_camera(o.kf);
+      }
+    }
+  } else {
+    vLP.reserve(lLocalMapPoints.size());
+    for (MapPointT* mp : lLocalMapPoints) {
+      vLP.push_back(LocalPoint{mp, mp->GetObservations(), vertex_id(mp->mnId, mp->mnClientId, false)});
+      for (const auto& ob : vLP.back().obs) note_camera(ob.first);
     }
   }
   ORBGPU_GLUE_T("observations + fixed cameras");
@@ -633,41 +738,70 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   auto kf_index = [&](KeyFrameT* kf) -> int { const KfRec* r = kf_rec(kf); return r ? r->col : -1; };
   ORBGPU_GLUE_T("keyframe table");
   // the points in ascending vertex id: a permutation is sorted, not the records (each holds a std::map)
-  std::vector<std::pair<size_t, uint32_t>> order(vLP.size());
-  for (size_t j = 0; j < vLP.size(); j++) order[j] = {vLP[j].vid, (uint32_t)j};
-  std::sort(order.begin(), order.end());
+  const size_t n_pts = kCached ? vRec.size() : vLP.size();
+  std::vector<std::pair<size_t, uint32_t>> order(n_pts);
+  if constexpr (kCached) { for (size_t j = 0; j < n_pts; j++) order[j] = {Cache::instance().recs[vRec[j]].vid, (uint32_t)j}; }
+  else { for (size_t j = 0; j < n_pts; j++) order[j] = {vLP[j].vid, (uint32_t)j}; }
+  // (a window's points mostly come in ascending id already: nothing to do then)
+  if (!std::is_sorted(order.begin(), order.end())) std::sort(order.begin(), order.end());
   ORBGPU_GLUE_T("sort points");
-  std::vector<MapPointT*> vMP(vLP.size());
+  std::vector<MapPointT*> vMP(n_pts);
+  std::vector<int32_t> recOf(kCached ? n_pts : 0);           // (cached path) record of problem point j
   // (the flat arrays of a call live in the calling thread -- LocalMapping -- across calls: no allocation, no zero fill per keyframe)
   static thread_local std::vector<float> pts, oposes, opts; static thread_local std::vector<lba_edge> edges;
   static thread_local std::vector<uint8_t> eout, edep; static thread_local std::vector<double> echi;
-  std::vector<std::pair<KeyFrameT*, MapPointT*>> edgeOwner;
-  pts.clear(); edges.clear();
-  pts.reserve(3 * vLP.size()); edges.reserve(8 * vLP.size()); edgeOwner.reserve(8 * vLP.size());
-  struct ObsRef { size_t vid; KeyFrameT* kf; int li; int col; };
-  std::vector<ObsRef> obs;
-  for (size_t j = 0; j < vLP.size(); j++) {
-    const LocalPoint& lp = vLP[order[j].second];
-    MapPointT* mp = lp.mp;
-    vMP[j] = mp;
-    const auto Xm = mp->GetWorldPos();                     // a clone (S/MapPoint.cc:GetWorldPos): keep it alive while it is read
-    const float* X = mat_f32(Xm);
-    pts.insert(pts.end(), X, X + 3);
-    // the reference walks a std::map<KeyFrame*, ...> (address order); here: by vertex id, which only permutes sums (E-6)
-    obs.clear();
-    for (const auto& ob : lp.obs) {
-      KeyFrameT* kf = ob.first;
-      const KfRec* kr = kf_rec(kf);
-      if (!kr || !kr->usable) continue;                                                      // :2003
-      const int li = std::get<0>(ob.second);
-      if (li < 0) continue;                                                                  // :2007
-      obs.push_back(ObsRef{kr->vid, kf, li, kr->col});
+  static thread_local std::vector<std::pair<KeyFrameT*, MapPointT*>> edgeOwner;
+  pts.clear(); edges.clear(); edgeOwner.clear();
+  pts.reserve(3 * n_pts); edges.reserve(8 * n_pts); edgeOwner.reserve(8 * n_pts);
+  if constexpr (kCached) {
+    Cache& C = Cache::instance();
+    kfCol.assign(kVidSpan, -2);                              // -2: not looked up yet, -1: not in the problem / not usable (:2003)
+    for (size_t j = 0; j < n_pts; j++) {
+      const int32_t ri = vRec[order[j].second];
+      const typename Cache::Rec& rc = C.recs[ri];
+      vMP[j] = rc.mp; recOf[j] = ri;
+      pts.insert(pts.end(), rc.pos, rc.pos + 3);
+      for (const auto& o : rc.obs) {                         // already by keyframe vertex id
+        if (o.li < 0) continue;                                                              // :2007
+        const size_t d = vid_hi - o.kf_vid;
+        int32_t col;
+        if (d < kVidSpan && kfCol[d] != -2) col = kfCol[d];
+        else {
+          const KfRec* kr = kf_rec(o.kf);
+          col = kr && kr->usable ? kr->col : -1;                                             // :2003
+          if (d < kVidSpan) kfCol[d] = col;
+        }
+        if (col < 0) continue;
+        edges.push_back(lba_edge{col, (int32_t)j, o.u, o.v, o.ur /* < 0: monocular (:2007) */, o.w});
+        edgeOwner.push_back({o.kf, rc.mp});
+      }
     }
-    std::sort(obs.begin(), obs.end(), [](const ObsRef& a, const ObsRef& b) { return a.vid < b.vid; });
-    for (const ObsRef& o : obs) {
-      const auto& kp = o.kf->mvKeysUn[o.li];
-      edges.push_back(lba_edge{o.col, (int32_t)j, kp.pt.x, kp.pt.y, o.kf->mvuRight[o.li] /* < 0: monocular (:2007) */, o.kf->mvInvLevelSigma2[kp.octave]});
-      edgeOwner.push_back({o.kf, mp});
+  } else {
+    struct ObsRef { size_t vid; KeyFrameT* kf; int li; int col; };
+    std::vector<ObsRef> obs;
+    for (size_t j = 0; j < n_pts; j++) {
+      const LocalPoint& lp = vLP[order[j].second];
+      MapPointT* mp = lp.mp;
+      vMP[j] = mp;
+      const auto Xm = mp->GetWorldPos();                     // a clone (S/MapPoint.cc:GetWorldPos): keep it alive while it is read
+      const float* X = mat_f32(Xm);
+      pts.insert(pts.end(), X, X + 3);
+      // the reference walks a std::map<KeyFrame*, ...> (address order); here: by vertex id, which only permutes sums (E-6)
+      obs.clear();
+      for (const auto& ob : lp.obs) {
+        KeyFrameT* kf = ob.first;
+        const KfRec* kr = kf_rec(kf);
+        if (!kr || !kr->usable) continue;                                                    // :2003
+        const int li = std::get<0>(ob.second);
+        if (li < 0) continue;                                                                // :2007
+        obs.push_back(ObsRef{kr->vid, kf, li, kr->col});
+      }
+      std::sort(obs.begin(), obs.end(), [](const ObsRef& a, const ObsRef& b) { return a.vid < b.vid; });
+      for (const ObsRef& o : obs) {
+        const auto& kp = o.kf->mvKeysUn[o.li];
+        edges.push_back(lba_edge{o.col, (int32_t)j, kp.pt.x, kp.pt.y, o.kf->mvuRight[o.li] /* < 0: monocular (:2007) */, o.kf->mvInvLevelSigma2[kp.octave]});
+        edgeOwner.push_back({o.kf, mp});
+      }
     }
   }
   ORBGPU_GLUE_T("points + edges");
@@ -683,8 +817,9 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   ORBGPU_GLUE_T("solve (Ops::lba)");
   if (R.status != LBA_APPLIED) return R.status;                                              // :2127-2129 and :2257-2261: nothing is written
   std::vector<std::pair<KeyFrameT*, MapPointT*>> vToErase;                                   // :2207-2253
+  std::vector<uint8_t> obsErased(kCached ? n_pts : 0, 0);    // (cached path) points that lose an observation below: re-read next time
   for (size_t k = 0; k < edges.size(); k++)
-    if (!edgeOwner[k].second->isBad() && eout[k]) vToErase.push_back(edgeOwner[k]);
+    if (!edgeOwner[k].second->isBad() && eout[k]) { vToErase.push_back(edgeOwner[k]); if (kCached) obsErased[edges[k].point] = 1; }
   std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                                   // :2263
   for (auto& e : vToErase) { e.first->EraseMapPointMatch(e.second); e.second->EraseObservation(e.first); }   // :2279-2286
   for (KeyFrameT* kf : lLocalKeyFrames) {                                                    // :2318-2372 (SetPose)
@@ -698,8 +833,14 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
       Xd[0] = opts[3 * j]; Xd[1] = opts[3 * j + 1]; Xd[2] = opts[3 * j + 2];
       vMP[j]->SetWorldPos(X, true);                                                          // :2386
       vMP[j]->UpdateNormalAndDepth();
+      if constexpr (kCached) {                               // what this thread knows of the point is current again
+        typename Cache::Rec& rc = Cache::instance().recs[recOf[j]];
+        if (obsErased[j]) rc.valid = false;
+        else { rc.pos[0] = Xd[0]; rc.pos[1] = Xd[1]; rc.pos[2] = Xd[2]; rc.stamp = vMP[j]->mnChangeStamp; }
+      }
     }
   }
+  if constexpr (kCached) Cache::instance().drop_unseen(n_pts);
   pMap->IncreaseChangeIndex();                                                               // :2397 (Tracking reads it: mbMapUpdated)
   ORBGPU_GLUE_T("write-back");
   return R.status;

@@ -196,12 +196,34 @@ int main(int argc, char** argv) {
     auto reset_po = [&]() { Cur.mvpMapPoints = after_map; Cur.mTcw = Tguess; std::fill(Cur.mvbOutlier.begin(), Cur.mvbOutlier.end(), false); };
     rows.push_back(measure("PoseOptimization", reps, 5, reset_po, [&]() { return od::PoseOptimization<TimedOps>(&Cur); }));
     rows.back().work = n_corr;
-    // ---- LocalMapping: LocalBundleAdjustment on a 20 + 10 keyframe window of 2000 points (the window is rebuilt for every call:
-    // a solve erases observations and moves the map)
+    // ---- LocalMapping: LocalBundleAdjustment on 20 + 10 keyframe windows of 2000 points.  First row: consecutive windows of one map
+    // (each for a new keyframe that sees a third of the last one's points; windows 3-8 of 8 are timed) -- what LocalMapping does, and
+    // what the glue's window cache is for.  Second row: a fresh map per call (nothing to reuse: the cost of a first window).
     {
-      Row r; r.name = "LocalBundleAdjustment (20 free + 10 fixed KFs, 2000 points)";
-      const int nrep = std::max(reps / 4, 4);
+      Row r; r.name = "LocalBundleAdjustment (20 free + 10 fixed KFs, 2000 points; consecutive windows)";
+      const int nscene = std::max(reps / 16, 2);
+      for (int i = 0; i < nscene; i++) {
+        od::LbaWindowCache<KeyFrame, MapPoint>::instance().clear();      // (the last scene's points are gone)
+        Agent B;
+        KeyFrame* cur = build_lba_scene(B, 21, 10, 2000, 0.03, 99);
+        bool mbAbortBA = false; int num_fixed = 0;
+        for (int w = 0; w < 8; w++) {
+          TimedOps::t_call = TimedOps::t_upload = 0;
+          const double t0 = now_us();
+          od::LocalBundleAdjustment<TimedOps>(cur, &mbAbortBA, &B.map, num_fixed, 0);
+          const double dt = now_us() - t0;
+          if (w >= 2) { r.total += dt; r.call += TimedOps::t_call; r.reps++; int ne = 0; for (auto& kf : B.kfs) ne += (int)kf->mvKeysUn.size(); r.work = ne; }
+          cur = next_keyframe(B, cur, w);
+        }
+      }
+      r.total /= r.reps; r.call /= r.reps;
+      rows.push_back(r);
+    }
+    {
+      Row r; r.name = "LocalBundleAdjustment (first window of a map: every point read)";
+      const int nrep = std::max(reps / 8, 3);
       for (int i = 0; i < nrep + 2; i++) {
+        od::LbaWindowCache<KeyFrame, MapPoint>::instance().clear();
         Agent B;
         KeyFrame* cur = build_lba_scene(B, 21, 10, 2000, 0.03, 99);
         bool mbAbortBA = false; int num_fixed = 0;
@@ -213,6 +235,7 @@ int main(int argc, char** argv) {
       }
       r.total /= r.reps; r.call /= r.reps;
       rows.push_back(r);
+      od::LbaWindowCache<KeyFrame, MapPoint>::instance().clear();
     }
     // ---- report
     std::fprintf(stderr, "%-66s %10s %10s %10s %10s %7s\n", "call through the reference-side glue (C2 sizes)", "total us", "C-ABI us", "upload us", "glue us", "glue %");

@@ -26,6 +26,7 @@ namespace od = orbgpu::dropin;
 struct OracleOps {       // the same entry points over the CPU oracle: views instead of device handles
   static constexpr bool kUsesResidentFrame = false;
   static constexpr bool kExactLocalMap = true;      // the reference's semantics: every point's fields are read on every call (no cache)
+  static constexpr bool kNoLbaCache = true;         // ... and every local-BA window reads every point (no window cache)
   static int is_in_frustum(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim, uint8_t* in_view,
                            float* px, float* py, float* pxr, float* depth, int32_t* level, float* vcos) {
     return oracle_is_in_frustum(&v, Tcw, &pts, lim, in_view, px, py, pxr, depth, level, vcos);
@@ -248,6 +249,7 @@ struct BaOut { int status, num_fixed, erased, change_index, locked_poses, locked
 // that many microseconds after the call starts
 template <class Ops>
 static BaOut run_lba(int n_local, int n_far, int n_pts, double outlier_frac, bool stop, unsigned seed, double raise_after_us = -1.0) {
+  od::LbaWindowCache<KeyFrame, MapPoint>::instance().clear();       // (the points of the last scene are gone: MapPoints never are, in the reference)
   Agent A; BaOut o;
   KeyFrame* cur = build_lba_scene(A, n_local, n_far, n_pts, outlier_frac, seed);
   bool mbAbortBA = stop;                                            // I/LocalMapping.h:155
@@ -345,6 +347,36 @@ int main() {
         EXPECT(bg.change_index == 0 && bg.locked_poses == 0 && bg.locked_points == 0, "a rejected / aborted LBA must not bump the change index");
       }
       EXPECT(bg.change_index == bc.change_index && bg.locked_poses == bc.locked_poses && bg.locked_points == bc.locked_points, "write-back calls differ");
+    }
+    // ---- five consecutive windows of one map (a new keyframe each, points moved / observations erased by the solves in between): the
+    // product through the glue's window cache, the oracle reading every point of every window
+    {
+      auto windows = [](auto ops_tag) {
+        using Ops = decltype(ops_tag);
+        od::LbaWindowCache<KeyFrame, MapPoint>::instance().clear();
+        Agent A; BaOut o{};
+        KeyFrame* cur = build_lba_scene(A, 10, 5, 700, 0.03, 77);
+        bool mbAbortBA = false;
+        for (int w = 0; w < 5; w++) {
+          o.status = od::LocalBundleAdjustment<Ops>(cur, &mbAbortBA, &A.map, o.num_fixed, 0);
+          cur = next_keyframe(A, cur, w);
+        }
+        o.change_index = A.map.GetMapChangeIndex(); o.erased = 0;
+        long copies = 0;
+        for (auto& kf : A.kfs) { o.poses.insert(o.poses.end(), kf->Tcw.ptr<float>(0), kf->Tcw.ptr<float>(0) + 16); for (auto* p : kf->mvpMapPoints) o.erased += p == nullptr; }
+        for (auto& p : A.points) { o.points.insert(o.points.end(), p->mWorldPos.ptr<float>(0), p->mWorldPos.ptr<float>(0) + 3); o.normal_updates.push_back(p->n_normal_updates); copies += p->n_obs_copies; }
+        o.locked_points = (int)copies;
+        od::LbaWindowCache<KeyFrame, MapPoint>::instance().clear();
+        return o;
+      };
+      const BaOut wg = windows(od::GpuOps{}), wc = windows(OracleOps{});
+      std::printf("LocalBundleAdjustment, five consecutive windows: %d observations erased, change index %d, GetObservations copies %d (window cache) vs %d\n",
+                  wg.erased, wg.change_index, wg.locked_points, wc.locked_points);
+      EXPECT(wg.status == wc.status && wg.erased == wc.erased && wg.change_index == wc.change_index && wg.change_index == 5, "windows: status %d vs %d, erased %d vs %d",
+             wg.status, wc.status, wg.erased, wc.erased);
+      EXPECT(max_abs_diff(wg.poses, wc.poses) <= 1e-4f && max_abs_diff(wg.points, wc.points) <= 1e-4f && wg.normal_updates == wc.normal_updates,
+             "windows: poses %g points %g", max_abs_diff(wg.poses, wc.poses), max_abs_diff(wg.points, wc.points));
+      EXPECT(2 * wg.locked_points < wc.locked_points, "the window cache re-read %d points where the uncached glue read %d", wg.locked_points, wc.locked_points);
     }
     // ---- InterruptBA() DURING the solve: Tracking sets LocalMapping::mbAbortBA -- the very bool behind pbStopFlag -- from a
     // second thread at an arbitrary moment.  Wherever the product saw it (it reports how many LM trials it had evaluated),

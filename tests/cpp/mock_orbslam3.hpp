@@ -44,13 +44,18 @@ class MapPoint {
   bool isBad() const { return mbBad; }
   Map* GetMap() const { return mpMap; }
   int Observations() const { return nObs; }
-  Mat GetWorldPos() const { return mWorldPos; }
+  Mat GetWorldPos() const { n_pos_clones++; return mWorldPos; }
   Mat GetNormal() const { return mNormalVector; }
   Mat GetDescriptor() const { return mDescriptor; }
   int n_locked_pos_writes = 0;
-  void SetWorldPos(const Mat& X, bool bLock = false, bool /*bLockSend*/ = false) { mWorldPos = X; n_locked_pos_writes += bLock; }   // I/MapPoint.h:126
-  std::map<KeyFrame*, std::tuple<int, int>> GetObservations() const { return mObservations; }
-  void EraseObservation(KeyFrame* kf) { if (mObservations.erase(kf)) nObs--; }
+  // the change counter the glue's local-BA window cache looks for (one member, ++ in the four mutators)
+  long unsigned mnChangeStamp = 0;
+  mutable int n_obs_copies = 0, n_pos_clones = 0;
+  void SetWorldPos(const Mat& X, bool bLock = false, bool /*bLockSend*/ = false) { mWorldPos = X; n_locked_pos_writes += bLock; mnChangeStamp++; }   // I/MapPoint.h:126
+  std::map<KeyFrame*, std::tuple<int, int>> GetObservations() const { n_obs_copies++; return mObservations; }
+  void AddObservation(KeyFrame* kf, int idx) { if (!mObservations.count(kf)) nObs++; mObservations[kf] = std::make_tuple(idx, -1); mnChangeStamp++; }
+  void EraseObservation(KeyFrame* kf) { if (mObservations.erase(kf)) nObs--; mnChangeStamp++; }
+  void SetBadFlag() { mbBad = true; mObservations.clear(); nObs = 0; mnChangeStamp++; }
   void UpdateNormalAndDepth() { n_normal_updates++; }
 };
 

@@ -195,3 +195,25 @@ static KeyFrame* build_lba_scene(Agent& A, int n_local, int n_far, int n_pts, do
   return cur;
 }
 
+// The keyframe after `cur` as LocalMapping would insert it: covisible with `cur` and all but the oldest of its neighbours, observing
+// a third of cur's points (MapPoint::AddObservation: the points' change counters move, as in the reference with INTEGRATION.md's hook).
+static inline KeyFrame* next_keyframe(Agent& B, KeyFrame* cur, int round) {
+  std::unique_ptr<KeyFrame> kf(new KeyFrame(*cur));
+  kf->mnId = cur->mnId + 1; kf->mnBALocalForKF = ~0ul; kf->mnBAFixedForKF = ~0ul;
+  kf->mvKeysUn.clear(); kf->mvuRight.clear(); kf->mvpMapPoints.clear();
+  kf->mvpOrderedConnectedKeyFrames.clear();
+  for (size_t q = 1; q < cur->mvpOrderedConnectedKeyFrames.size(); q++) kf->mvpOrderedConnectedKeyFrames.push_back(cur->mvpOrderedConnectedKeyFrames[q]);
+  kf->mvpOrderedConnectedKeyFrames.push_back(cur);
+  for (size_t li0 = 0; li0 < cur->mvpMapPoints.size(); li0++) {
+    MapPoint* mp = cur->mvpMapPoints[li0];
+    if (!mp || mp->isBad() || (mp->mnId + round) % 3 != 0) continue;
+    const int li = (int)kf->mvKeysUn.size();
+    kf->mvKeysUn.push_back(cur->mvKeysUn[li0]); kf->mvuRight.push_back(cur->mvuRight[li0]); kf->mvpMapPoints.push_back(mp);
+    mp->AddObservation(kf.get(), li);
+  }
+  KeyFrame* out = kf.get();
+  B.kfs.push_back(std::move(kf));
+  return out;
+}
+
+

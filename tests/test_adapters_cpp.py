@@ -41,6 +41,26 @@ def test_host_side_compiles_links_and_fails_loudly_without_gpu(name, with_oracle
     assert r.returncode == 3 and "no usable HIP device" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+def test_lba_window_cache_flattens_the_same_problems_as_the_uncached_glue():
+    """tests/cpp/glue_cache_check (host only: the entry-point set records the flattened problem and returns a synthetic solve): six
+    consecutive local-BA windows of one map with observations added and erased, points moved and made bad and a new keyframe between
+    them -- the glue with its window cache (MapPoint::mnChangeStamp, INTEGRATION.md) and the glue reading every point produce
+    byte-identical problems, and the cached run copies a third of the observation maps."""
+    exe = _build("glue_cache_check")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL OK" in r.stdout and r.stdout.count("identical") == 6, (r.stdout, r.stderr)
+
+
+def test_lba_glue_alone_is_timed_on_the_host():
+    """tests/cpp/glue_cpu_bench: the LocalBundleAdjustment glue over the mocks with an entry-point set that returns at once."""
+    import json
+    exe = _build("glue_cpu_bench")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert 0 < d["lba_glue_cached_us"] < 0.7 * d["lba_glue_uncached_us"], d
+
+
 @pytest.mark.gpu
 def test_opencv_signature_branches_run_on_gpu():
     """ORBextractor::operator()(cv::InputArray, cv::InputArray, vector<cv::KeyPoint>&, cv::OutputArray, vector<int>&) -- the reference's exact
@@ -79,7 +99,11 @@ def test_dropin_bench_times_the_path_through_the_glue():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     rows = d["dropin_bench"]
-    assert len(rows) == 7 and d["frames_per_s_frame_path"] > 0 and d["local_map_points"] > 2000
+    assert len(rows) == 8 and d["frames_per_s_frame_path"] > 0 and d["local_map_points"] > 2000
+    # the local BA's window cache: consecutive windows of one map cost the glue less than half of a first window
+    lba_next = [r for n, r in rows.items() if "consecutive windows" in n][0]
+    lba_first = [r for n, r in rows.items() if "first window of a map" in n][0]
+    assert lba_next["glue_us"] < 0.5 * lba_first["glue_us"], (lba_next, lba_first)
     # the glue's cache of the flattened local map: on a frame whose local map is the previous frame's nothing is cloned or uploaded
     cached = [r for n, r in rows.items() if "unchanged since the last frame" in n][0]
     fresh = [r for n, r in rows.items() if "after a keyframe" in n][0]
