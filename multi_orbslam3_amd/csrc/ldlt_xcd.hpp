@@ -43,7 +43,7 @@ constexpr int kMaxNS = 8;                   // tile slots per wavefront in the p
 constexpr int kMaxT = ldltm::kMaxT;
 constexpr int kNY = 5;                      // 64-lane groups of the solution vector (n_pad <= 320)
 // flag words
-constexpr int kFDiag = 0, kFPanel = 32, kFWave = kFPanel + kMaxT * kMaxT, kFElect = kFWave + 64, kFBad = kFElect + 8;
+constexpr int kFDiag = 0, kFPanel = 32, kFWave = kFPanel + kMaxT * kMaxT, kFElect = kFWave + 128, kFBad = kFElect + 16;
 constexpr int kFlagStride = 640;             // one copy of the flags per participant (its wavefronts poll that copy only)
 constexpr int kFlagWords = kFlagStride * kMaxP;
 // scratch (doubles)
@@ -111,7 +111,7 @@ __host__ inline bool plan_fits(int n, int np, int ns) {
 __host__ inline int plan_max_slots(const Plan& P) { int m = 0; for (int w = 0; w < kMaxW; w++) for (int s = 0; s < kMaxNS; s++) if (P.tile[w][s] >= 0 && s + 1 > m) m = s + 1; return m; }
 
 #ifdef LDLTX_PROFILE
-__device__ long long g_xprof[512];
+__device__ long long g_xprof[1024];
 #define LDLTX_T(i) do { if (lane == 0) g_xprof[(i)] = wall_clock64(); } while (0)
 #else
 #define LDLTX_T(i) do { } while (0)
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   __syncthreads();
   const int gw = rank * kWgWaves + wv;
 #ifdef LDLTX_PROFILE
-  if (tid == 0) { atomicAdd((unsigned long long*)&g_xprof[1], 1ull); g_xprof[4 + rank] = t_enter; }
+  if (tid == 0) { atomicAdd((unsigned long long*)&g_xprof[1], 1ull); g_xprof[560 + rank] = t_enter; }
 #endif
   const Geo G = make_geo(n);
   const int T = G.T, n_pad = G.n_pad, cb = G.cb;
@@ -281,6 +281,8 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   // which the chain wavefronts of those columns publish at about the same time; for k = j - 1 the pivots of (j, j) follow at
   // once.  One hand-over per tile row on the critical path.
   const bool chain_wave = plan.chain[gw] != 0;
+  // (a chain wavefront shares its SIMD with one that updates up to four tiles, 16 matrix instructions back to back: it goes first)
+  if (chain_wave) __builtin_amdgcn_s_setprio(3);
   bool on[kNS], isdiag[kNS];
   const unsigned* fpa[kNS]; const unsigned* fpb[kNS];
   unsigned offa[kNS], offw[kNS];
@@ -478,12 +480,12 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   // x_J.  The dependent chain is one readlane + one FMA per column and moves from wavefront to wavefront at block boundaries.
   publish(kFWave + gw, false);
 #ifdef LDLTX_PROFILE
-  LDLTX_T(256 + gw);
+  LDLTX_T(600 + gw);
 #endif
   if (rank != 0 || wv >= kNY || 64 * wv >= n_pad) return;
   for (;;) {
-    const unsigned f = lane < kW ? ld_flag(&flags[kFWave + lane]) : epoch;
-    if (__builtin_amdgcn_ballot_w64(f != epoch) == 0 || bail_) break;
+    const unsigned f = lane < kW ? ld_flag(&flags[kFWave + lane]) : epoch, f2 = lane + 64 < kW ? ld_flag(&flags[kFWave + 64 + lane]) : epoch;
+    if (__builtin_amdgcn_ballot_w64(f != epoch || f2 != epoch) == 0 || bail_) break;
     __builtin_amdgcn_s_sleep(1);
     LDLTX_DOG(4, 0, 0);
   }

@@ -166,7 +166,7 @@ int main(int argc, char** argv) {
 #endif
     printf("n=%3d T=%2d ok=%d max|dx|=%.3e (max|x|=%.3e) %s   %.2f us/launch\n", n, g.T, ok, err, mx, good ? "ok" : "FAIL", 1000.0 * ms / reps);
     fails += !good;
-    for (int np = 8; np <= 8 && ldltx::supports(n); np += 4) {   // the same system on four / eight compute units of one XCD
+    for (int np = ldltx::kMaxP; np <= ldltx::kMaxP && ldltx::supports(n); np += 4) {   // the same system on four / eight compute units of one XCD
       static ldltx::Context cx;
       if (!ldltx::plan_fits(n, np, 4)) continue;
       CK(hipMemset(dx, 0, n * 8)); CK(hipMemset(dok, 0xFF, 4));
@@ -214,14 +214,14 @@ int main(int argc, char** argv) {
       }
 #ifdef LDLTX_PROFILE
       {
-        long long z[512] = {0}, pr[512];
+        long long z[1024] = {0}, pr[1024];
         for (int q = 430; q < 460; q++) z[q] = 0x7fffffffffffffffll;
         CK(hipMemcpyToSymbol(HIP_SYMBOL(ldltx::g_xprof), z, sizeof(z)));
         CK(ldltx::launch(cx, n, dS, dx, dok, 0, np));
         CK(hipDeviceSynchronize());
         CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(ldltx::g_xprof), sizeof(pr)));
-        long long t0 = pr[4];
-        for (int q = 1; q < np; q++) t0 = std::min(t0, pr[4 + q]);
+        long long t0 = pr[560];
+        for (int q = 1; q < np; q++) t0 = std::min(t0, pr[560 + q]);
         auto us = [&](long long t) { return (t - t0) * 0.01; };
         printf("   xcd prof: participants %lld safe %lld; placed %.2f; all waves done %.2f; end %.2f us\n", pr[1], pr[12], us(pr[0]), us(pr[2]), us(pr[3]));
         printf("   back-substitution (start, own block from, to):");
@@ -230,7 +230,7 @@ int main(int argc, char** argv) {
         for (int w = 0; w < 5; w++) printf(" %lld", pr[330 + w]);
         printf("\n");
         printf("   wave done:");
-        for (int w = 0; w < 8 * np; w++) printf(" %.1f", us(pr[256 + w]));
+        for (int w = 0; w < 8 * np; w++) printf(" %.1f", us(pr[600 + w]));
         printf("\n");
         for (int k = 0; k < g.Tp; k++)
           if (np == 8) printf("    row %2d: pivots start %.2f done %.2f published %.2f | chain panel: seen %.2f G loaded %.2f, computed %.2f published %.2f done %.2f\n", k, us(pr[16 + 8 * k + 0]), us(pr[16 + 8 * k + 1]), us(pr[16 + 8 * k + 2]), us(pr[16 + 8 * k + 6]), us(pr[16 + 8 * k + 3]), us(pr[16 + 8 * k + 4]), us(pr[16 + 8 * k + 5]), us(pr[16 + 8 * k + 7]));
