@@ -1151,9 +1151,9 @@ def main():
         lm_per_ba = stats["lba_iters"] / max(stats["lba_calls"], 1)
         # the variant ldltm::pick() chooses for this many unknowns (tile rows T of the bordered matrix)
         ldlt_T = ((((n_unk + 3) & ~3) + 1) + 15) // 16
-        xcd_on = os.environ.get("ORBG_LDLT_XCD", "1") != "0"          # (lba.hip: the eight-workgroup kernel from 16 tile rows on)
-        ldlt_name = (("ldltm::k_ldlt_cols" if ldlt_T <= 8 else "ldltm::k_ldlt_mfma" if ldlt_T <= 9 else
-                      "ldltm::k_ldlt_big" if ldlt_T <= 15 else "ldltx::k_ldlt_xcd" if xcd_on and ldlt_T <= 19 else "ldltm::k_ldlt_big48")
+        xcd_on = os.environ.get("ORBG_LDLT_XCD", "1") != "0"          # (lba.hip: the eight-workgroup kernel from 9 tile rows on)
+        ldlt_name = (("ldltm::k_ldlt_cols" if ldlt_T <= 8 else "ldltx::k_ldlt_xcd" if xcd_on and ldlt_T <= 19 else "ldltm::k_ldlt_mfma" if ldlt_T <= 9 else
+                      "ldltm::k_ldlt_big" if ldlt_T <= 15 else "ldltm::k_ldlt_big48")
                      if solver_mfma else "k_wide_panel / k_wide_update")
         per_step = {ldlt_name: ldlt_ms * lm_per_ba / FRAMES_PER_KF if solver_n else 0.0, "fast_cells_kernel": fast_ms if fast_n else 0.0}
         for kname, (kms, kn) in chain_ms.items():

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-c
 mkdir -p "$HERE/obj"
 pids=()
 for f in extractor matcher lba pose_opt bow; do
-  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/wave.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/stereo_finalize.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/ldlt_mfma.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/se3.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/grid_build.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/ldlt_jump_tables.inc" -nt "$HERE/obj/$f.o" ] || [ "$HERE/orb_pattern_data.inc" -nt "$HERE/obj/$f.o" ] || [ "$HERE/build.sh" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/orbgpu.h" -nt "$HERE/obj/$f.o" ]; then
+  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/wave.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/stereo_finalize.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/ldlt_mfma.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/ldlt_xcd.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/se3.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/grid_build.hpp" -nt "$HERE/obj/$f.o" ] || [ "$HERE/ldlt_jump_tables.inc" -nt "$HERE/obj/$f.o" ] || [ "$HERE/orb_pattern_data.inc" -nt "$HERE/obj/$f.o" ] || [ "$HERE/build.sh" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/orbgpu.h" -nt "$HERE/obj/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi

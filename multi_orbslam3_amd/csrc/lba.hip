@@ -16,7 +16,7 @@
 //                   also produce b_s,i = bp_i - sum_l Hpl_il Dinv_l bl_l
 //   ldlt_mfma.hpp   one workgroup: dense LDL^T + solve of the reduced camera system on the FP64 matrix cores
 //                   (v_mfma_f64_16x16x4_f64; 16x16 tiles in registers, dataflow between wavefronts) up to 50 free poses;
-//   ldlt_xcd.hpp    the same on eight workgroups of one XCD (hand-overs through that XCD's L2) from 16 tile rows on (40+ free poses);
+//   ldlt_xcd.hpp    the same on eight workgroups of one XCD (hand-overs through that XCD's L2) from 9 tile rows on (21+ free poses);
 //                   k_wide_panel / k_wide_update / k_wide_back: the blocked many-workgroup LDL^T of larger windows
 //   k_update        thread/vertex: x_l = Dinv_l (bl_l - sum_i Hpl_il^T x_i); trial state = exp(x_p) * T  /  X + x_l
 //   k_finish        one workgroup: robust chi2, computeScale, max-diagonal -> pinned host record
@@ -1303,16 +1303,16 @@ struct StopRef {
 // ORBG_LDLT_WIDE=1 sends every window to the many-workgroup blocked LDL^T (k_wide_*: the solver of windows beyond 50 free poses) so
 // that tests can run it on small problems.  Round 5 removed the measured-slower variants of rounds 1-4 (vector-ALU LDL^T kernels,
 // the fused solve + update launch, the A/B forms of the start of a solve): docs/experiments.md keeps their numbers.
-// ORBG_LDLT_XCD=0 keeps windows of 40 .. 50 free poses on the one-workgroup kernel instead of the eight-workgroup one
+// ORBG_LDLT_XCD=0 keeps windows of 21 .. 50 free poses on the one-workgroup kernels instead of the eight-workgroup one
 // (ldlt_xcd.hpp); =safe forces that kernel's agent-scope hand-overs (the path it takes by itself when its workgroups do not
-// share an XCD); =all uses it from 14 tile rows on (tests).
+// share an XCD).
 struct LbaSwitches {
   bool ldlt_wide = false;
-  int ldlt_xcd = 1;                    // 0 off, 1 where it pays, 2 forced safe hand-overs, 3 wherever it can run
+  int ldlt_xcd = 1;                    // 0 off, 1 on (9 .. 19 tile rows), 2 on with forced safe hand-overs
   static LbaSwitches from_env() {
     LbaSwitches w;
     w.ldlt_wide = getenv("ORBG_LDLT_WIDE") != nullptr;
-    if (const char* e = getenv("ORBG_LDLT_XCD")) w.ldlt_xcd = !strcmp(e, "0") ? 0 : !strcmp(e, "safe") ? 2 : !strcmp(e, "all") ? 3 : 1;
+    if (const char* e = getenv("ORBG_LDLT_XCD")) w.ldlt_xcd = !strcmp(e, "0") ? 0 : !strcmp(e, "safe") ? 2 : 1;
     return w;
   }
 };
@@ -1720,8 +1720,8 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   if (use_mfma) {
     if ((rc = h->d_St.reserve(ldltm::tile_image_doubles(n))) || (rc = h->d_wfac.reserve(ldltm::wglob_doubles(ldltm::make_geo(n))))) return rc;
   }
-  // 40 .. 50 free poses: the same tile image, factored by eight workgroups of one XCD (ldlt_xcd.hpp)
-  const bool use_xcd = use_mfma && sw.ldlt_xcd != 0 && (sw.ldlt_xcd == 3 ? ldltx::supports(n) : ldltx::pays(n));
+  // 21 .. 50 free poses: the same tile image, factored by eight workgroups of one XCD (ldlt_xcd.hpp)
+  const bool use_xcd = use_mfma && sw.ldlt_xcd != 0 && ldltx::pays(n);
   if (use_xcd && !h->ldlt_x.scr) {
     if ((rc = h->d_xscr.reserve(ldltx::scratch_doubles())) || (rc = h->d_xflags.reserve(ldltx::kFlagWords))) return rc;
     ORBG_HIP(hipMemsetAsync(h->d_xflags.p, 0, ldltx::kFlagWords * sizeof(unsigned), st));

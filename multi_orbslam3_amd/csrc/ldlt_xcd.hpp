@@ -56,10 +56,12 @@ __host__ inline size_t scratch_doubles() { return kWOff + ldltm::wglob_doubles(m
 struct Plan { short tile[kMaxW][kMaxNS]; signed char chain[kMaxW]; int np, ns, force_safe; };       // tile index j(j+1)/2 + i per wavefront slot (-1: none), in processing order
 
 __host__ inline bool plan_fits(int n, int np, int ns);
-// the systems this kernel can take (tools/micro/ldlt_mfma_test: it is ahead of ldltm::k_ldlt_big48 from 16 tile rows on -- 72 / 85 /
-// 92 us against 81 / 99 / 111 us at 16 / 18 / 19 rows -- level at 15, behind below)
-__host__ inline bool supports(int n) { const Geo g = make_geo(n); return n >= 1 && g.T >= 14 && g.T <= kMaxT - 1 && g.n_pad <= 64 * kNY && plan_fits(n, kMaxP, 4); }
-__host__ inline bool pays(int n) { return supports(n) && make_geo(n).T >= 16; }
+// The systems this kernel takes: 9 .. 19 tile rows (21 .. 50 free poses).  Inside a local BA it is ahead of the one-workgroup kernels
+// at every such size (tools/lba_sizes.py, same box: the whole solve 0.688 vs 0.703 ms at 21 free poses, 0.842 vs 0.913 at 29, 0.998
+// vs 1.112 at 36, 1.10 vs 1.26 at 40, 1.36 vs 1.68 at 50); alone (tools/micro/ldlt_mfma_test) only from 16 tile rows on (72 / 85 /
+// 92 us against 81 / 99 / 111 us at 16 / 18 / 19 rows; level at 15).  8 tile rows (the C2 window) stay on ldltm::k_ldlt_cols: 19.6 us.
+__host__ inline bool supports(int n) { const Geo g = make_geo(n); return n >= 1 && g.T >= 9 && g.T <= kMaxT - 1 && g.n_pad <= 64 * kNY && plan_fits(n, kMaxP, 4); }
+__host__ inline bool pays(int n) { return supports(n); }
 
 // Tiles to wavefronts.  Column j's last kChain tiles go to one "chain" wavefront (consecutive columns on different compute units)
 // that holds nothing else; the other tiles, column by column, to whichever other wavefront holds the fewest, ordered by (row, column).

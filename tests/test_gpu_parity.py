@@ -786,15 +786,15 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
     """Free-pose counts around every kernel boundary of the reduced-camera-system solve: the matrix-core column kernel
     (<= 20 poses, 1..8 tile columns), the four-wavefront tile kernel (9 tile rows: 21..23 poses), the 512-thread kernels with their
     tile store in the accumulation / high vector registers in their four instantiations (10 / 11..13 / 14..15 / 16..19 tile rows:
-    <= 26 / 34 / 39 / 50 poses), the eight-workgroup kernel of one XCD (ldlt_xcd.hpp: default from 16 tile rows = 40 free poses on;
-    run here from 14 rows on, with its same-L2 hand-overs and with the agent-scope ones it falls back to, and switched off), and the
+    <= 26 / 34 / 39 / 50 poses), the eight-workgroup kernel of one XCD (ldlt_xcd.hpp: the default from 9 tile rows = 21 free poses on;
+    run here with its same-L2 hand-overs, with the agent-scope ones it falls back to, and switched off for the one-workgroup kernels), and the
     many-workgroup blocked kernels of windows with more than 50 free poses (forced here on every size by ORBG_LDLT_WIDE)."""
     prob = synth.make_lba_problem(n_free=nf, n_fixed=3, n_points=40 * nf + 60, mono_frac=0.2, seed=100 + nf)
     p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
     o = ob.lba_solve(p)
     variants = [{}, {"ORBG_LDLT_WIDE": "1"}]
-    if nf >= 36:
-        variants += [{"ORBG_LDLT_XCD": "all"}, {"ORBG_LDLT_XCD": "safe"}, {"ORBG_LDLT_XCD": "0"}]
+    if nf >= 21:
+        variants += [{"ORBG_LDLT_XCD": "safe"}, {"ORBG_LDLT_XCD": "0"}]
     for env in variants:
         for key in ("ORBG_LDLT_WIDE", "ORBG_LDLT_XCD"):
             monkeypatch.delenv(key, raising=False)
