@@ -35,6 +35,9 @@ ORBG_BENCH_SHARE_GPU=1 python3 bench.py --config C5 --gpus 2 --steps 200 --warmu
 python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-secondary --no-dropin --server-tick 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_line_server_tick.json" || true
 tests/cpp/dropin_bench 40 > "$OUT/dropin_bench.json" 2> "$OUT/dropin_bench.txt" || true
 tools/micro/fp64_latency > "$OUT/micro_fp64_issue.txt" 2>&1 || true
+[ -x tools/micro/ldlt_mfma_test_prof ] && timeout 120 tools/micro/ldlt_mfma_test_prof > "$OUT/ldlt_xcd_timeline.txt" 2>&1 || true
+[ -x tools/micro/readlane_chain ] && timeout 60 tools/micro/readlane_chain > "$OUT/micro_readlane_chain.txt" 2>&1 || true
+for v in 0 1; do ORBG_LDLT_XCD=$v python3 tools/lba_sizes.py 30; done > "$OUT/lba_sizes_xcd_off_on.txt" 2>&1 || true
 python3 tools/search_large_map.py 1 8 32 128 > "$OUT/search_large_map.txt" 2>&1 || true
 python3 tools/po_time.py > "$OUT/pose_opt_time.txt" 2>&1 || true
 python3 tools/micro/po_prof.py > "$OUT/pose_opt_phases.txt" 2>&1 || true
