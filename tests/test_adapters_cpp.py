@@ -51,6 +51,17 @@ def test_lba_window_cache_flattens_the_same_problems_as_the_uncached_glue():
     assert r.returncode == 0 and "ALL OK" in r.stdout and r.stdout.count("identical") == 6, (r.stdout, r.stderr)
 
 
+def test_ldlt_xcd_plan_and_schedule_for_every_size():
+    """tests/cpp/ldlt_xcd_plan_check.hip (host only, built with hipcc): for all 176 system sizes the eight-workgroup LDL^T takes, every
+    tile has exactly one wavefront slot, chain wavefronts hold the last four tiles of a column, and the kernel's row-by-row schedule
+    -- replayed as WAIT / PUBLISH programs over the same flags -- runs to the end (no wait cycle), publishing every G and every panel
+    tile exactly once."""
+    exe = os.path.join(CPP, "ldlt_xcd_plan_check")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-o", exe, os.path.join(CPP, "ldlt_xcd_plan_check.hip")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "176 system sizes checked: ALL OK" in r.stdout, (r.stdout[-2000:], r.stderr[-500:])
+
+
 def test_lba_glue_alone_is_timed_on_the_host():
     """tests/cpp/glue_cpu_bench: the LocalBundleAdjustment glue over the mocks with an entry-point set that returns at once."""
     import json
