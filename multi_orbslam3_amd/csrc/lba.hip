@@ -27,6 +27,7 @@
 
 #include <condition_variable>
 #include <atomic>
+#include <unistd.h>
 #include <mutex>
 #include <thread>
 
@@ -1726,6 +1727,8 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
     if ((rc = h->d_xscr.reserve(ldltx::scratch_doubles())) || (rc = h->d_xflags.reserve(ldltx::kFlagWords))) return rc;
     ORBG_HIP(hipMemsetAsync(h->d_xflags.p, 0, ldltx::kFlagWords * sizeof(unsigned), st));
     h->ldlt_x.bind(h->d_xscr.p, h->d_xflags.p);
+    static std::atomic<int> n_users{0};              // users of one process on different XCDs; processes sharing a GPU differ by pid
+    h->ldlt_x.pick = ((int)getpid() + n_users.fetch_add(1)) & 7;
   }
   int cur = 0;   // index of the buffer holding the current estimate
   // k_update's workgroup size: the kernel is a chain of dependent memory round trips per landmark; small workgroups spread the same

@@ -8,8 +8,10 @@
 //     XCD's L2): 0.45 us from the flag store to the reader seeing it, 0.16 .. 0.6 us per load round trip (quiet .. 64 wavefronts
 //     polling); tools/micro/xcd_handover measured 0.59 us per 2 KB hand-over against 0.93 / 1.25 us for an agent-scope release /
 //     acquire pair inside / across XCDs.  Coherent ONLY because all participants share one L2 -- so:
-// Placement: a grid of 57 blocks; blocks 0, 8, .., 56 take part (the dispatcher deals a grid's workgroups round-robin over the 8
-// XCDs), the others leave at once.  Every participant posts HW_REG_XCC_ID; if the ids differ (another partition mode, a changed
+// Placement: a grid of up to 64 blocks; blocks x, x + 8, .., x + 56 take part (the dispatcher deals a grid's workgroups round-robin
+// over the 8 XCDs), the others leave at once.  x differs from user to user (process id + handle number): the participants spin
+// until all eight are resident, so solves that run at the same time must not crowd one XCD's 32 compute units -- with the
+// users spread over the XCDs that takes more than 32 concurrent solves of 21+ free poses on one GPU (one agent per GPU has one).  Every participant posts HW_REG_XCC_ID; if the ids differ (another partition mode, a changed
 // dispatcher) every hand-over becomes an agent-scope release / acquire pair: slower (147 us), correct, tested (ORBG_LDLT_XCD=safe).
 // Flags carry the launch's number (epoch): nothing is cleared between launches.
 // Schedule: column j's last four tiles (j-3, j) .. (j, j) sit on one "chain" wavefront, which per row k = j-3 .. j-1 spins on
@@ -53,7 +55,7 @@ constexpr size_t kDvOff = kGbOff + kGbDoubles, kDvDoubles = (size_t)kMaxT * 16;
 constexpr size_t kWOff = kDvOff + kDvDoubles;
 __host__ inline size_t scratch_doubles() { return kWOff + ldltm::wglob_doubles(make_geo(16 * kMaxT - 20)) + 1024; }
 
-struct Plan { short tile[kMaxW][kMaxNS]; signed char chain[kMaxW]; int np, ns, force_safe; };       // tile index j(j+1)/2 + i per wavefront slot (-1: none), in processing order
+struct Plan { short tile[kMaxW][kMaxNS]; signed char chain[kMaxW]; int np, ns, force_safe, pick; };       // tile index j(j+1)/2 + i per wavefront slot (-1: none), in processing order
 
 __host__ inline bool plan_fits(int n, int np, int ns);
 // The systems this kernel takes: 9 .. 19 tile rows (21 .. 50 free poses).  Inside a local BA it is ahead of the one-workgroup kernels
@@ -69,7 +71,7 @@ __host__ inline Plan make_plan(int n, int np, int ns) {
   const Geo g = make_geo(n);
   const int W = np * kWgWaves;
   Plan P;
-  P.np = np; P.ns = ns; P.force_safe = 0;
+  P.np = np; P.ns = ns; P.force_safe = 0; P.pick = 0;
   int cnt[kMaxW];
   bool chain[kMaxW];
   for (int w = 0; w < kMaxW; w++) { cnt[w] = 0; chain[w] = false; for (int s = 0; s < kMaxNS; s++) P.tile[w][s] = -1; }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   // ---- which workgroups take part: block 8 r is participant r (the dispatcher deals a grid's workgroups round-robin over the 8
   // XCDs, so these share one); the others leave at once.  Every participant posts its XCC id; if they differ after all (another
   // partition mode, a changed dispatcher) `safe` turns the hand-overs into agent-scope release / acquire pairs -- slower, correct.
-  if ((blockIdx.x & 7u) != 0) return;
+  if ((blockIdx.x & 7u) != (unsigned)plan.pick) return;
   const int rank = blockIdx.x >> 3;
   const unsigned my_xcc = xcc_id() & 0xFFu, ep = epoch & 0xFFFFFFu;
   if (tid == 0) {
@@ -583,6 +585,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
 // (bind) or the context's own (ensure: the micro-benchmark).
 struct Context {
   double* scr = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int plan_n = -1; Plan plan; bool owned = false;
+  int pick = 0;                             // which XCD's blocks take part (0 .. 7)
   void bind(double* scratch /* scratch_doubles() */, unsigned* zeroed_flags /* kFlagWords */) { scr = scratch; flags = zeroed_flags; owned = false; epoch = 0; }
   hipError_t ensure() {
     if (scr) return hipSuccess;
@@ -602,12 +605,13 @@ __host__ inline hipError_t launch(Context& c, int n, const double* St, double* x
   if (np != kMaxP || !plan_fits(n, np, ns)) return hipErrorInvalidValue;
   if (c.plan_n != n) { c.plan = make_plan(n, np, ns); c.plan_n = n; }
   c.plan.force_safe = force_safe;
+  c.plan.pick = c.pick & 7;
   c.epoch = (c.epoch + 1) & 0xFFFFFFu;
   if (c.epoch == 0) {                        // once per 16 M launches: stale flags of the same epoch value must not survive the wrap
     if ((e = hipMemsetAsync(c.flags, 0, kFlagWords * sizeof(unsigned), st)) != hipSuccess) return e;
     c.epoch = 1;
   }
-  hipLaunchKernelGGL(k_ldlt_xcd, dim3(8 * (np - 1) + 1), dim3(kThreads), 0, st, n, St, x, ok, c.scr, c.flags, c.epoch, c.plan);
+  hipLaunchKernelGGL(k_ldlt_xcd, dim3(8 * (np - 1) + (c.pick & 7) + 1), dim3(kThreads), 0, st, n, St, x, ok, c.scr, c.flags, c.epoch, c.plan);
   return hipGetLastError();
 }
 

@@ -168,6 +168,7 @@ int main(int argc, char** argv) {
     fails += !good;
     for (int np = ldltx::kMaxP; np <= ldltx::kMaxP && ldltx::supports(n); np += 4) {   // the same system on four / eight compute units of one XCD
       static ldltx::Context cx;
+      cx.pick = si & 7;                      // (every size on another XCD)
       if (!ldltx::plan_fits(n, np, 4)) continue;
       CK(hipMemset(dx, 0, n * 8)); CK(hipMemset(dok, 0xFF, 4));
       CK(ldltx::launch(cx, n, dS, dx, dok, 0, np));
