@@ -1,6 +1,6 @@
 // Dense LDL^T + solve of the reduced camera system on EIGHT workgroups of ONE XCD (round 5).  The C4 window (50 free poses, 300
 // unknowns, 19 tile rows) takes 111 us alone and 140 us next to the tracking streams on the one compute unit of
-// ldltm::k_ldlt_big48; here 92 / 96 us.  The 190 tiles of 16 x 16 live in the registers of 64 wavefronts on 8 compute units that share
+// ldltm::k_ldlt_big48; here 84 / 92-100 us.  The 190 tiles of 16 x 16 live in the registers of 64 wavefronts on 8 compute units that share
 // an L2.  What ldltm::k_ldlt_mfma hands from wavefront to wavefront through LDS -- G = L_kk^-1 and D^-1 of a diagonal tile, the
 // -R / W images of a panel tile, the "published" flags -- goes through global memory that stays in that L2:
 //   * stores are plain (the vector L1 writes through), s_waitcnt vmcnt(0), then a relaxed agent-scope store of the flag word;
@@ -16,8 +16,8 @@
 // Flags carry the launch's number (epoch): nothing is cleared between launches.
 // Schedule: column j's last four tiles (j-3, j) .. (j, j) sit on one "chain" wavefront, which per row k = j-3 .. j-1 spins on
 // G_k's flag, solves (k, j), updates the tiles below from registers / one L2 image, and for k = j-1 runs the pivots of (j, j) at
-// once: ONE hand-over per tile row on the critical path.  The other tiles, <= 4 per wavefront, are walked row by row (wait for
-// the row's panel images, update; wait for G, solve, publish).  Same arithmetic per tile as ldltm::k_ldlt_mfma (pivot pairs as
+// once: ONE hand-over per tile row on the critical path.  The other tiles, <= 4 per wavefront, are taken one after the other (every
+// row above the tile, then G of its row, the solve, the publication).  Same arithmetic per tile as ldltm::k_ldlt_mfma (pivot pairs as
 // rank-2 matrix instructions, G collected on an identity copy) in one fixed order: bitwise reproducible.  The back-substitution
 // runs on five wavefronts of workgroup 0, one per 64-row block, x posted through LDS.  DESIGN.md section 8 has the timeline.
 #pragma once
@@ -60,8 +60,8 @@ struct Plan { short tile[kMaxW][kMaxNS]; signed char chain[kMaxW]; int np, ns, f
 __host__ inline bool plan_fits(int n, int np, int ns);
 // The systems this kernel takes: 9 .. 19 tile rows (21 .. 50 free poses).  Inside a local BA it is ahead of the one-workgroup kernels
 // at every such size (tools/lba_sizes.py, same box: the whole solve 0.688 vs 0.703 ms at 21 free poses, 0.842 vs 0.913 at 29, 0.998
-// vs 1.112 at 36, 1.10 vs 1.26 at 40, 1.36 vs 1.68 at 50); alone (tools/micro/ldlt_mfma_test) only from 16 tile rows on (72 / 85 /
-// 92 us against 81 / 99 / 111 us at 16 / 18 / 19 rows; level at 15).  8 tile rows (the C2 window) stay on ldltm::k_ldlt_cols: 19.6 us.
+// vs 1.112 at 36, 1.10 vs 1.26 at 40, 1.36 vs 1.68 at 50); alone (tools/micro/ldlt_mfma_test) 32 / 38 / 52 / 65 / 77 / 84 us against
+// 34 / 42 / 63 / 80 / 99 / 111 us at 9 / 10 / 13 / 16 / 18 / 19 rows.  8 tile rows (the C2 window) stay on ldltm::k_ldlt_cols: 19.6 us.
 __host__ inline bool supports(int n) { const Geo g = make_geo(n); return n >= 1 && g.T >= 9 && g.T <= kMaxT - 1 && g.n_pad <= 64 * kNY && plan_fits(n, kMaxP, 4); }
 __host__ inline bool pays(int n) { return supports(n); }
 
@@ -83,16 +83,17 @@ __host__ inline Plan make_plan(int n, int np, int ns) {
     cnt[w] = kChain;
     for (int q = 0; q < kChain; q++) P.tile[w][q] = j - (kChain - 1) + q >= 0 ? (short)ldltm::tile_index(j - (kChain - 1) + q, j) : (short)-1;
   }
-  // the other tiles column by column to whichever wavefront holds the fewest.  (Four tiles of one ROW per wavefront -- slots in
-  // lockstep, one shared -R image -- was slower: 100 us against 92; a row's panel tiles then come from four wavefronts only and
-  // every other wavefront waits for the last of them.)
-  for (int j = kChain; j < g.T; j++)
-    for (int i = 0; i + kChain <= j; i++) {
-      int best = -1;
-      for (int w = 0; w < W; w++)
-        if (!chain[w] && cnt[w] < ns && (best < 0 || cnt[w] < cnt[best])) best = w;
-      put(best, i, j);
-    }
+  // the other tiles in (row, column) order, dealt round the other wavefronts: a wavefront takes its tiles one after the other, so
+  // its tiles should be rows apart (with 45 wavefronts for 120 tiles: rows 0-3, 3-7, 8+) -- the second one then has caught up
+  // on its rows long before its G arrives.  (Dealt by column to the least loaded wavefront, tiles of neighbouring rows met on one
+  // wavefront and the later one came out 4-8 us after its G; four tiles of one ROW per wavefront was slower still.)
+  {
+    int order[kMaxW], no = 0;                // the other wavefronts, walking the workgroups round-robin
+    for (int q = 0; q < kWgWaves; q++) for (int p2 = 0; p2 < np; p2++) if (!chain[p2 * kWgWaves + q]) order[no++] = p2 * kWgWaves + q;
+    int t = 0;
+    for (int i = 0; i + kChain < g.T; i++)
+      for (int j = i + kChain; j < g.T; j++) { put(order[t % no], i, j); t++; }
+  }
   for (int w = 0; w < kMaxW; w++) P.chain[w] = chain[w];
   for (int w = 0; w < W; w++) {             // order by (row, column); insertion sort of <= 8 entries
     if (P.chain[w]) continue;
@@ -309,6 +310,93 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   auto spin = [&](const unsigned* f, int where, int a2) {
     while (__builtin_amdgcn_readfirstlane(ld_flag(f)) != epoch && !bail_) { LDLTX_DOG(where, a2, 0); }
   };
+  // ---- a wavefront that holds no chain tiles takes its tiles ONE AFTER THE OTHER, in row order: every row above the tile (up to
+  // kRB rows' operand images in flight together: rows published long ago are caught up on at the matrix-instruction rate), then G of
+  // the tile's row, the solve, the publication.  Walking all its tiles row by row (the loop below, still used by the chain
+  // wavefronts for the rows above their four tiles) made a tile wait for the latest flag of the OTHER tiles' rows, and a row's
+  // panel tiles came out up to 7 us after its G.  Waits are for rows above the tile only and tiles are taken in row order: no cycle.
+  if (!chain_wave) {
+    constexpr int kRB = 4;
+    auto take = [&](d4 c, const int i, const int j) __attribute__((always_inline)) {
+      const unsigned* fa = f_panel + i; const unsigned* fb = f_panel + j;
+      unsigned oa_off = (unsigned)i * 512u, ow_off = (unsigned)j * 512u + 256u;
+      int r = 0;
+      while (r < i) {
+        const int nb = min(kRB, i - r);
+        int m = 0;
+        for (;;) {
+          unsigned f1[kRB], f2[kRB];
+#pragma unroll
+          for (int u = 0; u < kRB; u++) { const unsigned d = (unsigned)min(u, nb - 1) * row_words; f1[u] = ld_flag(fa + d); f2[u] = ld_flag(fb + d); }
+          bool run = true;
+          m = 0;
+#pragma unroll
+          for (int u = 0; u < kRB; u++) {
+            run = run && u < nb && __builtin_amdgcn_readfirstlane(f1[u]) == epoch && __builtin_amdgcn_readfirstlane(f2[u]) == epoch;
+            m += run;
+          }
+          if (m > 0 || bail_) break;
+          LDLTX_DOG(3, r, i * 100 + j);
+        }
+        if (bail_) break;
+        acquire();
+        double oa[kRB][4], ow[kRB][4];
+#pragma unroll
+        for (int u = 0; u < kRB; u++) {            // (rows past the ready ones re-read the last ready row: no branch around loads)
+          const unsigned d = (unsigned)min(u, m - 1) * row_doubles;
+          const double* const pa = Pan + oa_off + d + lane;
+          const double* const pw = Pan + ow_off + d + lane;
+#pragma unroll
+          for (int q = 0; q < 4; q++) { oa[u][q] = ld_l2(pa + q * 64); ow[u][q] = ld_l2(pw + q * 64); }
+        }
+#pragma unroll
+        for (int u = 0; u < kRB; u++) {
+          if (u < m) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) c = mfma(oa[u][q], ow[u][q], c);
+          }
+        }
+        r += m; fa += (unsigned)m * row_words; fb += (unsigned)m * row_words; oa_off += (unsigned)m * row_doubles; ow_off += (unsigned)m * row_doubles;
+      }
+      // the tile against G_i
+      spin(f_diag + i, 1, i);
+      acquire();
+      double Gf[4], dv4[4];
+      const double* const gk = Gb + (size_t)i * 16 * kGld;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + i * 16 + lr + 4 * q); }
+      d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
+      R0 = mfma(Gf[0], c[0], R0);
+      R1 = mfma(Gf[2], c[2], R1);
+      R0 = mfma(Gf[1], c[1], R0);
+      R1 = mfma(Gf[3], c[3], R1);
+      double* const pb = Pan + ((size_t)(i * T + j) * 2) * 256 + lane;
+      double w4[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const double rr = R0[g] + R1[g];
+        w4[g] = rr * dv4[g];
+        pb[g * 64] = -rr;
+        pb[256 + g * 64] = w4[g];
+      }
+      publish(kFPanel + i * T + j, true);
+#ifdef LDLTX_PROFILE
+      if (lane == 0) { atomicMax((unsigned long long*)&g_xprof[400 + i], (unsigned long long)wall_clock64()); atomicMin((unsigned long long*)&g_xprof[430 + i], (unsigned long long)wall_clock64()); }
+#endif
+      const int J = 16 * j + lc;
+      if (J <= cb) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) wm_store(16 * i + lr + 4 * g, J, w4[g]);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < kNS; s++) {
+      int i = ti0[s], j = tj0[s];
+      asm volatile("" : "+s"(i), "+s"(j));
+      if (on[s]) take(acc[s], i, j);
+    }
+    r_end = 0;
+  }
   for (int r = 0; r < r_end; r++) {
     // (opaque copies: everything derived from a slot's tile position is loop-invariant, and hoisted out of this loop it costs 64
     // vector registers of store addresses and spills)

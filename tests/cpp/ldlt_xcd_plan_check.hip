@@ -1,7 +1,8 @@
 // Host-only check of csrc/ldlt_xcd.hpp's tile plan and schedule for every system size the kernel takes (no GPU: only the __host__
 // plan builder runs).  (1) every tile of the upper triangle sits in exactly one wavefront slot; a chain wavefront holds exactly the
 // last kChain tiles of its column, in row order, diagonal last; the others hold at most four tiles in (row, column) order.
-// (2) the row-by-row schedule of the kernel, replayed as a set of programs of WAIT / PUBLISH steps over the same flags, runs to the
+// (2) the schedule of the kernel (chain wavefronts: the rows above their tiles, then their chain steps; the others: tile after tile),
+// replayed as a set of programs of WAIT / PUBLISH steps over the same flags, runs to the
 // end from any interleaving (a fixed point over "who can advance"): no wait is for something only a later step of a waiting
 // wavefront would publish.     hipcc -O1 -o ldlt_xcd_plan_check ldlt_xcd_plan_check.hip && ./ldlt_xcd_plan_check
 #include <cstdio>
@@ -60,17 +61,13 @@ int main() {
         if (cnt > 4) { std::printf("n=%d: wavefront %d holds %d tiles\n", n, w, cnt); bad++; }
         for (int s = 1; s < 4; s++)
           if (on[s] && (!on[s - 1] || ti[s - 1] * 64 + tj[s - 1] >= ti[s] * 64 + tj[s])) { std::printf("n=%d: wavefront %d slots out of (row, column) order\n", n, w); bad++; }
-        int r_end = 0;
-        for (int s = 0; s < 4; s++) if (on[s] && ti[s] + 1 > r_end) r_end = ti[s] + 1;
-        for (int r = 0; r < r_end; r++) {
-          bool first = true;
-          for (int s = 0; s < 4; s++)
-            if (on[s] && ti[s] == r) {
-              if (ti[s] == tj[s]) { std::printf("n=%d: wavefront %d holds diagonal tile %d without being a chain wavefront\n", n, w, r); bad++; }
-              if (first) { prog[w].push_back({false, r}); first = false; }
-              prog[w].push_back({true, 64 + r * 32 + tj[s]});
-            }
-          for (int s = 0; s < 4; s++) if (on[s] && ti[s] > r) { prog[w].push_back({false, 64 + r * 32 + ti[s]}); prog[w].push_back({false, 64 + r * 32 + tj[s]}); }
+        // the kernel's program: tile after tile -- every row above it, then G of its row, then its publication
+        for (int s = 0; s < 4; s++) {
+          if (!on[s]) continue;
+          if (ti[s] == tj[s]) { std::printf("n=%d: wavefront %d holds diagonal tile %d without being a chain wavefront\n", n, w, ti[s]); bad++; }
+          for (int r = 0; r < ti[s]; r++) { prog[w].push_back({false, 64 + r * 32 + ti[s]}); prog[w].push_back({false, 64 + r * 32 + tj[s]}); }
+          prog[w].push_back({false, ti[s]});
+          prog[w].push_back({true, 64 + ti[s] * 32 + tj[s]});
         }
       }
     }
