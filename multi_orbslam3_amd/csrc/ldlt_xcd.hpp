@@ -276,15 +276,13 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
       if (I < J && I < n_pad && J <= cb) wm_store(I, J, Wc[g]);
     }
   };
-  // ---- the schedule of a wavefront, row by row (no polling sweeps: a sweep over four slots was three dependent L2 round trips and
-  // took 2-3 us; a tile advanced one row per sweep and the wavefronts ran rows behind the chain).  For r = 0, 1, ..:
-  //   * its panel tiles of row r (those not held by a chain wavefront): wait for G_r, solve, publish;
-  //   * its tiles below row r: wait for the two panel images of row r of each, all operand images in flight together, update.
-  // Every wait is for something of row r published by wavefronts that have only rows < r behind them: no cycle.  A chain
-  // wavefront (tiles (j-3, j) .. (j, j) in slots 0 .. 3) does rows < j-3 like this, then per row k = j-3, j-2, j-1: spins on G_k's
-  // flag, solves (k, j), updates the diagonal tile from registers and the tiles between with the -R images of (k, k+1) ..,
-  // which the chain wavefronts of those columns publish at about the same time; for k = j - 1 the pivots of (j, j) follow at
-  // once.  One hand-over per tile row on the critical path.
+  // ---- the schedule.  A chain wavefront (tiles (j-3, j) .. (j, j) in slots 0 .. 3) first applies the rows above its tiles, row by
+  // row: wait for the row's panel images of its four tiles, all operand images in flight together, update.  Then per row k = j-3,
+  // j-2, j-1: it spins on G_k's flag, solves (k, j), updates the diagonal tile from registers and the tiles between with the -R
+  // images of (k, k+1) .., which the chain wavefronts of those columns publish at about the same time; for k = j - 1 the pivots
+  // of (j, j) follow at once.  One hand-over per tile row on the critical path.  The other wavefronts: see below.  Every wait is
+  // for something of a row above, published by wavefronts that have only rows above behind them: no cycle
+  // (tests/cpp/ldlt_xcd_plan_check.hip replays the schedule for every size).
   const bool chain_wave = plan.chain[gw] != 0;
   // (a chain wavefront shares its SIMD with one that updates up to four tiles, 16 matrix instructions back to back: it goes first)
   if (chain_wave) __builtin_amdgcn_s_setprio(3);
@@ -403,58 +401,6 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
     int ti[kNS], tj[kNS];
 #pragma unroll
     for (int s = 0; s < kNS; s++) { ti[s] = ti0[s]; tj[s] = tj0[s]; asm volatile("" : "+s"(ti[s]), "+s"(tj[s])); }
-    // ---- panel tiles of row r: all solved and stored, ONE wait for the stores, then their flags (a wait per tile is a store
-    // round trip, 0.5 us, per tile)
-    bool have_g = false, pan[kNS];
-    double Gf[4] = {0, 0, 0, 0}, dv4[4] = {0, 0, 0, 0}, wk[kNS][4];
-#pragma unroll
-    for (int s = 0; s < kNS; s++) {
-      pan[s] = !chain_wave && on[s] && ti[s] == r && !isdiag[s];
-      if (pan[s]) {
-        const int j = tj[s];
-        if (!have_g) {
-          spin(f_diag + r, 1, r);
-          acquire();
-          const double* const gk = Gb + (size_t)r * 16 * kGld;
-#pragma unroll
-          for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + r * 16 + lr + 4 * q); }
-          have_g = true;
-        }
-        const d4 X = acc[s];
-        d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
-        R0 = mfma(Gf[0], X[0], R0);
-        R1 = mfma(Gf[2], X[2], R1);
-        R0 = mfma(Gf[1], X[1], R0);
-        R1 = mfma(Gf[3], X[3], R1);
-        double* const pb = Pan + ((size_t)(r * T + j) * 2) * 256 + lane;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const double rr = R0[g] + R1[g];
-          wk[s][g] = rr * dv4[g];
-          pb[g * 64] = -rr;
-          pb[256 + g * 64] = wk[s][g];
-        }
-      }
-    }
-    if (have_g) {
-      if (safe) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int s = 0; s < kNS; s++) {
-        if (pan[s]) {
-          const int j = tj[s];
-          if (lane < kMaxP) __hip_atomic_store(flags + lane * kFlagStride + kFPanel + r * T + j, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef LDLTX_PROFILE
-          if (lane == 0) { atomicMax((unsigned long long*)&g_xprof[400 + r], (unsigned long long)wall_clock64()); atomicMin((unsigned long long*)&g_xprof[430 + r], (unsigned long long)wall_clock64()); }
-#endif
-          const int J = 16 * j + lc;
-          if (J <= cb) {
-#pragma unroll
-            for (int g = 0; g < 4; g++) wm_store(16 * r + lr + 4 * g, J, wk[s][g]);
-          }
-        }
-      }
-    }
     // ---- tiles below row r: all their flags, then all their operand images, then the updates
     bool need[kNS], any = false;
 #pragma unroll

@@ -107,7 +107,7 @@ def test_other_configurations_produce_a_line(name):
     assert d["roofline"]["bracketed_launches"] >= 1
     assert d["parity"]["ok"] is True and d["parity"]["frames"] == 20          # the in-job gate runs for every configuration
     if name == "C4":
-        assert d["roofline"]["unknowns"] == 300 and "k_ldlt_big48" in d["roofline"]["kernel"]
+        assert d["roofline"]["unknowns"] == 300 and "k_ldlt_xcd" in d["roofline"]["kernel"]       # (ORBG_LDLT_XCD=0: k_ldlt_big48)
     else:
         # a monocular agent is a first-class agent: fused constructor, pipelined, the C++ loop
         assert d["config"]["host_images_in_step"] is True and "libagentloop" in d["config"]["tracking_loop"]

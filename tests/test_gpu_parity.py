@@ -1641,18 +1641,21 @@ def test_one_stream_per_handle_is_still_a_working_configuration():
 
 def test_ldlt_kernels_against_a_long_double_host_factorisation():
     """tools/micro/ldlt_mfma_test: every LDL^T kernel of csrc/ldlt_mfma.hpp (column kernel, 8-wavefront tile kernel, the four forms
-    of the 4-wavefront kernel) on random SPD systems of 6 ... 300 unknowns against a long-double factorisation on the host
-    (|dx| <= 1e-10 max|x|), the operand layout probe of v_mfma_f64_16x16x4_f64 and the zero-pivot flag.  Built without the
-    in-kernel timeline (-DNO_PROFILE: the code the library ships)."""
+    of the 4-wavefront kernel) and the eight-workgroup kernel of csrc/ldlt_xcd.hpp (from 9 tile rows on: after one launch, after
+    210, and with its agent-scope hand-overs forced) on random SPD systems of 6 ... 300 unknowns against a long-double factorisation
+    on the host (|dx| <= 1e-10 max|x|), the operand layout probe of v_mfma_f64_16x16x4_f64 and the zero-pivot flags.  Built
+    without the in-kernel timelines (-DNO_PROFILE: the code the library ships)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "tools", "micro", "ldlt_mfma_test.hip")
     exe = os.path.join(root, "tools", "micro", "ldlt_mfma_test_np")
     hdr = os.path.join(root, "multi_orbslam3_amd", "csrc", "ldlt_mfma.hpp")
+    hdr2 = os.path.join(root, "multi_orbslam3_amd", "csrc", "ldlt_xcd.hpp")
     inc = os.path.join(root, "multi_orbslam3_amd", "csrc", "ldlt_jump_tables.inc")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in (src, hdr, inc)):
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in (src, hdr, hdr2, inc)):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-DNO_PROFILE", "-o", exe, src],
                               timeout=900)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ALL OK" in r.stdout and "FAIL" not in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
     sizes = [ln for ln in r.stdout.splitlines() if ln.startswith("n=")]
-    assert len(sizes) == 14, sizes
+    assert len(sizes) == 16, sizes
+    assert sum("xcd (8 workgroups" in ln for ln in r.stdout.splitlines()) == 9 and "xcd zero pivot: ok=0 ok" in r.stdout, r.stdout[-3000:]
