@@ -66,7 +66,7 @@ __host__ inline bool supports(int n) { const Geo g = make_geo(n); return n >= 1 
 __host__ inline bool pays(int n) { return supports(n); }
 
 // Tiles to wavefronts.  Column j's last kChain tiles go to one "chain" wavefront (consecutive columns on different compute units)
-// that holds nothing else; the other tiles, column by column, to whichever other wavefront holds the fewest, ordered by (row, column).
+// that holds nothing else; the other tiles are dealt round the other wavefronts in (row, column) order.
 __host__ inline Plan make_plan(int n, int np, int ns) {
   const Geo g = make_geo(n);
   const int W = np * kWgWaves;
