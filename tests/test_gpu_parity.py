@@ -809,6 +809,38 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
         assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), (nf, env)
 
 
+def test_lba_large_windows_solved_concurrently_by_three_handles():
+    """Three LocalMapping threads of one process (three handles) solve 38 / 45 / 50 free-pose windows at the same time, eight times
+    over: their eight-workgroup LDL^T kernels (ldlt_xcd.hpp) spin on each other's hand-overs while the others' workgroups are being
+    placed -- on different XCDs per handle -- and every result is the oracle's."""
+    import threading
+    probs = []
+    for nf in (38, 45, 50):
+        prob = synth.make_lba_problem(n_free=nf, n_fixed=4, n_points=30 * nf, mono_frac=0.2, seed=500 + nf)
+        p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+        probs.append((p, keep, ob.lba_solve(p)))
+    results = [[] for _ in probs]
+
+    def work(k):
+        opt = api.Optimizer()
+        for _ in range(8):
+            results[k].append(opt.LocalBundleAdjustment(probs[k][0]))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(probs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a concurrent solve did not finish"
+    for k, (p, keep, o) in enumerate(probs):
+        assert len(results[k]) == 8
+        for g in results[k]:
+            assert g.status == o.status and g.iters == o.iters
+            assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4
+            assert np.array_equal(g.edge_outlier, o.edge_outlier)
+            assert np.array_equal(g.poses, results[k][0].poses)          # ... and the same bits every time
+
+
 @pytest.mark.parametrize("nf", [51, 52, 56, 64, 65, 83, 120])
 def test_lba_windows_beyond_the_benchmark_sizes(nf):
     """More than 50 free poses (a covisibility window of ORB-SLAM3 is not bounded): from 51 on the reduced camera system is
