@@ -292,12 +292,14 @@ int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewin
 // change while its observation count, its distance range and the map's change index all stay the same between two consecutive frames
 // (an erase + add pair on one point within one frame time); kLocalMapMaxAge calls bound even that.  Define
 // ORBGPU_DROPIN_EXACT_LOCAL_MAP to read every point's statics on every call (the reference's cost, no assumption).
+// (Later in round 5: a MapPoint that carries the change counter of INTEGRATION.md section 3 makes this cache exact -- see below.)
 // A Map type without GetMapChangeIndex() does not compile here (there would be no signal for moved points at all).
 constexpr unsigned kLocalMapMaxAge = 30;
 struct LocalMapCache {
   std::vector<const void*> ptrs;
   std::vector<float> pos, nrm, dmin, dmax;
   std::vector<int32_t> nobs_seen;                  // Observations() when the statics of point i were read
+  std::vector<unsigned long> stamp;                // MapPoint::mnChangeStamp when they were read (points that carry one)
   std::vector<uint8_t> desc, have;                 // have[i]: the statics of point i were read (bad points are never read)
   const void* map = nullptr; long long change_index = -1;
   unsigned age = 0;
@@ -305,6 +307,15 @@ struct LocalMapCache {
   void invalidate() { ptrs.clear(); map = nullptr; change_index = -1; age = 0; index.clear(); index_valid = false; }
 };
 template <class Ops> inline LocalMapCache& local_map_cache() { static thread_local LocalMapCache c; return c; }    // (one per entry-point set)
+// A MapPoint that carries a change counter (long unsigned mnChangeStamp, ++ in every mutator of the fields read here: INTEGRATION.md
+// section 3) makes this cache EXACT: a point's statics are re-read if and only if its counter moved -- no change index, no age
+// bound, no assumption.  An entry-point set with `kNoChangeStamp = true` keeps the counter-less rules (tests).
+template <class T, class = void> struct has_change_stamp : std::false_type {};
+template <class T> struct has_change_stamp<T, std::void_t<decltype(std::declval<T&>().mnChangeStamp)>> : std::true_type {};
+template <class Ops, class = void> struct stamp_off : std::false_type {};
+template <class Ops> struct stamp_off<Ops, std::void_t<decltype(Ops::kNoChangeStamp)>> : std::integral_constant<bool, Ops::kNoChangeStamp> {};
+template <class MapPointT> auto stamp_of(const MapPointT* p, int) -> decltype((unsigned long)p->mnChangeStamp) { return (unsigned long)p->mnChangeStamp; }
+template <class MapPointT> unsigned long stamp_of(const MapPointT*, long) { return 0; }
 template <class Ops, class = void> struct has_search_local_resident : std::false_type {};
 template <class Ops> struct has_search_local_resident<Ops, decltype((void)&Ops::search_local_resident)> : std::true_type {};
 template <class MapPointT> auto change_index_of(MapPointT* p, int) -> decltype((long long)p->GetMap()->GetMapChangeIndex()) {
@@ -349,8 +360,14 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
     if (!map && !bad[i]) { map = (const void*)p->GetMap(); ci = change_index_of(p, 0); }
   }
   // ---- static fields: reuse / patch / re-read
+#ifdef ORBGPU_DROPIN_EXACT_LOCAL_MAP
+  constexpr bool kStamped = false;
+#else
+  constexpr bool kStamped = has_change_stamp<MapPointT>::value && !stamp_off<Ops>::value && !exact_local_map<Ops>::value;
+#endif
   auto read_statics = [&](int i) {
     MapPointT* p = vpLocalMapPoints[i];
+    C.stamp[i] = stamp_of(p, 0);                       // BEFORE the fields: a change during the read is seen on the next call
     const auto X = p->GetWorldPos(); const auto nv = p->GetNormal(); const auto Dm = p->GetDescriptor();
     std::memcpy(&C.pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&C.nrm[3 * (size_t)i], mat_f32(nv), 12);
     C.dmin[i] = p->mfMinDistance; C.dmax[i] = p->mfMaxDistance;
@@ -361,12 +378,13 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
   // a cached point is DIRTY when its observation count or its distance range is not what it was when its statics were read
   auto dirty = [&](int i) {
     const MapPointT* p = vpLocalMapPoints[i];
+    if (kStamped) return C.stamp[i] != stamp_of(p, 0);
     return C.nobs_seen[i] != nobs[i] || C.dmin[i] != p->mfMinDistance || C.dmax[i] != p->mfMaxDistance;
   };
 #ifdef ORBGPU_DROPIN_EXACT_LOCAL_MAP
   const bool fresh = true;
 #else
-  const bool fresh = exact_local_map<Ops>::value || C.ptrs.empty() || C.map != map || C.change_index != ci || C.age >= kLocalMapMaxAge;
+  const bool fresh = exact_local_map<Ops>::value || C.ptrs.empty() || C.map != map || (!kStamped && (C.change_index != ci || C.age >= kLocalMapMaxAge));
 #endif
   bool statics_same = false;
   if (!fresh && (int)C.ptrs.size() == M && std::memcmp(C.ptrs.data(), vpLocalMapPoints.data(), sizeof(void*) * (size_t)M) == 0) {
@@ -381,23 +399,27 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
     if (!C.index_valid) { C.index.clear(); C.index.reserve(C.ptrs.size() * 2); for (size_t j = 0; j < C.ptrs.size(); j++) if (C.have[j]) C.index.emplace(C.ptrs[j], (int)j); }
     std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M); std::vector<uint8_t> desc(32 * (size_t)M), have(M, 0);
     std::vector<int32_t> seen(M, 0);
+    std::vector<unsigned long> stamps(M, 0);
     std::vector<int> todo;
     for (int i = 0; i < M; i++) {
       const auto it = C.index.find((const void*)vpLocalMapPoints[i]);
       const MapPointT* p = vpLocalMapPoints[i];
       const size_t j = it != C.index.end() ? (size_t)it->second : 0;
-      if (it != C.index.end() && !bad[i] && C.nobs_seen[j] == nobs[i] && C.dmin[j] == p->mfMinDistance && C.dmax[j] == p->mfMaxDistance) {
+      const bool known = it != C.index.end() && !bad[i] &&
+                         (kStamped ? C.stamp[j] == stamp_of(p, 0) : C.nobs_seen[j] == nobs[i] && C.dmin[j] == p->mfMinDistance && C.dmax[j] == p->mfMaxDistance);
+      if (known) {
         std::memcpy(&pos[3 * (size_t)i], &C.pos[3 * j], 12); std::memcpy(&nrm[3 * (size_t)i], &C.nrm[3 * j], 12);
         dmin[i] = C.dmin[j]; dmax[i] = C.dmax[j]; std::memcpy(&desc[32 * (size_t)i], &C.desc[32 * j], 32); have[i] = 1; seen[i] = C.nobs_seen[j];
+        stamps[i] = C.stamp[j];
       } else if (!bad[i]) todo.push_back(i);
     }
-    C.pos.swap(pos); C.nrm.swap(nrm); C.dmin.swap(dmin); C.dmax.swap(dmax); C.desc.swap(desc); C.have.swap(have); C.nobs_seen.swap(seen);
+    C.pos.swap(pos); C.nrm.swap(nrm); C.dmin.swap(dmin); C.dmax.swap(dmax); C.desc.swap(desc); C.have.swap(have); C.nobs_seen.swap(seen); C.stamp.swap(stamps);
     C.ptrs.assign((const void* const*)vpLocalMapPoints.data(), (const void* const*)vpLocalMapPoints.data() + M);
     for (int i : todo) read_statics(i);
     C.index_valid = false; C.age++;
   } else {
     C.pos.assign(3 * (size_t)M, 0.f); C.nrm.assign(3 * (size_t)M, 0.f); C.dmin.assign(M, 0.f); C.dmax.assign(M, 0.f); C.desc.assign(32 * (size_t)M, 0); C.have.assign(M, 0);
-    C.nobs_seen.assign(M, 0);
+    C.nobs_seen.assign(M, 0); C.stamp.assign(M, 0);
     C.ptrs.assign((const void* const*)vpLocalMapPoints.data(), (const void* const*)vpLocalMapPoints.data() + M);
     for (int i = 0; i < M; i++) if (!bad[i]) read_statics(i);
     C.map = map; C.change_index = ci; C.age = 0; C.index_valid = false;
@@ -545,8 +567,6 @@ int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMa
 // lets the calling thread (LocalMapping) keep each point's flattened observation list and position from window to window and
 // re-read only the points whose counter moved -- by this function's own write-back, which knows what it wrote, or by anybody else.
 // Without the member the points are read as before; an entry-point set with `kNoLbaCache = true` also reads them as before (tests).
-template <class T, class = void> struct has_change_stamp : std::false_type {};
-template <class T> struct has_change_stamp<T, std::void_t<decltype(std::declval<T&>().mnChangeStamp)>> : std::true_type {};
 template <class Ops, class = void> struct lba_cache_off : std::false_type {};
 template <class Ops> struct lba_cache_off<Ops, std::void_t<decltype(Ops::kNoLbaCache)>> : std::integral_constant<bool, Ops::kNoLbaCache> {};
 

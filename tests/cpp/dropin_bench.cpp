@@ -177,11 +177,22 @@ int main(int argc, char** argv) {
     Cur.mnId = 7;
     auto reset_fused = [&]() { reset_local(); for (auto* p : local) p->mnLastFrameSeen = ~0ul; };
     // a frame whose local map is the previous frame's (4 of 5 frames at one keyframe per 5 frames): the flattened statics and the device
-    // copy are reused; and a frame after a keyframe (the local BA's write-back moved the map's change index): everything is read again
+    // copy are reused; and a frame after a keyframe: the points the local BA moved are read again (all of them for a MapPoint type
+    // without a change counter: the map's change index moved)
     rows.push_back(measure("SearchLocalPoints (fused; local map unchanged since the last frame)", reps, 5, reset_fused,
                            [&]() { return od::SearchLocalPoints<TimedOps>(Cur, local, 1.0f, false, 50.0f, 0.8f); }));
-    rows.push_back(measure("SearchLocalPoints (fused; after a keyframe: map change index moved, full re-read + upload)", reps, 5,
-                           [&]() { reset_fused(); if (!local.empty() && local[0]->GetMap()) local[0]->GetMap()->IncreaseChangeIndex(); },
+    // (what a keyframe does to the local map before the next frame: the local BA's write-back -- SetWorldPos + UpdateNormalAndDepth on
+    // the window's points, four in five of the local map here, and the map's change index -- and ProcessNewKeyFrame's new observations)
+    auto after_keyframe = [&]() {
+      reset_fused();
+      for (size_t j = 0; j < local.size(); j++) {
+        if (j % 5 == 4) continue;
+        local[j]->SetWorldPos(local[j]->GetWorldPos(), true);
+        local[j]->UpdateNormalAndDepth();
+      }
+      if (!local.empty() && local[0]->GetMap()) local[0]->GetMap()->IncreaseChangeIndex();
+    };
+    rows.push_back(measure("SearchLocalPoints (fused; after a keyframe: the local BA moved 4 in 5 points, re-read + upload)", reps, 5, after_keyframe,
                            [&]() { return od::SearchLocalPoints<TimedOps>(Cur, local, 1.0f, false, 50.0f, 0.8f); }));
     rows.push_back(measure("SearchLocalPoints as two calls (isInFrustum loop + SearchByProjection(F, MPs))", reps, 5, reset_fused, [&]() {
       od::isInFrustumAll<TimedOps>(Cur, local, 0.5f);

@@ -23,6 +23,9 @@
 using namespace mock;
 namespace od = orbgpu::dropin;
 
+struct GpuHeuristicOps : od::GpuOps {   // the product's entry points with the counter-less rules of the local-map cache (a MapPoint without mnChangeStamp)
+  static constexpr bool kNoChangeStamp = true;
+};
 struct OracleOps {       // the same entry points over the CPU oracle: views instead of device handles
   static constexpr bool kUsesResidentFrame = false;
   static constexpr bool kExactLocalMap = true;      // the reference's semantics: every point's fields are read on every call (no cache)
@@ -170,27 +173,30 @@ static TrackOut run_tracking(orbgpu::ORBextractor& rig, const std::vector<uint8_
       varied(90, 0, 60);                                   // uploads the map: features 0..59 of the matched ones hold their points
       varied(91, 60, 120);                                 // cached map, OTHER held features: the first 60 points are candidates again
       varied(92, 0, 0);                                    // nothing held
-      for (size_t j = 3; j < local.size(); j += 29) local[j]->mbBad = true;       // points culled by LocalMapping between two frames
+      for (size_t j = 3; j < local.size(); j += 29) { local[j]->mbBad = true; local[j]->Touch(); }       // points culled by LocalMapping between two frames
       varied(93, 30, 90);
-      for (size_t j = 1; j < local.size(); j += 7) local[j]->nObs = (local[j]->nObs + 1) % 3;     // Observations() moved (0 lets a feature be overwritten, S/ORBmatcher.cc:89-91)
+      for (size_t j = 1; j < local.size(); j += 7) { local[j]->nObs = (local[j]->nObs + 1) % 3; local[j]->Touch(); }     // Observations() moved (0 lets a feature be overwritten, S/ORBmatcher.cc:89-91)
       varied(94, 30, 90);
       for (size_t j = 2; j < local.size(); j += 5) {       // ProcessNewKeyFrame: one more observation, another medoid descriptor, a wider distance range
         MapPoint* p = local[j], *q = local[(j + 11) % local.size()];
-        p->nObs += 1; p->mDescriptor = q->mDescriptor; p->mfMaxDistance *= 1.3f; p->mfMinDistance *= 0.8f;
+        p->nObs += 1; p->mDescriptor = q->mDescriptor; p->mfMaxDistance *= 1.3f; p->mfMinDistance *= 0.8f; p->Touch();
       }
       varied(95, 10, 50);
       varied(96, 50, 10);                                  // (nothing held) the re-described points once more, from the refreshed cache
-      for (size_t j = 0; j < local.size(); j++) { local[j]->nObs = keep[j].nObs; local[j]->mDescriptor = keep[j].desc; local[j]->mfMinDistance = keep[j].dmin; local[j]->mfMaxDistance = keep[j].dmax; }
+      for (size_t j = 0; j < local.size(); j++) { local[j]->nObs = keep[j].nObs; local[j]->mDescriptor = keep[j].desc; local[j]->mfMinDistance = keep[j].dmin; local[j]->mfMaxDistance = keep[j].dmax; local[j]->Touch(); }
     }
     od::local_map_cache<Ops>().invalidate();
     for (size_t j = 0; j < local.size(); j++) local[j]->mbBad = (j % 41) == 7;
     again(local, 78);                                      // (the cache is warm again, as after a_cached)
     std::vector<Mat> saved;
-    for (size_t j = 0; j < local.size(); j += 3) { saved.push_back(local[j]->mWorldPos); local[j]->mWorldPos.ptr<float>(0)[2] += 40.0f; }
+    for (size_t j = 0; j < local.size(); j += 3) {         // moved by somebody's SetWorldPos, the map's change index untouched
+      saved.push_back(local[j]->mWorldPos);
+      Mat X = local[j]->mWorldPos; X.ptr<float>(0)[2] += 40.0f; local[j]->SetWorldPos(X);
+    }
     o.a_stale = again(local, 79);
     A.map.IncreaseChangeIndex();
     o.a_moved = again(local, 80);
-    { size_t q = 0; for (size_t j = 0; j < local.size(); j += 3) local[j]->mWorldPos = saved[q++]; }
+    { size_t q = 0; for (size_t j = 0; j < local.size(); j += 3) local[j]->SetWorldPos(saved[q++]); }
     A.map.IncreaseChangeIndex();
     again(local, 81);
     std::vector<MapPoint*> other(local.begin() + 100, local.end());
@@ -291,28 +297,37 @@ int main() {
     EXPECT(g.n_frame == c.n_frame && g.a_frame == c.a_frame && g.n_frame > 100, "SearchByProjection(Cur, Last) %d vs %d", g.n_frame, c.n_frame);
     EXPECT(g.n_fused == c.n_fused && g.a_fused == c.a_fused && g.vis_sum == c.vis_sum && g.n_fused > 100, "SearchLocalPoints (fused) %d vs %d, visible sums %d vs %d",
            g.n_fused, c.n_fused, g.vis_sum, c.vis_sum);
-    {
-      auto ndiff = [](const std::vector<int>& a, const std::vector<int>& b) { int d = (int)(a.size() != b.size()); for (size_t i = 0; i < a.size() && i < b.size(); i++) d += a[i] != b[i]; return d; };
-      EXPECT(g.a_cached == g.a_fused && c.a_cached == c.a_fused, "SearchLocalPoints on the cached local map differs from the first call (%d / %d features)",
+    auto ndiff = [](const std::vector<int>& a, const std::vector<int>& b) { int d = (int)(a.size() != b.size()); for (size_t i = 0; i < a.size() && i < b.size(); i++) d += a[i] != b[i]; return d; };
+    // the local-map cache of the glue: with the mocks' change counter (exact) and with the counter-less rules
+    auto check_local_map_cache = [&](const TrackOut& g, bool stamped, const char* what) {
+      EXPECT(g.n_fused == c.n_fused && g.a_fused == c.a_fused && g.vis_sum == c.vis_sum, "[%s] SearchLocalPoints (fused) %d vs %d", what, g.n_fused, c.n_fused);
+      EXPECT(g.a_cached == g.a_fused && c.a_cached == c.a_fused, "[%s] SearchLocalPoints on the cached local map differs from the first call (%d / %d features)", what,
              ndiff(g.a_cached, g.a_fused), ndiff(c.a_cached, c.a_fused));
-      EXPECT(g.a_varied.size() == 7 && c.a_varied.size() == 7, "varied-state calls missing");
+      EXPECT(g.a_varied.size() == 7 && c.a_varied.size() == 7, "[%s] varied-state calls missing", what);
       for (size_t q = 0; q < g.a_varied.size() && q < c.a_varied.size(); q++) {
         int nm = 0; for (int v : g.a_varied[q]) nm += v >= 0;
         EXPECT(g.a_varied[q] == c.a_varied[q] && g.vis_varied[q] == c.vis_varied[q] && nm > 100,
-               "SearchLocalPoints with changing per-frame state, call %zu: %d features differ from the oracle's fresh read (visible sums %d vs %d, %d matched)", q,
+               "[%s] SearchLocalPoints with changing per-frame state, call %zu: %d features differ from the oracle's fresh read (visible sums %d vs %d, %d matched)", what, q,
                ndiff(g.a_varied[q], c.a_varied[q]), g.vis_varied[q], c.vis_varied[q], nm);
       }
       EXPECT(g.vis_varied[1] != g.vis_varied[2] && ndiff(g.a_varied[2], g.a_varied[3]) > 0 && ndiff(g.a_varied[4], g.a_varied[5]) + ndiff(g.a_varied[3], g.a_varied[4]) > 0,
-             "the varied-state calls do not exercise anything (visible sums %d %d; %d / %d / %d features differ between consecutive calls)", g.vis_varied[1],
+             "[%s] the varied-state calls do not exercise anything (visible sums %d %d; %d / %d / %d features differ between consecutive calls)", what, g.vis_varied[1],
              g.vis_varied[2], ndiff(g.a_varied[2], g.a_varied[3]), ndiff(g.a_varied[3], g.a_varied[4]), ndiff(g.a_varied[4], g.a_varied[5]));
-      EXPECT(g.a_stale == g.a_fused, "moved points were noticed without a change of the map's change index (%d features)", ndiff(g.a_stale, g.a_fused));
-      EXPECT(g.a_moved == c.a_moved && ndiff(g.a_moved, g.a_fused) > 20, "after IncreaseChangeIndex: %d features differ between the entry-point sets, %d from the unmoved map",
+      if (stamped)      // SetWorldPos moved the points' counters: seen at once, change index or not
+        EXPECT(g.a_stale == c.a_stale && ndiff(g.a_stale, g.a_fused) > 20, "[%s] points moved by SetWorldPos: %d features differ from the oracle's fresh read, %d from the unmoved map", what,
+               ndiff(g.a_stale, c.a_stale), ndiff(g.a_stale, g.a_fused));
+      else              // without a counter only the map's change index tells: the documented staleness until the next write-back
+        EXPECT(g.a_stale == g.a_fused, "[%s] moved points were noticed without a change of the map's change index (%d features)", what, ndiff(g.a_stale, g.a_fused));
+      EXPECT(g.a_moved == c.a_moved && ndiff(g.a_moved, g.a_fused) > 20, "[%s] after IncreaseChangeIndex: %d features differ between the entry-point sets, %d from the unmoved map", what,
              ndiff(g.a_moved, c.a_moved), ndiff(g.a_moved, g.a_fused));
-      EXPECT(g.a_delta == g.a_delta_fresh && c.a_delta == c.a_delta_fresh && g.a_delta == c.a_delta, "another pointer sequence: patched cache vs fresh read %d / %d, GPU vs oracle %d",
+      EXPECT(g.a_delta == g.a_delta_fresh && c.a_delta == c.a_delta_fresh && g.a_delta == c.a_delta, "[%s] another pointer sequence: patched cache vs fresh read %d / %d, GPU vs oracle %d", what,
              ndiff(g.a_delta, g.a_delta_fresh), ndiff(c.a_delta, c.a_delta_fresh), ndiff(g.a_delta, c.a_delta));
       int nd = 0; for (int v : g.a_delta) nd += v >= 0;
-      EXPECT(nd > 100, "the patched local map matched only %d features", nd);
-    }
+      EXPECT(nd > 100, "[%s] the patched local map matched only %d features", what, nd);
+    };
+    check_local_map_cache(g, true, "change counter");
+    g_seed = 7; const TrackOut gh = run_tracking<GpuHeuristicOps>(rig, tex);
+    check_local_map_cache(gh, false, "no change counter");
     EXPECT(g.n_bow == c.n_bow && g.a_bow == c.a_bow && g.n_bow > 20, "SearchByBoW %d vs %d", g.n_bow, c.n_bow);
     EXPECT(g.n_reloc1 == c.n_reloc1 && g.n_reloc2 == c.n_reloc2 && g.a_reloc == c.a_reloc && g.n_reloc1 > 20,
            "SearchByProjection(F, KF, sAlreadyFound): %d / %d vs %d / %d new matches", g.n_reloc1, g.n_reloc2, c.n_reloc1, c.n_reloc2);

@@ -48,7 +48,7 @@ class MapPoint {
   Mat GetNormal() const { return mNormalVector; }
   Mat GetDescriptor() const { return mDescriptor; }
   int n_locked_pos_writes = 0;
-  // the change counter the glue's local-BA window cache looks for (one member, ++ in the four mutators)
+  // the change counter the glue's caches look for (one member, ++ in the mutators of what the glue reads)
   long unsigned mnChangeStamp = 0;
   mutable int n_obs_copies = 0, n_pos_clones = 0;
   void SetWorldPos(const Mat& X, bool bLock = false, bool /*bLockSend*/ = false) { mWorldPos = X; n_locked_pos_writes += bLock; mnChangeStamp++; }   // I/MapPoint.h:126
@@ -56,7 +56,8 @@ class MapPoint {
   void AddObservation(KeyFrame* kf, int idx) { if (!mObservations.count(kf)) nObs++; mObservations[kf] = std::make_tuple(idx, -1); mnChangeStamp++; }
   void EraseObservation(KeyFrame* kf) { if (mObservations.erase(kf)) nObs--; mnChangeStamp++; }
   void SetBadFlag() { mbBad = true; mObservations.clear(); nObs = 0; mnChangeStamp++; }
-  void UpdateNormalAndDepth() { n_normal_updates++; }
+  void UpdateNormalAndDepth() { n_normal_updates++; mnChangeStamp++; }
+  void Touch() { mnChangeStamp++; }      // what ComputeDistinctiveDescriptors / UpdateNormalAndDepth do to the counter when a test writes their fields directly
 };
 
 class Map {
