@@ -118,6 +118,28 @@ int main() {
   }
   std::printf("GetObservations copies: cached %ld, uncached %ld; GetWorldPos clones: cached %ld, uncached %ld\n", oc[0], oc[1], pc[0], pc[1]);
   if (!(oc[0] * 3 < oc[1])) { std::printf("the cache did not spare the observation copies\n"); bad++; }
+  // ---- the cache's bookkeeping alone: 12000 points seen in an old window, 1500 in recent ones -> the old records are dropped, the
+  // table is rebuilt, every recent point is still found under its address and no address maps to a foreign record
+  {
+    auto& C = od::LbaWindowCache<KeyFrame, MapPoint>::instance();
+    C.clear();
+    std::vector<std::unique_ptr<MapPoint>> pts;
+    for (int i = 0; i < 12000; i++) { pts.emplace_back(new MapPoint); pts.back()->mnId = 50000 + i; }
+    C.call = 1;
+    for (auto& p : pts) { auto& r = C.recs[C.find_or_add(p.get())]; r.id = p->mnId; r.valid = true; r.seen = 1; }
+    C.call = 20;
+    for (int i = 0; i < 1500; i++) C.recs[C.find_or_add(pts[8 * i].get())].seen = 20;
+    const size_t before = C.recs.size();
+    C.drop_unseen(1500);
+    int wrong = 0;
+    for (int i = 0; i < 1500; i++) { const auto& r = C.recs[C.find_or_add(pts[8 * i].get())]; wrong += !(r.mp == pts[8 * i].get() && r.valid && r.id == pts[8 * i]->mnId); }
+    const size_t kept = C.recs.size();
+    const int32_t again = C.find_or_add(pts[1].get());             // a dropped point comes back as a fresh (invalid) record
+    wrong += C.recs[again].valid || C.recs[again].mp != pts[1].get();
+    std::printf("cache bookkeeping: %zu records before, %zu after dropping the unseen, %d wrong look-ups\n", before, kept, wrong);
+    if (before != 12000 || kept != 1500 || wrong) bad++;
+    C.clear();
+  }
   std::printf(bad ? "FAILED\n" : "ALL OK\n");
   return bad ? 1 : 0;
 }
