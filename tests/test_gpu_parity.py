@@ -1691,3 +1691,7 @@ def test_ldlt_kernels_against_a_long_double_host_factorisation():
     sizes = [ln for ln in r.stdout.splitlines() if ln.startswith("n=")]
     assert len(sizes) == 16, sizes
     assert sum("xcd (8 workgroups" in ln for ln in r.stdout.splitlines()) == 9 and "xcd zero pivot: ok=0 ok" in r.stdout, r.stdout[-3000:]
+    # 20000 launches of the eight-workgroup kernel on two alternating systems, the participating XCD changing every 64 launches and the
+    # launch counter wrapping half way: every sampled result bit-identical to the first of its size, no wait that does not end
+    r = subprocess.run([exe, "stress", "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "stress: 20000 launches, ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -68,11 +69,50 @@ int main(int argc, char** argv) {
     printf("mfma_f64_16x16x4 layout probe: %s (%d mismatches)\n", bad ? "FAIL" : "ok", bad);
     fails += bad != 0;
   }
+  if (argc > 2 && !strcmp(argv[1], "stress")) {
+    // ./ldlt_mfma_test stress N: N launches of the eight-workgroup kernel on two alternating systems (150 and 300 unknowns, other
+    // XCD every 64 launches), every result compared bit for bit with the first one of its size
+    const int N = atoi(argv[2]);
+    std::mt19937_64 rs(777);
+    std::normal_distribution<double> G01(0.0, 1.0);
+    struct Sys { int n; double* dS; double* dx; int* dok; std::vector<double> first; } sys[2] = {{150}, {300}};
+    for (auto& y : sys) {
+      const int n = y.n;
+      std::vector<double> M((size_t)n * n), S((size_t)n * n), b(n);
+      for (auto& v : M) v = G01(rs);
+      for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) { double a = 0; for (int k = 0; k < n; k++) a += M[(size_t)i * n + k] * M[(size_t)j * n + k]; if (i == j) a += 0.05 * n; S[(size_t)i * n + j] = S[(size_t)j * n + i] = a; }
+      for (auto& v : b) v = G01(rs);
+      std::vector<double> im(ldltm::tile_image_doubles(n), 0.0);
+      for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { const int pos = ldltm::tile_image_pos(r, c); if (pos >= 0) im[pos] = S[(size_t)r * n + c]; }
+      for (int r = 0; r < n; r++) ldltm::image_put_rhs(im.data(), n, r, b[r]);
+      CK(hipMalloc(&y.dS, im.size() * 8)); CK(hipMalloc(&y.dx, n * 8)); CK(hipMalloc(&y.dok, 4));
+      CK(hipMemcpy(y.dS, im.data(), im.size() * 8, hipMemcpyHostToDevice));
+      CK(ldltm::launch_image_pad(n, y.dS, 0));
+    }
+    ldltx::Context cx[2];
+    int bad = 0;
+    for (int it = 0; it < N; it++) {
+      Sys& y = sys[it & 1];
+      ldltx::Context& c = cx[it & 1];
+      c.pick = (it >> 6) & 7;
+      if (it == N / 2 || it == N / 2 + 1) c.epoch = 0xFFFFFDu;          // the launch counter wraps three launches later (flags cleared, counter restarts)
+      CK(ldltx::launch(c, y.n, y.dS, y.dx, y.dok, 0));
+      if (it < 2 || it % 997 == 0 || it >= N - 2 || (it >= N / 2 && it < N / 2 + 12)) {
+        std::vector<double> x(y.n); int ok = 0;
+        CK(hipMemcpy(x.data(), y.dx, y.n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok, y.dok, 4, hipMemcpyDeviceToHost));
+        if (y.first.empty()) y.first = x;
+        if (ok != 1 || memcmp(x.data(), y.first.data(), y.n * 8)) { printf("launch %d (n=%d): ok=%d, result differs from the first\n", it, y.n, ok); bad++; }
+      }
+    }
+    CK(hipDeviceSynchronize());
+    printf("stress: %d launches, %s\n", N, bad ? "FAILED" : "ALL OK");
+    return bad ? 1 : 0;
+  }
   std::mt19937_64 rng(12345);
   std::normal_distribution<double> N01(0.0, 1.0);
   const int sizes_all[] = {6, 12, 18, 60, 96, 114, 120, 126, 132, 138, 150, 204, 222, 240, 270, 300};
   const int sizes_q[] = {120};   // quick mode: the C2 window only
-  const bool quick = argc > 1;
+  const bool quick = argc > 1 && strcmp(argv[1], "stress");
   const int* sizes = quick ? sizes_q : sizes_all;
   const int nsizes = quick ? 1 : 16;
   for (int si = 0; si < nsizes; si++) {
