@@ -122,12 +122,19 @@ __device__ long long g_xprof[1024];
 #define LDLTX_T(i) do { } while (0)
 #endif
 
-#ifdef LDLTX_WATCHDOG                       // (micro-benchmark builds: a wait that does not end reports where and lets the kernel finish)
+// Every in-kernel wait is bounded: after ~16 M polls (seconds; a hand-over takes a microsecond) the wavefront gives up, marks the
+// solve as failed (ok = 0: the LM step is rejected like a non-positive pivot) and lets the kernel end -- a participant that the
+// dispatcher never placed must not turn into a GPU that never comes back.  -DLDLTX_WATCHDOG (micro-benchmark builds) gives up
+// sooner and records which wait it was.
+#ifdef LDLTX_WATCHDOG
 __device__ int g_xdog[16];
-#define LDLTX_DOG(where, a, b) do { if (++dog_ > (1 << 22)) { if (lane == 0 && atomicAdd(&g_xdog[0], 1) == 0) { g_xdog[1] = (where); g_xdog[2] = gw_; g_xdog[3] = (a); g_xdog[4] = (b); } bail_ = true; } } while (0)
+#define LDLTX_DOG_LIMIT (1 << 22)
+#define LDLTX_DOG_RECORD(where, a, b) do { if (lane == 0 && atomicAdd(&g_xdog[0], 1) == 0) { g_xdog[1] = (where); g_xdog[2] = gw_; g_xdog[3] = (a); g_xdog[4] = (b); } } while (0)
 #else
-#define LDLTX_DOG(where, a, b) do { } while (0)
+#define LDLTX_DOG_LIMIT (1 << 24)
+#define LDLTX_DOG_RECORD(where, a, b) do { } while (0)
 #endif
+#define LDLTX_DOG(where, a, b) do { if (++dog_ > LDLTX_DOG_LIMIT) { LDLTX_DOG_RECORD(where, a, b); if (lane == 0) __hip_atomic_store(flags + kFBad, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bail_ = true; } } while (0)
 
 __device__ __forceinline__ unsigned xcc_id() {
   unsigned v;
@@ -148,8 +155,8 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   const int kP = plan.np, kW = kP * kWgWaves;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
-  [[maybe_unused]] int dog_ = 0, gw_ = (int)(blockIdx.x >> 3) * kWgWaves + wv;
-  [[maybe_unused]] bool bail_ = false;
+  int dog_ = 0; [[maybe_unused]] const int gw_ = (int)(blockIdx.x >> 3) * kWgWaves + wv;
+  bool bail_ = false;                      // a wait gave up (LDLTX_DOG): every later wait of this wavefront returns at once
 #ifdef LDLTX_PROFILE
   const long long t_enter = wall_clock64();
 #endif
@@ -204,6 +211,8 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
     const unsigned f = ld_flag(flags + kFElect + min(lane, kP - 1));
     if (__builtin_amdgcn_ballot_w64((f >> 8) != ep) == 0) { safe = plan.force_safe || __builtin_amdgcn_ballot_w64((f & 0xFFu) != my_xcc) != 0; break; }
     __builtin_amdgcn_s_sleep(1);
+    LDLTX_DOG(7, 0, 0);                    // (a participant that was never placed)
+    if (bail_) { safe = true; break; }
   }
 #ifdef LDLTX_PROFILE
   if (gw == 0) { LDLTX_T(0); if (lane == 0) g_xprof[12] = safe; }

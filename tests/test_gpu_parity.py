@@ -1695,3 +1695,11 @@ def test_ldlt_kernels_against_a_long_double_host_factorisation():
     # launch counter wrapping half way: every sampled result bit-identical to the first of its size, no wait that does not end
     r = subprocess.run([exe, "stress", "20000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "stress: 20000 launches, ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+    # a participant that the dispatcher never places (here: a grid one participant short): every wait gives up after its bound, the
+    # solve comes back failed (ok = 0) instead of never (-DXWATCHDOG: the bound is 4 M polls instead of 16 M, and the wait is named)
+    exe_wd = os.path.join(root, "tools", "micro", "ldlt_mfma_test_wd")
+    if not os.path.exists(exe_wd) or os.path.getmtime(exe_wd) < max(os.path.getmtime(p) for p in (src, hdr, hdr2, inc)):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-DNO_PROFILE", "-DXWATCHDOG", "-o", exe_wd, src],
+                              timeout=900)
+    r = subprocess.run([exe_wd], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "xcd with a participant missing: ok=0" in r.stdout and "FAIL" not in r.stdout, r.stdout[-2000:] + r.stderr[-500:]

@@ -280,6 +280,20 @@ int main(int argc, char** argv) {
         printf("\n");
       }
 #endif
+#ifdef LDLTX_WATCHDOG
+      if (n == 300 && np == 8) {   // a participant that is never placed (a grid one participant short): every wait gives up, ok = 0, no hang
+        cx.epoch++;
+        hipLaunchKernelGGL(ldltx::k_ldlt_xcd, dim3(8 * (np - 2) + 1), dim3(ldltx::kThreads), 0, 0, n, dS, dx, dok, cx.scr, cx.flags, cx.epoch, cx.plan);
+        CK(hipDeviceSynchronize());
+        int ok3 = -7, dg[16];
+        CK(hipMemcpy(&ok3, dok, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpyFromSymbol(dg, HIP_SYMBOL(ldltx::g_xdog), sizeof(dg)));
+        printf("   xcd with a participant missing: ok=%d, %d waits gave up (first: where %d) %s\n", ok3, dg[0], dg[1], ok3 == 0 && dg[0] > 0 && dg[1] == 7 ? "ok" : "FAIL");
+        fails += !(ok3 == 0 && dg[0] > 0 && dg[1] == 7);
+        int z[16] = {0};
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(ldltx::g_xdog), z, sizeof(z)));
+      }
+#endif
       if (n == 300 && np == 8) {
         std::vector<double> S2 = S;
         for (int i = 0; i < n; i++) S2[i] = S2[(size_t)i * n] = 0.0;
