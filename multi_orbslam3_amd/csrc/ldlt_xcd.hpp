@@ -14,6 +14,8 @@
 // users spread over the XCDs that takes more than 32 concurrent solves of 21+ free poses on one GPU (one agent per GPU has one).  Every participant posts HW_REG_XCC_ID; if the ids differ (another partition mode, a changed
 // dispatcher) every hand-over becomes an agent-scope release / acquire pair: slower (147 us), correct, tested (ORBG_LDLT_XCD=safe).
 // Flags carry the launch's number (epoch): nothing is cleared between launches.
+// G and D^-1 of a diagonal tile -- the one hand-over per tile row on the critical path -- travel without a flag, as self-validating
+// (value, value ^ tag) pairs: the producer does not wait for its stores and the consumer's poll is its load (see st_pair / get_G).
 // Schedule: column j's last four tiles (j-3, j) .. (j, j) sit on one "chain" wavefront, which per row k = j-3 .. j-1 spins on
 // G_k's flag, solves (k, j), updates the tiles below from registers / one L2 image, and for k = j-1 runs the pivots of (j, j) at
 // once: ONE hand-over per tile row on the critical path.  The other tiles, <= 4 per wavefront, are taken one after the other (every
@@ -45,13 +47,13 @@ constexpr int kMaxNS = 8;                   // tile slots per wavefront in the p
 constexpr int kMaxT = ldltm::kMaxT;
 constexpr int kNY = 5;                      // 64-lane groups of the solution vector (n_pad <= 320)
 // flag words
-constexpr int kFDiag = 0, kFPanel = 32, kFWave = kFPanel + kMaxT * kMaxT, kFElect = kFWave + 128, kFBad = kFElect + 16;
+constexpr int kFDiag = 0 /* (unused since G travels as self-validating pairs) */, kFPanel = 32, kFWave = kFPanel + kMaxT * kMaxT, kFElect = kFWave + 128, kFBad = kFElect + 16;
 constexpr int kFlagStride = 640;             // one copy of the flags per participant (its wavefronts poll that copy only)
 constexpr int kFlagWords = kFlagStride * kMaxP;
 // scratch (doubles)
 constexpr size_t kPanOff = 0, kPanDoubles = (size_t)kMaxT * kMaxT * 512;
-constexpr size_t kGbOff = kPanOff + kPanDoubles, kGbDoubles = (size_t)kMaxT * 16 * kGld;
-constexpr size_t kDvOff = kGbOff + kGbDoubles, kDvDoubles = (size_t)kMaxT * 16;
+constexpr size_t kGbOff = kPanOff + kPanDoubles, kGbDoubles = 2 * (size_t)kMaxT * 16 * kGld;      // (value, value ^ tag) pairs
+constexpr size_t kDvOff = kGbOff + kGbDoubles, kDvDoubles = 2 * (size_t)kMaxT * 16;
 constexpr size_t kWOff = kDvOff + kDvDoubles;
 __host__ inline size_t scratch_doubles() { return kWOff + ldltm::wglob_doubles(make_geo(16 * kMaxT - 20)) + 1024; }
 
@@ -178,12 +180,11 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   const Geo G = make_geo(n);
   const int T = G.T, n_pad = G.n_pad, cb = G.cb;
   double* const Pan = scr + kPanOff;      // [T][T][2][256]: -R and W of panel tile (k, j), operand layout = accumulator layout
-  double* const Gb = scr + kGbOff;        // [T][16 * kGld]
-  double* const Dv = scr + kDvOff;        // [T][16]
+  double* const Gb = scr + kGbOff;        // [T][16 * kGld] self-validating pairs
+  double* const Dv = scr + kDvOff;        // [T][16] self-validating pairs
   double* const Wg = scr + kWOff;         // the unit upper factor, column-packed: entry (I, J), I < J, at J (J - 1) / 2 + I
   // (every participant polls its own copy of the G / panel flags: sixty-four wavefronts polling one cache line queue up in the
   // L2 channel that holds it -- an idle sweep took 3 us; the publisher writes the eight copies with one store instruction)
-  unsigned* const f_diag = flags + rank * kFlagStride + kFDiag;
   unsigned* const f_panel = flags + rank * kFlagStride + kFPanel;
   auto wm_store = [&](int I, int J, double v) { Wg[J * (J - 1) / 2 + I] = v; };
 
@@ -223,6 +224,55 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
     if (lane < (copies ? kMaxP : 1)) __hip_atomic_store(flags + lane * kFlagStride + idx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto acquire = [&]() { if (safe) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); };
+  // G and D^-1 of a diagonal tile travel WITHOUT a flag: every value v is stored as the pair (v, v ^ tag), tag a 64-bit hash of
+  // the launch number, with two agent-scope 8-byte stores; a reader loads both words and takes the value when their XOR is the tag
+  // -- a word of an earlier launch, or one of the two not yet arrived, fails the test (two unrelated doubles XOR to the tag with
+  // probability 2^-64).  The producer does not wait for its stores (0.25 us per tile row on the chain), the consumer's poll IS its
+  // load (one L2 round trip instead of flag + data), and the words are coherent across XCDs as they are (agent-scope accesses).
+  const unsigned long long tag = (0x9E3779B97F4A7C15ull * (unsigned long long)(epoch + 1u)) | 1ull;
+  auto st_pair = [&](double* p, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    if (safe) {                              // across XCDs: write-through stores
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, b ^ tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {                                 // one L2: plain stores (the vector L1 writes through to it)
+      typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<ull2*>(p) = ull2{b, b ^ tag};
+    }
+  };
+  // G_k (as the panel's A operand chunks) and D_k^-1 for this lane; `eager`: the caller's next step is this G (a chain wavefront):
+  // poll with the full load; otherwise poll one word first (sixteen wavefronts polling 8 KB each would be 400 GB/s of L2 traffic)
+  auto get_G = [&](int k, double (&Gf)[4], double (&dv4)[4], bool eager) {
+    const double* const gk = Gb + (size_t)k * 32 * kGld;
+    const double* const dk = Dv + (size_t)k * 32;
+    if (!eager) {
+      for (;;) {
+        const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(dk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(dk) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane((unsigned)((a ^ b) == tag)) || bail_) break;
+        LDLTX_DOG(1, k, 0);
+      }
+    }
+    for (;;) {
+      unsigned long long a[8], b[8];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const unsigned long long* const pg = reinterpret_cast<const unsigned long long*>(gk + 2 * ((4 * q + lr) * kGld + lc));
+        const unsigned long long* const pd = reinterpret_cast<const unsigned long long*>(dk + 2 * (lr + 4 * q));
+        a[q] = __hip_atomic_load(pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b[q] = __hip_atomic_load(pg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a[4 + q] = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b[4 + q] = __hip_atomic_load(pd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      bool good = true;
+#pragma unroll
+      for (int q = 0; q < 8; q++) good = good && (a[q] ^ b[q]) == tag;
+      if (__builtin_amdgcn_ballot_w64(!good) == 0 || bail_) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { Gf[q] = __longlong_as_double((long long)a[q]); dv4[q] = __longlong_as_double((long long)a[4 + q]); }
+        break;
+      }
+      LDLTX_DOG(1, k, 1);
+    }
+  };
 
   // ---- the pivots of diagonal tile k, two per matrix instruction (ldltm::k_ldlt_mfma's `factor`), G and D^-1 to the L2
   auto factor = [&](int k) {
@@ -272,12 +322,11 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
     }
     const bool good = fabs(rlast) < INFINITY;
     LDLTX_T(16 + 8 * k + 1);
-    double* const gk = Gb + (size_t)k * 16 * kGld;
+    double* const gk = Gb + (size_t)k * 32 * kGld;
 #pragma unroll
-    for (int g = 0; g < 4; g++) gk[lc * kGld + lr + 4 * g] = Gc[g];
-    if (lane < 16) Dv[k * 16 + lane] = dvv;
+    for (int g = 0; g < 4; g++) st_pair(gk + 2 * (lc * kGld + lr + 4 * g), Gc[g]);
+    if (lane < 16) st_pair(Dv + (size_t)k * 32 + 2 * lane, dvv);
     if (!good && lane == 0) __hip_atomic_store(flags + kFBad, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    publish(kFDiag + k, true);
     LDLTX_T(16 + 8 * k + 2);
 #pragma unroll
     for (int g = 0; g < 4; g++) {              // the factor's rows are not needed before the back-substitution
@@ -366,12 +415,8 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
         r += m; fa += (unsigned)m * row_words; fb += (unsigned)m * row_words; oa_off += (unsigned)m * row_doubles; ow_off += (unsigned)m * row_doubles;
       }
       // the tile against G_i
-      spin(f_diag + i, 1, i);
-      acquire();
       double Gf[4], dv4[4];
-      const double* const gk = Gb + (size_t)i * 16 * kGld;
-#pragma unroll
-      for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + i * 16 + lr + 4 * q); }
+      get_G(i, Gf, dv4, false);
       d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
       R0 = mfma(Gf[0], c[0], R0);
       R1 = mfma(Gf[2], c[2], R1);
@@ -457,14 +502,9 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
       constexpr int S = decltype(SC)::value;
       if (!on[S]) return;
       const int k = ti[S], j = tj[S];
-      spin(f_diag + k, 1, k);
-      acquire();
-      if (S == D - 1) LDLTX_T(16 + 8 * k + 6);
       double Gf[4], dv4[4];
-      const double* const gk = Gb + (size_t)k * 16 * kGld;
-#pragma unroll
-      for (int q = 0; q < 4; q++) { Gf[q] = ld_l2(gk + (4 * q + lr) * kGld + lc); dv4[q] = ld_l2(Dv + k * 16 + lr + 4 * q); }
-      if (S == D - 1) LDLTX_T(16 + 8 * k + 3);
+      get_G(k, Gf, dv4, true);
+      if (S == D - 1) { LDLTX_T(16 + 8 * k + 6); LDLTX_T(16 + 8 * k + 3); }
       const d4 X = acc[S];
       d4 R0 = {0.0, 0.0, 0.0, 0.0}, R1 = {0.0, 0.0, 0.0, 0.0};
       R0 = mfma(Gf[0], X[0], R0);
