@@ -553,6 +553,11 @@ int lba_wait(lba_handle* h, double* solve_ms /* wall time of that solve on the w
 int lba_set_profiling(lba_handle* h, int on, int reset);
 int lba_get_solver_stats(lba_handle* h, double* sum_ms, int64_t* n_brackets, int32_t* n_unknowns, int32_t* matrix_core);
 int lba_event_overhead(lba_handle* h, int reps, float* ms);
+/* Health of the handle's solver: how many launches of the eight-workgroup LDL^T (windows of 21 .. 50 free poses) gave up waiting
+ * for a participant the dispatcher did not place within 2 s.  Such a launch is NOT taken for a non-positive-definite system (which
+ * g2o answers with a rejected LM step, G/core/optimization_algorithm_levenberg.cpp:118-127): the window is solved again on the
+ * one-workgroup kernels, which the handle then keeps using, and the event is counted here.  0 on a healthy box. */
+int lba_get_watchdog_count(lba_handle* h, int64_t* n_timeouts);
 
 /* ---------------------------------------------------------------- pose-only optimisation */
 

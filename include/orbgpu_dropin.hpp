@@ -225,6 +225,17 @@ inline size_t vertex_id(long unsigned id, unsigned client, bool is_kf) {       /
   return is_kf ? IDRANGE * client + id : IDRANGE * (MAXAGENTS + client) + id;
 }
 
+// ------------------------------------------------------------------------------------------------ MapPoint access
+// The scale-invariance range as the members hold it.  mfMinDistance / mfMaxDistance are PROTECTED in the reference
+// (I/MapPoint.h:244,281-282) and its public getters return 0.8f * / 1.2f * the members (S/MapPoint.cc:617-627), from which the
+// members cannot be recovered bit for bit -- and PredictScale (S/MapPoint.cc:646-661), which the device evaluates, needs the raw
+// mfMaxDistance.  INTEGRATION.md's list of reference-side edits therefore adds two public getters, GetMinDistance() /
+// GetMaxDistance() (edit E1); a MapPoint type whose members are accessible (a friend declaration, an older fork) works unchanged.
+template <class MapPointT> auto min_distance_raw(MapPointT* p, int) -> decltype((float)p->GetMinDistance()) { return p->GetMinDistance(); }
+template <class MapPointT> auto min_distance_raw(MapPointT* p, long) -> decltype((float)p->mfMinDistance) { return p->mfMinDistance; }
+template <class MapPointT> auto max_distance_raw(MapPointT* p, int) -> decltype((float)p->GetMaxDistance()) { return p->GetMaxDistance(); }
+template <class MapPointT> auto max_distance_raw(MapPointT* p, long) -> decltype((float)p->mfMaxDistance) { return p->mfMaxDistance; }
+
 // ------------------------------------------------------------------------------------------------ isInFrustum (batch)
 // The loop of Tracking::SearchLocalPoints (S/Tracking.cc:3111-3128): F.isInFrustum(pMP, 0.5) for every candidate, which
 // stores the mTrack* fields in the map point (S/Frame.cc:529-538) and counts the visible ones.
@@ -238,9 +249,9 @@ int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewin
     MapPointT* p = vpMPs[i];
     const auto X = p->GetWorldPos(); const auto nv = p->GetNormal();
     std::memcpy(&pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&nrm[3 * (size_t)i], mat_f32(nv), 12);
-    // raw members (protected in the reference: add two getters there); the 0.8 / 1.2 factors of GetMin/MaxDistanceInvariance
-    // (S/MapPoint.cc:617-627) are applied inside the call
-    dmin[i] = p->mfMinDistance; dmax[i] = p->mfMaxDistance;
+    // the raw members (INTEGRATION.md edit E1); the 0.8 / 1.2 factors of GetMin/MaxDistanceInvariance (S/MapPoint.cc:617-627) are
+    // applied inside the call
+    dmin[i] = min_distance_raw(p, 0); dmax[i] = max_distance_raw(p, 0);
     const auto Dm = p->GetDescriptor();
     std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
     bad[i] = p->isBad(); nobs[i] = p->Observations();
@@ -269,31 +280,23 @@ int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewin
 // viewer, through F.mmProjectPoints: call isInFrustumAll instead when they are needed).  `th` is the value the reference
 // derives from the sensor / IMU / relocalisation state (:3131-3151).  Returns the number of matches (nToMatch == 0: 0).
 //
-// Round 4 -- the object walking is off the per-frame path WITHOUT touching the reference's classes.  Of the 148 us this body took at
-// C2 sizes, 97 were one GetWorldPos / GetNormal / GetDescriptor clone per local map point, every frame, for values that change when
-// (a) Tracking::UpdateLocalPoints puts other points into mvpLocalMapPoints (S/Tracking.cc:3157-3197) -- visible here as a different
-// pointer sequence -- or (b) LocalMapping moved / re-described points, which ends in the local BA's write-back and its
-// pMap->IncreaseChangeIndex() (S/Optimizer.cc:2375-2408; the glue's own LocalBundleAdjustment below does the same), like every
-// other map-changing optimisation (S/Optimizer.cc:960,1807, S/LoopClosing.cc:1197-2827).  The calling thread therefore keeps the
-// flattened STATIC fields of the last call: same map, same change index, same pointer sequence => they are reused and the map the last
-// call uploaded stays resident on the device (Ops::search_local_resident); a different pointer sequence => the points seen before are
-// copied from the cache and only the new ones are cloned; another map or change index, or kLocalMapMaxAge calls without a refresh (a
-// keyframe whose local BA was aborted re-describes points without moving the index: the bound on that staleness) => everything is
-// read again.  The per-frame fields -- mnLastFrameSeen, isBad(), Observations() -- are read every call, as the reference does.
-//
-// Round 5 -- what the map's change index does NOT cover.  LocalMapping re-describes points WITHOUT moving the index: ProcessNewKeyFrame
-// (AddObservation + UpdateNormalAndDepth + ComputeDistinctiveDescriptors per point of the new keyframe, S/LocalMapping.cc:405-425),
-// SearchInNeighbors' fusions (:857-859, :968-969), Tracking's own new points (S/Tracking.cc:2295-2296, :4053-4055), and a local BA
-// that is aborted returns before IncreaseChangeIndex (S/Optimizer.cc:2127-2129).  Every one of them changes the point's OBSERVATIONS
-// first (the descriptor is the medoid of the observations' descriptors, normal / distance range are functions of the observing
-// keyframes) or its distance members.  So every call compares, per point, what it reads anyway -- Observations() -- and the two raw
-// distance members with the values cached next to the statics: a point whose count or range moved is re-read (three clones for that
-// point only) and the resident map is uploaded again for this call.  What remains assumed: a point's descriptor / normal do not
-// change while its observation count, its distance range and the map's change index all stay the same between two consecutive frames
-// (an erase + add pair on one point within one frame time); kLocalMapMaxAge calls bound even that.  Define
-// ORBGPU_DROPIN_EXACT_LOCAL_MAP to read every point's statics on every call (the reference's cost, no assumption).
-// (Later in round 5: a MapPoint that carries the change counter of INTEGRATION.md section 3 makes this cache exact -- see below.)
-// A Map type without GetMapChangeIndex() does not compile here (there would be no signal for moved points at all).
+// What is read when (round 6: the reference's semantics are the default).
+//  * A MapPoint WITHOUT a change counter -- the reference's class as it is, plus edit E1 -- : every call reads every point's world
+//    position, normal, distance range and descriptor, exactly as the reference's isInFrustum + SearchByProjection do (three clones
+//    per point: 97 of the 148 us this body takes at C2 sizes).  No cache, no assumption.
+//  * A MapPoint WITH the change counter of INTEGRATION.md edit E2 (std::atomic<unsigned long> mnChangeStamp, incremented once per
+//    call by the six mutators of the fields read here, after their stores): the calling thread keeps the flattened static fields of
+//    its last call and the device keeps the map that call uploaded; a point is re-read if and only if its counter moved -- by the
+//    local BA's write-back, ProcessNewKeyFrame, a fusion, anybody.  Exact as well: nothing is assumed about which code paths
+//    change a point.  The per-frame fields -- mnLastFrameSeen, isBad(), Observations() -- are read on every call in both forms.
+//  * OPT-IN, counter-less cache (-DORBGPU_DROPIN_HEURISTIC_LOCAL_MAP, or an entry-point set with kHeuristicLocalMap = true), for
+//    an integrator who wants the cached speed without touching MapPoint.cc: statics are reused while the map, its
+//    GetMapChangeIndex() and the pointer sequence are the same and a point's Observations() and distance range are what they were
+//    when it was read, for at most kLocalMapMaxAge calls.  It is NOT the reference's semantics: a point re-described without a
+//    change of any of those (an erase + add pair on one point within one frame time; SetWorldPos by a thread that does not move the
+//    change index) is seen only at the next refresh.  dropin_parity pins exactly that difference.
+// -DORBGPU_DROPIN_EXACT_LOCAL_MAP forces the first form even with a counter (A/B measurements).
+// A Map type without GetMapChangeIndex() compiles in the two exact forms; the heuristic one needs it (static_assert below).
 constexpr unsigned kLocalMapMaxAge = 30;
 struct LocalMapCache {
   std::vector<const void*> ptrs;
@@ -307,15 +310,15 @@ struct LocalMapCache {
   void invalidate() { ptrs.clear(); map = nullptr; change_index = -1; age = 0; index.clear(); index_valid = false; }
 };
 template <class Ops> inline LocalMapCache& local_map_cache() { static thread_local LocalMapCache c; return c; }    // (one per entry-point set)
-// A MapPoint that carries a change counter (long unsigned mnChangeStamp, ++ in every mutator of the fields read here: INTEGRATION.md
-// section 3) makes this cache EXACT: a point's statics are re-read if and only if its counter moved -- no change index, no age
-// bound, no assumption.  An entry-point set with `kNoChangeStamp = true` keeps the counter-less rules (tests).
+// An entry-point set with `kNoChangeStamp = true` behaves as if MapPoint had no counter (tests: the mocks carry one).
 template <class T, class = void> struct has_change_stamp : std::false_type {};
 template <class T> struct has_change_stamp<T, std::void_t<decltype(std::declval<T&>().mnChangeStamp)>> : std::true_type {};
 template <class Ops, class = void> struct stamp_off : std::false_type {};
 template <class Ops> struct stamp_off<Ops, std::void_t<decltype(Ops::kNoChangeStamp)>> : std::integral_constant<bool, Ops::kNoChangeStamp> {};
 template <class MapPointT> auto stamp_of(const MapPointT* p, int) -> decltype((unsigned long)p->mnChangeStamp) { return (unsigned long)p->mnChangeStamp; }
 template <class MapPointT> unsigned long stamp_of(const MapPointT*, long) { return 0; }
+template <class Ops, class = void> struct heuristic_local_map : std::false_type {};
+template <class Ops> struct heuristic_local_map<Ops, std::void_t<decltype(Ops::kHeuristicLocalMap)>> : std::integral_constant<bool, Ops::kHeuristicLocalMap> {};
 template <class Ops, class = void> struct has_search_local_resident : std::false_type {};
 template <class Ops> struct has_search_local_resident<Ops, decltype((void)&Ops::search_local_resident)> : std::true_type {};
 template <class MapPointT> auto change_index_of(MapPointT* p, int) -> decltype((long long)p->GetMap()->GetMapChangeIndex()) {
@@ -326,12 +329,9 @@ template <class MapPointT> auto change_index_of(MapPointT* p, int) -> decltype((
 // kExactLocalMap = true` (tests/cpp: the oracle's set, so that the product's cache is checked against uncached semantics)
 template <class Ops, class = void> struct exact_local_map : std::false_type {};
 template <class Ops> struct exact_local_map<Ops, typename std::enable_if<Ops::kExactLocalMap>::type> : std::true_type {};
-template <class MapPointT> struct no_change_index : std::false_type {};
-template <class MapPointT> long long change_index_of(MapPointT*, long) {
-  static_assert(no_change_index<MapPointT>::value, "orbgpu::dropin::SearchLocalPoints needs MapPoint::GetMap()->GetMapChangeIndex() (I/Map.h): without it "
-                                                   "nothing signals that the local BA moved the points");
-  return 0;
-}
+template <class MapPointT> long long change_index_of(MapPointT*, long) { return -1; }       // (no GetMapChangeIndex(): only the exact forms may be used)
+template <class MapPointT, class = void> struct has_change_index : std::false_type {};
+template <class MapPointT> struct has_change_index<MapPointT, std::void_t<decltype(std::declval<MapPointT&>().GetMap()->GetMapChangeIndex())>> : std::true_type {};
 
 template <class Ops = GpuOps, class FrameT, class MapPointT>
 int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints, float th, bool bFarPoints, float thFarPoints, float mfNNratio = 0.8f) {
@@ -359,33 +359,36 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
     nobs[i] = bad[i] ? 0 : p->Observations();
     if (!map && !bad[i]) { map = (const void*)p->GetMap(); ci = change_index_of(p, 0); }
   }
-  // ---- static fields: reuse / patch / re-read
+  // ---- static fields: read (the default without a counter) / reuse, patch, re-read (counter: exact; heuristic: opt-in)
 #ifdef ORBGPU_DROPIN_EXACT_LOCAL_MAP
-  constexpr bool kStamped = false;
+  constexpr bool kStamped = false, kHeuristic = false;
 #else
   constexpr bool kStamped = has_change_stamp<MapPointT>::value && !stamp_off<Ops>::value && !exact_local_map<Ops>::value;
+#ifdef ORBGPU_DROPIN_HEURISTIC_LOCAL_MAP
+  constexpr bool kHeuristic = !kStamped && !exact_local_map<Ops>::value;
+#else
+  constexpr bool kHeuristic = !kStamped && !exact_local_map<Ops>::value && heuristic_local_map<Ops>::value;
 #endif
+#endif
+  static_assert(!kHeuristic || has_change_index<MapPointT>::value, "the counter-less local-map cache needs MapPoint::GetMap()->GetMapChangeIndex() (I/Map.h): "
+                                                                    "without it nothing signals that the local BA moved the points");
   auto read_statics = [&](int i) {
     MapPointT* p = vpLocalMapPoints[i];
     C.stamp[i] = stamp_of(p, 0);                       // BEFORE the fields: a change during the read is seen on the next call
     const auto X = p->GetWorldPos(); const auto nv = p->GetNormal(); const auto Dm = p->GetDescriptor();
     std::memcpy(&C.pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&C.nrm[3 * (size_t)i], mat_f32(nv), 12);
-    C.dmin[i] = p->mfMinDistance; C.dmax[i] = p->mfMaxDistance;
+    C.dmin[i] = min_distance_raw(p, 0); C.dmax[i] = max_distance_raw(p, 0);
     std::memcpy(&C.desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
     C.nobs_seen[i] = nobs[i];
     C.have[i] = 1;
   };
   // a cached point is DIRTY when its observation count or its distance range is not what it was when its statics were read
   auto dirty = [&](int i) {
-    const MapPointT* p = vpLocalMapPoints[i];
+    MapPointT* p = vpLocalMapPoints[i];
     if (kStamped) return C.stamp[i] != stamp_of(p, 0);
-    return C.nobs_seen[i] != nobs[i] || C.dmin[i] != p->mfMinDistance || C.dmax[i] != p->mfMaxDistance;
+    return C.nobs_seen[i] != nobs[i] || C.dmin[i] != min_distance_raw(p, 0) || C.dmax[i] != max_distance_raw(p, 0);
   };
-#ifdef ORBGPU_DROPIN_EXACT_LOCAL_MAP
-  const bool fresh = true;
-#else
-  const bool fresh = exact_local_map<Ops>::value || C.ptrs.empty() || C.map != map || (!kStamped && (C.change_index != ci || C.age >= kLocalMapMaxAge));
-#endif
+  const bool fresh = !(kStamped || kHeuristic) || C.ptrs.empty() || C.map != map || (kHeuristic && (C.change_index != ci || C.age >= kLocalMapMaxAge));
   bool statics_same = false;
   if (!fresh && (int)C.ptrs.size() == M && std::memcmp(C.ptrs.data(), vpLocalMapPoints.data(), sizeof(void*) * (size_t)M) == 0) {
     statics_same = true;
@@ -403,10 +406,10 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
     std::vector<int> todo;
     for (int i = 0; i < M; i++) {
       const auto it = C.index.find((const void*)vpLocalMapPoints[i]);
-      const MapPointT* p = vpLocalMapPoints[i];
+      MapPointT* p = vpLocalMapPoints[i];
       const size_t j = it != C.index.end() ? (size_t)it->second : 0;
       const bool known = it != C.index.end() && !bad[i] &&
-                         (kStamped ? C.stamp[j] == stamp_of(p, 0) : C.nobs_seen[j] == nobs[i] && C.dmin[j] == p->mfMinDistance && C.dmax[j] == p->mfMaxDistance);
+                         (kStamped ? C.stamp[j] == stamp_of(p, 0) : C.nobs_seen[j] == nobs[i] && C.dmin[j] == min_distance_raw(p, 0) && C.dmax[j] == max_distance_raw(p, 0));
       if (known) {
         std::memcpy(&pos[3 * (size_t)i], &C.pos[3 * j], 12); std::memcpy(&nrm[3 * (size_t)i], &C.nrm[3 * j], 12);
         dmin[i] = C.dmin[j]; dmax[i] = C.dmax[j]; std::memcpy(&desc[32 * (size_t)i], &C.desc[32 * j], 32); have[i] = 1; seen[i] = C.nobs_seen[j];
@@ -521,7 +524,7 @@ int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapP
     if (found[i]) continue;
     const auto X = p->GetWorldPos(); const auto Dm = p->GetDescriptor();
     std::memcpy(&pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
-    dmin[i] = p->mfMinDistance; dmax[i] = p->mfMaxDistance;                                   // raw members: the 0.8 / 1.2 factors are applied inside
+    dmin[i] = min_distance_raw(p, 0); dmax[i] = max_distance_raw(p, 0);                       // raw members (edit E1): the 0.8 / 1.2 factors are applied inside
   }
   orbm_worldpoints_view wv{NK, pos.data(), nrm.data(), dmin.data(), dmax.data(), desc.data(), nobs.data(), bad.data(), nullptr};
   // CurrentFrame.mvpMapPoints[i2] != NULL blocks feature i2, whatever the point's observations (:2246-2247)
@@ -563,10 +566,11 @@ int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMa
 // Consecutive local-BA windows share ~95 % of their map points.  Reading a point costs the reference a std::map copy
 // (GetObservations) and a matrix clone (GetWorldPos), both under the point's mutexes, plus a sort of its observations: two thirds of
 // the glue's time.  A MapPoint type that carries a change counter
-//     long unsigned mnChangeStamp = 0;     // ++ in AddObservation, EraseObservation, SetWorldPos, SetBadFlag
+//     std::atomic<unsigned long> mnChangeStamp{0};     // +1 per call of AddObservation, EraseObservation, SetWorldPos, SetBadFlag,
+//                                                      // UpdateNormalAndDepth, ComputeDistinctiveDescriptors (INTEGRATION.md edit E2)
 // lets the calling thread (LocalMapping) keep each point's flattened observation list and position from window to window and
 // re-read only the points whose counter moved -- by this function's own write-back, which knows what it wrote, or by anybody else.
-// Without the member the points are read as before; an entry-point set with `kNoLbaCache = true` also reads them as before (tests).
+// Without the member the points are read as the reference reads them; an entry-point set with `kNoLbaCache = true` also does (tests).
 template <class Ops, class = void> struct lba_cache_off : std::false_type {};
 template <class Ops> struct lba_cache_off<Ops, std::void_t<decltype(Ops::kNoLbaCache)>> : std::integral_constant<bool, Ops::kNoLbaCache> {};
 
@@ -676,7 +680,7 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
     for (MapPointT* mp : lLocalMapPoints) {
       const int32_t ri = C.find_or_add(mp);
       typename Cache::Rec& rc = C.recs[ri];
-      const long unsigned stamp = mp->mnChangeStamp;        // read BEFORE the point: a change during the read is seen next time
+      const long unsigned stamp = stamp_of(mp, 0);          // read BEFORE the point: a change during the read is seen next time
       if (!rc.valid || rc.id != mp->mnId || rc.stamp != stamp) {
         rc.id = mp->mnId; rc.stamp = stamp; rc.valid = true; rc.vid = vertex_id(mp->mnId, mp->mnClientId, false);
         rc.obs.clear();
@@ -853,10 +857,16 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
       Xd[0] = opts[3 * j]; Xd[1] = opts[3 * j + 1]; Xd[2] = opts[3 * j + 2];
       vMP[j]->SetWorldPos(X, true);                                                          // :2386
       vMP[j]->UpdateNormalAndDepth();
-      if constexpr (kCached) {                               // what this thread knows of the point is current again
+      if constexpr (kCached) {
+        // What this thread knows of the point is current again IF nobody else touched it since it was read at the top of this call
+        // (the solve ran without the map mutex, and the point's own mutexes are not held here): the counter must have moved by
+        // exactly this thread's own two mutator calls (edit E2: once per call of SetWorldPos / UpdateNormalAndDepth).  Anything
+        // else -- AddObservation / EraseObservation / SetWorldPos / SetBadFlag by Tracking or the Communicator meanwhile -- and
+        // the record is dropped: the point is read again in the next window.
         typename Cache::Rec& rc = Cache::instance().recs[recOf[j]];
-        if (obsErased[j]) rc.valid = false;
-        else { rc.pos[0] = Xd[0]; rc.pos[1] = Xd[1]; rc.pos[2] = Xd[2]; rc.stamp = vMP[j]->mnChangeStamp; }
+        const long unsigned now = stamp_of(vMP[j], 0);
+        if (obsErased[j] || now - rc.stamp != 2) rc.valid = false;
+        else { rc.pos[0] = Xd[0]; rc.pos[1] = Xd[1]; rc.pos[2] = Xd[2]; rc.stamp = now; }
       }
     }
   }

@@ -136,7 +136,7 @@ EXPORTED_SYMBOLS = [
     "orbm_frame_download",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "lba_solve_async", "lba_wait", "pose_optimize",
     "lba_solve_b", "lba_solve_hb", "lba_solve_async_b",
-    "lba_set_profiling", "lba_get_solver_stats", "lba_event_overhead",
+    "lba_set_profiling", "lba_get_solver_stats", "lba_event_overhead", "lba_get_watchdog_count",
     "orbd_database_create", "orbd_database_destroy", "orbd_detect_n_best_candidates",
     "orbx_set_stream", "orbm_frame_set_stream", "orbm_map_set_stream", "lba_set_stream", "orbv_vocab_set_stream", "orbd_database_set_stream",
     "pose_opt_set_stream", "orbx_get_ctor_timeline", "orbm_map_set_observations", "orbm_search_by_projection_reloc", "orbm_lastview_create", "orbm_lastview_destroy", "orbm_lastview_upload",

@@ -702,6 +702,12 @@ class Optimizer:
         capi.check(self.lib.lba_get_solver_stats(self.h, C.byref(s), C.byref(n), C.byref(nu), C.byref(mc)), "lba_get_solver_stats")
         return s.value, n.value, nu.value, bool(mc.value)
 
+    def watchdog_count(self):
+        """Launches of the eight-workgroup LDL^T that timed out waiting for a participant (each re-solved on the one-workgroup kernels)."""
+        n = C.c_int64(0)
+        capi.check(self.lib.lba_get_watchdog_count(self.h, C.byref(n)), "lba_get_watchdog_count")
+        return n.value
+
     def event_overhead_ms(self, reps=100):
         ms = C.c_float(0.0)
         capi.check(self.lib.lba_event_overhead(self.h, int(reps), C.byref(ms)), "lba_event_overhead")

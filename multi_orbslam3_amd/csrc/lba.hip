@@ -1310,10 +1310,11 @@ struct StopRef {
 struct LbaSwitches {
   bool ldlt_wide = false;
   int ldlt_xcd = 1;                    // 0 off, 1 on (9 .. 19 tile rows), 2 on with forced safe hand-overs
+  bool ldlt_xcd_short_once = false;    // test hook (ORBG_LDLT_XCD=short): the handle's first eight-workgroup launch misses a participant
   static LbaSwitches from_env() {
     LbaSwitches w;
     w.ldlt_wide = getenv("ORBG_LDLT_WIDE") != nullptr;
-    if (const char* e = getenv("ORBG_LDLT_XCD")) w.ldlt_xcd = !strcmp(e, "0") ? 0 : !strcmp(e, "safe") ? 2 : 1;
+    if (const char* e = getenv("ORBG_LDLT_XCD")) { w.ldlt_xcd = !strcmp(e, "0") ? 0 : !strcmp(e, "safe") ? 2 : 1; w.ldlt_xcd_short_once = !strcmp(e, "short"); }
     return w;
   }
 };
@@ -1324,6 +1325,7 @@ struct lba_handle {
   LbaSwitches sw;
   ldltm::AttrCache ldlt_attr;          // which kernels of THIS handle's device already allow their dynamic LDS size
   ldltx::Context ldlt_x;               // flags / scratch / launch counter of the eight-workgroup LDL^T
+  long long xcd_timeouts = 0;          // launches of it that reported kOkTimedOut (each one: the window re-solved on the one-workgroup kernels)
   DevBuf<double> d_xscr;
   DevBuf<unsigned> d_xflags;
   DevBuf<lba_edge> d_edges;
@@ -1452,7 +1454,23 @@ static int upload_arena(lba_handle* h, size_t off0, size_t off1, hipStream_t st)
   return ORBG_OK;
 }
 
+// internal: k_ldlt_xcd reported kOkTimedOut during this attempt (never leaves the library)
+constexpr int kRcLdltTimedOut = -70001;
+static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r);
+// A launch of the eight-workgroup LDL^T whose participants were not all placed in time says so (ldlt_xcd.hpp: kOkTimedOut) instead of
+// posing as a non-positive-definite system, which the LM loop would answer with a rejected step and another trajectory than the
+// reference's.  The window is then solved again from the caller's (untouched) problem with that kernel switched off for this handle
+// -- the ORBG_LDLT_XCD=0 path, parity-tested like the default -- and the event is counted (lba_get_watchdog_count).
 static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r) {
+  int rc = lba_solve_attempt(h, p, stop_ref, r);
+  if (rc != kRcLdltTimedOut) return rc;
+  h->xcd_timeouts++;
+  h->sw.ldlt_xcd = 0;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return ORBG_HIP_ERROR;
+  rc = lba_solve_attempt(h, p, stop_ref, r);
+  return rc == kRcLdltTimedOut ? ORBG_HIP_ERROR : rc;
+}
+static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r) {
   if (!h) return ORBG_BAD_ARG;
   const LbaSwitches& sw = h->sw;
   if (!h || !p || !r || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0) return ORBG_BAD_ARG;
@@ -1726,6 +1744,8 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   if (use_xcd && !h->ldlt_x.scr) {
     if ((rc = h->d_xscr.reserve(ldltx::scratch_doubles())) || (rc = h->d_xflags.reserve(ldltx::kFlagWords))) return rc;
     ORBG_HIP(hipMemsetAsync(h->d_xflags.p, 0, ldltx::kFlagWords * sizeof(unsigned), st));
+    // (the G / D^-1 pair region: a fresh nonce per bind already makes stale pairs of a recycled allocation fail their test; zero all the same)
+    ORBG_HIP(hipMemsetAsync(h->d_xscr.p + ldltx::kGbOff, 0, (ldltx::kWOff - ldltx::kGbOff) * sizeof(double), st));
     h->ldlt_x.bind(h->d_xscr.p, h->d_xflags.p);
     static std::atomic<int> n_users{0};              // users of one process on different XCDs; processes sharing a GPU differ by pid
     h->ldlt_x.pick = ((int)getpid() + n_users.fetch_add(1)) & 7;
@@ -1770,7 +1790,7 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
                        Hlls[ls], lambda, with_ok ? h->d_ok.p : (int*)nullptr, want_scale, want_maxdiag, h->rec.d, 0.0, (double*)nullptr);
     ORBG_HIP(hipGetLastError());
     ORBG_HIP(hipStreamSynchronize(st));
-    return ORBG_OK;
+    return with_ok && h->rec.h->ok == ldltx::kOkTimedOut ? kRcLdltTimedOut : ORBG_OK;
   };
   auto poll_record = [&]() -> int {
     // the last workgroup of k_errors publishes the record and then its sequence number: spin on that word (the
@@ -1790,7 +1810,8 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     if (!got) ORBG_HIP(hipStreamSynchronize(st));
-    return ORBG_OK;
+    // the eight-workgroup LDL^T gave up waiting for a participant: not an LM verdict -- the caller re-solves the window (lba_solve_impl)
+    return h->rec.h->ok == ldltx::kOkTimedOut ? kRcLdltTimedOut : ORBG_OK;
   };
 
   // results block (one pinned allocation the export kernel writes straight into) and its launcher: also used speculatively
@@ -1827,7 +1848,9 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
       const bool bracket = h->prof_on && !prof_pending && prof_this_solve;
       if (bracket) ORBG_HIP(hipEventRecord(h->prof_ev[0], st));
       if (use_xcd) {
-        ORBG_HIP(ldltx::launch(h->ldlt_x, n, h->d_St.p, h->d_x.p, h->d_ok.p, st, ldltx::kMaxP, sw.ldlt_xcd == 2));
+        const bool one_short = h->sw.ldlt_xcd_short_once;
+        h->sw.ldlt_xcd_short_once = false;
+        ORBG_HIP(ldltx::launch(h->ldlt_x, n, h->d_St.p, h->d_x.p, h->d_ok.p, st, ldltx::kMaxP, sw.ldlt_xcd == 2, one_short));
       } else if (use_mfma) {
         ORBG_HIP(ldltm::launch(n, h->d_St.p, h->d_x.p, h->d_ok.p, h->d_wfac.p, st, &h->ldlt_attr));
       } else {
@@ -2228,6 +2251,12 @@ extern "C" int lba_get_solver_stats(lba_handle* h, double* sum_ms, int64_t* n_br
   *sum_ms = h->prof_sum_ms; *n_brackets = h->prof_n;
   if (n_unknowns) *n_unknowns = h->prof_n_unknowns;
   if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !h->sw.ldlt_wide;
+  return ORBG_OK;
+}
+
+extern "C" int lba_get_watchdog_count(lba_handle* h, int64_t* n_timeouts) {
+  if (!h || !n_timeouts) return ORBG_BAD_ARG;
+  *n_timeouts = h->xcd_timeouts;
   return ORBG_OK;
 }
 

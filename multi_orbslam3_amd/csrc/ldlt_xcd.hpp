@@ -24,6 +24,10 @@
 // runs on five wavefronts of workgroup 0, one per 64-row block, x posted through LDS.  DESIGN.md section 8 has the timeline.
 #pragma once
 
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <type_traits>
 
 #include "ldlt_mfma.hpp"
@@ -47,7 +51,7 @@ constexpr int kMaxNS = 8;                   // tile slots per wavefront in the p
 constexpr int kMaxT = ldltm::kMaxT;
 constexpr int kNY = 5;                      // 64-lane groups of the solution vector (n_pad <= 320)
 // flag words
-constexpr int kFDiag = 0 /* (unused since G travels as self-validating pairs) */, kFPanel = 32, kFWave = kFPanel + kMaxT * kMaxT, kFElect = kFWave + 128, kFBad = kFElect + 16;
+constexpr int kFDiag = 0 /* (unused since G travels as self-validating pairs) */, kFPanel = 32, kFWave = kFPanel + kMaxT * kMaxT, kFElect = kFWave + 128, kFBad = kFElect + 16, kFDog = kFBad + 1;
 constexpr int kFlagStride = 640;             // one copy of the flags per participant (its wavefronts poll that copy only)
 constexpr int kFlagWords = kFlagStride * kMaxP;
 // scratch (doubles)
@@ -55,9 +59,16 @@ constexpr size_t kPanOff = 0, kPanDoubles = (size_t)kMaxT * kMaxT * 512;
 constexpr size_t kGbOff = kPanOff + kPanDoubles, kGbDoubles = 2 * (size_t)kMaxT * 16 * kGld;      // (value, value ^ tag) pairs
 constexpr size_t kDvOff = kGbOff + kGbDoubles, kDvDoubles = 2 * (size_t)kMaxT * 16;
 constexpr size_t kWOff = kDvOff + kDvDoubles;
-__host__ inline size_t scratch_doubles() { return kWOff + ldltm::wglob_doubles(make_geo(16 * kMaxT - 20)) + 1024; }
+// (the factor's store is sized for all 64 * kNY columns: the back-substitution preloads the 64 columns of a wavefront's block
+// whether or not the system reaches them -- masked where used, but read)
+__host__ inline size_t scratch_doubles() {
+  const size_t w = ldltm::wglob_doubles(make_geo(16 * kMaxT - 20)), full = (size_t)(64 * kNY) * (64 * kNY + 1) / 2;
+  return kWOff + (w > full ? w : full) + 1024;
+}
+// *ok_flag of a launch whose waits gave up (LDLTX_DOG): neither "solved" (1) nor "not positive definite" (0)
+constexpr int kOkTimedOut = -2;
 
-struct Plan { short tile[kMaxW][kMaxNS]; signed char chain[kMaxW]; int np, ns, force_safe, pick; };       // tile index j(j+1)/2 + i per wavefront slot (-1: none), in processing order
+struct Plan { short tile[kMaxW][kMaxNS]; signed char chain[kMaxW]; int np, ns, force_safe, pick; unsigned long long nonce; };       // tile index j(j+1)/2 + i per wavefront slot (-1: none), in processing order
 
 __host__ inline bool plan_fits(int n, int np, int ns);
 // The systems this kernel takes: 9 .. 19 tile rows (21 .. 50 free poses).  Inside a local BA it is ahead of the one-workgroup kernels
@@ -73,7 +84,7 @@ __host__ inline Plan make_plan(int n, int np, int ns) {
   const Geo g = make_geo(n);
   const int W = np * kWgWaves;
   Plan P;
-  P.np = np; P.ns = ns; P.force_safe = 0; P.pick = 0;
+  P.np = np; P.ns = ns; P.force_safe = 0; P.pick = 0; P.nonce = 0;
   int cnt[kMaxW];
   bool chain[kMaxW];
   for (int w = 0; w < kMaxW; w++) { cnt[w] = 0; chain[w] = false; for (int s = 0; s < kMaxNS; s++) P.tile[w][s] = -1; }
@@ -124,19 +135,22 @@ __device__ long long g_xprof[1024];
 #define LDLTX_T(i) do { } while (0)
 #endif
 
-// Every in-kernel wait is bounded: after ~16 M polls (seconds; a hand-over takes a microsecond) the wavefront gives up, marks the
-// solve as failed (ok = 0: the LM step is rejected like a non-positive pivot) and lets the kernel end -- a participant that the
-// dispatcher never placed must not turn into a GPU that never comes back.  -DLDLTX_WATCHDOG (micro-benchmark builds) gives up
-// sooner and records which wait it was.
+// Every in-kernel wait is bounded IN TIME: a wavefront that has been in the kernel for kDogTicks of the 100 MHz wall clock (2 s; a
+// launch takes 0.1 ms, a hand-over a microsecond) and is still waiting gives up, marks the launch as TIMED OUT (kFDog; *ok_flag =
+// kOkTimedOut -- distinct from a non-positive pivot, which is an LM verdict: lba.hip re-solves a timed-out window on the
+// one-workgroup kernel and counts it) and lets the kernel end -- a participant that the dispatcher never placed must not turn into a
+// GPU that never comes back.  The clock is read once per 1024 polls of a wait (a poll is 0.1 .. 1 us).  Time, not a poll count:
+// a live launch whose participants are placed late behind long kernels of other streams must not trip it.  -DLDLTX_WATCHDOG
+// (micro-benchmark builds) gives up after 0.25 s and records which wait it was.
 #ifdef LDLTX_WATCHDOG
 __device__ int g_xdog[16];
-#define LDLTX_DOG_LIMIT (1 << 22)
+constexpr long long kDogTicks = 25000000ll;
 #define LDLTX_DOG_RECORD(where, a, b) do { if (lane == 0 && atomicAdd(&g_xdog[0], 1) == 0) { g_xdog[1] = (where); g_xdog[2] = gw_; g_xdog[3] = (a); g_xdog[4] = (b); } } while (0)
 #else
-#define LDLTX_DOG_LIMIT (1 << 24)
+constexpr long long kDogTicks = 200000000ll;
 #define LDLTX_DOG_RECORD(where, a, b) do { } while (0)
 #endif
-#define LDLTX_DOG(where, a, b) do { if (++dog_ > LDLTX_DOG_LIMIT) { LDLTX_DOG_RECORD(where, a, b); if (lane == 0) __hip_atomic_store(flags + kFBad, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bail_ = true; } } while (0)
+#define LDLTX_DOG(where, a, b) do { if ((++dog_ & 1023) == 0 && (long long)wall_clock64() - t_dog0_ > kDogTicks) { LDLTX_DOG_RECORD(where, a, b); if (lane == 0) { __hip_atomic_store(flags + kFBad, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(flags + kFDog, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } bail_ = true; } } while (0)
 
 __device__ __forceinline__ unsigned xcc_id() {
   unsigned v;
@@ -158,6 +172,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
   int dog_ = 0; [[maybe_unused]] const int gw_ = (int)(blockIdx.x >> 3) * kWgWaves + wv;
+  const long long t_dog0_ = (long long)wall_clock64();      // the wavefront's start: the time base of every wait's bound
   bool bail_ = false;                      // a wait gave up (LDLTX_DOG): every later wait of this wavefront returns at once
 #ifdef LDLTX_PROFILE
   const long long t_enter = wall_clock64();
@@ -229,7 +244,9 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   // -- a word of an earlier launch, or one of the two not yet arrived, fails the test (two unrelated doubles XOR to the tag with
   // probability 2^-64).  The producer does not wait for its stores (0.25 us per tile row on the chain), the consumer's poll IS its
   // load (one L2 round trip instead of flag + data), and the words are coherent across XCDs as they are (agent-scope accesses).
-  const unsigned long long tag = (0x9E3779B97F4A7C15ull * (unsigned long long)(epoch + 1u)) | 1ull;
+  // (plan.nonce: fresh per Context::bind and per wrap of the launch counter -- a recycled allocation or a reused launch number
+  // cannot carry pairs that pass for this launch's)
+  const unsigned long long tag = ((0x9E3779B97F4A7C15ull * (unsigned long long)(epoch + 1u)) ^ plan.nonce) | 1ull;
   auto st_pair = [&](double* p, double v) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     if (safe) {                              // across XCDs: write-through stores
@@ -578,6 +595,7 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
   }
   acquire();
   const int ok = ld_flag(flags + kFBad) != epoch;
+  const bool timed_out = ld_flag(flags + kFDog) == epoch || bail_;
   if (wv == 0) LDLTX_T(2);
   if (ok) {
     const int I = 64 * wv + lane, lo = 64 * wv;
@@ -661,15 +679,28 @@ __global__ __launch_bounds__(kThreads) void k_ldlt_xcd(int n, const double* __re
 #endif
     if (I < n) x[I] = y;
   }
-  if (wv == 0) { LDLTX_T(3); if (lane == 0) *ok_flag = ok; }
+  if (wv == 0) { LDLTX_T(3); if (lane == 0) *ok_flag = timed_out ? kOkTimedOut : ok; }
 }
 
 // Host side: scratch + flags of one user (an lba handle); the epoch advances with every launch.  The memory is the caller's
 // (bind) or the context's own (ensure: the micro-benchmark).
+// What the scratch may hold when a context starts on it: the flags must be zero (stale launch numbers would pass for published
+// tiles); the G / D^-1 pair region (kGbOff .. kWOff) may hold anything -- a pair is accepted only under this context's tag, a hash of
+// (nonce, launch number), and the nonce is fresh per bind / ensure and per wrap of the 24-bit launch counter, so pairs left by a
+// destroyed handle in a recycled allocation, or by this context 16 M launches ago, fail the test like any two unrelated words
+// (2^-63).  lba.hip zeroes the region next to the flags all the same.
+__host__ inline unsigned long long fresh_nonce() {
+  static std::atomic<unsigned long long> counter{0};
+  timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  unsigned long long z = (counter.fetch_add(1) + 1) * 0x9E3779B97F4A7C15ull ^ ((unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec) ^ ((unsigned long long)getpid() << 40);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;      // splitmix64 finaliser
+  return z ^ (z >> 31);
+}
 struct Context {
   double* scr = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int plan_n = -1; Plan plan; bool owned = false;
   int pick = 0;                             // which XCD's blocks take part (0 .. 7)
-  void bind(double* scratch /* scratch_doubles() */, unsigned* zeroed_flags /* kFlagWords */) { scr = scratch; flags = zeroed_flags; owned = false; epoch = 0; }
+  unsigned long long nonce = 0;
+  void bind(double* scratch /* scratch_doubles() */, unsigned* zeroed_flags /* kFlagWords */) { scr = scratch; flags = zeroed_flags; owned = false; epoch = 0; nonce = fresh_nonce(); }
   hipError_t ensure() {
     if (scr) return hipSuccess;
     hipError_t e = hipMalloc((void**)&scr, scratch_doubles() * sizeof(double));
@@ -677,11 +708,14 @@ struct Context {
     if ((e = hipMalloc((void**)&flags, kFlagWords * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMemset(flags, 0, kFlagWords * sizeof(unsigned))) != hipSuccess) return e;
     owned = true;
+    nonce = fresh_nonce();
     return hipDeviceSynchronize();
   }
   void release() { if (owned) { if (scr) (void)hipFree(scr); if (flags) (void)hipFree(flags); } scr = nullptr; flags = nullptr; }
 };
-__host__ inline hipError_t launch(Context& c, int n, const double* St, double* x, int* ok, hipStream_t st, int np = 8, bool force_safe = false) {
+// one_short (test hook): the grid ends one participant early, as if the dispatcher never placed it -- every wait of the others runs
+// into its bound and the launch reports kOkTimedOut
+__host__ inline hipError_t launch(Context& c, int n, const double* St, double* x, int* ok, hipStream_t st, int np = 8, bool force_safe = false, bool one_short = false) {
   hipError_t e = c.ensure();
   if (e != hipSuccess) return e;
   const int ns = 4;
@@ -693,8 +727,10 @@ __host__ inline hipError_t launch(Context& c, int n, const double* St, double* x
   if (c.epoch == 0) {                        // once per 16 M launches: stale flags of the same epoch value must not survive the wrap
     if ((e = hipMemsetAsync(c.flags, 0, kFlagWords * sizeof(unsigned), st)) != hipSuccess) return e;
     c.epoch = 1;
+    c.nonce = fresh_nonce();                 // ... nor pairs tagged with a launch number that comes round again
   }
-  hipLaunchKernelGGL(k_ldlt_xcd, dim3(8 * (np - 1) + (c.pick & 7) + 1), dim3(kThreads), 0, st, n, St, x, ok, c.scr, c.flags, c.epoch, c.plan);
+  c.plan.nonce = c.nonce;
+  hipLaunchKernelGGL(k_ldlt_xcd, dim3(8 * (np - 1 - (one_short ? 1 : 0)) + (c.pick & 7) + 1), dim3(kThreads), 0, st, n, St, x, ok, c.scr, c.flags, c.epoch, c.plan);
   return hipGetLastError();
 }
 

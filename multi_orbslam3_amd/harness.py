@@ -501,9 +501,13 @@ class ServerTick:
                     return
                 if self.error is None:
                     self._process(*job)
-            except Exception as e:                           # reported by drain(): a failing server must not hang the agents
+            except Exception as e:                           # reported by tick() / drain(): a failing server must not hang the agents
                 self.error = e
             finally:
+                # the buffer set of this job is free again WHATEVER happened to the job (failed, or skipped because an earlier one
+                # failed): rank 0 waits on this event two ticks later, in front of a collective every other rank is already in
+                if job is not None:
+                    job[1].set()
                 self.q.task_done()
 
     # ---- agent side
@@ -528,6 +532,8 @@ class ServerTick:
         if self.busy[b] is not None:
             self.busy[b].wait()                              # the server thread has finished with this buffer set (two ticks ago)
         got = self.grp.all_gather_keyframe_blocks(self.bufs2[b], blocks, with_poses=True)
+        if self.is_server and self.error is not None:        # (after the collective: the other ranks are not left waiting in it)
+            raise self.error
         t1 = time.perf_counter()
         self.stats["exchange_s"] += t1 - t0
         self.stats["ticks"] += 1
@@ -569,8 +575,7 @@ class ServerTick:
                 record.append(dict(agent=a, n=n, wire=wire_host, blk=blk, T=T, bow=(bw, bv), fv=(fn, fs, ff), con=con, before=before,
                                    loop=loop_c, merge=merge_c, cand=cand, m12=m12, nb=nb, matched=matched, nproj=nproj))
         self.last = record
-        self.stats["server_s"] += time.perf_counter() - t1
-        done.set()
+        self.stats["server_s"] += time.perf_counter() - t1        # (_serve releases `done`, on every path)
 
     def drain(self):
         """Every tick exchanged so far has been processed by the server thread (rank 0; a no-op elsewhere)."""

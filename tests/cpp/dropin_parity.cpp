@@ -23,8 +23,13 @@
 using namespace mock;
 namespace od = orbgpu::dropin;
 
-struct GpuHeuristicOps : od::GpuOps {   // the product's entry points with the counter-less rules of the local-map cache (a MapPoint without mnChangeStamp)
+struct GpuHeuristicOps : od::GpuOps {   // the product's entry points with the OPT-IN counter-less cache of the local map (-DORBGPU_DROPIN_HEURISTIC_LOCAL_MAP)
   static constexpr bool kNoChangeStamp = true;
+  static constexpr bool kHeuristicLocalMap = true;
+};
+struct GpuUnmodifiedOps : od::GpuOps {  // the product's entry points as they compile against the reference's MapPoint as it is (+ edit E1): no counter, no cache
+  static constexpr bool kNoChangeStamp = true;
+  static constexpr bool kNoLbaCache = true;
 };
 struct OracleOps {       // the same entry points over the CPU oracle: views instead of device handles
   static constexpr bool kUsesResidentFrame = false;
@@ -326,8 +331,10 @@ int main() {
       EXPECT(nd > 100, "[%s] the patched local map matched only %d features", what, nd);
     };
     check_local_map_cache(g, true, "change counter");
+    g_seed = 7; const TrackOut gu = run_tracking<GpuUnmodifiedOps>(rig, tex);
+    check_local_map_cache(gu, true, "unmodified MapPoint: every call reads every point (the default)");
     g_seed = 7; const TrackOut gh = run_tracking<GpuHeuristicOps>(rig, tex);
-    check_local_map_cache(gh, false, "no change counter");
+    check_local_map_cache(gh, false, "opt-in counter-less cache");
     EXPECT(g.n_bow == c.n_bow && g.a_bow == c.a_bow && g.n_bow > 20, "SearchByBoW %d vs %d", g.n_bow, c.n_bow);
     EXPECT(g.n_reloc1 == c.n_reloc1 && g.n_reloc2 == c.n_reloc2 && g.a_reloc == c.a_reloc && g.n_reloc1 > 20,
            "SearchByProjection(F, KF, sAlreadyFound): %d / %d vs %d / %d new matches", g.n_reloc1, g.n_reloc2, c.n_reloc1, c.n_reloc2);

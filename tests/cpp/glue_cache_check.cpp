@@ -1,6 +1,6 @@
 // The glue's local-BA window cache (include/orbgpu_dropin.hpp, LbaWindowCache) against the uncached glue, host only: two identical
 // scenes go through six windows each with the same changes in between (observations added and erased, points moved, made bad, a new
-// keyframe), one through an entry-point set that allows the cache, one through a set that forbids it; every flattened problem, every
+// keyframe) and DURING each solve (observations added by "another thread" between the glue's read and its write-back), one through an entry-point set that allows the cache, one through a set that forbids it; every flattened problem, every
 // status and the final map must be identical, and the cached run must have read far fewer points.
 //   g++ -O2 -std=c++17 -I include -I tests/cpp tests/cpp/glue_cache_check.cpp -L multi_orbslam3_amd -lorbgpu -o glue_cache_check
 #include <cstdio>
@@ -16,6 +16,8 @@ struct Captured {
 };
 static std::vector<Captured> g_cap[2];
 static int g_which = 0;
+static Agent* g_agent = nullptr;          // the scene of the run in progress: "another thread" changes points DURING the solve
+static int g_round = 0;
 
 template <bool NoCache>
 struct CaptureOps {
@@ -26,6 +28,22 @@ struct CaptureOps {
     c.poses.assign(p.poses, p.poses + 16 * (size_t)p.n_poses); c.points.assign(p.points, p.points + 3 * (size_t)p.n_points);
     c.fixed.assign(p.pose_fixed, p.pose_fixed + p.n_poses); c.edges.assign(p.edges, p.edges + p.n_edges);
     g_cap[g_which].push_back(std::move(c));
+    // while the solve runs (no map mutex is held, S/Optimizer.cc:2127-2263) another thread -- Tracking creating points, the Communicator
+    // applying a server update -- gives a few of the window's points a new observation.  The glue read those points BEFORE the solve
+    // and writes them back AFTER it: its record of such a point is stale the moment the write-back ends, and must not be kept.
+    for (auto& up : g_agent->points) {
+      MapPoint* mp = up.get();
+      if (mp->isBad()) continue;
+      const unsigned key = (unsigned)(mp->mnId * 2246822519u) ^ (unsigned)(g_round * 7919u);
+      if (key % 53 != 2) continue;
+      KeyFrame* kf = g_agent->kfs[(key >> 7) % g_agent->kfs.size()].get();
+      if (mp->mObservations.count(kf)) continue;
+      const int li = (int)kf->mvKeysUn.size();
+      kf->mvKeysUn.push_back(KeyPoint{{120.f + (float)(key % 380), 90.f + (float)(key % 280)}, 31.f, 0.f, 20.f, (int)(key % 4)});
+      kf->mvuRight.push_back((key & 2) ? -1.f : 70.f + (float)(key % 280));
+      kf->mvpMapPoints.push_back(mp);
+      mp->AddObservation(kf, li);
+    }
     // a deterministic "solve": every free pose and every point moves a little, one edge in 41 is an outlier
     std::memcpy(r.poses, p.poses, sizeof(float) * 16 * (size_t)p.n_poses);
     for (int i = 0; i < p.n_poses; i++) if (!p.pose_fixed[i]) r.poses[16 * i + 3] += 0.001f * (float)(i % 7);
@@ -42,7 +60,9 @@ static void run(int which, long* obs_copies, long* pos_clones) {
   Agent B;
   KeyFrame* cur = build_lba_scene(B, 21, 10, 2000, 0.03, 99);
   bool stop = false; int nf = 0;
+  g_agent = &B;
   for (int round = 0; round < 6; round++) {
+    g_round = round;
     od::LocalBundleAdjustment<Ops>(cur, &stop, &B.map, nf, 0);
     // what LocalMapping / LoopClosing do between two windows, on points chosen by id (the scenes are built identically)
     for (size_t j = 0; j < B.points.size(); j++) {

@@ -2,6 +2,7 @@
 // or writes, under the reference's own names, so that include/orbgpu_dropin.hpp -- the glue that
 // would be pasted into S/ORBmatcher.cc / S/Optimizer.cc -- compiles and runs without OpenCV / g2o / ROS.
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -28,18 +29,25 @@ struct KeyPoint { Point2f pt; float size, angle, response; int octave; };
 
 class Map; class KeyFrame;
 
+// Access sections mirror the reference's headers: what is `protected:` there is MOCK_PROTECTED here -- public for the tests (which set
+// scenes up by writing members directly), protected under -DMOCK_STRICT_ACCESS, the build in which tests/cpp/glue_access_check.cpp
+// instantiates every template of include/orbgpu_dropin.hpp: the glue then compiles only if it stays within what the reference's
+// classes let an outsider touch, plus the edits INTEGRATION.md lists.  tests/test_reference_access.py holds the partition below
+// against the reference's own headers (I/MapPoint.h, I/KeyFrame.h, I/Frame.h, I/Map.h) where they are present.
+#ifdef MOCK_STRICT_ACCESS
+#define MOCK_PROTECTED protected
+#else
+#define MOCK_PROTECTED public
+#endif
+
 class MapPoint {
- public:
+ public:      // ---- public in the reference (I/MapPoint.h:118-242)
   long unsigned mnId = 0; uint8_t mnClientId = 0;
   long unsigned mnBALocalForKF = ~0ul;
   // fields Frame::isInFrustum stores (S/Frame.cc:529-538)
   bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackDepth = 0, mTrackViewCos = 0; int mnTrackScaleLevel = 0;
-  float mfMinDistance = 0, mfMaxDistance = 0;
-  Mat mWorldPos{3, 1, 4}, mNormalVector{3, 1, 4}, mDescriptor{1, 32, 1};
-  std::map<KeyFrame*, std::tuple<int, int>> mObservations;
-  bool mbBad = false; Map* mpMap = nullptr; int nObs = 0;
-  int n_normal_updates = 0;
-  long unsigned mnLastFrameSeen = ~0ul; int mnVisible = 1;
+  int nObs = 0;
+  long unsigned mnLastFrameSeen = ~0ul;
   void IncreaseVisible(int n = 1) { mnVisible += n; }                   // S/MapPoint.cc:427-431
   bool isBad() const { return mbBad; }
   Map* GetMap() const { return mpMap; }
@@ -47,56 +55,70 @@ class MapPoint {
   Mat GetWorldPos() const { n_pos_clones++; return mWorldPos; }
   Mat GetNormal() const { return mNormalVector; }
   Mat GetDescriptor() const { return mDescriptor; }
-  int n_locked_pos_writes = 0;
-  // the change counter the glue's caches look for (one member, ++ in the mutators of what the glue reads)
-  long unsigned mnChangeStamp = 0;
-  mutable int n_obs_copies = 0, n_pos_clones = 0;
   void SetWorldPos(const Mat& X, bool bLock = false, bool /*bLockSend*/ = false) { mWorldPos = X; n_locked_pos_writes += bLock; mnChangeStamp++; }   // I/MapPoint.h:126
   std::map<KeyFrame*, std::tuple<int, int>> GetObservations() const { n_obs_copies++; return mObservations; }
   void AddObservation(KeyFrame* kf, int idx) { if (!mObservations.count(kf)) nObs++; mObservations[kf] = std::make_tuple(idx, -1); mnChangeStamp++; }
   void EraseObservation(KeyFrame* kf) { if (mObservations.erase(kf)) nObs--; mnChangeStamp++; }
   void SetBadFlag() { mbBad = true; mObservations.clear(); nObs = 0; mnChangeStamp++; }
   void UpdateNormalAndDepth() { n_normal_updates++; mnChangeStamp++; }
+ public:      // ---- reference-side edits ("Reference-side edits": E1 two getters, E2 the change counter)
+  float GetMinDistance() const { return mfMinDistance; }
+  float GetMaxDistance() const { return mfMaxDistance; }
+  std::atomic<unsigned long> mnChangeStamp{0};       // +1 per call of the six mutators of what the glue reads, after their stores
+ MOCK_PROTECTED:   // ---- protected in the reference (I/MapPoint.h:244-300)
+  float mfMinDistance = 0, mfMaxDistance = 0;
+  Mat mWorldPos{3, 1, 4}, mNormalVector{3, 1, 4}, mDescriptor{1, 32, 1};
+  std::map<KeyFrame*, std::tuple<int, int>> mObservations;
+  bool mbBad = false; Map* mpMap = nullptr;
+  int mnVisible = 1;
+ public:      // ---- test instrumentation (no counterpart in the reference; the glue never names these)
+  int n_normal_updates = 0;
+  int n_locked_pos_writes = 0;
+  mutable int n_obs_copies = 0, n_pos_clones = 0;
   void Touch() { mnChangeStamp++; }      // what ComputeDistinctiveDescriptors / UpdateNormalAndDepth do to the counter when a test writes their fields directly
 };
 
 class Map {
- public:
-  long unsigned mnInitKFid = 0; bool mbInertial = false;
+ public:      // ---- public in the reference (I/Map.h:56-162)
   std::mutex mMutexMapUpdate;
-  int mnMapChange = 0;
   void IncreaseChangeIndex() { mnMapChange++; }                       // I/Map.h:100-101
   int GetMapChangeIndex() const { return mnMapChange; }
   long unsigned GetInitKFid() const { return mnInitKFid; }
-  bool IsInertial() const { return mbInertial; }
+  bool IsInertial() const { return mbIsInertial; }
+ MOCK_PROTECTED:   // ---- protected in the reference (I/Map.h:164-210)
+  long unsigned mnInitKFid = 0; bool mbIsInertial = false;
+  int mnMapChange = 0;
 };
 
 typedef std::map<unsigned, std::vector<unsigned>> FeatureVector;     // DBoW2::FeatureVector (D/FeatureVector.h:24-25)
 
 class KeyFrame {
- public:
+ public:      // ---- public in the reference (I/KeyFrame.h:268-533)
   long unsigned mnId = 0; uint8_t mnClientId = 0;
   long unsigned mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul;
   float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
   std::vector<KeyPoint> mvKeysUn; std::vector<float> mvuRight, mvInvLevelSigma2;
   Mat mDescriptors; FeatureVector mFeatVec;
-  std::vector<MapPoint*> mvpMapPoints; std::vector<KeyFrame*> mvpOrderedConnectedKeyFrames;
-  Mat Tcw{4, 4, 4};
-  bool mbBad = false; Map* mpMap = nullptr;
   bool isBad() const { return mbBad; }
   Map* GetMap() const { return mpMap; }
   std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() const { return mvpOrderedConnectedKeyFrames; }
   std::vector<MapPoint*> GetMapPointMatches() const { return mvpMapPoints; }
   Mat GetPose() const { return Tcw; }
-  int n_locked_pose_writes = 0;
   void SetPose(const Mat& T, bool bLock = false, bool /*bLockSend*/ = false) { Tcw = T; n_locked_pose_writes += bLock; }          // I/KeyFrame.h:276
   void EraseMapPointMatch(MapPoint* mp) { for (auto& p : mvpMapPoints) if (p == mp) p = nullptr; }
+ MOCK_PROTECTED:   // ---- protected in the reference (I/KeyFrame.h:535-632)
+  std::vector<MapPoint*> mvpMapPoints; std::vector<KeyFrame*> mvpOrderedConnectedKeyFrames;
+  Mat Tcw{4, 4, 4};
+  bool mbBad = false; Map* mpMap = nullptr;
+ public:      // ---- test instrumentation
+  int n_locked_pose_writes = 0;
 };
 
 class Frame {
- public:
-  long unsigned mnId = 0;
+ public:      // ---- reference-side edits (optional)
   void* mpGpuFrame = nullptr;           // the device-resident copy the constructor adapter left (an orbgpu::FrameOnDevice*), or none
+ public:      // ---- public in the reference (I/Frame.h:49-252)
+  long unsigned mnId = 0;
   int N = 0;
   std::vector<KeyPoint> mvKeys, mvKeysUn; Mat mDescriptors;
   std::vector<float> mvuRight, mvDepth, mvInvLevelSigma2;

@@ -809,6 +809,35 @@ def test_lba_window_sizes_cover_every_ldlt_kernel(nf, monkeypatch):
         assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-9), (nf, env)
 
 
+def test_lba_ldlt_timeout_is_not_taken_for_a_rejected_step(monkeypatch):
+    """A launch of the eight-workgroup LDL^T whose participants are not all placed (ORBG_LDLT_XCD=short: the handle's first such launch
+    is one participant short; its waits give up after 2 s of wall-clock time) reports TIMED OUT, not "not positive definite": the LM
+    loop must not answer it with a rejected step (another trajectory than the oracle's).  The window is re-solved on the one-workgroup
+    kernels -- same status, iterations, trial counts, outlier sets and state as the oracle -- the handle counts the event, and its next
+    window is solved without another one."""
+    prob = synth.make_lba_problem(n_free=30, n_fixed=3, n_points=1260, mono_frac=0.2, seed=130)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    o = ob.lba_solve(p)
+    monkeypatch.setenv("ORBG_LDLT_XCD", "short")
+    opt = api.Optimizer()
+    monkeypatch.delenv("ORBG_LDLT_XCD")
+    assert opt.watchdog_count() == 0
+    import time
+    t0 = time.time()
+    g = opt.LocalBundleAdjustment(p)
+    took = time.time() - t0
+    assert opt.watchdog_count() == 1 and 1.5 < took < 10.0, (opt.watchdog_count(), took)
+    for rep in range(2):
+        assert g.status == o.status == capi.LBA_APPLIED and g.iters == o.iters
+        assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= 1e-4
+        assert np.array_equal(g.edge_outlier, o.edge_outlier)
+        tg, to = g.trace_rows(), o.trace_rows()
+        assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2]) and np.allclose(tg[:, 1], to[:, 1], rtol=1e-9)
+        g = opt.LocalBundleAdjustment(p)
+    assert opt.watchdog_count() == 1
+    opt.close()
+
+
 def test_lba_large_windows_solved_concurrently_by_three_handles():
     """Three LocalMapping threads of one process (three handles) solve 38 / 45 / 50 free-pose windows at the same time, eight times
     over: their eight-workgroup LDL^T kernels (ldlt_xcd.hpp) spin on each other's hand-overs while the others' workgroups are being
@@ -1695,11 +1724,13 @@ def test_ldlt_kernels_against_a_long_double_host_factorisation():
     # launch counter wrapping half way: every sampled result bit-identical to the first of its size, no wait that does not end
     r = subprocess.run([exe, "stress", "20000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "stress: 20000 launches, ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
-    # a participant that the dispatcher never places (here: a grid one participant short): every wait gives up after its bound, the
-    # solve comes back failed (ok = 0) instead of never (-DXWATCHDOG: the bound is 4 M polls instead of 16 M, and the wait is named)
+    # a participant that the dispatcher never places (here: a grid one participant short): every wait gives up after its bound (wall-clock
+    # time since the wavefront started), the launch comes back as TIMED OUT (ok = -2: distinct from 0 = not positive definite, which
+    # is an LM verdict) instead of never, and the context's next launch is a good one (-DXWATCHDOG: the bound is 0.25 s instead of 2 s,
+    # and the wait is named)
     exe_wd = os.path.join(root, "tools", "micro", "ldlt_mfma_test_wd")
     if not os.path.exists(exe_wd) or os.path.getmtime(exe_wd) < max(os.path.getmtime(p) for p in (src, hdr, hdr2, inc)):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-DNO_PROFILE", "-DXWATCHDOG", "-o", exe_wd, src],
                               timeout=900)
     r = subprocess.run([exe_wd], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "xcd with a participant missing: ok=0" in r.stdout and "FAIL" not in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+    assert r.returncode == 0 and "xcd with a participant missing: ok=-2" in r.stdout and "xcd after the timed-out launch: ok=1 ok" in r.stdout and "FAIL" not in r.stdout, r.stdout[-2000:] + r.stderr[-500:]

@@ -208,3 +208,61 @@ def test_cgroup_quota_and_throttle_readers(monkeypatch, tmp_path):
     assert harness.cgroup_cpu_quota() == 2.5 and harness.cgroup_throttled() == (3, 7000)
     files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "-1\n"
     assert harness.cgroup_cpu_quota() is None
+
+
+def test_a_failing_server_thread_releases_its_buffers_and_the_error_reaches_the_tick():
+    """harness.ServerTick: rank 0 hands every tick's gathered blocks to a server thread and, two ticks later, waits for that job's
+    event before it reuses the buffer set -- in front of an all-gather the other ranks are already in.  A job that raises (or that is
+    skipped because an earlier one raised) must still release its event, and the next tick must re-raise the error after its
+    collective instead of blocking (no GPU: the thread's machinery alone, with a server whose work fails on the second job)."""
+    import queue
+    import threading
+    import time
+
+    from multi_orbslam3_amd import harness
+
+    st = object.__new__(harness.ServerTick)
+    st.np = np
+    st.q, st.error, st.is_server, st.shared_gpu = queue.Queue(), None, True, False
+    st.stats = dict(ticks=0, exchange_s=0.0)
+    st.pending, st.busy, st.bufs2 = [], [None, None], [None, None]
+    calls = []
+
+    def process(got, done):
+        calls.append(got)
+        if got == "job1":
+            raise RuntimeError("server work failed")
+    st._process = process
+
+    class Grp:
+        def all_gather_keyframe_blocks(self, bufs, blocks, with_poses=True):
+            return "job%d" % st.stats["ticks"]
+    st.grp = Grp()
+    st.thread = threading.Thread(target=st._serve, daemon=True)
+    st.thread.start()
+    st.tick()                                  # job0: fine
+    st.tick()                                  # job1: raises in the server thread
+    t0 = time.time()
+    raised = []
+
+    def third():
+        try:
+            st.tick()                          # waits for job0's event (set), exchanges, then sees the error
+        except RuntimeError as e:
+            raised.append(str(e))
+    th = threading.Thread(target=third, daemon=True)
+    th.start()
+    th.join(10.0)
+    if not raised:                             # the error may land just after the third tick's check: the fourth one sees it for sure
+        st.q.join()
+        th = threading.Thread(target=third, daemon=True)
+        th.start()
+        th.join(10.0)
+    assert not th.is_alive() and raised == ["server work failed"], (raised, time.time() - t0)
+    assert st.busy[0].is_set() or st.busy[1].is_set()
+    st.q.join()
+    assert all(ev is None or ev.is_set() for ev in st.busy)      # every job handed over -- processed, failed or skipped -- released its buffers
+    assert calls[:2] == ["job0", "job1"] and "job2" not in calls  # jobs after the failure are skipped, not run on a broken server
+    with __import__("pytest").raises(RuntimeError):
+        st.drain()
+    st.q.put(None)
