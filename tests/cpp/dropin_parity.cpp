@@ -31,46 +31,7 @@ struct GpuUnmodifiedOps : od::GpuOps {  // the product's entry points as they co
   static constexpr bool kNoChangeStamp = true;
   static constexpr bool kNoLbaCache = true;
 };
-struct OracleOps {       // the same entry points over the CPU oracle: views instead of device handles
-  static constexpr bool kUsesResidentFrame = false;
-  static constexpr bool kExactLocalMap = true;      // the reference's semantics: every point's fields are read on every call (no cache)
-  static constexpr bool kNoLbaCache = true;         // ... and every local-BA window reads every point (no window cache)
-  static int is_in_frustum(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float lim, uint8_t* in_view,
-                           float* px, float* py, float* pxr, float* depth, int32_t* level, float* vcos) {
-    return oracle_is_in_frustum(&v, Tcw, &pts, lim, in_view, px, py, pxr, depth, level, vcos);
-  }
-  static int search_mps(const od::FrameKey&, const orbm_frame_view& v, const orbm_mappoints_view& mps, float th, int far_points, float th_far, float nnratio,
-                        int32_t* amp, int32_t* aob, int* n) {
-    return oracle_search_by_projection_mps(&v, &mps, th, far_points, th_far, nnratio, amp, aob, n);
-  }
-  static int search_frame(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono, int check_ori,
-                          int32_t* amp, int32_t* aob, int* n) {
-    return oracle_search_by_projection_frame(&v, Tcw, &last, th, mono, check_ori, amp, aob, n);
-  }
-  static int search_reloc(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
-                          const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
-    return oracle_search_by_projection_reloc(&v, Tcw, &kf_pts, found, kf_angle, th, orb_dist, check_ori, amp, n);
-  }
-  static int search_bow(const od::FrameKey&, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf, const uint8_t* kf_valid,
-                        const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori, int32_t* matches, int* n) {
-    return oracle_search_by_bow(&v, &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
-  }
-  static int search_local(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float th, int far_points,
-                          float th_far, float nnratio, int32_t* amp, int32_t* aob, int* n, uint8_t* in_frustum) {
-    const int m = pts.m;
-    std::vector<float> px(m), py(m), pxr(m), dep(m), vc(m); std::vector<int32_t> lvl(m);
-    oracle_is_in_frustum(&v, Tcw, &pts, 0.5f, in_frustum, px.data(), py.data(), pxr.data(), dep.data(), lvl.data(), vc.data());
-    for (int i = 0; i < m; i++)
-      if ((pts.skip && pts.skip[i]) || pts.bad[i]) in_frustum[i] = 0;
-    return oracle_search_local_points(&v, &pts, Tcw, th, far_points, th_far, nnratio, amp, aob, n);
-  }
-  // (the oracle polls an int32: the bool is sampled -- the cases that raise it DURING the solve go through OracleAtTrialOps)
-  static int lba(const lba_problem& p, const volatile bool* stop, lba_result& r) {
-    volatile int32_t s = (stop && *stop) ? 1 : 0;
-    return oracle_lba_solve(&p, &s, &r);
-  }
-  static int pose_opt(const pose_opt_problem& p, pose_opt_result& r) { return oracle_pose_optimize(&p, &r); }
-};
+#include "oracle_ops.hpp"
 
 // The product's entry points with a tap on the solver's report: LM iterations per round and the number of LM trials that
 // had been evaluated when the solve ended (= when it saw the flag, for an aborted one).

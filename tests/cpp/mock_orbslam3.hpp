@@ -57,10 +57,13 @@ class MapPoint {
   Mat GetDescriptor() const { return mDescriptor; }
   void SetWorldPos(const Mat& X, bool bLock = false, bool /*bLockSend*/ = false) { mWorldPos = X; n_locked_pos_writes += bLock; mnChangeStamp++; }   // I/MapPoint.h:126
   std::map<KeyFrame*, std::tuple<int, int>> GetObservations() const { n_obs_copies++; return mObservations; }
-  void AddObservation(KeyFrame* kf, int idx) { if (!mObservations.count(kf)) nObs++; mObservations[kf] = std::make_tuple(idx, -1); mnChangeStamp++; }
-  void EraseObservation(KeyFrame* kf) { if (mObservations.erase(kf)) nObs--; mnChangeStamp++; }
-  void SetBadFlag() { mbBad = true; mObservations.clear(); nObs = 0; mnChangeStamp++; }
-  void UpdateNormalAndDepth() { n_normal_updates++; mnChangeStamp++; }
+  // (virtual: tests/cpp/closed_loop.cpp derives points whose mutators follow S/MapPoint.cc statement by statement -- stereo
+  //  observations count twice, a point that falls to two observations turns bad, the normal and the distance range are recomputed)
+  virtual ~MapPoint() {}
+  virtual void AddObservation(KeyFrame* kf, int idx) { if (!mObservations.count(kf)) nObs++; mObservations[kf] = std::make_tuple(idx, -1); mnChangeStamp++; }
+  virtual void EraseObservation(KeyFrame* kf) { if (mObservations.erase(kf)) nObs--; mnChangeStamp++; }
+  virtual void SetBadFlag() { mbBad = true; mObservations.clear(); nObs = 0; mnChangeStamp++; }
+  virtual void UpdateNormalAndDepth() { n_normal_updates++; mnChangeStamp++; }
  public:      // ---- reference-side edits ("Reference-side edits": E1 two getters, E2 the change counter)
   float GetMinDistance() const { return mfMinDistance; }
   float GetMaxDistance() const { return mfMaxDistance; }

@@ -100,6 +100,41 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
     assert r.returncode == 0 and "dropin parity ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-1000:])
 
 
+def test_closed_loop_scenario_tracks_on_the_oracle_alone():
+    """tests/cpp/closed_loop --oracle-only (no GPU): the synthetic stereo agent of the closed-loop parity run -- every frame through the
+    reference-signature glue over the CPU oracle, feeding on its own poses, matches, keyframes and local-BA results -- keeps track
+    for 60 frames and 12 keyframes.  Pins the scenario itself (the scaffolding between the hot-path calls) where no GPU is needed."""
+    exe = _build("closed_loop", with_oracle=True)
+    r = subprocess.run([exe, "60", "5", "--oracle-only"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "oracle-only run: 12 keyframes, 10 applied local BAs" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_closed_loop_200_frames_product_and_oracle_each_feeding_on_their_own_outputs():
+    """tests/cpp/closed_loop: 200 frames / 40 keyframes of a stereo agent through the glue, once over liborbgpu (frames from the device
+    constructor, the change-counter caches of the local map and of the local-BA window in use), once over liborbgpu as it compiles
+    against an unmodified MapPoint (no caches), once over the CPU oracle; every run carries its OWN state from call to call as
+    Tracking::Track / LocalMapping do (S/Tracking.cc:2572-2811, S/LocalMapping.cc:140-379): the motion model from its own poses,
+    the last frame's points after its own outlier decisions, the local map from its own covisibility graph, new points, culling,
+    fusions, and the local BA's write-back and erasures.
+    (1) Shadow: every entry-point call of the product runs (~1900: searches, PoseOptimization, local BA, distinctive descriptors) is
+    repeated on the oracle with identical inputs: match arrays / flags / counts / iteration counts exact, poses <= 1e-5 (measured:
+    one float32 ulp), local-BA state <= 1e-4 (measured 1.5e-8).
+    (2) Independent runs: every discrete digest equal on every one of the 200 frames (features, both match arrays, outlier flags,
+    local-map make-up, new / culled / fused points, local-BA status / iterations / fixed keyframes, bad points, observation counts);
+    poses and keyframe poses <= 1e-4, point state <= 5e-2 (an ulp fed back through a motion model and a local BA that stops short of
+    convergence: tests/cpp/closed_loop.cpp's header has the measured spread)."""
+    import json
+    exe = _build("closed_loop", with_oracle=True)
+    r = subprocess.run([exe, "200", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "closed loop ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-1000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["closed_loop"]
+    assert d["ok"] and d["frames"] == 200 and d["keyframes"] == 40 and d["local_bas_applied"] >= 30
+    assert d["first_divergent_frame"] == -1 and d["first_divergent_frame_no_caches"] == -1
+    assert d["shadow_calls"] >= 1800 and d["shadow_mismatches"] == 0 and d["shadow_max_pose_abs_diff"] <= 1e-6 and d["shadow_max_lba_abs_diff"] <= 1e-4
+    assert d["bit_identical_leading_frames"] >= 10 and d["max_pose_abs_diff"] <= 1e-4
+
+
 @pytest.mark.gpu
 def test_dropin_bench_times_the_path_through_the_glue():
     """tests/cpp/dropin_bench: every call of the per-frame path and the local BA through the reference-signature glue over the
