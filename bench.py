@@ -537,6 +537,10 @@ def main():
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip tests/cpp/dropin_bench (the per-frame path and the local BA timed through the reference-signature glue "
                          "over mock Frame / KeyFrame / MapPoint objects; reported as value_dropin)")
+    ap.add_argument("--closed-loop-frames", type=int, default=200,
+                    help="in-job closed-loop parity (tests/cpp/closed_loop, rank 0, config C2): this many frames of a stereo agent through the "
+                         "reference-signature glue, product and oracle each feeding on their own outputs, every product call shadowed on "
+                         "the oracle; reported as parity.closed_loop, a violation fails the job like the open-loop gate (0: skip)")
     ap.add_argument("--profile-stages", action="store_true", help="bracket every extractor stage with HIP events")
     ap.add_argument("--no-numa-pin", action="store_true",
                     help="do not restrict the process to the CPUs of the GPU's NUMA node (default: like numactl --cpunodebind)")
@@ -1370,6 +1374,13 @@ def main():
                 if not sp["ok"]:
                     parity["ok"] = False
                     parity.setdefault("violations", []).append("server tick: %s" % {k2: v for k2, v in sp.items() if v is False})
+        # ---- closed loop (rank 0): state carried from call to call, 200 frames, product vs oracle (tests/cpp/closed_loop.cpp)
+        if rank == 0 and args.closed_loop_frames > 0 and args.config == "C2" and "skipped" not in parity:
+            cl = run_closed_loop(args.closed_loop_frames)
+            parity["closed_loop"] = cl
+            if cl.get("ok") is not True:
+                parity["ok"] = False
+                parity.setdefault("violations", []).append("closed loop: %s" % {k2: v for k2, v in cl.items() if k2 in ("error", "shadow_mismatches", "first_divergent_frame", "first_divergent_frame_no_caches")})
         oks = grp.gather_floats(1.0 if parity.get("ok", True) else 0.0)
         parity["agents_ok"] = [bool(v) for v in oks]
         parity["agent_digests"] = [int(v) for v in grp.gather_floats(float(parity.get("agent_digest", 0)))]
@@ -1414,6 +1425,33 @@ def run_dropin_bench():
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     except Exception as e:                                # the headline does not depend on it
         return {"error": repr(e)[:300]}
+
+
+def run_closed_loop(n_frames):
+    """tests/cpp/closed_loop (built by __graft_entry__.build(); rebuilt here if missing): the closed-loop parity run.  The executable
+    links the oracle -- it is the checker, outside every timed region -- and liborbgpu; its last JSON line is the report."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "closed_loop")
+    try:
+        if not os.path.exists(exe):
+            import __graft_entry__ as ge
+            ge.build_closed_loop()
+        t0 = time.time()
+        r = subprocess.run([exe, str(int(n_frames)), "5"], capture_output=True, text=True, timeout=900)
+        rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if not rows:
+            return {"ok": False, "error": "closed_loop exit code %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
+        d = json.loads(rows[-1])["closed_loop"]
+        d["ok"] = bool(d.get("ok")) and r.returncode == 0
+        d["wall_s"] = round(time.time() - t0, 1)
+        d["what"] = ("stereo agent through include/orbgpu_dropin.hpp over mock Frame / KeyFrame / MapPoint / Map objects: motion model -> "
+                     "SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints -> PoseOptimization every frame, keyframe + "
+                     "LocalBundleAdjustment every 5th; the product run and the oracle run each carry their own state; shadow_* = every "
+                     "product call repeated on the oracle with identical inputs; first_divergent_frame = -1: every discrete digest equal "
+                     "on every frame")
+        return d
+    except Exception as e:
+        return {"ok": False, "error": repr(e)[:300]}
 
 
 def run_server_tick(grp, api, views, torch, device, frames, kf_chunks, fv, LM, scene, reps=50):

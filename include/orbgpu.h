@@ -408,6 +408,25 @@ typedef struct orbv_vocab_view {
 typedef struct orbv_vocab orbv_vocab;
 int orbv_vocab_create(int device, const orbv_vocab_view* view, orbv_vocab** out);
 int orbv_vocab_destroy(orbv_vocab* v);
+/* The vocabulary in the reference's own file format: bool TemplatedVocabulary::loadFromTextFile(const std::string&),
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1427 -- the ORBvoc.txt that System / ClientSystem hand to it -- parsed on the
+ * host into an orbv_vocab_view (line 1: `k L scoring weighting`; line i: `parent isLeaf d0..d31 weight`, node ids in file order from 1,
+ * children in file order, word ids to the isLeaf > 0 nodes in file order).  m_nodes is protected in the reference
+ * (TemplatedVocabulary.h:405-423): this is the way in that needs no edit there.
+ * flags: ORBV_TEXT_KEEP_TRAILING_NODE reproduces the extra node the reference's `while(!f.eof()) getline` loop makes of the empty
+ * line after the last newline (a child of the root, no children, weight 0; its descriptor is indeterminate in the reference and zero
+ * here); default: the tree the file describes.  A malformed file (header out of range, a node line with fewer than 35 fields, a
+ * parent that is not an earlier node, node lines after a blank line): ORBG_BAD_ARG.
+ * orbv_text_* is the host-only half (no GPU needed); orbv_vocab_from_text = load + orbv_vocab_create + free.
+ * scoring (ScoringType, BowVector.h:48-56; ORBvoc.txt: 0 = L1_NORM) selects the BowVector normalisation as mustNormalize() reports it;
+ * orbv_score_l1 / orbd_detect_n_best_candidates implement the L1 score only. */
+enum { ORBV_TEXT_KEEP_TRAILING_NODE = 1 };
+typedef struct orbv_text orbv_text;
+int orbv_text_load(const char* path, int flags, orbv_text** out);
+/* the parsed tree as a view (pointers valid until orbv_text_free); k / scoring / n_words may be NULL */
+int orbv_text_view(const orbv_text* t, orbv_vocab_view* view, int32_t* k, int32_t* scoring, int32_t* n_words);
+int orbv_text_free(orbv_text* t);
+int orbv_vocab_from_text(int device, const char* path, int flags, orbv_vocab** out);
 /* void transform(const TDescriptor& feature, WordId&, WordValue&, NodeId* nid, int levelsup), TemplatedVocabulary.h:1214-1260,
  * for n descriptors (host memory, n x 32): word_id[n], node_id[n] (node at level L - levelsup; 0 = root when that level is
  * <= 0 or -- pinned, the reference leaves it uninitialised -- when a leaf is reached above it), weight[n]. */

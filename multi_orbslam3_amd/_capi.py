@@ -79,6 +79,23 @@ class VocabView(C.Structure):
 
 ORBV_TF_IDF, ORBV_TF, ORBV_IDF, ORBV_BINARY = 0, 1, 2, 3
 ORBV_NORM_NONE, ORBV_NORM_L1, ORBV_NORM_L2 = 0, 1, 2
+ORBV_TEXT_KEEP_TRAILING_NODE = 1
+
+
+def vocab_view_arrays(v, k=None, scoring=None, n_words=None):
+    """Copies of the arrays an orbv_vocab_view points at (a view handed out by a text loader dies with its handle)."""
+    import numpy as np
+    n = int(v.n_nodes)
+
+    def arr(p, count, dt):
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(dt)), shape=(count,)).copy() if count else np.zeros(0, dt)
+    cs = arr(v.child_start, n + 1, C.c_int32)
+    out = dict(child_start=cs, child_ids=arr(v.child_ids, int(cs[-1]), C.c_int32), desc=arr(v.desc, n * 32, C.c_uint8).reshape(n, 32),
+               weight=arr(v.weight, n, C.c_double), word_id=arr(v.word_id, n, C.c_int32), L=int(v.L), weighting=int(v.weighting),
+               scoring_norm=int(v.scoring_norm))
+    if k is not None:
+        out.update(k=int(k), scoring=int(scoring), n_words=int(n_words))
+    return out
 
 
 class LbaProblem(C.Structure):
@@ -131,7 +148,7 @@ EXPORTED_SYMBOLS = [
     "orbm_search_by_projection_mps", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
     "orbm_search_local_points", "orbm_search_local_points_vis", "orbm_search_by_projection_frame", "orbm_search_by_bow",
     "orbm_search_by_projection_sim3", "orbm_search_by_bow_kf",
-    "orbv_vocab_create", "orbv_vocab_destroy", "orbv_transform", "orbv_transform_frame", "orbv_bow_assemble",
+    "orbv_vocab_create", "orbv_vocab_destroy", "orbv_text_load", "orbv_text_view", "orbv_text_free", "orbv_vocab_from_text", "orbv_transform", "orbv_transform_frame", "orbv_bow_assemble",
     "orbm_distinctive_descriptors", "orbv_score_l1", "orbk_wire_bytes", "orbk_pack_frame", "orbk_frame_from_wire",
     "orbm_frame_download",
     "lba_solve", "lba_create", "lba_destroy", "lba_solve_h", "lba_solve_async", "lba_wait", "pose_optimize",

@@ -587,7 +587,16 @@ class ORBVocabulary:
         self.lib = capi.load()
         self.h = C.c_void_p()
         self._keep = keep
-        capi.check(self.lib.orbv_vocab_create(device, C.byref(view), C.byref(self.h)), "orbv_vocab_create")
+        if view is not None:
+            capi.check(self.lib.orbv_vocab_create(device, C.byref(view), C.byref(self.h)), "orbv_vocab_create")
+
+    @classmethod
+    def loadFromTextFile(cls, path, device=0, keep_trailing_node=False):
+        """ORBVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1427): the reference's ORBvoc.txt straight onto the device."""
+        voc = cls(None, None, device)
+        flags = capi.ORBV_TEXT_KEEP_TRAILING_NODE if keep_trailing_node else 0
+        capi.check(voc.lib.orbv_vocab_from_text(int(device), str(path).encode(), flags, C.byref(voc.h)), "orbv_vocab_from_text")
+        return voc
 
     def close(self):
         if getattr(self, "h", None):
@@ -625,6 +634,19 @@ class ORBVocabulary:
                                               _vp(ff), C.byref(nn)), "orbv_bow_assemble")
         k = nn.value
         return (bw[: nw.value].copy(), bv[: nw.value].copy()), (fn[:k].copy(), fs[: k + 1].copy(), ff[: int(fs[k]) if k else 0].copy())
+
+
+def load_text_vocabulary(path, keep_trailing_node=False):
+    """The host-only half of the loader (no GPU): dict of the flattened tree's arrays + k, scoring, n_words."""
+    lib = capi.load()
+    h = C.c_void_p()
+    capi.check(lib.orbv_text_load(str(path).encode(), capi.ORBV_TEXT_KEEP_TRAILING_NODE if keep_trailing_node else 0, C.byref(h)), "orbv_text_load")
+    try:
+        v = capi.VocabView(); k, sc, nw = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        capi.check(lib.orbv_text_view(h, C.byref(v), C.byref(k), C.byref(sc), C.byref(nw)), "orbv_text_view")
+        return capi.vocab_view_arrays(v, k.value, sc.value, nw.value)
+    finally:
+        lib.orbv_text_free(h)
 
 
 def BowScoreL1(q_word, q_value, cand_start, cand_word, cand_value, device=0):

@@ -15,7 +15,8 @@ for f in extractor matcher lba pose_opt bow; do
 done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC $FLAGS -x hip -c "$HERE/misc.cpp" -o "$HERE/obj/misc.o"
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/extractor.o" "$HERE/obj/matcher.o" "$HERE/obj/lba.o" "$HERE/obj/pose_opt.o" "$HERE/obj/bow.o" "$HERE/obj/misc.o"
+g++ -O2 -std=c++17 -fPIC -Wall -c "$HERE/vocab_text.cpp" -o "$HERE/obj/vocab_text.o"      # host C++ only: the ORBvoc.txt parser
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/extractor.o" "$HERE/obj/matcher.o" "$HERE/obj/lba.o" "$HERE/obj/pose_opt.o" "$HERE/obj/bow.o" "$HERE/obj/misc.o" "$HERE/obj/vocab_text.o"
 # the Tracking-thread loop above the C-ABI (host C++ only: plain g++ against liborbgpu.so)
 g++ -O2 -std=c++17 -fPIC -shared -Wall "$HERE/agent_loop.cpp" -o "$HERE/../libagentloop.so" -L"$HERE/.." -lorbgpu -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib -L/opt/rocm/lib
 echo "built $OUT"

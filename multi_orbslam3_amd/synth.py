@@ -305,3 +305,34 @@ def make_vocabulary(k=10, L=3, seed=0xB0C, stop_frac=0.03, descriptors=None):
         word_id[i] = w
         weight[i] = 0.0 if rng.rand() < stop_frac else float(np.log(1.0 + 50.0 * rng.rand() + 1.0))
     return dict(child_start=child_start, child_ids=child_ids, desc=desc, weight=weight, word_id=word_id, L=L, k=k)
+
+
+def make_full_vocabulary(k=10, L=6, seed=0x0B0C, stop_frac=0.02):
+    """A COMPLETE k-ary tree of depth L in the heap layout (children of node i: k i + 1 .. k i + k; ids grow downwards as DBoW2's do),
+    vectorised so that the reference's size -- k = 10, L = 6: 1 111 111 nodes, 10^6 words, 35 MB of descriptors, what ORBvoc.txt holds --
+    takes seconds.  A child's descriptor is its parent's with a few dozen bits flipped (a walk then has a meaningful nearest child at
+    every level); leaf weights play the idf, written with six significant digits (what saveToTextFile keeps), a few of them 0
+    (stopped words).  Returns the arrays of views.vocab_view + k."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    n_inner = (k ** L - 1) // (k - 1)
+    n = (k ** (L + 1) - 1) // (k - 1)
+    desc = np.zeros((n, 32), np.uint8)
+    lo = 0
+    for lvl in range(L):
+        cnt = k ** lvl
+        parents = desc[lo: lo + cnt]
+        first = k * lo + 1
+        flips = rng.randint(0, 256, (cnt * k, 32)).astype(np.uint8) & rng.randint(0, 256, (cnt * k, 32)).astype(np.uint8)
+        if lvl > 0:
+            flips &= rng.randint(0, 256, (cnt * k, 32)).astype(np.uint8)
+        desc[first: first + cnt * k] = np.repeat(parents, k, axis=0) ^ flips
+        lo += cnt
+    child_start = np.minimum(np.arange(n + 1, dtype=np.int64), n_inner) * k
+    child_ids = np.arange(1, n, dtype=np.int32)
+    word_id = np.zeros(n, np.int32)
+    word_id[n_inner:] = np.arange(n - n_inner, dtype=np.int32)
+    weight = np.zeros(n, np.float64)
+    w = np.log(2.0 + 50.0 * rng.rand(n - n_inner))
+    w[rng.rand(n - n_inner) < stop_frac] = 0.0
+    weight[n_inner:] = np.array([float("%.6g" % x) for x in w]) if n - n_inner <= 20000 else np.round(w, 4)      # (<= 6 significant digits either way)
+    return dict(child_start=child_start.astype(np.int32), child_ids=child_ids, desc=desc, weight=weight, word_id=word_id, L=L, k=k)

@@ -18,7 +18,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("extractor.cc", "matching.cc", "lba.cc", "bow.cc", "orb_oracle.h",
+    srcs = [os.path.join(_HERE, f) for f in ("extractor.cc", "matching.cc", "lba.cc", "bow.cc", "vocab_text.cc", "orb_oracle.h",
                                              "orb_pattern_data.inc", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "orbgpu.h"))
     stale = force or not os.path.exists(LIB_PATH) or any(
@@ -380,6 +380,23 @@ def vocab_bow(voc, desc, levelsup=4):
                                 C.c_void_p(ff.ctypes.data), C.byref(nn)))
     k = nn.value
     return (bw[: nw.value].copy(), bv[: nw.value].copy()), (fn[:k].copy(), fs[: k + 1].copy(), ff[: int(fs[k]) if k else 0].copy())
+
+
+def vocab_save_text(voc, k, path, scoring=0):
+    """saveToTextFile's bytes for a flattened tree (TemplatedVocabulary.h:1431-1450)."""
+    _chk(lib().oracle_vocab_save_text(C.byref(voc), int(k), int(scoring), str(path).encode()))
+
+
+def vocab_load_text(path, keep_trailing_node=False):
+    """loadFromTextFile with the reference's stream operations -> dict of the view's arrays (+ k, scoring, n_words)."""
+    h = C.c_void_p()
+    _chk(lib().oracle_vocab_load_text(str(path).encode(), int(bool(keep_trailing_node)), C.byref(h)))
+    try:
+        v = capi.VocabView(); k, sc, nw = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _chk(lib().oracle_vocab_text_view(h, C.byref(v), C.byref(k), C.byref(sc), C.byref(nw)))
+        return capi.vocab_view_arrays(v, k.value, sc.value, nw.value)
+    finally:
+        lib().oracle_vocab_text_free(h)
 
 
 def distinctive_descriptors(desc, start):

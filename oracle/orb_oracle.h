@@ -106,6 +106,13 @@ int oracle_vocab_transform(const orbv_vocab_view* v, const uint8_t* desc, int n,
                            double* weight);
 int oracle_vocab_bow(const orbv_vocab_view* v, const uint8_t* desc, int n, int levelsup, int32_t* bow_word, double* bow_value,
                      int32_t* n_words, uint32_t* fv_node, uint32_t* fv_start, uint32_t* fv_feat, int32_t* n_fv_nodes);
+/* the vocabulary's text format (TemplatedVocabulary.h:1338-1450): reader with the reference's stream operations, writer of
+ * saveToTextFile's bytes (six significant digits per weight) */
+typedef struct oracle_vocab oracle_vocab;
+int oracle_vocab_load_text(const char* path, int keep_trailing_node, oracle_vocab** out);
+int oracle_vocab_text_view(const oracle_vocab* t, orbv_vocab_view* view, int32_t* k, int32_t* scoring, int32_t* n_words);
+int oracle_vocab_text_free(oracle_vocab* t);
+int oracle_vocab_save_text(const orbv_vocab_view* v, int k, int scoring, const char* path);
 int oracle_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int m, int32_t* best);
 int oracle_score_l1(const int32_t* q_word, const double* q_value, int nq, const int32_t* cand_start, const int32_t* cand_word,
                     const double* cand_value, int m, double* score);

@@ -59,6 +59,10 @@ def test_bench_line_has_the_contract_fields():
     pr = d["parity"]
     assert pr["ok"] is True and pr["frames"] == 20 and pr["extract_bit_exact"] and pr["stereo_bit_exact"] and pr["match_frame_equal"]
     assert pr["match_map_equal"] and pr["lba_iters_equal"] and pr["lba_max_abs"] <= 1e-4 and "libagentloop" in pr["loop"]
+    # ... and the closed loop: 200 frames through the reference-signature glue, product and oracle each on their own outputs
+    cl = pr["closed_loop"]
+    assert cl["ok"] is True and cl["frames"] == 200 and cl["keyframes"] == 40 and cl["first_divergent_frame"] == -1 and cl["first_divergent_frame_no_caches"] == -1
+    assert cl["shadow_calls"] >= 1800 and cl["shadow_mismatches"] == 0 and cl["shadow_max_lba_abs_diff"] <= 1e-4
 
 
 @pytest.mark.gpu

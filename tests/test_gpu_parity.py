@@ -1465,6 +1465,73 @@ def test_vocabulary_transform_parity(scene, k, L, levelsup):
     assert voc.transform_features(np.zeros((0, 32), np.uint8), levelsup)[0].shape == (0,)
 
 
+def test_vocabulary_from_text_at_the_references_size(scene, tmp_path):
+    """ORBvoc.txt's size through ORBvoc.txt's format: a k = 10, L = 6 tree (1 111 111 nodes, 10^6 words, 35 MB of descriptors) written
+    as saveToTextFile writes it, loaded onto the device by orbv_vocab_from_text (the product's loadFromTextFile: no reference-side
+    access to m_nodes) and by the oracle's stream-based reader.  transform() of real frames' descriptors -- word, node at four levels up,
+    weight per feature; BowVector and FeatureVector -- bit-equal; then KeyFrameDatabase::DetectNBestCandidates over a database of 400
+    keyframes whose BowVectors come from that vocabulary (an inverted file of 10^6 words): candidate lists and scores identical."""
+    v = synth.make_full_vocabulary(10, 6)
+    vv, keep = views.vocab_view(v["child_start"], v["child_ids"], v["desc"], v["weight"], v["word_id"], v["L"])
+    path = str(tmp_path / "voc6.txt")
+    ob.vocab_save_text(vv, 10, path)
+    voc = api.ORBVocabulary.loadFromTextFile(path)
+    o_arr = ob.vocab_load_text(path)
+    os.remove(path)
+    for key in ("child_start", "child_ids", "desc", "weight", "word_id"):
+        assert np.array_equal(o_arr[key], v[key]), key
+    ov, okeep = views.vocab_view(o_arr["child_start"], o_arr["child_ids"], o_arr["desc"], o_arr["weight"], o_arr["word_id"], o_arr["L"])
+    frames = [helpers.oracle_stereo_frame(scene, t) for t in (2, 9)]
+    for fr in frames:
+        for levelsup in (4, 2):
+            g = voc.transform_features(fr["desc"], levelsup)
+            o = ob.vocab_transform(ov, fr["desc"], levelsup)
+            for a, b in zip(g, o):
+                assert np.array_equal(a, b)
+            assert len(np.unique(o[0])) > 0.9 * len(fr["desc"])        # a million words: nearly every feature its own
+        (gw, gv), (gn, gs, gf) = voc.transform(fr["desc"], 4)
+        (ow, ovv), (on, os_, of) = ob.vocab_bow(ov, fr["desc"], 4)
+        assert np.array_equal(gw, ow) and np.array_equal(gv, ovv) and np.array_equal(gn, on) and np.array_equal(gs, os_) and np.array_equal(gf, of)
+        assert 10 <= len(gn) <= 100                                    # FeatureVector nodes: level L - 4 = 2 of the tree
+    # features resident on the device
+    fv, keep2 = helpers.frame_view_of(scene, frames[0])
+    F = api.Frame().upload(fv, keep2)
+    g2 = voc.transform_features(frame=F, levelsup=4)
+    for a, b in zip(g2, ob.vocab_transform(ov, frames[0]["desc"], 4)):
+        assert np.array_equal(a, b)
+    # ---- a database over the million words: 400 keyframes = noisy copies of 40 "places" (descriptor sets), BowVectors through the oracle
+    rng = np.random.RandomState(66)
+    base = np.concatenate([fr["desc"] for fr in frames])
+    places = [base[rng.choice(len(base), 700, replace=False)] for _ in range(40)]
+    bows, inv = [], {}
+    for kf in range(400):
+        d = places[(kf // 5) % 40].copy()
+        flip = rng.rand(len(d)) < 0.3                                   # a third of the features change a few bits: other words
+        d[flip] ^= (rng.randint(0, 256, (int(flip.sum()), 32)).astype(np.uint8) & rng.randint(0, 256, (int(flip.sum()), 32)).astype(np.uint8)
+                    & rng.randint(0, 256, (int(flip.sum()), 32)).astype(np.uint8))
+        (bw, bv), _fvec = ob.vocab_bow(ov, d, 4)
+        bows.append((bw, bv))
+        for w in bw:
+            inv.setdefault(int(w), []).append(kf)
+    covis = [[j for j in (kf - 1, kf + 1, kf - 2, kf + 2) if 0 <= j < 400] for kf in range(400)]
+    map_id = (np.arange(400) // 200).astype(np.int32)
+    dv, dkeep = views.database_view(inv, bows, covis, map_id, np.zeros(400, np.uint8), np.zeros(400, np.uint8), 10 ** 6)
+    D = api.KeyFrameDatabase(dv, dkeep)
+    pg, po = np.zeros(400, np.float32), np.zeros(400, np.float32)
+    total = 0
+    for q in range(12):
+        kq = int(rng.randint(400))
+        (qw, qv), _f = voc.transform(places[(kq // 5) % 40], 4)        # the query's BowVector from the DEVICE vocabulary
+        con = np.zeros(400, np.uint8)
+        con[max(kq - 2, 0): kq + 3] = 1
+        gl, gm = D.DetectNBestCandidates(qw, qv, con, int(map_id[kq]), 3, pg)
+        ol, om = ob.detect_n_best_candidates(dv, qw, qv, con, int(map_id[kq]), 3, po)
+        assert np.array_equal(gl, ol) and np.array_equal(gm, om), (q, gl, ol, gm, om)
+        assert np.array_equal(pg.view(np.uint32), po.view(np.uint32)), q
+        total += len(gl) + len(gm)
+    assert total > 12
+
+
 def test_distinctive_descriptors_parity(scene):
     """MapPoint::ComputeDistinctiveDescriptors (row f-3) for a batch of map points, incl. empty, single, tied and >128 lists."""
     rng = np.random.RandomState(4)
