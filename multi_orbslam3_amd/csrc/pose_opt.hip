@@ -253,7 +253,7 @@ __device__ __forceinline__ void po_hessian(const PoEval<V>& e, V om, M mono, con
 // lanes 0..5 of each wave.
 // -DPO_PROFILE: cycles of thread 0 per phase, summed over the call (build, reduce, solve, trial evaluation, trial sum, rest)
 #ifdef PO_PROFILE
-__device__ long long g_po_prof[8];
+__device__ long long g_po_prof[16];
 #define PO_T0() long long po_t = clock64()
 #define PO_ACC(slot) do { const long long po_n = clock64(); if (threadIdx.x == 0) g_po_prof[slot] += po_n - po_t; po_t = po_n; } while (0)
 #else
@@ -514,61 +514,94 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
 }
 
 
-// ---- The same solve with EIGHT wavefronts for up to 512 correspondences (what Tracking hands over: 300-700 per call at 1000-2000
-// features): one correspondence per thread, kept in registers, two wavefronts per SIMD.  A lone wavefront issues a dependent FP64
-// instruction every 8.3-9 cycles where the pipe takes one per 4.2 (tools/micro/fp64_latency): the per-correspondence phases
+// ---- The same solve with EIGHT wavefronts for up to 1024 correspondences (what Tracking hands over: 300-700 per call at 1000-2000
+// features): one or two correspondences per thread, kept in registers, two wavefronts per SIMD.  A lone wavefront issues a dependent
+// FP64 instruction every 8.3-9 cycles where the pipe takes one per 4.2 (tools/micro/fp64_latency): the per-correspondence phases
 // (linearisation, trial evaluation) of the four-wavefront kernel run at ~9 cycles per instruction; with a second wavefront on every
-// SIMD they share the issue slots.  What made round 3's eight-wavefront attempt slower is avoided: the LM trial solves (6 x 6 LDL^T
-// + exponential map, ~1200 FP64 instructions) run on wavefronts 0-3 only, one candidate each, while 4-7 wait at the barrier; and the
-// block sums keep the ORDER of the four-wavefront kernel -- correspondences t and t + 256 sit on neighbouring lanes, the even one adds
-// its neighbour's term behind its own (exactly what thread t did there), then the same tree over those 256 sums -- so every sum,
-// every LM decision and every result is bit-identical to pose_opt_kernel.
+// SIMD they share the issue slots.  The LM trial solves (6 x 6 LDL^T + exponential map, ~1200 FP64 instructions) run on wavefronts
+// 0-3 only, one candidate each, while 4-7 wait at the barrier.
+// Round 6 -- the block sums.  Round 5 kept the four-wavefront kernel's summation ORDER here (lane-pair exchange, then that kernel's
+// LDS transpose: 28 x 512 doubles through LDS and three barriers per linearisation, four barriers per trial) so that both kernels
+// gave the same bits; its own cycle model showed a quarter of the kernel in those sums (83 k of 325 k cycles for 18 linearisations,
+// 68 k for 41 trials).  The order is free: g2o adds the edges serially, the oracle does the same, and what is pinned against the
+// oracle is the outlier set, the inlier count and the pose (tests/test_gpu_parity.py), not the bits of a sum.  Now: the 28 sums of a
+// linearisation fold across the lanes of each wavefront by recursive halving -- v_permlane32_swap / v_permlane16_swap (gfx950) hand
+// half of a lane's values to its partner while it takes the partner's other half, 14 + 7 pair-adds, then four DPP row steps on the 7
+// values left -- and only 8 x 28 wave totals cross LDS (one barrier + one to publish); a trial's sum is a DPP tree per wavefront and
+// eight totals.  Fixed order, bit-reproducible run to run; NOT the four-wavefront kernel's bits any more (n > 1024 still runs there).
 constexpr int kPoWide = 512;
-// the value the neighbouring lane (lane ^ 1) holds: one DPP move per 32-bit half (quad_perm [1, 0, 3, 2])
-__device__ __forceinline__ double po_lane_partner(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
+// (X, Y) -> in lanes 0-31 X summed over the lane pair (l, l + 32), in lanes 32-63 Y summed over it.  v_permlane32_swap exchanges the upper
+// 32 lanes of its first operand with the lower 32 of its second: X' = [X.lo | Y.lo], Y' = [X.hi | Y.hi]; X' + Y' is the fold.
+__device__ __forceinline__ double po_fold32(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
-// Threads 2t and 2t + 1 hold the correspondences t and t + 256 of the four-wavefront kernel's thread t: the even lane adds its
-// neighbour's term behind its own (no LDS, no barrier) and plays thread t in that kernel's reduction.
-template <int NV>
-__device__ inline void po_block_reduce_wide(const double* vals, double* s_acc, double* s_part, double* out) {
-  const int tid = threadIdx.x, t = tid >> 1;
-  const int col = (t >> 5) * 33 + (t & 31);
-#pragma unroll
-  for (int v = 0; v < NV; v++) {
-    const double sum = vals[v] + po_lane_partner(vals[v]);
-    if (!(tid & 1)) s_acc[v * kPoRow + col] = sum;
-  }
-  __syncthreads();
-  if (tid < NV * 8) {
-    const double* p = s_acc + (tid >> 3) * kPoRow + (tid & 7) * 33;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) { a0 += p[4 * j]; a1 += p[4 * j + 1]; a2 += p[4 * j + 2]; a3 += p[4 * j + 3]; }
-    s_part[tid] = (a0 + a1) + (a2 + a3);
-  }
-  __syncthreads();
-  if (tid < NV) {
-    const double* p = s_part + tid * 8;
-    out[tid] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-  }
-  __syncthreads();
+// the same across rows of 16 lanes: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second:
+// X' = [X.r0, Y.r0, X.r2, Y.r2], Y' = [X.r1, Y.r1, X.r3, Y.r3]; even rows of X' + Y' hold X over the row pair, odd rows Y
+__device__ __forceinline__ double po_fold16(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
-// sum of one term per thread in the four-wavefront kernel's order: (term of t) + (term of t + 256) on the even lane, then that
-// kernel's DPP tree over its threads 0..255 (wavefronts 0-3 here, through LDS) and the four wave totals in wave order
-__device__ __forceinline__ double po_block_sum_wide(double v, double* s_pair, double (*wsum)[4], int slot) {
-  const int tid = threadIdx.x;
-  const double pr = v + po_lane_partner(v);
-  if (!(tid & 1)) s_pair[tid >> 1] = pr;
-  __syncthreads();
-  if (tid < 256) {
-    const double w = wave_sum_f64(s_pair[tid]);
-    if ((tid & 63) == 0) wsum[slot][tid >> 6] = w;
+// sum over the 16 lanes of a row, valid in the row's last lane (row_shr 1, 2, 4, 8: the scan of wave.hpp without its cross-row steps)
+__device__ __forceinline__ double po_row_sum(double v) {
+#define PO_DPP64(ctrl)                                                                              \
+  {                                                                                                 \
+    /* bound_ctrl: a lane without a source reads 0 -- no "old" operand to initialise (one v_mov less per DPP move) */ \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, true); \
+    v += __hiloint2double(hi, lo);                                                                  \
   }
+  PO_DPP64(0x111) PO_DPP64(0x112) PO_DPP64(0x114) PO_DPP64(0x118)
+#undef PO_DPP64
+  return v;
+}
+// Block-wide sums of 28 per-thread values (8 wavefronts), out[0..28) valid for every thread afterwards.  v is consumed.
+// After the two folds a lane of row r holds, in v[j], the value with index (r >> 1) * 14 + (r & 1) * 7 + j summed over the four lanes
+// of its column c: 8 wavefronts x 16 columns = 128 partial sums per index go through LDS (7 stores per lane instead of 28), thread
+// (index, column) adds the eight wavefronts' partials of its column in wave order, a DPP row sum adds the 16 columns.  (All of it in
+// registers -- four more DPP steps on the 7 values in every wavefront -- was 215 instructions per wavefront, eight times over on
+// four SIMDs: 3600 cycles per linearisation; this is ~100.)
+#ifdef PO_PROFILE
+#define PO_SUB(slot) do { const long long po_n = clock64(); if (threadIdx.x == 0) g_po_prof[slot] += po_n - *po_tp; *po_tp = po_n; } while (0)
+#else
+#define PO_SUB(slot) do { } while (0)
+#endif
+__device__ inline void po_block_reduce_free(double (&v)[28], double* s_p /* [8][28][16] */, double* out, [[maybe_unused]] long long* po_tp = nullptr) {
+  const int tid = threadIdx.x, lane = tid & 63, row = lane >> 4, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 14; j++) v[j] = po_fold32(v[j], v[j + 14]);
+  PO_SUB(8);
+#pragma unroll
+  for (int j = 0; j < 7; j++) v[j] = po_fold16(v[j], v[j + 7]);
+  PO_SUB(9);
+  {
+    double* dst = s_p + ((wave * 28 + (row >> 1) * 14 + (row & 1) * 7) << 4) + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 7; j++) dst[16 * j] = v[j];
+  }
+  PO_SUB(10);
   __syncthreads();
-  return ((wsum[slot][0] + wsum[slot][1]) + wsum[slot][2]) + wsum[slot][3];
+  PO_SUB(11);
+  if (tid < 28 * 16) {                       // thread (index = tid >> 4, column = tid & 15)
+    const double* p = s_p + tid;
+    constexpr int kW = 28 * 16;
+    double t = ((p[0] + p[kW]) + (p[2 * kW] + p[3 * kW])) + ((p[4 * kW] + p[5 * kW]) + (p[6 * kW] + p[7 * kW]));
+    t = po_row_sum(t);
+    if ((tid & 15) == 15) out[tid >> 4] = t;
+  }
+  PO_SUB(12);
+  __syncthreads();
+  PO_SUB(13);
+}
+// sum of one term per thread: DPP tree per wavefront, the eight wave totals in wave order (`slot` alternates between consecutive
+// calls: one barrier per sum)
+__device__ __forceinline__ double po_block_sum_free(double v, double (*w8)[8], int slot) {
+  const double w = wave_sum_f64(v);
+  if ((threadIdx.x & 63) == 0) w8[slot][threadIdx.x >> 6] = w;
+  __syncthreads();
+  const double* p = w8[slot];
+  return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
 }
 // exact count (every term 0 or 1): any order
 __device__ __forceinline__ double po_block_count_wide(double v, double* s_cnt) {
@@ -582,23 +615,19 @@ __device__ __forceinline__ double po_block_count_wide(double v, double* s_cnt) {
   return s;
 }
 
-// NP = 1: n <= 512, one correspondence per thread; NP = 2: n <= 1024, lanes 2t / 2t + 1 hold (t, t + 512) / (t + 256, t + 768) and the
-// even lane collects the four-wavefront kernel's sum order ((h_t + h_t+256) + h_t+512) + h_t+768 with one neighbour exchange per pass.
+// NP = 1: n <= 512, one correspondence per thread; NP = 2: n <= 1024, two (a thread adds its own two terms first).
 template <int NP>
 __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const float* g_Xw, const float* g_ou, const float* g_ov, const float* g_our,
                                                                 const float* g_oinv, Cam cam, PoseQ T0, PoseQ* __restrict__ T_out,
                                                                 uint8_t* __restrict__ outlier_out, int* __restrict__ stats, double* __restrict__ chi_out,
                                                                 unsigned seq) {
-  __shared__ double s_acc[28 * kPoRow];
-  __shared__ double s_part[28 * 8];
+  __shared__ double s_w[8 * 28 * 16];
   __shared__ double red[28];
-  __shared__ double s_wsum[2][4];
+  __shared__ double s_w8[2][8];
   __shared__ double s_cnt[8];
-  __shared__ double s_pair[256];
   __shared__ double s_cand[4][14];
   int sum_slot = 0;
   const int tid = threadIdx.x;
-  const bool even = !(tid & 1);
   const int li = min(tid & 63, 5);
   const double dM = (float)sqrt(5.991), dS = (float)sqrt(7.815);
   const double dsqM = dM * dM, dsqS = dS * dS;
@@ -609,7 +638,7 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
   double my_chi2[NP];                                        // last evaluated chi2 of the correspondence
 #pragma unroll
   for (int p = 0; p < NP; p++) {
-    const int i_mine = (tid >> 1) + 256 * (tid & 1) + 512 * p;       // pass p: lanes 2t, 2t + 1 <-> correspondences t + 512 p, t + 256 + 512 p
+    const int i_mine = tid + 512 * p;                                // correspondences tid, tid + 512 (coalesced reads)
     have[p] = i_mine < n;
     const int i = have[p] ? i_mine : 0;
     idx[p] = i;
@@ -642,12 +671,6 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
       for (int k = 0; k < 28; k++) acc[k] = 0;
 #pragma unroll
       for (int p = 0; p < NP; p++) {
-        if (p > 0) {
-          // the even lane takes its neighbour's term of the pass before (it now holds what thread t held after correspondence
-          // t + 256 (p - 1) ... in the four-wavefront kernel), the odd lane starts the pass from zero
-#pragma unroll
-          for (int k = 0; k < 28; k++) { const double nb = po_lane_partner(acc[k]); acc[k] = even ? acc[k] + nb : 0.0; }
-        }
         if (active[p]) {
           const double X[3] = {(double)Xf[p][0], (double)Xf[p][1], (double)Xf[p][2]};
           const double om = (double)omf[p];
@@ -662,7 +685,11 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
         }
       }
       PO_ACC(0);
-      po_block_reduce_wide<28>(acc, s_acc, s_part, red);
+#ifdef PO_PROFILE
+      po_block_reduce_free(acc, s_w, red, &po_t);
+#else
+      po_block_reduce_free(acc, s_w, red);
+#endif
       PO_ACC(1);
       double Hrow[6], b[6];
 #pragma unroll
@@ -722,7 +749,6 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
         double tchi = 0;
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-          if (p > 0) { const double nb = po_lane_partner(tchi); tchi = even ? tchi + nb : 0.0; }
           if (active[p]) {
             const double X[3] = {(double)Xf[p][0], (double)Xf[p][1], (double)Xf[p][2]};
             PoEval<double> e1;
@@ -731,7 +757,7 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
           }
         }
         PO_ACC(3);
-        double tempChi = po_block_sum_wide(tchi, s_pair, s_wsum, sum_slot); sum_slot ^= 1;
+        double tempChi = po_block_sum_free(tchi, s_w8, sum_slot); sum_slot ^= 1;
         PO_ACC(4);
         if (!ok2) tempChi = 1.7976931348623157e308;
         rho = currentChi - tempChi;
@@ -794,7 +820,7 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
 #ifdef PO_PROFILE
 extern "C" int pose_opt_debug_prof(long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_po_prof), sizeof(g_po_prof)) != hipSuccess) return -1;
-  if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_po_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  if (reset) { long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_po_prof), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
 #endif

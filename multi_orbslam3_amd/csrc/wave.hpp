@@ -54,7 +54,15 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     const int lo = ORBG_DPP(0, __double2loint(v), ctrl, rmask), hi = ORBG_DPP(0, __double2hiint(v), ctrl, rmask); \
     v += __hiloint2double(hi, lo);                                                                 \
   }
-  ORBG_DPP64(0x111, 0xF) ORBG_DPP64(0x112, 0xF) ORBG_DPP64(0x114, 0xF) ORBG_DPP64(0x118, 0xF) ORBG_DPP64(0x142, 0xA) ORBG_DPP64(0x143, 0xC)
+  // (row_shr steps with bound_ctrl: a lane without a source reads 0, so no "old" operand has to be zeroed first -- one v_mov less per
+  // DPP move; the two row_bcast steps write only the rows of their mask and need the zero in the others)
+#define ORBG_DPP64B(ctrl)                                                                          \
+  {                                                                                                \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, true); \
+    v += __hiloint2double(hi, lo);                                                                 \
+  }
+  ORBG_DPP64B(0x111) ORBG_DPP64B(0x112) ORBG_DPP64B(0x114) ORBG_DPP64B(0x118) ORBG_DPP64(0x142, 0xA) ORBG_DPP64(0x143, 0xC)
+#undef ORBG_DPP64B
 #undef ORBG_DPP64
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);

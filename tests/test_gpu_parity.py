@@ -1414,12 +1414,20 @@ def test_pose_optimization_parity(n, of, mono):
     p, keep = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"])
     g = api.Optimizer().PoseOptimization(p)
     o = ob.pose_optimize(p)
-    assert g.iters == o.iters and g.n_inliers == o.n_inliers
+    # what the caller sees: the outlier flags, the inlier count, the pose.  The kernel adds the per-correspondence terms in a tree
+    # order (round 6: lane folds), g2o / the oracle serially; "chi2 improved by less than 1e-3" is a threshold on sums that differ
+    # in their last bits, so a round may run one LM iteration more or less (the sweep below counts how often: a few per cent) --
+    # the round then ends a hair further down the same valley
+    assert g.n_inliers == o.n_inliers
     assert np.array_equal(g.outliers, o.outliers)
-    assert np.abs(g.Tcw - o.Tcw).max() <= 1e-4
-    assert np.allclose(g.chi2, o.chi2, rtol=1e-8, atol=1e-9)
+    assert np.abs(g.Tcw.astype(np.float64) - o.Tcw.astype(np.float64)).max() <= 1e-6
+    assert all(abs(a - b) <= 1 for a, b in zip(g.iters, o.iters)), (g.iters, o.iters)
+    if g.iters == o.iters:
+        assert np.allclose(g.chi2, o.chi2, rtol=1e-8, atol=1e-9)
+    else:
+        assert np.allclose(g.chi2, o.chi2, rtol=1e-4, atol=1e-6)
     g2 = api.Optimizer().PoseOptimization(p)
-    assert np.array_equal(g.Tcw, g2.Tcw)
+    assert np.array_equal(g.Tcw, g2.Tcw) and g.iters == g2.iters        # bit-reproducible run to run
 
 
 def test_lba_async_matches_blocking_call():

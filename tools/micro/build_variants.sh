@@ -11,7 +11,7 @@ bash "$C/build.sh" > /dev/null
 /opt/rocm/bin/hipcc $FLAGS -DPO_PROFILE -c "$C/pose_opt.hip" -o "$T/pose_opt.o" &
 /opt/rocm/bin/hipcc $FLAGS -DOCT_PROFILE -c "$C/extractor.hip" -o "$T/extractor.o" &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$V/liborbgpu_poprof.so" "$C/obj/extractor.o" "$C/obj/matcher.o" "$C/obj/lba.o" "$T/pose_opt.o" "$C/obj/bow.o" "$C/obj/misc.o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$V/liborbgpu_octprof.so" "$T/extractor.o" "$C/obj/matcher.o" "$C/obj/lba.o" "$C/obj/pose_opt.o" "$C/obj/bow.o" "$C/obj/misc.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$V/liborbgpu_poprof.so" "$C/obj/extractor.o" "$C/obj/matcher.o" "$C/obj/lba.o" "$T/pose_opt.o" "$C/obj/bow.o" "$C/obj/misc.o" "$C/obj/vocab_text.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$V/liborbgpu_octprof.so" "$T/extractor.o" "$C/obj/matcher.o" "$C/obj/lba.o" "$C/obj/pose_opt.o" "$C/obj/bow.o" "$C/obj/misc.o" "$C/obj/vocab_text.o"
 rm -rf "$T"
 echo "built $V/liborbgpu_poprof.so $V/liborbgpu_octprof.so"

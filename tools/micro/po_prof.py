@@ -9,7 +9,7 @@ opt = api.Optimizer(0)
 pr = synth.make_pose_opt_problem(n=450, seed=77)
 po, keep = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"], device=0)
 lib = _capi.load()
-buf = (C.c_longlong * 8)()
+buf = (C.c_longlong * 16)()
 lib.pose_opt_debug_prof.argtypes = [C.c_void_p, C.c_int]
 for _ in range(3):
     opt.PoseOptimization(po)
@@ -21,3 +21,4 @@ tot = sum(buf[i] for i in range(6))
 print("iters", r.iters, "total cycles", tot)
 for i, nm in enumerate(names):
     print("%-14s %8d cycles  %5.1f %%" % (nm, buf[i], 100.0 * buf[i] / tot))
+print("inside reduce28 (thread 0): fold32 %d, fold16 %d, LDS stores %d, barrier %d, column sums %d, barrier %d" % tuple(buf[8:14]))
