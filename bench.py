@@ -431,12 +431,16 @@ def server_tick_parity(server, views):
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N rank processes of this same command (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment, as torch.distributed.run sets them), rank 0 inheriting stdout -- it prints the ONE line.  The parent
-    never initialises the GPU (torch.cuda.device_count() does not on this image).  Returns the exit code: 0 when every rank returned 0;
+    never loads the HIP runtime: it counts the GPUs in the KFD topology under /sys (harness.count_gpus_without_runtime; only where
+    sysfs does not show it does it fall back to torch.cuda.device_count()).  Returns the exit code: 0 when every rank returned 0;
     2 when the node has fewer GPUs than ranks (ORBG_BENCH_SHARE_GPU=1, a test aid, lets ranks share the GPUs that exist)."""
     import socket
     import subprocess
-    import torch
-    n_dev = torch.cuda.device_count()
+    from multi_orbslam3_amd import harness as _h
+    n_dev = _h.count_gpus_without_runtime()
+    if n_dev is None:
+        import torch
+        n_dev = torch.cuda.device_count()
     if n_dev < n and os.environ.get("ORBG_BENCH_SHARE_GPU") != "1":
         sys.stderr.write("bench.py: --gpus %d but this node has %d GPU%s (one agent per GPU; ORBG_BENCH_SHARE_GPU=1 shares them for a dry run)\n"
                          % (n, n_dev, "" if n_dev == 1 else "s"))
@@ -1290,6 +1294,9 @@ def main():
                                          "called through the reference-signature glue (include/orbgpu_dropin.hpp) on mock Frame / MapPoint "
                                          "objects, synchronous constructor, one thread: frames/s of that frame path; per-call glue / upload / "
                                          "C-ABI microseconds under config.dropin")
+            line["value_dropin_with_pose_opt"] = dropin.get("frames_per_s_frame_path_with_pose_opt")
+            line["value_dropin_with_pose_opt_note"] = ("the same + both Optimizer::PoseOptimization calls of a frame (S/Tracking.cc:2649, :2712) through the glue: "
+                                                       "what an UNCHANGED Tracking thread (synchronous constructor, one thread) gets per frame")
             line["config"]["dropin"] = dropin
         if server_tick is not None:
             line["config"]["server_tick"] = server_tick
@@ -1387,12 +1394,19 @@ def main():
         parity["agent_ids"] = [args.first_agent + r_ for r_ in range(world)]
         if not all(parity["agents_ok"]):
             parity["ok"] = False
+    # rank -> GPU -> NUMA node -> CPU sets: where every agent of the job ran (what a multi-GPU run must show next to its scaling figure)
+    place = harness.gpu_placement(device)
+    place.update(rank=rank, agent=args.first_agent + rank, cpu_affinity=cpu_affinity,
+                 cores=None if core_pair is None else {"tracking": sorted(core_pair[0]), "local_ba_worker": sorted(core_pair[1]) if len(core_pair) > 1 else None,
+                                                       "image_ingest": sorted(core_pair[2]) if len(core_pair) > 2 else None})
+    placement = grp.gather_objects(place)
     kinds = grp.gather_floats(0.0 if stereo else 1.0)
     pol = grp.gather_floats(float(sum(1 << j for j, r in enumerate(("caller", "lba", "ingest")) if wait_policy[r] == "block")))
     server_report = server.report() if server is not None else None
     if rank == 0:
         line["parity"] = parity
         line["config"]["agents"] = ["stereo" if v == 0.0 else "mono" for v in kinds]
+        line["config"]["placement_per_rank"] = placement
         line["config"]["wait_policy_per_rank"] = ["".join(("b" if (int(v) >> j) & 1 else "s") for j in range(3)) + " (tracking / local-BA worker / ingest: s = spins, b = blocks)"
                                                   for v in pol]
         if server_report is not None:

@@ -20,6 +20,49 @@ def _parse_cpulist(text):
     return cpus
 
 
+def count_gpus_without_runtime():
+    """GPUs of this node as the KFD topology lists them (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with simd_count > 0 is
+    a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set -- WITHOUT loading the HIP runtime: a launcher process
+    that starts its ranks as children must not have touched the GPU (on this pool a process that has may not replace itself, and
+    the count must not depend on what torch.cuda.device_count() does or does not initialise).  None when sysfs does not show it."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in sorted(os.listdir(base)):
+            props = {}
+            with open(os.path.join(base, node, "properties")) as f:
+                for ln in f:
+                    kv = ln.split()
+                    if len(kv) == 2:
+                        props[kv[0]] = kv[1]
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
+def gpu_placement(device_index):
+    """Where an agent runs: its GPU's PCI address and NUMA node, and the CPUs the process is allowed on right now (a dict for the
+    bench line's per-rank table; fields are None where the topology is not visible)."""
+    out = {"device": int(device_index), "pci": None, "numa_node": None, "cpus": sorted(os.sched_getaffinity(0))}
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        out["pci"] = bdf
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            out["numa_node"] = int(f.read().strip())
+    except Exception:
+        pass
+    return out
+
+
 def pin_to_gpu_numa_node(device_index):
     """Restrict this process (and the threads it creates afterwards: the library's LBA worker) to the CPUs of the NUMA node
     the GPU hangs off -- what `numactl --cpunodebind` does for a deployed agent.  The per-frame path spins on words in pinned
@@ -241,6 +284,14 @@ class AgentGroup:
         out = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
         self.dist.all_gather(out, mine)
         return [float(v[0]) for v in out]
+
+    def gather_objects(self, obj):
+        """One small picklable object per rank -> list over ranks (on every rank; control plane)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def timed(self, fn, steps, sync=None):
         """barrier + sync, exactly `steps` calls of fn(i), sync + barrier; returns MAX-over-ranks seconds."""

@@ -207,6 +207,12 @@ int main(int argc, char** argv) {
     auto reset_po = [&]() { Cur.mvpMapPoints = after_map; Cur.mTcw = Tguess; std::fill(Cur.mvbOutlier.begin(), Cur.mvbOutlier.end(), false); };
     rows.push_back(measure("PoseOptimization", reps, 5, reset_po, [&]() { return od::PoseOptimization<TimedOps>(&Cur); }));
     rows.back().work = n_corr;
+    // ... and the FIRST call of a frame (S/Tracking.cc:2649): on the matches of SearchByProjection(Cur, Last) alone
+    int n_corr1 = 0; for (auto* p : after_frame) n_corr1 += p != nullptr;
+    auto reset_po1 = [&]() { Cur.mvpMapPoints = after_frame; Cur.mTcw = Tguess; std::fill(Cur.mvbOutlier.begin(), Cur.mvbOutlier.end(), false); };
+    rows.push_back(measure("PoseOptimization (first call of a frame: the frame-to-frame matches)", reps, 5, reset_po1, [&]() { return od::PoseOptimization<TimedOps>(&Cur); }));
+    rows.back().work = n_corr1;
+    const double po_second = rows[rows.size() - 2].total, po_first = rows.back().total;
     // ---- LocalMapping: LocalBundleAdjustment on 20 + 10 keyframe windows of 2000 points.  First row: consecutive windows of one map
     // (each for a new keyframe that sees a third of the last one's points; windows 3-8 of 8 are timed) -- what LocalMapping does, and
     // what the glue's window cache is for.  Second row: a fresh map per call (nothing to reuse: the cost of a first window).
@@ -265,8 +271,11 @@ int main(int argc, char** argv) {
       else if (i == 2) frame_path += 0.8 * r.total;
       else if (i == 3) frame_path += 0.2 * r.total;
     }
-    char tail[512];
-    std::snprintf(tail, sizeof(tail), "}, \"frame_path_us\": %.1f, \"frames_per_s_frame_path\": %.1f, \"local_map_points\": %zu, \"reps\": %d}", frame_path, 1e6 / frame_path,
+    char tail[768];
+    // ... and what an unchanged Tracking thread gets per frame: the same + both PoseOptimization calls (S/Tracking.cc:2649, :2712)
+    const double full_path = frame_path + po_first + po_second;
+    std::snprintf(tail, sizeof(tail), "}, \"frame_path_us\": %.1f, \"frames_per_s_frame_path\": %.1f, \"frame_path_with_pose_opt_us\": %.1f, "
+                  "\"frames_per_s_frame_path_with_pose_opt\": %.1f, \"local_map_points\": %zu, \"reps\": %d}", frame_path, 1e6 / frame_path, full_path, 1e6 / full_path,
                   local.size(), reps);
     js += tail;
     std::printf("%s\n", js.c_str());

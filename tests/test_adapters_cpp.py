@@ -145,7 +145,8 @@ def test_dropin_bench_times_the_path_through_the_glue():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     rows = d["dropin_bench"]
-    assert len(rows) == 8 and d["frames_per_s_frame_path"] > 0 and d["local_map_points"] > 2000
+    assert len(rows) == 9 and d["frames_per_s_frame_path"] > 0 and d["local_map_points"] > 2000
+    assert 0 < d["frames_per_s_frame_path_with_pose_opt"] < d["frames_per_s_frame_path"]
     # the local BA's window cache: consecutive windows of one map cost the glue less than half of a first window
     lba_next = [r for n, r in rows.items() if "consecutive windows" in n][0]
     lba_first = [r for n, r in rows.items() if "first window of a map" in n][0]

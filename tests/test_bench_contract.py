@@ -267,6 +267,23 @@ def test_self_launched_ranks_and_the_in_job_parity_gate():
     assert pr["lba_max_abs"] <= 1e-4 and pr["lba_trace_max_rel"] <= 1e-9 and pr["keypoints_checked"] > 30000
 
 
+@pytest.mark.gpu
+def test_eight_ranks_dry_run_of_the_c5_job_on_a_shared_gpu():
+    """`python bench.py --gpus 8 --config C5` exactly as it would be typed on an 8-GPU node, here with all eight ranks on the box's one GPU
+    (ORBG_BENCH_SHARE_GPU=1; the server tick's exchange then goes through gloo): the launcher counts the GPUs without loading the HIP
+    runtime, eight rank processes come up, ONE line with n_gpus == 8 comes back, the mixed mono / stereo agent kinds of configs[4] are
+    in place, every agent's in-job parity gate is green, and the line says where every rank ran (rank -> GPU -> NUMA node -> CPUs).
+    The rate it prints says nothing -- eight agents share one GPU and this box's CPU quota; the code path is the 8-GPU one."""
+    common = ["--steps", "20", "--warmup", "5", "--no-secondary", "--no-dropin", "--no-cpu-baseline", "--repeats", "1", "--prewarm-steps", "20"]
+    d = _run_bench(["--config", "C5", "--gpus", "8"] + common, share=True, timeout=1500)
+    assert d["n_gpus"] == 8 and d["config"]["name"] == "C5" and len(d["config"]["agents"]) == 8 and set(d["config"]["agents"]) == {"stereo", "mono"}
+    pr = d["parity"]
+    assert pr["ok"] is True and pr["agents_ok"] == [True] * 8 and len(set(pr["agent_digests"])) >= 2 and pr["server_tick"]["ok"] is True
+    pl = d["config"]["placement_per_rank"]
+    assert [p["rank"] for p in pl] == list(range(8)) and all(p["device"] == 0 and p["cpus"] for p in pl)
+    assert d["config"]["server_tick_in_job"]["ticks"] >= 1
+
+
 def _last_json_line(stdout):
     lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, stdout[-2000:]
