@@ -53,7 +53,8 @@ CONFIGS = {
                      "(20 free + 10 fixed KFs, 2000 points)"),
     "C4": dict(W=1280, H=720, stereo=True, n_features=2000, lba=(50, 20, 8000), mono_frac=0.0, frame_cap=8192, map_cap=131072, local_kfs=50,
                label="C4 (single-GPU part of configs[3]): 1 client stereo 1280x720 synthetic, 2000 ORB feat/frame, 50-KF local BA "
-                     "window (50 free + 20 fixed KFs, 8000 points); visual edges only (IMU types are out of scope)"),
+                     "window (50 free + 20 fixed KFs, 8000 points); the VISUAL local BA, i.e. what a stereo-inertial client runs before its IMU is "
+                     "initialised (Optimizer::LocalBundleAdjustment; LocalInertialBA and the IMU types are out of SURVEY section 8's scope)"),
     "mono": dict(W=640, H=480, stereo=False, n_features=1000, lba=(20, 10, 2000), mono_frac=1.0, frame_cap=4096, map_cap=32768, local_kfs=20,
                  label="mono agent of configs[4]: 1 client mono 640x480 synthetic (Frame::Frame(mono), S/Frame.cc:260-358: host image -> "
                        "ExtractORB with lapping area {0,1000} -> grid, one fused submission), 1000 ORB feat/frame, 20-KF local BA of monocular edges"),
@@ -1143,18 +1144,6 @@ def main():
         ldlt_ms_raw = solver_sum_ms / max(solver_n, 1)
         ldlt_ms = max(ldlt_ms_raw - lba_ev_overhead_ms, 1e-6)
         ldlt_tflops = ldlt_flops / (ldlt_ms * 1e-3) / 1e12 if solver_n else 0.0
-        # HBM-side traffic of that kernel: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this same
-        # command, KB per launch), committed under profiles/ (newest round)
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_per_kernel.json")))[-1]
-            pm = json.load(open(pj))
-            key = [k2 for k2 in pm if "k_ldlt" in k2][0]
-            traffic = int(1024 * (pm[key]["FETCH_SIZE_KB_avg"] + pm[key]["WRITE_SIZE_KB_avg"]))
-            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)" % os.path.basename(pj)
-        except Exception:
-            pass
         # ---- which kernel dominates the step?  device time per step = average launch x launches per step
         lm_per_ba = stats["lba_iters"] / max(stats["lba_calls"], 1)
         # the variant ldltm::pick() chooses for this many unknowns (tile rows T of the bordered matrix)
@@ -1163,6 +1152,21 @@ def main():
         ldlt_name = (("ldltm::k_ldlt_cols" if ldlt_T <= 8 else "ldltx::k_ldlt_xcd" if xcd_on and ldlt_T <= 19 else "ldltm::k_ldlt_mfma" if ldlt_T <= 9 else
                       "ldltm::k_ldlt_big" if ldlt_T <= 15 else "ldltm::k_ldlt_big48")
                      if solver_mfma else "k_wide_panel / k_wide_update")
+        # HBM-side traffic of THAT kernel on THIS configuration: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of this
+        # same command, KB per launch), committed under profiles/ (newest round; C4 has a file of its own: a 300 x 300 triangle is
+        # 361 KB, the C2 kernel's 58 KB says nothing about it).  No matching kernel in the file: null, not somebody else's figure.
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            suffix = "" if args.config == "C2" else "_" + args.config
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_per_kernel%s.json" % suffix)))[-1]
+            pm = json.load(open(pj))
+            want = ldlt_name.split("::")[-1].split(" ")[0]
+            key = [k2 for k2 in pm if want in k2][0]
+            traffic = int(1024 * (pm[key]["FETCH_SIZE_KB_avg"] + pm[key]["WRITE_SIZE_KB_avg"]))
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; kernel %s)" % (os.path.basename(pj), key)
+        except Exception:
+            pass
         per_step = {ldlt_name: ldlt_ms * lm_per_ba / FRAMES_PER_KF if solver_n else 0.0, "fast_cells_kernel": fast_ms if fast_n else 0.0}
         for kname, (kms, kn) in chain_ms.items():
             per_step[kname] = kms

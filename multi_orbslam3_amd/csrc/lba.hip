@@ -49,6 +49,22 @@ using namespace orbg_se3;
 
 namespace {
 
+// -DLBA_PROFILE (tools/micro/build_variants.sh -> liborbgpu_lbaprof.so, tools/micro/lba_prof.py): wall-clock stamps (100 MHz, common
+// to all compute units) of the three per-LM-step kernels next to the LDL^T -- every workgroup's first and last instruction, and the
+// phases of one workgroup of each role -- for the floor models of DESIGN.md section 8.  Slots: [kernel 0..2][0..7] phases of the
+// sampled workgroup, [8 + 2 b], [9 + 2 b] start / end of workgroup b (b < 1020).
+#ifdef LBA_PROFILE
+__device__ long long g_lba_prof[3][8 + 2 * 1020];
+#define LBA_PROF_BEGIN(kern) const int lbp_k = (kern); const long long lbp_t0 = (long long)wall_clock64(); \
+  if (threadIdx.x == 0 && blockIdx.x < 1020) g_lba_prof[lbp_k][8 + 2 * blockIdx.x] = lbp_t0
+#define LBA_PROF_END() do { if (threadIdx.x == 0 && blockIdx.x < 1020) g_lba_prof[lbp_k][9 + 2 * blockIdx.x] = (long long)wall_clock64(); } while (0)
+#define LBA_PROF_PHASE(block, slot) do { if (threadIdx.x == 0 && (int)blockIdx.x == (block)) g_lba_prof[lbp_k][slot] = (long long)wall_clock64() - lbp_t0; } while (0)
+#else
+#define LBA_PROF_BEGIN(kern) do { } while (0)
+#define LBA_PROF_END() do { } while (0)
+#define LBA_PROF_PHASE(block, slot) do { } while (0)
+#endif
+
 __device__ inline void edge_error(const PoseQ& T, const double* X, const Cam& c, const lba_edge& e, double* err, double* Xc) {
   double r[3];
   quat_rotate(T.q, X, r);
@@ -77,7 +93,13 @@ struct Huber { double delta_mono, dsqr_mono, delta_stereo, dsqr_stereo; };
 // ---------------------------------------------------------------------------------------------- kernels
 
 // residuals + chi2 + robust rho (computeActiveErrors + activeRobustChi2); block partial sums in fixed order
-struct HostRec { double chi2, scale, maxdiag, chi2_init; int ok; unsigned seq; };   // seq is written last: the host spins on it   // what the host reads per LM trial (mapped pinned memory)
+// what the host reads per LM trial (mapped pinned memory).  Round 6: chi2, scale and ok of a trial travel as self-validating pairs
+// (value, value ^ tag(seq)) written with system-scope stores -- the host takes the record when seq is the one it waits for AND the
+// three pairs check out under that tag.  Before, a system-scope release fence stood between the values and seq: on gfx950 that is
+// a write-back of the XCD's whole L2, microseconds while the launch's edge workgroups have megabytes of Jacobian blocks dirty in
+// it (the publisher workgroup ended 2.5 us after everybody else; tools/micro/lba_prof.py).  No ordering is needed now.
+struct HostRec { double chi2, scale, maxdiag, chi2_init; int ok; unsigned seq; unsigned long long c_chi2, c_scale, c_ok; };
+__host__ __device__ inline unsigned long long rec_tag(unsigned seq) { return (0x9E3779B97F4A7C15ull * ((unsigned long long)seq + 1ull)) | 1ull; }
 
 // Results of a solve, written by the GPU straight into the caller-visible pinned block (no copy commands): per edge a flag
 // byte (bit 0 = isDepthPositive() with the final estimate, bit 1 = outlier: chi2 > 5.991 / 7.815 or depth <= 0,
@@ -110,25 +132,12 @@ __global__ __launch_bounds__(256) void k_export(int n_edges, int n_poses, int n_
 // trial started from (by value, or from device memory at the start of a round) and where to leave lambda for the accepted case.
 struct LmIn { double cur_chi, lambda; const double* chi_p; const double* lambda_p; double* lambda_next; };
 
-__device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const double* __restrict__ partial, unsigned* __restrict__ ticket,
-                                                     const double* __restrict__ scale_partial, int n_scale_partial,
-                                                     const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq,
-                                                     const LmIn lm = LmIn{0, 0, nullptr, nullptr, nullptr}) {
-  __shared__ int s_last;
+// the tail: all n_edge_blocks partials are in memory and visible to this workgroup
+__device__ __forceinline__ void publish_trial_tail(int n_edge_blocks, const double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                   const double* __restrict__ scale_partial, int n_scale_partial,
+                                                   const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq, const LmIn lm,
+                                                   int ok_override = 1) {
   __shared__ double parts[1024];
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (unsigned)n_edge_blocks - 1);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
   const int np = n_edge_blocks;
   // all partials are fetched in parallel, then summed by one thread in index order
   const int tot = min(np + n_scale_partial, 1024);
@@ -140,8 +149,17 @@ __device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const do
     for (int i = 0; i < np; i++) chi += i < 1024 ? parts[i] : __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = 0; i < n_scale_partial; i++)
       scale += np + i < 1024 ? parts[np + i] : __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int okv = ok_flag ? *ok_flag : 1;
-    rec->chi2 = chi; rec->scale = scale; rec->ok = okv;     // maxdiag / chi2_init stay as k_finish left them
+    const int okv = ok_override != 1 ? ok_override : ok_flag ? *ok_flag : 1;
+    {                                                       // maxdiag / chi2_init stay as k_finish left them
+      const unsigned long long tg = rec_tag(seq), bc = (unsigned long long)__double_as_longlong(chi), bs = (unsigned long long)__double_as_longlong(scale);
+      unsigned long long* r64 = reinterpret_cast<unsigned long long*>(rec);
+      __hip_atomic_store(r64 + 0, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(r64 + 1, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&rec->ok, okv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&rec->c_chi2, bc ^ tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&rec->c_scale, bs ^ tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&rec->c_ok, (unsigned long long)(unsigned)okv ^ tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (lm.lambda_next) {
       // lambda of the NEXT iteration if this trial is accepted -- the host's arithmetic (levenberg.cpp:116-141), operation for
       // operation, so that a solve launched speculatively with it is the solve the host would have launched
@@ -156,9 +174,53 @@ __device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const do
       *lm.lambda_next = lam * fmax(1. / 3., alpha);
     }
     *ticket = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                  // system-scope release of the record (no acquire half: no L2 invalidation)
-    *reinterpret_cast<volatile unsigned*>(&rec->seq) = seq;       // the host polls this word instead of hipStreamSynchronize
+    __hip_atomic_store(&rec->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word instead of hipStreamSynchronize
   }
+}
+// a workgroup has written partial[its index]: make it visible and count it
+__device__ __forceinline__ unsigned trial_arrive(unsigned* __restrict__ ticket) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish_trial_record(int n_edge_blocks, const double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                     const double* __restrict__ scale_partial, int n_scale_partial,
+                                                     const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq,
+                                                     const LmIn lm = LmIn{0, 0, nullptr, nullptr, nullptr}) {
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = (trial_arrive(ticket) == (unsigned)n_edge_blocks - 1);
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  publish_trial_tail(n_edge_blocks, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, lm);
+}
+// Round 6 -- the fused linearisation kernels (k_errlin, k_errlin_prep) keep ONE workgroup for the record: their edge workgroups only
+// arrive (trial_arrive) and go on with their Jacobians; the publisher waits until all have arrived and publishes.  Before, the edge
+// workgroup that arrived last published -- the acquire, 76 dependent additions, the system-scope release -- and only then started
+// its Jacobians: it ended 5 us after every other workgroup of the launch (tools/micro/lba_prof.py: 11.0 against 5.6 us), and the
+// kernels queued behind the launch waited for it.  The wait is bounded (2 s of wall clock: a launch takes 10 us); if it ever
+// expires the record says so (ok = kOkPublishTimedOut) and the solve returns ORBG_INTERNAL instead of hanging.
+constexpr int kOkPublishTimedOut = -3;
+__device__ __forceinline__ void publish_trial_when_all_arrived(int n_edge_blocks, const double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                               const double* __restrict__ scale_partial, int n_scale_partial,
+                                                               const int* __restrict__ ok_flag, HostRec* __restrict__ rec, unsigned seq, const LmIn lm) {
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    const long long t0 = (long long)wall_clock64();
+    int ok = 1;
+    for (unsigned polls = 0;; polls++) {
+      if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)n_edge_blocks) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((polls & 1023u) == 1023u && (long long)wall_clock64() - t0 > 200000000ll) { ok = kOkPublishTimedOut; break; }
+    }
+    s_ok = ok;                              // (no acquire: the tail reads the partials with agent-scope loads, past this XCD's L2)
+  }
+  __syncthreads();
+  publish_trial_tail(n_edge_blocks, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, lm, s_ok);
 }
 
 // (returns this thread's chi2 -- the caller may go on with it: k_errors_export)
@@ -278,9 +340,9 @@ __device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double
 
 // thread per edge; the 256 x 27 block of results is staged in LDS and written as ONE contiguous, coalesced chunk
 // FUSED: the residuals are computed here (and stored, with their chi2 and the workgroup's robust partial sum) instead of being
-// read back from a preceding k_errors launch -- same functions, same inputs, same bits.  The partial sum is written, and the
-// trial record published by the last workgroup, BEFORE the Jacobians: the host gets its verdict ~5 us earlier and its
-// decision latency hides behind the rest of this kernel and k_reduce_points.
+// read back from a preceding k_errors launch -- same functions, same inputs, same bits.  The partial sum is written (and counted:
+// trial_arrive) BEFORE the Jacobians; the launch's publisher workgroup publishes the trial record as soon as every edge workgroup
+// has arrived: the host gets its verdict ~5 us before the kernel ends and its decision latency hides behind the Jacobians.
 struct TrialPublish {
   double* partial; unsigned* ticket; const double* scale_partial; int n_scale_partial; const int* ok_flag; HostRec* rec; unsigned seq;
   int n_edge_blocks;
@@ -326,9 +388,15 @@ __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_
       if ((int)threadIdx.x < s2) red_f[threadIdx.x] += red_f[threadIdx.x + s2];
       __syncthreads();
     }
-    if (threadIdx.x == 0) pub.partial[bid] = red_f[0];
-    publish_trial_record(pub.n_edge_blocks, pub.partial, pub.ticket, pub.scale_partial, pub.n_scale_partial, pub.ok_flag, pub.rec, pub.seq,
-                         pub.lm);
+    if (threadIdx.x == 0) {
+      // (the launch's publisher workgroup does the rest.  The partial goes out as ONE agent-scope store -- written through to where
+      // every XCD reads it -- and is counted once that store is acknowledged: no release fence, i.e. no write-back of this XCD's L2
+      // with the launch's Jacobian blocks in it, in any of the 44 edge workgroups, and no acquire in the publisher, which reads the
+      // partials with agent-scope loads)
+      __hip_atomic_store(&pub.partial[bid], red_f[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(pub.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (live) {
     double* out = stage + threadIdx.x * kEB;
@@ -474,34 +542,47 @@ __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__
 // Point workgroups of the fused launch: Hll and b_l of "their" landmark straight from its edges (residual, Huber weight and
 // the 3x3 point Jacobian recomputed with the functions the edge workgroups use -- same bits as summing their per-edge
 // blocks in k_reduce_points, in the same edge order), so that no separate reduction launch is needed.
+// Round 6: FOUR lanes per landmark (a quad).  Lane q takes the landmark's edges q, q + 4, q + 8, ... of its list -- a landmark has
+// 5.5 observations on average and up to a few dozen, and with one thread per landmark the slowest thread of a workgroup walked its
+// list for 9-10 us (two or three dependent memory round trips per chunk of four edges) while the pose and edge workgroups of the
+// same launch were done after 6 (tools/micro/lba_prof.py).  The four partial sums are added as ((s0 + s1) + s2) + s3 on lane 0 of
+// the quad (DPP quad_perm); k_reduce_points, the same reduction over stored blocks, uses the same decomposition: same bits.
+__device__ __forceinline__ double quad_get(double v, int src /* compile-time 1..3 */) {
+  int lo, hi;
+  if (src == 1) { lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x55, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x55, 0xF, 0xF, true); }
+  else if (src == 2) { lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xAA, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xAA, 0xF, 0xF, true); }
+  else { lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xFF, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xFF, 0xF, 0xF, true); }
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void lin_points_block(int bid, int nL, const int* __restrict__ pt_start, const int* __restrict__ pt_edges,
                                                    const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                    const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ Hll,
                                                    double* __restrict__ bl) {
-  const int l = bid * 256 + threadIdx.x;
-  if (l >= nL) return;
+  const int t = bid * 256 + threadIdx.x;
+  const int l = min(t >> 2, nL - 1), q = t & 3;            // (threads past the last landmark repeat it: all 64 lanes stay in the DPP moves)
+  const bool mine = (t >> 2) < nL;
   double acc[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) acc[i] = 0;
   const int jb = pt_start[l], je = pt_start[l + 1];
-  for (int j0 = jb; j0 < je; j0 += 4) {
-    // indices, then edges, then poses of a chunk of four are requested before the first use
-    int id[4];
+  for (int j0 = jb + q; j0 < je; j0 += 8) {
+    // this lane's next two edges (j0, j0 + 4): indices, then edges, then poses are requested for both before the first use
+    int id[2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) id[q] = pt_edges[min(j0 + q, je - 1)];
-    lba_edge ev[4];
+    for (int u = 0; u < 2; u++) id[u] = pt_edges[min(j0 + 4 * u, je - 1)];
+    lba_edge ev[2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) ev[q] = edges[id[q]];
-    PoseQ Tv[4];
+    for (int u = 0; u < 2; u++) ev[u] = edges[id[u]];
+    PoseQ Tv[2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) Tv[q] = poses[ev[q].pose];
+    for (int u = 0; u < 2; u++) Tv[u] = poses[ev[u].pose];
     const double* X = points + 3 * (size_t)ev[0].point;       // every edge of the list observes this landmark
     const double Xl[3] = {X[0], X[1], X[2]};
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (j0 + q < je) {
-        const lba_edge e = ev[q];
-        const PoseQ T = Tv[q];
+    for (int u = 0; u < 2; u++)
+      if (j0 + 4 * u < je) {
+        const lba_edge e = ev[u];
+        const PoseQ T = Tv[u];
         const bool mono = e.ur < 0;
         const int D = mono ? 2 : 3;
         double er[3], Xc[3];
@@ -538,9 +619,16 @@ __device__ __forceinline__ void lin_points_block(int bid, int nL, const int* __r
         }
       }
   }
-  for (int i = 0; i < 6; i++) Hll[6 * (size_t)l + i] = acc[i];
-  for (int i = 0; i < 3; i++) bl[3 * (size_t)l + i] = acc[6 + i];
+#pragma unroll
+  for (int i = 0; i < 9; i++) acc[i] = ((acc[i] + quad_get(acc[i], 1)) + quad_get(acc[i], 2)) + quad_get(acc[i], 3);     // (meaningful on lane 0 of the quad)
+  if (mine && q == 0) {
+    for (int i = 0; i < 6; i++) Hll[6 * (size_t)l + i] = acc[i];
+    for (int i = 0; i < 3; i++) bl[3 * (size_t)l + i] = acc[6 + i];
+  }
 }
+// workgroups behind the pose and edge workgroups of a fused linearisation launch: the landmark quads, then ONE publisher
+__host__ __device__ inline int errlin_point_blocks(int nL) { return (4 * nL + 255) / 256; }
+__host__ __device__ inline int errlin_tail_blocks(int nL) { return errlin_point_blocks(nL) + 1; }
 
 __global__ __launch_bounds__(256) void k_lin_all(int nP, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
                                                 const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
@@ -567,14 +655,18 @@ __global__ __launch_bounds__(256) void k_errlin(int nP, int n_edges, const lba_e
                                                int nL, const int* __restrict__ pt_start, const int* __restrict__ pt_edges,
                                                double* __restrict__ Hll, double* __restrict__ bl, LmIn lm) {
   const int bid = (int)blockIdx.x;
+  LBA_PROF_BEGIN(0);
   if (bid < nP) {
     lin_poses_block<true>(bid, ps_start, ps_edges, edges, poses, points, c, hb, err, chi2, Hpp, bp);
   } else if (bid < nP + n_edge_blocks) {
     linearize_block<true>(bid - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB,
                           TrialPublish{partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, n_edge_blocks, lm});
-  } else {
+  } else if (bid - nP - n_edge_blocks < errlin_point_blocks(nL)) {
     lin_points_block(bid - nP - n_edge_blocks, nL, pt_start, pt_edges, edges, poses, points, c, hb, Hll, bl);
+  } else {
+    publish_trial_when_all_arrived(n_edge_blocks, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, lm);
   }
+  LBA_PROF_END();
 }
 
 
@@ -587,8 +679,14 @@ __global__ __launch_bounds__(256) void k_reduce_points(int nL, const int* __rest
 #pragma unroll
   for (int i = 0; i < 9; i++) acc[i] = 0;
   // the edge list is walked in chunks of 4 whose indices, then blocks, are all requested before the first use: two memory
-  // round trips per chunk instead of two per edge (the chain of dependent loads is what this kernel costs); same sum order
+  // round trips per chunk instead of two per edge (the chain of dependent loads is what this kernel costs).  Sum order: the
+  // fused launch's landmark quads (lin_points_block) -- edge j of the list goes to partial sum j & 3, then ((s0 + s1) + s2) + s3
   const int jb = pt_start[l], je = pt_start[l + 1];
+  double part[4][9];
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int i = 0; i < 9; i++) part[q][i] = 0;
   for (int j0 = jb; j0 < je; j0 += 4) {
     int id[4];
 #pragma unroll
@@ -604,9 +702,11 @@ __global__ __launch_bounds__(256) void k_reduce_points(int nL, const int* __rest
     for (int q = 0; q < 4; q++)
       if (j0 + q < je) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) acc[i] += v[q][i];
+        for (int i = 0; i < 9; i++) part[q][i] += v[q][i];
       }
   }
+#pragma unroll
+  for (int i = 0; i < 9; i++) acc[i] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
   for (int i = 0; i < 6; i++) Hll[6 * (size_t)l + i] = acc[i];
   for (int i = 0; i < 3; i++) bl[3 * (size_t)l + i] = acc[6 + i];
 }
@@ -799,8 +899,10 @@ __global__ __launch_bounds__(256) void k_errlin_prep(int n_errlin_blocks, int n_
   } else if (bid < nP + n_edge_blocks) {
     linearize_block<true>(bid - nP, n_edges, edges, poses, points, c, hb, err, chi2, pose_col, point_col, EB,
                           TrialPublish{partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, n_edge_blocks, lm});
-  } else {
+  } else if (bid - nP - n_edge_blocks < errlin_point_blocks(nL)) {
     lin_points_block(bid - nP - n_edge_blocks, nL, pt_start, pt_edges, edges, poses, points, c, hb, Hll, bl);
+  } else {
+    publish_trial_when_all_arrived(n_edge_blocks, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq, lm);
   }
 }
 
@@ -868,6 +970,15 @@ __global__ __launch_bounds__(256) void k_build_items(int nP, int nL, const unsig
   build_items_block((int)blockIdx.x, nP, nL, lm_mask, pf_start, pf_edges, pf_col, items, cap, pair_count);
 }
 
+// Round 6, measured and dropped (tools/micro/lba_prof.py: the launch is as long as its 20 DIAGONAL pairs -- every landmark of a pose, ~550
+// items, 230 KB of Jacobian blocks through one compute unit: item loop 6.3 us, block sums at 7.6, end 8.8; the 190 off-diagonal pairs
+// end after 3.5):
+//  * 512 threads per pair: the first thread was through its items after 3.7 us, the block sums were complete no earlier (7.96 against
+//    7.56 us), with two transposes of 21 values for eight wavefronts or with the upper four folded into the one-pass transpose; 9.4 us;
+//  * a thread's item records of all three rounds requested up front: 8.94 against 9.03 us (the loop is not waiting for them);
+//  * each diagonal pair on FOUR workgroups (a quarter of the items each, 42 block sums per quarter through agent-scope stores, a ticket,
+//    the last one adds the quarters in order): item loop 3.0 us, sums at 4.9 -- and 4-5 us for the store / ticket / load hand-over
+//    between workgroups on different XCDs: 10.3 us.
 template <int PASSES>      // 1: all 42 values in one transpose (88 KB of LDS: one workgroup per compute unit), 2: two passes of 21 (44 KB: three)
 __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __restrict__ pair_i1, const int* __restrict__ pair_i2,
                                                         const int* __restrict__ pair_start, const PairItem* __restrict__ items,
@@ -888,6 +999,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
   constexpr int kSeg = 65, kRow = 4 * kSeg + 1, kPass = 42 / PASSES;
   __shared__ double red[kPass * kRow];
   __shared__ double part[42][4];
+  LBA_PROF_BEGIN(1);
   // XCD-aware workgroup -> pair map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2;
   // consecutive pairs share a pose and with it that pose's edge blocks, so every XCD takes a contiguous run of the pair list
   // (the b/8-th workgroup of XCD k gets the k-th run's b/8-th pair)
@@ -934,6 +1046,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
       for (int a = 0; a < 6; a++) cacc[a] += BD[3 * a] * b[0] + BD[3 * a + 1] * b[1] + BD[3 * a + 2] * b[2];
     }
   }
+  LBA_PROF_PHASE(0, 0);               // workgroup 0 = pair (0, 0), a diagonal pair: the item loop is done
   const int slot = (tid >> 6) * kSeg + (tid & 63);
   const int nval = diag ? 42 : 36;
 #pragma unroll
@@ -954,6 +1067,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
     }
   }
   __syncthreads();
+  LBA_PROF_PHASE(0, 1);               // ... the 42 block sums are in LDS
   const int n = 6 * nP;
   if (tid < 36) {
     const double s = ((part[tid][0] + part[tid][1]) + part[tid][2]) + part[tid][3];
@@ -982,6 +1096,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
     bs[6 * i1 + a] = v;
     if (St) ldltm::image_put_rhs(St, n, 6 * i1 + a, v);     // the solver reads the right-hand side as the matrix' border column
   }
+  LBA_PROF_END();
 }
 
 // ---- Blocked LDL^T + solve over MANY workgroups, for windows beyond the matrix-core kernels (more than 50 free poses:
@@ -1141,6 +1256,7 @@ __global__ __launch_bounds__(NT) void k_update(int n_poses, int n_points, int nP
                                                PoseQ* __restrict__ poses_out, double* __restrict__ points_out,
                                                const double* __restrict__ bp, double* __restrict__ scale_partial,
                                                const double* __restrict__ lambda_p) {
+  LBA_PROF_BEGIN(2);
   const double lambda = lambda_p ? *lambda_p : lambda_v;
   __shared__ double red[NT];
   const int i = blockIdx.x * NT + threadIdx.x;
@@ -1197,6 +1313,7 @@ __global__ __launch_bounds__(NT) void k_update(int n_poses, int n_points, int nP
       poses_out[p] = poses[p];
     }
   }
+  LBA_PROF_PHASE(0, 0);               // workgroup 0: its 64 landmarks are updated
   // fixed-order block sum -> one partial per block (the last block of the following k_errors adds them up in index order)
   red[threadIdx.x] = sc;
   __syncthreads();
@@ -1205,6 +1322,7 @@ __global__ __launch_bounds__(NT) void k_update(int n_poses, int n_points, int nP
     __syncthreads();
   }
   if (threadIdx.x == 0) scale_partial[blockIdx.x] = red[0];
+  LBA_PROF_END();
 }
 
 // one workgroup: chi2 = sum partial[] (fixed order), scale = sum x (lambda x + b), maxdiag; -> pinned record
@@ -1800,8 +1918,15 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
     bool got = false;
     if (orbg::poll_allowed()) {              // (the policy of the thread that runs the solve: caller or local-BA worker)
       timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+      const unsigned long long tg = rec_tag(want);
+      const volatile HostRec* hr = h->rec.h;
       for (unsigned spins = 0; !got; spins++) {
-        if (*w == want) { got = true; break; }
+        if (*w == want) {
+          // ... and the three pairs of THIS record have arrived (they and seq are independent stores)
+          const double c = hr->chi2, sc = hr->scale; const int okv = hr->ok;
+          unsigned long long bc, bs; memcpy(&bc, &c, 8); memcpy(&bs, &sc, 8);
+          if ((bc ^ hr->c_chi2) == tg && (bs ^ hr->c_scale) == tg && (((unsigned long long)(unsigned)okv) ^ hr->c_ok) == tg) { got = true; break; }
+        }
         if ((spins & 0xFFFF) == 0xFFFF) {
           timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
           if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 50.0) break;
@@ -1810,6 +1935,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     if (!got) ORBG_HIP(hipStreamSynchronize(st));
+    if (h->rec.h->ok == kOkPublishTimedOut) return ORBG_INTERNAL;      // (a fused linearisation's publisher never saw all edge workgroups arrive)
     // the eight-workgroup LDL^T gave up waiting for a participant: not an LM verdict -- the caller re-solves the window (lba_solve_impl)
     return h->rec.h->ok == ldltx::kOkTimedOut ? kRcLdltTimedOut : ORBG_OK;
   };
@@ -1923,7 +2049,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
           if (may_continue) {
             // residuals + record + linearisation of the trial state in ONE launch
             const int set = ls ^ 1;
-            const int n_blocks_l = (nL + 255) / 256;       // the landmark reduction rides in the same launch (point workgroups)
+            const int n_blocks_l = errlin_tail_blocks(nL);   // the landmark reduction (quads) and the record's publisher ride in the same launch
             hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[trial],
                                pointsB[trial], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                                D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u, h->d_ok.p,
@@ -2026,7 +2152,8 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
   const bool first2 = dev_lists && NE > 0 && nL > 0 && !terminate();
   if (first2 && dev_csr) {
     const int set = ls ^ 1;
-    const int n_blocks_l = (nL + 255) / 256;
+    const int n_blocks_l = (nL + 255) / 256;              // (k_csr_sort: one thread per landmark)
+    const int n_tail = errlin_tail_blocks(nL);
     uint8_t* const B = h->up_d.p;
     hipLaunchKernelGGL(k_csr_fill, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, D.pose_col, D.point_col, reinterpret_cast<int*>(B + o_cur_pt),
                        reinterpret_cast<int*>(B + o_cur_ps), reinterpret_cast<int*>(B + o_cur_pf), const_cast<int*>(D.pt_edges),
@@ -2035,7 +2162,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
                        const_cast<int*>(D.ps_edges), D.pt_start, const_cast<int*>(D.pt_edges), D.pf_start, const_cast<int*>(D.pf_edges),
                        const_cast<int*>(D.pf_col), reinterpret_cast<unsigned long long*>(B + o_lm_mask), D.edges, D.pose_col, n,
                        use_mfma ? h->d_St.p : (double*)nullptr, h->d_x.p, n_zero);
-    hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
+    hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_tail), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
                        pointsB[cur], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                        D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, 0, (const int*)nullptr,
                        h->rec.d, h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
@@ -2048,7 +2175,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
     err_valid = true; spec_ready = true; fin_version = version;
   } else if (first2) {
     const int set = ls ^ 1;
-    const int n_blocks_l = (nL + 255) / 256, n_err = nP + n_blocks_e + n_blocks_l, nsb = (nL + 255) / 256;
+    const int n_blocks_l = errlin_tail_blocks(nL), n_err = nP + n_blocks_e + n_blocks_l, nsb = (nL + 255) / 256;
     hipLaunchKernelGGL(k_errlin_prep, dim3(n_err + nsb + kPrep256Pad + kPrep256Zero), dim3(256), 0, st, n_err, nsb,
                        const_cast<int*>(D.pf_edges), const_cast<int*>(D.pf_col), D.pf_start,
                        reinterpret_cast<unsigned long long*>(h->up_d.p + o_lm_mask), n, use_mfma ? h->d_St.p : (double*)nullptr,
@@ -2068,7 +2195,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
       // residuals + linearisation of the initial estimate in the fused kernel of the later trials (its record is not waited
       // for: it carries the sequence number the host has already seen)
       const int set = ls ^ 1;
-      const int n_blocks_l = (nL + 255) / 256;
+      const int n_blocks_l = errlin_tail_blocks(nL);
       hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
                          pointsB[cur], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                          D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, 0, (const int*)nullptr,
@@ -2253,6 +2380,14 @@ extern "C" int lba_get_solver_stats(lba_handle* h, double* sum_ms, int64_t* n_br
   if (matrix_core) *matrix_core = h->prof_n_unknowns >= 1 && ldltm::supports(h->prof_n_unknowns) && !h->sw.ldlt_wide;
   return ORBG_OK;
 }
+
+#ifdef LBA_PROFILE
+extern "C" int lba_debug_prof(long long* out /* 3 x (8 + 2040) */, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lba_prof), sizeof(g_lba_prof)) != hipSuccess) return -1;
+  if (reset) { static long long z[3][8 + 2 * 1020]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lba_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 extern "C" int lba_get_watchdog_count(lba_handle* h, int64_t* n_timeouts) {
   if (!h || !n_timeouts) return ORBG_BAD_ARG;

@@ -19,6 +19,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -o run -
 PMC="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-dropin --lba-mode inline --no-pipeline"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_fetch.log" 2>&1 || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_write.log" 2>&1 || true
+C4PMC="--config C4 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-dropin --lba-mode inline --no-pipeline"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c4" -o run -- python3 "$R/bench.py" $C4PMC > "$OUT/pmc_fetch_c4.log" 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c4" -o run -- python3 "$R/bench.py" $C4PMC > "$OUT/pmc_write_c4.log" 2>&1 || true
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_mfma.log" 2>&1 || true
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_sq" -o run -- python3 "$R/bench.py" $PMC > "$OUT/pmc_sq.log" 2>&1 || true
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma_c4" -o run -- python3 "$R/bench.py" --config C4 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-dropin --lba-mode inline --no-pipeline > "$OUT/pmc_mfma_c4.log" 2>&1 || true
@@ -49,9 +52,13 @@ python3 tools/lba_timeline.py "$(find "$OUT/stats_async" -name "*kernel_trace.cs
 python3 tools/micro/oct_prof.py > "$OUT/octree_phases.txt" 2>&1 || true
 SPREAD=0 python3 tools/search_large_map.py 1 8 32 128 > "$OUT/search_large_map_dense.txt" 2>&1 || true
 python3 tools/po_sweep.py 500 > "$OUT/pose_opt_sweep.txt" 2>&1 || true
+python3 tools/vocab_time.py 200 > "$OUT/vocab_full_size.txt" 2>&1 || true
+tests/cpp/closed_loop 200 5 > "$OUT/closed_loop.txt" 2>&1 || true
 bash tools/bench_driver_repeat.sh 5 > "$OUT/bench_driver_repeat.txt" 2>&1 || true
 f=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 profiles/pmc_aggregate.py FETCH_SIZE="$f" WRITE_SIZE="$w" > "$OUT/pmc_fetch_write_per_kernel.json" || true; fi
+f=$(find "$OUT/pmc_fetch_c4" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write_c4" -name "*counter_collection.csv" | head -1)
+if [ -n "$f" ] && [ -n "$w" ]; then python3 profiles/pmc_aggregate.py FETCH_SIZE="$f" WRITE_SIZE="$w" > "$OUT/pmc_fetch_write_per_kernel_C4.json" || true; fi
 for grp in pmc_mfma pmc_sq pmc_mfma_c4; do
   c=$(find "$OUT/$grp" -name "*counter_collection.csv" | head -1)
   if [ -n "$c" ]; then python3 profiles/pmc_counters.py "$c" > "$OUT/${grp}_per_kernel.txt" || true; fi
