@@ -145,10 +145,26 @@ __device__ __forceinline__ void publish_trial_tail(int n_edge_blocks, const doub
     parts[i] = __hip_atomic_load(i < np ? &partial[i] : &scale_partial[i - np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (threadIdx.x == 0) {
-    double chi = 0, scale = 0;
-    for (int i = 0; i < np; i++) chi += i < 1024 ? parts[i] : __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = 0; i < n_scale_partial; i++)
-      scale += np + i < 1024 ? parts[np + i] : __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // index order, sixteen LDS reads in flight per step: written as one read per addition the loop is a chain of dependent LDS round
+    // trips (~130 cycles each: 76 partials 4 us, the 299 of a C4 window 14 us -- the publisher ended that long after every other
+    // workgroup of the launch, tools/micro/lba_prof.py)
+    auto ordered_sum = [&](int first, int count) {
+      double acc = 0;
+      int i = 0;
+      for (; i + 16 <= count; i += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = parts[first + i + u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += v[u];
+      }
+      for (; i < count; i++) acc += parts[first + i];
+      return acc;
+    };
+    const int np_l = min(np, 1024), ns_l = max(min(np + n_scale_partial, 1024) - np_l, 0);
+    double chi = ordered_sum(0, np_l), scale = ordered_sum(np_l, ns_l);
+    for (int i = np_l; i < np; i++) chi += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = ns_l; i < n_scale_partial; i++) scale += __hip_atomic_load(&scale_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int okv = ok_override != 1 ? ok_override : ok_flag ? *ok_flag : 1;
     {                                                       // maxdiag / chi2_init stay as k_finish left them
       const unsigned long long tg = rec_tag(seq), bc = (unsigned long long)__double_as_longlong(chi), bs = (unsigned long long)__double_as_longlong(scale);
