@@ -1078,7 +1078,15 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(int nP, const int* __re
       const int o = tid >> 2, q = tid & 3;
       const double* r = red + o * kRow + q * kSeg;
       double s = 0;
-      for (int k = 0; k < 64; k++) s += r[k];
+      // (index order, sixteen LDS reads in flight per step -- see publish_trial_tail)
+#pragma unroll
+      for (int k0 = 0; k0 < 64; k0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = r[k0 + u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) s += v[u];
+      }
       part[ps * kPass + o][q] = s;
     }
   }
@@ -1355,8 +1363,17 @@ __device__ __forceinline__ void finish_block(int n_partial, const double* __rest
   __syncthreads();
   double chi = 0;
   if (tid == 0) {
-    for (int i = 0; i < n_partial && i < 1024; i++) chi += parts[i];
-    for (int i = 1024; i < n_partial; i++) chi += partial[i];
+    const int nl = min(n_partial, 1024);
+    int i = 0;
+    for (; i + 16 <= nl; i += 16) {          // (index order, sixteen LDS reads in flight per step)
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = parts[i + u];
+#pragma unroll
+      for (int u = 0; u < 16; u++) chi += v[u];
+    }
+    for (; i < nl; i++) chi += parts[i];
+    for (i = 1024; i < n_partial; i++) chi += partial[i];
   }
   double sc = 0;
   if (want_scale) {
