@@ -501,7 +501,32 @@ int orbm_frame_download(orbm_frame* f, orbx_keypoint* kps, uint8_t* desc);
 
 /* ---------------------------------------------------------------- local bundle adjustment */
 
-/* One reprojection edge (S/Optimizer.cc:2021-2084): mono if ur < 0, stereo otherwise. */
+/* A GeometricCamera as the optimiser's edges use it (I/CameraModels/GeometricCamera.h:77-92): GetType() and the parameter vector
+ * mvParameters = {fx, fy, cx, cy} (Pinhole) / {fx, fy, cx, cy, k1, k2, k3, k4} (KannalaBrandt8), float32 as the reference keeps them. */
+#define ORBG_CAM_PINHOLE 0           /* GeometricCamera::CAM_PINHOLE */
+#define ORBG_CAM_KANNALA_BRANDT8 1   /* GeometricCamera::CAM_FISHEYE */
+typedef struct orbg_camera {
+  int32_t model;
+  float fx, fy, cx, cy;
+  float k[4];                        /* k1..k4 of KannalaBrandt8 (mvParameters[4..7]); ignored for a pinhole */
+} orbg_camera;
+/* The cameras of a KeyFrame / Frame whose edges go through GeometricCamera::project / projectJac: mpCamera, and -- for the
+ * two-fisheye rig (NLeft != -1) -- mpCamera2 with mTrl, the right camera's pose in the left camera's frame
+ * (I/KeyFrame.h:635-642, I/Frame.h:277-297).  One rig per problem: every keyframe of a map holds the same camera objects. */
+typedef struct orbg_camera_rig {
+  orbg_camera left;                  /* mpCamera: EdgeSE3ProjectXYZ / EdgeSE3ProjectXYZOnlyPose (I/OptimizableTypes.h:31-57,89-115) */
+  int32_t has_right;                 /* mpCamera2 != NULL */
+  orbg_camera right;                 /* mpCamera2: EdgeSE3ProjectXYZToBody / EdgeSE3ProjectXYZOnlyPoseToBody (:59-87,117-144) */
+  float Trl[12];                     /* mTrl, 3 x 4 row-major float32 (Converter::toSE3Quat reads exactly these, S/Converter.cc:34-44) */
+} orbg_camera_rig;
+/* `ur` of an observation made by the RIGHT camera of the rig (get<1>(indexes) != -1, S/Optimizer.cc:2086-2120; i >= Nleft,
+ * :1121-1150): u, v are then mvKeysRight[rightIndex].pt and the edge is the *ToBody kind.  In a problem whose rig has a right camera
+ * any ur <= -1.5 reads as this (mvuRight is -1 throughout on such frames); in every other problem a negative ur is a monocular
+ * observation, as it always was. */
+#define LBA_UR_RIGHT_CAMERA (-2.0f)
+
+/* One reprojection edge (S/Optimizer.cc:2021-2120): stereo if ur >= 0, the right camera's if ur == LBA_UR_RIGHT_CAMERA, mono
+ * otherwise (the reference's mvuRight is -1 there). */
 typedef struct lba_edge {
   int32_t pose;        /* index into poses[] */
   int32_t point;       /* index into points[] */
@@ -522,6 +547,10 @@ typedef struct lba_problem {
   double lambda_init;          /* 0 = auto (tau*max diag); 100 for inertial maps, S/Optimizer.cc:1924-1925 */
   int32_t its_round1, its_round2;  /* 5 and 10, S/Optimizer.cc:2132,2203 */
   int32_t device;
+  /* NULL: mpCamera is the pinhole {fx, fy, cx, cy} above and there is no second camera (every BASELINE configuration).  Otherwise
+   * the monocular edges project through rig->left and the right camera's edges through rig->right after mTrl; stereo edges
+   * (g2o::EdgeStereoSE3ProjectXYZ carries its own fx, fy, cx, cy, bf, S/Optimizer.cc:2071-2075) keep using the five scalars. */
+  const orbg_camera_rig* rig;
 } lba_problem;
 
 typedef struct lba_result {
@@ -580,7 +609,7 @@ int lba_get_watchdog_count(lba_handle* h, int64_t* n_timeouts);
 
 /* ---------------------------------------------------------------- pose-only optimisation */
 
-/* Everything Optimizer::PoseOptimization(Frame*) reads (S/Optimizer.cc:964-1278, mpCamera2 == NULL): one entry per
+/* Everything Optimizer::PoseOptimization(Frame*) reads (S/Optimizer.cc:964-1278): one entry per
  * feature that holds a map point. */
 typedef struct pose_opt_problem {
   int32_t n;               /* nInitialCorrespondences */
@@ -592,6 +621,10 @@ typedef struct pose_opt_problem {
   float fx, fy, cx, cy, bf;
   float Tcw[16];           /* pFrame->mTcw (row-major), the estimate every round restarts from */
   int32_t device;
+  /* NULL: Frame::mpCamera is the pinhole above, mpCamera2 == NULL.  Otherwise as in lba_problem: entries with
+   * ur == LBA_UR_RIGHT_CAMERA are features i >= Nleft (u, v = mvKeysRight[i - Nleft].pt, S/Optimizer.cc:1121-1150), the other
+   * monocular entries project through rig->left (u, v = mvKeys[i].pt, :1091-1119). */
+  const orbg_camera_rig* rig;
 } pose_opt_problem;
 
 typedef struct pose_opt_result {

@@ -98,12 +98,26 @@ def vocab_view_arrays(v, k=None, scoring=None, n_words=None):
     return out
 
 
+class Camera(C.Structure):
+    """orbg_camera: model (0 pinhole, 1 KannalaBrandt8), fx fy cx cy, k1..k4."""
+    _fields_ = [("model", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("k", C.c_float * 4)]
+
+
+class CameraRig(C.Structure):
+    """orbg_camera_rig: mpCamera, mpCamera2 (has_right), mTrl (3 x 4 row-major)."""
+    _fields_ = [("left", Camera), ("has_right", C.c_int32), ("right", Camera), ("Trl", C.c_float * 12)]
+
+
+CAM_PINHOLE, CAM_KANNALA_BRANDT8 = 0, 1
+UR_RIGHT_CAMERA = -2.0
+
+
 class LbaProblem(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p), ("edges", C.c_void_p),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
                 ("lambda_init", C.c_double), ("its_round1", C.c_int32), ("its_round2", C.c_int32),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("rig", C.POINTER(CameraRig))]
 
 
 class LbaResult(C.Structure):
@@ -117,7 +131,7 @@ class LbaResult(C.Structure):
 class PoseOptProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("Xw", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("ur", C.c_void_p),
                 ("inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
-                ("bf", C.c_float), ("Tcw", C.c_float * 16), ("device", C.c_int32)]
+                ("bf", C.c_float), ("Tcw", C.c_float * 16), ("device", C.c_int32), ("rig", C.POINTER(CameraRig))]
 
 
 class DatabaseView(C.Structure):

@@ -38,6 +38,7 @@
 #include <cmath>
 #include <limits>
 #include <numeric>
+#include <type_traits>
 
 using namespace orbg;
 
@@ -83,6 +84,45 @@ __device__ inline void edge_error(const PoseQ& T, const double* X, const Cam& c,
   }
 }
 
+// The same for a problem that carries an orbg_camera_rig: stereo edges as above; monocular edges through mpCamera->project
+// (EdgeSE3ProjectXYZ::computeError, I/OptimizableTypes.h:99-104); the right camera's through mpCamera2 after (mTrl * T)
+// (EdgeSE3ProjectXYZToBody::computeError, :127-132).  Xc: the point in the frame of the camera that made the observation.
+__device__ inline void edge_error(const PoseQ& T, const double* X, const CamRig& g, const lba_edge& e, double* err, double* Xc) {
+  if (e.ur >= 0) { edge_error(T, X, g.c, e, err, Xc); return; }
+  double r[3], uv[2];
+  if (g.has_right && ur_is_right(e.ur)) {
+    PoseQ Trw;
+    se3_mul(g.Trl, T, &Trw);
+    quat_rotate(Trw.q, X, r);
+    Xc[0] = r[0] + Trw.t[0]; Xc[1] = r[1] + Trw.t[1]; Xc[2] = r[2] + Trw.t[2];
+    cam_project(g.right, Xc, uv);
+  } else {
+    quat_rotate(T.q, X, r);
+    Xc[0] = r[0] + T.t[0]; Xc[1] = r[1] + T.t[1]; Xc[2] = r[2] + T.t[2];
+    cam_project(g.left, Xc, uv);
+  }
+  err[0] = (double)e.u - uv[0]; err[1] = (double)e.v - uv[1]; err[2] = 0;
+}
+
+// isDepthPositive() of an edge: z of the point in the observing camera's frame (G/types/types_six_dof_expmap.h:163-167,
+// I/OptimizableTypes.h:106-110,134-138)
+__device__ inline bool edge_depth_positive(const PoseQ& T, const double* X, const Cam&, const lba_edge&) {
+  double rr[3];
+  quat_rotate(T.q, X, rr);
+  return rr[2] + T.t[2] > 0.0;
+}
+__device__ inline bool edge_depth_positive(const PoseQ& T, const double* X, const CamRig& g, const lba_edge& e) {
+  double rr[3];
+  if (g.has_right && ur_is_right(e.ur)) {
+    PoseQ Trw;
+    se3_mul(g.Trl, T, &Trw);
+    quat_rotate(Trw.q, X, rr);
+    return rr[2] + Trw.t[2] > 0.0;
+  }
+  quat_rotate(T.q, X, rr);
+  return rr[2] + T.t[2] > 0.0;
+}
+
 __device__ inline void huber(double e, double delta, double dsqr, double* rho0, double* rho1) {
   if (e <= dsqr) { *rho0 = e; *rho1 = 1.; }
   else { const double s = sqrt(e); *rho0 = 2 * s * delta - dsqr; *rho1 = delta / s; }
@@ -104,17 +144,16 @@ __host__ __device__ inline unsigned long long rec_tag(unsigned seq) { return (0x
 // Results of a solve, written by the GPU straight into the caller-visible pinned block (no copy commands): per edge a flag
 // byte (bit 0 = isDepthPositive() with the final estimate, bit 1 = outlier: chi2 > 5.991 / 7.815 or depth <= 0,
 // S/Optimizer.cc:2131-2166) and optionally its chi2; the final poses and points.
+template <class CamT>
 __global__ __launch_bounds__(256) void k_export(int n_edges, int n_poses, int n_points, const lba_edge* __restrict__ edges,
-                                               const PoseQ* __restrict__ poses, const double* __restrict__ points,
+                                               const PoseQ* __restrict__ poses, const double* __restrict__ points, CamT cam,
                                                const double* __restrict__ chi2, uint8_t* __restrict__ out_flags,
                                                double* __restrict__ out_chi2, PoseQ* __restrict__ out_poses,
                                                double* __restrict__ out_points) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k < n_edges) {
     const lba_edge e = edges[k];
-    double rr[3];
-    quat_rotate(poses[e.pose].q, points + 3 * (size_t)e.point, rr);
-    const bool depth_pos = rr[2] + poses[e.pose].t[2] > 0.0;
+    const bool depth_pos = edge_depth_positive(poses[e.pose], points + 3 * (size_t)e.point, cam, e);
     const double thr = e.ur < 0 ? 5.991 : 7.815;
     const double c = chi2[k];
     const bool outlier = c > thr || !depth_pos;
@@ -240,8 +279,9 @@ __device__ __forceinline__ void publish_trial_when_all_arrived(int n_edge_blocks
 }
 
 // (returns this thread's chi2 -- the caller may go on with it: k_errors_export)
+template <class CamT>
 __device__ __forceinline__ double errors_block(int bid, int n_edge_blocks, int n_edges, const lba_edge* __restrict__ edges,
-                                               const PoseQ* __restrict__ poses, const double* __restrict__ points, Cam cam, Huber hb,
+                                               const PoseQ* __restrict__ poses, const double* __restrict__ points, CamT cam, Huber hb,
                                                double* __restrict__ err, double* __restrict__ chi2, double* __restrict__ partial,
                                                int final_mode, unsigned* __restrict__ ticket, const double* __restrict__ scale_partial,
                                                int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec,
@@ -275,8 +315,9 @@ __device__ __forceinline__ double errors_block(int bid, int n_edge_blocks, int n
   if (final_mode) publish_trial_record(n_edge_blocks, partial, ticket, scale_partial, n_scale_partial, ok_flag, rec, seq);
   return c_out;
 }
+template <class CamT>
 __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                               const double* __restrict__ points, Cam cam, Huber hb, double* __restrict__ err,
+                                               const double* __restrict__ points, CamT cam, Huber hb, double* __restrict__ err,
                                                double* __restrict__ chi2, double* __restrict__ partial,
                                                int final_mode, unsigned* __restrict__ ticket, const double* __restrict__ scale_partial,
                                                int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec,
@@ -286,8 +327,9 @@ __global__ __launch_bounds__(256) void k_errors(int n_edges, const lba_edge* __r
 }
 // The last evaluation of a solve and the export of the state it evaluated (speculative: dropped if the trial is rejected) in
 // one launch: the export needs nothing of the other workgroups (an edge's flags follow from its own chi2).
+template <class CamT>
 __global__ __launch_bounds__(256) void k_errors_export(int n_edge_blocks, int n_edges, const lba_edge* __restrict__ edges,
-                                                      const PoseQ* __restrict__ poses, const double* __restrict__ points, Cam cam, Huber hb,
+                                                      const PoseQ* __restrict__ poses, const double* __restrict__ points, CamT cam, Huber hb,
                                                       double* __restrict__ err, double* __restrict__ chi2, double* __restrict__ partial,
                                                       unsigned* __restrict__ ticket, const double* __restrict__ scale_partial,
                                                       int n_scale_partial, const int* __restrict__ ok_flag, HostRec* __restrict__ rec,
@@ -302,9 +344,7 @@ __global__ __launch_bounds__(256) void k_errors_export(int n_edge_blocks, int n_
   bool depth_pos = false; double thr = 0;
   if (k < n_edges) {
     const lba_edge e = edges[k];
-    double rr[3];
-    quat_rotate(poses[e.pose].q, points + 3 * (size_t)e.point, rr);
-    depth_pos = rr[2] + poses[e.pose].t[2] > 0.0;
+    depth_pos = edge_depth_positive(poses[e.pose], points + 3 * (size_t)e.point, cam, e);
     thr = e.ur < 0 ? 5.991 : 7.815;
   }
   // the flags need this edge's chi2: computed below, so the residual part runs first for the values and the flags are
@@ -322,7 +362,8 @@ __global__ __launch_bounds__(256) void k_errors_export(int n_edge_blocks, int n_
 constexpr int kEB = 27;
 
 // Jacobians of one edge (stereo: G/types/types_six_dof_expmap.cpp:228-274; mono: S/OptimizableTypes.cpp:139-160)
-__device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double z, const Cam& c, bool mono, double* A, double* B) {
+__device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double z, const Cam& c, float ur, double* A, double* B) {
+  const bool mono = ur < 0;
   double R[9];
   quat_to_R(T.q, R);
   const double iz = 1.0 / z, iz2 = iz * iz;     // one division per edge; the reference divides term by term (<= 2 ulp apart)
@@ -354,6 +395,50 @@ __device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double
   }
 }
 
+// With a camera rig: (x, y, z) = T.map(X) is the point in the LEFT camera's (body) frame for every kind of edge.
+//   monocular  S/OptimizableTypes.cpp:139-160   Xi = -projectJac(X_l) * R(T),                  Xj = -projectJac(X_l) * SE3deriv(X_l)
+//   right cam  S/OptimizableTypes.cpp:192-214   Xi = -projectJac(X_r) * R(mTrl * T),  Xj = -projectJac(X_r) * R(mTrl) * SE3deriv(X_l),
+//              X_r = mTrl.map(X_l)
+__device__ inline void edge_jacobians(const PoseQ& T, double x, double y, double z, const CamRig& g, float ur, double* A, double* B) {
+  if (ur >= 0) { edge_jacobians(T, x, y, z, g.c, ur, A, B); return; }
+  const double Xl[3] = {x, y, z};
+  double R[9], J[6], M[6];
+  if (g.has_right && ur_is_right(ur)) {
+    double rr[3], Xr[3], Rrl[9];
+    quat_rotate(g.Trl.q, Xl, rr);
+    Xr[0] = rr[0] + g.Trl.t[0]; Xr[1] = rr[1] + g.Trl.t[1]; Xr[2] = rr[2] + g.Trl.t[2];
+    cam_project_jac(g.right, Xr, J);
+#pragma unroll
+    for (int i = 0; i < 6; i++) J[i] = -J[i];
+    PoseQ Trw;
+    se3_mul(g.Trl, T, &Trw);
+    quat_to_R(Trw.q, R);
+    quat_to_R(g.Trl.q, Rrl);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) M[3 * i + j] = J[3 * i] * Rrl[j] + J[3 * i + 1] * Rrl[3 + j] + J[3 * i + 2] * Rrl[6 + j];
+  } else {
+    cam_project_jac(g.left, Xl, J);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { J[i] = -J[i]; M[i] = J[i]; }
+    quat_to_R(T.q, R);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) A[3 * i + j] = J[3 * i] * R[j] + J[3 * i + 1] * R[3 + j] + J[3 * i + 2] * R[6 + j];
+  const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) B[6 * i + j] = M[3 * i] * S[j] + M[3 * i + 1] * S[6 + j] + M[3 * i + 2] * S[12 + j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) A[6 + j] = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) B[12 + j] = 0;
+}
+
 // thread per edge; the 256 x 27 block of results is staged in LDS and written as ONE contiguous, coalesced chunk
 // FUSED: the residuals are computed here (and stored, with their chi2 and the workgroup's robust partial sum) instead of being
 // read back from a preceding k_errors launch -- same functions, same inputs, same bits.  The partial sum is written (and counted:
@@ -365,9 +450,43 @@ struct TrialPublish {
   LmIn lm;
 };
 
-template <bool FUSED>
+// Hpl = B^T (w Omega) A (6 x 3) of edge k2 alone: what linearize_block writes for its own edge, for the edges a primary adds up
+// (camera rigs: a keyframe may observe a landmark with both cameras)
+template <bool FUSED, class CamT>
+__device__ inline void edge_hpl(const PoseQ& T, const double* X, const CamT& c, const Huber& hb, const lba_edge& e, int k2,
+                                const double* __restrict__ err, const double* __restrict__ chi2, double* H) {
+  const bool mono = e.ur < 0;
+  const int D = mono ? 2 : 3;
+  const double om = (double)e.inv_sigma2;
+  double er[3], chi_k = 0;
+  if constexpr (FUSED) {
+    double Xc[3];
+    edge_error(T, X, c, e, er, Xc);
+    for (int i = 0; i < D; i++) chi_k += er[i] * (om * er[i]);
+  } else {
+    er[0] = err[3 * (size_t)k2]; er[1] = err[3 * (size_t)k2 + 1]; er[2] = err[3 * (size_t)k2 + 2];
+    chi_k = chi2[k2];
+  }
+  double rho0, rho1;
+  huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
+  double r[3], A[9], B[18];
+  quat_rotate(T.q, X, r);
+  edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, e.ur, A, B);
+  const double wom = rho1 * om;
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int cidx = 0; cidx < 3; cidx++) {
+      double h = 0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) h += B[6 * i + a] * wom * A[3 * i + cidx];
+      H[3 * a + cidx] = h;
+    }
+}
+
+template <bool FUSED, class CamT>
 __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                                  const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ err,
+                                                  const double* __restrict__ points, CamT c, Huber hb, double* __restrict__ err,
                                                   double* __restrict__ chi2, const int* __restrict__ pose_col,
                                                   const int* __restrict__ point_col, double* __restrict__ EB, const TrialPublish pub) {
   __shared__ double stage[256 * kEB];
@@ -419,7 +538,7 @@ __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_
     double r[3];
     quat_rotate(T.q, X, r);
     double A[9], B[18];
-    edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
+    edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, e.ur, A, B);
     const double om = (double)e.inv_sigma2;
     const double wom = rho1 * om;
     // rows >= D of A/B/omega_r are exact zeros for monocular edges, so every loop runs a constant 3 rows and
@@ -455,15 +574,38 @@ __device__ __forceinline__ void linearize_block(int bid, int n_edges, const lba_
       out[o++] = lf ? sacc : 0.0;
     }
   }
+  if constexpr (std::is_same<CamT, CamRig>::value) {
+    // A keyframe of a two-camera rig observes a landmark up to twice (left and right camera: two edges between the same two vertices,
+    // adjacent in the reference's creation order, S/Optimizer.cc:2021-2120).  g2o adds both into the one Hpl block of the vertex
+    // pair; here the FIRST edge of such a run carries the sum and the others carry zero, so that the Schur complement and the
+    // back-substitution -- which go by the per-landmark lists of first edges (the host leaves the others out) -- see one block per
+    // (keyframe, landmark) as they do everywhere else.  Hll / bl / Hpp / bp are sums over all edges and need nothing of this.
+    if (live) {
+      double* out = stage + threadIdx.x * kEB;
+      if (k > 0 && edges[k - 1].pose == e.pose && edges[k - 1].point == e.point) {
+#pragma unroll
+        for (int i = 0; i < 18; i++) out[i] = 0.0;
+      } else if (pose_col[e.pose] >= 0 && point_col[e.point] >= 0) {
+        for (int k2 = k + 1; k2 < n_edges; k2++) {
+          const lba_edge e2 = edges[k2];
+          if (e2.pose != e.pose || e2.point != e.point) break;
+          double H2[18];
+          edge_hpl<FUSED>(T, X, c, hb, e2, k2, err, chi2, H2);
+#pragma unroll
+          for (int i = 0; i < 18; i++) out[i] += H2[i];
+        }
+      }
+    }
+  }
   __syncthreads();
   const int valid = min(256, n_edges - bid * 256);
   double* dst = EB + (size_t)bid * 256 * kEB;
   for (int i = threadIdx.x; i < valid * kEB; i += 256) dst[i] = stage[i];
 }
-template <bool FUSED>
+template <bool FUSED, class CamT>
 __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
                                                   const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                                  const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
+                                                  const double* __restrict__ points, CamT c, Huber hb, const double* __restrict__ err,
                                                   const double* __restrict__ chi2, double* __restrict__ Hpp, double* __restrict__ bp) {
   __shared__ double wpart[4][27];
   const int p = bid;
@@ -511,7 +653,7 @@ __device__ __forceinline__ void lin_poses_block(int bid, const int* __restrict__
         chi_k = chi2[k];
       }
       double A[9], B[18];
-      edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
+      edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, e.ur, A, B);
       double rho0, rho1;
       huber(chi_k, mono ? hb.delta_mono : hb.delta_stereo, mono ? hb.dsqr_mono : hb.dsqr_stereo, &rho0, &rho1);
       const double om = (double)e.inv_sigma2;
@@ -570,9 +712,10 @@ __device__ __forceinline__ double quad_get(double v, int src /* compile-time 1..
   else { lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xFF, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xFF, 0xF, 0xF, true); }
   return __hiloint2double(hi, lo);
 }
+template <class CamT>
 __device__ __forceinline__ void lin_points_block(int bid, int nL, const int* __restrict__ pt_start, const int* __restrict__ pt_edges,
                                                    const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                                   const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ Hll,
+                                                   const double* __restrict__ points, CamT c, Huber hb, double* __restrict__ Hll,
                                                    double* __restrict__ bl) {
   const int t = bid * 256 + threadIdx.x;
   const int l = min(t >> 2, nL - 1), q = t & 3;            // (threads past the last landmark repeat it: all 64 lanes stay in the DPP moves)
@@ -611,7 +754,7 @@ __device__ __forceinline__ void lin_points_block(int bid, int nL, const int* __r
         double r[3];
         quat_rotate(T.q, Xl, r);
         double A[9], B[18];
-        edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, mono, A, B);
+        edge_jacobians(T, r[0] + T.t[0], r[1] + T.t[1], r[2] + T.t[2], c, e.ur, A, B);
         const double wom = rho1 * om;
         double omega_r[3];
 #pragma unroll
@@ -646,8 +789,9 @@ __device__ __forceinline__ void lin_points_block(int bid, int nL, const int* __r
 __host__ __device__ inline int errlin_point_blocks(int nL) { return (4 * nL + 255) / 256; }
 __host__ __device__ inline int errlin_tail_blocks(int nL) { return errlin_point_blocks(nL) + 1; }
 
+template <class CamT>
 __global__ __launch_bounds__(256) void k_lin_all(int nP, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                                const double* __restrict__ points, Cam c, Huber hb, const double* __restrict__ err,
+                                                const double* __restrict__ points, CamT c, Huber hb, const double* __restrict__ err,
                                                 const double* __restrict__ chi2, const int* __restrict__ pose_col,
                                                 const int* __restrict__ point_col, double* __restrict__ EB,
                                                 const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
@@ -660,8 +804,9 @@ __global__ __launch_bounds__(256) void k_lin_all(int nP, int n_edges, const lba_
 // k_errors (final mode) + k_lin_all in one launch, for the speculative path of the LM driver: residuals, chi2 and the robust
 // partial sums of the TRIAL state, its linearisation into the other set of buffers, and -- by the edge workgroup that
 // finishes last -- the record the host is waiting for.  One launch floor (~5 us) less per accepted trial.
+template <class CamT>
 __global__ __launch_bounds__(256) void k_errlin(int nP, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                               const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ err,
+                                               const double* __restrict__ points, CamT c, Huber hb, double* __restrict__ err,
                                                double* __restrict__ chi2, const int* __restrict__ pose_col,
                                                const int* __restrict__ point_col, double* __restrict__ EB,
                                                const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
@@ -885,11 +1030,12 @@ __global__ __launch_bounds__(256) void k_csr_sort(int nP, int nL, const int* __r
 // First launch of a solve: the linearisation of the initial estimate and, in further workgroups, everything else that needs
 // only the first upload -- the per-landmark observation lists (256 landmarks per workgroup, lists of up to 16 entries sorted
 // in LDS), the padding of the tile image, the zeroed step vector.  (Two launches: 12 + 6.6 us one after the other.)
+template <class CamT>
 __global__ __launch_bounds__(256) void k_errlin_prep(int n_errlin_blocks, int n_sort_blocks, int* __restrict__ pf_edges_w, int* __restrict__ pf_col_w,
                                                     const int* __restrict__ pf_start, unsigned long long* __restrict__ lm_mask,
                                                     int n_unknowns, double* __restrict__ St, double* __restrict__ xzero, int n_zero,
                                                     int nP, int n_edges, const lba_edge* __restrict__ edges, const PoseQ* __restrict__ poses,
-                                               const double* __restrict__ points, Cam c, Huber hb, double* __restrict__ err,
+                                               const double* __restrict__ points, CamT c, Huber hb, double* __restrict__ err,
                                                double* __restrict__ chi2, const int* __restrict__ pose_col,
                                                const int* __restrict__ point_col, double* __restrict__ EB,
                                                const int* __restrict__ ps_start, const int* __restrict__ ps_edges,
@@ -1608,6 +1754,8 @@ static int upload_arena(lba_handle* h, size_t off0, size_t off1, hipStream_t st)
 // internal: k_ldlt_xcd reported kOkTimedOut during this attempt (never leaves the library)
 constexpr int kRcLdltTimedOut = -70001;
 static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r);
+template <class CamT>
+static int lba_solve_attempt_t(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r, const CamT& cam);
 // A launch of the eight-workgroup LDL^T whose participants were not all placed in time says so (ldlt_xcd.hpp: kOkTimedOut) instead of
 // posing as a non-positive-definite system, which the LM loop would answer with a rejected step and another trajectory than the
 // reference's.  The window is then solved again from the caller's (untouched) problem with that kernel switched off for this handle
@@ -1621,7 +1769,18 @@ static int lba_solve_impl(lba_handle* h, const lba_problem* p, StopRef stop_ref,
   rc = lba_solve_attempt(h, p, stop_ref, r);
   return rc == kRcLdltTimedOut ? ORBG_HIP_ERROR : rc;
 }
+// The kernels that evaluate edges exist twice: for the five pinhole scalars (every BASELINE configuration; unchanged code) and for
+// a problem that carries a camera rig (fisheye models, the right camera's *ToBody edges).
 static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r) {
+  if (!h || !p) return ORBG_BAD_ARG;
+  const Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
+  if (!p->rig) return lba_solve_attempt_t(h, p, stop_ref, r, cam);
+  CamRig g;
+  if (!cam_rig_from(*p->rig, cam, &g)) return ORBG_BAD_ARG;
+  return lba_solve_attempt_t(h, p, stop_ref, r, g);
+}
+template <class CamT>
+static int lba_solve_attempt_t(lba_handle* h, const lba_problem* p, StopRef stop_ref, lba_result* r, const CamT& cam) {
   if (!h) return ORBG_BAD_ARG;
   const LbaSwitches& sw = h->sw;
   if (!h || !p || !r || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0) return ORBG_BAD_ARG;
@@ -1710,6 +1869,19 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
       }
     }
   }
+  // Camera rigs: the second, third .. edge of a run of edges between the same keyframe and landmark (left and right camera, adjacent
+  // in the reference's creation order) is left out of the per-landmark lists of free observations that the Schur complement and the
+  // back-substitution walk -- the run's first edge carries the Hpl block of the vertex pair (linearize_block).
+  constexpr bool kRig = std::is_same<CamT, CamRig>::value;
+  std::vector<uint8_t> rig_secondary;
+  if constexpr (kRig) {
+    rig_secondary.assign((size_t)std::max(NE, 1), 0);
+    for (int k = 1; k < NE; k++)
+      if (edges[k].pose == edges[k - 1].pose && edges[k].point == edges[k - 1].point) {
+        rig_secondary[k] = 1;
+        if (!p->pose_fixed[edges[k].pose]) pf_raw[edges[k].point]--;
+      }
+  }
   if (NE > 0) {
     // (k_upload16: the runtime's blit kernel takes ~50 us for these 190 KB)
     const unsigned n16 = (unsigned)((sizeof(lba_edge) * (size_t)NE + 15) / 16);
@@ -1753,7 +1925,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
   const bool dev_lists = dev_items && nP >= 1 && ldltm::supports(6 * nP);
   // ... and the device fills the lists itself (k_csr_fill / k_csr_sort) when a pose's list fits the sorting workgroup
   // (measured: a wash at C2 -- 7.7 + 15.2 us of kernels for a 29 us host pass -- and -20 us at C4: used from 16 k edges on)
-  const bool dev_csr = dev_lists && NE > 0 && nL > 0 && max_pose_edges <= kCsrPoseCap && NE >= 16384;
+  const bool dev_csr = dev_lists && NE > 0 && nL > 0 && max_pose_edges <= kCsrPoseCap && NE >= 16384 && !kRig;
   const size_t o_lm_mask = take(8 * (size_t)nL);
   const size_t o_pair_i1 = take(4 * (size_t)n_pairs_all), o_pair_i2 = take(4 * (size_t)n_pairs_all), o_pair_start = take(4 * ((size_t)n_pairs_all + 1));
   const size_t o_items = take(dev_items ? 0 : sizeof(PairItem) * n_items);
@@ -1781,7 +1953,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
     memcpy(H + o_cur_pt, pt_start, 4 * (size_t)nL); memcpy(H + o_cur_ps, ps_start, 4 * (size_t)nP); memcpy(H + o_cur_pf, pf_start, 4 * (size_t)nL);
   } else {
     std::vector<int>& f1 = h->s_f1; std::vector<int>& f2 = h->s_f2; std::vector<int>& f3 = h->s_f3;
-    if (runs == nL) {
+    if (runs == nL && !kRig) {
       // every landmark's edges are consecutive (the reference's order): a landmark's list positions are carried in registers along
       // its run instead of in per-landmark cursors (the same store-to-load chains as above), and the "pose is free" test selects
       // the destination (a junk word for edges of fixed poses) instead of branching on a one-in-three condition
@@ -1810,7 +1982,10 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
       for (int k = 0; k < NE; k++) {
         const int lc = point_col[edges[k].point], pc = pose_col[edges[k].pose];
         pt_edges[f1[lc]++] = k;
-        if (pc >= 0) { ps_edges[f2[pc]++] = k; pf_edges[f3[lc]++] = k; }
+        if (pc >= 0) {
+          ps_edges[f2[pc]++] = k;
+          if (!kRig || !rig_secondary[k]) pf_edges[f3[lc]++] = k;
+        }
       }
     }
   }
@@ -1876,7 +2051,6 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
   double* const pointsB[3] = {reinterpret_cast<double*>(h->up_d.p + o_points), h->d_points[1].p, h->d_points[0].p};
 
   const double t_c = now_s();
-  Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
   Huber hb;
   hb.delta_mono = (float)std::sqrt(5.991); hb.dsqr_mono = hb.delta_mono * hb.delta_mono;          // S/Optimizer.cc:1991-1992
   hb.delta_stereo = (float)std::sqrt(7.815); hb.dsqr_stereo = hb.delta_stereo * hb.delta_stereo;
@@ -1914,7 +2088,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
   // final_mode: the last block also publishes {robust chi2, computeScale(), solver flag} to the host record
   auto launch_errors = [&](int buf, int final_mode) {
     if (NE > 0)
-      hipLaunchKernelGGL(k_errors, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, posesB[buf], pointsB[buf], cam, hb,
+      hipLaunchKernelGGL(k_errors<CamT>, dim3(n_blocks_e), dim3(256), 0, st, NE, D.edges, posesB[buf], pointsB[buf], cam, hb,
                          h->d_err.p, h->d_chi2.p, h->d_partial.p, final_mode, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u,
                          h->d_ok.p, h->rec.d, final_mode ? ++h->rec_seq : 0u);
   };
@@ -1929,7 +2103,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
   bool spec_ready = false;         // set ls^1 holds the linearisation of the current estimate
   auto launch_linearise = [&](int buf, int set) {
     if (NE > 0 || nP > 0)
-      hipLaunchKernelGGL(k_lin_all, dim3(nP + (NE > 0 ? n_blocks_e : 0)), dim3(256), 0, st, nP, NE, D.edges, posesB[buf],
+      hipLaunchKernelGGL(k_lin_all<CamT>, dim3(nP + (NE > 0 ? n_blocks_e : 0)), dim3(256), 0, st, nP, NE, D.edges, posesB[buf],
                          pointsB[buf], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                          D.ps_edges, Hpps[set], bps[set]);
     if (nL > 0)
@@ -1982,7 +2156,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
   auto launch_export = [&](int buf) {
     const int n_thr = std::max(std::max(NE, NP), 3 * NX);
     if (n_thr > 0)
-      hipLaunchKernelGGL(k_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, NE, NP, NX, D.edges, posesB[buf], pointsB[buf],
+      hipLaunchKernelGGL(k_export<CamT>, dim3((n_thr + 255) / 256), dim3(256), 0, st, NE, NP, NX, D.edges, posesB[buf], pointsB[buf], cam,
                          h->d_chi2.p, h->dl_h.d + d_flags_o, r->edge_chi2 ? reinterpret_cast<double*>(h->dl_h.d + d_chi_o) : (double*)nullptr,
                          reinterpret_cast<PoseQ*>(h->dl_h.d + d_poses_o), reinterpret_cast<double*>(h->dl_h.d + d_points_o));
   };
@@ -2083,7 +2257,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
             // residuals + record + linearisation of the trial state in ONE launch
             const int set = ls ^ 1;
             const int n_blocks_l = errlin_tail_blocks(nL);   // the landmark reduction (quads) and the record's publisher ride in the same launch
-            hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[trial],
+            hipLaunchKernelGGL(k_errlin<CamT>, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[trial],
                                pointsB[trial], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                                D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, n_blocks_u, h->d_ok.p,
                                h->rec.d, ++h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
@@ -2103,7 +2277,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
             fused_export = last_round && (it + 1 >= iterations || nBad >= 2) && !lambda_on_device;
             if (fused_export) {
               const int n_thr = std::max(std::max(NE, NP), 3 * NX);
-              hipLaunchKernelGGL(k_errors_export, dim3((n_thr + 255) / 256), dim3(256), 0, st, n_blocks_e, NE, D.edges, posesB[trial],
+              hipLaunchKernelGGL(k_errors_export<CamT>, dim3((n_thr + 255) / 256), dim3(256), 0, st, n_blocks_e, NE, D.edges, posesB[trial],
                                  pointsB[trial], cam, hb, h->d_err.p, h->d_chi2.p, h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p,
                                  n_blocks_u, h->d_ok.p, h->rec.d, ++h->rec_seq, NP, NX, h->dl_h.d + d_flags_o,
                                  r->edge_chi2 ? reinterpret_cast<double*>(h->dl_h.d + d_chi_o) : (double*)nullptr,
@@ -2195,7 +2369,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
                        const_cast<int*>(D.ps_edges), D.pt_start, const_cast<int*>(D.pt_edges), D.pf_start, const_cast<int*>(D.pf_edges),
                        const_cast<int*>(D.pf_col), reinterpret_cast<unsigned long long*>(B + o_lm_mask), D.edges, D.pose_col, n,
                        use_mfma ? h->d_St.p : (double*)nullptr, h->d_x.p, n_zero);
-    hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_tail), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
+    hipLaunchKernelGGL(k_errlin<CamT>, dim3(nP + n_blocks_e + n_tail), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
                        pointsB[cur], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                        D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, 0, (const int*)nullptr,
                        h->rec.d, h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],
@@ -2209,7 +2383,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
   } else if (first2) {
     const int set = ls ^ 1;
     const int n_blocks_l = errlin_tail_blocks(nL), n_err = nP + n_blocks_e + n_blocks_l, nsb = (nL + 255) / 256;
-    hipLaunchKernelGGL(k_errlin_prep, dim3(n_err + nsb + kPrep256Pad + kPrep256Zero), dim3(256), 0, st, n_err, nsb,
+    hipLaunchKernelGGL(k_errlin_prep<CamT>, dim3(n_err + nsb + kPrep256Pad + kPrep256Zero), dim3(256), 0, st, n_err, nsb,
                        const_cast<int*>(D.pf_edges), const_cast<int*>(D.pf_col), D.pf_start,
                        reinterpret_cast<unsigned long long*>(h->up_d.p + o_lm_mask), n, use_mfma ? h->d_St.p : (double*)nullptr,
                        h->d_x.p, n_zero,
@@ -2229,7 +2403,7 @@ static int lba_solve_attempt(lba_handle* h, const lba_problem* p, StopRef stop_r
       // for: it carries the sequence number the host has already seen)
       const int set = ls ^ 1;
       const int n_blocks_l = errlin_tail_blocks(nL);
-      hipLaunchKernelGGL(k_errlin, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
+      hipLaunchKernelGGL(k_errlin<CamT>, dim3(nP + n_blocks_e + n_blocks_l), dim3(256), 0, st, nP, NE, D.edges, posesB[cur],
                          pointsB[cur], cam, hb, h->d_err.p, h->d_chi2.p, D.pose_col, D.point_col, EBs[set], D.ps_start,
                          D.ps_edges, Hpps[set], bps[set], h->d_partial.p, h->d_ticket.p, h->d_scale_partial.p, 0, (const int*)nullptr,
                          h->rec.d, h->rec_seq, n_blocks_e, nL, D.pt_start, D.pt_edges, Hlls[set], bls[set],

@@ -205,7 +205,7 @@ __device__ __forceinline__ void po_eval(const PoseQ& T, const V* X, V uu, V vv, 
 }
 // J^T (w Omega) J (21 entries, upper triangle row-major) and J^T (w Omega) r (6) of one evaluation -> hh[27]
 template <class V, class M>
-__device__ __forceinline__ void po_hessian(const PoEval<V>& e, V om, M mono, const Cam& cam, V* hh) {
+__device__ __forceinline__ void po_hessian(const PoEval<V>& e, V om, M mono, const Cam& cam, V* hh, V /*ur: the rig form below needs it*/) {
   // Jacobian (D x 6): mono S/OptimizableTypes.cpp:49-63, stereo types_six_dof_expmap.cpp:375-404
   const V xx = e.Xc[0], yy = e.Xc[1], iz = e.iz, iz2 = iz * iz;
   const V zero = po_c<V>(0.0);
@@ -246,6 +246,82 @@ __device__ __forceinline__ void po_hessian(const PoEval<V>& e, V om, M mono, con
     hh[o++] = sacc;
   }
 }
+// ---- the same three pieces for a Frame with a camera rig (pose_opt_problem::rig, S/Optimizer.cc:1085-1151), one correspondence
+// per call: monocular entries through mpCamera->project / projectJac (EdgeSE3ProjectXYZOnlyPose, I/OptimizableTypes.h:40-44,
+// S/OptimizableTypes.cpp:46-62), the right camera's after mTrl (EdgeSE3ProjectXYZOnlyPoseToBody, I/OptimizableTypes.h:69-73,
+// S/OptimizableTypes.cpp:90-108); stereo entries as above.  PoEval::Xc is the point in the LEFT camera's frame throughout.
+__device__ inline void po_rig_residual(const PoseQ& T, const double* X, const double* Xl, double u, double v, double ur, const CamRig& g,
+                                       double* err) {
+  double uv[2];
+  if (g.has_right && ur_is_right((float)ur)) {
+    PoseQ Trw;
+    se3_mul(g.Trl, T, &Trw);
+    double r[3];
+    quat_rotate(Trw.q, X, r);
+    const double Xr[3] = {r[0] + Trw.t[0], r[1] + Trw.t[1], r[2] + Trw.t[2]};
+    cam_project(g.right, Xr, uv);
+  } else {
+    cam_project(g.left, Xl, uv);
+  }
+  err[0] = u - uv[0]; err[1] = v - uv[1]; err[2] = 0;
+}
+__device__ inline void po_edge_error(const PoseQ& T, const float* X, float u, float v, float ur, const CamRig& g, double* err, double* Xc) {
+  if (ur >= 0) { po_edge_error(T, X, u, v, ur, g.c, err, Xc); return; }
+  const double Xd[3] = {X[0], X[1], X[2]};
+  double iz;
+  po_cam_point<double>(T, Xd, Xc, &iz);
+  po_rig_residual(T, Xd, Xc, (double)u, (double)v, (double)ur, g, err);
+}
+template <class V, class M>
+__device__ __forceinline__ void po_eval(const PoseQ& T, const V* X, V uu, V vv, V ur, V om, M mono, bool robust, const CamRig& g,
+                                        double dM, double dS, double dsqM, double dsqS, PoEval<V>* e) {
+  static_assert(sizeof(V) == sizeof(double), "the rig form evaluates one correspondence per call");
+  if (ur >= 0) { po_eval<V, M>(T, X, uu, vv, ur, om, mono, robust, g.c, dM, dS, dsqM, dsqS, e); return; }
+  po_cam_point<double>(T, X, e->Xc, &e->iz);
+  po_rig_residual(T, X, e->Xc, uu, vv, ur, g, e->err);
+  e->c2 = e->err[0] * (om * e->err[0]) + e->err[1] * (om * e->err[1]);
+  po_huber<double>(robust, e->c2, dM, dsqM, 1.0, &e->rho0, &e->rho1);
+}
+template <class V, class M>
+__device__ __forceinline__ void po_hessian(const PoEval<V>& e, V om, M mono, const CamRig& g, V* hh, V ur) {
+  static_assert(sizeof(V) == sizeof(double), "the rig form evaluates one correspondence per call");
+  if (ur >= 0) { po_hessian<V, M>(e, om, mono, g.c, hh, ur); return; }
+  const double x = e.Xc[0], y = e.Xc[1], z = e.Xc[2];
+  double P[6], Mx[6];
+  if (g.has_right && ur_is_right((float)ur)) {
+    double rr[3], Rrl[9];
+    quat_rotate(g.Trl.q, e.Xc, rr);
+    const double Xr[3] = {rr[0] + g.Trl.t[0], rr[1] + g.Trl.t[1], rr[2] + g.Trl.t[2]};
+    cam_project_jac(g.right, Xr, P);
+#pragma unroll
+    for (int i = 0; i < 6; i++) P[i] = -P[i];
+    quat_to_R(g.Trl.q, Rrl);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Mx[3 * i + j] = P[3 * i] * Rrl[j] + P[3 * i + 1] * Rrl[3 + j] + P[3 * i + 2] * Rrl[6 + j];
+  } else {
+    cam_project_jac(g.left, e.Xc, P);
+#pragma unroll
+    for (int i = 0; i < 6; i++) Mx[i] = -P[i];
+  }
+  const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+  double J[12];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) J[6 * i + j] = Mx[3 * i] * S[j] + Mx[3 * i + 1] * S[6 + j] + Mx[3 * i + 2] * S[12 + j];
+  const double wom = e.rho1 * om;
+  const double orr[2] = {-(om * e.err[0]) * e.rho1, -(om * e.err[1]) * e.rho1};
+  int o = 0;
+#pragma unroll
+  for (int a2 = 0; a2 < 6; a2++)
+#pragma unroll
+    for (int c3 = a2; c3 < 6; c3++) hh[o++] = J[a2] * (wom * J[c3]) + J[6 + a2] * (wom * J[6 + c3]);
+#pragma unroll
+  for (int a2 = 0; a2 < 6; a2++) hh[o++] = J[a2] * orr[0] + J[6 + a2] * orr[1];
+}
+
 // Optimizer::PoseOptimization (S/Optimizer.cc:992-1290) in ONE launch of one workgroup: 4 rounds x up to 10
 // Levenberg-Marquardt iterations (g2o OptimizationAlgorithmLevenberg semantics), outlier re-classification after
 // each round.  The LM state (pose, lambda, gains) is kept identically in every thread -- all of them read the same
@@ -330,7 +406,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
           PoEval<double> e1;
           po_eval<double, bool>(T, X, (double)ou[i0], (double)ov[i0], ur1, om1, mono1, robust, cam, dM, dS, dsqM, dsqS, &e1);
           double h1[27];
-          po_hessian<double, bool>(e1, om1, mono1, cam, h1);
+          po_hessian<double, bool>(e1, om1, mono1, cam, h1, ur1);
           s_chi2[i0] = e1.c2;
           acc[27] += e1.rho0;
 #pragma unroll
@@ -353,7 +429,7 @@ __global__ __launch_bounds__(kPoThreads) void pose_opt_kernel(int n, const float
           po_eval<D2, B2>(T, X, uu, vv, ur, om, mono, robust, cam, dM, dS, dsqM, dsqS, &e2);
         }
         D2 hh[27];
-        po_hessian<D2, B2>(e2, om, mono, cam, hh);
+        po_hessian<D2, B2>(e2, om, mono, cam, hh, ur);
         if (act0) {
           s_chi2[i0] = e2.c2.a;
           acc[27] += e2.rho0.a;
@@ -616,9 +692,10 @@ __device__ __forceinline__ double po_block_count_wide(double v, double* s_cnt) {
 }
 
 // NP = 1: n <= 512, one correspondence per thread; NP = 2: n <= 1024, two (a thread adds its own two terms first).
-template <int NP>
+// CamT: Cam (the five pinhole scalars: every BASELINE configuration) or CamRig (a Frame with mpCamera / mpCamera2 models; NP up to 8).
+template <int NP, class CamT = Cam>
 __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const float* g_Xw, const float* g_ou, const float* g_ov, const float* g_our,
-                                                                const float* g_oinv, Cam cam, PoseQ T0, PoseQ* __restrict__ T_out,
+                                                                const float* g_oinv, CamT cam, PoseQ T0, PoseQ* __restrict__ T_out,
                                                                 uint8_t* __restrict__ outlier_out, int* __restrict__ stats, double* __restrict__ chi_out,
                                                                 unsigned seq) {
   __shared__ double s_w[8 * 28 * 16];
@@ -677,7 +754,7 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
           PoEval<double> e1;
           po_eval<double, bool>(T, X, (double)uf[p], (double)vf[p], (double)urf[p], om, mono[p], robust, cam, dM, dS, dsqM, dsqS, &e1);
           double h1[27];
-          po_hessian<double, bool>(e1, om, mono[p], cam, h1);
+          po_hessian<double, bool>(e1, om, mono[p], cam, h1, (double)urf[p]);
           my_chi2[p] = e1.c2;
           acc[27] += e1.rho0;
 #pragma unroll
@@ -851,6 +928,7 @@ extern "C" int pose_opt_set_stream(int device, void* hip_stream) {
 extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
   if (!p || !r || p->n < 0 || (p->n > 0 && (!p->Xw || !p->u || !p->v || !p->ur || !p->inv_sigma2 || !r->outlier))) return ORBG_BAD_ARG;
   if (p->n > kPoThreads * kPoMaxPer) return ORBG_CAP_EXCEEDED;
+  if (p->rig && p->n > 8 * kPoWide) return ORBG_CAP_EXCEEDED;           // (the rig form runs on the wide kernel only: 4096 correspondences)
   int rc = select_device(p->device);
   if (rc) return rc;
   const int n = p->n;
@@ -896,12 +974,24 @@ extern "C" int pose_optimize(const pose_opt_problem* p, pose_opt_result* r) {
     T0.t[0] = T[3]; T0.t[1] = T[7]; T0.t[2] = T[11];
   }
   Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
+  CamRig rig;
+  if (p->rig && !cam_rig_from(*p->rig, cam, &rig)) return ORBG_BAD_ARG;
   static thread_local unsigned po_seq = 0;
   po_seq = (po_seq + 1) & 0x7FFFFFFFu;
   if (po_seq == 0) po_seq = 1;
   volatile int* seq_word = reinterpret_cast<volatile int*>(sc.stage.h + out_off + sizeof(PoseQ) + 4 * sizeof(double)) + 7;
   *seq_word = 0;
-  if (n <= kPoWide)
+  if (p->rig) {
+    // a Frame with camera models / a second camera: the wide kernel over CamRig, up to eight correspondences per thread
+#define ORBG_PO_RIG(NP)                                                                                                              \
+  hipLaunchKernelGGL((pose_opt_wide_kernel<NP, CamRig>), dim3(1), dim3(kPoWide), 0, sc.stream, n, dX, dX + 3 * (size_t)n,            \
+                     dX + 4 * (size_t)n, dX + 5 * (size_t)n, dX + 6 * (size_t)n, rig, T0, dT, dflag, dstats, dchi, po_seq)
+    if (n <= kPoWide) ORBG_PO_RIG(1);
+    else if (n <= 2 * kPoWide) ORBG_PO_RIG(2);
+    else if (n <= 4 * kPoWide) ORBG_PO_RIG(4);
+    else ORBG_PO_RIG(8);
+#undef ORBG_PO_RIG
+  } else if (n <= kPoWide)
     hipLaunchKernelGGL(pose_opt_wide_kernel<1>, dim3(1), dim3(kPoWide), 0, sc.stream, n, dX, dX + 3 * (size_t)n, dX + 4 * (size_t)n,
                        dX + 5 * (size_t)n, dX + 6 * (size_t)n, cam, T0, dT, dflag, dstats, dchi, po_seq);
   else if (n <= 2 * kPoWide)

@@ -64,6 +64,104 @@ __host__ __device__ inline void quat_normalize(double* q) {   // SE3Quat::normal
   q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
 }
 
+// SE3Quat::operator* (G/types/se3quat.h:104-110): t = a.t + a.q * b.t, q = a.q * b.q, normalizeRotation()
+__host__ __device__ inline void se3_mul(const PoseQ& a, const PoseQ& b, PoseQ* out) {
+  double rt[3];
+  quat_rotate(a.q, b.t, rt);
+  out->t[0] = a.t[0] + rt[0]; out->t[1] = a.t[1] + rt[1]; out->t[2] = a.t[2] + rt[2];
+  const double* x = a.q; const double* y = b.q;
+  out->q[3] = x[3] * y[3] - x[0] * y[0] - x[1] * y[1] - x[2] * y[2];
+  out->q[0] = x[3] * y[0] + x[0] * y[3] + x[1] * y[2] - x[2] * y[1];
+  out->q[1] = x[3] * y[1] + x[1] * y[3] + x[2] * y[0] - x[0] * y[2];
+  out->q[2] = x[3] * y[2] + x[2] * y[3] + x[0] * y[1] - x[1] * y[0];
+  quat_normalize(out->q);
+}
+
+// ---- the cameras behind GeometricCamera::project / projectJac (Eigen forms), for the problems that carry an orbg_camera_rig
+// (include/orbgpu.h): Pinhole S/CameraModels/Pinhole.cpp:41-47,81-91; KannalaBrandt8 S/CameraModels/KannalaBrandt8.cpp:52-69,166-196.
+// mvParameters are float32 in the reference and meet doubles everywhere they are used: kept here as the doubles they promote to.
+struct CamModelD { int model; double fx, fy, cx, cy, k1, k2, k3, k4; };
+// Cam c: the five scalars the stereo edges carry; left / right / Trl: mpCamera, mpCamera2, Converter::toSE3Quat(mTrl)
+struct CamRig { Cam c; CamModelD left, right; PoseQ Trl; int has_right; };
+
+__device__ inline void cam_project(const CamModelD& m, const double* v, double* uv) {
+  if (m.model == 1) {
+    // theta and psi are float32 VALUES in the reference (atan2f / sqrtf): the correctly rounded float of the double result here
+    const double x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
+    const double theta = (double)(float)atan2((double)sqrtf((float)x2_plus_y2), (double)(float)v[2]);
+    const double psi = (double)(float)atan2((double)(float)v[1], (double)(float)v[0]);
+    const double theta2 = theta * theta;
+    const double theta3 = theta * theta2;
+    const double theta5 = theta3 * theta2;
+    const double theta7 = theta5 * theta2;
+    const double theta9 = theta7 * theta2;
+    const double r = theta + m.k1 * theta3 + m.k2 * theta5 + m.k3 * theta7 + m.k4 * theta9;
+    double sn, cs;
+    sincos(psi, &sn, &cs);
+    uv[0] = m.fx * r * cs + m.cx;
+    uv[1] = m.fy * r * sn + m.cy;
+  } else {
+    uv[0] = m.fx * v[0] / v[2] + m.cx;
+    uv[1] = m.fy * v[1] / v[2] + m.cy;
+  }
+}
+
+// J = d project / d v, 2 x 3 row-major
+__device__ inline void cam_project_jac(const CamModelD& m, const double* v, double* J) {
+  if (m.model == 1) {
+    const double x2 = v[0] * v[0], y2 = v[1] * v[1], z2 = v[2] * v[2];
+    const double r2 = x2 + y2;
+    const double r = sqrt(r2);
+    const double r3 = r2 * r;
+    const double theta = atan2(r, v[2]);
+    const double theta2 = theta * theta, theta3 = theta2 * theta;
+    const double theta4 = theta2 * theta2, theta5 = theta4 * theta;
+    const double theta6 = theta2 * theta4, theta7 = theta6 * theta;
+    const double theta8 = theta4 * theta4, theta9 = theta8 * theta;
+    const double f = theta + theta3 * m.k1 + theta5 * m.k2 + theta7 * m.k3 + theta9 * m.k4;
+    const double fd = 1 + 3 * m.k1 * theta2 + 5 * m.k2 * theta4 + 7 * m.k3 * theta6 + 9 * m.k4 * theta8;
+    const double den = r2 * (r2 + z2);
+    J[0] = m.fx * (fd * v[2] * x2 / den + f * y2 / r3);
+    J[3] = m.fy * (fd * v[2] * v[1] * v[0] / den - f * v[1] * v[0] / r3);
+    J[1] = m.fx * (fd * v[2] * v[1] * v[0] / den - f * v[1] * v[0] / r3);
+    J[4] = m.fy * (fd * v[2] * y2 / den + f * x2 / r3);
+    J[2] = -m.fx * fd * v[0] / (r2 + z2);
+    J[5] = -m.fy * fd * v[1] / (r2 + z2);
+  } else {
+    J[0] = m.fx / v[2]; J[1] = 0.0; J[2] = -m.fx * v[0] / (v[2] * v[2]);
+    J[3] = 0.0; J[4] = m.fy / v[2]; J[5] = -m.fy * v[1] / (v[2] * v[2]);
+  }
+}
+
+// orbg_camera / orbg_camera_rig (include/orbgpu.h; templates so that this header needs no other) -> what the kernels take;
+// Converter::toSE3Quat(mTrl) (S/Converter.cc:34-44) as for the keyframe poses.  false: a camera model this library does not know.
+template <class CameraC>
+inline bool cam_model_from(const CameraC& c, CamModelD* m) {
+  if (c.model != 0 && c.model != 1) return false;
+  *m = CamModelD{c.model, c.fx, c.fy, c.cx, c.cy, c.k[0], c.k[1], c.k[2], c.k[3]};
+  return true;
+}
+template <class RigC>
+inline bool cam_rig_from(const RigC& rig, const Cam& scalars, CamRig* g) {
+  g->c = scalars;
+  g->has_right = rig.has_right ? 1 : 0;
+  if (!cam_model_from(rig.left, &g->left)) return false;
+  g->right = g->left;
+  g->Trl = PoseQ{{0, 0, 0, 1}, {0, 0, 0}};
+  if (rig.has_right) {
+    if (!cam_model_from(rig.right, &g->right)) return false;
+    const float* T = rig.Trl;
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    quat_from_R(R, g->Trl.q);
+    quat_normalize(g->Trl.q);
+    g->Trl.t[0] = T[3]; g->Trl.t[1] = T[7]; g->Trl.t[2] = T[11];
+  }
+  return true;
+}
+
+// `ur` of an observation made by the rig's right camera (LBA_UR_RIGHT_CAMERA, include/orbgpu.h)
+__host__ __device__ inline bool ur_is_right(float ur) { return ur <= -1.5f; }
+
 // estimate = SE3Quat::exp(update) * estimate   (G/types/se3quat.h:225-260,102-110)
 __device__ inline void pose_oplus(const PoseQ& T, const double* u, PoseQ* out) {
   const double om0 = u[0], om1 = u[1], om2 = u[2];

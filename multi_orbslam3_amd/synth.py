@@ -268,6 +268,140 @@ def make_pose_opt_problem(n=500, seed=0xF00D, width=640, height=480, outlier_fra
                 inv_sigma2=inv_s2, cam=(fx, fy, cx, cy, bf), Tcw=T0.astype(np.float32), T_true=T_true, bad=bad)
 
 
+# ---------------------------------------------------------------- two-fisheye rig (mpCamera2 != NULL, NLeft != -1)
+# TUM-VI-like 512 x 512 KannalaBrandt8 cameras (the reference ships no settings file; values of that order)
+KB8_LEFT = (capi.CAM_KANNALA_BRANDT8, 190.978, 190.973, 254.932, 256.897, 0.00348, 0.000715, -0.00205, 0.000203)
+KB8_RIGHT = (capi.CAM_KANNALA_BRANDT8, 190.442, 190.435, 252.598, 254.917, 0.00340, 0.00177, -0.00266, 0.000330)
+
+
+def rig_Trl():
+    """mTrl: the right camera's pose in the left camera's frame (10 cm baseline, a degree of misalignment)."""
+    T = np.eye(4)
+    T[:3, :3] = _rot(0.012, -0.02, 0.006)
+    T[:3, 3] = [-0.101, 0.0012, -0.0009]
+    return T
+
+
+def kb8_project(cam, X):
+    """KannalaBrandt8::project (or Pinhole::project for a pinhole tuple) in float64: for making observations; the oracle holds the
+    reference's float32 form."""
+    X = np.asarray(X, np.float64)
+    if cam[0] == capi.CAM_PINHOLE:
+        return np.stack([cam[1] * X[..., 0] / X[..., 2] + cam[3], cam[2] * X[..., 1] / X[..., 2] + cam[4]], -1)
+    _, fx, fy, cx, cy, k1, k2, k3, k4 = cam
+    r = np.hypot(X[..., 0], X[..., 1])
+    th = np.arctan2(r, X[..., 2])
+    psi = np.arctan2(X[..., 1], X[..., 0])
+    d = th + k1 * th ** 3 + k2 * th ** 5 + k3 * th ** 7 + k4 * th ** 9
+    return np.stack([fx * d * np.cos(psi) + cx, fy * d * np.sin(psi) + cy], -1)
+
+
+def _kb8_ray(cam, u, v, rng_depth):
+    """A point at depth-along-ray rng_depth whose projection is near (u, v) (first-order inverse: theta = r / f)."""
+    _, fx, fy, cx, cy = cam[:5]
+    mx, my = (u - cx) / fx, (v - cy) / fy
+    if cam[0] == capi.CAM_PINHOLE:
+        d = np.array([mx, my, 1.0])
+        return rng_depth * d / np.linalg.norm(d)
+    th = np.hypot(mx, my)
+    psi = np.arctan2(my, mx)
+    return rng_depth * np.array([np.sin(th) * np.cos(psi), np.sin(th) * np.sin(psi), np.cos(th)])
+
+
+def make_lba_rig_problem(n_free=8, n_fixed=4, n_points=600, seed=0xF15E, size=512, outlier_frac=0.03, right_frac=0.6, left_frac=0.9,
+                         left=KB8_LEFT, right=KB8_RIGHT):
+    """A local BA window of a two-fisheye rig (S/Optimizer.cc:2021-2120 with mpCamera2): every observation of a point by a keyframe is a
+    monocular edge through mpCamera (left) and / or an EdgeSE3ProjectXYZToBody through mpCamera2 after mTrl (right, ur =
+    LBA_UR_RIGHT_CAMERA); no stereo edges (mvuRight is -1 on such frames).  Edges in creation order: per point, per keyframe,
+    left then right."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    Trl = rig_Trl()
+    P = n_free + n_fixed
+    poses_true = np.zeros((P, 4, 4))
+    for k in range(P):
+        R = _rot(0.03 * np.sin(0.3 * k), 0.05 * np.sin(0.2 * k + 1.0), 0.02 * np.sin(0.5 * k))
+        Cc = np.array([0.10 * k, 0.02 * np.sin(0.4 * k), 0.03 * np.cos(0.3 * k)])
+        poses_true[k] = np.eye(4)
+        poses_true[k, :3, :3] = R
+        poses_true[k, :3, 3] = -R @ Cc
+    sc = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sc[i] = np.float32(sc[i - 1] * np.float32(1.2))
+    inv_s2 = (np.float32(1.0) / (sc * sc)).astype(np.float32)
+    points_true = np.zeros((n_points, 3))
+    edges = []
+    for j in range(n_points):
+        nobs = rng.randint(3, 8)
+        k0 = rng.randint(0, max(P - nobs, 0) + 1)
+        kc = min(k0 + nobs // 2, P - 1)
+        Pc = _kb8_ray(left, rng.uniform(40, size - 40), rng.uniform(40, size - 40), rng.uniform(1.5, 8.0))
+        Xw = poses_true[kc, :3, :3].T @ (Pc - poses_true[kc, :3, 3])
+        points_true[j] = Xw
+        for k in range(k0, min(k0 + nobs, P)):
+            Xl = poses_true[k, :3, :3] @ Xw + poses_true[k, :3, 3]
+            Xr = Trl[:3, :3] @ Xl + Trl[:3, 3]
+            for is_right, Xc, cam, frac in ((False, Xl, left, left_frac), (True, Xr, right, right_frac)):
+                if Xc[2] < 0.2 or rng.rand() > frac:
+                    continue
+                uv = kb8_project(cam, Xc)
+                if not (5 <= uv[0] < size - 5 and 5 <= uv[1] < size - 5):
+                    continue
+                octave = rng.randint(0, 8)
+                noise = rng.randn(2) * float(sc[octave])
+                if rng.rand() < outlier_frac:
+                    noise += rng.choice([-20, 20], 2)
+                edges.append((k, j, uv[0] + noise[0], uv[1] + noise[1], capi.UR_RIGHT_CAMERA if is_right else -1.0, inv_s2[octave]))
+    E = np.zeros(len(edges), dtype=capi.EDGE_DTYPE)
+    for i, e in enumerate(edges):
+        E[i] = (e[0], e[1], np.float32(e[2]), np.float32(e[3]), np.float32(e[4]), e[5])
+    poses0 = np.zeros((P, 16), np.float32)
+    fixed = np.zeros(P, np.uint8)
+    fixed[:n_fixed] = 1
+    for k in range(P):
+        T = poses_true[k].copy()
+        if not fixed[k]:
+            T = perturb_pose(T, rng, sigma_rot_deg=0.3, sigma_t=0.01)
+        poses0[k] = T.astype(np.float32).reshape(16)
+    points0 = (points_true + rng.randn(n_points, 3) * 0.02).astype(np.float32)
+    # the five scalars of a KeyFrame (fx, fy, cx, cy, mbf): only stereo edges read them; there are none here
+    return dict(poses=poses0, pose_fixed=fixed, points=points0, edges=E, cam=(left[1], left[2], left[3], left[4], 0.0),
+                rig=(left, right, Trl.astype(np.float32)), poses_true=poses_true, points_true=points_true)
+
+
+def make_pose_opt_rig_problem(n_left=300, n_right=200, seed=0xF15F, size=512, outlier_frac=0.1, sigma_rot_deg=0.5, sigma_t=0.02,
+                              left=KB8_LEFT, right=KB8_RIGHT):
+    """Correspondences of a two-fisheye Frame for Optimizer::PoseOptimization (S/Optimizer.cc:1085-1151): features i < Nleft are
+    mvKeys (left camera), the others mvKeysRight (ur = LBA_UR_RIGHT_CAMERA)."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    Trl = rig_Trl()
+    T_true = np.eye(4)
+    T_true[:3, :3] = _rot(0.05, -0.03, 0.02)
+    T_true[:3, 3] = [0.1, -0.05, 0.2]
+    n = n_left + n_right
+    sc = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sc[i] = np.float32(sc[i - 1] * np.float32(1.2))
+    Xw = np.zeros((n, 3)); u = np.zeros(n); v = np.zeros(n); ur = np.full(n, -1.0)
+    octv = rng.randint(0, 8, n)
+    for i in range(n):
+        is_right = i >= n_left
+        cam = right if is_right else left
+        Pc = _kb8_ray(cam, rng.uniform(30, size - 30), rng.uniform(30, size - 30), rng.uniform(1.5, 8.0))    # in the observing camera
+        Xl = Trl[:3, :3].T @ (Pc - Trl[:3, 3]) if is_right else Pc
+        Xw[i] = T_true[:3, :3].T @ (Xl - T_true[:3, 3])
+        uv = kb8_project(cam, Pc) + rng.randn(2) * float(sc[octv[i]])
+        u[i], v[i] = uv
+        if is_right:
+            ur[i] = capi.UR_RIGHT_CAMERA
+    bad = rng.rand(n) < outlier_frac
+    u[bad] += rng.choice([-25, 25], bad.sum()); v[bad] += rng.choice([-25, 25], bad.sum())
+    inv_s2 = (np.float32(1.0) / (sc * sc)).astype(np.float32)[octv]
+    T0 = perturb_pose(T_true, rng, sigma_rot_deg, sigma_t)
+    return dict(Xw=Xw.astype(np.float32), u=u.astype(np.float32), v=v.astype(np.float32), ur=ur.astype(np.float32),
+                inv_sigma2=inv_s2, cam=(left[1], left[2], left[3], left[4], 0.0), rig=(left, right, Trl.astype(np.float32)),
+                Tcw=T0.astype(np.float32), T_true=T_true, bad=bad)
+
+
 # ---------------------------------------------------------------- synthetic vocabulary (ORBvoc.txt is not in the reference tree)
 def make_vocabulary(k=10, L=3, seed=0xB0C, stop_frac=0.03, descriptors=None):
     """A k-ary tree of depth L in DBoW2's node layout (node ids in creation order, children after parents): node descriptors are

@@ -92,8 +92,29 @@ def vocab_view(child_start, child_ids, desc, weight, word_id, L, weighting=capi.
     return v, arrs
 
 
-def lba_problem(poses, pose_fixed, points, edges, cam, lambda_init=0.0, its=(5, 10), device=0):
-    """poses: (P,16) or (P,4,4) float32; edges: structured EDGE_DTYPE; cam = (fx, fy, cx, cy, bf)."""
+def camera_rig(left, right=None, Trl=None):
+    """orbg_camera_rig from (model, fx, fy, cx, cy[, k1, k2, k3, k4]) tuples: mpCamera, mpCamera2 and mTrl (3x4 or 4x4)."""
+    rig = capi.CameraRig()
+
+    def fill(dst, cam):
+        dst.model = int(cam[0])
+        dst.fx, dst.fy, dst.cx, dst.cy = [float(np.float32(c)) for c in cam[1:5]]
+        ks = list(cam[5:9]) + [0.0] * (4 - len(cam[5:9]))
+        for i in range(4):
+            dst.k[i] = float(np.float32(ks[i]))
+
+    fill(rig.left, left)
+    rig.has_right = 0 if right is None else 1
+    if right is not None:
+        fill(rig.right, right)
+        T = np.asarray(Trl, np.float32).reshape(-1)[:12]
+        for i in range(12):
+            rig.Trl[i] = float(T[i])
+    return rig
+
+
+def lba_problem(poses, pose_fixed, points, edges, cam, lambda_init=0.0, its=(5, 10), device=0, rig=None):
+    """poses: (P,16) or (P,4,4) float32; edges: structured EDGE_DTYPE; cam = (fx, fy, cx, cy, bf); rig: camera_rig(...) or None."""
     poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 16))
     pose_fixed = _c(pose_fixed, np.uint8)
     points = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(-1, 3))
@@ -105,7 +126,9 @@ def lba_problem(poses, pose_fixed, points, edges, cam, lambda_init=0.0, its=(5, 
     p.lambda_init = float(lambda_init)
     p.its_round1, p.its_round2 = int(its[0]), int(its[1])
     p.device = int(device)
-    return p, [poses, pose_fixed, points, edges]
+    if rig is not None:
+        p.rig = C.pointer(rig)
+    return p, [poses, pose_fixed, points, edges, rig]
 
 
 class LbaOutput:
@@ -144,8 +167,8 @@ class LbaOutput:
         return self.trace[: self.c.trace_len].copy()
 
 
-def pose_opt_problem(Xw, u, v, ur, inv_sigma2, cam, Tcw, device=0):
-    """cam = (fx, fy, cx, cy, bf); Tcw = pFrame->mTcw (4x4)."""
+def pose_opt_problem(Xw, u, v, ur, inv_sigma2, cam, Tcw, device=0, rig=None):
+    """cam = (fx, fy, cx, cy, bf); Tcw = pFrame->mTcw (4x4); rig: camera_rig(...) or None."""
     arrs = [_c(np.asarray(Xw, np.float32).reshape(-1, 3), np.float32), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32),
             _c(inv_sigma2, np.float32)]
     p = capi.PoseOptProblem()
@@ -156,6 +179,9 @@ def pose_opt_problem(Xw, u, v, ur, inv_sigma2, cam, Tcw, device=0):
     for i in range(16):
         p.Tcw[i] = float(T[i])
     p.device = int(device)
+    if rig is not None:
+        p.rig = C.pointer(rig)
+        arrs.append(rig)
     return p, arrs
 
 

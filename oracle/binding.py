@@ -465,6 +465,29 @@ def lba_edge_eval(q, t, X, cam5, edge):
     return err, A.reshape(3, 3), B.reshape(3, 6)
 
 
+def camera_project(cam, X):
+    """GeometricCamera::project / projectJac of cam = (model, fx, fy, cx, cy[, k1..k4]) at X: (uv, 2x3 Jacobian)."""
+    rig = views.camera_rig(cam)
+    X = np.ascontiguousarray(X, np.float64)
+    uv, J = np.zeros(2), np.zeros(6)
+    lib().oracle_camera_project(C.byref(rig.left), C.c_void_p(X.ctypes.data), C.c_void_p(uv.ctypes.data), C.c_void_p(J.ctypes.data))
+    return uv, J.reshape(2, 3)
+
+
+def lba_edge_eval_rig(q, t, X, cam5, rig, edge):
+    """One edge of a problem with a camera rig: (err, d err / d point, d err / d pose, point in the observing camera's frame)."""
+    q = np.ascontiguousarray(q, np.float64)
+    t = np.ascontiguousarray(t, np.float64)
+    X = np.ascontiguousarray(X, np.float64)
+    cam = np.ascontiguousarray(cam5, np.float32)
+    e = np.ascontiguousarray(edge, dtype=capi.EDGE_DTYPE).reshape(1)
+    err, A, B, Xc = np.zeros(3), np.zeros(9), np.zeros(18), np.zeros(3)
+    lib().oracle_lba_edge_eval_rig(C.c_void_p(q.ctypes.data), C.c_void_p(t.ctypes.data), C.c_void_p(X.ctypes.data),
+                                   C.c_void_p(cam.ctypes.data), C.byref(rig), C.c_void_p(e.ctypes.data), C.c_void_p(err.ctypes.data),
+                                   C.c_void_p(A.ctypes.data), C.c_void_p(B.ctypes.data), C.c_void_p(Xc.ctypes.data))
+    return err, A.reshape(3, 3), B.reshape(3, 6), Xc
+
+
 def pose_optimize(problem):
     out = views.PoseOptOutput(problem.n)
     _chk(lib().oracle_pose_optimize(C.byref(problem), C.byref(out.c)))

@@ -23,6 +23,8 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -140,14 +142,137 @@ void pose_oplus(PoseQ& T, const double u[6]) {
 
 struct Cam { double fx, fy, cx, cy, bf; float bf_f; };
 
+// Converter::toSE3Quat(cv::Mat) -- S/Converter.cc:34-44: float32 entries into an Eigen double matrix, SE3Quat(R, t)
+PoseQ pose_from_3x4(const float* T, int row_stride) {
+  PoseQ P;
+  const double R[9] = {T[0], T[1], T[2], T[row_stride], T[row_stride + 1], T[row_stride + 2], T[2 * row_stride], T[2 * row_stride + 1],
+                       T[2 * row_stride + 2]};
+  P.q = quat_from_R(R);
+  normalize_rotation(P.q);
+  P.t[0] = T[3]; P.t[1] = T[row_stride + 3]; P.t[2] = T[2 * row_stride + 3];
+  return P;
+}
+
+// GeometricCamera::project(const Eigen::Vector3d&) / projectJac(const Eigen::Vector3d&): what the ORB_SLAM3:: edges call
+// (I/OptimizableTypes.h:43,72,103,131; S/OptimizableTypes.cpp:46-62,90-108,139-160,192-214).  mvParameters are float32 and are
+// promoted where they meet a double.
+//   Pinhole          S/CameraModels/Pinhole.cpp:41-47, 81-91
+//   KannalaBrandt8   S/CameraModels/KannalaBrandt8.cpp:52-69 (theta and psi through atan2f / sqrtf: float32 values), 166-196
+struct CamModel { int model; float p[8]; };
+
+void cam_project(const CamModel& c, const double v[3], double uv[2]) {
+  if (c.model == ORBG_CAM_KANNALA_BRANDT8) {
+    const double x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
+    const double theta = atan2f(sqrtf(x2_plus_y2), v[2]);
+    const double psi = atan2f(v[1], v[0]);
+    const double theta2 = theta * theta;
+    const double theta3 = theta * theta2;
+    const double theta5 = theta3 * theta2;
+    const double theta7 = theta5 * theta2;
+    const double theta9 = theta7 * theta2;
+    const double r = theta + c.p[4] * theta3 + c.p[5] * theta5 + c.p[6] * theta7 + c.p[7] * theta9;
+    uv[0] = c.p[0] * r * std::cos(psi) + c.p[2];
+    uv[1] = c.p[1] * r * std::sin(psi) + c.p[3];
+  } else {
+    uv[0] = c.p[0] * v[0] / v[2] + c.p[2];
+    uv[1] = c.p[1] * v[1] / v[2] + c.p[3];
+  }
+}
+
+// J = d project / d v, 2 x 3 row-major
+void cam_project_jac(const CamModel& c, const double v[3], double J[6]) {
+  if (c.model == ORBG_CAM_KANNALA_BRANDT8) {
+    const double x2 = v[0] * v[0], y2 = v[1] * v[1], z2 = v[2] * v[2];
+    const double r2 = x2 + y2;
+    const double r = std::sqrt(r2);
+    const double r3 = r2 * r;
+    const double theta = std::atan2(r, v[2]);
+    const double theta2 = theta * theta, theta3 = theta2 * theta;
+    const double theta4 = theta2 * theta2, theta5 = theta4 * theta;
+    const double theta6 = theta2 * theta4, theta7 = theta6 * theta;
+    const double theta8 = theta4 * theta4, theta9 = theta8 * theta;
+    const double f = theta + theta3 * c.p[4] + theta5 * c.p[5] + theta7 * c.p[6] + theta9 * c.p[7];
+    const double fd = 1 + 3 * c.p[4] * theta2 + 5 * c.p[5] * theta4 + 7 * c.p[6] * theta6 + 9 * c.p[7] * theta8;
+    J[0] = c.p[0] * (fd * v[2] * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+    J[3] = c.p[1] * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
+    J[1] = c.p[0] * (fd * v[2] * v[1] * v[0] / (r2 * (r2 + z2)) - f * v[1] * v[0] / r3);
+    J[4] = c.p[1] * (fd * v[2] * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+    J[2] = -c.p[0] * fd * v[0] / (r2 + z2);
+    J[5] = -c.p[1] * fd * v[1] / (r2 + z2);
+  } else {
+    J[0] = c.p[0] / v[2]; J[1] = 0.f; J[2] = -c.p[0] * v[0] / (v[2] * v[2]);
+    J[3] = 0.f; J[4] = c.p[1] / v[2]; J[5] = -c.p[1] * v[1] / (v[2] * v[2]);
+  }
+}
+
+// mpCamera / mpCamera2 / mTrl of the keyframes (orbg_camera_rig).  on == false: the pinhole-only problem every BASELINE
+// configuration is; its monocular edge is written out below with the five scalars (the same expressions as Pinhole::project /
+// projectJac give).
+struct Rig {
+  bool on = false, has_right = false;
+  CamModel left{}, right{};
+  PoseQ Trl{};          // Converter::toSE3Quat(mTrl), S/Converter.cc:34-44
+};
+
+CamModel cam_model_of(const orbg_camera& c) {
+  CamModel m;
+  m.model = c.model;
+  m.p[0] = c.fx; m.p[1] = c.fy; m.p[2] = c.cx; m.p[3] = c.cy;
+  for (int i = 0; i < 4; i++) m.p[4 + i] = c.k[i];
+  return m;
+}
+
+Rig rig_of(const orbg_camera_rig* r) {
+  Rig g;
+  if (!r) return g;
+  g.on = true;
+  g.left = cam_model_of(r->left);
+  g.has_right = r->has_right != 0;
+  if (g.has_right) {
+    g.right = cam_model_of(r->right);
+    g.Trl = pose_from_3x4(r->Trl, 4);
+  }
+  return g;
+}
+
+// SE3Quat::operator* -- G/types/se3quat.h:104-110
+PoseQ se3_mul(const PoseQ& a, const PoseQ& b) {
+  PoseQ r;
+  double rt[3];
+  quat_rotate(a.q, b.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
+  r.q = quat_mul(a.q, b.q);
+  normalize_rotation(r.q);
+  return r;
+}
+
+inline bool edge_is_right(float ur) { return ur <= -1.5f; }      // LBA_UR_RIGHT_CAMERA
+
 // computeError: stereo G/types/types_six_dof_expmap.h:156-161 + cam_project cpp:190-197 (invz is float32);
 // mono I/OptimizableTypes.h:99-104 + Pinhole::project S/CameraModels/Pinhole.cpp:41-47.
 inline int edge_dim(const lba_edge& e) { return e.ur < 0 ? 2 : 3; }
 
-void edge_error(const PoseQ& T, const double X[3], const Cam& c, const lba_edge& e, double err[3], double Xc[3]) {
+// Xc: the point in the frame of the camera that made the observation (what isDepthPositive() looks at).
+void edge_error(const PoseQ& T, const double X[3], const Cam& c, const Rig& rig, const lba_edge& e, double err[3], double Xc[3]) {
   double r[3];
+  if (rig.has_right && edge_is_right(e.ur)) {
+    // EdgeSE3ProjectXYZToBody::computeError, I/OptimizableTypes.h:127-132: obs - pCamera->project((mTrl * T).map(X))
+    const PoseQ Trw = se3_mul(rig.Trl, T);
+    quat_rotate(Trw.q, X, r);
+    for (int i = 0; i < 3; i++) Xc[i] = r[i] + Trw.t[i];
+    double uv[2];
+    cam_project(rig.right, Xc, uv);
+    err[0] = (double)e.u - uv[0]; err[1] = (double)e.v - uv[1]; err[2] = 0;
+    return;
+  }
   quat_rotate(T.q, X, r);
   for (int i = 0; i < 3; i++) Xc[i] = r[i] + T.t[i];
+  if (e.ur < 0 && rig.on) {                                   // EdgeSE3ProjectXYZ::computeError through mpCamera, I/OptimizableTypes.h:99-104
+    double uv[2];
+    cam_project(rig.left, Xc, uv);
+    err[0] = (double)e.u - uv[0]; err[1] = (double)e.v - uv[1]; err[2] = 0;
+    return;
+  }
   if (e.ur < 0) {
     err[0] = (double)e.u - (c.fx * Xc[0] / Xc[2] + c.cx);
     err[1] = (double)e.v - (c.fy * Xc[1] / Xc[2] + c.cy);
@@ -163,10 +288,42 @@ void edge_error(const PoseQ& T, const double X[3], const Cam& c, const lba_edge&
 
 // linearizeOplus: stereo cpp:228-274, mono S/OptimizableTypes.cpp:139-160 (+ projectJac Pinhole.cpp:81-91).
 // A = d err / d point (D x 3), B = d err / d pose (D x 6, [omega, upsilon]).
-void edge_jacobians(const PoseQ& T, const double Xc[3], const Cam& c, const lba_edge& e, double A[9], double B[18]) {
+// Xc = T.map(X), the point in the LEFT camera's (body) frame, for every kind of edge.
+void edge_jacobians(const PoseQ& T, const double Xc[3], const Cam& c, const Rig& rig, const lba_edge& e, double A[9], double B[18]) {
   double R[9];
-  quat_to_R(T.q, R);
   const double x = Xc[0], y = Xc[1], z = Xc[2];
+  if (rig.on && e.ur < 0) {
+    const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    double J[6], M[6];
+    if (rig.has_right && edge_is_right(e.ur)) {
+      // EdgeSE3ProjectXYZToBody::linearizeOplus, S/OptimizableTypes.cpp:192-214: X_r = mTrl.map(T_lw.map(X_w));
+      // Xi = -projectJac(X_r) * (mTrl * T_lw).rotation();  Xj = -projectJac(X_r) * mTrl.rotation() * SE3deriv(X_l)
+      double rr[3], Xr[3];
+      quat_rotate(rig.Trl.q, Xc, rr);
+      for (int i = 0; i < 3; i++) Xr[i] = rr[i] + rig.Trl.t[i];
+      cam_project_jac(rig.right, Xr, J);
+      for (int i = 0; i < 6; i++) J[i] = -J[i];
+      const PoseQ Trw = se3_mul(rig.Trl, T);
+      quat_to_R(Trw.q, R);
+      double Rrl[9];
+      quat_to_R(rig.Trl.q, Rrl);
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 3; j++) M[3 * i + j] = J[3 * i] * Rrl[j] + J[3 * i + 1] * Rrl[3 + j] + J[3 * i + 2] * Rrl[6 + j];
+    } else {
+      // EdgeSE3ProjectXYZ::linearizeOplus, S/OptimizableTypes.cpp:139-160, through mpCamera->projectJac
+      cam_project_jac(rig.left, Xc, J);
+      for (int i = 0; i < 6; i++) { J[i] = -J[i]; M[i] = J[i]; }
+      quat_to_R(T.q, R);
+    }
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 3; j++) A[3 * i + j] = J[3 * i] * R[j] + J[3 * i + 1] * R[3 + j] + J[3 * i + 2] * R[6 + j];
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 6; j++) B[6 * i + j] = M[3 * i] * S[j] + M[3 * i + 1] * S[6 + j] + M[3 * i + 2] * S[12 + j];
+    for (int j = 0; j < 3; j++) A[6 + j] = 0;
+    for (int j = 0; j < 6; j++) B[12 + j] = 0;
+    return;
+  }
+  quat_to_R(T.q, R);
   if (e.ur < 0) {
     // projectJac = -[fx/z 0 -fx x/z^2; 0 fy/z -fy y/z^2]
     const double J[6] = {-(c.fx / z), -0.0, -(-c.fx * x / (z * z)), -0.0, -(c.fy / z), -(-c.fy * y / (z * z))};
@@ -258,6 +415,7 @@ bool ldlt_solve(std::vector<double>& S, int n, const double* b, double* x) {
 struct Lba {
   const lba_problem* p;
   Cam cam;
+  Rig rig;
   std::vector<PoseQ> poses;
   std::vector<double> points;          // 3 per point
   std::vector<int> pose_col, point_col;  // hessian index or -1
@@ -267,6 +425,10 @@ struct Lba {
   std::vector<double> chi2;            // per edge
   // system
   std::vector<double> Hpp, Hll, Hpl, bp, bl;   // Hpp: nP x 36, Hll: nL x 9, Hpl: per edge 18 (6x3), b
+  // g2o keeps ONE Hpl block per (pose, landmark) vertex pair (BlockSolver::buildStructure: _Hpl->block(ind1, ind2, true),
+  // G/core/block_solver.hpp:218-240) and every edge between the two adds into it.  With a camera rig a keyframe observes a landmark
+  // up to twice (left and right camera): hpl_slot[k] is the first edge of k's vertex pair, whose 18 values hold that block.
+  std::vector<int> hpl_slot;
   std::vector<double> x;               // 6nP + 3nL
   double delta_mono, delta_stereo, dsqr_mono, dsqr_stereo;
   const volatile int32_t* stop;
@@ -283,7 +445,7 @@ struct Lba {
     for (int k = 0; k < p->n_edges; k++) {
       const lba_edge& e = p->edges[k];
       double Xc[3];
-      edge_error(poses[e.pose], &points[3 * e.point], cam, e, &err[3 * k], Xc);
+      edge_error(poses[e.pose], &points[3 * e.point], cam, rig, e, &err[3 * k], Xc);
       const double om = (double)e.inv_sigma2;
       const int D = edge_dim(e);
       double c = 0;
@@ -312,7 +474,7 @@ struct Lba {
       quat_rotate(poses[e.pose].q, &points[3 * e.point], r);
       for (int i = 0; i < 3; i++) Xc[i] = r[i] + poses[e.pose].t[i];
       double A[9], B[18];
-      edge_jacobians(poses[e.pose], Xc, cam, e, A, B);
+      edge_jacobians(poses[e.pose], Xc, cam, rig, e, A, B);
       const int D = edge_dim(e);
       const bool mono = D == 2;
       double rho[2];
@@ -349,7 +511,7 @@ struct Lba {
             for (int c = 0; c < 3; c++) {
               double h = 0;
               for (int i = 0; i < D; i++) h += B[6 * i + a] * wom * A[3 * i + c];
-              Hpl[18 * k + 3 * a + c] += h;
+              Hpl[18 * (size_t)hpl_slot[k] + 3 * a + c] += h;
             }
       }
     }
@@ -430,8 +592,31 @@ extern "C" void oracle_lba_edge_eval(const double* q4, const double* t3, const d
   T.t[0] = t3[0]; T.t[1] = t3[1]; T.t[2] = t3[2];
   Cam c{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4], cam5[4]};
   double Xc[3];
-  edge_error(T, X3, c, *e, err3, Xc);
-  edge_jacobians(T, Xc, c, *e, Jpoint9, Jpose18);
+  const Rig none;
+  edge_error(T, X3, c, none, *e, err3, Xc);
+  edge_jacobians(T, Xc, c, none, *e, Jpoint9, Jpose18);
+}
+
+// the same with the cameras of a rig (monocular / right-camera edges through GeometricCamera::project / projectJac)
+extern "C" void oracle_lba_edge_eval_rig(const double* q4, const double* t3, const double* X3, const float* cam5, const orbg_camera_rig* rig,
+                                         const lba_edge* e, double* err3, double* Jpoint9, double* Jpose18, double* Xcam3) {
+  PoseQ T;
+  T.q = {q4[0], q4[1], q4[2], q4[3]};
+  T.t[0] = t3[0]; T.t[1] = t3[1]; T.t[2] = t3[2];
+  Cam c{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4], cam5[4]};
+  const Rig g = rig_of(rig);
+  double Xobs[3], r[3], Xc[3];
+  edge_error(T, X3, c, g, *e, err3, Xobs);
+  quat_rotate(T.q, X3, r);
+  for (int i = 0; i < 3; i++) Xc[i] = r[i] + T.t[i];
+  edge_jacobians(T, Xc, c, g, *e, Jpoint9, Jpose18);
+  if (Xcam3) for (int i = 0; i < 3; i++) Xcam3[i] = Xobs[i];
+}
+
+extern "C" void oracle_camera_project(const orbg_camera* cam, const double* X3, double* uv2, double* J6) {
+  const CamModel m = cam_model_of(*cam);
+  if (uv2) cam_project(m, X3, uv2);
+  if (J6) cam_project_jac(m, X3, J6);
 }
 
 extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r) {
@@ -440,6 +625,12 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
   s.p = p;
   s.stop = stop_flag;
   s.cam = Cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
+  s.rig = rig_of(p->rig);
+  if (s.rig.on) {
+    if ((s.rig.left.model != ORBG_CAM_PINHOLE && s.rig.left.model != ORBG_CAM_KANNALA_BRANDT8) ||
+        (s.rig.has_right && s.rig.right.model != ORBG_CAM_PINHOLE && s.rig.right.model != ORBG_CAM_KANNALA_BRANDT8))
+      return ORBG_BAD_ARG;
+  }
   const float thHuberMono = (float)std::sqrt(5.991), thHuberStereo = (float)std::sqrt(7.815);   // S/Optimizer.cc:1991-1992
   s.delta_mono = thHuberMono; s.dsqr_mono = s.delta_mono * s.delta_mono;
   s.delta_stereo = thHuberStereo; s.dsqr_stereo = s.delta_stereo * s.delta_stereo;
@@ -465,10 +656,16 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
     if (!p->pose_fixed[i] && pose_deg[i] > 0) { s.pose_col[i] = s.nP++; s.active_pose.push_back(i); }
   for (int i = 0; i < p->n_points; i++)
     if (point_deg[i] > 0) { s.point_col[i] = s.nL++; s.active_point.push_back(i); }
-  std::vector<std::vector<int>> edges_of_point(s.nL);
+  s.hpl_slot.resize((size_t)p->n_edges);
+  {
+    std::map<std::pair<int, int>, int> first_edge;
+    for (int k = 0; k < p->n_edges; k++)
+      s.hpl_slot[k] = first_edge.emplace(std::make_pair(p->edges[k].pose, p->edges[k].point), k).first->second;
+  }
+  std::vector<std::vector<int>> edges_of_point(s.nL);      // per landmark: its Hpl blocks (one per observing free pose)
   for (int k = 0; k < p->n_edges; k++) {
     const int lc = s.point_col[p->edges[k].point];
-    if (lc >= 0 && s.pose_col[p->edges[k].pose] >= 0) edges_of_point[lc].push_back(k);
+    if (lc >= 0 && s.pose_col[p->edges[k].pose] >= 0 && s.hpl_slot[k] == k) edges_of_point[lc].push_back(k);
   }
   for (auto& v : edges_of_point)
     std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return s.pose_col[p->edges[a].pose] < s.pose_col[p->edges[b].pose]; });
@@ -572,8 +769,14 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
   for (int k = 0; k < p->n_edges; k++) {
     const lba_edge& e = p->edges[k];
     double r3[3], Xc[3];
-    quat_rotate(s.poses[e.pose].q, &s.points[3 * e.point], r3);
-    for (int i = 0; i < 3; i++) Xc[i] = r3[i] + s.poses[e.pose].t[i];
+    if (s.rig.has_right && edge_is_right(e.ur)) {              // ((mTrl * T).map(X))(2) > 0, I/OptimizableTypes.h:134-138
+      const PoseQ Trw = se3_mul(s.rig.Trl, s.poses[e.pose]);
+      quat_rotate(Trw.q, &s.points[3 * e.point], r3);
+      for (int i = 0; i < 3; i++) Xc[i] = r3[i] + Trw.t[i];
+    } else {
+      quat_rotate(s.poses[e.pose].q, &s.points[3 * e.point], r3);
+      for (int i = 0; i < 3; i++) Xc[i] = r3[i] + s.poses[e.pose].t[i];
+    }
     const bool depth_pos = Xc[2] > 0.0;
     const double thr = e.ur < 0 ? 5.991 : 7.815;
     const bool outlier = s.chi2[k] > thr || !depth_pos;
@@ -590,21 +793,37 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
 
 
 // ------------------------------------------------------------------------------------------------
-// Optimizer::PoseOptimization(Frame*) -- S/Optimizer.cc:964-1278 (mpCamera2 == NULL branch): one SE3 vertex,
-// unary edges EdgeSE3ProjectXYZOnlyPose (I/OptimizableTypes.h:31-57, S/OptimizableTypes.cpp:49-63) and
-// g2o::EdgeStereoSE3ProjectXYZOnlyPose (G/types/types_six_dof_expmap.{h:208-236,cpp:339-346,375-404}),
+// Optimizer::PoseOptimization(Frame*) -- S/Optimizer.cc:964-1278: one SE3 vertex, unary edges
+// EdgeSE3ProjectXYZOnlyPose (I/OptimizableTypes.h:31-57, S/OptimizableTypes.cpp:49-63),
+// g2o::EdgeStereoSE3ProjectXYZOnlyPose (G/types/types_six_dof_expmap.{h:208-236,cpp:339-346,375-404}) and -- with the
+// two-camera rig, :1085-1151 -- EdgeSE3ProjectXYZOnlyPoseToBody (I/OptimizableTypes.h:59-87, S/OptimizableTypes.cpp:90-108),
 // BlockSolver_6_3 over LinearSolverDense (Eigen::LDLT, must be positive: G/solvers/linear_solver_dense.h:105-110),
 // Levenberg-Marquardt as in oracle_lba_solve.
 namespace {
 
-struct PoEdge { double X[3]; double u, v, ur; double om; bool mono; };
+struct PoEdge { double X[3]; double u, v, ur; double om; bool mono; bool right; };
 
 // error of a pose-only edge; stereo: invz is float32, bf*invz is a DOUBLE product here (bf is a double member,
 // unlike the binary stereo edge whose cam_project takes `const float &bf`)
-void po_error(const PoseQ& T, const PoEdge& e, const Cam& c, double err[3], double Xc[3]) {
+void po_error(const PoseQ& T, const PoEdge& e, const Cam& c, const Rig& rig, double err[3], double Xc[3]) {
   double r[3];
+  if (e.right) {      // EdgeSE3ProjectXYZOnlyPoseToBody::computeError, I/OptimizableTypes.h:69-73
+    const PoseQ Trw = se3_mul(rig.Trl, T);
+    quat_rotate(Trw.q, e.X, r);
+    for (int i = 0; i < 3; i++) Xc[i] = r[i] + Trw.t[i];
+    double uv[2];
+    cam_project(rig.right, Xc, uv);
+    err[0] = e.u - uv[0]; err[1] = e.v - uv[1]; err[2] = 0;
+    return;
+  }
   quat_rotate(T.q, e.X, r);
   for (int i = 0; i < 3; i++) Xc[i] = r[i] + T.t[i];
+  if (e.mono && rig.on) {     // EdgeSE3ProjectXYZOnlyPose::computeError through mpCamera, I/OptimizableTypes.h:40-44
+    double uv[2];
+    cam_project(rig.left, Xc, uv);
+    err[0] = e.u - uv[0]; err[1] = e.v - uv[1]; err[2] = 0;
+    return;
+  }
   if (e.mono) {
     err[0] = e.u - (c.fx * Xc[0] / Xc[2] + c.cx);
     err[1] = e.v - (c.fy * Xc[1] / Xc[2] + c.cy);
@@ -617,8 +836,31 @@ void po_error(const PoseQ& T, const PoEdge& e, const Cam& c, double err[3], doub
   }
 }
 
-void po_jacobian(const double Xc[3], const PoEdge& e, const Cam& c, double J[18]) {
+// Xc = T.map(Xw): the point in the left camera's frame for every kind of edge
+void po_jacobian(const double Xc[3], const PoEdge& e, const Cam& c, const Rig& rig, double J[18]) {
   const double x = Xc[0], y = Xc[1], z = Xc[2];
+  if (rig.on && e.mono) {
+    // S/OptimizableTypes.cpp:46-62 (-projectJac(xyz_trans) * SE3deriv) and :90-108 (-projectJac(X_r) * mTrl.rotation() * SE3deriv(X_l))
+    const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+    double P[6], M[6];
+    if (e.right) {
+      double rr[3], Xr[3], Rrl[9];
+      quat_rotate(rig.Trl.q, Xc, rr);
+      for (int i = 0; i < 3; i++) Xr[i] = rr[i] + rig.Trl.t[i];
+      cam_project_jac(rig.right, Xr, P);
+      for (int i = 0; i < 6; i++) P[i] = -P[i];
+      quat_to_R(rig.Trl.q, Rrl);
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 3; j++) M[3 * i + j] = P[3 * i] * Rrl[j] + P[3 * i + 1] * Rrl[3 + j] + P[3 * i + 2] * Rrl[6 + j];
+    } else {
+      cam_project_jac(rig.left, Xc, P);
+      for (int i = 0; i < 6; i++) M[i] = -P[i];
+    }
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 6; j++) J[6 * i + j] = M[3 * i] * S[j] + M[3 * i + 1] * S[6 + j] + M[3 * i + 2] * S[12 + j];
+    for (int j = 0; j < 6; j++) J[12 + j] = 0;
+    return;
+  }
   if (e.mono) {
     const double P[6] = {-(c.fx / z), -0.0, -(-c.fx * x / (z * z)), -0.0, -(c.fy / z), -(-c.fy * y / (z * z))};
     const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
@@ -665,11 +907,16 @@ extern "C" int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* 
   for (int i = 0; i < n; i++) r->outlier[i] = 0;                              // mvbOutlier[i] = false   (:1015,1046)
   if (n < 3) return ORBG_OK;                                                   // :1180-1181
   Cam cam{p->fx, p->fy, p->cx, p->cy, p->bf, p->bf};
+  const Rig rig = rig_of(p->rig);
+  if (rig.on && ((rig.left.model != ORBG_CAM_PINHOLE && rig.left.model != ORBG_CAM_KANNALA_BRANDT8) ||
+                 (rig.has_right && rig.right.model != ORBG_CAM_PINHOLE && rig.right.model != ORBG_CAM_KANNALA_BRANDT8)))
+    return ORBG_BAD_ARG;
   const double deltaMono = (float)std::sqrt(5.991), deltaStereo = (float)std::sqrt(7.815);   // :1001-1002
   std::vector<PoEdge> E(n);
   for (int i = 0; i < n; i++) {
     E[i].X[0] = p->Xw[3 * i]; E[i].X[1] = p->Xw[3 * i + 1]; E[i].X[2] = p->Xw[3 * i + 2];
     E[i].u = p->u[i]; E[i].v = p->v[i]; E[i].ur = p->ur[i]; E[i].om = p->inv_sigma2[i]; E[i].mono = p->ur[i] < 0;
+    E[i].right = rig.has_right && edge_is_right(p->ur[i]);      // (without a second camera any negative ur is a monocular entry, as ever)
   }
   PoseQ T0;
   {
@@ -689,7 +936,7 @@ extern "C" int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* 
     for (int i = 0; i < n; i++) {
       if (level[i]) continue;
       double Xc[3];
-      po_error(Tc, E[i], cam, &err[3 * i], Xc);
+      po_error(Tc, E[i], cam, rig, &err[3 * i], Xc);
       double c = 0;
       const int D = E[i].mono ? 2 : 3;
       for (int k = 0; k < D; k++) c += err[3 * i + k] * (E[i].om * err[3 * i + k]);
@@ -725,7 +972,7 @@ extern "C" int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* 
         quat_rotate(T.q, E[i].X, r3);
         for (int k = 0; k < 3; k++) Xc[k] = r3[k] + T.t[k];
         double J[18];
-        po_jacobian(Xc, E[i], cam, J);
+        po_jacobian(Xc, E[i], cam, rig, J);
         const int D = E[i].mono ? 2 : 3;
         double w = 1.0;
         if (robust) { double rho[2]; const double d = E[i].mono ? deltaMono : deltaStereo; huber(chi2[i], d, d * d, rho); w = rho[1]; }
@@ -786,7 +1033,7 @@ extern "C" int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* 
     for (int i = 0; i < n; i++) {
       if (r->outlier[i]) {
         double Xc[3];
-        po_error(T, E[i], cam, &err[3 * i], Xc);
+        po_error(T, E[i], cam, rig, &err[3 * i], Xc);
         double c = 0;
         const int D = E[i].mono ? 2 : 3;
         for (int k = 0; k < D; k++) c += err[3 * i + k] * (E[i].om * err[3 * i + k]);

@@ -126,6 +126,11 @@ int oracle_wire_unpack(const uint8_t* wire, int n, orbx_keypoint* kps, uint8_t* 
 int oracle_lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
 int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* r);
 /* pieces for the known-answer tests */
+/* GeometricCamera::project / projectJac (Eigen forms) of a pinhole / KannalaBrandt8 camera: uv2 and the 2 x 3 row-major Jacobian */
+void oracle_camera_project(const orbg_camera* cam, const double* X3, double* uv2, double* J6);
+/* one edge of a problem with a camera rig (see oracle_lba_edge_eval); Xcam3 (may be NULL): the point in the observing camera's frame */
+void oracle_lba_edge_eval_rig(const double* q4_xyzw, const double* t3, const double* X3, const float* cam5, const orbg_camera_rig* rig,
+                              const lba_edge* e, double* err3, double* Jpoint9, double* Jpose18, double* Xcam3);
 void oracle_se3_exp(const double* upd6 /*omega,upsilon*/, double* q4_xyzw, double* t3);
 void oracle_lba_edge_eval(const double* q4_xyzw, const double* t3, const double* X3, const float* cam5 /*fx fy cx cy bf*/,
                           const lba_edge* e, double* err3, double* Jpoint9, double* Jpose18);

@@ -1406,6 +1406,81 @@ def test_c4_sizes_matchers_2000_features_8k_map_points():
     assert o4[1] > 100 and g4[1] == o4[1] and np.array_equal(g4[0], o4[0])
 
 
+@pytest.mark.parametrize("shape", [(8, 4, 600, "kb8"), (20, 10, 2000, "kb8"), (30, 6, 1500, "kb8"), (6, 3, 300, "pinhole_left"),
+                                   (10, 4, 500, "left_only")])
+def test_lba_with_the_two_fisheye_rig(shape):
+    """LocalBundleAdjustment of keyframes with mpCamera2 (S/Optimizer.cc:2021-2120): monocular edges through KannalaBrandt8::project /
+    projectJac, the right camera's observations as EdgeSE3ProjectXYZToBody after mTrl -- vs. the oracle.  theta and psi of
+    KannalaBrandt8::project are float32 values of atan2f / sqrtf (S/CameraModels/KannalaBrandt8.cpp:52-56): the device rounds the
+    double atan2 to float, the oracle calls this host's atan2f -- a last-bit difference there moves a residual by ~1e-5 px, hence the
+    looser tolerance on chi2 than for the pinhole problems."""
+    nf, nx, npts, kind = shape
+    kw = {}
+    if kind == "pinhole_left":
+        kw = dict(left=(capi.CAM_PINHOLE, 190.978, 190.973, 254.932, 256.897))
+    if kind == "left_only":
+        kw = dict(right_frac=0.0)
+    prob = synth.make_lba_rig_problem(n_free=nf, n_fixed=nx, n_points=npts, seed=0xF15E + nf, **kw)
+    left, right, Trl = prob["rig"]
+    rig = views.camera_rig(left, None, None) if kind == "left_only" else views.camera_rig(left, right, Trl)
+    p, keep = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"], rig=rig)
+    n_right = int((prob["edges"]["ur"] <= -1.5).sum())
+    assert (n_right == 0) == (kind == "left_only") and len(prob["edges"]) > 4 * npts // 2
+    g = api.Optimizer().LocalBundleAdjustment(p)
+    o = ob.lba_solve(p)
+    assert g.status == o.status == capi.LBA_APPLIED
+    assert g.iters == o.iters
+    # (left camera only = a monocular window: a landmark seen three times over 20 cm of baseline has a depth that the last bits of the
+    # residuals move by millimetres; the poses, which all landmarks constrain, do not move)
+    assert np.abs(g.poses - o.poses).max() <= 1e-4 and np.abs(g.points - o.points).max() <= (5e-3 if kind == "left_only" else 1e-4)
+    assert (g.edge_outlier != o.edge_outlier).sum() <= 1 and np.array_equal(g.edge_depth_pos, o.edge_depth_pos)
+    tg, to = g.trace_rows(), o.trace_rows()
+    assert tg.shape == to.shape and np.array_equal(tg[:, 2], to[:, 2])
+    assert np.allclose(tg[:, 1], to[:, 1], rtol=1e-6)
+    assert g.chi2[1] < 0.8 * g.chi2[0]
+    g2 = api.Optimizer().LocalBundleAdjustment(p)
+    assert np.array_equal(g.poses, g2.poses) and np.array_equal(g.points, g2.points)
+
+
+def test_lba_rig_with_a_pinhole_left_camera_and_no_right_one_is_the_pinhole_problem():
+    """A rig that only restates mpCamera = Pinhole{fx, fy, cx, cy} must give the result of the five scalars (the monocular edge
+    through Pinhole::project / projectJac is the edge the scalar path writes out)."""
+    prob = synth.make_lba_problem(n_free=8, n_fixed=4, n_points=500, mono_frac=0.5, seed=77)
+    fx, fy, cx, cy, bf = prob["cam"]
+    p0, k0 = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"])
+    p1, k1 = views.lba_problem(prob["poses"], prob["pose_fixed"], prob["points"], prob["edges"], prob["cam"],
+                               rig=views.camera_rig((capi.CAM_PINHOLE, fx, fy, cx, cy)))
+    g0 = api.Optimizer().LocalBundleAdjustment(p0)
+    g1 = api.Optimizer().LocalBundleAdjustment(p1)
+    assert g0.iters == g1.iters and np.array_equal(g0.edge_outlier, g1.edge_outlier)
+    assert np.abs(g0.poses - g1.poses).max() <= 1e-6 and np.abs(g0.points - g1.points).max() <= 1e-6
+    o1 = ob.lba_solve(p1)
+    assert o1.iters == g1.iters and np.abs(o1.poses - g1.poses).max() <= 1e-4
+
+
+@pytest.mark.parametrize("nl,nr,of", [(300, 200, 0.1), (600, 400, 0.3), (40, 0, 0.0), (0, 60, 0.0), (1500, 1200, 0.2), (2200, 1800, 0.05),
+                                      (5, 4, 0.0)])
+def test_pose_optimization_with_the_two_fisheye_rig(nl, nr, of):
+    """PoseOptimization of a Frame with Nleft != -1 (S/Optimizer.cc:1085-1151): features of the left camera through
+    EdgeSE3ProjectXYZOnlyPose with KannalaBrandt8, those of the right camera through EdgeSE3ProjectXYZOnlyPoseToBody."""
+    pr = synth.make_pose_opt_rig_problem(n_left=nl, n_right=nr, outlier_frac=of, seed=0xF15F + nl)
+    rig = views.camera_rig(*pr["rig"])
+    p, keep = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"], rig=rig)
+    g = api.Optimizer().PoseOptimization(p)
+    o = ob.pose_optimize(p)
+    # a correspondence whose chi2 sits within the float32-atan2 difference of the 5.991 threshold may fall on either side
+    assert abs(g.n_inliers - o.n_inliers) <= 1 and (g.outliers != o.outliers).sum() <= 1
+    assert np.abs(g.Tcw.astype(np.float64) - o.Tcw.astype(np.float64)).max() <= 1e-5
+    # near the optimum "did chi2 improve" is decided 1e-9 relative to chi2 -- below the 1e-8 the float32 atan2 leaves between the two
+    # sides -- so a round may stop an iteration or two apart (measured both ways round), a hair further along the same valley
+    assert all(abs(a - b) <= 2 for a, b in zip(g.iters, o.iters)), (g.iters, o.iters)
+    assert np.allclose(g.chi2, o.chi2, rtol=5e-3, atol=1e-6)
+    if nl + nr >= 100:
+        assert np.abs(g.Tcw - pr["T_true"]).max() < np.abs(pr["Tcw"] - pr["T_true"]).max()
+    g2 = api.Optimizer().PoseOptimization(p)
+    assert np.array_equal(g.Tcw, g2.Tcw) and g.iters == g2.iters
+
+
 @pytest.mark.parametrize("n,of,mono", [(500, 0.1, 0.2), (900, 0.3, 0.0), (40, 0.0, 1.0), (8, 0.0, 0.0), (2, 0.0, 0.0), (1, 0.0, 0.0),
                                        (2000, 0.2, 0.1), (3500, 0.05, 0.5), (257, 0.6, 0.3), (513, 0.0, 1.0)])
 def test_pose_optimization_parity(n, of, mono):

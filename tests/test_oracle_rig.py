@@ -1,0 +1,177 @@
+"""Known-answer tests for the oracle's camera models and the edges of a two-camera rig (CPU only).
+
+The reference ships no vectors for these (parity unpinned); what can be pinned from first principles is pinned here:
+KannalaBrandt8::project against the closed form in float64, projectJac and the edge Jacobians against central differences of
+the oracle's own error functions, the *ToBody edge against the monocular edge of a camera placed at mTrl * T, one Hpl block per
+(keyframe, landmark) vertex pair (g2o's BlockSolver) against the same window with the second observation moved to a twin landmark."""
+import numpy as np
+import pytest
+
+from multi_orbslam3_amd import _capi as capi
+from multi_orbslam3_amd import synth, views
+from oracle import binding as ob
+
+
+def _quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _quat_rot(q, v):
+    u = np.array(q[:3])
+    uv = 2 * np.cross(u, v)
+    return v + q[3] * uv + np.cross(u, uv)
+
+
+def _quat_from_R(R):
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+
+
+def _oplus(q, t, upd):
+    """VertexSE3Expmap::oplusImpl: exp(upd) * T."""
+    eq, et = ob.se3_exp(upd)
+    return _quat_mul(eq, q), et + _quat_rot(eq, t)
+
+
+@pytest.mark.parametrize("cam", [synth.KB8_LEFT, synth.KB8_RIGHT, (capi.CAM_PINHOLE, 458.6, 457.3, 367.2, 248.4)])
+def test_camera_project_and_its_jacobian(cam):
+    rng = np.random.RandomState(5)
+    cam = (cam[0],) + tuple(float(np.float32(c)) for c in cam[1:])          # mvParameters are float32
+    for _ in range(200):
+        X = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(0.3, 8.0)])
+        uv, J = ob.camera_project(cam, X)
+        ref = synth.kb8_project(cam, X)
+        # theta and psi are float32 values in the reference's KannalaBrandt8::project (atan2f): ~1e-7 rad x f = ~3e-5 px
+        assert np.abs(uv - ref).max() < (2e-4 if cam[0] == capi.CAM_KANNALA_BRANDT8 else 1e-9)
+        Jn = np.zeros((2, 3))
+        for i in range(3):
+            d = np.zeros(3); d[i] = 1e-4
+            Jn[:, i] = (synth.kb8_project(cam, X + d) - synth.kb8_project(cam, X - d)) / 2e-4
+        assert np.abs(J - Jn).max() < 1e-4 * max(1.0, np.abs(J).max())
+
+
+def test_pinhole_model_of_a_rig_is_the_scalar_monocular_edge():
+    """EdgeSE3ProjectXYZ through Pinhole::project / projectJac = the edge the five scalars give (same expressions)."""
+    rng = np.random.RandomState(6)
+    fx, fy, cx, cy = 458.6, 457.3, 367.2, 248.4
+    rig = views.camera_rig((capi.CAM_PINHOLE, fx, fy, cx, cy))
+    for _ in range(50):
+        q = rng.randn(4); q /= np.linalg.norm(q); q *= np.sign(q[3])
+        t = rng.randn(3) * 0.3
+        X = _quat_rot(q * np.array([-1, -1, -1, 1]), np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(1, 6)]) - t)
+        e = np.zeros(1, capi.EDGE_DTYPE); e[0] = (0, 0, 300.0, 200.0, -1.0, 0.7)
+        a = ob.lba_edge_eval(q, t, X, (fx, fy, cx, cy, 40.0), e)
+        b = ob.lba_edge_eval_rig(q, t, X, (fx, fy, cx, cy, 40.0), rig, e)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("right", [False, True])
+def test_rig_edge_jacobians_against_central_differences(right):
+    """d err / d point and d err / d (omega, upsilon) of EdgeSE3ProjectXYZ (KannalaBrandt8) and EdgeSE3ProjectXYZToBody."""
+    rng = np.random.RandomState(7 + right)
+    Trl = synth.rig_Trl().astype(np.float32)
+    rig = views.camera_rig(synth.KB8_LEFT, synth.KB8_RIGHT, Trl)
+    cam5 = (190.0, 190.0, 255.0, 257.0, 0.0)
+    for _ in range(40):
+        q = np.array([0.02, -0.03, 0.01, 1.0]) + rng.randn(4) * 0.01; q /= np.linalg.norm(q)
+        t = rng.randn(3) * 0.2
+        Xc = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(1.0, 6.0)])
+        X = _quat_rot(q * np.array([-1, -1, -1, 1]), Xc - t)
+        e = np.zeros(1, capi.EDGE_DTYPE); e[0] = (0, 0, 250.0, 260.0, capi.UR_RIGHT_CAMERA if right else -1.0, 1.0)
+        err, A, B, Xobs = ob.lba_edge_eval_rig(q, t, X, cam5, rig, e)
+        if right:     # the observing camera's frame is mTrl * T
+            Xl = _quat_rot(q, X) + t
+            assert np.abs(Xobs - (Trl[:3, :3].astype(np.float64) @ Xl + Trl[:3, 3])).max() < 1e-6
+        h = 1e-3          # (the error goes through float32 atan2: ~3e-5 px of noise, 0.015 after the division by 2 h)
+        An = np.zeros((2, 3)); Bn = np.zeros((2, 6))
+        for i in range(3):
+            d = np.zeros(3); d[i] = h
+            An[:, i] = (ob.lba_edge_eval_rig(q, t, X + d, cam5, rig, e)[0][:2] - ob.lba_edge_eval_rig(q, t, X - d, cam5, rig, e)[0][:2]) / (2 * h)
+        for i in range(6):
+            d = np.zeros(6); d[i] = h
+            qp, tp = _oplus(q, t, d); qm, tm = _oplus(q, t, -d)
+            Bn[:, i] = (ob.lba_edge_eval_rig(qp, tp, X, cam5, rig, e)[0][:2] - ob.lba_edge_eval_rig(qm, tm, X, cam5, rig, e)[0][:2]) / (2 * h)
+        assert np.abs(A[:2] - An).max() < 0.1 and np.abs(A[:2]).max() > 10
+        assert np.abs(B[:2] - Bn).max() < 0.1 + 1e-3 * np.abs(B).max() and np.abs(B[:2]).max() > 10
+        assert np.all(A[2] == 0) and np.all(B[2] == 0) and err[2] == 0
+
+
+def test_right_camera_edge_is_the_monocular_edge_of_a_camera_at_Trl_T():
+    """EdgeSE3ProjectXYZToBody::computeError (I/OptimizableTypes.h:127-132) = EdgeSE3ProjectXYZ::computeError with pose mTrl * T and
+    camera mpCamera2."""
+    rng = np.random.RandomState(9)
+    Trl = synth.rig_Trl().astype(np.float32)
+    rig = views.camera_rig(synth.KB8_LEFT, synth.KB8_RIGHT, Trl)
+    rig_r = views.camera_rig(synth.KB8_RIGHT)
+    qrl = _quat_from_R(Trl[:3, :3].astype(np.float64)); qrl /= np.linalg.norm(qrl)
+    for _ in range(30):
+        q = np.array([0.05, 0.02, -0.04, 1.0]) + rng.randn(4) * 0.02; q /= np.linalg.norm(q)
+        t = rng.randn(3) * 0.2
+        X = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(2.0, 6.0)])
+        e = np.zeros(1, capi.EDGE_DTYPE); e[0] = (0, 0, 240.0, 250.0, capi.UR_RIGHT_CAMERA, 1.0)
+        e_m = e.copy(); e_m["ur"] = -1.0
+        q2 = _quat_mul(qrl, q); q2 /= np.linalg.norm(q2)
+        t2 = Trl[:3, 3].astype(np.float64) + _quat_rot(qrl, t)
+        a = ob.lba_edge_eval_rig(q, t, X, (1, 1, 0, 0, 0), rig, e)
+        b = ob.lba_edge_eval_rig(q2, t2, X, (1, 1, 0, 0, 0), rig_r, e_m)
+        assert np.abs(a[0] - b[0]).max() < 2e-4               # (float32 atan2 of arguments that differ in their last bits)
+        assert np.abs(a[1] - b[1]).max() < 1e-6 * max(1.0, np.abs(a[1]).max())      # d err / d point: the same matrix
+
+
+def test_lba_of_a_rig_window_converges_and_flags_the_planted_outliers():
+    pr = synth.make_lba_rig_problem(n_free=8, n_fixed=4, n_points=500, seed=11)
+    rig = views.camera_rig(*pr["rig"])
+    p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"], rig=rig)
+    o = ob.lba_solve(p)
+    assert o.status == capi.LBA_APPLIED and o.chi2[1] < 0.75 * o.chi2[0]
+    free = pr["pose_fixed"] == 0
+    Tt = pr["poses_true"][:, :3, 3]
+    e0 = np.abs(pr["poses"].reshape(-1, 4, 4)[free, :3, 3] - Tt[free]).mean()
+    e1 = np.abs(o.poses.reshape(-1, 4, 4)[free, :3, 3] - Tt[free]).mean()
+    assert e1 < 0.9 * e0          # (190 px of focal length: a pixel of noise is 0.3 degrees -- the floor is millimetres)
+    assert 0.01 * len(pr["edges"]) < o.n_outliers < 0.12 * len(pr["edges"])
+    assert (pr["edges"]["ur"] <= -1.5).sum() > 500 and (pr["edges"]["ur"] == -1.0).sum() > 500
+
+
+def test_two_observations_of_a_landmark_by_one_keyframe_share_one_hpl_block():
+    """g2o keeps one Hpl block per (pose, landmark) vertex pair and both cameras' edges add into it (BlockSolver::buildStructure,
+    G/core/block_solver.hpp:218-240).  Known answer: a window in which the right camera's observations are tied to TWIN landmarks
+    (same position, own vertex) is a different problem with the same minimum when the twins are held together by the data -- but the
+    FIRST linearisation's cost and gradient are identical sums; what is checked is that the solve with shared blocks is a descent
+    (chi2 falls every iteration, no rejected first trial), which the unsymmetrised cross term of a per-edge Schur complement is not."""
+    pr = synth.make_lba_rig_problem(n_free=6, n_fixed=3, n_points=300, seed=12, outlier_frac=0.0)
+    rig = views.camera_rig(*pr["rig"])
+    p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"], rig=rig)
+    o = ob.lba_solve(p)
+    tr = o.trace_rows()
+    assert len(tr) >= 3 and np.all(np.diff(tr[:, 1]) <= 1e-9) and tr[0, 2] == 1
+    # and the result does not depend on which of the two edges of a pair comes first
+    E = pr["edges"].copy()
+    k = 0
+    while k + 1 < len(E):
+        if E[k]["pose"] == E[k + 1]["pose"] and E[k]["point"] == E[k + 1]["point"]:
+            E[[k, k + 1]] = E[[k + 1, k]]
+            k += 2
+        else:
+            k += 1
+    p2, keep2 = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], E, pr["cam"], rig=rig)
+    o2 = ob.lba_solve(p2)
+    assert o2.iters == o.iters and np.abs(o2.poses - o.poses).max() < 1e-5 and np.abs(o2.points - o.points).max() < 1e-4
+
+
+def test_pose_optimization_of_a_rig_frame_recovers_the_pose_and_the_outliers():
+    pr = synth.make_pose_opt_rig_problem(n_left=300, n_right=200, outlier_frac=0.1, seed=13)
+    p, keep = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"],
+                                     rig=views.camera_rig(*pr["rig"]))
+    o = ob.pose_optimize(p)
+    assert np.abs(o.Tcw - pr["T_true"]).max() < 0.4 * np.abs(pr["Tcw"] - pr["T_true"]).max()
+    assert (o.outliers.astype(bool) == pr["bad"]).mean() > 0.93
+    assert o.n_inliers == 500 - int(o.outliers.sum())
+    # without the second camera every negative ur is a monocular entry of the LEFT camera: the right camera's features then do not fit
+    p2, keep2 = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"],
+                                       rig=views.camera_rig(pr["rig"][0]))
+    o2 = ob.pose_optimize(p2)
+    assert o2.outliers[300:].mean() > 0.5
