@@ -220,6 +220,28 @@ struct FeatVecFlat {          // the std::map in key ord
   }
 };
 
+// The cameras of a KeyFrame / Frame as the optimiser's edges use them (I/CameraModels/GeometricCamera.h:77-92): returns true -- and
+// fills `rig` -- when the edges cannot be written with the five pinhole scalars alone: a second camera (mpCamera2, the two-fisheye
+// rig, with mTrl) or a first one that is not a pinhole (monocular fisheye).
+template <class CamT> inline void fill_camera(orbg_camera& c, CamT* cam) {
+  c.model = (int32_t)cam->GetType();
+  c.fx = cam->getParameter(0); c.fy = cam->getParameter(1); c.cx = cam->getParameter(2); c.cy = cam->getParameter(3);
+  for (int i = 0; i < 4; i++) c.k[i] = cam->size() > (size_t)(4 + i) ? cam->getParameter(4 + i) : 0.f;
+}
+template <class ObjT> inline bool make_rig(ObjT* obj, orbg_camera_rig& rig) {
+  std::memset(&rig, 0, sizeof(rig));
+  if (!obj->mpCamera) return false;
+  if (!obj->mpCamera2 && obj->mpCamera->GetType() == ORBG_CAM_PINHOLE) return false;
+  fill_camera(rig.left, obj->mpCamera);
+  if (obj->mpCamera2) {
+    rig.has_right = 1;
+    fill_camera(rig.right, obj->mpCamera2);
+    const float* Trl = mat_f32(obj->mTrl);                     // 3 x 4 (or 4 x 4) CV_32F, row-major: Converter::toSE3Quat reads rows 0..2
+    std::memcpy(rig.Trl, Trl, 12 * sizeof(float));
+  }
+  return true;
+}
+
 inline size_t vertex_id(long unsigned id, unsigned client, bool is_kf) {       // Optimizer::GetID, I/Optimizer.h:104-112
   const size_t IDRANGE = 1000000, MAXAGENTS = 4;                                // I/Optimizer.h:23-24
   return is_kf ? IDRANGE * client + id : IDRANGE * (MAXAGENTS + client) + id;
@@ -576,7 +598,8 @@ template <class Ops> struct lba_cache_off<Ops, std::void_t<decltype(Ops::kNoLbaC
 
 template <class KeyFrameT, class MapPointT>
 struct LbaWindowCache {
-  struct Obs { KeyFrameT* kf; size_t kf_vid; int li; float u, v, ur, w; };
+  // li / u v ur w: the left camera's observation; ri / u2 v2 w2: the right camera's (rigs only: get<1>(indexes) - NLeft, -1 otherwise)
+  struct Obs { KeyFrameT* kf; size_t kf_vid; int li; float u, v, ur, w; int ri; float u2, v2, w2; };
   struct Rec {
     MapPointT* mp = nullptr; long unsigned id = 0, stamp = 0, seen = 0; bool valid = false;
     size_t vid = 0; float pos[3] = {0, 0, 0};
@@ -686,10 +709,15 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
         rc.obs.clear();
         for (const auto& ob : mp->GetObservations()) {
           KeyFrameT* kf = ob.first;
-          typename Cache::Obs o{kf, vertex_id(kf->mnId, kf->mnClientId, true), std::get<0>(ob.second), 0.f, 0.f, 0.f, 0.f};
+          typename Cache::Obs o{kf, vertex_id(kf->mnId, kf->mnClientId, true), std::get<0>(ob.second), 0.f, 0.f, 0.f, 0.f, -1, 0.f, 0.f, 0.f};
           if (o.li >= 0) {
             const auto& kp = kf->mvKeysUn[o.li];
             o.u = kp.pt.x; o.v = kp.pt.y; o.ur = kf->mvuRight[o.li]; o.w = kf->mvInvLevelSigma2[kp.octave];
+          }
+          if (kf->mpCamera2 && std::get<1>(ob.second) != -1) {                               // :2086-2093
+            o.ri = std::get<1>(ob.second) - kf->NLeft;
+            const auto& kp = kf->mvKeysRight[o.ri];
+            o.u2 = kp.pt.x; o.v2 = kp.pt.y; o.w2 = kf->mvInvLevelSigma2[kp.octave];
           }
           rc.obs.push_back(o);
         }
@@ -786,7 +814,7 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
       vMP[j] = rc.mp; recOf[j] = ri;
       pts.insert(pts.end(), rc.pos, rc.pos + 3);
       for (const auto& o : rc.obs) {                         // already by keyframe vertex id
-        if (o.li < 0) continue;                                                              // :2007
+        if (o.li < 0 && o.ri < 0) continue;                                                  // :2007, :2086
         const size_t d = vid_hi - o.kf_vid;
         int32_t col;
         if (d < kVidSpan && kfCol[d] != -2) col = kfCol[d];
@@ -796,12 +824,18 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
           if (d < kVidSpan) kfCol[d] = col;
         }
         if (col < 0) continue;
-        edges.push_back(lba_edge{col, (int32_t)j, o.u, o.v, o.ur /* < 0: monocular (:2007) */, o.w});
-        edgeOwner.push_back({o.kf, rc.mp});
+        if (o.li >= 0) {
+          edges.push_back(lba_edge{col, (int32_t)j, o.u, o.v, o.ur /* < 0: monocular (:2007) */, o.w});
+          edgeOwner.push_back({o.kf, rc.mp});
+        }
+        if (o.ri >= 0) {                                                                     // the right camera's edge (:2086-2120)
+          edges.push_back(lba_edge{col, (int32_t)j, o.u2, o.v2, LBA_UR_RIGHT_CAMERA, o.w2});
+          edgeOwner.push_back({o.kf, rc.mp});
+        }
       }
     }
   } else {
-    struct ObsRef { size_t vid; KeyFrameT* kf; int li; int col; };
+    struct ObsRef { size_t vid; KeyFrameT* kf; int li; int col; int ri; };
     std::vector<ObsRef> obs;
     for (size_t j = 0; j < n_pts; j++) {
       const LocalPoint& lp = vLP[order[j].second];
@@ -817,20 +851,31 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
         const KfRec* kr = kf_rec(kf);
         if (!kr || !kr->usable) continue;                                                    // :2003
         const int li = std::get<0>(ob.second);
-        if (li < 0) continue;                                                                // :2007
-        obs.push_back(ObsRef{kr->vid, kf, li, kr->col});
+        const int ri = kf->mpCamera2 && std::get<1>(ob.second) != -1 ? std::get<1>(ob.second) - kf->NLeft : -1;   // :2086-2093
+        if (li < 0 && ri < 0) continue;                                                      // :2007, :2086
+        obs.push_back(ObsRef{kr->vid, kf, li, kr->col, ri});
       }
       std::sort(obs.begin(), obs.end(), [](const ObsRef& a, const ObsRef& b) { return a.vid < b.vid; });
       for (const ObsRef& o : obs) {
-        const auto& kp = o.kf->mvKeysUn[o.li];
-        edges.push_back(lba_edge{o.col, (int32_t)j, kp.pt.x, kp.pt.y, o.kf->mvuRight[o.li] /* < 0: monocular (:2007) */, o.kf->mvInvLevelSigma2[kp.octave]});
-        edgeOwner.push_back({o.kf, mp});
+        if (o.li >= 0) {
+          const auto& kp = o.kf->mvKeysUn[o.li];
+          edges.push_back(lba_edge{o.col, (int32_t)j, kp.pt.x, kp.pt.y, o.kf->mvuRight[o.li] /* < 0: monocular (:2007) */, o.kf->mvInvLevelSigma2[kp.octave]});
+          edgeOwner.push_back({o.kf, mp});
+        }
+        if (o.ri >= 0) {                                                                     // the right camera's edge (:2086-2120)
+          const auto& kp = o.kf->mvKeysRight[o.ri];
+          edges.push_back(lba_edge{o.col, (int32_t)j, kp.pt.x, kp.pt.y, LBA_UR_RIGHT_CAMERA, o.kf->mvInvLevelSigma2[kp.octave]});
+          edgeOwner.push_back({o.kf, mp});
+        }
       }
     }
   }
   ORBGPU_GLUE_T("points + edges");
   lba_problem P{(int32_t)vKF.size(), (int32_t)vMP.size(), (int32_t)edges.size(), poses.data(), fixed.data(), pts.data(), edges.data(),
-                pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, pMap->IsInertial() ? 100.0 : 0.0 /* :1924-1925 */, 5, 10, 0};
+                pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, pMap->IsInertial() ? 100.0 : 0.0 /* :1924-1925 */, 5, 10, 0, nullptr};
+  // (the keyframes of a map hold the same camera objects: the window's cameras are the current keyframe's)
+  orbg_camera_rig rig;
+  if (make_rig(pKF, rig)) P.rig = &rig;
   oposes.resize(poses.size()); opts.resize(pts.size()); eout.resize(edges.size()); edep.resize(edges.size()); echi.resize(edges.size());
   lba_result R{}; R.poses = oposes.data(); R.points = opts.data(); R.edge_outlier = eout.data(); R.edge_depth_pos = edep.data(); R.edge_chi2 = echi.data();
   // *pbStopFlag is LocalMapping::mbAbortBA, a bool Tracking raises through InterruptBA() while this runs (S/LocalMapping.cc:381-386):
@@ -876,25 +921,31 @@ int LocalBundleAdjustment(KeyFrameT* pKF, bool* pbStopFlag, MapT* pMap, int& num
   return R.status;
 }
 
-// int Optimizer::PoseOptimization(Frame *pFrame), S/Optimizer.cc:964-1278 (mpCamera2 == NULL: the rectified-stereo / mono rigs
-// of every BASELINE configuration)
+// int Optimizer::PoseOptimization(Frame *pFrame), S/Optimizer.cc:964-1278: the rectified-stereo / mono frames of every BASELINE
+// configuration (mpCamera2 == NULL, :1012-1083) and the two-fisheye rig (:1085-1151: features i < Nleft are mvKeys[i] seen by mpCamera,
+// the others mvKeysRight[i - Nleft] seen by mpCamera2 after mTrl)
 template <class Ops = GpuOps, class FrameT>
 int PoseOptimization(FrameT* pFrame) {
   const int N = pFrame->N;
   std::vector<float> Xw, u, v, ur, w; std::vector<int> featIdx;
+  const bool two_cameras = pFrame->mpCamera2 != nullptr;
   for (int i = 0; i < N; i++) {
     auto* pMP = pFrame->mvpMapPoints[i];
     if (!pMP) continue;
-    pFrame->mvbOutlier[i] = false;                                                           // :1030, :1061
-    const auto& kp = pFrame->mvKeysUn[i];
+    pFrame->mvbOutlier[i] = false;                                                           // :1030, :1061, :1094, :1128
+    const bool right = two_cameras && i >= pFrame->Nleft;
+    const auto& kp = !two_cameras ? pFrame->mvKeysUn[i] : right ? pFrame->mvKeysRight[i - pFrame->Nleft] : pFrame->mvKeys[i];
     const auto Xm = pMP->GetWorldPos();
     const float* X = mat_f32(Xm);
-    Xw.insert(Xw.end(), X, X + 3); u.push_back(kp.pt.x); v.push_back(kp.pt.y); ur.push_back(pFrame->mvuRight[i]);
+    Xw.insert(Xw.end(), X, X + 3); u.push_back(kp.pt.x); v.push_back(kp.pt.y);
+    ur.push_back(!two_cameras ? pFrame->mvuRight[i] : right ? LBA_UR_RIGHT_CAMERA : -1.f);
     w.push_back(pFrame->mvInvLevelSigma2[kp.octave]); featIdx.push_back(i);
   }
   if (featIdx.size() < 3) return 0;                                                          // :1160-1161
   pose_opt_problem P{(int32_t)featIdx.size(), Xw.data(), u.data(), v.data(), ur.data(), w.data(), pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy,
-                     pFrame->mbf, {0}, 0};
+                     pFrame->mbf, {0}, 0, nullptr};
+  orbg_camera_rig rig;
+  if (make_rig(pFrame, rig)) P.rig = &rig;
   std::memcpy(P.Tcw, mat_f32(pFrame->mTcw), 64);
   std::vector<uint8_t> outlier(featIdx.size());
   pose_opt_result R{}; R.outlier = outlier.data();

@@ -220,10 +220,12 @@ struct BaOut { int status, num_fixed, erased, change_index, locked_poses, locked
 // raise_after_us >= 0: a second thread (Tracking calling LocalMapping::InterruptBA, S/LocalMapping.cc:381-386) sets the bool
 // that many microseconds after the call starts
 template <class Ops>
-static BaOut run_lba(int n_local, int n_far, int n_pts, double outlier_frac, bool stop, unsigned seed, double raise_after_us = -1.0) {
+static BaOut run_lba(int n_local, int n_far, int n_pts, double outlier_frac, bool stop, unsigned seed, double raise_after_us = -1.0,
+                     bool two_fisheye_rig = false) {
   od::LbaWindowCache<KeyFrame, MapPoint>::instance().clear();       // (the points of the last scene are gone: MapPoints never are, in the reference)
   Agent A; BaOut o;
-  KeyFrame* cur = build_lba_scene(A, n_local, n_far, n_pts, outlier_frac, seed);
+  KeyFrame* cur = two_fisheye_rig ? build_lba_rig_scene(A, n_local, n_far, n_pts, outlier_frac, seed)
+                                  : build_lba_scene(A, n_local, n_far, n_pts, outlier_frac, seed);
   bool mbAbortBA = stop;                                            // I/LocalMapping.h:155
   std::thread tracking;
   if (raise_after_us >= 0)
@@ -330,6 +332,39 @@ int main() {
         EXPECT(bg.change_index == 0 && bg.locked_poses == 0 && bg.locked_points == 0, "a rejected / aborted LBA must not bump the change index");
       }
       EXPECT(bg.change_index == bc.change_index && bg.locked_poses == bc.locked_poses && bg.locked_points == bc.locked_points, "write-back calls differ");
+    }
+    // ---- keyframes of the two-fisheye rig (mpCamera2 != NULL, NLeft != -1): a keyframe observes a point with the left camera, the right
+    // one or both -- monocular edges through KannalaBrandt8, EdgeSE3ProjectXYZToBody for the right camera (S/Optimizer.cc:2021-2120) --
+    // through the glue with the window cache (the mocks have the change counter) and without it
+    {
+      const BaOut bg = run_lba<od::GpuOps>(8, 4, 500, 0.03, false, 123, -1.0, true);
+      const BaOut bu = run_lba<GpuUnmodifiedOps>(8, 4, 500, 0.03, false, 123, -1.0, true);
+      const BaOut bc = run_lba<OracleOps>(8, 4, 500, 0.03, false, 123, -1.0, true);
+      std::printf("LocalBundleAdjustment [two-fisheye rig]: status %d, %d fixed KFs, %d observations erased\n", bg.status, bg.num_fixed, bg.erased);
+      EXPECT(bg.status == LBA_APPLIED && bc.status == LBA_APPLIED && bu.status == LBA_APPLIED, "rig window: status %d / %d / %d", bg.status, bu.status, bc.status);
+      EXPECT(bg.num_fixed == bc.num_fixed && bg.erased > 0 && std::abs(bg.erased - bc.erased) <= 1, "rig window: %d fixed / %d erased vs %d / %d", bg.num_fixed,
+             bg.erased, bc.num_fixed, bc.erased);
+      EXPECT(max_abs_diff(bg.poses, bc.poses) <= 1e-4f && max_abs_diff(bg.points, bc.points) <= 1e-4f, "rig window: poses %g points %g",
+             max_abs_diff(bg.poses, bc.poses), max_abs_diff(bg.points, bc.points));
+      EXPECT(max_abs_diff(bg.poses, bu.poses) == 0.f && max_abs_diff(bg.points, bu.points) == 0.f && bg.erased == bu.erased,
+             "rig window: the window cache changes the result (poses %g points %g)", max_abs_diff(bg.poses, bu.poses), max_abs_diff(bg.points, bu.points));
+    }
+    // ---- PoseOptimization of a Frame of that rig (S/Optimizer.cc:1085-1151)
+    {
+      auto run = [](auto ops_tag, std::vector<bool>& outl, std::vector<float>& pose) {
+        using Ops = decltype(ops_tag);
+        Agent A;
+        Frame* F = build_rig_frame(A, 300, 220, 0.1, 321);
+        const int n = od::PoseOptimization<Ops>(F);
+        outl = F->mvbOutlier; pose.assign(F->mTcw.ptr<float>(0), F->mTcw.ptr<float>(0) + 16);
+        return n;
+      };
+      std::vector<bool> og, oc; std::vector<float> pg, pc;
+      const int ng = run(od::GpuOps{}, og, pg), nc = run(OracleOps{}, oc, pc);
+      int nd = 0, nb = 0; for (size_t i = 0; i < og.size(); i++) { nd += og[i] != oc[i]; nb += og[i]; }
+      std::printf("PoseOptimization [two-fisheye rig]: %d inliers, %d flagged\n", ng, nb);
+      EXPECT(std::abs(ng - nc) <= 1 && nd <= 1 && ng > 350 && nb >= 20, "rig frame: inliers %d vs %d, %d flags differ, %d flagged", ng, nc, nd, nb);
+      EXPECT(max_abs_diff(pg, pc) <= 1e-4f, "rig frame: pose differs by %g", max_abs_diff(pg, pc));
     }
     // ---- five consecutive windows of one map (a new keyframe each, points moved / observations erased by the solves in between): the
     // product through the glue's window cache, the oracle reading every point of every window

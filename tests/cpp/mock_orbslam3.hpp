@@ -95,12 +95,29 @@ class Map {
 
 typedef std::map<unsigned, std::vector<unsigned>> FeatureVector;     // DBoW2::FeatureVector (D/FeatureVector.h:24-25)
 
+// GeometricCamera (I/CameraModels/GeometricCamera.h:50-105): the three members the glue reads, all public there
+class GeometricCamera {
+ public:
+  GeometricCamera(unsigned type, std::vector<float> params) : mnType(type), mvParameters(std::move(params)) {}
+  float getParameter(const int i) { return mvParameters[i]; }
+  size_t size() { return mvParameters.size(); }
+  unsigned int GetType() { return mnType; }
+ protected:
+  unsigned int mnType;
+  std::vector<float> mvParameters;
+};
+
 class KeyFrame {
  public:      // ---- public in the reference (I/KeyFrame.h:268-533)
   long unsigned mnId = 0; uint8_t mnClientId = 0;
   long unsigned mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul;
   float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
   std::vector<KeyPoint> mvKeysUn; std::vector<float> mvuRight, mvInvLevelSigma2;
+  // (I/KeyFrame.h:634-648) the cameras and, for the two-fisheye rig, the right camera's keypoints
+  GeometricCamera* mpCamera = nullptr; GeometricCamera* mpCamera2 = nullptr;
+  Mat mTrl{3, 4, 4};
+  std::vector<KeyPoint> mvKeysRight;
+  int NLeft = -1, NRight = -1;
   Mat mDescriptors; FeatureVector mFeatVec;
   bool isBad() const { return mbBad; }
   Map* GetMap() const { return mpMap; }
@@ -131,6 +148,11 @@ class Frame {
   float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0;   // statics in the reference
   int mnScaleLevels = 8; float mfScaleFactor = 1.2f;
   void SetPose(const Mat& T) { mTcw = T; }
+  // (I/Frame.h:169, 276-297) the cameras and, for the two-fisheye rig, the right camera's keypoints (features i >= Nleft)
+  GeometricCamera* mpCamera = nullptr; GeometricCamera* mpCamera2 = nullptr;
+  Mat mTrl{3, 4, 4};
+  std::vector<KeyPoint> mvKeysRight;
+  int Nleft = -1, Nright = -1;
 };
 
 // the matrix access points include/orbgpu_dropin.hpp asks for

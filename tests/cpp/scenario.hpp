@@ -79,6 +79,7 @@ static std::vector<uint8_t> render(const std::vector<uint8_t>& tex, const double
 static Mat mat44(const double T[16]) { Mat m(4, 4, 4); for (int i = 0; i < 16; i++) m.ptr<float>(0)[i] = (float)T[i]; return m; }
 
 struct Agent {          // everything one run (one Ops) owns: frames, map points, keyframes
+  std::vector<std::unique_ptr<GeometricCamera>> cameras;           // (rig scenes) mpCamera / mpCamera2 of every keyframe and frame
   std::vector<std::unique_ptr<orbgpu::FrameOnDevice>> dev_frames;
   std::vector<std::unique_ptr<Frame>> frames;
   std::vector<std::unique_ptr<MapPoint>> points;
@@ -193,6 +194,146 @@ static KeyFrame* build_lba_scene(Agent& A, int n_local, int n_far, int n_pts, do
     A.points.push_back(std::move(mp));
   }
   return cur;
+}
+
+// ------------------------------------------------------------------------------------------------ two-fisheye rig (mpCamera2 != NULL)
+// TUM-VI-like 512 x 512 KannalaBrandt8 cameras, the right one 10 cm to the side and a degree out of line (mTrl)
+static const float KB8_L[8] = {190.978f, 190.973f, 254.932f, 256.897f, 0.00348f, 0.000715f, -0.00205f, 0.000203f};
+static const float KB8_R[8] = {190.442f, 190.435f, 252.598f, 254.917f, 0.00340f, 0.00177f, -0.00266f, 0.000330f};
+static void kb8_project(const float* c, const double X[3], double uv[2]) {
+  const double r = std::sqrt(X[0] * X[0] + X[1] * X[1]), th = std::atan2(r, X[2]), psi = std::atan2(X[1], X[0]);
+  const double t2 = th * th, d = th * (1 + t2 * (c[4] + t2 * (c[5] + t2 * (c[6] + t2 * c[7]))));
+  uv[0] = c[0] * d * std::cos(psi) + c[2]; uv[1] = c[1] * d * std::sin(psi) + c[3];
+}
+static void rig_Trl(double T[12]) {
+  double R[9]; rot(0.012, -0.02, 0.006, R);
+  const double t[3] = {-0.101, 0.0012, -0.0009};
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * i + j]; T[4 * i + 3] = t[i]; }
+}
+static void give_rig(Agent& A, GeometricCamera*& c1, GeometricCamera*& c2, Mat& mTrl) {
+  if (A.cameras.empty()) {
+    A.cameras.emplace_back(new GeometricCamera(1u, std::vector<float>(KB8_L, KB8_L + 8)));
+    A.cameras.emplace_back(new GeometricCamera(1u, std::vector<float>(KB8_R, KB8_R + 8)));
+  }
+  c1 = A.cameras[0].get(); c2 = A.cameras[1].get();
+  double T[12]; rig_Trl(T);
+  mTrl = Mat(3, 4, 4);
+  for (int i = 0; i < 12; i++) mTrl.ptr<float>(0)[i] = (float)T[i];
+}
+constexpr int kRigNLeft = 4096;           // KeyFrame::NLeft of the rig scenes: right-camera feature r has index NLeft + r in the observations
+
+// build_lba_scene for keyframes of the two-fisheye rig: every observation of a point by a keyframe is made by the left camera
+// (mvKeysUn, mvuRight = -1), by the right one (mvKeysRight, index NLeft + r in the point's observation tuple) or by both
+// (S/Optimizer.cc:2021-2120 makes one edge per camera).
+static KeyFrame* build_lba_rig_scene(Agent& A, int n_local, int n_far, int n_pts, double outlier_frac, unsigned seed) {
+  g_seed = seed;
+  const int P = n_local + n_far;
+  std::vector<std::vector<double>> Tt(P, std::vector<double>(16));
+  float isig[8]; { float s = 1.f; for (int l = 0; l < 8; l++) { isig[l] = 1.f / (s * s); s *= 1.2f; } }
+  double Trl[12]; rig_Trl(Trl);
+  for (int k = 0; k < P; k++) {
+    double R[9]; rot(0.03 * std::sin(0.3 * k), 0.05 * std::sin(0.2 * k + 1.0), 0.02 * std::sin(0.5 * k), R);
+    const double C[3] = {0.10 * k, 0.02 * std::sin(0.4 * k), 0.03 * std::cos(0.3 * k)};
+    for (int i = 0; i < 16; i++) Tt[k][i] = (i % 5 == 0) ? 1 : 0;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tt[k][4 * i + j] = R[3 * i + j]; Tt[k][4 * i + 3] = -(R[3 * i] * C[0] + R[3 * i + 1] * C[1] + R[3 * i + 2] * C[2]); }
+    std::unique_ptr<KeyFrame> kf(new KeyFrame);
+    kf->mnId = 10 + k; kf->fx = KB8_L[0]; kf->fy = KB8_L[1]; kf->cx = KB8_L[2]; kf->cy = KB8_L[3]; kf->mbf = 0.f; kf->mpMap = &A.map;
+    kf->mvInvLevelSigma2.assign(isig, isig + 8);
+    give_rig(A, kf->mpCamera, kf->mpCamera2, kf->mTrl);
+    kf->NLeft = kRigNLeft;
+    double Tn[16]; for (int i = 0; i < 16; i++) Tn[i] = Tt[k][i];
+    Tn[3] += 0.01 * nrand(); Tn[7] += 0.01 * nrand(); Tn[11] += 0.01 * nrand();
+    kf->Tcw = mat44(Tn);
+    A.kfs.push_back(std::move(kf));
+  }
+  A.map.mnInitKFid = 0;
+  KeyFrame* cur = A.kfs[P - 1].get();
+  for (int k = n_far; k <= P - 2; k++) cur->mvpOrderedConnectedKeyFrames.push_back(A.kfs[k].get());
+  for (int j = 0; j < n_pts; j++) {
+    const int nobs = std::min(3 + (int)(rnd() % 5), P), k0 = rnd() % (P - nobs + 1), kc = std::min(k0 + nobs / 2, P - 1);
+    const double depth = 1.5 + 6.5 * urand(), th = 0.9 * urand(), psi = 6.283185307179586 * urand();
+    const double Pc[3] = {depth * std::sin(th) * std::cos(psi), depth * std::sin(th) * std::sin(psi), depth * std::cos(th)};
+    const double* T = Tt[kc].data();
+    double Xw[3];
+    for (int a = 0; a < 3; a++) Xw[a] = T[a] * (Pc[0] - T[3]) + T[4 + a] * (Pc[1] - T[7]) + T[8 + a] * (Pc[2] - T[11]);
+    std::unique_ptr<MapPoint> mp(new MapPoint);
+    mp->mnId = 100 + j; mp->mpMap = &A.map;
+    for (int a = 0; a < 3; a++) mp->mWorldPos.ptr<float>(0)[a] = (float)(Xw[a] + 0.02 * nrand());
+    for (int k = k0; k < k0 + nobs; k++) {
+      const double* Tk = Tt[k].data();
+      double Xl[3], Xr[3];
+      for (int a = 0; a < 3; a++) Xl[a] = Tk[4 * a] * Xw[0] + Tk[4 * a + 1] * Xw[1] + Tk[4 * a + 2] * Xw[2] + Tk[4 * a + 3];
+      for (int a = 0; a < 3; a++) Xr[a] = Trl[4 * a] * Xl[0] + Trl[4 * a + 1] * Xl[1] + Trl[4 * a + 2] * Xl[2] + Trl[4 * a + 3];
+      KeyFrame* kf = A.kfs[k].get();
+      int li = -1, ri = -1;
+      for (int side = 0; side < 2; side++) {
+        const double* Xc = side ? Xr : Xl;
+        if (Xc[2] < 0.2 || urand() > (side ? 0.6 : 0.9)) continue;
+        double uv[2]; kb8_project(side ? KB8_R : KB8_L, Xc, uv);
+        if (!(uv[0] >= 5 && uv[0] < 507 && uv[1] >= 5 && uv[1] < 507)) continue;
+        const int oct = rnd() % 4; const double sig = std::pow(1.2, oct);
+        double pu = uv[0] + sig * nrand(), pv = uv[1] + sig * nrand();
+        if (urand() < outlier_frac) { pu += (urand() < 0.5 ? -1 : 1) * (15 + 20 * urand()); pv += (urand() < 0.5 ? -1 : 1) * (15 + 20 * urand()); }
+        const KeyPoint kp{{(float)pu, (float)pv}, 31.f, 0.f, 20.f, oct};
+        if (!side) { li = (int)kf->mvKeysUn.size(); kf->mvKeysUn.push_back(kp); kf->mvuRight.push_back(-1.f); }
+        else { ri = kRigNLeft + (int)kf->mvKeysRight.size(); kf->mvKeysRight.push_back(kp); }
+      }
+      if (li < 0 && ri < 0) continue;
+      kf->mvpMapPoints.push_back(mp.get());
+      mp->mObservations[kf] = std::make_tuple(li, ri);
+      mp->nObs++;
+    }
+    A.points.push_back(std::move(mp));
+  }
+  return cur;
+}
+
+// A Frame of the two-fisheye rig with n_left + n_right tracked map points (features i < Nleft: mvKeys, the others: mvKeysRight,
+// S/Optimizer.cc:1085-1151), pixel noise, gross outliers, mTcw = truth perturbed.
+static Frame* build_rig_frame(Agent& A, int n_left, int n_right, double outlier_frac, unsigned seed) {
+  g_seed = seed;
+  std::unique_ptr<Frame> F(new Frame);
+  double R[9]; rot(0.05, -0.03, 0.02, R);
+  double T[16]; for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0) ? 1 : 0;
+  const double t[3] = {0.1, -0.05, 0.2};
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * i + j]; T[4 * i + 3] = t[i]; }
+  double Trl[12]; rig_Trl(Trl);
+  give_rig(A, F->mpCamera, F->mpCamera2, F->mTrl);
+  F->Nleft = n_left; F->Nright = n_right; F->N = n_left + n_right;
+  float isig[8]; { float s = 1.f; for (int l = 0; l < 8; l++) { isig[l] = 1.f / (s * s); s *= 1.2f; } }
+  F->mvInvLevelSigma2.assign(isig, isig + 8);
+  F->mvpMapPoints.assign(F->N, nullptr); F->mvbOutlier.assign(F->N, false); F->mvuRight.assign(F->N, -1.f);
+  for (int i = 0; i < F->N; i++) {
+    const bool right = i >= n_left;
+    const double depth = 1.5 + 6.5 * urand(), th = 0.9 * urand(), psi = 6.283185307179586 * urand();
+    const double Pc[3] = {depth * std::sin(th) * std::cos(psi), depth * std::sin(th) * std::sin(psi), depth * std::cos(th)};   // in the observing camera
+    double Xl[3];
+    if (right) { for (int a = 0; a < 3; a++) Xl[a] = Trl[a] * (Pc[0] - Trl[3]) + Trl[4 + a] * (Pc[1] - Trl[7]) + Trl[8 + a] * (Pc[2] - Trl[11]); }
+    else { for (int a = 0; a < 3; a++) Xl[a] = Pc[a]; }
+    double Xw[3];
+    for (int a = 0; a < 3; a++) Xw[a] = T[a] * (Xl[0] - T[3]) + T[4 + a] * (Xl[1] - T[7]) + T[8 + a] * (Xl[2] - T[11]);
+    double uv[2]; kb8_project(right ? KB8_R : KB8_L, Pc, uv);
+    const int oct = rnd() % 8; const double sig = std::pow(1.2, oct);
+    double pu = uv[0] + sig * nrand(), pv = uv[1] + sig * nrand();
+    if (urand() < outlier_frac) { pu += (urand() < 0.5 ? -25 : 25); pv += (urand() < 0.5 ? -25 : 25); }
+    const KeyPoint kp{{(float)pu, (float)pv}, 31.f, 0.f, 20.f, oct};
+    if (right) F->mvKeysRight.push_back(kp); else F->mvKeys.push_back(kp);
+    if (i % 7 == 3) continue;                                    // (features without a map point)
+    std::unique_ptr<MapPoint> mp(new MapPoint);
+    mp->mnId = 100 + i; mp->mpMap = &A.map;
+    for (int a = 0; a < 3; a++) mp->mWorldPos.ptr<float>(0)[a] = (float)Xw[a];
+    F->mvpMapPoints[i] = mp.get();
+    A.points.push_back(std::move(mp));
+  }
+  F->mvKeysUn = F->mvKeys;
+  double Tn[16]; for (int i = 0; i < 16; i++) Tn[i] = T[i];
+  { double dR[9], Rn[9]; rot(0.008, -0.006, 0.005, dR);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rn[3 * i + j] = 0; for (int k = 0; k < 3; k++) Rn[3 * i + j] += dR[3 * i + k] * R[3 * k + j]; }
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tn[4 * i + j] = Rn[3 * i + j]; Tn[4 * i + 3] = t[i] + 0.02 * nrand(); } }
+  F->mTcw = mat44(Tn);
+  Frame* out = F.get();
+  A.frames.push_back(std::move(F));
+  return out;
 }
 
 // The keyframe after `cur` as LocalMapping would insert it: covisible with `cur` and all but the oldest of its neighbours, observing

@@ -94,10 +94,12 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
     """Extractor / stereo Frame constructor, isInFrustum, SearchByProjection x2, SearchByBoW, PoseOptimization and
     LocalBundleAdjustment (graph collection, vToErase, 50 %-outlier early return, pbStopFlag raised before AND -- by a second
     thread, through the reference's own bool -- during the solve, SetPose / SetWorldPos lock flags, Map change index) with the
-    reference's signatures."""
+    reference's signatures; and both optimisers on keyframes / a Frame of the two-fisheye rig (mpCamera2, NLeft: KannalaBrandt8
+    models, the right camera's ToBody edges), with and without the glue's window cache."""
     exe = _build("dropin_parity", with_oracle=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "dropin parity ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-1000:])
+    assert "LocalBundleAdjustment [two-fisheye rig]: status 0" in r.stdout and "PoseOptimization [two-fisheye rig]:" in r.stdout, r.stdout[-3000:]
 
 
 def test_closed_loop_scenario_tracks_on_the_oracle_alone():
