@@ -1385,6 +1385,13 @@ def main():
                 if not sp["ok"]:
                     parity["ok"] = False
                     parity.setdefault("violations", []).append("server tick: %s" % {k2: v for k2, v in sp.items() if v is False})
+        # ---- the optimisers on frames of a two-camera rig (no BASELINE configuration has one: a parity-only leg, rank 0)
+        if rank == 0 and "skipped" not in parity:
+            rp = rig_parity(api, views)
+            parity["camera_rig"] = rp
+            if rp.get("ok") is not True:
+                parity["ok"] = False
+                parity.setdefault("violations", []).append("camera rig: %s" % {k2: v for k2, v in rp.items() if k2 != "what"})
         # ---- closed loop (rank 0): state carried from call to call, 200 frames, product vs oracle (tests/cpp/closed_loop.cpp)
         if rank == 0 and args.closed_loop_frames > 0 and args.config == "C2" and "skipped" not in parity:
             cl = run_closed_loop(args.closed_loop_frames)
@@ -1443,6 +1450,40 @@ def run_dropin_bench():
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     except Exception as e:                                # the headline does not depend on it
         return {"error": repr(e)[:300]}
+
+
+def rig_parity(api, views):
+    """LocalBundleAdjustment and PoseOptimization on keyframes / a Frame of a two-fisheye rig (KannalaBrandt8 models, the right camera's
+    EdgeSE3ProjectXYZToBody edges, S/Optimizer.cc:1085-1151, 2021-2120) against the oracle.  The oracle is the checker here, outside
+    every timed region."""
+    try:
+        from multi_orbslam3_amd import synth
+        from oracle import binding as ob
+        pr = synth.make_lba_rig_problem(n_free=8, n_fixed=4, n_points=600)
+        p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"], rig=views.camera_rig(*pr["rig"]))
+        opt = api.Optimizer()
+        g = opt.LocalBundleAdjustment(p)
+        o = ob.lba_solve(p)
+        d = {"lba_edges": int(p.n_edges), "lba_right_camera_edges": int((pr["edges"]["ur"] <= -1.5).sum()),
+             "lba_iterations_equal": bool(g.iters == o.iters and g.status == o.status),
+             "lba_max_pose_diff": float(np.abs(g.poses - o.poses).max()), "lba_max_point_diff": float(np.abs(g.points - o.points).max()),
+             "lba_outlier_flags_differing": int((g.edge_outlier != o.edge_outlier).sum())}
+        po = synth.make_pose_opt_rig_problem(n_left=300, n_right=200)
+        q, keep2 = views.pose_opt_problem(po["Xw"], po["u"], po["v"], po["ur"], po["inv_sigma2"], po["cam"], po["Tcw"],
+                                          rig=views.camera_rig(*po["rig"]))
+        g2 = opt.PoseOptimization(q)
+        o2 = ob.pose_optimize(q)
+        d.update({"pose_opt_max_pose_diff": float(np.abs(g2.Tcw.astype(np.float64) - o2.Tcw.astype(np.float64)).max()),
+                  "pose_opt_outlier_flags_differing": int((g2.outliers != o2.outliers).sum()),
+                  "pose_opt_inliers": [int(g2.n_inliers), int(o2.n_inliers)]})
+        d["ok"] = bool(d["lba_iterations_equal"] and d["lba_max_pose_diff"] <= 1e-4 and d["lba_max_point_diff"] <= 1e-4 and
+                       d["lba_outlier_flags_differing"] <= 1 and d["pose_opt_max_pose_diff"] <= 1e-5 and
+                       d["pose_opt_outlier_flags_differing"] <= 1)
+        d["what"] = ("8 + 4 keyframes / 600 points of a two-fisheye rig through lba_solve_h, 300 + 200 features through pose_optimize, "
+                     "product vs oracle; tolerances of tests/test_gpu_parity.py (-k rig)")
+        return d
+    except Exception as e:
+        return {"ok": False, "error": repr(e)[:300]}
 
 
 def run_closed_loop(n_frames):
