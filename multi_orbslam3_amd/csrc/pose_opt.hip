@@ -330,9 +330,13 @@ __device__ __forceinline__ void po_hessian(const PoEval<V>& e, V om, M mono, con
 // -DPO_PROFILE: cycles of thread 0 per phase, summed over the call (build, reduce, solve, trial evaluation, trial sum, rest)
 #ifdef PO_PROFILE
 __device__ long long g_po_prof[16];
+#define PO_IN0() po_s = clock64()
+#define PO_IN(slot) do { const long long po_m = clock64(); if (threadIdx.x == 0) g_po_prof[slot] += po_m - po_s; po_s = po_m; } while (0)
 #define PO_T0() long long po_t = clock64()
 #define PO_ACC(slot) do { const long long po_n = clock64(); if (threadIdx.x == 0) g_po_prof[slot] += po_n - po_t; po_t = po_n; } while (0)
 #else
+#define PO_IN0() do { } while (0)
+#define PO_IN(slot) do { } while (0)
 #define PO_T0() do { } while (0)
 #define PO_ACC(slot) do { } while (0)
 #endif
@@ -732,6 +736,9 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
   int nBad = 0;
   if (tid == 0) { for (int k = 0; k < 7; k++) stats[k] = 0; for (int k = 0; k < 4; k++) chi_out[k] = 0; }
   PO_T0();
+#ifdef PO_PROFILE
+  long long po_s = 0;
+#endif
   for (int round = 0; round < 4; round++) {
     T = T0;                                                   // setEstimate(toSE3Quat(mTcw)) every round (:1191)
     bool active[NP];
@@ -794,9 +801,12 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
             const int wv = tid >> 6;
             for (int cc = 0; cc < wv; cc++) { lam_c *= ni_c; ni_c *= 2; }
             double xc[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
+            PO_IN0();
             const bool okc = po_solve6(Hrow, b_li, li, lam_c, xc);
+            PO_IN(6);
             PoseQ Tc;
             pose_oplus_series(T, xc, &Tc);
+            PO_IN(7);
             if ((tid & 63) == 0) {
               double* sc = s_cand[wv];
 #pragma unroll
@@ -809,7 +819,9 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
             }
           }
           __syncthreads();
+          PO_IN(14);
         }
+        PO_IN0();
         const bool ok2 = s_cand[cslot][13] != 0.0;
         PoseQ Tt;
         if (ok2) {
@@ -822,6 +834,7 @@ __global__ __launch_bounds__(kPoWide) void pose_opt_wide_kernel(int n, const flo
         } else {
           pose_oplus_series(T, x, &Tt);                     // the solve failed: update with whatever x holds, as g2o does
         }
+        PO_IN(15);
         PO_ACC(2);
         double tchi = 0;
 #pragma unroll

@@ -22,3 +22,4 @@ print("iters", r.iters, "total cycles", tot)
 for i, nm in enumerate(names):
     print("%-14s %8d cycles  %5.1f %%" % (nm, buf[i], 100.0 * buf[i] / tot))
 print("inside reduce28 (thread 0): fold32 %d, fold16 %d, LDS stores %d, barrier %d, column sums %d, barrier %d" % tuple(buf[8:14]))
+print("inside solve6+oplus (thread 0 of wavefront 0): po_solve6 %d, pose_oplus_series %d, candidate to LDS + barrier %d, candidate back from LDS %d" % (buf[6], buf[7], buf[14], buf[15]))
