@@ -29,6 +29,39 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.LbaProblem) % 8 == 0 and capi.LbaProblem.lambda_init.offset % 8 == 0
 
 
+def test_ctypes_mirrors_of_the_problem_structs_have_the_headers_layout(tmp_path):
+    """sizeof / offsetof of the optimiser's problem structs and the camera rig, asked of the C compiler, against the ctypes mirrors
+    the Python host side fills (a field added to one side only would shift every pointer behind it)."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    fields = {"lba_problem": ("LbaProblem", ["n_poses", "poses", "edges", "fx", "lambda_init", "its_round1", "device", "rig"]),
+              "pose_opt_problem": ("PoseOptProblem", ["n", "Xw", "inv_sigma2", "fx", "Tcw", "device", "rig"]),
+              "orbg_camera": ("Camera", ["model", "fx", "cy", "k"]),
+              "orbg_camera_rig": ("CameraRig", ["left", "has_right", "right", "Trl"]),
+              "lba_result": ("LbaResult", ["poses", "edge_outlier", "status", "chi2_initial", "trace", "trace_len"]),
+              "pose_opt_result": ("PoseOptResult", ["Tcw", "outlier", "n_inliers", "iters", "chi2"])}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "orbgpu.h"', 'int main(void) {']
+    for cname, (_, fl) in fields.items():
+        lines.append('  printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for f in fl:
+            lines.append('  printf(" %%zu", offsetof(%s, %s));' % (cname, f))
+        lines.append('  printf("\\n");')
+    lines.append("  return 0; }")
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).splitlines()
+    assert len(out) == len(fields)
+    for ln in out:
+        parts = ln.split()
+        pyname, fl = fields[parts[0]]
+        cls = getattr(capi, pyname)
+        assert C.sizeof(cls) == int(parts[1]), (parts[0], C.sizeof(cls), parts[1])
+        for f, off in zip(fl, parts[2:]):
+            assert getattr(cls, f).offset == int(off), (parts[0], f, getattr(cls, f).offset, off)
+    assert capi.UR_RIGHT_CAMERA == -2.0 and "#define LBA_UR_RIGHT_CAMERA (-2.0f)" in open(os.path.join(ROOT, "include", "orbgpu.h")).read()
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     lib = capi.load()
     if lib.orbg_device_count() > 0:

@@ -138,10 +138,10 @@ def test_lba_of_a_rig_window_converges_and_flags_the_planted_outliers():
 
 def test_two_observations_of_a_landmark_by_one_keyframe_share_one_hpl_block():
     """g2o keeps one Hpl block per (pose, landmark) vertex pair and both cameras' edges add into it (BlockSolver::buildStructure,
-    G/core/block_solver.hpp:218-240).  Known answer: a window in which the right camera's observations are tied to TWIN landmarks
-    (same position, own vertex) is a different problem with the same minimum when the twins are held together by the data -- but the
-    FIRST linearisation's cost and gradient are identical sums; what is checked is that the solve with shared blocks is a descent
-    (chi2 falls every iteration, no rejected first trial), which the unsymmetrised cross term of a per-edge Schur complement is not."""
+    G/core/block_solver.hpp:218-240).  A Schur complement taken over per-EDGE blocks instead loses the symmetric half of the cross
+    term Hpl_left Hll^-1 Hpl_right^T on the pose's diagonal block: the step is then no Gauss-Newton step and the first trials get
+    rejected.  Pinned here: on an outlier-free window every iteration's first trial is accepted and chi2 falls monotonically, and the
+    result does not depend on which of the two edges of a pair comes first in the list."""
     pr = synth.make_lba_rig_problem(n_free=6, n_fixed=3, n_points=300, seed=12, outlier_frac=0.0)
     rig = views.camera_rig(*pr["rig"])
     p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"], rig=rig)
