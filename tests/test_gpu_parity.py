@@ -1458,6 +1458,26 @@ def test_lba_rig_with_a_pinhole_left_camera_and_no_right_one_is_the_pinhole_prob
     assert o1.iters == g1.iters and np.abs(o1.poses - g1.poses).max() <= 1e-4
 
 
+@pytest.mark.parametrize("kind", ["pinhole_stereo", "rig"])
+def test_lba_first_lm_step_is_the_dense_gauss_newton_step(kind):
+    """The PRODUCT against first principles, not against the oracle's solver: the state after the first accepted LM trial (k_errlin,
+    k_schur, the matrix-core LDL^T, k_update) against the dense normal equations over all unknowns solved with numpy (tests/dense_lm.py;
+    only the per-edge residuals / Jacobians come from the oracle, and those are pinned against central differences on the CPU)."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dense_lm import dense_first_step, first_step_of
+    if kind == "rig":
+        pr = synth.make_lba_rig_problem(n_free=6, n_fixed=3, n_points=150, seed=31, outlier_frac=0.02)
+        rig = views.camera_rig(*pr["rig"])
+    else:
+        pr = synth.make_lba_problem(n_free=6, n_fixed=3, n_points=150, seed=32, mono_frac=0.3)
+        rig = None
+    g = first_step_of(lambda p, stop: api.Optimizer().LocalBundleAdjustment(p, pbStopFlag=stop), pr, rig)
+    poses, points, dx = dense_first_step(pr, rig)
+    assert np.abs(poses - g.poses.reshape(-1, 4, 4)[:, :3, :]).max() < 2e-6 and np.abs(points - g.points).max() < 5e-6
+    assert np.abs(dx).max() > 1e-3
+
+
 @pytest.mark.parametrize("nl,nr,of", [(300, 200, 0.1), (600, 400, 0.3), (40, 0, 0.0), (0, 60, 0.0), (1500, 1200, 0.2), (2200, 1800, 0.05),
                                       (5, 4, 0.0)])
 def test_pose_optimization_with_the_two_fisheye_rig(nl, nr, of):

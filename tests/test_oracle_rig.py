@@ -178,56 +178,27 @@ def test_pose_optimization_of_a_rig_frame_recovers_the_pose_and_the_outliers():
 
 
 def test_first_lm_step_of_a_rig_window_is_the_dense_gauss_newton_step():
-    """Known answer for the whole linear algebra of one LM iteration on a window with doubled vertex pairs: the dense normal equations
-    (J^T W J + lambda I) dx = -J^T W r over ALL unknowns, assembled here from the oracle's per-edge residuals and Jacobians (which the
-    tests above pin against central differences), solved with numpy, applied with exp() -- against the oracle's state after its first
-    accepted trial (Schur complement on one Hpl block per vertex pair, LDL^T, back-substitution).  A Schur complement over per-edge
-    blocks fails this at the 1e-3 level."""
+    """Known answer for the whole linear algebra of one LM iteration on a window with doubled vertex pairs: tests/dense_lm.py (the dense
+    normal equations over all unknowns, solved with numpy) against the oracle's state after its first accepted trial (Schur complement on
+    one Hpl block per vertex pair, LDL^T, back-substitution).  A Schur complement over per-edge blocks fails this at the 1e-3 level."""
+    from dense_lm import dense_first_step, first_step_of
     pr = synth.make_lba_rig_problem(n_free=3, n_fixed=2, n_points=40, seed=21, outlier_frac=0.0)
-    E = pr["edges"]
-    pairs = set()
-    n_dup = 0
-    for e in E:
-        n_dup += (int(e["pose"]), int(e["point"])) in pairs
-        pairs.add((int(e["pose"]), int(e["point"])))
+    seen, n_dup = set(), 0
+    for e in pr["edges"]:
+        n_dup += (int(e["pose"]), int(e["point"])) in seen
+        seen.add((int(e["pose"]), int(e["point"])))
     assert n_dup > 20
     rig = views.camera_rig(*pr["rig"])
-    p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], E, pr["cam"], rig=rig)
-    stop = np.array([-1], np.int32)                     # raised once one LM trial has been evaluated
-    o = ob.lba_solve(p, stop_flag=stop)
-    assert o.iters == (1, 0)
-    # --- the same step, densely
-    P = len(pr["poses"]); free = [i for i in range(P) if not pr["pose_fixed"][i]]
-    pcol = {i: c for c, i in enumerate(free)}
-    L = len(pr["points"])
-    nu = 6 * len(free) + 3 * L
-    H = np.zeros((nu, nu)); b = np.zeros(nu)
-    quats, ts = [], []
-    for i in range(P):
-        T = pr["poses"][i].reshape(4, 4).astype(np.float64)
-        q = _quat_from_R(T[:3, :3]); q /= np.linalg.norm(q)
-        quats.append(q); ts.append(T[:3, 3].copy())
-    X0 = pr["points"].astype(np.float64)
-    delta = float(np.float32(np.sqrt(5.991)))
-    for e in E:
-        i, l = int(e["pose"]), int(e["point"])
-        err, A, B, _ = ob.lba_edge_eval_rig(quats[i], ts[i], X0[l], pr["cam"], rig, np.array([e], capi.EDGE_DTYPE))
-        om = float(e["inv_sigma2"])
-        c2 = om * float(err[:2] @ err[:2])
-        w = 1.0 if c2 <= delta * delta else delta / np.sqrt(c2)
-        J = np.zeros((2, nu))
-        if i in pcol:
-            J[:, 6 * pcol[i]:6 * pcol[i] + 6] = B[:2]
-        J[:, 6 * len(free) + 3 * l:6 * len(free) + 3 * l + 3] = A[:2]
-        H += J.T @ (w * om * J); b -= J.T @ (w * om * err[:2])
-    lam = 1e-5 * np.abs(np.diag(H)).max()
-    dx = np.linalg.solve(H + lam * np.eye(nu), b)
-    for i in free:
-        q, t = _oplus(quats[i], ts[i], dx[6 * pcol[i]:6 * pcol[i] + 6])
-        q /= np.linalg.norm(q)
-        To = o.poses[i].reshape(4, 4).astype(np.float64)
-        R = np.array([_quat_rot(q, ex) for ex in np.eye(3)]).T
-        assert np.abs(R - To[:3, :3]).max() < 2e-6 and np.abs(t - To[:3, 3]).max() < 2e-6, i
-    Xn = X0 + dx[6 * len(free):].reshape(L, 3)
-    assert np.abs(Xn - o.points).max() < 5e-6
+    o = first_step_of(lambda p, stop: ob.lba_solve(p, stop_flag=stop), pr, rig)
+    poses, points, dx = dense_first_step(pr, rig)
+    assert np.abs(poses - o.poses.reshape(-1, 4, 4)[:, :3, :]).max() < 2e-6 and np.abs(points - o.points).max() < 5e-6
     assert np.abs(dx).max() > 1e-3                      # (a step three orders of magnitude above the tolerance)
+
+
+def test_first_lm_step_of_a_pinhole_stereo_window_is_the_dense_gauss_newton_step():
+    from dense_lm import dense_first_step, first_step_of
+    pr = synth.make_lba_problem(n_free=4, n_fixed=2, n_points=60, seed=22, mono_frac=0.3)
+    o = first_step_of(lambda p, stop: ob.lba_solve(p, stop_flag=stop), pr)
+    poses, points, dx = dense_first_step(pr)
+    assert np.abs(poses - o.poses.reshape(-1, 4, 4)[:, :3, :]).max() < 2e-6 and np.abs(points - o.points).max() < 5e-6
+    assert np.abs(dx).max() > 1e-3
