@@ -1,0 +1,237 @@
+"""The arithmetic of the optimiser's edges, EVALUATED FROM THE REFERENCE'S OWN SOURCE TEXT and held against the oracle (CPU only; runs
+where /root/reference is present, i.e. in the build container -- the GPU box has no reference).
+
+The reference cannot be compiled here (no OpenCV / Eigen), but the bodies of its camera models and of g2o's stereo edge are plain
+scalar C++: assignments of arithmetic expressions over doubles, floats and a few libm calls.  This test cuts those bodies out of the
+sources where they lie, translates each statement mechanically (declared type -> rounding on assignment, `f` literals -> float32,
+`M(i,j)` -> indexing, atan2f / sqrtf -> float32 libm) and executes them with numpy scalars, whose promotion rules for float32 /
+float64 operands are C's.  Nothing of the reference is copied into the repository: the text is read, evaluated and compared.
+What it pins: that oracle/lba.cc's restatement of these formulas computes what the reference's text computes (to rounding), which
+the finite-difference tests cannot say (they only say the Jacobian belongs to the residual)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from multi_orbslam3_amd import _capi as capi
+from multi_orbslam3_amd import views
+from oracle import binding as ob
+
+REF = "/root/reference/src/orb_slam3_ros/orb_slam3"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference is only present in the build container")
+
+F32, F64 = np.float32, np.float64
+ENV = {
+    "F32": F32, "F64": F64,
+    "atan2f": lambda a, b: F32(np.arctan2(F32(a), F32(b))), "sqrtf": lambda a: F32(np.sqrt(F32(a))),
+    "atan2": lambda a, b: F64(np.arctan2(F64(a), F64(b))), "sqrt": lambda a: F64(np.sqrt(F64(a))),
+    "cos": lambda a: F64(np.cos(F64(a))), "sin": lambda a: F64(np.sin(F64(a))),
+}
+
+
+def _body(path, signature_regex):
+    """The text between the braces of the first function whose signature matches."""
+    text = open(path).read()
+    m = re.search(signature_regex, text)
+    assert m, signature_regex
+    i = text.index("{", m.end() - 1)
+    depth, j = 0, i
+    while True:
+        depth += text[j] == "{"
+        depth -= text[j] == "}"
+        if depth == 0:
+            break
+        j += 1
+    body = re.sub(r"/\*.*?\*/", " ", text[i + 1:j], flags=re.S)
+    return re.sub(r"//[^\n]*", " ", body)
+
+
+def _split_top(s, sep=","):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        depth += ch in "([{"
+        depth -= ch in ")]}"
+        if ch == sep and depth == 0:
+            out.append(cur); cur = ""
+        else:
+            cur += ch
+    out.append(cur)
+    return out
+
+
+def _expr(e, matrices):
+    e = re.sub(r"(?<![\w.])(\d+\.\d*|\.\d+|\d+)f\b", r"F32(\1)", e)                       # 1.0f, 0.f
+    e = re.sub(r"(?<![\w.(])(\d+\.\d*|\.\d+)(?![\w.)])", r"F64(\1)", e)                   # 1. , 0.5   (not inside F32(...))
+    for mname in matrices:
+        e = re.sub(r"\b%s\s*\(\s*(\d)\s*,\s*(\d)\s*\)" % re.escape(mname), r"%s[\1][\2]" % mname, e)
+    return e
+
+
+def run_cpp(body, env, matrices=(), skip=("return", "Eigen::", "Vector3d res", "VertexSE3Expmap", "VertexSBAPointXYZ", "SE3Quat T",
+                                          "Vector3d xyz", "const Matrix3d R")):
+    """Execute the scalar statements of a function body in `env` (variables pre-set by the caller)."""
+    env = dict(ENV, **env)
+    for st in (s.strip().replace("\n", " ") for s in body.split(";")):
+        if not st or any(st.startswith(k) or (" " + k) in (" " + st[:40]) for k in skip):
+            continue
+        m = re.match(r"^(?:const\s+)?(double|float)\s+(.*)$", st)
+        if m:
+            wrap = "F64" if m.group(1) == "double" else "F32"
+            for piece in _split_top(m.group(2)):
+                name, expr = piece.split("=", 1)
+                exec("%s = %s(%s)" % (name.strip(), wrap, _expr(expr, matrices)), env)
+            continue
+        lhs, expr = st.split("=", 1)
+        exec("%s = F64(%s)" % (_expr(lhs.strip(), matrices), _expr(expr, matrices)), env)
+    return env
+
+
+KB8 = (capi.CAM_KANNALA_BRANDT8, 190.978, 190.973, 254.932, 256.897, 0.00348, 0.000715, -0.00205, 0.000203)
+PIN = (capi.CAM_PINHOLE, 458.654, 457.296, 367.215, 248.375)
+
+
+def _points(n, seed):
+    rng = np.random.RandomState(seed)
+    return np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), rng.uniform(0.3, 8.0, n)], 1)
+
+
+@pytest.mark.parametrize("name,cam", [("KannalaBrandt8", KB8), ("Pinhole", PIN)])
+def test_camera_project_and_projectjac_are_the_references_text(name, cam):
+    path = os.path.join(REF, "src", "CameraModels", name + ".cpp")
+    proj = _body(path, r"Eigen::Vector2d\s+%s::project\s*\(\s*const\s+Eigen::Vector3d\s*&\s*v3D\s*\)\s*\{" % name)
+    jac = _body(path, r"Eigen::Matrix<double,\s*2,\s*3>\s+%s::projectJac\s*\(\s*const\s+Eigen::Vector3d\s*&\s*v3D\s*\)\s*\{" % name)
+    p = [F32(c) for c in cam[1:]]                                   # std::vector<float> mvParameters
+    jname = "JacGood" if name == "KannalaBrandt8" else "Jac"
+    for X in _points(300, 41):
+        v = [F64(x) for x in X]
+        e1 = run_cpp(proj, {"mvParameters": p, "v3D": v, "res": [F64(0), F64(0)]})
+        e2 = run_cpp(jac, {"mvParameters": p, "v3D": v, jname: [[F64(0)] * 3, [F64(0)] * 3]}, matrices=(jname,))
+        uv, J = ob.camera_project(cam, X)
+        # (KannalaBrandt8: theta and psi are float32 results of atan2f -- numpy's float32 arctan2 and this host's libm may differ in the
+        # last bit, ~1e-7 rad x 191 px; everything else is the same operations on the same values)
+        assert np.abs(np.array(e1["res"], np.float64) - uv).max() <= (1e-4 if name == "KannalaBrandt8" else 0.0), (X, e1["res"], uv)
+        Jr = np.array(e2[jname], np.float64)
+        assert np.abs(Jr - J).max() <= 4e-16 * max(1.0, np.abs(J).max()) * 64, (X, Jr, J)
+
+
+def test_stereo_edge_is_the_text_of_g2os_edge():
+    """g2o::EdgeStereoSE3ProjectXYZ: cam_project (float invz, float bf * invz) and linearizeOplus, G/types/types_six_dof_expmap.cpp."""
+    path = os.path.join(REF, "Thirdparty", "g2o", "g2o", "types", "types_six_dof_expmap.cpp")
+    proj = _body(path, r"Vector3d\s+EdgeStereoSE3ProjectXYZ::cam_project\s*\([^)]*\)\s*const\s*\{")
+    lin = _body(path, r"void\s+EdgeStereoSE3ProjectXYZ::linearizeOplus\s*\(\s*\)\s*\{")
+    fx, fy, cx, cy, bf = 458.654, 457.296, 367.215, 248.375, 47.906
+    rng = np.random.RandomState(42)
+    for _ in range(100):
+        q = np.array([0.03, -0.02, 0.04, 1.0]) + rng.randn(4) * 0.02; q /= np.linalg.norm(q)
+        t = rng.randn(3) * 0.2
+        X = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(1.5, 7.0)])
+        obs = (300.0, 200.0, 280.0)
+        e = np.zeros(1, capi.EDGE_DTYPE); e[0] = (0, 0, obs[0], obs[1], obs[2], 1.0)
+        err, A, B = ob.lba_edge_eval(q, t, X, (fx, fy, cx, cy, bf), e)
+        # T.map(X) and R = toRotationMatrix() from the quaternion (Eigen; pinned in tests/test_oracle_lba.py)
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        Xc = R @ X + t
+        # fx, fy, cx, cy are double members of the edge, bf a `const float&` argument (EdgeStereoSE3ProjectXYZ::fx .. bf, types_six_dof_expmap.h:168)
+        env = {"trans_xyz": [F64(c) for c in Xc], "fx": F64(F32(fx)), "fy": F64(F32(fy)), "cx": F64(F32(cx)), "cy": F64(F32(cy)), "bf": F32(bf),
+               "res": [F64(0)] * 3}
+        res = run_cpp(proj, env)["res"]
+        ref_err = np.array([F64(F32(obs[k])) - res[k] for k in range(3)])
+        assert np.abs(ref_err - err).max() < 1e-9, (ref_err, err)
+        env = {"xyz_trans": [F64(c) for c in Xc], "R": [[F64(v) for v in row] for row in R], "fx": F64(F32(fx)), "fy": F64(F32(fy)),
+               "bf": F64(F32(bf)), "_jacobianOplusXi": [[F64(0)] * 3 for _ in range(3)], "_jacobianOplusXj": [[F64(0)] * 6 for _ in range(3)]}
+        out = run_cpp(lin, env, matrices=("_jacobianOplusXi", "_jacobianOplusXj", "R"))
+        Ai, Bj = np.array(out["_jacobianOplusXi"], np.float64), np.array(out["_jacobianOplusXj"], np.float64)
+        assert np.abs(Ai - A).max() < 1e-9 * max(1.0, np.abs(A).max()) and np.abs(Bj - B).max() < 1e-9 * max(1.0, np.abs(B).max())
+
+
+def _se3deriv(body, x, y, z):
+    """The `SE3deriv << ...;` comma initialiser of a linearizeOplus body (3 x 6, row-major), evaluated at (x, y, z)."""
+    m = re.search(r"SE3deriv\s*<<(.*?);", body, flags=re.S)
+    assert m
+    vals = [eval(_expr(v.strip(), ()), dict(ENV, x=F64(x), y=F64(y), z=F64(z), x_w=F64(x), y_w=F64(y), z_w=F64(z))) for v in _split_top(m.group(1).replace("\n", " "))]
+    assert len(vals) == 18
+    return np.array(vals, np.float64).reshape(3, 6)
+
+
+def _text_jac(name, cam, X):
+    path = os.path.join(REF, "src", "CameraModels", name + ".cpp")
+    jac = _body(path, r"Eigen::Matrix<double,\s*2,\s*3>\s+%s::projectJac\s*\(\s*const\s+Eigen::Vector3d\s*&\s*v3D\s*\)\s*\{" % name)
+    jname = "JacGood" if name == "KannalaBrandt8" else "Jac"
+    e = run_cpp(jac, {"mvParameters": [F32(c) for c in cam[1:]], "v3D": [F64(c) for c in X], jname: [[F64(0)] * 3, [F64(0)] * 3]}, matrices=(jname,))
+    return np.array(e[jname], np.float64)
+
+
+def _R_of(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.parametrize("right", [False, True])
+def test_camera_model_edges_are_built_from_the_references_text(right):
+    """EdgeSE3ProjectXYZ / EdgeSE3ProjectXYZToBody::linearizeOplus (S/OptimizableTypes.cpp:139-160, 192-214): the `SE3deriv << ...`
+    initialiser and KannalaBrandt8::projectJac are EVALUATED from the reference's text; how the body composes them (which point enters
+    projectJac, which rotation multiplies it) is read off the same lines:  Xi = -projectJac(X) * R,  Xj = -projectJac(X) [* R(mTrl)] * SE3deriv."""
+    from multi_orbslam3_amd import synth
+    fn = "EdgeSE3ProjectXYZToBody" if right else "EdgeSE3ProjectXYZ"
+    body = _body(os.path.join(REF, "src", "OptimizableTypes.cpp"), r"void\s+%s::linearizeOplus\s*\(\s*\)\s*\{" % fn)
+    assert ("mTrl.rotation().toRotationMatrix() * SE3deriv" in body) == right and "pCamera->projectJac" in body
+    Trl = synth.rig_Trl().astype(np.float32)
+    rig = views.camera_rig(synth.KB8_LEFT, synth.KB8_RIGHT, Trl)
+    Rrl = Trl[:3, :3].astype(np.float64)
+    # (Converter::toSE3Quat goes through a quaternion: the rotation the oracle uses is the orthonormalised one)
+    qrl = np.array([Rrl[2, 1] - Rrl[1, 2], Rrl[0, 2] - Rrl[2, 0], Rrl[1, 0] - Rrl[0, 1], 0.0])
+    w = np.sqrt(max(0.0, 1 + np.trace(Rrl))) / 2
+    qrl = np.append(qrl[:3] / (4 * w), w); qrl /= np.linalg.norm(qrl)
+    Rrl_q = _R_of(qrl)
+    rng = np.random.RandomState(43 + right)
+    for _ in range(60):
+        q = np.array([0.03, -0.02, 0.04, 1.0]) + rng.randn(4) * 0.02; q /= np.linalg.norm(q)
+        t = rng.randn(3) * 0.2
+        X = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(1.5, 7.0)])
+        e = np.zeros(1, capi.EDGE_DTYPE); e[0] = (0, 0, 250.0, 260.0, capi.UR_RIGHT_CAMERA if right else -1.0, 1.0)
+        err, A, B, Xobs = ob.lba_edge_eval_rig(q, t, X, (1, 1, 0, 0, 0), rig, e)
+        R = _R_of(q)
+        Xl = R @ X + t
+        S = _se3deriv(body, *Xl)
+        if right:
+            Xr = Rrl_q @ Xl + Trl[:3, 3].astype(np.float64)
+            J = _text_jac("KannalaBrandt8", synth.KB8_RIGHT, Xr)
+            A_ref, B_ref = -J @ (Rrl_q @ R), -J @ Rrl_q @ S
+        else:
+            J = _text_jac("KannalaBrandt8", synth.KB8_LEFT, Xl)
+            A_ref, B_ref = -J @ R, -J @ S
+        assert np.abs(A_ref - A[:2]).max() < 1e-8 * max(1.0, np.abs(A).max()), (A_ref, A)
+        assert np.abs(B_ref - B[:2]).max() < 1e-8 * max(1.0, np.abs(B).max()), (B_ref, B)
+
+
+def test_descriptor_distance_bit_hack_is_a_population_count():
+    """ORBmatcher::DescriptorDistance (S/ORBmatcher.cc:2358-2374): the three statements of its loop body, evaluated from the text on
+    uint32 words, against the oracle's Hamming distance."""
+    body = _body(os.path.join(REF, "src", "ORBmatcher.cc"), r"int\s+ORBmatcher::DescriptorDistance\s*\([^)]*\)\s*\{")
+    loop = body[body.index("{", body.index("for")) + 1:body.rindex("}")]
+    stmts = [re.sub(r"\s+", " ", s.strip()) for s in loop.split(";") if s.strip()]
+    assert len(stmts) == 4 and stmts[0].startswith("unsigned int v") and stmts[3].startswith("dist +=")
+    rng = np.random.RandomState(44)
+    for _ in range(200):
+        a = rng.randint(0, 256, 32).astype(np.uint8); b = rng.randint(0, 256, 32).astype(np.uint8)
+        pa, pb = a.view(np.uint32), b.view(np.uint32)
+        dist = 0
+        for i in range(8):
+            env = {"v": 0, "dist": dist, "pa_": int(pa[i]), "pb_": int(pb[i])}
+            for st in stmts:
+                st = st.replace("unsigned int ", "").replace("*pa", "pa_").replace("*pb", "pb_")
+                # (unsigned int arithmetic wraps at 32 bits: every product / sum is masked where C would wrap it)
+                st = st.replace("* 0x1010101)", "* 0x1010101 & 0xFFFFFFFF)")
+                if st.startswith("dist +="):
+                    exec("dist += " + st.split("+=", 1)[1], env)
+                else:
+                    name, expr = st.split("=", 1)
+                    exec("%s = (%s) & 0xFFFFFFFF" % (name.strip(), expr), env)
+            dist = env["dist"]
+        assert dist == ob.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
