@@ -235,3 +235,136 @@ def test_descriptor_distance_bit_hack_is_a_population_count():
                     exec("%s = (%s) & 0xFFFFFFFF" % (name.strip(), expr), env)
             dist = env["dist"]
         assert dist == ob.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+
+
+# ---------------------------------------------------------------------------------------------- statements with loops
+class CBlock:
+    """A slightly larger subset of C for bodies with counted loops: `for (int i = A; i < B; i++) { ... }`, declarations, assignments,
+    compound assignments (`+=`, `*=`: evaluated in the C type of the left side), element assignments into typed arrays, casts of the
+    form `(float)name` / `(double)name`.  types: C type of every variable the text does not declare itself ('float', 'double', 'int',
+    'float[]', 'int[]')."""
+
+    WRAP = {"float": "F32", "double": "F64", "int": "I32", "float[]": "F32", "int[]": "I32", "double[]": "F64"}
+
+    def __init__(self, env, types, skip=()):
+        self.env = dict(ENV, I32=lambda a: int(a), **env)
+        self.env.setdefault("max", max)
+        self.types = dict(types)
+        self.skip = tuple(skip)
+
+    def _e(self, e):
+        e = e.replace("std::max", "max")
+        e = re.sub(r"\(\s*(float|double)\s*\)\s*pow\s*\(", lambda m: "%s(pow_(" % self.WRAP[m.group(1)], e)
+        # (the call's closing parenthesis closes pow_: add one for the cast)
+        if "pow_(" in e:
+            i = e.index("pow_(") + 5
+            depth = 1
+            while depth:
+                depth += e[i] == "("
+                depth -= e[i] == ")"
+                i += 1
+            e = e[:i] + ")" + e[i:]
+        e = re.sub(r"\(\s*(float|double)\s*\)\s*(\w+)", lambda m: "%s(%s)" % (self.WRAP[m.group(1)], m.group(2)), e)
+        return _expr(e, ())
+
+    def _assign(self, lhs, expr):
+        lhs = lhs.strip()
+        base = re.match(r"\w+", lhs).group(0)
+        t = self.types[base + "[]"] if "[" in lhs and base + "[]" in self.types else self.types.get(base)
+        if "[" in lhs and t is None:
+            t = self.types[base]
+        exec("%s = %s(%s)" % (lhs, self.WRAP[t], self._e(expr)), self.env)
+
+    def stmt(self, st):
+        st = re.sub(r"\s+", " ", st.strip())
+        if not st or any(k in st for k in self.skip):
+            return
+        m = re.match(r"^(?:const )?(float|double|int) (\w+) ?= ?(.*)$", st)
+        if m:
+            self.types[m.group(2)] = m.group(1)
+            return self._assign(m.group(2), m.group(3))
+        m = re.match(r"^(.+?) ?([+*-])= ?(.*)$", st)
+        if m and "==" not in st and not st.split("=")[0].rstrip().endswith(("<", ">", "!")):
+            return self._assign(m.group(1), "%s %s (%s)" % (m.group(1), m.group(2), m.group(3)))
+        lhs, expr = st.split("=", 1)
+        self._assign(lhs, expr)
+
+    def run(self, text):
+        i = 0
+        while i < len(text):
+            m = re.compile(r"\s*for\s*\(\s*int\s+(\w+)\s*=\s*([^;]+);\s*\1\s*<\s*([^;]+);\s*\1\+\+\s*\)\s*\{").match(text, i)
+            if m:
+                j, depth = m.end(), 1
+                while depth:
+                    depth += text[j] == "{"
+                    depth -= text[j] == "}"
+                    j += 1
+                lo, hi = int(eval(self._e(m.group(2)), self.env)), int(eval(self._e(m.group(3)), self.env))
+                self.types[m.group(1)] = "int"
+                for k in range(lo, hi):
+                    self.env[m.group(1)] = k
+                    self.run(text[m.end():j - 1])
+                i = j
+                continue
+            j = text.find(";", i)
+            if j < 0:
+                break
+            self.stmt(text[i:j])
+            i = j + 1
+        return self.env
+
+
+def _cv_round(x):        # cvRound: nearest, ties to even (lrint)
+    return int(np.rint(np.float64(x)))
+
+
+@pytest.mark.parametrize("nfeatures,scale,nlevels", [(1000, 1.2, 8), (2000, 1.2, 8), (1500, 1.1, 12), (500, 1.4, 5)])
+def test_extractor_scale_tables_and_feature_quotas_are_the_constructors_text(nfeatures, scale, nlevels):
+    """ORBextractor::ORBextractor (S/ORBextractor.cc:408-445): mvScaleFactor / mvLevelSigma2 / their inverses as cumulative float32
+    products and the per-level feature quotas, executed from the constructor's text, against the oracle's tables -- bit for bit."""
+    body = _body(os.path.join(REF, "src", "ORBextractor.cc"), r"iniThFAST\(_iniThFAST\),\s*minThFAST\(_minThFAST\)\s*\{")
+    body = body[:body.index("const int npoints")]
+    arr = lambda: [F32(0)] * nlevels
+    env = {"nfeatures": nfeatures, "scaleFactor": F32(scale), "nlevels": nlevels, "mvScaleFactor": arr(), "mvLevelSigma2": arr(),
+           "mvInvScaleFactor": arr(), "mvInvLevelSigma2": arr(), "mnFeaturesPerLevel": [0] * nlevels, "cvRound": _cv_round,
+           "pow_": lambda a, b: F64(np.power(F64(a), F64(b)))}
+    types = {"nfeatures": "int", "scaleFactor": "float", "nlevels": "int", "mvScaleFactor": "float[]", "mvLevelSigma2": "float[]",
+             "mvInvScaleFactor": "float[]", "mvInvLevelSigma2": "float[]", "mnFeaturesPerLevel": "int[]"}
+    out = CBlock(env, types, skip=(".resize(",)).run(body)
+    sc, isc, sg, isg, quota = ob.Extractor(n_features=nfeatures, scale_factor=scale, n_levels=nlevels).tables()
+    for mine, theirs, key in ((out["mvScaleFactor"], sc, "scale"), (out["mvInvScaleFactor"], isc, "inv_scale"),
+                              (out["mvLevelSigma2"], sg, "sigma2"), (out["mvInvLevelSigma2"], isg, "inv_sigma2")):
+        assert np.array_equal(np.array(mine, np.float32), theirs), (key, mine, theirs)
+    assert list(out["mnFeaturesPerLevel"]) == list(quota) and sum(quota) == nfeatures
+
+
+def test_grid_cell_of_a_keypoint_is_posingrids_text():
+    """Frame::PosInGrid (S/Frame.cc:699-709): the two rounding statements and the bounds test, executed from the text in float32, against
+    the cell the oracle's grid files every keypoint under (cell id = posX * 48 + posY; a keypoint outside the grid is in no cell)."""
+    body = _body(os.path.join(REF, "src", "Frame.cc"), r"bool\s+Frame::PosInGrid\s*\([^)]*\)\s*\{")
+    two = body[:body.index("if")].replace("kp.pt.x", "kp_x").replace("kp.pt.y", "kp_y")
+    cond = re.search(r"if\s*\((.*?)\)\s*return false", body, flags=re.S).group(1)
+    assert two.count("round(") == 2 and "FRAME_GRID_COLS" in cond
+    rng = np.random.RandomState(45)
+    n = 3000
+    bounds = (-12.5, 655.25, -7.75, 490.5)                 # undistorted image bounds reach outside the image (S/Frame.cc:767-783)
+    kps = np.zeros(n, capi.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(bounds[0] - 4, bounds[1] + 4, n).astype(np.float32); kps["y"] = rng.uniform(bounds[2] - 4, bounds[3] + 4, n).astype(np.float32)
+    kps["x"][:200] = np.float32(bounds[0]) + np.arange(200, dtype=np.float32) * np.float32((bounds[1] - bounds[0]) / 128.0)   # cell borders: ties of round()
+    fv, keep = views.frame_view(kps, np.zeros((n, 32), np.uint8), bounds=bounds, cam=(458.6, 457.3, 367.2, 248.4, 47.9, 0.1))
+    start, items = ob.build_grid(fv)
+    cell_of = np.full(n, -1)
+    for c in range(capi.GRID_COLS * capi.GRID_ROWS):
+        cell_of[items[start[c]:start[c + 1]]] = c
+    inv_w = F32(F32(capi.GRID_COLS) / F32(F32(bounds[1]) - F32(bounds[0])))       # S/Frame.cc:137-138
+    inv_h = F32(F32(capi.GRID_ROWS) / F32(F32(bounds[3]) - F32(bounds[2])))
+    c_round = lambda a: type(a)(np.copysign(np.floor(np.abs(a) + type(a)(0.5)), a))      # round(): half away from zero
+    n_out = 0
+    for i in range(n):
+        env = {"kp_x": F32(kps["x"][i]), "kp_y": F32(kps["y"][i]), "mnMinX": F32(bounds[0]), "mnMinY": F32(bounds[2]),
+               "mfGridElementWidthInv": inv_w, "mfGridElementHeightInv": inv_h, "round": c_round, "posX": 0, "posY": 0}
+        out = CBlock(env, {"posX": "int", "posY": "int"}).run(two)
+        outside = eval(cond.replace("||", " or "), dict(out, FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS))
+        n_out += bool(outside)
+        assert cell_of[i] == (-1 if outside else out["posX"] * capi.GRID_ROWS + out["posY"]), (i, kps[i], out["posX"], out["posY"], cell_of[i])
+    assert 20 < n_out < 300
