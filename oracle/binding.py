@@ -108,6 +108,25 @@ def fast_atan2(y, x):
     return float(lib().oracle_fast_atan2(C.c_float(y), C.c_float(x)))
 
 
+def orb_descriptor(img, x, y, angle_deg):
+    """computeOrbDescriptor of the keypoint (x, y, angle) on the (already blurred) image img."""
+    img = np.ascontiguousarray(img, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().oracle_orb_descriptor(C.c_float(angle_deg), C.c_void_p(img.ctypes.data), img.shape[1], int(x), int(y), C.c_void_p(d.ctypes.data))
+    return d
+
+
+def three_maxima(bin_sizes):
+    b = np.ascontiguousarray(bin_sizes, np.int32)
+    out = np.zeros(3, np.int32)
+    lib().oracle_three_maxima(C.c_void_p(b.ctypes.data), len(b), C.c_void_p(out.ctypes.data))
+    return [int(v) for v in out]
+
+
+def rot_bin(a, b):
+    return int(lib().oracle_rot_bin(C.c_float(a), C.c_float(b)))
+
+
 def hamming(a, b):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     b = np.ascontiguousarray(b, dtype=np.uint8)
@@ -142,6 +161,12 @@ class Extractor:
         arrs = [np.zeros(nl, np.float32) for _ in range(4)] + [np.zeros(nl, np.int32)]
         _chk(lib().oracle_get_tables(self.h, *[C.c_void_p(a.ctypes.data) for a in arrs]))
         return arrs
+
+    def ic_angle(self, img, x, y):
+        """IC_Angle of the keypoint (x, y) on the level image img (degrees)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        lib().oracle_ic_angle.restype = C.c_float
+        return float(lib().oracle_ic_angle(self.h, C.c_void_p(img.ctypes.data), img.shape[1], int(x), int(y)))
 
     def umax(self):
         u = np.zeros(16, np.int32)

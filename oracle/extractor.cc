@@ -536,6 +536,16 @@ static void orb_descriptor(float kp_angle, const uint8_t* center, int step, uint
   }
 }
 
+// IC_Angle of one keypoint on a caller-supplied level image, for the known-answer tests: the radius-15 disc must lie inside
+extern "C" float oracle_ic_angle(const oracle_extractor* e, const uint8_t* img, int stride, int x, int y) {
+  return ic_angle(img + (size_t)y * stride + x, stride, e->umax);
+}
+
+// one descriptor on a caller-supplied (already blurred) image, for the known-answer tests: the patch around (x, y) must lie inside
+extern "C" void oracle_orb_descriptor(float kp_angle_deg, const uint8_t* img, int stride, int x, int y, uint8_t* desc32) {
+  orb_descriptor(kp_angle_deg, img + (size_t)y * stride + x, stride, desc32);
+}
+
 // ORBextractor::operator() -- S/ORBextractor.cc:1068-1150 (ComputeKeyPointsOctTree :763-878 inlined).
 extern "C" int oracle_extract(oracle_extractor* e, const uint8_t* img, int width, int height, int stride,
                               int lap0, int lap1, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out,

@@ -188,6 +188,16 @@ inline int rot_bin(float a1, float a2) {   // S/ORBmatcher.cc:2082-2087 (factor 
 }
 }  // namespace
 
+// the two pieces of the rotation-consistency check, for the known-answer tests
+extern "C" void oracle_three_maxima(const int32_t* bin_sizes, int L, int32_t* ind3) {
+  std::vector<std::vector<int>> h(L);
+  for (int i = 0; i < L; i++) h[i].assign((size_t)bin_sizes[i], 0);
+  int a = -1, b = -1, c = -1;
+  three_maxima(h.data(), L, a, b, c);
+  ind3[0] = a; ind3[1] = b; ind3[2] = c;
+}
+extern "C" int oracle_rot_bin(float angle_a, float angle_b) { return rot_bin(angle_a, angle_b); }
+
 // ORBmatcher::DescriptorDistance -- S/ORBmatcher.cc:2358-2374
 extern "C" int oracle_hamming(const uint8_t* a, const uint8_t* b) {
   int dist = 0;

@@ -40,6 +40,10 @@ void oracle_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_
 void oracle_gaussian_blur7_taps(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, const int* taps4);
 float oracle_fast_atan2(float y, float x);
 int  oracle_hamming(const uint8_t* a, const uint8_t* b);
+/* IC_Angle (S/ORBextractor.cc:75-102) of one keypoint on a level image; the radius-15 disc must lie inside */
+float oracle_ic_angle(const oracle_extractor* e, const uint8_t* img, int stride, int x, int y);
+/* computeOrbDescriptor (S/ORBextractor.cc:105-145) of one keypoint on an already blurred image; the 31 x 31 patch must lie inside */
+void oracle_orb_descriptor(float kp_angle_deg, const uint8_t* img, int stride, int x, int y, uint8_t* desc32);
 
 /* ---- extractor (S/ORBextractor.cc) */
 int oracle_extractor_create(const orbx_config* cfg, oracle_extractor** out);
@@ -73,6 +77,10 @@ int oracle_is_in_frustum(const orbm_frame_view* view, const float* Tcw, const or
                          float* proj_xr, float* track_depth, int32_t* scale_level, float* view_cos);
 
 /* ---- matchers (S/ORBmatcher.cc) */
+/* ORBmatcher::ComputeThreeMaxima (:2312-2353) on the bin sizes of a rotation histogram (ind1..3 start at -1), and the bin of a pair of
+ * keypoint angles (:2082-2087 with factor = 1.0f / HISTO_LENGTH, :1978) */
+void oracle_three_maxima(const int32_t* bin_sizes, int L, int32_t* ind3);
+int  oracle_rot_bin(float angle_a, float angle_b);
 int oracle_hamming_matrix(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* dist);
 int oracle_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out4);
 int oracle_search_by_projection_mps(const orbm_frame_view* view, const orbm_mappoints_view* mps, float th,

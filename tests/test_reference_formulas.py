@@ -368,3 +368,185 @@ def test_grid_cell_of_a_keypoint_is_posingrids_text():
         n_out += bool(outside)
         assert cell_of[i] == (-1 if outside else out["posX"] * capi.GRID_ROWS + out["posY"]), (i, kps[i], out["posX"], out["posY"], cell_of[i])
     assert 20 < n_out < 300
+
+
+def test_rbrief_descriptor_is_computeorbdescriptors_text():
+    """computeOrbDescriptor (S/ORBextractor.cc:104-145): factorPI, the steering (float cos / sin of the float angle), the GET_VALUE macro
+    (cvRound of float32 sums, row * step + column) and the sixteen comparisons per byte, all taken from the text -- with the 256 point
+    pairs of bit_pattern_31_ parsed from the same file -- against the oracle's descriptor of the same keypoint: 32 bytes, bit for bit."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.cosf.restype = libm.sinf.restype = ctypes.c_float
+    libm.cosf.argtypes = libm.sinf.argtypes = [ctypes.c_float]
+    text = re.sub(r"//[^\n]*", " ", open(os.path.join(REF, "src", "ORBextractor.cc")).read())
+    m = re.search(r"static int bit_pattern_31_\[256\*4\]\s*=\s*\{(.*?)\};", text, flags=re.S)
+    nums = [int(v) for v in re.findall(r"-?\d+", re.sub(r"/\*.*?\*/", " ", m.group(1), flags=re.S))]
+    assert len(nums) == 1024
+    pattern_all = [(nums[2 * k], nums[2 * k + 1]) for k in range(512)]            # const Point* pattern = (const Point*)bit_pattern_31_
+    fpi = re.search(r"const float factorPI\s*=\s*(.*?);", text).group(1)
+    factorPI = eval(_expr(fpi.replace("(float)", "F32"), ()), dict(ENV, CV_PI=F64(3.1415926535897932384626433832795)))
+    assert isinstance(factorPI, np.float32)
+    body = _body(os.path.join(REF, "src", "ORBextractor.cc"), r"static void computeOrbDescriptor\s*\([^)]*\)\s*\{")
+    macro = re.search(r"#define GET_VALUE\(idx\)(.*?)\n\s*\n", body, flags=re.S).group(1).replace("\\", " ")
+    macro = re.sub(r"pattern\[idx\]\.x", "pattern[idx][0]", re.sub(r"pattern\[idx\]\.y", "pattern[idx][1]", macro))
+    head = [st.strip() for st in body[:body.index("const uchar* center")].split(";") if st.strip()]
+    assert head[0].startswith("float angle") and head[1].startswith("float a")
+    loop = body[body.index("{", body.index("for (int i = 0; i < 32")) + 1:body.index("#undef")]
+    stmts = [re.sub(r"\s+", " ", st.strip()) for st in loop[:loop.rindex("}")].split(";") if st.strip()]
+    assert stmts[0] == "int t0, t1, val" and stmts[-1] == "desc[i] = (uchar)val" and sum("GET_VALUE" in st for st in stmts) == 16
+
+    class Center:
+        def __init__(self, img, y, x): self.f, self.o = img.reshape(-1), y * img.shape[1] + x
+        def __getitem__(self, off): return int(self.f[self.o + int(off)])
+
+    typed = {"cos": lambda v: F32(libm.cosf(float(v))), "sin": lambda v: F32(libm.sinf(float(v)))}     # cos(float) / sin(float): the float overloads
+    rng = np.random.RandomState(46)
+    for trial in range(60):
+        img = rng.randint(0, 256, (64, 72)).astype(np.uint8)
+        x, y = int(rng.randint(20, 50)), int(rng.randint(20, 44))
+        ang = F32(rng.uniform(0, 360)) if trial else F32(0.0)
+        env = dict(ENV, **typed)
+        env.update(kpt_angle=ang, factorPI=factorPI)
+        exec("angle = F32(" + head[0].split("=", 1)[1].replace("(float)kpt.angle", "F32(kpt_angle)") + ")", env)
+        for piece in _split_top(head[1][len("float "):]):
+            name, expr = piece.split("=", 1)
+            exec("%s = F32(%s)" % (name.strip(), expr.replace("(float)", "")), env)            # (float)cos(angle): a cast of cos(float)'s float result
+        assert isinstance(env["a"], np.float32) and isinstance(env["b"], np.float32)
+        env.update(center=Center(img, y, x), step=img.shape[1], cvRound=_cv_round, desc=[0] * 32)
+        for i in range(32):
+            env["pattern"] = pattern_all[16 * i:16 * i + 16]
+            env["i"] = i
+            exec("GET_VALUE = lambda idx: " + macro.strip(), env)
+            for st in stmts[1:]:
+                exec(st.replace("(uchar)val", "int(val) & 255"), env)
+        assert np.array_equal(np.array(env["desc"], np.uint8), ob.orb_descriptor(img, x, y, float(ang))), (trial, x, y, ang)
+
+
+# ---------------------------------------------------------------------------------------------- integer code with nested loops
+def cond_fix(c):
+    """A C condition as Python: float32 literals and `(float)name` casts as in _expr, && / || as and / or."""
+    c = re.sub(r"\(float\)\s*(\w+)", r"F32(\1)", c)
+    return _expr(c, ()).replace("&&", " and ").replace("||", " or ")
+
+
+def c_to_python(body, indent="    "):
+    """Transliterates a C body of integer statements with counted `for` loops (`for (int v = A; v <= B; ++v)`, braced or single-statement
+    bodies) into Python source: loops become range() loops, `int a = x, b = y` becomes two assignments, everything else is left as it
+    stands (C's integer expressions over small values are Python's)."""
+    out, depth, i = [], 0, 0
+    body = re.sub(r"\s+", " ", body)
+    pending = []          # loops opened without a brace: closed after the next statement
+
+    def emit(line):
+        out.append(indent * depth + line)
+
+    while i < len(body):
+        if body[i] in " ":
+            i += 1; continue
+        m = re.compile(r"for ?\( ?int (\w+) ?= ?([^;]+); ?\1 ?(<=|<) ?([^;]+); ?(?:\+\+\1|\1\+\+) ?\)\s*(\{?)").match(body, i)
+        if m:
+            hi = m.group(4) if m.group(3) == "<" else "(%s) + 1" % m.group(4)
+            emit("for %s in range(%s, %s):" % (m.group(1), m.group(2), hi))
+            depth += 1
+            pending.append(m.group(5) == "")
+            i = m.end()
+            continue
+        m = re.compile(r"(else if|if|else)\s*(\()?").match(body, i)
+        if m and (m.group(1) == "else" or m.group(2)):
+            j = m.end()
+            cond = ""
+            if m.group(2):
+                d2 = 1
+                while d2:
+                    d2 += body[j] == "("
+                    d2 -= body[j] == ")"
+                    j += 1
+                cond = body[m.end():j - 1]
+            kw = {"if": "if", "else if": "elif", "else": "else"}[m.group(1)]
+            emit("%s%s:" % (kw, (" " + cond_fix(cond)) if cond else ""))
+            depth += 1
+            k = j
+            while body[k] == " ":
+                k += 1
+            pending.append(body[k] != "{")
+            i = k + (body[k] == "{")
+            continue
+        if body[i] == "}":
+            depth -= 1; pending.pop(); i += 1
+            continue
+        j = body.index(";", i)
+        st = body[i:j].strip()
+        i = j + 1
+        if st.startswith("return") or st.startswith("const uchar*"):
+            continue
+        m = re.match(r"^int (.*)$", st)
+        if m:
+            for piece in _split_top(m.group(1)):
+                emit(_expr(re.sub(r"\(int\)", "", piece.strip()), ()))
+        else:
+            emit(_expr(re.sub(r"\(int\)", "", st), ()))
+        while pending and pending[-1]:
+            depth -= 1; pending.pop()
+    return "\n".join(out)
+
+
+def test_keypoint_orientation_moments_are_ic_angles_text():
+    """IC_Angle (S/ORBextractor.cc:75-102): the integer moments m_01 / m_10 over the radius-15 disc, computed by the function's own
+    loops (transliterated statement by statement), then cv::fastAtan2 as the oracle restates it -- against the oracle's angle."""
+    body = _body(os.path.join(REF, "src", "ORBextractor.cc"), r"static float IC_Angle\s*\([^)]*\)\s*\{")
+    src = c_to_python(body)
+    assert src.count("for ") == 3 and "m_01 += v * v_sum" in src and "image.step1()" in src
+    ext = ob.Extractor()
+    umax = [int(v) for v in ext.umax()]
+    assert umax == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+
+    class Center:
+        def __init__(self, img, y, x): self.f, self.o = img.reshape(-1), y * img.shape[1] + x
+        def __getitem__(self, off): return int(self.f[self.o + off])
+
+    class Image:
+        def __init__(self, img): self.img = img
+        def step1(self): return self.img.shape[1]
+
+    rng = np.random.RandomState(47)
+    for trial in range(40):
+        img = rng.randint(0, 256, (48, 56)).astype(np.uint8)
+        if trial % 4 == 0:
+            img = (np.add.outer(np.arange(48) * rng.randint(-3, 4), np.arange(56) * rng.randint(-3, 4)) % 256).astype(np.uint8)   # strong gradients
+        x, y = int(rng.randint(16, 40)), int(rng.randint(16, 32))
+        env = {"center": Center(img, y, x), "image": Image(img), "u_max": umax, "HALF_PATCH_SIZE": 15}
+        exec(src, env)
+        ang = ob.fast_atan2(float(env["m_01"]), float(env["m_10"]))
+        assert ang == ext.ic_angle(img, x, y), (trial, env["m_01"], env["m_10"], ang)
+
+
+def test_rotation_histogram_pieces_are_the_references_text():
+    """ORBmatcher::ComputeThreeMaxima (S/ORBmatcher.cc:2312-2353, its float32 `0.1f * (float)max1` tests included) and the histogram bin
+    of a matched pair (:2082-2087 with `factor = 1.0f/HISTO_LENGTH`, :1978), transliterated from the text, against the oracle."""
+    body = _body(os.path.join(REF, "src", "ORBmatcher.cc"), r"void\s+ORBmatcher::ComputeThreeMaxima\s*\([^)]*\)\s*\{")
+    src = c_to_python(body.replace("const int s = histo[i].size()", "int s = histo[i]"))
+    assert src.count("elif") == 3 and "F32(0.1)" in src
+    rng = np.random.RandomState(48)
+    for trial in range(300):
+        L = 30
+        h = rng.randint(0, [3, 12, 60][trial % 3], L)
+        if trial % 5 == 0:
+            h[rng.randint(0, L)] = 200                      # one dominant bin: the 10 % tests fire
+        if trial % 7 == 0:
+            h[:] = 0
+        env = {"histo": [int(v) for v in h], "L": L, "ind1": -1, "ind2": -1, "ind3": -1, "F32": F32}
+        exec(src, env)
+        assert [env["ind1"], env["ind2"], env["ind3"]] == ob.three_maxima(h), (trial, h)
+    text = open(os.path.join(REF, "src", "ORBmatcher.cc")).read()
+    i0 = text.index("float rot = kpLF.angle-kpCF.angle;")
+    piece = text[i0:text.index("assert(bin>=0", i0)].replace("kpLF.angle", "aL").replace("kpCF.angle", "aC")
+    src2 = c_to_python(piece.replace("float rot =", "rot =").replace("int bin =", "bin ="))
+    factor = F32(F32(1.0) / 30)                            # const float factor = 1.0f/HISTO_LENGTH
+    c_round = lambda a: int(np.copysign(np.floor(np.abs(F64(a)) + 0.5), a))
+    for _ in range(2000):
+        aL, aC = F32(rng.uniform(0, 360)), F32(rng.uniform(0, 360))
+        if rng.rand() < 0.1:
+            aC = F32((float(aL) + 345.0 + rng.choice([-1e-4, 0, 1e-4])) % 360)            # bin borders (15 degrees past a multiple of 30)
+        env = {"aL": aL, "aC": aC, "factor": factor, "round": c_round, "HISTO_LENGTH": 30, "F32": F32, "F64": F64}
+        exec(src2, env)
+        assert env["bin"] == ob.rot_bin(float(aL), float(aC)), (aL, aC, env["bin"])
