@@ -108,6 +108,14 @@ def fast_atan2(y, x):
     return float(lib().oracle_fast_atan2(C.c_float(y), C.c_float(x)))
 
 
+def fast_cell_grid(level_w, level_h):
+    """The cells of ComputeKeyPointsOctTree at a level of that size: (n x {x0, x1, y0, y1, row, column}, wCell, hCell)."""
+    r = np.zeros((4096, 6), np.int32)
+    wc, hc = C.c_int32(0), C.c_int32(0)
+    n = lib().oracle_fast_cell_grid(int(level_w), int(level_h), C.c_void_p(r.ctypes.data), 4096, C.byref(wc), C.byref(hc))
+    return r[:n].copy(), wc.value, hc.value
+
+
 def orb_descriptor(img, x, y, angle_deg):
     """computeOrbDescriptor of the keypoint (x, y, angle) on the (already blurred) image img."""
     img = np.ascontiguousarray(img, np.uint8)

@@ -497,6 +497,35 @@ extern "C" int oracle_distribute_octree(const int32_t* xys, int n, int min_x, in
   return (int)keep.size();
 }
 
+// The cells cv::FAST is run on, level by level: ComputeKeyPointsOctTree's tiling, S/ORBextractor.cc:771-804 (W = 30, +6 px of overlap,
+// the float / int mix of the reference kept).  [x0, x1) x [y0, y1) in level coordinates; (i, j) = the cell's row and column.
+struct FastCell { int x0, x1, y0, y1, i, j; };
+static bool level_cells(int lw, int lh, std::vector<FastCell>& out, int* w_cell, int* h_cell) {
+  const float W = 30;
+  const int minBorderX = kEdge - 3, minBorderY = minBorderX;
+  const int maxBorderX = lw - kEdge + 3;
+  const int maxBorderY = lh - kEdge + 3;
+  const float fw = (float)(maxBorderX - minBorderX), fh = (float)(maxBorderY - minBorderY);
+  const int nCols = (int)(fw / W), nRows = (int)(fh / W);
+  if (nCols < 1 || nRows < 1) return false;
+  const int wCell = (int)std::ceil(fw / nCols), hCell = (int)std::ceil(fh / nRows);
+  *w_cell = wCell; *h_cell = hCell;
+  for (int i = 0; i < nRows; i++) {
+    const float iniY = (float)(minBorderY + i * hCell);
+    float maxY = iniY + hCell + 6;
+    if (iniY >= maxBorderY - 3) continue;
+    if (maxY > maxBorderY) maxY = (float)maxBorderY;
+    for (int j = 0; j < nCols; j++) {
+      const float iniX = (float)(minBorderX + j * wCell);
+      float maxX = iniX + wCell + 6;
+      if (iniX >= maxBorderX - 6) continue;
+      if (maxX > maxBorderX) maxX = (float)maxBorderX;
+      out.push_back(FastCell{(int)iniX, (int)maxX, (int)iniY, (int)maxY, i, j});
+    }
+  }
+  return true;
+}
+
 // IC_Angle -- S/ORBextractor.cc:75-102
 static float ic_angle(const uint8_t* center, int step, const int* umax) {
   int m_01 = 0, m_10 = 0;
@@ -536,6 +565,20 @@ static void orb_descriptor(float kp_angle, const uint8_t* center, int step, uint
   }
 }
 
+// the FAST cells of a level, row by row (ComputeKeyPointsOctTree, S/ORBextractor.cc:771-804), for the known-answer tests
+extern "C" int oracle_fast_cell_grid(int level_w, int level_h, int32_t* rects6, int cap, int32_t* w_cell, int32_t* h_cell) {
+  std::vector<FastCell> cells;
+  int wc = 0, hc = 0;
+  if (!level_cells(level_w, level_h, cells, &wc, &hc)) return 0;
+  if (w_cell) *w_cell = wc;
+  if (h_cell) *h_cell = hc;
+  for (size_t k = 0; k < cells.size() && (int)k < cap; k++) {
+    const FastCell& c = cells[k];
+    rects6[6 * k] = c.x0; rects6[6 * k + 1] = c.x1; rects6[6 * k + 2] = c.y0; rects6[6 * k + 3] = c.y1; rects6[6 * k + 4] = c.i; rects6[6 * k + 5] = c.j;
+  }
+  return (int)cells.size();
+}
+
 // IC_Angle of one keypoint on a caller-supplied level image, for the known-answer tests: the radius-15 disc must lie inside
 extern "C" float oracle_ic_angle(const oracle_extractor* e, const uint8_t* img, int stride, int x, int y) {
   return ic_angle(img + (size_t)y * stride + x, stride, e->umax);
@@ -557,37 +600,25 @@ extern "C" int oracle_extract(oracle_extractor* e, const uint8_t* img, int width
 
   struct LevelKp { float x, y, angle, response; };
   std::vector<std::vector<LevelKp>> all(nl);
-  const float W = 30;
   for (int level = 0; level < nl; ++level) {                       // :769-873
     const int minBorderX = kEdge - 3, minBorderY = minBorderX;
     const int maxBorderX = e->lw[level] - kEdge + 3;
     const int maxBorderY = e->lh[level] - kEdge + 3;
     std::vector<OracleCand>& cand = e->cands[level];
     cand.clear();
-    const float fw = (float)(maxBorderX - minBorderX), fh = (float)(maxBorderY - minBorderY);
-    const int nCols = (int)(fw / W), nRows = (int)(fh / W);
-    if (nCols < 1 || nRows < 1) continue;   // level too small for a single cell (reference would divide by 0)
-    const int wCell = (int)std::ceil(fw / nCols), hCell = (int)std::ceil(fh / nRows);
+    int wCell = 0, hCell = 0;
+    std::vector<FastCell> cells;
+    if (!level_cells(e->lw[level], e->lh[level], cells, &wCell, &hCell)) continue;   // level too small for a single cell (reference would divide by 0)
     const uint8_t* base = e->level_ptr(level);
     const int ls = e->lstride[level];
     std::vector<int32_t> cell(3 * 4096);
-    for (int i = 0; i < nRows; i++) {
-      const float iniY = (float)(minBorderY + i * hCell);
-      float maxY = iniY + hCell + 6;
-      if (iniY >= maxBorderY - 3) continue;
-      if (maxY > maxBorderY) maxY = (float)maxBorderY;
-      for (int j = 0; j < nCols; j++) {
-        const float iniX = (float)(minBorderX + j * wCell);
-        float maxX = iniX + wCell + 6;
-        if (iniX >= maxBorderX - 6) continue;
-        if (maxX > maxBorderX) maxX = (float)maxBorderX;
-        const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
-        const uint8_t* sub = base + (size_t)y0 * ls + x0;
-        int nk = oracle_fast_detect(sub, cw, ch, ls, e->cfg.ini_th_fast, 1, cell.data(), 4096);   // :808
-        if (nk == 0) nk = oracle_fast_detect(sub, cw, ch, ls, e->cfg.min_th_fast, 1, cell.data(), 4096);   // :825-828
-        for (int k = 0; k < nk; k++)                                                              // :845-850
-          cand.push_back({cell[3 * k] + j * wCell, cell[3 * k + 1] + i * hCell, cell[3 * k + 2]});
-      }
+    for (const FastCell& c : cells) {
+      const int x0 = c.x0, y0 = c.y0, cw = c.x1 - x0, ch = c.y1 - y0;
+      const uint8_t* sub = base + (size_t)y0 * ls + x0;
+      int nk = oracle_fast_detect(sub, cw, ch, ls, e->cfg.ini_th_fast, 1, cell.data(), 4096);   // :808
+      if (nk == 0) nk = oracle_fast_detect(sub, cw, ch, ls, e->cfg.min_th_fast, 1, cell.data(), 4096);   // :825-828
+      for (int k = 0; k < nk; k++)                                                              // :845-850
+        cand.push_back({cell[3 * k] + c.j * wCell, cell[3 * k + 1] + c.i * hCell, cell[3 * k + 2]});
     }
     std::vector<int> keep = distribute_octree(cand, minBorderX, maxBorderX, minBorderY, maxBorderY, e->feats_per_level[level],
                                               e->cfg.octree_oldest_first != 0);

@@ -40,6 +40,8 @@ void oracle_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_
 void oracle_gaussian_blur7_taps(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, const int* taps4);
 float oracle_fast_atan2(float y, float x);
 int  oracle_hamming(const uint8_t* a, const uint8_t* b);
+/* the cells cv::FAST runs on at a level of that size (S/ORBextractor.cc:771-804): n x {x0, x1, y0, y1, row, column}, returns n */
+int  oracle_fast_cell_grid(int level_w, int level_h, int32_t* rects6, int cap, int32_t* w_cell, int32_t* h_cell);
 /* IC_Angle (S/ORBextractor.cc:75-102) of one keypoint on a level image; the radius-15 disc must lie inside */
 float oracle_ic_angle(const oracle_extractor* e, const uint8_t* img, int stride, int x, int y);
 /* computeOrbDescriptor (S/ORBextractor.cc:105-145) of one keypoint on an already blurred image; the 31 x 31 patch must lie inside */

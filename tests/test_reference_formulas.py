@@ -429,7 +429,7 @@ def cond_fix(c):
     return _expr(c, ()).replace("&&", " and ").replace("||", " or ")
 
 
-def c_to_python(body, indent="    "):
+def c_to_python(body, indent="    ", typed_ints=False):
     """Transliterates a C body of integer statements with counted `for` loops (`for (int v = A; v <= B; ++v)`, braced or single-statement
     bodies) into Python source: loops become range() loops, `int a = x, b = y` becomes two assignments, everything else is left as it
     stands (C's integer expressions over small values are Python's)."""
@@ -479,10 +479,16 @@ def c_to_python(body, indent="    "):
         i = j + 1
         if st.startswith("return") or st.startswith("const uchar*"):
             continue
-        m = re.match(r"^int (.*)$", st)
+        m = re.match(r"^(?:const )?(int|float|double) (.*)$", st)
         if m:
-            for piece in _split_top(m.group(1)):
-                emit(_expr(re.sub(r"\(int\)", "", piece.strip()), ()))
+            for piece in _split_top(m.group(2)):
+                piece = _expr(re.sub(r"\(int\)", "", piece.strip()), ())
+                if m.group(1) == "int" or "=" not in piece:
+                    # (an int initialised from a float expression truncates: `const int nCols = width/W`)
+                    emit(re.sub(r"^(\w+) ?= ?(.*)$", r"\1 = as_int(\2)", piece) if typed_ints else piece)
+                else:
+                    name, expr = piece.split("=", 1)
+                    emit("%s = %s(%s)" % (name.strip(), {"float": "F32", "double": "F64"}[m.group(1)], expr.strip()))
         else:
             emit(_expr(re.sub(r"\(int\)", "", st), ()))
         while pending and pending[-1]:
@@ -550,3 +556,27 @@ def test_rotation_histogram_pieces_are_the_references_text():
         env = {"aL": aL, "aC": aC, "factor": factor, "round": c_round, "HISTO_LENGTH": 30, "F32": F32, "F64": F64}
         exec(src2, env)
         assert env["bin"] == ob.rot_bin(float(aL), float(aC)), (aL, aC, env["bin"])
+
+
+def test_fast_cell_tiling_is_computekeypointsocttrees_text():
+    """The cells cv::FAST is run on (S/ORBextractor.cc:771-804): border offsets, `nCols = width/W` (float to int), `wCell = ceil(width/nCols)`,
+    the +6 overlap, the two `continue`s and the clamps -- the loop nest transliterated from the text with its float / int declarations,
+    the FAST call replaced by recording the cell -- against the oracle's cells for every pyramid level of C2 and C4 and odd sizes."""
+    body = _body(os.path.join(REF, "src", "ORBextractor.cc"), r"void\s+ORBextractor::ComputeKeyPointsOctTree\s*\([^)]*\)\s*\{")
+    i0 = body.index("const int minBorderX")
+    i1 = body.index("vector<cv::KeyPoint> vKeysCell;")
+    piece = body[i0:i1]
+    piece = re.sub(r"vector<cv::KeyPoint> vToDistributeKeys;\s*vToDistributeKeys\.reserve\([^;]*\);", "", piece)
+    piece = piece.replace("mvImagePyramid[level].cols", "level_w").replace("mvImagePyramid[level].rows", "level_h")
+    # close the two loops the cut left open, with the cell recorded where FAST would run
+    src = c_to_python(piece + " cells.append((as_int(iniX), as_int(maxX), as_int(iniY), as_int(maxY), i, j)); } }", typed_ints=True)
+    assert src.count("for ") == 2 and src.count("continue") == 2 and "F32(" in src
+    sizes = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134),
+             (1280, 720), (1067, 600), (889, 500), (741, 417), (617, 347), (514, 289), (429, 241), (357, 201), (752, 480), (101, 97), (64, 2000)]
+    for lw, lh in sizes:
+        env = {"level_w": lw, "level_h": lh, "EDGE_THRESHOLD": 19, "W": F32(30), "cells": [], "F32": F32, "F64": F64,
+               "as_int": lambda v: int(v), "ceil": lambda v: np.ceil(v)}
+        exec(src, env)
+        rects, wc, hc = ob.fast_cell_grid(lw, lh)
+        assert [tuple(int(v) for v in r) for r in rects] == env["cells"], (lw, lh)
+        assert (wc, hc) == (env["wCell"], env["hCell"]) and len(rects) > 0
