@@ -263,6 +263,14 @@ def image_bounds(width, height, cam4, dist5):
     return (float(min(m[0, 0], m[2, 0])), float(max(m[1, 0], m[3, 0])), float(min(m[0, 1], m[1, 1])), float(max(m[2, 1], m[3, 1])))
 
 
+def stereo_subpixel(dists, bestincR, scaleduR0, scale_of_level, uL, minD, maxD, bf):
+    d = np.ascontiguousarray(dists, np.float32)
+    ur, dp = C.c_float(0), C.c_float(0)
+    ok = lib().oracle_stereo_subpixel(C.c_void_p(d.ctypes.data), (len(d) - 1) // 2, int(bestincR), C.c_float(scaleduR0), C.c_float(scale_of_level),
+                                      C.c_float(uL), C.c_float(minD), C.c_float(maxD), C.c_float(bf), C.byref(ur), C.byref(dp))
+    return bool(ok), np.float32(ur.value), np.float32(dp.value)
+
+
 def build_grid(fv):
     start = np.zeros(capi.GRID_COLS * capi.GRID_ROWS + 1, np.int32)
     items = np.zeros(max(fv.n, 1), np.int32)

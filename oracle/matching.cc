@@ -693,6 +693,28 @@ extern "C" int oracle_search_by_bow_kf(const orbm_frame_view* kf2, const orbm_fe
 }
 
 // Frame::ComputeStereoMatches -- S/Frame.cc:785-963.
+// Sub-pixel match by parabola fitting and the disparity test of ComputeStereoMatches -- S/Frame.cc:918-946.  vDists: the 2 L + 1 SAD
+// values of the sliding window, bestincR the offset of the smallest (not at either end).  false: the reference `continue`s / stores nothing.
+static bool stereo_subpixel(const float* vDists, int L, int bestincR, float scaleduR0, float scale_of_level, float uL, float minD, float maxD,
+                            float bf, float* uright, float* depth) {
+  const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+  const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+  if (deltaR < -1 || deltaR > 1) return false;
+  float bestuR = scale_of_level * ((float)scaleduR0 + (float)bestincR + deltaR);
+  float disparity = (uL - bestuR);
+  if (disparity >= minD && disparity < maxD) {
+    if (disparity <= 0) { disparity = 0.01; bestuR = (float)(uL - 0.01); }   // double literals, :937-941
+    *depth = bf / disparity;
+    *uright = bestuR;
+    return true;
+  }
+  return false;
+}
+extern "C" int oracle_stereo_subpixel(const float* dists, int L, int bestincR, float scaleduR0, float scale_of_level, float uL, float minD,
+                                      float maxD, float bf, float* uright, float* depth) {
+  return stereo_subpixel(dists, L, bestincR, scaleduR0, scale_of_level, uL, minD, maxD, bf, uright, depth) ? 1 : 0;
+}
+
 extern "C" int oracle_stereo_match(oracle_extractor* left, oracle_extractor* right,
                                    const orbx_keypoint* kps_l, const uint8_t* desc_l, int N,
                                    const orbx_keypoint* kps_r, const uint8_t* desc_r, int Nr,
@@ -769,15 +791,10 @@ extern "C" int oracle_stereo_match(oracle_extractor* left, oracle_extractor* rig
         vDists[L + incR] = dist;
       }
       if (bestincR == -L || bestincR == L) continue;
-      const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
-      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
-      if (deltaR < -1 || deltaR > 1) continue;
-      float bestuR = scaleF[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
-      float disparity = (uL - bestuR);
-      if (disparity >= minD && disparity < maxD) {
-        if (disparity <= 0) { disparity = 0.01; bestuR = (float)(uL - 0.01); }   // double literals, :937-941
-        depth[iL] = bf / disparity;
-        uright[iL] = bestuR;
+      float ur_sub, depth_sub;
+      if (stereo_subpixel(vDists, L, bestincR, scaleduR0, scaleF[kpL.octave], uL, minD, maxD, bf, &ur_sub, &depth_sub)) {
+        depth[iL] = depth_sub;
+        uright[iL] = ur_sub;
         vDistIdx.push_back({bestDistS, iL});
       }
     }

@@ -71,6 +71,9 @@ int oracle_stereo_match(oracle_extractor* left, oracle_extractor* right,
 /* cv::undistortPoints(src, dst, K, distCoeffs, Mat(), P = K) as Frame::UndistortKeyPoints / ComputeImageBounds call it
  * (S/Frame.cc:740,767): xy = n x {x, y} float32, in place allowed.  dist NULL or k1 == 0: copy (S/Frame.cc:723-727). */
 int oracle_undistort_points(const float* xy_in, int n, float fx, float fy, float cx, float cy, const orbx_distortion* dist, float* xy_out);
+/* the parabola fit and disparity test at the end of a left keypoint's stereo match (S/Frame.cc:918-946); 1: uright / depth written */
+int oracle_stereo_subpixel(const float* dists, int L, int bestincR, float scaleduR0, float scale_of_level, float uL, float minD, float maxD,
+                           float bf, float* uright, float* depth);
 int oracle_build_grid(const orbm_frame_view* view, int32_t* cell_start, int32_t* cell_items);
 int oracle_features_in_area(const orbm_frame_view* view, float x, float y, float r, int min_level,
                             int max_level, int32_t* out_idx, int cap);

@@ -429,13 +429,15 @@ def cond_fix(c):
     return _expr(c, ()).replace("&&", " and ").replace("||", " or ")
 
 
-def c_to_python(body, indent="    ", typed_ints=False):
+def c_to_python(body, indent="    ", typed_ints=False, float_vars=()):
     """Transliterates a C body of integer statements with counted `for` loops (`for (int v = A; v <= B; ++v)`, braced or single-statement
     bodies) into Python source: loops become range() loops, `int a = x, b = y` becomes two assignments, everything else is left as it
     stands (C's integer expressions over small values are Python's)."""
     out, depth, i = [], 0, 0
     body = re.sub(r"\s+", " ", body)
+    body = re.sub(r"\(float\)\s*(\w+)", r"F32(\1)", body)                    # (float)name
     pending = []          # loops opened without a brace: closed after the next statement
+    floats = set(float_vars)          # variables of C type float: a plain assignment to one rounds to float32
 
     def emit(line):
         out.append(indent * depth + line)
@@ -488,9 +490,15 @@ def c_to_python(body, indent="    ", typed_ints=False):
                     emit(re.sub(r"^(\w+) ?= ?(.*)$", r"\1 = as_int(\2)", piece) if typed_ints else piece)
                 else:
                     name, expr = piece.split("=", 1)
+                    if m.group(1) == "float":
+                        floats.add(name.strip())
                     emit("%s = %s(%s)" % (name.strip(), {"float": "F32", "double": "F64"}[m.group(1)], expr.strip()))
         else:
-            emit(_expr(re.sub(r"\(int\)", "", st), ()))
+            st2 = _expr(re.sub(r"\(int\)", "", st), ())
+            ma = re.match(r"^(\w+(?:\[[^\]]*\])?) ?= ?(?!=)(.*)$", st2)
+            if ma and re.match(r"\w+", ma.group(1)).group(0) in floats:
+                st2 = "%s = F32(%s)" % (ma.group(1), ma.group(2))
+            emit(st2)
         while pending and pending[-1]:
             depth -= 1; pending.pop()
     return "\n".join(out)
@@ -580,3 +588,47 @@ def test_fast_cell_tiling_is_computekeypointsocttrees_text():
         rects, wc, hc = ob.fast_cell_grid(lw, lh)
         assert [tuple(int(v) for v in r) for r in rects] == env["cells"], (lw, lh)
         assert (wc, hc) == (env["wCell"], env["hCell"]) and len(rects) > 0
+
+
+def test_stereo_subpixel_step_is_computestereomatches_text():
+    """The end of a left keypoint's stereo match (S/Frame.cc:918-946): the parabola through three SAD values, the `deltaR` range test, the
+    re-scaled coordinate, the disparity test and the `disparity = 0.01` clamp with its double literals stored into floats -- transliterated
+    from the text -- against the oracle's step: matched or not, uRight and depth as float32 bits."""
+    body = _body(os.path.join(REF, "src", "Frame.cc"), r"void\s+Frame::ComputeStereoMatches\s*\(\s*\)\s*\{")
+    i0 = body.index("const float dist1 = vDists[L+bestincR-1];")
+    i1 = body.index("vDistIdx.push_back(pair<int,int>(bestDist,iL));")
+    piece = body[i0:i1].replace("mvScaleFactors[kpL.octave]", "scale_of_level") + " matched = True; }"
+    src = "for once in range(1):\n" + "\n".join("    " + ln for ln in c_to_python(piece, float_vars=("mvDepth", "mvuRight")).splitlines())
+    assert src.count("continue") == 1 and "F32(F64(0.01))" in src and "F32(uL-F64(0.01))" in src
+    rng = np.random.RandomState(49)
+    n_match = n_clamp = n_skip = 0
+    for trial in range(3000):
+        L = 5
+        base = rng.randint(50, 4000)
+        d = (base + np.abs(np.arange(-L, L + 1) + rng.uniform(-0.9, 0.9)) * rng.randint(5, 400) + rng.randint(0, 30, 2 * L + 1)).astype(np.int64)
+        if trial % 11 == 0:
+            d[:] = base                                    # a flat window: 0 / 0
+        vd = d.astype(np.float32)
+        binc = int(np.argmin(vd[1:-1])) + 1 - L
+        octave = rng.randint(0, 8)
+        scale = F32(1.2) ** 0 if octave == 0 else F32(np.prod([F32(1.2)] * octave, dtype=np.float32))
+        uL = F32(rng.uniform(20, 620))
+        disp = rng.choice([rng.uniform(-3, 3), rng.uniform(0, 60), rng.uniform(55, 80)])
+        scaleduR0 = F32(np.round((float(uL) - disp) / float(scale)))
+        minD, maxD, mbf = F32(0), F32(rng.choice([40.0, 64.36, 75.0])), F32(38.0)
+        if trial % 13 == 5:                                # disparity exactly 0: the `disparity = 0.01` clamp (octave 0, symmetric parabola)
+            vd = (base + np.abs(np.arange(-L, L + 1) - 1) * 37).astype(np.float32); binc = 1
+            scale = F32(1.0); scaleduR0 = F32(rng.randint(30, 600)); uL = F32(float(scaleduR0) + binc)
+        env = {"vDists": [F32(v) for v in vd], "L": L, "bestincR": binc, "scaleduR0": scaleduR0, "scale_of_level": scale, "uL": uL, "minD": minD,
+               "maxD": maxD, "mbf": mbf, "mvDepth": [F32(-1)], "mvuRight": [F32(-1)], "iL": 0, "matched": False, "F32": F32, "F64": F64}
+        with np.errstate(all="ignore"):
+            exec(src, env)
+        ok, ur, dp = ob.stereo_subpixel(vd, binc, float(scaleduR0), float(scale), float(uL), float(minD), float(maxD), float(mbf))
+        assert ok == env["matched"], (trial, vd, binc)
+        if ok:
+            assert ur.tobytes() == F32(env["mvuRight"][0]).tobytes() and dp.tobytes() == F32(env["mvDepth"][0]).tobytes(), (trial, ur, dp, env["mvuRight"], env["mvDepth"])
+            n_match += 1
+            n_clamp += float(dp) == float(F32(mbf / F32(F64(0.01))))
+        else:
+            n_skip += 1
+    assert n_match > 500 and n_skip > 300 and n_clamp > 5, (n_match, n_skip, n_clamp)
