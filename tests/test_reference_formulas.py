@@ -429,7 +429,7 @@ def cond_fix(c):
     return _expr(c, ()).replace("&&", " and ").replace("||", " or ")
 
 
-def c_to_python(body, indent="    ", typed_ints=False, float_vars=()):
+def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_returns=False):
     """Transliterates a C body of integer statements with counted `for` loops (`for (int v = A; v <= B; ++v)`, braced or single-statement
     bodies) into Python source: loops become range() loops, `int a = x, b = y` becomes two assignments, everything else is left as it
     stands (C's integer expressions over small values are Python's)."""
@@ -479,13 +479,20 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=()):
         j = body.index(";", i)
         st = body[i:j].strip()
         i = j + 1
-        if st.startswith("return") or st.startswith("const uchar*"):
+        if st.startswith("const uchar*") or (st.startswith("return") and not keep_returns):
             continue
-        m = re.match(r"^(?:const )?(int|float|double) (.*)$", st)
+        if st.startswith("return"):
+            emit(st)
+            while pending and pending[-1]:
+                depth -= 1; pending.pop()
+            continue
+        m = re.match(r"^(?:const )?(int|float|double|bool) (.*)$", st)
         if m:
             for piece in _split_top(m.group(2)):
                 piece = _expr(re.sub(r"\(int\)", "", piece.strip()), ())
-                if m.group(1) == "int" or "=" not in piece:
+                if m.group(1) == "bool":
+                    emit(cond_fix(piece))
+                elif m.group(1) == "int" or "=" not in piece:
                     # (an int initialised from a float expression truncates: `const int nCols = width/W`)
                     emit(re.sub(r"^(\w+) ?= ?(.*)$", r"\1 = as_int(\2)", piece) if typed_ints else piece)
                 else:
@@ -632,3 +639,56 @@ def test_stereo_subpixel_step_is_computestereomatches_text():
         else:
             n_skip += 1
     assert n_match > 500 and n_skip > 300 and n_clamp > 5, (n_match, n_skip, n_clamp)
+
+
+def test_getfeaturesinarea_is_the_references_text():
+    """Frame::GetFeaturesInArea (S/Frame.cc:628-697, the Nleft == -1 / left-grid forms of its two ternaries): the floor / ceil cell range with
+    its four early returns, the level filter and the strict |dx| < r, |dy| < r tests, the loops transliterated from the text and run
+    over the oracle's grid -- against the oracle's GetFeaturesInArea, index lists equal in order."""
+    body = _body(os.path.join(REF, "src", "Frame.cc"), r"vector<size_t>\s+Frame::GetFeaturesInArea\s*\([^)]*\)\s*const\s*\{")
+    body = body.replace("vector<size_t> vIndices;", "vIndices = [];").replace("vIndices.reserve(N);", "")
+    body = body.replace("const vector<size_t> vCell = (!bRight) ? mGrid[ix][iy] : mGridRight[ix][iy];", "vCell = mGrid[ix][iy];")
+    body = body.replace("vCell.empty()", "len(vCell) == 0").replace("for(size_t j=0, jend=vCell.size(); j<jend; j++)", "for(int j=0; j<len(vCell); j++)")
+    body = re.sub(r"const cv::KeyPoint &kpUn = \(Nleft == -1\) \? mvKeysUn\[vCell\[j\]\]\s*:\s*\(!bRight\) \? mvKeys\[vCell\[j\]\]\s*:\s*mvKeysRight\[vCell\[j\]\];",
+                  "kpUn = mvKeysUn[vCell[j]];", body)
+    body = body.replace("vIndices.push_back(", "vIndices.append(").replace("fabs(", "abs(").replace("(int)FRAME_GRID", "FRAME_GRID")
+    assert "mvKeysRight" not in body and "?" not in body
+    py = c_to_python(body, typed_ints=True, keep_returns=True)
+    assert py.count("return vIndices") == 5 and py.count("for ") == 3 and py.count("continue") == 3
+    src = "def get_features_in_area():\n" + "\n".join("    " + ln for ln in py.splitlines())
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o): self.pt, self.octave = Pt(x, y), int(o)
+
+    rng = np.random.RandomState(50)
+    n = 1500
+    bounds = (-12.5, 655.25, -7.75, 490.5)
+    kps = np.zeros(n, capi.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(bounds[0], bounds[1], n).astype(np.float32); kps["y"] = rng.uniform(bounds[2], bounds[3], n).astype(np.float32)
+    kps["octave"] = rng.randint(0, 8, n)
+    fv, keep = views.frame_view(kps, np.zeros((n, 32), np.uint8), bounds=bounds, cam=(458.6, 457.3, 367.2, 248.4, 47.9, 0.1))
+    start, items = ob.build_grid(fv)
+    grid = [[[int(v) for v in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)]
+            for ix in range(capi.GRID_COLS)]
+    keys = [Kp(k["x"], k["y"], k["octave"]) for k in kps]
+    inv_w = F32(F32(capi.GRID_COLS) / F32(F32(bounds[1]) - F32(bounds[0])))
+    inv_h = F32(F32(capi.GRID_ROWS) / F32(F32(bounds[3]) - F32(bounds[2])))
+    n_hits = 0
+    for trial in range(400):
+        x = F32(rng.uniform(bounds[0] - 40, bounds[1] + 40)); y = F32(rng.uniform(bounds[2] - 40, bounds[3] + 40))
+        r = F32(rng.choice([3.0, 7.0, 15.0, 28.8, 60.0]))
+        lo, hi = [(-1, -1), (0, 7), (2, 3), (1, -1), (-1, 4)][trial % 5]
+        if trial % 9 == 0:                                   # a keypoint exactly r away: the strict '<'
+            k = keys[rng.randint(0, n)]; x = F32(k.pt.x - r); y = k.pt.y
+        env = {"x": x, "y": y, "r": r, "minLevel": lo, "maxLevel": hi, "mnMinX": F32(bounds[0]), "mnMinY": F32(bounds[2]),
+               "mfGridElementWidthInv": inv_w, "mfGridElementHeightInv": inv_h, "FRAME_GRID_COLS": capi.GRID_COLS, "FRAME_GRID_ROWS": capi.GRID_ROWS,
+               "mGrid": grid, "mvKeysUn": keys, "floor": np.floor, "ceil": np.ceil, "as_int": lambda v: int(v), "F32": F32, "F64": F64}
+        exec(src, env)
+        mine = env["get_features_in_area"]()
+        theirs = [int(v) for v in ob.features_in_area(fv, float(x), float(y), float(r), lo, hi)]
+        assert mine == theirs, (trial, x, y, r, lo, hi, mine[:5], theirs[:5])
+        n_hits += len(mine)
+    assert n_hits > 2000
