@@ -423,6 +423,38 @@ def test_rbrief_descriptor_is_computeorbdescriptors_text():
 
 
 # ---------------------------------------------------------------------------------------------- integer code with nested loops
+def ternary(e):
+    """`a ? b : c` (right-associative, nested) as Python conditional expressions."""
+    depth = 0
+    for i, ch in enumerate(e):
+        depth += ch in "([{"
+        depth -= ch in ")]}"
+        if ch == "?" and depth == 0:
+            nest, d2 = 0, 0
+            for j in range(i + 1, len(e)):
+                d2 += e[j] in "([{"
+                d2 -= e[j] in ")]}"
+                if d2 == 0 and e[j] == "?":
+                    nest += 1
+                elif d2 == 0 and e[j] == ":" and e[j + 1:j + 2] != ":" and e[j - 1:j] != ":":
+                    if nest == 0:
+                        return "((%s) if (%s) else (%s))" % (ternary(e[i + 1:j].strip()), cond_fix(e[:i].strip()), ternary(e[j + 1:].strip()))
+                    nest -= 1
+    return e
+
+
+def cpp_prepare(text):
+    """Text-level rules that make a C++ body of the reference digestible for c_to_python: member access, boolean literals, container
+    sizes, logical not."""
+    text = text.replace("->", ".")
+    text = re.sub(r"\btrue\b", "True", re.sub(r"\bfalse\b", "False", text))
+    text = re.sub(r"([\w\.\[\]]+)\.size\(\)", r"len(\1)", text)
+    text = re.sub(r"!\s*([\w\.\[\]]+)\.empty\(\)", r"(len(\1) != 0)", text)
+    text = re.sub(r"([\w\.\[\]]+)\.empty\(\)", r"(len(\1) == 0)", text)
+    text = re.sub(r"!(?!=)", " not ", text)
+    return text
+
+
 def cond_fix(c):
     """A C condition as Python: float32 literals and `(float)name` casts as in _expr, && / || as and / or."""
     c = re.sub(r"\(float\)\s*(\w+)", r"F32(\1)", c)
@@ -445,7 +477,14 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
     while i < len(body):
         if body[i] in " ":
             i += 1; continue
-        m = re.compile(r"for ?\( ?int (\w+) ?= ?([^;]+); ?\1 ?(<=|<) ?([^;]+); ?(?:\+\+\1|\1\+\+) ?\)\s*(\{?)").match(body, i)
+        m = re.compile(r"foreach ?\( ?(\w+) ?, ?([\w\.\[\]]+) ?\)\s*(\{?)").match(body, i)          # marker put in by the caller for iterator loops
+        if m:
+            emit("for %s in %s:" % (m.group(1), m.group(2)))
+            depth += 1
+            pending.append(m.group(3) == "")
+            i = m.end()
+            continue
+        m = re.compile(r"for ?\( ?(?:int|size_t) (\w+) ?= ?([^;]+); ?\1 ?(<=|<) ?([^;]+); ?(?:\+\+\1|\1\+\+) ?\)\s*(\{?)").match(body, i)
         if m:
             hi = m.group(4) if m.group(3) == "<" else "(%s) + 1" % m.group(4)
             emit("for %s in range(%s, %s):" % (m.group(1), m.group(2), hi))
@@ -486,7 +525,7 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
             while pending and pending[-1]:
                 depth -= 1; pending.pop()
             continue
-        m = re.match(r"^(?:const )?(int|float|double|bool) (.*)$", st)
+        m = re.match(r"^(?:const )?(int|float|double|bool) &?(.*)$", st)
         if m:
             for piece in _split_top(m.group(2)):
                 piece = _expr(re.sub(r"\(int\)", "", piece.strip()), ())
@@ -500,8 +539,16 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
                     if m.group(1) == "float":
                         floats.add(name.strip())
                     emit("%s = %s(%s)" % (name.strip(), {"float": "F32", "double": "F64"}[m.group(1)], expr.strip()))
+        elif re.match(r"^[\w\.\[\]]+\+\+$", st):
+            emit(st[:-2] + " += 1")
+        elif re.match(r"^(?:const )?[\w:<>]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(?!=)", st) and not re.match(r"^(\w+) ?[\+\-\*/]?= ", st):
+            mm = re.match(r"^(?:const )?[\w:<>]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(.*)$", st)
+            emit("%s = %s" % (mm.group(1), ternary(_expr(mm.group(2), ()))))          # a declaration of any other type: the type is dropped
         else:
             st2 = _expr(re.sub(r"\(int\)", "", st), ())
+            if "?" in st2 and "=" in st2:
+                lhs_, rhs_ = st2.split("=", 1)
+                st2 = lhs_ + "= " + ternary(rhs_.strip())
             ma = re.match(r"^(\w+(?:\[[^\]]*\])?) ?= ?(?!=)(.*)$", st2)
             if ma and re.match(r"\w+", ma.group(1)).group(0) in floats:
                 st2 = "%s = F32(%s)" % (ma.group(1), ma.group(2))
@@ -692,3 +739,118 @@ def test_getfeaturesinarea_is_the_references_text():
         assert mine == theirs, (trial, x, y, r, lo, hi, mine[:5], theirs[:5])
         n_hits += len(mine)
     assert n_hits > 2000
+
+
+def _get_features_in_area_source():
+    """Frame::GetFeaturesInArea as a Python function of (F, x, y, r, minLevel, maxLevel) -- see test_getfeaturesinarea_is_the_references_text."""
+    body = _body(os.path.join(REF, "src", "Frame.cc"), r"vector<size_t>\s+Frame::GetFeaturesInArea\s*\([^)]*\)\s*const\s*\{")
+    body = body.replace("vector<size_t> vIndices;", "vIndices = [];").replace("vIndices.reserve(N);", "")
+    body = body.replace("const vector<size_t> vCell = (!bRight) ? mGrid[ix][iy] : mGridRight[ix][iy];", "vCell = mGrid[ix][iy];")
+    body = body.replace("vCell.empty()", "len(vCell) == 0").replace("for(size_t j=0, jend=vCell.size(); j<jend; j++)", "for(int j=0; j<len(vCell); j++)")
+    body = re.sub(r"const cv::KeyPoint &kpUn = \(Nleft == -1\) \? mvKeysUn\[vCell\[j\]\]\s*:\s*\(!bRight\) \? mvKeys\[vCell\[j\]\]\s*:\s*mvKeysRight\[vCell\[j\]\];",
+                  "kpUn = mvKeysUn[vCell[j]];", body)
+    body = body.replace("vIndices.push_back(", "vIndices.append(").replace("fabs(", "abs(").replace("(int)FRAME_GRID", "FRAME_GRID")
+    py = c_to_python(body, typed_ints=True, keep_returns=True)
+    return "def GetFeaturesInArea(x, y, r, minLevel=-1, maxLevel=-1, bRight=False):\n" + "\n".join("    " + ln for ln in py.splitlines())
+
+
+def test_searchbyprojection_of_map_points_is_the_references_text():
+    """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) -- S/ORBmatcher.cc:44-214 -- WHOLE: the
+    function's text (both camera branches; the right-camera one never runs with Nleft == -1 but is transliterated with the rest),
+    RadiusByViewingCos and Frame::GetFeaturesInArea are transliterated statement by statement and run on Python stand-ins for Frame /
+    MapPoint that hold the same fields; the assignments F.mvpMapPoints and the match count it leaves are compared with the oracle's
+    on the same inputs.  What is NOT the reference's here: DescriptorDistance is a numpy population count (its text is checked above),
+    and the data structures."""
+    path = os.path.join(REF, "src", "ORBmatcher.cc")
+    body = _body(path, r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&F,\s*const\s+vector<MapPoint\*>\s*&vpMapPoints[^)]*\)\s*\{")
+    body = re.sub(r"for\(vector<size_t>::const_iterator vit=vIndices\.begin\(\), vend=vIndices\.end\(\); vit!=vend; vit\+\+\)\s*\{\s*const size_t idx = \*vit;",
+                  "foreach(idx, vIndices) {", body)
+    assert body.count("foreach(idx, vIndices)") == 2
+    body = body.replace("int nmatches=0, left = 0, right = 0;", "int nmatches=0; int left = 0; int right = 0;")
+    src = c_to_python(cpp_prepare(body), keep_returns=True)
+    assert src.count("for ") == 3 and "GetFeaturesInArea" in src and "mvLeftToRightMatch" in src and src.count("continue") >= 7
+    rad = c_to_python(cpp_prepare(_body(path, r"float\s+ORBmatcher::RadiusByViewingCos\s*\([^)]*\)\s*\{")), keep_returns=True)
+    prog = ("def RadiusByViewingCos(viewCos):\n" + "\n".join("    " + ln for ln in rad.splitlines()) +
+            "\ndef SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints):\n" + "\n".join("    " + ln for ln in src.splitlines()))
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o): self.pt, self.octave = Pt(x, y), int(o)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[i]
+
+    class MP:
+        pass
+
+    class Frame:
+        pass
+
+    rng = np.random.RandomState(51)
+    for trial in range(6):
+        n, m = 900, 700
+        bounds = (0.0, 640.0, 0.0, 480.0)
+        kps = np.zeros(n, capi.KEYPOINT_DTYPE)
+        kps["x"] = rng.uniform(5, 635, n).astype(np.float32); kps["y"] = rng.uniform(5, 475, n).astype(np.float32)
+        kps["octave"] = rng.randint(0, 8, n)
+        desc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+        uright = np.where(rng.rand(n) < 0.7, kps["x"] - rng.uniform(2, 40, n), -1.0).astype(np.float32)
+        fv, keep = views.frame_view(kps, desc, uright=uright, depth=np.where(uright > 0, 5.0, -1.0).astype(np.float32), bounds=bounds,
+                                    cam=(458.6, 457.3, 320.0, 240.0, 38.0, 0.08))
+        start, items = ob.build_grid(fv)
+        sc = np.ones(8, np.float32)
+        for l in range(1, 8):
+            sc[l] = np.float32(sc[l - 1] * np.float32(1.2))
+        # map points: most of them sit near a feature and carry its descriptor with a few bits flipped; several compete for a feature
+        tgt = rng.randint(0, n, m)
+        px = (kps["x"][tgt] + rng.uniform(-6, 6, m)).astype(np.float32); py = (kps["y"][tgt] + rng.uniform(-6, 6, m)).astype(np.float32)
+        mdesc = desc[tgt].copy()
+        flips = rng.randint(0, 256, (m, 32)).astype(np.uint8) & rng.randint(0, 256, (m, 32)).astype(np.uint8) & rng.randint(0, 256, (m, 32)).astype(np.uint8)
+        mdesc ^= np.where(rng.rand(m, 1) < 0.8, flips & rng.randint(0, 256, (m, 32)).astype(np.uint8), flips)
+        level = np.clip(kps["octave"][tgt] + rng.randint(0, 2, m), 0, 7).astype(np.int32)
+        pxr = np.where(uright[tgt] > 0, uright[tgt] + rng.uniform(-8, 8, m), px - 10).astype(np.float32)
+        in_view = (rng.rand(m) < 0.9).astype(np.uint8); bad = (rng.rand(m) < 0.03).astype(np.uint8)
+        depth = rng.uniform(1, 60, m).astype(np.float32); vcos = rng.uniform(0.99, 1.0, m).astype(np.float32)
+        n_obs = rng.randint(0, 4, m).astype(np.int32)
+        th = [1.0, 3.0, 5.0, 1.0, 15.0, 3.0][trial]; far = trial % 2; th_far = 40.0; nnratio = 0.8
+        amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+        occ = rng.rand(n) < 0.15                                 # features that already hold a point (of another search), some never observed
+        amp0[occ] = 100000 + np.arange(occ.sum()); aob0[occ] = rng.randint(0, 3, occ.sum())
+        mv, keep2 = views.mappoints_view(in_view, bad, px, py, pxr, depth, level, vcos, mdesc, n_obs)
+        amp, aob, nm = ob.search_by_projection_mps(fv, mv, th, far, th_far, nnratio, amp0, aob0)
+        # ---- the reference's text on stand-ins
+        env = dict(ENV, F32=F32, F64=F64, abs=abs, fabs=abs, TH_HIGH=100, mfNNratio=F32(nnratio), as_int=lambda v: int(v), floor=np.floor, ceil=np.ceil,
+                   DescriptorDistance=lambda a, b: int(np.unpackbits(a ^ b).sum()))
+        F = Frame()
+        F.Nleft = -1; F.mvuRight = [F32(v) for v in uright]; F.mvScaleFactors = [F32(v) for v in sc]
+        F.mvKeysUn = [Kp(k["x"], k["y"], k["octave"]) for k in kps]; F.mvKeys = F.mvKeysUn; F.mvKeysRight = []
+        F.mDescriptors = Desc(desc); F.mvLeftToRightMatch = [-1] * n; F.mvRightToLeftMatch = []
+        others = {}
+        F.mvpMapPoints = [None] * n
+        for i in np.nonzero(occ)[0]:
+            o = MP(); o.id = int(amp0[i]); o.nobs = int(aob0[i]); o.Observations = (lambda o=o: o.nobs)
+            F.mvpMapPoints[i] = o
+        genv = dict(env, mnMinX=F32(bounds[0]), mnMinY=F32(bounds[2]), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
+                    mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / F32(F32(bounds[1]) - F32(bounds[0]))),
+                    mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / F32(F32(bounds[3]) - F32(bounds[2]))),
+                    mGrid=[[[int(v) for v in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)]
+                           for ix in range(capi.GRID_COLS)], mvKeysUn=F.mvKeysUn)
+        exec(_get_features_in_area_source(), genv)
+        F.GetFeaturesInArea = lambda x, y, r, lo=-1, hi=-1, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), lo, hi, bRight)
+        pts = []
+        for i in range(m):
+            q = MP()
+            q.id = i; q.mbTrackInView = bool(in_view[i]); q.mbTrackInViewR = False; q.mTrackDepth = F32(depth[i]); q.bad = bool(bad[i])
+            q.isBad = (lambda q=q: q.bad); q.mnTrackScaleLevel = int(level[i]); q.mTrackViewCos = F32(vcos[i])
+            q.mTrackProjX = F32(px[i]); q.mTrackProjY = F32(py[i]); q.mTrackProjXR = F32(pxr[i]); q.nobs = int(n_obs[i])
+            q.GetDescriptor = (lambda q=q, i=i: mdesc[i]); q.Observations = (lambda q=q: q.nobs)
+            q.mnTrackScaleLevelR = -1; q.mTrackViewCosR = F32(0); q.mTrackProjYR = F32(0)
+            pts.append(q)
+        exec(prog, env)
+        nm_ref = env["SearchByProjection"](F, pts, F32(th), bool(far), F32(th_far))
+        amp_ref = np.array([-1 if p_ is None else p_.id for p_ in F.mvpMapPoints], np.int32)
+        assert nm_ref == nm and nm > 100, (trial, nm_ref, nm)
+        assert np.array_equal(amp_ref, amp), (trial, np.nonzero(amp_ref != amp)[0][:10])
