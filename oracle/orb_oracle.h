@@ -9,7 +9,9 @@
  * PARITY STATUS: "parity unpinned" -- the reference ships no tests, golden vectors or fixtures for
  * this path and cannot be compiled in the authoring container (needs
  * OpenCV, Eigen, ROS), so this restatement is pinned only against first-principles known-answer
- * tests (tests/test_oracle_*.py).  Arithmetic that lives in un-vendored
+ * tests (tests/test_oracle_*.py) and -- where the reference's text is plain scalar / loop code -- against that
+ * text executed statement by statement (tests/test_reference_formulas.py: tables, cell tiling, IC_Angle, rBRIEF, grid, stereo
+ * sub-pixel step, camera models, g2o's stereo edge, both tracking SearchByProjection overloads whole).  Arithmetic that lives in un-vendored
  * third parties (OpenCV 3.2-era cv::resize / cv::FAST / cv::GaussianBlur / cv::fastAtan2 /
  * cvRound; Eigen >= 3.1 fixed-size algebra + SimplicialLDLT) is restated from their published
  * algorithms.

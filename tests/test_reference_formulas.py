@@ -529,6 +529,8 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
         if m:
             for piece in _split_top(m.group(2)):
                 piece = _expr(re.sub(r"\(int\)", "", piece.strip()), ())
+                if "?" in piece and "=" in piece:
+                    piece = piece.split("=", 1)[0] + "= " + ternary(piece.split("=", 1)[1].strip())
                 if m.group(1) == "bool":
                     emit(cond_fix(piece))
                 elif m.group(1) == "int" or "=" not in piece:
@@ -541,6 +543,8 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
                     emit("%s = %s(%s)" % (name.strip(), {"float": "F32", "double": "F64"}[m.group(1)], expr.strip()))
         elif re.match(r"^[\w\.\[\]]+\+\+$", st):
             emit(st[:-2] + " += 1")
+        elif re.match(r"^[\w\.\[\]]+--$", st):
+            emit(st[:-2] + " -= 1")
         elif re.match(r"^(?:const )?[\w:<>]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(?!=)", st) and not re.match(r"^(\w+) ?[\+\-\*/]?= ", st):
             mm = re.match(r"^(?:const )?[\w:<>]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(.*)$", st)
             emit("%s = %s" % (mm.group(1), ternary(_expr(mm.group(2), ()))))          # a declaration of any other type: the type is dropped
@@ -854,3 +858,149 @@ def test_searchbyprojection_of_map_points_is_the_references_text():
         amp_ref = np.array([-1 if p_ is None else p_.id for p_ in F.mvpMapPoints], np.int32)
         assert nm_ref == nm and nm > 100, (trial, nm_ref, nm)
         assert np.array_equal(amp_ref, amp), (trial, np.nonzero(amp_ref != amp)[0][:10])
+
+
+class MatF:
+    """Stand-in for the cv::Mat expressions of the matchers (CV_32F): the products and sums in float32, a row of a product accumulated left to
+    right -- the arithmetic the oracle restates for them (OpenCV itself is not in the tree: this part is NOT pinned)."""
+
+    def __init__(self, a): self.a = np.asarray(a, np.float32).reshape(np.asarray(a).shape if np.asarray(a).ndim == 2 else (-1, 1))
+    def rowRange(self, i, j): return MatF(self.a[i:j, :])
+    def colRange(self, i, j): return MatF(self.a[:, i:j])
+    def col(self, j): return MatF(self.a[:, j:j + 1])
+    def t(self): return MatF(self.a.T.copy())
+    def __neg__(self): return MatF(-self.a)
+    def __add__(self, o): return MatF(self.a + o.a)
+    def at(self, i, j=0): return F32(self.a[i, j])
+
+    def __mul__(self, o):
+        out = np.zeros((self.a.shape[0], o.a.shape[1]), np.float32)
+        for i in range(out.shape[0]):
+            for j in range(out.shape[1]):
+                acc = F32(self.a[i, 0] * o.a[0, j])
+                for k in range(1, self.a.shape[1]):
+                    acc = F32(acc + F32(self.a[i, k] * o.a[k, j]))
+                out[i, j] = acc
+        return MatF(out)
+
+
+@pytest.mark.parametrize("case", ["stereo_forward", "stereo_sideways", "stereo_backward", "mono", "no_orientation_check"])
+def test_searchbyprojection_of_the_last_frame_is_the_references_text(case):
+    """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) -- S/ORBmatcher.cc:1970-2186 -- WHOLE, with
+    ComputeThreeMaxima, Frame::GetFeaturesInArea and Pinhole::project(Point3f) transliterated from the text and run on stand-ins: the
+    forward / backward / sideways level windows, the stereo `ur` test, the rotation histogram and the removal of the matches outside its
+    three maxima -- assignments and count against the oracle's.  (The cv::Mat products are the stand-in's float32 arithmetic: see MatF.)"""
+    path = os.path.join(REF, "src", "ORBmatcher.cc")
+    body = _body(path, r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&CurrentFrame,\s*const\s+Frame\s*&LastFrame[^)]*\)\s*\{")
+    body = re.sub(r"for\(vector<size_t>::const_iterator vit=vIndices2\.begin\(\), vend=vIndices2\.end\(\); vit!=vend; vit\+\+\)\s*\{\s*const size_t i2 = \*vit;",
+                  "foreach(i2, vIndices2) {", body)
+    assert body.count("foreach(i2, vIndices2)") == 2
+    body = re.sub(r"vector<int> rotHist\[HISTO_LENGTH\];\s*for\(int i=0;i<HISTO_LENGTH;i\+\+\)\s*rotHist\[i\]\.reserve\(500\);", "rotHist = [[] for _ in range(HISTO_LENGTH)];", body)
+    body = body.replace("vector<size_t> vIndices2;", "").replace(".at<float>(", ".at(").replace(".push_back(", ".append(")
+    body = re.sub(r"assert\([^;]*\);", "", body).replace("static_cast<MapPoint*>(NULL)", "None")
+    body = body.replace("ComputeThreeMaxima(rotHist,HISTO_LENGTH,ind1,ind2,ind3);", "ind = ComputeThreeMaxima(rotHist,HISTO_LENGTH,ind1,ind2,ind3); ind1 = ind[0]; ind2 = ind[1]; ind3 = ind[2];")
+    body = body.replace("for(size_t j=0, jend=rotHist[i].size(); j<jend; j++)", "for(int j=0; j<len(rotHist[i]); j++)")
+    src = c_to_python(cpp_prepare(body), keep_returns=True)
+    assert src.count("GetFeaturesInArea") == 6 and "rotHist[bin].append(bestIdx2)" in src and "nmatches -= 1" in src
+    tm = _body(path, r"void\s+ORBmatcher::ComputeThreeMaxima\s*\([^)]*\)\s*\{")
+    tm_src = c_to_python(cpp_prepare(tm.replace("const int s = histo[i].size()", "int s = len(histo[i])")))
+    pj = _body(os.path.join(REF, "src", "CameraModels", "Pinhole.cpp"), r"cv::Point2f\s+Pinhole::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    ex, ey = _split_top(re.search(r"return cv::Point2f\((.*)\)\s*;", pj, flags=re.S).group(1).replace("\n", " "))
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def ComputeThreeMaxima(histo, L, ind1, ind2, ind3):\n" + ind(tm_src) + "\n    return (ind1, ind2, ind3)\n" +
+            "def SearchByProjection(CurrentFrame, LastFrame, th, bMono):\n" + ind(src))
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o, a): self.pt, self.octave, self.angle = Pt(x, y), int(o), F32(a)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[i]
+
+    class Obj:
+        pass
+
+    fx, fy, cx, cy, bf, b = F32(458.6), F32(457.3), F32(320.0), F32(240.0), F32(38.0), F32(0.0829)
+    params = [fx, fy, cx, cy]
+
+    class Cam:
+        def project(self, m):
+            env = {"mvParameters": params, "p3D": Obj()}
+            env["p3D"].x, env["p3D"].y, env["p3D"].z = m.at(0), m.at(1), m.at(2)
+            return Pt(eval(ex, env), eval(ey, env))
+
+    rng = np.random.RandomState({"stereo_forward": 61, "stereo_sideways": 62, "stereo_backward": 63, "mono": 64, "no_orientation_check": 65}[case])
+    n, N = 900, 800
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    kps = np.zeros(n, capi.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(5, 635, n).astype(np.float32); kps["y"] = rng.uniform(5, 475, n).astype(np.float32)
+    kps["octave"] = rng.randint(0, 8, n); kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    desc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    mono = case == "mono"
+    dz = {"stereo_forward": 0.35, "stereo_backward": -0.35}.get(case, 0.01)
+    Tc = np.eye(4, dtype=np.float32); Tc[:3, :3] = np.array([[0.9998, -0.012, 0.016], [0.0121, 0.9999, -0.006], [-0.0159, 0.0062, 0.9998]], np.float32)
+    Tc[:3, 3] = [0.02, -0.01, -dz]                       # the camera moved along +z by dz since the last frame (tlc.z = dz)
+    Tl = np.eye(4, dtype=np.float32)
+    depth_true = rng.uniform(2, 20, n).astype(np.float32)
+    uright = np.where((rng.rand(n) < 0.7) & (not mono), kps["x"] - bf / depth_true, -1.0).astype(np.float32)
+    fv, keep = views.frame_view(kps, desc, uright=uright, depth=np.where(uright > 0, depth_true, -1.0).astype(np.float32), bounds=bounds,
+                                cam=(float(fx), float(fy), float(cx), float(cy), float(bf), float(b)))
+    start, items = ob.build_grid(fv)
+    sc = np.ones(8, np.float32)
+    for l in range(1, 8):
+        sc[l] = np.float32(sc[l - 1] * np.float32(1.2))
+    # last frame: most of its features are map points that re-project next to a current feature with a similar descriptor
+    tgt = rng.randint(0, n, N)
+    u = kps["x"][tgt] + rng.uniform(-4, 4, N); v = kps["y"][tgt] + rng.uniform(-4, 4, N); z = depth_true[tgt].astype(np.float64)
+    Pc = np.stack([(u - float(cx)) * z / float(fx), (v - float(cy)) * z / float(fy), z], 1)
+    Xw = ((Pc - Tc[:3, 3].astype(np.float64)) @ Tc[:3, :3].astype(np.float64)).astype(np.float32)
+    if case == "stereo_sideways":
+        Xw[:40, 2] = -5.0                                 # points behind the camera: invzc < 0
+    ldesc = desc[tgt] ^ (rng.randint(0, 256, (N, 32)).astype(np.uint8) & rng.randint(0, 256, (N, 32)).astype(np.uint8) & rng.randint(0, 256, (N, 32)).astype(np.uint8))
+    loct = np.clip(kps["octave"][tgt] + rng.randint(-1, 2, N), 0, 7).astype(np.int32)
+    rot_common = 23.0
+    langle = ((kps["angle"][tgt] + rot_common + rng.uniform(-5, 5, N) + np.where(rng.rand(N) < 0.15, rng.uniform(60, 300, N), 0)) % 360).astype(np.float32)
+    mp_valid = (rng.rand(N) < 0.85).astype(np.uint8); outl = (rng.rand(N) < 0.05).astype(np.uint8); n_obs = rng.randint(0, 4, N).astype(np.int32)
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    occ = rng.rand(n) < 0.1
+    amp0[occ] = 100000 + np.arange(occ.sum()); aob0[occ] = rng.randint(0, 3, occ.sum())
+    th = 15.0 if mono else 7.0
+    check = case != "no_orientation_check"
+    lv, keep2 = views.lastframe_view(mp_valid, outl, Xw, ldesc, loct, langle, n_obs, Tl)
+    amp, aob, nm = ob.search_by_projection_frame(fv, Tc, lv, th, int(mono), int(check), amp0, aob0)
+    # ---- the reference's text on stand-ins
+    env = dict(ENV, F32=F32, F64=F64, abs=abs, fabs=abs, TH_HIGH=100, HISTO_LENGTH=30, mbCheckOrientation=check, as_int=lambda v: int(v), floor=np.floor,
+               ceil=np.ceil, round=lambda a: int(np.copysign(np.floor(np.abs(F64(a)) + 0.5), a)), DescriptorDistance=lambda a, b2: int(np.unpackbits(a ^ b2).sum()))
+    Cur, Last = Obj(), Obj()
+    Cur.mTcw = MatF(Tc); Cur.mb = b; Cur.mbf = bf; Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY = [F32(v) for v in bounds]
+    Cur.mpCamera = Cam(); Cur.mvScaleFactors = [F32(v) for v in sc]; Cur.Nleft = -1; Cur.mvuRight = [F32(v) for v in uright]
+    Cur.mDescriptors = Desc(desc); Cur.mvKeysUn = [Kp(k["x"], k["y"], k["octave"], k["angle"]) for k in kps]; Cur.mvKeys = Cur.mvKeysUn; Cur.mvKeysRight = []
+    Cur.mTrl = MatF(np.eye(4, dtype=np.float32)[:3])
+    Cur.mvpMapPoints = [None] * n
+    for i in np.nonzero(occ)[0]:
+        o = Obj(); o.id = int(amp0[i]); o.nobs = int(aob0[i]); o.Observations = (lambda o=o: o.nobs)
+        Cur.mvpMapPoints[i] = o
+    genv = dict(env, mnMinX=F32(bounds[0]), mnMinY=F32(bounds[2]), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
+                mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / F32(F32(bounds[1]) - F32(bounds[0]))),
+                mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / F32(F32(bounds[3]) - F32(bounds[2]))),
+                mGrid=[[[int(v) for v in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)]
+                       for ix in range(capi.GRID_COLS)], mvKeysUn=Cur.mvKeysUn)
+    exec(_get_features_in_area_source(), genv)
+    Cur.GetFeaturesInArea = lambda x, y, r, lo=-1, hi=-1, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), lo, hi, bRight)
+    Last.mTcw = MatF(Tl); Last.N = N; Last.Nleft = -1; Last.mvbOutlier = [bool(v) for v in outl]
+    Last.mvKeys = [Kp(0, 0, loct[i], langle[i]) for i in range(N)]; Last.mvKeysUn = Last.mvKeys; Last.mvKeysRight = []
+    Last.mvpMapPoints = []
+    for i in range(N):
+        if not mp_valid[i]:
+            Last.mvpMapPoints.append(None); continue
+        q = Obj(); q.id = i; q.nobs = int(n_obs[i])
+        q.GetWorldPos = (lambda i=i: MatF(Xw[i].reshape(3, 1))); q.GetDescriptor = (lambda i=i: ldesc[i]); q.Observations = (lambda q=q: q.nobs)
+        Last.mvpMapPoints.append(q)
+    exec(prog, env)
+    nm_ref = env["SearchByProjection"](Cur, Last, F32(th), bool(mono))
+    amp_ref = np.array([-1 if p_ is None else p_.id for p_ in Cur.mvpMapPoints], np.int32)
+    assert nm_ref == nm and nm > 150, (case, nm_ref, nm)
+    assert np.array_equal(amp_ref, amp), (case, np.nonzero(amp_ref != amp)[0][:10])
