@@ -469,7 +469,8 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
     body = re.sub(r"\s+", " ", body)
     body = re.sub(r"\(float\)\s*(\w+)", r"F32(\1)", body)                    # (float)name
     pending = []          # loops opened without a brace: closed after the next statement
-    floats = set(float_vars)          # variables of C type float: a plain assignment to one rounds to float32
+    floats = set()                    # scalars the text declares float: a plain assignment to one rounds to float32
+    float_arrays = set(float_vars)    # float vectors (named by the caller): an element assignment rounds to float32
 
     def emit(line):
         out.append(indent * depth + line)
@@ -553,9 +554,10 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
             if "?" in st2 and "=" in st2:
                 lhs_, rhs_ = st2.split("=", 1)
                 st2 = lhs_ + "= " + ternary(rhs_.strip())
-            ma = re.match(r"^(\w+(?:\[[^\]]*\])?) ?= ?(?!=)(.*)$", st2)
-            if ma and re.match(r"\w+", ma.group(1)).group(0) in floats:
-                st2 = "%s = F32(%s)" % (ma.group(1), ma.group(2))
+            ma = re.match(r"^(\w+)(\[.*\])? ?= ?(?!=)(.*)$", st2)
+            if ma and ((ma.group(2) is None and ma.group(1) in floats) or (ma.group(2) is not None and ma.group(1) in float_arrays)) \
+                    and "=" not in (ma.group(2) or ""):
+                st2 = "%s%s = F32(%s)" % (ma.group(1), ma.group(2) or "", ma.group(3))
             emit(st2)
         while pending and pending[-1]:
             depth -= 1; pending.pop()
@@ -1004,3 +1006,70 @@ def test_searchbyprojection_of_the_last_frame_is_the_references_text(case):
     amp_ref = np.array([-1 if p_ is None else p_.id for p_ in Cur.mvpMapPoints], np.int32)
     assert nm_ref == nm and nm > 150, (case, nm_ref, nm)
     assert np.array_equal(amp_ref, amp), (case, np.nonzero(amp_ref != amp)[0][:10])
+
+
+class ImgMat:
+    """Stand-in for the cv::Mat image patches of ComputeStereoMatches: rowRange / colRange with the float arguments the text passes
+    (converted to int as the implicit conversion does), convertTo(CV_16S) in place, `patch - scalar`, at(r, c)."""
+
+    def __init__(self, a): self.a = np.asarray(a)
+    rows = property(lambda self: self.a.shape[0])
+    cols = property(lambda self: self.a.shape[1])
+    def rowRange(self, i, j): return ImgMat(self.a[int(i):int(j), :])
+    def colRange(self, i, j): return ImgMat(self.a[:, int(i):int(j)])
+    def convertTo(self, dst, code): dst.a = self.a.astype(np.int16)
+    def at(self, r, c): return self.a[int(r), int(c)]
+    def __sub__(self, v): return ImgMat(self.a - (v.a if isinstance(v, ImgMat) else v))
+
+
+def test_computestereomatches_is_the_references_text(small_scene):
+    """Frame::ComputeStereoMatches (S/Frame.cc:785-963) WHOLE -- the row table of the right keypoints, the Hamming search over a row's
+    candidates within the octave and disparity limits, the 11 x 11 SAD over eleven offsets on the keypoint's pyramid level, the parabola,
+    the disparity test, the median-of-SAD rejection -- transliterated from the text and run on the oracle's own keypoints, descriptors
+    and pyramid levels of a synthetic stereo pair: mvuRight and mvDepth against the oracle's, float32 bit for bit."""
+    import helpers
+    fr = helpers.oracle_stereo_frame(small_scene, 0, 500)
+    body = _body(os.path.join(REF, "src", "Frame.cc"), r"void\s+Frame::ComputeStereoMatches\s*\(\s*\)\s*\{")
+    rep = [("mvuRight = vector<float>(N,-1.0f);", "mvuRight = [F32(-1.0)] * N;"), ("mvDepth = vector<float>(N,-1.0f);", "mvDepth = [F32(-1.0)] * N;"),
+           ("vector<vector<size_t> > vRowIndices(nRows,vector<size_t>());", "vRowIndices = [[] for _ in range(nRows)];"),
+           ("vector<pair<int, int> > vDistIdx;", "vDistIdx = [];"), ("vDistIdx.reserve(N);", ""), ("vRowIndices[vL]", "vRowIndices[int(vL)]"),
+           ("ORBmatcher::", ""), ("vector<float> vDists;", "vDists = [F32(0)] * 11;"), ("vDists.resize(2*L+1);", ""),
+           ("pair<int,int>(bestDist,iL)", "(bestDist,iL)"), ("sort(vDistIdx.begin(),vDistIdx.end());", "vDistIdx.sort();"),
+           ("vDistIdx[vDistIdx.size()/2].first", "vDistIdx[len(vDistIdx)//2][0]"),
+           ("for(int i=vDistIdx.size()-1;i>=0;i--)", "ridx = list(reversed(range(len(vDistIdx)))); foreach(i, ridx)"),
+           ("vDistIdx[i].first", "vDistIdx[i][0]"), ("vDistIdx[i].second", "vDistIdx[i][1]"), (".push_back(", ".append("),
+           (".at<short>(", ".at("), ("cv::norm(", "cv_norm("), ("cv::NORM_L1", "NORM_L1"), ("cv::Mat IL", "IL"), ("cv::Mat IR", "IR")]
+    for a, b in rep:
+        assert a in body, a
+        body = body.replace(a, b)
+    body = re.sub(r"for\(int i=0; i<nRows; i\+\+\)\s*vRowIndices\[i\]\.reserve\(200\);", "", body)
+    src = c_to_python(cpp_prepare(body), typed_ints=True, float_vars=("mvDepth", "mvuRight", "vDists"))
+    assert src.count("for ") == 7 and src.count("continue") >= 6 and "cv_norm(IL,IR,NORM_L1)" in src and "break" in src
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, k): self.pt, self.octave = Pt(k["x"], k["y"]), int(k["octave"])
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[int(i)]
+
+    class Ex:
+        def __init__(self, ex): self.mvImagePyramid = [ImgMat(ex.level(l)) for l in range(8)]
+
+    sc, isc = fr["exL"].tables()[0], fr["exL"].tables()[1]
+    N = len(fr["kps"])
+    env = dict(ENV, F32=F32, F64=F64, as_int=lambda v: int(v), floor=np.floor, ceil=np.ceil, TH_HIGH=100, TH_LOW=50, INT_MAX=2147483647, CV_16S=3, NORM_L1=2,
+               round=lambda a: F32(np.copysign(np.floor(np.abs(F32(a)) + F32(0.5)), a)),
+               cv_norm=lambda a, b, t: F64(np.abs(a.a.astype(np.int64) - b.a.astype(np.int64)).sum()),
+               DescriptorDistance=lambda a, b: int(np.unpackbits(a ^ b).sum()),
+               N=N, mvKeys=[Kp(k) for k in fr["kps"]], mvKeysRight=[Kp(k) for k in fr["kps_r"]], mDescriptors=Desc(fr["desc"]),
+               mDescriptorsRight=Desc(fr["desc_r"]), mvScaleFactors=[F32(v) for v in sc], mvInvScaleFactors=[F32(v) for v in isc],
+               mb=F32(small_scene.cam["b"]), mbf=F32(small_scene.cam["bf"]), mpORBextractorLeft=Ex(fr["exL"]), mpORBextractorRight=Ex(fr["exR"]))
+    with np.errstate(all="ignore"):
+        exec(src, env)
+    ur = np.array([F32(v) for v in env["mvuRight"]], np.float32); dp = np.array([F32(v) for v in env["mvDepth"]], np.float32)
+    assert (ur > 0).sum() > 100 and (ur > 0).sum() < N
+    assert ur.tobytes() == fr["uright"].tobytes() and dp.tobytes() == fr["depth"].tobytes(), (np.nonzero(ur != fr["uright"])[0][:10],)
