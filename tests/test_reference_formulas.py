@@ -458,6 +458,7 @@ def cpp_prepare(text):
 def cond_fix(c):
     """A C condition as Python: float32 literals and `(float)name` casts as in _expr, && / || as and / or."""
     c = re.sub(r"\(float\)\s*(\w+)", r"F32(\1)", c)
+    c = re.sub(r"\(int\)", "", c)
     return _expr(c, ()).replace("&&", " and ").replace("||", " or ")
 
 
@@ -492,6 +493,21 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
             depth += 1
             pending.append(m.group(5) == "")
             i = m.end()
+            continue
+        m = re.compile(r"while ?\(").match(body, i)
+        if m:
+            j, d2 = m.end(), 1
+            while d2:
+                d2 += body[j] == "("
+                d2 -= body[j] == ")"
+                j += 1
+            emit("while %s:" % cond_fix(body[m.end():j - 1]))
+            depth += 1
+            k = j
+            while body[k] == " ":
+                k += 1
+            pending.append(body[k] != "{")
+            i = k + (body[k] == "{")
             continue
         m = re.compile(r"(else if|if|else)\s*(\()?").match(body, i)
         if m and (m.group(1) == "else" or m.group(2)):
@@ -1073,3 +1089,128 @@ def test_computestereomatches_is_the_references_text(small_scene):
     ur = np.array([F32(v) for v in env["mvuRight"]], np.float32); dp = np.array([F32(v) for v in env["mvDepth"]], np.float32)
     assert (ur > 0).sum() > 100 and (ur > 0).sum() < N
     assert ur.tobytes() == fr["uright"].tobytes() and dp.tobytes() == fr["depth"].tobytes(), (np.nonzero(ur != fr["uright"])[0][:10],)
+
+
+# ---------------------------------------------------------------------------------------------- std::list with stable iterators
+class CppList:
+    """std::list<T> for the transliterated DistributeOctTree: push_front / push_back COPY the element into a fresh list node (which gets
+    the next `address`: the allocation order, see ExtractorNode.seq), erase(it) returns the iterator after it, iterators stay valid."""
+
+    class Node:
+        __slots__ = ("v", "prev", "next")
+
+    class It:
+        def __init__(self, lst, node): object.__setattr__(self, "_l", lst); object.__setattr__(self, "_n", node)
+        def __eq__(self, o): return self._n is o._n
+        def __ne__(self, o): return self._n is not o._n
+        def __iadd__(self, k): return CppList.It(self._l, self._n.next)
+        def __getattr__(self, name): return getattr(self._n.v, name)
+        def __setattr__(self, name, val): setattr(self._n.v, name, val)
+
+    def __init__(self):
+        self.head = CppList.Node(); self.head.v = None; self.head.prev = self.head.next = self.head; self.n = 0
+
+    def _insert_before(self, at, v):
+        nd = CppList.Node(); nd.v = v.copy_into_list(); nd.prev, nd.next = at.prev, at
+        at.prev.next = nd; at.prev = nd; self.n += 1
+
+    def push_back(self, v): self._insert_before(self.head, v)
+    def push_front(self, v): self._insert_before(self.head.next, v)
+    def front(self): return self.head.next.v
+    def back(self): return self.head.prev.v
+    def begin(self): return CppList.It(self, self.head.next)
+    def end(self): return CppList.It(self, self.head)
+    def __len__(self): return self.n
+
+    def erase(self, it):
+        nd = it._n
+        nd.prev.next, nd.next.prev = nd.next, nd.prev
+        self.n -= 1
+        return CppList.It(self, nd.next)
+
+    def values(self):
+        nd = self.head.next
+        while nd is not self.head:
+            yield nd.v
+            nd = nd.next
+
+
+def test_distributeocttree_is_the_references_text():
+    """ORBextractor::DistributeOctTree with ExtractorNode::DivideNode (S/ORBextractor.cc:479-761) WHOLE: the initial nodes, the breadth-first
+    splitting with children pushed to the FRONT of the list, the switch to splitting the most populated nodes first once one more
+    round would overshoot N (sort of (size, node address) pairs, walked from the back; among equally populated nodes the later
+    allocation wins, as the oracle's default assumes of the heap), erasing through the iterator a node keeps of itself, the best
+    response per node -- transliterated from the text over a std::list stand-in with stable iterators -- against the oracle's retained
+    keypoints, in list order."""
+    path = os.path.join(REF, "src", "ORBextractor.cc")
+    seq = [0]
+
+    class Point2i:
+        def __init__(self, x, y): self.x, self.y = int(x), int(y)
+
+    class ExtractorNode:
+        def __init__(self):
+            self.vKeys = []; self.UL = self.UR = self.BL = self.BR = None; self.bNoMore = False; self.lit = None; self.seq = -1
+        def copy_into_list(self):
+            c = ExtractorNode(); c.vKeys = list(self.vKeys); c.UL, c.UR, c.BL, c.BR = self.UL, self.UR, self.BL, self.BR
+            c.bNoMore = self.bNoMore; c.lit = self.lit
+            seq[0] += 1; c.seq = seq[0]                    # the list node's place in allocation order (its `address`)
+            return c
+        def __lt__(self, o): return self.seq < o.seq       # std::sort of pair<int, ExtractorNode*>: ties by address
+
+    def prep(body):
+        body = re.sub(r"[\w\.\[\]]+\.reserve\([^;]*\);", "", body)
+        body = body.replace("cv::Point2i(", "Point2i(").replace("static_cast<float>(", "F32(").replace(".push_back(", ".append(")
+        body = re.sub(r"(?<![&\w])&(?=[A-Za-z_])", "", body)
+        return body
+
+    dn = prep(_body(path, r"void\s+ExtractorNode::DivideNode\s*\([^)]*\)\s*\{"))
+    dn = re.sub(r"(?<![\w\.])(UL|UR|BL|BR|vKeys)\b", r"self.\1", dn)
+    dn_src = c_to_python(cpp_prepare(dn), typed_ints=True)
+    assert dn_src.count("bNoMore = True") == 4 and "self.vKeys[i]" in dn_src
+    body = prep(_body(path, r"vector<cv::KeyPoint>\s+ORBextractor::DistributeOctTree\s*\([^)]*\)\s*\{"))
+    rep = [("list<ExtractorNode> lNodes;", "lNodes = CppList();"), ("vector<ExtractorNode*> vpIniNodes;", ""), ("vpIniNodes.resize(nIni);", "vpIniNodes = [None] * nIni;"),
+           ("ExtractorNode ni;", "ni = ExtractorNode();"), ("lNodes.append(ni);", "lNodes.push_back(ni);"), ("vpIniNodes[kp.pt.x/hX]", "vpIniNodes[int(kp.pt.x/hX)]"),
+           ("vector<pair<int,ExtractorNode*> > vSizeAndPointerToNode;", "vSizeAndPointerToNode = [];"), ("make_pair(", "("),
+           ("vector<pair<int,ExtractorNode*> > vPrevSizeAndPointerToNode = vSizeAndPointerToNode;", "vPrevSizeAndPointerToNode = list(vSizeAndPointerToNode);"),
+           ("sort(vPrevSizeAndPointerToNode.begin(),vPrevSizeAndPointerToNode.end());", "vPrevSizeAndPointerToNode.sort();"),
+           ("for(int j=vPrevSizeAndPointerToNode.size()-1;j>=0;j--)", "ridx = list(reversed(range(len(vPrevSizeAndPointerToNode)))); foreach(j, ridx)"),
+           ("vPrevSizeAndPointerToNode[j].second", "vPrevSizeAndPointerToNode[j][1]"), ("vector<cv::KeyPoint> vResultKeys;", "vResultKeys = [];"),
+           ("for(list<ExtractorNode>::iterator lit=lNodes.begin(); lit!=lNodes.end(); lit++)", "allnodes = list(lNodes.values()); foreach(lit, allnodes)"),
+           ("vResultKeys.append(*pKP);", "vResultKeys.append(pKP);")]
+    for a, b in rep:
+        assert a in body, a
+        body = body.replace(a, b)
+    body = body.replace("ExtractorNode n1,n2,n3,n4;", "n1 = ExtractorNode(); n2 = ExtractorNode(); n3 = ExtractorNode(); n4 = ExtractorNode();")
+    src = c_to_python(cpp_prepare(body), typed_ints=True, keep_returns=True)
+    assert src.count("while ") == 4 and src.count("lNodes.push_front(") == 8 and "lNodes.erase(vPrevSizeAndPointerToNode[j][1].lit)" in src
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = "def DivideNode(self, n1, n2, n3, n4):\n" + ind(dn_src) + "\ndef DistributeOctTree(vToDistributeKeys, minX, maxX, minY, maxY, N, level):\n" + ind(src)
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, r, idx): self.pt, self.response, self.idx = Pt(x, y), F32(r), idx
+
+    env = dict(ENV, F32=F32, F64=F64, as_int=lambda v: int(v), ceil=np.ceil, CppList=CppList, ExtractorNode=ExtractorNode, Point2i=Point2i, nfeatures=1000,
+               round=lambda a: F32(np.copysign(np.floor(np.abs(F32(a)) + F32(0.5)), a)))
+    exec(prog, env)
+    ExtractorNode.DivideNode = env["DivideNode"]
+    rng = np.random.RandomState(52)
+    for trial, (w, h, n, target) in enumerate([(608, 448, 3000, 217), (501, 368, 1500, 181), (147, 102, 400, 60), (1248, 688, 9000, 434),
+                                               (608, 448, 150, 217), (412, 301, 2500, 151), (608, 448, 40, 30), (900, 300, 800, 100)]):     # (nIni = round(w / h) = 0 for portrait
+                                               # windows: the reference divides by it)
+        xy = np.unique(np.stack([rng.randint(0, w, n), rng.randint(0, h, n)], 1), axis=0)
+        if trial % 2:
+            xy = xy[(xy[:, 0] % 7 < 3) | (rng.rand(len(xy)) < 0.2)]                          # clustered columns: many equal node populations
+        rng.shuffle(xy)
+        score = rng.randint(7, 120, len(xy)) if trial != 2 else np.full(len(xy), 20)        # (equal responses: the first key of a node wins)
+        cand = np.concatenate([xy, score[:, None]], 1).astype(np.int32)
+        kept = ob.distribute_octree(cand, 16, 16 + w, 16, 16 + h, target)
+        seq[0] = 0
+        keys = [Kp(c[0], c[1], c[2], i) for i, c in enumerate(cand)]
+        res = env["DistributeOctTree"](keys, 16, 16 + w, 16, 16 + h, target, 0)
+        mine = np.array([[int(k.pt.x), int(k.pt.y), int(k.response)] for k in res], np.int32).reshape(-1, 3)
+        assert len(mine) == len(kept) and len(kept) >= min(target, len(cand)) * 0.6, (trial, len(mine), len(kept))
+        assert np.array_equal(mine, kept), (trial, np.nonzero((mine != kept).any(1))[0][:5])
