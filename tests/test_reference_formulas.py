@@ -562,8 +562,8 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
             emit(st[:-2] + " += 1")
         elif re.match(r"^[\w\.\[\]]+--$", st):
             emit(st[:-2] + " -= 1")
-        elif re.match(r"^(?:const )?[\w:<>]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(?!=)", st) and not re.match(r"^(\w+) ?[\+\-\*/]?= ", st):
-            mm = re.match(r"^(?:const )?[\w:<>]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(.*)$", st)
+        elif re.match(r"^(?:const )?[\w:<>\*,]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(?!=)", st) and not re.match(r"^(\w+) ?[\+\-\*/]?= ", st):
+            mm = re.match(r"^(?:const )?[\w:<>\*,]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(.*)$", st)
             emit("%s = %s" % (mm.group(1), ternary(_expr(mm.group(2), ()))))          # a declaration of any other type: the type is dropped
         else:
             st2 = _expr(re.sub(r"\(int\)", "", st), ())
@@ -1214,3 +1214,94 @@ def test_distributeocttree_is_the_references_text():
         mine = np.array([[int(k.pt.x), int(k.pt.y), int(k.response)] for k in res], np.int32).reshape(-1, 3)
         assert len(mine) == len(kept) and len(kept) >= min(target, len(cand)) * 0.6, (trial, len(mine), len(kept))
         assert np.array_equal(mine, kept), (trial, np.nonzero((mine != kept).any(1))[0][:5])
+
+
+class CppMap:
+    """std::map<unsigned, std::vector<unsigned>> (DBoW2::FeatureVector) for the transliterated SearchByBoW: ordered keys, begin / end /
+    lower_bound, iterators with first / second and ++."""
+
+    class It:
+        def __init__(self, m, i): self.m, self.i = m, i
+        def __eq__(self, o): return self.i == o.i
+        def __ne__(self, o): return self.i != o.i
+        def __iadd__(self, k): return CppMap.It(self.m, self.i + 1)
+        first = property(lambda self: self.m.keys[self.i])
+        second = property(lambda self: self.m.vals[self.i])
+
+    def __init__(self, d): self.keys = sorted(d); self.vals = [list(d[k]) for k in self.keys]
+    def begin(self): return CppMap.It(self, 0)
+    def end(self): return CppMap.It(self, len(self.keys))
+
+    def lower_bound(self, key):
+        import bisect
+        return CppMap.It(self, bisect.bisect_left(self.keys, key))
+
+
+@pytest.mark.parametrize("check", [True, False])
+def test_searchbybow_of_a_keyframe_is_the_references_text(check):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) -- S/ORBmatcher.cc:269-471 -- WHOLE: the merge of the two
+    FeatureVectors (equal node: match inside it; else lower_bound on the one behind), best / second-best Hamming per keyframe feature over
+    the frame features of the node that are still free, TH_LOW and the float ratio test, the rotation histogram -- transliterated from
+    the text (std::map stand-in with lower_bound) -- against the oracle's matches."""
+    path = os.path.join(REF, "src", "ORBmatcher.cc")
+    body = _body(path, r"int\s+ORBmatcher::SearchByBoW\s*\(\s*KeyFrame\*\s*pKF,\s*Frame\s*&F,[^)]*\)\s*\{")
+    body = body.replace("unsigned int", "unsigned").replace("static_cast<float>(", "F32(").replace(".push_back(", ".append(")
+    body = body.replace("vpMapPointMatches = vector<MapPoint*>(F.N,static_cast<MapPoint*>(NULL));", "vpMapPointMatches.clear(); vpMapPointMatches.extend([None] * F.N);")
+    body = re.sub(r"vector<int> rotHist\[HISTO_LENGTH\];\s*for\(int i=0;i<HISTO_LENGTH;i\+\+\)\s*rotHist\[i\]\.reserve\(500\);", "rotHist = [[] for _ in range(HISTO_LENGTH)];", body)
+    body = re.sub(r"assert\([^;]*\);", "", body).replace("static_cast<MapPoint*>(NULL)", "None")
+    body = body.replace("ComputeThreeMaxima(rotHist,HISTO_LENGTH,ind1,ind2,ind3);", "ind = ComputeThreeMaxima(rotHist,HISTO_LENGTH,ind1,ind2,ind3); ind1 = ind[0]; ind2 = ind[1]; ind3 = ind[2];")
+    body = body.replace("for(size_t j=0, jend=rotHist[i].size(); j<jend; j++)", "for(int j=0; j<len(rotHist[i]); j++)")
+    src = c_to_python(cpp_prepare(body), keep_returns=True)
+    assert src.count("while ") == 1 and src.count("lower_bound") == 2 and "bestDist1R" in src and "or  True" in src
+    tm = _body(path, r"void\s+ORBmatcher::ComputeThreeMaxima\s*\([^)]*\)\s*\{")
+    tm_src = c_to_python(cpp_prepare(tm.replace("const int s = histo[i].size()", "int s = len(histo[i])")))
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def ComputeThreeMaxima(histo, L, ind1, ind2, ind3):\n" + ind(tm_src) + "\n    return (ind1, ind2, ind3)\n" +
+            "def SearchByBoW(pKF, F, vpMapPointMatches):\n" + ind(src))
+
+    class Kp:
+        def __init__(self, a): self.angle = F32(a)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[int(i)]
+
+    class Obj:
+        pass
+
+    rng = np.random.RandomState(53 + check)
+    nkf, n, n_nodes = 700, 800, 90
+    kdesc = rng.randint(0, 256, (nkf, 32)).astype(np.uint8)
+    knode = rng.randint(0, n_nodes, nkf) * 3                                   # node ids with gaps: lower_bound has something to skip
+    kangle = rng.uniform(0, 360, nkf).astype(np.float32)
+    src_kf = rng.randint(0, nkf, n)
+    flips = rng.randint(0, 256, (n, 32)).astype(np.uint8) & rng.randint(0, 256, (n, 32)).astype(np.uint8) & rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    fdesc = kdesc[src_kf] ^ np.where(rng.rand(n, 1) < 0.7, flips & rng.randint(0, 256, (n, 32)).astype(np.uint8), rng.randint(0, 256, (n, 32)).astype(np.uint8))
+    fnode = np.where(rng.rand(n) < 0.85, knode[src_kf], rng.randint(0, n_nodes * 3 + 5, n))
+    fangle = ((kangle[src_kf] - 31.0 + rng.uniform(-6, 6, n) + np.where(rng.rand(n) < 0.2, rng.uniform(50, 310, n), 0)) % 360).astype(np.float32)
+    valid = (rng.rand(nkf) < 0.8).astype(np.uint8)
+    kps = np.zeros(n, capi.KEYPOINT_DTYPE); kps["angle"] = fangle; kps["x"] = 10; kps["y"] = 10
+    fv, keep = views.frame_view(kps, fdesc, bounds=(0, 640, 0, 480), cam=(458.6, 457.3, 320.0, 240.0, 38.0, 0.08))
+    nF, sF, iF = views.featvec_from_nodes(fnode); nK, sK, iK = views.featvec_from_nodes(knode)
+    fvF, k1 = views.featvec_view(nF, sF, iF); fvK, k2 = views.featvec_view(nK, sK, iK)
+    matches, nm = ob.search_by_bow(fv, fvF, kdesc, valid, kangle, fvK, 0.7, check)
+    # ---- the reference's text on stand-ins
+    env = dict(ENV, F32=F32, F64=F64, TH_LOW=50, HISTO_LENGTH=30, mbCheckOrientation=check, mfNNratio=F32(0.7),
+               round=lambda a: int(np.copysign(np.floor(np.abs(F64(a)) + 0.5), a)), DescriptorDistance=lambda a, b: int(np.unpackbits(a ^ b).sum()))
+    pKF, F = Obj(), Obj()
+    mps = []
+    for i in range(nkf):
+        q = Obj(); q.id = i; q.isBad = (lambda: False)
+        mps.append(q if valid[i] else None)
+    pKF.GetMapPointMatches = lambda: mps
+    pKF.mFeatVec = CppMap({int(k): [int(v) for v in np.nonzero(knode == k)[0]] for k in np.unique(knode)})
+    pKF.mDescriptors = Desc(kdesc); pKF.mpCamera2 = None; pKF.NLeft = -1
+    pKF.mvKeysUn = [Kp(a) for a in kangle]; pKF.mvKeys = pKF.mvKeysUn; pKF.mvKeysRight = []
+    F.N = n; F.Nleft = -1; F.mpCamera2 = None; F.mDescriptors = Desc(fdesc); F.mvKeys = [Kp(a) for a in fangle]; F.mvKeysRight = []
+    F.mFeatVec = CppMap({int(k): [int(v) for v in np.nonzero(fnode == k)[0]] for k in np.unique(fnode)})
+    exec(prog, env)
+    out = []
+    nm_ref = env["SearchByBoW"](pKF, F, out)
+    mine = np.array([-1 if p_ is None else p_.id for p_ in out], np.int32)
+    assert nm_ref == nm and nm > 150, (nm_ref, nm)
+    assert np.array_equal(mine, matches), np.nonzero(mine != matches)[0][:10]
