@@ -1305,3 +1305,63 @@ def test_searchbybow_of_a_keyframe_is_the_references_text(check):
     mine = np.array([-1 if p_ is None else p_.id for p_ in out], np.int32)
     assert nm_ref == nm and nm > 150, (nm_ref, nm)
     assert np.array_equal(mine, matches), np.nonzero(mine != matches)[0][:10]
+
+
+def test_bag_of_words_transform_is_dbow2s_text():
+    """TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (D/TemplatedVocabulary.h:1218-1260: the descent -- first child,
+    strictly smaller distance replaces it, the node at level L - levelsup -- its do / while rewritten as `while True ... break`) and the
+    tf-idf accumulation of transform(features, BowVector, FeatureVector, levelsup) (:1127-1200) with BowVector::addWeight / normalize and
+    FeatureVector::addFeature restated over an ordered map as their few lines read (D/BowVector.cpp:34-84, D/FeatureVector.cpp:31-45) --
+    against the oracle's word ids, node ids, weights, BowVector (float64 bits) and FeatureVector."""
+    from multi_orbslam3_amd import synth
+    path = os.path.join(REF, "Thirdparty", "DBoW2", "DBoW2", "TemplatedVocabulary.h")
+    body = _body(path, r"void\s+TemplatedVocabulary<TDescriptor,F>::transform\(const TDescriptor &feature,\s*WordId &word_id, WordValue &weight, NodeId \*nid, int levelsup\) const\s*\{")
+    rep = [("vector<NodeId> nodes;", ""), ("typename vector<NodeId>::const_iterator nit;", ""), ("nid != NULL", "True"), ("*nid", "nid_out"),
+           ("do {", "while(True) {"), ("F::distance(", "F_distance("),
+           ("for(nit = nodes.begin() + 1; nit != nodes.end(); ++nit) { NodeId id = *nit;", "rest = nodes[1:]; foreach(id, rest) {")]
+    body = re.sub(r"\s+", " ", body)
+    body = re.sub(r"\} while\( !m_nodes\[final_id\]\.isLeaf\(\) \);", "if(m_nodes[final_id].isLeaf()) break; }", body)
+    for a, b in rep:
+        assert a in body, a
+        body = body.replace(a, b)
+    assert "++current_level;" in body
+    body = body.replace("++current_level;", "current_level++;")
+    src = c_to_python(cpp_prepare(body), typed_ints=False)
+    assert "while True:" in src and "break" in src and "if d < best_d:" in src
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = "def transform(feature, m_nodes, m_L, levelsup):\n    nid_out = 0\n" + ind(src) + "\n    return (word_id, weight, nid_out)"
+
+    class Node:
+        def __init__(self): self.children = []; self.descriptor = None; self.weight = F64(0); self.word_id = 0
+        def isLeaf(self): return len(self.children) == 0
+
+    for (k, L, levelsup, seed) in ((10, 3, 2, 1), (6, 4, 4, 2), (10, 3, 5, 3), (4, 5, 1, 4)):
+        voc = synth.make_vocabulary(k=k, L=L, seed=seed)
+        vv, keep = views.vocab_view(voc["child_start"], voc["child_ids"], voc["desc"], voc["weight"], voc["word_id"], voc["L"])
+        nodes = []
+        for i in range(len(voc["child_start"]) - 1):
+            nd = Node(); nd.children = [int(c) for c in voc["child_ids"][voc["child_start"][i]:voc["child_start"][i + 1]]]
+            nd.descriptor = voc["desc"][i]; nd.weight = F64(voc["weight"][i]); nd.word_id = int(voc["word_id"][i])
+            nodes.append(nd)
+        rng = np.random.RandomState(60 + seed)
+        feats = voc["desc"][rng.randint(1, len(nodes), 400)] ^ (rng.randint(0, 256, (400, 32)).astype(np.uint8) & rng.randint(0, 256, (400, 32)).astype(np.uint8) & rng.randint(0, 256, (400, 32)).astype(np.uint8))
+        env = dict(ENV, F64=F64, F32=F32, F_distance=lambda a, b: F64(int(np.unpackbits(a ^ b).sum())))
+        exec(prog, env)
+        wid, nid, w = ob.vocab_transform(vv, feats, levelsup)
+        bow, fvec = {}, {}
+        for i, f in enumerate(feats):
+            word_id, weight, nid_out = env["transform"](f, nodes, voc["L"], levelsup)
+            assert (word_id, nid_out) == (int(wid[i]), int(nid[i])) and F64(weight).tobytes() == F64(w[i]).tobytes(), (i, word_id, wid[i], nid_out, nid[i])
+            if weight > 0:                                  # not stopped (:1158): v.addWeight(id, w); fv.addFeature(nid, i_feature)
+                bow[word_id] = F64(bow[word_id] + weight) if word_id in bow else F64(weight)
+                fvec.setdefault(nid_out, []).append(i)
+        norm = F64(0.0)                                     # BowVector::normalize(L1): ascending word id
+        for kk in sorted(bow):
+            norm = F64(norm + abs(bow[kk]))
+        if norm > 0.0:
+            for kk in bow:
+                bow[kk] = F64(bow[kk] / norm)
+        (bw, bv), (fn, fs, ff) = ob.vocab_bow(vv, feats, levelsup)
+        assert [int(x) for x in bw] == sorted(bow) and all(F64(bow[int(a)]).tobytes() == F64(b).tobytes() for a, b in zip(bw, bv))
+        assert [int(x) for x in fn] == sorted(fvec) and all([int(x) for x in ff[fs[j]:fs[j + 1]]] == fvec[int(fn[j])] for j in range(len(fn)))
+        assert len(bow) > 20
