@@ -562,6 +562,8 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
             emit(st[:-2] + " += 1")
         elif re.match(r"^[\w\.\[\]]+--$", st):
             emit(st[:-2] + " -= 1")
+        elif re.match(r"^\+\+[\w\.\[\]]+$", st):
+            emit(st[2:] + " += 1")
         elif re.match(r"^(?:const )?[\w:<>\*,]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(?!=)", st) and not re.match(r"^(\w+) ?[\+\-\*/]?= ", st):
             mm = re.match(r"^(?:const )?[\w:<>\*,]+(?: ?[\*&])? [\*&]?(\w+) ?= ?(.*)$", st)
             emit("%s = %s" % (mm.group(1), ternary(_expr(mm.group(2), ()))))          # a declaration of any other type: the type is dropped
@@ -1365,3 +1367,173 @@ def test_bag_of_words_transform_is_dbow2s_text():
         assert [int(x) for x in bw] == sorted(bow) and all(F64(bow[int(a)]).tobytes() == F64(b).tobytes() for a, b in zip(bw, bv))
         assert [int(x) for x in fn] == sorted(fvec) and all([int(x) for x in ff[fs[j]:fs[j + 1]]] == fvec[int(fn[j])] for j in range(len(fn)))
         assert len(bow) > 20
+
+
+@pytest.mark.parametrize("seed,outl", [(71, 0.05), (72, 0.0), (73, 0.25)])
+def test_levenberg_marquardt_driver_is_g2os_text(seed, outl):
+    """OptimizationAlgorithmLevenberg::solve / computeLambdaInit / computeScale (G/core/optimization_algorithm_levenberg.cpp:61-194) and
+    SparseOptimizer::optimize (G/core/sparse_optimizer.cpp:354-420) -- the LM control flow: lambda init, the trial loop with push / pop,
+    rho and its scale, the cubic gain and its clamps, `ni`, the `qmax` / `rho == 0` termination and the three-bad-iterations stop --
+    transliterated (its do / while as `while True ... break`, members as attributes) and run over a DENSE numpy solver in place of
+    the block solver (the linear algebra is pinned elsewhere: tests/dense_lm.py), as Optimizer::LocalBundleAdjustment drives it:
+    optimize(5), then optimize(10).  Iteration counts and trials per iteration equal the oracle's; lambda and chi2 per iteration agree
+    to 1e-6 / 1e-8 relative (dense solve against Schur complement + LDL^T)."""
+    from multi_orbslam3_amd import synth
+    from dense_lm import quat_from_R, oplus
+    G = os.path.join(REF, "Thirdparty", "g2o", "g2o", "core")
+
+    def prep(body, methods):
+        body = re.sub(r"assert\([^;]*\);", "", body)
+        body = body.replace("printVerbose(cerr)", "printVerbose(None)")
+        body = re.sub(r"(?<=[;{}])\s*cerr[^;]*;", "", body)
+        body = body.replace("G2OBatchStatistics::globalStats()", "None").replace("std::numeric_limits<double>::max()", "DBL_MAX")
+        body = body.replace("(std::min)(", "min(").replace("(std::max)(", "max(").replace("std::max(", "max(").replace("fabs(", "abs(")
+        body = re.sub(r"OptimizationAlgorithm::(Fail|OK)", r'"\1"', body)
+        body = re.sub(r"return (Terminate|OK);", r'return "\1";', body)
+        body = re.sub(r"(?<![\w\.>])(_[a-zA-Z]\w*)", r"self.\1", body)
+        for mth in methods:
+            body = re.sub(r"(?<![\w\.>])%s\(" % mth, "self.%s(" % mth, body)
+        return body
+
+    solve = prep(_body(os.path.join(G, "optimization_algorithm_levenberg.cpp"), r"OptimizationAlgorithmLevenberg::solve\(int iteration, bool online\)\s*\{"),
+                 ("computeLambdaInit", "computeScale"))
+    solve = re.sub(r"\s+", " ", solve)
+    assert "do {" in solve and "} while (rho<0 && qmax < self._maxTrialsAfterFailure->value() && ! self._optimizer->terminate());" in solve
+    solve = solve.replace("do {", "while(True) {")
+    solve = solve.replace("} while (rho<0 && qmax < self._maxTrialsAfterFailure->value() && ! self._optimizer->terminate());",
+                          "if(!(rho<0 && qmax < self._maxTrialsAfterFailure->value() && ! self._optimizer->terminate())) break; } "
+                          "self._levenbergIterations = qmax; self.last_chi = currentChi;")
+    solve = solve.replace("int& qmax = self._levenbergIterations;", "int qmax = 0;")
+    solve_src = c_to_python(cpp_prepare(solve), keep_returns=True)
+    assert "alpha = F64(F64(1.)-pow((2*rho-1),3))" in solve_src and solve_src.count("self._optimizer.pop()") == 1 and "self._nBad>=3" in solve_src
+    lam = prep(_body(os.path.join(G, "optimization_algorithm_levenberg.cpp"), r"double\s+OptimizationAlgorithmLevenberg::computeLambdaInit\(\)\s*const\s*\{"), ())
+    lam = lam.replace("self._optimizer->indexMapping().size()", "len(self._optimizer->indexMapping())")
+    lam_src = c_to_python(cpp_prepare(lam), keep_returns=True)
+    sca_src = c_to_python(cpp_prepare(prep(_body(os.path.join(G, "optimization_algorithm_levenberg.cpp"), r"double\s+OptimizationAlgorithmLevenberg::computeScale\(\)\s*const\s*\{"), ())), keep_returns=True)
+    opt = prep(_body(os.path.join(G, "sparse_optimizer.cpp"), r"int\s+SparseOptimizer::optimize\(int iterations, bool online\)\s*\{"),
+               ("terminate", "preIteration", "postIteration", "verbose", "computeActiveErrors", "activeRobustChi2"))
+    opt = re.sub(r"\s+", " ", opt)
+    assert "for (int i=0; i<iterations && ! self.terminate() && ok; i++){" in opt
+    opt = opt.replace("for (int i=0; i<iterations && ! self.terminate() && ok; i++){", "int i = 0; while(i<iterations && ! self.terminate() && ok) {")
+    opt = opt.replace("self.postIteration(i);", "self.postIteration(i); i++;")
+    opt = opt.replace("G2OBatchStatistics& cstat = self._batchStatistics[i];", "cstat = self._batchStatistics[i];").replace("G2OBatchStatistics::setGlobalStats(&cstat);", "")
+    opt = opt.replace("self._ivMap.size()", "len(self._ivMap)").replace("self._activeEdges.size()", "len(self._activeEdges)").replace("self._activeVertices.size()", "len(self._activeVertices)")
+    opt_src = c_to_python(cpp_prepare(opt), keep_returns=True)
+    assert 'ok = ( result == "OK" )' in opt_src and "cjIterations += 1" in opt_src
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def lm_solve(self, iteration, online):\n" + ind(solve_src) + "\ndef lm_lambda_init(self):\n" + ind(lam_src) +
+            "\ndef lm_scale(self):\n" + ind(sca_src) + "\ndef so_optimize(self, iterations, online=False):\n" + ind(opt_src))
+    env = dict(ENV, F64=F64, F32=F32, DBL_MAX=F64(np.finfo(np.float64).max), get_monotonic_time=lambda: 0.0, pow=lambda a, b: F64(np.power(F64(a), F64(b))),
+               g2o_isfinite=lambda v: bool(np.isfinite(v)), abs=abs, min=min, max=max)
+    exec(prog, env)
+
+    pr = synth.make_lba_problem(n_free=5, n_fixed=3, n_points=120, seed=seed, outlier_frac=outl, mono_frac=0.2)
+    p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"])
+    o = ob.lba_solve(p)
+    E = pr["edges"]
+    P = len(pr["poses"]); free = [i for i in range(P) if not pr["pose_fixed"][i]]
+    pcol = {i: c for c, i in enumerate(free)}
+    L = len(pr["points"]); nP = len(free); nu = 6 * nP + 3 * L
+    d_mono, d_st = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+
+    class Param:
+        def __init__(self, v): self.v = v
+        def value(self): return self.v
+
+    class Vertex:
+        def __init__(self, S, off, dim): self.S, self.off, self.dim = S, off, dim
+        def dimension(self): return self.dim
+        def hessian(self, i, j): return F64(self.S.H[self.off + i, self.off + j])
+
+    class System:                                            # _optimizer and _solver in one: the graph state and a dense normal-equation solver
+        def __init__(self):
+            self.q, self.t = [], []
+            for i in range(P):
+                T = np.asarray(pr["poses"][i], np.float32).reshape(4, 4).astype(np.float64)
+                qq = quat_from_R(T[:3, :3]); self.q.append(qq / np.linalg.norm(qq)); self.t.append(T[:3, 3].copy())
+            self.X = np.asarray(pr["points"], np.float64).copy()
+            self.stack = []; self.err = [None] * len(E); self.chi = np.zeros(len(E)); self.H = np.zeros((nu, nu)); self.bv = np.zeros(nu); self.xv = np.zeros(nu)
+            self.verts = [Vertex(self, 6 * c, 6) for c in range(nP)] + [Vertex(self, 6 * nP + 3 * l, 3) for l in range(L)]
+        def buildStructure(self): return True
+        def indexMapping(self): return self.verts
+        def terminate(self): return False
+        def computeActiveErrors(self):
+            for k, e in enumerate(E):
+                err, A, B = ob.lba_edge_eval(self.q[int(e["pose"])], self.t[int(e["pose"])], self.X[int(e["point"])], pr["cam"], np.array([e], capi.EDGE_DTYPE))
+                D = 2 if e["ur"] < 0 else 3
+                self.err[k] = (err, A, B, D)
+                c = 0.0
+                for i in range(D):
+                    c += err[i] * (float(e["inv_sigma2"]) * err[i])
+                self.chi[k] = c
+        def _rho(self, k):
+            d = d_mono if self.err[k][3] == 2 else d_st
+            c = self.chi[k]
+            return (c, 1.0) if c <= d * d else (2 * np.sqrt(c) * d - d * d, d / np.sqrt(c))
+        def activeRobustChi2(self):
+            s = 0.0
+            for k in range(len(E)):
+                s += self._rho(k)[0]
+            return F64(s)
+        def buildSystem(self):
+            self.H[:] = 0; self.bv[:] = 0
+            for k, e in enumerate(E):
+                err, A, B, D = self.err[k]
+                w = self._rho(k)[1]; om = float(e["inv_sigma2"])
+                J = np.zeros((D, nu)); i, l = int(e["pose"]), int(e["point"])
+                if i in pcol:
+                    J[:, 6 * pcol[i]:6 * pcol[i] + 6] = B[:D]
+                J[:, 6 * nP + 3 * l:6 * nP + 3 * l + 3] = A[:D]
+                self.H += J.T @ (w * om * J); self.bv -= J.T @ (w * om * err[:D])
+        def setLambda(self, lam, backup): self.lam = float(lam)
+        def restoreDiagonal(self): pass
+        def solve(self):
+            try:
+                self.xv = np.linalg.solve(self.H + self.lam * np.eye(nu), self.bv)
+                return bool(np.isfinite(self.xv).all())
+            except np.linalg.LinAlgError:
+                return False
+        def x(self): return [F64(v) for v in self.xv]
+        def b(self): return [F64(v) for v in self.bv]
+        def vectorSize(self): return nu
+        def update(self, x):
+            x = np.array(x, np.float64)
+            for i in free:
+                self.q[i], self.t[i] = oplus(self.q[i], self.t[i], x[6 * pcol[i]:6 * pcol[i] + 6])
+                self.q[i] = self.q[i] / np.linalg.norm(self.q[i])
+            self.X = self.X + x[6 * nP:].reshape(L, 3)
+        def push(self): self.stack.append(([a.copy() for a in self.q], [a.copy() for a in self.t], self.X.copy()))
+        def pop(self): self.q, self.t, self.X = self.stack.pop()
+        def discardTop(self): self.stack.pop()
+
+    class Levenberg:
+        solve = env["lm_solve"]; computeLambdaInit = env["lm_lambda_init"]; computeScale = env["lm_scale"]
+        def __init__(self, S):
+            self._optimizer = S; self._solver = S; self._tau = F64(1e-5); self._goodStepUpperScale = F64(2.) / F64(3.); self._goodStepLowerScale = F64(1.) / F64(3.)
+            self._userLambdaInit = Param(F64(0)); self._maxTrialsAfterFailure = Param(10); self._currentLambda = F64(-1); self._ni = F64(2); self._nBad = 0
+            self._levenbergIterations = 0; self.last_chi = F64(0); self.trace = []
+        def init(self, online): return True
+
+    class SparseOpt:
+        optimize = env["so_optimize"]
+        def __init__(self, S, alg):
+            self.S, self._algorithm = S, alg; self._ivMap = S.verts; self._batchStatistics = []; self._computeBatchStatistics = False
+            self._activeEdges = list(range(len(E))); self._activeVertices = S.verts
+        def terminate(self): return False
+        def preIteration(self, i): pass
+        def postIteration(self, i): self._algorithm.trace.append((float(self._algorithm._currentLambda), float(self._algorithm.last_chi), int(self._algorithm._levenbergIterations)))
+        def verbose(self): return False
+        def computeActiveErrors(self): self.S.computeActiveErrors()
+        def activeRobustChi2(self): return self.S.activeRobustChi2()
+
+    S = System(); alg = Levenberg(S); so = SparseOpt(S, alg)
+    it1 = so.optimize(5)                                      # S/Optimizer.cc:2130-2132
+    it2 = so.optimize(10)                                     # :2202-2203
+    tr = np.array(alg.trace); to = o.trace_rows()
+    assert (it1, it2) == o.iters, ((it1, it2), o.iters)
+    assert tr.shape == to.shape and np.array_equal(tr[:, 2], to[:, 2]), (tr[:, 2], to[:, 2])
+    assert np.allclose(tr[:, 0], to[:, 0], rtol=1e-6) and np.allclose(tr[:, 1], to[:, 1], rtol=1e-8)
+    Rf = o.poses.reshape(-1, 4, 4)
+    for i in free:
+        assert np.abs(S.t[i] - Rf[i, :3, 3]).max() < 1e-5
+    assert np.abs(S.X - o.points).max() < 1e-4
