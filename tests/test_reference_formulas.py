@@ -1369,17 +1369,9 @@ def test_bag_of_words_transform_is_dbow2s_text():
         assert len(bow) > 20
 
 
-@pytest.mark.parametrize("seed,outl", [(71, 0.05), (72, 0.0), (73, 0.25)])
-def test_levenberg_marquardt_driver_is_g2os_text(seed, outl):
-    """OptimizationAlgorithmLevenberg::solve / computeLambdaInit / computeScale (G/core/optimization_algorithm_levenberg.cpp:61-194) and
-    SparseOptimizer::optimize (G/core/sparse_optimizer.cpp:354-420) -- the LM control flow: lambda init, the trial loop with push / pop,
-    rho and its scale, the cubic gain and its clamps, `ni`, the `qmax` / `rho == 0` termination and the three-bad-iterations stop --
-    transliterated (its do / while as `while True ... break`, members as attributes) and run over a DENSE numpy solver in place of
-    the block solver (the linear algebra is pinned elsewhere: tests/dense_lm.py), as Optimizer::LocalBundleAdjustment drives it:
-    optimize(5), then optimize(10).  Iteration counts and trials per iteration equal the oracle's; lambda and chi2 per iteration agree
-    to 1e-6 / 1e-8 relative (dense solve against Schur complement + LDL^T)."""
-    from multi_orbslam3_amd import synth
-    from dense_lm import quat_from_R, oplus
+def _g2o_lm_program():
+    """lm_solve / lm_lambda_init / lm_scale (OptimizationAlgorithmLevenberg) and so_optimize (SparseOptimizer::optimize) as Python functions of
+    `self`, transliterated from g2o's text: see test_levenberg_marquardt_driver_is_g2os_text."""
     G = os.path.join(REF, "Thirdparty", "g2o", "g2o", "core")
 
     def prep(body, methods):
@@ -1426,6 +1418,21 @@ def test_levenberg_marquardt_driver_is_g2os_text(seed, outl):
     env = dict(ENV, F64=F64, F32=F32, DBL_MAX=F64(np.finfo(np.float64).max), get_monotonic_time=lambda: 0.0, pow=lambda a, b: F64(np.power(F64(a), F64(b))),
                g2o_isfinite=lambda v: bool(np.isfinite(v)), abs=abs, min=min, max=max)
     exec(prog, env)
+    return env
+
+
+@pytest.mark.parametrize("seed,outl", [(71, 0.05), (72, 0.0), (73, 0.25)])
+def test_levenberg_marquardt_driver_is_g2os_text(seed, outl):
+    """OptimizationAlgorithmLevenberg::solve / computeLambdaInit / computeScale (G/core/optimization_algorithm_levenberg.cpp:61-194) and
+    SparseOptimizer::optimize (G/core/sparse_optimizer.cpp:354-420) -- the LM control flow: lambda init, the trial loop with push / pop,
+    rho and its scale, the cubic gain and its clamps, `ni`, the `qmax` / `rho == 0` termination and the three-bad-iterations stop --
+    transliterated (its do / while as `while True ... break`, members as attributes) and run over a DENSE numpy solver in place of
+    the block solver (the linear algebra is pinned elsewhere: tests/dense_lm.py), as Optimizer::LocalBundleAdjustment drives it:
+    optimize(5), then optimize(10).  Iteration counts and trials per iteration equal the oracle's; lambda and chi2 per iteration agree
+    to 1e-6 / 1e-8 relative (dense solve against Schur complement + LDL^T)."""
+    from multi_orbslam3_amd import synth
+    from dense_lm import quat_from_R, oplus
+    env = _g2o_lm_program()
 
     pr = synth.make_lba_problem(n_free=5, n_fixed=3, n_points=120, seed=seed, outlier_frac=outl, mono_frac=0.2)
     p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"])
@@ -1537,3 +1544,138 @@ def test_levenberg_marquardt_driver_is_g2os_text(seed, outl):
     for i in free:
         assert np.abs(S.t[i] - Rf[i, :3, 3]).max() < 1e-5
     assert np.abs(S.X - o.points).max() < 1e-4
+
+
+@pytest.mark.parametrize("seed,n,outl", [(81, 300, 0.15), (82, 120, 0.4), (83, 8, 0.0), (84, 600, 0.05)])
+def test_poseoptimization_rounds_are_the_references_text(seed, n, outl):
+    """Optimizer::PoseOptimization (S/Optimizer.cc:1163-1275): the four rounds -- setEstimate(mTcw), initializeOptimization(0), optimize(10),
+    then every edge re-classified (an excluded edge gets a fresh error, an active one keeps its last), level 1 / 0, the robust kernel
+    dropped after the third round, the early exit below ten edges -- transliterated from the text, over edge stand-ins and g2o's own
+    Levenberg-Marquardt driver (the transliteration of the test above) on a dense 6 x 6 system.  Monocular correspondences (for which
+    the pose-only edge is the binary edge with the point held): outlier flags, inlier count and iterations per round equal the
+    oracle's, the pose to 1e-6."""
+    from multi_orbslam3_amd import synth
+    from dense_lm import quat_from_R, oplus, quat_rot
+    env = _g2o_lm_program()
+    body = _body(os.path.join(REF, "src", "Optimizer.cc"), r"int\s+Optimizer::PoseOptimization\s*\(\s*Frame\s*\*pFrame\s*\)\s*\{")
+    piece = body[body.index("const float chi2Mono[4]"):body.index("// Recover optimized pose") if "// Recover optimized pose" in body else body.index("g2o::VertexSE3Expmap* vSE3_recov")]
+    piece = re.sub(r"const float chi2Mono\[4\]=\{([^}]*)\};", lambda m: "chi2Mono = [%s];" % ", ".join("F32(%s)" % v.strip() for v in m.group(1).split(",")), piece)
+    piece = re.sub(r"const float chi2Stereo\[4\]=\{([^}]*)\};", lambda m: "chi2Stereo = [%s];" % ", ".join("F32(%s)" % v.strip() for v in m.group(1).split(",")), piece)
+    piece = re.sub(r"const int its\[4\]=\{([^}]*)\};", r"its = [\1];", piece)
+    piece = re.sub(r"for\(size_t i=0, iend=(\w+)\.size\(\); i<iend; i\+\+\)", r"for(int i=0; i<len(\1); i++)", piece)
+    piece = piece.replace("Converter::toSE3Quat(", "Converter_toSE3Quat(").replace("optimizer.edges().size()", "len(optimizer.edges())")
+    src = c_to_python(cpp_prepare(piece))
+    assert src.count("for ") == 4 and src.count("e.setRobustKernel(0)") == 3 and "e.computeError()" in src and "break" in src
+    prog = "def rounds(pFrame, optimizer, vSE3, vpEdgesMono, vnIndexEdgeMono, vpEdgesMono_FHR, vnIndexEdgeRight, vpEdgesStereo, vnIndexEdgeStereo):\n" + \
+           "\n".join("    " + ln for ln in src.splitlines()) + "\n    return nBad"
+    exec(prog, env)
+
+    pr = synth.make_pose_opt_problem(n=n, seed=seed, outlier_frac=outl, mono_frac=1.0)
+    p, keep = views.pose_opt_problem(pr["Xw"], pr["u"], pr["v"], pr["ur"], pr["inv_sigma2"], pr["cam"], pr["Tcw"])
+    o = ob.pose_optimize(p)
+    d_mono = float(np.float32(np.sqrt(5.991)))
+
+    class Param:
+        def __init__(self, v): self.v = v
+        def value(self): return self.v
+
+    class VSE3:                                               # g2o::VertexSE3Expmap
+        def __init__(self): self.q = None; self.t = None; self.H = np.zeros((6, 6))
+        def setEstimate(self, qt): self.q, self.t = qt[0].copy(), qt[1].copy()
+        def dimension(self): return 6
+        def hessian(self, i, j): return F64(self.H[i, j])
+
+    v0 = VSE3()
+
+    class Edge:                                               # ORB_SLAM3::EdgeSE3ProjectXYZOnlyPose
+        def __init__(self, i):
+            self.e = np.zeros(1, capi.EDGE_DTYPE); self.e[0] = (0, 0, pr["u"][i], pr["v"][i], -1.0, pr["inv_sigma2"][i])
+            self.X = pr["Xw"][i].astype(np.float64); self.lvl = 0; self.robust = True; self.err = np.zeros(3); self.B = None
+        def computeError(self):
+            self.err, A, self.B = ob.lba_edge_eval(v0.q, v0.t, self.X, pr["cam"], self.e)
+        def chi2(self):
+            om = float(self.e["inv_sigma2"][0]); return F64(self.err[0] * (om * self.err[0]) + self.err[1] * (om * self.err[1]))
+        def setLevel(self, l): self.lvl = l
+        def setRobustKernel(self, k): self.robust = False
+
+    edges = [Edge(i) for i in range(n)]
+
+    class Optim:                                              # the g2o::SparseOptimizer of PoseOptimization with its dense 6 x 6 solver
+        optimize = env["so_optimize"]
+        def __init__(self):
+            self._ivMap = [v0]; self._batchStatistics = []; self._computeBatchStatistics = False; self._activeVertices = [v0]; self._activeEdges = []
+            self.stack = []; self.bv = np.zeros(6); self.xv = np.zeros(6); self.iters = []
+            alg = type("LM", (), {"solve": env["lm_solve"], "computeLambdaInit": env["lm_lambda_init"], "computeScale": env["lm_scale"], "init": lambda self_, online: True})()
+            alg._optimizer = self; alg._solver = self; alg._tau = F64(1e-5); alg._goodStepUpperScale = F64(2.) / F64(3.); alg._goodStepLowerScale = F64(1.) / F64(3.)
+            alg._userLambdaInit = Param(F64(0)); alg._maxTrialsAfterFailure = Param(10); alg._currentLambda = F64(-1); alg._ni = F64(2); alg._nBad = 0
+            alg._levenbergIterations = 0; alg.last_chi = F64(0)
+            self._algorithm = alg
+        def edges(self): return edges
+        def initializeOptimization(self, level): self._activeEdges = [e for e in edges if e.lvl == level]
+        def terminate(self): return False
+        def preIteration(self, i): pass
+        def postIteration(self, i): pass
+        def verbose(self): return False
+        def buildStructure(self): return True
+        def indexMapping(self): return [v0]
+        def computeActiveErrors(self):
+            for e in self._activeEdges:
+                e.computeError()
+        def _rho(self, e):
+            c = float(e.chi2())
+            if not e.robust or c <= d_mono * d_mono:
+                return c, 1.0
+            return 2 * np.sqrt(c) * d_mono - d_mono * d_mono, d_mono / np.sqrt(c)
+        def activeRobustChi2(self):
+            s_ = 0.0
+            for e in self._activeEdges:
+                s_ += self._rho(e)[0]
+            return F64(s_)
+        def buildSystem(self):
+            v0.H[:] = 0; self.bv[:] = 0
+            for e in self._activeEdges:
+                w = self._rho(e)[1]; om = float(e.e["inv_sigma2"][0]); J = e.B[:2]
+                v0.H += J.T @ (w * om * J); self.bv -= J.T @ (w * om * e.err[:2])
+        def setLambda(self, lam, backup): self.lam = float(lam)
+        def restoreDiagonal(self): pass
+        def solve(self):                                      # LinearSolverDense: Eigen::LDLT, which must report a positive matrix
+            M = v0.H + self.lam * np.eye(6)
+            try:
+                np.linalg.cholesky(M)
+            except np.linalg.LinAlgError:
+                return False
+            self.xv = np.linalg.solve(M, self.bv)
+            return bool(np.isfinite(self.xv).all())
+        def x(self): return [F64(v) for v in self.xv]
+        def b(self): return [F64(v) for v in self.bv]
+        def vectorSize(self): return 6
+        def update(self, x):
+            v0.q, v0.t = oplus(v0.q, v0.t, np.array(x, np.float64)); v0.q = v0.q / np.linalg.norm(v0.q)
+        def push(self): self.stack.append((v0.q.copy(), v0.t.copy()))
+        def pop(self): v0.q, v0.t = self.stack.pop()
+        def discardTop(self): self.stack.pop()
+
+    opt = Optim()
+    real_optimize = opt.optimize
+    def counted(its):
+        if not opt._activeEdges:
+            opt.iters.append(0); return 0
+        k = real_optimize(its); opt.iters.append(k); return k
+    opt.optimize = counted
+
+    def to_se3(T):
+        T = np.asarray(T, np.float32).reshape(4, 4).astype(np.float64)
+        q = quat_from_R(T[:3, :3])
+        return q / np.linalg.norm(q), T[:3, 3].copy()
+
+    class Fr:
+        pass
+    pFrame = Fr(); pFrame.mTcw = pr["Tcw"]; pFrame.mvbOutlier = [False] * n
+    env["Converter_toSE3Quat"] = to_se3
+    if n >= 3:
+        nBad = env["rounds"](pFrame, opt, v0, edges, list(range(n)), [], [], [], [])
+        assert np.array_equal(np.array(pFrame.mvbOutlier, np.uint8), o.outliers), np.nonzero(np.array(pFrame.mvbOutlier, np.uint8) != o.outliers)[0][:10]
+        assert n - nBad == o.n_inliers
+        assert tuple(opt.iters + [0] * (4 - len(opt.iters))) == tuple(o.iters), (opt.iters, o.iters)
+        R = np.array([quat_rot(v0.q, ex) for ex in np.eye(3)]).T
+        assert np.abs(R - o.Tcw[:3, :3]).max() < 1e-6 and np.abs(v0.t - o.Tcw[:3, 3]).max() < 1e-6
