@@ -1679,3 +1679,72 @@ def test_poseoptimization_rounds_are_the_references_text(seed, n, outl):
         assert tuple(opt.iters + [0] * (4 - len(opt.iters))) == tuple(o.iters), (opt.iters, o.iters)
         R = np.array([quat_rot(v0.q, ex) for ex in np.eye(3)]).T
         assert np.abs(R - o.Tcw[:3, :3]).max() < 1e-6 and np.abs(v0.t - o.Tcw[:3, 3]).max() < 1e-6
+
+
+@pytest.mark.parametrize("check", [True, False])
+def test_searchbybow_between_keyframes_is_the_references_text(check):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) -- S/ORBmatcher.cc:819-959 (the server's loop / merge matcher) --
+    WHOLE: FeatureVector merge, best / second-best among the second keyframe's unmatched valid points of the node, the strict TH_LOW and the
+    float ratio test, vbMatched2, the rotation histogram -- transliterated from the text -- against the oracle's matches12."""
+    path = os.path.join(REF, "src", "ORBmatcher.cc")
+    body = _body(path, r"int\s+ORBmatcher::SearchByBoW\s*\(\s*KeyFrame\s*\*pKF1,\s*KeyFrame\s*\*pKF2,[^)]*\)\s*\{")
+    body = body.replace("static_cast<float>(", "F32(").replace(".push_back(", ".append(")
+    body = body.replace("vpMatches12 = vector<MapPoint*>(vpMapPoints1.size(),static_cast<MapPoint*>(NULL));", "vpMatches12.clear(); vpMatches12.extend([None] * len(vpMapPoints1));")
+    body = body.replace("vector<bool> vbMatched2(vpMapPoints2.size(),false);", "vbMatched2 = [False] * len(vpMapPoints2);")
+    body = re.sub(r"vector<int> rotHist\[HISTO_LENGTH\];\s*for\(int i=0;i<HISTO_LENGTH;i\+\+\)\s*rotHist\[i\]\.reserve\(500\);", "rotHist = [[] for _ in range(HISTO_LENGTH)];", body)
+    body = re.sub(r"assert\([^;]*\);", "", body).replace("static_cast<MapPoint*>(NULL)", "None")
+    body = body.replace("ComputeThreeMaxima(rotHist,HISTO_LENGTH,ind1,ind2,ind3);", "ind = ComputeThreeMaxima(rotHist,HISTO_LENGTH,ind1,ind2,ind3); ind1 = ind[0]; ind2 = ind[1]; ind3 = ind[2];")
+    body = body.replace("for(size_t j=0, jend=rotHist[i].size(); j<jend; j++)", "for(int j=0; j<len(rotHist[i]); j++)")
+    body = body.replace("for(size_t i1=0, iend1=f1it->second.size(); i1<iend1; i1++)", "for(int i1=0; i1<len(f1it->second); i1++)")
+    body = body.replace("for(size_t i2=0, iend2=f2it->second.size(); i2<iend2; i2++)", "for(int i2=0; i2<len(f2it->second); i2++)")
+    src = c_to_python(cpp_prepare(body), keep_returns=True)
+    assert src.count("while ") == 1 and src.count("lower_bound") == 2 and "vbMatched2[bestIdx2]=True" in src
+    tm = _body(path, r"void\s+ORBmatcher::ComputeThreeMaxima\s*\([^)]*\)\s*\{")
+    tm_src = c_to_python(cpp_prepare(tm.replace("const int s = histo[i].size()", "int s = len(histo[i])")))
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def ComputeThreeMaxima(histo, L, ind1, ind2, ind3):\n" + ind(tm_src) + "\n    return (ind1, ind2, ind3)\n" +
+            "def SearchByBoW(pKF1, pKF2, vpMatches12):\n" + ind(src))
+
+    class Kp:
+        def __init__(self, a): self.angle = F32(a)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[int(i)]
+
+    class Obj:
+        pass
+
+    rng = np.random.RandomState(90 + check)
+    n1, n2, n_nodes = 700, 750, 80
+    d1 = rng.randint(0, 256, (n1, 32)).astype(np.uint8); node1 = rng.randint(0, n_nodes, n1) * 2; ang1 = rng.uniform(0, 360, n1).astype(np.float32)
+    src1 = rng.randint(0, n1, n2)
+    flips = rng.randint(0, 256, (n2, 32)).astype(np.uint8) & rng.randint(0, 256, (n2, 32)).astype(np.uint8) & rng.randint(0, 256, (n2, 32)).astype(np.uint8)
+    d2 = d1[src1] ^ np.where(rng.rand(n2, 1) < 0.7, flips & rng.randint(0, 256, (n2, 32)).astype(np.uint8), rng.randint(0, 256, (n2, 32)).astype(np.uint8))
+    node2 = np.where(rng.rand(n2) < 0.85, node1[src1], rng.randint(0, n_nodes * 2 + 3, n2))
+    ang2 = ((ang1[src1] - 17.0 + rng.uniform(-6, 6, n2) + np.where(rng.rand(n2) < 0.2, rng.uniform(50, 310, n2), 0)) % 360).astype(np.float32)
+    valid1 = (rng.rand(n1) < 0.8).astype(np.uint8); valid2 = (rng.rand(n2) < 0.8).astype(np.uint8)
+    kps2 = np.zeros(n2, capi.KEYPOINT_DTYPE); kps2["angle"] = ang2; kps2["x"] = 10; kps2["y"] = 10
+    kf2, keep = views.frame_view(kps2, d2, bounds=(0, 640, 0, 480), cam=(458.6, 457.3, 320.0, 240.0, 38.0, 0.08))
+    a, b_, c = views.featvec_from_nodes(node1); fv1, k1 = views.featvec_view(a, b_, c)
+    a, b_, c = views.featvec_from_nodes(node2); fv2, k2 = views.featvec_view(a, b_, c)
+    matches12, nm = ob.search_by_bow_kf(kf2, fv2, valid2, d1, valid1, ang1, fv1, 0.75, check)
+    env = dict(ENV, F32=F32, F64=F64, TH_LOW=50, HISTO_LENGTH=30, mbCheckOrientation=check, mfNNratio=F32(0.75),
+               round=lambda v: int(np.copysign(np.floor(np.abs(F64(v)) + 0.5), v)), DescriptorDistance=lambda x, y: int(np.unpackbits(x ^ y).sum()))
+
+    def keyframe(desc, node, ang, valid):
+        kf = Obj(); mps = []
+        for i in range(len(desc)):
+            q = Obj(); q.id = i; q.isBad = (lambda: False)
+            mps.append(q if valid[i] else None)
+        kf.GetMapPointMatches = lambda: mps
+        kf.mFeatVec = CppMap({int(k): [int(v) for v in np.nonzero(node == k)[0]] for k in np.unique(node)})
+        kf.mDescriptors = Desc(desc); kf.NLeft = -1; kf.mvKeysUn = [Kp(v) for v in ang]
+        return kf
+
+    exec(prog, env)
+    out = []
+    nm_ref = env["SearchByBoW"](keyframe(d1, node1, ang1, valid1), keyframe(d2, node2, ang2, valid2), out)
+    mine = np.array([-1 if p_ is None else p_.id for p_ in out], np.int32)
+    assert nm_ref == nm and nm > 120, (nm_ref, nm)
+    assert np.array_equal(mine, matches12), np.nonzero(mine != matches12)[0][:10]
