@@ -1748,3 +1748,32 @@ def test_searchbybow_between_keyframes_is_the_references_text(check):
     mine = np.array([-1 if p_ is None else p_.id for p_ in out], np.int32)
     assert nm_ref == nm and nm > 120, (nm_ref, nm)
     assert np.array_equal(mine, matches12), np.nonzero(mine != matches12)[0][:10]
+
+
+def test_distinctive_descriptor_choice_is_the_references_text():
+    """MapPoint::ComputeDistinctiveDescriptors (S/MapPoint.cc:490-517): the pairwise distance table, each row sorted, the element at
+    index 0.5 * (N - 1) (truncated) as its median, the first row with the smallest median -- transliterated -- against the oracle's choice."""
+    body = _body(os.path.join(REF, "src", "MapPoint.cc"), r"void\s+MapPoint::ComputeDistinctiveDescriptors\s*\(\s*\)\s*\{")
+    piece = body[body.index("const size_t N = vDescriptors.size();"):body.index("unique_lock<mutex> lock(mMutexFeatures);")]
+    piece = piece[:piece.rindex("{")]
+    rep = [("float Distances[N][N];", "Distances = [[F32(0)] * N for _ in range(N)];"), ("ORBmatcher::", ""),
+           ("vector<int> vDists(Distances[i],Distances[i]+N);", "vDists = [int(v) for v in Distances[i]];"),
+           ("sort(vDists.begin(),vDists.end());", "vDists.sort();"), ("vDists[0.5*(N-1)]", "vDists[int(0.5*(N-1))]")]
+    for a, b in rep:
+        assert a in piece, a
+        piece = piece.replace(a, b)
+    src = c_to_python(cpp_prepare(piece))
+    assert src.count("for i in range(0, N)") == 2 and "for j in range(i+1, N)" in src and "median<BestMedian" in src
+    rng = np.random.RandomState(95)
+    groups, starts = [], [0]
+    for g in range(300):
+        m = rng.choice([1, 2, 3, 4, 5, 8, 13, 30])
+        base = rng.randint(0, 256, 32).astype(np.uint8)
+        d = np.stack([base ^ (rng.randint(0, 256, 32).astype(np.uint8) & rng.randint(0, 256, 32).astype(np.uint8) & rng.randint(0, 256, 32).astype(np.uint8) if rng.rand() < 0.8 else rng.randint(0, 256, 32).astype(np.uint8))
+                      for _ in range(m)])
+        groups.append(d); starts.append(starts[-1] + m)
+    best = ob.distinctive_descriptors(np.concatenate(groups), np.array(starts, np.int32))
+    for g, d in enumerate(groups):
+        env = dict(ENV, F32=F32, F64=F64, INT_MAX=2147483647, vDescriptors=[r for r in d], DescriptorDistance=lambda a, b: int(np.unpackbits(a ^ b).sum()))
+        exec(src, env)
+        assert env["BestIdx"] == int(best[g]), (g, len(d), env["BestIdx"], best[g])
