@@ -538,7 +538,7 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
         if st.startswith("const uchar*") or (st.startswith("return") and not keep_returns):
             continue
         if st.startswith("return"):
-            emit(st)
+            emit(("return " + _expr(st[len("return"):].strip(), ())).rstrip())
             while pending and pending[-1]:
                 depth -= 1; pending.pop()
             continue
@@ -891,7 +891,9 @@ class MatF:
     def t(self): return MatF(self.a.T.copy())
     def __neg__(self): return MatF(-self.a)
     def __add__(self, o): return MatF(self.a + o.a)
+    def __sub__(self, o): return MatF(self.a - o.a)
     def at(self, i, j=0): return F32(self.a[i, j])
+    def norm(self): return F32(np.sqrt(np.sum(self.a.astype(np.float64).reshape(-1) ** 2)))      # cv::norm(NORM_L2): double accumulator
 
     def __mul__(self, o):
         out = np.zeros((self.a.shape[0], o.a.shape[1]), np.float32)
@@ -1777,3 +1779,137 @@ def test_distinctive_descriptor_choice_is_the_references_text():
         env = dict(ENV, F32=F32, F64=F64, INT_MAX=2147483647, vDescriptors=[r for r in d], DescriptorDistance=lambda a, b: int(np.unpackbits(a ^ b).sum()))
         exec(src, env)
         assert env["BestIdx"] == int(best[g]), (g, len(d), env["BestIdx"], best[g])
+
+
+@pytest.mark.parametrize("check", [True, False])
+def test_searchbyprojection_for_relocalisation_is_the_references_text(check):
+    """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist) -- S/ORBmatcher.cc:2188-2310 -- WHOLE, with
+    MapPoint::PredictScale / GetMin- / GetMaxDistanceInvariance (S/MapPoint.cc:617-661) transliterated too: no depth-sign test, inclusive
+    bounds, the distance range, the level window, ANY point on a feature blocks it, ORBdist, the rotation histogram -- against the
+    oracle.  (cv::Mat products / norm: the stand-in's arithmetic, as for the other overloads.)"""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    path = os.path.join(REF, "src", "ORBmatcher.cc")
+    body = _body(path, r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&CurrentFrame,\s*KeyFrame\s*\*pKF,\s*const\s+set<MapPoint\*>[^)]*\)\s*\{")
+    body = re.sub(r"for\(vector<size_t>::const_iterator vit=vIndices2\.begin\(\); vit!=vIndices2\.end\(\); vit\+\+\)\s*\{\s*const size_t i2 = \*vit;", "foreach(i2, vIndices2) {", body)
+    assert body.count("foreach(i2, vIndices2)") == 1
+    body = re.sub(r"vector<int> rotHist\[HISTO_LENGTH\];\s*for\(int i=0;i<HISTO_LENGTH;i\+\+\)\s*rotHist\[i\]\.reserve\(500\);", "rotHist = [[] for _ in range(HISTO_LENGTH)];", body)
+    body = body.replace(".push_back(", ".append(").replace("cv::norm(PO)", "PO.norm()").replace("&CurrentFrame", "CurrentFrame").replace("=NULL;", "=None;")
+    body = re.sub(r"assert\([^;]*\);", "", body)
+    body = body.replace("ComputeThreeMaxima(rotHist,HISTO_LENGTH,ind1,ind2,ind3);", "ind = ComputeThreeMaxima(rotHist,HISTO_LENGTH,ind1,ind2,ind3); ind1 = ind[0]; ind2 = ind[1]; ind3 = ind[2];")
+    body = body.replace("for(size_t j=0, jend=rotHist[i].size(); j<jend; j++)", "for(int j=0; j<len(rotHist[i]); j++)")
+    body = body.replace("for(size_t i=0, iend=vpMPs.size(); i<iend; i++)", "for(int i=0; i<len(vpMPs); i++)")
+    src = c_to_python(cpp_prepare(body), keep_returns=True)
+    assert "sAlreadyFound.count(pMP)" in src and "PredictScale(dist3D,CurrentFrame)" in src and "bestDist<=ORBdist" in src
+    mp_path = os.path.join(REF, "src", "MapPoint.cc")
+    ps = _body(mp_path, r"int\s+MapPoint::PredictScale\s*\(\s*const float &currentDist,\s*Frame\*\s*pF\s*\)\s*\{")
+    ps = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", ps).replace("float ratio;", "")
+    ps = re.sub(r"\{\s*(ratio = [^;]*;)\s*\}", r"\1", ps)
+    ps = re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", ps)
+    ps_src = c_to_python(cpp_prepare(ps), typed_ints=True, keep_returns=True, float_vars=())
+    assert "ceil(log(ratio)/pF.mfLogScaleFactor)" in ps_src
+    getters = {}
+    for nm in ("GetMinDistanceInvariance", "GetMaxDistanceInvariance"):
+        g = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", _body(mp_path, r"float\s+MapPoint::%s\s*\(\s*\)\s*\{" % nm))
+        g = re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", g)
+        getters[nm] = c_to_python(cpp_prepare(g), keep_returns=True)
+    tm = _body(path, r"void\s+ORBmatcher::ComputeThreeMaxima\s*\([^)]*\)\s*\{")
+    tm_src = c_to_python(cpp_prepare(tm.replace("const int s = histo[i].size()", "int s = len(histo[i])")))
+    pj = _body(os.path.join(REF, "src", "CameraModels", "Pinhole.cpp"), r"cv::Point2f\s+Pinhole::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    ex, ey = _split_top(re.search(r"return cv::Point2f\((.*)\)\s*;", pj, flags=re.S).group(1).replace("\n", " "))
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def ComputeThreeMaxima(histo, L, ind1, ind2, ind3):\n" + ind(tm_src) + "\n    return (ind1, ind2, ind3)\n" +
+            "def PredictScale(self, currentDist, pF):\n" + ind(ps_src) + "\n" +
+            "def GetMinDistanceInvariance(self):\n" + ind(getters["GetMinDistanceInvariance"]) + "\n" +
+            "def GetMaxDistanceInvariance(self):\n" + ind(getters["GetMaxDistanceInvariance"]) + "\n" +
+            "def SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist):\n" + ind(src))
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o, a): self.pt, self.octave, self.angle = Pt(x, y), int(o), F32(a)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[int(i)]
+
+    class Obj:
+        pass
+
+    class AlreadyFound:
+        def __init__(self, ids): self.ids = set(ids)
+        def count(self, p_): return 1 if p_.id in self.ids else 0
+
+    fx, fy, cx, cy, bf, b = F32(458.6), F32(457.3), F32(320.0), F32(240.0), F32(38.0), F32(0.0829)
+    params = [fx, fy, cx, cy]
+
+    class Cam:
+        def project(self, m):
+            e2 = {"mvParameters": params, "p3D": Obj()}
+            e2["p3D"].x, e2["p3D"].y, e2["p3D"].z = m.at(0), m.at(1), m.at(2)
+            return Pt(eval(ex, e2), eval(ey, e2))
+
+    rng = np.random.RandomState(97 + check)
+    n, m = 900, 700
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    kps = np.zeros(n, capi.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(5, 635, n).astype(np.float32); kps["y"] = rng.uniform(5, 475, n).astype(np.float32)
+    kps["octave"] = rng.randint(0, 8, n); kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    desc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    fv, keep = views.frame_view(kps, desc, bounds=bounds, cam=(float(fx), float(fy), float(cx), float(cy), float(bf), float(b)))
+    start, items = ob.build_grid(fv)
+    sc = np.ones(8, np.float32)
+    for l in range(1, 8):
+        sc[l] = np.float32(sc[l - 1] * np.float32(1.2))
+    Tc = np.eye(4, dtype=np.float32); Tc[:3, :3] = np.array([[0.9998, -0.012, 0.016], [0.0121, 0.9999, -0.006], [-0.0159, 0.0062, 0.9998]], np.float32)
+    Tc[:3, 3] = [0.3, -0.1, 0.2]
+    tgt = rng.randint(0, n, m)
+    z = rng.uniform(2, 20, m)
+    u = kps["x"][tgt] + rng.uniform(-5, 5, m); v = kps["y"][tgt] + rng.uniform(-5, 5, m)
+    Pc = np.stack([(u - float(cx)) * z / float(fx), (v - float(cy)) * z / float(fy), z], 1)
+    Xw = ((Pc - Tc[:3, 3].astype(np.float64)) @ Tc[:3, :3].astype(np.float64)).astype(np.float32)
+    Xw[:30, 2] -= 60.0                                      # behind the camera: no depth-sign test in this overload
+    mdesc = desc[tgt] ^ (rng.randint(0, 256, (m, 32)).astype(np.uint8) & rng.randint(0, 256, (m, 32)).astype(np.uint8) & rng.randint(0, 256, (m, 32)).astype(np.uint8))
+    ref_oct = np.clip(kps["octave"][tgt] + rng.randint(-1, 2, m), 0, 7)
+    Ow = -(Tc[:3, :3].astype(np.float64).T @ Tc[:3, 3].astype(np.float64))
+    dist = np.linalg.norm(Xw.astype(np.float64) - Ow, axis=1)
+    # (0.93: the predicted level is ceil(log(maxd / dist) / log 1.2) -- keep the ratio off the powers of 1.2, where the last bit of dist decides)
+    maxd = (dist * sc[ref_oct] * 0.93).astype(np.float32) * rng.choice([1.0, 1.0, 1.0, 0.5, 3.0], m).astype(np.float32); mind = (maxd / sc[7]).astype(np.float32)
+    bad = (rng.rand(m) < 0.1).astype(np.uint8); found = (rng.rand(m) < 0.1).astype(np.uint8)
+    kangle = ((kps["angle"][tgt] + 40.0 + rng.uniform(-6, 6, m) + np.where(rng.rand(m) < 0.2, rng.uniform(50, 310, m), 0)) % 360).astype(np.float32)
+    amp0 = np.full(n, -1, np.int32); occ = rng.rand(n) < 0.1; amp0[occ] = 100000 + np.arange(occ.sum())
+    wv, keep2 = views.worldpoints_view(Xw, np.zeros((m, 3), np.float32), mind, maxd, mdesc, np.ones(m, np.int32), bad)
+    amp, nm = ob.search_by_projection_reloc(fv, Tc, wv, kangle, amp0, 10.0, 100, check, found)
+    # ---- the reference's text on stand-ins
+    env = dict(ENV, F32=F32, F64=F64, abs=abs, fabs=abs, HISTO_LENGTH=30, mbCheckOrientation=check, as_int=lambda x: int(x), floor=np.floor, ceil=np.ceil,
+               log=lambda x: F32(libm.logf(float(F32(x)))), round=lambda a: int(np.copysign(np.floor(np.abs(F64(a)) + 0.5), a)),
+               DescriptorDistance=lambda a, b2: int(np.unpackbits(a ^ b2).sum()))
+    exec(prog, env)
+    Cur, KF = Obj(), Obj()
+    Cur.mTcw = MatF(Tc); Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY = [F32(x) for x in bounds]; Cur.mpCamera = Cam()
+    Cur.mvScaleFactors = [F32(x) for x in sc]; Cur.mDescriptors = Desc(desc); Cur.mvKeysUn = [Kp(k["x"], k["y"], k["octave"], k["angle"]) for k in kps]
+    Cur.mfLogScaleFactor = F32(np.log(np.float32(1.2))); Cur.mnScaleLevels = 8
+    Cur.mvpMapPoints = [None] * n
+    for i in np.nonzero(occ)[0]:
+        o = Obj(); o.id = int(amp0[i]); Cur.mvpMapPoints[i] = o
+    genv = dict(env, mnMinX=F32(bounds[0]), mnMinY=F32(bounds[2]), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
+                mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / F32(F32(bounds[1]) - F32(bounds[0]))),
+                mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / F32(F32(bounds[3]) - F32(bounds[2]))),
+                mGrid=[[[int(x) for x in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)]
+                       for ix in range(capi.GRID_COLS)], mvKeysUn=Cur.mvKeysUn)
+    exec(_get_features_in_area_source(), genv)
+    Cur.GetFeaturesInArea = lambda x, y, r, lo=-1, hi=-1, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), lo, hi, bRight)
+    MPc = type("MapPoint", (), {"PredictScale": env["PredictScale"], "GetMinDistanceInvariance": env["GetMinDistanceInvariance"],
+                                "GetMaxDistanceInvariance": env["GetMaxDistanceInvariance"]})
+    mps = []
+    for i in range(m):
+        q = MPc(); q.id = i; q.mfMaxDistance = F32(maxd[i]); q.mfMinDistance = F32(mind[i]); q.bad = bool(bad[i])
+        q.isBad = (lambda q=q: q.bad); q.GetWorldPos = (lambda i=i: MatF(Xw[i].reshape(3, 1))); q.GetDescriptor = (lambda i=i: mdesc[i])
+        mps.append(q)
+    KF.GetMapPointMatches = lambda: mps
+    KF.mvKeysUn = [Kp(0, 0, 0, a) for a in kangle]
+    nm_ref = env["SearchByProjection"](Cur, KF, AlreadyFound(np.nonzero(found)[0]), F32(10.0), 100)
+    amp_ref = np.array([-1 if p_ is None else p_.id for p_ in Cur.mvpMapPoints], np.int32)
+    assert nm_ref == nm and nm > 150, (nm_ref, nm)
+    assert np.array_equal(amp_ref, amp), np.nonzero(amp_ref != amp)[0][:10]
