@@ -1913,3 +1913,33 @@ def test_searchbyprojection_for_relocalisation_is_the_references_text(check):
     amp_ref = np.array([-1 if p_ is None else p_.id for p_ in Cur.mvpMapPoints], np.int32)
     assert nm_ref == nm and nm > 150, (nm_ref, nm)
     assert np.array_equal(amp_ref, amp), np.nonzero(amp_ref != amp)[0][:10]
+
+
+def test_l1_score_is_dbow2s_text():
+    """DBoW2::L1Scoring::score (D/ScoringObject.cpp:23-68): the merge of two BowVectors with lower_bound, the term
+    |vi - wi| - |vi| - |wi| accumulated over the common words in ascending order, -score / 2 -- transliterated -- against the oracle's
+    scores, float64 bit for bit."""
+    body = _body(os.path.join(REF, "Thirdparty", "DBoW2", "DBoW2", "ScoringObject.cpp"), r"double\s+L1Scoring::score\s*\([^)]*\)\s*const\s*\{")
+    body = body.replace("BowVector::const_iterator v1_it, v2_it;", "").replace("const WordValue& vi", "double vi").replace("const WordValue& wi", "double wi")
+    body = body.replace("++v1_it;", "v1_it++;").replace("++v2_it;", "v2_it++;").replace("fabs(", "abs(")
+    src = c_to_python(cpp_prepare(body), keep_returns=True)
+    assert src.count("lower_bound") == 2 and "score += abs(vi - wi) - abs(vi) - abs(wi)" in src and "score = -score/F64(2.0)" in src
+
+    class BowMap(CppMap):
+        def __init__(self, words, values): self.keys = [int(w) for w in words]; self.vals = [F64(v) for v in values]
+
+    rng = np.random.RandomState(99)
+    q_words = np.sort(rng.choice(5000, 300, replace=False)); q_vals = rng.rand(300); q_vals /= q_vals.sum()
+    cands, starts, cw, cv = [], [0], [], []
+    for c in range(60):
+        k = rng.randint(1, 400)
+        w = np.sort(np.unique(np.concatenate([rng.choice(q_words, rng.randint(0, min(k, 200))), rng.choice(5000, k)])))
+        vals = rng.rand(len(w)); vals /= vals.sum()
+        cands.append((w, vals)); cw.extend(w); cv.extend(vals); starts.append(starts[-1] + len(w))
+    scores = ob.score_l1(q_words, q_vals, starts, cw, cv)
+    env = dict(ENV, F64=F64, F32=F32, abs=abs)
+    exec("def score(v1, v2):\n" + "\n".join("    " + ln for ln in src.splitlines()), env)
+    for c, (w, vals) in enumerate(cands):
+        mine = env["score"](BowMap(q_words, q_vals), BowMap(w, vals))
+        assert F64(mine).tobytes() == F64(scores[c]).tobytes(), (c, mine, scores[c])
+    assert (scores > 0).sum() > 30
