@@ -1943,3 +1943,103 @@ def test_l1_score_is_dbow2s_text():
         mine = env["score"](BowMap(q_words, q_vals), BowMap(w, vals))
         assert F64(mine).tobytes() == F64(scores[c]).tobytes(), (c, mine, scores[c])
     assert (scores > 0).sum() > 30
+
+
+def test_detectnbestcandidates_is_the_references_text():
+    """KeyFrameDatabase::DetectNBestCandidates (S/KeyFrameDatabase.cc:594-731) WHOLE: the walk of the inverted file with the per-keyframe
+    query marks, `minCommonWords = maxCommonWords * 0.8f`, the L1 scores (DBoW2's text, transliterated above), the accumulation over the
+    ten best covisible keyframes, the stable descending sort and the loop / merge split by map -- transliterated over stand-ins for
+    KeyFrame / Map -- against the oracle's candidates and place scores, query after query on one database (the marks persist).
+    (No bad keyframe in the data: the reference's `continue` on one does not advance its iterator.)"""
+    import helpers
+    body = _body(os.path.join(REF, "src", "KeyFrameDatabase.cc"), r"void\s+KeyFrameDatabase::DetectNBestCandidates\s*\([^)]*\)\s*\{")
+    rep = [("list<KeyFrame*> lKFsSharingWords;", "lKFsSharingWords = [];"), ("set<KeyFrame*> spConnectedKF;", ""), ("unique_lock<mutex> lock(mMutex);", ""),
+           ("for(DBoW2::BowVector::const_iterator vit=pKF->mBowVec.begin(), vend=pKF->mBowVec.end(); vit != vend; vit++)", "bowitems = pKF->mBowVec.items(); foreach(vit, bowitems)"),
+           ("for(list<KeyFrame*>::iterator lit=lKFs.begin(), lend= lKFs.end(); lit!=lend; lit++) { KeyFrame* pKFi=*lit;", "foreach(pKFi, lKFs) {"),
+           ("list<pair<float,KeyFrame*> > lScoreAndMatch;", "lScoreAndMatch = [];"), ("list<pair<float,KeyFrame*> > lAccScoreAndMatch;", "lAccScoreAndMatch = [];"),
+           ("for(list<pair<float,KeyFrame*> >::iterator it=lScoreAndMatch.begin(), itend=lScoreAndMatch.end(); it!=itend; it++)", "foreach(it, lScoreAndMatch)"),
+           ("for(vector<KeyFrame*>::iterator vit=vpNeighs.begin(), vend=vpNeighs.end(); vit!=vend; vit++) { KeyFrame* pKF2 = *vit;", "foreach(pKF2, vpNeighs) {"),
+           ("lAccScoreAndMatch.sort(compFirst);", "lAccScoreAndMatch.sort(key=compFirstKey);"), ("set<KeyFrame*> spAlreadyAddedKF;", "spAlreadyAddedKF = CppSet();"),
+           ("list<pair<float,KeyFrame*> >::iterator it=lAccScoreAndMatch.begin();", "it = ListIt(lAccScoreAndMatch);"), ("make_pair(", "Pair(")]
+    body = re.sub(r"\s+", " ", body)
+    body = re.sub(r"[\w\.]+\.reserve\([^;]*\);", "", body)
+    for a, b in rep:
+        assert a in body, a
+        body = body.replace(a, b)
+    assert body.count("for(list<KeyFrame*>::iterator lit=lKFsSharingWords.begin(), lend= lKFsSharingWords.end(); lit!=lend; lit++)") == 2
+    body = body.replace("for(list<KeyFrame*>::iterator lit=lKFsSharingWords.begin(), lend= lKFsSharingWords.end(); lit!=lend; lit++) { if((*lit)->mnPlaceRecognitionWords>maxCommonWords) maxCommonWords=(*lit)->mnPlaceRecognitionWords; }",
+                        "foreach(litv, lKFsSharingWords) { if(litv->mnPlaceRecognitionWords>maxCommonWords) maxCommonWords=litv->mnPlaceRecognitionWords; }")
+    body = body.replace("for(list<KeyFrame*>::iterator lit=lKFsSharingWords.begin(), lend= lKFsSharingWords.end(); lit!=lend; lit++) { KeyFrame* pKFi = *lit;", "foreach(pKFi, lKFsSharingWords) {")
+    assert "::iterator" not in body and "*lit" not in body
+    body = re.sub(r"\s+", " ", body)
+    assert "{ spConnectedKF = pKF->GetConnectedKeyFrames();" in body
+    body = body.replace("{ spConnectedKF = pKF->GetConnectedKeyFrames();", "if(True) { spConnectedKF = pKF->GetConnectedKeyFrames();")      # (the mutex's bare block)
+    body = body.replace(".push_back(", ".append(")
+    src = c_to_python(cpp_prepare(body), typed_ints=True, keep_returns=True)
+    assert "minCommonWords = as_int(maxCommonWords*F32(0.8))" in src and "lAccScoreAndMatch.sort(key=compFirstKey)" in src and src.count("while ") == 1
+    sc_body = _body(os.path.join(REF, "Thirdparty", "DBoW2", "DBoW2", "ScoringObject.cpp"), r"double\s+L1Scoring::score\s*\([^)]*\)\s*const\s*\{")
+    sc_body = sc_body.replace("BowVector::const_iterator v1_it, v2_it;", "").replace("const WordValue& vi", "double vi").replace("const WordValue& wi", "double wi")
+    sc_body = sc_body.replace("++v1_it;", "v1_it++;").replace("++v2_it;", "v2_it++;").replace("fabs(", "abs(")
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def l1score(v1, v2):\n" + ind(c_to_python(cpp_prepare(sc_body), keep_returns=True)) +
+            "\ndef DetectNBestCandidates(mvInvertedFile, mpVoc, pKF, vpLoopCand, vpMergeCand, nNumCandidates):\n" + ind(src))
+
+    class Pair:
+        def __init__(self, a, b): self.first, self.second = a, b
+
+    class ListIt:
+        def __init__(self, lst, i=0): self.l, self.i = lst, i
+        def __iadd__(self, k): return ListIt(self.l, self.i + 1)
+        first = property(lambda self: self.l[self.i].first)
+        second = property(lambda self: self.l[self.i].second)
+
+    class CppSet:
+        def __init__(self, it=()): self.s = set(id(x) for x in it)
+        def count(self, x): return 1 if id(x) in self.s else 0
+        def insert(self, x): self.s.add(id(x))
+
+    class BowMap(CppMap):
+        def __init__(self, words, values): self.keys = [int(w) for w in words]; self.vals = [F64(v) for v in values]
+        def items(self): return [Pair(k, v) for k, v in zip(self.keys, self.vals)]
+
+    class MapS:
+        def __init__(self, mid): self.id = mid
+        def IsBad(self): return False
+
+    class KF:
+        pass
+
+    rng = np.random.RandomState(101)
+    db = helpers.random_database(rng, bad_frac=0.0)
+    v, keep = views.database_view(db["inv"], db["bows"], db["covis"], db["map_id"], db["bad"], db["map_bad"], db["n_words"])
+    K = len(db["bows"])
+    maps = {int(m): MapS(int(m)) for m in np.unique(db["map_id"])}
+    kfs = []
+    for k in range(K):
+        f = KF(); f.idx = k; f.mnId = 1000 + k; f.mnPlaceRecognitionQuery = -1; f.mnPlaceRecognitionWords = 0; f.mPlaceRecognitionScore = F32(0)
+        f.mBowVec = BowMap(*db["bows"][k]); f.map = maps[int(db["map_id"][k])]
+        f.GetMap = (lambda f=f: f.map); f.isBad = (lambda: False)
+        kfs.append(f)
+    for k in range(K):
+        kfs[k].GetBestCovisibilityKeyFrames = (lambda n, k=k: [kfs[j] for j in db["covis"][k]][:n])
+    inverted = [[kfs[j] for j in db["inv"].get(w, [])] for w in range(db["n_words"])]
+    env = dict(ENV, F32=F32, F64=F64, abs=abs, as_int=lambda x: int(x), Pair=Pair, ListIt=ListIt, CppSet=CppSet, compFirstKey=lambda pr_: -float(pr_.first))
+    exec(prog, env)
+    voc = type("Voc", (), {"score": staticmethod(lambda a, b: env["l1score"](a, b))})()
+    place_o = np.zeros(K, np.float32)
+    hits = 0
+    for qn in range(15):
+        kq = int(rng.randint(K))
+        qw, qv = db["bows"][kq]
+        con = np.zeros(K, np.uint8); con[max(kq - 3, 0): kq + 4] = 1
+        loop, merge = ob.detect_n_best_candidates(v, qw, qv, con, int(db["map_id"][kq]), 3, place_o)
+        q = KF(); q.mnId = 50000 + qn; q.mBowVec = BowMap(qw, qv); q.map = maps[int(db["map_id"][kq])]; q.GetMap = (lambda q=q: q.map)
+        q.GetConnectedKeyFrames = (lambda con=con: CppSet(kfs[j] for j in np.nonzero(con)[0]))
+        vl, vm = [], []
+        env["DetectNBestCandidates"](inverted, voc, q, vl, vm, 3)
+        assert [f.idx for f in vl] == loop.tolist() and [f.idx for f in vm] == merge.tolist(), (qn, [f.idx for f in vl], loop, [f.idx for f in vm], merge)
+        scored = np.array([f.mnPlaceRecognitionQuery == q.mnId for f in kfs])
+        mine = np.array([f.mPlaceRecognitionScore for f in kfs], np.float32)
+        assert np.array_equal(mine[scored & (mine != 0)], place_o[scored & (mine != 0)])
+        hits += len(vl) + len(vm)
+    assert hits > 15
