@@ -894,6 +894,14 @@ class MatF:
     def __sub__(self, o): return MatF(self.a - o.a)
     def at(self, i, j=0): return F32(self.a[i, j])
     def norm(self): return F32(np.sqrt(np.sum(self.a.astype(np.float64).reshape(-1) ** 2)))      # cv::norm(NORM_L2): double accumulator
+    def row(self, i): return MatF(self.a[i:i + 1, :])
+    def __truediv__(self, v): return MatF(self.a / F32(v))
+
+    def dot(self, o):                                         # cv::Mat::dot: a double sum
+        acc = F64(0)
+        for x, y in zip(self.a.reshape(-1), o.a.reshape(-1)):
+            acc = F64(acc + F64(x) * F64(y))
+        return acc
 
     def __mul__(self, o):
         out = np.zeros((self.a.shape[0], o.a.shape[1]), np.float32)
@@ -2043,3 +2051,144 @@ def test_detectnbestcandidates_is_the_references_text():
         assert np.array_equal(mine[scored & (mine != 0)], place_o[scored & (mine != 0)])
         hits += len(vl) + len(vm)
     assert hits > 15
+
+
+def _keyframe_get_features_in_area_source():
+    """KeyFrame::GetFeaturesInArea (S/KeyFrame.cc:889-940) as a Python function of (x, y, r, bRight)."""
+    body = _body(os.path.join(REF, "src", "KeyFrame.cc"), r"vector<size_t>\s+KeyFrame::GetFeaturesInArea\s*\([^)]*\)\s*const\s*\{")
+    body = body.replace("vector<size_t> vIndices;", "vIndices = [];").replace("vIndices.reserve(N);", "")
+    body = body.replace("const vector<size_t> vCell = (!bRight) ? mGrid[ix][iy] : mGridRight[ix][iy];", "vCell = mGrid[ix][iy];")
+    body = body.replace("for(size_t j=0, jend=vCell.size(); j<jend; j++)", "for(int j=0; j<len(vCell); j++)")
+    body = re.sub(r"const cv::KeyPoint &kpUn = \(NLeft == -1\) \? mvKeysUn\[vCell\[j\]\]\s*:\s*\(!bRight\) \? mvKeys\[vCell\[j\]\]\s*:\s*mvKeysRight\[vCell\[j\]\];",
+                  "kpUn = mvKeysUn[vCell[j]];", body)
+    body = body.replace("vIndices.push_back(", "vIndices.append(").replace("fabs(", "abs(").replace("(int)mnGrid", "mnGrid")
+    assert "?" not in body
+    py = c_to_python(body, typed_ints=True, keep_returns=True)
+    return "def GetFeaturesInArea(x, y, r, bRight=False):\n" + "\n".join("    " + ln for ln in py.splitlines())
+
+
+def test_searchbyprojection_with_a_sim3_is_the_references_text():
+    """ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, vpPoints, vpMatched, th, ratioHamming) -- S/ORBmatcher.cc:473-587, the server's
+    loop / merge matcher -- WHOLE, with KeyFrame::GetFeaturesInArea and IsInImage (S/KeyFrame.cc:889-945), MapPoint::PredictScale(dist, pKF)
+    and the distance getters transliterated: the Sim3 decomposition, depth sign, image bounds (half open here), distance range, the 60-degree
+    test on the normal, the level filter inside the window, TH_LOW * ratioHamming -- against the oracle."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    path = os.path.join(REF, "src", "ORBmatcher.cc")
+    body = _body(path, r"int\s+ORBmatcher::SearchByProjection\s*\(\s*KeyFrame\*\s*pKF,\s*cv::Mat Scw,\s*const vector<MapPoint\*> &vpPoints,\s*vector<MapPoint\*> &vpMatched, int th, float ratioHamming\)\s*\{")
+    body = re.sub(r"for\(vector<size_t>::const_iterator vit=vIndices\.begin\(\), vend=vIndices\.end\(\); vit!=vend; vit\+\+\)\s*\{\s*const size_t idx = \*vit;", "foreach(idx, vIndices) {", body)
+    rep = [("set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());", "spAlreadyFound = IdSet(vpMatched);"), ("spAlreadyFound.erase(static_cast<MapPoint*>(NULL));", ""),
+           ("for(int iMP=0, iendMP=vpPoints.size(); iMP<iendMP; iMP++)", "for(int iMP=0; iMP<len(vpPoints); iMP++)"), (".at<float>(", ".at("),
+           ("cv::Point3f(x,y,z)", "Point3f(x,y,z)"), ("cv::norm(PO)", "PO.norm()"), ("sqrt(sRcw.row(0).dot(sRcw.row(0)))", "sqrt(sRcw.row(0).dot(sRcw.row(0)))")]
+    for a, b in rep:
+        assert a in body, a
+        body = body.replace(a, b)
+    src = c_to_python(cpp_prepare(body), keep_returns=True)
+    assert "pKF.IsInImage(uv.x,uv.y)" in src and "PO.dot(Pn)<F64(0.5)*dist" in src and "bestDist<=TH_LOW*ratioHamming" in src
+    mp_path = os.path.join(REF, "src", "MapPoint.cc")
+    ps = _body(mp_path, r"int\s+MapPoint::PredictScale\s*\(\s*const float &currentDist,\s*KeyFrame\*\s*pKF\s*\)\s*\{")
+    ps = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", ps).replace("float ratio;", "")
+    ps = re.sub(r"\{\s*(ratio = [^;]*;)\s*\}", r"\1", ps)
+    ps = re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", ps)
+    ps_src = c_to_python(cpp_prepare(ps), typed_ints=True, keep_returns=True)
+    getters = {}
+    for nm in ("GetMinDistanceInvariance", "GetMaxDistanceInvariance"):
+        g = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", _body(mp_path, r"float\s+MapPoint::%s\s*\(\s*\)\s*\{" % nm))
+        getters[nm] = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", g)), keep_returns=True)
+    isin = c_to_python(cpp_prepare(_body(os.path.join(REF, "src", "KeyFrame.cc"), r"bool\s+KeyFrame::IsInImage\s*\([^)]*\)\s*const\s*\{")).replace("&&", " and "), keep_returns=True)
+    pj = _body(os.path.join(REF, "src", "CameraModels", "Pinhole.cpp"), r"cv::Point2f\s+Pinhole::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    ex, ey = _split_top(re.search(r"return cv::Point2f\((.*)\)\s*;", pj, flags=re.S).group(1).replace("\n", " "))
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def PredictScale(self, currentDist, pKF):\n" + ind(ps_src) + "\ndef GetMinDistanceInvariance(self):\n" + ind(getters["GetMinDistanceInvariance"]) +
+            "\ndef GetMaxDistanceInvariance(self):\n" + ind(getters["GetMaxDistanceInvariance"]) +
+            "\ndef SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming):\n" + ind(src))
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o): self.pt, self.octave = Pt(x, y), int(o)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[int(i)]
+
+    class Obj:
+        pass
+
+    class IdSet:
+        def __init__(self, lst): self.ids = set(p_.id for p_ in lst if p_ is not None)
+        def count(self, p_): return 1 if p_.id in self.ids else 0
+
+    class Point3f:
+        def __init__(self, x, y, z): self.x, self.y, self.z = F32(x), F32(y), F32(z)
+
+    fx, fy, cx, cy = F32(458.6), F32(457.3), F32(320.0), F32(240.0)
+    params = [fx, fy, cx, cy]
+
+    class Cam:
+        def project(self, p3):
+            return Pt(eval(ex, {"mvParameters": params, "p3D": p3}), eval(ey, {"mvParameters": params, "p3D": p3}))
+
+    rng = np.random.RandomState(103)
+    n, m = 900, 800
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    kps = np.zeros(n, capi.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(5, 635, n).astype(np.float32); kps["y"] = rng.uniform(5, 475, n).astype(np.float32); kps["octave"] = rng.randint(0, 8, n)
+    desc = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    fv, keep = views.frame_view(kps, desc, bounds=bounds, cam=(float(fx), float(fy), float(cx), float(cy), 38.0, 0.08))
+    start, items = ob.build_grid(fv)
+    sc = np.ones(8, np.float32)
+    for l in range(1, 8):
+        sc[l] = np.float32(sc[l - 1] * np.float32(1.2))
+    scale = 1.37
+    R = np.array([[0.9998, -0.012, 0.016], [0.0121, 0.9999, -0.006], [-0.0159, 0.0062, 0.9998]])
+    t = np.array([0.3, -0.1, 0.2])
+    Scw = np.eye(4, dtype=np.float32); Scw[:3, :3] = (scale * R).astype(np.float32); Scw[:3, 3] = (scale * t).astype(np.float32)
+    tgt = rng.randint(0, n, m)
+    z = rng.uniform(2, 20, m)
+    u = kps["x"][tgt] + rng.uniform(-4, 4, m); v = kps["y"][tgt] + rng.uniform(-4, 4, m)
+    Pc = np.stack([(u - float(cx)) * z / float(fx), (v - float(cy)) * z / float(fy), z], 1)
+    Xw = ((Pc - t) @ R).astype(np.float32)
+    Xw[:30, 2] -= 60.0
+    Ow = -(R.T @ t)
+    PO = Xw.astype(np.float64) - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    normal = (PO / dist[:, None] + rng.randn(m, 3) * np.where(rng.rand(m, 1) < 0.2, 1.5, 0.1)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    mdesc = desc[tgt] ^ (rng.randint(0, 256, (m, 32)).astype(np.uint8) & rng.randint(0, 256, (m, 32)).astype(np.uint8) & rng.randint(0, 256, (m, 32)).astype(np.uint8))
+    ref_oct = np.clip(kps["octave"][tgt] + rng.randint(0, 2, m), 0, 7)
+    maxd = (dist * sc[ref_oct] * 0.93).astype(np.float32) * rng.choice([1.0, 1.0, 1.0, 0.5, 3.0], m).astype(np.float32); mind = (maxd / sc[7]).astype(np.float32)
+    bad = (rng.rand(m) < 0.08).astype(np.uint8)
+    matched0 = np.full(n, -1, np.int32)
+    pre = rng.choice(n, 80, replace=False); matched0[pre] = rng.choice(m, 80, replace=False)          # features that already hold one of the points
+    found = np.zeros(m, np.uint8); found[matched0[pre]] = 1
+    wv, keep2 = views.worldpoints_view(Xw, normal, mind, maxd, mdesc, np.ones(m, np.int32), bad)
+    matched, nm = ob.search_by_projection_sim3(fv, wv, Scw, matched0, 8, ratio_hamming=1.0, already_found=found)
+    env = dict(ENV, F32=F32, F64=F64, abs=abs, TH_LOW=50, as_int=lambda x: int(x), floor=np.floor, ceil=np.ceil, IdSet=IdSet, Point3f=Point3f,
+               log=lambda x: F32(libm.logf(float(F32(x)))), DescriptorDistance=lambda a, b2: int(np.unpackbits(a ^ b2).sum()))
+    exec(prog, env)
+    MPc = type("MapPoint", (), {"PredictScale": env["PredictScale"], "GetMinDistanceInvariance": env["GetMinDistanceInvariance"],
+                                "GetMaxDistanceInvariance": env["GetMaxDistanceInvariance"]})
+    mps = []
+    for i in range(m):
+        q = MPc(); q.id = i; q.mfMaxDistance = F32(maxd[i]); q.mfMinDistance = F32(mind[i]); q.bad = bool(bad[i]); q.isBad = (lambda q=q: q.bad)
+        q.GetWorldPos = (lambda i=i: MatF(Xw[i].reshape(3, 1))); q.GetNormal = (lambda i=i: MatF(normal[i].reshape(3, 1))); q.GetDescriptor = (lambda i=i: mdesc[i])
+        mps.append(q)
+    KF = Obj()
+    KF.fx, KF.fy, KF.cx, KF.cy = fx, fy, cx, cy; KF.mpCamera = Cam(); KF.mvScaleFactors = [F32(x) for x in sc]; KF.mfLogScaleFactor = F32(np.log(np.float32(1.2)))
+    KF.mnScaleLevels = 8; KF.mvKeysUn = [Kp(k["x"], k["y"], k["octave"]) for k in kps]; KF.mDescriptors = Desc(desc)
+    genv = dict(env, mnMinX=F32(bounds[0]), mnMinY=F32(bounds[2]), mnMaxX=F32(bounds[1]), mnMaxY=F32(bounds[3]), mnGridCols=capi.GRID_COLS, mnGridRows=capi.GRID_ROWS,
+                mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / F32(F32(bounds[1]) - F32(bounds[0]))),
+                mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / F32(F32(bounds[3]) - F32(bounds[2]))),
+                mGrid=[[[int(x) for x in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)]
+                       for ix in range(capi.GRID_COLS)], mvKeysUn=KF.mvKeysUn)
+    exec(_keyframe_get_features_in_area_source(), genv)
+    exec("def IsInImage(x, y):\n" + ind(isin), genv)
+    KF.GetFeaturesInArea = lambda x, y, r, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), bRight)
+    KF.IsInImage = lambda x, y: genv["IsInImage"](F32(x), F32(y))
+    vpMatched = [None if j < 0 else mps[j] for j in matched0]
+    nm_ref = env["SearchByProjection"](KF, MatF(Scw), mps, vpMatched, 8, F32(1.0))
+    mine = np.array([-1 if p_ is None else p_.id for p_ in vpMatched], np.int32)
+    assert nm_ref == nm and nm > 150, (nm_ref, nm)
+    assert np.array_equal(mine, matched), np.nonzero(mine != matched)[0][:10]
