@@ -506,6 +506,12 @@ def lba_edge_eval(q, t, X, cam5, edge):
     return err, A.reshape(3, 3), B.reshape(3, 6)
 
 
+def robust_huber(e, delta):
+    r = np.zeros(2)
+    lib().oracle_robust_huber(C.c_double(e), C.c_double(delta), C.c_void_p(r.ctypes.data))
+    return r
+
+
 def camera_project(cam, X):
     """GeometricCamera::project / projectJac of cam = (model, fx, fy, cx, cy[, k1..k4]) at X: (uv, 2x3 Jacobian)."""
     rig = views.camera_rig(cam)

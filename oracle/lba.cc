@@ -613,6 +613,11 @@ extern "C" void oracle_lba_edge_eval_rig(const double* q4, const double* t3, con
   if (Xcam3) for (int i = 0; i < 3; i++) Xcam3[i] = Xobs[i];
 }
 
+// RobustKernelHuber::robustify's rho and rho' for the known-answer tests
+extern "C" void oracle_robust_huber(double e, double delta, double* rho2) {
+  huber(e, delta, delta * delta, rho2);
+}
+
 extern "C" void oracle_camera_project(const orbg_camera* cam, const double* X3, double* uv2, double* J6) {
   const CamModel m = cam_model_of(*cam);
   if (uv2) cam_project(m, X3, uv2);

@@ -141,6 +141,8 @@ int oracle_wire_unpack(const uint8_t* wire, int n, orbx_keypoint* kps, uint8_t* 
 int oracle_lba_solve(const lba_problem* p, const volatile int32_t* stop_flag, lba_result* r);
 int oracle_pose_optimize(const pose_opt_problem* p, pose_opt_result* r);
 /* pieces for the known-answer tests */
+/* RobustKernelHuber::robustify (G/core/robust_kernel_impl.cpp:78-91): rho2 = {rho(e), rho'(e)} */
+void oracle_robust_huber(double e, double delta, double* rho2);
 /* GeometricCamera::project / projectJac (Eigen forms) of a pinhole / KannalaBrandt8 camera: uv2 and the 2 x 3 row-major Jacobian */
 void oracle_camera_project(const orbg_camera* cam, const double* X3, double* uv2, double* J6);
 /* one edge of a problem with a camera rig (see oracle_lba_edge_eval); Xcam3 (may be NULL): the point in the observing camera's frame */

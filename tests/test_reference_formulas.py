@@ -2192,3 +2192,63 @@ def test_searchbyprojection_with_a_sim3_is_the_references_text():
     mine = np.array([-1 if p_ is None else p_.id for p_ in vpMatched], np.int32)
     assert nm_ref == nm and nm > 150, (nm_ref, nm)
     assert np.array_equal(mine, matched), np.nonzero(mine != matched)[0][:10]
+
+
+def test_huber_kernel_and_se3_exponential_are_g2os_text():
+    """RobustKernelHuber::robustify (G/core/robust_kernel_impl.cpp:78-91) against the oracle's rho / rho' (float64 bits), and SE3Quat::exp
+    with skew() (G/types/se3quat.h:223-257, G/types/se3_ops.hpp:27-38) -- the small-angle branch at theta < 1e-5 and the Rodrigues
+    branch, over a 3 x 3 matrix stand-in with Eigen's operators -- against the rotation and translation of the oracle's exp()."""
+    G = os.path.join(REF, "Thirdparty", "g2o", "g2o")
+    hub = _body(os.path.join(G, "core", "robust_kernel_impl.cpp"), r"void\s+RobustKernelHuber::robustify\s*\([^)]*\)\s*const\s*\{")
+    hub = re.sub(r"(?<![\w\.])(_delta|dsqr)\b", r"self_\1", hub)
+    hsrc = c_to_python(cpp_prepare(hub))
+    assert "rho[1] = self__delta / sqrte" in hsrc
+    rng = np.random.RandomState(105)
+    for _ in range(500):
+        delta = float(np.float32(np.sqrt(rng.choice([5.991, 7.815]))))
+        e = float(rng.choice([rng.uniform(0, 5), rng.uniform(5, 9), rng.uniform(9, 500), delta * delta]))
+        env = dict(ENV, F64=F64, rho=[F64(0)] * 3, e=F64(e), self__delta=F64(delta), self_dsqr=F64(delta) * F64(delta))
+        exec(hsrc, env)
+        o = ob.robust_huber(e, delta)
+        assert F64(env["rho"][0]).tobytes() == F64(o[0]).tobytes() and F64(env["rho"][1]).tobytes() == F64(o[1]).tobytes(), (e, env["rho"], o)
+
+    class M3:                                                 # Eigen::Matrix3d with the operators exp() uses
+        def __init__(self, a): self.a = np.asarray(a, np.float64)
+        def __add__(self, o): return M3(self.a + o.a)
+        def __mul__(self, o): return M3(self.a @ o.a) if isinstance(o, M3) else (V3(self.a @ o.a) if isinstance(o, V3) else M3(self.a * o))
+        def __rmul__(self, k): return M3(F64(k) * self.a)
+        def fill(self, v): self.a[:] = v
+        def __call__(self, i, j): return self.a[i, j]
+
+    class V3:
+        def __init__(self, a): self.a = np.asarray(a, np.float64)
+        def norm(self): return F64(np.sqrt(self.a[0] * self.a[0] + self.a[1] * self.a[1] + self.a[2] * self.a[2]))
+        def __call__(self, i): return F64(self.a[i])
+        def __getitem__(self, i): return F64(self.a[i])
+        def __setitem__(self, i, v): self.a[i] = v
+
+    sk = _body(os.path.join(G, "types", "se3_ops.hpp"), r"Matrix3d\s+skew\s*\(\s*const\s+Vector3d\s*&\s*v\s*\)\s*\{")
+    sk = sk.replace("Matrix3d m;", "m = M3(np.zeros((3, 3)));")
+    sk = re.sub(r"m\((\d),(\d)\)\s*=", r"m.a[\1][\2] =", sk)
+    sk_src = c_to_python(cpp_prepare(sk), keep_returns=True)
+    ex = _body(os.path.join(G, "types", "se3quat.h"), r"static\s+SE3Quat\s+exp\s*\(\s*const\s+Vector6d\s*&\s*update\s*\)\s*\{")
+    ex = ex.replace("Vector3d omega;", "omega = V3(np.zeros(3));").replace("Vector3d upsilon;", "upsilon = V3(np.zeros(3));").replace("Matrix3d R;", "").replace("Matrix3d V;", "")
+    ex = ex.replace("Matrix3d::Identity()", "I3").replace("return SE3Quat(Quaterniond(R),V*upsilon);", "return (R, V*upsilon);")
+    ex_src = c_to_python(cpp_prepare(ex), keep_returns=True)
+    assert "if theta<F64(0.00001):" in ex_src and "pow(theta,3)" in ex_src
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    env = dict(ENV, F64=F64, np=np, M3=M3, V3=V3, I3=M3(np.eye(3)), pow=lambda a, b: F64(np.power(F64(a), F64(b))))
+    exec("def skew(v):\n" + ind(sk_src) + "\ndef se3_exp(update):\n" + ind(ex_src), env)
+    for trial in range(300):
+        upd = np.concatenate([rng.randn(3) * rng.choice([1e-7, 1e-3, 0.05, 1.0]), rng.randn(3) * 0.3])
+        if trial % 10 == 0:
+            upd[:3] = upd[:3] / np.linalg.norm(upd[:3]) * rng.choice([0.9e-5, 1.1e-5])             # either side of the branch
+        R, t = env["se3_exp"]([F64(x) for x in upd])
+        q, to = ob.se3_exp(upd)
+        x, y, z, w = q
+        Ro = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        # (the oracle returns the NORMALISED quaternion of R, as SE3Quat's constructor does: the small-angle R is not exactly orthonormal)
+        tol = 1e-9 if np.linalg.norm(upd[:3]) < 1e-4 else 1e-12
+        assert np.abs(R.a - Ro).max() < max(tol, 4 * np.linalg.norm(upd[:3]) ** 2 if np.linalg.norm(upd[:3]) < 1e-5 else tol), (trial, upd)
+        assert np.abs(t.a - to).max() < 1e-14 * max(1.0, np.abs(to).max()) * 16, (trial, t.a, to)
