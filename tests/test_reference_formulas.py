@@ -2252,3 +2252,50 @@ def test_huber_kernel_and_se3_exponential_are_g2os_text():
         tol = 1e-9 if np.linalg.norm(upd[:3]) < 1e-4 else 1e-12
         assert np.abs(R.a - Ro).max() < max(tol, 4 * np.linalg.norm(upd[:3]) ** 2 if np.linalg.norm(upd[:3]) < 1e-5 else tol), (trial, upd)
         assert np.abs(t.a - to).max() < 1e-14 * max(1.0, np.abs(to).max()) * 16, (trial, t.a, to)
+
+
+def test_lapping_area_partition_is_operator_calls_text(small_scene):
+    """ORBextractor::operator() (S/ORBextractor.cc:1105-1149): keypoints whose x lies in [vLappingArea[0], vLappingArea[1]] are written from the
+    BACK of the output (stereoIndex--), the others from the front, level by level, descriptors alongside; the return value is the count of
+    the others -- the loop transliterated (blur / descriptor calls cut out) and fed the oracle's own keypoints of an extraction without a
+    lapping area (which come out level by level in detection order) -- against the oracle's extraction WITH one."""
+    L, R, Tcw = small_scene.stereo_pair(0)
+    ex = ob.Extractor(n_features=500, max_width=small_scene.W, max_height=small_scene.H)
+    rc, k0, d0, nmono0 = ex.extract(L, lap=(0, 0))
+    lap = (int(small_scene.W * 0.3), int(small_scene.W * 0.6))
+    rc, k1, d1, nmono1 = ex.extract(L, lap=lap)
+    assert rc == 0 and len(k0) == len(k1) and 0 < nmono1 < len(k1)
+    body = _body(os.path.join(REF, "src", "ORBextractor.cc"), r"int\s+ORBextractor::operator\(\)\s*\([^)]*\)\s*\{")
+    piece = body[body.index("int offset = 0;"):]
+    piece = re.sub(r"Mat workingMat = [^;]*;", "", piece)
+    piece = re.sub(r"GaussianBlur\([^;]*;", "", piece)
+    piece = re.sub(r"computeDescriptors\([^;]*;", "", piece)
+    rep = [("Mat desc = cv::Mat(nkeypointsLevel, 32, CV_8U);", "desc = descs[level];"), ("int monoIndex = 0, stereoIndex = nkeypoints-1;", "int monoIndex = 0; int stereoIndex = nkeypoints-1;"),
+           ("_keypoints.at(stereoIndex) = (*keypoint);", "_keypoints[stereoIndex] = keypoint;"), ("_keypoints.at(monoIndex) = (*keypoint);", "_keypoints[monoIndex] = keypoint;"),
+           ("desc.row(i).copyTo(descriptors.row(stereoIndex));", "descriptors[stereoIndex] = desc[i];"), ("desc.row(i).copyTo(descriptors.row(monoIndex));", "descriptors[monoIndex] = desc[i];")]
+    piece = re.sub(r"\s+", " ", piece)
+    piece = re.sub(r"for \(vector<KeyPoint>::iterator keypoint = keypoints\.begin\(\), keypointEnd = keypoints\.end\(\); keypoint != keypointEnd; \+\+keypoint\)\s*\{", "foreach(keypoint, keypoints) {", piece)
+    for a, b in rep:
+        assert a in piece, a
+        piece = piece.replace(a, b)
+    src = c_to_python(cpp_prepare(piece), keep_returns=True)
+    assert "stereoIndex -= 1" in src and "monoIndex += 1" in src and "keypoint.pt *= scale" in src
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+        def __imul__(self, s_): return Pt(F32(self.x * s_), F32(self.y * s_))
+
+    class Kp:
+        def __init__(self, i): self.pt, self.i = Pt(k0["x"][i], k0["y"][i]), i
+
+    n = len(k0)
+    levels = [[Kp(i) for i in range(n) if k0["octave"][i] == l] for l in range(8)]
+    assert [kp.i for lv in levels for kp in lv] == list(range(n))           # (no lapping area: level by level, detection order)
+    env = dict(ENV, F32=F32, F64=F64, nlevels=8, nkeypoints=n, allKeypoints=levels, descs=[[d0[kp.i] for kp in lv] for lv in levels],
+               mvScaleFactor=[F32(1.0)] * 8,          # (the oracle's keypoints are already in level-0 pixels: the scaling is pinned with the tables)
+               vLappingArea=[lap[0], lap[1]], _keypoints=[None] * n, descriptors=[None] * n)
+    exec("def partition():\n" + "\n".join("    " + ln for ln in src.splitlines()), env)
+    n_mono = env["partition"]()
+    assert n_mono == nmono1
+    order = [kp.i for kp in env["_keypoints"]]
+    assert np.array_equal(k0[order], k1) and np.array_equal(np.array(env["descriptors"]), d1)
