@@ -884,12 +884,16 @@ class MatF:
     """Stand-in for the cv::Mat expressions of the matchers (CV_32F): the products and sums in float32, a row of a product accumulated left to
     right -- the arithmetic the oracle restates for them (OpenCV itself is not in the tree: this part is NOT pinned)."""
 
-    def __init__(self, a): self.a = np.asarray(a, np.float32).reshape(np.asarray(a).shape if np.asarray(a).ndim == 2 else (-1, 1))
+    def __init__(self, a, via_gemm=False):
+        self.a = np.asarray(a, np.float32).reshape(np.asarray(a).shape if np.asarray(a).ndim == 2 else (-1, 1))
+        # an operand that is a transpose expression (`-Rcw.t()*tcw`) sends the product through cv::gemm's general path, whose
+        # accumulators are double; plain 3 x 3 by 3 x 1 products take gemm's small-matrix special case, float throughout (Appendix A)
+        self.via_gemm = via_gemm
     def rowRange(self, i, j): return MatF(self.a[i:j, :])
     def colRange(self, i, j): return MatF(self.a[:, i:j])
     def col(self, j): return MatF(self.a[:, j:j + 1])
-    def t(self): return MatF(self.a.T.copy())
-    def __neg__(self): return MatF(-self.a)
+    def t(self): return MatF(self.a.T.copy(), via_gemm=True)
+    def __neg__(self): return MatF(-self.a, via_gemm=self.via_gemm)
     def __add__(self, o): return MatF(self.a + o.a)
     def __sub__(self, o): return MatF(self.a - o.a)
     def at(self, i, j=0): return F32(self.a[i, j])
@@ -904,6 +908,8 @@ class MatF:
         return acc
 
     def __mul__(self, o):
+        if self.via_gemm:
+            return MatF((self.a.astype(np.float64) @ o.a.astype(np.float64)).astype(np.float32))
         out = np.zeros((self.a.shape[0], o.a.shape[1]), np.float32)
         for i in range(out.shape[0]):
             for j in range(out.shape[1]):
@@ -2299,3 +2305,89 @@ def test_lapping_area_partition_is_operator_calls_text(small_scene):
     assert n_mono == nmono1
     order = [kp.i for kp in env["_keypoints"]]
     assert np.array_equal(k0[order], k1) and np.array_equal(np.array(env["descriptors"]), d1)
+
+
+def test_isinfrustum_is_the_references_text():
+    """Frame::isInFrustum (S/Frame.cc:466-543, the Nleft == -1 branch) with MapPoint::PredictScale(dist, Frame*): depth sign, inclusive image
+    bounds, the distance range from the two getters, the viewing-cosine limit, the predicted level, the seven fields left on the
+    MapPoint -- transliterated -- against the oracle's isInFrustum outputs (float32 bits; cv::Mat arithmetic: the stand-in's)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    body = _body(os.path.join(REF, "src", "Frame.cc"), r"bool\s+Frame::isInFrustum\s*\(\s*MapPoint\s*\*pMP,\s*float viewingCosLimit\s*\)\s*\{")
+    piece = body[body.index("pMP->mbTrackInView = false;"):body.index("else{")]
+    piece = piece[:piece.rindex("}")]                          # the if(Nleft == -1) block's body
+    piece = piece.replace(".at<float>(", ".at(").replace("cv::norm(Pc)", "Pc.norm()").replace("cv::norm(PO)", "PO.norm()").replace("PredictScale(dist,this)", "PredictScale(dist,thisF)")
+    src = c_to_python(cpp_prepare(piece), keep_returns=True)
+    assert src.count("return False") == 5 and "viewCos = F32(PO.dot(Pn)/dist)" in src and "pMP.mTrackProjXR = uv.x - mbf*invz" in src
+    mp_path = os.path.join(REF, "src", "MapPoint.cc")
+    ps = _body(mp_path, r"int\s+MapPoint::PredictScale\s*\(\s*const float &currentDist,\s*Frame\*\s*pF\s*\)\s*\{")
+    ps = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", ps).replace("float ratio;", "")
+    ps = re.sub(r"\{\s*(ratio = [^;]*;)\s*\}", r"\1", ps)
+    ps_src = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", ps)), typed_ints=True, keep_returns=True)
+    getters = {}
+    for nm in ("GetMinDistanceInvariance", "GetMaxDistanceInvariance"):
+        g = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", _body(mp_path, r"float\s+MapPoint::%s\s*\(\s*\)\s*\{" % nm))
+        getters[nm] = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", g)), keep_returns=True)
+    pj = _body(os.path.join(REF, "src", "CameraModels", "Pinhole.cpp"), r"cv::Point2f\s+Pinhole::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    ex, ey = _split_top(re.search(r"return cv::Point2f\((.*)\)\s*;", pj, flags=re.S).group(1).replace("\n", " "))
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def PredictScale(self, currentDist, pF):\n" + ind(ps_src) + "\ndef GetMinDistanceInvariance(self):\n" + ind(getters["GetMinDistanceInvariance"]) +
+            "\ndef GetMaxDistanceInvariance(self):\n" + ind(getters["GetMaxDistanceInvariance"]) + "\ndef isInFrustum(pMP, viewingCosLimit):\n" + ind(src) + "\n    return True")
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Obj:
+        pass
+
+    fx, fy, cx, cy, bf = F32(458.6), F32(457.3), F32(320.0), F32(240.0), F32(38.0)
+    params = [fx, fy, cx, cy]
+
+    class Cam:
+        def project(self, m):
+            e2 = {"mvParameters": params, "p3D": Obj()}
+            e2["p3D"].x, e2["p3D"].y, e2["p3D"].z = m.at(0), m.at(1), m.at(2)
+            return Pt(eval(ex, e2), eval(ey, e2))
+
+    rng = np.random.RandomState(107)
+    m = 1500
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    Tc = np.eye(4, dtype=np.float32); Tc[:3, :3] = np.array([[0.9998, -0.012, 0.016], [0.0121, 0.9999, -0.006], [-0.0159, 0.0062, 0.9998]], np.float32)
+    Tc[:3, 3] = [0.3, -0.1, 0.2]
+    R, t = Tc[:3, :3].astype(np.float64), Tc[:3, 3].astype(np.float64)
+    z = rng.uniform(-3, 25, m)
+    u = rng.uniform(-60, 700, m); v = rng.uniform(-60, 540, m)
+    Pc = np.stack([(u - float(cx)) * z / float(fx), (v - float(cy)) * z / float(fy), z], 1)
+    Xw = ((Pc - t) @ R).astype(np.float32)
+    Ow = -(R.T @ t)
+    PO = Xw.astype(np.float64) - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    normal = (PO / dist[:, None] + rng.randn(m, 3) * np.where(rng.rand(m, 1) < 0.3, 1.2, 0.1)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    sc = np.ones(8, np.float32)
+    for l in range(1, 8):
+        sc[l] = np.float32(sc[l - 1] * np.float32(1.2))
+    maxd = (dist * sc[rng.randint(0, 8, m)] * 0.93).astype(np.float32) * rng.choice([1.0, 1.0, 0.4, 4.0], m).astype(np.float32); mind = (maxd / sc[7]).astype(np.float32)
+    kps = np.zeros(4, capi.KEYPOINT_DTYPE)
+    fv, keep = views.frame_view(kps, np.zeros((4, 32), np.uint8), bounds=bounds, cam=(float(fx), float(fy), float(cx), float(cy), float(bf), 0.08))
+    wv, keep2 = views.worldpoints_view(Xw, normal, mind, maxd, np.zeros((m, 32), np.uint8), np.ones(m, np.int32), np.zeros(m, np.uint8))
+    o = ob.is_in_frustum(fv, Tc, wv, 0.5)
+    thisF = Obj(); thisF.mfLogScaleFactor = F32(np.log(np.float32(1.2))); thisF.mnScaleLevels = 8
+    Rm, tm = MatF(Tc[:3, :3]), MatF(Tc[:3, 3].reshape(3, 1))
+    env = dict(ENV, F32=F32, F64=F64, as_int=lambda x: int(x), ceil=np.ceil, log=lambda x: F32(libm.logf(float(F32(x)))), thisF=thisF,
+               mRcw=Rm, mtcw=tm, mOw=-Rm.t() * tm, mpCamera=Cam(), mbf=bf, mnMinX=F32(bounds[0]), mnMaxX=F32(bounds[1]), mnMinY=F32(bounds[2]), mnMaxY=F32(bounds[3]))
+    exec(prog, env)
+    MPc = type("MapPoint", (), {"PredictScale": env["PredictScale"], "GetMinDistanceInvariance": env["GetMinDistanceInvariance"],
+                                "GetMaxDistanceInvariance": env["GetMaxDistanceInvariance"]})
+    n_in = 0
+    for i in range(m):
+        q = MPc(); q.mfMaxDistance = F32(maxd[i]); q.mfMinDistance = F32(mind[i]); q.mbTrackInView = None
+        q.GetWorldPos = (lambda i=i: MatF(Xw[i].reshape(3, 1))); q.GetNormal = (lambda i=i: MatF(normal[i].reshape(3, 1)))
+        res = env["isInFrustum"](q, F32(0.5))
+        assert bool(res) == bool(o["track_in_view"][i]) and bool(q.mbTrackInView) == bool(res), i
+        if res:
+            n_in += 1
+            mine = np.array([q.mTrackProjX, q.mTrackProjY, q.mTrackProjXR, q.mTrackDepth, q.mTrackViewCos], np.float32)
+            theirs = np.array([o[k][i] for k in ("proj_x", "proj_y", "proj_xr", "track_depth", "view_cos")], np.float32)
+            assert mine.tobytes() == theirs.tobytes() and q.mnTrackScaleLevel == int(o["scale_level"][i]), (i, mine, theirs, q.mnTrackScaleLevel, o["scale_level"][i])
+    assert 150 < n_in < m - 300
