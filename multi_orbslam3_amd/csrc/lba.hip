@@ -1874,7 +1874,10 @@ static int lba_solve_attempt_t(lba_handle* h, const lba_problem* p, StopRef stop
   // back-substitution walk -- the run's first edge carries the Hpl block of the vertex pair (linearize_block).
   constexpr bool kRig = std::is_same<CamT, CamRig>::value;
   std::vector<uint8_t> rig_secondary;
+  int n_right_edges = 0;           // EdgeSE3ProjectXYZToBody edges: counted among the outliers, NOT in the 50 % rule's denominator (:2256)
   if constexpr (kRig) {
+    if (cam.has_right)
+      for (int k = 0; k < NE; k++) n_right_edges += ur_is_right(edges[k].ur) ? 1 : 0;
     rig_secondary.assign((size_t)std::max(NE, 1), 0);
     for (int k = 1; k < NE; k++)
       if (edges[k].pose == edges[k - 1].pose && edges[k].point == edges[k - 1].point) {
@@ -2551,7 +2554,9 @@ static int lba_solve_attempt_t(lba_handle* h, const lba_problem* p, StopRef stop
     else memcpy(r->edge_chi2, h->dl_h.h + d_chi_o, 8 * (size_t)NE);
   }
   r->n_outliers = n_out;
-  if (NE > 0 && n_out >= NE * 0.5) r->status = LBA_REJECTED_OUTLIERS;
+  // vToErase.size() >= (vpMapPointEdgeMono.size() + vpMapPointEdgeStereo.size()) * 0.5  (S/Optimizer.cc:2256: the right camera's edges
+  // are in vToErase but not in the sum)
+  if (NE > 0 && n_out >= (NE - n_right_edges) * 0.5) r->status = LBA_REJECTED_OUTLIERS;
   for (int i = 0; i < NP; i++) {                       // Converter::toCvMat(SE3Quat)
     double R[9];
     quat_to_R(rposes[i].q, R);

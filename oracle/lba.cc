@@ -791,7 +791,11 @@ extern "C" int oracle_lba_solve(const lba_problem* p, const volatile int32_t* st
     n_out += outlier;
   }
   r->n_outliers = n_out;
-  if (n_out >= p->n_edges * 0.5 && p->n_edges > 0) r->status = LBA_REJECTED_OUTLIERS;   // :2257-2261
+  // :2256-2261 -- vToErase.size() >= (vpMapPointEdgeMono.size() + vpMapPointEdgeStereo.size()) * 0.5: the right camera's edges are in
+  // vToErase but not in the sum (a window of right-camera edges alone is always refused)
+  int n_not_right = 0;
+  for (int k = 0; k < p->n_edges; k++) n_not_right += !(s.rig.has_right && edge_is_right(p->edges[k].ur));
+  if (n_out >= n_not_right * 0.5 && p->n_edges > 0) r->status = LBA_REJECTED_OUTLIERS;
   write_back();
   return ORBG_OK;
 }

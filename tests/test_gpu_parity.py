@@ -1442,6 +1442,24 @@ def test_lba_with_the_two_fisheye_rig(shape):
     assert np.array_equal(g.poses, g2.poses) and np.array_equal(g.points, g2.points)
 
 
+def test_lba_rig_windows_50_percent_rule_counts_the_left_cameras_edges_only():
+    """S/Optimizer.cc:2256: the local BA returns without writing when vToErase holds at least half as many observations as there are
+    monocular + stereo edges -- the right camera's edges are in vToErase but not in that sum.  A window whose right-camera observations
+    are off by 30 px has fewer outliers than half of ALL its edges and still is refused; the product and the oracle agree (and the
+    reference's own text, run in tests/test_reference_formulas.py, says the same)."""
+    pr = synth.make_lba_rig_problem(n_free=4, n_fixed=2, n_points=90, seed=113, outlier_frac=0.0)
+    right = pr["edges"]["ur"] <= -1.5
+    sel = np.sort(np.concatenate([np.nonzero(right)[0], np.nonzero(~right)[0][::3]]))
+    E = pr["edges"][sel].copy()
+    E["u"][E["ur"] <= -1.5] += 30.0
+    p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], E, pr["cam"], rig=views.camera_rig(*pr["rig"]))
+    g = api.Optimizer().LocalBundleAdjustment(p)
+    o = ob.lba_solve(p)
+    n_left = int((E["ur"] > -1.5).sum())
+    assert g.status == o.status == capi.LBA_REJECTED_OUTLIERS
+    assert g.n_outliers == o.n_outliers and 0.5 * n_left <= g.n_outliers < 0.5 * len(E)
+
+
 def test_lba_rig_with_a_pinhole_left_camera_and_no_right_one_is_the_pinhole_problem():
     """A rig that only restates mpCamera = Pinhole{fx, fy, cx, cy} must give the result of the five scalars (the monocular edge
     through Pinhole::project / projectJac is the edge the scalar path writes out)."""

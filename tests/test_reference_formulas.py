@@ -1385,6 +1385,111 @@ def test_bag_of_words_transform_is_dbow2s_text():
         assert len(bow) > 20
 
 
+def _dense_lba(pr, env, rig=None):
+    """The graph state of a local-BA window with a DENSE normal-equation solver, behind the interfaces g2o's transliterated driver calls
+    (_optimizer and _solver in one), plus the driver objects: returns (system, SparseOptimizer stand-in).  Per-edge residuals and
+    Jacobians come from the oracle's edge evaluation."""
+    from dense_lm import quat_from_R, oplus
+    E = pr["edges"]
+    P = len(pr["poses"]); free = [i for i in range(P) if not pr["pose_fixed"][i]]
+    pcol = {i: c for c, i in enumerate(free)}
+    L = len(pr["points"]); nP = len(free); nu = 6 * nP + 3 * L
+    d_mono, d_st = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+
+    class Param:
+        def __init__(self, v): self.v = v
+        def value(self): return self.v
+
+    class Vertex:
+        def __init__(self, S, off, dim): self.S, self.off, self.dim = S, off, dim
+        def dimension(self): return self.dim
+        def hessian(self, i, j): return F64(self.S.H[self.off + i, self.off + j])
+
+    class System:                                            # _optimizer and _solver in one: the graph state and a dense normal-equation solver
+        def __init__(self):
+            self.q, self.t = [], []
+            for i in range(P):
+                T = np.asarray(pr["poses"][i], np.float32).reshape(4, 4).astype(np.float64)
+                qq = quat_from_R(T[:3, :3]); self.q.append(qq / np.linalg.norm(qq)); self.t.append(T[:3, 3].copy())
+            self.X = np.asarray(pr["points"], np.float64).copy()
+            self.stack = []; self.err = [None] * len(E); self.chi = np.zeros(len(E)); self.H = np.zeros((nu, nu)); self.bv = np.zeros(nu); self.xv = np.zeros(nu)
+            self.verts = [Vertex(self, 6 * c, 6) for c in range(nP)] + [Vertex(self, 6 * nP + 3 * l, 3) for l in range(L)]
+        def buildStructure(self): return True
+        def indexMapping(self): return self.verts
+        def terminate(self): return False
+        def computeActiveErrors(self):
+            for k, e in enumerate(E):
+                err, A, B = (ob.lba_edge_eval(self.q[int(e["pose"])], self.t[int(e["pose"])], self.X[int(e["point"])], pr["cam"], np.array([e], capi.EDGE_DTYPE)) if rig is None else ob.lba_edge_eval_rig(self.q[int(e["pose"])], self.t[int(e["pose"])], self.X[int(e["point"])], pr["cam"], rig, np.array([e], capi.EDGE_DTYPE))[:3])
+                D = 2 if e["ur"] < 0 else 3
+                self.err[k] = (err, A, B, D)
+                c = 0.0
+                for i in range(D):
+                    c += err[i] * (float(e["inv_sigma2"]) * err[i])
+                self.chi[k] = c
+        def _rho(self, k):
+            d = d_mono if self.err[k][3] == 2 else d_st
+            c = self.chi[k]
+            return (c, 1.0) if c <= d * d else (2 * np.sqrt(c) * d - d * d, d / np.sqrt(c))
+        def activeRobustChi2(self):
+            s = 0.0
+            for k in range(len(E)):
+                s += self._rho(k)[0]
+            return F64(s)
+        def buildSystem(self):
+            self.H[:] = 0; self.bv[:] = 0
+            for k, e in enumerate(E):
+                err, A, B, D = self.err[k]
+                w = self._rho(k)[1]; om = float(e["inv_sigma2"])
+                J = np.zeros((D, nu)); i, l = int(e["pose"]), int(e["point"])
+                if i in pcol:
+                    J[:, 6 * pcol[i]:6 * pcol[i] + 6] = B[:D]
+                J[:, 6 * nP + 3 * l:6 * nP + 3 * l + 3] = A[:D]
+                self.H += J.T @ (w * om * J); self.bv -= J.T @ (w * om * err[:D])
+        def setLambda(self, lam, backup): self.lam = float(lam)
+        def restoreDiagonal(self): pass
+        def solve(self):
+            try:
+                self.xv = np.linalg.solve(self.H + self.lam * np.eye(nu), self.bv)
+                return bool(np.isfinite(self.xv).all())
+            except np.linalg.LinAlgError:
+                return False
+        def x(self): return [F64(v) for v in self.xv]
+        def b(self): return [F64(v) for v in self.bv]
+        def vectorSize(self): return nu
+        def update(self, x):
+            x = np.array(x, np.float64)
+            for i in free:
+                self.q[i], self.t[i] = oplus(self.q[i], self.t[i], x[6 * pcol[i]:6 * pcol[i] + 6])
+                self.q[i] = self.q[i] / np.linalg.norm(self.q[i])
+            self.X = self.X + x[6 * nP:].reshape(L, 3)
+        def push(self): self.stack.append(([a.copy() for a in self.q], [a.copy() for a in self.t], self.X.copy()))
+        def pop(self): self.q, self.t, self.X = self.stack.pop()
+        def discardTop(self): self.stack.pop()
+
+    class Levenberg:
+        solve = env["lm_solve"]; computeLambdaInit = env["lm_lambda_init"]; computeScale = env["lm_scale"]
+        def __init__(self, S):
+            self._optimizer = S; self._solver = S; self._tau = F64(1e-5); self._goodStepUpperScale = F64(2.) / F64(3.); self._goodStepLowerScale = F64(1.) / F64(3.)
+            self._userLambdaInit = Param(F64(0)); self._maxTrialsAfterFailure = Param(10); self._currentLambda = F64(-1); self._ni = F64(2); self._nBad = 0
+            self._levenbergIterations = 0; self.last_chi = F64(0); self.trace = []
+        def init(self, online): return True
+
+    class SparseOpt:
+        optimize = env["so_optimize"]
+        def __init__(self, S, alg):
+            self.S, self._algorithm = S, alg; self._ivMap = S.verts; self._batchStatistics = []; self._computeBatchStatistics = False
+            self._activeEdges = list(range(len(E))); self._activeVertices = S.verts
+        def terminate(self): return False
+        def preIteration(self, i): pass
+        def postIteration(self, i): self._algorithm.trace.append((float(self._algorithm._currentLambda), float(self._algorithm.last_chi), int(self._algorithm._levenbergIterations)))
+        def verbose(self): return False
+        def computeActiveErrors(self): self.S.computeActiveErrors()
+        def activeRobustChi2(self): return self.S.activeRobustChi2()
+
+    S = System(); alg = Levenberg(S); so = SparseOpt(S, alg)
+    return S, so
+
+
 def _g2o_lm_program():
     """lm_solve / lm_lambda_init / lm_scale (OptimizationAlgorithmLevenberg) and so_optimize (SparseOptimizer::optimize) as Python functions of
     `self`, transliterated from g2o's text: see test_levenberg_marquardt_driver_is_g2os_text."""
@@ -1453,103 +1558,9 @@ def test_levenberg_marquardt_driver_is_g2os_text(seed, outl):
     pr = synth.make_lba_problem(n_free=5, n_fixed=3, n_points=120, seed=seed, outlier_frac=outl, mono_frac=0.2)
     p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"])
     o = ob.lba_solve(p)
-    E = pr["edges"]
-    P = len(pr["poses"]); free = [i for i in range(P) if not pr["pose_fixed"][i]]
-    pcol = {i: c for c, i in enumerate(free)}
-    L = len(pr["points"]); nP = len(free); nu = 6 * nP + 3 * L
-    d_mono, d_st = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
-
-    class Param:
-        def __init__(self, v): self.v = v
-        def value(self): return self.v
-
-    class Vertex:
-        def __init__(self, S, off, dim): self.S, self.off, self.dim = S, off, dim
-        def dimension(self): return self.dim
-        def hessian(self, i, j): return F64(self.S.H[self.off + i, self.off + j])
-
-    class System:                                            # _optimizer and _solver in one: the graph state and a dense normal-equation solver
-        def __init__(self):
-            self.q, self.t = [], []
-            for i in range(P):
-                T = np.asarray(pr["poses"][i], np.float32).reshape(4, 4).astype(np.float64)
-                qq = quat_from_R(T[:3, :3]); self.q.append(qq / np.linalg.norm(qq)); self.t.append(T[:3, 3].copy())
-            self.X = np.asarray(pr["points"], np.float64).copy()
-            self.stack = []; self.err = [None] * len(E); self.chi = np.zeros(len(E)); self.H = np.zeros((nu, nu)); self.bv = np.zeros(nu); self.xv = np.zeros(nu)
-            self.verts = [Vertex(self, 6 * c, 6) for c in range(nP)] + [Vertex(self, 6 * nP + 3 * l, 3) for l in range(L)]
-        def buildStructure(self): return True
-        def indexMapping(self): return self.verts
-        def terminate(self): return False
-        def computeActiveErrors(self):
-            for k, e in enumerate(E):
-                err, A, B = ob.lba_edge_eval(self.q[int(e["pose"])], self.t[int(e["pose"])], self.X[int(e["point"])], pr["cam"], np.array([e], capi.EDGE_DTYPE))
-                D = 2 if e["ur"] < 0 else 3
-                self.err[k] = (err, A, B, D)
-                c = 0.0
-                for i in range(D):
-                    c += err[i] * (float(e["inv_sigma2"]) * err[i])
-                self.chi[k] = c
-        def _rho(self, k):
-            d = d_mono if self.err[k][3] == 2 else d_st
-            c = self.chi[k]
-            return (c, 1.0) if c <= d * d else (2 * np.sqrt(c) * d - d * d, d / np.sqrt(c))
-        def activeRobustChi2(self):
-            s = 0.0
-            for k in range(len(E)):
-                s += self._rho(k)[0]
-            return F64(s)
-        def buildSystem(self):
-            self.H[:] = 0; self.bv[:] = 0
-            for k, e in enumerate(E):
-                err, A, B, D = self.err[k]
-                w = self._rho(k)[1]; om = float(e["inv_sigma2"])
-                J = np.zeros((D, nu)); i, l = int(e["pose"]), int(e["point"])
-                if i in pcol:
-                    J[:, 6 * pcol[i]:6 * pcol[i] + 6] = B[:D]
-                J[:, 6 * nP + 3 * l:6 * nP + 3 * l + 3] = A[:D]
-                self.H += J.T @ (w * om * J); self.bv -= J.T @ (w * om * err[:D])
-        def setLambda(self, lam, backup): self.lam = float(lam)
-        def restoreDiagonal(self): pass
-        def solve(self):
-            try:
-                self.xv = np.linalg.solve(self.H + self.lam * np.eye(nu), self.bv)
-                return bool(np.isfinite(self.xv).all())
-            except np.linalg.LinAlgError:
-                return False
-        def x(self): return [F64(v) for v in self.xv]
-        def b(self): return [F64(v) for v in self.bv]
-        def vectorSize(self): return nu
-        def update(self, x):
-            x = np.array(x, np.float64)
-            for i in free:
-                self.q[i], self.t[i] = oplus(self.q[i], self.t[i], x[6 * pcol[i]:6 * pcol[i] + 6])
-                self.q[i] = self.q[i] / np.linalg.norm(self.q[i])
-            self.X = self.X + x[6 * nP:].reshape(L, 3)
-        def push(self): self.stack.append(([a.copy() for a in self.q], [a.copy() for a in self.t], self.X.copy()))
-        def pop(self): self.q, self.t, self.X = self.stack.pop()
-        def discardTop(self): self.stack.pop()
-
-    class Levenberg:
-        solve = env["lm_solve"]; computeLambdaInit = env["lm_lambda_init"]; computeScale = env["lm_scale"]
-        def __init__(self, S):
-            self._optimizer = S; self._solver = S; self._tau = F64(1e-5); self._goodStepUpperScale = F64(2.) / F64(3.); self._goodStepLowerScale = F64(1.) / F64(3.)
-            self._userLambdaInit = Param(F64(0)); self._maxTrialsAfterFailure = Param(10); self._currentLambda = F64(-1); self._ni = F64(2); self._nBad = 0
-            self._levenbergIterations = 0; self.last_chi = F64(0); self.trace = []
-        def init(self, online): return True
-
-    class SparseOpt:
-        optimize = env["so_optimize"]
-        def __init__(self, S, alg):
-            self.S, self._algorithm = S, alg; self._ivMap = S.verts; self._batchStatistics = []; self._computeBatchStatistics = False
-            self._activeEdges = list(range(len(E))); self._activeVertices = S.verts
-        def terminate(self): return False
-        def preIteration(self, i): pass
-        def postIteration(self, i): self._algorithm.trace.append((float(self._algorithm._currentLambda), float(self._algorithm.last_chi), int(self._algorithm._levenbergIterations)))
-        def verbose(self): return False
-        def computeActiveErrors(self): self.S.computeActiveErrors()
-        def activeRobustChi2(self): return self.S.activeRobustChi2()
-
-    S = System(); alg = Levenberg(S); so = SparseOpt(S, alg)
+    S, so = _dense_lba(pr, env)
+    alg = so._algorithm
+    free = [i for i in range(len(pr["poses"])) if not pr["pose_fixed"][i]]
     it1 = so.optimize(5)                                      # S/Optimizer.cc:2130-2132
     it2 = so.optimize(10)                                     # :2202-2203
     tr = np.array(alg.trace); to = o.trace_rows()
@@ -2391,3 +2402,84 @@ def test_isinfrustum_is_the_references_text():
             theirs = np.array([o[k][i] for k in ("proj_x", "proj_y", "proj_xr", "track_depth", "view_cos")], np.float32)
             assert mine.tobytes() == theirs.tobytes() and q.mnTrackScaleLevel == int(o["scale_level"][i]), (i, mine, theirs, q.mnTrackScaleLevel, o["scale_level"][i])
     assert 150 < n_in < m - 300
+
+
+@pytest.mark.parametrize("kind", ["pinhole", "pinhole_mostly_outliers", "rig", "rig_many_right_outliers"])
+def test_localbundleadjustment_optimisation_section_is_the_references_text(kind):
+    """Optimizer::LocalBundleAdjustment, S/Optimizer.cc:2126-2261: the stop-flag checks, optimize(5), the (inactive) inlier checks, optimize(10),
+    vToErase from chi2 (of the LAST evaluated errors) and isDepthPositive() per edge kind, and the early return when vToErase holds at
+    least half as many entries as there are monocular + stereo edges (the right camera's edges are in vToErase but not in that sum) --
+    transliterated, over g2o's transliterated driver and the dense solver -- against the oracle: status, iterations, the erased set."""
+    from multi_orbslam3_amd import synth
+    env = _g2o_lm_program()
+    body = _body(os.path.join(REF, "src", "Optimizer.cc"), r"void\s+Optimizer::LocalBundleAdjustment\s*\(\s*KeyFrame\s*\*pKF,\s*bool\s*\*\s*pbStopFlag,\s*Map\s*\*\s*pMap,\s*int&\s*num_fixedKF[^)]*\)\s*\{")
+    piece = body[body.index("if(pbStopFlag) if(*pbStopFlag) return;") if "if(pbStopFlag) if(*pbStopFlag) return;" in body else body.index("optimizer.initializeOptimization();") - 80:]
+    piece = piece[piece.index("if(pbStopFlag)"):piece.index("bRedrawError = true;")]
+    piece = re.sub(r"\s+", " ", piece)
+    assert piece.startswith("if(pbStopFlag) if(*pbStopFlag) return;")
+    piece = piece.replace("if(pbStopFlag) if(*pbStopFlag) return;", 'if(pbStopFlag) if(*pbStopFlag) return "ABORTED";', 1)
+    piece = re.sub(r"Verbose::PrintMess\([^;]*;", "", piece)
+    assert piece.rstrip().endswith("return;")
+    piece = piece.rstrip()[:-len("return;")] + 'return "REJECTED"; }'
+    piece = piece.replace("*pbStopFlag", "pbStopFlag[0]").replace("make_pair(", "(").replace(".push_back(", ".append(")
+    piece = piece.replace("vector<pair<KeyFrame*,MapPoint*> > vToErase;", "vToErase = [];").replace("bool bRedrawError = false;", "")
+    piece = re.sub(r"vToErase\.reserve\([^;]*;", "", piece)
+    piece = re.sub(r"for\(size_t i=0, iend=(\w+)\.size\(\); i<iend; ?i\+\+\)", r"for(int i=0; i<len(\1); i++)", piece)
+    src = c_to_python(cpp_prepare(piece), keep_returns=True)
+    assert src.count("optimizer.optimize(") == 2 and "len(vToErase) >= (len(vpMapPointEdgeMono)+len(vpMapPointEdgeStereo)) * F64(0.5)" in src
+    prog = ("def lba_section(pbStopFlag, optimizer, vpEdgesMono, vpMapPointEdgeMono, vpEdgeKFMono, vpEdgesBody, vpMapPointEdgeBody, vpEdgeKFBody, "
+            "vpEdgesStereo, vpMapPointEdgeStereo, vpEdgeKFStereo, erased):\n" + "\n".join("    " + ln for ln in src.splitlines()) +
+            "\n    erased.extend(vToErase)\n    return \"APPLIED\"")
+    exec(prog, env)
+
+    rig = None
+    if kind == "pinhole":
+        pr = synth.make_lba_problem(n_free=5, n_fixed=3, n_points=120, seed=111, outlier_frac=0.06, mono_frac=0.3)
+    elif kind == "pinhole_mostly_outliers":
+        pr = synth.make_lba_problem(n_free=4, n_fixed=2, n_points=80, seed=112, outlier_frac=0.8, mono_frac=0.3)
+    else:
+        pr = synth.make_lba_rig_problem(n_free=4, n_fixed=2, n_points=90, seed=113, outlier_frac=0.05 if kind == "rig" else 0.0)
+        if kind == "rig_many_right_outliers":                # right-camera observations off by 30 px: more outliers than HALF of the left edges
+            right = pr["edges"]["ur"] <= -1.5
+            keep_left = np.nonzero(~right)[0][::3]
+            sel = np.sort(np.concatenate([np.nonzero(right)[0], keep_left]))
+            pr["edges"] = pr["edges"][sel].copy()
+            r2 = pr["edges"]["ur"] <= -1.5
+            pr["edges"]["u"][r2] += 30.0
+        rig = views.camera_rig(*pr["rig"])
+    p, keep = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"], rig=rig)
+    o = ob.lba_solve(p)
+    S, so = _dense_lba(pr, env, rig)
+    E = pr["edges"]
+
+    class MPs:
+        def isBad(self): return False
+
+    class Edge:
+        def __init__(self, k): self.k = k
+        def chi2(self): return F64(S.chi[self.k])
+        def isDepthPositive(self):
+            e = E[self.k]; i, l = int(e["pose"]), int(e["point"])
+            if rig is not None:
+                return bool(ob.lba_edge_eval_rig(S.q[i], S.t[i], S.X[l], pr["cam"], rig, np.array([e], capi.EDGE_DTYPE))[3][2] > 0.0)
+            from dense_lm import quat_rot
+            return bool((quat_rot(S.q[i], S.X[l]) + S.t[i])[2] > 0.0)
+
+    counts = []
+    real = so.optimize
+    so.optimize = lambda n: counts.append(real(n)) or counts[-1]
+    so.initializeOptimization = lambda level=0: None
+    kinds = {"mono": [k for k in range(len(E)) if -1.5 < E[k]["ur"] < 0], "body": [k for k in range(len(E)) if E[k]["ur"] <= -1.5],
+             "stereo": [k for k in range(len(E)) if E[k]["ur"] >= 0]}
+    erased = []
+    args = []
+    for nm in ("mono", "body", "stereo"):
+        args += [[Edge(k) for k in kinds[nm]], [MPs() for _ in kinds[nm]], list(kinds[nm])]
+    status = env["lba_section"](None, so, *args, erased)
+    want = {"pinhole": capi.LBA_APPLIED, "pinhole_mostly_outliers": capi.LBA_REJECTED_OUTLIERS, "rig": capi.LBA_APPLIED, "rig_many_right_outliers": capi.LBA_REJECTED_OUTLIERS}[kind]
+    assert o.status == want and status == {capi.LBA_APPLIED: "APPLIED", capi.LBA_REJECTED_OUTLIERS: "REJECTED"}[want], (kind, status, o.status, o.n_outliers, len(E))
+    assert tuple(counts) == o.iters, (counts, o.iters)
+    if status == "APPLIED":
+        assert sorted(k for k, mp in erased) == [int(k) for k in np.nonzero(o.edge_outlier)[0]]
+    if kind == "rig_many_right_outliers":                    # ... fewer outliers than half of ALL edges: the sum really leaves the right camera's out
+        assert o.n_outliers < 0.5 * len(E) and o.n_outliers >= 0.5 * (len(kinds["mono"]) + len(kinds["stereo"]))
