@@ -530,7 +530,14 @@ def c_to_python(body, indent="    ", typed_ints=False, float_vars=(), keep_retur
             i = k + (body[k] == "{")
             continue
         if body[i] == "}":
+            if out and out[-1].rstrip().endswith(":"):
+                emit("pass")                                  # a block left empty (its only statement was cut, or commented out in the text)
             depth -= 1; pending.pop(); i += 1
+            # the braced block may have been the single statement of an unbraced `if` / `for` above it (`if(pMP) if(..) { .. }`): that one
+            # ends here too -- unless an `else` follows, which continues the construct
+            if not re.compile(r" *else\b").match(body, i):
+                while pending and pending[-1]:
+                    depth -= 1; pending.pop()
             continue
         j = body.index(";", i)
         st = body[i:j].strip()
@@ -2483,3 +2490,174 @@ def test_localbundleadjustment_optimisation_section_is_the_references_text(kind)
         assert sorted(k for k, mp in erased) == [int(k) for k in np.nonzero(o.edge_outlier)[0]]
     if kind == "rig_many_right_outliers":                    # ... fewer outliers than half of ALL edges: the sum really leaves the right camera's out
         assert o.n_outliers < 0.5 * len(E) and o.n_outliers >= 0.5 * (len(kinds["mono"]) + len(kinds["stereo"]))
+
+
+def test_glues_local_ba_problem_is_the_graph_the_references_text_builds():
+    """include/orbgpu_dropin.hpp's LocalBundleAdjustment (the C++ glue, run on mock objects by tests/cpp/glue_lba_dump, whose entry-point set
+    records the flattened lba_problem) against Optimizer::LocalBundleAdjustment's OWN graph construction -- S/Optimizer.cc:1810-2124:
+    local keyframes from the covisibility list, local points, fixed cameras, the "two lowest ids" rule, VertexSE3Expmap / VertexSBAPointXYZ
+    with Optimizer::GetID ids and fixed flags, one edge per observation (mono, stereo, right camera) with measurement, information and
+    Huber delta -- transliterated and run on Python stand-ins rebuilt from the same scene, over an optimizer stand-in that records
+    addVertex / addEdge.  Same keyframes with the same fixed flags, same points, same edges (as sets: the glue orders by vertex id where
+    the reference walks pointer-keyed maps, which only permutes sums), same num_fixedKF, same initial lambda."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "tests", "cpp")
+    exe = os.path.join(cpp, "glue_lba_dump")
+    lib_dir = os.path.join(root, "multi_orbslam3_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", os.path.join(root, "include"), "-I", cpp, os.path.join(cpp, "glue_lba_dump.cpp"),
+                           "-o", exe, "-pthread", "-L", lib_dir, "-lorbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.check_output([exe], text=True)
+    scenes = [json.loads(("{\"scene\"" + part) if not part.startswith("{") else part) for part in out.split("\n{\"scene\"") if part.strip()]
+    assert len(scenes) == 4
+
+    body = _body(os.path.join(REF, "src", "Optimizer.cc"), r"void\s+Optimizer::LocalBundleAdjustment\s*\(\s*KeyFrame\s*\*pKF,\s*bool\s*\*\s*pbStopFlag,\s*Map\s*\*\s*pMap,\s*int&\s*num_fixedKF[^)]*\)\s*\{")
+    body = re.sub(r"\s+", " ", body)
+    piece = body[:body.index("if(pbStopFlag) if(*pbStopFlag) return;")]
+    # ---- textual adaptations (iterator loops -> foreach, container declarations, g2o / Eigen construction syntax)
+    piece = re.sub(r"Verbose::PrintMess\([^;]*;", "", piece)
+    piece = re.sub(r"[\w\.]+\.reserve\([^;]*;", "", piece)
+    piece = re.sub(r"for\(list<(KeyFrame|MapPoint)\*>::iterator lit=(\w+)\.begin\(\) ?, lend=\2\.end\(\); lit!=lend; lit\+\+\) \{ (KeyFrame|MapPoint)\* (\w+) = \*lit;", r"foreach(\4, \2) {", piece)
+    piece = piece.replace("for(vector<MapPoint*>::iterator vit=vpMPs.begin(), vend=vpMPs.end(); vit!=vend; vit++) { MapPoint* pMP = *vit;", "foreach(pMP, vpMPs) {")
+    piece = piece.replace("for(list<MapPoint*>::iterator lit=lLocalMapPoints.begin(), lend=lLocalMapPoints.end(); lit!=lend; lit++) { map<KeyFrame*,tuple<int,int>> observations = (*lit)->GetObservations();",
+                          "foreach(litv, lLocalMapPoints) { observations = litv->GetObservations();")
+    piece = re.sub(r"for\(map<KeyFrame\*,tuple<int,int>>::(?:const_)?iterator mit=observations\.begin\(\), mend=observations\.end\(\); mit!=mend; mit\+\+\)", "obsitems = observations.items(); foreach(mit, obsitems)", piece)
+    piece = piece.replace("for(int i=0, iend=vNeighKFs.size(); i<iend; i++)", "for(int i=0; i<len(vNeighKFs); i++)")
+    piece = piece.replace("list<KeyFrame*>::iterator lit=lLocalKeyFrames.begin();", "").replace("for(; lit != lLocalKeyFrames.end(); lit++) { KeyFrame* pKFi = *lit;", "foreach(pKFi, lLocalKeyFrames) {")
+    for decl in ("list<KeyFrame*> lLocalKeyFrames;", "list<MapPoint*> lLocalMapPoints;", "list<KeyFrame*> lFixedCameras;"):
+        assert decl in piece, decl
+        piece = piece.replace(decl, decl.split()[-1][:-1] + " = CppVec();")
+    piece = piece.replace("set<MapPoint*> sNumObsMP;", "").replace("KeyFrame* pLowerKf;", "pLowerKf = None;").replace("KeyFrame* pSecondLowerKF;", "pSecondLowerKF = None;")
+    piece = re.sub(r"vector<[\w:]+\*> (vp\w+);", r"\1 = CppVec();", piece)
+    piece = piece.replace("g2o::SparseOptimizer optimizer;", "optimizer = SparseOptimizerRec();").replace("g2o::BlockSolver_6_3::LinearSolverType * linearSolver;", "")
+    piece = piece.replace("new g2o::LinearSolverEigen<g2o::BlockSolver_6_3::PoseMatrixType>()", "None").replace("new g2o::BlockSolver_6_3(linearSolver)", "None")
+    piece = piece.replace("new g2o::OptimizationAlgorithmLevenberg(solver_ptr)", "LevenbergRec()")
+    piece = re.sub(r"new ([\w:]+)\(\)", r"\1()", piece).replace("new g2o::RobustKernelHuber;", "g2o::RobustKernelHuber();")
+    piece = re.sub(r"dynamic_cast<g2o::OptimizableGraph::Vertex\*> ?\(", "(", piece)
+    piece = re.sub(r"Eigen::Matrix<double,(\d),1> obs;", r"obs = Vec(\1);", piece)
+    piece = re.sub(r"obs << ([^;]*);", r"obs.set(\1);", piece)
+    piece = piece.replace("Eigen::Matrix2d::Identity()", "Identity(2)").replace("Eigen::Matrix3d::Identity()", "Identity(3)").replace("Eigen::Matrix3d Info =", "Info =")
+    piece = re.sub(r"get<(\d)>\(([^()]*)\)", r"(\2)[\1]", piece)
+    piece = re.sub(r"(g2o|ORB_SLAM3)::(\w+)", r"\1_\2", piece).replace("Optimizer::GetID(", "GetID(").replace("Converter::", "Converter_")
+    piece = piece.replace("cv::KeyPoint kp = ", "kp = ").replace(".push_back(", ".append(").replace("unsigned long maxKFid", "int maxKFid")
+    src = c_to_python(cpp_prepare(piece), typed_ints=False)
+    assert src.count("optimizer.addEdge(e)") == 3 and src.count("optimizer.addVertex(") == 3 and "lLocalKeyFrames.remove(pLowerKf)" in src
+    gid = _body(os.path.join(REF, "include", "Optimizer.h"), r"size_t\s+static\s+GetID\s*\([^)]*\)\s*\{")
+    gid_src = c_to_python(cpp_prepare(gid.replace("unsigned(", "int(")), keep_returns=True)
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def GetID(mId, mClientId, bIsKf):\n" + ind(gid_src) +
+            "\ndef build(pKF, pbStopFlag, pMap, LocalBASize):\n    num_fixedKF = 0\n" + ind(src) + "\n    return optimizer, num_fixedKF, solver")
+
+    class CppVec(list):                                      # std::list / std::vector of pointers: push_back, remove(value), size
+        def remove(self, v):
+            while v in self:
+                list.remove(self, v)
+
+    class Pair:
+        def __init__(self, a, b): self.first, self.second = a, b
+
+    class ObsMap:                                            # std::map<KeyFrame*, tuple<int,int>>: iteration in KEY (address) order -- here: as stored
+        def __init__(self, items): self._items = items
+        def items(self): return [Pair(k, v) for k, v in self._items]
+
+    class Vec:
+        def __init__(self, n): self.v = [None] * n
+        def set(self, *a): self.v = [float(x) for x in a]
+
+    class Identity:
+        def __init__(self, n): self.n, self.k = n, 1.0
+        def __mul__(self, k):
+            r = Identity(self.n); r.k = float(k); return r
+
+    class Rec:                                               # vertices, edges, kernels: remember what the text sets
+        def __init__(self, kind): self.kind = kind; self.fixed = False; self.v = {}
+        def setEstimate(self, e): self.est = e
+        def setId(self, i): self.id = int(i)
+        def setFixed(self, f): self.fixed = bool(f)
+        def setMarginalized(self, m): self.marg = bool(m)
+        def setVertex(self, k, vtx): self.v[k] = vtx
+        def setMeasurement(self, o): self.meas = list(o.v)
+        def setInformation(self, I): self.info = (I.n, I.k)
+        def setRobustKernel(self, rk): self.rk = rk
+        def setDelta(self, d): self.delta = float(d)
+
+    class SparseOptimizerRec:
+        def __init__(self): self.vertices = {}; self.edges = []
+        def setAlgorithm(self, a): self.alg = a
+        def setVerbose(self, v): pass
+        def setForceStopFlag(self, f): pass
+        def addVertex(self, vtx): self.vertices[vtx.id] = vtx
+        def vertex(self, i): return self.vertices[int(i)]
+        def addEdge(self, e): self.edges.append(e)
+
+    class LevenbergRec:
+        def __init__(self): self.user_lambda = 0.0
+        def setUserLambdaInit(self, v): self.user_lambda = float(v)
+
+    for sc in scenes:
+        class MapS:
+            pass
+        maps = [MapS(), MapS()]
+        maps[0].GetInitKFid = lambda: sc["init_kf"]; maps[0].IsInertial = lambda: bool(sc["inertial"])
+        kfs, mps = {}, {}
+
+        class KFs:
+            pass
+        for d in sc["kfs"]:
+            f = KFs(); f.d = d; f.mnId = d["id"]; f.mnClientId = d["client"]; f.mnBALocalForKF = -1; f.mnBAFixedForKF = -1
+            f.isBad = (lambda d=d: bool(d["bad"])); f.GetMap = (lambda d=d: maps[d["map"]]); f.GetPose = (lambda d=d: tuple(d["pose"]))
+            f.mvKeysUn = [type("Kp", (), {"pt": type("P", (), {"x": F32(k[0]), "y": F32(k[1])})(), "octave": k[2]})() for k in d["keysUn"]]
+            f.mvKeysRight = [type("Kp", (), {"pt": type("P", (), {"x": F32(k[0]), "y": F32(k[1])})(), "octave": k[2]})() for k in d["keysRight"]]
+            f.mvuRight = [F32(x) for x in d["uRight"]]; f.mvInvLevelSigma2 = [F32(x) for x in d["invSigma2"]]
+            f.fx, f.fy, f.cx, f.cy, f.mbf = [F32(d[k]) for k in ("fx", "fy", "cx", "cy", "mbf")]
+            f.NLeft = d["NLeft"]; f.mpCamera = "cam1"; f.mpCamera2 = "cam2" if d["camera2"] else None; f.mTrl = "Trl"
+            kfs[d["id"]] = f
+
+        class MPs:
+            pass
+        for d in sc["mps"]:
+            q = MPs(); q.mnId = d["id"]; q.mnClientId = d["client"]; q.mnBALocalForKF = -1
+            q.isBad = (lambda d=d: bool(d["bad"])); q.GetMap = (lambda d=d: maps[d["map"]]); q.GetWorldPos = (lambda d=d: tuple(d["pos"]))
+            q.GetObservations = (lambda d=d: ObsMap([(kfs[o[0]], (o[1], o[2])) for o in d["obs"]]))
+            mps[d["id"]] = q
+        for d in sc["kfs"]:
+            kfs[d["id"]].GetVectorCovisibleKeyFrames = (lambda d=d: [kfs[i] for i in d["covisible"]])
+            kfs[d["id"]].GetMapPointMatches = (lambda d=d: [None if j < 0 else mps[j] for j in d["matches"]])
+        env = dict(ENV, F32=F32, F64=F64, CppVec=CppVec, Vec=Vec, Identity=Identity, SparseOptimizerRec=SparseOptimizerRec, LevenbergRec=LevenbergRec,
+                   IDRANGE=1000000, MAXAGENTS=4, Converter_toSE3Quat=lambda T: T, Converter_toVector3d=lambda X: X,
+                   g2o_VertexSE3Expmap=lambda: Rec("pose"), g2o_VertexSBAPointXYZ=lambda: Rec("point"), ORB_SLAM3_EdgeSE3ProjectXYZ=lambda: Rec("mono"),
+                   ORB_SLAM3_EdgeSE3ProjectXYZToBody=lambda: Rec("body"), g2o_EdgeStereoSE3ProjectXYZ=lambda: Rec("stereo"), g2o_RobustKernelHuber=lambda: Rec("huber"))
+        exec(prog, env)
+        optimizer, num_fixed, solver = env["build"](kfs[sc["current_kf"]], None, maps[0], 0)
+        # ---- what the glue handed the C-ABI, keyed the same way
+        pb = sc["problem"]
+        pose_of_kf = {tuple(np.float32(d["pose"]).tolist()): d for d in sc["kfs"]}
+        pos_of_mp = {tuple(np.float32(d["pos"]).tolist()): d for d in sc["mps"]}
+        P = len(pb["fixed"])
+        g_kf = [pose_of_kf[tuple(np.float32(pb["poses"][16 * i:16 * i + 16]).tolist())] for i in range(P)]
+        g_mp = [pos_of_mp[tuple(np.float32(pb["points"][3 * j:3 * j + 3]).tolist())] for j in range(len(pb["points"]) // 3)]
+        ref_poses = {v.id: v for v in optimizer.vertices.values() if v.kind == "pose"}
+        ref_points = {v.id: v for v in optimizer.vertices.values() if v.kind == "point"}
+        gid_f = env["GetID"]
+        assert {gid_f(d["id"], d["client"], True): bool(pb["fixed"][i]) for i, d in enumerate(g_kf)} == {i: v.fixed for i, v in ref_poses.items()}, sc["scene"]
+        assert sorted(gid_f(d["id"], d["client"], False) for d in g_mp) == sorted(ref_points), sc["scene"]
+        ids = [gid_f(d["id"], d["client"], True) for d in g_kf]
+        assert ids == sorted(ids)                                # the glue lists the keyframes in ascending vertex id
+        assert all(tuple(np.float32(v.est).tolist()) == tuple(np.float32(kfs_d["pose"]).tolist()) for v, kfs_d in ((ref_poses[gid_f(d["id"], d["client"], True)], d) for d in g_kf))
+        delta_mono, delta_stereo = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+
+        def glue_edge(e):
+            kf, mp = g_kf[e[0]], g_mp[e[1]]
+            kind = "stereo" if e[4] >= 0 else ("body" if e[4] <= -1.5 and pb["has_right"] else "mono")
+            meas = (e[2], e[3], e[4]) if kind == "stereo" else (e[2], e[3])
+            return (gid_f(kf["id"], kf["client"], True), gid_f(mp["id"], mp["client"], False), kind, tuple(float(np.float32(m)) for m in meas), float(np.float32(e[5])))
+
+        def ref_edge(e):
+            assert e.rk.delta == (delta_stereo if e.kind == "stereo" else delta_mono) and e.info[0] == (3 if e.kind == "stereo" else 2)
+            return (e.v[1].id, e.v[0].id, e.kind, tuple(float(np.float32(m)) for m in e.meas), float(np.float32(e.info[1])))
+
+        ge, re_ = sorted(glue_edge(e) for e in pb["edges"]), sorted(ref_edge(e) for e in optimizer.edges)
+        assert ge == re_, (sc["scene"], len(ge), len(re_), [x for x in ge if x not in re_][:3], [x for x in re_ if x not in ge][:3])
+        assert num_fixed == sc["num_fixed"] and float(pb["lambda_init"]) == (100.0 if sc["inertial"] else 0.0) == float(solver.user_lambda), sc["scene"]
+        assert len(ge) > 500 and (sum(1 for e in ge if e[2] == "body") > 300) == (sc["scene"] == "two-fisheye rig")
