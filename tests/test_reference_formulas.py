@@ -2661,3 +2661,148 @@ def test_glues_local_ba_problem_is_the_graph_the_references_text_builds():
         assert ge == re_, (sc["scene"], len(ge), len(re_), [x for x in ge if x not in re_][:3], [x for x in re_ if x not in ge][:3])
         assert num_fixed == sc["num_fixed"] and float(pb["lambda_init"]) == (100.0 if sc["inertial"] else 0.0) == float(solver.user_lambda), sc["scene"]
         assert len(ge) > 500 and (sum(1 for e in ge if e[2] == "body") > 300) == (sc["scene"] == "two-fisheye rig")
+
+
+def test_glues_searchlocalpoints_is_trackings_own_text():
+    """include/orbgpu_dropin.hpp's SearchLocalPoints (run host-only over the oracle's entry points by tests/cpp/glue_track_dump) against
+    Tracking::SearchLocalPoints' OWN text (S/Tracking.cc:3083-3155) with Frame::isInFrustum, MapPoint::PredictScale and
+    ORBmatcher::SearchByProjection transliterated below it, on Python stand-ins of the same scene: which features hold which point
+    afterwards, every point's mnLastFrameSeen, visible count and mbTrackInView, the bad point dropped from the frame -- three scenes
+    (regular; coarser search with the far-point filter; a tiny local map)."""
+    import ctypes
+    import json
+    import subprocess
+    libm = ctypes.CDLL("libm.so.6"); libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "tests", "cpp"); exe = os.path.join(cpp, "glue_track_dump")
+    lib_dir = os.path.join(root, "multi_orbslam3_amd"); odir = os.path.join(root, "oracle")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", os.path.join(root, "include"), "-I", cpp, os.path.join(cpp, "glue_track_dump.cpp"),
+                           "-o", exe, "-pthread", "-L", lib_dir, "-lorbgpu", "-L", odir, "-loracle", "-Wl,-rpath," + lib_dir, "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.check_output([exe], text=True)
+    scenes = [json.loads(("{\"scene\"" + part) if not part.startswith("{") else part) for part in out.split("\n{\"scene\"") if part.strip()]
+    assert len(scenes) == 3
+    # ---- the reference's text
+    tr = _body(os.path.join(REF, "src", "Tracking.cc"), r"void\s+Tracking::SearchLocalPoints\s*\(\s*\)\s*\{")
+    tr = re.sub(r"\s+", " ", tr)
+    rep = [("for(vector<MapPoint*>::iterator vit=mCurrentFrame.mvpMapPoints.begin(), vend=mCurrentFrame.mvpMapPoints.end(); vit!=vend; vit++) { MapPoint* pMP = *vit;",
+            "for(int iv=0; iv<len(mCurrentFrame.mvpMapPoints); iv++) { MapPoint* pMP = mCurrentFrame.mvpMapPoints[iv];"),
+           ("*vit = static_cast<MapPoint*>(NULL);", "mCurrentFrame.mvpMapPoints[iv] = None;"),
+           ("for(vector<MapPoint*>::iterator vit=mvpLocalMapPoints.begin(), vend=mvpLocalMapPoints.end(); vit!=vend; vit++) { MapPoint* pMP = *vit;", "foreach(pMP, mvpLocalMapPoints) {"),
+           ("cv::Point2f(", "Point2f("), ("ORBmatcher matcher(0.8);", "matcher = ORBmatcher(0.8);")]
+    for a, b in rep:
+        assert a in tr, a
+        tr = tr.replace(a, b)
+    tr_src = c_to_python(cpp_prepare(tr))
+    assert "mCurrentFrame.isInFrustum(pMP," in tr_src and "matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, mpLocalMapper.mbFarPoints, mpLocalMapper.mThFarPoints)" in tr_src
+    fr = _body(os.path.join(REF, "src", "Frame.cc"), r"bool\s+Frame::isInFrustum\s*\(\s*MapPoint\s*\*pMP,\s*float viewingCosLimit\s*\)\s*\{")
+    fr = fr[fr.index("pMP->mbTrackInView = false;"):fr.index("else{")]
+    fr = fr[:fr.rindex("}")].replace(".at<float>(", ".at(").replace("cv::norm(Pc)", "Pc.norm()").replace("cv::norm(PO)", "PO.norm()").replace("PredictScale(dist,this)", "PredictScale(dist,thisF)")
+    fr_src = c_to_python(cpp_prepare(fr), keep_returns=True)
+    mp_path = os.path.join(REF, "src", "MapPoint.cc")
+    ps = _body(mp_path, r"int\s+MapPoint::PredictScale\s*\(\s*const float &currentDist,\s*Frame\*\s*pF\s*\)\s*\{")
+    ps = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", ps).replace("float ratio;", "")
+    ps = re.sub(r"\{\s*(ratio = [^;]*;)\s*\}", r"\1", ps)
+    ps_src = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", ps)), typed_ints=True, keep_returns=True)
+    getters = {}
+    for nm in ("GetMinDistanceInvariance", "GetMaxDistanceInvariance"):
+        g = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", _body(mp_path, r"float\s+MapPoint::%s\s*\(\s*\)\s*\{" % nm))
+        getters[nm] = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", g)), keep_returns=True)
+    mpath = os.path.join(REF, "src", "ORBmatcher.cc")
+    sb = _body(mpath, r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&F,\s*const\s+vector<MapPoint\*>\s*&vpMapPoints[^)]*\)\s*\{")
+    sb = re.sub(r"for\(vector<size_t>::const_iterator vit=vIndices\.begin\(\), vend=vIndices\.end\(\); vit!=vend; vit\+\+\)\s*\{\s*const size_t idx = \*vit;", "foreach(idx, vIndices) {", sb)
+    sb = sb.replace("int nmatches=0, left = 0, right = 0;", "int nmatches=0; int left = 0; int right = 0;")
+    sb_src = c_to_python(cpp_prepare(sb), keep_returns=True)
+    rad = c_to_python(cpp_prepare(_body(mpath, r"float\s+ORBmatcher::RadiusByViewingCos\s*\([^)]*\)\s*\{")), keep_returns=True)
+    pj = _body(os.path.join(REF, "src", "CameraModels", "Pinhole.cpp"), r"cv::Point2f\s+Pinhole::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    ex, ey = _split_top(re.search(r"return cv::Point2f\((.*)\)\s*;", pj, flags=re.S).group(1).replace("\n", " "))
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def PredictScale(self, currentDist, pF):\n" + ind(ps_src) + "\ndef GetMinDistanceInvariance(self):\n" + ind(getters["GetMinDistanceInvariance"]) +
+            "\ndef GetMaxDistanceInvariance(self):\n" + ind(getters["GetMaxDistanceInvariance"]) + "\ndef RadiusByViewingCos(viewCos):\n" + ind(rad) +
+            "\ndef SearchByProjection_text(F, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio):\n" + ind(sb_src) +
+            "\ndef SearchLocalPoints_text(mCurrentFrame, mvpLocalMapPoints, mSensor, mpAtlas, mnLastRelocFrameId, mState, mpLocalMapper):\n" + ind(tr_src))
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o): self.pt, self.octave = Pt(x, y), int(o)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[int(i)]
+
+    class Obj:
+        pass
+
+    for sc in scenes:
+        fd = sc["frame"]; N = fd["N"]
+        desc = np.frombuffer(bytes.fromhex(fd["desc"]), np.uint8).reshape(N, 32)
+        kps = np.zeros(N, capi.KEYPOINT_DTYPE)
+        kps["x"] = [k[0] for k in fd["keys"]]; kps["y"] = [k[1] for k in fd["keys"]]; kps["octave"] = [k[2] for k in fd["keys"]]
+        bounds = (0.0, 640.0, 0.0, 480.0)
+        fv, keep = views.frame_view(kps, desc, uright=np.array(fd["uRight"], np.float32), depth=np.zeros(N, np.float32), bounds=bounds,
+                                    cam=(fd["fx"], fd["fy"], fd["cx"], fd["cy"], fd["mbf"], fd["mb"]))
+        start, items = ob.build_grid(fv)
+        sfs = np.ones(8, np.float32)
+        for l in range(1, 8):
+            sfs[l] = np.float32(sfs[l - 1] * np.float32(1.2))
+        Tc = np.array(fd["Tcw"], np.float32).reshape(4, 4)
+        params = [F32(fd["fx"]), F32(fd["fy"]), F32(fd["cx"]), F32(fd["cy"])]
+
+        class Cam:
+            def project(self, m):
+                e2 = {"mvParameters": params, "p3D": Obj()}
+                e2["p3D"].x, e2["p3D"].y, e2["p3D"].z = m.at(0), m.at(1), m.at(2)
+                return Pt(eval(ex, e2), eval(ey, e2))
+
+        thisF = Obj(); thisF.mfLogScaleFactor = F32(np.log(np.float32(1.2))); thisF.mnScaleLevels = 8
+        Rm, tm = MatF(Tc[:3, :3]), MatF(Tc[:3, 3].reshape(3, 1))
+        env = dict(ENV, F32=F32, F64=F64, abs=abs, fabs=abs, as_int=lambda x: int(x), floor=np.floor, ceil=np.ceil, TH_HIGH=100,
+                   log=lambda x: F32(libm.logf(float(F32(x)))), DescriptorDistance=lambda a, b: int(np.unpackbits(a ^ b).sum()),
+                   Point2f=Pt, RGBD=2, IMU_MONOCULAR=3, IMU_STEREO=4, LOST=3, RECENTLY_LOST=4)
+        exec(prog, env)
+        fenv = dict(env, thisF=thisF, mRcw=Rm, mtcw=tm, mOw=-Rm.t() * tm, mpCamera=Cam(), mbf=F32(fd["mbf"]), mnMinX=F32(bounds[0]), mnMaxX=F32(bounds[1]),
+                    mnMinY=F32(bounds[2]), mnMaxY=F32(bounds[3]))
+        exec("def isInFrustum(pMP, viewingCosLimit):\n" + ind(fr_src) + "\n    return True", fenv)
+        genv = dict(env, mnMinX=F32(bounds[0]), mnMinY=F32(bounds[2]), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
+                    mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / F32(F32(bounds[1]) - F32(bounds[0]))),
+                    mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / F32(F32(bounds[3]) - F32(bounds[2]))),
+                    mGrid=[[[int(x) for x in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)]
+                           for ix in range(capi.GRID_COLS)], mvKeysUn=[Kp(*k) for k in fd["keys"]])
+        exec(_get_features_in_area_source(), genv)
+        MPc = type("MapPoint", (), {"PredictScale": env["PredictScale"], "GetMinDistanceInvariance": env["GetMinDistanceInvariance"],
+                                    "GetMaxDistanceInvariance": env["GetMaxDistanceInvariance"]})
+        pts = {}
+        for d in sc["points"]:
+            q = MPc(); q.mnId = d["id"]; q.bad = bool(d["bad"]); q.nobs = d["nobs"]; q.visible = d["visible"]; q.mnLastFrameSeen = -1
+            q.mfMinDistance = F32(d["mind"]); q.mfMaxDistance = F32(d["maxd"]); q.mbTrackInView = False; q.mbTrackInViewR = False
+            q.isBad = (lambda q=q: q.bad); q.Observations = (lambda q=q: q.nobs)
+            q.IncreaseVisible = (lambda n=1, q=q: setattr(q, "visible", q.visible + n))
+            q.GetWorldPos = (lambda d=d: MatF(np.array(d["pos"], np.float32).reshape(3, 1))); q.GetNormal = (lambda d=d: MatF(np.array(d["normal"], np.float32).reshape(3, 1)))
+            q.GetDescriptor = (lambda d=d: np.frombuffer(bytes.fromhex(d["desc"]), np.uint8)) if "desc" in d else None
+            q.mnTrackScaleLevelR = -1; q.mTrackViewCosR = F32(0); q.mTrackProjYR = F32(0); q.mTrackProjXR = F32(0); q.mTrackDepth = F32(0)
+            pts[d["id"]] = q
+        F = Obj()
+        F.mnId = fd["id"]; F.Nleft = -1; F.mvpMapPoints = [None if j < 0 else pts[j] for j in fd["held_before"]]; F.mmProjectPoints = {}
+        F.isInFrustum = lambda pMP, lim: fenv["isInFrustum"](pMP, F32(lim))
+        F.GetFeaturesInArea = lambda x, y, r, lo=-1, hi=-1, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), lo, hi, bRight)
+        F.mvuRight = [F32(x) for x in fd["uRight"]]; F.mvScaleFactors = [F32(x) for x in sfs]; F.mvKeysUn = genv["mvKeysUn"]; F.mvKeys = F.mvKeysUn; F.mvKeysRight = []
+        F.mDescriptors = Desc(desc); F.mvLeftToRightMatch = [-1] * N; F.mvRightToLeftMatch = []
+        nn_holder = {}
+
+        class ORBmatcher:
+            def __init__(self, nnratio): self.r = F32(nnratio)
+            def SearchByProjection(self, Fr, vp, th, far, thfar): return env["SearchByProjection_text"](Fr, vp, F32(th), bool(far), F32(thfar), self.r)
+        env["ORBmatcher"] = ORBmatcher
+        atlas = Obj(); atlas.isImuInitialized = lambda: False
+        lm = Obj(); lm.mbFarPoints = bool(fd["far"]); lm.mThFarPoints = F32(fd["th_far"])
+        local = [pts[d["id"]] for d in sc["points"] if d["local"]]
+        # th: 1 for a stereo sensor without IMU; 5 right after a relocalisation (:3147-3148) -- the scenes' two values
+        last_reloc = fd["id"] if fd["th"] == 5 else -10
+        env["SearchLocalPoints_text"](F, local, 1, atlas, last_reloc, 2, lm)
+        res = sc["result"]
+        assert [(-1 if p_ is None else p_.mnId) for p_ in F.mvpMapPoints] == res["held_after"], sc["scene"]
+        for pid, last_seen, visible, in_view in res["points_after"]:
+            q = pts[pid]
+            assert (q.mnLastFrameSeen, q.visible, int(bool(q.mbTrackInView))) == (last_seen, visible, in_view), (sc["scene"], pid, q.mnLastFrameSeen, q.visible, q.mbTrackInView, last_seen, visible, in_view)
+        assert sum(1 for a, b in zip(fd["held_before"], res["held_after"]) if a != b) > (5 if sc["scene"] == 2 else 150)
