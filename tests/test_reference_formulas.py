@@ -2492,6 +2492,54 @@ def test_localbundleadjustment_optimisation_section_is_the_references_text(kind)
         assert o.n_outliers < 0.5 * len(E) and o.n_outliers >= 0.5 * (len(kinds["mono"]) + len(kinds["stereo"]))
 
 
+# ---- recording stand-ins of the g2o graph objects: the glue tests below run the reference's graph CONSTRUCTION text over them
+class CppVec(list):                                      # std::list / std::vector of pointers: push_back, remove(value), size
+    def remove(self, v):
+        while v in self:
+            list.remove(self, v)
+
+class GPair:
+    def __init__(self, a, b): self.first, self.second = a, b
+
+class ObsMap:                                            # std::map<KeyFrame*, tuple<int,int>>: iteration in KEY (address) order -- here: as stored
+    def __init__(self, items): self._items = items
+    def items(self): return [GPair(k, v) for k, v in self._items]
+
+class Vec:
+    def __init__(self, n): self.v = [None] * n
+    def set(self, *a): self.v = [float(x) for x in a]
+
+class Identity:
+    def __init__(self, n): self.n, self.k = n, 1.0
+    def __mul__(self, k):
+        r = Identity(self.n); r.k = float(k); return r
+
+class Rec:                                               # vertices, edges, kernels: remember what the text sets
+    def __init__(self, kind): self.kind = kind; self.fixed = False; self.v = {}
+    def setEstimate(self, e): self.est = e
+    def setId(self, i): self.id = int(i)
+    def setFixed(self, f): self.fixed = bool(f)
+    def setMarginalized(self, m): self.marg = bool(m)
+    def setVertex(self, k, vtx): self.v[k] = vtx
+    def setMeasurement(self, o): self.meas = list(o.v)
+    def setInformation(self, I): self.info = (I.n, I.k)
+    def setRobustKernel(self, rk): self.rk = rk
+    def setDelta(self, d): self.delta = float(d)
+
+class SparseOptimizerRec:
+    def __init__(self): self.vertices = {}; self.edges = []
+    def setAlgorithm(self, a): self.alg = a
+    def setVerbose(self, v): pass
+    def setForceStopFlag(self, f): pass
+    def addVertex(self, vtx): self.vertices[vtx.id] = vtx
+    def vertex(self, i): return self.vertices[int(i)]
+    def addEdge(self, e): self.edges.append(e)
+
+class LevenbergRec:
+    def __init__(self): self.user_lambda = 0.0
+    def setUserLambdaInit(self, v): self.user_lambda = float(v)
+
+
 def test_glues_local_ba_problem_is_the_graph_the_references_text_builds():
     """include/orbgpu_dropin.hpp's LocalBundleAdjustment (the C++ glue, run on mock objects by tests/cpp/glue_lba_dump, whose entry-point set
     records the flattened lba_problem) against Optimizer::LocalBundleAdjustment's OWN graph construction -- S/Optimizer.cc:1810-2124:
@@ -2548,52 +2596,6 @@ def test_glues_local_ba_problem_is_the_graph_the_references_text_builds():
     ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
     prog = ("def GetID(mId, mClientId, bIsKf):\n" + ind(gid_src) +
             "\ndef build(pKF, pbStopFlag, pMap, LocalBASize):\n    num_fixedKF = 0\n" + ind(src) + "\n    return optimizer, num_fixedKF, solver")
-
-    class CppVec(list):                                      # std::list / std::vector of pointers: push_back, remove(value), size
-        def remove(self, v):
-            while v in self:
-                list.remove(self, v)
-
-    class Pair:
-        def __init__(self, a, b): self.first, self.second = a, b
-
-    class ObsMap:                                            # std::map<KeyFrame*, tuple<int,int>>: iteration in KEY (address) order -- here: as stored
-        def __init__(self, items): self._items = items
-        def items(self): return [Pair(k, v) for k, v in self._items]
-
-    class Vec:
-        def __init__(self, n): self.v = [None] * n
-        def set(self, *a): self.v = [float(x) for x in a]
-
-    class Identity:
-        def __init__(self, n): self.n, self.k = n, 1.0
-        def __mul__(self, k):
-            r = Identity(self.n); r.k = float(k); return r
-
-    class Rec:                                               # vertices, edges, kernels: remember what the text sets
-        def __init__(self, kind): self.kind = kind; self.fixed = False; self.v = {}
-        def setEstimate(self, e): self.est = e
-        def setId(self, i): self.id = int(i)
-        def setFixed(self, f): self.fixed = bool(f)
-        def setMarginalized(self, m): self.marg = bool(m)
-        def setVertex(self, k, vtx): self.v[k] = vtx
-        def setMeasurement(self, o): self.meas = list(o.v)
-        def setInformation(self, I): self.info = (I.n, I.k)
-        def setRobustKernel(self, rk): self.rk = rk
-        def setDelta(self, d): self.delta = float(d)
-
-    class SparseOptimizerRec:
-        def __init__(self): self.vertices = {}; self.edges = []
-        def setAlgorithm(self, a): self.alg = a
-        def setVerbose(self, v): pass
-        def setForceStopFlag(self, f): pass
-        def addVertex(self, vtx): self.vertices[vtx.id] = vtx
-        def vertex(self, i): return self.vertices[int(i)]
-        def addEdge(self, e): self.edges.append(e)
-
-    class LevenbergRec:
-        def __init__(self): self.user_lambda = 0.0
-        def setUserLambdaInit(self, v): self.user_lambda = float(v)
 
     for sc in scenes:
         class MapS:
@@ -2661,6 +2663,112 @@ def test_glues_local_ba_problem_is_the_graph_the_references_text_builds():
         assert ge == re_, (sc["scene"], len(ge), len(re_), [x for x in ge if x not in re_][:3], [x for x in re_ if x not in ge][:3])
         assert num_fixed == sc["num_fixed"] and float(pb["lambda_init"]) == (100.0 if sc["inertial"] else 0.0) == float(solver.user_lambda), sc["scene"]
         assert len(ge) > 500 and (sum(1 for e in ge if e[2] == "body") > 300) == (sc["scene"] == "two-fisheye rig")
+
+
+def test_glues_pose_optimization_problem_is_the_edge_set_the_references_text_collects():
+    """include/orbgpu_dropin.hpp's PoseOptimization (run on mock Frames by tests/cpp/glue_po_dump, whose entry-point set records the
+    flattened pose_opt_problem and answers with a synthetic result) against Optimizer::PoseOptimization's OWN collection text --
+    S/Optimizer.cc:964-1161: the SE3 vertex from mTcw, one EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose /
+    EdgeSE3ProjectXYZOnlyPoseToBody per feature that holds a point, its measurement, information, Huber delta, Xw, intrinsics, the
+    mvbOutlier resets and the "fewer than three correspondences" return -- transliterated and run on Python stand-ins of the same Frame
+    over a recording optimizer.  The k-th edge the text creates is the k-th correspondence the glue hands over (both walk the features
+    in order), which also pins the write-back: outlier flag k lands on the feature the text's vnIndexEdge* names."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "tests", "cpp")
+    exe = os.path.join(cpp, "glue_po_dump")
+    lib_dir = os.path.join(root, "multi_orbslam3_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", os.path.join(root, "include"), "-I", cpp, os.path.join(cpp, "glue_po_dump.cpp"),
+                           "-o", exe, "-pthread", "-L", lib_dir, "-lorbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.check_output([exe], text=True)
+    scenes = [json.loads(ln) for ln in out.splitlines() if ln.strip()]
+    assert len(scenes) == 3
+
+    body = _body(os.path.join(REF, "src", "Optimizer.cc"), r"int\s+Optimizer::PoseOptimization\s*\(\s*Frame\s*\*\s*pFrame\s*\)\s*\{")
+    body = re.sub(r"//[^\n]*", "", body)
+    body = re.sub(r"\s+", " ", body)
+    stop = "if(nInitialCorrespondences<3) return 0;"
+    piece = body[:body.index(stop)]
+    piece = re.sub(r"[\w\.]+\.reserve\([^;]*;", "", piece)
+    piece = piece.replace("{ unique_lock<mutex> lock(MapPoint::mGlobalMutex);", "if(true) {")
+    piece = piece.replace("g2o::SparseOptimizer optimizer;", "optimizer = SparseOptimizerRec();").replace("g2o::BlockSolver_6_3::LinearSolverType * linearSolver;", "")
+    piece = piece.replace("new g2o::LinearSolverDense<g2o::BlockSolver_6_3::PoseMatrixType>()", "None").replace("new g2o::BlockSolver_6_3(linearSolver)", "None")
+    piece = piece.replace("new g2o::OptimizationAlgorithmLevenberg(solver_ptr)", "LevenbergRec()")
+    piece = re.sub(r"vector<[\w:]+ ?\*> (vp\w+);", r"\1 = CppVec();", piece)
+    piece = re.sub(r"vector<size_t> (\w+), (\w+);", r"\1 = CppVec(); \2 = CppVec();", piece).replace("vector<size_t> vnIndexEdgeStereo;", "vnIndexEdgeStereo = CppVec();")
+    piece = re.sub(r"new ([\w:]+)\(\)", r"\1()", piece).replace("new g2o::RobustKernelHuber;", "g2o::RobustKernelHuber();")
+    piece = re.sub(r"dynamic_cast<g2o::OptimizableGraph::Vertex ?\*> ?\(", "(", piece)
+    piece = re.sub(r"Eigen::Matrix<double, ?(\d), ?1> obs;", r"obs = Vec(\1);", piece)
+    piece = re.sub(r"obs << ([^;]*);", r"obs.set(\1);", piece)
+    piece = piece.replace("Eigen::Matrix2d::Identity()", "Identity(2)").replace("Eigen::Matrix3d::Identity()", "Identity(3)").replace("Eigen::Matrix3d Info =", "Info =")
+    piece = re.sub(r"(g2o|ORB_SLAM3)::(\w+)", r"\1_\2", piece).replace("Converter::", "Converter_")
+    piece = piece.replace("const cv::KeyPoint &kpUn = ", "kpUn = ").replace("cv::KeyPoint kpUn;", "kpUn = None;").replace("const float &kp_ur = ", "kp_ur = ").replace("cv::Mat Xw = ", "Xw = ")
+    piece = re.sub(r"Xw\.at<float>\((\d)\)", r"Xw[\1]", piece).replace(".push_back(", ".append(")
+    src = c_to_python(cpp_prepare(piece), typed_ints=False)
+    assert src.count("optimizer.addEdge(e)") == 4 and src.count("pFrame.mvbOutlier[i] = False") == 4 and "vnIndexEdgeRight.append(i)" in src
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = "def collect(pFrame):\n" + ind(src) + "\n    return optimizer, nInitialCorrespondences, vnIndexEdgeMono, vnIndexEdgeStereo, vnIndexEdgeRight, vpEdgesMono, vpEdgesStereo, vpEdgesMono_FHR\n"
+
+    class EdgeRec(Rec):
+        def __init__(self, kind):
+            Rec.__init__(self, kind)
+            self.Xw = [None] * 3
+
+    kp = lambda k: type("Kp", (), {"pt": type("P", (), {"x": F32(k[0]), "y": F32(k[1])})(), "octave": k[2]})()
+    for sc in scenes:
+        class Fr:
+            pass
+        F = Fr()
+        F.N, F.Nleft = sc["N"], sc["Nleft"]
+        F.mTcw = tuple(sc["Tcw"]); F.mTrl = "Trl"; F.mpCamera = "cam1"; F.mpCamera2 = "cam2" if sc["camera2"] else None
+        F.mvKeysUn, F.mvKeys, F.mvKeysRight = [kp(k) for k in sc["keysUn"]], [kp(k) for k in sc["keys"]], [kp(k) for k in sc["keysRight"]]
+        F.mvuRight = [F32(x) for x in sc["uRight"]]; F.mvInvLevelSigma2 = [F32(x) for x in sc["invSigma2"]]
+        F.fx, F.fy, F.cx, F.cy, F.mbf = [F32(sc[k]) for k in ("fx", "fy", "cx", "cy", "mbf")]
+        F.mvbOutlier = [bool(b) for b in sc["outlier_before"]]
+        F.mvpMapPoints = [None if X is None else type("MP", (), {"GetWorldPos": (lambda self, X=X: [F32(x) for x in X])})() for X in sc["points"]]
+        env = dict(ENV, F32=F32, F64=F64, CppVec=CppVec, Vec=Vec, Identity=Identity, SparseOptimizerRec=SparseOptimizerRec, LevenbergRec=LevenbergRec,
+                   Converter_toSE3Quat=lambda T: T, g2o_VertexSE3Expmap=lambda: Rec("pose"), ORB_SLAM3_EdgeSE3ProjectXYZOnlyPose=lambda: EdgeRec("mono"),
+                   ORB_SLAM3_EdgeSE3ProjectXYZOnlyPoseToBody=lambda: EdgeRec("body"), g2o_EdgeStereoSE3ProjectXYZOnlyPose=lambda: EdgeRec("stereo"),
+                   g2o_RobustKernelHuber=lambda: Rec("huber"), sqrt=np.sqrt)
+        exec(prog, env)
+        optimizer, n_init, idx_mono, idx_stereo, idx_right, e_mono, e_stereo, e_right = env["collect"](F)
+        feature_of = {id(e): i for es, idx in ((e_mono, idx_mono), (e_stereo, idx_stereo), (e_right, idx_right)) for e, i in zip(es, idx)}
+        assert len(optimizer.edges) == n_init == len(feature_of)
+        pb = sc["problem"]
+        if n_init < 3:                                           # the text returns 0 here; so does the glue, with nothing handed to the C-ABI
+            assert sc["ret"] == 0 and len(pb["u"]) == 0 and sc["Tcw_after"] == sc["Tcw"]
+            assert [int(b) for b in F.mvbOutlier] == sc["outlier_after"]
+            continue
+        vtx = optimizer.vertices[0]
+        assert vtx.kind == "pose" and not vtx.fixed and tuple(np.float32(vtx.est).tolist()) == tuple(np.float32(pb["Tcw"]).tolist())
+        assert len(pb["u"]) == n_init and pb["has_rig"] == sc["camera2"] == pb["has_right"]
+        delta_mono, delta_stereo = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+        kinds = {"mono": 0, "stereo": 0, "body": 0}
+        expect_outlier = list(F.mvbOutlier)                      # after the text's resets
+        for k, e in enumerate(optimizer.edges):
+            kinds[e.kind] += 1
+            assert e.v[0] is vtx and e.rk.delta == (delta_stereo if e.kind == "stereo" else delta_mono) and e.info[0] == (3 if e.kind == "stereo" else 2)
+            assert [float(np.float32(x)) for x in e.Xw] == [float(np.float32(x)) for x in pb["Xw"][3 * k:3 * k + 3]], (sc["scene"], k)
+            assert float(np.float32(e.info[1])) == float(np.float32(pb["w"][k]))
+            ur = pb["ur"][k]
+            glue_kind = "stereo" if ur >= 0 else ("body" if ur <= -1.5 and pb["has_right"] else "mono")
+            assert glue_kind == e.kind, (sc["scene"], k, ur, e.kind)
+            meas = [pb["u"][k], pb["v"][k]] + ([ur] if e.kind == "stereo" else [])
+            assert [float(np.float32(m)) for m in e.meas] == [float(np.float32(m)) for m in meas]
+            if e.kind == "stereo":
+                assert [float(np.float32(x)) for x in (e.fx, e.fy, e.cx, e.cy, e.bf)] == [float(np.float32(x)) for x in pb["cam"]]
+            else:
+                assert e.pCamera == ("cam2" if e.kind == "body" else "cam1") and (e.kind != "body" or e.mTrl == "Trl")
+            expect_outlier[feature_of[id(e)]] = (k % 3) == 0     # the recording entry point's answer, written back by feature
+        assert [int(b) for b in expect_outlier] == sc["outlier_after"], sc["scene"]
+        assert sc["ret"] == n_init - sum(1 for k in range(n_init) if k % 3 == 0)
+        moved = list(np.float32(sc["Tcw"])); moved[3] = np.float32(moved[3] + np.float32(0.25))
+        assert [float(x) for x in moved] == [float(np.float32(x)) for x in sc["Tcw_after"]]
+        if sc["camera2"]:
+            assert kinds["body"] > 50 and kinds["mono"] > 50 and kinds["stereo"] == 0
+        else:
+            assert kinds["mono"] > 50 and kinds["stereo"] > 100 and kinds["body"] == 0
 
 
 def test_glues_searchlocalpoints_is_trackings_own_text():
