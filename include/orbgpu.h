@@ -519,6 +519,29 @@ typedef struct orbg_camera_rig {
   orbg_camera right;                 /* mpCamera2: EdgeSE3ProjectXYZToBody / EdgeSE3ProjectXYZOnlyPoseToBody (:59-87,117-144) */
   float Trl[12];                     /* mTrl, 3 x 4 row-major float32 (Converter::toSE3Quat reads exactly these, S/Converter.cc:34-44) */
 } orbg_camera_rig;
+/* ---- two-camera rig frames in the matcher (Frame::Nleft != -1, S/Frame.cc:1017-1091): the two cameras' features are two orbm_frame
+ * objects -- `left` holds mvKeys[0, Nleft) with mGrid, `right` holds mvKeysRight with mGridRight (S/Frame.cc:360-391), neither has
+ * uRight; entry Nleft + i of Frame::mvpMapPoints / mDescriptors is feature i of `right`.
+ *
+ * orbm_is_in_frustum_rig: Frame::isInFrustum for such a frame (S/Frame.cc:545-554): isInFrustumChecks (:1154-1231) through
+ * rig->left for the left camera and through rig->right after mTrl for the right one; Tlr = Frame::mTlr (3 x 4 row-major, its
+ * translation enters the right camera's centre, :1164).  Outputs, m entries each, per camera: mbTrackInView(R), mTrackProjX(R) /
+ * mTrackProjY(R), mTrackDepth(R), mnTrackScaleLevel(R) (-1 where the checks fail, :546-547), mTrackViewCos(R); fields of a point that
+ * fails a camera's checks are 0 (the reference leaves the previous frame's values there). */
+int orbm_is_in_frustum_rig(orbm_frame* left, const float* Tcw /*16*/, const orbg_camera_rig* rig, const float* Tlr /*12*/,
+                           const orbm_worldpoints_view* pts, float viewing_cos_limit, uint8_t* in_view, float* proj_x, float* proj_y,
+                           float* track_depth, int32_t* scale_level, float* view_cos, uint8_t* in_view_r, float* proj_x_r, float* proj_y_r,
+                           float* track_depth_r, int32_t* scale_level_r, float* view_cos_r);
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) on such a frame (S/ORBmatcher.cc:44-214
+ * with the right camera's block :145-211).  mps: the left camera's track fields and the per-point fields (bad, track_depth, desc,
+ * n_obs; proj_xr is not read); mps_r: track_in_view = mbTrackInViewR, proj_x / proj_y = mTrackProjXR / mTrackProjYR, scale_level =
+ * mnTrackScaleLevelR, view_cos = mTrackViewCosR (its other fields are not read).  left_to_right[Nleft] = Frame::mvLeftToRightMatch,
+ * right_to_left[Nright] = mvRightToLeftMatch (-1 = none): a match on one side is also written to the stereo partner on the other
+ * (:132-136,199-203).  assigned_mp / assigned_obs have Nleft + Nright entries (in/out, as orbm_search_by_projection_mps). */
+int orbm_search_by_projection_mps_rig(orbm_frame* left, orbm_frame* right, const orbm_mappoints_view* mps, const orbm_mappoints_view* mps_r,
+                                      const int32_t* left_to_right, const int32_t* right_to_left, float th, int far_points,
+                                      float th_far_points, float nnratio, int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+
 /* `ur` of an observation made by the RIGHT camera of the rig (get<1>(indexes) != -1, S/Optimizer.cc:2086-2120; i >= Nleft,
  * :1121-1150): u, v are then mvKeysRight[rightIndex].pt and the edge is the *ToBody kind.  In a problem whose rig has a right camera
  * any ur <= -1.5 reads as this (mvuRight is -1 throughout on such frames); in every other problem a negative ur is a monocular

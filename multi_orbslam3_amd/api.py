@@ -396,6 +396,20 @@ class Frame:
                    "orbm_is_in_frustum")
         return out
 
+    def isInFrustumRig(self, Tcw, rig, Tlr, wv, viewingCosLimit=0.5):
+        """Frame::isInFrustum of a two-camera frame (S/Frame.cc:545-554,1154-1231); self is the LEFT camera's frame.  Returns the two
+        cameras' track fields (left dict, right dict)."""
+        m = wv.m
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        tlr = np.ascontiguousarray(np.asarray(Tlr, np.float32).reshape(-1)[:12])
+        keys = ("track_in_view", "proj_x", "proj_y", "track_depth", "scale_level", "view_cos")
+        mk = lambda: dict(track_in_view=np.zeros(m, np.uint8), proj_x=np.zeros(m, np.float32), proj_y=np.zeros(m, np.float32),
+                          track_depth=np.zeros(m, np.float32), scale_level=np.zeros(m, np.int32), view_cos=np.zeros(m, np.float32))
+        a, b = mk(), mk()
+        capi.check(self.lib.orbm_is_in_frustum_rig(self.h, _vp(T), C.byref(rig), _vp(tlr), C.byref(wv), C.c_float(viewingCosLimit),
+                                                   *[_vp(d[k]) for d in (a, b) for k in keys]), "orbm_is_in_frustum_rig")
+        return a, b
+
 
 class LocalMap:
     """Device-resident local map points (positions, normals, distances, descriptors)."""
@@ -481,6 +495,18 @@ class ORBmatcher:
         capi.check(self.lib.orbm_search_by_projection_mps(F.h, C.byref(mv), C.c_float(th), int(bFarPoints),
                                                           C.c_float(thFarPoints), C.c_float(self.mfNNratio), _vp(amp),
                                                           _vp(aob), C.byref(n)), "orbm_search_by_projection_mps")
+        return amp, aob, n.value
+
+    def SearchByProjectionRig(self, FL, FR, mv, mv_r, left_to_right, right_to_left, th=1.0, bFarPoints=False, thFarPoints=50.0,
+                              assigned_mp=None, assigned_obs=None):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, ...) on a two-camera frame (S/ORBmatcher.cc:44-214 with :145-211)."""
+        amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+        aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+        l2r = np.ascontiguousarray(left_to_right, np.int32); r2l = np.ascontiguousarray(right_to_left, np.int32)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_projection_mps_rig(FL.h, FR.h, C.byref(mv), C.byref(mv_r), _vp(l2r), _vp(r2l), C.c_float(th),
+                                                              int(bFarPoints), C.c_float(thFarPoints), C.c_float(self.mfNNratio), _vp(amp),
+                                                              _vp(aob), C.byref(n)), "orbm_search_by_projection_mps_rig")
         return amp, aob, n.value
 
     def SearchLocalPoints(self, F, local_map, Tcw, th=1.0, bFarPoints=False, thFarPoints=50.0, assigned_mp=None,

@@ -212,6 +212,71 @@ __global__ __launch_bounds__(256) void frustum_kernel(FrameParams fp, PoseF P, W
   t.level[i] = f.level; t.view_cos[i] = f.view_cos;
 }
 
+// ---- two-camera rig (Frame::Nleft != -1): Frame::isInFrustumChecks for either camera (S/Frame.cc:1154-1231)
+struct RigCamF { int model; float fx, fy, cx, cy, k[4]; };
+struct RigSideF { float R[9], t[3], twc[3]; RigCamF cam; };   // mR, mt, twc of :1158-1170 and the camera the side projects through
+
+// GeometricCamera::project(cv::Mat) -> project(cv::Point3f): Pinhole.cpp:41-47, KannalaBrandt8.cpp:28-44 (float32 throughout; the
+// float32 atan2 / cos / sin are taken as the rounded float64 ones)
+__device__ __forceinline__ void rig_project(const RigCamF& c, const float* p, float* uv) {
+  if (c.model == ORBG_CAM_KANNALA_BRANDT8) {
+    const float x2_plus_y2 = p[0] * p[0] + p[1] * p[1];
+    const float theta = (float)atan2((double)sqrtf(x2_plus_y2), (double)p[2]);
+    const float psi = (float)atan2((double)p[1], (double)p[0]);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const float r = theta + c.k[0] * theta3 + c.k[1] * theta5 + c.k[2] * theta7 + c.k[3] * theta9;
+    uv[0] = c.fx * r * (float)cos((double)psi) + c.cx;
+    uv[1] = c.fy * r * (float)sin((double)psi) + c.cy;
+  } else {
+    uv[0] = c.fx * p[0] / p[2] + c.cx;
+    uv[1] = c.fy * p[1] / p[2] + c.cy;
+  }
+}
+
+__device__ __forceinline__ TrackFields rig_frustum_check(const FrameParams& fp, const RigSideF& S, const float* X, const float* Pn,
+                                                         float min_raw, float max_raw, float limit) {
+  TrackFields f;
+  f.in_view = 0; f.px = 0.f; f.py = 0.f; f.pxr = 0.f; f.depth = 0.f; f.view_cos = 0.f; f.level = -1;
+  float Pc[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float t0 = S.R[3 * i] * X[0] + S.R[3 * i + 1] * X[1] + S.R[3 * i + 2] * X[2];
+    Pc[i] = t0 + S.t[i];
+  }
+  const float Pc_dist = norm3d(Pc);
+  if (Pc[2] < 0.0f) return f;
+  float uv[2];
+  rig_project(S.cam, Pc, uv);
+  if (uv[0] < fp.min_x || uv[0] > fp.max_x) return f;
+  if (uv[1] < fp.min_y || uv[1] > fp.max_y) return f;
+  const float maxDistance = 1.2f * max_raw, minDistance = 0.8f * min_raw;
+  const float PO[3] = {X[0] - S.twc[0], X[1] - S.twc[1], X[2] - S.twc[2]};
+  const float dist = norm3d(PO);
+  if (dist < minDistance || dist > maxDistance) return f;
+  const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+  const float viewCos = (float)(dot / (double)dist);
+  if (viewCos < limit) return f;
+  const float ratio = max_raw / dist;
+  const float lg = (float)log((double)ratio);
+  int nScale = (int)ceilf(lg / fp.log_sf);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= fp.n_levels) nScale = fp.n_levels - 1;
+  f.in_view = 1; f.px = uv[0]; f.py = uv[1]; f.depth = Pc_dist; f.level = nScale; f.view_cos = viewCos;
+  return f;
+}
+
+__global__ __launch_bounds__(256) void frustum_rig_kernel(FrameParams fp, RigSideF L, RigSideF R, WorldPtsDev w, float limit, TrackDev tl, TrackDev tr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w.m) return;
+  const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
+  const float N[3] = {w.normal[3 * i], w.normal[3 * i + 1], w.normal[3 * i + 2]};
+  const float mn = w.min_dist[i], mx = w.max_dist[i];
+  const TrackFields a = rig_frustum_check(fp, L, X, N, mn, mx, limit);
+  const TrackFields b = rig_frustum_check(fp, R, X, N, mn, mx, limit);
+  tl.in_view[i] = (uint8_t)a.in_view; tl.px[i] = a.px; tl.py[i] = a.py; tl.depth[i] = a.depth; tl.level[i] = a.level; tl.view_cos[i] = a.view_cos;
+  tr.in_view[i] = (uint8_t)b.in_view; tr.px[i] = b.px; tr.py[i] = b.py; tr.depth[i] = b.depth; tr.level[i] = b.level; tr.view_cos[i] = b.view_cos;
+}
+
 // ------------------------------------------------------------------------------------------------
 // window search: one wavefront per query
 
@@ -1670,6 +1735,178 @@ extern "C" int orbm_search_local_points_vis(orbm_frame* f, orbm_map* mp, const f
     for (int i = 0; i < m; i++) in_frustum[i] = (R[i].count & kQVisible) ? 1 : 0;
   }
   return commit_mps(f, m, mp->n_obs.data(), nnratio, assigned_mp, assigned_obs, nmatches);
+}
+
+// ---- two-camera rig frames (Frame::Nleft != -1)
+
+static RigCamF rig_cam_of(const orbg_camera& c) {
+  RigCamF r;
+  r.model = c.model; r.fx = c.fx; r.fy = c.fy; r.cx = c.cx; r.cy = c.cy;
+  for (int i = 0; i < 4; i++) r.k[i] = c.k[i];
+  return r;
+}
+// S/Frame.cc:1158-1170: the cv::Mat products of the right camera (float32 small-matrix rules, as make_pose)
+static RigSideF rig_side_of(const PoseF& P, const orbg_camera_rig* rig, const float* Tlr, bool right) {
+  RigSideF s;
+  if (!right) {
+    memcpy(s.R, P.R, sizeof(s.R)); memcpy(s.t, P.t, sizeof(s.t)); memcpy(s.twc, P.Ow, sizeof(s.twc));
+    s.cam = rig_cam_of(rig->left);
+    return s;
+  }
+  const float* Trl = rig->Trl;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) s.R[3 * i + j] = Trl[4 * i] * P.R[j] + Trl[4 * i + 1] * P.R[3 + j] + Trl[4 * i + 2] * P.R[6 + j];
+    const float t0 = Trl[4 * i] * P.t[0] + Trl[4 * i + 1] * P.t[1] + Trl[4 * i + 2] * P.t[2];
+    s.t[i] = t0 + Trl[4 * i + 3];
+    const float w0 = P.R[i] * Tlr[3] + P.R[3 + i] * Tlr[7] + P.R[6 + i] * Tlr[11];
+    s.twc[i] = w0 + P.Ow[i];
+  }
+  s.cam = rig_cam_of(rig->right);
+  return s;
+}
+
+extern "C" int orbm_is_in_frustum_rig(orbm_frame* f, const float* Tcw, const orbg_camera_rig* rig, const float* Tlr, const orbm_worldpoints_view* pts,
+                                      float limit, uint8_t* in_view, float* proj_x, float* proj_y, float* track_depth, int32_t* scale_level,
+                                      float* view_cos, uint8_t* in_view_r, float* proj_x_r, float* proj_y_r, float* track_depth_r,
+                                      int32_t* scale_level_r, float* view_cos_r) {
+  if (!f || !Tcw || !rig || !Tlr || !pts || pts->m < 0 || !rig->has_right) return ORBG_BAD_ARG;
+  for (const orbg_camera* c : {&rig->left, &rig->right})
+    if (c->model != ORBG_CAM_PINHOLE && c->model != ORBG_CAM_KANNALA_BRANDT8) return ORBG_BAD_ARG;
+  if (pts->m > 0 && (!pts->pos || !pts->normal || !pts->min_dist || !pts->max_dist || !in_view || !proj_x || !proj_y || !track_depth ||
+                     !scale_level || !view_cos || !in_view_r || !proj_x_r || !proj_y_r || !track_depth_r || !scale_level_r || !view_cos_r))
+    return ORBG_BAD_ARG;
+  int rc = select_device(f->device);
+  if (rc) return rc;
+  if (pts->m == 0) return ORBG_OK;
+  const size_t n = (size_t)pts->m;
+  if ((rc = stage_begin(f, n * (32 + 2 * 21) + 16 * 24))) return rc;
+  WorldPtsDev w;
+  w.m = pts->m;
+  w.pos = stage_add(f, pts->pos, 3 * n); w.normal = stage_add(f, pts->normal, 3 * n);
+  w.min_dist = stage_add(f, pts->min_dist, n); w.max_dist = stage_add(f, pts->max_dist, n);
+  w.desc = nullptr; w.bad = nullptr; w.skip = nullptr;
+  auto out_region = [&](size_t bytes) { f->stage_off = (f->stage_off + 15) & ~(size_t)15; const size_t o = f->stage_off; f->stage_off += bytes; return o; };
+  size_t off[2][6];
+  TrackDev t[2];
+  uint8_t* D = f->stage.d;
+  for (int sd = 0; sd < 2; sd++) {
+    off[sd][0] = out_region(n);
+    for (int k = 1; k < 6; k++) off[sd][k] = out_region(4 * n);
+    t[sd].in_view = D + off[sd][0]; t[sd].px = reinterpret_cast<float*>(D + off[sd][1]); t[sd].py = reinterpret_cast<float*>(D + off[sd][2]);
+    t[sd].depth = reinterpret_cast<float*>(D + off[sd][3]); t[sd].level = reinterpret_cast<int*>(D + off[sd][4]);
+    t[sd].view_cos = reinterpret_cast<float*>(D + off[sd][5]); t[sd].pxr = nullptr;
+  }
+  PoseF P;
+  make_pose(Tcw, &P);
+  hipLaunchKernelGGL(frustum_rig_kernel, dim3((pts->m + 255) / 256), dim3(256), 0, f->stream, f->fp, rig_side_of(P, rig, Tlr, false),
+                     rig_side_of(P, rig, Tlr, true), w, limit, t[0], t[1]);
+  ORBG_HIP(hipGetLastError());
+  if ((rc = f->sig.sync(f->stream))) return rc;
+  const uint8_t* Hh = f->stage.h;
+  void* outs[2][6] = {{in_view, proj_x, proj_y, track_depth, scale_level, view_cos},
+                      {in_view_r, proj_x_r, proj_y_r, track_depth_r, scale_level_r, view_cos_r}};
+  for (int sd = 0; sd < 2; sd++)
+    for (int k = 0; k < 6; k++) memcpy(outs[sd][k], Hh + off[sd][k], k == 0 ? n : 4 * n);
+  return ORBG_OK;
+}
+
+// One camera's window searches of the rig form of SearchByProjection(Frame, MapPoints): the kernel of the single-camera form on that
+// camera's frame; `amp` / `aob`: the occupancy the kernel filters by (that camera's part of mvpMapPoints), or NULL for none.
+static int search_mps_rig_side(orbm_frame* f, const orbm_mappoints_view* pt, const uint8_t* in_view, const float* px, const float* py,
+                               const int32_t* level, const float* view_cos, float th, int far_points, float th_far_points, const int32_t* amp,
+                               const int32_t* aob) {
+  const int m = pt->m, n = f->fp.n;
+  int rc;
+  if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 6 * 4)))) return rc;
+  hipStream_t st = f->stream;
+  std::vector<int32_t> none;
+  if (!amp) { none.assign((size_t)std::max(n, 1), -1); amp = none.data(); aob = nullptr; }
+  stage_occupancy(f, amp, aob, n);
+  MpsDev mp;
+  mp.m = m;
+  mp.in_view = stage_add(f, in_view, m); mp.bad = stage_add(f, pt->bad, m);
+  mp.desc = stage_add(f, pt->desc, (size_t)m * 32);
+  mp.px = stage_add(f, px, m); mp.py = stage_add(f, py, m); mp.pxr = mp.px;   // (not read: the frame has no uRight)
+  mp.depth = stage_add(f, pt->track_depth, m); mp.view_cos = stage_add(f, view_cos, m);
+  mp.level = stage_add(f, level, m);
+  if ((rc = stage_commit(f))) return rc;
+  FrameDev F = frame_dev(f);
+  F.uright = nullptr;                                     // S/ORBmatcher.cc:93: the mvuRight test is for Nleft == -1 only
+  return run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
+    hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, mp, th, far_points, th_far_points, cnt, cnt_next,
+                       f->list.d, list_cap, f->results.d);
+  });
+}
+
+extern "C" int orbm_search_by_projection_mps_rig(orbm_frame* L, orbm_frame* R, const orbm_mappoints_view* mps, const orbm_mappoints_view* mps_r,
+                                                 const int32_t* l2r, const int32_t* r2l, float th, int far_points, float th_far_points,
+                                                 float nnratio, int32_t* amp, int32_t* aob, int* nmatches_out) {
+  if (!L || !R || L == R || !mps || !mps_r || !amp || !aob || mps->m < 0 || mps_r->m != mps->m || L->device != R->device) return ORBG_BAD_ARG;
+  const int m = mps->m, nl = L->fp.n, nr = R->fp.n;
+  if ((nl > 0 && !l2r) || (nr > 0 && !r2l)) return ORBG_BAD_ARG;
+  for (int i = 0; i < nl; i++) if (l2r[i] < -1 || l2r[i] >= nr) return ORBG_BAD_ARG;
+  for (int i = 0; i < nr; i++) if (r2l[i] < -1 || r2l[i] >= nl) return ORBG_BAD_ARG;
+  int rc = select_device(L->device);
+  if (rc) return rc;
+  if (nmatches_out) *nmatches_out = 0;
+  if (m == 0) return ORBG_OK;
+  // the right camera's block is entered only with a predicted level (:146-147)
+  std::vector<uint8_t> in_view_r((size_t)m);
+  for (int i = 0; i < m; i++) in_view_r[i] = mps_r->track_in_view[i] && mps_r->scale_level[i] != -1;
+  const std::vector<int32_t> amp0(amp, amp + nl + nr), aob0(aob, aob + nl + nr);
+  cache_keypoint_fields(L); cache_keypoint_fields(R);
+  // Pass 0: the kernels leave out the features that hold a point with observations at entry, the commit those taken since.  A
+  // stereo partner is written whatever it held (:133,200): should that replace a point with observations by one without, the
+  // feature has become free and the lists lack it -- pass 1 repeats the call on lists nothing was left out of.
+  for (int pass = 0; pass < 2; pass++) {
+    const bool filtered = pass == 0;
+    std::copy(amp0.begin(), amp0.end(), amp); std::copy(aob0.begin(), aob0.end(), aob);
+    if ((rc = search_mps_rig_side(L, mps, mps->track_in_view, mps->proj_x, mps->proj_y, mps->scale_level, mps->view_cos, th, far_points,
+                                  th_far_points, filtered ? amp : nullptr, filtered ? aob : nullptr)))
+      return rc;
+    if ((rc = search_mps_rig_side(R, mps, in_view_r.data(), mps_r->proj_x, mps_r->proj_y, mps_r->scale_level, mps_r->view_cos, 1.0f, far_points,
+                                  th_far_points, filtered ? amp + nl : nullptr, filtered ? aob + nl : nullptr)))
+      return rc;
+    const QResult* RL = L->results.h;
+    const QResult* RR = R->results.h;
+    bool freed = false;
+    int nmatches = 0;
+    auto assign = [&](int g, int i) {
+      if (filtered && amp0[g] >= 0 && aob0[g] > 0 && mps->n_obs[i] <= 0) freed = true;
+      amp[g] = i; aob[g] = mps->n_obs[i];
+    };
+    for (int i = 0; i < m && !freed; i++) {
+      if (mps->track_in_view[i] && RL[i].n_top) {                                            // :62-143
+        Pick pk;
+        if ((rc = pick_unclaimed(L, RL[i], 2, [&](int idx) { return amp[idx] >= 0 && aob[idx] > 0; }, &pk))) return rc;
+        if (pk.idx1 >= 0 && pk.dist1 <= TH_HIGH) {
+          const int bestLevel = L->hk_oct[pk.idx1], bestLevel2 = pk.idx2 >= 0 ? L->hk_oct[pk.idx2] : -1;
+          if (bestLevel == bestLevel2 && pk.dist1 > nnratio * pk.dist2) continue;            // :126-127 leaves the point
+          if (bestLevel != bestLevel2 || pk.dist1 <= nnratio * pk.dist2) {
+            assign(pk.idx1, i);
+            if (l2r[pk.idx1] != -1) { assign(l2r[pk.idx1] + nl, i); nmatches++; }
+            nmatches++;
+          }
+        }
+      }
+      if (in_view_r[i] && RR[i].n_top) {                                                      // :145-211
+        Pick pk;
+        if ((rc = pick_unclaimed(R, RR[i], 2, [&](int idx) { return amp[idx + nl] >= 0 && aob[idx + nl] > 0; }, &pk))) return rc;
+        if (pk.idx1 >= 0 && pk.dist1 <= TH_HIGH) {
+          const int bestLevel = R->hk_oct[pk.idx1], bestLevel2 = pk.idx2 >= 0 ? R->hk_oct[pk.idx2] : -1;
+          if (bestLevel == bestLevel2 && pk.dist1 > nnratio * pk.dist2) continue;
+          if (r2l[pk.idx1] != -1) { assign(r2l[pk.idx1], i); nmatches++; }
+          assign(pk.idx1 + nl, i);
+          nmatches++;
+        }
+      }
+    }
+    if (!freed) {
+      if (nmatches_out) *nmatches_out = nmatches;
+      return ORBG_OK;
+    }
+  }
+  return ORBG_INTERNAL;
 }
 
 // Common part of the two entry points below.  `stage_view`: the view is packed into the frame's pinned staging block and read there

@@ -402,6 +402,84 @@ def make_pose_opt_rig_problem(n_left=300, n_right=200, seed=0xF15F, size=512, ou
                 Tcw=T0.astype(np.float32), T_true=T_true, bad=bad)
 
 
+def make_rig_track_scene(n_points=1500, n_distract=300, seed=0xF1E0, size=512, left=KB8_LEFT, right=KB8_RIGHT, stereo_frac=0.4,
+                         occupied_frac=0.08, zero_obs_frac=0.05):
+    """A two-camera Frame (Nleft != -1) and a local map for Frame::isInFrustum / SearchByProjection(Frame, MapPoints) in their rig form
+    (S/Frame.cc:545-554,1154-1231; S/ORBmatcher.cc:44-214): points seen by one or both cameras, features at their (noisy) projections
+    with descriptors a few bits away, near-twins for the ratio test, distractors, stereo partners (mvLeftToRightMatch /
+    mvRightToLeftMatch), features that already hold a point (with and without observations), bad and zero-observation points."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    Trl = rig_Trl()
+    Tlr = np.linalg.inv(Trl)
+    Tcw = np.eye(4)
+    Tcw[:3, :3] = _rot(0.04, -0.06, 0.03)
+    Tcw[:3, 3] = [0.2, -0.1, 0.15]
+    Rwc, Ow = Tcw[:3, :3].T, -Tcw[:3, :3].T @ Tcw[:3, 3]
+    sf = np.float32(1.2)
+    pos = np.zeros((n_points, 3)); normal = np.zeros((n_points, 3)); max_d = np.zeros(n_points); lvl = rng.randint(0, 8, n_points)
+    for i in range(n_points):
+        cam = left if rng.rand() < 0.5 else right
+        Pc = _kb8_ray(cam, rng.uniform(-40, size + 40), rng.uniform(-40, size + 40), rng.uniform(1.5, 9.0))
+        Xl = Pc if cam is left else Tlr[:3, :3] @ Pc + Tlr[:3, 3]
+        pos[i] = Rwc @ Xl + Ow
+        d = pos[i] - Ow
+        dist = np.linalg.norm(d)
+        nrm = d / dist + rng.randn(3) * (0.9 if rng.rand() < 0.08 else 0.15)          # some seen at too steep an angle
+        normal[i] = nrm / np.linalg.norm(nrm)
+        max_d[i] = dist * 1.2 ** (lvl[i] - rng.uniform(0.25, 0.75)) * (3.0 if rng.rand() < 0.03 else 1.0)
+    min_d = max_d / 1.2 ** 7 * np.where(rng.rand(n_points) < 0.03, 40.0, 1.0)           # some out of their distance range
+    desc = rng.randint(0, 256, (n_points, 32)).astype(np.uint8)
+    n_obs = np.where(rng.rand(n_points) < zero_obs_frac, 0, rng.randint(1, 9, n_points)).astype(np.int32)
+    bad = (rng.rand(n_points) < 0.04).astype(np.uint8)
+
+    def noisy(d, bits):
+        d = d.copy()
+        for b in rng.choice(256, bits, replace=False):
+            d[b >> 3] ^= 1 << (b & 7)
+        return d
+
+    feats = {"L": [], "R": []}                                   # (x, y, octave, desc, point or -1)
+    for i in range(n_points):
+        Xc = Tcw[:3, :3] @ pos[i] + Tcw[:3, 3]
+        for side, cam, X in (("L", left, Xc), ("R", right, Trl[:3, :3] @ Xc + Trl[:3, 3])):
+            if X[2] <= 0.05 or rng.rand() < 0.25:
+                continue
+            uv = kb8_project(cam, X) + rng.randn(2) * (1.2 if rng.rand() < 0.85 else 9.0)         # some only a wider window finds
+            if not (2 < uv[0] < size - 2 and 2 < uv[1] < size - 2):
+                continue
+            o = int(np.clip(lvl[i] - (1 if rng.rand() < 0.3 else 0), 0, 7))
+            feats[side].append((uv[0], uv[1], o, noisy(desc[i], rng.randint(0, 45)), i))
+            if rng.rand() < 0.15:                                                         # a near-twin: the ratio test's business
+                feats[side].append((uv[0] + rng.randn(), uv[1] + rng.randn(), o if rng.rand() < 0.6 else max(o - 1, 0),
+                                    noisy(desc[i], rng.randint(5, 50)), -1))
+    for side in "LR":
+        for _ in range(n_distract):
+            feats[side].append((rng.uniform(2, size - 2), rng.uniform(2, size - 2), rng.randint(0, 8), rng.randint(0, 256, 32).astype(np.uint8), -1))
+        order = rng.permutation(len(feats[side]))
+        feats[side] = [feats[side][k] for k in order]
+
+    def arrays(fl):
+        k = np.zeros(len(fl), capi.KEYPOINT_DTYPE)
+        k["x"] = [f[0] for f in fl]; k["y"] = [f[1] for f in fl]; k["octave"] = [f[2] for f in fl]
+        k["size"] = 31.0; k["angle"] = rng.uniform(0, 360, len(fl)).astype(np.float32)
+        return k, np.stack([f[3] for f in fl]).astype(np.uint8), np.array([f[4] for f in fl])
+
+    kl, dl, pl = arrays(feats["L"]); kr, dr, pr = arrays(feats["R"])
+    l2r = np.full(len(kl), -1, np.int32); r2l = np.full(len(kr), -1, np.int32)
+    where_r = {p: j for j, p in enumerate(pr) if p >= 0}
+    for j, p in enumerate(pl):
+        if p >= 0 and p in where_r and rng.rand() < stereo_frac:
+            l2r[j] = where_r[p]; r2l[where_r[p]] = j
+    n = len(kl) + len(kr)
+    amp0 = np.full(n, -1, np.int32); aob0 = np.zeros(n, np.int32)
+    occ = rng.rand(n) < occupied_frac
+    amp0[occ] = rng.randint(0, n_points, occ.sum()); aob0[occ] = rng.randint(0, 4, occ.sum())
+    return dict(Tcw=Tcw.astype(np.float32), Trl=Trl.astype(np.float32), Tlr=Tlr.astype(np.float32)[:3], left=left, right=right, size=size,
+                pos=pos.astype(np.float32), normal=normal.astype(np.float32), min_dist=min_d.astype(np.float32), max_dist=max_d.astype(np.float32),
+                desc=desc, n_obs=n_obs, bad=bad, kps_left=kl, desc_left=dl, kps_right=kr, desc_right=dr, left_to_right=l2r, right_to_left=r2l,
+                assigned_mp=amp0, assigned_obs=aob0)
+
+
 # ---------------------------------------------------------------- synthetic vocabulary (ORBvoc.txt is not in the reference tree)
 def make_vocabulary(k=10, L=3, seed=0xB0C, stop_frac=0.03, descriptors=None):
     """A k-ary tree of depth L in DBoW2's node layout (node ids in creation order, children after parents): node descriptors are

@@ -326,6 +326,34 @@ def search_by_projection_mps(fv, mv, th, far, th_far, nnratio, assigned_mp, assi
     return amp, aob, n.value
 
 
+RIG_TRACK_KEYS = ("track_in_view", "proj_x", "proj_y", "track_depth", "scale_level", "view_cos")
+
+
+def is_in_frustum_rig(fv, Tcw, rig, Tlr, wv, limit=0.5):
+    """Both cameras' track fields of a rig frame: (left dict, right dict), keys RIG_TRACK_KEYS."""
+    m = wv.m
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    tlr = np.ascontiguousarray(Tlr, np.float32).reshape(12)
+    mk = lambda: dict(track_in_view=np.zeros(m, np.uint8), proj_x=np.zeros(m, np.float32), proj_y=np.zeros(m, np.float32),
+                      track_depth=np.zeros(m, np.float32), scale_level=np.zeros(m, np.int32), view_cos=np.zeros(m, np.float32))
+    a, b = mk(), mk()
+    _chk(lib().oracle_is_in_frustum_rig(C.byref(fv), C.c_void_p(T.ctypes.data), C.byref(rig), C.c_void_p(tlr.ctypes.data), C.byref(wv), C.c_float(limit),
+                                        *[C.c_void_p(d[k].ctypes.data) for d in (a, b) for k in RIG_TRACK_KEYS]))
+    return a, b
+
+
+def search_by_projection_mps_rig(fv_left, fv_right, mv, mv_r, left_to_right, right_to_left, th, far, th_far, nnratio, assigned_mp, assigned_obs):
+    amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+    aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
+    l2r = np.ascontiguousarray(left_to_right, np.int32)
+    r2l = np.ascontiguousarray(right_to_left, np.int32)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_projection_mps_rig(C.byref(fv_left), C.byref(fv_right), C.byref(mv), C.byref(mv_r), C.c_void_p(l2r.ctypes.data),
+                                                   C.c_void_p(r2l.ctypes.data), C.c_float(th), int(far), C.c_float(th_far), C.c_float(nnratio),
+                                                   C.c_void_p(amp.ctypes.data), C.c_void_p(aob.ctypes.data), C.byref(n)))
+    return amp, aob, n.value
+
+
 def search_local_points(fv, wv, Tcw, th, far, th_far, nnratio, assigned_mp, assigned_obs):
     amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
     aob = np.ascontiguousarray(assigned_obs, np.int32).copy()

@@ -357,6 +357,165 @@ extern "C" int oracle_search_by_projection_mps(const orbm_frame_view* view, cons
   return ORBG_OK;
 }
 
+// ---- two-camera rig (Frame::Nleft != -1): isInFrustum / SearchByProjection(Frame, MapPoints)
+//
+// GeometricCamera::project(cv::Mat) as Frame::isInFrustumChecks calls it: Pinhole (S/CameraModels/Pinhole.cpp:41-47) and
+// KannalaBrandt8 (S/CameraModels/KannalaBrandt8.cpp:28-49), both on cv::Point3f, float32 throughout (cos / sin of a float: the float
+// overloads -- <math.h> comes in through OpenCV's C headers).
+inline void rig_cam_project(const orbg_camera& c, const float* p, float* uv) {
+  if (c.model == ORBG_CAM_KANNALA_BRANDT8) {
+    const float x2_plus_y2 = p[0] * p[0] + p[1] * p[1];
+    const float theta = atan2f(sqrtf(x2_plus_y2), p[2]);
+    const float psi = atan2f(p[1], p[0]);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const float r = theta + c.k[0] * theta3 + c.k[1] * theta5 + c.k[2] * theta7 + c.k[3] * theta9;
+    uv[0] = c.fx * r * cosf(psi) + c.cx;
+    uv[1] = c.fy * r * sinf(psi) + c.cy;
+  } else {
+    uv[0] = c.fx * p[0] / p[2] + c.cx;
+    uv[1] = c.fy * p[1] / p[2] + c.cy;
+  }
+}
+
+// Frame::isInFrustumChecks -- S/Frame.cc:1154-1231.  mR / mt / twc of the right camera are cv::Mat products (float32 small-matrix path):
+//   mR = Rrl * mRcw;  mt = Rrl * mtcw + trl;  twc = mRwc * tlr + mOw   (:1160-1164)
+struct RigSide { float R[9], t[3], twc[3]; };
+RigSide rig_side(const Pose& pose, const float* Trl, const float* Tlr, bool right) {
+  RigSide s;
+  if (!right) {
+    std::memcpy(s.R, pose.R, sizeof(s.R)); std::memcpy(s.t, pose.t, sizeof(s.t)); std::memcpy(s.twc, pose.Ow, sizeof(s.twc));
+    return s;
+  }
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) s.R[3 * i + j] = Trl[4 * i] * pose.R[j] + Trl[4 * i + 1] * pose.R[3 + j] + Trl[4 * i + 2] * pose.R[6 + j];
+    const float t0 = Trl[4 * i] * pose.t[0] + Trl[4 * i + 1] * pose.t[1] + Trl[4 * i + 2] * pose.t[2];
+    s.t[i] = (float)(t0 + Trl[4 * i + 3]);
+    const float w0 = pose.R[i] * Tlr[3] + pose.R[3 + i] * Tlr[7] + pose.R[6 + i] * Tlr[11];   // mRwc = mRcw.t(), a stored matrix
+    s.twc[i] = (float)(w0 + pose.Ow[i]);
+  }
+  return s;
+}
+TrackFields rig_frustum_checks(const orbm_frame_view* v, const ScaleTables& st, const RigSide& side, const orbg_camera& cam, const float* P,
+                               const float* Pn, float min_dist_raw, float max_dist_raw, float limit) {
+  TrackFields f{false, 0.f, 0.f, 0.f, 0.f, 0.f, -1};
+  float Pc[3];
+  for (int i = 0; i < 3; i++) {
+    const float t0 = side.R[3 * i] * P[0] + side.R[3 * i + 1] * P[1] + side.R[3 * i + 2] * P[2];
+    Pc[i] = (float)(t0 + side.t[i]);
+  }
+  const float Pc_dist = norm3(Pc);
+  if (Pc[2] < 0.0f) return f;
+  float uv[2];
+  rig_cam_project(cam, Pc, uv);
+  if (uv[0] < v->min_x || uv[0] > v->max_x) return f;
+  if (uv[1] < v->min_y || uv[1] > v->max_y) return f;
+  const float maxDistance = 1.2f * max_dist_raw, minDistance = 0.8f * min_dist_raw;
+  const float PO[3] = {P[0] - side.twc[0], P[1] - side.twc[1], P[2] - side.twc[2]};
+  const float dist = norm3(PO);
+  if (dist < minDistance || dist > maxDistance) return f;
+  const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+  const float viewCos = (float)(dot / dist);
+  if (viewCos < limit) return f;
+  const float ratio = max_dist_raw / dist;
+  int nScale = (int)std::ceil(std::log(ratio) / st.log_sf);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= v->n_levels) nScale = v->n_levels - 1;
+  f.in_view = true; f.px = uv[0]; f.py = uv[1]; f.level = nScale; f.view_cos = viewCos; f.depth = Pc_dist;
+  return f;
+}
+
+// Frame::isInFrustum, Nleft != -1 -- S/Frame.cc:545-554: both cameras' checks; a point that fails a camera's checks has
+// mbTrackInView(R) = false and mnTrackScaleLevel(R) = -1 (the other fields keep stale values in the reference: 0 here).
+extern "C" int oracle_is_in_frustum_rig(const orbm_frame_view* view, const float* Tcw, const orbg_camera_rig* rig, const float* Tlr,
+                                        const orbm_worldpoints_view* pts, float limit, uint8_t* in_view, float* px, float* py, float* depth,
+                                        int32_t* level, float* view_cos, uint8_t* in_view_r, float* px_r, float* py_r, float* depth_r,
+                                        int32_t* level_r, float* view_cos_r) {
+  ScaleTables st(view);
+  Pose pose(Tcw);
+  const RigSide L = rig_side(pose, rig->Trl, Tlr, false), R = rig_side(pose, rig->Trl, Tlr, true);
+  for (int i = 0; i < pts->m; i++) {
+    const TrackFields a = rig_frustum_checks(view, st, L, rig->left, pts->pos + 3 * i, pts->normal + 3 * i, pts->min_dist[i], pts->max_dist[i], limit);
+    const TrackFields b = rig_frustum_checks(view, st, R, rig->right, pts->pos + 3 * i, pts->normal + 3 * i, pts->min_dist[i], pts->max_dist[i], limit);
+    in_view[i] = a.in_view; px[i] = a.px; py[i] = a.py; depth[i] = a.depth; level[i] = a.level; view_cos[i] = a.view_cos;
+    in_view_r[i] = b.in_view; px_r[i] = b.px; py_r[i] = b.py; depth_r[i] = b.depth; level_r[i] = b.level; view_cos_r[i] = b.view_cos;
+  }
+  return ORBG_OK;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) -- S/ORBmatcher.cc:44-214 with
+// Nleft != -1: `left` / `right` are the two cameras' features (mvKeys with mGrid, mvKeysRight with mGridRight; a right feature i is
+// entry Nleft + i of mvpMapPoints / mDescriptors), `mps` the left camera's track fields, `mps_r` the right camera's
+// (mbTrackInViewR, mTrackProjXR / YR, mnTrackScaleLevelR, mTrackViewCosR; bad / track_depth / desc / n_obs are read from `mps`).
+extern "C" int oracle_search_by_projection_mps_rig(const orbm_frame_view* left, const orbm_frame_view* right, const orbm_mappoints_view* mps,
+                                                   const orbm_mappoints_view* mps_r, const int32_t* left_to_right, const int32_t* right_to_left,
+                                                   float th, int far_points, float th_far_points, float nnratio, int32_t* assigned_mp,
+                                                   int32_t* assigned_obs, int* nmatches_out) {
+  ScaleTables st(left);
+  const Grid gl = build_grid(left), gr = build_grid(right);
+  const int Nleft = left->n;
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  std::vector<int> vIndices;
+  for (int iMP = 0; iMP < mps->m; iMP++) {
+    if (!mps->track_in_view[iMP] && !mps_r->track_in_view[iMP]) continue;      // :53
+    if (far_points && mps->track_depth[iMP] > th_far_points) continue;         // :56
+    if (mps->bad[iMP]) continue;                                               // :59
+    const uint8_t* dMP = mps->desc + 32 * (size_t)iMP;
+    if (mps->track_in_view[iMP]) {                                             // :62-143
+      const int nPredictedLevel = mps->scale_level[iMP];
+      float r = (mps->view_cos[iMP] > 0.998) ? 2.5f : 4.0f;
+      if (bFactor) r *= th;
+      features_in_area(left, gl, mps->proj_x[iMP], mps->proj_y[iMP], r * st.scale[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+      if (!vIndices.empty()) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+          if (assigned_mp[idx] >= 0 && assigned_obs[idx] > 0) continue;        // :89-91 (no mvuRight test: Nleft != -1, :93)
+          const int dist = oracle_hamming(dMP, left->desc + 32 * (size_t)idx);
+          if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = left->kps[idx].octave; bestIdx = idx; }
+          else if (dist < bestDist2) { bestLevel2 = left->kps[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;   // :126-127: leaves the POINT, the right camera's block too
+          if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+            assigned_mp[bestIdx] = iMP; assigned_obs[bestIdx] = mps->n_obs[iMP];
+            if (left_to_right[bestIdx] != -1) {                                // :132-136
+              assigned_mp[left_to_right[bestIdx] + Nleft] = iMP; assigned_obs[left_to_right[bestIdx] + Nleft] = mps->n_obs[iMP];
+              nmatches++;
+            }
+            nmatches++;
+          }
+        }
+      }
+    }
+    if (mps_r->track_in_view[iMP]) {                                           // :145-211
+      const int nPredictedLevel = mps_r->scale_level[iMP];
+      if (nPredictedLevel != -1) {
+        const float r = (mps_r->view_cos[iMP] > 0.998) ? 2.5f : 4.0f;           // (th is not applied here)
+        features_in_area(right, gr, mps_r->proj_x[iMP], mps_r->proj_y[iMP], r * st.scale[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+          if (assigned_mp[idx + Nleft] >= 0 && assigned_obs[idx + Nleft] > 0) continue;
+          const int dist = oracle_hamming(dMP, right->desc + 32 * (size_t)idx);
+          if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = right->kps[idx].octave; bestIdx = idx; }
+          else if (dist < bestDist2) { bestLevel2 = right->kps[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+          if (right_to_left[bestIdx] != -1) {                                  // :199-203: whatever that left feature held
+            assigned_mp[right_to_left[bestIdx]] = iMP; assigned_obs[right_to_left[bestIdx]] = mps->n_obs[iMP];
+            nmatches++;
+          }
+          assigned_mp[bestIdx + Nleft] = iMP; assigned_obs[bestIdx + Nleft] = mps->n_obs[iMP];
+          nmatches++;
+        }
+      }
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
 // Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153): isInFrustum(.,0.5) then SearchByProjection.
 extern "C" int oracle_search_local_points(const orbm_frame_view* view, const orbm_worldpoints_view* pts, const float* Tcw,
                                           float th, int far_points, float th_far_points, float nnratio,

@@ -93,6 +93,16 @@ int oracle_hamming_best2(const uint8_t* q, int nq, const uint8_t* t, int nt, int
 int oracle_search_by_projection_mps(const orbm_frame_view* view, const orbm_mappoints_view* mps, float th,
                                     int far_points, float th_far_points, float nnratio,
                                     int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+/* Two-camera rig frames (Frame::Nleft != -1): Frame::isInFrustum with isInFrustumChecks for both cameras (S/Frame.cc:545-554,1154-1231;
+ * Tlr = Frame::mTlr, 3 x 4) and SearchByProjection(Frame, MapPoints) with the right camera's block (S/ORBmatcher.cc:44-214) */
+int oracle_is_in_frustum_rig(const orbm_frame_view* view, const float* Tcw, const orbg_camera_rig* rig, const float* Tlr,
+                             const orbm_worldpoints_view* pts, float viewing_cos_limit, uint8_t* in_view, float* px, float* py, float* depth,
+                             int32_t* level, float* view_cos, uint8_t* in_view_r, float* px_r, float* py_r, float* depth_r,
+                             int32_t* level_r, float* view_cos_r);
+int oracle_search_by_projection_mps_rig(const orbm_frame_view* left, const orbm_frame_view* right, const orbm_mappoints_view* mps,
+                                        const orbm_mappoints_view* mps_r, const int32_t* left_to_right, const int32_t* right_to_left,
+                                        float th, int far_points, float th_far_points, float nnratio, int32_t* assigned_mp,
+                                        int32_t* assigned_obs, int* nmatches);
 int oracle_search_local_points(const orbm_frame_view* view, const orbm_worldpoints_view* pts, const float* Tcw,
                                float th, int far_points, float th_far_points, float nnratio,
                                int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);

@@ -79,3 +79,25 @@ def random_database(rng, n_kfs=300, n_words=4000, words_per_kf=(60, 260), n_maps
     bad = (rng.rand(n_kfs) < bad_frac).astype(np.uint8)
     map_bad = np.zeros(n_kfs, np.uint8)
     return dict(inv=inv, bows=bows, covis=covis, map_id=map_id, bad=bad, map_bad=map_bad, n_words=n_words)
+
+
+def rig_track_views(sc):
+    """Views of synth.make_rig_track_scene: (left frame view, right frame view, world points view, camera rig, keep-alive list)."""
+    from multi_orbslam3_amd import views
+    bounds = (0, sc["size"], 0, sc["size"])
+    cam = (sc["left"][1], sc["left"][2], sc["left"][3], sc["left"][4], 0.0, 0.0)
+    fl, k1 = views.frame_view(sc["kps_left"], sc["desc_left"], None, None, bounds, cam)
+    fr, k2 = views.frame_view(sc["kps_right"], sc["desc_right"], None, None, bounds, cam)
+    wv, k3 = views.worldpoints_view(sc["pos"], sc["normal"], sc["min_dist"], sc["max_dist"], sc["desc"], sc["n_obs"], sc["bad"])
+    rig = views.camera_rig(sc["left"], sc["right"], sc["Trl"])
+    return fl, fr, wv, rig, [k1, k2, k3]
+
+
+def rig_mappoint_views(sc, a, b):
+    """orbm_mappoints_view pair (left camera's track fields, right camera's) from the two dicts of is_in_frustum_rig."""
+    from multi_orbslam3_amd import views
+    mv, k4 = views.mappoints_view(a["track_in_view"], sc["bad"], a["proj_x"], a["proj_y"], a["proj_x"], a["track_depth"], a["scale_level"],
+                                  a["view_cos"], sc["desc"], sc["n_obs"])
+    mvr, k5 = views.mappoints_view(b["track_in_view"], sc["bad"], b["proj_x"], b["proj_y"], b["proj_x"], b["track_depth"], b["scale_level"],
+                                   b["view_cos"], sc["desc"], sc["n_obs"])
+    return mv, mvr, [k4, k5]

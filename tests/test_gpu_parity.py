@@ -1922,3 +1922,79 @@ def test_ldlt_kernels_against_a_long_double_host_factorisation():
                               timeout=900)
     r = subprocess.run([exe_wd], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "xcd with a participant missing: ok=-2" in r.stdout and "xcd after the timed-out launch: ok=1 ok" in r.stdout and "FAIL" not in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+
+
+RIG_CAMERAS = {"two fisheyes": (synth.KB8_LEFT, synth.KB8_RIGHT),
+               "two pinholes": ((capi.CAM_PINHOLE, 260.0, 259.0, 255.0, 257.0), (capi.CAM_PINHOLE, 261.0, 260.5, 253.0, 256.0))}
+
+
+@pytest.mark.parametrize("cams", sorted(RIG_CAMERAS))
+def test_is_in_frustum_of_a_two_camera_frame(cams):
+    """Frame::isInFrustum with Nleft != -1 (S/Frame.cc:545-554): isInFrustumChecks through either camera (:1154-1231) -- flags and
+    predicted levels equal the oracle's; projections within 1e-4 px (KannalaBrandt8::project goes through atan2f / cosf / sinf,
+    which the device takes as the rounded float64 functions and the oracle from the host's libm), depths and viewing cosines bit-equal."""
+    left, right = RIG_CAMERAS[cams]
+    sc = synth.make_rig_track_scene(left=left, right=right)
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    F = api.Frame().upload(fl, keep[0])
+    g = F.isInFrustumRig(sc["Tcw"], rig, sc["Tlr"], wv)
+    o = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    for side in (0, 1):
+        assert 700 < int(o[side]["track_in_view"].sum()) < len(sc["pos"]) - 200
+        for k in ob.RIG_TRACK_KEYS:
+            a, b = g[side][k], o[side][k]
+            if k in ("proj_x", "proj_y") and cams == "two fisheyes":
+                assert np.abs(a.astype(np.float64) - b).max() <= 1e-4, (side, k)      # pixels (one ulp of psi moves r cos(psi) by 2e-5)
+            elif a.dtype == np.float32:
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (side, k)
+            else:
+                assert np.array_equal(a, b), (side, k)
+    both = o[0]["track_in_view"] & o[1]["track_in_view"]
+    assert 0 < int(both.sum()) < int((o[0]["track_in_view"] | o[1]["track_in_view"]).sum())     # points only one camera sees
+    assert (o[0]["scale_level"][o[0]["track_in_view"] == 0] == -1).all()
+
+
+@pytest.mark.parametrize("th,far,case", [(1.0, False, "plain"), (3.0, True, "plain"), (1.0, True, "freed"), (15.0, False, "crowded")])
+def test_search_by_projection_map_points_on_a_two_camera_frame(th, far, case):
+    """ORBmatcher::SearchByProjection(Frame, MapPoints) with Nleft != -1 (S/ORBmatcher.cc:44-214): the left camera's block with the
+    stereo partner on the right written along, the right camera's block (:145-211: its own grid, no th, partner on the left written
+    whatever it held), a failed ratio test on the left leaving the point altogether -- match arrays and counts equal the oracle's.
+    "freed": most points have no observations and many features hold a point at entry, so that a partner write frees a feature the
+    kernels had left out (the call repeats on unfiltered lists); "crowded": th = 15 on a frame where a fifth of the features is taken."""
+    kw = dict(plain={}, freed=dict(zero_obs_frac=0.6, occupied_frac=0.35, stereo_frac=0.9, seed=0xF1E1), crowded=dict(occupied_frac=0.2, seed=0xF1E2))[case]
+    sc = synth.make_rig_track_scene(**kw)
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    mv, mvr, keep2 = helpers.rig_mappoint_views(sc, a, b)
+    FL, FR = api.Frame().upload(fl, keep[0]), api.Frame().upload(fr, keep[1])
+    m = api.ORBmatcher(0.8)
+    g = m.SearchByProjectionRig(FL, FR, mv, mvr, sc["left_to_right"], sc["right_to_left"], th, far, 6.0, sc["assigned_mp"], sc["assigned_obs"])
+    o = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], th, far, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"])
+    nl = len(sc["kps_left"])
+    changed = o[0] != sc["assigned_mp"]
+    assert o[2] > 300 and changed[:nl].sum() > 100 and changed[nl:].sum() > 100
+    assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    if case == "freed":                                       # the scene does contain the event the second pass exists for
+        occ0 = (sc["assigned_mp"] >= 0) & (sc["assigned_obs"] > 0)
+        assert int((occ0 & changed & (o[1] == 0)).sum()) > 0
+    # a second call on the result: features taken by the first are not candidates any more
+    g2 = m.SearchByProjectionRig(FL, FR, mv, mvr, sc["left_to_right"], sc["right_to_left"], th, far, 6.0, g[0], g[1])
+    o2 = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], th, far, 6.0, 0.8, o[0], o[1])
+    assert g2[2] == o2[2] and np.array_equal(g2[0], o2[0]) and np.array_equal(g2[1], o2[1])
+
+
+def test_rig_search_refuses_what_it_cannot_be():
+    sc = synth.make_rig_track_scene(n_points=50, n_distract=20)
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    mv, mvr, keep2 = helpers.rig_mappoint_views(sc, a, b)
+    FL, FR = api.Frame().upload(fl, keep[0]), api.Frame().upload(fr, keep[1])
+    m = api.ORBmatcher(0.8)
+    with pytest.raises(capi.OrbGpuError):                     # one frame object for both cameras
+        m.SearchByProjectionRig(FL, FL, mv, mvr, sc["left_to_right"], sc["right_to_left"], 1.0, False, 0.0, sc["assigned_mp"], sc["assigned_obs"])
+    bad = sc["left_to_right"].copy(); bad[0] = len(sc["kps_right"])
+    with pytest.raises(capi.OrbGpuError):                     # a partner index outside the right camera's features
+        m.SearchByProjectionRig(FL, FR, mv, mvr, bad, sc["right_to_left"], 1.0, False, 0.0, sc["assigned_mp"], sc["assigned_obs"])
+    mono = views.camera_rig(sc["left"])
+    with pytest.raises(capi.OrbGpuError):                     # isInFrustum of a rig needs the right camera
+        FL.isInFrustumRig(sc["Tcw"], mono, sc["Tlr"], wv)

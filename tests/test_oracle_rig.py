@@ -202,3 +202,67 @@ def test_first_lm_step_of_a_pinhole_stereo_window_is_the_dense_gauss_newton_step
     poses, points, dx = dense_first_step(pr)
     assert np.abs(poses - o.poses.reshape(-1, 4, 4)[:, :3, :]).max() < 2e-6 and np.abs(points - o.points).max() < 5e-6
     assert np.abs(dx).max() > 1e-3
+
+
+# ---------------------------------------------------------------- the matcher on two-camera frames (S/Frame.cc:545-554,1154-1231; S/ORBmatcher.cc:44-214)
+
+def _rig_scene(**kw):
+    import helpers
+    sc = synth.make_rig_track_scene(**kw)
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    return sc, fl, fr, wv, rig, keep
+
+
+def test_right_cameras_frustum_is_the_left_one_of_a_frame_at_Trl_Tcw():
+    """isInFrustumChecks(bRight): projecting through mpCamera2 after mTrl and measuring distances from the right camera's centre is
+    what a single camera at Trl * Tcw does -- same flags and levels (but for points on a limit), projections within 1e-3 px (the
+    products are rounded at other places)."""
+    sc, fl, fr, wv, rig, keep = _rig_scene(n_points=1200, n_distract=10)
+    a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    T2 = np.eye(4); T2[:3] = sc["Trl"][:3].astype(np.float64)
+    T_right = (T2 @ sc["Tcw"].astype(np.float64)).astype(np.float32)
+    swapped = views.camera_rig(sc["right"], sc["left"], sc["Trl"])
+    c, _ = ob.is_in_frustum_rig(fl, T_right, swapped, sc["Tlr"], wv)
+    same = b["track_in_view"] == c["track_in_view"]
+    assert same.mean() > 0.995 and 500 < int(b["track_in_view"].sum()) < 1100
+    both = (b["track_in_view"] & c["track_in_view"]).astype(bool)
+    assert (b["scale_level"][both] == c["scale_level"][both]).mean() > 0.99
+    for k in ("proj_x", "proj_y"):
+        assert np.abs(b[k][both] - c[k][both]).max() < 1e-3
+    assert np.abs(b["track_depth"][both] - c["track_depth"][both]).max() < 1e-5 and np.abs(b["view_cos"][both] - c["view_cos"][both]).max() < 1e-5
+    # a point that fails a camera's checks: flag 0, level -1 (S/Frame.cc:546-551)
+    assert (a["scale_level"][a["track_in_view"] == 0] == -1).all() and (a["scale_level"][a["track_in_view"] == 1] >= 0).all()
+
+
+def test_rig_search_without_partners_and_without_the_right_camera_is_the_single_camera_search():
+    """With no point in the right camera's view and no stereo partners the rig form of SearchByProjection(Frame, MapPoints) runs the
+    left camera's block only: the single-camera search on the left camera's features (which has no mvuRight here)."""
+    sc, fl, fr, wv, rig, keep = _rig_scene(n_points=900, n_distract=150)
+    import helpers
+    a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    b = {k: v.copy() for k, v in b.items()}; b["track_in_view"][:] = 0
+    mv, mvr, keep2 = helpers.rig_mappoint_views(sc, a, b)
+    nl, nr = len(sc["kps_left"]), len(sc["kps_right"])
+    none_l, none_r = np.full(nl, -1, np.int32), np.full(nr, -1, np.int32)
+    for th in (1.0, 4.0):
+        o = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, none_l, none_r, th, True, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"])
+        s = ob.search_by_projection_mps(fl, mv, th, True, 6.0, 0.8, sc["assigned_mp"][:nl], sc["assigned_obs"][:nl])
+        assert o[2] == s[2] > 200 and np.array_equal(o[0][:nl], s[0]) and np.array_equal(o[1][:nl], s[1])
+        assert np.array_equal(o[0][nl:], sc["assigned_mp"][nl:])
+
+
+def test_rig_search_writes_stereo_partners_and_counts_them():
+    """Every match of the left block whose feature has a partner is also written to Nleft + partner and counted twice (S/ORBmatcher.cc:132-138);
+    a match of the right block overwrites whatever its partner on the left held (:199-203)."""
+    sc, fl, fr, wv, rig, keep = _rig_scene(n_points=900, n_distract=150, stereo_frac=0.9)
+    import helpers
+    a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    mv, mvr, keep2 = helpers.rig_mappoint_views(sc, a, b)
+    nl = len(sc["kps_left"])
+    amp, aob, n = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], 1.0, False, 0.0, 0.8, sc["assigned_mp"], sc["assigned_obs"])
+    changed = np.nonzero(amp != sc["assigned_mp"])[0]
+    assert n >= len(changed) > 400                               # (a feature can be written twice: n counts writes)
+    l2r = sc["left_to_right"]
+    linked = [j for j in changed if j < nl and l2r[j] >= 0]
+    agree = sum(1 for j in linked if amp[nl + l2r[j]] == amp[j])
+    assert len(linked) > 100 and agree > 0.9 * len(linked)       # (the right block may re-assign a partner afterwards)

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from multi_orbslam3_amd import _capi as capi
-from multi_orbslam3_amd import views
+from multi_orbslam3_amd import synth, views
 from oracle import binding as ob
 
 REF = "/root/reference/src/orb_slam3_ros/orb_slam3"
@@ -2409,6 +2409,216 @@ def test_isinfrustum_is_the_references_text():
             theirs = np.array([o[k][i] for k in ("proj_x", "proj_y", "proj_xr", "track_depth", "view_cos")], np.float32)
             assert mine.tobytes() == theirs.tobytes() and q.mnTrackScaleLevel == int(o["scale_level"][i]), (i, mine, theirs, q.mnTrackScaleLevel, o["scale_level"][i])
     assert 150 < n_in < m - 300
+
+
+def _get_features_in_area_source_rig():
+    """Frame::GetFeaturesInArea with BOTH of its ternaries as they stand (mGrid / mGridRight, mvKeysUn / mvKeys / mvKeysRight)."""
+    body = _body(os.path.join(REF, "src", "Frame.cc"), r"vector<size_t>\s+Frame::GetFeaturesInArea\s*\([^)]*\)\s*const\s*\{")
+    body = body.replace("vector<size_t> vIndices;", "vIndices = [];").replace("vIndices.reserve(N);", "")
+    body = re.sub(r"\s+", " ", body)
+    m1 = re.search(r"const vector<size_t> vCell = ([^;]*);", body)
+    body = body.replace(m1.group(0), "vCell = %s;" % ternary(cpp_prepare(m1.group(1))))
+    m2 = re.search(r"const cv::KeyPoint &kpUn = ([^;]*);", body)
+    body = body.replace(m2.group(0), "kpUn = %s;" % ternary(cpp_prepare(m2.group(1))))
+    body = body.replace("vCell.empty()", "len(vCell) == 0").replace("for(size_t j=0, jend=vCell.size(); j<jend; j++)", "for(int j=0; j<len(vCell); j++)")
+    body = body.replace("vIndices.push_back(", "vIndices.append(").replace("fabs(", "abs(").replace("(int)FRAME_GRID", "FRAME_GRID")
+    py = c_to_python(body, typed_ints=True, keep_returns=True)
+    assert "mGridRight[ix][iy]" in py and "mvKeysRight[vCell[j]]" in py and py.count("return vIndices") == 5
+    return "def GetFeaturesInArea(x, y, r, minLevel=-1, maxLevel=-1, bRight=False):\n" + "\n".join("    " + ln for ln in py.splitlines())
+
+
+def _rig_scene_views(sc):
+    bounds = (0, sc["size"], 0, sc["size"])
+    cam = (sc["left"][1], sc["left"][2], sc["left"][3], sc["left"][4], 0.0, 0.0)
+    fl, k1 = views.frame_view(sc["kps_left"], sc["desc_left"], None, None, bounds, cam)
+    fr, k2 = views.frame_view(sc["kps_right"], sc["desc_right"], None, None, bounds, cam)
+    wv, k3 = views.worldpoints_view(sc["pos"], sc["normal"], sc["min_dist"], sc["max_dist"], sc["desc"], sc["n_obs"], sc["bad"])
+    return fl, fr, wv, views.camera_rig(sc["left"], sc["right"], sc["Trl"]), [k1, k2, k3]
+
+
+@pytest.mark.parametrize("th,far,kw", [(1.0, False, {}), (3.0, True, {}), (1.0, True, dict(zero_obs_frac=0.6, occupied_frac=0.35, stereo_frac=0.9, seed=0xF1E1)),
+                                       (15.0, False, dict(occupied_frac=0.2, seed=0xF1E2))])
+def test_searchbyprojection_of_map_points_on_a_two_camera_frame_is_the_references_text(th, far, kw):
+    """The same text as test_searchbyprojection_of_map_points_is_the_references_text -- ORBmatcher::SearchByProjection(Frame&, const
+    vector<MapPoint*>&, ...), S/ORBmatcher.cc:44-214 -- now run with Nleft != -1: the left block writing the stereo partner, the
+    right camera's block (:145-211) on mGridRight / mvKeysRight / descriptor rows Nleft + i, Frame::GetFeaturesInArea with both of its
+    ternaries -- against the oracle's rig form on the same two-camera scene: every entry of mvpMapPoints and the match count."""
+    path = os.path.join(REF, "src", "ORBmatcher.cc")
+    body = _body(path, r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&F,\s*const\s+vector<MapPoint\*>\s*&vpMapPoints[^)]*\)\s*\{")
+    body = re.sub(r"for\(vector<size_t>::const_iterator vit=vIndices\.begin\(\), vend=vIndices\.end\(\); vit!=vend; vit\+\+\)\s*\{\s*const size_t idx = \*vit;",
+                  "foreach(idx, vIndices) {", body)
+    body = body.replace("int nmatches=0, left = 0, right = 0;", "int nmatches=0; int left = 0; int right = 0;")
+    src = c_to_python(cpp_prepare(body), keep_returns=True)
+    rad = c_to_python(cpp_prepare(_body(path, r"float\s+ORBmatcher::RadiusByViewingCos\s*\([^)]*\)\s*\{")), keep_returns=True)
+    prog = ("def RadiusByViewingCos(viewCos):\n" + "\n".join("    " + ln for ln in rad.splitlines()) +
+            "\ndef SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints):\n" + "\n".join("    " + ln for ln in src.splitlines()))
+    sc = synth.make_rig_track_scene(n_points=900, n_distract=200, **kw)
+    fl, fr, wv, rig, keep = _rig_scene_views(sc)
+    a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    mk = lambda d: views.mappoints_view(d["track_in_view"], sc["bad"], d["proj_x"], d["proj_y"], d["proj_x"], d["track_depth"], d["scale_level"], d["view_cos"], sc["desc"], sc["n_obs"])
+    (mv, k4), (mvr, k5) = mk(a), mk(b)
+    amp, aob, nm = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], th, far, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"])
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o): self.pt, self.octave = Pt(x, y), int(o)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[i]
+
+    class MP:
+        pass
+
+    class Frame:
+        pass
+
+    nl, nr = len(sc["kps_left"]), len(sc["kps_right"])
+    scl = np.ones(8, np.float32)
+    for l in range(1, 8):
+        scl[l] = np.float32(scl[l - 1] * np.float32(1.2))
+    env = dict(ENV, F32=F32, F64=F64, abs=abs, fabs=abs, TH_HIGH=100, mfNNratio=F32(0.8), as_int=lambda v: int(v), floor=np.floor, ceil=np.ceil,
+               DescriptorDistance=lambda x, y: int(np.unpackbits(x ^ y).sum()))
+    F = Frame()
+    F.Nleft = nl; F.mvuRight = [F32(-1)] * (nl + nr); F.mvScaleFactors = [F32(v) for v in scl]
+    F.mvKeys = [Kp(k["x"], k["y"], k["octave"]) for k in sc["kps_left"]]; F.mvKeysUn = F.mvKeys
+    F.mvKeysRight = [Kp(k["x"], k["y"], k["octave"]) for k in sc["kps_right"]]
+    F.mDescriptors = Desc(np.concatenate([sc["desc_left"], sc["desc_right"]]))
+    F.mvLeftToRightMatch = [int(v) for v in sc["left_to_right"]]; F.mvRightToLeftMatch = [int(v) for v in sc["right_to_left"]]
+    F.mvpMapPoints = [None] * (nl + nr)
+    for i in np.nonzero(sc["assigned_mp"] >= 0)[0]:
+        o = MP(); o.id = 100000 + int(sc["assigned_mp"][i]); o.nobs = int(sc["assigned_obs"][i]); o.Observations = (lambda o=o: o.nobs)
+        F.mvpMapPoints[i] = o
+    grids = []
+    for fv in (fl, fr):
+        start, items = ob.build_grid(fv)
+        grids.append([[[int(v) for v in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)]
+                      for ix in range(capi.GRID_COLS)])
+    size = F32(sc["size"])
+    genv = dict(env, Nleft=nl, mnMinX=F32(0), mnMinY=F32(0), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
+                mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / size), mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / size),
+                mGrid=grids[0], mGridRight=grids[1], mvKeysUn=F.mvKeysUn, mvKeys=F.mvKeys, mvKeysRight=F.mvKeysRight)
+    exec(_get_features_in_area_source_rig(), genv)
+    F.GetFeaturesInArea = lambda x, y, r, lo=-1, hi=-1, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), lo, hi, bRight)
+    pts = []
+    for i in range(len(sc["pos"])):
+        q = MP()
+        q.id = i; q.bad = bool(sc["bad"][i]); q.isBad = (lambda q=q: q.bad); q.nobs = int(sc["n_obs"][i]); q.Observations = (lambda q=q: q.nobs)
+        q.GetDescriptor = (lambda i=i: sc["desc"][i])
+        q.mbTrackInView = bool(a["track_in_view"][i]); q.mTrackDepth = F32(a["track_depth"][i]); q.mnTrackScaleLevel = int(a["scale_level"][i])
+        q.mTrackViewCos = F32(a["view_cos"][i]); q.mTrackProjX = F32(a["proj_x"][i]); q.mTrackProjY = F32(a["proj_y"][i])
+        q.mbTrackInViewR = bool(b["track_in_view"][i]); q.mnTrackScaleLevelR = int(b["scale_level"][i]); q.mTrackViewCosR = F32(b["view_cos"][i])
+        q.mTrackProjXR = F32(b["proj_x"][i]); q.mTrackProjYR = F32(b["proj_y"][i])
+        pts.append(q)
+    exec(prog, env)
+    nm_ref = env["SearchByProjection"](F, pts, F32(th), bool(far), F32(6.0))
+    amp_ref = np.array([-1 if p_ is None else (p_.id if p_.id < 100000 else -2) for p_ in F.mvpMapPoints], np.int64)
+    mine = np.where(amp == sc["assigned_mp"], np.where(amp >= 0, -2, -1), amp)          # entries the call left alone: -2 (held something) / -1
+    rewritten = (amp == sc["assigned_mp"]) & (amp >= 0) & (amp_ref >= 0)                 # (a feature re-assigned the very index it held)
+    mine = np.where(rewritten, amp, mine)
+    assert nm_ref == nm and nm > 200, (nm_ref, nm)
+    assert np.array_equal(amp_ref, mine), np.nonzero(amp_ref != mine)[0][:10]
+    nobs_ref = np.array([0 if p_ is None else p_.nobs for p_ in F.mvpMapPoints])
+    assert np.array_equal(nobs_ref[amp_ref != -1], aob[amp_ref != -1])
+    assert (amp_ref[:nl] >= 0).sum() > 100 and (amp_ref[nl:] >= 0).sum() > 100
+
+
+@pytest.mark.parametrize("cams", ["fisheye", "pinhole"])
+def test_isinfrustum_of_a_two_camera_frame_is_the_references_text(cams):
+    """Frame::isInFrustumChecks (S/Frame.cc:1154-1231) for both cameras, as the Nleft != -1 branch of Frame::isInFrustum calls it
+    (:545-554), with KannalaBrandt8::project(cv::Point3f) / Pinhole::project and MapPoint::PredictScale transliterated: flags, levels and
+    the five track fields per camera against the oracle's (float32 bits; atan2f / cosf / sinf / logf / sqrtf are the host's libm in
+    both; cv::Mat arithmetic: the stand-in's)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    for f_, n_ in (("logf", 1), ("sqrtf", 1), ("cosf", 1), ("sinf", 1), ("atan2f", 2)):
+        getattr(libm, f_).restype = ctypes.c_float; getattr(libm, f_).argtypes = [ctypes.c_float] * n_
+    f1 = lambda name: (lambda x: F32(getattr(libm, name)(float(F32(x)))))
+    body = _body(os.path.join(REF, "src", "Frame.cc"), r"bool\s+Frame::isInFrustumChecks\s*\(\s*MapPoint\s*\*pMP,\s*float viewingCosLimit,\s*bool bRight\s*\)\s*\{")
+    piece = body.replace("cv::Mat mR, mt, twc;", "").replace("cv::Point2f uv;", "")
+    piece = re.sub(r"cv::Mat (\w+) = ", r"\1 = ", piece)
+    piece = piece.replace(".at<float>(", ".at(").replace("cv::norm(Pc)", "Pc.norm()").replace("cv::norm(PO)", "PO.norm()").replace("PredictScale(dist,this)", "PredictScale(dist,thisF)")
+    src = c_to_python(cpp_prepare(piece), keep_returns=True)
+    flat = src.replace(" ", "")
+    assert src.count("return False") == 5 and "mR=Rrl*mRcw" in flat and "twc=mRwc*mTlr.rowRange(0,3).col(3)+mOw" in flat and "pMP.mnTrackScaleLevelR=nPredictedLevel" in flat
+    outer = _body(os.path.join(REF, "src", "Frame.cc"), r"bool\s+Frame::isInFrustum\s*\(\s*MapPoint\s*\*pMP,\s*float viewingCosLimit\s*\)\s*\{")
+    outer = outer[outer.rindex("else{") + 5:]
+    outer = outer[:outer.index("}")]
+    outer_src = c_to_python(cpp_prepare(re.sub(r"pMP\s*->\s*", "pMP->", outer)), keep_returns=True).replace("||", " or ")
+    assert "pMP.mnTrackScaleLevelR=-1" in outer_src.replace(" ", "") and "isInFrustumChecks(pMP,viewingCosLimit,True)" in outer_src.replace(" ", "")
+    mp_path = os.path.join(REF, "src", "MapPoint.cc")
+    ps = _body(mp_path, r"int\s+MapPoint::PredictScale\s*\(\s*const float &currentDist,\s*Frame\*\s*pF\s*\)\s*\{")
+    ps = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", ps).replace("float ratio;", "")
+    ps = re.sub(r"\{\s*(ratio = [^;]*;)\s*\}", r"\1", ps)
+    ps_src = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", ps)), typed_ints=True, keep_returns=True)
+    getters = {}
+    for nm in ("GetMinDistanceInvariance", "GetMaxDistanceInvariance"):
+        g = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", _body(mp_path, r"float\s+MapPoint::%s\s*\(\s*\)\s*\{" % nm))
+        getters[nm] = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", g)), keep_returns=True)
+    # the cameras' project(cv::Point3f): statements, then the two expressions of the returned Point2f
+    kb = _body(os.path.join(REF, "src", "CameraModels", "KannalaBrandt8.cpp"), r"cv::Point2f\s+KannalaBrandt8::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    kb_ret = re.search(r"return cv::Point2f\((.*)\)\s*;", kb, flags=re.S)
+    kx, ky = _split_top(kb_ret.group(1).replace("\n", " "))
+    kb_src = c_to_python(cpp_prepare(kb[:kb_ret.start()]), keep_returns=True)
+    assert "theta = F32(atan2f(sqrtf(x2_plus_y2), p3D.z))" in kb_src.replace("  ", " ") or "atan2f" in kb_src
+    pj = _body(os.path.join(REF, "src", "CameraModels", "Pinhole.cpp"), r"cv::Point2f\s+Pinhole::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    ex, ey = _split_top(re.search(r"return cv::Point2f\((.*)\)\s*;", pj, flags=re.S).group(1).replace("\n", " "))
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def PredictScale(self, currentDist, pF):\n" + ind(ps_src) + "\ndef GetMinDistanceInvariance(self):\n" + ind(getters["GetMinDistanceInvariance"]) +
+            "\ndef GetMaxDistanceInvariance(self):\n" + ind(getters["GetMaxDistanceInvariance"]) +
+            "\ndef kb8_project(p3D, mvParameters):\n" + ind(kb_src) + "\n    return Pt(" + _expr(kx, ()) + ", " + _expr(ky, ()) + ")" +
+            "\ndef isInFrustumChecks(pMP, viewingCosLimit, bRight=False):\n" + ind(src) +
+            "\ndef isInFrustum(pMP, viewingCosLimit):\n" + ind(outer_src))
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Obj:
+        pass
+
+    left, right = (synth.KB8_LEFT, synth.KB8_RIGHT) if cams == "fisheye" else ((capi.CAM_PINHOLE, 260.0, 259.0, 255.0, 257.0), (capi.CAM_PINHOLE, 261.0, 260.5, 253.0, 256.0))
+    sc = synth.make_rig_track_scene(n_points=1200, n_distract=10, left=left, right=right)
+    fl, fr, wv, rig, keep = _rig_scene_views(sc)
+    o = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    env = dict(ENV, F32=F32, F64=F64, as_int=lambda x: int(x), ceil=np.ceil, log=f1("logf"), sqrtf=f1("sqrtf"), cos=f1("cosf"), sin=f1("sinf"),
+               atan2f=lambda y, x: F32(libm.atan2f(float(F32(y)), float(F32(x)))), Pt=Pt)
+
+    class Cam:
+        def __init__(self, c): self.model = c[0]; self.p = [F32(v) for v in c[1:]]
+        def project(self, m):
+            p3 = Obj(); p3.x, p3.y, p3.z = m.at(0), m.at(1), m.at(2)
+            if self.model == capi.CAM_KANNALA_BRANDT8:
+                return env["kb8_project"](p3, self.p)
+            e2 = dict(env, mvParameters=self.p, p3D=p3)
+            return Pt(eval(_expr(ex, ()), e2), eval(_expr(ey, ()), e2))
+
+    thisF = Obj(); thisF.mfLogScaleFactor = F32(np.log(np.float32(1.2))); thisF.mnScaleLevels = 8
+    Tc = sc["Tcw"]
+    Rm, tm = MatF(Tc[:3, :3]), MatF(Tc[:3, 3].reshape(3, 1))
+    size = F32(sc["size"])
+    env.update(thisF=thisF, mRcw=Rm, mtcw=tm, mOw=-Rm.t() * tm, mRwc=MatF(Tc[:3, :3].T.copy()), mTrl=MatF(sc["Trl"][:3]), mTlr=MatF(sc["Tlr"][:3]),
+               mpCamera=Cam(left), mpCamera2=Cam(right), mnMinX=F32(0), mnMaxX=size, mnMinY=F32(0), mnMaxY=size)
+    exec(prog, env)
+    MPc = type("MapPoint", (), {"PredictScale": env["PredictScale"], "GetMinDistanceInvariance": env["GetMinDistanceInvariance"],
+                                "GetMaxDistanceInvariance": env["GetMaxDistanceInvariance"]})
+    n_in = [0, 0]
+    for i in range(len(sc["pos"])):
+        q = MPc(); q.mfMaxDistance = F32(sc["max_dist"][i]); q.mfMinDistance = F32(sc["min_dist"][i])
+        q.GetWorldPos = (lambda i=i: MatF(sc["pos"][i].reshape(3, 1))); q.GetNormal = (lambda i=i: MatF(sc["normal"][i].reshape(3, 1)))
+        res = env["isInFrustum"](q, F32(0.5))
+        assert bool(res) == bool(o[0]["track_in_view"][i] or o[1]["track_in_view"][i]), i
+        for side, (flag, names) in enumerate(((q.mbTrackInView, ("mTrackProjX", "mTrackProjY", "mTrackDepth", "mTrackViewCos", "mnTrackScaleLevel")),
+                                              (q.mbTrackInViewR, ("mTrackProjXR", "mTrackProjYR", "mTrackDepthR", "mTrackViewCosR", "mnTrackScaleLevelR")))):
+            assert bool(flag) == bool(o[side]["track_in_view"][i]), (i, side)
+            assert getattr(q, names[4]) == int(o[side]["scale_level"][i]), (i, side)
+            if flag:
+                n_in[side] += 1
+                mine = np.array([getattr(q, nm_) for nm_ in names[:4]], np.float32)
+                theirs = np.array([o[side][k][i] for k in ("proj_x", "proj_y", "track_depth", "view_cos")], np.float32)
+                assert mine.tobytes() == theirs.tobytes(), (i, side, mine, theirs)
+    assert min(n_in) > 500 and max(n_in) < len(sc["pos"]) - 100
 
 
 @pytest.mark.parametrize("kind", ["pinhole", "pinhole_mostly_outliers", "rig", "rig_many_right_outliers"])
