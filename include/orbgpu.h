@@ -542,6 +542,15 @@ int orbm_search_by_projection_mps_rig(orbm_frame* left, orbm_frame* right, const
                                       const int32_t* left_to_right, const int32_t* right_to_left, float th, int far_points,
                                       float th_far_points, float nnratio, int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) with CurrentFrame.Nleft != -1
+ * (S/ORBmatcher.cc:1970-2186): per map point of the last frame the left camera's search through rig->left (mpCamera->project), then
+ * (:2092-2160) the point in the right camera's frame (rig->Trl) projected -- through mpCamera again, as the reference does -- and
+ * searched in the right camera's grid; a point whose left window holds no feature is not searched on the right either (:2033).
+ * `last`: the last frame's Nleft + Nright entries (octave / angle of mvKeys resp. mvKeysRight).  assigned_*: Nleft + Nright entries. */
+int orbm_search_by_projection_frame_rig(orbm_frame* left, orbm_frame* right, const float* Tcw_cur, const orbg_camera_rig* rig,
+                                        const orbm_lastframe_view* last, float th, int mono, int check_orientation, int32_t* assigned_mp,
+                                        int32_t* assigned_obs, int* nmatches);
+
 /* `ur` of an observation made by the RIGHT camera of the rig (get<1>(indexes) != -1, S/Optimizer.cc:2086-2120; i >= Nleft,
  * :1121-1150): u, v are then mvKeysRight[rightIndex].pt and the edge is the *ToBody kind.  In a problem whose rig has a right camera
  * any ur <= -1.5 reads as this (mvuRight is -1 throughout on such frames); in every other problem a negative ur is a monocular

@@ -759,6 +759,56 @@ __global__ __launch_bounds__(256) void search_frame_kernel(FrameParams fp, Frame
   window_search(fp, F, q, qd, i, L.n, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
 }
 
+// SearchByProjection(CurrentFrame, LastFrame) on a two-camera frame (S/ORBmatcher.cc:1996-2160): `right` = 0: the left camera's
+// query (:2001-2031); 1: the query of :2093-2110 -- the point taken into the right camera's frame by mTrl and projected through
+// mpCamera (as the text has it), searched in the right camera's grid without an image-bounds test.  Either is made only for a point the
+// left camera's tests let through.
+struct TrlF { float m[12]; };
+__global__ __launch_bounds__(256) void search_frame_rig_kernel(FrameParams fp, FrameDev F, LastDev L, PoseF Pc, RigCamF cam, TrlF Trl, int right,
+                                                              float th, int forward, int backward, int* list_counter, int* counter_next,
+                                                              uint32_t* list, int list_cap, QResult* results) {
+  __shared__ uint32_t s_stage[4][kListStage];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= L.n) return;
+  Query q;
+  q.valid = 0; q.x = q.y = q.r = 0; q.min_level = q.max_level = 0; q.ur_ref = 0;
+  const uint8_t l_valid = L.mp_valid[i], l_outlier = L.outlier[i];
+  const float X[3] = {L.world_pos[3 * i], L.world_pos[3 * i + 1], L.world_pos[3 * i + 2]};
+  const int l_oct = L.octave[i];
+  const QDesc qd = load_qdesc(L.desc + (size_t)i * 32);
+  if (l_valid && !l_outlier) {
+    float x3Dc[3];
+    pose_map(Pc, X, x3Dc);
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);
+    if (!(invzc < 0)) {
+      float uv[2];
+      rig_project(cam, x3Dc, uv);
+      if (!(uv[0] < fp.min_x || uv[0] > fp.max_x) && !(uv[1] < fp.min_y || uv[1] > fp.max_y)) {
+        if (right) {
+          float x3Dr[3];
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const float t0 = Trl.m[4 * a] * x3Dc[0] + Trl.m[4 * a + 1] * x3Dc[1] + Trl.m[4 * a + 2] * x3Dc[2];
+            x3Dr[a] = t0 + Trl.m[4 * a + 3];
+          }
+          rig_project(cam, x3Dr, uv);
+        }
+        // (a projection that is not a number selects no cell in the reference: (int)floor(NaN) is INT_MIN there)
+        if (isfinite(uv[0]) && isfinite(uv[1])) {
+          q.valid = 1;
+          q.x = uv[0]; q.y = uv[1];
+          q.r = th * fp.scale[l_oct];
+          if (forward) { q.min_level = l_oct; q.max_level = -1; }
+          else if (backward) { q.min_level = 0; q.max_level = l_oct; }
+          else { q.min_level = l_oct - 1; q.max_level = l_oct + 1; }
+        }
+      }
+    }
+  }
+  window_search(fp, F, q, qd, i, L.n, list_counter, list, list_cap, results + i, s_stage[threadIdx.x >> 6]);
+}
+
 // SearchByBoW inner loops (S/ORBmatcher.cc:297-371): one wavefront per keyframe feature of a shared node.
 struct BowJob { int kf_idx; int f_begin, f_end; };   // frame-side bucket [f_begin,f_end) in fvF.feat_idx
 
@@ -1907,6 +1957,81 @@ extern "C" int orbm_search_by_projection_mps_rig(orbm_frame* L, orbm_frame* R, c
     }
   }
   return ORBG_INTERNAL;
+}
+
+extern "C" int orbm_search_by_projection_frame_rig(orbm_frame* FL, orbm_frame* FR, const float* Tcw_cur, const orbg_camera_rig* rig,
+                                                   const orbm_lastframe_view* last, float th, int mono, int check_orientation,
+                                                   int32_t* amp, int32_t* aob, int* nmatches_out) {
+  if (!FL || !FR || FL == FR || !Tcw_cur || !rig || !rig->has_right || !last || !amp || !aob || last->n < 0 || FL->device != FR->device)
+    return ORBG_BAD_ARG;
+  if (rig->left.model != ORBG_CAM_PINHOLE && rig->left.model != ORBG_CAM_KANNALA_BRANDT8) return ORBG_BAD_ARG;
+  int rc = select_device(FL->device);
+  if (rc) return rc;
+  const int m = last->n, nl = FL->fp.n;
+  if (nmatches_out) *nmatches_out = 0;
+  if (m == 0) return ORBG_OK;
+  PoseF Pc, Pl;
+  make_pose(Tcw_cur, &Pc);
+  make_pose(last->Tcw, &Pl);
+  float tlc[3];
+  for (int i = 0; i < 3; i++) {
+    const float t0 = Pl.R[3 * i] * Pc.Ow[0] + Pl.R[3 * i + 1] * Pc.Ow[1] + Pl.R[3 * i + 2] * Pc.Ow[2];
+    tlc[i] = t0 + Pl.t[i];
+  }
+  const int forward = tlc[2] > FL->fp.b && !mono;
+  const int backward = -tlc[2] > FL->fp.b && !mono;
+  const RigCamF cam = rig_cam_of(rig->left);
+  TrlF Trl;
+  memcpy(Trl.m, rig->Trl, sizeof(Trl.m));
+  // The kernels list every candidate of a window, taken or not: "the left camera's window is empty" ends a point's turn (:2033-2034)
+  // and must be told from "every candidate in it is taken"; the commit below tests mvpMapPoints as it stands at that moment.
+  for (int side = 0; side < 2; side++) {
+    orbm_frame* f = side ? FR : FL;
+    const int n = f->fp.n;
+    if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 12 + 4)))) return rc;
+    const std::vector<int32_t> none((size_t)std::max(n, 1), -1);
+    stage_occupancy(f, none.data(), nullptr, n);
+    LastDev L;
+    L.n = m;
+    L.mp_valid = stage_add(f, last->mp_valid, m); L.outlier = stage_add(f, last->outlier, m);
+    L.desc = stage_add(f, last->desc, (size_t)m * 32);
+    L.world_pos = stage_add(f, last->world_pos, (size_t)m * 3);
+    L.octave = stage_add(f, last->octave, m);
+    if ((rc = stage_commit(f))) return rc;
+    FrameDev F = frame_dev(f);
+    F.uright = nullptr;                                    // :2049: the mvuRight test is for Nleft == -1 only
+    hipStream_t st = f->stream;
+    rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
+      hipLaunchKernelGGL(search_frame_rig_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, L, Pc, cam, Trl, side, th, forward, backward,
+                         cnt, cnt_next, f->list.d, list_cap, f->results.d);
+    });
+    if (rc) return rc;
+  }
+  cache_keypoint_fields(FL); cache_keypoint_fields(FR);
+  RotHist rotHist(FL->rot_entries);
+  int nmatches = 0;
+  const QResult* RL = FL->results.h;
+  const QResult* RR = FR->results.h;
+  for (int i = 0; i < m; i++) {
+    if (RL[i].n_top == 0) continue;                        // no query, or vIndices2.empty()
+    Pick pk;
+    if ((rc = pick_unclaimed(FL, RL[i], 1, [&](int idx) { return amp[idx] >= 0 && aob[idx] > 0; }, &pk))) return rc;
+    if (pk.idx1 >= 0 && pk.dist1 <= TH_HIGH) {
+      amp[pk.idx1] = i; aob[pk.idx1] = last->n_obs[i];
+      nmatches++;
+      if (check_orientation) rotHist.add(rot_bin(last->angle[i], FL->hk_angle[pk.idx1]), pk.idx1);
+    }
+    if (RR[i].n_top == 0) continue;
+    if ((rc = pick_unclaimed(FR, RR[i], 1, [&](int idx) { return amp[idx + nl] >= 0 && aob[idx + nl] > 0; }, &pk))) return rc;
+    if (pk.idx1 >= 0 && pk.dist1 <= TH_HIGH) {
+      amp[pk.idx1 + nl] = i; aob[pk.idx1 + nl] = last->n_obs[i];
+      nmatches++;
+      if (check_orientation) rotHist.add(rot_bin(last->angle[i], FR->hk_angle[pk.idx1]), pk.idx1 + nl);
+    }
+  }
+  if (check_orientation) rotHist.reject_outside_three_maxima([&](int idx) { amp[idx] = -1; aob[idx] = 0; nmatches--; });
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
 }
 
 // Common part of the two entry points below.  `stage_view`: the view is packed into the frame's pinned staging block and read there

@@ -438,6 +438,7 @@ def make_rig_track_scene(n_points=1500, n_distract=300, seed=0xF1E0, size=512, l
             d[b >> 3] ^= 1 << (b & 7)
         return d
 
+    base_angle = rng.uniform(0, 360, n_points)
     feats = {"L": [], "R": []}                                   # (x, y, octave, desc, point or -1)
     for i in range(n_points):
         Xc = Tcw[:3, :3] @ pos[i] + Tcw[:3, 3]
@@ -461,7 +462,9 @@ def make_rig_track_scene(n_points=1500, n_distract=300, seed=0xF1E0, size=512, l
     def arrays(fl):
         k = np.zeros(len(fl), capi.KEYPOINT_DTYPE)
         k["x"] = [f[0] for f in fl]; k["y"] = [f[1] for f in fl]; k["octave"] = [f[2] for f in fl]
-        k["size"] = 31.0; k["angle"] = rng.uniform(0, 360, len(fl)).astype(np.float32)
+        k["size"] = 31.0
+        k["angle"] = [np.float32((base_angle[f[4]] + rng.randn() * 2.0 + (140.0 if rng.rand() < 0.05 else 0.0)) % 360.0) if f[4] >= 0 else rng.uniform(0, 360)
+                      for f in fl]
         return k, np.stack([f[3] for f in fl]).astype(np.uint8), np.array([f[4] for f in fl])
 
     kl, dl, pl = arrays(feats["L"]); kr, dr, pr = arrays(feats["R"])
@@ -477,7 +480,22 @@ def make_rig_track_scene(n_points=1500, n_distract=300, seed=0xF1E0, size=512, l
     return dict(Tcw=Tcw.astype(np.float32), Trl=Trl.astype(np.float32), Tlr=Tlr.astype(np.float32)[:3], left=left, right=right, size=size,
                 pos=pos.astype(np.float32), normal=normal.astype(np.float32), min_dist=min_d.astype(np.float32), max_dist=max_d.astype(np.float32),
                 desc=desc, n_obs=n_obs, bad=bad, kps_left=kl, desc_left=dl, kps_right=kr, desc_right=dr, left_to_right=l2r, right_to_left=r2l,
-                assigned_mp=amp0, assigned_obs=aob0)
+                assigned_mp=amp0, assigned_obs=aob0, level=lvl, base_angle=base_angle)
+
+
+def rig_last_frame(sc, n_last=900, seed=5, motion=(0.0, 0.0, 0.0)):
+    """A last frame for SearchByProjection(CurrentFrame, LastFrame) on the scene above: its features hold the scene's first n_last points
+    (some none, some flagged outliers), octave / angle near the current features' of the same point; Tcw_last = the current pose moved by
+    `motion` (in the camera frame: z decides bForward / bBackward)."""
+    rng = np.random.RandomState(seed)
+    n_last = min(n_last, len(sc["pos"]))
+    T_last = sc["Tcw"].astype(np.float64).copy()
+    T_last[:3, 3] += np.asarray(motion, np.float64)
+    return dict(mp_valid=(rng.rand(n_last) < 0.85).astype(np.uint8), outlier=(rng.rand(n_last) < 0.06).astype(np.uint8),
+                world_pos=sc["pos"][:n_last].copy(), desc=sc["desc"][:n_last].copy(),
+                octave=np.clip(sc["level"][:n_last] + rng.choice([-1, 0, 0, 0, 1], n_last), 0, 7).astype(np.int32),
+                angle=((sc["base_angle"][:n_last] + rng.randn(n_last) * 2.0) % 360.0).astype(np.float32), n_obs=sc["n_obs"][:n_last].copy(),
+                Tcw=T_last.astype(np.float32))
 
 
 # ---------------------------------------------------------------- synthetic vocabulary (ORBvoc.txt is not in the reference tree)

@@ -516,6 +516,90 @@ extern "C" int oracle_search_by_projection_mps_rig(const orbm_frame_view* left, 
   return ORBG_OK;
 }
 
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) -- S/ORBmatcher.cc:1970-2186 with
+// CurrentFrame.Nleft != -1: the left camera's search through mpCamera->project, then (:2092-2160) the point moved into the right
+// camera's frame by mTrl and projected -- through mpCamera again, as the text has it -- into mGridRight.  `last` holds the last frame's
+// Nleft + Nright entries (octave / angle of mvKeys resp. mvKeysRight).
+extern "C" int oracle_search_by_projection_frame_rig(const orbm_frame_view* left, const orbm_frame_view* right, const float* Tcw_cur,
+                                                     const orbg_camera_rig* rig, const orbm_lastframe_view* last, float th, int mono,
+                                                     int check_ori, int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches_out) {
+  ScaleTables st(left);
+  const Grid gl = build_grid(left), gr = build_grid(right);
+  const int Nleft = left->n;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  Pose pc(Tcw_cur), pl(last->Tcw);
+  float tlc[3];
+  pl.map(pc.Ow, tlc);
+  const bool bForward = tlc[2] > left->b && !mono;
+  const bool bBackward = -tlc[2] > left->b && !mono;
+  std::vector<int> vIndices2;
+  const float* Trl = rig->Trl;
+  for (int i = 0; i < last->n; i++) {
+    if (!last->mp_valid[i] || last->outlier[i]) continue;
+    float x3Dc[3];
+    pc.map(last->world_pos + 3 * i, x3Dc);
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    if (invzc < 0) continue;
+    float uv[2];
+    rig_cam_project(rig->left, x3Dc, uv);
+    if (uv[0] < left->min_x || uv[0] > left->max_x) continue;
+    if (uv[1] < left->min_y || uv[1] > left->max_y) continue;
+    const int nLastOctave = last->octave[i];
+    const float radius = th * st.scale[nLastOctave];
+    auto window = [&](const orbm_frame_view* v, const Grid& g, const float* c) {
+      if (!std::isfinite(c[0]) || !std::isfinite(c[1])) { vIndices2.clear(); return; }    // (int)floor(NaN) is INT_MIN on x86: no cell
+      if (bForward) features_in_area(v, g, c[0], c[1], radius, nLastOctave, -1, vIndices2);
+      else if (bBackward) features_in_area(v, g, c[0], c[1], radius, 0, nLastOctave, vIndices2);
+      else features_in_area(v, g, c[0], c[1], radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+    };
+    window(left, gl, uv);
+    if (vIndices2.empty()) continue;                                              // :2033-2034: the right camera is not tried either
+    const uint8_t* dMP = last->desc + 32 * (size_t)i;
+    {
+      int bestDist = 256, bestIdx2 = -1;
+      for (int i2 : vIndices2) {
+        if (assigned_mp[i2] >= 0 && assigned_obs[i2] > 0) continue;
+        const int dist = oracle_hamming(dMP, left->desc + 32 * (size_t)i2);
+        if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+      }
+      if (bestDist <= TH_HIGH) {
+        assigned_mp[bestIdx2] = i; assigned_obs[bestIdx2] = last->n_obs[i];
+        nmatches++;
+        if (check_ori) rotHist[rot_bin(last->angle[i], left->kps[bestIdx2].angle)].push_back(bestIdx2);
+      }
+    }
+    float x3Dr[3];
+    for (int a = 0; a < 3; a++) {
+      const float t0 = Trl[4 * a] * x3Dc[0] + Trl[4 * a + 1] * x3Dc[1] + Trl[4 * a + 2] * x3Dc[2];
+      x3Dr[a] = (float)(t0 + Trl[4 * a + 3]);
+    }
+    float uvr[2];
+    rig_cam_project(rig->left, x3Dr, uvr);                                         // :2095: mpCamera, not mpCamera2
+    window(right, gr, uvr);
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (assigned_mp[i2 + Nleft] >= 0 && assigned_obs[i2 + Nleft] > 0) continue;
+      const int dist = oracle_hamming(dMP, right->desc + 32 * (size_t)i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      assigned_mp[bestIdx2 + Nleft] = i; assigned_obs[bestIdx2 + Nleft] = last->n_obs[i];
+      nmatches++;
+      if (check_ori) rotHist[rot_bin(last->angle[i], right->kps[bestIdx2].angle)].push_back(bestIdx2 + Nleft);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int idx : rotHist[i]) { assigned_mp[idx] = -1; assigned_obs[idx] = 0; nmatches--; }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
 // Tracking::SearchLocalPoints body (S/Tracking.cc:3111-3153): isInFrustum(.,0.5) then SearchByProjection.
 extern "C" int oracle_search_local_points(const orbm_frame_view* view, const orbm_worldpoints_view* pts, const float* Tcw,
                                           float th, int far_points, float th_far_points, float nnratio,

@@ -103,6 +103,10 @@ int oracle_search_by_projection_mps_rig(const orbm_frame_view* left, const orbm_
                                         const orbm_mappoints_view* mps_r, const int32_t* left_to_right, const int32_t* right_to_left,
                                         float th, int far_points, float th_far_points, float nnratio, int32_t* assigned_mp,
                                         int32_t* assigned_obs, int* nmatches);
+/* SearchByProjection(CurrentFrame, LastFrame, th, bMono) with CurrentFrame.Nleft != -1 (S/ORBmatcher.cc:1970-2186 incl. :2092-2160) */
+int oracle_search_by_projection_frame_rig(const orbm_frame_view* left, const orbm_frame_view* right, const float* Tcw_cur,
+                                          const orbg_camera_rig* rig, const orbm_lastframe_view* last, float th, int mono,
+                                          int check_orientation, int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
 int oracle_search_local_points(const orbm_frame_view* view, const orbm_worldpoints_view* pts, const float* Tcw,
                                float th, int far_points, float th_far_points, float nnratio,
                                int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);

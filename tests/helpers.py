@@ -85,7 +85,7 @@ def rig_track_views(sc):
     """Views of synth.make_rig_track_scene: (left frame view, right frame view, world points view, camera rig, keep-alive list)."""
     from multi_orbslam3_amd import views
     bounds = (0, sc["size"], 0, sc["size"])
-    cam = (sc["left"][1], sc["left"][2], sc["left"][3], sc["left"][4], 0.0, 0.0)
+    cam = (sc["left"][1], sc["left"][2], sc["left"][3], sc["left"][4], 0.0, 0.1)                    # (mb: the forward / backward test of the frame search)
     fl, k1 = views.frame_view(sc["kps_left"], sc["desc_left"], None, None, bounds, cam)
     fr, k2 = views.frame_view(sc["kps_right"], sc["desc_right"], None, None, bounds, cam)
     wv, k3 = views.worldpoints_view(sc["pos"], sc["normal"], sc["min_dist"], sc["max_dist"], sc["desc"], sc["n_obs"], sc["bad"])

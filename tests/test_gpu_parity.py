@@ -1998,3 +1998,30 @@ def test_rig_search_refuses_what_it_cannot_be():
     mono = views.camera_rig(sc["left"])
     with pytest.raises(capi.OrbGpuError):                     # isInFrustum of a rig needs the right camera
         FL.isInFrustumRig(sc["Tcw"], mono, sc["Tlr"], wv)
+
+
+@pytest.mark.parametrize("case", ["sideways", "forward", "backward", "mono_flag", "no_orientation_check", "crowded", "pinholes"])
+def test_search_by_projection_last_frame_on_a_two_camera_frame(case):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) with CurrentFrame.Nleft != -1 (S/ORBmatcher.cc:1970-2186): the
+    left camera's search, the right camera's (:2092-2160, the point moved by mTrl and projected through mpCamera), a point whose left
+    window is empty skipped on both sides, level windows by the direction of motion, the rotation histogram over both cameras'
+    matches -- match arrays and counts equal the oracle's."""
+    kw = dict(crowded=dict(occupied_frac=0.3, seed=0xF1E3), pinholes=dict(left=RIG_CAMERAS["two pinholes"][0], right=RIG_CAMERAS["two pinholes"][1])).get(case, {})
+    sc = synth.make_rig_track_scene(**kw)
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    motion = dict(forward=(0.02, 0.0, 0.4), backward=(0.0, -0.03, -0.4)).get(case, (0.03, 0.01, 0.02))
+    last = synth.rig_last_frame(sc, motion=motion)
+    lv, keep2 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+    FL, FR = api.Frame().upload(fl, keep[0]), api.Frame().upload(fr, keep[1])
+    check = case != "no_orientation_check"
+    mono = case == "mono_flag"
+    m = api.ORBmatcher(0.9, check)
+    nl = len(sc["kps_left"])
+    for th in (7.0, 15.0):
+        g = m.SearchByProjectionFrameRig(FL, FR, sc["Tcw"], rig, lv, th, mono, sc["assigned_mp"], sc["assigned_obs"])
+        o = ob.search_by_projection_frame_rig(fl, fr, sc["Tcw"], rig, lv, th, mono, check, sc["assigned_mp"], sc["assigned_obs"])
+        changed = o[0] != sc["assigned_mp"]
+        assert o[2] > 250 and changed[:nl].sum() > 100 and changed[nl:].sum() > 100, (th, o[2])
+        assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1]), th
+    with pytest.raises(capi.OrbGpuError):
+        m.SearchByProjectionFrameRig(FL, FL, sc["Tcw"], rig, lv, 7.0, mono, sc["assigned_mp"], sc["assigned_obs"])

@@ -927,12 +927,9 @@ class MatF:
         return MatF(out)
 
 
-@pytest.mark.parametrize("case", ["stereo_forward", "stereo_sideways", "stereo_backward", "mono", "no_orientation_check"])
-def test_searchbyprojection_of_the_last_frame_is_the_references_text(case):
-    """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) -- S/ORBmatcher.cc:1970-2186 -- WHOLE, with
-    ComputeThreeMaxima, Frame::GetFeaturesInArea and Pinhole::project(Point3f) transliterated from the text and run on stand-ins: the
-    forward / backward / sideways level windows, the stereo `ur` test, the rotation histogram and the removal of the matches outside its
-    three maxima -- assignments and count against the oracle's.  (The cv::Mat products are the stand-in's float32 arithmetic: see MatF.)"""
+def _search_last_frame_program():
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) with ComputeThreeMaxima as Python source, and the two expressions
+    of Pinhole::project(Point3f)'s returned point."""
     path = os.path.join(REF, "src", "ORBmatcher.cc")
     body = _body(path, r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&CurrentFrame,\s*const\s+Frame\s*&LastFrame[^)]*\)\s*\{")
     body = re.sub(r"for\(vector<size_t>::const_iterator vit=vIndices2\.begin\(\), vend=vIndices2\.end\(\); vit!=vend; vit\+\+\)\s*\{\s*const size_t i2 = \*vit;",
@@ -952,6 +949,17 @@ def test_searchbyprojection_of_the_last_frame_is_the_references_text(case):
     ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
     prog = ("def ComputeThreeMaxima(histo, L, ind1, ind2, ind3):\n" + ind(tm_src) + "\n    return (ind1, ind2, ind3)\n" +
             "def SearchByProjection(CurrentFrame, LastFrame, th, bMono):\n" + ind(src))
+
+    return prog, ex, ey
+
+
+@pytest.mark.parametrize("case", ["stereo_forward", "stereo_sideways", "stereo_backward", "mono", "no_orientation_check"])
+def test_searchbyprojection_of_the_last_frame_is_the_references_text(case):
+    """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) -- S/ORBmatcher.cc:1970-2186 -- WHOLE, with
+    ComputeThreeMaxima, Frame::GetFeaturesInArea and Pinhole::project(Point3f) transliterated from the text and run on stand-ins: the
+    forward / backward / sideways level windows, the stereo `ur` test, the rotation histogram and the removal of the matches outside its
+    three maxima -- assignments and count against the oracle's.  (The cv::Mat products are the stand-in's float32 arithmetic: see MatF.)"""
+    prog, ex, ey = _search_last_frame_program()
 
     class Pt:
         def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
@@ -2619,6 +2627,122 @@ def test_isinfrustum_of_a_two_camera_frame_is_the_references_text(cams):
                 theirs = np.array([o[side][k][i] for k in ("proj_x", "proj_y", "track_depth", "view_cos")], np.float32)
                 assert mine.tobytes() == theirs.tobytes(), (i, side, mine, theirs)
     assert min(n_in) > 500 and max(n_in) < len(sc["pos"]) - 100
+
+
+def _camera_standins_from_text():
+    """A factory of GeometricCamera stand-ins whose project(cv::Mat) runs the text of KannalaBrandt8::project(cv::Point3f) /
+    Pinhole::project(cv::Point3f) (float32; atan2f / sqrtf / cosf / sinf from the host's libm)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    for f_, n_ in (("sqrtf", 1), ("cosf", 1), ("sinf", 1), ("atan2f", 2)):
+        getattr(libm, f_).restype = ctypes.c_float; getattr(libm, f_).argtypes = [ctypes.c_float] * n_
+    f1 = lambda name: (lambda x: F32(getattr(libm, name)(float(F32(x)))))
+    kb = _body(os.path.join(REF, "src", "CameraModels", "KannalaBrandt8.cpp"), r"cv::Point2f\s+KannalaBrandt8::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    kb_ret = re.search(r"return cv::Point2f\((.*)\)\s*;", kb, flags=re.S)
+    kx, ky = _split_top(kb_ret.group(1).replace("\n", " "))
+    kb_src = c_to_python(cpp_prepare(kb[:kb_ret.start()]), keep_returns=True)
+    pj = _body(os.path.join(REF, "src", "CameraModels", "Pinhole.cpp"), r"cv::Point2f\s+Pinhole::project\s*\(\s*const\s+cv::Point3f\s*&p3D\s*\)\s*\{")
+    ex, ey = _split_top(re.search(r"return cv::Point2f\((.*)\)\s*;", pj, flags=re.S).group(1).replace("\n", " "))
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    env = dict(ENV, F32=F32, F64=F64, sqrtf=f1("sqrtf"), cos=f1("cosf"), sin=f1("sinf"), atan2f=lambda y, x: F32(libm.atan2f(float(F32(y)), float(F32(x)))), Pt=Pt)
+    exec("def kb8_project(p3D, mvParameters):\n" + "\n".join("    " + ln for ln in kb_src.splitlines()) + "\n    return Pt(" + _expr(kx, ()) + ", " + _expr(ky, ()) + ")", env)
+
+    class P3:
+        pass
+
+    class Cam:
+        def __init__(self, c): self.model = c[0]; self.p = [F32(v) for v in c[1:]]
+        def project(self, m):
+            p3 = P3(); p3.x, p3.y, p3.z = m.at(0), m.at(1), m.at(2)
+            if self.model == capi.CAM_KANNALA_BRANDT8:
+                return env["kb8_project"](p3, self.p)
+            e2 = dict(env, mvParameters=self.p, p3D=p3)
+            return Pt(eval(_expr(ex, ()), e2), eval(_expr(ey, ()), e2))
+
+    return Cam
+
+
+@pytest.mark.parametrize("case", ["sideways", "forward", "backward", "no_orientation_check", "pinholes"])
+def test_searchbyprojection_of_the_last_frame_on_a_two_camera_frame_is_the_references_text(case):
+    """The same text as test_searchbyprojection_of_the_last_frame_is_the_references_text (S/ORBmatcher.cc:1970-2186), now run with
+    CurrentFrame.Nleft != -1 and a two-camera LastFrame: the left camera's block on mvKeys / mGrid, the right camera's block
+    (:2092-2160: mTrl, mpCamera->project, mGridRight, descriptor rows and mvpMapPoints entries Nleft + i), the rotation histogram over
+    both -- against the oracle's rig form: every entry of mvpMapPoints and the match count."""
+    prog, ex, ey = _search_last_frame_program()
+    Cam = _camera_standins_from_text()
+    kw = dict(pinholes=dict(left=(capi.CAM_PINHOLE, 260.0, 259.0, 255.0, 257.0), right=(capi.CAM_PINHOLE, 261.0, 260.5, 253.0, 256.0))).get(case, {})
+    sc = synth.make_rig_track_scene(n_points=900, n_distract=200, **kw)
+    fl, fr, wv, rig, keep = _rig_scene_views(sc)
+    fl.b = 0.1
+    motion = dict(forward=(0.02, 0.0, 0.4), backward=(0.0, -0.03, -0.4)).get(case, (0.03, 0.01, 0.02))
+    last = synth.rig_last_frame(sc, n_last=700, motion=motion)
+    lv, keep2 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+    check = case != "no_orientation_check"
+    th = 7.0
+    amp, aob, nm = ob.search_by_projection_frame_rig(fl, fr, sc["Tcw"], rig, lv, th, 0, int(check), sc["assigned_mp"], sc["assigned_obs"])
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o, a): self.pt, self.octave, self.angle = Pt(x, y), int(o), F32(a)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[i]
+
+    class Obj:
+        pass
+
+    nl, nr = len(sc["kps_left"]), len(sc["kps_right"])
+    scl = np.ones(8, np.float32)
+    for l in range(1, 8):
+        scl[l] = np.float32(scl[l - 1] * np.float32(1.2))
+    env = dict(ENV, F32=F32, F64=F64, abs=abs, fabs=abs, TH_HIGH=100, HISTO_LENGTH=30, mbCheckOrientation=check, as_int=lambda v: int(v), floor=np.floor,
+               ceil=np.ceil, round=lambda a: int(np.copysign(np.floor(np.abs(F64(a)) + 0.5), a)), DescriptorDistance=lambda a, b2: int(np.unpackbits(a ^ b2).sum()))
+    size = F32(sc["size"])
+    Cur, Last = Obj(), Obj()
+    Cur.mTcw = MatF(sc["Tcw"]); Cur.mb = F32(0.1); Cur.mbf = F32(0); Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY = F32(0), size, F32(0), size
+    Cur.mpCamera = Cam(sc["left"]); Cur.mpCamera2 = Cam(sc["right"]); Cur.mvScaleFactors = [F32(v) for v in scl]; Cur.Nleft = nl
+    Cur.mvuRight = [F32(-1)] * (nl + nr); Cur.mTrl = MatF(sc["Trl"][:3])
+    Cur.mDescriptors = Desc(np.concatenate([sc["desc_left"], sc["desc_right"]]))
+    Cur.mvKeys = [Kp(k["x"], k["y"], k["octave"], k["angle"]) for k in sc["kps_left"]]; Cur.mvKeysUn = Cur.mvKeys
+    Cur.mvKeysRight = [Kp(k["x"], k["y"], k["octave"], k["angle"]) for k in sc["kps_right"]]
+    Cur.mvpMapPoints = [None] * (nl + nr)
+    for i in np.nonzero(sc["assigned_mp"] >= 0)[0]:
+        o = Obj(); o.id = -2; o.nobs = int(sc["assigned_obs"][i]); o.Observations = (lambda o=o: o.nobs)
+        Cur.mvpMapPoints[i] = o
+    grids = []
+    for fv in (fl, fr):
+        start, items = ob.build_grid(fv)
+        grids.append([[[int(v) for v in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)]
+                      for ix in range(capi.GRID_COLS)])
+    genv = dict(env, Nleft=nl, mnMinX=F32(0), mnMinY=F32(0), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
+                mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / size), mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / size),
+                mGrid=grids[0], mGridRight=grids[1], mvKeysUn=Cur.mvKeysUn, mvKeys=Cur.mvKeys, mvKeysRight=Cur.mvKeysRight)
+    exec(_get_features_in_area_source_rig(), genv)
+    Cur.GetFeaturesInArea = lambda x, y, r, lo=-1, hi=-1, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), lo, hi, bRight)
+    N = len(last["mp_valid"]); NlastLeft = N // 2                 # the last frame's entries: its first half the left camera's, the rest the right one's
+    Last.mTcw = MatF(last["Tcw"]); Last.N = N; Last.Nleft = NlastLeft; Last.mvbOutlier = [bool(v) for v in last["outlier"]]
+    keys = [Kp(0, 0, last["octave"][i], last["angle"][i]) for i in range(N)]
+    Last.mvKeys = keys[:NlastLeft]; Last.mvKeysUn = Last.mvKeys; Last.mvKeysRight = keys[NlastLeft:]
+    Last.mvpMapPoints = []
+    for i in range(N):
+        if not last["mp_valid"][i]:
+            Last.mvpMapPoints.append(None); continue
+        q = Obj(); q.id = i; q.nobs = int(last["n_obs"][i])
+        q.GetWorldPos = (lambda i=i: MatF(last["world_pos"][i].reshape(3, 1))); q.GetDescriptor = (lambda i=i: last["desc"][i]); q.Observations = (lambda q=q: q.nobs)
+        Last.mvpMapPoints.append(q)
+    exec(prog, env)
+    nm_ref = env["SearchByProjection"](Cur, Last, F32(th), False)
+    amp_ref = np.array([-1 if p_ is None else p_.id for p_ in Cur.mvpMapPoints], np.int64)
+    mine = np.where(amp == sc["assigned_mp"], np.where(amp >= 0, -2, -1), amp)
+    assert nm_ref == nm and nm > 200, (case, nm_ref, nm)
+    assert np.array_equal(amp_ref, mine), (case, np.nonzero(amp_ref != mine)[0][:10])
+    assert (amp_ref[:nl] >= 0).sum() > 80 and (amp_ref[nl:] >= 0).sum() > 80
 
 
 @pytest.mark.parametrize("kind", ["pinhole", "pinhole_mostly_outliers", "rig", "rig_many_right_outliers"])
