@@ -27,6 +27,7 @@
 #include <memory>
 #include <mutex>
 #include <set>
+#include <stdexcept>
 #include <tuple>
 #include <type_traits>
 #include <unordered_map>
@@ -110,6 +111,25 @@ struct GpuOps {
   static int search_frame(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_lastframe_view& last, float th, int mono,
                           int check_ori, int32_t* amp, int32_t* aob, int* n) {
     return orbm_search_by_projection_frame(frame(key, v).handle(), Tcw, &last, th, mono, check_ori, amp, aob, n);
+  }
+  // ---- two-camera Frames (Nleft != -1): the cameras' features are two device frames
+  static int is_in_frustum_rig(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbg_camera_rig& rig, const float* Tlr,
+                               const orbm_worldpoints_view& pts, float lim, uint8_t* in_view, float* px, float* py, float* depth, int32_t* level,
+                               float* vcos, uint8_t* in_view_r, float* px_r, float* py_r, float* depth_r, int32_t* level_r, float* vcos_r) {
+    return orbm_is_in_frustum_rig(frame(key, v).handle(), Tcw, &rig, Tlr, &pts, lim, in_view, px, py, depth, level, vcos, in_view_r, px_r, py_r,
+                                  depth_r, level_r, vcos_r);
+  }
+  static int search_mps_rig(const FrameKey& kl, const orbm_frame_view& vl, const FrameKey& kr, const orbm_frame_view& vr, const orbm_mappoints_view& mps,
+                            const orbm_mappoints_view& mps_r, const int32_t* l2r, const int32_t* r2l, float th, int far_points, float th_far,
+                            float nnratio, int32_t* amp, int32_t* aob, int* n) {
+    FrameOnDevice& L = frame(kl, vl); FrameOnDevice& R = frame(kr, vr);
+    return orbm_search_by_projection_mps_rig(L.handle(), R.handle(), &mps, &mps_r, l2r, r2l, th, far_points, th_far, nnratio, amp, aob, n);
+  }
+  static int search_frame_rig(const FrameKey& kl, const orbm_frame_view& vl, const FrameKey& kr, const orbm_frame_view& vr, const float* Tcw,
+                              const orbg_camera_rig& rig, const orbm_lastframe_view& last, float th, int mono, int check_ori, int32_t* amp,
+                              int32_t* aob, int* n) {
+    FrameOnDevice& L = frame(kl, vl); FrameOnDevice& R = frame(kr, vr);
+    return orbm_search_by_projection_frame_rig(L.handle(), R.handle(), Tcw, &rig, &last, th, mono, check_ori, amp, aob, n);
   }
   // isInFrustum(., 0.5) for every non-skipped point + SearchByProjection(F, points) in one device pass; in_frustum[m] out
   static int search_local(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, float th,
@@ -204,6 +224,29 @@ void flatten_assignments(const FrameT& F, std::vector<int32_t>& amp, std::vector
   for (int i = 0; i < F.N; i++)
     if (F.mvpMapPoints[i]) { amp[i] = INT32_MAX; aob[i] = F.mvpMapPoints[i]->Observations(); }
 }
+
+// A two-camera Frame (Nleft != -1, S/Frame.cc:1017-1091): the left camera's features are mvKeys[0, Nleft) with descriptor rows
+// [0, Nleft) and mGrid, the right camera's mvKeysRight with rows Nleft + i and mGridRight (S/Frame.cc:360-391) -- two frames for the
+// entry points (no uRight on either: mvuRight is -1 throughout such a frame).
+template <class Ops, class FrameT>
+void flatten_rig_frame(const FrameT& F, FrameFlat& L, FrameFlat& R) {
+  const int nl = F.Nleft, nr = F.N - F.Nleft;
+  auto fill = [&](FrameFlat& o, const auto& keys, int n, int row0, const void* id) {
+    o.key.id = id; o.key.resident = nullptr;
+    o.kps.resize(n); o.desc.resize((size_t)n * 32);
+    for (int i = 0; i < n; i++) {
+      const auto& kp = keys[i];
+      o.kps[i] = orbx_keypoint{kp.pt.x, kp.pt.y, kp.size, kp.angle, kp.response, (int32_t)kp.octave};
+      std::memcpy(&o.desc[(size_t)32 * i], mat_u8(F.mDescriptors, row0 + i), 32);
+    }
+    o.v = orbm_frame_view{n, o.kps.data(), o.desc.data(), nullptr, nullptr, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY,
+                          F.fx, F.fy, F.cx, F.cy, F.mbf, F.mb, F.mnScaleLevels, F.mfScaleFactor};
+  };
+  fill(L, F.mvKeys, nl, 0, &F);
+  fill(R, F.mvKeysRight, nr, nl, reinterpret_cast<const char*>(&F) + 1);
+}
+template <class Ops, class = void> struct has_rig_matcher : std::false_type {};
+template <class Ops> struct has_rig_matcher<Ops, decltype((void)&Ops::search_mps_rig)> : std::true_type {};
 
 template <class FeatVecT>
 struct FeatVecFlat {          // the std::map in key order
@@ -319,6 +362,90 @@ int isInFrustumAll(FrameT& F, const std::vector<MapPointT*>& vpMPs, float viewin
 //    change index) is seen only at the next refresh.  dropin_parity pins exactly that difference.
 // -DORBGPU_DROPIN_EXACT_LOCAL_MAP forces the first form even with a counter (A/B measurements).
 // A Map type without GetMapChangeIndex() compiles in the two exact forms; the heuristic one needs it (static_assert below).
+// Frame::isInFrustum for every candidate of a two-camera Frame (S/Frame.cc:545-554): both cameras' checks in one device pass; the
+// fields land in the map points as isInFrustumChecks leaves them (:1212-1227), the flags and the -1 levels of :546-551 included.
+// Returns the number of points either camera sees.
+template <class Ops, class FrameT, class MapPointT>
+int isInFrustumRigAll(FrameT& F, const FrameFlat& L, const orbg_camera_rig& rig, const std::vector<MapPointT*>& vpMPs, float viewingCosLimit) {
+  const int M = (int)vpMPs.size();
+  std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M); std::vector<uint8_t> bad(M); std::vector<int32_t> nobs(M);
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = vpMPs[i];
+    const auto X = p->GetWorldPos(); const auto nv = p->GetNormal();
+    std::memcpy(&pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&nrm[3 * (size_t)i], mat_f32(nv), 12);
+    dmin[i] = min_distance_raw(p, 0); dmax[i] = max_distance_raw(p, 0);
+    bad[i] = p->isBad(); nobs[i] = p->Observations();
+  }
+  orbm_worldpoints_view wv{M, pos.data(), nrm.data(), dmin.data(), dmax.data(), nullptr, nobs.data(), bad.data(), nullptr};
+  std::vector<uint8_t> inv[2]; std::vector<float> px[2], py[2], dep[2], vc[2]; std::vector<int32_t> lvl[2];
+  for (int s = 0; s < 2; s++) { inv[s].resize(M); px[s].resize(M); py[s].resize(M); dep[s].resize(M); vc[s].resize(M); lvl[s].resize(M); }
+  check(Ops::is_in_frustum_rig(L.key, L.v, mat_f32(F.mTcw), rig, mat_f32(F.mTlr), wv, viewingCosLimit, inv[0].data(), px[0].data(), py[0].data(),
+                               dep[0].data(), lvl[0].data(), vc[0].data(), inv[1].data(), px[1].data(), py[1].data(), dep[1].data(), lvl[1].data(),
+                               vc[1].data()), "isInFrustum (two cameras)");
+  int n = 0;
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = vpMPs[i];
+    p->mbTrackInView = inv[0][i] != 0; p->mbTrackInViewR = inv[1][i] != 0;
+    p->mnTrackScaleLevel = lvl[0][i]; p->mnTrackScaleLevelR = lvl[1][i];                     // (-1 where the checks failed)
+    if (inv[0][i]) { p->mTrackProjX = px[0][i]; p->mTrackProjY = py[0][i]; p->mTrackDepth = dep[0][i]; p->mTrackViewCos = vc[0][i]; }
+    if (inv[1][i]) { p->mTrackProjXR = px[1][i]; p->mTrackProjYR = py[1][i]; p->mTrackDepthR = dep[1][i]; p->mTrackViewCosR = vc[1][i]; }
+    n += inv[0][i] || inv[1][i];
+  }
+  return n;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) on a two-camera Frame
+// (S/ORBmatcher.cc:44-214 with the right camera's block): the track fields of both cameras as isInFrustum left them in the points.
+template <class Ops, class FrameT, class MapPointT>
+int SearchByProjectionRig(FrameT& F, const FrameFlat& L, const FrameFlat& R, const std::vector<MapPointT*>& vpMapPoints, const float th,
+                          const bool bFarPoints, const float thFarPoints, float mfNNratio) {
+  const int M = (int)vpMapPoints.size();
+  std::vector<uint8_t> inv(M), invr(M), bad(M), desc(32 * (size_t)M); std::vector<float> px(M), py(M), dep(M), vc(M), pxr(M), pyr(M), vcr(M);
+  std::vector<int32_t> lvl(M), lvlr(M), nobs(M);
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = vpMapPoints[i];
+    inv[i] = p->mbTrackInView; invr[i] = p->mbTrackInViewR; bad[i] = p->isBad(); nobs[i] = p->Observations(); dep[i] = p->mTrackDepth;
+    px[i] = p->mTrackProjX; py[i] = p->mTrackProjY; lvl[i] = p->mnTrackScaleLevel; vc[i] = p->mTrackViewCos;
+    pxr[i] = p->mTrackProjXR; pyr[i] = p->mTrackProjYR; lvlr[i] = p->mnTrackScaleLevelR; vcr[i] = p->mTrackViewCosR;
+    const auto Dm = p->GetDescriptor();
+    std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
+  }
+  orbm_mappoints_view mv{M, inv.data(), bad.data(), px.data(), py.data(), px.data(), dep.data(), lvl.data(), vc.data(), desc.data(), nobs.data()};
+  orbm_mappoints_view mvr{M, invr.data(), bad.data(), pxr.data(), pyr.data(), pxr.data(), dep.data(), lvlr.data(), vcr.data(), desc.data(), nobs.data()};
+  std::vector<int32_t> l2r(F.mvLeftToRightMatch.begin(), F.mvLeftToRightMatch.end()), r2l(F.mvRightToLeftMatch.begin(), F.mvRightToLeftMatch.end());
+  l2r.resize((size_t)F.Nleft, -1); r2l.resize((size_t)(F.N - F.Nleft), -1);
+  std::vector<int32_t> amp, aob; flatten_assignments(F, amp, aob);
+  int n = 0;
+  check(Ops::search_mps_rig(L.key, L.v, R.key, R.v, mv, mvr, l2r.data(), r2l.data(), th, bFarPoints, thFarPoints, mfNNratio, amp.data(), aob.data(), &n),
+        "SearchByProjection(F, MPs), two cameras");
+  for (int i = 0; i < F.N; i++)
+    if (amp[i] >= 0 && amp[i] != INT32_MAX) F.mvpMapPoints[i] = vpMapPoints[amp[i]];
+  return n;
+}
+
+// Tracking::SearchLocalPoints on a two-camera Frame: the same three steps (S/Tracking.cc:3083-3155), every point read on every call.
+template <class Ops, class FrameT, class MapPointT>
+int SearchLocalPointsRig(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints, float th, bool bFarPoints, float thFarPoints, float mfNNratio) {
+  orbg_camera_rig rig;
+  if (!make_rig(&F, rig) || !rig.has_right) throw std::runtime_error("orbgpu dropin: a Frame with Nleft != -1 needs mpCamera2");
+  std::vector<MapPointT*> cand;
+  for (MapPointT* pMP : vpLocalMapPoints) {                                                   // :3112-3115
+    if (pMP->mnLastFrameSeen == F.mnId) continue;
+    if (pMP->isBad()) continue;
+    cand.push_back(pMP);
+  }
+  if (cand.empty()) return 0;
+  FrameFlat L, R; flatten_rig_frame<Ops>(F, L, R);
+  isInFrustumRigAll<Ops>(F, L, rig, cand, 0.5f);
+  int nToMatch = 0;
+  for (MapPointT* pMP : cand)
+    if (pMP->mbTrackInView || pMP->mbTrackInViewR) { pMP->IncreaseVisible(); nToMatch++; }    // :3117-3121
+  if (nToMatch == 0) return 0;
+  // (the reference hands SearchByProjection ALL local points: the ones left out here were seen in this frame -- both flags cleared
+  //  above -- or are bad, and SearchByProjection passes over either, :53-60)
+  return SearchByProjectionRig<Ops>(F, L, R, cand, th, bFarPoints, thFarPoints, mfNNratio);
+}
+
 constexpr unsigned kLocalMapMaxAge = 30;
 struct LocalMapCache {
   std::vector<const void*> ptrs;
@@ -363,9 +490,14 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
     pMP->IncreaseVisible();
     pMP->mnLastFrameSeen = F.mnId;
     pMP->mbTrackInView = false;
+    pMP->mbTrackInViewR = false;
   }
   const int M = (int)vpLocalMapPoints.size();
   if (M == 0) return 0;
+  if (F.Nleft != -1) {                                                                        // a two-camera Frame
+    if constexpr (has_rig_matcher<Ops>::value) return SearchLocalPointsRig<Ops>(F, vpLocalMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
+    else throw std::runtime_error("orbgpu dropin: this entry-point set has no two-camera matcher");
+  }
   FrameFlat ff; flatten_frame<Ops>(F, ff);
   LocalMapCache& C = local_map_cache<Ops>();
   // ---- per-frame fields of every point (:3112-3115) + which map / change index the points belong to
@@ -480,6 +612,10 @@ template <class Ops = GpuOps, class FrameT, class MapPointT>
 int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th, const bool bFarPoints,
                        const float thFarPoints, float mfNNratio) {
   const int M = (int)vpMapPoints.size();
+  if (F.Nleft != -1) {
+    if constexpr (has_rig_matcher<Ops>::value) { FrameFlat L, R; flatten_rig_frame<Ops>(F, L, R); return SearchByProjectionRig<Ops>(F, L, R, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio); }
+    else throw std::runtime_error("orbgpu dropin: this entry-point set has no two-camera matcher");
+  }
   FrameFlat ff; flatten_frame<Ops>(F, ff);
   std::vector<uint8_t> inv(M), bad(M), desc(32 * (size_t)M); std::vector<float> px(M), py(M), pxr(M), dep(M), vc(M);
   std::vector<int32_t> lvl(M), nobs(M);
@@ -504,13 +640,17 @@ int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, co
 template <class Ops = GpuOps, class FrameT>
 int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono, bool mbCheckOrientation) {
   const int NL = LastFrame.N;
-  FrameFlat ff; flatten_frame<Ops>(CurrentFrame, ff);
+  const bool kRig = CurrentFrame.Nleft != -1;
+  FrameFlat ff, ffR;
+  if (kRig) flatten_rig_frame<Ops>(CurrentFrame, ff, ffR); else flatten_frame<Ops>(CurrentFrame, ff);
   std::vector<uint8_t> valid(NL), outl(NL), desc(32 * (size_t)NL); std::vector<float> pos(3 * (size_t)NL), ang(NL);
   std::vector<int32_t> oct(NL), nobs(NL);
   for (int i = 0; i < NL; i++) {
     auto* p = LastFrame.mvpMapPoints[i];
     valid[i] = p != nullptr; outl[i] = LastFrame.mvbOutlier[i];
-    oct[i] = LastFrame.mvKeys[i].octave; ang[i] = LastFrame.mvKeysUn[i].angle;
+    const bool lastRight = LastFrame.Nleft != -1 && i >= LastFrame.Nleft;                     // :2018-2019, :2075-2077
+    oct[i] = lastRight ? LastFrame.mvKeysRight[i - LastFrame.Nleft].octave : LastFrame.mvKeys[i].octave;
+    ang[i] = LastFrame.Nleft == -1 ? LastFrame.mvKeysUn[i].angle : lastRight ? LastFrame.mvKeysRight[i - LastFrame.Nleft].angle : LastFrame.mvKeys[i].angle;
     if (p) { const auto Xm = p->GetWorldPos(); const auto Dm = p->GetDescriptor();
              std::memcpy(&pos[3 * (size_t)i], mat_f32(Xm), 12); std::memcpy(&desc[32 * (size_t)i], mat_u8(Dm, 0), 32);
              nobs[i] = p->Observations(); }
@@ -519,11 +659,21 @@ int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const floa
   std::memcpy(lv.Tcw, mat_f32(LastFrame.mTcw), 64);
   std::vector<int32_t> amp, aob; flatten_assignments(CurrentFrame, amp, aob);
   int n = 0;
+  if (kRig) {
+    if constexpr (has_rig_matcher<Ops>::value) {
+      orbg_camera_rig rig;
+      if (!make_rig(&CurrentFrame, rig) || !rig.has_right) throw std::runtime_error("orbgpu dropin: a Frame with Nleft != -1 needs mpCamera2");
+      check(Ops::search_frame_rig(ff.key, ff.v, ffR.key, ffR.v, mat_f32(CurrentFrame.mTcw), rig, lv, th, bMono, mbCheckOrientation, amp.data(),
+                                  aob.data(), &n), "SearchByProjection(Cur, Last), two cameras");
+    } else throw std::runtime_error("orbgpu dropin: this entry-point set has no two-camera matcher");
+  } else
   check(Ops::search_frame(ff.key, ff.v, mat_f32(CurrentFrame.mTcw), lv, th, bMono, mbCheckOrientation, amp.data(), aob.data(), &n),
         "SearchByProjection(Cur, Last)");
-  for (int i = 0; i < CurrentFrame.N; i++)
-    if (amp[i] >= 0 && amp[i] != INT32_MAX) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[amp[i]];   // :2077 (rotation-histogram
-  return n;                                                                                                  //  rejects, :2170, come back as -1)
+  for (int i = 0; i < CurrentFrame.N; i++) {
+    if (amp[i] >= 0 && amp[i] != INT32_MAX) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[amp[i]];   // :2077
+    else if (amp[i] == -1) CurrentFrame.mvpMapPoints[i] = nullptr;      // rotation-histogram rejects (:2170) -- also of a feature that held a point without observations
+  }
+  return n;
 }
 
 // int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,

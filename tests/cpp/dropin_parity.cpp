@@ -366,6 +366,43 @@ int main() {
       EXPECT(std::abs(ng - nc) <= 1 && nd <= 1 && ng > 350 && nb >= 20, "rig frame: inliers %d vs %d, %d flags differ, %d flagged", ng, nc, nd, nb);
       EXPECT(max_abs_diff(pg, pc) <= 1e-4f, "rig frame: pose differs by %g", max_abs_diff(pg, pc));
     }
+    // ---- the matcher on a Frame of that rig (Nleft != -1): Tracking::SearchLocalPoints (isInFrustum through either camera, the
+    // right camera's block of SearchByProjection, stereo partners) and SearchByProjection(CurrentFrame, LastFrame)
+    {
+      struct RigOut { std::vector<long> a_local, a_frame; int n_local = 0, n_frame = 0, vis = 0, seen = 0; std::vector<float> fields; };
+      auto run = [](auto ops_tag, double dz) {
+        using Ops = decltype(ops_tag);
+        RigOut o;
+        Agent A;
+        RigTrack S = build_rig_track_scene(A, 4242, 1200, 250, dz);
+        auto ids = [](const Frame& F, std::vector<long>& out) { out.clear(); for (MapPoint* p : F.mvpMapPoints) out.push_back(p ? (long)p->mnId : -1); };
+        Frame F1(*S.cur);                                          // SearchByProjection(Cur, Last) as TrackWithMotionModel calls it: on an empty frame
+        std::fill(F1.mvpMapPoints.begin(), F1.mvpMapPoints.end(), nullptr);
+        o.n_frame = od::SearchByProjection<Ops>(F1, *S.last, 7.0f, false, true);
+        ids(F1, o.a_frame);
+        o.n_local = od::SearchLocalPoints<Ops>(*S.cur, S.local, 3.0f, true, 7.0f, 0.8f);
+        ids(*S.cur, o.a_local);
+        for (MapPoint* p : S.local) {
+          o.vis += p->mnVisible; o.seen += p->mnLastFrameSeen == S.cur->mnId;
+          if (p->mbTrackInView) { o.fields.push_back(p->mTrackProjX); o.fields.push_back(p->mTrackProjY); o.fields.push_back(p->mTrackDepth); o.fields.push_back(p->mTrackViewCos); o.fields.push_back((float)p->mnTrackScaleLevel); }
+          else o.fields.push_back(-7.f);
+          if (p->mbTrackInViewR) { o.fields.push_back(p->mTrackProjXR); o.fields.push_back(p->mTrackProjYR); o.fields.push_back(p->mTrackDepthR); o.fields.push_back(p->mTrackViewCosR); o.fields.push_back((float)p->mnTrackScaleLevelR); }
+          else o.fields.push_back((float)p->mnTrackScaleLevelR - 9.f);
+        }
+        return o;
+      };
+      for (double dz : {0.02, 0.4, -0.4}) {
+        const RigOut g = run(od::GpuOps{}, dz), c = run(OracleOps{}, dz);
+        int nl = 0, nf = 0; for (size_t i = 0; i < g.a_local.size(); i++) nl += g.a_local[i] != c.a_local[i];
+        for (size_t i = 0; i < g.a_frame.size(); i++) nf += g.a_frame[i] != c.a_frame[i];
+        std::printf("two-camera Frame (last frame %+.2f m): SearchByProjection(Cur, Last) %d matches, SearchLocalPoints %d matches\n", dz, g.n_frame, g.n_local);
+        EXPECT(g.n_frame == c.n_frame && nf == 0 && g.n_frame > 150, "rig frame: SearchByProjection(Cur, Last) %d vs %d, %d features differ", g.n_frame, c.n_frame, nf);
+        EXPECT(g.n_local == c.n_local && nl == 0 && g.n_local > 300, "rig frame: SearchLocalPoints %d vs %d, %d features differ", g.n_local, c.n_local, nl);
+        EXPECT(g.vis == c.vis && g.seen == c.seen && g.seen > 20, "rig frame: visible sums %d vs %d, seen %d vs %d", g.vis, c.vis, g.seen, c.seen);
+        EXPECT(g.fields.size() == c.fields.size() && max_abs_diff(g.fields, c.fields) <= 1e-4f, "rig frame: track fields differ by %g (%zu vs %zu values)",
+               g.fields.size() == c.fields.size() ? max_abs_diff(g.fields, c.fields) : -1.f, g.fields.size(), c.fields.size());
+      }
+    }
     // ---- five consecutive windows of one map (a new keyframe each, points moved / observations erased by the solves in between): the
     // product through the glue's window cache, the oracle reading every point of every window
     {

@@ -46,6 +46,8 @@ class MapPoint {
   long unsigned mnBALocalForKF = ~0ul;
   // fields Frame::isInFrustum stores (S/Frame.cc:529-538)
   bool mbTrackInView = false; float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackDepth = 0, mTrackViewCos = 0; int mnTrackScaleLevel = 0;
+  // ... and Frame::isInFrustumChecks for the right camera of a rig (S/Frame.cc:1212-1218; I/MapPoint.h:208-213)
+  bool mbTrackInViewR = false; float mTrackProjYR = 0, mTrackDepthR = 0, mTrackViewCosR = 0; int mnTrackScaleLevelR = 0;
   int nObs = 0;
   long unsigned mnLastFrameSeen = ~0ul;
   void IncreaseVisible(int n = 1) { mnVisible += n; }                   // S/MapPoint.cc:427-431
@@ -153,6 +155,8 @@ class Frame {
   Mat mTrl{3, 4, 4};
   std::vector<KeyPoint> mvKeysRight;
   int Nleft = -1, Nright = -1;
+  Mat mTlr{3, 4, 4};
+  std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;      // (I/Frame.h:285) stereo partners of the two cameras' features, -1 = none
 };
 
 // the matrix access points include/orbgpu_dropin.hpp asks for

@@ -25,6 +25,21 @@ struct OracleOps {       // the same entry points over the CPU oracle: views ins
                           int32_t* amp, int32_t* aob, int* n) {
     return oracle_search_by_projection_frame(&v, Tcw, &last, th, mono, check_ori, amp, aob, n);
   }
+  static int is_in_frustum_rig(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbg_camera_rig& rig, const float* Tlr,
+                               const orbm_worldpoints_view& pts, float lim, uint8_t* in_view, float* px, float* py, float* depth, int32_t* level,
+                               float* vcos, uint8_t* in_view_r, float* px_r, float* py_r, float* depth_r, int32_t* level_r, float* vcos_r) {
+    return oracle_is_in_frustum_rig(&v, Tcw, &rig, Tlr, &pts, lim, in_view, px, py, depth, level, vcos, in_view_r, px_r, py_r, depth_r, level_r, vcos_r);
+  }
+  static int search_mps_rig(const od::FrameKey&, const orbm_frame_view& vl, const od::FrameKey&, const orbm_frame_view& vr, const orbm_mappoints_view& mps,
+                            const orbm_mappoints_view& mps_r, const int32_t* l2r, const int32_t* r2l, float th, int far_points, float th_far,
+                            float nnratio, int32_t* amp, int32_t* aob, int* n) {
+    return oracle_search_by_projection_mps_rig(&vl, &vr, &mps, &mps_r, l2r, r2l, th, far_points, th_far, nnratio, amp, aob, n);
+  }
+  static int search_frame_rig(const od::FrameKey&, const orbm_frame_view& vl, const od::FrameKey&, const orbm_frame_view& vr, const float* Tcw,
+                              const orbg_camera_rig& rig, const orbm_lastframe_view& last, float th, int mono, int check_ori, int32_t* amp,
+                              int32_t* aob, int* n) {
+    return oracle_search_by_projection_frame_rig(&vl, &vr, Tcw, &rig, &last, th, mono, check_ori, amp, aob, n);
+  }
   static int search_reloc(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
                           const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
     return oracle_search_by_projection_reloc(&v, Tcw, &kf_pts, found, kf_angle, th, orb_dist, check_ori, amp, n);

@@ -336,6 +336,137 @@ static Frame* build_rig_frame(Agent& A, int n_left, int n_right, double outlier_
   return out;
 }
 
+// A tracking scene of the two-fisheye rig for the matcher's two-camera forms (Frame::isInFrustum :545-554, SearchByProjection(Frame,
+// MapPoints) :44-214, SearchByProjection(CurrentFrame, LastFrame) :1970-2186): a local map, a current Frame whose two cameras see its
+// points at noisy positions with descriptors a few bits away (near-twins, distractors, stereo partners, features that already hold a
+// point, points seen in this frame already, bad points), and a two-camera last frame holding some of the points.
+struct RigTrack { Frame* cur = nullptr; Frame* last = nullptr; std::vector<MapPoint*> local; };
+static RigTrack build_rig_track_scene(Agent& A, unsigned seed, int n_points = 1200, int n_distract = 250, double dz_last = 0.02) {
+  g_seed = seed;
+  RigTrack out;
+  const float size = 512.f;
+  std::unique_ptr<Frame> F(new Frame);
+  F->mnId = 7;
+  double R[9]; rot(0.04, -0.06, 0.03, R);
+  const double t[3] = {0.2, -0.1, 0.15};
+  double T[16]; for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0) ? 1 : 0;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * i + j]; T[4 * i + 3] = t[i]; }
+  F->mTcw = mat44(T);
+  double Ow[3]; for (int i = 0; i < 3; i++) Ow[i] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
+  double Trl[12]; rig_Trl(Trl);
+  give_rig(A, F->mpCamera, F->mpCamera2, F->mTrl);
+  // mTlr = mTrl^-1 (in the reference mTlr is the setting and mTrl derived from it, S/Frame.cc:1073-1079)
+  F->mTlr = Mat(3, 4, 4);
+  for (int i = 0; i < 3; i++) {
+    double tt = 0;
+    for (int j = 0; j < 3; j++) { F->mTlr.ptr<float>(0)[4 * i + j] = (float)Trl[4 * j + i]; tt -= Trl[4 * j + i] * Trl[4 * j + 3]; }
+    F->mTlr.ptr<float>(0)[4 * i + 3] = (float)tt;
+  }
+  F->mnMinX = 0; F->mnMaxX = size; F->mnMinY = 0; F->mnMaxY = size; F->fx = KB8_L[0]; F->fy = KB8_L[1]; F->cx = KB8_L[2]; F->cy = KB8_L[3]; F->mbf = 0; F->mb = 0.1f;
+  struct Feat { float x, y; int oct; float angle; uint8_t d[32]; int point; };
+  std::vector<Feat> fl, fr;
+  auto noisy = [&](const uint8_t* d, int bits, uint8_t* o) { std::memcpy(o, d, 32); for (int b = 0; b < bits; b++) { const int k = rnd() % 256; o[k >> 3] ^= (uint8_t)(1u << (k & 7)); } };
+  std::vector<double> base_angle(n_points); std::vector<int> lvl(n_points);
+  for (int i = 0; i < n_points; i++) {
+    const bool via_right = urand() < 0.5;
+    const float* cam = via_right ? KB8_R : KB8_L;
+    const double u = -40 + (size + 80) * urand(), v = -40 + (size + 80) * urand(), depth = 1.5 + 7.5 * urand();
+    const double mx = (u - cam[2]) / cam[0], my = (v - cam[3]) / cam[1], th = std::sqrt(mx * mx + my * my), psi = std::atan2(my, mx);
+    const double Pc[3] = {depth * std::sin(th) * std::cos(psi), depth * std::sin(th) * std::sin(psi), depth * std::cos(th)};
+    double Xl[3];
+    if (via_right) { for (int a = 0; a < 3; a++) Xl[a] = Trl[a] * (Pc[0] - Trl[3]) + Trl[4 + a] * (Pc[1] - Trl[7]) + Trl[8 + a] * (Pc[2] - Trl[11]); }
+    else { for (int a = 0; a < 3; a++) Xl[a] = Pc[a]; }
+    double Xw[3]; for (int a = 0; a < 3; a++) Xw[a] = R[a] * (Xl[0] - t[0]) + R[3 + a] * (Xl[1] - t[1]) + R[6 + a] * (Xl[2] - t[2]);
+    std::unique_ptr<MapPoint> mp(new MapPoint);
+    mp->mnId = 1000 + i; mp->mpMap = &A.map;
+    double d[3] = {Xw[0] - Ow[0], Xw[1] - Ow[1], Xw[2] - Ow[2]};
+    const double dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double spread = urand() < 0.08 ? 0.9 : 0.15;
+    double nv[3], nn = 0; for (int a = 0; a < 3; a++) { nv[a] = d[a] / dist + spread * nrand(); nn += nv[a] * nv[a]; }
+    lvl[i] = rnd() % 8; base_angle[i] = 360 * urand();
+    for (int a = 0; a < 3; a++) { mp->mWorldPos.ptr<float>(0)[a] = (float)Xw[a]; mp->mNormalVector.ptr<float>(0)[a] = (float)(nv[a] / std::sqrt(nn)); }
+    const double maxd = dist * std::pow(1.2, lvl[i] - (0.25 + 0.5 * urand())) * (urand() < 0.03 ? 3.0 : 1.0);
+    mp->mfMaxDistance = (float)maxd; mp->mfMinDistance = (float)(maxd / std::pow(1.2, 7) * (urand() < 0.03 ? 40.0 : 1.0));
+    for (int b = 0; b < 32; b++) mp->mDescriptor.ptr<uint8_t>(0)[b] = (uint8_t)rnd();
+    mp->nObs = urand() < 0.05 ? 0 : 1 + (int)(rnd() % 8);
+    if (urand() < 0.04) mp->mbBad = true;
+    // the two cameras' features of the point
+    const double Xc[3] = {Xl[0], Xl[1], Xl[2]};
+    double Xr[3]; for (int a = 0; a < 3; a++) Xr[a] = Trl[4 * a] * Xc[0] + Trl[4 * a + 1] * Xc[1] + Trl[4 * a + 2] * Xc[2] + Trl[4 * a + 3];
+    for (int side = 0; side < 2; side++) {
+      const double* X = side ? Xr : Xc;
+      if (X[2] <= 0.05 || urand() < 0.25) continue;
+      double uv[2]; kb8_project(side ? KB8_R : KB8_L, X, uv);
+      const double sig = urand() < 0.85 ? 1.2 : 9.0;
+      uv[0] += sig * nrand(); uv[1] += sig * nrand();
+      if (!(uv[0] > 2 && uv[0] < size - 2 && uv[1] > 2 && uv[1] < size - 2)) continue;
+      Feat f; f.x = (float)uv[0]; f.y = (float)uv[1]; f.oct = std::max(0, lvl[i] - (urand() < 0.3 ? 1 : 0)); f.point = i;
+      f.angle = (float)std::fmod(base_angle[i] + 2 * nrand() + (urand() < 0.05 ? 140.0 : 0.0) + 720.0, 360.0);
+      noisy(mp->mDescriptor.ptr<uint8_t>(0), (int)(rnd() % 45), f.d);
+      (side ? fr : fl).push_back(f);
+      if (urand() < 0.15) { Feat g = f; g.x += (float)nrand(); g.y += (float)nrand(); g.point = -1; if (urand() > 0.6) g.oct = std::max(g.oct - 1, 0);
+                            noisy(mp->mDescriptor.ptr<uint8_t>(0), 5 + (int)(rnd() % 45), g.d); g.angle = (float)(360 * urand()); (side ? fr : fl).push_back(g); }
+    }
+    out.local.push_back(mp.get());
+    A.points.push_back(std::move(mp));
+  }
+  for (int side = 0; side < 2; side++) {
+    std::vector<Feat>& v = side ? fr : fl;
+    for (int k = 0; k < n_distract; k++) { Feat f; f.x = (float)(2 + (size - 4) * urand()); f.y = (float)(2 + (size - 4) * urand()); f.oct = rnd() % 8; f.angle = (float)(360 * urand());
+                                           f.point = -1; for (int b = 0; b < 32; b++) f.d[b] = (uint8_t)rnd(); v.push_back(f); }
+    for (size_t k = v.size(); k > 1; k--) std::swap(v[k - 1], v[rnd() % k]);
+  }
+  const int nl = (int)fl.size(), nr = (int)fr.size();
+  F->Nleft = nl; F->Nright = nr; F->N = nl + nr;
+  F->mDescriptors = Mat(F->N, 32, 1);
+  for (int i = 0; i < F->N; i++) {
+    const Feat& f = i < nl ? fl[i] : fr[i - nl];
+    const KeyPoint kp{{f.x, f.y}, 31.f, f.angle, 20.f, f.oct};
+    if (i < nl) F->mvKeys.push_back(kp); else F->mvKeysRight.push_back(kp);
+    std::memcpy(F->mDescriptors.ptr<uint8_t>(i), f.d, 32);
+  }
+  F->mvKeysUn = F->mvKeys;
+  F->mvuRight.assign(F->N, -1.f); F->mvDepth.assign(F->N, -1.f); F->mvbOutlier.assign(F->N, false);
+  float isig[8]; { float s = 1.f; for (int l = 0; l < 8; l++) { isig[l] = 1.f / (s * s); s *= 1.2f; } }
+  F->mvInvLevelSigma2.assign(isig, isig + 8);
+  F->mvLeftToRightMatch.assign(nl, -1); F->mvRightToLeftMatch.assign(nr, -1);
+  { std::map<int, int> where_r; for (int j = 0; j < nr; j++) if (fr[j].point >= 0) where_r[fr[j].point] = j;
+    for (int j = 0; j < nl; j++) { if (fl[j].point < 0 || urand() > 0.4) continue; auto it = where_r.find(fl[j].point);
+                                   if (it != where_r.end()) { F->mvLeftToRightMatch[j] = it->second; F->mvRightToLeftMatch[it->second] = j; } } }
+  // features that already hold a point: some of them local points (which SearchLocalPoints then marks as seen), some foreign ones
+  F->mvpMapPoints.assign(F->N, nullptr);
+  for (int i = 0; i < F->N; i++) {
+    if (urand() > 0.08) continue;
+    if (urand() < 0.5) { F->mvpMapPoints[i] = out.local[rnd() % out.local.size()]; continue; }
+    std::unique_ptr<MapPoint> mp(new MapPoint);
+    mp->mnId = 50000 + i; mp->mpMap = &A.map; mp->nObs = (int)(rnd() % 3);
+    F->mvpMapPoints[i] = mp.get();
+    A.points.push_back(std::move(mp));
+  }
+  out.cur = F.get();
+  A.frames.push_back(std::move(F));
+  // the last frame: two cameras too; its entries hold some of the points
+  std::unique_ptr<Frame> Lf(new Frame(*out.cur));
+  Lf->mnId = 6;
+  const int NL = 700, NLl = 380;
+  Lf->N = NL; Lf->Nleft = NLl; Lf->Nright = NL - NLl;
+  Lf->mvKeys.clear(); Lf->mvKeysRight.clear(); Lf->mvpMapPoints.assign(NL, nullptr); Lf->mvbOutlier.assign(NL, false);
+  for (int i = 0; i < NL; i++) {
+    const int pi = i % n_points;
+    const KeyPoint kp{{0.f, 0.f}, 31.f, (float)std::fmod(base_angle[pi] + 2 * nrand() + 720.0, 360.0), 20.f, std::min(7, std::max(0, lvl[pi] + (int)(rnd() % 3) - 1))};
+    if (i < NLl) Lf->mvKeys.push_back(kp); else Lf->mvKeysRight.push_back(kp);
+    if (urand() < 0.85) Lf->mvpMapPoints[i] = out.local[pi];
+    Lf->mvbOutlier[i] = urand() < 0.06;
+  }
+  Lf->mvKeysUn = Lf->mvKeys;
+  double Tl[16]; for (int i = 0; i < 16; i++) Tl[i] = T[i];
+  Tl[3] += 0.03; Tl[7] += 0.01; Tl[11] += dz_last;
+  Lf->mTcw = mat44(Tl);
+  out.last = Lf.get();
+  A.frames.push_back(std::move(Lf));
+  return out;
+}
+
 // The keyframe after `cur` as LocalMapping would insert it: covisible with `cur` and all but the oldest of its neighbours, observing
 // a third of cur's points (MapPoint::AddObservation: the points' change counters move, as in the reference with INTEGRATION.md's hook).
 static inline KeyFrame* next_keyframe(Agent& B, KeyFrame* cur, int round) {

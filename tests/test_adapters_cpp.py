@@ -95,11 +95,14 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
     LocalBundleAdjustment (graph collection, vToErase, 50 %-outlier early return, pbStopFlag raised before AND -- by a second
     thread, through the reference's own bool -- during the solve, SetPose / SetWorldPos lock flags, Map change index) with the
     reference's signatures; and both optimisers on keyframes / a Frame of the two-fisheye rig (mpCamera2, NLeft: KannalaBrandt8
-    models, the right camera's ToBody edges), with and without the glue's window cache."""
+    models, the right camera's ToBody edges), with and without the glue's window cache; Tracking::SearchLocalPoints and
+    SearchByProjection(CurrentFrame, LastFrame) on a two-camera Frame of that rig (Nleft != -1: isInFrustum through either camera, the
+    right camera's search blocks, stereo partners) -- assignments, visible counts and the track fields left in the map points."""
     exe = _build("dropin_parity", with_oracle=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "dropin parity ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-1000:])
     assert "LocalBundleAdjustment [two-fisheye rig]: status 0" in r.stdout and "PoseOptimization [two-fisheye rig]:" in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("two-camera Frame (last frame") == 3, r.stdout[-3000:]      # the matcher's two-camera forms through the glue
 
 
 def test_closed_loop_scenario_tracks_on_the_oracle_alone():
