@@ -54,6 +54,7 @@ SPREAD=0 python3 tools/search_large_map.py 1 8 32 128 > "$OUT/search_large_map_d
 python3 tools/po_sweep.py 500 > "$OUT/pose_opt_sweep.txt" 2>&1 || true
 python3 tools/vocab_time.py 200 > "$OUT/vocab_full_size.txt" 2>&1 || true
 python3 tools/rig_time.py > "$OUT/rig_time.txt" 2>&1 || true
+python3 tools/rig_match_time.py > "$OUT/rig_match_time.txt" 2>&1 || true
 tests/cpp/closed_loop 200 5 > "$OUT/closed_loop.txt" 2>&1 || true
 bash tools/bench_driver_repeat.sh 5 > "$OUT/bench_driver_repeat.txt" 2>&1 || true
 f=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)

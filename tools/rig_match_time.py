@@ -1,0 +1,50 @@
+"""Wall time of the matcher's two-camera forms (Frame::Nleft != -1: isInFrustum through either camera, SearchByProjection(Frame, MapPoints)
+with the right camera's block, SearchByProjection(CurrentFrame, LastFrame)) next to the CPU oracle on the same scene:
+python tools/rig_match_time.py  (on a GPU box)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from multi_orbslam3_amd import api, synth, views  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+import helpers  # noqa: E402
+
+
+def timed(fn, reps):
+    fn(); fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return 1e6 * float(np.median(ts))
+
+
+def main():
+    for n_points, n_distract in ((1500, 300), (4000, 600)):
+        sc = synth.make_rig_track_scene(n_points=n_points, n_distract=n_distract)
+        fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+        FL, FR = api.Frame().upload(fl, keep[0]), api.Frame().upload(fr, keep[1])
+        a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+        mv, mvr, keep2 = helpers.rig_mappoint_views(sc, a, b)
+        m = api.ORBmatcher(0.8, True)
+        last = synth.rig_last_frame(sc, n_last=min(1000, n_points))
+        lv, keep3 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+        args = (sc["left_to_right"], sc["right_to_left"], 3.0, True, 6.0, sc["assigned_mp"], sc["assigned_obs"])
+        g1 = timed(lambda: FL.isInFrustumRig(sc["Tcw"], rig, sc["Tlr"], wv), 50)
+        o1 = timed(lambda: ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv), 10)
+        g2 = timed(lambda: m.SearchByProjectionRig(FL, FR, mv, mvr, *args), 50)
+        o2 = timed(lambda: ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], 3.0, True, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"]), 10)
+        g3 = timed(lambda: m.SearchByProjectionFrameRig(FL, FR, sc["Tcw"], rig, lv, 7.0, False, sc["assigned_mp"], sc["assigned_obs"]), 50)
+        o3 = timed(lambda: ob.search_by_projection_frame_rig(fl, fr, sc["Tcw"], rig, lv, 7.0, 0, 1, sc["assigned_mp"], sc["assigned_obs"]), 10)
+        print(f"two-camera frame, {len(sc['kps_left'])} + {len(sc['kps_right'])} features, {n_points} map points:")
+        print(f"  isInFrustum (both cameras)                 {g1:7.1f} us   oracle {o1:8.1f} us")
+        print(f"  SearchByProjection(Frame, MapPoints)       {g2:7.1f} us   oracle {o2:8.1f} us")
+        print(f"  SearchByProjection(CurrentFrame, LastFrame) {g3:6.1f} us   oracle {o3:8.1f} us   ({len(last['mp_valid'])} last-frame entries)")
+
+
+if __name__ == "__main__":
+    main()
