@@ -1454,7 +1454,7 @@ def run_dropin_bench():
 
 def rig_parity(api, views):
     """LocalBundleAdjustment and PoseOptimization on keyframes / a Frame of a two-fisheye rig (KannalaBrandt8 models, the right camera's
-    EdgeSE3ProjectXYZToBody edges, S/Optimizer.cc:1085-1151, 2021-2120) against the oracle.  The oracle is the checker here, outside
+    EdgeSE3ProjectXYZToBody edges, S/Optimizer.cc:1085-1151, 2021-2120) and the tracking matchers on a two-camera Frame against the oracle.  The oracle is the checker here, outside
     every timed region."""
     try:
         from multi_orbslam3_amd import synth
@@ -1476,11 +1476,40 @@ def rig_parity(api, views):
         d.update({"pose_opt_max_pose_diff": float(np.abs(g2.Tcw.astype(np.float64) - o2.Tcw.astype(np.float64)).max()),
                   "pose_opt_outlier_flags_differing": int((g2.outliers != o2.outliers).sum()),
                   "pose_opt_inliers": [int(g2.n_inliers), int(o2.n_inliers)]})
+        # the tracking matchers on a two-camera Frame (Nleft != -1): isInFrustum through either camera, SearchByProjection(Frame, MapPoints)
+        # with the right camera's block, SearchByProjection(CurrentFrame, LastFrame) -- S/Frame.cc:545-554, S/ORBmatcher.cc:44-214, 1970-2186
+        sc = synth.make_rig_track_scene()
+        bounds = (0, sc["size"], 0, sc["size"])
+        cam = (sc["left"][1], sc["left"][2], sc["left"][3], sc["left"][4], 0.0, 0.1)
+        fl, k1 = views.frame_view(sc["kps_left"], sc["desc_left"], None, None, bounds, cam)
+        fr, k2 = views.frame_view(sc["kps_right"], sc["desc_right"], None, None, bounds, cam)
+        wv, k3 = views.worldpoints_view(sc["pos"], sc["normal"], sc["min_dist"], sc["max_dist"], sc["desc"], sc["n_obs"], sc["bad"])
+        rig = views.camera_rig(sc["left"], sc["right"], sc["Trl"])
+        FL, FR = api.Frame().upload(fl, k1), api.Frame().upload(fr, k2)
+        gt, ot = FL.isInFrustumRig(sc["Tcw"], rig, sc["Tlr"], wv), ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+        mk = lambda t: views.mappoints_view(t["track_in_view"], sc["bad"], t["proj_x"], t["proj_y"], t["proj_x"], t["track_depth"], t["scale_level"],
+                                            t["view_cos"], sc["desc"], sc["n_obs"])
+        (mv, k4), (mvr, k5) = mk(ot[0]), mk(ot[1])
+        m = api.ORBmatcher(0.8, True)
+        gs = m.SearchByProjectionRig(FL, FR, mv, mvr, sc["left_to_right"], sc["right_to_left"], 3.0, True, 6.0, sc["assigned_mp"], sc["assigned_obs"])
+        os_ = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], 3.0, True, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"])
+        last = synth.rig_last_frame(sc)
+        lv, k6 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+        gf = m.SearchByProjectionFrameRig(FL, FR, sc["Tcw"], rig, lv, 7.0, False, sc["assigned_mp"], sc["assigned_obs"])
+        of = ob.search_by_projection_frame_rig(fl, fr, sc["Tcw"], rig, lv, 7.0, 0, 1, sc["assigned_mp"], sc["assigned_obs"])
+        d.update({"matcher_features": [len(sc["kps_left"]), len(sc["kps_right"])], "matcher_map_points": int(wv.m),
+                  "frustum_flags_and_levels_equal": bool(all(np.array_equal(gt[s_][k], ot[s_][k]) for s_ in (0, 1) for k in ("track_in_view", "scale_level"))),
+                  "frustum_max_projection_diff_px": float(max(np.abs(gt[s_][k].astype(np.float64) - ot[s_][k]).max() for s_ in (0, 1) for k in ("proj_x", "proj_y"))),
+                  "search_map_points_matches": [int(gs[2]), int(os_[2])], "search_map_points_features_differing": int((gs[0] != os_[0]).sum()),
+                  "search_last_frame_matches": [int(gf[2]), int(of[2])], "search_last_frame_features_differing": int((gf[0] != of[0]).sum())})
         d["ok"] = bool(d["lba_iterations_equal"] and d["lba_max_pose_diff"] <= 1e-4 and d["lba_max_point_diff"] <= 1e-4 and
                        d["lba_outlier_flags_differing"] <= 1 and d["pose_opt_max_pose_diff"] <= 1e-5 and
-                       d["pose_opt_outlier_flags_differing"] <= 1)
+                       d["pose_opt_outlier_flags_differing"] <= 1 and d["frustum_flags_and_levels_equal"] and
+                       d["frustum_max_projection_diff_px"] <= 1e-4 and gs[2] == os_[2] > 300 and d["search_map_points_features_differing"] == 0 and
+                       gf[2] == of[2] > 200 and d["search_last_frame_features_differing"] == 0)
         d["what"] = ("8 + 4 keyframes / 600 points of a two-fisheye rig through lba_solve_h, 300 + 200 features through pose_optimize, "
-                     "product vs oracle; tolerances of tests/test_gpu_parity.py (-k rig)")
+                     "isInFrustum / SearchByProjection(F, MPs) / SearchByProjection(Cur, Last) on a two-camera frame; "
+                     "product vs oracle; tolerances of tests/test_gpu_parity.py (-k 'rig or two_camera')")
         return d
     except Exception as e:
         return {"ok": False, "error": repr(e)[:300]}

@@ -551,6 +551,16 @@ int orbm_search_by_projection_frame_rig(orbm_frame* left, orbm_frame* right, con
                                         const orbm_lastframe_view* last, float th, int mono, int check_orientation, int32_t* assigned_mp,
                                         int32_t* assigned_obs, int* nmatches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*>&) with F.Nleft != -1 (S/ORBmatcher.cc:269-471, the branch
+ * :342-430): `f` holds ALL of the Frame's features -- mvKeys then mvKeysRight, descriptor rows as in mDescriptors, indices as in
+ * F.mFeatVec -- and n_left = F.Nleft.  Per keyframe feature the best two of a vocabulary bucket are kept per camera; the left
+ * camera's best passes TH_LOW and the ratio test, the right camera's best only TH_LOW, and only when the left one passed TH_LOW
+ * (:373-428).  kf_angle[i]: the keyframe keypoint's angle (mvKeysUn / mvKeys / mvKeysRight as :379-382 picks).  Other arguments and
+ * `matches` as orbm_search_by_bow. */
+int orbm_search_by_bow_rig(orbm_frame* f, int n_left, const orbm_featvec_view* fv_frame, const uint8_t* kf_desc, int nkf,
+                           const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fv_kf, float nnratio,
+                           int check_orientation, int32_t* matches, int* nmatches);
+
 /* `ur` of an observation made by the RIGHT camera of the rig (get<1>(indexes) != -1, S/Optimizer.cc:2086-2120; i >= Nleft,
  * :1121-1150): u, v are then mvKeysRight[rightIndex].pt and the edge is the *ToBody kind.  In a problem whose rig has a right camera
  * any ur <= -1.5 reads as this (mvuRight is -1 throughout on such frames); in every other problem a negative ur is a monocular

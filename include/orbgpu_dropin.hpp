@@ -167,6 +167,11 @@ struct GpuOps {
                         int32_t* matches, int* n) {
     return orbm_search_by_bow(frame(key, v).handle(), &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
   }
+  static int search_bow_rig(const FrameKey& key, const orbm_frame_view& v_all, int n_left, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf,
+                            const uint8_t* kf_valid, const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori,
+                            int32_t* matches, int* n) {
+    return orbm_search_by_bow_rig(frame(key, v_all).handle(), n_left, &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
+  }
   // the relocalisation overload: the keyframe's points go up as a map of their own (a candidate keyframe is searched once or twice)
   static int search_reloc(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
                           const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
@@ -244,6 +249,20 @@ void flatten_rig_frame(const FrameT& F, FrameFlat& L, FrameFlat& R) {
   };
   fill(L, F.mvKeys, nl, 0, &F);
   fill(R, F.mvKeysRight, nr, nl, reinterpret_cast<const char*>(&F) + 1);
+}
+// ... and ALL of its features as one frame (mvKeys then mvKeysRight: the index space of F.mFeatVec and of mvpMapPoints), for SearchByBoW
+template <class Ops, class FrameT>
+void flatten_rig_frame_all(const FrameT& F, FrameFlat& o) {
+  const int N = F.N, nl = F.Nleft;
+  o.key.id = reinterpret_cast<const char*>(&F) + 2; o.key.resident = nullptr;
+  o.kps.resize(N); o.desc.resize((size_t)N * 32);
+  for (int i = 0; i < N; i++) {
+    const auto& kp = i < nl ? F.mvKeys[i] : F.mvKeysRight[i - nl];
+    o.kps[i] = orbx_keypoint{kp.pt.x, kp.pt.y, kp.size, kp.angle, kp.response, (int32_t)kp.octave};
+    std::memcpy(&o.desc[(size_t)32 * i], mat_u8(F.mDescriptors, i), 32);
+  }
+  o.v = orbm_frame_view{N, o.kps.data(), o.desc.data(), nullptr, nullptr, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY,
+                        F.fx, F.fy, F.cx, F.cy, F.mbf, F.mb, F.mnScaleLevels, F.mfScaleFactor};
 }
 template <class Ops, class = void> struct has_rig_matcher : std::false_type {};
 template <class Ops> struct has_rig_matcher<Ops, decltype((void)&Ops::search_mps_rig)> : std::true_type {};
@@ -715,17 +734,26 @@ template <class Ops = GpuOps, class KeyFrameT, class FrameT, class MapPointT>
 int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches, float mfNNratio, bool mbCheckOrientation) {
   const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
   const int NK = (int)vpMapPointsKF.size();
-  FrameFlat ff; flatten_frame<Ops>(F, ff);
+  const bool kRig = F.Nleft != -1;                                                            // a two-camera Frame: :342-430
+  FrameFlat ff;
+  if (kRig) flatten_rig_frame_all<Ops>(F, ff); else flatten_frame<Ops>(F, ff);
   std::vector<uint8_t> kdesc(32 * (size_t)NK), kvalid(NK); std::vector<float> kang(NK);
   for (int i = 0; i < NK; i++) {
     std::memcpy(&kdesc[32 * (size_t)i], mat_u8(pKF->mDescriptors, i), 32);
     kvalid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();                               // :322-325
-    kang[i] = pKF->mvKeysUn[i].angle;
+    kang[i] = !pKF->mpCamera2 ? pKF->mvKeysUn[i].angle                                          // :379-382
+              : i >= pKF->NLeft ? pKF->mvKeysRight[i - pKF->NLeft].angle : pKF->mvKeys[i].angle;
   }
   FeatVecFlat<decltype(F.mFeatVec)> fF(F.mFeatVec);
   FeatVecFlat<decltype(pKF->mFeatVec)> fK(pKF->mFeatVec);
   std::vector<int32_t> matches(F.N, -1);
   int n = 0;
+  if (kRig) {
+    if constexpr (has_rig_matcher<Ops>::value)
+      check(Ops::search_bow_rig(ff.key, ff.v, F.Nleft, fF.v, kdesc.data(), NK, kvalid.data(), kang.data(), fK.v, mfNNratio, mbCheckOrientation,
+                                matches.data(), &n), "SearchByBoW(KF, F), two cameras");
+    else throw std::runtime_error("orbgpu dropin: this entry-point set has no two-camera matcher");
+  } else
   check(Ops::search_bow(ff.key, ff.v, fF.v, kdesc.data(), NK, kvalid.data(), kang.data(), fK.v, mfNNratio, mbCheckOrientation, matches.data(), &n),
         "SearchByBoW(KF, F)");
   vpMapPointMatches.assign(F.N, static_cast<MapPointT*>(nullptr));                           // :273

@@ -576,6 +576,18 @@ class ORBmatcher:
         return matches[: F.n].copy(), n.value
 
 
+    def SearchByBoWRig(self, F, n_left, fvF, kf_desc, kf_mp_valid, kf_angle, fvK):
+        """SearchByBoW(KeyFrame*, Frame&, ...) on a two-camera Frame (S/ORBmatcher.cc:342-430); F holds all Nleft + Nright features."""
+        kf_desc = np.ascontiguousarray(kf_desc, np.uint8)
+        kf_mp_valid = np.ascontiguousarray(kf_mp_valid, np.uint8)
+        kf_angle = np.ascontiguousarray(kf_angle, np.float32)
+        matches = np.zeros(max(F.n, 1), np.int32)
+        n = C.c_int(0)
+        capi.check(self.lib.orbm_search_by_bow_rig(F.h, int(n_left), C.byref(fvF), _vp(kf_desc), len(kf_desc), _vp(kf_mp_valid), _vp(kf_angle),
+                                                   C.byref(fvK), C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _vp(matches), C.byref(n)),
+                   "orbm_search_by_bow_rig")
+        return matches[: F.n].copy(), n.value
+
     def SearchByProjectionSim3(self, pKF, Scw, points, vpMatched, th, ratioHamming=1.0, already_found=None, with_kfs=False):
         """(KeyFrame*, Scw, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming): S/ORBmatcher.cc:473-587
         (with_kfs=False) and :589-700 (with_kfs=True).  points: LocalMap resident on the device."""

@@ -816,12 +816,15 @@ __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restri
                                                         const uint8_t* __restrict__ tvalid /*target eligibility or NULL*/,
                                                         const uint8_t* __restrict__ kf_desc, const BowJob* __restrict__ jobs,
                                                         int n_jobs, int* list_counter, int* counter_next, uint32_t* list, int list_cap,
-                                                        QResult* results) {
+                                                        QResult* results, int n_left = -1) {
+  // n_left >= 0 (a two-camera Frame, S/ORBmatcher.cc:342-370): the first half of the jobs ranks the left camera's features of a
+  // bucket (index < n_left), the second half -- the same queries again -- the right camera's
   if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;   // the overflow counter the NEXT search on this frame will use
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= n_jobs) return;
   const BowJob job = jobs[j];
+  const int side = n_left >= 0 ? (j >= (n_jobs >> 1) ? 1 : 0) : -1;
   const int total = job.f_end - job.f_begin;
   QResult res;
   int base = j * kSlot;
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(256) void search_bow_kernel(const uint8_t* __restri
   for (int p = lane; p < total; p += 64) {
     const int idx = (int)f_feat_idx[job.f_begin + p];
     unsigned entry = 0xFFFFFFFFu;
-    if (!tvalid || tvalid[idx]) {
+    if ((!tvalid || tvalid[idx]) && (side < 0 || (idx >= n_left) == (side == 1))) {
       const uint4 b0 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32);
       const uint4 b1 = *reinterpret_cast<const uint4*>(fdesc + (size_t)idx * 32 + 16);
       const int d = popc256(a0, a1, b0, b1);
@@ -2217,7 +2220,7 @@ extern "C" int orbm_search_by_projection_frame_resident(orbm_frame* f, const flo
 // SearchByBoW(KeyFrame*, KeyFrame*) (:819-959, by_query = true).  Queries = the flattened pKF / pKF1 side; targets = f.
 static int bow_common(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t* t_valid, const uint8_t* kf_desc, int nkf,
                       const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fvK, float nnratio,
-                      int check_orientation, bool by_query, int32_t* matches, int* nmatches_out) {
+                      int check_orientation, bool by_query, int32_t* matches, int* nmatches_out, int n_left = -1) {
   int rc = select_device(f->device);
   if (rc) return rc;
   const int n = f->fp.n;
@@ -2244,8 +2247,10 @@ static int bow_common(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t
       }
     }
   }
+  const int nq = (int)jobs.size();                         // queries: the valid KF features in the merge-join's order
+  if (nq == 0) return ORBG_OK;
+  if (n_left >= 0) jobs.insert(jobs.end(), jobs.begin(), jobs.begin() + nq);   // (two-camera Frame) ... once per camera
   const int nj = (int)jobs.size();
-  if (nj == 0) return ORBG_OK;
   const int nfi = (int)fvF->start[fvF->n_nodes];
   for (int i = 0; i < nfi; i++)
     if ((int)fvF->feat_idx[i] >= n) return ORBG_BAD_ARG;
@@ -2258,7 +2263,7 @@ static int bow_common(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t
   if ((rc = stage_commit(f))) return rc;
   rc = run_search(f, nj, [&](int list_cap, int* cnt, int* cnt_next) {
     hipLaunchKernelGGL(search_bow_kernel, dim3((nj + 3) / 4), dim3(256), 0, st, f->desc_p, d_fidx, d_tvalid, d_kfdesc,
-                       d_jobs, nj, cnt, cnt_next, f->list.d, list_cap, f->results.d);
+                       d_jobs, nj, cnt, cnt_next, f->list.d, list_cap, f->results.d, n_left);
   });
   if (rc) return rc;
   cache_keypoint_fields(f);
@@ -2268,6 +2273,29 @@ static int bow_common(orbm_frame* f, const orbm_featvec_view* fvF, const uint8_t
   int nmatches = 0;
   const QResult* R = f->results.h;
   auto is_taken = [&](int idx) { return taken[idx] != 0; };
+  if (n_left >= 0) {                                       // S/ORBmatcher.cc:342-430: the best two per camera; the right camera's best under the left's gate
+    for (int j = 0; j < nq; j++) {
+      Pick pl, pr;
+      if (R[j].n_top == 0) continue;                       // no left candidate: bestDist1 = 256 > TH_LOW, neither block runs
+      if ((rc = pick_unclaimed(f, R[j], 2, is_taken, &pl))) return rc;
+      if (pl.idx1 < 0 || pl.dist1 > TH_LOW) continue;
+      if (R[nq + j].n_top && (rc = pick_unclaimed(f, R[nq + j], 1, is_taken, &pr))) return rc;
+      const int q = jobs[j].kf_idx;
+      if (static_cast<float>(pl.dist1) < nnratio * static_cast<float>(pl.dist2)) {
+        taken[pl.idx1] = 1; matches[pl.idx1] = q;
+        if (check_orientation) rotHist.add(rot_bin(kf_angle[q], f->hk_angle[pl.idx1]), pl.idx1);
+        nmatches++;
+      }
+      if (pr.idx1 >= 0 && pr.dist1 <= TH_LOW) {            // (`|| true`, :401: no ratio test)
+        taken[pr.idx1] = 1; matches[pr.idx1] = q;
+        if (check_orientation) rotHist.add(rot_bin(kf_angle[q], f->hk_angle[pr.idx1]), pr.idx1);
+        nmatches++;
+      }
+    }
+    if (check_orientation) rotHist.reject_outside_three_maxima([&](int idx) { matches[idx] = -1; nmatches--; });
+    if (nmatches_out) *nmatches_out = nmatches;
+    return ORBG_OK;
+  }
   for (int j = 0; j < nj; j++) {
     __builtin_prefetch(&R[j + 16]);
     const QResult& r = R[j];
@@ -2299,6 +2327,15 @@ extern "C" int orbm_search_by_bow(orbm_frame* f, const orbm_featvec_view* fvF, c
   return bow_common(f, fvF, nullptr, kf_desc, nkf, kf_mp_valid, kf_angle, fvK, nnratio, check_orientation, false, matches,
                     nmatches_out);
 }
+
+extern "C" int orbm_search_by_bow_rig(orbm_frame* f, int n_left, const orbm_featvec_view* fvF, const uint8_t* kf_desc, int nkf,
+                                      const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fvK, float nnratio,
+                                      int check_orientation, int32_t* matches, int* nmatches_out) {
+  if (!f || !fvF || !fvK || !kf_desc || !kf_mp_valid || !matches || nkf < 0 || (check_orientation && !kf_angle) || n_left < 0 || n_left > f->fp.n)
+    return ORBG_BAD_ARG;
+  return bow_common(f, fvF, nullptr, kf_desc, nkf, kf_mp_valid, kf_angle, fvK, nnratio, check_orientation, false, matches, nmatches_out, n_left);
+}
+
 
 extern "C" int orbm_search_by_bow_kf(orbm_frame* kf2, const orbm_featvec_view* fv2, const uint8_t* mp_valid2,
                                      const uint8_t* desc1, int n1, const uint8_t* mp_valid1, const float* angle1,

@@ -400,6 +400,18 @@ def search_by_bow(fv, fvF, kf_desc, kf_mp_valid, kf_angle, fvK, nnratio, check_o
     return matches[: fv.n].copy(), n.value
 
 
+def search_by_bow_rig(fv, n_left, fvF, kf_desc, kf_mp_valid, kf_angle, fvK, nnratio, check_ori):
+    kf_desc = np.ascontiguousarray(kf_desc, np.uint8)
+    kf_mp_valid = np.ascontiguousarray(kf_mp_valid, np.uint8)
+    kf_angle = np.ascontiguousarray(kf_angle, np.float32)
+    matches = np.zeros(max(fv.n, 1), np.int32)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_bow_rig(C.byref(fv), int(n_left), C.byref(fvF), C.c_void_p(kf_desc.ctypes.data), len(kf_desc),
+                                        C.c_void_p(kf_mp_valid.ctypes.data), C.c_void_p(kf_angle.ctypes.data), C.byref(fvK), C.c_float(nnratio),
+                                        int(check_ori), C.c_void_p(matches.ctypes.data), C.byref(n)))
+    return matches[: fv.n].copy(), n.value
+
+
 def search_by_projection_sim3(kf, pts, Scw, matched, th, ratio_hamming=1.0, already_found=None, with_kfs=False):
     matched = np.ascontiguousarray(matched, np.int32).copy()
     S = np.ascontiguousarray(Scw, np.float32).reshape(16)

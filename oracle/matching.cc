@@ -686,6 +686,65 @@ extern "C" int oracle_search_by_projection_frame(const orbm_frame_view* cur, con
 }
 
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) -- S/ORBmatcher.cc:269-471, Nleft == -1.
+// SearchByBoW(KeyFrame*, Frame&, ...) on a two-camera Frame (F.Nleft != -1) -- S/ORBmatcher.cc:342-430: `view` holds all N = Nleft +
+// Nright features (mvKeys then mvKeysRight; descriptor rows as in mDescriptors), the best two of a bucket are kept per camera, the right
+// camera's best is taken -- without a ratio test (`|| true`, :401) -- only under the left one's `bestDist1 <= TH_LOW` (:373-399).
+extern "C" int oracle_search_by_bow_rig(const orbm_frame_view* view, int n_left, const orbm_featvec_view* fvF, const uint8_t* kf_desc, int nkf,
+                                        const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fvK, float nnratio,
+                                        int check_ori, int32_t* matches, int* nmatches_out) {
+  (void)nkf;
+  for (int i = 0; i < view->n; i++) matches[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int k = 0, f = 0;
+  while (k < fvK->n_nodes && f < fvF->n_nodes) {
+    if (fvK->node_id[k] == fvF->node_id[f]) {
+      for (uint32_t a = fvK->start[k]; a < fvK->start[k + 1]; a++) {
+        const uint32_t realIdxKF = fvK->feat_idx[a];
+        if (!kf_mp_valid[realIdxKF]) continue;
+        const uint8_t* dKF = kf_desc + 32 * (size_t)realIdxKF;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256, bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+        for (uint32_t b = fvF->start[f]; b < fvF->start[f + 1]; b++) {
+          const int realIdxF = (int)fvF->feat_idx[b];
+          if (matches[realIdxF] >= 0) continue;
+          const int dist = oracle_hamming(dKF, view->desc + 32 * (size_t)realIdxF);
+          if (realIdxF < n_left && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+          else if (realIdxF < n_left && dist < bestDist2) bestDist2 = dist;
+          if (realIdxF >= n_left && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+          else if (realIdxF >= n_left && dist < bestDist2R) bestDist2R = dist;
+        }
+        if (bestDist1 <= TH_LOW) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches[bestIdxF] = (int)realIdxKF;
+            if (check_ori) rotHist[rot_bin(kf_angle[realIdxKF], view->kps[bestIdxF].angle)].push_back(bestIdxF);
+            nmatches++;
+          }
+          if (bestDist1R <= TH_LOW) {
+            matches[bestIdxFR] = (int)realIdxKF;
+            if (check_ori) rotHist[rot_bin(kf_angle[realIdxKF], view->kps[bestIdxFR].angle)].push_back(bestIdxFR);
+            nmatches++;
+          }
+        }
+      }
+      k++; f++;
+    } else if (fvK->node_id[k] < fvF->node_id[f]) {
+      k = (int)(std::lower_bound(fvK->node_id, fvK->node_id + fvK->n_nodes, fvF->node_id[f]) - fvK->node_id);
+    } else {
+      f = (int)(std::lower_bound(fvF->node_id, fvF->node_id + fvF->n_nodes, fvK->node_id[k]) - fvF->node_id);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { matches[idx] = -1; nmatches--; }
+    }
+  }
+  if (nmatches_out) *nmatches_out = nmatches;
+  return ORBG_OK;
+}
+
 extern "C" int oracle_search_by_bow(const orbm_frame_view* view, const orbm_featvec_view* fvF,
                                     const uint8_t* kf_desc, int nkf, const uint8_t* kf_mp_valid, const float* kf_angle,
                                     const orbm_featvec_view* fvK, float nnratio, int check_ori,

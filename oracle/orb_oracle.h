@@ -107,6 +107,10 @@ int oracle_search_by_projection_mps_rig(const orbm_frame_view* left, const orbm_
 int oracle_search_by_projection_frame_rig(const orbm_frame_view* left, const orbm_frame_view* right, const float* Tcw_cur,
                                           const orbg_camera_rig* rig, const orbm_lastframe_view* last, float th, int mono,
                                           int check_orientation, int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);
+/* SearchByBoW(KeyFrame*, Frame&, ...) with F.Nleft != -1 (S/ORBmatcher.cc:342-430): view = all Nleft + Nright features */
+int oracle_search_by_bow_rig(const orbm_frame_view* view, int n_left, const orbm_featvec_view* fv_frame, const uint8_t* kf_desc, int nkf,
+                             const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fv_kf, float nnratio,
+                             int check_orientation, int32_t* matches, int* nmatches);
 int oracle_search_local_points(const orbm_frame_view* view, const orbm_worldpoints_view* pts, const float* Tcw,
                                float th, int far_points, float th_far_points, float nnratio,
                                int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);

@@ -369,7 +369,7 @@ int main() {
     // ---- the matcher on a Frame of that rig (Nleft != -1): Tracking::SearchLocalPoints (isInFrustum through either camera, the
     // right camera's block of SearchByProjection, stereo partners) and SearchByProjection(CurrentFrame, LastFrame)
     {
-      struct RigOut { std::vector<long> a_local, a_frame; int n_local = 0, n_frame = 0, vis = 0, seen = 0; std::vector<float> fields; };
+      struct RigOut { std::vector<long> a_local, a_frame, a_bow; int n_local = 0, n_frame = 0, n_bow = 0, vis = 0, seen = 0; std::vector<float> fields; };
       auto run = [](auto ops_tag, double dz) {
         using Ops = decltype(ops_tag);
         RigOut o;
@@ -380,6 +380,9 @@ int main() {
         std::fill(F1.mvpMapPoints.begin(), F1.mvpMapPoints.end(), nullptr);
         o.n_frame = od::SearchByProjection<Ops>(F1, *S.last, 7.0f, false, true);
         ids(F1, o.a_frame);
+        { std::vector<MapPoint*> vm;                               // SearchByBoW(KF, F) as TrackReferenceKeyFrame calls it
+          o.n_bow = od::SearchByBoW<Ops>(S.ref, *S.cur, vm, 0.7f, true);
+          for (MapPoint* p : vm) o.a_bow.push_back(p ? (long)p->mnId : -1); }
         o.n_local = od::SearchLocalPoints<Ops>(*S.cur, S.local, 3.0f, true, 7.0f, 0.8f);
         ids(*S.cur, o.a_local);
         for (MapPoint* p : S.local) {
@@ -395,9 +398,10 @@ int main() {
         const RigOut g = run(od::GpuOps{}, dz), c = run(OracleOps{}, dz);
         int nl = 0, nf = 0; for (size_t i = 0; i < g.a_local.size(); i++) nl += g.a_local[i] != c.a_local[i];
         for (size_t i = 0; i < g.a_frame.size(); i++) nf += g.a_frame[i] != c.a_frame[i];
-        std::printf("two-camera Frame (last frame %+.2f m): SearchByProjection(Cur, Last) %d matches, SearchLocalPoints %d matches\n", dz, g.n_frame, g.n_local);
+        std::printf("two-camera Frame (last frame %+.2f m): SearchByProjection(Cur, Last) %d matches, SearchLocalPoints %d matches, SearchByBoW(KF, F) %d matches\n", dz, g.n_frame, g.n_local, g.n_bow);
         EXPECT(g.n_frame == c.n_frame && nf == 0 && g.n_frame > 150, "rig frame: SearchByProjection(Cur, Last) %d vs %d, %d features differ", g.n_frame, c.n_frame, nf);
         EXPECT(g.n_local == c.n_local && nl == 0 && g.n_local > 300, "rig frame: SearchLocalPoints %d vs %d, %d features differ", g.n_local, c.n_local, nl);
+        EXPECT(g.n_bow == c.n_bow && g.a_bow == c.a_bow && g.n_bow > 100, "rig frame: SearchByBoW(KF, F) %d vs %d matches", g.n_bow, c.n_bow);
         EXPECT(g.vis == c.vis && g.seen == c.seen && g.seen > 20, "rig frame: visible sums %d vs %d, seen %d vs %d", g.vis, c.vis, g.seen, c.seen);
         EXPECT(g.fields.size() == c.fields.size() && max_abs_diff(g.fields, c.fields) <= 1e-4f, "rig frame: track fields differ by %g (%zu vs %zu values)",
                g.fields.size() == c.fields.size() ? max_abs_diff(g.fields, c.fields) : -1.f, g.fields.size(), c.fields.size());

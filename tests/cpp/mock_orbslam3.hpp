@@ -114,7 +114,7 @@ class KeyFrame {
   long unsigned mnId = 0; uint8_t mnClientId = 0;
   long unsigned mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul;
   float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
-  std::vector<KeyPoint> mvKeysUn; std::vector<float> mvuRight, mvInvLevelSigma2;
+  std::vector<KeyPoint> mvKeys, mvKeysUn; std::vector<float> mvuRight, mvInvLevelSigma2;
   // (I/KeyFrame.h:634-648) the cameras and, for the two-fisheye rig, the right camera's keypoints
   GeometricCamera* mpCamera = nullptr; GeometricCamera* mpCamera2 = nullptr;
   Mat mTrl{3, 4, 4};

@@ -340,7 +340,7 @@ static Frame* build_rig_frame(Agent& A, int n_left, int n_right, double outlier_
 // MapPoints) :44-214, SearchByProjection(CurrentFrame, LastFrame) :1970-2186): a local map, a current Frame whose two cameras see its
 // points at noisy positions with descriptors a few bits away (near-twins, distractors, stereo partners, features that already hold a
 // point, points seen in this frame already, bad points), and a two-camera last frame holding some of the points.
-struct RigTrack { Frame* cur = nullptr; Frame* last = nullptr; std::vector<MapPoint*> local; };
+struct RigTrack { Frame* cur = nullptr; Frame* last = nullptr; std::vector<MapPoint*> local; KeyFrame* ref = nullptr; };
 static RigTrack build_rig_track_scene(Agent& A, unsigned seed, int n_points = 1200, int n_distract = 250, double dz_last = 0.02) {
   g_seed = seed;
   RigTrack out;
@@ -464,6 +464,30 @@ static RigTrack build_rig_track_scene(Agent& A, unsigned seed, int n_points = 12
   Lf->mTcw = mat44(Tl);
   out.last = Lf.get();
   A.frames.push_back(std::move(Lf));
+  // the reference keyframe of TrackReferenceKeyFrame: a two-camera keyframe whose features hold the first 900 points (descriptors a few
+  // bits off, angles near the current features'); feature vectors of both over a stand-in vocabulary (word = the descriptor's leading bits)
+  {
+    std::unique_ptr<KeyFrame> kf(new KeyFrame);
+    kf->mnId = 3; kf->mpMap = &A.map;
+    kf->mpCamera = out.cur->mpCamera; kf->mpCamera2 = out.cur->mpCamera2; kf->mTrl = out.cur->mTrl;
+    const int NK = std::min(900, n_points), NKl = (NK * 4) / 7;
+    kf->NLeft = NKl; kf->NRight = NK - NKl;
+    kf->mDescriptors = Mat(NK, 32, 1);
+    kf->mvpMapPoints.assign(NK, nullptr);
+    for (int i = 0; i < NK; i++) {
+      const KeyPoint kp{{0.f, 0.f}, 31.f, (float)std::fmod(base_angle[i] + 2 * nrand() + 720.0, 360.0), 20.f, lvl[i]};
+      if (i < NKl) kf->mvKeys.push_back(kp); else kf->mvKeysRight.push_back(kp);
+      uint8_t* d = kf->mDescriptors.ptr<uint8_t>(i);
+      std::memcpy(d, out.local[i]->mDescriptor.ptr<uint8_t>(0), 32);
+      for (int b = 0, nb = (int)(rnd() % 24); b < nb; b++) { const int k = 8 + rnd() % 248; d[k >> 3] ^= (uint8_t)(1u << (k & 7)); }    // (byte 0 kept: the word)
+      if (urand() < 0.85) kf->mvpMapPoints[i] = out.local[i];
+      kf->mFeatVec[d[0] >> 3].push_back((unsigned)i);
+    }
+    kf->mvKeysUn = kf->mvKeys;
+    for (int i = 0; i < out.cur->N; i++) out.cur->mFeatVec[out.cur->mDescriptors.ptr<uint8_t>(i)[0] >> 3].push_back((unsigned)i);
+    out.ref = kf.get();
+    A.kfs.push_back(std::move(kf));
+  }
   return out;
 }
 

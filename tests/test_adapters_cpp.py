@@ -95,8 +95,8 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
     LocalBundleAdjustment (graph collection, vToErase, 50 %-outlier early return, pbStopFlag raised before AND -- by a second
     thread, through the reference's own bool -- during the solve, SetPose / SetWorldPos lock flags, Map change index) with the
     reference's signatures; and both optimisers on keyframes / a Frame of the two-fisheye rig (mpCamera2, NLeft: KannalaBrandt8
-    models, the right camera's ToBody edges), with and without the glue's window cache; Tracking::SearchLocalPoints and
-    SearchByProjection(CurrentFrame, LastFrame) on a two-camera Frame of that rig (Nleft != -1: isInFrustum through either camera, the
+    models, the right camera's ToBody edges), with and without the glue's window cache; Tracking::SearchLocalPoints,
+    SearchByProjection(CurrentFrame, LastFrame) and SearchByBoW(KeyFrame, Frame) on a two-camera Frame of that rig (Nleft != -1: isInFrustum through either camera, the
     right camera's search blocks, stereo partners) -- assignments, visible counts and the track fields left in the map points."""
     exe = _build("dropin_parity", with_oracle=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)

@@ -67,6 +67,9 @@ def test_bench_line_has_the_contract_fields():
     rg = pr["camera_rig"]
     assert rg["ok"] is True and rg["lba_right_camera_edges"] > 500 and rg["lba_iterations_equal"] and rg["lba_max_pose_diff"] <= 1e-4
     assert rg["pose_opt_max_pose_diff"] <= 1e-5
+    # ... and Tracking's matchers on a two-camera frame of that rig
+    assert rg["frustum_flags_and_levels_equal"] and rg["search_map_points_features_differing"] == 0 and rg["search_last_frame_features_differing"] == 0
+    assert rg["search_map_points_matches"][0] == rg["search_map_points_matches"][1] > 300
 
 
 @pytest.mark.gpu

@@ -2025,3 +2025,45 @@ def test_search_by_projection_last_frame_on_a_two_camera_frame(case):
         assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1]), th
     with pytest.raises(capi.OrbGpuError):
         m.SearchByProjectionFrameRig(FL, FL, sc["Tcw"], rig, lv, 7.0, mono, sc["assigned_mp"], sc["assigned_obs"])
+
+
+def _rig_bow_scene(sc, n_kf=900, seed=9, shift=5):
+    """A keyframe holding the scene's first n_kf points (descriptors a few bits off the points', angles near the frame features'), the
+    two-camera frame's ALL-features view, and the two feature vectors over a stand-in vocabulary (node = leading descriptor bits)."""
+    rng = np.random.RandomState(seed)
+    kps = np.concatenate([sc["kps_left"], sc["kps_right"]]); desc = np.concatenate([sc["desc_left"], sc["desc_right"]])
+    bounds = (0, sc["size"], 0, sc["size"])
+    fv, keep = views.frame_view(kps, desc, None, None, bounds, (sc["left"][1], sc["left"][2], sc["left"][3], sc["left"][4], 0.0, 0.1))
+    kf_desc = sc["desc"][:n_kf].copy()
+    flips = rng.randint(0, 256, kf_desc.shape).astype(np.uint8) & rng.randint(0, 256, kf_desc.shape).astype(np.uint8) & rng.randint(0, 256, kf_desc.shape).astype(np.uint8) \
+        & rng.randint(0, 256, kf_desc.shape).astype(np.uint8)
+    flips[:, 0] &= 0x07                                   # (keep the node bits: the vocabulary puts near descriptors into one word)
+    kf_desc ^= flips
+    kf_angle = ((sc["base_angle"][:n_kf] + rng.randn(n_kf) * 2.0) % 360.0).astype(np.float32)
+    valid = (rng.rand(n_kf) < 0.85).astype(np.uint8)
+    node = lambda d: d[:, 0].astype(np.int64) >> shift
+    fvF, kF = views.featvec_view(*views.featvec_from_nodes(node(desc)))
+    fvK, kK = views.featvec_view(*views.featvec_from_nodes(node(kf_desc)))
+    return fv, keep, fvF, fvK, kf_desc, kf_angle, valid, [kF, kK]
+
+
+@pytest.mark.parametrize("case", ["fine_nodes", "coarse_nodes", "no_orientation_check", "no_right_features_in_the_vectors"])
+def test_search_by_bow_on_a_two_camera_frame(case):
+    """ORBmatcher::SearchByBoW(KeyFrame, Frame) with F.Nleft != -1 (S/ORBmatcher.cc:342-430): the best two of a bucket per camera, the
+    left camera's best through TH_LOW and the ratio test, the right camera's through TH_LOW alone and only under the left's gate, both
+    written into vpMapPointMatches and the rotation histogram -- matches and count equal the oracle's."""
+    sc = synth.make_rig_track_scene()
+    shift = 3 if case == "fine_nodes" else 5
+    fv, keep, fvF, fvK, kf_desc, kf_angle, valid, keep2 = _rig_bow_scene(sc, shift=shift)
+    nl = len(sc["kps_left"])
+    n_left = fv.n if case == "no_right_features_in_the_vectors" else nl      # (every feature counts as the left camera's: the single-camera rule per bucket)
+    check = case != "no_orientation_check"
+    F = api.Frame().upload(fv, keep)
+    g = api.ORBmatcher(0.7, check).SearchByBoWRig(F, n_left, fvF, kf_desc, valid, kf_angle, fvK)
+    o = ob.search_by_bow_rig(fv, n_left, fvF, kf_desc, valid, kf_angle, fvK, 0.7, check)
+    assert g[1] == o[1] and np.array_equal(g[0], o[0]), case
+    if case == "no_right_features_in_the_vectors":
+        s = ob.search_by_bow(fv, fvF, kf_desc, valid, kf_angle, fvK, 0.7, check)
+        assert s[1] == o[1] and np.array_equal(s[0], o[0])
+    else:
+        assert o[1] > 150 and (o[0][:nl] >= 0).sum() > 60 and (o[0][nl:] >= 0).sum() > 60, (o[1], (o[0][:nl] >= 0).sum(), (o[0][nl:] >= 0).sum())

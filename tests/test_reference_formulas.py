@@ -1270,12 +1270,15 @@ class CppMap:
         return CppMap.It(self, bisect.bisect_left(self.keys, key))
 
 
+@pytest.mark.parametrize("rig", [False, True])
 @pytest.mark.parametrize("check", [True, False])
-def test_searchbybow_of_a_keyframe_is_the_references_text(check):
+def test_searchbybow_of_a_keyframe_is_the_references_text(check, rig):
     """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) -- S/ORBmatcher.cc:269-471 -- WHOLE: the merge of the two
     FeatureVectors (equal node: match inside it; else lower_bound on the one behind), best / second-best Hamming per keyframe feature over
     the frame features of the node that are still free, TH_LOW and the float ratio test, the rotation histogram -- transliterated from
-    the text (std::map stand-in with lower_bound) -- against the oracle's matches."""
+    the text (std::map stand-in with lower_bound) -- against the oracle's matches.  rig: the same text with F.Nleft != -1 and two-camera
+    keyframe / frame stand-ins (:342-430: best two per camera, the right camera's best under the left one's gate and without a ratio
+    test, keypoints from mvKeys / mvKeysRight) against the oracle's rig form."""
     path = os.path.join(REF, "src", "ORBmatcher.cc")
     body = _body(path, r"int\s+ORBmatcher::SearchByBoW\s*\(\s*KeyFrame\*\s*pKF,\s*Frame\s*&F,[^)]*\)\s*\{")
     body = body.replace("unsigned int", "unsigned").replace("static_cast<float>(", "F32(").replace(".push_back(", ".append(")
@@ -1317,7 +1320,11 @@ def test_searchbybow_of_a_keyframe_is_the_references_text(check):
     fv, keep = views.frame_view(kps, fdesc, bounds=(0, 640, 0, 480), cam=(458.6, 457.3, 320.0, 240.0, 38.0, 0.08))
     nF, sF, iF = views.featvec_from_nodes(fnode); nK, sK, iK = views.featvec_from_nodes(knode)
     fvF, k1 = views.featvec_view(nF, sF, iF); fvK, k2 = views.featvec_view(nK, sK, iK)
-    matches, nm = ob.search_by_bow(fv, fvF, kdesc, valid, kangle, fvK, 0.7, check)
+    n_left, nkf_left = (n * 5) // 9, (nkf * 4) // 7
+    if rig:
+        matches, nm = ob.search_by_bow_rig(fv, n_left, fvF, kdesc, valid, kangle, fvK, 0.7, check)
+    else:
+        matches, nm = ob.search_by_bow(fv, fvF, kdesc, valid, kangle, fvK, 0.7, check)
     # ---- the reference's text on stand-ins
     env = dict(ENV, F32=F32, F64=F64, TH_LOW=50, HISTO_LENGTH=30, mbCheckOrientation=check, mfNNratio=F32(0.7),
                round=lambda a: int(np.copysign(np.floor(np.abs(F64(a)) + 0.5), a)), DescriptorDistance=lambda a, b: int(np.unpackbits(a ^ b).sum()))
@@ -1332,12 +1339,18 @@ def test_searchbybow_of_a_keyframe_is_the_references_text(check):
     pKF.mvKeysUn = [Kp(a) for a in kangle]; pKF.mvKeys = pKF.mvKeysUn; pKF.mvKeysRight = []
     F.N = n; F.Nleft = -1; F.mpCamera2 = None; F.mDescriptors = Desc(fdesc); F.mvKeys = [Kp(a) for a in fangle]; F.mvKeysRight = []
     F.mFeatVec = CppMap({int(k): [int(v) for v in np.nonzero(fnode == k)[0]] for k in np.unique(fnode)})
+    if rig:
+        pKF.mpCamera2 = Obj(); pKF.NLeft = nkf_left; pKF.mvKeys = [Kp(a) for a in kangle[:nkf_left]]; pKF.mvKeysRight = [Kp(a) for a in kangle[nkf_left:]]
+        pKF.mvKeysUn = None
+        F.mpCamera2 = Obj(); F.Nleft = n_left; F.mvKeys = [Kp(a) for a in fangle[:n_left]]; F.mvKeysRight = [Kp(a) for a in fangle[n_left:]]
     exec(prog, env)
     out = []
     nm_ref = env["SearchByBoW"](pKF, F, out)
     mine = np.array([-1 if p_ is None else p_.id for p_ in out], np.int32)
-    assert nm_ref == nm and nm > 150, (nm_ref, nm)
+    assert nm_ref == nm and nm > (100 if rig else 150), (nm_ref, nm)
     assert np.array_equal(mine, matches), np.nonzero(mine != matches)[0][:10]
+    if rig:
+        assert (matches[:n_left] >= 0).sum() > 30 and (matches[n_left:] >= 0).sum() > 30
 
 
 def test_bag_of_words_transform_is_dbow2s_text():
