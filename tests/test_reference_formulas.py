@@ -3261,3 +3261,153 @@ def test_glues_searchlocalpoints_is_trackings_own_text():
             q = pts[pid]
             assert (q.mnLastFrameSeen, q.visible, int(bool(q.mbTrackInView))) == (last_seen, visible, in_view), (sc["scene"], pid, q.mnLastFrameSeen, q.visible, q.mbTrackInView, last_seen, visible, in_view)
         assert sum(1 for a, b in zip(fd["held_before"], res["held_after"]) if a != b) > (5 if sc["scene"] == 2 else 150)
+
+
+def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
+    """include/orbgpu_dropin.hpp's SearchLocalPoints on a two-camera Frame (Nleft != -1; run host-only over the oracle's entry points by
+    tests/cpp/glue_track_rig_dump) against Tracking::SearchLocalPoints' OWN text (S/Tracking.cc:3083-3155) with the Nleft != -1 branch of
+    Frame::isInFrustum, Frame::isInFrustumChecks, KannalaBrandt8::project, MapPoint::PredictScale, Frame::GetFeaturesInArea (both
+    ternaries) and ORBmatcher::SearchByProjection transliterated below it, on Python stand-ins of the same scene: which of the
+    Nleft + Nright features hold which point afterwards, every point's mnLastFrameSeen, visible count, both cameras' flags, levels and
+    -- where a camera sees the point -- the float32 bits of its track fields.  Two scenes (regular; th = 5 with the far-point filter)."""
+    import ctypes
+    import json
+    import subprocess
+    libm = ctypes.CDLL("libm.so.6"); libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "tests", "cpp"); exe = os.path.join(cpp, "glue_track_rig_dump")
+    lib_dir = os.path.join(root, "multi_orbslam3_amd"); odir = os.path.join(root, "oracle")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", os.path.join(root, "include"), "-I", cpp, os.path.join(cpp, "glue_track_rig_dump.cpp"),
+                           "-o", exe, "-pthread", "-L", lib_dir, "-lorbgpu", "-L", odir, "-loracle", "-Wl,-rpath," + lib_dir, "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.check_output([exe], text=True)
+    scenes = [json.loads(("{\"scene\"" + part) if not part.startswith("{") else part) for part in out.split("\n{\"scene\"") if part.strip()]
+    assert len(scenes) == 2
+    # ---- the reference's text
+    tr = re.sub(r"\s+", " ", _body(os.path.join(REF, "src", "Tracking.cc"), r"void\s+Tracking::SearchLocalPoints\s*\(\s*\)\s*\{"))
+    for a, b in [("for(vector<MapPoint*>::iterator vit=mCurrentFrame.mvpMapPoints.begin(), vend=mCurrentFrame.mvpMapPoints.end(); vit!=vend; vit++) { MapPoint* pMP = *vit;",
+                  "for(int iv=0; iv<len(mCurrentFrame.mvpMapPoints); iv++) { MapPoint* pMP = mCurrentFrame.mvpMapPoints[iv];"),
+                 ("*vit = static_cast<MapPoint*>(NULL);", "mCurrentFrame.mvpMapPoints[iv] = None;"),
+                 ("for(vector<MapPoint*>::iterator vit=mvpLocalMapPoints.begin(), vend=mvpLocalMapPoints.end(); vit!=vend; vit++) { MapPoint* pMP = *vit;", "foreach(pMP, mvpLocalMapPoints) {"),
+                 ("cv::Point2f(", "Point2f("), ("ORBmatcher matcher(0.8);", "matcher = ORBmatcher(0.8);")]:
+        assert a in tr, a
+        tr = tr.replace(a, b)
+    tr_src = c_to_python(cpp_prepare(tr))
+    fpath = os.path.join(REF, "src", "Frame.cc")
+    chk = _body(fpath, r"bool\s+Frame::isInFrustumChecks\s*\(\s*MapPoint\s*\*pMP,\s*float viewingCosLimit,\s*bool bRight\s*\)\s*\{")
+    chk = re.sub(r"cv::Mat (\w+) = ", r"\1 = ", chk.replace("cv::Mat mR, mt, twc;", "").replace("cv::Point2f uv;", ""))
+    chk = chk.replace(".at<float>(", ".at(").replace("cv::norm(Pc)", "Pc.norm()").replace("cv::norm(PO)", "PO.norm()").replace("PredictScale(dist,this)", "PredictScale(dist,thisF)")
+    chk_src = c_to_python(cpp_prepare(chk), keep_returns=True)
+    outer = _body(fpath, r"bool\s+Frame::isInFrustum\s*\(\s*MapPoint\s*\*pMP,\s*float viewingCosLimit\s*\)\s*\{")
+    outer = outer[outer.rindex("else{") + 5:]
+    outer_src = c_to_python(cpp_prepare(re.sub(r"pMP\s*->\s*", "pMP->", outer[:outer.index("}")])), keep_returns=True).replace("||", " or ")
+    mp_path = os.path.join(REF, "src", "MapPoint.cc")
+    ps = _body(mp_path, r"int\s+MapPoint::PredictScale\s*\(\s*const float &currentDist,\s*Frame\*\s*pF\s*\)\s*\{")
+    ps = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", ps).replace("float ratio;", "")
+    ps = re.sub(r"\{\s*(ratio = [^;]*;)\s*\}", r"\1", ps)
+    ps_src = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", ps)), typed_ints=True, keep_returns=True)
+    getters = {}
+    for nm in ("GetMinDistanceInvariance", "GetMaxDistanceInvariance"):
+        g = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", _body(mp_path, r"float\s+MapPoint::%s\s*\(\s*\)\s*\{" % nm))
+        getters[nm] = c_to_python(cpp_prepare(re.sub(r"(?<![\w\.])(mfMaxDistance|mfMinDistance)\b", r"self.\1", g)), keep_returns=True)
+    mpath = os.path.join(REF, "src", "ORBmatcher.cc")
+    sb = _body(mpath, r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&F,\s*const\s+vector<MapPoint\*>\s*&vpMapPoints[^)]*\)\s*\{")
+    sb = re.sub(r"for\(vector<size_t>::const_iterator vit=vIndices\.begin\(\), vend=vIndices\.end\(\); vit!=vend; vit\+\+\)\s*\{\s*const size_t idx = \*vit;", "foreach(idx, vIndices) {", sb)
+    sb = sb.replace("int nmatches=0, left = 0, right = 0;", "int nmatches=0; int left = 0; int right = 0;")
+    sb_src = c_to_python(cpp_prepare(sb), keep_returns=True)
+    rad = c_to_python(cpp_prepare(_body(mpath, r"float\s+ORBmatcher::RadiusByViewingCos\s*\([^)]*\)\s*\{")), keep_returns=True)
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def PredictScale(self, currentDist, pF):\n" + ind(ps_src) + "\ndef GetMinDistanceInvariance(self):\n" + ind(getters["GetMinDistanceInvariance"]) +
+            "\ndef GetMaxDistanceInvariance(self):\n" + ind(getters["GetMaxDistanceInvariance"]) + "\ndef RadiusByViewingCos(viewCos):\n" + ind(rad) +
+            "\ndef SearchByProjection_text(F, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio):\n" + ind(sb_src) +
+            "\ndef SearchLocalPoints_text(mCurrentFrame, mvpLocalMapPoints, mSensor, mpAtlas, mnLastRelocFrameId, mState, mpLocalMapper):\n" + ind(tr_src))
+    Cam = _camera_standins_from_text()
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class Kp:
+        def __init__(self, x, y, o): self.pt, self.octave = Pt(x, y), int(o)
+
+    class Desc:
+        def __init__(self, a): self.a = a
+        def row(self, i): return self.a[int(i)]
+
+    class Obj:
+        pass
+
+    for sc in scenes:
+        fd = sc["frame"]; N, nl = fd["N"], fd["Nleft"]
+        desc = np.frombuffer(bytes.fromhex(fd["desc"]), np.uint8).reshape(N, 32)
+        size = float(fd["size"])
+        grids, keysets = [], []
+        for keys, dd in ((fd["keys"], desc[:nl]), (fd["keysRight"], desc[nl:])):
+            kps = np.zeros(len(keys), capi.KEYPOINT_DTYPE)
+            kps["x"] = [k[0] for k in keys]; kps["y"] = [k[1] for k in keys]; kps["octave"] = [k[2] for k in keys]
+            fv, keep = views.frame_view(kps, dd, None, None, (0.0, size, 0.0, size), (1.0, 1.0, 0.0, 0.0, 0.0, fd["mb"]))
+            start, items = ob.build_grid(fv)
+            grids.append([[[int(x) for x in items[start[ix * capi.GRID_ROWS + iy]:start[ix * capi.GRID_ROWS + iy + 1]]] for iy in range(capi.GRID_ROWS)] for ix in range(capi.GRID_COLS)])
+            keysets.append([Kp(*k) for k in keys])
+        sfs = np.ones(8, np.float32)
+        for l in range(1, 8):
+            sfs[l] = np.float32(sfs[l - 1] * np.float32(1.2))
+        Tc = np.array(fd["Tcw"], np.float32).reshape(4, 4)
+        thisF = Obj(); thisF.mfLogScaleFactor = F32(np.log(np.float32(1.2))); thisF.mnScaleLevels = 8
+        Rm, tm = MatF(Tc[:3, :3]), MatF(Tc[:3, 3].reshape(3, 1))
+        env = dict(ENV, F32=F32, F64=F64, abs=abs, fabs=abs, as_int=lambda x: int(x), floor=np.floor, ceil=np.ceil, TH_HIGH=100,
+                   log=lambda x: F32(libm.logf(float(F32(x)))), DescriptorDistance=lambda a, b: int(np.unpackbits(a ^ b).sum()),
+                   Point2f=Pt, RGBD=2, IMU_MONOCULAR=3, IMU_STEREO=4, LOST=3, RECENTLY_LOST=4)
+        exec(prog, env)
+        fenv = dict(env, thisF=thisF, mRcw=Rm, mtcw=tm, mOw=-Rm.t() * tm, mRwc=MatF(Tc[:3, :3].T.copy()), mTrl=MatF(np.array(fd["Trl"], np.float32).reshape(3, 4)),
+                    mTlr=MatF(np.array(fd["Tlr"], np.float32).reshape(3, 4)), mpCamera=Cam([capi.CAM_KANNALA_BRANDT8] + fd["cam_left"]),
+                    mpCamera2=Cam([capi.CAM_KANNALA_BRANDT8] + fd["cam_right"]), mnMinX=F32(0), mnMaxX=F32(size), mnMinY=F32(0), mnMaxY=F32(size))
+        exec("def isInFrustumChecks(pMP, viewingCosLimit, bRight=False):\n" + ind(chk_src) + "\ndef isInFrustum(pMP, viewingCosLimit):\n" + ind(outer_src), fenv)
+        genv = dict(env, Nleft=nl, mnMinX=F32(0), mnMinY=F32(0), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
+                    mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / F32(size)), mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / F32(size)),
+                    mGrid=grids[0], mGridRight=grids[1], mvKeysUn=keysets[0], mvKeys=keysets[0], mvKeysRight=keysets[1])
+        exec(_get_features_in_area_source_rig(), genv)
+        MPc = type("MapPoint", (), {"PredictScale": env["PredictScale"], "GetMinDistanceInvariance": env["GetMinDistanceInvariance"],
+                                    "GetMaxDistanceInvariance": env["GetMaxDistanceInvariance"]})
+        pts = {}
+        for d in sc["points"]:
+            q = MPc(); q.mnId = d["id"]; q.bad = bool(d["bad"]); q.nobs = d["nobs"]; q.visible = d["visible"]; q.mnLastFrameSeen = -1
+            q.mfMinDistance = F32(d["mind"]); q.mfMaxDistance = F32(d["maxd"]); q.mbTrackInView = False; q.mbTrackInViewR = False
+            q.isBad = (lambda q=q: q.bad); q.Observations = (lambda q=q: q.nobs)
+            q.IncreaseVisible = (lambda n=1, q=q: setattr(q, "visible", q.visible + n))
+            q.GetWorldPos = (lambda d=d: MatF(np.array(d["pos"], np.float32).reshape(3, 1))); q.GetNormal = (lambda d=d: MatF(np.array(d["normal"], np.float32).reshape(3, 1)))
+            q.GetDescriptor = (lambda d=d: np.frombuffer(bytes.fromhex(d["desc"]), np.uint8))
+            q.mnTrackScaleLevel = 0; q.mnTrackScaleLevelR = 0
+            for nm in ("mTrackProjX", "mTrackProjY", "mTrackDepth", "mTrackViewCos", "mTrackProjXR", "mTrackProjYR", "mTrackDepthR", "mTrackViewCosR"):
+                setattr(q, nm, F32(0))
+            pts[d["id"]] = q
+        F = Obj()
+        F.mnId = fd["id"]; F.Nleft = nl; F.mvpMapPoints = [None if j < 0 else pts[j] for j in fd["held_before"]]; F.mmProjectPoints = {}
+        F.isInFrustum = lambda pMP, lim: fenv["isInFrustum"](pMP, F32(lim))
+        F.GetFeaturesInArea = lambda x, y, r, lo=-1, hi=-1, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), lo, hi, bRight)
+        F.mvuRight = [F32(-1)] * N; F.mvScaleFactors = [F32(x) for x in sfs]; F.mvKeys = keysets[0]; F.mvKeysUn = keysets[0]; F.mvKeysRight = keysets[1]
+        F.mDescriptors = Desc(desc); F.mvLeftToRightMatch = fd["l2r"]; F.mvRightToLeftMatch = fd["r2l"]
+
+        class ORBmatcher:
+            def __init__(self, nnratio): self.r = F32(nnratio)
+            def SearchByProjection(self, Fr, vp, th, far, thfar): return env["SearchByProjection_text"](Fr, vp, F32(th), bool(far), F32(thfar), self.r)
+        env["ORBmatcher"] = ORBmatcher
+        atlas = Obj(); atlas.isImuInitialized = lambda: False
+        lm = Obj(); lm.mbFarPoints = bool(fd["far"]); lm.mThFarPoints = F32(fd["th_far"])
+        local = [pts[d["id"]] for d in sc["points"] if d["local"]]
+        last_reloc = fd["id"] if fd["th"] == 5 else -10
+        env["SearchLocalPoints_text"](F, local, 1, atlas, last_reloc, 2, lm)
+        res = sc["result"]
+        assert [(-1 if p_ is None else p_.mnId) for p_ in F.mvpMapPoints] == res["held_after"], sc["scene"]
+        n_l = n_r = 0
+        for row in res["points_after"]:
+            pid, last_seen, visible, in_view, in_view_r, lvl, lvl_r = row[:7]
+            q = pts[pid]
+            assert (q.mnLastFrameSeen, q.visible, int(bool(q.mbTrackInView)), int(bool(q.mbTrackInViewR))) == (last_seen, visible, in_view, in_view_r), (sc["scene"], pid)
+            assert (q.mnTrackScaleLevel, q.mnTrackScaleLevelR) == (lvl, lvl_r), (sc["scene"], pid)      # -1 where a camera's checks failed, untouched (0) for a point not tried
+            if in_view:
+                n_l += 1
+                assert q.mnTrackScaleLevel == lvl and np.array([q.mTrackProjX, q.mTrackProjY, q.mTrackDepth, q.mTrackViewCos], np.float32).tobytes() == np.array(row[7:11], np.float32).tobytes(), (sc["scene"], pid)
+            if in_view_r:
+                n_r += 1
+                assert q.mnTrackScaleLevelR == lvl_r and np.array([q.mTrackProjXR, q.mTrackProjYR, q.mTrackDepthR, q.mTrackViewCosR], np.float32).tobytes() == np.array(row[11:15], np.float32).tobytes(), (sc["scene"], pid)
+        changed = [i for i, (a, b) in enumerate(zip(fd["held_before"], res["held_after"])) if a != b]
+        assert sum(1 for i in changed if i < nl) > 50 and sum(1 for i in changed if i >= nl) > 50 and n_l > 100 and n_r > 100
