@@ -1505,7 +1505,7 @@ def rig_parity(api, views):
         d["ok"] = bool(d["lba_iterations_equal"] and d["lba_max_pose_diff"] <= 1e-4 and d["lba_max_point_diff"] <= 1e-4 and
                        d["lba_outlier_flags_differing"] <= 1 and d["pose_opt_max_pose_diff"] <= 1e-5 and
                        d["pose_opt_outlier_flags_differing"] <= 1 and d["frustum_flags_and_levels_equal"] and
-                       d["frustum_max_projection_diff_px"] <= 1e-4 and gs[2] == os_[2] > 300 and d["search_map_points_features_differing"] == 0 and
+                       d["frustum_max_projection_diff_px"] <= 3e-4 and gs[2] == os_[2] > 300 and d["search_map_points_features_differing"] == 0 and
                        gf[2] == of[2] > 200 and d["search_last_frame_features_differing"] == 0)
         d["what"] = ("8 + 4 keyframes / 600 points of a two-fisheye rig through lba_solve_h, 300 + 200 features through pose_optimize, "
                      "isInFrustum / SearchByProjection(F, MPs) / SearchByProjection(Cur, Last) on a two-camera frame; "

@@ -1636,6 +1636,42 @@ static int run_search(orbm_frame* f, int n_queries, LaunchFn launch, const volat
   return ORBG_CAP_EXCEEDED;
 }
 
+// Two searches -- the two cameras of a rig frame, each on its own frame object -- in flight together: both launched, then both awaited
+// (one host round trip instead of two; the frames' streams may be the same one, then the kernels run back to back).  A list that
+// did not fit is rare (run_search's slack): that side alone is repeated through run_search.
+template <typename LaunchA, typename LaunchB>
+static int run_search_pair(orbm_frame* a, orbm_frame* b, int n_queries, LaunchA launch_a, LaunchB launch_b) {
+  int rc;
+  orbm_frame* fs[2] = {a, b};
+  for (orbm_frame* f : fs) {
+    if ((rc = f->results.reserve((size_t)std::max(n_queries, 1)))) return rc;
+    const size_t slots = (size_t)n_queries * kSlot;
+    if (f->list.cap < slots + (1 << 16) && (rc = f->list.reserve(slots + (1 << 18)))) return rc;
+  }
+  for (int k = 0; k < 2; k++) {
+    orbm_frame* f = fs[k];
+    int* cur = f->d_counter.p + (f->search_seq & 1);
+    int* nxt = f->d_counter.p + ((f->search_seq + 1) & 1);
+    f->search_seq++;
+    const int cap = (int)std::min<size_t>(f->list.cap, (size_t)1 << 30);
+    if (k == 0) launch_a(cap, cur, nxt); else launch_b(cap, cur, nxt);
+    ORBG_HIP(hipGetLastError());
+    if ((rc = f->sig.post(f->stream))) return rc;
+  }
+  for (orbm_frame* f : fs)
+    if ((rc = f->sig.wait(f->stream))) return rc;
+  for (int k = 0; k < 2; k++) {
+    orbm_frame* f = fs[k];
+    size_t total = 0;
+    const QResult* R = f->results.h;
+    for (int i = 0; i < n_queries; i++) total = std::max(total, (size_t)R[i].base + (size_t)(R[i].count & kQCountMask));
+    if (total <= f->list.cap) continue;
+    if ((rc = f->list.reserve(total + total / 4))) return rc;
+    if ((rc = k == 0 ? run_search(f, n_queries, launch_a) : run_search(f, n_queries, launch_b))) return rc;
+  }
+  return ORBG_OK;
+}
+
 // The two (or one) best candidates of query r that have not been claimed since the kernel ran, in the order the
 // reference's sequential scan would find them.  The kernel's top-4 decides whenever it can (it holds every candidate,
 // or enough unclaimed ones); otherwise the query's full list is re-scanned.
@@ -1864,18 +1900,18 @@ extern "C" int orbm_is_in_frustum_rig(orbm_frame* f, const float* Tcw, const orb
 }
 
 // One camera's window searches of the rig form of SearchByProjection(Frame, MapPoints): the kernel of the single-camera form on that
-// camera's frame; `amp` / `aob`: the occupancy the kernel filters by (that camera's part of mvpMapPoints), or NULL for none.
-static int search_mps_rig_side(orbm_frame* f, const orbm_mappoints_view* pt, const uint8_t* in_view, const float* px, const float* py,
-                               const int32_t* level, const float* view_cos, float th, int far_points, float th_far_points, const int32_t* amp,
-                               const int32_t* aob) {
+// camera's frame; `amp` / `aob`: the occupancy the kernel filters by (that camera's part of mvpMapPoints), or NULL for none.  Stages
+// the inputs and returns the launch.
+struct MpsRigSide { MpsDev mp; FrameDev F; };
+static int stage_mps_rig_side(orbm_frame* f, const orbm_mappoints_view* pt, const uint8_t* in_view, const float* px, const float* py,
+                              const int32_t* level, const float* view_cos, const int32_t* amp, const int32_t* aob, MpsRigSide* out) {
   const int m = pt->m, n = f->fp.n;
   int rc;
   if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 6 * 4)))) return rc;
-  hipStream_t st = f->stream;
   std::vector<int32_t> none;
   if (!amp) { none.assign((size_t)std::max(n, 1), -1); amp = none.data(); aob = nullptr; }
   stage_occupancy(f, amp, aob, n);
-  MpsDev mp;
+  MpsDev& mp = out->mp;
   mp.m = m;
   mp.in_view = stage_add(f, in_view, m); mp.bad = stage_add(f, pt->bad, m);
   mp.desc = stage_add(f, pt->desc, (size_t)m * 32);
@@ -1883,12 +1919,9 @@ static int search_mps_rig_side(orbm_frame* f, const orbm_mappoints_view* pt, con
   mp.depth = stage_add(f, pt->track_depth, m); mp.view_cos = stage_add(f, view_cos, m);
   mp.level = stage_add(f, level, m);
   if ((rc = stage_commit(f))) return rc;
-  FrameDev F = frame_dev(f);
-  F.uright = nullptr;                                     // S/ORBmatcher.cc:93: the mvuRight test is for Nleft == -1 only
-  return run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
-    hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, mp, th, far_points, th_far_points, cnt, cnt_next,
-                       f->list.d, list_cap, f->results.d);
-  });
+  out->F = frame_dev(f);
+  out->F.uright = nullptr;                                // S/ORBmatcher.cc:93: the mvuRight test is for Nleft == -1 only
+  return ORBG_OK;
 }
 
 extern "C" int orbm_search_by_projection_mps_rig(orbm_frame* L, orbm_frame* R, const orbm_mappoints_view* mps, const orbm_mappoints_view* mps_r,
@@ -1914,12 +1947,22 @@ extern "C" int orbm_search_by_projection_mps_rig(orbm_frame* L, orbm_frame* R, c
   for (int pass = 0; pass < 2; pass++) {
     const bool filtered = pass == 0;
     std::copy(amp0.begin(), amp0.end(), amp); std::copy(aob0.begin(), aob0.end(), aob);
-    if ((rc = search_mps_rig_side(L, mps, mps->track_in_view, mps->proj_x, mps->proj_y, mps->scale_level, mps->view_cos, th, far_points,
-                                  th_far_points, filtered ? amp : nullptr, filtered ? aob : nullptr)))
+    MpsRigSide sl, sr;
+    if ((rc = stage_mps_rig_side(L, mps, mps->track_in_view, mps->proj_x, mps->proj_y, mps->scale_level, mps->view_cos, filtered ? amp : nullptr,
+                                 filtered ? aob : nullptr, &sl)) ||
+        (rc = stage_mps_rig_side(R, mps, in_view_r.data(), mps_r->proj_x, mps_r->proj_y, mps_r->scale_level, mps_r->view_cos,
+                                 filtered ? amp + nl : nullptr, filtered ? aob + nl : nullptr, &sr)))
       return rc;
-    if ((rc = search_mps_rig_side(R, mps, in_view_r.data(), mps_r->proj_x, mps_r->proj_y, mps_r->scale_level, mps_r->view_cos, 1.0f, far_points,
-                                  th_far_points, filtered ? amp + nl : nullptr, filtered ? aob + nl : nullptr)))
-      return rc;
+    rc = run_search_pair(L, R, m,
+      [&](int list_cap, int* cnt, int* cnt_next) {
+        hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, L->stream, L->fp, sl.F, sl.mp, th, far_points, th_far_points, cnt,
+                           cnt_next, L->list.d, list_cap, L->results.d);
+      },
+      [&](int list_cap, int* cnt, int* cnt_next) {                 // (th is not applied to the right camera's window, :148-151)
+        hipLaunchKernelGGL(search_mps_kernel, dim3((m + 3) / 4), dim3(256), 0, R->stream, R->fp, sr.F, sr.mp, 1.0f, far_points, th_far_points, cnt,
+                           cnt_next, R->list.d, list_cap, R->results.d);
+      });
+    if (rc) return rc;
     const QResult* RL = L->results.h;
     const QResult* RR = R->results.h;
     bool freed = false;
@@ -1988,28 +2031,31 @@ extern "C" int orbm_search_by_projection_frame_rig(orbm_frame* FL, orbm_frame* F
   memcpy(Trl.m, rig->Trl, sizeof(Trl.m));
   // The kernels list every candidate of a window, taken or not: "the left camera's window is empty" ends a point's turn (:2033-2034)
   // and must be told from "every candidate in it is taken"; the commit below tests mvpMapPoints as it stands at that moment.
+  LastDev Ls[2]; FrameDev Fs[2];
   for (int side = 0; side < 2; side++) {
     orbm_frame* f = side ? FR : FL;
     const int n = f->fp.n;
     if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 12 + 4)))) return rc;
     const std::vector<int32_t> none((size_t)std::max(n, 1), -1);
     stage_occupancy(f, none.data(), nullptr, n);
-    LastDev L;
+    LastDev& L = Ls[side];
     L.n = m;
     L.mp_valid = stage_add(f, last->mp_valid, m); L.outlier = stage_add(f, last->outlier, m);
     L.desc = stage_add(f, last->desc, (size_t)m * 32);
     L.world_pos = stage_add(f, last->world_pos, (size_t)m * 3);
     L.octave = stage_add(f, last->octave, m);
     if ((rc = stage_commit(f))) return rc;
-    FrameDev F = frame_dev(f);
-    F.uright = nullptr;                                    // :2049: the mvuRight test is for Nleft == -1 only
-    hipStream_t st = f->stream;
-    rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
-      hipLaunchKernelGGL(search_frame_rig_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, L, Pc, cam, Trl, side, th, forward, backward,
-                         cnt, cnt_next, f->list.d, list_cap, f->results.d);
-    });
-    if (rc) return rc;
+    Fs[side] = frame_dev(f);
+    Fs[side].uright = nullptr;                             // :2049: the mvuRight test is for Nleft == -1 only
   }
+  auto launch = [&](int side) {
+    return [&, side](int list_cap, int* cnt, int* cnt_next) {
+      orbm_frame* f = side ? FR : FL;
+      hipLaunchKernelGGL(search_frame_rig_kernel, dim3((m + 3) / 4), dim3(256), 0, f->stream, f->fp, Fs[side], Ls[side], Pc, cam, Trl, side, th, forward,
+                         backward, cnt, cnt_next, f->list.d, list_cap, f->results.d);
+    };
+  };
+  if ((rc = run_search_pair(FL, FR, m, launch(0), launch(1)))) return rc;
   cache_keypoint_fields(FL); cache_keypoint_fields(FR);
   RotHist rotHist(FL->rot_entries);
   int nmatches = 0;

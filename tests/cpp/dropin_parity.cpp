@@ -403,7 +403,7 @@ int main() {
         EXPECT(g.n_local == c.n_local && nl == 0 && g.n_local > 300, "rig frame: SearchLocalPoints %d vs %d, %d features differ", g.n_local, c.n_local, nl);
         EXPECT(g.n_bow == c.n_bow && g.a_bow == c.a_bow && g.n_bow > 100, "rig frame: SearchByBoW(KF, F) %d vs %d matches", g.n_bow, c.n_bow);
         EXPECT(g.vis == c.vis && g.seen == c.seen && g.seen > 20, "rig frame: visible sums %d vs %d, seen %d vs %d", g.vis, c.vis, g.seen, c.seen);
-        EXPECT(g.fields.size() == c.fields.size() && max_abs_diff(g.fields, c.fields) <= 1e-4f, "rig frame: track fields differ by %g (%zu vs %zu values)",
+        EXPECT(g.fields.size() == c.fields.size() && max_abs_diff(g.fields, c.fields) <= 3e-4f, "rig frame: track fields differ by %g (%zu vs %zu values)",
                g.fields.size() == c.fields.size() ? max_abs_diff(g.fields, c.fields) : -1.f, g.fields.size(), c.fields.size());
       }
     }

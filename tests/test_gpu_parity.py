@@ -1931,7 +1931,7 @@ RIG_CAMERAS = {"two fisheyes": (synth.KB8_LEFT, synth.KB8_RIGHT),
 @pytest.mark.parametrize("cams", sorted(RIG_CAMERAS))
 def test_is_in_frustum_of_a_two_camera_frame(cams):
     """Frame::isInFrustum with Nleft != -1 (S/Frame.cc:545-554): isInFrustumChecks through either camera (:1154-1231) -- flags and
-    predicted levels equal the oracle's; projections within 1e-4 px (KannalaBrandt8::project goes through atan2f / cosf / sinf,
+    predicted levels equal the oracle's; projections within 3e-4 px (KannalaBrandt8::project goes through atan2f / cosf / sinf,
     which the device takes as the rounded float64 functions and the oracle from the host's libm), depths and viewing cosines bit-equal."""
     left, right = RIG_CAMERAS[cams]
     sc = synth.make_rig_track_scene(left=left, right=right)
@@ -1944,7 +1944,7 @@ def test_is_in_frustum_of_a_two_camera_frame(cams):
         for k in ob.RIG_TRACK_KEYS:
             a, b = g[side][k], o[side][k]
             if k in ("proj_x", "proj_y") and cams == "two fisheyes":
-                assert np.abs(a.astype(np.float64) - b).max() <= 1e-4, (side, k)      # pixels (one ulp of psi moves r cos(psi) by 2e-5)
+                assert np.abs(a.astype(np.float64) - b).max() <= 3e-4, (side, k)      # pixels (one ulp of psi moves f r cos(psi) by up to 1e-4)
             elif a.dtype == np.float32:
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (side, k)
             else:

@@ -40,10 +40,28 @@ def main():
         o2 = timed(lambda: ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], 3.0, True, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"]), 10)
         g3 = timed(lambda: m.SearchByProjectionFrameRig(FL, FR, sc["Tcw"], rig, lv, 7.0, False, sc["assigned_mp"], sc["assigned_obs"]), 50)
         o3 = timed(lambda: ob.search_by_projection_frame_rig(fl, fr, sc["Tcw"], rig, lv, 7.0, 0, 1, sc["assigned_mp"], sc["assigned_obs"]), 10)
+        # the usual local map: every point observed -- no stereo-partner write can free a feature, one pass
+        sc1 = synth.make_rig_track_scene(n_points=n_points, n_distract=n_distract, zero_obs_frac=0.0)
+        sc1["assigned_obs"][:] = np.maximum(sc1["assigned_obs"], 1)
+        fl1, fr1, wv1, rig1, keep1 = helpers.rig_track_views(sc1)
+        FL1, FR1 = api.Frame().upload(fl1, keep1[0]), api.Frame().upload(fr1, keep1[1])
+        a1, b1 = ob.is_in_frustum_rig(fl1, sc1["Tcw"], rig1, sc1["Tlr"], wv1)
+        mv1, mvr1, keep4 = helpers.rig_mappoint_views(sc1, a1, b1)
+        g2b = timed(lambda: m.SearchByProjectionRig(FL1, FR1, mv1, mvr1, sc1["left_to_right"], sc1["right_to_left"], 3.0, True, 6.0, sc1["assigned_mp"], sc1["assigned_obs"]), 50)
+        o2b = timed(lambda: ob.search_by_projection_mps_rig(fl1, fr1, mv1, mvr1, sc1["left_to_right"], sc1["right_to_left"], 3.0, True, 6.0, 0.8, sc1["assigned_mp"], sc1["assigned_obs"]), 10)
+        # SearchByBoW(KeyFrame, Frame): all features in one frame object, 900 keyframe features, 32 words
+        import test_gpu_parity as tg
+        fva, keepa, fvF, fvK, kf_desc, kf_angle, valid, keepb = tg._rig_bow_scene(sc, shift=3)
+        FA = api.Frame().upload(fva, keepa)
+        mb = api.ORBmatcher(0.7, True)
+        g4 = timed(lambda: mb.SearchByBoWRig(FA, len(sc["kps_left"]), fvF, kf_desc, valid, kf_angle, fvK), 50)
+        o4 = timed(lambda: ob.search_by_bow_rig(fva, len(sc["kps_left"]), fvF, kf_desc, valid, kf_angle, fvK, 0.7, True), 10)
         print(f"two-camera frame, {len(sc['kps_left'])} + {len(sc['kps_right'])} features, {n_points} map points:")
         print(f"  isInFrustum (both cameras)                 {g1:7.1f} us   oracle {o1:8.1f} us")
         print(f"  SearchByProjection(Frame, MapPoints)       {g2:7.1f} us   oracle {o2:8.1f} us")
         print(f"  SearchByProjection(CurrentFrame, LastFrame) {g3:6.1f} us   oracle {o3:8.1f} us   ({len(last['mp_valid'])} last-frame entries)")
+        print(f"  SearchByProjection(Frame, MapPoints), every point observed {g2b:6.1f} us   oracle {o2b:8.1f} us")
+        print(f"  SearchByBoW(KeyFrame, Frame), 900 keyframe features {g4:6.1f} us   oracle {o4:8.1f} us")
 
 
 if __name__ == "__main__":
