@@ -561,6 +561,31 @@ int orbm_search_by_bow_rig(orbm_frame* f, int n_left, const orbm_featvec_view* f
                            const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fv_kf, float nnratio,
                            int check_orientation, int32_t* matches, int* nmatches);
 
+/* Frame::ComputeStereoFishEyeMatches (S/Frame.cc:1093-1150): the left-right matcher of the two-fisheye Frame constructor.  The
+ * features of the two cameras' lapping areas -- [mono_left, n_left) and [mono_right, n_right): ORBextractor::operator() puts them
+ * behind the monocular ones (S/ORBextractor.cc:1136-1160, orbx_extract's lapping arguments) -- are matched brute force (the two
+ * nearest right descriptors per left one: cv::BFMatcher::knnMatch, k = 2, NORM_HAMMING), kept under Lowe's ratio 0.7, and
+ * triangulated by KannalaBrandt8::TriangulateMatches (parallax, positive depth in both cameras, reprojection error against
+ * 5.991 sigma^2 in both; S/CameraModels/KannalaBrandt8.cpp:335-420).  Both cameras must be ORBG_CAM_KANNALA_BRANDT8.
+ * Outputs: left_to_right[n_left] = mvLeftToRightMatch, right_to_left[n_right] = mvRightToLeftMatch (-1 = none; of several left features
+ * that pick one right feature the last one stays there, as in the reference's loop), depth[n_left] = mvDepth (-1), points3d[3 n_left] =
+ * mvStereo3Dpoints (written where a match was accepted), *n_matches = nMatches.
+ * The homogeneous solve of Triangulate is cv::SVD::compute in the reference (float32, one-sided Jacobi); here: the smallest
+ * eigenvector of A^T A in float64 -- depths and points agree with an OpenCV build to float32 rounding, not to the bit. */
+typedef struct orbx_fisheye_stereo_view {
+  int32_t n_left, n_right, mono_left, mono_right;    /* Nleft, Nright, monoLeft, monoRight */
+  const orbx_keypoint* kps_left;                     /* mvKeys */
+  const orbx_keypoint* kps_right;                    /* mvKeysRight */
+  const uint8_t* desc_left;                          /* mDescriptors, n_left x 32 */
+  const uint8_t* desc_right;                         /* mDescriptorsRight, n_right x 32 */
+  const float* level_sigma2;                         /* mvLevelSigma2 */
+  int32_t n_levels;
+  orbg_camera left, right;                           /* mpCamera, mpCamera2 */
+  float Tlr[12];                                     /* mTlr, 3 x 4 row-major: mRlr, mtlr (S/Frame.cc:1073-1074) */
+} orbx_fisheye_stereo_view;
+int orbx_fisheye_stereo_matches(int device, const orbx_fisheye_stereo_view* view, int32_t* left_to_right, int32_t* right_to_left, float* depth,
+                                float* points3d, int* n_matches);
+
 /* `ur` of an observation made by the RIGHT camera of the rig (get<1>(indexes) != -1, S/Optimizer.cc:2086-2120; i >= Nleft,
  * :1121-1150): u, v are then mvKeysRight[rightIndex].pt and the edge is the *ToBody kind.  In a problem whose rig has a right camera
  * any ur <= -1.5 reads as this (mvuRight is -1 throughout on such frames); in every other problem a negative ur is a monocular

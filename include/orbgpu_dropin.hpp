@@ -172,6 +172,9 @@ struct GpuOps {
                             int32_t* matches, int* n) {
     return orbm_search_by_bow_rig(frame(key, v_all).handle(), n_left, &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
   }
+  static int fisheye_stereo(const orbx_fisheye_stereo_view& v, int32_t* l2r, int32_t* r2l, float* depth, float* p3d, int* n) {
+    return orbx_fisheye_stereo_matches(0, &v, l2r, r2l, depth, p3d, n);
+  }
   // the relocalisation overload: the keyframe's points go up as a map of their own (a candidate keyframe is searched once or twice)
   static int search_reloc(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
                           const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
@@ -321,6 +324,36 @@ template <class MapPointT> auto max_distance_raw(MapPointT* p, int) -> decltype(
 template <class MapPointT> auto max_distance_raw(MapPointT* p, long) -> decltype((float)p->mfMaxDistance) { return p->mfMaxDistance; }
 
 // ------------------------------------------------------------------------------------------------ isInFrustum (batch)
+// void Frame::ComputeStereoFishEyeMatches(), S/Frame.cc:1093-1150 -- the left-right matcher of the two-fisheye Frame constructor, called
+// where the reference calls it (after the two ExtractORB threads have joined: mvKeys / mvKeysRight, mDescriptors / mDescriptorsRight,
+// monoLeft / monoRight are set, mDescriptors still holds the left camera's rows only).  Leaves mvLeftToRightMatch, mvRightToLeftMatch,
+// mvDepth, mvuRight (-1 throughout), mvStereo3Dpoints and mnCloseMPs = 0 as the reference does.
+template <class Ops = GpuOps, class FrameT>
+int ComputeStereoFishEyeMatches(FrameT& F) {
+  const int nl = (int)F.mvKeys.size(), nr = (int)F.mvKeysRight.size();
+  std::vector<orbx_keypoint> kl(nl), kr(nr); std::vector<uint8_t> dl((size_t)nl * 32), dr((size_t)nr * 32);
+  for (int i = 0; i < nl; i++) { const auto& kp = F.mvKeys[i]; kl[i] = orbx_keypoint{kp.pt.x, kp.pt.y, kp.size, kp.angle, kp.response, (int32_t)kp.octave};
+                                 std::memcpy(&dl[(size_t)32 * i], mat_u8(F.mDescriptors, i), 32); }
+  for (int i = 0; i < nr; i++) { const auto& kp = F.mvKeysRight[i]; kr[i] = orbx_keypoint{kp.pt.x, kp.pt.y, kp.size, kp.angle, kp.response, (int32_t)kp.octave};
+                                 std::memcpy(&dr[(size_t)32 * i], mat_u8(F.mDescriptorsRight, i), 32); }
+  orbx_fisheye_stereo_view v{};
+  v.n_left = nl; v.n_right = nr; v.mono_left = F.monoLeft; v.mono_right = F.monoRight;
+  v.kps_left = kl.data(); v.kps_right = kr.data(); v.desc_left = dl.data(); v.desc_right = dr.data();
+  v.level_sigma2 = F.mvLevelSigma2.data(); v.n_levels = (int32_t)F.mvLevelSigma2.size();
+  fill_camera(v.left, F.mpCamera); fill_camera(v.right, F.mpCamera2);
+  std::memcpy(v.Tlr, mat_f32(F.mTlr), 12 * sizeof(float));
+  std::vector<int32_t> l2r(std::max(nl, 1)), r2l(std::max(nr, 1)); std::vector<float> depth(std::max(nl, 1)), p3d(3 * (size_t)std::max(nl, 1));
+  int n = 0;
+  check(Ops::fisheye_stereo(v, l2r.data(), r2l.data(), depth.data(), p3d.data(), &n), "ComputeStereoFishEyeMatches");
+  F.mvLeftToRightMatch.assign(l2r.begin(), l2r.begin() + nl); F.mvRightToLeftMatch.assign(r2l.begin(), r2l.begin() + nr);
+  F.mvDepth.assign(depth.begin(), depth.begin() + nl); F.mvuRight.assign(nl, -1.f);
+  F.mvStereo3Dpoints.assign(nl, decltype(F.mTcw)());
+  for (int i = 0; i < nl; i++)
+    if (l2r[i] >= 0) make_mat(F.mvStereo3Dpoints[i], 3, 1, &p3d[3 * (size_t)i]);
+  F.mnCloseMPs = 0;
+  return n;
+}
+
 // The loop of Tracking::SearchLocalPoints (S/Tracking.cc:3111-3128): F.isInFrustum(pMP, 0.5) for every candidate, which
 // stores the mTrack* fields in the map point (S/Frame.cc:529-538) and counts the visible ones.
 template <class Ops = GpuOps, class FrameT, class MapPointT>

@@ -108,6 +108,13 @@ class CameraRig(C.Structure):
     _fields_ = [("left", Camera), ("has_right", C.c_int32), ("right", Camera), ("Trl", C.c_float * 12)]
 
 
+class FisheyeStereoView(C.Structure):
+    """orbx_fisheye_stereo_view: the inputs of Frame::ComputeStereoFishEyeMatches."""
+    _fields_ = [("n_left", C.c_int32), ("n_right", C.c_int32), ("mono_left", C.c_int32), ("mono_right", C.c_int32),
+                ("kps_left", C.c_void_p), ("kps_right", C.c_void_p), ("desc_left", C.c_void_p), ("desc_right", C.c_void_p),
+                ("level_sigma2", C.c_void_p), ("n_levels", C.c_int32), ("left", Camera), ("right", Camera), ("Tlr", C.c_float * 12)]
+
+
 CAM_PINHOLE, CAM_KANNALA_BRANDT8 = 0, 1
 UR_RIGHT_CAMERA = -2.0
 
@@ -159,7 +166,7 @@ EXPORTED_SYMBOLS = [
     "orbx_extract_stereo_dev", "orbx_get_level", "orbx_get_level_bordered", "orbx_get_candidates", "orbx_stereo_match",
     "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_upload", "orbm_frame_from_extractor", "orbx_frame_stereo_dev", "orbx_frame_stereo", "orbx_frame_stereo_dev_submit", "orbx_frame_stereo_dev_wait", "orbx_frame_stereo_submit", "orbx_frame_stereo_wait", "orbx_set_frame_outputs",
     "orbm_frame_get_grid", "orbm_hamming_matrix", "orbm_hamming_best2", "orbm_is_in_frustum",
-    "orbm_search_by_projection_mps", "orbm_is_in_frustum_rig", "orbm_search_by_projection_mps_rig", "orbm_search_by_projection_frame_rig", "orbm_search_by_bow_rig", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
+    "orbm_search_by_projection_mps", "orbm_is_in_frustum_rig", "orbm_search_by_projection_mps_rig", "orbm_search_by_projection_frame_rig", "orbm_search_by_bow_rig", "orbx_fisheye_stereo_matches", "orbm_map_create", "orbm_map_destroy", "orbm_map_upload",
     "orbm_search_local_points", "orbm_search_local_points_vis", "orbm_search_by_projection_frame", "orbm_search_by_bow",
     "orbm_search_by_projection_sim3", "orbm_search_by_bow_kf",
     "orbv_vocab_create", "orbv_vocab_destroy", "orbv_text_load", "orbv_text_view", "orbv_text_free", "orbv_vocab_from_text", "orbv_transform", "orbv_transform_frame", "orbv_bow_assemble",

@@ -411,6 +411,17 @@ class Frame:
         return a, b
 
 
+def ComputeStereoFishEyeMatches(view, device=0):
+    """Frame::ComputeStereoFishEyeMatches (S/Frame.cc:1093-1150) on an orbx_fisheye_stereo_view: (mvLeftToRightMatch, mvRightToLeftMatch,
+    mvDepth, mvStereo3Dpoints as (Nleft, 3), nMatches)."""
+    l2r = np.zeros(max(view.n_left, 1), np.int32); r2l = np.zeros(max(view.n_right, 1), np.int32)
+    depth = np.zeros(max(view.n_left, 1), np.float32); p3d = np.zeros((max(view.n_left, 1), 3), np.float32)
+    n = C.c_int(0)
+    capi.check(capi.load().orbx_fisheye_stereo_matches(int(device), C.byref(view), _vp(l2r), _vp(r2l), _vp(depth), _vp(p3d), C.byref(n)),
+               "orbx_fisheye_stereo_matches")
+    return l2r[: view.n_left], r2l[: view.n_right], depth[: view.n_left], p3d[: view.n_left], n.value
+
+
 class LocalMap:
     """Device-resident local map points (positions, normals, distances, descriptors)."""
 

@@ -215,6 +215,12 @@ __global__ __launch_bounds__(256) void frustum_kernel(FrameParams fp, PoseF P, W
 // ---- two-camera rig (Frame::Nleft != -1): Frame::isInFrustumChecks for either camera (S/Frame.cc:1154-1231)
 struct RigCamF { int model; float fx, fy, cx, cy, k[4]; };
 struct RigSideF { float R[9], t[3], twc[3]; RigCamF cam; };   // mR, mt, twc of :1158-1170 and the camera the side projects through
+static RigCamF rig_cam_of(const orbg_camera& c) {
+  RigCamF r;
+  r.model = c.model; r.fx = c.fx; r.fy = c.fy; r.cx = c.cx; r.cy = c.cy;
+  for (int i = 0; i < 4; i++) r.k[i] = c.k[i];
+  return r;
+}
 
 // GeometricCamera::project(cv::Mat) -> project(cv::Point3f): Pinhole.cpp:41-47, KannalaBrandt8.cpp:28-44 (float32 throughout; the
 // float32 atan2 / cos / sin are taken as the rounded float64 ones)
@@ -1350,6 +1356,238 @@ static int hamming_common(int device, const uint8_t* q, int nq, const uint8_t* t
 extern "C" int orbm_hamming_matrix(int device, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* dist) {
   return hamming_common(device, q, nq, t, nt, dist, true);
 }
+// ------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoFishEyeMatches (S/Frame.cc:1093-1150): brute-force 2-nearest-neighbour Hamming match of the two cameras'
+// lapping-area features, Lowe's ratio, KannalaBrandt8::TriangulateMatches per surviving pair.  One wavefront per left feature: the
+// lanes stride over the right descriptors, the two smallest (distance, index) keys of the wavefront are its knnMatch row; lane 0
+// then runs the triangulation (a 4 x 4 null vector: Jacobi rotations on A^T A in float64 where the reference calls cv::SVD).
+
+struct FisheyeDev {
+  int nq, nt, mono_left, mono_right;
+  const orbx_keypoint* kl; const orbx_keypoint* kr;        // the lapping-area keypoints only
+  const uint8_t* dl; const uint8_t* dr;
+  const float* sigma2;
+  RigCamF cam1, cam2;
+  float Tlr[12];
+  int* l2r; float* depth; float* p3d;                      // nq entries each (p3d: 3 nq)
+  int* r2l;                                                // nt entries, preset to -1
+  int* n_matches;
+};
+
+// KannalaBrandt8::unproject, S/CameraModels/KannalaBrandt8.cpp:103-133
+__device__ __forceinline__ void kb8_unproject(const RigCamF& c, float u, float v, float* ray) {
+  const float pwx = (u - c.cx) / c.fx, pwy = (v - c.cy) / c.fy;
+  float scale = 1.f;
+  float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+  theta_d = fminf(fmaxf((float)(-3.1415926535897932384626433832795 / 2.f), theta_d), (float)(3.1415926535897932384626433832795 / 2.f));
+  if (theta_d > 1e-8) {
+    float theta = theta_d;
+    for (int j = 0; j < 10; j++) {
+      const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+      const float k0 = c.k[0] * theta2, k1 = c.k[1] * theta4, k2 = c.k[2] * theta6, k3 = c.k[3] * theta8;
+      const float theta_fix = (theta * (1 + k0 + k1 + k2 + k3) - theta_d) / (1 + 3 * k0 + 5 * k1 + 7 * k2 + 9 * k3);
+      theta = theta - theta_fix;
+      if (fabsf(theta_fix) < 1e-6f) break;
+    }
+    scale = (float)tan((double)theta) / theta_d;
+  }
+  ray[0] = pwx * scale; ray[1] = pwy * scale; ray[2] = 1.f;
+}
+
+__device__ void null_vector4(double S[4][4], double* v) {   // eigenvector of the smallest eigenvalue of a symmetric 4 x 4: cyclic Jacobi
+  double V[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) V[i][j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int q = p + 1; q < 4; q++) off += S[p][q] * S[p][q];
+    if (off < 1e-300) break;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int q = p + 1; q < 4; q++) {
+        if (S[p][q] == 0.0) continue;
+        const double tau = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double a = S[k][p], b = S[k][q]; S[k][p] = cs * a - sn * b; S[k][q] = sn * a + cs * b; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double a = S[p][k], b = S[q][k]; S[p][k] = cs * a - sn * b; S[q][k] = sn * a + cs * b; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = cs * a - sn * b; V[k][q] = sn * a + cs * b; }
+      }
+  }
+  int m = 0;
+#pragma unroll
+  for (int i = 1; i < 4; i++) if (S[i][i] < S[m][m]) m = i;
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = V[k][0] * (m == 0) + V[k][1] * (m == 1) + V[k][2] * (m == 2) + V[k][3] * (m == 3);
+}
+
+// KannalaBrandt8::TriangulateMatches, :335-403 (Triangulate :405-420)
+__device__ float kb8_triangulate_matches(const FisheyeDev& D, const orbx_keypoint& kp1, const orbx_keypoint& kp2, float sigmaLevel, float unc, float* p3D) {
+  float r1[3], r2[3], r21[3];
+  kb8_unproject(D.cam1, kp1.x, kp1.y, r1);
+  kb8_unproject(D.cam2, kp2.x, kp2.y, r2);
+  const float* T = D.Tlr;
+#pragma unroll
+  for (int i = 0; i < 3; i++) r21[i] = T[4 * i] * r2[0] + T[4 * i + 1] * r2[1] + T[4 * i + 2] * r2[2];
+  auto dot = [](const float* a, const float* b) { return (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]; };
+  const float cosParallaxRays = (float)(dot(r1, r21) / (sqrt(dot(r1, r1)) * sqrt(dot(r21, r21))));
+  if (cosParallaxRays > 0.9998) return -1;
+  float R21[9], t21[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) R21[3 * i + j] = T[4 * j + i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { const float t0 = R21[3 * i] * T[3] + R21[3 * i + 1] * T[7] + R21[3 * i + 2] * T[11]; t21[i] = -t0; }
+  float Tcw2[12];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) Tcw2[4 * i + j] = R21[3 * i + j];
+    Tcw2[4 * i + 3] = t21[i];
+  }
+  float A[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float e2 = j == 2 ? 1.f : 0.f, e0 = j == 0 ? 1.f : 0.f, e1 = j == 1 ? 1.f : 0.f;      // rows of Tcw1 = [I | 0]
+    A[0][j] = r1[0] * e2 - e0;
+    A[1][j] = r1[1] * e2 - e1;
+    A[2][j] = r2[0] * Tcw2[8 + j] - Tcw2[j];
+    A[3][j] = r2[1] * Tcw2[8 + j] - Tcw2[4 + j];
+  }
+  double S[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) { double acc = 0; for (int k = 0; k < 4; k++) acc += (double)A[k][i] * (double)A[k][j]; S[i][j] = acc; }
+  double v[4];
+  null_vector4(S, v);
+  float x3D[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) x3D[i] = (float)(v[i] / v[3]);
+  const float z1 = x3D[2];
+  if (!(z1 > 0)) return -1;
+  const float z2 = (float)(dot(R21 + 6, x3D) + (double)t21[2]);
+  if (!(z2 > 0)) return -1;
+  float uv1[2];
+  rig_project(D.cam1, x3D, uv1);
+  const float errX1 = uv1[0] - kp1.x, errY1 = uv1[1] - kp1.y;
+  if ((double)(errX1 * errX1 + errY1 * errY1) > 5.991 * (double)sigmaLevel) return -1;
+  float x3D2[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { const float t0 = R21[3 * i] * x3D[0] + R21[3 * i + 1] * x3D[1] + R21[3 * i + 2] * x3D[2]; x3D2[i] = t0 + t21[i]; }
+  float uv2[2];
+  rig_project(D.cam2, x3D2, uv2);
+  const float errX2 = uv2[0] - kp2.x, errY2 = uv2[1] - kp2.y;
+  if ((double)(errX2 * errX2 + errY2 * errY2) > 5.991 * (double)unc) return -1;
+  p3D[0] = x3D[0]; p3D[1] = x3D[1]; p3D[2] = x3D[2];
+  return z1;
+}
+
+__global__ __launch_bounds__(256) void fisheye_stereo_kernel(FisheyeDev D) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= D.nq) return;
+  const uint4 a0 = *reinterpret_cast<const uint4*>(D.dl + (size_t)q * 32), a1 = *reinterpret_cast<const uint4*>(D.dl + (size_t)q * 32 + 16);
+  unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;                  // (distance << 16 | index): equal distances rank by index
+  for (int t = lane; t < D.nt; t += 64) {
+    const uint4 b0 = *reinterpret_cast<const uint4*>(D.dr + (size_t)t * 32), b1 = *reinterpret_cast<const uint4*>(D.dr + (size_t)t * 32 + 16);
+    const unsigned key = ((unsigned)popc256(a0, a1, b0, b1) << 16) | (unsigned)t;
+    if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {                     // the two smallest keys of the wavefront
+    const unsigned o1 = __shfl_xor(k1, off, 64), o2 = __shfl_xor(k2, off, 64);
+    const unsigned lo = min(k1, o1), hi = max(k1, o1);
+    k2 = min(hi, min(k2, o2));
+    k1 = lo;
+  }
+  if (lane != 0) return;
+  D.l2r[q] = -1; D.depth[q] = -1.0f;
+  if (D.nt < 2) return;
+  const int d1 = (int)(k1 >> 16), i1 = (int)(k1 & 0xFFFF), d2 = (int)(k2 >> 16);
+  if (!((double)(float)d1 < (double)(float)d2 * 0.7)) return;  // Lowe's ratio, :1137
+  const orbx_keypoint kl = D.kl[q], kr = D.kr[i1];
+  float p3D[3];
+  const float z = kb8_triangulate_matches(D, kl, kr, D.sigma2[kl.octave], D.sigma2[kr.octave], p3D);
+  if (z > 0.0001f) {
+    D.l2r[q] = i1 + D.mono_right;
+    D.depth[q] = z;
+    D.p3d[3 * q] = p3D[0]; D.p3d[3 * q + 1] = p3D[1]; D.p3d[3 * q + 2] = p3D[2];
+    atomicMax(D.r2l + i1, q + D.mono_left);                    // several left features on one right feature: the last one stays (:1145)
+    atomicAdd(D.n_matches, 1);
+  }
+}
+
+extern "C" int orbx_fisheye_stereo_matches(int device, const orbx_fisheye_stereo_view* v, int32_t* left_to_right, int32_t* right_to_left, float* depth,
+                                           float* points3d, int* n_matches) {
+  if (!v || !left_to_right || !right_to_left || !depth || !points3d || v->n_left < 0 || v->n_right < 0 || v->mono_left < 0 || v->mono_left > v->n_left ||
+      v->mono_right < 0 || v->mono_right > v->n_right || v->n_levels < 1 || !v->level_sigma2)
+    return ORBG_BAD_ARG;
+  if (v->left.model != ORBG_CAM_KANNALA_BRANDT8 || v->right.model != ORBG_CAM_KANNALA_BRANDT8) return ORBG_BAD_ARG;
+  const int nq = v->n_left - v->mono_left, nt = v->n_right - v->mono_right;
+  if (nt > 65535) return ORBG_CAP_EXCEEDED;
+  if ((nq > 0 && (!v->kps_left || !v->desc_left)) || (nt > 0 && (!v->kps_right || !v->desc_right))) return ORBG_BAD_ARG;
+  for (int i = 0; i < nq; i++) { const int o = v->kps_left[v->mono_left + i].octave; if (o < 0 || o >= v->n_levels) return ORBG_BAD_ARG; }
+  for (int i = 0; i < nt; i++) { const int o = v->kps_right[v->mono_right + i].octave; if (o < 0 || o >= v->n_levels) return ORBG_BAD_ARG; }
+  int rc = select_device(device);
+  if (rc) return rc;
+  for (int i = 0; i < v->n_left; i++) { left_to_right[i] = -1; depth[i] = -1.0f; }
+  for (int i = 0; i < v->n_right; i++) right_to_left[i] = -1;
+  if (n_matches) *n_matches = 0;
+  if (nq == 0 || nt < 2) return ORBG_OK;
+  // one pinned block in, one out (buffers of the calling thread, kept from frame to frame)
+  struct Scratch { int device = -1; PinnedBuf<uint8_t> in, out; DevBuf<uint8_t> din, dout; };
+  static thread_local Scratch S;
+  if (S.device != device) { S.in.release(); S.out.release(); S.din = DevBuf<uint8_t>(); S.dout = DevBuf<uint8_t>(); S.device = device; }
+  auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_kl = 0, o_kr = up(o_kl + (size_t)nq * sizeof(orbx_keypoint)), o_dl = up(o_kr + (size_t)nt * sizeof(orbx_keypoint)), o_dr = up(o_dl + (size_t)nq * 32),
+               o_sg = up(o_dr + (size_t)nt * 32), in_bytes = up(o_sg + (size_t)v->n_levels * 4);
+  const size_t p_l2r = 0, p_dep = up(p_l2r + (size_t)nq * 4), p_p3d = up(p_dep + (size_t)nq * 4), p_r2l = up(p_p3d + (size_t)nq * 12), p_n = up(p_r2l + (size_t)nt * 4),
+               out_bytes = up(p_n + 4);
+  if ((rc = S.in.reserve(in_bytes)) || (rc = S.out.reserve(out_bytes)) || (rc = S.din.reserve(in_bytes)) || (rc = S.dout.reserve(out_bytes))) return rc;
+  memcpy(S.in.h + o_kl, v->kps_left + v->mono_left, (size_t)nq * sizeof(orbx_keypoint));
+  memcpy(S.in.h + o_kr, v->kps_right + v->mono_right, (size_t)nt * sizeof(orbx_keypoint));
+  memcpy(S.in.h + o_dl, v->desc_left + (size_t)v->mono_left * 32, (size_t)nq * 32);
+  memcpy(S.in.h + o_dr, v->desc_right + (size_t)v->mono_right * 32, (size_t)nt * 32);
+  memcpy(S.in.h + o_sg, v->level_sigma2, (size_t)v->n_levels * 4);
+  orbg::MiscStream ms;
+  if ((rc = ms.open())) return rc;
+  ORBG_HIP(hipMemcpyAsync(S.din.p, S.in.h, in_bytes, hipMemcpyHostToDevice, ms.s));
+  ORBG_HIP(hipMemsetAsync(S.dout.p + p_r2l, 0xFF, out_bytes - p_r2l, ms.s));          // r2l = -1 ...
+  ORBG_HIP(hipMemsetAsync(S.dout.p + p_n, 0, 4, ms.s));                               // ... and the match counter = 0
+  FisheyeDev D;
+  D.nq = nq; D.nt = nt; D.mono_left = v->mono_left; D.mono_right = v->mono_right;
+  D.kl = reinterpret_cast<const orbx_keypoint*>(S.din.p + o_kl); D.kr = reinterpret_cast<const orbx_keypoint*>(S.din.p + o_kr);
+  D.dl = S.din.p + o_dl; D.dr = S.din.p + o_dr; D.sigma2 = reinterpret_cast<const float*>(S.din.p + o_sg);
+  D.cam1 = rig_cam_of(v->left); D.cam2 = rig_cam_of(v->right);
+  memcpy(D.Tlr, v->Tlr, sizeof(D.Tlr));
+  D.l2r = reinterpret_cast<int*>(S.dout.p + p_l2r); D.depth = reinterpret_cast<float*>(S.dout.p + p_dep); D.p3d = reinterpret_cast<float*>(S.dout.p + p_p3d);
+  D.r2l = reinterpret_cast<int*>(S.dout.p + p_r2l); D.n_matches = reinterpret_cast<int*>(S.dout.p + p_n);
+  hipLaunchKernelGGL(fisheye_stereo_kernel, dim3((nq + 3) / 4), dim3(256), 0, ms.s, D);
+  ORBG_HIP(hipGetLastError());
+  ORBG_HIP(hipMemcpyAsync(S.out.h, S.dout.p, out_bytes, hipMemcpyDeviceToHost, ms.s));
+  ORBG_HIP(hipStreamSynchronize(ms.s));
+  const int* h_l2r = reinterpret_cast<const int*>(S.out.h + p_l2r); const float* h_dep = reinterpret_cast<const float*>(S.out.h + p_dep);
+  const float* h_p3d = reinterpret_cast<const float*>(S.out.h + p_p3d); const int* h_r2l = reinterpret_cast<const int*>(S.out.h + p_r2l);
+  for (int q = 0; q < nq; q++) {
+    left_to_right[v->mono_left + q] = h_l2r[q]; depth[v->mono_left + q] = h_dep[q];
+    if (h_l2r[q] >= 0) memcpy(points3d + 3 * (size_t)(v->mono_left + q), h_p3d + 3 * (size_t)q, 12);
+  }
+  for (int t = 0; t < nt; t++) right_to_left[v->mono_right + t] = h_r2l[t];
+  if (n_matches) *n_matches = *reinterpret_cast<const int*>(S.out.h + p_n);
+  return ORBG_OK;
+}
+
 extern "C" int orbm_hamming_best2(int device, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out4) {
   return hamming_common(device, q, nq, t, nt, out4, false);
 }
@@ -1828,12 +2066,6 @@ extern "C" int orbm_search_local_points_vis(orbm_frame* f, orbm_map* mp, const f
 
 // ---- two-camera rig frames (Frame::Nleft != -1)
 
-static RigCamF rig_cam_of(const orbg_camera& c) {
-  RigCamF r;
-  r.model = c.model; r.fx = c.fx; r.fy = c.fy; r.cx = c.cx; r.cy = c.cy;
-  for (int i = 0; i < 4; i++) r.k[i] = c.k[i];
-  return r;
-}
 // S/Frame.cc:1158-1170: the cv::Mat products of the right camera (float32 small-matrix rules, as make_pose)
 static RigSideF rig_side_of(const PoseF& P, const orbg_camera_rig* rig, const float* Tlr, bool right) {
   RigSideF s;

@@ -498,6 +498,60 @@ def rig_last_frame(sc, n_last=900, seed=5, motion=(0.0, 0.0, 0.0)):
                 Tcw=T_last.astype(np.float32))
 
 
+def make_fisheye_stereo_scene(n_stereo=700, n_mono_left=300, n_mono_right=260, n_distract=150, seed=0xF15C, size=512, left=KB8_LEFT, right=KB8_RIGHT):
+    """The two feature sets of a two-fisheye Frame before Frame::ComputeStereoFishEyeMatches (S/Frame.cc:1093-1150): monocular features
+    first, then the lapping-area ones -- 3-D points seen by both cameras (pixel noise by level, descriptors a few bits apart; some
+    with a wrong partner position: the reprojection test's business; some far away: the parallax test's), near-duplicate descriptors
+    for the ratio test, distractors."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    Trl = rig_Trl(); Tlr = np.linalg.inv(Trl)
+    sc = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sc[i] = np.float32(sc[i - 1] * np.float32(1.2))
+    sigma2 = (sc * sc).astype(np.float32)
+
+    def rand_feats(n):
+        k = np.zeros(n, capi.KEYPOINT_DTYPE)
+        k["x"] = rng.uniform(5, size - 5, n); k["y"] = rng.uniform(5, size - 5, n); k["octave"] = rng.randint(0, 8, n); k["size"] = 31.0
+        return k, rng.randint(0, 256, (n, 32)).astype(np.uint8)
+
+    kl_m, dl_m = rand_feats(n_mono_left); kr_m, dr_m = rand_feats(n_mono_right)
+    L, R = [], []
+    for i in range(n_stereo):
+        depth = rng.uniform(0.6, 9.0) if rng.rand() < 0.9 else rng.uniform(40.0, 400.0)        # far points: too little parallax
+        Pl = _kb8_ray(left, rng.uniform(160, size - 20), rng.uniform(40, size - 40), depth)
+        Pr = Trl[:3, :3] @ Pl + Trl[:3, 3]
+        o = rng.randint(0, 8)
+        uvl = kb8_project(left, Pl) + rng.randn(2) * 0.6 * float(sc[o])
+        uvr = kb8_project(right, Pr) + rng.randn(2) * 0.6 * float(sc[o])
+        if rng.rand() < 0.08:
+            uvr += rng.choice([-1, 1], 2) * rng.uniform(6, 30, 2)                            # a wrong partner: reprojection error
+        d = rng.randint(0, 256, 32).astype(np.uint8)
+        dr_ = d.copy()
+        for b in rng.choice(256, rng.randint(0, 40), replace=False):
+            dr_[b >> 3] ^= 1 << (b & 7)
+        L.append((uvl[0], uvl[1], o, d)); R.append((uvr[0], uvr[1], min(7, max(0, o + rng.randint(-1, 2))), dr_))
+        if rng.rand() < 0.12:                                                                 # a second right feature nearly as close: Lowe's ratio
+            d2 = dr_.copy()
+            for b in rng.choice(256, rng.randint(1, 12), replace=False):
+                d2[b >> 3] ^= 1 << (b & 7)
+            R.append((uvr[0] + rng.randn() * 3, uvr[1] + rng.randn() * 3, o, d2))
+    for lst in (L, R):
+        k, d = rand_feats(n_distract)
+        lst.extend((k["x"][j], k["y"][j], int(k["octave"][j]), d[j]) for j in range(n_distract))
+    pl, pr = rng.permutation(len(L)), rng.permutation(len(R))
+    L = [L[j] for j in pl]; R = [R[j] for j in pr]
+
+    def pack(mono_k, mono_d, lst):
+        k = np.zeros(len(lst), capi.KEYPOINT_DTYPE)
+        k["x"] = [f[0] for f in lst]; k["y"] = [f[1] for f in lst]; k["octave"] = [f[2] for f in lst]; k["size"] = 31.0
+        return np.concatenate([mono_k, k]), np.concatenate([mono_d, np.stack([f[3] for f in lst])]).astype(np.uint8)
+
+    kl, dl = pack(kl_m, dl_m, L); kr, dr = pack(kr_m, dr_m, R)
+    return dict(kps_left=kl, desc_left=dl, mono_left=n_mono_left, kps_right=kr, desc_right=dr, mono_right=n_mono_right, left=left, right=right,
+                Tlr=Tlr.astype(np.float32)[:3], Trl=Trl.astype(np.float32)[:3], level_sigma2=sigma2)
+
+
 # ---------------------------------------------------------------- synthetic vocabulary (ORBvoc.txt is not in the reference tree)
 def make_vocabulary(k=10, L=3, seed=0xB0C, stop_frac=0.03, descriptors=None):
     """A k-ary tree of depth L in DBoW2's node layout (node ids in creation order, children after parents): node descriptors are

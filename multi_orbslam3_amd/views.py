@@ -113,6 +113,23 @@ def camera_rig(left, right=None, Trl=None):
     return rig
 
 
+def fisheye_stereo_view(kps_left, desc_left, mono_left, kps_right, desc_right, mono_right, left, right, Tlr, level_sigma2):
+    """orbx_fisheye_stereo_view: mvKeys / mvKeysRight with their descriptors, monoLeft / monoRight (the lapping-area features sit
+    behind them), the two KannalaBrandt8 cameras as (model, fx, fy, cx, cy, k1..k4) tuples, mTlr (3x4 or 4x4), mvLevelSigma2."""
+    kl = np.ascontiguousarray(kps_left, dtype=capi.KEYPOINT_DTYPE); kr = np.ascontiguousarray(kps_right, dtype=capi.KEYPOINT_DTYPE)
+    dl = _c(desc_left, np.uint8); dr = _c(desc_right, np.uint8); sg = _c(level_sigma2, np.float32)
+    v = capi.FisheyeStereoView()
+    v.n_left, v.n_right, v.mono_left, v.mono_right = len(kl), len(kr), int(mono_left), int(mono_right)
+    v.kps_left, v.kps_right, v.desc_left, v.desc_right, v.level_sigma2 = capi.ptr(kl), capi.ptr(kr), capi.ptr(dl), capi.ptr(dr), capi.ptr(sg)
+    v.n_levels = len(sg)
+    rig = camera_rig(left, right, np.eye(4)[:3])
+    v.left, v.right = rig.left, rig.right
+    T = np.asarray(Tlr, np.float32).reshape(-1)[:12]
+    for i in range(12):
+        v.Tlr[i] = float(T[i])
+    return v, [kl, kr, dl, dr, sg]
+
+
 def lba_problem(poses, pose_fixed, points, edges, cam, lambda_init=0.0, its=(5, 10), device=0, rig=None):
     """poses: (P,16) or (P,4,4) float32; edges: structured EDGE_DTYPE; cam = (fx, fy, cx, cy, bf); rig: camera_rig(...) or None."""
     poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 16))

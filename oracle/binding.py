@@ -365,6 +365,30 @@ def search_by_projection_frame_rig(fv_left, fv_right, Tcw_cur, rig, lv, th, mono
     return amp, aob, n.value
 
 
+def fisheye_stereo_matches(view):
+    l2r = np.zeros(max(view.n_left, 1), np.int32); r2l = np.zeros(max(view.n_right, 1), np.int32)
+    depth = np.zeros(max(view.n_left, 1), np.float32); p3d = np.zeros((max(view.n_left, 1), 3), np.float32)
+    n = C.c_int(0)
+    _chk(lib().oracle_fisheye_stereo_matches(C.byref(view), C.c_void_p(l2r.ctypes.data), C.c_void_p(r2l.ctypes.data), C.c_void_p(depth.ctypes.data),
+                                             C.c_void_p(p3d.ctypes.data), C.byref(n)))
+    return l2r[: view.n_left], r2l[: view.n_right], depth[: view.n_left], p3d[: view.n_left], n.value
+
+
+def kb8_unproject(cam, u, v):
+    ray = np.zeros(3, np.float32)
+    lib().oracle_kb8_unproject(C.byref(cam), C.c_float(u), C.c_float(v), C.c_void_p(ray.ctypes.data))
+    return ray
+
+
+def kb8_triangulate_matches(cam1, cam2, uv1, uv2, Tlr, sigma1, sigma2):
+    a = np.ascontiguousarray(uv1, np.float32); b = np.ascontiguousarray(uv2, np.float32); T = np.ascontiguousarray(np.asarray(Tlr, np.float32).reshape(-1)[:12])
+    p = np.zeros(3, np.float32)
+    lib().oracle_kb8_triangulate_matches.restype = C.c_float
+    z = lib().oracle_kb8_triangulate_matches(C.byref(cam1), C.byref(cam2), C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(T.ctypes.data),
+                                             C.c_float(sigma1), C.c_float(sigma2), C.c_void_p(p.ctypes.data))
+    return float(z), p
+
+
 def search_local_points(fv, wv, Tcw, th, far, th_far, nnratio, assigned_mp, assigned_obs):
     amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
     aob = np.ascontiguousarray(assigned_obs, np.int32).copy()

@@ -111,6 +111,12 @@ int oracle_search_by_projection_frame_rig(const orbm_frame_view* left, const orb
 int oracle_search_by_bow_rig(const orbm_frame_view* view, int n_left, const orbm_featvec_view* fv_frame, const uint8_t* kf_desc, int nkf,
                              const uint8_t* kf_mp_valid, const float* kf_angle, const orbm_featvec_view* fv_kf, float nnratio,
                              int check_orientation, int32_t* matches, int* nmatches);
+/* Frame::ComputeStereoFishEyeMatches (S/Frame.cc:1093-1150) with KannalaBrandt8::TriangulateMatches -- oracle/fisheye.cc */
+int oracle_fisheye_stereo_matches(const orbx_fisheye_stereo_view* view, int32_t* left_to_right, int32_t* right_to_left, float* depth,
+                                  float* points3d, int* n_matches);
+void oracle_kb8_unproject(const orbg_camera* cam, float u, float v, float* ray3);
+float oracle_kb8_triangulate_matches(const orbg_camera* cam1, const orbg_camera* cam2, const float* uv1, const float* uv2, const float* Tlr,
+                                     float sigma1, float sigma2, float* p3D);
 int oracle_search_local_points(const orbm_frame_view* view, const orbm_worldpoints_view* pts, const float* Tcw,
                                float th, int far_points, float th_far_points, float nnratio,
                                int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches);

@@ -407,6 +407,23 @@ int main() {
                g.fields.size() == c.fields.size() ? max_abs_diff(g.fields, c.fields) : -1.f, g.fields.size(), c.fields.size());
       }
     }
+    // ---- Frame::ComputeStereoFishEyeMatches of the two-fisheye Frame constructor (S/Frame.cc:1093-1150)
+    {
+      auto run = [](auto ops_tag, std::vector<int>& l2r, std::vector<int>& r2l, std::vector<float>& dep, std::vector<float>& pts) {
+        using Ops = decltype(ops_tag);
+        Agent A;
+        Frame* F = build_fisheye_ctor_frame(A, 6161);
+        const int n = od::ComputeStereoFishEyeMatches<Ops>(*F);
+        l2r = F->mvLeftToRightMatch; r2l = F->mvRightToLeftMatch; dep = F->mvDepth; pts.clear();
+        for (int i = 0; i < F->Nleft; i++) for (int a = 0; a < 3; a++) pts.push_back(l2r[i] >= 0 ? F->mvStereo3Dpoints[i].ptr<float>(0)[a] : 0.f);
+        return n;
+      };
+      std::vector<int> lg, rg, lc, rc2; std::vector<float> dg, dc, pg, pc;
+      const int ng = run(od::GpuOps{}, lg, rg, dg, pg), nc = run(OracleOps{}, lc, rc2, dc, pc);
+      std::printf("ComputeStereoFishEyeMatches [two-fisheye rig]: %d matches of %zu + %zu features\n", ng, lg.size(), rg.size());
+      EXPECT(ng == nc && lg == lc && rg == rc2 && ng > 150, "fisheye constructor: %d vs %d matches, partner arrays %s", ng, nc, (lg == lc && rg == rc2) ? "equal" : "differ");
+      EXPECT(max_abs_diff(dg, dc) <= 1e-3f && max_abs_diff(pg, pc) <= 1e-3f, "fisheye constructor: depths differ by %g, points by %g", max_abs_diff(dg, dc), max_abs_diff(pg, pc));
+    }
     // ---- five consecutive windows of one map (a new keyframe each, points moved / observations erased by the solves in between): the
     // product through the glue's window cache, the oracle reading every point of every window
     {

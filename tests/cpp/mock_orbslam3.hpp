@@ -157,6 +157,8 @@ class Frame {
   int Nleft = -1, Nright = -1;
   Mat mTlr{3, 4, 4};
   std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;      // (I/Frame.h:285) stereo partners of the two cameras' features, -1 = none
+  // (I/Frame.h:183,188,232,282,292) what Frame::ComputeStereoFishEyeMatches reads and leaves
+  Mat mDescriptorsRight; int monoLeft = 0, monoRight = 0; std::vector<float> mvLevelSigma2; std::vector<Mat> mvStereo3Dpoints; int mnCloseMPs = 0;
 };
 
 // the matrix access points include/orbgpu_dropin.hpp asks for

@@ -44,6 +44,9 @@ struct OracleOps {       // the same entry points over the CPU oracle: views ins
                             const uint8_t* kf_valid, const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori, int32_t* matches, int* n) {
     return oracle_search_by_bow_rig(&v_all, n_left, &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, matches, n);
   }
+  static int fisheye_stereo(const orbx_fisheye_stereo_view& v, int32_t* l2r, int32_t* r2l, float* depth, float* p3d, int* n) {
+    return oracle_fisheye_stereo_matches(&v, l2r, r2l, depth, p3d, n);
+  }
   static int search_reloc(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
                           const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
     return oracle_search_by_projection_reloc(&v, Tcw, &kf_pts, found, kf_angle, th, orb_dist, check_ori, amp, n);

@@ -491,6 +491,53 @@ static RigTrack build_rig_track_scene(Agent& A, unsigned seed, int n_points = 12
   return out;
 }
 
+// A two-fisheye Frame as its constructor has it when it calls ComputeStereoFishEyeMatches (S/Frame.cc:1079): monocular features first,
+// then the lapping-area ones -- 3-D points seen by both cameras (pixel noise by level, descriptors a few bits apart; some with a wrong
+// partner position, some too far for any parallax), second right features nearly as close (Lowe's ratio), distractors.
+static Frame* build_fisheye_ctor_frame(Agent& A, unsigned seed, int n_stereo = 600, int n_mono = 250, int n_distract = 120) {
+  g_seed = seed;
+  std::unique_ptr<Frame> F(new Frame);
+  give_rig(A, F->mpCamera, F->mpCamera2, F->mTrl);
+  double Trl[12]; rig_Trl(Trl);
+  F->mTlr = Mat(3, 4, 4);
+  for (int i = 0; i < 3; i++) { double tt = 0; for (int j = 0; j < 3; j++) { F->mTlr.ptr<float>(0)[4 * i + j] = (float)Trl[4 * j + i]; tt -= Trl[4 * j + i] * Trl[4 * j + 3]; }
+                                F->mTlr.ptr<float>(0)[4 * i + 3] = (float)tt; }
+  float sc = 1.f; for (int l = 0; l < 8; l++) { F->mvLevelSigma2.push_back(sc * sc); sc *= 1.2f; }
+  struct Feat { float x, y; int oct; uint8_t d[32]; };
+  auto random_feat = [&]() { Feat f; f.x = (float)(5 + 502 * urand()); f.y = (float)(5 + 502 * urand()); f.oct = rnd() % 8; for (int b = 0; b < 32; b++) f.d[b] = (uint8_t)rnd(); return f; };
+  std::vector<Feat> ml, mr, sl, sr;
+  for (int i = 0; i < n_mono; i++) { ml.push_back(random_feat()); if (i % 8) mr.push_back(random_feat()); }
+  for (int i = 0; i < n_stereo; i++) {
+    const double depth = urand() < 0.9 ? 0.6 + 8.4 * urand() : 40 + 360 * urand();
+    const double u = 160 + 330 * urand(), v = 40 + 430 * urand();
+    const double mx = (u - KB8_L[2]) / KB8_L[0], my = (v - KB8_L[3]) / KB8_L[1], th = std::sqrt(mx * mx + my * my), psi = std::atan2(my, mx);
+    const double Pl[3] = {depth * std::sin(th) * std::cos(psi), depth * std::sin(th) * std::sin(psi), depth * std::cos(th)};
+    double Pr[3]; for (int a = 0; a < 3; a++) Pr[a] = Trl[4 * a] * Pl[0] + Trl[4 * a + 1] * Pl[1] + Trl[4 * a + 2] * Pl[2] + Trl[4 * a + 3];
+    const int o = rnd() % 8; const double sig = 0.6 * std::pow(1.2, o);
+    double uvl[2], uvr[2]; kb8_project(KB8_L, Pl, uvl); kb8_project(KB8_R, Pr, uvr);
+    Feat a, b; a.x = (float)(uvl[0] + sig * nrand()); a.y = (float)(uvl[1] + sig * nrand()); a.oct = o;
+    b.x = (float)(uvr[0] + sig * nrand()); b.y = (float)(uvr[1] + sig * nrand()); b.oct = std::min(7, std::max(0, o + (int)(rnd() % 3) - 1));
+    if (urand() < 0.08) { b.x += (float)((urand() < 0.5 ? -1 : 1) * (6 + 24 * urand())); b.y += (float)((urand() < 0.5 ? -1 : 1) * (6 + 24 * urand())); }
+    for (int k = 0; k < 32; k++) a.d[k] = (uint8_t)rnd();
+    std::memcpy(b.d, a.d, 32);
+    for (int k = 0, nb = (int)(rnd() % 40); k < nb; k++) { const int bit = rnd() % 256; b.d[bit >> 3] ^= (uint8_t)(1u << (bit & 7)); }
+    sl.push_back(a); sr.push_back(b);
+    if (urand() < 0.12) { Feat c = b; c.x += (float)(3 * nrand()); c.y += (float)(3 * nrand()); for (int k = 0, nb = 1 + (int)(rnd() % 11); k < nb; k++) { const int bit = rnd() % 256; c.d[bit >> 3] ^= (uint8_t)(1u << (bit & 7)); } sr.push_back(c); }
+  }
+  for (int i = 0; i < n_distract; i++) { sl.push_back(random_feat()); sr.push_back(random_feat()); }
+  for (size_t k = sl.size(); k > 1; k--) std::swap(sl[k - 1], sl[rnd() % k]);
+  for (size_t k = sr.size(); k > 1; k--) std::swap(sr[k - 1], sr[rnd() % k]);
+  F->monoLeft = (int)ml.size(); F->monoRight = (int)mr.size();
+  ml.insert(ml.end(), sl.begin(), sl.end()); mr.insert(mr.end(), sr.begin(), sr.end());
+  F->Nleft = (int)ml.size(); F->Nright = (int)mr.size(); F->N = F->Nleft + F->Nright;
+  F->mDescriptors = Mat(F->Nleft, 32, 1); F->mDescriptorsRight = Mat(F->Nright, 32, 1);
+  for (int i = 0; i < F->Nleft; i++) { F->mvKeys.push_back(KeyPoint{{ml[i].x, ml[i].y}, 31.f, 0.f, 20.f, ml[i].oct}); std::memcpy(F->mDescriptors.ptr<uint8_t>(i), ml[i].d, 32); }
+  for (int i = 0; i < F->Nright; i++) { F->mvKeysRight.push_back(KeyPoint{{mr[i].x, mr[i].y}, 31.f, 0.f, 20.f, mr[i].oct}); std::memcpy(F->mDescriptorsRight.ptr<uint8_t>(i), mr[i].d, 32); }
+  Frame* out = F.get();
+  A.frames.push_back(std::move(F));
+  return out;
+}
+
 // The keyframe after `cur` as LocalMapping would insert it: covisible with `cur` and all but the oldest of its neighbours, observing
 // a third of cur's points (MapPoint::AddObservation: the points' change counters move, as in the reference with INTEGRATION.md's hook).
 static inline KeyFrame* next_keyframe(Agent& B, KeyFrame* cur, int round) {

@@ -38,6 +38,7 @@ def test_ctypes_mirrors_of_the_problem_structs_have_the_headers_layout(tmp_path)
               "pose_opt_problem": ("PoseOptProblem", ["n", "Xw", "inv_sigma2", "fx", "Tcw", "device", "rig"]),
               "orbg_camera": ("Camera", ["model", "fx", "cy", "k"]),
               "orbg_camera_rig": ("CameraRig", ["left", "has_right", "right", "Trl"]),
+              "orbx_fisheye_stereo_view": ("FisheyeStereoView", ["n_left", "mono_right", "kps_left", "desc_right", "level_sigma2", "n_levels", "left", "right", "Tlr"]),
               "lba_result": ("LbaResult", ["poses", "edge_outlier", "status", "chi2_initial", "trace", "trace_len"]),
               "pose_opt_result": ("PoseOptResult", ["Tcw", "outlier", "n_inliers", "iters", "chi2"])}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "orbgpu.h"', 'int main(void) {']

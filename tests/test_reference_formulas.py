@@ -3411,3 +3411,149 @@ def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
                 assert q.mnTrackScaleLevelR == lvl_r and np.array([q.mTrackProjXR, q.mTrackProjYR, q.mTrackDepthR, q.mTrackViewCosR], np.float32).tobytes() == np.array(row[11:15], np.float32).tobytes(), (sc["scene"], pid)
         changed = [i for i, (a, b) in enumerate(zip(fd["held_before"], res["held_after"])) if a != b]
         assert sum(1 for i in changed if i < nl) > 50 and sum(1 for i in changed if i >= nl) > 50 and n_l > 100 and n_r > 100
+
+
+def _fisheye_text_programs():
+    """KannalaBrandt8::unproject, Triangulate, TriangulateMatches and Frame::ComputeStereoFishEyeMatches as Python source (the cv::Mat
+    expressions on MatF stand-ins; cv::SVD::compute and cv::BFMatcher::knnMatch are OpenCV's: numpy stand-ins, named SVD_compute /
+    BFmatcher)."""
+    kpath = os.path.join(REF, "src", "CameraModels", "KannalaBrandt8.cpp")
+    un = _body(kpath, r"cv::Point3f\s+KannalaBrandt8::unproject\s*\(\s*const\s+cv::Point2f\s*&p2D\s*\)\s*\{")
+    un = re.sub(r"//[^\n]*", "", un)
+    un = un.replace("cv::Point2f pw((p2D.x - mvParameters[2]) / mvParameters[0], (p2D.y - mvParameters[3]) / mvParameters[1]);",
+                    "pw = Pt((p2D.x - mvParameters[2]) / mvParameters[0], (p2D.y - mvParameters[3]) / mvParameters[1]);")
+    un = un.replace("float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;",
+                    "float theta2 = theta * theta; float theta4 = theta2 * theta2; float theta6 = theta4 * theta2; float theta8 = theta4 * theta4;")
+    un = un.replace("float k0_theta2 = mvParameters[4] * theta2, k1_theta4 = mvParameters[5] * theta4;", "float k0_theta2 = mvParameters[4] * theta2; float k1_theta4 = mvParameters[5] * theta4;")
+    un = un.replace("float k2_theta6 = mvParameters[6] * theta6, k3_theta8 = mvParameters[7] * theta8;", "float k2_theta6 = mvParameters[6] * theta6; float k3_theta8 = mvParameters[7] * theta8;")
+    un = un.replace("std::tan(", "tanf(").replace("CV_PI / 2.f", "HALF_PI").replace("return cv::Point3f(pw.x * scale, pw.y * scale, 1.f);", "return P3(pw.x * scale, pw.y * scale, F32(1));")
+    un_src = c_to_python(cpp_prepare(un), keep_returns=True)
+    assert "for j in range(0, 10)" in un_src.replace("range(0,10)", "range(0, 10)") and "break" in un_src and "theta_fix" in un_src
+    tri = _body(kpath, r"void\s+KannalaBrandt8::Triangulate\s*\([^)]*\)\s*\{")
+    tri = tri.replace("cv::Mat A(4,4,CV_32F);", "A = MatF(np.zeros((4, 4), np.float32));")
+    tri = re.sub(r"A\.row\((\d)\) = ([^;]*);", r"A.setrow(\1, \2);", tri)
+    tri = tri.replace("cv::Mat u,w,vt;", "").replace("cv::SVD::compute(A,w,u,vt,cv::SVD::MODIFY_A| cv::SVD::FULL_UV);", "vt = SVD_compute(A);").replace(".at<float>(", ".at(")
+    tri_src = c_to_python(cpp_prepare(tri), keep_returns=True)
+    assert "x3D = vt.row(3).t()" in tri_src and "x3D = x3D.rowRange(0,3)/x3D.at(3)" in tri_src.replace(" ", "").replace("x3D=", "x3D = ") or "rowRange" in tri_src
+    tm = _body(kpath, r"float\s+KannalaBrandt8::TriangulateMatches\s*\([^)]*\)\s*\{")
+    tm = re.sub(r"//[^\n]*", "", tm)
+    tm = re.sub(r"cv::Mat Tcw1 = \(cv::Mat_<float>\(3,4\) << ([^;]*)\);", r"Tcw1 = MatF(np.array([\1], np.float32).reshape(3, 4));", tm)
+    tm = tm.replace("cv::Point2f p11,p22;", "p11 = Pt(0, 0); p22 = Pt(0, 0);").replace("const float* pr1 = r1.ptr<float>();", "pr1 = r1.ptr();").replace("const float* pr2 = r2.ptr<float>();", "pr2 = r2.ptr();")
+    tm = tm.replace("cv::Mat x3D;", "").replace("cv::Mat Tcw2;", "").replace("cv::hconcat(R21,t21,Tcw2);", "Tcw2 = hconcat(R21,t21);").replace("Triangulate(p11,p22,Tcw1,Tcw2,x3D);", "x3D = Triangulate(self, p11,p22,Tcw1,Tcw2);")
+    tm = re.sub(r"cv::Mat (\w+) = ", r"\1 = ", tm).replace("cv::Point2f uv1 = ", "uv1 = ").replace("cv::Point2f uv2 = ", "uv2 = ")
+    tm = tm.replace(".at<float>(", ".at(").replace("cv::norm(r1)", "F64(r1.norm64())").replace("cv::norm(r21)", "F64(r21.norm64())").replace("this->", "self.").replace("p3D = x3D.clone();", "p3D.assign(x3D.clone());")
+    tm = re.sub(r"(\d)\.f\b", r"\1.0", tm)
+    tm_src = c_to_python(cpp_prepare(tm), keep_returns=True)
+    assert tm_src.count("return -1") == 5 and "return z1" in tm_src and "cosParallaxRays" in tm_src
+    fr = _body(os.path.join(REF, "src", "Frame.cc"), r"void\s+Frame::ComputeStereoFishEyeMatches\s*\(\s*\)\s*\{")
+    fr = re.sub(r"//[^\n]*", "", fr)
+    fr = re.sub(r"vector<cv::KeyPoint> stereo(Left|Right)\([^;]*\);", "", fr)
+    fr = fr.replace("cv::Mat stereoDescLeft = mDescriptors.rowRange(monoLeft, mDescriptors.rows);", "stereoDescLeft = mDescriptors[monoLeft:];")
+    fr = fr.replace("cv::Mat stereoDescRight = mDescriptorsRight.rowRange(monoRight, mDescriptorsRight.rows);", "stereoDescRight = mDescriptorsRight[monoRight:];")
+    fr = fr.replace("mvLeftToRightMatch = vector<int>(Nleft,-1);", "mvLeftToRightMatch = [-1] * Nleft;").replace("mvRightToLeftMatch = vector<int>(Nright,-1);", "mvRightToLeftMatch = [-1] * Nright;")
+    fr = fr.replace("mvDepth = vector<float>(Nleft,-1.0f);", "mvDepth = [F32(-1)] * Nleft;").replace("mvuRight = vector<float>(Nleft,-1);", "mvuRight = [F32(-1)] * Nleft;")
+    fr = fr.replace("mvStereo3Dpoints = vector<cv::Mat>(Nleft);", "mvStereo3Dpoints = [None] * Nleft;").replace("vector<vector<cv::DMatch>> matches;", "")
+    fr = fr.replace("BFmatcher.knnMatch(stereoDescLeft,stereoDescRight,matches,2);", "matches = BFmatcher.knnMatch(stereoDescLeft,stereoDescRight,2);")
+    fr = fr.replace("for(vector<vector<cv::DMatch>>::iterator it = matches.begin(); it != matches.end(); ++it){", "foreach(it, matches) {").replace("(*it)", "it")
+    fr = fr.replace("cv::Mat p3D;", "p3D = Holder();").replace("float sigma1 = mvLevelSigma2[mvKeys[it[0].queryIdx + monoLeft].octave], sigma2 = ", "float sigma1 = mvLevelSigma2[mvKeys[it[0].queryIdx + monoLeft].octave]; float sigma2 = ")
+    fr = fr.replace("static_cast<KannalaBrandt8*>(mpCamera)->TriangulateMatches(", "mpCamera.TriangulateMatches(").replace("= p3D.clone();", "= p3D.value.clone();")
+    fr = fr.replace("mvLevelSigma2[mvKeys[it[0].queryIdx + monoLeft].octave]", "mvLevelSigma2[mvKeys[it[0].queryIdx + monoLeft].octave]")
+    fr_src = c_to_python(cpp_prepare(fr), keep_returns=True)
+    assert "mvRightToLeftMatch[it[0].trainIdx + monoRight] = it[0].queryIdx + monoLeft" in fr_src and "0.7" in fr_src
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    return ("def unproject(self, p2D):\n    mvParameters = self.p\n" + ind(un_src) +
+            "\ndef Triangulate(self, p1, p2, Tcw1, Tcw2):\n" + ind(tri_src) + "\n    return x3D" +
+            "\ndef TriangulateMatches(self, pCamera2, kp1, kp2, R12, t12, sigmaLevel, unc, p3D):\n" + ind(tm_src) +
+            "\ndef ComputeStereoFishEyeMatches(mvKeys, mvKeysRight, mDescriptors, mDescriptorsRight, monoLeft, monoRight, Nleft, Nright, mvLevelSigma2, mpCamera, mpCamera2, mRlr, mtlr):\n" +
+            "    nMatches = 0\n" + ind(fr_src) + "\n    return mvLeftToRightMatch, mvRightToLeftMatch, mvDepth, mvStereo3Dpoints, nMatches")
+
+
+def test_fisheye_stereo_matcher_is_the_references_text():
+    """Frame::ComputeStereoFishEyeMatches (S/Frame.cc:1093-1150) with KannalaBrandt8::TriangulateMatches, Triangulate and unproject
+    (S/CameraModels/KannalaBrandt8.cpp:103-133,335-420), transliterated and run on stand-ins, against the oracle: unproject float32 bit for
+    bit on 2000 pixels; mvLeftToRightMatch / mvRightToLeftMatch / nMatches equal; mvDepth and mvStereo3Dpoints to 2e-5 relative.  OpenCV's
+    two calls are stand-ins here AND restated in the oracle -- that part is not pinned by this test: cv::BFMatcher::knnMatch = the two
+    smallest distances, lower index first on ties; cv::SVD::compute = numpy's SVD of the float32 system (the oracle: Jacobi on A^T A)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    for f_, n_ in (("sqrtf", 1), ("cosf", 1), ("sinf", 1), ("tanf", 1), ("atan2f", 2), ("fminf", 2), ("fmaxf", 2), ("fabsf", 1)):
+        getattr(libm, f_).restype = ctypes.c_float; getattr(libm, f_).argtypes = [ctypes.c_float] * n_
+    f1 = lambda name: (lambda x: F32(getattr(libm, name)(float(F32(x)))))
+    f2 = lambda name: (lambda x, y: F32(getattr(libm, name)(float(F32(x)), float(F32(y)))))
+    prog = _fisheye_text_programs()
+    CamProj = _camera_standins_from_text()
+
+    class Pt:
+        def __init__(self, x, y): self.x, self.y = F32(x), F32(y)
+
+    class P3:
+        def __init__(self, x, y, z): self.x, self.y, self.z = F32(x), F32(y), F32(z)
+
+    class Holder:
+        def __init__(self): self.value = None
+        def assign(self, m): self.value = m
+
+    class M(MatF):                                             # the few more cv::Mat operations this text needs
+        def ptr(self): return [F32(x) for x in self.a.reshape(-1)]
+        def clone(self): return M(self.a.copy())
+        def norm64(self): return np.sqrt(np.sum(self.a.astype(np.float64).reshape(-1) ** 2))
+        def setrow(self, i, m): self.a[i, :] = m.a.reshape(-1)
+        def row(self, i): return M(self.a[i:i + 1, :])
+        def rowRange(self, i, j): return M(self.a[i:j, :])
+        def colRange(self, i, j): return M(self.a[:, i:j])
+        def col(self, j): return M(self.a[:, j:j + 1])
+        def t(self): return M(self.a.T.copy())                 # (a stored transpose: cv::Mat R21 = R12.t())
+        def __rmul__(self, s): return M((F32(s) * self.a).astype(np.float32))
+        def __sub__(self, o): return M(self.a - o.a)
+        def __add__(self, o): return M(self.a + o.a)
+        def __neg__(self): return M(-self.a)
+        def __truediv__(self, v): return M((self.a.astype(np.float64) / np.float64(v)).astype(np.float32))
+        def __mul__(self, o): return M(MatF(self.a) .__mul__(MatF(o.a)).a)
+
+    def svd_compute(A):
+        return M(np.linalg.svd(A.a.astype(np.float64))[2].astype(np.float32))
+
+    class Knn:
+        def knnMatch(self, q, t, k):
+            out = []
+            for i in range(len(q)):
+                d = np.unpackbits(q[i][None, :] ^ t, axis=1).sum(1)
+                order = np.argsort(d, kind="stable")[:k]
+                out.append([type("DMatch", (), {"queryIdx": i, "trainIdx": int(j), "distance": F32(d[j])})() for j in order])
+            return out
+
+    env = dict(ENV, F32=F32, F64=F64, np=np, MatF=M, Pt=Pt, P3=P3, Holder=Holder, hconcat=lambda a, b: M(np.concatenate([a.a, b.a], 1)), SVD_compute=svd_compute,
+               BFmatcher=Knn(), sqrtf=f1("sqrtf"), tanf=f1("tanf"), fminf=f2("fminf"), fmaxf=f2("fmaxf"), fabsf=f1("fabsf"), HALF_PI=F64(np.pi) / F32(2), precision=F32(1e-6))
+    exec(prog, env)
+
+    class Cam:
+        def __init__(self, c): self.p = [F32(x) for x in c[1:]]; self.proj = CamProj(c)
+        def unproject(self, p2D): return env["unproject"](self, p2D)
+        def unprojectMat(self, pt):
+            r = env["unproject"](self, pt); return M(np.array([r.x, r.y, r.z], np.float32).reshape(3, 1))
+        def project(self, m): return self.proj.project(m)
+        def TriangulateMatches(self, cam2, kp1, kp2, R12, t12, s1, s2, p3D): return env["TriangulateMatches"](self, cam2, kp1, kp2, R12, t12, s1, s2, p3D)
+
+    sc = synth.make_fisheye_stereo_scene(n_stereo=350, n_mono_left=120, n_mono_right=100, n_distract=80)
+    camL, camR = Cam(sc["left"]), Cam(sc["right"])
+    rig = views.camera_rig(sc["left"], sc["right"], sc["Trl"])
+    rng = np.random.RandomState(5)
+    for _ in range(2000):                                      # unproject: float32 bit for bit, image corners and the principal point included
+        u, v = (F32(rng.uniform(-20, 540)), F32(rng.uniform(-20, 540))) if _ > 3 else [(254.932, 256.897), (0, 0), (512, 512), (254.9321, 256.897)][_]
+        r = env["unproject"](camL, Pt(u, v))
+        assert np.array([r.x, r.y, r.z], np.float32).tobytes() == ob.kb8_unproject(rig.left, float(F32(u)), float(F32(v))).tobytes(), (u, v)
+    v_, keep = views.fisheye_stereo_view(sc["kps_left"], sc["desc_left"], sc["mono_left"], sc["kps_right"], sc["desc_right"], sc["mono_right"], sc["left"],
+                                         sc["right"], sc["Tlr"], sc["level_sigma2"])
+    l2r, r2l, depth, p3d, n = ob.fisheye_stereo_matches(v_)
+
+    class Kp:
+        def __init__(self, k): self.pt = Pt(k["x"], k["y"]); self.octave = int(k["octave"])
+    Tlr = M(sc["Tlr"])
+    out = env["ComputeStereoFishEyeMatches"]([Kp(k) for k in sc["kps_left"]], [Kp(k) for k in sc["kps_right"]], sc["desc_left"], sc["desc_right"], sc["mono_left"],
+                                             sc["mono_right"], len(sc["kps_left"]), len(sc["kps_right"]), [F32(x) for x in sc["level_sigma2"]], camL, camR,
+                                             Tlr.rowRange(0, 3).colRange(0, 3), Tlr.col(3))
+    assert out[4] == n and n > 60 and list(out[0]) == list(l2r) and list(out[1]) == list(r2l), (out[4], n)
+    hit = np.nonzero(l2r >= 0)[0]
+    td = np.array([float(out[2][i]) for i in hit]); tp = np.stack([out[3][i].a.reshape(3) for i in hit])
+    assert np.abs(td - depth[hit]).max() <= 2e-5 * np.abs(depth[hit]).max() and np.abs(tp - p3d[hit]).max() <= 2e-5 * np.abs(p3d[hit]).max()
+    assert all(float(out[2][i]) == -1.0 for i in range(len(l2r)) if l2r[i] < 0)

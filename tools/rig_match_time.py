@@ -64,5 +64,18 @@ def main():
         print(f"  SearchByBoW(KeyFrame, Frame), 900 keyframe features {g4:6.1f} us   oracle {o4:8.1f} us")
 
 
+def fisheye_ctor():
+    """Frame::ComputeStereoFishEyeMatches (the left-right matcher of the two-fisheye Frame constructor)."""
+    for kw in (dict(), dict(n_stereo=1500, n_mono_left=600, n_mono_right=550, n_distract=300)):
+        sc = synth.make_fisheye_stereo_scene(**kw)
+        v, keep = views.fisheye_stereo_view(sc["kps_left"], sc["desc_left"], sc["mono_left"], sc["kps_right"], sc["desc_right"], sc["mono_right"], sc["left"],
+                                            sc["right"], sc["Tlr"], sc["level_sigma2"])
+        g = timed(lambda: api.ComputeStereoFishEyeMatches(v), 50)
+        o = timed(lambda: ob.fisheye_stereo_matches(v), 5)
+        print(f"ComputeStereoFishEyeMatches, {v.n_left} + {v.n_right} features ({v.n_left - v.mono_left} x {v.n_right - v.mono_right} in the lapping areas): "
+              f"{g:.1f} us   oracle {o:.1f} us   ({api.ComputeStereoFishEyeMatches(v)[4]} matches)")
+
+
 if __name__ == "__main__":
     main()
+    fisheye_ctor()
