@@ -1369,9 +1369,7 @@ struct FisheyeDev {
   const float* sigma2;
   RigCamF cam1, cam2;
   float Tlr[12];
-  int* l2r; float* depth; float* p3d;                      // nq entries each (p3d: 3 nq)
-  int* r2l;                                                // nt entries, preset to -1
-  int* n_matches;
+  int* l2r; float* depth; float* p3d;                      // nq entries each (p3d: 3 nq): mapped pinned memory, read by the host after the signal
 };
 
 // KannalaBrandt8::unproject, S/CameraModels/KannalaBrandt8.cpp:103-133
@@ -1401,12 +1399,14 @@ __device__ void null_vector4(double S[4][4], double* v) {   // eigenvector of th
 #pragma unroll
     for (int j = 0; j < 4; j++) V[i][j] = i == j ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0;
+    double off = 0, diag = 0;
 #pragma unroll
-    for (int p = 0; p < 4; p++)
+    for (int p = 0; p < 4; p++) {
+      diag += S[p][p] * S[p][p];
 #pragma unroll
       for (int q = p + 1; q < 4; q++) off += S[p][q] * S[p][q];
-    if (off < 1e-300) break;
+    }
+    if (off <= 1e-28 * diag) break;                         // eigenvectors to ~1e-14: far below the float32 the result is rounded to
 #pragma unroll
     for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -1523,8 +1523,6 @@ __global__ __launch_bounds__(256) void fisheye_stereo_kernel(FisheyeDev D) {
     D.l2r[q] = i1 + D.mono_right;
     D.depth[q] = z;
     D.p3d[3 * q] = p3D[0]; D.p3d[3 * q + 1] = p3D[1]; D.p3d[3 * q + 2] = p3D[2];
-    atomicMax(D.r2l + i1, q + D.mono_left);                    // several left features on one right feature: the last one stays (:1145)
-    atomicAdd(D.n_matches, 1);
   }
 }
 
@@ -1545,46 +1543,47 @@ extern "C" int orbx_fisheye_stereo_matches(int device, const orbx_fisheye_stereo
   for (int i = 0; i < v->n_right; i++) right_to_left[i] = -1;
   if (n_matches) *n_matches = 0;
   if (nq == 0 || nt < 2) return ORBG_OK;
-  // one pinned block in, one out (buffers of the calling thread, kept from frame to frame)
-  struct Scratch { int device = -1; PinnedBuf<uint8_t> in, out; DevBuf<uint8_t> din, dout; };
+  // one pinned block in (one copy to the device), results straight into mapped pinned memory (buffers of the calling thread, kept from
+  // frame to frame); mvRightToLeftMatch and nMatches follow from mvLeftToRightMatch on the host (:1144-1145: the last left feature stays)
+  struct Scratch { int device = -1; PinnedBuf<uint8_t> in, out; DevBuf<uint8_t> din; StreamSignal sig; hipStream_t st = nullptr; };
   static thread_local Scratch S;
-  if (S.device != device) { S.in.release(); S.out.release(); S.din = DevBuf<uint8_t>(); S.dout = DevBuf<uint8_t>(); S.device = device; }
+  if (S.device != device) {
+    S.in.release(); S.out.release(); S.din = DevBuf<uint8_t>(); S.sig.release(); S.sig = StreamSignal(); S.device = device;
+    if (S.st) { release_stream(S.st); S.st = nullptr; }
+    ORBG_HIP(create_stream(&S.st, "misc"));             // the library's M stream (kept: a stream object per call costs a synchronisation)
+  }
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
   const size_t o_kl = 0, o_kr = up(o_kl + (size_t)nq * sizeof(orbx_keypoint)), o_dl = up(o_kr + (size_t)nt * sizeof(orbx_keypoint)), o_dr = up(o_dl + (size_t)nq * 32),
                o_sg = up(o_dr + (size_t)nt * 32), in_bytes = up(o_sg + (size_t)v->n_levels * 4);
-  const size_t p_l2r = 0, p_dep = up(p_l2r + (size_t)nq * 4), p_p3d = up(p_dep + (size_t)nq * 4), p_r2l = up(p_p3d + (size_t)nq * 12), p_n = up(p_r2l + (size_t)nt * 4),
-               out_bytes = up(p_n + 4);
-  if ((rc = S.in.reserve(in_bytes)) || (rc = S.out.reserve(out_bytes)) || (rc = S.din.reserve(in_bytes)) || (rc = S.dout.reserve(out_bytes))) return rc;
+  const size_t p_l2r = 0, p_dep = up(p_l2r + (size_t)nq * 4), p_p3d = up(p_dep + (size_t)nq * 4), out_bytes = up(p_p3d + (size_t)nq * 12);
+  if ((rc = S.in.reserve(in_bytes)) || (rc = S.out.reserve(out_bytes)) || (rc = S.din.reserve(in_bytes))) return rc;
   memcpy(S.in.h + o_kl, v->kps_left + v->mono_left, (size_t)nq * sizeof(orbx_keypoint));
   memcpy(S.in.h + o_kr, v->kps_right + v->mono_right, (size_t)nt * sizeof(orbx_keypoint));
   memcpy(S.in.h + o_dl, v->desc_left + (size_t)v->mono_left * 32, (size_t)nq * 32);
   memcpy(S.in.h + o_dr, v->desc_right + (size_t)v->mono_right * 32, (size_t)nt * 32);
   memcpy(S.in.h + o_sg, v->level_sigma2, (size_t)v->n_levels * 4);
-  orbg::MiscStream ms;
-  if ((rc = ms.open())) return rc;
-  ORBG_HIP(hipMemcpyAsync(S.din.p, S.in.h, in_bytes, hipMemcpyHostToDevice, ms.s));
-  ORBG_HIP(hipMemsetAsync(S.dout.p + p_r2l, 0xFF, out_bytes - p_r2l, ms.s));          // r2l = -1 ...
-  ORBG_HIP(hipMemsetAsync(S.dout.p + p_n, 0, 4, ms.s));                               // ... and the match counter = 0
+  ORBG_HIP(hipMemcpyAsync(S.din.p, S.in.h, in_bytes, hipMemcpyHostToDevice, S.st));
   FisheyeDev D;
   D.nq = nq; D.nt = nt; D.mono_left = v->mono_left; D.mono_right = v->mono_right;
   D.kl = reinterpret_cast<const orbx_keypoint*>(S.din.p + o_kl); D.kr = reinterpret_cast<const orbx_keypoint*>(S.din.p + o_kr);
   D.dl = S.din.p + o_dl; D.dr = S.din.p + o_dr; D.sigma2 = reinterpret_cast<const float*>(S.din.p + o_sg);
   D.cam1 = rig_cam_of(v->left); D.cam2 = rig_cam_of(v->right);
   memcpy(D.Tlr, v->Tlr, sizeof(D.Tlr));
-  D.l2r = reinterpret_cast<int*>(S.dout.p + p_l2r); D.depth = reinterpret_cast<float*>(S.dout.p + p_dep); D.p3d = reinterpret_cast<float*>(S.dout.p + p_p3d);
-  D.r2l = reinterpret_cast<int*>(S.dout.p + p_r2l); D.n_matches = reinterpret_cast<int*>(S.dout.p + p_n);
-  hipLaunchKernelGGL(fisheye_stereo_kernel, dim3((nq + 3) / 4), dim3(256), 0, ms.s, D);
+  D.l2r = reinterpret_cast<int*>(S.out.d + p_l2r); D.depth = reinterpret_cast<float*>(S.out.d + p_dep); D.p3d = reinterpret_cast<float*>(S.out.d + p_p3d);
+  hipLaunchKernelGGL(fisheye_stereo_kernel, dim3((nq + 3) / 4), dim3(256), 0, S.st, D);
   ORBG_HIP(hipGetLastError());
-  ORBG_HIP(hipMemcpyAsync(S.out.h, S.dout.p, out_bytes, hipMemcpyDeviceToHost, ms.s));
-  ORBG_HIP(hipStreamSynchronize(ms.s));
+  if ((rc = S.sig.sync(S.st))) return rc;
   const int* h_l2r = reinterpret_cast<const int*>(S.out.h + p_l2r); const float* h_dep = reinterpret_cast<const float*>(S.out.h + p_dep);
-  const float* h_p3d = reinterpret_cast<const float*>(S.out.h + p_p3d); const int* h_r2l = reinterpret_cast<const int*>(S.out.h + p_r2l);
+  const float* h_p3d = reinterpret_cast<const float*>(S.out.h + p_p3d);
+  int nm = 0;
   for (int q = 0; q < nq; q++) {
     left_to_right[v->mono_left + q] = h_l2r[q]; depth[v->mono_left + q] = h_dep[q];
-    if (h_l2r[q] >= 0) memcpy(points3d + 3 * (size_t)(v->mono_left + q), h_p3d + 3 * (size_t)q, 12);
+    if (h_l2r[q] < 0) continue;
+    memcpy(points3d + 3 * (size_t)(v->mono_left + q), h_p3d + 3 * (size_t)q, 12);
+    right_to_left[h_l2r[q]] = v->mono_left + q;             // ascending q: the last one stays
+    nm++;
   }
-  for (int t = 0; t < nt; t++) right_to_left[v->mono_right + t] = h_r2l[t];
-  if (n_matches) *n_matches = *reinterpret_cast<const int*>(S.out.h + p_n);
+  if (n_matches) *n_matches = nm;
   return ORBG_OK;
 }
 

@@ -53,9 +53,9 @@ inline void kb8_unproject_f(const orbg_camera& c, float u, float v, float* ray) 
 void smallest_eigenvector4(double S[4][4], double* v) {
   double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
   for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0;
-    for (int p = 0; p < 4; p++) for (int q = p + 1; q < 4; q++) off += S[p][q] * S[p][q];
-    if (off < 1e-300) break;
+    double off = 0, diag = 0;
+    for (int p = 0; p < 4; p++) { diag += S[p][p] * S[p][p]; for (int q = p + 1; q < 4; q++) off += S[p][q] * S[p][q]; }
+    if (off <= 1e-28 * diag) break;                         // eigenvectors to ~1e-14: far below the float32 the result is rounded to
     for (int p = 0; p < 4; p++)
       for (int q = p + 1; q < 4; q++) {
         if (S[p][q] == 0.0) continue;
