@@ -1502,13 +1502,23 @@ def rig_parity(api, views):
                   "frustum_max_projection_diff_px": float(max(np.abs(gt[s_][k].astype(np.float64) - ot[s_][k]).max() for s_ in (0, 1) for k in ("proj_x", "proj_y"))),
                   "search_map_points_matches": [int(gs[2]), int(os_[2])], "search_map_points_features_differing": int((gs[0] != os_[0]).sum()),
                   "search_last_frame_matches": [int(gf[2]), int(of[2])], "search_last_frame_features_differing": int((gf[0] != of[0]).sum())})
+        # ... and the left-right matcher of the two-fisheye Frame constructor (Frame::ComputeStereoFishEyeMatches, S/Frame.cc:1093-1150)
+        fs = synth.make_fisheye_stereo_scene()
+        fsv, k7 = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"],
+                                            fs["right"], fs["Tlr"], fs["level_sigma2"])
+        gc, oc = api.ComputeStereoFishEyeMatches(fsv), ob.fisheye_stereo_matches(fsv)
+        hit = oc[0] >= 0
+        d.update({"fisheye_stereo_matches": [int(gc[4]), int(oc[4])],
+                  "fisheye_partner_arrays_equal": bool(np.array_equal(gc[0], oc[0]) and np.array_equal(gc[1], oc[1])),
+                  "fisheye_max_relative_depth_diff": float(np.abs(gc[2][hit] - oc[2][hit]).max() / np.abs(oc[2][hit]).max()) if hit.any() else 0.0})
         d["ok"] = bool(d["lba_iterations_equal"] and d["lba_max_pose_diff"] <= 1e-4 and d["lba_max_point_diff"] <= 1e-4 and
                        d["lba_outlier_flags_differing"] <= 1 and d["pose_opt_max_pose_diff"] <= 1e-5 and
+                       d["fisheye_partner_arrays_equal"] and gc[4] == oc[4] > 150 and d["fisheye_max_relative_depth_diff"] <= 1e-5 and
                        d["pose_opt_outlier_flags_differing"] <= 1 and d["frustum_flags_and_levels_equal"] and
                        d["frustum_max_projection_diff_px"] <= 3e-4 and gs[2] == os_[2] > 300 and d["search_map_points_features_differing"] == 0 and
                        gf[2] == of[2] > 200 and d["search_last_frame_features_differing"] == 0)
         d["what"] = ("8 + 4 keyframes / 600 points of a two-fisheye rig through lba_solve_h, 300 + 200 features through pose_optimize, "
-                     "isInFrustum / SearchByProjection(F, MPs) / SearchByProjection(Cur, Last) on a two-camera frame; "
+                     "isInFrustum / SearchByProjection(F, MPs) / SearchByProjection(Cur, Last) on a two-camera frame, ComputeStereoFishEyeMatches; "
                      "product vs oracle; tolerances of tests/test_gpu_parity.py (-k 'rig or two_camera')")
         return d
     except Exception as e:

@@ -70,6 +70,7 @@ def test_bench_line_has_the_contract_fields():
     # ... and Tracking's matchers on a two-camera frame of that rig
     assert rg["frustum_flags_and_levels_equal"] and rg["search_map_points_features_differing"] == 0 and rg["search_last_frame_features_differing"] == 0
     assert rg["search_map_points_matches"][0] == rg["search_map_points_matches"][1] > 300
+    assert rg["fisheye_partner_arrays_equal"] and rg["fisheye_stereo_matches"][0] == rg["fisheye_stereo_matches"][1] > 150
 
 
 @pytest.mark.gpu
