@@ -371,7 +371,9 @@ int orbm_search_by_projection_sim3(orbm_frame* kf, orbm_map* pts, const float* S
 
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), S/ORBmatcher.cc:819-959.
  * kf2 = pKF2 with its feature vector fv2 and mp_valid2[i] = (MapPoint present and not bad); the pKF1 side is flattened
- * as for orbm_search_by_bow.  matches12[n1] out: feature index in pKF2 (-> vpMapPoints2[idx]) or -1. */
+ * as for orbm_search_by_bow.  matches12[n1] out: feature index in pKF2 (-> vpMapPoints2[idx]) or -1.
+ * Two-camera keyframes (NLeft != -1): the reference leaves out every feature with index >= mvKeysUn.size() on either side
+ * (:854-856, :874-876) -- pass mp_valid1 / mp_valid2 = 0 for those. */
 /* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
  * const int ORBdist) -- the relocalisation overload, I/ORBmatcher.h:54, S/ORBmatcher.cc:2188-2310 (Tracking::Relocalization,
  * S/Tracking.cc:3372-3410: th = 10 / ORBdist = 100, then th = 3 / ORBdist = 64).  kf_points: pKF->GetMapPointMatches() uploaded
