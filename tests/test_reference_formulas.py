@@ -3557,3 +3557,156 @@ def test_fisheye_stereo_matcher_is_the_references_text():
     td = np.array([float(out[2][i]) for i in hit]); tp = np.stack([out[3][i].a.reshape(3) for i in hit])
     assert np.abs(td - depth[hit]).max() <= 2e-5 * np.abs(depth[hit]).max() and np.abs(tp - p3d[hit]).max() <= 2e-5 * np.abs(p3d[hit]).max()
     assert all(float(out[2][i]) == -1.0 for i in range(len(l2r)) if l2r[i] < 0)
+
+
+def test_glues_local_ba_write_back_is_the_references_text():
+    """include/orbgpu_dropin.hpp's LocalBundleAdjustment after the solve (run by tests/cpp/glue_lba_writeback_dump over an entry-point set
+    that answers with a synthetic solve) against the reference's OWN text of that part -- S/Optimizer.cc:2205-2400: vToErase from the
+    edges' chi2 / isDepthPositive (a point that turned bad meanwhile keeps its observation), the erasures (EraseMapPointMatch +
+    EraseObservation), SetPose(.., true) for every local keyframe, SetWorldPos(.., true) + UpdateNormalAndDepth() for every local point,
+    one IncreaseChangeIndex() -- transliterated and run on Python stand-ins of the same window: every keyframe's pose, lock-flag count
+    and matches, every point's position, lock-flag count, UpdateNormalAndDepth count and observations, the map's change index.  A
+    pinhole window, a two-fisheye-rig window, and the 50 %-outlier refusal (nothing may be written)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "tests", "cpp"); exe = os.path.join(cpp, "glue_lba_writeback_dump")
+    lib_dir = os.path.join(root, "multi_orbslam3_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wno-unused-function", "-I", os.path.join(root, "include"), "-I", cpp, os.path.join(cpp, "glue_lba_writeback_dump.cpp"),
+                           "-o", exe, "-pthread", "-L", lib_dir, "-lorbgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.check_output([exe], text=True)
+    scenes = [json.loads(("{\"scene\"" + part) if not part.startswith("{") else part) for part in out.split("\n{\"scene\"") if part.strip()]
+    assert len(scenes) == 3
+    body = _body(os.path.join(REF, "src", "Optimizer.cc"), r"void\s+Optimizer::LocalBundleAdjustment\s*\(\s*KeyFrame\s*\*pKF,\s*bool\s*\*\s*pbStopFlag,\s*Map\s*\*\s*pMap,\s*int&\s*num_fixedKF[^)]*\)\s*\{")
+    body = re.sub(r"//[^\n]*", "", body)
+    piece = re.sub(r"\s+", " ", body[body.index("vector<pair<KeyFrame*,MapPoint*> > vToErase;"):])
+    piece = re.sub(r"Verbose::PrintMess\([^;]*;", "", piece)
+    # the two diagnostic blocks (file output under bRedrawError, which is never true past the early return; statistics for a keyframe that
+    # moved by more than a metre) are cut at their braces
+    def cut_block(text, head):
+        i = text.index(head); j = text.index("{", i); depth = 0
+        for k in range(j, len(text)):
+            depth += text[k] == "{"; depth -= text[k] == "}"
+            if depth == 0:
+                return text[:i] + text[k + 1:]
+        raise AssertionError(head)
+    while "if(bRedrawError)" in piece:
+        piece = cut_block(piece, "if(bRedrawError)")
+    piece = cut_block(piece, "if(dist > 1.0)")
+    early = piece.index("if(vToErase.size() >= (vpMapPointEdgeMono.size()+vpMapPointEdgeStereo.size()) * 0.5)")
+    piece = piece[:early] + 'if(refused) { return "REFUSED"; }' + cut_block(piece[early:], "if(vToErase.size() >=")
+    for a, b in [("vector<pair<KeyFrame*,MapPoint*> > vToErase;", "vToErase = [];"), ("bool bRedrawError = false;", ""), ("bool bShowStats = false;", ""),
+                 ("unique_lock<mutex> lock(pMap->mMutexMapUpdate);", "pMap.mMutexMapUpdate.lock();"), ("map<KeyFrame*, int> mspInitialConnectedKFs;", ""),
+                 ("map<KeyFrame*, int> mspInitialObservationKFs;", ""), ("map<KeyFrame*, int> mspFinalConnectedKFs;", ""), ("map<KeyFrame*, int> mspFinalObservationKFs;", ""),
+                 ("for(list<KeyFrame*>::iterator lit=lLocalKeyFrames.begin(), lend=lLocalKeyFrames.end(); lit!=lend; lit++) { KeyFrame* pKFi = *lit;", "foreach(pKFi, lLocalKeyFrames) {"),
+                 ("for(list<MapPoint*>::iterator lit=lLocalMapPoints.begin(), lend=lLocalMapPoints.end(); lit!=lend; lit++) { MapPoint* pMP = *lit;", "foreach(pMP, lLocalMapPoints) {"),
+                 ("g2o::SE3Quat SE3quat = vSE3->estimate();", "SE3quat = vSE3->estimate();"), ("cv::Mat Tiw = ", "Tiw = "), ("cv::Mat Tco_cn = ", "Tco_cn = "),
+                 ("cv::Vec3d trasl = ", "trasl = "), ("double dist = cv::norm(trasl);", "dist = trasl.norm();")]:
+        assert a in piece, a
+        piece = piece.replace(a, b)
+    piece = re.sub(r"vToErase\.reserve\([^;]*;", "", piece).replace("make_pair(", "(").replace(".push_back(", ".append(")
+    piece = re.sub(r"for\(size_t i=0, iend=(\w+)\.size\(\); i<iend; ?i\+\+\)", r"for(int i=0; i<len(\1); i++)", piece)
+    piece = piece.replace("for(size_t i=0;i<vToErase.size();i++)", "for(int i=0; i<len(vToErase); i++)").replace("vToErase[i].first", "vToErase[i][0]").replace("vToErase[i].second", "vToErase[i][1]")
+    piece = re.sub(r"g2o::VertexSE3Expmap\* vSE3 = static_cast<g2o::VertexSE3Expmap\*> ?\(", "vSE3 = (", piece)
+    piece = re.sub(r"g2o::VertexSBAPointXYZ\* vPoint = static_cast<g2o::VertexSBAPointXYZ\*> ?\(", "vPoint = (", piece)
+    piece = piece.replace("Optimizer::GetID(", "GetID(").replace("Converter::", "Converter_")
+    src = c_to_python(cpp_prepare(piece), keep_returns=True)
+    assert src.count("vToErase.append(") == 3 and "pKFi.SetPose(Converter_toCvMat(SE3quat), True)" in src and "pMP.SetWorldPos(Converter_toCvMat(vPoint.estimate()), True)" in src
+    assert "pMP.UpdateNormalAndDepth()" in src and "pMap.IncreaseChangeIndex()" in src and "pMPi.EraseObservation(pKFi)" in src and "pMap.mMutexMapUpdate.lock()" in src
+    gid = _body(os.path.join(REF, "include", "Optimizer.h"), r"size_t\s+static\s+GetID\s*\([^)]*\)\s*\{")
+    gid_src = c_to_python(cpp_prepare(gid.replace("unsigned(", "int(")), keep_returns=True)
+    ind = lambda text: "\n".join("    " + ln for ln in text.splitlines())
+    prog = ("def GetID(mId, mClientId, bIsKf):\n" + ind(gid_src) +
+            "\ndef write_back(refused, optimizer, pMap, pKF, lLocalKeyFrames, lLocalMapPoints, vpEdgesMono, vpMapPointEdgeMono, vpEdgeKFMono, vpEdgesBody, vpMapPointEdgeBody, "
+            "vpEdgeKFBody, vpEdgesStereo, vpMapPointEdgeStereo, vpEdgeKFStereo):\n" + ind(src) + "\n    return \"APPLIED\"")
+
+    class Mat4:
+        def __init__(self, a): self.a = np.asarray(a, np.float32).reshape(4, 4)
+        def inv(self): return Mat4(np.linalg.inv(self.a.astype(np.float64)))
+        def __mul__(self, o): return Mat4(self.a.astype(np.float64) @ o.a.astype(np.float64))
+        def rowRange(self, i, j): return Sub(self.a[i:j, :])
+
+    class Sub:
+        def __init__(self, a): self.a = a
+        def col(self, j): return Sub(self.a[:, j])
+        def norm(self): return float(np.linalg.norm(self.a.astype(np.float64)))
+
+    for sc in scenes:
+        class Mutex:
+            locked = 0
+            def lock(self): Mutex.locked += 1
+        class MapS:
+            pass
+        pMap = MapS(); pMap.change = sc["before"]["change_index"]; pMap.mMutexMapUpdate = Mutex()
+        pMap.IncreaseChangeIndex = lambda: setattr(pMap, "change", pMap.change + 1)
+        kfs, mps = {}, {}
+        class KF:
+            pass
+        class MP:
+            pass
+        for d in sc["before"]["kfs"]:
+            k = KF(); k.mnId, k.mnClientId = d["id"], d["client"]; k.pose = Mat4(d["pose"]); k.locked = d["locked_writes"]; k.matches = list(d["matches"])
+            k.GetPose = (lambda k=k: k.pose)
+            def set_pose(T, lock=False, k=k): k.pose = T; k.locked += bool(lock)
+            k.SetPose = set_pose
+            k.EraseMapPointMatch = (lambda mp, k=k: setattr(k, "matches", [-1 if m == mp.mnId else m for m in k.matches]))
+            kfs[d["id"]] = k
+        for d in sc["before"]["mps"]:
+            m = MP(); m.mnId, m.mnClientId = d["id"], d["client"]; m.pos = np.array(d["pos"], np.float32); m.locked = d["locked_writes"]; m.updates = d["normal_updates"]
+            m.obs = list(d["obs"]); m.bad = bool(d["bad"]) or d["id"] == sc["turned_bad"]
+            m.isBad = (lambda m=m: m.bad)
+            def set_pos(X, lock=False, m=m): m.pos = np.asarray(X, np.float32); m.locked += bool(lock)
+            m.SetWorldPos = set_pos
+            m.UpdateNormalAndDepth = (lambda m=m: setattr(m, "updates", m.updates + 1))
+            m.EraseObservation = (lambda kf, m=m: setattr(m, "obs", [o for o in m.obs if o != kf.mnId]))
+            mps[d["id"]] = m
+        refused = sc["status"] == 2
+        env = dict(ENV, F32=F32, F64=F64, Converter_toCvMat=lambda x: x, IDRANGE=1000000, MAXAGENTS=4)
+        exec(prog, env)
+        gid_f = env["GetID"]
+
+        class Vtx:
+            def __init__(self, est): self.est = est
+            def estimate(self): return self.est
+
+        class Opt:
+            v = {}
+            def vertex(self, i): return Opt.v[int(i)]
+        Opt.v = {}
+        lkf, lmp = [], []
+        if not refused:
+            for i, kid in enumerate(sc["pose_kf"]):
+                if not sc["fixed"][i]:
+                    lkf.append(kfs[kid])
+                Opt.v[gid_f(kid, kfs[kid].mnClientId, True)] = Vtx(Mat4(sc["poses_out"][16 * i:16 * i + 16]))
+            for j, pid in enumerate(sc["point_mp"]):
+                lmp.append(mps[pid]); Opt.v[gid_f(pid, mps[pid].mnClientId, False)] = Vtx(np.array(sc["points_out"][3 * j:3 * j + 3], np.float32))
+
+        class Edge:
+            def __init__(self, flagged, depth_pos): self.f, self.d = flagged, depth_pos
+            def chi2(self): return F64(50.0) if (self.f and self.d) else F64(1.0)
+            def isDepthPositive(self): return bool(self.d)
+        groups = {"mono": ([], [], []), "body": ([], [], []), "stereo": ([], [], [])}
+        for kid, pid, ur, flagged, dpos in sc["edges"]:
+            kind = "stereo" if ur >= 0 else ("body" if ur <= -1.5 and sc["has_right"] else "mono")
+            g = groups[kind]; g[0].append(Edge(flagged, dpos)); g[1].append(mps[pid]); g[2].append(kfs[kid])
+        res = env["write_back"](refused, Opt(), pMap, kfs[sc["current_kf"]], lkf, lmp, *groups["mono"], *groups["body"], *groups["stereo"])
+        assert res == ("REFUSED" if refused else "APPLIED") and Mutex.locked == (0 if refused else 1)
+        after = sc["after"]
+        assert pMap.change == after["change_index"] == sc["before"]["change_index"] + (0 if refused else 1), sc["scene"]
+        n_moved = n_erased = 0
+        for d in after["kfs"]:
+            k = kfs[d["id"]]
+            assert np.array_equal(np.float32(k.pose.a).reshape(-1), np.float32(d["pose"])) and k.locked == d["locked_writes"] and k.matches == d["matches"], (sc["scene"], d["id"])
+            n_moved += d["locked_writes"]
+        for d in after["mps"]:
+            m = mps[d["id"]]
+            assert np.array_equal(m.pos, np.float32(d["pos"])) and m.locked == d["locked_writes"] and m.updates == d["normal_updates"] and sorted(m.obs) == sorted(d["obs"]), (sc["scene"], d["id"])
+        before_obs = {d["id"]: len(d["obs"]) for d in sc["before"]["mps"]}
+        n_erased = sum(before_obs[d["id"]] - len(d["obs"]) for d in after["mps"])
+        if refused:
+            assert n_moved == 0 and n_erased == 0 and after == sc["before"]
+        else:
+            assert n_moved >= 7 and n_erased > 150
+            bad = [d for d in after["mps"] if d["id"] == sc["turned_bad"]][0]            # its flagged observation was NOT erased
+            assert sc["edges"][3][3] == 1 and sc["edges"][3][0] in bad["obs"]
