@@ -29,3 +29,4 @@ template int od::SearchByBoW<od::GpuOps, KeyFrame, Frame, MapPoint>(KeyFrame*, F
 template int od::LocalBundleAdjustment<od::GpuOps, KeyFrame, Map>(KeyFrame*, bool*, Map*, int&, int);
 template int od::LocalBundleAdjustment<NoStampOps, KeyFrame, Map>(KeyFrame*, bool*, Map*, int&, int);
 template int od::PoseOptimization<od::GpuOps, Frame>(Frame*);
+template int od::ComputeStereoFishEyeMatches<od::GpuOps, Frame>(Frame&);
