@@ -529,7 +529,10 @@ typedef struct orbg_camera_rig {
  * rig->left for the left camera and through rig->right after mTrl for the right one; Tlr = Frame::mTlr (3 x 4 row-major, its
  * translation enters the right camera's centre, :1164).  Outputs, m entries each, per camera: mbTrackInView(R), mTrackProjX(R) /
  * mTrackProjY(R), mTrackDepth(R), mnTrackScaleLevel(R) (-1 where the checks fail, :546-547), mTrackViewCos(R); fields of a point that
- * fails a camera's checks are 0 (the reference leaves the previous frame's values there). */
+ * fails a camera's checks are 0 (the reference leaves the previous frame's values there).
+ * rig->has_right == 0: ONE camera behind a model -- a monocular fisheye Frame (Nleft == -1, mpCamera a KannalaBrandt8): the Nleft == -1
+ * branch of Frame::isInFrustum (S/Frame.cc:466-543) makes the same checks through mpCamera->project; the left outputs are written, the
+ * right ones (and Tlr) may be NULL.  (orbm_is_in_frustum is that branch for a pinhole.) */
 int orbm_is_in_frustum_rig(orbm_frame* left, const float* Tcw /*16*/, const orbg_camera_rig* rig, const float* Tlr /*12*/,
                            const orbm_worldpoints_view* pts, float viewing_cos_limit, uint8_t* in_view, float* proj_x, float* proj_y,
                            float* track_depth, int32_t* scale_level, float* view_cos, uint8_t* in_view_r, float* proj_x_r, float* proj_y_r,
@@ -548,7 +551,9 @@ int orbm_search_by_projection_mps_rig(orbm_frame* left, orbm_frame* right, const
  * (S/ORBmatcher.cc:1970-2186): per map point of the last frame the left camera's search through rig->left (mpCamera->project), then
  * (:2092-2160) the point in the right camera's frame (rig->Trl) projected -- through mpCamera again, as the reference does -- and
  * searched in the right camera's grid; a point whose left window holds no feature is not searched on the right either (:2033).
- * `last`: the last frame's Nleft + Nright entries (octave / angle of mvKeys resp. mvKeysRight).  assigned_*: Nleft + Nright entries. */
+ * `last`: the last frame's Nleft + Nright entries (octave / angle of mvKeys resp. mvKeysRight).  assigned_*: Nleft + Nright entries.
+ * rig->has_right == 0 and right == NULL: a monocular Frame whose camera is a model (Nleft == -1, mpCamera a KannalaBrandt8): the left
+ * camera's search alone, through mpCamera->project (orbm_search_by_projection_frame is the same for a pinhole). */
 int orbm_search_by_projection_frame_rig(orbm_frame* left, orbm_frame* right, const float* Tcw_cur, const orbg_camera_rig* rig,
                                         const orbm_lastframe_view* last, float th, int mono, int check_orientation, int32_t* assigned_mp,
                                         int32_t* assigned_obs, int* nmatches);

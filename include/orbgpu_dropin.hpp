@@ -128,7 +128,9 @@ struct GpuOps {
   static int search_frame_rig(const FrameKey& kl, const orbm_frame_view& vl, const FrameKey& kr, const orbm_frame_view& vr, const float* Tcw,
                               const orbg_camera_rig& rig, const orbm_lastframe_view& last, float th, int mono, int check_ori, int32_t* amp,
                               int32_t* aob, int* n) {
-    FrameOnDevice& L = frame(kl, vl); FrameOnDevice& R = frame(kr, vr);
+    FrameOnDevice& L = frame(kl, vl);
+    if (!rig.has_right) return orbm_search_by_projection_frame_rig(L.handle(), nullptr, Tcw, &rig, &last, th, mono, check_ori, amp, aob, n);
+    FrameOnDevice& R = frame(kr, vr);
     return orbm_search_by_projection_frame_rig(L.handle(), R.handle(), Tcw, &rig, &last, th, mono, check_ori, amp, aob, n);
   }
   // isInFrustum(., 0.5) for every non-skipped point + SearchByProjection(F, points) in one device pass; in_frustum[m] out
@@ -475,6 +477,47 @@ int SearchByProjectionRig(FrameT& F, const FrameFlat& L, const FrameFlat& R, con
   return n;
 }
 
+template <class Ops, class FrameT, class MapPointT>
+int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints, float mfNNratio);
+// Tracking::SearchLocalPoints on a monocular Frame whose camera is a model (Nleft == -1, mpCamera a KannalaBrandt8): isInFrustum's
+// Nleft == -1 branch projects through mpCamera->project (S/Frame.cc:489); the search itself is the single-camera one.
+template <class Ops, class FrameT, class MapPointT>
+int SearchLocalPointsModelCamera(FrameT& F, const orbg_camera_rig& rig, const std::vector<MapPointT*>& vpLocalMapPoints, float th, bool bFarPoints,
+                                 float thFarPoints, float mfNNratio) {
+  std::vector<MapPointT*> cand;
+  for (MapPointT* pMP : vpLocalMapPoints) {
+    if (pMP->mnLastFrameSeen == F.mnId) continue;
+    if (pMP->isBad()) continue;
+    cand.push_back(pMP);
+  }
+  if (cand.empty()) return 0;
+  const int M = (int)cand.size();
+  FrameFlat ff; flatten_frame<Ops>(F, ff);
+  ff.key.resident = nullptr;
+  std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M); std::vector<uint8_t> bad(M, 0); std::vector<int32_t> nobs(M);
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = cand[i];
+    const auto X = p->GetWorldPos(); const auto nv = p->GetNormal();
+    std::memcpy(&pos[3 * (size_t)i], mat_f32(X), 12); std::memcpy(&nrm[3 * (size_t)i], mat_f32(nv), 12);
+    dmin[i] = min_distance_raw(p, 0); dmax[i] = max_distance_raw(p, 0); nobs[i] = p->Observations();
+  }
+  orbm_worldpoints_view wv{M, pos.data(), nrm.data(), dmin.data(), dmax.data(), nullptr, nobs.data(), bad.data(), nullptr};
+  std::vector<uint8_t> inv(M); std::vector<float> px(M), py(M), dep(M), vc(M); std::vector<int32_t> lvl(M);
+  check(Ops::is_in_frustum_rig(ff.key, ff.v, mat_f32(F.mTcw), rig, nullptr, wv, 0.5f, inv.data(), px.data(), py.data(), dep.data(), lvl.data(), vc.data(),
+                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "isInFrustum (camera model)");
+  int nToMatch = 0;
+  for (int i = 0; i < M; i++) {
+    MapPointT* p = cand[i];
+    p->mbTrackInView = inv[i] != 0;
+    if (!inv[i]) continue;
+    p->mTrackProjX = px[i]; p->mTrackProjY = py[i]; p->mTrackDepth = dep[i]; p->mnTrackScaleLevel = lvl[i]; p->mTrackViewCos = vc[i];
+    p->mTrackProjXR = px[i];                                  // (uv.x - mbf * invz with mbf = 0 on a monocular frame; read only for features with uRight)
+    p->IncreaseVisible(); nToMatch++;
+  }
+  if (nToMatch == 0) return 0;
+  return SearchByProjection<Ops>(F, cand, th, bFarPoints, thFarPoints, mfNNratio);
+}
+
 // Tracking::SearchLocalPoints on a two-camera Frame: the same three steps (S/Tracking.cc:3083-3155), every point read on every call.
 template <class Ops, class FrameT, class MapPointT>
 int SearchLocalPointsRig(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints, float th, bool bFarPoints, float thFarPoints, float mfNNratio) {
@@ -549,6 +592,10 @@ int SearchLocalPoints(FrameT& F, const std::vector<MapPointT*>& vpLocalMapPoints
   if (F.Nleft != -1) {                                                                        // a two-camera Frame
     if constexpr (has_rig_matcher<Ops>::value) return SearchLocalPointsRig<Ops>(F, vpLocalMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
     else throw std::runtime_error("orbgpu dropin: this entry-point set has no two-camera matcher");
+  }
+  if constexpr (has_rig_matcher<Ops>::value) {                                                // a monocular Frame whose camera is a model (a fisheye)
+    orbg_camera_rig rig1;
+    if (make_rig(&F, rig1)) return SearchLocalPointsModelCamera<Ops>(F, rig1, vpLocalMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
   }
   FrameFlat ff; flatten_frame<Ops>(F, ff);
   LocalMapCache& C = local_map_cache<Ops>();
@@ -711,6 +758,15 @@ int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const floa
   std::memcpy(lv.Tcw, mat_f32(LastFrame.mTcw), 64);
   std::vector<int32_t> amp, aob; flatten_assignments(CurrentFrame, amp, aob);
   int n = 0;
+  orbg_camera_rig rig1;
+  const bool kModel = !kRig && has_rig_matcher<Ops>::value && make_rig(&CurrentFrame, rig1);          // a monocular Frame whose camera is a model
+  if (kModel) {
+    if constexpr (has_rig_matcher<Ops>::value) {
+      ff.key.resident = nullptr;
+      check(Ops::search_frame_rig(ff.key, ff.v, FrameKey{}, orbm_frame_view{}, mat_f32(CurrentFrame.mTcw), rig1, lv, th, bMono, mbCheckOrientation, amp.data(),
+                                  aob.data(), &n), "SearchByProjection(Cur, Last), camera model");
+    }
+  } else
   if (kRig) {
     if constexpr (has_rig_matcher<Ops>::value) {
       orbg_camera_rig rig;

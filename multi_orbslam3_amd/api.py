@@ -521,12 +521,13 @@ class ORBmatcher:
         return amp, aob, n.value
 
     def SearchByProjectionFrameRig(self, FL, FR, Tcw_cur, rig, lv, th, bMono=False, assigned_mp=None, assigned_obs=None):
-        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) on a two-camera current frame (S/ORBmatcher.cc:1970-2186 with :2092-2160)."""
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) on a two-camera current frame (S/ORBmatcher.cc:1970-2186 with :2092-2160);
+        FR = None with a rig that has no right camera: one camera behind a model (a monocular fisheye frame)."""
         amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
         aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
         T = np.ascontiguousarray(Tcw_cur, np.float32).reshape(16)
         n = C.c_int(0)
-        capi.check(self.lib.orbm_search_by_projection_frame_rig(FL.h, FR.h, _vp(T), C.byref(rig), C.byref(lv), C.c_float(th), int(bMono),
+        capi.check(self.lib.orbm_search_by_projection_frame_rig(FL.h, FR.h if FR is not None else None, _vp(T), C.byref(rig), C.byref(lv), C.c_float(th), int(bMono),
                                                                 int(self.mbCheckOrientation), _vp(amp), _vp(aob), C.byref(n)),
                    "orbm_search_by_projection_frame_rig")
         return amp, aob, n.value

@@ -271,15 +271,16 @@ __device__ __forceinline__ TrackFields rig_frustum_check(const FrameParams& fp, 
   return f;
 }
 
-__global__ __launch_bounds__(256) void frustum_rig_kernel(FrameParams fp, RigSideF L, RigSideF R, WorldPtsDev w, float limit, TrackDev tl, TrackDev tr) {
+__global__ __launch_bounds__(256) void frustum_rig_kernel(FrameParams fp, RigSideF L, RigSideF R, int has_right, WorldPtsDev w, float limit, TrackDev tl, TrackDev tr) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= w.m) return;
   const float X[3] = {w.pos[3 * i], w.pos[3 * i + 1], w.pos[3 * i + 2]};
   const float N[3] = {w.normal[3 * i], w.normal[3 * i + 1], w.normal[3 * i + 2]};
   const float mn = w.min_dist[i], mx = w.max_dist[i];
   const TrackFields a = rig_frustum_check(fp, L, X, N, mn, mx, limit);
-  const TrackFields b = rig_frustum_check(fp, R, X, N, mn, mx, limit);
   tl.in_view[i] = (uint8_t)a.in_view; tl.px[i] = a.px; tl.py[i] = a.py; tl.depth[i] = a.depth; tl.level[i] = a.level; tl.view_cos[i] = a.view_cos;
+  if (!has_right) return;                                   // a single camera behind a model (Nleft == -1, mpCamera a fisheye)
+  const TrackFields b = rig_frustum_check(fp, R, X, N, mn, mx, limit);
   tr.in_view[i] = (uint8_t)b.in_view; tr.px[i] = b.px; tr.py[i] = b.py; tr.depth[i] = b.depth; tr.level[i] = b.level; tr.view_cos[i] = b.view_cos;
 }
 
@@ -2089,11 +2090,13 @@ extern "C" int orbm_is_in_frustum_rig(orbm_frame* f, const float* Tcw, const orb
                                       float limit, uint8_t* in_view, float* proj_x, float* proj_y, float* track_depth, int32_t* scale_level,
                                       float* view_cos, uint8_t* in_view_r, float* proj_x_r, float* proj_y_r, float* track_depth_r,
                                       int32_t* scale_level_r, float* view_cos_r) {
-  if (!f || !Tcw || !rig || !Tlr || !pts || pts->m < 0 || !rig->has_right) return ORBG_BAD_ARG;
-  for (const orbg_camera* c : {&rig->left, &rig->right})
-    if (c->model != ORBG_CAM_PINHOLE && c->model != ORBG_CAM_KANNALA_BRANDT8) return ORBG_BAD_ARG;
+  if (!f || !Tcw || !rig || !pts || pts->m < 0 || (rig->has_right && !Tlr)) return ORBG_BAD_ARG;
+  const bool two = rig->has_right != 0;                     // one camera behind a model (Nleft == -1, S/Frame.cc:466-543 with mpCamera->project): left outputs only
+  if ((rig->left.model != ORBG_CAM_PINHOLE && rig->left.model != ORBG_CAM_KANNALA_BRANDT8) ||
+      (two && rig->right.model != ORBG_CAM_PINHOLE && rig->right.model != ORBG_CAM_KANNALA_BRANDT8))
+    return ORBG_BAD_ARG;
   if (pts->m > 0 && (!pts->pos || !pts->normal || !pts->min_dist || !pts->max_dist || !in_view || !proj_x || !proj_y || !track_depth ||
-                     !scale_level || !view_cos || !in_view_r || !proj_x_r || !proj_y_r || !track_depth_r || !scale_level_r || !view_cos_r))
+                     !scale_level || !view_cos || (two && (!in_view_r || !proj_x_r || !proj_y_r || !track_depth_r || !scale_level_r || !view_cos_r))))
     return ORBG_BAD_ARG;
   int rc = select_device(f->device);
   if (rc) return rc;
@@ -2119,13 +2122,13 @@ extern "C" int orbm_is_in_frustum_rig(orbm_frame* f, const float* Tcw, const orb
   PoseF P;
   make_pose(Tcw, &P);
   hipLaunchKernelGGL(frustum_rig_kernel, dim3((pts->m + 255) / 256), dim3(256), 0, f->stream, f->fp, rig_side_of(P, rig, Tlr, false),
-                     rig_side_of(P, rig, Tlr, true), w, limit, t[0], t[1]);
+                     rig_side_of(P, rig, Tlr, two), two ? 1 : 0, w, limit, t[0], t[1]);
   ORBG_HIP(hipGetLastError());
   if ((rc = f->sig.sync(f->stream))) return rc;
   const uint8_t* Hh = f->stage.h;
   void* outs[2][6] = {{in_view, proj_x, proj_y, track_depth, scale_level, view_cos},
                       {in_view_r, proj_x_r, proj_y_r, track_depth_r, scale_level_r, view_cos_r}};
-  for (int sd = 0; sd < 2; sd++)
+  for (int sd = 0; sd < (two ? 2 : 1); sd++)
     for (int k = 0; k < 6; k++) memcpy(outs[sd][k], Hh + off[sd][k], k == 0 ? n : 4 * n);
   return ORBG_OK;
 }
@@ -2239,8 +2242,11 @@ extern "C" int orbm_search_by_projection_mps_rig(orbm_frame* L, orbm_frame* R, c
 extern "C" int orbm_search_by_projection_frame_rig(orbm_frame* FL, orbm_frame* FR, const float* Tcw_cur, const orbg_camera_rig* rig,
                                                    const orbm_lastframe_view* last, float th, int mono, int check_orientation,
                                                    int32_t* amp, int32_t* aob, int* nmatches_out) {
-  if (!FL || !FR || FL == FR || !Tcw_cur || !rig || !rig->has_right || !last || !amp || !aob || last->n < 0 || FL->device != FR->device)
-    return ORBG_BAD_ARG;
+  if (!FL || !Tcw_cur || !rig || !last || !amp || !aob || last->n < 0) return ORBG_BAD_ARG;
+  // rig->has_right == 0 with right == NULL: ONE camera behind a model (CurrentFrame.Nleft == -1 and mpCamera a fisheye): the left
+  // camera's search alone (:2001-2091 with mpCamera->project; no mvuRight on a monocular frame)
+  const bool two = rig->has_right != 0;
+  if (two ? (!FR || FL == FR || FL->device != FR->device) : FR != nullptr) return ORBG_BAD_ARG;
   if (rig->left.model != ORBG_CAM_PINHOLE && rig->left.model != ORBG_CAM_KANNALA_BRANDT8) return ORBG_BAD_ARG;
   int rc = select_device(FL->device);
   if (rc) return rc;
@@ -2263,7 +2269,7 @@ extern "C" int orbm_search_by_projection_frame_rig(orbm_frame* FL, orbm_frame* F
   // The kernels list every candidate of a window, taken or not: "the left camera's window is empty" ends a point's turn (:2033-2034)
   // and must be told from "every candidate in it is taken"; the commit below tests mvpMapPoints as it stands at that moment.
   LastDev Ls[2]; FrameDev Fs[2];
-  for (int side = 0; side < 2; side++) {
+  for (int side = 0; side < (two ? 2 : 1); side++) {
     orbm_frame* f = side ? FR : FL;
     const int n = f->fp.n;
     if ((rc = stage_begin(f, (size_t)n * 8 + (size_t)m * (2 + 32 + 12 + 4)))) return rc;
@@ -2286,12 +2292,13 @@ extern "C" int orbm_search_by_projection_frame_rig(orbm_frame* FL, orbm_frame* F
                          backward, cnt, cnt_next, f->list.d, list_cap, f->results.d);
     };
   };
-  if ((rc = run_search_pair(FL, FR, m, launch(0), launch(1)))) return rc;
-  cache_keypoint_fields(FL); cache_keypoint_fields(FR);
+  if ((rc = two ? run_search_pair(FL, FR, m, launch(0), launch(1)) : run_search(FL, m, launch(0)))) return rc;
+  cache_keypoint_fields(FL);
+  if (two) cache_keypoint_fields(FR);
   RotHist rotHist(FL->rot_entries);
   int nmatches = 0;
   const QResult* RL = FL->results.h;
-  const QResult* RR = FR->results.h;
+  const QResult* RR = two ? FR->results.h : nullptr;
   for (int i = 0; i < m; i++) {
     if (RL[i].n_top == 0) continue;                        // no query, or vIndices2.empty()
     Pick pk;
@@ -2301,7 +2308,7 @@ extern "C" int orbm_search_by_projection_frame_rig(orbm_frame* FL, orbm_frame* F
       nmatches++;
       if (check_orientation) rotHist.add(rot_bin(last->angle[i], FL->hk_angle[pk.idx1]), pk.idx1);
     }
-    if (RR[i].n_top == 0) continue;
+    if (!two || RR[i].n_top == 0) continue;
     if ((rc = pick_unclaimed(FR, RR[i], 1, [&](int idx) { return amp[idx + nl] >= 0 && aob[idx + nl] > 0; }, &pk))) return rc;
     if (pk.idx1 >= 0 && pk.dist1 <= TH_HIGH) {
       amp[pk.idx1 + nl] = i; aob[pk.idx1 + nl] = last->n_obs[i];

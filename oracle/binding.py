@@ -359,7 +359,7 @@ def search_by_projection_frame_rig(fv_left, fv_right, Tcw_cur, rig, lv, th, mono
     aob = np.ascontiguousarray(assigned_obs, np.int32).copy()
     T = np.ascontiguousarray(Tcw_cur, np.float32).reshape(16)
     n = C.c_int(0)
-    _chk(lib().oracle_search_by_projection_frame_rig(C.byref(fv_left), C.byref(fv_right), C.c_void_p(T.ctypes.data), C.byref(rig), C.byref(lv),
+    _chk(lib().oracle_search_by_projection_frame_rig(C.byref(fv_left), C.byref(fv_right) if fv_right is not None else None, C.c_void_p(T.ctypes.data), C.byref(rig), C.byref(lv),
                                                      C.c_float(th), int(mono), int(check_ori), C.c_void_p(amp.ctypes.data),
                                                      C.c_void_p(aob.ctypes.data), C.byref(n)))
     return amp, aob, n.value

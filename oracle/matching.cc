@@ -432,11 +432,14 @@ extern "C" int oracle_is_in_frustum_rig(const orbm_frame_view* view, const float
                                         int32_t* level_r, float* view_cos_r) {
   ScaleTables st(view);
   Pose pose(Tcw);
-  const RigSide L = rig_side(pose, rig->Trl, Tlr, false), R = rig_side(pose, rig->Trl, Tlr, true);
+  // rig->has_right == 0: ONE camera behind a model -- the Nleft == -1 branch of Frame::isInFrustum (S/Frame.cc:466-543) with
+  // mpCamera->project: the same checks in the same order; the left outputs only
+  const RigSide L = rig_side(pose, rig->Trl, Tlr, false), R = rig_side(pose, rig->Trl, Tlr, rig->has_right != 0);
   for (int i = 0; i < pts->m; i++) {
     const TrackFields a = rig_frustum_checks(view, st, L, rig->left, pts->pos + 3 * i, pts->normal + 3 * i, pts->min_dist[i], pts->max_dist[i], limit);
-    const TrackFields b = rig_frustum_checks(view, st, R, rig->right, pts->pos + 3 * i, pts->normal + 3 * i, pts->min_dist[i], pts->max_dist[i], limit);
     in_view[i] = a.in_view; px[i] = a.px; py[i] = a.py; depth[i] = a.depth; level[i] = a.level; view_cos[i] = a.view_cos;
+    if (!rig->has_right) continue;
+    const TrackFields b = rig_frustum_checks(view, st, R, rig->right, pts->pos + 3 * i, pts->normal + 3 * i, pts->min_dist[i], pts->max_dist[i], limit);
     in_view_r[i] = b.in_view; px_r[i] = b.px; py_r[i] = b.py; depth_r[i] = b.depth; level_r[i] = b.level; view_cos_r[i] = b.view_cos;
   }
   return ORBG_OK;
@@ -524,7 +527,8 @@ extern "C" int oracle_search_by_projection_frame_rig(const orbm_frame_view* left
                                                      const orbg_camera_rig* rig, const orbm_lastframe_view* last, float th, int mono,
                                                      int check_ori, int32_t* assigned_mp, int32_t* assigned_obs, int* nmatches_out) {
   ScaleTables st(left);
-  const Grid gl = build_grid(left), gr = build_grid(right);
+  const bool two = rig->has_right != 0 && right != nullptr;        // one camera behind a model (Nleft == -1): the left block alone
+  const Grid gl = build_grid(left), gr = two ? build_grid(right) : Grid();
   const int Nleft = left->n;
   int nmatches = 0;
   std::vector<int> rotHist[HISTO_LENGTH];
@@ -569,6 +573,7 @@ extern "C" int oracle_search_by_projection_frame_rig(const orbm_frame_view* left
         if (check_ori) rotHist[rot_bin(last->angle[i], left->kps[bestIdx2].angle)].push_back(bestIdx2);
       }
     }
+    if (!two) continue;
     float x3Dr[3];
     for (int a = 0; a < 3; a++) {
       const float t0 = Trl[4 * a] * x3Dc[0] + Trl[4 * a + 1] * x3Dc[1] + Trl[4 * a + 2] * x3Dc[2];

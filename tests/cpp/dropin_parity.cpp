@@ -407,6 +407,41 @@ int main() {
                g.fields.size() == c.fields.size() ? max_abs_diff(g.fields, c.fields) : -1.f, g.fields.size(), c.fields.size());
       }
     }
+    // ---- a MONOCULAR fisheye Frame (Nleft == -1, mpCamera a KannalaBrandt8, no mpCamera2): isInFrustum and SearchByProjection(Cur, Last)
+    // project through the camera model (S/Frame.cc:489, S/ORBmatcher.cc:2012)
+    {
+      struct MonoOut { std::vector<long> a_local, a_frame; int n_local = 0, n_frame = 0, vis = 0; };
+      auto run = [](auto ops_tag) {
+        using Ops = decltype(ops_tag);
+        MonoOut o;
+        Agent A;
+        RigTrack S = build_rig_track_scene(A, 4343, 1200, 250, 0.02);
+        auto mono_of = [](const Frame& F) {                          // the left camera alone
+          Frame M(F);
+          const int nl = F.Nleft;
+          M.Nleft = -1; M.Nright = -1; M.N = nl; M.mpCamera2 = nullptr;
+          M.mvKeys.resize(nl); M.mvKeysUn = M.mvKeys; M.mvKeysRight.clear(); M.mvuRight.assign(nl, -1.f); M.mvDepth.assign(nl, -1.f);
+          M.mvpMapPoints.resize(nl); M.mvbOutlier.resize(nl);
+          Mat d(nl, 32, 1); std::memcpy(d.ptr<uint8_t>(0), F.mDescriptors.ptr<uint8_t>(0), (size_t)nl * 32); M.mDescriptors = d;
+          M.mvLeftToRightMatch.clear(); M.mvRightToLeftMatch.clear(); M.mFeatVec.clear();
+          return M;
+        };
+        Frame cur = mono_of(*S.cur), last = mono_of(*S.last);
+        auto ids = [](const Frame& F, std::vector<long>& out) { out.clear(); for (MapPoint* p : F.mvpMapPoints) out.push_back(p ? (long)p->mnId : -1); };
+        Frame F1(cur);
+        std::fill(F1.mvpMapPoints.begin(), F1.mvpMapPoints.end(), nullptr);
+        o.n_frame = od::SearchByProjection<Ops>(F1, last, 15.0f, true, true);
+        ids(F1, o.a_frame);
+        o.n_local = od::SearchLocalPoints<Ops>(cur, S.local, 3.0f, true, 7.0f, 0.8f);
+        ids(cur, o.a_local);
+        for (MapPoint* p : S.local) o.vis += p->mnVisible;
+        return o;
+      };
+      const MonoOut g = run(od::GpuOps{}), c = run(OracleOps{});
+      std::printf("monocular fisheye Frame: SearchByProjection(Cur, Last) %d matches, SearchLocalPoints %d matches\n", g.n_frame, g.n_local);
+      EXPECT(g.n_frame == c.n_frame && g.a_frame == c.a_frame && g.n_frame > 100, "mono fisheye: SearchByProjection(Cur, Last) %d vs %d", g.n_frame, c.n_frame);
+      EXPECT(g.n_local == c.n_local && g.a_local == c.a_local && g.vis == c.vis && g.n_local > 200, "mono fisheye: SearchLocalPoints %d vs %d, visible sums %d vs %d", g.n_local, c.n_local, g.vis, c.vis);
+    }
     // ---- Frame::ComputeStereoFishEyeMatches of the two-fisheye Frame constructor (S/Frame.cc:1093-1150)
     {
       auto run = [](auto ops_tag, std::vector<int>& l2r, std::vector<int>& r2l, std::vector<float>& dep, std::vector<float>& pts) {

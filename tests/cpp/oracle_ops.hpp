@@ -38,7 +38,7 @@ struct OracleOps {       // the same entry points over the CPU oracle: views ins
   static int search_frame_rig(const od::FrameKey&, const orbm_frame_view& vl, const od::FrameKey&, const orbm_frame_view& vr, const float* Tcw,
                               const orbg_camera_rig& rig, const orbm_lastframe_view& last, float th, int mono, int check_ori, int32_t* amp,
                               int32_t* aob, int* n) {
-    return oracle_search_by_projection_frame_rig(&vl, &vr, Tcw, &rig, &last, th, mono, check_ori, amp, aob, n);
+    return oracle_search_by_projection_frame_rig(&vl, rig.has_right ? &vr : nullptr, Tcw, &rig, &last, th, mono, check_ori, amp, aob, n);
   }
   static int search_bow_rig(const od::FrameKey&, const orbm_frame_view& v_all, int n_left, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf,
                             const uint8_t* kf_valid, const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori, int32_t* matches, int* n) {

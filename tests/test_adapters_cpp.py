@@ -104,6 +104,7 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
     assert "LocalBundleAdjustment [two-fisheye rig]: status 0" in r.stdout and "PoseOptimization [two-fisheye rig]:" in r.stdout, r.stdout[-3000:]
     assert r.stdout.count("two-camera Frame (last frame") == 3, r.stdout[-3000:]      # the matcher's two-camera forms through the glue
     assert "ComputeStereoFishEyeMatches [two-fisheye rig]:" in r.stdout, r.stdout[-3000:]
+    assert "monocular fisheye Frame:" in r.stdout, r.stdout[-3000:]
 
 
 def test_closed_loop_scenario_tracks_on_the_oracle_alone():

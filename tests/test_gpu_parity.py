@@ -1995,9 +1995,9 @@ def test_rig_search_refuses_what_it_cannot_be():
     bad = sc["left_to_right"].copy(); bad[0] = len(sc["kps_right"])
     with pytest.raises(capi.OrbGpuError):                     # a partner index outside the right camera's features
         m.SearchByProjectionRig(FL, FR, mv, mvr, bad, sc["right_to_left"], 1.0, False, 0.0, sc["assigned_mp"], sc["assigned_obs"])
-    mono = views.camera_rig(sc["left"])
-    with pytest.raises(capi.OrbGpuError):                     # isInFrustum of a rig needs the right camera
-        FL.isInFrustumRig(sc["Tcw"], mono, sc["Tlr"], wv)
+    odd = views.camera_rig(sc["left"], sc["right"], sc["Trl"]); odd.right.model = 7
+    with pytest.raises(capi.OrbGpuError):                     # a camera model the library does not know
+        FL.isInFrustumRig(sc["Tcw"], odd, sc["Tlr"], wv)
 
 
 @pytest.mark.parametrize("case", ["sideways", "forward", "backward", "mono_flag", "no_orientation_check", "crowded", "pinholes"])
@@ -2093,3 +2093,36 @@ def test_fisheye_stereo_matches_of_the_frame_constructor(case):
     # every accepted pair is mutual unless a later left feature took the right one over
     back = o[1][o[0][hit]]
     assert (back >= np.nonzero(hit)[0]).all() and (back == np.nonzero(hit)[0]).mean() > 0.9
+
+
+def test_matcher_with_one_camera_behind_a_model():
+    """A monocular fisheye frame (Nleft == -1, mpCamera a KannalaBrandt8, no second camera): Frame::isInFrustum's Nleft == -1 branch and
+    SearchByProjection(CurrentFrame, LastFrame) project through mpCamera->project (S/Frame.cc:489, S/ORBmatcher.cc:2012).  The rig
+    entry points with a rig that has no right camera: the frustum's left outputs are the two-camera call's left outputs, the frame
+    search (right frame = NULL) equals the oracle's and differs from the pinhole entry point on the same inputs."""
+    sc = synth.make_rig_track_scene()
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    mono = views.camera_rig(sc["left"])
+    F = api.Frame().upload(fl, keep[0])
+    g_two, _ = F.isInFrustumRig(sc["Tcw"], rig, sc["Tlr"], wv)
+    g_one, g_none = F.isInFrustumRig(sc["Tcw"], mono, sc["Tlr"], wv)
+    o_one, _ = ob.is_in_frustum_rig(fl, sc["Tcw"], mono, sc["Tlr"], wv)
+    for k in ob.RIG_TRACK_KEYS:
+        assert np.array_equal(g_one[k], g_two[k]), k
+        if k in ("proj_x", "proj_y"):
+            assert np.abs(g_one[k].astype(np.float64) - o_one[k]).max() <= 3e-4, k
+        else:
+            assert np.array_equal(g_one[k], o_one[k]), k
+    assert not g_none["track_in_view"].any()
+    last = synth.rig_last_frame(sc)
+    lv, keep2 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+    m = api.ORBmatcher(0.9, True)
+    nl = len(sc["kps_left"])
+    amp0, aob0 = sc["assigned_mp"][:nl], sc["assigned_obs"][:nl]
+    g = m.SearchByProjectionFrameRig(F, None, sc["Tcw"], mono, lv, 15.0, True, amp0, aob0)
+    o = ob.search_by_projection_frame_rig(fl, None, sc["Tcw"], mono, lv, 15.0, 1, 1, amp0, aob0)
+    assert g[2] == o[2] > 150 and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    p = ob.search_by_projection_frame(fl, sc["Tcw"], lv, 15.0, 1, 1, amp0, aob0)          # the pinhole of the view: another projection
+    assert not np.array_equal(p[0], o[0])
+    with pytest.raises(capi.OrbGpuError):                     # a right frame without a right camera
+        m.SearchByProjectionFrameRig(F, api.Frame().upload(fr, keep[1]), sc["Tcw"], mono, lv, 15.0, True, amp0, aob0)
