@@ -384,6 +384,11 @@ int orbm_search_by_projection_sim3(orbm_frame* kf, orbm_map* pts, const float* S
 int orbm_search_by_projection_reloc(orbm_frame* cur, orbm_map* kf_points, const float* Tcw_cur /*16*/, const uint8_t* already_found /*m or NULL*/,
                                     const float* kf_angle /*m*/, float th, int orb_dist, int check_orientation,
                                     int32_t* assigned_mp, int* nmatches);
+struct orbg_camera;
+/* ... the same with CurrentFrame.mpCamera a camera model (a monocular fisheye frame): :2217 projects through it. */
+int orbm_search_by_projection_reloc_cam(orbm_frame* cur, orbm_map* kf_points, const float* Tcw_cur /*16*/, const struct orbg_camera* cam,
+                                        const uint8_t* already_found /*m or NULL*/, const float* kf_angle /*m*/, float th, int orb_dist,
+                                        int check_orientation, int32_t* assigned_mp, int* nmatches);
 int orbm_search_by_bow_kf(orbm_frame* kf2, const orbm_featvec_view* fv2, const uint8_t* mp_valid2,
                           const uint8_t* desc1, int n1, const uint8_t* mp_valid1, const float* angle1,
                           const orbm_featvec_view* fv1, float nnratio, int check_orientation,

@@ -185,6 +185,13 @@ struct GpuOps {
     s.reloc_map->Upload(kf_pts);
     return orbm_search_by_projection_reloc(frame(key, v).handle(), s.reloc_map->handle(), Tcw, found, kf_angle, th, orb_dist, check_ori, amp, n);
   }
+  static int search_reloc_cam(const FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbg_camera& cam, const orbm_worldpoints_view& kf_pts,
+                              const uint8_t* found, const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
+    ThreadState& s = state();
+    if (!s.reloc_map) s.reloc_map.reset(new MapPointsOnDevice(std::max(kf_pts.m, 4096)));
+    s.reloc_map->Upload(kf_pts);
+    return orbm_search_by_projection_reloc_cam(frame(key, v).handle(), s.reloc_map->handle(), Tcw, &cam, found, kf_angle, th, orb_dist, check_ori, amp, n);
+  }
   // pbStopFlag goes through as it is: the library polls the caller's bool (lba_solve_hb)
   static int lba(const lba_problem& p, const volatile bool* stop, lba_result& r) {
     ThreadState& s = state();
@@ -811,6 +818,15 @@ int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapP
   std::vector<int32_t> amp(CurrentFrame.N);
   for (int i = 0; i < CurrentFrame.N; i++) amp[i] = CurrentFrame.mvpMapPoints[i] ? INT32_MAX : -1;
   int n = 0;
+  orbg_camera_rig rig1;
+  const bool kModel = has_rig_matcher<Ops>::value && CurrentFrame.Nleft == -1 && make_rig(&CurrentFrame, rig1);   // a monocular Frame whose camera is a model (:2217)
+  if (kModel) {
+    if constexpr (has_rig_matcher<Ops>::value) {
+      ff.key.resident = nullptr;
+      check(Ops::search_reloc_cam(ff.key, ff.v, mat_f32(CurrentFrame.mTcw), rig1.left, wv, found.data(), ang.data(), th, ORBdist, mbCheckOrientation, amp.data(), &n),
+            "SearchByProjection(Cur, KF, sAlreadyFound), camera model");
+    }
+  } else
   check(Ops::search_reloc(ff.key, ff.v, mat_f32(CurrentFrame.mTcw), wv, found.data(), ang.data(), th, ORBdist, mbCheckOrientation, amp.data(), &n),
         "SearchByProjection(Cur, KF, sAlreadyFound)");
   for (int i = 0; i < CurrentFrame.N; i++)

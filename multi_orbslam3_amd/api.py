@@ -612,7 +612,7 @@ class ORBmatcher:
                    "orbm_search_by_projection_sim3")
         return matched, n.value
 
-    def SearchByProjectionReloc(self, CurrentFrame, Tcw, kf_points, kf_angle, assigned_mp, th, ORBdist, already_found=None):
+    def SearchByProjectionReloc(self, CurrentFrame, Tcw, kf_points, kf_angle, assigned_mp, th, ORBdist, already_found=None, camera=None):
         """(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist): the relocalisation overload,
         S/ORBmatcher.cc:2188-2310.  kf_points: the keyframe's map point matches, feature by feature, as a LocalMap resident on the
         device (bad = no point / isBad()); kf_angle: pKF->mvKeysUn[i].angle; assigned_mp >= 0 where the frame already holds a point."""
@@ -621,6 +621,11 @@ class ORBmatcher:
         ang = np.ascontiguousarray(kf_angle, np.float32)
         af = None if already_found is None else np.ascontiguousarray(already_found, np.uint8)
         n = C.c_int(0)
+        if camera is not None:                              # CurrentFrame.mpCamera is a camera model (an orbg_camera): a monocular fisheye frame
+            capi.check(self.lib.orbm_search_by_projection_reloc_cam(CurrentFrame.h, kf_points.h, _vp(T), C.byref(camera), _vp(af), _vp(ang), C.c_float(th),
+                                                                    int(ORBdist), int(self.mbCheckOrientation), _vp(amp), C.byref(n)),
+                       "orbm_search_by_projection_reloc_cam")
+            return amp, n.value
         capi.check(self.lib.orbm_search_by_projection_reloc(CurrentFrame.h, kf_points.h, _vp(T), _vp(af), _vp(ang), C.c_float(th), int(ORBdist),
                                                             int(self.mbCheckOrientation), _vp(amp), C.byref(n)),
                    "orbm_search_by_projection_reloc")

@@ -686,9 +686,11 @@ __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameD
 // bounds inclusive on both sides (:2219-2222), distance range with the 0.8 / 1.2 invariance factors (:2228-2233), PredictScale on
 // the FRAME's scale tables (:2235), window th * scale, levels nPredictedLevel - 1 .. + 1 (:2238-2240); a feature that holds ANY map
 // point is not a candidate (:2246-2247: the occupancy the host stages has no "observations > 0" condition here).
+// kModel: CurrentFrame.mpCamera->project is a camera model's (a monocular fisheye frame) instead of the pinhole of the frame view
+template <bool kModel>
 __global__ __launch_bounds__(256) void search_reloc_kernel(FrameParams fp, FrameDev F, WorldPtsDev w, const uint8_t* __restrict__ found,
                                                           PoseF P, float th, int* list_counter, int* counter_next, uint32_t* list,
-                                                          int list_cap, QResult* results) {
+                                                          int list_cap, QResult* results, RigCamF cam) {
   __shared__ uint32_t s_stage[4][kListStage];
   if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;   // the overflow counter the NEXT search on this frame will use
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -702,8 +704,9 @@ __global__ __launch_bounds__(256) void search_reloc_kernel(FrameParams fp, Frame
   if (!(w_bad || w_skip || w_found)) {
     float Pc[3];
     pose_map(P, X, Pc);
-    const float u = fp.fx * Pc[0] / Pc[2] + fp.cx;
-    const float v = fp.fy * Pc[1] / Pc[2] + fp.cy;
+    float u, v;
+    if constexpr (kModel) { float uv[2]; rig_project(cam, Pc, uv); u = uv[0]; v = uv[1]; }
+    else { u = fp.fx * Pc[0] / Pc[2] + fp.cx; v = fp.fy * Pc[1] / Pc[2] + fp.cy; }
     if (!(u < fp.min_x || u > fp.max_x) && !(v < fp.min_y || v > fp.max_y)) {
       const float maxDistance = 1.2f * max_raw, minDistance = 0.8f * min_raw;
       const float PO[3] = {X[0] - P.Ow[0], X[1] - P.Ow[1], X[2] - P.Ow[2]};
@@ -2697,9 +2700,21 @@ extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const
 // the candidate kernel above, then the serial commit (:2265-2281: a feature taken by an earlier point of this call is no candidate
 // for a later one) and the rotation-consistency vote (:2284-2306).  kf_points: the keyframe's GetMapPointMatches() uploaded feature
 // by feature (orbm_map_upload: bad[i] = no point or isBad()); kf_angle[i] = pKF->mvKeysUn[i].angle.
+static int search_reloc_common(orbm_frame* f, orbm_map* mp, const float* Tcw, const uint8_t* already_found, const float* kf_angle, float th, int orb_dist,
+                               int check_orientation, int32_t* assigned_mp, int* nmatches_out, const orbg_camera* cam);
 extern "C" int orbm_search_by_projection_reloc(orbm_frame* f, orbm_map* mp, const float* Tcw, const uint8_t* already_found,
                                                const float* kf_angle, float th, int orb_dist, int check_orientation,
                                                int32_t* assigned_mp, int* nmatches_out) {
+  return search_reloc_common(f, mp, Tcw, already_found, kf_angle, th, orb_dist, check_orientation, assigned_mp, nmatches_out, nullptr);
+}
+extern "C" int orbm_search_by_projection_reloc_cam(orbm_frame* f, orbm_map* mp, const float* Tcw, const orbg_camera* cam, const uint8_t* already_found,
+                                                   const float* kf_angle, float th, int orb_dist, int check_orientation,
+                                                   int32_t* assigned_mp, int* nmatches_out) {
+  if (!cam || (cam->model != ORBG_CAM_PINHOLE && cam->model != ORBG_CAM_KANNALA_BRANDT8)) return ORBG_BAD_ARG;
+  return search_reloc_common(f, mp, Tcw, already_found, kf_angle, th, orb_dist, check_orientation, assigned_mp, nmatches_out, cam);
+}
+static int search_reloc_common(orbm_frame* f, orbm_map* mp, const float* Tcw, const uint8_t* already_found, const float* kf_angle, float th, int orb_dist,
+                               int check_orientation, int32_t* assigned_mp, int* nmatches_out, const orbg_camera* cam) {
   if (!f || !mp || !Tcw || !assigned_mp || f->device != mp->device || (check_orientation && !kf_angle)) return ORBG_BAD_ARG;
   int rc = select_device(f->device);
   if (rc) return rc;
@@ -2718,8 +2733,10 @@ extern "C" int orbm_search_by_projection_reloc(orbm_frame* f, orbm_map* mp, cons
   F.uright = nullptr;                                          // no stereo gate in this overload
   if ((rc = map_sync_to(mp, st))) return rc;
   rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
-    hipLaunchKernelGGL(search_reloc_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P, th, cnt, cnt_next,
-                       f->list.d, list_cap, f->results.d);
+    if (cam) hipLaunchKernelGGL(search_reloc_kernel<true>, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P, th, cnt, cnt_next,
+                                f->list.d, list_cap, f->results.d, rig_cam_of(*cam));
+    else hipLaunchKernelGGL(search_reloc_kernel<false>, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P, th, cnt, cnt_next,
+                            f->list.d, list_cap, f->results.d, RigCamF{});
   });
   if (rc) return rc;
   cache_keypoint_fields(f);

@@ -461,6 +461,19 @@ def search_by_projection_reloc(cur, Tcw_cur, pts, kf_angle, assigned_mp, th, orb
     return amp, n.value
 
 
+def search_by_projection_reloc_cam(cur, Tcw_cur, cam, pts, kf_angle, assigned_mp, th, orb_dist, check_ori=True, already_found=None):
+    """... with CurrentFrame.mpCamera a camera model (cam: an orbg_camera)."""
+    amp = np.ascontiguousarray(assigned_mp, np.int32).copy()
+    T = np.ascontiguousarray(Tcw_cur, np.float32).reshape(16)
+    ang = np.ascontiguousarray(kf_angle, np.float32)
+    af = None if already_found is None else np.ascontiguousarray(already_found, np.uint8)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_projection_reloc_cam(C.byref(cur), C.c_void_p(T.ctypes.data), C.byref(cam), C.byref(pts),
+                                                     None if af is None else C.c_void_p(af.ctypes.data), C.c_void_p(ang.ctypes.data),
+                                                     C.c_float(th), int(orb_dist), int(bool(check_ori)), C.c_void_p(amp.ctypes.data), C.byref(n)))
+    return amp, n.value
+
+
 def search_by_bow_kf(kf2, fv2, mp_valid2, desc1, mp_valid1, angle1, fv1, nnratio, check_ori):
     desc1 = np.ascontiguousarray(desc1, np.uint8)
     mp_valid1 = np.ascontiguousarray(mp_valid1, np.uint8)

@@ -892,9 +892,23 @@ extern "C" int oracle_search_by_projection_sim3(const orbm_frame_view* kf, const
 // searches only respect points with observations); on exit newly matched features hold the index i of the keyframe's point.
 // Quirks kept: no depth-sign test before Pinhole::project (:2214-2217), bounds inclusive on both sides (:2219-2222), levels
 // nPredictedLevel-1 .. nPredictedLevel+1 (:2240), no viewing-angle test, no stereo gate.
+static int search_by_projection_reloc_impl(const orbm_frame_view* cur, const float* Tcw_cur, const orbm_worldpoints_view* pts, const uint8_t* already_found,
+                                          const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* assigned_mp, int* nmatches_out,
+                                          const orbg_camera* cam);
 extern "C" int oracle_search_by_projection_reloc(const orbm_frame_view* cur, const float* Tcw_cur, const orbm_worldpoints_view* pts,
                                                  const uint8_t* already_found, const float* kf_angle, float th, int orb_dist,
                                                  int check_ori, int32_t* assigned_mp, int* nmatches_out) {
+  return search_by_projection_reloc_impl(cur, Tcw_cur, pts, already_found, kf_angle, th, orb_dist, check_ori, assigned_mp, nmatches_out, nullptr);
+}
+// ... with CurrentFrame.mpCamera a camera model (a monocular fisheye frame): :2217 projects through it
+extern "C" int oracle_search_by_projection_reloc_cam(const orbm_frame_view* cur, const float* Tcw_cur, const orbg_camera* cam, const orbm_worldpoints_view* pts,
+                                                     const uint8_t* already_found, const float* kf_angle, float th, int orb_dist,
+                                                     int check_ori, int32_t* assigned_mp, int* nmatches_out) {
+  return search_by_projection_reloc_impl(cur, Tcw_cur, pts, already_found, kf_angle, th, orb_dist, check_ori, assigned_mp, nmatches_out, cam);
+}
+static int search_by_projection_reloc_impl(const orbm_frame_view* cur, const float* Tcw_cur, const orbm_worldpoints_view* pts, const uint8_t* already_found,
+                                          const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* assigned_mp, int* nmatches_out,
+                                          const orbg_camera* cam) {
   const ScaleTables st(cur);
   const Grid g = build_grid(cur);
   const Pose pose(Tcw_cur);
@@ -906,8 +920,9 @@ extern "C" int oracle_search_by_projection_reloc(const orbm_frame_view* cur, con
     const float* x3Dw = pts->pos + 3 * (size_t)i;
     float x3Dc[3];
     pose.map(x3Dw, x3Dc);                                               // Rcw*x3Dw+tcw
-    const float u = cur->fx * x3Dc[0] / x3Dc[2] + cur->cx;              // Pinhole::project(cv::Point3f)
-    const float v = cur->fy * x3Dc[1] / x3Dc[2] + cur->cy;
+    float u = cur->fx * x3Dc[0] / x3Dc[2] + cur->cx;                    // Pinhole::project(cv::Point3f)
+    float v = cur->fy * x3Dc[1] / x3Dc[2] + cur->cy;
+    if (cam) { float uv[2]; rig_cam_project(*cam, x3Dc, uv); u = uv[0]; v = uv[1]; }
     if (u < cur->min_x || u > cur->max_x) continue;
     if (v < cur->min_y || v > cur->max_y) continue;
     const float PO[3] = {x3Dw[0] - pose.Ow[0], x3Dw[1] - pose.Ow[1], x3Dw[2] - pose.Ow[2]};

@@ -410,7 +410,7 @@ int main() {
     // ---- a MONOCULAR fisheye Frame (Nleft == -1, mpCamera a KannalaBrandt8, no mpCamera2): isInFrustum and SearchByProjection(Cur, Last)
     // project through the camera model (S/Frame.cc:489, S/ORBmatcher.cc:2012)
     {
-      struct MonoOut { std::vector<long> a_local, a_frame; int n_local = 0, n_frame = 0, vis = 0; };
+      struct MonoOut { std::vector<long> a_local, a_frame, a_reloc; int n_local = 0, n_frame = 0, n_reloc = 0, vis = 0; };
       auto run = [](auto ops_tag) {
         using Ops = decltype(ops_tag);
         MonoOut o;
@@ -432,13 +432,20 @@ int main() {
         std::fill(F1.mvpMapPoints.begin(), F1.mvpMapPoints.end(), nullptr);
         o.n_frame = od::SearchByProjection<Ops>(F1, last, 15.0f, true, true);
         ids(F1, o.a_frame);
+        { Frame F2(cur);                                           // Relocalization's guided search against the reference keyframe's points
+          std::fill(F2.mvpMapPoints.begin(), F2.mvpMapPoints.end(), nullptr);
+          std::set<MapPoint*> already; for (size_t i = 0; i < S.local.size(); i += 9) already.insert(S.local[i]);
+          S.ref->mvKeysUn = S.ref->mvKeys; S.ref->mvKeysUn.insert(S.ref->mvKeysUn.end(), S.ref->mvKeysRight.begin(), S.ref->mvKeysRight.end());
+          o.n_reloc = od::SearchByProjection<Ops>(F2, S.ref, already, 10.0f, 100, true);
+          ids(F2, o.a_reloc); }
         o.n_local = od::SearchLocalPoints<Ops>(cur, S.local, 3.0f, true, 7.0f, 0.8f);
         ids(cur, o.a_local);
         for (MapPoint* p : S.local) o.vis += p->mnVisible;
         return o;
       };
       const MonoOut g = run(od::GpuOps{}), c = run(OracleOps{});
-      std::printf("monocular fisheye Frame: SearchByProjection(Cur, Last) %d matches, SearchLocalPoints %d matches\n", g.n_frame, g.n_local);
+      std::printf("monocular fisheye Frame: SearchByProjection(Cur, Last) %d matches, SearchLocalPoints %d matches, relocalisation search %d matches\n", g.n_frame, g.n_local, g.n_reloc);
+      EXPECT(g.n_reloc == c.n_reloc && g.a_reloc == c.a_reloc && g.n_reloc > 100, "mono fisheye: SearchByProjection(F, KF, found) %d vs %d", g.n_reloc, c.n_reloc);
       EXPECT(g.n_frame == c.n_frame && g.a_frame == c.a_frame && g.n_frame > 100, "mono fisheye: SearchByProjection(Cur, Last) %d vs %d", g.n_frame, c.n_frame);
       EXPECT(g.n_local == c.n_local && g.a_local == c.a_local && g.vis == c.vis && g.n_local > 200, "mono fisheye: SearchLocalPoints %d vs %d, visible sums %d vs %d", g.n_local, c.n_local, g.vis, c.vis);
     }

@@ -47,6 +47,10 @@ struct OracleOps {       // the same entry points over the CPU oracle: views ins
   static int fisheye_stereo(const orbx_fisheye_stereo_view& v, int32_t* l2r, int32_t* r2l, float* depth, float* p3d, int* n) {
     return oracle_fisheye_stereo_matches(&v, l2r, r2l, depth, p3d, n);
   }
+  static int search_reloc_cam(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbg_camera& cam, const orbm_worldpoints_view& kf_pts,
+                              const uint8_t* found, const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
+    return oracle_search_by_projection_reloc_cam(&v, Tcw, &cam, &kf_pts, found, kf_angle, th, orb_dist, check_ori, amp, n);
+  }
   static int search_reloc(const od::FrameKey&, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
                           const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
     return oracle_search_by_projection_reloc(&v, Tcw, &kf_pts, found, kf_angle, th, orb_dist, check_ori, amp, n);

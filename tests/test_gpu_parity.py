@@ -2126,3 +2126,31 @@ def test_matcher_with_one_camera_behind_a_model():
     assert not np.array_equal(p[0], o[0])
     with pytest.raises(capi.OrbGpuError):                     # a right frame without a right camera
         m.SearchByProjectionFrameRig(F, api.Frame().upload(fr, keep[1]), sc["Tcw"], mono, lv, 15.0, True, amp0, aob0)
+
+
+@pytest.mark.parametrize("th,orb_dist", [(10.0, 100), (3.0, 64)])
+def test_relocalisation_search_with_a_camera_model(th, orb_dist):
+    """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) on a monocular fisheye frame: S/ORBmatcher.cc:2217 projects through
+    CurrentFrame.mpCamera, a KannalaBrandt8 here -- orbm_search_by_projection_reloc_cam against the oracle; with a PINHOLE handed in as
+    the model it is the pinhole entry point."""
+    sc = synth.make_rig_track_scene()
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    rng = np.random.RandomState(31)
+    nk = 900                                                     # the candidate keyframe's features hold the scene's first 900 points
+    bad = sc["bad"][:nk].copy(); bad[rng.rand(nk) < 0.1] = 1     # (features without a point)
+    found = (rng.rand(nk) < 0.1).astype(np.uint8)
+    kv, keep2 = views.worldpoints_view(sc["pos"][:nk], sc["normal"][:nk], sc["min_dist"][:nk], sc["max_dist"][:nk], sc["desc"][:nk], sc["n_obs"][:nk], bad, None)
+    kf_angle = ((sc["base_angle"][:nk] + rng.randn(nk) * 2.0) % 360.0).astype(np.float32)
+    nl = len(sc["kps_left"])
+    amp0 = np.where(sc["assigned_mp"][:nl] >= 0, 2 ** 31 - 1, -1).astype(np.int32)
+    F = api.Frame().upload(fl, keep[0])
+    KP = api.LocalMap().upload(kv)
+    m = api.ORBmatcher(0.75, True)
+    cam = views.camera_rig(sc["left"]).left
+    g = m.SearchByProjectionReloc(F, sc["Tcw"], KP, kf_angle, amp0, th, orb_dist, found, camera=cam)
+    o = ob.search_by_projection_reloc_cam(fl, sc["Tcw"], cam, kv, kf_angle, amp0, th, orb_dist, True, found)
+    assert o[1] > 150 and g[1] == o[1] and np.array_equal(g[0], o[0])
+    pin = views.camera_rig((capi.CAM_PINHOLE, fl.fx, fl.fy, fl.cx, fl.cy)).left
+    gp = m.SearchByProjectionReloc(F, sc["Tcw"], KP, kf_angle, amp0, th, orb_dist, found, camera=pin)
+    g0 = m.SearchByProjectionReloc(F, sc["Tcw"], KP, kf_angle, amp0, th, orb_dist, found)
+    assert gp[1] == g0[1] and np.array_equal(gp[0], g0[0]) and not np.array_equal(g0[0], g[0])

@@ -1835,7 +1835,8 @@ def test_distinctive_descriptor_choice_is_the_references_text():
 
 
 @pytest.mark.parametrize("check", [True, False])
-def test_searchbyprojection_for_relocalisation_is_the_references_text(check):
+@pytest.mark.parametrize("camera", ["pinhole", "fisheye"])
+def test_searchbyprojection_for_relocalisation_is_the_references_text(check, camera):
     """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist) -- S/ORBmatcher.cc:2188-2310 -- WHOLE, with
     MapPoint::PredictScale / GetMin- / GetMaxDistanceInvariance (S/MapPoint.cc:617-661) transliterated too: no depth-sign test, inclusive
     bounds, the distance range, the level window, ANY point on a feature blocks it, ORBdist, the rotation histogram -- against the
@@ -1921,6 +1922,9 @@ def test_searchbyprojection_for_relocalisation_is_the_references_text(check):
     z = rng.uniform(2, 20, m)
     u = kps["x"][tgt] + rng.uniform(-5, 5, m); v = kps["y"][tgt] + rng.uniform(-5, 5, m)
     Pc = np.stack([(u - float(cx)) * z / float(fx), (v - float(cy)) * z / float(fy), z], 1)
+    kb8 = (capi.CAM_KANNALA_BRANDT8, 290.0, 291.0, 318.0, 242.0, 0.0035, 0.0007, -0.002, 0.0002)
+    if camera == "fisheye":                                  # a monocular fisheye frame: mpCamera a KannalaBrandt8 (:2217 projects through it)
+        Pc = np.stack([synth._kb8_ray(kb8, u[i], v[i], z[i]) for i in range(m)])
     Xw = ((Pc - Tc[:3, 3].astype(np.float64)) @ Tc[:3, :3].astype(np.float64)).astype(np.float32)
     Xw[:30, 2] -= 60.0                                      # behind the camera: no depth-sign test in this overload
     mdesc = desc[tgt] ^ (rng.randint(0, 256, (m, 32)).astype(np.uint8) & rng.randint(0, 256, (m, 32)).astype(np.uint8) & rng.randint(0, 256, (m, 32)).astype(np.uint8))
@@ -1934,13 +1938,17 @@ def test_searchbyprojection_for_relocalisation_is_the_references_text(check):
     amp0 = np.full(n, -1, np.int32); occ = rng.rand(n) < 0.1; amp0[occ] = 100000 + np.arange(occ.sum())
     wv, keep2 = views.worldpoints_view(Xw, np.zeros((m, 3), np.float32), mind, maxd, mdesc, np.ones(m, np.int32), bad)
     amp, nm = ob.search_by_projection_reloc(fv, Tc, wv, kangle, amp0, 10.0, 100, check, found)
+    cam_obj = Cam()
+    if camera == "fisheye":
+        amp, nm = ob.search_by_projection_reloc_cam(fv, Tc, views.camera_rig(kb8).left, wv, kangle, amp0, 10.0, 100, check, found)
+        cam_obj = _camera_standins_from_text()(kb8)
     # ---- the reference's text on stand-ins
     env = dict(ENV, F32=F32, F64=F64, abs=abs, fabs=abs, HISTO_LENGTH=30, mbCheckOrientation=check, as_int=lambda x: int(x), floor=np.floor, ceil=np.ceil,
                log=lambda x: F32(libm.logf(float(F32(x)))), round=lambda a: int(np.copysign(np.floor(np.abs(F64(a)) + 0.5), a)),
                DescriptorDistance=lambda a, b2: int(np.unpackbits(a ^ b2).sum()))
     exec(prog, env)
     Cur, KF = Obj(), Obj()
-    Cur.mTcw = MatF(Tc); Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY = [F32(x) for x in bounds]; Cur.mpCamera = Cam()
+    Cur.mTcw = MatF(Tc); Cur.mnMinX, Cur.mnMaxX, Cur.mnMinY, Cur.mnMaxY = [F32(x) for x in bounds]; Cur.mpCamera = cam_obj
     Cur.mvScaleFactors = [F32(x) for x in sc]; Cur.mDescriptors = Desc(desc); Cur.mvKeysUn = [Kp(k["x"], k["y"], k["octave"], k["angle"]) for k in kps]
     Cur.mfLogScaleFactor = F32(np.log(np.float32(1.2))); Cur.mnScaleLevels = 8
     Cur.mvpMapPoints = [None] * n
