@@ -385,6 +385,9 @@ int orbm_search_by_projection_reloc(orbm_frame* cur, orbm_map* kf_points, const 
                                     const float* kf_angle /*m*/, float th, int orb_dist, int check_orientation,
                                     int32_t* assigned_mp, int* nmatches);
 struct orbg_camera;
+/* orbm_search_by_projection_sim3 with camera_project = 1 and pKF->mpCamera a camera model (a fisheye keyframe): :515 projects through it. */
+int orbm_search_by_projection_sim3_cam(orbm_frame* kf, orbm_map* pts, const float* Scw /*16, row-major Sim3*/, const struct orbg_camera* cam,
+                                       const uint8_t* already_found, int th, float ratio_hamming, int32_t* matched, int* nmatches);
 /* ... the same with CurrentFrame.mpCamera a camera model (a monocular fisheye frame): :2217 projects through it. */
 int orbm_search_by_projection_reloc_cam(orbm_frame* cur, orbm_map* kf_points, const float* Tcw_cur /*16*/, const struct orbg_camera* cam,
                                         const uint8_t* already_found /*m or NULL*/, const float* kf_angle /*m*/, float th, int orb_dist,

@@ -177,7 +177,7 @@ EXPORTED_SYMBOLS = [
     "lba_set_profiling", "lba_get_solver_stats", "lba_event_overhead", "lba_get_watchdog_count",
     "orbd_database_create", "orbd_database_destroy", "orbd_detect_n_best_candidates",
     "orbx_set_stream", "orbm_frame_set_stream", "orbm_map_set_stream", "lba_set_stream", "orbv_vocab_set_stream", "orbd_database_set_stream",
-    "pose_opt_set_stream", "orbx_get_ctor_timeline", "orbm_map_set_observations", "orbm_search_by_projection_reloc", "orbm_search_by_projection_reloc_cam", "orbm_lastview_create", "orbm_lastview_destroy", "orbm_lastview_upload",
+    "pose_opt_set_stream", "orbx_get_ctor_timeline", "orbm_map_set_observations", "orbm_search_by_projection_reloc", "orbm_search_by_projection_reloc_cam", "orbm_search_by_projection_sim3_cam", "orbm_lastview_create", "orbm_lastview_destroy", "orbm_lastview_upload",
     "orbm_search_by_projection_frame_resident", "orbg_quiesce", "orbg_set_wait_policy", "orbg_get_wait_policy",
     "orbx_frame_mono", "orbx_frame_mono_dev", "orbx_frame_mono_submit", "orbx_frame_mono_dev_submit", "orbx_frame_mono_wait",
     "orbx_set_frame_outputs_un", "orbx_undistort_points",

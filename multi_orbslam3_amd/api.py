@@ -600,13 +600,17 @@ class ORBmatcher:
                    "orbm_search_by_bow_rig")
         return matches[: F.n].copy(), n.value
 
-    def SearchByProjectionSim3(self, pKF, Scw, points, vpMatched, th, ratioHamming=1.0, already_found=None, with_kfs=False):
+    def SearchByProjectionSim3(self, pKF, Scw, points, vpMatched, th, ratioHamming=1.0, already_found=None, with_kfs=False, camera=None):
         """(KeyFrame*, Scw, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming): S/ORBmatcher.cc:473-587
         (with_kfs=False) and :589-700 (with_kfs=True).  points: LocalMap resident on the device."""
         matched = np.ascontiguousarray(vpMatched, np.int32).copy()
         S = np.ascontiguousarray(Scw, np.float32).reshape(16)
         af = None if already_found is None else np.ascontiguousarray(already_found, np.uint8)
         n = C.c_int(0)
+        if camera is not None:                              # pKF->mpCamera is a camera model (an orbg_camera): a fisheye keyframe
+            capi.check(self.lib.orbm_search_by_projection_sim3_cam(pKF.h, points.h, _vp(S), C.byref(camera), _vp(af), int(th), C.c_float(ratioHamming),
+                                                                   _vp(matched), C.byref(n)), "orbm_search_by_projection_sim3_cam")
+            return matched, n.value
         capi.check(self.lib.orbm_search_by_projection_sim3(pKF.h, points.h, _vp(S), _vp(af), int(th), C.c_float(ratioHamming),
                                                            0 if with_kfs else 1, _vp(matched), C.byref(n)),
                    "orbm_search_by_projection_sim3")

@@ -631,9 +631,11 @@ __global__ __launch_bounds__(256) void search_culled_kernel(FrameParams fp, Fram
 }
 
 // SearchByProjection(KeyFrame*, Scw, ...) candidate tests (S/ORBmatcher.cc:495-548 / :612-667) fused with the window search
+// kModel: pKF->mpCamera->project (:515) is a camera model's (a fisheye keyframe) instead of the pinhole of the keyframe's view
+template <bool kModel>
 __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameDev F, WorldPtsDev w, const uint8_t* __restrict__ found,
                                                          PoseF P, int camera_project, int th, int* list_counter, int* counter_next, uint32_t* list,
-                                                         int list_cap, QResult* results) {
+                                                         int list_cap, QResult* results, RigCamF cam) {
   __shared__ uint32_t s_stage[4][kListStage];
   if (blockIdx.x == 0 && threadIdx.x == 0) *counter_next = 0;   // the overflow counter the NEXT search on this frame will use
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -647,7 +649,9 @@ __global__ __launch_bounds__(256) void search_sim3_kernel(FrameParams fp, FrameD
     pose_map(P, X, Pc);
     if (!(Pc[2] < 0.0f)) {
       float u, v;
-      if (camera_project) {
+      if constexpr (kModel) {
+        float uv[2]; rig_project(cam, Pc, uv); u = uv[0]; v = uv[1];
+      } else if (camera_project) {
         u = fp.fx * Pc[0] / Pc[2] + fp.cx;
         v = fp.fy * Pc[1] / Pc[2] + fp.cy;
       } else {
@@ -2636,9 +2640,20 @@ extern "C" int orbm_search_by_bow_kf(orbm_frame* kf2, const orbm_featvec_view* f
 
 // SearchByProjection(KeyFrame*, Scw, ...): Sim3 decomposition (S/ORBmatcher.cc:484-488) with the cv::Mat float conventions
 // spelled out in the oracle (scale by (float)(1/(double)scw)), then the candidate kernel and the serial commit (:556-583).
+static int search_sim3_common(orbm_frame* f, orbm_map* mp, const float* Scw, const uint8_t* already_found, int th, float ratio_hamming, int camera_project,
+                              int32_t* matched, int* nmatches_out, const orbg_camera* cam);
 extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const float* Scw, const uint8_t* already_found,
                                               int th, float ratio_hamming, int camera_project, int32_t* matched,
                                               int* nmatches_out) {
+  return search_sim3_common(f, mp, Scw, already_found, th, ratio_hamming, camera_project, matched, nmatches_out, nullptr);
+}
+extern "C" int orbm_search_by_projection_sim3_cam(orbm_frame* f, orbm_map* mp, const float* Scw, const orbg_camera* cam, const uint8_t* already_found,
+                                                  int th, float ratio_hamming, int32_t* matched, int* nmatches_out) {
+  if (!cam || (cam->model != ORBG_CAM_PINHOLE && cam->model != ORBG_CAM_KANNALA_BRANDT8)) return ORBG_BAD_ARG;
+  return search_sim3_common(f, mp, Scw, already_found, th, ratio_hamming, 1, matched, nmatches_out, cam);
+}
+static int search_sim3_common(orbm_frame* f, orbm_map* mp, const float* Scw, const uint8_t* already_found, int th, float ratio_hamming, int camera_project,
+                              int32_t* matched, int* nmatches_out, const orbg_camera* cam) {
   if (!f || !mp || !Scw || !matched || f->device != mp->device) return ORBG_BAD_ARG;
   int rc = select_device(f->device);
   if (rc) return rc;
@@ -2669,8 +2684,10 @@ extern "C" int orbm_search_by_projection_sim3(orbm_frame* f, orbm_map* mp, const
   F.uright = nullptr;                                          // no stereo gate in the KeyFrame searches
   if ((rc = map_sync_to(mp, st))) return rc;
   rc = run_search(f, m, [&](int list_cap, int* cnt, int* cnt_next) {
-    hipLaunchKernelGGL(search_sim3_kernel, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P,
-                       camera_project, th, cnt, cnt_next, f->list.d, list_cap, f->results.d);
+    if (cam) hipLaunchKernelGGL(search_sim3_kernel<true>, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P,
+                       camera_project, th, cnt, cnt_next, f->list.d, list_cap, f->results.d, rig_cam_of(*cam));
+    else hipLaunchKernelGGL(search_sim3_kernel<false>, dim3((m + 3) / 4), dim3(256), 0, st, f->fp, F, map_dev(mp), d_found, P,
+                       camera_project, th, cnt, cnt_next, f->list.d, list_cap, f->results.d, RigCamF{});
   });
   if (rc) return rc;
   std::vector<uint8_t> claimed(std::max(n, 1), 0);

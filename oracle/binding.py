@@ -448,6 +448,18 @@ def search_by_projection_sim3(kf, pts, Scw, matched, th, ratio_hamming=1.0, alre
     return matched, n.value
 
 
+def search_by_projection_sim3_cam(kf, pts, Scw, cam, matched, th, ratio_hamming=1.0, already_found=None):
+    """... with pKF->mpCamera a camera model (cam: an orbg_camera)."""
+    matched = np.ascontiguousarray(matched, np.int32).copy()
+    S = np.ascontiguousarray(Scw, np.float32).reshape(16)
+    af = None if already_found is None else np.ascontiguousarray(already_found, np.uint8)
+    n = C.c_int(0)
+    _chk(lib().oracle_search_by_projection_sim3_cam(C.byref(kf), C.byref(pts), C.c_void_p(S.ctypes.data), C.byref(cam),
+                                                    None if af is None else C.c_void_p(af.ctypes.data), int(th), C.c_float(ratio_hamming),
+                                                    C.c_void_p(matched.ctypes.data), C.byref(n)))
+    return matched, n.value
+
+
 def search_by_projection_reloc(cur, Tcw_cur, pts, kf_angle, assigned_mp, th, orb_dist, check_ori=True, already_found=None):
     """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, set<MapPoint*>&, th, ORBdist), S/ORBmatcher.cc:2188-2310."""
     amp = np.ascontiguousarray(assigned_mp, np.int32).copy()

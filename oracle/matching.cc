@@ -825,9 +825,20 @@ static void sim3_pose(const float* S, float* T16) {
 // which projects with a float invz instead of Pinhole::project).  matched[idx] >= 0 means vpMatched[idx] != NULL on entry;
 // on exit newly matched features hold the index of the candidate point.  already_found[i] = 1 when vpPoints[i] is
 // a member of vpMatched on entry (spAlreadyFound, :491-492).
+static int search_by_projection_sim3_impl(const orbm_frame_view* kf, const orbm_worldpoints_view* pts, const float* Scw, const uint8_t* already_found, int th,
+                                         float ratio_hamming, int camera_project, int32_t* matched, int* nmatches_out, const orbg_camera* cam);
 extern "C" int oracle_search_by_projection_sim3(const orbm_frame_view* kf, const orbm_worldpoints_view* pts, const float* Scw,
                                                 const uint8_t* already_found, int th, float ratio_hamming,
                                                 int camera_project, int32_t* matched, int* nmatches_out) {
+  return search_by_projection_sim3_impl(kf, pts, Scw, already_found, th, ratio_hamming, camera_project, matched, nmatches_out, nullptr);
+}
+// ... :473-587 with pKF->mpCamera a camera model (a fisheye keyframe): :515 projects through it
+extern "C" int oracle_search_by_projection_sim3_cam(const orbm_frame_view* kf, const orbm_worldpoints_view* pts, const float* Scw, const orbg_camera* cam,
+                                                    const uint8_t* already_found, int th, float ratio_hamming, int32_t* matched, int* nmatches_out) {
+  return search_by_projection_sim3_impl(kf, pts, Scw, already_found, th, ratio_hamming, 1, matched, nmatches_out, cam);
+}
+static int search_by_projection_sim3_impl(const orbm_frame_view* kf, const orbm_worldpoints_view* pts, const float* Scw, const uint8_t* already_found, int th,
+                                         float ratio_hamming, int camera_project, int32_t* matched, int* nmatches_out, const orbg_camera* cam) {
   const ScaleTables st(kf);
   const Grid g = build_grid(kf);
   float T16[16];
@@ -842,7 +853,9 @@ extern "C" int oracle_search_by_projection_sim3(const orbm_frame_view* kf, const
     pose.map(p3Dw, p3Dc);
     if (p3Dc[2] < 0.0) continue;
     float u, v;
-    if (camera_project) {                     // Pinhole::project(cv::Point3f)  S/CameraModels/Pinhole.cpp:28-31
+    if (cam) {
+      float uv[2]; rig_cam_project(*cam, p3Dc, uv); u = uv[0]; v = uv[1];
+    } else if (camera_project) {              // Pinhole::project(cv::Point3f)  S/CameraModels/Pinhole.cpp:28-31
       u = kf->fx * p3Dc[0] / p3Dc[2] + kf->cx;
       v = kf->fy * p3Dc[1] / p3Dc[2] + kf->cy;
     } else {                                  // :631-635

@@ -117,6 +117,9 @@ int oracle_fisheye_stereo_matches(const orbx_fisheye_stereo_view* view, int32_t*
 void oracle_kb8_unproject(const orbg_camera* cam, float u, float v, float* ray3);
 float oracle_kb8_triangulate_matches(const orbg_camera* cam1, const orbg_camera* cam2, const float* uv1, const float* uv2, const float* Tlr,
                                      float sigma1, float sigma2, float* p3D);
+/* SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) with pKF->mpCamera a camera model (S/ORBmatcher.cc:515) */
+int oracle_search_by_projection_sim3_cam(const orbm_frame_view* kf, const orbm_worldpoints_view* pts, const float* Scw, const orbg_camera* cam,
+                                         const uint8_t* already_found, int th, float ratio_hamming, int32_t* matched, int* nmatches);
 /* the relocalisation overload with CurrentFrame.mpCamera a camera model (S/ORBmatcher.cc:2217) */
 int oracle_search_by_projection_reloc_cam(const orbm_frame_view* cur, const float* Tcw_cur, const orbg_camera* cam, const orbm_worldpoints_view* pts,
                                           const uint8_t* already_found, const float* kf_angle, float th, int orb_dist, int check_orientation,

@@ -2154,3 +2154,28 @@ def test_relocalisation_search_with_a_camera_model(th, orb_dist):
     gp = m.SearchByProjectionReloc(F, sc["Tcw"], KP, kf_angle, amp0, th, orb_dist, found, camera=pin)
     g0 = m.SearchByProjectionReloc(F, sc["Tcw"], KP, kf_angle, amp0, th, orb_dist, found)
     assert gp[1] == g0[1] and np.array_equal(gp[0], g0[0]) and not np.array_equal(g0[0], g[0])
+
+
+@pytest.mark.parametrize("th,ratio,scale", [(3, 1.5, 1.0), (8, 1.0, 1.4)])
+def test_sim3_keyframe_search_with_a_camera_model(th, ratio, scale):
+    """Server-side SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) on a fisheye keyframe: S/ORBmatcher.cc:515
+    projects through pKF->mpCamera -- orbm_search_by_projection_sim3_cam against the oracle; with a PINHOLE handed in as the model it
+    is orbm_search_by_projection_sim3 (camera_project = 1)."""
+    sc = synth.make_rig_track_scene()
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    rng = np.random.RandomState(33)
+    S = sc["Tcw"].copy(); S[:3, :] *= np.float32(scale)
+    nl = len(sc["kps_left"])
+    matched0 = np.where(rng.rand(nl) < 0.15, 3, -1).astype(np.int32)
+    found = (rng.rand(wv.m) < 0.1).astype(np.uint8)
+    F = api.Frame().upload(fl, keep[0])
+    LM = api.LocalMap().upload(wv)
+    m = api.ORBmatcher(0.75, True)
+    cam = views.camera_rig(sc["left"]).left
+    g = m.SearchByProjectionSim3(F, S, LM, matched0, th, ratio, found, camera=cam)
+    o = ob.search_by_projection_sim3_cam(fl, wv, S, cam, matched0, th, ratio, found)
+    assert o[1] > 100 and g[1] == o[1] and np.array_equal(g[0], o[0])
+    pin = views.camera_rig((capi.CAM_PINHOLE, fl.fx, fl.fy, fl.cx, fl.cy)).left
+    gp = m.SearchByProjectionSim3(F, S, LM, matched0, th, ratio, found, camera=pin)
+    g0 = m.SearchByProjectionSim3(F, S, LM, matched0, th, ratio, found)
+    assert gp[1] == g0[1] and np.array_equal(gp[0], g0[0]) and not np.array_equal(g0[0], g[0])

@@ -2120,7 +2120,8 @@ def _keyframe_get_features_in_area_source():
     return "def GetFeaturesInArea(x, y, r, bRight=False):\n" + "\n".join("    " + ln for ln in py.splitlines())
 
 
-def test_searchbyprojection_with_a_sim3_is_the_references_text():
+@pytest.mark.parametrize("camera", ["pinhole", "fisheye"])
+def test_searchbyprojection_with_a_sim3_is_the_references_text(camera):
     """ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, vpPoints, vpMatched, th, ratioHamming) -- S/ORBmatcher.cc:473-587, the server's
     loop / merge matcher -- WHOLE, with KeyFrame::GetFeaturesInArea and IsInImage (S/KeyFrame.cc:889-945), MapPoint::PredictScale(dist, pKF)
     and the distance getters transliterated: the Sim3 decomposition, depth sign, image bounds (half open here), distance range, the 60-degree
@@ -2202,6 +2203,9 @@ def test_searchbyprojection_with_a_sim3_is_the_references_text():
     z = rng.uniform(2, 20, m)
     u = kps["x"][tgt] + rng.uniform(-4, 4, m); v = kps["y"][tgt] + rng.uniform(-4, 4, m)
     Pc = np.stack([(u - float(cx)) * z / float(fx), (v - float(cy)) * z / float(fy), z], 1)
+    kb8 = (capi.CAM_KANNALA_BRANDT8, 290.0, 291.0, 318.0, 242.0, 0.0035, 0.0007, -0.002, 0.0002)
+    if camera == "fisheye":                                  # a fisheye keyframe: pKF->mpCamera a KannalaBrandt8 (:515 projects through it)
+        Pc = np.stack([synth._kb8_ray(kb8, u[i_], v[i_], z[i_]) for i_ in range(len(z))])
     Xw = ((Pc - t) @ R).astype(np.float32)
     Xw[:30, 2] -= 60.0
     Ow = -(R.T @ t)
@@ -2218,6 +2222,10 @@ def test_searchbyprojection_with_a_sim3_is_the_references_text():
     found = np.zeros(m, np.uint8); found[matched0[pre]] = 1
     wv, keep2 = views.worldpoints_view(Xw, normal, mind, maxd, mdesc, np.ones(m, np.int32), bad)
     matched, nm = ob.search_by_projection_sim3(fv, wv, Scw, matched0, 8, ratio_hamming=1.0, already_found=found)
+    cam_obj = Cam()
+    if camera == "fisheye":
+        matched, nm = ob.search_by_projection_sim3_cam(fv, wv, Scw, views.camera_rig(kb8).left, matched0, 8, 1.0, found)
+        cam_obj = _camera_standins_from_text()(kb8)
     env = dict(ENV, F32=F32, F64=F64, abs=abs, TH_LOW=50, as_int=lambda x: int(x), floor=np.floor, ceil=np.ceil, IdSet=IdSet, Point3f=Point3f,
                log=lambda x: F32(libm.logf(float(F32(x)))), DescriptorDistance=lambda a, b2: int(np.unpackbits(a ^ b2).sum()))
     exec(prog, env)
@@ -2229,7 +2237,7 @@ def test_searchbyprojection_with_a_sim3_is_the_references_text():
         q.GetWorldPos = (lambda i=i: MatF(Xw[i].reshape(3, 1))); q.GetNormal = (lambda i=i: MatF(normal[i].reshape(3, 1))); q.GetDescriptor = (lambda i=i: mdesc[i])
         mps.append(q)
     KF = Obj()
-    KF.fx, KF.fy, KF.cx, KF.cy = fx, fy, cx, cy; KF.mpCamera = Cam(); KF.mvScaleFactors = [F32(x) for x in sc]; KF.mfLogScaleFactor = F32(np.log(np.float32(1.2)))
+    KF.fx, KF.fy, KF.cx, KF.cy = fx, fy, cx, cy; KF.mpCamera = cam_obj; KF.mvScaleFactors = [F32(x) for x in sc]; KF.mfLogScaleFactor = F32(np.log(np.float32(1.2)))
     KF.mnScaleLevels = 8; KF.mvKeysUn = [Kp(k["x"], k["y"], k["octave"]) for k in kps]; KF.mDescriptors = Desc(desc)
     genv = dict(env, mnMinX=F32(bounds[0]), mnMinY=F32(bounds[2]), mnMaxX=F32(bounds[1]), mnMaxY=F32(bounds[3]), mnGridCols=capi.GRID_COLS, mnGridRows=capi.GRID_ROWS,
                 mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / F32(F32(bounds[1]) - F32(bounds[0]))),
@@ -2690,7 +2698,9 @@ def _camera_standins_from_text():
     class Cam:
         def __init__(self, c): self.model = c[0]; self.p = [F32(v) for v in c[1:]]
         def project(self, m):
-            p3 = P3(); p3.x, p3.y, p3.z = m.at(0), m.at(1), m.at(2)
+            p3 = P3()
+            if hasattr(m, "at"): p3.x, p3.y, p3.z = m.at(0), m.at(1), m.at(2)      # project(cv::Mat)
+            else: p3.x, p3.y, p3.z = F32(m.x), F32(m.y), F32(m.z)                  # project(cv::Point3f)
             if self.model == capi.CAM_KANNALA_BRANDT8:
                 return env["kb8_project"](p3, self.p)
             e2 = dict(env, mvParameters=self.p, p3D=p3)
