@@ -76,9 +76,16 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert lib.orbd_database_create(0, C.byref(dv), C.byref(f)) == capi.ORBG_NO_DEVICE
     q = np.zeros((1, 32), np.uint8); d = np.zeros((1, 1), np.int32)
     assert lib.orbm_hamming_matrix(0, C.c_void_p(q.ctypes.data), 1, C.c_void_p(q.ctypes.data), 1, C.c_void_p(d.ctypes.data)) == capi.ORBG_NO_DEVICE
-    from multi_orbslam3_amd import api
+    from multi_orbslam3_amd import api, synth, views
     with pytest.raises(capi.OrbGpuError):
         api.ORBextractor()
+    # the left-right matcher of the two-fisheye Frame constructor is a stand-alone entry point: no handle, no fallback either
+    fs = synth.make_fisheye_stereo_scene(n_stereo=20, n_mono_left=5, n_mono_right=5, n_distract=5)
+    v, keep = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"], fs["right"],
+                                        fs["Tlr"], fs["level_sigma2"])
+    with pytest.raises(capi.OrbGpuError) as e:
+        api.ComputeStereoFishEyeMatches(v)
+    assert e.value.code == capi.ORBG_NO_DEVICE
 
 
 def test_product_never_references_the_oracle():
