@@ -2179,3 +2179,49 @@ def test_sim3_keyframe_search_with_a_camera_model(th, ratio, scale):
     gp = m.SearchByProjectionSim3(F, S, LM, matched0, th, ratio, found, camera=pin)
     g0 = m.SearchByProjectionSim3(F, S, LM, matched0, th, ratio, found)
     assert gp[1] == g0[1] and np.array_equal(gp[0], g0[0]) and not np.array_equal(g0[0], g[0])
+
+
+def test_two_camera_matchers_over_forty_scenes():
+    """The two-camera forms over forty seeded scenes (sizes, occupancy, stereo partners, zero-observation points, motion and th vary with the
+    seed): isInFrustum flags and levels, SearchByProjection(Frame, MapPoints), SearchByProjection(CurrentFrame, LastFrame), SearchByBoW and
+    ComputeStereoFishEyeMatches -- every discrete output equal to the oracle's in every scene (the float32 atan2 / cos / sin / tan of
+    KannalaBrandt8 differ in the last place between the device and the host's libm: a window edge or a threshold would have to sit within
+    1e-4 px of a projection for a result to flip)."""
+    m8, m7 = api.ORBmatcher(0.8, True), api.ORBmatcher(0.7, True)
+    bad = []
+    for seed in range(int(os.environ.get("ORBG_SWEEP_SCENES", "40"))):
+        rng = np.random.RandomState(1000 + seed)
+        sc = synth.make_rig_track_scene(n_points=int(rng.randint(300, 1600)), n_distract=int(rng.randint(20, 400)), seed=0x5000 + seed,
+                                        stereo_frac=float(rng.uniform(0.1, 0.9)), occupied_frac=float(rng.uniform(0.0, 0.3)), zero_obs_frac=float(rng.uniform(0.0, 0.3)))
+        fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+        FL, FR = api.Frame().upload(fl, keep[0]), api.Frame().upload(fr, keep[1])
+        g, o = FL.isInFrustumRig(sc["Tcw"], rig, sc["Tlr"], wv), ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+        if not all(np.array_equal(g[s][k], o[s][k]) for s in (0, 1) for k in ("track_in_view", "scale_level")):
+            bad.append((seed, "frustum"))
+        mv, mvr, keep2 = helpers.rig_mappoint_views(sc, o[0], o[1])
+        th = float(rng.choice([1.0, 3.0, 5.0, 15.0])); far = bool(rng.rand() < 0.5)
+        a = m8.SearchByProjectionRig(FL, FR, mv, mvr, sc["left_to_right"], sc["right_to_left"], th, far, 6.0, sc["assigned_mp"], sc["assigned_obs"])
+        b = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], th, far, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"])
+        if not (a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+            bad.append((seed, "search map points"))
+        last = synth.rig_last_frame(sc, n_last=min(900, len(sc["pos"])), seed=seed, motion=(0.03, 0.01, float(rng.choice([-0.4, 0.02, 0.4]))))
+        lv, keep3 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+        thf = float(rng.choice([7.0, 15.0]))
+        a = m8.SearchByProjectionFrameRig(FL, FR, sc["Tcw"], rig, lv, thf, False, sc["assigned_mp"], sc["assigned_obs"])
+        b = ob.search_by_projection_frame_rig(fl, fr, sc["Tcw"], rig, lv, thf, 0, 1, sc["assigned_mp"], sc["assigned_obs"])
+        if not (a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+            bad.append((seed, "search last frame"))
+        fv, keepa, fvF, fvK, kf_desc, kf_angle, valid, keepb = _rig_bow_scene(sc, n_kf=min(900, len(sc["pos"])), seed=seed, shift=int(rng.choice([3, 5])))
+        FA = api.Frame().upload(fv, keepa)
+        a = m7.SearchByBoWRig(FA, len(sc["kps_left"]), fvF, kf_desc, valid, kf_angle, fvK)
+        b = ob.search_by_bow_rig(fv, len(sc["kps_left"]), fvF, kf_desc, valid, kf_angle, fvK, 0.7, True)
+        if not (a[1] == b[1] and np.array_equal(a[0], b[0])):
+            bad.append((seed, "bow"))
+        fs = synth.make_fisheye_stereo_scene(n_stereo=int(rng.randint(100, 900)), n_mono_left=int(rng.randint(0, 300)), n_mono_right=int(rng.randint(0, 300)),
+                                             n_distract=int(rng.randint(0, 200)), seed=0x6000 + seed)
+        v, keep4 = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"],
+                                             fs["right"], fs["Tlr"], fs["level_sigma2"])
+        a, b = api.ComputeStereoFishEyeMatches(v), ob.fisheye_stereo_matches(v)
+        if not (a[4] == b[4] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+            bad.append((seed, "fisheye stereo"))
+    assert not bad, bad
