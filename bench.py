@@ -1399,6 +1399,12 @@ def main():
             if cl.get("ok") is not True:
                 parity["ok"] = False
                 parity.setdefault("violations", []).append("closed loop: %s" % {k2: v for k2, v in cl.items() if k2 in ("error", "shadow_mismatches", "first_divergent_frame", "first_divergent_frame_no_caches")})
+            # ... and of a two-fisheye agent (tests/cpp/rig_loop.cpp: the constructor's stereo matcher, the two-camera matchers, both optimisers)
+            rl = run_rig_loop(120)
+            parity["rig_closed_loop"] = rl
+            if rl.get("ok") is not True:
+                parity["ok"] = False
+                parity.setdefault("violations", []).append("rig closed loop: %s" % {k2: v for k2, v in rl.items() if k2 != "what"})
         oks = grp.gather_floats(1.0 if parity.get("ok", True) else 0.0)
         parity["agents_ok"] = [bool(v) for v in oks]
         parity["agent_digests"] = [int(v) for v in grp.gather_floats(float(parity.get("agent_digest", 0)))]
@@ -1547,6 +1553,28 @@ def run_closed_loop(n_frames):
                      "LocalBundleAdjustment every 5th; the product run and the oracle run each carry their own state; shadow_* = every "
                      "product call repeated on the oracle with identical inputs; first_divergent_frame = -1: every discrete digest equal "
                      "on every frame")
+        return d
+    except Exception as e:
+        return {"ok": False, "error": repr(e)[:300]}
+
+
+def run_rig_loop(n_frames):
+    """tests/cpp/rig_loop (built with closed_loop): a two-fisheye agent through the glue, product vs oracle, each on its own outputs."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "rig_loop")
+    try:
+        if not os.path.exists(exe):
+            import __graft_entry__ as ge
+            ge.build_closed_loop()
+        r = subprocess.run([exe, str(int(n_frames))], capture_output=True, text=True, timeout=600)
+        rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if not rows:
+            return {"ok": False, "error": "rig_loop exit code %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
+        d = json.loads(rows[-1])["rig_loop"]
+        d["ok"] = bool(d.get("ok")) and r.returncode == 0
+        d["what"] = ("two-fisheye agent through include/orbgpu_dropin.hpp over mock objects: ComputeStereoFishEyeMatches -> motion model -> "
+                     "SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints -> PoseOptimization every frame; the product run and "
+                     "the oracle run each carry their own state; first_divergent_frame = -1: every discrete digest equal on every frame")
         return d
     except Exception as e:
         return {"ok": False, "error": repr(e)[:300]}

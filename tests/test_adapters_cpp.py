@@ -32,7 +32,7 @@ def _no_gpu():
     return _capi.load().orbg_device_count() <= 0
 
 
-@pytest.mark.parametrize("name,with_oracle", [("adapter_smoke", False), ("dropin_parity", True), ("dropin_bench", False), ("opencv_branches", False)])
+@pytest.mark.parametrize("name,with_oracle", [("adapter_smoke", False), ("dropin_parity", True), ("dropin_bench", False), ("opencv_branches", False), ("rig_loop", True)])
 def test_host_side_compiles_links_and_fails_loudly_without_gpu(name, with_oracle):
     exe = _build(name, with_oracle)
     if not _no_gpu():
@@ -105,6 +105,23 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
     assert r.stdout.count("two-camera Frame (last frame") == 3, r.stdout[-3000:]      # the matcher's two-camera forms through the glue
     assert "ComputeStereoFishEyeMatches [two-fisheye rig]:" in r.stdout, r.stdout[-3000:]
     assert "monocular fisheye Frame:" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_rig_closed_loop_120_frames_product_and_oracle_each_feeding_on_their_own_outputs():
+    """tests/cpp/rig_loop: 120 frames of a two-fisheye agent through the glue -- ComputeStereoFishEyeMatches, the motion model,
+    SearchByProjection(Cur, Last), PoseOptimization, outliers dropped, SearchLocalPoints, PoseOptimization, mLastFrame, as Tracking::Track
+    does -- once over liborbgpu, once over the CPU oracle, each run carrying its OWN poses, matches and outlier decisions from frame to
+    frame: stereo partners, both match arrays, both outlier sets and the inlier counts equal on every frame, poses within 1e-4
+    (measured 2e-7 over the first 40 frames), the agent keeps track of the truth (a few millimetres)."""
+    import json
+    exe = _build("rig_loop", with_oracle=True)
+    r = subprocess.run([exe, "120"], capture_output=True, text=True, timeout=600)
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and rows, (r.returncode, r.stdout[-2000:], r.stderr[-500:])
+    d = json.loads(rows[-1])["rig_loop"]
+    assert d["ok"] and d["frames"] == 120 and d["first_divergent_frame"] == -1 and d["max_pose_diff"] <= 1e-4 and d["mean_inliers"] > 500, d
+    assert d["max_pose_error_vs_truth"] < 0.05, d
 
 
 def test_closed_loop_scenario_tracks_on_the_oracle_alone():
