@@ -1,10 +1,12 @@
 // Closed loop of a two-fisheye agent through the reference-signature glue (include/orbgpu_dropin.hpp): K frames, each built from the SAME
 // synthetic observations of a fixed map (features of both cameras: noisy projections, descriptors a few bits off, distractors), then
 //   ComputeStereoFishEyeMatches -> motion model -> SearchByProjection(Cur, Last) -> PoseOptimization -> outliers dropped ->
-//   SearchLocalPoints -> PoseOptimization -> outliers dropped -> mLastFrame
+//   SearchLocalPoints -> PoseOptimization -> outliers dropped -> mLastFrame; every eighth frame a keyframe + LocalBundleAdjustment
+//   (write-back into this run's own keyframes and map points, flagged observations erased)
 // as Tracking::Track does (S/Tracking.cc:2590-2811, TrackWithMotionModel :2928-3010, TrackLocalMap :3012-3081) -- once over liborbgpu,
 // once over the CPU oracle, EACH RUN FEEDING ON ITS OWN poses, matches and outlier decisions.  Per-frame digests (stereo partners, both
-// match arrays, outlier flags, inlier counts) must be equal on every frame, poses within 1e-4; the first divergent frame is reported.
+// match arrays, outlier flags, inlier counts, local-BA status / fixed keyframes, observation counts) must be equal on every frame, poses and
+// keyframe poses within 1e-4, point positions within 5e-2; the first divergent frame is reported.
 //   rig_loop [frames]          exit code 0 = no divergence
 #include <cmath>
 #include <cstdio>
@@ -16,7 +18,8 @@
 #include "../../oracle/orb_oracle.h"
 #include "oracle_ops.hpp"
 
-struct Digest { std::vector<int> l2r; std::vector<long> after_motion, after_local; std::vector<bool> outl1, outl2; int n_stereo = 0, n_motion = 0, in1 = 0, n_local = 0, in2 = 0; std::vector<float> pose; };
+struct Digest { std::vector<int> l2r; std::vector<long> after_motion, after_local; std::vector<bool> outl1, outl2; int n_stereo = 0, n_motion = 0, in1 = 0, n_local = 0, in2 = 0; std::vector<float> pose;
+                int lba_status = -99, lba_fixed = -1, obs_total = 0; std::vector<float> points, kf_poses; };
 
 struct World { std::vector<std::unique_ptr<MapPoint>> pts; std::vector<double> base_angle; std::vector<int> lvl; Map map; };
 
@@ -137,6 +140,38 @@ static std::vector<Digest> run(int K) {
     d.outl2 = F->mvbOutlier;
     drop_outliers(*F);
     d.pose.assign(F->mTcw.ptr<float>(0), F->mTcw.ptr<float>(0) + 16);
+    // every eighth frame becomes a keyframe and LocalMapping runs its local BA (S/LocalMapping.cc:245): observations of both cameras
+    // (the tuple's second entry is NLeft + the right camera's index), the window = the last five keyframes, the write-back moves
+    // keyframe poses and THIS run's map points, flagged observations are erased
+    if (k % 8 == 0) {
+      std::unique_ptr<KeyFrame> kf(new KeyFrame);
+      kf->mnId = (long unsigned)A.kfs.size(); kf->mpMap = &W.map;
+      kf->fx = F->fx; kf->fy = F->fy; kf->cx = F->cx; kf->cy = F->cy; kf->mbf = 0.f; kf->mvInvLevelSigma2 = F->mvInvLevelSigma2;
+      kf->mpCamera = F->mpCamera; kf->mpCamera2 = F->mpCamera2; kf->mTrl = F->mTrl; kf->NLeft = F->Nleft; kf->NRight = F->Nright;
+      kf->mvKeys = F->mvKeys; kf->mvKeysUn = F->mvKeys; kf->mvKeysRight = F->mvKeysRight; kf->mvuRight.assign(F->Nleft, -1.f);
+      kf->Tcw = F->mTcw;
+      kf->mvpMapPoints = F->mvpMapPoints;
+      for (int i = 0; i < F->N; i++) {
+        MapPoint* mp = F->mvpMapPoints[i];
+        if (!mp) continue;
+        auto it = mp->mObservations.find(kf.get());
+        int li = -1, ri = -1;
+        if (it != mp->mObservations.end()) { li = std::get<0>(it->second); ri = std::get<1>(it->second); } else mp->nObs++;
+        if (i < F->Nleft) li = i; else ri = i;                                                    // (i >= Nleft IS NLeft + the right index)
+        mp->mObservations[kf.get()] = std::make_tuple(li, ri);
+        mp->Touch();                                                                                // (MapPoint::AddObservation moves the change counter, INTEGRATION.md edit E2)
+      }
+      for (int q = (int)A.kfs.size() - 1; q >= 0 && (int)kf->mvpOrderedConnectedKeyFrames.size() < 5; q--) kf->mvpOrderedConnectedKeyFrames.push_back(A.kfs[q].get());
+      KeyFrame* cur_kf = kf.get();
+      A.kfs.push_back(std::move(kf));
+      if (A.kfs.size() >= 2) {
+        bool stop = false; int num_fixed = -1;
+        d.lba_status = od::LocalBundleAdjustment<Ops>(cur_kf, &stop, &W.map, num_fixed, 0);
+        d.lba_fixed = num_fixed;
+      }
+      for (auto& p : W.pts) { d.obs_total += p->nObs; for (int a = 0; a < 3; a++) d.points.push_back(p->mWorldPos.ptr<float>(0)[a]); }
+      for (auto& q : A.kfs) for (int a = 0; a < 16; a++) d.kf_poses.push_back(q->Tcw.ptr<float>(0)[a]);
+    }
     out.push_back(d);
     last2 = std::move(last); last = std::move(F);
   }
@@ -147,22 +182,30 @@ int main(int argc, char** argv) {
   const int K = argc > 1 ? std::atoi(argv[1]) : 40;
   if (orbg_device_count() <= 0) { std::printf("no usable HIP device\n"); return 3; }
   const std::vector<Digest> g = run<od::GpuOps>(K), c = run<OracleOps>(K);
-  int first = -1; double worst = 0, worst_truth = 0; long matches = 0;
+  int first = -1, n_lba = 0, n_kf = 0; double worst = 0, worst_truth = 0, worst_pt = 0, worst_kf = 0; long matches = 0;
   for (int k = 0; k < K; k++) {
     const Digest &a = g[k], &b = c[k];
     const bool same = a.l2r == b.l2r && a.after_motion == b.after_motion && a.after_local == b.after_local && a.outl1 == b.outl1 && a.outl2 == b.outl2 &&
-                      a.n_stereo == b.n_stereo && a.n_motion == b.n_motion && a.n_local == b.n_local && a.in1 == b.in1 && a.in2 == b.in2;
+                      a.n_stereo == b.n_stereo && a.n_motion == b.n_motion && a.n_local == b.n_local && a.in1 == b.in1 && a.in2 == b.in2 &&
+                      a.lba_status == b.lba_status && a.lba_fixed == b.lba_fixed && a.obs_total == b.obs_total && a.points.size() == b.points.size();
     double dp = 0; for (int i = 0; i < 16; i++) dp = std::max(dp, (double)std::fabs(a.pose[i] - b.pose[i]));
     worst = std::max(worst, dp);
+    if (same) { for (size_t i = 0; i < a.points.size(); i++) worst_pt = std::max(worst_pt, (double)std::fabs(a.points[i] - b.points[i]));
+                for (size_t i = 0; i < a.kf_poses.size() && i < b.kf_poses.size(); i++) worst_kf = std::max(worst_kf, (double)std::fabs(a.kf_poses[i] - b.kf_poses[i])); }
+    if (a.lba_status == 0) n_lba++;
+    if (a.lba_status != -99) n_kf++;
     double T[16]; true_pose(k, T); double dt = 0; for (int i = 0; i < 16; i++) dt = std::max(dt, std::fabs(a.pose[i] - T[i]));
     worst_truth = std::max(worst_truth, dt);
     matches += a.in2;
-    if ((!same || dp > 1e-4) && first < 0) first = k;
+    // (gates as tests/cpp/closed_loop.cpp: a local BA that stops short of convergence returns weakly observed points millimetres apart for inputs
+    //  micrometres apart -- poses and keyframe poses 1e-4, point positions 5e-2)
+    if ((!same || dp > 1e-4 || worst_pt > 5e-2 || worst_kf > 1e-4) && first < 0) first = k;
     if (k < 3 || k == K - 1 || !same)
-      std::printf("frame %2d: stereo %d, motion model %d matches -> %d inliers, local map %d matches -> %d inliers, pose diff %.2e%s\n", k, a.n_stereo, a.n_motion, a.in1, a.n_local, a.in2, dp,
-                  same ? "" : "   DIGESTS DIFFER");
+      std::printf("frame %2d: stereo %d, motion model %d matches -> %d inliers, local map %d matches -> %d inliers, pose diff %.2e, local BA %d (%d fixed), %d observations%s\n", k, a.n_stereo,
+                  a.n_motion, a.in1, a.n_local, a.in2, dp, a.lba_status, a.lba_fixed, a.obs_total, same ? "" : "   DIGESTS DIFFER");
   }
-  std::printf("{\"rig_loop\": {\"frames\": %d, \"first_divergent_frame\": %d, \"max_pose_diff\": %.3g, \"max_pose_error_vs_truth\": %.3g, \"mean_inliers\": %.1f, \"ok\": %s}}\n", K, first, worst,
-              worst_truth, (double)matches / K, first < 0 ? "true" : "false");
+  std::printf("{\"rig_loop\": {\"frames\": %d, \"first_divergent_frame\": %d, \"max_pose_diff\": %.3g, \"max_pose_error_vs_truth\": %.3g, \"mean_inliers\": %.1f, "
+              "\"local_bas\": %d, \"local_bas_applied\": %d, \"max_point_diff\": %.3g, \"max_keyframe_pose_diff\": %.3g, \"ok\": %s}}\n", K, first, worst,
+              worst_truth, (double)matches / K, n_kf, n_lba, worst_pt, worst_kf, first < 0 ? "true" : "false");
   return first < 0 ? 0 : 1;
 }

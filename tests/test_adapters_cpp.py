@@ -111,7 +111,7 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
 def test_rig_closed_loop_120_frames_product_and_oracle_each_feeding_on_their_own_outputs():
     """tests/cpp/rig_loop: 120 frames of a two-fisheye agent through the glue -- ComputeStereoFishEyeMatches, the motion model,
     SearchByProjection(Cur, Last), PoseOptimization, outliers dropped, SearchLocalPoints, PoseOptimization, mLastFrame, as Tracking::Track
-    does -- once over liborbgpu, once over the CPU oracle, each run carrying its OWN poses, matches and outlier decisions from frame to
+    does, every eighth frame a keyframe and LocalBundleAdjustment over the last keyframes (write-back, erasures) -- once over liborbgpu, once over the CPU oracle, each run carrying its OWN poses, matches and outlier decisions from frame to
     frame: stereo partners, both match arrays, both outlier sets and the inlier counts equal on every frame, poses within 1e-4
     (measured 2e-7 over the first 40 frames), the agent keeps track of the truth (a few millimetres)."""
     import json
@@ -121,7 +121,7 @@ def test_rig_closed_loop_120_frames_product_and_oracle_each_feeding_on_their_own
     assert r.returncode == 0 and rows, (r.returncode, r.stdout[-2000:], r.stderr[-500:])
     d = json.loads(rows[-1])["rig_loop"]
     assert d["ok"] and d["frames"] == 120 and d["first_divergent_frame"] == -1 and d["max_pose_diff"] <= 1e-4 and d["mean_inliers"] > 500, d
-    assert d["max_pose_error_vs_truth"] < 0.05, d
+    assert d["max_pose_error_vs_truth"] < 0.05 and d["local_bas"] >= 14 and d["local_bas_applied"] >= 12 and d["max_keyframe_pose_diff"] <= 1e-4 and d["max_point_diff"] <= 5e-2, d
 
 
 def test_closed_loop_scenario_tracks_on_the_oracle_alone():
