@@ -1572,9 +1572,15 @@ def run_rig_loop(n_frames):
             return {"ok": False, "error": "rig_loop exit code %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
         d = json.loads(rows[-1])["rig_loop"]
         d["ok"] = bool(d.get("ok")) and r.returncode == 0
+        r2 = subprocess.run([exe, str(int(n_frames)), "--shadow"], capture_output=True, text=True, timeout=600)      # every call repeated on the oracle with identical inputs
+        rows2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+        sh = json.loads(rows2[-1])["rig_loop_shadow"] if rows2 else {"ok": False, "error": (r2.stdout + r2.stderr)[-300:]}
+        d["shadow"] = sh
+        d["ok"] = d["ok"] and bool(sh.get("ok")) and r2.returncode == 0
         d["what"] = ("two-fisheye agent through include/orbgpu_dropin.hpp over mock objects: ComputeStereoFishEyeMatches -> motion model -> "
                      "SearchByProjection(Cur, Last) -> PoseOptimization -> SearchLocalPoints -> PoseOptimization every frame; the product run and "
-                     "the oracle run each carry their own state; first_divergent_frame = -1: every discrete digest equal on every frame")
+                     "the oracle run each carry their own state (a fisheye agent's runs may part by a match or two where a projection sits within 1e-4 px of a "
+                     "window edge: ok = they stay together); shadow = every product call repeated on the oracle with identical inputs, exact")
         return d
     except Exception as e:
         return {"ok": False, "error": repr(e)[:300]}

@@ -109,19 +109,30 @@ def test_dropin_glue_matches_the_oracle_through_the_same_mocks():
 
 @pytest.mark.gpu
 def test_rig_closed_loop_120_frames_product_and_oracle_each_feeding_on_their_own_outputs():
-    """tests/cpp/rig_loop: 120 frames of a two-fisheye agent through the glue -- ComputeStereoFishEyeMatches, the motion model,
-    SearchByProjection(Cur, Last), PoseOptimization, outliers dropped, SearchLocalPoints, PoseOptimization, mLastFrame, as Tracking::Track
-    does, every eighth frame a keyframe and LocalBundleAdjustment over the last keyframes (write-back, erasures) -- once over liborbgpu, once over the CPU oracle, each run carrying its OWN poses, matches and outlier decisions from frame to
-    frame: stereo partners, both match arrays, both outlier sets and the inlier counts equal on every frame, poses within 1e-4
-    (measured 2e-7 over the first 40 frames), the agent keeps track of the truth (a few millimetres)."""
+    """tests/cpp/rig_loop: 120 frames of a two-fisheye agent through the glue -- ComputeStereoFishEyeMatches, the motion model (frames 10,
+    30, .. : TrackReferenceKeyFrame's SearchByBoW instead), SearchByProjection(Cur, Last), PoseOptimization, outliers dropped,
+    SearchLocalPoints, PoseOptimization, mLastFrame, as Tracking::Track does, every eighth frame a keyframe and LocalBundleAdjustment over
+    the last keyframes (write-back, erasures) -- each run carrying its OWN poses, matches, outlier decisions, keyframes and map points.
+    (1) --shadow: every entry-point call of the product run (~730) repeated on the oracle with identical inputs: every match array, stereo
+    partner array, frustum flag and level, outlier set, local-BA status and iteration count equal; poses 1e-4, local-BA state 5e-2.
+    (2) Independent runs: KannalaBrandt8::project goes through the device's resp. the host libm's float32 atan2 / cos / sin, which differ
+    in the last place (projections: 1e-4 px), so once in a few hundred frames a feature that close to a window's edge makes the runs
+    differ by a match or two (here: frame 118, 2 entries) -- asked for: the runs stay together (at most 8 match entries in any frame,
+    poses and keyframe poses 1e-3, points 5e-2), all local BAs applied, the agent keeps track of the truth."""
     import json
     exe = _build("rig_loop", with_oracle=True)
+    r = subprocess.run([exe, "120", "--shadow"], capture_output=True, text=True, timeout=600)
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and rows, (r.returncode, r.stdout[-2000:], r.stderr[-500:])
+    sh = json.loads(rows[-1])["rig_loop_shadow"]
+    assert sh["ok"] and sh["mismatches"] == 0 and sh["calls"] > 700 and sh["max_projection_diff_px"] <= 3e-4, sh
     r = subprocess.run([exe, "120"], capture_output=True, text=True, timeout=600)
     rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and rows, (r.returncode, r.stdout[-2000:], r.stderr[-500:])
     d = json.loads(rows[-1])["rig_loop"]
-    assert d["ok"] and d["frames"] == 120 and d["first_divergent_frame"] == -1 and d["max_pose_diff"] <= 1e-4 and d["mean_inliers"] > 500, d
-    assert d["max_pose_error_vs_truth"] < 0.05 and d["local_bas"] >= 14 and d["local_bas_applied"] >= 12 and d["max_keyframe_pose_diff"] <= 1e-4 and d["max_point_diff"] <= 5e-2, d
+    assert d["ok"] and d["frames"] == 120 and d["first_divergent_frame"] in (-1,) + tuple(range(40, 120)) and d["max_pose_diff"] <= 1e-3 and d["mean_inliers"] > 500, d
+    assert d["max_pose_error_vs_truth"] < 0.05 and d["local_bas"] >= 14 and d["local_bas_applied"] >= 12 and d["max_keyframe_pose_diff"] <= 1e-3 and d["max_point_diff"] <= 5e-2, d
+    assert d["max_match_entries_differing_in_a_frame"] <= 8, d
 
 
 def test_closed_loop_scenario_tracks_on_the_oracle_alone():
