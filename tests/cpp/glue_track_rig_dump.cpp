@@ -32,11 +32,20 @@ static void dump_ints(const char* name, const std::vector<int>& v) {
 }
 
 int main() {
-  for (int scene = 0; scene < 2; scene++) {
+  for (int scene = 0; scene < 3; scene++) {
     Agent A;
-    RigTrack S = build_rig_track_scene(A, 900u + scene, scene ? 300 : 800, scene ? 60 : 200);
-    Frame& F = *S.cur;
-    const float th = scene ? 5.f : 1.f; const bool far_pts = scene == 1; const float th_far = 6.f;
+    RigTrack S = build_rig_track_scene(A, 900u + scene, scene == 1 ? 300 : 800, scene == 1 ? 60 : 200);
+    Frame mono;                                                   // scene 2: the left camera alone -- a MONOCULAR fisheye Frame (Nleft == -1, mpCamera a KannalaBrandt8)
+    if (scene == 2) {
+      const Frame& C = *S.cur; const int nl = C.Nleft;
+      mono = C; mono.Nleft = -1; mono.Nright = -1; mono.N = nl; mono.mpCamera2 = nullptr;
+      mono.mvKeys.resize(nl); mono.mvKeysUn = mono.mvKeys; mono.mvKeysRight.clear(); mono.mvuRight.assign(nl, -1.f); mono.mvDepth.assign(nl, -1.f);
+      mono.mvpMapPoints.resize(nl); mono.mvbOutlier.resize(nl);
+      Mat d(nl, 32, 1); std::memcpy(d.ptr<uint8_t>(0), C.mDescriptors.ptr<uint8_t>(0), (size_t)nl * 32); mono.mDescriptors = d;
+      mono.mvLeftToRightMatch.assign(nl, -1); mono.mvRightToLeftMatch.clear();
+    }
+    Frame& F = scene == 2 ? mono : *S.cur;
+    const float th = scene == 1 ? 5.f : 1.f; const bool far_pts = scene == 1; const float th_far = 6.f;
     std::printf("{\"scene\": %d, \"frame\": {\"id\": %lu, \"N\": %d, \"Nleft\": %d, \"th\": %.9g, \"far\": %d, \"th_far\": %.9g, \"size\": %.9g, \"mb\": %.9g, ", scene, F.mnId, F.N, F.Nleft, th,
                 (int)far_pts, th_far, F.mnMaxX, F.mb);
     dump_floats("Tcw", F.mTcw.ptr<float>(0), 16); std::printf(", "); dump_floats("Trl", F.mTrl.ptr<float>(0), 12); std::printf(", "); dump_floats("Tlr", F.mTlr.ptr<float>(0), 12);

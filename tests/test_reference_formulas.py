@@ -3306,7 +3306,9 @@ def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
     Frame::isInFrustum, Frame::isInFrustumChecks, KannalaBrandt8::project, MapPoint::PredictScale, Frame::GetFeaturesInArea (both
     ternaries) and ORBmatcher::SearchByProjection transliterated below it, on Python stand-ins of the same scene: which of the
     Nleft + Nright features hold which point afterwards, every point's mnLastFrameSeen, visible count, both cameras' flags, levels and
-    -- where a camera sees the point -- the float32 bits of its track fields.  Two scenes (regular; th = 5 with the far-point filter)."""
+    -- where a camera sees the point -- the float32 bits of its track fields.  Three scenes: regular; th = 5 with the far-point filter; and
+    a MONOCULAR fisheye Frame (Nleft == -1, mpCamera the KannalaBrandt8: the Nleft == -1 branch of Frame::isInFrustum, S/Frame.cc:466-543,
+    through the camera model -- the glue's SearchLocalPointsModelCamera)."""
     import ctypes
     import json
     import subprocess
@@ -3318,7 +3320,7 @@ def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
                            "-o", exe, "-pthread", "-L", lib_dir, "-lorbgpu", "-L", odir, "-loracle", "-Wl,-rpath," + lib_dir, "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
     out = subprocess.check_output([exe], text=True)
     scenes = [json.loads(("{\"scene\"" + part) if not part.startswith("{") else part) for part in out.split("\n{\"scene\"") if part.strip()]
-    assert len(scenes) == 2
+    assert len(scenes) == 3                                   # two-camera, two-camera with th = 5 and the far-point filter, ONE fisheye camera (Nleft == -1)
     # ---- the reference's text
     tr = re.sub(r"\s+", " ", _body(os.path.join(REF, "src", "Tracking.cc"), r"void\s+Tracking::SearchLocalPoints\s*\(\s*\)\s*\{"))
     for a, b in [("for(vector<MapPoint*>::iterator vit=mCurrentFrame.mvpMapPoints.begin(), vend=mCurrentFrame.mvpMapPoints.end(); vit!=vend; vit++) { MapPoint* pMP = *vit;",
@@ -3337,6 +3339,10 @@ def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
     outer = _body(fpath, r"bool\s+Frame::isInFrustum\s*\(\s*MapPoint\s*\*pMP,\s*float viewingCosLimit\s*\)\s*\{")
     outer = outer[outer.rindex("else{") + 5:]
     outer_src = c_to_python(cpp_prepare(re.sub(r"pMP\s*->\s*", "pMP->", outer[:outer.index("}")])), keep_returns=True).replace("||", " or ")
+    fr1 = _body(fpath, r"bool\s+Frame::isInFrustum\s*\(\s*MapPoint\s*\*pMP,\s*float viewingCosLimit\s*\)\s*\{")
+    fr1 = fr1[fr1.index("pMP->mbTrackInView = false;"):fr1.index("else{")]
+    fr1 = fr1[:fr1.rindex("}")].replace(".at<float>(", ".at(").replace("cv::norm(Pc)", "Pc.norm()").replace("cv::norm(PO)", "PO.norm()").replace("PredictScale(dist,this)", "PredictScale(dist,thisF)")
+    mono_src = c_to_python(cpp_prepare(fr1), keep_returns=True)                      # the Nleft == -1 branch (:466-543): scene 2
     mp_path = os.path.join(REF, "src", "MapPoint.cc")
     ps = _body(mp_path, r"int\s+MapPoint::PredictScale\s*\(\s*const float &currentDist,\s*Frame\*\s*pF\s*\)\s*\{")
     ps = re.sub(r"unique_lock<mutex> lock\w*\([^)]*\);", "", ps).replace("float ratio;", "")
@@ -3374,6 +3380,9 @@ def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
 
     for sc in scenes:
         fd = sc["frame"]; N, nl = fd["N"], fd["Nleft"]
+        one = nl == -1                                           # a monocular fisheye Frame
+        if one:
+            nl = N
         desc = np.frombuffer(bytes.fromhex(fd["desc"]), np.uint8).reshape(N, 32)
         size = float(fd["size"])
         grids, keysets = [], []
@@ -3398,7 +3407,10 @@ def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
                     mTlr=MatF(np.array(fd["Tlr"], np.float32).reshape(3, 4)), mpCamera=Cam([capi.CAM_KANNALA_BRANDT8] + fd["cam_left"]),
                     mpCamera2=Cam([capi.CAM_KANNALA_BRANDT8] + fd["cam_right"]), mnMinX=F32(0), mnMaxX=F32(size), mnMinY=F32(0), mnMaxY=F32(size))
         exec("def isInFrustumChecks(pMP, viewingCosLimit, bRight=False):\n" + ind(chk_src) + "\ndef isInFrustum(pMP, viewingCosLimit):\n" + ind(outer_src), fenv)
-        genv = dict(env, Nleft=nl, mnMinX=F32(0), mnMinY=F32(0), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
+        if one:
+            fenv["mbf"] = F32(0)
+            exec("def isInFrustum(pMP, viewingCosLimit):\n" + ind(mono_src) + "\n    return True", fenv)
+        genv = dict(env, Nleft=-1 if one else nl, mnMinX=F32(0), mnMinY=F32(0), FRAME_GRID_COLS=capi.GRID_COLS, FRAME_GRID_ROWS=capi.GRID_ROWS,
                     mfGridElementWidthInv=F32(F32(capi.GRID_COLS) / F32(size)), mfGridElementHeightInv=F32(F32(capi.GRID_ROWS) / F32(size)),
                     mGrid=grids[0], mGridRight=grids[1], mvKeysUn=keysets[0], mvKeys=keysets[0], mvKeysRight=keysets[1])
         exec(_get_features_in_area_source_rig(), genv)
@@ -3417,7 +3429,7 @@ def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
                 setattr(q, nm, F32(0))
             pts[d["id"]] = q
         F = Obj()
-        F.mnId = fd["id"]; F.Nleft = nl; F.mvpMapPoints = [None if j < 0 else pts[j] for j in fd["held_before"]]; F.mmProjectPoints = {}
+        F.mnId = fd["id"]; F.Nleft = -1 if one else nl; F.mvpMapPoints = [None if j < 0 else pts[j] for j in fd["held_before"]]; F.mmProjectPoints = {}
         F.isInFrustum = lambda pMP, lim: fenv["isInFrustum"](pMP, F32(lim))
         F.GetFeaturesInArea = lambda x, y, r, lo=-1, hi=-1, bRight=False: genv["GetFeaturesInArea"](F32(x), F32(y), F32(r), lo, hi, bRight)
         F.mvuRight = [F32(-1)] * N; F.mvScaleFactors = [F32(x) for x in sfs]; F.mvKeys = keysets[0]; F.mvKeysUn = keysets[0]; F.mvKeysRight = keysets[1]
@@ -3447,7 +3459,7 @@ def test_glues_searchlocalpoints_on_a_two_camera_frame_is_trackings_own_text():
                 n_r += 1
                 assert q.mnTrackScaleLevelR == lvl_r and np.array([q.mTrackProjXR, q.mTrackProjYR, q.mTrackDepthR, q.mTrackViewCosR], np.float32).tobytes() == np.array(row[11:15], np.float32).tobytes(), (sc["scene"], pid)
         changed = [i for i, (a, b) in enumerate(zip(fd["held_before"], res["held_after"])) if a != b]
-        assert sum(1 for i in changed if i < nl) > 50 and sum(1 for i in changed if i >= nl) > 50 and n_l > 100 and n_r > 100
+        assert sum(1 for i in changed if i < nl) > 50 and n_l > 100 and (one or (sum(1 for i in changed if i >= nl) > 50 and n_r > 100))
 
 
 def _fisheye_text_programs():
