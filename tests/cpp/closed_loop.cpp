@@ -65,6 +65,7 @@ struct LoopTap : Base {          // + the solver's report of the last local BA
 };
 // The product's entry points, every call repeated on the oracle with the same inputs and compared on the spot (check (1) above).
 // The frame's host-side view (the product works on the device-resident copy) is set by the agent before it calls the glue.
+static int& bow_frames() { static int n = 0; return n; }      // frames tracked through TrackReferenceKeyFrame's SearchByBoW (all runs of the process)
 struct Shadow {
   static const orbm_frame_view*& view() { static const orbm_frame_view* v = nullptr; return v; }
   static long& calls() { static long n = 0; return n; }
@@ -83,6 +84,16 @@ struct GpuShadowBase : od::GpuOps {
     oracle_search_by_projection_frame(Shadow::view(), Tcw, &last, th, mono, check_ori, amp2.data(), aob2.data(), &n2);
     Shadow::calls()++;
     if (n2 != *n || std::memcmp(amp, amp2.data(), 4 * (size_t)N) || std::memcmp(aob, aob2.data(), 4 * (size_t)N)) Shadow::fail("SearchByProjection(Cur, Last)", "match arrays differ");
+    return rc;
+  }
+  static int search_bow(const od::FrameKey& key, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf, const uint8_t* kf_valid,
+                        const float* kf_angle, const orbm_featvec_view& fvKF, float nnratio, int check_ori, int32_t* matches, int* n) {
+    const int N = Shadow::view()->n;
+    const int rc = od::GpuOps::search_bow(key, v, fvF, kf_desc, nkf, kf_valid, kf_angle, fvKF, nnratio, check_ori, matches, n);
+    std::vector<int32_t> m2(N); int n2 = 0;
+    oracle_search_by_bow(Shadow::view(), &fvF, kf_desc, nkf, kf_valid, kf_angle, &fvKF, nnratio, check_ori, m2.data(), &n2);
+    Shadow::calls()++;
+    if (n2 != *n || std::memcmp(matches, m2.data(), 4 * (size_t)N)) Shadow::fail("SearchByBoW(KF, F)", "matches differ");
     return rc;
   }
   static int search_local_resident(const od::FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& pts, const uint8_t* excluded,
@@ -395,6 +406,7 @@ struct Tracker {
     if (N) std::memcpy(F->mDescriptors.ptr<uint8_t>(0), f.desc.data(), (size_t)N * 32);
     F->mvpMapPoints.assign(N, nullptr); F->mvbOutlier.assign(N, false);
     F->mvInvLevelSigma2 = inv_sigma2;
+    for (int i = 0; i < N; i++) F->mFeatVec[f.desc[(size_t)32 * i] >> 5].push_back((unsigned)i);      // ComputeBoW over a stand-in vocabulary (eight words: the leading bits)
     d.N = N;
     d.h_feat = fnv(f.keys.data(), f.keys.size() * sizeof(orbx_keypoint));
     d.h_feat = fnv(f.desc.data(), f.desc.size(), d.h_feat); d.h_feat = fnv(f.ur.data(), f.ur.size() * 4, d.h_feat); d.h_feat = fnv(f.dp.data(), f.dp.size() * 4, d.h_feat);
@@ -464,7 +476,7 @@ struct Tracker {
     std::unique_ptr<LKeyFrame> kf(new LKeyFrame);
     kf->mnId = kfs.size(); kf->fx = FX; kf->fy = FX; kf->cx = CX; kf->cy = CY; kf->mbf = BF; kf->mpMap = &map;
     kf->mvKeysUn = F.mvKeysUn; kf->mvuRight = F.mvuRight; kf->mvDepth = F.mvDepth; kf->mvInvLevelSigma2 = F.mvInvLevelSigma2; kf->mDescriptors = F.mDescriptors;
-    kf->mvpMapPoints = F.mvpMapPoints; kf->Tcw = F.mTcw;
+    kf->mvpMapPoints = F.mvpMapPoints; kf->Tcw = F.mTcw; kf->mFeatVec = F.mFeatVec;
     LKeyFrame* out = kf.get();
     g_kf_by_id[out->mnId] = out;
     kfs.push_back(std::move(kf));
@@ -647,8 +659,17 @@ struct Tracker {
     // ---- TrackWithMotionModel (S/Tracking.cc:2572-2686)
     float Tpred[16]; mul44(vel, last->mTcw.ptr<float>(0), Tpred);
     F.mTcw = mat44f(Tpred);
+    bool by_bow = false;
+    if (k % 25 == 12 && !kfs.empty()) {
+      // ---- TrackReferenceKeyFrame (S/Tracking.cc:2860-2926): SearchByBoW against the reference keyframe, the last pose as the guess
+      std::vector<MapPoint*> vm;
+      const int nb = od::SearchByBoW<Ops>(static_cast<KeyFrame*>(kfs.back().get()), F, vm, 0.7f, true);
+      if (nb >= 15) { F.mvpMapPoints = vm; F.mTcw = last->mTcw; d.n_frame = nb; by_bow = true; bow_frames()++; }
+    }
+    if (!by_bow) {
     d.n_frame = od::SearchByProjection<Ops>(F, *last, 7.0f, false, true);
     if (d.n_frame < 20) { std::fill(F.mvpMapPoints.begin(), F.mvpMapPoints.end(), nullptr); d.n_frame = od::SearchByProjection<Ops>(F, *last, 14.0f, false, true); }
+    }
     d.h_assign1 = hash_assign(F);
     if (d.n_frame < 20) { lost = true; return; }
     d.n_inl1 = od::PoseOptimization<Ops>(&F);
@@ -767,7 +788,7 @@ int main(int argc, char** argv) {
     int n_kf = 0, n_lba = 0, max_it = 0; long matched = 0;
     for (auto& d : c) { n_kf += d.is_kf; n_lba += d.lba_status == LBA_APPLIED; max_it = std::max(max_it, d.it1 + d.it2); matched += d.n_tracked; }
     if ((int)c.size() != n_frames) { std::printf("the oracle run lost track: the scenario is broken\n"); return 1; }
-    if (oracle_only) { std::printf("oracle-only run: %d keyframes, %d applied local BAs, %.1f tracked points a frame, %.1f s\n", n_kf, n_lba, (double)matched / n_frames, tc); return 0; }
+    if (oracle_only) { std::printf("oracle-only run: %d keyframes, %d applied local BAs, %.1f tracked points a frame, %d frames through SearchByBoW, %.1f s\n", n_kf, n_lba, (double)matched / n_frames, bow_frames(), tc); return 0; }
     const std::vector<Digest> g = run<GpuLoopOps, GpuFront>(seq, n_frames, kf_every, "product entry points (change-counter caches)", &tg);
     float wp = 0, ws = 0, wp2 = 0, ws2 = 0;
     const int d1 = compare(g, c, "product vs oracle", &wp, &ws);
@@ -784,8 +805,8 @@ int main(int argc, char** argv) {
     const bool ok = d1 < 0 && d2 < 0 && Shadow::fails() == 0;
     std::printf("{\"closed_loop\": {\"frames\": %d, \"keyframes\": %d, \"local_bas_applied\": %d, \"shadow_calls\": %ld, \"shadow_mismatches\": %ld, \"shadow_max_pose_abs_diff\": %.3g, "
                 "\"shadow_max_lba_abs_diff\": %.3g, \"first_divergent_frame\": %d, \"first_divergent_frame_no_caches\": %d, \"bit_identical_leading_frames\": %d, "
-                "\"max_pose_abs_diff\": %.3g, \"max_map_state_abs_diff\": %.3g, \"ok\": %s}}\n", n_frames, n_kf, n_lba, Shadow::calls(), Shadow::fails(), Shadow::worst_pose(), Shadow::worst_lba(),
-                d1, d2, bit_equal, std::max(wp, wp2), std::max(ws, ws2), ok ? "true" : "false");
+                "\"max_pose_abs_diff\": %.3g, \"max_map_state_abs_diff\": %.3g, \"frames_through_search_by_bow_per_run\": %d, \"ok\": %s}}\n", n_frames, n_kf, n_lba, Shadow::calls(), Shadow::fails(), Shadow::worst_pose(), Shadow::worst_lba(),
+                d1, d2, bit_equal, std::max(wp, wp2), std::max(ws, ws2), bow_frames() / 3, ok ? "true" : "false");
     if (!ok) return 1;
     std::printf("closed loop ok\n");
     return 0;
