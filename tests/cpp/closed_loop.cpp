@@ -65,6 +65,7 @@ struct LoopTap : Base {          // + the solver's report of the last local BA
 };
 // The product's entry points, every call repeated on the oracle with the same inputs and compared on the spot (check (1) above).
 // The frame's host-side view (the product works on the device-resident copy) is set by the agent before it calls the glue.
+static int& reloc_frames() { static int n = 0; return n; }    // frames that went through Relocalization's guided search
 static int& bow_frames() { static int n = 0; return n; }      // frames tracked through TrackReferenceKeyFrame's SearchByBoW (all runs of the process)
 struct Shadow {
   static const orbm_frame_view*& view() { static const orbm_frame_view* v = nullptr; return v; }
@@ -84,6 +85,16 @@ struct GpuShadowBase : od::GpuOps {
     oracle_search_by_projection_frame(Shadow::view(), Tcw, &last, th, mono, check_ori, amp2.data(), aob2.data(), &n2);
     Shadow::calls()++;
     if (n2 != *n || std::memcmp(amp, amp2.data(), 4 * (size_t)N) || std::memcmp(aob, aob2.data(), 4 * (size_t)N)) Shadow::fail("SearchByProjection(Cur, Last)", "match arrays differ");
+    return rc;
+  }
+  static int search_reloc(const od::FrameKey& key, const orbm_frame_view& v, const float* Tcw, const orbm_worldpoints_view& kf_pts, const uint8_t* found,
+                          const float* kf_angle, float th, int orb_dist, int check_ori, int32_t* amp, int* n) {
+    const int N = Shadow::view()->n;
+    std::vector<int32_t> amp2(amp, amp + N); int n2 = 0;
+    const int rc = od::GpuOps::search_reloc(key, v, Tcw, kf_pts, found, kf_angle, th, orb_dist, check_ori, amp, n);
+    oracle_search_by_projection_reloc(Shadow::view(), Tcw, &kf_pts, found, kf_angle, th, orb_dist, check_ori, amp2.data(), &n2);
+    Shadow::calls()++;
+    if (n2 != *n || std::memcmp(amp, amp2.data(), 4 * (size_t)N)) Shadow::fail("SearchByProjection(F, KF, sAlreadyFound)", "match arrays differ");
     return rc;
   }
   static int search_bow(const od::FrameKey& key, const orbm_frame_view& v, const orbm_featvec_view& fvF, const uint8_t* kf_desc, int nkf, const uint8_t* kf_valid,
@@ -363,6 +374,7 @@ struct Digest {
   int n_local_kfs = 0, n_local_pts = 0; uint64_t h_local = 0;
   int n_local = 0; uint64_t h_assign2 = 0; int n_inl2 = 0; uint64_t h_outl2 = 0; float pose2[16] = {0};
   int n_tracked = 0;
+  int n_reloc = -1; uint64_t h_reloc = 0;                          // (frames 31, 81, ..) what Relocalization's refinement leaves on a copy of the frame
   int is_kf = 0, n_new = 0, n_culled = 0, n_fused = 0, lba_status = -1, it1 = 0, it2 = 0, n_fixed = 0, n_bad_total = 0, n_kf_matches = 0; uint64_t h_obs = 0;
   std::vector<float> state;                                      // after the local BA: every good point's position / normal / range (8 values), then every keyframe's pose
   size_t n_point_values = 0;
@@ -666,6 +678,45 @@ struct Tracker {
       const int nb = od::SearchByBoW<Ops>(static_cast<KeyFrame*>(kfs.back().get()), F, vm, 0.7f, true);
       if (nb >= 15) { F.mvpMapPoints = vm; F.mTcw = last->mTcw; d.n_frame = nb; by_bow = true; bow_frames()++; }
     }
+    if (k % 50 == 31 && !kfs.empty()) {
+      // ---- Tracking::Relocalization's refinement (S/Tracking.cc:3385-3500) against the last keyframe as the one candidate, on a COPY of
+      // the frame (the agent itself goes on with the motion model: a relocalisation that changes its state makes the independent runs part
+      // at the first correspondence whose chi2 sits on PoseOptimization's threshold -- tried: frame 91 of 200): SearchByBoW (0.75), the PnP
+      // solver's answer stood in for by the last pose and by "the first 40 matches are its inliers" (the solver is not on the path),
+      // PoseOptimization, outliers dropped, and -- fewer than 50 inliers -- SearchByProjection(F, pKF, sFound, 10, 100), PoseOptimization,
+      // and between 30 and 50 once more with (3, 64)
+      Frame R(F);
+      KeyFrame* pKF = static_cast<KeyFrame*>(kfs.back().get());
+      std::vector<MapPoint*> vm;
+      const int nb = od::SearchByBoW<Ops>(pKF, R, vm, 0.75f, true);
+      d.n_reloc = 0;
+      if (nb >= 15) {
+        R.mTcw = last->mTcw;
+        std::set<MapPoint*> sFound;
+        int taken = 0;
+        for (int j = 0; j < R.N; j++) {
+          if (vm[j] && taken < 40) { R.mvpMapPoints[j] = vm[j]; sFound.insert(vm[j]); taken++; } else R.mvpMapPoints[j] = nullptr;
+        }
+        int nGood = od::PoseOptimization<Ops>(&R);
+        if (nGood >= 10) {
+          for (int io = 0; io < R.N; io++) if (R.mvbOutlier[io]) R.mvpMapPoints[io] = nullptr;
+          if (nGood < 50) {
+            int nadditional = od::SearchByProjection<Ops>(R, pKF, sFound, 10.f, 100, true);
+            if (nadditional + nGood >= 50) {
+              nGood = od::PoseOptimization<Ops>(&R);
+              if (nGood > 30 && nGood < 50) {
+                sFound.clear();
+                for (int ip = 0; ip < R.N; ip++) if (R.mvpMapPoints[ip]) sFound.insert(R.mvpMapPoints[ip]);
+                nadditional = od::SearchByProjection<Ops>(R, pKF, sFound, 3.f, 64, true);
+                if (nGood + nadditional >= 50) { nGood = od::PoseOptimization<Ops>(&R); for (int io = 0; io < R.N; io++) if (R.mvbOutlier[io]) R.mvpMapPoints[io] = nullptr; }
+              }
+            }
+          }
+          d.n_reloc = nGood; d.h_reloc = hash_assign(R);
+          reloc_frames()++;
+        }
+      }
+    }
     if (!by_bow) {
     d.n_frame = od::SearchByProjection<Ops>(F, *last, 7.0f, false, true);
     if (d.n_frame < 20) { std::fill(F.mvpMapPoints.begin(), F.mvpMapPoints.end(), nullptr); d.n_frame = od::SearchByProjection<Ops>(F, *last, 14.0f, false, true); }
@@ -745,7 +796,7 @@ static int compare(const std::vector<Digest>& g, const std::vector<Digest>& c, c
 #define FIELD(f) if (a.f != b.f) { std::printf("DIVERGED [%s] at frame %zu: %s %lld vs %lld\n", what, k, #f, (long long)a.f, (long long)b.f); return (int)k; }
     FIELD(N) FIELD(h_feat) FIELD(n_frame) FIELD(h_assign1) FIELD(n_inl1) FIELD(h_outl1)
     if (p1 > kPoseTol) { std::printf("DIVERGED [%s] at frame %zu: pose after the first PoseOptimization differs by %g\n", what, k, p1); return (int)k; }
-    FIELD(n_local_kfs) FIELD(n_local_pts) FIELD(h_local) FIELD(n_local) FIELD(h_assign2) FIELD(n_inl2) FIELD(h_outl2)
+    FIELD(n_local_kfs) FIELD(n_local_pts) FIELD(h_local) FIELD(n_local) FIELD(h_assign2) FIELD(n_inl2) FIELD(h_outl2) FIELD(n_reloc) FIELD(h_reloc)
     if (p2 > kPoseTol) { std::printf("DIVERGED [%s] at frame %zu: pose after the second PoseOptimization differs by %g\n", what, k, p2); return (int)k; }
     if (std::getenv("CLOSED_LOOP_VERBOSE") && (p1 > 1e-7f || p2 > 1e-7f)) std::printf("   [%s] frame %zu: pose differences %.3g / %.3g\n", what, k, p1, p2);
     FIELD(n_tracked) FIELD(is_kf) FIELD(n_new) FIELD(n_culled) FIELD(n_fused) FIELD(lba_status) FIELD(it1) FIELD(it2) FIELD(n_fixed) FIELD(n_bad_total) FIELD(n_kf_matches) FIELD(h_obs)
@@ -788,7 +839,7 @@ int main(int argc, char** argv) {
     int n_kf = 0, n_lba = 0, max_it = 0; long matched = 0;
     for (auto& d : c) { n_kf += d.is_kf; n_lba += d.lba_status == LBA_APPLIED; max_it = std::max(max_it, d.it1 + d.it2); matched += d.n_tracked; }
     if ((int)c.size() != n_frames) { std::printf("the oracle run lost track: the scenario is broken\n"); return 1; }
-    if (oracle_only) { std::printf("oracle-only run: %d keyframes, %d applied local BAs, %.1f tracked points a frame, %d frames through SearchByBoW, %.1f s\n", n_kf, n_lba, (double)matched / n_frames, bow_frames(), tc); return 0; }
+    if (oracle_only) { std::printf("oracle-only run: %d keyframes, %d applied local BAs, %.1f tracked points a frame, %d frames through SearchByBoW, %d through the relocalisation search, %.1f s\n", n_kf, n_lba, (double)matched / n_frames, bow_frames(), reloc_frames(), tc); return 0; }
     const std::vector<Digest> g = run<GpuLoopOps, GpuFront>(seq, n_frames, kf_every, "product entry points (change-counter caches)", &tg);
     float wp = 0, ws = 0, wp2 = 0, ws2 = 0;
     const int d1 = compare(g, c, "product vs oracle", &wp, &ws);
@@ -805,8 +856,8 @@ int main(int argc, char** argv) {
     const bool ok = d1 < 0 && d2 < 0 && Shadow::fails() == 0;
     std::printf("{\"closed_loop\": {\"frames\": %d, \"keyframes\": %d, \"local_bas_applied\": %d, \"shadow_calls\": %ld, \"shadow_mismatches\": %ld, \"shadow_max_pose_abs_diff\": %.3g, "
                 "\"shadow_max_lba_abs_diff\": %.3g, \"first_divergent_frame\": %d, \"first_divergent_frame_no_caches\": %d, \"bit_identical_leading_frames\": %d, "
-                "\"max_pose_abs_diff\": %.3g, \"max_map_state_abs_diff\": %.3g, \"frames_through_search_by_bow_per_run\": %d, \"ok\": %s}}\n", n_frames, n_kf, n_lba, Shadow::calls(), Shadow::fails(), Shadow::worst_pose(), Shadow::worst_lba(),
-                d1, d2, bit_equal, std::max(wp, wp2), std::max(ws, ws2), bow_frames() / 3, ok ? "true" : "false");
+                "\"max_pose_abs_diff\": %.3g, \"max_map_state_abs_diff\": %.3g, \"frames_through_search_by_bow_per_run\": %d, \"frames_through_the_relocalisation_search_per_run\": %d, \"ok\": %s}}\n", n_frames, n_kf, n_lba, Shadow::calls(), Shadow::fails(), Shadow::worst_pose(), Shadow::worst_lba(),
+                d1, d2, bit_equal, std::max(wp, wp2), std::max(ws, ws2), bow_frames() / 3, reloc_frames() / 3, ok ? "true" : "false");
     if (!ok) return 1;
     std::printf("closed loop ok\n");
     return 0;
