@@ -92,6 +92,29 @@ def make_matching_pose_bow(sc):
     print("local", loc[2], "sim3", sim[1], "bow_kf", bow[1], "pose_opt", po.iters, po.n_inliers, "words", len(bw))
 
 
+def make_rig_and_fisheye():
+    """Two-camera frames (Frame::Nleft != -1) and the fisheye constructor's stereo matcher: the scene's INPUTS and the oracle's outputs."""
+    sc = synth.make_rig_track_scene(n_points=350, n_distract=60, seed=0x601D)
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    mv, mvr, keep2 = helpers.rig_mappoint_views(sc, a, b)
+    srch = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], 3.0, True, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"])
+    last = synth.rig_last_frame(sc, n_last=300, seed=3, motion=(0.03, 0.01, 0.02))
+    lv, keep3 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+    frm = ob.search_by_projection_frame_rig(fl, fr, sc["Tcw"], rig, lv, 7.0, 0, 1, sc["assigned_mp"], sc["assigned_obs"])
+    fs = synth.make_fisheye_stereo_scene(n_stereo=220, n_mono_left=60, n_mono_right=50, n_distract=40, seed=0x601E)
+    v, keep4 = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"], fs["right"],
+                                         fs["Tlr"], fs["level_sigma2"])
+    st = ob.fisheye_stereo_matches(v)
+    scene = {"sc_" + k: np.asarray(val) for k, val in sc.items() if k not in ("left", "right", "size")}
+    scene.update({"last_" + k: np.asarray(val) for k, val in last.items()})
+    scene.update({"fs_" + k: np.asarray(val) for k, val in fs.items() if k not in ("left", "right")})
+    np.savez_compressed(os.path.join(OUT, "rig_and_fisheye.npz"), cam_left=np.float64(sc["left"]), cam_right=np.float64(sc["right"]), size=np.float64([sc["size"]]),
+                        **scene, **{"fl_" + k: a[k] for k in ob.RIG_TRACK_KEYS}, **{"fr_" + k: b[k] for k in ob.RIG_TRACK_KEYS},
+                        srch_amp=srch[0], srch_aob=srch[1], srch_n=np.int32([srch[2]]), frm_amp=frm[0], frm_aob=frm[1], frm_n=np.int32([frm[2]]),
+                        st_l2r=st[0], st_r2l=st[1], st_depth=st[2], st_p3d=st[3], st_n=np.int32([st[4]]))
+
+
 def make_appendix_f():
     """SURVEY.md Appendix F's larger fixtures: the 96x72 and 640x480 extractions (per-level candidates, kept keypoints, angles,
     descriptors, the constructor's tables) and the C2-sized local BA (20 free + 10 fixed keyframes, 2000 points) with its
@@ -130,6 +153,9 @@ def make_appendix_f():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "appendix_f":
         make_appendix_f()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rig":
+        make_rig_and_fisheye()
     else:
         main()
         make_appendix_f()
+        make_rig_and_fisheye()

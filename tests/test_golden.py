@@ -7,6 +7,7 @@ import pytest
 
 from multi_orbslam3_amd import synth, views
 from oracle import binding as ob
+import helpers
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -210,3 +211,66 @@ def test_gpu_extractor_tables_equal_the_oracles_and_the_fixture():
                 assert np.array_equal(a, g[key]), key
         assert int(got[4].sum()) == nf
         assert np.array_equal(ex.GetScaleFactors(), got[0]) and np.array_equal(ex.GetInverseScaleSigmaSquares(), got[3])
+
+
+def _rig_fixture():
+    g = _load("rig_and_fisheye.npz")
+    sc = {k[3:]: g[k] for k in g.files if k.startswith("sc_")}
+    sc["left"], sc["right"], sc["size"] = tuple([int(g["cam_left"][0])] + [float(x) for x in g["cam_left"][1:]]), tuple([int(g["cam_right"][0])] + [float(x) for x in g["cam_right"][1:]]), float(g["size"][0])
+    last = {k[5:]: g[k] for k in g.files if k.startswith("last_")}
+    fs = {k[3:]: g[k] for k in g.files if k.startswith("fs_")}
+    fs["left"], fs["right"], fs["mono_left"], fs["mono_right"] = sc["left"], sc["right"], int(fs["mono_left"]), int(fs["mono_right"])
+    return g, sc, last, fs
+
+
+def _rig_fixture_checks(g, frustum, search, frame_search, stereo, exact_projections):
+    a, b = frustum
+    for side, d in (("fl_", a), ("fr_", b)):
+        for k in ("track_in_view", "scale_level"):
+            assert np.array_equal(d[k], g[side + k]), (side, k)
+        for k in ("proj_x", "proj_y", "track_depth", "view_cos"):
+            if exact_projections or k in ("track_depth", "view_cos"):
+                assert np.array_equal(d[k].view(np.uint32), g[side + k].view(np.uint32)), (side, k)
+            else:
+                assert np.abs(d[k].astype(np.float64) - g[side + k]).max() <= 3e-4, (side, k)
+    assert search[2] == int(g["srch_n"][0]) and np.array_equal(search[0], g["srch_amp"]) and np.array_equal(search[1], g["srch_aob"])
+    assert frame_search[2] == int(g["frm_n"][0]) and np.array_equal(frame_search[0], g["frm_amp"]) and np.array_equal(frame_search[1], g["frm_aob"])
+    assert stereo[4] == int(g["st_n"][0]) and np.array_equal(stereo[0], g["st_l2r"]) and np.array_equal(stereo[1], g["st_r2l"])
+    hit = g["st_l2r"] >= 0
+    assert np.allclose(stereo[2][hit], g["st_depth"][hit], rtol=1e-5) and np.allclose(stereo[3][hit], g["st_p3d"][hit], rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_reproduces_golden_rig_and_fisheye():
+    """tests/golden/rig_and_fisheye.npz: a two-camera frame with its local map and last frame, and the two feature sets of a fisheye
+    constructor -- the oracle's isInFrustum (both cameras), SearchByProjection(F, MPs), SearchByProjection(Cur, Last) and
+    ComputeStereoFishEyeMatches outputs as they were when the fixture was made."""
+    g, sc, last, fs = _rig_fixture()
+    assert int(g["srch_n"][0]) > 100 and int(g["frm_n"][0]) > 60 and int(g["st_n"][0]) > 40
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    a, b = ob.is_in_frustum_rig(fl, sc["Tcw"], rig, sc["Tlr"], wv)
+    mv, mvr, keep2 = helpers.rig_mappoint_views(sc, a, b)
+    srch = ob.search_by_projection_mps_rig(fl, fr, mv, mvr, sc["left_to_right"], sc["right_to_left"], 3.0, True, 6.0, 0.8, sc["assigned_mp"], sc["assigned_obs"])
+    lv, keep3 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+    frm = ob.search_by_projection_frame_rig(fl, fr, sc["Tcw"], rig, lv, 7.0, 0, 1, sc["assigned_mp"], sc["assigned_obs"])
+    v, keep4 = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"], fs["right"],
+                                         fs["Tlr"], fs["level_sigma2"])
+    _rig_fixture_checks(g, (a, b), srch, frm, ob.fisheye_stereo_matches(v), exact_projections=True)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_rig_and_fisheye():
+    """The HIP path against the committed fixture (not against a fresh oracle run): the track fields of the fixture go into the searches."""
+    from multi_orbslam3_amd import api
+    g, sc, last, fs = _rig_fixture()
+    fl, fr, wv, rig, keep = helpers.rig_track_views(sc)
+    FL, FR = api.Frame().upload(fl, keep[0]), api.Frame().upload(fr, keep[1])
+    frustum = FL.isInFrustumRig(sc["Tcw"], rig, sc["Tlr"], wv)
+    fix = [{k: g[side + k] for k in ob.RIG_TRACK_KEYS} for side in ("fl_", "fr_")]
+    mv, mvr, keep2 = helpers.rig_mappoint_views(sc, fix[0], fix[1])
+    m = api.ORBmatcher(0.8, True)
+    srch = m.SearchByProjectionRig(FL, FR, mv, mvr, sc["left_to_right"], sc["right_to_left"], 3.0, True, 6.0, sc["assigned_mp"], sc["assigned_obs"])
+    lv, keep3 = views.lastframe_view(last["mp_valid"], last["outlier"], last["world_pos"], last["desc"], last["octave"], last["angle"], last["n_obs"], last["Tcw"])
+    frm = m.SearchByProjectionFrameRig(FL, FR, sc["Tcw"], rig, lv, 7.0, False, sc["assigned_mp"], sc["assigned_obs"])
+    v, keep4 = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"], fs["right"],
+                                         fs["Tlr"], fs["level_sigma2"])
+    _rig_fixture_checks(g, frustum, srch, frm, api.ComputeStereoFishEyeMatches(v), exact_projections=False)
