@@ -106,13 +106,24 @@ def make_rig_and_fisheye():
     v, keep4 = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"], fs["right"],
                                          fs["Tlr"], fs["level_sigma2"])
     st = ob.fisheye_stereo_matches(v)
+    # the two optimisers on a rig: KannalaBrandt8 models, the right camera's ToBody edges (S/Optimizer.cc:1085-1151, 2021-2120)
+    pr = synth.make_lba_rig_problem(n_free=4, n_fixed=2, n_points=90, seed=0x601F)
+    p, keepp = views.lba_problem(pr["poses"], pr["pose_fixed"], pr["points"], pr["edges"], pr["cam"], rig=views.camera_rig(*pr["rig"]))
+    lo = ob.lba_solve(p)
+    po = synth.make_pose_opt_rig_problem(n_left=120, n_right=80, seed=0x6020)
+    q, keepq = views.pose_opt_problem(po["Xw"], po["u"], po["v"], po["ur"], po["inv_sigma2"], po["cam"], po["Tcw"], rig=views.camera_rig(*po["rig"]))
+    oo = ob.pose_optimize(q)
+    opt = dict(lba_poses=pr["poses"], lba_pose_fixed=pr["pose_fixed"], lba_points=pr["points"], lba_edges=pr["edges"], lba_cam=np.float32(pr["cam"]), lba_Trl=np.float32(pr["rig"][2]),
+               lba_out_poses=lo.poses, lba_out_points=lo.points, lba_out_outlier=lo.edge_outlier, lba_iters=np.array(lo.iters), lba_status=np.array([lo.status]),
+               po_Xw=po["Xw"], po_u=po["u"], po_v=po["v"], po_ur=po["ur"], po_w=po["inv_sigma2"], po_cam=np.float32(po["cam"]), po_Tcw=po["Tcw"],
+               po_out_T=oo.Tcw, po_out_outliers=oo.outliers, po_out_inliers=np.array([oo.n_inliers]), po_out_iters=np.array(oo.iters))
     scene = {"sc_" + k: np.asarray(val) for k, val in sc.items() if k not in ("left", "right", "size")}
     scene.update({"last_" + k: np.asarray(val) for k, val in last.items()})
     scene.update({"fs_" + k: np.asarray(val) for k, val in fs.items() if k not in ("left", "right")})
     np.savez_compressed(os.path.join(OUT, "rig_and_fisheye.npz"), cam_left=np.float64(sc["left"]), cam_right=np.float64(sc["right"]), size=np.float64([sc["size"]]),
                         **scene, **{"fl_" + k: a[k] for k in ob.RIG_TRACK_KEYS}, **{"fr_" + k: b[k] for k in ob.RIG_TRACK_KEYS},
                         srch_amp=srch[0], srch_aob=srch[1], srch_n=np.int32([srch[2]]), frm_amp=frm[0], frm_aob=frm[1], frm_n=np.int32([frm[2]]),
-                        st_l2r=st[0], st_r2l=st[1], st_depth=st[2], st_p3d=st[3], st_n=np.int32([st[4]]))
+                        st_l2r=st[0], st_r2l=st[1], st_depth=st[2], st_p3d=st[3], st_n=np.int32([st[4]]), **opt)
 
 
 def make_appendix_f():

@@ -240,6 +240,20 @@ def _rig_fixture_checks(g, frustum, search, frame_search, stereo, exact_projecti
     assert np.allclose(stereo[2][hit], g["st_depth"][hit], rtol=1e-5) and np.allclose(stereo[3][hit], g["st_p3d"][hit], rtol=1e-5, atol=1e-6)
 
 
+def _rig_optimiser_problems(g):
+    rig = views.camera_rig(tuple([int(g["cam_left"][0])] + [float(x) for x in g["cam_left"][1:]]), tuple([int(g["cam_right"][0])] + [float(x) for x in g["cam_right"][1:]]), g["lba_Trl"])
+    p, keep = views.lba_problem(g["lba_poses"], g["lba_pose_fixed"], g["lba_points"], g["lba_edges"], tuple(g["lba_cam"]), rig=rig)
+    q, keep2 = views.pose_opt_problem(g["po_Xw"], g["po_u"], g["po_v"], g["po_ur"], g["po_w"], tuple(g["po_cam"]), g["po_Tcw"], rig=rig)
+    return p, q, [keep, keep2, rig]
+
+
+def _rig_optimiser_checks(g, lo, po, tol):
+    assert lo.status == int(g["lba_status"][0]) and tuple(lo.iters) == tuple(g["lba_iters"]) and int((g["lba_edges"]["ur"] <= -1.5).sum()) > 100
+    assert np.allclose(lo.poses, g["lba_out_poses"], atol=tol) and np.allclose(lo.points, g["lba_out_points"], atol=tol)
+    assert int((lo.edge_outlier != g["lba_out_outlier"]).sum()) <= (0 if tol < 1e-5 else 1)
+    assert po.n_inliers == int(g["po_out_inliers"][0]) and np.array_equal(po.outliers, g["po_out_outliers"]) and np.allclose(po.Tcw, g["po_out_T"], atol=max(tol / 10, 1e-6))
+
+
 def test_oracle_reproduces_golden_rig_and_fisheye():
     """tests/golden/rig_and_fisheye.npz: a two-camera frame with its local map and last frame, and the two feature sets of a fisheye
     constructor -- the oracle's isInFrustum (both cameras), SearchByProjection(F, MPs), SearchByProjection(Cur, Last) and
@@ -255,6 +269,8 @@ def test_oracle_reproduces_golden_rig_and_fisheye():
     v, keep4 = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"], fs["right"],
                                          fs["Tlr"], fs["level_sigma2"])
     _rig_fixture_checks(g, (a, b), srch, frm, ob.fisheye_stereo_matches(v), exact_projections=True)
+    p, q, keep5 = _rig_optimiser_problems(g)
+    _rig_optimiser_checks(g, ob.lba_solve(p), ob.pose_optimize(q), 1e-6)
 
 
 @pytest.mark.gpu
@@ -274,3 +290,6 @@ def test_gpu_reproduces_golden_rig_and_fisheye():
     v, keep4 = views.fisheye_stereo_view(fs["kps_left"], fs["desc_left"], fs["mono_left"], fs["kps_right"], fs["desc_right"], fs["mono_right"], fs["left"], fs["right"],
                                          fs["Tlr"], fs["level_sigma2"])
     _rig_fixture_checks(g, frustum, srch, frm, api.ComputeStereoFishEyeMatches(v), exact_projections=False)
+    p, q, keep5 = _rig_optimiser_problems(g)
+    opt = api.Optimizer()
+    _rig_optimiser_checks(g, opt.LocalBundleAdjustment(p), opt.PoseOptimization(q), 1e-4)
