@@ -56,6 +56,7 @@ python3 tools/vocab_time.py 200 > "$OUT/vocab_full_size.txt" 2>&1 || true
 python3 tools/rig_time.py > "$OUT/rig_time.txt" 2>&1 || true
 python3 tools/rig_match_time.py > "$OUT/rig_match_time.txt" 2>&1 || true
 tests/cpp/closed_loop 200 5 > "$OUT/closed_loop.txt" 2>&1 || true
+{ tests/cpp/rig_loop 120 --shadow; tests/cpp/rig_loop 120; } > "$OUT/rig_loop.txt" 2>&1 || true
 bash tools/bench_driver_repeat.sh 5 > "$OUT/bench_driver_repeat.txt" 2>&1 || true
 f=$(find "$OUT/pmc_fetch" -name "*counter_collection.csv" | head -1); w=$(find "$OUT/pmc_write" -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 profiles/pmc_aggregate.py FETCH_SIZE="$f" WRITE_SIZE="$w" > "$OUT/pmc_fetch_write_per_kernel.json" || true; fi
