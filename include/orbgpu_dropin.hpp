@@ -499,8 +499,7 @@ int SearchLocalPointsModelCamera(FrameT& F, const orbg_camera_rig& rig, const st
   }
   if (cand.empty()) return 0;
   const int M = (int)cand.size();
-  FrameFlat ff; flatten_frame<Ops>(F, ff);
-  ff.key.resident = nullptr;
+  FrameFlat ff; flatten_frame<Ops>(F, ff);                     // (a device-resident frame serves as it is: only its bounds, scale table and features are read)
   std::vector<float> pos(3 * (size_t)M), nrm(3 * (size_t)M), dmin(M), dmax(M); std::vector<uint8_t> bad(M, 0); std::vector<int32_t> nobs(M);
   for (int i = 0; i < M; i++) {
     MapPointT* p = cand[i];
@@ -769,7 +768,6 @@ int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const floa
   const bool kModel = !kRig && has_rig_matcher<Ops>::value && make_rig(&CurrentFrame, rig1);          // a monocular Frame whose camera is a model
   if (kModel) {
     if constexpr (has_rig_matcher<Ops>::value) {
-      ff.key.resident = nullptr;
       check(Ops::search_frame_rig(ff.key, ff.v, FrameKey{}, orbm_frame_view{}, mat_f32(CurrentFrame.mTcw), rig1, lv, th, bMono, mbCheckOrientation, amp.data(),
                                   aob.data(), &n), "SearchByProjection(Cur, Last), camera model");
     }
@@ -822,7 +820,6 @@ int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapP
   const bool kModel = has_rig_matcher<Ops>::value && CurrentFrame.Nleft == -1 && make_rig(&CurrentFrame, rig1);   // a monocular Frame whose camera is a model (:2217)
   if (kModel) {
     if constexpr (has_rig_matcher<Ops>::value) {
-      ff.key.resident = nullptr;
       check(Ops::search_reloc_cam(ff.key, ff.v, mat_f32(CurrentFrame.mTcw), rig1.left, wv, found.data(), ang.data(), th, ORBdist, mbCheckOrientation, amp.data(), &n),
             "SearchByProjection(Cur, KF, sAlreadyFound), camera model");
     }
