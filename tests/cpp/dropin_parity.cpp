@@ -444,6 +444,22 @@ int main() {
         return o;
       };
       const MonoOut g = run(od::GpuOps{}), c = run(OracleOps{});
+      {                                                            // ... and with the Frame's features already on the device (Frame::mpGpuFrame, INTEGRATION.md edit E3)
+        Agent A;
+        RigTrack S = build_rig_track_scene(A, 4343, 1200, 250, 0.02);
+        Frame cur(*S.cur);
+        const int nl = cur.Nleft;
+        cur.Nleft = -1; cur.Nright = -1; cur.N = nl; cur.mpCamera2 = nullptr; cur.mvKeys.resize(nl); cur.mvKeysUn = cur.mvKeys; cur.mvKeysRight.clear();
+        cur.mvuRight.assign(nl, -1.f); cur.mvDepth.assign(nl, -1.f); cur.mvpMapPoints.resize(nl); cur.mvbOutlier.resize(nl);
+        { Mat d(nl, 32, 1); std::memcpy(d.ptr<uint8_t>(0), S.cur->mDescriptors.ptr<uint8_t>(0), (size_t)nl * 32); cur.mDescriptors = d; }
+        od::FrameFlat host; od::flatten_frame<OracleOps>(cur, host);
+        orbgpu::FrameOnDevice dev(4096);
+        dev.Upload(host.v);
+        cur.mpGpuFrame = &dev;
+        const int n_res = od::SearchLocalPoints<od::GpuOps>(cur, S.local, 3.0f, true, 7.0f, 0.8f);
+        std::vector<long> a_res; for (MapPoint* p : cur.mvpMapPoints) a_res.push_back(p ? (long)p->mnId : -1);
+        EXPECT(n_res == g.n_local && a_res == g.a_local, "mono fisheye with a device-resident frame: SearchLocalPoints %d vs %d", n_res, g.n_local);
+      }
       std::printf("monocular fisheye Frame: SearchByProjection(Cur, Last) %d matches, SearchLocalPoints %d matches, relocalisation search %d matches\n", g.n_frame, g.n_local, g.n_reloc);
       EXPECT(g.n_reloc == c.n_reloc && g.a_reloc == c.a_reloc && g.n_reloc > 100, "mono fisheye: SearchByProjection(F, KF, found) %d vs %d", g.n_reloc, c.n_reloc);
       EXPECT(g.n_frame == c.n_frame && g.a_frame == c.a_frame && g.n_frame > 100, "mono fisheye: SearchByProjection(Cur, Last) %d vs %d", g.n_frame, c.n_frame);
