@@ -1400,7 +1400,7 @@ __device__ __forceinline__ void kb8_unproject(const RigCamF& c, float u, float v
   ray[0] = pwx * scale; ray[1] = pwy * scale; ray[2] = 1.f;
 }
 
-__device__ void null_vector4(double S[4][4], double* v) {   // eigenvector of the smallest eigenvalue of a symmetric 4 x 4: cyclic Jacobi
+__device__ __forceinline__ void null_vector4(double (&S)[4][4], double (&v)[4]) {   // eigenvector of the smallest eigenvalue of a symmetric 4 x 4: cyclic Jacobi
   double V[4][4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -1432,14 +1432,15 @@ __device__ void null_vector4(double S[4][4], double* v) {   // eigenvector of th
       }
   }
   int m = 0;
+  double smallest = S[0][0];                                // (compile-time indices only: a dynamically indexed array lives in scratch memory)
 #pragma unroll
-  for (int i = 1; i < 4; i++) if (S[i][i] < S[m][m]) m = i;
+  for (int i = 1; i < 4; i++) if (S[i][i] < smallest) { smallest = S[i][i]; m = i; }
 #pragma unroll
-  for (int k = 0; k < 4; k++) v[k] = V[k][0] * (m == 0) + V[k][1] * (m == 1) + V[k][2] * (m == 2) + V[k][3] * (m == 3);
+  for (int k = 0; k < 4; k++) v[k] = m == 0 ? V[k][0] : m == 1 ? V[k][1] : m == 2 ? V[k][2] : V[k][3];
 }
 
 // KannalaBrandt8::TriangulateMatches, :335-403 (Triangulate :405-420)
-__device__ float kb8_triangulate_matches(const FisheyeDev& D, const orbx_keypoint& kp1, const orbx_keypoint& kp2, float sigmaLevel, float unc, float* p3D) {
+__device__ __forceinline__ float kb8_triangulate_matches(const FisheyeDev& D, const orbx_keypoint& kp1, const orbx_keypoint& kp2, float sigmaLevel, float unc, float (&p3D)[3]) {
   float r1[3], r2[3], r21[3];
   kb8_unproject(D.cam1, kp1.x, kp1.y, r1);
   kb8_unproject(D.cam2, kp2.x, kp2.y, r2);
